@@ -1,0 +1,292 @@
+// ref_shim.cpp -- OUR code (not reference code): a plain-C facade over the
+// reference's public cv:: API so that tests / golden generators / bench.py's
+// cpu_baseline leg can drive the REAL reference (oracle/_ref/libocvref.so)
+// through ctypes.  TEST INFRASTRUCTURE ONLY: nothing under opencv_amd/ or
+// libmi355cv.so links or loads this.
+//
+// Convention: images are (ptr, step_bytes, width, height, cvtype); the caller
+// pre-allocates dst with the size/type the cv:: function will produce; every
+// function returns 0 on success, -1 on a cv::Exception, -2 if cv:: reallocated
+// dst (caller passed the wrong geometry).
+#include <opencv2/core.hpp>
+#include <opencv2/core/utility.hpp>
+#include <opencv2/imgproc.hpp>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace cv;
+
+static inline Mat M(const void* p, size_t step, int w, int h, int type)
+{
+    return Mat(h, w, type, const_cast<void*>(p), step);
+}
+
+#define REF_TRY try {
+#define REF_END(dstmat, dstptr) \
+        if ((const void*)(dstmat).data != (const void*)(dstptr)) return -2; return 0; \
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
+
+extern "C" {
+
+int ref_setNumThreads(int n) { cv::setNumThreads(n); return cv::getNumThreads(); }
+int ref_getNumThreads() { return cv::getNumThreads(); }
+int ref_getNumberOfCPUs() { return cv::getNumberOfCPUs(); }
+const char* ref_buildInformation() { static std::string s = cv::getBuildInformation(); return s.c_str(); }
+int ref_checkHardwareSupport(int feature) { return cv::checkHardwareSupport(feature) ? 1 : 0; }
+
+// cv::RNG(seed).fill(mat, UNIFORM, lo, hi): the reference's own synthetic-input generator
+int ref_rngFill(void* p, size_t step, int w, int h, int type, unsigned long long seed, double lo, double hi)
+{
+    REF_TRY
+    Mat m = M(p, step, w, h, type);
+    RNG rng(seed);
+    rng.fill(m, RNG::UNIFORM, lo, hi);
+    REF_END(m, p)
+}
+
+int ref_borderInterpolate(int p, int len, int borderType)
+{
+    try { return cv::borderInterpolate(p, len, borderType); } catch (...) { return -1000000; }
+}
+
+int ref_copyMakeBorder(const void* s, size_t ss, int w, int h, int type, void* d, size_t ds,
+                       int top, int bottom, int left, int right, int borderType, const double* value)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w + left + right, h + top + bottom, type);
+    Scalar v = value ? Scalar(value[0], value[1], value[2], value[3]) : Scalar();
+    cv::copyMakeBorder(src, dst, top, bottom, left, right, borderType, v);
+    REF_END(dst, d)
+}
+
+int ref_GaussianBlur(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type,
+                     int kw, int kh, double sigma1, double sigma2, int borderType)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    cv::GaussianBlur(src, dst, Size(kw, kh), sigma1, sigma2, borderType, cv::ALGO_HINT_ACCURATE);
+    REF_END(dst, d)
+}
+
+// GaussianBlur on an ROI of a larger parent image (non-isolated borders read the parent)
+int ref_GaussianBlurROI(const void* parent, size_t ss, int pw, int ph, int type, int rx, int ry, int w, int h,
+                        void* d, size_t ds, int kw, int kh, double sigma1, double sigma2, int borderType)
+{
+    REF_TRY
+    Mat par = M(parent, ss, pw, ph, type), dst = M(d, ds, w, h, type);
+    Mat src = par(Rect(rx, ry, w, h));
+    cv::GaussianBlur(src, dst, Size(kw, kh), sigma1, sigma2, borderType, cv::ALGO_HINT_ACCURATE);
+    REF_END(dst, d)
+}
+
+int ref_getGaussianKernel(int n, double sigma, double* out)
+{
+    try { Mat k = cv::getGaussianKernel(n, sigma, CV_64F); memcpy(out, k.ptr<double>(), n * sizeof(double)); return 0; }
+    catch (...) { return -1; }
+}
+
+int ref_filter2D(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int ddepth,
+                 const void* k, int kw, int kh, int ktype, int ax, int ay, double delta, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    Mat kernel = M(k, (size_t)kw * CV_ELEM_SIZE(ktype), kw, kh, ktype);
+    cv::filter2D(src, dst, ddepth, kernel, Point(ax, ay), delta, borderType);
+    REF_END(dst, d)
+}
+
+int ref_filter2DROI(const void* parent, size_t ss, int pw, int ph, int stype, int rx, int ry, int w, int h,
+                    void* d, size_t ds, int ddepth, const void* k, int kw, int kh, int ktype, int ax, int ay,
+                    double delta, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat par = M(parent, ss, pw, ph, stype), dst = M(d, ds, w, h, dtype);
+    Mat src = par(Rect(rx, ry, w, h));
+    Mat kernel = M(k, (size_t)kw * CV_ELEM_SIZE(ktype), kw, kh, ktype);
+    cv::filter2D(src, dst, ddepth, kernel, Point(ax, ay), delta, borderType);
+    REF_END(dst, d)
+}
+
+int ref_sepFilter2D(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int ddepth,
+                    const void* kx, int kxlen, const void* ky, int kylen, int ktype, int ax, int ay,
+                    double delta, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    Mat KX = M(kx, (size_t)kxlen * CV_ELEM_SIZE(ktype), kxlen, 1, ktype);
+    Mat KY = M(ky, (size_t)kylen * CV_ELEM_SIZE(ktype), kylen, 1, ktype);
+    cv::sepFilter2D(src, dst, ddepth, KX, KY, Point(ax, ay), delta, borderType);
+    REF_END(dst, d)
+}
+
+int ref_boxFilter(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int ddepth,
+                  int kw, int kh, int ax, int ay, int normalize, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    cv::boxFilter(src, dst, ddepth, Size(kw, kh), Point(ax, ay), normalize != 0, borderType);
+    REF_END(dst, d)
+}
+
+int ref_Sobel(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int ddepth,
+              int dx, int dy, int ksize, double scale, double delta, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    cv::Sobel(src, dst, ddepth, dx, dy, ksize, scale, delta, borderType);
+    REF_END(dst, d)
+}
+
+int ref_Scharr(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int ddepth,
+               int dx, int dy, double scale, double delta, int borderType)
+{
+    REF_TRY
+    int dtype = CV_MAKETYPE(ddepth < 0 ? CV_MAT_DEPTH(stype) : ddepth, CV_MAT_CN(stype));
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    cv::Scharr(src, dst, ddepth, dx, dy, scale, delta, borderType);
+    REF_END(dst, d)
+}
+
+int ref_cvtColor(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int dtype, int code)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, dtype);
+    cv::cvtColor(src, dst, code, CV_MAT_CN(dtype), cv::ALGO_HINT_ACCURATE);
+    REF_END(dst, d)
+}
+
+int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
+               double fx, double fy, int interpolation)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    cv::resize(src, dst, Size(dw, dh), fx, fy, interpolation);
+    REF_END(dst, d)
+}
+
+int ref_warpAffine(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
+                   const double* M6, int flags, int borderMode, const double* bv)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    Mat Mm(2, 3, CV_64F, const_cast<double*>(M6));
+    cv::warpAffine(src, dst, Mm, Size(dw, dh), flags, borderMode, Scalar(bv[0], bv[1], bv[2], bv[3]));
+    REF_END(dst, d)
+}
+
+int ref_warpPerspective(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
+                        const double* M9, int flags, int borderMode, const double* bv)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    Mat Mm(3, 3, CV_64F, const_cast<double*>(M9));
+    cv::warpPerspective(src, dst, Mm, Size(dw, dh), flags, borderMode, Scalar(bv[0], bv[1], bv[2], bv[3]));
+    REF_END(dst, d)
+}
+
+int ref_remap(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
+              const float* mapx, size_t mxs, const float* mapy, size_t mys, int interpolation, int borderMode,
+              const double* bv)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    Mat mx = M(mapx, mxs, dw, dh, CV_32FC1), my = M(mapy, mys, dw, dh, CV_32FC1);
+    cv::remap(src, dst, mx, my, interpolation, borderMode, Scalar(bv[0], bv[1], bv[2], bv[3]));
+    REF_END(dst, d)
+}
+
+int ref_getRotationMatrix2D(double cx, double cy, double angle, double scale, double* M6)
+{
+    try { Mat m = cv::getRotationMatrix2D(Point2f((float)cx, (float)cy), angle, scale); memcpy(M6, m.ptr<double>(), 6 * sizeof(double)); return 0; }
+    catch (...) { return -1; }
+}
+
+int ref_cornerHarris(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype,
+                     int blockSize, int ksize, double k, int borderType)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, CV_32FC1);
+    cv::cornerHarris(src, dst, blockSize, ksize, k, borderType);
+    REF_END(dst, d)
+}
+
+int ref_cornerMinEigenVal(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype,
+                          int blockSize, int ksize, int borderType)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, CV_32FC1);
+    cv::cornerMinEigenVal(src, dst, blockSize, ksize, borderType);
+    REF_END(dst, d)
+}
+
+// returns number of corners written (<= maxCorners) or negative on error; corners = x0,y0,x1,y1,...
+int ref_goodFeaturesToTrack(const void* s, size_t ss, int w, int h, int stype, float* corners, int maxCorners,
+                            double qualityLevel, double minDistance, int blockSize, int gradientSize,
+                            int useHarris, double k)
+{
+    try {
+        Mat src = M(s, ss, w, h, stype);
+        std::vector<Point2f> pts;
+        cv::goodFeaturesToTrack(src, pts, maxCorners, qualityLevel, minDistance, noArray(), blockSize,
+                                gradientSize, useHarris != 0, k);
+        for (size_t i = 0; i < pts.size(); i++) { corners[2 * i] = pts[i].x; corners[2 * i + 1] = pts[i].y; }
+        return (int)pts.size();
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
+}
+
+int ref_pyrDown(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type, int borderType)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    cv::pyrDown(src, dst, Size(dw, dh), borderType);
+    REF_END(dst, d)
+}
+
+int ref_matchTemplate(const void* img, size_t is, int iw, int ih, const void* t, size_t ts, int tw, int th, int type,
+                      void* res, size_t rs, int method)
+{
+    REF_TRY
+    Mat I = M(img, is, iw, ih, type), T = M(t, ts, tw, th, type);
+    Mat R = M(res, rs, iw - tw + 1, ih - th + 1, CV_32FC1);
+    cv::matchTemplate(I, T, R, method);
+    REF_END(R, res)
+}
+
+int ref_integral(const void* s, size_t ss, int w, int h, int stype, void* sum, size_t sums, int sdepth,
+                 void* sq, size_t sqs, int sqdepth)
+{
+    REF_TRY
+    int cn = CV_MAT_CN(stype);
+    Mat src = M(s, ss, w, h, stype), S = M(sum, sums, w + 1, h + 1, CV_MAKETYPE(sdepth, cn));
+    if (sq) {
+        Mat Q = M(sq, sqs, w + 1, h + 1, CV_MAKETYPE(sqdepth, cn));
+        cv::integral(src, S, Q, sdepth, sqdepth);
+        if ((void*)Q.data != sq) return -2;
+    } else
+        cv::integral(src, S, sdepth);
+    REF_END(S, sum)
+}
+
+int ref_dilate3x3(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    cv::dilate(src, dst, Mat());
+    REF_END(dst, d)
+}
+
+int ref_threshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, double thresh, double maxval, int ttype)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    cv::threshold(src, dst, thresh, maxval, ttype);
+    REF_END(dst, d)
+}
+
+} // extern "C"
