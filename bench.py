@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: Mpix/s of cv::GaussianBlur 5x5 (sigma=0) on
+3840x2160 CV_8U frames + achieved HBM GB/s against the MI355X roofline.
+
+A "step" is one pass of the hot path over one batch: B device-resident 4K 8UC1 frames per GPU through
+mi355cv_gaussianBlurBinomialBatch (one launch, grid-z = frame).  Frames are independent units, so N GPUs
+= N processes (torchrun) each owning its own frames: weak scaling, no data-path collective; the only
+collective is the RCCL broadcast of the shared filter taps at plan time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W4K, H4K = 3840, 2160
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_PIXEL = 2.0     # 1 B read + 1 B written per 8UC1 pixel
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference CPU path on this box's host cores, bounded sample (rank 0, N=1 only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    rng = np.random.default_rng(809564)
+    frame = rng.integers(0, 256, (H4K, W4K), dtype=np.uint8)
+    ref = orc.load_ref()
+    if ref is not None:
+        cores = ref.ref_getNumberOfCPUs()
+        ref.ref_setNumThreads(cores)
+        orc.ref_GaussianBlur(frame, 5, 0, 0, 4)          # warm-up (thread pool, page faults)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.ref_GaussianBlur(frame, 5, 0, 0, 4)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 2000:
+                break
+        return {"value": round(n * W4K * H4K / dt / 1e6, 1), "unit": "Mpix/s", "cores": int(cores), "kind": "reference",
+                "sample": f"{n} x cv::GaussianBlur(5x5,sigma=0,REFLECT_101) on one 3840x2160 CV_8UC1 frame, "
+                          f"{cores} threads (oracle/_ref build of the reference: SSE3 baseline + AVX2/AVX512 dispatch, pthreads), {dt:.1f} s"}
+    crop = np.ascontiguousarray(frame[:540, :960])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.orc_gaussianBlurBinomialU8(crop, 5, 4)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s:
+            break
+    return {"value": round(n * crop.size / dt / 1e6, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x oracle C restatement on a 960x540 crop, 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "128")),
+                    help="4K frames per GPU per step (in+out = 2 x 8.29 MB x batch, far beyond the 256 MB LLC)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+
+    import opencv_amd as cv
+
+    # plan time: rank 0 owns the filter definition; RCCL broadcast over xGMI (bytes, once)
+    taps = torch.from_numpy(cv.getGaussianKernelQ8_binomial(5).astype(np.int32)).to(dev) if rank == 0 \
+        else torch.zeros(5, dtype=torch.int32, device=dev)
+    if dist is not None:
+        dist.broadcast(taps, src=0)
+    assert taps.cpu().tolist() == [16, 64, 96, 64, 16]
+
+    B = args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(809564 + rank)
+    frames = torch.randint(0, 256, (B, H4K, W4K), dtype=torch.uint8, device=dev, generator=g)
+    out = torch.empty_like(frames)
+
+    # parity gate before timing: frame 0 against the CPU checker (bit-exact)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    cv.GaussianBlurBatch(frames, 5, dst=out)
+    torch.cuda.synchronize()
+    if rank == 0:
+        want = orc.orc_gaussianBlurBinomialU8(frames[0, :256].cpu().numpy(), 5, 4)[:-2]
+        assert np.array_equal(out[0, :254].cpu().numpy(), want), "parity check failed"
+        assert torch.equal(out[B - 1, -64:], cv.GaussianBlur(frames[B - 1], 5)[-64:]), "batch != single-frame"
+
+    cv.set_async(True)
+    for _ in range(args.warmup):
+        cv.GaussianBlurBatch(frames, 5, dst=out)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()                      # launches are bound to torch's current stream (core.bind_stream)
+        cv.GaussianBlurBatch(frames, 5, dst=out)
+        ev[s][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cv.set_async(False)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        pix_per_step = B * W4K * H4K
+        value = world * pix_per_step * args.steps / elapsed / 1e6
+        achieved = ALGO_BYTES_PER_PIXEL * pix_per_step / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Mpix/s per GPU (4K CV_8U Gaussian5x5) + achieved HBM GB/s vs roofline, 1/2/4/8 GPUs",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "cv::GaussianBlur 5x5 sigma=0 BORDER_REFLECT_101 on 3840x2160 CV_8UC1, "
+                                   f"{B} device-resident frames per GPU per step (one batched launch)",
+                       "frames_per_gpu": B, "sharding": f"frames x{world}, no data-path collective"},
+            "per_gpu_mpix_s": round(value / world, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_binomial_roll<5,1>", "avg_launch_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PIXEL * pix_per_step)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

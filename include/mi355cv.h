@@ -74,8 +74,10 @@ typedef unsigned char mi355cv_uchar;
 MI355CV_API int  mi355cv_init(int device);
 MI355CV_API const char* mi355cv_version(void);
 MI355CV_API const char* mi355cv_lastError(void);
-/* stream used for launches made by the calling thread (NULL = library-owned per-thread stream) */
+/* stream used for launches made by the calling thread: exactly this hipStream_t (NULL = HIP's null
+ * stream).  Until called -- or after mi355cv_resetStream() -- a library-owned per-thread stream is used. */
 MI355CV_API int  mi355cv_setStream(void* hipStream);
+MI355CV_API int  mi355cv_resetStream(void);
 /* 1: calls on device-resident images return after enqueue (caller synchronises); 0 (default): synchronous */
 MI355CV_API int  mi355cv_setAsync(int enable);
 MI355CV_API int  mi355cv_synchronize(void);
@@ -106,6 +108,12 @@ MI355CV_API int mi355cv_gaussianBlur(const mi355cv_uchar* src_data, size_t src_s
         mi355cv_uchar* dst_data, size_t dst_step, int width, int height, int depth, int cn,
         size_t margin_left, size_t margin_top, size_t margin_right, size_t margin_bottom,
         size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type);
+
+/* a2: host-side tap generators.  getGaussianKernelBitExact (smooth.dispatch.cpp:81-198, also behind
+ * cv::getGaussianKernel :200) and getGaussianKernelFixedPoint_ED (:224-258; fractionBits 8 -> the Q8.8
+ * taps of the CV_8U path, 16 -> Q16.16 of CV_16U).  Bit-identical to the reference's softdouble code. */
+MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double* taps);
+MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps);
 
 /* Fixed-point separable smoothing with caller-supplied Q8.8 taps: the body of
  * GaussianBlurFixedPoint<uint16_t> (smooth.simd.hpp:2219; taps as produced by

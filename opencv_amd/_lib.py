@@ -1,0 +1,76 @@
+"""ctypes binding of libmi355cv.so (C ABI declared in include/mi355cv.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a hook
+answers NOT_IMPLEMENTED the caller gets an exception, never a silently
+different implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355cv.so")
+
+OK, NOT_IMPLEMENTED = 0, 1
+
+c_u8p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+
+
+class Mi355cvError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C opencv_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    sig = {
+        "mi355cv_init": (c_int, [c_int]),
+        "mi355cv_version": (ctypes.c_char_p, []),
+        "mi355cv_lastError": (ctypes.c_char_p, []),
+        "mi355cv_setStream": (c_int, [ctypes.c_void_p]),
+        "mi355cv_resetStream": (c_int, []),
+        "mi355cv_setAsync": (c_int, [c_int]),
+        "mi355cv_synchronize": (c_int, []),
+        "mi355cv_callCount": (ctypes.c_longlong, [ctypes.c_char_p]),
+        "mi355cv_deviceAlloc": (ctypes.c_void_p, [c_sz]),
+        "mi355cv_deviceFree": (c_int, [ctypes.c_void_p]),
+        "mi355cv_upload": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz]),
+        "mi355cv_download": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz]),
+        "mi355cv_gaussianBlurBinomial": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int,
+                                                 c_sz, c_sz, c_sz, c_sz, c_sz, c_int]),
+        "mi355cv_gaussianBlur": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int,
+                                         c_sz, c_sz, c_sz, c_sz, c_sz, c_sz, c_dbl, c_dbl, c_int]),
+        "mi355cv_getGaussianKernel": (c_int, [c_int, c_dbl, ctypes.c_void_p]),
+        "mi355cv_getGaussianKernelQ": (c_int, [c_int, c_dbl, c_int, ctypes.c_void_p]),
+        "mi355cv_gaussianBlurBinomialBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int,
+                                                      c_int, c_int, c_int, c_int, c_sz, c_int]),
+        "mi355cv_sepSmoothFixedU8": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int,
+                                             c_sz, c_sz, c_sz, c_sz, ctypes.c_void_p, c_int, ctypes.c_void_p, c_int, c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sig
+
+
+lib, SIGNATURES = _load()
+
+
+def check(code, entry):
+    """HAL return code -> exception (hal_replacement.hpp:1342-1357 semantics made loud)."""
+    if code == OK:
+        return
+    msg = lib.mi355cv_lastError().decode(errors="replace")
+    if code == NOT_IMPLEMENTED:
+        raise NotImplementedError(f"mi355cv_{entry}: NOT_IMPLEMENTED for these arguments ({msg}); no CPU fallback in opencv_amd")
+    raise Mi355cvError(f"mi355cv_{entry} failed with {code}: {msg}")
+
+
+def call_count(entry: str) -> int:
+    return int(lib.mi355cv_callCount(entry.encode()))

@@ -1,0 +1,86 @@
+// rt.h -- internal runtime of libmi355cv.so: per-thread HIP stream, pointer
+// classification, host<->HBM staging, error/trace bookkeeping.
+// Everything above this (the exported mi355cv_* hooks) speaks the HAL contract
+// of the reference (hal_replacement.hpp:1342-1357): never throw, return
+// OK / NOT_IMPLEMENTED / UNKNOWN.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/mi355cv.h"
+
+typedef unsigned char uchar;
+
+namespace mi355 {
+
+// border codes (core/base.hpp:332)
+enum { B_CONSTANT = 0, B_REPLICATE = 1, B_REFLECT = 2, B_WRAP = 3, B_REFLECT_101 = 4, B_TRANSPARENT = 5 };
+
+struct ThreadCtx;
+ThreadCtx& tctx();
+hipStream_t stream();
+bool asyncMode();
+bool disabled();                    // MI355CV_DISABLE=1 -> every hook answers NOT_IMPLEMENTED
+size_t minPixels();                 // MI355CV_MIN_PIXELS: host-resident images below this are declined
+int  setError(int code, const char* fmt, ...);
+void bump(const char* entry);       // per-entry completed-on-GPU counter
+bool ensureDevice();                // lazily selects the device; false if no usable GPU
+
+// true if p points into device or managed memory (launch in place)
+bool isDevicePtr(const void* p);
+
+// Stages host images into HBM scratch (and results back).  Device-resident
+// images pass through untouched.  One Stager per hook invocation.
+class Stager {
+public:
+    Stager();
+    ~Stager();
+    // input image: `rows` rows of `rowBytes` valid bytes at `p` with pitch `step`.
+    const uchar* in(const uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep);
+    // output image (contents undefined until the kernel writes them)
+    uchar* out(uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep);
+    // small parameter blocks (filter taps, tables): always copied, 256-B aligned
+    void* param(const void* host, size_t bytes);
+    // scratch in HBM that lives until finish()
+    void* scratch(size_t bytes);
+    // copies staged outputs back and synchronises when required.  Returns HAL code.
+    int finish(const char* entry);
+    bool anyHost() const { return anyHost_; }
+    bool failed() const { return failed_; }
+private:
+    struct Out { uchar* host; size_t hstep; uchar* dev; size_t dstep; size_t rowBytes; int rows; };
+    std::vector<Out> outs_;
+    bool anyHost_ = false, failed_ = false;
+    void* bump_(size_t bytes);
+};
+
+inline int divUp(int a, int b) { return (a + b - 1) / b; }
+
+#define MI355_CHECK_LAUNCH(entry)                                                        \
+    do { hipError_t e__ = hipGetLastError();                                             \
+         if (e__ != hipSuccess) return mi355::setError(MI355CV_ERROR_UNKNOWN, "%s: launch failed: %s", entry, hipGetErrorString(e__)); } while (0)
+
+} // namespace mi355
+
+// borderInterpolate (core/src/copy.cpp:748-793), device+host. Returns -1 for CONSTANT.
+__host__ __device__ inline int mi355_borderInterpolate(int p, int len, int borderType)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (borderType == mi355::B_REPLICATE) return p < 0 ? 0 : len - 1;
+    if (borderType == mi355::B_REFLECT || borderType == mi355::B_REFLECT_101) {
+        int delta = borderType == mi355::B_REFLECT_101;
+        if (len == 1) return 0;
+        do {
+            if (p < 0) p = -p - 1 + delta;
+            else p = len - 1 - (p - len) - delta;
+        } while ((unsigned)p >= (unsigned)len);
+        return p;
+    }
+    if (borderType == mi355::B_WRAP) {
+        if (p < 0) p -= ((p - len + 1) / len) * len;
+        if (p >= len) p %= len;
+        return p;
+    }
+    return -1;
+}

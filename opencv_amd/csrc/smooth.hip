@@ -1,0 +1,425 @@
+// smooth.hip -- row a1/a2 of SURVEY.md §8: cv::GaussianBlur on CV_8U.
+//
+// Reference semantics (modules/imgproc/src/smooth.simd.hpp:1926 fixedSmoothInvoker,
+// :546 hlineSmooth5N14641, :1561 vlineSmooth5N14641; fixedpoint.inl.hpp:325 ufixedpoint16):
+//   H[y][b]  = sum_i kx[i] * p[y][bI(x+i-rx)][c]            (u16, Q8.8, exact: sum kx == 256)
+//   dst[y][b] = ( sum_j ky[j] * H[bI(y+j-ry)][b] + 2^15 ) >> 16
+// For the sigma==0 binomial tables (smooth.dispatch.cpp:89-145) this collapses to
+//   5x5: (sum w_i w_j p + 128) >> 8,  w = 1 4 6 4 1         3x3: (sum w_i w_j p + 8) >> 4,  w = 1 2 1
+//
+// Two kernels:
+//  * k_binomial_roll<KS,CN>: the hot kernel.  HBM-bound (2 B/pixel algorithmic).  One lane owns
+//    16 consecutive bytes of a row (one global_load_dwordx4, one global_store_dwordx4) and walks
+//    DOWN the image keeping the last KS horizontally-filtered rows in registers (packed 2xu16 per
+//    VGPR), so every source byte is fetched once per vertical segment and there is no LDS round
+//    trip.  The +-R*cn neighbour bytes come from the adjacent lanes (ds_bpermute crossbar), from
+//    a 4-byte side load at the wave edges, or from borderInterpolate at the image edges.
+//  * k_sepfixed_generic: any taps / alignment / margins / tiny images.  One thread per output
+//    byte, straight from the formula above.  Correctness path, not a fast path.
+#include "rt.h"
+#include "gausskernel.h"
+
+using namespace mi355;
+
+namespace {
+
+// ---------------------------------------------------------------------------------- generic
+struct FixedTaps { uint16_t kx[33]; uint16_t ky[33]; int nx, ny; };
+
+__global__ __launch_bounds__(256) void k_sepfixed_generic(
+    const uchar* __restrict__ src, size_t sstep, size_t sframe,
+    uchar* __restrict__ dst, size_t dstep, size_t dframe,
+    int W, int H, int cn, int mL, int mT, int mR, int mB, int border, FixedTaps t)
+{
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (b >= W * cn || y >= H) return;
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    const int x = b / cn, c = b - x * cn;
+    const int fullW = mL + W + mR, fullH = mT + H + mB;
+    const int rx = t.nx / 2, ry = t.ny / 2;
+    uint32_t acc = 0;
+    for (int j = 0; j < t.ny; j++) {
+        int yy = mi355_borderInterpolate(y + mT + j - ry, fullH, border);
+        if (yy < 0) continue;                               // BORDER_CONSTANT: zero row (smooth.simd.hpp:2092)
+        const uchar* row = src + (ptrdiff_t)(yy - mT) * (ptrdiff_t)sstep;
+        uint32_t h = 0;
+        for (int i = 0; i < t.nx; i++) {
+            int xx = mi355_borderInterpolate(x + mL + i - rx, fullW, border);
+            if (xx < 0) continue;
+            h += (uint32_t)t.kx[i] * row[(ptrdiff_t)(xx - mL) * cn + c];
+        }
+        h = h > 0xFFFFu ? 0xFFFFu : h;                       // ufixedpoint16 saturating add (fixedpoint.inl.hpp:345)
+        uint64_t a = (uint64_t)acc + (uint64_t)t.ky[j] * h;
+        acc = a > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a; // ufixedpoint32 saturating add (:247)
+    }
+    uint32_t r = (uint32_t)(((uint64_t)acc + 0x8000u) >> 16);
+    dst[(size_t)y * dstep + b] = (uchar)(r > 255 ? 255 : r);
+}
+
+// ---------------------------------------------------------------------------------- rolling kernel
+constexpr int floordiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
+constexpr int mod2(int a) { return ((a % 2) + 2) % 2; }
+
+// The lane's window of one source row as two planes of packed u16 pairs:
+//   E[d] = (byte 4d, byte 4d+2), O[d] = (byte 4d+1, byte 4d+3), d = -HD .. 3+HD (array index d+HD)
+// pair<Q,S>(k): the two bytes (4k+Q+S, 4k+Q+S+2) as a packed u16 pair -- i.e. the neighbours at
+// byte distance S of output pair (plane Q, dword k).
+template <int Q, int S, int HD>
+__device__ __forceinline__ uint32_t pairAt(const uint32_t* E, const uint32_t* O, int k)
+{
+    constexpr int q2 = mod2(Q + S);
+    constexpr int f = floordiv2(Q + S);
+    const uint32_t* P = q2 ? O : E;
+    if constexpr (mod2(f) == 0) {
+        return P[k + f / 2 + HD];
+    } else {
+        constexpr int lo = floordiv2(f - 1) + 0;   // (f-1)/2, f odd
+        return __builtin_amdgcn_alignbit(P[k + lo + 1 + HD], P[k + lo + HD], 16);
+    }
+}
+
+template <int HD> struct RawRow {
+    uint4 m;              // the lane's 16 bytes
+    uint32_t hl[HD];      // side-loaded left halo (meaningful on lane 0 only)
+    uint32_t hr[HD];      // side-loaded right halo (lane 63 / last chunk only)
+};
+
+template <int KS, int CN> struct RollCfg {
+    static constexpr int R = KS / 2;
+    static constexpr int HB = R * CN;            // halo bytes per side
+    static constexpr int HD = (HB + 3) / 4;      // halo dwords per side
+};
+
+// issue the global loads of source row yy for this lane (no dependent ALU: keeps loads in flight)
+template <int KS, int CN>
+__device__ __forceinline__ void loadRow(RawRow<RollCfg<KS, CN>::HD>& r, const uchar* __restrict__ src, size_t sstep,
+                                        int yy, int W, int H, int c, int nchunks, int lane, int border)
+{
+    constexpr int HD = RollCfg<KS, CN>::HD, HB = RollCfg<KS, CN>::HB;
+    r.m = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < HD; d++) { r.hl[d] = 0; r.hr[d] = 0; }
+    const int ry = mi355_borderInterpolate(yy, H, border);
+    if (ry < 0 || c >= nchunks) return;          // constant border row / idle lane: zeros
+    const uchar* row = src + (size_t)ry * sstep;
+    r.m = *reinterpret_cast<const uint4*>(row + 16 * (size_t)c);
+    if (lane == 0) {
+        if (c > 0) {
+#pragma unroll
+            for (int d = 0; d < HD; d++) r.hl[d] = *reinterpret_cast<const uint32_t*>(row + 16 * (size_t)c - 4 * (HD - d));
+        } else {
+            // bytes -HB..-1 of the row = pixels -R..-1 by borderInterpolate
+#pragma unroll
+            for (int t = -HB; t < 0; t++) {
+                const int px = (t - (CN - 1)) / CN;            // floor(t/CN) for t<0
+                const int ch = t - px * CN;
+                const int sp = mi355_borderInterpolate(px, W, border);
+                const uint32_t v = sp < 0 ? 0u : row[sp * CN + ch];
+                r.hl[(4 * HD + t) >> 2] |= v << (8 * ((4 * HD + t) & 3));
+            }
+        }
+    }
+    if (c == nchunks - 1) {
+#pragma unroll
+        for (int t = 0; t < HB; t++) {
+            const int px = W + t / CN, ch = t % CN;
+            const int sp = mi355_borderInterpolate(px, W, border);
+            const uint32_t v = sp < 0 ? 0u : row[sp * CN + ch];
+            r.hr[t >> 2] |= v << (8 * (t & 3));
+        }
+    } else if (lane == 63) {
+#pragma unroll
+        for (int d = 0; d < HD; d++) r.hr[d] = *reinterpret_cast<const uint32_t*>(row + 16 * (size_t)c + 16 + 4 * d);
+    }
+}
+
+// horizontal pass of one row: raw bytes -> 8 packed-u16 dwords (Hrow[0..3] = even bytes, [4..7] = odd bytes)
+template <int KS, int CN>
+__device__ __forceinline__ void hfilter(uint32_t (&Hrow)[8], const RawRow<RollCfg<KS, CN>::HD>& r, int c, int nchunks, int lane)
+{
+    constexpr int HD = RollCfg<KS, CN>::HD;
+    constexpr int NW = 4 + 2 * HD;
+    uint32_t X[NW];
+    const uint32_t mv[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+#pragma unroll
+    for (int d = 0; d < HD; d++) {
+        uint32_t l = __shfl_up(mv[4 - HD + d], 1);
+        uint32_t rr = __shfl_down(mv[d], 1);
+        X[d] = (lane == 0) ? r.hl[d] : l;
+        X[HD + 4 + d] = (lane == 63 || c == nchunks - 1) ? r.hr[d] : rr;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) X[HD + d] = mv[d];
+    uint32_t E[NW], O[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++) {
+        E[d] = __builtin_amdgcn_perm(0u, X[d], 0x0c020c00u);   // (b0, b2) zero-extended to u16 pairs
+        O[d] = __builtin_amdgcn_perm(0u, X[d], 0x0c030c01u);   // (b1, b3)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (KS == 5) {
+            {   uint32_t a = pairAt<0, -2 * CN, HD>(E, O, k) + pairAt<0, 2 * CN, HD>(E, O, k);
+                uint32_t b = pairAt<0, -CN, HD>(E, O, k) + pairAt<0, CN, HD>(E, O, k);
+                uint32_t m = pairAt<0, 0, HD>(E, O, k);
+                Hrow[k] = a + (b << 2) + (m << 1) + (m << 2); }
+            {   uint32_t a = pairAt<1, -2 * CN, HD>(E, O, k) + pairAt<1, 2 * CN, HD>(E, O, k);
+                uint32_t b = pairAt<1, -CN, HD>(E, O, k) + pairAt<1, CN, HD>(E, O, k);
+                uint32_t m = pairAt<1, 0, HD>(E, O, k);
+                Hrow[4 + k] = a + (b << 2) + (m << 1) + (m << 2); }
+        } else {
+            Hrow[k]     = pairAt<0, -CN, HD>(E, O, k) + pairAt<0, CN, HD>(E, O, k) + (pairAt<0, 0, HD>(E, O, k) << 1);
+            Hrow[4 + k] = pairAt<1, -CN, HD>(E, O, k) + pairAt<1, CN, HD>(E, O, k) + (pairAt<1, 0, HD>(E, O, k) << 1);
+        }
+    }
+}
+
+template <int KS, int CN>
+__global__ __launch_bounds__(256) void k_binomial_roll(
+    const uchar* __restrict__ src, size_t sstep, size_t sframe,
+    uchar* __restrict__ dst, size_t dstep, size_t dframe,
+    int W, int H, int nchunks, int segRows, int border)
+{
+    constexpr int R = KS / 2, HD = RollCfg<KS, CN>::HD;
+    const int lane = threadIdx.x & 63;
+    const int c = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const int y0 = blockIdx.y * segRows;
+    const int y1 = min(H, y0 + segRows);
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    const bool active = c < nchunks;
+
+    uint32_t Hw[KS][8];
+    {   // prologue: rows y0-R .. y0+R-1 into slots 0..KS-2
+        RawRow<HD> pre[KS - 1];
+#pragma unroll
+        for (int i = 0; i < KS - 1; i++) loadRow<KS, CN>(pre[i], src, sstep, y0 - R + i, W, H, c, nchunks, lane, border);
+#pragma unroll
+        for (int i = 0; i < KS - 1; i++) hfilter<KS, CN>(Hw[i], pre[i], c, nchunks, lane);
+    }
+    for (int y = y0; y < y1; y += KS) {
+        RawRow<HD> raw[KS];
+#pragma unroll
+        for (int u = 0; u < KS; u++)
+            if (y + u < y1) loadRow<KS, CN>(raw[u], src, sstep, y + u + R, W, H, c, nchunks, lane, border);
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            if (y + u < y1) {
+                hfilter<KS, CN>(Hw[(KS - 1 + u) % KS], raw[u], c, nchunks, lane);
+                uint32_t o[4];
+                if constexpr (KS == 5) {
+                    const uint32_t* h0 = Hw[(u + 0) % 5]; const uint32_t* h1 = Hw[(u + 1) % 5];
+                    const uint32_t* h2 = Hw[(u + 2) % 5]; const uint32_t* h3 = Hw[(u + 3) % 5];
+                    const uint32_t* h4 = Hw[(u + 4) % 5];
+                    uint32_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        v[i] = (h0[i] + h4[i]) + ((h1[i] + h3[i]) << 2) + (h2[i] << 1) + (h2[i] << 2) + 0x00800080u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_perm(v[4 + k], v[k], 0x07030501u);  // (Ve.b1,Vo.b1,Ve.b3,Vo.b3) = >>8
+                } else {
+                    const uint32_t* h0 = Hw[(u + 0) % 3]; const uint32_t* h1 = Hw[(u + 1) % 3]; const uint32_t* h2 = Hw[(u + 2) % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t ve = ((h0[k] + h2[k] + (h1[k] << 1) + 0x00080008u) >> 4) & 0x00FF00FFu;
+                        uint32_t vo = ((h0[4 + k] + h2[4 + k] + (h1[4 + k] << 1) + 0x00080008u) >> 4) & 0x00FF00FFu;
+                        o[k] = ve | (vo << 8);
+                    }
+                }
+                if (active)
+                    *reinterpret_cast<uint4*>(dst + (size_t)(y + u) * dstep + 16 * (size_t)c) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+
+bool aligned16(const void* p, size_t step) { return (((uintptr_t)p | step) & 15) == 0; }
+
+int envInt(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
+
+template <int KS, int CN>
+void launchRoll(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nframes, int W, int H, int border, hipStream_t st)
+{
+    const int nchunks = W * CN / 16;
+    const int gx = divUp(nchunks, 256);
+    static const int segEnv = envInt("MI355CV_GAUSS_SEG", 0);
+    int seg;
+    if (segEnv > 0) seg = segEnv;
+    else {
+        // enough (strip x segment x frame) work items to fill 256 CUs several times over, while
+        // keeping the 2R re-read halo rows per segment small
+        long long stripsWaves = (long long)divUp(nchunks, 64) * nframes;
+        long long wantSeg = (16384 + stripsWaves - 1) / stripsWaves;
+        if (wantSeg < 1) wantSeg = 1;
+        seg = (int)((H + wantSeg - 1) / wantSeg);
+        if (seg < 4 * KS) seg = 4 * KS;
+    }
+    seg = divUp(seg, KS) * KS;
+    if (seg > H) seg = divUp(H, KS) * KS;
+    dim3 grid(gx, divUp(H, seg), nframes);
+    hipLaunchKernelGGL((k_binomial_roll<KS, CN>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, seg, border);
+}
+
+bool rollEligible(const uchar* s, size_t ss, size_t sf, const uchar* d, size_t ds, size_t df, int W, int H, int cn, int ks)
+{
+    if (ks != 3 && ks != 5) return false;
+    if (cn < 1 || cn > 4) return false;
+    if (!aligned16(s, ss) || !aligned16(d, ds) || (sf & 15) || (df & 15)) return false;
+    if ((W * cn) % 16 != 0) return false;
+    if (H < 1) return false;
+    return true;
+}
+
+int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe,
+              int nframes, int W, int H, int cn, int mL, int mT, int mR, int mB,
+              const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, bool binomial)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    const bool hostSrc = !isDevicePtr(src);
+    if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+
+    Stager stg;
+    size_t dss = 0, dds = 0;
+    const size_t rowB = (size_t)W * cn;
+    const uchar* dsrc; uchar* ddst;
+    if (nframes == 1) {
+        // stage the ROI together with its real margins (non-isolated borders read them)
+        const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * cn;
+        const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * cn, mT + H + mB, &dss);
+        if (!dtop) return MI355CV_NOT_IMPLEMENTED;
+        dsrc = dtop + (size_t)mT * dss + (size_t)mL * cn;
+        ddst = stg.out(dst, dstep, rowB, H, &dds);
+        if (!ddst) return MI355CV_NOT_IMPLEMENTED;
+    } else {
+        // batches are an HBM-resident construct: no per-frame staging
+        if (hostSrc || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+        dsrc = src; ddst = dst; dss = sstep; dds = dstep;
+    }
+    hipStream_t st = stream();
+    const bool noMargins = !(mL | mT | mR | mB);
+    if (binomial && noMargins && rollEligible(dsrc, dss, sframe, ddst, dds, dframe, W, H, cn, nx) && nx == ny) {
+#define ROLL(KS_, CN_) launchRoll<KS_, CN_>(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, border, st)
+        if (nx == 5) { switch (cn) { case 1: ROLL(5, 1); break; case 2: ROLL(5, 2); break; case 3: ROLL(5, 3); break; default: ROLL(5, 4); } }
+        else         { switch (cn) { case 1: ROLL(3, 1); break; case 2: ROLL(3, 2); break; case 3: ROLL(3, 3); break; default: ROLL(3, 4); } }
+#undef ROLL
+    } else {
+        FixedTaps t;
+        t.nx = nx; t.ny = ny;
+        for (int i = 0; i < 33; i++) { t.kx[i] = i < nx ? kx[i] : 0; t.ky[i] = i < ny ? ky[i] : 0; }
+        dim3 grid(divUp(W * cn, 64), divUp(H, 4), nframes);
+        hipLaunchKernelGGL(k_sepfixed_generic, grid, dim3(256), 0, st, dsrc, dss, sframe, ddst, dds, dframe,
+                           W, H, cn, mL, mT, mR, mB, border, t);
+    }
+    return stg.finish(entry);
+}
+
+// sigma==0 Q8.8 tables (smooth.dispatch.cpp:89-145 scaled by 256; cf. test_smooth_bitexact.cpp:14-20)
+const uint16_t kBinom1[1] = {256};
+const uint16_t kBinom3[3] = {64, 128, 64};
+const uint16_t kBinom5[5] = {16, 64, 96, 64, 16};
+const uint16_t kBinom7[7] = {8, 28, 56, 72, 56, 28, 8};
+const uint16_t kBinom9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
+
+const uint16_t* binomTaps(size_t k)
+{
+    switch (k) { case 1: return kBinom1; case 3: return kBinom3; case 5: return kBinom5; case 7: return kBinom7; case 9: return kBinom9; }
+    return nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+MI355CV_API int mi355cv_gaussianBlurBinomial(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int cn, size_t margin_left, size_t margin_top, size_t margin_right,
+        size_t margin_bottom, size_t ksize, int border_type)
+{
+    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    const uint16_t* k = binomTaps(ksize);
+    if (!k) return MI355CV_NOT_IMPLEMENTED;
+    return runSmooth("gaussianBlurBinomial", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
+                     (int)margin_left, (int)margin_top, (int)margin_right, (int)margin_bottom,
+                     k, (int)ksize, k, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED, true);
+}
+
+MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
+        int width, int height, int depth, int cn, size_t ksize, int border_type)
+{
+    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    const uint16_t* k = binomTaps(ksize);
+    if (!k) return MI355CV_NOT_IMPLEMENTED;
+    if (nframes == 1)
+        return runSmooth("gaussianBlurBinomialBatch", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
+                         0, 0, 0, 0, k, (int)ksize, k, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED, true);
+    return runSmooth("gaussianBlurBinomialBatch", src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride,
+                     nframes, width, height, cn, 0, 0, 0, 0, k, (int)ksize, k, (int)ksize,
+                     border_type & ~MI355CV_BORDER_ISOLATED, true);
+}
+
+MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int cn, size_t margin_left, size_t margin_top, size_t margin_right,
+        size_t margin_bottom, size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type)
+{
+    // 8U only here: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724).
+    // Other depths go through sepFilter2D in the reference (:825) -- see mi355cv_sepFilter*.
+    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    if (ksize_width > 33 || ksize_height > 33) return MI355CV_NOT_IMPLEMENTED;
+    if (sigmaY <= 0) sigmaY = sigmaX;
+    std::vector<int64_t> qx, qy;
+    if (!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)) return MI355CV_NOT_IMPLEMENTED;
+    if (!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)) return MI355CV_NOT_IMPLEMENTED;
+    uint16_t kx[33], ky[33];
+    for (size_t i = 0; i < ksize_width; i++) { if (qx[i] < 0 || qx[i] > 65535) return MI355CV_NOT_IMPLEMENTED; kx[i] = (uint16_t)qx[i]; }
+    for (size_t i = 0; i < ksize_height; i++) { if (qy[i] < 0 || qy[i] > 65535) return MI355CV_NOT_IMPLEMENTED; ky[i] = (uint16_t)qy[i]; }
+    bool binom = ksize_width == ksize_height && (ksize_width == 3 || ksize_width == 5);
+    if (binom) {
+        const uint16_t* b = binomTaps(ksize_width);
+        for (size_t i = 0; i < ksize_width; i++) if (kx[i] != b[i] || ky[i] != b[i]) binom = false;
+    }
+    return runSmooth("gaussianBlur", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
+                     (int)margin_left, (int)margin_top, (int)margin_right, (int)margin_bottom,
+                     kx, (int)ksize_width, ky, (int)ksize_height, border_type & ~MI355CV_BORDER_ISOLATED, binom);
+}
+
+// host-side tap generator, exported so bindings can show / test the exact Q8.8 kernel in use
+MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps)
+{
+    std::vector<int64_t> q;
+    if (!gaussianKernelFixedQ(n, sigma, fractionBits, q)) return MI355CV_NOT_IMPLEMENTED;
+    for (int i = 0; i < n; i++) taps[i] = q[i];
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double* taps)
+{
+    std::vector<double> k;
+    if (!gaussianKernelBitExact(n, sigma, k)) return MI355CV_NOT_IMPLEMENTED;
+    for (int i = 0; i < n; i++) taps[i] = k[i];
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_sepSmoothFixedU8(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
+        int width, int height, int cn, size_t margin_left, size_t margin_top, size_t margin_right, size_t margin_bottom,
+        const uint16_t* kx, int kxlen, const uint16_t* ky, int kylen, int border_type)
+{
+    if (!kx || !ky) return MI355CV_NOT_IMPLEMENTED;
+    bool binom = kxlen == kylen && (kxlen == 3 || kxlen == 5);
+    if (binom) {
+        const uint16_t* b = binomTaps(kxlen);
+        for (int i = 0; i < kxlen; i++) if (kx[i] != b[i] || ky[i] != b[i]) binom = false;
+    }
+    return runSmooth("sepSmoothFixedU8", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
+                     (int)margin_left, (int)margin_top, (int)margin_right, (int)margin_bottom,
+                     kx, kxlen, ky, kylen, border_type & ~MI355CV_BORDER_ISOLATED, binom);
+}
+
+} // extern "C"

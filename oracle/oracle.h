@@ -1,0 +1,48 @@
+/*
+ * oracle.h -- CPU restatement of the reference's imgproc hot path, in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the parity tests, smoke() and
+ * bench.py's cpu_baseline leg compare the HIP path against.  Nothing under
+ * opencv_amd/ (the product) may include, link, load or call it.
+ *
+ * Every function cites the reference file:line it restates.  The restatement is
+ * pinned two ways (tests/test_oracle_*.py, `-m "not gpu"`):
+ *   1. against the reference's own known-answer tests (test_smooth_bitexact.cpp
+ *      eval(), test_color.cpp adler32 hashes, ...), and
+ *   2. against the REAL reference built from /root/reference by oracle/ref/Makefile
+ *      (oracle/_ref/libocvref.so) and against golden vectors it generated
+ *      (tests/golden/, generator scripts committed next to them).
+ */
+#ifndef MI355CV_ORACLE_H
+#define MI355CV_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_BORDER_CONSTANT = 0, ORC_BORDER_REPLICATE = 1, ORC_BORDER_REFLECT = 2, ORC_BORDER_WRAP = 3,
+       ORC_BORDER_REFLECT_101 = 4 };
+
+/* core/src/copy.cpp:748-793 */
+int orc_borderInterpolate(int p, int len, int borderType);
+
+/* GaussianBlurFixedPoint<uint16_t> (smooth.simd.hpp:2219 -> fixedSmoothInvoker :1926), Q8.8 taps.
+ * margins: real pixels around the ROI (non-isolated borders), 0 for isolated. */
+void orc_sepSmoothFixedU8(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn,
+                          int mL, int mT, int mR, int mB,
+                          const uint16_t* kx, int nx, const uint16_t* ky, int ny, int borderType);
+/* sigma==0 tables of getGaussianKernelBitExact (smooth.dispatch.cpp:89-145) in Q8.8; returns 0 if ksize unsupported */
+int orc_binomialTapsQ8(int ksize, uint16_t* taps);
+/* cv::GaussianBlur(src8U, ksize x ksize, sigma=0) == cv_hal_gaussianBlurBinomial contract */
+int orc_gaussianBlurBinomialU8(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn,
+                               int mL, int mT, int mR, int mB, int ksize, int borderType);
+
+/* getGaussianKernelBitExact (smooth.dispatch.cpp:81-198) / getGaussianKernelFixedPoint_ED (:224-258) */
+int orc_getGaussianKernel(int n, double sigma, double* taps);
+int orc_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
