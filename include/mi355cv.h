@@ -84,6 +84,12 @@ MI355CV_API int  mi355cv_synchronize(void);
 /* number of times the named entry point ran its GPU path to completion in this process
  * (the analogue of the reference's CV_IMPL_ADD bookkeeping, core/private.hpp) */
 MI355CV_API long long mi355cv_callCount(const char* entry);
+/* experiment knobs (see tools/tune_gauss.py) and the streaming-copy probe used as the measured-copy
+ * roofline denominator */
+MI355CV_API int mi355cv_setParam(const char* key, int value);
+MI355CV_API int mi355cv_copyProbe(const void* src_dev, void* dst_dev, size_t bytes, int perThread, int nontemporal);
+MI355CV_API int mi355cv_copyProbeColwalk(const void* src_dev, void* dst_dev, int width_bytes, int height, int nframes,
+                                         int segRows, int unroll);
 /* device memory helpers for hosts without a HIP binding (images that live in HBM) */
 MI355CV_API void* mi355cv_deviceAlloc(size_t bytes);
 MI355CV_API int   mi355cv_deviceFree(void* p);

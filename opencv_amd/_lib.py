@@ -37,6 +37,9 @@ def _load():
         "mi355cv_setAsync": (c_int, [c_int]),
         "mi355cv_synchronize": (c_int, []),
         "mi355cv_callCount": (ctypes.c_longlong, [ctypes.c_char_p]),
+        "mi355cv_setParam": (c_int, [ctypes.c_char_p, c_int]),
+        "mi355cv_copyProbe": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz, c_int, c_int]),
+        "mi355cv_copyProbeColwalk": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_deviceAlloc": (ctypes.c_void_p, [c_sz]),
         "mi355cv_deviceFree": (c_int, [ctypes.c_void_p]),
         "mi355cv_upload": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz]),

@@ -18,6 +18,8 @@
 //    byte, straight from the formula above.  Correctness path, not a fast path.
 #include "rt.h"
 #include "gausskernel.h"
+#include <cstring>
+#include <cstdlib>
 
 using namespace mi355;
 
@@ -235,18 +237,338 @@ __global__ __launch_bounds__(256) void k_binomial_roll(
     }
 }
 
+// ---------------------------------------------------------------------------------- rolling kernel v2
+// Same arithmetic as k_binomial_roll, restructured after the first rocprof passes (profiles/r01_*):
+//  * one WAVE = one work item (strip of 64 chunks x segment of rows x frame); work items are ordered so
+//    that the resident waves sweep memory linearly, like a streaming copy;
+//  * the row loop is free of exec-mask branches and calls: v1's divergent edge loads made the compiler
+//    drain vmcnt to 0 every row.  Every lane issues the same two loads per row (its 16 B + one side
+//    dword whose address only differs on lanes 0 / 63), image-border halos are rebuilt from the lane's
+//    own registers, and border rows are resolved to scalars before the loop;
+//  * a KS-deep ring of in-flight row loads per wave (a slot is refilled right after it is consumed);
+//  * neighbour bytes through DPP wave_shr/wave_shl (one v_mov_dpp) instead of ds_bpermute;
+//  * optional non-temporal stores (results are never re-read by this kernel).
+// Handles BORDER_CONSTANT/REPLICATE/REFLECT/REFLECT_101 with W > KS/2 (halo source bytes then lie
+// inside the first/last 16-byte chunk); BORDER_WRAP and narrower images use k_binomial_roll.
+template <int HD> struct RawRow2 {
+    uint4 m;
+    uint32_t side[HD];   // lane 0: bytes just left of its chunk; lane 63: bytes just right of it
+};
+
+// Image-border halos are rebuilt from the edge lane's own 16 bytes with three v_perm per halo dword:
+//   t1 = perm(m.y, m.x, selA) gathers candidates from bytes 0..7, t2 = perm(m.w, m.z, selB) from bytes 8..15,
+//   halo = perm(t2, t1, selC) picks per byte (0x0c = constant zero).  Selectors are wave-uniform.
+template <int HD> struct EdgeSel {
+    uint32_t la[HD], lb[HD], lc[HD];   // left halo dwords
+    uint32_t ra[HD], rb[HD], rc[HD];   // right halo dwords
+};
+
+__device__ __forceinline__ void selSetByte(uint32_t& a, uint32_t& b, uint32_t& c, int j, int idx /* 0..15 or <0 */)
+{
+    const uint32_t sh = 8u * (uint32_t)j, clr = ~(0xffu << sh);
+    uint32_t va = 0x0cu, vb = 0x0cu, vc = 0x0cu;
+    if (idx >= 8)      { vb = (uint32_t)(idx - 8); vc = 4u + (uint32_t)j; }
+    else if (idx >= 0) { va = (uint32_t)idx;       vc = (uint32_t)j; }
+    a = (a & clr) | (va << sh); b = (b & clr) | (vb << sh); c = (c & clr) | (vc << sh);
+}
+
+__device__ __forceinline__ uint32_t gather16(const uint4& m, uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t t1 = __builtin_amdgcn_perm(m.y, m.x, a);
+    const uint32_t t2 = __builtin_amdgcn_perm(m.w, m.z, b);
+    return __builtin_amdgcn_perm(t2, t1, c);
+}
+
+template <int KS, int CN, bool NTL = false>
+__device__ __forceinline__ void issueRow(RawRow2<RollCfg<KS, CN>::HD>& r, const uchar* __restrict__ row, int mainOff, int sideOff)
+{
+    constexpr int HD = RollCfg<KS, CN>::HD;
+    if constexpr (NTL) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + mainOff));
+        r.m = make_uint4(v.x, v.y, v.z, v.w);
+    } else
+    r.m = *reinterpret_cast<const uint4*>(row + mainOff);
+#pragma unroll
+    for (int d = 0; d < HD; d++) r.side[d] = *reinterpret_cast<const uint32_t*>(row + sideOff + 4 * d);
+}
+
+template <int KS, int CN>
+__device__ __forceinline__ void hfilter2(uint32_t (&Hrow)[8], const RawRow2<RollCfg<KS, CN>::HD>& r,
+                                         bool hasFirst, bool hasLast, bool isLastChunk, const EdgeSel<RollCfg<KS, CN>::HD>& es)
+{
+    constexpr int HD = RollCfg<KS, CN>::HD;
+    constexpr int NW = 4 + 2 * HD;
+    uint32_t X[NW];
+    const uint32_t mv[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+    uint32_t hl[HD], hr[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d++) { hl[d] = r.side[d]; hr[d] = r.side[d]; }
+    if (hasFirst) {          // wave-uniform: lane 0 is chunk 0, its left halo is the image border
+#pragma unroll
+        for (int d = 0; d < HD; d++) hl[d] = gather16(r.m, es.la[d], es.lb[d], es.lc[d]);
+    }
+    uint32_t hb[HD];
+    if (hasLast) {           // wave-uniform: some lane is the last chunk, its right halo is the image border
+#pragma unroll
+        for (int d = 0; d < HD; d++) hb[d] = gather16(r.m, es.ra[d], es.rb[d], es.rc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < HD; d++) {
+        // wave_shr:1 -> lane i takes lane i-1, lane 0 keeps `old` (its left halo);  wave_shl:1 mirrors it
+        X[d] = __builtin_amdgcn_update_dpp(hl[d], mv[4 - HD + d], 0x138, 0xf, 0xf, false);
+        uint32_t rr = __builtin_amdgcn_update_dpp(hr[d], mv[d], 0x130, 0xf, 0xf, false);
+        if (hasLast) rr = isLastChunk ? hb[d] : rr;
+        X[HD + 4 + d] = rr;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) X[HD + d] = mv[d];
+    uint32_t E[NW], O[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++) {
+        E[d] = __builtin_amdgcn_perm(0u, X[d], 0x0c020c00u);
+        O[d] = __builtin_amdgcn_perm(0u, X[d], 0x0c030c01u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (KS == 5) {
+            {   uint32_t a = pairAt<0, -2 * CN, HD>(E, O, k) + pairAt<0, 2 * CN, HD>(E, O, k);
+                uint32_t b = pairAt<0, -CN, HD>(E, O, k) + pairAt<0, CN, HD>(E, O, k);
+                uint32_t m = pairAt<0, 0, HD>(E, O, k);
+                Hrow[k] = a + (b << 2) + (m << 1) + (m << 2); }
+            {   uint32_t a = pairAt<1, -2 * CN, HD>(E, O, k) + pairAt<1, 2 * CN, HD>(E, O, k);
+                uint32_t b = pairAt<1, -CN, HD>(E, O, k) + pairAt<1, CN, HD>(E, O, k);
+                uint32_t m = pairAt<1, 0, HD>(E, O, k);
+                Hrow[4 + k] = a + (b << 2) + (m << 1) + (m << 2); }
+        } else {
+            Hrow[k]     = pairAt<0, -CN, HD>(E, O, k) + pairAt<0, CN, HD>(E, O, k) + (pairAt<0, 0, HD>(E, O, k) << 1);
+            Hrow[4 + k] = pairAt<1, -CN, HD>(E, O, k) + pairAt<1, CN, HD>(E, O, k) + (pairAt<1, 0, HD>(E, O, k) << 1);
+        }
+    }
+}
+
+template <int KS, int CN, bool NT, bool NTL, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
+    const uchar* __restrict__ src, size_t sstep, size_t sframe,
+    uchar* __restrict__ dst, size_t dstep, size_t dframe,
+    int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border)
+{
+    constexpr int R = KS / 2, HD = RollCfg<KS, CN>::HD, HB = RollCfg<KS, CN>::HB;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int strip = wid % nstrips;
+    const int t0 = wid / nstrips;
+    const int seg = t0 % nseg;
+    const int frame = t0 / nseg;
+    if (frame >= nframes) return;
+    const int c = strip * 64 + lane;
+    const int y0 = seg * segRows;
+    const int y1 = min(H, y0 + segRows);
+    src += (size_t)frame * sframe;
+    dst += (size_t)frame * dframe;
+    const bool active = c < nchunks;
+    const bool hasFirst = strip == 0, hasLast = strip == nstrips - 1;
+    const bool isLastChunk = c == nchunks - 1;
+    const int ce = active ? c : nchunks - 1;                  // idle lanes re-read the last chunk (harmless)
+    const int mainOff = 16 * ce;
+    // One side-dword load per row for the whole wave, touching only two 64-byte sectors: lanes 0..31 read
+    // the bytes just left of the wave's first chunk (lane 0 consumes them), lanes 32..63 the bytes just right
+    // of its last chunk (lane 63 consumes them).  At the image edges the address degenerates to in-row bytes
+    // whose value is ignored (the halo is then rebuilt from the border rule).
+    const int c0 = strip * 64;
+    const int leftOff = c0 > 0 ? 16 * c0 - 4 * HD : 0;
+    const int rightOff = c0 + 64 < nchunks ? 16 * (c0 + 64) : 16 * (nchunks - 1);
+    const int sideOff = lane < 32 ? leftOff : rightOff;
+
+    // image-border halo bytes expressed as byte indices inside the first / last chunk (wave-uniform)
+    EdgeSel<HD> es;
+#pragma unroll
+    for (int d = 0; d < HD; d++) { es.la[d] = es.lb[d] = es.lc[d] = es.ra[d] = es.rb[d] = es.rc[d] = 0x0c0c0c0cu; }
+    if (hasFirst) {
+#pragma unroll
+        for (int t = 0; t < HB; t++) {
+            const int bt = t - HB;                             // byte position relative to the row start (<0)
+            const int px = (bt - (CN - 1)) / CN;               // floor(bt / CN)
+            const int sp = mi355_borderInterpolate(px, W, border);
+            const int pos = 4 * HD - HB + t;                   // byte position inside the HD halo dwords
+            selSetByte(es.la[pos >> 2], es.lb[pos >> 2], es.lc[pos >> 2], pos & 3, sp < 0 ? -1 : sp * CN + (bt - px * CN));
+        }
+    }
+    if (hasLast) {
+#pragma unroll
+        for (int t = 0; t < HB; t++) {
+            const int sp = mi355_borderInterpolate(W + t / CN, W, border);
+            selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - 16 * (nchunks - 1));
+        }
+    }
+    // rows: everything outside [0,H) is resolved here, the loop only selects
+    int rowBelow[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) rowBelow[i] = mi355_borderInterpolate(H + i, H, border);
+    auto rowIdx = [&](int yy) -> int {                         // yy >= 0
+        int ry = yy;
+#pragma unroll
+        for (int i = 0; i < R; i++) ry = (yy == H + i) ? rowBelow[i] : ry;
+        return ry;
+    };
+
+    uint32_t Hw[KS][8];
+#pragma unroll
+    for (int i = 0; i < KS - 1; i++) {      // prologue: rows y0-R .. y0+R-1 -> slots 0..KS-2
+        const int yy = y0 - R + i;
+        const int ry = (unsigned)yy < (unsigned)H ? yy : mi355_borderInterpolate(yy, H, border);
+        if (ry < 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) Hw[i][j] = 0;
+        } else {
+            RawRow2<HD> pre;
+            issueRow<KS, CN>(pre, src + (size_t)ry * sstep, mainOff, sideOff);
+            hfilter2<KS, CN>(Hw[i], pre, hasFirst, hasLast, isLastChunk, es);
+        }
+    }
+    RawRow2<HD> raw[KS];
+    int rvalid[KS];
+#pragma unroll
+    for (int u = 0; u < KS; u++) {          // prime the ring: rows y0+R+u
+        const int yy = min(y0 + u + R, H + R - 1);
+        const int ry = rowIdx(yy);
+        rvalid[u] = ry >= 0;
+        issueRow<KS, CN, NTL>(raw[u], src + (size_t)max(ry, 0) * sstep, mainOff, sideOff);
+    }
+    for (int y = y0; y < y1; y += KS) {
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            if (y + u < y1) {
+                uint32_t (&Hn)[8] = Hw[(KS - 1 + u) % KS];
+                if (rvalid[u]) hfilter2<KS, CN>(Hn, raw[u], hasFirst, hasLast, isLastChunk, es);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) Hn[j] = 0;
+                }
+                {   // refill this ring slot with the row needed KS iterations from now (clamped: always a legal address)
+                    const int yy = min(y + u + KS + R, H + R - 1);
+                    const int ry = rowIdx(yy);
+                    rvalid[u] = ry >= 0;
+                    issueRow<KS, CN, NTL>(raw[u], src + (size_t)max(ry, 0) * sstep, mainOff, sideOff);
+                }
+                uint32_t o[4];
+                if constexpr (KS == 5) {
+                    const uint32_t* h0 = Hw[(u + 0) % 5]; const uint32_t* h1 = Hw[(u + 1) % 5];
+                    const uint32_t* h2 = Hw[(u + 2) % 5]; const uint32_t* h3 = Hw[(u + 3) % 5];
+                    const uint32_t* h4 = Hw[(u + 4) % 5];
+                    uint32_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        v[i] = (h0[i] + h4[i]) + ((h1[i] + h3[i]) << 2) + (h2[i] << 1) + (h2[i] << 2) + 0x00800080u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_perm(v[4 + k], v[k], 0x07030501u);
+                } else {
+                    const uint32_t* h0 = Hw[(u + 0) % 3]; const uint32_t* h1 = Hw[(u + 1) % 3]; const uint32_t* h2 = Hw[(u + 2) % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t ve = ((h0[k] + h2[k] + (h1[k] << 1) + 0x00080008u) >> 4) & 0x00FF00FFu;
+                        uint32_t vo = ((h0[4 + k] + h2[4 + k] + (h1[4 + k] << 1) + 0x00080008u) >> 4) & 0x00FF00FFu;
+                        o[k] = ve | (vo << 8);
+                    }
+                }
+                if (active) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 ov = {o[0], o[1], o[2], o[3]};
+                    u32x4* dp = reinterpret_cast<u32x4*>(dst + (size_t)(y + u) * dstep + 16 * (size_t)c);
+                    if constexpr (NT) __builtin_nontemporal_store(ov, dp);
+                    else *dp = ov;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- copy probe
+// 16 B/lane streaming copy with the same launch geometry as the rolling kernel's traffic (1 read :
+// 1 write): the measured-copy denominator BASELINE.md asks for next to the 8 TB/s spec figure.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n16, int perThread)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    size_t base = ((size_t)blockIdx.x * perThread) * 256 + threadIdx.x;
+#pragma unroll 4
+    for (int i = 0; i < perThread; i++) {
+        size_t j = base + (size_t)i * 256;
+        if (j < n16) {
+            uint4 v = s[j];
+            u32x4 ov = {v.x, v.y, v.z, v.w};
+            if constexpr (NT) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(d + j));
+            else d[j] = v;
+        }
+    }
+}
+
+// column-walk copy probe: the rolling kernel's work decomposition and access order (wave = 1 KB wide strip
+// walking down `segRows` rows) with the arithmetic removed -- separates access-pattern effects from ALU/wait effects
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_copy_colwalk(const uchar* __restrict__ src, uchar* __restrict__ dst, size_t step, size_t frame,
+                                                      int H, int nchunks, int nstrips, int segRows, int nseg, int nframes)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int strip = wid % nstrips, t0 = wid / nstrips, seg = t0 % nseg, fr = t0 / nseg;
+    if (fr >= nframes) return;
+    const int c = strip * 64 + lane;
+    if (c >= nchunks) return;
+    const int y0 = seg * segRows, y1 = min(H, y0 + segRows);
+    const uchar* s = src + (size_t)fr * frame + 16 * (size_t)c;
+    uchar* d = dst + (size_t)fr * frame + 16 * (size_t)c;
+    for (int y = y0; y < y1; y += UNROLL) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = *reinterpret_cast<const uint4*>(s + (size_t)min(y + u, y1 - 1) * step);
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) if (y + u < y1) *reinterpret_cast<uint4*>(d + (size_t)(y + u) * step) = v[u];
+    }
+}
+
 // ---------------------------------------------------------------------------------- host side
 
 bool aligned16(const void* p, size_t step) { return (((uintptr_t)p | step) & 15) == 0; }
 
 int envInt(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
 
+int& tuneSeg() { static int v = envInt("MI355CV_GAUSS_SEG", 0); return v; }
+int& tuneVariant() { static int v = envInt("MI355CV_GAUSS_VARIANT", 3); return v; }   // 1: k_binomial_roll, 2: roll2, 3: roll2 + nt stores, 4: + nt loads
+
+template <int KS, int CN>
+void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nframes, int W, int H, int border, hipStream_t st, int nt)
+{
+    const int nchunks = W * CN / 16;
+    const int nstrips = divUp(nchunks, 64);
+    int seg = tuneSeg();
+    if (seg <= 0) {
+        // Short segments keep the set of rows being streamed at any instant compact (measured: 15-20 rows per
+        // work item beat 70 by 10 % on 128 x 4K frames although a 5x5 then re-reads 4/15 of its rows from
+        // L2/MALL); single frames go shorter still so that >= ~2 waves per SIMD exist at all.
+        long long per = (long long)nstrips * nframes;
+        long long wantSeg = (2048 + per - 1) / per;
+        seg = (int)((H + wantSeg - 1) / wantSeg);
+        if (seg > 4 * KS) seg = 4 * KS;
+        if (seg < KS) seg = KS;
+    }
+    seg = divUp(seg, KS) * KS;
+    if (seg > H) seg = divUp(H, KS) * KS;
+    const int nseg = divUp(H, seg);
+    const long long items = (long long)nstrips * nseg * nframes;
+    dim3 grid((unsigned)((items + 3) / 4));
+    if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
+    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, true, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
+    else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
+    else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
+}
+
 template <int KS, int CN>
 void launchRoll(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nframes, int W, int H, int border, hipStream_t st)
 {
     const int nchunks = W * CN / 16;
     const int gx = divUp(nchunks, 256);
-    static const int segEnv = envInt("MI355CV_GAUSS_SEG", 0);
+    const int segEnv = tuneSeg();
     int seg;
     if (segEnv > 0) seg = segEnv;
     else {
@@ -306,7 +628,8 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     hipStream_t st = stream();
     const bool noMargins = !(mL | mT | mR | mB);
     if (binomial && noMargins && rollEligible(dsrc, dss, sframe, ddst, dds, dframe, W, H, cn, nx) && nx == ny) {
-#define ROLL(KS_, CN_) launchRoll<KS_, CN_>(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, border, st)
+#define ROLL(KS_, CN_) do { if (tuneVariant() <= 1 || border == B_WRAP || W <= KS_ / 2) launchRoll<KS_, CN_>(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, border, st); \
+                            else launchRoll2<KS_, CN_>(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, border, st, tuneVariant() - 2); } while (0)
         if (nx == 5) { switch (cn) { case 1: ROLL(5, 1); break; case 2: ROLL(5, 2); break; case 3: ROLL(5, 3); break; default: ROLL(5, 4); } }
         else         { switch (cn) { case 1: ROLL(3, 1); break; case 2: ROLL(3, 2); break; case 3: ROLL(3, 3); break; default: ROLL(3, 4); } }
 #undef ROLL
@@ -388,6 +711,45 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
     return runSmooth("gaussianBlur", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
                      (int)margin_left, (int)margin_top, (int)margin_right, (int)margin_bottom,
                      kx, (int)ksize_width, ky, (int)ksize_height, border_type & ~MI355CV_BORDER_ISOLATED, binom);
+}
+
+// tuning knobs for experiments (tools/tune_gauss.py): "gauss_seg" rows per work item (0 = heuristic),
+// "gauss_variant" 1|2|3
+MI355CV_API int mi355cv_setParam(const char* key, int value)
+{
+    if (!key) return -1;
+    if (!strcmp(key, "gauss_seg")) { tuneSeg() = value; return 0; }
+    if (!strcmp(key, "gauss_variant")) { tuneVariant() = value; return 0; }
+    return -1;
+}
+
+// streaming-copy probe: copies `bytes` (multiple of 16) device->device with 16 B/lane accesses
+MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int perThread, int nt)
+{
+    if (!ensureDevice() || (bytes & 15) || perThread < 1) return MI355CV_NOT_IMPLEMENTED;
+    size_t n16 = bytes / 16;
+    size_t blocks = (n16 + (size_t)256 * perThread - 1) / ((size_t)256 * perThread);
+    if (nt) hipLaunchKernelGGL((k_copy16<true>), dim3((unsigned)blocks), dim3(256), 0, stream(), (const uint4*)src, (uint4*)dst, n16, perThread);
+    else    hipLaunchKernelGGL((k_copy16<false>), dim3((unsigned)blocks), dim3(256), 0, stream(), (const uint4*)src, (uint4*)dst, n16, perThread);
+    if (hipGetLastError() != hipSuccess) return MI355CV_ERROR_UNKNOWN;
+    if (!asyncMode()) hipStreamSynchronize(stream());
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int H, int nframes, int segRows, int unroll)
+{
+    if (!ensureDevice() || (W & 15)) return MI355CV_NOT_IMPLEMENTED;
+    const int nchunks = W / 16, nstrips = divUp(nchunks, 64), nseg = divUp(H, segRows);
+    const long long items = (long long)nstrips * nseg * nframes;
+    dim3 grid((unsigned)((items + 3) / 4));
+    const uchar* s = (const uchar*)src; uchar* d = (uchar*)dst;
+    if (unroll == 1) hipLaunchKernelGGL((k_copy_colwalk<1>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
+    else if (unroll == 2) hipLaunchKernelGGL((k_copy_colwalk<2>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
+    else if (unroll == 5) hipLaunchKernelGGL((k_copy_colwalk<5>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
+    else hipLaunchKernelGGL((k_copy_colwalk<10>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
+    if (hipGetLastError() != hipSuccess) return MI355CV_ERROR_UNKNOWN;
+    if (!asyncMode()) hipStreamSynchronize(stream());
+    return MI355CV_OK;
 }
 
 // host-side tap generator, exported so bindings can show / test the exact Q8.8 kernel in use

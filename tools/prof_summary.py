@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 csv output (tools/prof_gauss.sh) into a per-kernel summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_"
+
+
+def rows(path):
+    with open(path, newline="") as f:
+        yield from csv.DictReader(f)
+
+
+print("== kernel trace (ns) ==")
+for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    d = defaultdict(list)
+    for r in rows(p):
+        d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        v2 = sorted(v)
+        print(f"{k[:90]:90s} calls={len(v):5d} avg={sum(v)/len(v):12.0f} min={v2[0]:10d} med={v2[len(v2)//2]:10d} max={v2[-1]:10d}")
+for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("== rocprofv3 --stats ==")
+    print(open(p).read())
+print("== PMC (per-dispatch average over dispatches of kernels matching '%s') ==" % pat)
+for p in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in rows(p):
+        if pat in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        for c, v in cs.items():
+            print(f"{k[:60]:60s} {c:28s} n={len(v):4d} avg={sum(v)/len(v):18.1f}")
