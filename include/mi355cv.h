@@ -24,6 +24,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -134,6 +137,61 @@ MI355CV_API int mi355cv_sepSmoothFixedU8(const mi355cv_uchar* src_data, size_t s
 MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
         mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int cn, size_t ksize, int border_type);
+
+/* --------------------------------------------------- a3/a4/a5: linear filters */
+
+struct cvhalFilter2D;   /* opaque context, as in hal_replacement.hpp:87 */
+
+/* replace hal_ni_filterInit / hal_ni_filter / hal_ni_filterFree (hal_replacement.hpp:109,125,131);
+ * callers: replacementFilter2D filter.dispatch.cpp:1163-1185 (cv::filter2D).  Depths 8U/16U/16S/32F,
+ * any kernel size up to 1024 taps, any anchor, borders CONSTANT(0)/REPLICATE/REFLECT/WRAP/REFLECT_101. */
+MI355CV_API int mi355cv_filterInit(struct cvhalFilter2D** context, mi355cv_uchar* kernel_data, size_t kernel_step, int kernel_type,
+        int kernel_width, int kernel_height, int max_width, int max_height, int src_type, int dst_type, int borderType,
+        double delta, int anchor_x, int anchor_y, bool allowSubmatrix, bool allowInplace);
+MI355CV_API int mi355cv_filter(struct cvhalFilter2D* context, mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data,
+        size_t dst_step, int width, int height, int full_width, int full_height, int offset_x, int offset_y);
+MI355CV_API int mi355cv_filterFree(struct cvhalFilter2D* context);
+
+/* replace hal_ni_sepFilterInit / hal_ni_sepFilter / hal_ni_sepFilterFree (hal_replacement.hpp:155,171,177);
+ * callers: replacementSepFilter filter.dispatch.cpp:1362-1383 (cv::sepFilter2D, and through it Sobel/Scharr/
+ * GaussianBlur on non-8U depths). */
+MI355CV_API int mi355cv_sepFilterInit(struct cvhalFilter2D** context, int src_type, int dst_type, int kernel_type,
+        mi355cv_uchar* kernelx_data, int kernelx_length, mi355cv_uchar* kernely_data, int kernely_length,
+        int anchor_x, int anchor_y, double delta, int borderType);
+MI355CV_API int mi355cv_sepFilter(struct cvhalFilter2D* context, mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data,
+        size_t dst_step, int width, int height, int full_width, int full_height, int offset_x, int offset_y);
+MI355CV_API int mi355cv_sepFilterFree(struct cvhalFilter2D* context);
+
+/* replaces hal_ni_sobel (hal_replacement.hpp:1197; caller deriv.cpp:456) and hal_ni_scharr (:1224; caller deriv.cpp:511) */
+MI355CV_API int mi355cv_sobel(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right,
+        int margin_bottom, int dx, int dy, int ksize, double scale, double delta, int border_type);
+MI355CV_API int mi355cv_scharr(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right,
+        int margin_bottom, int dx, int dy, double scale, double delta, int border_type);
+
+/* replaces hal_ni_boxFilter (hal_replacement.hpp:1105; caller box_filter.dispatch.cpp:474) */
+MI355CV_API int mi355cv_boxFilter(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right,
+        int margin_bottom, size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type);
+
+/* --------------------------------------------------- a6: colour conversion */
+
+/* replaces hal_ni_cvtBGRtoGray (hal_replacement.hpp:442); caller hal::cvtBGRtoGray color_rgb.dispatch.cpp:276.
+ * depth 8U / 16U / 32F, scn 3|4.  8U/16U bit-exact (RGB2Gray<uchar> color_rgb.simd.hpp:660), 32F = the FMA chain
+ * of RGB2Gray<float> :608. */
+MI355CV_API int mi355cv_cvtBGRtoGray(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int scn, bool swapBlue);
+/* replaces hal_ni_cvtGraytoBGR (hal_replacement.hpp:456) */
+MI355CV_API int mi355cv_cvtGraytoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int dcn);
+/* replaces hal_ni_cvtBGRtoBGR (hal_replacement.hpp:395): reorder / add / drop alpha */
+MI355CV_API int mi355cv_cvtBGRtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int scn, int dcn, bool swapBlue);
+/* batched BGR->gray over device-resident frames (grid-z = frame) */
+MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
+        int width, int height, int depth, int scn, int swapBlue);
 
 #ifdef __cplusplus
 }

@@ -14,4 +14,39 @@
 #undef  cv_hal_gaussianBlurBinomial
 #define cv_hal_gaussianBlurBinomial mi355cv_gaussianBlurBinomial
 
+// hal_replacement.hpp:109-131 / callers filter.dispatch.cpp:1163-1185
+#undef  cv_hal_filterInit
+#define cv_hal_filterInit mi355cv_filterInit
+#undef  cv_hal_filter
+#define cv_hal_filter mi355cv_filter
+#undef  cv_hal_filterFree
+#define cv_hal_filterFree mi355cv_filterFree
+// hal_replacement.hpp:155-177 / callers filter.dispatch.cpp:1362-1383
+#undef  cv_hal_sepFilterInit
+#define cv_hal_sepFilterInit mi355cv_sepFilterInit
+#undef  cv_hal_sepFilter
+#define cv_hal_sepFilter mi355cv_sepFilter
+#undef  cv_hal_sepFilterFree
+#define cv_hal_sepFilterFree mi355cv_sepFilterFree
+// hal_replacement.hpp:1197 / deriv.cpp:456 ; :1224 / deriv.cpp:511
+#undef  cv_hal_sobel
+#define cv_hal_sobel mi355cv_sobel
+#undef  cv_hal_scharr
+#define cv_hal_scharr mi355cv_scharr
+// hal_replacement.hpp:1105 / box_filter.dispatch.cpp:474
+#undef  cv_hal_boxFilter
+#define cv_hal_boxFilter mi355cv_boxFilter
+// hal_replacement.hpp:1146 / smooth.dispatch.cpp:708,778,813
+#undef  cv_hal_gaussianBlur
+#define cv_hal_gaussianBlur mi355cv_gaussianBlur
+// hal_replacement.hpp:442 / caller color_rgb.dispatch.cpp:276
+#undef  cv_hal_cvtBGRtoGray
+#define cv_hal_cvtBGRtoGray mi355cv_cvtBGRtoGray
+// hal_replacement.hpp:456
+#undef  cv_hal_cvtGraytoBGR
+#define cv_hal_cvtGraytoBGR mi355cv_cvtGraytoBGR
+// hal_replacement.hpp:395
+#undef  cv_hal_cvtBGRtoBGR
+#define cv_hal_cvtBGRtoBGR mi355cv_cvtBGRtoBGR
+
 #endif

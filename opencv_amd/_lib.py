@@ -52,6 +52,24 @@ def _load():
         "mi355cv_getGaussianKernelQ": (c_int, [c_int, c_dbl, c_int, ctypes.c_void_p]),
         "mi355cv_gaussianBlurBinomialBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int,
                                                       c_int, c_int, c_int, c_int, c_sz, c_int]),
+        "mi355cv_filterInit": (c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_sz, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_dbl, c_int, c_int, ctypes.c_bool, ctypes.c_bool]),
+        "mi355cv_filter": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_filterFree": (c_int, [ctypes.c_void_p]),
+        "mi355cv_sepFilterInit": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, c_int, c_int, ctypes.c_void_p, c_int,
+                                          ctypes.c_void_p, c_int, c_int, c_int, c_dbl, c_int]),
+        "mi355cv_sepFilter": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_sepFilterFree": (c_int, [ctypes.c_void_p]),
+        "mi355cv_sobel": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
+        "mi355cv_scharr": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_dbl, c_dbl, c_int]),
+        "mi355cv_boxFilter": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_sz, c_sz, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtBGRtoGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
+        "mi355cv_cvtGraytoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int]),
+        "mi355cv_cvtBGRtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_bool]),
+        "mi355cv_cvtBGRtoGrayBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_sepSmoothFixedU8": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int,
                                              c_sz, c_sz, c_sz, c_sz, ctypes.c_void_p, c_int, ctypes.c_void_p, c_int, c_int]),
     }

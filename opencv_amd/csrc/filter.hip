@@ -1,0 +1,576 @@
+// filter.hip -- rows a3/a4 of SURVEY.md §8: cv::filter2D, cv::sepFilter2D, cv::Sobel, cv::Scharr.
+//
+// Reference semantics restated here:
+//  * filter2D (filter.simd.hpp:3103 Filter2D, :2146 FilterVec_8u, filter.dispatch.cpp:390 preprocess2DKernel):
+//      kernel -> float; s = delta; for every NON-ZERO tap in raster order: s = fma(float(px), k, s);
+//      dst = saturate_cast<DT>(s) (round-half-even for integer DT).  Correlation (kernel not flipped), anchor,
+//      borders by borderInterpolate over the FULL image when the ROI has real neighbours, BORDER_CONSTANT = 0.
+//  * sepFilter2D (filter.dispatch.cpp:305 createSeparableLinearFilter):
+//      - 8U->8U with both kernels smooth+symmetrical: bit-exact integer mode, taps*256 -> int32,
+//        dst = sat_u8((sum_j ky[j]*sum_i kx[i]*p + delta*2^16 + 2^15) >> 16)         (:326-352, FixedPtCastEx :2937)
+//      - 8U->16S with integer (anti)symmetrical kernels (Sobel/Scharr): exact int32, dst = sat_s16(sum + delta)
+//      - otherwise float: row sums s = k0*p0, s = fma(kk, pk, s) (RowFilter :2386), column in the
+//        (anti)symmetric pair form s = k0*r0 + delta, s += kk*(r[+k] +- r[-k]) (SymmColumnFilter :2679-2751) or the
+//        plain chain (ColumnFilter :2609), then saturate_cast<DT>.  Float results agree with the CPU to rounding
+//        (the CPU picks among several SIMD association orders); the parity bar there is 1e-4 relative.
+//  * Sobel / Scharr (deriv.cpp:87 getSobelKernels, :55 getScharrKernels, :414 cv::Sobel): kernels generated as the
+//    reference does, `scale` folded into the smoothing kernel, then the separable engine.
+//
+// The kernels in this file are the GENERAL path: one thread per output element, taps read through L1/L2.  They are
+// correct for every depth/border/anchor/ROI combination above.  The 4K 8U 3x3 configuration of BASELINE.json has
+// its own fast path (TODO next round: register-rolling 3x3).
+#include "rt.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+
+__device__ __forceinline__ float ldF(const uchar* row, int idx, int depth)
+{
+    switch (depth) {
+    case D8U:  return (float)row[idx];
+    case D16U: return (float)reinterpret_cast<const unsigned short*>(row)[idx];
+    case D16S: return (float)reinterpret_cast<const short*>(row)[idx];
+    default:   return reinterpret_cast<const float*>(row)[idx];
+    }
+}
+
+// saturate_cast<DT>(float): cvRound (round-half-even) then clamp (core/saturate.hpp:103-142)
+__device__ __forceinline__ void stF(uchar* row, int idx, int depth, float s)
+{
+    switch (depth) {
+    case D8U:  { float r = rintf(s); r = fminf(fmaxf(r, 0.f), 255.f); row[idx] = (uchar)(int)r; break; }
+    case D16U: { float r = rintf(s); r = fminf(fmaxf(r, 0.f), 65535.f); reinterpret_cast<unsigned short*>(row)[idx] = (unsigned short)(int)r; break; }
+    case D16S: { float r = rintf(s); r = fminf(fmaxf(r, -32768.f), 32767.f); reinterpret_cast<short*>(row)[idx] = (short)(int)r; break; }
+    default:   reinterpret_cast<float*>(row)[idx] = s;
+    }
+}
+
+struct Tap2D { float k; int dx, dy; };
+
+__global__ __launch_bounds__(256) void k_filter2d_generic(
+    const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+    int W, int H, int cn, int sdepth, int ddepth, int fullW, int fullH, int offX, int offY,
+    const Tap2D* __restrict__ taps, int ntaps, int ax, int ay, int kw, int kh, float delta, int border)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const int fx = x + offX - ax, fy = y + offY - ay;              // full-image coordinates of tap (0,0)
+    float s = delta;
+    if (fx >= 0 && fy >= 0 && fx + kw <= fullW && fy + kh <= fullH) {   // interior: no border logic
+        const uchar* base = src + (ptrdiff_t)(y - ay) * (ptrdiff_t)sstep;
+        const int e0 = (x - ax) * cn + ch;
+        for (int t = 0; t < ntaps; t++) {
+            const Tap2D tp = taps[t];
+            s = __builtin_fmaf(ldF(base + (ptrdiff_t)tp.dy * (ptrdiff_t)sstep, e0 + tp.dx * cn, sdepth), tp.k, s);
+        }
+    } else {
+        for (int t = 0; t < ntaps; t++) {
+            const Tap2D tp = taps[t];
+            const int yy = mi355_borderInterpolate(fy + tp.dy, fullH, border);
+            const int xx = mi355_borderInterpolate(fx + tp.dx, fullW, border);
+            float v = 0.f;
+            if (yy >= 0 && xx >= 0)
+                v = ldF(src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep, (xx - offX) * cn + ch, sdepth);
+            s = __builtin_fmaf(v, tp.k, s);
+        }
+    }
+    stF(dst + (size_t)y * dstep, e, ddepth, s);
+}
+
+// ---------------------------------------------------------------------------------- separable
+struct SepParams {
+    float kxf[33], kyf[33];
+    int   kxi[33], kyi[33];
+    int nx, ny, ax, ay;
+    int mode;        // 0 float, 1 int Q8 x Q8 (8U->8U), 2 int exact (8U->16S)
+    int symY;        // 1 symmetrical pair form, 2 anti-symmetrical pair form, 0 plain chain
+    float deltaF;
+    int deltaI;
+};
+
+__global__ __launch_bounds__(256) void k_sepfilter_generic(
+    const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+    int W, int H, int cn, int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border, SepParams p)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const int fx0 = x + offX - p.ax, fy0 = y + offY - p.ay;
+    int xs[33];
+    for (int i = 0; i < p.nx; i++) {
+        int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
+        xs[i] = xx < 0 ? -1 : (xx - offX) * cn + ch;
+    }
+    if (p.mode != 0) {
+        // integer modes: order of summation is irrelevant
+        long long acc = p.deltaI;
+        int ri[33];
+        for (int j = 0; j < p.ny; j++) {
+            const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
+            ri[j] = 0;
+            if (yy < 0) continue;
+            const uchar* row = src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep;
+            int rs = 0;
+            for (int i = 0; i < p.nx; i++) if (xs[i] >= 0) rs += p.kxi[i] * (int)row[xs[i]];
+            ri[j] = rs;
+            acc += (long long)p.kyi[j] * rs;
+        }
+        int a = (int)acc;                                      // the reference accumulates in int32 (wraps identically)
+        if (p.mode == 1 && p.ny > 1 && e < ((W * cn) & ~15)) {
+            // What the reference's AVX2 build computes for every element its 16-lane loop reaches
+            // (SymmColumnVec_32s8u, filter.simd.hpp:1011-1085): int32 row sums combined in FLOAT (taps * 2^-16, FMA
+            // chain, round-half-even).  Only its scalar tail (below) uses the integer (v + 2^15) >> 16 form.
+            const int c = p.ay;
+            float sF = __builtin_fmaf((float)ri[c], (float)p.kyi[c] * (1.0f / 65536.0f), p.deltaF);
+            for (int k = 1; k <= p.ny / 2; k++)
+                sF = __builtin_fmaf((float)(ri[c + k] + ri[c - k]), (float)p.kyi[c + k] * (1.0f / 65536.0f), sF);
+            float r = rintf(sF);
+            dst[(size_t)y * dstep + e] = (uchar)(int)fminf(fmaxf(r, 0.f), 255.f);
+        } else if (p.mode == 1) {
+            int r = (a + (1 << 15)) >> 16;
+            dst[(size_t)y * dstep + e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+        } else {
+            reinterpret_cast<short*>(dst + (size_t)y * dstep)[e] = (short)(a < -32768 ? -32768 : a > 32767 ? 32767 : a);
+        }
+        return;
+    }
+    // float mode: row sums as RowFilter does, for the ny rows this output needs
+    auto rowSum = [&](int j) -> float {
+        const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
+        const uchar* row = src + (ptrdiff_t)((yy < 0 ? offY : yy) - offY) * (ptrdiff_t)sstep;
+        float s = 0.f;
+        for (int i = 0; i < p.nx; i++) {
+            const float v = (yy < 0 || xs[i] < 0) ? 0.f : ldF(row, xs[i], sdepth);
+            s = i == 0 ? p.kxf[0] * v : __builtin_fmaf(p.kxf[i], v, s);
+        }
+        return s;
+    };
+    float s;
+    if (p.symY) {
+        const int c = p.ay;                                    // centred anchor is part of the symmetry test
+        s = __builtin_fmaf(p.kyf[c], rowSum(c), p.deltaF);
+        if (p.symY == 2) s = p.deltaF;
+        for (int k = 1; k <= p.ny / 2; k++) {
+            const float a = rowSum(c + k), b = rowSum(c - k);
+            s = __builtin_fmaf(p.kyf[c + k], p.symY == 1 ? a + b : a - b, s);
+        }
+    } else {
+        s = __builtin_fmaf(p.kyf[0], rowSum(0), p.deltaF);
+        for (int j = 1; j < p.ny; j++) s = __builtin_fmaf(p.kyf[j], rowSum(j), s);
+    }
+    stF(dst + (size_t)y * dstep, e, ddepth, s);
+}
+
+
+// ---------------------------------------------------------------------------------- box filter (row a5)
+// cv::boxFilter (box_filter.dispatch.cpp:440, createBoxFilter box_filter.simd.hpp:1250):
+//   8U->8U, area <= 256 : u16 sums; normalised result = ((s + dd) * ds) >> 23 with the reciprocal pair (ds, dd) of
+//                         ColumnSum<ushort,uchar> (:429-455); un-normalised = saturate_u8(s)
+//   other integer inputs: int32 sums; normalised = cvRound(float(s) * float(1/area)) (the SIMD body of
+//                         ColumnSum<int,uchar> :340-372), un-normalised = saturate(s)
+//   float input         : double sums (RowSum<float,double>, ColumnSum<double,float>), result = float(s * scale)
+struct BoxParams { int kw, kh, ax, ay, normalize, mode /*0 u16, 1 int, 2 double*/, divScale, divDelta; float scaleF; double scaleD; };
+
+__global__ __launch_bounds__(256) void k_box_generic(
+    const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+    int W, int H, int cn, int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border, BoxParams p)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const int fx0 = x + offX - p.ax, fy0 = y + offY - p.ay;
+    uchar* drow = dst + (size_t)y * dstep;
+    if (p.mode == 2) {
+        double s = 0.0;
+        for (int j = 0; j < p.kh; j++) {
+            const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
+            if (yy < 0) continue;
+            const uchar* row = src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep;
+            double rs = 0.0;
+            for (int i = 0; i < p.kw; i++) {
+                const int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
+                if (xx >= 0) rs += (double)reinterpret_cast<const float*>(row)[(xx - offX) * cn + ch];
+            }
+            s += rs;
+        }
+        reinterpret_cast<float*>(drow)[e] = (float)(p.normalize ? s * p.scaleD : s);
+        return;
+    }
+    int s = 0;
+    for (int j = 0; j < p.kh; j++) {
+        const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
+        if (yy < 0) continue;
+        const uchar* row = src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep;
+        for (int i = 0; i < p.kw; i++) {
+            const int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
+            if (xx < 0) continue;
+            const int idx = (xx - offX) * cn + ch;
+            s += sdepth == D8U ? (int)row[idx] : sdepth == D16U ? (int)reinterpret_cast<const unsigned short*>(row)[idx]
+                                                              : (int)reinterpret_cast<const short*>(row)[idx];
+        }
+    }
+    if (p.mode == 0) {
+        unsigned r = p.normalize ? (((unsigned)s + (unsigned)p.divDelta) * (unsigned)p.divScale) >> 23 : (unsigned)s;
+        drow[e] = (uchar)(p.normalize ? r : (r > 255u ? 255u : r));
+        return;
+    }
+    if (ddepth == D32F) { reinterpret_cast<float*>(drow)[e] = p.normalize ? (float)((double)s * p.scaleD) : (float)s; return; }
+    float v = p.normalize ? rintf((float)s * p.scaleF) : (float)s;
+    stF(drow, e, ddepth, v);
+}
+
+// ---------------------------------------------------------------------------------- host: contexts
+int depthSize(int d) { return d == D8U ? 1 : (d == D16U || d == D16S) ? 2 : d == D32F ? 4 : 0; }
+
+double kernelAt(const uchar* data, size_t step, int type, int r, int c)
+{
+    const uchar* p = data + (size_t)r * step;
+    switch (MI355CV_MAT_DEPTH(type)) {
+    case MI355CV_8U:  return p[c];
+    case MI355CV_8S:  return ((const signed char*)p)[c];
+    case MI355CV_16U: return ((const unsigned short*)p)[c];
+    case MI355CV_16S: return ((const short*)p)[c];
+    case MI355CV_32S: return ((const int*)p)[c];
+    case MI355CV_32F: return ((const float*)p)[c];
+    default:          return ((const double*)p)[c];
+    }
+}
+
+enum { K_GENERAL = 0, K_SYMMETRICAL = 1, K_ASYMMETRICAL = 2, K_SMOOTH = 4, K_INTEGER = 8 };
+
+// cv::getKernelType (filter.dispatch.cpp:225-259)
+int kernelType(const std::vector<double>& k, int anchor)
+{
+    const int sz = (int)k.size();
+    int type = K_SMOOTH + K_INTEGER;
+    if (anchor * 2 + 1 == sz) type |= K_SYMMETRICAL + K_ASYMMETRICAL;
+    double sum = 0;
+    for (int i = 0; i < sz; i++) {
+        const double a = k[i], b = k[sz - i - 1];
+        if (a != b) type &= ~K_SYMMETRICAL;
+        if (a != -b) type &= ~K_ASYMMETRICAL;
+        if (a < 0) type &= ~K_SMOOTH;
+        if (a != (double)(int)nearbyint(a)) type &= ~K_INTEGER;
+        sum += a;
+    }
+    if (std::fabs(sum - 1) > 1.1920928955078125e-7 * (std::fabs(sum) + 1)) type &= ~K_SMOOTH;
+    return type;
+}
+
+// createBitExactKernel_32S (filter.dispatch.cpp:288-303)
+bool bitExactKernel(const std::vector<double>& k, int bits, std::vector<int>& out)
+{
+    out.resize(k.size());
+    const double eps = 10 * 1.1920928955078125e-7 * (1 << bits);
+    for (size_t i = 0; i < k.size(); i++) {
+        const double v = k[i] * (1 << bits);
+        const int q = (int)nearbyint(v);
+        out[i] = q;
+        if (std::fabs(v - q) > eps) return false;
+    }
+    return true;
+}
+
+struct FilterCtx {
+    int kind;                       // 1 filter2D, 2 separable
+    int sdepth, ddepth, cn, border;
+    int ax, ay, kw, kh;
+    float delta;
+    std::vector<Tap2D> taps;
+    SepParams sp;
+};
+
+bool depthPairOk(int sd, int dd)
+{
+    if (sd == D8U) return dd == D8U || dd == D16U || dd == D16S || dd == D32F;
+    if (sd == D16U) return dd == D16U || dd == D32F;
+    if (sd == D16S) return dd == D16S || dd == D32F;
+    if (sd == D32F) return dd == D32F;
+    return false;
+}
+
+int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, const std::vector<double>& ky,
+            int ax, int ay, double delta, int border)
+{
+    c.kind = 2;
+    c.sdepth = MI355CV_MAT_DEPTH(stype); c.ddepth = MI355CV_MAT_DEPTH(dtype);
+    c.cn = MI355CV_MAT_CN(stype);
+    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)) return MI355CV_NOT_IMPLEMENTED;
+    const int nx = (int)kx.size(), ny = (int)ky.size();
+    if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return MI355CV_NOT_IMPLEMENTED;
+    if (ax < 0) ax = nx / 2;
+    if (ay < 0) ay = ny / 2;
+    if (ax >= nx || ay >= ny) return MI355CV_NOT_IMPLEMENTED;
+    c.border = border & ~MI355CV_BORDER_ISOLATED;
+    if (c.border < 0 || c.border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    SepParams& p = c.sp;
+    memset(&p, 0, sizeof p);
+    p.nx = nx; p.ny = ny; p.ax = ax; p.ay = ay;
+    const int rtype = kernelType(kx, ax), ctype = kernelType(ky, ay);
+    p.mode = 0;
+    if (c.sdepth == D8U &&
+        ((rtype == K_SMOOTH + K_SYMMETRICAL && ctype == K_SMOOTH + K_SYMMETRICAL && c.ddepth == D8U) ||
+         ((rtype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (ctype & (K_SYMMETRICAL + K_ASYMMETRICAL)) &&
+          (rtype & ctype & K_INTEGER) && c.ddepth == D16S))) {
+        const int bits = c.ddepth == D8U ? 8 : 0;
+        std::vector<int> qx, qy;
+        if (bitExactKernel(kx, bits, qx) && bitExactKernel(ky, bits, qy)) {
+            p.mode = bits ? 1 : 2;
+            for (int i = 0; i < nx; i++) p.kxi[i] = qx[i];
+            for (int i = 0; i < ny; i++) p.kyi[i] = qy[i];
+            const double d = delta * (double)(1 << (2 * bits));
+            p.deltaI = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (int)-2147483648LL : (int)nearbyint(d);
+        }
+    }
+    for (int i = 0; i < nx; i++) p.kxf[i] = (float)kx[i];
+    for (int i = 0; i < ny; i++) p.kyf[i] = (float)ky[i];
+    p.deltaF = (float)delta;
+    p.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
+    if (!(ny & 1)) p.symY = 0;
+    return MI355CV_OK;
+}
+
+int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, uchar* dst, size_t dstep,
+           int W, int H, int fullW, int fullH, int offX, int offY)
+{
+    if (disabled() || W <= 0 || H <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
+    Stager stg; size_t dss, dds;
+    // stage the whole parent region so that non-isolated borders can read real neighbours
+    const uchar* top = src - (ptrdiff_t)offY * (ptrdiff_t)sstep - (ptrdiff_t)offX * c.cn * se;
+    const uchar* dtop = stg.in(top, sstep, (size_t)fullW * c.cn * se, fullH, &dss);
+    uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
+    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
+    dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
+    hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
+                       fullW, fullH, offX, offY, c.border, c.sp);
+    return stg.finish(entry);
+}
+
+// getSobelKernels / getScharrKernels (deriv.cpp:55-162) as integer taps
+bool derivKernel(int order, int ksize, bool scharr, std::vector<int>& k)
+{
+    if (scharr) {
+        if (order == 0) k = {3, 10, 3}; else if (order == 1) k = {-1, 0, 1}; else return false;
+        return true;
+    }
+    if (ksize == 1 && order > 0) ksize = 3;
+    if (ksize % 2 == 0 || ksize > 31 || ksize <= order) return false;
+    if (ksize == 1) { k = {1}; return true; }
+    if (ksize == 3) {
+        if (order == 0) k = {1, 2, 1}; else if (order == 1) k = {-1, 0, 1}; else k = {1, -2, 1};
+        return true;
+    }
+    std::vector<int> kerI(ksize + 1, 0);
+    kerI[0] = 1;
+    for (int i = 0; i < ksize - order - 1; i++) {
+        int oldval = kerI[0];
+        for (int j = 1; j <= ksize; j++) { int nv = kerI[j] + kerI[j - 1]; kerI[j - 1] = oldval; oldval = nv; }
+    }
+    for (int i = 0; i < order; i++) {
+        int oldval = -kerI[0];
+        for (int j = 1; j <= ksize; j++) { int nv = kerI[j - 1] - kerI[j]; kerI[j - 1] = oldval; oldval = nv; }
+    }
+    k.assign(kerI.begin(), kerI.begin() + ksize);
+    return true;
+}
+
+int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int sdepth, int ddepth,
+             int cn, int mL, int mT, int mR, int mB, int dx, int dy, int ksize, bool scharr, double scale, double delta, int border)
+{
+    if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0)) return MI355CV_NOT_IMPLEMENTED;
+    std::vector<int> ix, iy;
+    if (!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)) return MI355CV_NOT_IMPLEMENTED;
+    // ktype = max(CV_32F, ddepth, sdepth) = CV_32F for every depth handled here; `kx *= scale` is evaluated
+    // in double and stored back as float (deriv.cpp:432-439)
+    std::vector<double> kx(ix.begin(), ix.end()), ky(iy.begin(), iy.end());
+    if (scale != 1) {
+        std::vector<double>& tgt = dx == 0 ? kx : ky;
+        for (double& v : tgt) v = (double)(float)(v * scale);
+    }
+    FilterCtx c;
+    int rc = sepInit(c, MI355CV_MAKETYPE(sdepth, cn), MI355CV_MAKETYPE(ddepth, cn), kx, ky, -1, -1, delta, border);
+    if (rc != MI355CV_OK) return rc;
+    return sepRun(entry, c, src, sstep, dst, dstep, W, H, mL + W + mR, mT + H + mB, mL, mT);
+}
+
+} // namespace
+
+struct cvhalFilter2D;   // opaque to the caller (hal_replacement.hpp:70-87)
+
+extern "C" {
+
+MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, size_t kernel_step, int kernel_type,
+        int kernel_width, int kernel_height, int max_width, int max_height, int src_type, int dst_type, int borderType,
+        double delta, int anchor_x, int anchor_y, bool allowSubmatrix, bool allowInplace)
+{
+    (void)max_width; (void)max_height; (void)allowSubmatrix;
+    if (!context || !kernel_data || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (allowInplace) return MI355CV_NOT_IMPLEMENTED;               // src == dst: a stencil cannot run in place on the GPU
+    if (MI355CV_MAT_CN(kernel_type) != 1 || kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024)
+        return MI355CV_NOT_IMPLEMENTED;
+    FilterCtx* c = new (std::nothrow) FilterCtx();
+    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    c->kind = 1;
+    c->sdepth = MI355CV_MAT_DEPTH(src_type); c->ddepth = MI355CV_MAT_DEPTH(dst_type); c->cn = MI355CV_MAT_CN(src_type);
+    c->border = borderType & ~MI355CV_BORDER_ISOLATED;
+    c->kw = kernel_width; c->kh = kernel_height;
+    c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
+    c->delta = (float)delta;                                         // saturate_cast<float>(delta), filter.simd.hpp:3113
+    if (c->cn != MI355CV_MAT_CN(dst_type) || !depthPairOk(c->sdepth, c->ddepth) || c->border < 0 || c->border > B_REFLECT_101 ||
+        c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return MI355CV_NOT_IMPLEMENTED; }
+    for (int i = 0; i < kernel_height; i++)
+        for (int j = 0; j < kernel_width; j++) {
+            const float v = (float)kernelAt(kernel_data, kernel_step, kernel_type, i, j);   // convertTo(CV_32F), :3201-3205
+            if (v == 0) continue;
+            c->taps.push_back({v, j, i});
+        }
+    if (c->taps.empty()) c->taps.push_back({0.f, 0, 0});              // nz == 0 -> one zero tap (:393-395)
+    *context = reinterpret_cast<cvhalFilter2D*>(c);
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
+        int width, int height, int full_width, int full_height, int offset_x, int offset_y)
+{
+    FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
+    if (!c || c->kind != 1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
+    Stager stg; size_t dss, dds;
+    const uchar* top = src_data - (ptrdiff_t)offset_y * (ptrdiff_t)src_step - (ptrdiff_t)offset_x * c->cn * se;
+    const uchar* dtop = stg.in(top, src_step, (size_t)full_width * c->cn * se, full_height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * de, height, &dds);
+    Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
+    if (!dtop || !dd || !dt) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* ds = dtop + (size_t)offset_y * dss + (size_t)offset_x * c->cn * se;
+    dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
+    hipLaunchKernelGGL(k_filter2d_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, c->cn, c->sdepth, c->ddepth,
+                       full_width, full_height, offset_x, offset_y, dt, (int)c->taps.size(), c->ax, c->ay, c->kw, c->kh, c->delta, c->border);
+    return stg.finish("filter");
+}
+
+MI355CV_API int mi355cv_filterFree(cvhalFilter2D* context)
+{
+    delete reinterpret_cast<FilterCtx*>(context);
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_sepFilterInit(cvhalFilter2D** context, int src_type, int dst_type, int kernel_type,
+        uchar* kernelx_data, int kernelx_length, uchar* kernely_data, int kernely_length,
+        int anchor_x, int anchor_y, double delta, int borderType)
+{
+    if (!context || !kernelx_data || !kernely_data || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1) return MI355CV_NOT_IMPLEMENTED;
+    std::vector<double> kx(kernelx_length), ky(kernely_length);
+    for (int i = 0; i < kernelx_length; i++) kx[i] = kernelAt(kernelx_data, 0, kernel_type, 0, i);
+    for (int i = 0; i < kernely_length; i++) ky[i] = kernelAt(kernely_data, 0, kernel_type, 0, i);
+    FilterCtx* c = new (std::nothrow) FilterCtx();
+    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    int rc = sepInit(*c, src_type, dst_type, kx, ky, anchor_x, anchor_y, delta, borderType);
+    if (rc != MI355CV_OK) { delete c; return rc; }
+    *context = reinterpret_cast<cvhalFilter2D*>(c);
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_sepFilter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
+        int width, int height, int full_width, int full_height, int offset_x, int offset_y)
+{
+    FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
+    if (!c || c->kind != 2) return MI355CV_NOT_IMPLEMENTED;
+    return sepRun("sepFilter", *c, src_data, src_step, dst_data, dst_step, width, height, full_width, full_height, offset_x, offset_y);
+}
+
+MI355CV_API int mi355cv_sepFilterFree(cvhalFilter2D* context)
+{
+    delete reinterpret_cast<FilterCtx*>(context);
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_sobel(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        int dx, int dy, int ksize, double scale, double delta, int border_type)
+{
+    const bool scharr = ksize <= 0;                                   // FILTER_SCHARR == -1 (getDerivKernels, deriv.cpp:165-171)
+    return derivRun("sobel", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn,
+                    margin_left, margin_top, margin_right, margin_bottom, dx, dy, ksize, scharr, scale, delta, border_type);
+}
+
+MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        int dx, int dy, double scale, double delta, int border_type)
+{
+    return derivRun("scharr", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn,
+                    margin_left, margin_top, margin_right, margin_bottom, dx, dy, 0, true, scale, delta, border_type);
+}
+
+MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
+{
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    const int kw = (int)ksize_width, kh = (int)ksize_height;
+    if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return MI355CV_NOT_IMPLEMENTED;
+    const int border = border_type & ~MI355CV_BORDER_ISOLATED;
+    if (border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    const bool okDepth = (src_depth == D8U && (dst_depth == D8U || dst_depth == D32F)) ||
+                         (src_depth == D16U && (dst_depth == D16U || dst_depth == D32F)) ||
+                         (src_depth == D16S && (dst_depth == D16S || dst_depth == D32F)) ||
+                         (src_depth == D32F && dst_depth == D32F);
+    if (!okDepth) return MI355CV_NOT_IMPLEMENTED;
+    BoxParams p; memset(&p, 0, sizeof p);
+    p.kw = kw; p.kh = kh;
+    p.ax = anchor_x < 0 ? kw / 2 : anchor_x; p.ay = anchor_y < 0 ? kh / 2 : anchor_y;
+    if (p.ax >= kw || p.ay >= kh) return MI355CV_NOT_IMPLEMENTED;
+    p.normalize = normalize ? 1 : 0;
+    const int area = kw * kh;
+    const double scale = 1.0 / area;
+    p.scaleD = scale; p.scaleF = (float)scale;
+    if (normalize && area == 1) p.normalize = 0;                       // scale == 1: the reference skips the multiply
+    if (src_depth == D32F) p.mode = 2;
+    else if (src_depth == D8U && dst_depth == D8U && area <= 256) {
+        p.mode = 0;
+        // ColumnSum<ushort,uchar> constructor (box_filter.simd.hpp:441-455)
+        const int d = (int)nearbyint(1.0 / scale);
+        double scalef = ((double)(1 << 23)) / d;
+        p.divScale = (int)std::floor(scalef);
+        scalef -= p.divScale;
+        p.divDelta = d / 2;
+        if (scalef < 0.5) p.divDelta++; else p.divScale++;
+    } else {
+        p.mode = 1;
+        const long long lim = src_depth == D8U ? (1LL << 23) : src_depth == D16U ? (1LL << 15) : (1LL << 16);
+        if (normalize && area > lim) return MI355CV_NOT_IMPLEMENTED;    // the reference switches to double sums there
+    }
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int se = depthSize(src_depth), de = depthSize(dst_depth);
+    const int fullW = margin_left + width + margin_right, fullH = margin_top + height + margin_bottom;
+    Stager stg; size_t dss, dds;
+    const uchar* top = src_data - (ptrdiff_t)margin_top * (ptrdiff_t)src_step - (ptrdiff_t)margin_left * cn * se;
+    const uchar* dtop = stg.in(top, src_step, (size_t)fullW * cn * se, fullH, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * de, height, &dds);
+    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* ds = dtop + (size_t)margin_top * dss + (size_t)margin_left * cn * se;
+    dim3 grid(divUp(width * cn, 64), divUp(height, 4));
+    hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
+                       fullW, fullH, margin_left, margin_top, border, p);
+    return stg.finish("boxFilter");
+}
+
+} // extern "C"

@@ -14,7 +14,12 @@ from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_32F,  # n
 L = _lib.lib
 _vp = ctypes.c_void_p
 
-__all__ = ["GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
+__all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
+           "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
+           "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
+           "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
+           "filter2D", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
+           "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
 
 _BINOM = {1: [256], 3: [64, 128, 64], 5: [16, 64, 96, 64, 16], 7: [8, 28, 56, 72, 56, 28, 8],
@@ -144,3 +149,208 @@ def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None):
                                              int(out.stride(0)), n, w, h, CV_8U, cn, k, borderType & ~BORDER_ISOLATED)
     _lib.check(rc, "gaussianBlurBinomialBatch")
     return out
+
+
+# ----------------------------------------------------------------------------- cvtColor (a6)
+# ColorConversionCodes (imgproc.hpp:537-563)
+COLOR_BGR2BGRA = COLOR_RGB2RGBA = 0
+COLOR_BGRA2BGR = COLOR_RGBA2RGB = 1
+COLOR_BGR2RGBA = COLOR_RGB2BGRA = 2
+COLOR_RGBA2BGR = COLOR_BGRA2RGB = 3
+COLOR_BGR2RGB = COLOR_RGB2BGR = 4
+COLOR_BGRA2RGBA = COLOR_RGBA2BGRA = 5
+COLOR_BGR2GRAY, COLOR_RGB2GRAY = 6, 7
+COLOR_GRAY2BGR = COLOR_GRAY2RGB = 8
+COLOR_GRAY2BGRA = COLOR_GRAY2RGBA = 9
+COLOR_BGRA2GRAY, COLOR_RGBA2GRAY = 10, 11
+
+# code -> (scn, dcn, swapBlue), as the switch in cv::cvtColor does (color.cpp:192-260 / color.hpp dcn helpers)
+_RGB2RGB = {COLOR_BGR2BGRA: (3, 4, False), COLOR_BGRA2BGR: (4, 3, False), COLOR_BGR2RGBA: (3, 4, True),
+            COLOR_RGBA2BGR: (4, 3, True), COLOR_BGR2RGB: (3, 3, True), COLOR_BGRA2RGBA: (4, 4, True)}
+_RGB2GRAY = {COLOR_BGR2GRAY: (3, False), COLOR_RGB2GRAY: (3, True), COLOR_BGRA2GRAY: (4, False), COLOR_RGBA2GRAY: (4, True)}
+_GRAY2RGB = {COLOR_GRAY2BGR: 3, COLOR_GRAY2BGRA: 4}
+
+
+def cvtColor(src, code, dst=None, dstCn=0):
+    """cv::cvtColor (color.cpp:192-) for the RGB<->RGB / RGB<->gray families; depth 8U, 16U, 32F."""
+    s = Img(src)
+    if code in _RGB2GRAY:
+        scn, swap = _RGB2GRAY[code]
+        if s.cn != scn:
+            raise ValueError(f"cvtColor: source must have {scn} channels")     # CvtHelper asserts, color.hpp:140
+        out = dst if dst is not None else empty_like_kind(src[..., 0], s.h, s.w, 1, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtBGRtoGray(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, scn, swap), "cvtBGRtoGray")
+        return out
+    if code in _GRAY2RGB:
+        dcn = _GRAY2RGB[code]
+        if s.cn != 1:
+            raise ValueError("cvtColor: source must be single-channel")
+        ref3 = src[..., None] if getattr(src, "ndim", 2) == 2 else src
+        out = dst if dst is not None else empty_like_kind(ref3, s.h, s.w, dcn, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtGraytoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn), "cvtGraytoBGR")
+        return out
+    if code in _RGB2RGB:
+        scn, dcn, swap = _RGB2RGB[code]
+        if s.cn != scn:
+            raise ValueError(f"cvtColor: source must have {scn} channels")
+        out = dst if dst is not None else empty_like_kind(src, s.h, s.w, dcn, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtBGRtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, scn, dcn, swap), "cvtBGRtoBGR")
+        return out
+    raise NotImplementedError(f"cvtColor: conversion code {code} is outside the hot path built so far")
+
+
+def cvtColorBatch(frames, code, dst=None):
+    """[N,H,W,C] device-resident frames -> gray [N,H,W], one launch."""
+    if code not in _RGB2GRAY:
+        raise NotImplementedError("cvtColorBatch: only *2GRAY")
+    scn, swap = _RGB2GRAY[code]
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    out = dst if dst is not None else torch.empty((n, h, w), dtype=frames.dtype, device=frames.device)
+    s0, d0 = Img(frames[0]), Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_cvtBGRtoGrayBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step,
+                                     int(out.stride(0)) * d0.esz, n, w, h, s0.depth, scn, int(swap))
+    _lib.check(rc, "cvtBGRtoGrayBatch")
+    return out
+
+
+# ----------------------------------------------------------------------------- linear filters (a3, a4, a5)
+def _np_kernel(k):
+    k = np.asarray(k)
+    if k.dtype not in (np.float32, np.float64, np.int32, np.uint8):
+        k = k.astype(np.float64 if k.dtype.kind == "f" else np.float32)
+    return np.ascontiguousarray(k)
+
+
+_K_TYPE = {np.dtype(np.uint8): 0, np.dtype(np.int32): 4, np.dtype(np.float32): 5, np.dtype(np.float64): 6}
+
+
+def _parent_geometry(src, roi, borderType):
+    """(view, full_w, full_h, off_x, off_y): the locateROI() information cv:: passes to the HAL for non-isolated borders."""
+    if roi is None:
+        s = Img(src)
+        return src, s, s.w, s.h, 0, 0
+    x0, y0, w, h = roi
+    view = src[y0:y0 + h, x0:x0 + w]
+    s = Img(view)
+    p = Img(src)
+    if borderType & BORDER_ISOLATED:
+        return view, s, s.w, s.h, 0, 0
+    return view, s, p.w, p.h, x0, y0
+
+
+def filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType=BORDER_DEFAULT, dst=None, roi=None):
+    """cv::filter2D (filter.dispatch.cpp:1521-1553) through cv_hal_filterInit / cv_hal_filter / cv_hal_filterFree.
+
+    `roi=(x, y, w, h)` filters a sub-rectangle of `src` the way a cv::Mat submatrix is filtered: borders read the
+    parent's real pixels unless BORDER_ISOLATED is set."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    if ddepth < 0:
+        ddepth = s.depth
+    k = _np_kernel(kernel)
+    if k.ndim == 1:
+        k = k[None, :]
+    kh, kw = k.shape
+    ax, ay = anchor
+    if ax < 0:
+        ax = kw // 2                                     # normalizeAnchor (filterengine.hpp:352)
+    if ay < 0:
+        ay = kh // 2
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
+    d = Img(out)
+    bind_stream(s, d)
+    ctx = ctypes.c_void_p()
+    rc = L.mi355cv_filterInit(ctypes.byref(ctx), k.ctypes.data, k.strides[0], _K_TYPE[k.dtype], kw, kh, s.w, s.h,
+                              s.type, d.type, borderType & ~BORDER_ISOLATED, float(delta), ax, ay,
+                              roi is not None, False)
+    _lib.check(rc, "filterInit")
+    try:
+        rc = L.mi355cv_filter(ctx, _vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, fw, fh, ox, oy)
+    finally:
+        L.mi355cv_filterFree(ctx)
+    _lib.check(rc, "filter")
+    return out
+
+
+def sepFilter2D(src, ddepth, kernelX, kernelY, anchor=(-1, -1), delta=0.0, borderType=BORDER_DEFAULT, dst=None, roi=None):
+    """cv::sepFilter2D (filter.dispatch.cpp:1555-1594) through cv_hal_sepFilterInit / sepFilter / sepFilterFree."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    if ddepth < 0:
+        ddepth = s.depth
+    kx = np.ascontiguousarray(np.asarray(kernelX, dtype=np.float64).ravel())
+    ky = np.ascontiguousarray(np.asarray(kernelY, dtype=np.float64).ravel())
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
+    d = Img(out)
+    bind_stream(s, d)
+    ctx = ctypes.c_void_p()
+    rc = L.mi355cv_sepFilterInit(ctypes.byref(ctx), s.type, d.type, 6, kx.ctypes.data, len(kx), ky.ctypes.data, len(ky),
+                                 anchor[0], anchor[1], float(delta), borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "sepFilterInit")
+    try:
+        rc = L.mi355cv_sepFilter(ctx, _vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, fw, fh, ox, oy)
+    finally:
+        L.mi355cv_sepFilterFree(ctx)
+    _lib.check(rc, "sepFilter")
+    return out
+
+
+def Sobel(src, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, borderType=BORDER_DEFAULT, dst=None, roi=None):
+    """cv::Sobel (deriv.cpp:414-466) through cv_hal_sobel; ksize=-1 (FILTER_SCHARR) selects the Scharr taps."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    if ddepth < 0:
+        ddepth = s.depth
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
+    d = Img(out)
+    bind_stream(s, d)
+    rc = L.mi355cv_sobel(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, d.depth, s.cn,
+                         ox, oy, fw - s.w - ox, fh - s.h - oy, dx, dy, ksize, float(scale), float(delta),
+                         borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "sobel")
+    return out
+
+
+def Scharr(src, ddepth, dx, dy, scale=1.0, delta=0.0, borderType=BORDER_DEFAULT, dst=None, roi=None):
+    """cv::Scharr (deriv.cpp:468-) through cv_hal_scharr."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    if ddepth < 0:
+        ddepth = s.depth
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
+    d = Img(out)
+    bind_stream(s, d)
+    rc = L.mi355cv_scharr(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, d.depth, s.cn,
+                          ox, oy, fw - s.w - ox, fh - s.h - oy, dx, dy, float(scale), float(delta),
+                          borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "scharr")
+    return out
+
+
+def boxFilter(src, ddepth, ksize, anchor=(-1, -1), normalize=True, borderType=BORDER_DEFAULT, dst=None, roi=None):
+    """cv::boxFilter (box_filter.dispatch.cpp:440-489) through cv_hal_boxFilter."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    if ddepth < 0:
+        ddepth = s.depth
+    kw, kh = _ksize(ksize)
+    if borderType != BORDER_CONSTANT and normalize and (borderType & BORDER_ISOLATED) != 0:   # :458-464
+        if s.h == 1:
+            kh = 1
+        if s.w == 1:
+            kw = 1
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
+    d = Img(out)
+    bind_stream(s, d)
+    rc = L.mi355cv_boxFilter(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, d.depth, s.cn,
+                             ox, oy, fw - s.w - ox, fh - s.h - oy, kw, kh, anchor[0], anchor[1], bool(normalize),
+                             borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "boxFilter")
+    return out
+
+
+def blur(src, ksize, anchor=(-1, -1), borderType=BORDER_DEFAULT, dst=None):
+    """cv::blur (box_filter.dispatch.cpp:492-499)."""
+    return boxFilter(src, -1, ksize, anchor, True, borderType, dst)

@@ -42,6 +42,24 @@ int orc_gaussianBlurBinomialU8(const uint8_t* src, size_t sstep, uint8_t* dst, s
 int orc_getGaussianKernel(int n, double sigma, double* taps);
 int orc_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps);
 
+/* color_rgb.simd.hpp: RGB2Gray :608/:660/:752, Gray2RGB :386, RGB2RGB :108.  depth = CV depth code (0,2,5) */
+void orc_cvtBGRtoGray(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int swapBlue);
+void orc_cvtGraytoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int dcn);
+void orc_cvtBGRtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int dcn, int swapBlue);
+
+/* linear filters, see oracle/filter.c.  (fullW, fullH, offX, offY) describe the parent image of the ROI. */
+void orc_filter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+                  int fullW, int fullH, int offX, int offY, const float* kernel, int kw, int kh, int ax, int ay,
+                  double delta, int border);
+void orc_sepFilter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+                     int fullW, int fullH, int offX, int offY, const double* kx, int nx, const double* ky, int ny,
+                     int ax, int ay, double delta, int border);
+int orc_derivKernel(int order, int ksize, int scharr, int* k);
+int orc_Sobel(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+              int fullW, int fullH, int offX, int offY, int dx, int dy, int ksize, double scale, double delta, int border);
+int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+                  int fullW, int fullH, int offX, int offY, int kw, int kh, int ax, int ay, int normalize, int border);
+
 #ifdef __cplusplus
 }
 #endif

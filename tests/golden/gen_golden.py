@@ -35,6 +35,15 @@ def gaussian_u8():
     print("gaussian_u8.npz:", out["n"], "cases")
 
 
+def color_rng0():
+    """test_color.cpp:2826: RNG(0).fill(263x255 CV_8UC3, UNIFORM, 0, 255) -- the input of Imgproc_cvtColor_BE"""
+    src = orc.ref_rng_fill((255, 263, 3), np.uint8, 0, 0, 255)
+    np.savez_compressed(os.path.join(HERE, "color_rng0.npz"), src=src,
+                        gray_bgr=orc.ref_cvtColor(src, 6, 1), gray_rgb=orc.ref_cvtColor(src, 7, 1))
+    print("color_rng0.npz")
+
+
 if __name__ == "__main__":
     assert orc.load_ref() is not None, "build oracle/_ref first"
     gaussian_u8()
+    color_rng0()

@@ -148,3 +148,153 @@ def ref_getGaussianKernel(n, sigma):
     k = np.zeros(n, np.float64)
     assert r.ref_getGaussianKernel(n, c_dbl(sigma), P(k)) == 0
     return k
+
+
+# ----------------------------------------------------------------------------- colour
+_GRAY = {6: (3, 0), 7: (3, 1), 10: (4, 0), 11: (4, 1)}
+_RGB = {0: (3, 4, 0), 1: (4, 3, 0), 2: (3, 4, 1), 3: (4, 3, 1), 4: (3, 3, 1), 5: (4, 4, 1)}
+
+
+def orc_cvtColor(src, code):
+    o = oracle()
+    h, w = src.shape[:2]
+    depth = _NP_DEPTH[src.dtype]
+    if code in _GRAY:
+        scn, swap = _GRAY[code]
+        dst = np.empty((h, w), src.dtype)
+        o.orc_cvtBGRtoGray(P(src), step(src), P(dst), step(dst), w, h, depth, scn, swap)
+    elif code in (8, 9):
+        dcn = 3 if code == 8 else 4
+        dst = np.empty((h, w, dcn), src.dtype)
+        o.orc_cvtGraytoBGR(P(src), step(src), P(dst), step(dst), w, h, depth, dcn)
+    else:
+        scn, dcn, swap = _RGB[code]
+        dst = np.empty((h, w, dcn), src.dtype)
+        o.orc_cvtBGRtoBGR(P(src), step(src), P(dst), step(dst), w, h, depth, scn, dcn, swap)
+    return dst
+
+
+def ref_cvtColor(src, code, dcn):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty((h, w) if dcn == 1 else (h, w, dcn), src.dtype)
+    rc = r.ref_cvtColor(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), cvtype(dst), code)
+    assert rc == 0, rc
+    return dst
+
+
+# ----------------------------------------------------------------------------- linear filters
+def _roi(src, roi):
+    """roi = (x0, y0, w, h) inside `src` (the parent) or None -> (view, fullW, fullH, offX, offY)"""
+    H, W = src.shape[:2]
+    if roi is None:
+        return src, W, H, 0, 0
+    x0, y0, w, h = roi
+    return src[y0:y0 + h, x0:x0 + w], W, H, x0, y0
+
+
+def _out(view, ddepth):
+    dt = _DEPTH_NP[ddepth if ddepth >= 0 else _NP_DEPTH[view.dtype]]
+    return np.empty(view.shape, dt)
+
+
+def orc_filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, border=4, roi=None):
+    o = oracle()
+    v, fw, fh, ox, oy = _roi(src, roi)
+    if border & 16:
+        fw, fh, ox, oy = v.shape[1], v.shape[0], 0, 0
+    dst = _out(v, ddepth)
+    k = np.ascontiguousarray(kernel, np.float32)
+    o.orc_filter2D(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
+                   fw, fh, ox, oy, P(k), k.shape[1], k.shape[0], anchor[0], anchor[1], c_dbl(delta), border & ~16)
+    return dst
+
+
+def orc_sepFilter2D(src, ddepth, kx, ky, anchor=(-1, -1), delta=0.0, border=4, roi=None):
+    o = oracle()
+    v, fw, fh, ox, oy = _roi(src, roi)
+    if border & 16:
+        fw, fh, ox, oy = v.shape[1], v.shape[0], 0, 0
+    dst = _out(v, ddepth)
+    kx = np.ascontiguousarray(np.asarray(kx).ravel(), np.float64)
+    ky = np.ascontiguousarray(np.asarray(ky).ravel(), np.float64)
+    o.orc_sepFilter2D(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
+                      fw, fh, ox, oy, P(kx), len(kx), P(ky), len(ky), anchor[0], anchor[1], c_dbl(delta), border & ~16)
+    return dst
+
+
+def orc_Sobel(src, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, border=4, roi=None):
+    o = oracle()
+    v, fw, fh, ox, oy = _roi(src, roi)
+    if border & 16:
+        fw, fh, ox, oy = v.shape[1], v.shape[0], 0, 0
+    dst = _out(v, ddepth)
+    rc = o.orc_Sobel(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
+                     fw, fh, ox, oy, dx, dy, ksize, c_dbl(scale), c_dbl(delta), border & ~16)
+    assert rc == 0
+    return dst
+
+
+def orc_boxFilter(src, ddepth, ksize, anchor=(-1, -1), normalize=True, border=4, roi=None):
+    o = oracle()
+    v, fw, fh, ox, oy = _roi(src, roi)
+    if border & 16:
+        fw, fh, ox, oy = v.shape[1], v.shape[0], 0, 0
+    dst = _out(v, ddepth)
+    o.orc_boxFilter(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
+                    fw, fh, ox, oy, ksize[0], ksize[1], anchor[0], anchor[1], int(normalize), border & ~16)
+    return dst
+
+
+def _ref_dst(src, ddepth):
+    return np.empty(src.shape, _DEPTH_NP[ddepth if ddepth >= 0 else _NP_DEPTH[src.dtype]])
+
+
+def ref_filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, border=4):
+    r = load_ref()
+    dst = _ref_dst(src, ddepth)
+    k = np.ascontiguousarray(kernel)
+    kt = _NP_DEPTH[k.dtype]
+    rc = r.ref_filter2D(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], cvtype(src), ddepth,
+                        P(k), k.shape[1], k.shape[0], kt, anchor[0], anchor[1], c_dbl(delta), border)
+    assert rc == 0, rc
+    return dst
+
+
+def ref_sepFilter2D(src, ddepth, kx, ky, anchor=(-1, -1), delta=0.0, border=4):
+    r = load_ref()
+    dst = _ref_dst(src, ddepth)
+    kx = np.ascontiguousarray(np.asarray(kx).ravel(), np.float32)
+    ky = np.ascontiguousarray(np.asarray(ky).ravel(), np.float32)
+    rc = r.ref_sepFilter2D(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], cvtype(src), ddepth,
+                           P(kx), len(kx), P(ky), len(ky), 5, anchor[0], anchor[1], c_dbl(delta), border)
+    assert rc == 0, rc
+    return dst
+
+
+def ref_Sobel(src, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, border=4):
+    r = load_ref()
+    dst = _ref_dst(src, ddepth)
+    if ksize <= 0:
+        rc = r.ref_Scharr(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], cvtype(src), ddepth, dx, dy,
+                          c_dbl(scale), c_dbl(delta), border)
+    else:
+        rc = r.ref_Sobel(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], cvtype(src), ddepth, dx, dy, ksize,
+                         c_dbl(scale), c_dbl(delta), border)
+    assert rc == 0, rc
+    return dst
+
+
+def ref_boxFilter(src, ddepth, ksize, anchor=(-1, -1), normalize=True, border=4):
+    r = load_ref()
+    dst = _ref_dst(src, ddepth)
+    rc = r.ref_boxFilter(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], cvtype(src), ddepth,
+                         ksize[0], ksize[1], anchor[0], anchor[1], int(normalize), border)
+    assert rc == 0, rc
+    return dst
+
+
+def rel_err(a, b):
+    """checkNormRelative of the reference's accelerated-backend tests (ts/ocl_test.hpp:309-314)"""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.finfo(np.float32).eps, max(np.max(np.abs(a)), np.max(np.abs(b)))))

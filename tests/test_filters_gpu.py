@@ -1,0 +1,148 @@
+"""GPU parity for rows a3-a6: filter2D, sepFilter2D, Sobel/Scharr, boxFilter, cvtColor -- through the C ABI,
+against the oracle.  Integer outputs bit-exact, CV_32F within 1e-4 relative (ts/ocl_test.hpp:309 norm)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_filter import SHARPEN, BORDERS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def rnd(shape, dtype, seed):
+    rng = np.random.default_rng(seed)
+    if dtype == np.float32:
+        return rng.random(shape, dtype=np.float32)
+    info = np.iinfo(dtype)
+    return rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
+
+
+def check(got, want, tol=1e-4):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    assert got.dtype == want.dtype and got.shape == want.shape
+    if want.dtype == np.float32:
+        import orc
+        assert orc.rel_err(got, want) <= tol
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_filter2d_8u(cv, orc, cn):
+    n0 = cv.call_count("filter")
+    for (w, h) in [(64, 9), (100, 33), (1, 1), (3, 2), (257, 19)]:
+        src = rnd((h, w, cn) if cn > 1 else (h, w), np.uint8, w)
+        for k, anchor, delta in [(SHARPEN, (-1, -1), 0.0), (np.ones((3, 3), np.float32) * 0.125, (-1, -1), 3.0),
+                                 (np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], np.float32) * 0.25, (0, 2), 128.0),
+                                 (np.array([[0.5, 0.25, 0.125, 0.0625, 0.0625]], np.float32), (1, 0), 0.0),
+                                 (np.zeros((3, 3), np.float32), (-1, -1), 7.0)]:
+            for border in BORDERS + [3]:
+                want = orc.orc_filter2D(src, -1, k, anchor, delta, border)
+                check(cv.filter2D(dev(src), -1, k, anchor, delta, border), want)
+        check(cv.filter2D(src, -1, SHARPEN), orc.orc_filter2D(src, -1, SHARPEN))            # host pointers
+    assert cv.call_count("filter") > n0
+
+
+def test_filter2d_depths_and_roi(cv, orc):
+    rng = np.random.default_rng(5)
+    k5 = (rng.uniform(-3, 10, (5, 5)) / 37.0).astype(np.float32)
+    for dtype, ddepth in [(np.uint8, 3), (np.uint8, 5), (np.uint16, -1), (np.int16, -1), (np.float32, -1), (np.uint8, -1), (np.uint8, 2)]:
+        src = rnd((37, 64, 3), dtype, 77)
+        for border in BORDERS:
+            check(cv.filter2D(dev(src), ddepth, k5, (-1, -1), 0.5, border), orc.orc_filter2D(src, ddepth, k5, (-1, -1), 0.5, border))
+    parent = rnd((40, 60, 3), np.uint8, 1)
+    for roi in [(5, 4, 30, 20), (0, 0, 16, 16), (58, 38, 2, 2)]:
+        for border in (1, 2, 4, 4 | 16):
+            want = orc.orc_filter2D(parent, -1, k5, (-1, -1), 0.0, border, roi=roi)
+            check(cv.filter2D(dev(parent), -1, k5, (-1, -1), 0.0, border, roi=roi), want)
+            check(cv.filter2D(parent, -1, k5, (-1, -1), 0.0, border, roi=roi), want)
+
+
+def test_filter2d_4k_config2(cv, orc):
+    """BASELINE config 2: cvtColor(BGR2GRAY) + filter2D 3x3 on 3840x2160 CV_8U."""
+    bgr = rnd((2160, 3840, 3), np.uint8, 809564)
+    gray = cv.cvtColor(dev(bgr), cv.COLOR_BGR2GRAY)
+    want_gray = orc.orc_cvtColor(bgr, 6)
+    check(gray, want_gray)
+    out = cv.filter2D(gray, -1, SHARPEN)
+    check(out, orc.orc_filter2D(want_gray, -1, SHARPEN))
+
+
+def test_sepfilter_modes(cv, orc):
+    src = rnd((41, 80, 3), np.uint8, 9)
+    s3, s5 = [0.25, 0.5, 0.25], [0.0625, 0.25, 0.375, 0.25, 0.0625]
+    for srcv in (src, np.ascontiguousarray(src[:, :77])):        # 77*3 = 231: 7 tail elements take the integer form
+        for kx, ky in [(s3, s3), (s5, s3), (s5, s5)]:
+            for border in BORDERS:
+                check(cv.sepFilter2D(dev(srcv), -1, kx, ky, (-1, -1), 0.0, border), orc.orc_sepFilter2D(srcv, -1, kx, ky, (-1, -1), 0.0, border))
+    for kx, ky in [([-1, 0, 1], [1, 2, 1]), ([1, 2, 1], [-1, 0, 1]), ([1, -2, 1], [3, 10, 3])]:
+        for border in BORDERS:
+            check(cv.sepFilter2D(dev(src), 3, kx, ky, (-1, -1), 2.0, border), orc.orc_sepFilter2D(src, 3, kx, ky, (-1, -1), 2.0, border))
+    rng = np.random.default_rng(1)
+    srcf = rnd((29, 64, 3), np.float32, 8)
+    kx = rng.uniform(-1, 1, 7).astype(np.float32); ky = rng.uniform(-1, 1, 5).astype(np.float32)
+    for border in BORDERS:
+        check(cv.sepFilter2D(dev(srcf), -1, kx, ky, (2, 1), 0.1, border), orc.orc_sepFilter2D(srcf, -1, kx, ky, (2, 1), 0.1, border))
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7, -1])
+def test_sobel_scharr(cv, orc, ksize):
+    src8 = rnd((33, 70), np.uint8, 3)
+    srcf = rnd((33, 70, 3), np.float32, 4)
+    for dx, dy in [(1, 0), (0, 1)] + ([(1, 1), (2, 0)] if ksize >= 3 else []):
+        for border in (0, 1, 2, 4):
+            check(cv.Sobel(dev(src8), cv.CV_16S, dx, dy, ksize, 1.0, 0.0, border), orc.orc_Sobel(src8, 3, dx, dy, ksize, 1.0, 0.0, border))
+            sc = 1.0 / (255.0 * 2 * 4)
+            check(cv.Sobel(dev(src8), cv.CV_32F, dx, dy, ksize, sc, 0.0, border), orc.orc_Sobel(src8, 5, dx, dy, ksize, sc, 0.0, border))
+            check(cv.Sobel(dev(srcf), -1, dx, dy, ksize, 1.0, 0.25, border), orc.orc_Sobel(srcf, -1, dx, dy, ksize, 1.0, 0.25, border))
+    if ksize == -1:
+        check(cv.Scharr(dev(src8), cv.CV_16S, 1, 0), orc.orc_Sobel(src8, 3, 1, 0, -1))
+
+
+def test_boxfilter(cv, orc):
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, -1)]:
+        src = rnd((31, 66, 3), dtype, 21)
+        for ksize, anchor in [((3, 3), (-1, -1)), ((5, 5), (-1, -1)), ((2, 2), (-1, -1)), ((7, 3), (1, 2)), ((16, 16), (-1, -1)), ((17, 17), (-1, -1))]:
+            for normalize in (True, False):
+                for border in (0, 1, 4):
+                    check(cv.boxFilter(dev(src), ddepth, ksize, anchor, normalize, border),
+                          orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border), tol=1e-6)
+    src = rnd((20, 33), np.uint8, 2)
+    check(cv.blur(src, (3, 3)), orc.orc_boxFilter(src, -1, (3, 3)))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_cvtcolor(cv, orc, dtype):
+    for (w, h) in [(1, 1), (7, 3), (64, 5), (263, 31), (1024, 4)]:
+        for code in range(12):
+            scn = {0: 3, 1: 4, 2: 3, 3: 4, 4: 3, 5: 4, 6: 3, 7: 3, 8: 1, 9: 1, 10: 4, 11: 4}[code]
+            src = rnd((h, w, scn) if scn > 1 else (h, w), dtype, 1000 + code + w)
+            want = orc.orc_cvtColor(src, code)
+            check(cv.cvtColor(dev(src), code), want, tol=1e-6)
+            if w == 263:
+                check(cv.cvtColor(src, code), want, tol=1e-6)
+
+
+def test_cvtcolor_known_answer_hash(cv):
+    """Imgproc_cvtColor_BE (test_color.cpp:2847-2849): adler32 of the GPU result on the RNG(0) image."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "color_rng0.npz"))
+    assert zlib.adler32(cv.cvtColor(dev(g["src"]), cv.COLOR_BGR2GRAY).cpu().numpy().tobytes()) == 0x3008c6b8
+    assert zlib.adler32(cv.cvtColor(dev(g["src"]), cv.COLOR_RGB2GRAY).cpu().numpy().tobytes()) == 0x416bd44a
+    frames = torch.from_numpy(np.stack([g["src"]] * 3)).cuda()
+    out = cv.cvtColorBatch(frames, cv.COLOR_BGR2GRAY)
+    for f in range(3):
+        assert zlib.adler32(out[f].cpu().numpy().tobytes()) == 0x3008c6b8

@@ -1,0 +1,103 @@
+"""Pins oracle/filter.c against the real reference (CPU only).
+
+Integer paths (8U filter2D via the FMA chain on exactly representable taps, sepFilter2D bit-exact modes, Sobel 8U->16S,
+box 8U) must agree bit for bit; float paths within the 1e-4 relative norm of the parity contract."""
+import numpy as np
+import pytest
+
+SHARPEN = np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32)
+BORDERS = [0, 1, 2, 4]          # filter engines reject BORDER_WRAP (FilterEngine__start asserts)
+
+
+def rnd(orc, shape, dtype, seed):
+    hi = {np.uint8: 256, np.uint16: 65536, np.int16: 32767, np.float32: 1.0}[dtype]
+    lo = -32768 if dtype == np.int16 else 0
+    return orc.ref_rng_fill(shape, dtype, seed, lo, hi)
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_filter2d_8u_exact_taps(orc, ref, cn):
+    for (w, h) in [(64, 9), (96, 33), (128, 5)]:        # widths the reference processes entirely in its SIMD body
+        src = rnd(orc, (h, w, cn) if cn > 1 else (h, w), np.uint8, 11 + w)
+        for k, anchor, delta in [(SHARPEN, (-1, -1), 0.0), (np.ones((3, 3), np.float32) * 0.125, (-1, -1), 3.0),
+                                 (np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], np.float32) * 0.25, (0, 2), 128.0),
+                                 (np.array([[0.5, 0.25, 0.125, 0.0625, 0.0625]], np.float32), (1, 0), 0.0)]:
+            for border in BORDERS:
+                want = orc.ref_filter2D(src, -1, k, anchor, delta, border)
+                got = orc.orc_filter2D(src, -1, k, anchor, delta, border)
+                assert np.array_equal(got, want), (w, h, cn, border, k.shape)
+
+
+def test_filter2d_other_depths(orc, ref):
+    rng = np.random.default_rng(5)
+    k5 = (rng.uniform(-3, 10, (5, 5)) / 37.0).astype(np.float32)      # perf_filter2d.cpp:31-34 style kernel
+    for dtype, ddepth, tol in [(np.uint8, 3, 0), (np.uint8, 5, 1e-6), (np.uint16, -1, 0), (np.int16, -1, 0), (np.float32, -1, 1e-6),
+                               (np.uint8, -1, 0)]:
+        src = rnd(orc, (37, 64, 3), dtype, 77)
+        for border in BORDERS:
+            want = orc.ref_filter2D(src, ddepth, k5, (-1, -1), 0.5, border)
+            got = orc.orc_filter2D(src, ddepth, k5, (-1, -1), 0.5, border)
+            if want.dtype == np.float32:
+                assert orc.rel_err(got, want) <= 1e-6
+            else:   # general float taps: an exact tie may round the other way in the CPU's scalar tail
+                assert int(np.max(np.abs(got.astype(np.int64) - want.astype(np.int64)))) <= 1
+                assert np.mean(got != want) < 1e-3
+
+
+def test_sepfilter_bitexact_modes(orc, ref):
+    src = rnd(orc, (41, 80, 3), np.uint8, 9)
+    smooth3, smooth5 = [0.25, 0.5, 0.25], [0.0625, 0.25, 0.375, 0.25, 0.0625]
+    for kx, ky in [(smooth3, smooth3), (smooth5, smooth3), (smooth5, smooth5)]:
+        for border in BORDERS:
+            want = orc.ref_sepFilter2D(src, -1, kx, ky, (-1, -1), 0.0, border)
+            got = orc.orc_sepFilter2D(src, -1, kx, ky, (-1, -1), 0.0, border)
+            assert np.array_equal(got, want)
+    for kx, ky in [([-1, 0, 1], [1, 2, 1]), ([1, 2, 1], [-1, 0, 1]), ([1, -2, 1], [3, 10, 3])]:
+        for border in BORDERS:
+            want = orc.ref_sepFilter2D(src, 3, kx, ky, (-1, -1), 2.0, border)
+            got = orc.orc_sepFilter2D(src, 3, kx, ky, (-1, -1), 2.0, border)
+            assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7, -1])
+def test_sobel_scharr(orc, ref, ksize):
+    src8 = rnd(orc, (33, 70), np.uint8, 3)
+    srcf = rnd(orc, (33, 70, 3), np.float32, 4)
+    for dx, dy in [(1, 0), (0, 1)] + ([(1, 1), (2, 0)] if ksize >= 3 else []):
+        for border in (1, 2, 4):
+            want = orc.ref_Sobel(src8, 3, dx, dy, ksize, 1.0, 0.0, border)          # 8U -> 16S exact
+            got = orc.orc_Sobel(src8, 3, dx, dy, ksize, 1.0, 0.0, border)
+            assert np.array_equal(got, want), (ksize, dx, dy, border)
+            sc = 1.0 / (255.0 * 2 * 4)
+            want = orc.ref_Sobel(src8, 5, dx, dy, ksize, sc, 0.0, border)            # 8U -> 32F scaled (cornerHarris)
+            got = orc.orc_Sobel(src8, 5, dx, dy, ksize, sc, 0.0, border)
+            assert orc.rel_err(got, want) <= 1e-6
+            want = orc.ref_Sobel(srcf, -1, dx, dy, ksize, 1.0, 0.25, border)
+            got = orc.orc_Sobel(srcf, -1, dx, dy, ksize, 1.0, 0.25, border)
+            assert orc.rel_err(got, want) <= 1e-6
+
+
+def test_sepfilter_float_general(orc, ref):
+    rng = np.random.default_rng(1)
+    src = rnd(orc, (29, 64, 3), np.float32, 8)
+    kx = rng.uniform(-1, 1, 7); ky = rng.uniform(-1, 1, 5)
+    for border in BORDERS:
+        want = orc.ref_sepFilter2D(src, -1, kx, ky, (2, 1), 0.1, border)
+        got = orc.orc_sepFilter2D(src, -1, kx.astype(np.float32), ky.astype(np.float32), (2, 1), 0.1, border)
+        assert orc.rel_err(got, want) <= 1e-6
+
+
+def test_boxfilter(orc, ref):
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, -1)]:
+        src = rnd(orc, (31, 66, 3), dtype, 21)
+        for ksize, anchor in [((3, 3), (-1, -1)), ((5, 5), (-1, -1)), ((2, 2), (-1, -1)), ((7, 3), (1, 2)), ((16, 16), (-1, -1)), ((17, 17), (-1, -1))]:
+            for normalize in (True, False):
+                for border in (0, 1, 4):
+                    want = orc.ref_boxFilter(src, ddepth, ksize, anchor, normalize, border)
+                    got = orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border)
+                    if want.dtype == np.float32:
+                        assert orc.rel_err(got, want) <= 2e-7, (dtype, ksize, normalize, border)
+                    elif dtype == np.uint8 and ksize[0] * ksize[1] <= 256:
+                        assert np.array_equal(got, want), (dtype, ksize, normalize, border)
+                    else:   # int32-sum normalisation: the CPU's scalar tail multiplies in double, its SIMD body in float
+                        assert int(np.max(np.abs(got.astype(np.int64) - want.astype(np.int64)))) <= 1
