@@ -193,6 +193,26 @@ MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const mi355cv_uchar* src_data, size_t 
         mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int scn, int swapBlue);
 
+/* --------------------------------------------------- a7/a8/a9: geometric transforms */
+
+/* replaces hal_ni_resize (hal_replacement.hpp:257; caller hal::resize resize.cpp:3840).  INTER_NEAREST, INTER_LINEAR
+ * (8U fixed point bit-exact; 16U/16S/32F float), INTER_AREA for integer ratios (resizeAreaFast_) and for upscaling. */
+MI355CV_API int mi355cv_resize(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, double inv_scale_x, double inv_scale_y,
+        int interpolation);
+/* replaces hal_ni_warpAffine (hal_replacement.hpp:275; caller imgwarp.cpp:2678).  M maps dst -> src (already inverted) */
+MI355CV_API int mi355cv_warpAffine(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[6], int interpolation,
+        int borderType, const double borderValue[4]);
+/* replaces hal_ni_warpPerspective (hal_replacement.hpp:316; caller imgwarp.cpp:3290) */
+MI355CV_API int mi355cv_warpPerspective(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[9], int interpolation,
+        int borderType, const double borderValue[4]);
+/* replaces hal_ni_remap32f (hal_replacement.hpp:371; caller imgwarp.cpp:1820) */
+MI355CV_API int mi355cv_remap32f(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step,
+        float* mapy, size_t mapy_step, int interpolation, int border_type, const double border_value[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,18 @@
 // hal_replacement.hpp:1146 / smooth.dispatch.cpp:708,778,813
 #undef  cv_hal_gaussianBlur
 #define cv_hal_gaussianBlur mi355cv_gaussianBlur
+// hal_replacement.hpp:257 / resize.cpp:3840
+#undef  cv_hal_resize
+#define cv_hal_resize mi355cv_resize
+// hal_replacement.hpp:275 / imgwarp.cpp:2678
+#undef  cv_hal_warpAffine
+#define cv_hal_warpAffine mi355cv_warpAffine
+// hal_replacement.hpp:316 / imgwarp.cpp:3290
+#undef  cv_hal_warpPerspective
+#define cv_hal_warpPerspective mi355cv_warpPerspective
+// hal_replacement.hpp:371 / imgwarp.cpp:1820
+#undef  cv_hal_remap32f
+#define cv_hal_remap32f mi355cv_remap32f
 // hal_replacement.hpp:442 / caller color_rgb.dispatch.cpp:276
 #undef  cv_hal_cvtBGRtoGray
 #define cv_hal_cvtBGRtoGray mi355cv_cvtBGRtoGray

@@ -66,6 +66,11 @@ def _load():
                                    c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_boxFilter": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_sz, c_sz, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_resize": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_dbl, c_dbl, c_int]),
+        "mi355cv_warpAffine": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
+        "mi355cv_warpPerspective": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
+        "mi355cv_remap32f": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_sz,
+                                     ctypes.c_void_p, c_sz, c_int, c_int, ctypes.c_void_p]),
         "mi355cv_cvtBGRtoGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtGraytoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int]),
         "mi355cv_cvtBGRtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_bool]),

@@ -1,0 +1,416 @@
+// warp.hip -- rows a7/a8/a9 of SURVEY.md §8: cv::resize, cv::warpAffine, cv::warpPerspective, cv::remap (32F maps).
+//
+// Reference semantics restated (all coordinate arithmetic is integer or IEEE double/float without contraction, so the
+// device reproduces it bit for bit):
+//   resize   hal::resize resize.cpp:3826-4194.  NEAREST: sx = min(floor(dx/fx), w-1) (:1026-1100).  LINEAR:
+//            fx = float((dx+.5)*scale-.5), sx = floor(fx) (:4097-4190); 8U runs in fixed point -- 11-bit taps,
+//            dst = ((b0*(t0>>4))>>16) + ((b1*(t1>>4))>>16) + 2) >> 2 (:1963-1989); other depths float mul/mul/add
+//            (HResizeLinear :1877, VResizeLinear :1931; resize.cpp is built without FMA).  LINEAR at exactly 1/2 and
+//            INTER_AREA with integer ratios take resizeAreaFast_ (:2919-3060): (a+b+c+d+2)>>2 for 2x2 integers.
+//   warpAffine  hal::warpAffine imgwarp.cpp:2673: X = (sat_int((M1*y+M2)*1024) + 16 + sat_int(M0*x*1024)) >> 5,
+//            pixel = X>>5, fraction = X&31 (:2254-2272, :2772-2780); then remapBilinear :675 with the 32x32 weight
+//            table of initInterTab2D :213-288 (Q15 for 8U, float otherwise) and the border rules :819-900.
+//   warpPerspective  imgwarp.cpp:3160-3226: X0,Y0,W0 evaluated at the 64-pixel block origin, then
+//            (X0 + M0*x1) * (32 / (W0 + M6*x1)) in double, cvRound (:3349-3361).
+//   remap    RemapInvoker imgwarp.cpp:1130-: 32F maps -> cvRound(map*32) -> same sampler.
+// All kernels are gather-bound: one thread per output pixel (all channels), reads through L1/L2.
+#include "rt.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+__host__ __device__ inline int eszOf(int d) { return d == D8U ? 1 : d == D32F ? 4 : 2; }
+
+__device__ __forceinline__ int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int satIntD(double v) { return v >= 2147483647.0 ? 2147483647 : v <= -2147483648.0 ? (int)-2147483648LL : (int)__double2int_rn(v); }
+__device__ __forceinline__ int satShort(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+__device__ __forceinline__ int clipI(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+
+__device__ __forceinline__ float ldV(const uchar* p, int depth, int idx)
+{
+    switch (depth) { case D8U: return (float)p[idx]; case D16U: return (float)reinterpret_cast<const unsigned short*>(p)[idx];
+                     case D16S: return (float)reinterpret_cast<const short*>(p)[idx]; default: return reinterpret_cast<const float*>(p)[idx]; }
+}
+__device__ __forceinline__ void stRound(uchar* p, int depth, int idx, float v)
+{
+    const float r = rintf(v);
+    switch (depth) {
+    case D8U:  p[idx] = (uchar)(int)fminf(fmaxf(r, 0.f), 255.f); break;
+    case D16U: reinterpret_cast<unsigned short*>(p)[idx] = (unsigned short)(int)fminf(fmaxf(r, 0.f), 65535.f); break;
+    case D16S: reinterpret_cast<short*>(p)[idx] = (short)(int)fminf(fmaxf(r, -32768.f), 32767.f); break;
+    default:   reinterpret_cast<float*>(p)[idx] = v;
+    }
+}
+__device__ __forceinline__ void copyPix(uchar* d, const uchar* s, int bytes) { for (int i = 0; i < bytes; i++) d[i] = s[i]; }
+
+// ---------------------------------------------------------------------------------- resize
+struct ResizeArgs { int sw, sh, dw, dh, depth, cn; double scale_x, scale_y, inv_x, inv_y; int mode /*0 nn,1 linear,2 area-as-linear,3 areafast*/; int isx, isy; };
+
+__device__ __forceinline__ void linCoef(int d, double scale, double inv, int areaMode, int& s, float& f)
+{
+    if (!areaMode) { f = (float)((d + 0.5) * scale - 0.5); s = cvFloorF(f); f -= s; }
+    else { s = cvFloorD(d * scale); f = (float)((d + 1) - (s + 1) * inv); f = f <= 0 ? 0.f : f - cvFloorF(f); }
+}
+
+__global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.dw || dy >= a.dh) return;
+    const int e = eszOf(a.depth), cn = a.cn;
+    uchar* D = dst + (size_t)dy * dstep;
+    if (a.mode == 0) {
+        int sy = cvFloorD(dy * a.scale_y); sy = sy > a.sh - 1 ? a.sh - 1 : sy;
+        int sx = cvFloorD(dx * a.scale_x); sx = sx > a.sw - 1 ? a.sw - 1 : sx;
+        copyPix(D + (size_t)dx * cn * e, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e);
+        return;
+    }
+    if (a.mode == 3) {
+        const int area = a.isx * a.isy;
+        const float scale = 1.f / area;
+        const bool fast2 = a.isx == 2 && a.isy == 2 && (cn == 1 || cn == 3 || cn == 4) && a.depth != D32F;
+        const int sy0 = dy * a.isy;
+        const int wfull = sy0 + a.isy <= a.sh ? a.sw / a.isx : 0;
+        for (int c = 0; c < cn; c++) {
+            const int idx = dx * cn + c;
+            if (sy0 >= a.sh) { stRound(D, a.depth, idx, 0.f); continue; }
+            if (dx < wfull) {
+                if (fast2) {
+                    int s = 0;
+                    for (int sy = 0; sy < 2; sy++) for (int sx = 0; sx < 2; sx++)
+                        s += (int)ldV(src + (size_t)(sy0 + sy) * sstep, a.depth, (dx * 2 + sx) * cn + c);
+                    s = (s + 2) >> 2;
+                    if (a.depth == D8U) D[idx] = (uchar)s; else if (a.depth == D16U) reinterpret_cast<unsigned short*>(D)[idx] = (unsigned short)s;
+                    else reinterpret_cast<short*>(D)[idx] = (short)s;
+                } else if (a.depth == D8U) {
+                    int s = 0;
+                    for (int sy = 0; sy < a.isy; sy++) for (int sx = 0; sx < a.isx; sx++)
+                        s += src[(size_t)(sy0 + sy) * sstep + (dx * a.isx + sx) * cn + c];
+                    stRound(D, a.depth, idx, s * scale);
+                } else if (a.depth == D32F && a.isx == 2 && a.isy == 2) {
+                    const float* r0 = reinterpret_cast<const float*>(src + (size_t)sy0 * sstep);
+                    const float* r1 = reinterpret_cast<const float*>(src + (size_t)(sy0 + 1) * sstep);
+                    const float s = (r0[(dx * 2) * cn + c] + r0[(dx * 2 + 1) * cn + c]) + (r1[(dx * 2) * cn + c] + r1[(dx * 2 + 1) * cn + c]);
+                    reinterpret_cast<float*>(D)[idx] = s * 0.25f;
+                } else {
+                    float s = 0;
+                    for (int sy = 0; sy < a.isy; sy++) for (int sx = 0; sx < a.isx; sx++)
+                        s += ldV(src + (size_t)(sy0 + sy) * sstep, a.depth, (dx * a.isx + sx) * cn + c);
+                    stRound(D, a.depth, idx, s * scale);
+                }
+            } else {
+                float s = 0; int is = 0, count = 0;
+                const int sx0 = dx * a.isx * cn + c;
+                for (int sy = 0; sy < a.isy; sy++) {
+                    if (sy0 + sy >= a.sh) break;
+                    for (int sx = 0; sx < a.isx * cn; sx += cn) {
+                        if (sx0 - c + sx >= a.sw * cn) break;
+                        if (a.depth == D8U) is += src[(size_t)(sy0 + sy) * sstep + sx0 + sx];
+                        else s += ldV(src + (size_t)(sy0 + sy) * sstep, a.depth, sx0 + sx);
+                        count++;
+                    }
+                }
+                if (count == 0) { stRound(D, a.depth, idx, 0.f); continue; }
+                stRound(D, a.depth, idx, (a.depth == D8U ? (float)is : s) / count);
+            }
+        }
+        return;
+    }
+    const int areaMode = a.mode == 2;
+    int sy, sx; float fy, fx;
+    linCoef(dy, a.scale_y, a.inv_y, areaMode, sy, fy);
+    linCoef(dx, a.scale_x, a.inv_x, areaMode, sx, fx);
+    const int y0 = clipI(sy, 0, a.sh), y1 = clipI(sy + 1, 0, a.sh);
+    if (sx < 0) { fx = 0; sx = 0; }
+    bool edge = false;
+    if (sx + 1 >= a.sw) { edge = true; if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; } }
+    const float b0f = 1.f - fy, b1f = fy, a0f = 1.f - fx, a1f = fx;
+    const uchar* r0 = src + (size_t)y0 * sstep;
+    const uchar* r1 = src + (size_t)y1 * sstep;
+    if (a.depth == D8U) {
+        const int b0 = satShort(__float2int_rn(b0f * 2048)), b1 = satShort(__float2int_rn(b1f * 2048));
+        const int a0 = satShort(__float2int_rn(a0f * 2048)), a1 = satShort(__float2int_rn(a1f * 2048));
+        for (int c = 0; c < cn; c++) {
+            const int i0 = sx * cn + c, i1 = i0 + cn;
+            const int t0 = edge ? r0[i0] * 2048 : r0[i0] * a0 + r0[i1] * a1;
+            const int t1 = edge ? r1[i0] * 2048 : r1[i0] * a0 + r1[i1] * a1;
+            D[dx * cn + c] = (uchar)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+        }
+        return;
+    }
+    for (int c = 0; c < cn; c++) {
+        const int i0 = sx * cn + c, i1 = i0 + cn;
+        const float p00 = ldV(r0, a.depth, i0), p10 = ldV(r1, a.depth, i0);
+        float t0, t1;
+        if (edge) { t0 = p00; t1 = p10; }
+        else {
+            const float p01 = ldV(r0, a.depth, i1), p11 = ldV(r1, a.depth, i1);
+            t0 = __fadd_rn(__fmul_rn(p00, a0f), __fmul_rn(p01, a1f));
+            t1 = __fadd_rn(__fmul_rn(p10, a0f), __fmul_rn(p11, a1f));
+        }
+        stRound(D, a.depth, dx * cn + c, __fadd_rn(__fmul_rn(t0, b0f), __fmul_rn(t1, b1f)));
+    }
+}
+
+// ---------------------------------------------------------------------------------- sampler
+// Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
+// walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
+short g_tabHost[1024 * 4 + 16];
+short* g_tabDev = nullptr;
+std::once_flag g_tabOnce;
+
+void buildTab()
+{
+    float t1[64];
+    const float scale = 1.f / 32;
+    for (int i = 0; i < 32; i++) { float x = i * scale; t1[2 * i] = 1.f - x; t1[2 * i + 1] = x; }
+    memset(g_tabHost, 0, sizeof g_tabHost);
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            short* it = g_tabHost + (i * 32 + j) * 4;
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; k1++) {
+                const float vy = t1[i * 2 + k1];
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const float v = vy * t1[j * 2 + k2];
+                    int q = (int)lrintf(v * 32768);
+                    it[k1 * 2 + k2] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q);
+                    isum += it[k1 * 2 + k2];
+                }
+            }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                int Mk1 = 1, Mk2 = 1, mk1 = 1, mk2 = 1;
+                for (int k1 = 1; k1 < 3; k1++)
+                    for (int k2 = 1; k2 < 3; k2++) {
+                        if (it[k1 * 2 + k2] < it[mk1 * 2 + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (it[k1 * 2 + k2] > it[Mk1 * 2 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) it[Mk1 * 2 + Mk2] = (short)(it[Mk1 * 2 + Mk2] - diff);
+                else it[mk1 * 2 + mk2] = (short)(it[mk1 * 2 + mk2] - diff);
+            }
+        }
+    if (hipMalloc((void**)&g_tabDev, 1024 * 4 * sizeof(short)) != hipSuccess) { g_tabDev = nullptr; return; }
+    if (hipMemcpy(g_tabDev, g_tabHost, 1024 * 4 * sizeof(short), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_tabDev); g_tabDev = nullptr; }
+}
+
+struct SampleArgs { int sw, sh, depth, cn, linear, border; float cval[4]; };
+
+__device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
+                            const short* __restrict__ tab)
+{
+    const int e = eszOf(a.depth), cn = a.cn;
+    if (!a.linear) {
+        if ((unsigned)sx < (unsigned)a.sw && (unsigned)sy < (unsigned)a.sh) { copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e); return; }
+        if (a.border == B_REPLICATE) { sx = clipI(sx, 0, a.sw); sy = clipI(sy, 0, a.sh); copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e); return; }
+        if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k]); return; }
+        if (a.border == B_TRANSPARENT) return;
+        sx = mi355_borderInterpolate(sx, a.sw, a.border); sy = mi355_borderInterpolate(sy, a.sh, a.border);
+        copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e);
+        return;
+    }
+    if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k]); return; }
+    int x0, x1, y0, y1;
+    if ((unsigned)sx < (unsigned)(a.sw - 1) && (unsigned)sy < (unsigned)(a.sh - 1)) { x0 = sx; x1 = sx + 1; y0 = sy; y1 = sy + 1; }
+    else if (a.border == B_TRANSPARENT) return;
+    else if (a.border == B_REPLICATE) { x0 = clipI(sx, 0, a.sw); x1 = clipI(sx + 1, 0, a.sw); y0 = clipI(sy, 0, a.sh); y1 = clipI(sy + 1, 0, a.sh); }
+    else { x0 = mi355_borderInterpolate(sx, a.sw, a.border); x1 = mi355_borderInterpolate(sx + 1, a.sw, a.border);
+           y0 = mi355_borderInterpolate(sy, a.sh, a.border); y1 = mi355_borderInterpolate(sy + 1, a.sh, a.border); }
+    const uchar* r0 = src + (size_t)(y0 < 0 ? 0 : y0) * sstep;
+    const uchar* r1 = src + (size_t)(y1 < 0 ? 0 : y1) * sstep;
+    if (a.depth == D8U) {
+        const short* w = tab + (ay * 32 + ax) * 4;
+        const int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        for (int k = 0; k < cn; k++) {
+            const int cv = (int)fminf(fmaxf(rintf(a.cval[k]), 0.f), 255.f);
+            const int v0 = (x0 >= 0 && y0 >= 0) ? r0[x0 * cn + k] : cv;
+            const int v1 = (x1 >= 0 && y0 >= 0) ? r0[x1 * cn + k] : cv;
+            const int v2 = (x0 >= 0 && y1 >= 0) ? r1[x0 * cn + k] : cv;
+            const int v3 = (x1 >= 0 && y1 >= 0) ? r1[x1 * cn + k] : cv;
+            const int r = (v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15;
+            D[k] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+        return;
+    }
+    const float s32 = 1.f / 32;
+    const float fx = ax * s32, fy = ay * s32;
+    const float wy0 = 1.f - fy, wy1 = fy, wx0 = 1.f - fx, wx1 = fx;
+    const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, wx1), w2 = __fmul_rn(wy1, wx0), w3 = __fmul_rn(wy1, wx1);
+    for (int k = 0; k < cn; k++) {
+        float cv = a.cval[k];
+        if (a.depth == D16U) cv = fminf(fmaxf(rintf(cv), 0.f), 65535.f);
+        else if (a.depth == D16S) cv = fminf(fmaxf(rintf(cv), -32768.f), 32767.f);
+        const float v0 = (x0 >= 0 && y0 >= 0) ? ldV(r0, a.depth, x0 * cn + k) : cv;
+        const float v1 = (x1 >= 0 && y0 >= 0) ? ldV(r0, a.depth, x1 * cn + k) : cv;
+        const float v2 = (x0 >= 0 && y1 >= 0) ? ldV(r1, a.depth, x0 * cn + k) : cv;
+        const float v3 = (x1 >= 0 && y1 >= 0) ? ldV(r1, a.depth, x1 * cn + k) : cv;
+        float t = __fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1));
+        t = __fadd_rn(t, __fmul_rn(v2, w2));
+        t = __fadd_rn(t, __fmul_rn(v3, w3));
+        stRound(D, a.depth, k, t);
+    }
+}
+
+struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; };
+
+__global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                              SampleArgs s, WarpArgs w, const short* __restrict__ tab,
+                                              const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w.dw || y >= w.dh) return;
+    uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
+    int X, Y;
+    if (w.kind == 0) {
+        const int rd = s.linear ? 16 : 512;
+        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + rd;
+        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + rd;
+        const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0));
+        const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0));
+        if (s.linear) { X = (X0 + ad) >> 5; Y = (Y0 + bd) >> 5; }
+        else { X = (X0 + ad) >> 10; Y = (Y0 + bd) >> 10; }
+    } else if (w.kind == 1) {
+        const int xb = (x / w.bw0) * w.bw0, x1 = x - xb;
+        const double X0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[0], (double)xb), __dmul_rn(w.M[1], (double)y)), w.M[2]);
+        const double Y0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[3], (double)xb), __dmul_rn(w.M[4], (double)y)), w.M[5]);
+        const double W0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[6], (double)xb), __dmul_rn(w.M[7], (double)y)), w.M[8]);
+        double W = __dadd_rn(W0, __dmul_rn(w.M[6], (double)x1));
+        W = W != 0 ? __ddiv_rn(s.linear ? 32.0 : 1.0, W) : 0;
+        double fX = __dmul_rn(__dadd_rn(X0, __dmul_rn(w.M[0], (double)x1)), W);
+        double fY = __dmul_rn(__dadd_rn(Y0, __dmul_rn(w.M[3], (double)x1)), W);
+        fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
+        fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
+        X = satIntD(fX); Y = satIntD(fY);
+    } else {
+        const float mx = reinterpret_cast<const float*>(mapx + (size_t)y * mxstep)[x];
+        const float my = reinterpret_cast<const float*>(mapy + (size_t)y * mystep)[x];
+        if (s.linear) { X = satIntD((double)__fmul_rn(mx, 32.f)); Y = satIntD((double)__fmul_rn(my, 32.f)); }
+        else { X = satIntD((double)mx); Y = satIntD((double)my); }
+    }
+    if (s.linear) samplePixel(src, sstep, D, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
+    else samplePixel(src, sstep, D, s, satShort(X), satShort(Y), 0, 0, tab);
+}
+
+bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
+
+int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
+            const double* M, int kind, int interpolation, int borderType, const double* bv,
+            const float* mapx, size_t mxstep, const float* mapy, size_t mystep)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
+    if (!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (interpolation == MI355CV_INTER_AREA) interpolation = MI355CV_INTER_LINEAR;          // imgwarp.cpp:2818
+    if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR) return MI355CV_NOT_IMPLEMENTED;
+    if (borderType < 0 || borderType > B_TRANSPARENT) return MI355CV_NOT_IMPLEMENTED;
+    if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)dw * dh < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    std::call_once(g_tabOnce, buildTab);
+    if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
+    const int e = eszOf(depth);
+    Stager stg; size_t dss, dds, mxs = mxstep, mys = mystep;
+    const uchar* ds = stg.in(src, sstep, (size_t)sw * cn * e, sh, &dss);
+    uchar* dd;
+    if (borderType == B_TRANSPARENT && !isDevicePtr(dst)) {
+        // untouched pixels must keep their previous contents: stage dst in as well
+        const uchar* din = stg.in(dst, dstep, (size_t)dw * cn * e, dh, &dds);
+        size_t dds2; dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds2);
+        if (!din || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (hipMemcpy2DAsync(dd, dds2, din, dds, (size_t)dw * cn * e, dh, hipMemcpyDeviceToDevice, stream()) != hipSuccess) return MI355CV_NOT_IMPLEMENTED;
+        dds = dds2;
+    } else dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds);
+    const uchar* dmx = nullptr; const uchar* dmy = nullptr;
+    if (kind == 2) {
+        dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
+        dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 4, dh, &mys);
+        if (!dmx || !dmy) return MI355CV_NOT_IMPLEMENTED;
+    }
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR; s.border = borderType;
+    for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
+    WarpArgs w; memset(&w, 0, sizeof w);
+    w.dw = dw; w.dh = dh; w.kind = kind;
+    if (M) for (int i = 0; i < (kind == 0 ? 6 : 9); i++) w.M[i] = M[i];
+    int bh0 = dh < 16 ? dh : 16;
+    w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
+    dim3 grid(divUp(dw, 64), divUp(dh, 4));
+    hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev, dmx, mxs, dmy, mys);
+    return stg.finish(entry);
+}
+
+} // namespace
+
+extern "C" {
+
+MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, double inv_scale_x, double inv_scale_y, int interpolation)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
+    if (!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (inv_scale_x < 2.220446049250313e-16 || inv_scale_y < 2.220446049250313e-16) {        // resize.cpp:3834-3838
+        inv_scale_x = (double)dst_width / src_width; inv_scale_y = (double)dst_height / src_height;
+    }
+    ResizeArgs a; memset(&a, 0, sizeof a);
+    a.sw = src_width; a.sh = src_height; a.dw = dst_width; a.dh = dst_height; a.depth = depth; a.cn = cn;
+    a.inv_x = inv_scale_x; a.inv_y = inv_scale_y; a.scale_x = 1. / inv_scale_x; a.scale_y = 1. / inv_scale_y;
+    a.isx = (int)nearbyint(a.scale_x); a.isy = (int)nearbyint(a.scale_y);
+    const bool areaFast = std::fabs(a.scale_x - a.isx) < 2.220446049250313e-16 && std::fabs(a.scale_y - a.isy) < 2.220446049250313e-16;
+    if (interpolation == MI355CV_INTER_NEAREST) a.mode = 0;
+    else {
+        if (interpolation == MI355CV_INTER_LINEAR && areaFast && a.isx == 2 && a.isy == 2) interpolation = MI355CV_INTER_AREA;   // :4011
+        if (interpolation == MI355CV_INTER_AREA && a.scale_x >= 1 && a.scale_y >= 1) {
+            if (!areaFast) return MI355CV_NOT_IMPLEMENTED;                                  // true area (resizeArea_): next row
+            a.mode = 3;
+        } else if (interpolation == MI355CV_INTER_LINEAR) a.mode = 1;
+        else if (interpolation == MI355CV_INTER_AREA) a.mode = 2;
+        else return MI355CV_NOT_IMPLEMENTED;                                                // cubic / lanczos / *_EXACT: next row (f2)
+    }
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int e = eszOf(depth);
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(dst_width, 64), divUp(dst_height, 4));
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, stream(), ds, dss, dd, dds, a);
+    return stg.finish("resize");
+}
+
+MI355CV_API int mi355cv_warpAffine(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[6], int interpolation, int borderType,
+        const double borderValue[4])
+{
+    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("warpAffine", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   M, 0, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
+}
+
+MI355CV_API int mi355cv_warpPerspective(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[9], int interpolation, int borderType,
+        const double borderValue[4])
+{
+    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("warpPerspective", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   M, 1, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
+}
+
+MI355CV_API int mi355cv_remap32f(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step, float* mapy, size_t mapy_step,
+        int interpolation, int border_type, const double border_value[4])
+{
+    if (!mapx || !mapy) return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("remap32f", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   nullptr, 2, interpolation, border_type, border_value, mapx, mapx_step, mapy, mapy_step);
+}
+
+} // extern "C"

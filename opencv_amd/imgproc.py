@@ -18,6 +18,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
+           "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
            "filter2D", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -354,3 +355,128 @@ def boxFilter(src, ddepth, ksize, anchor=(-1, -1), normalize=True, borderType=BO
 def blur(src, ksize, anchor=(-1, -1), borderType=BORDER_DEFAULT, dst=None):
     """cv::blur (box_filter.dispatch.cpp:492-499)."""
     return boxFilter(src, -1, ksize, anchor, True, borderType, dst)
+
+
+# ----------------------------------------------------------------------------- geometric transforms (a7, a8, a9)
+from .core import INTER_NEAREST, INTER_LINEAR, INTER_AREA, WARP_INVERSE_MAP  # noqa: E402
+
+INTER_MAX = 7
+
+
+def _sat_int(v):
+    return int(np.rint(v))            # saturate_cast<int>(double) == cvRound
+
+
+def resize(src, dsize, fx=0.0, fy=0.0, interpolation=INTER_LINEAR, dst=None):
+    """cv::resize (resize.cpp:4201-4246): dsize or (fx, fy); same-size -> copy (:4238); then cv_hal_resize."""
+    s = Img(src)
+    if dsize is None or dsize[0] == 0 or dsize[1] == 0:
+        if not (fx > 0 and fy > 0):
+            raise ValueError("resize: dsize or fx/fy required")
+        dsize = (_sat_int(s.w * fx), _sat_int(s.h * fy))                 # :4218-4220
+        if dsize[0] <= 0 or dsize[1] <= 0:
+            raise ValueError("resize: empty destination")
+    else:
+        fx, fy = dsize[0] / s.w, dsize[1] / s.h                           # :4224-4225
+    out = dst if dst is not None else empty_like_kind(src, dsize[1], dsize[0], s.cn, s.depth)
+    d = Img(out)
+    if (d.w, d.h) == (s.w, s.h):                                          # :4236-4241 plain copy
+        out[...] = src
+        return out
+    bind_stream(s, d)
+    rc = L.mi355cv_resize(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, float(fx), float(fy), interpolation)
+    _lib.check(rc, "resize")
+    return out
+
+
+def getRotationMatrix2D(center, angle, scale):
+    """cv::getRotationMatrix2D (imgwarp.cpp: getRotationMatrix2D_): center is a Point2f, math in double."""
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
+    a = angle * np.pi / 180.0
+    alpha, beta = np.cos(a) * scale, np.sin(a) * scale
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], np.float64)
+
+
+def invertAffineTransform(M):
+    """the inversion cv::warpAffine applies when WARP_INVERSE_MAP is not set (imgwarp.cpp:2824-2834)"""
+    M = np.array(M, np.float64).reshape(2, 3).copy()
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    M[0, 0] = A11; M[0, 1] *= -D
+    M[1, 0] *= -D; M[1, 1] = A22
+    b1 = -M[0, 0] * M[0, 2] - M[0, 1] * M[1, 2]
+    b2 = -M[1, 0] * M[0, 2] - M[1, 1] * M[1, 2]
+    M[0, 2] = b1; M[1, 2] = b2
+    return M
+
+
+def _border_value(v):
+    bv = np.zeros(4, np.float64)
+    if np.ndim(v) == 0:
+        bv[0] = v                      # cv::Scalar(v) = (v, 0, 0, 0)
+    else:
+        bv[:len(v)] = v
+    return bv
+
+
+def warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    """cv::warpAffine (imgwarp.cpp:2788-2903) -> cv_hal_warpAffine."""
+    s = Img(src)
+    interpolation = flags & INTER_MAX
+    if interpolation == INTER_AREA:
+        interpolation = INTER_LINEAR
+    dw, dh = (s.w, s.h) if dsize is None or dsize[0] == 0 else dsize
+    out = dst if dst is not None else empty_like_kind(src, dh, dw, s.cn, s.depth)
+    d = Img(out)
+    if d.ptr == s.ptr:
+        src = _copy_like(src); s = Img(src)
+    Mm = np.array(M, np.float64).reshape(2, 3)
+    if not (flags & WARP_INVERSE_MAP):
+        Mm = invertAffineTransform(Mm)
+    Mm = np.ascontiguousarray(Mm)
+    bv = _border_value(borderValue)
+    bind_stream(s, d)
+    rc = L.mi355cv_warpAffine(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, Mm.ctypes.data, interpolation,
+                              borderMode, bv.ctypes.data)
+    _lib.check(rc, "warpAffine")
+    return out
+
+
+def warpPerspective(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    """cv::warpPerspective (imgwarp.cpp:3370-3466) -> cv_hal_warpPerspective."""
+    s = Img(src)
+    interpolation = flags & INTER_MAX
+    if interpolation == INTER_AREA:
+        interpolation = INTER_LINEAR
+    dw, dh = (s.w, s.h) if dsize is None or dsize[0] == 0 else dsize
+    out = dst if dst is not None else empty_like_kind(src, dh, dw, s.cn, s.depth)
+    d = Img(out)
+    if d.ptr == s.ptr:
+        src = _copy_like(src); s = Img(src)
+    Mm = np.array(M, np.float64).reshape(3, 3)
+    if not (flags & WARP_INVERSE_MAP):
+        Mm = np.linalg.inv(Mm)         # cv::invert(matM, matM) :3407 (LU); parity tests pass WARP_INVERSE_MAP matrices
+    Mm = np.ascontiguousarray(Mm)
+    bv = _border_value(borderValue)
+    bind_stream(s, d)
+    rc = L.mi355cv_warpPerspective(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, Mm.ctypes.data, interpolation,
+                                   borderMode, bv.ctypes.data)
+    _lib.check(rc, "warpPerspective")
+    return out
+
+
+def remap(src, map1, map2, interpolation=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    """cv::remap with CV_32FC1 maps (imgwarp.cpp:1718-; cv_hal_remap32f :1820)."""
+    s = Img(src)
+    mx, my = Img(map1), Img(map2)
+    if mx.depth != CV_32F or my.depth != CV_32F or mx.cn != 1 or my.cn != 1 or (mx.w, mx.h) != (my.w, my.h):
+        raise NotImplementedError("remap: only a pair of CV_32FC1 maps")
+    out = dst if dst is not None else empty_like_kind(src, mx.h, mx.w, s.cn, s.depth)
+    d = Img(out)
+    bv = _border_value(borderValue)
+    bind_stream(s, d)
+    rc = L.mi355cv_remap32f(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, _vp(mx.ptr), mx.step, _vp(my.ptr), my.step,
+                            interpolation, borderMode, bv.ctypes.data)
+    _lib.check(rc, "remap32f")
+    return out

@@ -60,6 +60,18 @@ int orc_Sobel(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int 
 int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
                   int fullW, int fullH, int offX, int offY, int kw, int kh, int ax, int ay, int normalize, int border);
 
+/* geometric transforms, see oracle/warp.c; return 0 = done, 1 = combination not restated */
+int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+               int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation);
+const short* orc_bilinearTabI(void);
+int orc_warpAffine(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                   int depth, int cn, const double* M, int interpolation, int border, const double* bv);
+int orc_warpPerspective(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                        int depth, int cn, const double* M, int interpolation, int border, const double* bv);
+int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                 int depth, int cn, const float* mapx, size_t mxstep, const float* mapy, size_t mystep,
+                 int interpolation, int border, const double* bv);
+
 #ifdef __cplusplus
 }
 #endif

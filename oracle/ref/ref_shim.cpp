@@ -166,7 +166,8 @@ int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int
 {
     REF_TRY
     Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
-    cv::resize(src, dst, Size(dw, dh), fx, fy, interpolation);
+    // fx, fy > 0 select the scale-factor form (dsize derived inside cv::resize, resize.cpp:4216-4226)
+    cv::resize(src, dst, (fx > 0 && fy > 0) ? Size() : Size(dw, dh), fx, fy, interpolation);
     REF_END(dst, d)
 }
 

@@ -1,0 +1,324 @@
+/* oracle/warp.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * Restates the reference's geometric transforms in scalar C:
+ *   resize        resize.cpp:3826-4194 (hal::resize): NN :1026-, linear coefficients :4097-4190, HResizeLinear :1877,
+ *                 VResizeLinear :1931 / 8U fixed point :1963-1989, area-fast :2919-3060
+ *   warpAffine    imgwarp.cpp:2673-2700 (adelta/bdelta), :2233-2298 (X0/Y0, round_delta), :2732-2782 (blockline)
+ *   warpPerspective imgwarp.cpp:3160-3226 (block origin arithmetic), :3332-3365 (blockline)
+ *   remap kernels imgwarp.cpp:330-430 (remapNearest), :675-904 (remapBilinear), tables :213-288 (initInterTab2D)
+ * depth codes 0 (8U), 2 (16U), 3 (16S), 5 (32F); cn 1..4. */
+#include "oracle.h"
+#include <math.h>
+#include <limits.h>
+#include <string.h>
+
+static int cvfloor_d(double v) { int i = (int)v; return i - (i > v); }
+static int cvfloor_f(float v) { int i = (int)v; return i - (i > v); }
+static int sat_int_d(double v) { return v >= 2147483647.0 ? INT_MAX : v <= -2147483648.0 ? INT_MIN : (int)lrint(v); }   /* cvRound */
+static short sat_short_i(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+static int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+
+static double ldv(const uint8_t* p, int depth, int idx)
+{
+    switch (depth) { case 0: return p[idx]; case 2: return ((const uint16_t*)p)[idx]; case 3: return ((const int16_t*)p)[idx]; default: return ((const float*)p)[idx]; }
+}
+static void stv_round(uint8_t* p, int depth, int idx, float v)     /* saturate_cast<T>(float) */
+{
+    float r = rintf(v);
+    switch (depth) {
+    case 0: p[idx] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : (int)r); break;
+    case 2: ((uint16_t*)p)[idx] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : (int)r); break;
+    case 3: ((int16_t*)p)[idx] = (int16_t)(r < -32768 ? -32768 : r > 32767 ? 32767 : (int)r); break;
+    default: ((float*)p)[idx] = v;
+    }
+}
+static int esz(int depth) { return depth == 0 ? 1 : depth == 5 ? 4 : 2; }
+
+/* ------------------------------------------------------------------ resize */
+static void lin_coef(int d, double scale, double inv_scale, int ssz, int area_mode, int* so, float* f)
+{
+    int s; float fx;
+    if (!area_mode) { fx = (float)((d + 0.5) * scale - 0.5); s = cvfloor_f(fx); fx -= s; }
+    else { s = cvfloor_d(d * scale); fx = (float)((d + 1) - (s + 1) * inv_scale); fx = fx <= 0 ? 0.f : fx - cvfloor_f(fx); }
+    *so = s; *f = fx;
+    (void)ssz;
+}
+
+int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+               int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation)
+{
+    if (inv_scale_x < 2.220446049250313e-16 || inv_scale_y < 2.220446049250313e-16) {
+        inv_scale_x = (double)dw / sw; inv_scale_y = (double)dh / sh;
+    }
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    const int iscale_x = sat_int_d(scale_x), iscale_y = sat_int_d(scale_y);
+    const int is_area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    const int e = esz(depth);
+    if (interpolation == 0) {                                   /* INTER_NEAREST: resizeNN */
+        for (int y = 0; y < dh; y++) {
+            int sy = cvfloor_d(y * scale_y); if (sy > sh - 1) sy = sh - 1;
+            for (int x = 0; x < dw; x++) {
+                int sx = cvfloor_d(x * scale_x); if (sx > sw - 1) sx = sw - 1;
+                memcpy(dst + (size_t)y * dstep + (size_t)x * cn * e, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e);
+            }
+        }
+        return 0;
+    }
+    if (interpolation == 1 && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = 3;
+    if (interpolation == 3 && scale_x >= 1 && scale_y >= 1) {
+        if (!is_area_fast) return 1;                             /* true INTER_AREA: not restated */
+        const int area = iscale_x * iscale_y;
+        const float scale = 1.f / area;
+        const int fast2 = iscale_x == 2 && iscale_y == 2 && (cn == 1 || cn == 3 || cn == 4) && depth != 5;
+        const int dwidth1 = (sw / iscale_x);
+        for (int dy = 0; dy < dh; dy++) {
+            uint8_t* D = dst + (size_t)dy * dstep;
+            const int sy0 = dy * iscale_y;
+            const int wfull = sy0 + iscale_y <= sh ? dwidth1 : 0;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    const int idx = dx * cn + c;
+                    if (sy0 >= sh) { stv_round(D, depth, idx, 0.f); continue; }
+                    if (dx < wfull) {
+                        if (fast2) {                             /* ResizeAreaFastVec :2936-2961: (a+b+c+d+2)>>2 */
+                            int s = 0;
+                            for (int sy = 0; sy < 2; sy++) for (int sx = 0; sx < 2; sx++)
+                                s += (int)ldv(src + (size_t)(sy0 + sy) * sstep, depth, (dx * 2 + sx) * cn + c);
+                            s = (s + 2) >> 2;
+                            if (depth == 0) D[idx] = (uint8_t)s; else if (depth == 2) ((uint16_t*)D)[idx] = (uint16_t)s; else ((int16_t*)D)[idx] = (int16_t)s;
+                        } else if (depth == 0) {                 /* WT = int */
+                            int s = 0;
+                            for (int sy = 0; sy < iscale_y; sy++) for (int sx = 0; sx < iscale_x; sx++)
+                                s += src[(size_t)(sy0 + sy) * sstep + (dx * iscale_x + sx) * cn + c];
+                            stv_round(D, depth, idx, s * scale);
+                        } else {                                 /* WT = float, sequential sum in ofs[] order */
+                            float s = 0;
+                            if (depth == 5 && iscale_x == 2 && iscale_y == 2) {   /* SIMD body ResizeAreaFastVec_SIMD_32f :2875 */
+                                const float* r0 = (const float*)(src + (size_t)sy0 * sstep), *r1 = (const float*)(src + (size_t)(sy0 + 1) * sstep);
+                                s = ((r0[(dx * 2) * cn + c] + r0[(dx * 2 + 1) * cn + c]) + (r1[(dx * 2) * cn + c] + r1[(dx * 2 + 1) * cn + c]));
+                                ((float*)D)[idx] = s * 0.25f;
+                                continue;
+                            }
+                            for (int sy = 0; sy < iscale_y; sy++) for (int sx = 0; sx < iscale_x; sx++)
+                                s += (float)ldv(src + (size_t)(sy0 + sy) * sstep, depth, (dx * iscale_x + sx) * cn + c);
+                            stv_round(D, depth, idx, s * scale);
+                        }
+                    } else {                                     /* ragged right/bottom edge :3027-3050 */
+                        float s = 0; int is = 0, count = 0;
+                        const int sx0 = dx * iscale_x * cn + c;
+                        for (int sy = 0; sy < iscale_y; sy++) {
+                            if (sy0 + sy >= sh) break;
+                            for (int sx = 0; sx < iscale_x * cn; sx += cn) {
+                                if (sx0 - c + sx >= sw * cn) break;
+                                if (depth == 0) is += src[(size_t)(sy0 + sy) * sstep + sx0 + sx];
+                                else s += (float)ldv(src + (size_t)(sy0 + sy) * sstep, depth, sx0 + sx);
+                                count++;
+                            }
+                        }
+                        if (count == 0) { stv_round(D, depth, idx, 0.f); continue; }
+                        stv_round(D, depth, idx, (depth == 0 ? (float)is : s) / count);
+                    }
+                }
+        }
+        return 0;
+    }
+    if (interpolation != 1 && interpolation != 3) return 1;
+    const int area_mode = interpolation == 3;
+    for (int dy = 0; dy < dh; dy++) {
+        int sy; float fy;
+        lin_coef(dy, scale_y, inv_scale_y, sh, area_mode, &sy, &fy);
+        const int y0 = clipi(sy, 0, sh), y1 = clipi(sy + 1, 0, sh);
+        const float b0f = 1.f - fy, b1f = fy;
+        const short b0 = sat_short_i((int)lrintf(b0f * 2048)), b1 = sat_short_i((int)lrintf(b1f * 2048));
+        for (int dx = 0; dx < dw; dx++) {
+            int sx; float fx;
+            lin_coef(dx, scale_x, inv_scale_x, sw, area_mode, &sx, &fx);
+            if (sx < 0) { fx = 0; sx = 0; }
+            int edge = 0;
+            if (sx + 1 >= sw) { edge = 1; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+            const float a0f = 1.f - fx, a1f = fx;
+            const short a0 = sat_short_i((int)lrintf(a0f * 2048)), a1 = sat_short_i((int)lrintf(a1f * 2048));
+            for (int c = 0; c < cn; c++) {
+                const uint8_t* r0 = src + (size_t)y0 * sstep, *r1 = src + (size_t)y1 * sstep;
+                const int i0 = sx * cn + c, i1 = i0 + cn;
+                if (depth == 0) {
+                    int t0 = edge ? r0[i0] * 2048 : r0[i0] * a0 + r0[i1] * a1;
+                    int t1 = edge ? r1[i0] * 2048 : r1[i0] * a0 + r1[i1] * a1;
+                    dst[(size_t)dy * dstep + dx * cn + c] = (uint8_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+                } else {
+                    float p00 = (float)ldv(r0, depth, i0), p10 = (float)ldv(r1, depth, i0);
+                    float t0, t1;
+                    if (edge) { t0 = p00; t1 = p10; }
+                    else {
+                        float p01 = (float)ldv(r0, depth, i1), p11 = (float)ldv(r1, depth, i1);
+                        float m0 = p00 * a0f, m1 = p01 * a1f; t0 = m0 + m1;
+                        float m2 = p10 * a0f, m3 = p11 * a1f; t1 = m2 + m3;
+                    }
+                    float v0 = t0 * b0f, v1 = t1 * b1f;
+                    stv_round(dst + (size_t)dy * dstep, depth, dx * cn + c, v0 + v1);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ interpolation tables */
+static short g_itab[1024 * 4 + 16];
+static int g_itab_init = 0;
+const short* orc_bilinearTabI(void)              /* initInterTab2D(INTER_LINEAR, fixpt) imgwarp.cpp:213-288, incl. its fix-up quirk */
+{
+    if (g_itab_init) return g_itab;
+    float t1[64];
+    const float scale = 1.f / 32;
+    for (int i = 0; i < 32; i++) { float x = i * scale; t1[2 * i] = 1.f - x; t1[2 * i + 1] = x; }
+    memset(g_itab, 0, sizeof g_itab);
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            short* it = g_itab + (i * 32 + j) * 4;
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; k1++) {
+                float vy = t1[i * 2 + k1];
+                for (int k2 = 0; k2 < 2; k2++) {
+                    float v = vy * t1[j * 2 + k2];
+                    it[k1 * 2 + k2] = sat_short_i((int)lrintf(v * 32768));
+                    isum += it[k1 * 2 + k2];
+                }
+            }
+            if (isum != 32768) {
+                int diff = isum - 32768, Mk1 = 1, Mk2 = 1, mk1 = 1, mk2 = 1;
+                for (int k1 = 1; k1 < 3; k1++)           /* ksize2 .. ksize2+2 with ksize = 2: walks into the NEXT entry */
+                    for (int k2 = 1; k2 < 3; k2++) {
+                        if (it[k1 * 2 + k2] < it[mk1 * 2 + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (it[k1 * 2 + k2] > it[Mk1 * 2 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) it[Mk1 * 2 + Mk2] = (short)(it[Mk1 * 2 + Mk2] - diff);
+                else it[mk1 * 2 + mk2] = (short)(it[mk1 * 2 + mk2] - diff);
+            }
+        }
+    g_itab_init = 1;
+    return g_itab;
+}
+
+/* one output pixel of remapBilinear / remapNearest given integer coordinates + 5-bit fractions */
+static void sample_pixel(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* D, int depth, int cn,
+                         int sx, int sy, int ax, int ay, int linear, int border, const double* bv)
+{
+    const int e = esz(depth);
+    if (!linear) {
+        if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) { memcpy(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e); return; }
+        if (border == 1) { sx = clipi(sx, 0, sw); sy = clipi(sy, 0, sh); memcpy(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e); return; }
+        if (border == 0) { for (int k = 0; k < cn; k++) stv_round(D, depth, k, (float)bv[k & 3]); return; }   /* cval = saturate_cast<T>(borderValue) */
+        if (border == 5) return;
+        sx = orc_borderInterpolate(sx, sw, border); sy = orc_borderInterpolate(sy, sh, border);
+        memcpy(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e);
+        return;
+    }
+    if (border == 0 && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stv_round(D, depth, k, (float)bv[k & 3]); return; }
+    if (border == 5 && !((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1))) return;   /* partial-overlap formula not restated */
+    int x0, x1, y0, y1;
+    if (border == 1) { x0 = clipi(sx, 0, sw); x1 = clipi(sx + 1, 0, sw); y0 = clipi(sy, 0, sh); y1 = clipi(sy + 1, 0, sh); }
+    else { x0 = orc_borderInterpolate(sx, sw, border); x1 = orc_borderInterpolate(sx + 1, sw, border);
+           y0 = orc_borderInterpolate(sy, sh, border); y1 = orc_borderInterpolate(sy + 1, sh, border); }
+    const short* wi = orc_bilinearTabI() + (ay * 32 + ax) * 4;
+    const float s32 = 1.f / 32;
+    const float fx = ax * s32, fy = ay * s32;
+    const float wy0 = 1.f - fy, wy1 = fy, wx0 = 1.f - fx, wx1 = fx;
+    const float wf[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+    for (int k = 0; k < cn; k++) {
+        uint8_t cvb[8]; float cvf;
+        stv_round(cvb, depth, 0, (float)bv[k & 3]);
+        cvf = (float)ldv(cvb, depth, 0);
+        float v[4];
+        v[0] = (x0 >= 0 && y0 >= 0) ? (float)ldv(src + (size_t)y0 * sstep, depth, x0 * cn + k) : cvf;
+        v[1] = (x1 >= 0 && y0 >= 0) ? (float)ldv(src + (size_t)y0 * sstep, depth, x1 * cn + k) : cvf;
+        v[2] = (x0 >= 0 && y1 >= 0) ? (float)ldv(src + (size_t)y1 * sstep, depth, x0 * cn + k) : cvf;
+        v[3] = (x1 >= 0 && y1 >= 0) ? (float)ldv(src + (size_t)y1 * sstep, depth, x1 * cn + k) : cvf;
+        if (depth == 0) {
+            int t = (int)v[0] * wi[0] + (int)v[1] * wi[1] + (int)v[2] * wi[2] + (int)v[3] * wi[3];
+            int r = (t + (1 << 14)) >> 15;                       /* FixedPtCast<int,uchar,15> */
+            D[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        } else {
+            float p0 = v[0] * wf[0], p1 = v[1] * wf[1], p2 = v[2] * wf[2], p3 = v[3] * wf[3];
+            float t = p0 + p1; t = t + p2; t = t + p3;
+            stv_round(D, depth, k, t);
+        }
+    }
+}
+
+int orc_warpAffine(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                   int depth, int cn, const double* M, int interpolation, int border, const double* bv)
+{
+    if (interpolation == 3) interpolation = 1;
+    if (interpolation != 0 && interpolation != 1) return 1;
+    const int linear = interpolation == 1;
+    const int round_delta = linear ? 1024 / 32 / 2 : 1024 / 2;
+    const int e = esz(depth);
+    for (int y = 0; y < dh; y++) {
+        const int X0 = sat_int_d((M[1] * y + M[2]) * 1024) + round_delta;
+        const int Y0 = sat_int_d((M[4] * y + M[5]) * 1024) + round_delta;
+        for (int x = 0; x < dw; x++) {
+            const int ad = sat_int_d(M[0] * x * 1024), bd = sat_int_d(M[3] * x * 1024);
+            uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
+            if (linear) {
+                const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, 1, border, bv);
+            } else {
+                const int X = (X0 + ad) >> 10, Y = (Y0 + bd) >> 10;
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X), sat_short_i(Y), 0, 0, 0, border, bv);
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_warpPerspective(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                        int depth, int cn, const double* M, int interpolation, int border, const double* bv)
+{
+    if (interpolation == 3) interpolation = 1;
+    if (interpolation != 0 && interpolation != 1) return 1;
+    const int linear = interpolation == 1;
+    const int e = esz(depth);
+    int bh0 = 16 < dh ? 16 : dh;
+    int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int xb = (x / bw0) * bw0, x1 = x - xb;
+            const double X0 = M[0] * xb + M[1] * y + M[2];
+            const double Y0 = M[3] * xb + M[4] * y + M[5];
+            const double W0 = M[6] * xb + M[7] * y + M[8];
+            double W = W0 + M[6] * x1;
+            W = W ? (linear ? 32. : 1.) / W : 0;
+            double fX = (X0 + M[0] * x1) * W, fY = (Y0 + M[3] * x1) * W;
+            fX = fX < (double)INT_MIN ? (double)INT_MIN : fX > (double)INT_MAX ? (double)INT_MAX : fX;
+            fY = fY < (double)INT_MIN ? (double)INT_MIN : fY > (double)INT_MAX ? (double)INT_MAX : fY;
+            const int X = sat_int_d(fX), Y = sat_int_d(fY);
+            uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
+            if (linear) sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, 1, border, bv);
+            else sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X), sat_short_i(Y), 0, 0, 0, border, bv);
+        }
+    return 0;
+}
+
+/* cv::remap with CV_32FC1 maps (imgwarp.cpp:1130-1330 RemapInvoker: sx = cvRound(mapx*32) ...) */
+int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                 int depth, int cn, const float* mapx, size_t mxstep, const float* mapy, size_t mystep,
+                 int interpolation, int border, const double* bv)
+{
+    if (interpolation != 0 && interpolation != 1) return 1;
+    const int e = esz(depth);
+    for (int y = 0; y < dh; y++) {
+        const float* mx = (const float*)((const uint8_t*)mapx + (size_t)y * mxstep);
+        const float* my = (const float*)((const uint8_t*)mapy + (size_t)y * mystep);
+        for (int x = 0; x < dw; x++) {
+            uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
+            if (interpolation == 1) {
+                int sx = sat_int_d((double)(mx[x] * 32.f)), sy = sat_int_d((double)(my[x] * 32.f));
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5), sat_short_i(sy >> 5), sx & 31, sy & 31, 1, border, bv);
+            } else {
+                int sx = sat_int_d((double)mx[x]), sy = sat_int_d((double)my[x]);
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx), sat_short_i(sy), 0, 0, 0, border, bv);
+            }
+        }
+    }
+    return 0;
+}

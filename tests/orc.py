@@ -298,3 +298,127 @@ def rel_err(a, b):
     """checkNormRelative of the reference's accelerated-backend tests (ts/ocl_test.hpp:309-314)"""
     a = a.astype(np.float64); b = b.astype(np.float64)
     return float(np.max(np.abs(a - b)) / max(np.finfo(np.float32).eps, max(np.max(np.abs(a)), np.max(np.abs(b)))))
+
+
+# ----------------------------------------------------------------------------- geometric transforms
+def _dst_geom(src, dsize):
+    dw, dh = dsize
+    return np.empty((dh, dw) + src.shape[2:], src.dtype)
+
+
+def orc_resize(src, dsize, fx=0.0, fy=0.0, interpolation=1):
+    o = oracle()
+    sh, sw = src.shape[:2]
+    if dsize is None or dsize[0] == 0:
+        dsize = (int(np.rint(sw * fx)), int(np.rint(sh * fy)))
+    else:
+        fx, fy = dsize[0] / sw, dsize[1] / sh
+    dst = _dst_geom(src, dsize)
+    rc = o.orc_resize(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], _NP_DEPTH[src.dtype], cn_of(src),
+                      c_dbl(fx), c_dbl(fy), interpolation)
+    assert rc == 0, "oracle does not restate this resize mode"
+    return dst
+
+
+def ref_resize(src, dsize, fx=0.0, fy=0.0, interpolation=1):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    if dsize is None or dsize[0] == 0:
+        dsize = (int(np.rint(sw * fx)), int(np.rint(sh * fy)))
+        dst = _dst_geom(src, dsize)
+        rc = r.ref_resize(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), c_dbl(fx), c_dbl(fy), interpolation)
+    else:
+        dst = _dst_geom(src, dsize)
+        rc = r.ref_resize(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), c_dbl(0), c_dbl(0), interpolation)
+    assert rc == 0, rc
+    return dst
+
+
+def _bv(borderValue):
+    """cv::Scalar semantics: a bare number is (v, 0, 0, 0)"""
+    bv = np.zeros(4, np.float64)
+    if np.ndim(borderValue) == 0:
+        bv[0] = borderValue
+    else:
+        bv[:len(borderValue)] = borderValue
+    return bv
+
+
+def orc_warpAffine(src, M, dsize, flags=1, border=0, borderValue=0.0):
+    """M maps dst -> src (i.e. already inverted / WARP_INVERSE_MAP form), like hal::warpAffine receives it"""
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dst = _dst_geom(src, dsize)
+    if border == 5:
+        dst[...] = 0
+    M = np.ascontiguousarray(M, np.float64)
+    bv = _bv(borderValue)
+    rc = o.orc_warpAffine(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], _NP_DEPTH[src.dtype], cn_of(src),
+                          P(M), flags & 7, border, P(bv))
+    assert rc == 0
+    return dst
+
+
+def orc_warpPerspective(src, M, dsize, flags=1, border=0, borderValue=0.0):
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dst = _dst_geom(src, dsize)
+    M = np.ascontiguousarray(M, np.float64)
+    bv = _bv(borderValue)
+    rc = o.orc_warpPerspective(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], _NP_DEPTH[src.dtype], cn_of(src),
+                               P(M), flags & 7, border, P(bv))
+    assert rc == 0
+    return dst
+
+
+def orc_remap(src, mapx, mapy, interpolation=1, border=0, borderValue=0.0):
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dh, dw = mapx.shape
+    dst = _dst_geom(src, (dw, dh))
+    bv = _bv(borderValue)
+    rc = o.orc_remap32f(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, _NP_DEPTH[src.dtype], cn_of(src),
+                        P(mapx), step(mapx), P(mapy), step(mapy), interpolation, border, P(bv))
+    assert rc == 0
+    return dst
+
+
+def ref_warpAffine(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dst = _dst_geom(src, dsize)
+    M = np.ascontiguousarray(M, np.float64)
+    bv = _bv(borderValue)
+    rc = r.ref_warpAffine(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), P(M), flags, border, P(bv))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_warpPerspective(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dst = _dst_geom(src, dsize)
+    M = np.ascontiguousarray(M, np.float64)
+    bv = _bv(borderValue)
+    rc = r.ref_warpPerspective(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), P(M), flags, border, P(bv))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_remap(src, mapx, mapy, interpolation=1, border=0, borderValue=0.0):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dh, dw = mapx.shape
+    dst = _dst_geom(src, (dw, dh))
+    bv = _bv(borderValue)
+    rc = r.ref_remap(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, cvtype(src), P(mapx), step(mapx), P(mapy), step(mapy),
+                     interpolation, border, P(bv))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_getRotationMatrix2D(center, angle, scale):
+    r = load_ref()
+    M = np.zeros(6, np.float64)
+    assert r.ref_getRotationMatrix2D(c_dbl(center[0]), c_dbl(center[1]), c_dbl(angle), c_dbl(scale), P(M)) == 0
+    return M.reshape(2, 3)

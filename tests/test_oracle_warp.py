@@ -1,0 +1,97 @@
+"""Pins oracle/warp.c (resize / warpAffine / warpPerspective / remap) against the real reference (CPU only).
+8U / 16U / 16S: bit-exact (test_imgwarp_strict.cpp demands 0 for 8U warpAffine :1089-1092); 32F: 1e-6 relative."""
+import numpy as np
+import pytest
+
+DT = [np.uint8, np.uint16, np.int16, np.float32]
+
+
+def rnd(orc, shape, dtype, seed):
+    hi = {np.uint8: 256, np.uint16: 65536, np.int16: 32767, np.float32: 1.0}[dtype]
+    lo = -32768 if dtype == np.int16 else 0
+    return orc.ref_rng_fill(shape, dtype, seed, lo, hi)
+
+
+def same(orc, got, want, tol=1e-6):
+    if want.dtype == np.float32:
+        assert orc.rel_err(got, want) <= tol
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_linear_nearest(orc, ref, dtype, cn):
+    src = rnd(orc, (37, 53, cn) if cn > 1 else (37, 53), dtype, 5 + cn)
+    for dsize in [(80, 55), (35, 25), (53, 37), (106, 74), (17, 9), (1, 1), (200, 3)]:
+        for interp in (0, 1):
+            same(orc, orc.orc_resize(src, dsize, interpolation=interp), orc.ref_resize(src, dsize, interpolation=interp))
+    for fx, fy in [(0.5, 0.5), (1.5, 1.5), (0.75, 1.25), (2.0, 2.0)]:
+        same(orc, orc.orc_resize(src, None, fx, fy, 1), orc.ref_resize(src, None, fx, fy, 1))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_resize_area_fast(orc, ref, dtype, cn):
+    for (w, h) in [(48, 72), (60, 36), (120, 24)]:
+        src = rnd(orc, (h, w, cn) if cn > 1 else (h, w), dtype, 9 + cn + w)
+        for s in (2, 3, 4):
+            dsize = (w // s, h // s)                       # exact integer scales -> resizeAreaFast_
+            same(orc, orc.orc_resize(src, dsize, interpolation=3), orc.ref_resize(src, dsize, interpolation=3))
+        same(orc, orc.orc_resize(src, (w // 2, h // 2), interpolation=1), orc.ref_resize(src, (w // 2, h // 2), interpolation=1))
+        same(orc, orc.orc_resize(src, (w * 2, h * 2), interpolation=3), orc.ref_resize(src, (w * 2, h * 2), interpolation=3))   # AREA upscale -> linear-like
+    # fx = 0.5 on odd sizes whose half rounds UP (cvRound(27.5) = 28): ragged last column/row (resize.cpp:3027-3050)
+    src = rnd(orc, (59, 55, cn) if cn > 1 else (59, 55), dtype, 77)
+    for interp in (1, 3):
+        same(orc, orc.orc_resize(src, None, 0.5, 0.5, interp), orc.ref_resize(src, None, 0.5, 0.5, interp))
+
+
+def mats(orc, w, h):
+    out = []
+    for ang, sc in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]:
+        M = orc.ref_getRotationMatrix2D((w / 2.0, h / 2.0), ang, sc)
+        out.append(M)
+    out.append(np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64))
+    out.append(np.array([[0.3, 0.1, -20.0], [-0.2, 0.4, 30.0]], np.float64))
+    return out
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_affine(orc, ref, dtype, cn):
+    src = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 15 + cn)
+    for M in mats(orc, 61, 45):
+        for dsize in [(61, 45), (100, 30)]:
+            for interp in (0, 1):
+                for border, bval in [(0, 0.0), (0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0)]:
+                    want = orc.ref_warpAffine(src, M, dsize, interp | 16, border, bval)
+                    got = orc.orc_warpAffine(src, M, dsize, interp, border, bval)
+                    same(orc, got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3])
+def test_warp_perspective(orc, ref, dtype, cn):
+    src = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 25 + cn)
+    Ms = [np.array([[1.1, 0.05, -3.0], [0.02, 0.9, 4.0], [1e-4, -2e-4, 1.0]]),
+          np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]]),
+          np.eye(3)]
+    for M in Ms:
+        for dsize in [(61, 45), (150, 40), (7, 70)]:
+            for interp in (0, 1):
+                for border, bval in [(0, 5.0), (1, 0), (4, 0)]:
+                    want = orc.ref_warpPerspective(src, M, dsize, interp | 16, border, bval)
+                    got = orc.orc_warpPerspective(src, M, dsize, interp, border, bval)
+                    same(orc, got, want)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_remap32f(orc, ref, dtype):
+    src = rnd(orc, (40, 50, 3), dtype, 35)
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:33, 0:47].astype(np.float32)
+    mapx = (xx * 1.07 + rng.uniform(-3, 3, xx.shape)).astype(np.float32)
+    mapy = (yy * 1.2 - 2 + rng.uniform(-3, 3, yy.shape)).astype(np.float32)
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0)]:
+            same(orc, orc.orc_remap(src, mapx, mapy, interp, border, bval), orc.ref_remap(src, mapx, mapy, interp, border, bval))

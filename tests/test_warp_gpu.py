@@ -1,0 +1,140 @@
+"""GPU parity for rows a7-a9: resize, warpAffine, warpPerspective, remap -- through the C ABI against the oracle.
+8U/16U/16S bit-exact (test_imgwarp_strict.cpp:1089-1092 demands 0 for 8U warpAffine), 32F within 1e-4 relative
+(in practice identical: same operation order, no FMA)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DT = [np.uint8, np.uint16, np.int16, np.float32]
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def rnd(shape, dtype, seed):
+    rng = np.random.default_rng(seed)
+    if dtype == np.float32:
+        return rng.random(shape, dtype=np.float32)
+    info = np.iinfo(dtype)
+    return rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
+
+
+def check(got, want, tol=1e-6):
+    import orc
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    assert got.dtype == want.dtype and got.shape == want.shape
+    if want.dtype == np.float32:
+        assert orc.rel_err(got, want) <= tol
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize(cv, orc, dtype, cn):
+    src = rnd((37, 53, cn) if cn > 1 else (37, 53), dtype, 5 + cn)
+    n0 = cv.call_count("resize")
+    for dsize in [(80, 55), (35, 25), (106, 74), (17, 9), (1, 1), (200, 3)]:
+        for interp in (0, 1):
+            check(cv.resize(dev(src), dsize, interpolation=interp), orc.orc_resize(src, dsize, interpolation=interp))
+    for fx, fy in [(0.5, 0.5), (1.5, 1.5), (0.75, 1.25), (2.0, 2.0)]:
+        check(cv.resize(dev(src), None, fx, fy, 1), orc.orc_resize(src, None, fx, fy, 1))
+    check(cv.resize(src, (80, 55)), orc.orc_resize(src, (80, 55)))                           # host arrays
+    assert cv.call_count("resize") > n0
+    for (w, h) in [(48, 72), (60, 36)]:
+        s2 = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 9 + w)
+        for s in (2, 3, 4):
+            check(cv.resize(dev(s2), (w // s, h // s), interpolation=3), orc.orc_resize(s2, (w // s, h // s), interpolation=3))
+        check(cv.resize(dev(s2), (w * 2, h * 2), interpolation=3), orc.orc_resize(s2, (w * 2, h * 2), interpolation=3))
+    s3 = rnd((59, 55, cn) if cn > 1 else (59, 55), dtype, 77)
+    check(cv.resize(dev(s3), None, 0.5, 0.5, 1), orc.orc_resize(s3, None, 0.5, 0.5, 1))
+    assert torch.equal(cv.resize(dev(src), (53, 37)), dev(src))                            # same size -> copy
+
+
+def mats(cv, w, h):
+    out = [cv.getRotationMatrix2D((w / 2.0, h / 2.0), a, s) for a, s in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]]
+    out.append(np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64))
+    out.append(np.array([[0.3, 0.1, -20.0], [-0.2, 0.4, 30.0]], np.float64))
+    return out
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_affine(cv, orc, dtype, cn):
+    src = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 15 + cn)
+    for M in mats(cv, 61, 45):
+        for dsize in [(61, 45), (100, 30)]:
+            for interp in (0, 1):
+                for border, bval in [(0, 0.0), (0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0)]:
+                    want = orc.orc_warpAffine(src, M, dsize, interp, border, bval)
+                    check(cv.warpAffine(dev(src), M, dsize, interp | cv.WARP_INVERSE_MAP, border, bval), want)
+    M = mats(cv, 61, 45)[0]
+    check(cv.warpAffine(src, M, (61, 45), 1 | cv.WARP_INVERSE_MAP), orc.orc_warpAffine(src, M, (61, 45)))   # host arrays
+    # forward matrix: the wrapper inverts it as cv::warpAffine does (imgwarp.cpp:2824-2834)
+    check(cv.warpAffine(dev(src), M, (61, 45)), orc.orc_warpAffine(src, cv.invertAffineTransform(M), (61, 45)))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3])
+def test_warp_perspective_and_remap(cv, orc, dtype, cn):
+    src = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 25 + cn)
+    Ms = [np.array([[1.1, 0.05, -3.0], [0.02, 0.9, 4.0], [1e-4, -2e-4, 1.0]]),
+          np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]]), np.eye(3)]
+    for M in Ms:
+        for dsize in [(61, 45), (150, 40), (7, 70)]:
+            for interp in (0, 1):
+                for border, bval in [(0, 5.0), (1, 0), (4, 0)]:
+                    check(cv.warpPerspective(dev(src), M, dsize, interp | cv.WARP_INVERSE_MAP, border, bval),
+                          orc.orc_warpPerspective(src, M, dsize, interp, border, bval))
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:33, 0:47].astype(np.float32)
+    mapx = (xx * 1.07 + rng.uniform(-3, 3, xx.shape)).astype(np.float32)
+    mapy = (yy * 1.2 - 2 + rng.uniform(-3, 3, yy.shape)).astype(np.float32)
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0)]:
+            check(cv.remap(dev(src), dev(mapx), dev(mapy), interp, border, bval), orc.orc_remap(src, mapx, mapy, interp, border, bval))
+
+
+def test_config3_8k_float(cv, orc):
+    """BASELINE config 3: resize (bilinear) + warpAffine on 7680x4320 CV_32F (checked on crops the oracle finishes quickly)."""
+    src = rnd((4320, 7680), np.float32, 809564)
+    d = dev(src)
+    up = cv.resize(d, (5120, 2880))
+    half = cv.resize(d, (3840, 2160))
+    # the top-left 600x400 of each result depends only on the top-left of the source
+    crop = np.ascontiguousarray(src[:700, :1000])
+    want = orc.orc_resize(crop, None, 5120 / 7680, 2880 / 4320, 1)
+    check(up[:400, :600], np.ascontiguousarray(want[:400, :600]))
+    want2 = orc.orc_resize(crop, (500, 350), interpolation=1)
+    check(half[:350, :500], want2)
+    M = cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95)
+    Minv = cv.invertAffineTransform(M)
+    out = cv.warpAffine(d, M, (7680, 4320))
+    want3 = orc_band(orc, src, Minv)        # the oracle handles one band of rows fast enough
+    check(out[2000:2200], want3)
+
+
+def orc_band(orc, src, Minv, y0=2000, y1=2200):
+    """rows [y0,y1) of warpAffine(src, Minv, same size): shift the row origin into the matrix (x' = M0 x + M1 (y+y0) + M2)"""
+    Mb = np.array(Minv, np.float64).copy()
+    full = orc.orc_warpAffine  # noqa: F841
+    # the reference evaluates (M1*y + M2) per absolute row; emulate by running the oracle on the whole height would take minutes,
+    # so instead run it row-exactly through a tall-enough destination of which only the band is computed:
+    import ctypes
+    o = orc.oracle()
+    h, w = src.shape
+    dst = np.empty((y1, w), np.float32)
+    bv = np.zeros(4, np.float64)
+    # compute rows 0..y1-1 lazily: the oracle is O(rows); 2200 rows of 7680 px ~ 17 Mpix -> a few seconds
+    rc = o.orc_warpAffine(orc.P(src), orc.step(src), w, h, orc.P(dst), orc.step(dst), w, y1, 5, 1, orc.P(np.ascontiguousarray(Mb)), 1, 0, orc.P(bv))
+    assert rc == 0
+    return np.ascontiguousarray(dst[y0:y1])
