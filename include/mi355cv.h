@@ -213,6 +213,37 @@ MI355CV_API int mi355cv_remap32f(int src_type, const mi355cv_uchar* src_data, si
         mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step,
         float* mapy, size_t mapy_step, int interpolation, int border_type, const double border_value[4]);
 
+/* --------------------------------------------------- a10/a11/a12: corners and pyramids */
+
+/* replace hal_ni_pyrdown (hal_replacement.hpp:1244) and hal_ni_pyrdown_offset (:1268); caller cv::pyrDown pyramids.cpp:1371,1377.
+ * depth 8U/16U/16S/32F, cn 1..4, every border cv::pyrDown accepts. */
+MI355CV_API int mi355cv_pyrdown(const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, int depth, int cn, int border_type);
+MI355CV_API int mi355cv_pyrdown_offset(const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, int depth, int cn,
+        int margin_left, int margin_top, int margin_right, int margin_bottom, int border_type);
+MI355CV_API int mi355cv_pyrdownBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes,
+        int depth, int cn, int border_type);
+/* cv::buildPyramid (pyramids.cpp:1616-1643) has no HAL hook: dst_data[i] / dst_step[i] receive level i+1. */
+MI355CV_API int mi355cv_buildPyramid(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
+        mi355cv_uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type);
+
+/* cv::cornerHarris (corner.cpp:634) / cv::cornerMinEigenVal (:604) have no HAL hook: fused entry points with the cv::
+ * argument list.  src_type CV_8UC1 or CV_32FC1, dst CV_32FC1. */
+MI355CV_API int mi355cv_cornerHarris(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_type, int blockSize, int ksize, double k, int borderType);
+MI355CV_API int mi355cv_cornerMinEigenVal(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_type, int blockSize, int ksize, int borderType);
+MI355CV_API int mi355cv_cornerHarrisBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int src_type,
+        int blockSize, int ksize, double k, int borderType);
+/* cv::goodFeaturesToTrack (featureselect.cpp:382): returns the number of corners written to `corners` (x,y pairs),
+ * -1 if the arguments are unsupported, -2 on a device failure.  `quality` and `mask_data` may be NULL. */
+MI355CV_API int mi355cv_goodFeaturesToTrack(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int src_type,
+        float* corners, float* quality, int maxCorners, double qualityLevel, double minDistance,
+        const mi355cv_uchar* mask_data, size_t mask_step, int blockSize, int gradientSize, int useHarrisDetector, double harrisK);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,11 @@
 // hal_replacement.hpp:371 / imgwarp.cpp:1820
 #undef  cv_hal_remap32f
 #define cv_hal_remap32f mi355cv_remap32f
+// hal_replacement.hpp:1244,1268 / pyramids.cpp:1371,1377
+#undef  cv_hal_pyrdown
+#define cv_hal_pyrdown mi355cv_pyrdown
+#undef  cv_hal_pyrdown_offset
+#define cv_hal_pyrdown_offset mi355cv_pyrdown_offset
 // hal_replacement.hpp:442 / caller color_rgb.dispatch.cpp:276
 #undef  cv_hal_cvtBGRtoGray
 #define cv_hal_cvtBGRtoGray mi355cv_cvtBGRtoGray

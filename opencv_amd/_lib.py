@@ -71,6 +71,15 @@ def _load():
         "mi355cv_warpPerspective": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
         "mi355cv_remap32f": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_sz,
                                      ctypes.c_void_p, c_sz, c_int, c_int, ctypes.c_void_p]),
+        "mi355cv_pyrdown": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_pyrdown_offset": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_pyrdownBatch": (c_int, [c_u8p, c_sz, c_sz, c_int, c_int, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_buildPyramid": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_sz), c_int, c_int]),
+        "mi355cv_cornerHarris": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_dbl, c_int]),
+        "mi355cv_cornerMinEigenVal": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_cornerHarrisBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_int]),
+        "mi355cv_goodFeaturesToTrack": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, c_dbl,
+                                                c_u8p, c_sz, c_int, c_int, c_int, c_dbl]),
         "mi355cv_cvtBGRtoGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtGraytoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int]),
         "mi355cv_cvtBGRtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_bool]),

@@ -1,0 +1,474 @@
+// corner.hip -- rows a10/a11/a12 of SURVEY.md §8: cv::cornerHarris / cornerMinEigenVal, cv::goodFeaturesToTrack,
+// cv::pyrDown / cv::buildPyramid.
+//
+// Reference semantics:
+//   cornerEigenValsVecs (corner.cpp:237-322): Dx, Dy = Sobel(src, CV_32F, scale = 1/(2^(ks-1) * bs * [255 if 8U])),
+//     cov = (dx^2, dx*dy, dy^2) in float, boxFilter(cov, bs x bs, normalize=false) with double sums and the border
+//     rule applied to COV (i.e. to the derivative positions), then calcHarris :104-155 R = (a*c - b*b) - (k*(a+c))*(a+c)
+//     or calcMinEigenVal :52-100 (a+c)/2 - sqrt(((a-c)/2)^2 + b^2), all float.
+//   The reference makes ~5 full-image passes (70 B/pixel of traffic); here everything between the 8-bit source and
+//   the float response stays inside one workgroup: source tile (+halo) -> LDS, both derivative planes -> LDS, box
+//   sums + response from LDS.  HBM traffic = 1 B read + 4 B written per pixel (1080p: 10.4 MB/frame).
+//   goodFeaturesToTrack (featureselect.cpp:382-548): max -> THRESH_TOZERO -> 3x3 dilate equality test on the GPU,
+//     candidates compacted to a list; the sort (value desc, address desc) and the min-distance grid stay on the host
+//     as in the reference's own OpenCL path (:75-360).
+//   pyrDown (pyramids.cpp:883-1037): 5x5 [1 4 6 4 1]^2 at even pixels, (S + 128) >> 8 for integers, * 1/256 for float,
+//     including the tabR column stepping of :897-910 for non-default dsize.
+#include "rt.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+
+// ---------------------------------------------------------------------------------- pyrDown
+__global__ __launch_bounds__(256) void k_pyrdown(const uchar* __restrict__ src, size_t sstep, size_t sframe, int sw, int sh,
+                                                 uchar* __restrict__ dst, size_t dstep, size_t dframe, int dw, int dh,
+                                                 int depth, int cn, int mL, int mT, int mR, int mB, int border)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= dw * cn || y >= dh) return;
+    src += (size_t)blockIdx.z * sframe; dst += (size_t)blockIdx.z * dframe;
+    const int x = e / cn, c = e - x * cn;
+    const int fullW = mL + sw + mR, fullH = mT + sh + mB;
+    int width0 = (sw - 3) / 2 + 1; if (width0 > dw) width0 = dw;
+    const int cx = x < width0 ? 2 * x : 2 * width0 + (x - width0);      // tabR stepping, pyramids.cpp:897-910
+    int xs[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) xs[i] = (mi355_borderInterpolate(cx + i - 2 + mL, fullW, border) - mL) * cn + c;
+    uchar* drow = dst + (size_t)y * dstep;
+    if (depth == D32F) {
+        float rows[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int yy = mi355_borderInterpolate(2 * y + j - 2 + mT, fullH, border) - mT;
+            const float* r = reinterpret_cast<const float*>(src + (ptrdiff_t)yy * (ptrdiff_t)sstep);
+            const float p0 = r[xs[0]], p1 = r[xs[1]], p2 = r[xs[2]], p3 = r[xs[3]], p4 = r[xs[4]];
+            float t = __fmul_rn(p2, 6.f);
+            t = __fadd_rn(t, __fmul_rn(__fadd_rn(p1, p3), 4.f)); t = __fadd_rn(t, p0); t = __fadd_rn(t, p4);
+            rows[j] = t;
+        }
+        float t = __fmul_rn(rows[2], 6.f);
+        t = __fadd_rn(t, __fmul_rn(__fadd_rn(rows[1], rows[3]), 4.f)); t = __fadd_rn(t, rows[0]); t = __fadd_rn(t, rows[4]);
+        reinterpret_cast<float*>(drow)[e] = __fmul_rn(t, 1.f / 256);
+        return;
+    }
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int yy = mi355_borderInterpolate(2 * y + j - 2 + mT, fullH, border) - mT;
+        const uchar* r = src + (ptrdiff_t)yy * (ptrdiff_t)sstep;
+        int v[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+            v[i] = depth == D8U ? (int)r[xs[i]] : depth == D16U ? (int)reinterpret_cast<const unsigned short*>(r)[xs[i]]
+                                                               : (int)reinterpret_cast<const short*>(r)[xs[i]];
+        const int rs = v[2] * 6 + (v[1] + v[3]) * 4 + v[0] + v[4];
+        const int wj = j == 2 ? 6 : (j == 1 || j == 3) ? 4 : 1;
+        acc += wj * rs;
+    }
+    const int o = (acc + 128) >> 8;
+    if (depth == D8U) drow[e] = (uchar)o;
+    else if (depth == D16U) reinterpret_cast<unsigned short*>(drow)[e] = (unsigned short)o;
+    else reinterpret_cast<short*>(drow)[e] = (short)o;
+}
+
+int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe, int sw, int sh, uchar* dst, size_t dstep, size_t dframe,
+               int dw, int dh, int nframes, int depth, int cn, int mL, int mT, int mR, int mB, int border)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    border &= ~MI355CV_BORDER_ISOLATED;
+    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;   // pyramids.cpp:1352 forbids CONSTANT
+    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)sw * sh < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
+    Stager stg; size_t dss = sstep, dds = dstep;
+    const uchar* ds = src; uchar* dd = dst;
+    if (nframes == 1) {
+        const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * cn * e;
+        const uchar* dtop = stg.in(top, sstep, (size_t)(mL + sw + mR) * cn * e, mT + sh + mB, &dss);
+        dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds);
+        if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+        ds = dtop + (size_t)mT * dss + (size_t)mL * cn * e;
+    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, stream(), ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, depth, cn, mL, mT, mR, mB, border);
+    return stg.finish(entry);
+}
+
+// ---------------------------------------------------------------------------------- fused corner response
+constexpr int CT_X = 64, CT_Y = 16;     // outputs per workgroup
+
+struct CornerArgs {
+    int W, H, sdepth, bs, ax, ay, border, harris;
+    float kf;
+    // separable derivative taps as cv::Sobel / cv::Scharr generate them (deriv.cpp:55-162, :432-439)
+    float dxRow[8], dxCol[8], dyRow[8], dyCol[8];
+    int nRow, nCol;                     // tap counts of the row / column kernels (same for Dx and Dy except ksize == 1)
+    int dxNRow, dxNCol, dyNRow, dyNCol;
+    int rx, ry;                         // halo radii of the source tile
+};
+
+__device__ __forceinline__ float sepAt(const float* S, int SW, int ly, int lx, const float* kr, int nr, const float* kc, int nc, bool colAsym)
+{
+    // row sums of RowFilter (s = k0*v0; s = fma(ki, vi, s)) for the nc rows, then SymmColumnFilter's pair form
+    const int cr = nr / 2, cc = nc / 2;
+    float rsum[8];
+    for (int j = 0; j < nc; j++) {
+        const float* row = S + (ly + j - cc) * SW + (lx - cr);
+        float s = kr[0] * row[0];
+        for (int i = 1; i < nr; i++) s = __builtin_fmaf(kr[i], row[i], s);
+        rsum[j] = s;
+    }
+    float s = colAsym ? 0.f : __builtin_fmaf(kc[cc], rsum[cc], 0.f);
+    for (int k = 1; k <= cc; k++)
+        s = __builtin_fmaf(kc[cc + k], colAsym ? rsum[cc + k] - rsum[cc - k] : rsum[cc + k] + rsum[cc - k], s);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                      uchar* __restrict__ dst, size_t dstep, size_t dframe, CornerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    src += (size_t)blockIdx.z * sframe; dst += (size_t)blockIdx.z * dframe;
+    const int X0 = blockIdx.x * CT_X, Y0 = blockIdx.y * CT_Y;
+    const int bx = a.bs - 1 - a.ax, by = a.bs - 1 - a.ay;
+    const int PW = CT_X + a.bs - 1, PH = CT_Y + a.bs - 1;          // derivative planes: positions [X0-ax, X0+CT_X-1+bx]
+    const int SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;              // source tile: planes region +- (rx, ry)
+    float* S = lds;
+    float* Pdx = S + SW * SH;
+    float* Pdy = Pdx + PW * PH;
+    const int tid = threadIdx.x;
+    // 1. source tile, border-extended: S(p) = src(borderInterpolate(p)); BORDER_CONSTANT contributes 0
+    const int sx0 = X0 - a.ax - a.rx, sy0 = Y0 - a.ay - a.ry;
+    for (int i = tid; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int yy = mi355_borderInterpolate(sy0 + ly, a.H, a.border);
+        const int xx = mi355_borderInterpolate(sx0 + lx, a.W, a.border);
+        float v = 0.f;
+        if (yy >= 0 && xx >= 0) {
+            const uchar* row = src + (size_t)yy * sstep;
+            v = a.sdepth == D8U ? (float)row[xx] : reinterpret_cast<const float*>(row)[xx];
+        }
+        S[i] = v;
+    }
+    __syncthreads();
+    // 2. derivative planes at in-image positions of the plane region
+    for (int i = tid; i < PW * PH; i += 256) {
+        const int ly = i / PW, lx = i - ly * PW;
+        const int py = Y0 - a.ay + ly, px = X0 - a.ax + lx;
+        float dx = 0.f, dy = 0.f;
+        if ((unsigned)py < (unsigned)a.H && (unsigned)px < (unsigned)a.W) {
+            dx = sepAt(S, SW, ly + a.ry, lx + a.rx, a.dxRow, a.dxNRow, a.dxCol, a.dxNCol, false);   // Dx: derivative along x, smoothing (symmetric) along y
+            dy = sepAt(S, SW, ly + a.ry, lx + a.rx, a.dyRow, a.dyNRow, a.dyCol, a.dyNCol, a.dyNCol > 1);   // Dy: smoothing along x, derivative (antisymmetric) along y
+        }
+        Pdx[i] = dx; Pdy[i] = dy;
+    }
+    __syncthreads();
+    // 3. box sums of the products (double, as RowSum<float,double>/ColumnSum<double,float>) + response
+    const int tx = tid & 63;
+    const int x = X0 + tx;
+    if (x >= a.W) return;
+    int lxs[16];
+    for (int i = 0; i < a.bs; i++) {
+        int q = mi355_borderInterpolate(x - a.ax + i, a.W, a.border);
+        lxs[i] = q < 0 ? -1 : min(max(q - (X0 - a.ax), 0), PW - 1);
+    }
+    for (int ty = tid >> 6; ty < CT_Y; ty += 4) {
+        const int y = Y0 + ty;
+        if (y >= a.H) break;
+        double sxx = 0, sxy = 0, syy = 0;
+        for (int j = 0; j < a.bs; j++) {
+            int q = mi355_borderInterpolate(y - a.ay + j, a.H, a.border);
+            if (q < 0) continue;
+            const int ly = min(max(q - (Y0 - a.ay), 0), PH - 1);
+            double rxx = 0, rxy = 0, ryy = 0;
+            for (int i = 0; i < a.bs; i++) {
+                if (lxs[i] < 0) continue;
+                const float dx = Pdx[ly * PW + lxs[i]], dy = Pdy[ly * PW + lxs[i]];
+                rxx += (double)__fmul_rn(dx, dx); rxy += (double)__fmul_rn(dx, dy); ryy += (double)__fmul_rn(dy, dy);
+            }
+            sxx += rxx; sxy += rxy; syy += ryy;
+        }
+        const float A = (float)sxx, B = (float)sxy, C = (float)syy;
+        float r;
+        if (a.harris) {
+            const float acbb = __fsub_rn(__fmul_rn(A, C), __fmul_rn(B, B));
+            const float ac = __fadd_rn(A, C);
+            r = __fsub_rn(acbb, __fmul_rn(__fmul_rn(a.kf, ac), ac));
+        } else {
+            const float ah = __fmul_rn(A, 0.5f), ch = __fmul_rn(C, 0.5f);
+            const float t = __fsub_rn(ah, ch);
+            const float u = __fadd_rn(__fmul_rn(B, B), __fmul_rn(t, t));
+            r = __fsub_rn(__fadd_rn(ah, ch), __fsqrt_rn(u));
+        }
+        reinterpret_cast<float*>(dst + (size_t)y * dstep)[x] = r;
+    }
+    (void)bx; (void)by;
+}
+
+bool derivTaps(int order, int ksize, bool scharr, std::vector<int>& k)
+{
+    if (scharr) { if (order == 0) k = {3, 10, 3}; else k = {-1, 0, 1}; return true; }
+    if (ksize == 1 && order > 0) ksize = 3;
+    if (ksize % 2 == 0 || ksize > 7 || ksize <= order) return false;
+    if (ksize == 1) { k = {1}; return true; }
+    if (ksize == 3) { if (order == 0) k = {1, 2, 1}; else k = {-1, 0, 1}; return true; }
+    std::vector<int> kerI(ksize + 1, 0);
+    kerI[0] = 1;
+    for (int i = 0; i < ksize - order - 1; i++) { int ov = kerI[0]; for (int j = 1; j <= ksize; j++) { int nv = kerI[j] + kerI[j - 1]; kerI[j - 1] = ov; ov = nv; } }
+    for (int i = 0; i < order; i++) { int ov = -kerI[0]; for (int j = 1; j <= ksize; j++) { int nv = kerI[j - 1] - kerI[j]; kerI[j - 1] = ov; ov = nv; } }
+    k.assign(kerI.begin(), kerI.begin() + ksize);
+    return true;
+}
+
+int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t dds, size_t dframe, int nframes,
+                 int W, int H, int sdepth, int blockSize, int ksize, double k, int border, bool harris, hipStream_t st)
+{
+    CornerArgs a; memset(&a, 0, sizeof a);
+    a.W = W; a.H = H; a.sdepth = sdepth; a.bs = blockSize; a.ax = blockSize / 2; a.ay = blockSize / 2; a.border = border;
+    a.harris = harris; a.kf = (float)k;
+    double scale = (double)(1 << ((ksize > 0 ? ksize : 3) - 1)) * blockSize;       // corner.cpp:247-252
+    if (ksize < 0) scale *= 2.0;
+    if (sdepth == D8U) scale *= 255.0;
+    scale = 1.0 / scale;
+    const bool scharr = ksize <= 0;
+    std::vector<int> d1, s0x, s0y;
+    // Dx = Sobel(1,0): kx = derivative taps, ky = smoothing taps * scale; Dy = Sobel(0,1): kx = smoothing * scale, ky = derivative
+    std::vector<int> dxr, dxc, dyr, dyc;
+    if (!derivTaps(1, ksize, scharr, dxr) || !derivTaps(0, ksize, scharr, dxc) || !derivTaps(0, ksize, scharr, dyr) || !derivTaps(1, ksize, scharr, dyc))
+        return MI355CV_NOT_IMPLEMENTED;
+    a.dxNRow = (int)dxr.size(); a.dxNCol = (int)dxc.size(); a.dyNRow = (int)dyr.size(); a.dyNCol = (int)dyc.size();
+    for (int i = 0; i < a.dxNRow; i++) a.dxRow[i] = (float)dxr[i];
+    for (int i = 0; i < a.dxNCol; i++) a.dxCol[i] = (float)((double)dxc[i] * scale);     // `ky *= scale` (dx != 0)
+    for (int i = 0; i < a.dyNRow; i++) a.dyRow[i] = (float)((double)dyr[i] * scale);     // `kx *= scale` (dx == 0)
+    for (int i = 0; i < a.dyNCol; i++) a.dyCol[i] = (float)dyc[i];
+    if (scale == 1) { /* unreachable for the depths handled; kept for symmetry with cv::Sobel */ }
+    a.rx = std::max(a.dxNRow, a.dyNRow) / 2; a.ry = std::max(a.dxNCol, a.dyNCol) / 2;
+    const int PW = CT_X + a.bs - 1, PH = CT_Y + a.bs - 1, SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;
+    const size_t lds = (size_t)(SW * SH + 2 * PW * PH) * sizeof(float);
+    dim3 grid(divUp(W, CT_X), divUp(H, CT_Y), nframes);
+    hipLaunchKernelGGL(k_corner_fused, grid, dim3(256), lds, st, ds, dss, sframe, dd, dds, dframe, a);
+    return MI355CV_OK;
+}
+
+int runCorner(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+              int W, int H, int src_type, int blockSize, int ksize, double k, int borderType, bool harris)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    const int sdepth = MI355CV_MAT_DEPTH(src_type);
+    if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return MI355CV_NOT_IMPLEMENTED;   // corner.cpp:254
+    const int border = borderType & ~MI355CV_BORDER_ISOLATED;
+    if (border == B_WRAP || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;          // FilterEngine rejects WRAP
+    if (blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss = sstep, dds = dstep;
+    const uchar* ds = src; uchar* dd = dst;
+    if (nframes == 1) {
+        ds = stg.in(src, sstep, (size_t)W * (sdepth == D8U ? 1 : 4), H, &dss);
+        dd = stg.out(dst, dstep, (size_t)W * 4, H, &dds);
+        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
+    int rc = launchCorner(ds, dss, sframe, dd, dds, dframe, nframes, W, H, sdepth, blockSize, ksize, k, border, harris, stream());
+    if (rc != MI355CV_OK) return rc;
+    return stg.finish(entry);
+}
+
+// ---------------------------------------------------------------------------------- goodFeaturesToTrack
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ inline float ord2f(unsigned o) { unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; memcpy(&f, &u, 4); return f; }
+
+__global__ __launch_bounds__(256) void k_maxval(const float* __restrict__ eig, size_t estep, const uchar* __restrict__ mask, size_t mstep,
+                                                int W, int H, unsigned* __restrict__ out)
+{
+    unsigned best = 0;                                  // below every real float in the ordered encoding
+    for (int y = blockIdx.x; y < H; y += gridDim.x) {
+        const float* row = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(eig) + (size_t)y * estep);
+        for (int x = threadIdx.x; x < W; x += 256)
+            if (!mask || mask[(size_t)y * mstep + x]) best = max(best, f2ord(row[x]));
+    }
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));      // wave64 reduction
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+}
+
+struct Cand { float v; int idx; };
+
+__global__ __launch_bounds__(256) void k_gftt_candidates(const float* __restrict__ eig, size_t estep, const uchar* __restrict__ mask, size_t mstep,
+                                                         int W, int H, const unsigned* __restrict__ maxOrd, double quality,
+                                                         Cand* __restrict__ out, unsigned* __restrict__ count, unsigned capacity)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+    if (x >= W - 1 || y >= H - 1) return;
+    unsigned mo = *maxOrd;
+    unsigned mu = (mo & 0x80000000u) ? (mo & 0x7fffffffu) : ~mo;
+    const double maxVal = mo == 0 ? 0.0 : (double)__uint_as_float(mu);
+    const float thr = (float)(maxVal * quality);          // cv::threshold converts the double threshold to the image depth
+    auto T = [&](int yy, int xx) { float v = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(eig) + (size_t)yy * estep)[xx]; return v > thr ? v : 0.f; };
+    const float v = T(y, x);
+    if (v == 0.f || (mask && !mask[(size_t)y * mstep + x])) return;
+    float m = v;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) m = fmaxf(m, T(y + j, x + i));
+    if (v != m) return;
+    const unsigned slot = atomicAdd(count, 1u);
+    if (slot < capacity) { out[slot].v = v; out[slot].idx = y * W + x; }
+}
+
+} // namespace
+
+extern "C" {
+
+MI355CV_API int mi355cv_pyrdown(const uchar* src_data, size_t src_step, int src_width, int src_height, uchar* dst_data, size_t dst_step,
+                                int dst_width, int dst_height, int depth, int cn, int border_type)
+{
+    return runPyrDown("pyrdown", src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, depth, cn, 0, 0, 0, 0, border_type);
+}
+
+MI355CV_API int mi355cv_pyrdown_offset(const uchar* src_data, size_t src_step, int src_width, int src_height, uchar* dst_data, size_t dst_step,
+                                       int dst_width, int dst_height, int depth, int cn, int margin_left, int margin_top, int margin_right,
+                                       int margin_bottom, int border_type)
+{
+    return runPyrDown("pyrdown_offset", src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, depth, cn,
+                      margin_left, margin_top, margin_right, margin_bottom, border_type);
+}
+
+MI355CV_API int mi355cv_pyrdownBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+                                     uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes,
+                                     int depth, int cn, int border_type)
+{
+    return runPyrDown("pyrdownBatch", src_data, src_step, nframes == 1 ? 0 : src_frame_stride, src_width, src_height, dst_data, dst_step,
+                      nframes == 1 ? 0 : dst_frame_stride, dst_width, dst_height, nframes, depth, cn, 0, 0, 0, 0, border_type);
+}
+
+// cv::buildPyramid (pyramids.cpp:1616-1643): level 0 is the source itself; levels 1..maxlevel by pyrDown of the previous one.
+// dst_data[i], dst_step[i] describe level i+1 ((w+1)/2 x (h+1)/2 of the previous level), pre-allocated by the caller.
+MI355CV_API int mi355cv_buildPyramid(const uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
+                                     uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type)
+{
+    if (!dst_data || !dst_step || maxlevel < 0) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* s = src_data; size_t ss = src_step; int w = width, h = height;
+    for (int l = 0; l < maxlevel; l++) {
+        const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+        int rc = runPyrDown("buildPyramid", s, ss, 0, w, h, dst_data[l], dst_step[l], 0, dw, dh, 1, depth, cn, 0, 0, 0, 0, border_type);
+        if (rc != MI355CV_OK) return l == 0 ? rc : MI355CV_ERROR_UNKNOWN;
+        s = dst_data[l]; ss = dst_step[l]; w = dw; h = dh;
+    }
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_cornerHarris(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                     int src_type, int blockSize, int ksize, double k, int borderType)
+{
+    return runCorner("cornerHarris", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, src_type, blockSize, ksize, k, borderType, true);
+}
+
+MI355CV_API int mi355cv_cornerMinEigenVal(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                          int src_type, int blockSize, int ksize, int borderType)
+{
+    return runCorner("cornerMinEigenVal", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, src_type, blockSize, ksize, 0.0, borderType, false);
+}
+
+MI355CV_API int mi355cv_cornerHarrisBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step,
+                                          size_t dst_frame_stride, int nframes, int width, int height, int src_type, int blockSize, int ksize,
+                                          double k, int borderType)
+{
+    return runCorner("cornerHarrisBatch", src_data, src_step, nframes == 1 ? 0 : src_frame_stride, dst_data, dst_step,
+                     nframes == 1 ? 0 : dst_frame_stride, nframes, width, height, src_type, blockSize, ksize, k, borderType, true);
+}
+
+// cv::goodFeaturesToTrack (featureselect.cpp:382-548).  corners: x0,y0,x1,y1,... (capacity maxCorners pairs, or width*height
+// when maxCorners <= 0); quality (optional) receives the response of each returned corner.  Returns the corner count (>= 0),
+// -1 when the arguments are not supported (nothing computed), -2 on a device failure.
+MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_step, int width, int height, int src_type,
+                                            float* corners, float* quality, int maxCorners, double qualityLevel, double minDistance,
+                                            const uchar* mask_data, size_t mask_step, int blockSize, int gradientSize,
+                                            int useHarrisDetector, double harrisK)
+{
+    if (disabled() || !corners || qualityLevel <= 0 || minDistance < 0 || width <= 0 || height <= 0) return -1;
+    const int sdepth = MI355CV_MAT_DEPTH(src_type);
+    if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return -1;
+    if (!ensureDevice()) return -1;
+    Stager stg; size_t dss, dms = mask_step;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * (sdepth == D8U ? 1 : 4), height, &dss);
+    const uchar* dm = nullptr;
+    if (mask_data) dm = stg.in(mask_data, mask_step, (size_t)width, height, &dms);
+    const size_t estep = ((size_t)width * 4 + 255) & ~size_t(255);
+    uchar* eig = (uchar*)stg.scratch(estep * height);
+    const unsigned capacity = (unsigned)std::min<size_t>((size_t)width * height, (size_t)1 << 26);
+    Cand* cand = (Cand*)stg.scratch((size_t)capacity * sizeof(Cand));
+    unsigned* ctr = (unsigned*)stg.scratch(256);
+    if (!ds || !eig || !cand || !ctr || (mask_data && !dm)) return -1;
+    hipStream_t st = stream();
+    // cv::cornerHarris / cornerMinEigenVal with the default border (BORDER_DEFAULT, featureselect.cpp:408-411)
+    int rc = launchCorner(ds, dss, 0, eig, estep, 0, 1, width, height, sdepth, blockSize, gradientSize, harrisK, B_REFLECT_101, useHarrisDetector != 0, st);
+    if (rc != MI355CV_OK) return -1;
+    if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_maxval, dim3(std::min(height, 1024)), dim3(256), 0, st, (const float*)eig, estep, dm, dms, width, height, ctr);
+    if (width > 2 && height > 2) {
+        dim3 grid(divUp(width - 2, 64), divUp(height - 2, 4));
+        hipLaunchKernelGGL(k_gftt_candidates, grid, dim3(256), 0, st, (const float*)eig, estep, dm, dms, width, height, ctr, qualityLevel, cand, ctr + 1, capacity);
+    }
+    unsigned hc[2] = {0, 0};
+    if (hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2 ;
+    const unsigned total = std::min(hc[1], capacity);
+    std::vector<Cand> c(total);
+    if (total && (hipMemcpyAsync(c.data(), cand, (size_t)total * sizeof(Cand), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+        return -2;
+    (void)stg.finish("goodFeaturesToTrack");
+    // std::sort with greaterThanPtr (featureselect.cpp:55-60): value descending, equal values -> higher address first
+    std::sort(c.begin(), c.end(), [](const Cand& p, const Cand& q) { return p.v > q.v ? true : p.v < q.v ? false : p.idx > q.idx; });
+    int n = 0;
+    const int cap = maxCorners > 0 ? maxCorners : width * height;
+    if (minDistance >= 1) {                                          // :451-525 grid-based rejection
+        const int cell = (int)nearbyint(minDistance);
+        const int gw = (width + cell - 1) / cell, gh = (height + cell - 1) / cell;
+        std::vector<std::vector<int>> grid((size_t)gw * gh);
+        const double md2 = minDistance * minDistance;
+        for (unsigned i = 0; i < total; i++) {
+            const int y = c[i].idx / width, x = c[i].idx % width;
+            const int xc = x / cell, yc = y / cell;
+            const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+            bool good = true;
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (int j : grid[(size_t)yy * gw + xx]) {
+                        const float dx = x - corners[2 * j], dy = y - corners[2 * j + 1];
+                        if (dx * dx + dy * dy < md2) { good = false; break; }
+                    }
+            if (good) {
+                if (n >= cap) break;
+                corners[2 * n] = (float)x; corners[2 * n + 1] = (float)y;
+                if (quality) quality[n] = c[i].v;
+                grid[(size_t)yc * gw + xc].push_back(n);
+                n++;
+                if (maxCorners > 0 && n == maxCorners) break;
+            }
+        }
+    } else {
+        for (unsigned i = 0; i < total && n < cap; i++) {
+            corners[2 * n] = (float)(c[i].idx % width); corners[2 * n + 1] = (float)(c[i].idx / width);
+            if (quality) quality[n] = c[i].v;
+            n++;
+            if (maxCorners > 0 && n == maxCorners) break;
+        }
+    }
+    return n;
+}
+
+} // extern "C"

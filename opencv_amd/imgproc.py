@@ -18,6 +18,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
+           "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
            "filter2D", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
@@ -480,3 +481,107 @@ def remap(src, map1, map2, interpolation=INTER_LINEAR, borderMode=BORDER_CONSTAN
                             interpolation, borderMode, bv.ctypes.data)
     _lib.check(rc, "remap32f")
     return out
+
+
+# ----------------------------------------------------------------------------- pyramids and corners (a10, a11, a12)
+def pyrDown(src, dstsize=None, borderType=BORDER_DEFAULT, dst=None, margins=None):
+    """cv::pyrDown (pyramids.cpp:1348-1395) -> cv_hal_pyrdown / cv_hal_pyrdown_offset."""
+    if (borderType & ~BORDER_ISOLATED) == BORDER_CONSTANT:
+        raise ValueError("pyrDown: BORDER_CONSTANT is not allowed")               # CV_Assert :1352
+    s = Img(src)
+    dw, dh = ((s.w + 1) // 2, (s.h + 1) // 2) if dstsize is None or dstsize[0] == 0 else dstsize
+    out = dst if dst is not None else empty_like_kind(src, dh, dw, s.cn, s.depth)
+    d = Img(out)
+    bind_stream(s, d)
+    if margins is not None and not (borderType & BORDER_ISOLATED):
+        rc = L.mi355cv_pyrdown_offset(_vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, s.depth, s.cn,
+                                      margins[0], margins[1], margins[2], margins[3], borderType & ~BORDER_ISOLATED)
+    else:
+        rc = L.mi355cv_pyrdown(_vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, s.depth, s.cn, borderType)
+    _lib.check(rc, "pyrdown")
+    return out
+
+
+def buildPyramid(src, maxlevel, borderType=BORDER_DEFAULT):
+    """cv::buildPyramid (pyramids.cpp:1616-1643): [src, level1, ..., level maxlevel]; one C-ABI call for all levels."""
+    if (borderType & ~BORDER_ISOLATED) == BORDER_CONSTANT:
+        raise ValueError("buildPyramid: BORDER_CONSTANT is not allowed")
+    s = Img(src)
+    levels, w, h = [src], s.w, s.h
+    for _ in range(maxlevel):
+        w, h = (w + 1) // 2, (h + 1) // 2
+        levels.append(empty_like_kind(src, h, w, s.cn, s.depth))
+    if maxlevel > 0:
+        imgs = [Img(l) for l in levels[1:]]
+        ptrs = (ctypes.c_void_p * maxlevel)(*[i.ptr for i in imgs])
+        steps = (ctypes.c_size_t * maxlevel)(*[i.step for i in imgs])
+        bind_stream(s, imgs[0])
+        _lib.check(L.mi355cv_buildPyramid(_vp(s.ptr), s.step, s.w, s.h, s.depth, s.cn, ptrs, steps, maxlevel, borderType), "buildPyramid")
+    return levels
+
+
+def buildPyramidBatch(frames, maxlevel, borderType=BORDER_DEFAULT):
+    """[N,H,W(,C)] device frames -> list of per-level batches, one launch per level."""
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    cn = int(frames.shape[3]) if frames.dim() == 4 else 1
+    out, cur = [frames], frames
+    for _ in range(maxlevel):
+        dw, dh = (w + 1) // 2, (h + 1) // 2
+        nxt = torch.empty((n, dh, dw) + ((cn,) if frames.dim() == 4 else ()), dtype=frames.dtype, device=frames.device)
+        s0, d0 = Img(cur[0]), Img(nxt[0])
+        bind_stream(s0, d0)
+        rc = L.mi355cv_pyrdownBatch(_vp(s0.ptr), s0.step, int(cur.stride(0)) * s0.esz, w, h, _vp(d0.ptr), d0.step, int(nxt.stride(0)) * d0.esz,
+                                    dw, dh, n, s0.depth, cn, borderType)
+        _lib.check(rc, "pyrdownBatch")
+        out.append(nxt)
+        cur, w, h = nxt, dw, dh
+    return out
+
+
+def cornerHarris(src, blockSize, ksize, k, borderType=BORDER_DEFAULT, dst=None):
+    """cv::cornerHarris (corner.cpp:634-653): CV_8UC1 / CV_32FC1 -> CV_32FC1, fused on the GPU."""
+    s = Img(src)
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, 1, CV_32F)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_cornerHarris(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.type, blockSize, ksize, float(k), borderType), "cornerHarris")
+    return out
+
+
+def cornerMinEigenVal(src, blockSize, ksize=3, borderType=BORDER_DEFAULT, dst=None):
+    """cv::cornerMinEigenVal (corner.cpp:604-631)."""
+    s = Img(src)
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, 1, CV_32F)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_cornerMinEigenVal(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.type, blockSize, ksize, borderType), "cornerMinEigenVal")
+    return out
+
+
+def cornerHarrisBatch(frames, blockSize, ksize, k, borderType=BORDER_DEFAULT, dst=None):
+    """[N,H,W] device frames (uint8 or float32) -> [N,H,W] float32 responses, one launch."""
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    out = dst if dst is not None else torch.empty((n, h, w), dtype=torch.float32, device=frames.device)
+    s0, d0 = Img(frames[0]), Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_cornerHarrisBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * 4, n, w, h,
+                                     s0.type, blockSize, ksize, float(k), borderType)
+    _lib.check(rc, "cornerHarrisBatch")
+    return out
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3, gradientSize=3,
+                        useHarrisDetector=False, k=0.04, returnQuality=False):
+    """cv::goodFeaturesToTrack (featureselect.cpp:382-548): Nx2 float32 corner array (x, y)."""
+    s = Img(image)
+    cap = maxCorners if maxCorners > 0 else s.w * s.h
+    corners = np.zeros((cap, 2), np.float32)
+    quality = np.zeros(cap, np.float32)
+    m = Img(mask) if mask is not None else None
+    bind_stream(s)
+    n = L.mi355cv_goodFeaturesToTrack(_vp(s.ptr), s.step, s.w, s.h, s.type, corners.ctypes.data, quality.ctypes.data, maxCorners,
+                                      float(qualityLevel), float(minDistance), _vp(m.ptr) if m else None, m.step if m else 0,
+                                      blockSize, gradientSize, int(useHarrisDetector), float(k))
+    if n < 0:
+        _lib.check(1 if n == -1 else -1, "goodFeaturesToTrack")
+    return (corners[:n].copy(), quality[:n].copy()) if returnQuality else corners[:n].copy()

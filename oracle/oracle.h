@@ -72,6 +72,15 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
                  int depth, int cn, const float* mapx, size_t mxstep, const float* mapy, size_t mystep,
                  int interpolation, int border, const double* bv);
 
+/* corners / pyramids, see oracle/corner.c */
+int orc_cornerResponse(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int sdepth,
+                       int blockSize, int ksize, double k, int border, int harris);
+int orc_pyrDown(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                int mL, int mT, int mR, int mB, int border);
+int orc_goodFeaturesToTrack(const uint8_t* src, size_t sstep, int w, int h, int sdepth, float* corners, int maxCorners,
+                            double qualityLevel, double minDistance, const uint8_t* mask, size_t mstep,
+                            int blockSize, int gradientSize, int useHarris, double k);
+
 #ifdef __cplusplus
 }
 #endif

