@@ -244,6 +244,22 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const mi355cv_uchar* src_data, size_
         float* corners, float* quality, int maxCorners, double qualityLevel, double minDistance,
         const mi355cv_uchar* mask_data, size_t mask_step, int blockSize, int gradientSize, int useHarrisDetector, double harrisK);
 
+/* --------------------------------------------------- a13: template matching */
+
+/* cv::matchTemplate (templmatch.cpp:1158) has no HAL hook.  type CV_8UC1..C4 / CV_32FC1..C4, result CV_32FC1
+ * (img_width - templ_width + 1) x (img_height - templ_height + 1), method = cv::TemplateMatchModes 0..5. */
+MI355CV_API int mi355cv_matchTemplate(const mi355cv_uchar* img_data, size_t img_step, int img_width, int img_height,
+        const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
+        mi355cv_uchar* result_data, size_t result_step, int method);
+/* frames x one shared template (frames shard, the template is replicated) */
+MI355CV_API int mi355cv_matchTemplateBatch(const mi355cv_uchar* img_data, size_t img_step, size_t img_frame_stride, int nframes,
+        int img_width, int img_height, const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height,
+        int type, mi355cv_uchar* result_data, size_t result_step, size_t result_frame_stride, int method);
+/* replaces hal_ni_integral (hal_replacement.hpp:977; caller sumpixels.dispatch.cpp:415): CV_64F sum / sqsum of 8U or 32F */
+MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355cv_uchar* src_data, size_t src_step,
+        mi355cv_uchar* sum_data, size_t sum_step, mi355cv_uchar* sqsum_data, size_t sqsum_step,
+        mi355cv_uchar* tilted_data, size_t tilted_step, int width, int height, int cn);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,9 @@
 #define cv_hal_pyrdown mi355cv_pyrdown
 #undef  cv_hal_pyrdown_offset
 #define cv_hal_pyrdown_offset mi355cv_pyrdown_offset
+// hal_replacement.hpp:977 / sumpixels.dispatch.cpp:415
+#undef  cv_hal_integral
+#define cv_hal_integral mi355cv_integral
 // hal_replacement.hpp:442 / caller color_rgb.dispatch.cpp:276
 #undef  cv_hal_cvtBGRtoGray
 #define cv_hal_cvtBGRtoGray mi355cv_cvtBGRtoGray

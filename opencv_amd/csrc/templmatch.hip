@@ -1,0 +1,392 @@
+// templmatch.hip -- row a13 of SURVEY.md §8: cv::matchTemplate (+ cv::integral).
+//
+// Reference: cv::matchTemplate templmatch.cpp:1158-1194 = crossCorr (:566-760, block-wise float FFT correlation)
+// followed by common_matchTemplate (:906-1029, double integral images + per-method normalisation and clamping).
+// Here the correlation is evaluated EXACTLY instead of through FFTs:
+//   * CV_8UC1, template up to 128x128 (BASELINE config 5): a Toeplitz-expanded-template GEMM on the matrix cores,
+//     v_mfma_i32_32x32x32_i8.  For template row r and a strip of 32 outputs, out[y, x0+n] = sum_k I[y+r, x0+k] *
+//     T[r, k-n]: A = image rows (M = output rows), B[k][n] = T[r][k-n] is generated on chip from the LDS-resident
+//     template (16 KB) by unaligned reads, K = 32-byte steps along the row.  Pixels are biased to signed
+//     (p - 128) so they fit i8; the bias is undone exactly with the window sums the normaliser needs anyway:
+//     sum I*T = acc + 128*sum_window(I) + 128*sum(T) - 128^2*tw*th.  int32 accumulation is exact (|acc| < 2^31).
+//     8-bit inputs on the i8 path run at twice the bf16 MFMA rate named in BASELINE.json and give the integer-exact
+//     correlation (a bf16 GEMM of the same operands differs only by fp32 accumulation rounding).
+//   * everything else (CV_32F, multi-channel, bigger templates): a direct kernel, exact integers for 8U, double for 32F.
+// The post-processing restates common_matchTemplate on window sums from GPU-built integral images (double).
+#include "rt.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D32S = MI355CV_32S, D32F = MI355CV_32F, D64F = MI355CV_64F };
+
+// ---------------------------------------------------------------------------------- integral images
+// sum/sqsum are (H+1) x (W+1) x cn doubles, first row/column zero (cv::integral layout, sumpixels.simd.hpp).
+__global__ __launch_bounds__(256) void k_integral_rows(const uchar* __restrict__ src, size_t sstep, size_t sframe, int W, int H, int cn, int depth,
+                                                       double* __restrict__ sum, double* __restrict__ sq, size_t istep /*doubles*/, size_t iframe)
+{
+    const int y = blockIdx.x, c = blockIdx.y;
+    src += (size_t)blockIdx.z * sframe; sum += (size_t)blockIdx.z * iframe; if (sq) sq += (size_t)blockIdx.z * iframe;
+    const uchar* row = src + (size_t)y * sstep;
+    const int chunk = (W + 255) / 256;
+    const int x0 = threadIdx.x * chunk, x1 = min(W, x0 + chunk);
+    double s = 0, q = 0;
+    for (int x = x0; x < x1; x++) {
+        const double v = depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c];
+        s += v; q += v * v;
+    }
+    __shared__ double ss[256], qq[256];
+    ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele inclusive scan over the 256 chunk totals
+        double a = 0, b = 0;
+        if ((int)threadIdx.x >= o) { a = ss[threadIdx.x - o]; b = qq[threadIdx.x - o]; }
+        __syncthreads();
+        ss[threadIdx.x] += a; qq[threadIdx.x] += b;
+        __syncthreads();
+    }
+    double ps = threadIdx.x ? ss[threadIdx.x - 1] : 0.0, pq = threadIdx.x ? qq[threadIdx.x - 1] : 0.0;
+    double* srow = sum + (size_t)(y + 1) * istep;
+    double* qrow = sq ? sq + (size_t)(y + 1) * istep : nullptr;
+    if (threadIdx.x == 0) { srow[c] = 0; if (qrow) qrow[c] = 0; }
+    for (int x = x0; x < x1; x++) {
+        const double v = depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c];
+        ps += v; pq += v * v;
+        srow[(x + 1) * cn + c] = ps;
+        if (qrow) qrow[(x + 1) * cn + c] = pq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_integral_cols(double* __restrict__ sum, double* __restrict__ sq, size_t istep, size_t iframe, int Wc /* (W+1)*cn */, int H)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= Wc) return;
+    sum += (size_t)blockIdx.z * iframe; if (sq) sq += (size_t)blockIdx.z * iframe;
+    double s = 0, q = 0;
+    sum[x] = 0; if (sq) sq[x] = 0;
+    for (int y = 1; y <= H; y++) {
+        s += sum[(size_t)y * istep + x]; sum[(size_t)y * istep + x] = s;
+        if (sq) { q += sq[(size_t)y * istep + x]; sq[(size_t)y * istep + x] = q; }
+    }
+}
+
+// ---------------------------------------------------------------------------------- direct correlation (general path)
+__global__ __launch_bounds__(256) void k_ccorr_direct(const uchar* __restrict__ img, size_t istep, size_t iframe, const uchar* __restrict__ tpl, size_t tstep,
+                                                      int tw, int th, int cn, int depth, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= rw || y >= rh) return;
+    img += (size_t)blockIdx.z * iframe;
+    float* rrow = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep);
+    const int n = tw * cn;
+    if (depth == D8U) {
+        long long acc = 0;
+        for (int r = 0; r < th; r++) {
+            const uchar* ir = img + (size_t)(y + r) * istep + (size_t)x * cn;
+            const uchar* tr = tpl + (size_t)r * tstep;
+            int a = 0;                                                   // one row: n * 255^2 < 2^31 for n <= 33025
+            for (int j = 0; j < n; j++) a += (int)ir[j] * (int)tr[j];
+            acc += a;
+        }
+        rrow[x] = (float)(double)acc;
+    } else {
+        double acc = 0;
+        for (int r = 0; r < th; r++) {
+            const float* ir = reinterpret_cast<const float*>(img + (size_t)(y + r) * istep) + (size_t)x * cn;
+            const float* tr = reinterpret_cast<const float*>(tpl + (size_t)r * tstep);
+            for (int j = 0; j < n; j++) acc += (double)ir[j] * (double)tr[j];
+        }
+        rrow[x] = (float)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------- MFMA correlation (8UC1, tw,th <= 128)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MT_BM = 256, MT_BN = 128;        // outputs per workgroup: 4 waves x (2 M-tiles x 4 N-tiles) of 32x32
+constexpr int MT_PPITCH = 272;                 // LDS image patch pitch: 256 columns + 16 so that consecutive rows rotate the 16-B slot
+constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero bytes + 128 + 40 zero bytes
+
+__global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
+                                                       const uchar* __restrict__ tpl, size_t tstep, int tw, int th,
+                                                       const double* __restrict__ isum, size_t sumstep, size_t sumframe, long long tplSum,
+                                                       float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar smem[];
+    uchar* P = smem;                                             // (MT_BM + th - 1) x MT_PPITCH signed pixels
+    const int prow = MT_BM + th - 1;
+    uchar* T = smem + (size_t)prow * MT_PPITCH;                  // th x MT_TPITCH signed taps, zero padded
+    img += (size_t)blockIdx.z * iframe;
+    isum += (size_t)blockIdx.z * sumframe;
+    const int X0 = blockIdx.x * MT_BN, Y0 = blockIdx.y * MT_BM;
+    const int tid = threadIdx.x;
+    // ---- stage: image patch as (p - 128), zero outside the image
+    for (int i = tid; i < prow * (256 / 16); i += 256) {
+        const int ry = i >> 4, cb = i & 15;
+        const int yy = Y0 + ry, xx = X0 + cb * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yy < ih) {
+            const uchar* g = img + (size_t)yy * istep + xx;
+            if (xx + 16 <= iw && ((((uintptr_t)g) & 15) == 0)) {
+                v = *reinterpret_cast<const uint4*>(g);
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+            } else {
+                unsigned w[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16; b++) if (xx + b < iw) w[b >> 2] |= (unsigned)(g[b] ^ 0x80) << (8 * (b & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        *reinterpret_cast<uint4*>(P + (size_t)ry * MT_PPITCH + cb * 16) = v;
+    }
+    // ---- stage: template as (t - 128) with 32 zero bytes in front and zeros behind
+    for (int i = tid; i < th * (MT_TPITCH / 4); i += 256) {
+        const int r = i / (MT_TPITCH / 4), d = i - r * (MT_TPITCH / 4);
+        unsigned w = 0;
+        for (int b = 0; b < 4; b++) {
+            const int j = d * 4 + b - 32;
+            if (j >= 0 && j < tw) w |= (unsigned)(tpl[(size_t)r * tstep + j] ^ 0x80) << (8 * b);
+        }
+        reinterpret_cast<unsigned*>(T + (size_t)r * MT_TPITCH)[d] = w;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 31, h = lane >> 5;
+    const int KS = (tw + 31 + 31) / 32;                          // 32-byte K steps covering tw + 31 columns (<= 5)
+    // B operand addressing: lane (n = m, half h), step ks reads template bytes [32ks + 16h - n, +16) -> LDS offset + 32
+    int bOff[5], bSh[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) { const int o = 32 + 32 * ks + 16 * h - m; bOff[ks] = o & ~3; bSh[ks] = o & 3; }
+    v16i acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0;
+
+    const uchar* Pw = P + (size_t)(wave * 64 + m) * MT_PPITCH + 16 * h;
+    for (int r = 0; r < th; r++) {
+        const uchar* Tr = T + (size_t)r * MT_TPITCH;
+        v4i B[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ks++) {
+            if (ks < KS) {
+                const unsigned* tp = reinterpret_cast<const unsigned*>(Tr + bOff[ks]);
+                const unsigned d0 = tp[0], d1 = tp[1], d2 = tp[2], d3 = tp[3], d4 = tp[4];
+                B[ks].x = (int)__builtin_amdgcn_alignbyte(d1, d0, bSh[ks]);
+                B[ks].y = (int)__builtin_amdgcn_alignbyte(d2, d1, bSh[ks]);
+                B[ks].z = (int)__builtin_amdgcn_alignbyte(d3, d2, bSh[ks]);
+                B[ks].w = (int)__builtin_amdgcn_alignbyte(d4, d3, bSh[ks]);
+            } else B[ks] = v4i{0, 0, 0, 0};
+        }
+        v4i A[2][8];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int cb = 0; cb < 8; cb++)
+                A[mt][cb] = *reinterpret_cast<const v4i*>(Pw + (size_t)(32 * mt + r) * MT_PPITCH + 32 * cb);
+#pragma unroll
+        for (int ks = 0; ks < 5; ks++) {
+            if (ks < KS) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[mt][nt + ks], B[ks], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: undo the bias with the window sums, store float(corr)
+    const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int x = X0 + 32 * nt + m;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int y = Y0 + wave * 64 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (x < rw && y < rh) {
+                    const double* s0 = isum + (size_t)y * sumstep + x;
+                    const double* s1 = isum + (size_t)(y + th) * sumstep + x;
+                    const double wsum = s0[0] - s0[tw] - s1[0] + s1[tw];
+                    const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)wsum + cst;
+                    reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep)[x] = (float)(double)corr;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------- common_matchTemplate
+struct NormArgs { int method, cn, tw, th, rw, rh, allOne; double tmean[4], templNorm, templSum2, invArea; };
+
+__global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, size_t rstep, size_t rframe,
+                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, NormArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.rw || y >= a.rh) return;
+    float* rrow = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep);
+    if (a.allOne) { rrow[x] = 1.f; return; }
+    sum += (size_t)blockIdx.z * iframe; sq += (size_t)blockIdx.z * iframe;
+    const int numType = (a.method == 2 || a.method == 3) ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
+    const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
+    const int cn = a.cn;
+    const size_t i0 = (size_t)y * istep + (size_t)x * cn, i1 = i0 + (size_t)a.tw * cn, i2 = (size_t)(y + a.th) * istep + (size_t)x * cn, i3 = i2 + (size_t)a.tw * cn;
+    double num = rrow[x], t;
+    double wndMean2 = 0, wndSum2 = 0;
+    if (numType == 1) {
+        for (int k = 0; k < cn; k++) { t = sum[i0 + k] - sum[i1 + k] - sum[i2 + k] + sum[i3 + k]; wndMean2 += t * t; num -= t * a.tmean[k]; }
+        wndMean2 *= a.invArea;
+    }
+    if (isNormed || numType == 2) {
+        for (int k = 0; k < cn; k++) { t = sq[i0 + k] - sq[i1 + k] - sq[i2 + k] + sq[i3 + k]; wndSum2 += t; }
+        if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
+    }
+    if (isNormed) {
+        double diff2 = wndSum2 - wndMean2; diff2 = diff2 > 0 ? diff2 : 0;
+        double lim = 10 * 1.1920928955078125e-7 * wndSum2; lim = lim > 0.5 ? 0.5 : lim;
+        t = diff2 <= lim ? 0 : sqrt(diff2) * a.templNorm;
+        if (fabs(num) < t) num /= t;
+        else if (fabs(num) < t * 1.125) num = num > 0 ? 1 : -1;
+        else num = a.method != 1 ? 0 : 1;
+    }
+    rrow[x] = (float)num;
+}
+
+double pxHost(const uchar* p, int depth, int idx) { return depth == D8U ? (double)p[idx] : (double)reinterpret_cast<const float*>(p)[idx]; }
+
+int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, int nframes, int iw, int ih,
+             const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method)
+{
+    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    const int depth = MI355CV_MAT_DEPTH(type), cn = MI355CV_MAT_CN(type);
+    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > 5) return MI355CV_NOT_IMPLEMENTED;
+    if (tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1) return MI355CV_NOT_IMPLEMENTED;   // the size swap of :1172-1182 is left to the caller
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    const int e = depth == D8U ? 1 : 4;
+    const int rw = iw - tw + 1, rh = ih - th + 1;
+    Stager stg; size_t dis = istep, dts, drs = rstep;
+    const uchar* di = img; uchar* dr = res;
+    if (nframes == 1) {
+        di = stg.in(img, istep, (size_t)iw * cn * e, ih, &dis);
+        dr = stg.out(res, rstep, (size_t)rw * 4, rh, &drs);
+        if (!di || !dr) return MI355CV_NOT_IMPLEMENTED;
+    } else if (!isDevicePtr(img) || !isDevicePtr(res)) return MI355CV_NOT_IMPLEMENTED;
+    // the template is tiny: bring it to the host for its statistics, and to HBM for the kernels
+    std::vector<uchar> th_host((size_t)th * tw * cn * e);
+    if (isDevicePtr(tpl)) {
+        if (hipMemcpy2D(th_host.data(), (size_t)tw * cn * e, tpl, tstep, (size_t)tw * cn * e, th, hipMemcpyDeviceToHost) != hipSuccess) return MI355CV_NOT_IMPLEMENTED;
+    } else for (int r = 0; r < th; r++) memcpy(th_host.data() + (size_t)r * tw * cn * e, tpl + (size_t)r * tstep, (size_t)tw * cn * e);
+    const uchar* dt = stg.in(th_host.data(), (size_t)tw * cn * e, (size_t)tw * cn * e, th, &dts);
+    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    // template statistics (cv::meanStdDev, templmatch.cpp:931-958)
+    NormArgs na; memset(&na, 0, sizeof na);
+    na.method = method; na.cn = cn; na.tw = tw; na.th = th; na.rw = rw; na.rh = rh;
+    const double area = (double)tw * th; na.invArea = 1. / area;
+    double tsdv[4] = {0, 0, 0, 0}; long long tplSum = 0;
+    for (int c = 0; c < cn; c++) {
+        double s = 0, q = 0;
+        for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) { double v = pxHost(th_host.data() + (size_t)y * tw * cn * e, depth, x * cn + c); s += v; q += v * v; }
+        if (depth == D8U) tplSum += (long long)s;
+        na.tmean[c] = s * na.invArea;
+        double var = q * na.invArea - na.tmean[c] * na.tmean[c];
+        tsdv[c] = std::sqrt(var > 0 ? var : 0);
+    }
+    const int numType = (method == 2 || method == 3) ? 0 : (method == 4 || method == 5) ? 1 : 2;
+    if (method != 4) {
+        na.templNorm = tsdv[0] * tsdv[0] + tsdv[1] * tsdv[1] + tsdv[2] * tsdv[2] + tsdv[3] * tsdv[3];
+        if (na.templNorm < DBL_EPSILON && method == 5) na.allOne = 1;
+        na.templSum2 = na.templNorm + na.tmean[0] * na.tmean[0] + na.tmean[1] * na.tmean[1] + na.tmean[2] * na.tmean[2] + na.tmean[3] * na.tmean[3];
+        if (numType != 1) { na.tmean[0] = na.tmean[1] = na.tmean[2] = na.tmean[3] = 0; na.templNorm = na.templSum2; }
+        na.templSum2 /= na.invArea;
+        na.templNorm = std::sqrt(na.templNorm);
+        na.templNorm /= std::sqrt(na.invArea);
+    }
+    hipStream_t st = stream();
+    // integral images: needed by every method but TM_CCORR, and by the MFMA path's bias correction
+    const bool useMfma = depth == D8U && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
+                         (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024;
+    const bool needInt = method != 2 || useMfma;
+    const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
+    const size_t iframeD = isteps * (ih + 1);
+    double* dsum = nullptr; double* dsq = nullptr;
+    if (needInt) {
+        dsum = (double*)stg.scratch(iframeD * nframes * sizeof(double));
+        dsq = (double*)stg.scratch(iframeD * nframes * sizeof(double));
+        if (!dsum || !dsq) return MI355CV_NOT_IMPLEMENTED;
+        hipLaunchKernelGGL(k_integral_rows, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, dsq, isteps, iframeD);
+        hipLaunchKernelGGL(k_integral_cols, dim3(divUp((int)isteps, 256), 1, nframes), dim3(256), 0, st, dsum, dsq, isteps, iframeD, (int)isteps, ih);
+    }
+    if (useMfma) {
+        const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
+        static bool attrSet = false;
+        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
+        dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), nframes);
+        hipLaunchKernelGGL(k_ccorr_mfma_i8, grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, dsum, isteps, iframeD, tplSum,
+                           reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
+    } else {
+        dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
+        hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
+    }
+    if (method != 2) {
+        dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
+        hipLaunchKernelGGL(k_tm_normalize, grid, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, na);
+    }
+    return stg.finish(entry);
+}
+
+} // namespace
+
+extern "C" {
+
+// cv::matchTemplate (templmatch.cpp:1158) has no HAL hook: same argument meaning, raw pointers.  result is CV_32FC1 of
+// size (iw - tw + 1) x (ih - th + 1).  method = cv::TemplateMatchModes (imgproc.hpp:3844).
+MI355CV_API int mi355cv_matchTemplate(const uchar* img_data, size_t img_step, int img_width, int img_height,
+                                      const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
+                                      uchar* result_data, size_t result_step, int method)
+{
+    return runMatch("matchTemplate", img_data, img_step, 0, 1, img_width, img_height, templ_data, templ_step, templ_width, templ_height, type,
+                    result_data, result_step, 0, method);
+}
+
+MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_step, size_t img_frame_stride, int nframes, int img_width, int img_height,
+                                           const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
+                                           uchar* result_data, size_t result_step, size_t result_frame_stride, int method)
+{
+    return runMatch("matchTemplateBatch", img_data, img_step, nframes == 1 ? 0 : img_frame_stride, nframes, img_width, img_height, templ_data, templ_step,
+                    templ_width, templ_height, type, result_data, result_step, nframes == 1 ? 0 : result_frame_stride, method);
+}
+
+// replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415) for the depth
+// combinations matchTemplate-style consumers use: sum and sqsum CV_64F (source 8U or 32F), no tilted sum.
+MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar* src_data, size_t src_step, uchar* sum_data, size_t sum_step,
+                                 uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
+{
+    (void)tilted_step;
+    if (disabled() || tilted_data || !sum_data) return MI355CV_NOT_IMPLEMENTED;
+    if ((depth != D8U && depth != D32F) || sdepth != D64F || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (width <= 0 || height <= 0 || (sum_step % 8) || (sqsum_data && sqsum_step != sum_step)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, d1, d2 = 0;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * (depth == D8U ? 1 : 4), height, &dss);
+    uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * 8, height + 1, &d1);
+    uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * 8, height + 1, &d2) : nullptr;
+    if (!ds || !s1 || (sqsum_data && (!s2 || d2 != d1))) return MI355CV_NOT_IMPLEMENTED;
+    const size_t istep = d1 / 8;
+    hipStream_t st = stream();
+    hipLaunchKernelGGL(k_integral_rows, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (double*)s1, (double*)s2, istep, 0);
+    hipLaunchKernelGGL(k_integral_cols, dim3(divUp((width + 1) * cn, 256), 1, 1), dim3(256), 0, st, (double*)s1, (double*)s2, istep, 0, (width + 1) * cn, height);
+    return stg.finish("integral");
+}
+
+} // extern "C"

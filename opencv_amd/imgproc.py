@@ -18,6 +18,8 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
+           "matchTemplate", "matchTemplateBatch", "integral", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
+           "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
            "filter2D", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
@@ -585,3 +587,54 @@ def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
     if n < 0:
         _lib.check(1 if n == -1 else -1, "goodFeaturesToTrack")
     return (corners[:n].copy(), quality[:n].copy()) if returnQuality else corners[:n].copy()
+
+
+# ----------------------------------------------------------------------------- template matching (a13)
+TM_SQDIFF, TM_SQDIFF_NORMED, TM_CCORR, TM_CCORR_NORMED, TM_CCOEFF, TM_CCOEFF_NORMED = range(6)
+
+
+def matchTemplate(image, templ, method, result=None):
+    """cv::matchTemplate (templmatch.cpp:1158-1194): CV_8U / CV_32F, 1..4 channels, all six methods."""
+    s, t = Img(image), Img(templ)
+    if (s.depth, s.cn) != (t.depth, t.cn):
+        raise ValueError("matchTemplate: image and template must have the same type")        # CV_Assert :1164
+    if s.w < t.w or s.h < t.h:
+        raise NotImplementedError("matchTemplate: template larger than image (the reference swaps them)")
+    out = result if result is not None else empty_like_kind(image if s.cn == 1 else image[..., 0], s.h - t.h + 1, s.w - t.w + 1, 1, CV_32F)
+    d = Img(out)
+    bind_stream(s, d)
+    rc = L.mi355cv_matchTemplate(_vp(s.ptr), s.step, s.w, s.h, _vp(t.ptr), t.step, t.w, t.h, s.type, _vp(d.ptr), d.step, method)
+    _lib.check(rc, "matchTemplate")
+    return out
+
+
+def matchTemplateBatch(frames, templ, method, result=None):
+    """[N,H,W] device frames x one template -> [N,H-h+1,W-w+1] float32."""
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    t = Img(templ)
+    out = result if result is not None else torch.empty((n, h - t.h + 1, w - t.w + 1), dtype=torch.float32, device=frames.device)
+    s0, d0 = Img(frames[0]), Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_matchTemplateBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, n, w, h, _vp(t.ptr), t.step, t.w, t.h, s0.type,
+                                      _vp(d0.ptr), d0.step, int(out.stride(0)) * 4, method)
+    _lib.check(rc, "matchTemplateBatch")
+    return out
+
+
+def integral(src, sqsum=False):
+    """cv::integral with CV_64F outputs: (H+1)x(W+1)[xC] sum (and squared sum)."""
+    s = Img(src)
+    if torch is not None and isinstance(src, torch.Tensor):
+        shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
+        sm = torch.empty(shape, dtype=torch.float64, device=src.device)
+        sq = torch.empty(shape, dtype=torch.float64, device=src.device) if sqsum else None
+    else:
+        shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
+        sm = np.empty(shape, np.float64)
+        sq = np.empty(shape, np.float64) if sqsum else None
+    a, b = Img(sm), (Img(sq) if sqsum else None)
+    bind_stream(s, a)
+    rc = L.mi355cv_integral(s.depth, 6, 6, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
+                            None, 0, s.w, s.h, s.cn)
+    _lib.check(rc, "integral")
+    return (sm, sq) if sqsum else sm

@@ -81,6 +81,10 @@ int orc_goodFeaturesToTrack(const uint8_t* src, size_t sstep, int w, int h, int 
                             double qualityLevel, double minDistance, const uint8_t* mask, size_t mstep,
                             int blockSize, int gradientSize, int useHarris, double k);
 
+/* cv::matchTemplate, see oracle/templmatch.c */
+int orc_matchTemplate(const uint8_t* img, size_t istep, int iw, int ih, const uint8_t* tpl, size_t tstep, int tw, int th,
+                      int depth, int cn, float* result, size_t rstep, int method);
+
 #ifdef __cplusplus
 }
 #endif

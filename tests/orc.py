@@ -497,3 +497,24 @@ def ref_goodFeaturesToTrack(src, maxCorners, qualityLevel, minDistance, blockSiz
                                   blockSize, gradientSize, int(useHarris), c_dbl(k))
     assert n >= 0
     return buf[:n].copy()
+
+
+# ----------------------------------------------------------------------------- matchTemplate
+def orc_matchTemplate(img, templ, method):
+    o = oracle()
+    ih, iw = img.shape[:2]
+    th, tw = templ.shape[:2]
+    res = np.empty((ih - th + 1, iw - tw + 1), np.float32)
+    rc = o.orc_matchTemplate(P(img), step(img), iw, ih, P(templ), step(templ), tw, th, _NP_DEPTH[img.dtype], cn_of(img), P(res), step(res), method)
+    assert rc == 0
+    return res
+
+
+def ref_matchTemplate(img, templ, method):
+    r = load_ref()
+    ih, iw = img.shape[:2]
+    th, tw = templ.shape[:2]
+    res = np.empty((ih - th + 1, iw - tw + 1), np.float32)
+    rc = r.ref_matchTemplate(P(img), step(img), iw, ih, P(templ), step(templ), tw, th, cvtype(img), P(res), step(res), method)
+    assert rc == 0, rc
+    return res

@@ -1,0 +1,89 @@
+"""GPU parity for row a13: cv::matchTemplate (all six methods; direct and MFMA-i8 paths) and cv::integral -- through the
+C ABI against the oracle.  Results are CV_32F: 1e-4 relative (reference's own bound vs brute force is 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def rnd(shape, dtype, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random(shape, dtype=np.float32) if dtype == np.float32 else rng.integers(0, 256, shape, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3])
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+def test_modes_direct_path(cv, orc, dtype, cn, method):
+    for (iw, ih, tw, th) in [(64, 48, 8, 8), (97, 61, 17, 9), (40, 40, 40, 40), (130, 33, 5, 30)]:
+        img = rnd((ih, iw, cn) if cn > 1 else (ih, iw), dtype, 100 + iw)
+        tpl = rnd((th, tw, cn) if cn > 1 else (th, tw), dtype, 200 + tw)
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        assert orc.rel_err(got, want) <= 1e-5, (iw, ih, tw, th)
+    img, tpl = rnd((61, 97), dtype, 1), rnd((9, 17), dtype, 2)
+    assert orc.rel_err(cv.matchTemplate(img, tpl, method), orc.orc_matchTemplate(img, tpl, method)) <= 1e-5    # host arrays
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+def test_mfma_path_8uc1(cv, orc, method):
+    """>= 4096 outputs, CV_8UC1, template <= 128x128 -> v_mfma_i32_32x32x32_i8 path; the integer correlation is exact"""
+    for (iw, ih, tw, th) in [(300, 200, 16, 16), (513, 301, 128, 128), (400, 390, 33, 77), (700, 150, 100, 5), (1000, 130, 128, 1)]:
+        img = rnd((ih, iw), np.uint8, 10 + iw)
+        tpl = rnd((th, tw), np.uint8, 20 + tw)
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        if method == 2:
+            assert np.array_equal(got, want), (iw, ih, tw, th)          # exact integers rounded to float once
+        else:
+            assert orc.rel_err(got, want) <= 1e-6, (iw, ih, tw, th)
+
+
+def test_template_found_and_batch(cv, orc):
+    img = rnd((480, 640), np.uint8, 7)
+    tpl = np.ascontiguousarray(img[100:228, 200:328])
+    r = cv.matchTemplate(dev(img), dev(tpl), cv.TM_CCORR_NORMED).cpu().numpy()
+    assert np.unravel_index(np.argmax(r), r.shape) == (100, 200) and abs(r[100, 200] - 1.0) <= 1e-6
+    frames = np.stack([img, np.roll(img, 17, axis=1), np.roll(img, 5, axis=0)])
+    rb = cv.matchTemplateBatch(dev(frames), dev(tpl), cv.TM_CCORR_NORMED).cpu().numpy()
+    assert np.array_equal(rb[0], r)
+    for f in (1, 2):
+        assert orc.rel_err(rb[f], orc.orc_matchTemplate(frames[f], tpl, 3)) <= 1e-6
+
+
+def test_config5_4k(cv, orc):
+    """BASELINE config 5: TM_CCORR_NORMED, 3840x2160 CV_8UC1 x 128x128 -> 3713x2033 CV_32F (oracle on crops)."""
+    img = rnd((2160, 3840), np.uint8, 809564)
+    tpl = rnd((128, 128), np.uint8, 1)
+    r = cv.matchTemplate(dev(img), dev(tpl), cv.TM_CCORR_NORMED)
+    assert tuple(r.shape) == (2033, 3713)
+    for (y0, x0) in [(0, 0), (1900, 3500), (1000, 2000)]:
+        crop = np.ascontiguousarray(img[y0:y0 + 128 + 40, x0:x0 + 128 + 60])
+        want = orc.orc_matchTemplate(crop, tpl, 3)
+        got = r[y0:y0 + 41, x0:x0 + 61].cpu().numpy()
+        assert orc.rel_err(got, want) <= 1e-6
+
+
+def test_integral(cv, orc):
+    for dtype in (np.uint8, np.float32):
+        for cn in (1, 3):
+            src = rnd((37, 53, cn) if cn > 1 else (37, 53), dtype, 3)
+            s, q = cv.integral(dev(src), sqsum=True)
+            a = src.astype(np.float64)
+            ws = np.zeros((38, 54) + a.shape[2:]); wq = np.zeros_like(ws)
+            ws[1:, 1:] = a.cumsum(0).cumsum(1); wq[1:, 1:] = (a * a).cumsum(0).cumsum(1)
+            assert np.allclose(s.cpu().numpy(), ws, rtol=1e-13, atol=0) and np.allclose(q.cpu().numpy(), wq, rtol=1e-13, atol=0)
+            if dtype == np.uint8:
+                assert np.array_equal(s.cpu().numpy(), ws)
