@@ -57,6 +57,33 @@ def load_ref():
     return _ref
 
 
+_ref_hal = False
+
+
+def load_ref_hal():
+    """the reference built WITH include/mi355cv_hal.hpp registered as its custom HAL (oracle/ref/Makefile `hal`)"""
+    global _ref_hal
+    if _ref_hal is False:
+        p = os.path.join(ORACLE_DIR, "_ref", "libocvref_hal.so")
+        _ref_hal = ctypes.CDLL(p) if os.path.exists(p) else None
+    return _ref_hal
+
+
+class use_ref:
+    """context manager: route the ref_* helpers of this module to another build of the reference"""
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _ref
+        self.old = _ref
+        _ref = self.lib
+
+    def __exit__(self, *a):
+        global _ref
+        _ref = self.old
+
+
 def P(a):
     return vp(a.ctypes.data)
 

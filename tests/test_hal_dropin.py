@@ -1,0 +1,84 @@
+"""Drop-in boundary: the reference itself, rebuilt with include/mi355cv_hal.hpp registered as its custom HAL
+(oracle/_ref/libocvref_hal.so, recipe oracle/ref/Makefile `hal`), calls into libmi355cv.so from its own CALL_HAL sites.
+
+ * CPU (here): no GPU -> every hook answers CV_HAL_ERROR_NOT_IMPLEMENTED and the stock CPU path runs: results identical
+   to the plain build (this is exactly what the reference's samples/hal/c_hal exists to exercise).
+ * GPU (-m gpu): the same cv:: calls are served by the MI355X kernels; results identical for integer images, 1e-4 for
+   CV_32F; the library's call counters prove the GPU path ran.
+"""
+import numpy as np
+import pytest
+
+import orc as O
+
+
+def _calls(o, src8, src8c3, srcf):
+    """a tour of the hot path through the cv:: API of whatever build is active"""
+    out = {}
+    out["gauss5"] = o.ref_GaussianBlur(src8c3, 5, 0, 0, 4)
+    out["gauss3"] = o.ref_GaussianBlur(src8, 3, 0, 0, 1)
+    out["filter2d"] = o.ref_filter2D(src8, -1, np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32))
+    out["sep"] = o.ref_sepFilter2D(src8c3, -1, [0.25, 0.5, 0.25], [0.25, 0.5, 0.25])
+    out["sobel16s"] = o.ref_Sobel(src8, 3, 1, 0, 3)
+    out["sobel32f"] = o.ref_Sobel(srcf, -1, 0, 1, 5)
+    out["box"] = o.ref_boxFilter(src8c3, -1, (5, 5))
+    out["gray"] = o.ref_cvtColor(src8c3, 6, 1)
+    out["resize"] = o.ref_resize(src8c3, (100, 70))
+    out["resize_f"] = o.ref_resize(srcf, (150, 110))
+    M = o.ref_getRotationMatrix2D((64, 48), 7.0, 0.95)
+    out["warp"] = o.ref_warpAffine(src8c3, M, (128, 96), 1 | 16, 0, 0.0)
+    out["warp_f"] = o.ref_warpAffine(srcf, M, (128, 96), 1 | 16, 1, 0.0)
+    P3 = np.array([[1.1, 0.05, -3.0], [0.02, 0.9, 4.0], [1e-4, -2e-4, 1.0]])
+    out["persp"] = o.ref_warpPerspective(src8, P3, (128, 96), 1 | 16, 0, 0.0)
+    out["pyr"] = o.ref_pyrDown(src8c3)
+    out["harris"] = o.ref_cornerHarris(src8, 2, 3, 0.04)
+    out["mt"] = o.ref_matchTemplate(src8, np.ascontiguousarray(src8[10:26, 20:52]), 3)
+    return out
+
+
+def _inputs():
+    src8 = O.ref_rng_fill((96, 128), np.uint8, 1, 0, 256)
+    src8 = O.ref_GaussianBlur(src8, 5, 0, 0, 4)           # some structure for Harris
+    src8c3 = O.ref_rng_fill((96, 128, 3), np.uint8, 2, 0, 256)
+    srcf = O.ref_rng_fill((96, 128), np.float32, 3, 0, 1)
+    return src8, src8c3, srcf
+
+
+def _compare(a, b):
+    for k in a:
+        if a[k].dtype == np.float32:
+            assert O.rel_err(a[k], b[k]) <= 1e-4, k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_fallback_intact_without_gpu(ref):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see test_reference_runs_on_the_gpu")
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    src8, src8c3, srcf = _inputs()
+    plain = _calls(O, src8, src8c3, srcf)
+    with O.use_ref(hal):
+        through = _calls(O, src8, src8c3, srcf)
+    for k in plain:
+        assert np.array_equal(plain[k], through[k]), k
+
+
+@pytest.mark.gpu
+def test_reference_runs_on_the_gpu(ref):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None, "oracle/_ref/libocvref_hal.so missing"
+    src8, src8c3, srcf = _inputs()
+    plain = _calls(O, src8, src8c3, srcf)
+    names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
+             "warpPerspective", "pyrdown", "integral"]
+    before = {n: cv.call_count(n) for n in names}
+    with O.use_ref(hal):
+        through = _calls(O, src8, src8c3, srcf)
+    _compare(plain, through)
+    for n in names:
+        assert cv.call_count(n) > before[n], f"cv_hal_{n} was not served by the GPU"
