@@ -1,0 +1,84 @@
+"""Batch sharding across the GPUs of one node.
+
+Frames are independent units: a batch of B frames is split by index, one process per GPU (launched by
+`torch.distributed.run`), no collective on the data path.  The only collective is a broadcast of the shared, tiny
+parameters (filter taps, warp matrices, the template) from rank 0 at plan time -- RCCL over xGMI on GPUs, gloo on CPU.
+"""
+import os
+
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def world():
+    """(rank, world_size, local_rank) from the torchrun environment (single process when absent)"""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def frame_range(nframes, rank, world_size):
+    """frames [lo, hi) owned by `rank`: contiguous blocks, sizes differ by at most one (SURVEY.md §8e partitioning)"""
+    base, rem = divmod(nframes, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init(backend=None):
+    """initialise torch.distributed when launched with WORLD_SIZE > 1 (nccl == RCCL on ROCm, gloo on CPU)"""
+    rank, ws, local = world()
+    if ws == 1 or dist is None:
+        return rank, ws, local
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def broadcast_params(arr, src=0, device=None):
+    """plan-time broadcast of a small numpy parameter block from `src` to every rank; returns the array"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(arr)
+    rank = dist.get_rank()
+    a = np.ascontiguousarray(arr)
+    meta = torch.tensor([a.ndim] + list(a.shape) + [0] * (8 - a.ndim - 1) if rank == src else [0] * 8, dtype=torch.int64)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    meta = meta.to(dev)
+    dist.broadcast(meta, src)
+    nd = int(meta[0]); shape = [int(v) for v in meta[1:1 + nd]]
+    buf = torch.from_numpy(a.astype(np.float64)).to(dev) if rank == src else torch.empty(shape, dtype=torch.float64, device=dev)
+    dist.broadcast(buf, src)
+    return buf.cpu().numpy()
+
+
+def barrier():
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX-reduce one float over ranks (the timing reduction of bench.py)"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def gather_counts(n, device=None):
+    """SUM-reduce an integer (frames processed) over ranks"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(n)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t[0])

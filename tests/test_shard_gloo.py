@@ -1,0 +1,70 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the frame sharding, the plan-time parameter broadcast and the
+barrier + MAX timing reduction that bench.py uses on GPUs over RCCL."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frame_range_partitions_exactly():
+    from opencv_amd import shard
+    for n in (1, 7, 8, 255, 256, 257):
+        for ws in (1, 2, 3, 4, 8):
+            covered = []
+            for r in range(ws):
+                lo, hi = shard.frame_range(n, r, ws)
+                assert 0 <= lo <= hi <= n
+                covered += list(range(lo, hi))
+            assert covered == list(range(n))
+            sizes = [shard.frame_range(n, r, ws)[1] - shard.frame_range(n, r, ws)[0] for r in range(ws)]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard.frame_range(256, 3, 8) == (96, 128)       # config 4: 256 frames -> 32 per GPU
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, 'tests'))
+    from opencv_amd import shard
+    import orc
+    rank, ws, local = shard.init('gloo')
+    assert ws == 2
+    # plan time: rank 0 owns the filter definition
+    taps = shard.broadcast_params(np.array([16, 64, 96, 64, 16], np.float64) if rank == 0 else np.zeros(1))
+    assert taps.tolist() == [16, 64, 96, 64, 16]
+    M = shard.broadcast_params(np.arange(6, dtype=np.float64).reshape(2, 3) * 0.5 if rank == 0 else np.zeros(1))
+    assert M.shape == (2, 3) and M[1, 2] == 2.5
+    # data path: frames sharded by index, no collective; the CPU checker stands in for the GPU kernel here
+    B = 7
+    lo, hi = shard.frame_range(B, rank, ws)
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (B, 24, 32), dtype=np.uint8)          # same seed on every rank
+    mine = [orc.orc_sepSmoothFixedU8(frames[f], taps.astype(np.uint16), taps.astype(np.uint16), 4) for f in range(lo, hi)]
+    shard.barrier()
+    t = shard.max_over_ranks(1.0 + rank)
+    total = shard.gather_counts(hi - lo)
+    assert t == 2.0 and total == B
+    np.save(os.path.join(%r, f'shard_out_{rank}.npy'), np.stack(mine))
+    print(json.dumps({'rank': rank, 'range': [lo, hi]}))
+""")
+
+
+def test_two_process_gloo_sharding(tmp_path, orc):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, ROOT, str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    parts = [np.load(tmp_path / f"shard_out_{r}.npy") for r in range(2)]
+    got = np.concatenate(parts)
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (7, 24, 32), dtype=np.uint8)
+    want = np.stack([orc.orc_gaussianBlurBinomialU8(f, 5, 4) for f in frames])
+    assert got.shape == want.shape and np.array_equal(got, want)
