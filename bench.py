@@ -72,8 +72,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "128")),
                     help="4K frames per GPU per step (in+out = 2 x 8.29 MB x batch, far beyond the 256 MB LLC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +162,7 @@ def main():
             "per_gpu_mpix_s": round(value / world, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_binomial_roll2<5,1,nt-store>", "avg_launch_ms": round(kern_ms, 4),
+                         "kernel": "k_binomial_roll2<5,1,true,false,4>", "avg_launch_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PIXEL * pix_per_step)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -351,16 +351,25 @@ template <int KS, int CN, bool NT, bool NTL, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
     const uchar* __restrict__ src, size_t sstep, size_t sframe,
     uchar* __restrict__ dst, size_t dstep, size_t dframe,
-    int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border)
+    int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt)
 {
     constexpr int R = KS / 2, HD = RollCfg<KS, CN>::HD, HB = RollCfg<KS, CN>::HB;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int strip = wid % nstrips;
     const int t0 = wid / nstrips;
-    const int seg = t0 % nseg;
+    int seg = t0 % nseg;
     const int frame = t0 / nseg;
     if (frame >= nframes) return;
+    // alt: vertically adjacent segments are walked in opposite directions (even: down, odd: up) so that the R rows two
+    // neighbours share are touched by both at the same moment (both start there, or both end there), and the two
+    // neighbours are placed 8 work-item groups apart = on the same XCD (same L2) under the round-robin block placement.
+    int up = 0;
+    if (alt) {
+        const int g = seg >> 4, j = seg & 15;
+        if ((g << 4) + 16 <= nseg) seg = (g << 4) + 2 * (j & 7) + (j >> 3);
+        up = seg & 1;
+    }
     const int c = strip * 64 + lane;
     const int y0 = seg * segRows;
     const int y1 = min(H, y0 + segRows);
@@ -401,22 +410,24 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
             selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - 16 * (nchunks - 1));
         }
     }
-    // rows: everything outside [0,H) is resolved here, the loop only selects
-    int rowBelow[R];
+    // rows: everything outside [0,H) is resolved here, the loop only selects.  Logical row j of the segment (in walking
+    // order) is image row gy(j); the kernel is symmetric, so walking up needs no other change.
+    int rowBelow[R], rowAbove[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) rowBelow[i] = mi355_borderInterpolate(H + i, H, border);
-    auto rowIdx = [&](int yy) -> int {                         // yy >= 0
-        int ry = yy;
+    for (int i = 0; i < R; i++) { rowBelow[i] = mi355_borderInterpolate(H + i, H, border); rowAbove[i] = mi355_borderInterpolate(-1 - i, H, border); }
+    const int nrows = y1 - y0;
+    auto gy = [&](int j) -> int { return up ? y1 - 1 - j : y0 + j; };
+    auto rowIdx = [&](int g) -> int {                          // g in [-R, H+R)
+        int ry = g;
 #pragma unroll
-        for (int i = 0; i < R; i++) ry = (yy == H + i) ? rowBelow[i] : ry;
+        for (int i = 0; i < R; i++) { ry = (g == H + i) ? rowBelow[i] : ry; ry = (g == -1 - i) ? rowAbove[i] : ry; }
         return ry;
     };
 
     uint32_t Hw[KS][8];
 #pragma unroll
-    for (int i = 0; i < KS - 1; i++) {      // prologue: rows y0-R .. y0+R-1 -> slots 0..KS-2
-        const int yy = y0 - R + i;
-        const int ry = (unsigned)yy < (unsigned)H ? yy : mi355_borderInterpolate(yy, H, border);
+    for (int i = 0; i < KS - 1; i++) {      // prologue: logical rows -R .. R-1 -> slots 0..KS-2
+        const int ry = rowIdx(gy(min(i - R, nrows - 1 + R)));
         if (ry < 0) {
 #pragma unroll
             for (int j = 0; j < 8; j++) Hw[i][j] = 0;
@@ -429,16 +440,15 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
     RawRow2<HD> raw[KS];
     int rvalid[KS];
 #pragma unroll
-    for (int u = 0; u < KS; u++) {          // prime the ring: rows y0+R+u
-        const int yy = min(y0 + u + R, H + R - 1);
-        const int ry = rowIdx(yy);
+    for (int u = 0; u < KS; u++) {          // prime the ring: logical rows R+u
+        const int ry = rowIdx(gy(min(u + R, nrows - 1 + R)));
         rvalid[u] = ry >= 0;
         issueRow<KS, CN, NTL>(raw[u], src + (size_t)max(ry, 0) * sstep, mainOff, sideOff);
     }
-    for (int y = y0; y < y1; y += KS) {
+    for (int y = 0; y < nrows; y += KS) {
 #pragma unroll
         for (int u = 0; u < KS; u++) {
-            if (y + u < y1) {
+            if (y + u < nrows) {
                 uint32_t (&Hn)[8] = Hw[(KS - 1 + u) % KS];
                 if (rvalid[u]) hfilter2<KS, CN>(Hn, raw[u], hasFirst, hasLast, isLastChunk, es);
                 else {
@@ -446,8 +456,7 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
                     for (int j = 0; j < 8; j++) Hn[j] = 0;
                 }
                 {   // refill this ring slot with the row needed KS iterations from now (clamped: always a legal address)
-                    const int yy = min(y + u + KS + R, H + R - 1);
-                    const int ry = rowIdx(yy);
+                    const int ry = rowIdx(gy(min(y + u + KS + R, nrows - 1 + R)));
                     rvalid[u] = ry >= 0;
                     issueRow<KS, CN, NTL>(raw[u], src + (size_t)max(ry, 0) * sstep, mainOff, sideOff);
                 }
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
                 if (active) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     u32x4 ov = {o[0], o[1], o[2], o[3]};
-                    u32x4* dp = reinterpret_cast<u32x4*>(dst + (size_t)(y + u) * dstep + 16 * (size_t)c);
+                    u32x4* dp = reinterpret_cast<u32x4*>(dst + (size_t)gy(y + u) * dstep + 16 * (size_t)c);
                     if constexpr (NT) __builtin_nontemporal_store(ov, dp);
                     else *dp = ov;
                 }
@@ -536,6 +545,8 @@ int envInt(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v)
 int& tuneSeg() { static int v = envInt("MI355CV_GAUSS_SEG", 0); return v; }
 int& tuneVariant() { static int v = envInt("MI355CV_GAUSS_VARIANT", 3); return v; }   // 1: k_binomial_roll, 2: roll2, 3: roll2 + nt stores, 4: + nt loads
 
+int& tuneAlt() { static int v = envInt("MI355CV_GAUSS_ALT", 1); return v; }   // 1: alternate walking direction of vertical neighbours
+
 template <int KS, int CN>
 void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nframes, int W, int H, int border, hipStream_t st, int nt)
 {
@@ -543,24 +554,25 @@ void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size
     const int nstrips = divUp(nchunks, 64);
     int seg = tuneSeg();
     if (seg <= 0) {
-        // Short segments keep the set of rows being streamed at any instant compact (measured: 15-20 rows per
-        // work item beat 70 by 10 % on 128 x 4K frames although a 5x5 then re-reads 4/15 of its rows from
-        // L2/MALL); single frames go shorter still so that >= ~2 waves per SIMD exist at all.
+        // Short segments keep the set of rows being streamed at any instant compact.  Interleaved A/B on 128 x 4K
+        // frames (tools/ab_gauss.py, profiles/r01_ab_gauss.txt): 12 rows per work item with alternating walking
+        // direction = 71.1 % of 8 TB/s, 16 rows = 69.6 %, 20 rows = 68.1 % -- although a 5x5 then re-reads 4/12 of its
+        // rows (from L2, thanks to the pairing).  Single frames go shorter still so that >= ~2 waves per SIMD exist.
         long long per = (long long)nstrips * nframes;
         long long wantSeg = (2048 + per - 1) / per;
         seg = (int)((H + wantSeg - 1) / wantSeg);
-        if (seg > 4 * KS) seg = 4 * KS;
+        const int best = KS == 5 ? 12 : 16;
+        if (seg > best) seg = best;
         if (seg < KS) seg = KS;
     }
-    seg = divUp(seg, KS) * KS;
-    if (seg > H) seg = divUp(H, KS) * KS;
+    if (seg > H) seg = H;                       // any length works: the row loop guards its tail rows
     const int nseg = divUp(H, seg);
     const long long items = (long long)nstrips * nseg * nframes;
     dim3 grid((unsigned)((items + 3) / 4));
-    if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
-    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, true, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
-    else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
-    else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border);
+    if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
+    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, true, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
+    else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
+    else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
 }
 
 template <int KS, int CN>
@@ -720,6 +732,7 @@ MI355CV_API int mi355cv_setParam(const char* key, int value)
     if (!key) return -1;
     if (!strcmp(key, "gauss_seg")) { tuneSeg() = value; return 0; }
     if (!strcmp(key, "gauss_variant")) { tuneVariant() = value; return 0; }
+    if (!strcmp(key, "gauss_alt")) { tuneAlt() = value; return 0; }
     return -1;
 }
 

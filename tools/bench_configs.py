@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Secondary BASELINE.json configurations (2-5) on one GPU: time per call with HIP events on the launch stream, algorithmic
+bytes / flops per SURVEY.md §8d, fraction of the bounding roofline.  Prints one JSON object per configuration.
+(The headline metric lives in bench.py; this script feeds DESIGN.md and bench.py's `other_configs` field.)"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import opencv_amd as cv
+
+HBM, MFMA_BF16 = 8000.0, 2500.0        # GB/s, TFLOP/s (dense bf16; the i8 path's own peak is ~2x that)
+
+
+def timeit(fn, n=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def run(quick=False):
+    out = []
+    dev = "cuda"
+    cv.set_async(True)
+    g = torch.Generator(device=dev); g.manual_seed(809564)
+    # ---- config 2: cvtColor BGR2GRAY + filter2D 3x3 on 3840x2160 CV_8U
+    B2 = 16 if quick else 32
+    bgr = torch.randint(0, 256, (B2, 2160, 3840, 3), dtype=torch.uint8, device=dev, generator=g)
+    gray = torch.empty((B2, 2160, 3840), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: cv.cvtColorBatch(bgr, cv.COLOR_BGR2GRAY, dst=gray))
+    by = B2 * 3840 * 2160 * 4
+    out.append({"config": "cfg2a cvtColor BGR2GRAY 4K 8UC3", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
+                "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    k = np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32)
+    one = gray[0]; dst = torch.empty_like(one)
+    ms = timeit(lambda: cv.filter2D(one, -1, k, dst=dst))
+    by = 3840 * 2160 * 2
+    out.append({"config": "cfg2b filter2D 3x3 4K 8UC1 (single frame per call)", "frames": 1, "ms": round(ms, 4), "Mpix_s": round(8.2944 / ms * 1e3, 1),
+                "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    del bgr, gray
+    # ---- config 3: resize (bilinear) + warpAffine on 7680x4320 CV_32F
+    src = torch.rand((4320, 7680), dtype=torch.float32, device=dev, generator=g)
+    d1 = torch.empty((2880, 5120), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: cv.resize(src, (5120, 2880), dst=d1))
+    by = 132710400 + 58982400
+    out.append({"config": "cfg3a resize bilinear 8K->5120x2880 32F", "ms": round(ms, 4), "Mpix_s_src": round(33.1776 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    d2 = torch.empty((2160, 3840), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: cv.resize(src, (3840, 2160), dst=d2))
+    by = 132710400 + 33177600
+    out.append({"config": "cfg3b resize 8K->4K (area-fast 2x2) 32F", "ms": round(ms, 4), "Mpix_s_src": round(33.1776 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    M = cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95)
+    d3 = torch.empty_like(src)
+    ms = timeit(lambda: cv.warpAffine(src, M, (7680, 4320), dst=d3))
+    by = 265420800
+    out.append({"config": "cfg3c warpAffine bilinear 8K 32F rot 7deg", "ms": round(ms, 4), "Mpix_s": round(33.1776 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    del src, d1, d2, d3
+    # ---- config 4: cornerHarris + buildPyramid(4) on 1080p 8UC1 frames (32 per GPU = 256 / 8)
+    B4 = 32
+    fr = torch.randint(0, 256, (B4, 1080, 1920), dtype=torch.uint8, device=dev, generator=g)
+    resp = torch.empty((B4, 1080, 1920), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: cv.cornerHarrisBatch(fr, 2, 3, 0.04, dst=resp))
+    by = B4 * 10368000
+    out.append({"config": "cfg4a cornerHarris(2,3,0.04) 1080p 8UC1", "frames": B4, "ms": round(ms, 4), "frames_s": round(B4 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    ms = timeit(lambda: cv.buildPyramidBatch(fr, 4))
+    by = B4 * 3442560
+    out.append({"config": "cfg4b buildPyramid(4) 1080p 8UC1 (incl. output allocation)", "frames": B4, "ms": round(ms, 4), "frames_s": round(B4 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    del fr, resp
+    # ---- config 5: matchTemplate TM_CCORR_NORMED 4K x 128x128
+    B5 = 2 if quick else 4
+    img = torch.randint(0, 256, (B5, 2160, 3840), dtype=torch.uint8, device=dev, generator=g)
+    tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g)
+    res = torch.empty((B5, 2033, 3713), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: cv.matchTemplateBatch(img, tpl, cv.TM_CCORR_NORMED, result=res), n=5, warm=2)
+    fl = B5 * 2.4735e11
+    out.append({"config": "cfg5 matchTemplate TM_CCORR_NORMED 4K x 128x128 8UC1 (i8 MFMA + integrals + normalise)", "frames": B5, "ms": round(ms, 3),
+                "frames_s": round(B5 / ms * 1e3, 2), "bound": "mfma", "achieved_TFLOPs": round(fl / ms / 1e9, 1),
+                "frac_of_bf16_dense_peak": round(fl / ms / 1e9 / MFMA_BF16, 4)})
+    cv.set_async(False)
+    return out
+
+
+if __name__ == "__main__":
+    for r in run("--quick" in sys.argv):
+        print(json.dumps(r))

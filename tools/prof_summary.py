@@ -35,3 +35,26 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
     for k, cs in acc.items():
         for c, v in cs.items():
             print(f"{k[:60]:60s} {c:28s} n={len(v):4d} avg={sum(v)/len(v):18.1f}")
+
+# ---- HBM traffic of the headline kernel per launch, as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE come
+# from separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced
+# read stream -> doubled.  Median over dispatches (the parity-gate launches on single frames are the minority).
+import json
+import statistics
+vals = {}
+for p in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+    for r in rows(p):
+        if "k_binomial_roll2" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    f = statistics.median(vals["FETCH_SIZE"]) * 1024 * 2
+    w = statistics.median(vals["WRITE_SIZE"]) * 1024
+    j = {"kernel": "k_binomial_roll2<5,1>", "fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w),
+         "hbm_bytes_per_launch": int(f + w),
+         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 (gfx950 wide-read "
+                   "correction, MI355X_MICROARCH.md HBM section); median over the 128-frame dispatches; Infinity-Cache hits are "
+                   "included in FETCH_SIZE, so the L2-missing halo re-reads show up here even when MALL serves them"}
+    print("== traffic ==")
+    print(json.dumps(j))
+    if len(sys.argv) > 3:
+        json.dump(j, open(sys.argv[3], "w"), indent=1)

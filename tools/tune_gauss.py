@@ -55,8 +55,12 @@ for unroll in (1, 5, 10):
 
 variants = [int(v) for v in os.environ.get("VARIANTS", "1,2,3").split(",")]
 segs = [int(v) for v in os.environ.get("SEGS", "0,20,40,70,135,270,540,1080,2160").split(",")]
-for var in variants:
+alts = [int(v) for v in os.environ.get("ALTS", "0").split(",")]
+for var in [(v, a) for v in variants for a in alts]:
+    var, alt = var
     L.mi355cv_setParam(b"gauss_variant", var)
+    L.mi355cv_setParam(b"gauss_alt", alt)
+    print(f"--- alt={alt}")
     for seg in segs:
         L.mi355cv_setParam(b"gauss_seg", seg)
         cv.GaussianBlurBatch(frames, 5, dst=out)
