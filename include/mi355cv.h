@@ -151,6 +151,9 @@ MI355CV_API int mi355cv_filterInit(struct cvhalFilter2D** context, mi355cv_uchar
 MI355CV_API int mi355cv_filter(struct cvhalFilter2D* context, mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data,
         size_t dst_step, int width, int height, int full_width, int full_height, int offset_x, int offset_y);
 MI355CV_API int mi355cv_filterFree(struct cvhalFilter2D* context);
+/* batched form over device-resident whole frames, with a context from mi355cv_filterInit */
+MI355CV_API int mi355cv_filterBatch(struct cvhalFilter2D* context, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height);
 
 /* replace hal_ni_sepFilterInit / hal_ni_sepFilter / hal_ni_sepFilterFree (hal_replacement.hpp:155,171,177);
  * callers: replacementSepFilter filter.dispatch.cpp:1362-1383 (cv::sepFilter2D, and through it Sobel/Scharr/

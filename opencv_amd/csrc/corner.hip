@@ -117,20 +117,22 @@ struct CornerArgs {
     int rx, ry;                         // halo radii of the source tile
 };
 
-__device__ __forceinline__ float sepAt(const float* S, int SW, int ly, int lx, const float* kr, int nr, const float* kc, int nc, bool colAsym)
+// Separable derivative evaluation inside the tile, in the reference's association order:
+//   row pass   (RowFilter, filter.simd.hpp:2386):  r = k0*v0; r = fma(ki, vi, r)
+//   column pass (SymmColumnFilter :2679-2751):      symmetric  s = fma(kc, r_c, 0); s = fma(k_{c+j}, r_{c+j} + r_{c-j}, s)
+//                                                   antisymm.  s = 0;              s = fma(k_{c+j}, r_{c+j} - r_{c-j}, s)
+__device__ __forceinline__ float rowPass(const float* row, const float* k, int n)
 {
-    // row sums of RowFilter (s = k0*v0; s = fma(ki, vi, s)) for the nc rows, then SymmColumnFilter's pair form
-    const int cr = nr / 2, cc = nc / 2;
-    float rsum[8];
-    for (int j = 0; j < nc; j++) {
-        const float* row = S + (ly + j - cc) * SW + (lx - cr);
-        float s = kr[0] * row[0];
-        for (int i = 1; i < nr; i++) s = __builtin_fmaf(kr[i], row[i], s);
-        rsum[j] = s;
-    }
-    float s = colAsym ? 0.f : __builtin_fmaf(kc[cc], rsum[cc], 0.f);
-    for (int k = 1; k <= cc; k++)
-        s = __builtin_fmaf(kc[cc + k], colAsym ? rsum[cc + k] - rsum[cc - k] : rsum[cc + k] + rsum[cc - k], s);
+    float s = k[0] * row[0];
+    for (int i = 1; i < n; i++) s = __builtin_fmaf(k[i], row[i], s);
+    return s;
+}
+__device__ __forceinline__ float colPass(const float* col, int stride, const float* k, int n, bool asym)
+{
+    const int c = n / 2;
+    float s = asym ? 0.f : __builtin_fmaf(k[c], col[c * stride], 0.f);
+    for (int j = 1; j <= c; j++)
+        s = __builtin_fmaf(k[c + j], asym ? col[(c + j) * stride] - col[(c - j) * stride] : col[(c + j) * stride] + col[(c - j) * stride], s);
     return s;
 }
 
@@ -140,41 +142,47 @@ __global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     src += (size_t)blockIdx.z * sframe; dst += (size_t)blockIdx.z * dframe;
     const int X0 = blockIdx.x * CT_X, Y0 = blockIdx.y * CT_Y;
-    const int bx = a.bs - 1 - a.ax, by = a.bs - 1 - a.ay;
     const int PW = CT_X + a.bs - 1, PH = CT_Y + a.bs - 1;          // derivative planes: positions [X0-ax, X0+CT_X-1+bx]
-    const int SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;              // source tile: planes region +- (rx, ry)
-    float* S = lds;
-    float* Pdx = S + SW * SH;
+    const int SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;              // source tile: plane region +- (rx, ry)
+    const int rxd = a.dxNRow / 2, rxs = a.dyNRow / 2;              // radii of the two row kernels
+    float* S = lds;                                                // SH x SW   source, border-extended
+    float* Rd = S + SW * SH;                                       // SH x PW   row pass with the x-derivative taps  (for Dx)
+    float* Rs = Rd + PW * SH;                                      // SH x PW   row pass with the x-smoothing taps   (for Dy)
+    float* Pdx = Rs + PW * SH;                                     // PH x PW
     float* Pdy = Pdx + PW * PH;
-    const int tid = threadIdx.x;
-    // 1. source tile, border-extended: S(p) = src(borderInterpolate(p)); BORDER_CONSTANT contributes 0
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    // 1. source tile: S(p) = src(borderInterpolate(p)); BORDER_CONSTANT contributes 0
     const int sx0 = X0 - a.ax - a.rx, sy0 = Y0 - a.ay - a.ry;
-    for (int i = tid; i < SW * SH; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int yy = mi355_borderInterpolate(sy0 + ly, a.H, a.border);
+    for (int lx = tx; lx < SW; lx += 64) {
         const int xx = mi355_borderInterpolate(sx0 + lx, a.W, a.border);
-        float v = 0.f;
-        if (yy >= 0 && xx >= 0) {
-            const uchar* row = src + (size_t)yy * sstep;
-            v = a.sdepth == D8U ? (float)row[xx] : reinterpret_cast<const float*>(row)[xx];
+        for (int ly = ty; ly < SH; ly += 4) {
+            const int yy = mi355_borderInterpolate(sy0 + ly, a.H, a.border);
+            float v = 0.f;
+            if (yy >= 0 && xx >= 0) {
+                const uchar* row = src + (size_t)yy * sstep;
+                v = a.sdepth == D8U ? (float)row[xx] : reinterpret_cast<const float*>(row)[xx];
+            }
+            S[ly * SW + lx] = v;
         }
-        S[i] = v;
     }
     __syncthreads();
-    // 2. derivative planes at in-image positions of the plane region
-    for (int i = tid; i < PW * PH; i += 256) {
-        const int ly = i / PW, lx = i - ly * PW;
-        const int py = Y0 - a.ay + ly, px = X0 - a.ax + lx;
-        float dx = 0.f, dy = 0.f;
-        if ((unsigned)py < (unsigned)a.H && (unsigned)px < (unsigned)a.W) {
-            dx = sepAt(S, SW, ly + a.ry, lx + a.rx, a.dxRow, a.dxNRow, a.dxCol, a.dxNCol, false);   // Dx: derivative along x, smoothing (symmetric) along y
-            dy = sepAt(S, SW, ly + a.ry, lx + a.rx, a.dyRow, a.dyNRow, a.dyCol, a.dyNCol, a.dyNCol > 1);   // Dy: smoothing along x, derivative (antisymmetric) along y
+    // 2. row passes over every staged row, for the PW plane columns
+    for (int lx = tx; lx < PW; lx += 64)
+        for (int ly = ty; ly < SH; ly += 4) {
+            const float* row = S + ly * SW + lx + a.rx;
+            Rd[ly * PW + lx] = rowPass(row - rxd, a.dxRow, a.dxNRow);
+            Rs[ly * PW + lx] = rowPass(row - rxs, a.dyRow, a.dyNRow);
         }
-        Pdx[i] = dx; Pdy[i] = dy;
-    }
     __syncthreads();
-    // 3. box sums of the products (double, as RowSum<float,double>/ColumnSum<double,float>) + response
-    const int tx = tid & 63;
+    // 3. column passes -> derivative planes (only in-image positions are ever read back)
+    const int ryd = a.dxNCol / 2, rys = a.dyNCol / 2;
+    for (int lx = tx; lx < PW; lx += 64)
+        for (int ly = ty; ly < PH; ly += 4) {
+            Pdx[ly * PW + lx] = colPass(Rd + (ly + a.ry - ryd) * PW + lx, PW, a.dxCol, a.dxNCol, false);
+            Pdy[ly * PW + lx] = colPass(Rs + (ly + a.ry - rys) * PW + lx, PW, a.dyCol, a.dyNCol, a.dyNCol > 1);
+        }
+    __syncthreads();
+    // 4. box sums of the products (double, as RowSum<float,double>/ColumnSum<double,float>) + response
     const int x = X0 + tx;
     if (x >= a.W) return;
     int lxs[16];
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ 
         int q = mi355_borderInterpolate(x - a.ax + i, a.W, a.border);
         lxs[i] = q < 0 ? -1 : min(max(q - (X0 - a.ax), 0), PW - 1);
     }
-    for (int ty = tid >> 6; ty < CT_Y; ty += 4) {
-        const int y = Y0 + ty;
+    for (int oy = ty; oy < CT_Y; oy += 4) {
+        const int y = Y0 + oy;
         if (y >= a.H) break;
         double sxx = 0, sxy = 0, syy = 0;
         for (int j = 0; j < a.bs; j++) {
@@ -212,7 +220,6 @@ __global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ 
         }
         reinterpret_cast<float*>(dst + (size_t)y * dstep)[x] = r;
     }
-    (void)bx; (void)by;
 }
 
 bool derivTaps(int order, int ksize, bool scharr, std::vector<int>& k)
@@ -254,7 +261,7 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
     if (scale == 1) { /* unreachable for the depths handled; kept for symmetry with cv::Sobel */ }
     a.rx = std::max(a.dxNRow, a.dyNRow) / 2; a.ry = std::max(a.dxNCol, a.dyNCol) / 2;
     const int PW = CT_X + a.bs - 1, PH = CT_Y + a.bs - 1, SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;
-    const size_t lds = (size_t)(SW * SH + 2 * PW * PH) * sizeof(float);
+    const size_t lds = (size_t)(SW * SH + 2 * PW * SH + 2 * PW * PH) * sizeof(float);
     dim3 grid(divUp(W, CT_X), divUp(H, CT_Y), nframes);
     hipLaunchKernelGGL(k_corner_fused, grid, dim3(256), lds, st, ds, dss, sframe, dd, dds, dframe, a);
     return MI355CV_OK;

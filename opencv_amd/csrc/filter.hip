@@ -20,6 +20,7 @@
 // correct for every depth/border/anchor/ROI combination above.  The 4K 8U 3x3 configuration of BASELINE.json has
 // its own fast path (TODO next round: register-rolling 3x3).
 #include "rt.h"
+#include "roll.h"
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -84,6 +85,93 @@ __global__ __launch_bounds__(256) void k_filter2d_generic(
         }
     }
     stF(dst + (size_t)y * dstep, e, ddepth, s);
+}
+
+// ---------------------------------------------------------------------------------- filter2D, register-rolling fast path
+// CV_8U -> CV_8U, K x K taps (K = 3 or 5), centred anchor: the skeleton of roll.h with the last K source rows kept as
+// floats in registers.  Per output: s = delta; s = fma(float(p), k, s) over ALL K*K taps in raster order (a zero tap
+// leaves s unchanged bit for bit, so skipping them as the reference does changes nothing), cvRound, saturate --
+// FilterVec_8u, filter.simd.hpp:2146-2210.  HBM-bound: 2*cn bytes per pixel.
+struct DenseTaps { float k[25]; float delta; };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The float window of a row is held as pairs Q[m] = (p[m], p[m+8]) so that outputs i and i+8 of the lane advance together
+// through v_pk_fma_f32 (two FMAs per issue, tap broadcast by op_sel): the kernel would otherwise be VALU-bound at half the
+// HBM rate.  Each half keeps its own chain, so the accumulation order per pixel is still the raster order of the taps.
+template <int K, int CN, bool UP>
+__device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, uchar* __restrict__ dst, size_t dstep, const DenseTaps& t)
+{
+    constexpr int R = K / 2, HB = R * CN, HD = roll::Cfg<R, CN>::HD, NW = roll::Cfg<R, CN>::NW, NQ = 8 + 2 * HB;
+    f32x2 Q[K][NQ];
+    auto toFloat = [&](f32x2 (&q)[NQ], const roll::Raw<HD>& r, int valid) {
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < NQ; i++) q[i] = f32x2{0.f, 0.f};
+            return;
+        }
+        uint32_t X[NW];
+        cx.window(X, r);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int b0 = 4 * HD - HB + i, b1 = b0 + 8;
+            q[i].x = (float)((X[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
+            q[i].y = (float)((X[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) {                      // prologue: logical rows -R .. R-1
+        roll::Raw<HD> pre; int v;
+        cx.issue(pre, i - R, v);
+        toFloat(Q[i], pre, v);
+    }
+    roll::Raw<HD> raw[K]; int rv[K];
+#pragma unroll
+    for (int u = 0; u < K; u++) cx.issue(raw[u], u + R, rv[u]);
+    for (int y = 0; y < cx.nrows; y += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            if (y + u < cx.nrows) {
+                toFloat(Q[(K - 1 + u) % K], raw[u], rv[u]);
+                cx.issue(raw[u], y + u + K + R, rv[u]);
+                uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    f32x2 s = {t.delta, t.delta};
+#pragma unroll
+                    for (int dy = 0; dy < K; dy++) {
+                        // image row (y - R + dy) sits in slot (u + dy) when walking down, (u + K-1-dy) when walking up
+                        const f32x2* qr = Q[(u + (UP ? K - 1 - dy : dy)) % K];
+#pragma unroll
+                        for (int dx = 0; dx < K; dx++) {
+                            const float kv = t.k[dy * K + dx];
+                            s = __builtin_elementwise_fma(qr[i + dx * CN], f32x2{kv, kv}, s);
+                        }
+                    }
+                    // cvRound + saturate_cast<uchar>: round half-even, then the saturating byte conversion
+                    o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.x), i & 3, o[i >> 2]);
+                    o[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.y), i & 3, o[2 + (i >> 2)]);
+                }
+                if (cx.active) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + 16 * (size_t)cx.c));
+                }
+            }
+        }
+    }
+}
+
+template <int K, int CN>
+__global__ __launch_bounds__(256) void k_filter2d_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                       uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                       int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt, DenseTaps t)
+{
+    roll::Ctx<K / 2, K / 2, CN> cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    dst += (size_t)cx.frame * dframe;
+    if (cx.up) filterRows<K, CN, true>(cx, dst, dstep, t);
+    else       filterRows<K, CN, false>(cx, dst, dstep, t);
 }
 
 // ---------------------------------------------------------------------------------- separable
@@ -444,6 +532,48 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
     return MI355CV_OK;
 }
 
+// launches the rolling kernel when the geometry allows it; returns false otherwise
+static bool tryFilterRoll(const FilterCtx* c, const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t dds, size_t dframe, int nframes, int W, int H, hipStream_t st)
+{
+    const int K = c->kw;
+    if (c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2) return false;
+    if (!((K == 3 && (c->cn == 1 || c->cn == 3 || c->cn == 4)) || (K == 5 && c->cn == 1))) return false;
+    if (!roll::eligible(ds, dss, sframe, dd, dds, dframe, W, c->cn, K / 2, c->border)) return false;
+    DenseTaps t; memset(&t, 0, sizeof t);
+    for (const Tap2D& tp : c->taps) t.k[tp.dy * K + tp.dx] = tp.k;
+    t.delta = c->delta;
+    const roll::Geom g = roll::geometry(W, H, c->cn, nframes, K == 3 ? 16 : 12, K);
+#define FROLL(K_, CN_) hipLaunchKernelGGL((k_filter2d_roll<K_, CN_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, c->border, 1, t)
+    if (K == 3) { if (c->cn == 1) FROLL(3, 1); else if (c->cn == 3) FROLL(3, 3); else FROLL(3, 4); }
+    else FROLL(5, 1);
+#undef FROLL
+    return true;
+}
+
+// batched filter2D over device-resident frames with a context from mi355cv_filterInit (frames are whole images:
+// isolated borders)
+MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height)
+{
+    FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
+    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;
+    if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
+    if (!tryFilterRoll(c, src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, stream())) {
+        Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
+        if (!dt) return MI355CV_NOT_IMPLEMENTED;
+        const int se = depthSize(c->sdepth), de = depthSize(c->ddepth); (void)se; (void)de;
+        for (int f = 0; f < nframes; f++) {
+            dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
+            hipLaunchKernelGGL(k_filter2d_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * src_frame_stride, src_step,
+                               dst_data + (size_t)f * dst_frame_stride, dst_step, width, height, c->cn, c->sdepth, c->ddepth,
+                               width, height, 0, 0, dt, (int)c->taps.size(), c->ax, c->ay, c->kw, c->kh, c->delta, c->border);
+        }
+    }
+    return stg.finish("filterBatch");
+}
+
 MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
         int width, int height, int full_width, int full_height, int offset_x, int offset_y)
 {
@@ -459,6 +589,8 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
     if (!dtop || !dd || !dt) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)offset_y * dss + (size_t)offset_x * c->cn * se;
+    if (full_width == width && full_height == height && tryFilterRoll(c, ds, dss, 0, dd, dds, 0, 1, width, height, stream()))
+        return stg.finish("filter");
     dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_filter2d_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, c->cn, c->sdepth, c->ddepth,
                        full_width, full_height, offset_x, offset_y, dt, (int)c->taps.size(), c->ax, c->ay, c->kw, c->kh, c->delta, c->border);

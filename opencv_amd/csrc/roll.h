@@ -1,0 +1,176 @@
+// roll.h -- the register-rolling stencil skeleton shared by the HBM-bound 8-bit stencil kernels (measured design of the
+// headline Gaussian, smooth.hip k_binomial_roll2):
+//   * one WAVE = one work item: a strip of 64 16-byte chunks (1 KiB of a row) x a segment of rows x a frame, work items
+//     ordered strip -> segment -> frame so that resident waves sweep memory almost linearly;
+//   * a lane owns 16 consecutive bytes of a row (one dwordx4 load, one dwordx4 store) and walks the segment row by row,
+//     keeping the rows it still needs in registers; loads run ahead through a ring (a slot is refilled right after use);
+//   * +-RX*cn neighbour bytes: DPP wave_shr / wave_shl from the adjacent lane; the two lanes at the wave edge get theirs
+//     from one 4-byte side load per row (two 64-byte sectors per wave); image-border halos are rebuilt from the lane's own
+//     16 bytes with wave-uniform v_perm selectors; rows outside the image are resolved to scalars before the loop;
+//   * vertically adjacent segments walk in opposite directions and sit on the same XCD (alt), so the rows they share are
+//     in L2 when the second one asks.
+// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % 16 == 0, W > RX, border in {CONSTANT, REPLICATE,
+// REFLECT, REFLECT_101}.
+#pragma once
+#include "rt.h"
+
+namespace roll {
+
+template <int RX, int CN> struct Cfg {
+    static constexpr int HB = RX * CN;            // halo bytes per side
+    static constexpr int HD = (HB + 3) / 4;       // halo dwords per side
+    static constexpr int NW = 4 + 2 * HD;         // dwords of the assembled window
+};
+
+template <int HD> struct Raw { uint4 m; uint32_t side[HD]; };
+
+template <int HD> struct Edge { uint32_t la[HD], lb[HD], lc[HD], ra[HD], rb[HD], rc[HD]; };
+
+__device__ __forceinline__ void selSetByte(uint32_t& a, uint32_t& b, uint32_t& c, int j, int idx /* 0..15 or <0 */)
+{
+    const uint32_t sh = 8u * (uint32_t)j, clr = ~(0xffu << sh);
+    uint32_t va = 0x0cu, vb = 0x0cu, vc = 0x0cu;
+    if (idx >= 8)      { vb = (uint32_t)(idx - 8); vc = 4u + (uint32_t)j; }
+    else if (idx >= 0) { va = (uint32_t)idx;       vc = (uint32_t)j; }
+    a = (a & clr) | (va << sh); b = (b & clr) | (vb << sh); c = (c & clr) | (vc << sh);
+}
+
+__device__ __forceinline__ uint32_t gather16(const uint4& m, uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t t1 = __builtin_amdgcn_perm(m.y, m.x, a);
+    const uint32_t t2 = __builtin_amdgcn_perm(m.w, m.z, b);
+    return __builtin_amdgcn_perm(t2, t1, c);
+}
+
+template <int RX, int RY, int CN>
+struct Ctx {
+    static constexpr int HD = Cfg<RX, CN>::HD, HB = Cfg<RX, CN>::HB, NW = Cfg<RX, CN>::NW;
+    const uchar* src; size_t sstep;
+    int H, lane, c, nchunks, mainOff, sideOff, y0, y1, nrows, up, frame;
+    bool active, hasFirst, hasLast, isLastChunk;
+    Edge<HD> es;
+    int rowBelow[RY > 0 ? RY : 1], rowAbove[RY > 0 ? RY : 1];
+
+    // decode the work item of this wave; false when the wave has nothing to do
+    __device__ __forceinline__ bool init(const uchar* s, size_t ss, size_t sframe, int W, int H_, int nchunks_, int nstrips, int segRows, int nseg,
+                                         int nframes, int border, int alt)
+    {
+        lane = threadIdx.x & 63;
+        const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+        const int strip = wid % nstrips;
+        const int t0 = wid / nstrips;
+        int seg = t0 % nseg;
+        frame = t0 / nseg;
+        if (frame >= nframes) return false;
+        up = 0;
+        if (alt) {
+            const int g = seg >> 4, j = seg & 15;
+            if ((g << 4) + 16 <= nseg) seg = (g << 4) + 2 * (j & 7) + (j >> 3);
+            up = seg & 1;
+        }
+        H = H_; nchunks = nchunks_;
+        src = s + (size_t)frame * sframe; sstep = ss;
+        c = strip * 64 + lane;
+        y0 = seg * segRows; y1 = min(H, y0 + segRows); nrows = y1 - y0;
+        active = c < nchunks; hasFirst = strip == 0; hasLast = strip == nstrips - 1; isLastChunk = c == nchunks - 1;
+        mainOff = 16 * (active ? c : nchunks - 1);
+        const int c0 = strip * 64;
+        const int leftOff = c0 > 0 ? 16 * c0 - 4 * HD : 0;
+        const int rightOff = c0 + 64 < nchunks ? 16 * (c0 + 64) : 16 * (nchunks - 1);
+        sideOff = lane < 32 ? leftOff : rightOff;
+#pragma unroll
+        for (int d = 0; d < HD; d++) { es.la[d] = es.lb[d] = es.lc[d] = es.ra[d] = es.rb[d] = es.rc[d] = 0x0c0c0c0cu; }
+        if (hasFirst) {
+#pragma unroll
+            for (int t = 0; t < HB; t++) {
+                const int bt = t - HB;
+                const int px = (bt - (CN - 1)) / CN;               // floor(bt / CN)
+                const int sp = mi355_borderInterpolate(px, W, border);
+                const int pos = 4 * HD - HB + t;
+                selSetByte(es.la[pos >> 2], es.lb[pos >> 2], es.lc[pos >> 2], pos & 3, sp < 0 ? -1 : sp * CN + (bt - px * CN));
+            }
+        }
+        if (hasLast) {
+#pragma unroll
+            for (int t = 0; t < HB; t++) {
+                const int sp = mi355_borderInterpolate(W + t / CN, W, border);
+                selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - 16 * (nchunks - 1));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RY; i++) { rowBelow[i] = mi355_borderInterpolate(H + i, H, border); rowAbove[i] = mi355_borderInterpolate(-1 - i, H, border); }
+        return true;
+    }
+
+    // logical row j of the segment (walking order) -> image row
+    __device__ __forceinline__ int gy(int j) const { return up ? y1 - 1 - j : y0 + j; }
+    // image row g in [-RY, H+RY) -> source row index, or -1 for a BORDER_CONSTANT row
+    __device__ __forceinline__ int rowIdx(int g) const
+    {
+        int ry = g;
+#pragma unroll
+        for (int i = 0; i < RY; i++) { ry = (g == H + i) ? rowBelow[i] : ry; ry = (g == -1 - i) ? rowAbove[i] : ry; }
+        return ry;
+    }
+    // issue the loads of logical row j (clamped so that the address is always legal); valid = 0 for a constant-border row
+    __device__ __forceinline__ void issue(Raw<HD>& r, int j, int& valid) const
+    {
+        const int ry = rowIdx(gy(min(j, nrows - 1 + RY)));
+        valid = ry >= 0;
+        const uchar* row = src + (size_t)max(ry, 0) * sstep;
+        r.m = *reinterpret_cast<const uint4*>(row + mainOff);
+#pragma unroll
+        for (int d = 0; d < HD; d++) r.side[d] = *reinterpret_cast<const uint32_t*>(row + sideOff + 4 * d);
+    }
+    // the lane's window of one row as dwords: X[0..HD) left halo, X[HD..HD+4) own 16 bytes, X[HD+4..NW) right halo
+    __device__ __forceinline__ void window(uint32_t (&X)[NW], const Raw<HD>& r) const
+    {
+        const uint32_t mv[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+        uint32_t hl[HD], hr[HD], hb[HD];
+#pragma unroll
+        for (int d = 0; d < HD; d++) { hl[d] = r.side[d]; hr[d] = r.side[d]; }
+        if (hasFirst) {
+#pragma unroll
+            for (int d = 0; d < HD; d++) hl[d] = gather16(r.m, es.la[d], es.lb[d], es.lc[d]);
+        }
+        if (hasLast) {
+#pragma unroll
+            for (int d = 0; d < HD; d++) hb[d] = gather16(r.m, es.ra[d], es.rb[d], es.rc[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < HD; d++) {
+            X[d] = __builtin_amdgcn_update_dpp(hl[d], mv[4 - HD + d], 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps hl
+            uint32_t rr = __builtin_amdgcn_update_dpp(hr[d], mv[d], 0x130, 0xf, 0xf, false);       // wave_shl:1, lane 63 keeps hr
+            if (hasLast) rr = isLastChunk ? hb[d] : rr;
+            X[HD + 4 + d] = rr;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) X[HD + d] = mv[d];
+    }
+};
+
+// host side: eligibility of the rolling path and launch geometry
+inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t ds, size_t df, int W, int cn, int rx, int border)
+{
+    if ((((uintptr_t)s | ss | sf | (uintptr_t)d | ds | df) & 15) != 0) return false;
+    if ((W * cn) % 16 != 0 || W <= rx) return false;
+    return border == mi355::B_CONSTANT || border == mi355::B_REPLICATE || border == mi355::B_REFLECT || border == mi355::B_REFLECT_101;
+}
+
+struct Geom { int nchunks, nstrips, seg, nseg; unsigned blocks; };
+inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg)
+{
+    Geom g;
+    g.nchunks = W * cn / 16; g.nstrips = mi355::divUp(g.nchunks, 64);
+    long long per = (long long)g.nstrips * nframes;
+    long long wantSeg = (2048 + per - 1) / per;
+    int seg = (int)((H + wantSeg - 1) / wantSeg);
+    if (seg > bestSeg) seg = bestSeg;
+    if (seg < minSeg) seg = minSeg;
+    if (seg > H) seg = H;
+    g.seg = seg; g.nseg = mi355::divUp(H, seg);
+    g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4);
+    return g;
+}
+
+} // namespace roll

@@ -75,6 +75,61 @@ __global__ __launch_bounds__(256) void k_integral_cols(double* __restrict__ sum,
     }
 }
 
+// ---------------------------------------------------------------------------------- window sums (8UC1 fast path)
+// For CV_8UC1 the window sums sum(I) and sum(I^2) the post-processing needs are small exact integers (<= 255^2 * tw * th
+// < 2^31 for templates up to 181x181), so instead of two (H+1)x(W+1) double integral images (133 MB for a 4K frame and a
+// column scan that is one long dependency chain) they are produced directly as u32 by a separable sliding box:
+// rows via an LDS prefix scan, columns via 64-row chunks.  Differences of cv::integral's doubles give the same integers.
+__global__ __launch_bounds__(256) void k_wsum_rows(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int tw, int rw,
+                                                   unsigned* __restrict__ s1, unsigned* __restrict__ q1, size_t sframe /* elements */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned lw[];        // P[0..iw] and Q[0..iw]
+    unsigned* P = lw; unsigned* Q = lw + (iw + 1);
+    const int y = blockIdx.x;
+    const uchar* row = img + (size_t)blockIdx.z * iframe + (size_t)y * istep;
+    const int chunk = (iw + 255) / 256;
+    const int x0 = threadIdx.x * chunk, x1 = min(iw, x0 + chunk);
+    unsigned s = 0, q = 0;
+    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; s += v; q += v * v; }
+    __shared__ unsigned ss[256], qq[256];
+    ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        unsigned a = 0, b = 0;
+        if ((int)threadIdx.x >= o) { a = ss[threadIdx.x - o]; b = qq[threadIdx.x - o]; }
+        __syncthreads();
+        ss[threadIdx.x] += a; qq[threadIdx.x] += b;
+        __syncthreads();
+    }
+    unsigned ps = threadIdx.x ? ss[threadIdx.x - 1] : 0u, pq = threadIdx.x ? qq[threadIdx.x - 1] : 0u;
+    if (threadIdx.x == 0) { P[0] = 0; Q[0] = 0; }
+    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; ps += v; pq += v * v; P[x + 1] = ps; Q[x + 1] = pq; }
+    __syncthreads();
+    unsigned* so = s1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
+    unsigned* qo = q1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
+    for (int x = threadIdx.x; x < rw; x += 256) { so[x] = P[x + tw] - P[x]; qo[x] = Q[x + tw] - Q[x]; }
+}
+
+constexpr int WS_CH = 64;
+__global__ __launch_bounds__(256) void k_wsum_cols(const unsigned* __restrict__ s1, const unsigned* __restrict__ q1, size_t sframe, int th, int rw, int rh,
+                                                   unsigned* __restrict__ w1, unsigned* __restrict__ w2, size_t wframe)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= rw) return;
+    const int y0 = blockIdx.y * WS_CH;
+    s1 += (size_t)blockIdx.z * sframe; q1 += (size_t)blockIdx.z * sframe;
+    w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
+    unsigned s = 0, q = 0;
+    for (int r = 0; r < th; r++) { s += s1[(size_t)(y0 + r) * rw + x]; q += q1[(size_t)(y0 + r) * rw + x]; }
+    w1[(size_t)y0 * rw + x] = s; w2[(size_t)y0 * rw + x] = q;
+    const int yend = min(rh, y0 + WS_CH);
+    for (int y = y0 + 1; y < yend; y++) {
+        s += s1[(size_t)(y + th - 1) * rw + x] - s1[(size_t)(y - 1) * rw + x];
+        q += q1[(size_t)(y + th - 1) * rw + x] - q1[(size_t)(y - 1) * rw + x];
+        w1[(size_t)y * rw + x] = s; w2[(size_t)y * rw + x] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------- direct correlation (general path)
 __global__ __launch_bounds__(256) void k_ccorr_direct(const uchar* __restrict__ img, size_t istep, size_t iframe, const uchar* __restrict__ tpl, size_t tstep,
                                                       int tw, int th, int cn, int depth, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
@@ -116,7 +171,7 @@ constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero by
 
 __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
                                                        const uchar* __restrict__ tpl, size_t tstep, int tw, int th,
-                                                       const double* __restrict__ isum, size_t sumstep, size_t sumframe, long long tplSum,
+                                                       const unsigned* __restrict__ wsum, size_t wframe, long long tplSum,
                                                        float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
@@ -124,7 +179,7 @@ __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__
     const int prow = MT_BM + th - 1;
     uchar* T = smem + (size_t)prow * MT_PPITCH;                  // th x MT_TPITCH signed taps, zero padded
     img += (size_t)blockIdx.z * iframe;
-    isum += (size_t)blockIdx.z * sumframe;
+    wsum += (size_t)blockIdx.z * wframe;
     const int X0 = blockIdx.x * MT_BN, Y0 = blockIdx.y * MT_BM;
     const int tid = threadIdx.x;
     // ---- stage: image patch as (p - 128), zero outside the image
@@ -215,10 +270,7 @@ __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__
             for (int i = 0; i < 16; i++) {
                 const int y = Y0 + wave * 64 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (x < rw && y < rh) {
-                    const double* s0 = isum + (size_t)y * sumstep + x;
-                    const double* s1 = isum + (size_t)(y + th) * sumstep + x;
-                    const double wsum = s0[0] - s0[tw] - s1[0] + s1[tw];
-                    const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)wsum + cst;
+                    const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)wsum[(size_t)y * rw + x] + cst;
                     reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep)[x] = (float)(double)corr;
                 }
             }
@@ -226,17 +278,19 @@ __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__
 }
 
 // ---------------------------------------------------------------------------------- common_matchTemplate
-struct NormArgs { int method, cn, tw, th, rw, rh, allOne; double tmean[4], templNorm, templSum2, invArea; };
+struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW; double tmean[4], templNorm, templSum2, invArea; };
 
 __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, size_t rstep, size_t rframe,
-                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, NormArgs a)
+                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe,
+                                                      const unsigned* __restrict__ w1, const unsigned* __restrict__ w2, size_t wframe, NormArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.rw || y >= a.rh) return;
     float* rrow = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep);
     if (a.allOne) { rrow[x] = 1.f; return; }
-    sum += (size_t)blockIdx.z * iframe; sq += (size_t)blockIdx.z * iframe;
+    if (a.useW) { w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe; }
+    else { sum += (size_t)blockIdx.z * iframe; sq += (size_t)blockIdx.z * iframe; }
     const int numType = (a.method == 2 || a.method == 3) ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
     const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
     const int cn = a.cn;
@@ -244,11 +298,14 @@ __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, s
     double num = rrow[x], t;
     double wndMean2 = 0, wndSum2 = 0;
     if (numType == 1) {
-        for (int k = 0; k < cn; k++) { t = sum[i0 + k] - sum[i1 + k] - sum[i2 + k] + sum[i3 + k]; wndMean2 += t * t; num -= t * a.tmean[k]; }
+        for (int k = 0; k < cn; k++) {
+            t = a.useW ? (double)w1[(size_t)y * a.rw + x] : sum[i0 + k] - sum[i1 + k] - sum[i2 + k] + sum[i3 + k];
+            wndMean2 += t * t; num -= t * a.tmean[k];
+        }
         wndMean2 *= a.invArea;
     }
     if (isNormed || numType == 2) {
-        for (int k = 0; k < cn; k++) { t = sq[i0 + k] - sq[i1 + k] - sq[i2 + k] + sq[i3 + k]; wndSum2 += t; }
+        for (int k = 0; k < cn; k++) { t = a.useW ? (double)w2[(size_t)y * a.rw + x] : sq[i0 + k] - sq[i1 + k] - sq[i2 + k] + sq[i3 + k]; wndSum2 += t; }
         if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
     }
     if (isNormed) {
@@ -315,7 +372,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     // integral images: needed by every method but TM_CCORR, and by the MFMA path's bias correction
     const bool useMfma = depth == D8U && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
                          (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024;
-    const bool needInt = method != 2 || useMfma;
+    const bool needInt = method != 2 && !useMfma;
     const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
     const size_t iframeD = isteps * (ih + 1);
     double* dsum = nullptr; double* dsq = nullptr;
@@ -326,12 +383,24 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         hipLaunchKernelGGL(k_integral_rows, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, dsq, isteps, iframeD);
         hipLaunchKernelGGL(k_integral_cols, dim3(divUp((int)isteps, 256), 1, nframes), dim3(256), 0, st, dsum, dsq, isteps, iframeD, (int)isteps, ih);
     }
+    unsigned* w1 = nullptr; unsigned* w2 = nullptr;
+    const size_t wframe = (size_t)rw * rh, s1frame = (size_t)rw * ih;
+    if (useMfma) {
+        unsigned* s1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
+        unsigned* q1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
+        w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
+        w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
+        if (!s1 || !q1 || !w1 || !w2) return MI355CV_NOT_IMPLEMENTED;
+        hipLaunchKernelGGL(k_wsum_rows, dim3(ih, 1, nframes), dim3(256), (size_t)(iw + 1) * 8, st, di, dis, iframe, iw, tw, rw, s1, q1, s1frame);
+        hipLaunchKernelGGL(k_wsum_cols, dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
+        na.useW = 1;
+    }
     if (useMfma) {
         const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
         static bool attrSet = false;
         if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
         dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), nframes);
-        hipLaunchKernelGGL(k_ccorr_mfma_i8, grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, dsum, isteps, iframeD, tplSum,
+        hipLaunchKernelGGL(k_ccorr_mfma_i8, grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, w1, wframe, tplSum,
                            reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
     } else {
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
@@ -339,7 +408,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     }
     if (method != 2) {
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
-        hipLaunchKernelGGL(k_tm_normalize, grid, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, na);
+        hipLaunchKernelGGL(k_tm_normalize, grid, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, w1, w2, wframe, na);
     }
     return stg.finish(entry);
 }

@@ -22,7 +22,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "filter2D", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
+           "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
 
@@ -279,6 +279,34 @@ def filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType=BORDER_
     finally:
         L.mi355cv_filterFree(ctx)
     _lib.check(rc, "filter")
+    return out
+
+
+def filter2DBatch(frames, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType=BORDER_DEFAULT, dst=None):
+    """[N,H,W(,C)] device-resident frames, one launch (isolated borders: every frame is a whole image)."""
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    s0 = Img(frames[0])
+    if ddepth < 0:
+        ddepth = s0.depth
+    if ddepth != s0.depth:
+        raise NotImplementedError("filter2DBatch: ddepth must equal the source depth")
+    k = _np_kernel(kernel)
+    if k.ndim == 1:
+        k = k[None, :]
+    kh, kw = k.shape
+    ax = kw // 2 if anchor[0] < 0 else anchor[0]
+    ay = kh // 2 if anchor[1] < 0 else anchor[1]
+    out = dst if dst is not None else torch.empty_like(frames)
+    d0 = Img(out[0])
+    bind_stream(s0, d0)
+    ctx = ctypes.c_void_p()
+    _lib.check(L.mi355cv_filterInit(ctypes.byref(ctx), k.ctypes.data, k.strides[0], _K_TYPE[k.dtype], kw, kh, w, h, s0.type, d0.type,
+                                    borderType & ~BORDER_ISOLATED, float(delta), ax, ay, False, False), "filterInit")
+    try:
+        rc = L.mi355cv_filterBatch(ctx, _vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, n, w, h)
+    finally:
+        L.mi355cv_filterFree(ctx)
+    _lib.check(rc, "filterBatch")
     return out
 
 

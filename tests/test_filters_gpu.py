@@ -56,6 +56,33 @@ def test_filter2d_8u(cv, orc, cn):
     assert cv.call_count("filter") > n0
 
 
+@pytest.mark.parametrize("cn,K", [(1, 3), (3, 3), (4, 3), (1, 5)])
+def test_filter2d_rolling_path(cv, orc, cn, K):
+    """Geometries the register-rolling kernel takes ((W*cn) % 16 == 0): several strips, short/odd heights so that
+    segments walk both up and down, asymmetric float taps (catch a flipped row order), every border mode."""
+    rng = np.random.default_rng(100 * K + cn)
+    kern = (rng.random((K, K), dtype=np.float32) - 0.4).astype(np.float32) / K
+    for (w, h) in [(16, 1), (32, 2), (48, 5), (1040, 37), (2064, 70), (16 * 67, 131)]:
+        if w * cn % 16:
+            continue
+        src = rnd((h, w, cn) if cn > 1 else (h, w), np.uint8, w + h)
+        for border in BORDERS:
+            for k, delta in [(kern, 0.0), (kern * 3, 10.5)] + ([(SHARPEN, 0.0)] if K == 3 else []):
+                want = orc.orc_filter2D(src, -1, k, (-1, -1), delta, border)
+                check(cv.filter2D(dev(src), -1, k, (-1, -1), delta, border), want)
+    # batch: frames are isolated images
+    n = 5
+    fr = rnd((n, 40, 64, cn) if cn > 1 else (n, 40, 64), np.uint8, 9)
+    got = cv.filter2DBatch(dev(fr), -1, kern, (-1, -1), 2.0, 4).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], orc.orc_filter2D(fr[i], -1, kern, (-1, -1), 2.0, 4))
+    # batch on a geometry the rolling kernel declines (falls to the generic kernel per frame)
+    fr = rnd((3, 11, 50), np.uint8, 10)
+    got = cv.filter2DBatch(dev(fr), -1, kern, (-1, -1), 0.0, 1).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], orc.orc_filter2D(fr[i], -1, kern, (-1, -1), 0.0, 1))
+
+
 def test_filter2d_depths_and_roi(cv, orc):
     rng = np.random.default_rng(5)
     k5 = (rng.uniform(-3, 10, (5, 5)) / 37.0).astype(np.float32)

@@ -46,7 +46,16 @@ def run(quick=False):
     by = 3840 * 2160 * 2
     out.append({"config": "cfg2b filter2D 3x3 4K 8UC1 (single frame per call)", "frames": 1, "ms": round(ms, 4), "Mpix_s": round(8.2944 / ms * 1e3, 1),
                 "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
-    del bgr, gray
+    dstb = torch.empty_like(gray)
+    ms = timeit(lambda: cv.filter2DBatch(gray, -1, k, dst=dstb))
+    by = B2 * 3840 * 2160 * 2
+    out.append({"config": "cfg2c filter2D 3x3 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
+                "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    k5 = (np.arange(25, dtype=np.float32).reshape(5, 5) - 12) / 64
+    ms = timeit(lambda: cv.filter2DBatch(gray, -1, k5, dst=dstb))
+    out.append({"config": "cfg2d filter2D 5x5 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
+                "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    del bgr, gray, dstb
     # ---- config 3: resize (bilinear) + warpAffine on 7680x4320 CV_32F
     src = torch.rand((4320, 7680), dtype=torch.float32, device=dev, generator=g)
     d1 = torch.empty((2880, 5120), dtype=torch.float32, device=dev)
