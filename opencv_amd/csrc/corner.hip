@@ -15,10 +15,12 @@
 //   pyrDown (pyramids.cpp:883-1037): 5x5 [1 4 6 4 1]^2 at even pixels, (S + 128) >> 8 for integers, * 1/256 for float,
 //     including the tabR column stepping of :897-910 for non-default dsize.
 #include "rt.h"
+#include "roll.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 
 using namespace mi355;
 
@@ -222,6 +224,162 @@ __global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------- cornerHarris / MinEigenVal, rolling path
+// CV_8UC1, ksize 3, blockSize 2 (BASELINE config 4): the roll.h skeleton.  A lane owns 16 output pixels of a row and walks a
+// segment of rows; per source row it forms the two row passes (Rd = x-derivative taps, exact; Rs = scaled smoothing taps),
+// keeps the last two of each, and from three of them the derivatives Dx, Dy of the middle row; the 2x2 box of the products
+// is the sum over (previous, current) rows and (x-1, x) columns.  The reference accumulates those four floats in double
+// (RowSum<float,double>/ColumnSum<double,float>).  cornerMinEigenVal does the same here (its response cancels to a small
+// number on edges, so ulp-level differences in A, B, C would show at the 1e-5 level of the norm): bit-identical to the
+// LDS-tiled kernel.  cornerHarris is well conditioned and adds them in float, (p + c)[x-1] + (p + c)[x]: at most 2 ulp away
+// in A, B, C, < 1e-5 in the response norm against the 1e-4 bar; the f64 converts/adds were 16 of 40 VALU instructions per
+// pixel and made the kernel VALU-bound at several times the HBM time.
+// Values are held as pairs (column m, column m+8) so that the float work issues as v_pk_*_f32.
+// Borders are two-level like the reference: the source is extrapolated for the Sobel passes, the *covariance image* for the
+// box filter: the cov column left of x = 0 and the cov row above y = 0 are copies of an in-image cov column/row (or zero).
+// The sign of Dy flips in upward-walking segments; only (sum dx*dy)^2 is used, so nothing needs correcting.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+struct CornerRollArgs { float kr0, kr1, kr2, kc1, kc2, kf; };
+
+template <bool HARRIS, int CB>
+__global__ __launch_bounds__(256) void k_corner_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                     uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                     int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
+                                                     CornerRollArgs a)
+{
+    typedef roll::Ctx<2, 2, 1, CB> Cx;
+    typedef typename Cx::RawT RawT;
+    constexpr int NW = Cx::NW;
+    constexpr int NP = CB / 2;                         // output pairs (i, i + NP) per lane
+    constexpr int NC = NP + 1;                         // cov columns x0-1+m / x0-1+NP+m
+    constexpr int NS = NP + 3;                         // source columns x0-2+m / x0-2+NP+m
+    Cx cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    dst += (size_t)cx.frame * dframe;
+    struct RowR { f32x2 d[NC], s[NC]; };               // the two row passes of one source row
+    struct RowC { f32x2 a[NC], b[NC], c[NC]; };        // dx*dx, dx*dy, dy*dy of one derivative row
+    const int qx = mi355_borderInterpolate(-1, W, border);
+    const bool fixL = cx.hasFirst && cx.lane == 0;
+
+    auto rowPasses = [&](RowR& r, RawT raw, int valid) {
+        uint32_t X[NW];
+        if (!valid) {                                  // BORDER_CONSTANT row (window() only moves bytes)
+#pragma unroll
+            for (int d = 0; d < Cx::MD; d++) raw.m[d] = 0;
+            raw.side[0] = 0;
+        }
+        cx.window(X, raw);
+        f32x2 P[NS];
+#pragma unroll
+        for (int m = 0; m < NS; m++) {
+            const int b0 = 2 + m, b1 = b0 + NP;         // window bytes: X[0] holds columns x0-4 .. x0-1
+            P[m].x = (float)((X[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
+            P[m].y = (float)((X[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
+        }
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            r.d[m] = P[m + 2] - P[m];
+            f32x2 t = P[m] * f32x2{a.kr0, a.kr0};
+            t = __builtin_elementwise_fma(f32x2{a.kr1, a.kr1}, P[m + 1], t);
+            r.s[m] = __builtin_elementwise_fma(f32x2{a.kr2, a.kr2}, P[m + 2], t);
+        }
+    };
+    auto products = [&](RowC& o, const RowR& r0, const RowR& r1, const RowR& r2) {
+        f32x2 dx[NC], dy[NC];
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            const f32x2 c = r1.d[m] * f32x2{a.kc1, a.kc1};
+            dx[m] = __builtin_elementwise_fma(f32x2{a.kc2, a.kc2}, r2.d[m] + r0.d[m], c);
+            dy[m] = r2.s[m] - r0.s[m];
+        }
+        const float sx = qx < 0 ? 0.f : (qx == 0 ? dx[1].x : dx[2].x);
+        const float sy = qx < 0 ? 0.f : (qx == 0 ? dy[1].x : dy[2].x);
+        dx[0].x = fixL ? sx : dx[0].x;
+        dy[0].x = fixL ? sy : dy[0].x;
+#pragma unroll
+        for (int m = 0; m < NC; m++) { o.a[m] = dx[m] * dx[m]; o.b[m] = dx[m] * dy[m]; o.c[m] = dy[m] * dy[m]; }
+    };
+    // response row y from the product rows p (kept) and c (new); c replaces p
+    auto emit = [&](RowC& p, const RowC& c, int y) {
+        typedef typename std::conditional<HARRIS, f32x2, f64x2>::type acc2;      // see the header comment
+        acc2 vxx[NC], vxy[NC], vyy[NC];
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            vxx[m] = __builtin_convertvector(p.a[m], acc2) + __builtin_convertvector(c.a[m], acc2);
+            vxy[m] = __builtin_convertvector(p.b[m], acc2) + __builtin_convertvector(c.b[m], acc2);
+            vyy[m] = __builtin_convertvector(p.c[m], acc2) + __builtin_convertvector(c.c[m], acc2);
+            p.a[m] = c.a[m]; p.b[m] = c.b[m]; p.c[m] = c.c[m];
+        }
+        f32x2 o[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const f32x2 A = __builtin_convertvector(vxx[i] + vxx[i + 1], f32x2);
+            const f32x2 B = __builtin_convertvector(vxy[i] + vxy[i + 1], f32x2);
+            const f32x2 C = __builtin_convertvector(vyy[i] + vyy[i + 1], f32x2);
+            if (HARRIS) {
+                const f32x2 acbb = A * C - B * B;
+                const f32x2 ac = A + C;
+                o[i] = acbb - (f32x2{a.kf, a.kf} * ac) * ac;
+            } else {
+                const f32x2 ah = A * f32x2{0.5f, 0.5f}, ch = C * f32x2{0.5f, 0.5f};
+                const f32x2 t = ah - ch;
+                const f32x2 u = B * B + t * t;
+                o[i] = (ah + ch) - f32x2{__fsqrt_rn(u.x), __fsqrt_rn(u.y)};
+            }
+        }
+        if (cx.active) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4* out = reinterpret_cast<f32x4*>(dst + (size_t)y * dstep + 4 * CB * (size_t)cx.c);
+#pragma unroll
+            for (int q = 0; q < NP / 4; q++) {
+                __builtin_nontemporal_store(f32x4{o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x}, out + q);
+                __builtin_nontemporal_store(f32x4{o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y}, out + NP / 4 + q);
+            }
+        }
+    };
+
+    // cov rows in walking order: c_0 (prologue), c_1 .. c_n; step t emits image row gy(t-1) from (c_{t-1}, c_t) and needs the
+    // source rows with logical indices t-2+o .. t+o, o = up
+    const int o = cx.up;
+    RowR R[3]; RowC Cp;
+    {
+        RawT r0, r1, r2; int v0, v1, v2;
+        const bool virt = !cx.up && cx.y0 == 0;        // c_0 is the cov row above the image
+        const int qy = mi355_borderInterpolate(-1, H, border);
+        if (virt) { const int q = max(qy, 0); cx.issueImg(r0, q - 1, v0); cx.issueImg(r1, q, v1); cx.issueImg(r2, q + 1, v2); }
+        else { cx.issueImg(r0, cx.gy(o - 2), v0); cx.issueImg(r1, cx.gy(o - 1), v1); cx.issueImg(r2, cx.gy(o), v2); }
+        rowPasses(R[0], r0, v0); rowPasses(R[1], r1, v1); rowPasses(R[2], r2, v2);
+        products(Cp, R[0], R[1], R[2]);
+        if (virt) {
+            if (qy < 0) {
+#pragma unroll
+                for (int m = 0; m < NC; m++) { Cp.a[m] = f32x2{0.f, 0.f}; Cp.b[m] = f32x2{0.f, 0.f}; Cp.c[m] = f32x2{0.f, 0.f}; }
+            }
+            cx.issueImg(r1, -1, v1); cx.issueImg(r2, 0, v2);
+            rowPasses(R[1], r1, v1); rowPasses(R[2], r2, v2);
+        }
+    }
+    // now R[1], R[2] hold logical rows o-1, o;  ring of loads for logical rows o+1, o+2, o+3
+    RawT raw[3]; int rv[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) cx.issue(raw[u], o + 1 + u, rv[u]);
+    for (int t = 1; t <= cx.nrows; t += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            if (t + u <= cx.nrows) {
+                // step t+u: the new row goes to slot u (the one holding the oldest row); older rows in slots u+1, u+2 (mod 3)
+                rowPasses(R[u], raw[u], rv[u]);
+                cx.issue(raw[u], t + u + o + 3, rv[u]);
+                RowC Cn;
+                products(Cn, R[(u + 1) % 3], R[(u + 2) % 3], R[u]);
+                emit(Cp, Cn, cx.gy(t + u - 1));
+            }
+        }
+    }
+}
+
 bool derivTaps(int order, int ksize, bool scharr, std::vector<int>& k)
 {
     if (scharr) { if (order == 0) k = {3, 10, 3}; else k = {-1, 0, 1}; return true; }
@@ -260,6 +418,17 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
     for (int i = 0; i < a.dyNCol; i++) a.dyCol[i] = (float)dyc[i];
     if (scale == 1) { /* unreachable for the depths handled; kept for symmetry with cv::Sobel */ }
     a.rx = std::max(a.dxNRow, a.dyNRow) / 2; a.ry = std::max(a.dxNCol, a.dyNCol) / 2;
+    if (sdepth == D8U && ksize == 3 && blockSize == 2 && H >= 2 && std::getenv("MI355CV_CORNER_LDS") == nullptr &&
+        (((uintptr_t)dd | dds | dframe) & 15) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, W, 1, 2, border, 8)) {
+        CornerRollArgs ra = {a.dyRow[0], a.dyRow[1], a.dyRow[2], a.dxCol[1], a.dxCol[2], a.kf};
+        const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W % 16 == 0;
+        const roll::Geom g = roll::geometry(W, H, 1, nframes, 24, 4, wide ? 16 : 8);
+#define CROLL(HR, CB_) hipLaunchKernelGGL((k_corner_roll<HR, CB_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, 1, ra)
+        if (wide) { if (harris) CROLL(true, 16); else CROLL(false, 16); }
+        else { if (harris) CROLL(true, 8); else CROLL(false, 8); }
+#undef CROLL
+        return MI355CV_OK;
+    }
     const int PW = CT_X + a.bs - 1, PH = CT_Y + a.bs - 1, SW = PW + 2 * a.rx, SH = PH + 2 * a.ry;
     const size_t lds = (size_t)(SW * SH + 2 * PW * SH + 2 * PW * PH) * sizeof(float);
     dim3 grid(divUp(W, CT_X), divUp(H, CT_Y), nframes);

@@ -104,7 +104,7 @@ __device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, ucha
 {
     constexpr int R = K / 2, HB = R * CN, HD = roll::Cfg<R, CN>::HD, NW = roll::Cfg<R, CN>::NW, NQ = 8 + 2 * HB;
     f32x2 Q[K][NQ];
-    auto toFloat = [&](f32x2 (&q)[NQ], const roll::Raw<HD>& r, int valid) {
+    auto toFloat = [&](f32x2 (&q)[NQ], const typename roll::Ctx<K / 2, K / 2, CN>::RawT& r, int valid) {
         if (!valid) {
 #pragma unroll
             for (int i = 0; i < NQ; i++) q[i] = f32x2{0.f, 0.f};
@@ -121,11 +121,11 @@ __device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, ucha
     };
 #pragma unroll
     for (int i = 0; i < K - 1; i++) {                      // prologue: logical rows -R .. R-1
-        roll::Raw<HD> pre; int v;
+        typename roll::Ctx<K / 2, K / 2, CN>::RawT pre; int v;
         cx.issue(pre, i - R, v);
         toFloat(Q[i], pre, v);
     }
-    roll::Raw<HD> raw[K]; int rv[K];
+    typename roll::Ctx<K / 2, K / 2, CN>::RawT raw[K]; int rv[K];
 #pragma unroll
     for (int u = 0; u < K; u++) cx.issue(raw[u], u + R, rv[u]);
     for (int y = 0; y < cx.nrows; y += K) {

@@ -1,28 +1,30 @@
 // roll.h -- the register-rolling stencil skeleton shared by the HBM-bound 8-bit stencil kernels (measured design of the
 // headline Gaussian, smooth.hip k_binomial_roll2):
-//   * one WAVE = one work item: a strip of 64 16-byte chunks (1 KiB of a row) x a segment of rows x a frame, work items
+//   * one WAVE = one work item: a strip of 64 chunks of CB bytes (CB = 16: 1 KiB of a row; CB = 8 for kernels whose per-pixel
+//     register state is too large for 16 pixels per lane) x a segment of rows x a frame, work items
 //     ordered strip -> segment -> frame so that resident waves sweep memory almost linearly;
-//   * a lane owns 16 consecutive bytes of a row (one dwordx4 load, one dwordx4 store) and walks the segment row by row,
+//   * a lane owns CB consecutive bytes of a row (one dwordx4 / dwordx2 load) and walks the segment row by row,
 //     keeping the rows it still needs in registers; loads run ahead through a ring (a slot is refilled right after use);
 //   * +-RX*cn neighbour bytes: DPP wave_shr / wave_shl from the adjacent lane; the two lanes at the wave edge get theirs
 //     from one 4-byte side load per row (two 64-byte sectors per wave); image-border halos are rebuilt from the lane's own
 //     16 bytes with wave-uniform v_perm selectors; rows outside the image are resolved to scalars before the loop;
 //   * vertically adjacent segments walk in opposite directions and sit on the same XCD (alt), so the rows they share are
 //     in L2 when the second one asks.
-// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % 16 == 0, W > RX, border in {CONSTANT, REPLICATE,
-// REFLECT, REFLECT_101}.
+// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % CB == 0, W > RX, RX*cn <= CB, border in {CONSTANT,
+// REPLICATE, REFLECT, REFLECT_101}.
 #pragma once
 #include "rt.h"
 
 namespace roll {
 
-template <int RX, int CN> struct Cfg {
+template <int RX, int CN, int CB = 16> struct Cfg {
     static constexpr int HB = RX * CN;            // halo bytes per side
     static constexpr int HD = (HB + 3) / 4;       // halo dwords per side
-    static constexpr int NW = 4 + 2 * HD;         // dwords of the assembled window
+    static constexpr int MD = CB / 4;             // dwords of the lane's own chunk
+    static constexpr int NW = MD + 2 * HD;        // dwords of the assembled window
 };
 
-template <int HD> struct Raw { uint4 m; uint32_t side[HD]; };
+template <int HD, int MD = 4> struct Raw { uint32_t m[MD]; uint32_t side[HD]; };
 
 template <int HD> struct Edge { uint32_t la[HD], lb[HD], lc[HD], ra[HD], rb[HD], rc[HD]; };
 
@@ -35,16 +37,26 @@ __device__ __forceinline__ void selSetByte(uint32_t& a, uint32_t& b, uint32_t& c
     a = (a & clr) | (va << sh); b = (b & clr) | (vb << sh); c = (c & clr) | (vc << sh);
 }
 
-__device__ __forceinline__ uint32_t gather16(const uint4& m, uint32_t a, uint32_t b, uint32_t c)
+// four bytes picked out of the lane's own chunk (selectors from selSetByte; an 8-byte chunk only needs the first perm)
+template <int MD>
+__device__ __forceinline__ uint32_t gatherOwn(const uint32_t (&m)[MD], uint32_t a, uint32_t b, uint32_t c)
 {
-    const uint32_t t1 = __builtin_amdgcn_perm(m.y, m.x, a);
-    const uint32_t t2 = __builtin_amdgcn_perm(m.w, m.z, b);
+    const uint32_t t1 = __builtin_amdgcn_perm(m[1], m[0], a);
+    if (MD == 2) return t1;
+    const uint32_t t2 = __builtin_amdgcn_perm(m[MD - 1], m[MD - 2], b);
     return __builtin_amdgcn_perm(t2, t1, c);
 }
 
-template <int RX, int RY, int CN>
+template <int MD> __device__ __forceinline__ void loadChunk(uint32_t (&m)[MD], const uchar* p)
+{
+    if (MD == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); m[0] = v.x; m[1] = v.y; m[MD - 2] = v.z; m[MD - 1] = v.w; }
+    else { const uint2 v = *reinterpret_cast<const uint2*>(p); m[0] = v.x; m[1] = v.y; }
+}
+
+template <int RX, int RY, int CN, int CB = 16>
 struct Ctx {
-    static constexpr int HD = Cfg<RX, CN>::HD, HB = Cfg<RX, CN>::HB, NW = Cfg<RX, CN>::NW;
+    static constexpr int HD = Cfg<RX, CN, CB>::HD, HB = Cfg<RX, CN, CB>::HB, NW = Cfg<RX, CN, CB>::NW, MD = CB / 4;
+    typedef Raw<HD, MD> RawT;
     const uchar* src; size_t sstep;
     int H, lane, c, nchunks, mainOff, sideOff, y0, y1, nrows, up, frame;
     bool active, hasFirst, hasLast, isLastChunk;
@@ -73,10 +85,10 @@ struct Ctx {
         c = strip * 64 + lane;
         y0 = seg * segRows; y1 = min(H, y0 + segRows); nrows = y1 - y0;
         active = c < nchunks; hasFirst = strip == 0; hasLast = strip == nstrips - 1; isLastChunk = c == nchunks - 1;
-        mainOff = 16 * (active ? c : nchunks - 1);
+        mainOff = CB * (active ? c : nchunks - 1);
         const int c0 = strip * 64;
-        const int leftOff = c0 > 0 ? 16 * c0 - 4 * HD : 0;
-        const int rightOff = c0 + 64 < nchunks ? 16 * (c0 + 64) : 16 * (nchunks - 1);
+        const int leftOff = c0 > 0 ? CB * c0 - 4 * HD : 0;
+        const int rightOff = c0 + 64 < nchunks ? CB * (c0 + 64) : CB * (nchunks - 1);
         sideOff = lane < 32 ? leftOff : rightOff;
 #pragma unroll
         for (int d = 0; d < HD; d++) { es.la[d] = es.lb[d] = es.lc[d] = es.ra[d] = es.rb[d] = es.rc[d] = 0x0c0c0c0cu; }
@@ -94,7 +106,7 @@ struct Ctx {
 #pragma unroll
             for (int t = 0; t < HB; t++) {
                 const int sp = mi355_borderInterpolate(W + t / CN, W, border);
-                selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - 16 * (nchunks - 1));
+                selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - CB * (nchunks - 1));
             }
         }
 #pragma unroll
@@ -113,55 +125,65 @@ struct Ctx {
         return ry;
     }
     // issue the loads of logical row j (clamped so that the address is always legal); valid = 0 for a constant-border row
-    __device__ __forceinline__ void issue(Raw<HD>& r, int j, int& valid) const
+    __device__ __forceinline__ void issue(RawT& r, int j, int& valid) const
     {
         const int ry = rowIdx(gy(min(j, nrows - 1 + RY)));
         valid = ry >= 0;
         const uchar* row = src + (size_t)max(ry, 0) * sstep;
-        r.m = *reinterpret_cast<const uint4*>(row + mainOff);
+        loadChunk<MD>(r.m, row + mainOff);
 #pragma unroll
         for (int d = 0; d < HD; d++) r.side[d] = *reinterpret_cast<const uint32_t*>(row + sideOff + 4 * d);
     }
-    // the lane's window of one row as dwords: X[0..HD) left halo, X[HD..HD+4) own 16 bytes, X[HD+4..NW) right halo
-    __device__ __forceinline__ void window(uint32_t (&X)[NW], const Raw<HD>& r) const
+    // same, for an explicit image row g in [-RY, H+RY)
+    __device__ __forceinline__ void issueImg(RawT& r, int g, int& valid) const
     {
-        const uint32_t mv[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+        const int ry = rowIdx(g);
+        valid = ry >= 0;
+        const uchar* row = src + (size_t)max(ry, 0) * sstep;
+        loadChunk<MD>(r.m, row + mainOff);
+#pragma unroll
+        for (int d = 0; d < HD; d++) r.side[d] = *reinterpret_cast<const uint32_t*>(row + sideOff + 4 * d);
+    }
+    // the lane's window of one row as dwords: X[0..HD) left halo, X[HD..HD+MD) own bytes, X[HD+MD..NW) right halo
+    __device__ __forceinline__ void window(uint32_t (&X)[NW], const RawT& r) const
+    {
+        const uint32_t (&mv)[MD] = r.m;
         uint32_t hl[HD], hr[HD], hb[HD];
 #pragma unroll
         for (int d = 0; d < HD; d++) { hl[d] = r.side[d]; hr[d] = r.side[d]; }
         if (hasFirst) {
 #pragma unroll
-            for (int d = 0; d < HD; d++) hl[d] = gather16(r.m, es.la[d], es.lb[d], es.lc[d]);
+            for (int d = 0; d < HD; d++) hl[d] = gatherOwn<MD>(r.m, es.la[d], es.lb[d], es.lc[d]);
         }
         if (hasLast) {
 #pragma unroll
-            for (int d = 0; d < HD; d++) hb[d] = gather16(r.m, es.ra[d], es.rb[d], es.rc[d]);
+            for (int d = 0; d < HD; d++) hb[d] = gatherOwn<MD>(r.m, es.ra[d], es.rb[d], es.rc[d]);
         }
 #pragma unroll
         for (int d = 0; d < HD; d++) {
-            X[d] = __builtin_amdgcn_update_dpp(hl[d], mv[4 - HD + d], 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps hl
+            X[d] = __builtin_amdgcn_update_dpp(hl[d], mv[MD - HD + d], 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps hl
             uint32_t rr = __builtin_amdgcn_update_dpp(hr[d], mv[d], 0x130, 0xf, 0xf, false);       // wave_shl:1, lane 63 keeps hr
             if (hasLast) rr = isLastChunk ? hb[d] : rr;
-            X[HD + 4 + d] = rr;
+            X[HD + MD + d] = rr;
         }
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[HD + d] = mv[d];
+        for (int d = 0; d < MD; d++) X[HD + d] = mv[d];
     }
 };
 
 // host side: eligibility of the rolling path and launch geometry
-inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t ds, size_t df, int W, int cn, int rx, int border)
+inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t ds, size_t df, int W, int cn, int rx, int border, int cb = 16)
 {
     if ((((uintptr_t)s | ss | sf | (uintptr_t)d | ds | df) & 15) != 0) return false;
-    if ((W * cn) % 16 != 0 || W <= rx) return false;
+    if ((W * cn) % cb != 0 || W <= rx || rx * cn > cb) return false;
     return border == mi355::B_CONSTANT || border == mi355::B_REPLICATE || border == mi355::B_REFLECT || border == mi355::B_REFLECT_101;
 }
 
 struct Geom { int nchunks, nstrips, seg, nseg; unsigned blocks; };
-inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg)
+inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16)
 {
     Geom g;
-    g.nchunks = W * cn / 16; g.nstrips = mi355::divUp(g.nchunks, 64);
+    g.nchunks = W * cn / cb; g.nstrips = mi355::divUp(g.nchunks, 64);
     long long per = (long long)g.nstrips * nframes;
     long long wantSeg = (2048 + per - 1) / per;
     int seg = (int)((H + wantSeg - 1) / wantSeg);

@@ -47,6 +47,35 @@ def test_corner_response(cv, orc, dtype):
     assert orc.rel_err(cv.cornerHarris(img, 2, 3, 0.04), orc.orc_cornerHarris(img, 2, 3, 0.04)) <= 1e-4     # host arrays
 
 
+def test_corner_rolling_path(cv, orc):
+    """blockSize 2 / ksize 3 / CV_8UC1 with W % 8 == 0 takes the register-rolling kernel: both responses, every border mode,
+    heights that give one / several / ragged segments (walking up and down), several strips; within 1e-4 of the oracle;
+    against the LDS-tiled kernel (double box sums like the reference) MinEigenVal is bit-identical and Harris (float box
+    sums) within 1e-5."""
+    import os
+    rng = np.random.default_rng(17)
+    for (w, h) in [(16, 2), (8, 5), (24, 3), (64, 48), (520, 37), (1048, 37), (2064, 101), (1920, 270)]:
+        img = structured(max(h, 60), max(w, 80), 5 + w)[:h, :w].copy() if w < 2000 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for border in (0, 1, 2, 4):
+            want = orc.orc_cornerHarris(img, 2, 3, 0.04, border)
+            got = cv.cornerHarris(dev(img), 2, 3, 0.04, border).cpu().numpy()
+            assert orc.rel_err(got, want) <= 1e-4, (w, h, border)
+            wantm = orc.orc_cornerMinEigenVal(img, 2, 3, border)
+            gotm = cv.cornerMinEigenVal(dev(img), 2, 3, border).cpu().numpy()
+            assert orc.rel_err(gotm, wantm) <= 1e-4, (w, h, border)
+            os.environ["MI355CV_CORNER_LDS"] = "1"
+            try:
+                lds = cv.cornerHarris(dev(img), 2, 3, 0.04, border).cpu().numpy()
+                ldsm = cv.cornerMinEigenVal(dev(img), 2, 3, border).cpu().numpy()
+            finally:
+                del os.environ["MI355CV_CORNER_LDS"]
+            assert orc.rel_err(got, lds) <= 1e-5 and np.array_equal(gotm, ldsm), (w, h, border, orc.rel_err(got, lds), orc.rel_err(gotm, ldsm))
+    frames = rng.integers(0, 256, (5, 64, 96), dtype=np.uint8)
+    resp = cv.cornerHarrisBatch(dev(frames), 2, 3, 0.04).cpu().numpy()
+    for i in range(5):
+        assert orc.rel_err(resp[i], orc.orc_cornerHarris(frames[i], 2, 3, 0.04)) <= 1e-4
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_pyrdown(cv, orc, dtype, cn):
