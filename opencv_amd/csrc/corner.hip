@@ -81,6 +81,72 @@ __global__ __launch_bounds__(256) void k_pyrdown(const uchar* __restrict__ src, 
     else reinterpret_cast<short*>(drow)[e] = (short)o;
 }
 
+
+// pyrDown, rolling path: CV_8UC1, default destination size, even 16-aligned width.  The roll.h skeleton with two source rows
+// per output row.  Horizontal pass on packed even/odd byte planes (two 16-bit sums per dword, h <= 16*255), vertical pass on
+// the last five h rows (v <= 16*4080 fits 16 bits), (v + 128) >> 8 -- the integer arithmetic of PyrDownInvoker
+// (pyramids.cpp:873-1040), so bit-exact.  5 bytes of traffic per output pixel (4 read, 1 written).
+__global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                      uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                      int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border)
+{
+    typedef roll::Ctx<2, 2, 1, 16> Cx;
+    typedef typename Cx::RawT RawT;
+    Cx cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, 0)) return;
+    dst += (size_t)cx.frame * dframe;
+    struct HRow { uint32_t h[4]; };                    // h[i] = (hsum of output 2i, hsum of output 2i+1) as 2 x u16
+    auto hpass = [&](HRow& o, const RawT& raw) {
+        uint32_t X[Cx::NW];                            // X[0] = columns x0-4..x0-1, X[1..4] own, X[5] = x0+16..x0+19
+        cx.window(X, raw);
+        uint32_t ev[6], od[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { ev[i] = X[i] & 0x00ff00ffu; od[i] = (X[i] >> 8) & 0x00ff00ffu; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t em = __builtin_amdgcn_alignbit(ev[i + 1], ev[i], 16);      // (E[2i-1], E[2i])
+            const uint32_t ep = __builtin_amdgcn_alignbit(ev[i + 2], ev[i + 1], 16);  // (E[2i+1], E[2i+2])
+            const uint32_t om = __builtin_amdgcn_alignbit(od[i + 1], od[i], 16);      // (O[2i-1], O[2i])
+            o.h[i] = em + ep + 6u * ev[i + 1] + 4u * (om + od[i + 1]);
+        }
+    };
+    const int oy0 = cx.y0 >> 1, nout = (cx.nrows + 1) >> 1;
+    HRow h0, h1, h2;
+    {
+        RawT r0, r1, r2; int v;
+        cx.issueImg(r0, cx.y0 - 2, v); cx.issueImg(r1, cx.y0 - 1, v); cx.issueImg(r2, cx.y0, v);
+        hpass(h0, r0); hpass(h1, r1); hpass(h2, r2);
+    }
+    RawT raw[4]; int rv;
+#pragma unroll
+    for (int u = 0; u < 4; u++) cx.issueImg(raw[u], min(cx.y0 + 1 + u, H + 1), rv);
+    for (int t = 0; t < nout; t += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (t + u < nout) {
+                HRow h3, h4;
+                hpass(h3, raw[2 * u]); hpass(h4, raw[2 * u + 1]);
+                const int nxt = cx.y0 + 2 * (t + u) + 5;
+                cx.issueImg(raw[2 * u], min(nxt, H + 1), rv);
+                cx.issueImg(raw[2 * u + 1], min(nxt + 1, H + 1), rv);
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t v = h0.h[i] + h4.h[i] + 4u * (h1.h[i] + h3.h[i]) + 6u * h2.h[i];
+                    w[i] = ((v + 0x00800080u) >> 8) & 0x00ff00ffu;
+                }
+                if (cx.active) {
+                    uint2 ov;
+                    ov.x = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u);
+                    ov.y = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
+                    *reinterpret_cast<uint2*>(dst + (size_t)(oy0 + t + u) * dstep + 8 * (size_t)cx.c) = ov;
+                }
+                h0 = h2; h1 = h3; h2 = h4;
+            }
+        }
+    }
+}
+
 int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe, int sw, int sh, uchar* dst, size_t dstep, size_t dframe,
                int dw, int dh, int nframes, int depth, int cn, int mL, int mT, int mR, int mB, int border)
 {
@@ -101,6 +167,14 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
         if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
         ds = dtop + (size_t)mT * dss + (size_t)mL * cn * e;
     } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
+    if (depth == D8U && cn == 1 && !mL && !mT && !mR && !mB && dw * 2 == sw && dh == (sh + 1) / 2 && sh >= 2 && border != B_WRAP &&
+        (((uintptr_t)dd | dds | dframe) & 7) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, sw, 1, 2, border)) {
+        roll::Geom g = roll::geometry(sw, sh, 1, nframes, 32, 8);
+        if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
+        hipLaunchKernelGGL(k_pyrdown_roll, dim3(g.blocks), dim3(256), 0, stream(), ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips,
+                           g.seg, g.nseg, nframes, border);
+        return stg.finish(entry);
+    }
     dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);
     hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, stream(), ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, depth, cn, mL, mT, mR, mB, border);
     return stg.finish(entry);

@@ -99,6 +99,20 @@ def test_pyrdown(cv, orc, dtype, cn):
     assert (orc.rel_err(got, want) <= 1e-6) if dtype == np.float32 else np.array_equal(got, want)
 
 
+def test_pyrdown_rolling_path(cv, orc):
+    """CV_8UC1 with W % 16 == 0 and the default destination size takes the register-rolling kernel."""
+    rng = np.random.default_rng(23)
+    for (w, h) in [(16, 2), (16, 3), (32, 7), (64, 48), (1040, 37), (2064, 101), (1920, 135), (240, 135)]:
+        src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for border in (1, 2, 4):
+            assert np.array_equal(cv.pyrDown(dev(src), None, border).cpu().numpy(), orc.orc_pyrDown(src, None, border)), (w, h, border)
+    fr = rng.integers(0, 256, (5, 70, 96), dtype=np.uint8)
+    got = cv.buildPyramidBatch(dev(fr), 2)
+    for i in range(5):
+        l1 = orc.orc_pyrDown(fr[i]); l2 = orc.orc_pyrDown(l1)
+        assert np.array_equal(got[1][i].cpu().numpy(), l1) and np.array_equal(got[2][i].cpu().numpy(), l2)
+
+
 def test_build_pyramid_config4(cv, orc):
     """BASELINE config 4: cornerHarris(2,3,0.04) + buildPyramid(maxlevel=4) on 1920x1080 CV_8UC1 frames (batched)."""
     rng = np.random.default_rng(809564)
