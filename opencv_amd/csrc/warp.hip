@@ -158,6 +158,52 @@ __global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, s
     }
 }
 
+// resize, bilinear (and INTER_AREA upscaling, which is bilinear with other coefficients), single channel CV_32F / CV_8U: the
+// arithmetic of k_resize specialised.  A thread owns a destination column for RROWS rows: its horizontal coefficient is
+// computed once, both horizontal taps come from one unaligned 8-byte / 2-byte load per source row, and a wave walks down
+// so that the source rows shared by consecutive destination rows are L1 hits.
+constexpr int RROWS = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_lin1(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RROWS;
+    if (dx >= a.dw || yb >= a.dh) return;
+    const int areaMode = a.mode == 2;
+    int sx; float fx;
+    linCoef(dx, a.scale_x, a.inv_x, areaMode, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    bool edge = false;
+    if (sx + 1 >= a.sw) { edge = true; if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; } }
+    const float a0f = 1.f - fx, a1f = fx;
+    const int a0 = satShort(__float2int_rn(a0f * 2048)), a1 = satShort(__float2int_rn(a1f * 2048));
+    const int xoff = (edge ? sx - 1 : sx);                  // the pair (xoff, xoff+1) is always inside the row when sw >= 2
+    const int ye = min(yb + RROWS, a.dh);
+    for (int dy = yb; dy < ye; dy++) {
+        int sy; float fy;
+        linCoef(dy, a.scale_y, a.inv_y, areaMode, sy, fy);
+        const int y0 = clipI(sy, 0, a.sh), y1 = clipI(sy + 1, 0, a.sh);
+        const float b0f = 1.f - fy, b1f = fy;
+        const uchar* r0 = src + (size_t)y0 * sstep + (size_t)xoff * sizeof(T);
+        const uchar* r1 = src + (size_t)y1 * sstep + (size_t)xoff * sizeof(T);
+        if (sizeof(T) == 4) {
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            const f2u p0 = *reinterpret_cast<const f2u*>(r0), p1 = *reinterpret_cast<const f2u*>(r1);
+            float t0, t1;
+            if (edge) { t0 = p0.y; t1 = p1.y; }
+            else { t0 = __fadd_rn(__fmul_rn(p0.x, a0f), __fmul_rn(p0.y, a1f)); t1 = __fadd_rn(__fmul_rn(p1.x, a0f), __fmul_rn(p1.y, a1f)); }
+            reinterpret_cast<float*>(dst + (size_t)dy * dstep)[dx] = __fadd_rn(__fmul_rn(t0, b0f), __fmul_rn(t1, b1f));
+        } else {
+            typedef unsigned short u16u __attribute__((aligned(1)));
+            const int q0 = *reinterpret_cast<const u16u*>(r0), q1 = *reinterpret_cast<const u16u*>(r1);
+            const int b0 = satShort(__float2int_rn(b0f * 2048)), b1 = satShort(__float2int_rn(b1f * 2048));
+            const int t0 = edge ? (q0 >> 8) * 2048 : (q0 & 255) * a0 + (q0 >> 8) * a1;
+            const int t1 = edge ? (q1 >> 8) * 2048 : (q1 & 255) * a0 + (q1 >> 8) * a1;
+            (dst + (size_t)dy * dstep)[dx] = (uchar)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -298,6 +344,53 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
     else samplePixel(src, sstep, D, s, satShort(X), satShort(Y), 0, 0, tab);
 }
 
+// warpAffine, bilinear, single channel CV_32F / CV_8U: same arithmetic as k_warp + samplePixel, specialised so that the
+// inner loop is straight-line code.  A thread owns one destination column for WROWS consecutive rows (its column terms
+// sat_int(M0*x*1024), sat_int(M3*x*1024) are computed once); the two horizontally adjacent taps come from ONE unaligned
+// 8-byte (32F) / 2-byte (8U) load per source row; pixels whose 2x2 footprint is not strictly inside the source take the
+// generic sampler.  A wave walks down WROWS rows, so the source lines it touched for one row are in L1 for the next.
+constexpr int WROWS = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void k_warp_affine_lin1(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tab)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * WROWS;
+    if (x >= w.dw || yb >= w.dh) return;
+    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0));
+    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0));
+    const int ye = min(yb + WROWS, w.dh);
+    for (int y = yb; y < ye; y++) {
+        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+        const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
+        const int sx = satShort(X >> 5), sy = satShort(Y >> 5), ax = X & 31, ay = Y & 31;
+        uchar* D = dst + (size_t)y * dstep + (size_t)x * sizeof(T);
+        if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
+            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * sizeof(T);
+            if (sizeof(T) == 4) {
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                const f2u p0 = *reinterpret_cast<const f2u*>(r0), p1 = *reinterpret_cast<const f2u*>(r0 + sstep);
+                const float s32 = 1.f / 32;
+                const float fx = ax * s32, fy = ay * s32;
+                const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+                const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
+                float t = __fadd_rn(__fmul_rn(p0.x, w0), __fmul_rn(p0.y, w1));
+                t = __fadd_rn(t, __fmul_rn(p1.x, w2));
+                t = __fadd_rn(t, __fmul_rn(p1.y, w3));
+                *reinterpret_cast<float*>(D) = t;
+            } else {
+                typedef unsigned short u16u __attribute__((aligned(1)));
+                const unsigned p0 = *reinterpret_cast<const u16u*>(r0), p1 = *reinterpret_cast<const u16u*>(r0 + sstep);
+                const short4 wq = *reinterpret_cast<const short4*>(tab + (ay * 32 + ax) * 4);
+                const int r = ((int)(p0 & 255) * wq.x + (int)(p0 >> 8) * wq.y + (int)(p1 & 255) * wq.z + (int)(p1 >> 8) * wq.w + (1 << 14)) >> 15;
+                *D = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+        } else
+            samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab);
+    }
+}
+
 bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
@@ -341,6 +434,12 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (M) for (int i = 0; i < (kind == 0 ? 6 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
+    if (kind == 0 && s.linear && cn == 1 && (depth == D32F || depth == D8U) && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
+        dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS));
+        if (depth == D32F) hipLaunchKernelGGL(k_warp_affine_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
+        else hipLaunchKernelGGL(k_warp_affine_lin1<uchar>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
+        return stg.finish(entry);
+    }
     dim3 grid(divUp(dw, 64), divUp(dh, 4));
     hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev, dmx, mxs, dmy, mys);
     return stg.finish(entry);
@@ -381,6 +480,12 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if ((a.mode == 1 || a.mode == 2) && cn == 1 && (depth == D32F || depth == D8U) && src_width >= 2 && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
+        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
+        if (depth == D32F) hipLaunchKernelGGL(k_resize_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
+        else hipLaunchKernelGGL(k_resize_lin1<uchar>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
+        return stg.finish("resize");
+    }
     dim3 grid(divUp(dst_width, 64), divUp(dst_height, 4));
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, stream(), ds, dss, dd, dds, a);
     return stg.finish("resize");
