@@ -10,7 +10,7 @@
 //     16 bytes with wave-uniform v_perm selectors; rows outside the image are resolved to scalars before the loop;
 //   * vertically adjacent segments walk in opposite directions and sit on the same XCD (alt), so the rows they share are
 //     in L2 when the second one asks.
-// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % CB == 0, W > RX, RX*cn <= CB, border in {CONSTANT,
+// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % CB == 0, W > RX, (RX+1)*cn <= CB, border in {CONSTANT,
 // REPLICATE, REFLECT, REFLECT_101}.
 #pragma once
 #include "rt.h"
@@ -171,11 +171,33 @@ struct Ctx {
     }
 };
 
+// ---- packed byte planes --------------------------------------------------------------------------------------------
+// A window of NW dwords as two planes of packed u16 pairs: E[d] = (byte 4d, byte 4d+2), O[d] = (byte 4d+1, byte 4d+3) of
+// window dword d (window dword HD is the lane's first own dword).  pairAt<Q,S,HD>(E,O,k) = the bytes at distance S from the
+// output pair (plane Q, own dword k), i.e. window bytes (4(k+HD)+Q+S, +2), as a packed pair: a plane element or one alignbit.
+constexpr int floordiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
+constexpr int mod2(int a) { return ((a % 2) + 2) % 2; }
+template <int NW> __device__ __forceinline__ void planes(uint32_t (&E)[NW], uint32_t (&O)[NW], const uint32_t (&X)[NW])
+{
+#pragma unroll
+    for (int d = 0; d < NW; d++) { E[d] = X[d] & 0x00ff00ffu; O[d] = (X[d] >> 8) & 0x00ff00ffu; }
+}
+template <int Q, int S, int HD>
+__device__ __forceinline__ uint32_t pairAt(const uint32_t* E, const uint32_t* O, int k)
+{
+    constexpr int q2 = mod2(Q + S);
+    constexpr int f = floordiv2(Q + S);
+    const uint32_t* P = q2 ? O : E;
+    if constexpr (mod2(f) == 0) return P[k + f / 2 + HD];
+    else { constexpr int lo = floordiv2(f - 1); return __builtin_amdgcn_alignbit(P[k + lo + 1 + HD], P[k + lo + HD], 16); }
+}
+
 // host side: eligibility of the rolling path and launch geometry
 inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t ds, size_t df, int W, int cn, int rx, int border, int cb = 16)
 {
     if ((((uintptr_t)s | ss | sf | (uintptr_t)d | ds | df) & 15) != 0) return false;
-    if ((W * cn) % cb != 0 || W <= rx || rx * cn > cb) return false;
+    // halos come from the neighbouring chunk (rx*cn <= cb) and, at the image border, from pixels 0..rx of the lane's OWN chunk
+    if ((W * cn) % cb != 0 || W <= rx || (rx + 1) * cn > cb) return false;
     return border == mi355::B_CONSTANT || border == mi355::B_REPLICATE || border == mi355::B_REFLECT || border == mi355::B_REFLECT_101;
 }
 

@@ -1,0 +1,23 @@
+// seproll.h -- launchers of the register-rolling separable kernels (seproll.hip).  Each returns false when the geometry or
+// the parameters are outside what the rolling kernels cover; the caller then takes its generic kernel.
+#pragma once
+#include "rt.h"
+
+namespace mi355 {
+
+// u8 -> u8 separable smoothing with Q8.8 taps (cv::GaussianBlur on CV_8U, any sigma): nx == ny in {3,5,7,9}, cn in {1,3,4},
+// sum(kx) <= 256 and sum(ky) <= 256 (no saturation anywhere in the ufixedpoint16/32 arithmetic).
+bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                        int W, int H, int cn, const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, hipStream_t st);
+
+// u8 -> u8 normalised box filter with u16 sums (kw*kh <= 256): kw == kh in {3,5,7}, centred anchor, cn in {1,3,4};
+// divScale/divDelta = the reciprocal pair of ColumnSum<ushort,uchar>.
+bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                int W, int H, int cn, int ksize, unsigned divScale, unsigned divDelta, int border, hipStream_t st);
+
+// u8 -> s16 separable filter with small integer taps (cv::Sobel / cv::Scharr with scale 1, delta 0): n in {3,5}, cn == 1,
+// every intermediate and result within int16.
+bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                    int W, int H, const int* kx, const int* ky, int n, int border, hipStream_t st);
+
+} // namespace mi355

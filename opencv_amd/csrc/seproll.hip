@@ -1,0 +1,168 @@
+// seproll.hip -- register-rolling kernels for the separable 8-bit filters that are not the sigma-0 binomial Gaussian
+// (smooth.hip has its own tuned copy of the skeleton): Q8.8 Gaussian with arbitrary taps, normalised box filter, integer
+// derivative filters.  All are instances of one kernel: a wave walks a segment of rows (roll.h); per new source row a
+// horizontal pass produces that row's intermediates (kept for KY rows in registers, packed two 16-bit values per VGPR on
+// even/odd byte planes), a vertical pass over the ring produces the output row.  HBM-bound by design: every source byte is
+// fetched once per segment, outputs are written once with non-temporal stores.
+#include "seproll.h"
+#include "roll.h"
+
+using namespace mi355;
+
+namespace {
+
+// Policy interface:
+//   KX, KY, CN            taps and channels;  OUTB = bytes per output element (1 or 2)
+//   Args                  kernel parameters (by value)
+//   hpass(Inter&, E, O, args)                 one row's intermediates from the byte planes of its window
+//   vpass<UP>(ring, u, args, out[MD*OUTB])    output dwords of the lane from the KY ring rows; ring[(u + j) % KY] is the
+//                                             j-th row in WALKING order (image order reversed when UP)
+template <class P, bool UP>
+__device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN>& cx, uchar* __restrict__ dst, size_t dstep, const typename P::Args& a)
+{
+    typedef roll::Ctx<P::KX / 2, P::KY / 2, P::CN> Cx;
+    typedef typename Cx::RawT RawT;
+    constexpr int KY = P::KY, RY = KY / 2, NW = Cx::NW, MD = Cx::MD, OD = MD * P::OUTB;
+    typename P::Inter ring[KY];
+    auto hrow = [&](typename P::Inter& o, RawT raw, int valid) {
+        if (!valid) {                                  // BORDER_CONSTANT row: zeros (window() only moves bytes)
+#pragma unroll
+            for (int d = 0; d < MD; d++) raw.m[d] = 0;
+#pragma unroll
+            for (int d = 0; d < Cx::HD; d++) raw.side[d] = 0;
+        }
+        uint32_t X[NW], E[NW], O[NW];
+        cx.window(X, raw);
+        roll::planes<NW>(E, O, X);
+        P::hpass(o, E, O, a);
+    };
+#pragma unroll
+    for (int i = 0; i < KY - 1; i++) { RawT pre; int v; cx.issue(pre, i - RY, v); hrow(ring[i], pre, v); }
+    RawT raw[KY]; int rv[KY];
+#pragma unroll
+    for (int u = 0; u < KY; u++) cx.issue(raw[u], u + RY, rv[u]);
+    for (int y = 0; y < cx.nrows; y += KY) {
+#pragma unroll
+        for (int u = 0; u < KY; u++) {
+            if (y + u < cx.nrows) {
+                hrow(ring[(KY - 1 + u) % KY], raw[u], rv[u]);
+                cx.issue(raw[u], y + u + KY + RY, rv[u]);
+                uint32_t o[OD];
+                P::template vpass<UP>(ring, u, a, o);
+                if (cx.active) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + 16 * P::OUTB * (size_t)cx.c);
+#pragma unroll
+                    for (int q = 0; q < OD / 4; q++) __builtin_nontemporal_store(u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}, out + q);
+                }
+            }
+        }
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void k_sep_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                  int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
+                                                  typename P::Args a)
+{
+    roll::Ctx<P::KX / 2, P::KY / 2, P::CN> cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    dst += (size_t)cx.frame * dframe;
+    if (cx.up) sepRows<P, true>(cx, dst, dstep, a);
+    else       sepRows<P, false>(cx, dst, dstep, a);
+}
+
+template <class P>
+void launchSep(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int border,
+               int bestSeg, const typename P::Args& a, hipStream_t st)
+{
+    const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY);
+    hipLaunchKernelGGL((k_sep_roll<P>), dim3(g.blocks), dim3(256), 0, st, src, sstep, sframe, dst, dstep, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg,
+                       nframes, border, 1, a);
+}
+
+// take byte 2 of four 32-bit accumulators -> one dword (accumulators hold value << 16 with value <= 255)
+__device__ __forceinline__ uint32_t packB2(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const uint32_t lo = __builtin_amdgcn_perm(b1, b0, 0x0c0c0602u);      // (b0.byte2, b1.byte2, 0, 0)
+    const uint32_t hi = __builtin_amdgcn_perm(b3, b2, 0x06020c0cu);      // (0, 0, b2.byte2, b3.byte2)
+    return lo | hi;
+}
+
+// ---------------------------------------------------------------------------------- Q8.8 smoothing (fixedSmoothInvoker)
+// h = sum kx[i] * p (u16, exact because sum kx <= 256), acc = sum ky[j] * h_j (u32), dst = (acc + 2^15) >> 16
+// (smooth.simd.hpp:1926-2170, fixedpoint.inl.hpp:247-345).  Horizontal: one v_mad_u32_u24 per tap and PAIR of pixels (the two
+// 16-bit lanes cannot carry into each other); vertical: one v_dot2_u32_u16 per tap and pixel with (ky, 0) / (0, ky) operands.
+template <int K, int CN_>
+struct FixedSmooth {
+    static constexpr int KX = K, KY = K, CN = CN_, OUTB = 1, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, CN>::HD;
+    struct Args { uint32_t kx[K]; uint32_t kyLo[K], kyHi[K]; };
+    struct Inter { uint32_t e[4], o[4]; };
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    template <int Q, int I>
+    static __device__ __forceinline__ uint32_t hsum(const uint32_t* E, const uint32_t* O, int k, const Args& a)
+    {
+        const uint32_t v = roll::pairAt<Q, (I - R) * CN, HD>(E, O, k);
+        if constexpr (I == 0) return __umul24(v, a.kx[0]);
+        else {
+            // the compiler splits a mul24 chain into v_mul_u32_u24 + v_add3_u32; keep it one v_mad_u32_u24 per tap
+            const uint32_t acc = hsum<Q, I - 1>(E, O, k, a);
+            uint32_t d;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(v), "s"(a.kx[I]), "v"(acc));
+            return d;
+        }
+    }
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o.e[k] = hsum<0, K - 1>(E, O, k, a); o.o[k] = hsum<1, K - 1>(E, O, k, a); }
+    }
+    static __device__ __forceinline__ uint32_t dot(uint32_t h, uint32_t k, uint32_t acc)
+    {
+        return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h), __builtin_bit_cast(u16x2, k), acc, false);
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t el = 0x8000u, eh = 0x8000u, ol = 0x8000u, oh = 0x8000u;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const Inter& r = ring[(u + j) % K];
+                const int t = UP ? K - 1 - j : j;
+                el = dot(r.e[k], a.kyLo[t], el); eh = dot(r.e[k], a.kyHi[t], eh);
+                ol = dot(r.o[k], a.kyLo[t], ol); oh = dot(r.o[k], a.kyHi[t], oh);
+            }
+            out[k] = packB2(el, ol, eh, oh);            // bytes 4k, 4k+1, 4k+2, 4k+3
+        }
+    }
+};
+
+} // namespace
+
+namespace mi355 {
+
+bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                        int W, int H, int cn, const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, hipStream_t st)
+{
+    if (nx != ny || (nx != 3 && nx != 5 && nx != 7 && nx != 9) || !(cn == 1 || cn == 3 || cn == 4)) return false;
+    unsigned sx = 0, sy = 0;
+    for (int i = 0; i < nx; i++) { sx += kx[i]; sy += ky[i]; }
+    if (sx > 256 || sy > 256) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, nx / 2, border)) return false;
+#define FS(K_, CN_) do { typedef FixedSmooth<K_, CN_> P; P::Args a; \
+        for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.kyLo[i] = ky[i]; a.kyHi[i] = (uint32_t)ky[i] << 16; } \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+#define FSK(K_) do { if (cn == 1) FS(K_, 1); else if (cn == 3) FS(K_, 3); else FS(K_, 4); } while (0)
+    switch (nx) { case 3: FSK(3); break; case 5: FSK(5); break; case 7: FSK(7); break; default: FSK(9); }
+#undef FSK
+#undef FS
+    return true;
+}
+
+bool seprollBox(const uchar*, size_t, size_t, uchar*, size_t, size_t, int, int, int, int, int, unsigned, unsigned, int, hipStream_t) { return false; }
+bool seprollDeriv16(const uchar*, size_t, size_t, uchar*, size_t, size_t, int, int, int, const int*, const int*, int, int, hipStream_t) { return false; }
+
+} // namespace mi355

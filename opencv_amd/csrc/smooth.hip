@@ -18,6 +18,7 @@
 //    byte, straight from the formula above.  Correctness path, not a fast path.
 #include "rt.h"
 #include "gausskernel.h"
+#include "seproll.h"
 #include <cstring>
 #include <cstdlib>
 
@@ -645,6 +646,9 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
         if (nx == 5) { switch (cn) { case 1: ROLL(5, 1); break; case 2: ROLL(5, 2); break; case 3: ROLL(5, 3); break; default: ROLL(5, 4); } }
         else         { switch (cn) { case 1: ROLL(3, 1); break; case 2: ROLL(3, 2); break; case 3: ROLL(3, 3); break; default: ROLL(3, 4); } }
 #undef ROLL
+    } else if (noMargins && std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr &&
+               seprollFixedSmooth(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, kx, nx, ky, ny, border, st)) {
+        // any-sigma Q8.8 taps on the rolling skeleton
     } else {
         FixedTaps t;
         t.nx = nx; t.ny = ny;

@@ -71,6 +71,32 @@ def test_gaussianblur_wide_binomial(cv, orc, ksize):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("cn", [1, 3, 4])
+@pytest.mark.parametrize("ksize", [3, 5, 7, 9])
+def test_gaussianblur_any_sigma_rolling_path(cv, orc, cn, ksize):
+    """Q8.8 taps from sigma (and the 7/9 binomial tables) on geometries the rolling separable kernel takes
+    ((W*cn) % 16 == 0): taps from the oracle's bit-exact generator, result from the oracle's fixed-point filter."""
+    rng = np.random.default_rng(77 + ksize * 10 + cn)
+    for (w, h) in [(16, 1), (32, 2), (48, 5), (64, 23), (1040, 37), (2064, 70)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for sigma in (0.0, 0.8, 1.5, 3.1):
+            if sigma == 0.0 and ksize <= 5:
+                continue                                   # the binomial kernel of smooth.hip: covered above
+            k = [int(v) for v in orc.orc_getGaussianKernelQ(ksize, sigma)]
+            for border in (0, 1, 2, 4):
+                want = orc.orc_sepSmoothFixedU8(src, k, k, border)
+                got = cv.GaussianBlur(_dev(src), (ksize, ksize), sigma, sigma, border).cpu().numpy()
+                assert np.array_equal(got, want), (w, h, cn, ksize, sigma, border)
+    # extremes: all-255 input must stay 255 (no overflow of the 16-bit lanes), asymmetric taps through the explicit entry
+    src = np.full((20, 64, cn) if cn > 1 else (20, 64), 255, np.uint8)
+    assert (cv.GaussianBlur(_dev(src), (ksize, ksize), 1.1).cpu().numpy() == 255).all()
+    kx = list(range(1, ksize + 1)); kx[-1] += 256 - sum(kx)
+    ky = kx[::-1]
+    src = rng.integers(0, 256, (33, 96, cn) if cn > 1 else (33, 96), dtype=np.uint8)
+    for border in (0, 1, 2, 4):
+        assert np.array_equal(cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy(), orc.orc_sepSmoothFixedU8(src, kx, ky, border)), border
+
+
 def test_non_isolated_margins(cv, orc):
     """ROI inside a larger image: borders read the real neighbours (hal margins contract)."""
     rng = np.random.default_rng(7)

@@ -55,7 +55,30 @@ def run(quick=False):
     ms = timeit(lambda: cv.filter2DBatch(gray, -1, k5, dst=dstb))
     out.append({"config": "cfg2d filter2D 5x5 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
                 "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
-    del bgr, gray, dstb
+    # ---- the other filters of rows a3-a5 on one 4K 8UC1 frame (single-frame calls: launch overhead included)
+    one = gray[0]
+    MP = 8.2944
+
+    def line(name, ms, by):
+        out.append({"config": name, "ms": round(ms, 4), "Mpix_s": round(MP / ms * 1e3, 1), "bound": "hbm",
+                    "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    d16 = torch.empty((2160, 3840), dtype=torch.int16, device=dev)
+    d8 = torch.empty_like(one)
+    d32 = torch.empty((2160, 3840), dtype=torch.float32, device=dev)
+    line("a5 Sobel dx 3x3 4K 8U->16S", timeit(lambda: cv.Sobel(one, cv.CV_16S, 1, 0, 3, dst=d16)), 3840 * 2160 * 3)
+    line("a5 Sobel dx 3x3 4K 8U->32F", timeit(lambda: cv.Sobel(one, cv.CV_32F, 1, 0, 3, dst=d32)), 3840 * 2160 * 5)
+    line("a6 boxFilter 5x5 4K 8U", timeit(lambda: cv.boxFilter(one, -1, (5, 5), dst=d8)), 3840 * 2160 * 2)
+    line("a6 blur 3x3 4K 8U", timeit(lambda: cv.blur(one, (3, 3), dst=d8)), 3840 * 2160 * 2)
+    kx = np.array([0.25, 0.5, 0.25], np.float32)
+    line("a4 sepFilter2D 3x3 float taps 4K 8U", timeit(lambda: cv.sepFilter2D(one, -1, kx, kx, dst=d8)), 3840 * 2160 * 2)
+    line("a1 GaussianBlur 7x7 4K 8U", timeit(lambda: cv.GaussianBlur(one, (7, 7), 0, dst=d8)), 3840 * 2160 * 2)
+    line("a1 GaussianBlur 5x5 sigma 1.5 4K 8U", timeit(lambda: cv.GaussianBlur(one, (5, 5), 1.5, dst=d8)), 3840 * 2160 * 2)
+    line("a1 GaussianBlur 5x5 4K 8U single frame", timeit(lambda: cv.GaussianBlur(one, (5, 5), 0, dst=d8)), 3840 * 2160 * 2)
+    hd = bgr[0][:1080, :1920].contiguous(); hdd = torch.empty_like(hd)
+    ms = timeit(lambda: cv.GaussianBlur(hd, (5, 5), 0, dst=hdd))
+    out.append({"config": "cfg1 GaussianBlur 5x5 one 1080p 8UC3 frame", "ms": round(ms, 4), "Mpix_s": round(2.0736 / ms * 1e3, 1), "bound": "hbm",
+                "achieved_GBs": round(1920 * 1080 * 6 / ms / 1e6, 1), "frac": round(1920 * 1080 * 6 / ms / 1e6 / HBM, 4)})
+    del bgr, gray, dstb, d16, d8, d32
     # ---- config 3: resize (bilinear) + warpAffine on 7680x4320 CV_32F
     src = torch.rand((4320, 7680), dtype=torch.float32, device=dev, generator=g)
     d1 = torch.empty((2880, 5120), dtype=torch.float32, device=dev)
