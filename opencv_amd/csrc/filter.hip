@@ -21,6 +21,7 @@
 // its own fast path (TODO next round: register-rolling 3x3).
 #include "rt.h"
 #include "roll.h"
+#include "seproll.h"
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -443,6 +444,10 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
+    const SepParams& p = c.sp;
+    if (p.mode == 2 && c.ddepth == D16S && c.cn == 1 && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 && p.deltaI == 0 &&
+        fullW == W && fullH == H && seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, p.kxi, p.kyi, p.nx, c.border, stream()))
+        return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
                        fullW, fullH, offX, offY, c.border, c.sp);
@@ -699,6 +704,9 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * de, height, &dds);
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)margin_top * dss + (size_t)margin_left * cn * se;
+    if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 && fullW == width && fullH == height &&
+        seprollBox(ds, dss, 0, dd, dds, 0, 1, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
+        return stg.finish("boxFilter");
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
                        fullW, fullH, margin_left, margin_top, border, p);

@@ -140,6 +140,93 @@ struct FixedSmooth {
     }
 };
 
+
+// take byte 3 of four 32-bit values -> one dword
+__device__ __forceinline__ uint32_t packB3(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const uint32_t lo = __builtin_amdgcn_perm(b1, b0, 0x0c0c0703u);
+    const uint32_t hi = __builtin_amdgcn_perm(b3, b2, 0x07030c0cu);
+    return lo | hi;
+}
+
+// ---------------------------------------------------------------------------------- normalised box filter, u16 sums
+// RowSum<uchar,ushort> + ColumnSum<ushort,uchar> (box_filter.simd.hpp:429-560): s = sum of the K*K bytes (<= 65280),
+// dst = ((s + dd) * ds) >> 23.  Sums run on the packed planes (two pixels per add); the division is one v_mad_u32_u24 per
+// pixel with 2*ds, so that the quotient lands in byte 3: ((s + dd) * ds) >> 23 == (s * 2ds + 2*dd*ds) >> 24, all < 2^32.
+template <int K, int CN_>
+struct BoxU8 {
+    static constexpr int KX = K, KY = K, CN = CN_, OUTB = 1, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, CN>::HD;
+    struct Args { uint32_t ds2, c2; };
+    struct Inter { uint32_t e[4], o[4]; };
+    template <int Q, int I>
+    static __device__ __forceinline__ uint32_t hsum(const uint32_t* E, const uint32_t* O, int k)
+    {
+        const uint32_t v = roll::pairAt<Q, (I - R) * CN, HD>(E, O, k);
+        if constexpr (I == 0) return v; else return v + hsum<Q, I - 1>(E, O, k);
+    }
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args&)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o.e[k] = hsum<0, K - 1>(E, O, k); o.o[k] = hsum<1, K - 1>(E, O, k); }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int, const Args& a, uint32_t (&out)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t se = ring[0].e[k], so = ring[0].o[k];
+#pragma unroll
+            for (int j = 1; j < K; j++) { se += ring[j].e[k]; so += ring[j].o[k]; }
+            const uint32_t el = __umul24(se & 0xffffu, a.ds2) + a.c2, eh = __umul24(se >> 16, a.ds2) + a.c2;
+            const uint32_t ol = __umul24(so & 0xffffu, a.ds2) + a.c2, oh = __umul24(so >> 16, a.ds2) + a.c2;
+            out[k] = packB3(el, ol, eh, oh);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------- integer derivative filters, u8 -> s16
+// cv::Sobel / cv::Scharr with CV_16S output, scale 1, delta 0: exact integer arithmetic in the reference (SymmRowSmallVec_8u32s
+// filter.simd.hpp:530-860, SymmColumnSmallVec_32s16s :1420-1600), result within int16 by the host's range check, so the two
+// passes run as packed 16-bit multiply-adds (v_pk_mad_i16 / v_pk_mul_lo_u16) on the byte planes.
+template <int K>
+struct Deriv16 {
+    static constexpr int KX = K, KY = K, CN = 1, OUTB = 2, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, 1>::HD;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    struct Args { uint32_t kx[K], ky[K]; };              // taps splatted into both 16-bit halves
+    struct Inter { s16x2 e[4], o[4]; };
+    template <int Q, int I>
+    static __device__ __forceinline__ s16x2 hsum(const uint32_t* E, const uint32_t* O, int k, const Args& a)
+    {
+        const s16x2 v = __builtin_bit_cast(s16x2, roll::pairAt<Q, (I - R), HD>(E, O, k));
+        const s16x2 t = __builtin_bit_cast(s16x2, a.kx[I]);
+        if constexpr (I == 0) return v * t; else return v * t + hsum<Q, I - 1>(E, O, k, a);
+    }
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o.e[k] = hsum<0, K - 1>(E, O, k, a); o.o[k] = hsum<1, K - 1>(E, O, k, a); }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s16x2 se = {0, 0}, so = {0, 0};
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const Inter& r = ring[(u + j) % K];
+                const s16x2 t = __builtin_bit_cast(s16x2, a.ky[UP ? K - 1 - j : j]);
+                se = r.e[k] * t + se; so = r.o[k] * t + so;
+            }
+            const uint32_t ue = __builtin_bit_cast(uint32_t, se), uo = __builtin_bit_cast(uint32_t, so);
+            out[2 * k] = __builtin_amdgcn_perm(uo, ue, 0x05040100u);          // pixels 4k, 4k+1
+            out[2 * k + 1] = __builtin_amdgcn_perm(uo, ue, 0x07060302u);      // pixels 4k+2, 4k+3
+        }
+    }
+};
+
 } // namespace
 
 namespace mi355 {
@@ -162,7 +249,35 @@ bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* ds
     return true;
 }
 
-bool seprollBox(const uchar*, size_t, size_t, uchar*, size_t, size_t, int, int, int, int, int, unsigned, unsigned, int, hipStream_t) { return false; }
-bool seprollDeriv16(const uchar*, size_t, size_t, uchar*, size_t, size_t, int, int, int, const int*, const int*, int, int, hipStream_t) { return false; }
+bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                int W, int H, int cn, int ksize, unsigned divScale, unsigned divDelta, int border, hipStream_t st)
+{
+    if ((ksize != 3 && ksize != 5 && ksize != 7) || !(cn == 1 || cn == 3 || cn == 4)) return false;
+    if (divScale >= (1u << 22) || (unsigned long long)divDelta * divScale >= (1ull << 30)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, ksize / 2, border)) return false;
+#define BX(K_, CN_) do { typedef BoxU8<K_, CN_> P; P::Args a = {2u * divScale, 2u * divDelta * divScale}; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+#define BXK(K_) do { if (cn == 1) BX(K_, 1); else if (cn == 3) BX(K_, 3); else BX(K_, 4); } while (0)
+    switch (ksize) { case 3: BXK(3); break; case 5: BXK(5); break; default: BXK(7); }
+#undef BXK
+#undef BX
+    return true;
+}
+
+bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                    int W, int H, const int* kx, const int* ky, int n, int border, hipStream_t st)
+{
+    if (n != 3 && n != 5) return false;
+    long long ax = 0, ay = 0;
+    for (int i = 0; i < n; i++) { ax += kx[i] < 0 ? -kx[i] : kx[i]; ay += ky[i] < 0 ? -ky[i] : ky[i]; }
+    if (255 * ax > 32767 || 255 * ax * ay > 32767) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
+#define DV(K_) do { typedef Deriv16<K_> P; P::Args a; \
+        for (int i = 0; i < K_; i++) { a.kx[i] = ((uint32_t)kx[i] & 0xffffu) * 0x10001u; a.ky[i] = ((uint32_t)ky[i] & 0xffffu) * 0x10001u; } \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+    if (n == 3) DV(3); else DV(5);
+#undef DV
+    return true;
+}
 
 } // namespace mi355

@@ -139,6 +139,27 @@ def test_sobel_scharr(cv, orc, ksize):
         check(cv.Scharr(dev(src8), cv.CV_16S, 1, 0), orc.orc_Sobel(src8, 3, 1, 0, -1))
 
 
+def test_sobel_box_rolling_path(cv, orc):
+    """Geometries the rolling separable kernels take: Sobel/Scharr 8U->16S (ksize 3, 5, Scharr; every dx/dy order the
+    int16 range check admits) and the normalised 8U box filter (3, 5, 7; cn 1, 3, 4); bit-exact."""
+    for (w, h) in [(16, 1), (32, 2), (64, 23), (1040, 37), (2064, 70)]:
+        src = rnd((h, w), np.uint8, w + h)
+        for border in (0, 1, 2, 4):
+            for ksize, orders in [(3, [(1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]), (5, [(1, 0), (0, 1), (1, 1), (2, 0)]), (-1, [(1, 0), (0, 1)])]:
+                for dx, dy in orders:
+                    check(cv.Sobel(dev(src), cv.CV_16S, dx, dy, ksize, 1.0, 0.0, border), orc.orc_Sobel(src, 3, dx, dy, ksize, 1.0, 0.0, border))
+        for cn in (1, 3, 4):
+            if w * cn % 16:
+                continue
+            srcc = rnd((h, w, cn) if cn > 1 else (h, w), np.uint8, w + cn)
+            for k in (3, 5, 7):
+                for border in (0, 1, 2, 4):
+                    check(cv.boxFilter(dev(srcc), -1, (k, k), (-1, -1), True, border), orc.orc_boxFilter(srcc, -1, (k, k), (-1, -1), True, border))
+    full = np.full((40, 64), 255, np.uint8)
+    for k in (3, 5, 7):
+        assert (cv.blur(dev(full), (k, k)).cpu().numpy() == 255).all()
+
+
 def test_boxfilter(cv, orc):
     for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, -1)]:
         src = rnd((31, 66, 3), dtype, 21)
