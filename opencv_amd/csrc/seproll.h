@@ -20,4 +20,9 @@ bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
 bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                     int W, int H, const int* kx, const int* ky, int n, int border, hipStream_t st);
 
+// u8 -> f32 (outBytes 4) or u8 -> u8 (outBytes 1) separable filter on the FLOAT path of cv::sepFilter2D / cv::Sobel:
+// n in {3,5}, cn == 1, centred anchors; symY as SepParams (1 symmetric, 2 antisymmetric pair form, 0 plain chain).
+bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st);
+
 } // namespace mi355

@@ -227,6 +227,73 @@ struct Deriv16 {
     }
 };
 
+// ---------------------------------------------------------------------------------- float separable filter, u8 -> f32 / u8
+// The float path of cv::sepFilter2D / cv::Sobel (RowFilter filter.simd.hpp:2386: r = k0*v0, r = fma(ki, vi, r);
+// SymmColumnFilter :2679-2751 in its symmetric / antisymmetric pair form, ColumnFilter :2640 as a plain chain), in that
+// association order.  Values are held as pairs (pixel i, pixel i+8) so that every multiply-add is a v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int K, int SYM, int OUTB_>
+struct SepF32 {
+    static constexpr int KX = K, KY = K, CN = 1, OUTB = OUTB_, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, 1>::HD;
+    struct Args { float kx[K], ky[K], delta; };
+    struct Inter { f32x2 h[8]; };
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
+    {
+        // window byte b (0 = first halo byte of dword 0): even bytes of dword d in E[d] (low half = byte 0, high = byte 2)
+        auto byteAt = [&](int b) -> float {
+            const uint32_t w = (b & 1) ? O[b >> 2] : E[b >> 2];
+            return (float)((b & 2) ? (w >> 16) : (w & 0xffffu));
+        };
+        f32x2 Q[8 + 2 * R];
+#pragma unroll
+        for (int m = 0; m < 8 + 2 * R; m++) { Q[m].x = byteAt(4 * HD - R + m); Q[m].y = byteAt(4 * HD - R + m + 8); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            f32x2 r = Q[i] * f32x2{a.kx[0], a.kx[0]};
+#pragma unroll
+            for (int t = 1; t < K; t++) r = __builtin_elementwise_fma(f32x2{a.kx[t], a.kx[t]}, Q[i + t], r);
+            o.h[i] = r;
+        }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4 * OUTB_])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };     // image row t of the window
+        f32x2 o[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f32x2 d2 = {a.delta, a.delta};
+            f32x2 s;
+            if (SYM == 1 || SYM == 2) {
+                s = SYM == 1 ? __builtin_elementwise_fma(f32x2{a.ky[R], a.ky[R]}, row(R).h[i], d2) : d2;
+#pragma unroll
+                for (int k = 1; k <= R; k++) {
+                    const f32x2 p = SYM == 1 ? row(R + k).h[i] + row(R - k).h[i] : row(R + k).h[i] - row(R - k).h[i];
+                    s = __builtin_elementwise_fma(f32x2{a.ky[R + k], a.ky[R + k]}, p, s);
+                }
+            } else {
+                s = __builtin_elementwise_fma(f32x2{a.ky[0], a.ky[0]}, row(0).h[i], d2);
+#pragma unroll
+                for (int j = 1; j < K; j++) s = __builtin_elementwise_fma(f32x2{a.ky[j], a.ky[j]}, row(j).h[i], s);
+            }
+            o[i] = s;
+        }
+        if (OUTB_ == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { out[i] = __float_as_uint(o[i].x); out[8 + i] = __float_as_uint(o[i].y); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[q] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {            // cvRound + saturate_cast<uchar>
+                out[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].x), i & 3, out[i >> 2]);
+                out[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].y), i & 3, out[2 + (i >> 2)]);
+            }
+        }
+    }
+};
+
 } // namespace
 
 namespace mi355 {
@@ -277,6 +344,21 @@ bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, s
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
     if (n == 3) DV(3); else DV(5);
 #undef DV
+    return true;
+}
+
+bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
+{
+    if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
+#define SF(K_, S_, O_) do { typedef SepF32<K_, S_, O_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st); } while (0)
+#define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)
+    if (n == 3) { if (outBytes == 4) SFS(3, 4); else SFS(3, 1); }
+    else        { if (outBytes == 4) SFS(5, 4); else SFS(5, 1); }
+#undef SFS
+#undef SF
     return true;
 }
 

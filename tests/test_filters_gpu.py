@@ -155,6 +155,16 @@ def test_sobel_box_rolling_path(cv, orc):
             for k in (3, 5, 7):
                 for border in (0, 1, 2, 4):
                     check(cv.boxFilter(dev(srcc), -1, (k, k), (-1, -1), True, border), orc.orc_boxFilter(srcc, -1, (k, k), (-1, -1), True, border))
+        # float path: Sobel 8U -> 32F with a scale (what cornerHarris asks for), sepFilter2D with non-smooth / unsymmetric taps
+        sc = 1.0 / (255.0 * 2 * 4)
+        for border in (0, 1, 2, 4):
+            for ksize, orders in [(3, [(1, 0), (0, 1), (1, 1)]), (5, [(1, 0), (0, 1), (2, 0)]), (-1, [(1, 0), (0, 1)])]:
+                for dx, dy in orders:
+                    check(cv.Sobel(dev(src), cv.CV_32F, dx, dy, ksize, sc, 0.0, border), orc.orc_Sobel(src, 5, dx, dy, ksize, sc, 0.0, border))
+            for kx, ky, dl in [([-1, 0, 1], [0.3, 0.4, 0.3], 0.0), ([0.1, 0.5, 0.2], [0.7, -0.1, 0.2], 3.5), ([0.1, 0.2, 0.4, 0.2, 0.1], [-2, -1, 0, 1, 2], 128.0),
+                               ([0.05, 0.1, 0.4, 0.3, 0.15], [0.3, 0.3, 0.2, 0.1, 0.1], 0.0)]:
+                check(cv.sepFilter2D(dev(src), -1, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, -1, kx, ky, (-1, -1), dl, border))
+                check(cv.sepFilter2D(dev(src), cv.CV_32F, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, 5, kx, ky, (-1, -1), dl, border))
     full = np.full((40, 64), 255, np.uint8)
     for k in (3, 5, 7):
         assert (cv.blur(dev(full), (k, k)).cpu().numpy() == 255).all()
