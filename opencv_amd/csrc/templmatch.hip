@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 using namespace mi355;
@@ -169,17 +170,49 @@ constexpr int MT_BM = 256, MT_BN = 128;        // outputs per workgroup: 4 waves
 constexpr int MT_PPITCH = 272;                 // LDS image patch pitch: 256 columns + 16 so that consecutive rows rotate the 16-B slot
 constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero bytes + 128 + 40 zero bytes
 
-__global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
+// ---------------------------------------------------------------------------------- common_matchTemplate
+struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW; double tmean[4], templNorm, templSum2, invArea; };
+
+// one result element of common_matchTemplate (templmatch.cpp:906-1029) for a single-channel window: num = the raw
+// correlation as float, s = window sum, q = window sum of squares
+__device__ __forceinline__ float tmNormOne(float corr, double s, double q, const NormArgs& a)
+{
+    if (a.allOne) return 1.f;
+    const int numType = (a.method == 2 || a.method == 3) ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
+    const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
+    double num = corr, t;
+    double wndMean2 = 0, wndSum2 = 0;
+    if (numType == 1) { wndMean2 = s * s; num -= s * a.tmean[0]; wndMean2 *= a.invArea; }
+    if (isNormed || numType == 2) {
+        wndSum2 = q;
+        if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
+    }
+    if (isNormed) {
+        double diff2 = wndSum2 - wndMean2; diff2 = diff2 > 0 ? diff2 : 0;
+        double lim = 10 * 1.1920928955078125e-7 * wndSum2; lim = lim > 0.5 ? 0.5 : lim;
+        t = diff2 <= lim ? 0 : sqrt(diff2) * a.templNorm;
+        if (fabs(num) < t) num /= t;
+        else if (fabs(num) < t * 1.125) num = num > 0 ? 1 : -1;
+        else num = a.method != 1 ? 0 : 1;
+    }
+    return (float)num;
+}
+
+// KS = 32-byte K steps covering tw + 31 columns.  Operands of template row r+1 are fetched from LDS into a second register set
+// while the 8*KS MFMAs of row r run (one wave per SIMD: nothing else would hide the LDS latency); the epilogue undoes the bias
+// and applies the method's normalisation in place of a separate pass over the result.
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ccorr_mfma_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
                                                        const uchar* __restrict__ tpl, size_t tstep, int tw, int th,
-                                                       const unsigned* __restrict__ wsum, size_t wframe, long long tplSum,
-                                                       float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
+                                                       const unsigned* __restrict__ w1, const unsigned* __restrict__ w2, size_t wframe, long long tplSum,
+                                                       float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, NormArgs na)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
     uchar* P = smem;                                             // (MT_BM + th - 1) x MT_PPITCH signed pixels
     const int prow = MT_BM + th - 1;
     uchar* T = smem + (size_t)prow * MT_PPITCH;                  // th x MT_TPITCH signed taps, zero padded
     img += (size_t)blockIdx.z * iframe;
-    wsum += (size_t)blockIdx.z * wframe;
+    w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
     const int X0 = blockIdx.x * MT_BN, Y0 = blockIdx.y * MT_BM;
     const int tid = threadIdx.x;
     // ---- stage: image patch as (p - 128), zero outside the image
@@ -214,11 +247,11 @@ __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__
 
     const int wave = tid >> 6, lane = tid & 63;
     const int m = lane & 31, h = lane >> 5;
-    const int KS = (tw + 31 + 31) / 32;                          // 32-byte K steps covering tw + 31 columns (<= 5)
+    constexpr int NA = KS + 3;                                   // 32-byte column blocks of the patch an N-strip of 4 tiles touches
     // B operand addressing: lane (n = m, half h), step ks reads template bytes [32ks + 16h - n, +16) -> LDS offset + 32
-    int bOff[5], bSh[5];
+    int bOff[KS], bSh[KS];
 #pragma unroll
-    for (int ks = 0; ks < 5; ks++) { const int o = 32 + 32 * ks + 16 * h - m; bOff[ks] = o & ~3; bSh[ks] = o & 3; }
+    for (int ks = 0; ks < KS; ks++) { const int o = 32 + 32 * ks + 16 * h - m; bOff[ks] = o & ~3; bSh[ks] = o & 3; }
     v16i acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -227,70 +260,100 @@ __global__ __launch_bounds__(256) void k_ccorr_mfma_i8(const uchar* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0;
 
+    // A wave owns two M-tiles: output rows R0+m and R0+32+m, R0 = Y0 + 64*wave.  Tile 0 with template row r and tile 1 with
+    // template row r-32 read the SAME image rows R0 + j + m, j = r: the A fragment of image-row offset j is fetched once and
+    // feeds both (LDS reads of A were the bottleneck: 84 % of the LDS time, which equalled the MFMA time).  j runs over
+    // [0, th+32): tile 0 is active for j < th, tile 1 for j >= 32.
+    // The B fragments are kept as the five raw dwords per K step and byte-aligned only when consumed: aligning right after the
+    // load parks the wave on s_waitcnt for every template row (measured: 54 % of the wave cycles).
+    struct Frag { v4i A[NA]; unsigned R0[KS][5]; unsigned R1[KS][5]; };
     const uchar* Pw = P + (size_t)(wave * 64 + m) * MT_PPITCH + 16 * h;
-    for (int r = 0; r < th; r++) {
+    auto loadRaw = [&](unsigned (&R)[KS][5], int r) {
         const uchar* Tr = T + (size_t)r * MT_TPITCH;
-        v4i B[5];
 #pragma unroll
-        for (int ks = 0; ks < 5; ks++) {
-            if (ks < KS) {
-                const unsigned* tp = reinterpret_cast<const unsigned*>(Tr + bOff[ks]);
-                const unsigned d0 = tp[0], d1 = tp[1], d2 = tp[2], d3 = tp[3], d4 = tp[4];
-                B[ks].x = (int)__builtin_amdgcn_alignbyte(d1, d0, bSh[ks]);
-                B[ks].y = (int)__builtin_amdgcn_alignbyte(d2, d1, bSh[ks]);
-                B[ks].z = (int)__builtin_amdgcn_alignbyte(d3, d2, bSh[ks]);
-                B[ks].w = (int)__builtin_amdgcn_alignbyte(d4, d3, bSh[ks]);
-            } else B[ks] = v4i{0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ks++) {
+            const unsigned* tp = reinterpret_cast<const unsigned*>(Tr + bOff[ks]);
+#pragma unroll
+            for (int d = 0; d < 5; d++) R[ks][d] = tp[d];
         }
-        v4i A[2][8];
+    };
+    auto alignB = [&](const unsigned (&R)[5], int sh) -> v4i {
+        v4i B;
+        B.x = (int)__builtin_amdgcn_alignbyte(R[1], R[0], sh); B.y = (int)__builtin_amdgcn_alignbyte(R[2], R[1], sh);
+        B.z = (int)__builtin_amdgcn_alignbyte(R[3], R[2], sh); B.w = (int)__builtin_amdgcn_alignbyte(R[4], R[3], sh);
+        return B;
+    };
+#define TM_LOAD(F, T0_, T1_, J) do { const int j_ = (J); \
+        _Pragma("unroll") for (int cb = 0; cb < NA; cb++) (F).A[cb] = *reinterpret_cast<const v4i*>(Pw + (size_t)j_ * MT_PPITCH + 32 * cb); \
+        if (T0_) loadRaw((F).R0, j_); if (T1_) loadRaw((F).R1, j_ - 32); } while (0)
+#define TM_MFMA(F, T0_, T1_) do { \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) { \
+            v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}; \
+            if (T0_) b0 = alignB((F).R0[ks], bSh[ks]); if (T1_) b1 = alignB((F).R1[ks], bSh[ks]); \
+            _Pragma("unroll") for (int nt = 0; nt < 4; nt++) { \
+                if (T0_) acc[0][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8((F).A[nt + ks], b0, acc[0][nt], 0, 0, 0); \
+                if (T1_) acc[1][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8((F).A[nt + ks], b1, acc[1][nt], 0, 0, 0); } } } while (0)
+    // issue order inside one half-iteration (loads of the next fragment + MFMAs of the current one): per K step the byte
+    // alignment of its B operands, then its MFMAs with one LDS read slotted after every second (both tiles) / every (one tile)
+    // MFMA, so that the LDS queue (15 outstanding) never blocks the issue of matrix instructions
+#define TM_SCHED(T0_, T1_) do { \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) { \
+            __builtin_amdgcn_sched_group_barrier(0x002, ((T0_) && (T1_)) ? 8 : 4, 0); \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { \
+                __builtin_amdgcn_sched_group_barrier(0x008, ((T0_) && (T1_)) ? 2 : 1, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } } } while (0)
+    // one phase = a run of j with the same set of active tiles; fragments of j+1 are fetched while the MFMAs of j run
+#define TM_PHASE(T0_, T1_, JB, JE) do { const int jb_ = (JB), je_ = (JE); \
+        if (jb_ < je_) { Frag F0, F1; TM_LOAD(F0, T0_, T1_, jb_); int j = jb_; \
+            for (; j + 2 <= je_; j += 2) { \
+                TM_LOAD(F1, T0_, T1_, j + 1); TM_MFMA(F0, T0_, T1_); TM_SCHED(T0_, T1_); __builtin_amdgcn_sched_barrier(0); \
+                TM_LOAD(F0, T0_, T1_, min(j + 2, je_ - 1)); TM_MFMA(F1, T0_, T1_); TM_SCHED(T0_, T1_); __builtin_amdgcn_sched_barrier(0); } \
+            if (j < je_) TM_MFMA(F0, T0_, T1_); } } while (0)
+    TM_PHASE(true, false, 0, min(th, 32));
+    TM_PHASE(true, true, 32, th);
+    TM_PHASE(false, true, max(th, 32), th + 32);
+#undef TM_SCHED
+#undef TM_PHASE
+#undef TM_MFMA
+#undef TM_LOAD
+    // ---- epilogue: the accumulators go through LDS (the patch is no longer needed) so that the window sums are read and the
+    // result written as whole 512-byte rows; bias undone exactly, then the method's normalisation
+    const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
+    const bool needQ = na.method != 2 && na.method != 4;
+    int* E = reinterpret_cast<int*>(smem);                         // 128 rows (4 waves x 32) x 128 columns
+    uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < 2; mt++) {
+        __syncthreads();
 #pragma unroll
-            for (int cb = 0; cb < 8; cb++)
-                A[mt][cb] = *reinterpret_cast<const v4i*>(Pw + (size_t)(32 * mt + r) * MT_PPITCH + 32 * cb);
+        for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-        for (int ks = 0; ks < 5; ks++) {
-            if (ks < KS) {
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[mt][nt + ks], B[ks], acc[mt][nt], 0, 0, 0);
+            for (int i = 0; i < 16; i++)
+                E[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * MT_BN + 32 * nt + m] = acc[mt][nt][i];
+        __syncthreads();
+        for (int idx = tid; idx < 128 * MT_BN; idx += 256) {
+            const int row = idx / MT_BN, col = idx - row * MT_BN;
+            const int y = Y0 + (row >> 5) * 64 + 32 * mt + (row & 31), x = X0 + col;
+            if (x < rw && y < rh) {
+                const unsigned ws = w1[(size_t)y * rw + x];
+                const long long corr = (long long)E[idx] + 128LL * (long long)ws + cst;
+                float v = (float)(double)corr;
+                if (na.method != 2) v = tmNormOne(v, (double)ws, needQ ? (double)w2[(size_t)y * rw + x] : 0.0, na);
+                reinterpret_cast<float*>(rbase + (size_t)y * rstep)[x] = v;
             }
         }
     }
-    // ---- epilogue: undo the bias with the window sums, store float(corr)
-    const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const int x = X0 + 32 * nt + m;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int y = Y0 + wave * 64 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (x < rw && y < rh) {
-                    const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)wsum[(size_t)y * rw + x] + cst;
-                    reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep)[x] = (float)(double)corr;
-                }
-            }
-        }
 }
 
-// ---------------------------------------------------------------------------------- common_matchTemplate
-struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW; double tmean[4], templNorm, templSum2, invArea; };
-
 __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, size_t rstep, size_t rframe,
-                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe,
-                                                      const unsigned* __restrict__ w1, const unsigned* __restrict__ w2, size_t wframe, NormArgs a)
+                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, NormArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.rw || y >= a.rh) return;
     float* rrow = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep);
     if (a.allOne) { rrow[x] = 1.f; return; }
-    if (a.useW) { w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe; }
-    else { sum += (size_t)blockIdx.z * iframe; sq += (size_t)blockIdx.z * iframe; }
+    sum += (size_t)blockIdx.z * iframe; sq += (size_t)blockIdx.z * iframe;
     const int numType = (a.method == 2 || a.method == 3) ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
     const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
     const int cn = a.cn;
@@ -299,13 +362,13 @@ __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, s
     double wndMean2 = 0, wndSum2 = 0;
     if (numType == 1) {
         for (int k = 0; k < cn; k++) {
-            t = a.useW ? (double)w1[(size_t)y * a.rw + x] : sum[i0 + k] - sum[i1 + k] - sum[i2 + k] + sum[i3 + k];
+            t = sum[i0 + k] - sum[i1 + k] - sum[i2 + k] + sum[i3 + k];
             wndMean2 += t * t; num -= t * a.tmean[k];
         }
         wndMean2 *= a.invArea;
     }
     if (isNormed || numType == 2) {
-        for (int k = 0; k < cn; k++) { t = a.useW ? (double)w2[(size_t)y * a.rw + x] : sq[i0 + k] - sq[i1 + k] - sq[i2 + k] + sq[i3 + k]; wndSum2 += t; }
+        for (int k = 0; k < cn; k++) { t = sq[i0 + k] - sq[i1 + k] - sq[i2 + k] + sq[i3 + k]; wndSum2 += t; }
         if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
     }
     if (isNormed) {
@@ -397,18 +460,20 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     }
     if (useMfma) {
         const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
-        static bool attrSet = false;
-        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
         dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), nframes);
-        hipLaunchKernelGGL(k_ccorr_mfma_i8, grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, w1, wframe, tplSum,
-                           reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
+#define MFMA_LAUNCH(KS_) do { static bool attrSet = false; \
+        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; } \
+        hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, w1, w2, wframe, tplSum, \
+                           reinterpret_cast<float*>(dr), drs, rframe, rw, rh, na); } while (0)
+        switch ((tw + 62) / 32) { case 1: MFMA_LAUNCH(1); break; case 2: MFMA_LAUNCH(2); break; case 3: MFMA_LAUNCH(3); break; case 4: MFMA_LAUNCH(4); break; default: MFMA_LAUNCH(5); }
+#undef MFMA_LAUNCH
     } else {
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
         hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
-    }
-    if (method != 2) {
-        dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
-        hipLaunchKernelGGL(k_tm_normalize, grid, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, w1, w2, wframe, na);
+        if (method != 2) {
+            dim3 g2(divUp(rw, 64), divUp(rh, 4), nframes);
+            hipLaunchKernelGGL(k_tm_normalize, g2, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, na);
+        }
     }
     return stg.finish(entry);
 }
