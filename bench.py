@@ -69,6 +69,57 @@ def cpu_baseline(budget_s=12.0):
             "sample": f"{n} x oracle C restatement on a 960x540 crop, 1 thread, {dt:.1f} s"}
 
 
+def other_configs(with_cpu=True):
+    """BASELINE.json configs 2-5 on this GPU (tools/bench_configs.py: HIP-event times, algorithmic bytes / flops) with the
+    reference's CPU path timed beside them on the host cores (rank 0, N=1 only; reported, never part of `value`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    rows = bench_configs.run(quick=True)
+    if not with_cpu:
+        return rows
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    if orc.load_ref() is None:
+        return rows
+    rng = np.random.default_rng(809564)
+
+    def t(fn, reps=2):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    cpu = {}
+    bgr = rng.integers(0, 256, (H4K, W4K, 3), dtype=np.uint8)
+    gray = orc.ref_cvtColor(bgr, 6, 1)
+    cpu["cfg2a"] = t(lambda: orc.ref_cvtColor(bgr, 6, 1))
+    k = np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32)
+    cpu["cfg2c"] = t(lambda: orc.ref_filter2D(gray, -1, k))
+    f8k = rng.random((4320, 7680), dtype=np.float32)
+    cpu["cfg3a"] = t(lambda: orc.ref_resize(f8k, (5120, 2880)))
+    cpu["cfg3b"] = t(lambda: orc.ref_resize(f8k, (3840, 2160)))
+    M = orc.ref_getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95)
+    cpu["cfg3c"] = t(lambda: orc.ref_warpAffine(f8k, M, (7680, 4320), 1, 0, 0.0))
+    hd = np.ascontiguousarray(gray[:1080, :1920])
+    cpu["cfg4a"] = t(lambda: orc.ref_cornerHarris(hd, 2, 3, 0.04))
+
+    def pyr():
+        l = hd
+        for _ in range(4):
+            l = orc.ref_pyrDown(l)
+    cpu["cfg4b"] = t(pyr)
+    tpl = rng.integers(0, 256, (128, 128), dtype=np.uint8)
+    cpu["cfg5"] = t(lambda: orc.ref_matchTemplate(gray, tpl, 3), reps=1)
+    for r in rows:
+        key = r["config"].split()[0]
+        if key in cpu:
+            r["cpu_reference_ms_per_frame"] = round(cpu[key], 3)
+            if "frames" in r and "ms" in r:
+                r["gpu_ms_per_frame"] = round(r["ms"] / r["frames"], 4)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +128,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "128")),
                     help="4K frames per GPU per step (in+out = 2 x 8.29 MB x batch, far beyond the 256 MB LLC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs at N=1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,6 +219,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_other_configs:
+            del frames, out
+            torch.cuda.empty_cache()
+            try:
+                res["other_configs"] = other_configs(with_cpu=not args.no_cpu_baseline)
+            except Exception as e:                           # never let the secondary numbers take the headline down
+                res["other_configs"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,100 @@
+// mi355cv_cv.hpp -- cv::-identical C++ signatures for the hot-path functions that have NO imgproc HAL hook
+// (SURVEY.md §8b): cornerHarris, cornerMinEigenVal, goodFeaturesToTrack, buildPyramid, matchTemplate.  Header-only glue over
+// the C ABI of mi355cv.h: each wrapper calls the fused MI355X entry point and falls back to the stock cv:: function when the
+// library declines (unsupported arguments, no gfx950 device, MI355CV_DISABLE=1), exactly as a HAL hook returning
+// CV_HAL_ERROR_NOT_IMPLEMENTED would.  A call site switches by replacing `cv::` with `mi355cv::`.
+//
+//   reference signatures: imgproc.hpp  cornerHarris :1925, cornerMinEigenVal :1895, goodFeaturesToTrack :2077 / :2106,
+//                         buildPyramid :3308 (pyramids.cpp:1616), matchTemplate :3897 (templmatch.cpp:1158)
+#pragma once
+#include <vector>
+#include "opencv2/core.hpp"
+#include "opencv2/imgproc.hpp"
+#include "mi355cv.h"
+
+namespace mi355cv {
+
+inline void cornerHarris(cv::InputArray _src, cv::OutputArray _dst, int blockSize, int ksize, double k, int borderType = cv::BORDER_DEFAULT)
+{
+    cv::Mat src = _src.getMat();
+    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1)) {
+        _dst.create(src.size(), CV_32FC1);
+        cv::Mat dst = _dst.getMat();
+        if (mi355cv_cornerHarris(src.data, src.step, dst.data, dst.step, src.cols, src.rows, src.type(), blockSize, ksize, k, borderType) == MI355CV_OK)
+            return;
+    }
+    cv::cornerHarris(_src, _dst, blockSize, ksize, k, borderType);
+}
+
+inline void cornerMinEigenVal(cv::InputArray _src, cv::OutputArray _dst, int blockSize, int ksize = 3, int borderType = cv::BORDER_DEFAULT)
+{
+    cv::Mat src = _src.getMat();
+    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1)) {
+        _dst.create(src.size(), CV_32FC1);
+        cv::Mat dst = _dst.getMat();
+        if (mi355cv_cornerMinEigenVal(src.data, src.step, dst.data, dst.step, src.cols, src.rows, src.type(), blockSize, ksize, borderType) == MI355CV_OK)
+            return;
+    }
+    cv::cornerMinEigenVal(_src, _dst, blockSize, ksize, borderType);
+}
+
+inline void goodFeaturesToTrack(cv::InputArray _image, cv::OutputArray _corners, int maxCorners, double qualityLevel, double minDistance,
+                                cv::InputArray _mask = cv::noArray(), int blockSize = 3, int gradientSize = 3,
+                                bool useHarrisDetector = false, double k = 0.04)
+{
+    cv::Mat image = _image.getMat(), mask = _mask.empty() ? cv::Mat() : _mask.getMat();
+    const bool maskOk = mask.empty() || (mask.type() == CV_8UC1 && mask.size() == image.size());
+    if (image.dims <= 2 && (image.type() == CV_8UC1 || image.type() == CV_32FC1) && maskOk && qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0) {
+        // the entry point writes at most `cap` corners; with maxCorners <= 0 the reference returns every one it finds
+        const int cap = maxCorners > 0 ? maxCorners : image.rows * image.cols;
+        std::vector<cv::Point2f> pts((size_t)cap);
+        const int n = mi355cv_goodFeaturesToTrack(image.data, image.step, image.cols, image.rows, image.type(),
+                                                  cap ? reinterpret_cast<float*>(pts.data()) : nullptr, nullptr, maxCorners, qualityLevel, minDistance,
+                                                  mask.empty() ? nullptr : mask.data, mask.empty() ? 0 : (size_t)mask.step,
+                                                  blockSize, gradientSize, useHarrisDetector ? 1 : 0, k);
+        if (n >= 0) {
+            pts.resize((size_t)n);
+            cv::Mat(pts).convertTo(_corners, _corners.fixedType() ? _corners.type() : CV_32F);      // featureselect.cpp:470
+            return;
+        }
+    }
+    cv::goodFeaturesToTrack(_image, _corners, maxCorners, qualityLevel, minDistance, _mask, blockSize, gradientSize, useHarrisDetector, k);
+}
+
+inline void buildPyramid(cv::InputArray _src, cv::OutputArrayOfArrays _dst, int maxlevel, int borderType = cv::BORDER_DEFAULT)
+{
+    cv::Mat src = _src.getMat();
+    if (src.dims <= 2 && maxlevel >= 0 && maxlevel <= 30 && borderType != cv::BORDER_CONSTANT && !_dst.isUMatVector()) {
+        _dst.create(maxlevel + 1, 1, 0);
+        _dst.getMatRef(0) = src;                                          // level 0 is the source itself (pyramids.cpp:1634)
+        std::vector<uchar*> ptr((size_t)maxlevel);
+        std::vector<size_t> step((size_t)maxlevel);
+        cv::Size sz = src.size();
+        for (int i = 1; i <= maxlevel; i++) {
+            sz = cv::Size((sz.width + 1) / 2, (sz.height + 1) / 2);
+            _dst.create(sz, src.type(), i);
+            cv::Mat& m = _dst.getMatRef(i);
+            ptr[(size_t)i - 1] = m.data; step[(size_t)i - 1] = m.step;
+        }
+        if (maxlevel == 0 ||
+            mi355cv_buildPyramid(src.data, src.step, src.cols, src.rows, src.depth(), src.channels(), ptr.data(), step.data(), maxlevel, borderType) == MI355CV_OK)
+            return;
+    }
+    cv::buildPyramid(_src, _dst, maxlevel, borderType);
+}
+
+inline void matchTemplate(cv::InputArray _image, cv::InputArray _templ, cv::OutputArray _result, int method, cv::InputArray _mask = cv::noArray())
+{
+    cv::Mat image = _image.getMat(), templ = _templ.getMat();
+    if (_mask.empty() && image.dims <= 2 && image.type() == templ.type() && (image.depth() == CV_8U || image.depth() == CV_32F) &&
+        image.cols >= templ.cols && image.rows >= templ.rows && method >= cv::TM_SQDIFF && method <= cv::TM_CCOEFF_NORMED) {
+        _result.create(image.rows - templ.rows + 1, image.cols - templ.cols + 1, CV_32FC1);
+        cv::Mat result = _result.getMat();
+        if (mi355cv_matchTemplate(image.data, image.step, image.cols, image.rows, templ.data, templ.step, templ.cols, templ.rows, image.type(),
+                                  result.data, result.step, method) == MI355CV_OK)
+            return;
+    }
+    cv::matchTemplate(_image, _templ, _result, method, _mask);
+}
+
+} // namespace mi355cv

@@ -1,0 +1,48 @@
+// cvwrap_shim.cpp -- part of the `hal` build only: instantiates include/mi355cv_cv.hpp (the cv::-signature wrappers of the
+// functions without a HAL hook) against the reference's own headers and exposes them to the tests through a C facade, so that
+// the header is compiled and exercised, not just shipped.
+#include "mi355cv_cv.hpp"
+#include <cstdio>
+#include <cstring>
+using namespace cv;
+
+static Mat M(const void* p, size_t step, int w, int h, int type) { return Mat(h, w, type, const_cast<void*>(p), step); }
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+EXPORT int wrap_cornerHarris(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int blockSize, int ksize, double k, int borderType)
+{
+    try { Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, CV_32FC1); const uchar* p = dst.data;
+          mi355cv::cornerHarris(src, dst, blockSize, ksize, k, borderType); return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+EXPORT int wrap_cornerMinEigenVal(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype, int blockSize, int ksize, int borderType)
+{
+    try { Mat src = M(s, ss, w, h, stype), dst = M(d, ds, w, h, CV_32FC1); const uchar* p = dst.data;
+          mi355cv::cornerMinEigenVal(src, dst, blockSize, ksize, borderType); return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+EXPORT int wrap_goodFeaturesToTrack(const void* s, size_t ss, int w, int h, int stype, float* corners, int maxCorners, double qualityLevel,
+                                    double minDistance, int blockSize, int gradientSize, int useHarris, double k)
+{
+    try { Mat src = M(s, ss, w, h, stype); std::vector<Point2f> pts;
+          mi355cv::goodFeaturesToTrack(src, pts, maxCorners, qualityLevel, minDistance, noArray(), blockSize, gradientSize, useHarris != 0, k);
+          for (size_t i = 0; i < pts.size(); i++) { corners[2 * i] = pts[i].x; corners[2 * i + 1] = pts[i].y; }
+          return (int)pts.size(); }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+// levels 1..maxlevel are copied into the caller's buffers (tightly packed, level i at out[i-1])
+EXPORT int wrap_buildPyramid(const void* s, size_t ss, int w, int h, int type, void** out, int maxlevel, int borderType)
+{
+    try { Mat src = M(s, ss, w, h, type); std::vector<Mat> pyr;
+          mi355cv::buildPyramid(src, pyr, maxlevel, borderType);
+          if ((int)pyr.size() != maxlevel + 1) return -2;
+          for (int i = 1; i <= maxlevel; i++) { Mat dst(pyr[i].rows, pyr[i].cols, type, out[i - 1]); pyr[i].copyTo(dst); }
+          return 0; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+EXPORT int wrap_matchTemplate(const void* img, size_t is, int iw, int ih, const void* t, size_t ts, int tw, int th, int type, void* res, size_t rs, int method)
+{
+    try { Mat I = M(img, is, iw, ih, type), T = M(t, ts, tw, th, type), R = M(res, rs, iw - tw + 1, ih - th + 1, CV_32FC1); const uchar* p = R.data;
+          mi355cv::matchTemplate(I, T, R, method); return R.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}

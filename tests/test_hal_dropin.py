@@ -82,3 +82,78 @@ def test_reference_runs_on_the_gpu(ref):
     _compare(plain, through)
     for n in names:
         assert cv.call_count(n) > before[n], f"cv_hal_{n} was not served by the GPU"
+
+
+# ----------------------------------------------------------------------------- include/mi355cv_cv.hpp (functions without a HAL hook)
+def _wrap_calls(hal, src8):
+    """mi355cv::cornerHarris / cornerMinEigenVal / goodFeaturesToTrack / buildPyramid / matchTemplate (cv:: signatures),
+    compiled against the reference's headers into libocvref_hal.so (oracle/ref/cvwrap_shim.cpp)"""
+    import ctypes
+    c_int, c_sz, c_dbl, vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p
+    h, w = src8.shape
+    out = {}
+    d = np.empty((h, w), np.float32)
+    assert hal.wrap_cornerHarris(O.P(src8), O.step(src8), O.P(d), O.step(d), w, h, 0, 2, 3, c_dbl(0.04), 4) == 0
+    out["harris"] = d.copy()
+    assert hal.wrap_cornerMinEigenVal(O.P(src8), O.step(src8), O.P(d), O.step(d), w, h, 0, 3, 3, 4) == 0
+    out["mineig"] = d.copy()
+    pts = np.zeros((200, 2), np.float32)
+    n = hal.wrap_goodFeaturesToTrack(O.P(src8), O.step(src8), w, h, 0, pts.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 50,
+                                     c_dbl(0.01), c_dbl(5.0), 3, 3, 0, c_dbl(0.04))
+    assert n > 0
+    out["gftt"] = pts[:n].copy()
+    lv, sz = [], (w, h)
+    for _ in range(3):
+        sz = ((sz[0] + 1) // 2, (sz[1] + 1) // 2)
+        lv.append(np.empty((sz[1], sz[0]), np.uint8))
+    arr = (vp * 3)(*[l.ctypes.data for l in lv])
+    assert hal.wrap_buildPyramid(O.P(src8), O.step(src8), w, h, 0, arr, 3, 4) == 0
+    for i, l in enumerate(lv):
+        out[f"pyr{i + 1}"] = l
+    tpl = np.ascontiguousarray(src8[10:26, 20:52])
+    r = np.empty((h - 16 + 1, w - 32 + 1), np.float32)
+    assert hal.wrap_matchTemplate(O.P(src8), O.step(src8), w, h, O.P(tpl), O.step(tpl), 32, 16, 0, O.P(r), O.step(r), 5) == 0
+    out["mt"] = r
+    return out
+
+
+def _wrap_expected(src8):
+    exp = {"harris": O.ref_cornerHarris(src8, 2, 3, 0.04), "mineig": O.ref_cornerMinEigenVal(src8, 3, 3),
+           "gftt": O.ref_goodFeaturesToTrack(src8, 50, 0.01, 5.0, 3, 3, False, 0.04),
+           "mt": O.ref_matchTemplate(src8, np.ascontiguousarray(src8[10:26, 20:52]), 5)}
+    l = src8
+    for i in range(3):
+        l = O.ref_pyrDown(l)
+        exp[f"pyr{i + 1}"] = l
+    return exp
+
+
+def test_cv_signature_wrappers_fall_back_without_gpu(ref):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see test_cv_signature_wrappers_on_the_gpu")
+    hal = O.load_ref_hal()
+    if hal is None or not hasattr(hal, "wrap_cornerHarris"):
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    src8, _, _ = _inputs()
+    got, exp = _wrap_calls(hal, src8), _wrap_expected(src8)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k                       # the stock cv:: code ran
+
+
+@pytest.mark.gpu
+def test_cv_signature_wrappers_on_the_gpu(ref):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None and hasattr(hal, "wrap_cornerHarris"), "oracle/_ref/libocvref_hal.so missing or stale"
+    src8, _, _ = _inputs()
+    names = ["cornerHarris", "cornerMinEigenVal", "goodFeaturesToTrack", "buildPyramid", "matchTemplate"]
+    before = {n: cv.call_count(n) for n in names}
+    got, exp = _wrap_calls(hal, src8), _wrap_expected(src8)
+    for n in names:
+        assert cv.call_count(n) > before[n], f"mi355cv::{n} was not served by the GPU"
+    for k in ("harris", "mineig", "mt"):
+        assert O.rel_err(got[k], exp[k]) <= 1e-4, k
+    for k in ("pyr1", "pyr2", "pyr3"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert got["gftt"].shape == exp["gftt"].shape and set(map(tuple, got["gftt"])) == set(map(tuple, exp["gftt"]))
