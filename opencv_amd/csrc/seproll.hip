@@ -12,15 +12,16 @@ using namespace mi355;
 namespace {
 
 // Policy interface:
-//   KX, KY, CN            taps and channels;  OUTB = bytes per output element (1 or 2)
+//   KX, KY, CN, CB        taps, channels, source bytes per lane (16, or 8 when the outputs are 32-bit: a lane then writes
+//                         32 contiguous bytes);  OUTB = bytes per output element
 //   Args                  kernel parameters (by value)
 //   hpass(Inter&, E, O, args)                 one row's intermediates from the byte planes of its window
 //   vpass<UP>(ring, u, args, out[MD*OUTB])    output dwords of the lane from the KY ring rows; ring[(u + j) % KY] is the
 //                                             j-th row in WALKING order (image order reversed when UP)
 template <class P, bool UP>
-__device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN>& cx, uchar* __restrict__ dst, size_t dstep, const typename P::Args& a)
+__device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB>& cx, uchar* __restrict__ dst, size_t dstep, const typename P::Args& a)
 {
-    typedef roll::Ctx<P::KX / 2, P::KY / 2, P::CN> Cx;
+    typedef roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB> Cx;
     typedef typename Cx::RawT RawT;
     constexpr int KY = P::KY, RY = KY / 2, NW = Cx::NW, MD = Cx::MD, OD = MD * P::OUTB;
     typename P::Inter ring[KY];
@@ -51,7 +52,7 @@ __device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN>& 
                 P::template vpass<UP>(ring, u, a, o);
                 if (cx.active) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + 16 * P::OUTB * (size_t)cx.c);
+                    u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + P::CB * P::OUTB * (size_t)cx.c);
 #pragma unroll
                     for (int q = 0; q < OD / 4; q++) __builtin_nontemporal_store(u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}, out + q);
                 }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_sep_roll(const uchar* __restrict__ src,
                                                   int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
                                                   typename P::Args a)
 {
-    roll::Ctx<P::KX / 2, P::KY / 2, P::CN> cx;
+    roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB> cx;
     if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
     dst += (size_t)cx.frame * dframe;
     if (cx.up) sepRows<P, true>(cx, dst, dstep, a);
@@ -76,7 +77,7 @@ template <class P>
 void launchSep(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int border,
                int bestSeg, const typename P::Args& a, hipStream_t st)
 {
-    const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY);
+    const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY, P::CB);
     hipLaunchKernelGGL((k_sep_roll<P>), dim3(g.blocks), dim3(256), 0, st, src, sstep, sframe, dst, dstep, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg,
                        nframes, border, 1, a);
 }
@@ -95,7 +96,7 @@ __device__ __forceinline__ uint32_t packB2(uint32_t b0, uint32_t b1, uint32_t b2
 // 16-bit lanes cannot carry into each other); vertical: one v_dot2_u32_u16 per tap and pixel with (ky, 0) / (0, ky) operands.
 template <int K, int CN_>
 struct FixedSmooth {
-    static constexpr int KX = K, KY = K, CN = CN_, OUTB = 1, R = K / 2;
+    static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t kx[K]; uint32_t kyLo[K], kyHi[K]; };
     struct Inter { uint32_t e[4], o[4]; };
@@ -155,7 +156,7 @@ __device__ __forceinline__ uint32_t packB3(uint32_t b0, uint32_t b1, uint32_t b2
 // pixel with 2*ds, so that the quotient lands in byte 3: ((s + dd) * ds) >> 23 == (s * 2ds + 2*dd*ds) >> 24, all < 2^32.
 template <int K, int CN_>
 struct BoxU8 {
-    static constexpr int KX = K, KY = K, CN = CN_, OUTB = 1, R = K / 2;
+    static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t ds2, c2; };
     struct Inter { uint32_t e[4], o[4]; };
@@ -191,7 +192,7 @@ struct BoxU8 {
 // passes run as packed 16-bit multiply-adds (v_pk_mad_i16 / v_pk_mul_lo_u16) on the byte planes.
 template <int K>
 struct Deriv16 {
-    static constexpr int KX = K, KY = K, CN = 1, OUTB = 2, R = K / 2;
+    static constexpr int KX = K, KY = K, CN = 1, CB = 16, OUTB = 2, R = K / 2;
     static constexpr int HD = roll::Cfg<R, 1>::HD;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     struct Args { uint32_t kx[K], ky[K]; };              // taps splatted into both 16-bit halves
@@ -235,9 +236,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K, int SYM, int OUTB_>
 struct SepF32 {
     static constexpr int KX = K, KY = K, CN = 1, OUTB = OUTB_, R = K / 2;
-    static constexpr int HD = roll::Cfg<R, 1>::HD;
+    static constexpr int CB = OUTB_ == 4 ? 8 : 16;           // 32-bit outputs: 8 pixels per lane = 32 contiguous output bytes
+    static constexpr int NP = CB / 2;                        // pixel pairs (i, i + NP)
+    static constexpr int HD = roll::Cfg<R, 1, CB>::HD;
     struct Args { float kx[K], ky[K], delta; };
-    struct Inter { f32x2 h[8]; };
+    struct Inter { f32x2 h[NP]; };
     static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
     {
         // window byte b (0 = first halo byte of dword 0): even bytes of dword d in E[d] (low half = byte 0, high = byte 2)
@@ -245,11 +248,11 @@ struct SepF32 {
             const uint32_t w = (b & 1) ? O[b >> 2] : E[b >> 2];
             return (float)((b & 2) ? (w >> 16) : (w & 0xffffu));
         };
-        f32x2 Q[8 + 2 * R];
+        f32x2 Q[NP + 2 * R];
 #pragma unroll
-        for (int m = 0; m < 8 + 2 * R; m++) { Q[m].x = byteAt(4 * HD - R + m); Q[m].y = byteAt(4 * HD - R + m + 8); }
+        for (int m = 0; m < NP + 2 * R; m++) { Q[m].x = byteAt(4 * HD - R + m); Q[m].y = byteAt(4 * HD - R + m + NP); }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NP; i++) {
             f32x2 r = Q[i] * f32x2{a.kx[0], a.kx[0]};
 #pragma unroll
             for (int t = 1; t < K; t++) r = __builtin_elementwise_fma(f32x2{a.kx[t], a.kx[t]}, Q[i + t], r);
@@ -257,12 +260,12 @@ struct SepF32 {
         }
     }
     template <bool UP>
-    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4 * OUTB_])
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[(CB / 4) * OUTB_])
     {
         auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };     // image row t of the window
-        f32x2 o[8];
+        f32x2 o[NP];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NP; i++) {
             const f32x2 d2 = {a.delta, a.delta};
             f32x2 s;
             if (SYM == 1 || SYM == 2) {
@@ -281,14 +284,14 @@ struct SepF32 {
         }
         if (OUTB_ == 4) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { out[i] = __float_as_uint(o[i].x); out[8 + i] = __float_as_uint(o[i].y); }
+            for (int i = 0; i < NP; i++) { out[i] = __float_as_uint(o[i].x); out[NP + i] = __float_as_uint(o[i].y); }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) out[q] = 0;
+            for (int q = 0; q < CB / 4; q++) out[q] = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {            // cvRound + saturate_cast<uchar>
+            for (int i = 0; i < NP; i++) {            // cvRound + saturate_cast<uchar>
                 out[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].x), i & 3, out[i >> 2]);
-                out[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].y), i & 3, out[2 + (i >> 2)]);
+                out[NP / 4 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].y), i & 3, out[NP / 4 + (i >> 2)]);
             }
         }
     }
@@ -351,7 +354,7 @@ bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
                   int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
 {
     if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
 #define SF(K_, S_, O_) do { typedef SepF32<K_, S_, O_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st); } while (0)
 #define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)
