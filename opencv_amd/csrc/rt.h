@@ -20,6 +20,8 @@ enum { B_CONSTANT = 0, B_REPLICATE = 1, B_REFLECT = 2, B_WRAP = 3, B_REFLECT_101
 struct ThreadCtx;
 ThreadCtx& tctx();
 hipStream_t stream();
+hipStream_t auxStream();            // a second per-thread stream for work that may overlap the main one (ordered with events)
+hipEvent_t pooledEvent(int i);      // per-thread reusable events (timing disabled), i < 64
 bool asyncMode();
 bool disabled();                    // MI355CV_DISABLE=1 -> every hook answers NOT_IMPLEMENTED
 size_t minPixels();                 // MI355CV_MIN_PIXELS: host-resident images below this are declined

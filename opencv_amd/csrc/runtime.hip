@@ -22,6 +22,8 @@ struct Buf { void* p; size_t cap; bool busy; };
 struct ThreadCtx {
     hipStream_t own = nullptr;
     hipStream_t user = nullptr;
+    hipStream_t aux = nullptr;
+    hipEvent_t events[64] = {};
     bool useUser = false;
     bool async = false;
     std::vector<Buf> pool;
@@ -93,6 +95,21 @@ hipStream_t stream()
         if (hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking) != hipSuccess) c.own = nullptr;
     }
     return c.own;
+}
+
+hipStream_t auxStream()
+{
+    ThreadCtx& c = tctx();
+    if (!c.aux && hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking) != hipSuccess) c.aux = nullptr;
+    return c.aux;
+}
+
+hipEvent_t pooledEvent(int i)
+{
+    ThreadCtx& c = tctx();
+    if (i < 0 || i >= 64) return nullptr;
+    if (!c.events[i] && hipEventCreateWithFlags(&c.events[i], hipEventDisableTiming) != hipSuccess) c.events[i] = nullptr;
+    return c.events[i];
 }
 
 bool asyncMode() { return tctx().async; }

@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(256) void k_integral_cols(double* __restrict__ sum,
 __global__ __launch_bounds__(256) void k_wsum_rows(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int tw, int rw,
                                                    unsigned* __restrict__ s1, unsigned* __restrict__ q1, size_t sframe /* elements */)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned lw[];        // P[0..iw] and Q[0..iw]
-    unsigned* P = lw; unsigned* Q = lw + (iw + 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned lw[];        // prefix P[0..iw], used for the sums, then for the squares
+    unsigned* P = lw;                                                    // (15 KB for a 4K row: fits next to an MFMA workgroup's 130 KB)
     const int y = blockIdx.x;
     const uchar* row = img + (size_t)blockIdx.z * iframe + (size_t)y * istep;
     const int chunk = (iw + 255) / 256;
@@ -103,31 +104,56 @@ __global__ __launch_bounds__(256) void k_wsum_rows(const uchar* __restrict__ img
         __syncthreads();
     }
     unsigned ps = threadIdx.x ? ss[threadIdx.x - 1] : 0u, pq = threadIdx.x ? qq[threadIdx.x - 1] : 0u;
-    if (threadIdx.x == 0) { P[0] = 0; Q[0] = 0; }
-    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; ps += v; pq += v * v; P[x + 1] = ps; Q[x + 1] = pq; }
-    __syncthreads();
     unsigned* so = s1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
     unsigned* qo = q1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
-    for (int x = threadIdx.x; x < rw; x += 256) { so[x] = P[x + tw] - P[x]; qo[x] = Q[x + tw] - Q[x]; }
+    if (threadIdx.x == 0) P[0] = 0;
+    for (int x = x0; x < x1; x++) { ps += row[x]; P[x + 1] = ps; }
+    __syncthreads();
+    for (int x = threadIdx.x; x < rw; x += 256) so[x] = P[x + tw] - P[x];
+    __syncthreads();
+    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; pq += v * v; P[x + 1] = pq; }
+    __syncthreads();
+    for (int x = threadIdx.x; x < rw; x += 256) qo[x] = P[x + tw] - P[x];
 }
 
-constexpr int WS_CH = 64;
+constexpr int WS_CH = 128;
+// vertical window sums: one thread per column and chunk of WS_CH output rows; the loads of 8 rows are issued together (they do
+// not depend on the running sums), the sums then slide: + row (y+th-1), - row (y-1)
 __global__ __launch_bounds__(256) void k_wsum_cols(const unsigned* __restrict__ s1, const unsigned* __restrict__ q1, size_t sframe, int th, int rw, int rh,
                                                    unsigned* __restrict__ w1, unsigned* __restrict__ w2, size_t wframe)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= rw) return;
     const int y0 = blockIdx.y * WS_CH;
-    s1 += (size_t)blockIdx.z * sframe; q1 += (size_t)blockIdx.z * sframe;
-    w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
+    s1 += (size_t)blockIdx.z * sframe + x; q1 += (size_t)blockIdx.z * sframe + x;
+    w1 += (size_t)blockIdx.z * wframe + x; w2 += (size_t)blockIdx.z * wframe + x;
     unsigned s = 0, q = 0;
-    for (int r = 0; r < th; r++) { s += s1[(size_t)(y0 + r) * rw + x]; q += q1[(size_t)(y0 + r) * rw + x]; }
-    w1[(size_t)y0 * rw + x] = s; w2[(size_t)y0 * rw + x] = q;
+    int r = 0;
+    for (; r + 8 <= th; r += 8) {
+        unsigned a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u] = s1[(size_t)(y0 + r + u) * rw]; b[u] = q1[(size_t)(y0 + r + u) * rw]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s += a[u]; q += b[u]; }
+    }
+    for (; r < th; r++) { s += s1[(size_t)(y0 + r) * rw]; q += q1[(size_t)(y0 + r) * rw]; }
+    w1[(size_t)y0 * rw] = s; w2[(size_t)y0 * rw] = q;
     const int yend = min(rh, y0 + WS_CH);
-    for (int y = y0 + 1; y < yend; y++) {
-        s += s1[(size_t)(y + th - 1) * rw + x] - s1[(size_t)(y - 1) * rw + x];
-        q += q1[(size_t)(y + th - 1) * rw + x] - q1[(size_t)(y - 1) * rw + x];
-        w1[(size_t)y * rw + x] = s; w2[(size_t)y * rw + x] = q;
+    int y = y0 + 1;
+    for (; y + 8 <= yend; y += 8) {
+        unsigned a[8], b[8], c[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[u] = s1[(size_t)(y + u + th - 1) * rw]; b[u] = s1[(size_t)(y + u - 1) * rw];
+            c[u] = q1[(size_t)(y + u + th - 1) * rw]; d[u] = q1[(size_t)(y + u - 1) * rw];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s += a[u] - b[u]; q += c[u] - d[u]; w1[(size_t)(y + u) * rw] = s; w2[(size_t)(y + u) * rw] = q; }
+    }
+    for (; y < yend; y++) {
+        s += s1[(size_t)(y + th - 1) * rw] - s1[(size_t)(y - 1) * rw];
+        q += q1[(size_t)(y + th - 1) * rw] - q1[(size_t)(y - 1) * rw];
+        w1[(size_t)y * rw] = s; w2[(size_t)y * rw] = q;
     }
 }
 
@@ -173,76 +199,85 @@ constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero by
 // ---------------------------------------------------------------------------------- common_matchTemplate
 struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW; double tmean[4], templNorm, templSum2, invArea; };
 
-// one result element of common_matchTemplate (templmatch.cpp:906-1029) for a single-channel window: num = the raw
-// correlation as float, s = window sum, q = window sum of squares
+// one result element of common_matchTemplate (templmatch.cpp:906-1029) for a single-channel window: corr = the raw
+// correlation as float, s = window sum, q = window sum of squares.  Written without branches (every alternative is computed
+// and selected): inside the MFMA kernel's epilogue there is one wave per SIMD, so the only latency hiding available is the
+// interleaving of the 16 unrolled instances of this function, which basic-block boundaries would prevent.
 __device__ __forceinline__ float tmNormOne(float corr, double s, double q, const NormArgs& a)
 {
-    if (a.allOne) return 1.f;
     const int numType = (a.method == 2 || a.method == 3) ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
     const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
-    double num = corr, t;
-    double wndMean2 = 0, wndSum2 = 0;
-    if (numType == 1) { wndMean2 = s * s; num -= s * a.tmean[0]; wndMean2 *= a.invArea; }
-    if (isNormed || numType == 2) {
-        wndSum2 = q;
-        if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
-    }
-    if (isNormed) {
-        double diff2 = wndSum2 - wndMean2; diff2 = diff2 > 0 ? diff2 : 0;
-        double lim = 10 * 1.1920928955078125e-7 * wndSum2; lim = lim > 0.5 ? 0.5 : lim;
-        t = diff2 <= lim ? 0 : sqrt(diff2) * a.templNorm;
-        if (fabs(num) < t) num /= t;
-        else if (fabs(num) < t * 1.125) num = num > 0 ? 1 : -1;
-        else num = a.method != 1 ? 0 : 1;
-    }
-    return (float)num;
+    double num = corr;
+    const double wndMean2 = numType == 1 ? s * s * a.invArea : 0.0;
+    num = numType == 1 ? num - s * a.tmean[0] : num;
+    const double wndSum2 = (isNormed || numType == 2) ? q : 0.0;
+    const double sq = fmax(wndSum2 - 2 * num + a.templSum2, 0.0);
+    num = numType == 2 ? sq : num;
+    const double diff2 = fmax(wndSum2 - wndMean2, 0.0);
+    const double lim = fmin(10 * 1.1920928955078125e-7 * wndSum2, 0.5);
+    // hardware v_sqrt_f64 / v_rcp_f64 (~1e-15 relative) instead of the correctly rounded expansions: the value is rounded to
+    // float right after
+    const double t = diff2 <= lim ? 0.0 : __builtin_amdgcn_sqrt(diff2) * a.templNorm;
+    const double an = fabs(num);
+    const double clampv = an < t * 1.125 ? (num > 0 ? 1.0 : -1.0) : (a.method != 1 ? 0.0 : 1.0);
+    const double normed = an < t ? num * __builtin_amdgcn_rcp(t) : clampv;
+    num = isNormed ? normed : num;
+    return a.allOne ? 1.f : (float)num;
 }
 
 // KS = 32-byte K steps covering tw + 31 columns.  Operands of template row r+1 are fetched from LDS into a second register set
-// while the 8*KS MFMAs of row r run (one wave per SIMD: nothing else would hide the LDS latency); the epilogue undoes the bias
-// and applies the method's normalisation in place of a separate pass over the result.
+// while the 8*KS MFMAs of row r run (one wave per SIMD: nothing else would hide the LDS latency).  The kernel is pure matrix
+// work: it writes the raw int32 accumulators (correlation of the biased operands) into the result buffer; bias removal and
+// normalisation are the memory-bound k_tm_finish, which the host overlaps with the next frame's MFMA kernel on a second
+// stream (in-kernel they cost as much as the MFMA loop itself: 182k vs 197k clocks per workgroup, measured).
 template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ccorr_mfma_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
-                                                       const uchar* __restrict__ tpl, size_t tstep, int tw, int th,
-                                                       const unsigned* __restrict__ w1, const unsigned* __restrict__ w2, size_t wframe, long long tplSum,
-                                                       float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, NormArgs na)
+                                                       const uchar* __restrict__ tpl /* expanded: th x MT_TPITCH */, int tw, int th,
+                                                       int* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
     uchar* P = smem;                                             // (MT_BM + th - 1) x MT_PPITCH signed pixels
     const int prow = MT_BM + th - 1;
     uchar* T = smem + (size_t)prow * MT_PPITCH;                  // th x MT_TPITCH signed taps, zero padded
     img += (size_t)blockIdx.z * iframe;
-    w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
     const int X0 = blockIdx.x * MT_BN, Y0 = blockIdx.y * MT_BM;
     const int tid = threadIdx.x;
-    // ---- stage: image patch as (p - 128), zero outside the image
-    for (int i = tid; i < prow * (256 / 16); i += 256) {
-        const int ry = i >> 4, cb = i & 15;
-        const int yy = Y0 + ry, xx = X0 + cb * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (yy < ih) {
-            const uchar* g = img + (size_t)yy * istep + xx;
-            if (xx + 16 <= iw && ((((uintptr_t)g) & 15) == 0)) {
-                v = *reinterpret_cast<const uint4*>(g);
-                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-            } else {
-                unsigned w[4] = {0, 0, 0, 0};
-                for (int b = 0; b < 16; b++) if (xx + b < iw) w[b >> 2] |= (unsigned)(g[b] ^ 0x80) << (8 * (b & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+    // ---- stage: image patch as (p - 128), zero outside the image.  Loads are issued in batches of 8 per thread before any
+    // of them is consumed (one workgroup per CU: nothing else hides the global latency).
+    const bool fastPatch = X0 + 256 <= iw && ((((uintptr_t)img) | istep) & 15) == 0;
+    const int nP = prow * 16;
+    constexpr int SB = 12;                                       // loads in flight per thread (2 round trips for a 128-row template)
+    for (int i0 = 0; i0 < nP; i0 += 256 * SB) {
+        uint4 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int i = i0 + u * 256 + tid;
+            const int ry = i >> 4, cb = i & 15;
+            const int yy = Y0 + ry, xx = X0 + cb * 16;
+            v[u] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);       // becomes 0 after the bias flip
+            if (i < nP && yy < ih) {
+                const uchar* g = img + (size_t)yy * istep + xx;
+                if (fastPatch) v[u] = *reinterpret_cast<const uint4*>(g);
+                else {
+                    unsigned w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                    for (int b = 0; b < 16; b++) if (xx + b < iw) w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | ((unsigned)g[b] << (8 * (b & 3)));
+                    v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
             }
         }
-        *reinterpret_cast<uint4*>(P + (size_t)ry * MT_PPITCH + cb * 16) = v;
-    }
-    // ---- stage: template as (t - 128) with 32 zero bytes in front and zeros behind
-    for (int i = tid; i < th * (MT_TPITCH / 4); i += 256) {
-        const int r = i / (MT_TPITCH / 4), d = i - r * (MT_TPITCH / 4);
-        unsigned w = 0;
-        for (int b = 0; b < 4; b++) {
-            const int j = d * 4 + b - 32;
-            if (j >= 0 && j < tw) w |= (unsigned)(tpl[(size_t)r * tstep + j] ^ 0x80) << (8 * b);
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int i = i0 + u * 256 + tid;
+            if (i < nP) {
+                uint4 t4 = v[u];
+                t4.x ^= 0x80808080u; t4.y ^= 0x80808080u; t4.z ^= 0x80808080u; t4.w ^= 0x80808080u;
+                *reinterpret_cast<uint4*>(P + (size_t)(i >> 4) * MT_PPITCH + (i & 15) * 16) = t4;
+            }
         }
-        reinterpret_cast<unsigned*>(T + (size_t)r * MT_TPITCH)[d] = w;
     }
+    // ---- stage: the template arrives already as (t - 128) with 32 zero bytes in front and zeros behind, th x MT_TPITCH bytes
+    for (int i = tid; i < th * (MT_TPITCH / 8); i += 256)
+        reinterpret_cast<uint2*>(T)[i] = reinterpret_cast<const uint2*>(tpl)[i];
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -316,32 +351,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef TM_PHASE
 #undef TM_MFMA
 #undef TM_LOAD
-    // ---- epilogue: the accumulators go through LDS (the patch is no longer needed) so that the window sums are read and the
-    // result written as whole 512-byte rows; bias undone exactly, then the method's normalisation
-    const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
-    const bool needQ = na.method != 2 && na.method != 4;
-    int* E = reinterpret_cast<int*>(smem);                         // 128 rows (4 waves x 32) x 128 columns
+    // ---- epilogue: raw accumulators straight to the result buffer; one store instruction covers two 128-byte row segments
+    // (lanes 0-31: 32 consecutive columns of one row, lanes 32-63: the same columns four rows below)
     uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        __syncthreads();
+    for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int nt = 0; nt < 4; nt++) {
+            const int x = X0 + 32 * nt + m;
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                E[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * MT_BN + 32 * nt + m] = acc[mt][nt][i];
-        __syncthreads();
-        for (int idx = tid; idx < 128 * MT_BN; idx += 256) {
-            const int row = idx / MT_BN, col = idx - row * MT_BN;
-            const int y = Y0 + (row >> 5) * 64 + 32 * mt + (row & 31), x = X0 + col;
-            if (x < rw && y < rh) {
-                const unsigned ws = w1[(size_t)y * rw + x];
-                const long long corr = (long long)E[idx] + 128LL * (long long)ws + cst;
-                float v = (float)(double)corr;
-                if (na.method != 2) v = tmNormOne(v, (double)ws, needQ ? (double)w2[(size_t)y * rw + x] : 0.0, na);
-                reinterpret_cast<float*>(rbase + (size_t)y * rstep)[x] = v;
+            for (int i = 0; i < 16; i++) {
+                const int y = Y0 + wave * 64 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (x < rw && y < rh) reinterpret_cast<int*>(rbase + (size_t)y * rstep)[x] = acc[mt][nt][i];
             }
         }
+}
+
+// raw accumulators -> result: corr = acc + 128*sum_window(I) + 128*sum(T) - 128^2*tw*th (exact), then common_matchTemplate
+__global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size_t rstep, size_t rframe, const unsigned* __restrict__ w1,
+                                                   const unsigned* __restrict__ w2, size_t wframe, long long cst, NormArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (x >= a.rw) return;
+    w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
+    const bool needQ = a.method != 2 && a.method != 4;
+    int raw[4]; unsigned ws[4], wq[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int y = min(y0 + u, a.rh - 1);
+        raw[u] = *reinterpret_cast<const int*>(reinterpret_cast<const uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep + 4 * (size_t)x);
+        ws[u] = w1[(size_t)y * a.rw + x];
+        wq[u] = needQ ? w2[(size_t)y * a.rw + x] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long corr = (long long)raw[u] + 128LL * (long long)ws[u] + cst;
+        float v = (float)(double)corr;
+        if (a.method != 2) v = tmNormOne(v, (double)ws[u], (double)wq[u], a);
+        if (y0 + u < a.rh)
+            *reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)(y0 + u) * rstep + 4 * (size_t)x) = v;
     }
 }
 
@@ -446,27 +495,54 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         hipLaunchKernelGGL(k_integral_rows, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, dsq, isteps, iframeD);
         hipLaunchKernelGGL(k_integral_cols, dim3(divUp((int)isteps, 256), 1, nframes), dim3(256), 0, st, dsum, dsq, isteps, iframeD, (int)isteps, ih);
     }
-    unsigned* w1 = nullptr; unsigned* w2 = nullptr;
     const size_t wframe = (size_t)rw * rh, s1frame = (size_t)rw * ih;
     if (useMfma) {
+        // Per frame three memory-bound kernels (window sums of I and I^2, then bias removal + normalisation) and one MFMA kernel.
+        // The MFMA kernel occupies every CU with one workgroup (130 KB LDS, 4 waves) and touches memory only at its ends, so
+        // the others run beside it on an auxiliary stream: sums of frame f+1 and the finish of frame f-1 under the MFMAs of f.
         unsigned* s1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
         unsigned* q1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
-        w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
-        w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
-        if (!s1 || !q1 || !w1 || !w2) return MI355CV_NOT_IMPLEMENTED;
-        hipLaunchKernelGGL(k_wsum_rows, dim3(ih, 1, nframes), dim3(256), (size_t)(iw + 1) * 8, st, di, dis, iframe, iw, tw, rw, s1, q1, s1frame);
-        hipLaunchKernelGGL(k_wsum_cols, dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
+        unsigned* w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
+        unsigned* w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
+        // signed, zero-padded copy of the template in the kernel's LDS layout
+        std::vector<uchar> tx((size_t)th * MT_TPITCH, 0);
+        for (int r = 0; r < th; r++) for (int j = 0; j < tw; j++) tx[(size_t)r * MT_TPITCH + 32 + j] = (uchar)(th_host[(size_t)r * tw + j] ^ 0x80);
+        const uchar* dtx = (const uchar*)stg.param(tx.data(), tx.size());
+        if (!s1 || !q1 || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
         na.useW = 1;
-    }
-    if (useMfma) {
+        const bool serial = std::getenv("MI355CV_TM_SERIAL") != nullptr;            // experiments: everything on one stream
+        hipStream_t aux = serial ? st : auxStream();
+        hipEvent_t evIn = pooledEvent(0), evDone = pooledEvent(1);
+        if ((!serial && !aux) || !evIn || !evDone) return MI355CV_NOT_IMPLEMENTED;
         const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
-        dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), nframes);
+        const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
+        const int KS = (tw + 62) / 32;
+        (void)hipEventRecord(evIn, st);                               // inputs (staged copies, template) are ordered on the main stream
+        (void)hipStreamWaitEvent(aux, evIn, 0);
+        for (int f = 0; f < nframes; f++) {
+            const uchar* dif = di + (size_t)f * iframe;
+            hipLaunchKernelGGL(k_wsum_rows, dim3(ih, 1, 1), dim3(256), (size_t)(iw + 1) * 4, aux, dif, dis, 0, iw, tw, rw, s1 + f * s1frame, q1 + f * s1frame, s1frame);
+            hipLaunchKernelGGL(k_wsum_cols, dim3(divUp(rw, 256), divUp(rh, WS_CH), 1), dim3(256), 0, aux, s1 + f * s1frame, q1 + f * s1frame, s1frame, th, rw, rh,
+                               w1 + f * wframe, w2 + f * wframe, wframe);
+        }
+        for (int f = 0; f < nframes; f++) {
+            const uchar* dif = di + (size_t)f * iframe;
+            int* rf = reinterpret_cast<int*>(dr + (size_t)f * rframe);
+            dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), 1);
 #define MFMA_LAUNCH(KS_) do { static bool attrSet = false; \
-        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; } \
-        hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, di, dis, iframe, iw, ih, dt, dts, tw, th, w1, w2, wframe, tplSum, \
-                           reinterpret_cast<float*>(dr), drs, rframe, rw, rh, na); } while (0)
-        switch ((tw + 62) / 32) { case 1: MFMA_LAUNCH(1); break; case 2: MFMA_LAUNCH(2); break; case 3: MFMA_LAUNCH(3); break; case 4: MFMA_LAUNCH(4); break; default: MFMA_LAUNCH(5); }
+            if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; } \
+            hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, dif, dis, 0, iw, ih, dtx, tw, th, rf, drs, 0, rw, rh); } while (0)
+            switch (KS) { case 1: MFMA_LAUNCH(1); break; case 2: MFMA_LAUNCH(2); break; case 3: MFMA_LAUNCH(3); break; case 4: MFMA_LAUNCH(4); break; default: MFMA_LAUNCH(5); }
 #undef MFMA_LAUNCH
+            hipEvent_t evM = pooledEvent(2 + f % 62);
+            if (!evM) return MI355CV_ERROR_UNKNOWN;
+            (void)hipEventRecord(evM, st);
+            (void)hipStreamWaitEvent(aux, evM, 0);
+            hipLaunchKernelGGL(k_tm_finish, dim3(divUp(rw, 64), divUp(rh, 16), 1), dim3(256), 0, aux, reinterpret_cast<float*>(rf), drs, 0,
+                               w1 + f * wframe, w2 + f * wframe, wframe, cst, na);
+        }
+        (void)hipEventRecord(evDone, aux);
+        (void)hipStreamWaitEvent(st, evDone, 0);                      // everything after this call on the main stream sees the results
     } else {
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
         hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);

@@ -118,7 +118,7 @@ def run(quick=False):
     res = torch.empty((B5, 2033, 3713), dtype=torch.float32, device=dev)
     ms = timeit(lambda: cv.matchTemplateBatch(img, tpl, cv.TM_CCORR_NORMED, result=res), n=5, warm=2)
     fl = B5 * 2.4735e11
-    out.append({"config": "cfg5 matchTemplate TM_CCORR_NORMED 4K x 128x128 8UC1 (i8 MFMA + integrals + normalise)", "frames": B5, "ms": round(ms, 3),
+    out.append({"config": "cfg5 matchTemplate TM_CCORR_NORMED 4K x 128x128 8UC1 (i8 MFMA kernel + window sums + finish, two streams)", "frames": B5, "ms": round(ms, 3),
                 "frames_s": round(B5 / ms * 1e3, 2), "bound": "mfma", "achieved_TFLOPs": round(fl / ms / 1e9, 1),
                 "frac_of_bf16_dense_peak": round(fl / ms / 1e9 / MFMA_BF16, 4)})
     cv.set_async(False)
