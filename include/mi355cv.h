@@ -247,6 +247,14 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const mi355cv_uchar* src_data, size_
         float* corners, float* quality, int maxCorners, double qualityLevel, double minDistance,
         const mi355cv_uchar* mask_data, size_t mask_step, int blockSize, int gradientSize, int useHarrisDetector, double harrisK);
 
+/* --------------------------------------------------- f1: fixed-level threshold */
+
+/* replaces hal_ni_threshold (hal_replacement.hpp:1058; caller ThresholdRunner thresh.cpp:1365, once per row stripe).
+ * thresh / maxValue as cv::threshold hands them over (already floor/round/saturated for integer depths);
+ * depth CV_8U / CV_16U / CV_16S / CV_32F, thresholdType THRESH_BINARY .. THRESH_TOZERO_INV (0..4). */
+MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
+
 /* --------------------------------------------------- a13: template matching */
 
 /* cv::matchTemplate (templmatch.cpp:1158) has no HAL hook.  type CV_8UC1..C4 / CV_32FC1..C4, result CV_32FC1

@@ -68,5 +68,8 @@
 // hal_replacement.hpp:395
 #undef  cv_hal_cvtBGRtoBGR
 #define cv_hal_cvtBGRtoBGR mi355cv_cvtBGRtoBGR
+// hal_replacement.hpp:1058 / caller ThresholdRunner thresh.cpp:1365
+#undef  cv_hal_threshold
+#define cv_hal_threshold mi355cv_threshold
 
 #endif

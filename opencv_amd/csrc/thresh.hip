@@ -1,0 +1,78 @@
+// thresh.hip -- SURVEY.md §8 f1: cv_hal_threshold (hal_replacement.hpp:1058; caller ThresholdRunner thresh.cpp:1365, once per
+// row stripe of cv::threshold).  thresh / maxval arrive preprocessed by cv::threshold (floor / round / saturate for the
+// integer depths, thresh.cpp:1583-1680); per element dst = f(src > thresh) for the five fixed-level types
+// (thresh_8u :112, thresh_16u :300, thresh_16s :478, thresh_32f :652).  HBM-bound: 2 * elemSize bytes per element.
+#include "rt.h"
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+
+template <typename T> __device__ __forceinline__ T threshOne(T v, T t, T m, int type)
+{
+    const bool gt = v > t;
+    switch (type) {
+    case 0: return gt ? m : (T)0;
+    case 1: return gt ? (T)0 : m;
+    case 2: return gt ? t : v;
+    case 3: return gt ? v : (T)0;
+    default: return gt ? (T)0 : v;
+    }
+}
+
+// a thread owns 16 bytes of a row when the geometry allows (one dwordx4 load / non-temporal store), single elements otherwise
+template <typename T>
+__global__ __launch_bounds__(256) void k_threshold(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                   int n /* elements per row */, int h, T t, T m, int type, int vec)
+{
+    constexpr int EPV = 16 / sizeof(T);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    const T* s = reinterpret_cast<const T*>(src + (size_t)y * sstep);
+    T* d = reinterpret_cast<T*>(dst + (size_t)y * dstep);
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (vec) {
+        if (i * EPV >= n) return;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        union { u32x4 q; T e[EPV]; } a;
+        a.q = *reinterpret_cast<const u32x4*>(s + (size_t)i * EPV);
+#pragma unroll
+        for (int k = 0; k < EPV; k++) a.e[k] = threshOne<T>(a.e[k], t, m, type);
+        __builtin_nontemporal_store(a.q, reinterpret_cast<u32x4*>(d + (size_t)i * EPV));
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < EPV; k++) { const int x = i + k * (gridDim.x * 64); if (x < n) d[x] = threshOne<T>(s[x], t, m, type); }
+    }
+}
+
+} // namespace
+
+extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                             int depth, int cn, double thresh, double maxValue, int thresholdType)
+{
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (thresholdType < 0 || thresholdType > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
+    const int n = width * cn;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)n * e, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)n * e, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const int epv = 16 / e;
+    const int vec = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 15) == 0 && n % epv == 0) ? 1 : 0;
+    const int perRow = vec ? n / epv : divUp(n, epv);
+    dim3 grid(divUp(perRow, 64), divUp(height, 4));
+    hipStream_t st = stream();
+    switch (depth) {
+    case D8U:  hipLaunchKernelGGL(k_threshold<uchar>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (uchar)thresh, (uchar)maxValue, thresholdType, vec); break;
+    case D16U: hipLaunchKernelGGL(k_threshold<unsigned short>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (unsigned short)thresh, (unsigned short)maxValue, thresholdType, vec); break;
+    case D16S: hipLaunchKernelGGL(k_threshold<short>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (short)thresh, (short)maxValue, thresholdType, vec); break;
+    default:   hipLaunchKernelGGL(k_threshold<float>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (float)thresh, (float)maxValue, thresholdType, vec); break;
+    }
+    return stg.finish("threshold");
+}

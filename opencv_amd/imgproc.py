@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_32F,  # noqa: F401
+from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_16S, CV_32F,  # noqa: F401
                    BORDER_CONSTANT, BORDER_ISOLATED, BORDER_DEFAULT)
 
 L = _lib.lib
@@ -22,6 +22,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
+           "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -222,6 +223,43 @@ def cvtColorBatch(frames, code, dst=None):
                                      int(out.stride(0)) * d0.esz, n, w, h, s0.depth, scn, int(swap))
     _lib.check(rc, "cvtBGRtoGrayBatch")
     return out
+
+
+# ----------------------------------------------------------------------------- threshold (f1)
+THRESH_BINARY, THRESH_BINARY_INV, THRESH_TRUNC, THRESH_TOZERO, THRESH_TOZERO_INV = range(5)
+_SAT = {CV_8U: (0, 255), CV_16U: (0, 65535), CV_16S: (-32768, 32767)}
+
+
+def threshold(src, thresh, maxval, type, dst=None):
+    """cv::threshold (thresh.cpp:1542) for the fixed-level types: the reference's own preprocessing of (thresh, maxval) and its
+    degenerate-threshold shortcuts on the host side, the per-element rule through cv_hal_threshold.  Returns (retval, dst)."""
+    s = Img(src)
+    if type < 0 or type > 4:
+        raise NotImplementedError("threshold: OTSU / TRIANGLE estimate the level on the CPU in the reference; not on this path")
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
+    if s.depth in _SAT:
+        lo, hi = _SAT[s.depth]
+        ithresh = int(np.floor(thresh))
+        imaxval = int(np.rint(maxval))
+        if type == THRESH_TRUNC:
+            imaxval = ithresh
+        imaxval = min(max(imaxval, lo), hi)
+        if ithresh < lo or ithresh >= hi:                                   # thresh.cpp:1595-1609
+            if type in (THRESH_BINARY, THRESH_BINARY_INV) or (type in (THRESH_TRUNC, THRESH_TOZERO_INV) and ithresh < lo) or \
+                    (type == THRESH_TOZERO and ithresh >= hi):
+                v = (0 if ithresh >= hi else imaxval) if type == THRESH_BINARY else \
+                    (imaxval if ithresh >= hi else 0) if type == THRESH_BINARY_INV else 0
+                out[...] = v
+            elif out is not src:
+                out[...] = src
+            return float(ithresh), out
+        thresh, maxval = float(ithresh), float(imaxval)
+    elif s.depth != CV_32F:
+        raise NotImplementedError("threshold: depth")
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_threshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, float(thresh), float(maxval), int(type)), "threshold")
+    return float(thresh), out
 
 
 # ----------------------------------------------------------------------------- linear filters (a3, a4, a5)

@@ -161,6 +161,14 @@ int ref_cvtColor(const void* s, size_t ss, void* d, size_t ds, int w, int h, int
     REF_END(dst, d)
 }
 
+int ref_threshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, double thresh, double maxval, int ttype, double* retval)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    *retval = cv::threshold(src, dst, thresh, maxval, ttype);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {
@@ -279,14 +287,6 @@ int ref_dilate3x3(const void* s, size_t ss, void* d, size_t ds, int w, int h, in
     REF_TRY
     Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
     cv::dilate(src, dst, Mat());
-    REF_END(dst, d)
-}
-
-int ref_threshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, double thresh, double maxval, int ttype)
-{
-    REF_TRY
-    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
-    cv::threshold(src, dst, thresh, maxval, ttype);
     REF_END(dst, d)
 }
 

@@ -210,6 +210,28 @@ def ref_cvtColor(src, code, dcn):
     return dst
 
 
+# ----------------------------------------------------------------------------- threshold
+def orc_threshold(src, thresh, maxval, type):
+    o = oracle()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rv = ctypes.c_double(0)
+    rc = o.orc_threshold(P(src), step(src), P(dst), step(dst), w, h, _NP_DEPTH[src.dtype], cn_of(src), ctypes.c_double(thresh), ctypes.c_double(maxval),
+                         type, ctypes.byref(rv))
+    assert rc == 0, rc
+    return rv.value, dst
+
+
+def ref_threshold(src, thresh, maxval, type):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rv = ctypes.c_double(0)
+    rc = r.ref_threshold(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), ctypes.c_double(thresh), ctypes.c_double(maxval), type, ctypes.byref(rv))
+    assert rc == 0, rc
+    return rv.value, dst
+
+
 # ----------------------------------------------------------------------------- linear filters
 def _roi(src, roi):
     """roi = (x0, y0, w, h) inside `src` (the parent) or None -> (view, fullW, fullH, offX, offY)"""

@@ -1,0 +1,43 @@
+"""Pinning of the cv::threshold restatement (oracle/thresh.c) against the real reference (oracle/_ref): every depth on the path,
+every fixed-level type, thresholds inside, at and beyond the range (the degenerate shortcuts of thresh.cpp:1595-1609)."""
+import numpy as np
+import pytest
+
+import orc as O
+
+CASES = [(np.uint8, [-3.0, 0.0, 0.5, 17.9, 127.0, 254.0, 254.9, 255.0, 300.0], [200.0, 255.4, 300.0, -5.0]),
+         (np.uint16, [-1.0, 0.0, 1000.3, 65534.0, 65535.0, 70000.0], [60000.0, 65535.9, 1e6]),
+         (np.int16, [-40000.0, -32768.0, -5.5, 0.0, 12345.6, 32766.0, 32767.0, 40000.0], [30000.0, -123.0, 1e6]),
+         (np.float32, [-1.5, 0.0, 0.25, 0.999, 7.0], [1.0, -2.5, 255.0])]
+
+
+def _src(dtype, seed, shape=(37, 61, 3)):
+    rng = np.random.default_rng(seed)
+    if dtype == np.float32:
+        return (rng.random(shape, dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    info = np.iinfo(dtype)
+    a = rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
+    a.flat[:4] = [info.min, info.max, info.max - 1, info.min + 1]
+    return a
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("dtype,threshes,maxvals", CASES)
+def test_threshold_matches_reference(ref, dtype, threshes, maxvals):
+    src = _src(dtype, 11)
+    for t in threshes:
+        for m in maxvals:
+            for ttype in range(5):
+                rv_r, want = O.ref_threshold(src, t, m, ttype)
+                rv_o, got = O.orc_threshold(src, t, m, ttype)
+                assert rv_r == rv_o, (dtype, t, m, ttype)
+                assert np.array_equal(got, want), (dtype, t, m, ttype)
+
+
+def test_threshold_known_answers():
+    """hand-checkable vector (the rule of thresh_8u, thresh.cpp:112-): src > thresh"""
+    src = np.array([[0, 9, 10, 11, 255]], np.uint8)
+    exp = {0: [0, 0, 0, 200, 200], 1: [200, 200, 200, 0, 0], 2: [0, 9, 10, 10, 10], 3: [0, 0, 0, 11, 255], 4: [0, 9, 10, 0, 0]}
+    for ttype, e in exp.items():
+        rv, got = O.orc_threshold(src, 10.7, 200.2, ttype)
+        assert rv == 10.0 and got.tolist() == [e], ttype

@@ -1,0 +1,44 @@
+"""GPU parity for cv::threshold through cv_hal_threshold: every depth, every fixed-level type, thresholds inside /
+at / beyond the range, vectorised (16-byte) and ragged rows, in place, host pointers; bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_thresh import CASES, _src
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+@pytest.mark.parametrize("dtype,threshes,maxvals", CASES)
+def test_threshold(cv, orc, dtype, threshes, maxvals):
+    n0 = cv.call_count("threshold")
+    for shape in [(37, 61, 3), (16, 64), (5, 1), (1, 3), (33, 1024, 4)]:
+        src = _src(dtype, 3, shape)
+        d = torch.from_numpy(src).cuda()
+        for t in threshes:
+            for m in maxvals[:2]:
+                for ttype in range(5):
+                    rv_want, want = orc.orc_threshold(src, t, m, ttype)
+                    rv, got = cv.threshold(d, t, m, ttype)
+                    assert rv == rv_want and np.array_equal(got.cpu().numpy(), want), (dtype, shape, t, m, ttype)
+    src = _src(dtype, 4, (40, 80))
+    rv_want, want = orc.orc_threshold(src, threshes[2], maxvals[0], 3)
+    rv, got = cv.threshold(src, threshes[2], maxvals[0], 3)                      # host pointers
+    assert isinstance(got, np.ndarray) and np.array_equal(got, want)
+    d = torch.from_numpy(src).cuda()
+    cv.threshold(d, threshes[2], maxvals[0], 3, dst=d)                           # in place, as gftt uses it
+    assert np.array_equal(d.cpu().numpy(), want)
+    assert cv.call_count("threshold") > n0
+
+
+def test_threshold_4k_bandwidth_shape(cv, orc):
+    src = np.random.default_rng(5).integers(0, 256, (2160, 3840), dtype=np.uint8)
+    rv, got = cv.threshold(torch.from_numpy(src).cuda(), 127, 255, 0)
+    assert np.array_equal(got.cpu().numpy(), orc.orc_threshold(src, 127, 255, 0)[1])
