@@ -255,6 +255,19 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const mi355cv_uchar* src_data, size_
 MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
 
+/* --------------------------------------------------- f1: erode / dilate */
+
+/* replace hal_ni_morphInit / hal_ni_morph / hal_ni_morphFree (hal_replacement.hpp:207-233; caller halMorph
+ * morph.dispatch.cpp:190-220).  operation 0 = MORPH_ERODE, 1 = MORPH_DILATE; kernel = CV_8UC1 mask; iterations must be 1 (the
+ * reference folds iterated rectangles before the hook); borderValue all DBL_MAX = morphologyDefaultBorderValue(). */
+MI355CV_API int mi355cv_morphInit(struct cvhalFilter2D** context, int operation, int src_type, int dst_type, int max_width, int max_height,
+        int kernel_type, mi355cv_uchar* kernel_data, size_t kernel_step, int kernel_width, int kernel_height, int anchor_x, int anchor_y,
+        int borderType, const double borderValue[4], int iterations, bool allowSubmatrix, bool allowInplace);
+MI355CV_API int mi355cv_morph(struct cvhalFilter2D* context, mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int src_full_width, int src_full_height, int src_roi_x, int src_roi_y,
+        int dst_full_width, int dst_full_height, int dst_roi_x, int dst_roi_y);
+MI355CV_API int mi355cv_morphFree(struct cvhalFilter2D* context);
+
 /* --------------------------------------------------- a13: template matching */
 
 /* cv::matchTemplate (templmatch.cpp:1158) has no HAL hook.  type CV_8UC1..C4 / CV_32FC1..C4, result CV_32FC1

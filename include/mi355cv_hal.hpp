@@ -71,5 +71,12 @@
 // hal_replacement.hpp:1058 / caller ThresholdRunner thresh.cpp:1365
 #undef  cv_hal_threshold
 #define cv_hal_threshold mi355cv_threshold
+// hal_replacement.hpp:207-233 / caller halMorph morph.dispatch.cpp:190-220
+#undef  cv_hal_morphInit
+#define cv_hal_morphInit mi355cv_morphInit
+#undef  cv_hal_morph
+#define cv_hal_morph mi355cv_morph
+#undef  cv_hal_morphFree
+#define cv_hal_morphFree mi355cv_morphFree
 
 #endif

@@ -1,0 +1,143 @@
+// morph.hip -- SURVEY.md §8 f1: cv_hal_morphInit / cv_hal_morph / cv_hal_morphFree (hal_replacement.hpp:207-233; caller halMorph
+// morph.dispatch.cpp:190-220 from hal::morph :477, reached by cv::erode / cv::dilate / every step of cv::morphologyEx).
+// dst = min (erode) / max (dilate) of the source over the non-zero elements of the structuring element, border pixels by
+// borderInterpolate on the PARENT image (roi_* arguments) or the constant border value, whose default (all DBL_MAX) stands for
+// the identity of the operation (createMorphologyFilter morph.dispatch.cpp:110-128).  iterations == 1 only: the reference folds
+// iterated rectangles into one element before the hook (:963-972); iterated irregular elements fall back to the CPU.
+//   * k_morph_generic<T>: any element / anchor / depth (8U, 16U, 16S, 32F) / ROI; thread per output element.
+//   * seprollMorph (seproll.hip): u8, full K x K rectangle, K in {3,5,7}, on the register-rolling skeleton.
+#include "rt.h"
+#include "seproll.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace mi355;
+
+namespace {
+
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+
+struct MorphTap { short dx, dy; };
+struct MorphCtx {
+    int magic, op, depth, cn, kw, kh, ax, ay, border;
+    bool rect, defaultBorder;
+    float bv[4];                      // border value per channel, already saturated to the depth
+    std::vector<MorphTap> taps;
+};
+constexpr int MORPH_MAGIC = 0x4d525048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_morph_generic(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                       int W, int H, int cn, int fullW, int fullH, int offX, int offY, const MorphTap* __restrict__ taps, int ntaps,
+                                                       int ax, int ay, int erode, int border, float b0, float b1, float b2, float b3)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const T bval = (T)(ch == 0 ? b0 : ch == 1 ? b1 : ch == 2 ? b2 : b3);
+    T r = 0;
+    for (int t = 0; t < ntaps; t++) {
+        const int yy = mi355_borderInterpolate(y + offY + taps[t].dy - ay, fullH, border);
+        const int xx = mi355_borderInterpolate(x + offX + taps[t].dx - ax, fullW, border);
+        const T v = (yy < 0 || xx < 0) ? bval : reinterpret_cast<const T*>(src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep)[(xx - offX) * cn + ch];
+        r = t == 0 ? v : (erode ? (v < r ? v : r) : (v > r ? v : r));
+    }
+    reinterpret_cast<T*>(dst + (size_t)y * dstep)[e] = r;
+}
+
+float satBorder(double v, int depth)
+{
+    switch (depth) {
+    case D8U:  v = std::nearbyint(v); return (float)(v < 0 ? 0 : v > 255 ? 255 : v);
+    case D16U: v = std::nearbyint(v); return (float)(v < 0 ? 0 : v > 65535 ? 65535 : v);
+    case D16S: v = std::nearbyint(v); return (float)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+    default:   return (float)v;
+    }
+}
+
+} // namespace
+
+struct cvhalFilter2D;
+
+extern "C" {
+
+MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int src_type, int dst_type, int max_width, int max_height,
+        int kernel_type, uchar* kernel_data, size_t kernel_step, int kernel_width, int kernel_height, int anchor_x, int anchor_y,
+        int borderType, const double borderValue[4], int iterations, bool allowSubmatrix, bool allowInplace)
+{
+    (void)max_width; (void)max_height; (void)allowSubmatrix;
+    if (!context || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (operation != 0 && operation != 1) return MI355CV_NOT_IMPLEMENTED;          // MORPH_ERODE / MORPH_DILATE
+    if (iterations != 1 || allowInplace || src_type != dst_type) return MI355CV_NOT_IMPLEMENTED;
+    const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
+    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return MI355CV_NOT_IMPLEMENTED;
+    if (kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024) return MI355CV_NOT_IMPLEMENTED;
+    const int border = borderType & ~MI355CV_BORDER_ISOLATED;
+    if (border < 0 || border > B_REFLECT_101 || border == B_WRAP) return MI355CV_NOT_IMPLEMENTED;
+    MorphCtx* c = new (std::nothrow) MorphCtx();
+    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    c->magic = MORPH_MAGIC; c->op = operation; c->depth = depth; c->cn = cn; c->kw = kernel_width; c->kh = kernel_height; c->border = border;
+    c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
+    if (c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return MI355CV_NOT_IMPLEMENTED; }
+    for (int j = 0; j < kernel_height; j++)
+        for (int i = 0; i < kernel_width; i++)
+            if (kernel_data[(size_t)j * kernel_step + i]) c->taps.push_back({(short)i, (short)j});
+    if (c->taps.empty()) { delete c; return MI355CV_NOT_IMPLEMENTED; }               // the reference asserts a non-empty element
+    c->rect = (int)c->taps.size() == kernel_width * kernel_height;
+    c->defaultBorder = !borderValue || (borderValue[0] == DBL_MAX && borderValue[1] == DBL_MAX && borderValue[2] == DBL_MAX && borderValue[3] == DBL_MAX);
+    for (int k = 0; k < 4; k++) {
+        if (c->defaultBorder)
+            c->bv[k] = operation == 0 ? (depth == D8U ? 255.f : depth == D16U ? 65535.f : depth == D16S ? 32767.f : FLT_MAX)
+                                      : (depth == D8U || depth == D16U ? 0.f : depth == D16S ? -32768.f : -FLT_MAX);
+        else c->bv[k] = satBorder(borderValue[k], depth);
+    }
+    *context = reinterpret_cast<cvhalFilter2D*>(c);
+    return MI355CV_OK;
+}
+
+MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_full_width, int src_full_height, int src_roi_x, int src_roi_y, int dst_full_width, int dst_full_height, int dst_roi_x, int dst_roi_y)
+{
+    (void)dst_full_width; (void)dst_full_height; (void)dst_roi_x; (void)dst_roi_y;
+    MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
+    if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
+    Stager stg; size_t dss, dds;
+    const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;
+    const uchar* dtop = stg.in(top, src_step, (size_t)src_full_width * c->cn * e, src_full_height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * e, height, &dds);
+    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* ds = dtop + (size_t)src_roi_y * dss + (size_t)src_roi_x * c->cn * e;
+    hipStream_t st = stream();
+    const bool whole = src_full_width == width && src_full_height == height;
+    if (c->depth == D8U && c->rect && c->kw == c->kh && c->ax == c->kw / 2 && c->ay == c->kh / 2 && whole &&
+        (c->border != B_CONSTANT || c->defaultBorder) &&
+        seprollMorph(c->op == 0, ds, dss, 0, dd, dds, 0, 1, width, height, c->cn, c->kw, c->border, st))
+        return stg.finish("morph");
+    MorphTap* dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
+    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
+#define MORPH_GEN(T) hipLaunchKernelGGL(k_morph_generic<T>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, c->cn, src_full_width, src_full_height, \
+        src_roi_x, src_roi_y, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
+    switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; default: MORPH_GEN(float); }
+#undef MORPH_GEN
+    return stg.finish("morph");
+}
+
+MI355CV_API int mi355cv_morphFree(cvhalFilter2D* context)
+{
+    MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
+    if (!c || c->magic != MORPH_MAGIC) return MI355CV_NOT_IMPLEMENTED;
+    c->magic = 0;
+    delete c;
+    return MI355CV_OK;
+}
+
+} // extern "C"

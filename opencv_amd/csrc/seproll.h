@@ -25,4 +25,9 @@ bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, s
 bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                   int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st);
 
+// u8 erode / dilate with a full ksize x ksize rectangle (3/5/7), centred anchor, cn in {1,3,4}; BORDER_CONSTANT means the
+// DEFAULT border value of cv::erode / cv::dilate (the identity of the operation), the other border types extrapolate.
+bool seprollMorph(int erode, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, int cn, int ksize, int border, hipStream_t st);
+
 } // namespace mi355

@@ -15,6 +15,7 @@ namespace {
 //   KX, KY, CN, CB        taps, channels, source bytes per lane (16, or 8 when the outputs are 32-bit: a lane then writes
 //                         32 contiguous bytes);  OUTB = bytes per output element
 //   Args                  kernel parameters (by value)
+//   pre(m, side, args)                        applied to the raw dwords of a row right after the load (no-op for most)
 //   hpass(Inter&, E, O, args)                 one row's intermediates from the byte planes of its window
 //   vpass<UP>(ring, u, args, out[MD*OUTB])    output dwords of the lane from the KY ring rows; ring[(u + j) % KY] is the
 //                                             j-th row in WALKING order (image order reversed when UP)
@@ -26,6 +27,7 @@ __device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P
     constexpr int KY = P::KY, RY = KY / 2, NW = Cx::NW, MD = Cx::MD, OD = MD * P::OUTB;
     typename P::Inter ring[KY];
     auto hrow = [&](typename P::Inter& o, RawT raw, int valid) {
+        P::pre(raw.m, raw.side, a);                    // (morphology: erode = complement o dilate o complement)
         if (!valid) {                                  // BORDER_CONSTANT row: zeros (window() only moves bytes)
 #pragma unroll
             for (int d = 0; d < MD; d++) raw.m[d] = 0;
@@ -99,6 +101,7 @@ struct FixedSmooth {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t kx[K]; uint32_t kyLo[K], kyHi[K]; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
     struct Inter { uint32_t e[4], o[4]; };
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     template <int Q, int I>
@@ -159,6 +162,7 @@ struct BoxU8 {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t ds2, c2; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
     struct Inter { uint32_t e[4], o[4]; };
     template <int Q, int I>
     static __device__ __forceinline__ uint32_t hsum(const uint32_t* E, const uint32_t* O, int k)
@@ -196,6 +200,7 @@ struct Deriv16 {
     static constexpr int HD = roll::Cfg<R, 1>::HD;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     struct Args { uint32_t kx[K], ky[K]; };              // taps splatted into both 16-bit halves
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
     struct Inter { s16x2 e[4], o[4]; };
     template <int Q, int I>
     static __device__ __forceinline__ s16x2 hsum(const uint32_t* E, const uint32_t* O, int k, const Args& a)
@@ -240,6 +245,7 @@ struct SepF32 {
     static constexpr int NP = CB / 2;                        // pixel pairs (i, i + NP)
     static constexpr int HD = roll::Cfg<R, 1, CB>::HD;
     struct Args { float kx[K], ky[K], delta; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
     struct Inter { f32x2 h[NP]; };
     static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
     {
@@ -293,6 +299,52 @@ struct SepF32 {
                 out[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].x), i & 3, out[i >> 2]);
                 out[NP / 4 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(o[i].y), i & 3, out[NP / 4 + (i >> 2)]);
             }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------- erode / dilate, rectangular element, u8
+// MorphRowFilter / MorphColumnFilter (morph.simd.hpp:590-700): running max over the K x K window.  dilate with the default
+// constant border pads with 0, which is what a BORDER_CONSTANT halo is here; erode is computed as ~dilate(~src), so its default
+// border (255) is the same zero halo.  Max of packed 16-bit pairs: v_pk_max_u16 on the byte planes.
+template <int K, int CN_>
+struct MorphMax {
+    static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, CN>::HD;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    struct Args { uint32_t flip; };                      // 0 dilate, 0xffffffff erode
+    struct Inter { uint32_t e[4], o[4]; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&m)[MDn], uint32_t (&side)[HDn], const Args& a)
+    {
+#pragma unroll
+        for (int d = 0; d < MDn; d++) m[d] ^= a.flip;
+#pragma unroll
+        for (int d = 0; d < HDn; d++) side[d] ^= a.flip;
+    }
+    static __device__ __forceinline__ uint32_t mx(uint32_t a, uint32_t b)
+    {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+    }
+    template <int Q, int I>
+    static __device__ __forceinline__ uint32_t hmax(const uint32_t* E, const uint32_t* O, int k)
+    {
+        const uint32_t v = roll::pairAt<Q, (I - R) * CN, HD>(E, O, k);
+        if constexpr (I == 0) return v; else return mx(v, hmax<Q, I - 1>(E, O, k));
+    }
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args&)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o.e[k] = hmax<0, K - 1>(E, O, k); o.o[k] = hmax<1, K - 1>(E, O, k); }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int, const Args& a, uint32_t (&out)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t se = ring[0].e[k], so = ring[0].o[k];
+#pragma unroll
+            for (int j = 1; j < K; j++) { se = mx(se, ring[j].e[k]); so = mx(so, ring[j].o[k]); }
+            out[k] = (se | (so << 8)) ^ a.flip;            // bytes 4k..4k+3 = (E.lo, O.lo, E.hi, O.hi)
         }
     }
 };
@@ -362,6 +414,20 @@ bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
     else        { if (outBytes == 4) SFS(5, 4); else SFS(5, 1); }
 #undef SFS
 #undef SF
+    return true;
+}
+
+bool seprollMorph(int erode, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, int cn, int ksize, int border, hipStream_t st)
+{
+    if ((ksize != 3 && ksize != 5 && ksize != 7) || !(cn == 1 || cn == 3 || cn == 4)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, ksize / 2, border)) return false;
+#define MM(K_, CN_) do { typedef MorphMax<K_, CN_> P; P::Args a = {erode ? 0xffffffffu : 0u}; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+#define MMK(K_) do { if (cn == 1) MM(K_, 1); else if (cn == 3) MM(K_, 3); else MM(K_, 4); } while (0)
+    switch (ksize) { case 3: MMK(3); break; case 5: MMK(5); break; default: MMK(7); }
+#undef MMK
+#undef MM
     return true;
 }
 

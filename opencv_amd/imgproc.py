@@ -22,7 +22,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -260,6 +260,56 @@ def threshold(src, thresh, maxval, type, dst=None):
     bind_stream(s, d)
     _lib.check(L.mi355cv_threshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, float(thresh), float(maxval), int(type)), "threshold")
     return float(thresh), out
+
+
+# ----------------------------------------------------------------------------- erode / dilate (f1)
+MORPH_ERODE, MORPH_DILATE = 0, 1
+_DBL_MAX = 1.7976931348623157e308
+
+
+def _morph(op, src, kernel, anchor, iterations, borderType, borderValue, dst, roi):
+    """morphOp (morph.dispatch.cpp:935-1010): default 3x3 rectangle, iterations of a rectangle folded into one bigger rectangle,
+    then cv_hal_morphInit / cv_hal_morph / cv_hal_morphFree."""
+    view, s, fw, fh, ox, oy = _parent_geometry(src, roi, borderType)
+    k = None if kernel is None else np.ascontiguousarray(np.asarray(kernel) != 0, dtype=np.uint8)
+    ksz = (3, 3) if k is None else (k.shape[1], k.shape[0])
+    ax = ksz[0] // 2 if anchor[0] < 0 else anchor[0]
+    ay = ksz[1] // 2 if anchor[1] < 0 else anchor[1]
+    out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, s.depth)
+    if iterations == 0 or ksz == (1, 1):
+        out[...] = view
+        return out
+    if k is None:
+        k = np.ones((1 + 2 * iterations, 1 + 2 * iterations), np.uint8)
+        ax = ay = iterations
+        iterations = 1
+    elif iterations > 1 and int(k.sum()) == k.size:
+        ax, ay = ax * iterations, ay * iterations
+        k = np.ones((ksz[1] + (iterations - 1) * (ksz[1] - 1), ksz[0] + (iterations - 1) * (ksz[0] - 1)), np.uint8)
+        iterations = 1
+    bv = (ctypes.c_double * 4)(*([_DBL_MAX] * 4)) if borderValue is None else (ctypes.c_double * 4)(*_border_value(borderValue))
+    d = Img(out)
+    bind_stream(s, d)
+    ctx = ctypes.c_void_p()
+    rc = L.mi355cv_morphInit(ctypes.byref(ctx), op, s.type, d.type, s.w, s.h, 0, k.ctypes.data, k.strides[0], k.shape[1], k.shape[0], ax, ay,
+                             borderType & ~BORDER_ISOLATED, bv, iterations, roi is not None, False)
+    _lib.check(rc, "morphInit")
+    try:
+        rc = L.mi355cv_morph(ctx, _vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, fw, fh, ox, oy, s.w, s.h, 0, 0)
+    finally:
+        L.mi355cv_morphFree(ctx)
+    _lib.check(rc, "morph")
+    return out
+
+
+def erode(src, kernel=None, anchor=(-1, -1), iterations=1, borderType=BORDER_CONSTANT, borderValue=None, dst=None, roi=None):
+    """cv::erode (morph.dispatch.cpp:1013).  borderValue=None is morphologyDefaultBorderValue()."""
+    return _morph(MORPH_ERODE, src, kernel, anchor, iterations, borderType, borderValue, dst, roi)
+
+
+def dilate(src, kernel=None, anchor=(-1, -1), iterations=1, borderType=BORDER_CONSTANT, borderValue=None, dst=None, roi=None):
+    """cv::dilate (morph.dispatch.cpp:1024)."""
+    return _morph(MORPH_DILATE, src, kernel, anchor, iterations, borderType, borderValue, dst, roi)
 
 
 # ----------------------------------------------------------------------------- linear filters (a3, a4, a5)

@@ -91,6 +91,11 @@ int orc_thresholdHal(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dste
 int orc_threshold(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn,
                   double thresh, double maxval, int type, double* retval);
 
+/* cv::erode / cv::dilate, see oracle/morph.c (op 0 erode, 1 dilate; depth 0/2/3/5; borderValue all DBL_MAX = default) */
+int orc_morph(int op, const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn,
+              int fullW, int fullH, int offX, int offY, const uint8_t* kernel, size_t kstep, int kw, int kh, int ax, int ay,
+              int border, const double* borderValue);
+
 #ifdef __cplusplus
 }
 #endif

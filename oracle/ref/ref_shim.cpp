@@ -169,6 +169,19 @@ int ref_threshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, in
     REF_END(dst, d)
 }
 
+// op 0 erode, 1 dilate; kernel = kw x kh uchar mask (NULL -> default 3x3 rect); bv = NULL -> morphologyDefaultBorderValue()
+int ref_morph(int op, const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, const void* k, size_t ks, int kw, int kh,
+              int ax, int ay, int iterations, int borderType, const double* bv)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    Mat kernel = k ? M(k, ks, kw, kh, CV_8UC1) : Mat();
+    Scalar b = bv ? Scalar(bv[0], bv[1], bv[2], bv[3]) : cv::morphologyDefaultBorderValue();
+    if (op == 0) cv::erode(src, dst, kernel, Point(ax, ay), iterations, borderType, b);
+    else cv::dilate(src, dst, kernel, Point(ax, ay), iterations, borderType, b);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {

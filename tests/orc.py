@@ -232,6 +232,42 @@ def ref_threshold(src, thresh, maxval, type):
     return rv.value, dst
 
 
+# ----------------------------------------------------------------------------- morphology
+def _bvp(bv):
+    if bv is None:
+        return (ctypes.c_double * 4)(*([1.7976931348623157e308] * 4))      # DBL_MAX x4 = morphologyDefaultBorderValue()
+    v = list(np.atleast_1d(np.asarray(bv, dtype=np.float64))) + [0.0] * 4
+    return (ctypes.c_double * 4)(*v[:4])
+
+
+def orc_morph(op, src, kernel=None, anchor=(-1, -1), border=0, borderValue=None, roi=None):
+    o = oracle()
+    view, fullW, fullH, offX, offY = _roi(src, roi)
+    h, w = view.shape[:2]
+    k = np.ones((3, 3), np.uint8) if kernel is None else np.ascontiguousarray(kernel, dtype=np.uint8)
+    kh, kw = k.shape
+    ax = kw // 2 if anchor[0] < 0 else anchor[0]
+    ay = kh // 2 if anchor[1] < 0 else anchor[1]
+    dst = np.empty((h, w) + view.shape[2:], view.dtype)
+    rc = o.orc_morph(op, P(view), step(view), P(dst), step(dst), w, h, _NP_DEPTH[view.dtype], cn_of(view), fullW, fullH, offX, offY,
+                     P(k), c_sz(k.strides[0]), kw, kh, ax, ay, border & ~16, _bvp(borderValue))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_morph(op, src, kernel=None, anchor=(-1, -1), iterations=1, border=0, borderValue=None):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    k = None if kernel is None else np.ascontiguousarray(kernel, dtype=np.uint8)
+    bv = None if borderValue is None else _bvp(borderValue)
+    rc = r.ref_morph(op, P(src), step(src), P(dst), step(dst), w, h, cvtype(src), P(k) if k is not None else None,
+                     c_sz(k.strides[0]) if k is not None else c_sz(0), k.shape[1] if k is not None else 0, k.shape[0] if k is not None else 0,
+                     anchor[0], anchor[1], iterations, border, bv)
+    assert rc == 0, rc
+    return dst
+
+
 # ----------------------------------------------------------------------------- linear filters
 def _roi(src, roi):
     """roi = (x0, y0, w, h) inside `src` (the parent) or None -> (view, fullW, fullH, offX, offY)"""

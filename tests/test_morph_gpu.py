@@ -1,0 +1,66 @@
+"""GPU parity for cv::erode / cv::dilate through cv_hal_morphInit / cv_hal_morph / cv_hal_morphFree: every
+structuring element / anchor / depth / border of the oracle's own pinning matrix, the rolling fast path ((W*cn) % 16 == 0, full
+3/5/7 rectangles), ROIs with real neighbours, folded iterations; bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_morph import KERNELS, _src
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_morph_generic(cv, orc, dtype):
+    n0 = cv.call_count("morph")
+    for shape in [(23, 40), (17, 29, 3), (1, 9), (6, 1, 4)]:
+        src = _src(dtype, shape, 5 + len(shape))
+        for op, fn in ((0, cv.erode), (1, cv.dilate)):
+            for k, anchor in KERNELS:
+                for border, bv in [(0, None), (0, 7.0), (1, None), (2, None), (4, None)]:
+                    want = orc.orc_morph(op, src, k, anchor, border, bv)
+                    got = fn(dev(src), k, anchor, 1, border, bv).cpu().numpy()
+                    assert np.array_equal(got, want), (dtype, shape, op, None if k is None else k.shape, anchor, border, bv)
+    assert cv.call_count("morph") > n0
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_morph_rolling_path(cv, orc, cn):
+    rng = np.random.default_rng(cn)
+    for (w, h) in [(16, 1), (32, 2), (48, 5), (64, 23), (1040, 37), (2064, 70)]:
+        if w * cn % 16:
+            continue
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for K in (3, 5, 7):
+            k = np.ones((K, K), np.uint8)
+            for op, fn in ((0, cv.erode), (1, cv.dilate)):
+                for border in (0, 1, 2, 4):
+                    assert np.array_equal(fn(dev(src), k, (-1, -1), 1, border).cpu().numpy(), orc.orc_morph(op, src, k, (-1, -1), border)), (w, h, K, op, border)
+    # extremes stay extremes; iterations fold into a bigger rectangle; host pointers
+    full = np.full((20, 64, cn) if cn > 1 else (20, 64), 255, np.uint8)
+    assert (cv.erode(dev(full)).cpu().numpy() == 255).all() and (cv.dilate(dev(np.zeros_like(full))).cpu().numpy() == 0).all()
+    src = rng.integers(0, 256, (40, 64, cn) if cn > 1 else (40, 64), dtype=np.uint8)
+    assert np.array_equal(cv.dilate(dev(src), None, (-1, -1), 2).cpu().numpy(), orc.orc_morph(1, src, np.ones((5, 5), np.uint8)))
+    assert np.array_equal(cv.erode(src, None, (-1, -1), 3), orc.orc_morph(0, src, np.ones((7, 7), np.uint8)))
+
+
+def test_morph_roi_reads_real_neighbours(cv, orc):
+    parent = _src(np.uint8, (40, 60, 3), 2)
+    for roi in [(5, 4, 30, 20), (0, 0, 16, 16), (57, 38, 3, 2)]:
+        for border in (0, 1, 4, 4 | 16):
+            for op, fn in ((0, cv.erode), (1, cv.dilate)):
+                want = orc.orc_morph(op, parent, np.ones((5, 3), np.uint8), (-1, -1), border, None, roi=roi if not border & 16 else None) if not border & 16 else \
+                    orc.orc_morph(op, np.ascontiguousarray(parent[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]), np.ones((5, 3), np.uint8), (-1, -1), border & ~16)
+                got = fn(dev(parent), np.ones((5, 3), np.uint8), (-1, -1), 1, border, None, roi=roi).cpu().numpy()
+                assert np.array_equal(got, want), (roi, border, op)

@@ -1,0 +1,51 @@
+"""Pinning of the erode / dilate restatement (oracle/morph.c) against the real reference: rectangular, cross and arbitrary
+structuring elements, off-centre anchors, every depth on the path, default and explicit constant borders, extrapolating borders,
+folded iterations of a rectangular element."""
+import numpy as np
+import pytest
+
+import orc as O
+
+CROSS = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+ODD = np.array([[1, 0, 0, 1, 0], [0, 0, 1, 0, 0], [1, 1, 0, 0, 1]], np.uint8)
+KERNELS = [(None, (-1, -1)), (np.ones((3, 3), np.uint8), (-1, -1)), (np.ones((5, 5), np.uint8), (-1, -1)), (np.ones((2, 4), np.uint8), (3, 0)),
+           (CROSS, (-1, -1)), (ODD, (1, 2)), (np.ones((1, 7), np.uint8), (-1, -1)), (np.ones((7, 1), np.uint8), (0, 5))]
+
+
+def _src(dtype, shape, seed):
+    rng = np.random.default_rng(seed)
+    if dtype == np.float32:
+        return (rng.random(shape, dtype=np.float32) * 4 - 2).astype(np.float32)
+    info = np.iinfo(dtype)
+    return rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_morph_matches_reference(ref, dtype):
+    for shape in [(23, 40), (17, 29, 3), (1, 9), (6, 1, 4)]:
+        src = _src(dtype, shape, 5 + len(shape))
+        for op in (0, 1):
+            for k, anchor in KERNELS:
+                for border, bv in [(0, None), (0, 7.0), (1, None), (2, None), (4, None)]:
+                    want = O.ref_morph(op, src, k, anchor, 1, border, bv)
+                    got = O.orc_morph(op, src, k, anchor, border, bv)
+                    assert np.array_equal(got, want), (dtype, shape, op, None if k is None else k.shape, anchor, border, bv)
+
+
+@pytest.mark.ref
+def test_folded_iterations_equal_bigger_rectangle(ref):
+    """morphOp folds `iterations` of a rectangular element into one (:963-972): what reaches cv_hal_morph is iterations == 1"""
+    src = _src(np.uint8, (31, 45, 3), 9)
+    for op in (0, 1):
+        want = O.ref_morph(op, src, None, (-1, -1), 3, 0, None)                  # empty kernel, 3 iterations -> 7x7
+        assert np.array_equal(O.orc_morph(op, src, np.ones((7, 7), np.uint8)), want)
+        want = O.ref_morph(op, src, np.ones((3, 5), np.uint8), (-1, -1), 2, 4, None)
+        assert np.array_equal(O.orc_morph(op, src, np.ones((5, 9), np.uint8), (-1, -1), 4), want)
+
+
+def test_morph_known_answer():
+    src = np.array([[5, 1, 9], [7, 3, 2], [4, 8, 6]], np.uint8)
+    assert O.orc_morph(1, src).tolist() == [[7, 9, 9], [8, 9, 9], [8, 8, 8]]          # dilate: outside ignored
+    assert O.orc_morph(0, src).tolist() == [[1, 1, 1], [1, 1, 1], [3, 2, 2]]          # erode
+    assert O.orc_morph(0, src, None, (-1, -1), 0, 0.0)[0].tolist() == [0, 0, 0]        # explicit constant 0 border
