@@ -168,7 +168,8 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
         ds = dtop + (size_t)mT * dss + (size_t)mL * cn * e;
     } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
     if (depth == D8U && cn == 1 && !mL && !mT && !mR && !mB && dw * 2 == sw && dh == (sh + 1) / 2 && sh >= 2 && border != B_WRAP &&
-        (((uintptr_t)dd | dds | dframe) & 7) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, sw, 1, 2, border)) {
+        (((uintptr_t)dd | dds | dframe) & 7) == 0 && sw % 16 == 0 && (((uintptr_t)ds | dss | sframe) & 15) == 0 &&
+        roll::eligible(ds, dss, sframe, ds, dss, sframe, sw, 1, 2, border)) {
         roll::Geom g = roll::geometry(sw, sh, 1, nframes, 32, 8);
         if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
         hipLaunchKernelGGL(k_pyrdown_roll, dim3(g.blocks), dim3(256), 0, stream(), ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips,
@@ -403,15 +404,10 @@ __global__ __launch_bounds__(256) void k_corner_roll(const uchar* __restrict__ s
                 o[i] = (ah + ch) - f32x2{__fsqrt_rn(u.x), __fsqrt_rn(u.y)};
             }
         }
-        if (cx.active) {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4* out = reinterpret_cast<f32x4*>(dst + (size_t)y * dstep + 4 * CB * (size_t)cx.c);
+        uint32_t ow[CB];                                   // memory order: pixels 0..NP-1 are the .x halves, NP..2NP-1 the .y halves
 #pragma unroll
-            for (int q = 0; q < NP / 4; q++) {
-                __builtin_nontemporal_store(f32x4{o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x}, out + q);
-                __builtin_nontemporal_store(f32x4{o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y}, out + NP / 4 + q);
-            }
-        }
+        for (int i = 0; i < NP; i++) { ow[i] = __float_as_uint(o[i].x); ow[NP + i] = __float_as_uint(o[i].y); }
+        cx.template store<4>(dst, dstep, y, ow);
     };
 
     // cov rows in walking order: c_0 (prologue), c_1 .. c_n; step t emits image row gy(t-1) from (c_{t-1}, c_t) and needs the
@@ -493,9 +489,9 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
     if (scale == 1) { /* unreachable for the depths handled; kept for symmetry with cv::Sobel */ }
     a.rx = std::max(a.dxNRow, a.dyNRow) / 2; a.ry = std::max(a.dxNCol, a.dyNCol) / 2;
     if (sdepth == D8U && ksize == 3 && blockSize == 2 && H >= 2 && std::getenv("MI355CV_CORNER_LDS") == nullptr &&
-        (((uintptr_t)dd | dds | dframe) & 15) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, W, 1, 2, border, 8)) {
+        (((uintptr_t)dd | dds | dframe) & 3) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, W, 1, 2, border, 8)) {
         CornerRollArgs ra = {a.dyRow[0], a.dyRow[1], a.dyRow[2], a.dxCol[1], a.dxCol[2], a.kf};
-        const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W % 16 == 0;
+        const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W >= 16;
         const roll::Geom g = roll::geometry(W, H, 1, nframes, 24, 4, wide ? 16 : 8);
 #define CROLL(HR, CB_) hipLaunchKernelGGL((k_corner_roll<HR, CB_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, 1, ra)
         if (wide) { if (harris) CROLL(true, 16); else CROLL(false, 16); }

@@ -153,11 +153,7 @@ __device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, ucha
                     o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.x), i & 3, o[i >> 2]);
                     o[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.y), i & 3, o[2 + (i >> 2)]);
                 }
-                if (cx.active) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 ov = {o[0], o[1], o[2], o[3]};
-                    __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + 16 * (size_t)cx.c));
-                }
+                cx.template store<1>(dst, dstep, cx.gy(y + u), o);
             }
         }
     }

@@ -10,7 +10,11 @@
 //     16 bytes with wave-uniform v_perm selectors; rows outside the image are resolved to scalars before the loop;
 //   * vertically adjacent segments walk in opposite directions and sit on the same XCD (alt), so the rows they share are
 //     in L2 when the second one asks.
-// Requirements (checked on the host): 16-byte aligned rows, (W*cn) % CB == 0, W > RX, (RX+1)*cn <= CB, border in {CONSTANT,
+//   * a row whose byte length is not a multiple of CB ("ragged"): the last chunk is loaded from the last CB bytes of the row
+//     (so no byte outside the row is ever touched), its logical content -- the valid bytes followed by the border bytes its
+//     neighbours and its own outputs need -- is rebuilt from that load with the same kind of v_perm selectors, and its store is
+//     element-wise for the valid bytes only.  Everything else is unchanged, so aligned images pay nothing.
+// Requirements (checked on the host): W*cn >= CB, W > RX, (RX+1)*cn <= CB, border in {CONSTANT,
 // REPLICATE, REFLECT, REFLECT_101}.
 #pragma once
 #include "rt.h"
@@ -26,7 +30,7 @@ template <int RX, int CN, int CB = 16> struct Cfg {
 
 template <int HD, int MD = 4> struct Raw { uint32_t m[MD]; uint32_t side[HD]; };
 
-template <int HD> struct Edge { uint32_t la[HD], lb[HD], lc[HD], ra[HD], rb[HD], rc[HD]; };
+template <int HD, int MD = 4> struct Edge { uint32_t la[HD], lb[HD], lc[HD], ra[HD], rb[HD], rc[HD], oa[MD], ob[MD], oc[MD]; };
 
 __device__ __forceinline__ void selSetByte(uint32_t& a, uint32_t& b, uint32_t& c, int j, int idx /* 0..15 or <0 */)
 {
@@ -59,8 +63,9 @@ struct Ctx {
     typedef Raw<HD, MD> RawT;
     const uchar* src; size_t sstep;
     int H, lane, c, nchunks, mainOff, sideOff, y0, y1, nrows, up, frame;
-    bool active, hasFirst, hasLast, isLastChunk;
-    Edge<HD> es;
+    bool active, hasFirst, hasLast, isLastChunk, rag;
+    int vb;                                            // valid bytes of the last chunk (CB unless the row is ragged)
+    Edge<HD, MD> es;
     int rowBelow[RY > 0 ? RY : 1], rowAbove[RY > 0 ? RY : 1];
 
     // decode the work item of this wave; false when the wave has nothing to do
@@ -85,10 +90,13 @@ struct Ctx {
         c = strip * 64 + lane;
         y0 = seg * segRows; y1 = min(H, y0 + segRows); nrows = y1 - y0;
         active = c < nchunks; hasFirst = strip == 0; hasLast = strip == nstrips - 1; isLastChunk = c == nchunks - 1;
+        vb = W * CN - CB * (nchunks - 1);
+        rag = vb < CB;
         mainOff = CB * (active ? c : nchunks - 1);
+        if (rag && (!active || isLastChunk)) mainOff = W * CN - CB;      // the last CB bytes of the row
         const int c0 = strip * 64;
         const int leftOff = c0 > 0 ? CB * c0 - 4 * HD : 0;
-        const int rightOff = c0 + 64 < nchunks ? CB * (c0 + 64) : CB * (nchunks - 1);
+        const int rightOff = c0 + 64 < nchunks ? CB * (c0 + 64) : (rag ? W * CN - CB : CB * (nchunks - 1));   // (last strip: never used, only legal)
         sideOff = lane < 32 ? leftOff : rightOff;
 #pragma unroll
         for (int d = 0; d < HD; d++) { es.la[d] = es.lb[d] = es.lc[d] = es.ra[d] = es.rb[d] = es.rc[d] = 0x0c0c0c0cu; }
@@ -102,11 +110,30 @@ struct Ctx {
                 selSetByte(es.la[pos >> 2], es.lb[pos >> 2], es.lc[pos >> 2], pos & 3, sp < 0 ? -1 : sp * CN + (bt - px * CN));
             }
         }
-        if (hasLast) {
+#pragma unroll
+        for (int d = 0; d < MD; d++) { es.oa[d] = es.ob[d] = es.oc[d] = 0x0c0c0c0cu; }
+        if (hasLast && !rag) {
 #pragma unroll
             for (int t = 0; t < HB; t++) {
                 const int sp = mi355_borderInterpolate(W + t / CN, W, border);
                 selSetByte(es.ra[t >> 2], es.rb[t >> 2], es.rc[t >> 2], t & 3, sp < 0 ? -1 : sp * CN + (t % CN) - CB * (nchunks - 1));
+            }
+        }
+        if (hasLast && rag) {
+            // logical bytes j of the last chunk and its right halo: j < vb -> row byte CB*(nchunks-1)+j, then the border bytes;
+            // all expressed as positions in the load of the row's last CB bytes (only the first HB border bytes can matter)
+            const int base = W * CN - CB;
+#pragma unroll
+            for (int j = 0; j < CB + HB; j++) {
+                int idx = -1;
+                if (j < vb) idx = CB - vb + j;
+                else if (j - vb < HB) {
+                    const int t = j - vb;
+                    const int sp = mi355_borderInterpolate(W + t / CN, W, border);
+                    idx = sp < 0 ? -1 : sp * CN + (t % CN) - base;
+                }
+                if (j < CB) selSetByte(es.oa[j >> 2], es.ob[j >> 2], es.oc[j >> 2], j & 3, idx);
+                else selSetByte(es.ra[(j - CB) >> 2], es.rb[(j - CB) >> 2], es.rc[(j - CB) >> 2], (j - CB) & 3, idx);
             }
         }
 #pragma unroll
@@ -147,7 +174,13 @@ struct Ctx {
     // the lane's window of one row as dwords: X[0..HD) left halo, X[HD..HD+MD) own bytes, X[HD+MD..NW) right halo
     __device__ __forceinline__ void window(uint32_t (&X)[NW], const RawT& r) const
     {
-        const uint32_t (&mv)[MD] = r.m;
+        uint32_t mv[MD];
+#pragma unroll
+        for (int d = 0; d < MD; d++) mv[d] = r.m[d];
+        if (hasLast && rag) {
+#pragma unroll
+            for (int d = 0; d < MD; d++) { const uint32_t g = gatherOwn<MD>(r.m, es.oa[d], es.ob[d], es.oc[d]); mv[d] = isLastChunk ? g : mv[d]; }
+        }
         uint32_t hl[HD], hr[HD], hb[HD];
 #pragma unroll
         for (int d = 0; d < HD; d++) { hl[d] = r.side[d]; hr[d] = r.side[d]; }
@@ -168,6 +201,32 @@ struct Ctx {
         }
 #pragma unroll
         for (int d = 0; d < MD; d++) X[HD + d] = mv[d];
+    }
+    // the lane's outputs of image row y (OUTB bytes per source byte) -> memory; a ragged last chunk writes its valid elements only
+    template <int OUTB>
+    __device__ __forceinline__ void store(uchar* __restrict__ dst, size_t dstep, int y, const uint32_t (&o)[MD * OUTB]) const
+    {
+        if (!active) return;
+        uchar* p = dst + (size_t)y * dstep + (size_t)CB * OUTB * (size_t)c;
+        if (!(rag && isLastChunk)) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if constexpr ((MD * OUTB) % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < MD * OUTB / 4; q++)
+                    __builtin_nontemporal_store(u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}, reinterpret_cast<u32x4*>(p) + q);
+            } else
+                __builtin_nontemporal_store(u32x2{o[0], o[1]}, reinterpret_cast<u32x2*>(p));
+        } else {
+#pragma unroll
+            for (int e = 0; e < CB; e++) {
+                if (e < vb) {
+                    if constexpr (OUTB == 4) reinterpret_cast<uint32_t*>(p)[e] = o[e];
+                    else if constexpr (OUTB == 2) reinterpret_cast<unsigned short*>(p)[e] = (unsigned short)(o[e >> 1] >> (16 * (e & 1)));
+                    else p[e] = (uchar)(o[e >> 2] >> (8 * (e & 3)));
+                }
+            }
+        }
     }
 };
 
@@ -195,9 +254,13 @@ __device__ __forceinline__ uint32_t pairAt(const uint32_t* E, const uint32_t* O,
 // host side: eligibility of the rolling path and launch geometry
 inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t ds, size_t df, int W, int cn, int rx, int border, int cb = 16)
 {
-    if ((((uintptr_t)s | ss | sf | (uintptr_t)d | ds | df) & 15) != 0) return false;
+    // row starts need no alignment: gfx950 serves unaligned dwordx4 global accesses (at some cost in sectors touched)
+    (void)s; (void)ss; (void)sf; (void)d; (void)ds; (void)df;
     // halos come from the neighbouring chunk (rx*cn <= cb) and, at the image border, from pixels 0..rx of the lane's OWN chunk
-    if ((W * cn) % cb != 0 || W <= rx || (rx + 1) * cn > cb) return false;
+    // (for a ragged row: from the row's last cb bytes)
+    if (W * cn < cb || W <= rx || (rx + 1) * cn > cb) return false;
+    const int nchunks = (W * cn + cb - 1) / cb, vb = W * cn - cb * (nchunks - 1);
+    if (vb < cb && nchunks % 64 == 1 && vb < 4 * ((rx * cn + 3) / 4)) return false;   // the ragged chunk opens a strip: the previous strip's side load would cross the row end
     return border == mi355::B_CONSTANT || border == mi355::B_REPLICATE || border == mi355::B_REFLECT || border == mi355::B_REFLECT_101;
 }
 
@@ -205,7 +268,7 @@ struct Geom { int nchunks, nstrips, seg, nseg; unsigned blocks; };
 inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16)
 {
     Geom g;
-    g.nchunks = W * cn / cb; g.nstrips = mi355::divUp(g.nchunks, 64);
+    g.nchunks = mi355::divUp(W * cn, cb); g.nstrips = mi355::divUp(g.nchunks, 64);
     long long per = (long long)g.nstrips * nframes;
     long long wantSeg = (2048 + per - 1) / per;
     int seg = (int)((H + wantSeg - 1) / wantSeg);

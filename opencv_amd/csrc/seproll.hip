@@ -52,12 +52,7 @@ __device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P
                 cx.issue(raw[u], y + u + KY + RY, rv[u]);
                 uint32_t o[OD];
                 P::template vpass<UP>(ring, u, a, o);
-                if (cx.active) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)cx.gy(y + u) * dstep + P::CB * P::OUTB * (size_t)cx.c);
-#pragma unroll
-                    for (int q = 0; q < OD / 4; q++) __builtin_nontemporal_store(u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}, out + q);
-                }
+                cx.template store<P::OUTB>(dst, dstep, cx.gy(y + u), o);
             }
         }
     }
@@ -393,7 +388,7 @@ bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, s
     long long ax = 0, ay = 0;
     for (int i = 0; i < n; i++) { ax += kx[i] < 0 ? -kx[i] : kx[i]; ay += ky[i] < 0 ? -ky[i] : ky[i]; }
     if (255 * ax > 32767 || 255 * ax * ay > 32767) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & 1) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
 #define DV(K_) do { typedef Deriv16<K_> P; P::Args a; \
         for (int i = 0; i < K_; i++) { a.kx[i] = ((uint32_t)kx[i] & 0xffffu) * 0x10001u; a.ky[i] = ((uint32_t)ky[i] & 0xffffu) * 0x10001u; } \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
@@ -406,7 +401,7 @@ bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
                   int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
 {
     if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & 15) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
 #define SF(K_, S_, O_) do { typedef SepF32<K_, S_, O_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st); } while (0)
 #define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)

@@ -83,6 +83,37 @@ def test_filter2d_rolling_path(cv, orc, cn, K):
         assert np.array_equal(got[i], orc.orc_filter2D(fr[i], -1, kern, (-1, -1), 0.0, 1))
 
 
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_ragged_and_unaligned_rows_on_the_rolling_kernels(cv, orc, cn):
+    """Row lengths that are not a multiple of 16 bytes, on tightly packed (so mostly unaligned) rows and on padded / offset
+    views: the rolling kernels rebuild the last chunk from the row's last 16 bytes and store only its valid bytes."""
+    rng = np.random.default_rng(40 + cn)
+    kern = (rng.random((3, 3), dtype=np.float32) - 0.4).astype(np.float32) / 3
+    for (w, h) in [(17, 3), (23, 9), (100, 33), (1000, 21), (1027, 18), (2049, 7), (65 * 16 // cn + 1, 11)]:
+        if w * cn < 16:
+            continue
+        base = rng.integers(0, 256, (h, w + 5, cn) if cn > 1 else (h, w + 5), dtype=np.uint8)
+        views = [np.ascontiguousarray(base[:, :w]), base[:, 3:3 + w]]                    # packed rows; offset view with a pitch of w+5 pixels
+        for src in views:
+            d = torch.from_numpy(np.ascontiguousarray(base)).cuda()[:, 3:3 + w] if src is views[1] else dev(src)
+            srcc = np.ascontiguousarray(src)
+            for border in (0, 1, 2, 4):
+                check(cv.filter2D(d, -1, kern, (-1, -1), 1.5, border | 16), orc.orc_filter2D(srcc, -1, kern, (-1, -1), 1.5, border))
+                check(cv.boxFilter(d, -1, (5, 5), (-1, -1), True, border | 16), orc.orc_boxFilter(srcc, -1, (5, 5), (-1, -1), True, border))
+                check(cv.GaussianBlur(d, (5, 5), 1.2, 1.2, border | 16), orc.orc_sepSmoothFixedU8(srcc, [int(v) for v in orc.orc_getGaussianKernelQ(5, 1.2)],
+                                                                                              [int(v) for v in orc.orc_getGaussianKernelQ(5, 1.2)], border))
+                check(cv.GaussianBlur(d, (5, 5), 0, 0, border | 16), orc.orc_gaussianBlurBinomialU8(srcc, 5, border))
+                check(cv.dilate(d, np.ones((3, 3), np.uint8), (-1, -1), 1, border | 16), orc.orc_morph(1, srcc, np.ones((3, 3), np.uint8), (-1, -1), border))
+                check(cv.erode(d, np.ones((5, 5), np.uint8), (-1, -1), 1, border | 16), orc.orc_morph(0, srcc, np.ones((5, 5), np.uint8), (-1, -1), border))
+                if cn == 1:
+                    check(cv.Sobel(d, cv.CV_16S, 1, 0, 3, 1.0, 0.0, border | 16), orc.orc_Sobel(srcc, 3, 1, 0, 3, 1.0, 0.0, border))
+                    check(cv.Sobel(d, cv.CV_32F, 0, 1, 3, 0.5, 0.0, border | 16), orc.orc_Sobel(srcc, 5, 0, 1, 3, 0.5, 0.0, border))
+                    want = orc.orc_cornerHarris(srcc, 2, 3, 0.04, border)
+                    got = cv.cornerHarris(d, 2, 3, 0.04, border | 16).cpu().numpy()
+                    import orc as O
+                    assert O.rel_err(got, want) <= 1e-4, (w, h, border)
+
+
 def test_filter2d_depths_and_roi(cv, orc):
     rng = np.random.default_rng(5)
     k5 = (rng.uniform(-3, 10, (5, 5)) / 37.0).astype(np.float32)

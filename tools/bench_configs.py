@@ -77,6 +77,11 @@ def run(quick=False):
     line("f1 threshold BINARY 4K 8U", timeit(lambda: cv.threshold(one, 127, 255, cv.THRESH_BINARY, dst=d8)), 3840 * 2160 * 2)
     line("f1 dilate 3x3 4K 8U", timeit(lambda: cv.dilate(one, dst=d8)), 3840 * 2160 * 2)
     line("f1 erode 5x5 4K 8U", timeit(lambda: cv.erode(one, np.ones((5, 5), np.uint8), dst=d8)), 3840 * 2160 * 2)
+    rg = gray[0][:, :3838].contiguous(); rgd = torch.empty_like(rg)          # 3838-byte rows: ragged AND unaligned row starts
+    ms = timeit(lambda: cv.GaussianBlur(rg, (5, 5), 1.5, dst=rgd))
+    out.append({"config": "a1 GaussianBlur 5x5 sigma 1.5 on 3838x2160 8U (ragged, unaligned rows)", "ms": round(ms, 4), "Mpix_s": round(3838 * 2160 / ms / 1e3, 1)})
+    ms = timeit(lambda: cv.filter2D(rg, -1, k, dst=rgd))
+    out.append({"config": "a3 filter2D 3x3 on 3838x2160 8U (ragged, unaligned rows)", "ms": round(ms, 4), "Mpix_s": round(3838 * 2160 / ms / 1e3, 1)})
     hd = bgr[0][:1080, :1920].contiguous(); hdd = torch.empty_like(hd)
     ms = timeit(lambda: cv.GaussianBlur(hd, (5, 5), 0, dst=hdd))
     out.append({"config": "cfg1 GaussianBlur 5x5 one 1080p 8UC3 frame", "ms": round(ms, 4), "Mpix_s": round(2.0736 / ms * 1e3, 1), "bound": "hbm",
