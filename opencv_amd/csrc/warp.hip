@@ -204,6 +204,71 @@ __global__ __launch_bounds__(256) void k_resize_lin1(const uchar* __restrict__ s
     }
 }
 
+// the same for interleaved channels: a thread owns one destination PIXEL column; the 2*CN source elements of its two
+// horizontal taps are adjacent in memory and come from one unaligned load per source row (8 bytes for 3 or 4 8-bit channels,
+// CN float pairs otherwise); the last source columns, where that load would leave the row, read element by element
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void k_resize_linC(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RROWS;
+    if (dx >= a.dw || yb >= a.dh) return;
+    const int areaMode = a.mode == 2;
+    int sx; float fx;
+    linCoef(dx, a.scale_x, a.inv_x, areaMode, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    bool edge = false;
+    if (sx + 1 >= a.sw) { edge = true; if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; } }
+    const float a0f = 1.f - fx, a1f = fx;
+    const int a0 = satShort(__float2int_rn(a0f * 2048)), a1 = satShort(__float2int_rn(a1f * 2048));
+    const bool wide = sizeof(T) == 4 ? !edge : (sx * CN + 8 <= a.sw * CN);       // the 8-byte load stays inside the row
+    const int ye = min(yb + RROWS, a.dh);
+    for (int dy = yb; dy < ye; dy++) {
+        int sy; float fy;
+        linCoef(dy, a.scale_y, a.inv_y, areaMode, sy, fy);
+        const int y0 = clipI(sy, 0, a.sh), y1 = clipI(sy + 1, 0, a.sh);
+        const float b0f = 1.f - fy, b1f = fy;
+        const uchar* r0 = src + (size_t)y0 * sstep + (size_t)sx * CN * sizeof(T);
+        const uchar* r1 = src + (size_t)y1 * sstep + (size_t)sx * CN * sizeof(T);
+        if (sizeof(T) == 4) {
+            float* D = reinterpret_cast<float*>(dst + (size_t)dy * dstep) + (size_t)dx * CN;
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const float p00 = reinterpret_cast<const float*>(r0)[c], p10 = reinterpret_cast<const float*>(r1)[c];
+                float t0 = p00, t1 = p10;
+                if (!edge) {
+                    const float p01 = reinterpret_cast<const float*>(r0)[CN + c], p11 = reinterpret_cast<const float*>(r1)[CN + c];
+                    t0 = __fadd_rn(__fmul_rn(p00, a0f), __fmul_rn(p01, a1f)); t1 = __fadd_rn(__fmul_rn(p10, a0f), __fmul_rn(p11, a1f));
+                }
+                D[c] = __fadd_rn(__fmul_rn(t0, b0f), __fmul_rn(t1, b1f));
+            }
+        } else {
+            const int b0 = satShort(__float2int_rn(b0f * 2048)), b1 = satShort(__float2int_rn(b1f * 2048));
+            unsigned long long q0 = 0, q1 = 0;
+            if (wide) {
+                typedef unsigned long long u64u __attribute__((aligned(1)));
+                q0 = *reinterpret_cast<const u64u*>(r0); q1 = *reinterpret_cast<const u64u*>(r1);
+            } else {
+                const int nb = edge ? CN : 2 * CN;
+                for (int k = 0; k < nb; k++) { q0 |= (unsigned long long)r0[k] << (8 * k); q1 |= (unsigned long long)r1[k] << (8 * k); }
+            }
+            uchar* D = dst + (size_t)dy * dstep + (size_t)dx * CN;
+            unsigned pk = 0;
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const int p00 = (int)((q0 >> (8 * c)) & 255), p01 = (int)((q0 >> (8 * (CN + c))) & 255);
+                const int p10 = (int)((q1 >> (8 * c)) & 255), p11 = (int)((q1 >> (8 * (CN + c))) & 255);
+                const int t0 = edge ? p00 * 2048 : p00 * a0 + p01 * a1;
+                const int t1 = edge ? p10 * 2048 : p10 * a0 + p11 * a1;
+                const unsigned r = (unsigned)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2) & 255u;
+                pk |= r << (8 * c);
+            }
+            if (CN == 4) *reinterpret_cast<unsigned*>(D) = pk;
+            else { D[0] = (uchar)pk; D[1] = (uchar)(pk >> 8); D[2] = (uchar)(pk >> 16); }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -350,41 +415,77 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
 // 8-byte (32F) / 2-byte (8U) load per source row; pixels whose 2x2 footprint is not strictly inside the source take the
 // generic sampler.  A wave walks down WROWS rows, so the source lines it touched for one row are in L1 for the next.
 constexpr int WROWS = 8;
-template <typename T>
-__global__ __launch_bounds__(256) void k_warp_affine_lin1(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tab)
+template <typename T, int CN, int KIND /*0 affine, 1 perspective*/>
+__global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                  SampleArgs s, WarpArgs w, const short* __restrict__ tab)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * WROWS;
     if (x >= w.dw || yb >= w.dh) return;
-    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0));
-    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0));
+    const int ad = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0)) : 0;
+    const int bd = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0)) : 0;
+    const int xb = KIND == 1 ? (x / w.bw0) * w.bw0 : 0, x1 = x - xb;
+    // the pair (sx, sx+1) is read as ONE load of 2*CN elements where that cannot leave the row (3 channels: an 8-byte load for 6)
+    const int xlim = CN == 3 ? s.sw - 2 : s.sw - 1;
     const int ye = min(yb + WROWS, w.dh);
     for (int y = yb; y < ye; y++) {
-        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
-        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
-        const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
+        int X, Y;
+        if (KIND == 0) {
+            const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+            const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+            X = (X0 + ad) >> 5; Y = (Y0 + bd) >> 5;
+        } else {
+            const double X0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[0], (double)xb), __dmul_rn(w.M[1], (double)y)), w.M[2]);
+            const double Y0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[3], (double)xb), __dmul_rn(w.M[4], (double)y)), w.M[5]);
+            const double W0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[6], (double)xb), __dmul_rn(w.M[7], (double)y)), w.M[8]);
+            double W = __dadd_rn(W0, __dmul_rn(w.M[6], (double)x1));
+            W = W != 0 ? __ddiv_rn(32.0, W) : 0;
+            double fX = __dmul_rn(__dadd_rn(X0, __dmul_rn(w.M[0], (double)x1)), W);
+            double fY = __dmul_rn(__dadd_rn(Y0, __dmul_rn(w.M[3], (double)x1)), W);
+            fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
+            fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
+            X = satIntD(fX); Y = satIntD(fY);
+        }
         const int sx = satShort(X >> 5), sy = satShort(Y >> 5), ax = X & 31, ay = Y & 31;
-        uchar* D = dst + (size_t)y * dstep + (size_t)x * sizeof(T);
-        if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
-            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * sizeof(T);
+        uchar* D = dst + (size_t)y * dstep + (size_t)x * CN * sizeof(T);
+        if ((unsigned)sx < (unsigned)xlim && (unsigned)sy < (unsigned)(s.sh - 1)) {
+            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * CN * sizeof(T);
             if (sizeof(T) == 4) {
-                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-                const f2u p0 = *reinterpret_cast<const f2u*>(r0), p1 = *reinterpret_cast<const f2u*>(r0 + sstep);
                 const float s32 = 1.f / 32;
                 const float fx = ax * s32, fy = ay * s32;
                 const float wy0 = 1.f - fy, wx0 = 1.f - fx;
                 const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
-                float t = __fadd_rn(__fmul_rn(p0.x, w0), __fmul_rn(p0.y, w1));
-                t = __fadd_rn(t, __fmul_rn(p1.x, w2));
-                t = __fadd_rn(t, __fmul_rn(p1.y, w3));
-                *reinterpret_cast<float*>(D) = t;
+                float p0[2 * CN], p1[2 * CN];
+                typedef float fNu __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+                for (int q = 0; q < CN; q++) {
+                    const fNu v0 = reinterpret_cast<const fNu*>(r0)[q], v1 = reinterpret_cast<const fNu*>(r0 + sstep)[q];
+                    p0[2 * q] = v0.x; p0[2 * q + 1] = v0.y; p1[2 * q] = v1.x; p1[2 * q + 1] = v1.y;
+                }
+#pragma unroll
+                for (int c = 0; c < CN; c++) {
+                    float t = __fadd_rn(__fmul_rn(p0[c], w0), __fmul_rn(p0[CN + c], w1));
+                    t = __fadd_rn(t, __fmul_rn(p1[c], w2));
+                    t = __fadd_rn(t, __fmul_rn(p1[CN + c], w3));
+                    reinterpret_cast<float*>(D)[c] = t;
+                }
             } else {
-                typedef unsigned short u16u __attribute__((aligned(1)));
-                const unsigned p0 = *reinterpret_cast<const u16u*>(r0), p1 = *reinterpret_cast<const u16u*>(r0 + sstep);
                 const short4 wq = *reinterpret_cast<const short4*>(tab + (ay * 32 + ax) * 4);
-                const int r = ((int)(p0 & 255) * wq.x + (int)(p0 >> 8) * wq.y + (int)(p1 & 255) * wq.z + (int)(p1 >> 8) * wq.w + (1 << 14)) >> 15;
-                *D = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+                unsigned long long q0, q1;                       // the 2*CN bytes of each source row
+                if (CN == 1) {
+                    typedef unsigned short u16u __attribute__((aligned(1)));
+                    q0 = *reinterpret_cast<const u16u*>(r0); q1 = *reinterpret_cast<const u16u*>(r0 + sstep);
+                } else {
+                    typedef unsigned long long u64u __attribute__((aligned(1)));
+                    q0 = *reinterpret_cast<const u64u*>(r0); q1 = *reinterpret_cast<const u64u*>(r0 + sstep);
+                }
+#pragma unroll
+                for (int c = 0; c < CN; c++) {
+                    const int v0 = (int)((q0 >> (8 * c)) & 255), v1 = (int)((q0 >> (8 * (CN + c))) & 255);
+                    const int v2 = (int)((q1 >> (8 * c)) & 255), v3 = (int)((q1 >> (8 * (CN + c))) & 255);
+                    const int r = (v0 * wq.x + v1 * wq.y + v2 * wq.z + v3 * wq.w + (1 << 14)) >> 15;
+                    D[c] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+                }
             }
         } else
             samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab);
@@ -434,10 +535,15 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (M) for (int i = 0; i < (kind == 0 ? 6 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
-    if (kind == 0 && s.linear && cn == 1 && (depth == D32F || depth == D8U) && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
+    if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && (dss % e) == 0 &&
+        ((uintptr_t)ds % e) == 0) {
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS));
-        if (depth == D32F) hipLaunchKernelGGL(k_warp_affine_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
-        else hipLaunchKernelGGL(k_warp_affine_lin1<uchar>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
+#define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev)
+#define WLC(T_, K_) do { if (cn == 1) WL(T_, 1, K_); else if (cn == 3) WL(T_, 3, K_); else WL(T_, 4, K_); } while (0)
+        if (kind == 0) { if (depth == D32F) WLC(float, 0); else WLC(uchar, 0); }
+        else           { if (depth == D32F) WLC(float, 1); else WLC(uchar, 1); }
+#undef WLC
+#undef WL
         return stg.finish(entry);
     }
     dim3 grid(divUp(dw, 64), divUp(dh, 4));
@@ -484,6 +590,14 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
         dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
         if (depth == D32F) hipLaunchKernelGGL(k_resize_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
         else hipLaunchKernelGGL(k_resize_lin1<uchar>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
+        return stg.finish("resize");
+    }
+    if ((a.mode == 1 || a.mode == 2) && (cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
+        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
+#define RLC(T_, CN_) hipLaunchKernelGGL((k_resize_linC<T_, CN_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, a)
+        if (depth == D32F) { if (cn == 3) RLC(float, 3); else RLC(float, 4); }
+        else { if (cn == 3) RLC(uchar, 3); else RLC(uchar, 4); }
+#undef RLC
         return stg.finish("resize");
     }
     dim3 grid(divUp(dst_width, 64), divUp(dst_height, 4));

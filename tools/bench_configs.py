@@ -77,6 +77,25 @@ def run(quick=False):
     line("f1 threshold BINARY 4K 8U", timeit(lambda: cv.threshold(one, 127, 255, cv.THRESH_BINARY, dst=d8)), 3840 * 2160 * 2)
     line("f1 dilate 3x3 4K 8U", timeit(lambda: cv.dilate(one, dst=d8)), 3840 * 2160 * 2)
     line("f1 erode 5x5 4K 8U", timeit(lambda: cv.erode(one, np.ones((5, 5), np.uint8), dst=d8)), 3840 * 2160 * 2)
+    c3 = bgr[0]
+    def line2(name, ms, by):
+        out.append({"config": name, "ms": round(ms, 4), "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    r720 = torch.empty((720, 1280, 3), dtype=torch.uint8, device=dev); r1080 = torch.empty((1080, 1920, 3), dtype=torch.uint8, device=dev)
+    line2("a7 resize 4K 8UC3 -> 1280x720 bilinear", timeit(lambda: cv.resize(c3, (1280, 720), dst=r720)), 3840 * 2160 * 3 + 1280 * 720 * 3)
+    line2("a7 resize 4K 8UC3 -> 1920x1080 (area-fast)", timeit(lambda: cv.resize(c3, (1920, 1080), dst=r1080)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
+    up = torch.empty((2160, 3840, 3), dtype=torch.uint8, device=dev)
+    line2("a7 resize 1080p 8UC3 -> 4K bilinear", timeit(lambda: cv.resize(r1080, (3840, 2160), dst=up)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
+    Mw = cv.getRotationMatrix2D((1920.0, 1080.0), 7.0, 0.95)
+    line2("a8 warpAffine 4K 8UC3 rot 7deg", timeit(lambda: cv.warpAffine(c3, Mw, (3840, 2160), dst=up)), 3840 * 2160 * 6)
+    P3 = np.array([[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]])
+    line2("a9 warpPerspective 4K 8UC3", timeit(lambda: cv.warpPerspective(c3, P3, (3840, 2160), dst=up)), 3840 * 2160 * 6)
+    g1 = gray[0]; g1d = torch.empty_like(g1)
+    line2("a9 warpPerspective 4K 8UC1", timeit(lambda: cv.warpPerspective(g1, P3, (3840, 2160), dst=g1d)), 3840 * 2160 * 2)
+    rgb = torch.empty_like(c3)
+    line2("a6 cvtColor BGR2RGB 4K 8UC3", timeit(lambda: cv.cvtColor(c3, cv.COLOR_BGR2RGB, dst=rgb)), 3840 * 2160 * 6)
+    line2("a6 cvtColor GRAY2BGR 4K 8U", timeit(lambda: cv.cvtColor(g1, cv.COLOR_GRAY2BGR, dst=rgb)), 3840 * 2160 * 4)
+    line2("a1 GaussianBlur 5x5 4K 8UC3 (single frame)", timeit(lambda: cv.GaussianBlur(c3, (5, 5), 0, dst=rgb)), 3840 * 2160 * 6)
+    del r720, r1080, up, rgb, g1d
     rg = gray[0][:, :3838].contiguous(); rgd = torch.empty_like(rg)          # 3838-byte rows: ragged AND unaligned row starts
     ms = timeit(lambda: cv.GaussianBlur(rg, (5, 5), 1.5, dst=rgd))
     out.append({"config": "a1 GaussianBlur 5x5 sigma 1.5 on 3838x2160 8U (ragged, unaligned rows)", "ms": round(ms, 4), "Mpix_s": round(3838 * 2160 / ms / 1e3, 1)})
