@@ -28,53 +28,92 @@ namespace {
 enum { D8U = MI355CV_8U, D32S = MI355CV_32S, D32F = MI355CV_32F, D64F = MI355CV_64F };
 
 // ---------------------------------------------------------------------------------- integral images
-// sum/sqsum are (H+1) x (W+1) x cn doubles, first row/column zero (cv::integral layout, sumpixels.simd.hpp).
+// cv::integral layout (sumpixels.simd.hpp): (H+1) x (W+1) x cn, first row / column zero.  sum in int32 (8-bit sources: exact, the
+// reference's default) or double, squared sum in double.  Three passes, each with enough independent work to fill the chip:
+//   rows    one workgroup per (row, channel): chunked scan of the row -> row-wise prefix sums
+//   colseg  one thread per (column, segment of IS_SEG rows): prefix down the segment in place, segment total to `aux`
+//   coladd  one thread per (column, segment >= 1): adds the totals of the segments above
+// (a single thread walking a whole column would leave all but ~16 CUs idle and serialise 2160 dependent adds).
+constexpr int IS_SEG = 64;
+
+template <typename TS>
 __global__ __launch_bounds__(256) void k_integral_rows(const uchar* __restrict__ src, size_t sstep, size_t sframe, int W, int H, int cn, int depth,
-                                                       double* __restrict__ sum, double* __restrict__ sq, size_t istep /*doubles*/, size_t iframe)
+                                                       TS* __restrict__ sum, size_t sumStep /*elements*/, size_t sumFrame,
+                                                       double* __restrict__ sq, size_t sqStep, size_t sqFrame)
 {
     const int y = blockIdx.x, c = blockIdx.y;
-    src += (size_t)blockIdx.z * sframe; sum += (size_t)blockIdx.z * iframe; if (sq) sq += (size_t)blockIdx.z * iframe;
+    src += (size_t)blockIdx.z * sframe; sum += (size_t)blockIdx.z * sumFrame; if (sq) sq += (size_t)blockIdx.z * sqFrame;
     const uchar* row = src + (size_t)y * sstep;
     const int chunk = (W + 255) / 256;
     const int x0 = threadIdx.x * chunk, x1 = min(W, x0 + chunk);
-    double s = 0, q = 0;
-    for (int x = x0; x < x1; x++) {
-        const double v = depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c];
-        s += v; q += v * v;
-    }
-    __shared__ double ss[256], qq[256];
+    auto px = [&](int x) -> double { return depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c]; };
+    TS s = 0; double q = 0;
+    for (int x = x0; x < x1; x++) { const double v = px(x); s += (TS)v; q += v * v; }
+    __shared__ TS ss[256];
+    __shared__ double qq[256];
     ss[threadIdx.x] = s; qq[threadIdx.x] = q;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele inclusive scan over the 256 chunk totals
-        double a = 0, b = 0;
+        TS a = 0; double b = 0;
         if ((int)threadIdx.x >= o) { a = ss[threadIdx.x - o]; b = qq[threadIdx.x - o]; }
         __syncthreads();
         ss[threadIdx.x] += a; qq[threadIdx.x] += b;
         __syncthreads();
     }
-    double ps = threadIdx.x ? ss[threadIdx.x - 1] : 0.0, pq = threadIdx.x ? qq[threadIdx.x - 1] : 0.0;
-    double* srow = sum + (size_t)(y + 1) * istep;
-    double* qrow = sq ? sq + (size_t)(y + 1) * istep : nullptr;
+    TS ps = threadIdx.x ? ss[threadIdx.x - 1] : (TS)0; double pq = threadIdx.x ? qq[threadIdx.x - 1] : 0.0;
+    TS* srow = sum + (size_t)(y + 1) * sumStep;
+    double* qrow = sq ? sq + (size_t)(y + 1) * sqStep : nullptr;
     if (threadIdx.x == 0) { srow[c] = 0; if (qrow) qrow[c] = 0; }
     for (int x = x0; x < x1; x++) {
-        const double v = depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c];
-        ps += v; pq += v * v;
+        const double v = px(x);
+        ps += (TS)v; pq += v * v;
         srow[(x + 1) * cn + c] = ps;
         if (qrow) qrow[(x + 1) * cn + c] = pq;
     }
 }
 
-__global__ __launch_bounds__(256) void k_integral_cols(double* __restrict__ sum, double* __restrict__ sq, size_t istep, size_t iframe, int Wc /* (W+1)*cn */, int H)
+template <typename T>
+__global__ __launch_bounds__(256) void k_integral_colseg(T* __restrict__ a, size_t step, size_t frame, int Wc /* (W+1)*cn */, int H, T* __restrict__ aux, size_t auxFrame)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (x >= Wc) return;
-    sum += (size_t)blockIdx.z * iframe; if (sq) sq += (size_t)blockIdx.z * iframe;
-    double s = 0, q = 0;
-    sum[x] = 0; if (sq) sq[x] = 0;
-    for (int y = 1; y <= H; y++) {
-        s += sum[(size_t)y * istep + x]; sum[(size_t)y * istep + x] = s;
-        if (sq) { q += sq[(size_t)y * istep + x]; sq[(size_t)y * istep + x] = q; }
+    a += (size_t)blockIdx.z * frame + x; aux += (size_t)blockIdx.z * auxFrame;
+    const int y0 = 1 + seg * IS_SEG, y1 = min(H + 1, y0 + IS_SEG);
+    if (seg == 0) a[0] = 0;
+    T s = 0;
+    int y = y0;
+    for (; y + 8 <= y1; y += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = a[(size_t)(y + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s += v[u]; a[(size_t)(y + u) * step] = s; }
     }
+    for (; y < y1; y++) { s += a[(size_t)y * step]; a[(size_t)y * step] = s; }
+    aux[(size_t)seg * Wc + x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_integral_coladd(T* __restrict__ a, size_t step, size_t frame, int Wc, int H, const T* __restrict__ aux, size_t auxFrame)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y + 1;
+    if (x >= Wc) return;
+    a += (size_t)blockIdx.z * frame + x; aux += (size_t)blockIdx.z * auxFrame;
+    T off = 0;
+    for (int s = 0; s < seg; s++) off += aux[(size_t)s * Wc + x];
+    const int y0 = 1 + seg * IS_SEG, y1 = min(H + 1, y0 + IS_SEG);
+#pragma unroll 8
+    for (int y = y0; y < y1; y++) a[(size_t)y * step] += off;
+}
+
+// column passes over one array; aux = nseg x Wc scratch elements per frame
+template <typename T>
+void integralColumns(T* a, size_t step, size_t frame, int Wc, int H, int nframes, T* aux, hipStream_t st)
+{
+    const int nseg = divUp(H, IS_SEG);
+    hipLaunchKernelGGL(k_integral_colseg<T>, dim3(divUp(Wc, 256), nseg, nframes), dim3(256), 0, st, a, step, frame, Wc, H, aux, (size_t)nseg * Wc);
+    if (nseg > 1)
+        hipLaunchKernelGGL(k_integral_coladd<T>, dim3(divUp(Wc, 256), nseg - 1, nframes), dim3(256), 0, st, a, step, frame, Wc, H, aux, (size_t)nseg * Wc);
 }
 
 // ---------------------------------------------------------------------------------- window sums (8UC1 fast path)
@@ -492,8 +531,12 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         dsum = (double*)stg.scratch(iframeD * nframes * sizeof(double));
         dsq = (double*)stg.scratch(iframeD * nframes * sizeof(double));
         if (!dsum || !dsq) return MI355CV_NOT_IMPLEMENTED;
-        hipLaunchKernelGGL(k_integral_rows, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, dsq, isteps, iframeD);
-        hipLaunchKernelGGL(k_integral_cols, dim3(divUp((int)isteps, 256), 1, nframes), dim3(256), 0, st, dsum, dsq, isteps, iframeD, (int)isteps, ih);
+        const int nseg = divUp(ih, IS_SEG);
+        double* aux = (double*)stg.scratch((size_t)nseg * isteps * nframes * sizeof(double));
+        if (!aux) return MI355CV_NOT_IMPLEMENTED;
+        hipLaunchKernelGGL(k_integral_rows<double>, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, isteps, iframeD, dsq, isteps, iframeD);
+        integralColumns<double>(dsum, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
+        integralColumns<double>(dsq, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
     }
     const size_t wframe = (size_t)rw * rh, s1frame = (size_t)rw * ih;
     if (useMfma) {
@@ -576,26 +619,38 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
                     templ_width, templ_height, type, result_data, result_step, nframes == 1 ? 0 : result_frame_stride, method);
 }
 
-// replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415) for the depth
-// combinations matchTemplate-style consumers use: sum and sqsum CV_64F (source 8U or 32F), no tilted sum.
+// replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415): CV_8U sources with the sum in
+// CV_32S (the reference's default; exact) or CV_64F, CV_32F sources with CV_64F sums; squared sum in CV_64F; no tilted sum.
+// (CV_32F sums of 8-bit data depend on the summation order beyond 2^24 and are left to the CPU.)
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar* src_data, size_t src_step, uchar* sum_data, size_t sum_step,
                                  uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
 {
     (void)tilted_step;
     if (disabled() || tilted_data || !sum_data) return MI355CV_NOT_IMPLEMENTED;
-    if ((depth != D8U && depth != D32F) || sdepth != D64F || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (width <= 0 || height <= 0 || (sum_step % 8) || (sqsum_data && sqsum_step != sum_step)) return MI355CV_NOT_IMPLEMENTED;
+    const bool ok = (depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F);
+    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    const size_t se = sdepth == D32S ? 4 : 8;
+    if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return MI355CV_NOT_IMPLEMENTED;
+    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;     // would wrap; the CPU wraps its own way
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     Stager stg; size_t dss, d1, d2 = 0;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * (depth == D8U ? 1 : 4), height, &dss);
-    uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * 8, height + 1, &d1);
+    uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * se, height + 1, &d1);
     uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * 8, height + 1, &d2) : nullptr;
-    if (!ds || !s1 || (sqsum_data && (!s2 || d2 != d1))) return MI355CV_NOT_IMPLEMENTED;
-    const size_t istep = d1 / 8;
+    if (!ds || !s1 || (sqsum_data && !s2)) return MI355CV_NOT_IMPLEMENTED;
+    const int Wc = (width + 1) * cn, nseg = divUp(height, IS_SEG);
+    void* aux = stg.scratch((size_t)nseg * Wc * 8);
+    if (!aux) return MI355CV_NOT_IMPLEMENTED;
     hipStream_t st = stream();
-    hipLaunchKernelGGL(k_integral_rows, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (double*)s1, (double*)s2, istep, 0);
-    hipLaunchKernelGGL(k_integral_cols, dim3(divUp((width + 1) * cn, 256), 1, 1), dim3(256), 0, st, (double*)s1, (double*)s2, istep, 0, (width + 1) * cn, height);
+    if (sdepth == D32S) {
+        hipLaunchKernelGGL(k_integral_rows<int>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (int*)s1, d1 / 4, 0, (double*)s2, d2 / 8, 0);
+        integralColumns<int>((int*)s1, d1 / 4, 0, Wc, height, 1, (int*)aux, st);
+    } else {
+        hipLaunchKernelGGL(k_integral_rows<double>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (double*)s1, d1 / 8, 0, (double*)s2, d2 / 8, 0);
+        integralColumns<double>((double*)s1, d1 / 8, 0, Wc, height, 1, (double*)aux, st);
+    }
+    if (s2) integralColumns<double>((double*)s2, d2 / 8, 0, Wc, height, 1, (double*)aux, st);
     return stg.finish("integral");
 }
 

@@ -737,20 +737,25 @@ def matchTemplateBatch(frames, templ, method, result=None):
     return out
 
 
-def integral(src, sqsum=False):
-    """cv::integral with CV_64F outputs: (H+1)x(W+1)[xC] sum (and squared sum)."""
+def integral(src, sqsum=False, sdepth=-1):
+    """cv::integral: (H+1)x(W+1)[xC] sum and, optionally, squared sum (CV_64F).  sdepth -1 = the reference's default (CV_32S for
+    8-bit sources, CV_64F otherwise, sumpixels.dispatch.cpp:470-480); CV_32S and CV_64F are supported."""
     s = Img(src)
+    CV_32S, CV_64F = 4, 6
+    if sdepth <= 0:
+        sdepth = CV_32S if s.depth == CV_8U else CV_64F
+    if sdepth not in (CV_32S, CV_64F):
+        raise NotImplementedError("integral: sdepth")
+    shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
     if torch is not None and isinstance(src, torch.Tensor):
-        shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
-        sm = torch.empty(shape, dtype=torch.float64, device=src.device)
+        sm = torch.empty(shape, dtype=torch.int32 if sdepth == CV_32S else torch.float64, device=src.device)
         sq = torch.empty(shape, dtype=torch.float64, device=src.device) if sqsum else None
     else:
-        shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
-        sm = np.empty(shape, np.float64)
+        sm = np.empty(shape, np.int32 if sdepth == CV_32S else np.float64)
         sq = np.empty(shape, np.float64) if sqsum else None
     a, b = Img(sm), (Img(sq) if sqsum else None)
     bind_stream(s, a)
-    rc = L.mi355cv_integral(s.depth, 6, 6, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
+    rc = L.mi355cv_integral(s.depth, sdepth, CV_64F, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
                             None, 0, s.w, s.h, s.cn)
     _lib.check(rc, "integral")
     return (sm, sq) if sqsum else sm

@@ -77,13 +77,25 @@ def test_config5_4k(cv, orc):
 
 
 def test_integral(cv, orc):
+    """cv::integral: default depths (CV_32S sum for 8-bit sources), CV_64F sums, squared sums; sizes spanning one and several
+    column segments; exact for 8-bit sources, 1e-13 for float sources (double accumulation, order differs from the CPU's)."""
     for dtype in (np.uint8, np.float32):
         for cn in (1, 3):
-            src = rnd((37, 53, cn) if cn > 1 else (37, 53), dtype, 3)
-            s, q = cv.integral(dev(src), sqsum=True)
-            a = src.astype(np.float64)
-            ws = np.zeros((38, 54) + a.shape[2:]); wq = np.zeros_like(ws)
-            ws[1:, 1:] = a.cumsum(0).cumsum(1); wq[1:, 1:] = (a * a).cumsum(0).cumsum(1)
-            assert np.allclose(s.cpu().numpy(), ws, rtol=1e-13, atol=0) and np.allclose(q.cpu().numpy(), wq, rtol=1e-13, atol=0)
-            if dtype == np.uint8:
-                assert np.array_equal(s.cpu().numpy(), ws)
+            for (h, w) in [(37, 53), (1, 1), (64, 300), (65, 17), (200, 129), (1080, 1920)]:
+                if h * w > 10000 and cn == 3:
+                    continue
+                src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 3)
+                a = src.astype(np.float64)
+                ws = np.zeros((h + 1, w + 1) + a.shape[2:]); wq = np.zeros_like(ws)
+                ws[1:, 1:] = a.cumsum(0).cumsum(1); wq[1:, 1:] = (a * a).cumsum(0).cumsum(1)
+                s, q = cv.integral(dev(src), sqsum=True)
+                s, q = s.cpu().numpy(), q.cpu().numpy()
+                if dtype == np.uint8:
+                    assert s.dtype == np.int32 and np.array_equal(s, ws.astype(np.int64)) and np.array_equal(q, wq), (h, w, cn)
+                    s64 = cv.integral(dev(src), sdepth=6).cpu().numpy()
+                    assert s64.dtype == np.float64 and np.array_equal(s64, ws)
+                else:
+                    assert s.dtype == np.float64 and np.allclose(s, ws, rtol=1e-13, atol=0) and np.allclose(q, wq, rtol=1e-13, atol=0)
+    src = rnd((40, 70), np.uint8, 8)
+    s = cv.integral(src)                                                 # host pointers
+    assert isinstance(s, np.ndarray) and s[-1, -1] == int(src.sum())
