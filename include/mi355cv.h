@@ -268,6 +268,13 @@ MI355CV_API int mi355cv_morph(struct cvhalFilter2D* context, mi355cv_uchar* src_
         int dst_full_width, int dst_full_height, int dst_roi_x, int dst_roi_y);
 MI355CV_API int mi355cv_morphFree(struct cvhalFilter2D* context);
 
+/* --------------------------------------------------- f1: median filter */
+
+/* replaces hal_ni_medianBlur (hal_replacement.hpp:995; caller cv::medianBlur median_blur.dispatch.cpp:300).  CV_8U, ksize 3 or 5,
+ * 1/3/4 channels; everything else answers NOT_IMPLEMENTED (CPU fallback). */
+MI355CV_API int mi355cv_medianBlur(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int cn, int ksize);
+
 /* --------------------------------------------------- a13: template matching */
 
 /* cv::matchTemplate (templmatch.cpp:1158) has no HAL hook.  type CV_8UC1..C4 / CV_32FC1..C4, result CV_32FC1

@@ -78,5 +78,8 @@
 #define cv_hal_morph mi355cv_morph
 #undef  cv_hal_morphFree
 #define cv_hal_morphFree mi355cv_morphFree
+// hal_replacement.hpp:995 / caller median_blur.dispatch.cpp:300
+#undef  cv_hal_medianBlur
+#define cv_hal_medianBlur mi355cv_medianBlur
 
 #endif

@@ -1,0 +1,163 @@
+// median.hip -- SURVEY.md §8 f1: cv_hal_medianBlur (hal_replacement.hpp:995; caller cv::medianBlur median_blur.dispatch.cpp:300).
+// Exact median of the ksize x ksize neighbourhood per channel, BORDER_REPLICATE (median_blur.simd.hpp: sort network :493-760,
+// histogram forms :63-490 -- all of them return the exact median).  CV_8U, ksize 3 and 5, 1/3/4 channels, on the roll.h skeleton:
+// the last K source rows stay in registers as even/odd byte planes (two pixels per 32-bit lane), min / max are v_pk_min_u16 /
+// v_pk_max_u16.
+//   3x3: the three rows are sorted per column once (shared by the three outputs that use the column), then
+//        median = med3( max(lows), med3(mids), min(highs) )   -- 9 packed ops per pixel.
+//   5x5: a 113-exchange selection network (median_net.h, generated and verified by tools/gen_median_net.py).
+// HBM-bound for 3x3 (2*cn bytes per pixel); 5x5 is VALU-bound at ~113 packed exchanges per pixel pair.
+#include "rt.h"
+#include "roll.h"
+#include "median_net.h"
+
+using namespace mi355;
+
+namespace {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pmin(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pmax(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pmed3(uint32_t a, uint32_t b, uint32_t c) { return pmax(pmin(a, b), pmin(pmax(a, b), c)); }
+
+template <int K, int CN>
+__global__ __launch_bounds__(256) void k_median_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                     int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes)
+{
+    constexpr int R = K / 2;
+    typedef roll::Ctx<R, R, CN> Cx;
+    typedef typename Cx::RawT RawT;
+    constexpr int NW = Cx::NW, HD = Cx::HD;
+    Cx cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, B_REPLICATE, 1)) return;
+    dst += (size_t)cx.frame * dframe;
+    struct RowP { uint32_t E[NW], O[NW]; };
+    RowP ring[K];
+    auto planes = [&](RowP& p, const RawT& raw) { uint32_t X[NW]; cx.window(X, raw); roll::planes<NW>(p.E, p.O, X); };
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) { RawT pre; int v; cx.issue(pre, i - R, v); planes(ring[i], pre); }
+    RawT raw[K]; int rv[K];
+#pragma unroll
+    for (int u = 0; u < K; u++) cx.issue(raw[u], u + R, rv[u]);
+    for (int y = 0; y < cx.nrows; y += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            if (y + u < cx.nrows) {
+                planes(ring[(K - 1 + u) % K], raw[u]);
+                cx.issue(raw[u], y + u + K + R, rv[u]);
+                uint32_t o[4];
+                if constexpr (K == 3) {
+                    // per column: lo <= mid <= hi of the three rows (order of the rows is irrelevant)
+                    RowP lo, mi, hi;
+#pragma unroll
+                    for (int d = 0; d < NW; d++) {
+#pragma unroll
+                        for (int pl = 0; pl < 2; pl++) {
+                            const uint32_t a = pl ? ring[0].O[d] : ring[0].E[d], b = pl ? ring[1].O[d] : ring[1].E[d], c = pl ? ring[2].O[d] : ring[2].E[d];
+                            const uint32_t mn = pmin(a, b), mx = pmax(a, b);
+                            const uint32_t l = pmin(mn, c), h = pmax(mx, c), m = pmax(mn, pmin(mx, c));
+                            if (pl) { lo.O[d] = l; mi.O[d] = m; hi.O[d] = h; } else { lo.E[d] = l; mi.E[d] = m; hi.E[d] = h; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t r2[2];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            auto at = [&](const RowP& p, int sgn) { return q ? (sgn < 0 ? roll::pairAt<1, -CN, HD>(p.E, p.O, k) : sgn == 0 ? roll::pairAt<1, 0, HD>(p.E, p.O, k) : roll::pairAt<1, CN, HD>(p.E, p.O, k))
+                                                                                : (sgn < 0 ? roll::pairAt<0, -CN, HD>(p.E, p.O, k) : sgn == 0 ? roll::pairAt<0, 0, HD>(p.E, p.O, k) : roll::pairAt<0, CN, HD>(p.E, p.O, k)); };
+                            const uint32_t a = pmax(pmax(at(lo, -1), at(lo, 0)), at(lo, 1));
+                            const uint32_t b = pmed3(at(mi, -1), at(mi, 0), at(mi, 1));
+                            const uint32_t c = pmin(pmin(at(hi, -1), at(hi, 0)), at(hi, 1));
+                            r2[q] = pmed3(a, b, c);
+                        }
+                        o[k] = r2[0] | (r2[1] << 8);                 // bytes 4k..4k+3 = (E.lo, O.lo, E.hi, O.hi)
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t r2[2];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            uint32_t v[25];
+#pragma unroll
+                            for (int j = 0; j < 5; j++) {
+                                const RowP& p = ring[j];
+                                if (q) { v[5 * j] = roll::pairAt<1, -2 * CN, HD>(p.E, p.O, k); v[5 * j + 1] = roll::pairAt<1, -CN, HD>(p.E, p.O, k); v[5 * j + 2] = roll::pairAt<1, 0, HD>(p.E, p.O, k);
+                                         v[5 * j + 3] = roll::pairAt<1, CN, HD>(p.E, p.O, k); v[5 * j + 4] = roll::pairAt<1, 2 * CN, HD>(p.E, p.O, k); }
+                                else   { v[5 * j] = roll::pairAt<0, -2 * CN, HD>(p.E, p.O, k); v[5 * j + 1] = roll::pairAt<0, -CN, HD>(p.E, p.O, k); v[5 * j + 2] = roll::pairAt<0, 0, HD>(p.E, p.O, k);
+                                         v[5 * j + 3] = roll::pairAt<0, CN, HD>(p.E, p.O, k); v[5 * j + 4] = roll::pairAt<0, 2 * CN, HD>(p.E, p.O, k); }
+                            }
+#define CE(a, b) { const uint32_t t_ = pmin(v[a], v[b]); v[b] = pmax(v[a], v[b]); v[a] = t_; }
+                            MI355_MEDIAN25_NET(CE)
+#undef CE
+                            r2[q] = v[12];
+                        }
+                        o[k] = r2[0] | (r2[1] << 8);
+                    }
+                }
+                cx.template store<1>(dst, dstep, cx.gy(y + u), o);
+            }
+        }
+    }
+}
+
+// any geometry the rolling kernel declines (rows shorter than 16 bytes, a ragged chunk opening a strip): thread per element
+template <int K>
+__global__ __launch_bounds__(256) void k_median_generic(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int cn)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, c = e - x * cn;
+    constexpr int R = K / 2;
+    uint32_t v[K * K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uchar* row = src + (size_t)min(max(y + j - R, 0), H - 1) * sstep;
+#pragma unroll
+        for (int i = 0; i < K; i++) v[j * K + i] = row[min(max(x + i - R, 0), W - 1) * cn + c];
+    }
+    uint32_t r;
+    if constexpr (K == 3) {
+#define CE(a, b) { const uint32_t t_ = min(v[a], v[b]); v[b] = max(v[a], v[b]); v[a] = t_; }
+        CE(1, 2) CE(4, 5) CE(7, 8) CE(0, 1) CE(3, 4) CE(6, 7) CE(1, 2) CE(4, 5) CE(7, 8)          // sort the three rows
+        r = max(min(max(max(v[0], v[3]), v[6]), min(min(v[2], v[5]), v[8])),                        // med3(max of lows, med3 of mids, min of highs)
+                min(max(max(max(v[0], v[3]), v[6]), min(min(v[2], v[5]), v[8])), max(min(v[1], v[4]), min(max(v[1], v[4]), v[7]))));
+    } else {
+        MI355_MEDIAN25_NET(CE)
+#undef CE
+        r = v[12];
+    }
+    dst[(size_t)y * dstep + e] = (uchar)r;
+}
+
+} // namespace
+
+extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                              int depth, int cn, int ksize)
+{
+    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    const bool devSrc = isDevicePtr(src_data);
+    if (!devSrc && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (devSrc && src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;                  // in place on the device: a stencil cannot
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    hipStream_t st = stream();
+    if (!roll::eligible(ds, dss, 0, dd, dds, 0, width, cn, ksize / 2, B_REPLICATE)) {
+        dim3 grid(divUp(width * cn, 64), divUp(height, 4));
+        if (ksize == 3) hipLaunchKernelGGL(k_median_generic<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn);
+        else hipLaunchKernelGGL(k_median_generic<5>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn);
+        return stg.finish("medianBlur");
+    }
+    const roll::Geom g = roll::geometry(width, height, cn, 1, ksize == 3 ? 16 : 12, ksize);
+#define MED(K_, CN_) hipLaunchKernelGGL((k_median_roll<K_, CN_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, 0, dd, dds, 0, width, height, g.nchunks, g.nstrips, g.seg, g.nseg, 1)
+    if (ksize == 3) { if (cn == 1) MED(3, 1); else if (cn == 3) MED(3, 3); else MED(3, 4); }
+    else            { if (cn == 1) MED(5, 1); else if (cn == 3) MED(5, 3); else MED(5, 4); }
+#undef MED
+    return stg.finish("medianBlur");
+}

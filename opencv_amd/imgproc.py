@@ -22,7 +22,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COL
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -260,6 +260,22 @@ def threshold(src, thresh, maxval, type, dst=None):
     bind_stream(s, d)
     _lib.check(L.mi355cv_threshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, float(thresh), float(maxval), int(type)), "threshold")
     return float(thresh), out
+
+
+# ----------------------------------------------------------------------------- median (f1)
+def medianBlur(src, ksize, dst=None):
+    """cv::medianBlur (median_blur.dispatch.cpp:279) through cv_hal_medianBlur: CV_8U, ksize 3 / 5."""
+    s = Img(src)
+    if ksize % 2 != 1:
+        raise ValueError("medianBlur: ksize must be odd")
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
+    if ksize <= 1:
+        out[...] = src
+        return out
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_medianBlur(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, int(ksize)), "medianBlur")
+    return out
 
 
 # ----------------------------------------------------------------------------- erode / dilate (f1)

@@ -96,6 +96,9 @@ int orc_morph(int op, const uint8_t* src, size_t sstep, uint8_t* dst, size_t dst
               int fullW, int fullH, int offX, int offY, const uint8_t* kernel, size_t kstep, int kw, int kh, int ax, int ay,
               int border, const double* borderValue);
 
+/* cv::medianBlur, see oracle/median.c (odd ksize 3..31; depth 0/2/3/5) */
+int orc_medianBlur(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn, int ksize);
+
 #ifdef __cplusplus
 }
 #endif

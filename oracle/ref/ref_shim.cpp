@@ -182,6 +182,14 @@ int ref_morph(int op, const void* s, size_t ss, void* d, size_t ds, int w, int h
     REF_END(dst, d)
 }
 
+int ref_medianBlur(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, int ksize)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    cv::medianBlur(src, dst, ksize);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {

@@ -232,6 +232,25 @@ def ref_threshold(src, thresh, maxval, type):
     return rv.value, dst
 
 
+# ----------------------------------------------------------------------------- median
+def orc_medianBlur(src, ksize):
+    o = oracle()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rc = o.orc_medianBlur(P(src), step(src), P(dst), step(dst), w, h, _NP_DEPTH[src.dtype], cn_of(src), ksize)
+    assert rc == 0, rc
+    return dst
+
+
+def ref_medianBlur(src, ksize):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rc = r.ref_medianBlur(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), ksize)
+    assert rc == 0, rc
+    return dst
+
+
 # ----------------------------------------------------------------------------- morphology
 def _bvp(bv):
     if bv is None:

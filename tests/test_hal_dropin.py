@@ -33,6 +33,8 @@ def _calls(o, src8, src8c3, srcf):
     out["pyr"] = o.ref_pyrDown(src8c3)
     out["harris"] = o.ref_cornerHarris(src8, 2, 3, 0.04)
     out["mt"] = o.ref_matchTemplate(src8, np.ascontiguousarray(src8[10:26, 20:52]), 3)
+    out["median3"] = o.ref_medianBlur(src8c3, 3)
+    out["median5"] = o.ref_medianBlur(src8, 5)
     out["dilate"] = o.ref_morph(1, src8)
     out["erode5"] = o.ref_morph(0, src8c3, np.ones((5, 5), np.uint8), (-1, -1), 1, 4)
     out["thresh"] = o.ref_threshold(src8c3, 100.5, 200, 0)[1]
@@ -79,7 +81,7 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph"]
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur"]
     before = {n: cv.call_count(n) for n in names}
     with O.use_ref(hal):
         through = _calls(O, src8, src8c3, srcf)

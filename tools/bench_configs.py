@@ -76,6 +76,8 @@ def run(quick=False):
     line("a1 GaussianBlur 5x5 4K 8U single frame", timeit(lambda: cv.GaussianBlur(one, (5, 5), 0, dst=d8)), 3840 * 2160 * 2)
     line("f1 threshold BINARY 4K 8U", timeit(lambda: cv.threshold(one, 127, 255, cv.THRESH_BINARY, dst=d8)), 3840 * 2160 * 2)
     line("f1 integral 4K 8U -> 32S", timeit(lambda: cv.integral(one)), 3840 * 2160 * 5)
+    line("f1 medianBlur 3x3 4K 8U", timeit(lambda: cv.medianBlur(one, 3, dst=d8)), 3840 * 2160 * 2)
+    line("f1 medianBlur 5x5 4K 8U", timeit(lambda: cv.medianBlur(one, 5, dst=d8)), 3840 * 2160 * 2)
     line("f1 dilate 3x3 4K 8U", timeit(lambda: cv.dilate(one, dst=d8)), 3840 * 2160 * 2)
     line("f1 erode 5x5 4K 8U", timeit(lambda: cv.erode(one, np.ones((5, 5), np.uint8), dst=d8)), 3840 * 2160 * 2)
     c3 = bgr[0]
