@@ -247,6 +247,20 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const mi355cv_uchar* src_data, size_
         float* corners, float* quality, int maxCorners, double qualityLevel, double minDistance,
         const mi355cv_uchar* mask_data, size_t mask_step, int blockSize, int gradientSize, int useHarrisDetector, double harrisK);
 
+/* --------------------------------------------------- f1/f4: YUV family, CV_8U */
+
+/* replace hal_ni_cvtBGRtoYUV (hal_replacement.hpp:500), hal_ni_cvtYUVtoBGR (:533), hal_ni_cvtTwoPlaneYUVtoBGR (:664) and
+ * hal_ni_cvtTwoPlaneYUVtoBGREx (:701); callers color_yuv.dispatch.cpp:33, :86, :166, :144.  depth CV_8U only (other depths answer
+ * NOT_IMPLEMENTED).  The two-plane decoders take NV12 (uIdx 0) / NV21 (uIdx 1), even dst_width and dst_height. */
+MI355CV_API int mi355cv_cvtBGRtoYUV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int scn, bool swapBlue, bool isCbCr);
+MI355CV_API int mi355cv_cvtYUVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int dcn, bool swapBlue, bool isCbCr);
+MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx);
+MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const mi355cv_uchar* y_data, size_t y_step, const mi355cv_uchar* uv_data, size_t uv_step,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx);
+
 /* --------------------------------------------------- f1: fixed-level threshold */
 
 /* replaces hal_ni_threshold (hal_replacement.hpp:1058; caller ThresholdRunner thresh.cpp:1365, once per row stripe).

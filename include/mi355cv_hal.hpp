@@ -81,5 +81,14 @@
 // hal_replacement.hpp:995 / caller median_blur.dispatch.cpp:300
 #undef  cv_hal_medianBlur
 #define cv_hal_medianBlur mi355cv_medianBlur
+// hal_replacement.hpp:500, :533, :664, :701 / callers color_yuv.dispatch.cpp:33, :86, :166, :144
+#undef  cv_hal_cvtBGRtoYUV
+#define cv_hal_cvtBGRtoYUV mi355cv_cvtBGRtoYUV
+#undef  cv_hal_cvtYUVtoBGR
+#define cv_hal_cvtYUVtoBGR mi355cv_cvtYUVtoBGR
+#undef  cv_hal_cvtTwoPlaneYUVtoBGR
+#define cv_hal_cvtTwoPlaneYUVtoBGR mi355cv_cvtTwoPlaneYUVtoBGR
+#undef  cv_hal_cvtTwoPlaneYUVtoBGREx
+#define cv_hal_cvtTwoPlaneYUVtoBGREx mi355cv_cvtTwoPlaneYUVtoBGREx
 
 #endif

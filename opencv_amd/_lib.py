@@ -59,6 +59,10 @@ def _load():
                                       c_int, c_int, c_int, ctypes.POINTER(c_dbl), c_int, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_morph": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_morphFree": (c_int, [ctypes.c_void_p]),
+        "mi355cv_cvtBGRtoYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool]),
+        "mi355cv_cvtYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool]),
+        "mi355cv_cvtTwoPlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtTwoPlaneYUVtoBGREx": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_medianBlur": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_filterFree": (c_int, [ctypes.c_void_p]),

@@ -1,0 +1,144 @@
+// color_yuv.hip -- SURVEY.md §8 f1 / f4 (video ingest): the CV_8U members of the YUV family behind
+//   cv_hal_cvtBGRtoYUV (hal_replacement.hpp:500), cv_hal_cvtYUVtoBGR (:533), cv_hal_cvtTwoPlaneYUVtoBGR (:664) and
+//   cv_hal_cvtTwoPlaneYUVtoBGREx (:701); callers color_yuv.dispatch.cpp:33, :86, :166, :144.
+// Integer arithmetic of color_yuv.simd.hpp (its SIMD bodies and scalar tails agree, so one formula):
+//   BGR->YUV/YCrCb  RGB2YCrCb_i<uchar> :398   Y = (c0*s0 + c1*s1 + c2*s2 + 2^13) >> 14,  Cr/V = ((R - Y)*c3 + 128*2^14 + 2^13) >> 14, ...
+//   YUV/YCrCb->BGR  YCrCb2RGB_i<uchar> :739   b = Y + ((Cb-128)*c3 + 2^13) >> 14, ...
+//   NV12 / NV21     YUV420sp2RGB8Invoker :1195, 20-bit ITU-R BT.601: r = (max(Y-16,0)*1220542 + 1673527*(V-128) + 2^19) >> 20, ...
+// All HBM-bound: a thread handles four pixels (packed conversions) / one 2x2 block (4:2:0), plain coalesced loads and stores.
+#include "rt.h"
+
+using namespace mi355;
+
+namespace {
+
+__device__ __forceinline__ int sat8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+struct YuvFwd { int c0, c1, c2, c3, c4, bidx, yuvOrder; };
+struct YuvInv { int c0, c1, c2, c3, bidx, yuvOrder; };
+
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2yuv_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, YuvFwd a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
+    uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
+    const int s0 = s[0], s1 = s[1], s2 = s[2];
+    const int Y = (s0 * a.c0 + s1 * a.c1 + s2 * a.c2 + (1 << 13)) >> 14;
+    const int r = a.bidx ? s0 : s2, b = a.bidx ? s2 : s0;
+    const int Cr = ((r - Y) * a.c3 + (128 << 14) + (1 << 13)) >> 14;
+    const int Cb = ((b - Y) * a.c4 + (128 << 14) + (1 << 13)) >> 14;
+    d[0] = (uchar)sat8(Y); d[1 + a.yuvOrder] = (uchar)sat8(Cr); d[2 - a.yuvOrder] = (uchar)sat8(Cb);
+}
+
+template <int DCN>
+__global__ __launch_bounds__(256) void k_yuv2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, YuvInv a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar* s = src + (size_t)y * sstep + (size_t)x * 3;
+    uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
+    const int Y = s[0], Cr = s[1 + a.yuvOrder], Cb = s[2 - a.yuvOrder];
+    const int b = Y + (((Cb - 128) * a.c3 + (1 << 13)) >> 14);
+    const int g = Y + (((Cb - 128) * a.c2 + (Cr - 128) * a.c1 + (1 << 13)) >> 14);
+    const int r = Y + (((Cr - 128) * a.c0 + (1 << 13)) >> 14);
+    d[a.bidx] = (uchar)sat8(b); d[1] = (uchar)sat8(g); d[a.bidx ^ 2] = (uchar)sat8(r);
+    if (DCN == 4) d[3] = 255;
+}
+
+// one thread per 2x2 block: 2+2 luma bytes, one (U,V) pair, 4 output pixels
+template <int DCN>
+__global__ __launch_bounds__(256) void k_nv2bgr_u8(const uchar* __restrict__ yp, size_t ystep, const uchar* __restrict__ uvp, size_t uvstep,
+                                                   uchar* __restrict__ dst, size_t dstep, int W, int H, int bIdx, int uIdx)
+{
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * bx >= W || 2 * by >= H) return;
+    const uchar* uv = uvp + (size_t)by * uvstep + 2 * (size_t)bx;
+    const int uu = (int)uv[uIdx] - 128, vv = (int)uv[1 - uIdx] - 128;
+    const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uchar* yr = yp + (size_t)(2 * by + j) * ystep + 2 * (size_t)bx;
+        uchar* d = dst + (size_t)(2 * by + j) * dstep + 2 * (size_t)bx * DCN;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int yv = max((int)yr[i] - 16, 0) * 1220542;
+            d[i * DCN + 2 - bIdx] = (uchar)sat8((yv + ruv) >> 20);
+            d[i * DCN + 1] = (uchar)sat8((yv + guv) >> 20);
+            d[i * DCN + bIdx] = (uchar)sat8((yv + buv) >> 20);
+            if (DCN == 4) d[i * DCN + 3] = 255;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int scn, bool swapBlue, bool isCbCr)
+{
+    if (disabled() || depth != MI355CV_8U || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    YuvFwd a; a.c0 = 4899; a.c1 = 9617; a.c2 = 1868; a.c3 = isCbCr ? 11682 : 14369; a.c4 = isCbCr ? 9241 : 8061;
+    a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
+    if (a.bidx == 0) { const int t = a.c0; a.c0 = a.c2; a.c2 = t; }
+    dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (scn == 3) hipLaunchKernelGGL(k_bgr2yuv_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    else hipLaunchKernelGGL(k_bgr2yuv_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    return stg.finish("cvtBGRtoYUV");
+}
+
+MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int dcn, bool swapBlue, bool isCbCr)
+{
+    if (disabled() || depth != MI355CV_8U || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    YuvInv a; a.c0 = isCbCr ? 22987 : 18678; a.c1 = isCbCr ? -11698 : -9519; a.c2 = isCbCr ? -5636 : -6472; a.c3 = isCbCr ? 29049 : 33292;
+    a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
+    dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (dcn == 3) hipLaunchKernelGGL(k_yuv2bgr_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    else hipLaunchKernelGGL(k_yuv2bgr_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    return stg.finish("cvtYUVtoBGR");
+}
+
+MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step, const uchar* uv_data, size_t uv_step, uchar* dst_data, size_t dst_step,
+                                              int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx)
+{
+    if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
+        return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(y_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t ys, uvs, dds;
+    const uchar* dy = stg.in(y_data, y_step, (size_t)dst_width, dst_height, &ys);
+    const uchar* duv = stg.in(uv_data, uv_step, (size_t)dst_width, dst_height / 2, &uvs);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
+    if (!dy || !duv || !dd) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(dst_width / 2, 64), divUp(dst_height / 2, 4));
+    if (dcn == 3) hipLaunchKernelGGL(k_nv2bgr_u8<3>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    else hipLaunchKernelGGL(k_nv2bgr_u8<4>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    return stg.finish("cvtTwoPlaneYUVtoBGR");
+}
+
+MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,
+                                            int dcn, bool swapBlue, int uIdx)
+{
+    return mi355cv_cvtTwoPlaneYUVtoBGREx(src_data, src_step, src_data + src_step * (size_t)dst_height, src_step, dst_data, dst_step, dst_width, dst_height,
+                                         dcn, swapBlue, uIdx);
+}
+
+} // extern "C"

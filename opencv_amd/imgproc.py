@@ -14,7 +14,9 @@ from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_1
 L = _lib.lib
 _vp = ctypes.c_void_p
 
-__all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
+__all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB", "COLOR_BGR2YUV", "COLOR_RGB2YUV",
+           "COLOR_YUV2BGR", "COLOR_YUV2RGB", "COLOR_YUV2RGB_NV12", "COLOR_YUV2BGR_NV12", "COLOR_YUV2RGB_NV21", "COLOR_YUV2BGR_NV21",
+           "COLOR_YUV2RGBA_NV12", "COLOR_YUV2BGRA_NV12", "COLOR_YUV2RGBA_NV21", "COLOR_YUV2BGRA_NV21", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
@@ -174,6 +176,14 @@ _RGB2RGB = {COLOR_BGR2BGRA: (3, 4, False), COLOR_BGRA2BGR: (4, 3, False), COLOR_
             COLOR_RGBA2BGR: (4, 3, True), COLOR_BGR2RGB: (3, 3, True), COLOR_BGRA2RGBA: (4, 4, True)}
 _RGB2GRAY = {COLOR_BGR2GRAY: (3, False), COLOR_RGB2GRAY: (3, True), COLOR_BGRA2GRAY: (4, False), COLOR_RGBA2GRAY: (4, True)}
 _GRAY2RGB = {COLOR_GRAY2BGR: 3, COLOR_GRAY2BGRA: 4}
+# cv::ColorConversionCodes of the YUV family (imgproc.hpp:560-700): code -> (swapBlue, isCbCr) / (dcn, swapBlue, uIdx)
+COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB = 36, 37, 38, 39
+COLOR_BGR2YUV, COLOR_RGB2YUV, COLOR_YUV2BGR, COLOR_YUV2RGB = 82, 83, 84, 85
+COLOR_YUV2RGB_NV12, COLOR_YUV2BGR_NV12, COLOR_YUV2RGB_NV21, COLOR_YUV2BGR_NV21 = 90, 91, 92, 93
+COLOR_YUV2RGBA_NV12, COLOR_YUV2BGRA_NV12, COLOR_YUV2RGBA_NV21, COLOR_YUV2BGRA_NV21 = 94, 95, 96, 97
+_YUV_FWD = {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}
+_YUV_INV = {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}
+_YUV_NV = {90: (3, 1, 0), 91: (3, 0, 0), 92: (3, 1, 1), 93: (3, 0, 1), 94: (4, 1, 0), 95: (4, 0, 0), 96: (4, 1, 1), 97: (4, 0, 1)}
 
 
 def cvtColor(src, code, dst=None, dstCn=0):
@@ -206,6 +216,36 @@ def cvtColor(src, code, dst=None, dstCn=0):
         d = Img(out)
         bind_stream(s, d)
         _lib.check(L.mi355cv_cvtBGRtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, scn, dcn, swap), "cvtBGRtoBGR")
+        return out
+    if code in _YUV_FWD:
+        swap, cbcr = _YUV_FWD[code]
+        if s.cn not in (3, 4):
+            raise ValueError("cvtColor: source must have 3 or 4 channels")
+        ref3 = src[..., :3] if s.cn == 4 else src
+        out = dst if dst is not None else empty_like_kind(ref3, s.h, s.w, 3, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtBGRtoYUV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(swap), bool(cbcr)), "cvtBGRtoYUV")
+        return out
+    if code in _YUV_INV:
+        swap, cbcr = _YUV_INV[code]
+        dcn = dstCn if dstCn in (3, 4) else 3
+        if s.cn != 3:
+            raise ValueError("cvtColor: source must have 3 channels")
+        out = dst if dst is not None else empty_like_kind(src, s.h, s.w, dcn, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(swap), bool(cbcr)), "cvtYUVtoBGR")
+        return out
+    if code in _YUV_NV:
+        dcn, swap, uidx = _YUV_NV[code]
+        if s.cn != 1 or s.depth != CV_8U or s.h % 3 or s.w % 2:
+            raise ValueError("cvtColor: NV12/NV21 needs a CV_8UC1 image of (3/2 * height) x width, width and height even")    # color.cpp cvtColorTwoPlane
+        dh = s.h * 2 // 3
+        out = dst if dst is not None else empty_like_kind(src[..., None] if getattr(src, "ndim", 2) == 2 else src, dh, s.w, dcn, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtTwoPlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtTwoPlaneYUVtoBGR")
         return out
     raise NotImplementedError(f"cvtColor: conversion code {code} is outside the hot path built so far")
 

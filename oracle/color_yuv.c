@@ -1,0 +1,61 @@
+/* oracle/color_yuv.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * Restates the CV_8U paths of modules/imgproc/src/color_yuv.simd.hpp: RGB2YCrCb_i<uchar> :398-567 (scalar form :557-565),
+ * YCrCb2RGB_i<uchar> :739-880 (scalar form :866-880), and the 4:2:0 two-plane decoder YUV420sp2RGB8Invoker :1195-1316
+ * (uvToRGBuv :1043, yRGBuvToRGBA :1090); constants :66-92, :1018-1023 and color.simd_helpers.hpp:17-21. */
+#include "oracle.h"
+
+#define DESCALE14(x) (((x) + (1 << 13)) >> 14)
+static uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+void orc_cvtBGRtoYUV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr;
+    int C0 = 4899, C1 = 9617, C2 = 1868;                                    /* R2Y, G2Y, B2Y */
+    const int C3 = isCbCr ? 11682 : 14369, C4 = isCbCr ? 9241 : 8061;       /* YCRI / R2VI, YCBI / B2UI */
+    if (bidx == 0) { const int t = C0; C0 = C2; C2 = t; }
+    const int delta = 128 * (1 << 14);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* s = src + (size_t)y * sstep + (size_t)x * scn;
+            uint8_t* d = dst + (size_t)y * dstep + (size_t)x * 3;
+            const int Y = DESCALE14(s[0] * C0 + s[1] * C1 + s[2] * C2);
+            const int Cr = DESCALE14((s[bidx ^ 2] - Y) * C3 + delta);
+            const int Cb = DESCALE14((s[bidx] - Y) * C4 + delta);
+            d[0] = sat8(Y); d[1 + yuvOrder] = sat8(Cr); d[2 - yuvOrder] = sat8(Cb);
+        }
+}
+
+void orc_cvtYUVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr;
+    const int C0 = isCbCr ? 22987 : 18678, C1 = isCbCr ? -11698 : -9519, C2 = isCbCr ? -5636 : -6472, C3 = isCbCr ? 29049 : 33292;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* s = src + (size_t)y * sstep + (size_t)x * 3;
+            uint8_t* d = dst + (size_t)y * dstep + (size_t)x * dcn;
+            const int Y = s[0], Cr = s[1 + yuvOrder], Cb = s[2 - yuvOrder];
+            const int b = Y + DESCALE14((Cb - 128) * C3);
+            const int g = Y + DESCALE14((Cb - 128) * C2 + (Cr - 128) * C1);
+            const int r = Y + DESCALE14((Cr - 128) * C0);
+            d[bidx] = sat8(b); d[1] = sat8(g); d[bidx ^ 2] = sat8(r);
+            if (dcn == 4) d[3] = 255;
+        }
+}
+
+/* NV12 (uIdx 0) / NV21 (uIdx 1): Y plane dst_h x dst_w, interleaved chroma plane (dst_h/2) x dst_w; dst_w, dst_h even */
+void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t* uv_data, size_t uv_step, uint8_t* dst, size_t dstep,
+                             int dst_w, int dst_h, int dcn, int swapBlue, int uIdx)
+{
+    const int bIdx = swapBlue ? 2 : 0;
+    for (int j = 0; j < dst_h; j++)
+        for (int i = 0; i < dst_w; i++) {
+            const uint8_t* uv = uv_data + (size_t)(j / 2) * uv_step + (size_t)(i & ~1);
+            const int uu = (int)uv[uIdx] - 128, vv = (int)uv[1 - uIdx] - 128;
+            const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+            int yy = (int)y_data[(size_t)j * y_step + i] - 16; if (yy < 0) yy = 0;
+            const int yv = yy * 1220542;
+            uint8_t* d = dst + (size_t)j * dstep + (size_t)i * dcn;
+            d[2 - bIdx] = sat8((yv + ruv) >> 20); d[1] = sat8((yv + guv) >> 20); d[bIdx] = sat8((yv + buv) >> 20);
+            if (dcn == 4) d[3] = 255;
+        }
+}

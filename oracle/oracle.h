@@ -47,6 +47,12 @@ void orc_cvtBGRtoGray(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dst
 void orc_cvtGraytoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int dcn);
 void orc_cvtBGRtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int dcn, int swapBlue);
 
+/* color_yuv.simd.hpp, CV_8U: RGB2YCrCb_i :398, YCrCb2RGB_i :739, YUV420sp2RGB8Invoker :1195 (see oracle/color_yuv.c) */
+void orc_cvtBGRtoYUV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int isCbCr);
+void orc_cvtYUVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int isCbCr);
+void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t* uv_data, size_t uv_step, uint8_t* dst, size_t dstep,
+                             int dst_w, int dst_h, int dcn, int swapBlue, int uIdx);
+
 /* linear filters, see oracle/filter.c.  (fullW, fullH, offX, offY) describe the parent image of the ROI. */
 void orc_filter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
                   int fullW, int fullH, int offX, int offY, const float* kernel, int kw, int kh, int ax, int ay,

@@ -190,6 +190,15 @@ int ref_medianBlur(const void* s, size_t ss, void* d, size_t ds, int w, int h, i
     REF_END(dst, d)
 }
 
+// cvtColor whose destination geometry differs from the source's (4:2:0 decoders)
+int ref_cvtColorSz(const void* s, size_t ss, int sw, int sh, int stype, void* d, size_t ds, int dw, int dh, int dtype, int code)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, stype), dst = M(d, ds, dw, dh, dtype);
+    cv::cvtColor(src, dst, code, CV_MAT_CN(dtype), cv::ALGO_HINT_ACCURATE);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {

@@ -201,6 +201,46 @@ def orc_cvtColor(src, code):
     return dst
 
 
+# cv::ColorConversionCodes of the YUV family handled by oracle/color_yuv.c: code -> (kind, a, b, c)
+_YUV_FWD = {82: (3, 0, 0), 83: (3, 1, 0), 36: (3, 0, 1), 37: (3, 1, 1)}               # BGR2YUV, RGB2YUV, BGR2YCrCb, RGB2YCrCb -> (scn, swapBlue, isCbCr)
+_YUV_INV = {84: (3, 0, 0), 85: (3, 1, 0), 38: (3, 0, 1), 39: (3, 1, 1)}               # YUV2BGR, YUV2RGB, YCrCb2BGR, YCrCb2RGB -> (dcn, swapBlue, isCbCr)
+_YUV_NV = {90: (3, 1, 0), 91: (3, 0, 0), 92: (3, 1, 1), 93: (3, 0, 1), 94: (4, 1, 0), 95: (4, 0, 0), 96: (4, 1, 1), 97: (4, 0, 1)}   # *_NV12 / *_NV21 -> (dcn, swapBlue, uIdx)
+
+
+def orc_cvtColorYUV(src, code):
+    o = oracle()
+    h, w = src.shape[:2]
+    if code in _YUV_FWD:
+        scn, swap, cbcr = _YUV_FWD[code]
+        dst = np.empty((h, w, 3), np.uint8)
+        o.orc_cvtBGRtoYUV8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, cbcr)
+    elif code in _YUV_INV:
+        dcn, swap, cbcr = _YUV_INV[code]
+        dst = np.empty((h, w, dcn), np.uint8)
+        o.orc_cvtYUVtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, cbcr)
+    else:
+        dcn, swap, uidx = _YUV_NV[code]
+        dh = h * 2 // 3
+        dst = np.empty((dh, w, dcn), np.uint8)
+        uv = src[dh:]
+        o.orc_cvtTwoPlaneYUVtoBGR(P(src), step(src), vp(uv.ctypes.data), step(src), P(dst), step(dst), w, dh, dcn, swap, uidx)
+    return dst
+
+
+def ref_cvtColorYUV(src, code):
+    r = load_ref()
+    h, w = src.shape[:2]
+    if code in _YUV_NV:
+        dcn = _YUV_NV[code][0]
+        dst = np.empty((h * 2 // 3, w, dcn), np.uint8)
+    else:
+        dcn = 3 if code in _YUV_FWD else _YUV_INV[code][0]
+        dst = np.empty((h, w, dcn), np.uint8)
+    rc = r.ref_cvtColorSz(P(src), step(src), w, h, cvtype(src), P(dst), step(dst), w, dst.shape[0], cvtype(dst), code)
+    assert rc == 0, rc
+    return dst
+
+
 def ref_cvtColor(src, code, dcn):
     r = load_ref()
     h, w = src.shape[:2]

@@ -1,0 +1,46 @@
+"""Pinning of the CV_8U YUV / YCrCb / NV12 / NV21 restatement (oracle/color_yuv.c) against the real reference: widths that
+exercise the reference's SIMD body and its scalar tail, 3- and 4-channel sources / destinations, every code of the family, and
+the saturating corners of the colour cube."""
+import numpy as np
+import pytest
+
+import orc as O
+
+
+def _img(h, w, cn, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w, cn), dtype=np.uint8)
+    corners = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [16, 128, 128], [235, 240, 16], [1, 254, 3]], np.uint8)
+    n = min(len(corners), w)
+    a[0, :n, :3] = corners[:n]
+    return a
+
+
+@pytest.mark.ref
+def test_yuv_family_matches_reference(ref):
+    for (w, h) in [(1, 1), (7, 3), (64, 5), (263, 9), (1030, 2)]:
+        for code, (scn, _, _) in O._YUV_FWD.items():
+            for cn in (3, 4):
+                src = _img(h, w, cn, code + cn)
+                assert np.array_equal(O.orc_cvtColorYUV(src, code), O.ref_cvtColorYUV(src, code)), (w, h, code, cn)
+        for code in O._YUV_INV:
+            src = _img(h, w, 3, code)
+            assert np.array_equal(O.orc_cvtColorYUV(src, code), O.ref_cvtColorYUV(src, code)), (w, h, code)
+    for (w, h) in [(2, 2), (6, 4), (64, 8), (262, 6), (1030, 4)]:
+        rng = np.random.default_rng(w)
+        src = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)
+        src[0, :2] = [0, 255]; src[h, :2] = [255, 0]
+        for code in O._YUV_NV:
+            assert np.array_equal(O.orc_cvtColorYUV(src, code), O.ref_cvtColorYUV(src, code)), (w, h, code)
+
+
+def test_yuv_known_answers():
+    """grey stays grey: BGR (g,g,g) -> Y = g, U = V = 128 and back; NV12 (16,128,128) is black, (235,128,128) is white"""
+    g = np.full((2, 4, 3), 100, np.uint8)
+    yuv = O.orc_cvtColorYUV(g, 82)
+    assert (yuv[..., 0] == 100).all() and (yuv[..., 1:] == 128).all()
+    assert np.array_equal(O.orc_cvtColorYUV(yuv, 84), g)
+    nv = np.zeros((3, 2), np.uint8); nv[:2] = 16; nv[2] = 128
+    assert (O.orc_cvtColorYUV(nv, 91) == 0).all()
+    nv[:2] = 235
+    assert (O.orc_cvtColorYUV(nv, 91) == 255).all()

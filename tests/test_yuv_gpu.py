@@ -1,0 +1,45 @@
+"""GPU parity for the CV_8U YUV family through cv_hal_cvtBGRtoYUV / cvtYUVtoBGR / cvtTwoPlaneYUVtoBGR:
+every code, 3/4-channel sources and destinations, odd and large widths, host pointers; bit-exact against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import orc as O
+from test_oracle_yuv import _img
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def test_yuv_family(cv, orc):
+    for (w, h) in [(1, 1), (7, 3), (64, 5), (263, 9), (1030, 2), (1920, 16)]:
+        for code in O._YUV_FWD:
+            for cn in (3, 4):
+                src = _img(h, w, cn, code + cn)
+                assert np.array_equal(cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy(), orc.orc_cvtColorYUV(src, code)), (w, h, code, cn)
+        for code in O._YUV_INV:
+            src = _img(h, w, 3, code)
+            assert np.array_equal(cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy(), orc.orc_cvtColorYUV(src, code)), (w, h, code)
+            got4 = cv.cvtColor(torch.from_numpy(src).cuda(), code, dstCn=4).cpu().numpy()
+            assert np.array_equal(got4[..., :3], orc.orc_cvtColorYUV(src, code)) and (got4[..., 3] == 255).all()
+    src = _img(30, 50, 3, 1)
+    assert np.array_equal(cv.cvtColor(src, cv.COLOR_BGR2YCrCb), orc.orc_cvtColorYUV(src, 36))                     # host pointers
+
+
+def test_nv12_nv21(cv, orc):
+    for (w, h) in [(2, 2), (6, 4), (64, 8), (262, 6), (1030, 4), (1920, 1080)]:
+        rng = np.random.default_rng(w)
+        src = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)
+        for code in O._YUV_NV:
+            got = cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy()
+            assert np.array_equal(got, orc.orc_cvtColorYUV(src, code)), (w, h, code)
+    src = np.random.default_rng(3).integers(0, 256, (36, 40), dtype=np.uint8)
+    assert np.array_equal(cv.cvtColor(src, cv.COLOR_YUV2BGR_NV12), orc.orc_cvtColorYUV(src, 91))                   # host pointers
+    with pytest.raises(ValueError):
+        cv.cvtColor(torch.zeros((35, 40), dtype=torch.uint8, device="cuda"), cv.COLOR_YUV2BGR_NV12)

@@ -76,6 +76,10 @@ def run(quick=False):
     line("a1 GaussianBlur 5x5 4K 8U single frame", timeit(lambda: cv.GaussianBlur(one, (5, 5), 0, dst=d8)), 3840 * 2160 * 2)
     line("f1 threshold BINARY 4K 8U", timeit(lambda: cv.threshold(one, 127, 255, cv.THRESH_BINARY, dst=d8)), 3840 * 2160 * 2)
     line("f1 integral 4K 8U -> 32S", timeit(lambda: cv.integral(one)), 3840 * 2160 * 5)
+    nv = torch.randint(0, 256, (3240, 3840), dtype=torch.uint8, device=dev, generator=g); nvd = torch.empty((2160, 3840, 3), dtype=torch.uint8, device=dev)
+    line("f4 cvtColor NV12 -> BGR 4K", timeit(lambda: cv.cvtColor(nv, cv.COLOR_YUV2BGR_NV12, dst=nvd)), 3840 * 2160 * 4.5)
+    line("f1 cvtColor BGR -> YUV 4K", timeit(lambda: cv.cvtColor(bgr[0], cv.COLOR_BGR2YUV, dst=nvd)), 3840 * 2160 * 6)
+    del nv, nvd
     line("f1 medianBlur 3x3 4K 8U", timeit(lambda: cv.medianBlur(one, 3, dst=d8)), 3840 * 2160 * 2)
     line("f1 medianBlur 5x5 4K 8U", timeit(lambda: cv.medianBlur(one, 5, dst=d8)), 3840 * 2160 * 2)
     line("f1 dilate 3x3 4K 8U", timeit(lambda: cv.dilate(one, dst=d8)), 3840 * 2160 * 2)
