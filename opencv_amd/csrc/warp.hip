@@ -18,6 +18,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <vector>
+#include <algorithm>
 
 using namespace mi355;
 
@@ -267,6 +269,50 @@ __global__ __launch_bounds__(256) void k_resize_linC(const uchar* __restrict__ s
             else { D[0] = (uchar)pk; D[1] = (uchar)(pk >> 8); D[2] = (uchar)(pk >> 16); }
         }
     }
+}
+
+// true INTER_AREA (shrinking by non-integer ratios): computeResizeAreaTab resize.cpp:3334 + ResizeArea_Invoker :3181.  The two
+// tap tables are built on the host exactly as the reference builds them (double arithmetic, float weights); per output element
+// sum = b0*buf0, sum += bj*bufj with bufj = ((0 + S[k0]*a0) + S[k1]*a1) + ..., float multiply and add kept separate, then
+// saturate_cast<T>.  Thread per output element; the taps of a 4K -> 720p shrink are 3-4 per axis.
+struct AreaTap { int si; float alpha; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_area(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int dw, int dh, int cn, int depth,
+                                                     const AreaTap* __restrict__ xt, const int* __restrict__ xo, const AreaTap* __restrict__ yt, const int* __restrict__ yo)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= dw * cn || dy >= dh) return;
+    const int dx = e / cn, c = e - dx * cn;
+    const int k0 = xo[dx], k1 = xo[dx + 1], j0 = yo[dy], j1 = yo[dy + 1];
+    float sum = 0.f;
+    for (int j = j0; j < j1; j++) {
+        const T* S = reinterpret_cast<const T*>(src + (size_t)yt[j].si * sstep);
+        float buf = 0.f;
+        for (int k = k0; k < k1; k++) buf = __fadd_rn(buf, __fmul_rn((float)S[xt[k].si * cn + c], xt[k].alpha));
+        const float t = __fmul_rn(yt[j].alpha, buf);
+        sum = j == j0 ? t : __fadd_rn(sum, t);
+    }
+    stRound(dst + (size_t)dy * dstep, depth, e, sum);
+}
+
+int buildAreaTab(int ssize, int dsize, double scale, std::vector<AreaTap>& tab, std::vector<int>& ofs)
+{
+    tab.clear(); ofs.assign((size_t)dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+        ofs[(size_t)dx] = (int)tab.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cellWidth = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) tab.push_back({sx1 - 1, (float)((sx1 - fsx1) / cellWidth)});
+        for (int sx = sx1; sx < sx2; sx++) tab.push_back({sx, (float)(1.0 / cellWidth)});
+        if (fsx2 - sx2 > 1e-3) tab.push_back({sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth)});
+    }
+    ofs[(size_t)dsize] = (int)tab.size();
+    return (int)tab.size();
 }
 
 // ---------------------------------------------------------------------------------- sampler
@@ -573,8 +619,7 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     else {
         if (interpolation == MI355CV_INTER_LINEAR && areaFast && a.isx == 2 && a.isy == 2) interpolation = MI355CV_INTER_AREA;   // :4011
         if (interpolation == MI355CV_INTER_AREA && a.scale_x >= 1 && a.scale_y >= 1) {
-            if (!areaFast) return MI355CV_NOT_IMPLEMENTED;                                  // true area (resizeArea_): next row
-            a.mode = 3;
+            a.mode = areaFast ? 3 : 4;                                                       // 4: true area (resizeArea_)
         } else if (interpolation == MI355CV_INTER_LINEAR) a.mode = 1;
         else if (interpolation == MI355CV_INTER_AREA) a.mode = 2;
         else return MI355CV_NOT_IMPLEMENTED;                                                // cubic / lanczos / *_EXACT: next row (f2)
@@ -586,6 +631,20 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (a.mode == 4) {
+        std::vector<AreaTap> xt, yt; std::vector<int> xo, yo;
+        buildAreaTab(src_width, dst_width, a.scale_x, xt, xo); buildAreaTab(src_height, dst_height, a.scale_y, yt, yo);
+        const AreaTap* dxt = (const AreaTap*)stg.param(xt.data(), xt.size() * sizeof(AreaTap));
+        const AreaTap* dyt = (const AreaTap*)stg.param(yt.data(), yt.size() * sizeof(AreaTap));
+        const int* dxo = (const int*)stg.param(xo.data(), xo.size() * sizeof(int));
+        const int* dyo = (const int*)stg.param(yo.data(), yo.size() * sizeof(int));
+        if (!dxt || !dyt || !dxo || !dyo) return MI355CV_NOT_IMPLEMENTED;
+        dim3 g4(divUp(dst_width * cn, 64), divUp(dst_height, 4));
+#define RA(T_) hipLaunchKernelGGL(k_resize_area<T_>, g4, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, depth, dxt, dxo, dyt, dyo)
+        switch (depth) { case D8U: RA(uchar); break; case D16U: RA(unsigned short); break; case D16S: RA(short); break; default: RA(float); }
+#undef RA
+        return stg.finish("resize");
+    }
     if ((a.mode == 1 || a.mode == 2) && cn == 1 && (depth == D32F || depth == D8U) && src_width >= 2 && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
         dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
         if (depth == D32F) hipLaunchKernelGGL(k_resize_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);

@@ -9,6 +9,7 @@
 #include "oracle.h"
 #include <math.h>
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int cvfloor_d(double v) { int i = (int)v; return i - (i > v); }
@@ -43,6 +44,55 @@ static void lin_coef(int d, double scale, double inv_scale, int ssz, int area_mo
     (void)ssz;
 }
 
+/* true INTER_AREA (non-integer shrink ratios): computeResizeAreaTab resize.cpp:3334-3371 + ResizeArea_Invoker :3181-3305.
+ * Per output element: sum = b0*buf0, then sum += bj*bufj with bufj = (((0 + S[k0]*a0) + S[k1]*a1) + ...) -- float, separate
+ * multiply and add (resize.cpp is built without FMA contraction), rows / columns in table order; saturate_cast<T> at the end. */
+typedef struct { int si; float alpha; } AreaTap;
+static int areaTab(int ssize, int dsize, double scale, AreaTap* tab, int* ofs)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        ofs[dx] = k;
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        if (sx1 - fsx1 > 1e-3) { tab[k].si = sx1 - 1; tab[k++].alpha = (float)((sx1 - fsx1) / cellWidth); }
+        for (int sx = sx1; sx < sx2; sx++) { tab[k].si = sx; tab[k++].alpha = (float)(1.0 / cellWidth); }
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2; if (a > 1.) a = 1.; if (a > cellWidth) a = cellWidth;
+            tab[k].si = sx2; tab[k++].alpha = (float)(a / cellWidth);
+        }
+    }
+    ofs[dsize] = k;
+    return k;
+}
+
+static int resizeAreaGeneral(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                             int depth, int cn, double scale_x, double scale_y)
+{
+    AreaTap* xt = (AreaTap*)malloc(sizeof(AreaTap) * (size_t)(sw * 2 + 2)); int* xo = (int*)malloc(sizeof(int) * (size_t)(dw + 1));
+    AreaTap* yt = (AreaTap*)malloc(sizeof(AreaTap) * (size_t)(sh * 2 + 2)); int* yo = (int*)malloc(sizeof(int) * (size_t)(dh + 1));
+    if (!xt || !xo || !yt || !yo) { free(xt); free(xo); free(yt); free(yo); return 1; }
+    areaTab(sw, dw, scale_x, xt, xo); areaTab(sh, dh, scale_y, yt, yo);
+    for (int dy = 0; dy < dh; dy++)
+        for (int dx = 0; dx < dw; dx++)
+            for (int c = 0; c < cn; c++) {
+                float sum = 0.f;
+                for (int j = yo[dy]; j < yo[dy + 1]; j++) {
+                    const uint8_t* S = src + (size_t)yt[j].si * sstep;
+                    float buf = 0.f;
+                    for (int k = xo[dx]; k < xo[dx + 1]; k++) { const float p = ldv(S, depth, xt[k].si * cn + c) * xt[k].alpha; buf = buf + p; }
+                    const float t = yt[j].alpha * buf;
+                    sum = j == yo[dy] ? t : sum + t;
+                }
+                stv_round(dst + (size_t)dy * dstep, depth, dx * cn + c, sum);
+            }
+    free(xt); free(xo); free(yt); free(yo);
+    return 0;
+}
+
 int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation)
 {
@@ -65,7 +115,7 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
     }
     if (interpolation == 1 && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = 3;
     if (interpolation == 3 && scale_x >= 1 && scale_y >= 1) {
-        if (!is_area_fast) return 1;                             /* true INTER_AREA: not restated */
+        if (!is_area_fast) return resizeAreaGeneral(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, scale_x, scale_y);
         const int area = iscale_x * iscale_y;
         const float scale = 1.f / area;
         const int fast2 = iscale_x == 2 && iscale_y == 2 && (cn == 1 || cn == 3 || cn == 4) && depth != 5;

@@ -46,6 +46,18 @@ def test_resize_area_fast(orc, ref, dtype, cn):
         same(orc, orc.orc_resize(src, None, 0.5, 0.5, interp), orc.ref_resize(src, None, 0.5, 0.5, interp))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_resize_area_general(orc, ref, dtype, cn):
+    """true INTER_AREA: shrinking by non-integer ratios, and by an integer ratio on one axis only (resizeArea_, resize.cpp:3181)"""
+    for (w, h), dsizes in [((53, 37), [(20, 11), (52, 36), (17, 37), (53, 9)]), ((100, 100), [(33, 33), (99, 51)]), ((64, 48), [(32, 17), (21, 24)])]:
+        src = rnd(orc, (h, w, cn) if cn > 1 else (h, w), dtype, 3 + cn + w)
+        for dsize in dsizes:
+            same(orc, orc.orc_resize(src, dsize, interpolation=3), orc.ref_resize(src, dsize, interpolation=3))
+    src = rnd(orc, (45, 77, cn) if cn > 1 else (45, 77), dtype, 8)
+    same(orc, orc.orc_resize(src, None, 0.3, 0.7, 3), orc.ref_resize(src, None, 0.3, 0.7, 3))
+
+
 def mats(orc, w, h):
     out = []
     for ang, sc in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]:

@@ -60,6 +60,20 @@ def test_resize(cv, orc, dtype, cn):
     assert torch.equal(cv.resize(dev(src), (53, 37)), dev(src))                            # same size -> copy
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_area_general(cv, orc, dtype, cn):
+    """true INTER_AREA (non-integer shrink ratios): bit-exact for the integer depths, and for float too since every multiply /
+    add runs in the reference's order without contraction"""
+    for (w, h), dsizes in [((53, 37), [(20, 11), (52, 36), (17, 37), (53, 9)]), ((100, 100), [(33, 33), (99, 51)]), ((640, 480), [(213, 160), (400, 111)])]:
+        src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 3 + cn + w)
+        for dsize in dsizes:
+            got = cv.resize(dev(src), dsize, interpolation=3).cpu().numpy()
+            assert np.array_equal(got, orc.orc_resize(src, dsize, interpolation=3)), (w, h, dsize, dtype, cn)
+    src = rnd((45, 77, cn) if cn > 1 else (45, 77), dtype, 8)
+    assert np.array_equal(cv.resize(src, None, 0.3, 0.7, 3), orc.orc_resize(src, None, 0.3, 0.7, 3))          # host pointers
+
+
 def mats(cv, w, h):
     out = [cv.getRotationMatrix2D((w / 2.0, h / 2.0), a, s) for a, s in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]]
     out.append(np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64))

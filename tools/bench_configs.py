@@ -89,6 +89,7 @@ def run(quick=False):
         out.append({"config": name, "ms": round(ms, 4), "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
     r720 = torch.empty((720, 1280, 3), dtype=torch.uint8, device=dev); r1080 = torch.empty((1080, 1920, 3), dtype=torch.uint8, device=dev)
     line2("a7 resize 4K 8UC3 -> 1280x720 bilinear", timeit(lambda: cv.resize(c3, (1280, 720), dst=r720)), 3840 * 2160 * 3 + 1280 * 720 * 3)
+    line2("a7 resize 4K 8UC3 -> 1280x720 INTER_AREA (non-integer ratio)", timeit(lambda: cv.resize(c3, (1280, 720), interpolation=3, dst=r720)), 3840 * 2160 * 3 + 1280 * 720 * 3)
     line2("a7 resize 4K 8UC3 -> 1920x1080 (area-fast)", timeit(lambda: cv.resize(c3, (1920, 1080), dst=r1080)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
     up = torch.empty((2160, 3840, 3), dtype=torch.uint8, device=dev)
     line2("a7 resize 1080p 8UC3 -> 4K bilinear", timeit(lambda: cv.resize(r1080, (3840, 2160), dst=up)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
