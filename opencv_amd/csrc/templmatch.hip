@@ -72,6 +72,56 @@ __global__ __launch_bounds__(256) void k_integral_rows(const uchar* __restrict__
     }
 }
 
+// single-channel 8-bit rows, the common case: a thread owns 16 consecutive pixels (one 16-byte load when the row allows), the
+// 256 thread totals are scanned with wave shuffles + one LDS exchange, and the finished row goes through LDS so that the
+// global stores are lane-consecutive (a thread writing its own 16 results would touch 16 different 64-byte segments).
+template <typename TS>
+__global__ __launch_bounds__(256) void k_integral_rows_u8c1(const uchar* __restrict__ src, size_t sstep, size_t sframe, int W,
+                                                            TS* __restrict__ sum, size_t sumStep, size_t sumFrame,
+                                                            double* __restrict__ sq, size_t sqStep, size_t sqFrame)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar ldsraw[];
+    const int y = blockIdx.x;
+    src += (size_t)blockIdx.z * sframe; sum += (size_t)blockIdx.z * sumFrame; if (sq) sq += (size_t)blockIdx.z * sqFrame;
+    const uchar* row = src + (size_t)y * sstep;
+    const int per = 16 * ((((W + 255) / 256) + 15) / 16);          // pixels per thread, a multiple of 16
+    TS* LS = reinterpret_cast<TS*>(ldsraw);                          // W + 1 sums
+    double* LQ = reinterpret_cast<double*>(ldsraw + (((size_t)(W + 1) * sizeof(TS) + 15) & ~(size_t)15));   // W + 1 squared sums
+    const int x0 = threadIdx.x * per, x1 = min(W, x0 + per);
+    const bool vec = ((((uintptr_t)row) | sstep) & 15) == 0;
+    unsigned s = 0; unsigned long long q = 0;                      // exact: 255 * per and 255^2 * per are far below 2^32 / 2^64
+    for (int x = x0; x < x1; x += 16) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (vec && x + 16 <= W) { const uint4 v = *reinterpret_cast<const uint4*>(row + x); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else for (int b = 0; b < 16 && x + b < W; b++) w[b >> 2] |= (unsigned)row[x + b] << (8 * (b & 3));
+#pragma unroll
+        for (int b = 0; b < 16; b++) { const unsigned p = (w[b >> 2] >> (8 * (b & 3))) & 255u; s += p; q += p * p; }
+    }
+    // block-wide exclusive scan of (s, q): wave shuffle scan, then the four wave totals through LDS
+    __shared__ unsigned long long ws[4], wq[4];
+    unsigned long long ps = s, pq = q;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long a = __shfl_up(ps, o), b = __shfl_up(pq, o);
+        if (lane >= o) { ps += a; pq += b; }
+    }
+    if (lane == 63) { ws[wave] = ps; wq[wave] = pq; }
+    __syncthreads();
+    unsigned long long os = ps - s, oq = pq - q;                   // exclusive within the wave
+    for (int k = 0; k < wave; k++) { os += ws[k]; oq += wq[k]; }
+    if (threadIdx.x == 0) { LS[0] = 0; if (sq) LQ[0] = 0; }
+    TS rs = (TS)os; double rq = (double)oq;
+    for (int x = x0; x < x1; x++) {
+        const unsigned p = row[x];
+        rs += (TS)p; rq += (double)(p * p);
+        LS[x + 1] = rs; if (sq) LQ[x + 1] = rq;
+    }
+    __syncthreads();
+    TS* srow = sum + (size_t)(y + 1) * sumStep;
+    for (int x = threadIdx.x; x <= W; x += 256) srow[x] = LS[x];
+    if (sq) { double* qrow = sq + (size_t)(y + 1) * sqStep; for (int x = threadIdx.x; x <= W; x += 256) qrow[x] = LQ[x]; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_integral_colseg(T* __restrict__ a, size_t step, size_t frame, int Wc /* (W+1)*cn */, int H, T* __restrict__ aux, size_t auxFrame)
 {
@@ -643,11 +693,15 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     void* aux = stg.scratch((size_t)nseg * Wc * 8);
     if (!aux) return MI355CV_NOT_IMPLEMENTED;
     hipStream_t st = stream();
+    const size_t ldsFast = (((size_t)(width + 1) * se + 15) & ~(size_t)15) + (s2 ? (size_t)(width + 1) * 8 : 0);
+    const bool fastRows = depth == D8U && cn == 1 && ldsFast <= 60 * 1024;
     if (sdepth == D32S) {
-        hipLaunchKernelGGL(k_integral_rows<int>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (int*)s1, d1 / 4, 0, (double*)s2, d2 / 8, 0);
+        if (fastRows) hipLaunchKernelGGL(k_integral_rows_u8c1<int>, dim3(height, 1, 1), dim3(256), ldsFast, st, ds, dss, 0, width, (int*)s1, d1 / 4, 0, (double*)s2, d2 / 8, 0);
+        else hipLaunchKernelGGL(k_integral_rows<int>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (int*)s1, d1 / 4, 0, (double*)s2, d2 / 8, 0);
         integralColumns<int>((int*)s1, d1 / 4, 0, Wc, height, 1, (int*)aux, st);
     } else {
-        hipLaunchKernelGGL(k_integral_rows<double>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (double*)s1, d1 / 8, 0, (double*)s2, d2 / 8, 0);
+        if (fastRows) hipLaunchKernelGGL(k_integral_rows_u8c1<double>, dim3(height, 1, 1), dim3(256), ldsFast, st, ds, dss, 0, width, (double*)s1, d1 / 8, 0, (double*)s2, d2 / 8, 0);
+        else hipLaunchKernelGGL(k_integral_rows<double>, dim3(height, cn, 1), dim3(256), 0, st, ds, dss, 0, width, height, cn, depth, (double*)s1, d1 / 8, 0, (double*)s2, d2 / 8, 0);
         integralColumns<double>((double*)s1, d1 / 8, 0, Wc, height, 1, (double*)aux, st);
     }
     if (s2) integralColumns<double>((double*)s2, d2 / 8, 0, Wc, height, 1, (double*)aux, st);
