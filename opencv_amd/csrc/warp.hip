@@ -315,6 +315,89 @@ int buildAreaTab(int ssize, int dsize, double scale, std::vector<AreaTap>& tab, 
     return (int)tab.size();
 }
 
+// INTER_CUBIC for CV_8U / CV_32F (resize.cpp: coefficient set-up :4097-4190, interpolateCubic :964, HResizeCubic :1993,
+// VResizeCubic :2045).  The per-column / per-row taps are built on the host exactly as the reference builds them (float, A = -0.75;
+// 8U: * 2048 rounded to short).  The reference's vertical pass has a SIMD body and a scalar tail that round differently; both are
+// reproduced per element index: body = float S0*b0 + (S1*b1 + (S2*b2 + S3*b3)) (8U: taps * 2^-22, round half-even, saturate) for
+// e < (dw*cn / 8) * 8 (8U) or (dw*cn / 4) * 4 (32F); tail = exact integers (sum + 2^21) >> 22 (8U) / left-to-right float (32F).
+struct CubicTap { int s; float f[4]; short i[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_cubic(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
+                                                      const CubicTap* __restrict__ xt, const CubicTap* __restrict__ yt)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int width = dw * cn;
+    if (e >= width || dy >= dh) return;
+    const int dx = e / cn, c = e - dx * cn;
+    const CubicTap tx = xt[dx], ty = yt[dy];
+    int xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) xs[j] = clipI(tx.s - 1 + j, 0, sw) * cn + c;
+    if (sizeof(T) == 1) {
+        int S[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uchar* R = src + (size_t)clipI(ty.s - 1 + k, 0, sh) * sstep;
+            S[k] = R[xs[0]] * tx.i[0] + R[xs[1]] * tx.i[1] + R[xs[2]] * tx.i[2] + R[xs[3]] * tx.i[3];
+        }
+        int r;
+        if (e < (width / 8) * 8) {
+            const float sc = 1.f / (2048.f * 2048.f);
+            float t = __fmul_rn((float)S[3], __fmul_rn((float)ty.i[3], sc));
+            t = __fadd_rn(__fmul_rn((float)S[2], __fmul_rn((float)ty.i[2], sc)), t);
+            t = __fadd_rn(__fmul_rn((float)S[1], __fmul_rn((float)ty.i[1], sc)), t);
+            t = __fadd_rn(__fmul_rn((float)S[0], __fmul_rn((float)ty.i[0], sc)), t);
+            r = __float2int_rn(t);
+        } else
+            r = (S[0] * ty.i[0] + S[1] * ty.i[1] + S[2] * ty.i[2] + S[3] * ty.i[3] + (1 << 21)) >> 22;
+        (dst + (size_t)dy * dstep)[e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+    } else {
+        float S[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float* R = reinterpret_cast<const float*>(src + (size_t)clipI(ty.s - 1 + k, 0, sh) * sstep);
+            float v = __fmul_rn(R[xs[0]], tx.f[0]);
+            v = __fadd_rn(v, __fmul_rn(R[xs[1]], tx.f[1]));
+            v = __fadd_rn(v, __fmul_rn(R[xs[2]], tx.f[2]));
+            v = __fadd_rn(v, __fmul_rn(R[xs[3]], tx.f[3]));
+            S[k] = v;
+        }
+        float r;
+        if (e < (width / 4) * 4) {
+            float t = __fmul_rn(S[3], ty.f[3]);
+            t = __fadd_rn(__fmul_rn(S[2], ty.f[2]), t);
+            t = __fadd_rn(__fmul_rn(S[1], ty.f[1]), t);
+            r = __fadd_rn(__fmul_rn(S[0], ty.f[0]), t);
+        } else {
+            float t = __fmul_rn(S[0], ty.f[0]);
+            t = __fadd_rn(t, __fmul_rn(S[1], ty.f[1]));
+            t = __fadd_rn(t, __fmul_rn(S[2], ty.f[2]));
+            r = __fadd_rn(t, __fmul_rn(S[3], ty.f[3]));
+        }
+        reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+    }
+}
+
+void buildCubicTab(int dsize, double scale, std::vector<CubicTap>& tab)
+{
+    tab.resize((size_t)dsize);
+    const float A = -0.75f;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int sI = (int)f; sI -= sI > f;                                      // cvFloor
+        f -= sI;
+        CubicTap& t = tab[(size_t)d];
+        t.s = sI;
+        t.f[0] = ((A * (f + 1) - 5 * A) * (f + 1) + 8 * A) * (f + 1) - 4 * A;
+        t.f[1] = ((A + 2) * f - (A + 3)) * f * f + 1;
+        t.f[2] = ((A + 2) * (1 - f) - (A + 3)) * (1 - f) * (1 - f) + 1;
+        t.f[3] = 1.f - t.f[0] - t.f[1] - t.f[2];
+        for (int k = 0; k < 4; k++) { const long q = lrintf(t.f[k] * 2048); t.i[k] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q); }
+    }
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -622,7 +705,8 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
             a.mode = areaFast ? 3 : 4;                                                       // 4: true area (resizeArea_)
         } else if (interpolation == MI355CV_INTER_LINEAR) a.mode = 1;
         else if (interpolation == MI355CV_INTER_AREA) a.mode = 2;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // cubic / lanczos / *_EXACT: next row (f2)
+        else if (interpolation == 2 /*INTER_CUBIC*/ && (depth == D8U || depth == D32F)) a.mode = 5;
+        else return MI355CV_NOT_IMPLEMENTED;                                                // lanczos / *_EXACT / cubic on 16-bit depths: next row (f2)
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
@@ -631,6 +715,17 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (a.mode == 5) {
+        std::vector<CubicTap> xt, yt;
+        buildCubicTab(dst_width, a.scale_x, xt); buildCubicTab(dst_height, a.scale_y, yt);
+        const CubicTap* dxt = (const CubicTap*)stg.param(xt.data(), xt.size() * sizeof(CubicTap));
+        const CubicTap* dyt = (const CubicTap*)stg.param(yt.data(), yt.size() * sizeof(CubicTap));
+        if (!dxt || !dyt) return MI355CV_NOT_IMPLEMENTED;
+        dim3 g5(divUp(dst_width * cn, 64), divUp(dst_height, 4));
+        if (depth == D8U) hipLaunchKernelGGL(k_resize_cubic<uchar>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        else hipLaunchKernelGGL(k_resize_cubic<float>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        return stg.finish("resize");
+    }
     if (a.mode == 4) {
         std::vector<AreaTap> xt, yt; std::vector<int> xo, yo;
         buildAreaTab(src_width, dst_width, a.scale_x, xt, xo); buildAreaTab(src_height, dst_height, a.scale_y, yt, yo);

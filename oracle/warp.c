@@ -93,6 +93,87 @@ static int resizeAreaGeneral(const uint8_t* src, size_t sstep, int sw, int sh, u
     return 0;
 }
 
+/* INTER_CUBIC for CV_8U and CV_32F: hal::resize coefficient set-up resize.cpp:4097-4190 (interpolateCubic :964, A = -0.75, float;
+ * 8U: taps * 2048 rounded to short), HResizeCubic :1993 (taps at sx-1..sx+2, columns clamped into the row), VResizeCubic :2045
+ * on rows sy-1..sy+2 clamped into the image.  The vertical pass exists twice in the reference and both forms are reproduced:
+ *   - the SIMD body (VResizeCubicVec_32s8u :1410 for every element index below the last multiple of 8, VResizeCubicVec_32f :1491
+ *     below the last multiple of 4; SSE baseline, multiply and add separate): v = S0*b0 + (S1*b1 + (S2*b2 + S3*b3)) in float
+ *     (8U: taps scaled by 2^-22, result rounded half-even and saturated);
+ *   - the scalar tail: 8U exact integers, (sum + 2^21) >> 22 saturated; 32F ((S0*b0 + S1*b1) + S2*b2) + S3*b3. */
+static void cubic_coef(float x, float* c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static int resizeCubic(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                       int depth, int cn, double scale_x, double scale_y)
+{
+    if (depth != 0 && depth != 5) return 1;
+    const int fix = depth == 0;
+    const int width = dw * cn;
+    const int body = fix ? (width / 8) * 8 : (width / 4) * 4;
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = cvfloor_f(fy); fy -= sy;
+        float cb[4]; cubic_coef(fy, cb);
+        short ib[4]; for (int k = 0; k < 4; k++) ib[k] = sat_short_i((int)lrintf(cb[k] * 2048));
+        const uint8_t* rows[4];
+        for (int k = 0; k < 4; k++) rows[k] = src + (size_t)clipi(sy - 1 + k, 0, sh) * sstep;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            const int sx = cvfloor_f(fx); fx -= sx;
+            float ca[4]; cubic_coef(fx, ca);
+            short ia[4]; for (int k = 0; k < 4; k++) ia[k] = sat_short_i((int)lrintf(ca[k] * 2048));
+            int xs[4]; for (int j = 0; j < 4; j++) xs[j] = clipi(sx - 1 + j, 0, sw);
+            for (int c = 0; c < cn; c++) {
+                const int e = dx * cn + c;
+                if (fix) {
+                    int S[4];
+                    for (int k = 0; k < 4; k++) { int v = 0; for (int j = 0; j < 4; j++) v += rows[k][xs[j] * cn + c] * ia[j]; S[k] = v; }
+                    int r;
+                    if (e < body) {
+                        const float sc = 1.f / (2048.f * 2048.f);
+                        const float b0 = ib[0] * sc, b1 = ib[1] * sc, b2 = ib[2] * sc, b3 = ib[3] * sc;
+                        float t = (float)S[3] * b3;
+                        float m = (float)S[2] * b2; t = m + t;
+                        m = (float)S[1] * b1; t = m + t;
+                        m = (float)S[0] * b0; t = m + t;
+                        r = (int)lrintf(t);
+                    } else
+                        r = (S[0] * ib[0] + S[1] * ib[1] + S[2] * ib[2] + S[3] * ib[3] + (1 << 21)) >> 22;
+                    dst[(size_t)dy * dstep + e] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+                } else {
+                    float S[4];
+                    for (int k = 0; k < 4; k++) {
+                        const float* R = (const float*)rows[k];
+                        float v = R[xs[0] * cn + c] * ca[0];
+                        for (int j = 1; j < 4; j++) { const float m = R[xs[j] * cn + c] * ca[j]; v = v + m; }
+                        S[k] = v;
+                    }
+                    float r;
+                    if (e < body) {
+                        float t = S[3] * cb[3];
+                        float m = S[2] * cb[2]; t = m + t;
+                        m = S[1] * cb[1]; t = m + t;
+                        m = S[0] * cb[0]; r = m + t;
+                    } else {
+                        float t = S[0] * cb[0];
+                        float m = S[1] * cb[1]; t = t + m;
+                        m = S[2] * cb[2]; t = t + m;
+                        m = S[3] * cb[3]; r = t + m;
+                    }
+                    ((float*)(dst + (size_t)dy * dstep))[e] = r;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation)
 {
@@ -171,6 +252,7 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
         }
         return 0;
     }
+    if (interpolation == 2) return resizeCubic(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, scale_x, scale_y);
     if (interpolation != 1 && interpolation != 3) return 1;
     const int area_mode = interpolation == 3;
     for (int dy = 0; dy < dh; dy++) {

@@ -58,6 +58,18 @@ def test_resize_area_general(orc, ref, dtype, cn):
     same(orc, orc.orc_resize(src, None, 0.3, 0.7, 3), orc.ref_resize(src, None, 0.3, 0.7, 3))
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_cubic(orc, ref, dtype, cn):
+    """INTER_CUBIC: up- and down-scaling, destination row lengths with and without a SIMD tail (dw*cn % 8, % 4), tiny sources
+    whose taps clamp on both sides"""
+    for (w, h), dsizes in [((53, 37), [(80, 55), (20, 11), (106, 74), (161, 3)]), ((9, 9), [(31, 29), (8, 8)]), ((5, 3), [(17, 13)]), ((64, 48), [(32, 24), (100, 7)])]:
+        src = rnd(orc, (h, w, cn) if cn > 1 else (h, w), dtype, 6 + cn + w)
+        for dsize in dsizes:
+            got, want = orc.orc_resize(src, dsize, interpolation=2), orc.ref_resize(src, dsize, interpolation=2)
+            assert np.array_equal(got, want), (w, h, dsize, dtype, cn)
+
+
 def mats(orc, w, h):
     out = []
     for ang, sc in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]:

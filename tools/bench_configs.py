@@ -92,6 +92,7 @@ def run(quick=False):
     line2("a7 resize 4K 8UC3 -> 1280x720 INTER_AREA (non-integer ratio)", timeit(lambda: cv.resize(c3, (1280, 720), interpolation=3, dst=r720)), 3840 * 2160 * 3 + 1280 * 720 * 3)
     line2("a7 resize 4K 8UC3 -> 1920x1080 (area-fast)", timeit(lambda: cv.resize(c3, (1920, 1080), dst=r1080)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
     up = torch.empty((2160, 3840, 3), dtype=torch.uint8, device=dev)
+    line2("a7 resize 1080p 8UC3 -> 4K INTER_CUBIC", timeit(lambda: cv.resize(r1080, (3840, 2160), interpolation=2, dst=up)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
     line2("a7 resize 1080p 8UC3 -> 4K bilinear", timeit(lambda: cv.resize(r1080, (3840, 2160), dst=up)), 3840 * 2160 * 3 + 1920 * 1080 * 3)
     Mw = cv.getRotationMatrix2D((1920.0, 1080.0), 7.0, 0.95)
     line2("a8 warpAffine 4K 8UC3 rot 7deg", timeit(lambda: cv.warpAffine(c3, Mw, (3840, 2160), dst=up)), 3840 * 2160 * 6)
