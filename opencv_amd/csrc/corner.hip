@@ -492,7 +492,8 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
         (((uintptr_t)dd | dds | dframe) & 3) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, W, 1, 2, border, 8)) {
         CornerRollArgs ra = {a.dyRow[0], a.dyRow[1], a.dyRow[2], a.dxCol[1], a.dxCol[2], a.kf};
         const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W >= 16;
-        const roll::Geom g = roll::geometry(W, H, 1, nframes, 24, 4, wide ? 16 : 8);
+        const char* segEnv = std::getenv("MI355CV_CORNER_SEG");               // tuning experiments
+        const roll::Geom g = roll::geometry(W, H, 1, nframes, segEnv ? atoi(segEnv) : 36, 4, wide ? 16 : 8);
 #define CROLL(HR, CB_) hipLaunchKernelGGL((k_corner_roll<HR, CB_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, 1, ra)
         if (wide) { if (harris) CROLL(true, 16); else CROLL(false, 16); }
         else { if (harris) CROLL(true, 8); else CROLL(false, 8); }
