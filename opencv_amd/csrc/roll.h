@@ -18,6 +18,7 @@
 // REPLICATE, REFLECT, REFLECT_101}.
 #pragma once
 #include "rt.h"
+#include <cstdlib>
 
 namespace roll {
 
@@ -269,6 +270,7 @@ inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg,
 {
     Geom g;
     g.nchunks = mi355::divUp(W * cn, cb); g.nstrips = mi355::divUp(g.nchunks, 64);
+    if (const char* e = std::getenv("MI355CV_ROLL_SEG")) { const int v = atoi(e); if (v > 0) bestSeg = v; }     // tuning experiments
     long long per = (long long)g.nstrips * nframes;
     long long wantSeg = (2048 + per - 1) / per;
     int seg = (int)((H + wantSeg - 1) / wantSeg);
