@@ -441,12 +441,12 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
     const SepParams& p = c.sp;
-    if (p.mode == 2 && c.ddepth == D16S && c.cn == 1 && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 && p.deltaI == 0 &&
-        fullW == W && fullH == H && seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, p.kxi, p.kyi, p.nx, c.border, stream()))
+    if (p.mode == 2 && c.ddepth == D16S && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 && p.deltaI == 0 &&
+        fullW == W && fullH == H && seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, c.border, stream()))
         return stg.finish(entry);
-    if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && c.cn == 1 && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 &&
+    if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 &&
         fullW == W && fullH == H &&
-        seprollFloat(ds, dss, 0, dd, dds, 0, 1, W, H, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))
+        seprollFloat(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,

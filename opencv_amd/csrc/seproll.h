@@ -15,15 +15,15 @@ bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* ds
 bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                 int W, int H, int cn, int ksize, unsigned divScale, unsigned divDelta, int border, hipStream_t st);
 
-// u8 -> s16 separable filter with small integer taps (cv::Sobel / cv::Scharr with scale 1, delta 0): n in {3,5}, cn == 1,
+// u8 -> s16 separable filter with small integer taps (cv::Sobel / cv::Scharr with scale 1, delta 0): n in {3,5}, cn in {1,3,4},
 // every intermediate and result within int16.
 bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                    int W, int H, const int* kx, const int* ky, int n, int border, hipStream_t st);
+                    int W, int H, int cn, const int* kx, const int* ky, int n, int border, hipStream_t st);
 
 // u8 -> f32 (outBytes 4) or u8 -> u8 (outBytes 1) separable filter on the FLOAT path of cv::sepFilter2D / cv::Sobel:
-// n in {3,5}, cn == 1, centred anchors; symY as SepParams (1 symmetric, 2 antisymmetric pair form, 0 plain chain).
+// n in {3,5}, cn in {1,3}, centred anchors; symY as SepParams (1 symmetric, 2 antisymmetric pair form, 0 plain chain).
 bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                  int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st);
+                  int W, int H, int cn, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st);
 
 // u8 erode / dilate with a full ksize x ksize rectangle (3/5/7), centred anchor, cn in {1,3,4}; BORDER_CONSTANT means the
 // DEFAULT border value of cv::erode / cv::dilate (the identity of the operation), the other border types extrapolate.

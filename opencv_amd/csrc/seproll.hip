@@ -189,10 +189,10 @@ struct BoxU8 {
 // cv::Sobel / cv::Scharr with CV_16S output, scale 1, delta 0: exact integer arithmetic in the reference (SymmRowSmallVec_8u32s
 // filter.simd.hpp:530-860, SymmColumnSmallVec_32s16s :1420-1600), result within int16 by the host's range check, so the two
 // passes run as packed 16-bit multiply-adds (v_pk_mad_i16 / v_pk_mul_lo_u16) on the byte planes.
-template <int K>
+template <int K, int CN_>
 struct Deriv16 {
-    static constexpr int KX = K, KY = K, CN = 1, CB = 16, OUTB = 2, R = K / 2;
-    static constexpr int HD = roll::Cfg<R, 1>::HD;
+    static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 2, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, CN>::HD;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     struct Args { uint32_t kx[K], ky[K]; };              // taps splatted into both 16-bit halves
     template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
@@ -200,7 +200,7 @@ struct Deriv16 {
     template <int Q, int I>
     static __device__ __forceinline__ s16x2 hsum(const uint32_t* E, const uint32_t* O, int k, const Args& a)
     {
-        const s16x2 v = __builtin_bit_cast(s16x2, roll::pairAt<Q, (I - R), HD>(E, O, k));
+        const s16x2 v = __builtin_bit_cast(s16x2, roll::pairAt<Q, (I - R) * CN, HD>(E, O, k));
         const s16x2 t = __builtin_bit_cast(s16x2, a.kx[I]);
         if constexpr (I == 0) return v * t; else return v * t + hsum<Q, I - 1>(E, O, k, a);
     }
@@ -233,12 +233,12 @@ struct Deriv16 {
 // SymmColumnFilter :2679-2751 in its symmetric / antisymmetric pair form, ColumnFilter :2640 as a plain chain), in that
 // association order.  Values are held as pairs (pixel i, pixel i+8) so that every multiply-add is a v_pk_fma_f32.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int K, int SYM, int OUTB_>
+template <int K, int SYM, int OUTB_, int CN_>
 struct SepF32 {
-    static constexpr int KX = K, KY = K, CN = 1, OUTB = OUTB_, R = K / 2;
-    static constexpr int CB = OUTB_ == 4 ? 8 : 16;           // 32-bit outputs: 8 pixels per lane = 32 contiguous output bytes
-    static constexpr int NP = CB / 2;                        // pixel pairs (i, i + NP)
-    static constexpr int HD = roll::Cfg<R, 1, CB>::HD;
+    static constexpr int KX = K, KY = K, CN = CN_, OUTB = OUTB_, R = K / 2;
+    static constexpr int CB = OUTB_ == 4 ? 8 : 16;           // 32-bit outputs: 8 elements per lane = 32 contiguous output bytes
+    static constexpr int NP = CB / 2;                        // element pairs (i, i + NP)
+    static constexpr int HD = roll::Cfg<R, CN, CB>::HD;
     struct Args { float kx[K], ky[K], delta; };
     template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
     struct Inter { f32x2 h[NP]; };
@@ -249,14 +249,15 @@ struct SepF32 {
             const uint32_t w = (b & 1) ? O[b >> 2] : E[b >> 2];
             return (float)((b & 2) ? (w >> 16) : (w & 0xffffu));
         };
-        f32x2 Q[NP + 2 * R];
+        constexpr int HB = R * CN;
+        f32x2 Q[NP + 2 * HB];
 #pragma unroll
-        for (int m = 0; m < NP + 2 * R; m++) { Q[m].x = byteAt(4 * HD - R + m); Q[m].y = byteAt(4 * HD - R + m + NP); }
+        for (int m = 0; m < NP + 2 * HB; m++) { Q[m].x = byteAt(4 * HD - HB + m); Q[m].y = byteAt(4 * HD - HB + m + NP); }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             f32x2 r = Q[i] * f32x2{a.kx[0], a.kx[0]};
 #pragma unroll
-            for (int t = 1; t < K; t++) r = __builtin_elementwise_fma(f32x2{a.kx[t], a.kx[t]}, Q[i + t], r);
+            for (int t = 1; t < K; t++) r = __builtin_elementwise_fma(f32x2{a.kx[t], a.kx[t]}, Q[i + t * CN], r);
             o.h[i] = r;
         }
     }
@@ -382,33 +383,39 @@ bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
 }
 
 bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                    int W, int H, const int* kx, const int* ky, int n, int border, hipStream_t st)
+                    int W, int H, int cn, const int* kx, const int* ky, int n, int border, hipStream_t st)
 {
-    if (n != 3 && n != 5) return false;
+    if ((n != 3 && n != 5) || !(cn == 1 || cn == 3 || cn == 4)) return false;
     long long ax = 0, ay = 0;
     for (int i = 0; i < n; i++) { ax += kx[i] < 0 ? -kx[i] : kx[i]; ay += ky[i] < 0 ? -ky[i] : ky[i]; }
     if (255 * ax > 32767 || 255 * ax * ay > 32767) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & 1) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border)) return false;
-#define DV(K_) do { typedef Deriv16<K_> P; P::Args a; \
+    if ((((uintptr_t)dst | dstep | dframe) & 1) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, cn, n / 2, border)) return false;
+#define DV(K_, CN_) do { typedef Deriv16<K_, CN_> P; P::Args a; \
         for (int i = 0; i < K_; i++) { a.kx[i] = ((uint32_t)kx[i] & 0xffffu) * 0x10001u; a.ky[i] = ((uint32_t)ky[i] & 0xffffu) * 0x10001u; } \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
-    if (n == 3) DV(3); else DV(5);
+#define DVC(K_) do { if (cn == 1) DV(K_, 1); else if (cn == 3) DV(K_, 3); else DV(K_, 4); } while (0)
+    if (n == 3) DVC(3); else DVC(5);
+#undef DVC
 #undef DV
     return true;
 }
 
 bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                  int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
+                  int W, int H, int cn, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
 {
-    if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, 1, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
-#define SF(K_, S_, O_) do { typedef SepF32<K_, S_, O_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
+    if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2 || !(cn == 1 || cn == 3)) return false;
+    if (cn == 3 && outBytes == 4 && n == 5) return false;         // 2 pixels x 3 channels of halo do not fit an 8-byte chunk
+    if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, cn, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
+#define SF1(K_, S_, O_, CN_) do { typedef SepF32<K_, S_, O_, CN_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st); } while (0)
+#define SF(K_, S_, O_) do { if (cn == 1) SF1(K_, S_, O_, 1); else SF1(K_, S_, O_, 3); } while (0)
 #define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)
     if (n == 3) { if (outBytes == 4) SFS(3, 4); else SFS(3, 1); }
-    else        { if (outBytes == 4) SFS(5, 4); else SFS(5, 1); }
+    else if (outBytes == 4) { if (symY == 1) SF1(5, 1, 4, 1); else if (symY == 2) SF1(5, 2, 4, 1); else SF1(5, 0, 4, 1); }
+    else SFS(5, 1);
 #undef SFS
 #undef SF
+#undef SF1
     return true;
 }
 

@@ -196,6 +196,17 @@ def test_sobel_box_rolling_path(cv, orc):
                                ([0.05, 0.1, 0.4, 0.3, 0.15], [0.3, 0.3, 0.2, 0.1, 0.1], 0.0)]:
                 check(cv.sepFilter2D(dev(src), -1, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, -1, kx, ky, (-1, -1), dl, border))
                 check(cv.sepFilter2D(dev(src), cv.CV_32F, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, 5, kx, ky, (-1, -1), dl, border))
+    # multi-channel derivative / float-tap filters on the rolling kernels
+    for cn in (3, 4):
+        for (w, h) in [(32, 5), (64, 23), (1040, 37), (333, 19)]:
+            srcc = rnd((h, w, cn), np.uint8, w + cn)
+            for border in (0, 1, 4):
+                for ksize, dx, dy in [(3, 1, 0), (3, 0, 1), (5, 1, 1), (-1, 0, 1)]:
+                    check(cv.Sobel(dev(srcc), cv.CV_16S, dx, dy, ksize, 1.0, 0.0, border), orc.orc_Sobel(srcc, 3, dx, dy, ksize, 1.0, 0.0, border))
+                    check(cv.Sobel(dev(srcc), cv.CV_32F, dx, dy, ksize, 0.25, 0.0, border), orc.orc_Sobel(srcc, 5, dx, dy, ksize, 0.25, 0.0, border))
+                for kx, ky, dl in [([0.1, 0.5, 0.2], [0.7, -0.1, 0.2], 3.5), ([0.05, 0.1, 0.4, 0.3, 0.15], [0.3, 0.3, 0.2, 0.1, 0.1], 0.0)]:
+                    check(cv.sepFilter2D(dev(srcc), -1, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(srcc, -1, kx, ky, (-1, -1), dl, border))
+                    check(cv.sepFilter2D(dev(srcc), cv.CV_32F, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(srcc, 5, kx, ky, (-1, -1), dl, border))
     full = np.full((40, 64), 255, np.uint8)
     for k in (3, 5, 7):
         assert (cv.blur(dev(full), (k, k)).cpu().numpy() == 255).all()
