@@ -1,6 +1,6 @@
 // color_yuv.hip -- SURVEY.md §8 f1 / f4 (video ingest): the CV_8U members of the YUV family behind
-//   cv_hal_cvtBGRtoYUV (hal_replacement.hpp:500), cv_hal_cvtYUVtoBGR (:533), cv_hal_cvtTwoPlaneYUVtoBGR (:664) and
-//   cv_hal_cvtTwoPlaneYUVtoBGREx (:701); callers color_yuv.dispatch.cpp:33, :86, :166, :144.
+//   cv_hal_cvtBGRtoYUV (hal_replacement.hpp:500), cv_hal_cvtYUVtoBGR (:533), cv_hal_cvtTwoPlaneYUVtoBGR (:664),
+//   cv_hal_cvtTwoPlaneYUVtoBGREx (:701) and cv_hal_cvtThreePlaneYUVtoBGR (:763); callers color_yuv.dispatch.cpp:33, :86, :166, :144, :202.
 // Integer arithmetic of color_yuv.simd.hpp (its SIMD bodies and scalar tails agree, so one formula):
 //   BGR->YUV/YCrCb  RGB2YCrCb_i<uchar> :398   Y = (c0*s0 + c1*s1 + c2*s2 + 2^13) >> 14,  Cr/V = ((R - Y)*c3 + 128*2^14 + 2^13) >> 14, ...
 //   YUV/YCrCb->BGR  YCrCb2RGB_i<uchar> :739   b = Y + ((Cb-128)*c3 + 2^13) >> 14, ...
@@ -75,6 +75,34 @@ __global__ __launch_bounds__(256) void k_nv2bgr_u8(const uchar* __restrict__ yp,
     }
 }
 
+// I420 / YV12: the two quarter-size chroma planes follow the luma plane inside the same array, packed two chroma rows per array
+// row (cvtThreePlaneYUVtoBGR color_yuv.simd.hpp:2060-2087); a chroma sample is addressed through its linear index
+template <int DCN>
+__global__ __launch_bounds__(256) void k_i420_2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bIdx, int uIdx)
+{
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * bx >= W || 2 * by >= H) return;
+    const size_t plane = (size_t)(H / 2) * (size_t)(W / 2);
+    const size_t l0 = (size_t)by * (size_t)(W / 2) + (size_t)bx, l1 = plane + l0;
+    const int c0 = src[((size_t)H + l0 / W) * sstep + l0 % W], c1 = src[((size_t)H + l1 / W) * sstep + l1 % W];
+    const int uu = (uIdx ? c1 : c0) - 128, vv = (uIdx ? c0 : c1) - 128;
+    const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uchar* yr = src + (size_t)(2 * by + j) * sstep + 2 * (size_t)bx;
+        uchar* d = dst + (size_t)(2 * by + j) * dstep + 2 * (size_t)bx * DCN;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int yv = max((int)yr[i] - 16, 0) * 1220542;
+            d[i * DCN + 2 - bIdx] = (uchar)sat8((yv + ruv) >> 20);
+            d[i * DCN + 1] = (uchar)sat8((yv + guv) >> 20);
+            d[i * DCN + bIdx] = (uchar)sat8((yv + buv) >> 20);
+            if (DCN == 4) d[i * DCN + 3] = 255;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -132,6 +160,23 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
     if (dcn == 3) hipLaunchKernelGGL(k_nv2bgr_u8<3>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
     else hipLaunchKernelGGL(k_nv2bgr_u8<4>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
     return stg.finish("cvtTwoPlaneYUVtoBGR");
+}
+
+MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,
+                                              int dcn, bool swapBlue, int uIdx)
+{
+    if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
+        return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)dst_width, dst_height * 3 / 2, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(dst_width / 2, 64), divUp(dst_height / 2, 4));
+    if (dcn == 3) hipLaunchKernelGGL(k_i420_2bgr_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    else hipLaunchKernelGGL(k_i420_2bgr_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    return stg.finish("cvtThreePlaneYUVtoBGR");
 }
 
 MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,

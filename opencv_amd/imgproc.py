@@ -16,7 +16,9 @@ _vp = ctypes.c_void_p
 
 __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB", "COLOR_BGR2YUV", "COLOR_RGB2YUV",
            "COLOR_YUV2BGR", "COLOR_YUV2RGB", "COLOR_YUV2RGB_NV12", "COLOR_YUV2BGR_NV12", "COLOR_YUV2RGB_NV21", "COLOR_YUV2BGR_NV21",
-           "COLOR_YUV2RGBA_NV12", "COLOR_YUV2BGRA_NV12", "COLOR_YUV2RGBA_NV21", "COLOR_YUV2BGRA_NV21", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
+           "COLOR_YUV2RGBA_NV12", "COLOR_YUV2BGRA_NV12", "COLOR_YUV2RGBA_NV21", "COLOR_YUV2BGRA_NV21",
+           "COLOR_YUV2RGB_YV12", "COLOR_YUV2BGR_YV12", "COLOR_YUV2RGB_IYUV", "COLOR_YUV2BGR_IYUV", "COLOR_YUV2RGB_I420", "COLOR_YUV2BGR_I420",
+           "COLOR_YUV2RGBA_YV12", "COLOR_YUV2BGRA_YV12", "COLOR_YUV2RGBA_IYUV", "COLOR_YUV2BGRA_IYUV", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
@@ -183,6 +185,10 @@ COLOR_YUV2RGB_NV12, COLOR_YUV2BGR_NV12, COLOR_YUV2RGB_NV21, COLOR_YUV2BGR_NV21 =
 COLOR_YUV2RGBA_NV12, COLOR_YUV2BGRA_NV12, COLOR_YUV2RGBA_NV21, COLOR_YUV2BGRA_NV21 = 94, 95, 96, 97
 _YUV_FWD = {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}
 _YUV_INV = {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}
+COLOR_YUV2RGB_YV12, COLOR_YUV2BGR_YV12, COLOR_YUV2RGB_IYUV, COLOR_YUV2BGR_IYUV = 98, 99, 100, 101
+COLOR_YUV2RGB_I420, COLOR_YUV2BGR_I420 = 100, 101
+COLOR_YUV2RGBA_YV12, COLOR_YUV2BGRA_YV12, COLOR_YUV2RGBA_IYUV, COLOR_YUV2BGRA_IYUV = 102, 103, 104, 105
+_YUV_3P = {98: (3, 1, 1), 99: (3, 0, 1), 100: (3, 1, 0), 101: (3, 0, 0), 102: (4, 1, 1), 103: (4, 0, 1), 104: (4, 1, 0), 105: (4, 0, 0)}
 _YUV_NV = {90: (3, 1, 0), 91: (3, 0, 0), 92: (3, 1, 1), 93: (3, 0, 1), 94: (4, 1, 0), 95: (4, 0, 0), 96: (4, 1, 1), 97: (4, 0, 1)}
 
 
@@ -237,15 +243,18 @@ def cvtColor(src, code, dst=None, dstCn=0):
         bind_stream(s, d)
         _lib.check(L.mi355cv_cvtYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(swap), bool(cbcr)), "cvtYUVtoBGR")
         return out
-    if code in _YUV_NV:
-        dcn, swap, uidx = _YUV_NV[code]
+    if code in _YUV_NV or code in _YUV_3P:
+        dcn, swap, uidx = _YUV_NV[code] if code in _YUV_NV else _YUV_3P[code]
         if s.cn != 1 or s.depth != CV_8U or s.h % 3 or s.w % 2:
             raise ValueError("cvtColor: NV12/NV21 needs a CV_8UC1 image of (3/2 * height) x width, width and height even")    # color.cpp cvtColorTwoPlane
         dh = s.h * 2 // 3
         out = dst if dst is not None else empty_like_kind(src[..., None] if getattr(src, "ndim", 2) == 2 else src, dh, s.w, dcn, s.depth)
         d = Img(out)
         bind_stream(s, d)
-        _lib.check(L.mi355cv_cvtTwoPlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtTwoPlaneYUVtoBGR")
+        if code in _YUV_NV:
+            _lib.check(L.mi355cv_cvtTwoPlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtTwoPlaneYUVtoBGR")
+        else:
+            _lib.check(L.mi355cv_cvtThreePlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtThreePlaneYUVtoBGR")
         return out
     raise NotImplementedError(f"cvtColor: conversion code {code} is outside the hot path built so far")
 

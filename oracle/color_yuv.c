@@ -59,3 +59,26 @@ void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t
             if (dcn == 4) d[3] = 255;
         }
 }
+
+/* I420 / IYUV (uIdx 0) and YV12 (uIdx 1): one array of (dst_h * 3/2) rows x dst_w bytes -- Y plane, then the two quarter-size
+ * chroma planes packed back to back, two chroma rows per array row (cvtThreePlaneYUVtoBGR color_yuv.simd.hpp:2060-2087,
+ * YUV420p2RGB8Invoker :1318-1445).  Same per-pixel arithmetic as the two-plane decoder. */
+void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int dst_w, int dst_h, int dcn, int swapBlue, int uIdx)
+{
+    const int bIdx = swapBlue ? 2 : 0;
+    const size_t plane = (size_t)(dst_h / 2) * (size_t)(dst_w / 2);
+    for (int j = 0; j < dst_h; j++)
+        for (int i = 0; i < dst_w; i++) {
+            const size_t lin = (size_t)(j / 2) * (size_t)(dst_w / 2) + (size_t)(i / 2);
+            const size_t l0 = lin, l1 = plane + lin;                        /* first / second chroma plane */
+            const uint8_t c0 = src[((size_t)dst_h + l0 / dst_w) * sstep + l0 % dst_w];
+            const uint8_t c1 = src[((size_t)dst_h + l1 / dst_w) * sstep + l1 % dst_w];
+            const int uu = (int)(uIdx ? c1 : c0) - 128, vv = (int)(uIdx ? c0 : c1) - 128;
+            const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+            int yy = (int)src[(size_t)j * sstep + i] - 16; if (yy < 0) yy = 0;
+            const int yv = yy * 1220542;
+            uint8_t* d = dst + (size_t)j * dstep + (size_t)i * dcn;
+            d[2 - bIdx] = sat8((yv + ruv) >> 20); d[1] = sat8((yv + guv) >> 20); d[bIdx] = sat8((yv + buv) >> 20);
+            if (dcn == 4) d[3] = 255;
+        }
+}

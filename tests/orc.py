@@ -207,6 +207,10 @@ _YUV_INV = {84: (3, 0, 0), 85: (3, 1, 0), 38: (3, 0, 1), 39: (3, 1, 1)}         
 _YUV_NV = {90: (3, 1, 0), 91: (3, 0, 0), 92: (3, 1, 1), 93: (3, 0, 1), 94: (4, 1, 0), 95: (4, 0, 0), 96: (4, 1, 1), 97: (4, 0, 1)}   # *_NV12 / *_NV21 -> (dcn, swapBlue, uIdx)
 
 
+# *_YV12 (98, 99, 102, 103) and *_IYUV / *_I420 (100, 101, 104, 105) -> (dcn, swapBlue, uIdx)
+_YUV_3P = {98: (3, 1, 1), 99: (3, 0, 1), 100: (3, 1, 0), 101: (3, 0, 0), 102: (4, 1, 1), 103: (4, 0, 1), 104: (4, 1, 0), 105: (4, 0, 0)}
+
+
 def orc_cvtColorYUV(src, code):
     o = oracle()
     h, w = src.shape[:2]
@@ -218,6 +222,11 @@ def orc_cvtColorYUV(src, code):
         dcn, swap, cbcr = _YUV_INV[code]
         dst = np.empty((h, w, dcn), np.uint8)
         o.orc_cvtYUVtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, cbcr)
+    elif code in _YUV_3P:
+        dcn, swap, uidx = _YUV_3P[code]
+        dh = h * 2 // 3
+        dst = np.empty((dh, w, dcn), np.uint8)
+        o.orc_cvtThreePlaneYUVtoBGR(P(src), step(src), P(dst), step(dst), w, dh, dcn, swap, uidx)
     else:
         dcn, swap, uidx = _YUV_NV[code]
         dh = h * 2 // 3
@@ -230,8 +239,8 @@ def orc_cvtColorYUV(src, code):
 def ref_cvtColorYUV(src, code):
     r = load_ref()
     h, w = src.shape[:2]
-    if code in _YUV_NV:
-        dcn = _YUV_NV[code][0]
+    if code in _YUV_NV or code in _YUV_3P:
+        dcn = (_YUV_NV.get(code) or _YUV_3P[code])[0]
         dst = np.empty((h * 2 // 3, w, dcn), np.uint8)
     else:
         dcn = 3 if code in _YUV_FWD else _YUV_INV[code][0]

@@ -33,10 +33,10 @@ def test_yuv_family(cv, orc):
 
 
 def test_nv12_nv21(cv, orc):
-    for (w, h) in [(2, 2), (6, 4), (64, 8), (262, 6), (1030, 4), (1920, 1080)]:
+    for (w, h) in [(2, 2), (6, 4), (64, 8), (262, 6), (1030, 4), (1920, 1080), (642, 362)]:
         rng = np.random.default_rng(w)
         src = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)
-        for code in O._YUV_NV:
+        for code in list(O._YUV_NV) + list(O._YUV_3P):          # NV12 / NV21 and I420 / YV12 (h % 4 == 2 shifts the second chroma plane)
             got = cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy()
             assert np.array_equal(got, orc.orc_cvtColorYUV(src, code)), (w, h, code)
     src = np.random.default_rng(3).integers(0, 256, (36, 40), dtype=np.uint8)
