@@ -258,6 +258,9 @@ MI355CV_API int mi355cv_cvtYUVtoBGR(const mi355cv_uchar* src_data, size_t src_st
         int width, int height, int depth, int dcn, bool swapBlue, bool isCbCr);
 MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx);
+/* hal_ni_cvtBGRtoHSV (hal_replacement.hpp:596; caller color_hsv.dispatch.cpp:65): CV_8U, isHSV only (HLS and CV_32F decline) */
+MI355CV_API int mi355cv_cvtBGRtoHSV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV);
 /* hal_ni_cvtThreePlaneYUVtoBGR (hal_replacement.hpp:763): I420 / IYUV (uIdx 0) and YV12 (uIdx 1) in one array */
 MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx);

@@ -88,6 +88,8 @@
 #define cv_hal_cvtYUVtoBGR mi355cv_cvtYUVtoBGR
 #undef  cv_hal_cvtTwoPlaneYUVtoBGR
 #define cv_hal_cvtTwoPlaneYUVtoBGR mi355cv_cvtTwoPlaneYUVtoBGR
+#undef  cv_hal_cvtBGRtoHSV
+#define cv_hal_cvtBGRtoHSV mi355cv_cvtBGRtoHSV
 #undef  cv_hal_cvtThreePlaneYUVtoBGR
 #define cv_hal_cvtThreePlaneYUVtoBGR mi355cv_cvtThreePlaneYUVtoBGR
 #undef  cv_hal_cvtTwoPlaneYUVtoBGREx

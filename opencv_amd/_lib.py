@@ -62,6 +62,7 @@ def _load():
         "mi355cv_cvtBGRtoYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_cvtYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_cvtTwoPlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtBGRtoHSV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_cvtThreePlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtTwoPlaneYUVtoBGREx": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_medianBlur": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int]),

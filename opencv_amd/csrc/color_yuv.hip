@@ -7,6 +7,7 @@
 //   NV12 / NV21     YUV420sp2RGB8Invoker :1195, 20-bit ITU-R BT.601: r = (max(Y-16,0)*1220542 + 1673527*(V-128) + 2^19) >> 20, ...
 // All HBM-bound: a thread handles four pixels (packed conversions) / one 2x2 block (4:2:0), plain coalesced loads and stores.
 #include "rt.h"
+#include <cmath>
 
 using namespace mi355;
 
@@ -73,6 +74,27 @@ __global__ __launch_bounds__(256) void k_nv2bgr_u8(const uchar* __restrict__ yp,
             if (DCN == 4) d[i * DCN + 3] = 255;
         }
     }
+}
+
+// BGR/RGB -> HSV, CV_8U: RGB2HSV_b color_hsv.simd.hpp:47-262 -- integer arithmetic with the two reciprocal tables (hsv_shift 12)
+// that the host builds exactly as TablesSingleton does and passes in HBM.
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2hsv_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                    int bidx, int hr, const int* __restrict__ sdiv, const int* __restrict__ hdiv)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
+    uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
+    const int b = s[bidx], g = s[1], r = s[bidx ^ 2];
+    const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+    hh += hh < 0 ? hr : 0;
+    d[0] = (uchar)sat8(hh); d[1] = (uchar)sat; d[2] = (uchar)v;
 }
 
 // I420 / YV12: the two quarter-size chroma planes follow the luma plane inside the same array, packed two chroma rows per array
@@ -160,6 +182,29 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
     if (dcn == 3) hipLaunchKernelGGL(k_nv2bgr_u8<3>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
     else hipLaunchKernelGGL(k_nv2bgr_u8<4>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
     return stg.finish("cvtTwoPlaneYUVtoBGR");
+}
+
+// replaces hal_ni_cvtBGRtoHSV (hal_replacement.hpp:596; caller color_hsv.dispatch.cpp:65): CV_8U and HSV only (HLS / CV_32F decline)
+MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV)
+{
+    if (disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const int hr = isFullRange ? 256 : 180;
+    int tabs[512];                                                       // sdiv_table, hdiv_table (color_hsv.simd.hpp:70-78)
+    tabs[0] = tabs[256] = 0;
+    for (int i = 1; i < 256; i++) { tabs[i] = (int)nearbyint((255 << 12) / (1. * i)); tabs[256 + i] = (int)nearbyint((hr << 12) / (6. * i)); }
+    const int* dt = (const int*)stg.param(tabs, sizeof tabs);
+    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (scn == 3) hipLaunchKernelGGL(k_bgr2hsv_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hr, dt, dt + 256);
+    else hipLaunchKernelGGL(k_bgr2hsv_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hr, dt, dt + 256);
+    return stg.finish("cvtBGRtoHSV");
 }
 
 MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,

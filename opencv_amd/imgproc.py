@@ -17,7 +17,7 @@ _vp = ctypes.c_void_p
 __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB", "COLOR_BGR2YUV", "COLOR_RGB2YUV",
            "COLOR_YUV2BGR", "COLOR_YUV2RGB", "COLOR_YUV2RGB_NV12", "COLOR_YUV2BGR_NV12", "COLOR_YUV2RGB_NV21", "COLOR_YUV2BGR_NV21",
            "COLOR_YUV2RGBA_NV12", "COLOR_YUV2BGRA_NV12", "COLOR_YUV2RGBA_NV21", "COLOR_YUV2BGRA_NV21",
-           "COLOR_YUV2RGB_YV12", "COLOR_YUV2BGR_YV12", "COLOR_YUV2RGB_IYUV", "COLOR_YUV2BGR_IYUV", "COLOR_YUV2RGB_I420", "COLOR_YUV2BGR_I420",
+           "COLOR_BGR2HSV", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2HSV_FULL", "COLOR_YUV2RGB_YV12", "COLOR_YUV2BGR_YV12", "COLOR_YUV2RGB_IYUV", "COLOR_YUV2BGR_IYUV", "COLOR_YUV2RGB_I420", "COLOR_YUV2BGR_I420",
            "COLOR_YUV2RGBA_YV12", "COLOR_YUV2BGRA_YV12", "COLOR_YUV2RGBA_IYUV", "COLOR_YUV2BGRA_IYUV", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
@@ -183,6 +183,8 @@ COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB = 36, 37, 38,
 COLOR_BGR2YUV, COLOR_RGB2YUV, COLOR_YUV2BGR, COLOR_YUV2RGB = 82, 83, 84, 85
 COLOR_YUV2RGB_NV12, COLOR_YUV2BGR_NV12, COLOR_YUV2RGB_NV21, COLOR_YUV2BGR_NV21 = 90, 91, 92, 93
 COLOR_YUV2RGBA_NV12, COLOR_YUV2BGRA_NV12, COLOR_YUV2RGBA_NV21, COLOR_YUV2BGRA_NV21 = 94, 95, 96, 97
+COLOR_BGR2HSV, COLOR_RGB2HSV, COLOR_BGR2HSV_FULL, COLOR_RGB2HSV_FULL = 40, 41, 66, 67
+_HSV = {40: (0, 0), 41: (1, 0), 66: (0, 1), 67: (1, 1)}
 _YUV_FWD = {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}
 _YUV_INV = {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}
 COLOR_YUV2RGB_YV12, COLOR_YUV2BGR_YV12, COLOR_YUV2RGB_IYUV, COLOR_YUV2BGR_IYUV = 98, 99, 100, 101
@@ -222,6 +224,16 @@ def cvtColor(src, code, dst=None, dstCn=0):
         d = Img(out)
         bind_stream(s, d)
         _lib.check(L.mi355cv_cvtBGRtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, scn, dcn, swap), "cvtBGRtoBGR")
+        return out
+    if code in _HSV:
+        swap, full = _HSV[code]
+        if s.cn not in (3, 4):
+            raise ValueError("cvtColor: source must have 3 or 4 channels")
+        ref3 = src[..., :3] if s.cn == 4 else src
+        out = dst if dst is not None else empty_like_kind(ref3, s.h, s.w, 3, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtBGRtoHSV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(swap), bool(full), True), "cvtBGRtoHSV")
         return out
     if code in _YUV_FWD:
         swap, cbcr = _YUV_FWD[code]

@@ -3,6 +3,7 @@
  * YCrCb2RGB_i<uchar> :739-880 (scalar form :866-880), and the 4:2:0 two-plane decoder YUV420sp2RGB8Invoker :1195-1316
  * (uvToRGBuv :1043, yRGBuvToRGBA :1090); constants :66-92, :1018-1023 and color.simd_helpers.hpp:17-21. */
 #include "oracle.h"
+#include <math.h>
 
 #define DESCALE14(x) (((x) + (1 << 13)) >> 14)
 static uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
@@ -80,5 +81,30 @@ void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, s
             uint8_t* d = dst + (size_t)j * dstep + (size_t)i * dcn;
             d[2 - bIdx] = sat8((yv + ruv) >> 20); d[1] = sat8((yv + guv) >> 20); d[bIdx] = sat8((yv + buv) >> 20);
             if (dcn == 4) d[3] = 255;
+        }
+}
+
+/* BGR/RGB -> HSV, CV_8U: RGB2HSV_b color_hsv.simd.hpp:47-262 (scalar form :234-258; tables :70-78, hsv_shift 12).
+ * hrange = 180 (COLOR_*2HSV) or 256 (COLOR_*2HSV_FULL). */
+void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange)
+{
+    const int bidx = swapBlue ? 2 : 0, hr = fullRange ? 256 : 180;
+    int sdiv[256], hdiv[256];
+    sdiv[0] = hdiv[0] = 0;
+    for (int i = 1; i < 256; i++) { sdiv[i] = (int)lrint((255 << 12) / (1. * i)); hdiv[i] = (int)lrint((hr << 12) / (6. * i)); }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* s = src + (size_t)y * sstep + (size_t)x * scn;
+            uint8_t* d = dst + (size_t)y * dstep + (size_t)x * 3;
+            const int b = s[bidx], g = s[1], r = s[bidx ^ 2];
+            int v = b > g ? b : g; if (r > v) v = r;
+            int vmin = b < g ? b : g; if (r < vmin) vmin = r;
+            const int diff = v - vmin;
+            const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+            const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
+            int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+            hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+            hh += hh < 0 ? hr : 0;
+            d[0] = sat8(hh); d[1] = (uint8_t)sat; d[2] = (uint8_t)v;
         }
 }

@@ -55,6 +55,8 @@ void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t
 
 void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int dst_w, int dst_h, int dcn, int swapBlue, int uIdx);
 
+void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange);
+
 /* linear filters, see oracle/filter.c.  (fullW, fullH, offX, offY) describe the parent image of the ROI. */
 void orc_filter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
                   int fullW, int fullH, int offX, int offY, const float* kernel, int kw, int kh, int ax, int ay,

@@ -211,9 +211,17 @@ _YUV_NV = {90: (3, 1, 0), 91: (3, 0, 0), 92: (3, 1, 1), 93: (3, 0, 1), 94: (4, 1
 _YUV_3P = {98: (3, 1, 1), 99: (3, 0, 1), 100: (3, 1, 0), 101: (3, 0, 0), 102: (4, 1, 1), 103: (4, 0, 1), 104: (4, 1, 0), 105: (4, 0, 0)}
 
 
+_HSV = {40: (0, 0), 41: (1, 0), 66: (0, 1), 67: (1, 1)}                       # BGR2HSV, RGB2HSV, BGR2HSV_FULL, RGB2HSV_FULL -> (swapBlue, fullRange)
+
+
 def orc_cvtColorYUV(src, code):
     o = oracle()
     h, w = src.shape[:2]
+    if code in _HSV:
+        swap, full = _HSV[code]
+        dst = np.empty((h, w, 3), np.uint8)
+        o.orc_cvtBGRtoHSV8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, full)
+        return dst
     if code in _YUV_FWD:
         scn, swap, cbcr = _YUV_FWD[code]
         dst = np.empty((h, w, 3), np.uint8)
@@ -243,7 +251,7 @@ def ref_cvtColorYUV(src, code):
         dcn = (_YUV_NV.get(code) or _YUV_3P[code])[0]
         dst = np.empty((h * 2 // 3, w, dcn), np.uint8)
     else:
-        dcn = 3 if code in _YUV_FWD else _YUV_INV[code][0]
+        dcn = 3 if (code in _YUV_FWD or code in _HSV) else _YUV_INV[code][0]
         dst = np.empty((h, w, dcn), np.uint8)
     rc = r.ref_cvtColorSz(P(src), step(src), w, h, cvtype(src), P(dst), step(dst), w, dst.shape[0], cvtype(dst), code)
     assert rc == 0, rc

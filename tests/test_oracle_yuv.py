@@ -26,6 +26,10 @@ def test_yuv_family_matches_reference(ref):
         for code in O._YUV_INV:
             src = _img(h, w, 3, code)
             assert np.array_equal(O.orc_cvtColorYUV(src, code), O.ref_cvtColorYUV(src, code)), (w, h, code)
+        for code in O._HSV:                                      # BGR/RGB -> HSV, 180 and 256 hue ranges
+            for cn in (3, 4):
+                src = _img(h, w, cn, code + cn)
+                assert np.array_equal(O.orc_cvtColorYUV(src, code), O.ref_cvtColorYUV(src, code)), (w, h, code, cn)
     for (w, h) in [(2, 2), (6, 4), (64, 8), (262, 6), (1030, 4)]:
         rng = np.random.default_rng(w)
         src = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)

@@ -19,7 +19,7 @@ def cv():
 
 def test_yuv_family(cv, orc):
     for (w, h) in [(1, 1), (7, 3), (64, 5), (263, 9), (1030, 2), (1920, 16)]:
-        for code in O._YUV_FWD:
+        for code in list(O._YUV_FWD) + list(O._HSV):             # YUV / YCrCb and HSV (180 and 256 hue ranges)
             for cn in (3, 4):
                 src = _img(h, w, cn, code + cn)
                 assert np.array_equal(cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy(), orc.orc_cvtColorYUV(src, code)), (w, h, code, cn)
