@@ -275,6 +275,11 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const mi355cv_uchar* y_data, size_
 MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
 
+/* replaces hal_ni_adaptiveThreshold (hal_replacement.hpp:1038; caller cv::adaptiveThreshold thresh.cpp:1711): CV_8UC1,
+ * adaptiveMethod ADAPTIVE_THRESH_MEAN_C (0) with blockSize 3..15, thresholdType THRESH_BINARY (0) / THRESH_BINARY_INV (1). */
+MI355CV_API int mi355cv_adaptiveThreshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C);
+
 /* --------------------------------------------------- f1: erode / dilate */
 
 /* replace hal_ni_morphInit / hal_ni_morph / hal_ni_morphFree (hal_replacement.hpp:207-233; caller halMorph

@@ -69,6 +69,8 @@
 #undef  cv_hal_cvtBGRtoBGR
 #define cv_hal_cvtBGRtoBGR mi355cv_cvtBGRtoBGR
 // hal_replacement.hpp:1058 / caller ThresholdRunner thresh.cpp:1365
+#undef  cv_hal_adaptiveThreshold
+#define cv_hal_adaptiveThreshold mi355cv_adaptiveThreshold
 #undef  cv_hal_threshold
 #define cv_hal_threshold mi355cv_threshold
 // hal_replacement.hpp:207-233 / caller halMorph morph.dispatch.cpp:190-220

@@ -26,6 +26,7 @@ struct ThreadCtx {
     hipEvent_t events[64] = {};
     bool useUser = false;
     bool async = false;
+    int stagerDepth = 0;              // hooks may call other hooks (adaptiveThreshold -> boxFilter): only the outermost Stager recycles the pool
     std::vector<Buf> pool;
     ~ThreadCtx() {
         // process teardown order vs. the HIP runtime is undefined: leak on purpose
@@ -125,11 +126,12 @@ bool isDevicePtr(const void* p)
 
 // ------------------------------------------------------------------ Stager
 
-Stager::Stager() {}
+Stager::Stager() { tctx().stagerDepth++; }
 Stager::~Stager()
 {
-    // buffers handed out by this Stager become reusable; safe in stream order
-    for (auto& b : tctx().pool) b.busy = false;
+    // buffers handed out during this (outermost) hook become reusable; safe in stream order
+    if (--tctx().stagerDepth == 0)
+        for (auto& b : tctx().pool) b.busy = false;
 }
 
 void* Stager::bump_(size_t bytes)

@@ -3,6 +3,7 @@
 // integer depths, thresh.cpp:1583-1680); per element dst = f(src > thresh) for the five fixed-level types
 // (thresh_8u :112, thresh_16u :300, thresh_16s :478, thresh_32f :652).  HBM-bound: 2 * elemSize bytes per element.
 #include "rt.h"
+#include <cmath>
 
 using namespace mi355;
 
@@ -47,7 +48,55 @@ __global__ __launch_bounds__(256) void k_threshold(const uchar* __restrict__ src
     }
 }
 
+// dst = (src - mean > -idelta) ? maxval : 0  (THRESH_BINARY)  /  (src - mean <= -idelta) ? maxval : 0  (THRESH_BINARY_INV): the 768-entry
+// table of cv::adaptiveThreshold (thresh.cpp:1736-1745) evaluated directly
+__global__ __launch_bounds__(256) void k_adaptive(const uchar* __restrict__ src, size_t sstep, const uchar* __restrict__ mean, size_t mstep,
+                                                  uchar* __restrict__ dst, size_t dstep, int W, int H, int idelta, int maxval, int inv)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (x + k < W) {
+            const int v = (int)src[(size_t)y * sstep + x + k] - (int)mean[(size_t)y * mstep + x + k];
+            const bool on = inv ? v <= -idelta : v > -idelta;
+            dst[(size_t)y * dstep + x + k] = (uchar)(on ? maxval : 0);
+        }
+    }
+}
+
 } // namespace
+
+extern "C" MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type);
+
+// replaces hal_ni_adaptiveThreshold (hal_replacement.hpp:1038; caller cv::adaptiveThreshold thresh.cpp:1711): CV_8UC1,
+// ADAPTIVE_THRESH_MEAN_C with blockSize <= 15 (the exact u16 box filter; the Gaussian variant runs a float blur and is left to the
+// CPU), THRESH_BINARY / THRESH_BINARY_INV.  mean = boxFilter(src, blockSize, BORDER_REPLICATE | BORDER_ISOLATED), then the table.
+extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                                     double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C)
+{
+    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (adaptiveMethod != 0 /*ADAPTIVE_THRESH_MEAN_C*/ || (thresholdType != 0 && thresholdType != 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (blockSize < 3 || !(blockSize & 1) || blockSize > 15) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
+    const size_t mstep = ((size_t)width + 255) & ~(size_t)255;
+    uchar* mean = (uchar*)stg.scratch(mstep * height);
+    if (!ds || !dd || !mean) return MI355CV_NOT_IMPLEMENTED;
+    const int rc = mi355cv_boxFilter(ds, dss, mean, mstep, width, height, D8U, D8U, 1, 0, 0, 0, 0, (size_t)blockSize, (size_t)blockSize, -1, -1, true, B_REPLICATE);
+    if (rc != MI355CV_OK) return rc;
+    double mv = nearbyint(maxValue); mv = mv < 0 ? 0 : mv > 255 ? 255 : mv;                       // saturate_cast<uchar>(maxValue)
+    const int idelta = thresholdType == 0 ? (int)ceil(C) : (int)floor(C);
+    dim3 grid(divUp(divUp(width, 4), 64), divUp(height, 4));
+    hipLaunchKernelGGL(k_adaptive, grid, dim3(256), 0, stream(), ds, dss, mean, mstep, dd, dds, width, height, idelta, (int)mv, thresholdType);
+    return stg.finish("adaptiveThreshold");
+}
 
 extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                              int depth, int cn, double thresh, double maxValue, int thresholdType)

@@ -26,7 +26,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -321,6 +321,27 @@ def threshold(src, thresh, maxval, type, dst=None):
     bind_stream(s, d)
     _lib.check(L.mi355cv_threshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, float(thresh), float(maxval), int(type)), "threshold")
     return float(thresh), out
+
+
+ADAPTIVE_THRESH_MEAN_C, ADAPTIVE_THRESH_GAUSSIAN_C = 0, 1
+
+
+def adaptiveThreshold(src, maxValue, adaptiveMethod, thresholdType, blockSize, C, dst=None):
+    """cv::adaptiveThreshold (thresh.cpp:1693) through cv_hal_adaptiveThreshold: CV_8UC1, ADAPTIVE_THRESH_MEAN_C, blockSize <= 15."""
+    s = Img(src)
+    if s.depth != CV_8U or s.cn != 1:
+        raise ValueError("adaptiveThreshold: CV_8UC1 only")                                   # CV_Assert, :1699
+    if blockSize % 2 != 1 or blockSize <= 1:
+        raise ValueError("adaptiveThreshold: blockSize must be odd and > 1")
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, 1, s.depth)
+    if maxValue < 0:
+        out[...] = 0
+        return out
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_adaptiveThreshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, float(maxValue), int(adaptiveMethod), int(thresholdType),
+                                           int(blockSize), float(C)), "adaptiveThreshold")
+    return out
 
 
 # ----------------------------------------------------------------------------- median (f1)

@@ -109,6 +109,9 @@ int orc_morph(int op, const uint8_t* src, size_t sstep, uint8_t* dst, size_t dst
 /* cv::medianBlur, see oracle/median.c (odd ksize 3..31; depth 0/2/3/5) */
 int orc_medianBlur(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn, int ksize);
 
+int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
+                              int blockSize, double delta);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,14 @@ int ref_cvtColorSz(const void* s, size_t ss, int sw, int sh, int stype, void* d,
     REF_END(dst, d)
 }
 
+int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, double maxValue, int method, int ttype, int blockSize, double C)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, CV_8UC1), dst = M(d, ds, w, h, CV_8UC1);
+    cv::adaptiveThreshold(src, dst, maxValue, method, ttype, blockSize, C);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {

@@ -4,6 +4,7 @@
 #include "oracle.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
@@ -67,4 +68,28 @@ int orc_threshold(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
     if (depth != 5) return 1;
     *retval = thresh;
     return orc_thresholdHal(src, sstep, dst, dstep, w, h, depth, cn, thresh, maxval, type);
+}
+
+/* cv::adaptiveThreshold (thresh.cpp:1693-1763), ADAPTIVE_THRESH_MEAN_C: mean = boxFilter(src, blockSize x blockSize, normalised,
+ * BORDER_REPLICATE | BORDER_ISOLATED) in CV_8U, then dst = tab[src - mean + 255] with tab as built at :1736-1745. */
+int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+                  int fullW, int fullH, int offX, int offY, int kw, int kh, int ax, int ay, int normalize, int border);
+int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
+                              int blockSize, double delta)
+{
+    if ((type != 0 && type != 1) || blockSize < 3 || !(blockSize & 1)) return 1;
+    if (maxValue < 0) { for (int y = 0; y < h; y++) memset(dst + (size_t)y * dstep, 0, (size_t)w); return 0; }
+    uint8_t* mean = (uint8_t*)malloc((size_t)w * h);
+    if (!mean) return 1;
+    int rc = orc_boxFilter(src, sstep, mean, (size_t)w, w, h, 1, 0, 0, w, h, 0, 0, blockSize, blockSize, blockSize / 2, blockSize / 2, 1, ORC_BORDER_REPLICATE);
+    if (rc) { free(mean); return rc; }
+    int mv = cvRoundD(maxValue); mv = mv < 0 ? 0 : mv > 255 ? 255 : mv;
+    const int idelta = type == 0 ? (int)ceil(delta) : (int)floor(delta);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int i = src[(size_t)y * sstep + x] - mean[(size_t)y * w + x] + 255;
+            dst[(size_t)y * dstep + x] = (uint8_t)(type == 0 ? (i - 255 > -idelta ? mv : 0) : (i - 255 <= -idelta ? mv : 0));
+        }
+    free(mean);
+    return 0;
 }

@@ -344,6 +344,24 @@ def ref_morph(op, src, kernel=None, anchor=(-1, -1), iterations=1, border=0, bor
     return dst
 
 
+def orc_adaptiveThreshold(src, maxValue, type, blockSize, C):
+    o = oracle()
+    h, w = src.shape
+    dst = np.empty_like(src)
+    rc = o.orc_adaptiveThresholdMean(P(src), step(src), P(dst), step(dst), w, h, ctypes.c_double(maxValue), type, blockSize, ctypes.c_double(C))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_adaptiveThreshold(src, maxValue, method, type, blockSize, C):
+    r = load_ref()
+    h, w = src.shape
+    dst = np.empty_like(src)
+    rc = r.ref_adaptiveThreshold(P(src), step(src), P(dst), step(dst), w, h, ctypes.c_double(maxValue), method, type, blockSize, ctypes.c_double(C))
+    assert rc == 0, rc
+    return dst
+
+
 # ----------------------------------------------------------------------------- linear filters
 def _roi(src, roi):
     """roi = (x0, y0, w, h) inside `src` (the parent) or None -> (view, fullW, fullH, offX, offY)"""

@@ -41,3 +41,17 @@ def test_threshold_known_answers():
     for ttype, e in exp.items():
         rv, got = O.orc_threshold(src, 10.7, 200.2, ttype)
         assert rv == 10.0 and got.tolist() == [e], ttype
+
+
+@pytest.mark.ref
+def test_adaptive_threshold_mean_matches_reference(ref):
+    rng = np.random.default_rng(21)
+    for shape in [(37, 61), (64, 64), (5, 9), (1, 20)]:
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        for bs in (3, 5, 7, 11, 15):
+            for ttype in (0, 1):
+                for C in (0.0, 2.0, -3.5, 7.25):
+                    for mv in (255.0, 100.4):
+                        want = O.ref_adaptiveThreshold(src, mv, 0, ttype, bs, C)
+                        got = O.orc_adaptiveThreshold(src, mv, ttype, bs, C)
+                        assert np.array_equal(got, want), (shape, bs, ttype, C, mv)

@@ -42,3 +42,22 @@ def test_threshold_4k_bandwidth_shape(cv, orc):
     src = np.random.default_rng(5).integers(0, 256, (2160, 3840), dtype=np.uint8)
     rv, got = cv.threshold(torch.from_numpy(src).cuda(), 127, 255, 0)
     assert np.array_equal(got.cpu().numpy(), orc.orc_threshold(src, 127, 255, 0)[1])
+
+
+def test_adaptive_threshold(cv, orc):
+    rng = np.random.default_rng(21)
+    for shape in [(37, 61), (64, 64), (5, 9), (1, 20), (480, 640)]:
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        for bs in (3, 5, 7, 11, 15):
+            for ttype in (0, 1):
+                for C in (0.0, 2.0, -3.5):
+                    want = orc.orc_adaptiveThreshold(src, 255.0, ttype, bs, C)
+                    got = cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_MEAN_C, ttype, bs, C).cpu().numpy()
+                    assert np.array_equal(got, want), (shape, bs, ttype, C)
+    src = rng.integers(0, 256, (50, 70), dtype=np.uint8)
+    assert np.array_equal(cv.adaptiveThreshold(src, 200.0, 0, 0, 5, 3.0), orc.orc_adaptiveThreshold(src, 200.0, 0, 5, 3.0))      # host pointers
+    d = torch.from_numpy(src).cuda()
+    cv.adaptiveThreshold(d, 200.0, 0, 1, 7, 1.0, dst=d)                                                                       # in place
+    assert np.array_equal(d.cpu().numpy(), orc.orc_adaptiveThreshold(src, 200.0, 1, 7, 1.0))
+    with pytest.raises(NotImplementedError):
+        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 5, 0.0)
