@@ -280,6 +280,13 @@ MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step
 MI355CV_API int mi355cv_adaptiveThreshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C);
 
+/* --------------------------------------------------- f1: Canny */
+
+/* replaces hal_ni_canny (hal_replacement.hpp:1291; caller cv::Canny canny.cpp:864).  CV_8U, 1..4 channels, ksize 3 or 5; thresholds as
+ * cv::Canny passes them to the hook (before the L2 squaring and the floor).  dst CV_8UC1, 255 on edges. */
+MI355CV_API int mi355cv_canny(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int cn, double lowThreshold, double highThreshold, int ksize, bool L2gradient);
+
 /* --------------------------------------------------- f1: erode / dilate */
 
 /* replace hal_ni_morphInit / hal_ni_morph / hal_ni_morphFree (hal_replacement.hpp:207-233; caller halMorph

@@ -96,5 +96,8 @@
 #define cv_hal_cvtThreePlaneYUVtoBGR mi355cv_cvtThreePlaneYUVtoBGR
 #undef  cv_hal_cvtTwoPlaneYUVtoBGREx
 #define cv_hal_cvtTwoPlaneYUVtoBGREx mi355cv_cvtTwoPlaneYUVtoBGREx
+// hal_replacement.hpp:1291 / caller canny.cpp:864
+#undef  cv_hal_canny
+#define cv_hal_canny mi355cv_canny
 
 #endif

@@ -66,6 +66,7 @@ def _load():
         "mi355cv_cvtThreePlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtTwoPlaneYUVtoBGREx": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_medianBlur": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_canny": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_dbl, c_int, ctypes.c_bool]),
         "mi355cv_adaptiveThreshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_dbl, c_int, c_int, c_int, c_dbl]),
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_filterFree": (c_int, [ctypes.c_void_p]),

@@ -26,7 +26,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "Canny", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -321,6 +321,26 @@ def threshold(src, thresh, maxval, type, dst=None):
     bind_stream(s, d)
     _lib.check(L.mi355cv_threshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, float(thresh), float(maxval), int(type)), "threshold")
     return float(thresh), out
+
+
+def Canny(image, threshold1, threshold2, apertureSize=3, L2gradient=False, dst=None):
+    """cv::Canny (canny.cpp:823) through cv_hal_canny: CV_8U, 1-4 channels, aperture 3 or 5."""
+    s = Img(image)
+    if s.depth != CV_8U:
+        raise ValueError("Canny: CV_8U only")                                               # CV_Assert, :829
+    if apertureSize % 2 == 0 or apertureSize < 3 or apertureSize > 7:
+        raise ValueError("Canny: aperture size should be odd between 3 and 7")              # :845
+    lo, hi = float(threshold1), float(threshold2)
+    if apertureSize == 7:
+        lo, hi = lo / 16.0, hi / 16.0
+    if lo > hi:
+        lo, hi = hi, lo
+    ref2 = image[..., 0] if s.cn > 1 else image
+    out = dst if dst is not None else empty_like_kind(ref2, s.h, s.w, 1, CV_8U)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_canny(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.cn, lo, hi, int(apertureSize), bool(L2gradient)), "canny")
+    return out
 
 
 ADAPTIVE_THRESH_MEAN_C, ADAPTIVE_THRESH_GAUSSIAN_C = 0, 1

@@ -112,6 +112,10 @@ int orc_medianBlur(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
 int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
                               int blockSize, double delta);
 
+/* cv::Canny, see oracle/canny.c (CV_8U, 1..4 channels, aperture 3 / 5) */
+int orc_Canny(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, double low_thresh, double high_thresh,
+              int aperture, int L2);
+
 #ifdef __cplusplus
 }
 #endif

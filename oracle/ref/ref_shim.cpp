@@ -207,6 +207,14 @@ int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, i
     REF_END(dst, d)
 }
 
+int ref_Canny(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, double t1, double t2, int aperture, int L2)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, CV_8UC1);
+    cv::Canny(src, dst, t1, t2, aperture, L2 != 0);
+    REF_END(dst, d)
+}
+
 int ref_resize(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
                double fx, double fy, int interpolation)
 {

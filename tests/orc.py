@@ -362,6 +362,24 @@ def ref_adaptiveThreshold(src, maxValue, method, type, blockSize, C):
     return dst
 
 
+def orc_Canny(src, t1, t2, aperture=3, L2=False):
+    o = oracle()
+    h, w = src.shape[:2]
+    dst = np.empty((h, w), np.uint8)
+    rc = o.orc_Canny(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), ctypes.c_double(t1), ctypes.c_double(t2), aperture, int(L2))
+    assert rc == 0, rc
+    return dst
+
+
+def ref_Canny(src, t1, t2, aperture=3, L2=False):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty((h, w), np.uint8)
+    rc = r.ref_Canny(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), ctypes.c_double(t1), ctypes.c_double(t2), aperture, int(L2))
+    assert rc == 0, rc
+    return dst
+
+
 # ----------------------------------------------------------------------------- linear filters
 def _roi(src, roi):
     """roi = (x0, y0, w, h) inside `src` (the parent) or None -> (view, fullW, fullH, offX, offY)"""

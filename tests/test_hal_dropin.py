@@ -39,6 +39,8 @@ def _calls(o, src8, src8c3, srcf):
     out["i420"] = o.ref_cvtColorYUV(src8, 101)
     out["hsv"] = o.ref_cvtColorYUV(src8c3, 40)
     out["adaptive"] = o.ref_adaptiveThreshold(src8, 255.0, 0, 0, 7, 2.0)
+    out["canny"] = o.ref_Canny(src8, 30, 90)
+    out["canny3"] = o.ref_Canny(src8c3, 200, 400, 3, True)
     out["median3"] = o.ref_medianBlur(src8c3, 3)
     out["median5"] = o.ref_medianBlur(src8, 5)
     out["dilate"] = o.ref_morph(1, src8)
@@ -87,7 +89,7 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold"]
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold", "canny"]
     before = {n: cv.call_count(n) for n in names}
     with O.use_ref(hal):
         through = _calls(O, src8, src8c3, srcf)
