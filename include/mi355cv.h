@@ -280,6 +280,46 @@ MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step
 MI355CV_API int mi355cv_adaptiveThreshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C);
 
+/* --------------------------------------------------- f1 / f4: remaining integer colour conversions (csrc/color_misc.hip) */
+
+/* replaces hal_ni_cvtBGRtoTwoPlaneYUV (hal_replacement.hpp:743; caller color_yuv.dispatch.cpp:238): BGR/RGB(A) CV_8U -> NV12 (uIdx 1) / NV21 (uIdx 2) */
+MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* y_data, size_t y_step,
+        mi355cv_uchar* uv_data, size_t uv_step, int width, int height, int scn, bool swapBlue, int uIdx);
+/* replaces hal_ni_cvtBGRtoThreePlaneYUV (:797; caller color_yuv.dispatch.cpp:222): -> I420 / IYUV (uIdx 1) or YV12 (uIdx 2), one (3/2 height) x width array */
+MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int scn, bool swapBlue, int uIdx);
+/* replaces hal_ni_cvtOnePlaneYUVtoBGR (:833; caller color_yuv.dispatch.cpp:260): YUY2 / YVYU / UYVY (CV_8UC2) -> BGR/RGB(A) */
+MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int dcn, bool swapBlue, int uIdx, int ycn);
+/* replaces hal_ni_cvtOnePlaneBGRtoYUV (:866; caller color_yuv.dispatch.cpp:281) */
+MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
+        int width, int height, int scn, bool swapBlue, int uIdx, int ycn);
+/* replace hal_ni_cvtBGRtoXYZ (:564; caller color_lab.cpp:4134) and hal_ni_cvtXYZtoBGR (:579): CV_8U, CV_16U (CV_32F declines) */
+MI355CV_API int mi355cv_cvtBGRtoXYZ(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int depth, int scn, bool swapBlue);
+MI355CV_API int mi355cv_cvtXYZtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int depth, int dcn, bool swapBlue);
+/* replace hal_ni_cvtBGRtoBGR5x5 (:411), cvtBGR5x5toBGR (:427), cvtBGR5x5toGray (:470), cvtGraytoBGR5x5 (:484); callers color_rgb.dispatch.cpp */
+MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int scn, bool swapBlue, int greenBits);
+MI355CV_API int mi355cv_cvtBGR5x5toBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int dcn, bool swapBlue, int greenBits);
+MI355CV_API int mi355cv_cvtBGR5x5toGray(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int greenBits);
+MI355CV_API int mi355cv_cvtGraytoBGR5x5(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int greenBits);
+/* replace hal_ni_cvtRGBAtoMultipliedRGBA (:894) and hal_ni_cvtMultipliedRGBAtoRGBA (:907) */
+MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
+MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
+
+/* --------------------------------------------------- f1: histogram-driven point operations (csrc/hist.hip) */
+
+/* replaces hal_ni_equalize_hist (hal_replacement.hpp:1120; caller histogram.cpp:3455): CV_8UC1 */
+MI355CV_API int mi355cv_equalize_hist(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
+/* replaces hal_ni_threshold_otsu (:1077; caller thresh.cpp:1568): CV_8UC1 / CV_16UC1; *thresh receives the Otsu level */
+MI355CV_API int mi355cv_threshold_otsu(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int depth, double maxValue, int thresholdType, double* thresh);
+
 /* --------------------------------------------------- f1: Canny */
 
 /* replaces hal_ni_canny (hal_replacement.hpp:1291; caller cv::Canny canny.cpp:864).  CV_8U, 1..4 channels, ksize 3 or 5; thresholds as

@@ -96,6 +96,36 @@
 #define cv_hal_cvtThreePlaneYUVtoBGR mi355cv_cvtThreePlaneYUVtoBGR
 #undef  cv_hal_cvtTwoPlaneYUVtoBGREx
 #define cv_hal_cvtTwoPlaneYUVtoBGREx mi355cv_cvtTwoPlaneYUVtoBGREx
+// hal_replacement.hpp (line per hook) -- the remaining integer colour conversions and the histogram-driven point operations
+#undef  cv_hal_cvtBGRtoTwoPlaneYUV
+#define cv_hal_cvtBGRtoTwoPlaneYUV mi355cv_cvtBGRtoTwoPlaneYUV   // :743
+#undef  cv_hal_cvtBGRtoThreePlaneYUV
+#define cv_hal_cvtBGRtoThreePlaneYUV mi355cv_cvtBGRtoThreePlaneYUV   // :797
+#undef  cv_hal_cvtOnePlaneYUVtoBGR
+#define cv_hal_cvtOnePlaneYUVtoBGR mi355cv_cvtOnePlaneYUVtoBGR   // :833
+#undef  cv_hal_cvtOnePlaneBGRtoYUV
+#define cv_hal_cvtOnePlaneBGRtoYUV mi355cv_cvtOnePlaneBGRtoYUV   // :866
+#undef  cv_hal_cvtBGRtoXYZ
+#define cv_hal_cvtBGRtoXYZ mi355cv_cvtBGRtoXYZ   // :564
+#undef  cv_hal_cvtXYZtoBGR
+#define cv_hal_cvtXYZtoBGR mi355cv_cvtXYZtoBGR   // :579
+#undef  cv_hal_cvtBGRtoBGR5x5
+#define cv_hal_cvtBGRtoBGR5x5 mi355cv_cvtBGRtoBGR5x5   // :411
+#undef  cv_hal_cvtBGR5x5toBGR
+#define cv_hal_cvtBGR5x5toBGR mi355cv_cvtBGR5x5toBGR   // :427
+#undef  cv_hal_cvtBGR5x5toGray
+#define cv_hal_cvtBGR5x5toGray mi355cv_cvtBGR5x5toGray   // :470
+#undef  cv_hal_cvtGraytoBGR5x5
+#define cv_hal_cvtGraytoBGR5x5 mi355cv_cvtGraytoBGR5x5   // :484
+#undef  cv_hal_cvtRGBAtoMultipliedRGBA
+#define cv_hal_cvtRGBAtoMultipliedRGBA mi355cv_cvtRGBAtoMultipliedRGBA   // :894
+#undef  cv_hal_cvtMultipliedRGBAtoRGBA
+#define cv_hal_cvtMultipliedRGBAtoRGBA mi355cv_cvtMultipliedRGBAtoRGBA   // :907
+#undef  cv_hal_equalize_hist
+#define cv_hal_equalize_hist mi355cv_equalize_hist   // :1120
+#undef  cv_hal_threshold_otsu
+#define cv_hal_threshold_otsu mi355cv_threshold_otsu   // :1077
+
 // hal_replacement.hpp:1291 / caller canny.cpp:864
 #undef  cv_hal_canny
 #define cv_hal_canny mi355cv_canny

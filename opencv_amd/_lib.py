@@ -66,6 +66,20 @@ def _load():
         "mi355cv_cvtThreePlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtTwoPlaneYUVtoBGREx": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_medianBlur": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int]),
+        "mi355cv_cvtBGRtoTwoPlaneYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtBGRtoThreePlaneYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtOnePlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int, c_int]),
+        "mi355cv_cvtOnePlaneBGRtoYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int, c_int]),
+        "mi355cv_cvtBGRtoXYZ": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
+        "mi355cv_cvtXYZtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
+        "mi355cv_cvtBGRtoBGR5x5": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtBGR5x5toBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
+        "mi355cv_cvtBGR5x5toGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
+        "mi355cv_cvtGraytoBGR5x5": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
+        "mi355cv_cvtRGBAtoMultipliedRGBA": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
+        "mi355cv_cvtMultipliedRGBAtoRGBA": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
+        "mi355cv_equalize_hist": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
+        "mi355cv_threshold_otsu": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_int, ctypes.POINTER(ctypes.c_double)]),
         "mi355cv_canny": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_dbl, c_int, ctypes.c_bool]),
         "mi355cv_adaptiveThreshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_dbl, c_int, c_int, c_int, c_dbl]),
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),

@@ -26,7 +26,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
-           "Canny", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -268,7 +268,113 @@ def cvtColor(src, code, dst=None, dstCn=0):
         else:
             _lib.check(L.mi355cv_cvtThreePlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtThreePlaneYUVtoBGR")
         return out
+    if code in _MISC:
+        return _cvt_misc(src, s, code, dst, dstCn)
     raise NotImplementedError(f"cvtColor: conversion code {code} is outside the hot path built so far")
+
+
+def _misc_table():
+    """cvtColor codes (imgproc.hpp:565-864) of the remaining integer conversions -> (kind, parameters as color.cpp:200-372 derives them)"""
+    t = {}
+    for code, swap in ((32, 0), (33, 1)): t[code] = ("to_xyz", swap)
+    for code, swap in ((34, 0), (35, 1)): t[code] = ("from_xyz", swap)
+    for code, cn, swap, gb in ((12, 3, 0, 6), (13, 3, 1, 6), (16, 4, 0, 6), (17, 4, 1, 6), (22, 3, 0, 5), (23, 3, 1, 5), (26, 4, 0, 5), (27, 4, 1, 5)):
+        t[code] = ("to_5x5", cn, swap, gb)
+    for code, cn, swap, gb in ((14, 3, 0, 6), (15, 3, 1, 6), (18, 4, 0, 6), (19, 4, 1, 6), (24, 3, 0, 5), (25, 3, 1, 5), (28, 4, 0, 5), (29, 4, 1, 5)):
+        t[code] = ("from_5x5", cn, swap, gb)
+    t[20] = ("gray_to_5x5", 6); t[30] = ("gray_to_5x5", 5); t[21] = ("5x5_to_gray", 6); t[31] = ("5x5_to_gray", 5)
+    for code, dcn, swap, uidx, ycn in ((107, 3, 1, 0, 1), (108, 3, 0, 0, 1), (111, 4, 1, 0, 1), (112, 4, 0, 0, 1), (115, 3, 1, 0, 0), (116, 3, 0, 0, 0),
+                                       (117, 3, 1, 1, 0), (118, 3, 0, 1, 0), (119, 4, 1, 0, 0), (120, 4, 0, 0, 0), (121, 4, 1, 1, 0), (122, 4, 0, 1, 0)):
+        t[code] = ("dec422", dcn, swap, uidx, ycn)
+    for code, scn, swap, uidx, ycn in ((143, 3, 1, 0, 1), (144, 3, 0, 0, 1), (145, 4, 1, 0, 1), (146, 4, 0, 0, 1), (147, 3, 1, 0, 0), (148, 3, 0, 0, 0),
+                                       (149, 3, 1, 1, 0), (150, 3, 0, 1, 0), (151, 4, 1, 0, 0), (152, 4, 0, 0, 0), (153, 4, 1, 1, 0), (154, 4, 0, 1, 0)):
+        t[code] = ("enc422", scn, swap, uidx, ycn)
+    for code, scn, swap, uidx in ((127, 3, 1, 1), (128, 3, 0, 1), (129, 4, 1, 1), (130, 4, 0, 1), (131, 3, 1, 2), (132, 3, 0, 2), (133, 4, 1, 2), (134, 4, 0, 2)):
+        t[code] = ("enc420p", scn, swap, uidx)
+    t[125] = ("premul",); t[126] = ("unpremul",)
+    return t
+
+
+_MISC = _misc_table()
+
+
+def _like(src, h, w, cn, depth):
+    """a fresh array of the same kind (numpy / torch, device) as `src`"""
+    base = src
+    while getattr(base, "ndim", 2) > 2:
+        base = base[..., 0]
+    return empty_like_kind(base if cn == 1 else base[..., None], h, w, cn, depth)
+
+
+def _cvt_misc(src, s, code, dst, dstCn):
+    k = _MISC[code]
+    kind = k[0]
+
+    def need(cond, what):
+        if not cond:
+            raise ValueError("cvtColor: " + what)                                               # the CvtHelper assertions, color.hpp:140-170
+
+    a = None
+    if kind == "to_xyz":
+        need(s.cn in (3, 4) and s.depth in (CV_8U, CV_16U), "BGR2XYZ: 3 or 4 channels, CV_8U / CV_16U on this path")
+        out = dst if dst is not None else _like(src, s.h, s.w, 3, s.depth)
+        call = lambda d: L.mi355cv_cvtBGRtoXYZ(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]))
+    elif kind == "from_xyz":
+        need(s.cn == 3 and s.depth in (CV_8U, CV_16U), "XYZ2BGR: 3 channels, CV_8U / CV_16U on this path")
+        dcn = dstCn if dstCn in (3, 4) else 3
+        out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
+        call = lambda d: L.mi355cv_cvtXYZtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]))
+    elif kind == "to_5x5":
+        need(s.cn == k[1] and s.depth == CV_8U, f"source must be CV_8UC{k[1]}")
+        out = dst if dst is not None else _like(src, s.h, s.w, 2, CV_8U)
+        call = lambda d: L.mi355cv_cvtBGRtoBGR5x5(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.cn, bool(k[2]), k[3])
+    elif kind == "from_5x5":
+        need(s.cn == 2 and s.depth == CV_8U, "source must be CV_8UC2")
+        out = dst if dst is not None else _like(src, s.h, s.w, k[1], CV_8U)
+        call = lambda d: L.mi355cv_cvtBGR5x5toBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, k[1], bool(k[2]), k[3])
+    elif kind == "gray_to_5x5":
+        need(s.cn == 1 and s.depth == CV_8U, "source must be CV_8UC1")
+        out = dst if dst is not None else _like(src, s.h, s.w, 2, CV_8U)
+        call = lambda d: L.mi355cv_cvtGraytoBGR5x5(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, k[1])
+    elif kind == "5x5_to_gray":
+        need(s.cn == 2 and s.depth == CV_8U, "source must be CV_8UC2")
+        out = dst if dst is not None else _like(src, s.h, s.w, 1, CV_8U)
+        call = lambda d: L.mi355cv_cvtBGR5x5toGray(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, k[1])
+    elif kind == "dec422":
+        need(s.cn == 2 and s.depth == CV_8U and s.w % 2 == 0, "YUV 4:2:2 source must be CV_8UC2 with an even width")
+        out = dst if dst is not None else _like(src, s.h, s.w, k[1], CV_8U)
+        call = lambda d: L.mi355cv_cvtOnePlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, k[1], bool(k[2]), k[3], k[4])
+    elif kind == "enc422":
+        need(s.cn == k[1] and s.depth == CV_8U and s.w % 2 == 0, f"source must be CV_8UC{k[1]} with an even width")
+        out = dst if dst is not None else _like(src, s.h, s.w, 2, CV_8U)
+        call = lambda d: L.mi355cv_cvtOnePlaneBGRtoYUV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.cn, bool(k[2]), k[3], k[4])
+    elif kind == "enc420p":
+        need(s.cn == k[1] and s.depth == CV_8U and s.w % 2 == 0 and s.h % 2 == 0, f"source must be CV_8UC{k[1]} with even width and height")
+        out = dst if dst is not None else _like(src, s.h * 3 // 2, s.w, 1, CV_8U)
+        call = lambda d: L.mi355cv_cvtBGRtoThreePlaneYUV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.cn, bool(k[2]), k[3])
+    else:
+        need(s.cn == 4 and s.depth == CV_8U, "source must be CV_8UC4")
+        out = dst if dst is not None else _like(src, s.h, s.w, 4, CV_8U)
+        fn = L.mi355cv_cvtRGBAtoMultipliedRGBA if kind == "premul" else L.mi355cv_cvtMultipliedRGBAtoRGBA
+        call = lambda d: fn(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(call(d), "cvtColor(" + kind + ")")
+    return out
+
+
+def cvtColorBGR2NV(src, swapBlue=False, nv21=False, dst=None):
+    """cv::hal::cvtBGRtoTwoPlaneYUV (color_yuv.dispatch.cpp:231; no cvtColor code reaches it -- videoio's writers call it): BGR/RGB(A) ->
+    NV12 (or NV21) as one (3/2 * height) x width CV_8UC1 array, luma rows followed by the interleaved chroma rows."""
+    s = Img(src)
+    if s.cn not in (3, 4) or s.depth != CV_8U or s.w % 2 or s.h % 2:
+        raise ValueError("cvtColorBGR2NV: CV_8UC3 / CV_8UC4 with even width and height")
+    out = dst if dst is not None else _like(src, s.h * 3 // 2, s.w, 1, CV_8U)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_cvtBGRtoTwoPlaneYUV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, _vp(d.ptr + d.step * s.h), d.step, s.w, s.h, s.cn, bool(swapBlue),
+                                             2 if nv21 else 1), "cvtBGRtoTwoPlaneYUV")
+    return out
 
 
 def cvtColorBatch(frames, code, dst=None):
@@ -288,6 +394,7 @@ def cvtColorBatch(frames, code, dst=None):
 
 # ----------------------------------------------------------------------------- threshold (f1)
 THRESH_BINARY, THRESH_BINARY_INV, THRESH_TRUNC, THRESH_TOZERO, THRESH_TOZERO_INV = range(5)
+THRESH_OTSU, THRESH_TRIANGLE = 8, 16
 _SAT = {CV_8U: (0, 255), CV_16U: (0, 65535), CV_16S: (-32768, 32767)}
 
 
@@ -295,8 +402,18 @@ def threshold(src, thresh, maxval, type, dst=None):
     """cv::threshold (thresh.cpp:1542) for the fixed-level types: the reference's own preprocessing of (thresh, maxval) and its
     degenerate-threshold shortcuts on the host side, the per-element rule through cv_hal_threshold.  Returns (retval, dst)."""
     s = Img(src)
+    if type & THRESH_OTSU and not type & THRESH_TRIANGLE:                      # thresh.cpp:1563-1569 -> cv_hal_threshold_otsu
+        if s.cn != 1 or s.depth not in (CV_8U, CV_16U):
+            raise ValueError("threshold: THRESH_OTSU needs CV_8UC1 or CV_16UC1")
+        out = dst if dst is not None else empty_like_kind(src, s.h, s.w, 1, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        level = ctypes.c_double(0)
+        _lib.check(L.mi355cv_threshold_otsu(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, float(maxval), int(type & 7), ctypes.byref(level)),
+                   "threshold_otsu")
+        return level.value, out
     if type < 0 or type > 4:
-        raise NotImplementedError("threshold: OTSU / TRIANGLE estimate the level on the CPU in the reference; not on this path")
+        raise NotImplementedError("threshold: THRESH_TRIANGLE estimates the level on the CPU in the reference; not on this path")
     out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
     if s.depth in _SAT:
         lo, hi = _SAT[s.depth]
@@ -340,6 +457,18 @@ def Canny(image, threshold1, threshold2, apertureSize=3, L2gradient=False, dst=N
     d = Img(out)
     bind_stream(s, d)
     _lib.check(L.mi355cv_canny(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.cn, lo, hi, int(apertureSize), bool(L2gradient)), "canny")
+    return out
+
+
+def equalizeHist(src, dst=None):
+    """cv::equalizeHist (histogram.cpp:3436) through cv_hal_equalize_hist: CV_8UC1."""
+    s = Img(src)
+    if s.depth != CV_8U or s.cn != 1:
+        raise ValueError("equalizeHist: CV_8UC1 only")                                        # CV_Assert, :3440
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, 1, CV_8U)
+    d = Img(out)
+    bind_stream(s, d)
+    _lib.check(L.mi355cv_equalize_hist(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h), "equalize_hist")
     return out
 
 

@@ -57,6 +57,26 @@ void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, s
 
 void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange);
 
+/* oracle/color_misc.c: 4:2:0 / 4:2:2 encoders and decoder, XYZ (depth 0 / 2), 16-bit packed formats, premultiplied alpha */
+void orc_cvtBGRtoTwoPlaneYUV(const uint8_t* src, size_t sstep, uint8_t* y_data, size_t y_step, uint8_t* uv_data, size_t uv_step, int w, int h,
+                             int scn, int swapBlue, int uIdx);
+void orc_cvtBGRtoThreePlaneYUV(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int uIdx);
+void orc_cvtOnePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int uIdx, int ycn);
+void orc_cvtOnePlaneBGRtoYUV(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int uIdx, int ycn);
+int orc_cvtBGRtoXYZ(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int swapBlue);
+int orc_cvtXYZtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int dcn, int swapBlue);
+void orc_cvtBGRtoBGR5x5(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int greenBits);
+void orc_cvtBGR5x5toBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int greenBits);
+void orc_cvtBGR5x5toGray(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int greenBits);
+void orc_cvtGraytoBGR5x5(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int greenBits);
+void orc_cvtRGBAtoMultipliedRGBA(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
+void orc_cvtMultipliedRGBAtoRGBA(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
+
+/* oracle/hist.c */
+void orc_equalizeHist(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
+double orc_otsuFromHist(const int* hist, int N, int w, int h);
+int orc_thresholdOtsu(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, double maxval, int type, double* retval);
+
 /* linear filters, see oracle/filter.c.  (fullW, fullH, offX, offY) describe the parent image of the ROI. */
 void orc_filter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
                   int fullW, int fullH, int offX, int offY, const float* kernel, int kw, int kh, int ax, int ay,

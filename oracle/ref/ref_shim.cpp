@@ -11,6 +11,7 @@
 #include <opencv2/core.hpp>
 #include <opencv2/core/utility.hpp>
 #include <opencv2/imgproc.hpp>
+#include <opencv2/imgproc/hal/hal.hpp>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -204,6 +205,23 @@ int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, i
     REF_TRY
     Mat src = M(s, ss, w, h, CV_8UC1), dst = M(d, ds, w, h, CV_8UC1);
     cv::adaptiveThreshold(src, dst, maxValue, method, ttype, blockSize, C);
+    REF_END(dst, d)
+}
+
+// cv::hal::cvtBGRtoTwoPlaneYUV (no cvtColor code reaches it); dst = (h * 3/2) x w, Y rows then the interleaved chroma rows
+int ref_cvtBGRtoTwoPlaneYUV(const void* s, size_t ss, void* d, size_t ds, int w, int h, int scn, int swapBlue, int uIdx)
+{
+    try {
+        cv::hal::cvtBGRtoTwoPlaneYUV((const uchar*)s, ss, (uchar*)d, (uchar*)d + ds * h, ds, w, h, scn, swapBlue != 0, uIdx);
+        return 0;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref: %s\n", e.what()); return -1; }
+}
+
+int ref_equalizeHist(const void* s, size_t ss, void* d, size_t ds, int w, int h)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, CV_8UC1), dst = M(d, ds, w, h, CV_8UC1);
+    cv::equalizeHist(src, dst);
     REF_END(dst, d)
 }
 

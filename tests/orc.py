@@ -715,3 +715,116 @@ def ref_matchTemplate(img, templ, method):
     rc = r.ref_matchTemplate(P(img), step(img), iw, ih, P(templ), step(templ), tw, th, cvtype(img), P(res), step(res), method)
     assert rc == 0, rc
     return res
+
+
+# ----------------------------------------------------------------------------- remaining colour conversions (oracle/color_misc.c)
+def _misc_table():
+    t = {}
+    for code, swap in ((32, 0), (33, 1)): t[code] = ("to_xyz", swap)
+    for code, swap in ((34, 0), (35, 1)): t[code] = ("from_xyz", swap)
+    # 16-bit packed: (kind, cn, swapBlue, greenBits)
+    for code, cn, swap, gb in ((12, 3, 0, 6), (13, 3, 1, 6), (16, 4, 0, 6), (17, 4, 1, 6), (22, 3, 0, 5), (23, 3, 1, 5), (26, 4, 0, 5), (27, 4, 1, 5)):
+        t[code] = ("to_5x5", cn, swap, gb)
+    for code, cn, swap, gb in ((14, 3, 0, 6), (15, 3, 1, 6), (18, 4, 0, 6), (19, 4, 1, 6), (24, 3, 0, 5), (25, 3, 1, 5), (28, 4, 0, 5), (29, 4, 1, 5)):
+        t[code] = ("from_5x5", cn, swap, gb)
+    t[20] = ("gray_to_5x5", 6); t[30] = ("gray_to_5x5", 5); t[21] = ("5x5_to_gray", 6); t[31] = ("5x5_to_gray", 5)
+    # 4:2:2 decode: (dcn, swapBlue, uIdx, ycn)
+    for code, dcn, swap, uidx, ycn in ((107, 3, 1, 0, 1), (108, 3, 0, 0, 1), (111, 4, 1, 0, 1), (112, 4, 0, 0, 1), (115, 3, 1, 0, 0), (116, 3, 0, 0, 0),
+                                       (117, 3, 1, 1, 0), (118, 3, 0, 1, 0), (119, 4, 1, 0, 0), (120, 4, 0, 0, 0), (121, 4, 1, 1, 0), (122, 4, 0, 1, 0)):
+        t[code] = ("dec422", dcn, swap, uidx, ycn)
+    for code, scn, swap, uidx, ycn in ((143, 3, 1, 0, 1), (144, 3, 0, 0, 1), (145, 4, 1, 0, 1), (146, 4, 0, 0, 1), (147, 3, 1, 0, 0), (148, 3, 0, 0, 0),
+                                       (149, 3, 1, 1, 0), (150, 3, 0, 1, 0), (151, 4, 1, 0, 0), (152, 4, 0, 0, 0), (153, 4, 1, 1, 0), (154, 4, 0, 1, 0)):
+        t[code] = ("enc422", scn, swap, uidx, ycn)
+    # 4:2:0 planar encode: (scn, swapBlue, uIdx)   I420 / IYUV -> 1, YV12 -> 2
+    for code, scn, swap, uidx in ((127, 3, 1, 1), (128, 3, 0, 1), (129, 4, 1, 1), (130, 4, 0, 1), (131, 3, 1, 2), (132, 3, 0, 2), (133, 4, 1, 2), (134, 4, 0, 2)):
+        t[code] = ("enc420p", scn, swap, uidx)
+    t[125] = ("premul",); t[126] = ("unpremul",)
+    return t
+
+
+MISC_CODES = _misc_table()
+
+
+def misc_dst(src, code):
+    """shape / dtype of cvtColor's result for the codes in MISC_CODES"""
+    k = MISC_CODES[code]
+    h, w = src.shape[:2]
+    kind = k[0]
+    if kind == "to_xyz": return np.empty((h, w, 3), src.dtype)
+    if kind == "from_xyz": return np.empty((h, w, 3), src.dtype)
+    if kind in ("to_5x5", "gray_to_5x5"): return np.empty((h, w, 2), np.uint8)
+    if kind == "from_5x5": return np.empty((h, w, k[1]), np.uint8)
+    if kind == "5x5_to_gray": return np.empty((h, w), np.uint8)
+    if kind == "dec422": return np.empty((h, w, k[1]), np.uint8)
+    if kind == "enc422": return np.empty((h, w, 2), np.uint8)
+    if kind == "enc420p": return np.empty((h * 3 // 2, w), np.uint8)
+    return np.empty((h, w, 4), np.uint8)
+
+
+def orc_cvtColorMisc(src, code):
+    o = oracle()
+    k = MISC_CODES[code]
+    kind = k[0]
+    h, w = src.shape[:2]
+    dst = misc_dst(src, code)
+    a = (P(src), step(src), P(dst), step(dst), w, h)
+    if kind == "to_xyz": assert o.orc_cvtBGRtoXYZ(*a, _NP_DEPTH[src.dtype], src.shape[2], k[1]) == 0
+    elif kind == "from_xyz": assert o.orc_cvtXYZtoBGR(*a, _NP_DEPTH[src.dtype], 3, k[1]) == 0
+    elif kind == "to_5x5": o.orc_cvtBGRtoBGR5x5(*a, k[1], k[2], k[3])
+    elif kind == "from_5x5": o.orc_cvtBGR5x5toBGR(*a, k[1], k[2], k[3])
+    elif kind == "gray_to_5x5": o.orc_cvtGraytoBGR5x5(*a, k[1])
+    elif kind == "5x5_to_gray": o.orc_cvtBGR5x5toGray(*a, k[1])
+    elif kind == "dec422": o.orc_cvtOnePlaneYUVtoBGR(*a, k[1], k[2], k[3], k[4])
+    elif kind == "enc422": o.orc_cvtOnePlaneBGRtoYUV(*a, k[1], k[2], k[3], k[4])
+    elif kind == "enc420p": o.orc_cvtBGRtoThreePlaneYUV(*a, k[1], k[2], k[3])
+    elif kind == "premul": o.orc_cvtRGBAtoMultipliedRGBA(*a)
+    else: o.orc_cvtMultipliedRGBAtoRGBA(*a)
+    return dst
+
+
+def ref_cvtColorMisc(src, code):
+    r = load_ref()
+    dst = misc_dst(src, code)
+    rc = r.ref_cvtColorSz(P(src), step(src), src.shape[1], src.shape[0], cvtype(src), P(dst), step(dst), dst.shape[1], dst.shape[0], cvtype(dst), code)
+    assert rc == 0, rc
+    return dst
+
+
+def orc_cvtBGRtoTwoPlaneYUV(src, swapBlue, uIdx):
+    o = oracle()
+    h, w = src.shape[:2]
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    uv = dst[h:]
+    o.orc_cvtBGRtoTwoPlaneYUV(P(src), step(src), P(dst), step(dst), vp(uv.ctypes.data), step(dst), w, h, src.shape[2], int(swapBlue), uIdx)
+    return dst
+
+
+def orc_equalizeHist(src):
+    o = oracle()
+    dst = np.empty_like(src)
+    o.orc_equalizeHist(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0])
+    return dst
+
+
+def ref_equalizeHist(src):
+    r = load_ref()
+    dst = np.empty_like(src)
+    assert r.ref_equalizeHist(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0]) == 0
+    return dst
+
+
+def orc_thresholdOtsu(src, maxval, type):
+    o = oracle()
+    dst = np.empty_like(src)
+    rv = ctypes.c_double(0)
+    rc = o.orc_thresholdOtsu(P(src), step(src), P(dst), step(dst), src.shape[1], src.shape[0], _NP_DEPTH[src.dtype], ctypes.c_double(maxval), type, ctypes.byref(rv))
+    assert rc == 0, rc
+    return rv.value, dst
+
+
+def ref_cvtBGRtoTwoPlaneYUV(src, swapBlue, uIdx):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    assert r.ref_cvtBGRtoTwoPlaneYUV(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], int(swapBlue), uIdx) == 0
+    return dst

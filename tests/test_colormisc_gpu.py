@@ -1,0 +1,96 @@
+"""GPU parity (bit-exact) for the remaining integer colour hooks and the histogram-driven point operations, through
+the C ABI against the oracle: 4:2:0 / 4:2:2 encoders, the 4:2:2 decoder, XYZ (8U / 16U), 16-bit packed formats, premultiplied alpha,
+equalizeHist, THRESH_OTSU."""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_colormisc import src_for
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(2, 2), (34, 6), (130, 4), (642, 482), (1920, 1080)]
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def test_misc_codes(cv, orc):
+    for code in sorted(orc.MISC_CODES):
+        rng = np.random.default_rng(code)
+        for (w, h) in SIZES:
+            src = src_for(code, w, h, rng)
+            got = cv.cvtColor(dev(src), code).cpu().numpy()
+            want = orc.orc_cvtColorMisc(src, code)
+            assert got.shape == want.shape and np.array_equal(got, want), (code, w, h, int((got != want).sum()))
+        src = src_for(code, 320, 240, rng)
+        assert np.array_equal(cv.cvtColor(src, code), orc.orc_cvtColorMisc(src, code)), code              # host pointers
+
+
+def test_xyz_16u_and_alpha(cv, orc):
+    rng = np.random.default_rng(2)
+    for code in (32, 33, 34, 35):
+        src = rng.integers(0, 65536, (90, 401, 3), dtype=np.uint16)
+        assert np.array_equal(cv.cvtColor(dev(src), code).cpu().numpy(), orc.orc_cvtColorMisc(src, code)), code
+        ex = np.tile(np.array([[[0, 0, 255], [255, 0, 0], [0, 255, 0], [255, 255, 255], [0, 0, 0], [255, 255, 0], [3, 250, 7]]], np.uint8), (2, 7, 1))
+        assert np.array_equal(cv.cvtColor(dev(ex), code).cpu().numpy(), orc.orc_cvtColorMisc(ex, code)), code
+    src4 = rng.integers(0, 256, (33, 77, 4), dtype=np.uint8)
+    assert np.array_equal(cv.cvtColor(dev(src4), 32).cpu().numpy(), orc.orc_cvtColorMisc(src4, 32))           # BGRA source
+    v, a = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    src = np.stack([v, v[:, ::-1], 255 - v, a], axis=-1).copy()
+    for code in (125, 126):
+        assert np.array_equal(cv.cvtColor(dev(src), code).cpu().numpy(), orc.orc_cvtColorMisc(src, code)), code
+
+
+def test_two_plane_encode_round_trip(cv, orc):
+    rng = np.random.default_rng(4)
+    for (w, h) in [(2, 2), (130, 4), (642, 482), (1920, 1080)]:
+        for scn in (3, 4):
+            src = rng.integers(0, 256, (h, w, scn), dtype=np.uint8)
+            for swap in (False, True):
+                for nv21 in (False, True):
+                    got = cv.cvtColorBGR2NV(dev(src), swap, nv21).cpu().numpy()
+                    assert np.array_equal(got, orc.orc_cvtBGRtoTwoPlaneYUV(src, swap, 2 if nv21 else 1)), (w, h, scn, swap, nv21)
+    # encode -> decode comes back within the quantisation of the 4:2:0 format for a flat-chroma image
+    flat = np.empty((64, 64, 3), np.uint8); flat[...] = (40, 120, 200)
+    back = cv.cvtColor(cv.cvtColorBGR2NV(dev(flat)), 91).cpu().numpy()             # COLOR_YUV2BGR_NV12
+    assert np.abs(back.astype(int) - flat).max() <= 3
+
+
+def test_equalize_hist(cv, orc):
+    rng = np.random.default_rng(3)
+    n0 = cv.call_count("equalize_hist")
+    for (w, h) in [(1, 1), (7, 5), (64, 48), (641, 481), (1937, 1081)]:
+        for lo, hi in [(0, 256), (100, 140), (17, 18)]:
+            src = rng.integers(lo, hi, (h, w), dtype=np.uint8)
+            assert np.array_equal(cv.equalizeHist(dev(src)).cpu().numpy(), orc.orc_equalizeHist(src)), (w, h, lo, hi)
+    big = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
+    sub = dev(big)[5:2005, 3:3003]                                                 # unaligned ROI view of a larger device image
+    assert np.array_equal(cv.equalizeHist(sub).cpu().numpy(), orc.orc_equalizeHist(np.ascontiguousarray(big[5:2005, 3:3003])))
+    host = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    assert np.array_equal(cv.equalizeHist(host), orc.orc_equalizeHist(host))
+    assert cv.call_count("equalize_hist") > n0
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_threshold_otsu(cv, orc, dtype):
+    rng = np.random.default_rng(11)
+    top = 256 if dtype == np.uint8 else 65536
+    for (w, h) in [(9, 7), (320, 240), (1283, 721)]:
+        for mode in range(4):
+            if mode == 0: src = rng.integers(0, top, (h, w)).astype(dtype)
+            elif mode == 1: src = np.where(rng.random((h, w)) < 0.3, rng.integers(top // 8, top // 4, (h, w)), rng.integers(top // 2, top - 1, (h, w))).astype(dtype)
+            elif mode == 2: src = np.full((h, w), top // 3, dtype)
+            else: src = np.where(rng.random((h, w)) < 0.5, 0, top - 1).astype(dtype)
+            for ttype in range(5):
+                tv, td = orc.orc_thresholdOtsu(src, 200.4, ttype)
+                gv, gd = cv.threshold(dev(src), 0, 200.4, ttype | cv.THRESH_OTSU)
+                assert gv == tv and np.array_equal(gd.cpu().numpy(), td), (dtype, w, h, mode, ttype, gv, tv)

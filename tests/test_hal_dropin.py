@@ -41,6 +41,22 @@ def _calls(o, src8, src8c3, srcf):
     out["adaptive"] = o.ref_adaptiveThreshold(src8, 255.0, 0, 0, 7, 2.0)
     out["canny"] = o.ref_Canny(src8, 30, 90)
     out["canny3"] = o.ref_Canny(src8c3, 200, 400, 3, True)
+    out["i420enc"] = o.ref_cvtColorMisc(src8c3, 128)
+    out["yuy2dec"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 116)
+    out["uyvyenc"] = o.ref_cvtColorMisc(src8c3, 144)
+    out["xyz"] = o.ref_cvtColorMisc(src8c3, 32)
+    out["xyz2rgb"] = o.ref_cvtColorMisc(src8c3, 35)
+    out["bgr565"] = o.ref_cvtColorMisc(src8c3, 12)
+    out["bgr5552bgra"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 28)
+    out["5652gray"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 21)
+    out["gray2555"] = o.ref_cvtColorMisc(src8, 30)
+    rgba = np.concatenate([src8c3, src8[..., None]], axis=-1)
+    out["premul"] = o.ref_cvtColorMisc(rgba, 125)
+    out["unpremul"] = o.ref_cvtColorMisc(rgba, 126)
+    out["nv12enc"] = o.ref_cvtBGRtoTwoPlaneYUV(src8c3, 0, 1)
+    out["equalize"] = o.ref_equalizeHist(src8)
+    ov, od = o.ref_threshold(src8, 0.0, 255.0, 0 | 8)
+    out["otsu"] = od; out["otsu_level"] = np.array([ov])
     out["median3"] = o.ref_medianBlur(src8c3, 3)
     out["median5"] = o.ref_medianBlur(src8, 5)
     out["dilate"] = o.ref_morph(1, src8)
@@ -89,7 +105,9 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold", "canny"]
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold", "canny",
+             "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
+             "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu"]
     before = {n: cv.call_count(n) for n in names}
     with O.use_ref(hal):
         through = _calls(O, src8, src8c3, srcf)
