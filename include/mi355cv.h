@@ -67,6 +67,7 @@ typedef unsigned char mi355cv_uchar;
 #define MI355CV_INTER_NEAREST 0
 #define MI355CV_INTER_LINEAR  1
 #define MI355CV_INTER_CUBIC   2
+#define MI355CV_INTER_LANCZOS4 4
 #define MI355CV_INTER_AREA    3
 #define MI355CV_INTER_LINEAR_EXACT 5
 #define MI355CV_WARP_INVERSE_MAP 16
@@ -98,6 +99,10 @@ MI355CV_API void* mi355cv_deviceAlloc(size_t bytes);
 MI355CV_API int   mi355cv_deviceFree(void* p);
 MI355CV_API int   mi355cv_upload(void* dst_dev, const void* src_host, size_t bytes);
 MI355CV_API int   mi355cv_download(void* dst_host, const void* src_dev, size_t bytes);
+/* frame ingest / egress (the storage behind a cv::MatAllocator, core/mat.hpp:496-524): kind 0 = page-locked host memory
+ * (a host frame is then staged by one DMA at PCIe rate), kind 1 = managed memory (the hooks run on it in place).  NULL without a device. */
+MI355CV_API void* mi355cv_hostAlloc(size_t bytes, int kind);
+MI355CV_API int   mi355cv_hostFree(void* p, int kind);
 
 /* --------------------------------------------------- a1: Gaussian smoothing */
 

@@ -14,6 +14,51 @@
 
 namespace mi355cv {
 
+// cv::MatAllocator (core/mat.hpp:496-524) whose matrices live in memory the MI355X reaches without a pageable bounce:
+//   FrameAllocator::Pinned   page-locked host memory -- a hook still stages the frame through HBM, but as one DMA at PCIe rate;
+//   FrameAllocator::Managed  managed memory          -- hooks run on the matrix in place, CPU code keeps working on the same pointer.
+// Install per matrix (`m.allocator = &alloc; m.create(...)`) or process-wide (`cv::Mat::setDefaultAllocator(&alloc)`, mat.hpp:2169).
+// Without a gfx950 device the storage comes from cv::fastMalloc, so the same binary runs on a CPU-only host.
+class FrameAllocator : public cv::MatAllocator
+{
+public:
+    enum Kind { Pinned = 0, Managed = 1 };
+    explicit FrameAllocator(Kind kind = Pinned) : kind_(kind) {}
+
+    cv::UMatData* allocate(int dims, const int* sizes, int type, void* user, size_t* step, cv::AccessFlag, cv::UMatUsageFlags) const CV_OVERRIDE
+    {
+        size_t bytes = CV_ELEM_SIZE(type);                       // innermost dimension first: dense unless the caller brought its own steps
+        for (int d = dims - 1; d >= 0; d--) {
+            if (step) {
+                if (user && step[d] != cv::Mat::AUTO_STEP) { CV_Assert(bytes <= step[d]); bytes = step[d]; }
+                else step[d] = bytes;
+            }
+            bytes *= (size_t)sizes[d];
+        }
+        cv::UMatData* u = new cv::UMatData(this);
+        u->size = bytes;
+        if (user) { u->data = u->origdata = (uchar*)user; u->flags |= cv::UMatData::USER_ALLOCATED; return u; }
+        void* p = mi355cv_hostAlloc(bytes, (int)kind_);
+        u->userdata = p ? (void*)this : nullptr;                 // remembers which heap the block came from
+        if (!p) p = cv::fastMalloc(bytes);
+        u->data = u->origdata = (uchar*)p;
+        return u;
+    }
+    bool allocate(cv::UMatData* u, cv::AccessFlag, cv::UMatUsageFlags) const CV_OVERRIDE { return u != nullptr; }
+    void deallocate(cv::UMatData* u) const CV_OVERRIDE
+    {
+        if (!u) return;
+        CV_Assert(u->urefcount == 0 && u->refcount == 0);
+        if (!(u->flags & cv::UMatData::USER_ALLOCATED) && u->origdata) {
+            if (u->userdata) mi355cv_hostFree(u->origdata, (int)kind_); else cv::fastFree(u->origdata);
+            u->origdata = nullptr;
+        }
+        delete u;
+    }
+private:
+    Kind kind_;
+};
+
 inline void cornerHarris(cv::InputArray _src, cv::OutputArray _dst, int blockSize, int ksize, double k, int borderType = cv::BORDER_DEFAULT)
 {
     cv::Mat src = _src.getMat();

@@ -80,6 +80,8 @@ def _load():
         "mi355cv_cvtMultipliedRGBAtoRGBA": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
         "mi355cv_equalize_hist": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
         "mi355cv_threshold_otsu": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_int, ctypes.POINTER(ctypes.c_double)]),
+        "mi355cv_hostAlloc": (ctypes.c_void_p, [c_sz, c_int]),
+        "mi355cv_hostFree": (c_int, [ctypes.c_void_p, c_int]),
         "mi355cv_canny": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_dbl, c_int, ctypes.c_bool]),
         "mi355cv_adaptiveThreshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_dbl, c_int, c_int, c_int, c_dbl]),
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),

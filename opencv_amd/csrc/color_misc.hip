@@ -6,9 +6,10 @@
 //   cv_hal_cvtBGRtoXYZ (:564), cv_hal_cvtXYZtoBGR (:579)                    CV_8U and CV_16U (12-bit fixed point)
 //   cv_hal_cvtBGRtoBGR5x5 (:411), cvtBGR5x5toBGR (:427), cvtBGR5x5toGray (:470), cvtGraytoBGR5x5 (:484)
 //   cv_hal_cvtRGBAtoMultipliedRGBA (:894), cvtMultipliedRGBAtoRGBA (:907)
-// All of it is byte shuffling plus a handful of integer MACs per pixel: HBM-bound, one thread per pixel (pair / 2x2 block for the
-// subsampled formats).  Arithmetic follows color_yuv.simd.hpp:1473-1967, color_lab.cpp:251-936, color_rgb.simd.hpp:180-1096.
+// All of it is byte shuffling plus a handful of integer MACs per pixel: HBM-bound.  The 8-bit conversions run on the pix4 launch shape
+// (four pixels per lane, whole-dword traffic; pix4.h), the 4:2:0 encoders on its two-row variant below; CV_16U XYZ keeps one thread per pixel.  Arithmetic follows color_yuv.simd.hpp:1473-1967, color_lab.cpp:251-936, color_rgb.simd.hpp:180-1096.
 #include "rt.h"
+#include "pix4.h"
 
 using namespace mi355;
 
@@ -21,74 +22,110 @@ __device__ __forceinline__ int sat8(int v) { return min(max(v, 0), 255); }
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);                       \
     if (x >= (W_) || y >= (H_)) return
 
-// ---------------------------------------------------------------- 4:2:0 encoders: one thread per 2x2 block
+// ---------------------------------------------------------------- 4:2:0 encoders: one lane per 4x2 pixels (two chroma samples)
 template <int SCN, bool INTERLEAVE>
 __global__ __launch_bounds__(256) void k_enc420(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ yp, size_t ystep,
-                                                uchar* __restrict__ uvp, size_t uvstep, int W, int H, int swapBlue, int swapUV)
+                                                uchar* __restrict__ uvp, size_t uvstep, int W, int H, int swapBlue, int swapUV, int aligned)
 {
-    PIXEL_XY(W / 2, H / 2);
-    int r[4], g[4], b[4];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uchar* s = src + (size_t)(2 * y + j) * sstep + (size_t)(2 * x + i) * SCN;
-            b[2 * j + i] = s[swapBlue ? 2 : 0]; g[2 * j + i] = s[1]; r[2 * j + i] = s[swapBlue ? 0 : 2];
-        }
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y2 = blockIdx.y * 4 + (threadIdx.x >> 6);                     // row pair
+    if (x4 >= W || 2 * y2 >= H) return;
+    const int n = min(4, W - x4);                                           // 2 or 4 (W is even)
+    const bool fast = n == 4 && aligned;
+    pix4::Px<SCN> in[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        uchar* yr = yp + (size_t)(2 * y + j) * ystep + 2 * (size_t)x;
+        const uchar* s = src + (size_t)(2 * y2 + j) * sstep + (size_t)x4 * SCN;
+        if (fast) {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-            yr[i] = (uchar)sat8((269484 * r[2 * j + i] + 528482 * g[2 * j + i] + 102760 * b[2 * j + i] + (1 << 19) + (16 << 20)) >> 20);
+            for (int i = 0; i < SCN; i++) in[j].w[i] = ((const unsigned*)s)[i];
+        } else {
+            in[j].clear();
+#pragma unroll
+            for (int i = 0; i < 4 * SCN; i++) if (i < n * SCN) in[j].put(i, s[i]);
+        }
     }
-    int uu = sat8((-155188 * r[0] - 305135 * g[0] + 460324 * b[0] + (1 << 19) + (128 << 20)) >> 20);
-    int vv = sat8((460324 * r[0] - 385875 * g[0] - 74448 * b[0] + (1 << 19) + (128 << 20)) >> 20);
-    if (swapUV) { const int t = uu; uu = vv; vv = t; }
+    const int bo = swapBlue ? 2 : 0;
+    unsigned uvw = 0; int uu[2], vv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        unsigned yw = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int b = in[j].get(p * SCN + bo), g = in[j].get(p * SCN + 1), r = in[j].get(p * SCN + 2 - bo);
+            yw |= (unsigned)sat8((269484 * r + 528482 * g + 102760 * b + (1 << 19) + (16 << 20)) >> 20) << (8 * p);
+            if (j == 0 && (p & 1) == 0) {                                   // chroma from the top-left pixel of each 2x2 block
+                int u = sat8((-155188 * r - 305135 * g + 460324 * b + (1 << 19) + (128 << 20)) >> 20);
+                int v = sat8((460324 * r - 385875 * g - 74448 * b + (1 << 19) + (128 << 20)) >> 20);
+                if (swapUV) { const int t = u; u = v; v = t; }
+                uu[p >> 1] = u; vv[p >> 1] = v;
+            }
+        }
+        uchar* yr = yp + (size_t)(2 * y2 + j) * ystep + x4;
+        if (fast) *(unsigned*)yr = yw;
+        else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) if (p < n) yr[p] = (uchar)(yw >> (8 * p));
+        }
+    }
     if (INTERLEAVE) {
-        uchar* uv = uvp + (size_t)y * uvstep + 2 * (size_t)x;
-        uv[0] = (uchar)uu; uv[1] = (uchar)vv;
+        uchar* uv = uvp + (size_t)y2 * uvstep + x4;
+        uvw = (unsigned)uu[0] | ((unsigned)vv[0] << 8) | ((unsigned)uu[1] << 16) | ((unsigned)vv[1] << 24);
+        if (fast) *(unsigned*)uv = uvw;
+        else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) if (p < n) uv[p] = (uchar)(uvw >> (8 * p));
+        }
     } else {
-        const int sRow = 2 * y;                                             // RGB8toYUV420pInvoker's packed quarter planes (:1609-1610)
-        uvp[uvstep * (sRow / 4) + ((sRow / 2) % 2) * (W / 2) + x] = (uchar)uu;
-        uvp[uvstep * ((sRow + H) / 4) + (((sRow + H) / 2) % 2) * (W / 2) + x] = (uchar)vv;
+        const int sRow = 2 * y2, xc = x4 / 2;                               // RGB8toYUV420pInvoker's packed quarter planes (:1609-1610)
+        uchar* ur = uvp + uvstep * (sRow / 4) + ((sRow / 2) % 2) * (W / 2) + xc;
+        uchar* vr = uvp + uvstep * ((sRow + H) / 4) + (((sRow + H) / 2) % 2) * (W / 2) + xc;
+        ur[0] = (uchar)uu[0]; vr[0] = (uchar)vv[0];
+        if (n == 4) { ur[1] = (uchar)uu[1]; vr[1] = (uchar)vv[1]; }
     }
 }
 
-// ---------------------------------------------------------------- 4:2:2: one thread per pixel pair (4 source / destination bytes)
+// ---------------------------------------------------------------- 4:2:2: two pixel pairs per lane
 template <int DCN>
-__global__ __launch_bounds__(256) void k_dec422(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
-                                                int bIdx, int uidx, int vidx, int ycn)
-{
-    PIXEL_XY(W / 2, H);
-    const uchar* p = src + (size_t)y * sstep + 4 * (size_t)x;
-    const int uu = (int)p[uidx] - 128, vv = (int)p[vidx] - 128;
-    const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
-    uchar* d = dst + (size_t)y * dstep + 2 * (size_t)x * DCN;
+struct OpDec422 {
+    int bIdx, uidx, vidx, ycn;
+    __device__ __forceinline__ void operator()(const pix4::Px<2>& in, pix4::Px<DCN>& out) const {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int yv = max((int)p[ycn + 2 * k] - 16, 0) * 1220542;
-        d[k * DCN + 2 - bIdx] = (uchar)sat8((yv + ruv) >> 20);
-        d[k * DCN + 1] = (uchar)sat8((yv + guv) >> 20);
-        d[k * DCN + bIdx] = (uchar)sat8((yv + buv) >> 20);
-        if (DCN == 4) d[k * DCN + 3] = 255;
+        for (int q = 0; q < 2; q++) {
+            const unsigned grp = in.w[q];                                   // byte positions inside the group are run-time values
+            const int uu = (int)((grp >> (8 * uidx)) & 255u) - 128, vv = (int)((grp >> (8 * vidx)) & 255u) - 128;
+            const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int yv = max((int)((grp >> (8 * (ycn + 2 * k))) & 255u) - 16, 0) * 1220542, o = (2 * q + k) * DCN;
+                const int r = sat8((yv + ruv) >> 20), g = sat8((yv + guv) >> 20), b = sat8((yv + buv) >> 20);
+                out.put(o + 1, g);
+                if (bIdx) { out.put(o, r); out.put(o + 2, b); } else { out.put(o, b); out.put(o + 2, r); }
+                if (DCN == 4) out.put(o + 3, 255);
+            }
+        }
     }
-}
+};
 
 template <int SCN>
-__global__ __launch_bounds__(256) void k_enc422(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
-                                                int bIdx, int uidx, int vidx, int ycn)
-{
-    PIXEL_XY(W / 2, H);
-    const uchar* p1 = src + (size_t)y * sstep + 2 * (size_t)x * SCN; const uchar* p2 = p1 + SCN;
-    const int r1 = p1[2 - bIdx], g1 = p1[1], b1 = p1[bIdx], r2 = p2[2 - bIdx], g2 = p2[1], b2 = p2[bIdx];
-    uchar* row = dst + (size_t)y * dstep + 4 * (size_t)x;
-    row[ycn] = (uchar)sat8(((1 << 13) + r1 * 4211 + g1 * 8258 + b1 * 1606 + (1 << 14) * 16) >> 14);
-    row[ycn + 2] = (uchar)sat8(((1 << 13) + r2 * 4211 + g2 * 8258 + b2 * 1606 + (1 << 14) * 16) >> 14);
-    const int sr = r1 + r2, sg = g1 + g2, sb = b1 + b2;
-    row[uidx] = (uchar)sat8(((1 << 13) + sr * -1212 + sg * -2384 + sb * 3596 + (1 << 13) * 256) >> 14);
-    row[vidx] = (uchar)sat8(((1 << 13) + sr * 3596 + sg * -3015 + sb * -582 + (1 << 13) * 256) >> 14);
-}
+struct OpEnc422 {
+    int bIdx, uidx, vidx, ycn;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<2>& out) const {
+        // the byte positions inside a 4-byte group are run-time values: build the group with shifts
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int o1 = 2 * q * SCN, o2 = o1 + SCN;
+            const int b1 = bIdx ? in.get(o1 + 2) : in.get(o1), r1 = bIdx ? in.get(o1) : in.get(o1 + 2), g1 = in.get(o1 + 1);
+            const int b2 = bIdx ? in.get(o2 + 2) : in.get(o2), r2 = bIdx ? in.get(o2) : in.get(o2 + 2), g2 = in.get(o2 + 1);
+            const int y1 = sat8(((1 << 13) + r1 * 4211 + g1 * 8258 + b1 * 1606 + (1 << 14) * 16) >> 14);
+            const int y2 = sat8(((1 << 13) + r2 * 4211 + g2 * 8258 + b2 * 1606 + (1 << 14) * 16) >> 14);
+            const int sr = r1 + r2, sg = g1 + g2, sb = b1 + b2;
+            const int u = sat8(((1 << 13) + sr * -1212 + sg * -2384 + sb * 3596 + (1 << 13) * 256) >> 14);
+            const int v = sat8(((1 << 13) + sr * 3596 + sg * -3015 + sb * -582 + (1 << 13) * 256) >> 14);
+            out.w[q] = ((unsigned)y1 << (8 * ycn)) | ((unsigned)y2 << (8 * (ycn + 2))) | ((unsigned)u << (8 * uidx)) | ((unsigned)v << (8 * vidx));
+        }
+    }
+};
 
 // ---------------------------------------------------------------- XYZ
 struct Mat3 { int c[9]; };
@@ -106,56 +143,89 @@ __global__ __launch_bounds__(256) void k_xyz(const uchar* __restrict__ src, size
     if (DCN == 4) d[3] = (T)hi;
 }
 
+template <int SCN, int DCN>
+struct OpXyz8 {
+    Mat3 m;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<DCN>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int a = in.get(p * SCN), b = in.get(p * SCN + 1), c = in.get(p * SCN + 2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) out.put(p * DCN + k, sat8((a * m.c[3 * k] + b * m.c[3 * k + 1] + c * m.c[3 * k + 2] + (1 << 11)) >> 12));
+            if (DCN == 4) out.put(p * DCN + 3, 255);
+        }
+    }
+};
+
 // ---------------------------------------------------------------- 16-bit packed formats
 template <int SCN>
-__global__ __launch_bounds__(256) void k_to5x5(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bidx, int gb)
-{
-    PIXEL_XY(W, H);
-    const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
-    const int r = s[bidx ^ 2], g = s[1], b = s[bidx], a = SCN == 4 ? s[3] : 0;
-    ((unsigned short*)(dst + (size_t)y * dstep))[x] = gb == 6 ? (unsigned short)((b >> 3) | ((g & ~3) << 3) | ((r & ~7) << 8))
-                                                              : (unsigned short)((b >> 3) | ((g & ~7) << 2) | ((r & ~7) << 7) | (a ? 0x8000 : 0));
-}
+struct OpTo5x5 {
+    int bidx, gb;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<2>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int b = bidx ? in.get(p * SCN + 2) : in.get(p * SCN), r = bidx ? in.get(p * SCN) : in.get(p * SCN + 2), g = in.get(p * SCN + 1);
+            const int a = SCN == 4 ? in.get(p * SCN + 3) : 0;
+            const unsigned v = gb == 6 ? (unsigned)((b >> 3) | ((g & ~3) << 3) | ((r & ~7) << 8)) : (unsigned)((b >> 3) | ((g & ~7) << 2) | ((r & ~7) << 7) | (a ? 0x8000 : 0));
+            out.w[p >> 1] |= v << (16 * (p & 1));
+        }
+    }
+};
 
 template <int DCN>
-__global__ __launch_bounds__(256) void k_from5x5(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bidx, int gb)
-{
-    PIXEL_XY(W, H);
-    const unsigned t = ((const unsigned short*)(src + (size_t)y * sstep))[x];
-    uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
-    d[bidx] = (uchar)(t << 3);
-    if (gb == 6) { d[1] = (uchar)((t >> 3) & ~3u); d[bidx ^ 2] = (uchar)((t >> 8) & ~7u); if (DCN == 4) d[3] = 255; }
-    else { d[1] = (uchar)((t >> 2) & ~7u); d[bidx ^ 2] = (uchar)((t >> 7) & ~7u); if (DCN == 4) d[3] = (uchar)((t >> 15) * 255); }
-}
-
-__global__ __launch_bounds__(256) void k_5x5_to_gray(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int gb)
-{
-    PIXEL_XY(W, H);
-    const int t = ((const unsigned short*)(src + (size_t)y * sstep))[x];
-    const int b = (t << 3) & 0xf8, g = gb == 6 ? (t >> 3) & 0xfc : (t >> 2) & 0xf8, r = gb == 6 ? (t >> 8) & 0xf8 : (t >> 7) & 0xf8;
-    dst[(size_t)y * dstep + x] = (uchar)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
-}
-
-__global__ __launch_bounds__(256) void k_gray_to_5x5(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int gb)
-{
-    PIXEL_XY(W, H);
-    const int t = src[(size_t)y * sstep + x], t3 = t >> 3;
-    ((unsigned short*)(dst + (size_t)y * dstep))[x] = gb == 6 ? (unsigned short)(t3 | ((t & ~3) << 3) | (t3 << 11)) : (unsigned short)(t3 | (t3 << 5) | (t3 << 10));
-}
-
-// ---------------------------------------------------------------- premultiplied alpha
-template <bool UNDO>
-__global__ __launch_bounds__(256) void k_premul(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H)
-{
-    PIXEL_XY(W, H);
-    const uchar* s = src + (size_t)y * sstep + 4 * (size_t)x;
-    uchar* d = dst + (size_t)y * dstep + 4 * (size_t)x;
-    const int a = s[3];
+struct OpFrom5x5 {
+    int bidx, gb;
+    __device__ __forceinline__ void operator()(const pix4::Px<2>& in, pix4::Px<DCN>& out) const {
 #pragma unroll
-    for (int k = 0; k < 3; k++) d[k] = UNDO ? (uchar)(a == 0 ? 0 : min((s[k] * 255 + a / 2) / a, 255)) : (uchar)((s[k] * a + 128) / 255);
-    d[3] = (uchar)a;
-}
+        for (int p = 0; p < 4; p++) {
+            const unsigned t = (in.w[p >> 1] >> (16 * (p & 1))) & 0xffffu;
+            const int b = (t << 3) & 255, g = gb == 6 ? (t >> 3) & 0xfc : (t >> 2) & 0xf8, r = gb == 6 ? (t >> 8) & 0xf8 : (t >> 7) & 0xf8;
+            out.put(p * DCN + 1, g);
+            if (bidx) { out.put(p * DCN, r); out.put(p * DCN + 2, b); } else { out.put(p * DCN, b); out.put(p * DCN + 2, r); }
+            if (DCN == 4) out.put(p * DCN + 3, gb == 6 ? 255 : (int)(t >> 15) * 255);
+        }
+    }
+};
 
+struct Op5x5ToGray {
+    int gb;
+    __device__ __forceinline__ void operator()(const pix4::Px<2>& in, pix4::Px<1>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int t = (int)((in.w[p >> 1] >> (16 * (p & 1))) & 0xffffu);
+            const int b = (t << 3) & 0xf8, g = gb == 6 ? (t >> 3) & 0xfc : (t >> 2) & 0xf8, r = gb == 6 ? (t >> 8) & 0xf8 : (t >> 7) & 0xf8;
+            out.put(p, (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+        }
+    }
+};
+
+struct OpGrayTo5x5 {
+    int gb;
+    __device__ __forceinline__ void operator()(const pix4::Px<1>& in, pix4::Px<2>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int t = in.get(p), t3 = t >> 3;
+            const unsigned v = gb == 6 ? (unsigned)(t3 | ((t & ~3) << 3) | (t3 << 11)) : (unsigned)(t3 | (t3 << 5) | (t3 << 10));
+            out.w[p >> 1] |= v << (16 * (p & 1));
+        }
+    }
+};
+
+template <bool UNDO>
+struct OpPremul {
+    __device__ __forceinline__ void operator()(const pix4::Px<4>& in, pix4::Px<4>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int a = in.get(4 * p + 3);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int v = in.get(4 * p + k);
+                out.put(4 * p + k, UNDO ? (a == 0 ? 0 : min((v * 255 + a / 2) / a, 255)) : (v * a + 128) / 255);
+            }
+            out.put(4 * p + 3, a);
+        }
+    }
+};
 
 // the checks and staging every hook below shares
 #define MISC_PROLOGUE(sRowBytes, sRows, dRowBytes, dRows)                                                                        \
@@ -182,9 +252,10 @@ MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_st
     uchar* dy = stg.out(y_data, y_step, (size_t)width, height, &ys);
     uchar* duv = stg.out(uv_data, uv_step, (size_t)width, height / 2, &uvs);
     if (!ds || !dy || !duv) return MI355CV_NOT_IMPLEMENTED;
-    dim3 grid(divUp(width / 2, 64), divUp(height / 2, 4));
-    if (scn == 3) hipLaunchKernelGGL((k_enc420<3, true>), grid, dim3(256), 0, stream(), ds, dss, dy, ys, duv, uvs, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0);
-    else hipLaunchKernelGGL((k_enc420<4, true>), grid, dim3(256), 0, stream(), ds, dss, dy, ys, duv, uvs, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0);
+    dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
+    const int al = ((((uintptr_t)ds | dss | (uintptr_t)dy | ys | (uintptr_t)duv | uvs) & 3) == 0) ? 1 : 0;
+    if (scn == 3) hipLaunchKernelGGL((k_enc420<3, true>), grid, dim3(256), 0, stream(), ds, dss, dy, ys, duv, uvs, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0, al);
+    else hipLaunchKernelGGL((k_enc420<4, true>), grid, dim3(256), 0, stream(), ds, dss, dy, ys, duv, uvs, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0, al);
     return stg.finish("cvtBGRtoTwoPlaneYUV");
 }
 
@@ -193,10 +264,11 @@ MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_
 {
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * scn, height, width, height * 3 / 2);
-    dim3 grid(divUp(width / 2, 64), divUp(height / 2, 4));
+    dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
     uchar* uv = dd + dds * height;
-    if (scn == 3) hipLaunchKernelGGL((k_enc420<3, false>), grid, dim3(256), 0, st, ds, dss, dd, dds, uv, dds, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0);
-    else hipLaunchKernelGGL((k_enc420<4, false>), grid, dim3(256), 0, st, ds, dss, dd, dds, uv, dds, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0);
+    const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+    if (scn == 3) hipLaunchKernelGGL((k_enc420<3, false>), grid, dim3(256), 0, st, ds, dss, dd, dds, uv, dds, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0, al);
+    else hipLaunchKernelGGL((k_enc420<4, false>), grid, dim3(256), 0, st, ds, dss, dd, dds, uv, dds, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0, al);
     return stg.finish("cvtBGRtoThreePlaneYUV");
 }
 
@@ -207,9 +279,8 @@ MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_st
         return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
     const int uidx = 1 - ycn + uIdx * 2, vidx = (2 + uidx) % 4;
-    dim3 grid(divUp(width / 2, 64), divUp(height, 4));
-    if (dcn == 3) hipLaunchKernelGGL(k_dec422<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, uidx, vidx, ycn);
-    else hipLaunchKernelGGL(k_dec422<4>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, uidx, vidx, ycn);
+    if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpDec422<3>{swapBlue ? 2 : 0, uidx, vidx, ycn});
+    else pix4::launch<2, 4>(st, ds, dss, dd, dds, width, height, OpDec422<4>{swapBlue ? 2 : 0, uidx, vidx, ycn});
     return stg.finish("cvtOnePlaneYUVtoBGR");
 }
 
@@ -220,9 +291,8 @@ MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_st
         return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * scn, height, width * 2, height);
     const int uidx = 1 - ycn + uIdx * 2, vidx = (2 + uidx) % 4;
-    dim3 grid(divUp(width / 2, 64), divUp(height, 4));
-    if (scn == 3) hipLaunchKernelGGL(k_enc422<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, uidx, vidx, ycn);
-    else hipLaunchKernelGGL(k_enc422<4>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, uidx, vidx, ycn);
+    if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpEnc422<3>{swapBlue ? 2 : 0, uidx, vidx, ycn});
+    else pix4::launch<4, 2>(st, ds, dss, dd, dds, width, height, OpEnc422<4>{swapBlue ? 2 : 0, uidx, vidx, ycn});
     return stg.finish("cvtOnePlaneBGRtoYUV");
 }
 
@@ -236,8 +306,8 @@ MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, ucha
     Mat3 m; for (int i = 0; i < 9; i++) m.c[i] = k[i];
     if (!swapBlue) for (int r = 0; r < 3; r++) std::swap(m.c[3 * r], m.c[3 * r + 2]);
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (e == 1) { if (scn == 3) hipLaunchKernelGGL((k_xyz<uchar, 3, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m);
-                  else hipLaunchKernelGGL((k_xyz<uchar, 4, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m); }
+    if (e == 1) { if (scn == 3) pix4::launch<3, 3>(st, ds, dss, dd, dds, width, height, OpXyz8<3, 3>{m});
+                  else pix4::launch<4, 3>(st, ds, dss, dd, dds, width, height, OpXyz8<4, 3>{m}); }
     else { if (scn == 3) hipLaunchKernelGGL((k_xyz<unsigned short, 3, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m);
            else hipLaunchKernelGGL((k_xyz<unsigned short, 4, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m); }
     return stg.finish("cvtBGRtoXYZ");
@@ -253,8 +323,8 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, ucha
     Mat3 m; for (int i = 0; i < 9; i++) m.c[i] = k[i];
     if (!swapBlue) for (int c = 0; c < 3; c++) std::swap(m.c[c], m.c[6 + c]);
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (e == 1) { if (dcn == 3) hipLaunchKernelGGL((k_xyz<uchar, 3, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m);
-                  else hipLaunchKernelGGL((k_xyz<uchar, 3, 4>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m); }
+    if (e == 1) { if (dcn == 3) pix4::launch<3, 3>(st, ds, dss, dd, dds, width, height, OpXyz8<3, 3>{m});
+                  else pix4::launch<3, 4>(st, ds, dss, dd, dds, width, height, OpXyz8<3, 4>{m}); }
     else { if (dcn == 3) hipLaunchKernelGGL((k_xyz<unsigned short, 3, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m);
            else hipLaunchKernelGGL((k_xyz<unsigned short, 3, 4>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, m); }
     return stg.finish("cvtXYZtoBGR");
@@ -265,9 +335,8 @@ MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, u
 {
     if (disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * scn, height, width * 2, height);
-    dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (scn == 3) hipLaunchKernelGGL(k_to5x5<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, greenBits);
-    else hipLaunchKernelGGL(k_to5x5<4>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, greenBits);
+    if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<3>{swapBlue ? 2 : 0, greenBits});
+    else pix4::launch<4, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<4>{swapBlue ? 2 : 0, greenBits});
     return stg.finish("cvtBGRtoBGR5x5");
 }
 
@@ -276,9 +345,8 @@ MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, u
 {
     if (disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
-    dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (dcn == 3) hipLaunchKernelGGL(k_from5x5<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, greenBits);
-    else hipLaunchKernelGGL(k_from5x5<4>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, greenBits);
+    if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpFrom5x5<3>{swapBlue ? 2 : 0, greenBits});
+    else pix4::launch<2, 4>(st, ds, dss, dd, dds, width, height, OpFrom5x5<4>{swapBlue ? 2 : 0, greenBits});
     return stg.finish("cvtBGR5x5toBGR");
 }
 
@@ -286,7 +354,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, 
 {
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * 2, height, width, height);
-    hipLaunchKernelGGL(k_5x5_to_gray, dim3(divUp(width, 64), divUp(height, 4)), dim3(256), 0, st, ds, dss, dd, dds, width, height, greenBits);
+    pix4::launch<2, 1>(st, ds, dss, dd, dds, width, height, Op5x5ToGray{greenBits});
     return stg.finish("cvtBGR5x5toGray");
 }
 
@@ -294,7 +362,7 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, 
 {
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width, height, width * 2, height);
-    hipLaunchKernelGGL(k_gray_to_5x5, dim3(divUp(width, 64), divUp(height, 4)), dim3(256), 0, st, ds, dss, dd, dds, width, height, greenBits);
+    pix4::launch<1, 2>(st, ds, dss, dd, dds, width, height, OpGrayTo5x5{greenBits});
     return stg.finish("cvtGraytoBGR5x5");
 }
 
@@ -302,7 +370,7 @@ MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t sr
 {
     if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * 4, height, width * 4, height);
-    hipLaunchKernelGGL(k_premul<false>, dim3(divUp(width, 64), divUp(height, 4)), dim3(256), 0, st, ds, dss, dd, dds, width, height);
+    pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<false>{});
     return stg.finish("cvtRGBAtoMultipliedRGBA");
 }
 
@@ -310,7 +378,7 @@ MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const uchar* src_data, size_t sr
 {
     if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     MISC_PROLOGUE(width * 4, height, width * 4, height);
-    hipLaunchKernelGGL(k_premul<true>, dim3(divUp(width, 64), divUp(height, 4)), dim3(256), 0, st, ds, dss, dd, dds, width, height);
+    pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<true>{});
     return stg.finish("cvtMultipliedRGBAtoRGBA");
 }
 

@@ -5,8 +5,10 @@
 //   BGR->YUV/YCrCb  RGB2YCrCb_i<uchar> :398   Y = (c0*s0 + c1*s1 + c2*s2 + 2^13) >> 14,  Cr/V = ((R - Y)*c3 + 128*2^14 + 2^13) >> 14, ...
 //   YUV/YCrCb->BGR  YCrCb2RGB_i<uchar> :739   b = Y + ((Cb-128)*c3 + 2^13) >> 14, ...
 //   NV12 / NV21     YUV420sp2RGB8Invoker :1195, 20-bit ITU-R BT.601: r = (max(Y-16,0)*1220542 + 1673527*(V-128) + 2^19) >> 20, ...
-// All HBM-bound: a thread handles four pixels (packed conversions) / one 2x2 block (4:2:0), plain coalesced loads and stores.
+// All HBM-bound: the packed conversions run on the pix4 launch shape (four pixels per lane, whole-dword traffic; pix4.h), the 4:2:0
+// decoders take one 2x2 block per thread.
 #include "rt.h"
+#include "pix4.h"
 #include <cmath>
 
 using namespace mi355;
@@ -19,36 +21,37 @@ struct YuvFwd { int c0, c1, c2, c3, c4, bidx, yuvOrder; };
 struct YuvInv { int c0, c1, c2, c3, bidx, yuvOrder; };
 
 template <int SCN>
-__global__ __launch_bounds__(256) void k_bgr2yuv_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, YuvFwd a)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
-    uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
-    const int s0 = s[0], s1 = s[1], s2 = s[2];
-    const int Y = (s0 * a.c0 + s1 * a.c1 + s2 * a.c2 + (1 << 13)) >> 14;
-    const int r = a.bidx ? s0 : s2, b = a.bidx ? s2 : s0;
-    const int Cr = ((r - Y) * a.c3 + (128 << 14) + (1 << 13)) >> 14;
-    const int Cb = ((b - Y) * a.c4 + (128 << 14) + (1 << 13)) >> 14;
-    d[0] = (uchar)sat8(Y); d[1 + a.yuvOrder] = (uchar)sat8(Cr); d[2 - a.yuvOrder] = (uchar)sat8(Cb);
-}
+struct OpBgr2Yuv {
+    YuvFwd a;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<3>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int s0 = in.get(p * SCN), s1 = in.get(p * SCN + 1), s2 = in.get(p * SCN + 2);
+            const int Y = (s0 * a.c0 + s1 * a.c1 + s2 * a.c2 + (1 << 13)) >> 14;
+            const int r = a.bidx ? s0 : s2, b = a.bidx ? s2 : s0;
+            const int Cr = sat8(((r - Y) * a.c3 + (128 << 14) + (1 << 13)) >> 14);
+            const int Cb = sat8(((b - Y) * a.c4 + (128 << 14) + (1 << 13)) >> 14);
+            out.put(p * 3, sat8(Y)); out.put(p * 3 + 1, a.yuvOrder ? Cb : Cr); out.put(p * 3 + 2, a.yuvOrder ? Cr : Cb);
+        }
+    }
+};
 
 template <int DCN>
-__global__ __launch_bounds__(256) void k_yuv2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, YuvInv a)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uchar* s = src + (size_t)y * sstep + (size_t)x * 3;
-    uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
-    const int Y = s[0], Cr = s[1 + a.yuvOrder], Cb = s[2 - a.yuvOrder];
-    const int b = Y + (((Cb - 128) * a.c3 + (1 << 13)) >> 14);
-    const int g = Y + (((Cb - 128) * a.c2 + (Cr - 128) * a.c1 + (1 << 13)) >> 14);
-    const int r = Y + (((Cr - 128) * a.c0 + (1 << 13)) >> 14);
-    d[a.bidx] = (uchar)sat8(b); d[1] = (uchar)sat8(g); d[a.bidx ^ 2] = (uchar)sat8(r);
-    if (DCN == 4) d[3] = 255;
-}
+struct OpYuv2Bgr {
+    YuvInv a;
+    __device__ __forceinline__ void operator()(const pix4::Px<3>& in, pix4::Px<DCN>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int Y = in.get(p * 3), c1 = in.get(p * 3 + 1), c2 = in.get(p * 3 + 2);
+            const int Cr = a.yuvOrder ? c2 : c1, Cb = a.yuvOrder ? c1 : c2;
+            const int b = sat8(Y + (((Cb - 128) * a.c3 + (1 << 13)) >> 14));
+            const int g = sat8(Y + (((Cb - 128) * a.c2 + (Cr - 128) * a.c1 + (1 << 13)) >> 14));
+            const int r = sat8(Y + (((Cr - 128) * a.c0 + (1 << 13)) >> 14));
+            out.put(p * DCN, a.bidx ? r : b); out.put(p * DCN + 1, g); out.put(p * DCN + 2, a.bidx ? b : r);
+            if (DCN == 4) out.put(p * DCN + 3, 255);
+        }
+    }
+};
 
 // one thread per 2x2 block: 2+2 luma bytes, one (U,V) pair, 4 output pixels
 template <int DCN>
@@ -79,23 +82,23 @@ __global__ __launch_bounds__(256) void k_nv2bgr_u8(const uchar* __restrict__ yp,
 // BGR/RGB -> HSV, CV_8U: RGB2HSV_b color_hsv.simd.hpp:47-262 -- integer arithmetic with the two reciprocal tables (hsv_shift 12)
 // that the host builds exactly as TablesSingleton does and passes in HBM.
 template <int SCN>
-__global__ __launch_bounds__(256) void k_bgr2hsv_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
-                                                    int bidx, int hr, const int* __restrict__ sdiv, const int* __restrict__ hdiv)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
-    uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
-    const int b = s[bidx], g = s[1], r = s[bidx ^ 2];
-    const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
-    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
-    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
-    hh += hh < 0 ? hr : 0;
-    d[0] = (uchar)sat8(hh); d[1] = (uchar)sat; d[2] = (uchar)v;
-}
+struct OpBgr2Hsv {
+    int bidx, hr; const int* sdiv; const int* hdiv;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<3>& out) const {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c0 = in.get(p * SCN), g = in.get(p * SCN + 1), c2 = in.get(p * SCN + 2);
+            const int b = bidx ? c2 : c0, r = bidx ? c0 : c2;
+            const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+            const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+            const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
+            int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+            hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+            hh += hh < 0 ? hr : 0;
+            out.put(p * 3, sat8(hh)); out.put(p * 3 + 1, sat); out.put(p * 3 + 2, v);
+        }
+    }
+};
 
 // I420 / YV12: the two quarter-size chroma planes follow the luma plane inside the same array, packed two chroma rows per array
 // row (cvtThreePlaneYUVtoBGR color_yuv.simd.hpp:2060-2087); a chroma sample is addressed through its linear index
@@ -143,8 +146,8 @@ MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, ucha
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     if (a.bidx == 0) { const int t = a.c0; a.c0 = a.c2; a.c2 = t; }
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (scn == 3) hipLaunchKernelGGL(k_bgr2yuv_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
-    else hipLaunchKernelGGL(k_bgr2yuv_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    if (scn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Yuv<3>{a});
+    else pix4::launch<4, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Yuv<4>{a});
     return stg.finish("cvtBGRtoYUV");
 }
 
@@ -161,8 +164,8 @@ MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, ucha
     YuvInv a; a.c0 = isCbCr ? 22987 : 18678; a.c1 = isCbCr ? -11698 : -9519; a.c2 = isCbCr ? -5636 : -6472; a.c3 = isCbCr ? 29049 : 33292;
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (dcn == 3) hipLaunchKernelGGL(k_yuv2bgr_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
-    else hipLaunchKernelGGL(k_yuv2bgr_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+    if (dcn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpYuv2Bgr<3>{a});
+    else pix4::launch<3, 4>(stream(), ds, dss, dd, dds, width, height, OpYuv2Bgr<4>{a});
     return stg.finish("cvtYUVtoBGR");
 }
 
@@ -202,8 +205,8 @@ MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, ucha
     const int* dt = (const int*)stg.param(tabs, sizeof tabs);
     if (!dt) return MI355CV_NOT_IMPLEMENTED;
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (scn == 3) hipLaunchKernelGGL(k_bgr2hsv_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hr, dt, dt + 256);
-    else hipLaunchKernelGGL(k_bgr2hsv_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hr, dt, dt + 256);
+    if (scn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Hsv<3>{swapBlue ? 2 : 0, hr, dt, dt + 256});
+    else pix4::launch<4, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Hsv<4>{swapBlue ? 2 : 0, hr, dt, dt + 256});
     return stg.finish("cvtBGRtoHSV");
 }
 

@@ -250,6 +250,23 @@ MI355CV_API void* mi355cv_deviceAlloc(size_t bytes)
     return p;
 }
 MI355CV_API int mi355cv_deviceFree(void* p) { return hipFree(p) == hipSuccess ? 0 : -1; }
+
+// frame ingest / egress: host memory the DMA engines reach directly.  kind 0 = page-locked (hipHostMalloc): staging such
+// a frame through HBM is one DMA at PCIe rate instead of the driver's pageable bounce; kind 1 = managed (hipMallocManaged): the hooks run
+// on it in place (isDevicePtr), pages migrate on first touch from either side.
+MI355CV_API void* mi355cv_hostAlloc(size_t bytes, int kind)
+{
+    if (bytes == 0 || (kind != 0 && kind != 1) || !ensureDevice()) return nullptr;
+    void* p = nullptr;
+    const hipError_t e = kind == 0 ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMallocManaged(&p, bytes, hipMemAttachGlobal);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+MI355CV_API int mi355cv_hostFree(void* p, int kind)
+{
+    if (!p) return 0;
+    return (kind == 0 ? hipHostFree(p) : hipFree(p)) == hipSuccess ? 0 : -1;
+}
 MI355CV_API int mi355cv_upload(void* d, const void* h, size_t n) { return ensureDevice() && hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 MI355CV_API int mi355cv_download(void* h, const void* d, size_t n) { return ensureDevice() && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 

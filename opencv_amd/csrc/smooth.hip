@@ -749,7 +749,7 @@ MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int 
     if (nt) hipLaunchKernelGGL((k_copy16<true>), dim3((unsigned)blocks), dim3(256), 0, stream(), (const uint4*)src, (uint4*)dst, n16, perThread);
     else    hipLaunchKernelGGL((k_copy16<false>), dim3((unsigned)blocks), dim3(256), 0, stream(), (const uint4*)src, (uint4*)dst, n16, perThread);
     if (hipGetLastError() != hipSuccess) return MI355CV_ERROR_UNKNOWN;
-    if (!asyncMode()) hipStreamSynchronize(stream());
+    if (!asyncMode()) (void)hipStreamSynchronize(stream());
     return MI355CV_OK;
 }
 
@@ -765,7 +765,7 @@ MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int 
     else if (unroll == 5) hipLaunchKernelGGL((k_copy_colwalk<5>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
     else hipLaunchKernelGGL((k_copy_colwalk<10>), grid, dim3(256), 0, stream(), s, d, (size_t)W, (size_t)W * H, H, nchunks, nstrips, segRows, nseg, nframes);
     if (hipGetLastError() != hipSuccess) return MI355CV_ERROR_UNKNOWN;
-    if (!asyncMode()) hipStreamSynchronize(stream());
+    if (!asyncMode()) (void)hipStreamSynchronize(stream());
     return MI355CV_OK;
 }
 

@@ -398,6 +398,87 @@ void buildCubicTab(int dsize, double scale, std::vector<CubicTap>& tab)
     }
 }
 
+// INTER_LANCZOS4 (resize.cpp:974-1003 coefficients, :2066-2158 passes): 8 x 8 taps at s-3 .. s+4, clamped.  CV_8U is integer throughout
+// (taps * 2048 as shorts, (sum + 2^21) >> 22); CV_32F sums the row left to right and the column as the reference's vector body does
+// (S0*b0 + (S1*b1 + ( ... + S7*b7))) below the last multiple of four elements, left to right in its scalar tail.
+struct LanczosTap { int s; float f[8]; short i[8]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_lanczos(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
+                                                        const LanczosTap* __restrict__ xt, const LanczosTap* __restrict__ yt)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int width = dw * cn;
+    if (e >= width || dy >= dh) return;
+    const int dx = e / cn, c = e - dx * cn;
+    const LanczosTap tx = xt[dx], ty = yt[dy];
+    int xs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) xs[j] = clipI(tx.s - 3 + j, 0, sw) * cn + c;
+    if (sizeof(T) == 1) {
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uchar* R = src + (size_t)clipI(ty.s - 3 + k, 0, sh) * sstep;
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v += R[xs[j]] * tx.i[j];
+            r += v * ty.i[k];
+        }
+        r = (r + (1 << 21)) >> 22;
+        (dst + (size_t)dy * dstep)[e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+    } else {
+        float S[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float* R = reinterpret_cast<const float*>(src + (size_t)clipI(ty.s - 3 + k, 0, sh) * sstep);
+            float v = __fmul_rn(R[xs[0]], tx.f[0]);
+#pragma unroll
+            for (int j = 1; j < 8; j++) v = __fadd_rn(v, __fmul_rn(R[xs[j]], tx.f[j]));
+            S[k] = v;
+        }
+        float r;
+        if (e < (width / 4) * 4) {
+            r = __fmul_rn(S[7], ty.f[7]);
+#pragma unroll
+            for (int k = 6; k >= 0; k--) r = __fadd_rn(__fmul_rn(S[k], ty.f[k]), r);
+        } else {
+            r = __fmul_rn(S[0], ty.f[0]);
+#pragma unroll
+            for (int k = 1; k < 8; k++) r = __fadd_rn(r, __fmul_rn(S[k], ty.f[k]));
+        }
+        reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+    }
+}
+
+void buildLanczosTab(int dsize, double scale, std::vector<LanczosTap>& tab)
+{
+    static const double s45 = 0.70710678118654752440084436210485, pi = 3.1415926535897932384626433832795;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    tab.resize((size_t)dsize);
+    for (int d = 0; d < dsize; d++) {
+        float x = (float)((d + 0.5) * scale - 0.5);
+        int sI = (int)x; sI -= sI > x;                                      // cvFloor
+        x -= sI;
+        LanczosTap& t = tab[(size_t)d];
+        t.s = sI;
+        float sum = 0;
+        const double y0 = -(x + 3) * pi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+        for (int i = 0; i < 8; i++) {
+            const float y0_ = (x + 3 - i);
+            if (std::fabs(y0_) >= 1e-6f) { const double y = -y0_ * pi * 0.25; t.f[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y)); }
+            else t.f[i] = 1e30f;
+            sum += t.f[i];
+        }
+        sum = 1.f / sum;
+        for (int i = 0; i < 8; i++) {
+            t.f[i] *= sum;
+            const long q = lrintf(t.f[i] * 2048); t.i[i] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -706,7 +787,8 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
         } else if (interpolation == MI355CV_INTER_LINEAR) a.mode = 1;
         else if (interpolation == MI355CV_INTER_AREA) a.mode = 2;
         else if (interpolation == 2 /*INTER_CUBIC*/ && (depth == D8U || depth == D32F)) a.mode = 5;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // lanczos / *_EXACT / cubic on 16-bit depths: next row (f2)
+        else if (interpolation == 4 /*INTER_LANCZOS4*/ && (depth == D8U || depth == D32F)) a.mode = 6;
+        else return MI355CV_NOT_IMPLEMENTED;                                                // *_EXACT / cubic and lanczos on 16-bit depths: next row (f2)
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
@@ -724,6 +806,17 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
         dim3 g5(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         if (depth == D8U) hipLaunchKernelGGL(k_resize_cubic<uchar>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
         else hipLaunchKernelGGL(k_resize_cubic<float>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        return stg.finish("resize");
+    }
+    if (a.mode == 6) {
+        std::vector<LanczosTap> xt, yt;
+        buildLanczosTab(dst_width, a.scale_x, xt); buildLanczosTab(dst_height, a.scale_y, yt);
+        const LanczosTap* dxt = (const LanczosTap*)stg.param(xt.data(), xt.size() * sizeof(LanczosTap));
+        const LanczosTap* dyt = (const LanczosTap*)stg.param(yt.data(), yt.size() * sizeof(LanczosTap));
+        if (!dxt || !dyt) return MI355CV_NOT_IMPLEMENTED;
+        dim3 g6(divUp(dst_width * cn, 64), divUp(dst_height, 4));
+        if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g6, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        else hipLaunchKernelGGL(k_resize_lanczos<float>, g6, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
         return stg.finish("resize");
     }
     if (a.mode == 4) {

@@ -46,3 +46,22 @@ EXPORT int wrap_matchTemplate(const void* img, size_t is, int iw, int ih, const 
           mi355cv::matchTemplate(I, T, R, method); return R.data == p ? 0 : -2; }
     catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
+// FrameAllocator (include/mi355cv_cv.hpp): frames allocated by it -- a ROI clone, a pipeline of two HAL-served functions writing into
+// allocator-backed matrices -- behave like ordinary cv::Mat.  kind 0 pinned, 1 managed.  The result is copied to `d`.
+EXPORT int wrap_frameAllocatorTour(int kind, const void* s, size_t ss, int w, int h, int type, void* d, size_t ds)
+{
+    try {
+        mi355cv::FrameAllocator alloc(kind == 0 ? mi355cv::FrameAllocator::Pinned : mi355cv::FrameAllocator::Managed);
+        Mat src = M(s, ss, w, h, type), frame, blurred, out = M(d, ds, w, h, type);
+        frame.allocator = &alloc; blurred.allocator = &alloc;
+        frame.create(h, w, type);
+        src.copyTo(frame);
+        if (frame.u == nullptr || frame.u->currAllocator != &alloc) return -2;
+        cv::GaussianBlur(frame, blurred, Size(5, 5), 0, 0, BORDER_REFLECT_101);
+        if (blurred.allocator != &alloc) return -3;
+        Mat roi = blurred(Rect(w / 4, h / 4, w / 2, h / 2)).clone();          // clone() of a view goes through the same allocator
+        cv::GaussianBlur(blurred, frame, Size(3, 3), 0, 0, BORDER_REPLICATE);
+        frame.copyTo(out);
+        return roi.rows == h / 2 ? 0 : -4;
+    } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}

@@ -174,6 +174,79 @@ static int resizeCubic(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t
     return 0;
 }
 
+/* INTER_LANCZOS4 (CV_8U, CV_32F): interpolateLanczos4 resize.cpp:974-1003, HResizeLanczos4 :2066-2117, VResizeLanczos4 :2120-2158,
+ * table set-up :4100-4176.  Taps at sx-3 .. sx+4 / sy-3 .. sy+4, indices clamped to the image.
+ *   - CV_8U is integer throughout (VResizeNoVec, :3913-3916): taps * 2048 rounded to short, (sum + 2^21) >> 22, saturated;
+ *   - CV_32F: horizontal sums left to right; vertical pass = VResizeLanczos4Vec_32f (:1596-1621) for x below the last multiple of 4,
+ *     v = S0*b0 + (S1*b1 + ( ... + S7*b7)) with separate multiply and add (SSE baseline), left-to-right sums for the scalar tail. */
+static void lanczos_coef(float x, float* coeffs)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    float sum = 0;
+    const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const float y0_ = (x + 3 - i);
+        if (fabsf(y0_) >= 1e-6f) {
+            const double y = -y0_ * 3.1415926535897932384626433832795 * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else
+            coeffs[i] = 1e30f;
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+static int resizeLanczos4(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
+                          int depth, int cn, double scale_x, double scale_y)
+{
+    if (depth != 0 && depth != 5) return 1;
+    const int width = dw * cn, body = (width / 4) * 4;
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = cvfloor_f(fy); fy -= sy;
+        float cb[8]; lanczos_coef(fy, cb);
+        short ib[8]; for (int k = 0; k < 8; k++) ib[k] = sat_short_i((int)lrintf(cb[k] * 2048));
+        const uint8_t* rows[8];
+        for (int k = 0; k < 8; k++) rows[k] = src + (size_t)clipi(sy - 3 + k, 0, sh) * sstep;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            const int sx = cvfloor_f(fx); fx -= sx;
+            float ca[8]; lanczos_coef(fx, ca);
+            short ia[8]; for (int k = 0; k < 8; k++) ia[k] = sat_short_i((int)lrintf(ca[k] * 2048));
+            int xs[8]; for (int j = 0; j < 8; j++) xs[j] = clipi(sx - 3 + j, 0, sw);
+            for (int c = 0; c < cn; c++) {
+                const int e = dx * cn + c;
+                if (depth == 0) {
+                    int r = 0;
+                    for (int k = 0; k < 8; k++) { int v = 0; for (int j = 0; j < 8; j++) v += rows[k][xs[j] * cn + c] * ia[j]; r += v * ib[k]; }
+                    r = (r + (1 << 21)) >> 22;
+                    dst[(size_t)dy * dstep + e] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+                } else {
+                    float S[8];
+                    for (int k = 0; k < 8; k++) {
+                        const float* R = (const float*)rows[k];
+                        float v = R[xs[0] * cn + c] * ca[0];
+                        for (int j = 1; j < 8; j++) { const float m = R[xs[j] * cn + c] * ca[j]; v = v + m; }
+                        S[k] = v;
+                    }
+                    float r;
+                    if (e < body) {
+                        r = S[7] * cb[7];
+                        for (int k = 6; k >= 0; k--) { const float m = S[k] * cb[k]; r = m + r; }
+                    } else {
+                        r = S[0] * cb[0];
+                        for (int k = 1; k < 8; k++) { const float m = S[k] * cb[k]; r = r + m; }
+                    }
+                    ((float*)(dst + (size_t)dy * dstep))[e] = r;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation)
 {
@@ -253,6 +326,7 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
         return 0;
     }
     if (interpolation == 2) return resizeCubic(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, scale_x, scale_y);
+    if (interpolation == 4) return resizeLanczos4(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, scale_x, scale_y);
     if (interpolation != 1 && interpolation != 3) return 1;
     const int area_mode = interpolation == 3;
     for (int dy = 0; dy < dh; dy++) {

@@ -189,3 +189,41 @@ def test_cv_signature_wrappers_on_the_gpu(ref):
     for k in ("pyr1", "pyr2", "pyr3"):
         assert np.array_equal(got[k], exp[k]), k
     assert got["gftt"].shape == exp["gftt"].shape and set(map(tuple, got["gftt"])) == set(map(tuple, exp["gftt"]))
+
+
+def _alloc_tour(hal, kind, src):
+    import ctypes
+    out = np.empty_like(src)
+    rc = hal.wrap_frameAllocatorTour(kind, O.P(src), O.step(src), src.shape[1], src.shape[0], O.cvtype(src), O.P(out), O.step(out))
+    assert rc == 0, rc
+    return out
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_frame_allocator(ref, kind):
+    """mi355cv::FrameAllocator (pinned / managed cv::MatAllocator, SURVEY §8 f4): matrices it backs go through the reference's own code
+    (create, copyTo, ROI clone, GaussianBlur via the HAL) and give the stock result -- on a CPU-only host through its fastMalloc branch"""
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    src = O.ref_rng_fill((240, 320, 3), np.uint8, 5, 0, 256)
+    want = O.ref_GaussianBlur(O.ref_GaussianBlur(src, 5, 0, 0, 4), 3, 0, 0, 1)
+    assert np.array_equal(_alloc_tour(hal, kind, src), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1])
+def test_frame_allocator_gpu(ref, kind):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None
+    src = O.ref_rng_fill((480, 640, 3), np.uint8, 5, 0, 256)
+    want = O.ref_GaussianBlur(O.ref_GaussianBlur(src, 5, 0, 0, 4), 3, 0, 0, 1)
+    n0 = cv.call_count("gaussianBlurBinomial")
+    assert np.array_equal(_alloc_tour(hal, kind, src), want)
+    assert cv.call_count("gaussianBlurBinomial") >= n0 + 2
+    import ctypes
+    L = cv._lib.lib
+    p = L.mi355cv_hostAlloc(1 << 20, kind)
+    assert p, "hostAlloc failed on a GPU box"
+    assert L.mi355cv_hostFree(p, kind) == 0

@@ -70,6 +70,17 @@ def test_resize_cubic(orc, ref, dtype, cn):
             assert np.array_equal(got, want), (w, h, dsize, dtype, cn)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_lanczos4(orc, ref, dtype, cn):
+    """INTER_LANCZOS4: 8x8 taps, integer for CV_8U, SIMD body / scalar tail orders for CV_32F; sources smaller than the kernel"""
+    for (w, h), dsizes in [((53, 37), [(80, 55), (20, 11), (106, 74), (161, 3)]), ((9, 9), [(31, 29), (8, 8)]), ((5, 3), [(17, 13)]), ((64, 48), [(32, 24), (100, 7)])]:
+        src = rnd(orc, (h, w, cn) if cn > 1 else (h, w), dtype, 9 + cn + w)
+        for dsize in dsizes:
+            got, want = orc.orc_resize(src, dsize, interpolation=4), orc.ref_resize(src, dsize, interpolation=4)
+            assert np.array_equal(got, want), (w, h, dsize, dtype, cn)
+
+
 def mats(orc, w, h):
     out = []
     for ang, sc in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]:

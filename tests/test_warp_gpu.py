@@ -87,6 +87,19 @@ def test_resize_cubic(cv, orc, dtype, cn):
         cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=2)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_lanczos4(cv, orc, dtype, cn):
+    """INTER_LANCZOS4, bit-exact (CV_8U integer; CV_32F with the reference's body / tail summation orders)"""
+    for (w, h), dsizes in [((53, 37), [(80, 55), (20, 11), (106, 74), (161, 3)]), ((9, 9), [(31, 29), (8, 8)]), ((5, 3), [(17, 13)]), ((640, 480), [(1280, 960), (333, 222)])]:
+        src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 9 + cn + w)
+        for dsize in dsizes:
+            got = cv.resize(dev(src), dsize, interpolation=4).cpu().numpy()
+            assert np.array_equal(got, orc.orc_resize(src, dsize, interpolation=4)), (w, h, dsize, dtype, cn)
+    with pytest.raises(NotImplementedError):
+        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=4)
+
+
 def mats(cv, w, h):
     out = [cv.getRotationMatrix2D((w / 2.0, h / 2.0), a, s) for a, s in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0)]]
     out.append(np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64))
