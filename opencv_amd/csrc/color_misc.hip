@@ -45,14 +45,14 @@ __global__ __launch_bounds__(256) void k_enc420(const uchar* __restrict__ src, s
             for (int i = 0; i < 4 * SCN; i++) if (i < n * SCN) in[j].put(i, s[i]);
         }
     }
-    const int bo = swapBlue ? 2 : 0;
     unsigned uvw = 0; int uu[2], vv[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         unsigned yw = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int b = in[j].get(p * SCN + bo), g = in[j].get(p * SCN + 1), r = in[j].get(p * SCN + 2 - bo);
+            const int c0 = in[j].get(p * SCN), g = in[j].get(p * SCN + 1), c2 = in[j].get(p * SCN + 2);
+            const int b = swapBlue ? c2 : c0, r = swapBlue ? c0 : c2;       // (a run-time byte index would turn the registers into an array)
             yw |= (unsigned)sat8((269484 * r + 528482 * g + 102760 * b + (1 << 19) + (16 << 20)) >> 20) << (8 * p);
             if (j == 0 && (p & 1) == 0) {                                   // chroma from the top-left pixel of each 2x2 block
                 int u = sat8((-155188 * r - 305135 * g + 460324 * b + (1 << 19) + (128 << 20)) >> 20);

@@ -4,8 +4,11 @@ from Python is bounded by the ~25 us call overhead of the ctypes mirror, so the 
 this script under `rocprofv3 --kernel-trace --stats` (tools/prof_f1.sh -> profiles/r01g_f1_kernel_stats.csv); the JSON lines printed
 here carry the end-to-end view (calls in flight back to back, one synchronise at the end) and the host-pointer (PCIe-inclusive) rates."""
 import json
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import numpy as np
 import torch
