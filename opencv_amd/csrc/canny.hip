@@ -30,8 +30,11 @@ __global__ __launch_bounds__(256) void k_canny_magnms(const short* __restrict__ 
     __shared__ int smag[TH + 2][TW + 2];
     __shared__ short sgx[TH][TW], sgy[TH][TW];
     const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
-    for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
-        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+    auto put = [&](int ly, int lx, int bm, int bx, int by) {
+        smag[ly][lx] = bm;                                                  // outside the image: 0 (canny.cpp:390-, the zeroed border rows / columns)
+        if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) { sgx[ly - 1][lx - 1] = (short)bx; sgy[ly - 1][lx - 1] = (short)by; }
+    };
+    auto one = [&](int ly, int lx) {
         const int gx = X0 + lx - 1, gy = Y0 + ly - 1;
         int bm = 0, bx = 0, by = 0;
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
@@ -43,9 +46,26 @@ __global__ __launch_bounds__(256) void k_canny_magnms(const short* __restrict__ 
                 if (c == 0 || m > bm) { bm = m; bx = vx; by = vy; }
             }
         }
-        smag[ly][lx] = bm;                                                  // outside the image: 0 (canny.cpp:390-, the zeroed border rows / columns)
-        if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) { sgx[ly - 1][lx - 1] = (short)bx; sgy[ly - 1][lx - 1] = (short)by; }
+        put(ly, lx, bm, bx, by);
+    };
+    // the 64 tile columns of all 18 rows in groups of four pixels (single channel: one 8-byte load per gradient image), then the ring columns
+    for (int i = threadIdx.x; i < (TH + 2) * (TW / 4); i += 256) {
+        const int ly = i >> 4, c4 = (i & 15) * 4;
+        const int gx = X0 + c4, gy = Y0 + ly - 1;
+        if (cn == 1 && (unsigned)gy < (unsigned)H && gx + 3 < W) {
+            const uint2 vx = *(const uint2*)(dx + (size_t)gy * gstepS + gx), vy = *(const uint2*)(dy + (size_t)gy * gstepS + gx);
+            const unsigned wx[2] = {vx.x, vx.y}, wy[2] = {vy.x, vy.y};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int a = (short)(wx[p >> 1] >> (16 * (p & 1))), b = (short)(wy[p >> 1] >> (16 * (p & 1)));
+                put(ly, c4 + 1 + p, L2 ? a * a + b * b : abs(a) + abs(b), a, b);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) one(ly, c4 + 1 + p);
+        }
     }
+    if (threadIdx.x < 2 * (TH + 2)) one(threadIdx.x >> 1, (threadIdx.x & 1) ? TW + 1 : 0);
     __syncthreads();
     const int ly = threadIdx.x >> 4, lx0 = (threadIdx.x & 15) * 4;
     const int y = Y0 + ly;

@@ -6,7 +6,7 @@
 //   YUV/YCrCb->BGR  YCrCb2RGB_i<uchar> :739   b = Y + ((Cb-128)*c3 + 2^13) >> 14, ...
 //   NV12 / NV21     YUV420sp2RGB8Invoker :1195, 20-bit ITU-R BT.601: r = (max(Y-16,0)*1220542 + 1673527*(V-128) + 2^19) >> 20, ...
 // All HBM-bound: the packed conversions run on the pix4 launch shape (four pixels per lane, whole-dword traffic; pix4.h), the 4:2:0
-// decoders take one 2x2 block per thread.
+// decoders take 4x2 pixels per lane on the same dword traffic.
 #include "rt.h"
 #include "pix4.h"
 #include <cmath>
@@ -53,28 +53,62 @@ struct OpYuv2Bgr {
     }
 };
 
-// one thread per 2x2 block: 2+2 luma bytes, one (U,V) pair, 4 output pixels
-template <int DCN>
-__global__ __launch_bounds__(256) void k_nv2bgr_u8(const uchar* __restrict__ yp, size_t ystep, const uchar* __restrict__ uvp, size_t uvstep,
-                                                   uchar* __restrict__ dst, size_t dstep, int W, int H, int bIdx, int uIdx)
+// 4:2:0 decoders: one lane per 4x2 pixels -- two luma dwords, two chroma pairs (one dword when interleaved; four byte loads when planar,
+// where a chroma sample is addressed through its linear index inside the packed quarter planes that follow the luma rows,
+// cvtThreePlaneYUVtoBGR color_yuv.simd.hpp:2060-2087), DCN output dwords per row.  Rows or pitches that are not multiples of four
+// and the ragged end of a row use byte accesses.
+template <int DCN, bool PLANAR>
+__global__ __launch_bounds__(256) void k_dec420(const uchar* __restrict__ yp, size_t ystep, const uchar* __restrict__ cp, size_t cstep,
+                                                uchar* __restrict__ dst, size_t dstep, int W, int H, int bIdx, int uIdx, int aligned)
 {
-    const int bx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int by = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (2 * bx >= W || 2 * by >= H) return;
-    const uchar* uv = uvp + (size_t)by * uvstep + 2 * (size_t)bx;
-    const int uu = (int)uv[uIdx] - 128, vv = (int)uv[1 - uIdx] - 128;
-    const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y2 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= W || 2 * y2 >= H) return;
+    const int n = min(4, W - x4);                                           // 2 or 4 (W is even)
+    const bool fast = n == 4 && aligned;
+    int uu[2], vv[2];
+    if (PLANAR) {
+        const size_t plane = (size_t)(H / 2) * (size_t)(W / 2);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const size_t l0 = (size_t)y2 * (size_t)(W / 2) + (size_t)(x4 / 2 + (2 * q < n ? q : 0)), l1 = plane + l0;
+            const int c0 = cp[(l0 / W) * cstep + l0 % W], c1 = cp[(l1 / W) * cstep + l1 % W];
+            uu[q] = (uIdx ? c1 : c0) - 128; vv[q] = (uIdx ? c0 : c1) - 128;
+        }
+    } else {
+        const uchar* uv = cp + (size_t)y2 * cstep + x4;
+        unsigned w;
+        if (fast) w = *(const unsigned*)uv;
+        else { w = (unsigned)uv[0] | ((unsigned)uv[1] << 8); if (n == 4) w |= ((unsigned)uv[2] << 16) | ((unsigned)uv[3] << 24); }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c0 = (int)((w >> (16 * q)) & 255u), c1 = (int)((w >> (16 * q + 8)) & 255u);
+            uu[q] = (uIdx ? c1 : c0) - 128; vv[q] = (uIdx ? c0 : c1) - 128;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const uchar* yr = yp + (size_t)(2 * by + j) * ystep + 2 * (size_t)bx;
-        uchar* d = dst + (size_t)(2 * by + j) * dstep + 2 * (size_t)bx * DCN;
+        const uchar* yr = yp + (size_t)(2 * y2 + j) * ystep + x4;
+        unsigned yw;
+        if (fast) yw = *(const unsigned*)yr;
+        else { yw = (unsigned)yr[0] | ((unsigned)yr[1] << 8); if (n == 4) yw |= ((unsigned)yr[2] << 16) | ((unsigned)yr[3] << 24); }
+        pix4::Px<DCN> out; out.clear();
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int yv = max((int)yr[i] - 16, 0) * 1220542;
-            d[i * DCN + 2 - bIdx] = (uchar)sat8((yv + ruv) >> 20);
-            d[i * DCN + 1] = (uchar)sat8((yv + guv) >> 20);
-            d[i * DCN + bIdx] = (uchar)sat8((yv + buv) >> 20);
-            if (DCN == 4) d[i * DCN + 3] = 255;
+        for (int p = 0; p < 4; p++) {
+            const int u = uu[p >> 1], v = vv[p >> 1];
+            const int ruv = (1 << 19) + 1673527 * v, guv = (1 << 19) - 852492 * v - 409993 * u, buv = (1 << 19) + 2116026 * u;
+            const int yv = max((int)((yw >> (8 * p)) & 255u) - 16, 0) * 1220542;
+            const int r = sat8((yv + ruv) >> 20), g = sat8((yv + guv) >> 20), b = sat8((yv + buv) >> 20);
+            out.put(p * DCN, bIdx ? r : b); out.put(p * DCN + 1, g); out.put(p * DCN + 2, bIdx ? b : r);
+            if (DCN == 4) out.put(p * DCN + 3, 255);
+        }
+        uchar* d = dst + (size_t)(2 * y2 + j) * dstep + (size_t)x4 * DCN;
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < DCN; i++) ((unsigned*)d)[i] = out.w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * DCN; i++) if (i < n * DCN) d[i] = (uchar)out.get(i);
         }
     }
 }
@@ -99,34 +133,6 @@ struct OpBgr2Hsv {
         }
     }
 };
-
-// I420 / YV12: the two quarter-size chroma planes follow the luma plane inside the same array, packed two chroma rows per array
-// row (cvtThreePlaneYUVtoBGR color_yuv.simd.hpp:2060-2087); a chroma sample is addressed through its linear index
-template <int DCN>
-__global__ __launch_bounds__(256) void k_i420_2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bIdx, int uIdx)
-{
-    const int bx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int by = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (2 * bx >= W || 2 * by >= H) return;
-    const size_t plane = (size_t)(H / 2) * (size_t)(W / 2);
-    const size_t l0 = (size_t)by * (size_t)(W / 2) + (size_t)bx, l1 = plane + l0;
-    const int c0 = src[((size_t)H + l0 / W) * sstep + l0 % W], c1 = src[((size_t)H + l1 / W) * sstep + l1 % W];
-    const int uu = (uIdx ? c1 : c0) - 128, vv = (uIdx ? c0 : c1) - 128;
-    const int ruv = (1 << 19) + 1673527 * vv, guv = (1 << 19) - 852492 * vv - 409993 * uu, buv = (1 << 19) + 2116026 * uu;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uchar* yr = src + (size_t)(2 * by + j) * sstep + 2 * (size_t)bx;
-        uchar* d = dst + (size_t)(2 * by + j) * dstep + 2 * (size_t)bx * DCN;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int yv = max((int)yr[i] - 16, 0) * 1220542;
-            d[i * DCN + 2 - bIdx] = (uchar)sat8((yv + ruv) >> 20);
-            d[i * DCN + 1] = (uchar)sat8((yv + guv) >> 20);
-            d[i * DCN + bIdx] = (uchar)sat8((yv + buv) >> 20);
-            if (DCN == 4) d[i * DCN + 3] = 255;
-        }
-    }
-}
 
 } // namespace
 
@@ -181,9 +187,10 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
     const uchar* duv = stg.in(uv_data, uv_step, (size_t)dst_width, dst_height / 2, &uvs);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
     if (!dy || !duv || !dd) return MI355CV_NOT_IMPLEMENTED;
-    dim3 grid(divUp(dst_width / 2, 64), divUp(dst_height / 2, 4));
-    if (dcn == 3) hipLaunchKernelGGL(k_nv2bgr_u8<3>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
-    else hipLaunchKernelGGL(k_nv2bgr_u8<4>, grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    dim3 grid(divUp(divUp(dst_width, 4), 64), divUp(dst_height / 2, 4));
+    const int al = ((((uintptr_t)dy | ys | (uintptr_t)duv | uvs | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+    if (dcn == 3) hipLaunchKernelGGL((k_dec420<3, false>), grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx, al);
+    else hipLaunchKernelGGL((k_dec420<4, false>), grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx, al);
     return stg.finish("cvtTwoPlaneYUVtoBGR");
 }
 
@@ -221,9 +228,11 @@ MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_
     const uchar* ds = stg.in(src_data, src_step, (size_t)dst_width, dst_height * 3 / 2, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
-    dim3 grid(divUp(dst_width / 2, 64), divUp(dst_height / 2, 4));
-    if (dcn == 3) hipLaunchKernelGGL(k_i420_2bgr_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
-    else hipLaunchKernelGGL(k_i420_2bgr_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx);
+    dim3 grid(divUp(divUp(dst_width, 4), 64), divUp(dst_height / 2, 4));
+    const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+    const uchar* chroma = ds + dss * (size_t)dst_height;                    // the packed quarter planes start below the luma rows
+    if (dcn == 3) hipLaunchKernelGGL((k_dec420<3, true>), grid, dim3(256), 0, stream(), ds, dss, chroma, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx, al);
+    else hipLaunchKernelGGL((k_dec420<4, true>), grid, dim3(256), 0, stream(), ds, dss, chroma, dss, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx, al);
     return stg.finish("cvtThreePlaneYUVtoBGR");
 }
 
