@@ -325,6 +325,24 @@ MI355CV_API int mi355cv_equalize_hist(const mi355cv_uchar* src_data, size_t src_
 MI355CV_API int mi355cv_threshold_otsu(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, double maxValue, int thresholdType, double* thresh);
 
+/* --------------------------------------------------- f3: sparse pyramidal Lucas-Kanade (modules/video) */
+
+/* replaces hal_ni_ScharrDeriv (modules/video/src/hal_replacement.hpp:84; caller calcScharrDeriv lkpyramid.cpp:67): CV_8U cn 1..4 ->
+ * interleaved (dI/dx, dI/dy) CV_16S, 2*cn channels */
+MI355CV_API int mi355cv_ScharrDeriv(const mi355cv_uchar* src_data, size_t src_step, short* dst_data, size_t dst_step, int width, int height, int cn);
+/* replaces hal_ni_LKOpticalFlowLevel (modules/video/src/hal_replacement.hpp:54; caller LKTrackerInvoker::operator() lkpyramid.cpp:233): one
+ * pyramid level.  The three images must be readable one window beyond every edge (the padded pyramids of buildOpticalFlowPyramid).
+ * status is non-NULL at level 0 only; termination_epsilon is the squared threshold the caller prepares. */
+MI355CV_API int mi355cv_LKOpticalFlowLevel(const mi355cv_uchar* prev_data, size_t prev_data_step, const short* prev_deriv_data, size_t prev_deriv_step,
+        const mi355cv_uchar* next_data, size_t next_step, int width, int height, int cn,
+        const float* prev_points, float* next_points, size_t point_count, mi355cv_uchar* status, float* err,
+        const int win_width, const int win_height, int termination_count, double termination_epsilon,
+        bool get_min_eigen_vals, float min_eigen_vals_threshold);
+/* cv::copyMakeBorder (core/src/copy.cpp:1183; no HAL hook) for device-resident images: pixels of elem_size bytes, BORDER_CONSTANT = zeros;
+ * src may be the interior of dst (then only the frame is written) -- what buildOpticalFlowPyramid does at lkpyramid.cpp:804 */
+MI355CV_API int mi355cv_copyMakeBorder(const mi355cv_uchar* src_data, size_t src_step, int width, int height, mi355cv_uchar* dst_data, size_t dst_step,
+        int top, int bottom, int left, int right, int elem_size, int border_type);
+
 /* --------------------------------------------------- f1: Canny */
 
 /* replaces hal_ni_canny (hal_replacement.hpp:1291; caller cv::Canny canny.cpp:864).  CV_8U, 1..4 channels, ksize 3 or 5; thresholds as

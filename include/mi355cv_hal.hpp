@@ -126,6 +126,13 @@
 #undef  cv_hal_threshold_otsu
 #define cv_hal_threshold_otsu mi355cv_threshold_otsu   // :1077
 
+// modules/video/src/hal_replacement.hpp:54, :84 / callers lkpyramid.cpp:233, :67.  The video module includes the same
+// custom_hal.hpp as imgproc, after its own hal_ni_* stubs
+#undef  cv_hal_LKOpticalFlowLevel
+#define cv_hal_LKOpticalFlowLevel mi355cv_LKOpticalFlowLevel
+#undef  cv_hal_ScharrDeriv
+#define cv_hal_ScharrDeriv mi355cv_ScharrDeriv
+
 // hal_replacement.hpp:1291 / caller canny.cpp:864
 #undef  cv_hal_canny
 #define cv_hal_canny mi355cv_canny

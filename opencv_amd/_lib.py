@@ -80,6 +80,10 @@ def _load():
         "mi355cv_cvtMultipliedRGBAtoRGBA": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
         "mi355cv_equalize_hist": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
         "mi355cv_threshold_otsu": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_int, ctypes.POINTER(ctypes.c_double)]),
+        "mi355cv_ScharrDeriv": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
+        "mi355cv_LKOpticalFlowLevel": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_u8p, c_sz, c_u8p, c_u8p,
+                                               c_int, c_int, c_int, c_dbl, ctypes.c_bool, ctypes.c_float]),
+        "mi355cv_copyMakeBorder": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_hostAlloc": (ctypes.c_void_p, [c_sz, c_int]),
         "mi355cv_hostFree": (c_int, [ctypes.c_void_p, c_int]),
         "mi355cv_canny": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_dbl, c_int, ctypes.c_bool]),

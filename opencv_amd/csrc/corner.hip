@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_corner_fused(const uchar* __restrict__ 
             const float ah = __fmul_rn(A, 0.5f), ch = __fmul_rn(C, 0.5f);
             const float t = __fsub_rn(ah, ch);
             const float u = __fadd_rn(__fmul_rn(B, B), __fmul_rn(t, t));
-            r = __fsub_rn(__fadd_rn(ah, ch), __fsqrt_rn(u));
+            r = __fsub_rn(__fadd_rn(ah, ch), sqrtf(u));
         }
         reinterpret_cast<float*>(dst + (size_t)y * dstep)[x] = r;
     }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_corner_roll(const uchar* __restrict__ s
                 const f32x2 ah = A * f32x2{0.5f, 0.5f}, ch = C * f32x2{0.5f, 0.5f};
                 const f32x2 t = ah - ch;
                 const f32x2 u = B * B + t * t;
-                o[i] = (ah + ch) - f32x2{__fsqrt_rn(u.x), __fsqrt_rn(u.y)};
+                o[i] = (ah + ch) - f32x2{sqrtf(u.x), sqrtf(u.y)};
             }
         }
         uint32_t ow[CB];                                   // memory order: pixels 0..NP-1 are the .x halves, NP..2NP-1 the .y halves

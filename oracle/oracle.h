@@ -72,6 +72,12 @@ void orc_cvtGraytoBGR5x5(const uint8_t* src, size_t sstep, uint8_t* dst, size_t 
 void orc_cvtRGBAtoMultipliedRGBA(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
 void orc_cvtMultipliedRGBAtoRGBA(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
 
+/* oracle/lk.c: the video module's HAL granularity (modules/video/src/hal_replacement.hpp:54, :84) */
+void orc_ScharrDeriv(const uint8_t* src, size_t sstep, int16_t* dst, size_t dstepBytes, int w, int h, int cn);
+int orc_LKOpticalFlowLevel(const uint8_t* I, size_t stepI, const int16_t* derivI, size_t dstepBytes, const uint8_t* J, size_t stepJ,
+                           int width, int height, int cn, const float* prevPts, float* nextPts, size_t npts, uint8_t* status, float* err,
+                           int winW, int winH, int maxCount, double epsilon, int getMinEig, float minEigThreshold);
+
 /* oracle/hist.c */
 void orc_equalizeHist(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
 double orc_otsuFromHist(const int* hist, int N, int w, int h);

@@ -12,6 +12,7 @@
 #include <opencv2/core/utility.hpp>
 #include <opencv2/imgproc.hpp>
 #include <opencv2/imgproc/hal/hal.hpp>
+#include <opencv2/video/tracking.hpp>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -214,6 +215,18 @@ int ref_cvtBGRtoTwoPlaneYUV(const void* s, size_t ss, void* d, size_t ds, int w,
     try {
         cv::hal::cvtBGRtoTwoPlaneYUV((const uchar*)s, ss, (uchar*)d, (uchar*)d + ds * h, ds, w, h, scn, swapBlue != 0, uIdx);
         return 0;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref: %s\n", e.what()); return -1; }
+}
+
+// cv::calcOpticalFlowPyrLK: pts / next are npts x 2 floats; flags as cv:: (OPTFLOW_USE_INITIAL_FLOW 4, OPTFLOW_LK_GET_MIN_EIGENVALS 8)
+int ref_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* next, size_t ns, int w, int h, int type, const float* pts, float* nextPts, int npts,
+                             unsigned char* status, float* err, int winW, int winH, int maxLevel, int critType, int maxCount, double eps, int flags, double minEig)
+{
+    try {
+        Mat P = M(prev, ps, w, h, type), N = M(next, ns, w, h, type);
+        Mat prevPts(npts, 1, CV_32FC2, const_cast<float*>(pts)), nextM(npts, 1, CV_32FC2, nextPts), st(npts, 1, CV_8U, status), er(npts, 1, CV_32F, err);
+        cv::calcOpticalFlowPyrLK(P, N, prevPts, nextM, st, er, cv::Size(winW, winH), maxLevel, cv::TermCriteria(critType, maxCount, eps), flags, minEig);
+        return (nextM.data == (uchar*)nextPts && st.data == status && er.data == (uchar*)err) ? 0 : -2;
     } catch (const cv::Exception& e) { fprintf(stderr, "ref: %s\n", e.what()); return -1; }
 }
 

@@ -828,3 +828,100 @@ def ref_cvtBGRtoTwoPlaneYUV(src, swapBlue, uIdx):
     dst = np.empty((h * 3 // 2, w), np.uint8)
     assert r.ref_cvtBGRtoTwoPlaneYUV(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], int(swapBlue), uIdx) == 0
     return dst
+
+
+# ----------------------------------------------------------------------------- sparse pyramidal LK (oracle/lk.c)
+OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_LK_GET_MIN_EIGENVALS = 4, 8
+
+
+def lk_criteria(critType, maxCount, eps):
+    """SparsePyrLKOpticalFlowImpl::calc lkpyramid.cpp:1386-1395 -> (maxCount, squared epsilon)"""
+    maxCount = 30 if (critType & 1) == 0 else min(max(maxCount, 0), 100)
+    eps = 0.01 if (critType & 2) == 0 else min(max(eps, 0.0), 10.0)
+    return maxCount, eps * eps
+
+
+def lk_pad(img, winW, winH, mode):
+    """copyMakeBorder by the window size on every side; returns (padded, interior view)"""
+    pad = ((winH, winH), (winW, winW)) + (((0, 0),) if img.ndim == 3 else ())
+    p = np.pad(img, pad, mode=mode) if mode != "constant" else np.pad(img, pad, mode="constant")
+    return p, p[winH:winH + img.shape[0], winW:winW + img.shape[1]]
+
+
+def lk_pyramid(img, winW, winH, maxLevel, pyrdown):
+    """buildOpticalFlowPyramid lkpyramid.cpp:747-843 without derivatives: list of interior views of REFLECT_101-padded levels"""
+    levels = []
+    cur = img
+    for level in range(maxLevel + 1):
+        if level:
+            cur = pyrdown(levels[-1])
+        levels.append(lk_pad(np.ascontiguousarray(cur), winW, winH, "reflect")[1])
+        h, w = cur.shape[:2]
+        if (w + 1) // 2 <= winW or (h + 1) // 2 <= winH:
+            break
+    return levels
+
+
+def lk_drive(prev, nxt, pts, winSize, maxLevel, crit, flags, minEig, nextPts, pyrdown, scharr, tracker):
+    """the level loop of SparsePyrLKOpticalFlowImpl::calc (:1397-1424) + LKTrackerInvoker's per-level point scaling (:215-231), with the
+    three kernels supplied by the caller (oracle here, the MI355X hooks in the GPU tests)"""
+    winW, winH = winSize
+    maxCount, eps2 = lk_criteria(*crit)
+    pp = lk_pyramid(prev, winW, winH, maxLevel, pyrdown)
+    npyr = lk_pyramid(nxt, winW, winH, maxLevel, pyrdown)
+    maxLevel = min(len(pp), len(npyr)) - 1
+    n = len(pts)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(n, 2)
+    out = np.ascontiguousarray(nextPts, np.float32).reshape(n, 2).copy() if flags & OPTFLOW_USE_INITIAL_FLOW else np.empty((n, 2), np.float32)
+    status = np.ones(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    for level in range(maxLevel, -1, -1):
+        I, J = pp[level], npyr[level]
+        d = scharr(I)
+        dpad, dint = lk_pad(d, winW, winH, "constant")
+        scale = np.float32(1.0 / (1 << level))
+        prevScaled = pts * scale
+        if level == maxLevel:
+            out = out * scale if flags & OPTFLOW_USE_INITIAL_FLOW else prevScaled.copy()
+        else:
+            out = out * np.float32(2)
+        out = np.ascontiguousarray(out, np.float32)
+        tracker(I, dint, J, np.ascontiguousarray(prevScaled), out, status if level == 0 else None, err, winW, winH, maxCount, eps2,
+                bool(flags & OPTFLOW_LK_GET_MIN_EIGENVALS), np.float32(minEig))
+    return out, status, err
+
+
+def orc_ScharrDeriv(img):
+    o = oracle()
+    h, w = img.shape[:2]
+    cn = cn_of(img)
+    dst = np.empty((h, w, 2 * cn), np.int16)
+    o.orc_ScharrDeriv(P(img), step(img), P(dst), step(dst), w, h, cn)
+    return dst
+
+
+def orc_LKLevel(I, dI, J, prevPts, nextPts, status, err, winW, winH, maxCount, eps2, getMinEig, minEig):
+    o = oracle()
+    h, w = I.shape[:2]
+    rc = o.orc_LKOpticalFlowLevel(P(I), step(I), P(dI), step(dI), P(J), step(J), w, h, cn_of(I), P(prevPts), P(nextPts), ctypes.c_size_t(len(prevPts)),
+                                  P(status) if status is not None else None, P(err), winW, winH, maxCount, ctypes.c_double(eps2), int(getMinEig),
+                                  ctypes.c_float(minEig))
+    assert rc == 0
+
+
+def orc_calcOpticalFlowPyrLK(prev, nxt, pts, winSize=(21, 21), maxLevel=3, crit=(3, 30, 0.01), flags=0, minEig=1e-4, nextPts=None):
+    return lk_drive(prev, nxt, pts, winSize, maxLevel, crit, flags, minEig, nextPts, orc_pyrDown, orc_ScharrDeriv, orc_LKLevel)
+
+
+def ref_calcOpticalFlowPyrLK(prev, nxt, pts, winSize=(21, 21), maxLevel=3, crit=(3, 30, 0.01), flags=0, minEig=1e-4, nextPts=None):
+    r = load_ref()
+    n = len(pts)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(n, 2)
+    out = np.ascontiguousarray(nextPts, np.float32).reshape(n, 2).copy() if nextPts is not None else np.zeros((n, 2), np.float32)
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    h, w = prev.shape[:2]
+    rc = r.ref_calcOpticalFlowPyrLK(P(prev), step(prev), P(nxt), step(nxt), w, h, cvtype(prev), P(pts), P(out), n, P(status), P(err), winSize[0], winSize[1],
+                                    maxLevel, crit[0], crit[1], ctypes.c_double(crit[2]), flags, ctypes.c_double(minEig))
+    assert rc == 0, rc
+    return out, status, err

@@ -57,6 +57,11 @@ def _calls(o, src8, src8c3, srcf):
     out["equalize"] = o.ref_equalizeHist(src8)
     ov, od = o.ref_threshold(src8, 0.0, 255.0, 0 | 8)
     out["otsu"] = od; out["otsu_level"] = np.array([ov])
+    shifted = np.roll(src8, (1, 2), axis=(0, 1))
+    lkpts = (O.ref_rng_fill((120, 2), np.float32, 8, 0, 1) * np.float32([128, 96])).astype(np.float32)
+    lk = o.ref_calcOpticalFlowPyrLK(src8, shifted, lkpts, (21, 21), 2)
+    out["lk_status"] = lk[1]; out["lk_err"] = lk[2]
+    out["lk_pts"] = np.where(lk[1][:, None] > 0, lk[0], 0).astype(np.float32)
     out["median3"] = o.ref_medianBlur(src8c3, 3)
     out["median5"] = o.ref_medianBlur(src8, 5)
     out["dilate"] = o.ref_morph(1, src8)
@@ -107,7 +112,7 @@ def test_reference_runs_on_the_gpu(ref):
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
              "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold", "canny",
              "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
-             "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu"]
+             "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu", "ScharrDeriv", "LKOpticalFlowLevel"]
     before = {n: cv.call_count(n) for n in names}
     with O.use_ref(hal):
         through = _calls(O, src8, src8c3, srcf)

@@ -68,6 +68,19 @@ run("resize_lanczos4_x0.75", lambda: cv.resize(gray, (2880, 1620), interpolation
 run("resize_area_x0.6", lambda: cv.resize(gray, (2304, 1296), interpolation=3), n=10)
 cv.set_async(False)
 
+# §8 f3: sparse pyramidal LK on a 1920x1080 pair, 5000 points, 21x21 window, 3 pyramid levels above level 0, everything resident in HBM
+yy, xx = torch.meshgrid(torch.arange(1080, device="cuda"), torch.arange(1920, device="cuda"), indexing="ij")
+tex = (torch.sin(xx * 0.07) * torch.cos(yy * 0.05) + torch.sin((xx + yy) * 0.013) + 0.3 * torch.rand((1080, 1920), device="cuda", generator=g))
+prev = ((tex - tex.min()) / (tex.max() - tex.min()) * 255).to(torch.uint8)
+nxt = torch.roll(prev, (2, 3), dims=(0, 1))
+lkpts = torch.rand((5000, 2), device="cuda", generator=g) * torch.tensor([1900.0, 1060.0], device="cuda") + 10
+res = {}
+def lk():
+    res["r"] = cv.calcOpticalFlowPyrLK(prev, nxt, lkpts, None, (21, 21), 3)
+run("calcOpticalFlowPyrLK_1080p_5000pts", lk, n=5, extra={"frame": "1920x1080"})
+st = res["r"][1]; d = (res["r"][0] - lkpts)[st > 0]
+print(json.dumps({"hook": "calcOpticalFlowPyrLK_check", "tracked": int(st.sum()), "median_flow": [round(float(d[:, 0].median()), 3), round(float(d[:, 1].median()), 3)]}), flush=True)
+
 # host pointers: the hook stages the frame through HBM (H2D, kernel, D2H, synchronous).  Pageable vs page-locked (mi355cv_hostAlloc kind 0)
 import ctypes
 L = cv._lib.lib
