@@ -111,6 +111,10 @@ def other_configs(with_cpu=True):
     cpu["cfg4b"] = t(pyr)
     tpl = rng.integers(0, 256, (128, 128), dtype=np.uint8)
     cpu["cfg5"] = t(lambda: orc.ref_matchTemplate(gray, tpl, 3), reps=1)
+    try:
+        rows += next_rows(orc, t, gray, bgr, hd)
+    except Exception as e:                                      # reported rows only: never lose the headline line over them
+        rows.append({"config": "next rows", "error": repr(e)})
     for r in rows:
         key = r["config"].split()[0]
         if key in cpu:
@@ -118,6 +122,46 @@ def other_configs(with_cpu=True):
             if "frames" in r and "ms" in r:
                 r["gpu_ms_per_frame"] = round(r["ms"] / r["frames"], 4)
     return rows
+
+
+def next_rows(orc, t, gray, bgr, hd):
+    """SURVEY §8 "next" rows (f1 / f3 / f4) on one frame: end-to-end time per call through the Python mirror on device-resident data
+    (includes ~14 us of host time per hook call) beside the reference's CPU path.  Kernel durations: profiles/r01g_f1_kernel_stats.csv."""
+    import opencv_amd as cv
+
+    def g(fn, reps=10):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    dgray, dbgr, dhd = torch.from_numpy(gray).cuda(), torch.from_numpy(bgr).cuda(), torch.from_numpy(hd).cuda()
+    nv = np.ascontiguousarray(np.concatenate([gray, gray[: H4K // 2]], axis=0))
+    dnv = torch.from_numpy(nv).cuda()
+    out = []
+
+    def row(name, gpu_ms, cpu_ms):
+        out.append({"config": name, "gpu_ms_per_call": round(gpu_ms, 4), "cpu_reference_ms_per_frame": round(cpu_ms, 3), "speedup": round(cpu_ms / gpu_ms, 1)})
+
+    row("f1 Canny 3840x2160 8UC1 (50,150)", g(lambda: cv.Canny(dgray, 50, 150)), t(lambda: orc.ref_Canny(gray, 50, 150)))
+    row("f1 medianBlur 5x5 3840x2160 8UC1", g(lambda: cv.medianBlur(dgray, 5)), t(lambda: orc.ref_medianBlur(gray, 5)))
+    row("f1 equalizeHist 3840x2160", g(lambda: cv.equalizeHist(dgray)), t(lambda: orc.ref_equalizeHist(gray)))
+    row("f1 threshold OTSU 3840x2160", g(lambda: cv.threshold(dgray, 0, 255, 8)), t(lambda: orc.ref_threshold(gray, 0, 255, 8)))
+    row("f4 NV12->BGR 3840x2160", g(lambda: cv.cvtColor(dnv, 91)), t(lambda: orc.ref_cvtColorYUV(nv, 91)))
+    row("f4 BGR->I420 3840x2160", g(lambda: cv.cvtColor(dbgr, 128)), t(lambda: orc.ref_cvtColorMisc(bgr, 128)))
+    row("f2 resize LANCZOS4 4K->2880x1620 8UC1", g(lambda: cv.resize(dgray, (2880, 1620), interpolation=4), 5), t(lambda: orc.ref_resize(gray, (2880, 1620), interpolation=4)))
+    # f3: sparse pyramidal LK, 1080p pair, 5000 points, 21x21 window, 4 levels
+    rng = np.random.default_rng(7)
+    smooth = orc.ref_GaussianBlur(orc.ref_GaussianBlur(hd, 5, 0, 0, 4), 5, 0, 0, 4)
+    nxt = np.ascontiguousarray(np.roll(smooth, (2, 3), axis=(0, 1)))
+    pts = (rng.random((5000, 2)) * [1900, 1060] + 10).astype(np.float32)
+    dprev, dnext, dpts = torch.from_numpy(smooth).cuda(), torch.from_numpy(nxt).cuda(), torch.from_numpy(pts).cuda()
+    row("f3 calcOpticalFlowPyrLK 1920x1080, 5000 pts, 21x21, maxLevel 3", g(lambda: cv.calcOpticalFlowPyrLK(dprev, dnext, dpts, None, (21, 21), 3), 5),
+        t(lambda: orc.ref_calcOpticalFlowPyrLK(smooth, nxt, pts, (21, 21), 3)))
+    return out
 
 
 def main():

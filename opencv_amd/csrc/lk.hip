@@ -13,6 +13,7 @@
 // addresses.
 #include "rt.h"
 #include <cfloat>
+#include <cstdlib>
 
 using namespace mi355;
 
@@ -184,6 +185,132 @@ __global__ __launch_bounds__(64) void k_lk_level(LkArgs a)
     }
 }
 
+// The same computation with ONE WAVE PER POINT.  Everything that is integer -- the bilinear samples, the differences, the products
+// It*Ix, It*Iy -- is order-free, so the 64 lanes produce it element-parallel into LDS; what must stay sequential are the float
+// accumulations, and there are only 15 (gradient matrix) / 10 (mismatch vector) independent chains of them: the four lanes of each of
+// the reference's vector accumulators and its scalar tails.  Each chain is walked by one lane in the reference's order, the others wait;
+// the combine step is computed redundantly by every lane so all of them hold the same A, b, delta and take the same branches.
+// LDS per point: 3 shorts + 2 ints per window element.
+__global__ __launch_bounds__(64) void k_lk_wave(LkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar lds[];
+    const int pt = blockIdx.x, lane = threadIdx.x;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float halfX = (a.winW - 1) * 0.5f, halfY = (a.winH - 1) * 0.5f;
+    const int cn = a.cn, cn2 = cn * 2, n = a.winW * cn, n8 = (n / 8) * 8, E = n * a.winH, nt = n - n8;
+    const bool level0 = a.status != nullptr;
+    int* bx = (int*)lds; int* by = bx + E;
+    float* res = (float*)(by + E);
+    short* Iw = (short*)(res + 16); short* gx = Iw + E; short* gy = gx + E;
+
+    const float px = a.prevPts[2 * pt] - halfX, py = a.prevPts[2 * pt + 1] - halfY;
+    const int ipx = cvFloorF(px), ipy = cvFloorF(py);
+    if (ipx < -a.winW || ipx >= a.width || ipy < -a.winH || ipy >= a.height) {
+        if (level0 && lane == 0) { a.status[pt] = 0; if (a.err) a.err[pt] = 0; }
+        return;
+    }
+    Wts w = weights(px - ipx, py - ipy);
+    for (int e = lane; e < E; e += 64) {
+        const int y = e / n, x = e - y * n;
+        const uchar* src = a.I + (long)(y + ipy) * a.stepI + (long)ipx * cn + x;
+        const short* ds = a.dI + (long)(y + ipy) * a.dstep + (long)ipx * cn2 + 2 * x;
+        Iw[e] = (short)descale(src[0] * w.w00 + src[cn] * w.w01 + src[a.stepI] * w.w10 + src[a.stepI + cn] * w.w11, 14 - 5);
+        gx[e] = (short)descale(ds[0] * w.w00 + ds[cn2] * w.w01 + ds[a.dstep] * w.w10 + ds[a.dstep + cn2] * w.w11, 14);
+        gy[e] = (short)descale(ds[1] * w.w00 + ds[cn2 + 1] * w.w01 + ds[a.dstep + 1] * w.w10 + ds[a.dstep + cn2 + 1] * w.w11, 14);
+    }
+    __syncthreads();
+    if (lane < 12) {                                                    // lane l of qA11 / qA12 / qA22: elements x = l, l+4, ... < n8 of every row
+        const int which = lane >> 2, l = lane & 3;
+        float q = 0;
+        for (int y = 0; y < a.winH; y++)
+            for (int x = l; x < n8; x += 4) {
+                const float fx = (float)gx[y * n + x], fy = (float)gy[y * n + x];
+                q = (which == 0 ? fx * fx : which == 1 ? fx * fy : fy * fy) + q;
+            }
+        res[lane] = q;
+    } else if (lane < 15) {                                             // the scalar tails
+        const int which = lane - 12;
+        float acc = 0;
+        for (int y = 0; y < a.winH; y++)
+            for (int x = n8; x < n; x++) {
+                const int ix = gx[y * n + x], iy = gy[y * n + x];
+                acc += (float)(which == 0 ? ix * ix : which == 1 ? ix * iy : iy * iy);
+            }
+        res[lane] = acc;
+    }
+    __syncthreads();
+    const float iA11 = res[12] + ((res[0] + res[2]) + (res[1] + res[3]));
+    const float iA12 = res[13] + ((res[4] + res[6]) + (res[5] + res[7]));
+    const float iA22 = res[14] + ((res[8] + res[10]) + (res[9] + res[11]));
+    const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = __fdiv_rn(A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12), (float)(2 * a.winW * a.winH));
+    if (a.err && a.getMinEig && lane == 0) a.err[pt] = minEig;
+    if (minEig < a.minEigThreshold || D < FLT_EPSILON) { if (level0 && lane == 0) a.status[pt] = 0; return; }
+    D = __fdiv_rn(1.f, D);
+    float nx = a.nextPts[2 * pt] - halfX, ny = a.nextPts[2 * pt + 1] - halfY, pdx = 0, pdy = 0;
+    float outx = a.nextPts[2 * pt], outy = a.nextPts[2 * pt + 1];
+    bool lost = false;
+    for (int j = 0; j < a.maxCount; j++) {
+        const int inx = cvFloorF(nx), iny = cvFloorF(ny);
+        if (inx < -a.winW || inx >= a.width || iny < -a.winH || iny >= a.height) { lost = true; break; }
+        w = weights(nx - inx, ny - iny);
+        __syncthreads();                                                // the chains of the previous iteration have finished reading bx / by / res
+        for (int e = lane; e < E; e += 64) {
+            const int y = e / n, x = e - y * n;
+            const int It = sampleJ(a.J + (long)(y + iny) * a.stepJ + (long)inx * cn + x, a.stepJ, cn, w) - Iw[e];
+            bx[e] = It * gx[e]; by[e] = It * gy[e];
+        }
+        __syncthreads();
+        if (lane < 8) {                                                 // qb0[0..3], qb1[0..3]: per 8-element group, products k and k+4 summed as ints first
+            const int* arr = (lane & 1) ? by : bx;
+            const int k = (lane >> 1) & 1, hi = lane >> 2;              // lane 0..3 -> qb0 (k = 0, 0, 1, 1), lane 4..7 -> qb1 (k = 2, 2, 3, 3)
+            const int off = hi * 2 + k;
+            float q = 0;
+            for (int y = 0; y < a.winH; y++)
+                for (int g = 0; g < n8; g += 8) q += (float)(arr[y * n + g + off] + arr[y * n + g + off + 4]);
+            res[lane] = q;
+        } else if (lane < 10) {
+            const int* arr = lane == 8 ? bx : by;
+            float acc = 0;
+            for (int y = 0; y < a.winH; y++)
+                for (int x = n8; x < n; x++) acc += (float)arr[y * n + x];
+            res[lane] = acc;
+        }
+        __syncthreads();
+        const float s0 = res[0] + res[4], s1 = res[1] + res[5], s2 = res[2] + res[6], s3 = res[3] + res[7];
+        const float ib1 = res[8] + (s0 + s2), ib2 = res[9] + (s1 + s3);
+        const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+        const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+        nx += dx; ny += dy;
+        outx = nx + halfX; outy = ny + halfY;
+        if ((double)dx * dx + (double)dy * dy <= a.epsilon) break;
+        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { outx -= dx * 0.5f; outy -= dy * 0.5f; break; }
+        pdx = dx; pdy = dy;
+    }
+    if (lane == 0) { a.nextPts[2 * pt] = outx; a.nextPts[2 * pt + 1] = outy; }
+    bool ok = level0 ? a.status[pt] != 0 : false;                       // read before lane 0 may clear it: every lane sees the incoming value
+    if (lost) { ok = false; if (level0 && lane == 0) a.status[pt] = 0; }
+    if (level0 && ok && a.err && !a.getMinEig) {
+        const float ex = outx - halfX, ey = outy - halfY;
+        const int iex = cvFloorF(ex), iey = cvFloorF(ey);
+        if (iex < -a.winW || iex >= a.width || iey < -a.winH || iey >= a.height) { if (lane == 0) a.status[pt] = 0; return; }
+        w = weights(ex - iex, ey - iey);
+        __syncthreads();
+        for (int e = lane; e < E; e += 64) {
+            const int y = e / n, x = e - y * n;
+            bx[e] = sampleJ(a.J + (long)(y + iey) * a.stepJ + (long)iex * cn + x, a.stepJ, cn, w) - Iw[e];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            float errval = 0.f;
+            for (int e = 0; e < E; e++) errval += fabsf((float)bx[e]);
+            a.err[pt] = __fdiv_rn(errval * 1.f, (float)(32 * a.winW * cn * a.winH));
+        }
+    }
+    (void)nt;
+}
+
 // host array that is read AND written by the kernel: device copy that finish() writes back
 template <typename T>
 T* inout(Stager& stg, T* host, size_t count)
@@ -255,9 +382,10 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
     float* dNext = inout(stg, next_points, point_count * 2);
     uchar* dStatus = inout(stg, status, point_count);
     float* dErr = inout(stg, err, point_count);
-    const size_t winShorts = (size_t)3 * win_width * cn * win_height;
-    short* win = (short*)stg.scratch(winShorts * point_count * sizeof(short));
-    if (!dPrev || !dNext || (status && !dStatus) || (err && !dErr) || !win) return MI355CV_NOT_IMPLEMENTED;
+    const size_t E = (size_t)win_width * cn * win_height, ldsBytes = E * 14 + 64;
+    const bool perWave = ldsBytes <= 48 * 1024 && !getenv("MI355CV_LK_THREAD_PER_POINT");
+    short* win = perWave ? nullptr : (short*)stg.scratch(3 * E * point_count * sizeof(short));
+    if (!dPrev || !dNext || (status && !dStatus) || (err && !dErr) || (!perWave && !win)) return MI355CV_NOT_IMPLEMENTED;
     LkArgs a;
     a.I = dI + (size_t)win_height * sI + (size_t)win_width * cn; a.stepI = (long)sI;
     a.dI = (const short*)(dD + (size_t)win_height * sD + (size_t)win_width * cn * 4); a.dstep = (long)(sD / 2);
@@ -265,7 +393,8 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
     a.width = width; a.height = height; a.cn = cn; a.winW = win_width; a.winH = win_height; a.maxCount = termination_count; a.getMinEig = get_min_eigen_vals ? 1 : 0;
     a.epsilon = termination_epsilon; a.minEigThreshold = min_eigen_vals_threshold;
     a.prevPts = dPrev; a.nextPts = dNext; a.status = dStatus; a.err = dErr; a.npts = (int)point_count; a.win = win;
-    hipLaunchKernelGGL(k_lk_level, dim3(divUp((int)point_count, 64)), dim3(64), 0, stream(), a);
+    if (perWave) hipLaunchKernelGGL(k_lk_wave, dim3((unsigned)point_count), dim3(64), ldsBytes, stream(), a);
+    else hipLaunchKernelGGL(k_lk_level, dim3(divUp((int)point_count, 64)), dim3(64), 0, stream(), a);
     return stg.finish("LKOpticalFlowLevel");
 }
 

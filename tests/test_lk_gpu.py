@@ -74,6 +74,14 @@ def test_device_resident(cv, orc, cn, win):
     assert 0 < want[1].sum() < len(p)
 
 
+def test_large_window_takes_the_thread_per_point_kernel(cv, orc):
+    """61x61x3 windows need more LDS than the wave-per-point kernel may use: the one-thread-per-point kernel serves them"""
+    A, B = frames(200, 260, 3, 21)
+    p = points(200, 260, 150, 4)
+    got = cv.calcOpticalFlowPyrLK(dev(A), dev(B), dev(p), None, (61, 61), 1)
+    same(tuple(g.cpu().numpy() for g in got), orc.orc_calcOpticalFlowPyrLK(A, B, p, (61, 61), 1), "61x61x3")
+
+
 def test_flags_and_criteria(cv, orc):
     A, B = frames(200, 260, 1, 9, shift=(5.2, 3.1))
     p = points(200, 260, 250, 6)
