@@ -188,8 +188,10 @@ extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step,
     // passes are chained through one flag each: a pass that finds the flag of its predecessor clear returns at once, so a burst of
     // PASSES launches costs little once the map has converged, and the host looks at the last flag only
     constexpr int PASSES = 8;
-    const int maxRounds = (4 * (int)(hgrid.x + hgrid.y)) / PASSES + 8;               // far more than any chain needs
-    for (int round = 0; round < maxRounds; round++) {
+    // every productive pass promotes at least one candidate, so the number of passes is bounded by the number of pixels; a chain that
+    // winds through the tiles (a spiral) really does need one pass per tile crossing
+    const long long maxRounds = ((long long)width * height) / PASSES + 2;
+    for (long long round = 0; round < maxRounds; round++) {
         if (hipMemsetAsync(flag, 0, PASSES * sizeof(int), st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
         for (int k = 0; k < PASSES; k++)
             hipLaunchKernelGGL(k_canny_hyst, hgrid, dim3(256), 0, st, map, pitch, width, height, k ? flag + k - 1 : (const int*)nullptr, flag + k);
