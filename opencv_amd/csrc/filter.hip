@@ -444,6 +444,9 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (p.mode == 2 && c.ddepth == D16S && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 && p.deltaI == 0 &&
         fullW == W && fullH == H && seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, c.border, stream()))
         return stg.finish(entry);
+    if (p.mode == 1 && c.sdepth == D8U && c.ddepth == D8U && p.nx == p.ny && p.ny > 1 && p.ax == p.nx / 2 && p.ay == p.ny / 2 && fullW == W && fullH == H &&
+        seprollFix8U(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, p.deltaF, c.border, stream()))
+        return stg.finish(entry);
     if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 &&
         fullW == W && fullH == H &&
         seprollFloat(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))

@@ -17,6 +17,9 @@ bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
 
 // u8 -> s16 separable filter with small integer taps (cv::Sobel / cv::Scharr with scale 1, delta 0): n in {3,5}, cn in {1,3,4},
 // every intermediate and result within int16.
+// sepFilter2D 8U -> 8U with integer (x 2^8) smooth symmetric taps, the reference's float column pass; rows of a multiple of 16 elements only
+bool seprollFix8U(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, int cn, const int* kx, const int* ky, int n, float delta, int border, hipStream_t st);
 bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                     int W, int H, int cn, const int* kx, const int* ky, int n, int border, hipStream_t st);
 

@@ -140,6 +140,56 @@ struct FixedSmooth {
 };
 
 
+// ---------------------------------------------------------------------------------- sepFilter2D 8U -> 8U, "bit-exact" integer taps
+// cv::sepFilter2D with smooth symmetric kernels whose taps are multiples of 1/256 (createSeparableLinearFilter's fixed-point branch,
+// filter.dispatch.cpp:305-420): integer row sums (taps * 2^8), and a column pass that the reference's AVX2 build evaluates in FLOAT for
+// every element its 16-lane loop reaches (SymmColumnVec_32s8u filter.simd.hpp:1011-1085): s = fma(S_c, k_c 2^-16, delta),
+// s = fma(S_{c+k} + S_{c-k}, k_{c+k} 2^-16, s), rounded half-even and saturated.  Rows whose length is a multiple of 16 elements have no
+// scalar tail, which is the only case this policy is launched for.  Row sums are the packed u16 pairs of FixedSmooth (taps >= 0, sum <= 256).
+template <int K, int CN_>
+struct SepFix8U {
+    static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr int HD = roll::Cfg<R, CN>::HD;
+    struct Args { uint32_t kx[K]; float ky[K]; float delta; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
+    struct Inter { uint32_t e[4], o[4]; };
+    template <int Q, int I>
+    static __device__ __forceinline__ uint32_t hsum(const uint32_t* E, const uint32_t* O, int k, const Args& a)
+    {
+        const uint32_t v = roll::pairAt<Q, (I - R) * CN, HD>(E, O, k);
+        if constexpr (I == 0) return __umul24(v, a.kx[0]);
+        else {
+            const uint32_t acc = hsum<Q, I - 1>(E, O, k, a);
+            uint32_t d;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(v), "s"(a.kx[I]), "v"(acc));
+            return d;
+        }
+    }
+    static __device__ __forceinline__ void hpass(Inter& o, const uint32_t* E, const uint32_t* O, const Args& a)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o.e[k] = hsum<0, K - 1>(E, O, k, a); o.o[k] = hsum<1, K - 1>(E, O, k, a); }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };     // image row t of the window
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t o4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                    // output bytes 4k+q = (E.lo, O.lo, E.hi, O.hi)
+                auto at = [&](int t) -> uint32_t { const uint32_t w = (q & 1) ? row(t).o[k] : row(t).e[k]; return (q & 2) ? (w >> 16) : (w & 0xffffu); };
+                float sF = __builtin_fmaf((float)at(R), a.ky[R], a.delta);
+#pragma unroll
+                for (int d = 1; d <= R; d++) sF = __builtin_fmaf((float)(at(R + d) + at(R - d)), a.ky[R + d], sF);
+                o4 = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(sF), q, o4);
+            }
+            out[k] = o4;
+        }
+    }
+};
+
 // take byte 3 of four 32-bit values -> one dword
 __device__ __forceinline__ uint32_t packB3(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
 {
@@ -364,6 +414,25 @@ bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* ds
     switch (nx) { case 3: FSK(3); break; case 5: FSK(5); break; case 7: FSK(7); break; default: FSK(9); }
 #undef FSK
 #undef FS
+    return true;
+}
+
+bool seprollFix8U(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, int cn, const int* kx, const int* ky, int n, float delta, int border, hipStream_t st)
+{
+    if ((n != 3 && n != 5) || !(cn == 1 || cn == 3 || cn == 4) || ((size_t)W * cn) % 16 != 0) return false;
+    int sx = 0;
+    for (int i = 0; i < n; i++) { if (kx[i] < 0) return false; sx += kx[i]; }
+    if (sx > 256) return false;
+    for (int i = 0; i < n / 2; i++) if (ky[i] != ky[n - 1 - i]) return false;              // the pair form needs a symmetric column kernel
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, n / 2, border)) return false;
+#define FX(K_, CN_) do { typedef SepFix8U<K_, CN_> P; P::Args a; \
+        for (int i = 0; i < K_; i++) { a.kx[i] = (uint32_t)kx[i]; a.ky[i] = (float)ky[i] * (1.0f / 65536.0f); } a.delta = delta; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+#define FXK(K_) do { if (cn == 1) FX(K_, 1); else if (cn == 3) FX(K_, 3); else FX(K_, 4); } while (0)
+    if (n == 3) FXK(3); else FXK(5);
+#undef FXK
+#undef FX
     return true;
 }
 

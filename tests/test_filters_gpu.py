@@ -156,6 +156,21 @@ def test_sepfilter_modes(cv, orc):
         check(cv.sepFilter2D(dev(srcf), -1, kx, ky, (2, 1), 0.1, border), orc.orc_sepFilter2D(srcf, -1, kx, ky, (2, 1), 0.1, border))
 
 
+def test_sepfilter_fixed_point_rolling(cv, orc):
+    """8U -> 8U with taps that are multiples of 1/256 (the reference's integer row pass + float column pass): rows of a multiple of 16
+    elements run on the rolling kernel, the others (scalar tail in the reference) on the generic one; both bit-exact"""
+    taps = [[0.25, 0.5, 0.25], [0.125, 0.75, 0.125], [0.0625, 0.25, 0.375, 0.25, 0.0625], [0.0, 0.5, 0.0, 0.5, 0.0][:5]]
+    for cn in (1, 3, 4):
+        for (w, h) in [(64, 23), (1040, 37), (336, 19), (330, 11)]:
+            src = rnd((h, w, cn) if cn > 1 else (h, w), np.uint8, w + cn)
+            for k in taps:
+                for dl in (0.0, 3.0):
+                    for border in (0, 1, 2, 4):
+                        check(cv.sepFilter2D(dev(src), -1, k, k, (-1, -1), dl, border), orc.orc_sepFilter2D(src, -1, k, k, (-1, -1), dl, border))
+    big = rnd((2160, 3840), np.uint8, 5)
+    check(cv.sepFilter2D(dev(big), -1, taps[0], taps[0]), orc.orc_sepFilter2D(big, -1, taps[0], taps[0]))
+
+
 @pytest.mark.parametrize("ksize", [1, 3, 5, 7, -1])
 def test_sobel_scharr(cv, orc, ksize):
     src8 = rnd((33, 70), np.uint8, 3)
