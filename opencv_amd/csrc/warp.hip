@@ -15,6 +15,9 @@
 //   remap    RemapInvoker imgwarp.cpp:1130-: 32F maps -> cvRound(map*32) -> same sampler.
 // All kernels are gather-bound: one thread per output pixel (all channels), reads through L1/L2.
 #include "rt.h"
+#include <type_traits>
+#include <map>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -479,6 +482,129 @@ void buildLanczosTab(int dsize, double scale, std::vector<LanczosTap>& tab)
     }
 }
 
+// The separable form of the two kernels above for tiles of 64 x 16 output elements: the horizontal sums of every source row a tile
+// needs are computed ONCE into LDS (they are exactly the S_k of the per-output kernels, same tap order), then each output combines NT of
+// them vertically with the reference's body / tail formulas.  A 2x cubic upscale goes from 16 gathers + 20 MACs per output to about 3 + 7.
+// The host checks that no tile needs more than RMAX source rows (strong minification does; it stays on the per-output kernels).
+template <int NT> struct TapT { int s; float f[NT]; short i[NT]; };      // layout of CubicTap (NT = 4) and LanczosTap (NT = 8)
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
+                                                      const TapT<NT>* __restrict__ xt, const TapT<NT>* __restrict__ yt)
+{
+    constexpr int TW = 64, TH = 16, OFF = NT / 2 - 1;
+    typedef typename std::conditional<sizeof(T) == 1, int, float>::type HT;
+    extern __shared__ __attribute__((aligned(16))) uchar ldsRaw[];
+    HT* H = reinterpret_cast<HT*>(ldsRaw);
+    const int width = dw * cn;
+    const int lx = threadIdx.x & 63, e = blockIdx.x * TW + lx;
+    const int dy0 = blockIdx.y * TH, dyLast = min(dy0 + TH, dh) - 1;
+    const int rmin = yt[dy0].s - OFF, R = yt[dyLast].s - OFF + NT - 1 - rmin + 1;
+    if (e < width) {
+        const int dx = e / cn, c = e - dx * cn;
+        const TapT<NT> tx = xt[dx];
+        int xs[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) xs[j] = clipI(tx.s - OFF + j, 0, sw) * cn + c;
+        for (int r = threadIdx.x >> 6; r < R; r += 4) {
+            const uchar* rowp = src + (size_t)clipI(rmin + r, 0, sh) * sstep;
+            if (sizeof(T) == 1) {
+                int v = 0;
+#pragma unroll
+                for (int j = 0; j < NT; j++) v += rowp[xs[j]] * tx.i[j];
+                H[r * TW + lx] = (HT)v;
+            } else {
+                const float* Rf = reinterpret_cast<const float*>(rowp);
+                float v = __fmul_rn(Rf[xs[0]], tx.f[0]);
+#pragma unroll
+                for (int j = 1; j < NT; j++) v = __fadd_rn(v, __fmul_rn(Rf[xs[j]], tx.f[j]));
+                H[r * TW + lx] = (HT)v;
+            }
+        }
+    }
+    __syncthreads();
+    if (e >= width) return;
+#pragma unroll
+    for (int k4 = 0; k4 < TH / 4; k4++) {
+        const int dy = dy0 + (threadIdx.x >> 6) + 4 * k4;
+        if (dy >= dh) continue;
+        const TapT<NT> ty = yt[dy];
+        const HT* S = H + (ty.s - OFF - rmin) * TW + lx;                // S[k * TW] = horizontal sum of window row k
+        if (sizeof(T) == 1) {
+            int r;
+            if (NT == 4 && e < (width / 8) * 8) {                       // VResizeCubicVec_32s8u: float, taps * 2^-22, nested from the last row
+                const float sc = 1.f / (2048.f * 2048.f);
+                float t = __fmul_rn((float)S[3 * TW], __fmul_rn((float)ty.i[3], sc));
+                t = __fadd_rn(__fmul_rn((float)S[2 * TW], __fmul_rn((float)ty.i[2], sc)), t);
+                t = __fadd_rn(__fmul_rn((float)S[1 * TW], __fmul_rn((float)ty.i[1], sc)), t);
+                t = __fadd_rn(__fmul_rn((float)S[0], __fmul_rn((float)ty.i[0], sc)), t);
+                r = __float2int_rn(t);
+            } else {
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < NT; k++) acc += (int)S[k * TW] * ty.i[k];
+                r = (acc + (1 << 21)) >> 22;
+            }
+            (dst + (size_t)dy * dstep)[e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+        } else {
+            float r;
+            if (e < (width / 4) * 4) {
+                r = __fmul_rn((float)S[(NT - 1) * TW], ty.f[NT - 1]);
+#pragma unroll
+                for (int k = NT - 2; k >= 0; k--) r = __fadd_rn(__fmul_rn((float)S[k * TW], ty.f[k]), r);
+            } else {
+                r = __fmul_rn((float)S[0], ty.f[0]);
+#pragma unroll
+                for (int k = 1; k < NT; k++) r = __fadd_rn(r, __fmul_rn((float)S[k * TW], ty.f[k]));
+            }
+            reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+        }
+    }
+}
+
+// rows of LDS the tiled kernel needs for the tallest tile, or 0 when that exceeds what it may use
+template <class Tab> int tiledRows(const std::vector<Tab>& yt, int nt)
+{
+    int mx = 0;
+    const int dh = (int)yt.size();
+    for (int dy0 = 0; dy0 < dh; dy0 += 16) mx = std::max(mx, yt[(size_t)std::min(dy0 + 16, dh) - 1].s - yt[(size_t)dy0].s + nt);
+    static const bool off = getenv("MI355CV_RESIZE_TILED") && atoi(getenv("MI355CV_RESIZE_TILED")) == 0;
+    return (mx <= 64 && !off) ? mx : 0;
+}
+
+// Tap tables depend on (interpolation, destination length, scale) only, and building one costs more host time than the kernel that uses
+// it takes (Lanczos: two libm calls and eight divisions per entry, 0.2 ms for a 4K axis): keep the most recent ones resident in HBM.
+struct TabKey { int kind, n; double scale; bool operator<(const TabKey& o) const { return kind != o.kind ? kind < o.kind : n != o.n ? n < o.n : scale < o.scale; } };
+template <class Tab> struct TabEntry { const Tab* dev; int rows; unsigned long long stamp; };
+template <class Tab, class Build>
+bool cachedTab(int kind, int n, double scale, int nt, Build build, const Tab** dev, int* tileRows)
+{
+    static std::mutex mu;
+    static std::map<TabKey, TabEntry<Tab>> cache;
+    static unsigned long long clock = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    const TabKey key{kind, n, scale};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 32) {                                           // evict the least recently used table (stream order: no kernel
+            auto old = cache.begin();                                       // still reads it once the device is idle)
+            for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+            (void)hipDeviceSynchronize();
+            (void)hipFree(const_cast<Tab*>(old->second.dev));
+            cache.erase(old);
+        }
+        std::vector<Tab> host;
+        build(n, scale, host);
+        void* d = nullptr;
+        if (hipMalloc(&d, host.size() * sizeof(Tab)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemcpy(d, host.data(), host.size() * sizeof(Tab), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return false; }
+        it = cache.emplace(key, TabEntry<Tab>{(const Tab*)d, tiledRows(host, nt), 0}).first;
+    }
+    it->second.stamp = ++clock;
+    *dev = it->second.dev; *tileRows = it->second.rows;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -797,26 +923,28 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
-    if (a.mode == 5) {
-        std::vector<CubicTap> xt, yt;
-        buildCubicTab(dst_width, a.scale_x, xt); buildCubicTab(dst_height, a.scale_y, yt);
-        const CubicTap* dxt = (const CubicTap*)stg.param(xt.data(), xt.size() * sizeof(CubicTap));
-        const CubicTap* dyt = (const CubicTap*)stg.param(yt.data(), yt.size() * sizeof(CubicTap));
-        if (!dxt || !dyt) return MI355CV_NOT_IMPLEMENTED;
-        dim3 g5(divUp(dst_width * cn, 64), divUp(dst_height, 4));
-        if (depth == D8U) hipLaunchKernelGGL(k_resize_cubic<uchar>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
-        else hipLaunchKernelGGL(k_resize_cubic<float>, g5, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
-        return stg.finish("resize");
-    }
-    if (a.mode == 6) {
-        std::vector<LanczosTap> xt, yt;
-        buildLanczosTab(dst_width, a.scale_x, xt); buildLanczosTab(dst_height, a.scale_y, yt);
-        const LanczosTap* dxt = (const LanczosTap*)stg.param(xt.data(), xt.size() * sizeof(LanczosTap));
-        const LanczosTap* dyt = (const LanczosTap*)stg.param(yt.data(), yt.size() * sizeof(LanczosTap));
-        if (!dxt || !dyt) return MI355CV_NOT_IMPLEMENTED;
-        dim3 g6(divUp(dst_width * cn, 64), divUp(dst_height, 4));
-        if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g6, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
-        else hipLaunchKernelGGL(k_resize_lanczos<float>, g6, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+    if (a.mode == 5 || a.mode == 6) {
+        dim3 gt(divUp(dst_width * cn, 64), divUp(dst_height, 16)), g1(divUp(dst_width * cn, 64), divUp(dst_height, 4));
+        int rows = 0, unused = 0;
+        if (a.mode == 5) {
+            const CubicTap *dxt, *dyt;
+            if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows))
+                return MI355CV_NOT_IMPLEMENTED;
+            const TapT<4>* tx = reinterpret_cast<const TapT<4>*>(dxt); const TapT<4>* ty = reinterpret_cast<const TapT<4>*>(dyt);
+            if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 4>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
+            else if (rows) hipLaunchKernelGGL((k_resize_tiled<float, 4>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
+            else if (depth == D8U) hipLaunchKernelGGL(k_resize_cubic<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+            else hipLaunchKernelGGL(k_resize_cubic<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        } else {
+            const LanczosTap *dxt, *dyt;
+            if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows))
+                return MI355CV_NOT_IMPLEMENTED;
+            const TapT<8>* tx = reinterpret_cast<const TapT<8>*>(dxt); const TapT<8>* ty = reinterpret_cast<const TapT<8>*>(dyt);
+            if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 8>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
+            else if (rows) hipLaunchKernelGGL((k_resize_tiled<float, 8>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
+            else if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+            else hipLaunchKernelGGL(k_resize_lanczos<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+        }
         return stg.finish("resize");
     }
     if (a.mode == 4) {

@@ -83,6 +83,9 @@ def test_resize_cubic(cv, orc, dtype, cn):
         for dsize in dsizes:
             got = cv.resize(dev(src), dsize, interpolation=2).cpu().numpy()
             assert np.array_equal(got, orc.orc_resize(src, dsize, interpolation=2)), (w, h, dsize, dtype, cn)
+    big = rnd((480, 640, cn) if cn > 1 else (480, 640), dtype, 3)
+    for dsize in [(64, 48), (700, 31)]:                               # strong minification: the per-output kernel (a tile would need > 64 source rows)
+        assert np.array_equal(cv.resize(dev(big), dsize, interpolation=2).cpu().numpy(), orc.orc_resize(big, dsize, interpolation=2)), (dsize, dtype, cn)
     with pytest.raises(NotImplementedError):
         cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=2)
 
@@ -96,6 +99,9 @@ def test_resize_lanczos4(cv, orc, dtype, cn):
         for dsize in dsizes:
             got = cv.resize(dev(src), dsize, interpolation=4).cpu().numpy()
             assert np.array_equal(got, orc.orc_resize(src, dsize, interpolation=4)), (w, h, dsize, dtype, cn)
+    big = rnd((480, 640, cn) if cn > 1 else (480, 640), dtype, 4)
+    for dsize in [(64, 48), (700, 31)]:
+        assert np.array_equal(cv.resize(dev(big), dsize, interpolation=4).cpu().numpy(), orc.orc_resize(big, dsize, interpolation=4)), (dsize, dtype, cn)
     with pytest.raises(NotImplementedError):
         cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=4)
 
