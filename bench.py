@@ -161,6 +161,30 @@ def next_rows(orc, t, gray, bgr, hd):
     dprev, dnext, dpts = torch.from_numpy(smooth).cuda(), torch.from_numpy(nxt).cuda(), torch.from_numpy(pts).cuda()
     row("f3 calcOpticalFlowPyrLK 1920x1080, 5000 pts, 21x21, maxLevel 3", g(lambda: cv.calcOpticalFlowPyrLK(dprev, dnext, dpts, None, (21, 21), 3), 5),
         t(lambda: orc.ref_calcOpticalFlowPyrLK(smooth, nxt, pts, (21, 21), 3)))
+    # the tracking front end as one pipeline on a 1080p NV12 frame pair: decode -> gray -> Gaussian 5x5 -> goodFeaturesToTrack(1000) on the
+    # previous frame -> pyramidal LK into the current one.  GPU: every image stays in HBM (only the corner list crosses PCIe, as in cv::).
+    bgr0 = np.ascontiguousarray(np.stack([smooth, np.roll(smooth, 5, 1), np.roll(smooth, 9, 0)], axis=-1))
+    bgr1 = np.ascontiguousarray(np.roll(bgr0, (2, 3), axis=(0, 1)))
+    nv0, nv1 = orc.ref_cvtBGRtoTwoPlaneYUV(bgr0, 0, 1), orc.ref_cvtBGRtoTwoPlaneYUV(bgr1, 0, 1)
+    dnv0, dnv1 = torch.from_numpy(nv0).cuda(), torch.from_numpy(nv1).cuda()
+    ntracked = {}
+
+    def pipe_gpu():
+        g0 = cv.GaussianBlur(cv.cvtColor(cv.cvtColor(dnv0, 91), 6), (5, 5), 0)
+        g1 = cv.GaussianBlur(cv.cvtColor(cv.cvtColor(dnv1, 91), 6), (5, 5), 0)
+        c = cv.goodFeaturesToTrack(g0, 1000, 0.01, 10)
+        _, st, _ = cv.calcOpticalFlowPyrLK(g0, g1, torch.from_numpy(c).cuda(), None, (21, 21), 3)
+        ntracked["gpu"] = int(st.sum())
+
+    def pipe_cpu():
+        g0 = orc.ref_GaussianBlur(orc.ref_cvtColor(orc.ref_cvtColorYUV(nv0, 91), 6, 1), 5, 0, 0, 4)
+        g1 = orc.ref_GaussianBlur(orc.ref_cvtColor(orc.ref_cvtColorYUV(nv1, 91), 6, 1), 5, 0, 0, 4)
+        c = orc.ref_goodFeaturesToTrack(g0, 1000, 0.01, 10)
+        _, st, _ = orc.ref_calcOpticalFlowPyrLK(g0, g1, c, (21, 21), 3)
+        ntracked["cpu"] = int(st.sum())
+
+    row("f3 pipeline 1920x1080: 2x(NV12->BGR->GRAY->Gaussian5x5), goodFeaturesToTrack(1000), calcOpticalFlowPyrLK", g(pipe_gpu, 5), t(pipe_cpu))
+    out[-1]["tracked_gpu_cpu"] = [ntracked.get("gpu"), ntracked.get("cpu")]
     return out
 
 

@@ -70,6 +70,31 @@ __global__ __launch_bounds__(256) void k_lut_u8(const uchar* __restrict__ src, s
     for (int k = 0; k < 4; k++) if (x4 + k < W) d[k] = t[s[k]];
 }
 
+// the cumulative table of cv::equalizeHist (histogram.cpp:3472-3489) from the 256-bin histogram, one wave, bin i on lane i % 64: the
+// integer prefix sums are exact in any order, the float scale and the cvRound are single IEEE operations, so this equals the host loop
+__global__ __launch_bounds__(64) void k_equalize_lut(const unsigned* __restrict__ hist, int total, uchar* __restrict__ lut)
+{
+    __shared__ unsigned h[256];
+    __shared__ int first;
+    for (int i = threadIdx.x; i < 256; i += 64) h[i] = hist[i];
+    if (threadIdx.x == 0) first = 256;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) if (h[i]) atomicMin(&first, i);
+    __syncthreads();
+    const int i0 = first;
+    if ((int)h[i0] == total) { for (int i = threadIdx.x; i < 256; i += 64) lut[i] = (uchar)i0; return; }        // dst.setTo(i)
+    const float scale = __fdiv_rn(255.f, (float)(total - (int)h[i0]));
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int i = 0; i <= i0; i++) lut[i] = 0;
+        for (int i = i0 + 1; i < 256; i++) {
+            sum += (int)h[i];
+            const int r = __float2int_rn((float)sum * scale);
+            lut[i] = (uchar)min(max(r, 0), 255);
+        }
+    }
+}
+
 // histogram of a device-resident image into `host` (nbins entries); synchronises the stream
 bool histogramToHost(Stager& stg, const uchar* ds, size_t dss, int width, int height, int depth, std::vector<int>& host)
 {
@@ -103,25 +128,15 @@ MI355CV_API int mi355cv_equalize_hist(const uchar* src_data, size_t src_step, uc
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
-    std::vector<int> hist;
-    if (!histogramToHost(stg, ds, dss, width, height, MI355CV_8U, hist)) return MI355CV_ERROR_UNKNOWN;
-    // histogram.cpp:3472-3489
-    uchar lut[256] = {0};
-    int i = 0;
-    while (!hist[i]) ++i;
-    const int total = width * height;
-    if (hist[i] == total) for (int k = 0; k < 256; k++) lut[k] = (uchar)i;           // dst.setTo(i)
-    else {
-        const float scale = (256 - 1.f) / (total - hist[i]);
-        int sum = 0;
-        for (lut[i++] = 0; i < 256; ++i) {
-            sum += hist[i];
-            const long r = lrintf(sum * scale);
-            lut[i] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
-        }
-    }
-    const uchar* dl = (const uchar*)stg.param(lut, sizeof lut);
-    if (!dl) return MI355CV_NOT_IMPLEMENTED;
+    // histogram -> table -> per-pixel pass, all in stream order: no host round trip, so the hook stays asynchronous for images in HBM
+    unsigned* dh = (unsigned*)stg.scratch(256 * 4);
+    uchar* dl = (uchar*)stg.scratch(256);
+    if (!dh || !dl) return MI355CV_NOT_IMPLEMENTED;
+    hipStream_t st = stream();
+    if (hipMemsetAsync(dh, 0, 256 * 4, st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
+    const int rowsPerBlock = std::max(1, divUp(height, 512));
+    hipLaunchKernelGGL(k_hist_u8, dim3(divUp(height, rowsPerBlock)), dim3(256), 0, st, ds, dss, width, height, rowsPerBlock, dh);
+    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(64), 0, st, dh, width * height, dl);
     hipLaunchKernelGGL(k_lut_u8, dim3(divUp(divUp(width, 4), 64), divUp(height, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, width, height, dl);
     return stg.finish("equalize_hist");
 }
