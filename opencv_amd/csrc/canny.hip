@@ -27,12 +27,13 @@ constexpr int TW = 64, TH = 16;                      // output tile of one 256-t
 __global__ __launch_bounds__(256) void k_canny_magnms(const short* __restrict__ dx, const short* __restrict__ dy, size_t gstepS /*shorts*/, int W, int H, int cn,
                                                       int L2, int low, int high, uchar* __restrict__ map, size_t pitch)
 {
-    __shared__ int smag[TH + 2][TW + 2];
-    __shared__ short sgx[TH][TW], sgy[TH][TW];
+    // row stride 67 dwords: the four tile rows a wave works on (16 lanes each, 4 dwords apart) then fall into 64 different LDS banks
+    __shared__ int smag[TH + 2][TW + 3];
+    __shared__ int sg[TH][TW + 3];                                          // (gx, gy) of the chosen channel, packed low / high half
     const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
     auto put = [&](int ly, int lx, int bm, int bx, int by) {
         smag[ly][lx] = bm;                                                  // outside the image: 0 (canny.cpp:390-, the zeroed border rows / columns)
-        if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) { sgx[ly - 1][lx - 1] = (short)bx; sgy[ly - 1][lx - 1] = (short)by; }
+        if (lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) sg[ly - 1][lx - 1] = (int)(((unsigned)bx & 0xffffu) | ((unsigned)by << 16));
     };
     auto one = [&](int ly, int lx) {
         const int gx = X0 + lx - 1, gy = Y0 + ly - 1;
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(256) void k_canny_magnms(const short* __restrict__ 
         const int m = smag[ly + 1][lx + 1];
         bool keep = false;
         if (m > low) {
-            const int xs = sgx[ly][lx], ys = sgy[ly][lx];
+            const int gxy = sg[ly][lx];
+            const int xs = (short)(gxy & 0xffff), ys = gxy >> 16;
             const int ax = abs(xs), ay = abs(ys) << 15;
             const int tg22x = ax * 13573;                                   // tan(22.5 deg) * 2^15
             if (ay < tg22x) keep = m > smag[ly + 1][lx] && m >= smag[ly + 1][lx + 2];
