@@ -84,15 +84,17 @@ __global__ __launch_bounds__(64) void k_equalize_lut(const unsigned* __restrict_
     const int i0 = first;
     if ((int)h[i0] == total) { for (int i = threadIdx.x; i < 256; i += 64) lut[i] = (uchar)i0; return; }        // dst.setTo(i)
     const float scale = __fdiv_rn(255.f, (float)(total - (int)h[i0]));
-    if (threadIdx.x == 0) {
+    __shared__ __attribute__((aligned(4))) uchar l[256];
+    if (threadIdx.x == 0) {                                                 // 255 dependent integer adds: run them against LDS, not HBM
         int sum = 0;
-        for (int i = 0; i <= i0; i++) lut[i] = 0;
+        for (int i = 0; i <= i0; i++) l[i] = 0;
         for (int i = i0 + 1; i < 256; i++) {
             sum += (int)h[i];
-            const int r = __float2int_rn((float)sum * scale);
-            lut[i] = (uchar)min(max(r, 0), 255);
+            l[i] = (uchar)min(max(__float2int_rn((float)sum * scale), 0), 255);
         }
     }
+    __syncthreads();
+    reinterpret_cast<unsigned*>(lut)[threadIdx.x] = reinterpret_cast<const unsigned*>(l)[threadIdx.x];
 }
 
 // histogram of a device-resident image into `host` (nbins entries); synchronises the stream
