@@ -126,6 +126,25 @@
 #undef  cv_hal_threshold_otsu
 #define cv_hal_threshold_otsu mi355cv_threshold_otsu   // :1077
 
+// the *Approx variants (hal_replacement.hpp:516, :549, :681, :722, :780, :814, :851, :881) are offered first when the caller passes
+// ALGO_HINT_APPROX and "allow approximations"; the exact kernels qualify, so the same entry points serve them
+#undef  cv_hal_cvtBGRtoYUVApprox
+#define cv_hal_cvtBGRtoYUVApprox mi355cv_cvtBGRtoYUV
+#undef  cv_hal_cvtYUVtoBGRApprox
+#define cv_hal_cvtYUVtoBGRApprox mi355cv_cvtYUVtoBGR
+#undef  cv_hal_cvtTwoPlaneYUVtoBGRApprox
+#define cv_hal_cvtTwoPlaneYUVtoBGRApprox mi355cv_cvtTwoPlaneYUVtoBGR
+#undef  cv_hal_cvtTwoPlaneYUVtoBGRExApprox
+#define cv_hal_cvtTwoPlaneYUVtoBGRExApprox mi355cv_cvtTwoPlaneYUVtoBGREx
+#undef  cv_hal_cvtThreePlaneYUVtoBGRApprox
+#define cv_hal_cvtThreePlaneYUVtoBGRApprox mi355cv_cvtThreePlaneYUVtoBGR
+#undef  cv_hal_cvtBGRtoThreePlaneYUVApprox
+#define cv_hal_cvtBGRtoThreePlaneYUVApprox mi355cv_cvtBGRtoThreePlaneYUV
+#undef  cv_hal_cvtOnePlaneYUVtoBGRApprox
+#define cv_hal_cvtOnePlaneYUVtoBGRApprox mi355cv_cvtOnePlaneYUVtoBGR
+#undef  cv_hal_cvtOnePlaneBGRtoYUVApprox
+#define cv_hal_cvtOnePlaneBGRtoYUVApprox mi355cv_cvtOnePlaneBGRtoYUV
+
 // modules/video/src/hal_replacement.hpp:54, :84 / callers lkpyramid.cpp:233, :67.  The video module includes the same
 // custom_hal.hpp as imgproc, after its own hal_ni_* stubs
 #undef  cv_hal_LKOpticalFlowLevel

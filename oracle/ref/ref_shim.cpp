@@ -201,6 +201,15 @@ int ref_cvtColorSz(const void* s, size_t ss, int sw, int sh, int stype, void* d,
     REF_END(dst, d)
 }
 
+// same with ALGO_HINT_APPROX: the HAL build then goes through the cv_hal_*Approx hooks first (color_yuv.dispatch.cpp:28-31 etc.)
+int ref_cvtColorApprox(const void* s, size_t ss, int sw, int sh, int stype, void* d, size_t ds, int dw, int dh, int dtype, int code)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, stype), dst = M(d, ds, dw, dh, dtype);
+    cv::cvtColor(src, dst, code, CV_MAT_CN(dtype), cv::ALGO_HINT_APPROX);
+    REF_END(dst, d)
+}
+
 int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, int h, double maxValue, int method, int ttype, int blockSize, double C)
 {
     REF_TRY

@@ -925,3 +925,11 @@ def ref_calcOpticalFlowPyrLK(prev, nxt, pts, winSize=(21, 21), maxLevel=3, crit=
                                     maxLevel, crit[0], crit[1], ctypes.c_double(crit[2]), flags, ctypes.c_double(minEig))
     assert rc == 0, rc
     return out, status, err
+
+
+def ref_cvtColorApprox(src, code, dst):
+    """cv::cvtColor(..., ALGO_HINT_APPROX) into a preallocated dst of the right shape"""
+    r = load_ref()
+    rc = r.ref_cvtColorApprox(P(src), step(src), src.shape[1], src.shape[0], cvtype(src), P(dst), step(dst), dst.shape[1], dst.shape[0], cvtype(dst), code)
+    assert rc == 0, rc
+    return dst

@@ -62,6 +62,14 @@ def _calls(o, src8, src8c3, srcf):
     lk = o.ref_calcOpticalFlowPyrLK(src8, shifted, lkpts, (21, 21), 2)
     out["lk_status"] = lk[1]; out["lk_err"] = lk[2]
     out["lk_pts"] = np.where(lk[1][:, None] > 0, lk[0], 0).astype(np.float32)
+    # ALGO_HINT_APPROX: the *Approx hooks are tried first; they are bound to the exact kernels
+    out["approx_yuv"] = o.ref_cvtColorApprox(src8c3, 82, np.empty_like(src8c3))
+    out["approx_yuv2bgr"] = o.ref_cvtColorApprox(src8c3, 84, np.empty_like(src8c3))
+    out["approx_nv12"] = o.ref_cvtColorApprox(src8, 91, np.empty((64, 128, 3), np.uint8))
+    out["approx_i420"] = o.ref_cvtColorApprox(src8, 101, np.empty((64, 128, 3), np.uint8))
+    out["approx_i420enc"] = o.ref_cvtColorApprox(src8c3, 128, np.empty((144, 128), np.uint8))
+    out["approx_yuy2"] = o.ref_cvtColorApprox(np.ascontiguousarray(src8c3[..., :2]), 116, np.empty_like(src8c3))
+    out["approx_uyvy"] = o.ref_cvtColorApprox(src8c3, 144, np.empty((96, 128, 2), np.uint8))
     out["median3"] = o.ref_medianBlur(src8c3, 3)
     out["median5"] = o.ref_medianBlur(src8, 5)
     out["dilate"] = o.ref_morph(1, src8)
