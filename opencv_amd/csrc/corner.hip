@@ -24,6 +24,11 @@
 
 using namespace mi355;
 
+namespace mi355 {
+size_t sortKeysDescTemp(unsigned n);                                                                             // gftt_sort.hip (rocPRIM)
+bool sortKeysDesc(void* temp, size_t bytes, const unsigned long long* in, unsigned long long* out, unsigned n, hipStream_t st);
+}
+
 namespace {
 
 enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
@@ -551,11 +556,13 @@ __global__ __launch_bounds__(256) void k_maxval(const float* __restrict__ eig, s
     if (threadIdx.x == 0) atomicMax(out, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
-struct Cand { float v; int idx; };
+// a candidate as one sortable word: (order-preserving image of the response) << 32 | pixel index
+__device__ __forceinline__ unsigned ordF(float v) { const unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+inline float unordF(unsigned o) { const unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float v; memcpy(&v, &b, 4); return v; }
 
 __global__ __launch_bounds__(256) void k_gftt_candidates(const float* __restrict__ eig, size_t estep, const uchar* __restrict__ mask, size_t mstep,
                                                          int W, int H, const unsigned* __restrict__ maxOrd, double quality,
-                                                         Cand* __restrict__ out, unsigned* __restrict__ count, unsigned capacity)
+                                                         unsigned long long* __restrict__ out, unsigned* __restrict__ count, unsigned capacity)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256) void k_gftt_candidates(const float* __restrict
         for (int i = -1; i <= 1; i++) m = fmaxf(m, T(y + j, x + i));
     if (v != m) return;
     const unsigned slot = atomicAdd(count, 1u);
-    if (slot < capacity) { out[slot].v = v; out[slot].idx = y * W + x; }
+    if (slot < capacity) out[slot] = ((unsigned long long)ordF(v) << 32) | (unsigned)(y * W + x);
 }
 
 } // namespace
@@ -658,7 +665,7 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
     const size_t estep = ((size_t)width * 4 + 255) & ~size_t(255);
     uchar* eig = (uchar*)stg.scratch(estep * height);
     const unsigned capacity = (unsigned)std::min<size_t>((size_t)width * height, (size_t)1 << 26);
-    Cand* cand = (Cand*)stg.scratch((size_t)capacity * sizeof(Cand));
+    unsigned long long* cand = (unsigned long long*)stg.scratch((size_t)capacity * 8);
     unsigned* ctr = (unsigned*)stg.scratch(256);
     if (!ds || !eig || !cand || !ctr || (mask_data && !dm)) return -1;
     hipStream_t st = stream();
@@ -672,15 +679,31 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
         hipLaunchKernelGGL(k_gftt_candidates, grid, dim3(256), 0, st, (const float*)eig, estep, dm, dms, width, height, ctr, qualityLevel, cand, ctr + 1, capacity);
     }
     unsigned hc[2] = {0, 0};
-    if (hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2 ;
+    if (hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     const unsigned total = std::min(hc[1], capacity);
-    std::vector<Cand> c(total);
-    if (total && (hipMemcpyAsync(c.data(), cand, (size_t)total * sizeof(Cand), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-        return -2;
-    (void)stg.finish("goodFeaturesToTrack");
-    // std::sort with greaterThanPtr (featureselect.cpp:55-60): value descending, equal values -> higher address first
-    std::sort(c.begin(), c.end(), [](const Cand& p, const Cand& q) { return p.v > q.v ? true : p.v < q.v ? false : p.idx > q.idx; });
+    // order the candidates on the device (response, then address, both descending: std::sort with greaterThanPtr, featureselect.cpp:55-60, :447)
+    // and bring them over in chunks: the greedy minimum-distance pass below usually stops long before the end of the list
+    const unsigned long long* sorted = cand;
+    if (total > 1) {
+        const size_t tb = sortKeysDescTemp(total);
+        void* temp = stg.scratch(tb ? tb : 16);
+        unsigned long long* outKeys = (unsigned long long*)stg.scratch((size_t)total * 8);
+        if (!tb || !temp || !outKeys || !sortKeysDesc(temp, tb, cand, outKeys, total, st)) return -2;
+        sorted = outKeys;
+    }
+    std::vector<unsigned long long> c;
+    unsigned fetched = 0;
+    auto need = [&](unsigned i) -> bool {                                // make candidate i available on the host
+        if (i < fetched) return true;
+        const unsigned chunk = std::min(total - fetched, std::max(65536u, fetched));        // doubling chunks
+        c.resize((size_t)fetched + chunk);
+        if (hipMemcpyAsync(c.data() + fetched, sorted + fetched, (size_t)chunk * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return false;
+        fetched += chunk;
+        return true;
+    };
     int n = 0;
+    bool failed = false;
     const int cap = maxCorners > 0 ? maxCorners : width * height;
     if (minDistance >= 1) {                                          // :451-525 grid-based rejection
         const int cell = (int)nearbyint(minDistance);
@@ -688,7 +711,9 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
         std::vector<std::vector<int>> grid((size_t)gw * gh);
         const double md2 = minDistance * minDistance;
         for (unsigned i = 0; i < total; i++) {
-            const int y = c[i].idx / width, x = c[i].idx % width;
+            if (!need(i)) { failed = true; break; }
+            const int idx = (int)(unsigned)(c[i] & 0xffffffffu);
+            const int y = idx / width, x = idx % width;
             const int xc = x / cell, yc = y / cell;
             const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
             bool good = true;
@@ -701,7 +726,7 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
             if (good) {
                 if (n >= cap) break;
                 corners[2 * n] = (float)x; corners[2 * n + 1] = (float)y;
-                if (quality) quality[n] = c[i].v;
+                if (quality) quality[n] = unordF((unsigned)(c[i] >> 32));
                 grid[(size_t)yc * gw + xc].push_back(n);
                 n++;
                 if (maxCorners > 0 && n == maxCorners) break;
@@ -709,12 +734,16 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
         }
     } else {
         for (unsigned i = 0; i < total && n < cap; i++) {
-            corners[2 * n] = (float)(c[i].idx % width); corners[2 * n + 1] = (float)(c[i].idx / width);
-            if (quality) quality[n] = c[i].v;
+            if (!need(i)) { failed = true; break; }
+            const int idx = (int)(unsigned)(c[i] & 0xffffffffu);
+            corners[2 * n] = (float)(idx % width); corners[2 * n + 1] = (float)(idx / width);
+            if (quality) quality[n] = unordF((unsigned)(c[i] >> 32));
             n++;
             if (maxCorners > 0 && n == maxCorners) break;
         }
     }
+    (void)stg.finish("goodFeaturesToTrack");
+    if (failed) return -2;
     return n;
 }
 
