@@ -338,6 +338,13 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const mi355cv_uchar* prev_data, size_
         const float* prev_points, float* next_points, size_t point_count, mi355cv_uchar* status, float* err,
         const int win_width, const int win_height, int termination_count, double termination_epsilon,
         bool get_min_eigen_vals, float min_eigen_vals_threshold);
+/* cv::calcOpticalFlowPyrLK (lkpyramid.cpp:1432) in one call: frames staged once, padded pyramids, derivatives and all tracker levels on the
+ * device.  cv:: argument meaning (criteria = TermCriteria type / maxCount / epsilon, flags = OPTFLOW_*); err may be NULL.  Results are
+ * bit-identical to the reference's.  Returns 0, 1 (declined, nothing written) or < 0. */
+MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const mi355cv_uchar* prev_data, size_t prev_step, const mi355cv_uchar* next_data, size_t next_step,
+        int width, int height, int cn, const float* prev_points, float* next_points, int point_count, mi355cv_uchar* status, float* err,
+        int win_width, int win_height, int max_level, int criteria_type, int criteria_max_count, double criteria_epsilon,
+        int flags, double min_eig_threshold);
 /* cv::copyMakeBorder (core/src/copy.cpp:1183; no HAL hook) for device-resident images: pixels of elem_size bytes, BORDER_CONSTANT = zeros;
  * src may be the interior of dst (then only the frame is written) -- what buildOpticalFlowPyramid does at lkpyramid.cpp:804 */
 MI355CV_API int mi355cv_copyMakeBorder(const mi355cv_uchar* src_data, size_t src_step, int width, int height, mi355cv_uchar* dst_data, size_t dst_step,

@@ -142,4 +142,40 @@ inline void matchTemplate(cv::InputArray _image, cv::InputArray _templ, cv::Outp
     cv::matchTemplate(_image, _templ, _result, method, _mask);
 }
 
+#ifdef OPENCV_TRACKING_HPP      // cv::calcOpticalFlowPyrLK lives in opencv2/video/tracking.hpp; include it before this header to get the wrapper
+// cv::calcOpticalFlowPyrLK (video/tracking.hpp; lkpyramid.cpp:1432).  Two images (not precomputed pyramids) go through the one-call
+// entry point -- frames cross PCIe once, pyramids, derivatives and all levels run on the device, results bit-identical to cv:: --
+// everything else (pyramid vectors, UMat, unsupported arguments, no device) is handed to the stock function.
+inline void calcOpticalFlowPyrLK(cv::InputArray _prevImg, cv::InputArray _nextImg, cv::InputArray _prevPts, cv::InputOutputArray _nextPts,
+                                 cv::OutputArray _status, cv::OutputArray _err, cv::Size winSize = cv::Size(21, 21), int maxLevel = 3,
+                                 cv::TermCriteria criteria = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30, 0.01),
+                                 int flags = 0, double minEigThreshold = 1e-4)
+{
+    if (_prevImg.kind() == cv::_InputArray::MAT && _nextImg.kind() == cv::_InputArray::MAT) {
+        cv::Mat prev = _prevImg.getMat(), next = _nextImg.getMat(), pts = _prevPts.getMat();
+        const int n = pts.checkVector(2, CV_32F, true);
+        const bool initial = (flags & cv::OPTFLOW_USE_INITIAL_FLOW) != 0;
+        if (prev.dims <= 2 && prev.depth() == CV_8U && prev.type() == next.type() && prev.size() == next.size() && n > 0 && maxLevel >= 0 &&
+            winSize.width > 2 && winSize.height > 2) {
+            if (!initial) _nextPts.create(pts.size(), pts.type(), -1, true);
+            cv::Mat nextPts = _nextPts.getMat();
+            if (nextPts.checkVector(2, CV_32F, true) == n) {
+                _status.create(n, 1, CV_8U, -1, true);
+                cv::Mat status = _status.getMat(), err;
+                if (_err.needed()) { _err.create(n, 1, CV_32F, -1, true); err = _err.getMat(); }
+                // the entry point writes its outputs only when it succeeds; an initial guess it might clobber is kept aside for the fallback
+                cv::Mat guess = initial ? nextPts.clone() : cv::Mat();
+                if (status.isContinuous() && (err.empty() || err.isContinuous()) &&
+                    mi355cv_calcOpticalFlowPyrLK(prev.data, prev.step, next.data, next.step, prev.cols, prev.rows, prev.channels(), pts.ptr<float>(),
+                                                 nextPts.ptr<float>(), n, status.data, err.empty() ? nullptr : err.ptr<float>(), winSize.width, winSize.height,
+                                                 maxLevel, criteria.type, criteria.maxCount, criteria.epsilon, flags, minEigThreshold) == MI355CV_OK)
+                    return;
+                if (initial) guess.copyTo(nextPts);
+            }
+        }
+    }
+    cv::calcOpticalFlowPyrLK(_prevImg, _nextImg, _prevPts, _nextPts, _status, _err, winSize, maxLevel, criteria, flags, minEigThreshold);
+}
+#endif
+
 } // namespace mi355cv

@@ -83,6 +83,8 @@ def _load():
         "mi355cv_ScharrDeriv": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
         "mi355cv_LKOpticalFlowLevel": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_u8p, c_sz, c_u8p, c_u8p,
                                                c_int, c_int, c_int, c_dbl, ctypes.c_bool, ctypes.c_float]),
+        "mi355cv_calcOpticalFlowPyrLK": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_u8p, c_int, c_u8p, c_u8p,
+                                                 c_int, c_int, c_int, c_int, c_int, c_dbl, c_int, c_dbl]),
         "mi355cv_copyMakeBorder": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),
         "mi355cv_hostAlloc": (ctypes.c_void_p, [c_sz, c_int]),
         "mi355cv_hostFree": (c_int, [ctypes.c_void_p, c_int]),

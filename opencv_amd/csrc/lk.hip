@@ -12,6 +12,7 @@
 // both derivatives, 3 shorts per element) lives in an HBM scratch laid out element-major so that the lanes of a wave touch consecutive
 // addresses.
 #include "rt.h"
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -311,6 +312,24 @@ __global__ __launch_bounds__(64) void k_lk_wave(LkArgs a)
     (void)nt;
 }
 
+// per-level point set-up of LKTrackerInvoker (lkpyramid.cpp:215-231): prevScaled = prev * 2^-level; next = at the top level the
+// (scaled) initial guess or prevScaled, below it twice the estimate of the level above
+__global__ __launch_bounds__(256) void k_lk_scale_points(const float* __restrict__ prevPts, float* __restrict__ prevScaled, float* __restrict__ nextPts, int n2,
+                                                         float scale, int top, int useInitial)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n2) return;
+    const float p = prevPts[i] * scale;
+    prevScaled[i] = p;
+    nextPts[i] = top ? (useInitial ? nextPts[i] * scale : p) : nextPts[i] * 2.f;
+}
+
+__global__ __launch_bounds__(256) void k_fill_u8(uchar* __restrict__ p, int n, int v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (uchar)v;
+}
+
 // host array that is read AND written by the kernel: device copy that finish() writes back
 template <typename T>
 T* inout(Stager& stg, T* host, size_t count)
@@ -323,6 +342,9 @@ T* inout(Stager& stg, T* host, size_t count)
 }
 
 } // namespace
+
+extern "C" MI355CV_API int mi355cv_pyrdown(const uchar* src_data, size_t src_step, int src_width, int src_height, uchar* dst_data, size_t dst_step,
+                                           int dst_width, int dst_height, int depth, int cn, int border_type);
 
 extern "C" {
 
@@ -396,6 +418,98 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
     if (perWave) hipLaunchKernelGGL(k_lk_wave, dim3((unsigned)point_count), dim3(64), ldsBytes, stream(), a);
     else hipLaunchKernelGGL(k_lk_level, dim3(divUp((int)point_count, 64)), dim3(64), 0, stream(), a);
     return stg.finish("LKOpticalFlowLevel");
+}
+
+// cv::calcOpticalFlowPyrLK (lkpyramid.cpp:1432 -> SparsePyrLKOpticalFlowImpl::calc :1259) as ONE call: both frames go to HBM once, the padded
+// pyramids (buildOpticalFlowPyramid :747: pyrDown + BORDER_REFLECT_101 frame), the Scharr derivatives (zero frame) and every tracker
+// level run in stream order on the device, the three result vectors come back at the end.  The hook-per-level route above is what the
+// reference's own loop drives; for host images it re-stages the frames at every level and for every parallel_for_ stripe -- this entry is
+// what include/mi355cv_cv.hpp's mi355cv::calcOpticalFlowPyrLK calls instead.  criteria as cv::TermCriteria (type, maxCount, epsilon).
+// Returns MI355CV_OK, MI355CV_NOT_IMPLEMENTED (nothing written), or < 0.
+MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev_step, const uchar* next_data, size_t next_step, int width, int height, int cn,
+                                             const float* prev_points, float* next_points, int point_count, uchar* status, float* err,
+                                             int win_width, int win_height, int max_level, int criteria_type, int criteria_max_count, double criteria_epsilon,
+                                             int flags, double min_eig_threshold)
+{
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width <= 2 || win_height <= 2 || win_width > 64 || win_height > 64 || max_level < 0 ||
+        max_level > 16 || !prev_points || !next_points || !status || point_count < 0)
+        return MI355CV_NOT_IMPLEMENTED;
+    if (point_count == 0) return MI355CV_OK;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const bool useInitial = (flags & 4) != 0, getMinEig = (flags & 8) != 0;                // OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_LK_GET_MIN_EIGENVALS
+    int maxCount = (criteria_type & 1) == 0 ? 30 : std::min(std::max(criteria_max_count, 0), 100);                     // :1386-1395
+    double eps = (criteria_type & 2) == 0 ? 0.01 : std::min(std::max(criteria_epsilon, 0.), 10.);
+    eps *= eps;
+    Stager stg;
+    hipStream_t st = stream();
+    size_t sP, sN, tmp;
+    const uchar* dP = stg.in(prev_data, prev_step, (size_t)width * cn, height, &sP);
+    const uchar* dN = stg.in(next_data, next_step, (size_t)width * cn, height, &sN);
+    const size_t n2 = (size_t)point_count * 2;
+    const float* dPrev = (const float*)stg.in((const uchar*)prev_points, n2 * 4, n2 * 4, 1, &tmp);
+    float* dNext = useInitial ? inout(stg, next_points, n2) : (float*)stg.out((uchar*)next_points, n2 * 4, n2 * 4, 1, &tmp);
+    uchar* dStatus = stg.out(status, (size_t)point_count, (size_t)point_count, 1, &tmp);
+    float* dErr = err ? (float*)stg.out((uchar*)err, (size_t)point_count * 4, (size_t)point_count * 4, 1, &tmp) : nullptr;      // no err array: the tracker skips that pass (:694)
+    float* dScaled = (float*)stg.scratch(n2 * 4);
+    if (!dP || !dN || !dPrev || !dNext || !dStatus || (err && !dErr) || !dScaled) return MI355CV_NOT_IMPLEMENTED;
+    if (dErr && hipMemsetAsync(dErr, 0, (size_t)point_count * 4, st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
+    hipLaunchKernelGGL(k_fill_u8, dim3(divUp(point_count, 256)), dim3(256), 0, st, dStatus, point_count, 1);
+
+    // the two padded pyramids
+    struct Level { uchar* whole; size_t pitch; int w, h; uchar* inner; };
+    Level pyr[2][17];
+    int levels = 0;
+    for (int which = 0; which < 2; which++) {
+        int w = width, h = height, lv = 0;
+        for (;; lv++) {
+            Level& L = pyr[which][lv];
+            L.w = w; L.h = h;
+            L.pitch = (((size_t)(w + 2 * win_width) * cn) + 255) & ~(size_t)255;
+            L.whole = (uchar*)stg.scratch(L.pitch * (size_t)(h + 2 * win_height));
+            if (!L.whole) return MI355CV_NOT_IMPLEMENTED;
+            L.inner = L.whole + (size_t)win_height * L.pitch + (size_t)win_width * cn;
+            const int DW = w + 2 * win_width, DH = h + 2 * win_height;
+            if (lv == 0)
+                hipLaunchKernelGGL(k_copy_make_border, dim3(divUp(DW, 64), divUp(DH, 4)), dim3(256), 0, st, which ? dN : dP, which ? sN : sP, w, h, L.whole, L.pitch,
+                                   win_height, win_width, DW, DH, cn, (int)B_REFLECT_101, 0);
+            else {
+                const Level& U = pyr[which][lv - 1];
+                const int rc = mi355cv_pyrdown(U.inner, U.pitch, U.w, U.h, L.inner, L.pitch, w, h, MI355CV_8U, cn, B_REFLECT_101);
+                if (rc != MI355CV_OK) return rc;
+                hipLaunchKernelGGL(k_copy_make_border, dim3(divUp(DW, 64), divUp(DH, 4)), dim3(256), 0, st, L.inner, L.pitch, w, h, L.whole, L.pitch,
+                                   win_height, win_width, DW, DH, cn, (int)B_REFLECT_101, 1);
+            }
+            const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+            if (lv == max_level || nw <= win_width || nh <= win_height) break;                              // :836-840
+            w = nw; h = nh;
+        }
+        levels = which == 0 ? lv : std::min(levels, lv);
+    }
+    const size_t E = (size_t)win_width * cn * win_height, ldsBytes = E * 14 + 64;
+    const bool perWave = ldsBytes <= 48 * 1024 && !getenv("MI355CV_LK_THREAD_PER_POINT");
+    short* win = perWave ? nullptr : (short*)stg.scratch(3 * E * (size_t)point_count * sizeof(short));
+    // one derivative buffer, sized for level 0, reused by every level (as the reference does, :1398-1400)
+    const size_t dpitch0 = (((size_t)(width + 2 * win_width) * cn * 4) + 255) & ~(size_t)255;
+    uchar* dbuf = (uchar*)stg.scratch(dpitch0 * (size_t)(height + 2 * win_height));
+    if ((!perWave && !win) || !dbuf) return MI355CV_NOT_IMPLEMENTED;
+    for (int level = levels; level >= 0; level--) {
+        const Level& LI = pyr[0][level]; const Level& LJ = pyr[1][level];
+        const size_t dpitch = (((size_t)(LI.w + 2 * win_width) * cn * 4) + 255) & ~(size_t)255;
+        if (hipMemsetAsync(dbuf, 0, dpitch * (size_t)(LI.h + 2 * win_height), st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;       // the BORDER_CONSTANT frame (:1409)
+        uchar* dInner = dbuf + (size_t)win_height * dpitch + (size_t)win_width * cn * 4;
+        hipLaunchKernelGGL(k_scharr_deriv, dim3(divUp(LI.w * cn, 64), divUp(LI.h, 4)), dim3(256), 0, st, LI.inner, LI.pitch, dInner, dpitch, LI.w, LI.h, cn);
+        hipLaunchKernelGGL(k_lk_scale_points, dim3(divUp((int)n2, 256)), dim3(256), 0, st, dPrev, dScaled, dNext, (int)n2, (float)(1. / (1 << level)),
+                           level == levels ? 1 : 0, useInitial ? 1 : 0);
+        LkArgs a;
+        a.I = LI.inner; a.stepI = (long)LI.pitch; a.dI = (const short*)dInner; a.dstep = (long)(dpitch / 2); a.J = LJ.inner; a.stepJ = (long)LJ.pitch;
+        a.width = LI.w; a.height = LI.h; a.cn = cn; a.winW = win_width; a.winH = win_height; a.maxCount = maxCount; a.getMinEig = getMinEig ? 1 : 0;
+        a.epsilon = eps; a.minEigThreshold = (float)min_eig_threshold;
+        a.prevPts = dScaled; a.nextPts = dNext; a.status = level == 0 ? dStatus : nullptr; a.err = dErr; a.npts = point_count; a.win = win;
+        if (perWave) hipLaunchKernelGGL(k_lk_wave, dim3((unsigned)point_count), dim3(64), ldsBytes, st, a);
+        else hipLaunchKernelGGL(k_lk_level, dim3(divUp(point_count, 64)), dim3(64), 0, st, a);
+    }
+    return stg.finish("calcOpticalFlowPyrLK");
 }
 
 } // extern "C"

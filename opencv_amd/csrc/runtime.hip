@@ -194,7 +194,8 @@ int Stager::finish(const char* entry)
         e = hipMemcpy2DAsync(o.host, o.hstep, o.dev, o.dstep, o.rowBytes, o.rows, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(e));
     }
-    if (anyHost_ || !asyncMode()) {
+    // a hook called from inside another hook (device pointers, same stream) leaves the synchronisation to the outermost one
+    if (anyHost_ || (!asyncMode() && tctx().stagerDepth == 1)) {
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: execution failed: %s", entry, hipGetErrorString(e));
     }

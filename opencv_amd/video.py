@@ -13,7 +13,7 @@ from . import _lib
 from .core import Img, bind_stream, torch, CV_8U, BORDER_CONSTANT, BORDER_REFLECT_101, BORDER_ISOLATED
 from .imgproc import pyrDown
 
-__all__ = ["ScharrDeriv", "copyMakeBorder", "buildOpticalFlowPyramid", "LKOpticalFlowLevel", "calcOpticalFlowPyrLK",
+__all__ = ["ScharrDeriv", "copyMakeBorder", "buildOpticalFlowPyramid", "LKOpticalFlowLevel", "calcOpticalFlowPyrLK", "calcOpticalFlowPyrLK_hooks",
            "OPTFLOW_USE_INITIAL_FLOW", "OPTFLOW_LK_GET_MIN_EIGENVALS", "TERM_COUNT", "TERM_EPS"]
 
 L = _lib.lib
@@ -125,8 +125,9 @@ def LKOpticalFlowLevel(prevImg, prevDeriv, nextImg, prevPts, nextPts, status, er
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3, criteria=(TERM_COUNT | TERM_EPS, 30, 0.01), flags=0,
                          minEigThreshold=1e-4):
-    """cv::calcOpticalFlowPyrLK (lkpyramid.cpp:1432; SparsePyrLKOpticalFlowImpl::calc :1259).  prevPts: n x 2 float32 (same kind as the
-    images).  Returns (nextPts n x 2 float32, status n uint8, err n float32)."""
+    """cv::calcOpticalFlowPyrLK (lkpyramid.cpp:1432; SparsePyrLKOpticalFlowImpl::calc :1259) through the one-call entry point (pyramids,
+    derivatives and every level on the device).  prevPts: n x 2 float32 (same kind as the images).  Returns (nextPts n x 2 float32,
+    status n uint8, err n float32).  The same computation assembled from the video module's hooks: calcOpticalFlowPyrLK_hooks."""
     winW, winH = int(winSize[0]), int(winSize[1])
     if maxLevel < 0 or winW <= 2 or winH <= 2:
         raise ValueError("calcOpticalFlowPyrLK: maxLevel >= 0 and winSize > 2")                # CV_Assert, :1277
@@ -140,6 +141,45 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     if flags & OPTFLOW_USE_INITIAL_FLOW:
         if nextPts is None or int(nextPts.shape[0]) != n:
             raise ValueError("calcOpticalFlowPyrLK: OPTFLOW_USE_INITIAL_FLOW needs nextPts of the same length")      # :1297
+        out = nextPts.reshape(n, 2).to(device=prevImg.device, dtype=torch.float32).clone() if dev else np.array(np.asarray(nextPts).reshape(n, 2), np.float32)
+    else:
+        out = None
+    if n == 0:
+        return _empty(pts, (0, 2), np.float32), _empty(pts, (0,), np.uint8), _empty(pts, (0,), np.float32)
+    status = _empty(pts, (n,), np.uint8)
+    err = _empty(pts, (n,), np.float32)
+    if out is None:
+        out = _empty(pts, (n, 2), np.float32)
+    I, J = Img(prevImg), Img(nextImg)
+    if (I.w, I.h, I.cn, I.depth) != (J.w, J.h, J.cn, J.depth) or I.depth != CV_8U:
+        raise ValueError("calcOpticalFlowPyrLK: two CV_8U images of the same size and type")   # CV_Assert, :1416-1417, :753
+    bind_stream(I, J)
+    ptr = lambda a: _vp(a.data_ptr() if torch is not None and isinstance(a, torch.Tensor) else a.ctypes.data)
+    ctype, maxCount, eps = criteria
+    rc = L.mi355cv_calcOpticalFlowPyrLK(_vp(I.ptr), I.step, _vp(J.ptr), J.step, I.w, I.h, I.cn, ptr(pts), ptr(out), n, ptr(status), ptr(err), winW, winH,
+                                        int(maxLevel), int(ctype), int(maxCount), float(eps), int(flags), float(minEigThreshold))
+    _lib.check(rc, "calcOpticalFlowPyrLK")
+    return out, status, err
+
+
+def calcOpticalFlowPyrLK_hooks(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3, criteria=(TERM_COUNT | TERM_EPS, 30, 0.01), flags=0,
+                         minEigThreshold=1e-4):
+    """The level loop of SparsePyrLKOpticalFlowImpl::calc (lkpyramid.cpp:1397-1424) written out over the hooks the video module calls
+    itself -- cv_hal_pyrdown, cv_hal_ScharrDeriv, cv_hal_LKOpticalFlowLevel -- with the per-level point scaling of LKTrackerInvoker
+    (:215-231) done here.  Same arguments and results as calcOpticalFlowPyrLK."""
+    winW, winH = int(winSize[0]), int(winSize[1])
+    if maxLevel < 0 or winW <= 2 or winH <= 2:
+        raise ValueError("calcOpticalFlowPyrLK_hooks: maxLevel >= 0 and winSize > 2")                # CV_Assert, :1277
+    n = int(prevPts.shape[0])
+    dev = _is_dev(prevImg)
+    pts = prevPts.reshape(n, 2)
+    if dev:
+        pts = pts.to(device=prevImg.device, dtype=torch.float32).contiguous()
+    else:
+        pts = np.ascontiguousarray(np.asarray(pts), np.float32)
+    if flags & OPTFLOW_USE_INITIAL_FLOW:
+        if nextPts is None or int(nextPts.shape[0]) != n:
+            raise ValueError("calcOpticalFlowPyrLK_hooks: OPTFLOW_USE_INITIAL_FLOW needs nextPts of the same length")      # :1297
         out = nextPts.reshape(n, 2).to(device=prevImg.device, dtype=torch.float32).clone() if dev else np.array(np.asarray(nextPts).reshape(n, 2), np.float32)
     else:
         out = None

@@ -1,6 +1,7 @@
 // cvwrap_shim.cpp -- part of the `hal` build only: instantiates include/mi355cv_cv.hpp (the cv::-signature wrappers of the
 // functions without a HAL hook) against the reference's own headers and exposes them to the tests through a C facade, so that
 // the header is compiled and exercised, not just shipped.
+#include "opencv2/video/tracking.hpp"
 #include "mi355cv_cv.hpp"
 #include <cstdio>
 #include <cstring>
@@ -63,5 +64,22 @@ EXPORT int wrap_frameAllocatorTour(int kind, const void* s, size_t ss, int w, in
         cv::GaussianBlur(blurred, frame, Size(3, 3), 0, 0, BORDER_REPLICATE);
         frame.copyTo(out);
         return roi.rows == h / 2 ? 0 : -4;
+    } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
+// mi355cv::calcOpticalFlowPyrLK with std::vector outputs, as applications call it
+EXPORT int wrap_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* next, size_t ns, int w, int h, int type, const float* pts, float* nextPts, int npts,
+                                     unsigned char* status, float* err, int winW, int winH, int maxLevel, int critType, int maxCount, double eps, int flags, double minEig)
+{
+    try {
+        Mat P = M(prev, ps, w, h, type), N = M(next, ns, w, h, type);
+        std::vector<Point2f> p0(npts), p1;
+        for (int i = 0; i < npts; i++) p0[i] = Point2f(pts[2 * i], pts[2 * i + 1]);
+        if (flags & OPTFLOW_USE_INITIAL_FLOW) { p1.resize(npts); for (int i = 0; i < npts; i++) p1[i] = Point2f(nextPts[2 * i], nextPts[2 * i + 1]); }
+        std::vector<uchar> st; std::vector<float> er;
+        mi355cv::calcOpticalFlowPyrLK(P, N, p0, p1, st, er, Size(winW, winH), maxLevel, TermCriteria(critType, maxCount, eps), flags, minEig);
+        if ((int)p1.size() != npts || (int)st.size() != npts || (int)er.size() != npts) return -2;
+        for (int i = 0; i < npts; i++) { nextPts[2 * i] = p1[i].x; nextPts[2 * i + 1] = p1[i].y; status[i] = st[i]; err[i] = er[i]; }
+        return 0;
     } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }

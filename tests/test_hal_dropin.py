@@ -240,3 +240,43 @@ def test_frame_allocator_gpu(ref, kind):
     p = L.mi355cv_hostAlloc(1 << 20, kind)
     assert p, "hostAlloc failed on a GPU box"
     assert L.mi355cv_hostFree(p, kind) == 0
+
+
+def _wrap_lk(hal, A, B, p, win, maxLevel, flags=0, guess=None):
+    import ctypes
+    n = len(p)
+    out = np.array(guess, np.float32) if guess is not None else np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8); er = np.zeros(n, np.float32)
+    rc = hal.wrap_calcOpticalFlowPyrLK(O.P(A), O.step(A), O.P(B), O.step(B), A.shape[1], A.shape[0], O.cvtype(A), O.P(p), O.P(out), n, O.P(st), O.P(er),
+                                       win[0], win[1], maxLevel, 3, 30, ctypes.c_double(0.01), flags, ctypes.c_double(1e-4))
+    assert rc == 0, rc
+    return out, st, er
+
+
+def test_cv_signature_lk_wrapper(ref):
+    """mi355cv::calcOpticalFlowPyrLK (include/mi355cv_cv.hpp) with std::vector arguments: identical to cv::calcOpticalFlowPyrLK -- on the GPU
+    box through the one-call entry point, here (no device) through its fallback to the stock function"""
+    import torch
+    from test_oracle_lk import frames, points, same
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    for cn in (1, 3):
+        A, B = frames(200, 260, cn, 13 + cn)
+        p = points(200, 260, 200, 2)
+        same(_wrap_lk(hal, A, B, p, (21, 21), 3), O.ref_calcOpticalFlowPyrLK(A, B, p, (21, 21), 3), ("wrapper", cn))
+        guess = p + np.float32([1.5, -1.0])
+        same(_wrap_lk(hal, A, B, p, (15, 15), 2, 4, guess), O.ref_calcOpticalFlowPyrLK(A, B, p, (15, 15), 2, flags=4, nextPts=guess), ("wrapper initial", cn))
+
+
+@pytest.mark.gpu
+def test_cv_signature_lk_wrapper_gpu(ref):
+    import opencv_amd as cv
+    from test_oracle_lk import frames, points, same
+    hal = O.load_ref_hal()
+    assert hal is not None
+    A, B = frames(360, 480, 1, 17)
+    p = points(360, 480, 800, 2)
+    n0 = cv.call_count("calcOpticalFlowPyrLK")
+    same(_wrap_lk(hal, A, B, p, (21, 21), 3), O.ref_calcOpticalFlowPyrLK(A, B, p, (21, 21), 3), "wrapper gpu")
+    assert cv.call_count("calcOpticalFlowPyrLK") == n0 + 1

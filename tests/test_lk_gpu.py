@@ -74,6 +74,17 @@ def test_device_resident(cv, orc, cn, win):
     assert 0 < want[1].sum() < len(p)
 
 
+def test_hook_level_loop_equals_one_call(cv, orc):
+    """the mirror assembled from the video module's hooks (padded pyramids built with copyMakeBorder on the device) against the one-call
+    entry point and the oracle"""
+    A, B = frames(300, 420, 1, 31)
+    p = points(300, 420, 500, 3)
+    a = tuple(g.cpu().numpy() for g in cv.calcOpticalFlowPyrLK_hooks(dev(A), dev(B), dev(p), None, (15, 15), 3))
+    b = tuple(g.cpu().numpy() for g in cv.calcOpticalFlowPyrLK(dev(A), dev(B), dev(p), None, (15, 15), 3))
+    want = orc.orc_calcOpticalFlowPyrLK(A, B, p, (15, 15), 3)
+    same(a, want, "hooks"); same(b, want, "one call")
+
+
 def test_large_window_takes_the_thread_per_point_kernel(cv, orc):
     """61x61x3 windows need more LDS than the wave-per-point kernel may use: the one-thread-per-point kernel serves them"""
     A, B = frames(200, 260, 3, 21)
