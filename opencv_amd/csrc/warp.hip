@@ -605,6 +605,40 @@ bool cachedTab(int kind, int n, double scale, int nt, Build build, const Tab** d
     return true;
 }
 
+// the same residency for the INTER_AREA tables (taps + per-output offsets in one allocation), keyed by (source length, destination length, scale)
+struct AreaDev { const AreaTap* tab; const int* ofs; };
+bool cachedAreaTab(int ssize, int dsize, double scale, AreaDev* out)
+{
+    struct Key { int s, d; double sc; bool operator<(const Key& o) const { return s != o.s ? s < o.s : d != o.d ? d < o.d : sc < o.sc; } };
+    struct Entry { void* dev; size_t ofsAt; unsigned long long stamp; };
+    static std::mutex mu;
+    static std::map<Key, Entry> cache;
+    static unsigned long long clock = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    const Key key{ssize, dsize, scale};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 32) {
+            auto old = cache.begin();
+            for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+            (void)hipDeviceSynchronize();
+            (void)hipFree(old->second.dev);
+            cache.erase(old);
+        }
+        std::vector<AreaTap> tab; std::vector<int> ofs;
+        buildAreaTab(ssize, dsize, scale, tab, ofs);
+        const size_t tabBytes = (tab.size() * sizeof(AreaTap) + 15) & ~(size_t)15, ofsBytes = ofs.size() * sizeof(int);
+        void* d = nullptr;
+        if (hipMalloc(&d, tabBytes + ofsBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if ((!tab.empty() && hipMemcpy(d, tab.data(), tab.size() * sizeof(AreaTap), hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemcpy((uchar*)d + tabBytes, ofs.data(), ofsBytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return false; }
+        it = cache.emplace(key, Entry{d, tabBytes, 0}).first;
+    }
+    it->second.stamp = ++clock;
+    out->tab = (const AreaTap*)it->second.dev; out->ofs = (const int*)((const uchar*)it->second.dev + it->second.ofsAt);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -948,13 +982,9 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
         return stg.finish("resize");
     }
     if (a.mode == 4) {
-        std::vector<AreaTap> xt, yt; std::vector<int> xo, yo;
-        buildAreaTab(src_width, dst_width, a.scale_x, xt, xo); buildAreaTab(src_height, dst_height, a.scale_y, yt, yo);
-        const AreaTap* dxt = (const AreaTap*)stg.param(xt.data(), xt.size() * sizeof(AreaTap));
-        const AreaTap* dyt = (const AreaTap*)stg.param(yt.data(), yt.size() * sizeof(AreaTap));
-        const int* dxo = (const int*)stg.param(xo.data(), xo.size() * sizeof(int));
-        const int* dyo = (const int*)stg.param(yo.data(), yo.size() * sizeof(int));
-        if (!dxt || !dyt || !dxo || !dyo) return MI355CV_NOT_IMPLEMENTED;
+        AreaDev ax, ay;
+        if (!cachedAreaTab(src_width, dst_width, a.scale_x, &ax) || !cachedAreaTab(src_height, dst_height, a.scale_y, &ay)) return MI355CV_NOT_IMPLEMENTED;
+        const AreaTap* dxt = ax.tab; const int* dxo = ax.ofs; const AreaTap* dyt = ay.tab; const int* dyo = ay.ofs;
         dim3 g4(divUp(dst_width * cn, 64), divUp(dst_height, 4));
 #define RA(T_) hipLaunchKernelGGL(k_resize_area<T_>, g4, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, depth, dxt, dxo, dyt, dyo)
         switch (depth) { case D8U: RA(uchar); break; case D16U: RA(unsigned short); break; case D16S: RA(short); break; default: RA(float); }
