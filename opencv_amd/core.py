@@ -29,6 +29,7 @@ if torch is not None:
     if hasattr(torch, "uint16"):
         _T_DEPTH[torch.uint16] = CV_16U
     _DEPTH_T = {v: k for k, v in _T_DEPTH.items()}
+    _T_DEPTH_ESZ = {k: (v, torch.empty(0, dtype=k).element_size()) for k, v in _T_DEPTH.items()}
 
 
 def CV_MAKETYPE(depth, cn):
@@ -42,17 +43,18 @@ class Img:
     def __init__(self, a):
         self.obj = a
         if torch is not None and isinstance(a, torch.Tensor):
-            if a.dim() not in (2, 3):
+            sh, st = a.shape, a.stride()                      # one call each: this constructor runs twice per hook call
+            nd = len(sh)
+            if nd not in (2, 3):
                 raise ValueError("image must be HxW or HxWxC")
-            if a.dim() == 3 and a.stride(2) != 1 or a.dim() == 2 and a.shape[1] > 1 and a.stride(1) != 1:
+            if nd == 3 and st[2] != 1 or nd == 2 and sh[1] > 1 and st[1] != 1:
                 raise ValueError("image rows must be dense (channel-interleaved, unit stride)")
-            self.h, self.w = int(a.shape[0]), int(a.shape[1])
-            self.cn = int(a.shape[2]) if a.dim() == 3 else 1
-            if a.dim() == 3 and self.cn > 1 and a.stride(1) != self.cn:
+            self.h, self.w = sh[0], sh[1]
+            self.cn = sh[2] if nd == 3 else 1
+            if nd == 3 and self.cn > 1 and st[1] != self.cn:
                 raise ValueError("pixels must be contiguous within a row")
-            self.depth = _T_DEPTH[a.dtype]
-            self.esz = a.element_size()
-            self.step = int(a.stride(0)) * self.esz if self.h > 1 else self.w * self.cn * self.esz
+            self.depth, self.esz = _T_DEPTH_ESZ[a.dtype]
+            self.step = st[0] * self.esz if self.h > 1 else self.w * self.cn * self.esz
             self.ptr = a.data_ptr()
             self.device = a.is_cuda
         else:
@@ -85,6 +87,9 @@ def empty_like_kind(ref, h, w, cn, depth):
     return np.empty(shape, dtype=_DEPTH_NP[depth])
 
 
+_raw_stream = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None) if torch is not None else None
+
+
 def bind_stream(*imgs):
     """Launch on torch's current stream when the images live on a torch CUDA device."""
     if torch is None:
@@ -94,7 +99,9 @@ def bind_stream(*imgs):
             dev = im.obj.device
             if torch.cuda.current_device() != dev.index:
                 torch.cuda.set_device(dev)
-            _lib.lib.mi355cv_setStream(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            # the raw handle of torch's current stream (the public route builds a Stream object per call)
+            h = _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+            _lib.lib.mi355cv_setStream(ctypes.c_void_p(h))
             return
     _lib.lib.mi355cv_resetStream()
 
