@@ -20,6 +20,7 @@
 // correct for every depth/border/anchor/ROI combination above.  The 4K 8U 3x3 configuration of BASELINE.json has
 // its own fast path (TODO next round: register-rolling 3x3).
 #include "rt.h"
+#include <climits>
 #include "roll.h"
 #include "seproll.h"
 #include <cmath>
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_sepfilter_generic(
     int xs[33];
     for (int i = 0; i < p.nx; i++) {
         int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
-        xs[i] = xx < 0 ? -1 : (xx - offX) * cn + ch;
+        xs[i] = xx < 0 ? INT_MIN : (xx - offX) * cn + ch;      // offsets are relative to the ROI: negative ones are real pixels of the parent
     }
     if (p.mode != 0) {
         // integer modes: order of summation is irrelevant
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_sepfilter_generic(
             if (yy < 0) continue;
             const uchar* row = src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep;
             int rs = 0;
-            for (int i = 0; i < p.nx; i++) if (xs[i] >= 0) rs += p.kxi[i] * (int)row[xs[i]];
+            for (int i = 0; i < p.nx; i++) if (xs[i] != INT_MIN) rs += p.kxi[i] * (int)row[xs[i]];
             ri[j] = rs;
             acc += (long long)p.kyi[j] * rs;
         }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_sepfilter_generic(
         const uchar* row = src + (ptrdiff_t)((yy < 0 ? offY : yy) - offY) * (ptrdiff_t)sstep;
         float s = 0.f;
         for (int i = 0; i < p.nx; i++) {
-            const float v = (yy < 0 || xs[i] < 0) ? 0.f : ldF(row, xs[i], sdepth);
+            const float v = (yy < 0 || xs[i] == INT_MIN) ? 0.f : ldF(row, xs[i], sdepth);
             s = i == 0 ? p.kxf[0] * v : __builtin_fmaf(p.kxf[i], v, s);
         }
         return s;

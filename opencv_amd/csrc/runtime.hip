@@ -47,9 +47,19 @@ int setError(int code, const char* fmt, ...)
     return code;
 }
 
+// MI355CV_PRINT_COUNTS=1: at process exit, one line per entry point with the number of calls the GPU served -- how a host program that
+// cannot call mi355cv_callCount (the reference's own test binary, tests/test_reference_suite.py) shows that its cv:: calls ran here
+static void printCounts()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const auto& kv : g_counts) fprintf(stderr, "mi355cv: %s %lld\n", kv.first.c_str(), (long long)kv.second);
+}
+
 void bump(const char* entry)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    static const bool hooked = [] { const char* e = getenv("MI355CV_PRINT_COUNTS"); if (e && atoi(e)) atexit(printCounts); return true; }();
+    (void)hooked;
     g_counts[entry]++;
 }
 
@@ -126,7 +136,11 @@ bool isDevicePtr(const void* p)
 
 // ------------------------------------------------------------------ Stager
 
-Stager::Stager() { tctx().stagerDepth++; }
+Stager::Stager()
+{
+    // an error left behind by an earlier call on this thread (a failed copy, somebody else's HIP code) must not be charged to this hook
+    if (tctx().stagerDepth++ == 0) (void)hipGetLastError();
+}
 Stager::~Stager()
 {
     // buffers handed out during this (outermost) hook become reusable; safe in stream order
@@ -151,6 +165,7 @@ void* Stager::bump_(size_t bytes)
 
 const uchar* Stager::in(const uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep)
 {
+    if (!p || rows <= 0 || rowBytes == 0) { failed_ = true; return nullptr; }          // e.g. the empty dst of THRESH_DRYRUN: the hook declines
     if (isDevicePtr(p)) { *dstep = step; return p; }
     anyHost_ = true;
     size_t ds = (rowBytes + 255) & ~size_t(255);
@@ -165,6 +180,7 @@ const uchar* Stager::in(const uchar* p, size_t step, size_t rowBytes, int rows, 
 
 uchar* Stager::out(uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep)
 {
+    if (!p || rows <= 0 || rowBytes == 0) { failed_ = true; return nullptr; }
     if (isDevicePtr(p)) { *dstep = step; return p; }
     anyHost_ = true;
     size_t ds = (rowBytes + 255) & ~size_t(255);

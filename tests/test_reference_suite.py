@@ -1,0 +1,73 @@
+"""The reference's OWN imgproc accuracy tests (modules/imgproc/test/*.cpp + modules/ts with its bundled gtest), compiled where they lie by
+`make -C oracle/ref reftests` and linked against the HAL-enabled build of the reference (oracle/_ref/libocvref_hal.so -> libmi355cv.so):
+SURVEY §8c's "strongest drop-in proof".  TEST INFRASTRUCTURE ONLY.
+
+ * CPU (here): no device, every hook answers NOT_IMPLEMENTED, the binary checks the stock paths -- what must hold for a host without a GPU.
+ * GPU (-m gpu): the same binary, unchanged, with the hooks served by the MI355X kernels; the per-entry counters the library prints at
+   exit (MI355CV_PRINT_COUNTS=1) show which of them ran.
+
+Tests that load images from opencv_extra (not available offline) are excluded by name."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "opencv_test_imgproc_hal")
+
+NEEDS_DATA = ["Canny_Modes.*", "GaussianBlurVsBitexact.*", "GaussianBlur_Bitexact.regression_9863", "ImgProc_Bayer2RGBA.*", "ImgProc_BayerEdgeAwareDemosaicing.*",
+              "Imgproc_AdaptiveThreshold.*", "Imgproc_ColorBayer.*", "Imgproc_ColorBayerVNG.*", "Imgproc_ColorBayerVNG_Strict.*", "Imgproc_GoodFeatureToT.accuracy",
+              "Imgproc_sepFilter2D.*", "Imgproc_sepFilter2D_outTypes.*", "Imgproc_sepFilter2D_types.*"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/opencv_test_imgproc_hal not built (make -C oracle/ref reftests)")
+
+
+def run(positive, extra_env=None, timeout=600, exclude=()):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    flt = positive + "-" + ":".join(NEEDS_DATA + list(exclude))
+    p = subprocess.run([BIN, "--gtest_filter=" + flt, "--gtest_color=no"], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    ran = re.search(r"\[==========\] (\d+) tests? from \d+ test cases? ran", p.stdout)
+    passed = re.search(r"\[  PASSED  \] (\d+) tests?", p.stdout)
+    failed = re.findall(r"^\[  FAILED  \] (\S+)", p.stdout, re.M)
+    counts = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"^mi355cv: (\S+) (\d+)$", p.stderr, re.M))
+    return p.returncode, int(ran.group(1)) if ran else 0, int(passed.group(1)) if passed else 0, sorted(set(failed)), counts
+
+
+def test_reference_tests_pass_on_the_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see test_reference_tests_pass_on_the_gpu")
+    rc, ran, passed, failed, counts = run("*")
+    assert rc == 0 and not failed and ran == passed and ran > 800, (rc, ran, passed, failed[:10])
+    assert not counts                                   # nothing was served by a GPU
+
+
+# the subset run on the MI355X box: the reference's bit-exact suites plus the accuracy tests of the functions behind the hooks
+GPU_SET = "GaussianBlur_Bitexact.*:Resize_Bitexact.*:Imgproc_cvtColor_BE.*"
+
+
+@pytest.mark.gpu
+def test_reference_tests_pass_on_the_gpu():
+    rc, ran, passed, failed, counts = run(GPU_SET, {"MI355CV_PRINT_COUNTS": "1"})
+    assert rc == 0 and not failed and ran == passed and ran >= 50, (rc, ran, passed, failed[:10])
+    assert counts.get("gaussianBlurBinomial", 0) > 0 and counts.get("cvtBGRtoGray", 0) > 0, counts
+
+
+# Round 1 ran this wider set once on the MI355X box (gpurun_out of that session: 67 of 70 passed, every hook in the list below served by
+# the GPU) and the three failures led to fixes -- Imgproc_Sobel.borderTypes: the generic separable kernel mistook real pixels left of a ROI
+# for the constant border; Imgproc_Threshold.threshold_dryrun / regression_THRESH_TOZERO_IPP_16085: an empty dst (THRESH_DRYRUN) must make
+# the hook decline, and the error it left behind must not be charged to the next call.  The fixes were made after the last GPU session of
+# the round, hence not strict yet.
+GPU_SET_WIDE = ("Imgproc_Threshold*:Imgproc_Thresh*:Imgproc_Filter2D*:Imgproc_Sobel*:Imgproc_PyrDown*:Imgproc_cvtColor*:Imgproc_ColorGray*:Imgproc_Blur*:"
+                "Imgproc_GaussianBlur*:Imgproc_WarpAffine*:Imgproc_Resize*")
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="fixes for the 3 failures of the round-1 exploratory run are not yet re-run on a GPU")
+def test_reference_tests_wide_on_the_gpu():
+    rc, ran, passed, failed, counts = run(GPU_SET_WIDE, {"MI355CV_PRINT_COUNTS": "1"}, exclude=["Imgproc_Resize_Test*"])
+    assert rc == 0 and not failed and ran == passed and ran >= 60, (rc, ran, passed, failed[:10])
+    for hook in ("threshold", "threshold_otsu", "filter", "sepFilter", "sobel", "boxFilter", "resize", "warpAffine", "cvtBGRtoGray"):
+        assert counts.get(hook, 0) > 0, (hook, counts)
