@@ -489,7 +489,7 @@ bool derivKernel(int order, int ksize, bool scharr, std::vector<int>& k)
 int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int sdepth, int ddepth,
              int cn, int mL, int mT, int mR, int mB, int dx, int dy, int ksize, bool scharr, double scale, double delta, int border)
 {
-    if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0)) return MI355CV_NOT_IMPLEMENTED;
+    if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)) return MI355CV_NOT_IMPLEMENTED;
     std::vector<int> ix, iy;
     if (!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)) return MI355CV_NOT_IMPLEMENTED;
     // ktype = max(CV_32F, ddepth, sdepth) = CV_32F for every depth handled here; `kx *= scale` is evaluated
@@ -664,7 +664,7 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
     const int kw = (int)ksize_width, kh = (int)ksize_height;
     if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return MI355CV_NOT_IMPLEMENTED;
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;

@@ -106,7 +106,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
     (void)dst_full_width; (void)dst_full_height; (void)dst_roi_x; (void)dst_roi_y;
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
     if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
     Stager stg; size_t dss, dds;

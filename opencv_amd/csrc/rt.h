@@ -31,6 +31,8 @@ bool ensureDevice();                // lazily selects the device; false if no us
 
 // true if p points into device or managed memory (launch in place)
 bool isDevicePtr(const void* p);
+// src and dst are the same buffer in HBM: a stencil cannot run in place on the GPU (host images are staged into separate buffers, so they may)
+inline bool inPlaceOnDevice(const void* src, const void* dst) { return src == dst && src && isDevicePtr(src); }
 
 // Stages host images into HBM scratch (and results back).  Device-resident
 // images pass through untouched.  One Stager per hook invocation.

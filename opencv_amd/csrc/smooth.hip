@@ -620,6 +620,7 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     const bool hostSrc = !isDevicePtr(src);
     if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!hostSrc && src == dst) return MI355CV_NOT_IMPLEMENTED;            // in place on the device (cv::GaussianBlur itself clones, smooth.dispatch.cpp:685)
 
     Stager stg;
     size_t dss = 0, dds = 0;
