@@ -202,3 +202,51 @@ void orc_cvtMultipliedRGBAtoRGBA(const uint8_t* src, size_t sstep, uint8_t* dst,
             d[3] = (uint8_t)a;
         }
 }
+
+/* HSV -> BGR/RGB(A), CV_8U: HSV2RGB_b color_hsv.simd.hpp:518-667.  The reference's output depends on the vector width it runs with:
+ * the first floor(n / (4 * lanes)) * 4 * lanes pixels of every row go through HSV2RGB_simd (:372-430) and are TRUNCATED to 8 bits
+ * (v_trunc, :571-573), the rest of the row through HSV2RGB_native (:432-456) and is ROUNDED (saturate_cast, :656-658).  `lanes` is the
+ * number of floats per vector of the build that runs (8 for the AVX2 dispatch of oracle/ref, 4 for its SSE baseline). */
+#include <math.h>
+void orc_cvtHSVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int fullRange, int lanes)
+{
+    const int bidx = swapBlue ? 2 : 0, hrange = fullRange ? 255 : 180, blk = 4 * lanes;
+    const float hscale = 6.0f / hrange;
+    const int body = (w / blk) * blk;
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* s = src + (size_t)y * sstep + (size_t)x * 3;
+            uint8_t* d = dst + (size_t)y * dstep + (size_t)x * dcn;
+            float hh = s[0], ss = s[1] * (1.0f / 255.0f), vv = s[2] * (1.0f / 255.0f), b, g, r;
+            if (x < body) {
+                hh = hh * hscale;
+                const float pre = (float)(int)hh;
+                hh = hh - pre;
+                const float t1 = vv * (1.f - ss), t2 = vv * (1.f - ss * hh), t3 = vv * (1.f - ss * (1.f - hh));
+                float sec = pre * (1.0f / 6.0f);
+                sec = (float)(int)sec;
+                sec = pre - sec * 6.f;
+                const float tab[4] = {vv, t1, t2, t3};
+                const int si = (int)sec;
+                b = tab[sector_data[si][0]]; g = tab[sector_data[si][1]]; r = tab[sector_data[si][2]];
+                const int bi = (int)(b * 255.f), gi = (int)(g * 255.f), ri = (int)(r * 255.f);
+                d[bidx] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi); d[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi);
+                d[bidx ^ 2] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri);
+            } else {
+                if (ss == 0) b = g = r = vv;
+                else {
+                    hh *= hscale;
+                    int sector = (int)floorf(hh);
+                    hh -= sector;
+                    sector %= 6; sector += sector < 0 ? 6 : 0;
+                    const float tab[4] = {vv, vv * (1.f - ss), vv * (1.f - ss * hh), vv * (1.f - ss * (1.f - hh))};
+                    b = tab[sector_data[sector][0]]; g = tab[sector_data[sector][1]]; r = tab[sector_data[sector][2]];
+                }
+                const long bi = lrintf(b * 255.0f), gi = lrintf(g * 255.0f), ri = lrintf(r * 255.0f);
+                d[bidx] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi); d[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi);
+                d[bidx ^ 2] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri);
+            }
+            if (dcn == 4) d[3] = 255;
+        }
+}

@@ -78,6 +78,8 @@ int orc_LKOpticalFlowLevel(const uint8_t* I, size_t stepI, const int16_t* derivI
                            int width, int height, int cn, const float* prevPts, float* nextPts, size_t npts, uint8_t* status, float* err,
                            int winW, int winH, int maxCount, double epsilon, int getMinEig, float minEigThreshold);
 
+void orc_cvtHSVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int fullRange, int lanes);
+
 /* oracle/hist.c */
 void orc_equalizeHist(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
 double orc_otsuFromHist(const int* hist, int N, int w, int h);

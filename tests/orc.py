@@ -933,3 +933,16 @@ def ref_cvtColorApprox(src, code, dst):
     rc = r.ref_cvtColorApprox(P(src), step(src), src.shape[1], src.shape[0], cvtype(src), P(dst), step(dst), dst.shape[1], dst.shape[0], cvtype(dst), code)
     assert rc == 0, rc
     return dst
+
+
+_HSV_INV = {54: (0, 0), 55: (1, 0), 70: (0, 1), 71: (1, 1)}           # HSV2BGR, HSV2RGB, HSV2BGR_FULL, HSV2RGB_FULL -> (swapBlue, fullRange)
+
+
+def orc_cvtHSVtoBGR(src, code, dcn=3, lanes=8):
+    """lanes = floats per vector of the reference build that runs (8: the AVX2 dispatch of oracle/ref and of any x86 host with AVX2)"""
+    o = oracle()
+    h, w = src.shape[:2]
+    swap, full = _HSV_INV[code]
+    dst = np.empty((h, w, dcn), np.uint8)
+    o.orc_cvtHSVtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, full, lanes)
+    return dst

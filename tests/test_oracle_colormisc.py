@@ -52,6 +52,24 @@ def test_two_plane_encode(scn):
                 assert np.array_equal(o.orc_cvtBGRtoTwoPlaneYUV(src, swap, uidx), o.ref_cvtBGRtoTwoPlaneYUV(src, swap, uidx)), (w, h, swap, uidx)
 
 
+@pytest.mark.parametrize("code", [54, 55, 70, 71])
+def test_hsv_to_bgr_follows_the_vector_width(code):
+    """cv_hal_cvtHSVtoBGR is not bound yet: the reference truncates inside its vector loop and rounds in the scalar tail, so the
+    8-bit result depends on the lanes of the build that runs.  The restatement takes that width as a parameter; with 8 lanes (AVX2) it
+    equals the oracle/ref build bit for bit, and a 4-lane evaluation differs wherever the two loops split a row differently."""
+    rng = np.random.default_rng(code)
+    differs = 0
+    for (w, h) in [(1, 1), (31, 3), (32, 2), (70, 5), (130, 7), (641, 9)]:
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for dcn in (3, 4):
+            want = np.empty((h, w, dcn), np.uint8)
+            r = o.load_ref()
+            assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
+            assert np.array_equal(o.orc_cvtHSVtoBGR(src, code, dcn, 8), want), (w, h, dcn)
+            differs += int((o.orc_cvtHSVtoBGR(src, code, dcn, 4) != want).sum())
+    assert differs > 0
+
+
 def test_alpha_all_pairs():
     """every (value, alpha) pair, placed in vector bodies and in scalar tails"""
     v, a = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
