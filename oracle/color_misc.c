@@ -220,10 +220,13 @@ void orc_cvtHSVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
             uint8_t* d = dst + (size_t)y * dstep + (size_t)x * dcn;
             float hh = s[0], ss = s[1] * (1.0f / 255.0f), vv = s[2] * (1.0f / 255.0f), b, g, r;
             if (x < body) {
+                /* the AVX2 object of the reference is built with FMA3 and the compiler contracts the vector code's 1 - s*x into one fused
+                 * operation (found by pinning against oracle/ref: 0 differences in 4e5 pixels this way, dozens otherwise) */
                 hh = hh * hscale;
                 const float pre = (float)(int)hh;
                 hh = hh - pre;
-                const float t1 = vv * (1.f - ss), t2 = vv * (1.f - ss * hh), t3 = vv * (1.f - ss * (1.f - hh));
+                const float omh = 1.f - hh;
+                const float t1 = vv * (1.f - ss), t2 = vv * fmaf(-ss, hh, 1.f), t3 = vv * fmaf(-ss, omh, 1.f);
                 float sec = pre * (1.0f / 6.0f);
                 sec = (float)(int)sec;
                 sec = pre - sec * 6.f;
