@@ -523,7 +523,7 @@ int runCorner(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     if (blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg; size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {

@@ -432,7 +432,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
 {
     if (disabled() || W <= 0 || H <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
     Stager stg; size_t dss, dds;
     // stage the whole parent region so that non-isolated borders can read real neighbours
@@ -589,7 +589,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
     Stager stg; size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)offset_y * (ptrdiff_t)src_step - (ptrdiff_t)offset_x * c->cn * se;
@@ -699,7 +699,7 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
         if (normalize && area > lim) return MI355CV_NOT_IMPLEMENTED;    // the reference switches to double sums there
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(src_depth), de = depthSize(dst_depth);
     const int fullW = margin_left + width + margin_right, fullH = margin_top + height + margin_bottom;
     Stager stg; size_t dss, dds;

@@ -150,7 +150,7 @@ MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, u
     if (disabled() || !thresh || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_16U) || thresholdType < 0 || thresholdType > 4)
         return MI355CV_NOT_IMPLEMENTED;
     if ((long long)width * height > 0x7fffffffLL || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == MI355CV_8U ? 1 : 2;
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);

@@ -390,7 +390,7 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
         return MI355CV_NOT_IMPLEMENTED;
     if (point_count == 0) return MI355CV_OK;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;
     // the tracker reads up to one window beyond every image edge (the padded pyramids, hal_replacement.hpp:30-32): stage the padded rectangles
     const int pw = width + 2 * win_width, ph = height + 2 * win_height;
@@ -436,7 +436,7 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
         return MI355CV_NOT_IMPLEMENTED;
     if (point_count == 0) return MI355CV_OK;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const bool useInitial = (flags & 4) != 0, getMinEig = (flags & 8) != 0;                // OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_LK_GET_MIN_EIGENVALS
     int maxCount = (criteria_type & 1) == 0 ? 30 : std::min(std::max(criteria_max_count, 0), 100);                     // :1386-1395
     double eps = (criteria_type & 2) == 0 ? 0.01 : std::min(std::max(criteria_epsilon, 0.), 10.);

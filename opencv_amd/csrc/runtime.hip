@@ -1,5 +1,6 @@
 // runtime.hip -- process/thread runtime of libmi355cv.so (see rt.h).
 #include "rt.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -38,7 +39,13 @@ ThreadCtx& tctx() { static thread_local ThreadCtx c; return c; }
 static bool envFlag(const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; }
 
 bool disabled() { static bool d = envFlag("MI355CV_DISABLE"); return d; }
-size_t minPixels() { static size_t v = getenv("MI355CV_MIN_PIXELS") ? strtoull(getenv("MI355CV_MIN_PIXELS"), nullptr, 10) : 0; return v; }
+size_t minPixels(int cost)
+{
+    static const size_t v = getenv("MI355CV_MIN_PIXELS") ? strtoull(getenv("MI355CV_MIN_PIXELS"), nullptr, 10) : 0;
+    static const bool autoPolicy = getenv("MI355CV_HOST_POLICY") && !strcmp(getenv("MI355CV_HOST_POLICY"), "auto");
+    if (!autoPolicy) return v;
+    return cost == HOST_HEAVY ? std::max<size_t>(v, 64 * 64) : (size_t)-1;
+}
 
 int setError(int code, const char* fmt, ...)
 {

@@ -876,7 +876,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (borderType < 0 || borderType > B_TRANSPARENT) return MI355CV_NOT_IMPLEMENTED;
     if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)dw * dh < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)dw * dh < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     std::call_once(g_tabOnce, buildTab);
     if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
@@ -951,7 +951,7 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
         else return MI355CV_NOT_IMPLEMENTED;                                                // *_EXACT / cubic and lanczos on 16-bit depths: next row (f2)
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
