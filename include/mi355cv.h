@@ -317,6 +317,12 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const mi355cv_uchar* src_data, size_t sr
 MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
 MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
 
+/* would replace hal_ni_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95): CV_8U, HSV.  The reference's 8-bit result depends
+ * on its vector width (truncation in the vector loop, rounding in the scalar tail); this follows the 8-lane AVX2 build.  Not bound in
+ * mi355cv_hal.hpp until its parity test has run on the GPU (written after the last GPU session of round 1). */
+MI355CV_API int mi355cv_cvtHSVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+        int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV);
+
 /* --------------------------------------------------- f1: histogram-driven point operations (csrc/hist.hip) */
 
 /* replaces hal_ni_equalize_hist (hal_replacement.hpp:1120; caller histogram.cpp:3455): CV_8UC1 */

@@ -70,6 +70,7 @@ def _load():
         "mi355cv_cvtBGRtoThreePlaneYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtOnePlaneYUVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int, c_int]),
         "mi355cv_cvtOnePlaneBGRtoYUV": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int, c_int]),
+        "mi355cv_cvtHSVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_cvtBGRtoXYZ": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtXYZtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtBGRtoBGR5x5": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),

@@ -134,6 +134,57 @@ struct OpBgr2Hsv {
     }
 };
 
+// HSV -> BGR/RGB(A), CV_8U: HSV2RGB_b color_hsv.simd.hpp:518-667.  The reference truncates to 8 bits inside its vector loop (and its AVX2
+// object evaluates 1 - s*x fused) but rounds in the scalar tail, so the result depends on where a row splits: `body` = the pixels the
+// 8-lane (AVX2) loop covers, floor(W / 32) * 32 -- the width every x86 host with AVX2 runs, and the one oracle/ref pins.
+template <int DCN>
+__global__ __launch_bounds__(256) void k_hsv2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                    int bidx, float hscale, int body)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar* s = src + (size_t)y * sstep + (size_t)x * 3;
+    uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
+    float hh = (float)s[0];
+    const float ss = (float)s[1] * (1.0f / 255.0f), vv = (float)s[2] * (1.0f / 255.0f);
+    float tab[4];
+    tab[0] = vv;
+    int sector;
+    const bool inBody = x < body;
+    if (inBody) {
+        hh = hh * hscale;
+        const float pre = (float)(int)hh;
+        hh = hh - pre;
+        const float omh = 1.f - hh;
+        tab[1] = vv * (1.f - ss); tab[2] = vv * __builtin_fmaf(-ss, hh, 1.f); tab[3] = vv * __builtin_fmaf(-ss, omh, 1.f);
+        float sec = (float)(int)(pre * (1.0f / 6.0f));
+        sector = (int)(pre - sec * 6.f);
+    } else {
+        hh *= hscale;
+        sector = (int)floorf(hh);
+        hh -= (float)sector;
+        sector %= 6; sector += sector < 0 ? 6 : 0;
+        tab[1] = vv * (1.f - ss); tab[2] = vv * (1.f - ss * hh); tab[3] = vv * (1.f - ss * (1.f - hh));
+    }
+    // sector_data (color_hsv.simd.hpp:440): which of (v, p, q, t) goes to b, g, r
+    float b, g, r;
+    switch (sector) {
+    case 0: b = tab[1]; g = tab[3]; r = tab[0]; break;
+    case 1: b = tab[1]; g = tab[0]; r = tab[2]; break;
+    case 2: b = tab[3]; g = tab[0]; r = tab[1]; break;
+    case 3: b = tab[0]; g = tab[2]; r = tab[1]; break;
+    case 4: b = tab[0]; g = tab[1]; r = tab[3]; break;
+    default: b = tab[2]; g = tab[1]; r = tab[0]; break;
+    }
+    if (!inBody && ss == 0.f) b = g = r = vv;
+    int bi, gi, ri;
+    if (inBody) { bi = (int)(b * 255.f); gi = (int)(g * 255.f); ri = (int)(r * 255.f); }
+    else { bi = __float2int_rn(b * 255.f); gi = __float2int_rn(g * 255.f); ri = __float2int_rn(r * 255.f); }
+    d[bidx] = (uchar)sat8(bi); d[1] = (uchar)sat8(gi); d[bidx ^ 2] = (uchar)sat8(ri);
+    if (DCN == 4) d[3] = 255;
+}
+
 } // namespace
 
 extern "C" {
@@ -241,6 +292,26 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_st
 {
     return mi355cv_cvtTwoPlaneYUVtoBGREx(src_data, src_step, src_data + src_step * (size_t)dst_height, src_step, dst_data, dst_step, dst_width, dst_height,
                                          dcn, swapBlue, uIdx);
+}
+
+// cv_hal_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95), CV_8U HSV only.  NOT yet bound in mi355cv_hal.hpp: written
+// after the last GPU session of round 1 and exercised only by a non-strict parity test until it has run on the MI355X.
+MI355CV_API int mi355cv_cvtHSVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV)
+{
+    if (disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    const float hscale = 6.0f / (isFullRange ? 255 : 180);
+    const int body = (width / 32) * 32;
+    dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (dcn == 3) hipLaunchKernelGGL(k_hsv2bgr_u8<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hscale, body);
+    else hipLaunchKernelGGL(k_hsv2bgr_u8<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, swapBlue ? 2 : 0, hscale, body);
+    return stg.finish("cvtHSVtoBGR");
 }
 
 } // extern "C"

@@ -268,9 +268,22 @@ def cvtColor(src, code, dst=None, dstCn=0):
         else:
             _lib.check(L.mi355cv_cvtThreePlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtThreePlaneYUVtoBGR")
         return out
+    if code in _HSV_INV:                                                    # COLOR_HSV2BGR / RGB (54, 55) and *_FULL (70, 71)
+        swap, full = _HSV_INV[code]
+        dcn = dstCn if dstCn in (3, 4) else 3
+        if s.cn != 3 or s.depth != CV_8U:
+            raise ValueError("cvtColor: HSV2BGR needs a CV_8UC3 source on this path")
+        out = dst if dst is not None else empty_like_kind(src, s.h, s.w, dcn, s.depth)
+        d = Img(out)
+        bind_stream(s, d)
+        _lib.check(L.mi355cv_cvtHSVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(swap), bool(full), True), "cvtHSVtoBGR")
+        return out
     if code in _MISC:
         return _cvt_misc(src, s, code, dst, dstCn)
     raise NotImplementedError(f"cvtColor: conversion code {code} is outside the hot path built so far")
+
+
+_HSV_INV = {54: (0, 0), 55: (1, 0), 70: (0, 1), 71: (1, 1)}
 
 
 def _misc_table():

@@ -50,6 +50,17 @@ def test_xyz_16u_and_alpha(cv, orc):
         assert np.array_equal(cv.cvtColor(dev(src), code).cpu().numpy(), orc.orc_cvtColorMisc(src, code)), code
 
 
+@pytest.mark.xfail(strict=False, reason="mi355cv_cvtHSVtoBGR was written after the last GPU session of round 1; not bound in the HAL header until this passes")
+def test_hsv_to_bgr(cv, orc):
+    rng = np.random.default_rng(12)
+    for code in (54, 55, 70, 71):
+        for (w, h) in [(1, 1), (31, 3), (32, 2), (70, 5), (641, 9), (1920, 1080)]:
+            src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            for dcn in (3, 4):
+                got = cv.cvtColor(dev(src), code, dstCn=dcn).cpu().numpy()
+                assert np.array_equal(got, orc.orc_cvtHSVtoBGR(src, code, dcn, 8)), (code, w, h, dcn)
+
+
 def test_two_plane_encode_round_trip(cv, orc):
     rng = np.random.default_rng(4)
     for (w, h) in [(2, 2), (130, 4), (642, 482), (1920, 1080)]:
