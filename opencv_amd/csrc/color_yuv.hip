@@ -136,7 +136,7 @@ struct OpBgr2Hsv {
 
 // HSV -> BGR/RGB(A), CV_8U: HSV2RGB_b color_hsv.simd.hpp:518-667.  The reference truncates to 8 bits inside its vector loop (and its AVX2
 // object evaluates 1 - s*x fused) but rounds in the scalar tail, so the result depends on where a row splits: `body` = the pixels the
-// 8-lane (AVX2) loop covers, floor(W / 32) * 32 -- the width every x86 host with AVX2 runs, and the one oracle/ref pins.
+// 8-lane (AVX2) loop covers, floor(W / 32) * 32 -- the width every x86 host with AVX2 runs (the build the parity tests compare with).
 template <int DCN>
 __global__ __launch_bounds__(256) void k_hsv2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
                                                     int bidx, float hscale, int body)
