@@ -108,3 +108,42 @@ void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
             d[0] = sat8(hh); d[1] = (uint8_t)sat; d[2] = (uint8_t)v;
         }
 }
+
+/* the same integer formulas for CV_16U (RGB2YCrCb_i<ushort> color_yuv.simd.hpp:255-395, YCrCb2RGB_i<ushort> :890-1010): delta = 32768 */
+void orc_cvtBGRtoYUV16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr;
+    int C0 = 4899, C1 = 9617, C2 = 1868;
+    const int C3 = isCbCr ? 11682 : 14369, C4 = isCbCr ? 9241 : 8061;
+    if (bidx == 0) { const int t = C0; C0 = C2; C2 = t; }
+    const int delta = 32768 * (1 << 14);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint16_t* s = (const uint16_t*)((const uint8_t*)src + (size_t)y * sstepBytes) + (size_t)x * scn;
+            uint16_t* d = (uint16_t*)((uint8_t*)dst + (size_t)y * dstepBytes) + (size_t)x * 3;
+            const int Y = DESCALE14(s[0] * C0 + s[1] * C1 + s[2] * C2);
+            const int Cr = DESCALE14((s[bidx ^ 2] - Y) * C3 + delta);
+            const int Cb = DESCALE14((s[bidx] - Y) * C4 + delta);
+            d[0] = (uint16_t)(Y < 0 ? 0 : Y > 65535 ? 65535 : Y);
+            d[1 + yuvOrder] = (uint16_t)(Cr < 0 ? 0 : Cr > 65535 ? 65535 : Cr);
+            d[2 - yuvOrder] = (uint16_t)(Cb < 0 ? 0 : Cb > 65535 ? 65535 : Cb);
+        }
+}
+
+void orc_cvtYUVtoBGR16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr;
+    const int C0 = isCbCr ? 22987 : 18678, C1 = isCbCr ? -11698 : -9519, C2 = isCbCr ? -5636 : -6472, C3 = isCbCr ? 29049 : 33292;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint16_t* s = (const uint16_t*)((const uint8_t*)src + (size_t)y * sstepBytes) + (size_t)x * 3;
+            uint16_t* d = (uint16_t*)((uint8_t*)dst + (size_t)y * dstepBytes) + (size_t)x * dcn;
+            const int Y = s[0], Cr = s[1 + yuvOrder], Cb = s[2 - yuvOrder];
+            const int b = Y + DESCALE14((Cb - 32768) * C3);
+            const int g = Y + DESCALE14((Cb - 32768) * C2 + (Cr - 32768) * C1);
+            const int r = Y + DESCALE14((Cr - 32768) * C0);
+            d[bidx] = (uint16_t)(b < 0 ? 0 : b > 65535 ? 65535 : b); d[1] = (uint16_t)(g < 0 ? 0 : g > 65535 ? 65535 : g);
+            d[bidx ^ 2] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+            if (dcn == 4) d[3] = 65535;
+        }
+}

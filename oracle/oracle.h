@@ -53,6 +53,8 @@ void orc_cvtYUVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
 void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t* uv_data, size_t uv_step, uint8_t* dst, size_t dstep,
                              int dst_w, int dst_h, int dcn, int swapBlue, int uIdx);
 
+void orc_cvtBGRtoYUV16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int isCbCr);
+void orc_cvtYUVtoBGR16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int isCbCr);
 void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int dst_w, int dst_h, int dcn, int swapBlue, int uIdx);
 
 void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange);

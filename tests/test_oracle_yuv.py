@@ -50,3 +50,27 @@ def test_yuv_known_answers():
     assert (O.orc_cvtColorYUV(nv, 91) == 0).all()
     nv[:2] = 235
     assert (O.orc_cvtColorYUV(nv, 91) == 255).all()
+
+
+def test_yuv_16u_matches_reference():
+    """CV_16U members of the YUV / YCrCb family (integer, delta 32768): restated for the next round's kernels, pinned here"""
+    import orc as o
+    if o.load_ref() is None:
+        pytest.skip("oracle/_ref/libocvref.so not built")
+    rng = np.random.default_rng(3)
+    r = o.load_ref()
+    for (w, h) in [(1, 1), (7, 3), (33, 5), (640, 48)]:
+        for scn in (3, 4):
+            src = rng.integers(0, 65536, (h, w, scn), dtype=np.uint16)
+            for code, (swap, cb) in {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}.items():
+                want = np.empty((h, w, 3), np.uint16); got = np.empty((h, w, 3), np.uint16)
+                assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
+                o.oracle().orc_cvtBGRtoYUV16u(o.P(src), o.step(src), o.P(got), o.step(got), w, h, scn, swap, cb)
+                assert np.array_equal(got, want), (w, h, scn, code)
+        src = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+        for code, (swap, cb) in {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}.items():
+            for dcn in (3, 4):
+                want = np.empty((h, w, dcn), np.uint16); got = np.empty((h, w, dcn), np.uint16)
+                assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
+                o.oracle().orc_cvtYUVtoBGR16u(o.P(src), o.step(src), o.P(got), o.step(got), w, h, dcn, swap, cb)
+                assert np.array_equal(got, want), (w, h, dcn, code)
