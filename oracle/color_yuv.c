@@ -147,3 +147,22 @@ void orc_cvtYUVtoBGR16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, s
             if (dcn == 4) d[3] = 65535;
         }
 }
+
+/* CV_32F forward conversion (RGB2YCrCb_f<float> color_yuv.simd.hpp:134-212).  The 8-lane (AVX2 + FMA3) vector loop covers the first
+ * floor(n / 8) * 8 pixels of a row with explicit fused multiply-adds, y = fma(c0, s0, fma(c1, s1, c2*s2)); the scalar tail of the same
+ * object file is plain C that this toolchain contracts as fma(c2, s2, fma(c0, s0, c1*s1)).  Written that way the restatement equals the
+ * oracle/ref build bit for bit (tests/test_oracle_yuv.py); a kernel only has to meet the 1e-4 contract of CV_32F. */
+void orc_cvtBGRtoYUV32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr, body = (w / 8) * 8;
+    float C0 = 0.299f, C1 = 0.587f, C2 = 0.114f;
+    const float C3 = isCbCr ? 0.713f : 0.877f, C4 = isCbCr ? 0.564f : 0.492f, delta = 0.5f;
+    if (bidx == 0) { const float t = C0; C0 = C2; C2 = t; }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float* s = (const float*)((const uint8_t*)src + (size_t)y * sstepBytes) + (size_t)x * scn;
+            float* d = (float*)((uint8_t*)dst + (size_t)y * dstepBytes) + (size_t)x * 3;
+            const float Y = x < body ? fmaf(s[0], C0, fmaf(s[1], C1, s[2] * C2)) : fmaf(s[2], C2, fmaf(s[0], C0, s[1] * C1));
+            d[0] = Y; d[1 + yuvOrder] = fmaf(s[bidx ^ 2] - Y, C3, delta); d[2 - yuvOrder] = fmaf(s[bidx] - Y, C4, delta);
+        }
+}

@@ -74,3 +74,20 @@ def test_yuv_16u_matches_reference():
                 assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
                 o.oracle().orc_cvtYUVtoBGR16u(o.P(src), o.step(src), o.P(got), o.step(got), w, h, dcn, swap, cb)
                 assert np.array_equal(got, want), (w, h, dcn, code)
+
+
+def test_yuv_32f_forward_matches_reference():
+    """CV_32F BGR -> YUV / YCrCb: the vector body and the (compiler-contracted) scalar tail of the reference build, bit for bit"""
+    import orc as o
+    if o.load_ref() is None:
+        pytest.skip("oracle/_ref/libocvref.so not built")
+    rng = np.random.default_rng(3)
+    r = o.load_ref()
+    for (w, h) in [(1, 1), (7, 3), (33, 5), (643, 48)]:
+        for scn in (3, 4):
+            src = rng.random((h, w, scn), dtype=np.float32)
+            for code, (swap, cb) in {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}.items():
+                want = np.empty((h, w, 3), np.float32); got = np.empty((h, w, 3), np.float32)
+                assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
+                o.oracle().orc_cvtBGRtoYUV32f(o.P(src), o.step(src), o.P(got), o.step(got), w, h, scn, swap, cb)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, scn, code)
