@@ -9,6 +9,7 @@
 // decoders take 4x2 pixels per lane on the same dword traffic.
 #include "rt.h"
 #include "pix4.h"
+#include "hsv_math.h"
 #include <cmath>
 
 using namespace mi355;
@@ -146,42 +147,9 @@ __global__ __launch_bounds__(256) void k_hsv2bgr_u8(const uchar* __restrict__ sr
     if (x >= W || y >= H) return;
     const uchar* s = src + (size_t)y * sstep + (size_t)x * 3;
     uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
-    float hh = (float)s[0];
-    const float ss = (float)s[1] * (1.0f / 255.0f), vv = (float)s[2] * (1.0f / 255.0f);
-    float tab[4];
-    tab[0] = vv;
-    int sector;
-    const bool inBody = x < body;
-    if (inBody) {
-        hh = hh * hscale;
-        const float pre = (float)(int)hh;
-        hh = hh - pre;
-        const float omh = 1.f - hh;
-        tab[1] = vv * (1.f - ss); tab[2] = vv * __builtin_fmaf(-ss, hh, 1.f); tab[3] = vv * __builtin_fmaf(-ss, omh, 1.f);
-        float sec = (float)(int)(pre * (1.0f / 6.0f));
-        sector = (int)(pre - sec * 6.f);
-    } else {
-        hh *= hscale;
-        sector = (int)floorf(hh);
-        hh -= (float)sector;
-        sector %= 6; sector += sector < 0 ? 6 : 0;
-        tab[1] = vv * (1.f - ss); tab[2] = vv * (1.f - ss * hh); tab[3] = vv * (1.f - ss * (1.f - hh));
-    }
-    // sector_data (color_hsv.simd.hpp:440): which of (v, p, q, t) goes to b, g, r
-    float b, g, r;
-    switch (sector) {
-    case 0: b = tab[1]; g = tab[3]; r = tab[0]; break;
-    case 1: b = tab[1]; g = tab[0]; r = tab[2]; break;
-    case 2: b = tab[3]; g = tab[0]; r = tab[1]; break;
-    case 3: b = tab[0]; g = tab[2]; r = tab[1]; break;
-    case 4: b = tab[0]; g = tab[1]; r = tab[3]; break;
-    default: b = tab[2]; g = tab[1]; r = tab[0]; break;
-    }
-    if (!inBody && ss == 0.f) b = g = r = vv;
-    int bi, gi, ri;
-    if (inBody) { bi = (int)(b * 255.f); gi = (int)(g * 255.f); ri = (int)(r * 255.f); }
-    else { bi = __float2int_rn(b * 255.f); gi = __float2int_rn(g * 255.f); ri = __float2int_rn(r * 255.f); }
-    d[bidx] = (uchar)sat8(bi); d[1] = (uchar)sat8(gi); d[bidx ^ 2] = (uchar)sat8(ri);
+    int b, g, r;
+    mi355_hsv2bgr_px(s[0], s[1], s[2], x < body, hscale, b, g, r);
+    d[bidx] = (uchar)b; d[1] = (uchar)g; d[bidx ^ 2] = (uchar)r;
     if (DCN == 4) d[3] = 255;
 }
 
