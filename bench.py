@@ -3,9 +3,11 @@
 3840x2160 CV_8U frames + achieved HBM GB/s against the MI355X roofline.
 
 A "step" is one pass of the hot path over one batch: B device-resident 4K 8UC1 frames per GPU through
-mi355cv_gaussianBlurBinomialBatch (one launch, grid-z = frame).  Frames are independent units, so N GPUs
-= N processes (torchrun) each owning its own frames: weak scaling, no data-path collective; the only
-collective is the RCCL broadcast of the shared filter taps at plan time.
+mi355cv_gaussianBlurBinomialBatch (ONE launch over the whole batch).  B is sized for the GPU's HBM (pick_batch: 9216
+frames = 153 GB of source + destination on a 288 GB MI355X), so a step is ~26 ms and 20 steps span > 0.5 s.  Frames
+are independent units, so N GPUs = N processes each owning its own frames: weak scaling, no data-path collective; the
+only collective is the RCCL broadcast of the shared filter taps at plan time.  `python bench.py --gpus N`
+spawns the N ranks itself when no launcher did (torch.distributed.run) and refuses to run on fewer than N GPUs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline`.
 """
@@ -30,11 +32,14 @@ def cpu_baseline(budget_s=12.0):
     """Reference CPU path on this box's host cores, bounded sample (rank 0, N=1 only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    rng = np.random.default_rng(809564)
     NF = 32                                               # 32 distinct frames: 265 MB in + 265 MB out per sweep
-    frames = rng.integers(0, 256, (NF, H4K, W4K), dtype=np.uint8)
-    frame = frames[0]
     ref = orc.load_ref()
+    if ref is not None:
+        # SURVEY §8d: inputs from cv::RNG(809564) of the reference itself (rng.fill UNIFORM [0,256)), one tall Mat viewed as NF frames
+        frames = orc.ref_rng_fill((NF * H4K, W4K), np.uint8, 809564, 0, 256).reshape(NF, H4K, W4K)
+    else:
+        frames = np.random.default_rng(809564).integers(0, 256, (NF, H4K, W4K), dtype=np.uint8)
+    frame = frames[0]
     if ref is not None:
         import ctypes
         cores = ref.ref_getNumberOfCPUs()
@@ -56,7 +61,8 @@ def cpu_baseline(budget_s=12.0):
                 break
         return {"value": round(n * W4K * H4K / dt / 1e6, 1), "unit": "Mpix/s", "cores": int(cores), "kind": "reference",
                 "sample": f"{n} x cv::GaussianBlur(5x5,sigma=0,REFLECT_101) cycling over {NF} distinct 3840x2160 CV_8UC1 frames, "
-                          f"{cores} threads (oracle/_ref build of the reference: SSE3 baseline + AVX2/AVX512 dispatch, pthreads), {dt:.1f} s"}
+                          f"{cores} threads (oracle/_ref build of the reference: SSE3 baseline, smooth dispatched to AVX2 -- the widest its CMake lists --, "
+                          f"pthreads backend, no IPP / OpenCL), inputs from cv::RNG(809564), {dt:.1f} s"}
     crop = np.ascontiguousarray(frame[:540, :960])
     n, t0 = 0, time.perf_counter()
     while True:
@@ -188,29 +194,124 @@ def next_rows(orc, t, gray, bgr, hd):
     return out
 
 
+def pick_batch(dev, requested):
+    """4K frames per GPU per step.  The step is one pass of the hot path over one device-resident batch; the batch is sized for the GPU's
+    HBM (source + destination = 55 % of the free memory, at most 9216 frames = 153 GB on a 288 GB MI355X) so that a step is ~26 ms, the
+    working set is hundreds of times the 256 MB Infinity Cache, and 20 timed steps span > 0.5 s."""
+    if requested > 0:
+        return requested
+    free, _total = torch.cuda.mem_get_info(dev)
+    b = int(free * 0.55 / (2 * W4K * H4K)) // 128 * 128
+    return max(128, min(9216, b))
+
+
+def parity_gate(cv, frames, out, B):
+    """bit-exact check of the batch result before anything is timed: three whole frames against the plain-C restatement of the reference
+    (oracle/smooth.c), sixteen more against the single-frame hook (a different launch geometry of the same arithmetic)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    checked = []
+    for f in sorted({0, B // 2, B - 1}):
+        want = orc.orc_gaussianBlurBinomialU8(frames[f].cpu().numpy(), 5, 4)
+        assert np.array_equal(out[f].cpu().numpy(), want), f"parity check failed: frame {f} differs from the oracle"
+        checked.append(f)
+    rng = np.random.default_rng(1)
+    for f in rng.integers(0, B, 16).tolist():
+        assert torch.equal(out[f], cv.GaussianBlur(frames[f], 5)), f"batch != single-frame path on frame {f}"
+    return {"frames_vs_oracle": checked, "frames_vs_single_frame_hook": 16, "result": "bit-exact"}
+
+
+def copy_probe(frames, out, reps=3):
+    """the measured-copy denominator: a 16 B / lane device-to-device copy of the same batch, timed the same way"""
+    import ctypes
+    from opencv_amd import _lib
+    from opencv_amd.core import bind_stream, Img
+    bind_stream(Img(frames[0]))
+    nbytes = frames.numel()
+    call = lambda: _lib.lib.mi355cv_copyProbe(ctypes.c_void_p(frames.data_ptr()), ctypes.c_void_p(out.data_ptr()), nbytes, 4, 1)
+    assert call() == 0
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        call()
+    b.record(); torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
+def multi_gpu_legs(cv, dist, dev, rank, world):
+    """BASELINE configs 4 and 5 under N > 1: frames sharded by index, shared parameters broadcast from rank 0 over RCCL, no
+    data-path collective.  cfg4: 256 x 1080p frames -> cornerHarris + buildPyramid(4); cfg5: batched matchTemplate, one template."""
+    from opencv_amd import shard
+    rows = []
+
+    def timed(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]) / n
+
+    g = torch.Generator(device=dev); g.manual_seed(809564 + rank)
+    lo, hi = shard.frame_range(256, rank, world)
+    fr = torch.randint(0, 256, (hi - lo, 1080, 1920), dtype=torch.uint8, device=dev, generator=g)
+    resp = torch.empty((hi - lo, 1080, 1920), dtype=torch.float32, device=dev)
+    params = shard.broadcast_params(np.array([2, 3, 0.04]), 0, dev)              # blockSize, ksize, k: plan-time broadcast
+    bs, ks, kk = int(params[0]), int(params[1]), float(params[2])
+    cv.set_async(True)
+    s = timed(lambda: (cv.cornerHarrisBatch(fr, bs, ks, kk, dst=resp), cv.buildPyramidBatch(fr, 4)), 10)
+    rows.append({"config": f"cfg4 cornerHarris(2,3,0.04) + buildPyramid(4), 256 x 1080p 8UC1 sharded {hi - lo} frames / GPU", "n_gpus": world,
+                 "ms_per_pass": round(s * 1e3, 4), "frames_s": round(256 / s, 1)})
+    del fr, resp
+    B5 = 4
+    img = torch.randint(0, 256, (B5, H4K, W4K), dtype=torch.uint8, device=dev, generator=g)
+    tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g)
+    dist.broadcast(tpl, src=0)                                                   # the one shared template (16 KB) over RCCL
+    res = torch.empty((B5, H4K - 127, W4K - 127), dtype=torch.float32, device=dev)
+    s = timed(lambda: cv.matchTemplateBatch(img, tpl, cv.TM_CCORR_NORMED, result=res), 3, 1)
+    rows.append({"config": f"cfg5 matchTemplate TM_CCORR_NORMED 4K x 128x128 8UC1, {B5} frames / GPU, template broadcast", "n_gpus": world,
+                 "ms_per_pass": round(s * 1e3, 3), "frames_s": round(world * B5 / s, 2)})
+    cv.set_async(False)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "128")),
-                    help="4K frames per GPU per step (in+out = 2 x 8.29 MB x batch, far beyond the 256 MB LLC)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "0")),
+                    help="4K frames per GPU per step; 0 = sized for the GPU's HBM (see pick_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs at N=1)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from opencv_amd import shard                       # no launcher: become the launcher (N ranks, one per GPU, RCCL); loud when < N GPUs
+        sys.exit(shard.spawn_ranks(args.gpus, __file__, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} has no GPU (local_rank {local_rank}, {torch.cuda.device_count()} visible)")
     dist = None
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     import opencv_amd as cv
+    from opencv_amd import _lib
 
     # plan time: rank 0 owns the filter definition; RCCL broadcast over xGMI (bytes, once)
     taps = torch.from_numpy(cv.getGaussianKernelQ8_binomial(5).astype(np.int32)).to(dev) if rank == 0 \
@@ -219,21 +320,23 @@ def main():
         dist.broadcast(taps, src=0)
     assert taps.cpu().tolist() == [16, 64, 96, 64, 16]
 
-    B = args.batch
+    B = pick_batch(dev, args.batch)
+    if dist is not None:                                    # every rank runs the same per-GPU batch (weak scaling)
+        tb = torch.tensor([B], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MIN)
+        B = int(tb[0])
     g = torch.Generator(device=dev)
     g.manual_seed(809564 + rank)
-    frames = torch.randint(0, 256, (B, H4K, W4K), dtype=torch.uint8, device=dev, generator=g)
+    frames = torch.empty((B, H4K, W4K), dtype=torch.uint8, device=dev)
+    for lo in range(0, B, 256):                             # filled in slabs: the generator's scratch stays small next to a 76 GB batch
+        frames[lo:lo + 256] = torch.randint(0, 256, (min(256, B - lo), H4K, W4K), dtype=torch.uint8, device=dev, generator=g)
     out = torch.empty_like(frames)
 
-    # parity gate before timing: frame 0 against the CPU checker (bit-exact)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
+    # parity gate before timing (rank 0: against the CPU checker; every rank: the call must succeed)
     cv.GaussianBlurBatch(frames, 5, dst=out)
     torch.cuda.synchronize()
-    if rank == 0:
-        want = orc.orc_gaussianBlurBinomialU8(frames[0, :256].cpu().numpy(), 5, 4)[:-2]
-        assert np.array_equal(out[0, :254].cpu().numpy(), want), "parity check failed"
-        assert torch.equal(out[B - 1, -64:], cv.GaussianBlur(frames[B - 1], 5)[-64:]), "batch != single-frame"
+    kernel = _lib.lib.mi355cv_lastKernel().decode()
+    parity = parity_gate(cv, frames, out, B) if rank == 0 else None
 
     cv.set_async(True)
     for _ in range(args.warmup):
@@ -254,21 +357,39 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     cv.set_async(False)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_step = np.array([a.elapsed_time(b) for a, b in ev])
+    kern_ms = float(per_step.mean())
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
+    copy_gbs = copy_probe(frames, out) if rank == 0 else None
+
+    legs = None
+    if world > 1 and not args.no_other_configs:
+        del frames, out
+        torch.cuda.empty_cache()
+        try:
+            legs = multi_gpu_legs(cv, dist, dev, rank, world)
+        except Exception as e:
+            legs = [{"config": "multi-GPU legs", "error": repr(e)}]
 
     if rank == 0:
         pix_per_step = B * W4K * H4K
         value = world * pix_per_step * args.steps / elapsed / 1e6
-        achieved = ALGO_BYTES_PER_PIXEL * pix_per_step / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        algo = ALGO_BYTES_PER_PIXEL * pix_per_step
+        achieved = algo / (kern_ms * 1e-3) / 1e9
+        q = max(1, args.steps // 4)
+        # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this same command (tools/prof_gauss.sh), corrected
+        # as MI355X_MICROARCH.md prescribes; used only when it was taken on the kernel instance this run launched, scaled to this batch
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                j = json.load(open(tj))
+                if j.get("kernel", "").split(" grid=")[0] == kernel.split(" grid=")[0] and j.get("frames_per_launch"):
+                    traffic = int(j["hbm_bytes_per_launch"] * (B / j["frames_per_launch"]))
+                    traffic_src = j.get("source")
             except Exception:
                 traffic = None
         res = {
@@ -277,14 +398,24 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "cv::GaussianBlur 5x5 sigma=0 BORDER_REFLECT_101 on 3840x2160 CV_8UC1, "
-                                   f"{B} device-resident frames per GPU per step (one batched launch)",
-                       "frames_per_gpu": B, "sharding": f"frames x{world}, no data-path collective"},
+                                   f"{B} device-resident frames per GPU per step (one batched launch over {2 * B * W4K * H4K / 1e9:.1f} GB of HBM)",
+                       "frames_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "ranks": world,
+                       "collective": "RCCL broadcast of the filter taps at plan time" if world > 1 else "none (1 GPU)"},
             "per_gpu_mpix_s": round(value / world, 1),
+            "timed_region_s": round(elapsed, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_binomial_roll2<5,1,true,false,4>", "avg_launch_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PIXEL * pix_per_step)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "avg_launch_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": int(algo),
+                         "launch_ms": {"median": round(float(np.median(per_step)), 4), "p10": round(float(np.percentile(per_step, 10)), 4),
+                                       "p90": round(float(np.percentile(per_step, 90)), 4), "min": round(float(per_step.min()), 4),
+                                       "max": round(float(per_step.max()), 4), "first_quarter_mean": round(float(per_step[:q].mean()), 4),
+                                       "rest_mean": round(float(per_step[q:].mean()), 4) if args.steps > q else None},
+                         "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)},
+            "parity": parity,
         }
+        if legs is not None:
+            res["other_configs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_other_configs:

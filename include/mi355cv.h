@@ -74,12 +74,23 @@ typedef unsigned char mi355cv_uchar;
 
 /* ------------------------------------------------------------------ runtime */
 
-/* library / device bring-up; returns 0 when a gfx950 device is usable */
+/* library / device bring-up; returns 0 when a gfx950 device is usable.  `device` >= 0 names the process default device (first call wins;
+ * otherwise MI355CV_DEVICE, or the device the host program had current at first use). */
 MI355CV_API int  mi355cv_init(int device);
+/* multi-GPU in one process (one host thread + its streams per device, frames sharded by index, no data-path collective):
+ * mi355cv_setDevice binds the CALLING THREAD's hooks to a device ordinal (-1: back to the process default).  Streams, events and the scratch
+ * pool are kept per thread AND device; the host program's own current HIP device is put back when a hook returns; an image that lives in
+ * another GPU's memory makes the hook answer NOT_IMPLEMENTED (mi355cv_lastError names both devices).  Returns 0, or -1 for an ordinal that
+ * does not exist / is not gfx950. */
+MI355CV_API int  mi355cv_deviceCount(void);
+MI355CV_API int  mi355cv_setDevice(int device);
+MI355CV_API int  mi355cv_getDevice(void);
 MI355CV_API const char* mi355cv_version(void);
 MI355CV_API const char* mi355cv_lastError(void);
-/* stream used for launches made by the calling thread: exactly this hipStream_t (NULL = HIP's null
- * stream).  Until called -- or after mi355cv_resetStream() -- a library-owned per-thread stream is used. */
+/* template instance + launch geometry of the dominant kernel the calling thread launched last (bench.py reports it beside the roofline) */
+MI355CV_API const char* mi355cv_lastKernel(void);
+/* stream used for launches made by the calling thread on its current device (mi355cv_setDevice): exactly this hipStream_t (NULL = HIP's
+ * null stream).  Until called -- or after mi355cv_resetStream() -- a library-owned per-thread, per-device stream is used. */
 MI355CV_API int  mi355cv_setStream(void* hipStream);
 MI355CV_API int  mi355cv_resetStream(void);
 /* 1: calls on device-resident images return after enqueue (caller synchronises); 0 (default): synchronous */
@@ -88,6 +99,9 @@ MI355CV_API int  mi355cv_synchronize(void);
 /* number of times the named entry point ran its GPU path to completion in this process
  * (the analogue of the reference's CV_IMPL_ADD bookkeeping, core/private.hpp) */
 MI355CV_API long long mi355cv_callCount(const char* entry);
+/* image bytes the hooks of this process have moved over PCIe so far (host-resident images staged into HBM + results staged back); stays
+ * constant across calls on device-resident / managed images -- how a test shows that a pipeline ran in place in HBM */
+MI355CV_API long long mi355cv_stagedBytes(void);
 /* experiment knobs (see tools/tune_gauss.py) and the streaming-copy probe used as the measured-copy
  * roofline denominator */
 MI355CV_API int mi355cv_setParam(const char* key, int value);
@@ -116,8 +130,9 @@ MI355CV_API int mi355cv_gaussianBlurBinomial(const mi355cv_uchar* src_data, size
         size_t ksize, int border_type);
 
 /* replaces hal_ni_gaussianBlur (hal_replacement.hpp:1146); callers smooth.dispatch.cpp:708,778,813.
- * Implemented: depth 8U (Q8.8 fixed-point path of GaussianBlurFixedPoint, bit-exact for the
- * sigma==0 tables; sigma>0 kernels are generated as getGaussianKernelBitExact does) and 32F. */
+ * Implemented: depth 8U with zero margins = the Q8.8 fixed-point path of GaussianBlurFixedPoint (:720), bit-exact (sigma>0 kernels are
+ * generated as getGaussianKernelBitExact does).  Declined: other depths (the reference then runs sepFilter2D, whose hooks serve it) and an
+ * 8U submatrix with real margins (call site :813 -- there the CPU result is sepFilter2D with float taps, not the fixed-point one). */
 MI355CV_API int mi355cv_gaussianBlur(const mi355cv_uchar* src_data, size_t src_step,
         mi355cv_uchar* dst_data, size_t dst_step, int width, int height, int depth, int cn,
         size_t margin_left, size_t margin_top, size_t margin_right, size_t margin_bottom,
@@ -317,9 +332,9 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const mi355cv_uchar* src_data, size_t sr
 MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
 MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
 
-/* would replace hal_ni_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95): CV_8U, HSV.  The reference's 8-bit result depends
- * on its vector width (truncation in the vector loop, rounding in the scalar tail); this follows the 8-lane AVX2 build.  Not bound in
- * mi355cv_hal.hpp until its parity test has run on the GPU (written after the last GPU session of round 1). */
+/* replaces hal_ni_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95): CV_8U, HSV (HLS and CV_32F decline).  The reference's
+ * 8-bit result depends on its vector width (truncation in the vector loop, rounding in the scalar tail); this follows the 8-lane AVX2 build,
+ * the widest `color_hsv` is dispatched for (modules/imgproc/CMakeLists.txt: SSE2 SSE4_1 AVX2). */
 MI355CV_API int mi355cv_cvtHSVtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV);
 

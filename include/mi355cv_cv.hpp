@@ -16,13 +16,18 @@ namespace mi355cv {
 
 // cv::MatAllocator (core/mat.hpp:496-524) whose matrices live in memory the MI355X reaches without a pageable bounce:
 //   FrameAllocator::Pinned   page-locked host memory -- a hook still stages the frame through HBM, but as one DMA at PCIe rate;
-//   FrameAllocator::Managed  managed memory          -- hooks run on the matrix in place, CPU code keeps working on the same pointer.
+//   FrameAllocator::Managed  managed memory          -- hooks run on the matrix in place, CPU code keeps working on the same pointer;
+//   FrameAllocator::Device   HBM (hipMalloc)         -- the matrix LIVES on the GPU: hooks run on it in place with no PCIe
+//                            traffic at all, which is the regime the roofline numbers are quoted in.  The CPU must not dereference such a
+//                            matrix: fill / read it with mi355cv::upload / mi355cv::download, and only hand it to cv:: functions whose hook
+//                            serves the call (a call the library declines would fall back to CPU code on device memory).  Managed is the
+//                            forgiving variant of the same thing.
 // Install per matrix (`m.allocator = &alloc; m.create(...)`) or process-wide (`cv::Mat::setDefaultAllocator(&alloc)`, mat.hpp:2169).
 // Without a gfx950 device the storage comes from cv::fastMalloc, so the same binary runs on a CPU-only host.
 class FrameAllocator : public cv::MatAllocator
 {
 public:
-    enum Kind { Pinned = 0, Managed = 1 };
+    enum Kind { Pinned = 0, Managed = 1, Device = 2 };
     explicit FrameAllocator(Kind kind = Pinned) : kind_(kind) {}
 
     cv::UMatData* allocate(int dims, const int* sizes, int type, void* user, size_t* step, cv::AccessFlag, cv::UMatUsageFlags) const CV_OVERRIDE
@@ -38,7 +43,7 @@ public:
         cv::UMatData* u = new cv::UMatData(this);
         u->size = bytes;
         if (user) { u->data = u->origdata = (uchar*)user; u->flags |= cv::UMatData::USER_ALLOCATED; return u; }
-        void* p = mi355cv_hostAlloc(bytes, (int)kind_);
+        void* p = kind_ == Device ? mi355cv_deviceAlloc(bytes) : mi355cv_hostAlloc(bytes, (int)kind_);
         u->userdata = p ? (void*)this : nullptr;                 // remembers which heap the block came from
         if (!p) p = cv::fastMalloc(bytes);
         u->data = u->origdata = (uchar*)p;
@@ -50,19 +55,44 @@ public:
         if (!u) return;
         CV_Assert(u->urefcount == 0 && u->refcount == 0);
         if (!(u->flags & cv::UMatData::USER_ALLOCATED) && u->origdata) {
-            if (u->userdata) mi355cv_hostFree(u->origdata, (int)kind_); else cv::fastFree(u->origdata);
+            if (!u->userdata) cv::fastFree(u->origdata);
+            else if (kind_ == Device) mi355cv_deviceFree(u->origdata);
+            else mi355cv_hostFree(u->origdata, (int)kind_);
             u->origdata = nullptr;
         }
         delete u;
     }
+    Kind kind() const { return kind_; }
 private:
     Kind kind_;
 };
 
+// host <-> device copies for matrices backed by FrameAllocator::Device (row by row when either side has padded rows); any other pair of
+// matrices is copied with Mat::copyTo.  `dst` is created through its own allocator when it does not have the right geometry yet.
+inline void upload(const cv::Mat& host, cv::Mat& dev)
+{
+    dev.create(host.rows, host.cols, host.type());
+    const size_t row = (size_t)host.cols * host.elemSize();
+    if (host.isContinuous() && dev.isContinuous()) { CV_Assert(mi355cv_upload(dev.data, host.data, row * host.rows) == 0); return; }
+    for (int y = 0; y < host.rows; y++) CV_Assert(mi355cv_upload(dev.ptr(y), host.ptr(y), row) == 0);
+}
+inline void download(const cv::Mat& dev, cv::Mat& host)
+{
+    host.create(dev.rows, dev.cols, dev.type());
+    const size_t row = (size_t)dev.cols * dev.elemSize();
+    if (host.isContinuous() && dev.isContinuous()) { CV_Assert(mi355cv_download(host.data, dev.data, row * dev.rows) == 0); return; }
+    for (int y = 0; y < dev.rows; y++) CV_Assert(mi355cv_download(host.ptr(y), dev.ptr(y), row) == 0);
+}
+
+// the stock functions read REAL parent pixels around a submatrix unless BORDER_ISOLATED is set (cornerEigenValsVecs runs Sobel / boxFilter on
+// the view, corner.cpp:237; buildOpticalFlowPyramid's copyMakeBorder does the same, lkpyramid.cpp:747).  The fused entry points below get no
+// margins and treat their input as a whole image, so such calls are left to cv::.
+inline bool seesParent(const cv::Mat& m, int borderType) { return m.isSubmatrix() && !(borderType & cv::BORDER_ISOLATED); }
+
 inline void cornerHarris(cv::InputArray _src, cv::OutputArray _dst, int blockSize, int ksize, double k, int borderType = cv::BORDER_DEFAULT)
 {
     cv::Mat src = _src.getMat();
-    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1)) {
+    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1) && !seesParent(src, borderType)) {
         _dst.create(src.size(), CV_32FC1);
         cv::Mat dst = _dst.getMat();
         if (mi355cv_cornerHarris(src.data, src.step, dst.data, dst.step, src.cols, src.rows, src.type(), blockSize, ksize, k, borderType) == MI355CV_OK)
@@ -74,7 +104,7 @@ inline void cornerHarris(cv::InputArray _src, cv::OutputArray _dst, int blockSiz
 inline void cornerMinEigenVal(cv::InputArray _src, cv::OutputArray _dst, int blockSize, int ksize = 3, int borderType = cv::BORDER_DEFAULT)
 {
     cv::Mat src = _src.getMat();
-    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1)) {
+    if (src.dims <= 2 && (src.type() == CV_8UC1 || src.type() == CV_32FC1) && !seesParent(src, borderType)) {
         _dst.create(src.size(), CV_32FC1);
         cv::Mat dst = _dst.getMat();
         if (mi355cv_cornerMinEigenVal(src.data, src.step, dst.data, dst.step, src.cols, src.rows, src.type(), blockSize, ksize, borderType) == MI355CV_OK)
@@ -89,7 +119,8 @@ inline void goodFeaturesToTrack(cv::InputArray _image, cv::OutputArray _corners,
 {
     cv::Mat image = _image.getMat(), mask = _mask.empty() ? cv::Mat() : _mask.getMat();
     const bool maskOk = mask.empty() || (mask.type() == CV_8UC1 && mask.size() == image.size());
-    if (image.dims <= 2 && (image.type() == CV_8UC1 || image.type() == CV_32FC1) && maskOk && qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0) {
+    if (image.dims <= 2 && (image.type() == CV_8UC1 || image.type() == CV_32FC1) && maskOk && qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0 &&
+        !seesParent(image, cv::BORDER_DEFAULT)) {                          // featureselect.cpp:412-415 runs the corner measure with BORDER_DEFAULT
         // the entry point writes at most `cap` corners; with maxCorners <= 0 the reference returns every one it finds
         const int cap = maxCorners > 0 ? maxCorners : image.rows * image.cols;
         std::vector<cv::Point2f> pts((size_t)cap);
@@ -156,7 +187,7 @@ inline void calcOpticalFlowPyrLK(cv::InputArray _prevImg, cv::InputArray _nextIm
         const int n = pts.checkVector(2, CV_32F, true);
         const bool initial = (flags & cv::OPTFLOW_USE_INITIAL_FLOW) != 0;
         if (prev.dims <= 2 && prev.depth() == CV_8U && prev.type() == next.type() && prev.size() == next.size() && n > 0 && maxLevel >= 0 &&
-            winSize.width > 2 && winSize.height > 2) {
+            winSize.width > 2 && winSize.height > 2 && !prev.isSubmatrix() && !next.isSubmatrix()) {
             if (!initial) _nextPts.create(pts.size(), pts.type(), -1, true);
             cv::Mat nextPts = _nextPts.getMat();
             if (nextPts.checkVector(2, CV_32F, true) == n) {

@@ -92,6 +92,9 @@
 #define cv_hal_cvtTwoPlaneYUVtoBGR mi355cv_cvtTwoPlaneYUVtoBGR
 #undef  cv_hal_cvtBGRtoHSV
 #define cv_hal_cvtBGRtoHSV mi355cv_cvtBGRtoHSV
+// hal_replacement.hpp:613 / caller color_hsv.dispatch.cpp:95 (8U HSV; follows the 8-lane AVX2 build of HSV2RGB_b -- see mi355cv.h)
+#undef  cv_hal_cvtHSVtoBGR
+#define cv_hal_cvtHSVtoBGR mi355cv_cvtHSVtoBGR
 #undef  cv_hal_cvtThreePlaneYUVtoBGR
 #define cv_hal_cvtThreePlaneYUVtoBGR mi355cv_cvtThreePlaneYUVtoBGR
 #undef  cv_hal_cvtTwoPlaneYUVtoBGREx

@@ -30,13 +30,18 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     sig = {
         "mi355cv_init": (c_int, [c_int]),
+        "mi355cv_deviceCount": (c_int, []),
+        "mi355cv_setDevice": (c_int, [c_int]),
+        "mi355cv_getDevice": (c_int, []),
         "mi355cv_version": (ctypes.c_char_p, []),
         "mi355cv_lastError": (ctypes.c_char_p, []),
+        "mi355cv_lastKernel": (ctypes.c_char_p, []),
         "mi355cv_setStream": (c_int, [ctypes.c_void_p]),
         "mi355cv_resetStream": (c_int, []),
         "mi355cv_setAsync": (c_int, [c_int]),
         "mi355cv_synchronize": (c_int, []),
         "mi355cv_callCount": (ctypes.c_longlong, [ctypes.c_char_p]),
+        "mi355cv_stagedBytes": (ctypes.c_longlong, []),
         "mi355cv_setParam": (c_int, [ctypes.c_char_p, c_int]),
         "mi355cv_copyProbe": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz, c_int, c_int]),
         "mi355cv_copyProbeColwalk": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_int, c_int, c_int]),

@@ -1,5 +1,6 @@
 """Array plumbing shared by the host-side mirror: type codes, borders, buffers."""
 import ctypes
+import threading
 import numpy as np
 
 try:  # torch is plumbing (device memory + streams), not the product
@@ -54,7 +55,9 @@ class Img:
             if nd == 3 and self.cn > 1 and st[1] != self.cn:
                 raise ValueError("pixels must be contiguous within a row")
             self.depth, self.esz = _T_DEPTH_ESZ[a.dtype]
-            self.step = st[0] * self.esz if self.h > 1 else self.w * self.cn * self.esz
+            # a one-row view keeps its parent's step like a cv::Mat submatrix does (the hooks reach real rows above / below a ROI through it)
+            rowb = self.w * self.cn * self.esz
+            self.step = st[0] * self.esz if st[0] * self.esz >= rowb else rowb
             self.ptr = a.data_ptr()
             self.device = a.is_cuda
         else:
@@ -70,7 +73,8 @@ class Img:
                 raise ValueError("pixels must be contiguous within a row")
             if a.ndim == 2 and self.w > 1 and a.strides[1] != self.esz:
                 raise ValueError("image rows must be dense")
-            self.step = a.strides[0] if self.h > 1 else self.w * self.cn * self.esz
+            rowb = self.w * self.cn * self.esz
+            self.step = a.strides[0] if a.strides[0] >= rowb else rowb
             self.ptr = a.ctypes.data
             self.device = False
 
@@ -90,6 +94,9 @@ def empty_like_kind(ref, h, w, cn, depth):
 _raw_stream = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None) if torch is not None else None
 
 
+_tls = threading.local()   # .dev: device ordinal the calling thread's hooks were last bound to (the library's binding is per thread too)
+
+
 def bind_stream(*imgs):
     """Launch on torch's current stream when the images live on a torch CUDA device."""
     if torch is None:
@@ -97,8 +104,12 @@ def bind_stream(*imgs):
     for im in imgs:
         if im is not None and im.device:
             dev = im.obj.device
-            if torch.cuda.current_device() != dev.index:
-                torch.cuda.set_device(dev)
+            # the hooks of this thread run on the device that owns the image (one context per thread and device inside the library), on
+            # torch's current stream for THAT device; torch's own current device is left alone (the library restores it after each hook)
+            if getattr(_tls, "dev", None) != dev.index:
+                if _lib.lib.mi355cv_setDevice(dev.index) != 0:
+                    raise RuntimeError("mi355cv_setDevice(%d): %s" % (dev.index, _lib.lib.mi355cv_lastError().decode()))
+                _tls.dev = dev.index
             # the raw handle of torch's current stream (the public route builds a Stream object per call)
             h = _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
             _lib.lib.mi355cv_setStream(ctypes.c_void_p(h))

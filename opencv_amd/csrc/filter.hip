@@ -312,6 +312,14 @@ __global__ __launch_bounds__(256) void k_box_generic(
         return;
     }
     if (ddepth == D32F) { reinterpret_cast<float*>(drow)[e] = p.normalize ? (float)((double)s * p.scaleD) : (float)s; return; }
+    if (p.normalize && e >= ((W * cn) & ~7)) {
+        // the reference's scalar tail (the last (W*cn) % 8 elements of a row, box_filter.simd.hpp:380-385) multiplies in double
+        const double r = rint((double)s * p.scaleD);
+        if (ddepth == D8U) drow[e] = (uchar)(int)fmin(fmax(r, 0.0), 255.0);
+        else if (ddepth == D16U) reinterpret_cast<unsigned short*>(drow)[e] = (unsigned short)(int)fmin(fmax(r, 0.0), 65535.0);
+        else reinterpret_cast<short*>(drow)[e] = (short)(int)fmin(fmax(r, -32768.0), 32767.0);
+        return;
+    }
     float v = p.normalize ? rintf((float)s * p.scaleF) : (float)s;
     stF(drow, e, ddepth, v);
 }
@@ -434,9 +442,11 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
-    Stager stg; size_t dss, dds;
     // stage the whole parent region so that non-isolated borders can read real neighbours
     const uchar* top = src - (ptrdiff_t)offY * (ptrdiff_t)sstep - (ptrdiff_t)offX * c.cn * se;
+    if (overlapOnDevice(top, (size_t)(fullH - 1) * sstep + (size_t)fullW * c.cn * se, dst, (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
+        return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the device-resident source rows (in-place)", entry);
+    Stager stg; size_t dss, dds;
     const uchar* dtop = stg.in(top, sstep, (size_t)fullW * c.cn * se, fullH, &dss);
     uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -591,8 +601,18 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
-    Stager stg; size_t dss, dds;
+    // hal::filter2D tries the hook before its own DFT path (filter.dispatch.cpp:1436-1470): for a whole image and a kernel of >= 130 taps
+    // (8U -> 8U / 16S, 32F -> 32F; >= 50 otherwise) the CPU result comes from float FFTs (dftFilter2D :1274-1340), which a direct sum does
+    // not reproduce bit for bit -- leave those to the CPU
+    {
+        const bool fastTypes = (c->sdepth == D8U && (c->ddepth == D8U || c->ddepth == D16S)) || (c->sdepth == D32F && c->ddepth == D32F);
+        if (c->kw * c->kh >= (fastTypes ? 130 : 50) && offset_x == 0 && offset_y == 0 && width == full_width && height == full_height)
+            return setError(MI355CV_NOT_IMPLEMENTED, "filter: %dx%d kernel on a whole image is the reference's DFT case", c->kw, c->kh);
+    }
     const uchar* top = src_data - (ptrdiff_t)offset_y * (ptrdiff_t)src_step - (ptrdiff_t)offset_x * c->cn * se;
+    if (overlapOnDevice(top, (size_t)(full_height - 1) * src_step + (size_t)full_width * c->cn * se, dst_data, (size_t)(height - 1) * dst_step + (size_t)width * c->cn * de))
+        return setError(MI355CV_NOT_IMPLEMENTED, "filter: dst overlaps the device-resident source rows (in-place)");
+    Stager stg; size_t dss, dds;
     const uchar* dtop = stg.in(top, src_step, (size_t)full_width * c->cn * se, full_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * de, height, &dds);
     Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));

@@ -34,12 +34,27 @@ enum HostCost { HOST_CHEAP = 0, HOST_HEAVY = 1 };
 size_t minPixels(int cost = HOST_CHEAP);
 int  setError(int code, const char* fmt, ...);
 void bump(const char* entry);       // per-entry completed-on-GPU counter
-bool ensureDevice();                // lazily selects the device; false if no usable GPU
+void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)
+bool ensureDevice();                // makes the calling thread's device current (mi355cv_setDevice, else the process default); false if no usable GPU
+int  activeDevice();                // ordinal of that device (per-device caches key on it)
 
-// true if p points into device or managed memory (launch in place)
+// where an image lives: plain / page-locked host memory (staged through HBM), this thread's device or managed memory (launched in place),
+// or ANOTHER GPU's memory (the hook declines: the thread is bound to the wrong device for that image)
+enum PtrKind { PTR_HOST = 0, PTR_DEVICE = 1, PTR_FOREIGN = 2 };
+int  ptrKind(const void* p);
+// true if p points into this device's or managed memory (launch in place)
 bool isDevicePtr(const void* p);
 // src and dst are the same buffer in HBM: a stencil cannot run in place on the GPU (host images are staged into separate buffers, so they may)
 inline bool inPlaceOnDevice(const void* src, const void* dst) { return src == dst && src && isDevicePtr(src); }
+// the general form for hooks that get no allowInplace argument (cv_hal_sepFilter, cv_hal_filter): the device-resident rows a stencil reads,
+// [s, s + sbytes) -- the ROI plus the parent rows above / below it -- intersect the rows it writes.  FilterEngine is in-place safe on the CPU
+// (ring buffer of rows); GPU threads would read neighbours other threads have already overwritten, so such a call is left to the CPU.
+inline bool overlapOnDevice(const void* s, size_t sbytes, const void* d, size_t dbytes)
+{
+    const char* a = (const char*)s; const char* b = (const char*)d;
+    if (!a || !b || a + sbytes <= b || b + dbytes <= a) return false;
+    return isDevicePtr(s) && isDevicePtr(d);
+}
 
 // Stages host images into HBM scratch (and results back).  Device-resident
 // images pass through untouched.  One Stager per hook invocation.
@@ -64,6 +79,7 @@ private:
     std::vector<Out> outs_;
     bool anyHost_ = false, failed_ = false;
     void* bump_(size_t bytes);
+    bool foreign_(const void* p);
 };
 
 inline int divUp(int a, int b) { return (a + b - 1) / b; }

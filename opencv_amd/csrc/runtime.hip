@@ -12,13 +12,24 @@
 
 namespace mi355 {
 
-static std::atomic<int> g_device{-1};
-static std::atomic<int> g_deviceState{0};  // 0 unknown, 1 ok, -1 unusable
+// ---- devices.  A hook runs on the calling thread's device: the one chosen with mi355cv_setDevice on that thread, else the process default
+// (MI355CV_DEVICE, mi355cv_init(dev), or whatever device the host program had current when the library was first used).  Every thread keeps
+// one context (streams, events, scratch pool) PER DEVICE, so one C++ process can drive the 8 GPUs of a node from 8 host threads (SURVEY §8e:
+// "one host thread + >= 2 HIP streams per device"), and the host program's own current device is put back when the outermost hook returns.
+constexpr int MAX_DEV = 16;
+static std::atomic<int> g_defaultDev{-1};
+static std::atomic<int> g_nDev{-2};                 // -2 unknown, <= 0 none
+static std::atomic<int> g_devState[MAX_DEV];        // 0 unknown, 1 usable (gfx950), -1 not
 static std::mutex g_mu;
 static std::map<std::string, long long> g_counts;
+static std::atomic<long long> g_stagedBytes{0};   // image bytes the hooks moved over PCIe (host images staged in + results staged back)
 static thread_local char t_err[512] = "";
+static thread_local int t_dev = -1;                 // mi355cv_setDevice; -1 = process default
+static thread_local int t_active = 0;               // device of the hook that is running = index of the per-device thread context
+static thread_local int t_restore = -1;             // the caller's current device, to be put back by the outermost hook
+static thread_local int t_depth = 0;                // hooks may call other hooks (adaptiveThreshold -> boxFilter): only the outermost Stager recycles / restores
 
-struct Buf { void* p; size_t cap; bool busy; };
+struct Buf { void* p; size_t cap; bool busy; hipStream_t last; };
 
 struct ThreadCtx {
     hipStream_t own = nullptr;
@@ -27,14 +38,14 @@ struct ThreadCtx {
     hipEvent_t events[64] = {};
     bool useUser = false;
     bool async = false;
-    int stagerDepth = 0;              // hooks may call other hooks (adaptiveThreshold -> boxFilter): only the outermost Stager recycles the pool
     std::vector<Buf> pool;
     ~ThreadCtx() {
         // process teardown order vs. the HIP runtime is undefined: leak on purpose
     }
 };
 
-ThreadCtx& tctx() { static thread_local ThreadCtx c; return c; }
+ThreadCtx& tctx() { static thread_local ThreadCtx c[MAX_DEV]; return c[t_active]; }
+int activeDevice() { return t_active; }
 
 static bool envFlag(const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; }
 
@@ -45,6 +56,12 @@ size_t minPixels(int cost)
     static const bool autoPolicy = getenv("MI355CV_HOST_POLICY") && !strcmp(getenv("MI355CV_HOST_POLICY"), "auto");
     if (!autoPolicy) return v;
     return cost == HOST_HEAVY ? std::max<size_t>(v, 64 * 64) : (size_t)-1;
+}
+
+static thread_local char t_kernel[160] = "";
+void noteKernel(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(t_kernel, sizeof t_kernel, fmt, ap); va_end(ap);
 }
 
 int setError(int code, const char* fmt, ...)
@@ -70,39 +87,68 @@ void bump(const char* entry)
     g_counts[entry]++;
 }
 
-bool ensureDevice()
+static int deviceCount()
 {
-    int st = g_deviceState.load();
-    if (st == 0) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        st = g_deviceState.load();
-        if (st == 0) {
-            int n = 0;
-            if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); g_deviceState = -1; setError(MI355CV_NOT_IMPLEMENTED, "no HIP device"); return false; }
-            int dev = g_device.load();
-            if (dev < 0) {
-                if (hipGetDevice(&dev) != hipSuccess) dev = 0;   // honour a device the host already selected (e.g. torch.cuda.set_device)
+    int n = g_nDev.load();
+    if (n == -2) {
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 0; }
+        if (n > MAX_DEV) n = MAX_DEV;
+        g_nDev = n;
+    }
+    return n;
+}
+
+// the device this thread's hooks run on (no HIP state is touched); -1 without a usable GPU
+static int resolveDevice()
+{
+    const int n = deviceCount();
+    if (n <= 0) { setError(MI355CV_NOT_IMPLEMENTED, "no HIP device"); return -1; }
+    int d = t_dev;
+    if (d < 0) {
+        d = g_defaultDev.load();
+        if (d < 0) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            d = g_defaultDev.load();
+            if (d < 0) {
+                if (hipGetDevice(&d) != hipSuccess) d = 0;       // honour a device the host already selected (e.g. torch.cuda.set_device)
                 const char* e = getenv("MI355CV_DEVICE");
-                if (e) dev = atoi(e);
+                if (e) d = atoi(e);
+                if (d < 0 || d >= n) d = 0;
+                g_defaultDev = d;
             }
-            if (dev >= n) dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { g_deviceState = -1; return false; }
-            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !envFlag("MI355CV_ANY_ARCH")) {
-                g_deviceState = -1;
-                setError(MI355CV_NOT_IMPLEMENTED, "device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
-                return false;
-            }
-            g_device = dev;
-            g_deviceState = st = 1;
         }
     }
-    if (st != 1) return false;
+    if (d >= n) { setError(MI355CV_NOT_IMPLEMENTED, "device %d selected, %d visible", d, n); return -1; }
+    int st = g_devState[d].load();
+    if (st == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); st = -1; }
+        else if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !envFlag("MI355CV_ANY_ARCH")) {
+            st = -1;
+            setError(MI355CV_NOT_IMPLEMENTED, "device %d is %s, this library is built for gfx950 only", d, prop.gcnArchName);
+        } else st = 1;
+        g_devState[d] = st;
+    }
+    if (st != 1) return -1;
+    t_active = d;
+    return d;
+}
+
+bool ensureDevice()
+{
+    const int d = resolveDevice();
+    if (d < 0) return false;
     int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != g_device.load()) {
-        if (hipSetDevice(g_device.load()) != hipSuccess) return false;
+    if (hipGetDevice(&cur) != hipSuccess || cur != d) {
+        if (t_restore < 0 && cur >= 0) t_restore = cur;           // the host program's device: put back when the outermost hook returns
+        if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); return false; }
     }
     return true;
+}
+
+static void restoreDevice()
+{
+    if (t_restore >= 0) { (void)hipSetDevice(t_restore); t_restore = -1; }
 }
 
 hipStream_t stream()
@@ -132,27 +178,36 @@ hipEvent_t pooledEvent(int i)
 
 bool asyncMode() { return tctx().async; }
 
-bool isDevicePtr(const void* p)
+int ptrKind(const void* p)
 {
-    if (!p) return false;
+    if (!p) return PTR_HOST;
     hipPointerAttribute_t a;
     hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // unregistered host memory
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+    if (e != hipSuccess) { (void)hipGetLastError(); return PTR_HOST; }   // unregistered host memory
+    if (a.type == hipMemoryTypeManaged) return PTR_DEVICE;
+    if (a.type == hipMemoryTypeDevice) return a.device == t_active ? PTR_DEVICE : PTR_FOREIGN;
+    return PTR_HOST;
 }
+
+bool isDevicePtr(const void* p) { return ptrKind(p) == PTR_DEVICE; }
 
 // ------------------------------------------------------------------ Stager
 
 Stager::Stager()
 {
     // an error left behind by an earlier call on this thread (a failed copy, somebody else's HIP code) must not be charged to this hook
-    if (tctx().stagerDepth++ == 0) (void)hipGetLastError();
+    if (t_depth++ == 0) (void)hipGetLastError();
 }
 Stager::~Stager()
 {
-    // buffers handed out during this (outermost) hook become reusable; safe in stream order
-    if (--tctx().stagerDepth == 0)
-        for (auto& b : tctx().pool) b.busy = false;
+    // buffers handed out during this (outermost) hook become reusable: at once on the stream that used them (stream order), on any other
+    // stream only after that one has drained (bump_ checks) -- two asynchronous calls under different streams never share scratch
+    if (--t_depth == 0) {
+        ThreadCtx& c = tctx();
+        hipStream_t s = c.async ? stream() : nullptr;
+        for (auto& b : c.pool) if (b.busy) { b.busy = false; b.last = s; }
+        restoreDevice();
+    }
 }
 
 void* Stager::bump_(size_t bytes)
@@ -160,24 +215,45 @@ void* Stager::bump_(size_t bytes)
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
     auto& pool = tctx().pool;
+    hipStream_t cur = stream();
     int best = -1;
-    for (int i = 0; i < (int)pool.size(); i++)
-        if (!pool[i].busy && pool[i].cap >= bytes && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+    for (int i = 0; i < (int)pool.size(); i++) {
+        Buf& b = pool[i];
+        if (b.busy || b.cap < bytes || (best >= 0 && b.cap >= pool[best].cap)) continue;
+        if (b.last && b.last != cur) {                               // last used asynchronously on another stream
+            if (hipStreamQuery(b.last) != hipSuccess) { (void)hipGetLastError(); continue; }
+            b.last = nullptr;
+        }
+        best = i;
+    }
     if (best >= 0 && pool[best].cap <= 4 * bytes + (1 << 20)) { pool[best].busy = true; return pool[best].p; }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); failed_ = true; setError(MI355CV_NOT_IMPLEMENTED, "hipMalloc(%zu) failed", bytes); return nullptr; }
-    pool.push_back({p, bytes, true});
+    pool.push_back({p, bytes, true, nullptr});
     return p;
+}
+
+// a pointer into another GPU's memory: the thread is bound to the wrong device for this image -- decline (the caller falls back / raises)
+bool Stager::foreign_(const void* p)
+{
+    failed_ = true;
+    hipPointerAttribute_t a;
+    const int owner = hipPointerGetAttributes(&a, p) == hipSuccess ? a.device : -1;
+    setError(MI355CV_NOT_IMPLEMENTED, "image lives on device %d, this thread runs on device %d (mi355cv_setDevice)", owner, t_active);
+    return true;
 }
 
 const uchar* Stager::in(const uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep)
 {
     if (!p || rows <= 0 || rowBytes == 0) { failed_ = true; return nullptr; }          // e.g. the empty dst of THRESH_DRYRUN: the hook declines
-    if (isDevicePtr(p)) { *dstep = step; return p; }
+    const int kind = ptrKind(p);
+    if (kind == PTR_DEVICE) { *dstep = step; return p; }
+    if (kind == PTR_FOREIGN) { foreign_(p); return nullptr; }
     anyHost_ = true;
     size_t ds = (rowBytes + 255) & ~size_t(255);
     uchar* d = (uchar*)bump_(ds * (size_t)rows);
     if (!d) return nullptr;
+    g_stagedBytes += (long long)(rowBytes * (size_t)rows);
     if (hipMemcpy2DAsync(d, ds, p, step, rowBytes, rows, hipMemcpyHostToDevice, stream()) != hipSuccess) {
         failed_ = true; setError(MI355CV_NOT_IMPLEMENTED, "H2D staging failed: %s", hipGetErrorString(hipGetLastError())); return nullptr;
     }
@@ -188,7 +264,9 @@ const uchar* Stager::in(const uchar* p, size_t step, size_t rowBytes, int rows, 
 uchar* Stager::out(uchar* p, size_t step, size_t rowBytes, int rows, size_t* dstep)
 {
     if (!p || rows <= 0 || rowBytes == 0) { failed_ = true; return nullptr; }
-    if (isDevicePtr(p)) { *dstep = step; return p; }
+    const int kind = ptrKind(p);
+    if (kind == PTR_DEVICE) { *dstep = step; return p; }
+    if (kind == PTR_FOREIGN) { foreign_(p); return nullptr; }
     anyHost_ = true;
     size_t ds = (rowBytes + 255) & ~size_t(255);
     uchar* d = (uchar*)bump_(ds * (size_t)rows);
@@ -214,11 +292,12 @@ int Stager::finish(const char* entry)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: launch failed: %s", entry, hipGetErrorString(e));
     for (auto& o : outs_) {
+        g_stagedBytes += (long long)(o.rowBytes * (size_t)o.rows);
         e = hipMemcpy2DAsync(o.host, o.hstep, o.dev, o.dstep, o.rowBytes, o.rows, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(e));
     }
     // a hook called from inside another hook (device pointers, same stream) leaves the synchronisation to the outermost one
-    if (anyHost_ || (!asyncMode() && tctx().stagerDepth == 1)) {
+    if (anyHost_ || (!asyncMode() && t_depth == 1)) {
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: execution failed: %s", entry, hipGetErrorString(e));
     }
@@ -235,28 +314,53 @@ extern "C" {
 
 MI355CV_API int mi355cv_init(int device)
 {
-    if (device >= 0 && g_deviceState.load() == 0) g_device = device;
-    return ensureDevice() ? 0 : -1;
+    if (device >= 0 && g_defaultDev.load() < 0 && device < deviceCount()) g_defaultDev = device;
+    const bool ok = ensureDevice();
+    restoreDevice();
+    return ok ? 0 : -1;
 }
+
+MI355CV_API int mi355cv_deviceCount(void) { return deviceCount(); }
+
+MI355CV_API int mi355cv_setDevice(int device)
+{
+    if (device < 0) { t_dev = -1; return 0; }
+    if (device >= deviceCount()) { setError(MI355CV_ERROR_UNKNOWN, "mi355cv_setDevice(%d): %d device(s) visible", device, deviceCount()); return -1; }
+    const int before = t_dev;
+    t_dev = device;
+    if (resolveDevice() < 0) { t_dev = before; return -1; }
+    return 0;
+}
+
+MI355CV_API int mi355cv_getDevice(void) { return resolveDevice(); }
 
 MI355CV_API const char* mi355cv_version(void) { return "mi355cv 0.1 (gfx950; HAL mirror of OpenCV 4.12 imgproc hot path)"; }
 MI355CV_API const char* mi355cv_lastError(void) { return t_err; }
+MI355CV_API const char* mi355cv_lastKernel(void) { return t_kernel; }
 
 MI355CV_API int mi355cv_setStream(void* s)
 {
+    if (resolveDevice() < 0) return -1;
     ThreadCtx& c = tctx();
     c.user = (hipStream_t)s; c.useUser = true;    // NULL is HIP's null (legacy default) stream
     return 0;
 }
 
-MI355CV_API int mi355cv_resetStream(void) { tctx().useUser = false; return 0; }
+MI355CV_API int mi355cv_resetStream(void) { if (resolveDevice() < 0) return -1; tctx().useUser = false; return 0; }
 
-MI355CV_API int mi355cv_setAsync(int enable) { tctx().async = enable != 0; return 0; }
+MI355CV_API int mi355cv_setAsync(int enable)
+{
+    if (resolveDevice() < 0) return -1;
+    tctx().async = enable != 0;             // per thread and device, like the stream binding
+    return 0;
+}
 
 MI355CV_API int mi355cv_synchronize(void)
 {
     if (!ensureDevice()) return -1;
-    return hipStreamSynchronize(stream()) == hipSuccess ? 0 : -1;
+    const bool ok = hipStreamSynchronize(stream()) == hipSuccess;
+    restoreDevice();
+    return ok ? 0 : -1;
 }
 
 MI355CV_API long long mi355cv_callCount(const char* entry)
@@ -266,11 +370,14 @@ MI355CV_API long long mi355cv_callCount(const char* entry)
     return it == g_counts.end() ? 0 : it->second;
 }
 
+MI355CV_API long long mi355cv_stagedBytes(void) { return g_stagedBytes.load(); }
+
 MI355CV_API void* mi355cv_deviceAlloc(size_t bytes)
 {
     if (!ensureDevice()) return nullptr;
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    restoreDevice();
     return p;
 }
 MI355CV_API int mi355cv_deviceFree(void* p) { return hipFree(p) == hipSuccess ? 0 : -1; }
@@ -283,7 +390,8 @@ MI355CV_API void* mi355cv_hostAlloc(size_t bytes, int kind)
     if (bytes == 0 || (kind != 0 && kind != 1) || !ensureDevice()) return nullptr;
     void* p = nullptr;
     const hipError_t e = kind == 0 ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMallocManaged(&p, bytes, hipMemAttachGlobal);
-    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    restoreDevice();
     return p;
 }
 MI355CV_API int mi355cv_hostFree(void* p, int kind)
@@ -291,7 +399,17 @@ MI355CV_API int mi355cv_hostFree(void* p, int kind)
     if (!p) return 0;
     return (kind == 0 ? hipHostFree(p) : hipFree(p)) == hipSuccess ? 0 : -1;
 }
-MI355CV_API int mi355cv_upload(void* d, const void* h, size_t n) { return ensureDevice() && hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
-MI355CV_API int mi355cv_download(void* h, const void* d, size_t n) { return ensureDevice() && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+MI355CV_API int mi355cv_upload(void* d, const void* h, size_t n)
+{
+    const bool ok = ensureDevice() && hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess;
+    restoreDevice();
+    return ok ? 0 : -1;
+}
+MI355CV_API int mi355cv_download(void* h, const void* d, size_t n)
+{
+    const bool ok = ensureDevice() && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess;
+    restoreDevice();
+    return ok ? 0 : -1;
+}
 
 } // extern "C"

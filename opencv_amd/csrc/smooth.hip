@@ -570,6 +570,8 @@ void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size
     const int nseg = divUp(H, seg);
     const long long items = (long long)nstrips * nseg * nframes;
     dim3 grid((unsigned)((items + 3) / 4));
+    noteKernel("k_binomial_roll2<%d,%d,%s,%s,%d> grid=%u x256 seg=%d rows alt=%d", KS, CN, nt >= 1 ? "true" : "false", nt == 2 ? "true" : "false", nt == 3 ? 6 : 4,
+               grid.x, seg, tuneAlt());
     if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
     else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, true, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
     else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
@@ -712,6 +714,11 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
     // 8U only here: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724).
     // Other depths go through sepFilter2D in the reference (:825) -- see mi355cv_sepFilter*.
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    // Real pixels around the ROI mean the caller is the submatrix / non-isolated site (:813): the fixed-point branch (:658) is skipped there and
+    // the CPU result is sepFilter2D with float Gaussian taps, which can differ from Q8.8 by 1 LSB.  Decline: the reference then calls
+    // sepFilter2D itself, whose hook (mi355cv_sepFilter, ROI offsets included) reproduces that arithmetic.
+    if (margin_left | margin_top | margin_right | margin_bottom)
+        return mi355::setError(MI355CV_NOT_IMPLEMENTED, "gaussianBlur: submatrix with real margins is the reference's sepFilter2D case");
     if (ksize_width > 33 || ksize_height > 33) return MI355CV_NOT_IMPLEMENTED;
     if (sigmaY <= 0) sigmaY = sigmaX;
     std::vector<int64_t> qx, qy;

@@ -17,6 +17,7 @@
 #include "rt.h"
 #include <type_traits>
 #include <map>
+#include <memory>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -574,55 +575,58 @@ template <class Tab> int tiledRows(const std::vector<Tab>& yt, int nt)
 
 // Tap tables depend on (interpolation, destination length, scale) only, and building one costs more host time than the kernel that uses
 // it takes (Lanczos: two libm calls and eight divisions per entry, 0.2 ms for a 4K axis): keep the most recent ones resident in HBM.
-struct TabKey { int kind, n; double scale; bool operator<(const TabKey& o) const { return kind != o.kind ? kind < o.kind : n != o.n ? n < o.n : scale < o.scale; } };
-template <class Tab> struct TabEntry { const Tab* dev; int rows; unsigned long long stamp; };
+// An entry stays alive while the cache or a hook that fetched it holds a reference: eviction only drops the cache's, and the last owner frees
+// (hipFree waits for the kernels that still read the table), so a table cannot disappear between a fetch and the launch that uses it.
+struct DevBlock { void* p; ~DevBlock() { if (p) (void)hipFree(p); } };
+typedef std::shared_ptr<DevBlock> DevRef;
+struct TabKey { int dev, kind, n; double scale;
+                bool operator<(const TabKey& o) const { return dev != o.dev ? dev < o.dev : kind != o.kind ? kind < o.kind : n != o.n ? n < o.n : scale < o.scale; } };
+struct TabEntry { DevRef mem; int rows; unsigned long long stamp; };
 template <class Tab, class Build>
-bool cachedTab(int kind, int n, double scale, int nt, Build build, const Tab** dev, int* tileRows)
+bool cachedTab(int kind, int n, double scale, int nt, Build build, const Tab** dev, int* tileRows, DevRef* keep)
 {
     static std::mutex mu;
-    static std::map<TabKey, TabEntry<Tab>> cache;
+    static std::map<TabKey, TabEntry> cache;
     static unsigned long long clock = 0;
     std::lock_guard<std::mutex> lk(mu);
-    const TabKey key{kind, n, scale};
+    const TabKey key{activeDevice(), kind, n, scale};
     auto it = cache.find(key);
     if (it == cache.end()) {
-        if (cache.size() >= 32) {                                           // evict the least recently used table (stream order: no kernel
-            auto old = cache.begin();                                       // still reads it once the device is idle)
+        if (cache.size() >= 32) {                                           // drop the least recently used table
+            auto old = cache.begin();
             for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
-            (void)hipDeviceSynchronize();
-            (void)hipFree(const_cast<Tab*>(old->second.dev));
             cache.erase(old);
         }
         std::vector<Tab> host;
         build(n, scale, host);
         void* d = nullptr;
         if (hipMalloc(&d, host.size() * sizeof(Tab)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (hipMemcpy(d, host.data(), host.size() * sizeof(Tab), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return false; }
-        it = cache.emplace(key, TabEntry<Tab>{(const Tab*)d, tiledRows(host, nt), 0}).first;
+        DevRef mem(new DevBlock{d});
+        if (hipMemcpy(d, host.data(), host.size() * sizeof(Tab), hipMemcpyHostToDevice) != hipSuccess) return false;
+        it = cache.emplace(key, TabEntry{mem, tiledRows(host, nt), 0}).first;
     }
     it->second.stamp = ++clock;
-    *dev = it->second.dev; *tileRows = it->second.rows;
+    *dev = (const Tab*)it->second.mem->p; *tileRows = it->second.rows; *keep = it->second.mem;
     return true;
 }
 
 // the same residency for the INTER_AREA tables (taps + per-output offsets in one allocation), keyed by (source length, destination length, scale)
-struct AreaDev { const AreaTap* tab; const int* ofs; };
+struct AreaDev { const AreaTap* tab; const int* ofs; DevRef keep; };
 bool cachedAreaTab(int ssize, int dsize, double scale, AreaDev* out)
 {
-    struct Key { int s, d; double sc; bool operator<(const Key& o) const { return s != o.s ? s < o.s : d != o.d ? d < o.d : sc < o.sc; } };
-    struct Entry { void* dev; size_t ofsAt; unsigned long long stamp; };
+    struct Key { int dev, s, d; double sc;
+                 bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : s != o.s ? s < o.s : d != o.d ? d < o.d : sc < o.sc; } };
+    struct Entry { DevRef mem; size_t ofsAt; unsigned long long stamp; };
     static std::mutex mu;
     static std::map<Key, Entry> cache;
     static unsigned long long clock = 0;
     std::lock_guard<std::mutex> lk(mu);
-    const Key key{ssize, dsize, scale};
+    const Key key{activeDevice(), ssize, dsize, scale};
     auto it = cache.find(key);
     if (it == cache.end()) {
         if (cache.size() >= 32) {
             auto old = cache.begin();
             for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
-            (void)hipDeviceSynchronize();
-            (void)hipFree(old->second.dev);
             cache.erase(old);
         }
         std::vector<AreaTap> tab; std::vector<int> ofs;
@@ -630,12 +634,13 @@ bool cachedAreaTab(int ssize, int dsize, double scale, AreaDev* out)
         const size_t tabBytes = (tab.size() * sizeof(AreaTap) + 15) & ~(size_t)15, ofsBytes = ofs.size() * sizeof(int);
         void* d = nullptr;
         if (hipMalloc(&d, tabBytes + ofsBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        DevRef mem(new DevBlock{d});
         if ((!tab.empty() && hipMemcpy(d, tab.data(), tab.size() * sizeof(AreaTap), hipMemcpyHostToDevice) != hipSuccess) ||
-            hipMemcpy((uchar*)d + tabBytes, ofs.data(), ofsBytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return false; }
-        it = cache.emplace(key, Entry{d, tabBytes, 0}).first;
+            hipMemcpy((uchar*)d + tabBytes, ofs.data(), ofsBytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+        it = cache.emplace(key, Entry{mem, tabBytes, 0}).first;
     }
     it->second.stamp = ++clock;
-    out->tab = (const AreaTap*)it->second.dev; out->ofs = (const int*)((const uchar*)it->second.dev + it->second.ofsAt);
+    out->tab = (const AreaTap*)it->second.mem->p; out->ofs = (const int*)((const uchar*)it->second.mem->p + it->second.ofsAt); out->keep = it->second.mem;
     return true;
 }
 
@@ -643,10 +648,12 @@ bool cachedAreaTab(int ssize, int dsize, double scale, AreaDev* out)
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
 short g_tabHost[1024 * 4 + 16];
-short* g_tabDev = nullptr;
-std::once_flag g_tabOnce;
+std::once_flag g_tabHostOnce;
+constexpr int TAB_MAX_DEV = 16;
+short* g_tabDevs[TAB_MAX_DEV];
+std::mutex g_tabMu;
 
-void buildTab()
+void buildTabHost()
 {
     float t1[64];
     const float scale = 1.f / 32;
@@ -677,8 +684,22 @@ void buildTab()
                 else it[mk1 * 2 + mk2] = (short)(it[mk1 * 2 + mk2] - diff);
             }
         }
-    if (hipMalloc((void**)&g_tabDev, 1024 * 4 * sizeof(short)) != hipSuccess) { g_tabDev = nullptr; return; }
-    if (hipMemcpy(g_tabDev, g_tabHost, 1024 * 4 * sizeof(short), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_tabDev); g_tabDev = nullptr; }
+}
+
+// the table in the calling thread's device memory (one copy per device, made on first use)
+const short* deviceTab()
+{
+    std::call_once(g_tabHostOnce, buildTabHost);
+    const int dev = activeDevice();
+    if (dev < 0 || dev >= TAB_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tabMu);
+    if (!g_tabDevs[dev]) {
+        short* d = nullptr;
+        if (hipMalloc((void**)&d, 1024 * 4 * sizeof(short)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemcpy(d, g_tabHost, 1024 * 4 * sizeof(short), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        g_tabDevs[dev] = d;
+    }
+    return g_tabDevs[dev];
 }
 
 struct SampleArgs { int sw, sh, depth, cn, linear, border; float cval[4]; };
@@ -699,7 +720,48 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
     if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k]); return; }
     int x0, x1, y0, y1;
     if ((unsigned)sx < (unsigned)(a.sw - 1) && (unsigned)sy < (unsigned)(a.sh - 1)) { x0 = sx; x1 = sx + 1; y0 = sy; y1 = sy + 1; }
-    else if (a.border == B_TRANSPARENT) return;
+    else if (a.border == B_TRANSPARENT) {
+        // remapBilinear imgwarp.cpp:786-815: a point on the source's last column / row is blended from the neighbours it has and rescaled by
+        // (sum of all four weights) / (sum of the weights used); anything further out keeps the destination's previous contents
+        if (!(sx >= 0 && sx <= a.sw - 1 && sy >= 0 && sy <= a.sh - 1)) return;
+        const bool has1 = sx < a.sw - 1, has2 = sy < a.sh - 1, has3 = has1 && has2;
+        const uchar* S = src + (size_t)sy * sstep;
+        if (a.depth == D8U) {
+            const short* w = tab + (ay * 32 + ax) * 4;
+            int wTot = w[0];
+            if (has1) wTot += w[1];
+            if (has2) wTot += w[2];
+            if (has3) wTot += w[3];
+            if (wTot == 0) return;
+            const int wIni = (int)w[0] + w[1] + w[2] + w[3];
+            for (int k = 0; k < cn; k++) {
+                int t0 = S[sx * cn + k] * w[0];
+                if (has1) t0 += S[(sx + 1) * cn + k] * w[1];
+                if (has2) t0 += S[sstep + sx * cn + k] * w[2];
+                if (has3) t0 += S[sstep + (sx + 1) * cn + k] * w[3];
+                t0 = (int)__fdiv_rn(__fmul_rn((float)t0, (float)wIni), (float)wTot);
+                const int r = (t0 + (1 << 14)) >> 15;
+                D[k] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+            return;
+        }
+        const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32;
+        const float w0 = __fmul_rn(1.f - fy, 1.f - fx), w1 = __fmul_rn(1.f - fy, fx), w2 = __fmul_rn(fy, 1.f - fx), w3 = __fmul_rn(fy, fx);
+        float wTot = w0;
+        if (has1) wTot = __fadd_rn(wTot, w1);
+        if (has2) wTot = __fadd_rn(wTot, w2);
+        if (has3) wTot = __fadd_rn(wTot, w3);
+        if (wTot == 0.f) return;
+        const float wIni = __fadd_rn(__fadd_rn(__fadd_rn(w0, w1), w2), w3);
+        for (int k = 0; k < cn; k++) {
+            float t0 = __fmul_rn(ldV(S, a.depth, sx * cn + k), w0);
+            if (has1) t0 = __fadd_rn(t0, __fmul_rn(ldV(S, a.depth, (sx + 1) * cn + k), w1));
+            if (has2) t0 = __fadd_rn(t0, __fmul_rn(ldV(S + sstep, a.depth, sx * cn + k), w2));
+            if (has3) t0 = __fadd_rn(t0, __fmul_rn(ldV(S + sstep, a.depth, (sx + 1) * cn + k), w3));
+            stRound(D, a.depth, k, __fdiv_rn(__fmul_rn(t0, wIni), wTot));
+        }
+        return;
+    }
     else if (a.border == B_REPLICATE) { x0 = clipI(sx, 0, a.sw); x1 = clipI(sx + 1, 0, a.sw); y0 = clipI(sy, 0, a.sh); y1 = clipI(sy + 1, 0, a.sh); }
     else { x0 = mi355_borderInterpolate(sx, a.sw, a.border); x1 = mi355_borderInterpolate(sx + 1, a.sw, a.border);
            y0 = mi355_borderInterpolate(sy, a.sh, a.border); y1 = mi355_borderInterpolate(sy + 1, a.sh, a.border); }
@@ -877,7 +939,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)dw * dh < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
-    std::call_once(g_tabOnce, buildTab);
+    const short* g_tabDev = deviceTab();
     if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
     Stager stg; size_t dss, dds, mxs = mxstep, mys = mystep;
@@ -960,9 +1022,10 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     if (a.mode == 5 || a.mode == 6) {
         dim3 gt(divUp(dst_width * cn, 64), divUp(dst_height, 16)), g1(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         int rows = 0, unused = 0;
+        DevRef keepX, keepY;                                        // the tables stay alive until the launches below are enqueued
         if (a.mode == 5) {
             const CubicTap *dxt, *dyt;
-            if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows))
+            if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused, &keepX) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows, &keepY))
                 return MI355CV_NOT_IMPLEMENTED;
             const TapT<4>* tx = reinterpret_cast<const TapT<4>*>(dxt); const TapT<4>* ty = reinterpret_cast<const TapT<4>*>(dyt);
             if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 4>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
@@ -971,7 +1034,7 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
             else hipLaunchKernelGGL(k_resize_cubic<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
         } else {
             const LanczosTap *dxt, *dyt;
-            if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows))
+            if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused, &keepX) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows, &keepY))
                 return MI355CV_NOT_IMPLEMENTED;
             const TapT<8>* tx = reinterpret_cast<const TapT<8>*>(dxt); const TapT<8>* ty = reinterpret_cast<const TapT<8>*>(dyt);
             if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 8>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);

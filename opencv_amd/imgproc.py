@@ -616,11 +616,13 @@ def filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType=BORDER_
         ay = kh // 2
     out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
     d = Img(out)
+    if d.ptr == s.ptr and roi is None:               # in place: FilterEngine's row ring makes that safe on the CPU; here the source is cloned
+        view = _copy_like(view); s = Img(view)       # (with a roi the library declines a dst that overlaps the rows it reads)
     bind_stream(s, d)
     ctx = ctypes.c_void_p()
     rc = L.mi355cv_filterInit(ctypes.byref(ctx), k.ctypes.data, k.strides[0], _K_TYPE[k.dtype], kw, kh, s.w, s.h,
                               s.type, d.type, borderType & ~BORDER_ISOLATED, float(delta), ax, ay,
-                              roi is not None, False)
+                              roi is not None, d.ptr == s.ptr)
     _lib.check(rc, "filterInit")
     try:
         rc = L.mi355cv_filter(ctx, _vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, fw, fh, ox, oy)
@@ -667,6 +669,8 @@ def sepFilter2D(src, ddepth, kernelX, kernelY, anchor=(-1, -1), delta=0.0, borde
     ky = np.ascontiguousarray(np.asarray(kernelY, dtype=np.float64).ravel())
     out = dst if dst is not None else empty_like_kind(view, s.h, s.w, s.cn, ddepth)
     d = Img(out)
+    if d.ptr == s.ptr and roi is None:
+        view = _copy_like(view); s = Img(view)
     bind_stream(s, d)
     ctx = ctypes.c_void_p()
     rc = L.mi355cv_sepFilterInit(ctypes.byref(ctx), s.type, d.type, 6, kx.ctypes.data, len(kx), ky.ctypes.data, len(ky),

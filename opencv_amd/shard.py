@@ -28,6 +28,24 @@ def frame_range(nframes, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def spawn_ranks(n, script, argv, need_gpus=True, port=None):
+    """`python <script> --gpus N` without a launcher: run the same command line as N ranks -- one process per GPU -- under
+    torch.distributed.run on this node (rendezvous on 127.0.0.1) and return its exit code.  With need_gpus the request is refused when fewer
+    than N devices are visible: a multi-GPU number is never reported from fewer GPUs than it names."""
+    import subprocess
+    import sys
+    if need_gpus:
+        have = torch.cuda.device_count() if torch is not None and torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write(f"{os.path.basename(script)}: --gpus {n} requested but only {have} GPU(s) are visible -- refusing to report a "
+                             "multi-GPU number from fewer devices\n")
+            return 2
+    port = port or os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(script)] + list(argv)
+    return subprocess.call(cmd)
+
+
 def init(backend=None):
     """initialise torch.distributed when launched with WORLD_SIZE > 1 (nccl == RCCL on ROCm, gloo on CPU)"""
     rank, ws, local = world()

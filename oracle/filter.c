@@ -245,6 +245,15 @@ int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
                     unsigned r = normalize ? (((unsigned)si + (unsigned)divDelta) * (unsigned)divScale) >> 23 : (unsigned)si;
                     drow[e] = (uint8_t)(normalize ? r : (r > 255 ? 255 : r));
                 } else if (ddepth == 5) ((float*)drow)[e] = normalize ? (float)((double)si * scale) : (float)si;
+                else if (normalize && e >= ((w * cn) & ~7)) {
+                    /* ColumnSum<int, uchar / short / ushort> (box_filter.simd.hpp:339-385 and siblings): the vector loops (16 then 8 elements
+                     * per step on AVX2, 8 on SSE) round (float)s * (float)scale; the last (w*cn) % 8 elements of a row take the scalar
+                     * tail saturate_cast<T>(s * scale) in double */
+                    const double r = rint((double)si * scale);
+                    if (ddepth == 0) drow[e] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : (int)r);
+                    else if (ddepth == 2) ((uint16_t*)drow)[e] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : (int)r);
+                    else ((int16_t*)drow)[e] = (int16_t)(r < -32768 ? -32768 : r > 32767 ? 32767 : (int)r);
+                }
                 else stf(drow, e, ddepth, normalize ? rintf((float)si * (float)scale) : (float)si);
             }
     return 0;

@@ -67,6 +67,35 @@ EXPORT int wrap_frameAllocatorTour(int kind, const void* s, size_t ss, int w, in
     } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
 
+// FrameAllocator::Device: matrices that LIVE in HBM.  upload once, two cv:: calls served in place by the hooks (the intermediate never leaves
+// the GPU), download once.  Returns 0, or 1 when there is no device (nothing to test: the allocator then hands out ordinary host memory).
+EXPORT int wrap_deviceAllocatorTour(const void* s, size_t ss, int w, int h, int type, void* d, size_t ds)
+{
+    try {
+        if (mi355cv_init(-1) != 0) return 1;
+        mi355cv::FrameAllocator alloc(mi355cv::FrameAllocator::Device);
+        Mat src = M(s, ss, w, h, type), out = M(d, ds, w, h, type), frame, blurred, back;
+        frame.allocator = &alloc; blurred.allocator = &alloc;
+        mi355cv::upload(src, frame);
+        if (frame.u == nullptr || frame.u->currAllocator != &alloc) return -2;
+        cv::GaussianBlur(frame, blurred, Size(5, 5), 0, 0, BORDER_REFLECT_101);      // dst created through the same allocator: HBM
+        if (blurred.allocator != &alloc || blurred.u->currAllocator != &alloc) return -3;
+        cv::GaussianBlur(blurred, frame, Size(3, 3), 0, 0, BORDER_REPLICATE);
+        mi355cv::download(frame, back);
+        back.copyTo(out);
+        return 0;
+    } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
+// a submatrix without BORDER_ISOLATED: the wrappers must give what cv:: gives (real parent pixels at the ROI's edges)
+EXPORT int wrap_cornerHarrisRoi(const void* s, size_t ss, int pw, int ph, int stype, int x, int y, int w, int h, void* d, size_t ds, int blockSize, int ksize,
+                                double k, int borderType)
+{
+    try { Mat parent = M(s, ss, pw, ph, stype), dst = M(d, ds, w, h, CV_32FC1); const uchar* p = dst.data;
+          mi355cv::cornerHarris(parent(Rect(x, y, w, h)), dst, blockSize, ksize, k, borderType); return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
 // mi355cv::calcOpticalFlowPyrLK with std::vector outputs, as applications call it
 EXPORT int wrap_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* next, size_t ns, int w, int h, int type, const float* pts, float* nextPts, int npts,
                                      unsigned char* status, float* err, int winW, int winH, int maxLevel, int critType, int maxCount, double eps, int flags, double minEig)

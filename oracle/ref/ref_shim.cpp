@@ -311,6 +311,16 @@ int ref_cornerHarris(const void* s, size_t ss, void* d, size_t ds, int w, int h,
     REF_END(dst, d)
 }
 
+// cv::cornerHarris on a submatrix parent(Rect(x, y, w, h)) -- reads the parent's pixels around the ROI unless BORDER_ISOLATED is set
+int ref_cornerHarrisRoi(const void* s, size_t ss, int pw, int ph, int stype, int x, int y, int w, int h, void* d, size_t ds,
+                        int blockSize, int ksize, double k, int borderType)
+{
+    REF_TRY
+    Mat parent = M(s, ss, pw, ph, stype), dst = M(d, ds, w, h, CV_32FC1);
+    cv::cornerHarris(parent(Rect(x, y, w, h)), dst, blockSize, ksize, k, borderType);
+    REF_END(dst, d)
+}
+
 int ref_cornerMinEigenVal(const void* s, size_t ss, void* d, size_t ds, int w, int h, int stype,
                           int blockSize, int ksize, int borderType)
 {

@@ -420,7 +420,52 @@ static void sample_pixel(const uint8_t* src, size_t sstep, int sw, int sh, uint8
         return;
     }
     if (border == 0 && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stv_round(D, depth, k, (float)bv[k & 3]); return; }
-    if (border == 5 && !((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1))) return;   /* partial-overlap formula not restated */
+    if (border == 5 && !((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1))) {
+        /* BORDER_TRANSPARENT, remapBilinear imgwarp.cpp:786-815: a point on the last column / row lacks some of its four neighbours; it is
+         * computed from the ones it has, rescaled by (sum of all four weights) / (sum of the weights used); points outside stay untouched */
+        if (!(sx >= 0 && sx <= sw - 1 && sy >= 0 && sy <= sh - 1)) return;
+        const int has1 = sx < sw - 1, has2 = sy < sh - 1, has3 = has1 && has2;
+        const uint8_t* S = src + (size_t)sy * sstep;
+        if (depth == 0) {                                        /* WT = int, AT = short (the Q15 table incl. its fix-up quirk) */
+            const short* w = orc_bilinearTabI() + (ay * 32 + ax) * 4;
+            int w_tot = w[0];
+            if (has1) w_tot += w[1];
+            if (has2) w_tot += w[2];
+            if (has3) w_tot += w[3];
+            if (w_tot == 0) return;
+            const int w_ini = (int)w[0] + w[1] + w[2] + w[3];
+            for (int k = 0; k < cn; k++) {
+                int t0 = S[sx * cn + k] * w[0];
+                if (has1) t0 += S[(sx + 1) * cn + k] * w[1];
+                if (has2) t0 += S[sstep + sx * cn + k] * w[2];
+                if (has3) t0 += S[sstep + (sx + 1) * cn + k] * w[3];
+                const float q = (float)t0 * (float)w_ini;
+                t0 = (int)(q / (float)w_tot);
+                const int r = (t0 + (1 << 14)) >> 15;
+                D[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+        } else {                                                 /* WT = AT = float */
+            const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32;
+            const float w[4] = {(1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx};
+            float w_tot = 0; w_tot += w[0];
+            if (has1) w_tot += w[1];
+            if (has2) w_tot += w[2];
+            if (has3) w_tot += w[3];
+            if (w_tot == 0.f) return;
+            float w_ini = w[0] + w[1]; w_ini = w_ini + w[2]; w_ini = w_ini + w[3];
+            for (int k = 0; k < cn; k++) {
+                float t0 = 0;
+                { const float p = (float)ldv(S, depth, sx * cn + k) * w[0]; t0 += p; }
+                if (has1) { const float p = (float)ldv(S, depth, (sx + 1) * cn + k) * w[1]; t0 += p; }
+                if (has2) { const float p = (float)ldv(S + sstep, depth, sx * cn + k) * w[2]; t0 += p; }
+                if (has3) { const float p = (float)ldv(S + sstep, depth, (sx + 1) * cn + k) * w[3]; t0 += p; }
+                const float q = t0 * w_ini;
+                t0 = q / w_tot;
+                stv_round(D, depth, k, t0);
+            }
+        }
+        return;
+    }
     int x0, x1, y0, y1;
     if (border == 1) { x0 = clipi(sx, 0, sw); x1 = clipi(sx + 1, 0, sw); y0 = clipi(sy, 0, sh); y1 = clipi(sy + 1, 0, sh); }
     else { x0 = orc_borderInterpolate(sx, sw, border); x1 = orc_borderInterpolate(sx + 1, sw, border);

@@ -134,6 +134,18 @@ def ref_rng_fill(shape, dtype, seed, lo, hi):
     return a
 
 
+def ref_GaussianBlurROI(parent, roi, ksize, sigma1=0.0, sigma2=0.0, border=4):
+    """cv::GaussianBlur on the submatrix parent(Rect(x, y, w, h)): non-isolated borders read the parent's pixels around the ROI"""
+    r = load_ref()
+    x, y, w, h = roi
+    dst = np.empty((h, w) + parent.shape[2:], parent.dtype)
+    pw, ph = wh(parent)
+    kw, kh = (ksize, ksize) if isinstance(ksize, int) else ksize
+    rc = r.ref_GaussianBlurROI(P(parent), step(parent), pw, ph, cvtype(parent), x, y, w, h, P(dst), step(dst), kw, kh, c_dbl(sigma1), c_dbl(sigma2), border)
+    assert rc == 0, rc
+    return dst
+
+
 def ref_GaussianBlur(src, ksize, sigma1=0.0, sigma2=0.0, border=4):
     r = load_ref()
     dst = np.empty_like(src)
@@ -251,7 +263,7 @@ def ref_cvtColorYUV(src, code):
         dcn = (_YUV_NV.get(code) or _YUV_3P[code])[0]
         dst = np.empty((h * 2 // 3, w, dcn), np.uint8)
     else:
-        dcn = 3 if (code in _YUV_FWD or code in _HSV) else _YUV_INV[code][0]
+        dcn = 3 if (code in _YUV_FWD or code in _HSV or code in (54, 55, 70, 71)) else _YUV_INV[code][0]
         dst = np.empty((h, w, dcn), np.uint8)
     rc = r.ref_cvtColorSz(P(src), step(src), w, h, cvtype(src), P(dst), step(dst), w, dst.shape[0], cvtype(dst), code)
     assert rc == 0, rc
@@ -541,12 +553,14 @@ def _bv(borderValue):
     return bv
 
 
-def orc_warpAffine(src, M, dsize, flags=1, border=0, borderValue=0.0):
-    """M maps dst -> src (i.e. already inverted / WARP_INVERSE_MAP form), like hal::warpAffine receives it"""
+def orc_warpAffine(src, M, dsize, flags=1, border=0, borderValue=0.0, dst=None):
+    """M maps dst -> src (i.e. already inverted / WARP_INVERSE_MAP form), like hal::warpAffine receives it.  `dst`: previous contents of the
+    destination (BORDER_TRANSPARENT leaves unmapped pixels untouched); copied, not written."""
     o = oracle()
     sh, sw = src.shape[:2]
-    dst = _dst_geom(src, dsize)
-    if border == 5:
+    given = dst is not None
+    dst = np.ascontiguousarray(dst).copy() if given else _dst_geom(src, dsize)
+    if border == 5 and not given:
         dst[...] = 0
     M = np.ascontiguousarray(M, np.float64)
     bv = _bv(borderValue)
@@ -556,10 +570,10 @@ def orc_warpAffine(src, M, dsize, flags=1, border=0, borderValue=0.0):
     return dst
 
 
-def orc_warpPerspective(src, M, dsize, flags=1, border=0, borderValue=0.0):
+def orc_warpPerspective(src, M, dsize, flags=1, border=0, borderValue=0.0, dst=None):
     o = oracle()
     sh, sw = src.shape[:2]
-    dst = _dst_geom(src, dsize)
+    dst = _dst_geom(src, dsize) if dst is None else np.ascontiguousarray(dst).copy()
     M = np.ascontiguousarray(M, np.float64)
     bv = _bv(borderValue)
     rc = o.orc_warpPerspective(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], _NP_DEPTH[src.dtype], cn_of(src),
@@ -580,10 +594,10 @@ def orc_remap(src, mapx, mapy, interpolation=1, border=0, borderValue=0.0):
     return dst
 
 
-def ref_warpAffine(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0):
+def ref_warpAffine(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0, dst=None):
     r = load_ref()
     sh, sw = src.shape[:2]
-    dst = _dst_geom(src, dsize)
+    dst = _dst_geom(src, dsize) if dst is None else np.ascontiguousarray(dst).copy()
     M = np.ascontiguousarray(M, np.float64)
     bv = _bv(borderValue)
     rc = r.ref_warpAffine(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), P(M), flags, border, P(bv))
@@ -591,10 +605,10 @@ def ref_warpAffine(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0):
     return dst
 
 
-def ref_warpPerspective(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0):
+def ref_warpPerspective(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0, dst=None):
     r = load_ref()
     sh, sw = src.shape[:2]
-    dst = _dst_geom(src, dsize)
+    dst = _dst_geom(src, dsize) if dst is None else np.ascontiguousarray(dst).copy()
     M = np.ascontiguousarray(M, np.float64)
     bv = _bv(borderValue)
     rc = r.ref_warpPerspective(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), P(M), flags, border, P(bv))
@@ -638,8 +652,13 @@ def orc_cornerMinEigenVal(src, blockSize, ksize=3, border=4):
     return dst
 
 
-def ref_cornerHarris(src, blockSize, ksize, k, border=4):
+def ref_cornerHarris(src, blockSize, ksize, k, border=4, roi=None):
     r = load_ref()
+    if roi is not None:
+        x, y, w, h = roi
+        dst = np.empty((h, w), np.float32)
+        assert r.ref_cornerHarrisRoi(P(src), step(src), src.shape[1], src.shape[0], cvtype(src), x, y, w, h, P(dst), step(dst), blockSize, ksize, c_dbl(k), border) == 0
+        return dst
     h, w = src.shape
     dst = np.empty((h, w), np.float32)
     assert r.ref_cornerHarris(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), blockSize, ksize, c_dbl(k), border) == 0

@@ -50,7 +50,6 @@ def test_xyz_16u_and_alpha(cv, orc):
         assert np.array_equal(cv.cvtColor(dev(src), code).cpu().numpy(), orc.orc_cvtColorMisc(src, code)), code
 
 
-@pytest.mark.xfail(strict=False, reason="mi355cv_cvtHSVtoBGR was written after the last GPU session of round 1; not bound in the HAL header until this passes")
 def test_hsv_to_bgr(cv, orc):
     rng = np.random.default_rng(12)
     for code in (54, 55, 70, 71):

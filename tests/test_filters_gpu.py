@@ -156,7 +156,6 @@ def test_sepfilter_modes(cv, orc):
         check(cv.sepFilter2D(dev(srcf), -1, kx, ky, (2, 1), 0.1, border), orc.orc_sepFilter2D(srcf, -1, kx, ky, (2, 1), 0.1, border))
 
 
-@pytest.mark.xfail(strict=False, reason="added with the ROI fix of k_sepfilter_generic after the last GPU session of round 1")
 def test_sepfilter_and_sobel_roi(cv, orc):
     """a ROI inside a larger image with a non-isolated border: the taps left of / above the ROI are real pixels of the parent
     (the case the reference's Imgproc_Sobel.borderTypes checks)"""

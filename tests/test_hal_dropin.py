@@ -38,6 +38,11 @@ def _calls(o, src8, src8c3, srcf):
     out["nv12"] = o.ref_cvtColorYUV(src8, 91)
     out["i420"] = o.ref_cvtColorYUV(src8, 101)
     out["hsv"] = o.ref_cvtColorYUV(src8c3, 40)
+    out["hsv2bgr"] = o.ref_cvtColorYUV(src8c3, 54)
+    # a submatrix with real neighbours, sigma > 0: the reference skips its fixed-point branch there (smooth.dispatch.cpp:658) and runs sepFilter2D
+    # with float taps; cv_hal_gaussianBlur must decline that case and the sepFilter hook (ROI offsets) must reproduce it
+    out["gauss_roi_sigma"] = o.ref_GaussianBlurROI(src8c3, (9, 7, 100, 70), 5, 1.2, 1.2, 4)
+    out["gauss_roi_binomial"] = o.ref_GaussianBlurROI(src8, (3, 5, 64, 48), 5, 0, 0, 4)
     out["adaptive"] = o.ref_adaptiveThreshold(src8, 255.0, 0, 0, 7, 2.0)
     out["canny"] = o.ref_Canny(src8, 30, 90)
     out["canny3"] = o.ref_Canny(src8c3, 200, 400, 3, True)
@@ -118,7 +123,7 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "adaptiveThreshold", "canny",
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "canny",
              "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
              "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu", "ScharrDeriv", "LKOpticalFlowLevel"]
     before = {n: cv.call_count(n) for n in names}
@@ -240,6 +245,42 @@ def test_frame_allocator_gpu(ref, kind):
     p = L.mi355cv_hostAlloc(1 << 20, kind)
     assert p, "hostAlloc failed on a GPU box"
     assert L.mi355cv_hostFree(p, kind) == 0
+
+
+@pytest.mark.gpu
+def test_device_frame_allocator_runs_in_place_gpu(ref):
+    """mi355cv::FrameAllocator::Device (cv::MatAllocator handing out HBM, SURVEY §7 step 1): upload once, two cv::GaussianBlur calls of the
+    HAL-enabled reference served on the matrices where they live -- no image byte crosses PCIe between upload and download -- download once"""
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None
+    src = O.ref_rng_fill((1080, 1920, 3), np.uint8, 6, 0, 256)
+    want = O.ref_GaussianBlur(O.ref_GaussianBlur(src, 5, 0, 0, 4), 3, 0, 0, 1)
+    out = np.empty_like(src)
+    L = cv._lib.lib
+    n0, b0 = cv.call_count("gaussianBlurBinomial"), L.mi355cv_stagedBytes()
+    rc = hal.wrap_deviceAllocatorTour(O.P(src), O.step(src), src.shape[1], src.shape[0], O.cvtype(src), O.P(out), O.step(out))
+    assert rc == 0, rc
+    assert np.array_equal(out, want)
+    assert cv.call_count("gaussianBlurBinomial") == n0 + 2
+    assert L.mi355cv_stagedBytes() == b0, "a hook staged image bytes over PCIe although the matrices live in HBM"
+
+
+def test_cv_signature_wrappers_on_a_submatrix(ref):
+    """mi355cv::cornerHarris on a ROI without BORDER_ISOLATED reads the parent's real pixels exactly as cv::cornerHarris does (the fused entry
+    point sees no margins, so the wrapper leaves that case to cv::); with BORDER_ISOLATED the ROI is a whole image for both"""
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    import ctypes
+    parent = O.ref_rng_fill((90, 120), np.uint8, 9, 0, 256)
+    x, y, w, h = 10, 7, 64, 48
+    for border in (4, 4 | 16, 1):
+        got = np.empty((h, w), np.float32)
+        rc = hal.wrap_cornerHarrisRoi(O.P(parent), O.step(parent), 120, 90, O.cvtype(parent), x, y, w, h, O.P(got), O.step(got), 2, 3, ctypes.c_double(0.04), border)
+        assert rc == 0, rc
+        want = O.ref_cornerHarris(parent, 2, 3, 0.04, border, roi=(x, y, w, h))
+        assert O.rel_err(got, want) <= 1e-4, border
 
 
 def _wrap_lk(hal, A, B, p, win, maxLevel, flags=0, guess=None):

@@ -54,8 +54,8 @@ def test_two_plane_encode(scn):
 
 @pytest.mark.parametrize("code", [54, 55, 70, 71])
 def test_hsv_to_bgr_follows_the_vector_width(code):
-    """cv_hal_cvtHSVtoBGR is not bound yet: the reference truncates inside its vector loop and rounds in the scalar tail, so the
-    8-bit result depends on the lanes of the build that runs.  The restatement takes that width as a parameter; with 8 lanes (AVX2) it
+    """cv_hal_cvtHSVtoBGR: the reference truncates inside its vector loop and rounds in the scalar tail, so the
+    8-bit result depends on the lanes of the build that runs (the hook follows the 8-lane AVX2 build, the widest color_hsv is dispatched for).  The restatement takes that width as a parameter; with 8 lanes (AVX2) it
     equals the oracle/ref build bit for bit, and a 4-lane evaluation differs wherever the two loops split a row differently."""
     rng = np.random.default_rng(code)
     differs = 0

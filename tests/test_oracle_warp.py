@@ -104,6 +104,26 @@ def test_warp_affine(orc, ref, dtype, cn):
                     same(orc, got, want)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_transparent(orc, ref, dtype, cn):
+    """BORDER_TRANSPARENT: unmapped pixels keep dst's previous contents; points on the source's last row / column are blended from the
+    neighbours they have (remapBilinear imgwarp.cpp:786-815)"""
+    src = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 115 + cn)
+    Ms = list(mats(orc, 61, 45)) + [np.array([[1.0, 0, 0.25], [0, 1.0, 0.5]]), np.array([[0.5, 0, 30.0], [0, 0.5, 22.0]]), np.array([[1.0, 0, 0], [0, 1.0, 0]])]
+    for M in Ms:
+        for dsize in [(61, 45), (100, 30)]:
+            prev = rnd(orc, (dsize[1], dsize[0], cn) if cn > 1 else (dsize[1], dsize[0]), dtype, 7)
+            for interp in (0, 1):
+                want = orc.ref_warpAffine(src, M, dsize, interp | 16, 5, 0.0, dst=prev)
+                got = orc.orc_warpAffine(src, M, dsize, interp, 5, 0.0, dst=prev)
+                same(orc, got, want)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    prev = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 8)
+    for interp in (0, 1):
+        same(orc, orc.orc_warpPerspective(src, P, (61, 45), interp, 5, 0.0, dst=prev), orc.ref_warpPerspective(src, P, (61, 45), interp | 16, 5, 0.0, dst=prev))
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("cn", [1, 3])
 def test_warp_perspective(orc, ref, dtype, cn):

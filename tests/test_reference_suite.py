@@ -65,7 +65,6 @@ GPU_SET_WIDE = ("Imgproc_Threshold*:Imgproc_Thresh*:Imgproc_Filter2D*:Imgproc_So
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="fixes for the 3 failures of the round-1 exploratory run are not yet re-run on a GPU")
 def test_reference_tests_wide_on_the_gpu():
     rc, ran, passed, failed, counts = run(GPU_SET_WIDE, {"MI355CV_PRINT_COUNTS": "1"}, exclude=["Imgproc_Resize_Test*"])
     assert rc == 0 and not failed and ran == passed and ran >= 60, (rc, ran, passed, failed[:10])

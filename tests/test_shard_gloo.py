@@ -68,3 +68,40 @@ def test_two_process_gloo_sharding(tmp_path, orc):
     frames = rng.integers(0, 256, (7, 24, 32), dtype=np.uint8)
     want = np.stack([orc.orc_gaussianBlurBinomialU8(f, 5, 4) for f in frames])
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+SELF_SPAWN = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    from opencv_amd import shard
+    n = int(sys.argv[sys.argv.index('--gpus') + 1])
+    if 'WORLD_SIZE' not in os.environ and n > 1:               # what bench.py does when no launcher started it
+        sys.exit(shard.spawn_ranks(n, __file__, sys.argv[1:], need_gpus=False, port=29633))
+    rank, ws, local = shard.init('gloo')
+    assert ws == n, (ws, n)
+    total = shard.gather_counts(1)
+    assert total == n
+    open(os.path.join(%r, f'spawned_{rank}'), 'w').write(str(ws))
+""")
+
+
+def test_gpus_flag_spawns_its_own_ranks(tmp_path):
+    """`--gpus 2` with no launcher starts 2 ranks itself (the route bench.py takes; gloo stands in for RCCL here)"""
+    script = tmp_path / "selfspawn.py"
+    script.write_text(SELF_SPAWN % (ROOT, str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert sorted(os.listdir(tmp_path)).count("spawned_0") == 1 and (tmp_path / "spawned_1").read_text() == "2"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` on a box with fewer than N GPUs fails loudly instead of printing a 1-GPU line labelled N"""
+    import torch
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    if n < 2:
+        n = 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "GPU(s) are visible" in out.stderr and "metric" not in out.stdout, out.stdout + out.stderr

@@ -67,3 +67,66 @@ def test_concurrent_hooks(orc):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_device_binding_per_thread(orc):
+    """SURVEY §8e inside ONE process: a host thread binds its hooks to a device ordinal (mi355cv_setDevice), contexts are per thread and device,
+    an ordinal that does not exist is refused, and the host program's current device is left as it was."""
+    import ctypes
+    import opencv_amd as cv
+    from opencv_amd import _lib
+    L = _lib.lib
+    n = L.mi355cv_deviceCount()
+    assert n == torch.cuda.device_count() >= 1
+    assert L.mi355cv_setDevice(n) == -1 and b"visible" in L.mi355cv_lastError()        # loud, not a silent fallback to device 0
+    assert L.mi355cv_setDevice(0) == 0 and L.mi355cv_getDevice() == 0
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (2 * n, 270, 480), dtype=np.uint8)
+    want = [orc.orc_gaussianBlurBinomialU8(f, 5, 4) for f in frames]
+    got, errors = {}, []
+
+    def worker(d):
+        try:
+            assert L.mi355cv_setDevice(d) == 0 and L.mi355cv_getDevice() == d
+            for f in range(d, 2 * n, n):                       # frames sharded by index over the devices, one host thread each
+                src = torch.from_numpy(frames[f]).to(f"cuda:{d}")
+                got[f] = cv.GaussianBlur(src, (5, 5), 0).cpu().numpy()
+                # a raw C-ABI call on memory of this thread's device, own stream
+                L.mi355cv_resetStream()
+                p = L.mi355cv_deviceAlloc(2 * frames[f].size)
+                assert p
+                assert L.mi355cv_upload(ctypes.c_void_p(p), frames[f].ctypes.data, frames[f].size) == 0
+                rc = L.mi355cv_gaussianBlurBinomial(ctypes.c_void_p(p), 480, ctypes.c_void_p(p + frames[f].size), 480, 480, 270, 0, 1, 0, 0, 0, 0, 5, 4)
+                back = np.empty_like(frames[f])
+                assert rc == 0 and L.mi355cv_download(back.ctypes.data, ctypes.c_void_p(p + frames[f].size), back.size) == 0
+                assert np.array_equal(back, want[f])
+                L.mi355cv_deviceFree(ctypes.c_void_p(p))
+        except Exception as e:                                  # noqa: BLE001
+            errors.append((d, repr(e)))
+
+    before = torch.cuda.current_device()
+    ts = [threading.Thread(target=worker, args=(d,)) for d in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert torch.cuda.current_device() == before
+    for f in range(2 * n):
+        assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (the driver's 8-GPU node); a 1-GPU box runs test_device_binding_per_thread")
+def test_image_on_another_device_is_declined():
+    import opencv_amd as cv
+    from opencv_amd import _lib
+    import ctypes
+    L = _lib.lib
+    a = torch.zeros((64, 64), dtype=torch.uint8, device="cuda:1")
+    d = torch.empty_like(a)
+    assert L.mi355cv_setDevice(0) == 0
+    L.mi355cv_resetStream()
+    rc = L.mi355cv_gaussianBlurBinomial(ctypes.c_void_p(a.data_ptr()), 64, ctypes.c_void_p(d.data_ptr()), 64, 64, 64, 0, 1, 0, 0, 0, 0, 5, 4)
+    assert rc == 1 and b"device 1" in L.mi355cv_lastError()
+    # the Python mirror binds the thread to the image's device instead
+    assert torch.equal(cv.GaussianBlur(a, (5, 5), 0), d.zero_())

@@ -129,6 +129,26 @@ def test_warp_affine(cv, orc, dtype, cn):
     check(cv.warpAffine(dev(src), M, (61, 45)), orc.orc_warpAffine(src, cv.invertAffineTransform(M), (61, 45)))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_transparent(cv, orc, dtype, cn):
+    """BORDER_TRANSPARENT incl. the partial-overlap blend of the source's last row / column (imgwarp.cpp:786-815), device and host dst"""
+    src = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 115 + cn)
+    Ms = mats(cv, 61, 45) + [np.array([[1.0, 0, 0.25], [0, 1.0, 0.5]]), np.array([[0.5, 0, 30.0], [0, 0.5, 22.0]]), np.array([[1.0, 0, 0], [0, 1.0, 0]])]
+    for M in Ms:
+        for dsize in [(61, 45), (100, 30)]:
+            prev = rnd((dsize[1], dsize[0], cn) if cn > 1 else (dsize[1], dsize[0]), dtype, 7)
+            for interp in (0, 1):
+                want = orc.orc_warpAffine(src, M, dsize, interp, 5, 0.0, dst=prev)
+                check(cv.warpAffine(dev(src), M, dsize, interp | cv.WARP_INVERSE_MAP, 5, 0.0, dst=dev(prev.copy())), want)
+                check(cv.warpAffine(src, M, dsize, interp | cv.WARP_INVERSE_MAP, 5, 0.0, dst=prev.copy()), want)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    prev = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 8)
+    for interp in (0, 1):
+        check(cv.warpPerspective(dev(src), P, (61, 45), interp | cv.WARP_INVERSE_MAP, 5, 0.0, dst=dev(prev.copy())),
+              orc.orc_warpPerspective(src, P, (61, 45), interp, 5, 0.0, dst=prev))
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("cn", [1, 3])
 def test_warp_perspective_and_remap(cv, orc, dtype, cn):

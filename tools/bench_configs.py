@@ -27,9 +27,82 @@ def timeit(fn, n=20, warm=5):
     return a.elapsed_time(b) / n
 
 
-def run(quick=False):
+def parity_gates():
+    """a parity check before every timed configuration.  Each BASELINE config at its full size against the plain-C
+    restatement of the reference (oracle/, TEST INFRASTRUCTURE -- the checker, never the thing timed): whole frames where the oracle finishes
+    in about a second, otherwise the regions of the full-size result that depend on a crop of the input.  Returns {cfg key: verdict}."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import orc
+    rng = np.random.default_rng(809564)
+    res = {}
+
+    def dev(a):
+        return torch.from_numpy(a).cuda()
+
+    def rel(got, want):
+        return float(orc.rel_err(got.cpu().numpy() if isinstance(got, torch.Tensor) else got, want))
+
+    bgr = rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)
+    gray = cv.cvtColor(dev(bgr), cv.COLOR_BGR2GRAY)
+    wgray = orc.orc_cvtColor(bgr, 6)
+    assert np.array_equal(gray.cpu().numpy(), wgray), "cfg2a cvtColor differs from the oracle"
+    res["cfg2a"] = "bit-exact, whole 4K frame"
+    k = np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32)
+    gb = gray[None].expand(2, -1, -1).contiguous()
+    w3 = orc.orc_filter2D(wgray, -1, k)
+    assert np.array_equal(cv.filter2D(gray, -1, k).cpu().numpy(), w3) and np.array_equal(cv.filter2DBatch(gb, -1, k)[1].cpu().numpy(), w3), "cfg2 filter2D 3x3"
+    res["cfg2b"] = res["cfg2c"] = "bit-exact, whole 4K frame"
+    k5 = (np.arange(25, dtype=np.float32).reshape(5, 5) - 12) / 64
+    assert np.array_equal(cv.filter2DBatch(gb, -1, k5)[1].cpu().numpy(), orc.orc_filter2D(wgray, -1, k5)), "cfg2d filter2D 5x5"
+    res["cfg2d"] = "bit-exact, whole 4K frame"
+    hdf = np.ascontiguousarray(bgr[:1080, :1920])
+    assert np.array_equal(cv.GaussianBlur(dev(hdf), (5, 5), 0).cpu().numpy(), orc.orc_gaussianBlurBinomialU8(hdf, 5, 4)), "cfg1"
+    res["cfg1"] = "bit-exact, whole 1080p 8UC3 frame"
+    del gray, gb
+    src = rng.random((4320, 7680), dtype=np.float32)
+    d = dev(src)
+    crop = np.ascontiguousarray(src[:700, :1000])
+    e1 = rel(cv.resize(d, (5120, 2880))[:400, :600], np.ascontiguousarray(orc.orc_resize(crop, None, 5120 / 7680, 2880 / 4320, 1)[:400, :600]))
+    e2 = rel(cv.resize(d, (3840, 2160))[:350, :500], orc.orc_resize(crop, (500, 350), interpolation=1))
+    M = cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95)
+    Minv = np.ascontiguousarray(cv.invertAffineTransform(M), np.float64)
+    got = cv.warpAffine(d, M, (7680, 4320))
+    o = orc.oracle()
+    y1 = 700
+    want = np.empty((y1, 7680), np.float32); bv = np.zeros(4, np.float64)
+    assert o.orc_warpAffine(orc.P(src), orc.step(src), 7680, 4320, orc.P(want), orc.step(want), 7680, y1, 5, 1, orc.P(Minv), 1, 0, orc.P(bv)) == 0
+    e3 = rel(got[:y1], want)
+    assert max(e1, e2, e3) <= 1e-4, ("cfg3", e1, e2, e3)
+    res["cfg3a"] = f"rel {e1:.1e} (<= 1e-4), 600x400 region"; res["cfg3b"] = f"rel {e2:.1e}, 500x350 region"; res["cfg3c"] = f"rel {e3:.1e}, rows 0-{y1 - 1} of the 8K result"
+    del d, got
+    fr = rng.integers(0, 256, (3, 1080, 1920), dtype=np.uint8)
+    dfr = dev(fr)
+    e4 = rel(cv.cornerHarrisBatch(dfr, 2, 3, 0.04)[2], orc.orc_cornerHarris(fr[2], 2, 3, 0.04))
+    assert e4 <= 1e-4, ("cfg4a", e4)
+    res["cfg4a"] = f"rel {e4:.1e} (<= 1e-4), whole 1080p frame"
+    pyr = cv.buildPyramidBatch(dfr, 4)
+    lvl = fr[1]
+    for l in range(1, 5):
+        lvl = orc.orc_pyrDown(lvl)
+        assert np.array_equal(pyr[l][1].cpu().numpy(), lvl), ("cfg4b level", l)
+    res["cfg4b"] = "bit-exact, 4 levels of a 1080p frame"
+    img = rng.integers(0, 256, (2, 2160, 3840), dtype=np.uint8); tpl = rng.integers(0, 256, (128, 128), dtype=np.uint8)
+    r = cv.matchTemplateBatch(dev(img), dev(tpl), cv.TM_CCORR_NORMED)
+    e5 = 0.0
+    for (y0, x0) in [(0, 0), (1900, 3500), (1000, 2000)]:
+        c = np.ascontiguousarray(img[1, y0:y0 + 168, x0:x0 + 188])
+        e5 = max(e5, rel(r[1, y0:y0 + 41, x0:x0 + 61], orc.orc_matchTemplate(c, tpl, 3)))
+    assert e5 <= 1e-4, ("cfg5", e5)
+    res["cfg5"] = f"rel {e5:.1e} (<= 1e-4), three 61x41 regions of the 3713x2033 result"
+    torch.cuda.synchronize()
+    return res
+
+
+def run(quick=False, parity=True):
     out = []
     dev = "cuda"
+    gates = parity_gates() if parity else {}
+    torch.cuda.empty_cache()
     cv.set_async(True)
     g = torch.Generator(device=dev); g.manual_seed(809564)
     # ---- config 2: cvtColor BGR2GRAY + filter2D 3x3 on 3840x2160 CV_8U
@@ -158,6 +231,10 @@ def run(quick=False):
                 "frames_s": round(B5 / ms * 1e3, 2), "bound": "mfma", "achieved_TFLOPs": round(fl / ms / 1e9, 1),
                 "frac_of_bf16_dense_peak": round(fl / ms / 1e9 / MFMA_BF16, 4)})
     cv.set_async(False)
+    for r in out:
+        key = r["config"].split()[0]
+        if key in gates:
+            r["parity"] = gates[key]
     return out
 
 
