@@ -235,6 +235,17 @@ MI355CV_API int mi355cv_warpPerspective(int src_type, const mi355cv_uchar* src_d
 MI355CV_API int mi355cv_remap32f(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
         mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step,
         float* mapy, size_t mapy_step, int interpolation, int border_type, const double border_value[4]);
+/* cv::remap for every map representation it accepts (imgwarp.cpp:1718-1921; the HAL only has remap32f): (CV_32FC1, CV_32FC1), CV_32FC2, the
+ * fixed-point form of cv::convertMaps -- CV_16SC2 + CV_16UC1 / CV_16SC1 (bilinear, nearest), CV_16SC2 alone (nearest).  map*_type: cv type codes. */
+MI355CV_API int mi355cv_remap(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const void* map1, size_t map1_step, int map1_type,
+        const void* map2, size_t map2_step, int map2_type, int interpolation, int border_type, const double border_value[4]);
+/* cv::convertMaps (imgwarp.cpp:1925): float maps <-> CV_16SC2 (+ CV_16UC1), bit-exact with the reference's rounding */
+MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1_type, const void* map2, size_t map2_step, int map2_type,
+        void* dstmap1, size_t dstmap1_step, int dstmap1_type, void* dstmap2, size_t dstmap2_step, int width, int height, int nninterpolate);
+/* cv::warpPolar, forward direction (imgwarp.cpp:3731): map evaluation fused into the sampling kernel; WARP_INVERSE_MAP declines */
+MI355CV_API int mi355cv_warpPolar(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags);
 
 /* --------------------------------------------------- a10/a11/a12: corners and pyramids */
 
@@ -251,6 +262,10 @@ MI355CV_API int mi355cv_pyrdownBatch(const mi355cv_uchar* src_data, size_t src_s
 /* cv::buildPyramid (pyramids.cpp:1616-1643) has no HAL hook: dst_data[i] / dst_step[i] receive level i+1. */
 MI355CV_API int mi355cv_buildPyramid(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
         mi355cv_uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type);
+/* the same over a batch of device-resident frames, all levels of all frames enqueued by one call: dst_data[l-1] / dst_step[l-1] /
+ * dst_frame_stride[l-1] describe level l (frame 0's pointer, row pitch, bytes between frames) of pre-allocated arrays */
+MI355CV_API int mi355cv_buildPyramidBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int width, int height, int depth, int cn,
+        mi355cv_uchar* const* dst_data, const size_t* dst_step, const size_t* dst_frame_stride, int maxlevel, int nframes, int border_type);
 
 /* cv::cornerHarris (corner.cpp:634) / cv::cornerMinEigenVal (:604) have no HAL hook: fused entry points with the cv::
  * argument list.  src_type CV_8UC1 or CV_32FC1, dst CV_32FC1. */

@@ -1,5 +1,6 @@
 // mi355cv_cv.hpp -- cv::-identical C++ signatures for the hot-path functions that have NO imgproc HAL hook
-// (SURVEY.md §8b): cornerHarris, cornerMinEigenVal, goodFeaturesToTrack, buildPyramid, matchTemplate.  Header-only glue over
+// (SURVEY.md §8b): cornerHarris, cornerMinEigenVal, goodFeaturesToTrack, buildPyramid, matchTemplate -- and for the map
+// representations of remap the HAL does not cover, convertMaps and warpPolar.  Header-only glue over
 // the C ABI of mi355cv.h: each wrapper calls the fused MI355X entry point and falls back to the stock cv:: function when the
 // library declines (unsupported arguments, no gfx950 device, MI355CV_DISABLE=1), exactly as a HAL hook returning
 // CV_HAL_ERROR_NOT_IMPLEMENTED would.  A call site switches by replacing `cv::` with `mi355cv::`.
@@ -7,6 +8,7 @@
 //   reference signatures: imgproc.hpp  cornerHarris :1925, cornerMinEigenVal :1895, goodFeaturesToTrack :2077 / :2106,
 //                         buildPyramid :3308 (pyramids.cpp:1616), matchTemplate :3897 (templmatch.cpp:1158)
 #pragma once
+#include <climits>
 #include <vector>
 #include "opencv2/core.hpp"
 #include "opencv2/imgproc.hpp"
@@ -171,6 +173,67 @@ inline void matchTemplate(cv::InputArray _image, cv::InputArray _templ, cv::Outp
             return;
     }
     cv::matchTemplate(_image, _templ, _result, method, _mask);
+}
+
+// cv::remap (imgproc.hpp; imgwarp.cpp:1718).  The HAL only hooks the (CV_32FC1, CV_32FC1) pair of maps, which cv::remap already reaches; this wrapper
+// adds the other representations -- one CV_32FC2 map and the fixed-point maps cv::convertMaps produces -- and hands everything else to cv::.
+inline void remap(cv::InputArray _src, cv::OutputArray _dst, cv::InputArray _map1, cv::InputArray _map2, int interpolation,
+                  int borderMode = cv::BORDER_CONSTANT, const cv::Scalar& borderValue = cv::Scalar())
+{
+    cv::Mat src = _src.getMat(), map1 = _map1.getMat(), map2 = _map2.empty() ? cv::Mat() : _map2.getMat();
+    const bool pair32f = map1.type() == CV_32FC1 && map2.type() == CV_32FC1 && !map2.empty();
+    if (!pair32f && src.dims <= 2 && !map1.empty() && (map2.empty() || map2.size() == map1.size()) && !_dst.isUMat() &&
+        src.cols < SHRT_MAX && src.rows < SHRT_MAX && map1.cols < SHRT_MAX && map1.rows < SHRT_MAX) {
+        _dst.create(map1.size(), src.type());
+        cv::Mat dst = _dst.getMat();
+        if (dst.data == src.data) src = src.clone();
+        if (mi355cv_remap(src.type(), src.data, src.step, src.cols, src.rows, dst.data, dst.step, dst.cols, dst.rows, map1.data, map1.step, map1.type(),
+                          map2.empty() ? nullptr : map2.data, map2.empty() ? 0 : (size_t)map2.step, map2.empty() ? 0 : map2.type(), interpolation,
+                          borderMode, borderValue.val) == MI355CV_OK)
+            return;
+    }
+    cv::remap(_src, _dst, _map1, _map2, interpolation, borderMode, borderValue);
+}
+
+// cv::convertMaps (imgwarp.cpp:1925): float maps <-> CV_16SC2 (+ CV_16UC1)
+inline void convertMaps(cv::InputArray _map1, cv::InputArray _map2, cv::OutputArray _dstmap1, cv::OutputArray _dstmap2, int dstmap1type, bool nninterpolation = false)
+{
+    cv::Mat map1 = _map1.getMat(), map2 = _map2.empty() ? cv::Mat() : _map2.getMat();
+    int dt = dstmap1type;
+    if (dt <= 0) dt = map1.type() == CV_16SC2 ? CV_32FC2 : CV_16SC2;
+    const bool toFixed = dt == CV_16SC2 && ((map1.type() == CV_32FC1 && map2.type() == CV_32FC1 && !map2.empty()) || (map1.type() == CV_32FC2 && map2.empty()));
+    const bool toFloat = map1.type() == CV_16SC2 && (map2.empty() || map2.type() == CV_16UC1 || map2.type() == CV_16SC1) && (dt == CV_32FC1 || dt == CV_32FC2);
+    if ((toFixed || toFloat) && map1.dims <= 2 && (map2.empty() || map2.size() == map1.size()) && !_dstmap1.isUMat()) {
+        _dstmap1.create(map1.size(), dt);
+        cv::Mat d1 = _dstmap1.getMat(), d2;
+        const bool second = toFixed ? !nninterpolation : dt == CV_32FC1;
+        if (second) { _dstmap2.create(map1.size(), toFixed ? CV_16UC1 : CV_32FC1); d2 = _dstmap2.getMat(); }
+        else _dstmap2.release();
+        if (mi355cv_convertMaps(map1.data, map1.step, map1.type(), map2.empty() ? nullptr : map2.data, map2.empty() ? 0 : (size_t)map2.step,
+                                map2.empty() ? 0 : map2.type(), d1.data, d1.step, dt, second ? d2.data : nullptr, second ? (size_t)d2.step : 0,
+                                map1.cols, map1.rows, nninterpolation ? 1 : 0) == MI355CV_OK)
+            return;
+    }
+    cv::convertMaps(_map1, _map2, _dstmap1, _dstmap2, dstmap1type, nninterpolation);
+}
+
+// cv::warpPolar (imgwarp.cpp:3731): the forward direction runs as one kernel (map evaluation fused into the sampling); WARP_INVERSE_MAP and
+// whatever else the library declines go to cv::warpPolar, whose own remap call is served by the remap32f hook.
+inline void warpPolar(cv::InputArray _src, cv::OutputArray _dst, cv::Size dsize, cv::Point2f center, double maxRadius, int flags)
+{
+    cv::Mat src = _src.getMat();
+    if (!(flags & cv::WARP_INVERSE_MAP) && src.dims <= 2 && !_dst.isUMat() && src.cols < SHRT_MAX && src.rows < SHRT_MAX) {
+        if (dsize.width <= 0 && dsize.height <= 0) { dsize.width = cvRound(maxRadius); dsize.height = cvRound(maxRadius * CV_PI); }
+        else if (dsize.height <= 0) dsize.height = cvRound(dsize.width * CV_PI);
+        if (dsize.width > 0 && dsize.height > 0 && dsize.width < SHRT_MAX && dsize.height < SHRT_MAX) {
+            _dst.create(dsize, src.type());
+            cv::Mat dst = _dst.getMat();
+            if (dst.data == src.data) src = src.clone();
+            if (mi355cv_warpPolar(src.type(), src.data, src.step, src.cols, src.rows, dst.data, dst.step, dst.cols, dst.rows, center.x, center.y, maxRadius, flags) == MI355CV_OK)
+                return;
+        }
+    }
+    cv::warpPolar(_src, _dst, dsize, center, maxRadius, flags);
 }
 
 #ifdef OPENCV_TRACKING_HPP      // cv::calcOpticalFlowPyrLK lives in opencv2/video/tracking.hpp; include it before this header to get the wrapper

@@ -36,6 +36,12 @@ def _load():
         "mi355cv_version": (ctypes.c_char_p, []),
         "mi355cv_lastError": (ctypes.c_char_p, []),
         "mi355cv_lastKernel": (ctypes.c_char_p, []),
+        "mi355cv_remap": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int,
+                                  c_int, c_int, ctypes.c_void_p]),
+        "mi355cv_convertMaps": (c_int, [ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz,
+                                        c_int, c_int, c_int]),
+        "mi355cv_warpPolar": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_float, ctypes.c_float, c_dbl, c_int]),
+        "mi355cv_buildPyramidBatch": (c_int, [c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_int]),
         "mi355cv_setStream": (c_int, [ctypes.c_void_p]),
         "mi355cv_resetStream": (c_int, []),
         "mi355cv_setAsync": (c_int, [c_int]),

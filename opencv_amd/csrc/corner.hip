@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_pyrdown(const uchar* __restrict__ src, 
 // per output row.  Horizontal pass on packed even/odd byte planes (two 16-bit sums per dword, h <= 16*255), vertical pass on
 // the last five h rows (v <= 16*4080 fits 16 bits), (v + 128) >> 8 -- the integer arithmetic of PyrDownInvoker
 // (pyramids.cpp:873-1040), so bit-exact.  5 bytes of traffic per output pixel (4 read, 1 written).
+template <int D>
 __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
                                                       uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                       int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border)
@@ -122,16 +123,18 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
         cx.issueImg(r0, cx.y0 - 2, v); cx.issueImg(r1, cx.y0 - 1, v); cx.issueImg(r2, cx.y0, v);
         hpass(h0, r0); hpass(h1, r1); hpass(h2, r2);
     }
-    RawT raw[4]; int rv;
+    // ring of D source rows in flight per wave (D / 2 output rows ahead): small levels are a few thousand waves in all, so the bytes in flight
+    // per wave, not the wave count, is what covers the memory latency there
+    RawT raw[D]; int rv;
 #pragma unroll
-    for (int u = 0; u < 4; u++) cx.issueImg(raw[u], min(cx.y0 + 1 + u, H + 1), rv);
-    for (int t = 0; t < nout; t += 2) {
+    for (int u = 0; u < D; u++) cx.issueImg(raw[u], min(cx.y0 + 1 + u, H + 1), rv);
+    for (int t = 0; t < nout; t += D / 2) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < D / 2; u++) {
             if (t + u < nout) {
                 HRow h3, h4;
                 hpass(h3, raw[2 * u]); hpass(h4, raw[2 * u + 1]);
-                const int nxt = cx.y0 + 2 * (t + u) + 5;
+                const int nxt = cx.y0 + 2 * (t + u) + 1 + D;
                 cx.issueImg(raw[2 * u], min(nxt, H + 1), rv);
                 cx.issueImg(raw[2 * u + 1], min(nxt + 1, H + 1), rv);
                 uint32_t w[4];
@@ -150,6 +153,28 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
             }
         }
     }
+}
+
+// one level on device-resident images: the rolling kernel where its geometry applies, the per-output kernel otherwise
+void launchPyrDown(const uchar* ds, size_t dss, size_t sframe, int sw, int sh, uchar* dd, size_t dds, size_t dframe, int dw, int dh, int nframes,
+                   int depth, int cn, int mL, int mT, int mR, int mB, int border, hipStream_t st)
+{
+    if (depth == D8U && cn == 1 && !mL && !mT && !mR && !mB && dw * 2 == sw && dh == (sh + 1) / 2 && sh >= 2 && border != B_WRAP &&
+        (((uintptr_t)dd | dds | dframe) & 7) == 0 && sw % 16 == 0 && (((uintptr_t)ds | dss | sframe) & 15) == 0 &&
+        roll::eligible(ds, dss, sframe, ds, dss, sframe, sw, 1, 2, border)) {
+        // two source rows per output row; short segments when the batch is small so that every SIMD still gets several waves (the 4 halo
+        // rows a segment re-reads come from L2: its vertical neighbours run at the same time)
+        roll::Geom g = roll::geometry(sw, sh, 1, nframes, 32, 8, 16, 4096);
+        if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
+        const char* ringE = getenv("MI355CV_PYR_RING"); const int ringEnv = ringE ? atoi(ringE) : 0;   // tuning experiments
+        const int ring = ringEnv ? ringEnv : 8;
+        if (ring >= 12)     hipLaunchKernelGGL(k_pyrdown_roll<12>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
+        else if (ring >= 8) hipLaunchKernelGGL(k_pyrdown_roll<8>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
+        else                hipLaunchKernelGGL(k_pyrdown_roll<4>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
+        return;
+    }
+    dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, st, ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, depth, cn, mL, mT, mR, mB, border);
 }
 
 int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe, int sw, int sh, uchar* dst, size_t dstep, size_t dframe,
@@ -172,17 +197,7 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
         if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
         ds = dtop + (size_t)mT * dss + (size_t)mL * cn * e;
     } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
-    if (depth == D8U && cn == 1 && !mL && !mT && !mR && !mB && dw * 2 == sw && dh == (sh + 1) / 2 && sh >= 2 && border != B_WRAP &&
-        (((uintptr_t)dd | dds | dframe) & 7) == 0 && sw % 16 == 0 && (((uintptr_t)ds | dss | sframe) & 15) == 0 &&
-        roll::eligible(ds, dss, sframe, ds, dss, sframe, sw, 1, 2, border)) {
-        roll::Geom g = roll::geometry(sw, sh, 1, nframes, 32, 8);
-        if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
-        hipLaunchKernelGGL(k_pyrdown_roll, dim3(g.blocks), dim3(256), 0, stream(), ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips,
-                           g.seg, g.nseg, nframes, border);
-        return stg.finish(entry);
-    }
-    dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);
-    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, stream(), ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, depth, cn, mL, mT, mR, mB, border);
+    launchPyrDown(ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, nframes, depth, cn, mL, mT, mR, mB, border, stream());
     return stg.finish(entry);
 }
 
@@ -624,6 +639,31 @@ MI355CV_API int mi355cv_buildPyramid(const uchar* src_data, size_t src_step, int
         s = dst_data[l]; ss = dst_step[l]; w = dw; h = dh;
     }
     return MI355CV_OK;
+}
+
+// cv::buildPyramid over a batch of device-resident frames, every level of every frame enqueued by ONE call (levels 1..maxlevel into the
+// caller's pre-allocated arrays: dst_data[l-1] = level l of frame 0, frames dst_frame_stride[l-1] bytes apart).  Level l+1 only needs level l,
+// which the previous launch just wrote and L2 / Infinity Cache still hold, so the chain reads level 0 from HBM once.
+MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, int width, int height, int depth, int cn,
+                                          uchar* const* dst_data, const size_t* dst_step, const size_t* dst_frame_stride, int maxlevel, int nframes,
+                                          int border_type)
+{
+    if (disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    int border = border_type & ~MI355CV_BORDER_ISOLATED;
+    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data)) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
+    for (int l = 0; l < maxlevel; l++) if (!isDevicePtr(dst_data[l])) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
+    Stager stg;
+    const uchar* s = src_data; size_t ss = src_step, sf = nframes == 1 ? 0 : src_frame_stride; int w = width, h = height;
+    for (int l = 0; l < maxlevel; l++) {
+        const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+        const size_t df = nframes == 1 ? 0 : dst_frame_stride[l];
+        launchPyrDown(s, ss, sf, w, h, dst_data[l], dst_step[l], df, dw, dh, nframes, depth, cn, 0, 0, 0, 0, border, stream());
+        s = dst_data[l]; ss = dst_step[l]; sf = df; w = dw; h = dh;
+    }
+    return stg.finish("buildPyramidBatch");
 }
 
 MI355CV_API int mi355cv_cornerHarris(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,

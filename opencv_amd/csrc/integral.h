@@ -1,0 +1,11 @@
+// integral.h -- tiled cv::integral for 8-bit single-channel sources (integral.hip)
+#pragma once
+#include "rt.h"
+namespace mi355 {
+// scratch the tiled path needs (HBM, lives until the launches are enqueued in stream order)
+size_t integralTiledAuxBytes(int W, int H, int nframes, bool sq);
+// 8UC1 -> CV_32S or CV_64F sums (+ optional CV_64F squared sums); steps / frame strides in ELEMENTS of the respective output type.
+// Returns false when it does not apply (the caller then takes the general path).
+bool integralTiledU8(const uchar* src, size_t sstep, size_t sframe, int W, int H, int nframes, void* sum, size_t sumStepElems, size_t sumFrameElems, bool sumIsDouble,
+                     double* sq, size_t sqStepElems, size_t sqFrameElems, void* aux, hipStream_t st);
+}

@@ -266,13 +266,15 @@ inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t 
 }
 
 struct Geom { int nchunks, nstrips, seg, nseg; unsigned blocks; };
-inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16)
+// `wantWaves`: work items (waves) the launch should at least consist of, when the image has enough rows for that at >= minSeg rows each
+inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16, int wantWaves = 2048)
 {
     Geom g;
     g.nchunks = mi355::divUp(W * cn, cb); g.nstrips = mi355::divUp(g.nchunks, 64);
     if (const char* e = std::getenv("MI355CV_ROLL_SEG")) { const int v = atoi(e); if (v > 0) bestSeg = v; }     // tuning experiments
     long long per = (long long)g.nstrips * nframes;
-    long long wantSeg = (2048 + per - 1) / per;
+    if (const char* e = std::getenv("MI355CV_ROLL_WAVES")) { const int v = atoi(e); if (v > 0) wantWaves = v; }
+    long long wantSeg = (wantWaves + per - 1) / per;
     int seg = (int)((H + wantSeg - 1) / wantSeg);
     if (seg > bestSeg) seg = bestSeg;
     if (seg < minSeg) seg = minSeg;

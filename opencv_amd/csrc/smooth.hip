@@ -365,10 +365,18 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
     // alt: vertically adjacent segments are walked in opposite directions (even: down, odd: up) so that the R rows two
     // neighbours share are touched by both at the same moment (both start there, or both end there), and the two
     // neighbours are placed 8 work-item groups apart = on the same XCD (same L2) under the round-robin block placement.
+    // alt = log2 of the number of vertically adjacent segments that share an XCD (1: pairs, 2: quads, ...): inside such a group every boundary
+    // is walked towards by both neighbours at once (odd segments go up, even ones down), so its R halo rows come from L2 for one of them; only
+    // the group's outer boundaries are fetched twice -- 2R / (G * segRows) of the rows instead of 2R / (2 * segRows).
     int up = 0;
     if (alt) {
-        const int g = seg >> 4, j = seg & 15;
-        if ((g << 4) + 16 <= nseg) seg = (g << 4) + 2 * (j & 7) + (j >> 3);
+        const int G = 1 << alt, span = 8 * G;
+        const int g = seg / span, j = seg - g * span;
+        if ((g + 1) * span <= nseg) seg = g * span + G * (j & 7) + (j >> 3);
+        else if (alt > 1) {                                    // tail of the frame: pairs
+            const int base = g * span, t = seg - base, g2 = t >> 4, j2 = t & 15;
+            if (base + (g2 << 4) + 16 <= nseg) seg = base + (g2 << 4) + 2 * (j2 & 7) + (j2 >> 3);
+        }
         up = seg & 1;
     }
     const int c = strip * 64 + lane;

@@ -14,6 +14,7 @@
 //   * everything else (CV_32F, multi-channel, bigger templates): a direct kernel, exact integers for 8U, double for 32F.
 // The post-processing restates common_matchTemplate on window sums from GPU-built integral images (double).
 #include "rt.h"
+#include "integral.h"
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -690,9 +691,16 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * 8, height + 1, &d2) : nullptr;
     if (!ds || !s1 || (sqsum_data && !s2)) return MI355CV_NOT_IMPLEMENTED;
     const int Wc = (width + 1) * cn, nseg = divUp(height, IS_SEG);
+    hipStream_t st = stream();
+    static const bool tiledOff = getenv("MI355CV_INTEGRAL_TILED") && atoi(getenv("MI355CV_INTEGRAL_TILED")) == 0;
+    if (depth == D8U && cn == 1 && !tiledOff) {
+        // two passes over the pixels + carries (integral.hip) instead of a row pass and two column passes over the sum image
+        void* taux = stg.scratch(integralTiledAuxBytes(width, height, 1, s2 != nullptr));
+        if (taux && integralTiledU8(ds, dss, 0, width, height, 1, s1, d1 / se, 0, sdepth == D64F, (double*)s2, d2 / 8, 0, taux, st))
+            return stg.finish("integral");
+    }
     void* aux = stg.scratch((size_t)nseg * Wc * 8);
     if (!aux) return MI355CV_NOT_IMPLEMENTED;
-    hipStream_t st = stream();
     const size_t ldsFast = (((size_t)(width + 1) * se + 15) & ~(size_t)15) + (s2 ? (size_t)(width + 1) * 8 : 0);
     const bool fastRows = depth == D8U && cn == 1 && ldsFast <= 60 * 1024;
     if (sdepth == D32S) {

@@ -800,7 +800,21 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
     }
 }
 
-struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; };
+struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; int band /* XCD-banded tile order */; int gx, gy; };
+
+// Tile order.  Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2, so with the plain
+// x-fastest order the 8 horizontally adjacent tiles -- whose source footprints share cache lines -- land in 8 different L2s and each fetches
+// the shared lines again.  Banded order hands XCD k the k-th horizontal band of the tile grid (x-fastest inside the band): neighbours in
+// both directions then meet in one L2.
+__device__ __forceinline__ void tileOf(const WarpArgs& w, int& tx, int& ty)
+{
+    if (!w.band) { tx = blockIdx.x; ty = blockIdx.y; return; }
+    const int b = blockIdx.y * gridDim.x + blockIdx.x, total = w.gx * w.gy;
+    const int per = (total + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    if (t >= total) { tx = -1; ty = 0; return; }
+    ty = t / w.gx; tx = t - ty * w.gx;
+}
 
 __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                               SampleArgs s, WarpArgs w, const short* __restrict__ tab,
@@ -831,14 +845,72 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
         fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
         fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
         X = satIntD(fX); Y = satIntD(fY);
-    } else {
-        const float mx = reinterpret_cast<const float*>(mapx + (size_t)y * mxstep)[x];
-        const float my = reinterpret_cast<const float*>(mapy + (size_t)y * mystep)[x];
+    } else if (w.kind == 2 || w.kind == 3 || w.kind == 6) {
+        // float maps: kind 2 = two CV_32FC1 planes, kind 3 = one CV_32FC2 (RemapInvoker imgwarp.cpp:1233-1300), kind 6 = warpPolar's forward map
+        // evaluated in place (imgwarp.cpp:3776-3792: (float)(rho[x] * cos(phi_y) + cx) in double, the per-row cos / sin and the per-column
+        // radii come from the host, mapx = the radii, mapy = interleaved (cos, sin) doubles)
+        float mx, my;
+        if (w.kind == 2) {
+            mx = reinterpret_cast<const float*>(mapx + (size_t)y * mxstep)[x];
+            my = reinterpret_cast<const float*>(mapy + (size_t)y * mystep)[x];
+        } else if (w.kind == 3) {
+            const float2 m = reinterpret_cast<const float2*>(mapx + (size_t)y * mxstep)[x];
+            mx = m.x; my = m.y;
+        } else {
+            const double rho = (double)reinterpret_cast<const float*>(mapx)[x];
+            const double cp = reinterpret_cast<const double*>(mapy)[2 * y], sp = reinterpret_cast<const double*>(mapy)[2 * y + 1];
+            mx = (float)__dadd_rn(__dmul_rn(rho, cp), w.M[0]);
+            my = (float)__dadd_rn(__dmul_rn(rho, sp), w.M[1]);
+        }
         if (s.linear) { X = satIntD((double)__fmul_rn(mx, 32.f)); Y = satIntD((double)__fmul_rn(my, 32.f)); }
         else { X = satIntD((double)mx); Y = satIntD((double)my); }
+    } else {
+        // fixed-point maps (kind 4: CV_16SC2 + CV_16UC1 / CV_16SC1 fractions, kind 5: CV_16SC2 alone, nearest): integer source coordinates and,
+        // for bilinear, the index of the weight-table entry (ay * 32 + ax); nearest rounds with the fraction's halves (NNDeltaTab_i :237-238)
+        const short2 xy = reinterpret_cast<const short2*>(mapx + (size_t)y * mxstep)[x];
+        const int a = w.kind == 4 ? (int)(reinterpret_cast<const unsigned short*>(mapy + (size_t)y * mystep)[x] & 1023) : 0;
+        if (s.linear) { samplePixel(src, sstep, D, s, xy.x, xy.y, a & 31, a >> 5, tab); return; }
+        const int dx = w.kind == 4 ? ((a & 31) < 16 ? 1 : 0) : 0, dy = w.kind == 4 ? ((a >> 5) < 16 ? 1 : 0) : 0;
+        samplePixel(src, sstep, D, s, (short)(xy.x + dx), (short)(xy.y + dy), 0, 0, tab);
+        return;
     }
     if (s.linear) samplePixel(src, sstep, D, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
     else samplePixel(src, sstep, D, s, satShort(X), satShort(Y), 0, 0, tab);
+}
+
+// cv::convertMaps, float -> fixed point (imgwarp.cpp:2017-2120): ix = cvRound(x * 32), dst1 = (ix >> 5, iy >> 5) saturated to short,
+// dst2 = (iy & 31) * 32 + (ix & 31); with nninterpolate dst1 = the rounded coordinates and there is no dst2
+__global__ __launch_bounds__(256) void k_convert_maps_to_fixed(const uchar* __restrict__ m1, size_t m1step, const uchar* __restrict__ m2, size_t m2step, int interleaved,
+                                                               uchar* __restrict__ d1, size_t d1step, uchar* __restrict__ d2, size_t d2step, int w, int h, int nn)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    float fx, fy;
+    if (interleaved) { const float2 m = reinterpret_cast<const float2*>(m1 + (size_t)y * m1step)[x]; fx = m.x; fy = m.y; }
+    else { fx = reinterpret_cast<const float*>(m1 + (size_t)y * m1step)[x]; fy = reinterpret_cast<const float*>(m2 + (size_t)y * m2step)[x]; }
+    short2 o;
+    if (nn) { o.x = (short)satShort(satIntD((double)fx)); o.y = (short)satShort(satIntD((double)fy)); }
+    else {
+        const int ix = satIntD((double)__fmul_rn(fx, 32.f)), iy = satIntD((double)__fmul_rn(fy, 32.f));
+        o.x = (short)satShort(ix >> 5); o.y = (short)satShort(iy >> 5);
+        reinterpret_cast<unsigned short*>(d2 + (size_t)y * d2step)[x] = (unsigned short)((iy & 31) * 32 + (ix & 31));
+    }
+    reinterpret_cast<short2*>(d1 + (size_t)y * d1step)[x] = o;
+}
+
+// ... and back (imgwarp.cpp:2122-2200): x = X + (fxy & 31) / 32, y = Y + (fxy >> 5) / 32 in float, one multiply-add each (the reference's
+// v_muladd contracts on FMA builds and its scalar tail does not: the products are exact in float, so both give the same value)
+__global__ __launch_bounds__(256) void k_convert_maps_to_float(const uchar* __restrict__ m1, size_t m1step, const uchar* __restrict__ m2, size_t m2step,
+                                                               uchar* __restrict__ d1, size_t d1step, uchar* __restrict__ d2, size_t d2step, int interleaved, int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const short2 xy = reinterpret_cast<const short2*>(m1 + (size_t)y * m1step)[x];
+    const int fxy = m2 ? (int)(reinterpret_cast<const unsigned short*>(m2 + (size_t)y * m2step)[x] & 1023) : 0;
+    const float scale = 1.f / 32;
+    const float fx = __fadd_rn((float)xy.x, __fmul_rn((float)(fxy & 31), scale)), fy = __fadd_rn((float)xy.y, __fmul_rn((float)(fxy >> 5), scale));
+    if (interleaved) reinterpret_cast<float2*>(d1 + (size_t)y * d1step)[x] = make_float2(fx, fy);
+    else { reinterpret_cast<float*>(d1 + (size_t)y * d1step)[x] = fx; reinterpret_cast<float*>(d2 + (size_t)y * d2step)[x] = fy; }
 }
 
 // warpAffine, bilinear, single channel CV_32F / CV_8U: same arithmetic as k_warp + samplePixel, specialised so that the
@@ -851,8 +923,11 @@ template <typename T, int CN, int KIND /*0 affine, 1 perspective*/>
 __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                   SampleArgs s, WarpArgs w, const short* __restrict__ tab)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * WROWS;
+    int tx, ty;
+    tileOf(w, tx, ty);
+    if (tx < 0) return;
+    const int x = tx * 64 + (threadIdx.x & 63);
+    const int yb = (ty * 4 + (threadIdx.x >> 6)) * WROWS;
     if (x >= w.dw || yb >= w.dh) return;
     const int ad = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0)) : 0;
     const int bd = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0)) : 0;
@@ -924,6 +999,90 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
     }
 }
 
+// warpAffine, bilinear, single channel CV_32F, source staged per WAVE through LDS.  A wave owns 64 destination columns x LROWS rows.  Its
+// source footprint is a thin parallelogram whose bounding box follows from wave-uniform numbers alone (the coordinate X = X0(y) + ad(x) is
+// monotone in both terms, so the box corners are the strip's corners).  The box is copied into the wave's private LDS slab with full-width
+// 16-byte loads (every cache line it touches is read once, in whole sectors), then the four taps of every output come from LDS -- where a
+// 64-lane gather costs 2-4 cycles instead of the ~20 the vector L1 needs to return ten different lines.  No block barrier: a wave reads only
+// what it wrote itself.  Waves whose box leaves the image or does not fit the slab (strong minification) take the direct-gather code.
+// Same arithmetic as k_warp_lin / samplePixel, so the result is bit-identical.
+constexpr int LROWS = 16, LBH = 28, LBQ = 20, LPITCH = LBQ * 4 + 4;          // slab: LBH rows x 80 floats (pitch 84 floats: rows start 16 B apart in bank space)
+__global__ __launch_bounds__(256) void k_warp_affine_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                         SampleArgs s, WarpArgs w, const short* __restrict__ tab)
+{
+    __shared__ __attribute__((aligned(16))) float slab[4][LBH * LPITCH];
+    int tx, ty;
+    tileOf(w, tx, ty);
+    if (tx < 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = tx * 64 + lane;
+    const int yb = (ty * 4 + wv) * LROWS;
+    if (yb >= w.dh) return;
+    const int ye = min(yb + LROWS, w.dh);
+    const int xc = min(x, w.dw - 1);
+    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xc), 1024.0));
+    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xc), 1024.0));
+    // bounding box of the strip in the source: extremes of the row terms (wave-uniform) + extremes of the column terms (first / last lane)
+    const int xl = min(tx * 64 + 63, w.dw - 1);
+    const int adA = __builtin_amdgcn_readfirstlane(ad), bdA = __builtin_amdgcn_readfirstlane(bd);
+    const int adB = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xl), 1024.0)), bdB = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xl), 1024.0));
+    int X0lo = 0x7fffffff, X0hi = -0x7fffffff - 1, Y0lo = 0x7fffffff, Y0hi = -0x7fffffff - 1;
+    for (int y = yb; y < ye; y += (ye - 1 - yb > 0 ? ye - 1 - yb : 1)) {                  // the row terms are monotone in y: first and last row suffice
+        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+        X0lo = min(X0lo, X0); X0hi = max(X0hi, X0); Y0lo = min(Y0lo, Y0); Y0hi = max(Y0hi, Y0);
+    }
+    const long long Xlo = (long long)X0lo + min(adA, adB), Xhi = (long long)X0hi + max(adA, adB);
+    const long long Ylo = (long long)Y0lo + min(bdA, bdB), Yhi = (long long)Y0hi + max(bdA, bdB);
+    bool staged = Xlo > -0x7fffffffLL && Xhi < 0x7fffffffLL && Ylo > -0x7fffffffLL && Yhi < 0x7fffffffLL;
+    const int sxlo = (int)(Xlo >> 10), sxhi = (int)(Xhi >> 10) + 1, sylo = (int)(Ylo >> 10), syhi = (int)(Yhi >> 10) + 1;   // taps at sx, sx+1 / sy, sy+1
+    const int c0 = sxlo & ~3;
+    staged = staged && sxlo >= 0 && sylo >= 0 && sxhi < s.sw && syhi < s.sh && sxhi - c0 < 4 * LBQ && syhi - sylo < LBH && c0 + 4 * LBQ <= s.sw;
+    float* L = slab[wv];
+    if (staged) {
+        const int n = (syhi - sylo + 1) * LBQ;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        constexpr int NI = (LBH * LBQ + 63) / 64;                  // every load of the slab is in flight before the first LDS write waits for one
+        f4u v[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = lane + 64 * k, r = i / LBQ, q = i - r * LBQ;
+            if (i < n) v[k] = *reinterpret_cast<const f4u*>(src + (size_t)(sylo + r) * sstep + (size_t)(c0 + 4 * q) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = lane + 64 * k, r = i / LBQ, q = i - r * LBQ;
+            if (i < n) *reinterpret_cast<f4u*>(L + r * LPITCH + 4 * q) = v[k];
+        }
+    }
+    if (x >= w.dw) return;
+    for (int y = yb; y < ye; y++) {
+        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+        const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
+        const int sx = satShort(X >> 5), sy = satShort(Y >> 5), ax = X & 31, ay = Y & 31;
+        uchar* D = dst + (size_t)y * dstep + (size_t)x * 4;
+        const float s32 = 1.f / 32;
+        const float fx = ax * s32, fy = ay * s32;
+        const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+        const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
+        float p00, p01, p10, p11;
+        if (staged) {
+            const float* r0 = L + (sy - sylo) * LPITCH + (sx - c0);
+            p00 = r0[0]; p01 = r0[1]; p10 = r0[LPITCH]; p11 = r0[LPITCH + 1];
+        } else if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * 4;
+            const f2u v0 = *reinterpret_cast<const f2u*>(r0), v1 = *reinterpret_cast<const f2u*>(r0 + sstep);
+            p00 = v0.x; p01 = v0.y; p10 = v1.x; p11 = v1.y;
+        } else { samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab); continue; }
+        float t = __fadd_rn(__fmul_rn(p00, w0), __fmul_rn(p01, w1));
+        t = __fadd_rn(t, __fmul_rn(p10, w2));
+        t = __fadd_rn(t, __fmul_rn(p11, w3));
+        *reinterpret_cast<float*>(D) = t;
+    }
+}
+
 bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
@@ -958,18 +1117,41 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
         dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 4, dh, &mys);
         if (!dmx || !dmy) return MI355CV_NOT_IMPLEMENTED;
+    } else if (kind == 3) {                                                                  // one CV_32FC2 map
+        dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 8, dh, &mxs);
+        if (!dmx) return MI355CV_NOT_IMPLEMENTED;
+    } else if (kind == 4 || kind == 5) {                                                     // CV_16SC2 (+ CV_16UC1 fractions)
+        dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
+        if (kind == 4) dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 2, dh, &mys);
+        if (!dmx || (kind == 4 && !dmy)) return MI355CV_NOT_IMPLEMENTED;
+    } else if (kind == 6) {                                                                  // warpPolar tables (host arrays: dw radii, dh (cos, sin) pairs)
+        dmx = (const uchar*)stg.param(mapx, (size_t)dw * 4);
+        dmy = (const uchar*)stg.param(mapy, (size_t)dh * 16);
+        if (!dmx || !dmy) return MI355CV_NOT_IMPLEMENTED;
     }
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR; s.border = borderType;
     for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
     WarpArgs w; memset(&w, 0, sizeof w);
     w.dw = dw; w.dh = dh; w.kind = kind;
-    if (M) for (int i = 0; i < (kind == 0 ? 6 : 9); i++) w.M[i] = M[i];
+    if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
     if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && (dss % e) == 0 &&
         ((uintptr_t)ds % e) == 0) {
+        // experiment knob (tools/tune_r02.py): bit 0 XCD-banded tile order, bit 1 wave-staged LDS (32FC1 affine)
+        static const int variantDefault = 0;
+        const char* ve = getenv("MI355CV_WARP_VARIANT");
+        const int variant = ve ? atoi(ve) : variantDefault;
+        w.band = variant & 1;
+        if ((variant & 2) && kind == 0 && cn == 1 && depth == D32F && (dss & 3) == 0) {
+            dim3 g3(divUp(dw, 64), divUp(dh, 4 * LROWS));
+            w.gx = g3.x; w.gy = g3.y;
+            hipLaunchKernelGGL(k_warp_affine_lds, g3, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
+            return stg.finish(entry);
+        }
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS));
+        w.gx = g2.x; w.gy = g2.y;
 #define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev)
 #define WLC(T_, K_) do { if (cn == 1) WL(T_, 1, K_); else if (cn == 3) WL(T_, 3, K_); else WL(T_, 4, K_); } while (0)
         if (kind == 0) { if (depth == D32F) WLC(float, 0); else WLC(uchar, 0); }
@@ -1098,6 +1280,82 @@ MI355CV_API int mi355cv_remap32f(int src_type, const uchar* src_data, size_t src
     if (!mapx || !mapy) return MI355CV_NOT_IMPLEMENTED;
     return runWarp("remap32f", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    nullptr, 2, interpolation, border_type, border_value, mapx, mapx_step, mapy, mapy_step);
+}
+
+// cv::remap for every map representation it accepts (imgwarp.cpp:1718-1921; no HAL hook beyond remap32f): a pair of CV_32FC1 planes, one
+// CV_32FC2 map, or the fixed-point form convertMaps produces -- CV_16SC2 integer coordinates with CV_16UC1 / CV_16SC1 fractions (bilinear or
+// nearest) or CV_16SC2 alone (nearest).  NEAREST / LINEAR (AREA = LINEAR), every border mode incl. TRANSPARENT.  map types are cv type codes.
+MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const void* map1, size_t map1_step, int map1_type,
+        const void* map2, size_t map2_step, int map2_type, int interpolation, int border_type, const double border_value[4])
+{
+    if (!map1) return MI355CV_NOT_IMPLEMENTED;
+    const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
+    const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
+    if (interpolation & 32) return MI355CV_NOT_IMPLEMENTED;                                   // WARP_RELATIVE_MAP
+    int interp = interpolation & 7;
+    if (interp == MI355CV_INTER_AREA) interp = MI355CV_INTER_LINEAR;
+    if (map2 && map2_type == t16sc2 && (map1_type == t16uc1 || map1_type == t16sc1)) {        // either order is accepted (:1905-1909)
+        std::swap(map1, map2); std::swap(map1_step, map2_step); std::swap(map1_type, map2_type);
+    }
+    int kind;
+    if (map1_type == t32fc1 && map2 && map2_type == t32fc1) kind = 2;
+    else if (map1_type == t32fc2 && !map2) kind = 3;
+    else if (map1_type == t16sc2 && map2 && (map2_type == t16uc1 || map2_type == t16sc1)) kind = 4;
+    else if (map1_type == t16sc2 && !map2 && interp == MI355CV_INTER_NEAREST) kind = 5;
+    else return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("remap", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   nullptr, kind, interp, border_type, border_value, (const float*)map1, map1_step, (const float*)map2, map2_step);
+}
+
+// cv::convertMaps (imgwarp.cpp:1925-2260) between the float and the fixed-point map representations, device-resident or host maps:
+//   (CV_32FC1, CV_32FC1) or (CV_32FC2) -> CV_16SC2 + CV_16UC1 (nninterpolate: CV_16SC2 alone);  CV_16SC2 (+ CV_16UC1) -> CV_32FC1 pair or CV_32FC2
+MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1_type, const void* map2, size_t map2_step, int map2_type,
+        void* dstmap1, size_t dstmap1_step, int dstmap1_type, void* dstmap2, size_t dstmap2_step, int width, int height, int nninterpolate)
+{
+    if (disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
+    const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
+    const bool toFixed = dstmap1_type == t16sc2 && ((map1_type == t32fc1 && map2 && map2_type == t32fc1) || (map1_type == t32fc2 && !map2));
+    const bool toFloat = map1_type == t16sc2 && (!map2 || map2_type == t16uc1 || map2_type == t16sc1) && (dstmap1_type == t32fc1 || dstmap1_type == t32fc2);
+    if (!toFixed && !toFloat) return MI355CV_NOT_IMPLEMENTED;
+    if (toFixed && !nninterpolate && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
+    if (toFloat && dstmap1_type == t32fc1 && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t s1 = 0, s2 = 0, o1 = 0, o2 = 0;
+    const size_t e1 = map1_type == t32fc1 ? 4 : map1_type == t32fc2 ? 8 : 4;
+    const uchar* a = stg.in((const uchar*)map1, map1_step, (size_t)width * e1, height, &s1);
+    const uchar* b = map2 ? stg.in((const uchar*)map2, map2_step, (size_t)width * (toFixed ? 4 : 2), height, &s2) : nullptr;
+    const size_t f1 = dstmap1_type == t32fc1 ? 4 : dstmap1_type == t32fc2 ? 8 : 4;
+    uchar* c = stg.out((uchar*)dstmap1, dstmap1_step, (size_t)width * f1, height, &o1);
+    const bool needD2 = toFixed ? !nninterpolate : dstmap1_type == t32fc1;
+    uchar* d = needD2 ? stg.out((uchar*)dstmap2, dstmap2_step, (size_t)width * (toFixed ? 2 : 4), height, &o2) : nullptr;
+    if (!a || (map2 && !b) || !c || (needD2 && !d)) return MI355CV_NOT_IMPLEMENTED;
+    dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (toFixed) hipLaunchKernelGGL(k_convert_maps_to_fixed, grid, dim3(256), 0, stream(), a, s1, b, s2, map1_type == t32fc2 ? 1 : 0, c, o1, d, o2, width, height, nninterpolate ? 1 : 0);
+    else hipLaunchKernelGGL(k_convert_maps_to_float, grid, dim3(256), 0, stream(), a, s1, b, s2, c, o1, d, o2, dstmap1_type == t32fc2 ? 1 : 0, width, height);
+    return stg.finish("convertMaps");
+}
+
+// cv::warpPolar, forward direction (imgwarp.cpp:3731-3793: Cartesian image -> polar / semilog-polar image), as ONE kernel: the maps the
+// reference materialises (two CV_32F images) are evaluated per output pixel from dsize.width radii and dsize.height (cos, sin) pairs, which the
+// host computes exactly as the reference does (libm in double), followed by remap's sampling.  WARP_INVERSE_MAP is left to the reference
+// (its map needs cartToPolar / log in the CPU's own approximations; the remap it ends in is served by the remap32f hook).
+MI355CV_API int mi355cv_warpPolar(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags)
+{
+    if (disabled() || dst_width <= 0 || dst_height <= 0 || (flags & MI355CV_WARP_INVERSE_MAP)) return MI355CV_NOT_IMPLEMENTED;
+    const bool semiLog = (flags & 256) != 0;                                                  // WARP_POLAR_LOG
+    std::vector<float> rhos((size_t)dst_width);
+    std::vector<double> cs(2 * (size_t)dst_height);
+    if (semiLog) { const double Kmag = std::log(maxRadius) / dst_width; for (int r = 0; r < dst_width; r++) rhos[(size_t)r] = (float)(std::exp(r * Kmag) - 1.0); }
+    else { const double Kmag = maxRadius / dst_width; for (int r = 0; r < dst_width; r++) rhos[(size_t)r] = (float)(r * Kmag); }
+    const double Kangle = 6.283185307179586476925286766559 / dst_height;                      // CV_2PI
+    for (int p = 0; p < dst_height; p++) { const double k = Kangle * p; cs[2 * (size_t)p] = std::cos(k); cs[2 * (size_t)p + 1] = std::sin(k); }
+    const double M[2] = {(double)center_x, (double)center_y};
+    const double bv[4] = {0, 0, 0, 0};
+    return runWarp("warpPolar", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   M, 6, flags & 7, (flags & 8) ? B_CONSTANT : B_TRANSPARENT, bv, rhos.data(), 0, (const float*)cs.data(), 0);   // 8 = WARP_FILL_OUTLIERS
 }
 
 } // extern "C"

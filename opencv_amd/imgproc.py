@@ -25,7 +25,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "matchTemplate", "matchTemplateBatch", "integral", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
-           "resize", "warpAffine", "warpPerspective", "remap", "getRotationMatrix2D", "invertAffineTransform",
+           "resize", "warpAffine", "warpPerspective", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
            "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
@@ -849,19 +849,78 @@ def warpPerspective(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTAN
     return out
 
 
-def remap(src, map1, map2, interpolation=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
-    """cv::remap with CV_32FC1 maps (imgwarp.cpp:1718-; cv_hal_remap32f :1820)."""
+def remap(src, map1, map2=None, interpolation=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    """cv::remap (imgwarp.cpp:1718-1921).  A pair of CV_32FC1 maps goes through cv_hal_remap32f (:1820); the other representations -- one
+    CV_32FC2 map, or the fixed-point maps of convertMaps (CV_16SC2 + CV_16UC1, CV_16SC2 alone for nearest) -- through mi355cv_remap."""
     s = Img(src)
-    mx, my = Img(map1), Img(map2)
-    if mx.depth != CV_32F or my.depth != CV_32F or mx.cn != 1 or my.cn != 1 or (mx.w, mx.h) != (my.w, my.h):
-        raise NotImplementedError("remap: only a pair of CV_32FC1 maps")
-    out = dst if dst is not None else empty_like_kind(src, mx.h, mx.w, s.cn, s.depth)
+    m1 = Img(map1)
+    m2 = Img(map2) if map2 is not None else None
+    if m2 is not None and (m1.w, m1.h) != (m2.w, m2.h):
+        raise ValueError("remap: map sizes differ")
+    out = dst if dst is not None else empty_like_kind(src, m1.h, m1.w, s.cn, s.depth)
     d = Img(out)
+    if d.ptr == s.ptr:
+        src = _copy_like(src); s = Img(src)
     bv = _border_value(borderValue)
     bind_stream(s, d)
-    rc = L.mi355cv_remap32f(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, _vp(mx.ptr), mx.step, _vp(my.ptr), my.step,
-                            interpolation, borderMode, bv.ctypes.data)
-    _lib.check(rc, "remap32f")
+    if m2 is not None and m1.type == CV_MAKETYPE(CV_32F, 1) and m2.type == CV_MAKETYPE(CV_32F, 1):
+        rc = L.mi355cv_remap32f(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, _vp(m1.ptr), m1.step, _vp(m2.ptr), m2.step,
+                                interpolation, borderMode, bv.ctypes.data)
+        _lib.check(rc, "remap32f")
+        return out
+    rc = L.mi355cv_remap(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, _vp(m1.ptr), m1.step, m1.type,
+                         _vp(m2.ptr) if m2 is not None else None, m2.step if m2 is not None else 0, m2.type if m2 is not None else 0,
+                         interpolation, borderMode, bv.ctypes.data)
+    _lib.check(rc, "remap")
+    return out
+
+
+def convertMaps(map1, map2, dstmap1type, nninterpolation=False):
+    """cv::convertMaps (imgwarp.cpp:1925): (CV_32FC1, CV_32FC1) / CV_32FC2 -> (CV_16SC2, CV_16UC1) [CV_16SC2 alone with nninterpolation], and
+    CV_16SC2 (+ CV_16UC1) -> (CV_32FC1, CV_32FC1) / CV_32FC2.  Returns (dstmap1, dstmap2 or None)."""
+    m1 = Img(map1)
+    m2 = Img(map2) if map2 is not None else None
+    T16SC2, T16UC1, T32FC1, T32FC2 = CV_MAKETYPE(CV_16S, 2), CV_MAKETYPE(CV_16U, 1), CV_MAKETYPE(CV_32F, 1), CV_MAKETYPE(CV_32F, 2)
+    if dstmap1type <= 0:
+        dstmap1type = T32FC2 if m1.type == T16SC2 else T16SC2
+    if dstmap1type == T16SC2:
+        o1 = empty_like_kind(map1, m1.h, m1.w, 2, CV_16S)
+        o2 = None if nninterpolation else empty_like_kind(map1, m1.h, m1.w, 1, CV_16U)
+    elif dstmap1type == T32FC1:
+        o1, o2 = empty_like_kind(map1, m1.h, m1.w, 1, CV_32F), empty_like_kind(map1, m1.h, m1.w, 1, CV_32F)
+    elif dstmap1type == T32FC2:
+        o1, o2 = empty_like_kind(map1, m1.h, m1.w, 2, CV_32F), None
+    else:
+        raise ValueError("convertMaps: dstmap1type must be CV_16SC2, CV_32FC1 or CV_32FC2")
+    a, b = Img(o1), (Img(o2) if o2 is not None else None)
+    bind_stream(m1, a)
+    rc = L.mi355cv_convertMaps(_vp(m1.ptr), m1.step, m1.type, _vp(m2.ptr) if m2 is not None else None, m2.step if m2 is not None else 0,
+                               m2.type if m2 is not None else 0, _vp(a.ptr), a.step, dstmap1type, _vp(b.ptr) if b is not None else None,
+                               b.step if b is not None else 0, m1.w, m1.h, 1 if nninterpolation else 0)
+    _lib.check(rc, "convertMaps")
+    return o1, o2
+
+
+WARP_FILL_OUTLIERS, WARP_POLAR_LINEAR, WARP_POLAR_LOG = 8, 0, 256
+
+
+def warpPolar(src, dsize, center, maxRadius, flags, dst=None):
+    """cv::warpPolar (imgwarp.cpp:3731), forward direction; WARP_INVERSE_MAP raises (the reference's own path: maps on the CPU + cv_hal_remap32f)."""
+    s = Img(src)
+    dw, dh = dsize
+    if dw <= 0 and dh <= 0:                                       # :3737-3745
+        dw, dh = _cvRound(maxRadius), _cvRound(maxRadius * np.pi)
+    elif dh <= 0:
+        dh = _cvRound(dw * np.pi)
+    if dst is not None:
+        out = dst
+    else:
+        out = empty_like_kind(src, dh, dw, s.cn, s.depth)
+        out[...] = 0                                              # Mat::create leaves new memory as it is; BORDER_TRANSPARENT keeps it -- start from zeros
+    d = Img(out)
+    bind_stream(s, d)
+    rc = L.mi355cv_warpPolar(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, float(center[0]), float(center[1]), float(maxRadius), flags)
+    _lib.check(rc, "warpPolar")
     return out
 
 
@@ -902,21 +961,29 @@ def buildPyramid(src, maxlevel, borderType=BORDER_DEFAULT):
     return levels
 
 
-def buildPyramidBatch(frames, maxlevel, borderType=BORDER_DEFAULT):
-    """[N,H,W(,C)] device frames -> list of per-level batches, one launch per level."""
+def buildPyramidBatch(frames, maxlevel, borderType=BORDER_DEFAULT, dst=None):
+    """[N,H,W(,C)] device frames -> list of per-level batches [frames, level 1, ...]; every level of every frame is enqueued by one call
+    (mi355cv_buildPyramidBatch).  `dst`: the list a previous call returned, to reuse its level arrays."""
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     cn = int(frames.shape[3]) if frames.dim() == 4 else 1
-    out, cur = [frames], frames
-    for _ in range(maxlevel):
-        dw, dh = (w + 1) // 2, (h + 1) // 2
-        nxt = torch.empty((n, dh, dw) + ((cn,) if frames.dim() == 4 else ()), dtype=frames.dtype, device=frames.device)
-        s0, d0 = Img(cur[0]), Img(nxt[0])
-        bind_stream(s0, d0)
-        rc = L.mi355cv_pyrdownBatch(_vp(s0.ptr), s0.step, int(cur.stride(0)) * s0.esz, w, h, _vp(d0.ptr), d0.step, int(nxt.stride(0)) * d0.esz,
-                                    dw, dh, n, s0.depth, cn, borderType)
-        _lib.check(rc, "pyrdownBatch")
-        out.append(nxt)
-        cur, w, h = nxt, dw, dh
+    out = [frames]
+    for l in range(maxlevel):
+        w, h = (w + 1) // 2, (h + 1) // 2
+        shape = (n, h, w) + ((cn,) if frames.dim() == 4 else ())
+        lvl = dst[l + 1] if dst is not None else torch.empty(shape, dtype=frames.dtype, device=frames.device)
+        if tuple(lvl.shape) != shape or lvl.dtype != frames.dtype:
+            raise ValueError("dst level geometry mismatch")
+        out.append(lvl)
+    if maxlevel < 1:
+        return out
+    s0 = Img(frames[0])
+    imgs = [Img(l[0]) for l in out[1:]]
+    ptrs = (ctypes.c_void_p * maxlevel)(*[i.ptr for i in imgs])
+    steps = (ctypes.c_size_t * maxlevel)(*[i.step for i in imgs])
+    strides = (ctypes.c_size_t * maxlevel)(*[int(l.stride(0)) * s0.esz for l in out[1:]])
+    bind_stream(s0, imgs[0])
+    rc = L.mi355cv_buildPyramidBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, s0.w, s0.h, s0.depth, cn, ptrs, steps, strides, maxlevel, n, borderType)
+    _lib.check(rc, "buildPyramidBatch")
     return out
 
 

@@ -112,6 +112,13 @@ int orc_warpPerspective(const uint8_t* src, size_t sstep, int sw, int sh, uint8_
 int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                  int depth, int cn, const float* mapx, size_t mxstep, const float* mapy, size_t mystep,
                  int interpolation, int border, const double* bv);
+int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                  const void* map1, size_t m1step, const void* map2, size_t m2step, int kind, int interpolation, int border, const double* bv);
+void orc_convertMapsToFixed(const void* m1, size_t m1step, const void* m2, size_t m2step, int interleaved, void* d1, size_t d1step, void* d2, size_t d2step,
+                            int w, int h, int nn);
+void orc_convertMapsToFloat(const void* m1, size_t m1step, const void* m2, size_t m2step, void* d1, size_t d1step, void* d2, size_t d2step, int interleaved, int w, int h);
+int orc_warpPolar(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                  float cx, float cy, double maxRadius, int flags);
 
 /* corners / pyramids, see oracle/corner.c */
 int orc_cornerResponse(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int sdepth,

@@ -96,6 +96,26 @@ EXPORT int wrap_cornerHarrisRoi(const void* s, size_t ss, int pw, int ph, int st
     catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
 
+// mi355cv::convertMaps + mi355cv::remap on the fixed-point maps, and mi355cv::warpPolar: float maps in, the remapped / polar image out
+EXPORT int wrap_remapFixed(const void* s, size_t ss, int sw, int sh, int type, const float* mapx, size_t mxs, const float* mapy, size_t mys, int dw, int dh,
+                           void* d, size_t ds, int interpolation, int borderMode)
+{
+    try { Mat src = M(s, ss, sw, sh, type), mx = M(mapx, mxs, dw, dh, CV_32FC1), my = M(mapy, mys, dw, dh, CV_32FC1), dst = M(d, ds, dw, dh, type), m1, m2;
+          const uchar* p = dst.data;
+          mi355cv::convertMaps(mx, my, m1, m2, CV_16SC2, false);
+          if (m1.type() != CV_16SC2 || m2.type() != CV_16UC1) return -3;
+          mi355cv::remap(src, dst, m1, m2, interpolation, borderMode, Scalar(7, 8, 9, 10));
+          return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+EXPORT int wrap_warpPolar(const void* s, size_t ss, int sw, int sh, int type, void* d, size_t ds, int dw, int dh, float cx, float cy, double maxRadius, int flags)
+{
+    try { Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type); const uchar* p = dst.data;
+          mi355cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
+          return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
 // mi355cv::calcOpticalFlowPyrLK with std::vector outputs, as applications call it
 EXPORT int wrap_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* next, size_t ns, int w, int h, int type, const float* pts, float* nextPts, int npts,
                                      unsigned char* status, float* err, int winW, int winH, int maxLevel, int critType, int maxCount, double eps, int flags, double minEig)

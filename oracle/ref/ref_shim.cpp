@@ -296,6 +296,37 @@ int ref_remap(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int 
     REF_END(dst, d)
 }
 
+// cv::remap with any pair of map types (cv type codes; map2 may be NULL)
+int ref_remapMaps(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type,
+                  const void* m1, size_t m1s, int m1type, const void* m2, size_t m2s, int m2type, int interpolation, int borderMode, const double* bv)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    Mat a = M(m1, m1s, dw, dh, m1type), b = m2 ? M(m2, m2s, dw, dh, m2type) : Mat();
+    cv::remap(src, dst, a, b, interpolation, borderMode, Scalar(bv[0], bv[1], bv[2], bv[3]));
+    REF_END(dst, d)
+}
+
+int ref_convertMaps(const void* m1, size_t m1s, int m1type, const void* m2, size_t m2s, int m2type, void* d1, size_t d1s, int d1type, void* d2, size_t d2s, int d2type,
+                    int w, int h, int nninterpolate)
+{
+    try {
+        Mat a = M(m1, m1s, w, h, m1type), b = m2 ? M(m2, m2s, w, h, m2type) : Mat();
+        Mat o1 = M(d1, d1s, w, h, d1type), o2 = d2 ? M(d2, d2s, w, h, d2type) : Mat();
+        const uchar* p1 = o1.data; const uchar* p2 = o2.data;
+        cv::convertMaps(a, b, o1, o2, d1type, nninterpolate != 0);
+        return (o1.data == p1 && (!d2 || o2.data == p2)) ? 0 : -2;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref: %s\n", e.what()); return -1; }
+}
+
+int ref_warpPolar(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, int dw, int dh, int type, float cx, float cy, double maxRadius, int flags)
+{
+    REF_TRY
+    Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
+    cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
+    REF_END(dst, d)
+}
+
 int ref_getRotationMatrix2D(double cx, double cy, double angle, double scale, double* M6)
 {
     try { Mat m = cv::getRotationMatrix2D(Point2f((float)cx, (float)cy), angle, scale); memcpy(M6, m.ptr<double>(), 6 * sizeof(double)); return 0; }

@@ -573,3 +573,96 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
     }
     return 0;
 }
+
+/* cv::remap for the other map representations (RemapInvoker imgwarp.cpp:1143-1320): kind 3 = one CV_32FC2 map, kind 4 = CV_16SC2 coordinates +
+ * CV_16UC1 / CV_16SC1 fractions (index ay * 32 + ax of the weight table; nearest adds NNDeltaTab_i, :237-238 / :1178-1180), kind 5 = CV_16SC2
+ * alone (nearest: the coordinates as they are).  TEST INFRASTRUCTURE (the checker for mi355cv_remap). */
+int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                  const void* map1, size_t m1step, const void* map2, size_t m2step, int kind, int interpolation, int border, const double* bv)
+{
+    if (interpolation == 3) interpolation = 1;
+    if (interpolation != 0 && interpolation != 1) return 1;
+    const int e = esz(depth);
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
+            if (kind == 3) {
+                const float* m = (const float*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
+                if (interpolation == 1) {
+                    int sx = sat_int_d((double)(m[0] * 32.f)), sy = sat_int_d((double)(m[1] * 32.f));
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5), sat_short_i(sy >> 5), sx & 31, sy & 31, 1, border, bv);
+                } else {
+                    int sx = sat_int_d((double)m[0]), sy = sat_int_d((double)m[1]);
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx), sat_short_i(sy), 0, 0, 0, border, bv);
+                }
+            } else {
+                const short* xy = (const short*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
+                const int a = kind == 4 ? (((const uint16_t*)((const uint8_t*)map2 + (size_t)y * m2step))[x] & 1023) : 0;
+                if (interpolation == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, xy[0], xy[1], a & 31, a >> 5, 1, border, bv);
+                else {
+                    const int dx = kind == 4 ? (a & 31) < 16 : 0, dy = kind == 4 ? (a >> 5) < 16 : 0;
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, (short)(xy[0] + dx), (short)(xy[1] + dy), 0, 0, 0, border, bv);
+                }
+            }
+        }
+    return 0;
+}
+
+/* cv::convertMaps float -> fixed (imgwarp.cpp:2017-2120) and back (:2122-2200) */
+void orc_convertMapsToFixed(const void* m1, size_t m1step, const void* m2, size_t m2step, int interleaved, void* d1, size_t d1step, void* d2, size_t d2step,
+                            int w, int h, int nn)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float fx, fy;
+            if (interleaved) { const float* m = (const float*)((const uint8_t*)m1 + (size_t)y * m1step) + 2 * x; fx = m[0]; fy = m[1]; }
+            else { fx = ((const float*)((const uint8_t*)m1 + (size_t)y * m1step))[x]; fy = ((const float*)((const uint8_t*)m2 + (size_t)y * m2step))[x]; }
+            short* o = (short*)((uint8_t*)d1 + (size_t)y * d1step) + 2 * x;
+            if (nn) { o[0] = sat_short_i(sat_int_d((double)fx)); o[1] = sat_short_i(sat_int_d((double)fy)); }
+            else {
+                const int ix = sat_int_d((double)(fx * 32.f)), iy = sat_int_d((double)(fy * 32.f));
+                o[0] = sat_short_i(ix >> 5); o[1] = sat_short_i(iy >> 5);
+                ((uint16_t*)((uint8_t*)d2 + (size_t)y * d2step))[x] = (uint16_t)((iy & 31) * 32 + (ix & 31));
+            }
+        }
+}
+
+void orc_convertMapsToFloat(const void* m1, size_t m1step, const void* m2, size_t m2step, void* d1, size_t d1step, void* d2, size_t d2step, int interleaved, int w, int h)
+{
+    const float scale = 1.f / 32;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const short* xy = (const short*)((const uint8_t*)m1 + (size_t)y * m1step) + 2 * x;
+            const int fxy = m2 ? (((const uint16_t*)((const uint8_t*)m2 + (size_t)y * m2step))[x] & 1023) : 0;
+            const float px = (float)(fxy & 31) * scale, py = (float)(fxy >> 5) * scale;
+            const float fx = (float)xy[0] + px, fy = (float)xy[1] + py;
+            if (interleaved) { float* o = (float*)((uint8_t*)d1 + (size_t)y * d1step) + 2 * x; o[0] = fx; o[1] = fy; }
+            else { ((float*)((uint8_t*)d1 + (size_t)y * d1step))[x] = fx; ((float*)((uint8_t*)d2 + (size_t)y * d2step))[x] = fy; }
+        }
+}
+
+/* cv::warpPolar, forward direction (imgwarp.cpp:3731-3793): the two float maps as the reference builds them, then remap */
+int orc_warpPolar(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                  float cx, float cy, double maxRadius, int flags)
+{
+    if (flags & 16) return 1;
+    float* mx = (float*)malloc((size_t)dw * dh * sizeof(float));
+    float* my = (float*)malloc((size_t)dw * dh * sizeof(float));
+    float* rhos = (float*)malloc((size_t)dw * sizeof(float));
+    if (!mx || !my || !rhos) { free(mx); free(my); free(rhos); return 1; }
+    if (flags & 256) { const double Kmag = log(maxRadius) / dw; for (int r = 0; r < dw; r++) rhos[r] = (float)(exp(r * Kmag) - 1.0); }
+    else { const double Kmag = maxRadius / dw; for (int r = 0; r < dw; r++) rhos[r] = (float)(r * Kmag); }
+    const double Kangle = 6.283185307179586476925286766559 / dh;
+    for (int p = 0; p < dh; p++) {
+        const double KKy = Kangle * p, cp = cos(KKy), sp = sin(KKy);
+        for (int r = 0; r < dw; r++) {
+            const double t0 = rhos[r] * cp, t1 = rhos[r] * sp;
+            const double x = t0 + cx, y = t1 + cy;
+            mx[(size_t)p * dw + r] = (float)x; my[(size_t)p * dw + r] = (float)y;
+        }
+    }
+    const double bv[4] = {0, 0, 0, 0};
+    const int rc = orc_remap32f(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, mx, (size_t)dw * 4, my, (size_t)dw * 4, flags & 7, (flags & 8) ? 0 : 5, bv);
+    free(mx); free(my); free(rhos);
+    return rc;
+}

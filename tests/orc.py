@@ -594,6 +594,94 @@ def orc_remap(src, mapx, mapy, interpolation=1, border=0, borderValue=0.0):
     return dst
 
 
+def _map_type(a):
+    return cvtype(a) if a is not None else 0
+
+
+def _map_kind(map1, map2):
+    if map1.dtype == np.float32 and map1.ndim == 3: return 3
+    if map1.dtype == np.int16 and map2 is not None: return 4
+    if map1.dtype == np.int16: return 5
+    raise ValueError("map types")
+
+
+def orc_remapMaps(src, map1, map2, interpolation=1, border=0, borderValue=0.0, dst=None):
+    """cv::remap with a CV_32FC2 map or the fixed-point maps (CV_16SC2 [+ CV_16UC1])"""
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dh, dw = map1.shape[:2]
+    dst = np.ascontiguousarray(dst).copy() if dst is not None else _dst_geom(src, (dw, dh))
+    bv = _bv(borderValue)
+    rc = o.orc_remapMaps(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, _NP_DEPTH[src.dtype], cn_of(src), P(map1), step(map1),
+                         P(map2) if map2 is not None else None, step(map2) if map2 is not None else 0, _map_kind(map1, map2), interpolation, border, P(bv))
+    assert rc == 0
+    return dst
+
+
+def ref_remapMaps(src, map1, map2, interpolation=1, border=0, borderValue=0.0, dst=None):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dh, dw = map1.shape[:2]
+    dst = np.ascontiguousarray(dst).copy() if dst is not None else _dst_geom(src, (dw, dh))
+    bv = _bv(borderValue)
+    rc = r.ref_remapMaps(P(src), step(src), sw, sh, P(dst), step(dst), dw, dh, cvtype(src), P(map1), step(map1), _map_type(map1),
+                         P(map2) if map2 is not None else None, step(map2) if map2 is not None else 0, _map_type(map2), interpolation, border, P(bv))
+    assert rc == 0, rc
+    return dst
+
+
+def _convert_maps_out(map1, dsttype, nn):
+    h, w = map1.shape[:2]
+    if dsttype == "16sc2":
+        return np.empty((h, w, 2), np.int16), (None if nn else np.empty((h, w), np.uint16))
+    if dsttype == "32fc1":
+        return np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    return np.empty((h, w, 2), np.float32), None
+
+
+def orc_convertMaps(map1, map2, dsttype, nn=False):
+    o = oracle()
+    h, w = map1.shape[:2]
+    d1, d2 = _convert_maps_out(map1, dsttype, nn)
+    if dsttype == "16sc2":
+        o.orc_convertMapsToFixed(P(map1), step(map1), P(map2) if map2 is not None else None, step(map2) if map2 is not None else 0, 1 if map1.ndim == 3 else 0,
+                                 P(d1), step(d1), P(d2) if d2 is not None else None, step(d2) if d2 is not None else 0, w, h, 1 if nn else 0)
+    else:
+        o.orc_convertMapsToFloat(P(map1), step(map1), P(map2) if map2 is not None else None, step(map2) if map2 is not None else 0, P(d1), step(d1),
+                                 P(d2) if d2 is not None else None, step(d2) if d2 is not None else 0, 1 if dsttype == "32fc2" else 0, w, h)
+    return d1, d2
+
+
+def ref_convertMaps(map1, map2, dsttype, nn=False):
+    r = load_ref()
+    h, w = map1.shape[:2]
+    d1, d2 = _convert_maps_out(map1, dsttype, nn)
+    rc = r.ref_convertMaps(P(map1), step(map1), cvtype(map1), P(map2) if map2 is not None else None, step(map2) if map2 is not None else 0, _map_type(map2),
+                           P(d1), step(d1), cvtype(d1), P(d2) if d2 is not None else None, step(d2) if d2 is not None else 0, _map_type(d2), w, h, 1 if nn else 0)
+    assert rc == 0, rc
+    return d1, d2
+
+
+def orc_warpPolar(src, dsize, center, maxRadius, flags):
+    o = oracle()
+    sh, sw = src.shape[:2]
+    dst = np.zeros((dsize[1], dsize[0]) + src.shape[2:], src.dtype)
+    rc = o.orc_warpPolar(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], _NP_DEPTH[src.dtype], cn_of(src), ctypes.c_float(center[0]),
+                         ctypes.c_float(center[1]), c_dbl(maxRadius), flags)
+    assert rc == 0
+    return dst
+
+
+def ref_warpPolar(src, dsize, center, maxRadius, flags):
+    r = load_ref()
+    sh, sw = src.shape[:2]
+    dst = np.zeros((dsize[1], dsize[0]) + src.shape[2:], src.dtype)
+    rc = r.ref_warpPolar(P(src), step(src), sw, sh, P(dst), step(dst), dsize[0], dsize[1], cvtype(src), ctypes.c_float(center[0]), ctypes.c_float(center[1]),
+                         c_dbl(maxRadius), flags)
+    assert rc == 0, rc
+    return dst
+
+
 def ref_warpAffine(src, M, dsize, flags=1 | 16, border=0, borderValue=0.0, dst=None):
     r = load_ref()
     sh, sw = src.shape[:2]

@@ -283,6 +283,49 @@ def test_cv_signature_wrappers_on_a_submatrix(ref):
         assert O.rel_err(got, want) <= 1e-4, border
 
 
+def _wrap_warp_family(hal):
+    import ctypes
+    src = O.ref_rng_fill((60, 80, 3), np.uint8, 3, 0, 256)
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:45, 0:70].astype(np.float32)
+    mapx = (xx * 1.1 + rng.uniform(-2, 2, xx.shape)).astype(np.float32); mapy = (yy * 1.3 + rng.uniform(-2, 2, yy.shape)).astype(np.float32)
+    out = {}
+    for interp in (0, 1):
+        d = np.zeros((45, 70, 3), np.uint8)
+        rc = hal.wrap_remapFixed(O.P(src), O.step(src), 80, 60, O.cvtype(src), O.P(mapx), O.step(mapx), O.P(mapy), O.step(mapy), 70, 45, O.P(d), O.step(d), interp, 0)
+        assert rc == 0, rc
+        f1, f2 = O.ref_convertMaps(mapx, mapy, "16sc2", False)
+        assert np.array_equal(d, O.ref_remapMaps(src, f1, f2, interp, 0, (7, 8, 9, 10))), interp
+    for flags in (1 | 8, 1 | 256):
+        d = np.zeros((90, 64, 3), np.uint8)
+        rc = hal.wrap_warpPolar(O.P(src), O.step(src), 80, 60, O.cvtype(src), O.P(d), O.step(d), 64, 90, ctypes.c_float(40.0), ctypes.c_float(30.0), ctypes.c_double(35.0), flags)
+        assert rc == 0, rc
+        assert np.array_equal(d, O.ref_warpPolar(src, (64, 90), (40.0, 30.0), 35.0, flags)), flags
+
+
+def test_cv_signature_warp_family(ref):
+    """mi355cv::convertMaps / remap (fixed-point maps) / warpPolar with cv:: signatures equal the stock functions -- here through their fallback,
+    on the GPU box (test below) through the fused entry points"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see the _gpu variant")
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    _wrap_warp_family(hal)
+
+
+@pytest.mark.gpu
+def test_cv_signature_warp_family_gpu(ref):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None
+    n = {k: cv.call_count(k) for k in ("remap", "convertMaps", "warpPolar")}
+    _wrap_warp_family(hal)
+    for k in n:
+        assert cv.call_count(k) > n[k], k
+
+
 def _wrap_lk(hal, A, B, p, win, maxLevel, flags=0, guess=None):
     import ctypes
     n = len(p)

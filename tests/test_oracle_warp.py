@@ -150,3 +150,54 @@ def test_remap32f(orc, ref, dtype):
     for interp in (0, 1):
         for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0)]:
             same(orc, orc.orc_remap(src, mapx, mapy, interp, border, bval), orc.ref_remap(src, mapx, mapy, interp, border, bval))
+
+
+def _float_maps(seed, w=47, h=33, sw=50, sh=40):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    mapx = (xx * (sw / w) + rng.uniform(-3, 3, xx.shape)).astype(np.float32)
+    mapy = (yy * (sh / h) - 1 + rng.uniform(-3, 3, yy.shape)).astype(np.float32)
+    return mapx, mapy
+
+
+def test_convert_maps(orc, ref):
+    """cv::convertMaps in both directions, every representation (imgwarp.cpp:1925-2260)"""
+    mapx, mapy = _float_maps(5)
+    mapx[3, 4] = 17.515625; mapy[3, 4] = 8.984375           # exact 1/64 steps: ties of cvRound(x * 32)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    for nn in (False, True):
+        for m1, m2 in ((mapx, mapy), (xy, None)):
+            w1, w2 = orc.ref_convertMaps(m1, m2, "16sc2", nn)
+            g1, g2 = orc.orc_convertMaps(m1, m2, "16sc2", nn)
+            assert np.array_equal(g1, w1) and (nn or np.array_equal(g2, w2))
+    f1, f2 = orc.ref_convertMaps(mapx, mapy, "16sc2", False)
+    for dt in ("32fc1", "32fc2"):
+        w1, w2 = orc.ref_convertMaps(f1, f2, dt)
+        g1, g2 = orc.orc_convertMaps(f1, f2, dt)
+        assert np.array_equal(g1, w1) and (w2 is None or np.array_equal(g2, w2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_remap_other_map_types(orc, ref, dtype):
+    """cv::remap with a CV_32FC2 map and with the fixed-point maps of convertMaps (bilinear and nearest), incl. BORDER_TRANSPARENT"""
+    src = rnd(orc, (40, 50, 3), dtype, 36)
+    mapx, mapy = _float_maps(4)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.ref_convertMaps(mapx, mapy, "16sc2", False)
+    n1, _ = orc.ref_convertMaps(mapx, mapy, "16sc2", True)
+    prev = rnd(orc, (33, 47, 3), dtype, 37)
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0), (5, 0)]:
+            d0 = prev if border == 5 else None
+            same(orc, orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=d0), orc.ref_remapMaps(src, xy, None, interp, border, bval, dst=d0))
+            same(orc, orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=d0), orc.ref_remapMaps(src, f1, f2, interp, border, bval, dst=d0))
+        same(orc, orc.orc_remapMaps(src, n1, None, 0, 1, 0), orc.ref_remapMaps(src, n1, None, 0, 1, 0))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_polar_forward(orc, ref, dtype):
+    """cv::warpPolar, Cartesian -> polar / semilog-polar (imgwarp.cpp:3731-3793), with and without WARP_FILL_OUTLIERS"""
+    src = rnd(orc, (60, 80, 3), dtype, 41)
+    for flags in (1, 1 | 8, 0 | 8, 1 | 256, 1 | 256 | 8):
+        for dsize, center, rad in [((64, 90), (40.0, 30.0), 35.0), ((50, 157), (10.5, 50.25), 60.0)]:
+            same(orc, orc.orc_warpPolar(src, dsize, center, rad, flags), orc.ref_warpPolar(src, dsize, center, rad, flags))

@@ -204,3 +204,64 @@ def orc_band(orc, src, Minv, y0=2000, y1=2200):
     rc = o.orc_warpAffine(orc.P(src), orc.step(src), w, h, orc.P(dst), orc.step(dst), w, y1, 5, 1, orc.P(np.ascontiguousarray(Mb)), 1, 0, orc.P(bv))
     assert rc == 0
     return np.ascontiguousarray(dst[y0:y1])
+
+
+def _float_maps(seed, w=47, h=33, sw=50, sh=40):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    mapx = (xx * (sw / w) + rng.uniform(-3, 3, xx.shape)).astype(np.float32)
+    mapy = (yy * (sh / h) - 1 + rng.uniform(-3, 3, yy.shape)).astype(np.float32)
+    return mapx, mapy
+
+
+def test_convert_maps(cv, orc):
+    """cv::convertMaps both ways, device and host maps: bit-exact with the restatement (pinned to the reference in test_oracle_warp.py)"""
+    mapx, mapy = _float_maps(5)
+    mapx[3, 4] = 17.515625; mapy[3, 4] = 8.984375
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    T16SC2, T32FC1, T32FC2 = cv.CV_MAKETYPE(cv.CV_16S, 2), cv.CV_MAKETYPE(cv.CV_32F, 1), cv.CV_MAKETYPE(cv.CV_32F, 2)
+    for nn in (False, True):
+        for m1, m2 in ((mapx, mapy), (xy, None)):
+            w1, w2 = orc.orc_convertMaps(m1, m2, "16sc2", nn)
+            g1, g2 = cv.convertMaps(dev(m1), dev(m2) if m2 is not None else None, T16SC2, nn)
+            assert np.array_equal(g1.cpu().numpy(), w1) and (nn or np.array_equal(g2.cpu().numpy(), w2))
+            h1, h2 = cv.convertMaps(m1, m2, T16SC2, nn)                                      # host maps are staged
+            assert np.array_equal(h1, w1) and (nn or np.array_equal(h2, w2))
+    f1, f2 = orc.orc_convertMaps(mapx, mapy, "16sc2", False)
+    for code, name in ((T32FC1, "32fc1"), (T32FC2, "32fc2")):
+        w1, w2 = orc.orc_convertMaps(f1, f2, name)
+        g1, g2 = cv.convertMaps(dev(f1), dev(f2), code)
+        assert np.array_equal(g1.cpu().numpy(), w1) and (w2 is None or np.array_equal(g2.cpu().numpy(), w2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_remap_other_map_types(cv, orc, dtype):
+    """cv::remap with a CV_32FC2 map and with fixed-point maps (CV_16SC2 + CV_16UC1; CV_16SC2 alone for nearest)"""
+    src = rnd((40, 50, 3), dtype, 36)
+    mapx, mapy = _float_maps(4)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.orc_convertMaps(mapx, mapy, "16sc2", False)
+    n1, _ = orc.orc_convertMaps(mapx, mapy, "16sc2", True)
+    prev = rnd((33, 47, 3), dtype, 37)
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0), (5, 0)]:
+            for m1, m2 in ((xy, None), (f1, f2)):
+                want = orc.orc_remapMaps(src, m1, m2, interp, border, bval, dst=prev if border == 5 else None)
+                d0 = dev(prev.copy()) if border == 5 else None
+                check(cv.remap(dev(src), dev(m1), dev(m2) if m2 is not None else None, interp, border, bval, dst=d0), want)
+        check(cv.remap(dev(src), dev(n1), None, 0, 1, 0), orc.orc_remapMaps(src, n1, None, 0, 1, 0))
+    check(cv.remap(src, f1, f2, 1, 4, 0), orc.orc_remapMaps(src, f1, f2, 1, 4, 0))          # host arrays
+    with pytest.raises(NotImplementedError):
+        cv.remap(dev(src), dev(n1), None, 1, 0, 0)                                           # CV_16SC2 alone is a nearest-only representation
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_polar_forward(cv, orc, dtype):
+    src = rnd((60, 80, 3), dtype, 41)
+    for flags in (1, 1 | 8, 0 | 8, 1 | 256, 1 | 256 | 8):
+        for dsize, center, rad in [((64, 90), (40.0, 30.0), 35.0), ((50, 157), (10.5, 50.25), 60.0)]:
+            check(cv.warpPolar(dev(src), dsize, center, rad, flags), orc.orc_warpPolar(src, dsize, center, rad, flags))
+    with pytest.raises(NotImplementedError):
+        cv.warpPolar(dev(src), (64, 90), (40.0, 30.0), 35.0, 1 | 16)
+    big = rnd((1080, 1920), np.uint8, 42)
+    check(cv.warpPolar(dev(big), (1024, 2048), (960.0, 540.0), 600.0, 1 | 8), orc.orc_warpPolar(big, (1024, 2048), (960.0, 540.0), 600.0, 1 | 8))
