@@ -429,6 +429,17 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355
         mi355cv_uchar* sum_data, size_t sum_step, mi355cv_uchar* sqsum_data, size_t sqsum_step,
         mi355cv_uchar* tilted_data, size_t tilted_step, int width, int height, int cn);
 
+/* --------------------------------------------------- f3: features2d FAST corner detector (csrc/fast.hip) */
+/* replace hal_ni_FAST_dense / hal_ni_FAST_NMS (modules/features2d/src/hal_replacement.hpp:75, :87; caller hal_FAST fast.cpp:438-493, which is reached
+ * for threshold <= 20): dense score = largest t + 1 for which the pixel is a 9-of-16 corner at threshold t (0 in the 3-pixel frame); the suppression
+ * keeps scores strictly greater than their 8 neighbours.  `type`: cv::FastFeatureDetector::DetectorType, TYPE_9_16 (2) only. */
+MI355CV_API int mi355cv_FAST_dense(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height, int type);
+MI355CV_API int mi355cv_FAST_NMS(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height);
+/* cv::FAST (fast.cpp:496) as one call, any threshold: keypoints as (x, y, response) float triples in the reference's (raster) order, at most
+ * `capacity` written.  Returns the number found (>= 0; call again with a larger array if it exceeds capacity), -1 unsupported, -2 device failure. */
+MI355CV_API int mi355cv_FAST(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int threshold, int nonmax_suppression, int type,
+        float* keypoints_xyr, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

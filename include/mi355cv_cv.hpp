@@ -236,6 +236,29 @@ inline void warpPolar(cv::InputArray _src, cv::OutputArray _dst, cv::Size dsize,
     cv::warpPolar(_src, _dst, dsize, center, maxRadius, flags);
 }
 
+#ifdef OPENCV_FEATURES_2D_HPP   // cv::FAST lives in opencv2/features2d.hpp; include it before this header to get the wrapper
+// cv::FAST (features2d.hpp; fast.cpp:496).  TYPE_9_16 runs as one call on the GPU at any threshold (cv::FAST's own HAL route, hal_FAST, only covers
+// thresholds <= 20 and moves the score image over PCIe twice); everything else goes to the stock function.
+inline void FAST(cv::InputArray _image, std::vector<cv::KeyPoint>& keypoints, int threshold, bool nonmaxSuppression = true,
+                 cv::FastFeatureDetector::DetectorType type = cv::FastFeatureDetector::TYPE_9_16)
+{
+    cv::Mat image = _image.getMat();
+    if (image.dims <= 2 && image.type() == CV_8UC1 && type == cv::FastFeatureDetector::TYPE_9_16 && !image.empty()) {
+        std::vector<float> xyr(3 * 16384);
+        for (;;) {
+            const int cap = (int)(xyr.size() / 3);
+            const int n = mi355cv_FAST(image.data, image.step, image.cols, image.rows, threshold, nonmaxSuppression ? 1 : 0, (int)type, xyr.data(), cap);
+            if (n < 0) break;
+            if (n > cap) { xyr.resize(3 * (size_t)n); continue; }
+            keypoints.resize((size_t)n);
+            for (int i = 0; i < n; i++) keypoints[(size_t)i] = cv::KeyPoint(xyr[3 * (size_t)i], xyr[3 * (size_t)i + 1], 7.f, -1, xyr[3 * (size_t)i + 2]);
+            return;
+        }
+    }
+    cv::FAST(_image, keypoints, threshold, nonmaxSuppression, type);
+}
+#endif
+
 #ifdef OPENCV_TRACKING_HPP      // cv::calcOpticalFlowPyrLK lives in opencv2/video/tracking.hpp; include it before this header to get the wrapper
 // cv::calcOpticalFlowPyrLK (video/tracking.hpp; lkpyramid.cpp:1432).  Two images (not precomputed pyramids) go through the one-call
 // entry point -- frames cross PCIe once, pyramids, derivatives and all levels run on the device, results bit-identical to cv:: --

@@ -159,4 +159,11 @@
 #undef  cv_hal_canny
 #define cv_hal_canny mi355cv_canny
 
+// modules/features2d/src/hal_replacement.hpp:75, :87 (the same generated custom_hal.hpp is included by every module): FAST 9-of-16 as a dense
+// score image + its 3x3 suppression, consumed by the reference's hal_FAST (fast.cpp:438-493)
+#undef  cv_hal_FAST_dense
+#define cv_hal_FAST_dense mi355cv_FAST_dense
+#undef  cv_hal_FAST_NMS
+#define cv_hal_FAST_NMS mi355cv_FAST_NMS
+
 #endif

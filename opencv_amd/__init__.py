@@ -15,5 +15,6 @@ from ._lib import call_count, Mi355cvError  # noqa: F401
 from .core import *  # noqa: F401,F403
 from .imgproc import *  # noqa: F401,F403
 from .video import *  # noqa: F401,F403
+from .features2d import *  # noqa: F401,F403
 
 __version__ = "0.1"

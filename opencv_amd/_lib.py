@@ -36,6 +36,9 @@ def _load():
         "mi355cv_version": (ctypes.c_char_p, []),
         "mi355cv_lastError": (ctypes.c_char_p, []),
         "mi355cv_lastKernel": (ctypes.c_char_p, []),
+        "mi355cv_FAST_dense": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
+        "mi355cv_FAST_NMS": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
+        "mi355cv_FAST": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_int]),
         "mi355cv_remap": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int,
                                   c_int, c_int, ctypes.c_void_p]),
         "mi355cv_convertMaps": (c_int, [ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz,

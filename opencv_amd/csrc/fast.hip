@@ -1,0 +1,204 @@
+// fast.hip -- SURVEY §8 f3, "features2d detectors": the FAST corner detector (modules/features2d/src/fast.cpp) behind the features2d HAL
+//   cv_hal_FAST_dense (features2d/src/hal_replacement.hpp:75)   dense score image of the 9-of-16 detector
+//   cv_hal_FAST_NMS   (:87)                                     3x3 non-maximum suppression of a score image
+// which the reference's own hal_FAST (fast.cpp:438-493) turns into the keypoint list, plus the whole detector as one call on a device-resident
+// frame (mi355cv_FAST: scores, suppression and the raster-ordered keypoint list never leave the GPU until the list itself is fetched) -- the
+// consumer the §8 pipeline is missing after Harris / gftt / pyramids / LK.
+//
+// Dense score of a pixel = the largest t + 1 for which it is a corner at threshold t: over the 16 arcs of 9 contiguous ring pixels the best of
+// min(v - ring) (centre brighter) and -max(v - ring) (centre darker), clamped at 0.  cornerScore<16> (fast_score.cpp:108) is that minus one, and
+// "corner at threshold t" of FAST_t<16> (fast.cpp:58) is "dense score > t".  TYPE_5_8 / TYPE_7_12 are declined: the reference's code for them is
+// not the textbook detector (16-ring indexing in the quick-reject test, an out-of-period read in the vector cornerScore<12>, fast_score.cpp:218-221).
+#include "rt.h"
+#include <vector>
+
+namespace mi355 {
+size_t sortKeysDescTemp(unsigned n);                                                                             // gftt_sort.hip (rocPRIM)
+bool sortKeysDesc(void* temp, size_t bytes, const unsigned long long* in, unsigned long long* out, unsigned n, hipStream_t st);
+}
+
+using namespace mi355;
+
+namespace {
+
+typedef unsigned u32u __attribute__((aligned(1)));
+
+// ring of the 9-of-16 detector, makeOffsets (fast_score.cpp:52-56): (dx, dy), clockwise from (0, 3)
+__device__ constexpr int RX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__device__ constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// A thread owns 4 horizontally adjacent pixels x0..x0+3 (x0 a multiple of 4): the 7 rows y-3..y+3 of columns x0-4..x0+7 are three dwords per
+// row, every ring pixel of the four centres is a byte of those registers at a compile-time position, and the four scores leave as one dword.
+__global__ __launch_bounds__(256) void k_fast_dense16(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
+{
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= w || y >= h) return;
+    unsigned out = 0;
+    if (y >= 3 && y < h - 3) {
+        unsigned r[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uchar* row = src + (size_t)(y - 3 + j) * sstep;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int c = x0 - 4 + 4 * q;
+                unsigned v = 0;
+                if (c >= 0 && c + 4 <= w) v = *reinterpret_cast<const u32u*>(row + c);
+                else if (c >= 0) { for (int b = 0; b < 4; b++) if (c + b < w) v |= (unsigned)row[c + b] << (8 * b); }
+                r[j][q] = v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int x = x0 + p;
+            if (x < 3 || x >= w - 3) continue;
+            auto px = [&](int dx, int dy) -> int { const int col = 4 + p + dx; return (int)((r[3 + dy][col >> 2] >> (8 * (col & 3))) & 255u); };
+            const int v = px(0, 0);
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = v - px(RX[k], RY[k]);
+            // sliding minimum / maximum over 9 contiguous ring positions by doubling: 2, 4, 8, then the ninth
+            int mn[16], mx[16], t0[16], t1[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { t0[k] = min(mn[k], mn[(k + 2) & 15]); t1[k] = max(mx[k], mx[(k + 2) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { mn[k] = min(t0[k], t0[(k + 4) & 15]); mx[k] = max(t1[k], t1[(k + 4) & 15]); }
+            int best = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { best = max(best, min(mn[k], d[(k + 8) & 15])); best = max(best, -max(mx[k], d[(k + 8) & 15])); }
+            out |= (unsigned)min(best, 255) << (8 * p);
+        }
+    }
+    uchar* o = dst + (size_t)y * dstep + x0;
+    if (x0 + 4 <= w) *reinterpret_cast<u32u*>(o) = out;
+    else for (int b = 0; x0 + b < w; b++) o[b] = (uchar)(out >> (8 * b));
+}
+
+// keeps a score strictly greater than its 8 neighbours (0 outside the image), zeroes the rest; 4 pixels per thread
+__global__ __launch_bounds__(256) void k_fast_nms(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
+{
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= w || y >= h) return;
+    int a[3][6];                                                     // rows y-1..y+1, columns x0-1..x0+4
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int yy = y - 1 + j;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int xx = x0 - 1 + i;
+            a[j][i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (int)src[(size_t)yy * sstep + xx] : 0;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (x0 + p >= w) break;
+        const int s = a[1][1 + p];
+        const int n = max(max(max(a[0][p], a[0][p + 1]), max(a[0][p + 2], a[1][p])), max(max(a[1][p + 2], a[2][p]), max(a[2][p + 1], a[2][p + 2])));
+        dst[(size_t)y * dstep + x0 + p] = (uchar)(s > n ? s : 0);
+    }
+}
+
+// candidates of the final score image (interior pixels with score > thr): counted, then written as keys ~index : score so that a descending
+// sort puts them in raster order
+__global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ sc, size_t step, int w, int h, int thr, unsigned* __restrict__ counter,
+                                                      unsigned long long* __restrict__ keys, unsigned cap)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < 3 || y < 3 || x + 3 >= w || y + 3 >= h) return;
+    const int s = sc[(size_t)y * step + x];
+    if (s <= thr) return;
+    const unsigned i = atomicAdd(counter, 1u);
+    if (keys && i < cap) keys[i] = ((unsigned long long)(0xffffffffu - (unsigned)(y * w + x)) << 32) | (unsigned)s;
+}
+
+int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int w, int h, int type)
+{
+    if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) && (size_t)w * h < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t ss, ds;
+    const uchar* s = stg.in(src, sstep, (size_t)w, h, &ss);
+    uchar* d = stg.out(dst, dstep, (size_t)w, h, &ds);
+    if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
+    hipLaunchKernelGGL(k_fast_dense16, dim3(divUp(w, 256), divUp(h, 4)), dim3(256), 0, stream(), s, ss, d, ds, w, h);
+    return stg.finish(entry);
+}
+
+} // namespace
+
+extern "C" {
+
+// replaces hal_ni_FAST_dense (modules/features2d/src/hal_replacement.hpp:75; caller hal_FAST fast.cpp:445): TYPE_9_16 only
+MI355CV_API int mi355cv_FAST_dense(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int type)
+{
+    return runDense("FAST_dense", src_data, src_step, dst_data, dst_step, width, height, type);
+}
+
+// replaces hal_ni_FAST_NMS (:87; caller fast.cpp:454)
+MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
+{
+    if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg; size_t ss, ds;
+    const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
+    uchar* d = stg.out(dst_data, dst_step, (size_t)width, height, &ds);
+    if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
+    hipLaunchKernelGGL(k_fast_nms, dim3(divUp(width, 256), divUp(height, 4)), dim3(256), 0, stream(), s, ss, d, ds, width, height);
+    return stg.finish("FAST_NMS");
+}
+
+// cv::FAST (fast.cpp:496) in one call: keypoints as (x, y, response) float triples in the reference's order (raster), at most `capacity` of them
+// written.  Returns the number of keypoints found (may exceed capacity: call again with a larger array), -1 when the arguments are not
+// supported (nothing computed), -2 on a device failure.
+MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, int height, int threshold, int nonmax_suppression, int type,
+                             float* keypoints_xyr, int capacity)
+{
+    if (disabled() || type != 2 || width <= 0 || height <= 0 || !src_data || capacity < 0 || (capacity > 0 && !keypoints_xyr)) return -1;
+    if ((long long)width * height > 0x7fffffffLL) return -1;
+    if (!ensureDevice()) return -1;
+    Stager stg; size_t ss;
+    const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
+    const size_t pitch = ((size_t)width + 63) & ~(size_t)63;
+    uchar* sc = (uchar*)stg.scratch(pitch * height);
+    uchar* sup = nonmax_suppression ? (uchar*)stg.scratch(pitch * height) : nullptr;
+    unsigned* counter = (unsigned*)stg.scratch(16);
+    if (!s || !sc || (nonmax_suppression && !sup) || !counter) return -1;
+    hipStream_t st = stream();
+    const dim3 g4(divUp(width, 256), divUp(height, 4)), g1(divUp(width, 64), divUp(height, 4));
+    hipLaunchKernelGGL(k_fast_dense16, g4, dim3(256), 0, st, s, ss, sc, pitch, width, height);
+    const uchar* fin = sc;
+    if (nonmax_suppression) { hipLaunchKernelGGL(k_fast_nms, g4, dim3(256), 0, st, sc, pitch, sup, pitch, width, height); fin = sup; }
+    int thr = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;                          // fast.cpp:81
+    if (!thr && nonmax_suppression) thr = 1;                                                 // fast.cpp:467: with suppression a cornerScore of 0 never wins FAST_t's strict comparisons
+    unsigned n = 0;
+    if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u);
+    if (hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    if (n == 0 || capacity == 0) { const int rc = stg.finish("FAST"); return rc == MI355CV_OK ? (int)n : -2; }
+    unsigned long long* keys = (unsigned long long*)stg.scratch((size_t)n * 8);
+    unsigned long long* sorted = (unsigned long long*)stg.scratch((size_t)n * 8);
+    const size_t tb = sortKeysDescTemp(n);
+    void* temp = stg.scratch(tb ? tb : 16);
+    if (!keys || !sorted || !tb || !temp) return -2;
+    if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n);
+    if (!sortKeysDesc(temp, tb, keys, sorted, n, st)) return -2;
+    const unsigned take = n < (unsigned)capacity ? n : (unsigned)capacity;
+    std::vector<unsigned long long> host(take);
+    if (hipMemcpyAsync(host.data(), sorted, (size_t)take * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    for (unsigned i = 0; i < take; i++) {
+        const unsigned idx = 0xffffffffu - (unsigned)(host[i] >> 32), sv = (unsigned)(host[i] & 0xffffffffu);
+        keypoints_xyr[3 * i] = (float)(idx % (unsigned)width);
+        keypoints_xyr[3 * i + 1] = (float)(idx / (unsigned)width);
+        keypoints_xyr[3 * i + 2] = nonmax_suppression ? (float)((int)sv - 1) : 0.f;
+    }
+    const int rc = stg.finish("FAST");
+    return rc == MI355CV_OK ? (int)n : -2;
+}
+
+} // extern "C"

@@ -169,9 +169,15 @@ __global__ __launch_bounds__(256) void k_integral_carries(const unsigned* __rest
     unsigned* ro = (which ? rowcarQ : rowcar) + fo;
     // out of place: with the results in their own arrays no load has to wait behind a store that might alias it, so a thread's loads pipeline
     if (t < W) {
+        // 32 loads in flight per thread: the scan is a handful of memory round trips, not nTy of them
         unsigned run = 0;
-#pragma unroll 8
-        for (int ty = 0; ty < nTy; ty++) { const unsigned v = cs[(size_t)ty * Wp + t]; co[(size_t)ty * Wp + t] = run; run += v; }
+        for (int ty0 = 0; ty0 < nTy; ty0 += 32) {
+            unsigned v[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) v[u] = ty0 + u < nTy ? cs[(size_t)(ty0 + u) * Wp + t] : 0u;
+#pragma unroll
+            for (int u = 0; u < 32; u++) if (ty0 + u < nTy) { co[(size_t)(ty0 + u) * Wp + t] = run; run += v[u]; }
+        }
     } else if (t - W < H) {
         const int y = t - W;
         unsigned run = 0;

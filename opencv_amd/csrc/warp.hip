@@ -999,90 +999,6 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
     }
 }
 
-// warpAffine, bilinear, single channel CV_32F, source staged per WAVE through LDS.  A wave owns 64 destination columns x LROWS rows.  Its
-// source footprint is a thin parallelogram whose bounding box follows from wave-uniform numbers alone (the coordinate X = X0(y) + ad(x) is
-// monotone in both terms, so the box corners are the strip's corners).  The box is copied into the wave's private LDS slab with full-width
-// 16-byte loads (every cache line it touches is read once, in whole sectors), then the four taps of every output come from LDS -- where a
-// 64-lane gather costs 2-4 cycles instead of the ~20 the vector L1 needs to return ten different lines.  No block barrier: a wave reads only
-// what it wrote itself.  Waves whose box leaves the image or does not fit the slab (strong minification) take the direct-gather code.
-// Same arithmetic as k_warp_lin / samplePixel, so the result is bit-identical.
-constexpr int LROWS = 16, LBH = 28, LBQ = 20, LPITCH = LBQ * 4 + 4;          // slab: LBH rows x 80 floats (pitch 84 floats: rows start 16 B apart in bank space)
-__global__ __launch_bounds__(256) void k_warp_affine_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-                                                         SampleArgs s, WarpArgs w, const short* __restrict__ tab)
-{
-    __shared__ __attribute__((aligned(16))) float slab[4][LBH * LPITCH];
-    int tx, ty;
-    tileOf(w, tx, ty);
-    if (tx < 0) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = tx * 64 + lane;
-    const int yb = (ty * 4 + wv) * LROWS;
-    if (yb >= w.dh) return;
-    const int ye = min(yb + LROWS, w.dh);
-    const int xc = min(x, w.dw - 1);
-    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xc), 1024.0));
-    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xc), 1024.0));
-    // bounding box of the strip in the source: extremes of the row terms (wave-uniform) + extremes of the column terms (first / last lane)
-    const int xl = min(tx * 64 + 63, w.dw - 1);
-    const int adA = __builtin_amdgcn_readfirstlane(ad), bdA = __builtin_amdgcn_readfirstlane(bd);
-    const int adB = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xl), 1024.0)), bdB = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xl), 1024.0));
-    int X0lo = 0x7fffffff, X0hi = -0x7fffffff - 1, Y0lo = 0x7fffffff, Y0hi = -0x7fffffff - 1;
-    for (int y = yb; y < ye; y += (ye - 1 - yb > 0 ? ye - 1 - yb : 1)) {                  // the row terms are monotone in y: first and last row suffice
-        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
-        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
-        X0lo = min(X0lo, X0); X0hi = max(X0hi, X0); Y0lo = min(Y0lo, Y0); Y0hi = max(Y0hi, Y0);
-    }
-    const long long Xlo = (long long)X0lo + min(adA, adB), Xhi = (long long)X0hi + max(adA, adB);
-    const long long Ylo = (long long)Y0lo + min(bdA, bdB), Yhi = (long long)Y0hi + max(bdA, bdB);
-    bool staged = Xlo > -0x7fffffffLL && Xhi < 0x7fffffffLL && Ylo > -0x7fffffffLL && Yhi < 0x7fffffffLL;
-    const int sxlo = (int)(Xlo >> 10), sxhi = (int)(Xhi >> 10) + 1, sylo = (int)(Ylo >> 10), syhi = (int)(Yhi >> 10) + 1;   // taps at sx, sx+1 / sy, sy+1
-    const int c0 = sxlo & ~3;
-    staged = staged && sxlo >= 0 && sylo >= 0 && sxhi < s.sw && syhi < s.sh && sxhi - c0 < 4 * LBQ && syhi - sylo < LBH && c0 + 4 * LBQ <= s.sw;
-    float* L = slab[wv];
-    if (staged) {
-        const int n = (syhi - sylo + 1) * LBQ;
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-        constexpr int NI = (LBH * LBQ + 63) / 64;                  // every load of the slab is in flight before the first LDS write waits for one
-        f4u v[NI];
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int i = lane + 64 * k, r = i / LBQ, q = i - r * LBQ;
-            if (i < n) v[k] = *reinterpret_cast<const f4u*>(src + (size_t)(sylo + r) * sstep + (size_t)(c0 + 4 * q) * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int i = lane + 64 * k, r = i / LBQ, q = i - r * LBQ;
-            if (i < n) *reinterpret_cast<f4u*>(L + r * LPITCH + 4 * q) = v[k];
-        }
-    }
-    if (x >= w.dw) return;
-    for (int y = yb; y < ye; y++) {
-        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
-        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
-        const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
-        const int sx = satShort(X >> 5), sy = satShort(Y >> 5), ax = X & 31, ay = Y & 31;
-        uchar* D = dst + (size_t)y * dstep + (size_t)x * 4;
-        const float s32 = 1.f / 32;
-        const float fx = ax * s32, fy = ay * s32;
-        const float wy0 = 1.f - fy, wx0 = 1.f - fx;
-        const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
-        float p00, p01, p10, p11;
-        if (staged) {
-            const float* r0 = L + (sy - sylo) * LPITCH + (sx - c0);
-            p00 = r0[0]; p01 = r0[1]; p10 = r0[LPITCH]; p11 = r0[LPITCH + 1];
-        } else if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
-            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * 4;
-            const f2u v0 = *reinterpret_cast<const f2u*>(r0), v1 = *reinterpret_cast<const f2u*>(r0 + sstep);
-            p00 = v0.x; p01 = v0.y; p10 = v1.x; p11 = v1.y;
-        } else { samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab); continue; }
-        float t = __fadd_rn(__fmul_rn(p00, w0), __fmul_rn(p01, w1));
-        t = __fadd_rn(t, __fmul_rn(p10, w2));
-        t = __fadd_rn(t, __fmul_rn(p11, w3));
-        *reinterpret_cast<float*>(D) = t;
-    }
-}
-
 bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
@@ -1139,17 +1055,10 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
     if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && (dss % e) == 0 &&
         ((uintptr_t)ds % e) == 0) {
-        // experiment knob (tools/tune_r02.py): bit 0 XCD-banded tile order, bit 1 wave-staged LDS (32FC1 affine)
-        static const int variantDefault = 0;
-        const char* ve = getenv("MI355CV_WARP_VARIANT");
-        const int variant = ve ? atoi(ve) : variantDefault;
-        w.band = variant & 1;
-        if ((variant & 2) && kind == 0 && cn == 1 && depth == D32F && (dss & 3) == 0) {
-            dim3 g3(divUp(dw, 64), divUp(dh, 4 * LROWS));
-            w.gx = g3.x; w.gy = g3.y;
-            hipLaunchKernelGGL(k_warp_affine_lds, g3, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev);
-            return stg.finish(entry);
-        }
+        // XCD-banded tile order: on for CV_32F (8K 32F rotate: 73.5 vs 75.7 us), off for 8-bit sources, whose whole working set sits in one
+        // L2's reach anyway (4K 8UC3: 46.2 vs 43.8 us).  MI355CV_WARP_BAND=0/1 overrides (tools/tune_r02.py).
+        const char* ve = getenv("MI355CV_WARP_BAND");
+        w.band = ve ? atoi(ve) : (depth == D32F ? 1 : 0);
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS));
         w.gx = g2.x; w.gy = g2.y;
 #define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev)

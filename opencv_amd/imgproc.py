@@ -741,7 +741,7 @@ def blur(src, ksize, anchor=(-1, -1), borderType=BORDER_DEFAULT, dst=None):
 
 
 # ----------------------------------------------------------------------------- geometric transforms (a7, a8, a9)
-from .core import INTER_NEAREST, INTER_LINEAR, INTER_AREA, WARP_INVERSE_MAP  # noqa: E402
+from .core import INTER_NEAREST, INTER_LINEAR, INTER_AREA, WARP_INVERSE_MAP, CV_MAKETYPE  # noqa: E402
 
 INTER_MAX = 7
 

@@ -157,4 +157,9 @@ int orc_Canny(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int 
 #ifdef __cplusplus
 }
 #endif
+/* features2d FAST (fast.c) */
+int orc_FAST_dense(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int type);
+void orc_FAST_nms(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
+int orc_FAST(const uint8_t* src, size_t sstep, int w, int h, int threshold, int nonmax, int type, float* out, int cap);
+
 #endif

@@ -2,6 +2,7 @@
 // functions without a HAL hook) against the reference's own headers and exposes them to the tests through a C facade, so that
 // the header is compiled and exercised, not just shipped.
 #include "opencv2/video/tracking.hpp"
+#include "opencv2/features2d.hpp"
 #include "mi355cv_cv.hpp"
 #include <cstdio>
 #include <cstring>
@@ -113,6 +114,18 @@ EXPORT int wrap_warpPolar(const void* s, size_t ss, int sw, int sh, int type, vo
     try { Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type); const uchar* p = dst.data;
           mi355cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
           return dst.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
+// mi355cv::FAST with a std::vector<KeyPoint>, as applications call it: (x, y, response) triples out, returns the count
+EXPORT int wrap_FAST(const void* s, size_t ss, int w, int h, int threshold, int nonmax, int type, float* out, int cap)
+{
+    try { Mat src = M(s, ss, w, h, CV_8UC1); std::vector<KeyPoint> kp;
+          mi355cv::FAST(src, kp, threshold, nonmax != 0, (cv::FastFeatureDetector::DetectorType)type);
+          for (size_t i = 0; i < kp.size() && (int)i < cap; i++) {
+              if (kp[i].size != 7.f || kp[i].angle != -1.f || kp[i].octave != 0 || kp[i].class_id != -1) return -3;
+              out[3 * i] = kp[i].pt.x; out[3 * i + 1] = kp[i].pt.y; out[3 * i + 2] = kp[i].response; }
+          return (int)kp.size(); }
     catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
 

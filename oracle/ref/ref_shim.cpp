@@ -13,6 +13,7 @@
 #include <opencv2/imgproc.hpp>
 #include <opencv2/imgproc/hal/hal.hpp>
 #include <opencv2/video/tracking.hpp>
+#include <opencv2/features2d.hpp>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -325,6 +326,18 @@ int ref_warpPolar(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, 
     Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
     cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
     REF_END(dst, d)
+}
+
+// cv::FAST (modules/features2d): keypoints as (x, y, response) triples in the order the detector emits them; returns the count
+int ref_FAST(const void* s, size_t ss, int w, int h, int threshold, int nonmax, int type, float* out, int cap)
+{
+    try {
+        Mat src = M(s, ss, w, h, CV_8UC1);
+        std::vector<KeyPoint> kp;
+        cv::FAST(src, kp, threshold, nonmax != 0, (cv::FastFeatureDetector::DetectorType)type);
+        for (size_t i = 0; i < kp.size() && (int)i < cap; i++) { out[3 * i] = kp[i].pt.x; out[3 * i + 1] = kp[i].pt.y; out[3 * i + 2] = kp[i].response; }
+        return (int)kp.size();
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
 }
 
 int ref_getRotationMatrix2D(double cx, double cy, double angle, double scale, double* M6)

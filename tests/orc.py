@@ -1053,3 +1053,39 @@ def orc_cvtHSVtoBGR(src, code, dcn=3, lanes=8):
     dst = np.empty((h, w, dcn), np.uint8)
     o.orc_cvtHSVtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, full, lanes)
     return dst
+
+
+# ---------------------------------------------------------------------------------- features2d FAST
+def orc_FAST(src, threshold, nonmax=True, ftype=2, cap=200000):
+    """keypoints of cv::FAST as an (n, 3) array of (x, y, response) in raster order"""
+    o = oracle()
+    h, w = src.shape
+    out = np.zeros((cap, 3), np.float32)
+    n = o.orc_FAST(P(src), step(src), w, h, threshold, 1 if nonmax else 0, ftype, P(out), cap)
+    assert 0 <= n <= cap, n
+    return out[:n].copy()
+
+
+def ref_FAST(src, threshold, nonmax=True, ftype=2, cap=200000):
+    r = load_ref()
+    h, w = src.shape
+    out = np.zeros((cap, 3), np.float32)
+    n = r.ref_FAST(P(src), step(src), w, h, threshold, 1 if nonmax else 0, ftype, P(out), cap)
+    assert 0 <= n <= cap, n
+    return out[:n].copy()
+
+
+def orc_FAST_dense(src, ftype=2):
+    o = oracle()
+    h, w = src.shape
+    dst = np.empty_like(src)
+    assert o.orc_FAST_dense(P(src), step(src), P(dst), step(dst), w, h, ftype) == 0
+    return dst
+
+
+def orc_FAST_nms(scores):
+    o = oracle()
+    h, w = scores.shape
+    dst = np.empty_like(scores)
+    o.orc_FAST_nms(P(scores), step(scores), P(dst), step(dst), w, h)
+    return dst

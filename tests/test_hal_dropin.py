@@ -326,6 +326,44 @@ def test_cv_signature_warp_family_gpu(ref):
         assert cv.call_count(k) > n[k], k
 
 
+def _fast_tour(hal, through_hal_too):
+    src = O.ref_GaussianBlur(O.ref_rng_fill((200, 260), np.uint8, 21, 0, 256), 3, 0, 0, 4)
+    for thr, nonmax in ((10, True), (20, False), (35, True)):
+        want = O.ref_FAST(src, thr, nonmax, 2)
+        out = np.zeros((len(want) + 100, 3), np.float32)
+        n = hal.wrap_FAST(O.P(src), O.step(src), 260, 200, thr, 1 if nonmax else 0, 2, O.P(out), len(out))       # mi355cv::FAST (cv:: signature)
+        assert n == len(want) and np.array_equal(out[:n], want), (thr, nonmax, n, len(want))
+        if through_hal_too:                                                                                     # cv::FAST of the HAL-enabled build
+            with O.use_ref(hal):
+                assert np.array_equal(O.ref_FAST(src, thr, nonmax, 2), want), (thr, nonmax)
+    # a type the hooks decline: the stock path must answer
+    w5 = O.ref_FAST(src, 10, True, 0)
+    with O.use_ref(hal):
+        assert np.array_equal(O.ref_FAST(src, 10, True, 0), w5)
+
+
+def test_cv_signature_fast_wrapper(ref):
+    """mi355cv::FAST and cv::FAST of the HAL-enabled build give the stock keypoint lists (here through the fallbacks)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see the _gpu variant")
+    hal = O.load_ref_hal()
+    if hal is None:
+        pytest.skip("oracle/_ref/libocvref_hal.so not built")
+    _fast_tour(hal, True)
+
+
+@pytest.mark.gpu
+def test_cv_signature_fast_wrapper_gpu(ref):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None
+    n = {k: cv.call_count(k) for k in ("FAST", "FAST_dense", "FAST_NMS")}
+    _fast_tour(hal, True)
+    for k in n:
+        assert cv.call_count(k) > n[k], f"{k} was not served by the GPU"
+
+
 def _wrap_lk(hal, A, B, p, win, maxLevel, flags=0, guess=None):
     import ctypes
     n = len(p)

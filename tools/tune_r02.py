@@ -76,8 +76,8 @@ if "warp" in what:
     M = cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95)
     d3 = torch.empty_like(src)
     base = None
-    for var in os.environ.get("WARP_VARIANTS", "0,1,2,3").split(","):
-        os.environ["MI355CV_WARP_VARIANT"] = var
+    for var in os.environ.get("WARP_VARIANTS", "0,1").split(","):
+        os.environ["MI355CV_WARP_BAND"] = var
         cv.warpAffine(src, M, (7680, 4320), dst=d3)
         torch.cuda.synchronize()
         if base is None:
@@ -87,8 +87,8 @@ if "warp" in what:
     d8 = torch.empty_like(src8)
     Mw = cv.getRotationMatrix2D((1920.0, 1080.0), 7.0, 0.95)
     base = None
-    for var in os.environ.get("WARP_VARIANTS", "0,1,2,3").split(","):
-        os.environ["MI355CV_WARP_VARIANT"] = var
+    for var in os.environ.get("WARP_VARIANTS", "0,1").split(","):
+        os.environ["MI355CV_WARP_BAND"] = var
         cv.warpAffine(src8, Mw, (3840, 2160), dst=d8)
         torch.cuda.synchronize()
         if base is None:
@@ -97,8 +97,8 @@ if "warp" in what:
     g8 = torch.randint(0, 256, (2160, 3840), dtype=torch.uint8, device="cuda", generator=g)
     d1 = torch.empty_like(g8)
     base = None
-    for var in os.environ.get("WARP_VARIANTS", "0,1,2,3").split(","):
-        os.environ["MI355CV_WARP_VARIANT"] = var
+    for var in os.environ.get("WARP_VARIANTS", "0,1").split(","):
+        os.environ["MI355CV_WARP_BAND"] = var
         cv.warpAffine(g8, Mw, (3840, 2160), dst=d1)
         torch.cuda.synchronize()
         if base is None:
