@@ -162,27 +162,45 @@ __global__ __launch_bounds__(256) void k_integral_carries(const unsigned* __rest
         }
         return;
     }
-    const int t = blockIdx.x * 256 + threadIdx.x;
     const unsigned* cs = (which ? colsq : colsum) + fo;
     const unsigned* rs = (which ? rowsq : rowsum) + fo;
     unsigned* co = (which ? colcarQ : colcar) + fo;
     unsigned* ro = (which ? rowcarQ : rowcar) + fo;
-    // out of place: with the results in their own arrays no load has to wait behind a store that might alias it, so a thread's loads pipeline
-    if (t < W) {
-        // 32 loads in flight per thread: the scan is a handful of memory round trips, not nTy of them
-        unsigned run = 0;
-        for (int ty0 = 0; ty0 < nTy; ty0 += 32) {
-            unsigned v[32];
+    const int colBlocks = (W + 31) / 32;
+    if ((int)blockIdx.x < colBlocks) {
+        // column carries: a workgroup takes 32 columns x 8 chunks of tile rows.  Every thread loads its chunk at once (one memory round trip for
+        // the whole scan instead of nTy dependent ones in a handful of waves), the chunk sums are exchanged through LDS, and the exclusive
+        // prefixes are written from the registers.
+        __shared__ unsigned part[8][33];
+        const int c = threadIdx.x & 31, ck = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
+        const int per = (nTy + 7) / 8, t0 = ck * per, t1 = min(nTy, t0 + per);
+        unsigned v[32];
+        unsigned sum = 0;
+        if (per <= 32) {
 #pragma unroll
-            for (int u = 0; u < 32; u++) v[u] = ty0 + u < nTy ? cs[(size_t)(ty0 + u) * Wp + t] : 0u;
-#pragma unroll
-            for (int u = 0; u < 32; u++) if (ty0 + u < nTy) { co[(size_t)(ty0 + u) * Wp + t] = run; run += v[u]; }
+            for (int u = 0; u < 32; u++) { v[u] = (col < W && t0 + u < t1) ? cs[(size_t)(t0 + u) * Wp + col] : 0u; sum += v[u]; }
+        } else {
+            for (int t = t0; t < t1; t++) if (col < W) sum += cs[(size_t)t * Wp + col];
         }
-    } else if (t - W < H) {
-        const int y = t - W;
+        part[ck][c] = sum;
+        __syncthreads();
         unsigned run = 0;
-#pragma unroll 4
-        for (int tx = 0; tx < nTx; tx++) { const unsigned v = rs[(size_t)tx * H + y]; ro[(size_t)tx * H + y] = run; run += v; }
+        for (int k = 0; k < ck; k++) run += part[k][c];
+        if (col < W) {
+            if (per <= 32) {
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (t0 + u < t1) { co[(size_t)(t0 + u) * Wp + col] = run; run += v[u]; }
+            } else {
+                for (int t = t0; t < t1; t++) { const unsigned x = cs[(size_t)t * Wp + col]; co[(size_t)t * Wp + col] = run; run += x; }
+            }
+        }
+        return;
+    }
+    const int y = ((int)blockIdx.x - colBlocks) * 256 + threadIdx.x;
+    if (y < H) {
+        unsigned run = 0;
+#pragma unroll 8
+        for (int tx = 0; tx < nTx; tx++) { const unsigned x = rs[(size_t)tx * H + y]; ro[(size_t)tx * H + y] = run; run += x; }
     }
 }
 
@@ -343,7 +361,7 @@ bool integralTiledU8(const uchar* src, size_t sstep, size_t sframe, int W, int H
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     if (sq) hipLaunchKernelGGL((k_integral_tilesums<true>), grid, blk, 0, st, src, sstep, sframe, W, H, nTx, nTy, nframes, S.colsum, Q.colsum, S.rowsum, Q.rowsum, S.tileTot, Q.tileTot, Wp, perFrame);
     else    hipLaunchKernelGGL((k_integral_tilesums<false>), grid, blk, 0, st, src, sstep, sframe, W, H, nTx, nTy, nframes, S.colsum, Q.colsum, S.rowsum, Q.rowsum, S.tileTot, Q.tileTot, Wp, perFrame);
-    hipLaunchKernelGGL(k_integral_carries, dim3(divUp(W + H, 256) + 1, sq ? 2 : 1, nframes), blk, ((size_t)nTx * nTy + 16 * (size_t)nTx) * 8, st,
+    hipLaunchKernelGGL(k_integral_carries, dim3(divUp(W, 32) + divUp(H, 256) + 1, sq ? 2 : 1, nframes), blk, ((size_t)nTx * nTy + 16 * (size_t)nTx) * 8, st,
                        S.colsum, Q.colsum, S.rowsum, Q.rowsum, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.tileTot, Q.tileTot, S.corner, Q.corner,
                        W, H, Wp, nTx, nTy, perFrame, sq ? 1 : 0);
 #define ITILES(TS_, SQ_) hipLaunchKernelGGL((k_integral_tiles<TS_, SQ_>), grid, blk, 0, st, src, sstep, sframe, W, H, nTx, nTy, nframes, (TS_*)sum, sumStepElems, sumFrameElems, \

@@ -883,11 +883,12 @@ def convertMaps(map1, map2, dstmap1type, nninterpolation=False):
     T16SC2, T16UC1, T32FC1, T32FC2 = CV_MAKETYPE(CV_16S, 2), CV_MAKETYPE(CV_16U, 1), CV_MAKETYPE(CV_32F, 1), CV_MAKETYPE(CV_32F, 2)
     if dstmap1type <= 0:
         dstmap1type = T32FC2 if m1.type == T16SC2 else T16SC2
+    plane = map1[..., 0] if m1.cn > 1 else map1                  # a 2-D array of map1's kind: single-channel outputs are H x W, not H x W x 1
     if dstmap1type == T16SC2:
         o1 = empty_like_kind(map1, m1.h, m1.w, 2, CV_16S)
-        o2 = None if nninterpolation else empty_like_kind(map1, m1.h, m1.w, 1, CV_16U)
+        o2 = None if nninterpolation else empty_like_kind(plane, m1.h, m1.w, 1, CV_16U)
     elif dstmap1type == T32FC1:
-        o1, o2 = empty_like_kind(map1, m1.h, m1.w, 1, CV_32F), empty_like_kind(map1, m1.h, m1.w, 1, CV_32F)
+        o1, o2 = empty_like_kind(plane, m1.h, m1.w, 1, CV_32F), empty_like_kind(plane, m1.h, m1.w, 1, CV_32F)
     elif dstmap1type == T32FC2:
         o1, o2 = empty_like_kind(map1, m1.h, m1.w, 2, CV_32F), None
     else:
