@@ -809,10 +809,11 @@ struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 rem
 __device__ __forceinline__ void tileOf(const WarpArgs& w, int& tx, int& ty)
 {
     if (!w.band) { tx = blockIdx.x; ty = blockIdx.y; return; }
+    // bijection for any tile count: XCD k runs the blocks b = k, k + 8, ... -- q + (k < r) of them (q = total / 8, r = total % 8) -- and is
+    // given that many consecutive tiles, starting after the tiles of XCDs 0..k-1
     const int b = blockIdx.y * gridDim.x + blockIdx.x, total = w.gx * w.gy;
-    const int per = (total + 7) >> 3;
-    const int t = (b & 7) * per + (b >> 3);
-    if (t >= total) { tx = -1; ty = 0; return; }
+    const int k = b & 7, q = total >> 3, r = total & 7;
+    const int t = k * q + min(k, r) + (b >> 3);
     ty = t / w.gx; tx = t - ty * w.gx;
 }
 

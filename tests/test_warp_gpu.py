@@ -129,6 +129,18 @@ def test_warp_affine(cv, orc, dtype, cn):
     check(cv.warpAffine(dev(src), M, (61, 45)), orc.orc_warpAffine(src, cv.invertAffineTransform(M), (61, 45)))
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_tile_orders(cv, orc, dtype):
+    """destination sizes whose tile count is not a multiple of 8 (the XCD-banded tile order of the CV_32F kernels must still cover every tile:
+    the reference's own Imgproc_WarpAffine.accuracy caught a hole here), affine and perspective"""
+    src = rnd((180, 230), dtype, 55)
+    M = cv.getRotationMatrix2D((115.0, 90.0), 11.0, 0.9)
+    P = np.array([[1.05, 0.04, -6.0], [0.03, 0.95, 5.0], [1e-4, -1e-4, 1.0]])
+    for dsize in [(700, 300), (65, 33), (129, 97), (641, 479), (1000, 40)]:
+        check(cv.warpAffine(dev(src), M, dsize, 1 | cv.WARP_INVERSE_MAP, 1), orc.orc_warpAffine(src, M, dsize, 1, 1))
+        check(cv.warpPerspective(dev(src), P, dsize, 1 | cv.WARP_INVERSE_MAP, 0, 3.0), orc.orc_warpPerspective(src, P, dsize, 1, 0, 3.0))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_warp_transparent(cv, orc, dtype, cn):
