@@ -429,6 +429,30 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355
         mi355cv_uchar* sum_data, size_t sum_step, mi355cv_uchar* sqsum_data, size_t sqsum_step,
         mi355cv_uchar* tilted_data, size_t tilted_step, int width, int height, int cn);
 
+/* --------------------------------------------------- batches of device-resident frames (frames are the unit that shards)
+ * The frame-batched forms of the hooks above: `nframes` whole images of identical geometry, `*_frame_stride` bytes apart, borders per frame.
+ * One launch where the kernel takes a frame index (the rolling filters, nearest / bilinear / area-fast resize, the warps, threshold on
+ * back-to-back frames), otherwise the per-frame kernels enqueued by one call.  Device pointers only. */
+MI355CV_API int mi355cv_sobelBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data, size_t dst_step,
+        size_t dst_frame_stride, int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta,
+        int border_type);
+MI355CV_API int mi355cv_sepFilterBatch(struct cvhalFilter2D* context, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data,
+        size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height);
+MI355CV_API int mi355cv_boxFilterBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data, size_t dst_step,
+        size_t dst_frame_stride, int nframes, int width, int height, int src_depth, int dst_depth, int cn, size_t ksize_width, size_t ksize_height,
+        int anchor_x, int anchor_y, bool normalize, int border_type);
+MI355CV_API int mi355cv_thresholdBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data, size_t dst_step,
+        size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
+MI355CV_API int mi355cv_resizeBatch(int src_type, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y,
+        int interpolation);
+MI355CV_API int mi355cv_warpAffineBatch(int src_type, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[6], int interpolation,
+        int borderType, const double borderValue[4]);
+MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[9], int interpolation,
+        int borderType, const double borderValue[4]);
+
 /* --------------------------------------------------- f3: features2d FAST corner detector (csrc/fast.hip) */
 /* replace hal_ni_FAST_dense / hal_ni_FAST_NMS (modules/features2d/src/hal_replacement.hpp:75, :87; caller hal_FAST fast.cpp:438-493, which is reached
  * for threshold <= 20): dense score = largest t + 1 for which the pixel is a 9-of-16 corner at threshold t (0 in the 3-pixel frame); the suppression

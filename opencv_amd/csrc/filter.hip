@@ -468,6 +468,37 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     return stg.finish(entry);
 }
 
+// the same over a batch of device-resident whole frames (every frame its own image: isolated borders): one launch of the rolling kernels
+// where they apply, the generic kernel frame by frame otherwise (all in stream order, one synchronisation at most)
+int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H)
+{
+    if (disabled() || W <= 0 || H <= 0 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+    const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
+    if (overlapOnDevice(src, (size_t)(nframes - 1) * sframe + (size_t)(H - 1) * sstep + (size_t)W * c.cn * se,
+                        dst, (size_t)(nframes - 1) * dframe + (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
+        return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the source frames (in-place)", entry);
+    if (nframes == 1) { sframe = 0; dframe = 0; }
+    Stager stg;
+    const SepParams& p = c.sp;
+    const bool centred = p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2;
+    if (p.mode == 2 && c.ddepth == D16S && centred && p.deltaI == 0 &&
+        seprollDeriv16(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.cn, p.kxi, p.kyi, p.nx, c.border, stream()))
+        return stg.finish(entry);
+    if (p.mode == 1 && c.sdepth == D8U && c.ddepth == D8U && centred && p.ny > 1 &&
+        seprollFix8U(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.cn, p.kxi, p.kyi, p.nx, p.deltaF, c.border, stream()))
+        return stg.finish(entry);
+    if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && centred &&
+        seprollFloat(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))
+        return stg.finish(entry);
+    dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
+    for (int f = 0; f < nframes; f++)
+        hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep, W, H, c.cn, c.sdepth, c.ddepth,
+                           W, H, 0, 0, c.border, c.sp);
+    return stg.finish(entry);
+}
+
 // getSobelKernels / getScharrKernels (deriv.cpp:55-162) as integer taps
 bool derivKernel(int order, int ksize, bool scharr, std::vector<int>& k)
 {
@@ -497,7 +528,8 @@ bool derivKernel(int order, int ksize, bool scharr, std::vector<int>& k)
 }
 
 int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int sdepth, int ddepth,
-             int cn, int mL, int mT, int mR, int mB, int dx, int dy, int ksize, bool scharr, double scale, double delta, int border)
+             int cn, int mL, int mT, int mR, int mB, int dx, int dy, int ksize, bool scharr, double scale, double delta, int border,
+             int nframes = 0, size_t sframe = 0, size_t dframe = 0)
 {
     if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)) return MI355CV_NOT_IMPLEMENTED;
     std::vector<int> ix, iy;
@@ -512,6 +544,7 @@ int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size
     FilterCtx c;
     int rc = sepInit(c, MI355CV_MAKETYPE(sdepth, cn), MI355CV_MAKETYPE(ddepth, cn), kx, ky, -1, -1, delta, border);
     if (rc != MI355CV_OK) return rc;
+    if (nframes > 0) return sepRunBatch(entry, c, src, sstep, sframe, dst, dstep, dframe, nframes, W, H);
     return sepRun(entry, c, src, sstep, dst, dstep, W, H, mL + W + mR, mT + H + mB, mL, mT);
 }
 
@@ -680,7 +713,46 @@ MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* ds
                     margin_left, margin_top, margin_right, margin_bottom, dx, dy, 0, true, scale, delta, border_type);
 }
 
+// ---- batches of device-resident whole frames (frame strides in bytes; borders are per frame, i.e. isolated)
+MI355CV_API int mi355cv_sobelBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step, size_t dst_frame_stride,
+        int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta, int border_type)
+{
+    if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    return derivRun("sobelBatch", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn, 0, 0, 0, 0, dx, dy, ksize, ksize <= 0, scale, delta,
+                    border_type & ~MI355CV_BORDER_ISOLATED, nframes, src_frame_stride, dst_frame_stride);
+}
+
+MI355CV_API int mi355cv_sepFilterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step,
+        size_t dst_frame_stride, int nframes, int width, int height)
+{
+    FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
+    if (!c || c->kind != 2 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    return sepRunBatch("sepFilterBatch", *c, src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height);
+}
+
+static int boxRun(const char* entry, const uchar* src_data, size_t src_step, size_t sframe, uchar* dst_data, size_t dst_step, size_t dframe, int nframes, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type);
+
+MI355CV_API int mi355cv_boxFilterBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step, size_t dst_frame_stride,
+        int nframes, int width, int height, int src_depth, int dst_depth, int cn, size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize,
+        int border_type)
+{
+    if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    return boxRun("boxFilterBatch", src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, src_depth, dst_depth, cn,
+                  0, 0, 0, 0, ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type);
+}
+
 MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+        int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
+        size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
+{
+    return boxRun("boxFilter", src_data, src_step, 0, dst_data, dst_step, 0, 0, width, height, src_depth, dst_depth, cn, margin_left, margin_top, margin_right, margin_bottom,
+                  ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type);
+}
+
+// nframes == 0: the hook (one image, margins, host or device); nframes >= 1: a batch of device-resident whole frames
+static int boxRun(const char* entry, const uchar* src_data, size_t src_step, size_t sframe, uchar* dst_data, size_t dst_step, size_t dframe, int nframes, int width, int height,
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
@@ -722,6 +794,19 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(src_depth), de = depthSize(dst_depth);
     const int fullW = margin_left + width + margin_right, fullH = margin_top + height + margin_bottom;
+    if (nframes >= 1) {
+        if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+        if (nframes == 1) { sframe = 0; dframe = 0; }
+        Stager stg;
+        if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
+            seprollBox(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
+            return stg.finish(entry);
+        dim3 grid(divUp(width * cn, 64), divUp(height, 4));
+        for (int f = 0; f < nframes; f++)
+            hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * sframe, src_step, dst_data + (size_t)f * dframe, dst_step, width, height, cn,
+                               src_depth, dst_depth, width, height, 0, 0, border, p);
+        return stg.finish(entry);
+    }
     Stager stg; size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)margin_top * (ptrdiff_t)src_step - (ptrdiff_t)margin_left * cn * se;
     const uchar* dtop = stg.in(top, src_step, (size_t)fullW * cn * se, fullH, &dss);
@@ -730,11 +815,11 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
     const uchar* ds = dtop + (size_t)margin_top * dss + (size_t)margin_left * cn * se;
     if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 && fullW == width && fullH == height &&
         seprollBox(ds, dss, 0, dd, dds, 0, 1, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
-        return stg.finish("boxFilter");
+        return stg.finish(entry);
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
                        fullW, fullH, margin_left, margin_top, border, p);
-    return stg.finish("boxFilter");
+    return stg.finish(entry);
 }
 
 } // extern "C"

@@ -125,3 +125,21 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     }
     return stg.finish("threshold");
 }
+
+// batch of device-resident frames: a point operation, so frames that lie back to back are one tall image (one launch); otherwise frame by frame
+extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step,
+                                                  size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn, double thresh, double maxValue,
+                                                  int thresholdType)
+{
+    if (nframes < 1 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "thresholdBatch: device-resident frames only");
+    if (nframes == 1 || (src_frame_stride == src_step * (size_t)height && dst_frame_stride == dst_step * (size_t)height && (long long)height * nframes < 0x7fffffffLL))
+        return mi355cv_threshold(src_data, src_step, dst_data, dst_step, width, height * nframes, depth, cn, thresh, maxValue, thresholdType);
+    Stager outer;                                            // one synchronisation for the whole batch
+    for (int f = 0; f < nframes; f++) {
+        const int rc = mi355cv_threshold(src_data + (size_t)f * src_frame_stride, src_step, dst_data + (size_t)f * dst_frame_stride, dst_step, width, height, depth, cn,
+                                         thresh, maxValue, thresholdType);
+        if (rc != MI355CV_OK) return rc;
+    }
+    return outer.finish("thresholdBatch");
+}

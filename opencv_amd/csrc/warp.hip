@@ -56,7 +56,8 @@ __device__ __forceinline__ void stRound(uchar* p, int depth, int idx, float v)
 __device__ __forceinline__ void copyPix(uchar* d, const uchar* s, int bytes) { for (int i = 0; i < bytes; i++) d[i] = s[i]; }
 
 // ---------------------------------------------------------------------------------- resize
-struct ResizeArgs { int sw, sh, dw, dh, depth, cn; double scale_x, scale_y, inv_x, inv_y; int mode /*0 nn,1 linear,2 area-as-linear,3 areafast*/; int isx, isy; };
+struct ResizeArgs { int sw, sh, dw, dh, depth, cn; double scale_x, scale_y, inv_x, inv_y; int mode /*0 nn,1 linear,2 area-as-linear,3 areafast*/; int isx, isy;
+                    size_t sframe, dframe; /* bytes between the frames of a batch (grid z = frame) */ };
 
 __device__ __forceinline__ void linCoef(int d, double scale, double inv, int areaMode, int& s, float& f)
 {
@@ -66,6 +67,7 @@ __device__ __forceinline__ void linCoef(int d, double scale, double inv, int are
 
 __global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
 {
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= a.dw || dy >= a.dh) return;
@@ -172,6 +174,7 @@ constexpr int RROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void k_resize_lin1(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
 {
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RROWS;
     if (dx >= a.dw || yb >= a.dh) return;
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256) void k_resize_lin1(const uchar* __restrict__ s
 template <typename T, int CN>
 __global__ __launch_bounds__(256) void k_resize_linC(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, ResizeArgs a)
 {
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RROWS;
     if (dx >= a.dw || yb >= a.dh) return;
@@ -800,7 +804,8 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
     }
 }
 
-struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; int band /* XCD-banded tile order */; int gx, gy; };
+struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; int band /* XCD-banded tile order */; int gx, gy;
+                  size_t sframe, dframe; /* bytes between the frames of a batch (grid z = frame) */ };
 
 // Tile order.  Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2, so with the plain
 // x-fastest order the 8 horizontally adjacent tiles -- whose source footprints share cache lines -- land in 8 different L2s and each fetches
@@ -824,6 +829,7 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w.dw || y >= w.dh) return;
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
     uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
     int X, Y;
     if (w.kind == 0) {
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 {
     int tx, ty;
     tileOf(w, tx, ty);
-    if (tx < 0) return;
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
     const int x = tx * 64 + (threadIdx.x & 63);
     const int yb = (ty * 4 + (threadIdx.x >> 6)) * WROWS;
     if (x >= w.dw || yb >= w.dh) return;
@@ -1004,7 +1010,7 @@ bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
             const double* M, int kind, int interpolation, int borderType, const double* bv,
-            const float* mapx, size_t mxstep, const float* mapy, size_t mystep)
+            const float* mapx, size_t mxstep, const float* mapy, size_t mystep, int nframes = 1, size_t sframe = 0, size_t dframe = 0)
 {
     if (disabled()) return MI355CV_NOT_IMPLEMENTED;
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
@@ -1015,6 +1021,8 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)dw * dh < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (nframes < 1 || (nframes > 1 && (!isDevicePtr(src) || !isDevicePtr(dst))))
+        return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const short* g_tabDev = deviceTab();
     if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
@@ -1051,6 +1059,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
     WarpArgs w; memset(&w, 0, sizeof w);
     w.dw = dw; w.dh = dh; w.kind = kind;
+    w.sframe = nframes > 1 ? sframe : 0; w.dframe = nframes > 1 ? dframe : 0;
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
@@ -1060,7 +1069,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // L2's reach anyway (4K 8UC3: 46.2 vs 43.8 us).  MI355CV_WARP_BAND=0/1 overrides (tools/tune_r02.py).
         const char* ve = getenv("MI355CV_WARP_BAND");
         w.band = ve ? atoi(ve) : (depth == D32F ? 1 : 0);
-        dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS));
+        dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS), nframes);
         w.gx = g2.x; w.gy = g2.y;
 #define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev)
 #define WLC(T_, K_) do { if (cn == 1) WL(T_, 1, K_); else if (cn == 3) WL(T_, 3, K_); else WL(T_, 4, K_); } while (0)
@@ -1070,19 +1079,18 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
 #undef WL
         return stg.finish(entry);
     }
-    dim3 grid(divUp(dw, 64), divUp(dh, 4));
+    dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
     hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev, dmx, mxs, dmy, mys);
     return stg.finish(entry);
 }
 
 } // namespace
 
-extern "C" {
-
-MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
-        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, double inv_scale_x, double inv_scale_y, int interpolation)
+static int runResize(const char* entry, int src_type, const uchar* src_data, size_t src_step, size_t src_frame, int src_width, int src_height,
+                     uchar* dst_data, size_t dst_step, size_t dst_frame, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y,
+                     int interpolation)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     if (!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (inv_scale_x < 2.220446049250313e-16 || inv_scale_y < 2.220446049250313e-16) {        // resize.cpp:3834-3838
@@ -1107,6 +1115,19 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
+    if (nframes > 1) {
+        // batches are an HBM-resident construct; nearest / bilinear / area-fast run as ONE launch (grid z = frame), the table-driven modes frame by frame
+        if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+        if (a.mode >= 4) {
+            for (int f = 0; f < nframes; f++) {
+                const int rc = runResize(entry, src_type, src_data + (size_t)f * src_frame, src_step, 0, src_width, src_height, dst_data + (size_t)f * dst_frame, dst_step, 0,
+                                         dst_width, dst_height, 1, inv_scale_x, inv_scale_y, interpolation);
+                if (rc != MI355CV_OK) return rc;
+            }
+            return MI355CV_OK;
+        }
+        a.sframe = src_frame; a.dframe = dst_frame;
+    }
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
@@ -1134,7 +1155,7 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
             else if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
             else hipLaunchKernelGGL(k_resize_lanczos<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
         }
-        return stg.finish("resize");
+        return stg.finish(entry);
     }
     if (a.mode == 4) {
         AreaDev ax, ay;
@@ -1144,25 +1165,60 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
 #define RA(T_) hipLaunchKernelGGL(k_resize_area<T_>, g4, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, depth, dxt, dxo, dyt, dyo)
         switch (depth) { case D8U: RA(uchar); break; case D16U: RA(unsigned short); break; case D16S: RA(short); break; default: RA(float); }
 #undef RA
-        return stg.finish("resize");
+        return stg.finish(entry);
     }
     if ((a.mode == 1 || a.mode == 2) && cn == 1 && (depth == D32F || depth == D8U) && src_width >= 2 && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
-        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
+        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS), nframes);
         if (depth == D32F) hipLaunchKernelGGL(k_resize_lin1<float>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
         else hipLaunchKernelGGL(k_resize_lin1<uchar>, g2, dim3(256), 0, stream(), ds, dss, dd, dds, a);
-        return stg.finish("resize");
+        return stg.finish(entry);
     }
     if ((a.mode == 1 || a.mode == 2) && (cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
-        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS));
+        dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS), nframes);
 #define RLC(T_, CN_) hipLaunchKernelGGL((k_resize_linC<T_, CN_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, a)
         if (depth == D32F) { if (cn == 3) RLC(float, 3); else RLC(float, 4); }
         else { if (cn == 3) RLC(uchar, 3); else RLC(uchar, 4); }
 #undef RLC
-        return stg.finish("resize");
+        return stg.finish(entry);
     }
-    dim3 grid(divUp(dst_width, 64), divUp(dst_height, 4));
+    dim3 grid(divUp(dst_width, 64), divUp(dst_height, 4), nframes);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, stream(), ds, dss, dd, dds, a);
-    return stg.finish("resize");
+    return stg.finish(entry);
+}
+
+extern "C" {
+
+MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, int dst_width, int dst_height, double inv_scale_x, double inv_scale_y, int interpolation)
+{
+    return runResize("resize", src_type, src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, inv_scale_x, inv_scale_y, interpolation);
+}
+
+// batches of device-resident frames (frames are the unit that shards): every frame through the same transform, one launch where
+// the kernel takes a frame index (nearest / bilinear / area-fast resize, every warp), frame strides in bytes
+MI355CV_API int mi355cv_resizeBatch(int src_type, const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y, int interpolation)
+{
+    return runResize("resizeBatch", src_type, src_data, src_step, src_frame_stride, src_width, src_height, dst_data, dst_step, dst_frame_stride, dst_width, dst_height,
+                     nframes, inv_scale_x, inv_scale_y, interpolation);
+}
+
+MI355CV_API int mi355cv_warpAffineBatch(int src_type, const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[6], int interpolation, int borderType,
+        const double borderValue[4])
+{
+    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("warpAffineBatch", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   M, 0, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0, nframes, src_frame_stride, dst_frame_stride);
+}
+
+MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[9], int interpolation, int borderType,
+        const double borderValue[4])
+{
+    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    return runWarp("warpPerspectiveBatch", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
+                   M, 1, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0, nframes, src_frame_stride, dst_frame_stride);
 }
 
 MI355CV_API int mi355cv_warpAffine(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_16S, CV_32F,  # noqa: F401
+from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_16S, CV_32F, _DEPTH_T,  # noqa: F401
                    BORDER_CONSTANT, BORDER_ISOLATED, BORDER_DEFAULT)
 
 L = _lib.lib
@@ -25,7 +25,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "matchTemplate", "matchTemplateBatch", "integral", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
-           "resize", "warpAffine", "warpPerspective", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
+           "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
            "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
@@ -923,6 +923,133 @@ def warpPolar(src, dsize, center, maxRadius, flags, dst=None):
     rc = L.mi355cv_warpPolar(s.type, _vp(s.ptr), s.step, s.w, s.h, _vp(d.ptr), d.step, d.w, d.h, float(center[0]), float(center[1]), float(maxRadius), flags)
     _lib.check(rc, "warpPolar")
     return out
+
+
+# ----------------------------------------------------------------------------- frame batches of the single-image hooks
+def _batch_geom(frames):
+    if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dim() not in (3, 4):
+        raise ValueError("batch entries take a CUDA(ROCm) tensor [N,H,W(,C)]")
+    return int(frames.shape[0]), Img(frames[0])
+
+
+def _batch_out(frames, dst, shape, dtype):
+    if dst is not None:
+        if tuple(dst.shape) != tuple(shape) or dst.dtype != dtype:
+            raise ValueError("dst geometry mismatch")
+        return dst
+    return torch.empty(shape, dtype=dtype, device=frames.device)
+
+
+def SobelBatch(frames, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, borderType=BORDER_DEFAULT, dst=None):
+    """cv::Sobel over [N,H,W(,C)] device frames, one launch (ksize=-1: Scharr taps)"""
+    n, s0 = _batch_geom(frames)
+    if ddepth < 0:
+        ddepth = s0.depth
+    out = _batch_out(frames, dst, frames.shape, _DEPTH_T[ddepth])
+    d0 = Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_sobelBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, n, s0.w, s0.h, s0.depth, d0.depth,
+                              s0.cn, dx, dy, ksize, float(scale), float(delta), borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "sobelBatch")
+    return out
+
+
+def boxFilterBatch(frames, ddepth, ksize, anchor=(-1, -1), normalize=True, borderType=BORDER_DEFAULT, dst=None):
+    n, s0 = _batch_geom(frames)
+    if ddepth < 0:
+        ddepth = s0.depth
+    out = _batch_out(frames, dst, frames.shape, _DEPTH_T[ddepth])
+    d0 = Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_boxFilterBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, n, s0.w, s0.h, s0.depth,
+                                  d0.depth, s0.cn, ksize[0], ksize[1], anchor[0], anchor[1], bool(normalize), borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "boxFilterBatch")
+    return out
+
+
+def sepFilter2DBatch(frames, ddepth, kernelX, kernelY, anchor=(-1, -1), delta=0.0, borderType=BORDER_DEFAULT, dst=None):
+    n, s0 = _batch_geom(frames)
+    if ddepth < 0:
+        ddepth = s0.depth
+    out = _batch_out(frames, dst, frames.shape, _DEPTH_T[ddepth])
+    d0 = Img(out[0])
+    kx = np.ascontiguousarray(np.asarray(kernelX, dtype=np.float64).ravel())
+    ky = np.ascontiguousarray(np.asarray(kernelY, dtype=np.float64).ravel())
+    bind_stream(s0, d0)
+    ctx = ctypes.c_void_p()
+    _lib.check(L.mi355cv_sepFilterInit(ctypes.byref(ctx), s0.type, d0.type, 6, kx.ctypes.data, len(kx), ky.ctypes.data, len(ky), anchor[0], anchor[1], float(delta),
+                                       borderType & ~BORDER_ISOLATED), "sepFilterInit")
+    try:
+        rc = L.mi355cv_sepFilterBatch(ctx, _vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, n, s0.w, s0.h)
+    finally:
+        L.mi355cv_sepFilterFree(ctx)
+    _lib.check(rc, "sepFilterBatch")
+    return out
+
+
+def thresholdBatch(frames, thresh, maxval, type, dst=None):
+    """cv::threshold with a fixed level over [N,H,W(,C)] device frames (the automatic levels are per image: use threshold)"""
+    n, s0 = _batch_geom(frames)
+    if type & ~7:
+        raise NotImplementedError("thresholdBatch: fixed levels only")
+    out = _batch_out(frames, dst, frames.shape, frames.dtype)
+    d0 = Img(out[0])
+    if s0.depth != CV_8U:
+        raise NotImplementedError("thresholdBatch: CV_8U frames")
+    ith = int(np.floor(thresh))                              # thresh.cpp:1583-1610: integer levels for integer images
+    if ith < 0 or ith >= 255:
+        raise NotImplementedError("thresholdBatch: degenerate levels are constant fills (use threshold)")
+    th = float(ith)
+    mv = float(ith if type == THRESH_TRUNC else min(max(int(np.rint(maxval)), 0), 255))
+    bind_stream(s0, d0)
+    rc = L.mi355cv_thresholdBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, n, s0.w, s0.h, s0.depth, s0.cn,
+                                  th, mv, type)
+    _lib.check(rc, "thresholdBatch")
+    return out
+
+
+def resizeBatch(frames, dsize, fx=0.0, fy=0.0, interpolation=INTER_LINEAR, dst=None):
+    n, s0 = _batch_geom(frames)
+    if dsize is None or dsize[0] == 0:
+        dsize = (_cvRound(s0.w * fx), _cvRound(s0.h * fy))    # saturate_cast<int>(src.cols * fx), resize.cpp:4217
+    else:
+        fx, fy = dsize[0] / s0.w, dsize[1] / s0.h
+    shape = (n, dsize[1], dsize[0]) + tuple(frames.shape[3:])
+    out = _batch_out(frames, dst, shape, frames.dtype)
+    d0 = Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_resizeBatch(s0.type, _vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, s0.w, s0.h, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, d0.w, d0.h, n,
+                               float(fx), float(fy), interpolation)
+    _lib.check(rc, "resizeBatch")
+    return out
+
+
+def _warpBatch(fn, name, nM, frames, M, dsize, flags, borderMode, borderValue, dst, invert):
+    n, s0 = _batch_geom(frames)
+    interpolation = flags & INTER_MAX
+    dw, dh = (s0.w, s0.h) if dsize is None or dsize[0] == 0 else dsize
+    shape = (n, dh, dw) + tuple(frames.shape[3:])
+    out = _batch_out(frames, dst, shape, frames.dtype)
+    d0 = Img(out[0])
+    Mm = np.array(M, np.float64).reshape(nM // 3, 3)
+    if not (flags & WARP_INVERSE_MAP):
+        Mm = invert(Mm)
+    Mm = np.ascontiguousarray(Mm)
+    bv = _border_value(borderValue)
+    bind_stream(s0, d0)
+    rc = fn(s0.type, _vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, s0.w, s0.h, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, d0.w, d0.h, n,
+            Mm.ctypes.data, interpolation, borderMode, bv.ctypes.data)
+    _lib.check(rc, name)
+    return out
+
+
+def warpAffineBatch(frames, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    """cv::warpAffine with one matrix over [N,H,W(,C)] device frames, one launch"""
+    return _warpBatch(L.mi355cv_warpAffineBatch, "warpAffineBatch", 6, frames, M, dsize, flags, borderMode, borderValue, dst, invertAffineTransform)
+
+
+def warpPerspectiveBatch(frames, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0.0, dst=None):
+    return _warpBatch(L.mi355cv_warpPerspectiveBatch, "warpPerspectiveBatch", 9, frames, M, dsize, flags, borderMode, borderValue, dst, lambda m: np.linalg.inv(m))
 
 
 # ----------------------------------------------------------------------------- pyramids and corners (a10, a11, a12)

@@ -1,0 +1,67 @@
+"""Frame-batched entry points (frames are the unit that shards): N device-resident frames through ONE call must give, frame for
+frame, exactly what the single-image hook gives (those are checked against the oracle in the per-function suites) -- including frames that
+are views with padding between them and geometries the rolling kernels do not cover (the per-frame generic kernels inside the batch call)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def frames_u8(n, h, w, cn=1, seed=0, padded=False):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    shape = (n, h + (3 if padded else 0), w) + ((cn,) if cn > 1 else ())
+    t = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+    return t[:, :h] if padded else t
+
+
+def same(batch, singles):
+    for f, one in enumerate(singles):
+        assert batch[f].shape == one.shape and torch.equal(batch[f], one), f
+
+
+@pytest.mark.parametrize("cn,w,h", [(1, 640, 97), (3, 320, 61), (1, 333, 40)])
+def test_filter_family_batches(cv, cn, w, h):
+    fr = frames_u8(5, h, w, cn, seed=w, padded=(cn == 3))
+    same(cv.SobelBatch(fr, cv.CV_16S, 1, 0, 3), [cv.Sobel(f, cv.CV_16S, 1, 0, 3) for f in fr])
+    same(cv.SobelBatch(fr, cv.CV_32F, 0, 1, 3, 0.125), [cv.Sobel(f, cv.CV_32F, 0, 1, 3, 0.125) for f in fr])
+    same(cv.SobelBatch(fr, cv.CV_16S, 1, 0, -1, borderType=1), [cv.Sobel(f, cv.CV_16S, 1, 0, -1, borderType=1) for f in fr])
+    same(cv.boxFilterBatch(fr, -1, (5, 5)), [cv.boxFilter(f, -1, (5, 5)) for f in fr])
+    same(cv.boxFilterBatch(fr, -1, (7, 3), (1, 2), False, 2), [cv.boxFilter(f, -1, (7, 3), (1, 2), False, 2) for f in fr])
+    k3 = [0.25, 0.5, 0.25]
+    same(cv.sepFilter2DBatch(fr, -1, k3, k3), [cv.sepFilter2D(f, -1, k3, k3) for f in fr])
+    kx, ky = [0.1, 0.5, 0.2, 0.05, 0.15], [0.7, -0.1, 0.2]
+    same(cv.sepFilter2DBatch(fr, cv.CV_32F, kx, ky, delta=0.5), [cv.sepFilter2D(f, cv.CV_32F, kx, ky, delta=0.5) for f in fr])
+    same(cv.thresholdBatch(fr, 100.7, 200, 0), [cv.threshold(f, 100.7, 200, 0)[1] for f in fr])
+    same(cv.thresholdBatch(fr, 90, 0, 2), [cv.threshold(f, 90, 0, 2)[1] for f in fr])
+    with pytest.raises(NotImplementedError):
+        cv.thresholdBatch(fr.to(torch.int16), 1, 2, 0)
+
+
+@pytest.mark.parametrize("dtype,cn", [(torch.uint8, 1), (torch.uint8, 3), (torch.float32, 1)])
+def test_geometry_batches(cv, dtype, cn):
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    shape = (4, 120, 161) + ((cn,) if cn > 1 else ())
+    fr = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+    if dtype == torch.float32:
+        fr = fr.to(torch.float32) / 255
+    for dsize, interp in [((80, 60), 1), ((200, 150), 1), ((97, 33), 0), ((80, 60), 3), ((120, 90), 2)]:
+        same(cv.resizeBatch(fr, dsize, interpolation=interp), [cv.resize(f, dsize, interpolation=interp) for f in fr])
+    M = cv.getRotationMatrix2D((80.0, 60.0), 9.0, 0.9)
+    for flags, border in [(1, 0), (0, 1), (1 | cv.WARP_INVERSE_MAP, 4)]:
+        same(cv.warpAffineBatch(fr, M, (161, 120), flags, border, 7.0), [cv.warpAffine(f, M, (161, 120), flags, border, 7.0) for f in fr])
+    same(cv.warpAffineBatch(fr, M, (700, 300), 1 | cv.WARP_INVERSE_MAP, 1), [cv.warpAffine(f, M, (700, 300), 1 | cv.WARP_INVERSE_MAP, 1) for f in fr])
+    P = np.array([[1.05, 0.04, -6.0], [0.03, 0.95, 5.0], [1e-4, -1e-4, 1.0]])
+    same(cv.warpPerspectiveBatch(fr, P, (161, 120), 1 | cv.WARP_INVERSE_MAP, 0, 3.0), [cv.warpPerspective(f, P, (161, 120), 1 | cv.WARP_INVERSE_MAP, 0, 3.0) for f in fr])
+
+
+def test_batch_entries_refuse_host_memory(cv):
+    with pytest.raises(ValueError):
+        cv.SobelBatch(np.zeros((2, 8, 8), np.uint8), cv.CV_16S, 1, 0)

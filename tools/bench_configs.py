@@ -128,6 +128,22 @@ def run(quick=False, parity=True):
     ms = timeit(lambda: cv.filter2DBatch(gray, -1, k5, dst=dstb))
     out.append({"config": "cfg2d filter2D 5x5 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
                 "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    # ---- frame-batched forms of the single-image hooks (one call, one launch where the kernel takes a frame index): 16 x 4K 8UC1
+    def bline(name, ms, by):
+        out.append({"config": name, "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1), "bound": "hbm",
+                    "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    b16 = torch.empty((B2, 2160, 3840), dtype=torch.int16, device=dev)
+    bline("a4 Sobel dx 3x3 4K 8U->16S batch", timeit(lambda: cv.SobelBatch(gray, cv.CV_16S, 1, 0, 3, dst=b16)), B2 * 3840 * 2160 * 3)
+    del b16
+    bline("a5 boxFilter 5x5 4K 8U batch", timeit(lambda: cv.boxFilterBatch(gray, -1, (5, 5), dst=dstb)), B2 * 3840 * 2160 * 2)
+    kxb = np.array([0.25, 0.5, 0.25], np.float32)
+    bline("a4 sepFilter2D 3x3 (1/4,1/2,1/4) 4K 8U batch", timeit(lambda: cv.sepFilter2DBatch(gray, -1, kxb, kxb, dst=dstb)), B2 * 3840 * 2160 * 2)
+    bline("f1 threshold BINARY 4K 8U batch", timeit(lambda: cv.thresholdBatch(gray, 127, 255, 0, dst=dstb)), B2 * 3840 * 2160 * 2)
+    half = torch.empty((B2, 1080, 1920), dtype=torch.uint8, device=dev)
+    bline("a7 resize 4K 8UC1 -> 1080p (area-fast 2x2) batch", timeit(lambda: cv.resizeBatch(gray, (1920, 1080), dst=half)), B2 * (3840 * 2160 + 1920 * 1080))
+    del half
+    Mb = cv.getRotationMatrix2D((1920.0, 1080.0), 7.0, 0.95)
+    bline("a8 warpAffine 4K 8UC1 rot 7deg batch", timeit(lambda: cv.warpAffineBatch(gray, Mb, (3840, 2160), dst=dstb)), B2 * 3840 * 2160 * 2)
     # ---- the other filters of rows a3-a5 on one 4K 8UC1 frame (single-frame calls: launch overhead included)
     one = gray[0]
     MP = 8.2944
