@@ -49,10 +49,13 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     f = statistics.median(vals["FETCH_SIZE"]) * 1024 * 2
     w = statistics.median(vals["WRITE_SIZE"]) * 1024
-    j = {"kernel": "k_binomial_roll2<5,1>", "fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w),
-         "hbm_bytes_per_launch": int(f + w),
+    frames = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
+    j = {"kernel": "k_binomial_roll2<5,1,true,false,4>", "frames_per_launch": frames, "fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w),
+         "hbm_bytes_per_launch": int(f + w), "algorithmic_bytes_per_launch": (2 * 3840 * 2160 * frames) if frames else None,
+         "source": f"profiles/{tag}_gauss5x5_rocprof_summary.txt: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --batch {frames}`",
          "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 (gfx950 wide-read "
-                   "correction, MI355X_MICROARCH.md HBM section); median over the 128-frame dispatches; Infinity-Cache hits are "
+                   "correction, MI355X_MICROARCH.md HBM section); median over the batch dispatches; Infinity-Cache hits are "
                    "included in FETCH_SIZE, so the L2-missing halo re-reads show up here even when MALL serves them"}
     print("== traffic ==")
     print(json.dumps(j))
