@@ -153,24 +153,107 @@ __global__ __launch_bounds__(256) void k_hsv2bgr_u8(const uchar* __restrict__ sr
     if (DCN == 4) d[3] = 255;
 }
 
+// CV_16U / CV_32F members of the YUV / YCrCb family (RGB2YCrCb_i<ushort> color_yuv.simd.hpp:255-395, YCrCb2RGB_i<ushort> :890-1010: the 8-bit integer
+// formulas with delta = 32768; RGB2YCrCb_f<float> :134-212, YCrCb2RGB_f<float> :616-689: fused multiply-adds in the order of the reference's vector
+// loop).  One thread per pixel, 6-8 bytes (16U) / 12-16 bytes (32F) in and out per lane.
+struct YuvFwdF { float c0, c1, c2, c3, c4; int bidx, yuvOrder; };
+struct YuvInvF { float c0, c1, c2, c3; int bidx, yuvOrder; };
+
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2yuv16(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, YuvFwd a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned short* s = reinterpret_cast<const unsigned short*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+    unsigned short* d = reinterpret_cast<unsigned short*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+    const int s0 = s[0], s1 = s[1], s2 = s[2];
+    const int Y = (int)(((long long)s0 * a.c0 + (long long)s1 * a.c1 + (long long)s2 * a.c2 + (1 << 13)) >> 14);
+    const int r = a.bidx ? s0 : s2, b = a.bidx ? s2 : s0;
+    const int delta = 32768 * (1 << 14);
+    const int Cr = ((r - Y) * a.c3 + delta + (1 << 13)) >> 14, Cb = ((b - Y) * a.c4 + delta + (1 << 13)) >> 14;
+    const int cr = min(max(Cr, 0), 65535), cb = min(max(Cb, 0), 65535);
+    d[0] = (unsigned short)min(max(Y, 0), 65535); d[1] = (unsigned short)(a.yuvOrder ? cb : cr); d[2] = (unsigned short)(a.yuvOrder ? cr : cb);
+}
+
+template <int DCN>
+__global__ __launch_bounds__(256) void k_yuv2bgr16(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, YuvInv a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned short* s = reinterpret_cast<const unsigned short*>(src + (size_t)y * sstep) + (size_t)x * 3;
+    unsigned short* d = reinterpret_cast<unsigned short*>(dst + (size_t)y * dstep) + (size_t)x * DCN;
+    const int Y = s[0], c1 = s[1], c2 = s[2];
+    const int Cr = a.yuvOrder ? c2 : c1, Cb = a.yuvOrder ? c1 : c2;
+    const int b = Y + (int)(((long long)(Cb - 32768) * a.c3 + (1 << 13)) >> 14);
+    const int g = Y + (int)(((long long)(Cb - 32768) * a.c2 + (long long)(Cr - 32768) * a.c1 + (1 << 13)) >> 14);
+    const int r = Y + (int)(((long long)(Cr - 32768) * a.c0 + (1 << 13)) >> 14);
+    const unsigned short B = (unsigned short)min(max(b, 0), 65535), G = (unsigned short)min(max(g, 0), 65535), R = (unsigned short)min(max(r, 0), 65535);
+    d[0] = a.bidx ? R : B; d[1] = G; d[2] = a.bidx ? B : R;
+    if (DCN == 4) d[3] = 65535;
+}
+
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2yuv32f(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, YuvFwdF a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+    float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+    const float s0 = s[0], s1 = s[1], s2 = s[2];
+    const float Y = __fmaf_rn(s0, a.c0, __fmaf_rn(s1, a.c1, __fmul_rn(s2, a.c2)));
+    const float r = a.bidx ? s0 : s2, b = a.bidx ? s2 : s0;
+    const float Cr = __fmaf_rn(__fsub_rn(r, Y), a.c3, 0.5f), Cb = __fmaf_rn(__fsub_rn(b, Y), a.c4, 0.5f);
+    d[0] = Y; d[1] = a.yuvOrder ? Cb : Cr; d[2] = a.yuvOrder ? Cr : Cb;
+}
+
+template <int DCN>
+__global__ __launch_bounds__(256) void k_yuv2bgr32f(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, YuvInvF a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * 3;
+    float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * DCN;
+    const float Y = s[0], c1 = s[1], c2 = s[2];
+    const float cr = __fsub_rn(a.yuvOrder ? c2 : c1, 0.5f), cb = __fsub_rn(a.yuvOrder ? c1 : c2, 0.5f);
+    const float b = __fmaf_rn(cb, a.c3, Y), g = __fmaf_rn(cr, a.c1, __fmaf_rn(cb, a.c2, Y)), r = __fmaf_rn(cr, a.c0, Y);
+    d[0] = a.bidx ? r : b; d[1] = g; d[2] = a.bidx ? b : r;
+    if (DCN == 4) d[3] = 1.f;
+}
+
 } // namespace
+
 
 extern "C" {
 
 MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isCbCr)
 {
-    if (disabled() || depth != MI355CV_8U || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
+        return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     Stager stg; size_t dss, dds;
-    const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
-    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * esz, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * esz, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     YuvFwd a; a.c0 = 4899; a.c1 = 9617; a.c2 = 1868; a.c3 = isCbCr ? 11682 : 14369; a.c4 = isCbCr ? 9241 : 8061;
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     if (a.bidx == 0) { const int t = a.c0; a.c0 = a.c2; a.c2 = t; }
     dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (depth == MI355CV_16U) {
+        if (scn == 3) hipLaunchKernelGGL(k_bgr2yuv16<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+        else hipLaunchKernelGGL(k_bgr2yuv16<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+        return stg.finish("cvtBGRtoYUV");
+    }
+    if (depth == MI355CV_32F) {
+        YuvFwdF f; f.c0 = 0.299f; f.c1 = 0.587f; f.c2 = 0.114f; f.c3 = isCbCr ? 0.713f : 0.877f; f.c4 = isCbCr ? 0.564f : 0.492f;   // R2YF.., YCRF / R2VF, YCBF / B2UF
+        f.bidx = a.bidx; f.yuvOrder = a.yuvOrder;
+        if (f.bidx == 0) { const float t = f.c0; f.c0 = f.c2; f.c2 = t; }
+        if (scn == 3) hipLaunchKernelGGL(k_bgr2yuv32f<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, f);
+        else hipLaunchKernelGGL(k_bgr2yuv32f<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, f);
+        return stg.finish("cvtBGRtoYUV");
+    }
     if (scn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Yuv<3>{a});
     else pix4::launch<4, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Yuv<4>{a});
     return stg.finish("cvtBGRtoYUV");
@@ -179,16 +262,31 @@ MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isCbCr)
 {
-    if (disabled() || depth != MI355CV_8U || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
+        return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     Stager stg; size_t dss, dds;
-    const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
-    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3 * esz, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * esz, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     YuvInv a; a.c0 = isCbCr ? 22987 : 18678; a.c1 = isCbCr ? -11698 : -9519; a.c2 = isCbCr ? -5636 : -6472; a.c3 = isCbCr ? 29049 : 33292;
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     dim3 grid(divUp(width, 64), divUp(height, 4));
+    if (depth == MI355CV_16U) {
+        if (dcn == 3) hipLaunchKernelGGL(k_yuv2bgr16<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+        else hipLaunchKernelGGL(k_yuv2bgr16<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, a);
+        return stg.finish("cvtYUVtoBGR");
+    }
+    if (depth == MI355CV_32F) {
+        YuvInvF f;                                             // CR2RF, CR2GF, CB2GF, CB2BF / V2RF, V2GF, U2GF, U2BF (color.simd_helpers / color_yuv.simd.hpp)
+        f.c0 = isCbCr ? 1.403f : 1.140f; f.c1 = isCbCr ? -0.714f : -0.581f; f.c2 = isCbCr ? -0.344f : -0.395f; f.c3 = isCbCr ? 1.773f : 2.032f;
+        f.bidx = a.bidx; f.yuvOrder = a.yuvOrder;
+        if (dcn == 3) hipLaunchKernelGGL(k_yuv2bgr32f<3>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, f);
+        else hipLaunchKernelGGL(k_yuv2bgr32f<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, f);
+        return stg.finish("cvtYUVtoBGR");
+    }
     if (dcn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpYuv2Bgr<3>{a});
     else pix4::launch<3, 4>(stream(), ds, dss, dd, dds, width, height, OpYuv2Bgr<4>{a});
     return stg.finish("cvtYUVtoBGR");

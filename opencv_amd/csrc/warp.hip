@@ -567,6 +567,56 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
     }
 }
 
+// INTER_LINEAR_EXACT (resize_bitExact<ET, interpolationLinear<ET>>, resize.cpp:789-950): per-axis tables of (offset, weight of the second tap in
+// Q8 for 8U / Q16 for 16U and 16S) built on the host in the reference's arithmetic; horizontal pass exact in Q(shift), vertical pass a two-term dot
+// product rounded once.  A weight of 0 means the second tap is not read (left of the image / from the last pixel on: the clamped cases).
+struct ExactTap { int ofs; int c1; };
+template <typename T, int SHIFT>
+__global__ __launch_bounds__(256) void k_resize_exact(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int dw, int dh, int cn,
+                                                      const ExactTap* __restrict__ tx, const ExactTap* __restrict__ ty)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= dw * cn || y >= dh) return;
+    const int x = e / cn, c = e - x * cn;
+    const ExactTap ax = tx[x], ay = ty[y];
+    const long long one = 1LL << SHIFT;
+    long long H[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r == 1 && ay.c1 == 0) break;
+        const T* row = reinterpret_cast<const T*>(src + (size_t)(ay.ofs + r) * sstep);
+        const long long p0 = (long long)row[ax.ofs * cn + c];
+        const long long p1 = ax.c1 ? (long long)row[(ax.ofs + 1) * cn + c] : 0;
+        H[r] = (one - ax.c1) * p0 + (long long)ax.c1 * p1;
+    }
+    const long long v = (one - ay.c1) * H[0] + (long long)ay.c1 * H[1];
+    const long long r = (v + (1LL << (2 * SHIFT - 1))) >> (2 * SHIFT);
+    T* D = reinterpret_cast<T*>(dst + (size_t)y * dstep);
+    if (sizeof(T) == 1) D[e] = (T)(r < 0 ? 0 : r > 255 ? 255 : r);
+    else if (T(-1) > T(0)) D[e] = (T)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+    else D[e] = (T)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+}
+
+// interpolationLinear<ET>::getCoeffs / getMinMax (resize.cpp:794-826); softdouble there, IEEE double here (same roundings: built with -ffp-contract=off)
+void buildExactTaps(double inv_scale, int ssize, int dsize, int shift, std::vector<ExactTap>& t)
+{
+    t.assign((size_t)dsize, ExactTap{0, 0});
+    const double scale = 1.0 / inv_scale;
+    int minofst = 0, maxofst = dsize;
+    for (int d = 0; d < dsize; d++) {
+        const double fval = scale * ((double)d + 0.5) - 0.5;
+        const int ival = (int)std::floor(fval);
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) { t[(size_t)d].ofs = ival; t[(size_t)d].c1 = (int)std::nearbyint((fval - (double)ival) * (double)(1 << shift)); }
+            else { t[(size_t)d].ofs = ssize - 1; maxofst = std::min(maxofst, d); }
+        } else minofst = std::max(minofst, d + 1);
+    }
+    for (int d = 0; d < dsize; d++) {
+        if (d < minofst) t[(size_t)d] = ExactTap{0, 0};
+        else if (d >= maxofst) t[(size_t)d] = ExactTap{ssize - 1, 0};
+    }
+}
+
 // rows of LDS the tiled kernel needs for the tallest tile, or 0 when that exceeds what it may use
 template <class Tab> int tiledRows(const std::vector<Tab>& yt, int nt)
 {
@@ -1108,9 +1158,13 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
             a.mode = areaFast ? 3 : 4;                                                       // 4: true area (resizeArea_)
         } else if (interpolation == MI355CV_INTER_LINEAR) a.mode = 1;
         else if (interpolation == MI355CV_INTER_AREA) a.mode = 2;
+        else if (interpolation == MI355CV_INTER_LINEAR_EXACT && (depth == D8U || depth == D16U || depth == D16S)) {
+            // resize.cpp:3976-3990: exactly-half sizes are the (bit-exact) 2x2 area mean, except for 2 channels
+            if (areaFast && a.isx == 2 && a.isy == 2 && cn != 2) a.mode = 3; else a.mode = 7;
+        }
         else if (interpolation == 2 /*INTER_CUBIC*/ && (depth == D8U || depth == D32F)) a.mode = 5;
         else if (interpolation == 4 /*INTER_LANCZOS4*/ && (depth == D8U || depth == D32F)) a.mode = 6;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // *_EXACT / cubic and lanczos on 16-bit depths: next row (f2)
+        else return MI355CV_NOT_IMPLEMENTED;                                                // NEAREST_EXACT, LINEAR_EXACT on other depths, cubic / Lanczos on 16-bit depths
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
@@ -1155,6 +1209,20 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
             else if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
             else hipLaunchKernelGGL(k_resize_lanczos<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
         }
+        return stg.finish(entry);
+    }
+    if (a.mode == 7) {
+        const int shift = depth == D8U ? 8 : 16;
+        std::vector<ExactTap> hx, hy;
+        buildExactTaps(inv_scale_x, src_width, dst_width, shift, hx);
+        buildExactTaps(inv_scale_y, src_height, dst_height, shift, hy);
+        const ExactTap* dx = (const ExactTap*)stg.param(hx.data(), hx.size() * sizeof(ExactTap));
+        const ExactTap* dy = (const ExactTap*)stg.param(hy.data(), hy.size() * sizeof(ExactTap));
+        if (!dx || !dy) return MI355CV_NOT_IMPLEMENTED;
+        dim3 g7(divUp(dst_width * cn, 64), divUp(dst_height, 4));
+        if (depth == D8U) hipLaunchKernelGGL((k_resize_exact<uchar, 8>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
+        else if (depth == D16U) hipLaunchKernelGGL((k_resize_exact<unsigned short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
+        else hipLaunchKernelGGL((k_resize_exact<short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
         return stg.finish(entry);
     }
     if (a.mode == 4) {

@@ -166,3 +166,19 @@ void orc_cvtBGRtoYUV32f(const float* src, size_t sstepBytes, float* dst, size_t 
             d[0] = Y; d[1 + yuvOrder] = fmaf(s[bidx ^ 2] - Y, C3, delta); d[2 - yuvOrder] = fmaf(s[bidx] - Y, C4, delta);
         }
 }
+
+/* CV_32F inverse conversion (YCrCb2RGB_f<float> color_yuv.simd.hpp:616-689): the vector loop's fused multiply-adds, b = fma(cb, C3, y),
+ * g = fma(cr, C1, fma(cb, C2, y)), r = fma(cr, C0, y) with cb, cr already minus 0.5; the scalar tail's plain C contracts to the same forms. */
+void orc_cvtYUVtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int isCbCr)
+{
+    const int bidx = swapBlue ? 2 : 0, yuvOrder = !isCbCr;
+    const float C0 = isCbCr ? 1.403f : 1.140f, C1 = isCbCr ? -0.714f : -0.581f, C2 = isCbCr ? -0.344f : -0.395f, C3 = isCbCr ? 1.773f : 2.032f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float* s = (const float*)((const uint8_t*)src + (size_t)y * sstepBytes) + (size_t)x * 3;
+            float* d = (float*)((uint8_t*)dst + (size_t)y * dstepBytes) + (size_t)x * dcn;
+            const float Y = s[0], cr = s[1 + yuvOrder] - 0.5f, cb = s[2 - yuvOrder] - 0.5f;
+            d[bidx] = fmaf(cb, C3, Y); d[1] = fmaf(cr, C1, fmaf(cb, C2, Y)); d[bidx ^ 2] = fmaf(cr, C0, Y);
+            if (dcn == 4) d[3] = 1.f;
+        }
+}

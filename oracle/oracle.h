@@ -56,6 +56,7 @@ void orc_cvtTwoPlaneYUVtoBGR(const uint8_t* y_data, size_t y_step, const uint8_t
 void orc_cvtBGRtoYUV16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int isCbCr);
 void orc_cvtYUVtoBGR16u(const uint16_t* src, size_t sstepBytes, uint16_t* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int isCbCr);
 void orc_cvtBGRtoYUV32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int isCbCr);
+void orc_cvtYUVtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int isCbCr);
 void orc_cvtThreePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int dst_w, int dst_h, int dcn, int swapBlue, int uIdx);
 
 void orc_cvtBGRtoHSV8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange);

@@ -247,6 +247,63 @@ static int resizeLanczos4(const uint8_t* src, size_t sstep, int sw, int sh, uint
     return 0;
 }
 
+/* INTER_LINEAR_EXACT: resize_bitExact<ET, interpolationLinear<ET>> (resize.cpp:789-950) for 8U (ufixedpoint16, Q8.8), 16U (ufixedpoint32, Q16.16) and
+ * 16S (fixedpoint32).  Coordinates in softdouble there = IEEE double here: fval = scale * (d + 0.5) - 0.5, offset = floor, weight of the right / lower tap
+ * = cvRound(frac * 2^shift), the other = 2^shift - it; left of the image every output takes pixel 0, from the first offset >= size - 1 on the last
+ * pixel.  Horizontal pass exact in Q(shift), vertical pass a 2-term dot product rounded once: (v + 2^(2 shift - 1)) >> (2 shift). */
+typedef struct { int ofs; long long c1; } ExactTap;
+static void exact_taps(double inv_scale, int ssize, int dsize, int shift, ExactTap* t)
+{
+    const double scale = 1.0 / inv_scale;
+    int minofst = 0, maxofst = dsize;
+    for (int d = 0; d < dsize; d++) {
+        const double fval = scale * ((double)d + 0.5) - 0.5;
+        const int ival = cvfloor_d(fval);
+        t[d].ofs = 0; t[d].c1 = 0;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) { t[d].ofs = ival; t[d].c1 = (long long)lrint((fval - (double)ival) * (double)(1LL << shift)); }
+            else { t[d].ofs = ssize - 1; if (d < maxofst) maxofst = d; }
+        } else if (d + 1 > minofst) minofst = d + 1;
+    }
+    for (int d = 0; d < dsize; d++) {
+        if (d < minofst) { t[d].ofs = 0; t[d].c1 = 0; }
+        else if (d >= maxofst) { t[d].ofs = ssize - 1; t[d].c1 = 0; }
+    }
+}
+
+static int resizeLinearExact(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                             double inv_x, double inv_y)
+{
+    if (depth != 0 && depth != 2 && depth != 3) return 1;
+    const int shift = depth == 0 ? 8 : 16;
+    ExactTap* tx = (ExactTap*)malloc(sizeof(ExactTap) * (size_t)dw);
+    ExactTap* ty = (ExactTap*)malloc(sizeof(ExactTap) * (size_t)dh);
+    if (!tx || !ty) { free(tx); free(ty); return 1; }
+    exact_taps(inv_x, sw, dw, shift, tx);
+    exact_taps(inv_y, sh, dh, shift, ty);
+    const long long one = 1LL << shift;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+            for (int c = 0; c < cn; c++) {
+                long long H[2] = {0, 0};
+                for (int r = 0; r < 2; r++) {
+                    if (r == 1 && ty[y].c1 == 0) break;
+                    const uint8_t* row = src + (size_t)(ty[y].ofs + r) * sstep;
+                    const long long p0 = (long long)ldv(row, depth, tx[x].ofs * cn + c);
+                    const long long p1 = tx[x].c1 ? (long long)ldv(row, depth, (tx[x].ofs + 1) * cn + c) : 0;
+                    H[r] = (one - tx[x].c1) * p0 + tx[x].c1 * p1;
+                }
+                const long long v = (one - ty[y].c1) * H[0] + ty[y].c1 * H[1];
+                const long long r = (v + (1LL << (2 * shift - 1))) >> (2 * shift);
+                uint8_t* D = dst + (size_t)y * dstep;
+                if (depth == 0) D[x * cn + c] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+                else if (depth == 2) ((uint16_t*)D)[x * cn + c] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+                else ((int16_t*)D)[x * cn + c] = (int16_t)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+            }
+    free(tx); free(ty);
+    return 0;
+}
+
 int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                int depth, int cn, double inv_scale_x, double inv_scale_y, int interpolation)
 {
@@ -266,6 +323,10 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
             }
         }
         return 0;
+    }
+    if (interpolation == 5) {                                   /* INTER_LINEAR_EXACT, resize.cpp:3976-3990 */
+        if (is_area_fast && iscale_x == 2 && iscale_y == 2 && cn != 2) interpolation = 3;
+        else return resizeLinearExact(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, inv_scale_x, inv_scale_y);
     }
     if (interpolation == 1 && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = 3;
     if (interpolation == 3 && scale_x >= 1 && scale_y >= 1) {

@@ -1089,3 +1089,20 @@ def orc_FAST_nms(scores):
     dst = np.empty_like(scores)
     o.orc_FAST_nms(P(scores), step(scores), P(dst), step(dst), w, h)
     return dst
+
+
+def orc_cvtColorYUVwide(src, code, dcn=3):
+    """BGR <-> YUV / YCrCb on CV_16U / CV_32F images (codes 82, 83, 36, 37 forward; 84, 85, 38, 39 inverse)"""
+    o = oracle()
+    h, w = src.shape[:2]
+    fwd = {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}
+    inv = {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}
+    if code in fwd:
+        swap, cb = fwd[code]
+        dst = np.empty((h, w, 3), src.dtype)
+        (o.orc_cvtBGRtoYUV16u if src.dtype == np.uint16 else o.orc_cvtBGRtoYUV32f)(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, cb)
+    else:
+        swap, cb = inv[code]
+        dst = np.empty((h, w, dcn), src.dtype)
+        (o.orc_cvtYUVtoBGR16u if src.dtype == np.uint16 else o.orc_cvtYUVtoBGR32f)(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, cb)
+    return dst

@@ -201,3 +201,14 @@ def test_warp_polar_forward(orc, ref, dtype):
     for flags in (1, 1 | 8, 0 | 8, 1 | 256, 1 | 256 | 8):
         for dsize, center, rad in [((64, 90), (40.0, 30.0), 35.0), ((50, 157), (10.5, 50.25), 60.0)]:
             same(orc, orc.orc_warpPolar(src, dsize, center, rad, flags), orc.ref_warpPolar(src, dsize, center, rad, flags))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_resize_linear_exact(orc, ref, dtype, cn):
+    """INTER_LINEAR_EXACT (resize_bitExact, resize.cpp:789-950): up, down, exactly half (the 2x2 area mean, except for 2 channels), 1x1, thin"""
+    src = rnd(orc, (37, 53, cn) if cn > 1 else (37, 53), dtype, 7 + cn)
+    for dsize in [(80, 60), (20, 11), (53, 37), (106, 74), (26, 18), (27, 19), (1, 1), (200, 5), (7, 90)]:
+        assert np.array_equal(orc.orc_resize(src, dsize, interpolation=5), orc.ref_resize(src, dsize, interpolation=5)), (dsize, dtype, cn)
+    one = rnd(orc, (1, 9, cn) if cn > 1 else (1, 9), dtype, 3)
+    assert np.array_equal(orc.orc_resize(one, (20, 4), interpolation=5), orc.ref_resize(one, (20, 4), interpolation=5))

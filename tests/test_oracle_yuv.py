@@ -91,3 +91,20 @@ def test_yuv_32f_forward_matches_reference():
                 assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
                 o.oracle().orc_cvtBGRtoYUV32f(o.P(src), o.step(src), o.P(got), o.step(got), w, h, scn, swap, cb)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, scn, code)
+
+
+def test_yuv_32f_inverse_matches_reference():
+    """CV_32F YUV / YCrCb -> BGR(A): bit for bit"""
+    import orc as o
+    if o.load_ref() is None:
+        pytest.skip("oracle/_ref/libocvref.so not built")
+    rng = np.random.default_rng(4)
+    r = o.load_ref()
+    for (w, h) in [(1, 1), (7, 3), (33, 5), (643, 48)]:
+        src = rng.random((h, w, 3), dtype=np.float32)
+        for code in (84, 85, 38, 39):
+            for dcn in (3, 4):
+                want = np.empty((h, w, dcn), np.float32)
+                assert r.ref_cvtColorSz(o.P(src), o.step(src), w, h, o.cvtype(src), o.P(want), o.step(want), w, h, o.cvtype(want), code) == 0
+                got = o.orc_cvtColorYUVwide(src, code, dcn)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, dcn, code)

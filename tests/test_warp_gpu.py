@@ -277,3 +277,20 @@ def test_warp_polar_forward(cv, orc, dtype):
         cv.warpPolar(dev(src), (64, 90), (40.0, 30.0), 35.0, 1 | 16)
     big = rnd((1080, 1920), np.uint8, 42)
     check(cv.warpPolar(dev(big), (1024, 2048), (960.0, 540.0), 600.0, 1 | 8), orc.orc_warpPolar(big, (1024, 2048), (960.0, 540.0), 600.0, 1 | 8))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_resize_linear_exact(cv, orc, dtype, cn):
+    """INTER_LINEAR_EXACT on the GPU = the reference's fixed-point arithmetic, bit-exact (Resize_Bitexact.Linear8U of the reference's own test binary
+    now exercises this kernel instead of falling back)"""
+    src = rnd((37, 53, cn) if cn > 1 else (37, 53), dtype, 7 + cn)
+    for dsize in [(80, 60), (20, 11), (53, 37), (106, 74), (26, 18), (27, 19), (1, 1), (200, 5), (7, 90)]:
+        assert np.array_equal(cv.resize(dev(src), dsize, interpolation=5).cpu().numpy(), orc.orc_resize(src, dsize, interpolation=5)), (dsize, dtype, cn)
+    big = rnd((1080, 1920, cn) if cn > 1 else (1080, 1920), dtype, 9)
+    assert np.array_equal(cv.resize(dev(big), (1280, 720), interpolation=5).cpu().numpy(), orc.orc_resize(big, (1280, 720), interpolation=5))
+    fr = torch.from_numpy(np.stack([src, src[::-1].copy()])).cuda()
+    got = cv.resizeBatch(fr, (80, 60), interpolation=5)
+    assert np.array_equal(got[1].cpu().numpy(), orc.orc_resize(np.ascontiguousarray(src[::-1]), (80, 60), interpolation=5))
+    with pytest.raises(NotImplementedError):
+        cv.resize(dev(rnd((20, 30), np.float32, 1)), (40, 60), interpolation=5)

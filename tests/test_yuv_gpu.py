@@ -43,3 +43,23 @@ def test_nv12_nv21(cv, orc):
     assert np.array_equal(cv.cvtColor(src, cv.COLOR_YUV2BGR_NV12), orc.orc_cvtColorYUV(src, 91))                   # host pointers
     with pytest.raises(ValueError):
         cv.cvtColor(torch.zeros((35, 40), dtype=torch.uint8, device="cuda"), cv.COLOR_YUV2BGR_NV12)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_yuv_wide_depths(cv, orc, dtype):
+    """CV_16U (integer formulas, bit-exact) and CV_32F (<= 1e-4 relative; the forward restatement follows the reference's vector body / scalar tail
+    split, the kernel uses the body's form everywhere) members of the YUV / YCrCb family, both directions, 3 and 4 channels"""
+    rng = np.random.default_rng(8)
+    for (w, h) in [(1, 1), (7, 3), (33, 5), (643, 48), (1920, 1080)]:
+        for scn in (3, 4):
+            src = rng.integers(0, 65536, (h, w, scn), dtype=np.uint16) if dtype == np.uint16 else rng.random((h, w, scn), dtype=np.float32)
+            for code in (82, 83, 36, 37):
+                got = cv.cvtColor(torch.from_numpy(src).cuda(), code).cpu().numpy()
+                want = orc.orc_cvtColorYUVwide(src, code)
+                assert (np.array_equal(got, want) if dtype == np.uint16 else orc.rel_err(got, want) <= 1e-6), (w, h, scn, code)
+        src = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16) if dtype == np.uint16 else rng.random((h, w, 3), dtype=np.float32)
+        for code in (84, 85, 38, 39):
+            for dcn in (3, 4):
+                got = cv.cvtColor(torch.from_numpy(src).cuda(), code, dstCn=dcn).cpu().numpy()
+                want = orc.orc_cvtColorYUVwide(src, code, dcn)
+                assert (np.array_equal(got, want) if dtype == np.uint16 else orc.rel_err(got, want) <= 1e-6), (w, h, dcn, code)
