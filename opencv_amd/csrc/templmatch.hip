@@ -287,7 +287,7 @@ constexpr int MT_PPITCH = 272;                 // LDS image patch pitch: 256 col
 constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero bytes + 128 + 40 zero bytes
 
 // ---------------------------------------------------------------------------------- common_matchTemplate
-struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW; double tmean[4], templNorm, templSum2, invArea; };
+struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW, wp; double tmean[4], templNorm, templSum2, invArea; };
 
 // one result element of common_matchTemplate (templmatch.cpp:906-1029) for a single-channel window: corr = the raw
 // correlation as float, s = window sum, q = window sum of squares.  Written without branches (every alternative is computed
@@ -457,6 +457,227 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 }
 
+// ---- the same correlation with two workgroups per CU ----------------------------------------------------------------------------
+// k_ccorr_mfma_i8 keeps the whole (MT_BM + th - 1)-row patch in LDS: 130 KB, one workgroup and one wave per SIMD, so staging, MFMA
+// loop and epilogue of a CU run strictly one after the other and every stall inside the loop is exposed.  A wave, however, only ever
+// needs a 32-row window of the image (rows R0 + j + m for template-row step j) sliding down by one row per step.  Here each wave
+// keeps that window in a private ring of RG_RING rows: per step it fetches one 256-byte row from L2 (one dword per lane, two steps
+// ahead), writes it into the slot of the row that just left the window, and reads its A fragments from the ring.  No barrier after
+// the template is staged; 4 x 10.9 KB of rings + 25.6 KB of template = 69 KB, so two workgroups (two waves per SIMD) share a CU and
+// one's staging / epilogue / LDS waits hide under the other's matrix instructions.
+// Registers: 256 per wave at this occupancy, 128 of them accumulators, so operands are single-buffered and re-loaded in place as
+// soon as their last MFMA of the step has issued (A block c dies after K step c, the raw B dwords of K step ks right after their
+// byte alignment), which gives the same prefetch distance as a second register set.
+// Window sums (SUMS): the bias removal and the normalisation need, per output, the sums of I and I^2 over its tw x th window.  Every
+// image row already passes through the wave's registers on its way into the ring, four columns per lane, so the wave keeps running
+// column sums over the last th rows (add the row entering, subtract the row th above, re-read from L2) and, once per output row, turns
+// them into window sums with a prefix scan over the lanes (P[x + tw] - P[x], via 1 KB of LDS per wave).  ~8k VALU instructions per wave
+// in the shadow of 5k MFMAs (32 cycles each); it replaces two HBM-bound kernels (k_wsum_rows / k_wsum_cols, 70 us per 4K frame), which
+// cannot run beside this kernel because its two workgroups own every VGPR of the CU.  Needs th >= 66 so that the first output row
+// (image row th-1 entering) falls after tile 1 has started (step 32) - fewer loop variants.
+#ifndef RG_SCHED_ON
+#define RG_SCHED_ON 0
+#endif
+constexpr int RG_RING = 40, RG_RP = 272;
+constexpr int RG_WSCR = 1024;                   // per-wave LDS scratch for the prefix row (SUMS)
+
+__device__ __forceinline__ unsigned tmWaveScanIncl(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+struct RingSums { unsigned* w1; unsigned* w2; int wp; int rw; int rh; int tw; uchar* wscr; };
+
+template <int KS, bool FASTROW, bool SUMS>
+__device__ __forceinline__ void ccorrRingBody(const uchar* __restrict__ img, size_t istep, int iw, int ih, const uchar* T, uchar* ring, int th,
+                                              int X0, int R0, int lane, v16i (&acc)[2][4], const RingSums& ws)
+{
+    constexpr int NA = KS + 3;
+    const int m = lane & 31, h = lane >> 5;
+    const int xx = X0 + 4 * lane;
+    // Pixels right of the image / below it only ever meet outputs outside the result (or zero taps): clamp the address, keep whatever
+    // it holds.  FASTROW (4-byte aligned rows, iw % 4 == 0): one dword per lane, no lane straddles the right edge.  The bias flip
+    // (u8 -> s8) waits until the value goes into the ring, so that nothing touches the load's register while it is in flight.
+    const unsigned xc = (unsigned)min(xx, iw - 4);               // unsigned: uniform row pointer + 32-bit lane offset
+    auto loadRow = [&](int q) -> unsigned {
+        const uchar* g = img + (size_t)min(R0 + q, ih - 1) * istep;
+        if (FASTROW) return *reinterpret_cast<const unsigned*>(g + xc);
+        return (unsigned)g[(unsigned)min(xx, iw - 1)] | ((unsigned)g[(unsigned)min(xx + 1, iw - 1)] << 8) | ((unsigned)g[(unsigned)min(xx + 2, iw - 1)] << 16) |
+               ((unsigned)g[(unsigned)min(xx + 3, iw - 1)] << 24);
+    };
+    int bOff[KS], bSh[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) { const int o = 32 + 32 * ks + 16 * h - m; bOff[ks] = o & ~3; bSh[ks] = o & 3; }
+    unsigned C1[4] = {0, 0, 0, 0}, C2[4] = {0, 0, 0, 0};         // column sums of I, I^2 over the last th rows (SUMS)
+    auto addRow = [&](unsigned v) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const unsigned bb = (v >> (8 * i)) & 255u; C1[i] += bb; C2[i] += bb * bb; }
+    };
+    // row a enters the column sums, row b leaves: I by the difference, I^2 as (a - b)(a + b).  (Written as "+= a*a" followed by
+    // "-= b*b" hipcc 7.2 folds the pair into one v_dot4_u32_u8 of (a, b) with itself, i.e. it ADDS b*b.)
+    auto slideRow = [&](unsigned va, unsigned vb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int a = (int)((va >> (8 * i)) & 255u), b = (int)((vb >> (8 * i)) & 255u);
+            const int d = a - b;
+            C1[i] += (unsigned)d; C2[i] += (unsigned)(d * (a + b));
+        }
+    };
+    // window sums of output row y (relative to R0) from the column sums: P = exclusive prefix over the wave's 256 columns
+    auto emitRow = [&](int y) {
+        const int yy = R0 + y;
+        const bool st = lane < 32 && yy < ws.rh && xx < ws.rw;     // wp is a multiple of 4 and >= rw: the whole quad fits the row
+        const unsigned o = (unsigned)yy * (unsigned)ws.wp + (unsigned)xx;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned* C = k ? C2 : C1;
+            const unsigned p1 = C[0], p2 = p1 + C[1], p3 = p2 + C[2], t = p3 + C[3];
+            const unsigned E = tmWaveScanIncl(t) - t;
+            const uint4 D = make_uint4(E, E + p1, E + p2, E + p3);
+            *reinterpret_cast<uint4*>(ws.wscr + 16 * lane) = D;
+            const unsigned rdo = 4 * ((4 * lane + ws.tw) & 255);
+            uint4 W;
+            W.x = *reinterpret_cast<const unsigned*>(ws.wscr + rdo) - D.x;
+            W.y = *reinterpret_cast<const unsigned*>(ws.wscr + ((rdo + 4) & 1023)) - D.y;
+            W.z = *reinterpret_cast<const unsigned*>(ws.wscr + ((rdo + 8) & 1023)) - D.z;
+            W.w = *reinterpret_cast<const unsigned*>(ws.wscr + ((rdo + 12) & 1023)) - D.w;
+            if (st) *reinterpret_cast<uint4*>((k ? ws.w2 : ws.w1) + o) = W;
+        }
+    };
+    // prologue: rows 0..32 of the window (step 0 reads rows 0..31, and fetches the fragment of step 1 = rows 1..32)
+    {
+        constexpr int PB = 11;
+#pragma unroll
+        for (int q0 = 0; q0 < 33; q0 += PB) {
+            unsigned v[PB];
+#pragma unroll
+            for (int u = 0; u < PB; u++) v[u] = loadRow(q0 + u);
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                *reinterpret_cast<unsigned*>(ring + (q0 + u) * RG_RP + 4 * lane) = v[u] ^ 0x80808080u;
+                if (SUMS) addRow(v[u]);
+            }
+        }
+    }
+    unsigned ga = loadRow(33), gb = loadRow(34);
+    unsigned oa = SUMS ? loadRow(max(33 - th, 0)) : 0u;         // the row leaving the column sums at step 0 (none while 33 < th)
+    int wslot = 33;                                              // slot of the next row to write (row j + 33 at step j)
+    int aoff = m * RG_RP + 16 * h;                               // this lane's row (j + m) of the fragment being fetched
+    constexpr int RINGB = RG_RING * RG_RP;
+    v4i A[NA]; unsigned Rr0[KS][5], Rr1[KS][5];
+    auto loadRawK = [&](unsigned (&R)[5], int r, int ks) {
+        const unsigned* tp = reinterpret_cast<const unsigned*>(T + (size_t)r * MT_TPITCH + bOff[ks]);
+#pragma unroll
+        for (int d = 0; d < 5; d++) R[d] = tp[d];
+    };
+    auto alignB = [&](const unsigned (&R)[5], int sh) -> v4i {
+        v4i B;
+        B.x = (int)__builtin_amdgcn_alignbyte(R[1], R[0], sh); B.y = (int)__builtin_amdgcn_alignbyte(R[2], R[1], sh);
+        B.z = (int)__builtin_amdgcn_alignbyte(R[3], R[2], sh); B.w = (int)__builtin_amdgcn_alignbyte(R[4], R[3], sh);
+        return B;
+    };
+#pragma unroll
+    for (int cb = 0; cb < NA; cb++) A[cb] = *reinterpret_cast<const v4i*>(ring + aoff + 32 * cb);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) { loadRawK(Rr0[ks], 0, ks); loadRawK(Rr1[ks], 0, ks); }
+    aoff += RG_RP;                                               // m <= 31 < RG_RING - 1: no wrap yet
+
+    // one step: the MFMAs of template-row offset j on the operands in registers; meanwhile row j+33 goes into the ring, row j+35 is
+    // requested, and the operands of step j+1 replace the ones just consumed
+#define RG_STEP(T0_, T1_, OUT_) do { \
+        *reinterpret_cast<unsigned*>(ring + wslot * RG_RP + 4 * lane) = ga ^ 0x80808080u; \
+        if (SUMS) { slideRow(ga, j + 33 >= th ? oa : 0u); oa = loadRow(max(j + 34 - th, 0)); if (OUT_) emitRow(j + 34 - th); } \
+        ga = gb; gb = loadRow(j + 35); \
+        wslot = wslot + 1 == RG_RING ? 0 : wslot + 1; \
+        const int r0n = min(j + 1, th - 1), r1n = min(max(j - 31, 0), th - 1); \
+        const uchar* an = ring + aoff; \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) { \
+            v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}; \
+            if (T0_) b0 = alignB(Rr0[ks], bSh[ks]); if (T1_) b1 = alignB(Rr1[ks], bSh[ks]); \
+            loadRawK(Rr0[ks], r0n, ks); loadRawK(Rr1[ks], r1n, ks); \
+            _Pragma("unroll") for (int nt = 0; nt < 4; nt++) { \
+                if (T0_) acc[0][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[nt + ks], b0, acc[0][nt], 0, 0, 0); \
+                if (T1_) acc[1][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[nt + ks], b1, acc[1][nt], 0, 0, 0); } \
+            A[ks] = *reinterpret_cast<const v4i*>(an + 32 * ks); } \
+        _Pragma("unroll") for (int cb = KS; cb < NA; cb++) A[cb] = *reinterpret_cast<const v4i*>(an + 32 * cb); \
+        aoff += RG_RP; aoff = aoff >= RINGB ? aoff - RINGB : aoff; } while (0)
+    // issue order (experiment, RG_SCHED_ON): the ring write and the row request first, then per K step its byte alignments and its
+    // MFMAs with two LDS reads slotted after every pair (both tiles) / every one.  Measured: no difference with two waves per SIMD.
+#define RG_SCHED(T0_, T1_) do { if (RG_SCHED_ON && !SUMS) { \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, FASTROW ? 1 : 4, 0); \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) { \
+            __builtin_amdgcn_sched_group_barrier(0x002, ((T0_) && (T1_)) ? 8 : 4, 0); \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { \
+                __builtin_amdgcn_sched_group_barrier(0x008, ((T0_) && (T1_)) ? 2 : 1, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } } } } while (0)
+    int j = 0;
+    if (SUMS) {
+        // th >= 66: output row y = j + 34 - th is in [0, 64) for j in [th - 34, th + 30), which starts inside the both-tiles phase
+        for (; j < 32; j++) RG_STEP(true, false, false);
+        for (; j < th - 34; j++) RG_STEP(true, true, false);
+        for (; j < th; j++) RG_STEP(true, true, true);
+        for (; j < th + 30; j++) RG_STEP(false, true, true);
+        for (; j < th + 32; j++) RG_STEP(false, true, false);
+    } else {
+        for (; j < min(th, 32); j++) { RG_STEP(true, false, false); RG_SCHED(true, false); }
+        for (; j < 32; j++) RG_STEP(false, false, false);        // th < 32: the window keeps sliding until tile 1 starts
+        for (; j < th; j++) { RG_STEP(true, true, false); RG_SCHED(true, true); }
+        for (; j < th + 32; j++) { RG_STEP(false, true, false); RG_SCHED(false, true); }
+    }
+#undef RG_SCHED
+#undef RG_STEP
+}
+
+template <int KS, bool SUMS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ccorr_ring_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
+                                                       const uchar* __restrict__ tpl /* expanded: th x MT_TPITCH */, int tw, int th,
+                                                       int* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh,
+                                                       unsigned* __restrict__ w1, unsigned* __restrict__ w2, int wp, size_t wframe)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar smem[];
+    uchar* T = smem;                                             // th x MT_TPITCH signed taps, zero padded
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uchar* rings = smem + (((size_t)th * MT_TPITCH + 15) & ~(size_t)15);
+    uchar* ring = rings + (size_t)wave * (RG_RING * RG_RP);
+    img += (size_t)blockIdx.z * iframe;
+    const int X0 = blockIdx.x * MT_BN, Y0 = blockIdx.y * MT_BM, R0 = Y0 + wave * 64;
+    for (int i = tid; i < th * (MT_TPITCH / 8); i += 256)
+        reinterpret_cast<uint2*>(T)[i] = reinterpret_cast<const uint2*>(tpl)[i];
+    __syncthreads();                                             // the only barrier: from here on the waves are independent
+    v16i acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0;
+    RingSums ws;
+    ws.w1 = SUMS ? w1 + (size_t)blockIdx.z * wframe : nullptr; ws.w2 = SUMS ? w2 + (size_t)blockIdx.z * wframe : nullptr;
+    ws.wp = wp; ws.rw = rw; ws.rh = rh; ws.tw = tw; ws.wscr = rings + (size_t)4 * (RG_RING * RG_RP) + (size_t)wave * RG_WSCR;
+    const bool fastRow = (iw & 3) == 0 && ((((uintptr_t)img) | istep) & 3) == 0;
+    if (fastRow) ccorrRingBody<KS, true, SUMS>(img, istep, iw, ih, T, ring, th, X0, R0, lane, acc, ws);
+    else if (!SUMS) ccorrRingBody<KS, false, false>(img, istep, iw, ih, T, ring, th, X0, R0, lane, acc, ws);   // the host asks for SUMS on aligned rows only
+    const int m = lane & 31, h = lane >> 5;
+    uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int x = X0 + 32 * nt + m;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int y = R0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (x < rw && y < rh) reinterpret_cast<int*>(rbase + (size_t)y * rstep)[x] = acc[mt][nt][i];
+            }
+        }
+}
+
 // raw accumulators -> result: corr = acc + 128*sum_window(I) + 128*sum(T) - 128^2*tw*th (exact), then common_matchTemplate
 __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size_t rstep, size_t rframe, const unsigned* __restrict__ w1,
                                                    const unsigned* __restrict__ w2, size_t wframe, long long cst, NormArgs a)
@@ -471,8 +692,8 @@ __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size
     for (int u = 0; u < 4; u++) {
         const int y = min(y0 + u, a.rh - 1);
         raw[u] = *reinterpret_cast<const int*>(reinterpret_cast<const uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep + 4 * (size_t)x);
-        ws[u] = w1[(size_t)y * a.rw + x];
-        wq[u] = needQ ? w2[(size_t)y * a.rw + x] : 0u;
+        ws[u] = w1[(size_t)y * a.wp + x];
+        wq[u] = needQ ? w2[(size_t)y * a.wp + x] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -589,21 +810,29 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         integralColumns<double>(dsum, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
         integralColumns<double>(dsq, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
     }
-    const size_t wframe = (size_t)rw * rh, s1frame = (size_t)rw * ih;
+    const size_t s1frame = (size_t)rw * ih;
     if (useMfma) {
-        // Per frame three memory-bound kernels (window sums of I and I^2, then bias removal + normalisation) and one MFMA kernel.
-        // The MFMA kernel occupies every CU with one workgroup (130 KB LDS, 4 waves) and touches memory only at its ends, so
-        // the others run beside it on an auxiliary stream: sums of frame f+1 and the finish of frame f-1 under the MFMAs of f.
-        unsigned* s1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
-        unsigned* q1 = (unsigned*)stg.scratch(s1frame * nframes * 4);
+        // Per frame: the MFMA kernel, window sums of I and I^2, and the bias removal + normalisation (k_tm_finish).
+        //  * ring kernel with th >= 66 (the default): the window sums come out of the MFMA kernel itself; frames go in chunks of up to
+        //    four per launch (two workgroups of different frames per CU), and the finish of one chunk runs on the auxiliary stream.
+        //  * otherwise two memory-bound kernels (k_wsum_rows / k_wsum_cols) on the auxiliary stream, under the MFMAs.
+        static const bool ringOff = std::getenv("MI355CV_TM_RING") && atoi(std::getenv("MI355CV_TM_RING")) == 0;
+        static const bool fuseOff = std::getenv("MI355CV_TM_FUSE") && atoi(std::getenv("MI355CV_TM_FUSE")) == 0;
+        static const int chunkEnv = std::getenv("MI355CV_TM_CHUNK") ? atoi(std::getenv("MI355CV_TM_CHUNK")) : 0;
+        const bool ringK = !ringOff && iw >= 4;
+        const bool fused = ringK && !fuseOff && th >= 66 && (iw & 3) == 0 && ((((uintptr_t)di) | dis | (nframes > 1 ? iframe : 0)) & 3) == 0;
+        const int wp = fused ? (rw + 3) & ~3 : rw;
+        const size_t wframe = (size_t)wp * rh;
+        unsigned* s1 = fused ? nullptr : (unsigned*)stg.scratch(s1frame * nframes * 4);
+        unsigned* q1 = fused ? nullptr : (unsigned*)stg.scratch(s1frame * nframes * 4);
         unsigned* w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
         unsigned* w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
         // signed, zero-padded copy of the template in the kernel's LDS layout
         std::vector<uchar> tx((size_t)th * MT_TPITCH, 0);
         for (int r = 0; r < th; r++) for (int j = 0; j < tw; j++) tx[(size_t)r * MT_TPITCH + 32 + j] = (uchar)(th_host[(size_t)r * tw + j] ^ 0x80);
         const uchar* dtx = (const uchar*)stg.param(tx.data(), tx.size());
-        if (!s1 || !q1 || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
-        na.useW = 1;
+        if ((!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
+        na.useW = 1; na.wp = wp;
         const bool serial = std::getenv("MI355CV_TM_SERIAL") != nullptr;            // experiments: everything on one stream
         hipStream_t aux = serial ? st : auxStream();
         hipEvent_t evIn = pooledEvent(0), evDone = pooledEvent(1);
@@ -613,26 +842,36 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         const int KS = (tw + 62) / 32;
         (void)hipEventRecord(evIn, st);                               // inputs (staged copies, template) are ordered on the main stream
         (void)hipStreamWaitEvent(aux, evIn, 0);
-        for (int f = 0; f < nframes; f++) {
+        for (int f = 0; f < nframes && !fused; f++) {
             const uchar* dif = di + (size_t)f * iframe;
             hipLaunchKernelGGL(k_wsum_rows, dim3(ih, 1, 1), dim3(256), (size_t)(iw + 1) * 4, aux, dif, dis, 0, iw, tw, rw, s1 + f * s1frame, q1 + f * s1frame, s1frame);
             hipLaunchKernelGGL(k_wsum_cols, dim3(divUp(rw, 256), divUp(rh, WS_CH), 1), dim3(256), 0, aux, s1 + f * s1frame, q1 + f * s1frame, s1frame, th, rw, rh,
                                w1 + f * wframe, w2 + f * wframe, wframe);
         }
-        for (int f = 0; f < nframes; f++) {
+        // frames per MFMA launch
+        const int chunk = ringK ? std::max(1, std::min(chunkEnv > 0 ? chunkEnv : 4, nframes)) : 1;
+        const size_t ldsRing = (((size_t)th * MT_TPITCH + 15) & ~(size_t)15) + (size_t)4 * RG_RING * RG_RP + (size_t)4 * RG_WSCR;
+        for (int f = 0, c = 0; f < nframes; f += chunk, c++) {
+            const int nf = std::min(chunk, nframes - f);
             const uchar* dif = di + (size_t)f * iframe;
             int* rf = reinterpret_cast<int*>(dr + (size_t)f * rframe);
-            dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), 1);
-#define MFMA_LAUNCH(KS_) do { static bool attrSet = false; \
-            if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; } \
-            hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, dif, dis, 0, iw, ih, dtx, tw, th, rf, drs, 0, rw, rh); } while (0)
+            dim3 grid(divUp(rw, MT_BN), divUp(rh, MT_BM), nf);
+#define MFMA_LAUNCH(KS_) do { static bool attrSet[16] = {}; const int dv_ = activeDevice() & 15; \
+            if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_mfma_i8<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_ring_i8<KS_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_ring_i8<KS_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attrSet[dv_] = true; } \
+            if (fused) hipLaunchKernelGGL((k_ccorr_ring_i8<KS_, true>), grid, dim3(256), ldsRing, st, dif, dis, iframe, iw, ih, dtx, tw, th, rf, drs, rframe, rw, rh, \
+                                          w1 + f * wframe, w2 + f * wframe, wp, wframe); \
+            else if (ringK) hipLaunchKernelGGL((k_ccorr_ring_i8<KS_, false>), grid, dim3(256), ldsRing, st, dif, dis, iframe, iw, ih, dtx, tw, th, rf, drs, rframe, rw, rh, \
+                                               (unsigned*)nullptr, (unsigned*)nullptr, 0, (size_t)0); \
+            else hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, dif, dis, 0, iw, ih, dtx, tw, th, rf, drs, 0, rw, rh); } while (0)
             switch (KS) { case 1: MFMA_LAUNCH(1); break; case 2: MFMA_LAUNCH(2); break; case 3: MFMA_LAUNCH(3); break; case 4: MFMA_LAUNCH(4); break; default: MFMA_LAUNCH(5); }
 #undef MFMA_LAUNCH
-            hipEvent_t evM = pooledEvent(2 + f % 62);
+            hipEvent_t evM = pooledEvent(2 + c % 62);
             if (!evM) return MI355CV_ERROR_UNKNOWN;
             (void)hipEventRecord(evM, st);
             (void)hipStreamWaitEvent(aux, evM, 0);
-            hipLaunchKernelGGL(k_tm_finish, dim3(divUp(rw, 64), divUp(rh, 16), 1), dim3(256), 0, aux, reinterpret_cast<float*>(rf), drs, 0,
+            hipLaunchKernelGGL(k_tm_finish, dim3(divUp(rw, 64), divUp(rh, 16), nf), dim3(256), 0, aux, reinterpret_cast<float*>(rf), drs, rframe,
                                w1 + f * wframe, w2 + f * wframe, wframe, cst, na);
         }
         (void)hipEventRecord(evDone, aux);

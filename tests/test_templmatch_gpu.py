@@ -51,6 +51,25 @@ def test_mfma_path_8uc1(cv, orc, method):
             assert orc.rel_err(got, want) <= 1e-6, (iw, ih, tw, th)
 
 
+@pytest.mark.parametrize("method", [1, 3, 4, 5])
+def test_mfma_fused_window_sums(cv, orc, method):
+    """templates of >= 66 rows on 4-byte aligned rows: the window sums of I and I^2 come out of the MFMA kernel itself (running column
+    sums + a lane prefix scan per output row); several row blocks, widths that leave partial tiles, template widths that are not
+    multiples of 4, and the smallest / an odd template height"""
+    for (iw, ih, tw, th) in [(516, 700, 128, 128), (640, 480, 100, 66), (772, 400, 57, 127), (260, 330, 128, 67)]:
+        img = rnd((ih, iw), np.uint8, 30 + iw)
+        tpl = rnd((th, tw), np.uint8, 40 + tw)
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        assert orc.rel_err(got, want) <= 1e-6, (iw, ih, tw, th)
+    # the same frames through the batch entry (two workgroups of different frames per CU)
+    frames = np.stack([rnd((300, 640), np.uint8, 50 + k) for k in range(5)])
+    tpl = rnd((96, 80), np.uint8, 60)
+    rb = cv.matchTemplateBatch(dev(frames), dev(tpl), method).cpu().numpy()
+    for k in range(5):
+        assert orc.rel_err(rb[k], orc.orc_matchTemplate(frames[k], tpl, method)) <= 1e-6, k
+
+
 def test_template_found_and_batch(cv, orc):
     img = rnd((480, 640), np.uint8, 7)
     tpl = np.ascontiguousarray(img[100:228, 200:328])
