@@ -268,7 +268,7 @@ def multi_gpu_legs(cv, dist, dev, rank, world):
     rows.append({"config": f"cfg4 cornerHarris(2,3,0.04) + buildPyramid(4), 256 x 1080p 8UC1 sharded {hi - lo} frames / GPU", "n_gpus": world,
                  "ms_per_pass": round(s * 1e3, 4), "frames_s": round(256 / s, 1)})
     del fr, resp
-    B5 = 4
+    B5 = 8
     img = torch.randint(0, 256, (B5, H4K, W4K), dtype=torch.uint8, device=dev, generator=g)
     tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g)
     dist.broadcast(tpl, src=0)                                                   # the one shared template (16 KB) over RCCL

@@ -287,7 +287,7 @@ constexpr int MT_PPITCH = 272;                 // LDS image patch pitch: 256 col
 constexpr int MT_TPITCH = 200;                 // LDS template pitch: 32 zero bytes + 128 + 40 zero bytes
 
 // ---------------------------------------------------------------------------------- common_matchTemplate
-struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW, wp; double tmean[4], templNorm, templSum2, invArea; };
+struct NormArgs { int method, cn, tw, th, rw, rh, allOne, useW, wp; long long cst; double tmean[4], templNorm, templSum2, invArea; };
 
 // one result element of common_matchTemplate (templmatch.cpp:906-1029) for a single-channel window: corr = the raw
 // correlation as float, s = window sum, q = window sum of squares.  Written without branches (every alternative is computed
@@ -638,7 +638,8 @@ template <int KS, bool SUMS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ccorr_ring_i8(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int ih,
                                                        const uchar* __restrict__ tpl /* expanded: th x MT_TPITCH */, int tw, int th,
                                                        int* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh,
-                                                       unsigned* __restrict__ w1, unsigned* __restrict__ w2, int wp, size_t wframe)
+                                                       unsigned* __restrict__ w1, unsigned* __restrict__ w2, int wp, size_t wframe,
+                                                       int fin, const NormArgs* __restrict__ nap)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
     uchar* T = smem;                                             // th x MT_TPITCH signed taps, zero padded
@@ -665,6 +666,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else if (!SUMS) ccorrRingBody<KS, false, false>(img, istep, iw, ih, T, ring, th, X0, R0, lane, acc, ws);   // the host asks for SUMS on aligned rows only
     const int m = lane & 31, h = lane >> 5;
     uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;
+    if (SUMS && fin) {
+        // The finish in place: this wave wrote the window sums of exactly its 64 x 128 outputs (same wave, same addresses: the
+        // loads below follow those stores through the same L1 / L2 path), so bias removal and normalisation (k_tm_finish's
+        // arithmetic) run on the accumulators and the float result is stored once.  ~13k cycles of f64 per wave, under the other
+        // workgroup's MFMAs.
+        const NormArgs na = *nap;
+        const long long cst = na.cst;
+        const bool needQ = na.method != 2 && na.method != 4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);                               // the wave's own w1 / w2 stores have left
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int x = X0 + 32 * nt + m;
+                const unsigned xcl = (unsigned)min(x, rw - 1);
+                unsigned a1[16], a2[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int y = min(R0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h, rh - 1);
+                    const unsigned o = (unsigned)y * (unsigned)wp + xcl;
+                    a1[i] = ws.w1[o]; a2[i] = needQ ? ws.w2[o] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int y = R0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)a1[i] + cst;
+                    float v = (float)(double)corr;
+                    if (na.method != 2) v = tmNormOne(v, (double)a1[i], (double)a2[i], na);
+                    if (x < rw && y < rh) reinterpret_cast<float*>(rbase + (size_t)y * rstep)[x] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -680,8 +715,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // raw accumulators -> result: corr = acc + 128*sum_window(I) + 128*sum(T) - 128^2*tw*th (exact), then common_matchTemplate
 __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size_t rstep, size_t rframe, const unsigned* __restrict__ w1,
-                                                   const unsigned* __restrict__ w2, size_t wframe, long long cst, NormArgs a)
+                                                   const unsigned* __restrict__ w2, size_t wframe, const NormArgs* __restrict__ ap)
 {
+    const NormArgs a = *ap;
+    const long long cst = a.cst;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
     if (x >= a.rw) return;
@@ -706,8 +743,9 @@ __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size
 }
 
 __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, size_t rstep, size_t rframe,
-                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, NormArgs a)
+                                                      const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, const NormArgs* __restrict__ ap)
 {
+    const NormArgs a = *ap;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.rw || y >= a.rh) return;
@@ -742,7 +780,59 @@ __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, s
     rrow[x] = (float)num;
 }
 
-double pxHost(const uchar* p, int depth, int idx) { return depth == D8U ? (double)p[idx] : (double)reinterpret_cast<const float*>(p)[idx]; }
+// template statistics on the device (cv::meanStdDev, templmatch.cpp:931-958, and the constants common_matchTemplate derives from them,
+// :960-985): one workgroup, so that a device-resident template never has to visit the host and the call stays asynchronous.  Also
+// writes the MFMA kernels' copy of an 8UC1 template: (t - 128) as int8, MT_TPITCH bytes per row, 32 zero bytes in front, zeros behind.
+__global__ __launch_bounds__(256) void k_tm_tstats(const uchar* __restrict__ tpl, size_t tstep, int depth, NormArgs* __restrict__ ap, uchar* __restrict__ tx)
+{
+    __shared__ double red[2][4][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tw = ap->tw, th = ap->th, cn = ap->cn, method = ap->method;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int i = tid; i < tw * th; i += 256) {
+        const int y = i / tw, x = i - y * tw;
+        const uchar* row = tpl + (size_t)y * tstep;
+        for (int c = 0; c < cn; c++) {
+            const double v = depth == D8U ? (double)row[x * cn + c] : (double)reinterpret_cast<const float*>(row)[x * cn + c];
+            s[c] += v; q[c] += v * v;
+        }
+    }
+    for (int c = 0; c < 4; c++) {
+        double a = s[c], b = q[c];
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+        if (lane == 0) { red[0][wave][c] = a; red[1][wave][c] = b; }
+    }
+    if (tx) {
+        for (int i = tid; i < th * MT_TPITCH; i += 256) {
+            const int r = i / MT_TPITCH, j = i - r * MT_TPITCH - 32;
+            tx[i] = (j >= 0 && j < tw) ? (uchar)(tpl[(size_t)r * tstep + j] ^ 0x80) : (uchar)0;
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    NormArgs na = *ap;
+    double tsdv[4] = {0, 0, 0, 0}; long long tplSum = 0;
+    for (int c = 0; c < cn; c++) {
+        const double ss = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c], qq = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (depth == D8U) tplSum += (long long)ss;
+        na.tmean[c] = ss * na.invArea;
+        const double var = qq * na.invArea - na.tmean[c] * na.tmean[c];
+        tsdv[c] = sqrt(var > 0 ? var : 0);
+    }
+    const int numType = (method == 2 || method == 3) ? 0 : (method == 4 || method == 5) ? 1 : 2;
+    if (method != 4) {
+        na.templNorm = tsdv[0] * tsdv[0] + tsdv[1] * tsdv[1] + tsdv[2] * tsdv[2] + tsdv[3] * tsdv[3];
+        if (na.templNorm < DBL_EPSILON && method == 5) na.allOne = 1;
+        na.templSum2 = na.templNorm + na.tmean[0] * na.tmean[0] + na.tmean[1] * na.tmean[1] + na.tmean[2] * na.tmean[2] + na.tmean[3] * na.tmean[3];
+        if (numType != 1) { na.tmean[0] = na.tmean[1] = na.tmean[2] = na.tmean[3] = 0; na.templNorm = na.templSum2; }
+        na.templSum2 /= na.invArea;
+        na.templNorm = sqrt(na.templNorm);
+        na.templNorm /= sqrt(na.invArea);
+    }
+    na.cst = 128LL * tplSum - 16384LL * (long long)tw * th;
+    *ap = na;
+}
+
 
 int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, int nframes, int iw, int ih,
              const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method)
@@ -761,37 +851,18 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         dr = stg.out(res, rstep, (size_t)rw * 4, rh, &drs);
         if (!di || !dr) return MI355CV_NOT_IMPLEMENTED;
     } else if (!isDevicePtr(img) || !isDevicePtr(res)) return MI355CV_NOT_IMPLEMENTED;
-    // the template is tiny: bring it to the host for its statistics, and to HBM for the kernels
-    std::vector<uchar> th_host((size_t)th * tw * cn * e);
-    if (isDevicePtr(tpl)) {
-        if (hipMemcpy2D(th_host.data(), (size_t)tw * cn * e, tpl, tstep, (size_t)tw * cn * e, th, hipMemcpyDeviceToHost) != hipSuccess) return MI355CV_NOT_IMPLEMENTED;
-    } else for (int r = 0; r < th; r++) memcpy(th_host.data() + (size_t)r * tw * cn * e, tpl + (size_t)r * tstep, (size_t)tw * cn * e);
-    const uchar* dt = stg.in(th_host.data(), (size_t)tw * cn * e, (size_t)tw * cn * e, th, &dts);
+    // the template stays where it is (a host template is staged like any input); its statistics are computed on the device
+    const uchar* dt = stg.in(tpl, tstep, (size_t)tw * cn * e, th, &dts);
     if (!dt) return MI355CV_NOT_IMPLEMENTED;
-    // template statistics (cv::meanStdDev, templmatch.cpp:931-958)
     NormArgs na; memset(&na, 0, sizeof na);
     na.method = method; na.cn = cn; na.tw = tw; na.th = th; na.rw = rw; na.rh = rh;
     const double area = (double)tw * th; na.invArea = 1. / area;
-    double tsdv[4] = {0, 0, 0, 0}; long long tplSum = 0;
-    for (int c = 0; c < cn; c++) {
-        double s = 0, q = 0;
-        for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) { double v = pxHost(th_host.data() + (size_t)y * tw * cn * e, depth, x * cn + c); s += v; q += v * v; }
-        if (depth == D8U) tplSum += (long long)s;
-        na.tmean[c] = s * na.invArea;
-        double var = q * na.invArea - na.tmean[c] * na.tmean[c];
-        tsdv[c] = std::sqrt(var > 0 ? var : 0);
-    }
-    const int numType = (method == 2 || method == 3) ? 0 : (method == 4 || method == 5) ? 1 : 2;
-    if (method != 4) {
-        na.templNorm = tsdv[0] * tsdv[0] + tsdv[1] * tsdv[1] + tsdv[2] * tsdv[2] + tsdv[3] * tsdv[3];
-        if (na.templNorm < DBL_EPSILON && method == 5) na.allOne = 1;
-        na.templSum2 = na.templNorm + na.tmean[0] * na.tmean[0] + na.tmean[1] * na.tmean[1] + na.tmean[2] * na.tmean[2] + na.tmean[3] * na.tmean[3];
-        if (numType != 1) { na.tmean[0] = na.tmean[1] = na.tmean[2] = na.tmean[3] = 0; na.templNorm = na.templSum2; }
-        na.templSum2 /= na.invArea;
-        na.templNorm = std::sqrt(na.templNorm);
-        na.templNorm /= std::sqrt(na.invArea);
-    }
     hipStream_t st = stream();
+    auto uploadStats = [&](uchar* tx) -> const NormArgs* {
+        NormArgs* d = (NormArgs*)stg.param(&na, sizeof na);
+        if (d) hipLaunchKernelGGL(k_tm_tstats, dim3(1), dim3(256), 0, st, dt, dts, depth, d, tx);
+        return d;
+    };
     // integral images: needed by every method but TM_CCORR, and by the MFMA path's bias correction
     const bool useMfma = depth == D8U && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
                          (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024;
@@ -821,24 +892,24 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         static const int chunkEnv = std::getenv("MI355CV_TM_CHUNK") ? atoi(std::getenv("MI355CV_TM_CHUNK")) : 0;
         const bool ringK = !ringOff && iw >= 4;
         const bool fused = ringK && !fuseOff && th >= 66 && (iw & 3) == 0 && ((((uintptr_t)di) | dis | (nframes > 1 ? iframe : 0)) & 3) == 0;
+        static const bool finOff = std::getenv("MI355CV_TM_FIN") && atoi(std::getenv("MI355CV_TM_FIN")) == 0;
+        const bool fin = fused && !finOff;                                          // bias removal + normalisation in the MFMA kernel's epilogue
         const int wp = fused ? (rw + 3) & ~3 : rw;
         const size_t wframe = (size_t)wp * rh;
         unsigned* s1 = fused ? nullptr : (unsigned*)stg.scratch(s1frame * nframes * 4);
         unsigned* q1 = fused ? nullptr : (unsigned*)stg.scratch(s1frame * nframes * 4);
         unsigned* w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
         unsigned* w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
-        // signed, zero-padded copy of the template in the kernel's LDS layout
-        std::vector<uchar> tx((size_t)th * MT_TPITCH, 0);
-        for (int r = 0; r < th; r++) for (int j = 0; j < tw; j++) tx[(size_t)r * MT_TPITCH + 32 + j] = (uchar)(th_host[(size_t)r * tw + j] ^ 0x80);
-        const uchar* dtx = (const uchar*)stg.param(tx.data(), tx.size());
+        uchar* dtx = (uchar*)stg.scratch((size_t)th * MT_TPITCH);                // signed, zero-padded copy of the template in the kernels' LDS layout
         if ((!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
         na.useW = 1; na.wp = wp;
+        const NormArgs* dna = uploadStats(dtx);
+        if (!dna) return MI355CV_NOT_IMPLEMENTED;
         const bool serial = std::getenv("MI355CV_TM_SERIAL") != nullptr;            // experiments: everything on one stream
         hipStream_t aux = serial ? st : auxStream();
         hipEvent_t evIn = pooledEvent(0), evDone = pooledEvent(1);
         if ((!serial && !aux) || !evIn || !evDone) return MI355CV_NOT_IMPLEMENTED;
         const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
-        const long long cst = 128LL * tplSum - 16384LL * (long long)tw * th;
         const int KS = (tw + 62) / 32;
         (void)hipEventRecord(evIn, st);                               // inputs (staged copies, template) are ordered on the main stream
         (void)hipStreamWaitEvent(aux, evIn, 0);
@@ -849,7 +920,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                                w1 + f * wframe, w2 + f * wframe, wframe);
         }
         // frames per MFMA launch
-        const int chunk = ringK ? std::max(1, std::min(chunkEnv > 0 ? chunkEnv : 4, nframes)) : 1;
+        const int chunk = ringK ? std::max(1, std::min(chunkEnv > 0 ? chunkEnv : (fin ? 64 : 4), nframes)) : 1;
         const size_t ldsRing = (((size_t)th * MT_TPITCH + 15) & ~(size_t)15) + (size_t)4 * RG_RING * RG_RP + (size_t)4 * RG_WSCR;
         for (int f = 0, c = 0; f < nframes; f += chunk, c++) {
             const int nf = std::min(chunk, nframes - f);
@@ -861,27 +932,32 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_ring_i8<KS_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_ring_i8<KS_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attrSet[dv_] = true; } \
             if (fused) hipLaunchKernelGGL((k_ccorr_ring_i8<KS_, true>), grid, dim3(256), ldsRing, st, dif, dis, iframe, iw, ih, dtx, tw, th, rf, drs, rframe, rw, rh, \
-                                          w1 + f * wframe, w2 + f * wframe, wp, wframe); \
+                                          w1 + f * wframe, w2 + f * wframe, wp, wframe, fin ? 1 : 0, dna); \
             else if (ringK) hipLaunchKernelGGL((k_ccorr_ring_i8<KS_, false>), grid, dim3(256), ldsRing, st, dif, dis, iframe, iw, ih, dtx, tw, th, rf, drs, rframe, rw, rh, \
-                                               (unsigned*)nullptr, (unsigned*)nullptr, 0, (size_t)0); \
+                                               (unsigned*)nullptr, (unsigned*)nullptr, 0, (size_t)0, 0, dna); \
             else hipLaunchKernelGGL((k_ccorr_mfma_i8<KS_>), grid, dim3(256), lds, st, dif, dis, 0, iw, ih, dtx, tw, th, rf, drs, 0, rw, rh); } while (0)
             switch (KS) { case 1: MFMA_LAUNCH(1); break; case 2: MFMA_LAUNCH(2); break; case 3: MFMA_LAUNCH(3); break; case 4: MFMA_LAUNCH(4); break; default: MFMA_LAUNCH(5); }
 #undef MFMA_LAUNCH
+            if (fin) continue;
             hipEvent_t evM = pooledEvent(2 + c % 62);
             if (!evM) return MI355CV_ERROR_UNKNOWN;
             (void)hipEventRecord(evM, st);
             (void)hipStreamWaitEvent(aux, evM, 0);
             hipLaunchKernelGGL(k_tm_finish, dim3(divUp(rw, 64), divUp(rh, 16), nf), dim3(256), 0, aux, reinterpret_cast<float*>(rf), drs, rframe,
-                               w1 + f * wframe, w2 + f * wframe, wframe, cst, na);
+                               w1 + f * wframe, w2 + f * wframe, wframe, dna);
         }
-        (void)hipEventRecord(evDone, aux);
-        (void)hipStreamWaitEvent(st, evDone, 0);                      // everything after this call on the main stream sees the results
+        if (!fin) {
+            (void)hipEventRecord(evDone, aux);
+            (void)hipStreamWaitEvent(st, evDone, 0);                  // everything after this call on the main stream sees the results
+        }
     } else {
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
         hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
         if (method != 2) {
+            const NormArgs* dna = uploadStats(nullptr);
+            if (!dna) return MI355CV_NOT_IMPLEMENTED;
             dim3 g2(divUp(rw, 64), divUp(rh, 4), nframes);
-            hipLaunchKernelGGL(k_tm_normalize, g2, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, na);
+            hipLaunchKernelGGL(k_tm_normalize, g2, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, dna);
         }
     }
     return stg.finish(entry);
