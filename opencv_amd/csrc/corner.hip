@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
             const uint32_t em = __builtin_amdgcn_alignbit(ev[i + 1], ev[i], 16);      // (E[2i-1], E[2i])
             const uint32_t ep = __builtin_amdgcn_alignbit(ev[i + 2], ev[i + 1], 16);  // (E[2i+1], E[2i+2])
             const uint32_t om = __builtin_amdgcn_alignbit(od[i + 1], od[i], 16);      // (O[2i-1], O[2i])
-            o.h[i] = em + ep + 6u * ev[i + 1] + 4u * (om + od[i + 1]);
+            o.h[i] = sum146(em + ep, om + od[i + 1], ev[i + 1]);
         }
     };
     const int oy0 = cx.y0 >> 1, nout = (cx.nrows + 1) >> 1;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
                 uint32_t w[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t v = h0.h[i] + h4.h[i] + 4u * (h1.h[i] + h3.h[i]) + 6u * h2.h[i];
+                    const uint32_t v = sum146(h0.h[i] + h4.h[i], h1.h[i] + h3.h[i], h2.h[i]);
                     w[i] = ((v + 0x00800080u) >> 8) & 0x00ff00ffu;
                 }
                 if (cx.active) {
@@ -153,6 +153,187 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
             }
         }
     }
+}
+
+// Three pyramid levels in one launch (CV_8UC1, default sizes): buildPyramid's small levels are a few thousand waves each, so three dependent
+// launches cost three launch + load latencies.  Here a workgroup owns a T x T tile of the LAST level and walks back what it needs: (2T+3)^2 of
+// the level before, (4T+9)^2 of the first produced level, (8T+21)^2 source pixels (T = 16: 149 x 156 bytes of LDS, 1.4x redundant source
+// reads, served by L2 / Infinity Cache where the previous launch just left that level).  All tiles live in LDS in UNCLAMPED coordinates:
+// the loader fills source positions outside the image through the border rule, and after each level the entries outside that level's image
+// are filled from their border-mapped twins, so the 5x5 passes themselves never see a border.  A level is produced by column-pair threads
+// walking down the tile rows (two aligned LDS dwords per source row give the 7 bytes of an output pair -- the tile origin is 2*o-2, which
+// puts byte 4j at the left tap of pair j), keeping the last five horizontal sums in registers: the integer arithmetic of PyrDownInvoker
+// (pyramids.cpp:873-1040) in the packed 2 x u16 form of k_pyrdown_roll, hence bit-exact.  Every workgroup stores the part of each level its
+// last-level tile is the parent of: each output pixel is written exactly once.
+constexpr int P3_T = 16;
+constexpr int P3_NC = P3_T, P3_RC = P3_T;                              // tile columns (even) x rows per level: C = last, B, A = first produced, S = source
+constexpr int P3_NB = 2 * P3_NC + 4, P3_RB = 2 * P3_RC + 3;
+constexpr int P3_NA = 2 * P3_NB + 4, P3_RA = 2 * P3_RB + 3;
+constexpr int P3_NS = 2 * P3_NA + 4, P3_RS = 2 * P3_RA + 3;
+static_assert(P3_NS % 4 == 0 && P3_NA % 4 == 0 && P3_NB % 4 == 0 && P3_NC % 4 == 0, "tile rows are read as dwords");
+
+struct Pyr3Args {
+    const uchar* src; size_t sstep, sframe; int sw, sh;
+    uchar* d[3]; size_t dstep[3], dframe[3]; int dw[3], dh[3];
+    int border, tilesX, tilesY;
+};
+
+// the border rules k_pyr3 serves (REPLICATE, REFLECT, REFLECT_101), without the generic function's WRAP division
+__device__ __forceinline__ int pyr3Map(int p, int len, int border)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (border == B_REPLICATE) return p < 0 ? 0 : len - 1;
+    const int d = border == B_REFLECT_101;
+    do { p = p < 0 ? -p - 1 + d : 2 * len - 1 - p - d; } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// one level inside LDS: O (ROUT x NOUT bytes) from S (pitch SP bytes, 2*ROUT+3 rows): pair p of segment sg walks rows [r0, r1)
+template <int NOUT, int ROUT, int SP, int OP>
+__device__ __forceinline__ void pyr3Level(const uchar* S, uchar* O, int tid)
+{
+    constexpr int NP = NOUT / 2;
+    constexpr int NSEG = 256 / NP < ROUT ? 256 / NP : ROUT;
+    constexpr int RSEG = (ROUT + NSEG - 1) / NSEG;
+    if (tid >= NP * NSEG) return;
+    const int p = tid % NP, sg = tid / NP;
+    const int r0 = sg * RSEG, r1 = min(ROUT, r0 + RSEG);
+    auto hsum = [&](int srow) -> uint32_t {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(S + srow * SP + 4 * p);   // bytes b0..b7 = the source columns from the left tap of output 2p on
+        uint2 d; d.x = q[0]; d.y = q[1];
+        const uint32_t ev0 = d.x & 0x00ff00ffu, od0 = (d.x >> 8) & 0x00ff00ffu;        // (b0, b2), (b1, b3)
+        const uint32_t ev1 = d.y & 0x00ff00ffu, od1 = (d.y >> 8) & 0x00ff00ffu;        // (b4, b6), (b5, b7)
+        const uint32_t mid = __builtin_amdgcn_alignbit(ev1, ev0, 16);                  // (b2, b4)
+        const uint32_t odm = __builtin_amdgcn_alignbit(od1, od0, 16);                  // (b3, b5)
+        return sum146(ev0 + ev1, od0 + odm, mid);                                        // (b0+4b1+6b2+4b3+b4, b2+4b3+6b4+4b5+b6)
+    };
+    if (r0 >= r1) return;
+    uint32_t h0 = hsum(2 * r0), h1 = hsum(2 * r0 + 1), h2 = hsum(2 * r0 + 2);
+    for (int r = r0; r < r1; r++) {
+        const uint32_t h3 = hsum(2 * r + 3), h4 = hsum(2 * r + 4);
+        const uint32_t v = sum146(h0 + h4, h1 + h3, h2);
+        const uint32_t w = ((v + 0x00800080u) >> 8) & 0x00ff00ffu;
+        *reinterpret_cast<unsigned short*>(O + r * OP + 2 * p) = (unsigned short)((w & 0xffu) | ((w >> 8) & 0xff00u));
+        h0 = h2; h1 = h3; h2 = h4;
+    }
+}
+
+// a 5-tap pass over a level only ever asks for the two positions next to each image side: columns -2, -1, W, W+1 and rows -2, -1, H, H+1 of
+// the tile (where the tile holds them) take the values of their border-mapped twins -- columns first, then whole rows, so the corners follow.
+// The twins lie inside the tile for every position a later level uses; the index is clamped into the tile for the others.
+template <int N, int R, int PITCH>
+__device__ __forceinline__ void pyr3Border(uchar* Tl, int ox, int oy, int W, int H, int border, int tid, bool rows)
+{
+    if (ox >= 0 && oy >= 0 && ox + N <= W && oy + R <= H) return;                     // uniform per workgroup
+    for (int i = tid; i < 4 * R; i += 256) {
+        const int r = i >> 2, xi = i & 3;
+        const int x = xi < 2 ? xi - 2 : W + xi - 2, c = x - ox;
+        if ((unsigned)c >= (unsigned)N) continue;
+        const int xm = min(max(pyr3Map(x, W, border) - ox, 0), N - 1);
+        Tl[r * PITCH + c] = Tl[r * PITCH + xm];
+    }
+    if (!rows) return;
+    __syncthreads();
+    for (int i = tid; i < 4 * N; i += 256) {
+        const int c = i >> 2, yi = i & 3;
+        const int y = yi < 2 ? yi - 2 : H + yi - 2, r = y - oy;
+        if ((unsigned)r >= (unsigned)R) continue;
+        const int ym = min(max(pyr3Map(y, H, border) - oy, 0), R - 1);
+        Tl[r * PITCH + c] = Tl[ym * PITCH + c];
+    }
+}
+
+// the workgroup's own part of a level (the children of its last-level tile) from the LDS tile to the image, two bytes per lane
+template <int PITCH>
+__device__ __forceinline__ void pyr3Store(const uchar* Tl, int ox, int oy, int x0, int y0, int nx, int ny, int W, int H, uchar* dst, size_t dstep, int tid)
+{
+    const int npair = nx / 2;
+    for (int i = tid; i < npair * ny; i += 256) {
+        const int r = i / npair, c = 2 * (i - r * npair);
+        const int x = x0 + c, y = y0 + r;
+        if (y >= H || x >= W) continue;
+        const unsigned short v = *reinterpret_cast<const unsigned short*>(Tl + (y - oy) * PITCH + (x - ox));
+        uchar* d = dst + (size_t)y * dstep + x;
+        if (x + 1 < W) *reinterpret_cast<unsigned short*>(d) = v;
+        else *d = (uchar)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pyr3(Pyr3Args a)
+{
+    __shared__ __attribute__((aligned(16))) uchar tS[P3_RS * P3_NS];
+    __shared__ __attribute__((aligned(16))) uchar tA[P3_RA * P3_NA];
+    __shared__ __attribute__((aligned(16))) uchar tB[P3_RB * P3_NB];
+    __shared__ __attribute__((aligned(16))) uchar tC[P3_RC * P3_NC];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const uchar* src = a.src + (size_t)blockIdx.y * a.sframe;
+    const int xC = tx * P3_T, yC = ty * P3_T;
+    const int oxB = 2 * xC - 2, oyB = 2 * yC - 2, oxA = 2 * oxB - 2, oyA = 2 * oyB - 2, oxS = 2 * oxA - 2, oyS = 2 * oyA - 2;
+    // source tile: dword k of tile row r holds source columns oxS + 4k .. +3 of row oyS + r.  Rows go through the border rule here; a dword
+    // takes the bytes that lie inside the image from one unaligned 8-byte load clamped into the row, and the columns outside the image are
+    // then filled inside LDS from their mapped twins (pyr3Border).  All loads of a thread are issued before its first LDS write: a rolled
+    // loop would pay one cache latency per pass, 25 of them.
+    constexpr int NDW = P3_NS / 4, RPP = 256 / NDW, ITER = (P3_RS + RPP - 1) / RPP;       // RPP tile rows per pass
+    {
+        typedef unsigned long long u64u __attribute__((aligned(1)));
+        const int k = tid % NDW, rsub = tid / NDW;                                       // this thread's dword column; threads >= RPP * NDW idle
+        const int x = oxS + 4 * k;
+        const int xc = min(max(x, 0), a.sw - 8);                                          // sw >= 8
+        const int d = x - xc;                                                             // > 0: the dword starts right of the loaded bytes
+        const uchar* colp = src + xc;
+        const bool rowsInside = oyS >= 0 && oyS + P3_RS <= a.sh;                         // uniform per workgroup
+        unsigned long long q[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int r = min(it * RPP + rsub, P3_RS - 1);
+            const int y = rowsInside ? oyS + r : pyr3Map(oyS + r, a.sh, a.border);
+            q[it] = *reinterpret_cast<const u64u*>(colp + (size_t)y * a.sstep);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int r = it * RPP + rsub;
+            const uint32_t v = d >= 8 || d <= -8 ? 0u : d >= 0 ? (uint32_t)(q[it] >> (8 * d)) : (uint32_t)(q[it] << (-8 * d));
+            if (rsub < RPP && r < P3_RS) reinterpret_cast<uint32_t*>(tS)[r * NDW + k] = v;
+        }
+    }
+    __syncthreads();
+    pyr3Border<P3_NS, P3_RS, P3_NS>(tS, oxS, 0, a.sw, P3_RS, a.border, tid, false);      // columns only: the rows are already mapped
+    __syncthreads();
+    pyr3Level<P3_NA, P3_RA, P3_NS, P3_NA>(tS, tA, tid);
+    __syncthreads();
+    pyr3Border<P3_NA, P3_RA, P3_NA>(tA, oxA, oyA, a.dw[0], a.dh[0], a.border, tid, true);
+    __syncthreads();
+    pyr3Level<P3_NB, P3_RB, P3_NA, P3_NB>(tA, tB, tid);
+    __syncthreads();
+    pyr3Border<P3_NB, P3_RB, P3_NB>(tB, oxB, oyB, a.dw[1], a.dh[1], a.border, tid, true);
+    __syncthreads();
+    pyr3Level<P3_NC, P3_RC, P3_NB, P3_NC>(tB, tC, tid);
+    __syncthreads();
+    pyr3Store<P3_NA>(tA, oxA, oyA, 4 * xC, 4 * yC, 4 * P3_T, 4 * P3_T, a.dw[0], a.dh[0], a.d[0] + (size_t)blockIdx.y * a.dframe[0], a.dstep[0], tid);
+    pyr3Store<P3_NB>(tB, oxB, oyB, 2 * xC, 2 * yC, 2 * P3_T, 2 * P3_T, a.dw[1], a.dh[1], a.d[1] + (size_t)blockIdx.y * a.dframe[1], a.dstep[1], tid);
+    pyr3Store<P3_NC>(tC, xC, yC, xC, yC, P3_T, P3_T, a.dw[2], a.dh[2], a.d[2] + (size_t)blockIdx.y * a.dframe[2], a.dstep[2], tid);
+}
+
+// levels l+1..l+3 from level l in one launch where k_pyr3's geometry applies (CV_8UC1, default sizes, even destination addresses, a last level
+// of at least 4 x 4, borders that map into the neighbourhood); MI355CV_PYR_FUSE=0 keeps the level-by-level launches
+bool launchPyr3(const uchar* s, size_t ss, size_t sf, int w, int h, uchar* const* d, const size_t* dstep, const size_t* dframe, int nframes, int depth, int cn,
+                int border, hipStream_t st)
+{
+    const char* e = getenv("MI355CV_PYR_FUSE");
+    if (e && !atoi(e)) return false;
+    if (depth != D8U || cn != 1 || !(border == B_REPLICATE || border == B_REFLECT || border == B_REFLECT_101)) return false;
+    Pyr3Args a; a.src = s; a.sstep = ss; a.sframe = sf; a.sw = w; a.sh = h; a.border = border;
+    int pw = w, ph = h;
+    for (int l = 0; l < 3; l++) {
+        a.d[l] = d[l]; a.dstep[l] = dstep[l]; a.dframe[l] = nframes == 1 ? 0 : dframe[l];
+        a.dw[l] = (pw + 1) / 2; a.dh[l] = (ph + 1) / 2; pw = a.dw[l]; ph = a.dh[l];
+        if ((((uintptr_t)d[l]) | dstep[l] | a.dframe[l]) & 1) return false;
+    }
+    if (a.dw[2] < 4 || a.dh[2] < 4 || w < 8 || h < 8) return false;
+    a.tilesX = divUp(a.dw[2], P3_T); a.tilesY = divUp(a.dh[2], P3_T);
+    hipLaunchKernelGGL(k_pyr3, dim3(a.tilesX * a.tilesY, nframes), dim3(256), 0, st, a);
+    return true;
 }
 
 // one level on device-resident images: the rolling kernel where its geometry applies, the per-output kernel otherwise
@@ -660,6 +841,8 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
     for (int l = 0; l < maxlevel; l++) {
         const int dw = (w + 1) / 2, dh = (h + 1) / 2;
         const size_t df = nframes == 1 ? 0 : dst_frame_stride[l];
+        // the last three levels in one launch once the level they start from is small (its redundant tile reads come from cache)
+        if (l == maxlevel - 3 && l >= 1 && launchPyr3(s, ss, sf, w, h, dst_data + l, dst_step + l, dst_frame_stride + l, nframes, depth, cn, border, stream())) break;
         launchPyrDown(s, ss, sf, w, h, dst_data[l], dst_step[l], df, dw, dh, nframes, depth, cn, 0, 0, 0, 0, border, stream());
         s = dst_data[l]; ss = dst_step[l]; sf = df; w = dw; h = dh;
     }

@@ -88,6 +88,17 @@ inline int divUp(int a, int b) { return (a + b - 1) / b; }
     do { hipError_t e__ = hipGetLastError();                                             \
          if (e__ != hipSuccess) return mi355::setError(MI355CV_ERROR_UNKNOWN, "%s: launch failed: %s", entry, hipGetErrorString(e__)); } while (0)
 
+#ifdef __HIPCC__
+// (a << n) + b as ONE v_lshl_add_u32, and a + 4 b + 6 c on packed u16 pairs in four of them: written as plain C the optimiser folds the
+// 4 c + 2 c into a 32-bit multiply by 6 (v_mul_lo_u32), which is not a full-rate instruction
+__device__ __forceinline__ uint32_t lshlAdd(uint32_t a, int n, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(n), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sum146(uint32_t a, uint32_t b, uint32_t c) { return lshlAdd(c, 1, lshlAdd(b + c, 2, a)); }
+#endif
 } // namespace mi355
 
 // borderInterpolate (core/src/copy.cpp:748-793), device+host. Returns -1 for CONSTANT.

@@ -216,10 +216,14 @@ __global__ __launch_bounds__(256) void k_binomial_roll(
                     const uint32_t* h0 = Hw[(u + 0) % 5]; const uint32_t* h1 = Hw[(u + 1) % 5];
                     const uint32_t* h2 = Hw[(u + 2) % 5]; const uint32_t* h3 = Hw[(u + 3) % 5];
                     const uint32_t* h4 = Hw[(u + 4) % 5];
+                    // 6 h2 as 4 h2 + 2 h2 inside two shift-adds: four full-rate VALU operations per dword (add3, lshl_add, lshl_add, add3); written
+                    // as (h2 << 1) + (h2 << 2) the compiler emits v_mul_lo_u32 by 6, which issues at a quarter of that rate
                     uint32_t v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        v[i] = (h0[i] + h4[i]) + ((h1[i] + h3[i]) << 2) + (h2[i] << 1) + (h2[i] << 2) + 0x00800080u;
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t b4 = lshlAdd(h1[i] + h3[i] + h2[i], 2, 0x00800080u);
+                        v[i] = h0[i] + h4[i] + lshlAdd(h2[i], 1, b4);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_perm(v[4 + k], v[k], 0x07030501u);  // (Ve.b1,Vo.b1,Ve.b3,Vo.b3) = >>8
                 } else {
@@ -294,7 +298,7 @@ __device__ __forceinline__ void issueRow(RawRow2<RollCfg<KS, CN>::HD>& r, const 
     for (int d = 0; d < HD; d++) r.side[d] = *reinterpret_cast<const uint32_t*>(row + sideOff + 4 * d);
 }
 
-template <int KS, int CN>
+template <int KS, int CN, bool EB = true>
 __device__ __forceinline__ void hfilter2(uint32_t (&Hrow)[8], const RawRow2<RollCfg<KS, CN>::HD>& r,
                                          bool hasFirst, bool hasLast, bool isLastChunk, const EdgeSel<RollCfg<KS, CN>::HD>& es)
 {
@@ -305,21 +309,25 @@ __device__ __forceinline__ void hfilter2(uint32_t (&Hrow)[8], const RawRow2<Roll
     uint32_t hl[HD], hr[HD];
 #pragma unroll
     for (int d = 0; d < HD; d++) { hl[d] = r.side[d]; hr[d] = r.side[d]; }
-    if (hasFirst) {          // wave-uniform: lane 0 is chunk 0, its left halo is the image border
+    // the two edge cases are wave-uniform; the empty volatile asm keeps them real (scalar) branches -- if-converted into selects, their six
+    // v_perm would be paid by every strip of every row, and three strips in four have no image border on one or both sides
+    if (hasFirst) {          // lane 0 is chunk 0, its left halo is the image border
 #pragma unroll
-        for (int d = 0; d < HD; d++) hl[d] = gather16(r.m, es.la[d], es.lb[d], es.lc[d]);
+        for (int d = 0; d < HD; d++) { hl[d] = gather16(r.m, es.la[d], es.lb[d], es.lc[d]); if constexpr (EB) asm volatile("" : "+v"(hl[d])); }
     }
     uint32_t hb[HD];
-    if (hasLast) {           // wave-uniform: some lane is the last chunk, its right halo is the image border
 #pragma unroll
-        for (int d = 0; d < HD; d++) hb[d] = gather16(r.m, es.ra[d], es.rb[d], es.rc[d]);
+    for (int d = 0; d < HD; d++) hb[d] = 0;
+    if (hasLast) {           // some lane is the last chunk, its right halo is the image border
+#pragma unroll
+        for (int d = 0; d < HD; d++) { hb[d] = gather16(r.m, es.ra[d], es.rb[d], es.rc[d]); if constexpr (EB) asm volatile("" : "+v"(hb[d])); }
     }
 #pragma unroll
     for (int d = 0; d < HD; d++) {
         // wave_shr:1 -> lane i takes lane i-1, lane 0 keeps `old` (its left halo);  wave_shl:1 mirrors it
         X[d] = __builtin_amdgcn_update_dpp(hl[d], mv[4 - HD + d], 0x138, 0xf, 0xf, false);
         uint32_t rr = __builtin_amdgcn_update_dpp(hr[d], mv[d], 0x130, 0xf, 0xf, false);
-        if (hasLast) rr = isLastChunk ? hb[d] : rr;
+        if (hasLast) { rr = isLastChunk ? hb[d] : rr; if constexpr (EB) asm volatile("" : "+v"(rr)); }
         X[HD + 4 + d] = rr;
     }
 #pragma unroll
@@ -348,7 +356,7 @@ __device__ __forceinline__ void hfilter2(uint32_t (&Hrow)[8], const RawRow2<Roll
     }
 }
 
-template <int KS, int CN, bool NT, bool NTL, int WPS>
+template <int KS, int CN, bool NT, bool NTL, int WPS, bool EB = true>
 __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
     const uchar* __restrict__ src, size_t sstep, size_t sframe,
     uchar* __restrict__ dst, size_t dstep, size_t dframe,
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
         } else {
             RawRow2<HD> pre;
             issueRow<KS, CN>(pre, src + (size_t)ry * sstep, mainOff, sideOff);
-            hfilter2<KS, CN>(Hw[i], pre, hasFirst, hasLast, isLastChunk, es);
+            hfilter2<KS, CN, EB>(Hw[i], pre, hasFirst, hasLast, isLastChunk, es);
         }
     }
     RawRow2<HD> raw[KS];
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
         for (int u = 0; u < KS; u++) {
             if (y + u < nrows) {
                 uint32_t (&Hn)[8] = Hw[(KS - 1 + u) % KS];
-                if (rvalid[u]) hfilter2<KS, CN>(Hn, raw[u], hasFirst, hasLast, isLastChunk, es);
+                if (rvalid[u]) hfilter2<KS, CN, EB>(Hn, raw[u], hasFirst, hasLast, isLastChunk, es);
                 else {
 #pragma unroll
                     for (int j = 0; j < 8; j++) Hn[j] = 0;
@@ -476,8 +484,13 @@ __global__ __launch_bounds__(256, WPS) void k_binomial_roll2(
                     const uint32_t* h4 = Hw[(u + 4) % 5];
                     uint32_t v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        v[i] = (h0[i] + h4[i]) + ((h1[i] + h3[i]) << 2) + (h2[i] << 1) + (h2[i] << 2) + 0x00800080u;
+                    for (int i = 0; i < 8; i++) {                // four full-rate operations per dword, no multiply by 6 (see k_binomial_roll)
+                        if constexpr (EB) {
+                            const uint32_t b4 = lshlAdd(h1[i] + h3[i] + h2[i], 2, 0x00800080u);
+                            v[i] = h0[i] + h4[i] + lshlAdd(h2[i], 1, b4);
+                        } else
+                            v[i] = (h0[i] + h4[i]) + ((h1[i] + h3[i]) << 2) + (h2[i] << 1) + (h2[i] << 2) + 0x00800080u;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_perm(v[4 + k], v[k], 0x07030501u);
                 } else {
@@ -552,7 +565,7 @@ bool aligned16(const void* p, size_t step) { return (((uintptr_t)p | step) & 15)
 int envInt(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
 
 int& tuneSeg() { static int v = envInt("MI355CV_GAUSS_SEG", 0); return v; }
-int& tuneVariant() { static int v = envInt("MI355CV_GAUSS_VARIANT", 3); return v; }   // 1: k_binomial_roll, 2: roll2, 3: roll2 + nt stores, 4: + nt loads
+int& tuneVariant() { static int v = envInt("MI355CV_GAUSS_VARIANT", 3); return v; }   // 1: k_binomial_roll, 2: roll2, 3: roll2 + nt stores, 4: 3 with the edge halos as selects instead of branches, 5: 3 at 6 waves / SIMD
 
 int& tuneAlt() { static int v = envInt("MI355CV_GAUSS_ALT", 1); return v; }   // 1: alternate walking direction of vertical neighbours
 
@@ -578,10 +591,10 @@ void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size
     const int nseg = divUp(H, seg);
     const long long items = (long long)nstrips * nseg * nframes;
     dim3 grid((unsigned)((items + 3) / 4));
-    noteKernel("k_binomial_roll2<%d,%d,%s,%s,%d> grid=%u x256 seg=%d rows alt=%d", KS, CN, nt >= 1 ? "true" : "false", nt == 2 ? "true" : "false", nt == 3 ? 6 : 4,
+    noteKernel("k_binomial_roll2<%d,%d,%s,false,%d,%s> grid=%u x256 seg=%d rows alt=%d", KS, CN, nt >= 1 ? "true" : "false", nt == 3 ? 6 : 4, nt == 2 ? "false" : "true",
                grid.x, seg, tuneAlt());
     if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
-    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, true, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
+    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4, false>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
     else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
     else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
 }

@@ -976,55 +976,105 @@ __global__ __launch_bounds__(256) void k_convert_maps_to_float(const uchar* __re
 // 8-byte (32F) / 2-byte (8U) load per source row; pixels whose 2x2 footprint is not strictly inside the source take the
 // generic sampler.  A wave walks down WROWS rows, so the source lines it touched for one row are in L1 for the next.
 constexpr int WROWS = 8;
+template <int KIND>
+__device__ __forceinline__ void warpXY(const WarpArgs& w, int y, int ad, int bd, int xb, int x1, int& X, int& Y)
+{
+    if (KIND == 0) {
+        const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+        const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+        X = (X0 + ad) >> 5; Y = (Y0 + bd) >> 5;
+    } else {
+        const double X0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[0], (double)xb), __dmul_rn(w.M[1], (double)y)), w.M[2]);
+        const double Y0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[3], (double)xb), __dmul_rn(w.M[4], (double)y)), w.M[5]);
+        const double W0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[6], (double)xb), __dmul_rn(w.M[7], (double)y)), w.M[8]);
+        double W = __dadd_rn(W0, __dmul_rn(w.M[6], (double)x1));
+        W = W != 0 ? __ddiv_rn(32.0, W) : 0;
+        double fX = __dmul_rn(__dadd_rn(X0, __dmul_rn(w.M[0], (double)x1)), W);
+        double fY = __dmul_rn(__dadd_rn(Y0, __dmul_rn(w.M[3], (double)x1)), W);
+        fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
+        fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
+        X = satIntD(fX); Y = satIntD(fY);
+    }
+}
+
+// The kernel is bound by its VALU work, not by HBM or the gather (a pure shift, perfectly coalesced, ran no faster than a rotation), so the
+// per-pixel instruction count is what is kept low:
+//  * affine row terms X0(y), Y0(y) -- double arithmetic with saturation -- are wave-uniform: lane i (i < 8) evaluates row i of the wave's WROWS
+//    rows once, the loop takes them with v_readlane; the column terms are evaluated once per thread;
+//  * byte offsets are 32-bit (the host checks that both images are below 4 GB), one v_mad per tap address, saddr-form loads and stores;
+//  * the taps of a group of G rows are loaded back to back before the first is used (pixels whose footprint is not strictly inside the source
+//    load from offset 0 and are redone by the generic sampler afterwards).
 template <typename T, int CN, int KIND /*0 affine, 1 perspective*/>
-__global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+__global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep,
                                                   SampleArgs s, WarpArgs w, const short* __restrict__ tab)
 {
+    constexpr int G = sizeof(T) == 4 ? (CN == 1 ? 8 : CN == 3 ? 4 : 2) : 8;           // rows whose taps are in flight together
+    constexpr uint32_t ESZ = CN * sizeof(T);
+    typedef float fNu __attribute__((ext_vector_type(2), aligned(4)));
+    typedef unsigned short u16u __attribute__((aligned(1)));
+    typedef unsigned long long u64u __attribute__((aligned(1)));
     int tx, ty;
     tileOf(w, tx, ty);
     src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
-    const int x = tx * 64 + (threadIdx.x & 63);
-    const int yb = (ty * 4 + (threadIdx.x >> 6)) * WROWS;
-    if (x >= w.dw || yb >= w.dh) return;
+    const int lane = threadIdx.x & 63;
+    const int x = tx * 64 + lane;
+    const int yb = __builtin_amdgcn_readfirstlane((ty * 4 + (int)(threadIdx.x >> 6)) * WROWS);
+    if (yb >= w.dh) return;                                                              // wave-uniform
+    int X0v = 0, Y0v = 0;
+    if (KIND == 0) {                                                                     // all 64 lanes are still active here
+        const int yl = yb + (lane & (WROWS - 1));
+        X0v = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)yl), w.M[2]), 1024.0)) + 16;
+        Y0v = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)yl), w.M[5]), 1024.0)) + 16;
+    }
+    if (x >= w.dw) return;
     const int ad = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0)) : 0;
     const int bd = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0)) : 0;
     const int xb = KIND == 1 ? (x / w.bw0) * w.bw0 : 0, x1 = x - xb;
     // the pair (sx, sx+1) is read as ONE load of 2*CN elements where that cannot leave the row (3 channels: an 8-byte load for 6)
     const int xlim = CN == 3 ? s.sw - 2 : s.sw - 1;
-    const int ye = min(yb + WROWS, w.dh);
-    for (int y = yb; y < ye; y++) {
-        int X, Y;
-        if (KIND == 0) {
-            const int X0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
-            const int Y0 = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
-            X = (X0 + ad) >> 5; Y = (Y0 + bd) >> 5;
-        } else {
-            const double X0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[0], (double)xb), __dmul_rn(w.M[1], (double)y)), w.M[2]);
-            const double Y0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[3], (double)xb), __dmul_rn(w.M[4], (double)y)), w.M[5]);
-            const double W0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[6], (double)xb), __dmul_rn(w.M[7], (double)y)), w.M[8]);
-            double W = __dadd_rn(W0, __dmul_rn(w.M[6], (double)x1));
-            W = W != 0 ? __ddiv_rn(32.0, W) : 0;
-            double fX = __dmul_rn(__dadd_rn(X0, __dmul_rn(w.M[0], (double)x1)), W);
-            double fY = __dmul_rn(__dadd_rn(Y0, __dmul_rn(w.M[3], (double)x1)), W);
-            fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
-            fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
-            X = satIntD(fX); Y = satIntD(fY);
+    const uint32_t xoff = (uint32_t)x * ESZ;
+    unsigned slow = 0;                                                                   // rows left to the generic sampler
+#pragma unroll
+    for (int g0 = 0; g0 < WROWS; g0 += G) {
+        int Xs[G], Ys[G];
+        bool in[G];
+        fNu f0[sizeof(T) == 4 ? G * CN : 1], f1[sizeof(T) == 4 ? G * CN : 1];
+        unsigned long long q0[sizeof(T) == 4 ? 1 : G], q1[sizeof(T) == 4 ? 1 : G];
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int y = yb + g0 + i;
+            if (KIND == 0) {
+                Xs[i] = (__builtin_amdgcn_readlane(X0v, g0 + i) + ad) >> 5;
+                Ys[i] = (__builtin_amdgcn_readlane(Y0v, g0 + i) + bd) >> 5;
+            } else warpXY<KIND>(w, y, ad, bd, xb, x1, Xs[i], Ys[i]);
+            const int sx = satShort(Xs[i] >> 5), sy = satShort(Ys[i] >> 5);
+            const bool inside = (unsigned)sx < (unsigned)xlim && (unsigned)sy < (unsigned)(s.sh - 1);
+            in[i] = y < w.dh && inside;
+            if (y < w.dh && !inside) slow |= 1u << (g0 + i);
+            const uint32_t off = in[i] ? __umul24((uint32_t)sy, sstep) + (uint32_t)sx * ESZ : 0u;       // sy < 2^15, sstep < 2^24 (host check)
+            const uchar* r0 = src + off;
+            const uchar* r1 = src + (off + sstep);
+            if (sizeof(T) == 4) {
+#pragma unroll
+                for (int q = 0; q < CN; q++) { f0[i * CN + q] = reinterpret_cast<const fNu*>(r0)[q]; f1[i * CN + q] = reinterpret_cast<const fNu*>(r1)[q]; }
+            } else if (CN == 1) { q0[i] = *reinterpret_cast<const u16u*>(r0); q1[i] = *reinterpret_cast<const u16u*>(r1); }
+            else { q0[i] = *reinterpret_cast<const u64u*>(r0); q1[i] = *reinterpret_cast<const u64u*>(r1); }
         }
-        const int sx = satShort(X >> 5), sy = satShort(Y >> 5), ax = X & 31, ay = Y & 31;
-        uchar* D = dst + (size_t)y * dstep + (size_t)x * CN * sizeof(T);
-        if ((unsigned)sx < (unsigned)xlim && (unsigned)sy < (unsigned)(s.sh - 1)) {
-            const uchar* r0 = src + (size_t)sy * sstep + (size_t)sx * CN * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            if (!in[i]) continue;
+            const int y = yb + g0 + i;
+            const int ax = Xs[i] & 31, ay = Ys[i] & 31;
+            uchar* D = dst + (uint32_t)y * dstep + xoff;
             if (sizeof(T) == 4) {
                 const float s32 = 1.f / 32;
                 const float fx = ax * s32, fy = ay * s32;
                 const float wy0 = 1.f - fy, wx0 = 1.f - fx;
                 const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
                 float p0[2 * CN], p1[2 * CN];
-                typedef float fNu __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
                 for (int q = 0; q < CN; q++) {
-                    const fNu v0 = reinterpret_cast<const fNu*>(r0)[q], v1 = reinterpret_cast<const fNu*>(r0 + sstep)[q];
-                    p0[2 * q] = v0.x; p0[2 * q + 1] = v0.y; p1[2 * q] = v1.x; p1[2 * q + 1] = v1.y;
+                    p0[2 * q] = f0[i * CN + q].x; p0[2 * q + 1] = f0[i * CN + q].y; p1[2 * q] = f1[i * CN + q].x; p1[2 * q + 1] = f1[i * CN + q].y;
                 }
 #pragma unroll
                 for (int c = 0; c < CN; c++) {
@@ -1035,24 +1085,25 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
                 }
             } else {
                 const short4 wq = *reinterpret_cast<const short4*>(tab + (ay * 32 + ax) * 4);
-                unsigned long long q0, q1;                       // the 2*CN bytes of each source row
-                if (CN == 1) {
-                    typedef unsigned short u16u __attribute__((aligned(1)));
-                    q0 = *reinterpret_cast<const u16u*>(r0); q1 = *reinterpret_cast<const u16u*>(r0 + sstep);
-                } else {
-                    typedef unsigned long long u64u __attribute__((aligned(1)));
-                    q0 = *reinterpret_cast<const u64u*>(r0); q1 = *reinterpret_cast<const u64u*>(r0 + sstep);
-                }
 #pragma unroll
                 for (int c = 0; c < CN; c++) {
-                    const int v0 = (int)((q0 >> (8 * c)) & 255), v1 = (int)((q0 >> (8 * (CN + c))) & 255);
-                    const int v2 = (int)((q1 >> (8 * c)) & 255), v3 = (int)((q1 >> (8 * (CN + c))) & 255);
+                    const int v0 = (int)((q0[i] >> (8 * c)) & 255), v1 = (int)((q0[i] >> (8 * (CN + c))) & 255);
+                    const int v2 = (int)((q1[i] >> (8 * c)) & 255), v3 = (int)((q1[i] >> (8 * (CN + c))) & 255);
                     const int r = (v0 * wq.x + v1 * wq.y + v2 * wq.z + v3 * wq.w + (1 << 14)) >> 15;
                     D[c] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
                 }
             }
-        } else
-            samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab);
+        }
+    }
+    if (slow) {
+#pragma unroll 1
+        for (int i = 0; i < WROWS; i++) {
+            if (!((slow >> i) & 1)) continue;
+            const int y = yb + i;
+            int X, Y;
+            warpXY<KIND>(w, y, ad, bd, xb, x1, X, Y);
+            samplePixel(src, sstep, dst + (size_t)y * dstep + xoff, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
+        }
     }
 }
 
@@ -1113,15 +1164,17 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
-    if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && (dss % e) == 0 &&
+    if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && sh >= 2 && (dss % e) == 0 &&
+        (unsigned long long)sh * dss < (1ull << 32) && (unsigned long long)dh * dds < (1ull << 32) && dss < (1u << 24) &&
         ((uintptr_t)ds % e) == 0) {
-        // XCD-banded tile order: on for CV_32F (8K 32F rotate: 73.5 vs 75.7 us), off for 8-bit sources, whose whole working set sits in one
-        // L2's reach anyway (4K 8UC3: 46.2 vs 43.8 us).  MI355CV_WARP_BAND=0/1 overrides (tools/tune_r02.py).
+        // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean
+        // kernel the plain order is faster for small rotations (8K 32F, 7 degrees: 63.5 vs 71.0 us) and within 3 % otherwise.
+        // MI355CV_WARP_BAND=1 turns it on (tools/warp_probe.py).
         const char* ve = getenv("MI355CV_WARP_BAND");
-        w.band = ve ? atoi(ve) : (depth == D32F ? 1 : 0);
+        w.band = ve ? atoi(ve) : 0;
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS), nframes);
         w.gx = g2.x; w.gy = g2.y;
-#define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, g_tabDev)
+#define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev)
 #define WLC(T_, K_) do { if (cn == 1) WL(T_, 1, K_); else if (cn == 3) WL(T_, 3, K_); else WL(T_, 4, K_); } while (0)
         if (kind == 0) { if (depth == D32F) WLC(float, 0); else WLC(uchar, 0); }
         else           { if (depth == D32F) WLC(float, 1); else WLC(uchar, 1); }

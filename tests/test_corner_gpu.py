@@ -113,6 +113,40 @@ def test_pyrdown_rolling_path(cv, orc):
         assert np.array_equal(got[1][i].cpu().numpy(), l1) and np.array_equal(got[2][i].cpu().numpy(), l2)
 
 
+def test_build_pyramid_fused_levels(cv, orc, monkeypatch):
+    """buildPyramidBatch with maxlevel >= 4 produces its last three levels in one launch (k_pyr3): odd and even sizes at every level, sizes
+    smaller than one tile, several tiles with ragged edges, three border rules, views with a parent's step; equal to the level-by-level
+    launches (MI355CV_PYR_FUSE=0) and to the oracle"""
+    rng = np.random.default_rng(77)
+    for (w, h, n, ml) in [(1920, 1080, 2, 4), (640, 480, 3, 4), (512, 512, 1, 5), (333, 257, 2, 4), (130, 70, 2, 4), (1040, 1030, 1, 5), (96, 800, 2, 4)]:
+        fr = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        d = dev(fr)
+        for border in (4, 1, 2):
+            got = cv.buildPyramidBatch(d, ml, border)
+            monkeypatch.setenv("MI355CV_PYR_FUSE", "0")
+            ref = cv.buildPyramidBatch(d, ml, border)
+            monkeypatch.delenv("MI355CV_PYR_FUSE")
+            for l in range(1, ml + 1):
+                assert torch.equal(got[l], ref[l]), (w, h, border, l)
+            lvl = fr[n - 1]
+            for l in range(1, ml + 1):
+                lvl = orc.orc_pyrDown(lvl, None, border)
+                assert np.array_equal(got[l][n - 1].cpu().numpy(), lvl), (w, h, border, l)
+    # level arrays that are views into wider parents (odd byte offsets are declined to the level-by-level path, even ones are served)
+    fr = rng.integers(0, 256, (2, 300, 420), dtype=np.uint8)
+    d = dev(fr)
+    shapes = [(150, 210), (75, 105), (38, 53), (19, 27)]
+    for off in (2, 1):
+        parents = [torch.zeros((2, hh + 3, ww + 8), dtype=torch.uint8, device="cuda") for hh, ww in shapes]
+        dst = [d] + [p[:, 1:1 + hh, off:off + ww] for p, (hh, ww) in zip(parents, shapes)]
+        got = cv.buildPyramidBatch(d, 4, dst=dst)
+        lvl = fr[1]
+        for l in range(1, 5):
+            lvl = orc.orc_pyrDown(lvl)
+            assert np.array_equal(got[l][1].cpu().numpy(), lvl), (off, l)
+            assert int(parents[l - 1][:, 0].sum()) == 0 and int(parents[l - 1][:, :, :off].sum()) == 0
+
+
 def test_build_pyramid_config4(cv, orc):
     """BASELINE config 4: cornerHarris(2,3,0.04) + buildPyramid(maxlevel=4) on 1920x1080 CV_8UC1 frames (batched)."""
     rng = np.random.default_rng(809564)

@@ -141,6 +141,33 @@ def test_warp_tile_orders(cv, orc, dtype):
         check(cv.warpPerspective(dev(src), P, dsize, 1 | cv.WARP_INVERSE_MAP, 0, 3.0), orc.orc_warpPerspective(src, P, dsize, 1, 0, 3.0))
 
 
+def test_warp_32f_wide_sources(cv, orc):
+    """CV_32FC1 sources several tiles wide: rotations, strong magnification / minification, shear, borders, ragged destination sizes, perspective,
+    a view inside a parent, a batch -- the grouped-load bilinear kernel (k_warp_lin) on sources larger than one workgroup's footprint"""
+    src = rnd((200, 256), np.float32, 4242)
+    Ms = [cv.getRotationMatrix2D((128.0, 100.0), a, sc) for a, sc in [(7.0, 0.95), (33.0, 1.3), (-120.0, 0.6), (0.0, 1.0), (90.0, 1.0), (45.0, 3.5), (3.0, 0.3)]]
+    Ms += [np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64), np.array([[0.3, 0.1, -20.0], [-0.2, 0.4, 30.0]], np.float64),
+           np.array([[1.0, 0.9, -60.0], [0.0, 1.0, 0.0]], np.float64)]
+    P = [np.array([[1.05, 0.04, -6.0], [0.03, 0.95, 5.0], [1e-4, -1e-4, 1.0]]), np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])]
+    d = dev(src)
+    for dsize in [(256, 200), (300, 77), (65, 33), (640, 480)]:
+        for border, bval in [(0, 0.0), (0, 2.5), (1, 0), (4, 0)]:
+            for M in Ms:
+                got = cv.warpAffine(d, M, dsize, 1 | cv.WARP_INVERSE_MAP, border, bval)
+                check(got, orc.orc_warpAffine(src, M, dsize, 1, border, bval))
+            for M in P:
+                got = cv.warpPerspective(d, M, dsize, 1 | cv.WARP_INVERSE_MAP, border, bval)
+                check(got, orc.orc_warpPerspective(src, M, dsize, 1, border, bval))
+    # a view with a 16-byte aligned, non-zero origin and a parent's step; frames of a batch
+    big = rnd((3, 220, 272), np.float32, 99)
+    dbig = dev(big)
+    view = dbig[1, 8:208, 8:264]
+    check(cv.warpAffine(view, Ms[0], (256, 200), 1 | cv.WARP_INVERSE_MAP, 0, 0.0), orc.orc_warpAffine(np.ascontiguousarray(big[1, 8:208, 8:264]), Ms[0], (256, 200), 1, 0, 0.0))
+    outs = cv.warpAffineBatch(dbig, Ms[1], (272, 220), 1 | cv.WARP_INVERSE_MAP, 1)
+    for f in range(3):
+        check(outs[f], orc.orc_warpAffine(big[f], Ms[1], (272, 220), 1, 1))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_warp_transparent(cv, orc, dtype, cn):
