@@ -175,6 +175,13 @@ MI355CV_API int mi355cv_filterFree(struct cvhalFilter2D* context);
 MI355CV_API int mi355cv_filterBatch(struct cvhalFilter2D* context, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
         mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height);
 
+/* cv::cvtColor(COLOR_BGR2GRAY | RGB2GRAY | BGRA2GRAY | RGBA2GRAY) (color.cpp:192 -> hal::cvtBGRtoGray, color_rgb.dispatch.cpp:269) followed by
+ * cv::filter2D (filter.dispatch.cpp:1521) on device-resident CV_8UC3 / CV_8UC4 frames in one pass: the gray image is never written (SURVEY
+ * section 8d: 33.2 MB per 4K frame instead of 49.8 MB).  `context` from mi355cv_filterInit for CV_8UC1 -> CV_8UC1, 3x3 or 5x5, centred anchor;
+ * width a multiple of 16 pixels; NOT_IMPLEMENTED otherwise (make the two calls).  Bit-identical to the two-call sequence. */
+MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(struct cvhalFilter2D* context, const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int scn, bool swapBlue);
+
 /* replace hal_ni_sepFilterInit / hal_ni_sepFilter / hal_ni_sepFilterFree (hal_replacement.hpp:155,171,177);
  * callers: replacementSepFilter filter.dispatch.cpp:1362-1383 (cv::sepFilter2D, and through it Sobel/Scharr/
  * GaussianBlur on non-8U depths). */

@@ -115,6 +115,7 @@ def _load():
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_filterFree": (c_int, [ctypes.c_void_p]),
         "mi355cv_filterBatch": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int]),
+        "mi355cv_cvtBGRtoGrayFilterBatch": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_sepFilterInit": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, c_int, c_int, ctypes.c_void_p, c_int,
                                           ctypes.c_void_p, c_int, c_int, c_int, c_dbl, c_int]),
         "mi355cv_sepFilter": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_int]),

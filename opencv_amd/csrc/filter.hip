@@ -101,18 +101,71 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The float window of a row is held as pairs Q[m] = (p[m], p[m+8]) so that outputs i and i+8 of the lane advance together
 // through v_pk_fma_f32 (two FMAs per issue, tap broadcast by op_sel): the kernel would otherwise be VALU-bound at half the
 // HBM rate.  Each half keeps its own chain, so the accumulation order per pixel is still the raster order of the taps.
-template <int K, int CN, bool UP>
-__device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, uchar* __restrict__ dst, size_t dstep, const DenseTaps& t)
+// How a row reaches the lane: PlainRows loads the lane's 16 bytes of a CV_8U image as they are; GrayRows<SCN> loads the 16 x SCN bytes of a
+// BGR(A) / RGB(A) image and turns them into the 16 gray bytes cv::cvtColor would have written (RGB2Gray<uchar>, color_rgb.simd.hpp:660-748:
+// (c0 k0 + c1 k1 + c2 k2 + 2^14) >> 15) before anything else sees them -- the fused cvtColor -> filter2D pass of SURVEY §8d, which reads the
+// colour image once and never writes the gray one.
+template <int K, int CN> struct PlainRows {
+    typedef roll::Ctx<K / 2, K / 2, CN> Cx;
+    typedef typename Cx::RawT Raw;
+    __device__ __forceinline__ void issue(const Cx& cx, Raw& r, int j, int& valid) const { cx.issue(r, j, valid); }
+    __device__ __forceinline__ const typename Cx::RawT& bytes(const Raw& r) const { return r; }
+};
+template <int K, int SCN> struct GrayRows {
+    typedef roll::Ctx<K / 2, K / 2, 1> Cx;
+    static_assert(Cx::HD == 1 && Cx::MD == 4, "one side dword, 16-byte chunks");
+    struct Raw { uint32_t w[4 * SCN]; uint32_t s[SCN]; };
+    uint32_t k0, k1, k2;
+    __device__ __forceinline__ void issue(const Cx& cx, Raw& r, int j, int& valid) const
+    {
+        const int ry = cx.rowIdx(cx.gy(min(j, cx.nrows - 1 + K / 2)));
+        valid = ry >= 0;
+        const uchar* row = cx.src + (size_t)max(ry, 0) * cx.sstep;                    // cx.src / sstep describe the COLOUR image
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+        for (int i = 0; i < SCN; i++) {
+            const u32x4u v = *reinterpret_cast<const u32x4u*>(row + (size_t)SCN * cx.mainOff + 16 * i);
+            r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < SCN; i++) r.s[i] = *reinterpret_cast<const uint32_t*>(row + (size_t)SCN * cx.sideOff + 4 * i);
+    }
+    template <int NPX> __device__ __forceinline__ uint32_t gray4(const uint32_t* w, int first) const
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int b0 = (first + p) * SCN;
+            const uint32_t c0 = (w[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
+            const uint32_t c1 = (w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 0xffu;
+            const uint32_t c2 = (w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 0xffu;
+            acc |= ((c0 * k0 + c1 * k1 + c2 * k2 + (1u << 14)) >> 15) << (8 * p);
+        }
+        return acc;
+    }
+    __device__ __forceinline__ typename Cx::RawT bytes(const Raw& r) const
+    {
+        typename Cx::RawT g;
+#pragma unroll
+        for (int q = 0; q < 4; q++) g.m[q] = gray4<16>(r.w, 4 * q);
+        g.side[0] = gray4<4>(r.s, 0);
+        return g;
+    }
+};
+
+template <int K, int CN, bool UP, typename Rows>
+__device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, uchar* __restrict__ dst, size_t dstep, const DenseTaps& t, const Rows& rows)
 {
     constexpr int R = K / 2, HB = R * CN, HD = roll::Cfg<R, CN>::HD, NW = roll::Cfg<R, CN>::NW, NQ = 8 + 2 * HB;
     f32x2 Q[K][NQ];
-    auto toFloat = [&](f32x2 (&q)[NQ], const typename roll::Ctx<K / 2, K / 2, CN>::RawT& r, int valid) {
+    auto toFloat = [&](f32x2 (&q)[NQ], const typename Rows::Raw& rr, int valid) {
         if (!valid) {
 #pragma unroll
             for (int i = 0; i < NQ; i++) q[i] = f32x2{0.f, 0.f};
             return;
         }
         uint32_t X[NW];
+        const typename roll::Ctx<K / 2, K / 2, CN>::RawT r = rows.bytes(rr);
         cx.window(X, r);
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
@@ -123,19 +176,19 @@ __device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, ucha
     };
 #pragma unroll
     for (int i = 0; i < K - 1; i++) {                      // prologue: logical rows -R .. R-1
-        typename roll::Ctx<K / 2, K / 2, CN>::RawT pre; int v;
-        cx.issue(pre, i - R, v);
+        typename Rows::Raw pre; int v;
+        rows.issue(cx, pre, i - R, v);
         toFloat(Q[i], pre, v);
     }
-    typename roll::Ctx<K / 2, K / 2, CN>::RawT raw[K]; int rv[K];
+    typename Rows::Raw raw[K]; int rv[K];
 #pragma unroll
-    for (int u = 0; u < K; u++) cx.issue(raw[u], u + R, rv[u]);
+    for (int u = 0; u < K; u++) rows.issue(cx, raw[u], u + R, rv[u]);
     for (int y = 0; y < cx.nrows; y += K) {
 #pragma unroll
         for (int u = 0; u < K; u++) {
             if (y + u < cx.nrows) {
                 toFloat(Q[(K - 1 + u) % K], raw[u], rv[u]);
-                cx.issue(raw[u], y + u + K + R, rv[u]);
+                rows.issue(cx, raw[u], y + u + K + R, rv[u]);
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -168,8 +221,25 @@ __global__ __launch_bounds__(256) void k_filter2d_roll(const uchar* __restrict__
     roll::Ctx<K / 2, K / 2, CN> cx;
     if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
     dst += (size_t)cx.frame * dframe;
-    if (cx.up) filterRows<K, CN, true>(cx, dst, dstep, t);
-    else       filterRows<K, CN, false>(cx, dst, dstep, t);
+    const PlainRows<K, CN> rows;
+    if (cx.up) filterRows<K, CN, true>(cx, dst, dstep, t, rows);
+    else       filterRows<K, CN, false>(cx, dst, dstep, t, rows);
+}
+
+// cvtColor(BGR2GRAY / RGB2GRAY / BGRA2GRAY / RGBA2GRAY) followed by filter2D, in one pass: W is the width in pixels, the work split is that of
+// the gray image (a lane = 16 gray pixels = 16 SCN colour bytes)
+template <int K, int SCN>
+__global__ __launch_bounds__(256) void k_gray_filter2d_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                            uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                            int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt, DenseTaps t,
+                                                            int k0, int k1, int k2)
+{
+    roll::Ctx<K / 2, K / 2, 1> cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    dst += (size_t)cx.frame * dframe;
+    GrayRows<K, SCN> rows; rows.k0 = (uint32_t)k0; rows.k1 = (uint32_t)k1; rows.k2 = (uint32_t)k2;
+    if (cx.up) filterRows<K, 1, true>(cx, dst, dstep, t, rows);
+    else       filterRows<K, 1, false>(cx, dst, dstep, t, rows);
 }
 
 // ---------------------------------------------------------------------------------- separable
@@ -624,6 +694,36 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
         }
     }
     return stg.finish("filterBatch");
+}
+
+// cv::cvtColor(src, gray, COLOR_BGR2GRAY / RGB2GRAY / BGRA2GRAY / RGBA2GRAY) + cv::filter2D(gray, dst, ...) on device-resident CV_8UC3 / CV_8UC4
+// frames in ONE pass (33.2 MB per 4K frame instead of 49.8 MB): `context` comes from mi355cv_filterInit for CV_8UC1 -> CV_8UC1; the
+// intermediate gray image is never written.  Served for what the rolling filter kernel serves (3x3 / 5x5, centred anchor, rows of at least 16
+// pixels); NOT_IMPLEMENTED otherwise -- the caller then makes the two calls.  Results equal the two-call sequence bit for bit.
+MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride,
+        uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int scn, bool swapBlue)
+{
+    FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
+    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    const int K = c->kw;
+    if (c->cn != 1 || c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2)
+        return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoGrayFilterBatch: needs a centred 3x3 / 5x5 CV_8UC1 filter context");
+    if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
+    if (!roll::eligible(dst_data, dst_step, dst_frame_stride, dst_data, dst_step, dst_frame_stride, width, 1, K / 2, c->border) || (width & 15))
+        return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoGrayFilterBatch: width must be a multiple of 16 pixels");
+    Stager stg;
+    DenseTaps t; memset(&t, 0, sizeof t);
+    for (const Tap2D& tp : c->taps) t.k[tp.dy * K + tp.dx] = tp.k;
+    t.delta = c->delta;
+    const roll::Geom g = roll::geometry(width, height, 1, nframes, K == 3 ? 16 : 12, K);
+    const int k0 = swapBlue ? 9798 : 3735, k1 = 19235, k2 = swapBlue ? 3735 : 9798;      // color.simd_helpers.hpp:16-24 ({B2Y, G2Y, R2Y} in channel order)
+#define GROLL(K_, S_) hipLaunchKernelGGL((k_gray_filter2d_roll<K_, S_>), dim3(g.blocks), dim3(256), 0, stream(), src_data, src_step, src_frame_stride, dst_data, dst_step, \
+                                         dst_frame_stride, width, height, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, c->border, 1, t, k0, k1, k2)
+    if (K == 3) { if (scn == 3) GROLL(3, 3); else GROLL(3, 4); }
+    else        { if (scn == 3) GROLL(5, 3); else GROLL(5, 4); }
+#undef GROLL
+    return stg.finish("cvtBGRtoGrayFilterBatch");
 }
 
 MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,

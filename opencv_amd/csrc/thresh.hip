@@ -3,6 +3,7 @@
 // integer depths, thresh.cpp:1583-1680); per element dst = f(src > thresh) for the five fixed-level types
 // (thresh_8u :112, thresh_16u :300, thresh_16s :478, thresh_32f :652).  HBM-bound: 2 * elemSize bytes per element.
 #include "rt.h"
+#include <vector>
 #include <cmath>
 
 using namespace mi355;
@@ -66,35 +67,96 @@ __global__ __launch_bounds__(256) void k_adaptive(const uchar* __restrict__ src,
     }
 }
 
+// ADAPTIVE_THRESH_GAUSSIAN_C: the source as float (src.convertTo(CV_32F), thresh.cpp:1722) ...
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uchar* __restrict__ src, size_t sstep, float* __restrict__ dst, size_t dstepF, int W, int H)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (x + k < W) dst[(size_t)y * dstepF + x + k] = (float)src[(size_t)y * sstep + x + k];
+}
+
+// ... and the comparison against the blurred float image brought back to 8 bits (meanfloat.convertTo(mean, CV_8U): cvRound + saturate)
+__global__ __launch_bounds__(256) void k_adaptive_f(const uchar* __restrict__ src, size_t sstep, const float* __restrict__ mean, size_t mstepF,
+                                                    uchar* __restrict__ dst, size_t dstep, int W, int H, int idelta, int maxval, int inv)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (x + k < W) {
+            const float mf = __builtin_rintf(mean[(size_t)y * mstepF + x + k]);
+            const int m = (int)fminf(fmaxf(mf, 0.f), 255.f);
+            const int v = (int)src[(size_t)y * sstep + x + k] - m;
+            const bool on = inv ? v <= -idelta : v > -idelta;
+            dst[(size_t)y * dstep + x + k] = (uchar)(on ? maxval : 0);
+        }
+    }
+}
+
 } // namespace
 
 extern "C" MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type);
 
-// replaces hal_ni_adaptiveThreshold (hal_replacement.hpp:1038; caller cv::adaptiveThreshold thresh.cpp:1711): CV_8UC1,
-// ADAPTIVE_THRESH_MEAN_C with blockSize <= 15 (the exact u16 box filter; the Gaussian variant runs a float blur and is left to the
-// CPU), THRESH_BINARY / THRESH_BINARY_INV.  mean = boxFilter(src, blockSize, BORDER_REPLICATE | BORDER_ISOLATED), then the table.
+struct cvhalFilter2D;
+extern "C" MI355CV_API int mi355cv_sepFilterInit(cvhalFilter2D** context, int src_type, int dst_type, int kernel_type, uchar* kernelx_data, int kernelx_length,
+                                                 uchar* kernely_data, int kernely_length, int anchor_x, int anchor_y, double delta, int borderType);
+extern "C" MI355CV_API int mi355cv_sepFilter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                             int full_width, int full_height, int offset_x, int offset_y);
+extern "C" MI355CV_API int mi355cv_sepFilterFree(cvhalFilter2D* context);
+extern "C" MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double* taps);
+
+// replaces hal_ni_adaptiveThreshold (hal_replacement.hpp:1038; caller cv::adaptiveThreshold thresh.cpp:1711): CV_8UC1, THRESH_BINARY / THRESH_BINARY_INV.
+//   ADAPTIVE_THRESH_MEAN_C:     mean = boxFilter(src, blockSize, normalised, BORDER_REPLICATE | BORDER_ISOLATED) (thresh.cpp:1718), any odd blockSize the
+//                               box hook serves (u16 sums up to 15 x 15, int32 sums with the reference's float body / double tail beyond);
+//   ADAPTIVE_THRESH_GAUSSIAN_C: mean = saturate_cast<uchar>(GaussianBlur(float(src), blockSize, sigma = 0)) (thresh.cpp:1720-1727): the source as
+//                               CV_32F, the CV_32F separable path with the taps of getGaussianKernel(blockSize, -1, CV_32F) -- the very hook a CV_32F
+//                               cv::GaussianBlur lands in --, cvRound back to 8 bits;
+// then the table of :1736-1745 evaluated directly.
 extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                      double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C)
 {
     if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
-    if (adaptiveMethod != 0 /*ADAPTIVE_THRESH_MEAN_C*/ || (thresholdType != 0 && thresholdType != 1)) return MI355CV_NOT_IMPLEMENTED;
-    if (blockSize < 3 || !(blockSize & 1) || blockSize > 15) return MI355CV_NOT_IMPLEMENTED;
+    if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
-    const size_t mstep = ((size_t)width + 255) & ~(size_t)255;
-    uchar* mean = (uchar*)stg.scratch(mstep * height);
-    if (!ds || !dd || !mean) return MI355CV_NOT_IMPLEMENTED;
-    const int rc = mi355cv_boxFilter(ds, dss, mean, mstep, width, height, D8U, D8U, 1, 0, 0, 0, 0, (size_t)blockSize, (size_t)blockSize, -1, -1, true, B_REPLICATE);
-    if (rc != MI355CV_OK) return rc;
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     double mv = nearbyint(maxValue); mv = mv < 0 ? 0 : mv > 255 ? 255 : mv;                       // saturate_cast<uchar>(maxValue)
     const int idelta = thresholdType == 0 ? (int)ceil(C) : (int)floor(C);
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height, 4));
-    hipLaunchKernelGGL(k_adaptive, grid, dim3(256), 0, stream(), ds, dss, mean, mstep, dd, dds, width, height, idelta, (int)mv, thresholdType);
+    if (adaptiveMethod == 0) {
+        const size_t mstep = ((size_t)width + 255) & ~(size_t)255;
+        uchar* mean = (uchar*)stg.scratch(mstep * height);
+        if (!mean) return MI355CV_NOT_IMPLEMENTED;
+        const int rc = mi355cv_boxFilter(ds, dss, mean, mstep, width, height, D8U, D8U, 1, 0, 0, 0, 0, (size_t)blockSize, (size_t)blockSize, -1, -1, true, B_REPLICATE);
+        if (rc != MI355CV_OK) return rc;
+        hipLaunchKernelGGL(k_adaptive, grid, dim3(256), 0, stream(), ds, dss, mean, mstep, dd, dds, width, height, idelta, (int)mv, thresholdType);
+        return stg.finish("adaptiveThreshold");
+    }
+    const size_t fstep = (((size_t)width + 63) & ~(size_t)63);                                     // floats per row of the two CV_32F planes
+    float* sf = (float*)stg.scratch(fstep * 4 * height);
+    float* mf = (float*)stg.scratch(fstep * 4 * height);
+    if (!sf || !mf) return MI355CV_NOT_IMPLEMENTED;
+    std::vector<double> kd(blockSize);
+    if (mi355cv_getGaussianKernel(blockSize, 0.0, kd.data()) != MI355CV_OK) return MI355CV_NOT_IMPLEMENTED;
+    std::vector<float> kf(kd.begin(), kd.end());                                                   // getGaussianKernel(n, sigma, CV_32F): the double taps stored as float
+    cvhalFilter2D* ctx = nullptr;
+    int rc = mi355cv_sepFilterInit(&ctx, MI355CV_MAKETYPE(MI355CV_32F, 1), MI355CV_MAKETYPE(MI355CV_32F, 1), MI355CV_MAKETYPE(MI355CV_32F, 1), (uchar*)kf.data(), blockSize,
+                                   (uchar*)kf.data(), blockSize, -1, -1, 0.0, B_REPLICATE);
+    if (rc != MI355CV_OK) return rc;
+    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, stream(), ds, dss, sf, fstep, width, height);
+    rc = mi355cv_sepFilter(ctx, (uchar*)sf, fstep * 4, (uchar*)mf, fstep * 4, width, height, width, height, 0, 0);
+    mi355cv_sepFilterFree(ctx);
+    if (rc != MI355CV_OK) return rc;
+    hipLaunchKernelGGL(k_adaptive_f, grid, dim3(256), 0, stream(), ds, dss, mf, fstep, dd, dds, width, height, idelta, (int)mv, thresholdType);
     return stg.finish("adaptiveThreshold");
 }
 

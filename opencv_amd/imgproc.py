@@ -27,7 +27,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
            "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
-           "filter2D", "filter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
+           "filter2D", "filter2DBatch", "cvtColorFilter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
 
@@ -489,7 +489,8 @@ ADAPTIVE_THRESH_MEAN_C, ADAPTIVE_THRESH_GAUSSIAN_C = 0, 1
 
 
 def adaptiveThreshold(src, maxValue, adaptiveMethod, thresholdType, blockSize, C, dst=None):
-    """cv::adaptiveThreshold (thresh.cpp:1693) through cv_hal_adaptiveThreshold: CV_8UC1, ADAPTIVE_THRESH_MEAN_C, blockSize <= 15."""
+    """cv::adaptiveThreshold (thresh.cpp:1693) through cv_hal_adaptiveThreshold: CV_8UC1, ADAPTIVE_THRESH_MEAN_C (any odd block the box hook
+    serves) and ADAPTIVE_THRESH_GAUSSIAN_C (blockSize <= 33, the separable hook's tap limit)."""
     s = Img(src)
     if s.depth != CV_8U or s.cn != 1:
         raise ValueError("adaptiveThreshold: CV_8UC1 only")                                   # CV_Assert, :1699
@@ -657,6 +658,32 @@ def filter2DBatch(frames, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType
     finally:
         L.mi355cv_filterFree(ctx)
     _lib.check(rc, "filterBatch")
+    return out
+
+
+def cvtColorFilter2DBatch(frames, code, kernel, delta=0.0, borderType=BORDER_DEFAULT, dst=None):
+    """filter2D(cvtColor(frame, code), -1, kernel) for [N,H,W,3|4] CV_8U device frames and code in {BGR2GRAY, RGB2GRAY, BGRA2GRAY, RGBA2GRAY}, in ONE
+    pass over the colour frames (mi355cv_cvtBGRtoGrayFilterBatch): the gray frames are never written.  3x3 / 5x5 kernels, centred anchor, width a
+    multiple of 16; the library declines anything else (make the two calls then)."""
+    if code not in (COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_BGRA2GRAY, COLOR_RGBA2GRAY):
+        raise NotImplementedError("cvtColorFilter2DBatch: a colour -> gray code")
+    n, h, w, scn = (int(v) for v in frames.shape)
+    if scn != (4 if code in (COLOR_BGRA2GRAY, COLOR_RGBA2GRAY) else 3):
+        raise ValueError("channel count does not match the conversion code")
+    k = _np_kernel(kernel)
+    kh, kw = k.shape
+    out = dst if dst is not None else torch.empty((n, h, w), dtype=frames.dtype, device=frames.device)
+    s0, d0 = Img(frames[0]), Img(out[0])
+    bind_stream(s0, d0)
+    ctx = ctypes.c_void_p()
+    _lib.check(L.mi355cv_filterInit(ctypes.byref(ctx), k.ctypes.data, k.strides[0], _K_TYPE[k.dtype], kw, kh, w, h, d0.type, d0.type,
+                                    borderType & ~BORDER_ISOLATED, float(delta), kw // 2, kh // 2, False, False), "filterInit")
+    try:
+        rc = L.mi355cv_cvtBGRtoGrayFilterBatch(ctx, _vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz,
+                                               n, w, h, scn, code in (COLOR_RGB2GRAY, COLOR_RGBA2GRAY))
+    finally:
+        L.mi355cv_filterFree(ctx)
+    _lib.check(rc, "cvtBGRtoGrayFilterBatch")
     return out
 
 

@@ -150,6 +150,8 @@ int orc_medianBlur(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
 
 int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
                               int blockSize, double delta);
+int orc_adaptiveThresholdGaussian(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
+                                  int blockSize, double delta);
 
 /* cv::Canny, see oracle/canny.c (CV_8U, 1..4 channels, aperture 3 / 5) */
 int orc_Canny(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, double low_thresh, double high_thresh,

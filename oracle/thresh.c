@@ -93,3 +93,38 @@ int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, si
     free(mean);
     return 0;
 }
+
+
+/* cv::adaptiveThreshold with ADAPTIVE_THRESH_GAUSSIAN_C (thresh.cpp:1720-1727): src.convertTo(CV_32F); GaussianBlur(srcfloat, meanfloat,
+ * Size(blockSize, blockSize), 0, 0, BORDER_REPLICATE | BORDER_ISOLATED) -- for CV_32F that is sepFilter2D with the CV_32F taps of
+ * getGaussianKernel(blockSize, 0) (createGaussianKernels, smooth.dispatch.cpp:264-300) --; meanfloat.convertTo(mean, CV_8U); then the same table. */
+void orc_sepFilter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth, int ddepth,
+                     int fullW, int fullH, int offX, int offY, const double* kx, int nx, const double* ky, int ny,
+                     int ax, int ay, double delta, int border);
+int orc_getGaussianKernel(int n, double sigma, double* taps);
+int orc_adaptiveThresholdGaussian(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
+                                  int blockSize, double delta)
+{
+    if ((type != 0 && type != 1) || blockSize < 3 || !(blockSize & 1) || blockSize > 63) return 1;
+    if (maxValue < 0) { for (int y = 0; y < h; y++) memset(dst + (size_t)y * dstep, 0, (size_t)w); return 0; }
+    double kd[64];
+    if (orc_getGaussianKernel(blockSize, 0.0, kd)) return 1;
+    for (int i = 0; i < blockSize; i++) kd[i] = (double)(float)kd[i];                  /* the CV_32F kernel */
+    float* sf = (float*)malloc(sizeof(float) * (size_t)w * h);
+    float* mf = (float*)malloc(sizeof(float) * (size_t)w * h);
+    if (!sf || !mf) { free(sf); free(mf); return 1; }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) sf[(size_t)y * w + x] = (float)src[(size_t)y * sstep + x];
+    orc_sepFilter2D((const uint8_t*)sf, (size_t)w * 4, (uint8_t*)mf, (size_t)w * 4, w, h, 1, 5, 5, w, h, 0, 0, kd, blockSize, kd, blockSize, -1, -1, 0.0,
+                    ORC_BORDER_REPLICATE);
+    int mv = cvRoundD(maxValue); mv = mv < 0 ? 0 : mv > 255 ? 255 : mv;
+    const int idelta = type == 0 ? (int)ceil(delta) : (int)floor(delta);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int m = cvRoundD((double)mf[(size_t)y * w + x]); m = m < 0 ? 0 : m > 255 ? 255 : m;
+            const int v = src[(size_t)y * sstep + x] - m;
+            dst[(size_t)y * dstep + x] = (uint8_t)(type == 0 ? (v > -idelta ? mv : 0) : (v <= -idelta ? mv : 0));
+        }
+    free(sf); free(mf);
+    return 0;
+}

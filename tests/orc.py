@@ -356,11 +356,11 @@ def ref_morph(op, src, kernel=None, anchor=(-1, -1), iterations=1, border=0, bor
     return dst
 
 
-def orc_adaptiveThreshold(src, maxValue, type, blockSize, C):
+def orc_adaptiveThreshold(src, maxValue, type, blockSize, C, method=0):
     o = oracle()
     h, w = src.shape
     dst = np.empty_like(src)
-    rc = o.orc_adaptiveThresholdMean(P(src), step(src), P(dst), step(dst), w, h, ctypes.c_double(maxValue), type, blockSize, ctypes.c_double(C))
+    rc = (o.orc_adaptiveThresholdGaussian if method else o.orc_adaptiveThresholdMean)(P(src), step(src), P(dst), step(dst), w, h, ctypes.c_double(maxValue), type, blockSize, ctypes.c_double(C))
     assert rc == 0, rc
     return dst
 

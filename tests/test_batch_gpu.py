@@ -65,3 +65,25 @@ def test_geometry_batches(cv, dtype, cn):
 def test_batch_entries_refuse_host_memory(cv):
     with pytest.raises(ValueError):
         cv.SobelBatch(np.zeros((2, 8, 8), np.uint8), cv.CV_16S, 1, 0)
+
+
+@pytest.mark.parametrize("scn", [3, 4])
+def test_fused_cvtcolor_filter2d(cv, scn):
+    """cvtColorFilter2DBatch = filter2D(cvtColor(frame, *2GRAY), -1, K) in one pass over the colour frames: bit-identical to
+    the two batched calls -- which are pinned to the oracle elsewhere -- for 3x3 / 5x5 float and integer kernels, both channel orders, three
+    borders, delta, widths of one and of several 1 KiB strips, and heights that are not a multiple of the segment length"""
+    rng = np.random.default_rng(5 + scn)
+    ks = [np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32), (rng.uniform(-3, 10, (3, 3)) / 31.5).astype(np.float32),
+          (rng.uniform(-3, 10, (5, 5)) / 87.5).astype(np.float32), np.ones((5, 5), np.float32) / 25]
+    codes = [cv.COLOR_BGR2GRAY, cv.COLOR_RGB2GRAY] if scn == 3 else [cv.COLOR_BGRA2GRAY, cv.COLOR_RGBA2GRAY]
+    for (n, h, w) in [(2, 37, 64), (3, 101, 1040), (1, 64, 2064), (2, 5, 16)]:
+        fr = torch.from_numpy(rng.integers(0, 256, (n, h, w, scn), dtype=np.uint8)).cuda()
+        for code in codes:
+            gray = cv.cvtColorBatch(fr, code)
+            for k in ks:
+                for border, delta in [(4, 0.0), (1, 3.5), (0, 0.0), (2, -2.0)]:
+                    want = cv.filter2DBatch(gray, -1, k, delta=delta, borderType=border)
+                    got = cv.cvtColorFilter2DBatch(fr, code, k, delta=delta, borderType=border)
+                    assert torch.equal(got, want), (n, h, w, code, k.shape, border)
+    with pytest.raises(NotImplementedError):                   # a width that is not a multiple of 16 is declined, nothing is computed elsewhere
+        cv.cvtColorFilter2DBatch(torch.zeros((1, 20, 40, scn), dtype=torch.uint8, device="cuda"), codes[0], ks[0])

@@ -55,3 +55,24 @@ def test_adaptive_threshold_mean_matches_reference(ref):
                         want = O.ref_adaptiveThreshold(src, mv, 0, ttype, bs, C)
                         got = O.orc_adaptiveThreshold(src, mv, ttype, bs, C)
                         assert np.array_equal(got, want), (shape, bs, ttype, C, mv)
+
+
+@pytest.mark.ref
+def test_adaptive_threshold_gaussian_and_large_blocks_match_reference(ref):
+    """ADAPTIVE_THRESH_GAUSSIAN_C (float blur of the float image, back to 8 bits, thresh.cpp:1720-1727) and MEAN_C beyond 15 x 15 (int32 box
+    sums with the reference's float body / double tail) against the real reference"""
+    rng = np.random.default_rng(33)
+    for shape in [(37, 61), (64, 64), (5, 9), (1, 20), (150, 333)]:
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        smooth = np.clip(np.add.outer(np.arange(shape[0]) * 3, np.arange(shape[1]) * 2) % 256 + rng.integers(-2, 3, shape), 0, 255).astype(np.uint8)
+        for img in (src, smooth):
+            for bs in (3, 5, 7, 9, 11, 15, 21, 33):
+                for ttype in (0, 1):
+                    for C in (0.0, 2.0, -3.5):
+                        want = O.ref_adaptiveThreshold(img, 255.0, 1, ttype, bs, C)
+                        got = O.orc_adaptiveThreshold(img, 255.0, ttype, bs, C, method=1)
+                        assert np.array_equal(got, want), ("gaussian", shape, bs, ttype, C)
+            for bs in (17, 21, 31, 51):
+                want = O.ref_adaptiveThreshold(img, 200.0, 0, 0, bs, 1.5)
+                got = O.orc_adaptiveThreshold(img, 200.0, 0, bs, 1.5)
+                assert np.array_equal(got, want), ("mean", shape, bs)

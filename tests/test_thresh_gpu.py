@@ -59,5 +59,18 @@ def test_adaptive_threshold(cv, orc):
     d = torch.from_numpy(src).cuda()
     cv.adaptiveThreshold(d, 200.0, 0, 1, 7, 1.0, dst=d)                                                                       # in place
     assert np.array_equal(d.cpu().numpy(), orc.orc_adaptiveThreshold(src, 200.0, 1, 7, 1.0))
-    with pytest.raises(NotImplementedError):
-        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 5, 0.0)
+    # ADAPTIVE_THRESH_GAUSSIAN_C (float blur + cvRound, thresh.cpp:1720-1727) and MEAN_C blocks beyond 15 x 15 (int32 box sums)
+    for shape in [(37, 61), (5, 9), (1, 20), (480, 640)]:
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        for bs in (3, 5, 7, 11, 21, 33):
+            for ttype in (0, 1):
+                for C in (0.0, -3.5):
+                    want = orc.orc_adaptiveThreshold(src, 255.0, ttype, bs, C, method=1)
+                    got = cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, ttype, bs, C).cpu().numpy()
+                    assert np.array_equal(got, want), ("gaussian", shape, bs, ttype, C)
+        for bs in (17, 31, 51):
+            want = orc.orc_adaptiveThreshold(src, 200.0, 0, bs, 1.5)
+            assert np.array_equal(cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 200.0, cv.ADAPTIVE_THRESH_MEAN_C, 0, bs, 1.5).cpu().numpy(), want), ("mean", shape, bs)
+    assert np.array_equal(cv.adaptiveThreshold(src, 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 7, 2.0), orc.orc_adaptiveThreshold(src, 255.0, 0, 7, 2.0, method=1))   # host pointers
+    with pytest.raises(NotImplementedError):                      # more taps than the separable hook's context holds
+        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 101, 0.0)

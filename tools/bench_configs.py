@@ -124,6 +124,13 @@ def run(quick=False, parity=True):
     by = B2 * 3840 * 2160 * 2
     out.append({"config": "cfg2c filter2D 3x3 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
                 "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4)})
+    # the whole of config 2 in one pass: the colour frames are read once, the gray frames never exist (33 177 600 B per frame)
+    ms = timeit(lambda: cv.cvtColorFilter2DBatch(bgr, cv.COLOR_BGR2GRAY, k, dst=dstb))
+    assert torch.equal(dstb, cv.filter2DBatch(gray, -1, k)), "fused cvtColor + filter2D differs from the two calls"
+    by = B2 * 3840 * 2160 * 4
+    out.append({"config": "cfg2e cvtColor BGR2GRAY + filter2D 3x3 fused, 4K 8UC3 -> 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
+                "bound": "hbm", "achieved_GBs": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM, 4), "parity": "equal to the two-call sequence (whole batch)"})
+    by = B2 * 3840 * 2160 * 2
     k5 = (np.arange(25, dtype=np.float32).reshape(5, 5) - 12) / 64
     ms = timeit(lambda: cv.filter2DBatch(gray, -1, k5, dst=dstb))
     out.append({"config": "cfg2d filter2D 5x5 4K 8UC1 batch", "frames": B2, "ms": round(ms, 4), "Mpix_s": round(B2 * 8.2944 / ms * 1e3, 1),
