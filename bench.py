@@ -221,22 +221,22 @@ def parity_gate(cv, frames, out, B):
     return {"frames_vs_oracle": checked, "frames_vs_single_frame_hook": 16, "result": "bit-exact"}
 
 
-def copy_probe(frames, out, reps=3):
-    """the measured-copy denominator: a 16 B / lane device-to-device copy of the same batch, timed the same way"""
+def copy_probe(views, reps=2):
+    """the measured-copy denominator: a 16 B / lane device-to-device copy of the same sub-batches, launched and timed the same way"""
     import ctypes
     from opencv_amd import _lib
     from opencv_amd.core import bind_stream, Img
-    bind_stream(Img(frames[0]))
-    nbytes = frames.numel()
-    call = lambda: _lib.lib.mi355cv_copyProbe(ctypes.c_void_p(frames.data_ptr()), ctypes.c_void_p(out.data_ptr()), nbytes, 4, 1)
-    assert call() == 0
+    bind_stream(Img(views[0][0][0]))
+    calls = [(ctypes.c_void_p(f.data_ptr()), ctypes.c_void_p(o.data_ptr()), ctypes.c_size_t(f.numel())) for f, o in views]
+    assert _lib.lib.mi355cv_copyProbe(calls[0][0], calls[0][1], calls[0][2], 4, 1) == 0
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        call()
+        for sp, dp, nb in calls:
+            _lib.lib.mi355cv_copyProbe(sp, dp, nb, 4, 1)
     b.record(); torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    return 2.0 * sum(f.numel() for f, _ in views) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
 def multi_gpu_legs(cv, dist, dev, rank, world):
@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MI355CV_BENCH_BATCH", "0")),
                     help="4K frames per GPU per step; 0 = sized for the GPU's HBM (see pick_batch)")
+    ap.add_argument("--frames-per-launch", type=int, default=int(os.environ.get("MI355CV_BENCH_FPL", "512")),
+                    help="a step (one pass over the resident batch) is issued as consecutive launches over sub-batches of this many frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs)")
     args = ap.parse_args()
@@ -325,6 +327,12 @@ def main():
         tb = torch.tensor([B], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         B = int(tb[0])
+    # A step = ONE pass of the hot path over the whole resident batch, issued as B / FPL consecutive launches over sub-batches of FPL frames:
+    # the same 9216 frames ran 4-6 % slower as a single 1.66 M-workgroup launch than as 18 launches of 512 frames (tools/split_probe.py,
+    # profiles/r02_split_probe.txt) -- the library's batch entry splits a large batch the same way on its own; here the sub-batches are
+    # explicit so that every kernel launch gets its own pair of events.
+    FPL = max(1, min(args.frames_per_launch, B))
+    B = B // FPL * FPL
     g = torch.Generator(device=dev)
     g.manual_seed(809564 + rank)
     frames = torch.empty((B, H4K, W4K), dtype=torch.uint8, device=dev)
@@ -338,36 +346,44 @@ def main():
     kernel = _lib.lib.mi355cv_lastKernel().decode()
     parity = parity_gate(cv, frames, out, B) if rank == 0 else None
 
+    views = [(frames[lo:lo + FPL], out[lo:lo + FPL]) for lo in range(0, B, FPL)]
+    nl = len(views)
     cv.set_async(True)
+    cv.GaussianBlurBatch(views[0][0], 5, dst=views[0][1])
+    kernel = _lib.lib.mi355cv_lastKernel().decode()        # the instance and geometry of the timed launches
     for _ in range(args.warmup):
-        cv.GaussianBlurBatch(frames, 5, dst=out)
+        for f, o in views:
+            cv.GaussianBlurBatch(f, 5, dst=o)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps * nl + 1)]
     t0 = time.perf_counter()
+    k = 0
     for s in range(args.steps):
-        ev[s][0].record()                      # launches are bound to torch's current stream (core.bind_stream)
-        cv.GaussianBlurBatch(frames, 5, dst=out)
-        ev[s][1].record()
+        for f, o in views:
+            ev[k].record(); k += 1             # launches are bound to torch's current stream (core.bind_stream)
+            cv.GaussianBlurBatch(f, 5, dst=o)
+    ev[k].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     cv.set_async(False)
-    per_step = np.array([a.elapsed_time(b) for a, b in ev])
-    kern_ms = float(per_step.mean())
+    per_launch = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps * nl)])      # launch to launch: gaps included
+    per_step = per_launch.reshape(args.steps, nl).sum(axis=1)
+    kern_ms = float(per_launch.mean())
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
-    copy_gbs = copy_probe(frames, out) if rank == 0 else None
+    copy_gbs = copy_probe(views) if rank == 0 else None
 
     legs = None
     if world > 1 and not args.no_other_configs:
-        del frames, out
+        del frames, out, views
         torch.cuda.empty_cache()
         try:
             legs = multi_gpu_legs(cv, dist, dev, rank, world)
@@ -377,7 +393,7 @@ def main():
     if rank == 0:
         pix_per_step = B * W4K * H4K
         value = world * pix_per_step * args.steps / elapsed / 1e6
-        algo = ALGO_BYTES_PER_PIXEL * pix_per_step
+        algo = ALGO_BYTES_PER_PIXEL * FPL * W4K * H4K        # per kernel launch
         achieved = algo / (kern_ms * 1e-3) / 1e9
         q = max(1, args.steps // 4)
         # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this same command (tools/prof_gauss.sh), corrected
@@ -388,7 +404,7 @@ def main():
             try:
                 j = json.load(open(tj))
                 if j.get("kernel", "").split(" grid=")[0] == kernel.split(" grid=")[0] and j.get("frames_per_launch"):
-                    traffic = int(j["hbm_bytes_per_launch"] * (B / j["frames_per_launch"]))
+                    traffic = int(j["hbm_bytes_per_launch"] * (FPL / j["frames_per_launch"]))
                     traffic_src = j.get("source")
             except Exception:
                 traffic = None
@@ -398,8 +414,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "cv::GaussianBlur 5x5 sigma=0 BORDER_REFLECT_101 on 3840x2160 CV_8UC1, "
-                                   f"{B} device-resident frames per GPU per step (one batched launch over {2 * B * W4K * H4K / 1e9:.1f} GB of HBM)",
-                       "frames_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "ranks": world,
+                                   f"{B} device-resident frames per GPU per step ({2 * B * W4K * H4K / 1e9:.1f} GB of HBM: one pass = {nl} launches of {FPL} frames)",
+                       "frames_per_gpu": B, "frames_per_launch": FPL, "launches_per_step": nl, "sharding": f"frames x{world}, no data-path collective", "ranks": world,
                        "collective": "RCCL broadcast of the filter taps at plan time" if world > 1 else "none (1 GPU)"},
             "per_gpu_mpix_s": round(value / world, 1),
             "timed_region_s": round(elapsed, 4),
@@ -407,10 +423,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "avg_launch_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(algo),
-                         "launch_ms": {"median": round(float(np.median(per_step)), 4), "p10": round(float(np.percentile(per_step, 10)), 4),
-                                       "p90": round(float(np.percentile(per_step, 90)), 4), "min": round(float(per_step.min()), 4),
-                                       "max": round(float(per_step.max()), 4), "first_quarter_mean": round(float(per_step[:q].mean()), 4),
-                                       "rest_mean": round(float(per_step[q:].mean()), 4) if args.steps > q else None},
+                         "launches_timed": int(per_launch.size),
+                         "launch_ms": {"median": round(float(np.median(per_launch)), 4), "p10": round(float(np.percentile(per_launch, 10)), 4),
+                                       "p90": round(float(np.percentile(per_launch, 90)), 4), "min": round(float(per_launch.min()), 4),
+                                       "max": round(float(per_launch.max()), 4)},
+                         "step_ms": {"median": round(float(np.median(per_step)), 4), "min": round(float(per_step.min()), 4), "max": round(float(per_step.max()), 4),
+                                     "first_quarter_mean": round(float(per_step[:q].mean()), 4),
+                                     "rest_mean": round(float(per_step[q:].mean()), 4) if args.steps > q else None},
                          "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)},
             "parity": parity,
         }
@@ -419,7 +438,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_other_configs:
-            del frames, out
+            del frames, out, views
             torch.cuda.empty_cache()
             try:
                 res["other_configs"] = other_configs(with_cpu=not args.no_cpu_baseline)

@@ -568,6 +568,7 @@ int& tuneSeg() { static int v = envInt("MI355CV_GAUSS_SEG", 0); return v; }
 int& tuneVariant() { static int v = envInt("MI355CV_GAUSS_VARIANT", 3); return v; }   // 1: k_binomial_roll, 2: roll2, 3: roll2 + nt stores, 4: 3 with the edge halos as selects instead of branches, 5: 3 at 6 waves / SIMD
 
 int& tuneAlt() { static int v = envInt("MI355CV_GAUSS_ALT", 1); return v; }   // 1: alternate walking direction of vertical neighbours
+int& tuneLaunchWaves() { static int v = envInt("MI355CV_GAUSS_LAUNCH_WAVES", 393216); return v; }   // work items per launch of a batch (0: one launch)
 
 template <int KS, int CN>
 void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nframes, int W, int H, int border, hipStream_t st, int nt)
@@ -576,27 +577,40 @@ void launchRoll2(const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size
     const int nstrips = divUp(nchunks, 64);
     int seg = tuneSeg();
     if (seg <= 0) {
-        // Short segments keep the set of rows being streamed at any instant compact.  Interleaved A/B on 128 x 4K
-        // frames (tools/ab_gauss.py, profiles/r01_ab_gauss.txt): 12 rows per work item with alternating walking
-        // direction = 71.1 % of 8 TB/s, 16 rows = 69.6 %, 20 rows = 68.1 % -- although a 5x5 then re-reads 4/12 of its
-        // rows (from L2, thanks to the pairing).  Single frames go shorter still so that >= ~2 waves per SIMD exist.
+        // Short segments keep the set of rows being streamed at any instant compact, although a 5x5 then re-reads 4 / seg of its rows (from
+        // L2, thanks to the pairing).  Interleaved A/Bs (tools/ab_gauss.py, tools/footprint_sweep.py, profiles/r02_ab_gauss.txt): 12 and 16
+        // rows are within 2 % of each other and the order depends on the box; 16 won on three boxes out of four with this kernel (72.9-75.4 %
+        // against 70.8-73.3 %), 20 and 24 rows lose 2-4 %.  Single frames go shorter still so that >= ~2 waves per SIMD exist.
         long long per = (long long)nstrips * nframes;
         long long wantSeg = (2048 + per - 1) / per;
         seg = (int)((H + wantSeg - 1) / wantSeg);
-        const int best = KS == 5 ? 12 : 16;
+        const int best = 16;
         if (seg > best) seg = best;
         if (seg < KS) seg = KS;
     }
     if (seg > H) seg = H;                       // any length works: the row loop guards its tail rows
     const int nseg = divUp(H, seg);
-    const long long items = (long long)nstrips * nseg * nframes;
-    dim3 grid((unsigned)((items + 3) / 4));
-    noteKernel("k_binomial_roll2<%d,%d,%s,false,%d,%s> grid=%u x256 seg=%d rows alt=%d", KS, CN, nt >= 1 ? "true" : "false", nt == 3 ? 6 : 4, nt == 2 ? "false" : "true",
-               grid.x, seg, tuneAlt());
-    if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
-    else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4, false>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
-    else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
-    else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, s, ss, sf, d, ds, df, W, H, nchunks, nstrips, seg, nseg, nframes, border, tuneAlt());
+    // A pass over a large batch is issued as consecutive launches of at most ~tuneLaunchWaves() work items: the same 9216 x 4K frames ran at
+    // 70.0-71.0 % of 8 TB/s as ONE launch and at 73.3-75.4 % as 18 launches of 512 frames (tools/split_probe.py, same buffers, launch gaps
+    // included) -- over a very long launch the resident work items drift apart, which costs the shared halo rows their L2 hits and spreads the
+    // rows being streamed.  Stream order keeps the launches back to back.
+    const long long perFrame = (long long)nstrips * nseg;
+    long long chunk = tuneLaunchWaves() > 0 ? (tuneLaunchWaves() + perFrame - 1) / perFrame : nframes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > nframes) chunk = nframes;
+    const int nlaunch = (int)((nframes + chunk - 1) / chunk);
+    noteKernel("k_binomial_roll2<%d,%d,%s,false,%d,%s> grid=%u x256 seg=%d rows alt=%d, %d launch(es) of <= %lld frames", KS, CN, nt >= 1 ? "true" : "false", nt == 3 ? 6 : 4,
+               nt == 2 ? "false" : "true", (unsigned)((perFrame * chunk + 3) / 4), seg, tuneAlt(), nlaunch, chunk);
+    for (long long f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = (int)(nframes - f0 < chunk ? nframes - f0 : chunk);
+        const uchar* sp = s + (size_t)f0 * sf;
+        uchar* dp = d + (size_t)f0 * df;
+        dim3 grid((unsigned)((perFrame * nf + 3) / 4));
+        if (nt == 3)      hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 6>), grid, dim3(256), 0, st, sp, ss, sf, dp, ds, df, W, H, nchunks, nstrips, seg, nseg, nf, border, tuneAlt());
+        else if (nt == 2) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4, false>), grid, dim3(256), 0, st, sp, ss, sf, dp, ds, df, W, H, nchunks, nstrips, seg, nseg, nf, border, tuneAlt());
+        else if (nt == 1) hipLaunchKernelGGL((k_binomial_roll2<KS, CN, true, false, 4>), grid, dim3(256), 0, st, sp, ss, sf, dp, ds, df, W, H, nchunks, nstrips, seg, nseg, nf, border, tuneAlt());
+        else              hipLaunchKernelGGL((k_binomial_roll2<KS, CN, false, false, 4>), grid, dim3(256), 0, st, sp, ss, sf, dp, ds, df, W, H, nchunks, nstrips, seg, nseg, nf, border, tuneAlt());
+    }
 }
 
 template <int KS, int CN>
@@ -766,6 +780,7 @@ MI355CV_API int mi355cv_setParam(const char* key, int value)
     if (!strcmp(key, "gauss_seg")) { tuneSeg() = value; return 0; }
     if (!strcmp(key, "gauss_variant")) { tuneVariant() = value; return 0; }
     if (!strcmp(key, "gauss_alt")) { tuneAlt() = value; return 0; }
+    if (!strcmp(key, "gauss_launch_waves")) { tuneLaunchWaves() = value; return 0; }
     return -1;
 }
 
