@@ -975,7 +975,9 @@ __global__ __launch_bounds__(256) void k_convert_maps_to_float(const uchar* __re
 // sat_int(M0*x*1024), sat_int(M3*x*1024) are computed once); the two horizontally adjacent taps come from ONE unaligned
 // 8-byte (32F) / 2-byte (8U) load per source row; pixels whose 2x2 footprint is not strictly inside the source take the
 // generic sampler.  A wave walks down WROWS rows, so the source lines it touched for one row are in L1 for the next.
-constexpr int WROWS = 8;
+// rows per thread: 8 for CV_32F, 4 for CV_8U (measured, tools/warp_probe.py: 8-bit sources 39 / 25 / 31 us for C3 / C1 / C4 at 4 rows against 45 / 28 / 40
+// at 8 and 61 / 38 / 56 at 16; CV_32F 63.5 us at 8, 65.9 at 4, 72.8 at 16)
+template <typename T> constexpr int warpRows() { return sizeof(T) == 4 ? 8 : 4; }
 template <int KIND>
 __device__ __forceinline__ void warpXY(const WarpArgs& w, int y, int ad, int bd, int xb, int x1, int& X, int& Y)
 {
@@ -1008,7 +1010,8 @@ template <typename T, int CN, int KIND /*0 affine, 1 perspective*/>
 __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep,
                                                   SampleArgs s, WarpArgs w, const short* __restrict__ tab)
 {
-    constexpr int G = sizeof(T) == 4 ? (CN == 1 ? 8 : CN == 3 ? 4 : 2) : 8;           // rows whose taps are in flight together
+    constexpr int WROWS = warpRows<T>();
+    constexpr int G0 = sizeof(T) == 4 ? (CN == 1 ? 8 : CN == 3 ? 4 : 2) : 8, G = G0 < WROWS ? G0 : WROWS;   // rows whose taps are in flight together
     constexpr uint32_t ESZ = CN * sizeof(T);
     typedef float fNu __attribute__((ext_vector_type(2), aligned(4)));
     typedef unsigned short u16u __attribute__((aligned(1)));
@@ -1047,7 +1050,9 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
                 Xs[i] = (__builtin_amdgcn_readlane(X0v, g0 + i) + ad) >> 5;
                 Ys[i] = (__builtin_amdgcn_readlane(Y0v, g0 + i) + bd) >> 5;
             } else warpXY<KIND>(w, y, ad, bd, xb, x1, Xs[i], Ys[i]);
-            const int sx = satShort(Xs[i] >> 5), sy = satShort(Ys[i] >> 5);
+            // the saturation to short of the reference cannot turn an outside position into an inside one (sw, sh <= 32767): the unsaturated
+            // values decide; the generic sampler saturates for the others
+            const int sx = Xs[i] >> 5, sy = Ys[i] >> 5;
             const bool inside = (unsigned)sx < (unsigned)xlim && (unsigned)sy < (unsigned)(s.sh - 1);
             in[i] = y < w.dh && inside;
             if (y < w.dh && !inside) slow |= 1u << (g0 + i);
@@ -1060,6 +1065,8 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
             } else if (CN == 1) { q0[i] = *reinterpret_cast<const u16u*>(r0); q1[i] = *reinterpret_cast<const u16u*>(r1); }
             else { q0[i] = *reinterpret_cast<const u64u*>(r0); q1[i] = *reinterpret_cast<const u64u*>(r1); }
         }
+        // (taking a pixel's upper taps from the registers of the pixel above it, where they are the same two source pixels, and masking those
+        // lanes out of the load was tried: the per-lane conditions cost more than the lighter gather saves -- 8K 32F, 7 degrees: 69.7 vs 63.5 us)
 #pragma unroll
         for (int i = 0; i < G; i++) {
             if (!in[i]) continue;
@@ -1172,7 +1179,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // MI355CV_WARP_BAND=1 turns it on (tools/warp_probe.py).
         const char* ve = getenv("MI355CV_WARP_BAND");
         w.band = ve ? atoi(ve) : 0;
-        dim3 g2(divUp(dw, 64), divUp(dh, 4 * WROWS), nframes);
+        dim3 g2(divUp(dw, 64), divUp(dh, 4 * (depth == D32F ? warpRows<float>() : warpRows<uchar>())), nframes);
         w.gx = g2.x; w.gy = g2.y;
 #define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev)
 #define WLC(T_, K_) do { if (cn == 1) WL(T_, 1, K_); else if (cn == 3) WL(T_, 3, K_); else WL(T_, 4, K_); } while (0)
