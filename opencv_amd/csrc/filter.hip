@@ -190,22 +190,49 @@ __device__ __forceinline__ void filterRows(roll::Ctx<K / 2, K / 2, CN>& cx, ucha
                 toFloat(Q[(K - 1 + u) % K], raw[u], rv[u]);
                 rows.issue(cx, raw[u], y + u + K + R, rv[u]);
                 uint32_t o[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    f32x2 s = {t.delta, t.delta};
-#pragma unroll
+                if constexpr (K == 3) {
+                    // taps outermost: a zero tap is skipped by a scalar branch (the taps are wave-uniform), as the reference skips it -- the sums are the
+                    // same bit for bit either way, and a 3x3 sharpen / Laplacian then costs 5 of the 9 packed FMAs per output pair (the kernel is
+                    // VALU-bound at 3x3 already); the chain of every output still runs in raster order of the taps
+                    f32x2 s[8];
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) s[i] = f32x2{t.delta, t.delta};
+    #pragma unroll
                     for (int dy = 0; dy < K; dy++) {
                         // image row (y - R + dy) sits in slot (u + dy) when walking down, (u + K-1-dy) when walking up
                         const f32x2* qr = Q[(u + (UP ? K - 1 - dy : dy)) % K];
-#pragma unroll
+    #pragma unroll
                         for (int dx = 0; dx < K; dx++) {
                             const float kv = t.k[dy * K + dx];
-                            s = __builtin_elementwise_fma(qr[i + dx * CN], f32x2{kv, kv}, s);
+                            if (__builtin_amdgcn_readfirstlane(__float_as_int(kv)) != 0) {
+    #pragma unroll
+                                for (int i = 0; i < 8; i++) s[i] = __builtin_elementwise_fma(qr[i + dx * CN], f32x2{kv, kv}, s[i]);
+                            }
                         }
                     }
-                    // cvRound + saturate_cast<uchar>: round half-even, then the saturating byte conversion
-                    o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.x), i & 3, o[i >> 2]);
-                    o[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.y), i & 3, o[2 + (i >> 2)]);
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        // cvRound + saturate_cast<uchar>: round half-even, then the saturating byte conversion
+                        o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s[i].x), i & 3, o[i >> 2]);
+                        o[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s[i].y), i & 3, o[2 + (i >> 2)]);
+                    }
+                } else {
+                    // 5x5: outputs outermost (the eight accumulator pairs of the other order cost a wave per SIMD here)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        f32x2 s = {t.delta, t.delta};
+#pragma unroll
+                        for (int dy = 0; dy < K; dy++) {
+                            const f32x2* qr = Q[(u + (UP ? K - 1 - dy : dy)) % K];
+#pragma unroll
+                            for (int dx = 0; dx < K; dx++) {
+                                const float kv = t.k[dy * K + dx];
+                                s = __builtin_elementwise_fma(qr[i + dx * CN], f32x2{kv, kv}, s);
+                            }
+                        }
+                        o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.x), i & 3, o[i >> 2]);
+                        o[2 + (i >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(s.y), i & 3, o[2 + (i >> 2)]);
+                    }
                 }
                 cx.template store<1>(dst, dstep, cx.gy(y + u), o);
             }
