@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // workgroup's MFMAs.
         const NormArgs na = *nap;
         const long long cst = na.cst;
-        const bool needQ = na.method != 2 && na.method != 4;
+        const bool needQ = na.method != 2 && na.method != 4 && na.method != 6;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0);                               // the wave's own w1 / w2 stores have left
 #pragma unroll
@@ -694,7 +694,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int y = R0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
                     const long long corr = (long long)acc[mt][nt][i] + 128LL * (long long)a1[i] + cst;
                     float v = (float)(double)corr;
-                    if (na.method != 2) v = tmNormOne(v, (double)a1[i], (double)a2[i], na);
+                    if (na.method == 6) v = __int_as_float((int)corr);              // internal: the exact correlation as int32 (one plane of a multi-channel image)
+                    else if (na.method != 2) v = tmNormOne(v, (double)a1[i], (double)a2[i], na);
                     if (x < rw && y < rh) reinterpret_cast<float*>(rbase + (size_t)y * rstep)[x] = v;
                 }
             }
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
     if (x >= a.rw) return;
     w1 += (size_t)blockIdx.z * wframe; w2 += (size_t)blockIdx.z * wframe;
-    const bool needQ = a.method != 2 && a.method != 4;
+    const bool needQ = a.method != 2 && a.method != 4 && a.method != 6;
     int raw[4]; unsigned ws[4], wq[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -736,7 +737,8 @@ __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size
     for (int u = 0; u < 4; u++) {
         const long long corr = (long long)raw[u] + 128LL * (long long)ws[u] + cst;
         float v = (float)(double)corr;
-        if (a.method != 2) v = tmNormOne(v, (double)ws[u], (double)wq[u], a);
+        if (a.method == 6) v = __int_as_float((int)corr);
+        else if (a.method != 2) v = tmNormOne(v, (double)ws[u], (double)wq[u], a);
         if (y0 + u < a.rh)
             *reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)(y0 + u) * rstep + 4 * (size_t)x) = v;
     }
@@ -834,12 +836,66 @@ __global__ __launch_bounds__(256) void k_tm_tstats(const uchar* __restrict__ tpl
 }
 
 
+// multi-channel CV_8U through the single-channel MFMA path: the correlation of a cn-channel image with a cn-channel template is the sum of
+// the per-channel correlations (crossCorr, templmatch.cpp:566-760, accumulates the channels the same way), so the image and the template are
+// split into planes, every plane runs the i8 MFMA kernel as a TM_CCORR of its own, and the exact per-channel sums are added in double.
+__global__ __launch_bounds__(256) void k_tm_split(const uchar* __restrict__ src, size_t sstep, size_t sframe, int w, int h, int cn,
+                                                  uchar* __restrict__ dst, size_t dstep, size_t dplane, int nframes)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const uchar* s = src + (size_t)f * sframe + (size_t)y * sstep + (size_t)x * cn;
+    for (int c = 0; c < cn; c++) dst[((size_t)c * nframes + f) * dplane + (size_t)y * dstep + x] = s[c];       // planes ordered [channel][frame]
+}
+
+struct PlaneSums { const unsigned* w1[4]; const unsigned* w2[4]; int wp; size_t wframe; };
+
+// the sum over the channels and common_matchTemplate (templmatch.cpp:960-1035) from the per-channel window sums of I and I^2 the MFMA path
+// produces anyway (exact u32): no double integral images for the multi-channel image
+__global__ __launch_bounds__(256) void k_tm_finish_planes(const float* __restrict__ part, size_t pstep /* floats */, size_t pplane, int nframes,
+                                                          float* __restrict__ res, size_t rstep, size_t rframe, PlaneSums ps, const NormArgs* __restrict__ ap)
+{
+    const NormArgs a = *ap;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (x >= a.rw || y >= a.rh) return;
+    float* out = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)f * rframe + (size_t)y * rstep) + x;
+    const int cn = a.cn;
+    long long total = 0;                                                                // the planes hold exact int32 correlations
+    for (int c = 0; c < cn; c++) total += (long long)__float_as_int(part[((size_t)c * nframes + f) * pplane + (size_t)y * pstep + x]);
+    double num = (double)(float)(double)total;                                          // crossCorr's result is CV_32F: rounded once, as the reference's
+    if (a.method == 2) { *out = (float)num; return; }
+    if (a.allOne) { *out = 1.f; return; }
+    const int numType = a.method == 3 ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
+    const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
+    const size_t wi = (size_t)f * ps.wframe + (size_t)y * ps.wp + x;
+    double wndMean2 = 0, wndSum2 = 0, t;
+    if (numType == 1) {
+        for (int c = 0; c < cn; c++) { t = (double)ps.w1[c][wi]; wndMean2 += t * t; num -= t * a.tmean[c]; }
+        wndMean2 *= a.invArea;
+    }
+    if (isNormed || numType == 2) {
+        for (int c = 0; c < cn; c++) wndSum2 += (double)ps.w2[c][wi];
+        if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
+    }
+    if (isNormed) {
+        double diff2 = wndSum2 - wndMean2; diff2 = diff2 > 0 ? diff2 : 0;
+        double lim = 10 * 1.1920928955078125e-7 * wndSum2; lim = lim > 0.5 ? 0.5 : lim;
+        t = diff2 <= lim ? 0 : sqrt(diff2) * a.templNorm;
+        if (fabs(num) < t) num /= t;
+        else if (fabs(num) < t * 1.125) num = num > 0 ? 1 : -1;
+        else num = a.method != 1 ? 0 : 1;
+    }
+    *out = (float)num;
+}
+
+struct WOut { unsigned* w1; unsigned* w2; int wp; size_t wframe; };
+
 int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, int nframes, int iw, int ih,
-             const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method)
+             const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method, WOut* wout = nullptr)
 {
     if (disabled()) return MI355CV_NOT_IMPLEMENTED;
     const int depth = MI355CV_MAT_DEPTH(type), cn = MI355CV_MAT_CN(type);
-    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > 5) return MI355CV_NOT_IMPLEMENTED;
+    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > (wout ? 6 : 5)) return MI355CV_NOT_IMPLEMENTED;   // 6: internal, see k_tm_finish_planes
     if (tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1) return MI355CV_NOT_IMPLEMENTED;   // the size swap of :1172-1182 is left to the caller
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : 4;
@@ -866,7 +922,10 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     // integral images: needed by every method but TM_CCORR, and by the MFMA path's bias correction
     const bool useMfma = depth == D8U && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
                          (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024;
-    const bool needInt = method != 2 && !useMfma;
+    // CV_8U with 2-4 channels: per-channel planes through the MFMA path (each a TM_CCORR of CV_8UC1, by this same function)
+    const bool planes = depth == D8U && cn > 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
+                        (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024 && !(std::getenv("MI355CV_TM_PLANES") && atoi(std::getenv("MI355CV_TM_PLANES")) == 0);
+    const bool needInt = method != 2 && !useMfma && !planes;
     const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
     const size_t iframeD = isteps * (ih + 1);
     double* dsum = nullptr; double* dsq = nullptr;
@@ -903,6 +962,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         uchar* dtx = (uchar*)stg.scratch((size_t)th * MT_TPITCH);                // signed, zero-padded copy of the template in the kernels' LDS layout
         if ((!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
         na.useW = 1; na.wp = wp;
+        if (wout) { wout->w1 = w1; wout->w2 = w2; wout->wp = wp; wout->wframe = wframe; }
         const NormArgs* dna = uploadStats(dtx);
         if (!dna) return MI355CV_NOT_IMPLEMENTED;
         const bool serial = std::getenv("MI355CV_TM_SERIAL") != nullptr;            // experiments: everything on one stream
@@ -951,8 +1011,36 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
             (void)hipStreamWaitEvent(st, evDone, 0);                  // everything after this call on the main stream sees the results
         }
     } else {
+        bool done = false;
+        if (planes) {
+            const size_t pstep = ((size_t)iw + 15) & ~(size_t)15, pplane = pstep * ih;
+            const size_t tps = ((size_t)tw + 15) & ~(size_t)15, tplane = tps * th;
+            const size_t rps = ((size_t)rw + 3) & ~(size_t)3, rplane = rps * rh;                       // floats
+            uchar* pi = (uchar*)stg.scratch(pplane * nframes * cn);
+            uchar* tp = (uchar*)stg.scratch(tplane * cn);
+            float* part = (float*)stg.scratch(rplane * 4 * nframes * cn);
+            const NormArgs* dna = uploadStats(nullptr);                                                 // statistics of the cn-channel template
+            if (pi && tp && part && dna) {
+                hipLaunchKernelGGL(k_tm_split, dim3(divUp(iw, 64), divUp(ih, 4), nframes), dim3(256), 0, st, di, dis, nframes > 1 ? iframe : 0, iw, ih, cn, pi, pstep, pplane, nframes);
+                hipLaunchKernelGGL(k_tm_split, dim3(divUp(tw, 64), divUp(th, 4), 1), dim3(256), 0, st, dt, dts, 0, tw, th, cn, tp, tps, tplane, 1);
+                PlaneSums ps; memset(&ps, 0, sizeof ps);
+                done = true;
+                for (int c = 0; c < cn && done; c++) {
+                    WOut wo = {nullptr, nullptr, 0, 0};
+                    done = runMatch(entry, pi + (size_t)c * nframes * pplane, pstep, pplane, nframes, iw, ih, tp + (size_t)c * tplane, tps, tw, th, MI355CV_MAKETYPE(D8U, 1),
+                                    (uchar*)(part + (size_t)c * nframes * rplane), rps * 4, rplane * 4, 6, &wo) == MI355CV_OK && wo.w1 && wo.w2;
+                    ps.w1[c] = wo.w1; ps.w2[c] = wo.w2; ps.wp = wo.wp; ps.wframe = wo.wframe;
+                }
+                if (done)
+                    hipLaunchKernelGGL(k_tm_finish_planes, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, part, rps, rplane, nframes, reinterpret_cast<float*>(dr), drs,
+                                       nframes > 1 ? rframe : 0, ps, dna);
+            }
+            if (done) return stg.finish(entry);
+            if (method != 2) return setError(MI355CV_NOT_IMPLEMENTED, "%s: out of scratch memory for the per-channel planes", entry);   // (no integral images were built)
+        }
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
-        hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
+        if (!done)
+            hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
         if (method != 2) {
             const NormArgs* dna = uploadStats(nullptr);
             if (!dna) return MI355CV_NOT_IMPLEMENTED;

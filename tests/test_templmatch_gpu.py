@@ -70,6 +70,30 @@ def test_mfma_fused_window_sums(cv, orc, method):
         assert orc.rel_err(rb[k], orc.orc_matchTemplate(frames[k], tpl, method)) <= 1e-6, k
 
 
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cn", [3, 4, 2])
+def test_mfma_path_multichannel_8u(cv, orc, cn, method, monkeypatch):
+    """CV_8UC2 / C3 / C4 with >= 4096 outputs: per-channel planes through the i8 MFMA path, the exact per-channel correlations summed in
+    double, the multi-channel normalisation of common_matchTemplate on top; against the oracle and against the direct kernel
+    (MI355CV_TM_PLANES=0); single images (plane widths that are / are not multiples of 4) and a batch"""
+    for (iw, ih, tw, th) in [(300, 200, 16, 16), (516, 301, 128, 128), (401, 390, 33, 77)]:
+        img = rnd((ih, iw, cn), np.uint8, 70 + iw + cn)
+        tpl = rnd((th, tw, cn), np.uint8, 80 + tw)
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method)
+        assert orc.rel_err(got.cpu().numpy(), want) <= 1e-6, (iw, ih, tw, th)
+        monkeypatch.setenv("MI355CV_TM_PLANES", "0")
+        direct = cv.matchTemplate(dev(img), dev(tpl), method)
+        monkeypatch.delenv("MI355CV_TM_PLANES")
+        assert orc.rel_err(got.cpu().numpy(), direct.cpu().numpy()) <= 1e-5
+    if method in (3, 5):
+        frames = np.stack([rnd((260, 520, cn), np.uint8, 90 + k) for k in range(3)])
+        tpl = rnd((96, 80, cn), np.uint8, 91)
+        rb = cv.matchTemplateBatch(dev(frames), dev(tpl), method).cpu().numpy()
+        for k in range(3):
+            assert orc.rel_err(rb[k], orc.orc_matchTemplate(frames[k], tpl, method)) <= 1e-6, k
+
+
 def test_template_found_and_batch(cv, orc):
     img = rnd((480, 640), np.uint8, 7)
     tpl = np.ascontiguousarray(img[100:228, 200:328])
