@@ -23,6 +23,18 @@ for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         v2 = sorted(v)
         print(f"{k[:90]:90s} calls={len(v):5d} avg={sum(v)/len(v):12.0f} min={v2[0]:10d} med={v2[len(v2)//2]:10d} max={v2[-1]:10d}")
+# the headline kernel's launches of the TIMED geometry only (the parity gate adds a whole-batch launch and single-frame launches of the same
+# kernel, which is why the plain average above is not the per-launch time bench.py reports): same Grid_Size as the most frequent one
+for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    byg = defaultdict(list)
+    for r in rows(p):
+        if "k_binomial_roll2" in r["Kernel_Name"]:
+            byg[r.get("Grid_Size", r.get("Grid_Size_X", "?"))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if byg:
+        gsz, v = max(byg.items(), key=lambda kv: len(kv[1]))
+        v2 = sorted(v)
+        print(f"== headline kernel, launches of the timed geometry (Grid_Size {gsz}) ==")
+        print(f"calls={len(v)} avg={sum(v)/len(v):.0f} ns  median={v2[len(v2)//2]} ns  min={v2[0]} max={v2[-1]}")
 for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== rocprofv3 --stats ==")
     print(open(p).read())
