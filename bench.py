@@ -293,14 +293,19 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs)")
     args = ap.parse_args()
 
+    # test hook, never a reportable number: MI355CV_BENCH_SHARED_GPU=1 lets the N ranks share GPU 0 over gloo, so that the N > 1 code path
+    # (spawn, sharding, broadcasts, max-over-ranks timing, the cfg4 / cfg5 legs) can be exercised on a one-GPU box; the line says so
+    shared = os.environ.get("MI355CV_BENCH_SHARED_GPU") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         from opencv_amd import shard                       # no launcher: become the launcher (N ranks, one per GPU, RCCL); loud when < N GPUs
-        sys.exit(shard.spawn_ranks(args.gpus, __file__, sys.argv[1:]))
+        sys.exit(shard.spawn_ranks(args.gpus, __file__, sys.argv[1:], need_gpus=not shared))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if shared:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         sys.exit(f"bench.py: rank {rank} has no GPU (local_rank {local_rank}, {torch.cuda.device_count()} visible)")
     dist = None
@@ -309,7 +314,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
 
     import opencv_amd as cv
@@ -416,7 +424,7 @@ def main():
             "config": {"workload": "cv::GaussianBlur 5x5 sigma=0 BORDER_REFLECT_101 on 3840x2160 CV_8UC1, "
                                    f"{B} device-resident frames per GPU per step ({2 * B * W4K * H4K / 1e9:.1f} GB of HBM: one pass = {nl} launches of {FPL} frames)",
                        "frames_per_gpu": B, "frames_per_launch": FPL, "launches_per_step": nl, "sharding": f"frames x{world}, no data-path collective", "ranks": world,
-                       "collective": "RCCL broadcast of the filter taps at plan time" if world > 1 else "none (1 GPU)"},
+                       "collective": ("gloo (test mode)" if shared else "RCCL") + " broadcast of the filter taps at plan time" if world > 1 else "none (1 GPU)"},
             "per_gpu_mpix_s": round(value / world, 1),
             "timed_region_s": round(elapsed, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -433,6 +441,8 @@ def main():
                          "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)},
             "parity": parity,
         }
+        if shared:
+            res["test_mode"] = f"{world} ranks SHARE ONE GPU over gloo (MI355CV_BENCH_SHARED_GPU=1): a code-path test, not a measurement"
         if legs is not None:
             res["other_configs"] = legs
         if world == 1 and not args.no_cpu_baseline:

@@ -1016,6 +1016,14 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
     typedef float fNu __attribute__((ext_vector_type(2), aligned(4)));
     typedef unsigned short u16u __attribute__((aligned(1)));
     typedef unsigned long long u64u __attribute__((aligned(1)));
+    // 8-bit sources: the 1024 x 4 Q15 weights of initInterTab2D (8 KB) are copied into LDS once per workgroup -- read per pixel from global
+    // memory they were a third gather, and the most scattered one (64 lanes anywhere in 8 KB), on a path that is bound by the vector L1
+    __shared__ uint2 ltab[sizeof(T) == 1 ? 1024 : 1];
+    if (sizeof(T) == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) ltab[threadIdx.x + 256 * i] = reinterpret_cast<const uint2*>(tab)[threadIdx.x + 256 * i];
+        __syncthreads();
+    }
     int tx, ty;
     tileOf(w, tx, ty);
     src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
@@ -1091,7 +1099,8 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
                     reinterpret_cast<float*>(D)[c] = t;
                 }
             } else {
-                const short4 wq = *reinterpret_cast<const short4*>(tab + (ay * 32 + ax) * 4);
+                const uint2 wl = ltab[ay * 32 + ax];
+                short4 wq; wq.x = (short)(wl.x & 0xffff); wq.y = (short)(wl.x >> 16); wq.z = (short)(wl.y & 0xffff); wq.w = (short)(wl.y >> 16);
 #pragma unroll
                 for (int c = 0; c < CN; c++) {
                     const int v0 = (int)((q0[i] >> (8 * c)) & 255), v1 = (int)((q0[i] >> (8 * (CN + c))) & 255);

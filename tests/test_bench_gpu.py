@@ -1,0 +1,47 @@
+"""bench.py's contract on the GPU box: the default single-GPU line, and the N > 1 code path -- self-spawn, frame sharding, plan-time broadcasts,
+barrier + max-over-ranks timing, the cfg4 / cfg5 legs -- exercised by two ranks that share the one GPU of the test box over gloo
+(MI355CV_BENCH_SHARED_GPU=1: a code-path test, the line says so; the real multi-GPU numbers are the driver's to take)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args, env=None):
+    e = dict(os.environ); e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = run(["--batch", "256", "--frames-per-launch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mpix/s" and d["dtype"] == "u8" and d["scaling"] == "weak"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["config"]["launches_per_step"] == 2 and r["launches_timed"] == 6
+    assert r["algorithmic_bytes_per_launch"] == 2 * 128 * 3840 * 2160
+    assert d["parity"]["result"] == "bit-exact"
+
+
+def test_two_ranks_share_one_gpu():
+    d = run(["--gpus", "2", "--batch", "256", "--steps", "2", "--warmup", "1"], {"MI355CV_BENCH_SHARED_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and "test_mode" in d
+    assert d["value"] > 0 and abs(d["per_gpu_mpix_s"] * 2 - d["value"]) / d["value"] < 1e-3
+    legs = d["other_configs"]
+    assert len(legs) == 2 and all(l["n_gpus"] == 2 for l in legs)
+    assert "128 frames / GPU" in legs[0]["config"]                # 256 frames sharded over 2 ranks
+
+
+def test_refuses_more_gpus_than_visible():
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "refusing" in p.stderr
