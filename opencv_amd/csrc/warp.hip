@@ -328,6 +328,23 @@ int buildAreaTab(int ssize, int dsize, double scale, std::vector<AreaTap>& tab, 
 // 8U: * 2048 rounded to short).  The reference's vertical pass has a SIMD body and a scalar tail that round differently; both are
 // reproduced per element index: body = float S0*b0 + (S1*b1 + (S2*b2 + S3*b3)) (8U: taps * 2^-22, round half-even, saturate) for
 // e < (dw*cn / 8) * 8 (8U) or (dw*cn / 4) * 4 (32F); tail = exact integers (sum + 2^21) >> 22 (8U) / left-to-right float (32F).
+// CV_16U / CV_16S take the float path of CV_32F (HResizeCubic / HResizeLanczos4 <ushort | short, float, float>, resize.cpp:3890-3925): samples converted to
+// float, vertical result through Cast<float, T> = cvRound + saturation.  Their vector bodies are 8 elements wide (VResizeCubicVec_32f16u / 32f16s :1444-1488,
+// VResizeLanczos4Vec_32f16s :1562-1594: nested from the last row, like CV_32F's); CV_16U Lanczos runs the SSE4.1 routine on x86, which sums
+// left to right like the scalar tail (resize.sse4_1.cpp:189-226), so its body and tail coincide.
+template <typename T> __device__ __forceinline__ float ldE(const uchar* row, int idx) { return (float)reinterpret_cast<const T*>(row)[idx]; }
+template <typename T> __device__ __forceinline__ void stE(uchar* row, int idx, float v)
+{
+    if constexpr (sizeof(T) == 4) reinterpret_cast<float*>(row)[idx] = v;
+    else if constexpr (std::is_same<T, unsigned short>::value) { const int r = __float2int_rn(v); reinterpret_cast<unsigned short*>(row)[idx] = (unsigned short)(r < 0 ? 0 : r > 65535 ? 65535 : r); }
+    else { const int r = __float2int_rn(v); reinterpret_cast<short*>(row)[idx] = (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r); }
+}
+template <typename T, int NT> __device__ __forceinline__ int vecBody(int width)      // elements the reference's nested (last row first) vector form covers
+{
+    if (NT == 8 && std::is_same<T, unsigned short>::value) return 0;
+    return sizeof(T) == 4 ? (width / 4) * 4 : (width / 8) * 8;
+}
+
 struct CubicTap { int s; float f[4]; short i[4]; };
 
 template <typename T>
@@ -365,15 +382,15 @@ __global__ __launch_bounds__(256) void k_resize_cubic(const uchar* __restrict__ 
         float S[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float* R = reinterpret_cast<const float*>(src + (size_t)clipI(ty.s - 1 + k, 0, sh) * sstep);
-            float v = __fmul_rn(R[xs[0]], tx.f[0]);
-            v = __fadd_rn(v, __fmul_rn(R[xs[1]], tx.f[1]));
-            v = __fadd_rn(v, __fmul_rn(R[xs[2]], tx.f[2]));
-            v = __fadd_rn(v, __fmul_rn(R[xs[3]], tx.f[3]));
+            const uchar* R = src + (size_t)clipI(ty.s - 1 + k, 0, sh) * sstep;
+            float v = __fmul_rn(ldE<T>(R, xs[0]), tx.f[0]);
+            v = __fadd_rn(v, __fmul_rn(ldE<T>(R, xs[1]), tx.f[1]));
+            v = __fadd_rn(v, __fmul_rn(ldE<T>(R, xs[2]), tx.f[2]));
+            v = __fadd_rn(v, __fmul_rn(ldE<T>(R, xs[3]), tx.f[3]));
             S[k] = v;
         }
         float r;
-        if (e < (width / 4) * 4) {
+        if (e < vecBody<T, 4>(width)) {
             float t = __fmul_rn(S[3], ty.f[3]);
             t = __fadd_rn(__fmul_rn(S[2], ty.f[2]), t);
             t = __fadd_rn(__fmul_rn(S[1], ty.f[1]), t);
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(256) void k_resize_cubic(const uchar* __restrict__ 
             t = __fadd_rn(t, __fmul_rn(S[2], ty.f[2]));
             r = __fadd_rn(t, __fmul_rn(S[3], ty.f[3]));
         }
-        reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+        stE<T>(dst + (size_t)dy * dstep, e, r);
     }
 }
 
@@ -440,14 +457,14 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uchar* __restrict_
         float S[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const float* R = reinterpret_cast<const float*>(src + (size_t)clipI(ty.s - 3 + k, 0, sh) * sstep);
-            float v = __fmul_rn(R[xs[0]], tx.f[0]);
+            const uchar* R = src + (size_t)clipI(ty.s - 3 + k, 0, sh) * sstep;
+            float v = __fmul_rn(ldE<T>(R, xs[0]), tx.f[0]);
 #pragma unroll
-            for (int j = 1; j < 8; j++) v = __fadd_rn(v, __fmul_rn(R[xs[j]], tx.f[j]));
+            for (int j = 1; j < 8; j++) v = __fadd_rn(v, __fmul_rn(ldE<T>(R, xs[j]), tx.f[j]));
             S[k] = v;
         }
         float r;
-        if (e < (width / 4) * 4) {
+        if (e < vecBody<T, 8>(width)) {
             r = __fmul_rn(S[7], ty.f[7]);
 #pragma unroll
             for (int k = 6; k >= 0; k--) r = __fadd_rn(__fmul_rn(S[k], ty.f[k]), r);
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uchar* __restrict_
 #pragma unroll
             for (int k = 1; k < 8; k++) r = __fadd_rn(r, __fmul_rn(S[k], ty.f[k]));
         }
-        reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+        stE<T>(dst + (size_t)dy * dstep, e, r);
     }
 }
 
@@ -519,10 +536,9 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
                 for (int j = 0; j < NT; j++) v += rowp[xs[j]] * tx.i[j];
                 H[r * TW + lx] = (HT)v;
             } else {
-                const float* Rf = reinterpret_cast<const float*>(rowp);
-                float v = __fmul_rn(Rf[xs[0]], tx.f[0]);
+                float v = __fmul_rn(ldE<T>(rowp, xs[0]), tx.f[0]);
 #pragma unroll
-                for (int j = 1; j < NT; j++) v = __fadd_rn(v, __fmul_rn(Rf[xs[j]], tx.f[j]));
+                for (int j = 1; j < NT; j++) v = __fadd_rn(v, __fmul_rn(ldE<T>(rowp, xs[j]), tx.f[j]));
                 H[r * TW + lx] = (HT)v;
             }
         }
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
             (dst + (size_t)dy * dstep)[e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
         } else {
             float r;
-            if (e < (width / 4) * 4) {
+            if (e < vecBody<T, NT>(width)) {
                 r = __fmul_rn((float)S[(NT - 1) * TW], ty.f[NT - 1]);
 #pragma unroll
                 for (int k = NT - 2; k >= 0; k--) r = __fadd_rn(__fmul_rn((float)S[k * TW], ty.f[k]), r);
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
 #pragma unroll
                 for (int k = 1; k < NT; k++) r = __fadd_rn(r, __fmul_rn((float)S[k * TW], ty.f[k]));
             }
-            reinterpret_cast<float*>(dst + (size_t)dy * dstep)[e] = r;
+            stE<T>(dst + (size_t)dy * dstep, e, r);
         }
     }
 }
@@ -1231,9 +1247,9 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
             // resize.cpp:3976-3990: exactly-half sizes are the (bit-exact) 2x2 area mean, except for 2 channels
             if (areaFast && a.isx == 2 && a.isy == 2 && cn != 2) a.mode = 3; else a.mode = 7;
         }
-        else if (interpolation == 2 /*INTER_CUBIC*/ && (depth == D8U || depth == D32F)) a.mode = 5;
-        else if (interpolation == 4 /*INTER_LANCZOS4*/ && (depth == D8U || depth == D32F)) a.mode = 6;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // NEAREST_EXACT, LINEAR_EXACT on other depths, cubic / Lanczos on 16-bit depths
+        else if (interpolation == 2 /*INTER_CUBIC*/) a.mode = 5;
+        else if (interpolation == 4 /*INTER_LANCZOS4*/) a.mode = 6;
+        else return MI355CV_NOT_IMPLEMENTED;                                                // NEAREST_EXACT, LINEAR_EXACT on other depths
     }
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
@@ -1264,19 +1280,25 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
             if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused, &keepX) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows, &keepY))
                 return MI355CV_NOT_IMPLEMENTED;
             const TapT<4>* tx = reinterpret_cast<const TapT<4>*>(dxt); const TapT<4>* ty = reinterpret_cast<const TapT<4>*>(dyt);
-            if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 4>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
-            else if (rows) hipLaunchKernelGGL((k_resize_tiled<float, 4>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
-            else if (depth == D8U) hipLaunchKernelGGL(k_resize_cubic<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
-            else hipLaunchKernelGGL(k_resize_cubic<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+#define RZ_TILED(T_, NT_) hipLaunchKernelGGL((k_resize_tiled<T_, NT_>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty)
+#define RZ_BY_DEPTH(M_) do { if (depth == D8U) M_(uchar); else if (depth == D16U) M_(unsigned short); else if (depth == D16S) M_(short); else M_(float); } while (0)
+#define RZ_T4(T_) RZ_TILED(T_, 4)
+#define RZ_C(T_) hipLaunchKernelGGL(k_resize_cubic<T_>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt)
+            if (rows) RZ_BY_DEPTH(RZ_T4); else RZ_BY_DEPTH(RZ_C);
         } else {
             const LanczosTap *dxt, *dyt;
             if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused, &keepX) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows, &keepY))
                 return MI355CV_NOT_IMPLEMENTED;
             const TapT<8>* tx = reinterpret_cast<const TapT<8>*>(dxt); const TapT<8>* ty = reinterpret_cast<const TapT<8>*>(dyt);
-            if (rows && depth == D8U) hipLaunchKernelGGL((k_resize_tiled<uchar, 8>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
-            else if (rows) hipLaunchKernelGGL((k_resize_tiled<float, 8>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty);
-            else if (depth == D8U) hipLaunchKernelGGL(k_resize_lanczos<uchar>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
-            else hipLaunchKernelGGL(k_resize_lanczos<float>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt);
+#define RZ_T8(T_) RZ_TILED(T_, 8)
+#define RZ_L(T_) hipLaunchKernelGGL(k_resize_lanczos<T_>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt)
+            if (rows) RZ_BY_DEPTH(RZ_T8); else RZ_BY_DEPTH(RZ_L);
+#undef RZ_T8
+#undef RZ_L
+#undef RZ_T4
+#undef RZ_C
+#undef RZ_BY_DEPTH
+#undef RZ_TILED
         }
         return stg.finish(entry);
     }

@@ -93,6 +93,17 @@ static int resizeAreaGeneral(const uint8_t* src, size_t sstep, int sw, int sh, u
     return 0;
 }
 
+static float ldvE(const uint8_t* row, int depth, int idx)
+{
+    return depth == 5 ? ((const float*)row)[idx] : depth == 2 ? (float)((const uint16_t*)row)[idx] : (float)((const int16_t*)row)[idx];
+}
+static void st_cast(uint8_t* row, int depth, int idx, float v)          /* Cast<float, T>: identity, or cvRound + saturate_cast */
+{
+    if (depth == 5) { ((float*)row)[idx] = v; return; }
+    const long r = lrintf(v);
+    if (depth == 2) ((uint16_t*)row)[idx] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+    else ((int16_t*)row)[idx] = (int16_t)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+}
 /* INTER_CUBIC for CV_8U and CV_32F: hal::resize coefficient set-up resize.cpp:4097-4190 (interpolateCubic :964, A = -0.75, float;
  * 8U: taps * 2048 rounded to short), HResizeCubic :1993 (taps at sx-1..sx+2, columns clamped into the row), VResizeCubic :2045
  * on rows sy-1..sy+2 clamped into the image.  The vertical pass exists twice in the reference and both forms are reproduced:
@@ -112,10 +123,12 @@ static void cubic_coef(float x, float* c)
 static int resizeCubic(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                        int depth, int cn, double scale_x, double scale_y)
 {
-    if (depth != 0 && depth != 5) return 1;
+    if (depth != 0 && depth != 5 && depth != 2 && depth != 3) return 1;
     const int fix = depth == 0;
     const int width = dw * cn;
-    const int body = fix ? (width / 8) * 8 : (width / 4) * 4;
+    /* CV_16U / CV_16S (resize.cpp:3890-3899): the float passes of CV_32F on the converted samples, vector body 8 elements wide
+     * (VResizeCubicVec_32f16u / 32f16s :1444-1488), Cast<float, T> = cvRound + saturation at the end */
+    const int body = (fix || depth == 2 || depth == 3) ? (width / 8) * 8 : (width / 4) * 4;
     for (int dy = 0; dy < dh; dy++) {
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
         const int sy = cvfloor_f(fy); fy -= sy;
@@ -149,9 +162,8 @@ static int resizeCubic(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t
                 } else {
                     float S[4];
                     for (int k = 0; k < 4; k++) {
-                        const float* R = (const float*)rows[k];
-                        float v = R[xs[0] * cn + c] * ca[0];
-                        for (int j = 1; j < 4; j++) { const float m = R[xs[j] * cn + c] * ca[j]; v = v + m; }
+                        float v = ldvE(rows[k], depth, xs[0] * cn + c) * ca[0];
+                        for (int j = 1; j < 4; j++) { const float m = ldvE(rows[k], depth, xs[j] * cn + c) * ca[j]; v = v + m; }
                         S[k] = v;
                     }
                     float r;
@@ -166,7 +178,7 @@ static int resizeCubic(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t
                         m = S[2] * cb[2]; t = t + m;
                         m = S[3] * cb[3]; r = t + m;
                     }
-                    ((float*)(dst + (size_t)dy * dstep))[e] = r;
+                    st_cast(dst + (size_t)dy * dstep, depth, e, r);
                 }
             }
         }
@@ -201,8 +213,10 @@ static void lanczos_coef(float x, float* coeffs)
 static int resizeLanczos4(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                           int depth, int cn, double scale_x, double scale_y)
 {
-    if (depth != 0 && depth != 5) return 1;
-    const int width = dw * cn, body = (width / 4) * 4;
+    if (depth != 0 && depth != 5 && depth != 2 && depth != 3) return 1;
+    /* CV_16S: VResizeLanczos4Vec_32f16s (:1562-1594), 8 elements wide, nested from the last row; CV_16U on x86: the SSE4.1 routine
+     * (resize.sse4_1.cpp:189-226) sums left to right like the scalar tail, so there is no separate body */
+    const int width = dw * cn, body = depth == 5 ? (width / 4) * 4 : depth == 3 ? (width / 8) * 8 : 0;
     for (int dy = 0; dy < dh; dy++) {
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
         const int sy = cvfloor_f(fy); fy -= sy;
@@ -226,9 +240,8 @@ static int resizeLanczos4(const uint8_t* src, size_t sstep, int sw, int sh, uint
                 } else {
                     float S[8];
                     for (int k = 0; k < 8; k++) {
-                        const float* R = (const float*)rows[k];
-                        float v = R[xs[0] * cn + c] * ca[0];
-                        for (int j = 1; j < 8; j++) { const float m = R[xs[j] * cn + c] * ca[j]; v = v + m; }
+                        float v = ldvE(rows[k], depth, xs[0] * cn + c) * ca[0];
+                        for (int j = 1; j < 8; j++) { const float m = ldvE(rows[k], depth, xs[j] * cn + c) * ca[j]; v = v + m; }
                         S[k] = v;
                     }
                     float r;
@@ -239,7 +252,7 @@ static int resizeLanczos4(const uint8_t* src, size_t sstep, int sw, int sh, uint
                         r = S[0] * cb[0];
                         for (int k = 1; k < 8; k++) { const float m = S[k] * cb[k]; r = r + m; }
                     }
-                    ((float*)(dst + (size_t)dy * dstep))[e] = r;
+                    st_cast(dst + (size_t)dy * dstep, depth, e, r);
                 }
             }
         }

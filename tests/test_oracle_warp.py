@@ -58,7 +58,7 @@ def test_resize_area_general(orc, ref, dtype, cn):
     same(orc, orc.orc_resize(src, None, 0.3, 0.7, 3), orc.ref_resize(src, None, 0.3, 0.7, 3))
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.uint16, np.int16])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_cubic(orc, ref, dtype, cn):
     """INTER_CUBIC: up- and down-scaling, destination row lengths with and without a SIMD tail (dw*cn % 8, % 4), tiny sources
@@ -70,7 +70,7 @@ def test_resize_cubic(orc, ref, dtype, cn):
             assert np.array_equal(got, want), (w, h, dsize, dtype, cn)
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.uint16, np.int16])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_lanczos4(orc, ref, dtype, cn):
     """INTER_LANCZOS4: 8x8 taps, integer for CV_8U, SIMD body / scalar tail orders for CV_32F; sources smaller than the kernel"""

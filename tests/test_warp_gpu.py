@@ -74,10 +74,10 @@ def test_resize_area_general(cv, orc, dtype, cn):
     assert np.array_equal(cv.resize(src, None, 0.3, 0.7, 3), orc.orc_resize(src, None, 0.3, 0.7, 3))          # host pointers
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.uint16, np.int16])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_cubic(cv, orc, dtype, cn):
-    """INTER_CUBIC, bit-exact incl. the reference's SIMD-body / scalar-tail split of the vertical pass"""
+    """INTER_CUBIC, bit-exact incl. the reference's SIMD-body / scalar-tail split of the vertical pass (8U fixed point; 32F, 16U and 16S float)"""
     for (w, h), dsizes in [((53, 37), [(80, 55), (20, 11), (106, 74), (161, 3)]), ((9, 9), [(31, 29), (8, 8)]), ((5, 3), [(17, 13)]), ((640, 480), [(1280, 960), (333, 222)])]:
         src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 6 + cn + w)
         for dsize in dsizes:
@@ -86,14 +86,12 @@ def test_resize_cubic(cv, orc, dtype, cn):
     big = rnd((480, 640, cn) if cn > 1 else (480, 640), dtype, 3)
     for dsize in [(64, 48), (700, 31)]:                               # strong minification: the per-output kernel (a tile would need > 64 source rows)
         assert np.array_equal(cv.resize(dev(big), dsize, interpolation=2).cpu().numpy(), orc.orc_resize(big, dsize, interpolation=2)), (dsize, dtype, cn)
-    with pytest.raises(NotImplementedError):
-        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=2)
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.uint16, np.int16])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_lanczos4(cv, orc, dtype, cn):
-    """INTER_LANCZOS4, bit-exact (CV_8U integer; CV_32F with the reference's body / tail summation orders)"""
+    """INTER_LANCZOS4, bit-exact (CV_8U integer; CV_32F / CV_16S with the reference's body / tail summation orders, CV_16U left to right throughout)"""
     for (w, h), dsizes in [((53, 37), [(80, 55), (20, 11), (106, 74), (161, 3)]), ((9, 9), [(31, 29), (8, 8)]), ((5, 3), [(17, 13)]), ((640, 480), [(1280, 960), (333, 222)])]:
         src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 9 + cn + w)
         for dsize in dsizes:
@@ -103,7 +101,7 @@ def test_resize_lanczos4(cv, orc, dtype, cn):
     for dsize in [(64, 48), (700, 31)]:
         assert np.array_equal(cv.resize(dev(big), dsize, interpolation=4).cpu().numpy(), orc.orc_resize(big, dsize, interpolation=4)), (dsize, dtype, cn)
     with pytest.raises(NotImplementedError):
-        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=4)
+        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=6)          # INTER_NEAREST_EXACT: declined, never a CPU fallback
 
 
 def mats(cv, w, h):
