@@ -166,6 +166,48 @@ __global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, s
     }
 }
 
+// INTER_AREA by exactly 2 x 2 on CV_8U (resizeAreaFast_, ResizeAreaFastVec_SIMD_8u, resize.cpp:2806-2900: (s00 + s01 + s10 + s11 + 2) >> 2), even
+// source sizes: a lane produces FOUR destination pixels from 8 CN source bytes of each of the two source rows -- 8-byte loads, 4 CN-byte stores --
+// instead of a thread per destination pixel with byte loads; HBM-bound (5 bytes per destination byte)
+template <int CN>
+__global__ __launch_bounds__(256) void k_area2x2_u8(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                    int dw, int dh)
+{
+    constexpr int NS = 2 * CN;                                     // source dwords per row and lane (8 CN bytes)
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int ng = (dw + 3) >> 2;
+    if (g >= ng || dy >= dh) return;
+    const uchar* r0 = src + (size_t)blockIdx.z * sframe + (size_t)(2 * dy) * sstep + (size_t)g * 8 * CN;
+    const uchar* r1 = r0 + sstep;
+    uchar* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dstep + (size_t)g * 4 * CN;
+    if (4 * g + 4 <= dw) {
+        uint32_t a[NS], b[NS];
+#pragma unroll
+        for (int i = 0; i < CN; i++) {
+            const uint2 va = reinterpret_cast<const uint2*>(r0)[i], vb = reinterpret_cast<const uint2*>(r1)[i];
+            a[2 * i] = va.x; a[2 * i + 1] = va.y; b[2 * i] = vb.x; b[2 * i + 1] = vb.y;
+        }
+        uint32_t o[CN] = {};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const int i0 = (2 * p) * CN + c, i1 = i0 + CN, ob = p * CN + c;
+                const uint32_t s = ((a[i0 >> 2] >> (8 * (i0 & 3))) & 255u) + ((a[i1 >> 2] >> (8 * (i1 & 3))) & 255u) +
+                                   ((b[i0 >> 2] >> (8 * (i0 & 3))) & 255u) + ((b[i1 >> 2] >> (8 * (i1 & 3))) & 255u);
+                o[ob >> 2] |= ((s + 2) >> 2) << (8 * (ob & 3));
+            }
+#pragma unroll
+        for (int i = 0; i < CN; i++) reinterpret_cast<uint32_t*>(D)[i] = o[i];
+    } else {
+        for (int p = 0; 4 * g + p < dw; p++)
+            for (int c = 0; c < CN; c++) {
+                const int i0 = (2 * p) * CN + c, i1 = i0 + CN;
+                D[p * CN + c] = (uchar)((r0[i0] + r0[i1] + r1[i0] + r1[i1] + 2) >> 2);
+            }
+    }
+}
+
 // resize, bilinear (and INTER_AREA upscaling, which is bilinear with other coefficients), single channel CV_32F / CV_8U: the
 // arithmetic of k_resize specialised.  A thread owns a destination column for RROWS rows: its horizontal coefficient is
 // computed once, both horizontal taps come from one unaligned 8-byte / 2-byte load per source row, and a wave walks down
@@ -1314,6 +1356,14 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         if (depth == D8U) hipLaunchKernelGGL((k_resize_exact<uchar, 8>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
         else if (depth == D16U) hipLaunchKernelGGL((k_resize_exact<unsigned short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
         else hipLaunchKernelGGL((k_resize_exact<short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
+        return stg.finish(entry);
+    }
+    if (a.mode == 3 && depth == D8U && a.isx == 2 && a.isy == 2 && (cn == 1 || cn == 3 || cn == 4) && src_width == 2 * dst_width && src_height == 2 * dst_height &&
+        ((((uintptr_t)ds) | dss | a.sframe) & 7) == 0 && ((((uintptr_t)dd) | dds | a.dframe) & 3) == 0) {
+        dim3 g3(divUp(divUp(dst_width, 4), 64), divUp(dst_height, 4), nframes);
+        if (cn == 1) hipLaunchKernelGGL(k_area2x2_u8<1>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
+        else if (cn == 3) hipLaunchKernelGGL(k_area2x2_u8<3>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
+        else hipLaunchKernelGGL(k_area2x2_u8<4>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
         return stg.finish(entry);
     }
     if (a.mode == 4) {

@@ -60,6 +60,25 @@ def test_resize(cv, orc, dtype, cn):
     assert torch.equal(cv.resize(dev(src), (53, 37)), dev(src))                            # same size -> copy
 
 
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_area_2x2_u8(cv, orc, cn):
+    """CV_8U halved exactly (INTER_AREA, and INTER_LINEAR which becomes it, resize.cpp:4011): the four-pixels-per-lane kernel -- widths whose quarter
+    is / is not whole (the last lane's scalar tail), views with a parent's step, a batch; odd sizes keep the generic kernel"""
+    for (w, h) in [(64, 48), (70, 50), (8, 2), (1000, 36), (3840, 16)]:
+        src = rnd((h, w, cn), np.uint8, 31 + w + cn) if cn > 1 else rnd((h, w), np.uint8, 31 + w)
+        for interp in (3, 1):
+            check(cv.resize(dev(src), (w // 2, h // 2), interpolation=interp), orc.orc_resize(src, (w // 2, h // 2), interpolation=interp))
+    big = rnd((3, 60, 88, cn), np.uint8, 5) if cn > 1 else rnd((3, 60, 88), np.uint8, 5)
+    d = dev(big)
+    view = d[1, 4:52, 8:72]
+    check(cv.resize(view, (32, 24), interpolation=3), orc.orc_resize(np.ascontiguousarray(big[1, 4:52, 8:72]), (32, 24), interpolation=3))
+    out = cv.resizeBatch(d, (44, 30), interpolation=3)
+    for f in range(3):
+        check(out[f], orc.orc_resize(big[f], (44, 30), interpolation=3))
+    odd = rnd((51, 67, cn), np.uint8, 6) if cn > 1 else rnd((51, 67), np.uint8, 6)
+    check(cv.resize(dev(odd), (33, 25), interpolation=3), orc.orc_resize(odd, (33, 25), interpolation=3))
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_area_general(cv, orc, dtype, cn):
