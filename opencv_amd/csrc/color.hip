@@ -10,6 +10,7 @@
 //   RGB2RGB          :108-     channel reorder / add / drop alpha
 // All are HBM-bound element-wise passes (BGR2GRAY 8U: 3 B read + 1 B written per pixel).
 #include "rt.h"
+#include "pix4.h"
 
 using namespace mi355;
 
@@ -104,6 +105,31 @@ __global__ __launch_bounds__(256) void k_bgr2bgr(const uchar* __restrict__ src, 
     if (dcn == 4) d[3] = a;
 }
 
+// CV_8U channel shuffles on four pixels per lane (pix4.h: whole-dword loads and stores): gray -> BGR(A), BGR(A) <-> BGR(A) / RGB(A)
+template <int DCN> struct OpGray2Bgr {
+    __device__ __forceinline__ void operator()(const pix4::Px<1>& in, pix4::Px<DCN>& out) const
+    {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int g = in.get(p);
+            out.put(p * DCN, g); out.put(p * DCN + 1, g); out.put(p * DCN + 2, g);
+            if (DCN == 4) out.put(p * DCN + 3, 255);
+        }
+    }
+};
+template <int SCN, int DCN> struct OpBgr2Bgr {
+    int swapBlue;
+    __device__ __forceinline__ void operator()(const pix4::Px<SCN>& in, pix4::Px<DCN>& out) const
+    {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c0 = in.get(p * SCN), c1 = in.get(p * SCN + 1), c2 = in.get(p * SCN + 2);
+            out.put(p * DCN, swapBlue ? c2 : c0); out.put(p * DCN + 1, c1); out.put(p * DCN + 2, swapBlue ? c0 : c2);
+            if (DCN == 4) out.put(p * DCN + 3, SCN == 4 ? in.get(p * SCN + 3) : 255);
+        }
+    }
+};
+
 int esz(int depth) { return depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : depth == MI355CV_32F ? 4 : 0; }
 
 int runBgr2Gray(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe,
@@ -171,7 +197,10 @@ MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uch
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (depth == MI355CV_8U)       hipLaunchKernelGGL((k_gray2bgr<uchar>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, dcn, (uchar)255);
+    if (depth == MI355CV_8U) {
+        if (dcn == 3) pix4::launch<1, 3>(stream(), ds, dss, dd, dds, width, height, OpGray2Bgr<3>());
+        else          pix4::launch<1, 4>(stream(), ds, dss, dd, dds, width, height, OpGray2Bgr<4>());
+    }
     else if (depth == MI355CV_16U) hipLaunchKernelGGL((k_gray2bgr<unsigned short>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, dcn, (unsigned short)65535);
     else                           hipLaunchKernelGGL((k_gray2bgr<float>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, dcn, 1.0f);
     return stg.finish("cvtGraytoBGR");
@@ -189,7 +218,13 @@ MI355CV_API int mi355cv_cvtBGRtoBGR(const uchar* src_data, size_t src_step, ucha
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
     dim3 grid(divUp(width, 64), divUp(height, 4));
-    if (depth == MI355CV_8U)       hipLaunchKernelGGL((k_bgr2bgr<uchar>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, scn, dcn, (int)swapBlue, (uchar)255);
+    if (depth == MI355CV_8U) {
+        const int sb = swapBlue ? 1 : 0;
+        if (scn == 3 && dcn == 3)      pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Bgr<3, 3>{sb});
+        else if (scn == 3)             pix4::launch<3, 4>(stream(), ds, dss, dd, dds, width, height, OpBgr2Bgr<3, 4>{sb});
+        else if (dcn == 3)             pix4::launch<4, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Bgr<4, 3>{sb});
+        else                           pix4::launch<4, 4>(stream(), ds, dss, dd, dds, width, height, OpBgr2Bgr<4, 4>{sb});
+    }
     else if (depth == MI355CV_16U) hipLaunchKernelGGL((k_bgr2bgr<unsigned short>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, scn, dcn, (int)swapBlue, (unsigned short)65535);
     else                           hipLaunchKernelGGL((k_bgr2bgr<float>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, scn, dcn, (int)swapBlue, 1.0f);
     return stg.finish("cvtBGRtoBGR");
