@@ -317,6 +317,12 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const mi355cv_uchar* y_data, size_
 MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
 
+/* replaces hal_ni_bilateralFilter (hal_replacement.hpp:1016; caller cv::bilateralFilter bilateral_filter.dispatch.cpp:418): CV_8UC1 / CV_8UC3, radius <= 16,
+ * the float sums in the three forms of the reference's AVX2 build (vector body / 4-group tail / scalar rest), bit-exact.  The hook carries no margins: an
+ * image with padded rows and no BORDER_ISOLATED is declined (the reference pads a submatrix with its parent's pixels). */
+MI355CV_API int mi355cv_bilateralFilter(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
+                                        int depth, int cn, int d, double sigma_color, double sigma_space, int border_type);
+
 /* replaces hal_ni_adaptiveThreshold (hal_replacement.hpp:1038; caller cv::adaptiveThreshold thresh.cpp:1711): CV_8UC1,
  * adaptiveMethod ADAPTIVE_THRESH_MEAN_C (0) with blockSize 3..15, thresholdType THRESH_BINARY (0) / THRESH_BINARY_INV (1). */
 MI355CV_API int mi355cv_adaptiveThreshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,

@@ -71,6 +71,8 @@
 // hal_replacement.hpp:1058 / caller ThresholdRunner thresh.cpp:1365
 #undef  cv_hal_adaptiveThreshold
 #define cv_hal_adaptiveThreshold mi355cv_adaptiveThreshold
+#undef  cv_hal_bilateralFilter
+#define cv_hal_bilateralFilter mi355cv_bilateralFilter
 #undef  cv_hal_threshold
 #define cv_hal_threshold mi355cv_threshold
 // hal_replacement.hpp:207-233 / caller halMorph morph.dispatch.cpp:190-220

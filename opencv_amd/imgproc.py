@@ -26,7 +26,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
-           "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "bilateralFilter", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "cvtColorFilter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -504,6 +504,20 @@ def adaptiveThreshold(src, maxValue, adaptiveMethod, thresholdType, blockSize, C
     bind_stream(s, d)
     _lib.check(L.mi355cv_adaptiveThreshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, float(maxValue), int(adaptiveMethod), int(thresholdType),
                                            int(blockSize), float(C)), "adaptiveThreshold")
+    return out
+
+
+def bilateralFilter(src, d, sigmaColor, sigmaSpace, borderType=BORDER_DEFAULT, dst=None):
+    """cv::bilateralFilter (bilateral_filter.dispatch.cpp:393) through cv_hal_bilateralFilter: CV_8UC1 / CV_8UC3, radius <= 16.  A view with padded rows is
+    treated as the image it shows (BORDER_ISOLATED): the mirror has no parent to pad from."""
+    s = Img(src)
+    if s.depth != CV_8U or s.cn not in (1, 3):
+        raise NotImplementedError("bilateralFilter: CV_8UC1 / CV_8UC3")
+    out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
+    dd = Img(out)
+    bind_stream(s, dd)
+    _lib.check(L.mi355cv_bilateralFilter(_vp(s.ptr), s.step, _vp(dd.ptr), dd.step, s.w, s.h, s.depth, s.cn, int(d), float(sigmaColor), float(sigmaSpace),
+                                         int(borderType) | BORDER_ISOLATED), "bilateralFilter")
     return out
 
 

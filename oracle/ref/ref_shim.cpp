@@ -219,6 +219,14 @@ int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, i
     REF_END(dst, d)
 }
 
+int ref_bilateralFilter(const void* s, size_t ss, void* d, size_t ds, int w, int h, int cn, int dd, double sigmaColor, double sigmaSpace, int border)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, CV_8UC(cn)), dst = M(d, ds, w, h, CV_8UC(cn));
+    cv::bilateralFilter(src, dst, dd, sigmaColor, sigmaSpace, border);
+    REF_END(dst, d)
+}
+
 // cv::hal::cvtBGRtoTwoPlaneYUV (no cvtColor code reaches it); dst = (h * 3/2) x w, Y rows then the interleaved chroma rows
 int ref_cvtBGRtoTwoPlaneYUV(const void* s, size_t ss, void* d, size_t ds, int w, int h, int scn, int swapBlue, int uIdx)
 {

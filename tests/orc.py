@@ -374,6 +374,24 @@ def ref_adaptiveThreshold(src, maxValue, method, type, blockSize, C):
     return dst
 
 
+def orc_bilateralFilter(src, d, sigmaColor, sigmaSpace, border=4):
+    o = oracle()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rc = o.orc_bilateralFilter8u(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border & ~16)
+    assert rc == 0, rc
+    return dst
+
+
+def ref_bilateralFilter(src, d, sigmaColor, sigmaSpace, border=4):
+    r = load_ref()
+    h, w = src.shape[:2]
+    dst = np.empty_like(src)
+    rc = r.ref_bilateralFilter(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border)
+    assert rc == 0, rc
+    return dst
+
+
 def orc_Canny(src, t1, t2, aperture=3, L2=False):
     o = oracle()
     h, w = src.shape[:2]

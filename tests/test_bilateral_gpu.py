@@ -1,0 +1,43 @@
+"""GPU parity for cv::bilateralFilter (§8 f1, cv_hal_bilateralFilter) through the C ABI against the oracle, which is pinned bit for bit to the real
+reference (tests/test_oracle_thresh.py::test_bilateral_filter_matches_reference)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_bilateral_filter(cv, orc, cn):
+    rng = np.random.default_rng(11 + cn)
+    for (w, h) in [(97, 33), (64, 20), (41, 17), (130, 9), (333, 200)]:
+        shape = (h, w, cn) if cn > 1 else (h, w)
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        sm = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2) % 256).astype(np.uint8)
+        noisy = np.clip((np.repeat(sm[..., None], cn, -1) if cn > 1 else sm).astype(int) + rng.integers(-6, 7, shape), 0, 255).astype(np.uint8)
+        for img in (src, noisy):
+            for d, sc, ss in [(5, 25.0, 3.0), (9, 75.0, 75.0), (0, 30.0, 2.0), (3, 10.0, 1.0), (15, 40.0, 4.0)]:
+                for border in (4, 1, 0, 2):
+                    got = cv.bilateralFilter(torch.from_numpy(img).cuda(), d, sc, ss, border).cpu().numpy()
+                    assert np.array_equal(got, orc.orc_bilateralFilter(img, d, sc, ss, border)), (w, h, d, sc, ss, border)
+    img = rng.integers(0, 256, (50, 70, cn) if cn > 1 else (50, 70), dtype=np.uint8)
+    assert np.array_equal(cv.bilateralFilter(img, 7, 50.0, 3.0), orc.orc_bilateralFilter(img, 7, 50.0, 3.0))            # host arrays
+    with pytest.raises(NotImplementedError):
+        cv.bilateralFilter(torch.from_numpy(img).cuda(), 41, 50.0, 3.0)                                                # radius beyond the LDS tile: declined
+
+
+def test_bilateral_filter_4k_timing_shape(cv, orc):
+    """a 4K frame: the result of a crop that depends only on the crop's neighbourhood equals the oracle on that neighbourhood"""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
+    got = cv.bilateralFilter(torch.from_numpy(img).cuda(), 9, 75.0, 75.0)
+    crop = np.ascontiguousarray(img[:120, :264])
+    want = orc.orc_bilateralFilter(crop, 9, 75.0, 75.0)
+    assert np.array_equal(got[:100, :256].cpu().numpy(), want[:100, :256])       # (columns < 256 are vector-body columns in both)

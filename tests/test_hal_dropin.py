@@ -44,6 +44,9 @@ def _calls(o, src8, src8c3, srcf):
     out["gauss_roi_sigma"] = o.ref_GaussianBlurROI(src8c3, (9, 7, 100, 70), 5, 1.2, 1.2, 4)
     out["gauss_roi_binomial"] = o.ref_GaussianBlurROI(src8, (3, 5, 64, 48), 5, 0, 0, 4)
     out["adaptive"] = o.ref_adaptiveThreshold(src8, 255.0, 0, 0, 7, 2.0)
+    out["adaptive_gauss"] = o.ref_adaptiveThreshold(src8, 255.0, 1, 1, 11, -1.5)
+    out["bilateral"] = o.ref_bilateralFilter(src8, 9, 50.0, 5.0)
+    out["bilateral3"] = o.ref_bilateralFilter(src8c3, 5, 30.0, 2.0, 1)
     out["canny"] = o.ref_Canny(src8, 30, 90)
     out["canny3"] = o.ref_Canny(src8c3, 200, 400, 3, True)
     out["i420enc"] = o.ref_cvtColorMisc(src8c3, 128)
@@ -123,7 +126,7 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "canny",
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "bilateralFilter", "canny",
              "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
              "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu", "ScharrDeriv", "LKOpticalFlowLevel"]
     before = {n: cv.call_count(n) for n in names}

@@ -76,3 +76,21 @@ def test_adaptive_threshold_gaussian_and_large_blocks_match_reference(ref):
                 want = O.ref_adaptiveThreshold(img, 200.0, 0, 0, bs, 1.5)
                 got = O.orc_adaptiveThreshold(img, 200.0, 0, bs, 1.5)
                 assert np.array_equal(got, want), ("mean", shape, bs)
+
+
+@pytest.mark.ref
+def test_bilateral_filter_matches_reference(ref):
+    """cv::bilateralFilter 8UC1 / 8UC3: the three summation forms of the AVX2 build (vector body, 4-group 128-bit tail, scalar rest), the division /
+    reciprocal split between one and three channels, every border -- bit for bit against the real reference"""
+    rng = np.random.default_rng(3)
+    for cn in (1, 3):
+        for (w, h) in [(97, 33), (64, 20), (41, 17), (130, 9)]:
+            shape = (h, w, cn) if cn > 1 else (h, w)
+            src = rng.integers(0, 256, shape, dtype=np.uint8)
+            sm = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2) % 256).astype(np.uint8)
+            smooth = np.repeat(sm[..., None], cn, -1).copy() if cn > 1 else sm
+            noisy = np.clip(smooth.astype(int) + rng.integers(-6, 7, shape), 0, 255).astype(np.uint8)
+            for img in (src, noisy):
+                for d, sc, ss in [(5, 25.0, 3.0), (9, 75.0, 75.0), (0, 30.0, 2.0), (3, 10.0, 1.0), (15, 40.0, 4.0)]:
+                    for border in (4, 1, 0, 2):
+                        assert np.array_equal(O.orc_bilateralFilter(img, d, sc, ss, border), O.ref_bilateralFilter(img, d, sc, ss, border)), (cn, w, h, d, sc, ss, border)
