@@ -82,10 +82,11 @@ def test_mfma_path_multichannel_8u(cv, orc, cn, method, monkeypatch):
         want = orc.orc_matchTemplate(img, tpl, method)
         got = cv.matchTemplate(dev(img), dev(tpl), method)
         assert orc.rel_err(got.cpu().numpy(), want) <= 1e-6, (iw, ih, tw, th)
-        monkeypatch.setenv("MI355CV_TM_PLANES", "0")
-        direct = cv.matchTemplate(dev(img), dev(tpl), method)
-        monkeypatch.delenv("MI355CV_TM_PLANES")
-        assert orc.rel_err(got.cpu().numpy(), direct.cpu().numpy()) <= 1e-5
+        if tw == 16:                                                   # the direct kernel takes seconds on the larger cases
+            monkeypatch.setenv("MI355CV_TM_PLANES", "0")
+            direct = cv.matchTemplate(dev(img), dev(tpl), method)
+            monkeypatch.delenv("MI355CV_TM_PLANES")
+            assert orc.rel_err(got.cpu().numpy(), direct.cpu().numpy()) <= 1e-5
     if method in (3, 5):
         frames = np.stack([rnd((260, 520, cn), np.uint8, 90 + k) for k in range(3)])
         tpl = rnd((96, 80, cn), np.uint8, 91)
