@@ -785,13 +785,13 @@ __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, s
 // template statistics on the device (cv::meanStdDev, templmatch.cpp:931-958, and the constants common_matchTemplate derives from them,
 // :960-985): one workgroup, so that a device-resident template never has to visit the host and the call stays asynchronous.  Also
 // writes the MFMA kernels' copy of an 8UC1 template: (t - 128) as int8, MT_TPITCH bytes per row, 32 zero bytes in front, zeros behind.
-__global__ __launch_bounds__(256) void k_tm_tstats(const uchar* __restrict__ tpl, size_t tstep, int depth, NormArgs* __restrict__ ap, uchar* __restrict__ tx)
+__global__ __launch_bounds__(1024) void k_tm_tstats(const uchar* __restrict__ tpl, size_t tstep, int depth, NormArgs* __restrict__ ap, uchar* __restrict__ tx)
 {
-    __shared__ double red[2][4][4];
+    __shared__ double red[2][16][4];                        // one workgroup of 16 waves: the call's latency is this kernel's loops (58 us with 4 waves)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tw = ap->tw, th = ap->th, cn = ap->cn, method = ap->method;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (int i = tid; i < tw * th; i += 256) {
+    for (int i = tid; i < tw * th; i += 1024) {
         const int y = i / tw, x = i - y * tw;
         const uchar* row = tpl + (size_t)y * tstep;
         for (int c = 0; c < cn; c++) {
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_tm_tstats(const uchar* __restrict__ tpl
         if (lane == 0) { red[0][wave][c] = a; red[1][wave][c] = b; }
     }
     if (tx) {
-        for (int i = tid; i < th * MT_TPITCH; i += 256) {
+        for (int i = tid; i < th * MT_TPITCH; i += 1024) {
             const int r = i / MT_TPITCH, j = i - r * MT_TPITCH - 32;
             tx[i] = (j >= 0 && j < tw) ? (uchar)(tpl[(size_t)r * tstep + j] ^ 0x80) : (uchar)0;
         }
@@ -815,7 +815,8 @@ __global__ __launch_bounds__(256) void k_tm_tstats(const uchar* __restrict__ tpl
     NormArgs na = *ap;
     double tsdv[4] = {0, 0, 0, 0}; long long tplSum = 0;
     for (int c = 0; c < cn; c++) {
-        const double ss = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c], qq = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        double ss = 0, qq = 0;
+        for (int wv = 0; wv < 16; wv++) { ss += red[0][wv][c]; qq += red[1][wv][c]; }
         if (depth == D8U) tplSum += (long long)ss;
         na.tmean[c] = ss * na.invArea;
         const double var = qq * na.invArea - na.tmean[c] * na.tmean[c];
@@ -916,7 +917,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     hipStream_t st = stream();
     auto uploadStats = [&](uchar* tx) -> const NormArgs* {
         NormArgs* d = (NormArgs*)stg.param(&na, sizeof na);
-        if (d) hipLaunchKernelGGL(k_tm_tstats, dim3(1), dim3(256), 0, st, dt, dts, depth, d, tx);
+        if (d) hipLaunchKernelGGL(k_tm_tstats, dim3(1), dim3(1024), 0, st, dt, dts, depth, d, tx);
         return d;
     };
     // integral images: needed by every method but TM_CCORR, and by the MFMA path's bias correction

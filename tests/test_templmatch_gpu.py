@@ -76,7 +76,8 @@ def test_mfma_path_multichannel_8u(cv, orc, cn, method, monkeypatch):
     """CV_8UC2 / C3 / C4 with >= 4096 outputs: per-channel planes through the i8 MFMA path, the exact per-channel correlations summed in
     double, the multi-channel normalisation of common_matchTemplate on top; against the oracle and against the direct kernel
     (MI355CV_TM_PLANES=0); single images (plane widths that are / are not multiples of 4) and a batch"""
-    for (iw, ih, tw, th) in [(300, 200, 16, 16), (516, 301, 128, 128), (401, 390, 33, 77)]:
+    sizes = [(300, 200, 16, 16), (401, 390, 33, 77)] + ([(516, 301, 128, 128)] if method in (3, 4) else [])      # (the CPU oracle takes seconds per 128x128 case)
+    for (iw, ih, tw, th) in sizes:
         img = rnd((ih, iw, cn), np.uint8, 70 + iw + cn)
         tpl = rnd((th, tw, cn), np.uint8, 80 + tw)
         want = orc.orc_matchTemplate(img, tpl, method)
