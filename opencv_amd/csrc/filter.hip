@@ -130,16 +130,31 @@ template <int K, int SCN> struct GrayRows {
 #pragma unroll
         for (int i = 0; i < SCN; i++) r.s[i] = *reinterpret_cast<const uint32_t*>(row + (size_t)SCN * cx.sideOff + 4 * i);
     }
+    // four gray bytes from pixels first .. first+3 (first a multiple of 4).  c0 k0 + c1 k1 + c2 k2 = 256 (c . khi) + (c . klo) with the coefficients split into
+    // bytes, so each pixel costs two v_dot4_u32_u8 (the rounding constant rides in the second one's accumulator), one shift-add and one shift; a 3-byte
+    // pixel is brought into one dword by v_alignbyte where it straddles two, and the unused fourth byte meets a zero coefficient -- about half the
+    // instructions of extracting the bytes and chaining multiply-adds, in a kernel whose bound is the VALU
     template <int NPX> __device__ __forceinline__ uint32_t gray4(const uint32_t* w, int first) const
     {
-        uint32_t acc = 0;
+        const uint32_t KH = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16), KL = (k0 & 255u) | ((k1 & 255u) << 8) | ((k2 & 255u) << 16);
+        uint32_t px[4], acc = 0;
+        bool hiPos[4] = {false, false, false, false};                                 // pixel bytes at positions 1..3 of the dword instead of 0..2
+        if (SCN == 4) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) px[p] = w[first + p];
+        } else {
+            const uint32_t* g = w + (first / 4) * 3;
+            px[0] = g[0];
+            px[1] = __builtin_amdgcn_alignbyte(g[1], g[0], 3);
+            px[2] = __builtin_amdgcn_alignbyte(g[2], g[1], 2);
+            px[3] = g[2]; hiPos[3] = true;
+        }
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int b0 = (first + p) * SCN;
-            const uint32_t c0 = (w[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
-            const uint32_t c1 = (w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 0xffu;
-            const uint32_t c2 = (w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 0xffu;
-            acc |= ((c0 * k0 + c1 * k1 + c2 * k2 + (1u << 14)) >> 15) << (8 * p);
+            const uint32_t kh = hiPos[p] ? KH << 8 : KH, kl = hiPos[p] ? KL << 8 : KL;
+            const uint32_t hi = __builtin_amdgcn_udot4(px[p], kh, 0u, false);
+            const uint32_t lo = __builtin_amdgcn_udot4(px[p], kl, 1u << 14, false);
+            acc |= (((hi << 8) + lo) >> 15) << (8 * p);
         }
         return acc;
     }
