@@ -228,13 +228,13 @@ def copy_probe(views, reps=2):
     from opencv_amd.core import bind_stream, Img
     bind_stream(Img(views[0][0][0]))
     calls = [(ctypes.c_void_p(f.data_ptr()), ctypes.c_void_p(o.data_ptr()), ctypes.c_size_t(f.numel())) for f, o in views]
-    assert _lib.lib.mi355cv_copyProbe(calls[0][0], calls[0][1], calls[0][2], 4, 1) == 0
+    assert _lib.lib.mi355cv_copyProbe(calls[0][0], calls[0][1], calls[0][2], 1, 1) == 0      # one 16-byte chunk per lane: the fastest form measured (6.3-6.4 TB/s)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
         for sp, dp, nb in calls:
-            _lib.lib.mi355cv_copyProbe(sp, dp, nb, 4, 1)
+            _lib.lib.mi355cv_copyProbe(sp, dp, nb, 1, 1)
     b.record(); torch.cuda.synchronize()
     return 2.0 * sum(f.numel() for f, _ in views) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
