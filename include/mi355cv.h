@@ -317,6 +317,11 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const mi355cv_uchar* y_data, size_
 MI355CV_API int mi355cv_threshold(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, int depth, int cn, double thresh, double maxValue, int thresholdType);
 
+/* replaces hal_ni_imageMoments (hal_replacement.hpp:1309; caller cv::moments moments.cpp:578): the ten spatial moments m00, m10, m01, m20, m11, m02, m30, m21,
+ * m12, m03 of a single-channel CV_8U / CV_16U / CV_16S image (or of its non-zero mask, `binary`), bit-identical: exact integer tile moments on the GPU,
+ * the reference's double accumulation over the tiles on the host. */
+MI355CV_API int mi355cv_imageMoments(const mi355cv_uchar* src_data, size_t src_step, int src_type, int width, int height, bool binary, double m[10]);
+
 /* replaces hal_ni_bilateralFilter (hal_replacement.hpp:1016; caller cv::bilateralFilter bilateral_filter.dispatch.cpp:418): CV_8UC1 / CV_8UC3, radius <= 16,
  * the float sums in the three forms of the reference's AVX2 build (vector body / 4-group tail / scalar rest), bit-exact.  The hook carries no margins: an
  * image with padded rows and no BORDER_ISOLATED is declined (the reference pads a submatrix with its parent's pixels). */

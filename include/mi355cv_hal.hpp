@@ -73,6 +73,8 @@
 #define cv_hal_adaptiveThreshold mi355cv_adaptiveThreshold
 #undef  cv_hal_bilateralFilter
 #define cv_hal_bilateralFilter mi355cv_bilateralFilter
+#undef  cv_hal_imageMoments
+#define cv_hal_imageMoments mi355cv_imageMoments
 #undef  cv_hal_threshold
 #define cv_hal_threshold mi355cv_threshold
 // hal_replacement.hpp:207-233 / caller halMorph morph.dispatch.cpp:190-220

@@ -112,6 +112,7 @@ def _load():
         "mi355cv_hostFree": (c_int, [ctypes.c_void_p, c_int]),
         "mi355cv_canny": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_dbl, c_dbl, c_int, ctypes.c_bool]),
         "mi355cv_adaptiveThreshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_dbl, c_int, c_int, c_int, c_dbl]),
+        "mi355cv_imageMoments": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, ctypes.POINTER(ctypes.c_double)]),
         "mi355cv_bilateralFilter": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_threshold": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_filterFree": (c_int, [ctypes.c_void_p]),

@@ -26,7 +26,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
-           "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "bilateralFilter", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
+           "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "bilateralFilter", "moments", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "cvtColorFilter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
            "getGaussianKernel", "getGaussianKernelQ"]
@@ -505,6 +505,18 @@ def adaptiveThreshold(src, maxValue, adaptiveMethod, thresholdType, blockSize, C
     _lib.check(L.mi355cv_adaptiveThreshold(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, float(maxValue), int(adaptiveMethod), int(thresholdType),
                                            int(blockSize), float(C)), "adaptiveThreshold")
     return out
+
+
+def moments(src, binaryImage=False):
+    """cv::moments of a single-channel CV_8U / CV_16U / CV_16S image through cv_hal_imageMoments: the ten spatial moments as a dict (m00 .. m03); the central
+    and normalised moments follow from them as in completeMomentState (moments.cpp:33-66)."""
+    s = Img(src)
+    if s.cn != 1:
+        raise ValueError("moments: single-channel images")
+    bind_stream(s)
+    buf = (ctypes.c_double * 10)()
+    _lib.check(L.mi355cv_imageMoments(_vp(s.ptr), s.step, s.type, s.w, s.h, bool(binaryImage), buf), "imageMoments")
+    return dict(zip(("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03"), buf[:]))
 
 
 def bilateralFilter(src, d, sigmaColor, sigmaSpace, borderType=BORDER_DEFAULT, dst=None):

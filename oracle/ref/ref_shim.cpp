@@ -219,6 +219,17 @@ int ref_adaptiveThreshold(const void* s, size_t ss, void* d, size_t ds, int w, i
     REF_END(dst, d)
 }
 
+int ref_moments(const void* s, size_t ss, int w, int h, int type, int binary, double* m)
+{
+    try {
+        Mat src = M(s, ss, w, h, type);
+        const cv::Moments mo = cv::moments(src, binary != 0);
+        const double v[10] = {mo.m00, mo.m10, mo.m01, mo.m20, mo.m11, mo.m02, mo.m30, mo.m21, mo.m12, mo.m03};
+        for (int k = 0; k < 10; k++) m[k] = v[k];
+        return 0;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref: %s\n", e.what()); return -1; }
+}
+
 int ref_bilateralFilter(const void* s, size_t ss, void* d, size_t ds, int w, int h, int cn, int dd, double sigmaColor, double sigmaSpace, int border)
 {
     REF_TRY

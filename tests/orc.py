@@ -374,6 +374,24 @@ def ref_adaptiveThreshold(src, maxValue, method, type, blockSize, C):
     return dst
 
 
+def orc_moments(src, binary=False):
+    o = oracle()
+    h, w = src.shape
+    m = np.zeros(10, np.float64)
+    rc = o.orc_imageMoments(P(src), step(src), _NP_DEPTH[src.dtype], w, h, int(binary), P(m))
+    assert rc == 0, rc
+    return m
+
+
+def ref_moments(src, binary=False):
+    r = load_ref()
+    h, w = src.shape
+    m = np.zeros(10, np.float64)
+    rc = r.ref_moments(P(src), step(src), w, h, cvtype(src), int(binary), P(m))
+    assert rc == 0, rc
+    return m
+
+
 def orc_bilateralFilter(src, d, sigmaColor, sigmaSpace, border=4):
     o = oracle()
     h, w = src.shape[:2]

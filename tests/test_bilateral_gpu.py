@@ -41,3 +41,18 @@ def test_bilateral_filter_4k_timing_shape(cv, orc):
     crop = np.ascontiguousarray(img[:120, :264])
     want = orc.orc_bilateralFilter(crop, 9, 75.0, 75.0)
     assert np.array_equal(got[:100, :256].cpu().numpy(), want[:100, :256])       # (columns < 256 are vector-body columns in both)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
+def test_image_moments(cv, orc, dtype):
+    """cv_hal_imageMoments: the ten spatial moments equal the oracle's (pinned to cv::moments) as doubles, bit for bit"""
+    rng = np.random.default_rng(8)
+    info = np.iinfo(dtype)
+    for (w, h) in [(1, 1), (31, 5), (32, 32), (33, 65), (200, 97), (3840, 2160), (1000, 37)]:
+        for src in (rng.integers(info.min, int(info.max) + 1, (h, w), dtype=dtype), np.full((h, w), info.max, dtype=dtype)):
+            for binary in (False, True):
+                got = cv.moments(torch.from_numpy(src).cuda(), binary)
+                want = orc.orc_moments(src, binary)
+                assert [got[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")] == want.tolist(), (w, h, binary)
+    src = rng.integers(0, 256, (70, 90)).astype(dtype)
+    assert list(cv.moments(src).values()) == orc.orc_moments(src).tolist()                      # host arrays

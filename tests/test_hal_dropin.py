@@ -45,6 +45,8 @@ def _calls(o, src8, src8c3, srcf):
     out["gauss_roi_binomial"] = o.ref_GaussianBlurROI(src8, (3, 5, 64, 48), 5, 0, 0, 4)
     out["adaptive"] = o.ref_adaptiveThreshold(src8, 255.0, 0, 0, 7, 2.0)
     out["adaptive_gauss"] = o.ref_adaptiveThreshold(src8, 255.0, 1, 1, 11, -1.5)
+    out["moments"] = o.ref_moments(src8)
+    out["moments_bin16"] = o.ref_moments((src8.astype(np.uint16) * 200), True)
     out["bilateral"] = o.ref_bilateralFilter(src8, 9, 50.0, 5.0)
     out["bilateral3"] = o.ref_bilateralFilter(src8c3, 5, 30.0, 2.0, 1)
     out["canny"] = o.ref_Canny(src8, 30, 90)
@@ -126,7 +128,7 @@ def test_reference_runs_on_the_gpu(ref):
     src8, src8c3, srcf = _inputs()
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
-             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "bilateralFilter", "canny",
+             "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "bilateralFilter", "imageMoments", "canny",
              "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
              "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu", "ScharrDeriv", "LKOpticalFlowLevel"]
     before = {n: cv.call_count(n) for n in names}

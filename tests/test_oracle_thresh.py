@@ -94,3 +94,16 @@ def test_bilateral_filter_matches_reference(ref):
                 for d, sc, ss in [(5, 25.0, 3.0), (9, 75.0, 75.0), (0, 30.0, 2.0), (3, 10.0, 1.0), (15, 40.0, 4.0)]:
                     for border in (4, 1, 0, 2):
                         assert np.array_equal(O.orc_bilateralFilter(img, d, sc, ss, border), O.ref_bilateralFilter(img, d, sc, ss, border)), (cn, w, h, d, sc, ss, border)
+
+
+@pytest.mark.ref
+def test_image_moments_match_reference(ref):
+    """cv::moments (spatial moments m00 .. m03) for CV_8U / CV_16U / CV_16S, plain and binary: exact integer tile moments, the reference's double accumulation
+    over the 32 x 32 tiles in its order and grouping -- equal as doubles, a 4K frame included"""
+    rng = np.random.default_rng(4)
+    for dt in (np.uint8, np.uint16, np.int16):
+        info = np.iinfo(dt)
+        for (w, h) in [(1, 1), (31, 5), (32, 32), (33, 65), (200, 97), (3840, 2160), (1000, 37)]:
+            for src in (rng.integers(info.min, int(info.max) + 1, (h, w), dtype=dt), np.full((h, w), info.max, dtype=dt)):
+                for binary in (False, True):
+                    assert np.array_equal(O.orc_moments(src, binary), O.ref_moments(src, binary)), (dt, w, h, binary)
