@@ -42,6 +42,7 @@ int  activeDevice();                // ordinal of that device (per-device caches
 // or ANOTHER GPU's memory (the hook declines: the thread is bound to the wrong device for that image)
 enum PtrKind { PTR_HOST = 0, PTR_DEVICE = 1, PTR_FOREIGN = 2 };
 int  ptrKind(const void* p);
+void noteStagedBytes(long long n);                 // PCIe bytes moved outside Stager::in / out (pipelined host batches)
 // true if p points into this device's or managed memory (launch in place)
 bool isDevicePtr(const void* p);
 // src and dst are the same buffer in HBM: a stencil cannot run in place on the GPU (host images are staged into separate buffers, so they may)

@@ -23,6 +23,7 @@ static std::atomic<int> g_devState[MAX_DEV];        // 0 unknown, 1 usable (gfx9
 static std::mutex g_mu;
 static std::map<std::string, long long> g_counts;
 static std::atomic<long long> g_stagedBytes{0};   // image bytes the hooks moved over PCIe (host images staged in + results staged back)
+void noteStagedBytes(long long n) { g_stagedBytes += n; }
 static thread_local char t_err[512] = "";
 static thread_local int t_dev = -1;                 // mi355cv_setDevice; -1 = process default
 static thread_local int t_active = 0;               // device of the hook that is running = index of the per-device thread context

@@ -141,11 +141,23 @@ def sepSmoothFixedU8(src, kx, ky, borderType=BORDER_DEFAULT, dst=None, margins=(
 
 
 def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None):
-    """N independent frames [N,H,W(,C)] resident in HBM, one launch (frames shard, never split)."""
-    if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda:
-        raise ValueError("GaussianBlurBatch needs a CUDA(ROCm) tensor [N,H,W(,C)]")
+    """N independent frames [N,H,W(,C)] resident in HBM, one launch (frames shard, never split).  Frames in HOST memory (a CPU tensor,
+    ideally page-locked) take the library's pipelined path: chunks cross PCIe through two sets of device buffers, upload / filter / download overlapped."""
+    if torch is None or not isinstance(frames, torch.Tensor):
+        raise ValueError("GaussianBlurBatch needs a tensor [N,H,W(,C)] (CUDA(ROCm) resident, or a CPU tensor for the pipelined host path)")
     if frames.dim() not in (3, 4) or frames.dtype != torch.uint8:
         raise ValueError("frames must be uint8 [N,H,W] or [N,H,W,C]")
+    if not frames.is_cuda:
+        n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        cn = int(frames.shape[3]) if frames.dim() == 4 else 1
+        if not frames[0].is_contiguous():
+            raise ValueError("each frame must be contiguous")
+        out = dst if dst is not None else torch.empty_like(frames, pin_memory=frames.is_pinned())
+        k = ksize if isinstance(ksize, int) else ksize[0]
+        rc = L.mi355cv_gaussianBlurBinomialBatch(_vp(frames.data_ptr()), w * cn, int(frames.stride(0)), _vp(out.data_ptr()), w * cn, int(out.stride(0)), n, w, h, CV_8U, cn, k,
+                                                 borderType & ~BORDER_ISOLATED)
+        _lib.check(rc, "gaussianBlurBinomialBatch")
+        return out
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     cn = int(frames.shape[3]) if frames.dim() == 4 else 1
     if not frames[0].is_contiguous():

@@ -87,3 +87,19 @@ def test_fused_cvtcolor_filter2d(cv, scn):
                     assert torch.equal(got, want), (n, h, w, code, k.shape, border)
     with pytest.raises(NotImplementedError):                   # a width that is not a multiple of 16 is declined, nothing is computed elsewhere
         cv.cvtColorFilter2DBatch(torch.zeros((1, 20, 40, scn), dtype=torch.uint8, device="cuda"), codes[0], ks[0])
+
+
+def test_gaussian_batch_from_host_memory_is_pipelined(cv):
+    """a batch that lives in host memory (page-locked or pageable) crosses PCIe in chunks through two sets of device buffers; the result
+    equals the device-resident batch frame for frame, for chunk counts of one, two and several (odd and even), 1 and 3 channels"""
+    g = torch.Generator(); g.manual_seed(3)
+    for (n, h, w, cn, pinned) in [(5, 1080, 1920, 1, True), (40, 540, 960, 1, True), (3, 300, 400, 3, False), (33, 270, 480, 3, True), (2, 64, 64, 1, False)]:
+        shape = (n, h, w) + ((cn,) if cn > 1 else ())
+        host = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        if pinned:
+            host = host.pin_memory()
+        want = cv.GaussianBlurBatch(host.cuda(), 5).cpu()
+        staged0 = cv._lib.lib.mi355cv_stagedBytes()
+        got = cv.GaussianBlurBatch(host, 5)
+        assert got.device.type == "cpu" and torch.equal(got, want), (n, h, w, cn, pinned)
+        assert cv._lib.lib.mi355cv_stagedBytes() - staged0 == 2 * host.numel()          # every byte crossed PCIe once each way
