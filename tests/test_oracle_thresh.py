@@ -107,3 +107,16 @@ def test_image_moments_match_reference(ref):
             for src in (rng.integers(info.min, int(info.max) + 1, (h, w), dtype=dt), np.full((h, w), info.max, dtype=dt)):
                 for binary in (False, True):
                     assert np.array_equal(O.orc_moments(src, binary), O.ref_moments(src, binary)), (dt, w, h, binary)
+
+
+@pytest.mark.ref
+def test_gaussian_c_float_blur_is_bit_identical_on_8bit_valued_images(ref):
+    """the float blur inside ADAPTIVE_THRESH_GAUSSIAN_C (CV_32F GaussianBlur of an 8-bit valued image): the restated separable float path gives the
+    reference's floats bit for bit -- so the rounded mean, and with it the thresholded image, cannot differ by a tie"""
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (257, 333), dtype=np.uint8).astype(np.float32)
+    for bs in (3, 5, 7, 11, 21, 33):
+        k = O.ref_getGaussianKernel(bs, 0.0).astype(np.float32).ravel()
+        a = O.orc_sepFilter2D(src, 5, k, k, border=1)
+        b = O.ref_GaussianBlur(src, bs, 0.0, 0.0, 1 | 16)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), bs
