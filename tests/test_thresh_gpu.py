@@ -74,3 +74,15 @@ def test_adaptive_threshold(cv, orc):
     assert np.array_equal(cv.adaptiveThreshold(src, 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 7, 2.0), orc.orc_adaptiveThreshold(src, 255.0, 0, 7, 2.0, method=1))   # host pointers
     with pytest.raises(NotImplementedError):                      # more taps than the separable hook's context holds
         cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 101, 0.0)
+
+
+def test_gaussian_c_float_blur_bits(cv, orc):
+    """the CV_32F separable blur ADAPTIVE_THRESH_GAUSSIAN_C runs on the GPU gives the oracle's floats bit for bit on 8-bit valued images (the oracle gives
+    the reference's, tests/test_oracle_thresh.py): the rounded mean cannot differ by a tie"""
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (257, 333), dtype=np.uint8).astype(np.float32)
+    for bs in (3, 5, 7, 11, 21, 33):
+        k = cv.getGaussianKernel(bs, 0.0, 5)
+        got = cv.sepFilter2D(torch.from_numpy(src).cuda(), -1, k, k, borderType=1 | 16).cpu().numpy()
+        want = orc.orc_sepFilter2D(src, 5, k, k, border=1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), bs

@@ -201,6 +201,14 @@ def run(quick=False, parity=True):
     line2("a6 cvtColor GRAY2BGR 4K 8U", timeit(lambda: cv.cvtColor(g1, cv.COLOR_GRAY2BGR, dst=rgb)), 3840 * 2160 * 4)
     line2("a1 GaussianBlur 5x5 4K 8UC3 (single frame)", timeit(lambda: cv.GaussianBlur(c3, (5, 5), 0, dst=rgb)), 3840 * 2160 * 6)
     del r720, r1080, up, rgb, g1d
+    # the headline operation on SURVEY 8d's other geometries, batched (secondary: 8UC3; 1080p and 8K variants)
+    for name, shp in [("a1 GaussianBlur 5x5 4K 8UC3 batch of 64 (secondary headline geometry)", (64, 2160, 3840, 3)),
+                      ("a1 GaussianBlur 5x5 1080p 8UC1 batch of 512", (512, 1080, 1920)), ("a1 GaussianBlur 5x5 8K 8UC1 batch of 32", (32, 4320, 7680))]:
+        fb = torch.randint(0, 256, shp, dtype=torch.uint8, device=dev, generator=g); ob = torch.empty_like(fb)
+        ms = timeit(lambda: cv.GaussianBlurBatch(fb, 5, dst=ob), n=10, warm=3)
+        out.append({"config": name, "ms": round(ms, 4), "Mpix_s": round(shp[0] * shp[1] * shp[2] / ms / 1e3, 1), "bound": "hbm", "achieved_GBs": round(2 * fb.numel() / ms / 1e6, 1),
+                    "frac": round(2 * fb.numel() / ms / 1e6 / HBM, 4)})
+        del fb, ob
     rg = gray[0][:, :3838].contiguous(); rgd = torch.empty_like(rg)          # 3838-byte rows: ragged AND unaligned row starts
     ms = timeit(lambda: cv.GaussianBlur(rg, (5, 5), 1.5, dst=rgd))
     out.append({"config": "a1 GaussianBlur 5x5 sigma 1.5 on 3838x2160 8U (ragged, unaligned rows)", "ms": round(ms, 4), "Mpix_s": round(3838 * 2160 / ms / 1e3, 1)})
