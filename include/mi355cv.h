@@ -153,7 +153,8 @@ MI355CV_API int mi355cv_sepSmoothFixedU8(const mi355cv_uchar* src_data, size_t s
         const uint16_t* kx, int kxlen, const uint16_t* ky, int kylen, int border_type);
 
 /* Batched form (frames are independent units): `nframes` images of identical
- * geometry, frame f at src_data + f*src_frame_stride; one launch, grid-z = frame. */
+ * geometry, frame f at src_data + f*src_frame_stride; one launch, grid-z = frame.  Host-resident batches: the chunked two-buffer pipeline (see the
+ * batch section below). */
 MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
         mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int cn, size_t ksize, int border_type);
@@ -450,7 +451,9 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355
 /* --------------------------------------------------- batches of device-resident frames (frames are the unit that shards)
  * The frame-batched forms of the hooks above: `nframes` whole images of identical geometry, `*_frame_stride` bytes apart, borders per frame.
  * One launch where the kernel takes a frame index (the rolling filters, nearest / bilinear / area-fast resize, the warps, threshold on
- * back-to-back frames), otherwise the per-frame kernels enqueued by one call.  Device pointers only. */
+ * back-to-back frames), otherwise the per-frame kernels enqueued by one call.  Both ends in HBM -- or both in host memory (pageable or page-locked): the
+ * batch then crosses PCIe in chunks of <= 16 frames / 64 MB through two sets of device buffers, upload of chunk i+1 overlapped with the kernels and the
+ * download of chunk i.  mi355cv_buildPyramidBatch and mi355cv_matchTemplateBatch take device pointers only. */
 MI355CV_API int mi355cv_sobelBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data, size_t dst_step,
         size_t dst_frame_stride, int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta,
         int border_type);

@@ -182,6 +182,11 @@ MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const uchar* src_data, size_t src_step
                                           uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
                                           int width, int height, int depth, int scn, int swapBlue)
 {
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * scn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * depthBytes(depth), height, nframes};
+        return runHostBatch("cvtBGRtoGrayBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_cvtBGRtoGrayBatch(s, ss, sf, d, ds, df, nf, width, height, depth, scn, swapBlue); });
+    }
     return runBgr2Gray("cvtBGRtoGrayBatch", src_data, src_step, nframes == 1 ? 0 : src_frame_stride, dst_data, dst_step,
                        nframes == 1 ? 0 : dst_frame_stride, nframes, width, height, depth, scn, swapBlue != 0);
 }

@@ -802,6 +802,12 @@ MI355CV_API int mi355cv_pyrdownBatch(const uchar* src_data, size_t src_step, siz
                                      uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes,
                                      int depth, int cn, int border_type)
 {
+    if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        const size_t pix = (size_t)cn * depthBytes(depth);
+        const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
+        return runHostBatch("pyrdownBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_pyrdownBatch(s, ss, sf, src_width, src_height, d, ds, df, dst_width, dst_height, nf, depth, cn, border_type); });
+    }
     return runPyrDown("pyrdownBatch", src_data, src_step, nframes == 1 ? 0 : src_frame_stride, src_width, src_height, dst_data, dst_step,
                       nframes == 1 ? 0 : dst_frame_stride, dst_width, dst_height, nframes, depth, cn, 0, 0, 0, 0, border_type);
 }
@@ -865,6 +871,11 @@ MI355CV_API int mi355cv_cornerHarrisBatch(const uchar* src_data, size_t src_step
                                           size_t dst_frame_stride, int nframes, int width, int height, int src_type, int blockSize, int ksize,
                                           double k, int borderType)
 {
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type)), height, dst_data, dst_step, dst_frame_stride, (size_t)width * 4, height, nframes};
+        return runHostBatch("cornerHarrisBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_cornerHarrisBatch(s, ss, sf, d, ds, df, nf, width, height, src_type, blockSize, ksize, k, borderType); });
+    }
     return runCorner("cornerHarrisBatch", src_data, src_step, nframes == 1 ? 0 : src_frame_stride, dst_data, dst_step,
                      nframes == 1 ? 0 : dst_frame_stride, nframes, width, height, src_type, blockSize, ksize, k, borderType, true);
 }

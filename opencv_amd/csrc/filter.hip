@@ -721,6 +721,11 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * c->cn * depthBytes(c->sdepth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * c->cn * depthBytes(c->ddepth), height, nframes};
+        return runHostBatch("filterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_filterBatch(context, s, ss, sf, d, ds, df, nf, width, height); });
+    }
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;
     if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
@@ -747,6 +752,11 @@ MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uc
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * scn, height, dst_data, dst_step, dst_frame_stride, (size_t)width, height, nframes};
+        return runHostBatch("cvtBGRtoGrayFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_cvtBGRtoGrayFilterBatch(context, s, ss, sf, d, ds, df, nf, width, height, scn, swapBlue); });
+    }
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
     const int K = c->kw;
     if (c->cn != 1 || c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2)
@@ -860,6 +870,11 @@ MI355CV_API int mi355cv_sobelBatch(const uchar* src_data, size_t src_step, size_
         int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta, int border_type)
 {
     if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
+        return runHostBatch("sobelBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_sobelBatch(s, ss, sf, d, ds, df, nf, width, height, src_depth, dst_depth, cn, dx, dy, ksize, scale, delta, border_type); });
+    }
     return derivRun("sobelBatch", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn, 0, 0, 0, 0, dx, dy, ksize, ksize <= 0, scale, delta,
                     border_type & ~MI355CV_BORDER_ISOLATED, nframes, src_frame_stride, dst_frame_stride);
 }
@@ -869,6 +884,11 @@ MI355CV_API int mi355cv_sepFilterBatch(cvhalFilter2D* context, const uchar* src_
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 2 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * c->cn * depthBytes(c->sdepth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * c->cn * depthBytes(c->ddepth), height, nframes};
+        return runHostBatch("sepFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_sepFilterBatch(context, s, ss, sf, d, ds, df, nf, width, height); });
+    }
     return sepRunBatch("sepFilterBatch", *c, src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height);
 }
 
@@ -881,6 +901,11 @@ MI355CV_API int mi355cv_boxFilterBatch(const uchar* src_data, size_t src_step, s
         int border_type)
 {
     if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
+        return runHostBatch("boxFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_boxFilterBatch(s, ss, sf, d, ds, df, nf, width, height, src_depth, dst_depth, cn, ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type); });
+    }
     return boxRun("boxFilterBatch", src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, src_depth, dst_depth, cn,
                   0, 0, 0, 0, ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type);
 }

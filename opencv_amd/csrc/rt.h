@@ -8,6 +8,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <vector>
+#include <functional>
 #include "../../include/mi355cv.h"
 
 typedef unsigned char uchar;
@@ -83,6 +84,20 @@ private:
     bool foreign_(const void* p);
 };
 
+// A batch of whole frames that lives in HOST memory (ingest / egress): the frames cross PCIe in chunks through two sets of device
+// buffers -- the upload of chunk i+1 (aux stream) overlaps the kernels and the download of chunk i (main stream) -- and `run` is the entry's own
+// device-resident batch path, called once per chunk with dense device frames.  Source and destination frames may differ in geometry and type.
+struct HostBatch {
+    const uchar* src; size_t sstep, sframe, srowBytes; int srows;       // source frames: pitch, frame stride, valid bytes per row, rows
+    uchar* dst; size_t dstep, dframe, drowBytes; int drows;
+    int nframes;
+};
+typedef std::function<int(const uchar* s, size_t sstep, size_t sframe, uchar* d, size_t dstep, size_t dframe, int nframes)> HostBatchFn;
+// both ends are plain (pageable or page-locked) host memory: the batch entries take runHostBatch then
+bool hostBatchEligible(const void* src, const void* dst, int nframes);
+int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run);
+
+inline int depthBytes(int depth) { return depth <= 1 ? 1 : depth <= 3 ? 2 : depth <= 5 ? 4 : 8; }     // CV_8U .. CV_64F
 inline int divUp(int a, int b) { return (a + b - 1) / b; }
 
 #define MI355_CHECK_LAUNCH(entry)                                                        \

@@ -306,6 +306,60 @@ int Stager::finish(const char* entry)
     return MI355CV_OK;
 }
 
+// ------------------------------------------------------------------ pipelined host batches
+bool hostBatchEligible(const void* src, const void* dst, int nframes)
+{
+    return nframes >= 1 && src && dst && !disabled() && ensureDevice() && ptrKind(src) == PTR_HOST && ptrKind(dst) == PTR_HOST;
+}
+
+int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
+{
+    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
+    const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, dp = (hb.drowBytes + 255) & ~(size_t)255;
+    const size_t sfb = sp * (size_t)hb.srows, dfb = dp * (size_t)hb.drows;
+    int cf = (int)((size_t)(64u << 20) / std::max(sfb, dfb));           // frames per chunk: <= 64 MB per buffer, <= 16 frames
+    cf = cf < 1 ? 1 : cf > 16 ? 16 : cf; if (cf > hb.nframes) cf = hb.nframes;
+    uchar* din[2]; uchar* dout[2];
+    for (int b = 0; b < 2; b++) {
+        din[b] = (uchar*)stg.scratch(sfb * cf); dout[b] = (uchar*)stg.scratch(dfb * cf);
+        if (!din[b] || !dout[b]) return MI355CV_NOT_IMPLEMENTED;
+    }
+    hipStream_t st = stream(), aux = auxStream();
+    hipEvent_t inReady[2] = {pooledEvent(40), pooledEvent(41)}, bufFree[2] = {pooledEvent(42), pooledEvent(43)};
+    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return MI355CV_NOT_IMPLEMENTED;
+    const int nchunks = (hb.nframes + cf - 1) / cf;
+    auto upload = [&](int c) -> bool {
+        const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
+        if (c >= 2 && hipStreamWaitEvent(aux, bufFree[b], 0) != hipSuccess) return false;          // the buffers' previous chunk has been consumed and downloaded
+        for (int f = 0; f < nf; f++)
+            if (hipMemcpy2DAsync(din[b] + (size_t)f * sfb, sp, hb.src + (size_t)(f0 + f) * hb.sframe, hb.sstep, hb.srowBytes, hb.srows, hipMemcpyHostToDevice, aux) != hipSuccess)
+                return false;
+        return hipEventRecord(inReady[b], aux) == hipSuccess;
+    };
+    if (!upload(0)) return setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError()));
+    std::vector<char> was;
+    for (int c = 0; c < nchunks; c++) {
+        const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
+        if (c + 1 < nchunks && !upload(c + 1)) return setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError()));
+        if (hipStreamWaitEvent(st, inReady[b], 0) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+        auto& pool = tctx().pool;
+        was.assign(pool.size(), 0);
+        for (size_t i = 0; i < pool.size(); i++) was[i] = pool[i].busy;
+        const int rc = run(din[b], sp, sfb, dout[b], dp, dfb, nf);
+        // scratch the chunk's hook took from the pool is free for the next chunk's: same thread, same stream, stream order
+        for (size_t i = 0; i < tctx().pool.size(); i++) if (tctx().pool[i].busy && (i >= was.size() || !was[i])) tctx().pool[i].busy = false;
+        if (rc != MI355CV_OK) { (void)hipStreamSynchronize(aux); (void)hipStreamSynchronize(st); return rc; }
+        for (int f = 0; f < nf; f++)
+            if (hipMemcpy2DAsync(hb.dst + (size_t)(f0 + f) * hb.dframe, hb.dstep, dout[b] + (size_t)f * dfb, dp, hb.drowBytes, hb.drows, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(hipGetLastError()));
+        if (hipEventRecord(bufFree[b], st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+        g_stagedBytes += (long long)(hb.srowBytes * (size_t)hb.srows + hb.drowBytes * (size_t)hb.drows) * nf;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+    return stg.finish(entry);
+}
+
 } // namespace mi355
 
 // ------------------------------------------------------------------ exported runtime API

@@ -734,38 +734,10 @@ MI355CV_API int mi355cv_gaussianBlurBinomial(const uchar* src_data, size_t src_s
 static int gaussBatchFromHost(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int cn,
                               const uint16_t* k, int ks, int border)
 {
-    if (disabled() || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg;
-    const size_t rowB = (size_t)W * cn, pitch = (rowB + 255) & ~(size_t)255, fbytes = pitch * H;
-    int cf = (int)((size_t)(64u << 20) / fbytes); cf = cf < 1 ? 1 : cf > 16 ? 16 : cf; if (cf > nframes) cf = nframes;
-    uchar* din[2]; uchar* dout[2];
-    for (int b = 0; b < 2; b++) { din[b] = (uchar*)stg.scratch(fbytes * cf); dout[b] = (uchar*)stg.scratch(fbytes * cf); if (!din[b] || !dout[b]) return MI355CV_NOT_IMPLEMENTED; }
-    hipStream_t st = stream(), aux = auxStream();
-    hipEvent_t inReady[2] = {pooledEvent(40), pooledEvent(41)}, bufFree[2] = {pooledEvent(42), pooledEvent(43)};
-    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return MI355CV_NOT_IMPLEMENTED;
-    const int nchunks = (nframes + cf - 1) / cf;
-    auto upload = [&](int c) -> bool {
-        const int b = c & 1, f0 = c * cf, nf = std::min(cf, nframes - f0);
-        if (c >= 2 && hipStreamWaitEvent(aux, bufFree[b], 0) != hipSuccess) return false;          // the buffers' previous chunk has been downloaded
-        for (int f = 0; f < nf; f++)
-            if (hipMemcpy2DAsync(din[b] + (size_t)f * fbytes, pitch, src + (size_t)(f0 + f) * sframe, sstep, rowB, H, hipMemcpyHostToDevice, aux) != hipSuccess) return false;
-        return hipEventRecord(inReady[b], aux) == hipSuccess;
-    };
-    if (!upload(0)) return setError(MI355CV_ERROR_UNKNOWN, "gaussianBlurBinomialBatch: H2D failed: %s", hipGetErrorString(hipGetLastError()));
-    for (int c = 0; c < nchunks; c++) {
-        const int b = c & 1, f0 = c * cf, nf = std::min(cf, nframes - f0);
-        if (c + 1 < nchunks && !upload(c + 1)) return setError(MI355CV_ERROR_UNKNOWN, "gaussianBlurBinomialBatch: H2D failed: %s", hipGetErrorString(hipGetLastError()));
-        if (hipStreamWaitEvent(st, inReady[b], 0) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
-        const int rc = runSmooth("gaussianBlurBinomialBatch", din[b], pitch, nf > 1 ? fbytes : 0, dout[b], pitch, nf > 1 ? fbytes : 0, nf, W, H, cn, 0, 0, 0, 0, k, ks, k, ks, border, true);
-        if (rc != MI355CV_OK) return rc;
-        for (int f = 0; f < nf; f++)
-            if (hipMemcpy2DAsync(dst + (size_t)(f0 + f) * dframe, dstep, dout[b] + (size_t)f * fbytes, pitch, rowB, H, hipMemcpyDeviceToHost, st) != hipSuccess)
-                return setError(MI355CV_ERROR_UNKNOWN, "gaussianBlurBinomialBatch: D2H failed: %s", hipGetErrorString(hipGetLastError()));
-        if (hipEventRecord(bufFree[b], st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
-        noteStagedBytes((long long)(2 * rowB * (size_t)H * nf));
-    }
-    if (hipStreamSynchronize(st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "gaussianBlurBinomialBatch: %s", hipGetErrorString(hipGetLastError()));
-    return stg.finish("gaussianBlurBinomialBatch");
+    const HostBatch hb = {src, sstep, sframe, (size_t)W * cn, H, dst, dstep, dframe, (size_t)W * cn, H, nframes};
+    return runHostBatch("gaussianBlurBinomialBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+        return runSmooth("gaussianBlurBinomialBatch", s, ss, nf > 1 ? sf : 0, d, ds, nf > 1 ? df : 0, nf, W, H, cn, 0, 0, 0, 0, k, ks, k, ks, border, true);
+    });
 }
 
 MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride,
@@ -775,7 +747,7 @@ MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const uchar* src_data, size_t 
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
     const uint16_t* k = binomTaps(ksize);
     if (!k) return MI355CV_NOT_IMPLEMENTED;
-    if (nframes > 1 && width > 0 && height > 0 && cn >= 1 && cn <= 4 && ensureDevice() && ptrKind(src_data) == PTR_HOST && ptrKind(dst_data) == PTR_HOST)
+    if (nframes > 1 && width > 0 && height > 0 && cn >= 1 && cn <= 4 && hostBatchEligible(src_data, dst_data, nframes))
         return gaussBatchFromHost(src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, cn, k, (int)ksize,
                                   border_type & ~MI355CV_BORDER_ISOLATED);
     if (nframes == 1)

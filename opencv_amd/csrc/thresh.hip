@@ -194,6 +194,11 @@ extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t 
                                                   int thresholdType)
 {
     if (nframes < 1 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
+        const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(depth), height, nframes};
+        return runHostBatch("thresholdBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_thresholdBatch(s, ss, sf, d, ds, df, nf, width, height, depth, cn, thresh, maxValue, thresholdType); });
+    }
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "thresholdBatch: device-resident frames only");
     if (nframes == 1 || (src_frame_stride == src_step * (size_t)height && dst_frame_stride == dst_step * (size_t)height && (long long)height * nframes < 0x7fffffffLL))
         return mi355cv_threshold(src_data, src_step, dst_data, dst_step, width, height * nframes, depth, cn, thresh, maxValue, thresholdType);

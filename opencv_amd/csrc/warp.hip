@@ -1408,6 +1408,12 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
 MI355CV_API int mi355cv_resizeBatch(int src_type, const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y, int interpolation)
 {
+    if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
+        const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
+        return runHostBatch("resizeBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_resizeBatch(src_type, s, ss, sf, src_width, src_height, d, ds, df, dst_width, dst_height, nf, inv_scale_x, inv_scale_y, interpolation); });
+    }
     return runResize("resizeBatch", src_type, src_data, src_step, src_frame_stride, src_width, src_height, dst_data, dst_step, dst_frame_stride, dst_width, dst_height,
                      nframes, inv_scale_x, inv_scale_y, interpolation);
 }
@@ -1417,6 +1423,12 @@ MI355CV_API int mi355cv_warpAffineBatch(int src_type, const uchar* src_data, siz
         const double borderValue[4])
 {
     if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
+        const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
+        return runHostBatch("warpAffineBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_warpAffineBatch(src_type, s, ss, sf, src_width, src_height, d, ds, df, dst_width, dst_height, nf, M, interpolation, borderType, borderValue); });
+    }
     return runWarp("warpAffineBatch", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 0, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0, nframes, src_frame_stride, dst_frame_stride);
 }
@@ -1426,6 +1438,12 @@ MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const uchar* src_data
         const double borderValue[4])
 {
     if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
+        const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
+        return runHostBatch("warpPerspectiveBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return mi355cv_warpPerspectiveBatch(src_type, s, ss, sf, src_width, src_height, d, ds, df, dst_width, dst_height, nf, M, interpolation, borderType, borderValue); });
+    }
     return runWarp("warpPerspectiveBatch", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 1, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0, nframes, src_frame_stride, dst_frame_stride);
 }

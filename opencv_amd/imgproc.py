@@ -25,7 +25,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "matchTemplate", "matchTemplateBatch", "integral", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
-           "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
+           "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "pyrDownBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
            "Canny", "equalizeHist", "cvtColorBGR2NV", "THRESH_OTSU", "adaptiveThreshold", "ADAPTIVE_THRESH_MEAN_C", "ADAPTIVE_THRESH_GAUSSIAN_C", "medianBlur", "bilateralFilter", "moments", "erode", "dilate", "MORPH_ERODE", "MORPH_DILATE", "threshold", "THRESH_BINARY", "THRESH_BINARY_INV", "THRESH_TRUNC", "THRESH_TOZERO", "THRESH_TOZERO_INV",
            "filter2D", "filter2DBatch", "cvtColorFilter2DBatch", "sepFilter2D", "Sobel", "Scharr", "boxFilter", "blur",
            "GaussianBlur", "GaussianBlurBatch", "sepSmoothFixedU8", "getGaussianKernelQ8_binomial",
@@ -154,6 +154,7 @@ def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None):
             raise ValueError("each frame must be contiguous")
         out = dst if dst is not None else torch.empty_like(frames, pin_memory=frames.is_pinned())
         k = ksize if isinstance(ksize, int) else ksize[0]
+        bind_stream()                                         # host frames: the library's own streams
         rc = L.mi355cv_gaussianBlurBinomialBatch(_vp(frames.data_ptr()), w * cn, int(frames.stride(0)), _vp(out.data_ptr()), w * cn, int(out.stride(0)), n, w, h, CV_8U, cn, k,
                                                  borderType & ~BORDER_ISOLATED)
         _lib.check(rc, "gaussianBlurBinomialBatch")
@@ -408,7 +409,7 @@ def cvtColorBatch(frames, code, dst=None):
         raise NotImplementedError("cvtColorBatch: only *2GRAY")
     scn, swap = _RGB2GRAY[code]
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
-    out = dst if dst is not None else torch.empty((n, h, w), dtype=frames.dtype, device=frames.device)
+    out = dst if dst is not None else _batch_alloc(frames, (n, h, w), frames.dtype)
     s0, d0 = Img(frames[0]), Img(out[0])
     bind_stream(s0, d0)
     rc = L.mi355cv_cvtBGRtoGrayBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step,
@@ -685,7 +686,7 @@ def filter2DBatch(frames, ddepth, kernel, anchor=(-1, -1), delta=0.0, borderType
     kh, kw = k.shape
     ax = kw // 2 if anchor[0] < 0 else anchor[0]
     ay = kh // 2 if anchor[1] < 0 else anchor[1]
-    out = dst if dst is not None else torch.empty_like(frames)
+    out = dst if dst is not None else _batch_alloc(frames, frames.shape, frames.dtype)
     d0 = Img(out[0])
     bind_stream(s0, d0)
     ctx = ctypes.c_void_p()
@@ -710,7 +711,7 @@ def cvtColorFilter2DBatch(frames, code, kernel, delta=0.0, borderType=BORDER_DEF
         raise ValueError("channel count does not match the conversion code")
     k = _np_kernel(kernel)
     kh, kw = k.shape
-    out = dst if dst is not None else torch.empty((n, h, w), dtype=frames.dtype, device=frames.device)
+    out = dst if dst is not None else _batch_alloc(frames, (n, h, w), frames.dtype)
     s0, d0 = Img(frames[0]), Img(out[0])
     bind_stream(s0, d0)
     ctx = ctypes.c_void_p()
@@ -992,17 +993,25 @@ def warpPolar(src, dsize, center, maxRadius, flags, dst=None):
 
 # ----------------------------------------------------------------------------- frame batches of the single-image hooks
 def _batch_geom(frames):
-    if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dim() not in (3, 4):
-        raise ValueError("batch entries take a CUDA(ROCm) tensor [N,H,W(,C)]")
+    """frames: a tensor [N,H,W(,C)] -- resident in HBM (one launch), or a CPU tensor (ideally page-locked): the library then moves the batch across
+    PCIe in chunks through two sets of device buffers, upload / kernels / download overlapped (rt.h runHostBatch)"""
+    if torch is None or not isinstance(frames, torch.Tensor) or frames.dim() not in (3, 4):
+        raise ValueError("batch entries take a tensor [N,H,W(,C)] (CUDA(ROCm) resident, or a CPU tensor for the pipelined host path)")
     return int(frames.shape[0]), Img(frames[0])
+
+
+def _batch_alloc(frames, shape, dtype):
+    if frames.is_cuda:
+        return torch.empty(shape, dtype=dtype, device=frames.device)
+    return torch.empty(shape, dtype=dtype, pin_memory=frames.is_pinned())
 
 
 def _batch_out(frames, dst, shape, dtype):
     if dst is not None:
-        if tuple(dst.shape) != tuple(shape) or dst.dtype != dtype:
+        if tuple(dst.shape) != tuple(shape) or dst.dtype != dtype or dst.is_cuda != frames.is_cuda:
             raise ValueError("dst geometry mismatch")
         return dst
-    return torch.empty(shape, dtype=dtype, device=frames.device)
+    return _batch_alloc(frames, shape, dtype)
 
 
 def SobelBatch(frames, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, borderType=BORDER_DEFAULT, dst=None):
@@ -1136,6 +1145,21 @@ def pyrDown(src, dstsize=None, borderType=BORDER_DEFAULT, dst=None, margins=None
     return out
 
 
+def pyrDownBatch(frames, borderType=BORDER_DEFAULT, dst=None):
+    """cv::pyrDown over [N,H,W(,C)] frames -> [N,(H+1)/2,(W+1)/2(,C)], one launch (host-resident batches: the pipelined path)"""
+    if (borderType & ~BORDER_ISOLATED) == BORDER_CONSTANT:
+        raise ValueError("pyrDown: BORDER_CONSTANT is not allowed")
+    n, s0 = _batch_geom(frames)
+    shape = (n, (s0.h + 1) // 2, (s0.w + 1) // 2) + tuple(frames.shape[3:])
+    out = _batch_out(frames, dst, shape, frames.dtype)
+    d0 = Img(out[0])
+    bind_stream(s0, d0)
+    rc = L.mi355cv_pyrdownBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, s0.w, s0.h, _vp(d0.ptr), d0.step, int(out.stride(0)) * d0.esz, d0.w, d0.h, n,
+                                s0.depth, s0.cn, borderType & ~BORDER_ISOLATED)
+    _lib.check(rc, "pyrdownBatch")
+    return out
+
+
 def buildPyramid(src, maxlevel, borderType=BORDER_DEFAULT):
     """cv::buildPyramid (pyramids.cpp:1616-1643): [src, level1, ..., level maxlevel]; one C-ABI call for all levels."""
     if (borderType & ~BORDER_ISOLATED) == BORDER_CONSTANT:
@@ -1203,7 +1227,7 @@ def cornerMinEigenVal(src, blockSize, ksize=3, borderType=BORDER_DEFAULT, dst=No
 def cornerHarrisBatch(frames, blockSize, ksize, k, borderType=BORDER_DEFAULT, dst=None):
     """[N,H,W] device frames (uint8 or float32) -> [N,H,W] float32 responses, one launch."""
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
-    out = dst if dst is not None else torch.empty((n, h, w), dtype=torch.float32, device=frames.device)
+    out = dst if dst is not None else _batch_alloc(frames, (n, h, w), torch.float32)
     s0, d0 = Img(frames[0]), Img(out[0])
     bind_stream(s0, d0)
     rc = L.mi355cv_cornerHarrisBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, _vp(d0.ptr), d0.step, int(out.stride(0)) * 4, n, w, h,

@@ -103,3 +103,45 @@ def test_gaussian_batch_from_host_memory_is_pipelined(cv):
         got = cv.GaussianBlurBatch(host, 5)
         assert got.device.type == "cpu" and torch.equal(got, want), (n, h, w, cn, pinned)
         assert cv._lib.lib.mi355cv_stagedBytes() - staged0 == 2 * host.numel()          # every byte crossed PCIe once each way
+
+
+def test_every_batch_entry_takes_host_resident_frames(cv):
+    """every single-output batch entry accepts a batch that lives in host memory (page-locked or pageable) and runs it through
+    the two-buffer pipeline (rt.h runHostBatch).  The result equals the device-resident call frame for frame; every byte crosses PCIe once each
+    way; chunk counts of one, two and several (the chunk is <= 16 frames / 64 MB)."""
+    g = torch.Generator(); g.manual_seed(11)
+    M = cv.getRotationMatrix2D((200.0, 150.0), 9.0, 0.9)
+    P = np.array([[1.05, 0.04, -6.0], [0.03, 0.95, 5.0], [1e-4, -1e-4, 1.0]])
+    k3 = [0.25, 0.5, 0.25]
+    sharpen = np.array([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], np.float32)
+    ops = {
+        "sobel":   (1, lambda f: cv.SobelBatch(f, cv.CV_16S, 1, 0, 3)),
+        "box":     (3, lambda f: cv.boxFilterBatch(f, -1, (5, 5))),
+        "sep":     (1, lambda f: cv.sepFilter2DBatch(f, cv.CV_32F, k3, k3, delta=0.5)),
+        "thresh":  (3, lambda f: cv.thresholdBatch(f, 100, 255, 0)),
+        "resize":  (3, lambda f: cv.resizeBatch(f, (333, 200), interpolation=1)),
+        "affine":  (1, lambda f: cv.warpAffineBatch(f, M, (400, 300), 1, 0, 7.0)),
+        "persp":   (3, lambda f: cv.warpPerspectiveBatch(f, P, (384, 216), 1 | cv.WARP_INVERSE_MAP, 1)),
+        "gray":    (3, lambda f: cv.cvtColorBatch(f, cv.COLOR_BGR2GRAY)),
+        "filter":  (1, lambda f: cv.filter2DBatch(f, -1, sharpen)),
+        "fused":   (3, lambda f: cv.cvtColorFilter2DBatch(f, cv.COLOR_BGR2GRAY, sharpen)),
+        "pyrdown": (1, lambda f: cv.pyrDownBatch(f)),
+        "harris":  (1, lambda f: cv.cornerHarrisBatch(f, 2, 3, 0.04)),
+    }
+    for name, (cn, op) in ops.items():
+        for (n, h, w, pinned) in [(37, 300, 400, True), (3, 300, 400, False), (1, 300, 400, True)]:
+            shape = (n, h, w) + ((cn,) if cn > 1 else ())
+            host = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+            if pinned:
+                host = host.pin_memory()
+            want = op(host.cuda()).cpu()
+            staged0 = cv._lib.lib.mi355cv_stagedBytes()
+            got = op(host)
+            assert got.device.type == "cpu" and got.dtype == want.dtype and got.shape == want.shape, name
+            assert torch.equal(got, want), (name, n, pinned)
+            assert cv._lib.lib.mi355cv_stagedBytes() - staged0 == host.numel() + got.numel() * got.element_size(), name
+    # a large chunk count with big frames: 1080p, 40 frames -> several chunks in flight behind one another
+    host = torch.randint(0, 256, (40, 1080, 1920), dtype=torch.uint8, generator=g).pin_memory()
+    assert torch.equal(cv.SobelBatch(host, cv.CV_16S, 0, 1, 3), cv.SobelBatch(host.cuda(), cv.CV_16S, 0, 1, 3).cpu())
+    with pytest.raises((NotImplementedError, ValueError)):          # one end in HBM, the other on the host: not a batch the pipeline takes
+        cv.thresholdBatch(host[:2], 100, 255, 0, dst=torch.empty((2, 1080, 1920), dtype=torch.uint8, device="cuda"))
