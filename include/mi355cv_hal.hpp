@@ -116,6 +116,10 @@
 #define cv_hal_cvtBGRtoXYZ mi355cv_cvtBGRtoXYZ   // :564
 #undef  cv_hal_cvtXYZtoBGR
 #define cv_hal_cvtXYZtoBGR mi355cv_cvtXYZtoBGR   // :579
+#undef  cv_hal_cvtBGRtoLab
+#define cv_hal_cvtBGRtoLab mi355cv_cvtBGRtoLab   // :535
+#undef  cv_hal_cvtLabtoBGR
+#define cv_hal_cvtLabtoBGR mi355cv_cvtLabtoBGR   // :550
 #undef  cv_hal_cvtBGRtoBGR5x5
 #define cv_hal_cvtBGRtoBGR5x5 mi355cv_cvtBGRtoBGR5x5   // :411
 #undef  cv_hal_cvtBGR5x5toBGR

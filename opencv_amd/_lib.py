@@ -94,6 +94,9 @@ def _load():
         "mi355cv_cvtHSVtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool]),
         "mi355cv_cvtBGRtoXYZ": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtXYZtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
+        "mi355cv_cvtBGRtoLab": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool]),
+        "mi355cv_cvtLabtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool]),
+        "mi355cv_labTable": (c_int, [c_int, ctypes.c_void_p]),
         "mi355cv_cvtBGRtoBGR5x5": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtBGR5x5toBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_bool, c_int]),
         "mi355cv_cvtBGR5x5toGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),

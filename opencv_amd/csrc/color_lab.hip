@@ -1,0 +1,329 @@
+// color_lab.hip -- SURVEY.md §8 f1: CIE L*a*b* <-> BGR / RGB for CV_8U images behind cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR
+// (hal_replacement.hpp:535-565; callers hal::cvtBGRtoLab color_lab.cpp:4230, hal::cvtLabtoBGR :4327).  The reference's 8-bit paths are pure integer
+// arithmetic over small tables -- RGB2Lab_b (color_lab.cpp:1573) and Lab2RGBinteger (:2399, taken by Lab2RGB_b since enableBitExactness) -- so the
+// results here are bit-identical by construction once the tables are:
+//   gamma      256 x u16   sRGBGammaTab_b  = round(2040 * gamma(i / 255))                 createLabTabs :1258-1264
+//   cbrt      3072 x u16   LabCbrtTab_b    = round(2^15 * f(i / 2040)), f = Lab's cube-root / linear ramp   :1273-1279
+//   yf         256 x u32   LabToYF_b       = (y, ify) of every 8-bit L                    :1281-1306
+//   invGamma  4096 x u16   sRGBInvGammaTab_b = round(255 * gamma^-1(i / 4096))            :1265-1271
+// built once on the host (the reference's softfloat arithmetic restated with IEEE float / double operations, its Turkowski cube root
+// (softfloat.cpp:3897) restated as written) and kept in HBM per device; a workgroup copies what its kernel needs into LDS (6.5 KB forward, 9 KB
+// inverse) and converts 32 rows x 256 pixels, a lane owning 4 consecutive pixels of a row (dword traffic, pix4.h).  The a/b -> X/Z table of the
+// reference (initLUTforABXZ :1086, 147 KB) is two integer formulas, evaluated instead of looked up.
+// HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.  CV_32F images and L*u*v* are declined (the reference's own path then runs).
+#include "rt.h"
+#include "pix4.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+using namespace mi355;
+
+namespace {
+
+enum { LAB_SHIFT = 12, GAMMA_SHIFT = 3, LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT, N_CBRT = 256 * 3 / 2 * (1 << GAMMA_SHIFT), INV_GAMMA_SHIFT = 12,
+       N_INVG = 1 << INV_GAMMA_SHIFT, LBASE = 1 << 14 };
+
+struct LabTabs {
+    uint16_t gamma[256];
+    uint16_t cbrt[N_CBRT];
+    uint32_t yf[256];                  // y | ify << 16
+    uint16_t invGamma[N_INVG];
+};
+
+// softfloat.cpp:3897 f32_cbrt: |x| = fr * 8^k with 0.125 <= fr < 1, fr -> P(fr) / Q(fr) (quartic rational, double), the top 23 fraction bits kept
+float cubeRootTurkowski(float x)
+{
+    uint32_t v; std::memcpy(&v, &x, 4);
+    if (!(v & 0x7fffffffu)) return 0.f;
+    int ex = (int)((v >> 23) & 255) - 127, shx = ex % 3;
+    if (shx >= 0) shx -= 3;
+    ex = (ex - shx) / 3 - 1;
+    uint64_t b = ((uint64_t)(shx + 1023) << 52) | ((uint64_t)(v & 0x7fffffu) << 29);
+    double fr; std::memcpy(&fr, &b, 8);
+    const double p = (((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr + 119.1654824285581628956914143) * fr
+                      + 13.43250139086239872172837314) * fr + 0.1636161226585754240958355063;
+    const double q = (((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr + 168.5254414101568283957668343) * fr
+                      + 33.9905941350215598754191872) * fr + 1.0;
+    fr = p / q;
+    std::memcpy(&b, &fr, 8);
+    const uint32_t o = (v & 0x80000000u) | ((uint32_t)(ex + 127) << 23) | (uint32_t)((b & 0xfffffffffffffull) >> 29);
+    float y; std::memcpy(&y, &o, 4);
+    return y;
+}
+
+// color_lab.cpp:1011-1040: the sRGB transfer function and its inverse in double on a float argument, rounded to float
+float gammaFwd(float x)
+{
+    const double xd = x, xshift = 11.0 / 200.0;
+    return (float)(xd <= 809.0 / 20000.0 ? xd / (323.0 / 25.0) : std::pow((xd + xshift) / (1.0 + xshift), 12.0 / 5.0));
+}
+float gammaInv(float x)
+{
+    const double xd = x, xshift = 11.0 / 200.0;
+    return (float)(xd <= 7827.0 / 2500000.0 ? xd * (323.0 / 25.0) : std::pow(xd, 1.0 / (12.0 / 5.0)) * (1.0 + xshift) - xshift);
+}
+
+LabTabs g_host;
+std::once_flag g_hostOnce;
+
+void buildHost()
+{
+    LabTabs& t = g_host;
+    const float f255 = 255.f, intScale = (float)(255 * (1 << GAMMA_SHIFT));
+    for (int i = 0; i < 256; i++) t.gamma[i] = (uint16_t)lrintf(intScale * gammaFwd((float)i / f255));
+    const float invScale = 1.f / (float)N_INVG;
+    for (int i = 0; i < N_INVG; i++) t.invGamma[i] = (uint16_t)lrintf(f255 * gammaInv(invScale * (float)i));
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
+    const float cbScale = 1.f / (f255 * (float)(1 << GAMMA_SHIFT)), lshift2 = (float)(1 << LAB_SHIFT2);
+    for (int i = 0; i < N_CBRT; i++) {
+        const float x = cbScale * (float)i;
+        t.cbrt[i] = (uint16_t)lrintf(lshift2 * (x < lthresh ? fmaf(x, lscale, lbias) : cubeRootTurkowski(x)));
+    }
+    for (int i = 0; i < 256; i++) {
+        int y, ify;
+        if (i <= 20) {                                                                      // the linear part of L -> Y
+            y = (int)lrintf((float)(i * LBASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            const float s = 16.f / 116.f + (float)(i * 5) / (float)(3 * 17 * 29);
+            ify = (int)lrintf((float)LBASE * s);
+        } else {
+            const float a = (float)(i * 100 * LBASE) / (float)(255 * 116), b = (float)(16 * LBASE) / 116.f, fy = a + b;
+            ify = (int)lrintf(fy);
+            const float f2 = fy * fy, f3 = f2 * fy;
+            y = (int)lrintf(f3 / (float)(LBASE * LBASE));
+        }
+        t.yf[i] = (uint32_t)y | ((uint32_t)ify << 16);
+    }
+}
+
+enum { LAB_MAX_DEV = 64 };
+LabTabs* g_dev[LAB_MAX_DEV];
+std::mutex g_devMu;
+
+const LabTabs* deviceTabs()
+{
+    std::call_once(g_hostOnce, buildHost);
+    const int dev = activeDevice();
+    if (dev < 0 || dev >= LAB_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_devMu);
+    if (!g_dev[dev]) {
+        LabTabs* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(LabTabs)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemcpy(d, &g_host, sizeof(LabTabs), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        g_dev[dev] = d;
+    }
+    return g_dev[dev];
+}
+
+// the D65 white point and the sRGB primaries as the reference holds them (color_lab.cpp:103-128, :941: these decimals ARE its raw doubles)
+const double kD65[3] = {0.950456, 1.0, 1.088754};
+const double kRgb2Xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+const double kXyz2Rgb[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+
+struct Coef9 { int c[9]; };
+
+constexpr int ROWS_PER_BLOCK = 32;
+
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ int sat8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+// ---- forward: 4 pixels per lane, ROWS_PER_BLOCK rows per workgroup, tables in LDS
+template <int SCN, bool SRGB>
+__global__ __launch_bounds__(256) void k_bgr2lab_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int aligned,
+                                                     const LabTabs* __restrict__ tabs, Coef9 k)
+{
+    __shared__ uint16_t cb[N_CBRT];
+    __shared__ uint16_t gm[256];
+    for (int i = threadIdx.x; i < N_CBRT / 2; i += 256) ((unsigned*)cb)[i] = ((const unsigned*)tabs->cbrt)[i];
+    if (SRGB && threadIdx.x < 128) ((unsigned*)gm)[threadIdx.x] = ((const unsigned*)tabs->gamma)[threadIdx.x];
+    __syncthreads();
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (x4 >= W) return;
+    const int n = min(4, W - x4);
+    const bool fast = n == 4 && aligned;
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
+    const int yEnd = min(H, (int)(blockIdx.y + 1) * ROWS_PER_BLOCK);
+    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 4) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x4 * SCN;
+        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * 3;
+        pix4::Px<SCN> in; pix4::Px<3> out;
+        out.clear();
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < SCN; i++) in.w[i] = ((const unsigned*)s)[i];
+        } else {
+            in.clear();
+#pragma unroll
+            for (int i = 0; i < 4 * SCN; i++) if (i < n * SCN) in.put(i, s[i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            int R = in.get(p * SCN), G = in.get(p * SCN + 1), B = in.get(p * SCN + 2);               // channel order is folded into the coefficients
+            if (SRGB) { R = gm[R]; G = gm[G]; B = gm[B]; }
+            else { R <<= GAMMA_SHIFT; G <<= GAMMA_SHIFT; B <<= GAMMA_SHIFT; }
+            // every factor fits 24 bits (R, G, B <= 2040, coefficients < 2^13, table values < 2^16): v_mad_u32_u24 / v_mad_i32_i24, not the quarter-rate
+            // 32-bit multiply -- the products and sums are the reference's ints
+            const int fX = cb[descale(__mul24(R, k.c[0]) + __mul24(G, k.c[1]) + __mul24(B, k.c[2]), LAB_SHIFT)];
+            const int fY = cb[descale(__mul24(R, k.c[3]) + __mul24(G, k.c[4]) + __mul24(B, k.c[5]), LAB_SHIFT)];
+            const int fZ = cb[descale(__mul24(R, k.c[6]) + __mul24(G, k.c[7]) + __mul24(B, k.c[8]), LAB_SHIFT)];
+            out.put(p * 3, sat8(descale(__mul24(Lscale, fY) + Lshift, LAB_SHIFT2)));
+            out.put(p * 3 + 1, sat8(descale(__mul24(500, fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)));
+            out.put(p * 3 + 2, sat8(descale(__mul24(200, fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)));
+        }
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) ((unsigned*)d)[i] = out.w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; i++) if (i < n * 3) d[i] = (uchar)out.get(i);
+        }
+    }
+}
+
+// initLUTforABXZ (color_lab.cpp:1086-1110) as arithmetic: the linear ramp below 6/29 (C division truncates toward zero, i may be negative), the cube above
+__device__ __forceinline__ int abToXZ(int i)
+{
+    if (i <= 3390) return __mul24(i, 108) / 841 - LBASE * 16 / 116 * 108 / 841;
+    return __mul24(__mul24(i, i) >> 14, i) >> 14;                     // |i| < 2^15, i^2 >> 14 < 2^16
+}
+
+// ---- inverse
+template <int DCN, bool SRGB>
+__global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int aligned,
+                                                     const LabTabs* __restrict__ tabs, Coef9 k)
+{
+    __shared__ uint32_t yf[256];
+    __shared__ uint16_t ig[SRGB ? N_INVG : 2];
+    yf[threadIdx.x] = tabs->yf[threadIdx.x];
+    if (SRGB) for (int i = threadIdx.x; i < N_INVG / 2; i += 256) ((unsigned*)ig)[i] = ((const unsigned*)tabs->invGamma)[i];
+    __syncthreads();
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (x4 >= W) return;
+    const int n = min(4, W - x4);
+    const bool fast = n == 4 && aligned;
+    constexpr int shift = LAB_SHIFT + (14 - INV_GAMMA_SHIFT);
+    const int yEnd = min(H, (int)(blockIdx.y + 1) * ROWS_PER_BLOCK);
+    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 4) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x4 * 3;
+        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * DCN;
+        pix4::Px<3> in; pix4::Px<DCN> out;
+        out.clear();
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) in.w[i] = ((const unsigned*)s)[i];
+        } else {
+            in.clear();
+#pragma unroll
+            for (int i = 0; i < 12; i++) if (i < n * 3) in.put(i, s[i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int LL = in.get(p * 3), aa = in.get(p * 3 + 1), bb = in.get(p * 3 + 2);
+            const unsigned t = yf[LL];
+            const int yv = (int)(t & 0xffffu), ify = (int)(t >> 16);
+            const int adiv = ((__mul24(5 * aa, 53687) + (1 << 7)) >> 13) - 128 * LBASE / 500;
+            const int bdiv = ((__mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * LBASE / 200 + 1;
+            const int xv = abToXZ(ify + adiv), zv = abToXZ(ify - bdiv);
+            // |coefficient| < 2^15, -1335 <= x, z <= 88231, y <= 2^14: 24-bit factors, products below 2^31 (the reference's ints)
+            int ro = descale(__mul24(k.c[0], xv) + __mul24(k.c[1], yv) + __mul24(k.c[2], zv), shift);
+            int go = descale(__mul24(k.c[3], xv) + __mul24(k.c[4], yv) + __mul24(k.c[5], zv), shift);
+            int bo = descale(__mul24(k.c[6], xv) + __mul24(k.c[7], yv) + __mul24(k.c[8], zv), shift);
+            ro = max(0, min(N_INVG - 1, ro)); go = max(0, min(N_INVG - 1, go)); bo = max(0, min(N_INVG - 1, bo));
+            if (SRGB) { ro = ig[ro]; go = ig[go]; bo = ig[bo]; }
+            else { ro = ((ro << 8) - ro) >> INV_GAMMA_SHIFT; go = ((go << 8) - go) >> INV_GAMMA_SHIFT; bo = ((bo << 8) - bo) >> INV_GAMMA_SHIFT; }
+            out.put(p * DCN, sat8(bo)); out.put(p * DCN + 1, sat8(go)); out.put(p * DCN + 2, sat8(ro));
+            if (DCN == 4) out.put(p * 4 + 3, 255);
+        }
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < DCN; i++) ((unsigned*)d)[i] = out.w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * DCN; i++) if (i < n * DCN) d[i] = (uchar)out.get(i);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// replaces hal_ni_cvtBGRtoLab (hal_replacement.hpp:535-548): CV_8U, L*a*b*, sRGB or linear RGB; everything else is declined
+MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int scn, bool swapBlue, bool isLab, bool srgb)
+{
+    if (disabled() || depth != MI355CV_8U || !isLab || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const LabTabs* tabs = deviceTabs();
+    if (!tabs) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    // RGB2Lab_b's constructor (color_lab.cpp:1590-1606): rows of sRGB -> XYZ divided by the white point, 2^12 fixed point, the channel order folded in
+    Coef9 k; const int blueIdx = swapBlue ? 2 : 0;
+    for (int i = 0; i < 3; i++) {
+        const double ls = (double)(1 << LAB_SHIFT);
+        k.c[i * 3 + (blueIdx ^ 2)] = (int)lrint(ls * kRgb2Xyz[i * 3] / kD65[i]);
+        k.c[i * 3 + 1]             = (int)lrint(ls * kRgb2Xyz[i * 3 + 1] / kD65[i]);
+        k.c[i * 3 + blueIdx]       = (int)lrint(ls * kRgb2Xyz[i * 3 + 2] / kD65[i]);
+    }
+    const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+    const dim3 grid(divUp(divUp(width, 4), 64), divUp(height, ROWS_PER_BLOCK));
+    hipStream_t st = stream();
+#define LAUNCH(SCN_, SRGB_) hipLaunchKernelGGL((k_bgr2lab_u8<SCN_, SRGB_>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, al, tabs, k)
+    if (scn == 3) { if (srgb) LAUNCH(3, true); else LAUNCH(3, false); }
+    else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+    noteKernel("k_bgr2lab_u8<%d,%s> grid=%ux%u x256", scn, srgb ? "srgb" : "linear", grid.x, grid.y);
+    return stg.finish("cvtBGRtoLab");
+}
+
+// replaces hal_ni_cvtLabtoBGR (hal_replacement.hpp:550-565)
+MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
+                                    int depth, int dcn, bool swapBlue, bool isLab, bool srgb)
+{
+    if (disabled() || depth != MI355CV_8U || !isLab || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    const LabTabs* tabs = deviceTabs();
+    if (!tabs) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
+    Stager stg; size_t dss, dds;
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
+    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    // Lab2RGBinteger's constructor (color_lab.cpp:2415-2437): columns of XYZ -> sRGB times the white point; stored B, G, R, so the first row is blue's
+    Coef9 k; const int blueIdx = swapBlue ? 2 : 0;
+    for (int i = 0; i < 3; i++) {
+        const double ls = (double)(1 << LAB_SHIFT);
+        k.c[i + blueIdx * 3]       = (int)lrint(ls * kXyz2Rgb[i] * kD65[i]);
+        k.c[i + 3]                 = (int)lrint(ls * kXyz2Rgb[i + 3] * kD65[i]);
+        k.c[i + (blueIdx ^ 2) * 3] = (int)lrint(ls * kXyz2Rgb[i + 6] * kD65[i]);
+    }
+    const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+    const dim3 grid(divUp(divUp(width, 4), 64), divUp(height, ROWS_PER_BLOCK));
+    hipStream_t st = stream();
+#define LAUNCH(DCN_, SRGB_) hipLaunchKernelGGL((k_lab2bgr_u8<DCN_, SRGB_>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, al, tabs, k)
+    if (dcn == 3) { if (srgb) LAUNCH(3, true); else LAUNCH(3, false); }
+    else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+    noteKernel("k_lab2bgr_u8<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
+    return stg.finish("cvtLabtoBGR");
+}
+
+// diagnostics (tests): the host tables behind the two hooks.  which = 0 gamma (256 x u16), 1 cbrt (3072 x u16), 2 invGamma (4096 x u16),
+// 3 yf (256 x u32: y | ify << 16).  Returns the entry count; needs no GPU.
+MI355CV_API int mi355cv_labTable(int which, void* out)
+{
+    std::call_once(g_hostOnce, buildHost);
+    switch (which) {
+    case 0: std::memcpy(out, g_host.gamma, sizeof g_host.gamma); return 256;
+    case 1: std::memcpy(out, g_host.cbrt, sizeof g_host.cbrt); return N_CBRT;
+    case 2: std::memcpy(out, g_host.invGamma, sizeof g_host.invGamma); return N_INVG;
+    case 3: std::memcpy(out, g_host.yf, sizeof g_host.yf); return 256;
+    }
+    return -1;
+}
+
+} // extern "C"

@@ -1,0 +1,191 @@
+/* oracle/color_lab.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * Restates the CV_8U CIE L*a*b* conversions behind cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR (hal_replacement.hpp:535-565), the bit-exact
+ * integer paths the reference takes for 8-bit images:
+ *   - forward   RGB2Lab_b      color_lab.cpp:1573-1892 (scalar tail :1840-1853; the vector body computes the same integers)
+ *   - inverse   Lab2RGBinteger color_lab.cpp:2399-2691 (process() :2441-2493), which Lab2RGB_b :2713-2730 calls since enableBitExactness
+ *   - tables    createLabTabs  color_lab.cpp:1234-1342 (gamma :1023-1040, initLUTforABXZ :1086-1110), constants :941-1020
+ * The tables come from softfloat arithmetic in the reference.  softfloat's +, -, *, /, mulAdd and its conversions are IEEE-754 operations, so plain
+ * C float / double arithmetic (compiled with -ffp-contract=off) gives the same bits.  Two functions are approximations and are restated as such:
+ *   - cbrt(softfloat)      softfloat.cpp:3897-3931: Turkowski's quartic rational on the mantissa, evaluated in double, TRUNCATED to 23 bits;
+ *   - pow(softdouble, ..)  softfloat.cpp:3961-3987 = exp(y log x) with table + polynomial, accurate to a few ulp of double.  Its result is rounded to
+ *                          float and then to an integer table entry, so the C library's pow (also within an ulp) yields the same entries; the pin is
+ *                          the exhaustive comparison of all 2^24 inputs against the reference in tests/test_oracle_lab.py. */
+#include "oracle.h"
+#include <math.h>
+#include <string.h>
+
+enum { LAB_SHIFT = 12, GAMMA_SHIFT = 3, LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT, CBRT_TAB_B = 256 * 3 / 2 * (1 << GAMMA_SHIFT),
+       INV_GAMMA_SHIFT = 12, INV_GAMMA_TAB = 1 << INV_GAMMA_SHIFT, LUT_BASE = 1 << 14, LAB_BASE = 1 << 14, MIN_AB = -8145, ABXZ_N = LAB_BASE * 9 / 4 };
+
+static uint16_t sRGBGammaTab_b[256], linearGammaTab_b[256], LabCbrtTab_b[CBRT_TAB_B];
+static uint16_t sRGBInvGammaTab_b[INV_GAMMA_TAB], linearInvGammaTab_b[INV_GAMMA_TAB], LabToYF_b[512];
+static int abToXZ_b[ABXZ_N];
+static int tablesReady;
+
+static const double D65[3] = {0.950456, 1.0, 1.088754};
+static const double sRGB2XYZ_D65[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+static const double XYZ2sRGB_D65[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+
+/* f32_cbrt (softfloat.cpp:3897): x = fr * 2^(3 e'), 0.125 <= fr < 1; fr -> P(fr) / Q(fr) in double; the quotient's top 23 fraction bits are kept */
+static float cbrtTurkowski(float x)
+{
+    uint32_t v; memcpy(&v, &x, 4);
+    if ((v & 0x7fffffffu) == 0) return 0.f;
+    const int s = (int)(v >> 31);
+    int ex = (int)((v >> 23) & 255) - 127;
+    int shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3 - 1;
+    uint64_t fb = ((uint64_t)(shx + 1023) << 52) | ((uint64_t)(v & 0x7fffffu) << 29);
+    double fr; memcpy(&fr, &fb, 8);
+    const double num = (((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr + 119.1654824285581628956914143) * fr
+                        + 13.43250139086239872172837314) * fr + 0.1636161226585754240958355063;
+    const double den = (((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr + 168.5254414101568283957668343) * fr
+                        + 33.9905941350215598754191872) * fr + 1.0;
+    fr = num / den;
+    memcpy(&fb, &fr, 8);
+    const uint32_t out = ((uint32_t)s << 31) | ((uint32_t)(ex + 127) << 23) | (uint32_t)((fb & 0xfffffffffffffull) >> 29);
+    float y; memcpy(&y, &out, 4);
+    return y;
+}
+
+/* applyGamma / applyInvGamma (color_lab.cpp:1023-1040): double arithmetic on a float argument, the result rounded to float */
+static float applyGamma(float x)
+{
+    const double xd = x, thr = 809.0 / 20000.0, lowScale = 323.0 / 25.0, power = 12.0 / 5.0, xshift = 11.0 / 200.0;
+    return (float)(xd <= thr ? xd / lowScale : pow((xd + xshift) / (1.0 + xshift), power));
+}
+static float applyInvGamma(float x)
+{
+    const double xd = x, thr = 7827.0 / 2500000.0, lowScale = 323.0 / 25.0, power = 12.0 / 5.0, xshift = 11.0 / 200.0;
+    return (float)(xd <= thr ? xd * lowScale : pow(xd, 1.0 / power) * (1.0 + xshift) - xshift);
+}
+
+static void buildTables(void)
+{
+    if (tablesReady) return;
+    const float f255 = 255.f;
+    const float intScale = (float)(255 * (1 << GAMMA_SHIFT));
+    for (int i = 0; i < 256; i++) {
+        const float x = (float)i / f255;
+        sRGBGammaTab_b[i] = (uint16_t)lrintf(intScale * applyGamma(x));
+        linearGammaTab_b[i] = (uint16_t)(i * (1 << GAMMA_SHIFT));
+    }
+    const float invScale = 1.f / (float)INV_GAMMA_TAB;
+    for (int i = 0; i < INV_GAMMA_TAB; i++) {
+        const float x = invScale * (float)i;
+        sRGBInvGammaTab_b[i] = (uint16_t)lrintf(f255 * applyInvGamma(x));
+        linearInvGammaTab_b[i] = (uint16_t)(int)(f255 * x);
+    }
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
+    const float cbTabScale = 1.f / (f255 * (float)(1 << GAMMA_SHIFT)), lshift2 = (float)(1 << LAB_SHIFT2);
+    for (int i = 0; i < CBRT_TAB_B; i++) {
+        const float x = cbTabScale * (float)i;
+        LabCbrtTab_b[i] = (uint16_t)lrintf(lshift2 * (x < lthresh ? fmaf(x, lscale, lbias) : cbrtTurkowski(x)));
+    }
+    for (int i = 0; i < 256; i++) {
+        int y, ify;
+        if (i <= 20) {
+            y = (int)lrintf((float)(i * LUT_BASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            const float t = 16.f / 116.f + (float)(i * 5) / (float)(3 * 17 * 29);
+            ify = (int)lrintf((float)LUT_BASE * t);
+        } else {
+            const float a = (float)(i * 100 * LUT_BASE) / (float)(255 * 116), b = (float)(16 * LUT_BASE) / 116.f;
+            const float fy = a + b;
+            ify = (int)lrintf(fy);
+            const float f2 = fy * fy, f3 = f2 * fy;
+            y = (int)lrintf(f3 / (float)(LUT_BASE * LUT_BASE));
+        }
+        LabToYF_b[i * 2] = (uint16_t)y;
+        LabToYF_b[i * 2 + 1] = (uint16_t)ify;
+    }
+    for (int i = MIN_AB; i < ABXZ_N + MIN_AB; i++) {
+        int v;
+        if (i <= 3390) v = i * 108 / 841 - LUT_BASE * 16 / 116 * 108 / 841;
+        else v = i * i / LUT_BASE * i / LUT_BASE;
+        abToXZ_b[i - MIN_AB] = v;
+    }
+    tablesReady = 1;
+}
+
+static int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+static uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+/* RGB2Lab_b: coefficients :1590-1606 (rows divided by the white point, scaled by 2^12, rounded half to even), per pixel :1840-1853 */
+void orc_cvtBGRtoLab8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int srgb)
+{
+    buildTables();
+    const int blueIdx = swapBlue ? 2 : 0;
+    int C[9];
+    for (int i = 0; i < 3; i++) {
+        const double c0 = sRGB2XYZ_D65[i * 3], c1 = sRGB2XYZ_D65[i * 3 + 1], c2 = sRGB2XYZ_D65[i * 3 + 2], ls = (double)(1 << LAB_SHIFT);
+        C[i * 3 + (blueIdx ^ 2)] = (int)lrint(ls * c0 / D65[i]);
+        C[i * 3 + 1] = (int)lrint(ls * c1 / D65[i]);
+        C[i * 3 + blueIdx] = (int)lrint(ls * c2 / D65[i]);
+    }
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
+    const uint16_t* tab = srgb ? sRGBGammaTab_b : linearGammaTab_b;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstep;
+        uint8_t* d = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++, s += scn, d += 3) {
+            const int R = tab[s[0]], G = tab[s[1]], B = tab[s[2]];
+            const int fX = LabCbrtTab_b[descale(R * C[0] + G * C[1] + B * C[2], LAB_SHIFT)];
+            const int fY = LabCbrtTab_b[descale(R * C[3] + G * C[4] + B * C[5], LAB_SHIFT)];
+            const int fZ = LabCbrtTab_b[descale(R * C[6] + G * C[7] + B * C[8], LAB_SHIFT)];
+            d[0] = sat8(descale(Lscale * fY + Lshift, LAB_SHIFT2));
+            d[1] = sat8(descale(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+            d[2] = sat8(descale(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+        }
+    }
+}
+
+/* Lab2RGBinteger: coefficients :2415-2437, per pixel process() :2441-2493 and the store order of operator() :2675-2686 */
+void orc_cvtLabtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int srgb)
+{
+    buildTables();
+    const int blueIdx = swapBlue ? 2 : 0, BASE = 1 << 14, shift = LAB_SHIFT + (14 - INV_GAMMA_SHIFT);
+    int C[9];
+    for (int i = 0; i < 3; i++) {
+        const double c0 = XYZ2sRGB_D65[i], c1 = XYZ2sRGB_D65[i + 3], c2 = XYZ2sRGB_D65[i + 6], ls = (double)(1 << LAB_SHIFT);
+        C[i + blueIdx * 3] = (int)lrint(ls * c0 * D65[i]);
+        C[i + 3] = (int)lrint(ls * c1 * D65[i]);
+        C[i + (blueIdx ^ 2) * 3] = (int)lrint(ls * c2 * D65[i]);
+    }
+    for (int yy = 0; yy < h; yy++) {
+        const uint8_t* s = src + (size_t)yy * sstep;
+        uint8_t* d = dst + (size_t)yy * dstep;
+        for (int xx = 0; xx < w; xx++, s += 3, d += dcn) {
+            const int LL = s[0], aa = s[1], bb = s[2];
+            const int y = LabToYF_b[LL * 2], ify = LabToYF_b[LL * 2 + 1];
+            const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+            const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+            const int x = abToXZ_b[ify + adiv - MIN_AB], z = abToXZ_b[ify - bdiv - MIN_AB];
+            int ro = descale(C[0] * x + C[1] * y + C[2] * z, shift);
+            int go = descale(C[3] * x + C[4] * y + C[5] * z, shift);
+            int bo = descale(C[6] * x + C[7] * y + C[8] * z, shift);
+            ro = ro < 0 ? 0 : ro > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : ro;
+            go = go < 0 ? 0 : go > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : go;
+            bo = bo < 0 ? 0 : bo > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : bo;
+            if (srgb) { ro = sRGBInvGammaTab_b[ro]; go = sRGBInvGammaTab_b[go]; bo = sRGBInvGammaTab_b[bo]; }
+            else { ro = ((ro << 8) - ro) >> INV_GAMMA_SHIFT; go = ((go << 8) - go) >> INV_GAMMA_SHIFT; bo = ((bo << 8) - bo) >> INV_GAMMA_SHIFT; }
+            d[0] = sat8(bo); d[1] = sat8(go); d[2] = sat8(ro);
+            if (dcn == 4) d[3] = 255;
+        }
+    }
+}
+
+/* the tables themselves, for a direct comparison with the library's (tests): which = 0 sRGBGamma (256), 1 LabCbrt (3072), 2 sRGBInvGamma (4096),
+ * 3 LabToYF (512) as uint16; 4 abToXZ (36864) as int32 */
+int orc_labTable(int which, void* out)
+{
+    buildTables();
+    switch (which) {
+    case 0: memcpy(out, sRGBGammaTab_b, sizeof sRGBGammaTab_b); return 256;
+    case 1: memcpy(out, LabCbrtTab_b, sizeof LabCbrtTab_b); return CBRT_TAB_B;
+    case 2: memcpy(out, sRGBInvGammaTab_b, sizeof sRGBInvGammaTab_b); return INV_GAMMA_TAB;
+    case 3: memcpy(out, LabToYF_b, sizeof LabToYF_b); return 512;
+    case 4: memcpy(out, abToXZ_b, sizeof abToXZ_b); return ABXZ_N;
+    }
+    return -1;
+}

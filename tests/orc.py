@@ -256,6 +256,25 @@ def orc_cvtColorYUV(src, code):
     return dst
 
 
+# CIE L*a*b*, CV_8U: code -> (swapBlue, srgb); BGR2Lab, RGB2Lab, LBGR2Lab, LRGB2Lab / Lab2BGR, Lab2RGB, Lab2LBGR, Lab2LRGB
+_LAB_FWD = {44: (0, 1), 45: (1, 1), 74: (0, 0), 75: (1, 0)}
+_LAB_INV = {56: (0, 1), 57: (1, 1), 78: (0, 0), 79: (1, 0)}
+
+
+def orc_cvtColorLab(src, code, dcn=3):
+    o = oracle()
+    h, w = src.shape[:2]
+    if code in _LAB_FWD:
+        swap, srgb = _LAB_FWD[code]
+        dst = np.empty((h, w, 3), np.uint8)
+        o.orc_cvtBGRtoLab8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, srgb)
+    else:
+        swap, srgb = _LAB_INV[code]
+        dst = np.empty((h, w, dcn), np.uint8)
+        o.orc_cvtLabtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, srgb)
+    return dst
+
+
 def ref_cvtColorYUV(src, code):
     r = load_ref()
     h, w = src.shape[:2]

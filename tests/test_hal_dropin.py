@@ -56,6 +56,8 @@ def _calls(o, src8, src8c3, srcf):
     out["uyvyenc"] = o.ref_cvtColorMisc(src8c3, 144)
     out["xyz"] = o.ref_cvtColorMisc(src8c3, 32)
     out["xyz2rgb"] = o.ref_cvtColorMisc(src8c3, 35)
+    out["lab"] = o.ref_cvtColor(src8c3, 44, 3)
+    out["lab2lrgb"] = o.ref_cvtColor(src8c3, 79, 3)
     out["bgr565"] = o.ref_cvtColorMisc(src8c3, 12)
     out["bgr5552bgra"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 28)
     out["5652gray"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 21)
@@ -129,7 +131,7 @@ def test_reference_runs_on_the_gpu(ref):
     plain = _calls(O, src8, src8c3, srcf)
     names = ["gaussianBlurBinomial", "filter", "sepFilter", "sobel", "boxFilter", "cvtBGRtoGray", "resize", "warpAffine",
              "warpPerspective", "pyrdown", "integral", "threshold", "morph", "medianBlur", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "adaptiveThreshold", "bilateralFilter", "imageMoments", "canny",
-             "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoBGR5x5",
+             "cvtBGRtoTwoPlaneYUV", "cvtBGRtoThreePlaneYUV", "cvtOnePlaneYUVtoBGR", "cvtOnePlaneBGRtoYUV", "cvtBGRtoXYZ", "cvtXYZtoBGR", "cvtBGRtoLab", "cvtLabtoBGR", "cvtBGRtoBGR5x5",
              "cvtBGR5x5toBGR", "cvtBGR5x5toGray", "cvtGraytoBGR5x5", "cvtRGBAtoMultipliedRGBA", "cvtMultipliedRGBAtoRGBA", "equalize_hist", "threshold_otsu", "ScharrDeriv", "LKOpticalFlowLevel"]
     before = {n: cv.call_count(n) for n in names}
     with O.use_ref(hal):

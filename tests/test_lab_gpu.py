@@ -1,0 +1,72 @@
+"""cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR on the GPU (csrc/color_lab.hip) against oracle/color_lab.c, which tests/test_oracle_lab.py pins to the
+reference for every 8-bit colour: again EVERY colour in both directions (sRGB and linear), then the channel orders, 4-channel forms, ragged widths,
+unaligned views and host-resident images."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def all_colours():
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.empty((4096, 4096, 3), np.uint8)
+    img[..., 0] = (v & 255).reshape(4096, 4096)
+    img[..., 1] = ((v >> 8) & 255).reshape(4096, 4096)
+    img[..., 2] = (v >> 16).reshape(4096, 4096)
+    return img
+
+
+@pytest.mark.parametrize("code", [44, 75, 56, 79])
+def test_every_8bit_colour(cv, code):
+    img = all_colours()
+    got = cv.cvtColor(torch.from_numpy(img).cuda(), code).cpu().numpy()
+    want = orc.orc_cvtColorLab(img, code)
+    bad = np.flatnonzero((want != got).any(axis=2).ravel())
+    assert bad.size == 0, (code, bad.size, img.reshape(-1, 3)[bad[:5]], want.reshape(-1, 3)[bad[:5]], got.reshape(-1, 3)[bad[:5]])
+
+
+@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("scn", [3, 4])
+def test_forward(cv, code, scn):
+    rng = np.random.default_rng(code * 10 + scn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (35, 1024)]:
+        img = rng.integers(0, 256, (h, w, scn), dtype=np.uint8)
+        want = orc.orc_cvtColorLab(img, code)
+        assert np.array_equal(cv.cvtColor(torch.from_numpy(img).cuda(), code).cpu().numpy(), want), (code, scn, h, w)
+        assert np.array_equal(cv.cvtColor(img, code), want), ("host", code, scn, h, w)
+    parent = torch.from_numpy(rng.integers(0, 256, (70, 301, scn), dtype=np.uint8)).cuda()         # a view: odd row pitch, odd offset
+    view = parent[3:64, 5:298]
+    assert np.array_equal(cv.cvtColor(view, code).cpu().numpy(), orc.orc_cvtColorLab(np.ascontiguousarray(view.cpu().numpy()), code))
+
+
+@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("dcn", [3, 4])
+def test_inverse(cv, code, dcn):
+    rng = np.random.default_rng(code * 10 + dcn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (35, 1024)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = orc.orc_cvtColorLab(img, code, dcn)
+        assert np.array_equal(cv.cvtColor(torch.from_numpy(img).cuda(), code, dstCn=dcn).cpu().numpy(), want), (code, dcn, h, w)
+        assert np.array_equal(cv.cvtColor(img, code, dstCn=dcn), want), ("host", code, dcn, h, w)
+    parent = torch.from_numpy(rng.integers(0, 256, (70, 301, 3), dtype=np.uint8)).cuda()
+    view = parent[3:64, 5:298]
+    assert np.array_equal(cv.cvtColor(view, code, dstCn=dcn).cpu().numpy(), orc.orc_cvtColorLab(np.ascontiguousarray(view.cpu().numpy()), code, dcn))
+
+
+def test_declines(cv):
+    with pytest.raises((NotImplementedError, ValueError)):
+        cv.cvtColor(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), 44)
+    L = cv._lib.lib
+    a = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+    assert L.mi355cv_cvtBGRtoLab(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 0, 3, False, False, True) == 1          # L*u*v*: not built, the reference's path runs
+    assert L.mi355cv_cvtLabtoBGR(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 5, 3, False, True, True) == 1           # CV_32F

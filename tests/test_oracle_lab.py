@@ -1,0 +1,68 @@
+"""Pins oracle/color_lab.c (CV_8U L*a*b*, both directions) to the reference build in oracle/_ref: EVERY 8-bit colour -- all 2^24 BGR triples through
+BGR2Lab / LRGB2Lab and all 2^24 Lab triples through Lab2BGR / Lab2LRGB -- plus the remaining codes and the 4-channel forms on random images.
+The tables of the restatement (softfloat arithmetic restated as IEEE float / double, Turkowski's cube root, the C library's pow) are thereby
+checked entry by entry wherever an entry is reachable."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.skipif(orc.load_ref() is None, reason="oracle/_ref not built")
+
+
+def all_colours():
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.empty((4096, 4096, 3), np.uint8)
+    img[..., 0] = (v & 255).reshape(4096, 4096)
+    img[..., 1] = ((v >> 8) & 255).reshape(4096, 4096)
+    img[..., 2] = (v >> 16).reshape(4096, 4096)
+    return img
+
+
+@pytest.mark.parametrize("code", [44, 75, 56, 79])
+def test_every_8bit_colour(code):
+    img = all_colours()
+    want = orc.ref_cvtColor(img, code, 3)
+    got = orc.orc_cvtColorLab(img, code)
+    bad = np.flatnonzero((want != got).any(axis=2).ravel())
+    assert bad.size == 0, (code, bad.size, img.reshape(-1, 3)[bad[:5]], want.reshape(-1, 3)[bad[:5]], got.reshape(-1, 3)[bad[:5]])
+
+
+@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("scn", [3, 4])
+def test_forward_codes_and_channels(code, scn):
+    rng = np.random.default_rng(code * 10 + scn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641)]:
+        img = rng.integers(0, 256, (h, w, scn), dtype=np.uint8)
+        assert np.array_equal(orc.orc_cvtColorLab(img, code), orc.ref_cvtColor(img, code, 3)), (code, scn, h, w)
+
+
+@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("dcn", [3, 4])
+def test_inverse_codes_and_channels(code, dcn):
+    rng = np.random.default_rng(code * 10 + dcn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(orc.orc_cvtColorLab(img, code, dcn), orc.ref_cvtColor(img, code, dcn)), (code, dcn, h, w)
+
+
+def test_library_tables_equal_the_oracle_tables():
+    """the host-built tables of libmi355cv (csrc/color_lab.hip; no GPU involved) against the oracle's, which the tests above pin to the reference"""
+    import ctypes
+    from opencv_amd import _lib
+    o = orc.oracle()
+    o.orc_labTable.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    for which, n in [(0, 256), (1, 3072), (2, 4096)]:
+        a, b = np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        assert _lib.lib.mi355cv_labTable(which, a.ctypes.data) == n and o.orc_labTable(which, b.ctypes.data) == n
+        assert np.array_equal(a, b), which
+    yf, pairs = np.zeros(256, np.uint32), np.zeros(512, np.uint16)
+    assert _lib.lib.mi355cv_labTable(3, yf.ctypes.data) == 256 and o.orc_labTable(3, pairs.ctypes.data) == 512
+    assert np.array_equal(yf & 0xffff, pairs[0::2]) and np.array_equal(yf >> 16, pairs[1::2])
+    # the a/b -> X/Z table the kernel evaluates instead of loading (initLUTforABXZ): linear ramp (C division, truncating) below 3390, cube above
+    ab = np.zeros(36864, np.int32)
+    assert o.orc_labTable(4, ab.ctypes.data) == 36864
+    i = np.arange(-8145, 36864 - 8145, dtype=np.int64)
+    ramp = np.sign(i * 108) * (np.abs(i * 108) // 841) - 290
+    cube = ((i * i >> 14) * i) >> 14
+    assert np.array_equal(ab, np.where(i <= 3390, ramp, cube))

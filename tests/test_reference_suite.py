@@ -64,6 +64,6 @@ def test_whole_reference_suite_on_the_gpu():
     rc, ran, passed, failed, counts = run("*", {"MI355CV_PRINT_COUNTS": "1"}, timeout=1500)
     assert rc == 0 and not failed and ran == passed and ran > 800, (rc, ran, passed, failed[:10])
     for hook in ("threshold", "threshold_otsu", "filter", "sepFilter", "sobel", "scharr", "boxFilter", "resize", "warpAffine", "warpPerspective", "remap32f",
-                 "cvtBGRtoGray", "cvtBGRtoBGR", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "cvtBGRtoXYZ", "pyrdown", "integral", "medianBlur", "morph",
+                 "cvtBGRtoGray", "cvtBGRtoBGR", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "cvtBGRtoXYZ", "cvtBGRtoLab", "cvtLabtoBGR", "pyrdown", "integral", "medianBlur", "morph",
                  "equalize_hist", "gaussianBlurBinomial", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtOnePlaneYUVtoBGR"):
         assert counts.get(hook, 0) > 0, (hook, counts)

@@ -1,0 +1,18 @@
+"""cv::cvtColor BGR <-> L*a*b* on a 4K CV_8UC3 frame: GPU (HIP events, device-resident) vs the reference on the box's host threads."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import opencv_amd as cv
+from tune_r02 import timeit  # noqa: E402
+import orc
+cv.set_async(True)
+rng = np.random.default_rng(1)
+img = rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)
+d = torch.from_numpy(img).cuda(); out = torch.empty_like(d)
+for name, code in [("BGR2Lab", 44), ("LBGR2Lab", 74), ("Lab2BGR", 56), ("Lab2LBGR", 78)]:
+    us = timeit(lambda: cv.cvtColor(d, code, dst=out), n=20, warm=3)
+    t0 = time.perf_counter(); orc.ref_cvtColor(img, code, 3); cpu = (time.perf_counter() - t0) * 1e3
+    mb = 2 * img.size / 1e6
+    print(f"cvtColor {name} 4K 8UC3: GPU {us:7.2f} us = {mb / us:5.2f} TB/s ({mb / us / 8 * 100:4.1f} % of 8 TB/s), reference on the host threads {cpu:6.2f} ms", flush=True)
