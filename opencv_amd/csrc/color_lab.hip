@@ -1,4 +1,4 @@
-// color_lab.hip -- SURVEY.md §8 f1: CIE L*a*b* <-> BGR / RGB for CV_8U images behind cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR
+// color_lab.hip -- SURVEY.md §8 f1: CIE L*a*b* and L*u*v* <-> BGR / RGB for CV_8U images behind cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR
 // (hal_replacement.hpp:535-565; callers hal::cvtBGRtoLab color_lab.cpp:4230, hal::cvtLabtoBGR :4327).  The reference's 8-bit paths are pure integer
 // arithmetic over small tables -- RGB2Lab_b (color_lab.cpp:1573) and Lab2RGBinteger (:2399, taken by Lab2RGB_b since enableBitExactness) -- so the
 // results here are bit-identical by construction once the tables are:
@@ -10,7 +10,10 @@
 // (softfloat.cpp:3897) restated as written) and kept in HBM per device; a workgroup copies what its kernel needs into LDS (6.5 KB forward, 9 KB
 // inverse) and converts 32 rows x 256 pixels, a lane owning 4 consecutive pixels of a row (dword traffic, pix4.h).  The a/b -> X/Z table of the
 // reference (initLUTforABXZ :1086, 147 KB) is two integer formulas, evaluated instead of looked up.
-// HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.  CV_32F images and L*u*v* are declined (the reference's own path then runs).
+// HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.
+// L*u*v* (isLab == false), CV_8U: sRGB -> Luv by trilinear interpolation in the reference's 33^3 fixed-point table (RGB2Luvinterpolate :3276), Luv ->
+// sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  Declined (the reference's own path then runs): CV_32F images, and
+// L*u*v* from LINEAR RGB, which the reference computes in float.
 #include "rt.h"
 #include "pix4.h"
 #include <cmath>
@@ -119,6 +122,91 @@ const LabTabs* deviceTabs()
 const double kD65[3] = {0.950456, 1.0, 1.088754};
 const double kRgb2Xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
 const double kXyz2Rgb[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+
+// ---- L*u*v* tables (initLUTforLABLUVs16 color_lab.cpp:1126-1232, initLUTforLUV :1043-1084), built on first use:
+//   lut   33^3 grid points x (L, u, v, 0) as 14-bit fixed point int16 -- RGB2Luvinterpolate's table, one 8-byte entry per grid point (the reference
+//         stores every cell's eight corners; the upper neighbours it clamps never reach the last plane for 8-bit inputs: cell index <= 31)
+//   up    LuToUp_b [L][u] = round(16 * 9 (u + L un)),   vp   LvToVp_b [L][v] = round(2^24 * clamp(1 / (4 (v + L vn)), +-1/4))
+enum { LUV_DIM = 33, LUV_GRID = LUV_DIM * LUV_DIM * LUV_DIM };
+struct LuvTabs {
+    short lut[LUV_GRID * 4];
+    int up[256 * 256];
+    int vp[256 * 256];
+};
+LuvTabs* g_luvHost;                    // 0.8 MB: allocated when first needed
+std::once_flag g_luvHostOnce;
+
+inline float maxSoft(float a, float b) { return a > b ? a : b; }
+
+void buildLuvHost()
+{
+    std::call_once(g_hostOnce, buildHost);
+    LuvTabs* t = new LuvTabs;
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f, f255 = 255.f, eps = 1.1920928955078125e-7f;
+    const float uLow = -134.f, uRange = 220.f - -134.f, vLow = -140.f, vRange = 122.f - -140.f;
+    float dd = (float)(kD65[0] + kD65[1] * 15.0 + kD65[2] * 3.0);
+    dd = 1.f / maxSoft(dd, eps);
+    const float un = dd * 52.f * (float)kD65[0], vn = dd * 117.f * (float)kD65[1];
+    float C[9];                                                     // columns reversed: the table's first axis is blue
+    for (int i = 0; i < 3; i++) { C[i * 3 + 2] = (float)kRgb2Xyz[i * 3]; C[i * 3 + 1] = (float)kRgb2Xyz[i * 3 + 1]; C[i * 3] = (float)kRgb2Xyz[i * 3 + 2]; }
+    const float lld = (float)(LUV_DIM - 1), lbase = (float)LBASE, f9of4 = 9.f / 4.f;
+    float gam[LUV_DIM];
+    for (int p = 0; p < LUV_DIM; p++) gam[p] = gammaFwd((float)p / lld);
+    for (int r = 0; r < LUV_DIM; r++)
+        for (int q = 0; q < LUV_DIM; q++)
+            for (int p = 0; p < LUV_DIM; p++) {
+                const float R = gam[p], G = gam[q], B = gam[r];
+                float t0 = R * C[0], t1 = G * C[1], t2 = B * C[2];
+                const float X = (t0 + t1) + t2;
+                t0 = R * C[3]; t1 = G * C[4]; t2 = B * C[5];
+                const float Y = (t0 + t1) + t2;
+                t0 = R * C[6]; t1 = G * C[7]; t2 = B * C[8];
+                const float Z = (t0 + t1) + t2;
+                float L = Y < lthresh ? fmaf(Y, lscale, lbias) : cubeRootTurkowski(Y);
+                L = L * 116.f - 16.f;
+                const float y15 = 15.f * Y, z3 = 3.f * Z;
+                const float d = 52.f / maxSoft((X + y15) + z3, eps);
+                const float xd = X * d, u = L * (xd - un);
+                const float yd = (f9of4 * Y) * d, v = L * (yd - vn);
+                short* e = t->lut + 4 * ((r * LUV_DIM + q) * LUV_DIM + p);
+                e[0] = (short)lrintf((lbase * L) / 100.f);
+                e[1] = (short)lrintf((lbase * (u - uLow)) / uRange);
+                e[2] = (short)lrintf((lbase * (v - vLow)) / vRange);
+                e[3] = 0;
+            }
+    for (int LL = 0; LL < 256; LL++) {
+        const float L = (float)(LL * 100) / f255;
+        for (int uu = 0; uu < 256; uu++) {
+            const float u = ((float)uu * uRange) / f255 + uLow;
+            t->up[LL * 256 + uu] = (int)lrintf((9.f * (u + L * un)) * (float)(LBASE / 1024));
+        }
+        for (int vv = 0; vv < 256; vv++) {
+            const float v = ((float)vv * vRange) / f255 + vLow;
+            float vp = 0.25f / (v + L * vn);
+            if (vp > 0.25f) vp = 0.25f;
+            if (vp < -0.25f) vp = -0.25f;
+            t->vp[LL * 256 + vv] = (int)lrintf(vp * (float)(LBASE * 1024));
+        }
+    }
+    g_luvHost = t;
+}
+
+LuvTabs* g_luvDev[LAB_MAX_DEV];
+
+const LuvTabs* deviceLuvTabs()
+{
+    std::call_once(g_luvHostOnce, buildLuvHost);
+    const int dev = activeDevice();
+    if (dev < 0 || dev >= LAB_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_devMu);
+    if (!g_luvDev[dev]) {
+        LuvTabs* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(LuvTabs)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemcpy(d, g_luvHost, sizeof(LuvTabs), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        g_luvDev[dev] = d;
+    }
+    return g_luvDev[dev];
+}
 
 struct Coef9 { int c[9]; };
 
@@ -244,6 +332,122 @@ __global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ sr
     }
 }
 
+// ---- L*u*v* forward (sRGB): trilinear interpolation in the 33^3 table (trilinearInterpolate color_lab.cpp:1352-1392).  A channel value c selects
+// cell c >> 3 and the weight (2 c) & 15 of 16; the two corners along the first (blue) axis are adjacent entries: one 16-byte load, four per pixel.
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2luv_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int aligned,
+                                                     const LuvTabs* __restrict__ tabs, int bIdx)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= W || y >= H) return;
+    const int n = min(4, W - x4);
+    const bool fast = n == 4 && aligned;
+    const uchar* s = src + (size_t)y * sstep + (size_t)x4 * SCN;
+    uchar* d = dst + (size_t)y * dstep + (size_t)x4 * 3;
+    pix4::Px<SCN> in; pix4::Px<3> out;
+    out.clear();
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < SCN; i++) in.w[i] = ((const unsigned*)s)[i];
+    } else {
+        in.clear();
+#pragma unroll
+        for (int i = 0; i < 4 * SCN; i++) if (i < n * SCN) in.put(i, s[i]);
+    }
+    typedef short s16x8 __attribute__((ext_vector_type(8), aligned(8)));
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int c0 = in.get(p * SCN), c1 = in.get(p * SCN + 1), c2 = in.get(p * SCN + 2);
+        const int cb = bIdx ? c2 : c0, cg = c1, cr = bIdx ? c0 : c2;                     // table axes: blue, green, red
+        const int tx = cb >> 3, ty = cg >> 3, tz = cr >> 3, fx = (2 * cb) & 15, fy = (2 * cg) & 15, fz = (2 * cr) & 15;
+        const short* cell = tabs->lut + 4 * ((tz * LUV_DIM + ty) * LUV_DIM + tx);
+        int aL = 0, aU = 0, aV = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                                                     // k = 2 dq + dr (green, red); both blue corners per load
+            const int dq = k >> 1, dr = k & 1;
+            const s16x8 e = *reinterpret_cast<const s16x8*>(cell + 4 * ((dr * LUV_DIM + dq) * LUV_DIM));
+            const int wyz = __mul24(dq ? fy : 16 - fy, dr ? fz : 16 - fz);
+            const int w0 = __mul24(16 - fx, wyz), w1 = __mul24(fx, wyz);
+            aL += __mul24(e[0], w0) + __mul24(e[4], w1);
+            aU += __mul24(e[1], w0) + __mul24(e[5], w1);
+            aV += __mul24(e[2], w0) + __mul24(e[6], w1);
+        }
+        // CV_DESCALE(., 12), then / (LAB_BASE / 256) -- the sums are not negative
+        out.put(p * 3, sat8(descale(aL, 12) >> 6)); out.put(p * 3 + 1, sat8(descale(aU, 12) >> 6)); out.put(p * 3 + 2, sat8(descale(aV, 12) >> 6));
+    }
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) ((unsigned*)d)[i] = out.w[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; i++) if (i < n * 3) d[i] = (uchar)out.get(i);
+    }
+}
+
+// ---- L*u*v* inverse: Luv2RGBinteger::process (color_lab.cpp:3587-3646) as written (64-bit intermediates, C division)
+template <int DCN, bool SRGB>
+__global__ __launch_bounds__(256) void k_luv2bgr_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int aligned,
+                                                     const LabTabs* __restrict__ tabs, const LuvTabs* __restrict__ luv, Coef9 k)
+{
+    __shared__ uint32_t yf[256];
+    __shared__ uint16_t ig[SRGB ? N_INVG : 2];
+    yf[threadIdx.x] = tabs->yf[threadIdx.x];
+    if (SRGB) for (int i = threadIdx.x; i < N_INVG / 2; i += 256) ((unsigned*)ig)[i] = ((const unsigned*)tabs->invGamma)[i];
+    __syncthreads();
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (x4 >= W) return;
+    const int n = min(4, W - x4);
+    const bool fast = n == 4 && aligned;
+    constexpr int shift = LAB_SHIFT + (14 - INV_GAMMA_SHIFT);
+    const int yEnd = min(H, (int)(blockIdx.y + 1) * ROWS_PER_BLOCK);
+    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 4) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x4 * 3;
+        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * DCN;
+        pix4::Px<3> in; pix4::Px<DCN> out;
+        out.clear();
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) in.w[i] = ((const unsigned*)s)[i];
+        } else {
+            in.clear();
+#pragma unroll
+            for (int i = 0; i < 12; i++) if (i < n * 3) in.put(i, s[i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int LL = in.get(p * 3), uu = in.get(p * 3 + 1), vv = in.get(p * 3 + 2);
+            const int yv = (int)(yf[LL] & 0xffffu);
+            const int up = luv->up[LL * 256 + uu], vp = luv->vp[LL * 256 + vv];
+            const long long xv = (long long)up * (long long)vp;
+            int xi = (int)(xv / LBASE);
+            xi = (int)((long long)yv * xi / LBASE);
+            const long long vpl = (12 * 13 * 100 * (LBASE / 1024)) * (long long)(vp * LL);
+            long long zp = vpl - xv * (255 / 3);
+            zp /= LBASE;
+            const long long zq = zp - (long long)(5 * 255 * LBASE);
+            const int zm = (int)(yv * zq / LBASE);
+            int zi = zm / 256 + zm / 65536;
+            xi = max(0, min(2 * LBASE, xi)); zi = max(0, min(2 * LBASE, zi));
+            int ro = descale(k.c[0] * xi + k.c[1] * yv + k.c[2] * zi, shift);
+            int go = descale(k.c[3] * xi + k.c[4] * yv + k.c[5] * zi, shift);
+            int bo = descale(k.c[6] * xi + k.c[7] * yv + k.c[8] * zi, shift);
+            ro = max(0, min(N_INVG - 1, ro)); go = max(0, min(N_INVG - 1, go)); bo = max(0, min(N_INVG - 1, bo));
+            if (SRGB) { ro = ig[ro]; go = ig[go]; bo = ig[bo]; }
+            else { ro = ((ro << 8) - ro) >> INV_GAMMA_SHIFT; go = ((go << 8) - go) >> INV_GAMMA_SHIFT; bo = ((bo << 8) - bo) >> INV_GAMMA_SHIFT; }
+            out.put(p * DCN, sat8(bo)); out.put(p * DCN + 1, sat8(go)); out.put(p * DCN + 2, sat8(ro));
+            if (DCN == 4) out.put(p * 4 + 3, 255);
+        }
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < DCN; i++) ((unsigned*)d)[i] = out.w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * DCN; i++) if (i < n * DCN) d[i] = (uchar)out.get(i);
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -252,15 +456,26 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || depth != MI355CV_8U || !isLab || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || depth != MI355CV_8U || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    // L*u*v* from linear RGB is the reference's float path (RGB2Luv_b color_lab.cpp:3389-3392 interpolates for sRGB only): declined
+    if (!isLab && !srgb) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: L*u*v* from linear RGB takes the reference's float path");
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    const LabTabs* tabs = deviceTabs();
-    if (!tabs) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
+    const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
+    const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
+    if (!tabs && !luv) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!isLab) {
+        const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+        const dim3 grid(divUp(divUp(width, 4), 64), divUp(height, 4));
+        if (scn == 3) hipLaunchKernelGGL((k_bgr2luv_u8<3>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, al, luv, swapBlue ? 2 : 0);
+        else          hipLaunchKernelGGL((k_bgr2luv_u8<4>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, al, luv, swapBlue ? 2 : 0);
+        noteKernel("k_bgr2luv_u8<%d> grid=%ux%u x256", scn, grid.x, grid.y);
+        return stg.finish("cvtBGRtoLab");
+    }
     // RGB2Lab_b's constructor (color_lab.cpp:1590-1606): rows of sRGB -> XYZ divided by the white point, 2^12 fixed point, the channel order folded in
     Coef9 k; const int blueIdx = swapBlue ? 2 : 0;
     for (int i = 0; i < 3; i++) {
@@ -284,15 +499,34 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || depth != MI355CV_8U || !isLab || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || depth != MI355CV_8U || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = deviceTabs();
-    if (!tabs) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
+    const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
+    if (!tabs || (!isLab && !luv)) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
     Stager stg; size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!isLab) {
+        // Luv2RGBinteger's constructor (color_lab.cpp:3567-3584): XYZ -> sRGB in 2^12 fixed point, no white point (it is folded into the tables)
+        Coef9 kq; const int bi = swapBlue ? 2 : 0;
+        for (int i = 0; i < 3; i++) {
+            const double ls = (double)(1 << LAB_SHIFT);
+            kq.c[i + bi * 3]       = (int)lrint(ls * kXyz2Rgb[i]);
+            kq.c[i + 3]            = (int)lrint(ls * kXyz2Rgb[i + 3]);
+            kq.c[i + (bi ^ 2) * 3] = (int)lrint(ls * kXyz2Rgb[i + 6]);
+        }
+        const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
+        const dim3 grid(divUp(divUp(width, 4), 64), divUp(height, ROWS_PER_BLOCK));
+#define LAUNCH(DCN_, SRGB_) hipLaunchKernelGGL((k_luv2bgr_u8<DCN_, SRGB_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, al, tabs, luv, kq)
+        if (dcn == 3) { if (srgb) LAUNCH(3, true); else LAUNCH(3, false); }
+        else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+        noteKernel("k_luv2bgr_u8<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
+        return stg.finish("cvtLabtoBGR");
+    }
     // Lab2RGBinteger's constructor (color_lab.cpp:2415-2437): columns of XYZ -> sRGB times the white point; stored B, G, R, so the first row is blue's
     Coef9 k; const int blueIdx = swapBlue ? 2 : 0;
     for (int i = 0; i < 3; i++) {
@@ -313,7 +547,8 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
 }
 
 // diagnostics (tests): the host tables behind the two hooks.  which = 0 gamma (256 x u16), 1 cbrt (3072 x u16), 2 invGamma (4096 x u16),
-// 3 yf (256 x u32: y | ify << 16).  Returns the entry count; needs no GPU.
+// 3 yf (256 x u32: y | ify << 16), 4 the 33^3 x (L, u, v, 0) int16 table of RGB -> Luv, 5 / 6 LuToUp / LvToVp (65536 x i32).  Returns the entry
+// count; needs no GPU.
 MI355CV_API int mi355cv_labTable(int which, void* out)
 {
     std::call_once(g_hostOnce, buildHost);
@@ -322,6 +557,9 @@ MI355CV_API int mi355cv_labTable(int which, void* out)
     case 1: std::memcpy(out, g_host.cbrt, sizeof g_host.cbrt); return N_CBRT;
     case 2: std::memcpy(out, g_host.invGamma, sizeof g_host.invGamma); return N_INVG;
     case 3: std::memcpy(out, g_host.yf, sizeof g_host.yf); return 256;
+    case 4: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->lut, sizeof g_luvHost->lut); return LUV_GRID * 4;
+    case 5: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->up, sizeof g_luvHost->up); return 65536;
+    case 6: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->vp, sizeof g_luvHost->vp); return 65536;
     }
     return -1;
 }

@@ -18,6 +18,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "COLOR_YUV2BGR", "COLOR_YUV2RGB", "COLOR_YUV2RGB_NV12", "COLOR_YUV2BGR_NV12", "COLOR_YUV2RGB_NV21", "COLOR_YUV2BGR_NV21",
            "COLOR_YUV2RGBA_NV12", "COLOR_YUV2BGRA_NV12", "COLOR_YUV2RGBA_NV21", "COLOR_YUV2BGRA_NV21",
            "COLOR_BGR2Lab", "COLOR_RGB2Lab", "COLOR_LBGR2Lab", "COLOR_LRGB2Lab", "COLOR_Lab2BGR", "COLOR_Lab2RGB", "COLOR_Lab2LBGR", "COLOR_Lab2LRGB",
+           "COLOR_BGR2Luv", "COLOR_RGB2Luv", "COLOR_LBGR2Luv", "COLOR_LRGB2Luv", "COLOR_Luv2BGR", "COLOR_Luv2RGB", "COLOR_Luv2LBGR", "COLOR_Luv2LRGB",
            "COLOR_BGR2HSV", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2HSV_FULL", "COLOR_YUV2RGB_YV12", "COLOR_YUV2BGR_YV12", "COLOR_YUV2RGB_IYUV", "COLOR_YUV2BGR_IYUV", "COLOR_YUV2RGB_I420", "COLOR_YUV2BGR_I420",
            "COLOR_YUV2RGBA_YV12", "COLOR_YUV2BGRA_YV12", "COLOR_YUV2RGBA_IYUV", "COLOR_YUV2BGRA_IYUV", "COLOR_BGR2BGRA", "COLOR_RGB2RGBA", "COLOR_BGRA2BGR", "COLOR_RGBA2RGB", "COLOR_BGR2RGBA",
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
@@ -200,6 +201,8 @@ COLOR_YUV2RGBA_NV12, COLOR_YUV2BGRA_NV12, COLOR_YUV2RGBA_NV21, COLOR_YUV2BGRA_NV
 COLOR_BGR2HSV, COLOR_RGB2HSV, COLOR_BGR2HSV_FULL, COLOR_RGB2HSV_FULL = 40, 41, 66, 67
 COLOR_BGR2Lab, COLOR_RGB2Lab, COLOR_LBGR2Lab, COLOR_LRGB2Lab = 44, 45, 74, 75                  # imgproc.hpp:602-631
 COLOR_Lab2BGR, COLOR_Lab2RGB, COLOR_Lab2LBGR, COLOR_Lab2LRGB = 56, 57, 78, 79
+COLOR_BGR2Luv, COLOR_RGB2Luv, COLOR_LBGR2Luv, COLOR_LRGB2Luv = 50, 51, 76, 77
+COLOR_Luv2BGR, COLOR_Luv2RGB, COLOR_Luv2LBGR, COLOR_Luv2LRGB = 58, 59, 80, 81
 _HSV = {40: (0, 0), 41: (1, 0), 66: (0, 1), 67: (1, 1)}
 _YUV_FWD = {82: (0, 0), 83: (1, 0), 36: (0, 1), 37: (1, 1)}
 _YUV_INV = {84: (0, 0), 85: (1, 0), 38: (0, 1), 39: (1, 1)}
@@ -309,6 +312,8 @@ def _misc_table():
     for code, swap in ((34, 0), (35, 1)): t[code] = ("from_xyz", swap)
     for code, swap, srgb in ((44, 0, 1), (45, 1, 1), (74, 0, 0), (75, 1, 0)): t[code] = ("to_lab", swap, srgb)           # BGR2Lab, RGB2Lab, LBGR2Lab, LRGB2Lab
     for code, swap, srgb in ((56, 0, 1), (57, 1, 1), (78, 0, 0), (79, 1, 0)): t[code] = ("from_lab", swap, srgb)         # Lab2BGR, Lab2RGB, Lab2LBGR, Lab2LRGB
+    for code, swap, srgb in ((50, 0, 1), (51, 1, 1), (76, 0, 0), (77, 1, 0)): t[code] = ("to_luv", swap, srgb)           # BGR2Luv, RGB2Luv, LBGR2Luv, LRGB2Luv
+    for code, swap, srgb in ((58, 0, 1), (59, 1, 1), (80, 0, 0), (81, 1, 0)): t[code] = ("from_luv", swap, srgb)         # Luv2BGR, Luv2RGB, Luv2LBGR, Luv2LRGB
     for code, cn, swap, gb in ((12, 3, 0, 6), (13, 3, 1, 6), (16, 4, 0, 6), (17, 4, 1, 6), (22, 3, 0, 5), (23, 3, 1, 5), (26, 4, 0, 5), (27, 4, 1, 5)):
         t[code] = ("to_5x5", cn, swap, gb)
     for code, cn, swap, gb in ((14, 3, 0, 6), (15, 3, 1, 6), (18, 4, 0, 6), (19, 4, 1, 6), (24, 3, 0, 5), (25, 3, 1, 5), (28, 4, 0, 5), (29, 4, 1, 5)):
@@ -355,15 +360,15 @@ def _cvt_misc(src, s, code, dst, dstCn):
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtXYZtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]))
-    elif kind == "to_lab":
-        need(s.cn in (3, 4) and s.depth == CV_8U, "BGR2Lab: 3 or 4 channels, CV_8U on this path (CV_32F: the reference's float path is not built)")
+    elif kind in ("to_lab", "to_luv"):                      # the library declines L*u*v* from linear RGB (the reference's float path): NotImplementedError
+        need(s.cn in (3, 4) and s.depth == CV_8U, "BGR2Lab / BGR2Luv: 3 or 4 channels, CV_8U on this path (CV_32F: the reference's float path is not built)")
         out = dst if dst is not None else _like(src, s.h, s.w, 3, s.depth)
-        call = lambda d: L.mi355cv_cvtBGRtoLab(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]), True, bool(k[2]))
-    elif kind == "from_lab":
-        need(s.cn == 3 and s.depth == CV_8U, "Lab2BGR: 3 channels, CV_8U on this path")
+        call = lambda d: L.mi355cv_cvtBGRtoLab(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]), kind == "to_lab", bool(k[2]))
+    elif kind in ("from_lab", "from_luv"):
+        need(s.cn == 3 and s.depth == CV_8U, "Lab2BGR / Luv2BGR: 3 channels, CV_8U on this path")
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
-        call = lambda d: L.mi355cv_cvtLabtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]), True, bool(k[2]))
+        call = lambda d: L.mi355cv_cvtLabtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]), kind == "from_lab", bool(k[2]))
     elif kind == "to_5x5":
         need(s.cn == k[1] and s.depth == CV_8U, f"source must be CV_8UC{k[1]}")
         out = dst if dst is not None else _like(src, s.h, s.w, 2, CV_8U)

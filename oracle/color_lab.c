@@ -175,8 +175,148 @@ void orc_cvtLabtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
     }
 }
 
+/* ----------------------------------------------------------------------------------------------------------------- L*u*v*, CV_8U
+ *   - forward (sRGB only)  RGB2Luvinterpolate color_lab.cpp:3276-3376: trilinear interpolation (trilinearInterpolate :1352-1392) in a 33^3 table of
+ *                          (L, u, v) as 14-bit fixed point, built by initLUTforLABLUVs16 :1126-1232 in softfloat arithmetic; RGB2Luv_b :3378-3400 takes it
+ *                          for sRGB sources (linear RGB goes through the float path, which is not restated: the hook declines it)
+ *   - inverse              Luv2RGBinteger :3556-3915 (process() :3587-3646), tables from initLUTforLUV :1043-1084
+ * The vector bodies of the reference replace the scalar code's divisions by 2^14 with arithmetic shifts; the two differ only for negative
+ * intermediates, which the clamp to [0, 2] that follows maps to the same value -- tests/test_oracle_lab.py compares every colour. */
+enum { LUT_DIM = 33, TRI_SHIFT = 4, TRI_BASE = 1 << TRI_SHIFT };
+static int16_t RGB2LuvLUT[LUT_DIM * LUT_DIM * LUT_DIM * 3];
+static int LuToUp_b[256 * 256], LvToVp_b[256 * 256];
+static int luvReady;
+
+static float fmax2(float a, float b) { return a > b ? a : b; }          /* softfloat max(a, b) = a > b ? a : b */
+
+static void buildLuvTables(void)
+{
+    if (luvReady) return;
+    buildTables();
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
+    const float uLow = -134.f, uRange = 220.f - -134.f, vLow = -140.f, vRange = 122.f - -140.f, f255 = 255.f;
+    float dd = (float)(D65[0] + D65[1] * 15.0 + D65[2] * 3.0);
+    dd = 1.f / fmax2(dd, 1.1920928955078125e-7f);
+    const float un = dd * 52.f * (float)D65[0], vn = dd * 117.f * (float)D65[1];
+    float C[9];
+    for (int i = 0; i < 3; i++) { C[i * 3 + 2] = (float)sRGB2XYZ_D65[i * 3]; C[i * 3 + 1] = (float)sRGB2XYZ_D65[i * 3 + 1]; C[i * 3] = (float)sRGB2XYZ_D65[i * 3 + 2]; }
+    const float lld = (float)(LUT_DIM - 1), lbase = (float)LAB_BASE, f9of4 = 9.f / 4.f;
+    for (int p = 0; p < LUT_DIM; p++)
+        for (int q = 0; q < LUT_DIM; q++)
+            for (int r = 0; r < LUT_DIM; r++) {
+                const float R = applyGamma((float)p / lld), G = applyGamma((float)q / lld), B = applyGamma((float)r / lld);
+                float t0 = R * C[0], t1 = G * C[1], t2 = B * C[2];
+                const float X = (t0 + t1) + t2;
+                t0 = R * C[3]; t1 = G * C[4]; t2 = B * C[5];
+                const float Y = (t0 + t1) + t2;
+                t0 = R * C[6]; t1 = G * C[7]; t2 = B * C[8];
+                const float Z = (t0 + t1) + t2;
+                float L = Y < lthresh ? fmaf(Y, lscale, lbias) : cbrtTurkowski(Y);
+                L = L * 116.f - 16.f;
+                const float a15 = 15.f * Y, a3 = 3.f * Z;
+                const float d = 52.f / fmax2((X + a15) + a3, 1.1920928955078125e-7f);
+                const float xd = X * d, u = L * (xd - un);
+                const float yd = (f9of4 * Y) * d, v = L * (yd - vn);
+                int16_t* e = RGB2LuvLUT + p * 3 + q * LUT_DIM * 3 + r * LUT_DIM * LUT_DIM * 3;
+                e[0] = (int16_t)lrintf((lbase * L) / 100.f);
+                e[1] = (int16_t)lrintf((lbase * (u - uLow)) / uRange);
+                e[2] = (int16_t)lrintf((lbase * (v - vLow)) / vRange);
+            }
+    for (int LL = 0; LL < 256; LL++) {
+        const float L = (float)(LL * 100) / f255;
+        for (int uu = 0; uu < 256; uu++) {
+            const float u = ((float)uu * uRange) / f255 + uLow;
+            const float up = 9.f * (u + L * un);
+            LuToUp_b[LL * 256 + uu] = (int)lrintf(up * (float)(LUT_BASE / 1024));
+        }
+        for (int vv = 0; vv < 256; vv++) {
+            const float v = ((float)vv * vRange) / f255 + vLow;
+            float vp = 0.25f / (v + L * vn);
+            if (vp > 0.25f) vp = 0.25f;
+            if (vp < -0.25f) vp = -0.25f;
+            LvToVp_b[LL * 256 + vv] = (int)lrintf(vp * (float)(LUT_BASE * 1024));
+        }
+    }
+    luvReady = 1;
+}
+
+/* trilinearInterpolate :1352 on the plain 33^3 x 3 table: the packed table of the reference holds, for every cell, its eight corners with the upper
+ * neighbours clamped to the last grid point (fill_one :1112) */
+static void trilinear(int cx, int cy, int cz, int* a, int* b, int* c)
+{
+    const int tx = cx >> (14 - 5), ty = cy >> (14 - 5), tz = cz >> (14 - 5);
+    const int x = (cx >> (14 - 8 - 1)) & (TRI_BASE - 1), y = (cy >> (14 - 8 - 1)) & (TRI_BASE - 1), z = (cz >> (14 - 8 - 1)) & (TRI_BASE - 1);
+    int acc[3] = {0, 0, 0};
+    for (int i = 0; i < 8; i++) {
+        const int dp = i >> 2, dq = (i >> 1) & 1, dr = i & 1;
+        const int pp = tx + dp < LUT_DIM - 1 ? tx + dp : LUT_DIM - 1, qq = ty + dq < LUT_DIM - 1 ? ty + dq : LUT_DIM - 1, rr = tz + dr < LUT_DIM - 1 ? tz + dr : LUT_DIM - 1;
+        const int16_t* e = RGB2LuvLUT + pp * 3 + qq * LUT_DIM * 3 + rr * LUT_DIM * LUT_DIM * 3;
+        const int w = (dp ? x : TRI_BASE - x) * (dq ? y : TRI_BASE - y) * (dr ? z : TRI_BASE - z);
+        acc[0] += e[0] * w; acc[1] += e[1] * w; acc[2] += e[2] * w;
+    }
+    *a = descale(acc[0], TRI_SHIFT * 3); *b = descale(acc[1], TRI_SHIFT * 3); *c = descale(acc[2], TRI_SHIFT * 3);
+}
+
+void orc_cvtBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue)
+{
+    buildLuvTables();
+    const int bIdx = swapBlue ? 2 : 0, baseDiv = LAB_BASE / 256;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstep;
+        uint8_t* d = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++, s += scn, d += 3) {
+            int L, u, v;
+            trilinear(s[bIdx] * baseDiv, s[1] * baseDiv, s[bIdx ^ 2] * baseDiv, &L, &u, &v);
+            d[0] = sat8(L / baseDiv); d[1] = sat8(u / baseDiv); d[2] = sat8(v / baseDiv);
+        }
+    }
+}
+
+void orc_cvtLuvtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int srgb)
+{
+    buildLuvTables();
+    const int blueIdx = swapBlue ? 2 : 0, BASE = 1 << 14, shift = LAB_SHIFT + (14 - INV_GAMMA_SHIFT);
+    int C[9];
+    for (int i = 0; i < 3; i++) {
+        const double ls = (double)(1 << LAB_SHIFT);
+        C[i + blueIdx * 3] = (int)lrint(ls * XYZ2sRGB_D65[i]);
+        C[i + 3] = (int)lrint(ls * XYZ2sRGB_D65[i + 3]);
+        C[i + (blueIdx ^ 2) * 3] = (int)lrint(ls * XYZ2sRGB_D65[i + 6]);
+    }
+    for (int yy = 0; yy < h; yy++) {
+        const uint8_t* s = src + (size_t)yy * sstep;
+        uint8_t* d = dst + (size_t)yy * dstep;
+        for (int xx = 0; xx < w; xx++, s += 3, d += dcn) {
+            const int LL = s[0], uu = s[1], vv = s[2];
+            const int y = LabToYF_b[LL * 2];
+            const int up = LuToUp_b[LL * 256 + uu], vp = LvToVp_b[LL * 256 + vv];
+            const long long xv = (long long)up * (long long)vp;
+            int x = (int)(xv / BASE);
+            x = (int)((long long)y * x / BASE);
+            const long long vpl = (12 * 13 * 100 * (LUT_BASE / 1024)) * (long long)(vp * LL);
+            long long zp = vpl - xv * (255 / 3);
+            zp /= BASE;
+            const long long zq = zp - (long long)(5 * 255 * BASE);
+            const int zm = (int)(y * zq / BASE);
+            int z = zm / 256 + zm / 65536;
+            x = x < 0 ? 0 : x > 2 * BASE ? 2 * BASE : x;
+            z = z < 0 ? 0 : z > 2 * BASE ? 2 * BASE : z;
+            int ro = descale(C[0] * x + C[1] * y + C[2] * z, shift);
+            int go = descale(C[3] * x + C[4] * y + C[5] * z, shift);
+            int bo = descale(C[6] * x + C[7] * y + C[8] * z, shift);
+            ro = ro < 0 ? 0 : ro > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : ro;
+            go = go < 0 ? 0 : go > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : go;
+            bo = bo < 0 ? 0 : bo > INV_GAMMA_TAB - 1 ? INV_GAMMA_TAB - 1 : bo;
+            if (srgb) { ro = sRGBInvGammaTab_b[ro]; go = sRGBInvGammaTab_b[go]; bo = sRGBInvGammaTab_b[bo]; }
+            else { ro = ((ro << 8) - ro) >> INV_GAMMA_SHIFT; go = ((go << 8) - go) >> INV_GAMMA_SHIFT; bo = ((bo << 8) - bo) >> INV_GAMMA_SHIFT; }
+            d[0] = sat8(bo); d[1] = sat8(go); d[2] = sat8(ro);
+            if (dcn == 4) d[3] = 255;
+        }
+    }
+}
+
 /* the tables themselves, for a direct comparison with the library's (tests): which = 0 sRGBGamma (256), 1 LabCbrt (3072), 2 sRGBInvGamma (4096),
- * 3 LabToYF (512) as uint16; 4 abToXZ (36864) as int32 */
+ * 3 LabToYF (512) as uint16; 4 abToXZ (36864) as int32; 5 the 33^3 x 3 RGB -> Luv table as int16; 6 / 7 LuToUp / LvToVp (65536) as int32 */
 int orc_labTable(int which, void* out)
 {
     buildTables();
@@ -186,6 +326,9 @@ int orc_labTable(int which, void* out)
     case 2: memcpy(out, sRGBInvGammaTab_b, sizeof sRGBInvGammaTab_b); return INV_GAMMA_TAB;
     case 3: memcpy(out, LabToYF_b, sizeof LabToYF_b); return 512;
     case 4: memcpy(out, abToXZ_b, sizeof abToXZ_b); return ABXZ_N;
+    case 5: buildLuvTables(); memcpy(out, RGB2LuvLUT, sizeof RGB2LuvLUT); return LUT_DIM * LUT_DIM * LUT_DIM * 3;      /* int16 */
+    case 6: buildLuvTables(); memcpy(out, LuToUp_b, sizeof LuToUp_b); return 65536;                                     /* int32 */
+    case 7: buildLuvTables(); memcpy(out, LvToVp_b, sizeof LvToVp_b); return 65536;
     }
     return -1;
 }

@@ -85,6 +85,8 @@ int orc_LKOpticalFlowLevel(const uint8_t* I, size_t stepI, const int16_t* derivI
 /* color_lab.c: CV_8U L*a*b* (RGB2Lab_b color_lab.cpp:1573, Lab2RGBinteger :2399) */
 void orc_cvtBGRtoLab8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int srgb);
 void orc_cvtLabtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int srgb);
+void orc_cvtBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue);      /* sRGB only */
+void orc_cvtLuvtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int srgb);
 int orc_labTable(int which, void* out);
 void orc_cvtHSVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int fullRange, int lanes);
 

@@ -261,9 +261,22 @@ _LAB_FWD = {44: (0, 1), 45: (1, 1), 74: (0, 0), 75: (1, 0)}
 _LAB_INV = {56: (0, 1), 57: (1, 1), 78: (0, 0), 79: (1, 0)}
 
 
+_LUV_FWD = {50: 0, 51: 1}                                                     # BGR2Luv, RGB2Luv (sRGB; the linear codes 76 / 77 take the float path)
+_LUV_INV = {58: (0, 1), 59: (1, 1), 80: (0, 0), 81: (1, 0)}                    # Luv2BGR, Luv2RGB, Luv2LBGR, Luv2LRGB
+
+
 def orc_cvtColorLab(src, code, dcn=3):
     o = oracle()
     h, w = src.shape[:2]
+    if code in _LUV_FWD:
+        dst = np.empty((h, w, 3), np.uint8)
+        o.orc_cvtBGRtoLuv8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], _LUV_FWD[code])
+        return dst
+    if code in _LUV_INV:
+        swap, srgb = _LUV_INV[code]
+        dst = np.empty((h, w, dcn), np.uint8)
+        o.orc_cvtLuvtoBGR8u(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, srgb)
+        return dst
     if code in _LAB_FWD:
         swap, srgb = _LAB_FWD[code]
         dst = np.empty((h, w, 3), np.uint8)

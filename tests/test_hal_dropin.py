@@ -58,6 +58,8 @@ def _calls(o, src8, src8c3, srcf):
     out["xyz2rgb"] = o.ref_cvtColorMisc(src8c3, 35)
     out["lab"] = o.ref_cvtColor(src8c3, 44, 3)
     out["lab2lrgb"] = o.ref_cvtColor(src8c3, 79, 3)
+    out["luv"] = o.ref_cvtColor(src8c3, 51, 3)
+    out["luv2bgr"] = o.ref_cvtColor(src8c3, 58, 3)
     out["bgr565"] = o.ref_cvtColorMisc(src8c3, 12)
     out["bgr5552bgra"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 28)
     out["5652gray"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 21)

@@ -1,4 +1,4 @@
-"""cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR on the GPU (csrc/color_lab.hip) against oracle/color_lab.c, which tests/test_oracle_lab.py pins to the
+"""cv_hal_cvtBGRtoLab / cv_hal_cvtLabtoBGR (L*a*b* and L*u*v*, CV_8U) on the GPU (csrc/color_lab.hip) against oracle/color_lab.c, which tests/test_oracle_lab.py pins to the
 reference for every 8-bit colour: again EVERY colour in both directions (sRGB and linear), then the channel orders, 4-channel forms, ragged widths,
 unaligned views and host-resident images."""
 import numpy as np
@@ -26,7 +26,7 @@ def all_colours():
     return img
 
 
-@pytest.mark.parametrize("code", [44, 75, 56, 79])
+@pytest.mark.parametrize("code", [44, 75, 56, 79, 50, 51, 58, 81])
 def test_every_8bit_colour(cv, code):
     img = all_colours()
     got = cv.cvtColor(torch.from_numpy(img).cuda(), code).cpu().numpy()
@@ -35,7 +35,7 @@ def test_every_8bit_colour(cv, code):
     assert bad.size == 0, (code, bad.size, img.reshape(-1, 3)[bad[:5]], want.reshape(-1, 3)[bad[:5]], got.reshape(-1, 3)[bad[:5]])
 
 
-@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("code", [44, 45, 74, 75, 50, 51])
 @pytest.mark.parametrize("scn", [3, 4])
 def test_forward(cv, code, scn):
     rng = np.random.default_rng(code * 10 + scn)
@@ -49,7 +49,7 @@ def test_forward(cv, code, scn):
     assert np.array_equal(cv.cvtColor(view, code).cpu().numpy(), orc.orc_cvtColorLab(np.ascontiguousarray(view.cpu().numpy()), code))
 
 
-@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("code", [56, 57, 78, 79, 58, 59, 80, 81])
 @pytest.mark.parametrize("dcn", [3, 4])
 def test_inverse(cv, code, dcn):
     rng = np.random.default_rng(code * 10 + dcn)
@@ -68,5 +68,7 @@ def test_declines(cv):
         cv.cvtColor(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), 44)
     L = cv._lib.lib
     a = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
-    assert L.mi355cv_cvtBGRtoLab(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 0, 3, False, False, True) == 1          # L*u*v*: not built, the reference's path runs
+    assert L.mi355cv_cvtBGRtoLab(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 0, 3, False, False, False) == 1         # L*u*v* from linear RGB: the reference's float path runs
+    with pytest.raises(NotImplementedError):
+        cv.cvtColor(a, cv.COLOR_LBGR2Luv)
     assert L.mi355cv_cvtLabtoBGR(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 5, 3, False, True, True) == 1           # CV_32F

@@ -19,7 +19,7 @@ def all_colours():
     return img
 
 
-@pytest.mark.parametrize("code", [44, 75, 56, 79])
+@pytest.mark.parametrize("code", [44, 75, 56, 79, 50, 51, 58, 81])            # L*a*b* both ways, then L*u*v*: BGR2Luv, RGB2Luv, Luv2BGR, Luv2LRGB
 def test_every_8bit_colour(code):
     img = all_colours()
     want = orc.ref_cvtColor(img, code, 3)
@@ -28,7 +28,7 @@ def test_every_8bit_colour(code):
     assert bad.size == 0, (code, bad.size, img.reshape(-1, 3)[bad[:5]], want.reshape(-1, 3)[bad[:5]], got.reshape(-1, 3)[bad[:5]])
 
 
-@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("code", [44, 45, 74, 75, 50, 51])
 @pytest.mark.parametrize("scn", [3, 4])
 def test_forward_codes_and_channels(code, scn):
     rng = np.random.default_rng(code * 10 + scn)
@@ -37,7 +37,7 @@ def test_forward_codes_and_channels(code, scn):
         assert np.array_equal(orc.orc_cvtColorLab(img, code), orc.ref_cvtColor(img, code, 3)), (code, scn, h, w)
 
 
-@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("code", [56, 57, 78, 79, 58, 59, 80, 81])
 @pytest.mark.parametrize("dcn", [3, 4])
 def test_inverse_codes_and_channels(code, dcn):
     rng = np.random.default_rng(code * 10 + dcn)
@@ -66,3 +66,11 @@ def test_library_tables_equal_the_oracle_tables():
     ramp = np.sign(i * 108) * (np.abs(i * 108) // 841) - 290
     cube = ((i * i >> 14) * i) >> 14
     assert np.array_equal(ab, np.where(i <= 3390, ramp, cube))
+    # L*u*v*: the 33^3 grid (library: (L, u, v, 0) per point) and the two 256 x 256 tables of the inverse
+    grid, want = np.zeros(33 ** 3 * 4, np.int16), np.zeros(33 ** 3 * 3, np.int16)
+    assert _lib.lib.mi355cv_labTable(4, grid.ctypes.data) == grid.size and o.orc_labTable(5, want.ctypes.data) == want.size
+    assert np.array_equal(grid.reshape(-1, 4)[:, :3], want.reshape(-1, 3)) and not grid.reshape(-1, 4)[:, 3].any()
+    for mine, theirs in ((5, 6), (6, 7)):
+        a, b = np.zeros(65536, np.int32), np.zeros(65536, np.int32)
+        assert _lib.lib.mi355cv_labTable(mine, a.ctypes.data) == 65536 and o.orc_labTable(theirs, b.ctypes.data) == 65536
+        assert np.array_equal(a, b), mine

@@ -1,17 +1,34 @@
-"""cv::cvtColor BGR <-> L*a*b* on a 4K CV_8UC3 frame: GPU (HIP events, device-resident) vs the reference on the box's host threads."""
+"""cv::cvtColor BGR <-> L*a*b* / L*u*v* on a 4K CV_8UC3 frame: GPU (HIP events, device-resident) vs the reference on the box's host threads."""
 import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import opencv_amd as cv
-from tune_r02 import timeit  # noqa: E402
+
+
+def timeit(fn, n=30, warm=8):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / n * 1e3)
+    return min(ts)
+
+
 import orc
 cv.set_async(True)
 rng = np.random.default_rng(1)
 img = rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)
 d = torch.from_numpy(img).cuda(); out = torch.empty_like(d)
-for name, code in [("BGR2Lab", 44), ("LBGR2Lab", 74), ("Lab2BGR", 56), ("Lab2LBGR", 78)]:
+orc.ref_cvtColor(img[:64], 44, 3)                                # the reference builds its tables on the first call
+for name, code in [("BGR2Lab", 44), ("LBGR2Lab", 74), ("Lab2BGR", 56), ("Lab2LBGR", 78), ("BGR2Luv", 50), ("Luv2BGR", 58), ("Luv2LBGR", 80)]:
     us = timeit(lambda: cv.cvtColor(d, code, dst=out), n=20, warm=3)
     t0 = time.perf_counter(); orc.ref_cvtColor(img, code, 3); cpu = (time.perf_counter() - t0) * 1e3
     mb = 2 * img.size / 1e6
