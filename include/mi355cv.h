@@ -356,13 +356,15 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const mi355cv_uchar* src_data, size_t src_st
 /* replace hal_ni_cvtBGRtoLab (hal_replacement.hpp:535; caller hal::cvtBGRtoLab color_lab.cpp:4230) and hal_ni_cvtLabtoBGR (:550; caller :4327): CV_8U
  * L*a*b* from / to sRGB (COLOR_BGR2Lab ...) or linear RGB (COLOR_LBGR2Lab ...) -- the reference's bit-exact integer paths RGB2Lab_b (:1573) and
  * Lab2RGBinteger (:2399) -- and CV_8U L*u*v* (isLab == false): sRGB -> Luv through the reference's 33^3 interpolation table (RGB2Luvinterpolate :3276),
- * Luv -> sRGB / linear RGB by Luv2RGBinteger (:3556).  CV_32F, and L*u*v* from linear RGB (the reference's float path), decline (csrc/color_lab.hip) */
+ * Luv -> sRGB / linear RGB by Luv2RGBinteger (:3556) -- and CV_32F L*a*b* (RGB2Lab_f :1895, Lab2RGBfloat :2169, vector bodies and scalar row tails as the
+ * reference has them).  L*u*v* on CV_32F, and L*u*v* from linear RGB (the reference's float path), decline (csrc/color_lab.hip) */
 MI355CV_API int mi355cv_cvtBGRtoLab(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, int scn, bool swapBlue, bool isLab, bool srgb);
 MI355CV_API int mi355cv_cvtLabtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, int dcn, bool swapBlue, bool isLab, bool srgb);
 /* diagnostics: the host-built tables behind the two hooks (0 gamma 256 x u16, 1 cbrt 3072 x u16, 2 invGamma 4096 x u16, 3 (y | ify << 16) 256 x u32,
- * 4 RGB -> Luv grid 33^3 x 4 x i16, 5 / 6 LuToUp / LvToVp 65536 x i32); returns the entry count, needs no GPU */
+ * 4 RGB -> Luv grid 33^3 x 4 x i16, 5 / 6 LuToUp / LvToVp 65536 x i32, 7 RGB -> Lab grid, 8 / 9 the cube-root / inverse-gamma splines 4096 x f32);
+ * returns the entry count, needs no GPU */
 MI355CV_API int mi355cv_labTable(int which, void* out);
 /* replace hal_ni_cvtBGRtoBGR5x5 (:411), cvtBGR5x5toBGR (:427), cvtBGR5x5toGray (:470), cvtGraytoBGR5x5 (:484); callers color_rgb.dispatch.cpp */
 MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
@@ -458,6 +460,11 @@ MI355CV_API int mi355cv_matchTemplateBatch(const mi355cv_uchar* img_data, size_t
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355cv_uchar* src_data, size_t src_step,
         mi355cv_uchar* sum_data, size_t sum_step, mi355cv_uchar* sqsum_data, size_t sqsum_step,
         mi355cv_uchar* tilted_data, size_t tilted_step, int width, int height, int cn);
+
+/* cv::integral over `nframes` device-resident CV_8UC1 frames: sums in CV_32S or CV_64F (sdepth), optional CV_64F squared sums (sqsum_data may be
+ * NULL), each (height+1) x (width+1); strides in bytes; one set of launches for the whole batch */
+MI355CV_API int mi355cv_integralBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* sum_data, size_t sum_step,
+        size_t sum_frame_stride, mi355cv_uchar* sqsum_data, size_t sqsum_step, size_t sqsum_frame_stride, int nframes, int width, int height, int sdepth);
 
 /* --------------------------------------------------- batches of device-resident frames (frames are the unit that shards)
  * The frame-batched forms of the hooks above: `nframes` whole images of identical geometry, `*_frame_stride` bytes apart, borders per frame.

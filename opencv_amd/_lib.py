@@ -148,6 +148,7 @@ def _load():
         "mi355cv_matchTemplate": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_int]),
         "mi355cv_matchTemplateBatch": (c_int, [c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_sz, c_int]),
         "mi355cv_integral": (c_int, [c_int, c_int, c_int, c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
+        "mi355cv_integralBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int]),
         "mi355cv_cvtBGRtoGray": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, ctypes.c_bool]),
         "mi355cv_cvtGraytoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int]),
         "mi355cv_cvtBGRtoBGR": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_bool]),

@@ -11,14 +11,18 @@
 // inverse) and converts 32 rows x 256 pixels, a lane owning 4 consecutive pixels of a row (dword traffic, pix4.h).  The a/b -> X/Z table of the
 // reference (initLUTforABXZ :1086, 147 KB) is two integer formulas, evaluated instead of looked up.
 // HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.
+// L*a*b* on CV_32F images: the reference's float paths in the form of their vector bodies (RGB2Lab_f :1895 -- for sRGB the same 33^3 grid interpolation as
+// L*u*v*, for linear RGB a cubic spline for the cube root --, Lab2RGBfloat :2169); the last width % 8 pixels of a row in the form of its scalar tails (cubeRoot(),
+// divisions): the oracle written the same way equals the reference bit for bit on every case tested.
 // L*u*v* (isLab == false), CV_8U: sRGB -> Luv by trilinear interpolation in the reference's 33^3 fixed-point table (RGB2Luvinterpolate :3276), Luv ->
-// sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  Declined (the reference's own path then runs): CV_32F images, and
-// L*u*v* from LINEAR RGB, which the reference computes in float.
+// sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  Declined (the reference's own path then runs): L*u*v* on CV_32F
+// images, and L*u*v* from LINEAR RGB, which the reference computes in float.
 #include "rt.h"
 #include "pix4.h"
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 using namespace mi355;
 
@@ -132,6 +136,10 @@ struct LuvTabs {
     short lut[LUV_GRID * 4];
     int up[256 * 256];
     int vp[256 * 256];
+    // CV_32F L*a*b*: the RGB -> Lab grid of the same builder (L, a, b, 0) and the two cubic splines (1024 knots x (f, b, c, d), splineBuild color_lab.cpp:20)
+    short labGrid[LUV_GRID * 4];
+    float cbrtSpline[1024 * 4];
+    float invGammaSpline[1024 * 4];
 };
 LuvTabs* g_luvHost;                    // 0.8 MB: allocated when first needed
 std::once_flag g_luvHostOnce;
@@ -147,8 +155,13 @@ void buildLuvHost()
     float dd = (float)(kD65[0] + kD65[1] * 15.0 + kD65[2] * 3.0);
     dd = 1.f / maxSoft(dd, eps);
     const float un = dd * 52.f * (float)kD65[0], vn = dd * 117.f * (float)kD65[1];
-    float C[9];                                                     // columns reversed: the table's first axis is blue
-    for (int i = 0; i < 3; i++) { C[i * 3 + 2] = (float)kRgb2Xyz[i * 3]; C[i * 3 + 1] = (float)kRgb2Xyz[i * 3 + 1]; C[i * 3] = (float)kRgb2Xyz[i * 3 + 2]; }
+    float C[9], S[9];                                               // columns reversed: the table's first axis is blue; S = the Lab rows / white point
+    const double sw[3] = {1.0 / kD65[0], 1.0, 1.0 / kD65[2]};
+    for (int i = 0; i < 3; i++) {
+        C[i * 3 + 2] = (float)kRgb2Xyz[i * 3]; C[i * 3 + 1] = (float)kRgb2Xyz[i * 3 + 1]; C[i * 3] = (float)kRgb2Xyz[i * 3 + 2];
+        S[i * 3] = (float)(kRgb2Xyz[i * 3 + 2] * sw[i]); S[i * 3 + 1] = (float)(kRgb2Xyz[i * 3 + 1] * sw[i]); S[i * 3 + 2] = (float)(kRgb2Xyz[i * 3] * sw[i]);
+    }
+    const float f9033 = (float)(29 * 29 * 29) / 27.f;
     const float lld = (float)(LUV_DIM - 1), lbase = (float)LBASE, f9of4 = 9.f / 4.f;
     float gam[LUV_DIM];
     for (int p = 0; p < LUV_DIM; p++) gam[p] = gammaFwd((float)p / lld);
@@ -173,7 +186,54 @@ void buildLuvHost()
                 e[1] = (short)lrintf((lbase * (u - uLow)) / uRange);
                 e[2] = (short)lrintf((lbase * (v - vLow)) / vRange);
                 e[3] = 0;
+                // the Lab grid point (initLUTforLABLUVs16 :1171-1187)
+                float s0 = R * S[0], s1 = G * S[1], s2 = B * S[2];
+                const float Xl = (s0 + s1) + s2;
+                s0 = R * S[3]; s1 = G * S[4]; s2 = B * S[5];
+                const float Yl = (s0 + s1) + s2;
+                s0 = R * S[6]; s1 = G * S[7]; s2 = B * S[8];
+                const float Zl = (s0 + s1) + s2;
+                const float FX = Xl > lthresh ? cubeRootTurkowski(Xl) : fmaf(Xl, lscale, lbias);
+                const float FY = Yl > lthresh ? cubeRootTurkowski(Yl) : fmaf(Yl, lscale, lbias);
+                const float FZ = Zl > lthresh ? cubeRootTurkowski(Zl) : fmaf(Zl, lscale, lbias);
+                const float Ll = Yl > lthresh ? (116.f * FY - 16.f) : (f9033 * Yl);
+                const float al = 500.f * (FX - FY), bl = 200.f * (FY - FZ);
+                short* g = t->labGrid + 4 * ((r * LUV_DIM + q) * LUV_DIM + p);
+                g[0] = (short)lrintf((lbase * Ll) / 100.f);
+                g[1] = (short)lrintf((lbase * (al + 128.f)) / 256.f);
+                g[2] = (short)lrintf((lbase * (bl + 128.f)) / 256.f);
+                g[3] = 0;
             }
+    {
+        // cubic splines over 1024 intervals (splineBuild color_lab.cpp:20-47, float arithmetic): Lab's f() on [0, 1.5] and the inverse sRGB transfer on [0, 1]
+        std::vector<float> f(1025), ig(1025);
+        const float cbScale = 1.f / ((float)(1024 * 2) / 3.f), gScale = 1.f / 1024.f;
+        for (int i = 0; i <= 1024; i++) {
+            const float x = cbScale * (float)i;
+            f[i] = x < lthresh ? fmaf(x, lscale, lbias) : cubeRootTurkowski(x);
+            ig[i] = gammaInv(gScale * (float)i);
+        }
+        auto build = [](const std::vector<float>& fv, float* tab) {
+            const int n = 1024;
+            float cn = 0.f;
+            tab[0] = tab[1] = 0.f;
+            for (int i = 1; i < n; i++) {
+                const float tt = ((fv[i + 1] - fv[i] * 2.f) + fv[i - 1]) * 3.f;
+                const float l = 1.f / (4.f - tab[(i - 1) * 4]);
+                tab[i * 4] = l; tab[i * 4 + 1] = (tt - tab[(i - 1) * 4 + 1]) * l;
+            }
+            for (int j = 0; j < n; j++) {
+                const int i = n - j - 1;
+                const float c = tab[i * 4 + 1] - tab[i * 4] * cn;
+                const float b = (fv[i + 1] - fv[i]) - (cn + c * 2.f) / 3.f;
+                const float d = (cn - c) / 3.f;
+                tab[i * 4] = fv[i]; tab[i * 4 + 1] = b; tab[i * 4 + 2] = c; tab[i * 4 + 3] = d;
+                cn = c;
+            }
+        };
+        build(f, t->cbrtSpline);
+        build(ig, t->invGammaSpline);
+    }
     for (int LL = 0; LL < 256; LL++) {
         const float L = (float)(LL * 100) / f255;
         for (int uu = 0; uu < 256; uu++) {
@@ -448,6 +508,149 @@ __global__ __launch_bounds__(256) void k_luv2bgr_u8(const uchar* __restrict__ sr
     }
 }
 
+// ---------------------------------------------------------------------------------- CV_32F L*a*b* (one pixel per lane)
+// splineInterpolate (color_lab.cpp:50-58): the knot below x, then Horner on its four coefficients (one 16-byte load)
+__device__ __forceinline__ float splineAt(float x, const float* __restrict__ tab)
+{
+    int ix = (int)x;
+    ix = max(0, min(1023, ix));
+    x -= (float)ix;
+    const float4 t = *reinterpret_cast<const float4*>(tab + 4 * ix);
+    float r = t.w * x + t.z;
+    r = r * x + t.y;
+    return r * x + t.x;
+}
+
+struct CoefF9 { float c[9]; };
+
+// cv::cubeRoot (core/src/mathfuncs.cpp:104-140), which the scalar row tails of RGB2Lab_f call: Turkowski's rational on the float mantissa in double,
+// ROUNDED to float (the softfloat version used for the tables truncates)
+__device__ __forceinline__ float cubeRootRounded(float value)
+{
+    const uint32_t vi = __float_as_uint(value), ix = vi & 0x7fffffffu, sgn = vi & 0x80000000u;
+    int ex = (int)(ix >> 23) - 127, shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3;
+    const double fr = __uint_as_float((ix & ((1u << 23) - 1)) | ((uint32_t)(shx + 127) << 23));
+    const double num = (((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr + 119.1654824285581628956914143) * fr
+                        + 13.43250139086239872172837314) * fr + 0.1636161226585754240958355063;
+    const double den = (((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr + 168.5254414101568283957668343) * fr
+                        + 33.9905941350215598754191872) * fr + 1.0;
+    const float q = (float)(num / den);
+    const uint32_t qi = (uint32_t)((int)__float_as_uint(q) + (ex << 23) + (int)sgn) & ((vi << 1) != 0 ? 0xffffffffu : 0u);
+    return __uint_as_float(qi);
+}
+
+// RGB2Lab_f, sRGB (useInterpolation, color_lab.cpp:1955-2045): clip, 14-bit fixed point, trilinear interpolation in the RGB -> Lab grid, back to float
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2lab_f32_grid(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                           const LuvTabs* __restrict__ tabs, int bIdx)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+    float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+    auto clip = [](float v) { return v < 0.f ? 0.f : v <= 1.f ? v : 1.f; };
+    const int cx = (int)__builtin_rintf(clip(s[bIdx]) * 16384.f), cy = (int)__builtin_rintf(clip(s[1]) * 16384.f), cz = (int)__builtin_rintf(clip(s[bIdx ^ 2]) * 16384.f);
+    const int tx = cx >> 9, ty = cy >> 9, tz = cz >> 9, fx = (cx >> 5) & 15, fy = (cy >> 5) & 15, fz = (cz >> 5) & 15;
+    int aL = 0, aA = 0, aB = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int dp = i >> 2, dq = (i >> 1) & 1, dr = i & 1;
+        const int pp = min(tx + dp, LUV_DIM - 1), qq = min(ty + dq, LUV_DIM - 1), rr = min(tz + dr, LUV_DIM - 1);       // the last grid plane repeats (fill_one :1112)
+        const short4 e = *reinterpret_cast<const short4*>(tabs->labGrid + 4 * ((rr * LUV_DIM + qq) * LUV_DIM + pp));
+        const int w = __mul24(__mul24(dp ? fx : 16 - fx, dq ? fy : 16 - fy), dr ? fz : 16 - fz);
+        aL += __mul24(e.x, w); aA += __mul24(e.y, w); aB += __mul24(e.z, w);
+    }
+    const int iL = descale(aL, 12), ia = descale(aA, 12), ib = descale(aB, 12);
+    d[0] = (float)iL * (100.0f / 16384.f);
+    float t = (float)ia * (256.0f / 16384.f); d[1] = t + -128.f;
+    t = (float)ib * (256.0f / 16384.f); d[2] = t + -128.f;
+}
+
+// RGB2Lab_f, linear RGB (the float branch, vector body :2062-2130): XYZ, f() through the spline, L / a / b
+template <int SCN>
+__global__ __launch_bounds__(256) void k_bgr2lab_f32_lin(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                          const LuvTabs* __restrict__ tabs, CoefF9 k)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+    float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+    auto clip = [](float v) { return v < 0.f ? 0.f : v <= 1.f ? v : 1.f; };
+    const float R = clip(s[0]), G = clip(s[1]), B = clip(s[2]);
+    if (x >= (W & ~7)) {
+        // the last W % 8 pixels of a row are the reference's scalar tail (:2132-2157): sums left to right, cubeRoot() instead of the spline
+        const float a16 = 16.f / 116.f;
+        float t0 = R * k.c[0], t1 = G * k.c[1], t2 = B * k.c[2]; const float X = (t0 + t1) + t2;
+        t0 = R * k.c[3]; t1 = G * k.c[4]; t2 = B * k.c[5]; const float Y = (t0 + t1) + t2;
+        t0 = R * k.c[6]; t1 = G * k.c[7]; t2 = B * k.c[8]; const float Z = (t0 + t1) + t2;
+        float FX, FY, FZ, L;
+        if (X > 0.008856f) FX = cubeRootRounded(X); else { FX = 7.787f * X; FX = FX + a16; }
+        if (Y > 0.008856f) FY = cubeRootRounded(Y); else { FY = 7.787f * Y; FY = FY + a16; }
+        if (Z > 0.008856f) FZ = cubeRootRounded(Z); else { FZ = 7.787f * Z; FZ = FZ + a16; }
+        if (Y > 0.008856f) { L = 116.f * FY; L = L - 16.f; } else L = 903.3f * Y;
+        d[0] = L; d[1] = 500.f * (FX - FY); d[2] = 200.f * (FY - FZ);
+        return;
+    }
+    float t2 = B * k.c[2], t1 = G * k.c[1] + t2; const float X = R * k.c[0] + t1;
+    t2 = B * k.c[5]; t1 = G * k.c[4] + t2; const float Y = R * k.c[3] + t1;
+    t2 = B * k.c[8]; t1 = G * k.c[7] + t2; const float Z = R * k.c[6] + t1;
+    const float tabScale = (float)(1024 * 2) / 3.f;
+    const float FX = splineAt(X * tabScale, tabs->cbrtSpline), FY = splineAt(Y * tabScale, tabs->cbrtSpline), FZ = splineAt(Z * tabScale, tabs->cbrtSpline);
+    float L;
+    if (Y > 0.008856f) { L = 116.f * FY; L = L + -16.f; } else L = 903.3f * Y;
+    d[0] = L; d[1] = 500.f * (FX - FY); d[2] = 200.f * (FY - FZ);
+}
+
+// Lab2RGBfloat (vector body :2216-2325): L -> Y, a / b -> X / Z (products by reciprocal constants), XYZ -> RGB, clip, inverse sRGB transfer through the spline
+template <int DCN, bool SRGB>
+__global__ __launch_bounds__(256) void k_lab2bgr_f32(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                      const LuvTabs* __restrict__ tabs, CoefF9 k)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || yy >= H) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)yy * sstep) + (size_t)x * 3;
+    float* d = reinterpret_cast<float*>(dst + (size_t)yy * dstep) + (size_t)x * DCN;
+    const float li = s[0], ai = s[1], bi = s[2];
+    const float fThresh = 6.f / 29.f, c16_116 = 16.0f / 116.0f;
+    const float inv903 = 1.f / 903.3f, inv116 = 1.f / 116.0f, pinv500 = 1.f / 500.f, ninv200 = -1.f / 200.f, inv7787 = 1.f / 7.787f;
+    const bool tail = x >= (W & ~7);                  // the reference's scalar row tail (:2343-2385) divides where its vector body multiplies by a reciprocal
+    float y, fy;
+    if (li <= 8.f) { y = tail ? li / 903.3f : li * inv903; fy = 7.787f * y; fy = fy + c16_116; }
+    else { fy = tail ? (li + 16.0f) / 116.0f : (li + 16.0f) * inv116; y = fy * fy; y = y * fy; }
+    float fxz[2];
+    if (tail) { fxz[0] = ai / 500.0f; fxz[0] = fxz[0] + fy; fxz[1] = bi / 200.0f; fxz[1] = fy - fxz[1]; }
+    else { fxz[0] = ai * pinv500; fxz[0] = fxz[0] + fy; fxz[1] = bi * ninv200; fxz[1] = fxz[1] + fy; }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float f = fxz[j];
+        if (f <= fThresh) fxz[j] = tail ? (f - c16_116) / 7.787f : (f - c16_116) * inv7787;
+        else { const float t = f * f; fxz[j] = t * f; }
+    }
+    const float xv = fxz[0], zv = fxz[1];
+    float ro, go, bo;
+    if (tail) {
+        float t0 = k.c[0] * xv, t1 = k.c[1] * y, t2 = k.c[2] * zv; ro = (t0 + t1) + t2;
+        t0 = k.c[3] * xv; t1 = k.c[4] * y; t2 = k.c[5] * zv; go = (t0 + t1) + t2;
+        t0 = k.c[6] * xv; t1 = k.c[7] * y; t2 = k.c[8] * zv; bo = (t0 + t1) + t2;
+    } else {
+        float t2 = k.c[2] * zv, t1 = k.c[1] * y + t2; ro = k.c[0] * xv + t1;
+        t2 = k.c[5] * zv; t1 = k.c[4] * y + t2; go = k.c[3] * xv + t1;
+        t2 = k.c[8] * zv; t1 = k.c[7] * y + t2; bo = k.c[6] * xv + t1;
+    }
+    ro = ro < 1.f ? ro : 1.f; ro = ro > 0.f ? ro : 0.f;
+    go = go < 1.f ? go : 1.f; go = go > 0.f ? go : 0.f;
+    bo = bo < 1.f ? bo : 1.f; bo = bo > 0.f ? bo : 0.f;
+    if (SRGB) {
+        ro = splineAt(ro * 1024.f, tabs->invGammaSpline);
+        go = splineAt(go * 1024.f, tabs->invGammaSpline);
+        bo = splineAt(bo * 1024.f, tabs->invGammaSpline);
+    }
+    d[0] = ro; d[1] = go; d[2] = bo;
+    if (DCN == 4) d[3] = 1.f;
+}
+
 } // namespace
 
 extern "C" {
@@ -456,7 +659,36 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || depth != MI355CV_8U || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (depth == MI355CV_32F && isLab) {
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
+        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+        const LuvTabs* ft = deviceLuvTabs();
+        if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
+        Stager stg; size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * 4, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 12, height, &dds);
+        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        const dim3 grid(divUp(width, 64), divUp(height, 4));
+        const int bIdx = swapBlue ? 2 : 0;
+        if (srgb) {
+            if (scn == 3) hipLaunchKernelGGL((k_bgr2lab_f32_grid<3>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, bIdx);
+            else          hipLaunchKernelGGL((k_bgr2lab_f32_grid<4>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, bIdx);
+        } else {
+            // RGB2Lab_f's constructor (color_lab.cpp:1907-1930): rows scaled by 1 / white point in double, rounded to float, channel order folded in
+            CoefF9 kf; const double sw[3] = {1.0 / kD65[0], 1.0, 1.0 / kD65[2]};
+            for (int i = 0; i < 3; i++) {
+                kf.c[i * 3 + (bIdx ^ 2)] = (float)(sw[i] * kRgb2Xyz[i * 3]);
+                kf.c[i * 3 + 1]          = (float)(sw[i] * kRgb2Xyz[i * 3 + 1]);
+                kf.c[i * 3 + bIdx]       = (float)(sw[i] * kRgb2Xyz[i * 3 + 2]);
+            }
+            if (scn == 3) hipLaunchKernelGGL((k_bgr2lab_f32_lin<3>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, kf);
+            else          hipLaunchKernelGGL((k_bgr2lab_f32_lin<4>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, kf);
+        }
+        noteKernel("k_bgr2lab_f32_%s<%d> grid=%ux%u x256", srgb ? "grid" : "lin", scn, grid.x, grid.y);
+        return stg.finish("cvtBGRtoLab");
+    }
+    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
     // L*u*v* from linear RGB is the reference's float path (RGB2Luv_b color_lab.cpp:3389-3392 interpolates for sRGB only): declined
     if (!isLab && !srgb) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: L*u*v* from linear RGB takes the reference's float path");
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
@@ -499,7 +731,32 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || depth != MI355CV_8U || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (depth == MI355CV_32F && isLab) {
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
+        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+        const LuvTabs* ft = deviceLuvTabs();
+        if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
+        Stager stg; size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
+        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        // Lab2RGBfloat's constructor (color_lab.cpp:2188-2200): XYZ -> RGB columns times the white point, in double, rounded to float
+        CoefF9 kf; const int bi = swapBlue ? 2 : 0;
+        for (int i = 0; i < 3; i++) {
+            kf.c[i + (bi ^ 2) * 3] = (float)(kXyz2Rgb[i] * kD65[i]);
+            kf.c[i + 3]            = (float)(kXyz2Rgb[i + 3] * kD65[i]);
+            kf.c[i + bi * 3]       = (float)(kXyz2Rgb[i + 6] * kD65[i]);
+        }
+        const dim3 grid(divUp(width, 64), divUp(height, 4));
+#define LAUNCH(DCN_, SRGB_) hipLaunchKernelGGL((k_lab2bgr_f32<DCN_, SRGB_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, kf)
+        if (dcn == 3) { if (srgb) LAUNCH(3, true); else LAUNCH(3, false); }
+        else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+        noteKernel("k_lab2bgr_f32<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
+        return stg.finish("cvtLabtoBGR");
+    }
+    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = deviceTabs();
@@ -560,6 +817,9 @@ MI355CV_API int mi355cv_labTable(int which, void* out)
     case 4: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->lut, sizeof g_luvHost->lut); return LUV_GRID * 4;
     case 5: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->up, sizeof g_luvHost->up); return 65536;
     case 6: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->vp, sizeof g_luvHost->vp); return 65536;
+    case 7: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->labGrid, sizeof g_luvHost->labGrid); return LUV_GRID * 4;
+    case 8: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->cbrtSpline, sizeof g_luvHost->cbrtSpline); return 4096;
+    case 9: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->invGammaSpline, sizeof g_luvHost->invGammaSpline); return 4096;
     }
     return -1;
 }

@@ -1120,4 +1120,25 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     return stg.finish("integral");
 }
 
+// frame-batched form for device-resident CV_8UC1 frames: every frame's (H+1) x (W+1) CV_32S (or CV_64F) sum [+ CV_64F squared sum] from the
+// same three launches that serve one frame (integral.hip: the tile index carries the frame) -- the per-frame launches of a single 4K image are
+// latency-bound (2160 waves), a batch fills the machine.  Strides in bytes.
+MI355CV_API int mi355cv_integralBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* sum_data, size_t sum_step, size_t sum_frame_stride,
+                                      uchar* sqsum_data, size_t sqsum_step, size_t sqsum_frame_stride, int nframes, int width, int height, int sdepth)
+{
+    if (disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)) return MI355CV_NOT_IMPLEMENTED;
+    const size_t se = sdepth == D32S ? 4 : 8;
+    if ((sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))) return MI355CV_NOT_IMPLEMENTED;
+    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(sum_data) || (sqsum_data && !isDevicePtr(sqsum_data)))
+        return setError(MI355CV_NOT_IMPLEMENTED, "integralBatch: device-resident frames only");
+    if (nframes == 1) { src_frame_stride = 0; sum_frame_stride = 0; sqsum_frame_stride = 0; }
+    Stager stg;
+    void* taux = stg.scratch(integralTiledAuxBytes(width, height, nframes, sqsum_data != nullptr));
+    if (!taux || !integralTiledU8(src_data, src_step, src_frame_stride, width, height, nframes, sum_data, sum_step / se, sum_frame_stride / se, sdepth == D64F,
+                                  (double*)sqsum_data, sqsum_step / 8, sqsum_frame_stride / 8, taux, stream()))
+        return setError(MI355CV_NOT_IMPLEMENTED, "integralBatch: frame geometry outside the tiled path");
+    return stg.finish("integralBatch");
+}
+
 } // extern "C"

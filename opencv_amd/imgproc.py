@@ -24,7 +24,7 @@ __all__ = ["cvtColor", "cvtColorBatch", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "C
            "COLOR_RGB2BGRA", "COLOR_RGBA2BGR", "COLOR_BGRA2RGB", "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGRA2RGBA",
            "COLOR_RGBA2BGRA", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR", "COLOR_GRAY2RGB", "COLOR_GRAY2BGRA",
            "COLOR_GRAY2RGBA", "COLOR_BGRA2GRAY", "COLOR_RGBA2GRAY",
-           "matchTemplate", "matchTemplateBatch", "integral", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
+           "matchTemplate", "matchTemplateBatch", "integral", "integralBatch", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED",
            "pyrDown", "buildPyramid", "buildPyramidBatch", "cornerHarris", "cornerMinEigenVal", "cornerHarrisBatch", "goodFeaturesToTrack",
            "resize", "warpAffine", "warpPerspective", "SobelBatch", "boxFilterBatch", "sepFilter2DBatch", "thresholdBatch", "resizeBatch", "warpAffineBatch", "warpPerspectiveBatch", "pyrDownBatch", "remap", "convertMaps", "warpPolar", "WARP_FILL_OUTLIERS", "WARP_POLAR_LINEAR", "WARP_POLAR_LOG", "getRotationMatrix2D", "invertAffineTransform",
@@ -361,11 +361,11 @@ def _cvt_misc(src, s, code, dst, dstCn):
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtXYZtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]))
     elif kind in ("to_lab", "to_luv"):                      # the library declines L*u*v* from linear RGB (the reference's float path): NotImplementedError
-        need(s.cn in (3, 4) and s.depth == CV_8U, "BGR2Lab / BGR2Luv: 3 or 4 channels, CV_8U on this path (CV_32F: the reference's float path is not built)")
+        need(s.cn in (3, 4) and (s.depth == CV_8U or (s.depth == CV_32F and kind == "to_lab")), "BGR2Lab: 3 or 4 channels, CV_8U / CV_32F; BGR2Luv: CV_8U on this path")
         out = dst if dst is not None else _like(src, s.h, s.w, 3, s.depth)
         call = lambda d: L.mi355cv_cvtBGRtoLab(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]), kind == "to_lab", bool(k[2]))
     elif kind in ("from_lab", "from_luv"):
-        need(s.cn == 3 and s.depth == CV_8U, "Lab2BGR / Luv2BGR: 3 channels, CV_8U on this path")
+        need(s.cn == 3 and (s.depth == CV_8U or (s.depth == CV_32F and kind == "from_lab")), "Lab2BGR: 3 channels, CV_8U / CV_32F; Luv2BGR: CV_8U on this path")
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtLabtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]), kind == "from_lab", bool(k[2]))
@@ -1325,4 +1325,29 @@ def integral(src, sqsum=False, sdepth=-1):
     rc = L.mi355cv_integral(s.depth, sdepth, CV_64F, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
                             None, 0, s.w, s.h, s.cn)
     _lib.check(rc, "integral")
+    return (sm, sq) if sqsum else sm
+
+
+def integralBatch(frames, sqsum=False, sdepth=-1, dst=None):
+    """cv::integral over [N,H,W] device-resident CV_8U frames -> [N,H+1,W+1] int32 (or float64) sums [, float64 squared sums]: one set of launches
+    for the batch.  `dst`: the array (or pair) a previous call returned."""
+    if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dim() != 3 or frames.dtype != torch.uint8:
+        raise ValueError("integralBatch takes a CUDA(ROCm) uint8 tensor [N,H,W]")
+    CV_32S, CV_64F = 4, 6
+    if sdepth <= 0:
+        sdepth = CV_32S
+    if sdepth not in (CV_32S, CV_64F):
+        raise NotImplementedError("integralBatch: sdepth")
+    n, h, w = (int(v) for v in frames.shape)
+    if dst is not None:
+        sm, sq = dst if sqsum else (dst, None)
+    else:
+        sm = torch.empty((n, h + 1, w + 1), dtype=torch.int32 if sdepth == CV_32S else torch.float64, device=frames.device)
+        sq = torch.empty((n, h + 1, w + 1), dtype=torch.float64, device=frames.device) if sqsum else None
+    s0, a0 = Img(frames[0]), Img(sm[0])
+    b0 = Img(sq[0]) if sqsum else None
+    bind_stream(s0, a0)
+    rc = L.mi355cv_integralBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)), _vp(a0.ptr), a0.step, int(sm.stride(0)) * a0.esz,
+                                 _vp(b0.ptr) if b0 else None, b0.step if b0 else 0, int(sq.stride(0)) * 8 if sqsum else 0, n, w, h, sdepth)
+    _lib.check(rc, "integralBatch")
     return (sm, sq) if sqsum else sm

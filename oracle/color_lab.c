@@ -183,7 +183,7 @@ void orc_cvtLabtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
  * The vector bodies of the reference replace the scalar code's divisions by 2^14 with arithmetic shifts; the two differ only for negative
  * intermediates, which the clamp to [0, 2] that follows maps to the same value -- tests/test_oracle_lab.py compares every colour. */
 enum { LUT_DIM = 33, TRI_SHIFT = 4, TRI_BASE = 1 << TRI_SHIFT };
-static int16_t RGB2LuvLUT[LUT_DIM * LUT_DIM * LUT_DIM * 3];
+static int16_t RGB2LuvLUT[LUT_DIM * LUT_DIM * LUT_DIM * 3], RGB2LabLUT[LUT_DIM * LUT_DIM * LUT_DIM * 3];
 static int LuToUp_b[256 * 256], LvToVp_b[256 * 256];
 static int luvReady;
 
@@ -200,11 +200,34 @@ static void buildLuvTables(void)
     const float un = dd * 52.f * (float)D65[0], vn = dd * 117.f * (float)D65[1];
     float C[9];
     for (int i = 0; i < 3; i++) { C[i * 3 + 2] = (float)sRGB2XYZ_D65[i * 3]; C[i * 3 + 1] = (float)sRGB2XYZ_D65[i * 3 + 1]; C[i * 3] = (float)sRGB2XYZ_D65[i * 3 + 2]; }
+    float S[9];                                                     /* the Lab rows are divided by the white point, in double, then rounded */
+    {
+        const double sw[3] = {1.0 / D65[0], 1.0, 1.0 / D65[2]};
+        for (int i = 0; i < 3; i++) { S[i * 3] = (float)(sRGB2XYZ_D65[i * 3 + 2] * sw[i]); S[i * 3 + 1] = (float)(sRGB2XYZ_D65[i * 3 + 1] * sw[i]); S[i * 3 + 2] = (float)(sRGB2XYZ_D65[i * 3] * sw[i]); }
+    }
+    const float f9033 = (float)(29 * 29 * 29) / 27.f;
     const float lld = (float)(LUT_DIM - 1), lbase = (float)LAB_BASE, f9of4 = 9.f / 4.f;
     for (int p = 0; p < LUT_DIM; p++)
         for (int q = 0; q < LUT_DIM; q++)
             for (int r = 0; r < LUT_DIM; r++) {
                 const float R = applyGamma((float)p / lld), G = applyGamma((float)q / lld), B = applyGamma((float)r / lld);
+                {                                                   /* RGB -> Lab grid (:1171-1187) */
+                    float u0 = R * S[0], u1 = G * S[1], u2 = B * S[2];
+                    const float X = (u0 + u1) + u2;
+                    u0 = R * S[3]; u1 = G * S[4]; u2 = B * S[5];
+                    const float Y = (u0 + u1) + u2;
+                    u0 = R * S[6]; u1 = G * S[7]; u2 = B * S[8];
+                    const float Z = (u0 + u1) + u2;
+                    const float FX = X > lthresh ? cbrtTurkowski(X) : fmaf(X, lscale, lbias);
+                    const float FY = Y > lthresh ? cbrtTurkowski(Y) : fmaf(Y, lscale, lbias);
+                    const float FZ = Z > lthresh ? cbrtTurkowski(Z) : fmaf(Z, lscale, lbias);
+                    const float L = Y > lthresh ? (116.f * FY - 16.f) : (f9033 * Y);
+                    const float a = 500.f * (FX - FY), b = 200.f * (FY - FZ);
+                    int16_t* e = RGB2LabLUT + p * 3 + q * LUT_DIM * 3 + r * LUT_DIM * LUT_DIM * 3;
+                    e[0] = (int16_t)lrintf((lbase * L) / 100.f);
+                    e[1] = (int16_t)lrintf((lbase * (a + 128.f)) / 256.f);
+                    e[2] = (int16_t)lrintf((lbase * (b + 128.f)) / 256.f);
+                }
                 float t0 = R * C[0], t1 = G * C[1], t2 = B * C[2];
                 const float X = (t0 + t1) + t2;
                 t0 = R * C[3]; t1 = G * C[4]; t2 = B * C[5];
@@ -242,7 +265,7 @@ static void buildLuvTables(void)
 
 /* trilinearInterpolate :1352 on the plain 33^3 x 3 table: the packed table of the reference holds, for every cell, its eight corners with the upper
  * neighbours clamped to the last grid point (fill_one :1112) */
-static void trilinear(int cx, int cy, int cz, int* a, int* b, int* c)
+static void trilinear(const int16_t* LUT, int cx, int cy, int cz, int* a, int* b, int* c)
 {
     const int tx = cx >> (14 - 5), ty = cy >> (14 - 5), tz = cz >> (14 - 5);
     const int x = (cx >> (14 - 8 - 1)) & (TRI_BASE - 1), y = (cy >> (14 - 8 - 1)) & (TRI_BASE - 1), z = (cz >> (14 - 8 - 1)) & (TRI_BASE - 1);
@@ -250,7 +273,7 @@ static void trilinear(int cx, int cy, int cz, int* a, int* b, int* c)
     for (int i = 0; i < 8; i++) {
         const int dp = i >> 2, dq = (i >> 1) & 1, dr = i & 1;
         const int pp = tx + dp < LUT_DIM - 1 ? tx + dp : LUT_DIM - 1, qq = ty + dq < LUT_DIM - 1 ? ty + dq : LUT_DIM - 1, rr = tz + dr < LUT_DIM - 1 ? tz + dr : LUT_DIM - 1;
-        const int16_t* e = RGB2LuvLUT + pp * 3 + qq * LUT_DIM * 3 + rr * LUT_DIM * LUT_DIM * 3;
+        const int16_t* e = LUT + pp * 3 + qq * LUT_DIM * 3 + rr * LUT_DIM * LUT_DIM * 3;
         const int w = (dp ? x : TRI_BASE - x) * (dq ? y : TRI_BASE - y) * (dr ? z : TRI_BASE - z);
         acc[0] += e[0] * w; acc[1] += e[1] * w; acc[2] += e[2] * w;
     }
@@ -266,7 +289,7 @@ void orc_cvtBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
         uint8_t* d = dst + (size_t)y * dstep;
         for (int x = 0; x < w; x++, s += scn, d += 3) {
             int L, u, v;
-            trilinear(s[bIdx] * baseDiv, s[1] * baseDiv, s[bIdx ^ 2] * baseDiv, &L, &u, &v);
+            trilinear(RGB2LuvLUT, s[bIdx] * baseDiv, s[1] * baseDiv, s[bIdx ^ 2] * baseDiv, &L, &u, &v);
             d[0] = sat8(L / baseDiv); d[1] = sat8(u / baseDiv); d[2] = sat8(v / baseDiv);
         }
     }
@@ -315,6 +338,191 @@ void orc_cvtLuvtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
     }
 }
 
+/* ----------------------------------------------------------------------------------------------------------------- L*a*b*, CV_32F
+ *   - forward, sRGB     RGB2Lab_f color_lab.cpp:1895 with useInterpolation (:1905): clip to [0, 1], round to 14-bit fixed point, trilinear interpolation in
+ *                       the 33^3 RGB -> Lab grid, back to float (:1955-2045)
+ *   - forward, linear   the float branch (:2047-2160): XYZ rows, cube root through the cubic spline over LabCbrtTab (splineBuild :20, splineInterpolate :50)
+ *   - inverse           Lab2RGBfloat :2169-2395 (Lab2RGB_f :2694 forwards to it), sRGB through the spline over sRGBInvGammaTab
+ * written in the form of the reference's VECTOR bodies (products by reciprocal constants, a*b + c as two roundings -- the SSE3 baseline this file is
+ * compiled for has no fused multiply-add) for the first 8 * (width / 8) pixels of a row, and in the form of its scalar tails (divisions, sums left to
+ * right, cv::cubeRoot instead of the spline) for the last width % 8: tests/test_oracle_lab.py finds the result equal to the reference's bit for bit. */
+static float LabCbrtSpline[1024 * 4], InvGammaSpline[1024 * 4];
+static int splinesReady;
+
+static void splineBuild(const float* f, int n, float* tab)
+{
+    float cn = 0.f;
+    tab[0] = tab[1] = 0.f;
+    for (int i = 1; i < n; i++) {
+        const float t = ((f[i + 1] - f[i] * 2.f) + f[i - 1]) * 3.f;
+        const float l = 1.f / (4.f - tab[(i - 1) * 4]);
+        tab[i * 4] = l; tab[i * 4 + 1] = (t - tab[(i - 1) * 4 + 1]) * l;
+    }
+    for (int j = 0; j < n; j++) {
+        const int i = n - j - 1;
+        const float c = tab[i * 4 + 1] - tab[i * 4] * cn;
+        const float b = (f[i + 1] - f[i]) - (cn + c * 2.f) / 3.f;
+        const float d = (cn - c) / 3.f;
+        tab[i * 4] = f[i]; tab[i * 4 + 1] = b; tab[i * 4 + 2] = c; tab[i * 4 + 3] = d;
+        cn = c;
+    }
+}
+
+static float splineAt(float x, const float* tab, int n)
+{
+    int ix = (int)x;
+    ix = ix < 0 ? 0 : ix > n - 1 ? n - 1 : ix;
+    x -= (float)ix;
+    tab += ix * 4;
+    float r = tab[3] * x + tab[2];
+    r = r * x + tab[1];
+    return r * x + tab[0];
+}
+
+static void buildSplines(void)
+{
+    if (splinesReady) return;
+    static float f[1025], ig[1025];
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
+    const float cbScale = 1.f / ((float)(1024 * 2) / 3.f), gScale = 1.f / 1024.f;
+    for (int i = 0; i <= 1024; i++) {
+        const float x = cbScale * (float)i;
+        f[i] = x < lthresh ? fmaf(x, lscale, lbias) : cbrtTurkowski(x);
+        ig[i] = applyInvGamma(gScale * (float)i);
+    }
+    splineBuild(f, 1024, LabCbrtSpline);
+    splineBuild(ig, 1024, InvGammaSpline);
+    splinesReady = 1;
+}
+
+static float clip01(float v) { return v < 0.f ? 0.f : v <= 1.f ? v : 1.f; }
+
+/* cv::cubeRoot (core/src/mathfuncs.cpp:104-140): the same rational as above, but on a float mantissa and ROUNDED to float */
+static float cubeRootRounded(float value)
+{
+    uint32_t vi; memcpy(&vi, &value, 4);
+    const uint32_t ix = vi & 0x7fffffffu, sgn = vi & 0x80000000u;
+    int ex = (int)(ix >> 23) - 127, shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3;
+    uint32_t fi = (ix & ((1u << 23) - 1)) | ((uint32_t)(shx + 127) << 23);
+    float frf; memcpy(&frf, &fi, 4);
+    const double fr = frf;
+    const double num = (((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr + 119.1654824285581628956914143) * fr
+                        + 13.43250139086239872172837314) * fr + 0.1636161226585754240958355063;
+    const double den = (((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr + 168.5254414101568283957668343) * fr
+                        + 33.9905941350215598754191872) * fr + 1.0;
+    const float q = (float)(num / den);
+    uint32_t qi; memcpy(&qi, &q, 4);
+    qi = (uint32_t)((int32_t)qi + (ex << 23) + (int32_t)sgn) & ((vi << 1) != 0 ? 0xffffffffu : 0u);
+    float out; memcpy(&out, &qi, 4);
+    return out;
+}
+
+void orc_cvtBGRtoLab32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int srgb)
+{
+    buildLuvTables(); buildSplines();
+    const int bIdx = swapBlue ? 2 : 0;
+    float C[9];
+    {
+        const double sw[3] = {1.0 / D65[0], 1.0, 1.0 / D65[2]};
+        for (int i = 0; i < 3; i++) {
+            C[i * 3 + (bIdx ^ 2)] = (float)(sw[i] * sRGB2XYZ_D65[i * 3]);
+            C[i * 3 + 1] = (float)(sw[i] * sRGB2XYZ_D65[i * 3 + 1]);
+            C[i * 3 + bIdx] = (float)(sw[i] * sRGB2XYZ_D65[i * 3 + 2]);
+        }
+    }
+    const float tabScale = (float)(1024 * 2) / 3.f;
+    for (int y = 0; y < h; y++) {
+        const float* s = (const float*)((const uint8_t*)src + (size_t)y * sstepBytes);
+        float* d = (float*)((uint8_t*)dst + (size_t)y * dstepBytes);
+        for (int x = 0; x < w; x++, s += scn, d += 3) {
+            if (srgb) {
+                const float R = clip01(s[bIdx]), G = clip01(s[1]), B = clip01(s[bIdx ^ 2]);
+                int iL, ia, ib;
+                trilinear(RGB2LabLUT, (int)lrintf(R * 16384.f), (int)lrintf(G * 16384.f), (int)lrintf(B * 16384.f), &iL, &ia, &ib);
+                d[0] = (float)iL * (100.0f / 16384.f);
+                float t = (float)ia * (256.0f / 16384.f); d[1] = t + -128.f;
+                t = (float)ib * (256.0f / 16384.f); d[2] = t + -128.f;
+            } else if (x >= (w & ~7)) {                        /* the scalar tail of a row (:2132-2157): the last w % 8 pixels */
+                const float R = clip01(s[0]), G = clip01(s[1]), B = clip01(s[2]), a16 = 16.f / 116.f;
+                float t0 = R * C[0], t1 = G * C[1], t2 = B * C[2]; const float X = (t0 + t1) + t2;
+                t0 = R * C[3]; t1 = G * C[4]; t2 = B * C[5]; const float Y = (t0 + t1) + t2;
+                t0 = R * C[6]; t1 = G * C[7]; t2 = B * C[8]; const float Z = (t0 + t1) + t2;
+                float FX, FY, FZ, L;
+                if (X > 0.008856f) FX = cubeRootRounded(X); else { FX = 7.787f * X; FX = FX + a16; }
+                if (Y > 0.008856f) FY = cubeRootRounded(Y); else { FY = 7.787f * Y; FY = FY + a16; }
+                if (Z > 0.008856f) FZ = cubeRootRounded(Z); else { FZ = 7.787f * Z; FZ = FZ + a16; }
+                if (Y > 0.008856f) { L = 116.f * FY; L = L - 16.f; } else L = 903.3f * Y;
+                d[0] = L; d[1] = 500.f * (FX - FY); d[2] = 200.f * (FY - FZ);
+            } else {
+                const float R = clip01(s[0]), G = clip01(s[1]), B = clip01(s[2]);
+                float t2 = B * C[2], t1 = G * C[1] + t2; const float X = R * C[0] + t1;
+                t2 = B * C[5]; t1 = G * C[4] + t2; const float Y = R * C[3] + t1;
+                t2 = B * C[8]; t1 = G * C[7] + t2; const float Z = R * C[6] + t1;
+                const float FX = splineAt(X * tabScale, LabCbrtSpline, 1024), FY = splineAt(Y * tabScale, LabCbrtSpline, 1024), FZ = splineAt(Z * tabScale, LabCbrtSpline, 1024);
+                float L;
+                if (Y > 0.008856f) { L = 116.f * FY; L = L + -16.f; } else L = 903.3f * Y;
+                d[0] = L; d[1] = 500.f * (FX - FY); d[2] = 200.f * (FY - FZ);
+            }
+        }
+    }
+}
+
+void orc_cvtLabtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int srgb)
+{
+    buildSplines();
+    const int blueIdx = swapBlue ? 2 : 0;
+    float C[9];
+    for (int i = 0; i < 3; i++) {
+        C[i + (blueIdx ^ 2) * 3] = (float)(XYZ2sRGB_D65[i] * D65[i]);
+        C[i + 3] = (float)(XYZ2sRGB_D65[i + 3] * D65[i]);
+        C[i + blueIdx * 3] = (float)(XYZ2sRGB_D65[i + 6] * D65[i]);
+    }
+    const float lThresh = 8.f, fThresh = 6.f / 29.f, c16_116 = 16.0f / 116.0f;
+    const float inv903 = 1.f / 903.3f, inv116 = 1.f / 116.0f, pinv500 = 1.f / 500.f, ninv200 = -1.f / 200.f, inv7787 = 1.f / 7.787f;
+    for (int yy = 0; yy < h; yy++) {
+        const float* s = (const float*)((const uint8_t*)src + (size_t)yy * sstepBytes);
+        float* d = (float*)((uint8_t*)dst + (size_t)yy * dstepBytes);
+        for (int xx = 0; xx < w; xx++, s += 3, d += dcn) {
+            const float li = s[0], ai = s[1], bi = s[2];
+            const int tail = xx >= (w & ~7);                    /* the scalar tail of a row (:2343-2385) divides where the vector body multiplies by a reciprocal */
+            float y, fy;
+            if (li <= lThresh) { y = tail ? li / 903.3f : li * inv903; fy = 7.787f * y; fy = fy + c16_116; }
+            else { fy = tail ? (li + 16.0f) / 116.0f : (li + 16.0f) * inv116; y = fy * fy; y = y * fy; }
+            float fxz[2];
+            if (tail) { fxz[0] = ai / 500.0f; fxz[0] = fxz[0] + fy; fxz[1] = bi / 200.0f; fxz[1] = fy - fxz[1]; }
+            else { fxz[0] = ai * pinv500; fxz[0] = fxz[0] + fy; fxz[1] = bi * ninv200; fxz[1] = fxz[1] + fy; }
+            for (int j = 0; j < 2; j++) {
+                const float f = fxz[j];
+                if (f <= fThresh) fxz[j] = tail ? (f - c16_116) / 7.787f : (f - c16_116) * inv7787;
+                else { float t = f * f; fxz[j] = t * f; }
+            }
+            const float x = fxz[0], z = fxz[1];
+            float ro, go, bo;
+            if (tail) {
+                float t0 = C[0] * x, t1 = C[1] * y, t2 = C[2] * z; ro = (t0 + t1) + t2;
+                t0 = C[3] * x; t1 = C[4] * y; t2 = C[5] * z; go = (t0 + t1) + t2;
+                t0 = C[6] * x; t1 = C[7] * y; t2 = C[8] * z; bo = (t0 + t1) + t2;
+            } else {
+                float t2 = C[2] * z, t1 = C[1] * y + t2; ro = C[0] * x + t1;
+                t2 = C[5] * z; t1 = C[4] * y + t2; go = C[3] * x + t1;
+                t2 = C[8] * z; t1 = C[7] * y + t2; bo = C[6] * x + t1;
+            }
+            ro = ro < 1.f ? ro : 1.f; ro = ro > 0.f ? ro : 0.f;                  /* v_max(zero, v_min(ro, one)) */
+            go = go < 1.f ? go : 1.f; go = go > 0.f ? go : 0.f;
+            bo = bo < 1.f ? bo : 1.f; bo = bo > 0.f ? bo : 0.f;
+            if (srgb) {
+                ro = splineAt(ro * 1024.f, InvGammaSpline, 1024);
+                go = splineAt(go * 1024.f, InvGammaSpline, 1024);
+                bo = splineAt(bo * 1024.f, InvGammaSpline, 1024);
+            }
+            d[0] = ro; d[1] = go; d[2] = bo;
+            if (dcn == 4) d[3] = 1.f;
+        }
+    }
+}
+
 /* the tables themselves, for a direct comparison with the library's (tests): which = 0 sRGBGamma (256), 1 LabCbrt (3072), 2 sRGBInvGamma (4096),
  * 3 LabToYF (512) as uint16; 4 abToXZ (36864) as int32; 5 the 33^3 x 3 RGB -> Luv table as int16; 6 / 7 LuToUp / LvToVp (65536) as int32 */
 int orc_labTable(int which, void* out)
@@ -329,6 +537,9 @@ int orc_labTable(int which, void* out)
     case 5: buildLuvTables(); memcpy(out, RGB2LuvLUT, sizeof RGB2LuvLUT); return LUT_DIM * LUT_DIM * LUT_DIM * 3;      /* int16 */
     case 6: buildLuvTables(); memcpy(out, LuToUp_b, sizeof LuToUp_b); return 65536;                                     /* int32 */
     case 7: buildLuvTables(); memcpy(out, LvToVp_b, sizeof LvToVp_b); return 65536;
+    case 8: buildLuvTables(); memcpy(out, RGB2LabLUT, sizeof RGB2LabLUT); return LUT_DIM * LUT_DIM * LUT_DIM * 3;      /* int16 */
+    case 9: buildSplines(); memcpy(out, LabCbrtSpline, sizeof LabCbrtSpline); return 4096;                               /* float */
+    case 10: buildSplines(); memcpy(out, InvGammaSpline, sizeof InvGammaSpline); return 4096;
     }
     return -1;
 }

@@ -268,6 +268,16 @@ _LUV_INV = {58: (0, 1), 59: (1, 1), 80: (0, 0), 81: (1, 0)}                    #
 def orc_cvtColorLab(src, code, dcn=3):
     o = oracle()
     h, w = src.shape[:2]
+    if src.dtype == np.float32:                                   # L*a*b* only
+        if code in _LAB_FWD:
+            swap, srgb = _LAB_FWD[code]
+            dst = np.empty((h, w, 3), np.float32)
+            o.orc_cvtBGRtoLab32f(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, srgb)
+        else:
+            swap, srgb = _LAB_INV[code]
+            dst = np.empty((h, w, dcn), np.float32)
+            o.orc_cvtLabtoBGR32f(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, srgb)
+        return dst
     if code in _LUV_FWD:
         dst = np.empty((h, w, 3), np.uint8)
         o.orc_cvtBGRtoLuv8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], _LUV_FWD[code])

@@ -145,3 +145,21 @@ def test_every_batch_entry_takes_host_resident_frames(cv):
     assert torch.equal(cv.SobelBatch(host, cv.CV_16S, 0, 1, 3), cv.SobelBatch(host.cuda(), cv.CV_16S, 0, 1, 3).cpu())
     with pytest.raises((NotImplementedError, ValueError)):          # one end in HBM, the other on the host: not a batch the pipeline takes
         cv.thresholdBatch(host[:2], 100, 255, 0, dst=torch.empty((2, 1080, 1920), dtype=torch.uint8, device="cuda"))
+
+
+def test_integral_batch(cv):
+    """mi355cv_integralBatch: every frame's sum / squared sum equals the single-image hook's (which the per-function suite pins to the oracle), for CV_32S
+    and CV_64F sums, with and without squared sums, frames that are views with padding, widths around the 256-column tile and heights around 16 rows"""
+    for (n, h, w) in [(3, 37, 300), (2, 16, 255), (5, 101, 1040), (1, 64, 257), (4, 1, 1)]:
+        parent = frames_u8(n, h + 3, w, seed=h + w)
+        fr = parent[:, :h]
+        for sdepth in (4, 6):
+            got, gotq = cv.integralBatch(fr, sqsum=True, sdepth=sdepth)
+            plain = cv.integralBatch(fr, sdepth=sdepth)
+            for f in range(n):
+                want, wantq = cv.integral(fr[f], sqsum=True, sdepth=sdepth)
+                assert torch.equal(got[f], want) and torch.equal(gotq[f], wantq) and torch.equal(plain[f], want), (n, h, w, sdepth, f)
+    ref = torch.cumsum(torch.cumsum(fr[0].to(torch.int64), 0), 1)
+    assert torch.equal(got[0][1:, 1:].to(torch.int64), ref)
+    with pytest.raises(ValueError):
+        cv.integralBatch(fr.cpu())

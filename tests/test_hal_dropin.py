@@ -59,6 +59,10 @@ def _calls(o, src8, src8c3, srcf):
     out["lab"] = o.ref_cvtColor(src8c3, 44, 3)
     out["lab2lrgb"] = o.ref_cvtColor(src8c3, 79, 3)
     out["luv"] = o.ref_cvtColor(src8c3, 51, 3)
+    f3 = (src8c3.astype(np.float32) / 255).astype(np.float32)
+    out["lab32f"] = o.ref_cvtColor(f3, 44, 3)
+    out["lab32f_lin"] = o.ref_cvtColor(f3, 75, 3)
+    out["lab2bgr32f"] = o.ref_cvtColor(out["lab32f"], 56, 3)
     out["luv2bgr"] = o.ref_cvtColor(src8c3, 58, 3)
     out["bgr565"] = o.ref_cvtColorMisc(src8c3, 12)
     out["bgr5552bgra"] = o.ref_cvtColorMisc(np.ascontiguousarray(src8c3[..., :2]), 28)

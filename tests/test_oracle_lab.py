@@ -74,3 +74,50 @@ def test_library_tables_equal_the_oracle_tables():
         a, b = np.zeros(65536, np.int32), np.zeros(65536, np.int32)
         assert _lib.lib.mi355cv_labTable(mine, a.ctypes.data) == 65536 and o.orc_labTable(theirs, b.ctypes.data) == 65536
         assert np.array_equal(a, b), mine
+
+
+def _err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))))
+
+
+def _float_inputs(rng, h, w, cn):
+    img = (rng.random((h, w, cn), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)          # a tenth of the range outside [0, 1]: clipped by the conversion
+    img.reshape(-1, cn)[:6, :3] = [[0, 0, 0], [1, 1, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.001, 0.002, 0.0005]]
+    return img
+
+
+@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("scn", [3, 4])
+def test_float_forward(code, scn):
+    """CV_32F L*a*b*: identical to the reference, vector bodies and scalar row tails (the last width % 8 pixels) alike"""
+    rng = np.random.default_rng(code + scn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (50, 1032)]:
+        img = _float_inputs(rng, h, w, scn) if h * w > 6 else rng.random((h, w, scn), dtype=np.float32)
+        got, want = orc.orc_cvtColorLab(img, code), orc.ref_cvtColor(img, code, 3)
+        assert np.array_equal(got, want), (code, scn, h, w, _err(got, want))
+
+
+@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("dcn", [3, 4])
+def test_float_inverse(code, dcn):
+    rng = np.random.default_rng(code + dcn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641)]:
+        lab = np.empty((h, w, 3), np.float32)
+        lab[..., 0] = rng.random((h, w)) * 100
+        lab[..., 1:] = rng.random((h, w, 2)) * 254 - 127
+        got, want = orc.orc_cvtColorLab(lab, code, dcn), orc.ref_cvtColor(lab, code, dcn)
+        assert np.array_equal(got, want), (code, dcn, h, w, _err(got, want))
+
+
+def test_float_tables_equal_the_oracle_tables():
+    import ctypes
+    from opencv_amd import _lib
+    o = orc.oracle()
+    o.orc_labTable.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    grid, want = np.zeros(33 ** 3 * 4, np.int16), np.zeros(33 ** 3 * 3, np.int16)
+    assert _lib.lib.mi355cv_labTable(7, grid.ctypes.data) == grid.size and o.orc_labTable(8, want.ctypes.data) == want.size
+    assert np.array_equal(grid.reshape(-1, 4)[:, :3], want.reshape(-1, 3))
+    for mine, theirs in ((8, 9), (9, 10)):
+        a, b = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
+        assert _lib.lib.mi355cv_labTable(mine, a.ctypes.data) == 4096 and o.orc_labTable(theirs, b.ctypes.data) == 4096
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mine
