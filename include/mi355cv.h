@@ -357,7 +357,8 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const mi355cv_uchar* src_data, size_t src_st
  * L*a*b* from / to sRGB (COLOR_BGR2Lab ...) or linear RGB (COLOR_LBGR2Lab ...) -- the reference's bit-exact integer paths RGB2Lab_b (:1573) and
  * Lab2RGBinteger (:2399) -- and CV_8U L*u*v* (isLab == false): sRGB -> Luv through the reference's 33^3 interpolation table (RGB2Luvinterpolate :3276),
  * Luv -> sRGB / linear RGB by Luv2RGBinteger (:3556) -- and CV_32F L*a*b* (RGB2Lab_f :1895, Lab2RGBfloat :2169, vector bodies and scalar row tails as the
- * reference has them).  L*u*v* on CV_32F, and L*u*v* from linear RGB (the reference's float path), decline (csrc/color_lab.hip) */
+ * reference has them), CV_32F L*u*v* and CV_8U L*u*v* from linear RGB (RGB2Luvfloat :2868, Luv2RGBfloat :3057): every (depth, isLab, srgb) case the
+ * reference's pair of hooks receives (csrc/color_lab.hip) */
 MI355CV_API int mi355cv_cvtBGRtoLab(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, int scn, bool swapBlue, bool isLab, bool srgb);
 MI355CV_API int mi355cv_cvtLabtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,

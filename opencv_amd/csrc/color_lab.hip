@@ -15,8 +15,8 @@
 // L*u*v*, for linear RGB a cubic spline for the cube root --, Lab2RGBfloat :2169); the last width % 8 pixels of a row in the form of its scalar tails (cubeRoot(),
 // divisions): the oracle written the same way equals the reference bit for bit on every case tested.
 // L*u*v* (isLab == false), CV_8U: sRGB -> Luv by trilinear interpolation in the reference's 33^3 fixed-point table (RGB2Luvinterpolate :3276), Luv ->
-// sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  Declined (the reference's own path then runs): L*u*v* on CV_32F
-// images, and L*u*v* from LINEAR RGB, which the reference computes in float.
+// sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  L*u*v* on CV_32F images, and on CV_8U images in LINEAR RGB, follow the
+// reference's float paths (RGB2Luvfloat :2868, Luv2RGBfloat :3057) the same way as CV_32F L*a*b*.  Both hooks now serve every (depth, isLab, srgb) case.
 #include "rt.h"
 #include "pix4.h"
 #include <cmath>
@@ -140,6 +140,7 @@ struct LuvTabs {
     short labGrid[LUV_GRID * 4];
     float cbrtSpline[1024 * 4];
     float invGammaSpline[1024 * 4];
+    float gammaSpline[1024 * 4];
 };
 LuvTabs* g_luvHost;                    // 0.8 MB: allocated when first needed
 std::once_flag g_luvHostOnce;
@@ -206,12 +207,13 @@ void buildLuvHost()
             }
     {
         // cubic splines over 1024 intervals (splineBuild color_lab.cpp:20-47, float arithmetic): Lab's f() on [0, 1.5] and the inverse sRGB transfer on [0, 1]
-        std::vector<float> f(1025), ig(1025);
+        std::vector<float> f(1025), ig(1025), gf(1025);
         const float cbScale = 1.f / ((float)(1024 * 2) / 3.f), gScale = 1.f / 1024.f;
         for (int i = 0; i <= 1024; i++) {
             const float x = cbScale * (float)i;
             f[i] = x < lthresh ? fmaf(x, lscale, lbias) : cubeRootTurkowski(x);
             ig[i] = gammaInv(gScale * (float)i);
+            gf[i] = gammaFwd(gScale * (float)i);
         }
         auto build = [](const std::vector<float>& fv, float* tab) {
             const int n = 1024;
@@ -233,6 +235,7 @@ void buildLuvHost()
         };
         build(f, t->cbrtSpline);
         build(ig, t->invGammaSpline);
+        build(gf, t->gammaSpline);
     }
     for (int LL = 0; LL < 256; LL++) {
         const float L = (float)(LL * 100) / f255;
@@ -651,6 +654,122 @@ __global__ __launch_bounds__(256) void k_lab2bgr_f32(const uchar* __restrict__ s
     if (DCN == 4) d[3] = 1.f;
 }
 
+// ---------------------------------------------------------------------------------- CV_32F L*u*v*, and CV_8U L*u*v* from linear RGB
+struct LuvF { float c[9]; float un, vn; };
+
+// RGB2Luvfloat (color_lab.cpp:2868-3037): vector body for the first 8 * (W / 8) pixels of a row, scalar tail for the rest.  U8: RGB2Luv_b's float
+// branch (:3405-3545) -- bytes / 255 in, (L * 2.55, u, v scaled into 0..255) rounded and saturated out
+template <int SCN, bool SRGB, bool U8>
+__global__ __launch_bounds__(256) void k_bgr2luv_f32(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                      const LuvTabs* __restrict__ tabs, LuvF k)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float R, G, B;
+    if (U8) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
+        const float f255inv = 1.f / 255.f;
+        R = (float)s[0] * f255inv; G = (float)s[1] * f255inv; B = (float)s[2] * f255inv;
+    } else {
+        const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+        R = s[0]; G = s[1]; B = s[2];
+    }
+    const float tabScale = (float)(1024 * 2) / 3.f, eps = 1.1920928955078125e-7f;
+    float L, u, v;
+    if (x >= (W & ~7)) {
+        R = R < 0.f ? 0.f : R <= 1.f ? R : 1.f; G = G < 0.f ? 0.f : G <= 1.f ? G : 1.f; B = B < 0.f ? 0.f : B <= 1.f ? B : 1.f;
+        if (SRGB) { R = splineAt(R * 1024.f, tabs->gammaSpline); G = splineAt(G * 1024.f, tabs->gammaSpline); B = splineAt(B * 1024.f, tabs->gammaSpline); }
+        float t0 = R * k.c[0], t1 = G * k.c[1], t2 = B * k.c[2]; const float X = (t0 + t1) + t2;
+        t0 = R * k.c[3]; t1 = G * k.c[4]; t2 = B * k.c[5]; const float Y = (t0 + t1) + t2;
+        t0 = R * k.c[6]; t1 = G * k.c[7]; t2 = B * k.c[8]; const float Z = (t0 + t1) + t2;
+        L = splineAt(Y * tabScale, tabs->cbrtSpline);
+        L = 116.f * L; L = L - 16.f;
+        float den = 15 * Y; den = X + den; t0 = 3 * Z; den = den + t0;
+        const float dd = 52.f / (den > eps ? den : eps);
+        t0 = X * dd; u = L * (t0 - k.un);
+        t0 = (9 * 0.25f) * Y; t0 = t0 * dd; v = L * (t0 - k.vn);
+    } else {
+        R = R > 0.f ? R : 0.f; R = R < 1.f ? R : 1.f;
+        G = G > 0.f ? G : 0.f; G = G < 1.f ? G : 1.f;
+        B = B > 0.f ? B : 0.f; B = B < 1.f ? B : 1.f;
+        if (SRGB) { R = splineAt(R * 1024.f, tabs->gammaSpline); G = splineAt(G * 1024.f, tabs->gammaSpline); B = splineAt(B * 1024.f, tabs->gammaSpline); }
+        float t2 = B * k.c[2], t1 = G * k.c[1] + t2; const float X = R * k.c[0] + t1;
+        t2 = B * k.c[5]; t1 = G * k.c[4] + t2; const float Y = R * k.c[3] + t1;
+        t2 = B * k.c[8]; t1 = G * k.c[7] + t2; const float Z = R * k.c[6] + t1;
+        L = splineAt(Y * tabScale, tabs->cbrtSpline);
+        L = L * 116.f; L = L + -16.f;
+        float den = Z * 3.f + X; den = Y * 15.f + den;
+        const float dd = 52.f / (den > eps ? den : eps);
+        float t0 = X * dd + -k.un; u = L * t0;
+        t0 = (9.F * 0.25F) * Y; t0 = t0 * dd + -k.vn; v = L * t0;
+    }
+    if (U8) {
+        uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
+        const float fL = 255.f / 100.f, uRange = 354.f, vRange = 262.f, fu = 255.f / uRange, fv = 255.f / vRange, su = (134.f * 255.f) / uRange, sv = (140.f * 255.f) / vRange;
+        float t = L * fL; d[0] = (uchar)sat8((int)__builtin_rintf(t));
+        t = u * fu; t = t + su; d[1] = (uchar)sat8((int)__builtin_rintf(t));
+        t = v * fv; t = t + sv; d[2] = (uchar)sat8((int)__builtin_rintf(t));
+    } else {
+        float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+        d[0] = L; d[1] = u; d[2] = v;
+    }
+}
+
+// Luv2RGBfloat (color_lab.cpp:3057-3254): vector body / scalar tail as above (the tail has 1 / 903.3f where the body has 1 / 903.296296f)
+template <int DCN, bool SRGB>
+__global__ __launch_bounds__(256) void k_luv2bgr_f32(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H,
+                                                      const LuvTabs* __restrict__ tabs, LuvF k)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || yy >= H) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)yy * sstep) + (size_t)x * 3;
+    float* d = reinterpret_cast<float*>(dst + (size_t)yy * dstep) + (size_t)x * DCN;
+    const float L = s[0], u = s[1], v = s[2];
+    float R, G, B;
+    if (x >= (W & ~7)) {
+        float Y;
+        if (L >= 8) { Y = (L + 16.f) * (1.f / 116.f); const float t = Y * Y; Y = t * Y; }
+        else Y = L * (1.0f / 903.3f);
+        float up = L * k.un; up = 3.f * (u + up);
+        float vp = L * k.vn; vp = 0.25f / (v + vp);
+        if (vp > 0.25f) vp = 0.25f;
+        if (vp < -0.25f) vp = -0.25f;
+        float X = Y * 3.f; X = X * up; X = X * vp;
+        float Z = (12.f * 13.f) * L; Z = Z - up; Z = Z * vp; Z = Z - 5.f; Z = Y * Z;
+        float t0 = X * k.c[0], t1 = Y * k.c[1], t2 = Z * k.c[2]; R = (t0 + t1) + t2;
+        t0 = X * k.c[3]; t1 = Y * k.c[4]; t2 = Z * k.c[5]; G = (t0 + t1) + t2;
+        t0 = X * k.c[6]; t1 = Y * k.c[7]; t2 = Z * k.c[8]; B = (t0 + t1) + t2;
+        R = R < 0.f ? 0.f : R <= 1.f ? R : 1.f; G = G < 0.f ? 0.f : G <= 1.f ? G : 1.f; B = B < 0.f ? 0.f : B <= 1.f ? B : 1.f;
+    } else {
+        float Ylo = (L + 16.f) * (1.f / 116.f); { const float t = Ylo * Ylo; Ylo = t * Ylo; }
+        const float Yhi = L * (1.0f / 903.296296f);
+        const float Y = L >= 8.f ? Ylo : Yhi;
+        float up = L * k.un + u; up = 3.f * up;
+        float vp = L * k.vn + v; vp = 0.25f / vp;
+        vp = 0.25f < vp ? 0.25f : vp;
+        vp = -0.25f > vp ? -0.25f : vp;
+        float X = 3.f * up; X = X * vp;
+        float Z = L * (12.f * 13.f) + -up; Z = Z * vp + -5.f;
+        float t = X * k.c[0] + k.c[1]; t = Z * k.c[2] + t; R = t * Y;
+        t = X * k.c[3] + k.c[4]; t = Z * k.c[5] + t; G = t * Y;
+        t = X * k.c[6] + k.c[7]; t = Z * k.c[8] + t; B = t * Y;
+        R = R > 0.f ? R : 0.f; R = R < 1.f ? R : 1.f;
+        G = G > 0.f ? G : 0.f; G = G < 1.f ? G : 1.f;
+        B = B > 0.f ? B : 0.f; B = B < 1.f ? B : 1.f;
+    }
+    if (SRGB) { R = splineAt(R * 1024.f, tabs->invGammaSpline); G = splineAt(G * 1024.f, tabs->invGammaSpline); B = splineAt(B * 1024.f, tabs->invGammaSpline); }
+    d[0] = R; d[1] = G; d[2] = B;
+    if (DCN == 4) d[3] = 1.f;
+}
+
+// un, vn of the D65 white point as RGB2Luvfloat / Luv2RGBfloat derive them (:2902-2907, :3088-3093): the sum in double, everything after in float
+void luvWhitePoint(float* un, float* vn)
+{
+    float d = (float)(kD65[0] + kD65[1] * 15.0 + kD65[2] * 3.0);
+    d = 1.f / maxSoft(d, 1.1920928955078125e-7f);
+    *un = (d * 52.f) * (float)kD65[0]; *vn = (d * 117.f) * (float)kD65[1];
+}
+
 } // namespace
 
 extern "C" {
@@ -688,9 +807,31 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         noteKernel("k_bgr2lab_f32_%s<%d> grid=%ux%u x256", srgb ? "grid" : "lin", scn, grid.x, grid.y);
         return stg.finish("cvtBGRtoLab");
     }
-    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
-    // L*u*v* from linear RGB is the reference's float path (RGB2Luv_b color_lab.cpp:3389-3392 interpolates for sRGB only): declined
-    if (!isLab && !srgb) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: L*u*v* from linear RGB takes the reference's float path");
+    if (depth != MI355CV_8U && depth != MI355CV_32F) return MI355CV_NOT_IMPLEMENTED;
+    if (!isLab && (depth == MI355CV_32F || !srgb)) {
+        // L*u*v* in float: CV_32F images, and CV_8U images in linear RGB (RGB2Luv_b color_lab.cpp:3389-3392 interpolates in the grid for sRGB only)
+        const int e = depth == MI355CV_32F ? 4 : 1;
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return MI355CV_NOT_IMPLEMENTED;
+        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+        const LuvTabs* ft = deviceLuvTabs();
+        if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
+        Stager stg; size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * e, height, &dds);
+        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        LuvF kf;
+        for (int i = 0; i < 9; i++) kf.c[i] = (float)kRgb2Xyz[i];
+        if (!swapBlue) for (int i = 0; i < 3; i++) std::swap(kf.c[i * 3], kf.c[i * 3 + 2]);            // blueIdx == 0 (:2891)
+        luvWhitePoint(&kf.un, &kf.vn);
+        const dim3 grid(divUp(width, 64), divUp(height, 4));
+#define LAUNCH(SCN_, SRGB_, U8_) hipLaunchKernelGGL((k_bgr2luv_f32<SCN_, SRGB_, U8_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, kf)
+        if (depth == MI355CV_8U) { if (scn == 3) LAUNCH(3, false, true); else LAUNCH(4, false, true); }
+        else if (scn == 3) { if (srgb) LAUNCH(3, true, false); else LAUNCH(3, false, false); }
+        else               { if (srgb) LAUNCH(4, true, false); else LAUNCH(4, false, false); }
+#undef LAUNCH
+        noteKernel("k_bgr2luv_f32<%d,%s,%s> grid=%ux%u x256", scn, srgb ? "srgb" : "linear", e == 1 ? "u8" : "f32", grid.x, grid.y);
+        return stg.finish("cvtBGRtoLab");
+    }
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
@@ -754,6 +895,26 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
         else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
         noteKernel("k_lab2bgr_f32<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
+        return stg.finish("cvtLabtoBGR");
+    }
+    if (depth == MI355CV_32F) {                             // L*u*v*, CV_32F: Luv2RGBfloat
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
+        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+        const LuvTabs* ft = deviceLuvTabs();
+        if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
+        Stager stg; size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
+        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        LuvF kf; const int bi = swapBlue ? 2 : 0;
+        for (int i = 0; i < 3; i++) { kf.c[i + (bi ^ 2) * 3] = (float)kXyz2Rgb[i]; kf.c[i + 3] = (float)kXyz2Rgb[i + 3]; kf.c[i + bi * 3] = (float)kXyz2Rgb[i + 6]; }
+        luvWhitePoint(&kf.un, &kf.vn);
+        const dim3 grid(divUp(width, 64), divUp(height, 4));
+#define LAUNCH(DCN_, SRGB_) hipLaunchKernelGGL((k_luv2bgr_f32<DCN_, SRGB_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, ft, kf)
+        if (dcn == 3) { if (srgb) LAUNCH(3, true); else LAUNCH(3, false); }
+        else          { if (srgb) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+        noteKernel("k_luv2bgr_f32<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
         return stg.finish("cvtLabtoBGR");
     }
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
@@ -820,6 +981,7 @@ MI355CV_API int mi355cv_labTable(int which, void* out)
     case 7: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->labGrid, sizeof g_luvHost->labGrid); return LUV_GRID * 4;
     case 8: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->cbrtSpline, sizeof g_luvHost->cbrtSpline); return 4096;
     case 9: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->invGammaSpline, sizeof g_luvHost->invGammaSpline); return 4096;
+    case 10: std::call_once(g_luvHostOnce, buildLuvHost); std::memcpy(out, g_luvHost->gammaSpline, sizeof g_luvHost->gammaSpline); return 4096;
     }
     return -1;
 }

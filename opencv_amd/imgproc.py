@@ -360,12 +360,12 @@ def _cvt_misc(src, s, code, dst, dstCn):
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtXYZtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]))
-    elif kind in ("to_lab", "to_luv"):                      # the library declines L*u*v* from linear RGB (the reference's float path): NotImplementedError
-        need(s.cn in (3, 4) and (s.depth == CV_8U or (s.depth == CV_32F and kind == "to_lab")), "BGR2Lab: 3 or 4 channels, CV_8U / CV_32F; BGR2Luv: CV_8U on this path")
+    elif kind in ("to_lab", "to_luv"):
+        need(s.cn in (3, 4) and s.depth in (CV_8U, CV_32F), "BGR2Lab / BGR2Luv: 3 or 4 channels, CV_8U or CV_32F")
         out = dst if dst is not None else _like(src, s.h, s.w, 3, s.depth)
         call = lambda d: L.mi355cv_cvtBGRtoLab(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]), kind == "to_lab", bool(k[2]))
     elif kind in ("from_lab", "from_luv"):
-        need(s.cn == 3 and (s.depth == CV_8U or (s.depth == CV_32F and kind == "from_lab")), "Lab2BGR: 3 channels, CV_8U / CV_32F; Luv2BGR: CV_8U on this path")
+        need(s.cn == 3 and s.depth in (CV_8U, CV_32F), "Lab2BGR / Luv2BGR: 3 channels, CV_8U or CV_32F")
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtLabtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]), kind == "from_lab", bool(k[2]))

@@ -13,6 +13,7 @@
 #include "oracle.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 enum { LAB_SHIFT = 12, GAMMA_SHIFT = 3, LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT, CBRT_TAB_B = 256 * 3 / 2 * (1 << GAMMA_SHIFT),
        INV_GAMMA_SHIFT = 12, INV_GAMMA_TAB = 1 << INV_GAMMA_SHIFT, LUT_BASE = 1 << 14, LAB_BASE = 1 << 14, MIN_AB = -8145, ABXZ_N = LAB_BASE * 9 / 4 };
@@ -346,7 +347,7 @@ void orc_cvtLuvtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
  * written in the form of the reference's VECTOR bodies (products by reciprocal constants, a*b + c as two roundings -- the SSE3 baseline this file is
  * compiled for has no fused multiply-add) for the first 8 * (width / 8) pixels of a row, and in the form of its scalar tails (divisions, sums left to
  * right, cv::cubeRoot instead of the spline) for the last width % 8: tests/test_oracle_lab.py finds the result equal to the reference's bit for bit. */
-static float LabCbrtSpline[1024 * 4], InvGammaSpline[1024 * 4];
+static float LabCbrtSpline[1024 * 4], InvGammaSpline[1024 * 4], GammaSpline[1024 * 4];
 static int splinesReady;
 
 static void splineBuild(const float* f, int n, float* tab)
@@ -382,16 +383,18 @@ static float splineAt(float x, const float* tab, int n)
 static void buildSplines(void)
 {
     if (splinesReady) return;
-    static float f[1025], ig[1025];
+    static float f[1025], ig[1025], g[1025];
     const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
     const float cbScale = 1.f / ((float)(1024 * 2) / 3.f), gScale = 1.f / 1024.f;
     for (int i = 0; i <= 1024; i++) {
         const float x = cbScale * (float)i;
         f[i] = x < lthresh ? fmaf(x, lscale, lbias) : cbrtTurkowski(x);
         ig[i] = applyInvGamma(gScale * (float)i);
+        g[i] = applyGamma(gScale * (float)i);
     }
     splineBuild(f, 1024, LabCbrtSpline);
     splineBuild(ig, 1024, InvGammaSpline);
+    splineBuild(g, 1024, GammaSpline);
     splinesReady = 1;
 }
 
@@ -523,6 +526,145 @@ void orc_cvtLabtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t 
     }
 }
 
+/* ----------------------------------------------------------------------------------------------------------------- L*u*v*, CV_32F (and CV_8U from linear RGB)
+ *   - forward   RGB2Luvfloat color_lab.cpp:2868-3037 (vector body :2925-3003, scalar tail :3006-3032)
+ *   - inverse   Luv2RGBfloat :3057-3254 (vector body :3113-3205, scalar tail :3208-3247 -- note its 1/903.3f where the body has 1/903.296296f)
+ *   - CV_8U from linear RGB: RGB2Luv_b's float branch :3405-3545 = bytes / 255 -> RGB2Luvfloat -> scale, round, saturate
+ * each in the form of the vector body for the first 8 * (width / 8) pixels of a row and of the scalar tail for the rest. */
+static void luvWhite(float* un, float* vn, int inverse)
+{
+    float d = (float)(D65[0] + D65[1] * 15.0 + D65[2] * 3.0);
+    d = 1.f / fmax2(d, 1.1920928955078125e-7f);
+    if (inverse) { *un = (52.f * d) * (float)D65[0]; *vn = (117.f * d) * (float)D65[1]; }
+    else { *un = (d * 52.f) * (float)D65[0]; *vn = (d * 117.f) * (float)D65[1]; }
+}
+
+static void luvForwardRow(const float* s, int scn, float* d, int w, const float* C, float un, float vn, int srgb)
+{
+    const float tabScale = (float)(1024 * 2) / 3.f;
+    for (int x = 0; x < w; x++, s += scn, d += 3) {
+        float R = s[0], G = s[1], B = s[2], L, u, v;
+        if (x >= (w & ~7)) {                                /* scalar tail */
+            R = clip01(R); G = clip01(G); B = clip01(B);
+            if (srgb) { R = splineAt(R * 1024.f, GammaSpline, 1024); G = splineAt(G * 1024.f, GammaSpline, 1024); B = splineAt(B * 1024.f, GammaSpline, 1024); }
+            float t0 = R * C[0], t1 = G * C[1], t2 = B * C[2]; const float X = (t0 + t1) + t2;
+            t0 = R * C[3]; t1 = G * C[4]; t2 = B * C[5]; const float Y = (t0 + t1) + t2;
+            t0 = R * C[6]; t1 = G * C[7]; t2 = B * C[8]; const float Z = (t0 + t1) + t2;
+            L = splineAt(Y * tabScale, LabCbrtSpline, 1024);
+            L = 116.f * L; L = L - 16.f;
+            float den = 15 * Y; den = X + den; t0 = 3 * Z; den = den + t0;
+            const float dd = 52.f / (den > 1.1920928955078125e-7f ? den : 1.1920928955078125e-7f);      /* std::max(a, b): a < b ? b : a */
+            t0 = X * dd; u = L * (t0 - un);
+            t0 = (9 * 0.25f) * Y; t0 = t0 * dd; v = L * (t0 - vn);
+        } else {                                            /* vector body */
+            R = R > 0.f ? R : 0.f; R = R < 1.f ? R : 1.f;   /* v_min(v_max(R, zero), one) */
+            G = G > 0.f ? G : 0.f; G = G < 1.f ? G : 1.f;
+            B = B > 0.f ? B : 0.f; B = B < 1.f ? B : 1.f;
+            if (srgb) { R = splineAt(R * 1024.f, GammaSpline, 1024); G = splineAt(G * 1024.f, GammaSpline, 1024); B = splineAt(B * 1024.f, GammaSpline, 1024); }
+            float t2 = B * C[2], t1 = G * C[1] + t2; const float X = R * C[0] + t1;
+            t2 = B * C[5]; t1 = G * C[4] + t2; const float Y = R * C[3] + t1;
+            t2 = B * C[8]; t1 = G * C[7] + t2; const float Z = R * C[6] + t1;
+            L = splineAt(Y * tabScale, LabCbrtSpline, 1024);
+            L = L * 116.f; L = L + -16.f;
+            float den = Z * 3.f + X; den = Y * 15.f + den;
+            const float dd = 52.f / (den > 1.1920928955078125e-7f ? den : 1.1920928955078125e-7f);
+            float t0 = X * dd + -un; u = L * t0;
+            t0 = (9.F * 0.25F) * Y; t0 = t0 * dd + -vn; v = L * t0;
+        }
+        d[0] = L; d[1] = u; d[2] = v;
+    }
+}
+
+static void luvForwardCoeffs(float* C, int swapBlue)
+{
+    for (int i = 0; i < 9; i++) C[i] = (float)sRGB2XYZ_D65[i];
+    if (!swapBlue) for (int i = 0; i < 3; i++) { const float t = C[i * 3]; C[i * 3] = C[i * 3 + 2]; C[i * 3 + 2] = t; }      /* blueIdx == 0 */
+}
+
+void orc_cvtBGRtoLuv32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int srgb)
+{
+    buildSplines();
+    float C[9], un, vn;
+    luvForwardCoeffs(C, swapBlue); luvWhite(&un, &vn, 0);
+    for (int y = 0; y < h; y++)
+        luvForwardRow((const float*)((const uint8_t*)src + (size_t)y * sstepBytes), scn, (float*)((uint8_t*)dst + (size_t)y * dstepBytes), w, C, un, vn, srgb);
+}
+
+/* CV_8U, linear RGB (sRGB sources take the grid interpolation above): per row, bytes * (1 / 255.f) -> the float conversion -> L * 2.55, u, v into 0..255 */
+void orc_cvtLBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue)
+{
+    buildSplines();
+    float C[9], un, vn;
+    luvForwardCoeffs(C, swapBlue); luvWhite(&un, &vn, 0);
+    const float f255inv = 1.f / 255.f, fL = 255.f / 100.f, uLow = -134.f, uRange = 354.f, vLow = -140.f, vRange = 262.f;
+    const float fu = 255.f / uRange, fv = 255.f / vRange, su = (-uLow * 255.f) / uRange, sv = (-vLow * 255.f) / vRange;
+    float* in = (float*)malloc((size_t)w * 3 * sizeof(float));
+    float* out = (float*)malloc((size_t)w * 3 * sizeof(float));
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstep;
+        uint8_t* d = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++) for (int c = 0; c < 3; c++) in[x * 3 + c] = (float)s[x * scn + c] * f255inv;
+        luvForwardRow(in, 3, out, w, C, un, vn, 0);
+        for (int x = 0; x < w; x++) {
+            float t = out[x * 3] * fL; d[x * 3] = sat8((int)lrintf(t));
+            t = out[x * 3 + 1] * fu; t = t + su; d[x * 3 + 1] = sat8((int)lrintf(t));
+            t = out[x * 3 + 2] * fv; t = t + sv; d[x * 3 + 2] = sat8((int)lrintf(t));
+        }
+    }
+    free(in); free(out);
+}
+
+void orc_cvtLuvtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int srgb)
+{
+    buildSplines();
+    const int blueIdx = swapBlue ? 2 : 0;
+    float C[9], un, vn;
+    for (int i = 0; i < 3; i++) { C[i + (blueIdx ^ 2) * 3] = (float)XYZ2sRGB_D65[i]; C[i + 3] = (float)XYZ2sRGB_D65[i + 3]; C[i + blueIdx * 3] = (float)XYZ2sRGB_D65[i + 6]; }
+    luvWhite(&un, &vn, 1);
+    for (int yy = 0; yy < h; yy++) {
+        const float* s = (const float*)((const uint8_t*)src + (size_t)yy * sstepBytes);
+        float* d = (float*)((uint8_t*)dst + (size_t)yy * dstepBytes);
+        for (int x = 0; x < w; x++, s += 3, d += dcn) {
+            const float L = s[0], u = s[1], v = s[2];
+            float R, G, B;
+            if (x >= (w & ~7)) {                            /* scalar tail */
+                float Y;
+                if (L >= 8) { Y = (L + 16.f) * (1.f / 116.f); float t = Y * Y; Y = t * Y; }
+                else Y = L * (1.0f / 903.3f);
+                float up = L * un; up = 3.f * (u + up);
+                float vp = L * vn; vp = 0.25f / (v + vp);
+                if (vp > 0.25f) vp = 0.25f;
+                if (vp < -0.25f) vp = -0.25f;
+                float X = Y * 3.f; X = X * up; X = X * vp;
+                float Z = (12.f * 13.f) * L; Z = Z - up; Z = Z * vp; Z = Z - 5.f; Z = Y * Z;
+                float t0 = X * C[0], t1 = Y * C[1], t2 = Z * C[2]; R = (t0 + t1) + t2;
+                t0 = X * C[3]; t1 = Y * C[4]; t2 = Z * C[5]; G = (t0 + t1) + t2;
+                t0 = X * C[6]; t1 = Y * C[7]; t2 = Z * C[8]; B = (t0 + t1) + t2;
+                R = clip01(R); G = clip01(G); B = clip01(B);
+            } else {                                        /* vector body */
+                float Ylo = (L + 16.f) * (1.f / 116.f); { float t = Ylo * Ylo; Ylo = t * Ylo; }
+                const float Yhi = L * (1.0f / 903.296296f);
+                const float Y = L >= 8.f ? Ylo : Yhi;
+                float up = L * un + u; up = 3.f * up;
+                float vp = L * vn + v; vp = 0.25f / vp;
+                vp = 0.25f < vp ? 0.25f : vp;               /* v_min(v4inv, vp): SSE min(a, b) = a < b ? a : b */
+                vp = -0.25f > vp ? -0.25f : vp;             /* v_max(-0.25, .) */
+                float X = 3.f * up; X = X * vp;
+                float Z = L * (12.f * 13.f) + -up; Z = Z * vp + -5.f;
+                float t = X * C[0] + C[1]; t = Z * C[2] + t; R = t * Y;
+                t = X * C[3] + C[4]; t = Z * C[5] + t; G = t * Y;
+                t = X * C[6] + C[7]; t = Z * C[8] + t; B = t * Y;
+                R = R > 0.f ? R : 0.f; R = R < 1.f ? R : 1.f;
+                G = G > 0.f ? G : 0.f; G = G < 1.f ? G : 1.f;
+                B = B > 0.f ? B : 0.f; B = B < 1.f ? B : 1.f;
+            }
+            if (srgb) { R = splineAt(R * 1024.f, InvGammaSpline, 1024); G = splineAt(G * 1024.f, InvGammaSpline, 1024); B = splineAt(B * 1024.f, InvGammaSpline, 1024); }
+            d[0] = R; d[1] = G; d[2] = B;
+            if (dcn == 4) d[3] = 1.f;
+        }
+    }
+}
+
 /* the tables themselves, for a direct comparison with the library's (tests): which = 0 sRGBGamma (256), 1 LabCbrt (3072), 2 sRGBInvGamma (4096),
  * 3 LabToYF (512) as uint16; 4 abToXZ (36864) as int32; 5 the 33^3 x 3 RGB -> Luv table as int16; 6 / 7 LuToUp / LvToVp (65536) as int32 */
 int orc_labTable(int which, void* out)
@@ -540,6 +682,7 @@ int orc_labTable(int which, void* out)
     case 8: buildLuvTables(); memcpy(out, RGB2LabLUT, sizeof RGB2LabLUT); return LUT_DIM * LUT_DIM * LUT_DIM * 3;      /* int16 */
     case 9: buildSplines(); memcpy(out, LabCbrtSpline, sizeof LabCbrtSpline); return 4096;                               /* float */
     case 10: buildSplines(); memcpy(out, InvGammaSpline, sizeof InvGammaSpline); return 4096;
+    case 11: buildSplines(); memcpy(out, GammaSpline, sizeof GammaSpline); return 4096;
     }
     return -1;
 }

@@ -89,6 +89,9 @@ void orc_cvtBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t ds
 void orc_cvtLuvtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int srgb);
 void orc_cvtBGRtoLab32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int srgb);
 void orc_cvtLabtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int srgb);
+void orc_cvtBGRtoLuv32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int scn, int swapBlue, int srgb);
+void orc_cvtLuvtoBGR32f(const float* src, size_t sstepBytes, float* dst, size_t dstepBytes, int w, int h, int dcn, int swapBlue, int srgb);
+void orc_cvtLBGRtoLuv8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue);
 int orc_labTable(int which, void* out);
 void orc_cvtHSVtoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int fullRange, int lanes);
 

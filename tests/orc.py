@@ -262,13 +262,28 @@ _LAB_INV = {56: (0, 1), 57: (1, 1), 78: (0, 0), 79: (1, 0)}
 
 
 _LUV_FWD = {50: 0, 51: 1}                                                     # BGR2Luv, RGB2Luv (sRGB; the linear codes 76 / 77 take the float path)
+_LUV_FWD_ALL = {50: (0, 1), 51: (1, 1), 76: (0, 0), 77: (1, 0)}
 _LUV_INV = {58: (0, 1), 59: (1, 1), 80: (0, 0), 81: (1, 0)}                    # Luv2BGR, Luv2RGB, Luv2LBGR, Luv2LRGB
 
 
 def orc_cvtColorLab(src, code, dcn=3):
     o = oracle()
     h, w = src.shape[:2]
-    if src.dtype == np.float32:                                   # L*a*b* only
+    if src.dtype == np.float32 and (code in _LUV_FWD_ALL or code in _LUV_INV):
+        if code in _LUV_FWD_ALL:
+            swap, srgb = _LUV_FWD_ALL[code]
+            dst = np.empty((h, w, 3), np.float32)
+            o.orc_cvtBGRtoLuv32f(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], swap, srgb)
+        else:
+            swap, srgb = _LUV_INV[code]
+            dst = np.empty((h, w, dcn), np.float32)
+            o.orc_cvtLuvtoBGR32f(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, srgb)
+        return dst
+    if code in (76, 77):                                          # CV_8U L*u*v* from linear RGB: the float path underneath
+        dst = np.empty((h, w, 3), np.uint8)
+        o.orc_cvtLBGRtoLuv8u(P(src), step(src), P(dst), step(dst), w, h, src.shape[2], code - 76)
+        return dst
+    if src.dtype == np.float32:
         if code in _LAB_FWD:
             swap, srgb = _LAB_FWD[code]
             dst = np.empty((h, w, 3), np.float32)

@@ -67,7 +67,7 @@ def _err(a, b):
     return float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))))
 
 
-@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("code", [44, 45, 74, 75, 50, 51, 76, 77])
 @pytest.mark.parametrize("scn", [3, 4])
 def test_float_forward(cv, code, scn):
     """CV_32F L*a*b*: the kernels evaluate the oracle's expressions operation for operation (IEEE, no contraction): equal bits expected, north_star's
@@ -82,26 +82,41 @@ def test_float_forward(cv, code, scn):
     assert _err(cv.cvtColor(img, code), want) <= 1e-4                                               # host-resident image
 
 
-@pytest.mark.parametrize("code", [56, 57, 78, 79])
+@pytest.mark.parametrize("code", [56, 57, 78, 79, 58, 59, 80, 81])
 @pytest.mark.parametrize("dcn", [3, 4])
 def test_float_inverse(cv, code, dcn):
     rng = np.random.default_rng(code + dcn)
     for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (1080, 1920)]:
         lab = np.empty((h, w, 3), np.float32)
         lab[..., 0] = rng.random((h, w)) * 100
-        lab[..., 1:] = rng.random((h, w, 2)) * 254 - 127
+        if code in (56, 57, 78, 79):
+            lab[..., 1:] = rng.random((h, w, 2)) * 254 - 127
+        else:
+            lab[..., 1] = rng.random((h, w)) * 354 - 134
+            lab[..., 2] = rng.random((h, w)) * 262 - 140
         want = orc.orc_cvtColorLab(lab, code, dcn)
         got = cv.cvtColor(torch.from_numpy(lab).cuda(), code, dstCn=dcn).cpu().numpy()
         assert _err(got, want) <= 1e-4, (code, dcn, h, w, _err(got, want))
         assert np.mean(got == want) > 0.999, (code, dcn, h, w, float(np.mean(got == want)))
 
 
+@pytest.mark.parametrize("code", [76, 77])
+@pytest.mark.parametrize("scn", [3, 4])
+def test_luv_from_linear_rgb_8u(cv, code, scn):
+    rng = np.random.default_rng(code + scn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (1080, 1920)]:
+        img = rng.integers(0, 256, (h, w, scn), dtype=np.uint8)
+        want = orc.orc_cvtColorLab(img, code)
+        assert np.array_equal(cv.cvtColor(torch.from_numpy(img).cuda(), code).cpu().numpy(), want), (code, scn, h, w)
+    if scn == 3:
+        img = all_colours()
+        assert np.array_equal(cv.cvtColor(torch.from_numpy(img).cuda(), code).cpu().numpy(), orc.orc_cvtColorLab(img, code)), code
+
+
 def test_declines(cv):
     with pytest.raises((NotImplementedError, ValueError)):
-        cv.cvtColor(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), cv.COLOR_BGR2Luv)
+        cv.cvtColor(torch.zeros((8, 8, 3), dtype=torch.int16, device="cuda"), cv.COLOR_BGR2Luv)
     L = cv._lib.lib
     a = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
-    assert L.mi355cv_cvtBGRtoLab(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 0, 3, False, False, False) == 1         # L*u*v* from linear RGB: the reference's float path runs
-    with pytest.raises(NotImplementedError):
-        cv.cvtColor(a, cv.COLOR_LBGR2Luv)
-    assert L.mi355cv_cvtLabtoBGR(a.data_ptr(), 24, b.data_ptr(), 24, 2, 8, 5, 3, False, False, True) == 1          # L*u*v* on CV_32F
+    assert L.mi355cv_cvtBGRtoLab(a.data_ptr(), 24, b.data_ptr(), 24, 4, 8, 2, 3, False, False, False) == 1         # CV_16U: neither path of the reference's hook pair
+    assert L.mi355cv_cvtLabtoBGR(a.data_ptr(), 24, b.data_ptr(), 24, 8, 8, 0, 2, False, True, True) == 1           # two destination channels

@@ -86,10 +86,10 @@ def _float_inputs(rng, h, w, cn):
     return img
 
 
-@pytest.mark.parametrize("code", [44, 45, 74, 75])
+@pytest.mark.parametrize("code", [44, 45, 74, 75, 50, 51, 76, 77])
 @pytest.mark.parametrize("scn", [3, 4])
 def test_float_forward(code, scn):
-    """CV_32F L*a*b*: identical to the reference, vector bodies and scalar row tails (the last width % 8 pixels) alike"""
+    """CV_32F L*a*b* and L*u*v*: identical to the reference, vector bodies and scalar row tails (the last width % 8 pixels) alike"""
     rng = np.random.default_rng(code + scn)
     for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (50, 1032)]:
         img = _float_inputs(rng, h, w, scn) if h * w > 6 else rng.random((h, w, scn), dtype=np.float32)
@@ -97,14 +97,23 @@ def test_float_forward(code, scn):
         assert np.array_equal(got, want), (code, scn, h, w, _err(got, want))
 
 
-@pytest.mark.parametrize("code", [56, 57, 78, 79])
+def _lab_or_luv(rng, h, w, code):
+    lab = np.empty((h, w, 3), np.float32)
+    lab[..., 0] = rng.random((h, w)) * 100
+    if code in (56, 57, 78, 79):
+        lab[..., 1:] = rng.random((h, w, 2)) * 254 - 127
+    else:
+        lab[..., 1] = rng.random((h, w)) * 354 - 134
+        lab[..., 2] = rng.random((h, w)) * 262 - 140
+    return lab
+
+
+@pytest.mark.parametrize("code", [56, 57, 78, 79, 58, 59, 80, 81])
 @pytest.mark.parametrize("dcn", [3, 4])
 def test_float_inverse(code, dcn):
     rng = np.random.default_rng(code + dcn)
     for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641)]:
-        lab = np.empty((h, w, 3), np.float32)
-        lab[..., 0] = rng.random((h, w)) * 100
-        lab[..., 1:] = rng.random((h, w, 2)) * 254 - 127
+        lab = _lab_or_luv(rng, h, w, code)
         got, want = orc.orc_cvtColorLab(lab, code, dcn), orc.ref_cvtColor(lab, code, dcn)
         assert np.array_equal(got, want), (code, dcn, h, w, _err(got, want))
 
@@ -117,7 +126,23 @@ def test_float_tables_equal_the_oracle_tables():
     grid, want = np.zeros(33 ** 3 * 4, np.int16), np.zeros(33 ** 3 * 3, np.int16)
     assert _lib.lib.mi355cv_labTable(7, grid.ctypes.data) == grid.size and o.orc_labTable(8, want.ctypes.data) == want.size
     assert np.array_equal(grid.reshape(-1, 4)[:, :3], want.reshape(-1, 3))
-    for mine, theirs in ((8, 9), (9, 10)):
+    for mine, theirs in ((8, 9), (9, 10), (10, 11)):
         a, b = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
         assert _lib.lib.mi355cv_labTable(mine, a.ctypes.data) == 4096 and o.orc_labTable(theirs, b.ctypes.data) == 4096
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mine
+
+
+@pytest.mark.parametrize("code", [76, 77])
+@pytest.mark.parametrize("scn", [3, 4])
+def test_luv_from_linear_rgb_8u(code, scn):
+    """CV_8U L*u*v* from LINEAR RGB goes through the float conversion (RGB2Luv_b's float branch): bytes / 255 in, scaled and rounded out"""
+    rng = np.random.default_rng(code + scn)
+    for (h, w) in [(1, 1), (3, 7), (61, 333), (240, 641), (33, 1032)]:
+        img = rng.integers(0, 256, (h, w, scn), dtype=np.uint8)
+        assert np.array_equal(orc.orc_cvtColorLab(img, code), orc.ref_cvtColor(img, code, 3)), (code, scn, h, w)
+    # every colour once
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.empty((4096, 4096, 3), np.uint8)
+    img[..., 0] = (v & 255).reshape(4096, 4096); img[..., 1] = ((v >> 8) & 255).reshape(4096, 4096); img[..., 2] = (v >> 16).reshape(4096, 4096)
+    if scn == 3:
+        assert np.array_equal(orc.orc_cvtColorLab(img, code), orc.ref_cvtColor(img, code, 3)), code
