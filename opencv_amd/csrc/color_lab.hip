@@ -8,7 +8,7 @@
 //   invGamma  4096 x u16   sRGBInvGammaTab_b = round(255 * gamma^-1(i / 4096))            :1265-1271
 // built once on the host (the reference's softfloat arithmetic restated with IEEE float / double operations, its Turkowski cube root
 // (softfloat.cpp:3897) restated as written) and kept in HBM per device; a workgroup copies what its kernel needs into LDS (6.5 KB forward, 9 KB
-// inverse) and converts 32 rows x 256 pixels, a lane owning 4 consecutive pixels of a row (dword traffic, pix4.h).  The a/b -> X/Z table of the
+// inverse) and converts 16 rows x 256 pixels, a lane owning 4 consecutive pixels of a row (dword traffic, pix4.h).  The a/b -> X/Z table of the
 // reference (initLUTforABXZ :1086, 147 KB) is two integer formulas, evaluated instead of looked up.
 // HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.
 // L*a*b* on CV_32F images: the reference's float paths in the form of their vector bodies (RGB2Lab_f :1895 -- for sRGB the same 33^3 grid interpolation as
@@ -273,7 +273,7 @@ const LuvTabs* deviceLuvTabs()
 
 struct Coef9 { int c[9]; };
 
-constexpr int ROWS_PER_BLOCK = 32;
+constexpr int ROWS_PER_BLOCK = 16;                  // 4 rows per wave: a 4K frame is 8160 waves, 8 per SIMD
 
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 __device__ __forceinline__ int sat8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
@@ -294,11 +294,8 @@ __global__ __launch_bounds__(256) void k_bgr2lab_u8(const uchar* __restrict__ sr
     const bool fast = n == 4 && aligned;
     const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
     const int yEnd = min(H, (int)(blockIdx.y + 1) * ROWS_PER_BLOCK);
-    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 4) {
+    auto loadPx = [&](pix4::Px<SCN>& in, int y) {
         const uchar* s = src + (size_t)y * sstep + (size_t)x4 * SCN;
-        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * 3;
-        pix4::Px<SCN> in; pix4::Px<3> out;
-        out.clear();
         if (fast) {
 #pragma unroll
             for (int i = 0; i < SCN; i++) in.w[i] = ((const unsigned*)s)[i];
@@ -307,6 +304,10 @@ __global__ __launch_bounds__(256) void k_bgr2lab_u8(const uchar* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 4 * SCN; i++) if (i < n * SCN) in.put(i, s[i]);
         }
+    };
+    auto convert = [&](const pix4::Px<SCN>& in, int y) {
+        pix4::Px<3> out;
+        out.clear();
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             int R = in.get(p * SCN), G = in.get(p * SCN + 1), B = in.get(p * SCN + 2);               // channel order is folded into the coefficients
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void k_bgr2lab_u8(const uchar* __restrict__ sr
             out.put(p * 3 + 1, sat8(descale(__mul24(500, fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)));
             out.put(p * 3 + 2, sat8(descale(__mul24(200, fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)));
         }
+        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * 3;
         if (fast) {
 #pragma unroll
             for (int i = 0; i < 3; i++) ((unsigned*)d)[i] = out.w[i];
@@ -328,6 +330,15 @@ __global__ __launch_bounds__(256) void k_bgr2lab_u8(const uchar* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 12; i++) if (i < n * 3) d[i] = (uchar)out.get(i);
         }
+    };
+    // two rows per step, both loads issued before the first is consumed (a workgroup's waves are few: the load latency would otherwise sit in the loop)
+    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 8) {
+        const bool two = y + 4 < yEnd;
+        pix4::Px<SCN> a, b;
+        loadPx(a, y);
+        if (two) loadPx(b, y + 4);
+        convert(a, y);
+        if (two) convert(b, y + 4);
     }
 }
 
@@ -354,11 +365,8 @@ __global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ sr
     const bool fast = n == 4 && aligned;
     constexpr int shift = LAB_SHIFT + (14 - INV_GAMMA_SHIFT);
     const int yEnd = min(H, (int)(blockIdx.y + 1) * ROWS_PER_BLOCK);
-    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 4) {
+    auto loadPx = [&](pix4::Px<3>& in, int y) {
         const uchar* s = src + (size_t)y * sstep + (size_t)x4 * 3;
-        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * DCN;
-        pix4::Px<3> in; pix4::Px<DCN> out;
-        out.clear();
         if (fast) {
 #pragma unroll
             for (int i = 0; i < 3; i++) in.w[i] = ((const unsigned*)s)[i];
@@ -367,6 +375,10 @@ __global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 12; i++) if (i < n * 3) in.put(i, s[i]);
         }
+    };
+    auto convert = [&](const pix4::Px<3>& in, int y) {
+        pix4::Px<DCN> out;
+        out.clear();
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int LL = in.get(p * 3), aa = in.get(p * 3 + 1), bb = in.get(p * 3 + 2);
@@ -385,6 +397,7 @@ __global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ sr
             out.put(p * DCN, sat8(bo)); out.put(p * DCN + 1, sat8(go)); out.put(p * DCN + 2, sat8(ro));
             if (DCN == 4) out.put(p * 4 + 3, 255);
         }
+        uchar* d = dst + (size_t)y * dstep + (size_t)x4 * DCN;
         if (fast) {
 #pragma unroll
             for (int i = 0; i < DCN; i++) ((unsigned*)d)[i] = out.w[i];
@@ -392,6 +405,14 @@ __global__ __launch_bounds__(256) void k_lab2bgr_u8(const uchar* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 4 * DCN; i++) if (i < n * DCN) d[i] = (uchar)out.get(i);
         }
+    };
+    for (int y = blockIdx.y * ROWS_PER_BLOCK + (threadIdx.x >> 6); y < yEnd; y += 8) {        // two rows per step, loads first (see the forward kernel)
+        const bool two = y + 4 < yEnd;
+        pix4::Px<3> a, b;
+        loadPx(a, y);
+        if (two) loadPx(b, y + 4);
+        convert(a, y);
+        if (two) convert(b, y + 4);
     }
 }
 
