@@ -13,7 +13,7 @@
 // HBM-bound: (scn + 3) B per pixel forward, (3 + dcn) B inverse.
 // L*a*b* on CV_32F images: the reference's float paths in the form of their vector bodies (RGB2Lab_f :1895 -- for sRGB the same 33^3 grid interpolation as
 // L*u*v*, for linear RGB a cubic spline for the cube root --, Lab2RGBfloat :2169); the last width % 8 pixels of a row in the form of its scalar tails (cubeRoot(),
-// divisions): the oracle written the same way equals the reference bit for bit on every case tested.
+// divisions): the CPU restatement of the same form (tests) equals the reference bit for bit on every case tested.
 // L*u*v* (isLab == false), CV_8U: sRGB -> Luv by trilinear interpolation in the reference's 33^3 fixed-point table (RGB2Luvinterpolate :3276), Luv ->
 // sRGB / linear RGB by Luv2RGBinteger (:3556) -- tables restated the same way.  L*u*v* on CV_32F images, and on CV_8U images in LINEAR RGB, follow the
 // reference's float paths (RGB2Luvfloat :2868, Luv2RGBfloat :3057) the same way as CV_32F L*a*b*.  Both hooks now serve every (depth, isLab, srgb) case.
