@@ -129,6 +129,10 @@ int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst
 void orc_convertMapsToFixed(const void* m1, size_t m1step, const void* m2, size_t m2step, int interleaved, void* d1, size_t d1step, void* d2, size_t d2step,
                             int w, int h, int nn);
 void orc_convertMapsToFloat(const void* m1, size_t m1step, const void* m2, size_t m2step, void* d1, size_t d1step, void* d2, size_t d2step, int interleaved, int w, int h);
+int orc_warpPolarInverse(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                         float cx, float cy, double maxRadius, int flags);
+void orc_log32fRow(const float* s, float* d, int n);                                                   /* cv::log, CV_32F (mathfuncs_core.simd.hpp:759) */
+void orc_cartToPolarRow(const float* x, const float* y, float* mag, float* ang, int n);               /* cv::cartToPolar, radians (:123) */
 int orc_warpPolar(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
                   float cx, float cy, double maxRadius, int flags);
 

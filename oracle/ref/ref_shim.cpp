@@ -343,8 +343,31 @@ int ref_warpPolar(const void* s, size_t ss, int sw, int sh, void* d, size_t ds, 
 {
     REF_TRY
     Mat src = M(s, ss, sw, sh, type), dst = M(d, ds, dw, dh, type);
-    cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
+    if (flags & cv::WARP_INVERSE_MAP) {
+        // the inverse direction first writes the row-wrapped source into the destination array (imgwarp.cpp:3798), i.e. reallocates it: let it have its
+        // own array and copy the result out
+        Mat out;
+        cv::warpPolar(src, out, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
+        if (out.size() != dst.size() || out.type() != dst.type()) return -3;
+        out.copyTo(dst);
+    } else
+        cv::warpPolar(src, dst, Size(dw, dh), Point2f(cx, cy), maxRadius, flags);
     REF_END(dst, d)
+}
+
+// cv::log / cv::cartToPolar on one row of floats (the approximations warpPolar's inverse map is built from)
+int ref_log32f(const float* s, float* d, int n)
+{
+    try { Mat src(1, n, CV_32F, (void*)s), dst(1, n, CV_32F, d); cv::log(src, dst); return dst.data == (uchar*)d ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
+}
+int ref_cartToPolar32f(const float* x, const float* y, float* mag, float* ang, int n, int degrees)
+{
+    try {
+        Mat X(1, n, CV_32F, (void*)x), Y(1, n, CV_32F, (void*)y), Mg(1, n, CV_32F, mag), A(1, n, CV_32F, ang);
+        cv::cartToPolar(X, Y, Mg, A, degrees != 0);
+        return (Mg.data == (uchar*)mag && A.data == (uchar*)ang) ? 0 : -2;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
 }
 
 // cv::FAST (modules/features2d): keypoints as (x, y, response) triples in the order the detector emits them; returns the count

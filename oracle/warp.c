@@ -715,11 +715,119 @@ void orc_convertMapsToFloat(const void* m1, size_t m1step, const void* m2, size_
         }
 }
 
+/* ---- cv::warpPolar with WARP_INVERSE_MAP (imgwarp.cpp:3795-3845): polar / semilog-polar image -> Cartesian image.
+ * The source gets one wrapped row above and below (copyMakeBorder BORDER_WRAP), and for every destination pixel
+ *     (rho, phi) = (magnitude, angle) of (x - cx, y - cy) from cv::cartToPolar, [rho <- log(rho + 1) from cv::log,]  map = (rho / Kmag, phi / Kangle + 1)
+ * then remap.  cartToPolar and log are the reference's float approximations, restated in the form the AVX2 build of core runs them in
+ * (mathfuncs_core.simd.hpp cartToPolar32f_ :123-168 with v_atan_f32 :78-119 and fused multiply-adds, log32f :759-827 over the 256-entry table): a row of
+ * fewer than 16 (cartToPolar) / 8 (log) elements takes the scalar form instead, as does nothing else -- the vector loops re-run the last full vector over
+ * the tail.  cv::cartToPolar cuts a row into blocks of 1024 elements (mathfuncs.cpp:298), so the scalar form also serves a short LAST block. */
+static float atanVec(float y, float x, float scale)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795), p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795),
+                p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795), p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mn = ax < ay ? ax : ay, mx = ax > ay ? ax : ay;
+    const float c = mn / (mx + (float)2.2204460492503131e-16), cc = c * c;
+    float a = fmaf(fmaf(fmaf(cc, p7, p5), cc, p3), cc, p1) * c;
+    if (!(ax >= ay)) a = 90.f - a;
+    if (x < 0.f) a = 180.f - a;
+    if (y < 0.f) a = 360.f - a;
+    return a * scale;
+}
+static float atanScalar(float y, float x, float scale)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795), p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795),
+                p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795), p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    /* compiled inside the AVX2 unit with the compiler's default contraction: a*b + c becomes one fused operation */
+    if (ax >= ay) { c = ay / (ax + (float)2.2204460492503131e-16); c2 = c * c; a = fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c; }
+    else { c = ax / (ay + (float)2.2204460492503131e-16); c2 = c * c; a = fmaf(-(fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1)), c, 90.f); }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a * scale;
+}
+static void cartToPolarRow(const float* X, const float* Y, float* mag, float* ang, int len)
+{
+    const float scale = (float)(3.1415926535897932384626433832795 / 180);
+    for (int j = 0; j < len; j += 1024) {
+        const int n = len - j < 1024 ? len - j : 1024;
+        for (int i = 0; i < n; i++) {
+            const float x = X[j + i], y = Y[j + i];
+            if (n >= 16) { mag[j + i] = sqrtf(fmaf(x, x, y * y)); ang[j + i] = atanVec(y, x, scale); }
+            else { mag[j + i] = sqrtf(fmaf(x, x, y * y)); ang[j + i] = atanScalar(y, x, scale); }
+        }
+    }
+}
+static float logTab32f[512];
+static int logTabReady;
+static float log32fOne(float v, int vec)
+{
+    if (!logTabReady) {
+        for (int i = 0; i < 256; i++) { const double t = 1.0 + i / 256.0; logTab32f[2 * i] = (float)log(t); logTab32f[2 * i + 1] = (float)(1.0 / t); }
+        logTab32f[510] = (float)0.69314718055994530941723212145818; logTab32f[511] = 0.5f;        /* the last cell is measured from 2.0 (hence the -1/512 below) */
+        logTabReady = 1;
+    }
+    uint32_t i0; memcpy(&i0, &v, 4);
+    const uint32_t mant = (i0 & ((1u << 15) - 1)) | (127u << 23);
+    float bf; memcpy(&bf, &mant, 4);
+    const int idx = (int)((i0 >> (23 - 8 - 1)) & (255 * 2));
+    const float e = (float)((int)((i0 >> 23) & 0xff) - 127), ln2 = (float)0.69314718055994530941723212145818;
+    const float A0 = 0.3333333333333333333333333f, A1 = -0.5f, A2 = 1.f, delta = idx == 510 ? -1.f / 512 : 0.f;
+    if (vec) {
+        const float y0 = fmaf(e, ln2, logTab32f[idx]);
+        const float x0 = fmaf(bf - 1.f, logTab32f[idx + 1], delta);
+        float z = fmaf(x0, A0, A1);
+        z = fmaf(z, x0, A2);
+        return fmaf(z, x0, y0);
+    }
+    const float y0 = fmaf(e, ln2, logTab32f[idx]);
+    const float x0 = fmaf(bf - 1.f, logTab32f[idx + 1], delta);
+    return fmaf(fmaf(fmaf(A0, x0, A1), x0, A2), x0, y0);
+}
+
+/* the two approximations on their own (pinned against cv::log / cv::cartToPolar in tests/test_oracle_warp.py) */
+void orc_log32fRow(const float* s, float* d, int n) { for (int i = 0; i < n; i++) d[i] = log32fOne(s[i], n >= 8); }
+void orc_cartToPolarRow(const float* x, const float* y, float* mag, float* ang, int n) { cartToPolarRow(x, y, mag, ang, n); }
+
+int orc_warpPolarInverse(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
+                         float cx, float cy, double maxRadius, int flags)
+{
+    const int esz = (depth == 0 ? 1 : depth == 5 ? 4 : 2) * cn;
+    const size_t bstep = ((size_t)sw * esz + 15) & ~(size_t)15;
+    uint8_t* bordered = (uint8_t*)malloc(bstep * (size_t)(sh + 2));
+    float* mx = (float*)malloc((size_t)dw * dh * sizeof(float));
+    float* my = (float*)malloc((size_t)dw * dh * sizeof(float));
+    float* buf = (float*)malloc((size_t)dw * 4 * sizeof(float));
+    if (!bordered || !mx || !my || !buf) { free(bordered); free(mx); free(my); free(buf); return 1; }
+    for (int r = 0; r < sh + 2; r++) memcpy(bordered + (size_t)r * bstep, src + (size_t)((r - 1 + sh) % sh) * sstep, (size_t)sw * esz);      /* BORDER_WRAP, one row */
+    const int semiLog = (flags & 256) != 0;
+    const double Kangle = 6.283185307179586476925286766559 / sh;
+    const double Kmag = semiLog ? log(maxRadius) / sw : maxRadius / sw;
+    float *bx = buf, *by = buf + dw, *bp = buf + 2 * dw, *ba = buf + 3 * dw;
+    for (int x = 0; x < dw; x++) bx[x] = (float)x - cx;
+    for (int y = 0; y < dh; y++) {
+        for (int x = 0; x < dw; x++) by[x] = (float)y - cy;
+        cartToPolarRow(bx, by, bp, ba, dw);
+        if (semiLog) for (int x = 0; x < dw; x++) { const float t = bp[x] + 1.f; bp[x] = log32fOne(t, dw >= 8); }
+        for (int x = 0; x < dw; x++) {
+            const double rho = bp[x] / Kmag, phi = ba[x] / Kangle;
+            mx[(size_t)y * dw + x] = (float)rho;
+            my[(size_t)y * dw + x] = (float)phi + 1;
+        }
+    }
+    const double bv[4] = {0, 0, 0, 0};
+    const int rc = orc_remap32f(bordered, bstep, sw, sh + 2, dst, dstep, dw, dh, depth, cn, mx, (size_t)dw * 4, my, (size_t)dw * 4, flags & 7, (flags & 8) ? 0 : 5, bv);
+    free(bordered); free(mx); free(my); free(buf);
+    return rc;
+}
+
 /* cv::warpPolar, forward direction (imgwarp.cpp:3731-3793): the two float maps as the reference builds them, then remap */
 int orc_warpPolar(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
                   float cx, float cy, double maxRadius, int flags)
 {
-    if (flags & 16) return 1;
+    if (flags & 16) return orc_warpPolarInverse(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, cx, cy, maxRadius, flags);
     float* mx = (float*)malloc((size_t)dw * dh * sizeof(float));
     float* my = (float*)malloc((size_t)dw * dh * sizeof(float));
     float* rhos = (float*)malloc((size_t)dw * sizeof(float));

@@ -203,6 +203,47 @@ def test_warp_polar_forward(orc, ref, dtype):
             same(orc, orc.orc_warpPolar(src, dsize, center, rad, flags), orc.ref_warpPolar(src, dsize, center, rad, flags))
 
 
+def test_log_and_cart_to_polar_rows(orc, ref):
+    """the two float approximations cv::warpPolar's inverse map is built from, restated in oracle/warp.c in the form the AVX2 build of core runs them in:
+    cv::log over all 2^23 mantissas and random exponents, cv::cartToPolar (radians) over random vectors -- bit patterns compared, for row lengths on
+    both sides of the vector widths (8 / 16) and of cartToPolar's 1024-element blocks"""
+    import ctypes
+    o, r = orc.oracle(), orc.load_ref()
+    vp = ctypes.c_void_p
+    o.orc_log32fRow.argtypes = [vp, vp, ctypes.c_int]; r.ref_log32f.argtypes = [vp, vp, ctypes.c_int]
+    o.orc_cartToPolarRow.argtypes = [vp] * 4 + [ctypes.c_int]; r.ref_cartToPolar32f.argtypes = [vp] * 4 + [ctypes.c_int, ctypes.c_int]
+    P = lambda a: a.ctypes.data_as(vp)
+    rng = np.random.default_rng(1)
+    x = (np.arange(1 << 23, dtype=np.uint32) | (127 << 23)).view(np.float32)
+    a, b = np.zeros_like(x), np.zeros_like(x)
+    o.orc_log32fRow(P(x), P(a), x.size); assert r.ref_log32f(P(x), P(b), x.size) == 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for n in (1, 3, 7, 8, 9, 15, 16, 17, 1000, 1024, 1030, 1039, 1040, 50000):
+        x = np.exp(rng.random(n) * 40 - 20).astype(np.float32)
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        o.orc_log32fRow(P(x), P(a), n); assert r.ref_log32f(P(x), P(b), n) == 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("log", n)
+        xx = (rng.random(n, dtype=np.float32) * 200 - 100).astype(np.float32); yy = (rng.random(n, dtype=np.float32) * 200 - 100).astype(np.float32)
+        xx[: min(n, 3)] = [0.0, -0.0, 5.0][: min(n, 3)]; yy[: min(n, 3)] = [0.0, 3.0, 0.0][: min(n, 3)]
+        m1, a1, m2, a2 = (np.zeros(n, np.float32) for _ in range(4))
+        o.orc_cartToPolarRow(P(xx), P(yy), P(m1), P(a1), n); assert r.ref_cartToPolar32f(P(xx), P(yy), P(m2), P(a2), n, 0) == 0
+        assert np.array_equal(m1.view(np.uint32), m2.view(np.uint32)) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32)), ("cartToPolar", n)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_polar_inverse(orc, ref, dtype):
+    """cv::warpPolar with WARP_INVERSE_MAP (imgwarp.cpp:3795-3845), linear and semilog, nearest and bilinear, with WARP_FILL_OUTLIERS (without it the
+    reference leaves the outliers of its freshly allocated destination undefined).  Widths on both sides of the vector widths of cartToPolar / log."""
+    rng = np.random.default_rng(5)
+    for (sh, sw), dsize, center, rad in [((120, 160), (200, 150), (100.3, 74.6), 90.0), ((64, 100), (7, 9), (3.2, 4.1), 5.0),
+                                          ((256, 300), (1100, 40), (500.5, 20.2), 600.0), ((90, 77), (130, 131), (64.0, 66.0), 80.0)]:
+        for cn in (1, 3):
+            shape = (sh, sw) if cn == 1 else (sh, sw, cn)
+            src = rng.integers(0, 256, shape, dtype=np.uint8) if dtype == np.uint8 else rng.random(shape, dtype=np.float32)
+            for flags in (16 | 1 | 8, 16 | 0 | 8, 16 | 1 | 256 | 8, 16 | 0 | 256 | 8):
+                same(orc, orc.orc_warpPolar(src, dsize, center, rad, flags), orc.ref_warpPolar(src, dsize, center, rad, flags))
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
 @pytest.mark.parametrize("cn", [1, 2, 3, 4])
 def test_resize_linear_exact(orc, ref, dtype, cn):
