@@ -47,3 +47,46 @@ int orc_imageMoments(const uint8_t* src, size_t sstep, int depth /*0 8U, 2 16U, 
     }
     return 0;
 }
+
+/* CV_32F / CV_64F images: momentsInTile<float, double, double> / <double, double, double> (moments.cpp:307-357, no vector form) -- every sum is a chain of
+ * double additions in raster order inside the 32 x 32 tile, rows first, then the ten moments row by row; the tile loop is the one above. */
+int orc_imageMomentsF(const uint8_t* src, size_t sstep, int depth /*5 32F, 6 64F*/, int w, int h, int binary, double* m)
+{
+    if ((depth != 5 && depth != 6) || w <= 0 || h <= 0) return 1;
+    for (int k = 0; k < 10; k++) m[k] = 0;
+    for (int y = 0; y < h; y += 32) {
+        const int th = h - y < 32 ? h - y : 32;
+        for (int x = 0; x < w; x += 32) {
+            const int tw = w - x < 32 ? w - x : 32;
+            double mom[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < th; r++) {
+                const uint8_t* row = src + (size_t)(y + r) * sstep;
+                double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+                for (int c = 0; c < tw; c++) {
+                    double p = depth == 5 ? (double)((const float*)row)[x + c] : ((const double*)row)[x + c];
+                    if (binary) p = p != 0 ? 255 : 0;                       /* the tile is first compared with zero into a CV_8U tile (:523-528) */
+                    const double xp = c * p, xxp = xp * c;
+                    x0 += p; x1 += xp; x2 += xxp; x3 += xxp * c;
+                }
+                const double py = r * x0, sy = (double)(r * r);
+                mom[9] += py * sy; mom[8] += x1 * sy; mom[7] += x2 * r; mom[6] += x3; mom[5] += x0 * sy;
+                mom[4] += x1 * r; mom[3] += x2; mom[2] += py; mom[1] += x1; mom[0] += x0;
+            }
+            double mo[10];
+            for (int k = 0; k < 10; k++) mo[k] = mom[k];
+            if (binary) { const double s = 1. / 255; for (int k = 0; k < 10; k++) mo[k] *= s; }
+            const double xm = x * mo[0], ym = y * mo[0];
+            m[0] += mo[0];
+            m[1] += mo[1] + xm;
+            m[2] += mo[2] + ym;
+            m[3] += mo[3] + x * (mo[1] * 2 + xm);
+            m[4] += mo[4] + x * (mo[2] + ym) + y * mo[1];
+            m[5] += mo[5] + y * (mo[2] * 2 + ym);
+            m[6] += mo[6] + x * (3. * mo[3] + x * (3. * mo[1] + xm));
+            m[7] += mo[7] + x * (2 * (mo[4] + y * mo[1]) + x * (mo[2] + ym)) + y * mo[3];
+            m[8] += mo[8] + y * (2 * (mo[4] + x * mo[2]) + y * (mo[1] + xm)) + x * mo[5];
+            m[9] += mo[9] + y * (3. * mo[5] + y * (3. * mo[2] + ym));
+        }
+    }
+    return 0;
+}

@@ -166,6 +166,7 @@ int orc_medianBlur(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
 int orc_adaptiveThresholdMean(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
                               int blockSize, double delta);
 int orc_imageMoments(const uint8_t* src, size_t sstep, int depth, int w, int h, int binary, double* m);
+int orc_imageMomentsF(const uint8_t* src, size_t sstep, int depth, int w, int h, int binary, double* m);      /* CV_32F / CV_64F */
 int orc_bilateralFilter8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int d, double sigma_color,
                           double sigma_space, int border);
 int orc_adaptiveThresholdGaussian(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,

@@ -435,7 +435,8 @@ def orc_moments(src, binary=False):
     o = oracle()
     h, w = src.shape
     m = np.zeros(10, np.float64)
-    rc = o.orc_imageMoments(P(src), step(src), _NP_DEPTH[src.dtype], w, h, int(binary), P(m))
+    fn = o.orc_imageMomentsF if src.dtype in (np.float32, np.float64) else o.orc_imageMoments
+    rc = fn(P(src), step(src), _NP_DEPTH[src.dtype], w, h, int(binary), P(m))
     assert rc == 0, rc
     return m
 

@@ -109,6 +109,20 @@ def test_image_moments_match_reference(ref):
                     assert np.array_equal(O.orc_moments(src, binary), O.ref_moments(src, binary)), (dt, w, h, binary)
 
 
+def test_image_moments_float_match_reference(ref):
+    """cv::moments of CV_32F / CV_64F images: chains of double additions in raster order inside every 32 x 32 tile (no vector form in the reference) --
+    the restatement (oracle/moments.c orc_imageMomentsF) gives the reference's doubles bit for bit; the GPU kernel for these depths is not built yet
+    (the hook declines them), this pins what it will have to reproduce"""
+    rng = np.random.default_rng(2)
+    for dt in (np.float32, np.float64):
+        for (h, w) in [(1, 1), (31, 33), (64, 64), (100, 257), (480, 641), (1080, 1920)]:
+            img = (rng.random((h, w)) * 1000 - 300).astype(dt)
+            img[rng.random((h, w)) < 0.2] = 0
+            for binary in (False, True):
+                a, b = O.orc_moments(img, binary), O.ref_moments(img, binary)
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (dt, h, w, binary)
+
+
 @pytest.mark.ref
 def test_gaussian_c_float_blur_is_bit_identical_on_8bit_valued_images(ref):
     """the float blur inside ADAPTIVE_THRESH_GAUSSIAN_C (CV_32F GaussianBlur of an 8-bit valued image): the restated separable float path gives the
