@@ -3,11 +3,17 @@
 3840x2160 CV_8U frames + achieved HBM GB/s against the MI355X roofline.
 
 A "step" is one pass of the hot path over one batch: B device-resident 4K 8UC1 frames per GPU through
-mi355cv_gaussianBlurBinomialBatch (ONE launch over the whole batch).  B is sized for the GPU's HBM (pick_batch: 9216
-frames = 153 GB of source + destination on a 288 GB MI355X), so a step is ~26 ms and 20 steps span > 0.5 s.  Frames
-are independent units, so N GPUs = N processes each owning its own frames: weak scaling, no data-path collective; the
-only collective is the RCCL broadcast of the shared filter taps at plan time.  `python bench.py --gpus N`
-spawns the N ranks itself when no launcher did (torch.distributed.run) and refuses to run on fewer than N GPUs.
+mi355cv_gaussianBlurBinomialBatch, issued as B / 512 consecutive launches over sub-batches of 512 frames (each with its own
+event pair).  B is sized for the GPU's HBM (pick_batch: 9216 frames = 153 GB of source + destination on a 288 GB MI355X),
+so a step is ~26 ms and 20 steps span > 0.5 s.  Frames are independent units, so N GPUs = N processes each owning its own
+frames: weak scaling, no data-path collective; the only collective is the RCCL broadcast of the launch plan (filter size,
+border rule, frames per launch -- rank 0 decides, every rank runs what it received) at plan time.
+`python bench.py --gpus N` spawns the N ranks itself when no launcher did (torch.distributed.run) and refuses to run on
+fewer than N GPUs.
+
+`roofline.traffic` is measured IN this run: after the timed region rank 0 re-runs one sub-batch of the same launch geometry under
+`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, nothing else traced), together with a 16 B / lane copy of known
+size that calibrates both counters on this box (MI355X_MICROARCH.md, HBM section).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline`.
 """
@@ -28,8 +34,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PIXEL = 2.0     # 1 B read + 1 B written per 8UC1 pixel
 
 
+def host_cpu():
+    """CPU model and last-level cache of the box ("core count and CPU model printed")"""
+    model, llc = "unknown", None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        best = -1
+        base = "/sys/devices/system/cpu/cpu0/cache"
+        for d in os.listdir(base):
+            lvl = int(open(os.path.join(base, d, "level")).read())
+            if lvl > best and open(os.path.join(base, d, "type")).read().strip() != "Instruction":
+                best, llc = lvl, f"L{lvl} {open(os.path.join(base, d, 'size')).read().strip()}"
+    except (OSError, ValueError):
+        pass
+    return model, llc
+
+
 def cpu_baseline(budget_s=12.0):
     """Reference CPU path on this box's host cores, bounded sample (rank 0, N=1 only)."""
+    cpu_model, cpu_llc = host_cpu()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     NF = 32                                               # 32 distinct frames: 265 MB in + 265 MB out per sweep
@@ -60,6 +88,7 @@ def cpu_baseline(budget_s=12.0):
             if dt > budget_s or n >= 200000:
                 break
         return {"value": round(n * W4K * H4K / dt / 1e6, 1), "unit": "Mpix/s", "cores": int(cores), "kind": "reference",
+                "cpu_model": cpu_model, "cpu_llc": cpu_llc, "logical_cpus": os.cpu_count(),
                 "sample": f"{n} x cv::GaussianBlur(5x5,sigma=0,REFLECT_101) cycling over {NF} distinct 3840x2160 CV_8UC1 frames, "
                           f"{cores} threads (oracle/_ref build of the reference: SSE3 baseline, smooth dispatched to AVX2 -- the widest its CMake lists --, "
                           f"pthreads backend, no IPP / OpenCL), inputs from cv::RNG(809564), {dt:.1f} s"}
@@ -71,7 +100,7 @@ def cpu_baseline(budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s:
             break
-    return {"value": round(n * crop.size / dt / 1e6, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
+    return {"value": round(n * crop.size / dt / 1e6, 1), "unit": "Mpix/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "cpu_llc": cpu_llc,
             "sample": f"{n} x oracle C restatement on a 960x540 crop, 1 thread, {dt:.1f} s"}
 
 
@@ -80,7 +109,7 @@ def other_configs(with_cpu=True):
     reference's CPU path timed beside them on the host cores (rank 0, N=1 only; reported, never part of `value`)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs
-    rows = bench_configs.run(quick=True)
+    rows = bench_configs.run(quick=False)
     if not with_cpu:
         return rows
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -239,6 +268,85 @@ def copy_probe(views, reps=2):
     return 2.0 * sum(f.numel() for f, _ in views) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def pmc_child(fpl):
+    """the process rocprofv3 --pmc wraps (measure_traffic): two distinct sub-batches of the timed launch geometry through the headline kernel, and a
+    16 B / lane copy of one sub-batch whose byte count is known exactly -- the calibration of FETCH_SIZE / WRITE_SIZE on this box"""
+    import ctypes
+    import opencv_amd as cv
+    from opencv_amd import _lib
+    torch.cuda.set_device(0)
+    g = torch.Generator(device="cuda"); g.manual_seed(809564)
+    frames = torch.empty((2 * fpl, H4K, W4K), dtype=torch.uint8, device="cuda")
+    for lo in range(0, 2 * fpl, 256):
+        frames[lo:lo + 256] = torch.randint(0, 256, (min(256, 2 * fpl - lo), H4K, W4K), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.empty_like(frames)
+    cv.set_async(True)
+    for rep in range(3):
+        for lo in (0, fpl):
+            cv.GaussianBlurBatch(frames[lo:lo + fpl], 5, dst=out[lo:lo + fpl])
+    for rep in range(2):
+        for lo in (0, fpl):
+            assert _lib.lib.mi355cv_copyProbe(ctypes.c_void_p(frames[lo].data_ptr()), ctypes.c_void_p(out[lo].data_ptr()), ctypes.c_size_t(fpl * H4K * W4K), 1, 1) == 0
+    torch.cuda.synchronize()
+    print("PMC_CHILD_KERNEL " + _lib.lib.mi355cv_lastKernel().decode(), flush=True)
+    return 0
+
+
+def measure_traffic(fpl, kernel, timeout_s=240):
+    """roofline.traffic, measured in this run: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` as two separate passes (the two counters do not
+    fit the TCC's slots together; nothing else is traced) over `bench.py --pmc-child`.  Both counters are in KiB.  MI355X_MICROARCH.md: on gfx950
+    FETCH_SIZE reports half the bytes of a wide coalesced read and WRITE_SIZE is uncalibrated -- so both are calibrated here on a 16 B / lane copy of
+    known size run in the same passes, and the calibrated figures are what `traffic` reports (raw values and factors are kept beside them)."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    info = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --pmc-child` in this run; KiB -> bytes; "
+                      "calibrated on a 16 B/lane copy of known size in the same passes"}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        info["error"] = "rocprofv3 not found"; return info
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        info["error"] = "this run is itself under rocprofv3: nested counter collection skipped"; return info
+    copy_bytes = fpl * W4K * H4K
+    raw = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mi355cv_pmc_", dir="/tmp")
+        env = dict(os.environ); env["TMPDIR"] = "/tmp"
+        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--frames-per-launch", str(fpl)]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            info["error"] = f"{ctr} pass timed out"; shutil.rmtree(d, ignore_errors=True); return info
+        child_kernel = [l for l in p.stdout.splitlines() if l.startswith("PMC_CHILD_KERNEL ")]
+        vals = {"gauss": [], "copy": []}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f, newline="")):
+                if r.get("Counter_Name") != ctr:
+                    continue
+                if "k_binomial_roll2" in r["Kernel_Name"]:
+                    vals["gauss"].append(float(r["Counter_Value"]))
+                elif "k_copy16" in r["Kernel_Name"]:
+                    vals["copy"].append(float(r["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if p.returncode != 0 or not vals["gauss"] or not vals["copy"] or not child_kernel:
+            info["error"] = f"{ctr} pass: rc {p.returncode}, {len(vals['gauss'])} kernel rows; tail: {p.stdout[-300:]}"; return info
+        if child_kernel[0][len("PMC_CHILD_KERNEL "):].split(" grid=")[0] != kernel.split(" grid=")[0]:
+            info["error"] = "the profiled pass launched another kernel instance than the timed region"; return info
+        raw[ctr] = (statistics.median(vals["gauss"]) * 1024, statistics.median(vals["copy"]) * 1024, len(vals["gauss"]))
+    fcal = copy_bytes / raw["FETCH_SIZE"][1]
+    wcal = copy_bytes / raw["WRITE_SIZE"][1]
+    fetch, write = raw["FETCH_SIZE"][0] * fcal, raw["WRITE_SIZE"][0] * wcal
+    info.update({"frames_per_launch": fpl, "dispatches_sampled": raw["FETCH_SIZE"][2],
+                 "fetch_raw_bytes": int(raw["FETCH_SIZE"][0]), "write_raw_bytes": int(raw["WRITE_SIZE"][0]),
+                 "fetch_calibration": round(fcal, 4), "write_calibration": round(wcal, 4),
+                 "fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write), "hbm_bytes_per_launch": int(fetch + write),
+                 "algorithmic_bytes_per_launch": int(2 * copy_bytes), "traffic_over_algorithmic": round((fetch + write) / (2 * copy_bytes), 4)})
+    return info
+
+
 def multi_gpu_legs(cv, dist, dev, rank, world):
     """BASELINE configs 4 and 5 under N > 1: frames sharded by index, shared parameters broadcast from rank 0 over RCCL, no
     data-path collective.  cfg4: 256 x 1080p frames -> cornerHarris + buildPyramid(4); cfg5: batched matchTemplate, one template."""
@@ -290,12 +398,16 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=int(os.environ.get("MI355CV_BENCH_FPL", "512")),
                     help="a step (one pass over the resident batch) is issued as consecutive launches over sub-batches of this many frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2-5 (reported under other_configs)")
     args = ap.parse_args()
 
     # test hook, never a reportable number: MI355CV_BENCH_SHARED_GPU=1 lets the N ranks share GPU 0 over gloo, so that the N > 1 code path
     # (spawn, sharding, broadcasts, max-over-ranks timing, the cfg4 / cfg5 legs) can be exercised on a one-GPU box; the line says so
     shared = os.environ.get("MI355CV_BENCH_SHARED_GPU") == "1"
+    if args.pmc_child:
+        return pmc_child(args.frames_per_launch)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         from opencv_amd import shard                       # no launcher: become the launcher (N ranks, one per GPU, RCCL); loud when < N GPUs
         sys.exit(shard.spawn_ranks(args.gpus, __file__, sys.argv[1:], need_gpus=not shared))
@@ -323,12 +435,12 @@ def main():
     import opencv_amd as cv
     from opencv_amd import _lib
 
-    # plan time: rank 0 owns the filter definition; RCCL broadcast over xGMI (bytes, once)
-    taps = torch.from_numpy(cv.getGaussianKernelQ8_binomial(5).astype(np.int32)).to(dev) if rank == 0 \
-        else torch.zeros(5, dtype=torch.int32, device=dev)
+    # plan time: rank 0 owns the launch plan -- filter size, border rule, frames per launch -- and broadcasts it (RCCL over xGMI, a few bytes,
+    # once); every rank runs what it RECEIVED, so a rank that missed the broadcast would launch a different (and refused: ksize 0) filter
+    plan = torch.tensor([5, cv.BORDER_REFLECT_101, args.frames_per_launch] if rank == 0 else [0, 0, 0], dtype=torch.int32, device=dev)
     if dist is not None:
-        dist.broadcast(taps, src=0)
-    assert taps.cpu().tolist() == [16, 64, 96, 64, 16]
+        dist.broadcast(plan, src=0)
+    KS, BORDER, FPL_PLAN = (int(v) for v in plan.cpu().tolist())
 
     B = pick_batch(dev, args.batch)
     if dist is not None:                                    # every rank runs the same per-GPU batch (weak scaling)
@@ -339,7 +451,7 @@ def main():
     # the same 9216 frames ran 4-6 % slower as a single 1.66 M-workgroup launch than as 18 launches of 512 frames (tools/split_probe.py,
     # profiles/r02_split_probe.txt) -- the library's batch entry splits a large batch the same way on its own; here the sub-batches are
     # explicit so that every kernel launch gets its own pair of events.
-    FPL = max(1, min(args.frames_per_launch, B))
+    FPL = max(1, min(FPL_PLAN, B))
     B = B // FPL * FPL
     g = torch.Generator(device=dev)
     g.manual_seed(809564 + rank)
@@ -349,7 +461,7 @@ def main():
     out = torch.empty_like(frames)
 
     # parity gate before timing (rank 0: against the CPU checker; every rank: the call must succeed)
-    cv.GaussianBlurBatch(frames, 5, dst=out)
+    cv.GaussianBlurBatch(frames, KS, BORDER, dst=out)
     torch.cuda.synchronize()
     kernel = _lib.lib.mi355cv_lastKernel().decode()
     parity = parity_gate(cv, frames, out, B) if rank == 0 else None
@@ -357,11 +469,11 @@ def main():
     views = [(frames[lo:lo + FPL], out[lo:lo + FPL]) for lo in range(0, B, FPL)]
     nl = len(views)
     cv.set_async(True)
-    cv.GaussianBlurBatch(views[0][0], 5, dst=views[0][1])
+    cv.GaussianBlurBatch(views[0][0], KS, BORDER, dst=views[0][1])
     kernel = _lib.lib.mi355cv_lastKernel().decode()        # the instance and geometry of the timed launches
     for _ in range(args.warmup):
         for f, o in views:
-            cv.GaussianBlurBatch(f, 5, dst=o)
+            cv.GaussianBlurBatch(f, KS, BORDER, dst=o)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -372,7 +484,7 @@ def main():
     for s in range(args.steps):
         for f, o in views:
             ev[k].record(); k += 1             # launches are bound to torch's current stream (core.bind_stream)
-            cv.GaussianBlurBatch(f, 5, dst=o)
+            cv.GaussianBlurBatch(f, KS, BORDER, dst=o)
     ev[k].record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -404,18 +516,14 @@ def main():
         algo = ALGO_BYTES_PER_PIXEL * FPL * W4K * H4K        # per kernel launch
         achieved = algo / (kern_ms * 1e-3) / 1e9
         q = max(1, args.steps // 4)
-        # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this same command (tools/prof_gauss.sh), corrected
-        # as MI355X_MICROARCH.md prescribes; used only when it was taken on the kernel instance this run launched, scaled to this batch
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            try:
-                j = json.load(open(tj))
-                if j.get("kernel", "").split(" grid=")[0] == kernel.split(" grid=")[0] and j.get("frames_per_launch"):
-                    traffic = int(j["hbm_bytes_per_launch"] * (FPL / j["frames_per_launch"]))
-                    traffic_src = j.get("source")
-            except Exception:
-                traffic = None
+        # HBM bytes per launch from the PMC counters, measured in THIS run on THIS box (measure_traffic below)
+        traffic_info = None
+        if world == 1 and not args.no_pmc:
+            del frames, out, views
+            frames = out = views = None
+            torch.cuda.empty_cache()
+            traffic_info = measure_traffic(FPL, kernel)
+        traffic = traffic_info.get("hbm_bytes_per_launch") if traffic_info else None
         res = {
             "metric": "Mpix/s per GPU (4K CV_8U Gaussian5x5) + achieved HBM GB/s vs roofline, 1/2/4/8 GPUs",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -424,11 +532,11 @@ def main():
             "config": {"workload": "cv::GaussianBlur 5x5 sigma=0 BORDER_REFLECT_101 on 3840x2160 CV_8UC1, "
                                    f"{B} device-resident frames per GPU per step ({2 * B * W4K * H4K / 1e9:.1f} GB of HBM: one pass = {nl} launches of {FPL} frames)",
                        "frames_per_gpu": B, "frames_per_launch": FPL, "launches_per_step": nl, "sharding": f"frames x{world}, no data-path collective", "ranks": world,
-                       "collective": ("gloo (test mode)" if shared else "RCCL") + " broadcast of the filter taps at plan time" if world > 1 else "none (1 GPU)"},
+                       "collective": ("gloo (test mode)" if shared else "RCCL") + " broadcast of the launch plan (ksize, border, frames per launch) from rank 0 at plan time" if world > 1 else "none (1 GPU)"},
             "per_gpu_mpix_s": round(value / world, 1),
             "timed_region_s": round(elapsed, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_info,
                          "kernel": kernel, "avg_launch_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(algo),
                          "launches_timed": int(per_launch.size),
@@ -448,7 +556,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_other_configs:
-            del frames, out, views
+            frames = out = views = None
             torch.cuda.empty_cache()
             try:
                 res["other_configs"] = other_configs(with_cpu=not args.no_cpu_baseline)

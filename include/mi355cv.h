@@ -99,6 +99,12 @@ MI355CV_API int  mi355cv_synchronize(void);
 /* number of times the named entry point ran its GPU path to completion in this process
  * (the analogue of the reference's CV_IMPL_ADD bookkeeping, core/private.hpp) */
 MI355CV_API long long mi355cv_callCount(const char* entry);
+/* the other side of the ledger: calls a hook DECLINED (answered MI355CV_NOT_IMPLEMENTED, so that the caller ran its own CPU path --
+ * hal_replacement.hpp:1351-1357 makes that silent).  The HAL header (mi355cv_hal.hpp) and the Python mirror report every declined call
+ * through mi355cv_noteDecline under the reference's hook name ("warpAffine", "sepFilter", ...); mi355cv_declineCount(hook) reads one
+ * tally, mi355cv_declineCount(NULL) the total; MI355CV_PRINT_COUNTS=1 prints both ledgers at exit with the last reason per hook. */
+MI355CV_API void      mi355cv_noteDecline(const char* hook);
+MI355CV_API long long mi355cv_declineCount(const char* hook);
 /* image bytes the hooks of this process have moved over PCIe so far (host-resident images staged into HBM + results staged back); stays
  * constant across calls on device-resident / managed images -- how a test shows that a pipeline ran in place in HBM */
 MI355CV_API long long mi355cv_stagedBytes(void);

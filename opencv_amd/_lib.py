@@ -57,6 +57,8 @@ def _load():
         "mi355cv_setAsync": (c_int, [c_int]),
         "mi355cv_synchronize": (c_int, []),
         "mi355cv_callCount": (ctypes.c_longlong, [ctypes.c_char_p]),
+        "mi355cv_noteDecline": (None, [ctypes.c_char_p]),
+        "mi355cv_declineCount": (ctypes.c_longlong, [ctypes.c_char_p]),
         "mi355cv_stagedBytes": (ctypes.c_longlong, []),
         "mi355cv_setParam": (c_int, [ctypes.c_char_p, c_int]),
         "mi355cv_copyProbe": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz, c_int, c_int]),
@@ -172,9 +174,15 @@ def check(code, entry):
         return
     msg = lib.mi355cv_lastError().decode(errors="replace")
     if code == NOT_IMPLEMENTED:
+        lib.mi355cv_noteDecline(entry.encode())
         raise NotImplementedError(f"mi355cv_{entry}: NOT_IMPLEMENTED for these arguments ({msg}); no CPU fallback in opencv_amd")
     raise Mi355cvError(f"mi355cv_{entry} failed with {code}: {msg}")
 
 
 def call_count(entry: str) -> int:
     return int(lib.mi355cv_callCount(entry.encode()))
+
+
+def decline_count(entry=None) -> int:
+    """calls the named hook declined so far in this process (None: all hooks), see mi355cv_declineCount"""
+    return int(lib.mi355cv_declineCount(entry.encode() if entry is not None else None))

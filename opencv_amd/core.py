@@ -37,6 +37,17 @@ def CV_MAKETYPE(depth, cn):
     return depth + ((cn - 1) << 3)
 
 
+def _row_step(stride, rowb, h):
+    """Row step in bytes of a view.  A one-row view may carry any stride (numpy / torch report what they like for a length-1 axis): it gets
+    at least one row of bytes, like a one-row cv::Mat submatrix keeps its parent's step.  For h > 1 the rows must not overlap or run
+    backwards -- negative, zero (broadcast) or short strides would make the hooks read and write outside the buffer."""
+    if h <= 1:
+        return stride if stride >= rowb else rowb
+    if stride < rowb:
+        raise ValueError(f"image rows overlap or run backwards (row stride {stride} B < {rowb} B per row): pass a contiguous copy")
+    return stride
+
+
 class Img:
     """A 2-D image view handed to the C ABI: pointer, step (bytes), width, height, depth, channels."""
     __slots__ = ("obj", "ptr", "step", "w", "h", "depth", "cn", "device", "esz")
@@ -57,7 +68,7 @@ class Img:
             self.depth, self.esz = _T_DEPTH_ESZ[a.dtype]
             # a one-row view keeps its parent's step like a cv::Mat submatrix does (the hooks reach real rows above / below a ROI through it)
             rowb = self.w * self.cn * self.esz
-            self.step = st[0] * self.esz if st[0] * self.esz >= rowb else rowb
+            self.step = _row_step(st[0] * self.esz, rowb, self.h)
             self.ptr = a.data_ptr()
             self.device = a.is_cuda
         else:
@@ -74,7 +85,7 @@ class Img:
             if a.ndim == 2 and self.w > 1 and a.strides[1] != self.esz:
                 raise ValueError("image rows must be dense")
             rowb = self.w * self.cn * self.esz
-            self.step = a.strides[0] if a.strides[0] >= rowb else rowb
+            self.step = _row_step(a.strides[0], rowb, self.h)
             self.ptr = a.ctypes.data
             self.device = False
 

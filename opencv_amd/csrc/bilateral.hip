@@ -117,6 +117,7 @@ extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t
     int radius = d <= 0 ? (int)std::nearbyint(sigma_space * 1.5) : d / 2;
     if (radius < 1) radius = 1;
     if (radius > B_RMAX) return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: radius %d > %d", radius, B_RMAX);
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     std::vector<float> cw((size_t)256 * cn), sw;
@@ -130,7 +131,7 @@ extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t
             of.push_back((short)j); of.push_back((short)i);
         }
     const int maxk = (int)sw.size();
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn, height, &dds);
     const float* dcw = (const float*)stg.param(cw.data(), cw.size() * sizeof(float));

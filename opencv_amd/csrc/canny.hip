@@ -161,6 +161,7 @@ extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step,
                                          double lowThreshold, double highThreshold, int ksize, bool L2gradient)
 {
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     // canny.cpp:887-896 (the aperture-7 scaling and the swap happen before the hook)
@@ -171,7 +172,7 @@ extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step,
         if (hi > 0) hi *= hi;
     }
     const int low = (int)std::floor(lo), high = (int)std::floor(hi);
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
     const size_t gstep = (((size_t)width * cn * 2) + 255) & ~(size_t)255;             // bytes per row of the 16S gradient images

@@ -138,9 +138,9 @@ int runBgr2Gray(const char* entry, const uchar* src, size_t sstep, size_t sframe
     if (disabled()) return MI355CV_NOT_IMPLEMENTED;
     const int e = esz(depth);
     if (!e || (scn != 3 && scn != 4) || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg;
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {
@@ -196,8 +196,9 @@ MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uch
 {
     if (disabled()) return MI355CV_NOT_IMPLEMENTED;
     const int e = esz(depth);
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!e || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -216,9 +217,10 @@ MI355CV_API int mi355cv_cvtBGRtoBGR(const uchar* src_data, size_t src_step, ucha
 {
     if (disabled()) return MI355CV_NOT_IMPLEMENTED;
     const int e = esz(depth);
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;     // in-place reorder: leave to the caller's path
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;

@@ -801,11 +801,12 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
 {
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (depth == MI355CV_32F && isLab) {
+        Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
         if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
-        Stager stg; size_t dss, dds;
+        size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * 4, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 12, height, &dds);
         if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -832,11 +833,12 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
     if (!isLab && (depth == MI355CV_32F || !srgb)) {
         // L*u*v* in float: CV_32F images, and CV_8U images in linear RGB (RGB2Luv_b color_lab.cpp:3389-3392 interpolates in the grid for sRGB only)
         const int e = depth == MI355CV_32F ? 4 : 1;
+        Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return MI355CV_NOT_IMPLEMENTED;
         if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
-        Stager stg; size_t dss, dds;
+        size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * e, height, &dds);
         if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -853,12 +855,13 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         noteKernel("k_bgr2luv_f32<%d,%s,%s> grid=%ux%u x256", scn, srgb ? "srgb" : "linear", e == 1 ? "u8" : "f32", grid.x, grid.y);
         return stg.finish("cvtBGRtoLab");
     }
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs && !luv) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -895,11 +898,12 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
 {
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (depth == MI355CV_32F && isLab) {
+        Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
         if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
-        Stager stg; size_t dss, dds;
+        size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
         if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -919,11 +923,12 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
         return stg.finish("cvtLabtoBGR");
     }
     if (depth == MI355CV_32F) {                             // L*u*v*, CV_32F: Luv2RGBfloat
+        Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
         if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
-        Stager stg; size_t dss, dds;
+        size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
         if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -939,12 +944,13 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
         return stg.finish("cvtLabtoBGR");
     }
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = deviceTabs();
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs || (!isLab && !luv)) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;

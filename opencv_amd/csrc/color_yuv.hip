@@ -230,10 +230,11 @@ MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, ucha
 {
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
         return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * esz, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * esz, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -264,10 +265,11 @@ MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, ucha
 {
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
         return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3 * esz, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * esz, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -297,9 +299,10 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
 {
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
         return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(y_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t ys, uvs, dds;
+    size_t ys, uvs, dds;
     const uchar* dy = stg.in(y_data, y_step, (size_t)dst_width, dst_height, &ys);
     const uchar* duv = stg.in(uv_data, uv_step, (size_t)dst_width, dst_height / 2, &uvs);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
@@ -316,9 +319,10 @@ MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, ucha
                                     int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV)
 {
     if (disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -339,9 +343,10 @@ MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_
 {
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
         return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)dst_width, dst_height * 3 / 2, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -366,9 +371,10 @@ MI355CV_API int mi355cv_cvtHSVtoBGR(const uchar* src_data, size_t src_step, ucha
                                     int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV)
 {
     if (disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;

@@ -366,10 +366,11 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
     if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;   // pyramids.cpp:1352 forbids CONSTANT
     if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
     if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)sw * sh < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
-    Stager stg; size_t dss = sstep, dds = dstep;
+    size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {
         const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * cn * e;
@@ -718,9 +719,10 @@ int runCorner(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     if (border == B_WRAP || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;          // FilterEngine rejects WRAP
     if (blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss = sstep, dds = dstep;
+    size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {
         ds = stg.in(src, sstep, (size_t)W * (sdepth == D8U ? 1 : 4), H, &dss);
@@ -839,10 +841,10 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
     int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
     if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data)) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
     for (int l = 0; l < maxlevel; l++) if (!isDevicePtr(dst_data[l])) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
-    Stager stg;
     const uchar* s = src_data; size_t ss = src_step, sf = nframes == 1 ? 0 : src_frame_stride; int w = width, h = height;
     for (int l = 0; l < maxlevel; l++) {
         const int dw = (w + 1) / 2, dh = (h + 1) / 2;
@@ -891,8 +893,9 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
     if (disabled() || !corners || qualityLevel <= 0 || minDistance < 0 || width <= 0 || height <= 0) return -1;
     const int sdepth = MI355CV_MAT_DEPTH(src_type);
     if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return -1;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return -1;
-    Stager stg; size_t dss, dms = mask_step;
+    size_t dss, dms = mask_step;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * (sdepth == D8U ? 1 : 4), height, &dss);
     const uchar* dm = nullptr;
     if (mask_data) dm = stg.in(mask_data, mask_step, (size_t)width, height, &dms);

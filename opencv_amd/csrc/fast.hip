@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ 
 int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int w, int h, int type)
 {
     if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)w * h < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t ss, ds;
+    size_t ss, ds;
     const uchar* s = stg.in(src, sstep, (size_t)w, h, &ss);
     uchar* d = stg.out(dst, dstep, (size_t)w, h, &ds);
     if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
@@ -142,9 +143,10 @@ MI355CV_API int mi355cv_FAST_dense(const uchar* src_data, size_t src_step, uchar
 MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
     if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t ss, ds;
+    size_t ss, ds;
     const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
     uchar* d = stg.out(dst_data, dst_step, (size_t)width, height, &ds);
     if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
@@ -160,8 +162,9 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
 {
     if (disabled() || type != 2 || width <= 0 || height <= 0 || !src_data || capacity < 0 || (capacity > 0 && !keypoints_xyr)) return -1;
     if ((long long)width * height > 0x7fffffffLL) return -1;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return -1;
-    Stager stg; size_t ss;
+    size_t ss;
     const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
     const size_t pitch = ((size_t)width + 63) & ~(size_t)63;
     uchar* sc = (uchar*)stg.scratch(pitch * height);

@@ -551,6 +551,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
            int W, int H, int fullW, int fullH, int offX, int offY)
 {
     if (disabled() || W <= 0 || H <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
@@ -558,7 +559,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     const uchar* top = src - (ptrdiff_t)offY * (ptrdiff_t)sstep - (ptrdiff_t)offX * c.cn * se;
     if (overlapOnDevice(top, (size_t)(fullH - 1) * sstep + (size_t)fullW * c.cn * se, dst, (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the device-resident source rows (in-place)", entry);
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* dtop = stg.in(top, sstep, (size_t)fullW * c.cn * se, fullH, &dss);
     uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -585,6 +586,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
 int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H)
 {
     if (disabled() || W <= 0 || H <= 0 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
@@ -592,7 +594,6 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
                         dst, (size_t)(nframes - 1) * dframe + (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the source frames (in-place)", entry);
     if (nframes == 1) { sframe = 0; dframe = 0; }
-    Stager stg;
     const SepParams& p = c.sp;
     const bool centred = p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2;
     if (p.mode == 2 && c.ddepth == D16S && centred && p.deltaI == 0 &&
@@ -726,8 +727,8 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
         return runHostBatch("filterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
             return mi355cv_filterBatch(context, s, ss, sf, d, ds, df, nf, width, height); });
     }
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg;
     if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
     if (!tryFilterRoll(c, src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, stream())) {
         Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
@@ -757,6 +758,7 @@ MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uc
         return runHostBatch("cvtBGRtoGrayFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
             return mi355cv_cvtBGRtoGrayFilterBatch(context, s, ss, sf, d, ds, df, nf, width, height, scn, swapBlue); });
     }
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
     const int K = c->kw;
     if (c->cn != 1 || c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2)
@@ -764,7 +766,6 @@ MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uc
     if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
     if (!roll::eligible(dst_data, dst_step, dst_frame_stride, dst_data, dst_step, dst_frame_stride, width, 1, K / 2, c->border) || (width & 15))
         return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoGrayFilterBatch: width must be a multiple of 16 pixels");
-    Stager stg;
     DenseTaps t; memset(&t, 0, sizeof t);
     for (const Tap2D& tp : c->taps) t.k[tp.dy * K + tp.dx] = tp.k;
     t.delta = c->delta;
@@ -783,6 +784,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
@@ -797,7 +799,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     const uchar* top = src_data - (ptrdiff_t)offset_y * (ptrdiff_t)src_step - (ptrdiff_t)offset_x * c->cn * se;
     if (overlapOnDevice(top, (size_t)(full_height - 1) * src_step + (size_t)full_width * c->cn * se, dst_data, (size_t)(height - 1) * dst_step + (size_t)width * c->cn * de))
         return setError(MI355CV_NOT_IMPLEMENTED, "filter: dst overlaps the device-resident source rows (in-place)");
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* dtop = stg.in(top, src_step, (size_t)full_width * c->cn * se, full_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * de, height, &dds);
     Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
@@ -957,6 +959,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         const long long lim = src_depth == D8U ? (1LL << 23) : src_depth == D16U ? (1LL << 15) : (1LL << 16);
         if (normalize && area > lim) return MI355CV_NOT_IMPLEMENTED;    // the reference switches to double sums there
     }
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(src_depth), de = depthSize(dst_depth);
@@ -964,7 +967,6 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     if (nframes >= 1) {
         if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
         if (nframes == 1) { sframe = 0; dframe = 0; }
-        Stager stg;
         if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
             seprollBox(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
             return stg.finish(entry);
@@ -974,7 +976,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
                                src_depth, dst_depth, width, height, 0, 0, border, p);
         return stg.finish(entry);
     }
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)margin_top * (ptrdiff_t)src_step - (ptrdiff_t)margin_left * cn * se;
     const uchar* dtop = stg.in(top, src_step, (size_t)fullW * cn * se, fullH, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * de, height, &dds);

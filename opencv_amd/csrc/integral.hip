@@ -340,6 +340,9 @@ bool integralTiledU8(const uchar* src, size_t sstep, size_t sframe, int W, int H
                      double* sq, size_t sqStepElems, size_t sqFrameElems, void* aux, hipStream_t st)
 {
     if (W < 1 || H < 1 || nframes < 1 || !aux || !sum) return false;
+    // the squared partial sums (row / column carries of Q) are u32: 65025 * max(W, H) must stay below 2^32 (W, H <= 66051); beyond, the
+    // general three-pass path with its 64-bit sums serves the call
+    if (sq && (W > 66051 || H > 66051)) return false;
     int nTx, nTy;
     const size_t perFrame = auxWordsPerFrame(W, H, &nTx, &nTy);       // even: every array of every frame keeps its 8-byte alignment
     if (((size_t)nTx * nTy + 16 * (size_t)nTx) * 8 > 60 * 1024) return false;   // the 2-D prefix of the tile totals runs in one workgroup's LDS

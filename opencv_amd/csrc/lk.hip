@@ -351,9 +351,10 @@ extern "C" {
 MI355CV_API int mi355cv_ScharrDeriv(const uchar* src_data, size_t src_step, short* dst_data, size_t dst_step, int width, int height, int cn)
 {
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out((uchar*)dst_data, dst_step, (size_t)width * cn * 4, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -369,11 +370,11 @@ MI355CV_API int mi355cv_copyMakeBorder(const uchar* src_data, size_t src_step, i
     border_type &= ~MI355CV_BORDER_ISOLATED;
     if (disabled() || width <= 0 || height <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || elem_size < 1 || elem_size > 64 ||
         border_type < B_CONSTANT || border_type > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;              // a host-side copy is the CPU's job
     const int DW = left + width + right, DH = top + height + bottom;
     const int inPlace = src_data == dst_data + (size_t)top * dst_step + (size_t)left * elem_size && src_step == dst_step;
-    Stager stg;
     hipLaunchKernelGGL(k_copy_make_border, dim3(divUp(DW, 64), divUp(DH, 4)), dim3(256), 0, stream(), src_data, src_step, width, height, dst_data, dst_step,
                        top, left, DW, DH, elem_size, border_type, inPlace);
     return stg.finish("copyMakeBorder");
@@ -389,9 +390,9 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
         !prev_points || !next_points || (prev_deriv_step & 1) || point_count > 0x3fffffffu)
         return MI355CV_NOT_IMPLEMENTED;
     if (point_count == 0) return MI355CV_OK;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg;
     // the tracker reads up to one window beyond every image edge (the padded pyramids, hal_replacement.hpp:30-32): stage the padded rectangles
     const int pw = width + 2 * win_width, ph = height + 2 * win_height;
     size_t sI, sD, sJ;
@@ -435,13 +436,13 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
         max_level > 16 || !prev_points || !next_points || !status || point_count < 0)
         return MI355CV_NOT_IMPLEMENTED;
     if (point_count == 0) return MI355CV_OK;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(prev_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     const bool useInitial = (flags & 4) != 0, getMinEig = (flags & 8) != 0;                // OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_LK_GET_MIN_EIGENVALS
     int maxCount = (criteria_type & 1) == 0 ? 30 : std::min(std::max(criteria_max_count, 0), 100);                     // :1386-1395
     double eps = (criteria_type & 2) == 0 ? 0.01 : std::min(std::max(criteria_epsilon, 0.), 10.);
     eps *= eps;
-    Stager stg;
     hipStream_t st = stream();
     size_t sP, sN, tmp;
     const uchar* dP = stg.in(prev_data, prev_step, (size_t)width * cn, height, &sP);

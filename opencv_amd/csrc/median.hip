@@ -139,11 +139,12 @@ extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_
 {
     if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if (depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     const bool devSrc = isDevicePtr(src_data);
     if (!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     if (devSrc && src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;                  // in place on the device: a stencil cannot
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;

@@ -60,11 +60,12 @@ extern "C" MI355CV_API int mi355cv_imageMoments(const uchar* src_data, size_t sr
     if (disabled() || !src_data || !m || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     if (cn != 1 || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_16S)) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == MI355CV_8U ? 1 : 2;
     const int ntx = divUp(width, 32), nty = divUp(height, 32), ntiles = ntx * nty;
-    Stager stg; size_t dss;
+    size_t dss;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
     long long* dt = (long long*)stg.scratch((size_t)ntiles * 10 * sizeof(long long));
     if (!ds || !dt) return MI355CV_NOT_IMPLEMENTED;

@@ -106,10 +106,11 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
     (void)dst_full_width; (void)dst_full_height; (void)dst_roi_x; (void)dst_roi_y;
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
     if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;
     const uchar* dtop = stg.in(top, src_step, (size_t)src_full_width * c->cn * e, src_full_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * e, height, &dds);

@@ -25,6 +25,7 @@ static std::map<std::string, long long> g_counts;
 static std::atomic<long long> g_stagedBytes{0};   // image bytes the hooks moved over PCIe (host images staged in + results staged back)
 void noteStagedBytes(long long n) { g_stagedBytes += n; }
 static thread_local char t_err[512] = "";
+static thread_local bool t_errFresh = false;             // set by setError, taken by mi355cv_noteDecline: a reason is attributed to one declined call
 static thread_local int t_dev = -1;                 // mi355cv_setDevice; -1 = process default
 static thread_local int t_active = 0;               // device of the hook that is running = index of the per-device thread context
 static thread_local int t_restore = -1;             // the caller's current device, to be put back by the outermost hook
@@ -68,23 +69,30 @@ void noteKernel(const char* fmt, ...)
 int setError(int code, const char* fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof t_err, fmt, ap); va_end(ap);
+    t_errFresh = true;
     if (getenv("MI355CV_LOG")) fprintf(stderr, "[mi355cv] %s\n", t_err);
     return code;
 }
 
 // MI355CV_PRINT_COUNTS=1: at process exit, one line per entry point with the number of calls the GPU served -- how a host program that
 // cannot call mi355cv_callCount (the reference's own test binary, tests/test_reference_suite.py) shows that its cv:: calls ran here
+static std::map<std::string, std::pair<long long, std::string>> g_declines;      // hook -> (count, last reason)
 static void printCounts()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     for (const auto& kv : g_counts) fprintf(stderr, "mi355cv: %s %lld\n", kv.first.c_str(), (long long)kv.second);
+    for (const auto& kv : g_declines) fprintf(stderr, "mi355cv: declined %s %lld (last: %s)\n", kv.first.c_str(), kv.second.first, kv.second.second.c_str());
+}
+static void hookPrintCounts()
+{
+    static const bool hooked = [] { const char* e = getenv("MI355CV_PRINT_COUNTS"); if (e && atoi(e)) atexit(printCounts); return true; }();
+    (void)hooked;
 }
 
 void bump(const char* entry)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    static const bool hooked = [] { const char* e = getenv("MI355CV_PRINT_COUNTS"); if (e && atoi(e)) atexit(printCounts); return true; }();
-    (void)hooked;
+    hookPrintCounts();
     g_counts[entry]++;
 }
 
@@ -337,26 +345,29 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
                 return false;
         return hipEventRecord(inReady[b], aux) == hipSuccess;
     };
-    if (!upload(0)) return setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError()));
+    // every error exit below drains both streams first: ~Stager hands din[] / dout[] back to the pool, and DMA still in flight on the
+    // auxiliary stream must not land in scratch the thread's next hook has been given
+    auto fail = [&](int code) { (void)hipStreamSynchronize(aux); (void)hipStreamSynchronize(st); return code; };
+    if (!upload(0)) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError())));
     std::vector<char> was;
     for (int c = 0; c < nchunks; c++) {
         const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
-        if (c + 1 < nchunks && !upload(c + 1)) return setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError()));
-        if (hipStreamWaitEvent(st, inReady[b], 0) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+        if (c + 1 < nchunks && !upload(c + 1)) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError())));
+        if (hipStreamWaitEvent(st, inReady[b], 0) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
         auto& pool = tctx().pool;
         was.assign(pool.size(), 0);
         for (size_t i = 0; i < pool.size(); i++) was[i] = pool[i].busy;
         const int rc = run(din[b], sp, sfb, dout[b], dp, dfb, nf);
         // scratch the chunk's hook took from the pool is free for the next chunk's: same thread, same stream, stream order
         for (size_t i = 0; i < tctx().pool.size(); i++) if (tctx().pool[i].busy && (i >= was.size() || !was[i])) tctx().pool[i].busy = false;
-        if (rc != MI355CV_OK) { (void)hipStreamSynchronize(aux); (void)hipStreamSynchronize(st); return rc; }
+        if (rc != MI355CV_OK) return fail(rc);
         for (int f = 0; f < nf; f++)
             if (hipMemcpy2DAsync(hb.dst + (size_t)(f0 + f) * hb.dframe, hb.dstep, dout[b] + (size_t)f * dfb, dp, hb.drowBytes, hb.drows, hipMemcpyDeviceToHost, st) != hipSuccess)
-                return setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(hipGetLastError()));
-        if (hipEventRecord(bufFree[b], st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+                return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(hipGetLastError())));
+        if (hipEventRecord(bufFree[b], st) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
         g_stagedBytes += (long long)(hb.srowBytes * (size_t)hb.srows + hb.drowBytes * (size_t)hb.drows) * nf;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError()));
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
     return stg.finish(entry);
 }
 
@@ -423,6 +434,24 @@ MI355CV_API long long mi355cv_callCount(const char* entry)
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_counts.find(entry ? entry : "");
     return it == g_counts.end() ? 0 : it->second;
+}
+
+MI355CV_API void mi355cv_noteDecline(const char* hook)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    hookPrintCounts();
+    auto& d = g_declines[hook ? hook : "?"];
+    d.first++;
+    d.second = t_errFresh ? t_err : "no reason recorded (argument combination outside the GPU path)";
+    t_errFresh = false;
+}
+
+MI355CV_API long long mi355cv_declineCount(const char* hook)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!hook) { long long n = 0; for (const auto& kv : g_declines) n += kv.second.first; return n; }
+    auto it = g_declines.find(hook);
+    return it == g_declines.end() ? 0 : it->second.first;
 }
 
 MI355CV_API long long mi355cv_stagedBytes(void) { return g_stagedBytes.load(); }

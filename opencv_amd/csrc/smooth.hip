@@ -654,12 +654,12 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     if (W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
     if (nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)) return MI355CV_NOT_IMPLEMENTED;
     if (border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     const bool hostSrc = !isDevicePtr(src);
     if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     if (!hostSrc && src == dst) return MI355CV_NOT_IMPLEMENTED;            // in place on the device (cv::GaussianBlur itself clones, smooth.dispatch.cpp:685)
 
-    Stager stg;
     size_t dss = 0, dds = 0;
     const size_t rowB = (size_t)W * cn;
     const uchar* dsrc; uchar* ddst;

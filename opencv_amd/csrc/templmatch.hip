@@ -898,10 +898,11 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     const int depth = MI355CV_MAT_DEPTH(type), cn = MI355CV_MAT_CN(type);
     if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > (wout ? 6 : 5)) return MI355CV_NOT_IMPLEMENTED;   // 6: internal, see k_tm_finish_planes
     if (tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1) return MI355CV_NOT_IMPLEMENTED;   // the size swap of :1172-1182 is left to the caller
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : 4;
     const int rw = iw - tw + 1, rh = ih - th + 1;
-    Stager stg; size_t dis = istep, dts, drs = rstep;
+    size_t dis = istep, dts, drs = rstep;
     const uchar* di = img; uchar* dr = res;
     if (nframes == 1) {
         di = stg.in(img, istep, (size_t)iw * cn * e, ih, &dis);
@@ -1087,9 +1088,10 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     const size_t se = sdepth == D32S ? 4 : 8;
     if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return MI355CV_NOT_IMPLEMENTED;
     if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;     // would wrap; the CPU wraps its own way
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, d1, d2 = 0;
+    size_t dss, d1, d2 = 0;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * (depth == D8U ? 1 : 4), height, &dss);
     uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * se, height + 1, &d1);
     uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * 8, height + 1, &d2) : nullptr;
@@ -1130,10 +1132,10 @@ MI355CV_API int mi355cv_integralBatch(const uchar* src_data, size_t src_step, si
     const size_t se = sdepth == D32S ? 4 : 8;
     if ((sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))) return MI355CV_NOT_IMPLEMENTED;
     if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(sum_data) || (sqsum_data && !isDevicePtr(sqsum_data)))
         return setError(MI355CV_NOT_IMPLEMENTED, "integralBatch: device-resident frames only");
     if (nframes == 1) { src_frame_stride = 0; sum_frame_stride = 0; sqsum_frame_stride = 0; }
-    Stager stg;
     void* taux = stg.scratch(integralTiledAuxBytes(width, height, nframes, sqsum_data != nullptr));
     if (!taux || !integralTiledU8(src_data, src_step, src_frame_stride, width, height, nframes, sum_data, sum_step / se, sum_frame_stride / se, sdepth == D64F,
                                   (double*)sqsum_data, sqsum_step / 8, sqsum_frame_stride / 8, taux, stream()))

@@ -123,9 +123,10 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
     if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return MI355CV_NOT_IMPLEMENTED;
     if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -166,11 +167,12 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
     if (thresholdType < 0 || thresholdType > 4) return MI355CV_NOT_IMPLEMENTED;
     if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
     const int n = width * cn;
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)n * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)n * e, height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -199,10 +201,11 @@ extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t 
         return runHostBatch("thresholdBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
             return mi355cv_thresholdBatch(s, ss, sf, d, ds, df, nf, width, height, depth, cn, thresh, maxValue, thresholdType); });
     }
+    Stager outer;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return setError(MI355CV_NOT_IMPLEMENTED, "thresholdBatch: device-resident frames only");
     if (nframes == 1 || (src_frame_stride == src_step * (size_t)height && dst_frame_stride == dst_step * (size_t)height && (long long)height * nframes < 0x7fffffffLL))
         return mi355cv_threshold(src_data, src_step, dst_data, dst_step, width, height * nframes, depth, cn, thresh, maxValue, thresholdType);
-    Stager outer;                                            // one synchronisation for the whole batch
+                                               // one synchronisation for the whole batch
     for (int f = 0; f < nframes; f++) {
         const int rc = mi355cv_threshold(src_data + (size_t)f * src_frame_stride, src_step, dst_data + (size_t)f * dst_frame_stride, dst_step, width, height, depth, cn,
                                          thresh, maxValue, thresholdType);

@@ -1194,6 +1194,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR) return MI355CV_NOT_IMPLEMENTED;
     if (borderType < 0 || borderType > B_TRANSPARENT) return MI355CV_NOT_IMPLEMENTED;
     if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src) && (size_t)dw * dh < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
     if (nframes < 1 || (nframes > 1 && (!isDevicePtr(src) || !isDevicePtr(dst))))
@@ -1201,7 +1202,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     const short* g_tabDev = deviceTab();
     if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
-    Stager stg; size_t dss, dds, mxs = mxstep, mys = mystep;
+    size_t dss, dds, mxs = mxstep, mys = mystep;
     const uchar* ds = stg.in(src, sstep, (size_t)sw * cn * e, sh, &dss);
     uchar* dd;
     if (borderType == B_TRANSPARENT && !isDevicePtr(dst)) {
@@ -1293,6 +1294,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         else if (interpolation == 4 /*INTER_LANCZOS4*/) a.mode = 6;
         else return MI355CV_NOT_IMPLEMENTED;                                                // NEAREST_EXACT, LINEAR_EXACT on other depths
     }
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
     if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
@@ -1309,7 +1311,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         }
         a.sframe = src_frame; a.dframe = dst_frame;
     }
-    Stager stg; size_t dss, dds;
+    size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
     if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
@@ -1424,6 +1426,17 @@ MI355CV_API int mi355cv_warpAffineBatch(int src_type, const uchar* src_data, siz
 {
     if (!M) return MI355CV_NOT_IMPLEMENTED;
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
+        // such a batch goes frame by frame through the single-image path, which stages dst in as well
+        if (borderType == B_TRANSPARENT) {
+            for (int f = 0; f < nframes; f++) {
+                const int rc = runWarp("warpAffineBatch", src_type, src_data + (size_t)f * src_frame_stride, src_step, src_width, src_height,
+                                       dst_data + (size_t)f * dst_frame_stride, dst_step, dst_width, dst_height, M, 0, interpolation, borderType, borderValue,
+                                       nullptr, 0, nullptr, 0);
+                if (rc != MI355CV_OK) return rc;
+            }
+            return MI355CV_OK;
+        }
         const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
         const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
         return runHostBatch("warpAffineBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -1439,6 +1452,17 @@ MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const uchar* src_data
 {
     if (!M) return MI355CV_NOT_IMPLEMENTED;
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
+        // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
+        // such a batch goes frame by frame through the single-image path, which stages dst in as well
+        if (borderType == B_TRANSPARENT) {
+            for (int f = 0; f < nframes; f++) {
+                const int rc = runWarp("warpPerspectiveBatch", src_type, src_data + (size_t)f * src_frame_stride, src_step, src_width, src_height,
+                                       dst_data + (size_t)f * dst_frame_stride, dst_step, dst_width, dst_height, M, 1, interpolation, borderType, borderValue,
+                                       nullptr, 0, nullptr, 0);
+                if (rc != MI355CV_OK) return rc;
+            }
+            return MI355CV_OK;
+        }
         const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
         const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
         return runHostBatch("warpPerspectiveBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -1514,8 +1538,9 @@ MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1
     if (!toFixed && !toFloat) return MI355CV_NOT_IMPLEMENTED;
     if (toFixed && !nninterpolate && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
     if (toFloat && dstmap1_type == t32fc1 && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    Stager stg; size_t s1 = 0, s2 = 0, o1 = 0, o2 = 0;
+    size_t s1 = 0, s2 = 0, o1 = 0, o2 = 0;
     const size_t e1 = map1_type == t32fc1 ? 4 : map1_type == t32fc2 ? 8 : 4;
     const uchar* a = stg.in((const uchar*)map1, map1_step, (size_t)width * e1, height, &s1);
     const uchar* b = map2 ? stg.in((const uchar*)map2, map2_step, (size_t)width * (toFixed ? 4 : 2), height, &s2) : nullptr;

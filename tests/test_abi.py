@@ -30,8 +30,9 @@ def test_hal_header_maps_onto_exported_symbols():
     hal = os.path.join(ROOT, "include", "mi355cv_hal.hpp")
     txt = open(hal).read()
     lib = ctypes.CDLL(os.path.join(ROOT, "opencv_amd", "libmi355cv.so"))
-    pairs = re.findall(r"#define\s+(cv_hal_\w+)\s+(mi355cv_\w+)", txt)
-    assert pairs
+    # every binding goes through the counting shim: cv_hal_x(...) -> mi355cv_hal::counted("x", mi355cv_y, ...)
+    pairs = re.findall(r"#define\s+(cv_hal_\w+)\(\.\.\.\)\s+mi355cv_hal::counted\(\"\w+\",\s*(mi355cv_\w+),", txt)
+    assert len(pairs) >= 65
     for hook, sym in pairs:
         assert hasattr(lib, sym), (hook, sym)
         assert re.search(r"#undef\s+" + hook + r"\b", txt), hook

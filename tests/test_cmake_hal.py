@@ -27,5 +27,5 @@ def test_hal_package_is_consumable(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     run = subprocess.run([str(build / "hal_consumer")], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "cv_hal_gaussianBlurBinomial -> mi355cv_gaussianBlurBinomial" in run.stdout
-    assert "cv_hal_resize -> mi355cv_resize" in run.stdout and "cv_hal_cvtBGRtoGray -> mi355cv_cvtBGRtoGray" in run.stdout
+    assert 'cv_hal_gaussianBlurBinomial -> mi355cv_hal::counted("gaussianBlurBinomial", mi355cv_gaussianBlurBinomial, ARGS)' in run.stdout
+    assert 'mi355cv_resize, ARGS)' in run.stdout and 'mi355cv_cvtBGRtoGray, ARGS)' in run.stdout
