@@ -83,6 +83,13 @@ static void printCounts()
     for (const auto& kv : g_counts) fprintf(stderr, "mi355cv: %s %lld\n", kv.first.c_str(), (long long)kv.second);
     for (const auto& kv : g_declines) fprintf(stderr, "mi355cv: declined %s %lld (last: %s)\n", kv.first.c_str(), kv.second.first, kv.second.second.c_str());
 }
+// MI355CV_LEDGER=1: one line per served entry point and per declined hook on stderr, in call order -- a host program whose stdout names what it is
+// doing (a gtest binary) thereby shows, call by call, which of its steps ran on the GPU and which on its own CPU path (tests/test_reference_suite.py)
+static bool ledgerLog()
+{
+    static const bool on = [] { const char* e = getenv("MI355CV_LEDGER"); return e && atoi(e); }();
+    return on;
+}
 static void hookPrintCounts()
 {
     static const bool hooked = [] { const char* e = getenv("MI355CV_PRINT_COUNTS"); if (e && atoi(e)) atexit(printCounts); return true; }();
@@ -94,6 +101,7 @@ void bump(const char* entry)
     std::lock_guard<std::mutex> lk(g_mu);
     hookPrintCounts();
     g_counts[entry]++;
+    if (ledgerLog()) { fprintf(stderr, "[mi355cv] served %s\n", entry); fflush(stderr); }
 }
 
 static int deviceCount()
@@ -444,6 +452,7 @@ MI355CV_API void mi355cv_noteDecline(const char* hook)
     d.first++;
     d.second = t_errFresh ? t_err : "no reason recorded (argument combination outside the GPU path)";
     t_errFresh = false;
+    if (ledgerLog()) { fprintf(stderr, "[mi355cv] declined %s: %s\n", hook ? hook : "?", d.second.c_str()); fflush(stderr); }
 }
 
 MI355CV_API long long mi355cv_declineCount(const char* hook)

@@ -35,6 +35,47 @@ def run(positive, extra_env=None, timeout=600, exclude=()):
     return p.returncode, int(ran.group(1)) if ran else 0, int(passed.group(1)) if passed else 0, sorted(set(failed)), counts
 
 
+def ledger(positive="*", timeout=1500):
+    """Runs the binary with MI355CV_LEDGER=1 and stderr merged into stdout (gtest flushes stdout at every test start / end, the library flushes its
+    ledger lines), and attributes every served entry point / declined hook to the reference test that was running.
+    Returns (rc, {test: {"served": {entry: n}, "declined": {hook: n}, "reasons": {hook: last reason}}}, failed tests)."""
+    env = dict(os.environ); env["MI355CV_LEDGER"] = "1"
+    flt = positive + "-" + ":".join(NEEDS_DATA)
+    p = subprocess.run([BIN, "--gtest_filter=" + flt, "--gtest_color=no"], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True,
+                       errors="replace")
+    tests, cur = {}, None
+    for line in p.stdout.splitlines():
+        m = re.match(r"\[ RUN      \] (\S+)", line)
+        if m:
+            cur = tests.setdefault(m.group(1), {"served": {}, "declined": {}, "reasons": {}}); continue
+        if re.match(r"\[\s+(OK|FAILED)\s+\] ", line):
+            cur = None; continue
+        m = re.search(r"\[mi355cv\] served (\S+)", line)
+        if m and cur is not None:
+            cur["served"][m.group(1)] = cur["served"].get(m.group(1), 0) + 1; continue
+        m = re.search(r"\[mi355cv\] declined (\S+): (.*)", line)
+        if m and cur is not None:
+            cur["declined"][m.group(1)] = cur["declined"].get(m.group(1), 0) + 1
+            cur["reasons"][m.group(1)] = m.group(2)
+    failed = sorted(set(re.findall(r"^\[  FAILED  \] (\S+)", p.stdout, re.M)))
+    return p.returncode, tests, failed
+
+
+def test_ledger_on_the_fallback_names_every_hook_call_as_declined():
+    """without a GPU every hook call of a reference test is a declined one, and the ledger says so test by test"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see test_ledger_of_the_reference_suite_on_the_gpu")
+    rc, tests, failed = ledger("GaussianBlur_Bitexact.*:Imgproc_cvtColor_BE.*:Imgproc_Warp*")
+    assert rc == 0 and not failed and len(tests) >= 10
+    assert all(not t["served"] for t in tests.values())
+    declined = {}
+    for t in tests.values():
+        for h, n in t["declined"].items():
+            declined[h] = declined.get(h, 0) + n
+    assert declined.get("gaussianBlurBinomial", 0) > 0 and declined.get("cvtBGRtoGray", 0) > 0 and declined.get("warpAffine", 0) > 0, declined
+
+
 def test_reference_tests_pass_on_the_fallback():
     import torch
     if torch.cuda.is_available():
@@ -67,3 +108,38 @@ def test_whole_reference_suite_on_the_gpu():
                  "cvtBGRtoGray", "cvtBGRtoBGR", "cvtBGRtoYUV", "cvtYUVtoBGR", "cvtBGRtoHSV", "cvtHSVtoBGR", "cvtBGRtoXYZ", "cvtBGRtoLab", "cvtLabtoBGR", "pyrdown", "integral", "medianBlur", "morph",
                  "equalize_hist", "gaussianBlurBinomial", "cvtTwoPlaneYUVtoBGR", "cvtThreePlaneYUVtoBGR", "cvtOnePlaneYUVtoBGR"):
         assert counts.get(hook, 0) > 0, (hook, counts)
+
+
+# Which of the reference's tests ran on the GPU, which on the reference's own CPU path.  A hook declines what it cannot reproduce bit for
+# bit and small host-resident images by policy, and the HAL contract makes that silent -- this test makes it visible: per reference test the entry points
+# the GPU served and the hooks that declined (with the last reason), written to gpurun_out/reference_suite_ledger.txt (a copy is kept under profiles/).
+# Regression guard: a reference test that used to be served entirely by the GPU must not start falling back (tests/golden/reference_suite_gpu_only.txt,
+# written by the first GPU run of this test).
+@pytest.mark.gpu
+def test_ledger_of_the_reference_suite_on_the_gpu():
+    rc, tests, failed = ledger("*")
+    assert rc == 0 and not failed, failed[:10]
+    gpu_only = sorted(t for t, d in tests.items() if d["served"] and not d["declined"])
+    mixed = sorted(t for t, d in tests.items() if d["served"] and d["declined"])
+    cpu_only = sorted(t for t, d in tests.items() if d["declined"] and not d["served"])
+    none = sorted(t for t, d in tests.items() if not d["declined"] and not d["served"])
+    hooks = {}
+    for d in tests.values():
+        for h, n in d["declined"].items():
+            e = hooks.setdefault(h, [0, ""]); e[0] += n; e[1] = d["reasons"][h]
+    lines = [f"reference tests: {len(tests)}; GPU only {len(gpu_only)}, GPU + fallback {len(mixed)}, fallback only {len(cpu_only)}, no hook on their path {len(none)}", "",
+             "declined calls per hook (count, last reason):"]
+    lines += [f"  {h:28s} {n:7d}  {why}" for h, (n, why) in sorted(hooks.items())]
+    lines += ["", "tests that ran on the fallback only:"] + [f"  {t}: " + ", ".join(f"{h} x{n} ({tests[t]['reasons'][h]})" for h, n in sorted(tests[t]["declined"].items())) for t in cpu_only]
+    lines += ["", "tests served partly by the GPU, partly by the fallback:"] + [
+        f"  {t}: served " + ", ".join(f"{h} x{n}" for h, n in sorted(tests[t]["served"].items())) + "; declined " +
+        ", ".join(f"{h} x{n} ({tests[t]['reasons'][h]})" for h, n in sorted(tests[t]["declined"].items())) for t in mixed]
+    lines += ["", "tests served by the GPU only:"] + [f"  {t}" for t in gpu_only]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "reference_suite_ledger.txt"), "w").write("\n".join(lines) + "\n")
+    assert len(gpu_only) + len(mixed) >= 150, (len(gpu_only), len(mixed), len(cpu_only))
+    pinned = os.path.join(ROOT, "tests", "golden", "reference_suite_gpu_only.txt")
+    if os.path.exists(pinned):
+        want = [l.strip() for l in open(pinned) if l.strip() and not l.startswith("#")]
+        lost = sorted(set(want) - set(gpu_only))
+        assert not lost, ("reference tests that used to run on the GPU only now fall back", lost[:20])
