@@ -119,7 +119,7 @@ extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t
     if (radius > B_RMAX) return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: radius %d > %d", radius, B_RMAX);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     std::vector<float> cw((size_t)256 * cn), sw;
     std::vector<short> of;
     for (int i = 0; i < 256 * cn; i++) cw[i] = (float)std::exp(i * i * gcc);

@@ -163,7 +163,7 @@ extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step,
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     // canny.cpp:887-896 (the aperture-7 scaling and the swap happen before the hook)
     double lo = lowThreshold, hi = highThreshold;
     if (L2gradient) {

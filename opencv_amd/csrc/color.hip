@@ -140,7 +140,7 @@ int runBgr2Gray(const char* entry, const uchar* src, size_t sstep, size_t sframe
     if (!e || (scn != 3 && scn != 4) || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {

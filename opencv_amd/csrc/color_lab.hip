@@ -803,7 +803,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
         size_t dss, dds;
@@ -835,7 +835,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         const int e = depth == MI355CV_32F ? 4 : 1;
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return MI355CV_NOT_IMPLEMENTED;
-        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
         size_t dss, dds;
@@ -857,7 +857,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs && !luv) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
@@ -900,7 +900,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
         size_t dss, dds;
@@ -925,7 +925,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     if (depth == MI355CV_32F) {                             // L*u*v*, CV_32F: Luv2RGBfloat
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
         size_t dss, dds;
@@ -946,7 +946,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const LabTabs* tabs = deviceTabs();
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs || (!isLab && !luv)) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");

@@ -231,7 +231,7 @@ struct OpPremul {
 #define MISC_PROLOGUE(sRowBytes, sRows, dRowBytes, dRows)                                                                        \
     Stager stg; /* first: a declined call must also put the host's device back (~Stager) */                                       \
     if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;                                                  \
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;                           \
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;                           \
     size_t dss, dds;                                                                                                  \
     const uchar* ds = stg.in(src_data, src_step, (size_t)(sRowBytes), (sRows), &dss);                                             \
     uchar* dd = stg.out(dst_data, dst_step, (size_t)(dRowBytes), (dRows), &dds);                                                  \
@@ -248,7 +248,7 @@ MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_st
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t dss, ys, uvs;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dy = stg.out(y_data, y_step, (size_t)width, height, &ys);

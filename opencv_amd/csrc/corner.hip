@@ -368,7 +368,7 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
     if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)sw * sh < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)sw * sh, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
@@ -721,7 +721,7 @@ int runCorner(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {

@@ -120,7 +120,7 @@ int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size
     if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)w * h < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)w * h, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     size_t ss, ds;
     const uchar* s = stg.in(src, sstep, (size_t)w, h, &ss);
     uchar* d = stg.out(dst, dstep, (size_t)w, h, &ds);
@@ -145,7 +145,7 @@ MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* 
     if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t ss, ds;
     const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
     uchar* d = stg.out(dst_data, dst_step, (size_t)width, height, &ds);

@@ -553,7 +553,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (disabled() || W <= 0 || H <= 0) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)W * H < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
     // stage the whole parent region so that non-isolated borders can read real neighbours
     const uchar* top = src - (ptrdiff_t)offY * (ptrdiff_t)sstep - (ptrdiff_t)offX * c.cn * se;
@@ -786,7 +786,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     if (!c || c->kind != 1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
     // hal::filter2D tries the hook before its own DFT path (filter.dispatch.cpp:1436-1470): for a whole image and a kernel of >= 130 taps
     // (8U -> 8U / 16S, 32F -> 32F; >= 50 otherwise) the CPU result comes from float FFTs (dftFilter2D :1274-1340), which a direct sum does
@@ -961,7 +961,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     const int se = depthSize(src_depth), de = depthSize(dst_depth);
     const int fullW = margin_left + width + margin_right, fullH = margin_top + height + margin_bottom;
     if (nframes >= 1) {

@@ -126,7 +126,7 @@ MI355CV_API int mi355cv_equalize_hist(const uchar* src_data, size_t src_step, uc
     if (disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
@@ -152,7 +152,7 @@ MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, u
         return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if ((long long)width * height > 0x7fffffffLL || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == MI355CV_8U ? 1 : 2;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);

@@ -62,7 +62,7 @@ extern "C" MI355CV_API int mi355cv_imageMoments(const uchar* src_data, size_t sr
     if (cn != 1 || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_16S)) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == MI355CV_8U ? 1 : 2;
     const int ntx = divUp(width, 32), nty = divUp(height, 32), ntiles = ntx * nty;
     size_t dss;

@@ -108,7 +108,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
     if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
     size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;

@@ -33,6 +33,8 @@ bool disabled();                    // MI355CV_DISABLE=1 -> every hook answers N
 // The default policy ("always") accepts everything, which is what the parity tests and the HAL tour rely on.
 enum HostCost { HOST_CHEAP = 0, HOST_HEAVY = 1 };
 size_t minPixels(int cost = HOST_CHEAP);
+// host-resident image below the policy threshold: true, and the reason is recorded for mi355cv_lastError / the decline ledger
+bool hostImageTooSmall(const void* img, size_t pixels, size_t threshold);
 int  setError(int code, const char* fmt, ...);
 void bump(const char* entry);       // per-entry completed-on-GPU counter
 void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)

@@ -52,6 +52,14 @@ int activeDevice() { return t_active; }
 static bool envFlag(const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; }
 
 bool disabled() { static bool d = envFlag("MI355CV_DISABLE"); return d; }
+bool hostImageTooSmall(const void* img, size_t pixels, size_t threshold)
+{
+    if (pixels >= threshold || isDevicePtr(img)) return false;
+    setError(MI355CV_NOT_IMPLEMENTED, "host-resident image of %zu pixels, below the %zu-pixel policy threshold (two PCIe crossings cost more than the CPU path; "
+             "MI355CV_MIN_PIXELS, or keep the image in device memory)", pixels, threshold);
+    return true;
+}
+
 size_t minPixels(int cost)
 {
     static const size_t v = getenv("MI355CV_MIN_PIXELS") ? strtoull(getenv("MI355CV_MIN_PIXELS"), nullptr, 10) : 0;

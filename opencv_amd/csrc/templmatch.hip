@@ -1090,7 +1090,7 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;     // would wrap; the CPU wraps its own way
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t dss, d1, d2 = 0;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * (depth == D8U ? 1 : 4), height, &dss);
     uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * se, height + 1, &d1);

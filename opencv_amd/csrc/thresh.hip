@@ -125,7 +125,7 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
     if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
@@ -169,7 +169,7 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return MI355CV_NOT_IMPLEMENTED;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)width * height < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
     const int n = width * cn;
     size_t dss, dds;

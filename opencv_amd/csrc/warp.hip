@@ -24,6 +24,7 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
+#include "warp8.h"
 
 using namespace mi355;
 
@@ -1181,6 +1182,45 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
     }
 }
 
+
+// ---- CV_8U bilinear warpAffine / warpPerspective through an LDS tile (warp8.h has the why and every phase; this is the launch geometry) ------------------
+// A workgroup walks TPW horizontally adjacent 128 x th tiles (the 8 KB weight table it keeps in LDS is loaded once for all of them); per tile: box terms by
+// the first lanes -> barrier -> the source box into LDS + row / column terms -> barrier -> 16 (th = 32) or 8 destination pixels per thread.
+template <int CN, int KIND>
+__global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tab, int tpw)
+{
+    extern __shared__ __align__(16) uchar w8lds[];
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
+    const int tid = threadIdx.x, y0 = blockIdx.y * a.th;
+    for (int t = 0; t < tpw; t++) {
+        const int tx = blockIdx.x * tpw + t;
+        if (tx >= a.gx) break;                                                           // uniform
+        const int x0 = tx * warp8::TW;
+        if (t == 0) warp8::phaseA<KIND>(a, x0, y0, tab, w8lds, tid);
+        else { __syncthreads(); if (tid < (KIND == 0 ? 8 : 4)) warp8::boxTerm<KIND>(a, x0, y0, tid, reinterpret_cast<int*>(w8lds + warp8::OFF_TERMS)); }
+        __syncthreads();
+        const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS));
+        warp8::phaseB<CN, KIND>(a, b, x0, y0, src, w8lds, tid);
+        __syncthreads();
+        const unsigned redo = warp8::phaseC<CN, KIND>(a, b, x0, y0, w8lds, dst, tid);
+        if (redo) {
+            // pixels outside the tile's box: wholly outside the source under BORDER_CONSTANT is the common case (a rotated frame's corners) -- the border
+            // value, no sampling; everything else (partial footprints, the other border rules, BORDER_TRANSPARENT) is the generic sampler's
+            uint32_t cv = 0;
+#pragma unroll
+            for (int c = 0; c < CN; c++) cv |= (uint32_t)fminf(fmaxf(rintf(s.cval[c]), 0.f), 255.f) << (8 * c);
+            warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, w8lds, tid, [&](int x, int y, int X, int Y) {
+                const int sx = X >> 5, sy = Y >> 5;
+                uchar* D = dst + (size_t)y * a.dstep + (size_t)x * CN;
+                if (s.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) {
+#pragma unroll
+                    for (int c = 0; c < CN; c++) D[c] = (uchar)(cv >> (8 * c));
+                } else samplePixel(src, a.sstep, D, s, satShort(sx), satShort(sy), X & 31, Y & 31, tab);
+            });
+        }
+    }
+}
+
 bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
@@ -1196,7 +1236,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src) && (size_t)dw * dh < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src, (size_t)dw * dh, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
     if (nframes < 1 || (nframes > 1 && (!isDevicePtr(src) || !isDevicePtr(dst))))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const short* g_tabDev = deviceTab();
@@ -1242,6 +1282,21 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && sh >= 2 && (dss % e) == 0 &&
         (unsigned long long)sh * dss < (1ull << 32) && (unsigned long long)dh * dds < (1ull << 32) && dss < (1u << 24) &&
         ((uintptr_t)ds % e) == 0) {
+        // CV_8U: the LDS-tile kernel where it applies (4-byte aligned images, a source box that fits its LDS allotment); MI355CV_WARP8=0 keeps the
+        // thread-per-column kernel (A/B runs, tools/warp_probe.py)
+        static const bool warp8On = [] { const char* v = getenv("MI355CV_WARP8"); return !v || atoi(v) != 0; }();
+        warp8::Args a8; size_t lds8 = 0;
+        if (depth == D8U && warp8On && warp8::plan(a8, cn, kind, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8)) {
+            a8.sframe = w.sframe; a8.dframe = w.dframe;
+            const int tpw = 4;
+            dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
+#define W8(CN_, K_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
+            if (kind == 0) { if (cn == 1) W8(1, 0); else if (cn == 3) W8(3, 0); else W8(4, 0); }
+            else           { if (cn == 1) W8(1, 1); else if (cn == 3) W8(3, 1); else W8(4, 1); }
+#undef W8
+            noteKernel("k_warp8_tile<%d,%d> grid=%ux%ux%u x256 lds=%zu box<=%dx%d", cn, kind, g8.x, g8.y, g8.z, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+            return stg.finish(entry);
+        }
         // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean
         // kernel the plain order is faster for small rotations (8K 32F, 7 degrees: 63.5 vs 71.0 us) and within 3 % otherwise.
         // MI355CV_WARP_BAND=1 turns it on (tools/warp_probe.py).
@@ -1296,7 +1351,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) && (size_t)dst_width * dst_height < minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP)) return MI355CV_NOT_IMPLEMENTED;
+    if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))) return MI355CV_NOT_IMPLEMENTED;
     const int e = eszOf(depth);
     if (nframes > 1) {
         // batches are an HBM-resident construct; nearest / bilinear / area-fast run as ONE launch (grid z = frame), the table-driven modes frame by frame

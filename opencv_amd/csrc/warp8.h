@@ -1,0 +1,398 @@
+// warp8.h -- bilinear warpAffine / warpPerspective on CV_8U sources through an LDS tile (kernel k_warp8_tile, warp.hip).
+//
+// Why: the thread-per-column kernel (k_warp_lin<uchar>) gathers bytes -- a 64-lane 2-byte gather along a sloped line was served as ~61 vector-L1
+// accesses per wave load (profiles/r02_warp_pmc.txt), it stores bytes, and ran at 7-17 % of the HBM roofline.  Here a workgroup owns a 128 x TH
+// destination tile: it computes the EXACT bounding box of the tile's source footprint (the reference's fixed-point coordinate sums are monotone in
+// x and y, so the box of the four corners bounds every pixel), copies that box from HBM into LDS with whole aligned dwords (coalesced along rows),
+// and every lane then produces four horizontally adjacent destination pixels from LDS -- two unaligned ds_read per tap pair, the four Q15 weights as
+// two v_dot4_u32_u8 on byte-split weights -- and stores them as ONE dword (12 / 16 bytes for 3 / 4 channels).  Pixels whose 2x2 footprint is not
+// strictly inside the source take the generic sampler (borders, BORDER_TRANSPARENT blending).
+//
+// The arithmetic is the reference's (imgwarp.cpp:2233-2298 WarpAffineInvoker, :3160-3240 WarpPerspectiveInvoker, :675-904 remapBilinear<FixedPtCast>,
+// the 1024-entry Q15 table of initInterTab2D :213-275 with its fix-up quirk): coordinates in 1/1024 px rounded to 1/32, weights Q15, (sum + 2^14) >> 15.
+//
+// Everything here is __host__ __device__ and free of wave intrinsics so that tests/hostemu can run the very same staging and per-pixel code on the
+// CPU, thread by thread, against the pinned restatement (the GPU adds only the launch geometry).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define W8_HD __host__ __device__ __forceinline__
+#else
+#define W8_HD inline
+#endif
+
+namespace warp8 {
+
+enum { LX = 32, PX = 4, TW = LX * PX /* 128 destination pixels per tile row */, ROWS_PER_STEP = 8 /* 4 waves x 2 rows */, TAB_BYTES = 1024 * 8, MAX_TH = 32 };
+
+// what the host passes (one copy per launch)
+struct Args {
+    double M[9];                 // inverse map, as the hook receives it
+    int sw, sh, dw, dh;
+    uint32_t sstep, dstep;       // bytes, both multiples of 4; both images 4-byte aligned and below 4 GB
+    int th;                      // tile height: 32 (1 channel) or 16 (3 / 4 channels) = tileRows<CN>()
+    int ldsPitch;                // bytes per LDS row (multiple of 4, covers the widest tile box + 8 bytes of slack)
+    int ldsRows;                 // rows the LDS tile can hold
+    uint32_t pitchMagic;         // floor(2^32 / (ldsPitch / 4)) + 1: dword index -> row by one mul_hi
+    int bw0;                     // WarpPerspectiveInvoker's block width (the x the projective terms restart from)
+    int gx, gy;
+    unsigned long long sframe, dframe;
+};
+
+W8_HD int satIntD(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v >= 2147483647.0 ? 2147483647 : v <= -2147483648.0 ? (int)-2147483648LL : (int)__double2int_rn(v);
+#else
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int)-2147483648LL;
+    return (int)__builtin_rint(v);                       // round half to even, like cvRound / v_cvt_i32_f64
+#endif
+}
+W8_HD double dmul(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dmul_rn(a, b);
+#else
+    return a * b;                                        // the host emulation is compiled with -ffp-contract=off
+#endif
+}
+W8_HD double dadd(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dadd_rn(a, b);
+#else
+    return a + b;
+#endif
+}
+W8_HD double ddiv(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ddiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
+W8_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    return c + (a & 255) * (b & 255) + ((a >> 8) & 255) * ((b >> 8) & 255) + ((a >> 16) & 255) * ((b >> 16) & 255) + (a >> 24) * (b >> 24);
+#endif
+}
+W8_HD uint32_t ld16(const unsigned char* p)
+{
+    typedef unsigned short u16u __attribute__((aligned(1)));
+    return *reinterpret_cast<const u16u*>(p);
+}
+W8_HD unsigned long long ld64(const unsigned char* p)
+{
+    typedef unsigned long long u64u __attribute__((aligned(1)));
+    return *reinterpret_cast<const u64u*>(p);
+}
+
+// affine coordinate terms (WarpAffineInvoker imgwarp.cpp:2252-2262 with hal::warpAffineBlocklineNN's adelta / bdelta :2699-2713): 1/1024 px, round delta 16
+W8_HD int affRowX(const Args& a, int y) { return satIntD(dmul(dadd(dmul(a.M[1], (double)y), a.M[2]), 1024.0)) + 16; }
+W8_HD int affRowY(const Args& a, int y) { return satIntD(dmul(dadd(dmul(a.M[4], (double)y), a.M[5]), 1024.0)) + 16; }
+W8_HD int affColX(const Args& a, int x) { return satIntD(dmul(dmul(a.M[0], (double)x), 1024.0)); }
+W8_HD int affColY(const Args& a, int x) { return satIntD(dmul(dmul(a.M[3], (double)x), 1024.0)); }
+
+// projective coordinates in 1/32 px (WarpPerspectiveInvoker :3195-3235 / hal::warpPerspectiveBlockline: the row terms start at the block's first column)
+W8_HD void perspXY(const Args& a, int x, int y, int& X, int& Y)
+{
+    const int xb = (x / a.bw0) * a.bw0, x1 = x - xb;
+    const double X0 = dadd(dadd(dmul(a.M[0], (double)xb), dmul(a.M[1], (double)y)), a.M[2]);
+    const double Y0 = dadd(dadd(dmul(a.M[3], (double)xb), dmul(a.M[4], (double)y)), a.M[5]);
+    const double W0 = dadd(dadd(dmul(a.M[6], (double)xb), dmul(a.M[7], (double)y)), a.M[8]);
+    double W = dadd(W0, dmul(a.M[6], (double)x1));
+    W = W != 0 ? ddiv(32.0, W) : 0;
+    double fX = dmul(dadd(X0, dmul(a.M[0], (double)x1)), W);
+    double fY = dmul(dadd(Y0, dmul(a.M[3], (double)x1)), W);
+    fX = fX < -2147483648.0 ? -2147483648.0 : fX > 2147483647.0 ? 2147483647.0 : fX;
+    fY = fY < -2147483648.0 ? -2147483648.0 : fY > 2147483647.0 ? 2147483647.0 : fY;
+    X = satIntD(fX); Y = satIntD(fY);
+}
+
+// LDS layout of a workgroup (bytes): weight table | column terms (colX[128], colY[128]) | row terms (rowX[32], rowY[32]) | box terms | source tile
+enum { OFF_COL = TAB_BYTES, OFF_ROW = OFF_COL + 2 * TW * 4, OFF_TERMS = OFF_ROW + 2 * MAX_TH * 4, OFF_TILE = OFF_TERMS + 64 };
+
+// the box of source pixels a tile needs, clipped to the image: origin (cx0, cy0), cw x ch pixels (0 = nothing loadable), `all` = every destination pixel of
+// the tile has its 2x2 footprint strictly inside the box (no per-pixel test needed), `shift` = byte offset of pixel cx0 inside its aligned dword
+struct Box { int cx0, cy0, cw, ch, shift, all; };
+
+// The box is built from a handful of coordinate evaluations (`terms`), one per lane of the first wave, so that no thread walks the double arithmetic alone:
+//   affine       terms[0..7]  = rowX(y0), rowX(y1), colX(x0), colX(x1), rowY(y0), rowY(y1), colY(x0), colY(x1)
+//   perspective  terms[3i..3i+2] = X, Y (1/32 px) and the sign of the denominator at corner i of the tile (i = 0..3)
+template <int KIND> W8_HD int boxTermCount() { return KIND == 0 ? 8 : 12; }
+
+template <int KIND>
+W8_HD void boxTerm(const Args& a, int x0, int y0, int k, int* terms)
+{
+    const int x1 = (x0 + TW < a.dw ? x0 + TW : a.dw) - 1, y1 = (y0 + a.th < a.dh ? y0 + a.th : a.dh) - 1;
+    if (KIND == 0) {
+        const int v = (k & 2) ? ((k & 1) ? x1 : x0) : ((k & 1) ? y1 : y0);
+        terms[k] = k < 4 ? ((k & 2) ? affColX(a, v) : affRowX(a, v)) : ((k & 2) ? affColY(a, v) : affRowY(a, v));
+    } else if (k < 4) {
+        const int x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0;
+        perspXY(a, x, y, terms[3 * k], terms[3 * k + 1]);
+        const double w = dadd(dadd(dmul(a.M[6], (double)x), dmul(a.M[7], (double)y)), a.M[8]);
+        terms[3 * k + 2] = w > 0 ? 1 : w < 0 ? -1 : 0;
+    }
+}
+
+template <int CN, int KIND>
+W8_HD Box boxFromTerms(const Args& a, const int* t)
+{
+    Box b = {0, 0, 0, 0, 0, 0};
+    int bx0, bx1, by0, by1, exact = 1;
+    if (KIND == 0) {
+        // X5(x, y) = (rowX(y) + colX(x)) >> 5 with rowX, colX monotone (a rounded linear function each): the extremes are sums of the terms' extremes
+        bx0 = ((t[0] < t[1] ? t[0] : t[1]) + (t[2] < t[3] ? t[2] : t[3])) >> 10; bx1 = (((t[0] > t[1] ? t[0] : t[1]) + (t[2] > t[3] ? t[2] : t[3])) >> 10) + 1;
+        by0 = ((t[4] < t[5] ? t[4] : t[5]) + (t[6] < t[7] ? t[6] : t[7])) >> 10; by1 = (((t[4] > t[5] ? t[4] : t[5]) + (t[6] > t[7] ? t[6] : t[7])) >> 10) + 1;
+    } else {
+        // a projective map is monotone in x and in y on a rectangle its denominator does not vanish on, so the corners bound it; the reference restarts
+        // its row terms every bw0 columns, which moves a coordinate by rounding only: one pixel of margin, and the per-pixel test stays on
+        exact = 0;
+        const int sgn = t[2] + t[5] + t[8] + t[11];
+        if (sgn != 4 && sgn != -4) return b;
+        int mnx = t[0], mxx = t[0], mny = t[1], mxy = t[1];
+        for (int i = 1; i < 4; i++) {
+            mnx = t[3 * i] < mnx ? t[3 * i] : mnx; mxx = t[3 * i] > mxx ? t[3 * i] : mxx;
+            mny = t[3 * i + 1] < mny ? t[3 * i + 1] : mny; mxy = t[3 * i + 1] > mxy ? t[3 * i + 1] : mxy;
+        }
+        if (mnx < -(1 << 28) || mxx > (1 << 28) || mny < -(1 << 28) || mxy > (1 << 28)) return b;
+        bx0 = (mnx >> 5) - 1; bx1 = (mxx >> 5) + 2; by0 = (mny >> 5) - 1; by1 = (mxy >> 5) + 2;
+    }
+    b.cx0 = bx0 < 0 ? 0 : bx0; b.cy0 = by0 < 0 ? 0 : by0;
+    const int ex = bx1 > a.sw - 1 ? a.sw - 1 : bx1, ey = by1 > a.sh - 1 ? a.sh - 1 : by1;
+    b.cw = ex - b.cx0 + 1; b.ch = ey - b.cy0 + 1;
+    b.shift = (b.cx0 * CN) & 3;
+    if (b.cw < 2 || b.ch < 2 || b.ch > a.ldsRows || ((b.shift + b.cw * CN + 3) & ~3) + 8 > a.ldsPitch) { b.cw = 0; b.ch = 0; b.all = 0; return b; }
+    b.all = exact && bx0 >= 0 && by0 >= 0 && bx1 <= a.sw - 1 && by1 <= a.sh - 1;
+    return b;
+}
+
+// staging: thread `tid` of 256 copies its share of the box into the LDS tile, whole aligned dwords.  Row r of the tile starts at the aligned dword that
+// holds pixel (cx0, cy0 + r); sstep % 4 == 0 makes the in-dword shift the same for every row.  The last dword of the image's last row is assembled from
+// bytes (a whole-dword load could read up to 3 bytes past the last pixel).
+W8_HD void stage(const Args& a, const Box& b, int cn, const unsigned char* src, unsigned char* tile, int tid)
+{
+    if (b.cw == 0) return;
+    const uint32_t nd = (uint32_t)(b.shift + b.cw * cn + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;       // dwords per row to load / per LDS row
+    const uint32_t total = pd * (uint32_t)b.ch;
+    const unsigned char* base = src + (size_t)b.cy0 * a.sstep + (((size_t)b.cx0 * cn) & ~(size_t)3);
+    const unsigned char* last = src + (size_t)(a.sh - 1) * a.sstep + (size_t)a.sw * cn;                 // one past the image's last pixel byte
+    for (uint32_t i = (uint32_t)tid; i < total; i += 256) {
+        const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
+        if (c >= nd) continue;
+        const unsigned char* g = base + (size_t)r * a.sstep + 4 * (size_t)c;
+        uint32_t v;
+        if (g + 4 <= last) v = *reinterpret_cast<const uint32_t*>(g);
+        else { v = 0; for (int k = 0; k < 4; k++) if (g + k < last) v |= (uint32_t)g[k] << (8 * k); }
+        reinterpret_cast<uint32_t*>(tile)[i] = v;
+    }
+}
+
+// the Q15 weight table in the form the dot products want: entry (ay * 32 + ax) = { bytes (w >> 8) of the four weights, bytes (w & 255) }
+W8_HD void splitWeights(uint32_t s01, uint32_t s23, uint32_t& hi, uint32_t& lo)
+{
+    hi = ((s01 >> 8) & 255) | ((s01 >> 24) << 8) | (((s23 >> 8) & 255) << 16) | ((s23 >> 24) << 24);
+    lo = (s01 & 255) | (((s01 >> 16) & 255) << 8) | ((s23 & 255) << 16) | (((s23 >> 16) & 255) << 24);
+}
+
+// one destination pixel from the LDS tile: `p` points at its upper-left tap, (wh, wl) are the byte-split Q15 weights.  Returns CN bytes in the low bits.
+template <int CN>
+W8_HD uint32_t bilinearAt(const unsigned char* p, uint32_t pitch, uint32_t wh, uint32_t wl)
+{
+    if (CN == 1) {
+        const uint32_t t = ld16(p) | (ld16(p + pitch) << 16);                     // [p00 p01 p10 p11]
+        const uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
+        return r > 255 ? 255 : r;
+    }
+    const unsigned long long q0 = ld64(p), q1 = ld64(p + pitch);                // CN * 2 bytes of each row are taps, the rest is slack
+    uint32_t out = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < CN; c++) {
+        const uint32_t t = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q0 >> (8 * (CN + c))) & 255) << 8) |
+                           ((uint32_t)((q1 >> (8 * c)) & 255) << 16) | ((uint32_t)((q1 >> (8 * (CN + c))) & 255) << 24);
+        uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
+        r = r > 255 ? 255 : r;
+        out |= r << (8 * c);
+    }
+    return out;
+}
+
+// ---- the three phases of a workgroup (256 threads), separated by barriers in the kernel; tests/hostemu runs them thread by thread -------------------------
+// A: weight table into LDS in split form (every thread), box terms (the first lanes)
+template <int KIND>
+W8_HD void phaseA(const Args& a, int x0, int y0, const short* tab, unsigned char* lds, int tid)
+{
+    uint32_t* wt = reinterpret_cast<uint32_t*>(lds);
+    for (int i = tid; i < 1024; i += 256) {
+        const uint32_t s01 = reinterpret_cast<const uint32_t*>(tab)[2 * i], s23 = reinterpret_cast<const uint32_t*>(tab)[2 * i + 1];
+        splitWeights(s01, s23, wt[2 * i], wt[2 * i + 1]);
+    }
+    if (tid < (KIND == 0 ? 8 : 4)) boxTerm<KIND>(a, x0, y0, tid, reinterpret_cast<int*>(lds + OFF_TERMS));
+}
+
+// B: the source box into the tile; affine: column terms of the tile's 128 columns and row terms of its rows (box origin folded into the row terms)
+template <int CN, int KIND>
+W8_HD void phaseB(const Args& a, const Box& b, int x0, int y0, const unsigned char* src, unsigned char* lds, int tid)
+{
+    stage(a, b, CN, src, lds + OFF_TILE, tid);
+    if (KIND == 0) {
+        int* col = reinterpret_cast<int*>(lds + OFF_COL); int* row = reinterpret_cast<int*>(lds + OFF_ROW);
+        if (tid < TW) { col[tid] = affColX(a, x0 + tid); col[TW + tid] = affColY(a, x0 + tid); }
+        else if (tid < TW + a.th) { const int r = tid - TW; row[r] = affRowX(a, y0 + r) - (b.cx0 << 10); row[MAX_TH + r] = affRowY(a, y0 + r) - (b.cy0 << 10); }
+    }
+}
+
+// C: a lane = four horizontally adjacent destination pixels of one row per step, straight-line code: the four pixels are always evaluated (a pixel whose
+// footprint is not strictly inside the loaded box reads LDS offset 0 instead) and stored as one dword / three / four when all four are good; otherwise the
+// group's bit is set in the returned mask and the kernel redoes the whole group with the generic sampler afterwards (same arithmetic for interior pixels,
+// borders and BORDER_TRANSPARENT handled there).  ALL = the tile's box is known to contain every footprint: no per-pixel test at all.
+template <int CN> W8_HD constexpr int tileRows() { return CN == 1 ? 32 : 16; }
+
+W8_HD uint32_t mad24(uint32_t x, uint32_t y, uint32_t z)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(x, y) + z;
+#else
+    return x * y + z;
+#endif
+}
+
+template <int CN, int KIND, bool ALL>
+W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, unsigned char* dst, int tid)
+{
+    const uint32_t* wt = reinterpret_cast<const uint32_t*>(lds);
+    const int* col = reinterpret_cast<const int*>(lds + OFF_COL); const int* row = reinterpret_cast<const int*>(lds + OFF_ROW);
+    const unsigned char* tile = lds + OFF_TILE;
+    const int wave = tid >> 6, lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
+    const int x = x0 + lx * PX;
+    if (x >= a.dw) return 0;
+    const bool fullLane = x + PX <= a.dw;
+    int cX[PX], cY[PX];
+    if (KIND == 0) for (int p = 0; p < PX; p++) { cX[p] = col[lx * PX + p]; cY[p] = col[TW + lx * PX + p]; }
+    const uint32_t pitch = (uint32_t)a.ldsPitch, cwm = (uint32_t)(b.cw - 1), chm = (uint32_t)(b.ch - 1);
+    unsigned redo = 0;
+    constexpr int NSTEPS = tileRows<CN>() / ROWS_PER_STEP;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < NSTEPS; st++) {
+        const int yi = st * ROWS_PER_STEP + wave * 2 + ly, y = y0 + yi;
+        const int rX = KIND == 0 ? row[yi] : 0, rY = KIND == 0 ? row[MAX_TH + yi] : 0;
+        uint32_t px[PX]; bool ok = fullLane;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            int rx, ry, ax, ay;
+            if (KIND == 0) {
+                const int tX = rX + cX[p], tY = rY + cY[p];                 // 1/1024 px relative to the box origin
+                rx = tX >> 10; ry = tY >> 10; ax = (tX >> 5) & 31; ay = (tY >> 5) & 31;
+            } else {
+                int X, Y;
+                perspXY(a, x + p < a.dw ? x + p : a.dw - 1, y < a.dh ? y : a.dh - 1, X, Y);
+                rx = (X >> 5) - b.cx0; ry = (Y >> 5) - b.cy0; ax = X & 31; ay = Y & 31;
+            }
+            uint32_t off = mad24((uint32_t)ry, pitch, (uint32_t)(rx * CN + b.shift));
+            if (!ALL) {
+                const bool in = (uint32_t)rx < cwm && (uint32_t)ry < chm;
+                off = in ? off : 0u; ok = ok && in;
+            }
+            const uint32_t* w = wt + 2 * (ay * 32 + ax);
+            px[p] = bilinearAt<CN>(tile + off, pitch, w[0], w[1]);
+        }
+        if (y < a.dh) {
+            if (ok) {
+                unsigned char* D = dst + (size_t)y * a.dstep + (size_t)x * CN;
+                uint32_t* d = reinterpret_cast<uint32_t*>(D);
+                if (CN == 1) d[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                else if (CN == 3) { d[0] = px[0] | (px[1] << 24); d[1] = (px[1] >> 8) | (px[2] << 16); d[2] = (px[2] >> 16) | (px[3] << 8); }
+                else { d[0] = px[0]; d[1] = px[1]; d[2] = px[2]; d[3] = px[3]; }
+            } else redo |= 1u << st;
+        }
+    }
+    return redo;
+}
+
+template <int CN, int KIND>
+W8_HD unsigned phaseC(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, unsigned char* dst, int tid)
+{
+    if (b.cw == 0) {                                                  // nothing staged (box too large for the LDS allotment, or wholly outside): every group is redone
+        const int lane = tid & 63, x = x0 + (lane & (LX - 1)) * PX;
+        return x < a.dw ? (1u << (tileRows<CN>() / ROWS_PER_STEP)) - 1 : 0;
+    }
+    return b.all ? rowsC<CN, KIND, true>(a, b, x0, y0, lds, dst, tid) : rowsC<CN, KIND, false>(a, b, x0, y0, lds, dst, tid);
+}
+
+// the groups phaseC left: slow(x, y, X, Y) for every destination pixel of them, (X, Y) = its source coordinates in 1/32 px (affine: from the row / column
+// terms still in LDS, box origin added back)
+template <int CN, int KIND, class Slow>
+W8_HD void redoGroups(const Args& a, const Box& b, unsigned redo, int x0, int y0, const unsigned char* lds, int tid, Slow slow)
+{
+    const int* col = reinterpret_cast<const int*>(lds + OFF_COL); const int* row = reinterpret_cast<const int*>(lds + OFF_ROW);
+    const int wave = tid >> 6, lane = tid & 63, lx = lane & (LX - 1), x = x0 + lx * PX;
+    for (int st = 0; redo >> st; st++) {
+        if (!((redo >> st) & 1)) continue;
+        const int yi = st * ROWS_PER_STEP + wave * 2 + (lane >> 5), y = y0 + yi;
+        if (y >= a.dh) continue;
+        for (int p = 0; p < PX && x + p < a.dw; p++) {
+            int X, Y;
+            if (KIND == 0) { X = ((row[yi] + col[lx * PX + p]) >> 5) + (b.cx0 << 5); Y = ((row[MAX_TH + yi] + col[TW + lx * PX + p]) >> 5) + (b.cy0 << 5); }
+            else perspXY(a, x + p, y, X, Y);
+            slow(x + p, y, X, Y);
+        }
+    }
+}
+
+// host side: can the tile kernel take this call, and with how much LDS?  Affine: the box of a tile has the same size everywhere (up to rounding);
+// perspective: the boxes of the tiles at the image's corners, edge centres and centre are measured with the kernel's own code.  Tiles whose box exceeds
+// what was allotted take the generic sampler inside the kernel, so the estimate bounds speed, never correctness.
+inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int dw, int dh, size_t sstep, size_t dstep, const void* src, const void* dst, int bw0,
+                 size_t* ldsBytes)
+{
+    if (((uintptr_t)src | (uintptr_t)dst | sstep | dstep) & 3) return false;
+    if (sw < 2 || sh < 2 || dw < 1 || dh < 1 || (cn != 1 && cn != 3 && cn != 4)) return false;
+    if ((unsigned long long)sh * sstep >= (1ull << 32) || (unsigned long long)dh * dstep >= (1ull << 32)) return false;
+    a = Args();
+    for (int i = 0; i < (kind == 0 ? 6 : 9); i++) a.M[i] = M[i];
+    a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh; a.sstep = (uint32_t)sstep; a.dstep = (uint32_t)dstep; a.bw0 = bw0 > 0 ? bw0 : 1;
+    a.th = cn == 1 ? tileRows<1>() : tileRows<3>();
+    a.gx = (dw + TW - 1) / TW; a.gy = (dh + a.th - 1) / a.th;
+    auto ab = [](double v) { return v < 0 ? -v : v; };
+    double bw, bh;
+    if (kind == 0) {
+        // the fixed-point sums must stay far from the int range (the kernel's box relies on them being monotone)
+        const double lim = 1048576.0;                                                      // 2^20 pixels
+        if (!(ab(M[0]) * dw + ab(M[1]) * dh + ab(M[2]) < lim && ab(M[3]) * dw + ab(M[4]) * dh + ab(M[5]) < lim)) return false;
+        bw = ab(M[0]) * (TW - 1) + ab(M[1]) * (a.th - 1) + 4; bh = ab(M[3]) * (TW - 1) + ab(M[4]) * (a.th - 1) + 4;
+    } else {
+        a.ldsPitch = 1 << 20; a.ldsRows = 1 << 20;
+        bw = bh = 0;
+        const int txs[3] = {0, a.gx / 2, a.gx - 1}, tys[3] = {0, a.gy / 2, a.gy - 1};
+        for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) {
+            int terms[12];
+            for (int k = 0; k < 4; k++) boxTerm<1>(a, txs[i] * TW, tys[j] * a.th, k, terms);
+            const Box b = cn == 1 ? boxFromTerms<1, 1>(a, terms) : cn == 3 ? boxFromTerms<3, 1>(a, terms) : boxFromTerms<4, 1>(a, terms);
+            bw = bw > b.cw + 2 ? bw : b.cw + 2; bh = bh > b.ch + 2 ? bh : b.ch + 2;
+        }
+        if (bw < 4 || bh < 4) return false;                                                // every probed tile looks outside the source: nothing to stage
+    }
+    if (!(bw < 4096 && bh < 4096)) return false;
+    const int ibw = (int)bw + 1, ibh = (int)bh + 1;
+    a.ldsPitch = ((ibw * cn + 3 + 3) & ~3) + 8;
+    a.ldsRows = ibh;
+    a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
+    *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;
+    return *ldsBytes <= 40 * 1024 && (size_t)a.ldsPitch / 4 * a.ldsRows < 65536;
+}
+
+} // namespace warp8

@@ -1,0 +1,50 @@
+// tests/hostemu -- TEST INFRASTRUCTURE ONLY.  The LDS-tile warp kernel of opencv_amd/csrc/warp8.h run on the CPU: the same host plan, the same three
+// phases, executed thread by thread with barriers replaced by loop boundaries, one "workgroup" at a time.  Pixels the kernel hands to the generic
+// sampler are copied from `expect` (the pinned restatement's output) and counted -- the test compares every other pixel with the restatement.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "warp8.h"
+
+template <int CN, int KIND>
+static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, const short* tab, const unsigned char* expect, size_t estep, long long* stats)
+{
+    std::vector<unsigned char> lds(ldsBytes + 64);
+    for (int ty = 0; ty < a.gy; ty++)
+        for (int tx = 0; tx < a.gx; tx++) {
+            const int x0 = tx * warp8::TW, y0 = ty * a.th;
+            std::memset(lds.data(), 0xA5, lds.size());                      // stale LDS must never reach an output pixel
+            for (int tid = 0; tid < 256; tid++) warp8::phaseA<KIND>(a, x0, y0, tab, lds.data(), tid);
+            const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, reinterpret_cast<const int*>(lds.data() + warp8::OFF_TERMS));
+            for (int tid = 0; tid < 256; tid++) warp8::phaseB<CN, KIND>(a, b, x0, y0, src, lds.data(), tid);
+            stats[2] += b.all; stats[3] += b.cw == 0;
+            for (int tid = 0; tid < 256; tid++) {
+                const unsigned redo = warp8::phaseC<CN, KIND>(a, b, x0, y0, lds.data(), dst, tid);
+                warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, lds.data(), tid, [&](int x, int y, int X, int Y) {
+                    // the coordinates handed to the generic sampler must be the pixel's own (checked against a direct evaluation)
+                    int Xr, Yr;
+                    if (KIND == 0) { Xr = (warp8::affRowX(a, y) + warp8::affColX(a, x)) >> 5; Yr = (warp8::affRowY(a, y) + warp8::affColY(a, x)) >> 5; }
+                    else warp8::perspXY(a, x, y, Xr, Yr);
+                    if (X != Xr || Y != Yr) stats[3] += 1000000;
+                    std::memcpy(dst + (size_t)y * a.dstep + (size_t)x * CN, expect + (size_t)y * estep + (size_t)x * CN, CN);
+                    stats[1]++;
+                });
+            }
+        }
+    stats[0] = (long long)a.dw * a.dh - stats[1];
+}
+
+// stats: [0] pixels produced from the LDS tile, [1] pixels left to the generic sampler, [2] tiles with an exact all-inside box, [3] tiles with nothing staged
+extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, int kind, const double* M,
+                         const short* tab, const unsigned char* expect, size_t estep, long long* stats)
+{
+    warp8::Args a; size_t ldsBytes = 0;
+    int bh0 = dh < 16 ? dh : 16;
+    const int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
+    if (!warp8::plan(a, cn, kind, M, sw, sh, dw, dh, sstep, dstep, src, dst, bw0, &ldsBytes)) return 1;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (kind == 0) { if (cn == 1) run<1, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); else if (cn == 3) run<3, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); else run<4, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); }
+    else           { if (cn == 1) run<1, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); else if (cn == 3) run<3, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); else run<4, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); }
+    return 0;
+}

@@ -40,3 +40,71 @@ def test_hsv2bgr_arithmetic(emu, code):
         got = np.empty_like(src)
         emu.emu_hsv2bgr(o.P(src), o.step(src), o.P(got), o.step(got), w, src.shape[0], 3, swap, full)
         assert np.array_equal(got, o.orc_cvtHSVtoBGR(src, code, 3, 8)), (code, w)
+
+
+# ---- the LDS-tile warp kernel (opencv_amd/csrc/warp8.h): plan, staging, box logic and per-pixel arithmetic run thread by thread on the CPU --------
+@pytest.fixture(scope="module")
+def emu8():
+    src = os.path.join(ROOT, "tests", "hostemu", "warp8_emu.cpp")
+    out = os.path.join(ROOT, "tests", "hostemu", "libwarp8emu.so")
+    hdr = os.path.join(ROOT, "opencv_amd", "csrc", "warp8.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + os.path.join(ROOT, "opencv_amd", "csrc"), src, "-o", out])
+    lib = ctypes.CDLL(out)
+    lib.emu_warp8.restype = ctypes.c_int
+    return lib
+
+
+def _rot(cx, cy, deg, scale):
+    """the INVERSE map (dst -> src) of cv::getRotationMatrix2D(center, deg, scale), as the hook receives it"""
+    a = np.deg2rad(deg); al, be = scale * np.cos(a), scale * np.sin(a)
+    m = np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy], [0, 0, 1.0]])
+    return np.ascontiguousarray(np.linalg.inv(m)[:2])
+
+
+def _emu_warp(emu8, src, M, dsize, kind):
+    orc = o.oracle()
+    orc.orc_bilinearTabI.restype = ctypes.c_void_p
+    tab = ctypes.c_void_p(orc.orc_bilinearTabI())
+    M = np.ascontiguousarray(M, np.float64)
+    want = (o.orc_warpAffine if kind == 0 else o.orc_warpPerspective)(src, M, dsize, 1, 0, 0.0)
+    got = np.full_like(want, 0x5A)
+    stats = (ctypes.c_longlong * 4)()
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    rc = emu8.emu_warp8(o.P(src), o.step(src), src.shape[1], src.shape[0], o.P(got), o.step(got), dsize[0], dsize[1], cn, kind,
+                        o.P(M), tab, o.P(want), o.step(want), stats)
+    return rc, got, want, list(stats)
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
+    rng = np.random.default_rng(cn)
+    for (sw, sh, dw, dh, deg, sc) in [(640, 360, 640, 360, 7.0, 0.95), (400, 300, 520, 260, -33.0, 1.1), (256, 200, 131, 77, 90.0, 1.0), (512, 128, 512, 128, 0.0, 1.0),
+                                      (300, 300, 300, 300, 45.0, 0.6), (640, 480, 1280, 960, 3.0, 2.0)]:
+        shp = (sh, sw) if cn == 1 else (sh, sw, cn)
+        src = rng.integers(0, 256, shp, dtype=np.uint8)
+        if (sw * cn) % 4:
+            continue
+        M = _rot(sw / 2.0, sh / 2.0, deg, sc)
+        if (dw, dh) != (sw, sh):
+            M = M.copy(); M[:, :2] *= sw / dw                                   # dst pixel -> src pixel of a resized canvas
+        rc, got, want, st = _emu_warp(emu8, src, M, (dw, dh), 0)
+        if rc != 0:
+            continue                                                           # the plan declined (box too large for LDS): the old kernel serves it
+        assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, int(np.count_nonzero(got != want)))
+        assert st[0] > 0.5 * dw * dh, (cn, deg, st)                            # most pixels come from the tile path
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp8_perspective_tiles_on_the_cpu(emu8, cn):
+    rng = np.random.default_rng(10 + cn)
+    for (sw, sh, dw, dh, P3) in [(640, 360, 640, 360, [[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]]),
+                                 (320, 240, 400, 300, [[0.9, -0.2, 30.0], [0.15, 0.85, -10.0], [2e-4, 1e-4, 1.0]]),
+                                 (256, 256, 200, 190, [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [3e-3, 0.0, 1.0]])]:
+        shp = (sh, sw) if cn == 1 else (sh, sw, cn)
+        src = rng.integers(0, 256, shp, dtype=np.uint8)
+        rc, got, want, st = _emu_warp(emu8, src, np.array(P3), (dw, dh), 1)
+        if rc != 0:
+            continue
+        assert np.array_equal(got, want), (cn, sw, sh, int(np.count_nonzero(got != want)))
+        assert st[0] > 0.3 * dw * dh, (cn, st)
