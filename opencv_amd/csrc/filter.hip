@@ -565,15 +565,21 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
     const SepParams& p = c.sp;
-    if (p.mode == 2 && c.ddepth == D16S && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 && p.deltaI == 0 &&
-        fullW == W && fullH == H && seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, c.border, stream()))
+    // a submatrix with real pixels around it stays on the rolling kernels: they run on the parent's geometry and store the window (roll.h Win)
+    const Roi roiv = {fullW, fullH, offX, offY};
+    const Roi* roi = (fullW != W || fullH != H) ? &roiv : nullptr;
+    const bool centred = p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2;
+    if (p.mode == 2 && c.ddepth == D16S && centred && p.deltaI == 0 &&
+        seprollDeriv16(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, c.border, stream(), roi))
         return stg.finish(entry);
-    if (p.mode == 1 && c.sdepth == D8U && c.ddepth == D8U && p.nx == p.ny && p.ny > 1 && p.ax == p.nx / 2 && p.ay == p.ny / 2 && fullW == W && fullH == H &&
-        seprollFix8U(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, p.deltaF, c.border, stream()))
+    if (p.mode == 1 && c.sdepth == D8U && c.ddepth == D8U && centred && p.ny > 1 &&
+        seprollFix8U(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxi, p.kyi, p.nx, p.deltaF, c.border, stream(), roi))
         return stg.finish(entry);
-    if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2 &&
-        fullW == W && fullH == H &&
-        seprollFloat(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))
+    if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && centred &&
+        seprollFloat(ds, dss, 0, dd, dds, 0, 1, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream(), roi))
+        return stg.finish(entry);
+    if (p.mode == 0 && c.sdepth == D32F && c.ddepth == D32F && c.cn == 1 && centred &&
+        seprollF32(ds, dss, 0, dd, dds, 0, 1, W, H, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream(), roi))
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
@@ -604,6 +610,9 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
         return stg.finish(entry);
     if (p.mode == 0 && c.sdepth == D8U && (c.ddepth == D32F || c.ddepth == D8U) && centred &&
         seprollFloat(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.cn, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.ddepth == D32F ? 4 : 1, c.border, stream()))
+        return stg.finish(entry);
+    if (p.mode == 0 && c.sdepth == D32F && c.ddepth == D32F && c.cn == 1 && centred &&
+        seprollF32(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream()))
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     for (int f = 0; f < nframes; f++)
@@ -970,6 +979,9 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
             seprollBox(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
             return stg.finish(entry);
+        if (p.mode == 2 && src_depth == D32F && dst_depth == D32F && cn == 1 && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
+            seprollBoxF32(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, kw, p.normalize != 0, border, stream()))
+            return stg.finish(entry);
         dim3 grid(divUp(width * cn, 64), divUp(height, 4));
         for (int f = 0; f < nframes; f++)
             hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * sframe, src_step, dst_data + (size_t)f * dframe, dst_step, width, height, cn,
@@ -982,8 +994,13 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * de, height, &dds);
     if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
     const uchar* ds = dtop + (size_t)margin_top * dss + (size_t)margin_left * cn * se;
-    if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 && fullW == width && fullH == height &&
-        seprollBox(ds, dss, 0, dd, dds, 0, 1, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream()))
+    const Roi roiv = {fullW, fullH, margin_left, margin_top};
+    const Roi* roi = (fullW != width || fullH != height) ? &roiv : nullptr;       // a submatrix with real pixels around it: the rolling kernels store the window
+    if (p.mode == 0 && p.normalize && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
+        seprollBox(ds, dss, 0, dd, dds, 0, 1, width, height, cn, kw, (unsigned)p.divScale, (unsigned)p.divDelta, border, stream(), roi))
+        return stg.finish(entry);
+    if (p.mode == 2 && src_depth == D32F && dst_depth == D32F && cn == 1 && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
+        seprollBoxF32(ds, dss, 0, dd, dds, 0, 1, width, height, kw, p.normalize != 0, border, stream(), roi))
         return stg.finish(entry);
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,

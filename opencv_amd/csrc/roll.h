@@ -31,6 +31,13 @@ template <int RX, int CN, int CB = 16> struct Cfg {
 
 template <int HD, int MD = 4> struct Raw { uint32_t m[MD]; uint32_t side[HD]; };
 
+// A window of the image (a cv::Mat submatrix with real pixels around it, the HAL's offset_x / offset_y / full_width / full_height contract):
+// the kernel is handed the PARENT image -- chunks lie on the parent's rows, halos and borders are the parent's -- and produces only the
+// window: chunks that overlap its byte range [x0b, x1b) of a row, rows [y0, y1); the first / last chunk store just their bytes inside it.
+// `dst` is the window's own origin.  x1b < 0: the whole image.
+struct Win { int x0b, x1b, y0, y1; };
+__host__ __device__ inline Win wholeImage() { Win w = {0, -1, 0, -1}; return w; }
+
 template <int HD, int MD = 4> struct Edge { uint32_t la[HD], lb[HD], lc[HD], ra[HD], rb[HD], rc[HD], oa[MD], ob[MD], oc[MD]; };
 
 __device__ __forceinline__ void selSetByte(uint32_t& a, uint32_t& b, uint32_t& c, int j, int idx /* 0..15 or <0 */)
@@ -66,13 +73,18 @@ struct Ctx {
     int H, lane, c, nchunks, mainOff, sideOff, y0, y1, nrows, up, frame;
     bool active, hasFirst, hasLast, isLastChunk, rag;
     int vb;                                            // valid bytes of the last chunk (CB unless the row is ragged)
+    int wx0, wx1, wy0;                                 // window: byte range of a row that is stored, first row (whole image: 0, W*CN, 0)
     Edge<HD, MD> es;
     int rowBelow[RY > 0 ? RY : 1], rowAbove[RY > 0 ? RY : 1];
 
     // decode the work item of this wave; false when the wave has nothing to do
     __device__ __forceinline__ bool init(const uchar* s, size_t ss, size_t sframe, int W, int H_, int nchunks_, int nstrips, int segRows, int nseg,
-                                         int nframes, int border, int alt)
+                                         int nframes, int border, int alt, Win win = wholeImage())
     {
+        // nchunks_ = chunks of a PARENT row; nstrips / nseg = strips of 64 chunks over the window's chunk range / segments over its rows
+        if (win.x1b < 0) { win.x0b = 0; win.x1b = W * CN; win.y0 = 0; win.y1 = H_; }
+        wx0 = win.x0b; wx1 = win.x1b; wy0 = win.y0;
+        const int cA = win.x0b / CB, cB = (win.x1b - 1) / CB;
         lane = threadIdx.x & 63;
         const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
         const int strip = wid % nstrips;
@@ -88,14 +100,16 @@ struct Ctx {
         }
         H = H_; nchunks = nchunks_;
         src = s + (size_t)frame * sframe; sstep = ss;
-        c = strip * 64 + lane;
-        y0 = seg * segRows; y1 = min(H, y0 + segRows); nrows = y1 - y0;
-        active = c < nchunks; hasFirst = strip == 0; hasLast = strip == nstrips - 1; isLastChunk = c == nchunks - 1;
+        const int c0 = cA + strip * 64;
+        c = c0 + lane;
+        y0 = win.y0 + seg * segRows; y1 = min(win.y1, y0 + segRows); nrows = y1 - y0;
+        const bool live = c < nchunks;                 // the lane has a chunk of its own in the parent row (it may lie right of the window: it then
+                                                       // only feeds its left neighbour's halo)
+        active = c <= cB; hasFirst = c0 == 0; hasLast = c0 + 64 >= nchunks; isLastChunk = c == nchunks - 1;
         vb = W * CN - CB * (nchunks - 1);
         rag = vb < CB;
-        mainOff = CB * (active ? c : nchunks - 1);
-        if (rag && (!active || isLastChunk)) mainOff = W * CN - CB;      // the last CB bytes of the row
-        const int c0 = strip * 64;
+        mainOff = CB * (live ? c : nchunks - 1);
+        if (rag && (!live || isLastChunk)) mainOff = W * CN - CB;        // the last CB bytes of the row
         const int leftOff = c0 > 0 ? CB * c0 - 4 * HD : 0;
         const int rightOff = c0 + 64 < nchunks ? CB * (c0 + 64) : (rag ? W * CN - CB : CB * (nchunks - 1));   // (last strip: never used, only legal)
         sideOff = lane < 32 ? leftOff : rightOff;
@@ -203,13 +217,16 @@ struct Ctx {
 #pragma unroll
         for (int d = 0; d < MD; d++) X[HD + d] = mv[d];
     }
-    // the lane's outputs of image row y (OUTB bytes per source byte) -> memory; a ragged last chunk writes its valid elements only
+    // the lane's outputs of image row y (OUTB bytes per source byte) -> memory; a ragged last chunk writes its valid elements only, the first / last
+    // chunk of a window the elements inside it
     template <int OUTB>
     __device__ __forceinline__ void store(uchar* __restrict__ dst, size_t dstep, int y, const uint32_t (&o)[MD * OUTB]) const
     {
         if (!active) return;
-        uchar* p = dst + (size_t)y * dstep + (size_t)CB * OUTB * (size_t)c;
-        if (!(rag && isLastChunk)) {
+        const int b0 = CB * c;                                                // first byte of the chunk in the parent row
+        uchar* p = dst + (size_t)(y - wy0) * dstep + (ptrdiff_t)(b0 - wx0) * OUTB;
+        const int lo = max(wx0 - b0, 0), hi = min(min(wx1 - b0, CB), (rag && isLastChunk) ? vb : CB);
+        if (lo == 0 && hi == CB) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             if constexpr ((MD * OUTB) % 4 == 0) {
@@ -221,7 +238,7 @@ struct Ctx {
         } else {
 #pragma unroll
             for (int e = 0; e < CB; e++) {
-                if (e < vb) {
+                if (e >= lo && e < hi) {
                     if constexpr (OUTB == 4) reinterpret_cast<uint32_t*>(p)[e] = o[e];
                     else if constexpr (OUTB == 2) reinterpret_cast<unsigned short*>(p)[e] = (unsigned short)(o[e >> 1] >> (16 * (e & 1)));
                     else p[e] = (uchar)(o[e >> 2] >> (8 * (e & 3)));
@@ -266,11 +283,13 @@ inline bool eligible(const void* s, size_t ss, size_t sf, const void* d, size_t 
 }
 
 struct Geom { int nchunks, nstrips, seg, nseg; unsigned blocks; };
-// `wantWaves`: work items (waves) the launch should at least consist of, when the image has enough rows for that at >= minSeg rows each
-inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16, int wantWaves = 2048)
+// `wantWaves`: work items (waves) the launch should at least consist of, when the image has enough rows for that at >= minSeg rows each.
+// `win`: a window of the (W x H) image (see Win): strips cover the chunks that overlap it, segments its rows.
+inline Geom geometry(int W, int H, int cn, int nframes, int bestSeg, int minSeg, int cb = 16, int wantWaves = 2048, Win win = wholeImage())
 {
     Geom g;
     g.nchunks = mi355::divUp(W * cn, cb); g.nstrips = mi355::divUp(g.nchunks, 64);
+    if (win.x1b >= 0) { g.nstrips = mi355::divUp((win.x1b - 1) / cb - win.x0b / cb + 1, 64); H = win.y1 - win.y0; }
     if (const char* e = std::getenv("MI355CV_ROLL_SEG")) { const int v = atoi(e); if (v > 0) bestSeg = v; }     // tuning experiments
     long long per = (long long)g.nstrips * nframes;
     if (const char* e = std::getenv("MI355CV_ROLL_WAVES")) { const int v = atoi(e); if (v > 0) wantWaves = v; }

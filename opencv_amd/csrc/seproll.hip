@@ -34,10 +34,14 @@ __device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P
 #pragma unroll
             for (int d = 0; d < Cx::HD; d++) raw.side[d] = 0;
         }
-        uint32_t X[NW], E[NW], O[NW];
+        uint32_t X[NW];
         cx.window(X, raw);
-        roll::planes<NW>(E, O, X);
-        P::hpass(o, E, O, a);
+        if constexpr (P::RAWX) P::hpassX(o, X, a);      // 32-bit elements: the window's dwords are the elements
+        else {
+            uint32_t E[NW], O[NW];
+            roll::planes<NW>(E, O, X);
+            P::hpass(o, E, O, a);
+        }
     };
 #pragma unroll
     for (int i = 0; i < KY - 1; i++) { RawT pre; int v; cx.issue(pre, i - RY, v); hrow(ring[i], pre, v); }
@@ -61,22 +65,36 @@ __device__ __forceinline__ void sepRows(roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P
 template <class P>
 __global__ __launch_bounds__(256) void k_sep_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                   int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
-                                                  typename P::Args a)
+                                                  roll::Win win, typename P::Args a)
 {
     roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB> cx;
-    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt, win)) return;
     dst += (size_t)cx.frame * dframe;
     if (cx.up) sepRows<P, true>(cx, dst, dstep, a);
     else       sepRows<P, false>(cx, dst, dstep, a);
 }
 
+// `roi`: the image (src, W, H) is a window of a larger one whose pixels around it are real (the HAL's offset / full-size contract): the kernel then
+// runs on the PARENT's geometry and stores the window only (roll.h Win); `bpp` = bytes per pixel of the source as the policy counts channels
 template <class P>
 void launchSep(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int border,
-               int bestSeg, const typename P::Args& a, hipStream_t st)
+               int bestSeg, const typename P::Args& a, hipStream_t st, const Roi* roi = nullptr)
 {
-    const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY, P::CB);
+    roll::Win win = roll::wholeImage();
+    if (roi) {
+        win.x0b = roi->offX * P::CN; win.x1b = (roi->offX + W) * P::CN; win.y0 = roi->offY; win.y1 = roi->offY + H;
+        src -= (size_t)roi->offY * sstep + (size_t)roi->offX * P::CN;
+        W = roi->fullW; H = roi->fullH;
+    }
+    const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY, P::CB, 2048, win);
     hipLaunchKernelGGL((k_sep_roll<P>), dim3(g.blocks), dim3(256), 0, st, src, sstep, sframe, dst, dstep, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg,
-                       nframes, border, 1, a);
+                       nframes, border, 1, win, a);
+}
+
+// is (W x H at the ROI's offsets inside fullW x fullH) a call the rolling kernels take?  roll::eligible on the parent's geometry; a window needs nframes == 1
+inline bool roiEligible(const Roi* roi, int nframes, int W, int H)
+{
+    return !roi || (nframes == 1 && roi->offX >= 0 && roi->offY >= 0 && roi->offX + W <= roi->fullW && roi->offY + H <= roi->fullH);
 }
 
 // take byte 2 of four 32-bit accumulators -> one dword (accumulators hold value << 16 with value <= 255)
@@ -94,6 +112,7 @@ __device__ __forceinline__ uint32_t packB2(uint32_t b0, uint32_t b1, uint32_t b2
 template <int K, int CN_>
 struct FixedSmooth {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t kx[K]; uint32_t kyLo[K], kyHi[K]; };
     template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
@@ -149,6 +168,7 @@ struct FixedSmooth {
 template <int K, int CN_>
 struct SepFix8U {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t kx[K]; float ky[K]; float delta; };
     template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
@@ -205,6 +225,7 @@ __device__ __forceinline__ uint32_t packB3(uint32_t b0, uint32_t b1, uint32_t b2
 template <int K, int CN_>
 struct BoxU8 {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     struct Args { uint32_t ds2, c2; };
     template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
@@ -242,6 +263,7 @@ struct BoxU8 {
 template <int K, int CN_>
 struct Deriv16 {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 2, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     struct Args { uint32_t kx[K], ky[K]; };              // taps splatted into both 16-bit halves
@@ -286,6 +308,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K, int SYM, int OUTB_, int CN_>
 struct SepF32 {
     static constexpr int KX = K, KY = K, CN = CN_, OUTB = OUTB_, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int CB = OUTB_ == 4 ? 8 : 16;           // 32-bit outputs: 8 elements per lane = 32 contiguous output bytes
     static constexpr int NP = CB / 2;                        // element pairs (i, i + NP)
     static constexpr int HD = roll::Cfg<R, CN, CB>::HD;
@@ -349,6 +372,88 @@ struct SepF32 {
     }
 };
 
+// ---------------------------------------------------------------------------------- CV_32F -> CV_32F separable filter
+// cv::sepFilter2D / cv::Sobel / cv::GaussianBlur on CV_32FC1 (north_star's second parity class).  The skeleton moves bytes, so a float is handled as a
+// pixel of CN = 4 "channels": halos are RX whole floats, border rules act on whole floats, a lane owns four floats (one dwordx4 in, one out), and the
+// window's dwords ARE the elements (hpassX).  Arithmetic: the float path of the reference in the association order of its scalar / FMA forms, as
+// SepF32 above (RowFilter filter.simd.hpp:2386: r = k0*v0, r = fma(k_i, v_i, r); SymmColumnFilter :2679-2751 pair forms; ColumnFilter :2640 chain).
+template <int K, int SYM>
+struct SepF32F {
+    static constexpr int KX = K, KY = K, CN = 4, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = true;
+    struct Args { float kx[K], ky[K], delta; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
+    struct Inter { float h[4]; };
+    template <int NWn>
+    static __device__ __forceinline__ void hpassX(Inter& o, const uint32_t (&X)[NWn], const Args& a)
+    {
+        static_assert(NWn == 4 + 2 * R, "a float is one halo dword");
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float r = a.kx[0] * __uint_as_float(X[k]);
+#pragma unroll
+            for (int t = 1; t < K; t++) r = __builtin_fmaf(a.kx[t], __uint_as_float(X[k + t]), r);
+            o.h[k] = r;
+        }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };     // image row t of the window
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float s;
+            if (SYM == 1 || SYM == 2) {
+                s = SYM == 1 ? __builtin_fmaf(a.ky[R], row(R).h[k], a.delta) : a.delta;
+#pragma unroll
+                for (int d = 1; d <= R; d++)
+                    s = __builtin_fmaf(a.ky[R + d], SYM == 1 ? row(R + d).h[k] + row(R - d).h[k] : row(R + d).h[k] - row(R - d).h[k], s);
+            } else {
+                s = __builtin_fmaf(a.ky[0], row(0).h[k], a.delta);
+#pragma unroll
+                for (int j = 1; j < K; j++) s = __builtin_fmaf(a.ky[j], row(j).h[k], s);
+            }
+            out[k] = __float_as_uint(s);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------- box filter on CV_32FC1: sums in double
+// RowSum<float,double> + ColumnSum<double,float> (box_filter.simd.hpp:64-140, :176-260, selected at :1256-1265): the window's K*K floats are summed
+// in double -- here directly (K adds per row, K per column) instead of the reference's running sums, which differ from it by double rounding only,
+// eleven decimal digits below the float result -- and the result is float(s * scale) with the double scale 1 / (K*K), or float(s) un-normalised.
+template <int K>
+struct BoxF32 {
+    static constexpr int KX = K, KY = K, CN = 4, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = true;
+    struct Args { double scale; int normalize; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
+    struct Inter { double h[4]; };
+    template <int NWn>
+    static __device__ __forceinline__ void hpassX(Inter& o, const uint32_t (&X)[NWn], const Args&)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double r = (double)__uint_as_float(X[k]);
+#pragma unroll
+            for (int t = 1; t < K; t++) r = __dadd_rn(r, (double)__uint_as_float(X[k + t]));
+            o.h[k] = r;
+        }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double s = row(0).h[k];
+#pragma unroll
+            for (int j = 1; j < K; j++) s = __dadd_rn(s, row(j).h[k]);
+            out[k] = __float_as_uint(a.normalize ? (float)__dmul_rn(s, a.scale) : (float)s);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------- erode / dilate, rectangular element, u8
 // MorphRowFilter / MorphColumnFilter (morph.simd.hpp:590-700): running max over the K x K window.  dilate with the default
 // constant border pads with 0, which is what a BORDER_CONSTANT halo is here; erode is computed as ~dilate(~src), so its default
@@ -356,6 +461,7 @@ struct SepF32 {
 template <int K, int CN_>
 struct MorphMax {
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     struct Args { uint32_t flip; };                      // 0 dilate, 0xffffffff erode
@@ -400,16 +506,17 @@ struct MorphMax {
 namespace mi355 {
 
 bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                        int W, int H, int cn, const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, hipStream_t st)
+                        int W, int H, int cn, const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if (nx != ny || (nx != 3 && nx != 5 && nx != 7 && nx != 9) || !(cn == 1 || cn == 3 || cn == 4)) return false;
     unsigned sx = 0, sy = 0;
     for (int i = 0; i < nx; i++) { sx += kx[i]; sy += ky[i]; }
     if (sx > 256 || sy > 256) return false;
-    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, nx / 2, border)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, cn, nx / 2, border)) return false;
 #define FS(K_, CN_) do { typedef FixedSmooth<K_, CN_> P; P::Args a; \
         for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.kyLo[i] = ky[i]; a.kyHi[i] = (uint32_t)ky[i] << 16; } \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); } while (0)
 #define FSK(K_) do { if (cn == 1) FS(K_, 1); else if (cn == 3) FS(K_, 3); else FS(K_, 4); } while (0)
     switch (nx) { case 3: FSK(3); break; case 5: FSK(5); break; case 7: FSK(7); break; default: FSK(9); }
 #undef FSK
@@ -418,17 +525,18 @@ bool seprollFixedSmooth(const uchar* src, size_t sstep, size_t sframe, uchar* ds
 }
 
 bool seprollFix8U(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                  int W, int H, int cn, const int* kx, const int* ky, int n, float delta, int border, hipStream_t st)
+                  int W, int H, int cn, const int* kx, const int* ky, int n, float delta, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if ((n != 3 && n != 5) || !(cn == 1 || cn == 3 || cn == 4) || ((size_t)W * cn) % 16 != 0) return false;
     int sx = 0;
     for (int i = 0; i < n; i++) { if (kx[i] < 0) return false; sx += kx[i]; }
     if (sx > 256) return false;
     for (int i = 0; i < n / 2; i++) if (ky[i] != ky[n - 1 - i]) return false;              // the pair form needs a symmetric column kernel
-    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, n / 2, border)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, cn, n / 2, border)) return false;
 #define FX(K_, CN_) do { typedef SepFix8U<K_, CN_> P; P::Args a; \
         for (int i = 0; i < K_; i++) { a.kx[i] = (uint32_t)kx[i]; a.ky[i] = (float)ky[i] * (1.0f / 65536.0f); } a.delta = delta; \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); } while (0)
 #define FXK(K_) do { if (cn == 1) FX(K_, 1); else if (cn == 3) FX(K_, 3); else FX(K_, 4); } while (0)
     if (n == 3) FXK(3); else FXK(5);
 #undef FXK
@@ -437,13 +545,14 @@ bool seprollFix8U(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
 }
 
 bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                int W, int H, int cn, int ksize, unsigned divScale, unsigned divDelta, int border, hipStream_t st)
+                int W, int H, int cn, int ksize, unsigned divScale, unsigned divDelta, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if ((ksize != 3 && ksize != 5 && ksize != 7) || !(cn == 1 || cn == 3 || cn == 4)) return false;
     if (divScale >= (1u << 22) || (unsigned long long)divDelta * divScale >= (1ull << 30)) return false;
-    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, ksize / 2, border)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, cn, ksize / 2, border)) return false;
 #define BX(K_, CN_) do { typedef BoxU8<K_, CN_> P; P::Args a = {2u * divScale, 2u * divDelta * divScale}; \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); } while (0)
 #define BXK(K_) do { if (cn == 1) BX(K_, 1); else if (cn == 3) BX(K_, 3); else BX(K_, 4); } while (0)
     switch (ksize) { case 3: BXK(3); break; case 5: BXK(5); break; default: BXK(7); }
 #undef BXK
@@ -452,16 +561,17 @@ bool seprollBox(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
 }
 
 bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                    int W, int H, int cn, const int* kx, const int* ky, int n, int border, hipStream_t st)
+                    int W, int H, int cn, const int* kx, const int* ky, int n, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if ((n != 3 && n != 5) || !(cn == 1 || cn == 3 || cn == 4)) return false;
     long long ax = 0, ay = 0;
     for (int i = 0; i < n; i++) { ax += kx[i] < 0 ? -kx[i] : kx[i]; ay += ky[i] < 0 ? -ky[i] : ky[i]; }
     if (255 * ax > 32767 || 255 * ax * ay > 32767) return false;
-    if ((((uintptr_t)dst | dstep | dframe) & 1) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, cn, n / 2, border)) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & 1) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, roi ? roi->fullW : W, cn, n / 2, border)) return false;
 #define DV(K_, CN_) do { typedef Deriv16<K_, CN_> P; P::Args a; \
         for (int i = 0; i < K_; i++) { a.kx[i] = ((uint32_t)kx[i] & 0xffffu) * 0x10001u; a.ky[i] = ((uint32_t)ky[i] & 0xffffu) * 0x10001u; } \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); } while (0)
 #define DVC(K_) do { if (cn == 1) DV(K_, 1); else if (cn == 3) DV(K_, 3); else DV(K_, 4); } while (0)
     if (n == 3) DVC(3); else DVC(5);
 #undef DVC
@@ -470,13 +580,14 @@ bool seprollDeriv16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, s
 }
 
 bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                  int W, int H, int cn, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st)
+                  int W, int H, int cn, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2 || !(cn == 1 || cn == 3)) return false;
     if (cn == 3 && outBytes == 4 && n == 5) return false;         // 2 pixels x 3 channels of halo do not fit an 8-byte chunk
-    if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, W, cn, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
+    if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, roi ? roi->fullW : W, cn, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
 #define SF1(K_, S_, O_, CN_) do { typedef SepF32<K_, S_, O_, CN_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st, roi); } while (0)
 #define SF(K_, S_, O_) do { if (cn == 1) SF1(K_, S_, O_, 1); else SF1(K_, S_, O_, 3); } while (0)
 #define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)
     if (n == 3) { if (outBytes == 4) SFS(3, 4); else SFS(3, 1); }
@@ -488,13 +599,44 @@ bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
     return true;
 }
 
-bool seprollMorph(int erode, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-                  int W, int H, int cn, int ksize, int border, hipStream_t st)
+bool seprollF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int border, hipStream_t st, const Roi* roi)
 {
+    if (!roiEligible(roi, nframes, W, H)) return false;
+    if ((n != 3 && n != 5 && n != 7) || symY < 0 || symY > 2) return false;
+    if ((((uintptr_t)src | sstep | sframe | (uintptr_t)dst | dstep | dframe) & 3) != 0) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, 4, n / 2, border)) return false;
+#define FF(K_, S_) do { typedef SepF32F<K_, S_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st, roi); } while (0)
+#define FFS(K_) do { if (symY == 1) FF(K_, 1); else if (symY == 2) FF(K_, 2); else FF(K_, 0); } while (0)
+    switch (n) { case 3: FFS(3); break; case 5: FFS(5); break; default: FFS(7); }
+#undef FFS
+#undef FF
+    return true;
+}
+
+bool seprollBoxF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                   int W, int H, int ksize, bool normalize, int border, hipStream_t st, const Roi* roi)
+{
+    if (!roiEligible(roi, nframes, W, H)) return false;
+    if (ksize != 3 && ksize != 5 && ksize != 7) return false;
+    if ((((uintptr_t)src | sstep | sframe | (uintptr_t)dst | dstep | dframe) & 3) != 0) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, 4, ksize / 2, border)) return false;
+#define BF(K_) do { typedef BoxF32<K_> P; P::Args a = {1.0 / (double)(K_ * K_), normalize ? 1 : 0}; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st, roi); } while (0)
+    switch (ksize) { case 3: BF(3); break; case 5: BF(5); break; default: BF(7); }
+#undef BF
+    return true;
+}
+
+bool seprollMorph(int erode, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                  int W, int H, int cn, int ksize, int border, hipStream_t st, const Roi* roi)
+{
+    if (!roiEligible(roi, nframes, W, H)) return false;
     if ((ksize != 3 && ksize != 5 && ksize != 7) || !(cn == 1 || cn == 3 || cn == 4)) return false;
-    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, W, cn, ksize / 2, border)) return false;
+    if (!roll::eligible(src, sstep, sframe, dst, dstep, dframe, roi ? roi->fullW : W, cn, ksize / 2, border)) return false;
 #define MM(K_, CN_) do { typedef MorphMax<K_, CN_> P; P::Args a = {erode ? 0xffffffffu : 0u}; \
-        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st); } while (0)
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); } while (0)
 #define MMK(K_) do { if (cn == 1) MM(K_, 1); else if (cn == 3) MM(K_, 3); else MM(K_, 4); } while (0)
     switch (ksize) { case 3: MMK(3); break; case 5: MMK(5); break; default: MMK(7); }
 #undef MMK

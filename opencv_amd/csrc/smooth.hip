@@ -687,6 +687,10 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     } else if (noMargins && std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr &&
                seprollFixedSmooth(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, kx, nx, ky, ny, border, st)) {
         // any-sigma Q8.8 taps on the rolling skeleton
+    } else if (!noMargins && nframes == 1 && std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && [&] {
+                   // a submatrix with real pixels around it (cv_hal_gaussianBlurBinomial's margins): the rolling kernel on the parent's geometry, storing the window
+                   const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
+                   return seprollFixedSmooth(dsrc, dss, 0, ddst, dds, 0, 1, W, H, cn, kx, nx, ky, ny, border, st, &roi); }()) {
     } else {
         FixedTaps t;
         t.nx = nx; t.ny = ny;

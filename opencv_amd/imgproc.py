@@ -101,7 +101,13 @@ def GaussianBlur(src, ksize, sigmaX=0.0, sigmaY=0.0, borderType=BORDER_DEFAULT, 
         raise ValueError("ksize must be positive and odd")       # :293-294
     sigmaX, sigmaY = max(sigmaX, 0.0), max(sigmaY, 0.0)
     if s.depth != CV_8U:
-        raise NotImplementedError("GaussianBlur: only CV_8U so far")
+        # smooth.dispatch.cpp:800-826: every depth without a fixed-point path ends in sepFilter2D with the taps of createGaussianKernels (:280-304:
+        # getGaussianKernel(ksize, sigma, max(depth, CV_32F))); cv_hal_gaussianBlur declines these depths, the sepFilter hook serves them
+        if s.depth == CV_16U:
+            raise NotImplementedError("GaussianBlur: CV_16U runs the reference's Q16.16 fixed-point path (smooth.dispatch.cpp:726-760), not served")
+        kx = getGaussianKernel(kw, sigmaX, CV_32F)
+        ky = kx if (kh == kw and abs(sigmaY - sigmaX) < 2.220446049250313e-16) else getGaussianKernel(kh, sigmaY, CV_32F)
+        return sepFilter2D(src, -1, kx, ky, borderType=borderType, dst=dst)
     out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
     d = Img(out)
     if (d.h, d.w, d.cn, d.depth) != (s.h, s.w, s.cn, s.depth):

@@ -278,3 +278,69 @@ def test_cvtcolor_known_answer_hash(cv):
     out = cv.cvtColorBatch(frames, cv.COLOR_BGR2GRAY)
     for f in range(3):
         assert zlib.adler32(out[f].cpu().numpy().tobytes()) == 0x3008c6b8
+
+
+def _kernel(cv):
+    from opencv_amd import _lib
+    return _lib.lib.mi355cv_lastKernel().decode()
+
+
+def test_f32_rolling_filters(cv, orc):
+    """CV_32FC1 -> CV_32FC1 on the rolling kernels (north_star's second parity class): sepFilter2D with symmetric / antisymmetric / general taps of 3, 5
+    and 7, Sobel, GaussianBlur (which the reference runs as sepFilter2D with float taps), boxFilter with its double sums; ragged and unaligned rows;
+    <= 1e-6 relative against the restatement (the contract is 1e-4)."""
+    rng = np.random.default_rng(3)
+    for (w, h) in [(64, 23), (1040, 37), (333, 19), (4, 5), (2064, 70)]:
+        src = rnd((h, w), np.float32, w + h) * 255 - 100
+        for border in (0, 1, 2, 4):
+            for kx, ky, dl in [([0.25, 0.5, 0.25], [0.25, 0.5, 0.25], 0.0), ([-1, 0, 1], [1, 2, 1], 0.5), ([0.1, 0.5, 0.2], [0.7, -0.1, 0.2], 3.5),
+                               ([0.0625, 0.25, 0.375, 0.25, 0.0625], [0.0625, 0.25, 0.375, 0.25, 0.0625], 0.0), ([-1, -2, 0, 2, 1], [1, 4, 6, 4, 1], 0.0),
+                               (rng.uniform(-1, 1, 7).tolist(), rng.uniform(-1, 1, 7).tolist(), 0.25), ([0.05, 0.1, 0.4, 0.3, 0.15], [0.3, 0.3, 0.2, 0.1, 0.1], 0.0)]:
+                check(cv.sepFilter2D(dev(src), -1, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, -1, kx, ky, (-1, -1), dl, border), tol=1e-6)
+                if w >= 64 and len(kx) <= 7:
+                    assert "SepF32F" in _kernel(cv) or "k_sep_roll" in _kernel(cv), _kernel(cv)
+            for ksize, dx, dy in [(3, 1, 0), (3, 0, 1), (5, 1, 1), (7, 2, 0), (-1, 0, 1)]:
+                check(cv.Sobel(dev(src), -1, dx, dy, ksize, 0.5, 0.25, border), orc.orc_Sobel(src, -1, dx, dy, ksize, 0.5, 0.25, border), tol=1e-6)
+            for k in (3, 5, 7):
+                for normalize in (True, False):
+                    check(cv.boxFilter(dev(src), -1, (k, k), (-1, -1), normalize, border), orc.orc_boxFilter(src, -1, (k, k), (-1, -1), normalize, border), tol=1e-6)
+        for ks, sg in [(3, 0.0), (5, 1.2), (7, 0.0), (5, 0.0)]:
+            want = orc.ref_GaussianBlur(src, ks, sg, sg, 4) if orc.load_ref() is not None else None
+            got = cv.GaussianBlur(dev(src), (ks, ks), sg)
+            if want is not None:
+                check(got, want, tol=1e-6)
+    # a whole 4K frame, and the same through the batch entries
+    big = rnd((2160, 3840), np.float32, 11)
+    g5 = cv.getGaussianKernel(5, 1.2, cv.CV_32F)
+    want = orc.orc_sepFilter2D(big, -1, g5, g5)
+    check(cv.sepFilter2D(dev(big), -1, g5, g5), want, tol=1e-6)
+    fb = dev(np.stack([big, big[::-1].copy()]))
+    check(cv.sepFilter2DBatch(fb, -1, g5, g5)[0], want, tol=1e-6)
+    check(cv.boxFilterBatch(fb, -1, (5, 5))[0], orc.orc_boxFilter(big, -1, (5, 5)), tol=1e-6)
+    check(cv.SobelBatch(fb, cv.CV_32F, 1, 0, 3)[0], orc.orc_Sobel(big, -1, 1, 0, 3), tol=1e-6)
+
+
+def test_submatrix_calls_stay_on_the_rolling_kernels(cv, orc):
+    """A cv::Mat ROI with real pixels around it (the HAL's offset / full-size and margin contracts): the rolling kernels run on the parent's geometry and
+    store the window only -- every window position relative to the 16-byte chunk grid, windows touching the parent's edges, one-pixel windows;
+    8U fixed-point sepFilter2D, Sobel 8U->16S, float-tap sepFilter2D 8U->8U / 32F, CV_32F sepFilter2D and box, 8U box; results equal to the
+    restatement's ROI call; the kernel that ran is a rolling one."""
+    parent = rnd((96, 400), np.uint8, 77)
+    pf = rnd((96, 400), np.float32, 78)
+    s3 = [0.25, 0.5, 0.25]
+    rolled = 0
+    for roi in [(16, 8, 256, 40), (5, 4, 130, 20), (33, 1, 64, 94), (0, 0, 400, 96), (0, 3, 17, 5), (383, 90, 17, 6), (100, 50, 1, 1), (17, 17, 335, 3), (1, 0, 398, 96)]:
+        for border in (0, 1, 2, 4):
+            check(cv.Sobel(dev(parent), cv.CV_16S, 1, 0, 3, 1.0, 0.0, border, roi=roi), orc.orc_Sobel(parent, 3, 1, 0, 3, 1.0, 0.0, border, roi=roi))
+            rolled += "k_sep_roll" in _kernel(cv) or "Deriv16" in _kernel(cv)
+            check(cv.Sobel(dev(parent), cv.CV_16S, 1, 1, 5, 1.0, 0.0, border, roi=roi), orc.orc_Sobel(parent, 3, 1, 1, 5, 1.0, 0.0, border, roi=roi))
+            check(cv.sepFilter2D(dev(parent), -1, s3, s3, (-1, -1), 0.0, border, roi=roi), orc.orc_sepFilter2D(parent, -1, s3, s3, (-1, -1), 0.0, border, roi=roi))
+            kx, ky = [0.1, 0.5, 0.2], [0.7, -0.1, 0.2]
+            check(cv.sepFilter2D(dev(parent), -1, kx, ky, (-1, -1), 3.5, border, roi=roi), orc.orc_sepFilter2D(parent, -1, kx, ky, (-1, -1), 3.5, border, roi=roi))
+            check(cv.sepFilter2D(dev(parent), cv.CV_32F, kx, ky, (-1, -1), 3.5, border, roi=roi), orc.orc_sepFilter2D(parent, 5, kx, ky, (-1, -1), 3.5, border, roi=roi), tol=1e-6)
+            check(cv.sepFilter2D(dev(pf), -1, kx, ky, (-1, -1), 0.5, border, roi=roi), orc.orc_sepFilter2D(pf, -1, kx, ky, (-1, -1), 0.5, border, roi=roi), tol=1e-6)
+            g5 = [0.0625, 0.25, 0.375, 0.25, 0.0625]
+            check(cv.sepFilter2D(dev(pf), -1, g5, g5, (-1, -1), 0.0, border, roi=roi), orc.orc_sepFilter2D(pf, -1, g5, g5, (-1, -1), 0.0, border, roi=roi), tol=1e-6)
+            check(cv.boxFilter(dev(parent), -1, (5, 5), (-1, -1), True, border, roi=roi), orc.orc_boxFilter(parent, -1, (5, 5), (-1, -1), True, border, roi=roi))
+            check(cv.boxFilter(dev(pf), -1, (3, 3), (-1, -1), True, border, roi=roi), orc.orc_boxFilter(pf, -1, (3, 3), (-1, -1), True, border, roi=roi), tol=1e-6)
+    assert rolled >= 30, rolled
