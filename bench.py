@@ -52,6 +52,14 @@ def host_cpu():
                 best, llc = lvl, f"L{lvl} {open(os.path.join(base, d, 'size')).read().strip()}"
     except (OSError, ValueError):
         pass
+    if llc is None:                                             # containers often hide /sys/devices/system/cpu/*/cache: ask lscpu
+        try:
+            import subprocess
+            for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+                if line.strip().startswith("L3 cache"):
+                    llc = "L3 " + line.split(":", 1)[1].strip(); break
+        except Exception:
+            pass
     return model, llc
 
 

@@ -70,6 +70,7 @@ typedef unsigned char mi355cv_uchar;
 #define MI355CV_INTER_LANCZOS4 4
 #define MI355CV_INTER_AREA    3
 #define MI355CV_INTER_LINEAR_EXACT 5
+#define MI355CV_INTER_NEAREST_EXACT 6
 #define MI355CV_WARP_INVERSE_MAP 16
 
 /* ------------------------------------------------------------------ runtime */

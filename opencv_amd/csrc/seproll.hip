@@ -87,6 +87,7 @@ void launchSep(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t
         W = roi->fullW; H = roi->fullH;
     }
     const roll::Geom g = roll::geometry(W, H, P::CN, nframes, bestSeg, P::KY, P::CB, 2048, win);
+    noteKernel("k_sep_roll<%s K=%d bpp=%d> blocks=%u seg=%d rows%s", P::name(), P::KY, P::CN, g.blocks, g.seg, roi ? " window of a larger image" : "");
     hipLaunchKernelGGL((k_sep_roll<P>), dim3(g.blocks), dim3(256), 0, st, src, sstep, sframe, dst, dstep, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg,
                        nframes, border, 1, win, a);
 }
@@ -111,6 +112,7 @@ __device__ __forceinline__ uint32_t packB2(uint32_t b0, uint32_t b1, uint32_t b2
 // 16-bit lanes cannot carry into each other); vertical: one v_dot2_u32_u16 per tap and pixel with (ky, 0) / (0, ky) operands.
 template <int K, int CN_>
 struct FixedSmooth {
+    static const char* name() { return "FixedSmooth"; }
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
@@ -167,6 +169,7 @@ struct FixedSmooth {
 // scalar tail, which is the only case this policy is launched for.  Row sums are the packed u16 pairs of FixedSmooth (taps >= 0, sum <= 256).
 template <int K, int CN_>
 struct SepFix8U {
+    static const char* name() { return "SepFix8U"; }
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
@@ -224,6 +227,7 @@ __device__ __forceinline__ uint32_t packB3(uint32_t b0, uint32_t b1, uint32_t b2
 // pixel with 2*ds, so that the quotient lands in byte 3: ((s + dd) * ds) >> 23 == (s * 2ds + 2*dd*ds) >> 24, all < 2^32.
 template <int K, int CN_>
 struct BoxU8 {
+    static const char* name() { return "BoxU8"; }
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
@@ -262,6 +266,7 @@ struct BoxU8 {
 // passes run as packed 16-bit multiply-adds (v_pk_mad_i16 / v_pk_mul_lo_u16) on the byte planes.
 template <int K, int CN_>
 struct Deriv16 {
+    static const char* name() { return "Deriv16"; }
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 2, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;
@@ -307,6 +312,7 @@ struct Deriv16 {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K, int SYM, int OUTB_, int CN_>
 struct SepF32 {
+    static const char* name() { return "SepF32"; }
     static constexpr int KX = K, KY = K, CN = CN_, OUTB = OUTB_, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int CB = OUTB_ == 4 ? 8 : 16;           // 32-bit outputs: 8 elements per lane = 32 contiguous output bytes
@@ -379,6 +385,7 @@ struct SepF32 {
 // SepF32 above (RowFilter filter.simd.hpp:2386: r = k0*v0, r = fma(k_i, v_i, r); SymmColumnFilter :2679-2751 pair forms; ColumnFilter :2640 chain).
 template <int K, int SYM>
 struct SepF32F {
+    static const char* name() { return "SepF32F"; }
     static constexpr int KX = K, KY = K, CN = 4, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = true;
     struct Args { float kx[K], ky[K], delta; };
@@ -424,6 +431,7 @@ struct SepF32F {
 // eleven decimal digits below the float result -- and the result is float(s * scale) with the double scale 1 / (K*K), or float(s) un-normalised.
 template <int K>
 struct BoxF32 {
+    static const char* name() { return "BoxF32"; }
     static constexpr int KX = K, KY = K, CN = 4, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = true;
     struct Args { double scale; int normalize; };
@@ -460,6 +468,7 @@ struct BoxF32 {
 // border (255) is the same zero halo.  Max of packed 16-bit pairs: v_pk_max_u16 on the byte planes.
 template <int K, int CN_>
 struct MorphMax {
+    static const char* name() { return "MorphMax"; }
     static constexpr int KX = K, KY = K, CN = CN_, CB = 16, OUTB = 1, R = K / 2;
     static constexpr bool RAWX = false;
     static constexpr int HD = roll::Cfg<R, CN>::HD;

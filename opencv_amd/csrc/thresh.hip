@@ -12,22 +12,38 @@ namespace {
 
 enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
 
-template <typename T> __device__ __forceinline__ T threshOne(T v, T t, T m, int type)
+template <typename T, int TYPE> __device__ __forceinline__ T threshOne(T v, T t, T m)
 {
     const bool gt = v > t;
-    switch (type) {
-    case 0: return gt ? m : (T)0;
-    case 1: return gt ? (T)0 : m;
-    case 2: return gt ? t : v;
-    case 3: return gt ? v : (T)0;
-    default: return gt ? (T)0 : v;
-    }
+    if (TYPE == 0) return gt ? m : (T)0;
+    if (TYPE == 1) return gt ? (T)0 : m;
+    if (TYPE == 2) return gt ? t : v;
+    if (TYPE == 3) return gt ? v : (T)0;
+    return gt ? (T)0 : v;
 }
 
-// a thread owns 16 bytes of a row when the geometry allows (one dwordx4 load / non-temporal store), single elements otherwise
-template <typename T>
+// four 8-bit pixels of a dword at once: G = 0xff in every byte whose pixel is > t (unsigned compare on the two 16-bit planes: saturating subtract,
+// min with 1, times 0xff), then the five types are one bit-select each: dst = (G & A) | (~G & B)
+template <int TYPE> __device__ __forceinline__ uint32_t thresh4(uint32_t v, uint32_t t16 /* t in both 16-bit lanes */, uint32_t m4, uint32_t t4)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = {1, 1}, ff = {255, 255}, tt = __builtin_bit_cast(u16x2, t16);
+    const u16x2 e = __builtin_bit_cast(u16x2, v & 0x00ff00ffu), o = __builtin_bit_cast(u16x2, (v >> 8) & 0x00ff00ffu);
+    const u16x2 ge = __builtin_elementwise_min(__builtin_elementwise_sub_sat(e, tt), one) * ff;
+    const u16x2 go = __builtin_elementwise_min(__builtin_elementwise_sub_sat(o, tt), one) * ff;
+    const uint32_t G = __builtin_bit_cast(uint32_t, ge) | (__builtin_bit_cast(uint32_t, go) << 8);
+    if (TYPE == 0) return G & m4;
+    if (TYPE == 1) return ~G & m4;
+    if (TYPE == 2) return (G & t4) | (~G & v);
+    if (TYPE == 3) return G & v;
+    return ~G & v;
+}
+
+// a thread owns 16 bytes of a row when the geometry allows (one dwordx4 load / non-temporal store), single elements otherwise; the threshold type is
+// a template parameter (a run-time switch per element made this a branch-bound kernel: 56 % of HBM where a copy reaches 79 %)
+template <typename T, int TYPE>
 __global__ __launch_bounds__(256) void k_threshold(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-                                                   int n /* elements per row */, int h, T t, T m, int type, int vec)
+                                                   int n /* elements per row */, int h, T t, T m, int vec)
 {
     constexpr int EPV = 16 / sizeof(T);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -40,12 +56,18 @@ __global__ __launch_bounds__(256) void k_threshold(const uchar* __restrict__ src
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         union { u32x4 q; T e[EPV]; } a;
         a.q = *reinterpret_cast<const u32x4*>(s + (size_t)i * EPV);
+        if constexpr (sizeof(T) == 1) {
+            const uint32_t t16 = (uint32_t)t * 0x00010001u, m4 = (uint32_t)m * 0x01010101u, t4 = (uint32_t)t * 0x01010101u;
 #pragma unroll
-        for (int k = 0; k < EPV; k++) a.e[k] = threshOne<T>(a.e[k], t, m, type);
+            for (int k = 0; k < 4; k++) a.q[k] = thresh4<TYPE>(a.q[k], t16, m4, t4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPV; k++) a.e[k] = threshOne<T, TYPE>(a.e[k], t, m);
+        }
         __builtin_nontemporal_store(a.q, reinterpret_cast<u32x4*>(d + (size_t)i * EPV));
     } else {
 #pragma unroll 4
-        for (int k = 0; k < EPV; k++) { const int x = i + k * (gridDim.x * 64); if (x < n) d[x] = threshOne<T>(s[x], t, m, type); }
+        for (int k = 0; k < EPV; k++) { const int x = i + k * (gridDim.x * 64); if (x < n) d[x] = threshOne<T, TYPE>(s[x], t, m); }
     }
 }
 
@@ -181,12 +203,16 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     const int perRow = vec ? n / epv : divUp(n, epv);
     dim3 grid(divUp(perRow, 64), divUp(height, 4));
     hipStream_t st = stream();
+#define TH(T_, TY_) hipLaunchKernelGGL((k_threshold<T_, TY_>), grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (T_)thresh, (T_)maxValue, vec)
+#define THT(T_) do { switch (thresholdType) { case 0: TH(T_, 0); break; case 1: TH(T_, 1); break; case 2: TH(T_, 2); break; case 3: TH(T_, 3); break; default: TH(T_, 4); } } while (0)
     switch (depth) {
-    case D8U:  hipLaunchKernelGGL(k_threshold<uchar>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (uchar)thresh, (uchar)maxValue, thresholdType, vec); break;
-    case D16U: hipLaunchKernelGGL(k_threshold<unsigned short>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (unsigned short)thresh, (unsigned short)maxValue, thresholdType, vec); break;
-    case D16S: hipLaunchKernelGGL(k_threshold<short>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (short)thresh, (short)maxValue, thresholdType, vec); break;
-    default:   hipLaunchKernelGGL(k_threshold<float>, grid, dim3(256), 0, st, ds, dss, dd, dds, n, height, (float)thresh, (float)maxValue, thresholdType, vec); break;
+    case D8U:  THT(uchar); break;
+    case D16U: THT(unsigned short); break;
+    case D16S: THT(short); break;
+    default:   THT(float); break;
     }
+#undef THT
+#undef TH
     return stg.finish("threshold");
 }
 

@@ -58,6 +58,7 @@ __device__ __forceinline__ void copyPix(uchar* d, const uchar* s, int bytes) { f
 
 // ---------------------------------------------------------------------------------- resize
 struct ResizeArgs { int sw, sh, dw, dh, depth, cn; double scale_x, scale_y, inv_x, inv_y; int mode /*0 nn,1 linear,2 area-as-linear,3 areafast*/; int isx, isy;
+                    int nnExact, ifx, ifx0, ify, ify0;   /* INTER_NEAREST_EXACT: 16.16 steps and half-pixel offsets of resizeNN_bitexact (resize.cpp:1267-1289) */
                     size_t sframe, dframe; /* bytes between the frames of a batch (grid z = frame) */ };
 
 __device__ __forceinline__ void linCoef(int d, double scale, double inv, int areaMode, int& s, float& f)
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, s
     const int e = eszOf(a.depth), cn = a.cn;
     uchar* D = dst + (size_t)dy * dstep;
     if (a.mode == 0) {
-        int sy = cvFloorD(dy * a.scale_y); sy = sy > a.sh - 1 ? a.sh - 1 : sy;
-        int sx = cvFloorD(dx * a.scale_x); sx = sx > a.sw - 1 ? a.sw - 1 : sx;
+        int sy = a.nnExact ? (a.ify * dy + a.ify0) >> 16 : cvFloorD(dy * a.scale_y); sy = sy > a.sh - 1 ? a.sh - 1 : sy;
+        int sx = a.nnExact ? (a.ifx * dx + a.ifx0) >> 16 : cvFloorD(dx * a.scale_x); sx = sx > a.sw - 1 ? a.sw - 1 : sx;
         copyPix(D + (size_t)dx * cn * e, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e);
         return;
     }
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 // ---- CV_8U bilinear warpAffine / warpPerspective through an LDS tile (warp8.h has the why and every phase; this is the launch geometry) ------------------
 // A workgroup walks TPW horizontally adjacent 128 x th tiles (the 8 KB weight table it keeps in LDS is loaded once for all of them); per tile: box terms by
 // the first lanes -> barrier -> the source box into LDS + row / column terms -> barrier -> 16 (th = 32) or 8 destination pixels per thread.
-template <int CN, int KIND>
+template <int CN, int KIND, int FETCH>
 __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tab, int tpw)
 {
     extern __shared__ __align__(16) uchar w8lds[];
@@ -1199,23 +1200,17 @@ __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ sr
         if (t == 0) warp8::phaseA<KIND>(a, x0, y0, tab, w8lds, tid);
         else { __syncthreads(); if (tid < (KIND == 0 ? 8 : 4)) warp8::boxTerm<KIND>(a, x0, y0, tid, reinterpret_cast<int*>(w8lds + warp8::OFF_TERMS)); }
         __syncthreads();
-        const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS));
+        int terms[12];                                                                   // wave-uniform: the box arithmetic runs on the scalar unit
+#pragma unroll
+        for (int k = 0; k < (KIND == 0 ? 8 : 12); k++) terms[k] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS)[k]);
+        const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, terms);
         warp8::phaseB<CN, KIND>(a, b, x0, y0, src, w8lds, tid);
         __syncthreads();
-        const unsigned redo = warp8::phaseC<CN, KIND>(a, b, x0, y0, w8lds, dst, tid);
+        const unsigned redo = warp8::phaseC<CN, KIND, FETCH>(a, b, x0, y0, w8lds, dst, tid);
         if (redo) {
-            // pixels outside the tile's box: wholly outside the source under BORDER_CONSTANT is the common case (a rotated frame's corners) -- the border
-            // value, no sampling; everything else (partial footprints, the other border rules, BORDER_TRANSPARENT) is the generic sampler's
-            uint32_t cv = 0;
-#pragma unroll
-            for (int c = 0; c < CN; c++) cv |= (uint32_t)fminf(fmaxf(rintf(s.cval[c]), 0.f), 255.f) << (8 * c);
+            // what the tile path left: partial footprints on the source's rim, the border rules other than CONSTANT, BORDER_TRANSPARENT -- the generic sampler's
             warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, w8lds, tid, [&](int x, int y, int X, int Y) {
-                const int sx = X >> 5, sy = Y >> 5;
-                uchar* D = dst + (size_t)y * a.dstep + (size_t)x * CN;
-                if (s.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) {
-#pragma unroll
-                    for (int c = 0; c < CN; c++) D[c] = (uchar)(cv >> (8 * c));
-                } else samplePixel(src, a.sstep, D, s, satShort(sx), satShort(sy), X & 31, Y & 31, tab);
+                samplePixel(src, a.sstep, dst + (size_t)y * a.dstep + (size_t)x * CN, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
             });
         }
     }
@@ -1288,13 +1283,16 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         warp8::Args a8; size_t lds8 = 0;
         if (depth == D8U && warp8On && warp8::plan(a8, cn, kind, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8)) {
             a8.sframe = w.sframe; a8.dframe = w.dframe;
-            const int tpw = 4;
+            a8.constBorder = borderType == B_CONSTANT;
+            for (int k = 0; k < cn; k++) a8.cval |= (uint32_t)fminf(fmaxf(rintf(s.cval[k]), 0.f), 255.f) << (8 * k);
+            static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 4; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 0; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
-#define W8(CN_, K_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
-            if (kind == 0) { if (cn == 1) W8(1, 0); else if (cn == 3) W8(3, 0); else W8(4, 0); }
-            else           { if (cn == 1) W8(1, 1); else if (cn == 3) W8(3, 1); else W8(4, 1); }
+#define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
+            if (kind == 0) { if (cn == 1) { if (fetch) W8(1, 0, 1); else W8(1, 0, 0); } else if (cn == 3) W8(3, 0, 0); else W8(4, 0, 0); }
+            else           { if (cn == 1) { if (fetch) W8(1, 1, 1); else W8(1, 1, 0); } else if (cn == 3) W8(3, 1, 0); else W8(4, 1, 0); }
 #undef W8
-            noteKernel("k_warp8_tile<%d,%d> grid=%ux%ux%u x256 lds=%zu box<=%dx%d", cn, kind, g8.x, g8.y, g8.z, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+            noteKernel("k_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, kind, cn == 1 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
             return stg.finish(entry);
         }
         // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean
@@ -1335,7 +1333,13 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     a.isx = (int)nearbyint(a.scale_x); a.isy = (int)nearbyint(a.scale_y);
     const bool areaFast = std::fabs(a.scale_x - a.isx) < 2.220446049250313e-16 && std::fabs(a.scale_y - a.isy) < 2.220446049250313e-16;
     if (interpolation == MI355CV_INTER_NEAREST) a.mode = 0;
-    else {
+    else if (interpolation == MI355CV_INTER_NEAREST_EXACT) {
+        // resizeNN_bitexact (resize.cpp:1267-1289): source pixel = (ifx * x + ifx0) >> 16 in int arithmetic, steps rounded to 16.16, pixel centres aligned
+        if (src_width >= 32768 || src_height >= 32768) return MI355CV_NOT_IMPLEMENTED;          // (size << 16) must stay an int, as in the reference
+        a.mode = 0; a.nnExact = 1;
+        a.ifx = ((src_width << 16) + dst_width / 2) / dst_width; a.ifx0 = a.ifx / 2 - src_width % 2;
+        a.ify = ((src_height << 16) + dst_height / 2) / dst_height; a.ify0 = a.ify / 2 - src_height % 2;
+    } else {
         if (interpolation == MI355CV_INTER_LINEAR && areaFast && a.isx == 2 && a.isy == 2) interpolation = MI355CV_INTER_AREA;   // :4011
         if (interpolation == MI355CV_INTER_AREA && a.scale_x >= 1 && a.scale_y >= 1) {
             a.mode = areaFast ? 3 : 4;                                                       // 4: true area (resizeArea_)
@@ -1347,7 +1351,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         }
         else if (interpolation == 2 /*INTER_CUBIC*/) a.mode = 5;
         else if (interpolation == 4 /*INTER_LANCZOS4*/) a.mode = 6;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // NEAREST_EXACT, LINEAR_EXACT on other depths
+        else return MI355CV_NOT_IMPLEMENTED;                                                // LINEAR_EXACT on other depths
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;

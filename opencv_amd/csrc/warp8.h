@@ -39,6 +39,8 @@ struct Args {
     int bw0;                     // WarpPerspectiveInvoker's block width (the x the projective terms restart from)
     int gx, gy;
     unsigned long long sframe, dframe;
+    int constBorder;             // BORDER_CONSTANT: a pixel whose whole 2x2 footprint is outside the source is the border value, no sampling
+    uint32_t cval;               // the border value's channels as bytes (saturate_cast<uchar> of the cv::Scalar)
 };
 
 W8_HD int satIntD(double v)
@@ -88,10 +90,19 @@ W8_HD uint32_t ld16(const unsigned char* p)
     typedef unsigned short u16u __attribute__((aligned(1)));
     return *reinterpret_cast<const u16u*>(p);
 }
-W8_HD unsigned long long ld64(const unsigned char* p)
+W8_HD uint32_t ld32(const unsigned char* p)
 {
-    typedef unsigned long long u64u __attribute__((aligned(1)));
-    return *reinterpret_cast<const u64u*>(p);
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    return *reinterpret_cast<const u32u*>(p);
+}
+// ({hi, lo} >> 8 * sh) & 0xffffffff, sh in 0..3
+W8_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
+#endif
 }
 
 // affine coordinate terms (WarpAffineInvoker imgwarp.cpp:2252-2262 with hal::warpAffineBlocklineNN's adelta / bdelta :2699-2713): 1/1024 px, round delta 16
@@ -146,7 +157,7 @@ W8_HD void boxTerm(const Args& a, int x0, int y0, int k, int* terms)
 template <int CN, int KIND>
 W8_HD Box boxFromTerms(const Args& a, const int* t)
 {
-    Box b = {0, 0, 0, 0, 0, 0};
+    Box b = {0, 0, 0, 0, 0, 0};                                       // (perspective early-outs below: cw = ch = 0, the generic sampler takes the tile)
     int bx0, bx1, by0, by1, exact = 1;
     if (KIND == 0) {
         // X5(x, y) = (rowX(y) + colX(x)) >> 5 with rowX, colX monotone (a rounded linear function each): the extremes are sums of the terms' extremes
@@ -170,7 +181,10 @@ W8_HD Box boxFromTerms(const Args& a, const int* t)
     const int ex = bx1 > a.sw - 1 ? a.sw - 1 : bx1, ey = by1 > a.sh - 1 ? a.sh - 1 : by1;
     b.cw = ex - b.cx0 + 1; b.ch = ey - b.cy0 + 1;
     b.shift = (b.cx0 * CN) & 3;
-    if (b.cw < 2 || b.ch < 2 || b.ch > a.ldsRows || ((b.shift + b.cw * CN + 3) & ~3) + 8 > a.ldsPitch) { b.cw = 0; b.ch = 0; b.all = 0; return b; }
+    // less than a 2x2 footprint of the source under the box: nothing to stage, but every pixel can still be classified (ch = -1 marks this case: with
+    // BORDER_CONSTANT the tile is mostly border value); a box beyond the LDS allotment: the generic sampler takes the whole tile (cw = ch = 0)
+    if (b.cw < 2 || b.ch < 2) { b.cw = 0; b.ch = -1; b.shift = 0; b.all = 0; return b; }
+    if (b.ch > a.ldsRows || ((b.shift + b.cw * CN + 3) & ~3) + 8 > a.ldsPitch) { b.cw = 0; b.ch = 0; b.all = 0; return b; }
     b.all = exact && bx0 >= 0 && by0 >= 0 && bx1 <= a.sw - 1 && by1 <= a.sh - 1;
     return b;
 }
@@ -183,15 +197,15 @@ W8_HD void stage(const Args& a, const Box& b, int cn, const unsigned char* src, 
     if (b.cw == 0) return;
     const uint32_t nd = (uint32_t)(b.shift + b.cw * cn + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;       // dwords per row to load / per LDS row
     const uint32_t total = pd * (uint32_t)b.ch;
-    const unsigned char* base = src + (size_t)b.cy0 * a.sstep + (((size_t)b.cx0 * cn) & ~(size_t)3);
-    const unsigned char* last = src + (size_t)(a.sh - 1) * a.sstep + (size_t)a.sw * cn;                 // one past the image's last pixel byte
+    const uint32_t base = (uint32_t)b.cy0 * a.sstep + (((uint32_t)b.cx0 * (uint32_t)cn) & ~3u);          // both images are below 4 GB (host check)
+    const uint32_t last = (uint32_t)(a.sh - 1) * a.sstep + (uint32_t)a.sw * (uint32_t)cn;                // one past the image's last pixel byte
     for (uint32_t i = (uint32_t)tid; i < total; i += 256) {
         const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
         if (c >= nd) continue;
-        const unsigned char* g = base + (size_t)r * a.sstep + 4 * (size_t)c;
+        const uint32_t go = base + r * a.sstep + 4 * c;
         uint32_t v;
-        if (g + 4 <= last) v = *reinterpret_cast<const uint32_t*>(g);
-        else { v = 0; for (int k = 0; k < 4; k++) if (g + k < last) v |= (uint32_t)g[k] << (8 * k); }
+        if (go + 4 <= last) v = *reinterpret_cast<const uint32_t*>(src + go);
+        else { v = 0; for (uint32_t k = 0; k < 4; k++) if (go + k < last) v |= (uint32_t)src[go + k] << (8 * k); }
         reinterpret_cast<uint32_t*>(tile)[i] = v;
     }
 }
@@ -204,22 +218,37 @@ W8_HD void splitWeights(uint32_t s01, uint32_t s23, uint32_t& hi, uint32_t& lo)
 }
 
 // one destination pixel from the LDS tile: `p` points at its upper-left tap, (wh, wl) are the byte-split Q15 weights.  Returns CN bytes in the low bits.
-template <int CN>
+// LDS reads wider than a dword must sit on their natural alignment (a misaligned ds_read_b64 is replayed at 64 cycles per wave instruction), so taps are
+// fetched as dwords: FETCH 0 = unaligned 16- / 32-bit reads at the tap's own address; FETCH 1 (one channel) = the two ALIGNED dwords around it + a byte
+// funnel shift.
+template <int CN, int FETCH>
 W8_HD uint32_t bilinearAt(const unsigned char* p, uint32_t pitch, uint32_t wh, uint32_t wl)
 {
     if (CN == 1) {
-        const uint32_t t = ld16(p) | (ld16(p + pitch) << 16);                     // [p00 p01 p10 p11]
+        uint32_t t;
+        if (FETCH == 0) t = ld16(p) | (ld16(p + pitch) << 16);                        // [p00 p01 p10 p11]
+        else {
+            const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p - sh + pitch);    // pitch is a multiple of 4: same shift on the next row
+            const uint32_t r0 = alignbyte(q[1], q[0], sh), r1 = alignbyte(q1[1], q1[0], sh);
+            t = (r0 & 0xffffu) | (r1 << 16);
+        }
         const uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
         return r > 255 ? 255 : r;
     }
-    const unsigned long long q0 = ld64(p), q1 = ld64(p + pitch);                // CN * 2 bytes of each row are taps, the rest is slack
+    // CN * 2 bytes of each row are taps: 6 (an unaligned dword + a halfword) or 8 (two dwords, 4-byte aligned: a pixel is a dword)
+    uint32_t a0, a1, b0, b1;
+    if (CN == 3) { a0 = ld32(p); a1 = ld16(p + 4); b0 = ld32(p + pitch); b1 = ld16(p + pitch + 4); }
+    else { const uint32_t* q = reinterpret_cast<const uint32_t*>(p); const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p + pitch); a0 = q[0]; a1 = q[1]; b0 = q1[0]; b1 = q1[1]; }
+    const unsigned long long q0 = a0 | ((unsigned long long)a1 << 32), q1v = b0 | ((unsigned long long)b1 << 32);
     uint32_t out = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int c = 0; c < CN; c++) {
         const uint32_t t = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q0 >> (8 * (CN + c))) & 255) << 8) |
-                           ((uint32_t)((q1 >> (8 * c)) & 255) << 16) | ((uint32_t)((q1 >> (8 * (CN + c))) & 255) << 24);
+                           ((uint32_t)((q1v >> (8 * c)) & 255) << 16) | ((uint32_t)((q1v >> (8 * (CN + c))) & 255) << 24);
         uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
         r = r > 255 ? 255 : r;
         out |= r << (8 * c);
@@ -267,7 +296,7 @@ W8_HD uint32_t mad24(uint32_t x, uint32_t y, uint32_t z)
 #endif
 }
 
-template <int CN, int KIND, bool ALL>
+template <int CN, int KIND, bool ALL, int FETCH>
 W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, unsigned char* dst, int tid)
 {
     const uint32_t* wt = reinterpret_cast<const uint32_t*>(lds);
@@ -279,7 +308,7 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
     const bool fullLane = x + PX <= a.dw;
     int cX[PX], cY[PX];
     if (KIND == 0) for (int p = 0; p < PX; p++) { cX[p] = col[lx * PX + p]; cY[p] = col[TW + lx * PX + p]; }
-    const uint32_t pitch = (uint32_t)a.ldsPitch, cwm = (uint32_t)(b.cw - 1), chm = (uint32_t)(b.ch - 1);
+    const uint32_t pitch = (uint32_t)a.ldsPitch, cwm = b.cw > 0 ? (uint32_t)(b.cw - 1) : 0u, chm = b.ch > 0 ? (uint32_t)(b.ch - 1) : 0u;
     unsigned redo = 0;
     constexpr int NSTEPS = tileRows<CN>() / ROWS_PER_STEP;
 #if defined(__HIPCC__)
@@ -303,12 +332,18 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
                 rx = (X >> 5) - b.cx0; ry = (Y >> 5) - b.cy0; ax = X & 31; ay = Y & 31;
             }
             uint32_t off = mad24((uint32_t)ry, pitch, (uint32_t)(rx * CN + b.shift));
+            bool out = false;
             if (!ALL) {
+                // inside the staged box: sampled; the whole 2x2 footprint outside the source under BORDER_CONSTANT: the border value; the rest (partial
+                // footprints on the source's rim, the other border rules) leaves the group to the generic sampler
                 const bool in = (uint32_t)rx < cwm && (uint32_t)ry < chm;
-                off = in ? off : 0u; ok = ok && in;
+                const int sx = rx + b.cx0, sy = ry + b.cy0;
+                out = a.constBorder && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0);
+                off = in ? off : 0u; ok = ok && (in || out);
             }
             const uint32_t* w = wt + 2 * (ay * 32 + ax);
-            px[p] = bilinearAt<CN>(tile + off, pitch, w[0], w[1]);
+            px[p] = bilinearAt<CN, FETCH>(tile + off, pitch, w[0], w[1]);
+            if (!ALL) px[p] = out ? a.cval : px[p];
         }
         if (y < a.dh) {
             if (ok) {
@@ -323,14 +358,14 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
     return redo;
 }
 
-template <int CN, int KIND>
+template <int CN, int KIND, int FETCH = 0>
 W8_HD unsigned phaseC(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, unsigned char* dst, int tid)
 {
-    if (b.cw == 0) {                                                  // nothing staged (box too large for the LDS allotment, or wholly outside): every group is redone
+    if (b.cw == 0 && !(a.constBorder && b.ch == -1)) {                // nothing staged (box too large for the LDS allotment): every group is redone
         const int lane = tid & 63, x = x0 + (lane & (LX - 1)) * PX;
         return x < a.dw ? (1u << (tileRows<CN>() / ROWS_PER_STEP)) - 1 : 0;
     }
-    return b.all ? rowsC<CN, KIND, true>(a, b, x0, y0, lds, dst, tid) : rowsC<CN, KIND, false>(a, b, x0, y0, lds, dst, tid);
+    return b.all ? rowsC<CN, KIND, true, FETCH>(a, b, x0, y0, lds, dst, tid) : rowsC<CN, KIND, false, FETCH>(a, b, x0, y0, lds, dst, tid);
 }
 
 // the groups phaseC left: slow(x, y, X, Y) for every destination pixel of them, (X, Y) = its source coordinates in 1/32 px (affine: from the row / column

@@ -337,6 +337,18 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
         }
         return 0;
     }
+    if (interpolation == 6) {                                   /* INTER_NEAREST_EXACT: resizeNN_bitexact resize.cpp:1174-1289, 16.16 fixed point, pixel centres */
+        const int ifx = ((sw << 16) + dw / 2) / dw, ifx0 = ifx / 2 - sw % 2;
+        const int ify = ((sh << 16) + dh / 2) / dh, ify0 = ify / 2 - sh % 2;
+        for (int y = 0; y < dh; y++) {
+            int sy = (ify * y + ify0) >> 16; if (sy > sh - 1) sy = sh - 1;
+            for (int x = 0; x < dw; x++) {
+                int sx = (ifx * x + ifx0) >> 16; if (sx > sw - 1) sx = sw - 1;
+                memcpy(dst + (size_t)y * dstep + (size_t)x * cn * e, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e);
+            }
+        }
+        return 0;
+    }
     if (interpolation == 5) {                                   /* INTER_LINEAR_EXACT, resize.cpp:3976-3990 */
         if (is_area_fast && iscale_x == 2 && iscale_y == 2 && cn != 2) interpolation = 3;
         else return resizeLinearExact(src, sstep, sw, sh, dst, dstep, dw, dh, depth, cn, inv_scale_x, inv_scale_y);

@@ -7,7 +7,7 @@
 #include <vector>
 #include "warp8.h"
 
-template <int CN, int KIND>
+template <int CN, int KIND, int FETCH>
 static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, const short* tab, const unsigned char* expect, size_t estep, long long* stats)
 {
     std::vector<unsigned char> lds(ldsBytes + 64);
@@ -20,7 +20,7 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
             for (int tid = 0; tid < 256; tid++) warp8::phaseB<CN, KIND>(a, b, x0, y0, src, lds.data(), tid);
             stats[2] += b.all; stats[3] += b.cw == 0;
             for (int tid = 0; tid < 256; tid++) {
-                const unsigned redo = warp8::phaseC<CN, KIND>(a, b, x0, y0, lds.data(), dst, tid);
+                const unsigned redo = warp8::phaseC<CN, KIND, FETCH>(a, b, x0, y0, lds.data(), dst, tid);
                 warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, lds.data(), tid, [&](int x, int y, int X, int Y) {
                     // the coordinates handed to the generic sampler must be the pixel's own (checked against a direct evaluation)
                     int Xr, Yr;
@@ -37,14 +37,17 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
 
 // stats: [0] pixels produced from the LDS tile, [1] pixels left to the generic sampler, [2] tiles with an exact all-inside box, [3] tiles with nothing staged
 extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, int kind, const double* M,
-                         const short* tab, const unsigned char* expect, size_t estep, long long* stats)
+                         const short* tab, const unsigned char* expect, size_t estep, long long* stats, int constBorder, unsigned cval, int fetch)
 {
     warp8::Args a; size_t ldsBytes = 0;
     int bh0 = dh < 16 ? dh : 16;
     const int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
     if (!warp8::plan(a, cn, kind, M, sw, sh, dw, dh, sstep, dstep, src, dst, bw0, &ldsBytes)) return 1;
+    a.constBorder = constBorder; a.cval = cval;
     stats[0] = stats[1] = stats[2] = stats[3] = 0;
-    if (kind == 0) { if (cn == 1) run<1, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); else if (cn == 3) run<3, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); else run<4, 0>(a, ldsBytes, src, dst, tab, expect, estep, stats); }
-    else           { if (cn == 1) run<1, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); else if (cn == 3) run<3, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); else run<4, 1>(a, ldsBytes, src, dst, tab, expect, estep, stats); }
+#define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
+    if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) RUN(3, 0, 0); else RUN(4, 0, 0); }
+    else           { if (cn == 1) { if (fetch) RUN(1, 1, 1); else RUN(1, 1, 0); } else if (cn == 3) RUN(3, 1, 0); else RUN(4, 1, 0); }
+#undef RUN
     return 0;
 }

@@ -62,17 +62,18 @@ def _rot(cx, cy, deg, scale):
     return np.ascontiguousarray(np.linalg.inv(m)[:2])
 
 
-def _emu_warp(emu8, src, M, dsize, kind):
+def _emu_warp(emu8, src, M, dsize, kind, border=0, bval=(0, 0, 0, 0), fetch=0):
     orc = o.oracle()
     orc.orc_bilinearTabI.restype = ctypes.c_void_p
     tab = ctypes.c_void_p(orc.orc_bilinearTabI())
     M = np.ascontiguousarray(M, np.float64)
-    want = (o.orc_warpAffine if kind == 0 else o.orc_warpPerspective)(src, M, dsize, 1, 0, 0.0)
+    want = (o.orc_warpAffine if kind == 0 else o.orc_warpPerspective)(src, M, dsize, 1, border, bval)
     got = np.full_like(want, 0x5A)
     stats = (ctypes.c_longlong * 4)()
     cn = 1 if src.ndim == 2 else src.shape[2]
     rc = emu8.emu_warp8(o.P(src), o.step(src), src.shape[1], src.shape[0], o.P(got), o.step(got), dsize[0], dsize[1], cn, kind,
-                        o.P(M), tab, o.P(want), o.step(want), stats)
+                        o.P(M), tab, o.P(want), o.step(want), stats, int(border == 0),
+                        sum(int(min(max(round(bval[c]), 0), 255)) << (8 * c) for c in range(cn)), fetch)
     return rc, got, want, list(stats)
 
 
@@ -88,11 +89,12 @@ def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
         M = _rot(sw / 2.0, sh / 2.0, deg, sc)
         if (dw, dh) != (sw, sh):
             M = M.copy(); M[:, :2] *= sw / dw                                   # dst pixel -> src pixel of a resized canvas
-        rc, got, want, st = _emu_warp(emu8, src, M, (dw, dh), 0)
-        if rc != 0:
-            continue                                                           # the plan declined (box too large for LDS): the old kernel serves it
-        assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, int(np.count_nonzero(got != want)))
-        assert st[0] > 0.5 * dw * dh, (cn, deg, st)                            # most pixels come from the tile path
+        for border, bval, fetch in [(0, (0, 0, 0, 0), 0), (0, (17.4, 200, 3, 255), 1), (1, (0, 0, 0, 0), 0), (4, (0, 0, 0, 0), 1)]:
+            rc, got, want, st = _emu_warp(emu8, src, M, (dw, dh), 0, border, bval, fetch)
+            if rc != 0:
+                continue                                                       # the plan declined (box too large for LDS): the old kernel serves it
+            assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, border, fetch, int(np.count_nonzero(got != want)))
+            assert st[0] > (0.97 if border == 0 else 0.5) * dw * dh, (cn, deg, border, st)   # BORDER_CONSTANT: only the source's rim is left to the sampler
 
 
 @pytest.mark.parametrize("cn", [1, 3, 4])

@@ -237,12 +237,13 @@ def run(quick=False, parity=True):
     bline("a8 warpAffine 4K 8UC3 rot 7deg batch", lambda: cv.warpAffineBatch(bgr[:B3C], Mb, (W4, H4), dst=c3d), PIX4 * 6, B3C)
     bline("a9 warpPerspective 4K 8UC3 batch", lambda: cv.warpPerspectiveBatch(bgr[:B3C], P3, (W4, H4), dst=c3d), PIX4 * 6, B3C)
     # bilinear / cubic 2x upscales 1080p 8UC3 -> 4K 8UC3 (the 1080p sources are the top-left quarter of each colour frame: distinct memory per frame)
-    hdsrc = torch.empty((B3C, 1080, 1920, 3), dtype=torch.uint8, device=dev)
-    hdsrc.copy_(bgr[:B3C, :1080, :1920])
-    bline("a7 resize 1080p 8UC3 -> 4K bilinear batch", lambda: cv.resizeBatch(hdsrc, (W4, H4), dst=c3d), PIX4 * 3 + PIX4 * 3 // 4, B3C)
-    ms = timeit(per_frame(lambda i: cv.resize(hdsrc[i % B3C], (W4, H4), interpolation=2, dst=c3d[i % B3C])), max(2, N // 4), 1)
-    hbm_row("a7 resize 1080p 8UC3 -> 4K INTER_CUBIC (one call per frame)", B2, ms, B2 * (PIX4 * 3 + PIX4 * 3 // 4), {"kind": "per-frame calls"})
-    del hdsrc
+    BU = frames_for(PIX4 * 3 + PIX4 * 3 // 4, 8)                  # 72 frames: 31 MB per frame
+    hdsrc = torch.randint(0, 256, (BU, 1080, 1920, 3), dtype=torch.uint8, device=dev, generator=g)
+    upd = torch.empty((BU, H4, W4, 3), dtype=torch.uint8, device=dev)
+    bline("a7 resize 1080p 8UC3 -> 4K bilinear batch", lambda: cv.resizeBatch(hdsrc, (W4, H4), dst=upd), PIX4 * 3 + PIX4 * 3 // 4, BU)
+    ms = timeit(lambda: [cv.resize(hdsrc[i], (W4, H4), interpolation=2, dst=upd[i]) for i in range(BU)], max(2, N // 4), 1)
+    hbm_row("a7 resize 1080p 8UC3 -> 4K INTER_CUBIC (one call per frame)", BU, ms, BU * (PIX4 * 3 + PIX4 * 3 // 4), {"kind": "per-frame calls"})
+    del hdsrc, upd
 
     # ---- the other hooks on single 4K frames, one call per frame of the resident batch (call latency included)
     d16 = torch.empty((B2, H4, W4), dtype=torch.int16, device=dev)

@@ -34,11 +34,14 @@ W, H = 3840, 2160
 sections = sys.argv[1:] or ["warp8", "f32", "roi"]
 
 if "warp8" in sections:
-    print(f"== warp8 (MI355CV_WARP8={os.environ.get('MI355CV_WARP8', 'unset')})", flush=True)
+    print(f"== warp8 (MI355CV_WARP8={os.environ.get('MI355CV_WARP8', 'unset')} FETCH={os.environ.get('MI355CV_WARP8_FETCH', '0')} TPW={os.environ.get('MI355CV_WARP8_TPW', '4')})", flush=True)
     P = np.array([[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]])
     cases = [("rot 7deg x0.95", cv.getRotationMatrix2D((1920.0, 1080.0), 7.0, 0.95)), ("rot 33deg x1.3", cv.getRotationMatrix2D((1920.0, 1080.0), 33.0, 1.3)),
              ("rot 90deg", cv.getRotationMatrix2D((1920.0, 1080.0), 90.0, 1.0)), ("shift", np.array([[1, 0, 3.25], [0, 1, -2.5]], np.float64))]
+    cns = [int(c) for c in os.environ.get("PROBE_CN", "1,3,4").split(",")]
     for cn, B in ((1, 144), (3, 48), (4, 40)):
+        if cn not in cns:
+            continue
         shp = (B, H, W) if cn == 1 else (B, H, W, cn)
         s8 = torch.randint(0, 256, shp, dtype=torch.uint8, device="cuda", generator=g); d8 = torch.empty_like(s8)
         by = 2 * s8.numel()
