@@ -258,7 +258,8 @@ MI355CV_API int mi355cv_remap(int src_type, const mi355cv_uchar* src_data, size_
 /* cv::convertMaps (imgwarp.cpp:1925): float maps <-> CV_16SC2 (+ CV_16UC1), bit-exact with the reference's rounding */
 MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1_type, const void* map2, size_t map2_step, int map2_type,
         void* dstmap1, size_t dstmap1_step, int dstmap1_type, void* dstmap2, size_t dstmap2_step, int width, int height, int nninterpolate);
-/* cv::warpPolar, forward direction (imgwarp.cpp:3731): map evaluation fused into the sampling kernel; WARP_INVERSE_MAP declines */
+/* cv::warpPolar (imgwarp.cpp:3731-3845), both directions: the map is evaluated inside the sampling kernel -- forward from the per-row cos / sin and
+ * per-column radii, WARP_INVERSE_MAP from the reference's float approximations of cartToPolar and log (source with one wrapped row above and below) */
 MI355CV_API int mi355cv_warpPolar(int src_type, const mi355cv_uchar* src_data, size_t src_step, int src_width, int src_height,
         mi355cv_uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags);
 

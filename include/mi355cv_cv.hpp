@@ -217,12 +217,13 @@ inline void convertMaps(cv::InputArray _map1, cv::InputArray _map2, cv::OutputAr
     cv::convertMaps(_map1, _map2, _dstmap1, _dstmap2, dstmap1type, nninterpolation);
 }
 
-// cv::warpPolar (imgwarp.cpp:3731): the forward direction runs as one kernel (map evaluation fused into the sampling); WARP_INVERSE_MAP and
-// whatever else the library declines go to cv::warpPolar, whose own remap call is served by the remap32f hook.
+// cv::warpPolar (imgwarp.cpp:3731): both directions run with the map evaluated inside the sampling kernel (WARP_INVERSE_MAP: the reference's float
+// approximations of cartToPolar / log restated there); whatever the library declines goes to cv::warpPolar, whose own remap call is served by the
+// remap32f hook.
 inline void warpPolar(cv::InputArray _src, cv::OutputArray _dst, cv::Size dsize, cv::Point2f center, double maxRadius, int flags)
 {
     cv::Mat src = _src.getMat();
-    if (!(flags & cv::WARP_INVERSE_MAP) && src.dims <= 2 && !_dst.isUMat() && src.cols < SHRT_MAX && src.rows < SHRT_MAX) {
+    if (src.dims <= 2 && !_dst.isUMat() && src.cols < SHRT_MAX && src.rows < SHRT_MAX - 2) {
         if (dsize.width <= 0 && dsize.height <= 0) { dsize.width = cvRound(maxRadius); dsize.height = cvRound(maxRadius * CV_PI); }
         else if (dsize.height <= 0) dsize.height = cvRound(dsize.width * CV_PI);
         if (dsize.width > 0 && dsize.height > 0 && dsize.width < SHRT_MAX && dsize.height < SHRT_MAX) {

@@ -932,6 +932,48 @@ __device__ __forceinline__ void tileOf(const WarpArgs& w, int& tx, int& ty)
     ty = t / w.gx; tx = t - ty * w.gx;
 }
 
+
+// ---- cv::warpPolar with WARP_INVERSE_MAP (imgwarp.cpp:3795-3845): the map of a destination pixel is (rho / Kmag, phi / Kangle + 1) with (rho, phi) from
+// cv::cartToPolar of (x - cx, y - cy) and, for the semi-log form, rho <- cv::log(rho + 1).  Both are the reference's float approximations in the form its
+// AVX2 build runs them (core mathfuncs_core.simd.hpp: cartToPolar32f_ :123-168 with v_atan_f32 :78-119, log32f :759-827 over the 256-entry table), fused
+// multiply-adds where that build fuses; rows are cut into blocks of 1024 (mathfuncs.cpp:298) and a block of fewer than 16 (cartToPolar) / a row of fewer
+// than 8 (log) elements takes the scalar form, whose association differs.
+__device__ __forceinline__ float polarAtan(float y, float x, bool vec)
+{
+    const float k = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = __fmul_rn(0.9997878412794807f, k), p3 = __fmul_rn(-0.3258083974640975f, k), p5 = __fmul_rn(0.1555786518463281f, k), p7 = __fmul_rn(-0.04432655554792128f, k);
+    const float eps = (float)2.2204460492503131e-16, scale = (float)(3.1415926535897932384626433832795 / 180);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (vec) {
+        const float mn = ax < ay ? ax : ay, mx = ax > ay ? ax : ay;
+        const float c = __fdiv_rn(mn, __fadd_rn(mx, eps)), cc = __fmul_rn(c, c);
+        a = __fmul_rn(__fmaf_rn(__fmaf_rn(__fmaf_rn(cc, p7, p5), cc, p3), cc, p1), c);
+        if (!(ax >= ay)) a = __fsub_rn(90.f, a);
+    } else if (ax >= ay) {
+        const float c = __fdiv_rn(ay, __fadd_rn(ax, eps)), c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1), c);
+    } else {
+        const float c = __fdiv_rn(ax, __fadd_rn(ay, eps)), c2 = __fmul_rn(c, c);
+        a = __fmaf_rn(-(__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1)), c, 90.f);
+    }
+    if (x < 0.f) a = __fsub_rn(180.f, a);
+    if (y < 0.f) a = __fsub_rn(360.f, a);
+    return __fmul_rn(a, scale);
+}
+__device__ __forceinline__ float polarLog(float v, bool vec, const float* __restrict__ logTab /* 256 x (log(1 + i/256), 1 / (1 + i/256)) */)
+{
+    const uint32_t i0 = __float_as_uint(v);
+    const float bf = __uint_as_float((i0 & ((1u << 15) - 1)) | (127u << 23));
+    const int idx = (int)((i0 >> (23 - 8 - 1)) & (255 * 2));
+    const float e = (float)((int)((i0 >> 23) & 0xff) - 127), ln2 = (float)0.69314718055994530941723212145818;
+    const float A0 = 0.3333333333333333333333333f, A1 = -0.5f, A2 = 1.f, delta = idx == 510 ? -1.f / 512 : 0.f;
+    const float y0 = __fmaf_rn(e, ln2, logTab[idx]);
+    const float x0 = __fmaf_rn(__fsub_rn(bf, 1.f), logTab[idx + 1], delta);
+    if (vec) { float z = __fmaf_rn(x0, A0, A1); z = __fmaf_rn(z, x0, A2); return __fmaf_rn(z, x0, y0); }
+    return __fmaf_rn(__fmaf_rn(__fmaf_rn(A0, x0, A1), x0, A2), x0, y0);
+}
+
 __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                               SampleArgs s, WarpArgs w, const short* __restrict__ tab,
                                               const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
@@ -962,6 +1004,17 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
         fX = fmax(-2147483648.0, fmin(2147483647.0, fX));
         fY = fmax(-2147483648.0, fmin(2147483647.0, fY));
         X = satIntD(fX); Y = satIntD(fY);
+    } else if (w.kind == 7) {
+        // inverse warpPolar: M = {cx, cy, Kmag, Kangle, semiLog}; mapx = the log table; the source is the polar image with one wrapped row above and below
+        const float bx = __fsub_rn((float)x, (float)w.M[0]), by = __fsub_rn((float)y, (float)w.M[1]);
+        const int blockLen = min(1024, w.dw - (x & ~1023));
+        float rho = __fsqrt_rn(__fmaf_rn(bx, bx, __fmul_rn(by, by)));
+        const float phi = polarAtan(by, bx, blockLen >= 16);
+        if (w.M[4] != 0.0) rho = polarLog(__fadd_rn(rho, 1.f), w.dw >= 8, reinterpret_cast<const float*>(mapx));
+        const float mx = (float)__ddiv_rn((double)rho, w.M[2]);
+        const float my = __fadd_rn((float)__ddiv_rn((double)phi, w.M[3]), 1.f);
+        if (s.linear) { X = satIntD((double)__fmul_rn(mx, 32.f)); Y = satIntD((double)__fmul_rn(my, 32.f)); }
+        else { X = satIntD((double)mx); Y = satIntD((double)my); }
     } else if (w.kind == 2 || w.kind == 3 || w.kind == 6) {
         // float maps: kind 2 = two CV_32FC1 planes, kind 3 = one CV_32FC2 (RemapInvoker imgwarp.cpp:1233-1300), kind 6 = warpPolar's forward map
         // evaluated in place (imgwarp.cpp:3776-3792: (float)(rho[x] * cos(phi_y) + cx) in double, the per-row cos / sin and the per-column
@@ -1260,6 +1313,9 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
         if (kind == 4) dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 2, dh, &mys);
         if (!dmx || (kind == 4 && !dmy)) return MI355CV_NOT_IMPLEMENTED;
+    } else if (kind == 7) {                                                                  // inverse warpPolar: the 512-float log table (host array)
+        dmx = (const uchar*)stg.param(mapx, 512 * sizeof(float));
+        if (!dmx) return MI355CV_NOT_IMPLEMENTED;
     } else if (kind == 6) {                                                                  // warpPolar tables (host arrays: dw radii, dh (cos, sin) pairs)
         dmx = (const uchar*)stg.param(mapx, (size_t)dw * 4);
         dmy = (const uchar*)stg.param(mapy, (size_t)dh * 16);
@@ -1271,7 +1327,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     WarpArgs w; memset(&w, 0, sizeof w);
     w.dw = dw; w.dh = dh; w.kind = kind;
     w.sframe = nframes > 1 ? sframe : 0; w.dframe = nframes > 1 ? dframe : 0;
-    if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : 9); i++) w.M[i] = M[i];
+    if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : kind == 7 ? 5 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
     if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && sh >= 2 && (dss % e) == 0 &&
@@ -1621,8 +1677,41 @@ MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1
 MI355CV_API int mi355cv_warpPolar(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags)
 {
-    if (disabled() || dst_width <= 0 || dst_height <= 0 || (flags & MI355CV_WARP_INVERSE_MAP)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0) return MI355CV_NOT_IMPLEMENTED;
     const bool semiLog = (flags & 256) != 0;                                                  // WARP_POLAR_LOG
+    const double bv[4] = {0, 0, 0, 0};
+    if (flags & MI355CV_WARP_INVERSE_MAP) {
+        // polar / semi-log polar image -> Cartesian image (imgwarp.cpp:3795-3845): the source gets one wrapped row above and below (copyMakeBorder BORDER_WRAP),
+        // the map is evaluated per destination pixel in the kernel (k_warp kind 7), then cv::remap's sampling
+        const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
+        if (!depthOk(depth) || cn < 1 || cn > 4 || src_height + 2 > 32767) return MI355CV_NOT_IMPLEMENTED;
+        Stager outer;                                  // first: a declined call must also put the host's device back (~Stager)
+        if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+        if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        const size_t rowB = (size_t)src_width * cn * eszOf(depth), bstep = (rowB + 255) & ~(size_t)255;
+        size_t dss;
+        const uchar* ds = outer.in(src_data, src_step, rowB, src_height, &dss);
+        uchar* bordered = (uchar*)outer.scratch(bstep * (size_t)(src_height + 2));
+        if (!ds || !bordered) return MI355CV_NOT_IMPLEMENTED;
+        hipStream_t st = stream();
+        if (hipMemcpy2DAsync(bordered + bstep, bstep, ds, dss, rowB, src_height, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(bordered, ds + (size_t)(src_height - 1) * dss, rowB, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(bordered + bstep * (size_t)(src_height + 1), ds, rowB, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return setError(MI355CV_ERROR_UNKNOWN, "warpPolar: %s", hipGetErrorString(hipGetLastError()));
+        static float logTab[512]; static std::once_flag once;
+        std::call_once(once, [] {                                                           // the reference's logTab_f (mathfuncs_core: log(1 + i/256) and 1 / (1 + i/256) as floats)
+            for (int i = 0; i < 256; i++) { const double t = 1.0 + i / 256.0; logTab[2 * i] = (float)std::log(t); logTab[2 * i + 1] = (float)(1.0 / t); }
+            logTab[510] = (float)0.69314718055994530941723212145818; logTab[511] = 0.5f;       // the last cell is measured from 2.0
+        });
+        const double Kangle = 6.283185307179586476925286766559 / src_height;
+        const double Kmag = semiLog ? std::log(maxRadius) / src_width : maxRadius / src_width;
+        const double M[5] = {(double)center_x, (double)center_y, Kmag, Kangle, semiLog ? 1.0 : 0.0};
+        const int rc = runWarp("warpPolar", src_type, bordered, bstep, src_width, src_height + 2, dst_data, dst_step, dst_width, dst_height,
+                               M, 7, flags & 7, (flags & 8) ? B_CONSTANT : B_TRANSPARENT, bv, logTab, 0, nullptr, 0);
+        if (rc != MI355CV_OK) return rc;
+        if (!asyncMode() && hipStreamSynchronize(st) != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "warpPolar: %s", hipGetErrorString(hipGetLastError()));
+        return MI355CV_OK;
+    }
     std::vector<float> rhos((size_t)dst_width);
     std::vector<double> cs(2 * (size_t)dst_height);
     if (semiLog) { const double Kmag = std::log(maxRadius) / dst_width; for (int r = 0; r < dst_width; r++) rhos[(size_t)r] = (float)(std::exp(r * Kmag) - 1.0); }
@@ -1630,7 +1719,6 @@ MI355CV_API int mi355cv_warpPolar(int src_type, const uchar* src_data, size_t sr
     const double Kangle = 6.283185307179586476925286766559 / dst_height;                      // CV_2PI
     for (int p = 0; p < dst_height; p++) { const double k = Kangle * p; cs[2 * (size_t)p] = std::cos(k); cs[2 * (size_t)p + 1] = std::sin(k); }
     const double M[2] = {(double)center_x, (double)center_y};
-    const double bv[4] = {0, 0, 0, 0};
     return runWarp("warpPolar", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 6, flags & 7, (flags & 8) ? B_CONSTANT : B_TRANSPARENT, bv, rhos.data(), 0, (const float*)cs.data(), 0);   // 8 = WARP_FILL_OUTLIERS
 }

@@ -546,7 +546,7 @@ def adaptiveThreshold(src, maxValue, adaptiveMethod, thresholdType, blockSize, C
 
 
 def moments(src, binaryImage=False):
-    """cv::moments of a single-channel CV_8U / CV_16U / CV_16S image through cv_hal_imageMoments: the ten spatial moments as a dict (m00 .. m03); the central
+    """cv::moments of a single-channel CV_8U / CV_16U / CV_16S / CV_32F / CV_64F image through cv_hal_imageMoments: the ten spatial moments as a dict (m00 .. m03); the central
     and normalised moments follow from them as in completeMomentState (moments.cpp:33-66)."""
     s = Img(src)
     if s.cn != 1:
@@ -997,7 +997,8 @@ WARP_FILL_OUTLIERS, WARP_POLAR_LINEAR, WARP_POLAR_LOG = 8, 0, 256
 
 
 def warpPolar(src, dsize, center, maxRadius, flags, dst=None):
-    """cv::warpPolar (imgwarp.cpp:3731), forward direction; WARP_INVERSE_MAP raises (the reference's own path: maps on the CPU + cv_hal_remap32f)."""
+    """cv::warpPolar (imgwarp.cpp:3731): Cartesian -> polar / semi-log polar, and with WARP_INVERSE_MAP the way back (the map is evaluated in the kernel
+    with the reference's float approximations of cartToPolar / log)."""
     s = Img(src)
     dw, dh = dsize
     if dw <= 0 and dh <= 0:                                       # :3737-3745

@@ -56,3 +56,18 @@ def test_image_moments(cv, orc, dtype):
                 assert [got[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")] == want.tolist(), (w, h, binary)
     src = rng.integers(0, 256, (70, 90)).astype(dtype)
     assert list(cv.moments(src).values()) == orc.orc_moments(src).tolist()                      # host arrays
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_image_moments_float(cv, orc, dtype):
+    """CV_32F / CV_64F: every sum inside a 32 x 32 tile is a chain of double additions in raster order in the reference (momentsInTile<float / double, double,
+    double>); the kernel walks the chains in that order (a lane per tile row, then the rows one after the other), so the ten doubles are equal bit for bit"""
+    rng = np.random.default_rng(9)
+    for (w, h) in [(1, 1), (31, 5), (32, 32), (33, 65), (200, 97), (3840, 2160), (1000, 37), (64, 1)]:
+        for src in ((rng.random((h, w)) * 255 - 40).astype(dtype), np.full((h, w), 0.1, dtype=dtype), (rng.random((h, w)) < 0.3).astype(dtype)):
+            for binary in (False, True):
+                got = cv.moments(torch.from_numpy(src).cuda(), binary)
+                want = orc.orc_moments(src, binary)
+                assert [got[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")] == want.tolist(), (w, h, binary)
+    src = (rng.random((70, 90)) * 3).astype(dtype)
+    assert list(cv.moments(src).values()) == orc.orc_moments(src).tolist()                      # host arrays

@@ -253,3 +253,15 @@ def test_resize_linear_exact(orc, ref, dtype, cn):
         assert np.array_equal(orc.orc_resize(src, dsize, interpolation=5), orc.ref_resize(src, dsize, interpolation=5)), (dsize, dtype, cn)
     one = rnd(orc, (1, 9, cn) if cn > 1 else (1, 9), dtype, 3)
     assert np.array_equal(orc.orc_resize(one, (20, 4), interpolation=5), orc.ref_resize(one, (20, 4), interpolation=5))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_resize_nearest_exact(orc, ref, dtype, cn):
+    """INTER_NEAREST_EXACT (resizeNN_bitexact, resize.cpp:1174-1289): 16.16 steps, pixel centres; up, down, odd and even sizes, thin images"""
+    src = rnd(orc, (37, 53, cn) if cn > 1 else (37, 53), dtype, 11 + cn)
+    for dsize in [(80, 60), (20, 11), (53, 37), (106, 74), (26, 18), (27, 19), (1, 1), (200, 5), (7, 90), (159, 111)]:
+        assert np.array_equal(orc.orc_resize(src, dsize, interpolation=6), orc.ref_resize(src, dsize, interpolation=6)), (dsize, dtype, cn)
+    even = rnd(orc, (36, 52, cn) if cn > 1 else (36, 52), dtype, 5)
+    for dsize in [(13, 9), (104, 72), (51, 35)]:
+        assert np.array_equal(orc.orc_resize(even, dsize, interpolation=6), orc.ref_resize(even, dsize, interpolation=6)), (dsize, dtype, cn)

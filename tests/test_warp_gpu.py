@@ -317,8 +317,6 @@ def test_warp_polar_forward(cv, orc, dtype):
     for flags in (1, 1 | 8, 0 | 8, 1 | 256, 1 | 256 | 8):
         for dsize, center, rad in [((64, 90), (40.0, 30.0), 35.0), ((50, 157), (10.5, 50.25), 60.0)]:
             check(cv.warpPolar(dev(src), dsize, center, rad, flags), orc.orc_warpPolar(src, dsize, center, rad, flags))
-    with pytest.raises(NotImplementedError):
-        cv.warpPolar(dev(src), (64, 90), (40.0, 30.0), 35.0, 1 | 16)
     big = rnd((1080, 1920), np.uint8, 42)
     check(cv.warpPolar(dev(big), (1024, 2048), (960.0, 540.0), 600.0, 1 | 8), orc.orc_warpPolar(big, (1024, 2048), (960.0, 540.0), 600.0, 1 | 8))
 
@@ -338,3 +336,38 @@ def test_resize_linear_exact(cv, orc, dtype, cn):
     assert np.array_equal(got[1].cpu().numpy(), orc.orc_resize(np.ascontiguousarray(src[::-1]), (80, 60), interpolation=5))
     with pytest.raises(NotImplementedError):
         cv.resize(dev(rnd((20, 30), np.float32, 1)), (40, 60), interpolation=5)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_nearest_exact(cv, orc, dtype, cn):
+    """INTER_NEAREST_EXACT (resizeNN_bitexact: 16.16 fixed-point steps on pixel centres) -- equal to the restatement, which is pinned to cv::resize"""
+    src = rnd((37, 53, cn) if cn > 1 else (37, 53), dtype, 11 + cn)
+    for dsize in [(80, 60), (20, 11), (53, 37), (106, 74), (27, 19), (1, 1), (200, 5), (7, 90)]:
+        assert np.array_equal(cv.resize(dev(src), dsize, interpolation=6).cpu().numpy(), orc.orc_resize(src, dsize, interpolation=6)), (dsize, dtype, cn)
+    big = rnd((1080, 1920, cn) if cn > 1 else (1080, 1920), dtype, 9)
+    assert np.array_equal(cv.resize(dev(big), (3840, 2160), interpolation=6).cpu().numpy(), orc.orc_resize(big, (3840, 2160), interpolation=6))
+    assert np.array_equal(cv.resize(dev(big), (1281, 719), interpolation=6).cpu().numpy(), orc.orc_resize(big, (1281, 719), interpolation=6))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_polar_inverse(cv, orc, dtype):
+    """WARP_INVERSE_MAP: polar / semi-log polar image -> Cartesian image.  The map comes from the reference's float approximations of cartToPolar and log
+    (their vector forms; the scalar forms for rows narrower than 16 / 8 pixels), restated in the kernel; the restatement is pinned bit for bit to
+    cv::warpPolar (tests/test_oracle_warp.py), so the outputs compare as usual: 8-bit equal, CV_32F to 1e-4 of the range."""
+    for cn in (1, 3):
+        src = rnd((90, 64, cn) if cn > 1 else (90, 64), dtype, 43 + cn)
+        for flags in (1 | 16 | 8, 0 | 16 | 8, 1 | 16 | 256 | 8, 0 | 16 | 256 | 8):
+            for dsize, center, rad in [((80, 60), (40.0, 30.0), 35.0), ((12, 30), (5.5, 14.25), 20.0), ((7, 9), (3.0, 4.0), 6.0), ((1100, 40), (600.5, 20.0), 500.0)]:
+                check(cv.warpPolar(dev(src), dsize, center, rad, flags), orc.orc_warpPolar(src, dsize, center, rad, flags))
+    # without WARP_FILL_OUTLIERS the untouched pixels keep the destination's previous contents
+    src = rnd((90, 64), dtype, 47)
+    prev = rnd((60, 80), dtype, 48)
+    got = cv.warpPolar(dev(src), (80, 60), (40.0, 30.0), 20.0, 1 | 16, dst=dev(prev.copy()))
+    want = orc.orc_warpPolar(src, (80, 60), (40.0, 30.0), 20.0, 1 | 16 | 8)
+    filled = orc.orc_warpPolar(np.full_like(src, 1 if dtype == np.uint8 else 0.5), (80, 60), (40.0, 30.0), 20.0, 0 | 16 | 8) != 0      # where the map lands inside
+    g = got.cpu().numpy()
+    assert np.array_equal(g[~filled], prev[~filled])
+    big = rnd((2048, 1024), np.uint8, 49)
+    check(cv.warpPolar(dev(big), (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))
+    check(cv.warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))   # host image
