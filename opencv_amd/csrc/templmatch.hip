@@ -457,6 +457,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 }
 
+
+// ---------------------------------------------------------------------------------- MFMA correlation of CV_32FC1 images: three bf16 products
+// cv::matchTemplate on float images (crossCorr templmatch.cpp:566, the reference's FFT path in float).  A float x is split into bf16 pieces
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi); the three products hi*hi + hi*mid + mid*hi accumulated in fp32 by the matrix cores agree with
+// a plain fp32 correlation to <= 1e-6 of |corr| on non-negative images and 1e-7 of |I| |T| on zero-mean data (tools/split_bf16_study.py, profiles/
+// r02_split_bf16_study.txt; one product alone is 5-9e-5, too close to the 1e-4 contract).  The GEMM is the Toeplitz form of the 8-bit kernel above:
+//   M = 32 output rows, N = 32 output columns, K = image columns;  A[m][k] = I[y + r][k] (image rows as they are),  B[k][n] = T[r][k - n]
+// on v_mfma_f32_32x32x16_bf16.  A workgroup (4 waves, one per SIMD) owns 128 x 128 results: wave w the rows 32w .. 32w+31, four N tiles.  The template
+// is walked in chunks of BF_JC rows: per chunk the image rows the 128 output rows need (128 + BF_JC - 1 of them, 288 columns) and the chunk's template
+// rows (Toeplitz layout: 32 zeros, the row, zeros) are staged into LDS as bf16; per template row and 16-column K step a lane fetches its A operand as
+// one 16-byte LDS read (shared by the N tiles: block 2 nt + ks) and its B operand as five dwords + a 0 / 2-byte funnel shift.  The kernel handles ONE pair
+// of planes (image piece, template piece) and either writes or adds to the fp32 result, so the three products are three launches over planes that stay
+// in L2 / MALL; bias-free float data needs none of the 8-bit kernel's correction terms.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_BM = 128, BF_BN = 128, BF_JC = 32;
+constexpr int BF_PP = 592;                      // LDS patch pitch in bytes: 288 bf16 columns (128 + 16 * 10) + 16 bytes so that consecutive rows rotate the 16-byte slot
+constexpr int BF_TE = 200;                      // template row in elements: 32 zeros + 128 + 40 zeros
+constexpr int BF_TP = 2 * BF_TE;                // ... in bytes
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);        // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// float image -> two bf16 planes (hi, mid), rows of `pitch` elements (a multiple of 8, zero beyond the image's width)
+__global__ __launch_bounds__(256) void k_tm_split_bf16(const uchar* __restrict__ src, size_t sstep, size_t sframe, int w, int h, unsigned short* __restrict__ hi,
+                                                       unsigned short* __restrict__ mid, int pitch, size_t plane)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= pitch || y >= h) return;
+    const float v = x < w ? reinterpret_cast<const float*>(src + (size_t)blockIdx.z * sframe + (size_t)y * sstep)[x] : 0.f;
+    const unsigned short a = f32_to_bf16_rn(v);
+    const float r = __fsub_rn(v, __uint_as_float((uint32_t)a << 16));                     // exact: the remainder has at most 16 significant bits
+    const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
+    hi[o] = a; mid[o] = f32_to_bf16_rn(r);
+}
+
+// float template -> two bf16 planes in the kernel's Toeplitz row layout (th rows of BF_TE elements)
+__global__ __launch_bounds__(256) void k_tm_tpl_bf16(const uchar* __restrict__ tpl, size_t tstep, int tw, int th, unsigned short* __restrict__ hi, unsigned short* __restrict__ mid)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= th * BF_TE) return;
+    const int r = i / BF_TE, e = i - r * BF_TE, c = e - 32;
+    const float v = (c >= 0 && c < tw) ? reinterpret_cast<const float*>(tpl + (size_t)r * tstep)[c] : 0.f;
+    const unsigned short a = f32_to_bf16_rn(v);
+    hi[i] = a; mid[i] = f32_to_bf16_rn(__fsub_rn(v, __uint_as_float((uint32_t)a << 16)));
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ccorr_bf16(const unsigned short* __restrict__ img, int ipitch /* elements */, size_t iplane, int ih,
+        const unsigned short* __restrict__ tpl /* th x BF_TE */, int th, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar smem[];
+    uchar* P = smem;                                             // (BF_BM + BF_JC - 1) x BF_PP
+    uchar* T = smem + (size_t)(BF_BM + BF_JC - 1) * BF_PP;       // BF_JC x BF_TP
+    img += (size_t)blockIdx.z * iplane;
+    const int X0 = blockIdx.x * BF_BN, Y0 = blockIdx.y * BF_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    constexpr int NA = KS + 6;                                   // 32-byte (16-column) blocks of the patch the four N tiles touch over the K steps
+    constexpr int CPR = (16 * NA + 16 + 7) / 8;                  // 16-byte chunks staged per patch row
+    int bOff[KS], bSh[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) { const int o = 2 * (32 + 16 * ks + 8 * h - m); bOff[ks] = o & ~3; bSh[ks] = o & 3; }
+    v16f acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[b][i] = 0.f;
+    const uchar* Pw = P + (size_t)(wave * 32 + m) * BF_PP + 16 * h;
+
+    for (int j0 = 0; j0 < th; j0 += BF_JC) {
+        const int nj = min(BF_JC, th - j0), prow = BF_BM + nj - 1;
+        if (j0) __syncthreads();                                 // the previous chunk's operands are no longer needed
+        // ---- stage: image rows Y0 + j0 .. + prow - 1, columns X0 .. X0 + 8 CPR - 1, zero outside the plane; loads in batches of SB per thread
+        constexpr int SB = 8;
+        const int nP = prow * CPR;
+        for (int i0 = 0; i0 < nP; i0 += 256 * SB) {
+            uint4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int i = i0 + u * 256 + tid;
+                const int ry = i / CPR, cb = i - ry * CPR;
+                const int yy = Y0 + j0 + ry, xx = X0 + cb * 8;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < nP && yy < ih && xx < ipitch) v[u] = *reinterpret_cast<const uint4*>(img + (size_t)yy * ipitch + xx);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int i = i0 + u * 256 + tid;
+                if (i < nP) { const int ry = i / CPR, cb = i - ry * CPR; *reinterpret_cast<uint4*>(P + (size_t)ry * BF_PP + cb * 16) = v[u]; }
+            }
+        }
+        for (int i = tid; i < nj * (BF_TP / 16); i += 256)
+            reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(tpl + (size_t)j0 * BF_TE)[i];
+        __syncthreads();
+
+        // ---- compute: template rows j0 .. j0 + nj - 1; output row R0 + m with template row j reads patch row (32 wave + m) + (j - j0)
+        struct Frag { v4i A[NA]; unsigned R[KS][5]; };
+        auto load = [&](Frag& F, int jj) {
+#pragma unroll
+            for (int cb = 0; cb < NA; cb++) F.A[cb] = *reinterpret_cast<const v4i*>(Pw + (size_t)jj * BF_PP + 32 * cb);
+            const uchar* Tr = T + (size_t)jj * BF_TP;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const unsigned* tp = reinterpret_cast<const unsigned*>(Tr + bOff[ks]);
+#pragma unroll
+                for (int d = 0; d < 5; d++) F.R[ks][d] = tp[d];
+            }
+        };
+        auto mfma = [&](const Frag& F) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                v4i B;
+                B.x = (int)__builtin_amdgcn_alignbyte(F.R[ks][1], F.R[ks][0], bSh[ks]); B.y = (int)__builtin_amdgcn_alignbyte(F.R[ks][2], F.R[ks][1], bSh[ks]);
+                B.z = (int)__builtin_amdgcn_alignbyte(F.R[ks][3], F.R[ks][2], bSh[ks]); B.w = (int)__builtin_amdgcn_alignbyte(F.R[ks][4], F.R[ks][3], bSh[ks]);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.A[2 * nt + ks]), __builtin_bit_cast(bf16x8, B), acc[nt], 0, 0, 0);
+            }
+        };
+        Frag F0, F1;
+        load(F0, 0);
+        int jj = 0;
+        for (; jj + 2 <= nj; jj += 2) {                          // the next row's operands are fetched while this row's MFMAs run
+            load(F1, jj + 1); mfma(F0); __builtin_amdgcn_sched_barrier(0);
+            load(F0, min(jj + 2, nj - 1)); mfma(F1); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (jj < nj) mfma(F0);
+    }
+    // ---- epilogue: lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 the same columns four rows below
+    uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        const int x = X0 + 32 * nt + m;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int y = Y0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (x < rw && y < rh) {
+                float* d = reinterpret_cast<float*>(rbase + (size_t)y * rstep) + x;
+                *d = accumulate ? __fadd_rn(*d, acc[nt][i]) : acc[nt][i];
+            }
+        }
+    }
+}
+
 // ---- the same correlation with two workgroups per CU ----------------------------------------------------------------------------
 // k_ccorr_mfma_i8 keeps the whole (MT_BM + th - 1)-row patch in LDS: 130 KB, one workgroup and one wave per SIMD, so staging, MFMA
 // loop and epilogue of a CU run strictly one after the other and every stall inside the loop is exposed.  A wave, however, only ever
@@ -1039,6 +1187,34 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
             }
             if (done) return stg.finish(entry);
             if (method != 2) return setError(MI355CV_NOT_IMPLEMENTED, "%s: out of scratch memory for the per-channel planes", entry);   // (no integral images were built)
+        }
+        // CV_32FC1: three bf16 products on the matrix cores (k_ccorr_bf16); MI355CV_TM_BF16=0 keeps the direct kernel
+        static const bool bf16Off = std::getenv("MI355CV_TM_BF16") && atoi(std::getenv("MI355CV_TM_BF16")) == 0;
+        if (!done && !bf16Off && depth == D32F && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0) {
+            const int ipitch = (iw + 7) & ~7;
+            const size_t iplane = (size_t)ipitch * ih;
+            unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2);
+            unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2);
+            unsigned short* thi = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
+            unsigned short* tmid = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
+            if (ihi && imid && thi && tmid) {
+                hipLaunchKernelGGL(k_tm_split_bf16, dim3(divUp(ipitch, 64), divUp(ih, 4), nframes), dim3(256), 0, st, di, dis, nframes > 1 ? iframe : 0, iw, ih, ihi, imid, ipitch, iplane);
+                hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(th * BF_TE, 256)), dim3(256), 0, st, dt, dts, tw, th, thi, tmid);
+                const int KS = (tw + 31 + 15) / 16;                                           // K steps of 16 columns covering tw + 31
+                const size_t lds = (size_t)(BF_BM + BF_JC - 1) * BF_PP + (size_t)BF_JC * BF_TP;
+                dim3 gb(divUp(rw, BF_BN), divUp(rh, BF_BM), nframes);
+                float* rf = reinterpret_cast<float*>(dr);
+                const size_t rfr = nframes > 1 ? rframe : 0;
+#define BF_LAUNCH(KS_) do { static bool attrSet[16] = {}; const int dv_ = activeDevice() & 15; \
+                if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_bf16<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet[dv_] = true; } \
+                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 0); \
+                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); \
+                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); } while (0)
+                switch (KS) { case 1: case 2: BF_LAUNCH(2); break; case 3: case 4: BF_LAUNCH(4); break; case 5: case 6: BF_LAUNCH(6); break; case 7: case 8: BF_LAUNCH(8); break; default: BF_LAUNCH(10); }
+#undef BF_LAUNCH
+                noteKernel("k_ccorr_bf16<%d> x3 (hi*hi + hi*mid + mid*hi) grid=%ux%ux%u x256 lds=%zu", KS, gb.x, gb.y, gb.z, lds);
+                done = true;
+            }
         }
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);
         if (!done)

@@ -23,15 +23,18 @@ template <typename T, int TYPE> __device__ __forceinline__ T threshOne(T v, T t,
 }
 
 // four 8-bit pixels of a dword at once: G = 0xff in every byte whose pixel is > t (unsigned compare on the two 16-bit planes: saturating subtract,
-// min with 1, times 0xff), then the five types are one bit-select each: dst = (G & A) | (~G & B)
+// min with 1, times 0xff), then the five types are one bit-select each: dst = (G & A) | (~G & B).  The three packed 16-bit steps are written as
+// instructions: expressed with vector builtins (min(sub_sat(e, t), 1) * 255) this LLVM folds the whole expression to "all ones" and drops the load.
+__device__ __forceinline__ uint32_t gtMask2(uint32_t plane, uint32_t t16, uint32_t one2, uint32_t ff2)
+{
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_mul_lo_u16 %0, %0, %4" : "=&v"(d) : "v"(plane), "v"(t16), "v"(one2), "v"(ff2));
+    return d;                                              // 0x00ff in each 16-bit lane whose value is > t
+}
 template <int TYPE> __device__ __forceinline__ uint32_t thresh4(uint32_t v, uint32_t t16 /* t in both 16-bit lanes */, uint32_t m4, uint32_t t4)
 {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const u16x2 one = {1, 1}, ff = {255, 255}, tt = __builtin_bit_cast(u16x2, t16);
-    const u16x2 e = __builtin_bit_cast(u16x2, v & 0x00ff00ffu), o = __builtin_bit_cast(u16x2, (v >> 8) & 0x00ff00ffu);
-    const u16x2 ge = __builtin_elementwise_min(__builtin_elementwise_sub_sat(e, tt), one) * ff;
-    const u16x2 go = __builtin_elementwise_min(__builtin_elementwise_sub_sat(o, tt), one) * ff;
-    const uint32_t G = __builtin_bit_cast(uint32_t, ge) | (__builtin_bit_cast(uint32_t, go) << 8);
+    const uint32_t one2 = 0x00010001u, ff2 = 0x00ff00ffu;
+    const uint32_t G = gtMask2(v & 0x00ff00ffu, t16, one2, ff2) | (gtMask2((v >> 8) & 0x00ff00ffu, t16, one2, ff2) << 8);
     if (TYPE == 0) return G & m4;
     if (TYPE == 1) return ~G & m4;
     if (TYPE == 2) return (G & t4) | (~G & v);

@@ -210,6 +210,32 @@ __global__ __launch_bounds__(256) void k_area2x2_u8(const uchar* __restrict__ sr
     }
 }
 
+// INTER_AREA by exactly 2 x 2 on CV_32FC1 (cfg3's 8K -> 4K; ResizeAreaFastVec_SIMD_32f resize.cpp:2928-2960: (s00 + s01) + (s10 + s11), times 0.25f), even
+// source sizes: a lane produces FOUR destination floats from two dwordx4 loads of each of the two source rows and stores one dwordx4 -- the thread-per-pixel
+// form ran at 54 % of HBM (its 8-byte loads and 4-byte stores leave the memory system half-used); 20 bytes per destination float
+__global__ __launch_bounds__(256) void k_area2x2_f32(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                     int dw, int dh)
+{
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (4 * g >= dw || dy >= dh) return;
+    const float* r0 = reinterpret_cast<const float*>(src + (size_t)blockIdx.z * sframe + (size_t)(2 * dy) * sstep) + 8 * (size_t)g;
+    const float* r1 = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(r0) + sstep);
+    float* D = reinterpret_cast<float*>(dst + (size_t)blockIdx.z * dframe + (size_t)dy * dstep) + 4 * (size_t)g;
+    if (4 * g + 4 <= dw) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r0)), a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r0) + 1);
+        const f32x4 b0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r1)), b1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r1) + 1);
+        f32x4 o;
+        o.x = __fmul_rn(__fadd_rn(__fadd_rn(a0.x, a0.y), __fadd_rn(b0.x, b0.y)), 0.25f);
+        o.y = __fmul_rn(__fadd_rn(__fadd_rn(a0.z, a0.w), __fadd_rn(b0.z, b0.w)), 0.25f);
+        o.z = __fmul_rn(__fadd_rn(__fadd_rn(a1.x, a1.y), __fadd_rn(b1.x, b1.y)), 0.25f);
+        o.w = __fmul_rn(__fadd_rn(__fadd_rn(a1.z, a1.w), __fadd_rn(b1.z, b1.w)), 0.25f);
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(D));
+    } else {
+        for (int p = 0; 4 * g + p < dw; p++) D[p] = __fmul_rn(__fadd_rn(__fadd_rn(r0[2 * p], r0[2 * p + 1]), __fadd_rn(r1[2 * p], r1[2 * p + 1])), 0.25f);
+    }
+}
+
 // resize, bilinear (and INTER_AREA upscaling, which is bilinear with other coefficients), single channel CV_32F / CV_8U: the
 // arithmetic of k_resize specialised.  A thread owns a destination column for RROWS rows: its horizontal coefficient is
 // computed once, both horizontal taps come from one unaligned 8-byte / 2-byte load per source row, and a wave walks down
@@ -1342,13 +1368,13 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             a8.constBorder = borderType == B_CONSTANT;
             for (int k = 0; k < cn; k++) a8.cval |= (uint32_t)fminf(fmaxf(rintf(s.cval[k]), 0.f), 255.f) << (8 * k);
             static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 4; return t < 1 ? 1 : t > 64 ? 64 : t; }();
-            static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 0; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
+            static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
 #define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
-            if (kind == 0) { if (cn == 1) { if (fetch) W8(1, 0, 1); else W8(1, 0, 0); } else if (cn == 3) W8(3, 0, 0); else W8(4, 0, 0); }
-            else           { if (cn == 1) { if (fetch) W8(1, 1, 1); else W8(1, 1, 0); } else if (cn == 3) W8(3, 1, 0); else W8(4, 1, 0); }
+            if (kind == 0) { if (cn == 1) { if (fetch) W8(1, 0, 1); else W8(1, 0, 0); } else if (cn == 3) { if (fetch) W8(3, 0, 1); else W8(3, 0, 0); } else W8(4, 0, 0); }
+            else           { if (cn == 1) { if (fetch) W8(1, 1, 1); else W8(1, 1, 0); } else if (cn == 3) { if (fetch) W8(3, 1, 1); else W8(3, 1, 0); } else W8(4, 1, 0); }
 #undef W8
-            noteKernel("k_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, kind, cn == 1 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+            noteKernel("k_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, kind, cn != 4 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
             return stg.finish(entry);
         }
         // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean
@@ -1481,6 +1507,13 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         if (cn == 1) hipLaunchKernelGGL(k_area2x2_u8<1>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
         else if (cn == 3) hipLaunchKernelGGL(k_area2x2_u8<3>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
         else hipLaunchKernelGGL(k_area2x2_u8<4>, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
+        return stg.finish(entry);
+    }
+    if (a.mode == 3 && depth == D32F && cn == 1 && a.isx == 2 && a.isy == 2 && src_width == 2 * dst_width && src_height == 2 * dst_height &&
+        ((((uintptr_t)ds) | dss | a.sframe) & 15) == 0 && ((((uintptr_t)dd) | dds | a.dframe) & 15) == 0) {
+        dim3 g3(divUp(divUp(dst_width, 4), 64), divUp(dst_height, 4), nframes);
+        hipLaunchKernelGGL(k_area2x2_f32, g3, dim3(256), 0, stream(), ds, dss, a.sframe, dd, dds, a.dframe, dst_width, dst_height);
+        noteKernel("k_area2x2_f32 grid=%ux%ux%u x256", g3.x, g3.y, g3.z);
         return stg.finish(entry);
     }
     if (a.mode == 4) {

@@ -199,14 +199,32 @@ W8_HD void stage(const Args& a, const Box& b, int cn, const unsigned char* src, 
     const uint32_t total = pd * (uint32_t)b.ch;
     const uint32_t base = (uint32_t)b.cy0 * a.sstep + (((uint32_t)b.cx0 * (uint32_t)cn) & ~3u);          // both images are below 4 GB (host check)
     const uint32_t last = (uint32_t)(a.sh - 1) * a.sstep + (uint32_t)a.sw * (uint32_t)cn;                // one past the image's last pixel byte
-    for (uint32_t i = (uint32_t)tid; i < total; i += 256) {
-        const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
-        if (c >= nd) continue;
-        const uint32_t go = base + r * a.sstep + 4 * c;
-        uint32_t v;
-        if (go + 4 <= last) v = *reinterpret_cast<const uint32_t*>(src + go);
-        else { v = 0; for (uint32_t k = 0; k < 4; k++) if (go + k < last) v |= (uint32_t)src[go + k] << (8 * k); }
-        reinterpret_cast<uint32_t*>(tile)[i] = v;
+    // loads are issued in groups of NB before the first of them is stored to LDS: a thread that waits for every load on its own pays one memory
+    // round trip per dword (8 - 30 of them per tile), and nothing else in the workgroup can run until the tile is there
+    enum { NB = 8 };
+    for (uint32_t i0 = (uint32_t)tid; i0 < total; i0 += 256 * NB) {
+        uint32_t v[NB];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int u = 0; u < NB; u++) {
+            const uint32_t i = i0 + 256u * (uint32_t)u;
+            const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
+            // branch-free (a divergent byte-wise fallback made the compiler drain the load queue after every load): a dword that would cross the
+            // image's last byte is fetched from the last four bytes instead and shifted down; out-of-range slots re-read dword 0 of the box
+            const bool on = i < total && c < nd;
+            const uint32_t go = on ? base + r * a.sstep + 4 * c : base;
+            const uint32_t over = go + 4 > last ? go + 4 - last : 0u;            // 0..3
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            v[u] = *reinterpret_cast<const u32u*>(src + (go - over)) >> (8 * over);
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int u = 0; u < NB; u++) {
+            const uint32_t i = i0 + 256u * (uint32_t)u;
+            if (i < total) reinterpret_cast<uint32_t*>(tile)[i] = v[u];
+        }
     }
 }
 
@@ -217,39 +235,50 @@ W8_HD void splitWeights(uint32_t s01, uint32_t s23, uint32_t& hi, uint32_t& lo)
     lo = (s01 & 255) | (((s01 >> 16) & 255) << 8) | ((s23 & 255) << 16) | (((s23 >> 16) & 255) << 24);
 }
 
-// one destination pixel from the LDS tile: `p` points at its upper-left tap, (wh, wl) are the byte-split Q15 weights.  Returns CN bytes in the low bits.
-// LDS reads wider than a dword must sit on their natural alignment (a misaligned ds_read_b64 is replayed at 64 cycles per wave instruction), so taps are
-// fetched as dwords: FETCH 0 = unaligned 16- / 32-bit reads at the tap's own address; FETCH 1 (one channel) = the two ALIGNED dwords around it + a byte
-// funnel shift.
+// One destination pixel from the LDS tile in two steps, so that the LDS reads of a lane's four pixels can all be issued before the first result is needed:
+//   fetchTaps   `p` points at the pixel's upper-left tap; returns the 2 * CN tap bytes of the upper row in (t[0], t[1]) and of the lower row in (t[2], t[3])
+//   bilinearOf  the four Q15 weights (byte-split: wh, wl) applied to them; CN result bytes in the low bits
+// LDS reads wider than a dword must sit on their natural alignment (a misaligned ds_read_b64 is replayed at 64 cycles per wave instruction) and byte-misaligned
+// 16-bit reads measured slow as well (4K 8UC1, 7 degrees: 30.9 us per frame against 17.1 with aligned dwords + a byte funnel shift), so FETCH 1 -- the
+// default -- reads the ALIGNED dwords around the taps and shifts; FETCH 0 keeps the reads at the taps' own addresses (A/B runs).
 template <int CN, int FETCH>
-W8_HD uint32_t bilinearAt(const unsigned char* p, uint32_t pitch, uint32_t wh, uint32_t wl)
+W8_HD void fetchTaps(const unsigned char* p, uint32_t pitch, uint32_t (&t)[4])
+{
+    const unsigned char* p1 = p + pitch;
+    if (CN == 4) {                                                   // a pixel is a dword: always aligned
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p); const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1);
+        t[0] = q[0]; t[1] = q[1]; t[2] = q1[0]; t[3] = q1[1];
+    } else if (FETCH == 0) {
+        if (CN == 1) { t[0] = ld16(p); t[1] = 0; t[2] = ld16(p1); t[3] = 0; }
+        else { t[0] = ld32(p); t[1] = ld16(p + 4); t[2] = ld32(p1); t[3] = ld16(p1 + 4); }
+    } else {
+        const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;                 // pitch is a multiple of 4: the same shift on the next row
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh); const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1 - sh);
+        if (CN == 1) { t[0] = alignbyte(q[1], q[0], sh); t[1] = 0; t[2] = alignbyte(q1[1], q1[0], sh); t[3] = 0; }
+        else {
+            const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+            t[0] = alignbyte(a1, a0, sh); t[1] = alignbyte(a2, a1, sh); t[2] = alignbyte(b1, b0, sh); t[3] = alignbyte(b2, b1, sh);
+        }
+    }
+}
+
+template <int CN>
+W8_HD uint32_t bilinearOf(const uint32_t (&t)[4], uint32_t wh, uint32_t wl)
 {
     if (CN == 1) {
-        uint32_t t;
-        if (FETCH == 0) t = ld16(p) | (ld16(p + pitch) << 16);                        // [p00 p01 p10 p11]
-        else {
-            const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p - sh + pitch);    // pitch is a multiple of 4: same shift on the next row
-            const uint32_t r0 = alignbyte(q[1], q[0], sh), r1 = alignbyte(q1[1], q1[0], sh);
-            t = (r0 & 0xffffu) | (r1 << 16);
-        }
-        const uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
+        const uint32_t v = (t[0] & 0xffffu) | (t[2] << 16);                          // [p00 p01 p10 p11]
+        const uint32_t r = ((dot4(v, wh, 0) << 8) + dot4(v, wl, 1u << 14)) >> 15;
         return r > 255 ? 255 : r;
     }
-    // CN * 2 bytes of each row are taps: 6 (an unaligned dword + a halfword) or 8 (two dwords, 4-byte aligned: a pixel is a dword)
-    uint32_t a0, a1, b0, b1;
-    if (CN == 3) { a0 = ld32(p); a1 = ld16(p + 4); b0 = ld32(p + pitch); b1 = ld16(p + pitch + 4); }
-    else { const uint32_t* q = reinterpret_cast<const uint32_t*>(p); const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p + pitch); a0 = q[0]; a1 = q[1]; b0 = q1[0]; b1 = q1[1]; }
-    const unsigned long long q0 = a0 | ((unsigned long long)a1 << 32), q1v = b0 | ((unsigned long long)b1 << 32);
+    const unsigned long long q0 = t[0] | ((unsigned long long)t[1] << 32), q1 = t[2] | ((unsigned long long)t[3] << 32);
     uint32_t out = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int c = 0; c < CN; c++) {
-        const uint32_t t = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q0 >> (8 * (CN + c))) & 255) << 8) |
-                           ((uint32_t)((q1v >> (8 * c)) & 255) << 16) | ((uint32_t)((q1v >> (8 * (CN + c))) & 255) << 24);
-        uint32_t r = ((dot4(t, wh, 0) << 8) + dot4(t, wl, 1u << 14)) >> 15;
+        const uint32_t v = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q0 >> (8 * (CN + c))) & 255) << 8) |
+                           ((uint32_t)((q1 >> (8 * c)) & 255) << 16) | ((uint32_t)((q1 >> (8 * (CN + c))) & 255) << 24);
+        uint32_t r = ((dot4(v, wh, 0) << 8) + dot4(v, wl, 1u << 14)) >> 15;
         r = r > 255 ? 255 : r;
         out |= r << (8 * c);
     }
@@ -318,6 +347,8 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
         const int yi = st * ROWS_PER_STEP + wave * 2 + ly, y = y0 + yi;
         const int rX = KIND == 0 ? row[yi] : 0, rY = KIND == 0 ? row[MAX_TH + yi] : 0;
         uint32_t px[PX]; bool ok = fullLane;
+        uint32_t off[PX], wix[PX], tap[PX][4], wgt[PX][2]; bool outp[PX];
+        // (1) addresses of all four pixels, (2) every LDS read, (3) the arithmetic: a pixel's reads are in flight while its neighbours' are issued
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -331,19 +362,28 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
                 perspXY(a, x + p < a.dw ? x + p : a.dw - 1, y < a.dh ? y : a.dh - 1, X, Y);
                 rx = (X >> 5) - b.cx0; ry = (Y >> 5) - b.cy0; ax = X & 31; ay = Y & 31;
             }
-            uint32_t off = mad24((uint32_t)ry, pitch, (uint32_t)(rx * CN + b.shift));
-            bool out = false;
+            off[p] = mad24((uint32_t)ry, pitch, (uint32_t)(rx * CN + b.shift));
+            outp[p] = false;
             if (!ALL) {
                 // inside the staged box: sampled; the whole 2x2 footprint outside the source under BORDER_CONSTANT: the border value; the rest (partial
                 // footprints on the source's rim, the other border rules) leaves the group to the generic sampler
                 const bool in = (uint32_t)rx < cwm && (uint32_t)ry < chm;
                 const int sx = rx + b.cx0, sy = ry + b.cy0;
-                out = a.constBorder && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0);
-                off = in ? off : 0u; ok = ok && (in || out);
+                outp[p] = a.constBorder && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0);
+                off[p] = in ? off[p] : 0u; ok = ok && (in || outp[p]);
             }
-            const uint32_t* w = wt + 2 * (ay * 32 + ax);
-            px[p] = bilinearAt<CN, FETCH>(tile + off, pitch, w[0], w[1]);
-            if (!ALL) px[p] = out ? a.cval : px[p];
+            wix[p] = (uint32_t)(2 * (ay * 32 + ax));
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) { fetchTaps<CN, FETCH>(tile + off[p], pitch, tap[p]); wgt[p][0] = wt[wix[p]]; wgt[p][1] = wt[wix[p] + 1]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            px[p] = bilinearOf<CN>(tap[p], wgt[p][0], wgt[p][1]);
+            if (!ALL) px[p] = outp[p] ? a.cval : px[p];
         }
         if (y < a.dh) {
             if (ok) {

@@ -46,8 +46,8 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
     a.constBorder = constBorder; a.cval = cval;
     stats[0] = stats[1] = stats[2] = stats[3] = 0;
 #define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
-    if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) RUN(3, 0, 0); else RUN(4, 0, 0); }
-    else           { if (cn == 1) { if (fetch) RUN(1, 1, 1); else RUN(1, 1, 0); } else if (cn == 3) RUN(3, 1, 0); else RUN(4, 1, 0); }
+    if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) { if (fetch) RUN(3, 0, 1); else RUN(3, 0, 0); } else RUN(4, 0, 0); }
+    else           { if (cn == 1) { if (fetch) RUN(1, 1, 1); else RUN(1, 1, 0); } else if (cn == 3) { if (fetch) RUN(3, 1, 1); else RUN(3, 1, 0); } else RUN(4, 1, 0); }
 #undef RUN
     return 0;
 }

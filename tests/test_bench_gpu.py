@@ -25,6 +25,9 @@ def test_single_gpu_line():
     d = run(["--batch", "256", "--frames-per-launch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mpix/s" and d["dtype"] == "u8" and d["scaling"] == "weak"
     r = d["roofline"]
+    # traffic is measured in the run itself (rocprofv3 --pmc passes over a child, calibrated on a copy of known size)
+    t = r["traffic_detail"]
+    assert r["traffic"] and 0.95 <= t["traffic_over_algorithmic"] <= 1.5 and abs(t["fetch_calibration"] - 2.0) < 0.2 and abs(t["write_calibration"] - 1.0) < 0.2, t
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["config"]["launches_per_step"] == 2 and r["launches_timed"] == 6
     assert r["algorithmic_bytes_per_launch"] == 2 * 128 * 3840 * 2160
@@ -38,6 +41,17 @@ def test_two_ranks_share_one_gpu():
     legs = d["other_configs"]
     assert len(legs) == 2 and all(l["n_gpus"] == 2 for l in legs)
     assert "128 frames / GPU" in legs[0]["config"]                # 256 frames sharded over 2 ranks
+
+
+def test_eight_ranks_rehearsal_on_one_gpu():
+    """the driver's --gpus 8 launch plan at a reduced batch (8 ranks share the one GPU of the test box over gloo): spawn, sharding of the 256-frame cfg4 batch
+    into 32 frames per rank, the plan broadcast, max-over-ranks timing -- so that the first real 8-GPU run is not the first run of this path"""
+    d = run(["--gpus", "8", "--batch", "128", "--steps", "2", "--warmup", "1", "--no-pmc"], {"MI355CV_BENCH_SHARED_GPU": "1"})
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and "test_mode" in d
+    assert abs(d["per_gpu_mpix_s"] * 8 - d["value"]) / d["value"] < 1e-3
+    legs = d["other_configs"]
+    assert len(legs) == 2 and "32 frames / GPU" in legs[0]["config"]
+    assert "launch plan" in d["config"]["collective"]
 
 
 def test_refuses_more_gpus_than_visible():

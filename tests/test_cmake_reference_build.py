@@ -5,7 +5,7 @@ opencv_test_imgproc / opencv_test_video to oracle/_ref/cmake_hal/ (git-ignored, 
 
  * CPU (here): the generated header names our HAL, libopencv_imgproc.so needs libmi355cv.so, and the reference's bit-exact suites pass on the fallback
    with every hook call tallied as declined.
- * GPU (-m gpu): the reference's whole opencv_test_imgproc from THAT build passes with the hooks served by the MI355X."""
+ * GPU (-m gpu): the suites of the functions behind the hooks, from THAT build's opencv_test_imgproc, pass with the hooks served by the MI355X."""
 import os
 import re
 import subprocess
@@ -49,9 +49,19 @@ def test_cmake_build_passes_on_the_fallback():
     assert not served and declined.get("gaussianBlurBinomial", 0) > 0 and declined.get("warpAffine", 0) > 0, (served, declined)
 
 
+# the suites of the functions behind the hooks (the scope of oracle/ref's own reduced build of the test binary, tests/test_reference_suite.py): the cmake build's
+# binary also carries the reference's contour / histogram-comparison / Hough / ... suites, minutes of CPU-only work that no hook touches
+HOOK_SUITES = ("GaussianBlur_Bitexact.*:Resize_Bitexact.*:Imgproc_Erode.*:Imgproc_Dilate.*:Imgproc_MorphologyEx.*:Imgproc_Filter2D.*:Imgproc_Sobel.*:Imgproc_SpatialGradient.*:"
+               "Imgproc_Laplace.*:Imgproc_Blur.*:Imgproc_GaussianBlur.*:Imgproc_MedianBlur.*:Imgproc_PyramidDown.*:Imgproc_PyramidUp.*:Imgproc_MinEigenVal.*:Imgproc_EigenValsVecs.*:"
+               "Imgproc_PreCornerDetect.*:Imgproc_Integral.*:Imgproc_Morphology.*:Imgproc_MorphEx.*:Imgproc_Pyrdown.*:Imgproc_Color*:Imgproc_cvtColor_BE.*:ImgProc_RGB2YUV.*:"
+               "ImgProc_cvtColorTwoPlane.*:ImgProc_RGB2Lab.*:cvtColorUYVY.*:Imgproc_cvWarpAffine.*:Imgproc_resize_area.*:Imgproc_Resize*:Imgproc_WarpAffine*:Imgproc_WarpPerspective*:"
+               "Imgproc_Remap*:Resize.*:Imgproc_Warp.*:Imgproc_linearPolar.*:Imgproc_logPolar.*:Imgproc_warpPolar.*:Imgproc_Threshold.*:Imgproc_PyrUp.*:Imgproc_MatchTemplate.*:"
+               "Imgproc_BilateralFilter.*:Imgproc_Moments.*:cvt420/*:cvt422/*:matchTemplate_Modes.*:Imgproc_Hist/Imgproc_Equalize_Hist.*:Imgproc_FilterSupportedFormats.*")
+
+
 @pytest.mark.gpu
-def test_cmake_build_whole_suite_on_the_gpu():
-    rc, ran, passed, failed, served, declined = run("*")
-    assert rc == 0 and not failed and ran == passed and ran > 800, (rc, ran, passed, failed[:10])
+def test_cmake_build_hook_suites_on_the_gpu():
+    rc, ran, passed, failed, served, declined = run(HOOK_SUITES, timeout=600)
+    assert rc == 0 and not failed and ran == passed and ran > 250, (rc, ran, passed, failed[:10])
     for hook in ("gaussianBlurBinomial", "filter", "sepFilter", "boxFilter", "resize", "warpAffine", "warpPerspective", "cvtBGRtoGray", "pyrdown", "threshold", "integral"):
         assert served.get(hook, 0) > 0, (hook, served)

@@ -1,11 +1,14 @@
 """Re-entrancy (SURVEY §8b "Threading"): cv:: functions may be called concurrently from many host threads, so the hooks keep
 per-thread streams / staging pools.  Eight threads hammer different hooks on host arrays (staged) and device tensors at once;
 every result must equal the oracle's."""
+import os
 import threading
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -130,3 +133,48 @@ def test_image_on_another_device_is_declined():
     assert rc == 1 and b"device 1" in L.mi355cv_lastError()
     # the Python mirror binds the thread to the image's device instead
     assert torch.equal(cv.GaussianBlur(a, (5, 5), 0), d.zero_())
+
+
+def test_two_device_ordinals_in_one_process_on_a_one_gpu_box():
+    """drive >= 2 device ordinals from host threads in ONE process where only one GPU exists.  The HIP runtime is asked to expose the
+    GPU twice (HIP_VISIBLE_DEVICES=0,0 in a child process); if it does, the per-thread-per-device contexts are exercised on ordinals 0 and 1 through the
+    raw C ABI (own streams, own scratch pools, results equal to the restatement); if the runtime de-duplicates the list the child says so and the test
+    is skipped -- the real multi-ordinal run is test_device_binding_per_thread on the driver's 8-GPU node."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys, threading
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import orc
+from opencv_amd import _lib
+L = _lib.lib
+n = L.mi355cv_deviceCount()
+if n < 2:
+    print("ONE_ORDINAL"); sys.exit(0)
+rng = np.random.default_rng(5)
+frames = rng.integers(0, 256, (4, 270, 480), dtype=np.uint8)
+want = [orc.orc_gaussianBlurBinomialU8(f, 5, 4) for f in frames]
+errors = []
+def worker(d):
+    try:
+        assert L.mi355cv_setDevice(d) == 0 and L.mi355cv_getDevice() == d
+        for f in range(d, 4, 2):
+            p = L.mi355cv_deviceAlloc(2 * frames[f].size); assert p
+            assert L.mi355cv_upload(ctypes.c_void_p(p), frames[f].ctypes.data, frames[f].size) == 0
+            rc = L.mi355cv_gaussianBlurBinomial(ctypes.c_void_p(p), 480, ctypes.c_void_p(p + frames[f].size), 480, 480, 270, 0, 1, 0, 0, 0, 0, 5, 4)
+            back = np.empty_like(frames[f])
+            assert rc == 0 and L.mi355cv_download(back.ctypes.data, ctypes.c_void_p(p + frames[f].size), back.size) == 0
+            assert np.array_equal(back, want[f]), f
+            L.mi355cv_deviceFree(ctypes.c_void_p(p))
+    except Exception as e:
+        errors.append((d, repr(e)))
+ts = [threading.Thread(target=worker, args=(d,)) for d in (0, 1)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("ERRORS" if errors else "TWO_ORDINALS_OK", errors)
+'''
+    env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = "0,0"; env.pop("ROCR_VISIBLE_DEVICES", None)
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    if "ONE_ORDINAL" in p.stdout or p.returncode != 0 and "TWO_ORDINALS_OK" not in p.stdout and "ERRORS" not in p.stdout:
+        pytest.skip("the HIP runtime does not expose one GPU under two ordinals: " + (p.stdout + p.stderr)[-200:])
+    assert "TWO_ORDINALS_OK" in p.stdout, (p.stdout[-500:], p.stderr[-500:])

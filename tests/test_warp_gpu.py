@@ -120,7 +120,7 @@ def test_resize_lanczos4(cv, orc, dtype, cn):
     for dsize in [(64, 48), (700, 31)]:
         assert np.array_equal(cv.resize(dev(big), dsize, interpolation=4).cpu().numpy(), orc.orc_resize(big, dsize, interpolation=4)), (dsize, dtype, cn)
     with pytest.raises(NotImplementedError):
-        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=6)          # INTER_NEAREST_EXACT: declined, never a CPU fallback
+        cv.resize(dev(rnd((20, 30), np.uint16, 1)), (40, 60), interpolation=7)          # no such interpolation: declined, never a CPU fallback
 
 
 def mats(cv, w, h):
