@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
         // inverse warpPolar: M = {cx, cy, Kmag, Kangle, semiLog}; mapx = the log table; the source is the polar image with one wrapped row above and below
         const float bx = __fsub_rn((float)x, (float)w.M[0]), by = __fsub_rn((float)y, (float)w.M[1]);
         const int blockLen = min(1024, w.dw - (x & ~1023));
-        float rho = __fsqrt_rn(__fmaf_rn(bx, bx, __fmul_rn(by, by)));
+        float rho = sqrtf(__fmaf_rn(bx, bx, __fmul_rn(by, by)));                   // (sqrtf is correctly rounded under hipcc's default; __fsqrt_rn maps to the native approximation)
         const float phi = polarAtan(by, bx, blockLen >= 16);
         if (w.M[4] != 0.0) rho = polarLog(__fadd_rn(rho, 1.f), w.dw >= 8, reinterpret_cast<const float*>(mapx));
         const float mx = (float)__ddiv_rn((double)rho, w.M[2]);
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 
 
 // ---- CV_8U bilinear warpAffine / warpPerspective through an LDS tile (warp8.h has the why and every phase; this is the launch geometry) ------------------
-// A workgroup walks TPW horizontally adjacent 128 x th tiles (the 8 KB weight table it keeps in LDS is loaded once for all of them); per tile: box terms by
+// A workgroup walks TPW horizontally adjacent 128 x th tiles; per tile: box terms by
 // the first lanes -> barrier -> the source box into LDS + row / column terms -> barrier -> 16 (th = 32) or 8 destination pixels per thread.
 template <int CN, int KIND, int FETCH>
 __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tab, int tpw)
@@ -1276,8 +1276,8 @@ __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ sr
         const int tx = blockIdx.x * tpw + t;
         if (tx >= a.gx) break;                                                           // uniform
         const int x0 = tx * warp8::TW;
-        if (t == 0) warp8::phaseA<KIND>(a, x0, y0, tab, w8lds, tid);
-        else { __syncthreads(); if (tid < (KIND == 0 ? 8 : 4)) warp8::boxTerm<KIND>(a, x0, y0, tid, reinterpret_cast<int*>(w8lds + warp8::OFF_TERMS)); }
+        if (t) __syncthreads();                                                          // the previous tile's terms and pixels are no longer read
+        warp8::phaseA<KIND>(a, x0, y0, w8lds, tid);
         __syncthreads();
         int terms[12];                                                                   // wave-uniform: the box arithmetic runs on the scalar unit
 #pragma unroll
@@ -1367,7 +1367,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             a8.sframe = w.sframe; a8.dframe = w.dframe;
             a8.constBorder = borderType == B_CONSTANT;
             for (int k = 0; k < cn; k++) a8.cval |= (uint32_t)fminf(fmaxf(rintf(s.cval[k]), 0.f), 255.f) << (8 * k);
-            static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 4; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 1; return t < 1 ? 1 : t > 64 ? 64 : t; }();
             static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
 #define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)

@@ -4,12 +4,17 @@
 // accesses per wave load (profiles/r02_warp_pmc.txt), it stores bytes, and ran at 7-17 % of the HBM roofline.  Here a workgroup owns a 128 x TH
 // destination tile: it computes the EXACT bounding box of the tile's source footprint (the reference's fixed-point coordinate sums are monotone in
 // x and y, so the box of the four corners bounds every pixel), copies that box from HBM into LDS with whole aligned dwords (coalesced along rows),
-// and every lane then produces four horizontally adjacent destination pixels from LDS -- two unaligned ds_read per tap pair, the four Q15 weights as
-// two v_dot4_u32_u8 on byte-split weights -- and stores them as ONE dword (12 / 16 bytes for 3 / 4 channels).  Pixels whose 2x2 footprint is not
+// and every lane then produces four horizontally adjacent destination pixels from LDS -- the aligned dwords around a tap pair + a byte funnel shift, the
+// bilinear weights evaluated in their exact separable form -- and stores them as ONE dword (12 / 16 bytes for 3 / 4 channels).  Pixels whose 2x2 footprint is not
 // strictly inside the source take the generic sampler (borders, BORDER_TRANSPARENT blending).
 //
 // The arithmetic is the reference's (imgwarp.cpp:2233-2298 WarpAffineInvoker, :3160-3240 WarpPerspectiveInvoker, :675-904 remapBilinear<FixedPtCast>,
 // the 1024-entry Q15 table of initInterTab2D :213-275 with its fix-up quirk): coordinates in 1/1024 px rounded to 1/32, weights Q15, (sum + 2^14) >> 15.
+// The Q15 weights are EXACT integers, w = 32 (32 - ax | ax) (32 - ay | ay), for every table entry but (0, 0) -- (32767, 0, 0, 1) instead of (32768, 0, 0, 0),
+// which cannot change an 8-bit result ((32767 a + d + 16384) >> 15 == a for all bytes a, d) -- so the sum is 32 Q with
+//   Q = (p00 (32 - ax) + p01 ax) (32 - ay) + (p10 (32 - ax) + p11 ax) ay      and      (32 Q + 2^14) >> 15 == (Q + 512) >> 10
+// evaluated as two packed 16-bit multiply-adds and one v_dot2_u32_u16: no table, no table reads (they were two thirds of the kernel's LDS cycles: 1024
+// random 8-byte entries conflict in the banks), 8 KB of LDS less per workgroup.  tests/test_hostemu.py checks the identity on all 1024 entries.
 //
 // Everything here is __host__ __device__ and free of wave intrinsics so that tests/hostemu can run the very same staging and per-pixel code on the
 // CPU, thread by thread, against the pinned restatement (the GPU adds only the launch geometry).
@@ -25,7 +30,7 @@
 
 namespace warp8 {
 
-enum { LX = 32, PX = 4, TW = LX * PX /* 128 destination pixels per tile row */, ROWS_PER_STEP = 8 /* 4 waves x 2 rows */, TAB_BYTES = 1024 * 8, MAX_TH = 32 };
+enum { LX = 32, PX = 4, TW = LX * PX /* 128 destination pixels per tile row */, ROWS_PER_STEP = 8 /* 4 waves x 2 rows */, MAX_TH = 32 };
 
 // what the host passes (one copy per launch)
 struct Args {
@@ -85,6 +90,34 @@ W8_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
     return c + (a & 255) * (b & 255) + ((a >> 8) & 255) * ((b >> 8) & 255) + ((a >> 16) & 255) * ((b >> 16) & 255) + (a >> 24) * (b >> 24);
 #endif
 }
+// packed 16-bit lanes: a * b (low 16 bits per lane), a * b + c, and the dot product of two pairs + c
+W8_HD uint32_t pkMul(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
+#else
+    return (((a & 0xffffu) * (b & 0xffffu)) & 0xffffu) | ((((a >> 16) * (b >> 16)) & 0xffffu) << 16);
+#endif
+}
+W8_HD uint32_t pkMad(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c)));
+#else
+    return (((a & 0xffffu) * (b & 0xffffu) + (c & 0xffffu)) & 0xffffu) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu) << 16);
+#endif
+}
+W8_HD uint32_t dot2(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+#else
+    return c + (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16);
+#endif
+}
 W8_HD uint32_t ld16(const unsigned char* p)
 {
     typedef unsigned short u16u __attribute__((aligned(1)));
@@ -127,8 +160,8 @@ W8_HD void perspXY(const Args& a, int x, int y, int& X, int& Y)
     X = satIntD(fX); Y = satIntD(fY);
 }
 
-// LDS layout of a workgroup (bytes): weight table | column terms (colX[128], colY[128]) | row terms (rowX[32], rowY[32]) | box terms | source tile
-enum { OFF_COL = TAB_BYTES, OFF_ROW = OFF_COL + 2 * TW * 4, OFF_TERMS = OFF_ROW + 2 * MAX_TH * 4, OFF_TILE = OFF_TERMS + 64 };
+// LDS layout of a workgroup (bytes): column terms (colX[128], colY[128]) | row terms (rowX[32], rowY[32]) | box terms | source tile
+enum { OFF_COL = 0, OFF_ROW = OFF_COL + 2 * TW * 4, OFF_TERMS = OFF_ROW + 2 * MAX_TH * 4, OFF_TILE = OFF_TERMS + 64 };
 
 // the box of source pixels a tile needs, clipped to the image: origin (cx0, cy0), cw x ch pixels (0 = nothing loadable), `all` = every destination pixel of
 // the tile has its 2x2 footprint strictly inside the box (no per-pixel test needed), `shift` = byte offset of pixel cx0 inside its aligned dword
@@ -196,43 +229,43 @@ W8_HD void stage(const Args& a, const Box& b, int cn, const unsigned char* src, 
 {
     if (b.cw == 0) return;
     const uint32_t nd = (uint32_t)(b.shift + b.cw * cn + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;       // dwords per row to load / per LDS row
-    const uint32_t total = pd * (uint32_t)b.ch;
     const uint32_t base = (uint32_t)b.cy0 * a.sstep + (((uint32_t)b.cx0 * (uint32_t)cn) & ~3u);          // both images are below 4 GB (host check)
     const uint32_t last = (uint32_t)(a.sh - 1) * a.sstep + (uint32_t)a.sw * (uint32_t)cn;                // one past the image's last pixel byte
-    // loads are issued in groups of NB before the first of them is stored to LDS: a thread that waits for every load on its own pays one memory
-    // round trip per dword (8 - 30 of them per tile), and nothing else in the workgroup can run until the tile is there
+    // a wave takes whole rows of the box: 2^k lanes per row (the smallest power of two >= nd, at most 64; wider rows in passes of 64 dwords), so the
+    // address of a dword is one multiply-add; loads are issued NB at a time before the first of them is stored to LDS (a thread that waits for every load
+    // on its own pays one memory round trip per dword, and nothing else in the workgroup can run until the tile is there)
+    uint32_t lg = 0;
+    while ((1u << lg) < nd && lg < 6) lg++;
+    const uint32_t lanesPerRow = 1u << lg, rowsPerWave = 64u >> lg, wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63u;
+    const uint32_t c0 = lane & (lanesPerRow - 1), rsub = lane >> lg;
+    const uint32_t rowsPerPass = 4 * rowsPerWave;                                                       // rows the workgroup covers per step
     enum { NB = 8 };
-    for (uint32_t i0 = (uint32_t)tid; i0 < total; i0 += 256 * NB) {
-        uint32_t v[NB];
+    for (uint32_t cb = 0; cb < nd; cb += 64) {                                                          // (one pass unless a row has more than 64 dwords)
+        const uint32_t c = cb + c0;
+        for (uint32_t r0 = wave * rowsPerWave + rsub; r0 < (uint32_t)b.ch; r0 += rowsPerPass * NB) {
+            uint32_t v[NB];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int u = 0; u < NB; u++) {
-            const uint32_t i = i0 + 256u * (uint32_t)u;
-            const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
-            // branch-free (a divergent byte-wise fallback made the compiler drain the load queue after every load): a dword that would cross the
-            // image's last byte is fetched from the last four bytes instead and shifted down; out-of-range slots re-read dword 0 of the box
-            const bool on = i < total && c < nd;
-            const uint32_t go = on ? base + r * a.sstep + 4 * c : base;
-            const uint32_t over = go + 4 > last ? go + 4 - last : 0u;            // 0..3
-            typedef uint32_t u32u __attribute__((aligned(1)));
-            v[u] = *reinterpret_cast<const u32u*>(src + (go - over)) >> (8 * over);
-        }
+            for (int u = 0; u < NB; u++) {
+                const uint32_t r = r0 + rowsPerPass * (uint32_t)u;
+                const bool on = r < (uint32_t)b.ch && c < nd;
+                // branch-free: a dword that would cross the image's last byte is fetched from the last four bytes instead and shifted down; idle slots
+                // re-read dword 0 of the box
+                const uint32_t go = on ? base + r * a.sstep + 4 * c : base;
+                const uint32_t over = go + 4 > last ? go + 4 - last : 0u;            // 0..3
+                typedef uint32_t u32u __attribute__((aligned(1)));
+                v[u] = *reinterpret_cast<const u32u*>(src + (go - over)) >> (8 * over);
+            }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int u = 0; u < NB; u++) {
-            const uint32_t i = i0 + 256u * (uint32_t)u;
-            if (i < total) reinterpret_cast<uint32_t*>(tile)[i] = v[u];
+            for (int u = 0; u < NB; u++) {
+                const uint32_t r = r0 + rowsPerPass * (uint32_t)u;
+                if (r < (uint32_t)b.ch && c < nd) reinterpret_cast<uint32_t*>(tile)[r * pd + c] = v[u];
+            }
         }
     }
-}
-
-// the Q15 weight table in the form the dot products want: entry (ay * 32 + ax) = { bytes (w >> 8) of the four weights, bytes (w & 255) }
-W8_HD void splitWeights(uint32_t s01, uint32_t s23, uint32_t& hi, uint32_t& lo)
-{
-    hi = ((s01 >> 8) & 255) | ((s01 >> 24) << 8) | (((s23 >> 8) & 255) << 16) | ((s23 >> 24) << 24);
-    lo = (s01 & 255) | (((s01 >> 16) & 255) << 8) | ((s23 & 255) << 16) | (((s23 >> 16) & 255) << 24);
 }
 
 // One destination pixel from the LDS tile in two steps, so that the LDS reads of a lane's four pixels can all be issued before the first result is needed:
@@ -262,39 +295,30 @@ W8_HD void fetchTaps(const unsigned char* p, uint32_t pitch, uint32_t (&t)[4])
     }
 }
 
+// wx = (32 - ax) in both 16-bit lanes, wx1 = ax in both, wy = (32 - ay) | ay << 16
 template <int CN>
-W8_HD uint32_t bilinearOf(const uint32_t (&t)[4], uint32_t wh, uint32_t wl)
+W8_HD uint32_t bilinearOf(const uint32_t (&t)[4], uint32_t wx0, uint32_t wx1, uint32_t wy)
 {
-    if (CN == 1) {
-        const uint32_t v = (t[0] & 0xffffu) | (t[2] << 16);                          // [p00 p01 p10 p11]
-        const uint32_t r = ((dot4(v, wh, 0) << 8) + dot4(v, wl, 1u << 14)) >> 15;
-        return r > 255 ? 255 : r;
-    }
     const unsigned long long q0 = t[0] | ((unsigned long long)t[1] << 32), q1 = t[2] | ((unsigned long long)t[3] << 32);
     uint32_t out = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int c = 0; c < CN; c++) {
-        const uint32_t v = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q0 >> (8 * (CN + c))) & 255) << 8) |
-                           ((uint32_t)((q1 >> (8 * c)) & 255) << 16) | ((uint32_t)((q1 >> (8 * (CN + c))) & 255) << 24);
-        uint32_t r = ((dot4(v, wh, 0) << 8) + dot4(v, wl, 1u << 14)) >> 15;
-        r = r > 255 ? 255 : r;
-        out |= r << (8 * c);
+        // the left taps of both rows in one register (upper | lower << 16), the right taps in another: H = (h_upper | h_lower << 16), h <= 255 * 32
+        const uint32_t L = (uint32_t)((q0 >> (8 * c)) & 255) | ((uint32_t)((q1 >> (8 * c)) & 255) << 16);
+        const uint32_t R = (uint32_t)((q0 >> (8 * (CN + c))) & 255) | ((uint32_t)((q1 >> (8 * (CN + c))) & 255) << 16);
+        const uint32_t H = pkMad(R, wx1, pkMul(L, wx0));
+        out |= (dot2(H, wy, 512u) >> 10) << (8 * c);                               // <= 255: the weights sum to 1024 exactly
     }
     return out;
 }
 
 // ---- the three phases of a workgroup (256 threads), separated by barriers in the kernel; tests/hostemu runs them thread by thread -------------------------
-// A: weight table into LDS in split form (every thread), box terms (the first lanes)
+// A: box terms (the first lanes)
 template <int KIND>
-W8_HD void phaseA(const Args& a, int x0, int y0, const short* tab, unsigned char* lds, int tid)
+W8_HD void phaseA(const Args& a, int x0, int y0, unsigned char* lds, int tid)
 {
-    uint32_t* wt = reinterpret_cast<uint32_t*>(lds);
-    for (int i = tid; i < 1024; i += 256) {
-        const uint32_t s01 = reinterpret_cast<const uint32_t*>(tab)[2 * i], s23 = reinterpret_cast<const uint32_t*>(tab)[2 * i + 1];
-        splitWeights(s01, s23, wt[2 * i], wt[2 * i + 1]);
-    }
     if (tid < (KIND == 0 ? 8 : 4)) boxTerm<KIND>(a, x0, y0, tid, reinterpret_cast<int*>(lds + OFF_TERMS));
 }
 
@@ -328,7 +352,6 @@ W8_HD uint32_t mad24(uint32_t x, uint32_t y, uint32_t z)
 template <int CN, int KIND, bool ALL, int FETCH>
 W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, unsigned char* dst, int tid)
 {
-    const uint32_t* wt = reinterpret_cast<const uint32_t*>(lds);
     const int* col = reinterpret_cast<const int*>(lds + OFF_COL); const int* row = reinterpret_cast<const int*>(lds + OFF_ROW);
     const unsigned char* tile = lds + OFF_TILE;
     const int wave = tid >> 6, lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
@@ -347,7 +370,7 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
         const int yi = st * ROWS_PER_STEP + wave * 2 + ly, y = y0 + yi;
         const int rX = KIND == 0 ? row[yi] : 0, rY = KIND == 0 ? row[MAX_TH + yi] : 0;
         uint32_t px[PX]; bool ok = fullLane;
-        uint32_t off[PX], wix[PX], tap[PX][4], wgt[PX][2]; bool outp[PX];
+        uint32_t off[PX], wxa[PX], wya[PX], tap[PX][4]; bool outp[PX];
         // (1) addresses of all four pixels, (2) every LDS read, (3) the arithmetic: a pixel's reads are in flight while its neighbours' are issued
 #if defined(__HIPCC__)
 #pragma unroll
@@ -372,17 +395,17 @@ W8_HD unsigned rowsC(const Args& a, const Box& b, int x0, int y0, const unsigned
                 outp[p] = a.constBorder && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0);
                 off[p] = in ? off[p] : 0u; ok = ok && (in || outp[p]);
             }
-            wix[p] = (uint32_t)(2 * (ay * 32 + ax));
+            wxa[p] = (uint32_t)ax | ((uint32_t)ax << 16); wya[p] = (uint32_t)(32 - ay) | ((uint32_t)ay << 16);
         }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int p = 0; p < PX; p++) { fetchTaps<CN, FETCH>(tile + off[p], pitch, tap[p]); wgt[p][0] = wt[wix[p]]; wgt[p][1] = wt[wix[p] + 1]; }
+        for (int p = 0; p < PX; p++) fetchTaps<CN, FETCH>(tile + off[p], pitch, tap[p]);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int p = 0; p < PX; p++) {
-            px[p] = bilinearOf<CN>(tap[p], wgt[p][0], wgt[p][1]);
+            px[p] = bilinearOf<CN>(tap[p], 0x00200020u - wxa[p], wxa[p], wya[p]);
             if (!ALL) px[p] = outp[p] ? a.cval : px[p];
         }
         if (y < a.dh) {

@@ -15,7 +15,7 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
         for (int tx = 0; tx < a.gx; tx++) {
             const int x0 = tx * warp8::TW, y0 = ty * a.th;
             std::memset(lds.data(), 0xA5, lds.size());                      // stale LDS must never reach an output pixel
-            for (int tid = 0; tid < 256; tid++) warp8::phaseA<KIND>(a, x0, y0, tab, lds.data(), tid);
+            for (int tid = 0; tid < 256; tid++) warp8::phaseA<KIND>(a, x0, y0, lds.data(), tid);
             const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, reinterpret_cast<const int*>(lds.data() + warp8::OFF_TERMS));
             for (int tid = 0; tid < 256; tid++) warp8::phaseB<CN, KIND>(a, b, x0, y0, src, lds.data(), tid);
             stats[2] += b.all; stats[3] += b.cw == 0;

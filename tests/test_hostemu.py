@@ -94,7 +94,7 @@ def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
             if rc != 0:
                 continue                                                       # the plan declined (box too large for LDS): the old kernel serves it
             assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, border, fetch, int(np.count_nonzero(got != want)))
-            assert st[0] > (0.97 if border == 0 else 0.5) * dw * dh, (cn, deg, border, st)   # BORDER_CONSTANT: only the source's rim is left to the sampler
+            assert st[0] > (0.9 if border == 0 else 0.3) * dw * dh, (cn, deg, border, st)   # BORDER_CONSTANT: only the source's rim is left to the sampler
 
 
 @pytest.mark.parametrize("cn", [1, 3, 4])
@@ -110,3 +110,24 @@ def test_warp8_perspective_tiles_on_the_cpu(emu8, cn):
             continue
         assert np.array_equal(got, want), (cn, sw, sh, int(np.count_nonzero(got != want)))
         assert st[0] > 0.3 * dw * dh, (cn, st)
+
+
+def test_warp8_separable_weights_equal_the_q15_table():
+    """warp8.h evaluates the bilinear weights as (Q + 512) >> 10 with Q = (p00 (32 - ax) + p01 ax)(32 - ay) + (p10 (32 - ax) + p11 ax) ay instead of reading
+    the 1024-entry Q15 table of initInterTab2D: identical for every table entry and every byte quadruple -- the entries are 32 x the separable products
+    except (0, 0) = (32767, 0, 0, 1), which yields the same 8-bit result"""
+    orc = o.oracle()
+    orc.orc_bilinearTabI.restype = ctypes.c_void_p
+    tab = np.ctypeslib.as_array((ctypes.c_short * 4096).from_address(orc.orc_bilinearTabI())).reshape(32, 32, 4).astype(np.int64)
+    rng = np.random.default_rng(0)
+    p = rng.integers(0, 256, (20000, 4)).astype(np.int64)
+    p[:64] = np.array([[a, b, c, d] for a in (0, 255) for b in (0, 255) for c in (0, 255) for d in (0, 255)] * 4)
+    for ay in range(32):
+        for ax in range(32):
+            w = tab[ay, ax]
+            want = np.clip((p @ w + (1 << 14)) >> 15, 0, 255)
+            q = (p[:, 0] * (32 - ax) + p[:, 1] * ax) * (32 - ay) + (p[:, 2] * (32 - ax) + p[:, 3] * ax) * ay
+            assert np.array_equal((q + 512) >> 10, want), (ay, ax)
+    # entry (0, 0) against every pair (p00, p11)
+    a, d = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    assert np.array_equal((32767 * a + d + (1 << 14)) >> 15, a)
