@@ -172,6 +172,7 @@ inline void matchTemplate(cv::InputArray _image, cv::InputArray _templ, cv::Outp
                                   result.data, result.step, method) == MI355CV_OK)
             return;
     }
+    if (!_mask.empty()) mi355cv_noteDecline("matchTemplateMask");           // matchTemplateMask (templmatch.cpp:762): the reference's own path, on the record
     cv::matchTemplate(_image, _templ, _result, method, _mask);
 }
 

@@ -513,13 +513,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned short* __restrict__ tpl /* th x BF_TE */, int th, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
-    uchar* P = smem;                                             // (BF_BM + BF_JC - 1) x BF_PP
-    uchar* T = smem + (size_t)(BF_BM + BF_JC - 1) * BF_PP;       // BF_JC x BF_TP
+    constexpr int R = BF_BM + BF_JC - 1;                         // row slots of the patch: image row Y0 + g lives in slot g mod R
+    uchar* P = smem;                                             // R x BF_PP
+    uchar* T = smem + (size_t)R * BF_PP;                         // BF_JC x BF_TP
     img += (size_t)blockIdx.z * iplane;
     const int X0 = blockIdx.x * BF_BN, Y0 = blockIdx.y * BF_BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
     constexpr int NA = KS + 6;                                   // 32-byte (16-column) blocks of the patch the four N tiles touch over the K steps
-    constexpr int CPR = (16 * NA + 16 + 7) / 8;                  // 16-byte chunks staged per patch row
+    constexpr int CPR = 2 * NA + 2;                              // 16-byte chunks staged per patch row
     int bOff[KS], bSh[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) { const int o = 2 * (32 + 16 * ks + 8 * h - m); bOff[ks] = o & ~3; bSh[ks] = o & 3; }
@@ -528,53 +529,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int b = 0; b < 4; b++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[b][i] = 0.f;
-    const uchar* Pw = P + (size_t)(wave * 32 + m) * BF_PP + 16 * h;
 
-    for (int j0 = 0; j0 < th; j0 += BF_JC) {
-        const int nj = min(BF_JC, th - j0), prow = BF_BM + nj - 1;
-        if (j0) __syncthreads();                                 // the previous chunk's operands are no longer needed
-        // ---- stage: image rows Y0 + j0 .. + prow - 1, columns X0 .. X0 + 8 CPR - 1, zero outside the plane; loads in batches of SB per thread
+    // one 16-byte chunk of the image plane, zero outside it: patch row g (relative to Y0), chunk cb
+    auto fetch = [&](int g, int cb) -> uint4 {
+        const int yy = Y0 + g, xx = X0 + cb * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (yy < ih && xx < ipitch) v = *reinterpret_cast<const uint4*>(img + (size_t)yy * ipitch + xx);
+        return v;
+    };
+    // ---- the first chunk's rows 0 .. R - 1 and template rows 0 .. JC - 1; loads in batches of SB per thread
+    {
         constexpr int SB = 8;
-        const int nP = prow * CPR;
+        const int nrows = min(R, BF_BM + th - 1), nP = nrows * CPR;
         for (int i0 = 0; i0 < nP; i0 += 256 * SB) {
             uint4 v[SB];
 #pragma unroll
-            for (int u = 0; u < SB; u++) {
-                const int i = i0 + u * 256 + tid;
-                const int ry = i / CPR, cb = i - ry * CPR;
-                const int yy = Y0 + j0 + ry, xx = X0 + cb * 8;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < nP && yy < ih && xx < ipitch) v[u] = *reinterpret_cast<const uint4*>(img + (size_t)yy * ipitch + xx);
-            }
+            for (int u = 0; u < SB; u++) { const int i = i0 + u * 256 + tid; const int g = i / CPR; v[u] = i < nP ? fetch(g, i - g * CPR) : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-            for (int u = 0; u < SB; u++) {
-                const int i = i0 + u * 256 + tid;
-                if (i < nP) { const int ry = i / CPR, cb = i - ry * CPR; *reinterpret_cast<uint4*>(P + (size_t)ry * BF_PP + cb * 16) = v[u]; }
+            for (int u = 0; u < SB; u++) { const int i = i0 + u * 256 + tid; if (i < nP) { const int g = i / CPR; *reinterpret_cast<uint4*>(P + (size_t)g * BF_PP + (i - g * CPR) * 16) = v[u]; } }
+        }
+        const int nj0 = min(BF_JC, th);
+        for (int i = tid; i < nj0 * (BF_TP / 16); i += 256) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(tpl)[i];
+    }
+    __syncthreads();
+
+    constexpr int NPRE = (BF_JC * CPR + 255) / 256;              // chunks per thread of the BF_JC rows a later template chunk adds
+    for (int j0 = 0; j0 < th; j0 += BF_JC) {
+        const int nj = min(BF_JC, th - j0);
+        const bool more = j0 + BF_JC < th;
+        // ---- the NEXT chunk needs BF_JC more image rows (g = j0 + R .. j0 + R + BF_JC - 1; they replace rows j0 .. j0 + BF_JC - 1, which this chunk still reads):
+        // their loads are issued now and parked in registers under this chunk's MFMAs
+        uint4 pre[NPRE];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) {
+                const int i = u * 256 + tid, gr = i / CPR;
+                pre[u] = (gr < BF_JC && j0 + R + gr < BF_BM + th - 1) ? fetch(j0 + R + gr, i - gr * CPR) : make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        for (int i = tid; i < nj * (BF_TP / 16); i += 256)
-            reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(tpl + (size_t)j0 * BF_TE)[i];
-        __syncthreads();
-
-        // ---- compute: template rows j0 .. j0 + nj - 1; output row R0 + m with template row j reads patch row (32 wave + m) + (j - j0)
-        struct Frag { v4i A[NA]; unsigned R[KS][5]; };
+        // ---- compute: template rows j0 .. j0 + nj - 1; output row 32 wave + m with template row j reads image row g = j + 32 wave + m, slot g mod R (g < 2 R)
+        struct Frag { v4i A[NA]; unsigned R_[KS][5]; };
+        const int gbase = j0 + 32 * wave + m;
         auto load = [&](Frag& F, int jj) {
+            int g = gbase + jj; g = g >= R ? g - R : g;
+            const uchar* Pw = P + (size_t)g * BF_PP + 16 * h;
 #pragma unroll
-            for (int cb = 0; cb < NA; cb++) F.A[cb] = *reinterpret_cast<const v4i*>(Pw + (size_t)jj * BF_PP + 32 * cb);
+            for (int cb = 0; cb < NA; cb++) F.A[cb] = *reinterpret_cast<const v4i*>(Pw + 32 * cb);
             const uchar* Tr = T + (size_t)jj * BF_TP;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const unsigned* tp = reinterpret_cast<const unsigned*>(Tr + bOff[ks]);
 #pragma unroll
-                for (int d = 0; d < 5; d++) F.R[ks][d] = tp[d];
+                for (int d = 0; d < 5; d++) F.R_[ks][d] = tp[d];
             }
         };
         auto mfma = [&](const Frag& F) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 v4i B;
-                B.x = (int)__builtin_amdgcn_alignbyte(F.R[ks][1], F.R[ks][0], bSh[ks]); B.y = (int)__builtin_amdgcn_alignbyte(F.R[ks][2], F.R[ks][1], bSh[ks]);
-                B.z = (int)__builtin_amdgcn_alignbyte(F.R[ks][3], F.R[ks][2], bSh[ks]); B.w = (int)__builtin_amdgcn_alignbyte(F.R[ks][4], F.R[ks][3], bSh[ks]);
+                B.x = (int)__builtin_amdgcn_alignbyte(F.R_[ks][1], F.R_[ks][0], bSh[ks]); B.y = (int)__builtin_amdgcn_alignbyte(F.R_[ks][2], F.R_[ks][1], bSh[ks]);
+                B.z = (int)__builtin_amdgcn_alignbyte(F.R_[ks][3], F.R_[ks][2], bSh[ks]); B.w = (int)__builtin_amdgcn_alignbyte(F.R_[ks][4], F.R_[ks][3], bSh[ks]);
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.A[2 * nt + ks]), __builtin_bit_cast(bf16x8, B), acc[nt], 0, 0, 0);
@@ -588,6 +602,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             load(F0, min(jj + 2, nj - 1)); mfma(F1); __builtin_amdgcn_sched_barrier(0);
         }
         if (jj < nj) mfma(F0);
+        if (more) {
+            __syncthreads();                                     // every wave is done with rows j0 .. j0 + BF_JC - 1 and with this template chunk
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) {
+                const int i = u * 256 + tid, gr = i / CPR;
+                if (gr < BF_JC) { int g = j0 + R + gr; g -= R * (g / R); *reinterpret_cast<uint4*>(P + (size_t)g * BF_PP + (i - gr * CPR) * 16) = pre[u]; }
+            }
+            const int njn = min(BF_JC, th - (j0 + BF_JC));
+            for (int i = tid; i < njn * (BF_TP / 16); i += 256)
+                reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(tpl + (size_t)(j0 + BF_JC) * BF_TE)[i];
+            __syncthreads();
+        }
     }
     // ---- epilogue: lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 the same columns four rows below
     uchar* rbase = reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe;

@@ -1263,6 +1263,14 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 }
 
 
+// the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
+__global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.dw) { colT[i] = warp8::affColX(a, i); colT[a.dw + i] = warp8::affColY(a, i); }
+    if (i < a.dh) { rowT[i] = warp8::affRowX(a, i); rowT[a.dh + i] = warp8::affRowY(a, i); }
+}
+
 // ---- CV_8U bilinear warpAffine / warpPerspective through an LDS tile (warp8.h has the why and every phase; this is the launch geometry) ------------------
 // A workgroup walks TPW horizontally adjacent 128 x th tiles; per tile: box terms by
 // the first lanes -> barrier -> the source box into LDS + row / column terms -> barrier -> 16 (th = 32) or 8 destination pixels per thread.
@@ -1363,9 +1371,19 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // thread-per-column kernel (A/B runs, tools/warp_probe.py)
         static const bool warp8On = [] { const char* v = getenv("MI355CV_WARP8"); return !v || atoi(v) != 0; }();
         warp8::Args a8; size_t lds8 = 0;
-        if (depth == D8U && warp8On && warp8::plan(a8, cn, kind, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8)) {
+        // measured (profiles/r03_warp8.txt): the tile kernel wins for affine maps of 1- and 3-channel images (4K 8UC1 7 degrees 20.5 -> ~13 us per frame, 90 degrees
+        // 27 -> 20; 8UC3 33 -> 31 / 45 -> 27); 4-channel images and perspective maps (a double division per pixel either way) stay on the gather kernel
+        static const int warp8All = [] { const char* v = getenv("MI355CV_WARP8"); return v ? atoi(v) : 1; }();      // 2: every case the plan accepts (A/B runs)
+        if (depth == D8U && warp8On && (warp8All == 2 || (kind == 0 && cn != 4)) && warp8::plan(a8, cn, kind, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8)) {
             a8.sframe = w.sframe; a8.dframe = w.dframe;
             a8.constBorder = borderType == B_CONSTANT;
+            if (kind == 0) {
+                int* tt = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
+                if (tt) {
+                    hipLaunchKernelGGL(k_warp8_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), a8, tt, tt + 2 * dw);
+                    a8.colT = tt; a8.rowT = tt + 2 * dw;
+                }
+            }
             for (int k = 0; k < cn; k++) a8.cval |= (uint32_t)fminf(fmaxf(rintf(s.cval[k]), 0.f), 255.f) << (8 * k);
             static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 1; return t < 1 ? 1 : t > 64 ? 64 : t; }();
             static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs

@@ -44,6 +44,8 @@ struct Args {
     int bw0;                     // WarpPerspectiveInvoker's block width (the x the projective terms restart from)
     int gx, gy;
     unsigned long long sframe, dframe;
+    const int* colT;             // affine: colX[dw], colY[dw] -- the column terms of every destination column, evaluated once per call (k_warp8_terms) instead of
+    const int* rowT;             //         by every tile in double arithmetic; rowX[dh], rowY[dh] likewise.  nullptr: evaluate in place
     int constBorder;             // BORDER_CONSTANT: a pixel whose whole 2x2 footprint is outside the source is the border value, no sampling
     uint32_t cval;               // the border value's channels as bytes (saturate_cast<uchar> of the cv::Scalar)
 };
@@ -138,11 +140,16 @@ W8_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 #endif
 }
 
+// (the four functions below are the definitions; tcolX .. trowY read the per-call tables when the launch provided them)
 // affine coordinate terms (WarpAffineInvoker imgwarp.cpp:2252-2262 with hal::warpAffineBlocklineNN's adelta / bdelta :2699-2713): 1/1024 px, round delta 16
 W8_HD int affRowX(const Args& a, int y) { return satIntD(dmul(dadd(dmul(a.M[1], (double)y), a.M[2]), 1024.0)) + 16; }
 W8_HD int affRowY(const Args& a, int y) { return satIntD(dmul(dadd(dmul(a.M[4], (double)y), a.M[5]), 1024.0)) + 16; }
 W8_HD int affColX(const Args& a, int x) { return satIntD(dmul(dmul(a.M[0], (double)x), 1024.0)); }
 W8_HD int affColY(const Args& a, int x) { return satIntD(dmul(dmul(a.M[3], (double)x), 1024.0)); }
+W8_HD int tcolX(const Args& a, int x) { return a.colT ? a.colT[x < a.dw ? x : a.dw - 1] : affColX(a, x); }
+W8_HD int tcolY(const Args& a, int x) { return a.colT ? a.colT[a.dw + (x < a.dw ? x : a.dw - 1)] : affColY(a, x); }
+W8_HD int trowX(const Args& a, int y) { return a.rowT ? a.rowT[y < a.dh ? y : a.dh - 1] : affRowX(a, y); }
+W8_HD int trowY(const Args& a, int y) { return a.rowT ? a.rowT[a.dh + (y < a.dh ? y : a.dh - 1)] : affRowY(a, y); }
 
 // projective coordinates in 1/32 px (WarpPerspectiveInvoker :3195-3235 / hal::warpPerspectiveBlockline: the row terms start at the block's first column)
 W8_HD void perspXY(const Args& a, int x, int y, int& X, int& Y)
@@ -178,7 +185,7 @@ W8_HD void boxTerm(const Args& a, int x0, int y0, int k, int* terms)
     const int x1 = (x0 + TW < a.dw ? x0 + TW : a.dw) - 1, y1 = (y0 + a.th < a.dh ? y0 + a.th : a.dh) - 1;
     if (KIND == 0) {
         const int v = (k & 2) ? ((k & 1) ? x1 : x0) : ((k & 1) ? y1 : y0);
-        terms[k] = k < 4 ? ((k & 2) ? affColX(a, v) : affRowX(a, v)) : ((k & 2) ? affColY(a, v) : affRowY(a, v));
+        terms[k] = k < 4 ? ((k & 2) ? tcolX(a, v) : trowX(a, v)) : ((k & 2) ? tcolY(a, v) : trowY(a, v));
     } else if (k < 4) {
         const int x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0;
         perspXY(a, x, y, terms[3 * k], terms[3 * k + 1]);
@@ -229,41 +236,35 @@ W8_HD void stage(const Args& a, const Box& b, int cn, const unsigned char* src, 
 {
     if (b.cw == 0) return;
     const uint32_t nd = (uint32_t)(b.shift + b.cw * cn + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;       // dwords per row to load / per LDS row
+    const uint32_t total = pd * (uint32_t)b.ch;
     const uint32_t base = (uint32_t)b.cy0 * a.sstep + (((uint32_t)b.cx0 * (uint32_t)cn) & ~3u);          // both images are below 4 GB (host check)
     const uint32_t last = (uint32_t)(a.sh - 1) * a.sstep + (uint32_t)a.sw * (uint32_t)cn;                // one past the image's last pixel byte
-    // a wave takes whole rows of the box: 2^k lanes per row (the smallest power of two >= nd, at most 64; wider rows in passes of 64 dwords), so the
-    // address of a dword is one multiply-add; loads are issued NB at a time before the first of them is stored to LDS (a thread that waits for every load
-    // on its own pays one memory round trip per dword, and nothing else in the workgroup can run until the tile is there)
-    uint32_t lg = 0;
-    while ((1u << lg) < nd && lg < 6) lg++;
-    const uint32_t lanesPerRow = 1u << lg, rowsPerWave = 64u >> lg, wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63u;
-    const uint32_t c0 = lane & (lanesPerRow - 1), rsub = lane >> lg;
-    const uint32_t rowsPerPass = 4 * rowsPerWave;                                                       // rows the workgroup covers per step
+    // loads are issued in groups of NB before the first of them is stored to LDS: a thread that waits for every load on its own pays one memory
+    // round trip per dword (8 - 30 of them per tile), and nothing else in the workgroup can run until the tile is there.  (Handing whole rows to waves
+    // -- one multiply-add per address -- was measured slower: rows of 38 dwords leave 26 of 64 lanes idle and double the slots per thread.)
     enum { NB = 8 };
-    for (uint32_t cb = 0; cb < nd; cb += 64) {                                                          // (one pass unless a row has more than 64 dwords)
-        const uint32_t c = cb + c0;
-        for (uint32_t r0 = wave * rowsPerWave + rsub; r0 < (uint32_t)b.ch; r0 += rowsPerPass * NB) {
-            uint32_t v[NB];
+    for (uint32_t i0 = (uint32_t)tid; i0 < total; i0 += 256 * NB) {
+        uint32_t v[NB];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int u = 0; u < NB; u++) {
-                const uint32_t r = r0 + rowsPerPass * (uint32_t)u;
-                const bool on = r < (uint32_t)b.ch && c < nd;
-                // branch-free: a dword that would cross the image's last byte is fetched from the last four bytes instead and shifted down; idle slots
-                // re-read dword 0 of the box
-                const uint32_t go = on ? base + r * a.sstep + 4 * c : base;
-                const uint32_t over = go + 4 > last ? go + 4 - last : 0u;            // 0..3
-                typedef uint32_t u32u __attribute__((aligned(1)));
-                v[u] = *reinterpret_cast<const u32u*>(src + (go - over)) >> (8 * over);
-            }
+        for (int u = 0; u < NB; u++) {
+            const uint32_t i = i0 + 256u * (uint32_t)u;
+            const uint32_t r = (uint32_t)(((unsigned long long)i * a.pitchMagic) >> 32), c = i - r * pd;
+            // branch-free (a divergent byte-wise fallback made the compiler drain the load queue after every load): a dword that would cross the
+            // image's last byte is fetched from the last four bytes instead and shifted down; out-of-range slots re-read dword 0 of the box
+            const bool on = i < total && c < nd;
+            const uint32_t go = on ? base + r * a.sstep + 4 * c : base;
+            const uint32_t over = go + 4 > last ? go + 4 - last : 0u;            // 0..3
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            v[u] = *reinterpret_cast<const u32u*>(src + (go - over)) >> (8 * over);
+        }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int u = 0; u < NB; u++) {
-                const uint32_t r = r0 + rowsPerPass * (uint32_t)u;
-                if (r < (uint32_t)b.ch && c < nd) reinterpret_cast<uint32_t*>(tile)[r * pd + c] = v[u];
-            }
+        for (int u = 0; u < NB; u++) {
+            const uint32_t i = i0 + 256u * (uint32_t)u;
+            if (i < total) reinterpret_cast<uint32_t*>(tile)[i] = v[u];
         }
     }
 }
@@ -329,8 +330,8 @@ W8_HD void phaseB(const Args& a, const Box& b, int x0, int y0, const unsigned ch
     stage(a, b, CN, src, lds + OFF_TILE, tid);
     if (KIND == 0) {
         int* col = reinterpret_cast<int*>(lds + OFF_COL); int* row = reinterpret_cast<int*>(lds + OFF_ROW);
-        if (tid < TW) { col[tid] = affColX(a, x0 + tid); col[TW + tid] = affColY(a, x0 + tid); }
-        else if (tid < TW + a.th) { const int r = tid - TW; row[r] = affRowX(a, y0 + r) - (b.cx0 << 10); row[MAX_TH + r] = affRowY(a, y0 + r) - (b.cy0 << 10); }
+        if (tid < TW) { col[tid] = tcolX(a, x0 + tid); col[TW + tid] = tcolY(a, x0 + tid); }
+        else if (tid < TW + a.th) { const int r = tid - TW; row[r] = trowX(a, y0 + r) - (b.cx0 << 10); row[MAX_TH + r] = trowY(a, y0 + r) - (b.cy0 << 10); }
     }
 }
 

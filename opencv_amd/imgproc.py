@@ -1283,8 +1283,12 @@ def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
 TM_SQDIFF, TM_SQDIFF_NORMED, TM_CCORR, TM_CCORR_NORMED, TM_CCOEFF, TM_CCOEFF_NORMED = range(6)
 
 
-def matchTemplate(image, templ, method, result=None):
-    """cv::matchTemplate (templmatch.cpp:1158-1194): CV_8U / CV_32F, 1..4 channels, all six methods."""
+def matchTemplate(image, templ, method, result=None, mask=None):
+    """cv::matchTemplate (templmatch.cpp:1158-1194): CV_8U / CV_32F, 1..4 channels, all six methods.  With a mask the reference takes matchTemplateMask
+    (:762-905, combinations of crossCorr on float copies): not served -- the call raises, it never falls back to a CPU path."""
+    if mask is not None:
+        _lib.lib.mi355cv_noteDecline(b"matchTemplateMask")
+        raise NotImplementedError("matchTemplate with a mask (matchTemplateMask, templmatch.cpp:762) is not served by the GPU path; no CPU fallback in opencv_amd")
     s, t = Img(image), Img(templ)
     if (s.depth, s.cn) != (t.depth, t.cn):
         raise ValueError("matchTemplate: image and template must have the same type")        # CV_Assert :1164

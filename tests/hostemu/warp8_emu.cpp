@@ -44,6 +44,14 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
     const int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
     if (!warp8::plan(a, cn, kind, M, sw, sh, dw, dh, sstep, dstep, src, dst, bw0, &ldsBytes)) return 1;
     a.constBorder = constBorder; a.cval = cval;
+    std::vector<int> tt;
+    if (kind == 0 && (fetch & 2)) {                                   // the per-call term tables the launch would build (k_warp8_terms)
+        tt.resize(2 * (size_t)dw + 2 * (size_t)dh);
+        for (int i = 0; i < dw; i++) { tt[i] = warp8::affColX(a, i); tt[dw + i] = warp8::affColY(a, i); }
+        for (int i = 0; i < dh; i++) { tt[2 * dw + i] = warp8::affRowX(a, i); tt[2 * dw + dh + i] = warp8::affRowY(a, i); }
+        a.colT = tt.data(); a.rowT = tt.data() + 2 * dw;
+    }
+    fetch &= 1;
     stats[0] = stats[1] = stats[2] = stats[3] = 0;
 #define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
     if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) { if (fetch) RUN(3, 0, 1); else RUN(3, 0, 0); } else RUN(4, 0, 0); }

@@ -89,7 +89,7 @@ def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
         M = _rot(sw / 2.0, sh / 2.0, deg, sc)
         if (dw, dh) != (sw, sh):
             M = M.copy(); M[:, :2] *= sw / dw                                   # dst pixel -> src pixel of a resized canvas
-        for border, bval, fetch in [(0, (0, 0, 0, 0), 0), (0, (17.4, 200, 3, 255), 1), (1, (0, 0, 0, 0), 0), (4, (0, 0, 0, 0), 1)]:
+        for border, bval, fetch in [(0, (0, 0, 0, 0), 0), (0, (17.4, 200, 3, 255), 1), (1, (0, 0, 0, 0), 2), (4, (0, 0, 0, 0), 3)]:      # fetch bit 1: per-call term tables
             rc, got, want, st = _emu_warp(emu8, src, M, (dw, dh), 0, border, bval, fetch)
             if rc != 0:
                 continue                                                       # the plan declined (box too large for LDS): the old kernel serves it

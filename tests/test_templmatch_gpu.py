@@ -178,3 +178,13 @@ def test_bf16_split_path_32fc1(cv, orc, method):
     got = cv.matchTemplateBatch(dev(fr), dev(tpl), 3).cpu().numpy()
     for f in range(3):
         assert orc.rel_err(got[f], orc.orc_matchTemplate(fr[f], tpl, 3)) <= 1e-4, f
+
+
+def test_masked_matching_is_declined_loudly(cv):
+    """matchTemplateMask (templmatch.cpp:762-905) is not served: the mirror raises (never a silent CPU path) and the decline ledger records it"""
+    from opencv_amd import _lib
+    img, tpl = rnd((64, 80), np.uint8, 1), rnd((8, 8), np.uint8, 2)
+    n0 = _lib.decline_count("matchTemplateMask")
+    with pytest.raises(NotImplementedError):
+        cv.matchTemplate(dev(img), dev(tpl), 3, mask=dev(np.ones((8, 8), np.uint8)))
+    assert _lib.decline_count("matchTemplateMask") == n0 + 1

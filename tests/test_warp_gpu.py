@@ -365,9 +365,12 @@ def test_warp_polar_inverse(cv, orc, dtype):
     prev = rnd((60, 80), dtype, 48)
     got = cv.warpPolar(dev(src), (80, 60), (40.0, 30.0), 20.0, 1 | 16, dst=dev(prev.copy()))
     want = orc.orc_warpPolar(src, (80, 60), (40.0, 30.0), 20.0, 1 | 16 | 8)
-    filled = orc.orc_warpPolar(np.full_like(src, 1 if dtype == np.uint8 else 0.5), (80, 60), (40.0, 30.0), 20.0, 0 | 16 | 8) != 0      # where the map lands inside
+    yy, xx = np.mgrid[0:60, 0:80]
+    far = (xx - 40.0) ** 2 + (yy - 30.0) ** 2 > (20.0 + 3) ** 2                               # beyond maxRadius (+ the bilinear rim): the map leaves the source
+    near = (xx - 40.0) ** 2 + (yy - 30.0) ** 2 < (20.0 - 3) ** 2
     g = got.cpu().numpy()
-    assert np.array_equal(g[~filled], prev[~filled])
+    assert np.array_equal(g[far], prev[far]) and far.sum() > 1000
+    assert np.array_equal(g[near], want[near]) if dtype == np.uint8 else orc.rel_err(g[near], want[near]) <= 1e-6
     big = rnd((2048, 1024), np.uint8, 49)
     check(cv.warpPolar(dev(big), (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))
     check(cv.warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))   # host image
