@@ -268,6 +268,67 @@ __global__ __launch_bounds__(256) void k_filter2d_roll(const uchar* __restrict__
     else       filterRows<K, CN, false>(cx, dst, dstep, t, rows);
 }
 
+
+// cv::filter2D on CV_32FC1 -> CV_32FC1, 3x3 / 5x5, on the rolling skeleton: a float is a pixel of four "channels" of the byte skeleton (roll.h), so halos
+// are whole floats and the window's dwords are the elements.  The K row windows stay in registers; an output is delta + the taps in raster order, one
+// FMA each (Filter2D<float, Cast<float, float>, FilterVec_32f>, filter.simd.hpp:3103-3190: s0 = delta, s0 = fma(kf[k], src[k], s0) over the non-zero taps
+// -- a zero tap leaves the sum unchanged bit for bit).
+template <int K, bool UP>
+__device__ __forceinline__ void filterRowsF32(roll::Ctx<K / 2, K / 2, 4>& cx, uchar* __restrict__ dst, size_t dstep, const DenseTaps& t)
+{
+    typedef roll::Ctx<K / 2, K / 2, 4> Cx;
+    typedef typename Cx::RawT RawT;
+    constexpr int R = K / 2, NW = Cx::NW;
+    uint32_t Q[K][NW];
+    auto win = [&](uint32_t (&q)[NW], RawT raw, int valid) {
+        if (!valid) {
+#pragma unroll
+            for (int d = 0; d < Cx::MD; d++) raw.m[d] = 0;
+#pragma unroll
+            for (int d = 0; d < Cx::HD; d++) raw.side[d] = 0;
+        }
+        cx.window(q, raw);
+    };
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) { RawT pre; int v; cx.issue(pre, i - R, v); win(Q[i], pre, v); }
+    RawT raw[K]; int rv[K];
+#pragma unroll
+    for (int u = 0; u < K; u++) cx.issue(raw[u], u + R, rv[u]);
+    for (int y = 0; y < cx.nrows; y += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            if (y + u < cx.nrows) {
+                win(Q[(K - 1 + u) % K], raw[u], rv[u]);
+                cx.issue(raw[u], y + u + K + R, rv[u]);
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float s = t.delta;
+#pragma unroll
+                    for (int dy = 0; dy < K; dy++) {
+                        const uint32_t* qr = Q[(u + (UP ? K - 1 - dy : dy)) % K];     // image row y - R + dy
+#pragma unroll
+                        for (int dx = 0; dx < K; dx++) s = __builtin_fmaf(t.k[dy * K + dx], __uint_as_float(qr[k + dx]), s);
+                    }
+                    o[k] = __float_as_uint(s);
+                }
+                cx.template store<1>(dst, dstep, cx.gy(y + u), o);
+            }
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_filter2d_roll_f32(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                           int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, roll::Win win, DenseTaps t)
+{
+    roll::Ctx<K / 2, K / 2, 4> cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, 1, win)) return;
+    dst += (size_t)cx.frame * dframe;
+    if (cx.up) filterRowsF32<K, true>(cx, dst, dstep, t);
+    else       filterRowsF32<K, false>(cx, dst, dstep, t);
+}
+
 // cvtColor(BGR2GRAY / RGB2GRAY / BGRA2GRAY / RGBA2GRAY) followed by filter2D, in one pass: W is the width in pixels, the work split is that of
 // the gray image (a lane = 16 gray pixels = 16 SCN colour bytes)
 template <int K, int SCN>
@@ -710,6 +771,17 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
 static bool tryFilterRoll(const FilterCtx* c, const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t dds, size_t dframe, int nframes, int W, int H, hipStream_t st)
 {
     const int K = c->kw;
+    if (c->sdepth == D32F && c->ddepth == D32F && c->cn == 1 && c->kw == c->kh && (K == 3 || K == 5) && c->ax == K / 2 && c->ay == K / 2 &&
+        (((uintptr_t)ds | dss | sframe | (uintptr_t)dd | dds | dframe) & 3) == 0 && roll::eligible(ds, dss, sframe, dd, dds, dframe, W, 4, K / 2, c->border)) {
+        DenseTaps t; memset(&t, 0, sizeof t);
+        for (const Tap2D& tp : c->taps) t.k[tp.dy * K + tp.dx] = tp.k;
+        t.delta = c->delta;
+        const roll::Geom g = roll::geometry(W, H, 4, nframes, K == 3 ? 16 : 12, K);
+        if (K == 3) hipLaunchKernelGGL((k_filter2d_roll_f32<3>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, c->border, roll::wholeImage(), t);
+        else        hipLaunchKernelGGL((k_filter2d_roll_f32<5>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, c->border, roll::wholeImage(), t);
+        noteKernel("k_filter2d_roll_f32<%d> blocks=%u seg=%d rows", K, g.blocks, g.seg);
+        return true;
+    }
     if (c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2) return false;
     if (!((K == 3 && (c->cn == 1 || c->cn == 3 || c->cn == 4)) || (K == 5 && c->cn == 1))) return false;
     if (!roll::eligible(ds, dss, sframe, dd, dds, dframe, W, c->cn, K / 2, c->border)) return false;

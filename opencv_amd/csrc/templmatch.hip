@@ -172,36 +172,38 @@ void integralColumns(T* a, size_t step, size_t frame, int Wc, int H, int nframes
 // < 2^31 for templates up to 181x181), so instead of two (H+1)x(W+1) double integral images (133 MB for a 4K frame and a
 // column scan that is one long dependency chain) they are produced directly as u32 by a separable sliding box:
 // rows via an LDS prefix scan, columns via 64-row chunks.  Differences of cv::integral's doubles give the same integers.
+// (TS, TA) = (uchar, unsigned): exact integers; (float, double): the CV_32FC1 path, sums in double like the reference's integral images
+template <typename TS, typename TA>
 __global__ __launch_bounds__(256) void k_wsum_rows(const uchar* __restrict__ img, size_t istep, size_t iframe, int iw, int tw, int rw,
-                                                   unsigned* __restrict__ s1, unsigned* __restrict__ q1, size_t sframe /* elements */)
+                                                   TA* __restrict__ s1, TA* __restrict__ q1, size_t sframe /* elements */)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned lw[];        // prefix P[0..iw], used for the sums, then for the squares
-    unsigned* P = lw;                                                    // (15 KB for a 4K row: fits next to an MFMA workgroup's 130 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lwraw[];   // prefix P[0..iw], used for the sums, then for the squares
+    TA* P = reinterpret_cast<TA*>(lwraw);                                    // (15 KB for a 4K 8-bit row: fits next to an MFMA workgroup's 130 KB)
     const int y = blockIdx.x;
-    const uchar* row = img + (size_t)blockIdx.z * iframe + (size_t)y * istep;
+    const TS* row = reinterpret_cast<const TS*>(img + (size_t)blockIdx.z * iframe + (size_t)y * istep);
     const int chunk = (iw + 255) / 256;
     const int x0 = threadIdx.x * chunk, x1 = min(iw, x0 + chunk);
-    unsigned s = 0, q = 0;
-    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; s += v; q += v * v; }
-    __shared__ unsigned ss[256], qq[256];
+    TA s = 0, q = 0;
+    for (int x = x0; x < x1; x++) { const TA v = (TA)row[x]; s += v; q += v * v; }
+    __shared__ TA ss[256], qq[256];
     ss[threadIdx.x] = s; qq[threadIdx.x] = q;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        unsigned a = 0, b = 0;
+        TA a = 0, b = 0;
         if ((int)threadIdx.x >= o) { a = ss[threadIdx.x - o]; b = qq[threadIdx.x - o]; }
         __syncthreads();
         ss[threadIdx.x] += a; qq[threadIdx.x] += b;
         __syncthreads();
     }
-    unsigned ps = threadIdx.x ? ss[threadIdx.x - 1] : 0u, pq = threadIdx.x ? qq[threadIdx.x - 1] : 0u;
-    unsigned* so = s1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
-    unsigned* qo = q1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
+    TA ps = threadIdx.x ? ss[threadIdx.x - 1] : (TA)0, pq = threadIdx.x ? qq[threadIdx.x - 1] : (TA)0;
+    TA* so = s1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
+    TA* qo = q1 + (size_t)blockIdx.z * sframe + (size_t)y * rw;
     if (threadIdx.x == 0) P[0] = 0;
-    for (int x = x0; x < x1; x++) { ps += row[x]; P[x + 1] = ps; }
+    for (int x = x0; x < x1; x++) { ps += (TA)row[x]; P[x + 1] = ps; }
     __syncthreads();
     for (int x = threadIdx.x; x < rw; x += 256) so[x] = P[x + tw] - P[x];
     __syncthreads();
-    for (int x = x0; x < x1; x++) { const unsigned v = row[x]; pq += v * v; P[x + 1] = pq; }
+    for (int x = x0; x < x1; x++) { const TA v = (TA)row[x]; pq += v * v; P[x + 1] = pq; }
     __syncthreads();
     for (int x = threadIdx.x; x < rw; x += 256) qo[x] = P[x + tw] - P[x];
 }
@@ -209,18 +211,19 @@ __global__ __launch_bounds__(256) void k_wsum_rows(const uchar* __restrict__ img
 constexpr int WS_CH = 128;
 // vertical window sums: one thread per column and chunk of WS_CH output rows; the loads of 8 rows are issued together (they do
 // not depend on the running sums), the sums then slide: + row (y+th-1), - row (y-1)
-__global__ __launch_bounds__(256) void k_wsum_cols(const unsigned* __restrict__ s1, const unsigned* __restrict__ q1, size_t sframe, int th, int rw, int rh,
-                                                   unsigned* __restrict__ w1, unsigned* __restrict__ w2, size_t wframe)
+template <typename TA>
+__global__ __launch_bounds__(256) void k_wsum_cols(const TA* __restrict__ s1, const TA* __restrict__ q1, size_t sframe, int th, int rw, int rh,
+                                                   TA* __restrict__ w1, TA* __restrict__ w2, size_t wframe)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= rw) return;
     const int y0 = blockIdx.y * WS_CH;
     s1 += (size_t)blockIdx.z * sframe + x; q1 += (size_t)blockIdx.z * sframe + x;
     w1 += (size_t)blockIdx.z * wframe + x; w2 += (size_t)blockIdx.z * wframe + x;
-    unsigned s = 0, q = 0;
+    TA s = 0, q = 0;
     int r = 0;
     for (; r + 8 <= th; r += 8) {
-        unsigned a[8], b[8];
+        TA a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) { a[u] = s1[(size_t)(y0 + r + u) * rw]; b[u] = q1[(size_t)(y0 + r + u) * rw]; }
 #pragma unroll
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_wsum_cols(const unsigned* __restrict__ 
     const int yend = min(rh, y0 + WS_CH);
     int y = y0 + 1;
     for (; y + 8 <= yend; y += 8) {
-        unsigned a[8], b[8], c[8], d[8];
+        TA a[8], b[8], c[8], d[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             a[u] = s1[(size_t)(y + u + th - 1) * rw]; b[u] = s1[(size_t)(y + u - 1) * rw];
@@ -918,6 +921,18 @@ __global__ __launch_bounds__(256) void k_tm_finish(float* __restrict__ res, size
     }
 }
 
+// the same for the CV_32FC1 path: `res` holds the raw float correlation (k_ccorr_bf16), the window sums are doubles
+__global__ __launch_bounds__(256) void k_tm_finish_f(float* __restrict__ res, size_t rstep, size_t rframe, const double* __restrict__ w1,
+                                                     const double* __restrict__ w2, size_t wframe, int rwp, const NormArgs* __restrict__ ap)
+{
+    const NormArgs a = *ap;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.rw || y >= a.rh) return;
+    float* p = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)blockIdx.z * rframe + (size_t)y * rstep) + x;
+    const size_t o = (size_t)blockIdx.z * wframe + (size_t)y * rwp + x;
+    *p = tmNormOne(*p, w1[o], w2[o], a);
+}
+
 __global__ __launch_bounds__(256) void k_tm_normalize(float* __restrict__ res, size_t rstep, size_t rframe,
                                                       const double* __restrict__ sum, const double* __restrict__ sq, size_t istep, size_t iframe, const NormArgs* __restrict__ ap)
 {
@@ -1101,7 +1116,12 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     // CV_8U with 2-4 channels: per-channel planes through the MFMA path (each a TM_CCORR of CV_8UC1, by this same function)
     const bool planes = depth == D8U && cn > 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 &&
                         (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH <= 160 * 1024 && !(std::getenv("MI355CV_TM_PLANES") && atoi(std::getenv("MI355CV_TM_PLANES")) == 0);
-    const bool needInt = method != 2 && !useMfma && !planes;
+    // CV_32FC1: three bf16 products on the matrix cores (k_ccorr_bf16) and window sums by a separable sliding box in double; MI355CV_TM_BF16=0 keeps the
+    // direct kernel + integral images
+    static const bool bf16Off = std::getenv("MI355CV_TM_BF16") && atoi(std::getenv("MI355CV_TM_BF16")) == 0;
+    const bool bf16Path = !bf16Off && depth == D32F && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0 &&
+                          (size_t)(iw + 1) * 8 <= 56 * 1024 && (dis & 3) == 0 && ((nframes > 1 ? iframe : 0) & 3) == 0 && ((uintptr_t)di & 3) == 0;
+    const bool needInt = method != 2 && !useMfma && !planes && !bf16Path;
     const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
     const size_t iframeD = isteps * (ih + 1);
     double* dsum = nullptr; double* dsq = nullptr;
@@ -1151,8 +1171,8 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         (void)hipStreamWaitEvent(aux, evIn, 0);
         for (int f = 0; f < nframes && !fused; f++) {
             const uchar* dif = di + (size_t)f * iframe;
-            hipLaunchKernelGGL(k_wsum_rows, dim3(ih, 1, 1), dim3(256), (size_t)(iw + 1) * 4, aux, dif, dis, 0, iw, tw, rw, s1 + f * s1frame, q1 + f * s1frame, s1frame);
-            hipLaunchKernelGGL(k_wsum_cols, dim3(divUp(rw, 256), divUp(rh, WS_CH), 1), dim3(256), 0, aux, s1 + f * s1frame, q1 + f * s1frame, s1frame, th, rw, rh,
+            hipLaunchKernelGGL((k_wsum_rows<uchar, unsigned>), dim3(ih, 1, 1), dim3(256), (size_t)(iw + 1) * 4, aux, dif, dis, 0, iw, tw, rw, s1 + f * s1frame, q1 + f * s1frame, s1frame);
+            hipLaunchKernelGGL((k_wsum_cols<unsigned>), dim3(divUp(rw, 256), divUp(rh, WS_CH), 1), dim3(256), 0, aux, s1 + f * s1frame, q1 + f * s1frame, s1frame, th, rw, rh,
                                w1 + f * wframe, w2 + f * wframe, wframe);
         }
         // frames per MFMA launch
@@ -1214,16 +1234,21 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
             if (done) return stg.finish(entry);
             if (method != 2) return setError(MI355CV_NOT_IMPLEMENTED, "%s: out of scratch memory for the per-channel planes", entry);   // (no integral images were built)
         }
-        // CV_32FC1: three bf16 products on the matrix cores (k_ccorr_bf16); MI355CV_TM_BF16=0 keeps the direct kernel
-        static const bool bf16Off = std::getenv("MI355CV_TM_BF16") && atoi(std::getenv("MI355CV_TM_BF16")) == 0;
-        if (!done && !bf16Off && depth == D32F && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0) {
+        if (!done && bf16Path) {
             const int ipitch = (iw + 7) & ~7;
             const size_t iplane = (size_t)ipitch * ih;
             unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2);
             unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2);
             unsigned short* thi = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
             unsigned short* tmid = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
-            if (ihi && imid && thi && tmid) {
+            // window sums of I and I^2 for every method but TM_CCORR: rows by an LDS prefix scan, columns by sliding sums, all in double
+            const size_t s1frame = (size_t)rw * ih, wframe = (size_t)rw * rh;
+            double *s1 = nullptr, *q1 = nullptr, *w1 = nullptr, *w2 = nullptr;
+            if (method != 2) {
+                s1 = (double*)stg.scratch(s1frame * nframes * 8); q1 = (double*)stg.scratch(s1frame * nframes * 8);
+                w1 = (double*)stg.scratch(wframe * nframes * 8); w2 = (double*)stg.scratch(wframe * nframes * 8);
+            }
+            if (ihi && imid && thi && tmid && (method == 2 || (s1 && q1 && w1 && w2))) {
                 hipLaunchKernelGGL(k_tm_split_bf16, dim3(divUp(ipitch, 64), divUp(ih, 4), nframes), dim3(256), 0, st, di, dis, nframes > 1 ? iframe : 0, iw, ih, ihi, imid, ipitch, iplane);
                 hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(th * BF_TE, 256)), dim3(256), 0, st, dt, dts, tw, th, thi, tmid);
                 const int KS = (tw + 31 + 15) / 16;                                           // K steps of 16 columns covering tw + 31
@@ -1238,8 +1263,16 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); } while (0)
                 switch (KS) { case 1: case 2: BF_LAUNCH(2); break; case 3: case 4: BF_LAUNCH(4); break; case 5: case 6: BF_LAUNCH(6); break; case 7: case 8: BF_LAUNCH(8); break; default: BF_LAUNCH(10); }
 #undef BF_LAUNCH
+                if (method != 2) {
+                    const NormArgs* dna = uploadStats(nullptr);
+                    if (!dna) return MI355CV_NOT_IMPLEMENTED;
+                    hipLaunchKernelGGL((k_wsum_rows<float, double>), dim3(ih, 1, nframes), dim3(256), (size_t)(iw + 1) * 8, st, di, dis, nframes > 1 ? iframe : 0, iw, tw, rw, s1, q1, s1frame);
+                    hipLaunchKernelGGL((k_wsum_cols<double>), dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
+                    hipLaunchKernelGGL(k_tm_finish_f, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, rf, drs, rfr, w1, w2, wframe, rw, dna);
+                }
                 noteKernel("k_ccorr_bf16<%d> x3 (hi*hi + hi*mid + mid*hi) grid=%ux%ux%u x256 lds=%zu", KS, gb.x, gb.y, gb.z, lds);
                 done = true;
+                return stg.finish(entry);
             }
         }
         dim3 grid(divUp(rw, 64), divUp(rh, 4), nframes);

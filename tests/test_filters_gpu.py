@@ -344,3 +344,23 @@ def test_submatrix_calls_stay_on_the_rolling_kernels(cv, orc):
             check(cv.boxFilter(dev(parent), -1, (5, 5), (-1, -1), True, border, roi=roi), orc.orc_boxFilter(parent, -1, (5, 5), (-1, -1), True, border, roi=roi))
             check(cv.boxFilter(dev(pf), -1, (3, 3), (-1, -1), True, border, roi=roi), orc.orc_boxFilter(pf, -1, (3, 3), (-1, -1), True, border, roi=roi), tol=1e-6)
     assert rolled >= 30, rolled
+
+
+def test_filter2d_f32_rolling(cv, orc):
+    """cv::filter2D CV_32FC1 -> CV_32FC1, 3x3 and 5x5 with a centred anchor, on the rolling kernel (delta + the taps in raster order, one FMA each): <= 1e-6 of the
+    restatement; other anchors / sizes / channel counts keep the generic kernel and the same bound"""
+    rng = np.random.default_rng(12)
+    for (w, h) in [(64, 23), (1040, 37), (333, 19), (4, 5), (2064, 70)]:
+        src = rnd((h, w), np.float32, w + h) * 200 - 50
+        for K in (3, 5):
+            k = rng.uniform(-1, 1, (K, K)).astype(np.float32)
+            for border in (0, 1, 2, 4):
+                check(cv.filter2D(dev(src), -1, k, (-1, -1), 0.75, border), orc.orc_filter2D(src, -1, k, (-1, -1), 0.75, border), tol=1e-6)
+                if w >= 64:
+                    assert "k_filter2d_roll_f32" in _kernel(cv), _kernel(cv)
+        check(cv.filter2D(dev(src), -1, SHARPEN, (-1, -1), 0.0, 4), orc.orc_filter2D(src, -1, SHARPEN, (-1, -1), 0.0, 4), tol=1e-6)
+    big = rnd((2160, 3840), np.float32, 3)
+    k = rng.uniform(-1, 1, (3, 3)).astype(np.float32)
+    check(cv.filter2D(dev(big), -1, k), orc.orc_filter2D(big, -1, k), tol=1e-6)
+    src3 = rnd((40, 64, 3), np.float32, 5)
+    check(cv.filter2D(dev(src3), -1, k), orc.orc_filter2D(src3, -1, k), tol=1e-6)
