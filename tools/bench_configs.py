@@ -315,7 +315,9 @@ def run(quick=False, parity=True):
             out.append({"config": name, "error": repr(e)})
     for name, fn in [("a1 GaussianBlur 5x5 sigma 1.2 4K 32FC1 batch", lambda: cv.sepFilter2DBatch(f32, -1, cv.getGaussianKernel(5, 1.2).astype(np.float32), cv.getGaussianKernel(5, 1.2).astype(np.float32), dst=o32)),
                      ("a4 Sobel dx 3x3 4K 32F->32F batch", lambda: cv.SobelBatch(f32, cv.CV_32F, 1, 0, 3, dst=o32)),
-                     ("a5 boxFilter 5x5 4K 32FC1 batch", lambda: cv.boxFilterBatch(f32, -1, (5, 5), dst=o32))]:
+                     ("a5 boxFilter 5x5 4K 32FC1 batch", lambda: cv.boxFilterBatch(f32, -1, (5, 5), dst=o32)),
+                     ("a3 filter2D 3x3 4K 32FC1 batch", lambda: cv.filter2DBatch(f32, -1, k, dst=o32)),
+                     ("a3 filter2D 5x5 4K 32FC1 batch", lambda: cv.filter2DBatch(f32, -1, k5, dst=o32))]:
         try:
             ms = timeit(fn, N, WARM)
             hbm_row(name, BF, ms, BF * PIX4 * 8)
