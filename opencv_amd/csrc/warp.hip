@@ -1291,6 +1291,7 @@ __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ sr
 #pragma unroll
         for (int k = 0; k < (KIND == 0 ? 8 : 12); k++) terms[k] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS)[k]);
         const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, terms);
+        if (CN == 1 && KIND == 0 && a.skipLean && warp8::leanTile(a, b)) continue;       // uniform: k_warp8_lean1 wrote this tile
         warp8::phaseB<CN, KIND>(a, b, x0, y0, src, w8lds, tid);
         __syncthreads();
         const unsigned redo = warp8::phaseC<CN, KIND, FETCH>(a, b, x0, y0, w8lds, dst, tid);
@@ -1300,6 +1301,27 @@ __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ sr
                 samplePixel(src, a.sstep, dst + (size_t)y * a.dstep + (size_t)x * CN, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
             });
         }
+    }
+}
+
+// the lean path of warp8.h: one channel, affine, tiles whose source box lies wholly inside the image; every other tile is left to k_warp8_tile (skipLean)
+__global__ __launch_bounds__(256) void k_warp8_lean1(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw)
+{
+    extern __shared__ __align__(16) uchar w8lds[];
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
+    const int tid = threadIdx.x, y0 = blockIdx.y * a.th;
+    bool staged = false;
+    for (int t = 0; t < tpw; t++) {
+        const int tx = blockIdx.x * tpw + t;
+        if (tx >= a.gx) break;                                                           // uniform
+        const int x0 = tx * warp8::TW;
+        const warp8::Box b = warp8::leanBox(a, x0, y0);
+        if (!warp8::leanTile(a, b)) continue;                                            // uniform
+        if (staged) __syncthreads();                                                     // the previous tile's taps are no longer read
+        warp8::leanStage(a, b, src, w8lds, tid);
+        __syncthreads();
+        warp8::leanRows(a, b, x0, y0, w8lds, dst, tid);
+        staged = true;
     }
 }
 
@@ -1388,11 +1410,17 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 1; return t < 1 ? 1 : t > 64 ? 64 : t; }();
             static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
+            static const bool leanOn = [] { const char* v = getenv("MI355CV_WARP8_LEAN"); return !v || atoi(v) != 0; }();
+            const bool lean = leanOn && kind == 0 && cn == 1 && a8.colT;
+            if (lean) {
+                hipLaunchKernelGGL(k_warp8_lean1, g8, dim3(256), (size_t)a8.ldsPitch * a8.ldsRows, stream(), ds, dd, a8, tpw);
+                a8.skipLean = 1;
+            }
 #define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
             if (kind == 0) { if (cn == 1) { if (fetch) W8(1, 0, 1); else W8(1, 0, 0); } else if (cn == 3) { if (fetch) W8(3, 0, 1); else W8(3, 0, 0); } else W8(4, 0, 0); }
             else           { if (cn == 1) { if (fetch) W8(1, 1, 1); else W8(1, 1, 0); } else if (cn == 3) { if (fetch) W8(3, 1, 1); else W8(3, 1, 0); } else W8(4, 1, 0); }
 #undef W8
-            noteKernel("k_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, kind, cn != 4 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+            noteKernel("%sk_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", lean ? "k_warp8_lean1 (inside tiles) + " : "", cn, kind, cn != 4 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
             return stg.finish(entry);
         }
         // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean

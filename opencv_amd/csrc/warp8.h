@@ -48,6 +48,7 @@ struct Args {
     const int* rowT;             //         by every tile in double arithmetic; rowX[dh], rowY[dh] likewise.  nullptr: evaluate in place
     int constBorder;             // BORDER_CONSTANT: a pixel whose whole 2x2 footprint is outside the source is the border value, no sampling
     uint32_t cval;               // the border value's channels as bytes (saturate_cast<uchar> of the cv::Scalar)
+    int skipLean;                // the general tile kernel leaves the tiles leanTile() accepts alone (k_warp8_lean1 served them)
 };
 
 W8_HD int satIntD(double v)
@@ -452,6 +453,160 @@ W8_HD void redoGroups(const Args& a, const Box& b, unsigned redo, int x0, int y0
     }
 }
 
+// ---- the lean path: one channel, affine map, tiles whose box lies wholly inside the source (Box::all) --------------------------------------------------
+// Most tiles of a call are of this kind, and for them nothing of the general machinery is needed: no per-pixel inside test, no border rule, no term tables in
+// LDS.  The tile kernel above spends ~63 VALU instructions per pixel (profiles/r03_warp8.txt: VALU-issue bound at 92 % busy); this path is written against
+// an instruction budget instead -- per pixel 2 adds, 2 shifts, 2 bit-field extracts, 1 multiply-add for the LDS offset, 3 address ops, two ds_read2_b32 +
+// two v_alignbyte for the 2 x 2 taps, v_dot4 per tap row with the weights (32 - ax, ax) packed as bytes, and d * ay + 32 h0 + 512 for the column: ~21.
+// LDS holds the source box only (offset 0, so that the reads' immediate offsets stay in range); rows are staged wave by wave with a scalar row base.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W8_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define W8_UNI(x) (x)
+#endif
+
+W8_HD int imad24(int x, int y, int z)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(x, y) + z;
+#else
+    return x * y + z;
+#endif
+}
+
+// LDS address of the tile as an integer (folded into the row terms, so that the taps' addresses need no base add), and a dword pair read from such an address
+W8_HD uint32_t ldsBaseOf(const unsigned char* tile)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)tile;
+#else
+    (void)tile; return 0u;
+#endif
+}
+W8_HD void ldsPair(const unsigned char* tile, uint32_t addr, uint32_t& lo, uint32_t& hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(3))) uint32_t* q = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)addr;
+    (void)tile; lo = q[0]; hi = q[1];
+#else
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(tile + addr); lo = q[0]; hi = q[1];
+#endif
+}
+// acc with byte B replaced by (v >> 10) & 255: one SDWA shift on the device instead of shift + mask + or
+template <int B> W8_HD uint32_t shr10IntoByte(uint32_t acc, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t ten = 10u;
+    if (B == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
+    if (B == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
+    if (B == 3) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
+    return acc;
+#else
+    return (acc & ~(255u << (8 * B))) | (((v >> 10) & 255u) << (8 * B));
+#endif
+}
+
+// the tile's box from the call's term tables: uniform over the workgroup (scalar loads, scalar arithmetic)
+W8_HD Box leanBox(const Args& a, int x0, int y0)
+{
+    int t[8];
+    for (int k = 0; k < 8; k++) { boxTerm<0>(a, x0, y0, k, t); t[k] = W8_UNI(t[k]); }
+    return boxFromTerms<1, 0>(a, t);
+}
+
+// what the lean path takes: term tables present, every footprint inside the staged box, and no staged dword reaching past the image's last byte
+W8_HD bool leanTile(const Args& a, const Box& b)
+{
+    if (!b.all || !a.colT || !a.rowT) return false;
+    const int endB = (b.cx0 & ~3) + (((b.shift + b.cw + 3) >> 2) << 2);                // one past the last staged byte of a row
+    return !(b.cy0 + b.ch == a.sh && endB > a.sw);
+}
+
+// wave w copies box rows w, w + 4, ...: lane = dword of the row, the row's base is scalar, NB rows' loads are in flight before the first LDS write
+W8_HD void leanStage(const Args& a, const Box& b, const unsigned char* src, unsigned char* tile, int tid)
+{
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63;
+    const uint32_t nd = (uint32_t)(b.shift + b.cw + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;
+    const uint32_t base = (uint32_t)b.cy0 * a.sstep + ((uint32_t)b.cx0 & ~3u);
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tile);
+    enum { NB = 8 };
+    for (uint32_t c0 = 0; c0 < nd; c0 += 64) {
+        const uint32_t c = c0 + (uint32_t)lane, cc = c < nd ? c : nd - 1;
+        for (int r0 = wave; r0 < b.ch; r0 += 4 * NB) {
+            uint32_t v[NB];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int u = 0; u < NB; u++) {
+                const int r = r0 + 4 * u < b.ch ? r0 + 4 * u : b.ch - 1;                 // clamped, not skipped: the loads stay unconditional
+                v[u] = *reinterpret_cast<const uint32_t*>(src + (base + (uint32_t)r * a.sstep) + 4 * cc);
+            }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int u = 0; u < NB; u++) {
+                const int r = r0 + 4 * u;
+                if (r < b.ch && c < nd) tw[(uint32_t)r * pd + c] = v[u];
+            }
+        }
+    }
+}
+
+// a lane = four horizontally adjacent destination pixels of one row per step, two rows per wave, eight rows per step of the workgroup
+W8_HD void leanRows(const Args& a, const Box& b, int x0, int y0, const unsigned char* tile, unsigned char* dst, int tid)
+{
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
+    const int x = x0 + lx * PX;
+    if (x >= a.dw) return;
+    const bool full = x + PX <= a.dw;
+    int cX[PX], cY[PX];
+    if (full) { for (int p = 0; p < PX; p++) { cX[p] = a.colT[x + p]; cY[p] = a.colT[a.dw + x + p]; } }
+    else      { for (int p = 0; p < PX; p++) { cX[p] = tcolX(a, x + p); cY[p] = tcolY(a, x + p); } }
+    constexpr int NSTEPS = tileRows<1>() / ROWS_PER_STEP;
+    const int fx = (b.shift - b.cx0 + (int)ldsBaseOf(tile)) * 1024, fy = -b.cy0 * 1024;   // box origin, in-dword shift and the tile's LDS address folded into the row terms
+    int rX[NSTEPS], rY[NSTEPS];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < NSTEPS; st++) {
+        int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        y = y < a.dh ? y : a.dh - 1;
+        rX[st] = a.rowT[y] + fx; rY[st] = a.rowT[a.dh + y] + fy;
+    }
+    const uint32_t pitch = (uint32_t)a.ldsPitch;
+    uint32_t doff = (uint32_t)(y0 + wave * 2 + ly) * a.dstep + (uint32_t)x;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < NSTEPS; st++) {
+        const int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        uint32_t off[PX], a0[PX], a1[PX], b0[PX], b1[PX], px[PX]; int tXs[PX], tYs[PX];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            const int tX = rX[st] + cX[p], tY = rY[st] + cY[p];                        // 1/1024 px relative to the box's first staged byte / row
+            off[p] = mad24((uint32_t)(tY >> 10), pitch, (uint32_t)(tX >> 10));
+            tXs[p] = tX; tYs[p] = tY;
+            ldsPair(tile, off[p] & ~3u, a0[p], a1[p]); ldsPair(tile, (off[p] & ~3u) + pitch, b0[p], b1[p]);
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            const uint32_t sh = off[p] & 3u, ax = ((uint32_t)tXs[p] >> 5) & 31u, ay = ((uint32_t)tYs[p] >> 5) & 31u;
+            const uint32_t wx = mad24(ax, 255u, 32u);                                  // (32 - ax) | ax << 8
+            const uint32_t h0 = dot4(alignbyte(a1[p], a0[p], sh), wx, 0u), h1 = dot4(alignbyte(b1[p], b0[p], sh), wx, 0u);
+            px[p] = (uint32_t)imad24((int)h1 - (int)h0, (int)ay, (int)(h0 * 32u + 512u));            // h0 (32 - ay) + h1 ay + 512: the pixel is bits 10..17
+        }
+        if (y < a.dh) {
+            if (full) *reinterpret_cast<uint32_t*>(dst + doff) = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[0] >> 10, px[1]), px[2]), px[3]);
+            else for (int p = 0; p < PX && x + p < a.dw; p++) dst[doff + p] = (unsigned char)(px[p] >> 10);
+        }
+        doff += (uint32_t)ROWS_PER_STEP * a.dstep;
+    }
+}
+
 // host side: can the tile kernel take this call, and with how much LDS?  Affine: the box of a tile has the same size everywhere (up to rounding);
 // perspective: the boxes of the tiles at the image's corners, edge centres and centre are measured with the kernel's own code.  Tiles whose box exceeds
 // what was allotted take the generic sampler inside the kernel, so the estimate bounds speed, never correctness.
@@ -488,6 +643,7 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
     if (!(bw < 4096 && bh < 4096)) return false;
     const int ibw = (int)bw + 1, ibh = (int)bh + 1;
     a.ldsPitch = ((ibw * cn + 3 + 3) & ~3) + 8;
+    if (!((a.ldsPitch >> 2) & 1)) a.ldsPitch += 4;           // an odd number of dwords per row: the taps of a slanted line step through the LDS banks instead of revisiting them
     a.ldsRows = ibh;
     a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
     *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;

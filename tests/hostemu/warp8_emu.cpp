@@ -7,7 +7,7 @@
 #include <vector>
 #include "warp8.h"
 
-template <int CN, int KIND, int FETCH>
+template <int CN, int KIND, int FETCH, bool LEAN = false>
 static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, const short* tab, const unsigned char* expect, size_t estep, long long* stats)
 {
     std::vector<unsigned char> lds(ldsBytes + 64);
@@ -15,6 +15,15 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
         for (int tx = 0; tx < a.gx; tx++) {
             const int x0 = tx * warp8::TW, y0 = ty * a.th;
             std::memset(lds.data(), 0xA5, lds.size());                      // stale LDS must never reach an output pixel
+            if (LEAN && CN == 1 && KIND == 0) {                              // k_warp8_lean1 first; the general kernel then skips what it served
+                const warp8::Box lb = warp8::leanBox(a, x0, y0);
+                if (warp8::leanTile(a, lb)) {
+                    for (int tid = 0; tid < 256; tid++) warp8::leanStage(a, lb, src, lds.data(), tid);
+                    for (int tid = 0; tid < 256; tid++) warp8::leanRows(a, lb, x0, y0, lds.data(), dst, tid);
+                    stats[4]++;
+                    continue;
+                }
+            }
             for (int tid = 0; tid < 256; tid++) warp8::phaseA<KIND>(a, x0, y0, lds.data(), tid);
             const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, reinterpret_cast<const int*>(lds.data() + warp8::OFF_TERMS));
             for (int tid = 0; tid < 256; tid++) warp8::phaseB<CN, KIND>(a, b, x0, y0, src, lds.data(), tid);
@@ -35,7 +44,8 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
     stats[0] = (long long)a.dw * a.dh - stats[1];
 }
 
-// stats: [0] pixels produced from the LDS tile, [1] pixels left to the generic sampler, [2] tiles with an exact all-inside box, [3] tiles with nothing staged
+// stats: [0] pixels produced from the LDS tile, [1] pixels left to the generic sampler, [2] tiles with an exact all-inside box, [3] tiles with nothing staged,
+//        [4] tiles served by the lean path (fetch bit 2, with the term tables of bit 1)
 extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, int kind, const double* M,
                          const short* tab, const unsigned char* expect, size_t estep, long long* stats, int constBorder, unsigned cval, int fetch)
 {
@@ -51,8 +61,10 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
         for (int i = 0; i < dh; i++) { tt[2 * dw + i] = warp8::affRowX(a, i); tt[2 * dw + dh + i] = warp8::affRowY(a, i); }
         a.colT = tt.data(); a.rowT = tt.data() + 2 * dw;
     }
+    const bool lean = (fetch & 4) && a.colT;
     fetch &= 1;
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    if (lean && kind == 0 && cn == 1) { run<1, 0, 1, true>(a, ldsBytes, src, dst, tab, expect, estep, stats); return 0; }
 #define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
     if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) { if (fetch) RUN(3, 0, 1); else RUN(3, 0, 0); } else RUN(4, 0, 0); }
     else           { if (cn == 1) { if (fetch) RUN(1, 1, 1); else RUN(1, 1, 0); } else if (cn == 3) { if (fetch) RUN(3, 1, 1); else RUN(3, 1, 0); } else RUN(4, 1, 0); }
