@@ -1264,9 +1264,10 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 
 
 // the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
-__global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT)
+__global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT, uint32_t* __restrict__ work)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && work) work[0] = 0;                                                     // the list of tiles k_warp8_lean1 leaves to k_warp8_tile_list
     if (i < a.dw) { colT[i] = warp8::affColX(a, i); colT[a.dw + i] = warp8::affColY(a, i); }
     if (i < a.dh) { rowT[i] = warp8::affRowX(a, i); rowT[a.dh + i] = warp8::affRowY(a, i); }
 }
@@ -1274,6 +1275,27 @@ __global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restr
 // ---- CV_8U bilinear warpAffine / warpPerspective through an LDS tile (warp8.h has the why and every phase; this is the launch geometry) ------------------
 // A workgroup walks TPW horizontally adjacent 128 x th tiles; per tile: box terms by
 // the first lanes -> barrier -> the source box into LDS + row / column terms -> barrier -> 16 (th = 32) or 8 destination pixels per thread.
+template <int CN, int KIND, int FETCH>
+__device__ __forceinline__ void warp8Tile(const uchar* __restrict__ src, uchar* __restrict__ dst, const SampleArgs& s, const warp8::Args& a, const short* __restrict__ tab,
+                                          uchar* w8lds, int x0, int y0, int tid)
+{
+    warp8::phaseA<KIND>(a, x0, y0, w8lds, tid);
+    __syncthreads();
+    int terms[12];                                                                   // wave-uniform: the box arithmetic runs on the scalar unit
+#pragma unroll
+    for (int k = 0; k < (KIND == 0 ? 8 : 12); k++) terms[k] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS)[k]);
+    const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, terms);
+    warp8::phaseB<CN, KIND>(a, b, x0, y0, src, w8lds, tid);
+    __syncthreads();
+    const unsigned redo = warp8::phaseC<CN, KIND, FETCH>(a, b, x0, y0, w8lds, dst, tid);
+    if (redo) {
+        // what the tile path left: partial footprints on the source's rim, the border rules other than CONSTANT, BORDER_TRANSPARENT -- the generic sampler's
+        warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, w8lds, tid, [&](int x, int y, int X, int Y) {
+            samplePixel(src, a.sstep, dst + (size_t)y * a.dstep + (size_t)x * CN, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
+        });
+    }
+}
+
 template <int CN, int KIND, int FETCH>
 __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tab, int tpw)
 {
@@ -1283,45 +1305,59 @@ __global__ __launch_bounds__(256) void k_warp8_tile(const uchar* __restrict__ sr
     for (int t = 0; t < tpw; t++) {
         const int tx = blockIdx.x * tpw + t;
         if (tx >= a.gx) break;                                                           // uniform
-        const int x0 = tx * warp8::TW;
         if (t) __syncthreads();                                                          // the previous tile's terms and pixels are no longer read
-        warp8::phaseA<KIND>(a, x0, y0, w8lds, tid);
-        __syncthreads();
-        int terms[12];                                                                   // wave-uniform: the box arithmetic runs on the scalar unit
-#pragma unroll
-        for (int k = 0; k < (KIND == 0 ? 8 : 12); k++) terms[k] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS)[k]);
-        const warp8::Box b = warp8::boxFromTerms<CN, KIND>(a, terms);
-        if (CN == 1 && KIND == 0 && a.skipLean && warp8::leanTile(a, b)) continue;       // uniform: k_warp8_lean1 wrote this tile
-        warp8::phaseB<CN, KIND>(a, b, x0, y0, src, w8lds, tid);
-        __syncthreads();
-        const unsigned redo = warp8::phaseC<CN, KIND, FETCH>(a, b, x0, y0, w8lds, dst, tid);
-        if (redo) {
-            // what the tile path left: partial footprints on the source's rim, the border rules other than CONSTANT, BORDER_TRANSPARENT -- the generic sampler's
-            warp8::redoGroups<CN, KIND>(a, b, redo, x0, y0, w8lds, tid, [&](int x, int y, int X, int Y) {
-                samplePixel(src, a.sstep, dst + (size_t)y * a.dstep + (size_t)x * CN, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
-            });
-        }
+        warp8Tile<CN, KIND, FETCH>(src, dst, s, a, tab, w8lds, tx * warp8::TW, y0, tid);
     }
 }
 
-// the lean path of warp8.h: one channel, affine, tiles whose source box lies wholly inside the image; every other tile is left to k_warp8_tile (skipLean)
-__global__ __launch_bounds__(256) void k_warp8_lean1(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw)
+// the same tile code over a list of tiles (work[0] = count, work[1..] = (frame * gy + ty) * gx + tx): what k_warp8_lean1 left -- the tiles on the source's rim
+template <int CN, int KIND, int FETCH>
+__global__ __launch_bounds__(256) void k_warp8_tile_list(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tab,
+                                                         const uint32_t* __restrict__ work)
+{
+    extern __shared__ __align__(16) uchar w8lds[];
+    const uint32_t count = work[0];
+    const int tid = threadIdx.x;
+    bool first = true;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {                           // uniform
+        const uint32_t id = work[1 + i];
+        const uint32_t tx = id % (uint32_t)a.gx, rest = id / (uint32_t)a.gx, ty = rest % (uint32_t)a.gy, f = rest / (uint32_t)a.gy;
+        if (!first) __syncthreads();
+        first = false;
+        warp8Tile<CN, KIND, FETCH>(src + (size_t)f * a.sframe, dst + (size_t)f * a.dframe, s, a, tab, w8lds, (int)tx * warp8::TW, (int)ty * a.th, tid);
+    }
+}
+
+// the lean path of warp8.h: one channel, affine, tiles whose source box lies wholly inside the image.  A workgroup walks `tpw` tiles of one tile row with the
+// NEXT tile's box in flight in registers while it samples the current one (two LDS buffers, one barrier per tile); the tiles it cannot take -- the source's
+// rim -- go on a list for k_warp8_tile_list.
+template <int LW, int NR>
+__global__ __launch_bounds__(256) void k_warp8_lean1(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw, uint32_t* __restrict__ work)
 {
     extern __shared__ __align__(16) uchar w8lds[];
     src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
-    const int tid = threadIdx.x, y0 = blockIdx.y * a.th;
-    bool staged = false;
-    for (int t = 0; t < tpw; t++) {
-        const int tx = blockIdx.x * tpw + t;
-        if (tx >= a.gx) break;                                                           // uniform
-        const int x0 = tx * warp8::TW;
-        const warp8::Box b = warp8::leanBox(a, x0, y0);
-        if (!warp8::leanTile(a, b)) continue;                                            // uniform
-        if (staged) __syncthreads();                                                     // the previous tile's taps are no longer read
-        warp8::leanStage(a, b, src, w8lds, tid);
-        __syncthreads();
-        warp8::leanRows(a, b, x0, y0, w8lds, dst, tid);
-        staged = true;
+    const int tid = threadIdx.x, y0 = blockIdx.y * a.th, tx0 = blockIdx.x * tpw, n = min(tpw, a.gx - tx0);
+    warp8::LeanRowT rt;
+    warp8::leanRowTerms(a, y0, tid, rt);
+    uint32_t v[NR];
+    auto load = [&](const warp8::LBox& b) {
+        if (b.kind == warp8::LEAN_INSIDE) warp8::leanLoad<LW, NR, false>(a, b, src, tid, v);
+        else if (b.kind == warp8::LEAN_RIM) warp8::leanLoad<LW, NR, true>(a, b, src, tid, v);
+    };
+    warp8::LBox b = warp8::leanClassify(a, tx0 * warp8::TW, y0);
+    load(b);
+    for (int t = 0; t < n; t++) {                                                        // uniform
+        uchar* buf = w8lds + (t & 1) * a.leanBuf;
+        const int x0 = (tx0 + t) * warp8::TW;
+        if (b.kind == warp8::LEAN_INSIDE || b.kind == warp8::LEAN_RIM) warp8::leanStore<LW, NR>(a, b, buf, tid, v);
+        else if (b.kind == warp8::LEAN_NO && tid == 0) work[1 + atomicAdd(work, 1u)] = ((uint32_t)blockIdx.z * (uint32_t)a.gy + blockIdx.y) * (uint32_t)a.gx + (uint32_t)(tx0 + t);
+        warp8::LBox bn = b; bn.kind = warp8::LEAN_NO;
+        if (t + 1 < n) { bn = warp8::leanClassify(a, x0 + warp8::TW, y0); load(bn); }    // in flight across the barrier and the sampling below
+        __syncthreads();                                                                 // tile t is in buf; tile t - 1's readers are past their sampling
+        if (b.kind == warp8::LEAN_INSIDE) warp8::leanRows<false>(a, b, x0, y0, buf, dst, tid, rt);
+        else if (b.kind == warp8::LEAN_RIM) warp8::leanRows<true>(a, b, x0, y0, buf, dst, tid, rt);
+        else if (b.kind == warp8::LEAN_OUTSIDE) warp8::leanFill(a, x0, y0, dst, tid);
+        b = bn;
     }
 }
 
@@ -1399,10 +1435,13 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         if (depth == D8U && warp8On && (warp8All == 2 || (kind == 0 && cn != 4)) && warp8::plan(a8, cn, kind, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8)) {
             a8.sframe = w.sframe; a8.dframe = w.dframe;
             a8.constBorder = borderType == B_CONSTANT;
+            static const bool leanOn = [] { const char* v = getenv("MI355CV_WARP8_LEAN"); return !v || atoi(v) != 0; }();
+            uint32_t* work = nullptr;                                                        // tiles the lean kernel leaves to the general one: [0] = count, then ids
             if (kind == 0) {
                 int* tt = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
+                if (tt && leanOn && cn == 1 && a8.leanLW) work = (uint32_t*)stg.scratch(((size_t)a8.gx * a8.gy * nframes + 1) * sizeof(uint32_t));
                 if (tt) {
-                    hipLaunchKernelGGL(k_warp8_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), a8, tt, tt + 2 * dw);
+                    hipLaunchKernelGGL(k_warp8_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), a8, tt, tt + 2 * dw, work);
                     a8.colT = tt; a8.rowT = tt + 2 * dw;
                 }
             }
@@ -1410,17 +1449,25 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 1; return t < 1 ? 1 : t > 64 ? 64 : t; }();
             static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
-            static const bool leanOn = [] { const char* v = getenv("MI355CV_WARP8_LEAN"); return !v || atoi(v) != 0; }();
-            const bool lean = leanOn && kind == 0 && cn == 1 && a8.colT;
-            if (lean) {
-                hipLaunchKernelGGL(k_warp8_lean1, g8, dim3(256), (size_t)a8.ldsPitch * a8.ldsRows, stream(), ds, dd, a8, tpw);
-                a8.skipLean = 1;
+            static const int leanTpw = [] { const char* v = getenv("MI355CV_WARP8_LEAN_TPW"); const int t = v ? atoi(v) : 6; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            if (work) {
+                dim3 gl(divUp(a8.gx, leanTpw), a8.gy, nframes);
+                const size_t ldsL = 2 * (size_t)a8.leanBuf;
+#define WLN(LW_, NR_) if (a8.leanLW == LW_ && a8.leanNR == NR_) hipLaunchKernelGGL((k_warp8_lean1<LW_, NR_>), gl, dim3(256), ldsL, stream(), ds, dd, a8, leanTpw, work)
+                WLN(16, 6); WLN(16, 10); WLN(16, 14); WLN(16, 20); WLN(32, 6); WLN(32, 10); WLN(32, 14); WLN(32, 20); WLN(64, 6); WLN(64, 10); WLN(64, 14); WLN(64, 20);
+#undef WLN
+                const unsigned nl = (unsigned)std::min<size_t>((size_t)a8.gx * a8.gy * nframes, 256 * 5);
+                if (fetch) hipLaunchKernelGGL((k_warp8_tile_list<1, 0, 1>), dim3(nl), dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, work);
+                else       hipLaunchKernelGGL((k_warp8_tile_list<1, 0, 0>), dim3(nl), dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, work);
+                noteKernel("k_warp8_lean1<%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu (BORDER_CONSTANT: every tile; else the tiles inside the source) + k_warp8_tile_list<1,0,%d> grid=%u (what it left) box<=%dx%d",
+                           a8.leanLW, a8.leanNR, gl.x, gl.y, gl.z, leanTpw, ldsL, fetch, nl, a8.ldsPitch - 8, a8.ldsRows);
+                return stg.finish(entry);
             }
 #define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)
             if (kind == 0) { if (cn == 1) { if (fetch) W8(1, 0, 1); else W8(1, 0, 0); } else if (cn == 3) { if (fetch) W8(3, 0, 1); else W8(3, 0, 0); } else W8(4, 0, 0); }
             else           { if (cn == 1) { if (fetch) W8(1, 1, 1); else W8(1, 1, 0); } else if (cn == 3) { if (fetch) W8(3, 1, 1); else W8(3, 1, 0); } else W8(4, 1, 0); }
 #undef W8
-            noteKernel("%sk_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", lean ? "k_warp8_lean1 (inside tiles) + " : "", cn, kind, cn != 4 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+            noteKernel("k_warp8_tile<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, kind, cn != 4 ? fetch : 0, g8.x, g8.y, g8.z, tpw, lds8, (a8.ldsPitch - 8) / cn, a8.ldsRows);
             return stg.finish(entry);
         }
         // XCD-banded tile order: off by default.  It paid 3 % on CV_32F while the kernel was bound by its own instruction count; with the lean

@@ -49,6 +49,8 @@ struct Args {
     int constBorder;             // BORDER_CONSTANT: a pixel whose whole 2x2 footprint is outside the source is the border value, no sampling
     uint32_t cval;               // the border value's channels as bytes (saturate_cast<uchar> of the cv::Scalar)
     int skipLean;                // the general tile kernel leaves the tiles leanTile() accepts alone (k_warp8_lean1 served them)
+    int leanLW, leanNR;          // k_warp8_lean1's staging geometry: lanes per box row (16 / 32 / 64; 0 = no lean path) and rounds per tile
+    uint32_t leanBuf;            // bytes per LDS tile buffer of the lean kernel (two of them)
 };
 
 W8_HD int satIntD(double v)
@@ -131,13 +133,13 @@ W8_HD uint32_t ld32(const unsigned char* p)
     typedef uint32_t u32u __attribute__((aligned(1)));
     return *reinterpret_cast<const u32u*>(p);
 }
-// ({hi, lo} >> 8 * sh) & 0xffffffff, sh in 0..3
+// ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
 W8_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 #else
-    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (sh & 3u)));
 #endif
 }
 
@@ -506,54 +508,139 @@ template <int B> W8_HD uint32_t shr10IntoByte(uint32_t acc, uint32_t v)
 #endif
 }
 
-// the tile's box from the call's term tables: uniform over the workgroup (scalar loads, scalar arithmetic)
-W8_HD Box leanBox(const Args& a, int x0, int y0)
+// A tile as the lean kernel sees it (uniform over the workgroup: scalar loads, scalar arithmetic):
+//   LEAN_INSIDE   every 2 x 2 footprint inside the source: plain staging, no per-pixel test
+//   LEAN_RIM      BORDER_CONSTANT and footprints that reach outside: the staged box is cut to columns -1 .. sw and rows -1 .. sh of the source with the border value
+//                 in the positions outside the image (an apron one pixel wide is all bilinear taps can see), and a pixel's coordinates are clamped to
+//                 (-1, fraction 0) / (sw, fraction 0): such a pixel's taps are border value either way.  Also the inside tiles whose last staged dword
+//                 would reach past the image's last byte, or whose box has fewer rows than a staging round (the predicated loads are safe there)
+//   LEAN_OUTSIDE  BORDER_CONSTANT and the whole tile outside: the border value, no staging
+//   LEAN_NO       the general kernel's (other border rules on the rim, boxes beyond the staging geometry)
+enum { LEAN_NO = 0, LEAN_INSIDE = 1, LEAN_RIM = 2, LEAN_OUTSIDE = 3 };
+struct LBox { int cx0, cy0, cw, ch, shift, kind; };
+
+W8_HD LBox leanClassify(const Args& a, int x0, int y0)
 {
+    LBox L = {0, 0, 0, 0, 0, LEAN_NO};
+    if (!a.colT || !a.rowT || !a.leanLW) return L;
     int t[8];
     for (int k = 0; k < 8; k++) { boxTerm<0>(a, x0, y0, k, t); t[k] = W8_UNI(t[k]); }
-    return boxFromTerms<1, 0>(a, t);
+    // as boxFromTerms: X(x, y) = (rowX(y) + colX(x)) >> 10 with monotone terms, so the extremes are sums of the terms' extremes
+    const int bx0 = ((t[0] < t[1] ? t[0] : t[1]) + (t[2] < t[3] ? t[2] : t[3])) >> 10, bx1 = (((t[0] > t[1] ? t[0] : t[1]) + (t[2] > t[3] ? t[2] : t[3])) >> 10) + 1;
+    const int by0 = ((t[4] < t[5] ? t[4] : t[5]) + (t[6] < t[7] ? t[6] : t[7])) >> 10, by1 = (((t[4] > t[5] ? t[4] : t[5]) + (t[6] > t[7] ? t[6] : t[7])) >> 10) + 1;
+    const bool inside = bx0 >= 0 && by0 >= 0 && bx1 <= a.sw - 1 && by1 <= a.sh - 1;
+    if (!inside) {
+        if (!a.constBorder) return L;
+        if (bx1 < 0 || bx0 >= a.sw || by1 < 0 || by0 >= a.sh) { L.kind = LEAN_OUTSIDE; return L; }
+    }
+    const int lo = inside ? 0 : -1, hx = inside ? a.sw - 1 : a.sw, hy = inside ? a.sh - 1 : a.sh;
+    L.cx0 = bx0 > lo ? bx0 : lo; L.cy0 = by0 > lo ? by0 : lo;
+    L.cw = (bx1 < hx ? bx1 : hx) - L.cx0 + 1; L.ch = (by1 < hy ? by1 : hy) - L.cy0 + 1;
+    L.shift = L.cx0 & 3;
+    const int rpl = 64 / a.leanLW;
+    if (L.ch > a.ldsRows || L.ch > a.leanNR * 4 * rpl || ((L.shift + L.cw + 3) & ~3) + 8 > a.ldsPitch) return L;
+    const int endB = (L.cx0 & ~3) + (((L.shift + L.cw + 3) >> 2) << 2);                // one past the last staged byte of a row
+    L.kind = inside && L.ch >= rpl && !(L.cy0 + L.ch == a.sh && endB > a.sw) ? LEAN_INSIDE : LEAN_RIM;
+    return L;
 }
 
-// what the lean path takes: term tables present, every footprint inside the staged box, and no staged dword reaching past the image's last byte
-W8_HD bool leanTile(const Args& a, const Box& b)
+// Staging in two halves, so that a workgroup can have the NEXT tile's box in flight (in registers) while it samples the current one out of LDS:
+//   leanLoad   NR dword loads per lane: lane = (row sub-index, dword) of a round of 64 / LW box rows; rounds past the box's last row are moved up to end on it
+//              and dwords right of the box read its last dword (duplicates land on the same LDS address with the same value).  INSIDE: no predication at
+//              all, the row base of a round is scalar.  RIM: a dword / row outside the image is the border value, a dword across the image's right edge is
+//              fetched from the row's last four bytes and shifted down (nothing is read past a row's last pixel)
+//   leanStore  the same indices into the tile
+template <int LW, int NR, bool RIM>
+W8_HD void leanLoad(const Args& a, const LBox& b, const unsigned char* src, int tid, uint32_t (&v)[NR])
 {
-    if (!b.all || !a.colT || !a.rowT) return false;
-    const int endB = (b.cx0 & ~3) + (((b.shift + b.cw + 3) >> 2) << 2);                // one past the last staged byte of a row
-    return !(b.cy0 + b.ch == a.sh && endB > a.sw);
-}
-
-// wave w copies box rows w, w + 4, ...: lane = dword of the row, the row's base is scalar, NB rows' loads are in flight before the first LDS write
-W8_HD void leanStage(const Args& a, const Box& b, const unsigned char* src, unsigned char* tile, int tid)
-{
-    const int wave = W8_UNI(tid >> 6), lane = tid & 63;
-    const uint32_t nd = (uint32_t)(b.shift + b.cw + 3) >> 2, pd = (uint32_t)a.ldsPitch >> 2;
-    const uint32_t base = (uint32_t)b.cy0 * a.sstep + ((uint32_t)b.cx0 & ~3u);
-    uint32_t* tw = reinterpret_cast<uint32_t*>(tile);
-    enum { NB = 8 };
-    for (uint32_t c0 = 0; c0 < nd; c0 += 64) {
-        const uint32_t c = c0 + (uint32_t)lane, cc = c < nd ? c : nd - 1;
-        for (int r0 = wave; r0 < b.ch; r0 += 4 * NB) {
-            uint32_t v[NB];
+    constexpr int RPL = 64 / LW;
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63, sub = lane / LW, c = lane % LW;
+    const int nd = (b.shift + b.cw + 3) >> 2, cc = c < nd ? c : nd - 1;
+    if (!RIM) {
+        const uint32_t laneOff = (uint32_t)sub * a.sstep + 4u * (uint32_t)cc;
+        const uint32_t base = (uint32_t)b.cy0 * a.sstep + ((uint32_t)b.cx0 & ~3u);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int u = 0; u < NB; u++) {
-                const int r = r0 + 4 * u < b.ch ? r0 + 4 * u : b.ch - 1;                 // clamped, not skipped: the loads stay unconditional
-                v[u] = *reinterpret_cast<const uint32_t*>(src + (base + (uint32_t)r * a.sstep) + 4 * cc);
-            }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int u = 0; u < NB; u++) {
-                const int r = r0 + 4 * u;
-                if (r < b.ch && c < nd) tw[(uint32_t)r * pd + c] = v[u];
-            }
+        for (int j = 0; j < NR; j++) {
+            int start = (j * 4 + wave) * RPL;
+            start = start < b.ch - RPL ? start : b.ch - RPL;
+            v[j] = *reinterpret_cast<const uint32_t*>(src + (base + (uint32_t)start * a.sstep) + laneOff);
         }
+    } else {
+        const int x4 = (b.cx0 & ~3) + 4 * cc;                                           // the dword's first source column: -4 (all apron) or >= 0
+        const int nvalid = x4 < 0 ? 0 : a.sw - x4 >= 4 ? 4 : a.sw - x4 > 0 ? a.sw - x4 : 0;      // bytes of it inside the image
+        const uint32_t cv4 = (a.cval & 255u) * 0x01010101u;
+        const uint32_t mask = nvalid >= 4 ? 0xffffffffu : (1u << (8 * nvalid)) - 1u, shr = nvalid > 0 && nvalid < 4 ? 8u * (uint32_t)(4 - nvalid) : 0u;
+        const int xl = nvalid > 0 && nvalid < 4 ? a.sw - 4 : x4;                        // sw >= 4 (plan)
+        typedef uint32_t u32u __attribute__((aligned(1)));
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int j = 0; j < NR; j++) {
+            int start = (j * 4 + wave) * RPL;
+            start = start < b.ch - RPL ? start : b.ch - RPL;
+            start = start > 0 ? start : 0;
+            const int y = b.cy0 + start + sub;
+            const bool in = nvalid > 0 && (unsigned)y < (unsigned)a.sh;
+            const uint32_t off = in ? (uint32_t)y * a.sstep + (uint32_t)xl : 0u;
+            const uint32_t w = *reinterpret_cast<const u32u*>(src + off) >> shr;
+            v[j] = in ? (w & mask) | (cv4 & ~mask) : cv4;
+        }
+    }
+}
+template <int LW, int NR>
+W8_HD void leanStore(const Args& a, const LBox& b, unsigned char* tile, int tid, const uint32_t (&v)[NR])
+{
+    constexpr int RPL = 64 / LW;
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63, sub = lane / LW, c = lane % LW;
+    const int nd = (b.shift + b.cw + 3) >> 2, cc = c < nd ? c : nd - 1;
+    const uint32_t laneOff = (uint32_t)sub * (uint32_t)a.ldsPitch + 4u * (uint32_t)cc;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NR; j++) {
+        int start = (j * 4 + wave) * RPL;
+        start = start < b.ch - RPL ? start : b.ch - RPL;
+        start = start > 0 ? start : 0;
+        *reinterpret_cast<uint32_t*>(tile + (uint32_t)start * (uint32_t)a.ldsPitch + laneOff) = v[j];
+    }
+}
+
+// the row terms of a lane's rows (the same for every tile of a tile row: loaded once per workgroup)
+struct LeanRowT { int rX[MAX_TH / ROWS_PER_STEP], rY[MAX_TH / ROWS_PER_STEP]; };
+W8_HD void leanRowTerms(const Args& a, int y0, int tid, LeanRowT& rt)
+{
+    const int wave = W8_UNI(tid >> 6), ly = (tid & 63) >> 5;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < tileRows<1>() / ROWS_PER_STEP; st++) {
+        int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        y = y < a.dh ? y : a.dh - 1;
+        rt.rX[st] = a.rowT[y]; rt.rY[st] = a.rowT[a.dh + y];
+    }
+}
+
+// a tile wholly outside the source under BORDER_CONSTANT
+W8_HD void leanFill(const Args& a, int x0, int y0, unsigned char* dst, int tid)
+{
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
+    const int x = x0 + lx * PX;
+    if (x >= a.dw) return;
+    const uint32_t cv4 = (a.cval & 255u) * 0x01010101u;
+    for (int st = 0; st < tileRows<1>() / ROWS_PER_STEP; st++) {
+        const int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        if (y >= a.dh) break;
+        unsigned char* d = dst + (uint32_t)y * a.dstep + (uint32_t)x;
+        if (x + PX <= a.dw) *reinterpret_cast<uint32_t*>(d) = cv4;
+        else for (int p = 0; x + p < a.dw; p++) d[p] = (unsigned char)cv4;
     }
 }
 
 // a lane = four horizontally adjacent destination pixels of one row per step, two rows per wave, eight rows per step of the workgroup
-W8_HD void leanRows(const Args& a, const Box& b, int x0, int y0, const unsigned char* tile, unsigned char* dst, int tid)
+template <bool RIM>
+W8_HD void leanRows(const Args& a, const LBox& b, int x0, int y0, const unsigned char* tile, unsigned char* dst, int tid, const LeanRowT& rt)
 {
     const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
     const int x = x0 + lx * PX;
@@ -563,16 +650,12 @@ W8_HD void leanRows(const Args& a, const Box& b, int x0, int y0, const unsigned 
     if (full) { for (int p = 0; p < PX; p++) { cX[p] = a.colT[x + p]; cY[p] = a.colT[a.dw + x + p]; } }
     else      { for (int p = 0; p < PX; p++) { cX[p] = tcolX(a, x + p); cY[p] = tcolY(a, x + p); } }
     constexpr int NSTEPS = tileRows<1>() / ROWS_PER_STEP;
-    const int fx = (b.shift - b.cx0 + (int)ldsBaseOf(tile)) * 1024, fy = -b.cy0 * 1024;   // box origin, in-dword shift and the tile's LDS address folded into the row terms
-    int rX[NSTEPS], rY[NSTEPS];
+    const int fx = (b.shift - b.cx0 + (int)ldsBaseOf(tile)) * 1024, fy = -b.cy0 * 1024;   // box origin, in-dword shift and the tile's LDS address folded into the terms
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int st = 0; st < NSTEPS; st++) {
-        int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
-        y = y < a.dh ? y : a.dh - 1;
-        rX[st] = a.rowT[y] + fx; rY[st] = a.rowT[a.dh + y] + fy;
-    }
+    for (int p = 0; p < PX; p++) { cX[p] += fx; cY[p] += fy; }
+    const int loX = fx - 1024, hiX = fx + a.sw * 1024, loY = fy - 1024, hiY = fy + a.sh * 1024;     // RIM: source column -1 / sw and row -1 / sh, fraction 0
     const uint32_t pitch = (uint32_t)a.ldsPitch;
     uint32_t doff = (uint32_t)(y0 + wave * 2 + ly) * a.dstep + (uint32_t)x;
 #if defined(__HIPCC__)
@@ -585,7 +668,8 @@ W8_HD void leanRows(const Args& a, const Box& b, int x0, int y0, const unsigned 
 #pragma unroll
 #endif
         for (int p = 0; p < PX; p++) {
-            const int tX = rX[st] + cX[p], tY = rY[st] + cY[p];                        // 1/1024 px relative to the box's first staged byte / row
+            int tX = rt.rX[st] + cX[p], tY = rt.rY[st] + cY[p];                        // 1/1024 px relative to the box's first staged byte / row
+            if (RIM) { tX = tX < loX ? loX : tX > hiX ? hiX : tX; tY = tY < loY ? loY : tY > hiY ? hiY : tY; }
             off[p] = mad24((uint32_t)(tY >> 10), pitch, (uint32_t)(tX >> 10));
             tXs[p] = tX; tYs[p] = tY;
             ldsPair(tile, off[p] & ~3u, a0[p], a1[p]); ldsPair(tile, (off[p] & ~3u) + pitch, b0[p], b1[p]);
@@ -594,10 +678,12 @@ W8_HD void leanRows(const Args& a, const Box& b, int x0, int y0, const unsigned 
 #pragma unroll
 #endif
         for (int p = 0; p < PX; p++) {
-            const uint32_t sh = off[p] & 3u, ax = ((uint32_t)tXs[p] >> 5) & 31u, ay = ((uint32_t)tYs[p] >> 5) & 31u;
+            // v_alignbyte_b32 shifts by its operand's two low bits (measured on gfx950, tools/probes/alignbyte.hip): the byte offset goes in unmasked
+            const uint32_t ax = ((uint32_t)tXs[p] >> 5) & 31u, ay = ((uint32_t)tYs[p] >> 5) & 31u;
             const uint32_t wx = mad24(ax, 255u, 32u);                                  // (32 - ax) | ax << 8
-            const uint32_t h0 = dot4(alignbyte(a1[p], a0[p], sh), wx, 0u), h1 = dot4(alignbyte(b1[p], b0[p], sh), wx, 0u);
-            px[p] = (uint32_t)imad24((int)h1 - (int)h0, (int)ay, (int)(h0 * 32u + 512u));            // h0 (32 - ay) + h1 ay + 512: the pixel is bits 10..17
+            // both row sums carry + 16 (the dot product's free addend): 32 (h0 + 16) = 32 h0 + 512 is the rounding term, and the difference is unchanged
+            const uint32_t h0 = dot4(alignbyte(a1[p], a0[p], off[p]), wx, 16u), h1 = dot4(alignbyte(b1[p], b0[p], off[p]), wx, 16u);
+            px[p] = (h0 << 5) + (uint32_t)imad24((int)h1 - (int)h0, (int)ay, 0);                       // h0 (32 - ay) + h1 ay + 512: the pixel is bits 10..17
         }
         if (y < a.dh) {
             if (full) *reinterpret_cast<uint32_t*>(dst + doff) = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[0] >> 10, px[1]), px[2]), px[3]);
@@ -647,6 +733,15 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
     a.ldsRows = ibh;
     a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
     *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;
+    if (cn == 1 && kind == 0) {
+        const int ndMax = a.ldsPitch / 4 - 2, lw = ndMax <= 16 ? 16 : ndMax <= 32 ? 32 : ndMax <= 64 ? 64 : 0;
+        if (lw) {
+            const int rounds = (a.ldsRows + 4 * (64 / lw) - 1) / (4 * (64 / lw));
+            a.leanLW = lw; a.leanNR = rounds <= 6 ? 6 : rounds <= 10 ? 10 : rounds <= 14 ? 14 : rounds <= 20 ? 20 : 0;
+            if (!a.leanNR) a.leanLW = 0;
+            a.leanBuf = ((uint32_t)a.ldsPitch * (uint32_t)a.ldsRows + 15u) & ~15u;
+        }
+    }
     return *ldsBytes <= 40 * 1024 && (size_t)a.ldsPitch / 4 * a.ldsRows < 65536;
 }
 

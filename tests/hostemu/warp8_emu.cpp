@@ -7,6 +7,25 @@
 #include <vector>
 #include "warp8.h"
 
+template <int LW, int NR>
+static void leanTileT(const warp8::Args& a, const warp8::LBox& b, int x0, int y0, const unsigned char* src, unsigned char* lds, unsigned char* dst)
+{
+    static uint32_t v[256][NR];                                             // every thread's staging registers, between the two halves of the staging
+    const bool rim = b.kind == warp8::LEAN_RIM;
+    for (int tid = 0; tid < 256; tid++) { if (rim) warp8::leanLoad<LW, NR, true>(a, b, src, tid, v[tid]); else warp8::leanLoad<LW, NR, false>(a, b, src, tid, v[tid]); }
+    for (int tid = 0; tid < 256; tid++) warp8::leanStore<LW, NR>(a, b, lds, tid, v[tid]);
+    for (int tid = 0; tid < 256; tid++) {
+        warp8::LeanRowT rt; warp8::leanRowTerms(a, y0, tid, rt);
+        if (rim) warp8::leanRows<true>(a, b, x0, y0, lds, dst, tid, rt); else warp8::leanRows<false>(a, b, x0, y0, lds, dst, tid, rt);
+    }
+}
+static void leanTileEmu(const warp8::Args& a, const warp8::LBox& b, int x0, int y0, const unsigned char* src, unsigned char* lds, unsigned char* dst)
+{
+#define LT(LW_, NR_) if (a.leanLW == LW_ && a.leanNR == NR_) return leanTileT<LW_, NR_>(a, b, x0, y0, src, lds, dst)
+    LT(16, 6); LT(16, 10); LT(16, 14); LT(16, 20); LT(32, 6); LT(32, 10); LT(32, 14); LT(32, 20); LT(64, 6); LT(64, 10); LT(64, 14); LT(64, 20);
+#undef LT
+}
+
 template <int CN, int KIND, int FETCH, bool LEAN = false>
 static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, const short* tab, const unsigned char* expect, size_t estep, long long* stats)
 {
@@ -15,12 +34,16 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
         for (int tx = 0; tx < a.gx; tx++) {
             const int x0 = tx * warp8::TW, y0 = ty * a.th;
             std::memset(lds.data(), 0xA5, lds.size());                      // stale LDS must never reach an output pixel
-            if (LEAN && CN == 1 && KIND == 0) {                              // k_warp8_lean1 first; the general kernel then skips what it served
-                const warp8::Box lb = warp8::leanBox(a, x0, y0);
-                if (warp8::leanTile(a, lb)) {
-                    for (int tid = 0; tid < 256; tid++) warp8::leanStage(a, lb, src, lds.data(), tid);
-                    for (int tid = 0; tid < 256; tid++) warp8::leanRows(a, lb, x0, y0, lds.data(), dst, tid);
-                    stats[4]++;
+            if (LEAN && CN == 1 && KIND == 0) {                              // k_warp8_lean1 first; the general kernel then takes what it left
+                const warp8::LBox lb = warp8::leanClassify(a, x0, y0);
+                if (lb.kind == warp8::LEAN_OUTSIDE) {
+                    for (int tid = 0; tid < 256; tid++) warp8::leanFill(a, x0, y0, dst, tid);
+                    stats[4]++; stats[6]++;
+                    continue;
+                }
+                if (lb.kind != warp8::LEAN_NO) {
+                    leanTileEmu(a, lb, x0, y0, src, lds.data(), dst);
+                    stats[4]++; stats[5] += lb.kind == warp8::LEAN_RIM;
                     continue;
                 }
             }
@@ -45,7 +68,7 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
 }
 
 // stats: [0] pixels produced from the LDS tile, [1] pixels left to the generic sampler, [2] tiles with an exact all-inside box, [3] tiles with nothing staged,
-//        [4] tiles served by the lean path (fetch bit 2, with the term tables of bit 1)
+//        [4] tiles served by the lean path (fetch bit 2, with the term tables of bit 1), [5] of them rim tiles, [6] tiles wholly outside
 extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, int kind, const double* M,
                          const short* tab, const unsigned char* expect, size_t estep, long long* stats, int constBorder, unsigned cval, int fetch)
 {
@@ -63,7 +86,7 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
     }
     const bool lean = (fetch & 4) && a.colT;
     fetch &= 1;
-    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = stats[5] = stats[6] = 0;
     if (lean && kind == 0 && cn == 1) { run<1, 0, 1, true>(a, ldsBytes, src, dst, tab, expect, estep, stats); return 0; }
 #define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
     if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) { if (fetch) RUN(3, 0, 1); else RUN(3, 0, 0); } else RUN(4, 0, 0); }

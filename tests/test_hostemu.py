@@ -69,7 +69,7 @@ def _emu_warp(emu8, src, M, dsize, kind, border=0, bval=(0, 0, 0, 0), fetch=0):
     M = np.ascontiguousarray(M, np.float64)
     want = (o.orc_warpAffine if kind == 0 else o.orc_warpPerspective)(src, M, dsize, 1, border, bval)
     got = np.full_like(want, 0x5A)
-    stats = (ctypes.c_longlong * 5)()
+    stats = (ctypes.c_longlong * 7)()
     cn = 1 if src.ndim == 2 else src.shape[2]
     rc = emu8.emu_warp8(o.P(src), o.step(src), src.shape[1], src.shape[0], o.P(got), o.step(got), dsize[0], dsize[1], cn, kind,
                         o.P(M), tab, o.P(want), o.step(want), stats, int(border == 0),
@@ -80,9 +80,9 @@ def _emu_warp(emu8, src, M, dsize, kind, border=0, bval=(0, 0, 0, 0), fetch=0):
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
     rng = np.random.default_rng(cn)
-    lean_tiles = [0]
+    lean_tiles = [0, 0, 0]
     for (sw, sh, dw, dh, deg, sc) in [(640, 360, 640, 360, 7.0, 0.95), (400, 300, 520, 260, -33.0, 1.1), (256, 200, 131, 77, 90.0, 1.0), (512, 128, 512, 128, 0.0, 1.0),
-                                      (300, 300, 300, 300, 45.0, 0.6), (640, 480, 1280, 960, 3.0, 2.0)]:
+                                      (300, 300, 300, 300, 45.0, 0.6), (640, 480, 1280, 960, 3.0, 2.0), (256, 200, 132, 80, 90.0, 1.0), (400, 300, 400, 300, 33.0, 1.3), (384, 384, 384, 384, 90.0, 1.0), (384, 384, 384, 384, 80.0, 0.9)]:
         shp = (sh, sw) if cn == 1 else (sh, sw, cn)
         src = rng.integers(0, 256, shp, dtype=np.uint8)
         if (sw * cn) % 4:
@@ -97,9 +97,11 @@ def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
                 continue                                                       # the plan declined (box too large for LDS): the old kernel serves it
             assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, border, fetch, int(np.count_nonzero(got != want)))
             if cn == 1 and fetch == 7:
-                lean_tiles[0] += st[4]
+                lean_tiles[0] += st[4]; lean_tiles[1] += st[5]; lean_tiles[2] += st[6]
+                if border == 0:
+                    assert st[1] == 0 or st[4] == 0, (sw, sh, deg, st)   # BORDER_CONSTANT: where the lean kernel applies it takes every tile, nothing is left to the sampler
             assert st[0] > (0.9 if border == 0 else 0.3) * dw * dh, (cn, deg, border, st)   # BORDER_CONSTANT: only the source's rim is left to the sampler
-    assert cn != 1 or lean_tiles[0] > 20, lean_tiles
+    assert cn != 1 or (lean_tiles[0] > 20 and lean_tiles[1] > 10 and lean_tiles[2] > 0), lean_tiles
 
 
 @pytest.mark.parametrize("cn", [1, 3, 4])
