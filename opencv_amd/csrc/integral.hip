@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_integral_tilesums(const uchar* __restri
                                                            int Wp, size_t auxFrame)
 {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = (int)xcdContiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);     // neighbouring tiles (shared output lines) behind the same L2
     const int tx = wid % nTx, ty = (wid / nTx) % nTy, f = wid / (nTx * nTy);
     if (f >= nframes) return;
     src += (size_t)f * sframe;
@@ -210,13 +210,13 @@ template <> struct Acc<int>    { typedef unsigned T; static __device__ __forcein
 template <> struct Acc<double> { typedef unsigned long long T; static __device__ __forceinline__ double out(unsigned long long v) { return (double)v; } };
 
 template <typename TS>
-__device__ __forceinline__ void storeRow4(TS* __restrict__ drow, int c, int Wc, const typename Acc<TS>::T (&a)[4])
+__device__ __forceinline__ void storeRow4(TS* __restrict__ drow, int c, int Wc, const typename Acc<TS>::T (&a)[4], bool nt = false)
 {
     if (c + 4 <= Wc) {
         if (sizeof(TS) == 4) {
             typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
             i4u v; v.x = (int)a[0]; v.y = (int)a[1]; v.z = (int)a[2]; v.w = (int)a[3];
-            *reinterpret_cast<i4u*>(drow + c) = v;
+            if (nt) __builtin_nontemporal_store(v, reinterpret_cast<i4u*>(drow + c)); else *reinterpret_cast<i4u*>(drow + c) = v;
         } else {
             typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
             d2u v0, v1; v0.x = (double)a[0]; v0.y = (double)a[1]; v1.x = (double)a[2]; v1.y = (double)a[3];
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void k_integral_tiles(const uchar* __restrict_
                                                         TS* __restrict__ sum, size_t sumStep, size_t sumFrame, double* __restrict__ sq, size_t sqStep, size_t sqFrame,
                                                         const unsigned* __restrict__ colsum, const unsigned* __restrict__ colsq, const unsigned* __restrict__ rowsum,
                                                         const unsigned* __restrict__ rowsq, const unsigned long long* __restrict__ cornerArr,
-                                                        const unsigned long long* __restrict__ cornerArrQ, int Wp, size_t auxFrame)
+                                                        const unsigned long long* __restrict__ cornerArrQ, int Wp, size_t auxFrame, int nt)
 {
     typedef typename Acc<TS>::T A;
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = (int)xcdContiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);     // neighbouring tiles (shared output lines) behind the same L2
     const int tx = wid % nTx, ty = (wid / nTx) % nTy, f = wid / (nTx * nTy);
     if (f >= nframes) return;
     src += (size_t)f * sframe; sum += (size_t)f * sumFrame;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_integral_tiles(const uchar* __restrict_
         const unsigned rc = (unsigned)__builtin_amdgcn_readlane((int)rcAll, r);
         const unsigned base = rc + (waveScanIncl(a3) - a3);
         top[0] += (A)(base + a0); top[1] += (A)(base + a1); top[2] += (A)(base + a2); top[3] += (A)(base + a3);
-        if (c < Wc) storeRow4<TS>(sum + (size_t)(y + 1) * sumStep, c, Wc, top);
+        if (c < Wc) storeRow4<TS>(sum + (size_t)(y + 1) * sumStep, c, Wc, top, nt != 0);
         if (SQ) {
             const unsigned b0 = p0 * p0, b1 = b0 + p1 * p1, b2 = b1 + p2 * p2, b3 = b2 + p3 * p3;
             const unsigned rq = (unsigned)__builtin_amdgcn_readlane((int)rqAll, r);
@@ -367,8 +367,9 @@ bool integralTiledU8(const uchar* src, size_t sstep, size_t sframe, int W, int H
     hipLaunchKernelGGL(k_integral_carries, dim3(divUp(W, 32) + divUp(H, 256) + 1, sq ? 2 : 1, nframes), blk, ((size_t)nTx * nTy + 16 * (size_t)nTx) * 8, st,
                        S.colsum, Q.colsum, S.rowsum, Q.rowsum, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.tileTot, Q.tileTot, S.corner, Q.corner,
                        W, H, Wp, nTx, nTy, perFrame, sq ? 1 : 0);
+    static const int nt = [] { const char* v = getenv("MI355CV_INTEGRAL_NT"); return v ? atoi(v) : 0; }();      // nontemporal sum stores (A/B runs)
 #define ITILES(TS_, SQ_) hipLaunchKernelGGL((k_integral_tiles<TS_, SQ_>), grid, blk, 0, st, src, sstep, sframe, W, H, nTx, nTy, nframes, (TS_*)sum, sumStepElems, sumFrameElems, \
-                                            sq, sqStepElems, sqFrameElems, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.corner, Q.corner, Wp, perFrame)
+                                            sq, sqStepElems, sqFrameElems, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.corner, Q.corner, Wp, perFrame, nt)
     if (sumIsDouble) { if (sq) ITILES(double, true); else ITILES(double, false); }
     else             { if (sq) ITILES(int, true); else ITILES(int, false); }
 #undef ITILES

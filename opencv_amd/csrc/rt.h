@@ -102,6 +102,18 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
 inline int depthBytes(int depth) { return depth <= 1 ? 1 : depth <= 3 ? 2 : depth <= 5 ? 4 : 8; }     // CV_8U .. CV_64F
 inline int divUp(int a, int b) { return (a + b - 1) / b; }
 
+#if defined(__HIPCC__)
+// Workgroups of a 1-D grid go to the 8 XCDs round-robin (id % 8), each XCD behind its own L2.  A kernel whose neighbouring workgroups write the two halves of
+// the same 128-byte lines (rows whose pitch is not a multiple of the line: cv::integral's (W + 1)-element rows) sends every such line to memory twice as a
+// partial write when the neighbours sit on different XCDs -- measured with tools/probes/fillbw2.hip: 3.1-3.9 TB/s for rows of 3841 ints against 6.5 TB/s
+// when each XCD owns one contiguous run of workgroups.  This is that mapping: logical id = (id % 8) * (n / 8) + id / 8 (the last n % 8 ids keep their own).
+__device__ __forceinline__ unsigned xcdContiguous(unsigned id, unsigned n)
+{
+    const unsigned per = n >> 3;
+    return id < (per << 3) ? (id & 7u) * per + (id >> 3) : id;
+}
+#endif
+
 #define MI355_CHECK_LAUNCH(entry)                                                        \
     do { hipError_t e__ = hipGetLastError();                                             \
          if (e__ != hipSuccess) return mi355::setError(MI355CV_ERROR_UNKNOWN, "%s: launch failed: %s", entry, hipGetErrorString(e__)); } while (0)

@@ -1328,35 +1328,35 @@ __global__ __launch_bounds__(256) void k_warp8_tile_list(const uchar* __restrict
     }
 }
 
-// the lean path of warp8.h: one channel, affine, tiles whose source box lies wholly inside the image.  A workgroup walks `tpw` tiles of one tile row with the
-// NEXT tile's box in flight in registers while it samples the current one (two LDS buffers, one barrier per tile); the tiles it cannot take -- the source's
-// rim -- go on a list for k_warp8_tile_list.
-template <int LW, int NR>
-__global__ __launch_bounds__(256) void k_warp8_lean1(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw, uint32_t* __restrict__ work)
+// the lean path of warp8.h: one or three channels, affine.  A workgroup walks `tpw` tiles of one tile row with the NEXT tile's box in flight in registers while
+// it samples the current one (two LDS buffers, one barrier per tile); the tiles it cannot take (the source's rim under a border rule other than CONSTANT, boxes
+// beyond its staging geometry) go on a list for k_warp8_tile_list.
+template <int CN, int LW, int NR>
+__global__ __launch_bounds__(256) void k_warp8_lean(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw, uint32_t* __restrict__ work)
 {
     extern __shared__ __align__(16) uchar w8lds[];
     src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
     const int tid = threadIdx.x, y0 = blockIdx.y * a.th, tx0 = blockIdx.x * tpw, n = min(tpw, a.gx - tx0);
     warp8::LeanRowT rt;
-    warp8::leanRowTerms(a, y0, tid, rt);
+    warp8::leanRowTerms<CN>(a, y0, tid, rt);
     uint32_t v[NR];
     auto load = [&](const warp8::LBox& b) {
-        if (b.kind == warp8::LEAN_INSIDE) warp8::leanLoad<LW, NR, false>(a, b, src, tid, v);
-        else if (b.kind == warp8::LEAN_RIM) warp8::leanLoad<LW, NR, true>(a, b, src, tid, v);
+        if (b.kind == warp8::LEAN_INSIDE) warp8::leanLoad<CN, LW, NR, false>(a, b, src, tid, v);
+        else if (b.kind == warp8::LEAN_RIM) warp8::leanLoad<CN, LW, NR, true>(a, b, src, tid, v);
     };
-    warp8::LBox b = warp8::leanClassify(a, tx0 * warp8::TW, y0);
+    warp8::LBox b = warp8::leanClassify<CN>(a, tx0 * warp8::TW, y0);
     load(b);
     for (int t = 0; t < n; t++) {                                                        // uniform
         uchar* buf = w8lds + (t & 1) * a.leanBuf;
         const int x0 = (tx0 + t) * warp8::TW;
-        if (b.kind == warp8::LEAN_INSIDE || b.kind == warp8::LEAN_RIM) warp8::leanStore<LW, NR>(a, b, buf, tid, v);
+        if (b.kind == warp8::LEAN_INSIDE || b.kind == warp8::LEAN_RIM) warp8::leanStore<CN, LW, NR>(a, b, buf, tid, v);
         else if (b.kind == warp8::LEAN_NO && tid == 0) work[1 + atomicAdd(work, 1u)] = ((uint32_t)blockIdx.z * (uint32_t)a.gy + blockIdx.y) * (uint32_t)a.gx + (uint32_t)(tx0 + t);
         warp8::LBox bn = b; bn.kind = warp8::LEAN_NO;
-        if (t + 1 < n) { bn = warp8::leanClassify(a, x0 + warp8::TW, y0); load(bn); }    // in flight across the barrier and the sampling below
+        if (t + 1 < n) { bn = warp8::leanClassify<CN>(a, x0 + warp8::TW, y0); load(bn); }  // in flight across the barrier and the sampling below
         __syncthreads();                                                                 // tile t is in buf; tile t - 1's readers are past their sampling
-        if (b.kind == warp8::LEAN_INSIDE) warp8::leanRows<false>(a, b, x0, y0, buf, dst, tid, rt);
-        else if (b.kind == warp8::LEAN_RIM) warp8::leanRows<true>(a, b, x0, y0, buf, dst, tid, rt);
-        else if (b.kind == warp8::LEAN_OUTSIDE) warp8::leanFill(a, x0, y0, dst, tid);
+        if (b.kind == warp8::LEAN_INSIDE) warp8::leanRows<CN, false>(a, b, x0, y0, buf, dst, tid, rt);
+        else if (b.kind == warp8::LEAN_RIM) warp8::leanRows<CN, true>(a, b, x0, y0, buf, dst, tid, rt);
+        else if (b.kind == warp8::LEAN_OUTSIDE) warp8::leanFill<CN>(a, x0, y0, dst, tid);
         b = bn;
     }
 }
@@ -1439,7 +1439,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             uint32_t* work = nullptr;                                                        // tiles the lean kernel leaves to the general one: [0] = count, then ids
             if (kind == 0) {
                 int* tt = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
-                if (tt && leanOn && cn == 1 && a8.leanLW) work = (uint32_t*)stg.scratch(((size_t)a8.gx * a8.gy * nframes + 1) * sizeof(uint32_t));
+                if (tt && leanOn && (cn == 1 || cn == 3) && a8.leanLW) work = (uint32_t*)stg.scratch(((size_t)a8.gx * a8.gy * nframes + 1) * sizeof(uint32_t));
                 if (tt) {
                     hipLaunchKernelGGL(k_warp8_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), a8, tt, tt + 2 * dw, work);
                     a8.colT = tt; a8.rowT = tt + 2 * dw;
@@ -1453,14 +1453,17 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             if (work) {
                 dim3 gl(divUp(a8.gx, leanTpw), a8.gy, nframes);
                 const size_t ldsL = 2 * (size_t)a8.leanBuf;
-#define WLN(LW_, NR_) if (a8.leanLW == LW_ && a8.leanNR == NR_) hipLaunchKernelGGL((k_warp8_lean1<LW_, NR_>), gl, dim3(256), ldsL, stream(), ds, dd, a8, leanTpw, work)
-                WLN(16, 6); WLN(16, 10); WLN(16, 14); WLN(16, 20); WLN(32, 6); WLN(32, 10); WLN(32, 14); WLN(32, 20); WLN(64, 6); WLN(64, 10); WLN(64, 14); WLN(64, 20);
+#define WLN(CN_, LW_, NR_) if (cn == CN_ && a8.leanLW == LW_ && a8.leanNR == NR_) hipLaunchKernelGGL((k_warp8_lean<CN_, LW_, NR_>), gl, dim3(256), ldsL, stream(), ds, dd, a8, leanTpw, work)
+#define WLS(CN_, LW_) WLN(CN_, LW_, 6); WLN(CN_, LW_, 10); WLN(CN_, LW_, 14); WLN(CN_, LW_, 20)
+                WLS(1, 16); WLS(1, 32); WLS(1, 64); WLS(3, 32); WLS(3, 64); WLS(3, 128); WLS(3, 256);
+#undef WLS
 #undef WLN
                 const unsigned nl = (unsigned)std::min<size_t>((size_t)a8.gx * a8.gy * nframes, 256 * 5);
-                if (fetch) hipLaunchKernelGGL((k_warp8_tile_list<1, 0, 1>), dim3(nl), dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, work);
-                else       hipLaunchKernelGGL((k_warp8_tile_list<1, 0, 0>), dim3(nl), dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, work);
-                noteKernel("k_warp8_lean1<%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu (BORDER_CONSTANT: every tile; else the tiles inside the source) + k_warp8_tile_list<1,0,%d> grid=%u (what it left) box<=%dx%d",
-                           a8.leanLW, a8.leanNR, gl.x, gl.y, gl.z, leanTpw, ldsL, fetch, nl, a8.ldsPitch - 8, a8.ldsRows);
+#define WTL(CN_, F_) hipLaunchKernelGGL((k_warp8_tile_list<CN_, 0, F_>), dim3(nl), dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, work)
+                if (cn == 1) { if (fetch) WTL(1, 1); else WTL(1, 0); } else { if (fetch) WTL(3, 1); else WTL(3, 0); }
+#undef WTL
+                noteKernel("k_warp8_lean<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu (BORDER_CONSTANT: every tile; else the tiles inside the source) + k_warp8_tile_list<%d,0,%d> grid=%u (what it left) box<=%dx%d",
+                           cn, a8.leanLW, a8.leanNR, gl.x, gl.y, gl.z, leanTpw, ldsL, cn, fetch, nl, (a8.ldsPitch - 8) / cn, a8.ldsRows);
                 return stg.finish(entry);
             }
 #define W8(CN_, K_, F_) hipLaunchKernelGGL((k_warp8_tile<CN_, K_, F_>), g8, dim3(256), lds8, stream(), ds, dd, s, a8, g_tabDev, tpw)

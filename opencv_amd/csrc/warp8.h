@@ -49,7 +49,7 @@ struct Args {
     int constBorder;             // BORDER_CONSTANT: a pixel whose whole 2x2 footprint is outside the source is the border value, no sampling
     uint32_t cval;               // the border value's channels as bytes (saturate_cast<uchar> of the cv::Scalar)
     int skipLean;                // the general tile kernel leaves the tiles leanTile() accepts alone (k_warp8_lean1 served them)
-    int leanLW, leanNR;          // k_warp8_lean1's staging geometry: lanes per box row (16 / 32 / 64; 0 = no lean path) and rounds per tile
+    int leanLW, leanNR;          // k_warp8_lean's staging geometry: threads per box row (16 .. 256; 0 = no lean path) and rounds per tile
     uint32_t leanBuf;            // bytes per LDS tile buffer of the lean kernel (two of them)
 };
 
@@ -519,6 +519,7 @@ template <int B> W8_HD uint32_t shr10IntoByte(uint32_t acc, uint32_t v)
 enum { LEAN_NO = 0, LEAN_INSIDE = 1, LEAN_RIM = 2, LEAN_OUTSIDE = 3 };
 struct LBox { int cx0, cy0, cw, ch, shift, kind; };
 
+template <int CN>
 W8_HD LBox leanClassify(const Args& a, int x0, int y0)
 {
     LBox L = {0, 0, 0, 0, 0, LEAN_NO};
@@ -536,50 +537,55 @@ W8_HD LBox leanClassify(const Args& a, int x0, int y0)
     const int lo = inside ? 0 : -1, hx = inside ? a.sw - 1 : a.sw, hy = inside ? a.sh - 1 : a.sh;
     L.cx0 = bx0 > lo ? bx0 : lo; L.cy0 = by0 > lo ? by0 : lo;
     L.cw = (bx1 < hx ? bx1 : hx) - L.cx0 + 1; L.ch = (by1 < hy ? by1 : hy) - L.cy0 + 1;
-    L.shift = L.cx0 & 3;
-    const int rpl = 64 / a.leanLW;
-    if (L.ch > a.ldsRows || L.ch > a.leanNR * 4 * rpl || ((L.shift + L.cw + 3) & ~3) + 8 > a.ldsPitch) return L;
-    const int endB = (L.cx0 & ~3) + (((L.shift + L.cw + 3) >> 2) << 2);                // one past the last staged byte of a row
-    L.kind = inside && L.ch >= rpl && !(L.cy0 + L.ch == a.sh && endB > a.sw) ? LEAN_INSIDE : LEAN_RIM;
+    L.shift = (L.cx0 * CN) & 3;
+    const int rpr = 256 / a.leanLW, nd4 = (L.shift + L.cw * CN + 3) & ~3;               // rows per staging round; staged bytes per row
+    if (L.ch > a.ldsRows || L.ch > a.leanNR * rpr || nd4 + 8 > a.ldsPitch || nd4 > 4 * a.leanLW) return L;
+    const int endB = ((L.cx0 * CN) & ~3) + nd4;                                         // one past the last staged byte of a row
+    L.kind = inside && L.ch >= rpr && !(L.cy0 + L.ch == a.sh && endB > a.sw * CN) ? LEAN_INSIDE : LEAN_RIM;
     return L;
 }
 
 // Staging in two halves, so that a workgroup can have the NEXT tile's box in flight (in registers) while it samples the current one out of LDS:
-//   leanLoad   NR dword loads per lane: lane = (row sub-index, dword) of a round of 64 / LW box rows; rounds past the box's last row are moved up to end on it
-//              and dwords right of the box read its last dword (duplicates land on the same LDS address with the same value).  INSIDE: no predication at
-//              all, the row base of a round is scalar.  RIM: a dword / row outside the image is the border value, a dword across the image's right edge is
-//              fetched from the row's last four bytes and shifted down (nothing is read past a row's last pixel)
+//   leanLoad   NR dword loads per thread: thread = (row sub-index, dword) of a round of 256 / LW box rows; rounds past the box's last row are moved up to end
+//              on it and dwords right of the box read its last dword (duplicates land on the same LDS address with the same value).  INSIDE: no predication
+//              at all, the row base of a round is scalar.  RIM: a dword / row outside the image is the border value (per channel), a dword across the
+//              image's right edge is fetched from the row's last four bytes and shifted down (nothing is read past a row's last pixel)
 //   leanStore  the same indices into the tile
-template <int LW, int NR, bool RIM>
+template <int CN, int LW, int NR, bool RIM>
 W8_HD void leanLoad(const Args& a, const LBox& b, const unsigned char* src, int tid, uint32_t (&v)[NR])
 {
-    constexpr int RPL = 64 / LW;
-    const int wave = W8_UNI(tid >> 6), lane = tid & 63, sub = lane / LW, c = lane % LW;
-    const int nd = (b.shift + b.cw + 3) >> 2, cc = c < nd ? c : nd - 1;
+    constexpr int RPR = 256 / LW;
+    const int sub = LW >= 64 ? W8_UNI(tid / LW) : tid / LW, c = tid % LW;
+    const int nd = (b.shift + b.cw * CN + 3) >> 2, cc = c < nd ? c : nd - 1;
     if (!RIM) {
         const uint32_t laneOff = (uint32_t)sub * a.sstep + 4u * (uint32_t)cc;
-        const uint32_t base = (uint32_t)b.cy0 * a.sstep + ((uint32_t)b.cx0 & ~3u);
+        const uint32_t base = (uint32_t)b.cy0 * a.sstep + ((uint32_t)(b.cx0 * CN) & ~3u);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int j = 0; j < NR; j++) {
-            int start = (j * 4 + wave) * RPL;
-            start = start < b.ch - RPL ? start : b.ch - RPL;
+            int start = j * RPR;
+            start = start < b.ch - RPR ? start : b.ch - RPR;
             v[j] = *reinterpret_cast<const uint32_t*>(src + (base + (uint32_t)start * a.sstep) + laneOff);
         }
     } else {
-        const int x4 = (b.cx0 & ~3) + 4 * cc;                                           // the dword's first source column: -4 (all apron) or >= 0
-        const int nvalid = x4 < 0 ? 0 : a.sw - x4 >= 4 ? 4 : a.sw - x4 > 0 ? a.sw - x4 : 0;      // bytes of it inside the image
-        const uint32_t cv4 = (a.cval & 255u) * 0x01010101u;
+        const int rowB = a.sw * CN;                                                     // bytes of pixels in a source row
+        const int x4 = ((b.cx0 * CN) & ~3) + 4 * cc;                                    // the dword's first byte in its row: -4 (all apron) or >= 0
+        const int nvalid = x4 < 0 ? 0 : rowB - x4 >= 4 ? 4 : rowB - x4 > 0 ? rowB - x4 : 0;      // bytes of it inside the image
+        uint32_t cv4 = 0;                                                               // the border value as this dword's bytes: byte i is channel (x4 + i) mod CN
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; i++) { const int ch = CN == 1 ? 0 : ((x4 + i) % CN + CN) % CN; cv4 |= ((a.cval >> (8 * ch)) & 255u) << (8 * i); }
         const uint32_t mask = nvalid >= 4 ? 0xffffffffu : (1u << (8 * nvalid)) - 1u, shr = nvalid > 0 && nvalid < 4 ? 8u * (uint32_t)(4 - nvalid) : 0u;
-        const int xl = nvalid > 0 && nvalid < 4 ? a.sw - 4 : x4;                        // sw >= 4 (plan)
+        const int xl = nvalid > 0 && nvalid < 4 ? rowB - 4 : x4;                        // rowB >= 4 (plan)
         typedef uint32_t u32u __attribute__((aligned(1)));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int j = 0; j < NR; j++) {
-            int start = (j * 4 + wave) * RPL;
-            start = start < b.ch - RPL ? start : b.ch - RPL;
+            int start = j * RPR;
+            start = start < b.ch - RPR ? start : b.ch - RPR;
             start = start > 0 ? start : 0;
             const int y = b.cy0 + start + sub;
             const bool in = nvalid > 0 && (unsigned)y < (unsigned)a.sh;
@@ -589,19 +595,19 @@ W8_HD void leanLoad(const Args& a, const LBox& b, const unsigned char* src, int 
         }
     }
 }
-template <int LW, int NR>
+template <int CN, int LW, int NR>
 W8_HD void leanStore(const Args& a, const LBox& b, unsigned char* tile, int tid, const uint32_t (&v)[NR])
 {
-    constexpr int RPL = 64 / LW;
-    const int wave = W8_UNI(tid >> 6), lane = tid & 63, sub = lane / LW, c = lane % LW;
-    const int nd = (b.shift + b.cw + 3) >> 2, cc = c < nd ? c : nd - 1;
+    constexpr int RPR = 256 / LW;
+    const int sub = LW >= 64 ? W8_UNI(tid / LW) : tid / LW, c = tid % LW;
+    const int nd = (b.shift + b.cw * CN + 3) >> 2, cc = c < nd ? c : nd - 1;
     const uint32_t laneOff = (uint32_t)sub * (uint32_t)a.ldsPitch + 4u * (uint32_t)cc;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < NR; j++) {
-        int start = (j * 4 + wave) * RPL;
-        start = start < b.ch - RPL ? start : b.ch - RPL;
+        int start = j * RPR;
+        start = start < b.ch - RPR ? start : b.ch - RPR;
         start = start > 0 ? start : 0;
         *reinterpret_cast<uint32_t*>(tile + (uint32_t)start * (uint32_t)a.ldsPitch + laneOff) = v[j];
     }
@@ -609,13 +615,14 @@ W8_HD void leanStore(const Args& a, const LBox& b, unsigned char* tile, int tid,
 
 // the row terms of a lane's rows (the same for every tile of a tile row: loaded once per workgroup)
 struct LeanRowT { int rX[MAX_TH / ROWS_PER_STEP], rY[MAX_TH / ROWS_PER_STEP]; };
+template <int CN>
 W8_HD void leanRowTerms(const Args& a, int y0, int tid, LeanRowT& rt)
 {
     const int wave = W8_UNI(tid >> 6), ly = (tid & 63) >> 5;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int st = 0; st < tileRows<1>() / ROWS_PER_STEP; st++) {
+    for (int st = 0; st < tileRows<CN>() / ROWS_PER_STEP; st++) {
         int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
         y = y < a.dh ? y : a.dh - 1;
         rt.rX[st] = a.rowT[y]; rt.rY[st] = a.rowT[a.dh + y];
@@ -623,23 +630,34 @@ W8_HD void leanRowTerms(const Args& a, int y0, int tid, LeanRowT& rt)
 }
 
 // a tile wholly outside the source under BORDER_CONSTANT
+template <int CN>
 W8_HD void leanFill(const Args& a, int x0, int y0, unsigned char* dst, int tid)
 {
     const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
     const int x = x0 + lx * PX;
     if (x >= a.dw) return;
-    const uint32_t cv4 = (a.cval & 255u) * 0x01010101u;
-    for (int st = 0; st < tileRows<1>() / ROWS_PER_STEP; st++) {
+    uint32_t cv[CN];                                                                    // the 4 * CN bytes of four border pixels
+    for (int k = 0; k < CN; k++) { cv[k] = 0; for (int i = 0; i < 4; i++) cv[k] |= ((a.cval >> (8 * ((4 * k + i) % CN))) & 255u) << (8 * i); }
+    for (int st = 0; st < tileRows<CN>() / ROWS_PER_STEP; st++) {
         const int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
         if (y >= a.dh) break;
-        unsigned char* d = dst + (uint32_t)y * a.dstep + (uint32_t)x;
-        if (x + PX <= a.dw) *reinterpret_cast<uint32_t*>(d) = cv4;
-        else for (int p = 0; x + p < a.dw; p++) d[p] = (unsigned char)cv4;
+        unsigned char* d = dst + (uint32_t)y * a.dstep + (uint32_t)x * CN;
+        if (x + PX <= a.dw) for (int k = 0; k < CN; k++) reinterpret_cast<uint32_t*>(d)[k] = cv[k];
+        else for (int i = 0; i < (a.dw - x) * CN; i++) d[i] = (unsigned char)(cv[i >> 2] >> (8 * (i & 3)));
     }
 }
 
+W8_HD uint32_t ldsOne(const unsigned char* tile, uint32_t addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)tile; return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)addr;
+#else
+    return *reinterpret_cast<const uint32_t*>(tile + addr);
+#endif
+}
+
 // a lane = four horizontally adjacent destination pixels of one row per step, two rows per wave, eight rows per step of the workgroup
-template <bool RIM>
+template <int CN, bool RIM>
 W8_HD void leanRows(const Args& a, const LBox& b, int x0, int y0, const unsigned char* tile, unsigned char* dst, int tid, const LeanRowT& rt)
 {
     const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
@@ -649,30 +667,34 @@ W8_HD void leanRows(const Args& a, const LBox& b, int x0, int y0, const unsigned
     int cX[PX], cY[PX];
     if (full) { for (int p = 0; p < PX; p++) { cX[p] = a.colT[x + p]; cY[p] = a.colT[a.dw + x + p]; } }
     else      { for (int p = 0; p < PX; p++) { cX[p] = tcolX(a, x + p); cY[p] = tcolY(a, x + p); } }
-    constexpr int NSTEPS = tileRows<1>() / ROWS_PER_STEP;
-    const int fx = (b.shift - b.cx0 + (int)ldsBaseOf(tile)) * 1024, fy = -b.cy0 * 1024;   // box origin, in-dword shift and the tile's LDS address folded into the terms
+    constexpr int NSTEPS = tileRows<CN>() / ROWS_PER_STEP;
+    // box origin folded into the column terms; one channel: also the in-dword shift and the tile's LDS address (a pixel is a byte, so they are pixels too)
+    const int sb = b.shift + (int)ldsBaseOf(tile);
+    const int fx = (CN == 1 ? sb - b.cx0 : -b.cx0) * 1024, fy = -b.cy0 * 1024;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int p = 0; p < PX; p++) { cX[p] += fx; cY[p] += fy; }
     const int loX = fx - 1024, hiX = fx + a.sw * 1024, loY = fy - 1024, hiY = fy + a.sh * 1024;     // RIM: source column -1 / sw and row -1 / sh, fraction 0
     const uint32_t pitch = (uint32_t)a.ldsPitch;
-    uint32_t doff = (uint32_t)(y0 + wave * 2 + ly) * a.dstep + (uint32_t)x;
+    uint32_t doff = (uint32_t)(y0 + wave * 2 + ly) * a.dstep + (uint32_t)x * CN;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int st = 0; st < NSTEPS; st++) {
         const int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
-        uint32_t off[PX], a0[PX], a1[PX], b0[PX], b1[PX], px[PX]; int tXs[PX], tYs[PX];
+        uint32_t off[PX], a0[PX], a1[PX], a2[PX], b0[PX], b1[PX], b2[PX], px[PX][CN]; int tXs[PX], tYs[PX];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int p = 0; p < PX; p++) {
-            int tX = rt.rX[st] + cX[p], tY = rt.rY[st] + cY[p];                        // 1/1024 px relative to the box's first staged byte / row
+            int tX = rt.rX[st] + cX[p], tY = rt.rY[st] + cY[p];                        // 1/1024 px relative to the box's origin
             if (RIM) { tX = tX < loX ? loX : tX > hiX ? hiX : tX; tY = tY < loY ? loY : tY > hiY ? hiY : tY; }
-            off[p] = mad24((uint32_t)(tY >> 10), pitch, (uint32_t)(tX >> 10));
+            if (CN == 1) off[p] = mad24((uint32_t)(tY >> 10), pitch, (uint32_t)(tX >> 10));
+            else off[p] = mad24((uint32_t)(tY >> 10), pitch, mad24((uint32_t)(tX >> 10), (uint32_t)CN, (uint32_t)sb));
             tXs[p] = tX; tYs[p] = tY;
             ldsPair(tile, off[p] & ~3u, a0[p], a1[p]); ldsPair(tile, (off[p] & ~3u) + pitch, b0[p], b1[p]);
+            if (CN == 3) { a2[p] = ldsOne(tile, (off[p] & ~3u) + 8u); b2[p] = ldsOne(tile, (off[p] & ~3u) + pitch + 8u); }
         }
 #if defined(__HIPCC__)
 #pragma unroll
@@ -680,14 +702,36 @@ W8_HD void leanRows(const Args& a, const LBox& b, int x0, int y0, const unsigned
         for (int p = 0; p < PX; p++) {
             // v_alignbyte_b32 shifts by its operand's two low bits (measured on gfx950, tools/probes/alignbyte.hip): the byte offset goes in unmasked
             const uint32_t ax = ((uint32_t)tXs[p] >> 5) & 31u, ay = ((uint32_t)tYs[p] >> 5) & 31u;
-            const uint32_t wx = mad24(ax, 255u, 32u);                                  // (32 - ax) | ax << 8
-            // both row sums carry + 16 (the dot product's free addend): 32 (h0 + 16) = 32 h0 + 512 is the rounding term, and the difference is unchanged
-            const uint32_t h0 = dot4(alignbyte(a1[p], a0[p], off[p]), wx, 16u), h1 = dot4(alignbyte(b1[p], b0[p], off[p]), wx, 16u);
-            px[p] = (h0 << 5) + (uint32_t)imad24((int)h1 - (int)h0, (int)ay, 0);                       // h0 (32 - ay) + h1 ay + 512: the pixel is bits 10..17
+            if (CN == 1) {
+                const uint32_t wx = mad24(ax, 255u, 32u);                              // (32 - ax) | ax << 8
+                // both row sums carry + 16 (the dot product's free addend): 32 (h0 + 16) = 32 h0 + 512 is the rounding term, and the difference is unchanged
+                const uint32_t h0 = dot4(alignbyte(a1[p], a0[p], off[p]), wx, 16u), h1 = dot4(alignbyte(b1[p], b0[p], off[p]), wx, 16u);
+                px[p][0] = (h0 << 5) + (uint32_t)imad24((int)h1 - (int)h0, (int)ay, 0);                // h0 (32 - ay) + h1 ay + 512: the pixel is bits 10..17
+            } else {
+                // the taps' 8 bytes (left pixel b0..b2, right pixel b3..b5) as two dwords per row; channel c's pair is bytes c and c + 3: the weights sit on
+                // bytes 0 and 3 and the data is shifted under them
+                const uint32_t wx = mad24(ax, 0xffffffu, 32u);                         // (32 - ax) | ax << 24
+                const uint32_t eA0 = alignbyte(a1[p], a0[p], off[p]), eA1 = alignbyte(a2[p], a1[p], off[p]);
+                const uint32_t eB0 = alignbyte(b1[p], b0[p], off[p]), eB1 = alignbyte(b2[p], b1[p], off[p]);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int c = 0; c < CN; c++) {
+                    const uint32_t h0 = dot4(c ? alignbyte(eA1, eA0, (uint32_t)c) : eA0, wx, 16u), h1 = dot4(c ? alignbyte(eB1, eB0, (uint32_t)c) : eB0, wx, 16u);
+                    px[p][c] = (h0 << 5) + (uint32_t)imad24((int)h1 - (int)h0, (int)ay, 0);
+                }
+            }
         }
         if (y < a.dh) {
-            if (full) *reinterpret_cast<uint32_t*>(dst + doff) = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[0] >> 10, px[1]), px[2]), px[3]);
-            else for (int p = 0; p < PX && x + p < a.dw; p++) dst[doff + p] = (unsigned char)(px[p] >> 10);
+            if (full) {
+                if (CN == 1) *reinterpret_cast<uint32_t*>(dst + doff) = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[0][0] >> 10, px[1][0]), px[2][0]), px[3][0]);
+                else {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(dst + doff);               // 12 bytes: (p0: c0 c1 c2, p1: c0) (p1: c1 c2, p2: c0 c1) (p2: c2, p3: c0 c1 c2)
+                    d[0] = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[0][0] >> 10, px[0][1 % CN]), px[0][2 % CN]), px[1][0]);
+                    d[1] = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[1][1 % CN] >> 10, px[1][2 % CN]), px[2][0]), px[2][1 % CN]);
+                    d[2] = shr10IntoByte<3>(shr10IntoByte<2>(shr10IntoByte<1>(px[2][2 % CN] >> 10, px[3][0]), px[3][1 % CN]), px[3][2 % CN]);
+                }
+            } else for (int p = 0; p < PX && x + p < a.dw; p++) for (int c = 0; c < CN; c++) dst[doff + p * CN + c] = (unsigned char)(px[p][c] >> 10);
         }
         doff += (uint32_t)ROWS_PER_STEP * a.dstep;
     }
@@ -733,12 +777,14 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
     a.ldsRows = ibh;
     a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
     *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;
-    if (cn == 1 && kind == 0) {
-        const int ndMax = a.ldsPitch / 4 - 2, lw = ndMax <= 16 ? 16 : ndMax <= 32 ? 32 : ndMax <= 64 ? 64 : 0;
-        if (lw) {
-            const int rounds = (a.ldsRows + 4 * (64 / lw) - 1) / (4 * (64 / lw));
+    if ((cn == 1 || cn == 3) && kind == 0 && sw * cn >= 4) {
+        // k_warp8_lean's staging geometry: LW threads per box row (the row's dwords, a power of two), 256 / LW rows per round, NR rounds in registers
+        const int ndMax = a.ldsPitch / 4 - 2;
+        int lw = 16; while (lw < ndMax) lw *= 2;
+        if (lw <= 256) {
+            const int rounds = (a.ldsRows + 256 / lw - 1) / (256 / lw);
             a.leanLW = lw; a.leanNR = rounds <= 6 ? 6 : rounds <= 10 ? 10 : rounds <= 14 ? 14 : rounds <= 20 ? 20 : 0;
-            if (!a.leanNR) a.leanLW = 0;
+            if (!a.leanNR || (cn == 1 && lw > 64) || (cn == 3 && lw < 32)) a.leanLW = 0;           // (the instantiated combinations)
             a.leanBuf = ((uint32_t)a.ldsPitch * (uint32_t)a.ldsRows + 15u) & ~15u;
         }
     }

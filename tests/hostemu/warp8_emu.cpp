@@ -7,22 +7,25 @@
 #include <vector>
 #include "warp8.h"
 
-template <int LW, int NR>
+template <int CN, int LW, int NR>
 static void leanTileT(const warp8::Args& a, const warp8::LBox& b, int x0, int y0, const unsigned char* src, unsigned char* lds, unsigned char* dst)
 {
     static uint32_t v[256][NR];                                             // every thread's staging registers, between the two halves of the staging
     const bool rim = b.kind == warp8::LEAN_RIM;
-    for (int tid = 0; tid < 256; tid++) { if (rim) warp8::leanLoad<LW, NR, true>(a, b, src, tid, v[tid]); else warp8::leanLoad<LW, NR, false>(a, b, src, tid, v[tid]); }
-    for (int tid = 0; tid < 256; tid++) warp8::leanStore<LW, NR>(a, b, lds, tid, v[tid]);
+    for (int tid = 0; tid < 256; tid++) { if (rim) warp8::leanLoad<CN, LW, NR, true>(a, b, src, tid, v[tid]); else warp8::leanLoad<CN, LW, NR, false>(a, b, src, tid, v[tid]); }
+    for (int tid = 0; tid < 256; tid++) warp8::leanStore<CN, LW, NR>(a, b, lds, tid, v[tid]);
     for (int tid = 0; tid < 256; tid++) {
-        warp8::LeanRowT rt; warp8::leanRowTerms(a, y0, tid, rt);
-        if (rim) warp8::leanRows<true>(a, b, x0, y0, lds, dst, tid, rt); else warp8::leanRows<false>(a, b, x0, y0, lds, dst, tid, rt);
+        warp8::LeanRowT rt; warp8::leanRowTerms<CN>(a, y0, tid, rt);
+        if (rim) warp8::leanRows<CN, true>(a, b, x0, y0, lds, dst, tid, rt); else warp8::leanRows<CN, false>(a, b, x0, y0, lds, dst, tid, rt);
     }
 }
+template <int CN>
 static void leanTileEmu(const warp8::Args& a, const warp8::LBox& b, int x0, int y0, const unsigned char* src, unsigned char* lds, unsigned char* dst)
 {
-#define LT(LW_, NR_) if (a.leanLW == LW_ && a.leanNR == NR_) return leanTileT<LW_, NR_>(a, b, x0, y0, src, lds, dst)
-    LT(16, 6); LT(16, 10); LT(16, 14); LT(16, 20); LT(32, 6); LT(32, 10); LT(32, 14); LT(32, 20); LT(64, 6); LT(64, 10); LT(64, 14); LT(64, 20);
+#define LT(LW_, NR_) if (a.leanLW == LW_ && a.leanNR == NR_) return leanTileT<CN, LW_, NR_>(a, b, x0, y0, src, lds, dst)
+#define LTS(LW_) LT(LW_, 6); LT(LW_, 10); LT(LW_, 14); LT(LW_, 20)
+    LTS(16); LTS(32); LTS(64); LTS(128); LTS(256);
+#undef LTS
 #undef LT
 }
 
@@ -34,15 +37,15 @@ static void run(const warp8::Args& a, size_t ldsBytes, const unsigned char* src,
         for (int tx = 0; tx < a.gx; tx++) {
             const int x0 = tx * warp8::TW, y0 = ty * a.th;
             std::memset(lds.data(), 0xA5, lds.size());                      // stale LDS must never reach an output pixel
-            if (LEAN && CN == 1 && KIND == 0) {                              // k_warp8_lean1 first; the general kernel then takes what it left
-                const warp8::LBox lb = warp8::leanClassify(a, x0, y0);
+            if constexpr (LEAN && (CN == 1 || CN == 3) && KIND == 0) {                              // k_warp8_lean1 first; the general kernel then takes what it left
+                const warp8::LBox lb = warp8::leanClassify<CN>(a, x0, y0);
                 if (lb.kind == warp8::LEAN_OUTSIDE) {
-                    for (int tid = 0; tid < 256; tid++) warp8::leanFill(a, x0, y0, dst, tid);
+                    for (int tid = 0; tid < 256; tid++) warp8::leanFill<CN>(a, x0, y0, dst, tid);
                     stats[4]++; stats[6]++;
                     continue;
                 }
                 if (lb.kind != warp8::LEAN_NO) {
-                    leanTileEmu(a, lb, x0, y0, src, lds.data(), dst);
+                    leanTileEmu<CN>(a, lb, x0, y0, src, lds.data(), dst);
                     stats[4]++; stats[5] += lb.kind == warp8::LEAN_RIM;
                     continue;
                 }
@@ -88,6 +91,7 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
     fetch &= 1;
     stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = stats[5] = stats[6] = 0;
     if (lean && kind == 0 && cn == 1) { run<1, 0, 1, true>(a, ldsBytes, src, dst, tab, expect, estep, stats); return 0; }
+    if (lean && kind == 0 && cn == 3) { run<3, 0, 1, true>(a, ldsBytes, src, dst, tab, expect, estep, stats); return 0; }
 #define RUN(CN_, K_, F_) run<CN_, K_, F_>(a, ldsBytes, src, dst, tab, expect, estep, stats)
     if (kind == 0) { if (cn == 1) { if (fetch) RUN(1, 0, 1); else RUN(1, 0, 0); } else if (cn == 3) { if (fetch) RUN(3, 0, 1); else RUN(3, 0, 0); } else RUN(4, 0, 0); }
     else           { if (cn == 1) { if (fetch) RUN(1, 1, 1); else RUN(1, 1, 0); } else if (cn == 3) { if (fetch) RUN(3, 1, 1); else RUN(3, 1, 0); } else RUN(4, 1, 0); }
