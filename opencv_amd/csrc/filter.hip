@@ -788,7 +788,8 @@ static bool tryFilterRoll(const FilterCtx* c, const uchar* ds, size_t dss, size_
     DenseTaps t; memset(&t, 0, sizeof t);
     for (const Tap2D& tp : c->taps) t.k[tp.dy * K + tp.dx] = tp.k;
     t.delta = c->delta;
-    const roll::Geom g = roll::geometry(W, H, c->cn, nframes, K == 3 ? 16 : 12, K);
+    // 5x5: 32-row segments (a 4-row halo re-read per 32 rows instead of per 12; 64 x 4K sweep, profiles/r03_roll_seg_sweep.txt: 0.356 -> 0.408 of HBM)
+    const roll::Geom g = roll::geometry(W, H, c->cn, nframes, K == 3 ? 16 : 32, K);
 #define FROLL(K_, CN_) hipLaunchKernelGGL((k_filter2d_roll<K_, CN_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, c->border, 1, t)
     if (K == 3) { if (c->cn == 1) FROLL(3, 1); else if (c->cn == 3) FROLL(3, 3); else FROLL(3, 4); }
     else FROLL(5, 1);
