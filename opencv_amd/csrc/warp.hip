@@ -1361,6 +1361,41 @@ __global__ __launch_bounds__(256) void k_warp8_lean(const uchar* __restrict__ sr
     }
 }
 
+// ---- CV_8U bilinear resize through the lean kernel's LDS pipeline (warp8.h "bilinear resize ... on the lean kernel's machinery") ------------------------------
+__global__ __launch_bounds__(256) void k_resize8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.dw) { int sx; uint32_t a01; warp8::rzColTerm(a, i, sx, a01); colT[i] = sx; colT[a.dw + i] = (int)a01; }
+    if (i < a.dh) { int y0, y1; uint32_t b0, b1; warp8::rzRowTerm(a, i, y0, y1, b0, b1); rowT[i] = y0; rowT[a.dh + i] = y1; rowT[2 * a.dh + i] = (int)b0; rowT[3 * a.dh + i] = (int)b1; }
+}
+
+template <int CN, int LW, int NR>
+__global__ __launch_bounds__(256) void k_resize8_lean(const uchar* __restrict__ src, uchar* __restrict__ dst, warp8::Args a, int tpw)
+{
+    extern __shared__ __align__(16) uchar w8lds[];
+    src += (size_t)blockIdx.z * a.sframe; dst += (size_t)blockIdx.z * a.dframe;
+    const int tid = threadIdx.x, y0 = blockIdx.y * a.th, tx0 = blockIdx.x * tpw, n = min(tpw, a.gx - tx0);
+    warp8::RzRowT rt;
+    warp8::rzRowTerms<CN>(a, y0, tid, rt);
+    uint32_t v[NR];
+    auto load = [&](const warp8::LBox& b) {
+        if (b.kind == warp8::LEAN_INSIDE) warp8::leanLoad<CN, LW, NR, false>(a, b, src, tid, v);
+        else if (b.kind == warp8::LEAN_RIM) warp8::leanLoad<CN, LW, NR, true>(a, b, src, tid, v);
+    };
+    warp8::LBox b = warp8::rzClassify<CN>(a, tx0 * warp8::TW, y0);
+    load(b);
+    for (int t = 0; t < n; t++) {                                                        // uniform
+        uchar* buf = w8lds + (t & 1) * a.leanBuf;
+        const int x0 = (tx0 + t) * warp8::TW;
+        if (b.kind != warp8::LEAN_NO) warp8::leanStore<CN, LW, NR>(a, b, buf, tid, v);
+        warp8::LBox bn = b; bn.kind = warp8::LEAN_NO;
+        if (t + 1 < n) { bn = warp8::rzClassify<CN>(a, x0 + warp8::TW, y0); load(bn); }
+        __syncthreads();
+        if (b.kind != warp8::LEAN_NO) warp8::rzRows<CN>(a, b, x0, y0, buf, dst, tid, rt);
+        b = bn;
+    }
+}
+
 bool depthOk(int d) { return d == D8U || d == D16U || d == D16S || d == D32F; }
 
 int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int sw, int sh, uchar* dst, size_t dstep, int dw, int dh,
@@ -1621,6 +1656,29 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         switch (depth) { case D8U: RA(uchar); break; case D16U: RA(unsigned short); break; case D16S: RA(short); break; default: RA(float); }
 #undef RA
         return stg.finish(entry);
+    }
+    if ((a.mode == 1 || a.mode == 2) && depth == D8U && (cn == 1 || cn == 3)) {
+        // the LDS pipeline of the lean warp kernel (four pixels per lane, dword stores, taps out of a staged tile); the plan bounds every tile's source box from the
+        // scale factors, so a planned call has no tile the kernel cannot take.  MI355CV_RESIZE8_LEAN=0 keeps the column-owning kernels (A/B runs)
+        static const int rzOn = [] { const char* v = getenv("MI355CV_RESIZE8_LEAN"); return v ? atoi(v) : 1; }();
+        warp8::Args a8; size_t ldsR = 0;
+        if (rzOn && warp8::planResize(a8, cn, src_width, src_height, dst_width, dst_height, dss, dds, ds, dd, a.scale_x, a.inv_x, a.scale_y, a.inv_y, a.mode == 2, &ldsR)) {
+            int* tt = (int*)stg.scratch((size_t)(2 * dst_width + 4 * dst_height) * sizeof(int));
+            if (tt) {
+                a8.sframe = a.sframe; a8.dframe = a.dframe;
+                hipLaunchKernelGGL(k_resize8_terms, dim3(divUp(std::max(dst_width, dst_height), 256)), dim3(256), 0, stream(), a8, tt, tt + 2 * dst_width);
+                a8.colT = tt; a8.rowT = tt + 2 * dst_width;
+                const int tpw = 6;
+                dim3 gl(divUp(a8.gx, tpw), a8.gy, nframes);
+#define RZN(CN_, LW_, NR_) if (cn == CN_ && a8.leanLW == LW_ && a8.leanNR == NR_) hipLaunchKernelGGL((k_resize8_lean<CN_, LW_, NR_>), gl, dim3(256), ldsR, stream(), ds, dd, a8, tpw)
+#define RZS(CN_, LW_) RZN(CN_, LW_, 6); RZN(CN_, LW_, 10); RZN(CN_, LW_, 14); RZN(CN_, LW_, 20)
+                RZS(1, 16); RZS(1, 32); RZS(1, 64); RZS(3, 32); RZS(3, 64); RZS(3, 128); RZS(3, 256);
+#undef RZS
+#undef RZN
+                noteKernel("k_resize8_lean<%d,%d,%d> grid=%ux%ux%u x256 tpw=%d lds=%zu box<=%dx%d", cn, a8.leanLW, a8.leanNR, gl.x, gl.y, gl.z, tpw, ldsR, (a8.ldsPitch - 8) / cn, a8.ldsRows);
+                return stg.finish(entry);
+            }
+        }
     }
     if ((a.mode == 1 || a.mode == 2) && cn == 1 && (depth == D32F || depth == D8U) && src_width >= 2 && (dss % e) == 0 && ((uintptr_t)ds % e) == 0) {
         dim3 g2(divUp(dst_width, 64), divUp(dst_height, 4 * RROWS), nframes);

@@ -51,6 +51,7 @@ struct Args {
     int skipLean;                // the general tile kernel leaves the tiles leanTile() accepts alone (k_warp8_lean1 served them)
     int leanLW, leanNR;          // k_warp8_lean's staging geometry: threads per box row (16 .. 256; 0 = no lean path) and rounds per tile
     uint32_t leanBuf;            // bytes per LDS tile buffer of the lean kernel (two of them)
+    double rzScaleX, rzInvX, rzScaleY, rzInvY; int rzArea;      // bilinear resize on the same machinery (k_resize8_lean): cv::resize's scale factors; INTER_AREA's coefficient form
 };
 
 W8_HD int satIntD(double v)
@@ -494,19 +495,20 @@ W8_HD void ldsPair(const unsigned char* tile, uint32_t addr, uint32_t& lo, uint3
     const uint32_t* q = reinterpret_cast<const uint32_t*>(tile + addr); lo = q[0]; hi = q[1];
 #endif
 }
-// acc with byte B replaced by (v >> 10) & 255: one SDWA shift on the device instead of shift + mask + or
-template <int B> W8_HD uint32_t shr10IntoByte(uint32_t acc, uint32_t v)
+// acc with byte B replaced by (v >> SH) & 255: one SDWA shift on the device instead of shift + mask + or
+template <int B, int SH> W8_HD uint32_t shrIntoByte(uint32_t acc, uint32_t v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t ten = 10u;
+    const uint32_t ten = (uint32_t)SH;
     if (B == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
     if (B == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
     if (B == 3) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "s"(ten), "v"(v));
     return acc;
 #else
-    return (acc & ~(255u << (8 * B))) | (((v >> 10) & 255u) << (8 * B));
+    return (acc & ~(255u << (8 * B))) | (((v >> SH) & 255u) << (8 * B));
 #endif
 }
+template <int B> W8_HD uint32_t shr10IntoByte(uint32_t acc, uint32_t v) { return shrIntoByte<B, 10>(acc, v); }
 
 // A tile as the lean kernel sees it (uniform over the workgroup: scalar loads, scalar arithmetic):
 //   LEAN_INSIDE   every 2 x 2 footprint inside the source: plain staging, no per-pixel test
@@ -737,6 +739,201 @@ W8_HD void leanRows(const Args& a, const LBox& b, int x0, int y0, const unsigned
     }
 }
 
+inline void leanGeometry(Args& a, int cn);
+
+// ---- bilinear resize of 8-bit images on the lean kernel's machinery (k_resize8_lean) -----------------------------------------------------------------------
+// cv::resize INTER_LINEAR on CV_8U (resize.cpp: HResizeLinear + VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>): coefficients of 11 bits,
+//   t = p0 a0 + p1 a1 per tap row,  pixel = (((b0 (t0 >> 4)) >> 16) + ((b1 (t1 >> 4)) >> 16) + 2) >> 2.
+// An axis-aligned map needs no per-pixel coordinate arithmetic at all: a pixel's LDS offset is (row part) + (column part), both from per-call tables
+// (k_resize8_terms) -- colT: sx[dw] (clamped like the reference's xofs), a0 | a1 << 16 [dw]; rowT: y0[dh], y1[dh] (clamped rows), b0 << 12 [dh], b1 << 12 [dh].
+// (b (t >> 4)) >> 16 is one v_mul_hi_u32_u24 of (t & ~15) and (b << 12); the tap pair of a row is one v_perm_b32 into two 16-bit lanes + one v_dot2_u32_u16.
+W8_HD int floorF(float v) { const int i = (int)v; return i - ((float)i > v); }
+W8_HD int floorD(double v) { const int i = (int)v; return i - ((double)i > v); }
+W8_HD int rintF(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float2int_rn(v);
+#else
+    return (int)__builtin_rintf(v);
+#endif
+}
+W8_HD void rzCoef(int d, double scale, double inv, int areaMode, int& s, float& f)       // resize.cpp:3897-3925 (linear) / :3870-3895 (INTER_AREA upscale)
+{
+    if (!areaMode) { f = (float)(dadd(dmul((double)d + 0.5, scale), -0.5)); s = floorF(f); f -= (float)s; }
+    else { s = floorD(dmul((double)d, scale)); f = (float)dadd((double)(d + 1), -dmul((double)(s + 1), inv)); f = f <= 0 ? 0.f : f - (float)floorF(f); }
+}
+W8_HD int sat16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+W8_HD void rzColTerm(const Args& a, int dx, int& sx, uint32_t& a01)
+{
+    float fx; rzCoef(dx, a.rzScaleX, a.rzInvX, a.rzArea, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; }
+    const int a0 = sat16(rintF((1.f - fx) * 2048)), a1 = sat16(rintF(fx * 2048));
+    a01 = (uint32_t)a0 | ((uint32_t)a1 << 16);
+}
+W8_HD void rzRowTerm(const Args& a, int dy, int& y0, int& y1, uint32_t& b0s, uint32_t& b1s)
+{
+    int sy; float fy; rzCoef(dy, a.rzScaleY, a.rzInvY, a.rzArea, sy, fy);
+    y0 = sy >= 0 ? (sy < a.sh ? sy : a.sh - 1) : 0; y1 = sy + 1 >= 0 ? (sy + 1 < a.sh ? sy + 1 : a.sh - 1) : 0;
+    b0s = (uint32_t)sat16(rintF((1.f - fy) * 2048)) << 12; b1s = (uint32_t)sat16(rintF(fy * 2048)) << 12;
+}
+W8_HD uint32_t mulhi24(uint32_t x, uint32_t y)                                           // bits 47:32 of the product of two 24-bit values
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r;
+#else
+    return (uint32_t)(((unsigned long long)x * y) >> 32);
+#endif
+}
+// bytes i0 and i1 (0..7) of the 8 bytes (hi:lo) as two 16-bit lanes
+template <int I0, int I1> W8_HD uint32_t bytePair(uint32_t hi, uint32_t lo)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)I0 | ((uint32_t)I1 << 16));
+#else
+    const unsigned long long q = ((unsigned long long)hi << 32) | lo;
+    return (uint32_t)((q >> (8 * I0)) & 255u) | ((uint32_t)((q >> (8 * I1)) & 255u) << 16);
+#endif
+}
+
+// the source box of a destination tile, from the tables (the clamped indices are monotone in the destination index); every position is inside the image
+template <int CN>
+W8_HD LBox rzClassify(const Args& a, int x0, int y0)
+{
+    LBox L = {0, 0, 0, 0, 0, LEAN_NO};
+    if (!a.colT || !a.rowT || !a.leanLW) return L;
+    const int x1 = (x0 + TW < a.dw ? x0 + TW : a.dw) - 1, y1 = (y0 + a.th < a.dh ? y0 + a.th : a.dh) - 1;
+    const int sa = W8_UNI(a.colT[x0]), sb = W8_UNI(a.colT[x1]), ya = W8_UNI(a.rowT[y0]), yb = W8_UNI(a.rowT[a.dh + y1]);
+    L.cx0 = sa; L.cy0 = ya;
+    L.cw = (sb + 1 < a.sw ? sb + 1 : a.sw - 1) - sa + 1; L.ch = yb - ya + 1;
+    L.shift = (L.cx0 * CN) & 3;
+    const int rpr = 256 / a.leanLW, nd4 = (L.shift + L.cw * CN + 3) & ~3;
+    if (L.cw < 1 || L.ch < 1 || L.ch > a.ldsRows || L.ch > a.leanNR * rpr || nd4 + 8 > a.ldsPitch || nd4 > 4 * a.leanLW) return L;
+    const int endB = ((L.cx0 * CN) & ~3) + nd4;
+    L.kind = L.ch >= rpr && !(L.cy0 + L.ch == a.sh && endB > a.sw * CN) ? LEAN_INSIDE : LEAN_RIM;       // RIM = the predicated loader (no apron is ever read)
+    return L;
+}
+
+struct RzRowT { int r0[MAX_TH / ROWS_PER_STEP], dy[MAX_TH / ROWS_PER_STEP]; uint32_t b0[MAX_TH / ROWS_PER_STEP], b1[MAX_TH / ROWS_PER_STEP]; };
+template <int CN>
+W8_HD void rzRowTerms(const Args& a, int y0, int tid, RzRowT& rt)
+{
+    const int wave = W8_UNI(tid >> 6), ly = (tid & 63) >> 5;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < tileRows<CN>() / ROWS_PER_STEP; st++) {
+        int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        y = y < a.dh ? y : a.dh - 1;
+        rt.r0[st] = a.rowT[y]; rt.dy[st] = a.rowT[a.dh + y] - rt.r0[st];
+        rt.b0[st] = (uint32_t)a.rowT[2 * a.dh + y]; rt.b1[st] = (uint32_t)a.rowT[3 * a.dh + y];
+    }
+}
+
+template <int CN>
+W8_HD void rzRows(const Args& a, const LBox& b, int x0, int y0, const unsigned char* tile, unsigned char* dst, int tid, const RzRowT& rt)
+{
+    const int wave = W8_UNI(tid >> 6), lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
+    const int x = x0 + lx * PX;
+    if (x >= a.dw) return;
+    const bool full = x + PX <= a.dw;
+    uint32_t colOff[PX], a01[PX];
+    const int sb = b.shift + (int)ldsBaseOf(tile) - b.cx0 * CN;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int p = 0; p < PX; p++) {
+        const int xx = x + p < a.dw ? x + p : a.dw - 1;
+        colOff[p] = (uint32_t)(a.colT[xx] * CN + sb); a01[p] = (uint32_t)a.colT[a.dw + xx];
+    }
+    constexpr int NSTEPS = tileRows<CN>() / ROWS_PER_STEP;
+    const uint32_t pitch = (uint32_t)a.ldsPitch;
+    uint32_t doff = (uint32_t)(y0 + wave * 2 + ly) * a.dstep + (uint32_t)x * CN;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < NSTEPS; st++) {
+        const int y = y0 + st * ROWS_PER_STEP + wave * 2 + ly;
+        const uint32_t rowOff = (uint32_t)(rt.r0[st] - b.cy0) * pitch, pitch2 = rt.dy[st] ? pitch : 0u, b0s = rt.b0[st], b1s = rt.b1[st];
+        uint32_t off[PX], a0[PX], a1[PX], a2[PX], b0[PX], b1[PX], b2[PX], px[PX][CN];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            off[p] = rowOff + colOff[p];
+            ldsPair(tile, off[p] & ~3u, a0[p], a1[p]); ldsPair(tile, (off[p] & ~3u) + pitch2, b0[p], b1[p]);
+            if (CN == 3) { a2[p] = ldsOne(tile, (off[p] & ~3u) + 8u); b2[p] = ldsOne(tile, (off[p] & ~3u) + pitch2 + 8u); }
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            const uint32_t eA0 = alignbyte(a1[p], a0[p], off[p]), eB0 = alignbyte(b1[p], b0[p], off[p]);
+            uint32_t eA1 = 0, eB1 = 0;
+            if (CN == 3) { eA1 = alignbyte(a2[p], a1[p], off[p]); eB1 = alignbyte(b2[p], b1[p], off[p]); }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int c = 0; c < CN; c++) {
+                const uint32_t pa = c == 0 ? bytePair<0, CN>(eA1, eA0) : c == 1 ? bytePair<1, 1 + CN>(eA1, eA0) : bytePair<2, 2 + CN>(eA1, eA0);
+                const uint32_t pb = c == 0 ? bytePair<0, CN>(eB1, eB0) : c == 1 ? bytePair<1, 1 + CN>(eB1, eB0) : bytePair<2, 2 + CN>(eB1, eB0);
+                const uint32_t t0 = dot2(pa, a01[p], 0u), t1 = dot2(pb, a01[p], 0u);
+                px[p][c] = mulhi24(t0 & ~15u, b0s) + mulhi24(t1 & ~15u, b1s) + 2u;            // the pixel is bits 2..9
+            }
+        }
+        if (y < a.dh) {
+            if (full) {
+                if (CN == 1) *reinterpret_cast<uint32_t*>(dst + doff) = shrIntoByte<3, 2>(shrIntoByte<2, 2>(shrIntoByte<1, 2>((px[0][0] >> 2) & 255u, px[1][0]), px[2][0]), px[3][0]);
+                else {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(dst + doff);
+                    d[0] = shrIntoByte<3, 2>(shrIntoByte<2, 2>(shrIntoByte<1, 2>((px[0][0] >> 2) & 255u, px[0][1 % CN]), px[0][2 % CN]), px[1][0]);
+                    d[1] = shrIntoByte<3, 2>(shrIntoByte<2, 2>(shrIntoByte<1, 2>((px[1][1 % CN] >> 2) & 255u, px[1][2 % CN]), px[2][0]), px[2][1 % CN]);
+                    d[2] = shrIntoByte<3, 2>(shrIntoByte<2, 2>(shrIntoByte<1, 2>((px[2][2 % CN] >> 2) & 255u, px[3][0]), px[3][1 % CN]), px[3][2 % CN]);
+                }
+            } else for (int p = 0; p < PX && x + p < a.dw; p++) for (int c = 0; c < CN; c++) dst[doff + p * CN + c] = (unsigned char)(px[p][c] >> 2);
+        }
+        doff += (uint32_t)ROWS_PER_STEP * a.dstep;
+    }
+}
+
+// host side: can k_resize8_lean take this bilinear resize?  (the box of a tile is TW x th destination pixels times the scale factors, + the second tap)
+inline bool planResize(Args& a, int cn, int sw, int sh, int dw, int dh, size_t sstep, size_t dstep, const void* src, const void* dst,
+                       double scale_x, double inv_x, double scale_y, double inv_y, int areaMode, size_t* ldsBytes)
+{
+    if (((uintptr_t)src | (uintptr_t)dst | sstep | dstep) & 3) return false;
+    if (sw < 2 || sh < 1 || dw < 1 || dh < 1 || (cn != 1 && cn != 3) || sw * cn < 4) return false;
+    if ((unsigned long long)sh * sstep >= (1ull << 32) || (unsigned long long)dh * dstep >= (1ull << 32)) return false;
+    if (!(scale_x > 0 && scale_x < 64 && scale_y > 0 && scale_y < 64)) return false;
+    a = Args();
+    a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh; a.sstep = (uint32_t)sstep; a.dstep = (uint32_t)dstep;
+    a.rzScaleX = scale_x; a.rzInvX = inv_x; a.rzScaleY = scale_y; a.rzInvY = inv_y; a.rzArea = areaMode;
+    a.th = cn == 1 ? tileRows<1>() : tileRows<3>();
+    a.gx = (dw + TW - 1) / TW; a.gy = (dh + a.th - 1) / a.th;
+    const int ibw = (int)(TW * scale_x) + 4, ibh = (int)(a.th * scale_y) + 4;
+    a.ldsPitch = ((ibw * cn + 3 + 3) & ~3) + 8;
+    if (!((a.ldsPitch >> 2) & 1)) a.ldsPitch += 4;
+    a.ldsRows = ibh;
+    leanGeometry(a, cn);
+    *ldsBytes = 2 * (size_t)a.leanBuf;
+    return a.leanLW != 0;
+}
+
+// the lean kernels' staging geometry for a call whose LDS box is ldsPitch x ldsRows: LW threads per box row (the row's dwords, a power of two), 256 / LW rows
+// per round, NR rounds in registers; two LDS buffers within the 64 KB a workgroup may ask for
+inline void leanGeometry(Args& a, int cn)
+{
+    a.leanLW = a.leanNR = 0;
+    const int ndMax = a.ldsPitch / 4 - 2;
+    int lw = 16; while (lw < ndMax) lw *= 2;
+    if (lw > 256) return;
+    const int rounds = (a.ldsRows + 256 / lw - 1) / (256 / lw);
+    const int nr = rounds <= 6 ? 6 : rounds <= 10 ? 10 : rounds <= 14 ? 14 : rounds <= 20 ? 20 : 0;
+    if (!nr || (cn == 1 && lw > 64) || (cn == 3 && lw < 32)) return;                   // (the instantiated combinations)
+    a.leanBuf = ((uint32_t)a.ldsPitch * (uint32_t)a.ldsRows + 15u) & ~15u;
+    if (2 * (size_t)a.leanBuf > 64 * 1024) return;
+    a.leanLW = lw; a.leanNR = nr;
+}
+
 // host side: can the tile kernel take this call, and with how much LDS?  Affine: the box of a tile has the same size everywhere (up to rounding);
 // perspective: the boxes of the tiles at the image's corners, edge centres and centre are measured with the kernel's own code.  Tiles whose box exceeds
 // what was allotted take the generic sampler inside the kernel, so the estimate bounds speed, never correctness.
@@ -777,17 +974,7 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
     a.ldsRows = ibh;
     a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
     *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;
-    if ((cn == 1 || cn == 3) && kind == 0 && sw * cn >= 4) {
-        // k_warp8_lean's staging geometry: LW threads per box row (the row's dwords, a power of two), 256 / LW rows per round, NR rounds in registers
-        const int ndMax = a.ldsPitch / 4 - 2;
-        int lw = 16; while (lw < ndMax) lw *= 2;
-        if (lw <= 256) {
-            const int rounds = (a.ldsRows + 256 / lw - 1) / (256 / lw);
-            a.leanLW = lw; a.leanNR = rounds <= 6 ? 6 : rounds <= 10 ? 10 : rounds <= 14 ? 14 : rounds <= 20 ? 20 : 0;
-            if (!a.leanNR || (cn == 1 && lw > 64) || (cn == 3 && lw < 32)) a.leanLW = 0;           // (the instantiated combinations)
-            a.leanBuf = ((uint32_t)a.ldsPitch * (uint32_t)a.ldsRows + 15u) & ~15u;
-        }
-    }
+    if ((cn == 1 || cn == 3) && kind == 0 && sw * cn >= 4) leanGeometry(a, cn);
     return *ldsBytes <= 40 * 1024 && (size_t)a.ldsPitch / 4 * a.ldsRows < 65536;
 }
 

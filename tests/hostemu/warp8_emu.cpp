@@ -98,3 +98,47 @@ extern "C" int emu_warp8(const unsigned char* src, size_t sstep, int sw, int sh,
 #undef RUN
     return 0;
 }
+
+
+// ---- bilinear resize on the lean machinery (k_resize8_lean): tables as k_resize8_terms builds them, every tile through rzClassify / leanLoad / leanStore / rzRows ----
+template <int CN, int LW, int NR>
+static void rzTileT(const warp8::Args& a, const warp8::LBox& b, int x0, int y0, const unsigned char* src, unsigned char* lds, unsigned char* dst)
+{
+    static uint32_t v[256][NR];
+    const bool rim = b.kind == warp8::LEAN_RIM;
+    for (int tid = 0; tid < 256; tid++) { if (rim) warp8::leanLoad<CN, LW, NR, true>(a, b, src, tid, v[tid]); else warp8::leanLoad<CN, LW, NR, false>(a, b, src, tid, v[tid]); }
+    for (int tid = 0; tid < 256; tid++) warp8::leanStore<CN, LW, NR>(a, b, lds, tid, v[tid]);
+    for (int tid = 0; tid < 256; tid++) { warp8::RzRowT rt; warp8::rzRowTerms<CN>(a, y0, tid, rt); warp8::rzRows<CN>(a, b, x0, y0, lds, dst, tid, rt); }
+}
+template <int CN>
+static int rzRun(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, long long* stats)
+{
+    std::vector<unsigned char> lds(ldsBytes + 64);
+    for (int ty = 0; ty < a.gy; ty++)
+        for (int tx = 0; tx < a.gx; tx++) {
+            const int x0 = tx * warp8::TW, y0 = ty * a.th;
+            std::memset(lds.data(), 0xA5, lds.size());
+            const warp8::LBox b = warp8::rzClassify<CN>(a, x0, y0);
+            if (b.kind == warp8::LEAN_NO) { stats[1]++; continue; }
+            stats[0]++; stats[2] += b.kind == warp8::LEAN_RIM;
+#define LT(LW_, NR_) if (a.leanLW == LW_ && a.leanNR == NR_) rzTileT<CN, LW_, NR_>(a, b, x0, y0, src, lds.data(), dst)
+#define LTS(LW_) LT(LW_, 6); LT(LW_, 10); LT(LW_, 14); LT(LW_, 20)
+            LTS(16); LTS(32); LTS(64); LTS(128); LTS(256);
+#undef LTS
+#undef LT
+        }
+    return 0;
+}
+// stats: [0] tiles served, [1] tiles declined (their pixels stay untouched), [2] tiles through the predicated loader
+extern "C" int emu_resize8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn,
+                           double inv_scale_x, double inv_scale_y, int areaMode, long long* stats)
+{
+    warp8::Args a; size_t ldsBytes = 0;
+    if (!warp8::planResize(a, cn, sw, sh, dw, dh, sstep, dstep, src, dst, 1. / inv_scale_x, inv_scale_x, 1. / inv_scale_y, inv_scale_y, areaMode, &ldsBytes)) return 1;
+    std::vector<int> tt(2 * (size_t)dw + 4 * (size_t)dh);
+    for (int i = 0; i < dw; i++) { int sx; uint32_t a01; warp8::rzColTerm(a, i, sx, a01); tt[i] = sx; tt[dw + i] = (int)a01; }
+    for (int i = 0; i < dh; i++) { int y0, y1; uint32_t b0, b1; warp8::rzRowTerm(a, i, y0, y1, b0, b1); int* r = tt.data() + 2 * dw; r[i] = y0; r[dh + i] = y1; r[2 * dh + i] = (int)b0; r[3 * dh + i] = (int)b1; }
+    a.colT = tt.data(); a.rowT = tt.data() + 2 * dw;
+    stats[0] = stats[1] = stats[2] = 0;
+    return cn == 1 ? rzRun<1>(a, ldsBytes, src, dst, stats) : rzRun<3>(a, ldsBytes, src, dst, stats);
+}

@@ -138,3 +138,28 @@ def test_warp8_separable_weights_equal_the_q15_table():
     # entry (0, 0) against every pair (p00, p11)
     a, d = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
     assert np.array_equal((32767 * a + d + (1 << 14)) >> 15, a)
+
+
+def test_resize8_lean_tiles_on_the_cpu(emu8):
+    """k_resize8_lean's per-tile code (warp8.h rzClassify / leanLoad / leanStore / rzRows with the tables of k_resize8_terms) against the pinned restatement of
+    cv::resize INTER_LINEAR on CV_8U: up- and downscales, 1 and 3 channels, sizes that leave partial lanes and partial tiles, INTER_AREA's upscale coefficients"""
+    emu8.emu_resize8.restype = ctypes.c_int
+    rng = np.random.default_rng(5)
+    served = 0
+    for cn in (1, 3):
+        for (sw, sh, dw, dh, interp) in [(480, 270, 960, 540, 1), (480, 270, 720, 405, 1), (640, 360, 480, 270, 1), (400, 300, 1000, 700, 1), (336, 200, 1336, 804, 1),
+                                         (480, 270, 960, 540, 3), (300, 200, 452, 301, 1), (128, 64, 512, 256, 1)]:
+            if (sw * cn) % 4 or (dw * cn) % 4:
+                continue
+            src = rng.integers(0, 256, (sh, sw) if cn == 1 else (sh, sw, cn), dtype=np.uint8)
+            want = o.orc_resize(src, (dw, dh), interpolation=interp)
+            got = np.full_like(want, 0x5A)
+            stats = (ctypes.c_longlong * 3)()
+            rc = emu8.emu_resize8(o.P(src), o.step(src), sw, sh, o.P(got), o.step(got), dw, dh, cn, ctypes.c_double(dw / sw), ctypes.c_double(dh / sh),
+                                  int(interp == 3), stats)
+            if rc != 0:
+                continue
+            assert stats[1] == 0, (cn, sw, sh, dw, dh, list(stats))
+            assert np.array_equal(got, want), (cn, sw, sh, dw, dh, interp, int(np.count_nonzero(got != want)), list(stats))
+            served += stats[0]
+    assert served > 200

@@ -374,3 +374,22 @@ def test_warp_polar_inverse(cv, orc, dtype):
     big = rnd((2048, 1024), np.uint8, 49)
     check(cv.warpPolar(dev(big), (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))
     check(cv.warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8), orc.orc_warpPolar(big, (1920, 1080), (960.0, 540.0), 600.0, 1 | 16 | 8))   # host image
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_resize_bilinear_u8_on_the_lean_kernel(cv, orc, cn):
+    """CV_8U INTER_LINEAR (and INTER_AREA upscales) with 4-byte aligned rows run on k_resize8_lean (LDS pipeline of the lean warp kernel): identical to the
+    restatement for up- and downscales, partial lanes / tiles, a batch, and the predicated loader at the image's last row"""
+    from opencv_amd import _lib
+    for (sw, sh, dw, dh, interp) in [(480, 270, 960, 540, 1), (480, 270, 720, 404, 1), (640, 360, 480, 272, 1), (400, 300, 1000, 700, 1), (336, 200, 1336, 804, 1),
+                                     (480, 270, 960, 540, 3), (300, 200, 452, 301, 1), (128, 64, 512, 256, 1)]:
+        src = rnd((sh, sw, cn) if cn > 1 else (sh, sw), np.uint8, sw + cn)
+        got = cv.resize(dev(src), (dw, dh), interpolation=interp)
+        k = _lib.lib.mi355cv_lastKernel().decode()
+        assert np.array_equal(got.cpu().numpy(), orc.orc_resize(src, (dw, dh), interpolation=interp)), (cn, sw, sh, dw, dh, interp, k)
+        if (sw * cn) % 4 == 0 and (dw * cn) % 4 == 0 and not (cn == 3 and dw < sw):
+            assert "k_resize8_lean" in k, (cn, sw, dw, k)
+    frames = np.stack([rnd((270, 480, cn) if cn > 1 else (270, 480), np.uint8, 40 + i) for i in range(3)])
+    out = cv.resizeBatch(dev(frames), (960, 540))
+    for i in range(3):
+        assert np.array_equal(out[i].cpu().numpy(), orc.orc_resize(frames[i], (960, 540))), i
