@@ -29,9 +29,11 @@ ops = [
     ("filter2D 3x3 dense 8U 64x4K", lambda: cv.filter2DBatch(gray, -1, k3, dst=o8), 64, 2 * W * H),
     ("boxFilter 5x5 8U 64x4K", lambda: cv.boxFilterBatch(gray, -1, (5, 5), dst=o8), 64, 2 * W * H),
     ("sepFilter2D 3x3 8U 64x4K", lambda: cv.sepFilter2DBatch(gray, -1, np.array([.25, .5, .25], np.float32), np.array([.25, .5, .25], np.float32), dst=o8), 64, 2 * W * H),
+    ("Gaussian 5x5 s1.5 8U 64x4K", lambda: cv.GaussianBlurBatch(gray, (5, 5), 1.5, dst=o8) if False else cv.sepFilter2DBatch(gray, -1, np.array([.0625, .25, .375, .25, .0625], np.float32), np.array([.0625, .25, .375, .25, .0625], np.float32), dst=o8), 64, 2 * W * H),
+    ("medianBlur 3x3 1 frame", lambda: cv.medianBlur(gray[0], 3, dst=o8[0]), 1, 2 * W * H),
     ("pyrDown 256x1080p", lambda: cv.pyrDownBatch(hd, dst=half), 256, 1920 * 1080 * 5 // 4),
 ]
-segs = [None, 8, 12, 16, 24, 32, 48, 64, 96, 128]
+segs = [None] if os.environ.get('SWEEP_QUICK') else [None, 8, 12, 16, 24, 32, 48, 64, 96, 128]
 print(f"{'op':32s} " + " ".join(f"{('seg ' + str(s)) if s else 'default':>9s}" for s in segs) + "   (fraction of 8 TB/s)")
 for name, fn, frames, bpf in ops:
     row = []
@@ -46,6 +48,6 @@ for name, fn, frames, bpf in ops:
     os.environ.pop("MI355CV_ROLL_SEG", None)
     fn(); k = _lib.lib.mi355cv_lastKernel().decode()[:70]
     print(f"{name:32s} " + " ".join(row) + f"   [{k}]")
-for wv in (1024, 4096, 8192, 16384):
+for wv in (() if os.environ.get('SWEEP_QUICK') else (1024, 4096, 8192, 16384)):
     os.environ["MI355CV_ROLL_WAVES"] = str(wv)
     print(f"ROLL_WAVES={wv}: " + "  ".join(f"{name.split()[0]} {bpf * frames / timeit(fn) / 8e6:.3f}" for name, fn, frames, bpf in ops))
