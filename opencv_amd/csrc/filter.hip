@@ -642,6 +642,9 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (p.mode == 0 && c.sdepth == D32F && c.ddepth == D32F && c.cn == 1 && centred &&
         seprollF32(ds, dss, 0, dd, dds, 0, 1, W, H, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream(), roi))
         return stg.finish(entry);
+    if (p.mode == 0 && (c.sdepth == D16U || c.sdepth == D16S) && (c.ddepth == c.sdepth || c.ddepth == D32F) && c.cn == 1 && centred &&
+        seprollF16(ds, dss, 0, dd, dds, 0, 1, W, H, c.sdepth == D16S, c.ddepth == D32F, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream(), roi))
+        return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
                        fullW, fullH, offX, offY, c.border, c.sp);
@@ -674,6 +677,9 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
         return stg.finish(entry);
     if (p.mode == 0 && c.sdepth == D32F && c.ddepth == D32F && c.cn == 1 && centred &&
         seprollF32(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream()))
+        return stg.finish(entry);
+    if (p.mode == 0 && (c.sdepth == D16U || c.sdepth == D16S) && (c.ddepth == c.sdepth || c.ddepth == D32F) && c.cn == 1 && centred &&
+        seprollF16(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.sdepth == D16S, c.ddepth == D32F, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream()))
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     for (int f = 0; f < nframes; f++)

@@ -41,6 +41,10 @@ bool seprollMorph(int erode, const uchar* src, size_t sstep, size_t sframe, ucha
 bool seprollF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                 int W, int H, const float* kx, const float* ky, int n, int symY, float delta, int border, hipStream_t st, const Roi* roi = nullptr);
 
+// CV_16UC1 / CV_16SC1 -> the same depth (cvRound + saturate) or CV_32FC1, float taps: n in {3, 5}, centred anchors, symY as above
+bool seprollF16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                int W, int H, bool sgn, bool outFloat, const float* kx, const float* ky, int n, int symY, float delta, int border, hipStream_t st, const Roi* roi = nullptr);
+
 // CV_32FC1 box filter with double sums (the reference's RowSum<float,double> / ColumnSum<double,float>): ksize in {3,5,7}, centred anchor
 bool seprollBoxF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                    int W, int H, int ksize, bool normalize, int border, hipStream_t st, const Roi* roi = nullptr);

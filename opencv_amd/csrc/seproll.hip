@@ -624,6 +624,91 @@ bool seprollF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
     return true;
 }
 
+// ---------------------------------------------------------------------------------- CV_16U / CV_16S -> same depth or CV_32F, float taps
+// cv::sepFilter2D / cv::Sobel / cv::Scharr on 16-bit single-channel images (ktype CV_32F: RowFilter<ushort|short, float>, SymmColumnFilter / ColumnFilter with
+// Cast<float, ushort|short> = cvRound + saturate, filter.simd.hpp:2386, :2640-2751): a 16-bit element is a pixel of CN = 2 bytes for the skeleton, a lane owns
+// eight of them (one dwordx4 in), the window's dwords hold two elements each.  Arithmetic as SepF32F above.
+template <int K, int SYM, bool SGN, bool OUTF>
+struct SepF16 {
+    static const char* name() { return SGN ? (OUTF ? "SepF16<16S->32F>" : "SepF16<16S>") : (OUTF ? "SepF16<16U->32F>" : "SepF16<16U>"); }
+    static constexpr int KX = K, KY = K, CN = 2, CB = 16, OUTB = OUTF ? 2 : 1, R = K / 2;
+    static constexpr bool RAWX = true;
+    static constexpr int HD = roll::Cfg<R, CN, CB>::HD;
+    struct Args { float kx[K], ky[K], delta; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
+    struct Inter { float h[8]; };
+    template <int NWn>
+    static __device__ __forceinline__ void hpassX(Inter& o, const uint32_t (&X)[NWn], const Args& a)
+    {
+        static_assert(NWn == 4 + 2 * HD, "window = own four dwords + HD halo dwords per side");
+        float e[8 + 2 * R];                                           // elements first own - R .. last own + R
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * R; j++) {
+            const int idx = 2 * HD - R + j;                           // element index inside the window (two per dword)
+            const uint32_t w = (idx & 1) ? X[idx >> 1] >> 16 : X[idx >> 1] & 0xffffu;
+            e[j] = SGN ? (float)(short)w : (float)w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float r = a.kx[0] * e[k];
+#pragma unroll
+            for (int t = 1; t < K; t++) r = __builtin_fmaf(a.kx[t], e[k + t], r);
+            o.h[k] = r;
+        }
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args& a, uint32_t (&out)[4 * OUTB])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + (UP ? K - 1 - t : t)) % K]; };     // image row t of the window
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float s;
+            if (SYM == 1 || SYM == 2) {
+                s = SYM == 1 ? __builtin_fmaf(a.ky[R], row(R).h[k], a.delta) : a.delta;
+#pragma unroll
+                for (int d = 1; d <= R; d++)
+                    s = __builtin_fmaf(a.ky[R + d], SYM == 1 ? row(R + d).h[k] + row(R - d).h[k] : row(R + d).h[k] - row(R - d).h[k], s);
+            } else {
+                s = __builtin_fmaf(a.ky[0], row(0).h[k], a.delta);
+#pragma unroll
+                for (int j = 1; j < K; j++) s = __builtin_fmaf(a.ky[j], row(j).h[k], s);
+            }
+            v[k] = s;
+        }
+        if (OUTF) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) out[k] = __float_as_uint(v[k]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                             // saturate_cast<ushort|short>(float): cvRound, then clamp (core/saturate.hpp)
+                float r0 = __builtin_rintf(v[2 * q]), r1 = __builtin_rintf(v[2 * q + 1]);
+                r0 = SGN ? fminf(fmaxf(r0, -32768.f), 32767.f) : fminf(fmaxf(r0, 0.f), 65535.f);
+                r1 = SGN ? fminf(fmaxf(r1, -32768.f), 32767.f) : fminf(fmaxf(r1, 0.f), 65535.f);
+                out[q] = ((uint32_t)(int)r0 & 0xffffu) | ((uint32_t)(int)r1 << 16);
+            }
+        }
+    }
+};
+
+bool seprollF16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                int W, int H, bool sgn, bool outFloat, const float* kx, const float* ky, int n, int symY, float delta, int border, hipStream_t st, const Roi* roi)
+{
+    if (!roiEligible(roi, nframes, W, H)) return false;
+    if ((n != 3 && n != 5) || symY < 0 || symY > 2) return false;
+    if ((((uintptr_t)src | sstep | sframe) & 1) != 0 || (((uintptr_t)dst | dstep | dframe) & 3) != 0) return false;
+    if (!roll::eligible(src, sstep, sframe, src, sstep, sframe, roi ? roi->fullW : W, 2, n / 2, border)) return false;
+#define FH(K_, S_, G_, O_) do { typedef SepF16<K_, S_, G_, O_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
+        launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st, roi); } while (0)
+#define FHO(K_, S_) do { if (sgn) { if (outFloat) FH(K_, S_, true, true); else FH(K_, S_, true, false); } else { if (outFloat) FH(K_, S_, false, true); else FH(K_, S_, false, false); } } while (0)
+#define FHS(K_) do { if (symY == 1) FHO(K_, 1); else if (symY == 2) FHO(K_, 2); else FHO(K_, 0); } while (0)
+    if (n == 3) FHS(3); else FHS(5);
+#undef FHS
+#undef FHO
+#undef FH
+    return true;
+}
+
 bool seprollBoxF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                    int W, int H, int ksize, bool normalize, int border, hipStream_t st, const Roi* roi)
 {

@@ -320,6 +320,35 @@ def test_f32_rolling_filters(cv, orc):
     check(cv.SobelBatch(fb, cv.CV_32F, 1, 0, 3)[0], orc.orc_Sobel(big, -1, 1, 0, 3), tol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.int16])
+def test_16bit_sources_on_the_rolling_kernels(cv, orc, dtype):
+    """CV_16UC1 / CV_16SC1 sepFilter2D and Sobel / Scharr with float taps (the reference's RowFilter<ushort|short, float> + column filter with cvRound + saturate),
+    to the same depth and to CV_32F, on k_sep_roll<SepF16...>: a 16-bit element is a 2-byte pixel of the rolling skeleton.  Ragged and unaligned rows, every border
+    rule, values that saturate; bit-exact for the 16-bit outputs, <= 1e-6 relative for CV_32F."""
+    rng = np.random.default_rng(9)
+    lo, hi = (0, 65536) if dtype == np.uint16 else (-32768, 32768)
+    for (w, h) in [(64, 23), (1040, 37), (333, 19), (8, 5), (2064, 70)]:
+        src = rng.integers(lo, hi, (h, w)).astype(dtype)
+        for border in (0, 1, 2, 4):
+            for kx, ky, dl in [([0.25, 0.5, 0.25], [0.25, 0.5, 0.25], 0.0), ([-1, 0, 1], [1, 2, 1], 0.5), ([0.1, 0.5, 0.2], [0.7, -0.1, 0.2], 3.5),
+                               ([0.0625, 0.25, 0.375, 0.25, 0.0625], [0.0625, 0.25, 0.375, 0.25, 0.0625], 0.0), ([-1, -2, 0, 2, 1], [1, 4, 6, 4, 1], 0.0)]:
+                for ddepth in (-1, 5):
+                    got = cv.sepFilter2D(dev(src), ddepth, kx, ky, (-1, -1), dl, border)
+                    check(got, orc.orc_sepFilter2D(src, ddepth, kx, ky, (-1, -1), dl, border), tol=1e-6)
+                    if w >= 64 and w % 2 == 0:                               # rows of a multiple of 4 bytes
+                        assert "k_sep_roll<SepF16" in _kernel(cv), _kernel(cv)
+            if dtype == np.int16:
+                for ksize, dx, dy in [(3, 1, 0), (3, 0, 1), (5, 1, 1), (-1, 0, 1)]:
+                    check(cv.Sobel(dev(src // 64), -1, dx, dy, ksize, 1.0, 0.0, border), orc.orc_Sobel(src // 64, -1, dx, dy, ksize, 1.0, 0.0, border))
+    big = rng.integers(lo, hi, (2160, 3840)).astype(dtype)
+    g5 = cv.getGaussianKernel(5, 1.2, cv.CV_32F)
+    want = orc.orc_sepFilter2D(big, -1, g5, g5)
+    check(cv.sepFilter2D(dev(big), -1, g5, g5), want)
+    assert "k_sep_roll<SepF16" in _kernel(cv), _kernel(cv)
+    fb = dev(np.stack([big, big[::-1].copy()]))
+    check(cv.sepFilter2DBatch(fb, -1, g5, g5)[0], want)
+
+
 def test_submatrix_calls_stay_on_the_rolling_kernels(cv, orc):
     """A cv::Mat ROI with real pixels around it (the HAL's offset / full-size and margin contracts): the rolling kernels run on the parent's geometry and
     store the window only -- every window position relative to the 16-byte chunk grid, windows touching the parent's edges, one-pixel windows;
