@@ -45,6 +45,10 @@ bool seprollF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
 bool seprollF16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                 int W, int H, bool sgn, bool outFloat, const float* kx, const float* ky, int n, int symY, float delta, int border, hipStream_t st, const Roi* roi = nullptr);
 
+// CV_16UC1 sigma = 0 Gaussian (cv_hal_gaussianBlurBinomial on CV_16U): ksize 3 or 5, exact integer binomial sums with the reference's single rounding
+bool seprollBinom16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                    int W, int H, int ksize, int border, hipStream_t st, const Roi* roi = nullptr);
+
 // CV_32FC1 box filter with double sums (the reference's RowSum<float,double> / ColumnSum<double,float>): ksize in {3,5,7}, centred anchor
 bool seprollBoxF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                    int W, int H, int ksize, bool normalize, int border, hipStream_t st, const Roi* roi = nullptr);

@@ -709,6 +709,60 @@ bool seprollF16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_
     return true;
 }
 
+// ---------------------------------------------------------------------------------- CV_16UC1 sigma = 0 Gaussian 3x3 / 5x5
+// cv::GaussianBlur on CV_16U (smooth.dispatch.cpp:726-760 -> cv_hal_gaussianBlurBinomial; GaussianBlurFixedPointImpl<uint32_t, uint16_t, ufixedpoint32>):
+// hlineSmooth3N121 / 5N14641 shift every term into Q16.16 exactly ((s << 14) ..., no rounding, no saturation: the taps sum to 1), vlineSmooth3N121 / 5N14641
+// round once: (sum + 2^17) >> 18 resp. (sum + 2^19) >> 20 (smooth.simd.hpp:1425-1452, :1596-1632) -- i.e. (S + 8) >> 4 and (S + 128) >> 8 of the plain integer
+// binomial sums S, as for CV_8U.  A 16-bit element is a 2-byte pixel of the skeleton, eight per lane.
+template <int K>
+struct Binom16 {
+    static const char* name() { return "Binom16"; }
+    static constexpr int KX = K, KY = K, CN = 2, CB = 16, OUTB = 1, R = K / 2;
+    static constexpr bool RAWX = true;
+    static constexpr int HD = roll::Cfg<R, CN, CB>::HD;
+    struct Args { int unused; };
+    template <int MDn, int HDn> static __device__ __forceinline__ void pre(uint32_t (&)[MDn], uint32_t (&)[HDn], const Args&) {}
+    struct Inter { uint32_t h[8]; };
+    template <int NWn>
+    static __device__ __forceinline__ void hpassX(Inter& o, const uint32_t (&X)[NWn], const Args&)
+    {
+        static_assert(NWn == 4 + 2 * HD, "window = own four dwords + HD halo dwords per side");
+        uint32_t e[8 + 2 * R];
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * R; j++) {
+            const int idx = 2 * HD - R + j;
+            e[j] = (idx & 1) ? X[idx >> 1] >> 16 : X[idx >> 1] & 0xffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            o.h[k] = K == 3 ? e[k] + 2 * e[k + 1] + e[k + 2] : e[k] + e[k + 4] + 4 * (e[k + 1] + e[k + 3]) + 6 * e[k + 2];
+    }
+    template <bool UP>
+    static __device__ __forceinline__ void vpass(const Inter (&ring)[K], int u, const Args&, uint32_t (&out)[4])
+    {
+        auto row = [&](int t) -> const Inter& { return ring[(u + t) % K]; };               // symmetric taps: the direction of the walk does not matter
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            v[k] = K == 3 ? (row(0).h[k] + 2 * row(1).h[k] + row(2).h[k] + 8u) >> 4
+                          : (row(0).h[k] + row(4).h[k] + 4 * (row(1).h[k] + row(3).h[k]) + 6 * row(2).h[k] + 128u) >> 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) out[q] = v[2 * q] | (v[2 * q + 1] << 16);
+    }
+};
+
+bool seprollBinom16(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+                    int W, int H, int ksize, int border, hipStream_t st, const Roi* roi)
+{
+    if (!roiEligible(roi, nframes, W, H)) return false;
+    if (ksize != 3 && ksize != 5) return false;
+    if ((((uintptr_t)src | sstep | sframe) & 1) != 0 || (((uintptr_t)dst | dstep | dframe) & 3) != 0) return false;
+    if (!roll::eligible(src, sstep, sframe, src, sstep, sframe, roi ? roi->fullW : W, 2, ksize / 2, border)) return false;
+    if (ksize == 3) { typedef Binom16<3> P; P::Args a = {0}; launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 16, a, st, roi); }
+    else            { typedef Binom16<5> P; P::Args a = {0}; launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, 12, a, st, roi); }
+    return true;
+}
+
 bool seprollBoxF32(const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
                    int W, int H, int ksize, bool normalize, int border, hipStream_t st, const Roi* roi)
 {

@@ -702,6 +702,28 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     return stg.finish(entry);
 }
 
+// CV_16UC1, sigma = 0, 3x3 / 5x5: the rolling kernel or nothing (the reference's own Q16.16 path is the fallback)
+int runBinom16(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int mL, int mT, int mR, int mB, int ksize, int border)
+{
+    if (disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
+    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    const bool hostSrc = !isDevicePtr(src);
+    if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
+    if (!hostSrc && src == dst) return MI355CV_NOT_IMPLEMENTED;
+    size_t dss = 0, dds = 0;
+    const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * 2;
+    const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * 2, mT + H + mB, &dss);
+    if (!dtop) return MI355CV_NOT_IMPLEMENTED;
+    const uchar* dsrc = dtop + (size_t)mT * dss + (size_t)mL * 2;
+    uchar* ddst = stg.out(dst, dstep, (size_t)W * 2, H, &dds);
+    if (!ddst) return MI355CV_NOT_IMPLEMENTED;
+    const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
+    if (!seprollBinom16(dsrc, dss, 0, ddst, dds, 0, 1, W, H, ksize, border, stream(), (mL | mT | mR | mB) ? &roi : nullptr))
+        return setError(MI355CV_NOT_IMPLEMENTED, "%s: CV_16U geometry outside the rolling kernel", entry);
+    return stg.finish(entry);
+}
+
 // sigma==0 Q8.8 tables (smooth.dispatch.cpp:89-145 scaled by 256; cf. test_smooth_bitexact.cpp:14-20)
 const uint16_t kBinom1[1] = {256};
 const uint16_t kBinom3[3] = {64, 128, 64};
@@ -723,6 +745,9 @@ MI355CV_API int mi355cv_gaussianBlurBinomial(const uchar* src_data, size_t src_s
         int width, int height, int depth, int cn, size_t margin_left, size_t margin_top, size_t margin_right,
         size_t margin_bottom, size_t ksize, int border_type)
 {
+    if (depth == MI355CV_16U)
+        return runBinom16("gaussianBlurBinomial", src_data, src_step, dst_data, dst_step, width, height, cn, (int)margin_left, (int)margin_top, (int)margin_right,
+                                 (int)margin_bottom, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED);
     if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
     const uint16_t* k = binomTaps(ksize);
     if (!k) return MI355CV_NOT_IMPLEMENTED;

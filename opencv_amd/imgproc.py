@@ -104,7 +104,17 @@ def GaussianBlur(src, ksize, sigmaX=0.0, sigmaY=0.0, borderType=BORDER_DEFAULT, 
         # smooth.dispatch.cpp:800-826: every depth without a fixed-point path ends in sepFilter2D with the taps of createGaussianKernels (:280-304:
         # getGaussianKernel(ksize, sigma, max(depth, CV_32F))); cv_hal_gaussianBlur declines these depths, the sepFilter hook serves them
         if s.depth == CV_16U:
-            raise NotImplementedError("GaussianBlur: CV_16U runs the reference's Q16.16 fixed-point path (smooth.dispatch.cpp:726-760), not served")
+            # the reference's Q16.16 fixed-point path (smooth.dispatch.cpp:726-760): its only hook is cv_hal_gaussianBlurBinomial (sigma 0, square kernel)
+            if not (sigmaX == 0.0 and sigmaY == 0.0 and kw == kh and kw in (3, 5) and s.cn == 1):
+                raise NotImplementedError("GaussianBlur: CV_16U beyond the sigma-0 3x3 / 5x5 single-channel case runs the reference's Q16.16 path, not served")
+            out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
+            d = Img(out)
+            if d.ptr == s.ptr:
+                src = _copy_like(src); s = Img(src)
+            bind_stream(s, d)
+            rc = L.mi355cv_gaussianBlurBinomial(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, 0, 0, 0, 0, kw, borderType & ~BORDER_ISOLATED)
+            _lib.check(rc, "gaussianBlurBinomial")
+            return out
         kx = getGaussianKernel(kw, sigmaX, CV_32F)
         ky = kx if (kh == kw and abs(sigmaY - sigmaX) < 2.220446049250313e-16) else getGaussianKernel(kh, sigmaY, CV_32F)
         return sepFilter2D(src, -1, kx, ky, borderType=borderType, dst=dst)

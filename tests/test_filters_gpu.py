@@ -349,6 +349,37 @@ def test_16bit_sources_on_the_rolling_kernels(cv, orc, dtype):
     check(cv.sepFilter2DBatch(fb, -1, g5, g5)[0], want)
 
 
+def _np_binom16(src, k, border):
+    """cv::GaussianBlur on CV_16U with sigma 0: the plain integer binomial sums with ONE rounding, (S + 8) >> 4 for 3x3 and (S + 128) >> 8 for 5x5 (what the
+    reference's Q16.16 hline / vline pair evaluates to, smooth.simd.hpp:1425-1452, :1596-1632; pinned against the reference in tests/test_oracle_smooth16.py)"""
+    mode = {0: "constant", 1: "edge", 2: "symmetric", 3: "wrap", 4: "reflect"}[border]
+    r = k // 2
+    p = np.pad(src.astype(np.int64), r, mode=mode)
+    t = np.array([1, 2, 1] if k == 3 else [1, 4, 6, 4, 1], np.int64)
+    h = sum(t[i] * p[:, i:i + src.shape[1]] for i in range(k))
+    v = sum(t[i] * h[i:i + src.shape[0]] for i in range(k))
+    return ((v + (8 if k == 3 else 128)) >> (4 if k == 3 else 8)).astype(np.uint16)
+
+
+def test_gaussian_16u_binomial_on_the_rolling_kernel(cv, orc):
+    """cv_hal_gaussianBlurBinomial on CV_16UC1 (the one hook the reference's Q16.16 GaussianBlur path has, smooth.dispatch.cpp:726-760): k_sep_roll<Binom16>,
+    bit-exact against the integer restatement and, where the real reference travelled with the tree, against cv::GaussianBlur itself"""
+    rng = np.random.default_rng(4)
+    have_ref = orc.load_ref() is not None
+    for (w, h) in [(64, 23), (1040, 37), (334, 19), (8, 5), (2064, 70), (3840, 2160)]:
+        src = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+        src[0, :8] = 65535; src[-1, -8:] = 65535
+        for k in (3, 5):
+            for border in ((0, 1, 2, 4) if w < 3000 else (4,)):
+                got = cv.GaussianBlur(dev(src), (k, k), 0, borderType=border)
+                assert "k_sep_roll<Binom16" in _kernel(cv), _kernel(cv)
+                check(got, _np_binom16(src, k, border))
+                if have_ref and w < 3000:
+                    check(got, orc.ref_GaussianBlur(src, k, 0.0, 0.0, border))
+    with pytest.raises(NotImplementedError):
+        cv.GaussianBlur(dev(np.zeros((16, 16), np.uint16)), (7, 7), 0)
+
+
 def test_submatrix_calls_stay_on_the_rolling_kernels(cv, orc):
     """A cv::Mat ROI with real pixels around it (the HAL's offset / full-size and margin contracts): the rolling kernels run on the parent's geometry and
     store the window only -- every window position relative to the 16-byte chunk grid, windows touching the parent's edges, one-pixel windows;
