@@ -19,6 +19,7 @@
 // Everything here is __host__ __device__ and free of wave intrinsics so that tests/hostemu can run the very same staging and per-pixel code on the
 // CPU, thread by thread, against the pinned restatement (the GPU adds only the launch geometry).
 #pragma once
+#include <cstdlib>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -971,6 +972,12 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
     const int ibw = (int)bw + 1, ibh = (int)bh + 1;
     a.ldsPitch = ((ibw * cn + 3 + 3) & ~3) + 8;
     if (!((a.ldsPitch >> 2) & 1)) a.ldsPitch += 4;           // an odd number of dwords per row: the taps of a slanted line step through the LDS banks instead of revisiting them
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (const char* e = std::getenv("MI355CV_WARP8_PITCHMOD")) {      // tuning experiments: force (dwords per LDS row) mod 64
+        const int r = atoi(e) & 63;
+        while (((a.ldsPitch >> 2) & 63) != r) a.ldsPitch += 4;
+    }
+#endif
     a.ldsRows = ibh;
     a.pitchMagic = (uint32_t)((1ull << 32) / (uint32_t)(a.ldsPitch / 4)) + 1;
     *ldsBytes = (size_t)OFF_TILE + (size_t)a.ldsPitch * a.ldsRows;

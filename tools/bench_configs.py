@@ -325,14 +325,14 @@ def run(quick=False, parity=True):
             out.append({"config": name, "error": repr(e)})
     del f32, o32
     torch.cuda.empty_cache()
-    # CV_16SC1 sources on the rolling kernels (64 frames: 2 x 4 B / px x 64 x 4K = 2.1 GB per pass)
+    # CV_16SC1 sources on the rolling kernels (72 frames: 4 B / px x 72 x 4K = 2.4 GB per pass)
     try:
-        s16 = torch.randint(-32768, 32768, (64, H4, W4), dtype=torch.int16, device=dev, generator=g); o16 = torch.empty_like(s16)
+        s16 = torch.randint(-32768, 32768, (72, H4, W4), dtype=torch.int16, device=dev, generator=g); o16 = torch.empty_like(s16)
         g5 = cv.getGaussianKernel(5, 1.2).astype(np.float32)
         for name, fn in [("a1 sepFilter2D Gaussian 5x5 sigma 1.2 4K 16SC1 batch", lambda: cv.sepFilter2DBatch(s16, -1, g5, g5, dst=o16)),
                          ("a4 Sobel dx 3x3 4K 16S->16S batch", lambda: cv.SobelBatch(s16, -1, 1, 0, 3, dst=o16))]:
             ms = timeit(fn, N, WARM)
-            hbm_row(name, 64, ms, 64 * PIX4 * 4)
+            hbm_row(name, 72, ms, 72 * PIX4 * 4)
         del s16, o16
     except Exception as e:
         out.append({"config": "16S rolling rows", "error": repr(e)})
