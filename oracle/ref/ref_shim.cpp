@@ -472,4 +472,39 @@ int ref_dilate3x3(const void* s, size_t ss, void* d, size_t ds, int w, int h, in
     REF_END(dst, d)
 }
 
+// cv::ORB (modules/features2d/src/orb.cpp): keypoints as 28-byte records laid out like cv::KeyPoint (x, y, size, angle, response, octave, class_id),
+// descriptors as n rows of descriptorSize() bytes.  useProvided != 0: *n keypoints come in, descriptors of the ones that survive go out.
+// Returns the keypoint count (kps / desc hold at most cap of them), -1 on an exception.
+int ref_ORB(const void* s, size_t ss, int w, int h, int type, const void* mask, size_t ms, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
+            int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc)
+{
+    try {
+        static_assert(sizeof(KeyPoint) == 28, "KeyPoint layout");
+        Mat src = M(s, ss, w, h, type), m;
+        if (mask) m = M(mask, ms, w, h, CV_8UC1);
+        Ptr<ORB> orb = ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, (ORB::ScoreType)scoreType, patchSize, fastThreshold);
+        std::vector<KeyPoint> kp;
+        if (useProvided) kp.assign((const KeyPoint*)kps, (const KeyPoint*)kps + nIn);
+        Mat d;
+        if (doDesc) orb->detectAndCompute(src, m, kp, d, useProvided != 0);
+        else orb->detect(src, kp, m);
+        const int n = (int)kp.size(), take = n < cap ? n : cap;
+        if (take) memcpy(kps, kp.data(), (size_t)take * sizeof(KeyPoint));
+        if (doDesc && take && !d.empty()) for (int i = 0; i < take; i++) memcpy((uchar*)desc + (size_t)i * d.cols, d.ptr(i), d.cols);
+        return n;
+    } catch (const cv::Exception& e) { fprintf(stderr, "ref_shim: %s\n", e.what()); return -1; }
+}
+
+// cv::KeyPointsFilter::retainBest (keypoint.cpp:70): std::nth_element + std::partition of this libstdc++ on 28-byte keypoints, in place; returns the new count
+int ref_retainBest(void* kps, int n, int npoints)
+{
+    std::vector<KeyPoint> kp((const KeyPoint*)kps, (const KeyPoint*)kps + n);
+    KeyPointsFilter::retainBest(kp, npoints);
+    if (!kp.empty()) memcpy(kps, kp.data(), kp.size() * sizeof(KeyPoint));
+    return (int)kp.size();
+}
+
+float ref_fastAtan2(float y, float x) { return cv::fastAtan2(y, x); }
+
+
 } // extern "C"

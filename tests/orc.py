@@ -1200,3 +1200,62 @@ def orc_cvtColorYUVwide(src, code, dcn=3):
         dst = np.empty((h, w, dcn), src.dtype)
         (o.orc_cvtYUVtoBGR16u if src.dtype == np.uint16 else o.orc_cvtYUVtoBGR32f)(P(src), step(src), P(dst), step(dst), w, h, dcn, swap, cb)
     return dst
+
+
+# ---------------------------------------------------------------------------------- features2d ORB
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32), ("response", np.float32),
+                     ("octave", np.int32), ("class_id", np.int32)])          # cv::KeyPoint, 28 bytes
+ORB_DEFAULTS = dict(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2, scoreType=0, patchSize=31, fastThreshold=20)
+
+
+def _orb_call(fn, is_ref, src, keypoints, descriptors, cap, p):
+    h, w = src.shape[:2]
+    kps = np.zeros(cap, KP_DTYPE)
+    n_in = 0
+    if keypoints is not None:
+        n_in = len(keypoints)
+        kps = np.zeros(max(cap, n_in), KP_DTYPE)
+        kps[:n_in] = keypoints
+    desc = np.zeros((len(kps), 32), np.uint8)
+    c_f = ctypes.c_float
+    tail = [p["nfeatures"], c_f(p["scaleFactor"]), p["nlevels"], p["edgeThreshold"], p["firstLevel"], p["WTA_K"], p["scoreType"], p["patchSize"],
+            p["fastThreshold"], 1 if keypoints is not None else 0, P(kps), n_in, len(kps), P(desc), 1 if descriptors else 0]
+    if is_ref:
+        n = fn(P(src), step(src), w, h, cvtype(src), None, c_sz(0), *tail)
+    else:
+        n = fn(P(src), step(src), w, h, *tail)
+    assert 0 <= n <= len(kps), n
+    return kps[:n].copy(), (desc[:n].copy() if descriptors else None)
+
+
+def orc_ORB(src, keypoints=None, descriptors=True, cap=20000, **kw):
+    """cv::ORB::detectAndCompute by the restatement: (keypoints as a KP_DTYPE array in the reference's order, n x 32 descriptors)"""
+    return _orb_call(oracle().orc_ORB, False, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw))
+
+
+def ref_ORB(src, keypoints=None, descriptors=True, cap=20000, **kw):
+    return _orb_call(load_ref().ref_ORB, True, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw))
+
+
+def orb_scene(w, h, seed=0, texture=1.0):
+    """a synthetic scene with corners at many scales: smoothed noise plus rectangles and discs of random grey levels"""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w)).astype(np.float32)
+    k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    for _ in range(2):
+        img = np.apply_along_axis(lambda r: np.convolve(np.pad(r, 2, mode="reflect"), k, mode="valid"), 1, img)
+        img = np.apply_along_axis(lambda c: np.convolve(np.pad(c, 2, mode="reflect"), k, mode="valid"), 0, img)
+    img = 128 + (img - 128) * texture
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(max(6, w * h // 12000)):
+        cx, cy = rng.integers(0, w), rng.integers(0, h)
+        s = int(rng.integers(4, max(6, min(w, h) // 5)))
+        g = float(rng.integers(0, 256))
+        if rng.integers(0, 2):
+            a = rng.uniform(0, np.pi)
+            u = (xx - cx) * np.cos(a) + (yy - cy) * np.sin(a); v = -(xx - cx) * np.sin(a) + (yy - cy) * np.cos(a)
+            m = (np.abs(u) < s) & (np.abs(v) < s * rng.uniform(0.3, 1.0))
+        else:
+            m = (xx - cx) ** 2 + (yy - cy) ** 2 < s * s
+        img[m] = 0.6 * g + 0.4 * img[m]
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
