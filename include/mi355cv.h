@@ -512,6 +512,20 @@ MI355CV_API int mi355cv_FAST_NMS(const mi355cv_uchar* src_data, size_t src_step,
 MI355CV_API int mi355cv_FAST(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int threshold, int nonmax_suppression, int type,
         float* keypoints_xyr, int capacity);
 
+/* --------------------------------------------------- f3: features2d ORB (csrc/orb.hip) */
+/* cv::KeyPoint (core/types.hpp:777) and the arguments of cv::ORB::create (features2d.hpp:449-457; scoreType: ORB::HARRIS_SCORE 0, FAST_SCORE 1) */
+typedef struct mi355cv_KeyPoint { float x, y, size, angle, response; int octave, class_id; } mi355cv_KeyPoint;
+typedef struct mi355cv_OrbParams { int nfeatures; float scaleFactor; int nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize, fastThreshold; } mi355cv_OrbParams;
+/* cv::ORB::detectAndCompute (modules/features2d/src/orb.cpp:1012; the reference has no HAL hook for it) on a CV_8UC1 image in host or device
+ * memory: pyramid, FAST, Harris responses, orientation, smoothing and the rBRIEF descriptors on the GPU; the two culls (KeyPointsFilter::retainBest)
+ * on the host with the C++ library's nth_element, so keypoints leave in the reference's order.  `mask`: optional CV_8UC1 image of the same size.
+ * use_provided_keypoints != 0: describe the nkeypoints_in keypoints passed in (Feature2D::compute).  `descriptors`: rows of 32 bytes, or NULL to
+ * detect only.  At most `capacity` keypoints / rows are written.  Returns the keypoint count (>= 0; call again with larger arrays if it exceeds
+ * capacity -- nothing was written then), -1 arguments not served, -2 device failure. */
+MI355CV_API int mi355cv_ORB_detectAndCompute(const mi355cv_uchar* image, size_t step, int width, int height, const mi355cv_uchar* mask, size_t mask_step,
+        const mi355cv_OrbParams* params, int use_provided_keypoints, mi355cv_KeyPoint* keypoints, int nkeypoints_in, int capacity,
+        mi355cv_uchar* descriptors, size_t descriptors_step);
+
 #ifdef __cplusplus
 }
 #endif

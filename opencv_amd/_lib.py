@@ -46,6 +46,7 @@ def _load():
         "mi355cv_FAST_dense": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
         "mi355cv_FAST_NMS": (c_int, [c_u8p, c_sz, c_u8p, c_sz, c_int, c_int]),
         "mi355cv_FAST": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_int]),
+        "mi355cv_ORB_detectAndCompute": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, ctypes.c_void_p, c_int, ctypes.c_void_p, c_int, c_int, c_u8p, c_sz]),
         "mi355cv_remap": (c_int, [c_int, c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int,
                                   c_int, c_int, ctypes.c_void_p]),
         "mi355cv_convertMaps": (c_int, [ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz, c_int, ctypes.c_void_p, c_sz,

@@ -245,19 +245,30 @@ static void borderFill(uint8_t* pyr, int pitch, RectI r, int border, const uint8
     }
 }
 
-static int buildPyramid(const Layout* L, uint8_t* pyr, const uint8_t* img, size_t step, int w, int h, int firstLevel)
+/* mpyr / mask: the mask pyramid of orb.cpp:1104-1148 (interiors only: its constant ring is never read -- candidates are interior pixels);
+ * a resized mask level above firstLevel goes through cv::threshold(254, 0, THRESH_TOZERO), i.e. only 255 survives */
+static int buildPyramid(const Layout* L, uint8_t* pyr, const uint8_t* img, size_t step, int w, int h, int firstLevel, uint8_t* mpyr, const uint8_t* mask, size_t mstep)
 {
     const int pitch = L->bufW;
     const uint8_t* prev = img; size_t pstep = step; int pw = w, ph = h;
+    const uint8_t* prevM = mask; size_t pmstep = mstep;
     for (int level = 0; level < L->nLevels; level++) {
         const RectI r = L->layer[level];
         uint8_t* cur = pyr + (size_t)r.y * pitch + r.x;
+        uint8_t* curM = mpyr ? mpyr + (size_t)r.y * pitch + r.x : NULL;
         if (level != firstLevel) {
             if (orc_resize(prev, pstep, pw, ph, cur, (size_t)pitch, r.w, r.h, 0, 1, 0.0, 0.0, 5)) return 1;
             borderFill(pyr, pitch, r, L->border, NULL, 0);
-        } else
+            if (curM) {
+                if (orc_resize(prevM, pmstep, pw, ph, curM, (size_t)pitch, r.w, r.h, 0, 1, 0.0, 0.0, 5)) return 1;
+                if (level > firstLevel)
+                    for (int y = 0; y < r.h; y++) for (int x = 0; x < r.w; x++) if (curM[(size_t)y * pitch + x] <= 254) curM[(size_t)y * pitch + x] = 0;
+            }
+        } else {
             borderFill(pyr, pitch, r, L->border, img, step);
-        if (level > firstLevel) { prev = cur; pstep = (size_t)pitch; pw = r.w; ph = r.h; }
+            if (curM) for (int y = 0; y < r.h; y++) memcpy(curM + (size_t)y * pitch, mask + (size_t)y * mstep, (size_t)r.w);
+        }
+        if (level > firstLevel) { prev = cur; pstep = (size_t)pitch; pw = r.w; ph = r.h; prevM = curM; pmstep = (size_t)pitch; }
     }
     return 0;
 }
@@ -338,17 +349,52 @@ uint8_t* orc_orbPyramid(const uint8_t* img, size_t step, int w, int h, int nleve
     if (nlevels < 1 || nlevels > 64) return NULL;
     buildLayout(&L, w, h, nlevels, firstLevel, (double)scaleFactor, edgeThreshold, patchSize);
     uint8_t* pyr = (uint8_t*)calloc((size_t)L.bufW * L.bufH, 1);
-    if (!pyr || buildPyramid(&L, pyr, img, step, w, h, firstLevel)) { free(pyr); return NULL; }
+    if (!pyr || buildPyramid(&L, pyr, img, step, w, h, firstLevel, NULL, NULL, 0)) { free(pyr); return NULL; }
     out[0] = L.nLevels; out[1] = L.border; out[2] = L.bufW; out[3] = L.bufH;
     for (int i = 0; i < L.nLevels; i++) { out[4 + 4 * i] = L.layer[i].x; out[5 + 4 * i] = L.layer[i].y; out[6 + 4 * i] = L.layer[i].w; out[7 + 4 * i] = L.layer[i].h; }
     return pyr;
 }
 void orc_free(void* p) { free(p); }
 
-/* cv::ORB::detectAndCompute without a mask on a CV_8UC1 image.  useProvided: *count keypoints come in through kps.  Returns the keypoint count
- * (kps / desc are filled up to cap), -1 for parameters outside the restatement. */
-int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float scaleFactorF, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
-            int scoreType, int patchSize, int fastThreshold, int useProvided, void* kpsIO, int nIn, int cap, uint8_t* desc, int doDesc)
+/* cv::GaussianBlur(level, level, Size(7, 7), 2, 2, BORDER_REFLECT_101) on every level of the buffer, rings left as they are (orb.cpp:1183-1196) */
+static void blurLevels(const Layout* L, uint8_t* pyr)
+{
+    const int pitch = L->bufW;
+    double g[7];
+    orc_getGaussianKernel(7, 2.0, g);
+    for (int i = 0; i < 7; i++) g[i] = (double)(float)g[i];                  /* createGaussianKernels: CV_32F taps for an 8-bit image (smooth.dispatch.cpp:278) */
+    for (int l = 0; l < L->nLevels; l++) {
+        const RectI r = L->layer[l];
+        uint8_t* im = pyr + (size_t)r.y * pitch + r.x;
+        uint8_t* tmp = (uint8_t*)malloc((size_t)r.w * r.h);
+        /* the neighbours of the submatrix are its own reflected border, so the isolated form gives the same pixels */
+        orc_sepFilter2D(im, (size_t)pitch, tmp, (size_t)r.w, r.w, r.h, 1, 0, 0, r.w, r.h, 0, 0, g, 7, g, 7, -1, -1, 0.0, ORC_BORDER_REFLECT_101);
+        for (int y = 0; y < r.h; y++) memcpy(im + (size_t)y * pitch, tmp + (size_t)y * r.w, (size_t)r.w);
+        free(tmp);
+    }
+}
+
+/* the buffer the descriptors are sampled from (every level smoothed), layout as orc_orbPyramid */
+uint8_t* orc_orbPyramidBlurred(const uint8_t* img, size_t step, int w, int h, int nlevels, float scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out)
+{
+    uint8_t* pyr = orc_orbPyramid(img, step, w, h, nlevels, scaleFactor, edgeThreshold, firstLevel, patchSize, out);
+    if (!pyr) return NULL;
+    Layout L;
+    buildLayout(&L, w, h, nlevels, firstLevel, (double)scaleFactor, edgeThreshold, patchSize);
+    blurLevels(&L, pyr);
+    return pyr;
+}
+/* the sampling pattern of a parameter set as 2 * (512 or 128 * WTA_K) ints (orb.cpp:1205-1223); returns the count of ints */
+int orc_orbPattern(int patchSize, int wta_k, int* pat)
+{
+    buildPattern(patchSize, wta_k, pat);
+    return wta_k == 2 ? 1024 : 128 * wta_k * 2;
+}
+
+/* cv::ORB::detectAndCompute on a CV_8UC1 image, optional CV_8UC1 mask of the same size (NULL: none).  useProvided: nIn keypoints come in through kps
+ * (the mask is then unused, as in the reference).  Returns the keypoint count (kps / desc are filled up to cap), -1 for parameters outside the restatement. */
+int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* mask, size_t mstep, int nfeatures, float scaleFactorF, int nlevels, int edgeThreshold,
+                int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kpsIO, int nIn, int cap, uint8_t* desc, int doDesc)
 {
     const double scaleFactor = (double)scaleFactorF;                 /* ORB::create takes a float, the member is a double (orb.cpp:660, :1262) */
     KP* io = (KP*)kpsIO;
@@ -369,8 +415,9 @@ int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float 
     buildLayout(&L, w, h, nLevels, firstLevel, scaleFactor, edgeThreshold, patchSize);
     const int pitch = L.bufW;
     uint8_t* pyr = (uint8_t*)calloc((size_t)L.bufW * L.bufH, 1);
-    if (!pyr) return -1;
-    if (buildPyramid(&L, pyr, img, step, w, h, firstLevel)) { free(pyr); return -1; }
+    uint8_t* mpyr = (mask && !useProvided) ? (uint8_t*)calloc((size_t)L.bufW * L.bufH, 1) : NULL;
+    if (!pyr || (mask && !useProvided && !mpyr)) { free(pyr); free(mpyr); return -1; }
+    if (buildPyramid(&L, pyr, img, step, w, h, firstLevel, mpyr, mask, mstep)) { free(pyr); free(mpyr); return -1; }
 
     if (!useProvided) {
         /* computeKeyPoints :775-1000 */
@@ -390,7 +437,14 @@ int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float 
             int fcap = r.w * r.h / 4 + 16;
             float* f = (float*)malloc(sizeof(float) * 3 * fcap);
             int n = orc_FAST(im, (size_t)pitch, r.w, r.h, fastThreshold, 1, 2, f, fcap);
-            if (n < 0 || n > fcap) { free(f); free(umax); free(all); free(pyr); return -1; }
+            if (n < 0 || n > fcap) { free(f); free(umax); free(all); free(pyr); free(mpyr); return -1; }
+            if (mpyr) {                                                          /* FastFeatureDetector::detect -> KeyPointsFilter::runByPixelsMask (fast.cpp:583, keypoint.cpp:146-165) */
+                const uint8_t* mk = mpyr + (size_t)r.y * pitch + r.x;
+                int m = 0;
+                for (int i = 0; i < n; i++)
+                    if (mk[(size_t)(int)(f[3 * i + 1] + 0.5f) * pitch + (int)(f[3 * i] + 0.5f)] != 0) { f[3 * m] = f[3 * i]; f[3 * m + 1] = f[3 * i + 1]; f[3 * m + 2] = f[3 * i + 2]; m++; }
+                n = m;
+            }
             KP* k = (KP*)malloc(sizeof(KP) * (n + 1));
             for (int i = 0; i < n; i++) { k[i].x = f[3 * i]; k[i].y = f[3 * i + 1]; k[i].size = 7.f; k[i].angle = -1.f; k[i].response = f[3 * i + 2]; k[i].octave = 0; k[i].class_id = -1; }
             free(f);
@@ -438,18 +492,7 @@ int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float 
     if (doDesc && nAll) {
         int pat[1024];
         buildPattern(patchSize, wta_k, pat);
-        double g[7];
-        orc_getGaussianKernel(7, 2.0, g);
-        for (int i = 0; i < 7; i++) g[i] = (double)(float)g[i];                  /* createGaussianKernels: CV_32F taps for an 8-bit image (smooth.dispatch.cpp:278) */
-        for (int l = 0; l < nLevels; l++) {
-            const RectI r = L.layer[l];
-            uint8_t* im = pyr + (size_t)r.y * pitch + r.x;
-            uint8_t* tmp = (uint8_t*)malloc((size_t)r.w * r.h);
-            /* the neighbours of the submatrix are its own reflected border, so the isolated form gives the same pixels */
-            orc_sepFilter2D(im, (size_t)pitch, tmp, (size_t)r.w, r.w, r.h, 1, 0, 0, r.w, r.h, 0, 0, g, 7, g, 7, -1, -1, 0.0, ORC_BORDER_REFLECT_101);
-            for (int y = 0; y < r.h; y++) memcpy(im + (size_t)y * pitch, tmp + (size_t)y * r.w, (size_t)r.w);
-            free(tmp);
-        }
+        blurLevels(&L, pyr);
         for (int j = 0; j < nAll && j < cap; j++) {
             const RectI r = L.layer[all[j].octave];
             const float scale = 1.f / L.scale[all[j].octave];
@@ -458,6 +501,12 @@ int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float 
         }
     }
     for (int i = 0; i < nAll && i < cap; i++) io[i] = all[i];
-    free(all); free(pyr);
+    free(all); free(pyr); free(mpyr);
     return nAll;
+}
+
+int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
+            int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, uint8_t* desc, int doDesc)
+{
+    return orc_ORBmask(img, step, w, h, NULL, 0, nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, scoreType, patchSize, fastThreshold, useProvided, kps, nIn, cap, desc, doDesc);
 }

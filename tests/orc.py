@@ -1208,8 +1208,10 @@ KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32),
 ORB_DEFAULTS = dict(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2, scoreType=0, patchSize=31, fastThreshold=20)
 
 
-def _orb_call(fn, is_ref, src, keypoints, descriptors, cap, p):
+def _orb_call(fn, is_ref, src, keypoints, descriptors, cap, p, mask=None):
     h, w = src.shape[:2]
+    if mask is not None:
+        assert mask.shape == (h, w) and mask.dtype == np.uint8
     kps = np.zeros(cap, KP_DTYPE)
     n_in = 0
     if keypoints is not None:
@@ -1220,21 +1222,34 @@ def _orb_call(fn, is_ref, src, keypoints, descriptors, cap, p):
     c_f = ctypes.c_float
     tail = [p["nfeatures"], c_f(p["scaleFactor"]), p["nlevels"], p["edgeThreshold"], p["firstLevel"], p["WTA_K"], p["scoreType"], p["patchSize"],
             p["fastThreshold"], 1 if keypoints is not None else 0, P(kps), n_in, len(kps), P(desc), 1 if descriptors else 0]
+    m_args = [P(mask), step(mask)] if mask is not None else [None, c_sz(0)]
     if is_ref:
-        n = fn(P(src), step(src), w, h, cvtype(src), None, c_sz(0), *tail)
+        n = fn(P(src), step(src), w, h, cvtype(src), *m_args, *tail)
     else:
-        n = fn(P(src), step(src), w, h, *tail)
+        n = fn(P(src), step(src), w, h, *m_args, *tail)
     assert 0 <= n <= len(kps), n
     return kps[:n].copy(), (desc[:n].copy() if descriptors else None)
 
 
-def orc_ORB(src, keypoints=None, descriptors=True, cap=20000, **kw):
+def orc_ORB(src, keypoints=None, descriptors=True, cap=20000, mask=None, **kw):
     """cv::ORB::detectAndCompute by the restatement: (keypoints as a KP_DTYPE array in the reference's order, n x 32 descriptors)"""
-    return _orb_call(oracle().orc_ORB, False, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw))
+    return _orb_call(oracle().orc_ORBmask, False, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw), mask)
 
 
-def ref_ORB(src, keypoints=None, descriptors=True, cap=20000, **kw):
-    return _orb_call(load_ref().ref_ORB, True, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw))
+def ref_ORB(src, keypoints=None, descriptors=True, cap=20000, mask=None, **kw):
+    return _orb_call(load_ref().ref_ORB, True, src, keypoints, descriptors, cap, dict(ORB_DEFAULTS, **kw), mask)
+
+
+def orb_mask(w, h, seed=0):
+    """a mask with hard edges, a soft (1..254) ramp that the level thresholds eat differently, and isolated holes"""
+    rng = np.random.default_rng(1000 + seed)
+    m = np.full((h, w), 255, np.uint8)
+    m[:, : w // 5] = 0
+    m[h // 3: h // 2, w // 2: w // 2 + w // 6] = np.linspace(1, 254, w // 6).astype(np.uint8)[None, :]
+    m[rng.integers(0, h, 300), rng.integers(0, w, 300)] = 0
+    yy, xx = np.mgrid[0:h, 0:w]
+    m[(xx - 3 * w // 4) ** 2 + (yy - 2 * h // 3) ** 2 < (min(w, h) // 7) ** 2] = 0
+    return m
 
 
 def orb_scene(w, h, seed=0, texture=1.0):

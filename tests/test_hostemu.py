@@ -163,3 +163,134 @@ def test_resize8_lean_tiles_on_the_cpu(emu8):
             assert np.array_equal(got, want), (cn, sw, sh, dw, dh, interp, int(np.count_nonzero(got != want)), list(stats))
             served += stats[0]
     assert served > 200
+
+
+# ---- cv::ORB (opencv_amd/csrc/orb_math.h: per-lane arithmetic of the kernels; orb_host.h: the host control flow of orb.hip) ------------------------------
+@pytest.fixture(scope="module")
+def emuorb():
+    src = os.path.join(ROOT, "tests", "hostemu", "orb_emu.cpp")
+    out = os.path.join(ROOT, "tests", "hostemu", "liborbemu.so")
+    hdrs = [os.path.join(ROOT, "opencv_amd", "csrc", f) for f in ("orb_math.h", "orb_host.h", "orb_pattern.inc")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + os.path.join(ROOT, "opencv_amd", "csrc"), src, "-o", out])
+    lib = ctypes.CDLL(out)
+    lib.emu_orb_border.restype = ctypes.c_long
+    lib.emu_orb_fastAtan2.restype = ctypes.c_float
+    lib.emu_orb_fastAtan2.argtypes = [ctypes.c_float, ctypes.c_float]
+    return lib
+
+
+ORB_EMU_CASES = [
+    (640, 480, 0, {}),
+    (333, 222, 7, dict(edgeThreshold=5, nfeatures=2000, fastThreshold=5)),     # samples reach into the reflected ring
+    (400, 300, 6, dict(firstLevel=1)),                                        # level 0 is an upscale, the source image sits on level 1
+    (640, 480, 5, dict(WTA_K=4, edgeThreshold=19, patchSize=19)),             # random pattern
+    (500, 375, 4, dict(WTA_K=3, scaleFactor=1.5, nlevels=5)),
+    (97, 61, 8, dict(nlevels=3, edgeThreshold=8, patchSize=9)),
+]
+
+
+def _orb_layout(emuorb, w, h, p):
+    out = np.zeros(4 + 4 * 64, np.int32)
+    scales = np.zeros(64, np.float32)
+    pitch = emuorb.emu_orb_layout(w, h, p["nlevels"], p["firstLevel"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["patchSize"], o.P(out), o.P(scales))
+    return out, scales, pitch
+
+
+def _orc_pyramid(img, p, blurred=False):
+    orc = o.oracle()
+    fn = orc.orc_orbPyramidBlurred if blurred else orc.orc_orbPyramid
+    fn.restype = ctypes.c_void_p
+    out = np.zeros(4 + 4 * 64, np.int32)
+    h, w = img.shape
+    ptr = fn(o.P(img), o.step(img), w, h, p["nlevels"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["firstLevel"], p["patchSize"], o.P(out))
+    assert ptr
+    buf = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(out[3]), int(out[2]))).copy()
+    orc.orc_free(ctypes.c_void_p(ptr))
+    return buf, out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", ORB_EMU_CASES)
+def test_orb_kernel_lines_against_the_restatement(emuorb, w, h, seed, kw):
+    """layout, border pass, Harris + angle per keypoint and descriptor bytes as the kernels compute them, on the restatement's pyramid"""
+    p = dict(o.ORB_DEFAULTS, **kw)
+    img = o.orb_scene(w, h, seed)
+    pyr, lay = _orc_pyramid(img, p)
+    elay, scales, pitch = _orb_layout(emuorb, w, h, p)
+    assert np.array_equal(lay, elay) and pitch % 64 == 0 and pitch >= lay[2]
+    nl, border, bufW, bufH = (int(v) for v in lay[:4])
+    rects = lay[4:4 + 4 * nl].reshape(nl, 4)
+
+    # the border pass: interiors in place (every level but firstLevel), rings and the firstLevel interior written by the kernel's threads
+    mine = np.full((bufH, pitch), 0xA5, np.uint8)
+    covered = np.zeros((bufH, pitch), bool)
+    for l, (x, y, lw, lh) in enumerate(rects):
+        if l != p["firstLevel"]:
+            mine[y:y + lh, x:x + lw] = pyr[y:y + lh, x:x + lw]
+        covered[y - border:y + lh + border, x - border:x + lw + border] = True
+    for l in range(nl):
+        src = img if l == p["firstLevel"] else None
+        ran = emuorb.emu_orb_border(o.P(mine), w, h, nl, p["firstLevel"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["patchSize"], l,
+                                    o.P(src) if src is not None else None, o.step(src) if src is not None else ctypes.c_size_t(0))
+        assert ran > 0
+    assert np.array_equal(mine[:, :bufW][covered[:, :bufW]], pyr[covered[:, :bufW]])
+    assert np.all(mine[~covered] == 0xA5)                                        # nothing outside the extended rectangles is touched
+
+    # Harris response and angle of the final keypoints
+    kps, desc = o.orc_ORB(img, **kw)
+    assert len(kps) > 20
+    bl, _ = _orc_pyramid(img, p, blurred=True)
+    blp = np.zeros((bufH, pitch), np.uint8); blp[:, :bufW] = bl
+    got = np.zeros(2, np.float32)
+    d = np.zeros(32, np.uint8)
+    for k, want_d in zip(kps, desc):
+        l = int(k["octave"])
+        s = np.float32(1.0) / scales[l]
+        lx, ly = int(np.rint(np.float32(k["x"]) * s)), int(np.rint(np.float32(k["y"]) * s))
+        cx, cy = lx + int(rects[l][0]), ly + int(rects[l][1])
+        emuorb.emu_orb_score_angle(o.P(mine), pitch, cx, cy, p["patchSize"] // 2, ctypes.c_float(0.04), o.P(got))
+        assert got[1].view(np.int32) == k["angle"].view(np.int32), (k, got)
+        if p["scoreType"] == 0:
+            assert got[0].view(np.int32) == k["response"].view(np.int32), (k, got)
+        emuorb.emu_orb_desc(o.P(blp), pitch, cx, cy, ctypes.c_float(k["angle"]), p["patchSize"], p["WTA_K"], o.P(d))
+        assert np.array_equal(d, want_d), k
+
+
+def test_orb_host_tables_and_culls(emuorb):
+    orc = o.oracle()
+    orc.orc_fastAtan2.restype = ctypes.c_float
+    orc.orc_fastAtan2.argtypes = [ctypes.c_float, ctypes.c_float]
+    for patch, wta in [(31, 2), (31, 3), (31, 4), (19, 2), (19, 3), (9, 4), (127, 2), (64, 4)]:
+        want = np.zeros(1024, np.int32)
+        n = orc.orc_orbPattern(patch, wta, o.P(want))
+        got = np.zeros(1024, np.int8)
+        assert emuorb.emu_orb_pattern(patch, wta, o.P(got)) == n
+        assert np.array_equal(got[:n].astype(np.int32), want[:n]), (patch, wta)
+    for half in range(1, 64):
+        a, b = np.zeros(half + 2, np.int32), np.zeros(half + 2, np.int32)
+        orc.orc_orbUmax(half, o.P(a)); emuorb.emu_orb_umax(half, o.P(b))
+        assert np.array_equal(a, b), half
+    rng = np.random.default_rng(0)
+    for y, x in np.concatenate([rng.integers(-70000, 70000, (4000, 2)), [[0, 0], [0, 5], [5, 0], [0, -5], [-5, 0], [3, 3], [-3, 3], [3, -3], [-3, -3]]]):
+        assert np.float32(emuorb.emu_orb_fastAtan2(float(y), float(x))).view(np.int32) == np.float32(orc.orc_fastAtan2(float(y), float(x))).view(np.int32), (y, x)
+    # retainBest: the same survivors in the same order (std::nth_element of the C++ library on both sides of the product; the restatement is pinned to it)
+    for trial in range(200):
+        n = int(rng.integers(1, 700))
+        kp = np.zeros(n, o.KP_DTYPE)
+        kp["x"] = np.arange(n)
+        kp["response"] = rng.integers(0, 12, n) if trial % 2 else rng.random(n)
+        for npts in {0, 1, n // 3, n // 2, max(n - 1, 0), n, n + 5}:
+            a, b = kp.copy(), kp.copy()
+            na = emuorb.emu_orb_retainBest(o.P(a), n, npts)
+            nb = orc.orc_retainBest(o.P(b), n, npts)
+            assert na == nb and a[:na].tobytes() == b[:nb].tobytes(), (trial, n, npts)
+    # runByImageBorder: Rect(b, b, w - 2b, h - 2b).contains(Point(cvRound(x), cvRound(y)))
+    kp = np.zeros(2000, o.KP_DTYPE)
+    kp["x"] = rng.uniform(-5, 105, 2000).astype(np.float32); kp["y"] = rng.uniform(-5, 85, 2000).astype(np.float32)
+    kp["x"][:50] = np.float32(9.5); kp["x"][50:100] = np.float32(10.5); kp["y"][100:150] = np.float32(69.5)
+    a = kp.copy()
+    na = emuorb.emu_orb_runByImageBorder(o.P(a), len(a), 100, 80, 10)
+    rx, ry = np.rint(kp["x"]).astype(int), np.rint(kp["y"]).astype(int)
+    keep = (rx >= 10) & (rx < 90) & (ry >= 10) & (ry < 70)
+    assert na == keep.sum() and a[:na].tobytes() == kp[keep].tobytes()
+    assert emuorb.emu_orb_runByImageBorder(o.P(kp.copy()), len(kp), 20, 80, 10) == 0

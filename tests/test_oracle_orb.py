@@ -21,6 +21,8 @@ CASES = [
     (333, 222, 7, dict(edgeThreshold=5, nfeatures=2000, fastThreshold=5)),   # descriptors reach into the reflected border
     (97, 61, 8, dict(nlevels=3, edgeThreshold=8, patchSize=9)),
     (64, 48, 9, {}),                                                    # nothing survives the 31-pixel edge on the small levels
+    (640, 480, 12, dict(scaleFactor=2.0, nlevels=4, nfeatures=800)),    # exactly-half levels: INTER_LINEAR_EXACT becomes the 2 x 2 mean (resize.cpp:3976)
+    (641, 479, 13, dict(scaleFactor=2.0, nlevels=3, firstLevel=1)),     # and an exact 2 x upscale
 ]
 
 
@@ -34,6 +36,19 @@ def test_orb_restatement_equals_reference(w, h, seed, kw):
     for f in o.KP_DTYPE.names:
         assert np.array_equal(rk[f].view(np.int32), ok[f].view(np.int32)), f
     assert np.array_equal(rd, od)
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h,seed,kw", [(640, 480, 20, {}), (400, 300, 21, dict(firstLevel=1, nfeatures=800)), (500, 375, 22, dict(scoreType=1, scaleFactor=1.4, nlevels=6))])
+def test_orb_with_a_mask(w, h, seed, kw):
+    """the mask pyramid (resize + THRESH_TOZERO at 254 per level) and KeyPointsFilter::runByPixelsMask after FAST"""
+    img, mask = o.orb_scene(w, h, seed), o.orb_mask(w, h, seed)
+    rk, rd = o.ref_ORB(img, mask=mask, **kw)
+    ok, od = o.orc_ORB(img, mask=mask, **kw)
+    fk, _ = o.ref_ORB(img, **kw)
+    assert rk.tobytes() == ok.tobytes() and np.array_equal(rd, od)
+    assert len(rk) > 50 and rk.tobytes() != fk.tobytes()
+    assert np.all(mask[np.rint(rk["y"][rk["octave"] == kw.get("firstLevel", 0)]).astype(int), np.rint(rk["x"][rk["octave"] == kw.get("firstLevel", 0)]).astype(int)] != 0)
 
 
 @needs_ref
