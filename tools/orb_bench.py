@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import orc  # noqa: E402
 import opencv_amd as cv  # noqa: E402
 
