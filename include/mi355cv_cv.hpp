@@ -259,6 +259,75 @@ inline void FAST(cv::InputArray _image, std::vector<cv::KeyPoint>& keypoints, in
     }
     cv::FAST(_image, keypoints, threshold, nonmaxSuppression, type);
 }
+
+// cv::ORB (features2d.hpp:425-520; ORB_Impl, orb.cpp:655-1265).  The reference has no HAL hook for ORB: behind the imgproc / features2d hooks alone
+// every pyramid level's resize, FAST and blur would cross PCIe on its own.  mi355cv::ORB_create returns a cv::ORB whose detectAndCompute sends a
+// CV_8UC1 cv::Mat (and mask) through mi355cv_ORB_detectAndCompute -- one upload, pyramid / FAST / Harris / angles / smoothing / descriptors on the
+// device, keypoints and descriptors identical to cv::ORB's, order included -- and hands everything else (UMat, colour images, parameters the library
+// declines, no device) to the stock implementation it wraps.  Parameters live in the stock object, so getters / setters / write() behave as before.
+class ORB CV_FINAL : public cv::ORB
+{
+public:
+    explicit ORB(const cv::Ptr<cv::ORB>& stock) : stock_(stock) {}
+    void setMaxFeatures(int v) CV_OVERRIDE { stock_->setMaxFeatures(v); }            int getMaxFeatures() const CV_OVERRIDE { return stock_->getMaxFeatures(); }
+    void setScaleFactor(double v) CV_OVERRIDE { stock_->setScaleFactor(v); }          double getScaleFactor() const CV_OVERRIDE { return stock_->getScaleFactor(); }
+    void setNLevels(int v) CV_OVERRIDE { stock_->setNLevels(v); }                     int getNLevels() const CV_OVERRIDE { return stock_->getNLevels(); }
+    void setEdgeThreshold(int v) CV_OVERRIDE { stock_->setEdgeThreshold(v); }         int getEdgeThreshold() const CV_OVERRIDE { return stock_->getEdgeThreshold(); }
+    void setFirstLevel(int v) CV_OVERRIDE { stock_->setFirstLevel(v); }               int getFirstLevel() const CV_OVERRIDE { return stock_->getFirstLevel(); }
+    void setWTA_K(int v) CV_OVERRIDE { stock_->setWTA_K(v); }                         int getWTA_K() const CV_OVERRIDE { return stock_->getWTA_K(); }
+    void setScoreType(cv::ORB::ScoreType v) CV_OVERRIDE { stock_->setScoreType(v); }  cv::ORB::ScoreType getScoreType() const CV_OVERRIDE { return stock_->getScoreType(); }
+    void setPatchSize(int v) CV_OVERRIDE { stock_->setPatchSize(v); }                 int getPatchSize() const CV_OVERRIDE { return stock_->getPatchSize(); }
+    void setFastThreshold(int v) CV_OVERRIDE { stock_->setFastThreshold(v); }         int getFastThreshold() const CV_OVERRIDE { return stock_->getFastThreshold(); }
+    int descriptorSize() const CV_OVERRIDE { return stock_->descriptorSize(); }
+    int descriptorType() const CV_OVERRIDE { return stock_->descriptorType(); }
+    int defaultNorm() const CV_OVERRIDE { return stock_->defaultNorm(); }
+    bool empty() const CV_OVERRIDE { return stock_->empty(); }
+
+    void detectAndCompute(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray _descriptors,
+                          bool useProvidedKeypoints = false) CV_OVERRIDE
+    {
+        const bool doDesc = _descriptors.needed();
+        if ((_image.kind() == cv::_InputArray::MAT) && (_mask.empty() || _mask.kind() == cv::_InputArray::MAT) && !_descriptors.isUMat() &&
+            (doDesc || !useProvidedKeypoints)) {
+            cv::Mat image = _image.getMat(), mask = _mask.getMat();
+            // the member is a double that ORB::create filled from a float: the library takes the float back only when nothing is lost (setScaleFactor(1.3) is)
+            const double sf = stock_->getScaleFactor();
+            if (image.dims <= 2 && image.type() == CV_8UC1 && !image.empty() && (mask.empty() || (mask.type() == CV_8UC1 && mask.size() == image.size())) &&
+                (double)(float)sf == sf) {
+                static_assert(sizeof(cv::KeyPoint) == sizeof(mi355cv_KeyPoint), "cv::KeyPoint is the 28-byte record mi355cv_KeyPoint declares");
+                const mi355cv_OrbParams prm = {stock_->getMaxFeatures(), (float)sf, stock_->getNLevels(), stock_->getEdgeThreshold(), stock_->getFirstLevel(), stock_->getWTA_K(),
+                                               (int)stock_->getScoreType(), stock_->getPatchSize(), stock_->getFastThreshold()};
+                std::vector<cv::KeyPoint> kp(keypoints);
+                const int nIn = useProvidedKeypoints ? (int)kp.size() : 0;
+                size_t cap = std::max<size_t>((size_t)nIn, (size_t)std::max(prm.nfeatures, 0) + 64);
+                for (;;) {
+                    kp.resize(cap);
+                    cv::Mat desc;
+                    if (doDesc) desc.create((int)cap, 32, CV_8U);
+                    const int n = mi355cv_ORB_detectAndCompute(image.data, image.step, image.cols, image.rows, mask.empty() ? nullptr : mask.data, mask.empty() ? 0 : (size_t)mask.step, &prm,
+                                                               useProvidedKeypoints ? 1 : 0, reinterpret_cast<mi355cv_KeyPoint*>(kp.data()), nIn, (int)cap,
+                                                               doDesc ? desc.data : nullptr, doDesc ? (size_t)desc.step : 0);
+                    if (n < 0) break;                                             // declined or failed: nothing was written to the caller's arrays
+                    if ((size_t)n > cap) { cap = (size_t)n; if (useProvidedKeypoints) break; kp.assign(keypoints.begin(), keypoints.end()); continue; }
+                    kp.resize((size_t)n);
+                    keypoints.swap(kp);
+                    if (doDesc) { if (n == 0) _descriptors.release(); else desc.rowRange(0, n).copyTo(_descriptors); }
+                    return;
+                }
+            }
+        }
+        stock_->detectAndCompute(_image, _mask, keypoints, _descriptors, useProvidedKeypoints);
+    }
+    // Feature2D::detect / compute (feature2d.cpp:61-155) call detectAndCompute of *this
+private:
+    cv::Ptr<cv::ORB> stock_;
+};
+
+inline cv::Ptr<cv::ORB> ORB_create(int nfeatures = 500, float scaleFactor = 1.2f, int nlevels = 8, int edgeThreshold = 31, int firstLevel = 0, int WTA_K = 2,
+                                   cv::ORB::ScoreType scoreType = cv::ORB::HARRIS_SCORE, int patchSize = 31, int fastThreshold = 20)
+{
+    return cv::makePtr<mi355cv::ORB>(cv::ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize, fastThreshold));
+}
 #endif
 
 #ifdef OPENCV_TRACKING_HPP      // cv::calcOpticalFlowPyrLK lives in opencv2/video/tracking.hpp; include it before this header to get the wrapper

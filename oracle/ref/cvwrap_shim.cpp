@@ -129,6 +129,30 @@ EXPORT int wrap_FAST(const void* s, size_t ss, int w, int h, int threshold, int 
     catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
 
+// mi355cv::ORB_create(...)->detectAndCompute / detect / compute with std::vector<KeyPoint>, as applications call cv::ORB; arguments as ref_ORB (ref_shim.cpp).
+// setScale != 0: the scale factor is then set again through setScaleFactor(double) -- a value a float cannot hold keeps the call on the stock path.
+EXPORT int wrap_ORB(const void* s, size_t ss, int w, int h, int type, const void* mask, size_t ms, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
+                    int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc)
+{
+    try {
+        Mat src = M(s, ss, w, h, type), m;
+        if (mask) m = M(mask, ms, w, h, CV_8UC1);
+        Ptr<cv::ORB> orb = mi355cv::ORB_create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, (cv::ORB::ScoreType)scoreType, patchSize, fastThreshold);
+        if (orb->getMaxFeatures() != nfeatures || orb->getWTA_K() != wta_k || orb->descriptorSize() != 32 || orb->getDefaultName() != "Feature2D.ORB") return -3;
+        std::vector<KeyPoint> kp;
+        if (useProvided) kp.assign((const KeyPoint*)kps, (const KeyPoint*)kps + nIn);
+        Mat d;
+        if (doDesc && useProvided) orb->compute(src, kp, d);                       // Feature2D::compute -> detectAndCompute(..., true) of the wrapper
+        else if (doDesc) orb->detectAndCompute(src, m, kp, d);
+        else orb->detect(src, kp, m);
+        const int n = (int)kp.size(), take = n < cap ? n : cap;
+        if (doDesc && n && (d.rows != n || d.cols != 32 || d.type() != CV_8U)) return -4;
+        if (take) memcpy(kps, kp.data(), (size_t)take * sizeof(KeyPoint));
+        if (doDesc && take) for (int i = 0; i < take; i++) memcpy((uchar*)desc + (size_t)i * 32, d.ptr(i), 32);
+        return n;
+    } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
+
 // mi355cv::calcOpticalFlowPyrLK with std::vector outputs, as applications call it
 EXPORT int wrap_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* next, size_t ns, int w, int h, int type, const float* pts, float* nextPts, int npts,
                                      unsigned char* status, float* err, int winW, int winH, int maxLevel, int critType, int maxCount, double eps, int flags, double minEig)

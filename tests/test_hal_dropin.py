@@ -377,6 +377,48 @@ def test_cv_signature_fast_wrapper_gpu(ref):
         assert cv.call_count(k) > n[k], f"{k} was not served by the GPU"
 
 
+def _orb_tour(hal):
+    """mi355cv::ORB_create (cv::ORB's interface, include/mi355cv_cv.hpp) against the stock cv::ORB: detectAndCompute, detect, compute, with a mask;
+    and cv::ORB of the HAL-enabled build itself (its resize / FAST / sepFilter calls go through the hooks)"""
+    for (w, h, seed, kw, masked) in [(640, 480, 0, {}, False), (400, 300, 6, dict(firstLevel=1, nfeatures=700), True), (500, 375, 4, dict(WTA_K=3, scoreType=1), False)]:
+        img = O.orb_scene(w, h, seed)
+        mask = O.orb_mask(w, h, seed) if masked else None
+        p = dict(O.ORB_DEFAULTS, **kw)
+        wk, wd = O.ref_ORB(img, mask=mask, **kw)
+        gk, gd = O._orb_call(hal.wrap_ORB, True, img, None, True, 20000, p, mask)
+        assert len(wk) > 100 and gk.tobytes() == wk.tobytes() and np.array_equal(gd, wd), (w, h, kw)
+        dk, _ = O._orb_call(hal.wrap_ORB, True, img, None, False, 20000, p, mask)                      # detect only
+        assert dk.tobytes() == wk.tobytes()
+        sub = wk[::3].copy()[::-1].copy()                                                              # compute(): out of level order
+        ck, cd = O._orb_call(hal.wrap_ORB, True, img, sub, True, 20000, p)
+        rk, rd = O.ref_ORB(img, keypoints=sub, **kw)
+        assert ck.tobytes() == rk.tobytes() and np.array_equal(cd, rd)
+        with O.use_ref(hal):                                                                           # cv::ORB of the HAL-enabled build
+            hk, hd = O.ref_ORB(img, mask=mask, **kw)
+        assert hk.tobytes() == wk.tobytes() and np.array_equal(hd, wd)
+
+
+def test_cv_signature_orb_wrapper(ref):
+    """here (no device) mi355cv::ORB hands every call to the stock implementation it wraps: identical results"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see the _gpu variant")
+    hal = O.load_ref_hal()
+    if hal is None or not hasattr(hal, "wrap_ORB"):
+        pytest.skip("oracle/_ref/libocvref_hal.so not built (or built before wrap_ORB)")
+    _orb_tour(hal)
+
+
+@pytest.mark.gpu
+def test_cv_signature_orb_wrapper_gpu(ref):
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None and hasattr(hal, "wrap_ORB")
+    n = cv.call_count("ORB_detectAndCompute")
+    _orb_tour(hal)
+    assert cv.call_count("ORB_detectAndCompute") >= n + 9, "mi355cv::ORB was not served by the GPU"
+
+
 def _wrap_lk(hal, A, B, p, win, maxLevel, flags=0, guess=None):
     import ctypes
     n = len(p)
