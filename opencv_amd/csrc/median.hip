@@ -5,11 +5,17 @@
 // v_pk_max_u16.
 //   3x3: the three rows are sorted per column once (shared by the three outputs that use the column), then
 //        median = med3( max(lows), med3(mids), min(highs) )   -- 9 packed ops per pixel.
-//   5x5: a 113-exchange selection network (median_net.h, generated and verified by tools/gen_median_net.py).
-// HBM-bound for 3x3 (2*cn bytes per pixel); 5x5 is VALU-bound at ~113 packed exchanges per pixel pair.
+//   5x5: columns sorted once per position, then the median of five sorted columns by merging (median5_math.h: 391 exchanges per lane row of 16
+//        single-channel pixels, 9 + 61 per output word for 3 / 4 channels); MI355CV_MEDIAN5=net selects the former 113-exchange network on
+//        unordered values (median_net.h; 904 per lane row) for A/B runs.  Both generated and verified by tools/gen_median_net.py.
+// HBM-bound for 3x3 (2*cn bytes per pixel); 5x5 is VALU-bound.
 #include "rt.h"
 #include "roll.h"
 #include "median_net.h"
+#include "median5_math.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 using namespace mi355;
 
@@ -20,7 +26,7 @@ __device__ __forceinline__ uint32_t pmin(uint32_t a, uint32_t b) { return __buil
 __device__ __forceinline__ uint32_t pmax(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
 __device__ __forceinline__ uint32_t pmed3(uint32_t a, uint32_t b, uint32_t c) { return pmax(pmin(a, b), pmin(pmax(a, b), c)); }
 
-template <int K, int CN>
+template <int K, int CN, bool SORTED = true>
 __global__ __launch_bounds__(256) void k_median_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                      int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes)
 {
@@ -31,9 +37,15 @@ __global__ __launch_bounds__(256) void k_median_roll(const uchar* __restrict__ s
     Cx cx;
     if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, B_REPLICATE, 1)) return;
     dst += (size_t)cx.frame * dframe;
-    struct RowP { uint32_t E[NW], O[NW]; };
+    struct RowEO { uint32_t E[NW], O[NW]; };
+    // 5 x 5 on sorted columns, 3 / 4 channels: the ring holds window dwords, the planes are split off where a column is sorted (40 registers of state, not 80)
+    constexpr bool RAWRING = K == 5 && SORTED && CN > 1;
+    typedef typename std::conditional<RAWRING, med5::RowX<NW>, RowEO>::type RowP;
     RowP ring[K];
-    auto planes = [&](RowP& p, const RawT& raw) { uint32_t X[NW]; cx.window(X, raw); roll::planes<NW>(p.E, p.O, X); };
+    auto planes = [&](RowP& p, const RawT& raw) {
+        if constexpr (RAWRING) cx.window(p.X, raw);
+        else { uint32_t X[NW]; cx.window(X, raw); roll::planes<NW>(p.E, p.O, X); }
+    };
 #pragma unroll
     for (int i = 0; i < K - 1; i++) { RawT pre; int v; cx.issue(pre, i - R, v); planes(ring[i], pre); }
     RawT raw[K]; int rv[K];
@@ -73,6 +85,9 @@ __global__ __launch_bounds__(256) void k_median_roll(const uchar* __restrict__ s
                         }
                         o[k] = r2[0] | (r2[1] << 8);                 // bytes 4k..4k+3 = (E.lo, O.lo, E.hi, O.hi)
                     }
+                } else if constexpr (SORTED) {
+                    if constexpr (CN == 1) med5::row1(ring, o);
+                    else med5::rowN<CN, HD, NW>(ring, o);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -157,8 +172,13 @@ extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_
     }
     const roll::Geom g = roll::geometry(width, height, cn, 1, ksize == 3 ? 16 : 12, ksize);
 #define MED(K_, CN_) hipLaunchKernelGGL((k_median_roll<K_, CN_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, 0, dd, dds, 0, width, height, g.nchunks, g.nstrips, g.seg, g.nseg, 1)
+#define MEDN(CN_) hipLaunchKernelGGL((k_median_roll<5, CN_, false>), dim3(g.blocks), dim3(256), 0, st, ds, dss, 0, dd, dds, 0, width, height, g.nchunks, g.nstrips, g.seg, g.nseg, 1)
+    static const bool net5 = [] { const char* e = getenv("MI355CV_MEDIAN5"); return e && !strcmp(e, "net"); }();
     if (ksize == 3) { if (cn == 1) MED(3, 1); else if (cn == 3) MED(3, 3); else MED(3, 4); }
+    else if (net5)  { if (cn == 1) MEDN(1); else if (cn == 3) MEDN(3); else MEDN(4); }
     else            { if (cn == 1) MED(5, 1); else if (cn == 3) MED(5, 3); else MED(5, 4); }
+    noteKernel("k_median_roll<%d,%d,%s> grid=%u x256", ksize, cn, ksize == 5 && net5 ? "net" : "sorted-columns", g.blocks);
+#undef MEDN
 #undef MED
     return stg.finish("medianBlur");
 }

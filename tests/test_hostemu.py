@@ -294,3 +294,30 @@ def test_orb_host_tables_and_culls(emuorb):
     keep = (rx >= 10) & (rx < 90) & (ry >= 10) & (ry < 70)
     assert na == keep.sum() and a[:na].tobytes() == kp[keep].tobytes()
     assert emuorb.emu_orb_runByImageBorder(o.P(kp.copy()), len(kp), 20, 80, 10) == 0
+
+
+# ---- the 5 x 5 median on columns sorted once per position (opencv_amd/csrc/median5_math.h, networks of median_net.h) ---------------------------------
+@pytest.fixture(scope="module")
+def emumed():
+    src = os.path.join(ROOT, "tests", "hostemu", "median5_emu.cpp")
+    out = os.path.join(ROOT, "tests", "hostemu", "libmedian5emu.so")
+    hdrs = [os.path.join(ROOT, "opencv_amd", "csrc", f) for f in ("median5_math.h", "median_net.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "opencv_amd", "csrc"), src, "-o", out])
+    return ctypes.CDLL(out)
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_median5_sorted_columns_lines(emumed, cn):
+    """the kernel's per-lane lines on every 16-byte chunk of whole images: equal to the restatement of cv::medianBlur(5)"""
+    rng = np.random.default_rng(cn)
+    for (w, h) in [(16, 5), (17, 9), (64, 33), (131, 40), (5, 7), (257, 19)]:
+        shape = (h, w) if cn == 1 else (h, w, cn)
+        imgs = [rng.integers(0, 256, shape, dtype=np.uint8),
+                rng.integers(0, 4, shape, dtype=np.uint8) * 85,                                              # heavy ties
+                (rng.integers(0, 2, shape, dtype=np.uint8) * 255),                                           # salt and pepper
+                np.broadcast_to(np.arange(w, dtype=np.uint8).reshape((1, w) + (() if cn == 1 else (1,))), shape).copy()]
+        for img in imgs:
+            got = np.full_like(img, 0x5A)
+            assert emumed.emu_median5(o.P(img), o.step(img), o.P(got), o.step(got), w, h, cn) == 0
+            assert np.array_equal(got, o.orc_medianBlur(img, 5)), (cn, w, h)
