@@ -278,8 +278,8 @@ MI355CV_API int mi355cv_pyrdownBatch(const mi355cv_uchar* src_data, size_t src_s
 /* cv::buildPyramid (pyramids.cpp:1616-1643) has no HAL hook: dst_data[i] / dst_step[i] receive level i+1. */
 MI355CV_API int mi355cv_buildPyramid(const mi355cv_uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
         mi355cv_uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type);
-/* the same over a batch of device-resident frames, all levels of all frames enqueued by one call: dst_data[l-1] / dst_step[l-1] /
- * dst_frame_stride[l-1] describe level l (frame 0's pointer, row pitch, bytes between frames) of pre-allocated arrays */
+/* the same over a batch of frames, all levels of all frames enqueued by one call: dst_data[l-1] / dst_step[l-1] / dst_frame_stride[l-1] describe
+ * level l (frame 0's pointer, row pitch, bytes between frames) of pre-allocated arrays.  Frames and levels all in HBM, or all in host memory */
 MI355CV_API int mi355cv_buildPyramidBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, int width, int height, int depth, int cn,
         mi355cv_uchar* const* dst_data, const size_t* dst_step, const size_t* dst_frame_stride, int maxlevel, int nframes, int border_type);
 
@@ -480,7 +480,7 @@ MI355CV_API int mi355cv_integralBatch(const mi355cv_uchar* src_data, size_t src_
  * One launch where the kernel takes a frame index (the rolling filters, nearest / bilinear / area-fast resize, the warps, threshold on
  * back-to-back frames), otherwise the per-frame kernels enqueued by one call.  Both ends in HBM -- or both in host memory (pageable or page-locked): the
  * batch then crosses PCIe in chunks of <= 16 frames / 64 MB through two sets of device buffers, upload of chunk i+1 overlapped with the kernels and the
- * download of chunk i.  mi355cv_buildPyramidBatch and mi355cv_matchTemplateBatch take device pointers only. */
+ * download of chunk i; mi355cv_buildPyramidBatch (one output per level) and mi355cv_matchTemplateBatch included. */
 MI355CV_API int mi355cv_sobelBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride, mi355cv_uchar* dst_data, size_t dst_step,
         size_t dst_frame_stride, int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta,
         int border_type);

@@ -843,10 +843,23 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
     int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
     if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    // every frame and every level in host memory: chunks of frames cross PCIe through two sets of device buffers, the upload of
+    // chunk i + 1 under the kernels and the downloads of chunk i; the chunk itself is this entry on device pointers
+    bool allHost = hostBatchEligible(src_data, dst_data[0], nframes) && maxlevel <= HOST_BATCH_MAX_OUT;
+    for (int l = 1; l < maxlevel && allHost; l++) allHost = dst_data[l] && ptrKind(dst_data[l]) == PTR_HOST;
+    if (allHost) {
+        const size_t e = (size_t)depthBytes(depth) * cn;
+        HostBatchN hb; memset(&hb, 0, sizeof hb);
+        hb.src = src_data; hb.sstep = src_step; hb.sframe = src_frame_stride; hb.srowBytes = (size_t)width * e; hb.srows = height; hb.nout = maxlevel; hb.nframes = nframes;
+        int w = width, h = height;
+        for (int l = 0; l < maxlevel; l++) { w = (w + 1) / 2; h = (h + 1) / 2; hb.out[l] = {dst_data[l], dst_step[l], dst_frame_stride[l], (size_t)w * e, h}; }
+        return runHostBatchN("buildPyramidBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* const* d, const size_t* ds, const size_t* df, int nf) {
+            return mi355cv_buildPyramidBatch(s, ss, sf, width, height, depth, cn, d, ds, df, maxlevel, nf, border_type); });
+    }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data)) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
-    for (int l = 0; l < maxlevel; l++) if (!isDevicePtr(dst_data[l])) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: device-resident frames only");
+    if (!isDevicePtr(src_data)) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: frames and levels all in device memory, or all in host memory");
+    for (int l = 0; l < maxlevel; l++) if (!isDevicePtr(dst_data[l])) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: frames and levels all in device memory, or all in host memory");
     const uchar* s = src_data; size_t ss = src_step, sf = nframes == 1 ? 0 : src_frame_stride; int w = width, h = height;
     for (int l = 0; l < maxlevel; l++) {
         const int dw = (w + 1) / 2, dh = (h + 1) / 2;

@@ -105,10 +105,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uchar* __restrict__ src,
 // candidates of the final score image (interior pixels with score > thr): counted, then written as keys ~index : score so that a descending
 // sort puts them in raster order
 __global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ sc, size_t step, int w, int h, int thr, unsigned* __restrict__ counter,
-                                                      unsigned long long* __restrict__ keys, unsigned cap, const uchar* __restrict__ mask, size_t mstep)
+                                                      unsigned long long* __restrict__ keys, unsigned cap, const uchar* __restrict__ mask, size_t mstep, int edge)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < 3 || y < 3 || x + 3 >= w || y + 3 >= h) return;
+    if (x < edge || y < edge || x >= w - edge || y >= h - edge) return;                      // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) for ORB's levels; 0 elsewhere
     const int s = sc[(size_t)y * step + x];
     if (s <= thr) return;
     if (mask && mask[(size_t)y * mstep + x] == 0) return;                                    // KeyPointsFilter::runByPixelsMask (keypoint.cpp:146-165) on integer coordinates
@@ -140,10 +141,10 @@ void fastLaunchScores(const uchar* s, size_t ss, int w, int h, uchar* sc, uchar*
     hipLaunchKernelGGL(k_fast_dense16, g4, dim3(256), 0, st, s, ss, sc, pitch, w, h);
     if (sup) hipLaunchKernelGGL(k_fast_nms, g4, dim3(256), 0, st, sc, pitch, sup, pitch, w, h);
 }
-void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st)
+void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, int edge, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st)
 {
     const dim3 g1(divUp(w, 64), divUp(h, 4));
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, w, h, thr, counter, keys, cap, mask, mstep);
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, w, h, thr, counter, keys, cap, mask, mstep, edge);
 }
 }
 
@@ -196,7 +197,7 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     if (!thr && nonmax_suppression) thr = 1;                                                 // fast.cpp:467: with suppression a cornerScore of 0 never wins FAST_t's strict comparisons
     unsigned n = 0;
     if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u, (const uchar*)nullptr, (size_t)0);
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u, (const uchar*)nullptr, (size_t)0, 0);
     if (hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     if (n == 0 || capacity == 0) { const int rc = stg.finish("FAST"); return rc == MI355CV_OK ? (int)n : -2; }
     unsigned long long* keys = (unsigned long long*)stg.scratch((size_t)n * 8);
@@ -205,7 +206,7 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     void* temp = stg.scratch(tb ? tb : 16);
     if (!keys || !sorted || !tb || !temp) return -2;
     if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n, (const uchar*)nullptr, (size_t)0);
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n, (const uchar*)nullptr, (size_t)0, 0);
     if (!sortKeysDesc(temp, tb, keys, sorted, n, st)) return -2;
     const unsigned take = n < (unsigned)capacity ? n : (unsigned)capacity;
     std::vector<unsigned long long> host(take);

@@ -25,7 +25,7 @@
 
 namespace mi355 {
 void fastLaunchScores(const uchar* s, size_t ss, int w, int h, uchar* sc, uchar* sup, size_t pitch, hipStream_t st);                       // fast.hip
-void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st);
+void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, int edge, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st);
 size_t sortKeysDescTemp(unsigned n);                                                                                                      // gftt_sort.hip (rocPRIM)
 bool sortKeysDesc(void* temp, size_t bytes, const unsigned long long* in, unsigned long long* out, unsigned n, hipStream_t st);
 }
@@ -207,12 +207,17 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
         std::vector<unsigned> caps(nLevels);
         for (int l = 0; l < nLevels; l++) {
             const orbm::Layer r = L.layer[l];
-            caps[l] = (unsigned)(((size_t)(r.w + 1) / 2) * ((size_t)(r.h + 1) / 2) + 1);         // a 3 x 3 strict maximum: at most one per 2 x 2 block
+            // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) follows FAST at once: the collect pass applies it, so candidates near the edge never
+            // leave the GPU; a level no wider than the two borders has no keypoints at all
+            const int edge = p.edgeThreshold > 0 ? p.edgeThreshold : 0;
+            caps[l] = 0; keys[l] = nullptr;
+            if (edge > 0 && (r.h <= 2 * edge || r.w <= 2 * edge)) continue;
+            caps[l] = (unsigned)(((size_t)(r.w - 2 * edge + 2) / 2) * ((size_t)(r.h - 2 * edge + 2) / 2) + 1); // a 3 x 3 strict maximum: at most one per 2 x 2 block
             keys[l] = (unsigned long long*)stg.scratch((size_t)caps[l] * 8);
             if (!keys[l]) return -2;
             const uchar* im = pyr + (size_t)r.y * L.pitch + r.x;
             fastLaunchScores(im, (size_t)L.pitch, r.w, r.h, sc, sup, spitch, st);
-            fastLaunchCollect(sup, spitch, r.w, r.h, thr, mpyr ? mpyr + (size_t)r.y * L.pitch + r.x : nullptr, (size_t)L.pitch, counters + l, keys[l], caps[l], st);
+            fastLaunchCollect(sup, spitch, r.w, r.h, thr, mpyr ? mpyr + (size_t)r.y * L.pitch + r.x : nullptr, (size_t)L.pitch, edge, counters + l, keys[l], caps[l], st);
         }
         unsigned cnt[MAX_LEVELS];
         if (!copyD2H(cnt, counters, sizeof(unsigned) * MAX_LEVELS, st)) return -2;
@@ -232,18 +237,15 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
 
         std::vector<int> counts(nLevels);
         std::vector<KP> lvl;
+        std::vector<Cand> cand;
         for (int l = 0; l < nLevels; l++) {
             const orbm::Layer r = L.layer[l];
-            lvl.resize(hk[l].size());
-            for (size_t i = 0; i < hk[l].size(); i++) {
-                const unsigned idx = 0xffffffffu - (unsigned)(hk[l][i] >> 32), sv = (unsigned)(hk[l][i] & 0xffffffffu);
-                lvl[i] = {(float)(idx % (unsigned)r.w), (float)(idx / (unsigned)r.w), 7.f, -1.f, (float)((int)sv - 1), 0, -1};
-            }
-            runByImageBorder(lvl, r.w, r.h, p.edgeThreshold);
-            retainBest(lvl, p.scoreType == 0 ? 2 * nfl[l] : nfl[l]);
-            counts[l] = (int)lvl.size();
-            for (KP& k : lvl) { k.octave = l; k.size = p.patchSize * L.scale[l]; }
-            all.insert(all.end(), lvl.begin(), lvl.end());
+            cand.resize(hk[l].size());
+            for (size_t i = 0; i < hk[l].size(); i++) cand[i] = {(float)((int)(unsigned)(hk[l][i] & 0xffffffffu) - 1), 0xffffffffu - (unsigned)(hk[l][i] >> 32)};
+            retainBestCand(cand, p.scoreType == 0 ? 2 * nfl[l] : nfl[l]);
+            counts[l] = (int)cand.size();
+            const float size = p.patchSize * L.scale[l];
+            for (const Cand& c : cand) all.push_back({(float)(c.idx % (unsigned)r.w), (float)(c.idx / (unsigned)r.w), size, -1.f, c.response, l, -1});
         }
         if (!all.empty()) {
             const int n = (int)all.size(), half = p.patchSize / 2;

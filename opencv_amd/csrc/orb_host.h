@@ -70,6 +70,19 @@ inline void retainBest(std::vector<KP>& k, int npoints)
     k.resize(e - k.begin());
 }
 
+// The first cull of a level sees every FAST candidate inside the border (10^5 on a 4K level 0; the border test itself runs in the collect kernel): the
+// same two algorithms on 8-byte (response, pixel index) records instead of 28-byte keypoints.  std::nth_element / std::partition move elements by comparison outcomes and positions only, so the survivors and their order are
+// those of the keypoint vector (tests/test_hostemu.py holds both against the pinned restatement); keypoints are then built for the survivors alone.
+struct Cand { float response; uint32_t idx; };
+inline void retainBestCand(std::vector<Cand>& k, int npoints)
+{
+    if (npoints < 0 || k.size() <= (size_t)npoints) return;
+    if (npoints == 0) { k.clear(); return; }
+    std::nth_element(k.begin(), k.begin() + npoints - 1, k.end(), [](const Cand& a, const Cand& b) { return a.response > b.response; });
+    const float amb = k[npoints - 1].response;
+    auto e = std::partition(k.begin() + npoints, k.end(), [amb](const Cand& a) { return a.response >= amb; });
+    k.resize(e - k.begin());
+}
 // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119): Rect((b, b), (w - b, h - b)).contains(Point_<int>(pt)) -- the conversion rounds
 inline void runByImageBorder(std::vector<KP>& k, int w, int h, int b)
 {

@@ -99,6 +99,18 @@ typedef std::function<int(const uchar* s, size_t sstep, size_t sframe, uchar* d,
 bool hostBatchEligible(const void* src, const void* dst, int nframes);
 int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run);
 
+// The same pipeline for entries with several outputs per frame (cv::buildPyramid: one image per level): every output has its own geometry, the chunk
+// size is what the largest of them allows.  `run` gets the chunk's dense device frames and one (pointer, pitch, frame stride) triple per output.
+constexpr int HOST_BATCH_MAX_OUT = 32;
+struct HostBatchOut { uchar* dst; size_t dstep, dframe, drowBytes; int drows; };
+struct HostBatchN {
+    const uchar* src; size_t sstep, sframe, srowBytes; int srows;
+    int nout; HostBatchOut out[HOST_BATCH_MAX_OUT];
+    int nframes;
+};
+typedef std::function<int(const uchar* s, size_t sstep, size_t sframe, uchar* const* d, const size_t* dstep, const size_t* dframe, int nframes)> HostBatchNFn;
+int runHostBatchN(const char* entry, const HostBatchN& hb, const HostBatchNFn& run);
+
 inline int depthBytes(int depth) { return depth <= 1 ? 1 : depth <= 3 ? 2 : depth <= 5 ? 4 : 8; }     // CV_8U .. CV_64F
 inline int divUp(int a, int b) { return (a + b - 1) / b; }
 

@@ -387,6 +387,62 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
     return stg.finish(entry);
 }
 
+int runHostBatchN(const char* entry, const HostBatchN& hb, const HostBatchNFn& run)
+{
+    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT) return MI355CV_NOT_IMPLEMENTED;
+    for (int o = 0; o < hb.nout; o++) if (!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes) return MI355CV_NOT_IMPLEMENTED;
+    Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
+    const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, sfb = sp * (size_t)hb.srows;
+    size_t dp[HOST_BATCH_MAX_OUT], dfb[HOST_BATCH_MAX_OUT], perFrame = sfb;
+    for (int o = 0; o < hb.nout; o++) { dp[o] = (hb.out[o].drowBytes + 255) & ~(size_t)255; dfb[o] = dp[o] * (size_t)hb.out[o].drows; perFrame += dfb[o]; }
+    int cf = (int)((size_t)(128u << 20) / perFrame);                     // frames per chunk: <= 128 MB per set of buffers, <= 16 frames
+    cf = cf < 1 ? 1 : cf > 16 ? 16 : cf; if (cf > hb.nframes) cf = hb.nframes;
+    uchar* din[2]; uchar* dout[2][HOST_BATCH_MAX_OUT]; size_t dfs[HOST_BATCH_MAX_OUT];
+    for (int b = 0; b < 2; b++) {
+        din[b] = (uchar*)stg.scratch(sfb * cf);
+        if (!din[b]) return MI355CV_NOT_IMPLEMENTED;
+        for (int o = 0; o < hb.nout; o++) { dout[b][o] = (uchar*)stg.scratch(dfb[o] * cf); dfs[o] = dfb[o]; if (!dout[b][o]) return MI355CV_NOT_IMPLEMENTED; }
+    }
+    hipStream_t st = stream(), aux = auxStream();
+    hipEvent_t inReady[2] = {pooledEvent(44), pooledEvent(45)}, bufFree[2] = {pooledEvent(46), pooledEvent(47)};
+    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return MI355CV_NOT_IMPLEMENTED;
+    const int nchunks = (hb.nframes + cf - 1) / cf;
+    auto upload = [&](int c) -> bool {
+        const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
+        if (c >= 2 && hipStreamWaitEvent(aux, bufFree[b], 0) != hipSuccess) return false;          // the buffers' previous chunk has been consumed and downloaded
+        for (int f = 0; f < nf; f++)
+            if (hipMemcpy2DAsync(din[b] + (size_t)f * sfb, sp, hb.src + (size_t)(f0 + f) * hb.sframe, hb.sstep, hb.srowBytes, hb.srows, hipMemcpyHostToDevice, aux) != hipSuccess)
+                return false;
+        return hipEventRecord(inReady[b], aux) == hipSuccess;
+    };
+    auto fail = [&](int code) { (void)hipStreamSynchronize(aux); (void)hipStreamSynchronize(st); return code; };       // see runHostBatch
+    if (!upload(0)) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError())));
+    std::vector<char> was;
+    for (int c = 0; c < nchunks; c++) {
+        const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
+        if (c + 1 < nchunks && !upload(c + 1)) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: H2D failed: %s", entry, hipGetErrorString(hipGetLastError())));
+        if (hipStreamWaitEvent(st, inReady[b], 0) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
+        auto& pool = tctx().pool;
+        was.assign(pool.size(), 0);
+        for (size_t i = 0; i < pool.size(); i++) was[i] = pool[i].busy;
+        const int rc = run(din[b], sp, sfb, dout[b], dp, dfs, nf);
+        for (size_t i = 0; i < tctx().pool.size(); i++) if (tctx().pool[i].busy && (i >= was.size() || !was[i])) tctx().pool[i].busy = false;
+        if (rc != MI355CV_OK) return fail(rc);
+        long long bytes = (long long)(hb.srowBytes * (size_t)hb.srows) * nf;
+        for (int o = 0; o < hb.nout; o++) {
+            const HostBatchOut& ho = hb.out[o];
+            for (int f = 0; f < nf; f++)
+                if (hipMemcpy2DAsync(ho.dst + (size_t)(f0 + f) * ho.dframe, ho.dstep, dout[b][o] + (size_t)f * dfb[o], dp[o], ho.drowBytes, ho.drows, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(hipGetLastError())));
+            bytes += (long long)(ho.drowBytes * (size_t)ho.drows) * nf;
+        }
+        if (hipEventRecord(bufFree[b], st) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
+        g_stagedBytes += bytes;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(setError(MI355CV_ERROR_UNKNOWN, "%s: %s", entry, hipGetErrorString(hipGetLastError())));
+    return stg.finish(entry);
+}
+
 } // namespace mi355
 
 // ------------------------------------------------------------------ exported runtime API

@@ -1306,6 +1306,14 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
                                            const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
                                            uchar* result_data, size_t result_step, size_t result_frame_stride, int method)
 {
+    // frames and results in host memory: chunks through two sets of device buffers (rt.h runHostBatch); the template is staged per chunk
+    if (nframes > 1 && img_width >= templ_width && img_height >= templ_height && templ_width >= 1 && templ_height >= 1 && hostBatchEligible(img_data, result_data, nframes)) {
+        const int e = MI355CV_MAT_DEPTH(type) == D8U ? 1 : 4;
+        const HostBatch hb = {img_data, img_step, img_frame_stride, (size_t)img_width * MI355CV_MAT_CN(type) * e, img_height,
+                              result_data, result_step, result_frame_stride, (size_t)(img_width - templ_width + 1) * 4, img_height - templ_height + 1, nframes};
+        return runHostBatch("matchTemplateBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
+            return runMatch("matchTemplateBatch", s, ss, nf == 1 ? 0 : sf, nf, img_width, img_height, templ_data, templ_step, templ_width, templ_height, type, d, ds, nf == 1 ? 0 : df, method); });
+    }
     return runMatch("matchTemplateBatch", img_data, img_step, nframes == 1 ? 0 : img_frame_stride, nframes, img_width, img_height, templ_data, templ_step,
                     templ_width, templ_height, type, result_data, result_step, nframes == 1 ? 0 : result_frame_stride, method);
 }

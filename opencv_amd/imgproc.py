@@ -1215,16 +1215,18 @@ def buildPyramid(src, maxlevel, borderType=BORDER_DEFAULT):
 
 
 def buildPyramidBatch(frames, maxlevel, borderType=BORDER_DEFAULT, dst=None):
-    """[N,H,W(,C)] device frames -> list of per-level batches [frames, level 1, ...]; every level of every frame is enqueued by one call
-    (mi355cv_buildPyramidBatch).  `dst`: the list a previous call returned, to reuse its level arrays."""
+    """[N,H,W(,C)] frames -> list of per-level batches [frames, level 1, ...]; every level of every frame is enqueued by one call
+    (mi355cv_buildPyramidBatch).  `dst`: the list a previous call returned, to reuse its level arrays.  Frames in HBM: levels in HBM; a CPU tensor
+    (ideally page-locked): the batch crosses PCIe in chunks, the upload of the next chunk under the kernels and the downloads of this one's levels
+    (rt.h runHostBatchN)"""
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     cn = int(frames.shape[3]) if frames.dim() == 4 else 1
     out = [frames]
     for l in range(maxlevel):
         w, h = (w + 1) // 2, (h + 1) // 2
         shape = (n, h, w) + ((cn,) if frames.dim() == 4 else ())
-        lvl = dst[l + 1] if dst is not None else torch.empty(shape, dtype=frames.dtype, device=frames.device)
-        if tuple(lvl.shape) != shape or lvl.dtype != frames.dtype:
+        lvl = dst[l + 1] if dst is not None else _batch_alloc(frames, shape, frames.dtype)
+        if tuple(lvl.shape) != shape or lvl.dtype != frames.dtype or lvl.is_cuda != frames.is_cuda:
             raise ValueError("dst level geometry mismatch")
         out.append(lvl)
     if maxlevel < 1:
@@ -1313,10 +1315,13 @@ def matchTemplate(image, templ, method, result=None, mask=None):
 
 
 def matchTemplateBatch(frames, templ, method, result=None):
-    """[N,H,W] device frames x one template -> [N,H-h+1,W-w+1] float32."""
+    """[N,H,W(,C)] frames x one template -> [N,H-h+1,W-w+1] float32.  Frames (and results) in HBM, or both in host memory (a CPU tensor, ideally
+    page-locked: chunks through two sets of device buffers, rt.h runHostBatch); the template may live on either side."""
     n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     t = Img(templ)
-    out = result if result is not None else torch.empty((n, h - t.h + 1, w - t.w + 1), dtype=torch.float32, device=frames.device)
+    out = result if result is not None else _batch_alloc(frames, (n, h - t.h + 1, w - t.w + 1), torch.float32)
+    if out.is_cuda != frames.is_cuda:
+        raise ValueError("frames and results live in the same kind of memory")
     s0, d0 = Img(frames[0]), Img(out[0])
     bind_stream(s0, d0)
     rc = L.mi355cv_matchTemplateBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)) * s0.esz, n, w, h, _vp(t.ptr), t.step, t.w, t.h, s0.type,

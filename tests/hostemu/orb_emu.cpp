@@ -72,6 +72,15 @@ int emu_orb_retainBest(KP* k, int n, int npoints)
     for (size_t i = 0; i < v.size(); i++) k[i] = v[i];
     return (int)v.size();
 }
+// the culls on (response, pixel index) records: keypoints come in with x = pixel index, the survivors go back out in their order
+int emu_orb_cullCand(KP* k, int n, int w, int npoints)
+{
+    std::vector<Cand> c((size_t)n);
+    for (int i = 0; i < n; i++) c[(size_t)i] = {k[i].response, (uint32_t)k[i].class_id};
+    retainBestCand(c, npoints);
+    for (size_t i = 0; i < c.size(); i++) { k[i].response = c[i].response; k[i].class_id = (int)c[i].idx; k[i].x = (float)(c[i].idx % (unsigned)w); k[i].y = (float)(c[i].idx / (unsigned)w); }
+    return (int)c.size();
+}
 int emu_orb_runByImageBorder(KP* k, int n, int w, int h, int b)
 {
     std::vector<KP> v(k, k + n);

@@ -147,6 +147,46 @@ def test_every_batch_entry_takes_host_resident_frames(cv):
         cv.thresholdBatch(host[:2], 100, 255, 0, dst=torch.empty((2, 1080, 1920), dtype=torch.uint8, device="cuda"))
 
 
+def test_multi_output_batch_entries_take_host_resident_frames(cv):
+    """SURVEY section 8 f4, the entries with several outputs per frame: buildPyramidBatch (one image per level: rt.h runHostBatchN) and
+    matchTemplateBatch on frames that live in host memory equal the device-resident calls; every byte crosses PCIe once each way (the template
+    once per chunk); chunk counts of one, two and several"""
+    g = torch.Generator(); g.manual_seed(23)
+    for (n, h, w, cn, pinned) in [(37, 301, 403, 1, True), (3, 300, 400, 3, False), (1, 64, 48, 1, True), (19, 540, 960, 1, True)]:
+        shape = (n, h, w) + ((cn,) if cn > 1 else ())
+        host = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        if pinned:
+            host = host.pin_memory()
+        want = cv.buildPyramidBatch(host.cuda(), 3)
+        staged0 = cv._lib.lib.mi355cv_stagedBytes()
+        got = cv.buildPyramidBatch(host, 3)
+        assert len(got) == 4 and got[0] is host
+        for a, b in zip(got[1:], want[1:]):
+            assert a.device.type == "cpu" and torch.equal(a, b.cpu()), (n, h, w, cn)
+        assert cv._lib.lib.mi355cv_stagedBytes() - staged0 == host.numel() + sum(l.numel() for l in got[1:])
+        again = cv.buildPyramidBatch(host, 3, dst=got)                                          # levels of a previous call reused
+        assert all(a is b for a, b in zip(again, got))
+    f32 = torch.rand((5, 200, 300), generator=g)
+    for a, b in zip(cv.buildPyramidBatch(f32, 2)[1:], cv.buildPyramidBatch(f32.cuda(), 2)[1:]):
+        assert torch.equal(a, b.cpu())
+    with pytest.raises((NotImplementedError, ValueError)):                                      # levels in HBM for frames on the host
+        cv.buildPyramidBatch(host, 3, dst=want)
+    # matchTemplateBatch: CV_8U (MFMA path) and CV_32F, template on the host or in HBM
+    for (n, h, w, pinned) in [(21, 240, 320, True), (2, 240, 320, False)]:
+        host = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, generator=g)
+        if pinned:
+            host = host.pin_memory()
+        templ = host[0, 50:82, 60:108].contiguous()
+        for method in (3, 5, 1):
+            want = cv.matchTemplateBatch(host.cuda(), templ.cuda(), method).cpu()
+            got = cv.matchTemplateBatch(host, templ, method)
+            assert got.device.type == "cpu" and torch.equal(got, want), (n, method)
+            assert torch.equal(cv.matchTemplateBatch(host, templ.cuda(), method), want)
+    hf = torch.rand((6, 120, 160), generator=g).pin_memory()
+    tf = hf[2, 30:50, 40:70].contiguous()
+    assert torch.equal(cv.matchTemplateBatch(hf, tf, 5), cv.matchTemplateBatch(hf.cuda(), tf.cuda(), 5).cpu())
+
+
 def test_integral_batch(cv):
     """mi355cv_integralBatch: every frame's sum / squared sum equals the single-image hook's (which the per-function suite pins to the oracle), for CV_32S
     and CV_64F sums, with and without squared sums, frames that are views with padding, widths around the 256-column tile and heights around 16 rows"""

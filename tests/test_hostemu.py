@@ -294,6 +294,24 @@ def test_orb_host_tables_and_culls(emuorb):
     keep = (rx >= 10) & (rx < 90) & (ry >= 10) & (ry < 70)
     assert na == keep.sum() and a[:na].tobytes() == kp[keep].tobytes()
     assert emuorb.emu_orb_runByImageBorder(o.P(kp.copy()), len(kp), 20, 80, 10) == 0
+    # the first cull on 8-byte (response, pixel index) records gives the survivors of the keypoint form in the same order
+    for trial in range(60):
+        w, h, b = int(rng.integers(30, 200)), int(rng.integers(30, 120)), int(rng.integers(0, 14))
+        n = int(rng.integers(1, 3000))
+        idx = np.sort(rng.choice(w * h, size=min(n, w * h), replace=False)).astype(np.int32)            # raster order, like the sorted keys
+        n = len(idx)
+        kp = np.zeros(n, o.KP_DTYPE)
+        kp["x"] = idx % w; kp["y"] = idx // w; kp["class_id"] = idx
+        kp["response"] = rng.integers(0, 30, n) if trial % 2 else rng.integers(0, 255, n)
+        # the border test runs in the collect kernel (x, y are integers there): the list the host sees is already filtered
+        keep = (kp["x"] >= b) & (kp["x"] < w - b) & (kp["y"] >= b) & (kp["y"] < h - b) if b > 0 else np.ones(n, bool)
+        for npts in (0, 5, n // 4, n // 2, n, n + 3):
+            a, ref = kp[keep].copy(), kp.copy()
+            na = emuorb.emu_orb_cullCand(o.P(a), len(a), w, npts) if len(a) else 0
+            m = emuorb.emu_orb_runByImageBorder(o.P(ref), n, w, h, b)
+            assert m == keep.sum()
+            nb = orc.orc_retainBest(o.P(ref), m, npts)
+            assert na == nb and np.array_equal(a["class_id"][:na], ref["class_id"][:nb]) and np.array_equal(a["response"][:na], ref["response"][:nb]), (trial, npts)
 
 
 # ---- the 5 x 5 median on columns sorted once per position (opencv_amd/csrc/median5_math.h, networks of median_net.h) ---------------------------------
