@@ -33,6 +33,21 @@ def test_bilateral_filter(cv, orc, cn):
         cv.bilateralFilter(torch.from_numpy(img).cuda(), 41, 50.0, 3.0)                                                # radius beyond the LDS tile: declined
 
 
+def test_bilateral_row_range_is_filtered_as_an_image_of_its_own(cv, orc):
+    """cv_hal_bilateralFilter carries no margins (hal_replacement.hpp:1068): a full-width row range of a larger image is dense, so the hook cannot tell it
+    from a whole image and filters it with the border rule at its first and last rows, where cv::bilateralFilter's own code path pads with the
+    parent's real rows (copyMakeBorder without BORDER_ISOLATED).  The reference's bundled ndsrvp HAL does the same.  This test pins the divergence:
+    the range equals the filtered copy of the range, and differs from the range of the filtered parent in its first / last `radius` rows only."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (200, 160), dtype=np.uint8)
+    d, sc, ss, r = 9, 60.0, 4.0, 4
+    dev = torch.from_numpy(img).cuda()
+    got = cv.bilateralFilter(dev[60:140], d, sc, ss).cpu().numpy()
+    assert np.array_equal(got, orc.orc_bilateralFilter(np.ascontiguousarray(img[60:140]), d, sc, ss))
+    whole = orc.orc_bilateralFilter(img, d, sc, ss)[60:140]
+    assert np.array_equal(got[r:-r], whole[r:-r]) and not np.array_equal(got[:r], whole[:r])
+
+
 def test_bilateral_filter_4k_timing_shape(cv, orc):
     """a 4K frame: the result of a crop that depends only on the crop's neighbourhood equals the oracle on that neighbourhood"""
     rng = np.random.default_rng(5)

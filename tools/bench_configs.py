@@ -275,6 +275,26 @@ def run(quick=False, parity=True):
     line("f1 cvtColor BGR -> Lab 4K 8UC3", lambda i: cv.cvtColor(bgr[i % B3C], cv.COLOR_BGR2Lab, dst=c3d[i % B3C]), PIX4 * 6)
     line("a6 cvtColor GRAY2BGR 4K 8U", lambda i: cv.cvtColor(gray[i], cv.COLOR_GRAY2BGR, dst=c3d[i % B3C]), PIX4 * 4)
     line("a1 GaussianBlur 5x5 4K 8UC3", lambda i: cv.GaussianBlur(bgr[i % B3C], (5, 5), 0, dst=c3d[i % B3C]), PIX4 * 6)
+    # f3: cv::ORB as one call per frame (pyramid, FAST, Harris, angles, blur, descriptors on the GPU; the culls on the host): wall time per frame, no HBM
+    # fraction -- the call is launch- and host-bound.  Frames: a block-structured scene (corners at many scales), 8 distinct frames
+    try:
+        import time
+        yy, xx = torch.meshgrid(torch.arange(H4, device=dev), torch.arange(W4, device=dev), indexing="ij")
+        scene = torch.stack([((((xx + 37 * f) // 24 + (yy + 11 * f) // 18) * 67 + ((xx + 5 * f) // 96) * 31 + ((yy + 3 * f) // 72) * 53) % 256).to(torch.uint8) for f in range(8)])
+        scene = torch.clamp(scene.to(torch.int16) + torch.randint(-6, 7, scene.shape, device=dev, generator=g, dtype=torch.int16), 0, 255).to(torch.uint8)
+        for nm, fr, nf in (("f3 ORB detectAndCompute 4K 8UC1 nfeatures=5000", scene, 5000), ("f3 ORB detectAndCompute 1080p 8UC1 nfeatures=2000", scene[:, :1080, :1920].contiguous(), 2000)):
+            orb = cv.ORB_create(nfeatures=nf)
+            nk = [len(orb.detectAndCompute(fr[i])[0]) for i in range(8)]
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for rep in range(2):
+                for i in range(8):
+                    orb.detectAndCompute(fr[i])
+            torch.cuda.synchronize()
+            out.append({"config": nm + " (one call per device-resident frame; wall time, culls on the host)", "frames": 8, "ms_per_frame": round((time.perf_counter() - t0) / 16 * 1e3, 3),
+                        "keypoints_per_frame": round(sum(nk) / 8.0, 1)})
+        del scene, yy, xx
+    except Exception as e:
+        out.append({"config": "f3 ORB detectAndCompute", "error": repr(e)})
     nvs = torch.empty((B2, H4 * 3 // 2, W4), dtype=torch.uint8, device=dev)
     nvs[:, :H4] = gray; nvs[:, H4:] = gray[:, : H4 // 2]
     line("f4 cvtColor NV12 -> BGR 4K", lambda i: cv.cvtColor(nvs[i], cv.COLOR_YUV2BGR_NV12, dst=c3d[i % B3C]), PIX4 * 4.5)
