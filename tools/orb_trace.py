@@ -3,7 +3,10 @@ import sys
 import time
 import numpy as np
 import torch
-sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "tools")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("tests", "", "tools"):
+    sys.path.insert(0, os.path.join(ROOT, d))
 import opencv_amd as cv
 from orb_bench import scene
 
