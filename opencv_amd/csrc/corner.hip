@@ -766,21 +766,34 @@ __global__ __launch_bounds__(256) void k_gftt_candidates(const float* __restrict
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
-    if (x >= W - 1 || y >= H - 1) return;
-    unsigned mo = *maxOrd;
-    unsigned mu = (mo & 0x80000000u) ? (mo & 0x7fffffffu) : ~mo;
-    const double maxVal = mo == 0 ? 0.0 : (double)__uint_as_float(mu);
-    const float thr = (float)(maxVal * quality);          // cv::threshold converts the double threshold to the image depth
-    auto T = [&](int yy, int xx) { float v = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(eig) + (size_t)yy * estep)[xx]; return v > thr ? v : 0.f; };
-    const float v = T(y, x);
-    if (v == 0.f || (mask && !mask[(size_t)y * mstep + x])) return;
-    float m = v;
+    bool hit = x < W - 1 && y < H - 1;
+    float v = 0.f;
+    if (hit) {
+        unsigned mo = *maxOrd;
+        unsigned mu = (mo & 0x80000000u) ? (mo & 0x7fffffffu) : ~mo;
+        const double maxVal = mo == 0 ? 0.0 : (double)__uint_as_float(mu);
+        const float thr = (float)(maxVal * quality);          // cv::threshold converts the double threshold to the image depth
+        auto T = [&](int yy, int xx) { float t = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(eig) + (size_t)yy * estep)[xx]; return t > thr ? t : 0.f; };
+        v = T(y, x);
+        hit = !(v == 0.f || (mask && !mask[(size_t)y * mstep + x]));
+        if (hit) {
+            float m = v;
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
+            for (int j = -1; j <= 1; j++)
 #pragma unroll
-        for (int i = -1; i <= 1; i++) m = fmaxf(m, T(y + j, x + i));
-    if (v != m) return;
-    const unsigned slot = atomicAdd(count, 1u);
+                for (int i = -1; i <= 1; i++) m = fmaxf(m, T(y + j, x + i));
+            hit = v == m;
+        }
+    }
+    // one atomic per wavefront (a counter every candidate adds to by itself serialises on a textured frame, see k_fast_collect)
+    const unsigned long long wm = __ballot(hit);
+    if (!wm) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)wm) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(wm));
+    base = __shfl(base, leader, 64);
+    if (!hit) return;
+    const unsigned slot = base + (unsigned)__popcll(wm & ((1ull << lane) - 1ull));
     if (slot < capacity) out[slot] = ((unsigned long long)ordF(v) << 32) | (unsigned)(y * W + x);
 }
 

@@ -108,12 +108,20 @@ __global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ 
                                                       unsigned long long* __restrict__ keys, unsigned cap, const uchar* __restrict__ mask, size_t mstep, int edge)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 3 || y < 3 || x + 3 >= w || y + 3 >= h) return;
-    if (x < edge || y < edge || x >= w - edge || y >= h - edge) return;                      // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) for ORB's levels; 0 elsewhere
-    const int s = sc[(size_t)y * step + x];
-    if (s <= thr) return;
-    if (mask && mask[(size_t)y * mstep + x] == 0) return;                                    // KeyPointsFilter::runByPixelsMask (keypoint.cpp:146-165) on integer coordinates
-    const unsigned i = atomicAdd(counter, 1u);
+    bool hit = !(x < 3 || y < 3 || x + 3 >= w || y + 3 >= h) &&
+               !(x < edge || y < edge || x >= w - edge || y >= h - edge);                    // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) for ORB's levels; 0 elsewhere
+    int s = 0;
+    if (hit) { s = sc[(size_t)y * step + x]; hit = s > thr; }
+    if (hit && mask) hit = mask[(size_t)y * mstep + x] != 0;                                 // KeyPointsFilter::runByPixelsMask (keypoint.cpp:146-165) on integer coordinates
+    // one atomic per wavefront: a counter every candidate adds to by itself serialises a textured 4K level (200 us against 10; profiles/r03_orb_trace.txt)
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (!hit) return;
+    const unsigned i = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
     if (keys && i < cap) keys[i] = ((unsigned long long)(0xffffffffu - (unsigned)(y * w + x)) << 32) | (unsigned)s;
 }
 

@@ -592,14 +592,16 @@ bool seprollFloat(const uchar* src, size_t sstep, size_t sframe, uchar* dst, siz
                   int W, int H, int cn, const float* kx, const float* ky, int n, int symY, float delta, int outBytes, int border, hipStream_t st, const Roi* roi)
 {
     if (!roiEligible(roi, nframes, W, H)) return false;
-    if ((n != 3 && n != 5) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2 || !(cn == 1 || cn == 3)) return false;
+    if ((n != 3 && n != 5 && n != 7) || (outBytes != 1 && outBytes != 4) || symY < 0 || symY > 2 || !(cn == 1 || cn == 3)) return false;
     if (cn == 3 && outBytes == 4 && n == 5) return false;         // 2 pixels x 3 channels of halo do not fit an 8-byte chunk
+    if (n == 7 && (cn != 1 || outBytes != 1 || symY != 1)) return false;   // 7 taps: the symmetric 8-bit form only (cv::GaussianBlur 7 x 7 with a sigma that has no Q8 taps: ORB's blur)
     if ((((uintptr_t)dst | dstep | dframe) & (outBytes - 1)) != 0 || !roll::eligible(src, sstep, sframe, src, sstep, sframe, roi ? roi->fullW : W, cn, n / 2, border, outBytes == 4 ? 8 : 16)) return false;
 #define SF1(K_, S_, O_, CN_) do { typedef SepF32<K_, S_, O_, CN_> P; P::Args a; for (int i = 0; i < K_; i++) { a.kx[i] = kx[i]; a.ky[i] = ky[i]; } a.delta = delta; \
         launchSep<P>(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, border, K_ == 3 ? 16 : 12, a, st, roi); } while (0)
 #define SF(K_, S_, O_) do { if (cn == 1) SF1(K_, S_, O_, 1); else SF1(K_, S_, O_, 3); } while (0)
 #define SFS(K_, O_) do { if (symY == 1) SF(K_, 1, O_); else if (symY == 2) SF(K_, 2, O_); else SF(K_, 0, O_); } while (0)
     if (n == 3) { if (outBytes == 4) SFS(3, 4); else SFS(3, 1); }
+    else if (n == 7) SF1(7, 1, 1, 1);
     else if (outBytes == 4) { if (symY == 1) SF1(5, 1, 4, 1); else if (symY == 2) SF1(5, 2, 4, 1); else SF1(5, 0, 4, 1); }
     else SFS(5, 1);
 #undef SFS

@@ -228,6 +228,14 @@ def test_sobel_box_rolling_path(cv, orc):
                                ([0.05, 0.1, 0.4, 0.3, 0.15], [0.3, 0.3, 0.2, 0.1, 0.1], 0.0)]:
                 check(cv.sepFilter2D(dev(src), -1, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, -1, kx, ky, (-1, -1), dl, border))
                 check(cv.sepFilter2D(dev(src), cv.CV_32F, kx, ky, (-1, -1), dl, border), orc.orc_sepFilter2D(src, 5, kx, ky, (-1, -1), dl, border))
+    # seven symmetric float taps, 8U -> 8U: cv::GaussianBlur(7 x 7, sigma 2) as the reference runs it on a submatrix (sepFilter2D with float taps; ORB's blur)
+    g7 = orc.orc_getGaussianKernel(7, 2.0).astype(np.float32)
+    for (w, h) in [(64, 23), (1040, 37), (333, 19), (97, 61), (17, 9)]:
+        src = rnd((h, w), np.uint8, w + 7)
+        for border in (4, 1, 2, 0):
+            check(cv.sepFilter2D(dev(src), -1, g7, g7, (-1, -1), 0.0, border), orc.orc_sepFilter2D(src, -1, g7, g7, (-1, -1), 0.0, border))
+        win = dev(np.pad(src, ((9, 5), (13, 6)), mode="edge"))[9:9 + h, 13:13 + w]             # unaligned rows inside a larger buffer, isolated border
+        check(cv.sepFilter2D(win, -1, g7, g7, (-1, -1), 0.0, 4 | 16), orc.orc_sepFilter2D(src, -1, g7, g7, (-1, -1), 0.0, 4))
     # multi-channel derivative / float-tap filters on the rolling kernels
     for cn in (3, 4):
         for (w, h) in [(32, 5), (64, 23), (1040, 37), (333, 19)]:
