@@ -217,8 +217,8 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n, (const uchar*)nullptr, (size_t)0, 0);
     if (!sortKeysDesc(temp, tb, keys, sorted, n, st)) return -2;
     const unsigned take = n < (unsigned)capacity ? n : (unsigned)capacity;
-    std::vector<unsigned long long> host(take);
-    if (hipMemcpyAsync(host.data(), sorted, (size_t)take * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    const unsigned long long* host = (const unsigned long long*)stg.pinned((size_t)take * 8);     // page-locked landing zone: the list's size is the GPU's decision
+    if (!host || hipMemcpyAsync(const_cast<unsigned long long*>(host), sorted, (size_t)take * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     for (unsigned i = 0; i < take; i++) {
         const unsigned idx = 0xffffffffu - (unsigned)(host[i] >> 32), sv = (unsigned)(host[i] & 0xffffffffu);
         keypoints_xyr[3 * i] = (float)(idx % (unsigned)width);

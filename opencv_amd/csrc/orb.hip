@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <vector>
 
 namespace mi355 {
@@ -219,33 +220,56 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
             fastLaunchScores(im, (size_t)L.pitch, r.w, r.h, sc, sup, spitch, st);
             fastLaunchCollect(sup, spitch, r.w, r.h, thr, mpyr ? mpyr + (size_t)r.y * L.pitch + r.x : nullptr, (size_t)L.pitch, edge, counters + l, keys[l], caps[l], st);
         }
-        unsigned cnt[MAX_LEVELS];
-        if (!copyD2H(cnt, counters, sizeof(unsigned) * MAX_LEVELS, st)) return -2;
-        std::vector<std::vector<unsigned long long>> hk(nLevels);
+        // counters and candidate lists land in page-locked memory (Stager::pinned): their size is the GPU's decision, and a copy into pageable memory would
+        // go through the runtime's bounce buffer with the host blocked
+        unsigned* cnt = (unsigned*)stg.pinned(sizeof(unsigned) * MAX_LEVELS);
+        if (!cnt || !copyD2H(cnt, counters, sizeof(unsigned) * MAX_LEVELS, st)) return -2;
+        size_t total = 0;
+        std::vector<size_t> off(nLevels);
+        for (int l = 0; l < nLevels; l++) {
+            if (cnt[l] > caps[l]) { setError(MI355CV_ERROR_UNKNOWN, "ORB: FAST candidate bound exceeded on level %d", l); return -2; }
+            off[l] = total; total += cnt[l];
+        }
+        const unsigned long long* hk = (const unsigned long long*)stg.pinned((total ? total : 1) * 8);
+        if (!hk) return -2;
         for (int l = 0; l < nLevels; l++) {
             const unsigned n = cnt[l];
-            if (n > caps[l]) { setError(MI355CV_ERROR_UNKNOWN, "ORB: FAST candidate bound exceeded on level %d", l); return -2; }
             if (!n) continue;
             unsigned long long* sorted = (unsigned long long*)stg.scratch((size_t)n * 8);
             const size_t tb = sortKeysDescTemp(n);
             void* temp = stg.scratch(tb ? tb : 16);
             if (!sorted || !tb || !temp || !sortKeysDesc(temp, tb, keys[l], sorted, n, st)) return -2;
-            hk[l].resize(n);
-            if (hipMemcpyAsync(hk[l].data(), sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -2;
+            if (hipMemcpyAsync(const_cast<unsigned long long*>(hk) + off[l], sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -2;
         }
         if (hipStreamSynchronize(st) != hipSuccess) return -2;
 
+        // the first cull, level by level; long lists (a 4K level 0 has 10^5 candidates) on threads of their own: the levels are independent
+        std::vector<std::vector<Cand>> cands(nLevels);
+        auto cull = [&](int l) {
+            std::vector<Cand>& c = cands[l];
+            const unsigned long long* k = hk + off[l];
+            c.resize(cnt[l]);
+            for (size_t i = 0; i < c.size(); i++) c[i] = {(float)((int)(unsigned)(k[i] & 0xffffffffu) - 1), 0xffffffffu - (unsigned)(k[i] >> 32)};
+            retainBestCand(c, p.scoreType == 0 ? 2 * nfl[l] : nfl[l]);
+        };
+        {
+            std::vector<std::future<void>> side;
+            int big = 0;
+            for (int l = 0; l < nLevels; l++) big += cnt[l] >= 8192u;
+            for (int l = nLevels - 1; l >= 0; l--) {                       // the longest list (level firstLevel or 0) on the calling thread, last
+                if (cnt[l] >= 8192u && big > 1 && l != 0) side.push_back(std::async(std::launch::async, cull, l));
+                else if (l != 0) cull(l);
+            }
+            cull(0);
+            for (auto& f : side) f.get();
+        }
         std::vector<int> counts(nLevels);
         std::vector<KP> lvl;
-        std::vector<Cand> cand;
         for (int l = 0; l < nLevels; l++) {
             const orbm::Layer r = L.layer[l];
-            cand.resize(hk[l].size());
-            for (size_t i = 0; i < hk[l].size(); i++) cand[i] = {(float)((int)(unsigned)(hk[l][i] & 0xffffffffu) - 1), 0xffffffffu - (unsigned)(hk[l][i] >> 32)};
-            retainBestCand(cand, p.scoreType == 0 ? 2 * nfl[l] : nfl[l]);
-            counts[l] = (int)cand.size();
+            counts[l] = (int)cands[l].size();
             const float size = p.patchSize * L.scale[l];
-            for (const Cand& c : cand) all.push_back({(float)(c.idx % (unsigned)r.w), (float)(c.idx / (unsigned)r.w), size, -1.f, c.response, l, -1});
+            for (const Cand& c : cands[l]) all.push_back({(float)(c.idx % (unsigned)r.w), (float)(c.idx / (unsigned)r.w), size, -1.f, c.response, l, -1});
         }
         if (!all.empty()) {
             const int n = (int)all.size(), half = p.patchSize / 2;
@@ -258,8 +282,8 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
             float2* dout = (float2*)stg.scratch((size_t)n * sizeof(float2));
             if (!dk || !dum || !dout) return -2;
             hipLaunchKernelGGL(k_orb_score_angle, dim3(divUp(n, 4)), dim3(256), 0, st, pyr, L.pitch, dk, n, tab, dum, half, 0.04f, dout);
-            std::vector<float2> ho(n);
-            if (!copyD2H(ho.data(), dout, (size_t)n * sizeof(float2), st)) return -2;
+            const float2* ho = (const float2*)stg.pinned((size_t)n * sizeof(float2));
+            if (!ho || !copyD2H(const_cast<float2*>(ho), dout, (size_t)n * sizeof(float2), st)) return -2;
             for (int i = 0; i < n; i++) { all[i].angle = ho[i].y; if (p.scoreType == 0) all[i].response = ho[i].x; }
             if (p.scoreType == 0) {                                              // second cull per level on the Harris response (orb.cpp:941-961)
                 std::vector<KP> kept;

@@ -74,6 +74,10 @@ public:
     void* param(const void* host, size_t bytes);
     // scratch in HBM that lives until finish()
     void* scratch(size_t bytes);
+    // page-locked host memory that lives until the outermost hook returns (a per-thread pool, like the HBM scratch): the landing zone of results whose
+    // size the GPU decides (candidate lists) -- a device-to-host copy into pageable memory goes through the runtime's own bounce buffer at a fraction of
+    // the PCIe rate and blocks the host meanwhile
+    void* pinned(size_t bytes);
     // copies staged outputs back and synchronises when required.  Returns HAL code.
     int finish(const char* entry);
     bool anyHost() const { return anyHost_; }

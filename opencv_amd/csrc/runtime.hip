@@ -41,6 +41,7 @@ struct ThreadCtx {
     bool useUser = false;
     bool async = false;
     std::vector<Buf> pool;
+    std::vector<Buf> pinned;       // page-locked host buffers (Stager::pinned)
     ~ThreadCtx() {
         // process teardown order vs. the HIP runtime is undefined: leak on purpose
     }
@@ -231,6 +232,7 @@ Stager::~Stager()
         ThreadCtx& c = tctx();
         hipStream_t s = c.async ? stream() : nullptr;
         for (auto& b : c.pool) if (b.busy) { b.busy = false; b.last = s; }
+        for (auto& b : c.pinned) b.busy = false;          // the host has read them by now: every user synchronises before it looks
         restoreDevice();
     }
 }
@@ -310,6 +312,21 @@ void* Stager::param(const void* host, size_t bytes)
 }
 
 void* Stager::scratch(size_t bytes) { return bump_(bytes); }
+
+void* Stager::pinned(size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 4095) & ~size_t(4095);
+    auto& pool = tctx().pinned;
+    int best = -1;
+    for (int i = 0; i < (int)pool.size(); i++)
+        if (!pool[i].busy && pool[i].cap >= bytes && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+    if (best >= 0) { pool[best].busy = true; return pool[best].p; }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); failed_ = true; setError(MI355CV_NOT_IMPLEMENTED, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    pool.push_back({p, bytes, true, nullptr});
+    return p;
+}
 
 int Stager::finish(const char* entry)
 {
