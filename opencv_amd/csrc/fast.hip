@@ -10,6 +10,8 @@
 // "corner at threshold t" of FAST_t<16> (fast.cpp:58) is "dense score > t".  TYPE_5_8 / TYPE_7_12 are declined: the reference's code for them is
 // not the textbook detector (16-ring indexing in the quick-reject test, an out-of-period read in the vector cornerScore<12>, fast_score.cpp:218-221).
 #include "rt.h"
+#include "fast_levels.h"
+#include <algorithm>
 #include <vector>
 
 namespace mi355 {
@@ -29,10 +31,10 @@ __device__ constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0,
 
 // A thread owns 4 horizontally adjacent pixels x0..x0+3 (x0 a multiple of 4): the 7 rows y-3..y+3 of columns x0-4..x0+7 are three dwords per
 // row, every ring pixel of the four centres is a byte of those registers at a compile-time position, and the four scores leave as one dword.
-__global__ __launch_bounds__(256) void k_fast_dense16(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
+__device__ __forceinline__ void fastDenseBody(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, int bx, int by)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= w || y >= h) return;
     unsigned out = 0;
     if (y >= 3 && y < h - 3) {
@@ -77,11 +79,16 @@ __global__ __launch_bounds__(256) void k_fast_dense16(const uchar* __restrict__ 
     else for (int b = 0; x0 + b < w; b++) o[b] = (uchar)(out >> (8 * b));
 }
 
-// keeps a score strictly greater than its 8 neighbours (0 outside the image), zeroes the rest; 4 pixels per thread
-__global__ __launch_bounds__(256) void k_fast_nms(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
+__global__ __launch_bounds__(256) void k_fast_dense16(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    fastDenseBody(src, sstep, dst, dstep, w, h, blockIdx.x, blockIdx.y);
+}
+
+// keeps a score strictly greater than its 8 neighbours (0 outside the image), zeroes the rest; 4 pixels per thread
+__device__ __forceinline__ void fastNmsBody(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h, int bx, int by)
+{
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= w || y >= h) return;
     int a[3][6];                                                     // rows y-1..y+1, columns x0-1..x0+4
 #pragma unroll
@@ -102,17 +109,99 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uchar* __restrict__ src,
     }
 }
 
+__global__ __launch_bounds__(256) void k_fast_nms(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int w, int h)
+{
+    fastNmsBody(src, sstep, dst, dstep, w, h, blockIdx.x, blockIdx.y);
+}
+
+// ---- the same two passes over every level of a pyramid buffer in one launch each (cv::ORB, orb.hip): grid.y runs over the 4-row tiles of all levels,
+// FastLevels tells which level a tile belongs to; score buffers share the pyramid's geometry (a level's scores sit where its pixels do)
+__device__ __forceinline__ int levelOfTile(const mi355::FastLevels& L, int tile)
+{
+    int l = 0;
+    while (l + 1 < L.n && tile >= L.tile0[l + 1]) l++;
+    return l;
+}
+__global__ __launch_bounds__(256) void k_fast_dense16_levels(const uchar* __restrict__ pyr, size_t pitch, uchar* __restrict__ sc, mi355::FastLevels L)
+{
+    const int l = levelOfTile(L, blockIdx.y);
+    const size_t o = (size_t)L.y[l] * pitch + L.x[l];
+    fastDenseBody(pyr + o, pitch, sc + o, pitch, L.w[l], L.h[l], blockIdx.x, blockIdx.y - L.tile0[l]);
+}
+__global__ __launch_bounds__(256) void k_fast_nms_levels(const uchar* __restrict__ sc, size_t pitch, uchar* __restrict__ sup, mi355::FastLevels L)
+{
+    const int l = levelOfTile(L, blockIdx.y);
+    const size_t o = (size_t)L.y[l] * pitch + L.x[l];
+    fastNmsBody(sc + o, pitch, sup + o, pitch, L.w[l], L.h[l], blockIdx.x, blockIdx.y - L.tile0[l]);
+}
+
+// Candidates of all levels in raster order without a sort: a wavefront per image row counts its candidates (k_fast_rows<false>), one workgroup turns the
+// row counts into offsets and per-level totals (k_fast_row_scan), the same walk writes them (k_fast_rows<true>): keys ~index : score as below, level after
+// level, row after row, left to right.  A candidate: interior of the 3-pixel ring, inside the edge band, score > thr, mask != 0.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_fast_rows(const uchar* __restrict__ sup, size_t pitch, const uchar* __restrict__ mask, int thr, int edge, mi355::FastLevels L,
+                                                   unsigned* __restrict__ rowCount, const unsigned* __restrict__ rowOff, unsigned long long* __restrict__ keys)
+{
+    const int R = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (R >= L.row0[L.n]) return;
+    int l = 0;
+    while (l + 1 < L.n && R >= L.row0[l + 1]) l++;
+    const int y = R - L.row0[l], w = L.w[l], h = L.h[l];
+    const size_t o = (size_t)(L.y[l] + y) * pitch + L.x[l];
+    const bool rowIn = !(y < 3 || y + 3 >= h || y < edge || y >= h - edge);     // edge: KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119), which follows FAST at once
+    unsigned n = WRITE ? rowOff[R] : 0u;
+    if (rowIn) {
+        const int lo = max(3, edge), hi = min(w - 3, w - edge);               // candidates have lo <= x < hi
+        for (int x0 = lo & ~63; x0 < hi; x0 += 64) {
+            const int x = x0 + lane;
+            bool hit = x >= lo && x < hi;
+            int sv = 0;
+            if (hit) { sv = sup[o + x]; hit = sv > thr; }
+            if (hit && mask) hit = mask[o + x] != 0;                             // KeyPointsFilter::runByPixelsMask (keypoint.cpp:146-165) on integer coordinates
+            const unsigned long long m = __ballot(hit);
+            if (WRITE && hit) keys[n + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(0xffffffffu - (unsigned)(y * w + x)) << 32) | (unsigned)sv;
+            n += (unsigned)__popcll(m);
+        }
+    }
+    if (!WRITE && lane == 0) rowCount[R] = n;
+}
+
+// exclusive scan of the row counts (one workgroup of 1024 threads, a contiguous run of rows per thread); levelTotal[l] = candidates of level l, [n] = all
+__global__ __launch_bounds__(1024) void k_fast_row_scan(const unsigned* __restrict__ rowCount, unsigned* rowOff, unsigned* __restrict__ levelTotal, mi355::FastLevels L)
+{
+    __shared__ unsigned part[1024];
+    const int rows = L.row0[L.n], per = (rows + 1023) / 1024, t = threadIdx.x;
+    const int r0 = min(t * per, rows), r1 = min(r0 + per, rows);
+    unsigned s = 0;
+    for (int r = r0; r < r1; r++) s += rowCount[r];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = part[t] - s;                                              // exclusive prefix of this thread's first row
+    for (int r = r0; r < r1; r++) { rowOff[r] = run; run += rowCount[r]; }
+    __syncthreads();                                                          // the offsets written above are visible to the whole workgroup
+    const unsigned total = part[1023];
+    if (t <= L.n) {
+        const unsigned hiOff = t < L.n ? (L.row0[t + 1] < rows ? rowOff[L.row0[t + 1]] : total) : total;
+        const unsigned loOff = t < L.n ? (L.row0[t] < rows ? rowOff[L.row0[t]] : total) : 0u;
+        levelTotal[t] = hiOff - loOff;                                         // [l] = candidates of level l, [n] = all of them
+    }
+}
+
 // candidates of the final score image (interior pixels with score > thr): counted, then written as keys ~index : score so that a descending
 // sort puts them in raster order
 __global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ sc, size_t step, int w, int h, int thr, unsigned* __restrict__ counter,
-                                                      unsigned long long* __restrict__ keys, unsigned cap, const uchar* __restrict__ mask, size_t mstep, int edge)
+                                                      unsigned long long* __restrict__ keys, unsigned cap)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool hit = !(x < 3 || y < 3 || x + 3 >= w || y + 3 >= h) &&
-               !(x < edge || y < edge || x >= w - edge || y >= h - edge);                    // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) for ORB's levels; 0 elsewhere
+    bool hit = !(x < 3 || y < 3 || x + 3 >= w || y + 3 >= h);
     int s = 0;
     if (hit) { s = sc[(size_t)y * step + x]; hit = s > thr; }
-    if (hit && mask) hit = mask[(size_t)y * mstep + x] != 0;                                 // KeyPointsFilter::runByPixelsMask (keypoint.cpp:146-165) on integer coordinates
     // one atomic per wavefront: a counter every candidate adds to by itself serialises a textured 4K level (200 us against 10; profiles/r03_orb_trace.txt)
     const unsigned long long m = __ballot(hit);
     if (!m) return;
@@ -143,16 +232,23 @@ int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size
 
 // the detector's stages on device-resident images for callers inside the library (orb.hip runs them level by level on its pyramid buffer)
 namespace mi355 {
-void fastLaunchScores(const uchar* s, size_t ss, int w, int h, uchar* sc, uchar* sup, size_t pitch, hipStream_t st)
+// every level of a pyramid buffer at once (cv::ORB): dense scores and suppression into buffers of the pyramid's geometry, then the candidates of all
+// levels in raster order (rowCount / rowOff: one unsigned per image row of all levels; levelTotal: n + 1 counts; keys: room for every candidate)
+void fastLevelsScores(const uchar* pyr, size_t pitch, uchar* sc, uchar* sup, const FastLevels& L, hipStream_t st)
 {
-    const dim3 g4(divUp(w, 256), divUp(h, 4));
-    hipLaunchKernelGGL(k_fast_dense16, g4, dim3(256), 0, st, s, ss, sc, pitch, w, h);
-    if (sup) hipLaunchKernelGGL(k_fast_nms, g4, dim3(256), 0, st, sc, pitch, sup, pitch, w, h);
+    int maxW = 0;
+    for (int l = 0; l < L.n; l++) maxW = std::max(maxW, L.w[l]);
+    const dim3 g(divUp(maxW, 256), L.tile0[L.n]);
+    hipLaunchKernelGGL(k_fast_dense16_levels, g, dim3(256), 0, st, pyr, pitch, sc, L);
+    hipLaunchKernelGGL(k_fast_nms_levels, g, dim3(256), 0, st, sc, pitch, sup, L);
 }
-void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, int edge, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st)
+void fastLevelsCollect(const uchar* sup, size_t pitch, const uchar* mask, int thr, int edge, const FastLevels& L, unsigned* rowCount, unsigned* rowOff, unsigned* levelTotal,
+                       unsigned long long* keys, hipStream_t st)
 {
-    const dim3 g1(divUp(w, 64), divUp(h, 4));
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, w, h, thr, counter, keys, cap, mask, mstep, edge);
+    const dim3 g(divUp(L.row0[L.n], 4));
+    hipLaunchKernelGGL(k_fast_rows<false>, g, dim3(256), 0, st, sup, pitch, mask, thr, edge, L, rowCount, (const unsigned*)nullptr, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_fast_row_scan, dim3(1), dim3(1024), 0, st, rowCount, rowOff, levelTotal, L);
+    hipLaunchKernelGGL(k_fast_rows<true>, g, dim3(256), 0, st, sup, pitch, mask, thr, edge, L, rowCount, rowOff, keys);
 }
 }
 
@@ -205,7 +301,7 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     if (!thr && nonmax_suppression) thr = 1;                                                 // fast.cpp:467: with suppression a cornerScore of 0 never wins FAST_t's strict comparisons
     unsigned n = 0;
     if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u, (const uchar*)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u);
     if (hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     if (n == 0 || capacity == 0) { const int rc = stg.finish("FAST"); return rc == MI355CV_OK ? (int)n : -2; }
     unsigned long long* keys = (unsigned long long*)stg.scratch((size_t)n * 8);
@@ -214,7 +310,7 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     void* temp = stg.scratch(tb ? tb : 16);
     if (!keys || !sorted || !tb || !temp) return -2;
     if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n, (const uchar*)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n);
     if (!sortKeysDesc(temp, tb, keys, sorted, n, st)) return -2;
     const unsigned take = n < (unsigned)capacity ? n : (unsigned)capacity;
     const unsigned long long* host = (const unsigned long long*)stg.pinned((size_t)take * 8);     // page-locked landing zone: the list's size is the GPU's decision

@@ -6,8 +6,9 @@
 //   pyramid      every level = cv::resize(INTER_LINEAR_EXACT) of the previous one (mi355cv_resize, warp.hip k_resize_exact), packed side by side in one
 //                8-bit buffer with a BORDER_REFLECT_101 ring of max(edgeThreshold, ceil(halfPatch sqrt 2), 4) + 1 pixels (k_orb_border): the reference's
 //                own layout (orb.cpp:1056-1095), so Harris / angle / descriptor reads near a level's edge see the same pixels
-//   keypoints    per level FAST 9-16 with suppression (fast.hip kernels; candidates leave as sorted keys = raster order), culled on the host by
-//                KeyPointsFilter::runByImageBorder / retainBest -- std::nth_element + std::partition: the reference's output ORDER is that of the C++
+//   keypoints    FAST 9-16 with suppression on all levels in one launch per pass (fast.hip k_fast_*_levels), the candidates of all levels in raster order
+//                by a row count / scan / write (no sort, no atomics; the mask and image-border tests of KeyPointsFilter are part of the candidate test),
+//                culled on the host by KeyPointsFilter::retainBest -- std::nth_element + std::partition: the reference's output ORDER is that of the C++
 //                library, so the host side calls the same two algorithms --, then ONE kernel gives every candidate its Harris response (7 x 7 block of
 //                integer gradients) and its intensity-centroid angle (k_orb_score_angle: a wavefront per keypoint, exact integer sums, cv::fastAtan2's
 //                polynomial in the reference's operation order); second cull per level on the host
@@ -17,6 +18,7 @@
 #include "rt.h"
 #include "orb_math.h"
 #include "orb_host.h"
+#include "fast_levels.h"
 #include "gausskernel.h"
 #include <algorithm>
 #include <cmath>
@@ -25,10 +27,9 @@
 #include <vector>
 
 namespace mi355 {
-void fastLaunchScores(const uchar* s, size_t ss, int w, int h, uchar* sc, uchar* sup, size_t pitch, hipStream_t st);                       // fast.hip
-void fastLaunchCollect(const uchar* fin, size_t pitch, int w, int h, int thr, const uchar* mask, size_t mstep, int edge, unsigned* counter, unsigned long long* keys, unsigned cap, hipStream_t st);
-size_t sortKeysDescTemp(unsigned n);                                                                                                      // gftt_sort.hip (rocPRIM)
-bool sortKeysDesc(void* temp, size_t bytes, const unsigned long long* in, unsigned long long* out, unsigned n, hipStream_t st);
+void fastLevelsScores(const uchar* pyr, size_t pitch, uchar* sc, uchar* sup, const FastLevels& L, hipStream_t st);                         // fast.hip
+void fastLevelsCollect(const uchar* sup, size_t pitch, const uchar* mask, int thr, int edge, const FastLevels& L, unsigned* rowCount, unsigned* rowOff, unsigned* levelTotal,
+                       unsigned long long* keys, hipStream_t st);
 }
 
 using namespace mi355;
@@ -193,55 +194,46 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
             for (int l = 0; l < nLevels - 1; l++) { nfl[l] = cvRoundF(nd); sum += nfl[l]; nd *= factor; }
             nfl[nLevels - 1] = std::max(p.nfeatures - sum, 0);
         }
-        // FAST on every level: scores, suppression, candidate keys (one counter per level), then one look at the counters
-        int maxW = 0, maxH = 0;
-        for (int l = 0; l < nLevels; l++) { maxW = std::max(maxW, L.layer[l].w); maxH = std::max(maxH, L.layer[l].h); }
-        const size_t spitch = ((size_t)maxW + 63) & ~(size_t)63;
-        uchar* sc = (uchar*)stg.scratch(spitch * maxH);
-        uchar* sup = (uchar*)stg.scratch(spitch * maxH);
-        unsigned* counters = (unsigned*)stg.scratch(sizeof(unsigned) * MAX_LEVELS);
-        if (!sc || !sup || !counters) return -2;
-        if (hipMemsetAsync(counters, 0, sizeof(unsigned) * MAX_LEVELS, st) != hipSuccess) return -2;
-        int thr = p.fastThreshold < 0 ? 0 : p.fastThreshold > 255 ? 255 : p.fastThreshold;       // fast.cpp:81
-        if (!thr) thr = 1;                                                                      // fast.cpp:467 (suppression is always on here)
-        std::vector<unsigned long long*> keys(nLevels);
-        std::vector<unsigned> caps(nLevels);
+        // FAST on every level: scores and suppression of all levels in one launch each (buffers of the pyramid's geometry), the candidates of all levels in
+        // raster order by a row count, a scan and a write pass -- no sort, no atomics; KeyPointsFilter::runByPixelsMask / runByImageBorder
+        // (keypoint.cpp:107-165), which follow FAST at once in the reference, are part of the candidate test, so nothing near the edge leaves the GPU
+        static_assert(MAX_LEVELS <= FAST_MAX_LEVELS, "level tables");
+        FastLevels FL; memset(&FL, 0, sizeof FL);
+        FL.n = nLevels;
+        size_t bound = 0;
+        const int edge = p.edgeThreshold > 0 ? p.edgeThreshold : 0;
         for (int l = 0; l < nLevels; l++) {
             const orbm::Layer r = L.layer[l];
-            // KeyPointsFilter::runByImageBorder (keypoint.cpp:107-119) follows FAST at once: the collect pass applies it, so candidates near the edge never
-            // leave the GPU; a level no wider than the two borders has no keypoints at all
-            const int edge = p.edgeThreshold > 0 ? p.edgeThreshold : 0;
-            caps[l] = 0; keys[l] = nullptr;
-            if (edge > 0 && (r.h <= 2 * edge || r.w <= 2 * edge)) continue;
-            caps[l] = (unsigned)(((size_t)(r.w - 2 * edge + 2) / 2) * ((size_t)(r.h - 2 * edge + 2) / 2) + 1); // a 3 x 3 strict maximum: at most one per 2 x 2 block
-            keys[l] = (unsigned long long*)stg.scratch((size_t)caps[l] * 8);
-            if (!keys[l]) return -2;
-            const uchar* im = pyr + (size_t)r.y * L.pitch + r.x;
-            fastLaunchScores(im, (size_t)L.pitch, r.w, r.h, sc, sup, spitch, st);
-            fastLaunchCollect(sup, spitch, r.w, r.h, thr, mpyr ? mpyr + (size_t)r.y * L.pitch + r.x : nullptr, (size_t)L.pitch, edge, counters + l, keys[l], caps[l], st);
+            FL.x[l] = r.x; FL.y[l] = r.y; FL.w[l] = r.w; FL.h[l] = r.h;
+            FL.tile0[l + 1] = FL.tile0[l] + divUp(r.h, 4); FL.row0[l + 1] = FL.row0[l] + r.h;
+            if (r.w > 2 * edge && r.h > 2 * edge) bound += ((size_t)(r.w - 2 * edge + 2) / 2) * ((size_t)(r.h - 2 * edge + 2) / 2);   // 3 x 3 strict maxima: at most one per 2 x 2 block
         }
+        const int rows = FL.row0[nLevels];
+        if (FL.tile0[nLevels] > 65535) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: %d rows of pyramid exceed one launch", rows); return -1; }
+        uchar* sc = (uchar*)stg.scratch(bufBytes);
+        uchar* sup = (uchar*)stg.scratch(bufBytes);
+        unsigned* rowCount = (unsigned*)stg.scratch(sizeof(unsigned) * (size_t)rows);
+        unsigned* rowOff = (unsigned*)stg.scratch(sizeof(unsigned) * (size_t)rows);
+        unsigned* levelTotal = (unsigned*)stg.scratch(sizeof(unsigned) * (MAX_LEVELS + 1));
+        unsigned long long* keys = (unsigned long long*)stg.scratch((bound + 1) * 8);
+        if (!sc || !sup || !rowCount || !rowOff || !levelTotal || !keys) return -2;
+        int thr = p.fastThreshold < 0 ? 0 : p.fastThreshold > 255 ? 255 : p.fastThreshold;       // fast.cpp:81
+        if (!thr) thr = 1;                                                                      // fast.cpp:467 (suppression is always on here)
+        fastLevelsScores(pyr, (size_t)L.pitch, sc, sup, FL, st);
+        fastLevelsCollect(sup, (size_t)L.pitch, mpyr, thr, edge, FL, rowCount, rowOff, levelTotal, keys, st);
         // counters and candidate lists land in page-locked memory (Stager::pinned): their size is the GPU's decision, and a copy into pageable memory would
         // go through the runtime's bounce buffer with the host blocked
-        unsigned* cnt = (unsigned*)stg.pinned(sizeof(unsigned) * MAX_LEVELS);
-        if (!cnt || !copyD2H(cnt, counters, sizeof(unsigned) * MAX_LEVELS, st)) return -2;
-        size_t total = 0;
+        unsigned* cnt = (unsigned*)stg.pinned(sizeof(unsigned) * (MAX_LEVELS + 1));
+        if (!cnt || !copyD2H(cnt, levelTotal, sizeof(unsigned) * (size_t)(nLevels + 1), st)) return -2;
+        const size_t total = cnt[nLevels];
         std::vector<size_t> off(nLevels);
-        for (int l = 0; l < nLevels; l++) {
-            if (cnt[l] > caps[l]) { setError(MI355CV_ERROR_UNKNOWN, "ORB: FAST candidate bound exceeded on level %d", l); return -2; }
-            off[l] = total; total += cnt[l];
+        {
+            size_t run = 0;
+            for (int l = 0; l < nLevels; l++) { off[l] = run; run += cnt[l]; }
+            if (run != total || total > bound) { setError(MI355CV_ERROR_UNKNOWN, "ORB: FAST candidate counts inconsistent (%zu of at most %zu)", total, bound); return -2; }
         }
         const unsigned long long* hk = (const unsigned long long*)stg.pinned((total ? total : 1) * 8);
-        if (!hk) return -2;
-        for (int l = 0; l < nLevels; l++) {
-            const unsigned n = cnt[l];
-            if (!n) continue;
-            unsigned long long* sorted = (unsigned long long*)stg.scratch((size_t)n * 8);
-            const size_t tb = sortKeysDescTemp(n);
-            void* temp = stg.scratch(tb ? tb : 16);
-            if (!sorted || !tb || !temp || !sortKeysDesc(temp, tb, keys[l], sorted, n, st)) return -2;
-            if (hipMemcpyAsync(const_cast<unsigned long long*>(hk) + off[l], sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -2;
-        }
-        if (hipStreamSynchronize(st) != hipSuccess) return -2;
+        if (!hk || !copyD2H(const_cast<unsigned long long*>(hk), keys, total * 8, st)) return -2;
 
         // the first cull, level by level; long lists (a 4K level 0 has 10^5 candidates) on threads of their own: the levels are independent
         std::vector<std::vector<Cand>> cands(nLevels);

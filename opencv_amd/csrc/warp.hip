@@ -784,6 +784,38 @@ bool cachedAreaTab(int ssize, int dsize, double scale, AreaDev* out)
     return true;
 }
 
+// and for the INTER_LINEAR_EXACT tap tables, keyed by (source length, destination length, scale, fixed-point shift): a caller that resizes the same
+// geometry frame after frame (cv::ORB's pyramid: fourteen tables per frame) finds them resident instead of building and uploading them per call
+bool cachedExactTab(double inv_scale, int ssize, int dsize, int shift, const ExactTap** dev, DevRef* keep)
+{
+    struct Key { int dev, s, d, shift; double sc;
+                 bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : s != o.s ? s < o.s : d != o.d ? d < o.d : shift != o.shift ? shift < o.shift : sc < o.sc; } };
+    struct Entry { DevRef mem; unsigned long long stamp; };
+    static std::mutex mu;
+    static std::map<Key, Entry> cache;
+    static unsigned long long clock = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    const Key key{activeDevice(), ssize, dsize, shift, inv_scale};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 96) {
+            auto old = cache.begin();
+            for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+            cache.erase(old);
+        }
+        std::vector<ExactTap> tab;
+        buildExactTaps(inv_scale, ssize, dsize, shift, tab);
+        void* d = nullptr;
+        if (hipMalloc(&d, tab.size() * sizeof(ExactTap)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        DevRef mem(new DevBlock{d});
+        if (hipMemcpy(d, tab.data(), tab.size() * sizeof(ExactTap), hipMemcpyHostToDevice) != hipSuccess) return false;
+        it = cache.emplace(key, Entry{mem, 0}).first;
+    }
+    it->second.stamp = ++clock;
+    *dev = (const ExactTap*)it->second.mem->p; *keep = it->second.mem;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------- sampler
 // Q15 bilinear table, generated exactly as initInterTab2D does -- including its fix-up loop, which for ksize == 2
 // walks k1,k2 over {1,2} and therefore compares against (and may write into) the NEXT, not yet computed entry.
@@ -1620,12 +1652,10 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     }
     if (a.mode == 7) {
         const int shift = depth == D8U ? 8 : 16;
-        std::vector<ExactTap> hx, hy;
-        buildExactTaps(inv_scale_x, src_width, dst_width, shift, hx);
-        buildExactTaps(inv_scale_y, src_height, dst_height, shift, hy);
-        const ExactTap* dx = (const ExactTap*)stg.param(hx.data(), hx.size() * sizeof(ExactTap));
-        const ExactTap* dy = (const ExactTap*)stg.param(hy.data(), hy.size() * sizeof(ExactTap));
-        if (!dx || !dy) return MI355CV_NOT_IMPLEMENTED;
+        const ExactTap *dx, *dy;
+        DevRef keepX, keepY;                                        // the tables stay alive until the launch below is enqueued
+        if (!cachedExactTab(inv_scale_x, src_width, dst_width, shift, &dx, &keepX) || !cachedExactTab(inv_scale_y, src_height, dst_height, shift, &dy, &keepY))
+            return MI355CV_NOT_IMPLEMENTED;
         dim3 g7(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         if (depth == D8U) hipLaunchKernelGGL((k_resize_exact<uchar, 8>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
         else if (depth == D16U) hipLaunchKernelGGL((k_resize_exact<unsigned short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
