@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_gftt_candidates(const float* __restrict
             hit = v == m;
         }
     }
-    // one atomic per wavefront (a counter every candidate adds to by itself serialises on a textured frame, see k_fast_collect)
+    // one atomic per wavefront (a counter every candidate adds to by itself serialises on a textured frame: 1.7 ms per 4K ORB call in FAST's former collect kernel, profiles/r03_orb_trace.txt)
     const unsigned long long wm = __ballot(hit);
     if (!wm) return;
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)wm) - 1;

@@ -12,12 +12,8 @@
 #include "rt.h"
 #include "fast_levels.h"
 #include <algorithm>
+#include <cstring>
 #include <vector>
-
-namespace mi355 {
-size_t sortKeysDescTemp(unsigned n);                                                                             // gftt_sort.hip (rocPRIM)
-bool sortKeysDesc(void* temp, size_t bytes, const unsigned long long* in, unsigned long long* out, unsigned n, hipStream_t st);
-}
 
 using namespace mi355;
 
@@ -193,27 +189,6 @@ __global__ __launch_bounds__(1024) void k_fast_row_scan(const unsigned* __restri
     }
 }
 
-// candidates of the final score image (interior pixels with score > thr): counted, then written as keys ~index : score so that a descending
-// sort puts them in raster order
-__global__ __launch_bounds__(256) void k_fast_collect(const uchar* __restrict__ sc, size_t step, int w, int h, int thr, unsigned* __restrict__ counter,
-                                                      unsigned long long* __restrict__ keys, unsigned cap)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool hit = !(x < 3 || y < 3 || x + 3 >= w || y + 3 >= h);
-    int s = 0;
-    if (hit) { s = sc[(size_t)y * step + x]; hit = s > thr; }
-    // one atomic per wavefront: a counter every candidate adds to by itself serialises a textured 4K level (200 us against 10; profiles/r03_orb_trace.txt)
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (!hit) return;
-    const unsigned i = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-    if (keys && i < cap) keys[i] = ((unsigned long long)(0xffffffffu - (unsigned)(y * w + x)) << 32) | (unsigned)s;
-}
-
 int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int w, int h, int type)
 {
     if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return MI355CV_NOT_IMPLEMENTED;
@@ -299,22 +274,25 @@ MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, 
     if (nonmax_suppression) { hipLaunchKernelGGL(k_fast_nms, g4, dim3(256), 0, st, sc, pitch, sup, pitch, width, height); fin = sup; }
     int thr = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;                          // fast.cpp:81
     if (!thr && nonmax_suppression) thr = 1;                                                 // fast.cpp:467: with suppression a cornerScore of 0 never wins FAST_t's strict comparisons
-    unsigned n = 0;
-    if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, (unsigned long long*)nullptr, 0u);
-    if (hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    // candidates in raster order without a sort: a wavefront per row counts, one workgroup scans, the same walk writes (k_fast_rows)
+    FastLevels FL; memset(&FL, 0, sizeof FL);
+    FL.n = 1; FL.w[0] = width; FL.h[0] = height; FL.tile0[1] = divUp(height, 4); FL.row0[1] = height;
+    unsigned* rowCount = (unsigned*)stg.scratch(sizeof(unsigned) * (size_t)height);
+    unsigned* rowOff = (unsigned*)stg.scratch(sizeof(unsigned) * (size_t)height);
+    unsigned* tot = (unsigned*)stg.pinned(16);
+    if (!rowCount || !rowOff || !tot) return -2;
+    const dim3 gr(divUp(height, 4));
+    hipLaunchKernelGGL(k_fast_rows<false>, gr, dim3(256), 0, st, fin, pitch, (const uchar*)nullptr, thr, 0, FL, rowCount, (const unsigned*)nullptr, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_fast_row_scan, dim3(1), dim3(1024), 0, st, rowCount, rowOff, counter, FL);
+    if (hipMemcpyAsync(tot, counter, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    const unsigned n = tot[1];
     if (n == 0 || capacity == 0) { const int rc = stg.finish("FAST"); return rc == MI355CV_OK ? (int)n : -2; }
     unsigned long long* keys = (unsigned long long*)stg.scratch((size_t)n * 8);
-    unsigned long long* sorted = (unsigned long long*)stg.scratch((size_t)n * 8);
-    const size_t tb = sortKeysDescTemp(n);
-    void* temp = stg.scratch(tb ? tb : 16);
-    if (!keys || !sorted || !tb || !temp) return -2;
-    if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_fast_collect, g1, dim3(256), 0, st, fin, pitch, width, height, thr, counter, keys, n);
-    if (!sortKeysDesc(temp, tb, keys, sorted, n, st)) return -2;
+    if (!keys) return -2;
+    hipLaunchKernelGGL(k_fast_rows<true>, gr, dim3(256), 0, st, fin, pitch, (const uchar*)nullptr, thr, 0, FL, rowCount, (const unsigned*)rowOff, keys);
     const unsigned take = n < (unsigned)capacity ? n : (unsigned)capacity;
     const unsigned long long* host = (const unsigned long long*)stg.pinned((size_t)take * 8);     // page-locked landing zone: the list's size is the GPU's decision
-    if (!host || hipMemcpyAsync(const_cast<unsigned long long*>(host), sorted, (size_t)take * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    if (!host || hipMemcpyAsync(const_cast<unsigned long long*>(host), keys, (size_t)take * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     for (unsigned i = 0; i < take; i++) {
         const unsigned idx = 0xffffffffu - (unsigned)(host[i] >> 32), sv = (unsigned)(host[i] & 0xffffffffu);
         keypoints_xyr[3 * i] = (float)(idx % (unsigned)width);
