@@ -127,3 +127,32 @@ def test_orb_declines_and_errors(cv, orc):
     # a flat image: no keypoints, no descriptors
     k, d = cv.ORB_create().detectAndCompute(dev(np.full((240, 320), 77, np.uint8)))
     assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_orb_frames_across_host_threads(cv, orc):
+    """frames of a video on several host threads (per-thread streams, scratch pools and page-locked landing zones inside the library; ctypes releases
+    the GIL for the call): one call's host round trips and culls overlap the other calls' kernels.  Every frame's result equals the restatement's."""
+    import threading
+    frames = [orc.orb_scene(640, 480, 50 + i) for i in range(6)]
+    want = [orc.orc_ORB(f, nfeatures=800) for f in frames]
+    dev_frames = [dev(f) for f in frames]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            orb = cv.ORB_create(nfeatures=800)
+            for rep in range(4):
+                for i in range(tid, len(frames), 3):
+                    k, d = orb.detectAndCompute(dev_frames[i] if (rep + tid) % 2 else frames[i])
+                    if k.tobytes() != want[i][0].tobytes() or not np.array_equal(d, want[i][1]):
+                        errors.append((tid, rep, i))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
