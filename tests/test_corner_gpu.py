@@ -182,3 +182,24 @@ def test_good_features_to_track(cv, orc):
     want = orc.orc_goodFeaturesToTrack(img, 40, 0.01, 4.0, mask, 3, 3, False, 0.04)
     got = cv.goodFeaturesToTrack(dev(img), 40, 0.01, 4.0, dev(mask))
     assert got.shape == want.shape and set(map(tuple, got)) == set(map(tuple, want))
+
+
+def test_good_features_near_ties(cv, orc):
+    """A periodic scene: every corner of the pattern has the same neighbourhood, so the reference's responses tie exactly (its sort then orders ties by
+    address) while responses that agree to 1e-6 relative need not.  What must hold: with nothing truncated the SETS of corners are equal; where the
+    list is truncated (maxCorners) or thinned (minDistance) the two lists may differ only among corners whose responses tie within that noise."""
+    yy, xx = np.mgrid[0:240, 0:320]
+    img = (((xx // 16 + yy // 16) % 2) * 140 + 40 + ((xx // 16) % 3) * 9).astype(np.uint8)          # checkerboard, three column families of equal contrast steps
+    for harris in (False, True):
+        want = orc.orc_goodFeaturesToTrack(img, 0, 0.01, 0.0, None, 3, 3, harris, 0.04)
+        got, q = cv.goodFeaturesToTrack(dev(img), 0, 0.01, 0.0, None, 3, 3, harris, 0.04, returnQuality=True)
+        assert len(want) > 100 and set(map(tuple, got)) == set(map(tuple, want)), harris
+        qual = {tuple(c): v for c, v in zip(got, q)}
+        for maxc, md in [(40, 0.0), (0, 20.0), (25, 9.0)]:
+            w2 = orc.orc_goodFeaturesToTrack(img, maxc, 0.01, md, None, 3, 3, harris, 0.04)
+            g2 = cv.goodFeaturesToTrack(dev(img), maxc, 0.01, md, None, 3, 3, harris, 0.04)
+            assert len(g2) == len(w2), (harris, maxc, md)
+            diff = set(map(tuple, g2)) ^ set(map(tuple, w2))
+            if diff:                                                        # only corners that tie with one another may be exchanged
+                vals = np.array([qual[c] for c in diff])
+                assert vals.max() - vals.min() <= 2e-5 * abs(vals.max()), (harris, maxc, md, len(diff))
