@@ -25,6 +25,7 @@
 #include <vector>
 #include <algorithm>
 #include "warp8.h"
+#include "resize_tab8.h"
 
 using namespace mi355;
 
@@ -415,7 +416,7 @@ template <typename T, int NT> __device__ __forceinline__ int vecBody(int width) 
     return sizeof(T) == 4 ? (width / 4) * 4 : (width / 8) * 8;
 }
 
-struct CubicTap { int s; float f[4]; short i[4]; };
+typedef rt8::Tap<4> CubicTap;                                            // resize_tab8.h: {int s; float f[4]; short i[4];}
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_resize_cubic(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
@@ -475,28 +476,12 @@ __global__ __launch_bounds__(256) void k_resize_cubic(const uchar* __restrict__ 
     }
 }
 
-void buildCubicTab(int dsize, double scale, std::vector<CubicTap>& tab)
-{
-    tab.resize((size_t)dsize);
-    const float A = -0.75f;
-    for (int d = 0; d < dsize; d++) {
-        float f = (float)((d + 0.5) * scale - 0.5);
-        int sI = (int)f; sI -= sI > f;                                      // cvFloor
-        f -= sI;
-        CubicTap& t = tab[(size_t)d];
-        t.s = sI;
-        t.f[0] = ((A * (f + 1) - 5 * A) * (f + 1) + 8 * A) * (f + 1) - 4 * A;
-        t.f[1] = ((A + 2) * f - (A + 3)) * f * f + 1;
-        t.f[2] = ((A + 2) * (1 - f) - (A + 3)) * (1 - f) * (1 - f) + 1;
-        t.f[3] = 1.f - t.f[0] - t.f[1] - t.f[2];
-        for (int k = 0; k < 4; k++) { const long q = lrintf(t.f[k] * 2048); t.i[k] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q); }
-    }
-}
+using rt8::buildCubicTab;                                                // coefficients: resize_tab8.h
 
 // INTER_LANCZOS4 (resize.cpp:974-1003 coefficients, :2066-2158 passes): 8 x 8 taps at s-3 .. s+4, clamped.  CV_8U is integer throughout
 // (taps * 2048 as shorts, (sum + 2^21) >> 22); CV_32F sums the row left to right and the column as the reference's vector body does
 // (S0*b0 + (S1*b1 + ( ... + S7*b7))) below the last multiple of four elements, left to right in its scalar tail.
-struct LanczosTap { int s; float f[8]; short i[8]; };
+typedef rt8::Tap<8> LanczosTap;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_resize_lanczos(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
@@ -547,38 +532,13 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uchar* __restrict_
     }
 }
 
-void buildLanczosTab(int dsize, double scale, std::vector<LanczosTap>& tab)
-{
-    static const double s45 = 0.70710678118654752440084436210485, pi = 3.1415926535897932384626433832795;
-    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
-    tab.resize((size_t)dsize);
-    for (int d = 0; d < dsize; d++) {
-        float x = (float)((d + 0.5) * scale - 0.5);
-        int sI = (int)x; sI -= sI > x;                                      // cvFloor
-        x -= sI;
-        LanczosTap& t = tab[(size_t)d];
-        t.s = sI;
-        float sum = 0;
-        const double y0 = -(x + 3) * pi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
-        for (int i = 0; i < 8; i++) {
-            const float y0_ = (x + 3 - i);
-            if (std::fabs(y0_) >= 1e-6f) { const double y = -y0_ * pi * 0.25; t.f[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y)); }
-            else t.f[i] = 1e30f;
-            sum += t.f[i];
-        }
-        sum = 1.f / sum;
-        for (int i = 0; i < 8; i++) {
-            t.f[i] *= sum;
-            const long q = lrintf(t.f[i] * 2048); t.i[i] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q);
-        }
-    }
-}
+using rt8::buildLanczosTab;
 
 // The separable form of the two kernels above for tiles of 64 x 16 output elements: the horizontal sums of every source row a tile
 // needs are computed ONCE into LDS (they are exactly the S_k of the per-output kernels, same tap order), then each output combines NT of
 // them vertically with the reference's body / tail formulas.  A 2x cubic upscale goes from 16 gathers + 20 MACs per output to about 3 + 7.
 // The host checks that no tile needs more than RMAX source rows (strong minification does; it stays on the per-output kernels).
-template <int NT> struct TapT { int s; float f[NT]; short i[NT]; };      // layout of CubicTap (NT = 4) and LanczosTap (NT = 8)
+template <int NT> using TapT = rt8::Tap<NT>;                             // CubicTap (NT = 4) and LanczosTap (NT = 8)
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int sw, int sh, int dw, int dh, int cn,
@@ -651,6 +611,22 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
             stE<T>(dst + (size_t)dy * dstep, e, r);
         }
     }
+}
+
+// CV_8U cubic / Lanczos on tiles of 256 x 16 elements, four per lane, source bytes staged in LDS (resize_tab8.h; `rows`: the most source rows any tile needs)
+template <int NT>
+__global__ __launch_bounds__(256) void k_resize_tab8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, rt8::Geom g,
+                                                     const rt8::Tap<NT>* __restrict__ xt, const rt8::Tap<NT>* __restrict__ yt, int rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uchar ldsRaw[];
+    int* H = reinterpret_cast<int*>(ldsRaw);
+    uchar* ldsSrc = ldsRaw + (size_t)rows * rt8::TW * 4;
+    const rt8::Tile<NT> t = rt8::tileOf<NT>(g, blockIdx.x, blockIdx.y, xt, yt);
+    rt8::stage<NT>(threadIdx.x, g, t, src, sstep, ldsSrc);
+    __syncthreads();
+    rt8::hpass<NT>(threadIdx.x, g, t, xt, ldsSrc, H);
+    __syncthreads();
+    rt8::vpass<NT>(threadIdx.x, g, t, yt, H, dst, dstep);
 }
 
 // INTER_LINEAR_EXACT (resize_bitExact<ET, interpolationLinear<ET>>, resize.cpp:789-950): per-axis tables of (offset, weight of the second tap in
@@ -1623,6 +1599,17 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         dim3 gt(divUp(dst_width * cn, 64), divUp(dst_height, 16)), g1(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         int rows = 0, unused = 0;
         DevRef keepX, keepY;                                        // the tables stay alive until the launches below are enqueued
+        // CV_8U: tiles of 256 x 16 elements with the source bytes staged in LDS (resize_tab8.h) where a tile's rows fit; MI355CV_RESIZE_TAB8=0: the 64 x 16 kernel
+        static const bool tab8Off = getenv("MI355CV_RESIZE_TAB8") && atoi(getenv("MI355CV_RESIZE_TAB8")) == 0;
+        rt8::Geom geom8 = {src_width, src_height, dst_width, dst_height, cn, 0};
+        size_t lds8 = 0;
+        const dim3 g8(divUp(dst_width * cn, rt8::TW), divUp(dst_height, rt8::TH));
+        auto tab8 = [&](int nt) {
+            if (tab8Off) return false;
+            geom8.sp = rt8::stagePitch(cn, a.scale_x, nt);
+            lds8 = (size_t)rows * ((size_t)rt8::TW * 4 + (size_t)geom8.sp);
+            return lds8 <= 48 * 1024;                                 // within what a workgroup gets without asking for more
+        };
         if (a.mode == 5) {
             const CubicTap *dxt, *dyt;
             if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused, &keepX) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows, &keepY))
@@ -1632,7 +1619,10 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
 #define RZ_BY_DEPTH(M_) do { if (depth == D8U) M_(uchar); else if (depth == D16U) M_(unsigned short); else if (depth == D16S) M_(short); else M_(float); } while (0)
 #define RZ_T4(T_) RZ_TILED(T_, 4)
 #define RZ_C(T_) hipLaunchKernelGGL(k_resize_cubic<T_>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt)
-            if (rows) RZ_BY_DEPTH(RZ_T4); else RZ_BY_DEPTH(RZ_C);
+            if (rows && depth == D8U && tab8(4)) {
+                hipLaunchKernelGGL(k_resize_tab8<4>, g8, dim3(256), lds8, stream(), ds, dss, dd, dds, geom8, tx, ty, rows);
+                noteKernel("k_resize_tab8<4> grid=%ux%u x256 lds=%zu", g8.x, g8.y, lds8);
+            } else if (rows) RZ_BY_DEPTH(RZ_T4); else RZ_BY_DEPTH(RZ_C);
         } else {
             const LanczosTap *dxt, *dyt;
             if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused, &keepX) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows, &keepY))
@@ -1640,7 +1630,10 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
             const TapT<8>* tx = reinterpret_cast<const TapT<8>*>(dxt); const TapT<8>* ty = reinterpret_cast<const TapT<8>*>(dyt);
 #define RZ_T8(T_) RZ_TILED(T_, 8)
 #define RZ_L(T_) hipLaunchKernelGGL(k_resize_lanczos<T_>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt)
-            if (rows) RZ_BY_DEPTH(RZ_T8); else RZ_BY_DEPTH(RZ_L);
+            if (rows && depth == D8U && tab8(8)) {
+                hipLaunchKernelGGL(k_resize_tab8<8>, g8, dim3(256), lds8, stream(), ds, dss, dd, dds, geom8, tx, ty, rows);
+                noteKernel("k_resize_tab8<8> grid=%ux%u x256 lds=%zu", g8.x, g8.y, lds8);
+            } else if (rows) RZ_BY_DEPTH(RZ_T8); else RZ_BY_DEPTH(RZ_L);
 #undef RZ_T8
 #undef RZ_L
 #undef RZ_T4

@@ -1,0 +1,46 @@
+// resize_tab8_emu.cpp -- opencv_amd/csrc/resize_tab8.h (k_resize_tab8: CV_8U cubic / Lanczos resize on tiles of 256 x 16 elements) run on the CPU: every
+// workgroup of the launch grid, its 256 threads one after another through the three phases with the LDS arrays as plain buffers (sized exactly as the
+// host sizes them: a read or write outside them is caught by the guard bytes).  tests/test_hostemu.py compares with the pinned restatement.  Test infrastructure.
+#include "resize_tab8.h"
+#include <cstring>
+
+namespace {
+template <int NT, class Build>
+int run(Build build, const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, long* stats)
+{
+    using namespace rt8;
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    std::vector<Tap<NT>> xt, yt;
+    build(dw, scale_x, xt); build(dh, scale_y, yt);
+    int rows = 0;
+    for (int dy0 = 0; dy0 < dh; dy0 += TH) { const int last = (dy0 + TH < dh ? dy0 + TH : dh) - 1; const int r = yt[last].s - yt[dy0].s + NT; if (r > rows) rows = r; }
+    Geom g = {sw, sh, dw, dh, cn, stagePitch(cn, scale_x, NT)};
+    const size_t hInts = (size_t)rows * TW, sBytes = (size_t)rows * g.sp;
+    if (hInts * 4 + sBytes > 48 * 1024) return 1;                                   // the host would keep the 64 x 16 kernel
+    const int GUARD = 64;
+    std::vector<int> H(hInts + 2 * GUARD);
+    std::vector<unsigned char> S(sBytes + 2 * GUARD);
+    const int gx = (dw * cn + TW - 1) / TW, gy = (dh + TH - 1) / TH;
+    for (int by = 0; by < gy; by++) for (int bx = 0; bx < gx; bx++) {
+        for (auto& v : H) v = 0x5a5a5a5a;
+        memset(S.data(), 0xa5, S.size());
+        const Tile<NT> t = tileOf<NT>(g, bx, by, xt.data(), yt.data());
+        if (t.R > rows || t.nb > g.sp || t.nb < 1) return -2;                        // the host's bounds must hold for every tile
+        for (int tid = 0; tid < 256; tid++) stage<NT>(tid, g, t, src, sstep, S.data() + GUARD);
+        for (int tid = 0; tid < 256; tid++) hpass<NT>(tid, g, t, xt.data(), S.data() + GUARD, H.data() + GUARD);
+        for (int tid = 0; tid < 256; tid++) vpass<NT>(tid, g, t, yt.data(), H.data() + GUARD, dst, dstep);
+        for (int i = 0; i < GUARD; i++) if (H[i] != 0x5a5a5a5a || H[GUARD + hInts + i] != 0x5a5a5a5a || S[i] != 0xa5 || S[GUARD + sBytes + i] != 0xa5) return -3;
+        if (stats) { stats[0]++; if (t.R > stats[1]) stats[1] = t.R; if (t.nb > stats[2]) stats[2] = t.nb; }
+    }
+    if (stats) { stats[3] = rows; stats[4] = g.sp; }
+    return 0;
+}
+}
+
+// interpolation: 2 INTER_CUBIC, 4 INTER_LANCZOS4.  Returns 0, 1 when the geometry stays on the other kernels, < 0 on a violated bound.
+extern "C" int emu_resize_tab8(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, int interpolation, long* stats)
+{
+    if (interpolation == 2) return run<4>(rt8::buildCubicTab, src, sstep, sw, sh, dst, dstep, dw, dh, cn, stats);
+    if (interpolation == 4) return run<8>(rt8::buildLanczosTab, src, sstep, sw, sh, dst, dstep, dw, dh, cn, stats);
+    return -1;
+}

@@ -339,3 +339,39 @@ def test_median5_sorted_columns_lines(emumed, cn):
             got = np.full_like(img, 0x5A)
             assert emumed.emu_median5(o.P(img), o.step(img), o.P(got), o.step(got), w, h, cn) == 0
             assert np.array_equal(got, o.orc_medianBlur(img, 5)), (cn, w, h)
+
+
+# ---- CV_8U cubic / Lanczos resize on 256 x 16 tiles with staged source bytes (opencv_amd/csrc/resize_tab8.h) ---------------------------------------------
+@pytest.fixture(scope="module")
+def emurt8():
+    src = os.path.join(ROOT, "tests", "hostemu", "resize_tab8_emu.cpp")
+    out = os.path.join(ROOT, "tests", "hostemu", "libresizetab8emu.so")
+    hdr = os.path.join(ROOT, "opencv_amd", "csrc", "resize_tab8.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "opencv_amd", "csrc"), src, "-o", out])
+    return ctypes.CDLL(out)
+
+
+@pytest.mark.parametrize("interp", [2, 4])
+def test_resize_tab8_workgroups_on_the_cpu(emurt8, interp):
+    """k_resize_tab8's three phases, every workgroup of the grid thread by thread with guarded LDS buffers of the size the host gives them: equal to the
+    restatement of cv::resize(INTER_CUBIC / INTER_LANCZOS4) on CV_8U -- vector body and scalar tail of a row, clamped taps at all four edges, up- and
+    mild downscales, 1 / 3 / 4 channels; strong minification is reported as left to the other kernels"""
+    rng = np.random.default_rng(interp)
+    served = 0
+    for (sw, sh, dw, dh) in [(96, 54, 192, 108), (97, 61, 203, 131), (100, 80, 150, 170), (300, 200, 261, 170), (64, 48, 333, 111), (33, 7, 35, 9), (640, 360, 1280, 720),
+                             (500, 400, 125, 100)]:
+        for cn in (1, 3, 4):
+            src = rng.integers(0, 256, (sh, sw, cn) if cn > 1 else (sh, sw), dtype=np.uint8)
+            want = o.orc_resize(src, (dw, dh), interpolation=interp)
+            got = np.full_like(want, 0x77)
+            st = (ctypes.c_long * 5)()
+            rc = emurt8.emu_resize_tab8(o.P(src), o.step(src), sw, sh, o.P(got), o.step(got), dw, dh, cn, interp, st)
+            assert rc in (0, 1), (rc, sw, sh, dw, dh, cn)
+            if rc == 0:
+                served += 1
+                assert np.array_equal(got, want), (sw, sh, dw, dh, cn)
+                assert st[1] <= st[3] and st[2] <= st[4]
+            else:
+                assert (sw, dw) == (500, 125)                                      # 4 x minification: more staged rows than LDS holds
+    assert served >= 21
