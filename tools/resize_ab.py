@@ -38,10 +38,7 @@ print(json.dumps(dict(parity=ok, rows=rows)))
 
 for mode in ("tab8", "tiled64"):
     env = dict(os.environ)
-    if mode == "tiled64":
-        env["MI355CV_RESIZE_TAB8"] = "0"
-    else:
-        env.pop("MI355CV_RESIZE_TAB8", None)
+    env["MI355CV_RESIZE_TAB8"] = "0" if mode == "tiled64" else "1"
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=250)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     print(json.dumps({"mode": mode, "result": json.loads(line[-1]) if line else None, "err": r.stderr[-500:] if not line else ""}), flush=True)
