@@ -513,9 +513,10 @@ MI355CV_API int mi355cv_FAST(const mi355cv_uchar* src_data, size_t src_step, int
         float* keypoints_xyr, int capacity);
 
 /* --------------------------------------------------- f3: features2d ORB (csrc/orb.hip) */
-/* cv::KeyPoint (core/types.hpp:777) and the arguments of cv::ORB::create (features2d.hpp:449-457; scoreType: ORB::HARRIS_SCORE 0, FAST_SCORE 1) */
+/* cv::KeyPoint (core/types.hpp:777) and the parameters of cv::ORB (features2d.hpp:449-510; scoreType: ORB::HARRIS_SCORE 0, FAST_SCORE 1).  scaleFactor is the
+ * double the reference keeps: ORB::create takes a float (pass (double)(float)f for it), setScaleFactor a double */
 typedef struct mi355cv_KeyPoint { float x, y, size, angle, response; int octave, class_id; } mi355cv_KeyPoint;
-typedef struct mi355cv_OrbParams { int nfeatures; float scaleFactor; int nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize, fastThreshold; } mi355cv_OrbParams;
+typedef struct mi355cv_OrbParams { int nfeatures; double scaleFactor; int nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize, fastThreshold; } mi355cv_OrbParams;
 /* cv::ORB::detectAndCompute (modules/features2d/src/orb.cpp:1012; the reference has no HAL hook for it) on a CV_8UC1 image in host or device
  * memory: pyramid, FAST, Harris responses, orientation, smoothing and the rBRIEF descriptors on the GPU; the two culls (KeyPointsFilter::retainBest)
  * on the host with the C++ library's nth_element, so keypoints leave in the reference's order.  `mask`: optional CV_8UC1 image of the same size.

@@ -290,12 +290,10 @@ public:
         if ((_image.kind() == cv::_InputArray::MAT) && (_mask.empty() || _mask.kind() == cv::_InputArray::MAT) && !_descriptors.isUMat() &&
             (doDesc || !useProvidedKeypoints)) {
             cv::Mat image = _image.getMat(), mask = _mask.getMat();
-            // the member is a double that ORB::create filled from a float: the library takes the float back only when nothing is lost (setScaleFactor(1.3) is)
-            const double sf = stock_->getScaleFactor();
-            if (image.dims <= 2 && image.type() == CV_8UC1 && !image.empty() && (mask.empty() || (mask.type() == CV_8UC1 && mask.size() == image.size())) &&
-                (double)(float)sf == sf) {
+            const double sf = stock_->getScaleFactor();           // the double the stock object keeps (from create's float or from setScaleFactor)
+            if (image.dims <= 2 && image.type() == CV_8UC1 && !image.empty() && (mask.empty() || (mask.type() == CV_8UC1 && mask.size() == image.size()))) {
                 static_assert(sizeof(cv::KeyPoint) == sizeof(mi355cv_KeyPoint), "cv::KeyPoint is the 28-byte record mi355cv_KeyPoint declares");
-                const mi355cv_OrbParams prm = {stock_->getMaxFeatures(), (float)sf, stock_->getNLevels(), stock_->getEdgeThreshold(), stock_->getFirstLevel(), stock_->getWTA_K(),
+                const mi355cv_OrbParams prm = {stock_->getMaxFeatures(), sf, stock_->getNLevels(), stock_->getEdgeThreshold(), stock_->getFirstLevel(), stock_->getWTA_K(),
                                                (int)stock_->getScoreType(), stock_->getPatchSize(), stock_->getFastThreshold()};
                 std::vector<cv::KeyPoint> kp(keypoints);
                 const int nIn = useProvidedKeypoints ? (int)kp.size() : 0;

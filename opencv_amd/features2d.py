@@ -87,7 +87,7 @@ KEYPOINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.flo
 
 
 class _OrbParams(ctypes.Structure):
-    _fields_ = [("nfeatures", ctypes.c_int), ("scaleFactor", ctypes.c_float), ("nlevels", ctypes.c_int), ("edgeThreshold", ctypes.c_int),
+    _fields_ = [("nfeatures", ctypes.c_int), ("scaleFactor", ctypes.c_double), ("nlevels", ctypes.c_int), ("edgeThreshold", ctypes.c_int),
                 ("firstLevel", ctypes.c_int), ("WTA_K", ctypes.c_int), ("scoreType", ctypes.c_int), ("patchSize", ctypes.c_int), ("fastThreshold", ctypes.c_int)]
 
 
@@ -121,7 +121,7 @@ class ORB:
                 def setter(v):
                     if key == "firstLevel" and v < 0:
                         raise ValueError("ORB: firstLevel >= 0")
-                    self._p[key] = float(np.float32(v)) if key == "scaleFactor" else int(v)
+                    self._p[key] = float(v) if key == "scaleFactor" else int(v)         # setScaleFactor(double) keeps the double; ORB::create rounds to float (orb.cpp:660, :1262)
                 return setter
         raise AttributeError(name)
 

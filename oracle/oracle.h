@@ -177,16 +177,16 @@ int orc_Canny(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int 
               int aperture, int L2);
 
 /* features2d ORB, see oracle/orb.c.  Keypoints are 28-byte records laid out like cv::KeyPoint (x, y, size, angle, response, octave, class_id). */
-int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
+int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, double scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
             int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, uint8_t* desc, int doDesc);
-int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* mask, size_t mstep, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
+int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* mask, size_t mstep, int nfeatures, double scaleFactor, int nlevels, int edgeThreshold,
                 int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, uint8_t* desc, int doDesc);
 int orc_retainBest(void* kps, int n, int npoints);
 int orc_heapSelectCalls(void);
 float orc_fastAtan2(float y, float x);
 void orc_orbUmax(int halfPatch, int* umax);
-uint8_t* orc_orbPyramid(const uint8_t* img, size_t step, int w, int h, int nlevels, float scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out);
-uint8_t* orc_orbPyramidBlurred(const uint8_t* img, size_t step, int w, int h, int nlevels, float scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out);
+uint8_t* orc_orbPyramid(const uint8_t* img, size_t step, int w, int h, int nlevels, double scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out);
+uint8_t* orc_orbPyramidBlurred(const uint8_t* img, size_t step, int w, int h, int nlevels, double scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out);
 int orc_orbPattern(int patchSize, int wta_k, int* pat);
 void orc_free(void* p);
 

@@ -343,7 +343,7 @@ static void describe(const uint8_t* center, int step, float angleDeg, const int*
 
 /* the pyramid buffer of a parameter set, for tests that look at intermediate stages: returns bufW * bufH bytes (caller frees), layout in out[] =
  * {nLevels, border, bufW, bufH, then x, y, w, h per level} */
-uint8_t* orc_orbPyramid(const uint8_t* img, size_t step, int w, int h, int nlevels, float scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out)
+uint8_t* orc_orbPyramid(const uint8_t* img, size_t step, int w, int h, int nlevels, double scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out)
 {
     Layout L;
     if (nlevels < 1 || nlevels > 64) return NULL;
@@ -375,7 +375,7 @@ static void blurLevels(const Layout* L, uint8_t* pyr)
 }
 
 /* the buffer the descriptors are sampled from (every level smoothed), layout as orc_orbPyramid */
-uint8_t* orc_orbPyramidBlurred(const uint8_t* img, size_t step, int w, int h, int nlevels, float scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out)
+uint8_t* orc_orbPyramidBlurred(const uint8_t* img, size_t step, int w, int h, int nlevels, double scaleFactor, int edgeThreshold, int firstLevel, int patchSize, int* out)
 {
     uint8_t* pyr = orc_orbPyramid(img, step, w, h, nlevels, scaleFactor, edgeThreshold, firstLevel, patchSize, out);
     if (!pyr) return NULL;
@@ -393,10 +393,10 @@ int orc_orbPattern(int patchSize, int wta_k, int* pat)
 
 /* cv::ORB::detectAndCompute on a CV_8UC1 image, optional CV_8UC1 mask of the same size (NULL: none).  useProvided: nIn keypoints come in through kps
  * (the mask is then unused, as in the reference).  Returns the keypoint count (kps / desc are filled up to cap), -1 for parameters outside the restatement. */
-int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* mask, size_t mstep, int nfeatures, float scaleFactorF, int nlevels, int edgeThreshold,
+int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* mask, size_t mstep, int nfeatures, double scaleFactor, int nlevels, int edgeThreshold,
                 int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kpsIO, int nIn, int cap, uint8_t* desc, int doDesc)
 {
-    const double scaleFactor = (double)scaleFactorF;                 /* ORB::create takes a float, the member is a double (orb.cpp:660, :1262) */
+    /* scaleFactor: the double the reference keeps -- ORB::create fills it from a float, setScaleFactor from a double (orb.cpp:660, :1262) */
     KP* io = (KP*)kpsIO;
     if (patchSize < 2 || firstLevel < 0 || (wta_k != 2 && wta_k != 3 && wta_k != 4) || w <= 0 || h <= 0) return -1;
     int nLevels = nlevels;
@@ -505,7 +505,7 @@ int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* ma
     return nAll;
 }
 
-int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
+int orc_ORB(const uint8_t* img, size_t step, int w, int h, int nfeatures, double scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int wta_k,
             int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, uint8_t* desc, int doDesc)
 {
     return orc_ORBmask(img, step, w, h, NULL, 0, nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, scoreType, patchSize, fastThreshold, useProvided, kps, nIn, cap, desc, doDesc);

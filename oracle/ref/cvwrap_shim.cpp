@@ -130,14 +130,15 @@ EXPORT int wrap_FAST(const void* s, size_t ss, int w, int h, int threshold, int 
 }
 
 // mi355cv::ORB_create(...)->detectAndCompute / detect / compute with std::vector<KeyPoint>, as applications call cv::ORB; arguments as ref_ORB (ref_shim.cpp).
-// setScale != 0: the scale factor is then set again through setScaleFactor(double) -- a value a float cannot hold keeps the call on the stock path.
+// setScale > 0: the scale factor is then set again through setScaleFactor(double), which keeps the double.
 EXPORT int wrap_ORB(const void* s, size_t ss, int w, int h, int type, const void* mask, size_t ms, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
-                    int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc)
+                    int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc, double setScale)
 {
     try {
         Mat src = M(s, ss, w, h, type), m;
         if (mask) m = M(mask, ms, w, h, CV_8UC1);
         Ptr<cv::ORB> orb = mi355cv::ORB_create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, (cv::ORB::ScoreType)scoreType, patchSize, fastThreshold);
+        if (setScale > 0) orb->setScaleFactor(setScale);
         if (orb->getMaxFeatures() != nfeatures || orb->getWTA_K() != wta_k || orb->descriptorSize() != 32 || orb->getDefaultName() != "Feature2D.ORB") return -3;
         std::vector<KeyPoint> kp;
         if (useProvided) kp.assign((const KeyPoint*)kps, (const KeyPoint*)kps + nIn);

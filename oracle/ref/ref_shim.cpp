@@ -474,15 +474,16 @@ int ref_dilate3x3(const void* s, size_t ss, void* d, size_t ds, int w, int h, in
 
 // cv::ORB (modules/features2d/src/orb.cpp): keypoints as 28-byte records laid out like cv::KeyPoint (x, y, size, angle, response, octave, class_id),
 // descriptors as n rows of descriptorSize() bytes.  useProvided != 0: *n keypoints come in, descriptors of the ones that survive go out.
-// Returns the keypoint count (kps / desc hold at most cap of them), -1 on an exception.
+// setScale > 0: the scale factor is then set again through setScaleFactor(double).  Returns the keypoint count (kps / desc hold at most cap of them), -1 on an exception.
 int ref_ORB(const void* s, size_t ss, int w, int h, int type, const void* mask, size_t ms, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
-            int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc)
+            int firstLevel, int wta_k, int scoreType, int patchSize, int fastThreshold, int useProvided, void* kps, int nIn, int cap, void* desc, int doDesc, double setScale)
 {
     try {
         static_assert(sizeof(KeyPoint) == 28, "KeyPoint layout");
         Mat src = M(s, ss, w, h, type), m;
         if (mask) m = M(mask, ms, w, h, CV_8UC1);
         Ptr<ORB> orb = ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, (ORB::ScoreType)scoreType, patchSize, fastThreshold);
+        if (setScale > 0) orb->setScaleFactor(setScale);                      // the setter keeps a double, create a float
         std::vector<KeyPoint> kp;
         if (useProvided) kp.assign((const KeyPoint*)kps, (const KeyPoint*)kps + nIn);
         Mat d;

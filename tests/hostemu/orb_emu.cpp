@@ -8,7 +8,7 @@ using namespace orbh;
 extern "C" {
 
 // layout as oracle/orb.c's orc_orbPyramid reports it: {nLevels, border, bufW, bufH, then x, y, w, h per level}; returns the pitch the kernels use
-int emu_orb_layout(int w, int h, int nlevels, int firstLevel, float scaleFactor, int edgeThreshold, int patchSize, int* out, float* scales)
+int emu_orb_layout(int w, int h, int nlevels, int firstLevel, double scaleFactor, int edgeThreshold, int patchSize, int* out, float* scales)
 {
     Layout L;
     buildLayout(L, w, h, nlevels, firstLevel, (double)scaleFactor, edgeThreshold, patchSize);
@@ -18,7 +18,7 @@ int emu_orb_layout(int w, int h, int nlevels, int firstLevel, float scaleFactor,
 }
 
 // k_orb_border over its launch grid (every thread of every workgroup, including the ones the guards turn away); returns the count of threads that ran
-long emu_orb_border(unsigned char* pyr, int w, int h, int nlevels, int firstLevel, float scaleFactor, int edgeThreshold, int patchSize, int level, const unsigned char* src, size_t sstep)
+long emu_orb_border(unsigned char* pyr, int w, int h, int nlevels, int firstLevel, double scaleFactor, int edgeThreshold, int patchSize, int level, const unsigned char* src, size_t sstep)
 {
     Layout L;
     buildLayout(L, w, h, nlevels, firstLevel, (double)scaleFactor, edgeThreshold, patchSize);

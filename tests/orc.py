@@ -1220,8 +1220,12 @@ def _orb_call(fn, is_ref, src, keypoints, descriptors, cap, p, mask=None):
         kps[:n_in] = keypoints
     desc = np.zeros((len(kps), 32), np.uint8)
     c_f = ctypes.c_float
-    tail = [p["nfeatures"], c_f(p["scaleFactor"]), p["nlevels"], p["edgeThreshold"], p["firstLevel"], p["WTA_K"], p["scoreType"], p["patchSize"],
+    # ORB::create takes the scale factor as a float, setScaleFactor (key "setScaleFactor") as a double; the member is a double either way
+    set_scale = float(p.get("setScaleFactor", 0.0))
+    eff_scale = set_scale if set_scale > 0 else float(np.float32(p["scaleFactor"]))
+    rest = [p["nlevels"], p["edgeThreshold"], p["firstLevel"], p["WTA_K"], p["scoreType"], p["patchSize"],
             p["fastThreshold"], 1 if keypoints is not None else 0, P(kps), n_in, len(kps), P(desc), 1 if descriptors else 0]
+    tail = [p["nfeatures"], c_f(p["scaleFactor"])] + rest + [c_dbl(set_scale)] if is_ref else [p["nfeatures"], c_dbl(eff_scale)] + rest
     m_args = [P(mask), step(mask)] if mask is not None else [None, c_sz(0)]
     if is_ref:
         n = fn(P(src), step(src), w, h, cvtype(src), *m_args, *tail)

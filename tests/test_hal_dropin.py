@@ -396,6 +396,12 @@ def _orb_tour(hal):
         with O.use_ref(hal):                                                                           # cv::ORB of the HAL-enabled build
             hk, hd = O.ref_ORB(img, mask=mask, **kw)
         assert hk.tobytes() == wk.tobytes() and np.array_equal(hd, wd)
+    # setScaleFactor(double) on the wrapper: the double goes through to the library (and to the stock object)
+    img = O.orb_scene(300, 220, 31)
+    p = dict(O.ORB_DEFAULTS, setScaleFactor=1.8, nlevels=5, nfeatures=900)
+    wk, wd = O.ref_ORB(img, setScaleFactor=1.8, nlevels=5, nfeatures=900)
+    gk, gd = O._orb_call(hal.wrap_ORB, True, img, None, True, 20000, p)
+    assert gk.tobytes() == wk.tobytes() and np.array_equal(gd, wd)
 
 
 def test_cv_signature_orb_wrapper(ref):

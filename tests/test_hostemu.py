@@ -193,7 +193,7 @@ ORB_EMU_CASES = [
 def _orb_layout(emuorb, w, h, p):
     out = np.zeros(4 + 4 * 64, np.int32)
     scales = np.zeros(64, np.float32)
-    pitch = emuorb.emu_orb_layout(w, h, p["nlevels"], p["firstLevel"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["patchSize"], o.P(out), o.P(scales))
+    pitch = emuorb.emu_orb_layout(w, h, p["nlevels"], p["firstLevel"], ctypes.c_double(float(np.float32(p["scaleFactor"]))), p["edgeThreshold"], p["patchSize"], o.P(out), o.P(scales))
     return out, scales, pitch
 
 
@@ -203,7 +203,7 @@ def _orc_pyramid(img, p, blurred=False):
     fn.restype = ctypes.c_void_p
     out = np.zeros(4 + 4 * 64, np.int32)
     h, w = img.shape
-    ptr = fn(o.P(img), o.step(img), w, h, p["nlevels"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["firstLevel"], p["patchSize"], o.P(out))
+    ptr = fn(o.P(img), o.step(img), w, h, p["nlevels"], ctypes.c_double(float(np.float32(p["scaleFactor"]))), p["edgeThreshold"], p["firstLevel"], p["patchSize"], o.P(out))
     assert ptr
     buf = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(out[3]), int(out[2]))).copy()
     orc.orc_free(ctypes.c_void_p(ptr))
@@ -230,7 +230,7 @@ def test_orb_kernel_lines_against_the_restatement(emuorb, w, h, seed, kw):
         covered[y - border:y + lh + border, x - border:x + lw + border] = True
     for l in range(nl):
         src = img if l == p["firstLevel"] else None
-        ran = emuorb.emu_orb_border(o.P(mine), w, h, nl, p["firstLevel"], ctypes.c_float(p["scaleFactor"]), p["edgeThreshold"], p["patchSize"], l,
+        ran = emuorb.emu_orb_border(o.P(mine), w, h, nl, p["firstLevel"], ctypes.c_double(float(np.float32(p["scaleFactor"]))), p["edgeThreshold"], p["patchSize"], l,
                                     o.P(src) if src is not None else None, o.step(src) if src is not None else ctypes.c_size_t(0))
         assert ran > 0
     assert np.array_equal(mine[:, :bufW][covered[:, :bufW]], pyr[covered[:, :bufW]])

@@ -52,6 +52,22 @@ def test_orb_with_a_mask(w, h, seed, kw):
 
 
 @needs_ref
+def test_orb_scale_factor_set_as_a_double():
+    """ORB::create takes the scale factor as a float, setScaleFactor as a double (orb.cpp:660, :1262): 1.8 and float(1.8) give different level sizes.  Also the
+    geometry of the reference's own regression_16197 (test_orb.cpp:127: firstLevel 3, 1.8, patch 8, edge 8 -- level 0 is a 5.8 x upscale) on a scene with corners"""
+    img = o.orb_scene(300, 220, 31)
+    a = o.ref_ORB(img, setScaleFactor=1.8, nlevels=5, nfeatures=900)
+    b = o.orc_ORB(img, setScaleFactor=1.8, nlevels=5, nfeatures=900)
+    c = o.ref_ORB(img, scaleFactor=1.8, nlevels=5, nfeatures=900)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and len(a[0]) > 200
+    assert a[0].tobytes() != c[0].tobytes()                                  # the float and the double differ in the output
+    small = o.orb_scene(72, 72, 16197)
+    kw = dict(nlevels=5, firstLevel=3, setScaleFactor=1.8, patchSize=8, edgeThreshold=8)
+    ra, oa = o.ref_ORB(small, **kw), o.orc_ORB(small, **kw)
+    assert ra[0].tobytes() == oa[0].tobytes() and np.array_equal(ra[1], oa[1]) and len(ra[0]) > 20
+
+
+@needs_ref
 def test_orb_detect_only_and_provided_keypoints():
     img = o.orb_scene(480, 360, 11)
     rk, _ = o.ref_ORB(img, descriptors=False)

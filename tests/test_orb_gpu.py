@@ -112,6 +112,31 @@ def test_orb_full_hd_frame(cv, orc):
     same(cv.ORB_create(**kw).detectAndCompute(dev(img)), want)
 
 
+def test_orb_setters_and_the_reference_regressions(cv, orc):
+    """setScaleFactor keeps a double where ORB::create rounds to float (orb.cpp:660, :1262); the geometries of the reference's own ORB tests that need no
+    image file (modules/features2d/test/test_orb.cpp: crash_5031 -- compute() on a keypoint 5 rows from the top with an 18-level, patch-47 detector;
+    regression_16197 -- firstLevel 3, scale 1.8, patch 8)"""
+    img = orc.orb_scene(300, 220, 31)
+    orb = cv.ORB_create(nfeatures=900, nlevels=5)
+    orb.setScaleFactor(1.8)
+    assert orb.getScaleFactor() == 1.8
+    same(orb.detectAndCompute(dev(img)), orc.orc_ORB(img, setScaleFactor=1.8, nlevels=5, nfeatures=900))
+    same(cv.ORB_create(nfeatures=900, nlevels=5, scaleFactor=1.8).detectAndCompute(dev(img)), orc.orc_ORB(img, scaleFactor=1.8, nlevels=5, nfeatures=900))
+    small = orc.orb_scene(72, 72, 16197)
+    o2 = cv.ORB_create()
+    o2.setNLevels(5); o2.setFirstLevel(3); o2.setScaleFactor(1.8); o2.setPatchSize(8); o2.setEdgeThreshold(8)
+    same(o2.detectAndCompute(dev(small)), orc.orc_ORB(small, nlevels=5, firstLevel=3, setScaleFactor=1.8, patchSize=8, edgeThreshold=8))
+    k, d = o2.detectAndCompute(dev(np.zeros((72, 72), np.uint8)))                                # the reference's own input: all zeros
+    assert len(k) == 0 and d.shape == (0, 32)
+    o3 = cv.ORB_create(8000, 1.2, 18, 4, 0, 2, cv.ORB_HARRIS_SCORE, 47, 20)
+    kp = np.zeros(1, cv.KEYPOINT_DTYPE)
+    kp["x"], kp["y"], kp["size"], kp["angle"], kp["response"], kp["octave"], kp["class_id"] = 443, 5, 47, 53.4580612, 0.0000470733867, 0, -1
+    bgr = np.zeros((1080, 1920, 3), np.uint8)
+    gk, gd = o3.compute(dev(bgr), kp)
+    wk, wd = orc.orc_ORB(np.zeros((1080, 1920), np.uint8), keypoints=kp, nfeatures=8000, nlevels=18, edgeThreshold=4, patchSize=47)
+    assert gk.tobytes() == wk.tobytes() and np.array_equal(gd, wd) and len(gk) == 1
+
+
 def test_orb_declines_and_errors(cv, orc):
     img = dev(orc.orb_scene(320, 240, 1))
     with pytest.raises(ValueError):
