@@ -123,9 +123,9 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
     const bool provided = use_provided_keypoints != 0, doDesc = descriptors != nullptr;
     if (p.patchSize < 2 || p.patchSize > 127 || p.firstLevel < 0 || (p.WTA_K != 2 && p.WTA_K != 3 && p.WTA_K != 4) || (p.scoreType != 0 && p.scoreType != 1) || !(p.scaleFactor > 0.0))
         { setError(MI355CV_NOT_IMPLEMENTED, "ORB: parameters outside the served range"); return -1; }
-    if (provided && (nkeypoints_in < 0 || nkeypoints_in > capacity)) return -1;
-    if (doDesc && descriptors_step < 32) return -1;
-    if ((long long)width * height > 0x3fffffffLL) return -1;
+    if (provided && (nkeypoints_in < 0 || nkeypoints_in > capacity)) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: %d keypoints passed in, room for %d", nkeypoints_in, capacity); return -1; }
+    if (doDesc && descriptors_step < 32) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: descriptor rows are 32 bytes"); return -1; }
+    if ((long long)width * height > 0x3fffffffLL) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: image beyond 2^30 pixels"); return -1; }
     const double scaleFactor = p.scaleFactor;                               // the double the reference keeps (ORB::create fills it from a float, setScaleFactor from a double: orb.cpp:660,1262)
 
     std::vector<KP> all;

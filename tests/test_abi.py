@@ -58,3 +58,23 @@ def test_no_gpu_means_loud_failure_not_fallback():
     import opencv_amd as cv
     with pytest.raises(NotImplementedError):
         cv.GaussianBlur(np.zeros((32, 32), np.uint8), 5)
+
+
+def test_struct_layouts_of_the_c_abi_match_the_bindings(tmp_path):
+    """the records that cross the C ABI by value or by pointer (mi355cv_KeyPoint = cv::KeyPoint, mi355cv_OrbParams) as a C compiler lays them out from
+    include/mi355cv.h, against the ctypes / numpy declarations of the Python mirror"""
+    import subprocess
+    import numpy as np
+    from opencv_amd import features2d as f2d
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mi355cv.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mi355cv_KeyPoint), offsetof(mi355cv_KeyPoint, response), offsetof(mi355cv_KeyPoint, class_id),\n'
+                   '  sizeof(mi355cv_OrbParams), offsetof(mi355cv_OrbParams, scaleFactor), offsetof(mi355cv_OrbParams, nlevels), offsetof(mi355cv_OrbParams, WTA_K), offsetof(mi355cv_OrbParams, fastThreshold)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    P = f2d._OrbParams
+    want = [f2d.KEYPOINT_DTYPE.itemsize, f2d.KEYPOINT_DTYPE.fields["response"][1], f2d.KEYPOINT_DTYPE.fields["class_id"][1],
+            ctypes.sizeof(P), P.scaleFactor.offset, P.nlevels.offset, P.WTA_K.offset, P.fastThreshold.offset]
+    assert got == want, (got, want)
+    assert got[0] == 28 and np.dtype(f2d.KEYPOINT_DTYPE).isalignedstruct is False
