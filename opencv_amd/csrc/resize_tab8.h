@@ -76,6 +76,16 @@ constexpr int TW = 256, TH = 16;                                            // a
 struct Geom { int sw, sh, dw, dh, cn, sp; };                                // sp: LDS pitch of a staged row in bytes (host bound, multiple of 4)
 
 MI355_HD int clipI(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+// 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24: full rate; the 32-bit v_mul_lo_u32 is a quarter-rate instruction): both operands within +-2^23 --
+// a byte times a tap * 2048, a horizontal sum (< 2^21) times a tap, an index times a channel count or an LDS pitch
+MI355_HD int mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
 MI355_HD int roundHalfEven(float v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -112,7 +122,7 @@ MI355_HD void stage(int tid, const Geom& g, const Tile<NT>& t, const unsigned ch
 {
     for (int r = 0; r < t.R; r++) {
         const unsigned char* rowp = src + (size_t)clipI(t.rmin + r, 0, g.sh) * sstep + t.cb0;
-        for (int b = tid; b < t.nb; b += 256) ldsSrc[r * g.sp + b] = rowp[b];
+        for (int b = tid; b < t.nb; b += 256) ldsSrc[mul24(r, g.sp) + b] = rowp[b];
     }
 }
 
@@ -130,12 +140,12 @@ MI355_HD void hpass(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* xt
         const Tap<NT> tx = xt[dx];
         int xs[NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) xs[j] = clipI(tx.s - OFF + j, 0, g.sw) * g.cn + c - t.cb0;
+        for (int j = 0; j < NT; j++) xs[j] = mul24(clipI(tx.s - OFF + j, 0, g.sw), g.cn) + c - t.cb0;
         for (int r = w; r < t.R; r += 4) {
-            const unsigned char* row = ldsSrc + r * g.sp;
+            const unsigned char* row = ldsSrc + mul24(r, g.sp);
             int v = 0;
 #pragma unroll
-            for (int j = 0; j < NT; j++) v += (int)row[xs[j]] * tx.i[j];
+            for (int j = 0; j < NT; j++) v += mul24((int)row[xs[j]], (int)tx.i[j]);
             H[r * TW + el] = v;
         }
     }
@@ -167,7 +177,7 @@ MI355_HD void vpass(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* yt
             } else {
                 int acc = 0;
 #pragma unroll
-                for (int k = 0; k < NT; k++) acc += S[k * TW + q] * ty.i[k];
+                for (int k = 0; k < NT; k++) acc += mul24(S[k * TW + q], (int)ty.i[k]);
                 r = (acc + (1 << 21)) >> 22;
             }
             out |= (uint32_t)(r < 0 ? 0 : r > 255 ? 255 : r) << (8 * q);

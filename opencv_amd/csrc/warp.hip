@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
             if (sizeof(T) == 1) {
                 int v = 0;
 #pragma unroll
-                for (int j = 0; j < NT; j++) v += rowp[xs[j]] * tx.i[j];
+                for (int j = 0; j < NT; j++) v += rt8::mul24((int)rowp[xs[j]], (int)tx.i[j]);      // a byte times a tap * 2048: 24-bit multiply (full rate)
                 H[r * TW + lx] = (HT)v;
             } else {
                 float v = __fmul_rn(ldE<T>(rowp, xs[0]), tx.f[0]);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uchar* __restrict__ 
             } else {
                 int acc = 0;
 #pragma unroll
-                for (int k = 0; k < NT; k++) acc += (int)S[k * TW] * ty.i[k];
+                for (int k = 0; k < NT; k++) acc += rt8::mul24((int)S[k * TW], (int)ty.i[k]);
                 r = (acc + (1 << 21)) >> 22;
             }
             (dst + (size_t)dy * dstep)[e] = (uchar)(r < 0 ? 0 : r > 255 ? 255 : r);
@@ -641,6 +641,23 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uchar* __restrict__ 
     if (e >= dw * cn || y >= dh) return;
     const int x = e / cn, c = e - x * cn;
     const ExactTap ax = tx[x], ay = ty[y];
+    if constexpr (sizeof(T) == 1) {
+        // CV_8U, Q8 weights: every term fits 24 bits (255 * 256 * 256 < 2^24), so the two passes are 24-bit multiply-adds at full rate
+        // instead of 64-bit products (cv::ORB builds its pyramid with this kernel)
+        int H[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (r == 1 && ay.c1 == 0) break;
+            const uchar* row = src + (size_t)(ay.ofs + r) * sstep;
+            const int b0 = rt8::mul24(ax.ofs, cn) + c;
+            const int p0 = row[b0], p1 = ax.c1 ? (int)row[b0 + cn] : 0;
+            H[r] = rt8::mul24(256 - ax.c1, p0) + rt8::mul24(ax.c1, p1);
+        }
+        const int v = rt8::mul24(256 - ay.c1, H[0]) + rt8::mul24(ay.c1, H[1]);
+        const int r8 = (v + (1 << 15)) >> 16;
+        dst[(size_t)y * dstep + e] = (uchar)(r8 > 255 ? 255 : r8);
+        return;
+    }
     const long long one = 1LL << SHIFT;
     long long H[2] = {0, 0};
 #pragma unroll
