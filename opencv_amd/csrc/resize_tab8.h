@@ -116,36 +116,65 @@ MI355_HD Tile<NT> tileOf(const Geom& g, int bx, int by, const Tap<NT>* xt, const
     return t;
 }
 
-// stage: thread tid copies bytes tid, tid + 256, ... of every staged row
+// stage: thread tid copies bytes tid, tid + 256, ... of every staged row; eight rows' loads are issued before the first LDS store, so that their
+// latencies overlap (a load-store-load-store chain through byte pointers cannot be reordered by the compiler: one memory latency per row, and the
+// first version of this kernel was bound by exactly that -- profiles/r03_resize_tab8_ab.txt)
 template <int NT>
 MI355_HD void stage(int tid, const Geom& g, const Tile<NT>& t, const unsigned char* src, size_t sstep, unsigned char* ldsSrc)
 {
-    for (int r = 0; r < t.R; r++) {
-        const unsigned char* rowp = src + (size_t)clipI(t.rmin + r, 0, g.sh) * sstep + t.cb0;
-        for (int b = tid; b < t.nb; b += 256) ldsSrc[mul24(r, g.sp) + b] = rowp[b];
+    for (int b = tid; b < t.nb; b += 256) {
+        for (int r0 = 0; r0 < t.R; r0 += 8) {
+            unsigned char v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = r0 + k < t.R ? r0 + k : t.R - 1;             // the tail repeats the last row: always a legal address
+                v[k] = src[(size_t)clipI(t.rmin + r, 0, g.sh) * sstep + t.cb0 + b];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (r0 + k < t.R) ldsSrc[mul24(r0 + k, g.sp) + b] = v[k];
+        }
     }
 }
 
 // hpass: lane lx = tid & 63 owns elements e0 + lx, + 64, + 128, + 192 (neighbouring lanes read neighbouring source bytes and write neighbouring ints:
 // no LDS bank conflicts), wave w = tid >> 6 the staged rows w, w + 4, ...
+// the taps a thread needs in the two passes, fetched at the head of the workgroup's work so that these loads, the staging loads and each other overlap
+// (fetched where they are used, each costs a memory latency in front of a short loop: the first version of this kernel spent most of its time there)
+template <int NT> struct HTaps { Tap<NT> tx[4]; int cc[4]; };
+template <int NT> struct VTaps { Tap<NT> ty[TH / 4]; };
 template <int NT>
-MI355_HD void hpass(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* xt, const unsigned char* ldsSrc, int* H)
+MI355_HD void loadTaps(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* xt, const Tap<NT>* yt, HTaps<NT>& h, VTaps<NT>& v)
+{
+    const int lx = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int e = t.e0 + lx + 64 * q, ev = e < t.width ? e : t.width - 1;
+        const int dx = ev / g.cn;
+        h.cc[q] = ev - mul24(dx, g.cn);
+        h.tx[q] = xt[dx];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < TH / 4; k4++) { const int dy = t.dy0 + w + 4 * k4; v.ty[k4] = yt[dy < g.dh ? dy : g.dh - 1]; }
+}
+
+template <int NT>
+MI355_HD void hpass(int tid, const Geom& g, const Tile<NT>& t, const HTaps<NT>& ht, const unsigned char* ldsSrc, int* H)
 {
     constexpr int OFF = NT / 2 - 1;
     const int lx = tid & 63, w = tid >> 6;
+    const Tap<NT>* tx = ht.tx; const int* cc = ht.cc;
+#pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int el = lx + 64 * q, e = t.e0 + el;
-        if (e >= t.width) break;
-        const int dx = e / g.cn, c = e - dx * g.cn;
-        const Tap<NT> tx = xt[dx];
+        const int el = lx + 64 * q;
+        if (t.e0 + el >= t.width) break;
         int xs[NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) xs[j] = mul24(clipI(tx.s - OFF + j, 0, g.sw), g.cn) + c - t.cb0;
+        for (int j = 0; j < NT; j++) xs[j] = mul24(clipI(tx[q].s - OFF + j, 0, g.sw), g.cn) + cc[q] - t.cb0;
         for (int r = w; r < t.R; r += 4) {
             const unsigned char* row = ldsSrc + mul24(r, g.sp);
             int v = 0;
 #pragma unroll
-            for (int j = 0; j < NT; j++) v += mul24((int)row[xs[j]], (int)tx.i[j]);
+            for (int j = 0; j < NT; j++) v += mul24((int)row[xs[j]], (int)tx[q].i[j]);
             H[r * TW + el] = v;
         }
     }
@@ -153,16 +182,17 @@ MI355_HD void hpass(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* xt
 
 // vpass: lane lx owns the four NEIGHBOURING elements e0 + 4 lx .. + 3 (one dword of the destination row), rows dy0 + w + 4 k
 template <int NT>
-MI355_HD void vpass(int tid, const Geom& g, const Tile<NT>& t, const Tap<NT>* yt, const int* H, unsigned char* dst, size_t dstep)
+MI355_HD void vpass(int tid, const Geom& g, const Tile<NT>& t, const VTaps<NT>& vt, const int* H, unsigned char* dst, size_t dstep)
 {
     constexpr int OFF = NT / 2 - 1;
     const int lx = tid & 63, w = tid >> 6, el0 = 4 * lx, e = t.e0 + el0;
     if (e >= t.width) return;
     const int body = (t.width / 8) * 8;                                     // VResizeCubicVec_32s8u covers the first width / 8 * 8 elements of a row
+#pragma unroll
     for (int k4 = 0; k4 < TH / 4; k4++) {
         const int dy = t.dy0 + w + 4 * k4;
         if (dy >= g.dh) continue;
-        const Tap<NT> ty = yt[dy];
+        const Tap<NT>& ty = vt.ty[k4];
         const int* S = H + (ty.s - OFF - t.rmin) * TW + el0;               // S[k * TW + q]: horizontal sum of window row k for element q
         uint32_t out = 0; int n = 0;
         for (int q = 0; q < 4 && e + q < t.width; q++, n++) {

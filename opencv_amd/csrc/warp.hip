@@ -622,11 +622,13 @@ __global__ __launch_bounds__(256) void k_resize_tab8(const uchar* __restrict__ s
     int* H = reinterpret_cast<int*>(ldsRaw);
     uchar* ldsSrc = ldsRaw + (size_t)rows * rt8::TW * 4;
     const rt8::Tile<NT> t = rt8::tileOf<NT>(g, blockIdx.x, blockIdx.y, xt, yt);
+    rt8::HTaps<NT> ht; rt8::VTaps<NT> vt;
+    rt8::loadTaps<NT>(threadIdx.x, g, t, xt, yt, ht, vt);
     rt8::stage<NT>(threadIdx.x, g, t, src, sstep, ldsSrc);
     __syncthreads();
-    rt8::hpass<NT>(threadIdx.x, g, t, xt, ldsSrc, H);
+    rt8::hpass<NT>(threadIdx.x, g, t, ht, ldsSrc, H);
     __syncthreads();
-    rt8::vpass<NT>(threadIdx.x, g, t, yt, H, dst, dstep);
+    rt8::vpass<NT>(threadIdx.x, g, t, vt, H, dst, dstep);
 }
 
 // INTER_LINEAR_EXACT (resize_bitExact<ET, interpolationLinear<ET>>, resize.cpp:789-950): per-axis tables of (offset, weight of the second tap in

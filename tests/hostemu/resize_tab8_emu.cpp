@@ -26,9 +26,10 @@ int run(Build build, const unsigned char* src, size_t sstep, int sw, int sh, uns
         memset(S.data(), 0xa5, S.size());
         const Tile<NT> t = tileOf<NT>(g, bx, by, xt.data(), yt.data());
         if (t.R > rows || t.nb > g.sp || t.nb < 1) return -2;                        // the host's bounds must hold for every tile
-        for (int tid = 0; tid < 256; tid++) stage<NT>(tid, g, t, src, sstep, S.data() + GUARD);
-        for (int tid = 0; tid < 256; tid++) hpass<NT>(tid, g, t, xt.data(), S.data() + GUARD, H.data() + GUARD);
-        for (int tid = 0; tid < 256; tid++) vpass<NT>(tid, g, t, yt.data(), H.data() + GUARD, dst, dstep);
+        std::vector<HTaps<NT>> ht(256); std::vector<VTaps<NT>> vt(256);
+        for (int tid = 0; tid < 256; tid++) { loadTaps<NT>(tid, g, t, xt.data(), yt.data(), ht[tid], vt[tid]); stage<NT>(tid, g, t, src, sstep, S.data() + GUARD); }
+        for (int tid = 0; tid < 256; tid++) hpass<NT>(tid, g, t, ht[tid], S.data() + GUARD, H.data() + GUARD);
+        for (int tid = 0; tid < 256; tid++) vpass<NT>(tid, g, t, vt[tid], H.data() + GUARD, dst, dstep);
         for (int i = 0; i < GUARD; i++) if (H[i] != 0x5a5a5a5a || H[GUARD + hInts + i] != 0x5a5a5a5a || S[i] != 0xa5 || S[GUARD + sBytes + i] != 0xa5) return -3;
         if (stats) { stats[0]++; if (t.R > stats[1]) stats[1] = t.R; if (t.nb > stats[2]) stats[2] = t.nb; }
     }
