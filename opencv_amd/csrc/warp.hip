@@ -1619,14 +1619,14 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         int rows = 0, unused = 0;
         DevRef keepX, keepY;                                        // the tables stay alive until the launches below are enqueued
         // CV_8U: tiles of 256 x 16 elements with the source bytes staged in LDS (resize_tab8.h) where a tile's rows fit.  Measured against the 64 x 16 kernel
-        // (profiles/r03_resize_tab8_ab.txt): 1080p -> 4K cubic 8UC3 53.7 against 60.2 us, 8UC1 21.9 / 21.5, Lanczos 76.1 / 68.9, a 1.5 x cubic downscale
-        // 86.8 / 51.9 -- so it serves multi-channel cubic upscales only.  MI355CV_RESIZE_TAB8=1: wherever it is eligible, =0: never.
+        // (profiles/r03_resize_tab8_ab.txt): 1080p -> 4K cubic 8UC3 46.7 against 59.9 us, 8UC1 20.1 / 21.5, Lanczos 68.5 / 66.7, a 1.5 x cubic downscale
+        // 53.2 / 52.1 -- so it serves cubic upscales.  MI355CV_RESIZE_TAB8=1: wherever it is eligible, =0: never.
         static const int tab8Env = getenv("MI355CV_RESIZE_TAB8") ? atoi(getenv("MI355CV_RESIZE_TAB8")) : -1;
         rt8::Geom geom8 = {src_width, src_height, dst_width, dst_height, cn, 0};
         size_t lds8 = 0;
         const dim3 g8(divUp(dst_width * cn, rt8::TW), divUp(dst_height, rt8::TH));
         auto tab8 = [&](int nt) {
-            if (tab8Env == 0 || (tab8Env < 0 && !(nt == 4 && cn >= 3 && a.scale_x <= 1.0 && a.scale_y <= 1.0))) return false;
+            if (tab8Env == 0 || (tab8Env < 0 && !(nt == 4 && a.scale_x <= 1.0 && a.scale_y <= 1.0))) return false;
             geom8.sp = rt8::stagePitch(cn, a.scale_x, nt);
             lds8 = (size_t)rows * ((size_t)rt8::TW * 4 + (size_t)geom8.sp);
             return lds8 <= 48 * 1024;                                 // within what a workgroup gets without asking for more
