@@ -100,3 +100,56 @@ def gather_counts(n, device=None):
     t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t[0])
+
+
+def gather_ragged(rows, dst=0, device=None):
+    """Egress of a detector's output when the frames are sharded (SURVEY.md section 8e + f3): every rank holds one variable-length record array per frame it owns
+    (keypoints, descriptors: the number of rows is the GPU's decision), rank `dst` wants all of them in frame order.  `rows`: a list of 2-D uint8-viewable
+    numpy arrays of the same row width (one per owned frame, in frame order; ranks own contiguous frame blocks -- frame_range).  One all_gather of the
+    per-frame row counts, one padded all_gather of the bytes: two collectives, off the data path of the kernels.  Returns the list of all frames' arrays on
+    `dst`, None elsewhere (single process: the input)."""
+    arrs = [np.ascontiguousarray(a) for a in rows]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return arrs
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    width = 0
+    for a in arrs:
+        if a.ndim != 2:
+            raise ValueError("gather_ragged: 2-D record arrays expected")
+        width = max(width, a.shape[1] * a.itemsize)
+    dtype = arrs[0].dtype if arrs else None
+    # 1. how many frames and rows everybody has (frames per rank differ by at most one: pad the count vectors to the maximum)
+    meta = torch.tensor([len(arrs), width], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(ws)]
+    dist.all_gather(metas, meta)
+    nfr = [int(m[0]) for m in metas]
+    width = max(int(m[1]) for m in metas)
+    maxf = max(nfr) if nfr else 0
+    cnt = torch.zeros(max(maxf, 1), dtype=torch.int64, device=dev)
+    for i, a in enumerate(arrs):
+        cnt[i] = a.shape[0]
+    cnts = [torch.zeros_like(cnt) for _ in range(ws)]
+    dist.all_gather(cnts, cnt)
+    totals = [int(c[:n].sum()) for c, n in zip(cnts, nfr)]
+    # 2. the bytes, padded to the largest rank's total
+    maxb = max(max(totals) * width, 1)
+    mine = np.zeros(maxb, np.uint8)
+    if arrs and totals[rank]:
+        flat = np.concatenate([a.view(np.uint8).reshape(a.shape[0], -1) for a in arrs if a.shape[0]], axis=0)
+        mine[:flat.size] = flat.reshape(-1)
+    buf = torch.from_numpy(mine).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(ws)]
+    dist.all_gather(bufs, buf)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(ws):
+        raw = bufs[r].cpu().numpy()
+        off = 0
+        for f in range(nfr[r]):
+            n = int(cnts[r][f])
+            block = raw[off:off + n * width].reshape(n, width)
+            off += n * width
+            out.append(block.view(dtype).copy() if dtype is not None and dtype.itemsize > 1 and width % dtype.itemsize == 0 else block.copy())
+    return out

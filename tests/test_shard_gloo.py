@@ -54,6 +54,46 @@ WORKER = textwrap.dedent("""
 """)
 
 
+RAGGED_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, 'tests'))
+    from opencv_amd import shard
+    import orc
+    rank, ws, local = shard.init('gloo')
+    # a detector over sharded frames: every rank describes its own frames (the restatement of cv::ORB stands in for the GPU call), rank 0 collects
+    B = 5
+    lo, hi = shard.frame_range(B, rank, ws)
+    frames = [orc.orb_scene(160, 120, 70 + f) for f in range(B)]
+    kd = [orc.orc_ORB(frames[f], nfeatures=150, edgeThreshold=15, patchSize=15, nlevels=3) for f in range(lo, hi)]
+    kps = shard.gather_ragged([k.reshape(-1, 1).view(np.uint8).reshape(len(k), 28) for k, d in kd])
+    des = shard.gather_ragged([d for k, d in kd])
+    none = shard.gather_ragged([np.zeros((0, 32), np.uint8) for _ in range(lo, hi)])           # frames without keypoints
+    if rank == 0:
+        assert len(kps) == B and len(des) == B and [len(x) for x in none] == [0] * B
+        for f in range(B):
+            k, d = orc.orc_ORB(frames[f], nfeatures=150, edgeThreshold=15, patchSize=15, nlevels=3)
+            assert kps[f].tobytes() == k.tobytes() and np.array_equal(des[f], d) and len(k) > 10, f
+        print(json.dumps({'ok': True, 'frames': B}))
+    else:
+        assert kps is None and des is None
+""")
+
+
+def test_detector_output_gathered_over_ranks(tmp_path):
+    """f3 over sharded frames: variable-length keypoint / descriptor arrays of the frames each rank owns arrive on rank 0 in frame order (shard.gather_ragged:
+    an all_gather of the counts and one of the padded bytes), world size 2 and 3 over gloo"""
+    script = tmp_path / "ragged.py"
+    script.write_text(RAGGED_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for ws, port in ((2, 29731), (3, 29733)):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            str(script)], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert '"ok": true' in p.stdout
+
+
 def test_two_process_gloo_sharding(tmp_path, orc):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, ROOT, str(tmp_path)))
