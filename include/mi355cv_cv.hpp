@@ -282,6 +282,8 @@ public:
     int descriptorType() const CV_OVERRIDE { return stock_->descriptorType(); }
     int defaultNorm() const CV_OVERRIDE { return stock_->defaultNorm(); }
     bool empty() const CV_OVERRIDE { return stock_->empty(); }
+    void write(cv::FileStorage& fs) const CV_OVERRIDE { stock_->write(fs); }          // the parameters live in the stock object: so does their serialisation (orb.cpp:723-760)
+    void read(const cv::FileNode& fn) CV_OVERRIDE { stock_->read(fn); }
 
     void detectAndCompute(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray _descriptors,
                           bool useProvidedKeypoints = false) CV_OVERRIDE

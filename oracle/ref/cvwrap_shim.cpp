@@ -139,6 +139,16 @@ EXPORT int wrap_ORB(const void* s, size_t ss, int w, int h, int type, const void
         if (mask) m = M(mask, ms, w, h, CV_8UC1);
         Ptr<cv::ORB> orb = mi355cv::ORB_create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, wta_k, (cv::ORB::ScoreType)scoreType, patchSize, fastThreshold);
         if (setScale > 0) orb->setScaleFactor(setScale);
+        {   // write() / read() go to the stock object that holds the parameters: a round trip through a FileStorage in memory reproduces them
+            FileStorage fsw(".yml", FileStorage::WRITE | FileStorage::MEMORY);
+            orb->write(fsw);
+            const String txt = fsw.releaseAndGetString();
+            Ptr<cv::ORB> other = mi355cv::ORB_create();
+            FileStorage fsr(txt, FileStorage::READ | FileStorage::MEMORY);
+            other->read(fsr.root());
+            if (other->getMaxFeatures() != orb->getMaxFeatures() || other->getScaleFactor() != orb->getScaleFactor() || other->getNLevels() != orb->getNLevels() ||
+                other->getPatchSize() != orb->getPatchSize() || other->getWTA_K() != orb->getWTA_K() || other->getFastThreshold() != orb->getFastThreshold()) return -5;
+        }
         if (orb->getMaxFeatures() != nfeatures || orb->getWTA_K() != wta_k || orb->descriptorSize() != 32 || orb->getDefaultName() != "Feature2D.ORB") return -3;
         std::vector<KeyPoint> kp;
         if (useProvided) kp.assign((const KeyPoint*)kps, (const KeyPoint*)kps + nIn);
