@@ -292,9 +292,18 @@ def run(quick=False, parity=True):
             torch.cuda.synchronize()
             out.append({"config": nm + " (one call per device-resident frame; wall time, culls on the host)", "frames": 8, "ms_per_frame": round((time.perf_counter() - t0) / 16 * 1e3, 3),
                         "keypoints_per_frame": round(sum(nk) / 8.0, 1)})
+        for nm, fr in (("f3 FAST 9-16 thr 20 nonmax 4K 8UC1", scene), ("f3 FAST 9-16 thr 20 nonmax 1080p 8UC1", scene[:, :1080, :1920].contiguous())):
+            nk = [len(cv.FAST(fr[i], 20, True)) for i in range(8)]
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for rep in range(2):
+                for i in range(8):
+                    cv.FAST(fr[i], 20, True)
+            torch.cuda.synchronize()
+            out.append({"config": nm + " (one call per device-resident frame; wall time incl. the keypoint list's way to the host)", "frames": 8,
+                        "ms_per_frame": round((time.perf_counter() - t0) / 16 * 1e3, 3), "keypoints_per_frame": round(sum(nk) / 8.0, 1)})
         del scene, yy, xx
     except Exception as e:
-        out.append({"config": "f3 ORB detectAndCompute", "error": repr(e)})
+        out.append({"config": "f3 ORB / FAST", "error": repr(e)})
     nvs = torch.empty((B2, H4 * 3 // 2, W4), dtype=torch.uint8, device=dev)
     nvs[:, :H4] = gray; nvs[:, H4:] = gray[:, : H4 // 2]
     line("f4 cvtColor NV12 -> BGR 4K", lambda i: cv.cvtColor(nvs[i], cv.COLOR_YUV2BGR_NV12, dst=c3d[i % B3C]), PIX4 * 4.5)
