@@ -28,7 +28,7 @@ def FAST(image, threshold, nonmaxSuppression=True, type=FAST_TYPE_9_16):
     if s.depth != CV_8U or s.cn != 1:
         raise ValueError("FAST: CV_8UC1 image expected")
     bind_stream(s)
-    cap = 1 << 14
+    cap = max(1 << 14, (s.w * s.h) >> 6)               # one keypoint per 64 pixels fits without a second call on ordinary frames
     while True:
         out = np.empty((cap, 3), np.float32)
         n = L.mi355cv_FAST(_vp(s.ptr), s.step, s.w, s.h, int(threshold), 1 if nonmaxSuppression else 0, int(type), out.ctypes.data, cap)
