@@ -1,0 +1,46 @@
+"""The rows furthest from their roofline at the end of round 3, each called a few times on resident frames -- the workload of tools/why_slow.sh, which wraps it
+in rocprofv3 --pmc passes and splits every kernel's wave cycles into parked (s_waitcnt / barrier), issue-stalled and issuing."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import opencv_amd as cv  # noqa: E402
+
+cv.set_async(True)
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+H4, W4 = 2160, 3840
+gray = torch.randint(0, 256, (8, H4, W4), dtype=torch.uint8, device="cuda", generator=g)
+bgr = torch.randint(0, 256, (4, H4, W4, 3), dtype=torch.uint8, device="cuda", generator=g)
+hd3 = torch.randint(0, 256, (4, 1080, 1920, 3), dtype=torch.uint8, device="cuda", generator=g)
+out1 = torch.empty_like(gray); out3 = torch.empty_like(bgr)
+up3 = torch.empty((4, H4, W4, 3), dtype=torch.uint8, device="cuda")
+s16 = torch.empty((8, H4, W4), dtype=torch.int16, device="cuda")
+f32 = torch.empty((8, H4, W4), dtype=torch.float32, device="cuda")
+P3 = np.array([[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]])
+k5 = (np.arange(25, dtype=np.float32).reshape(5, 5) - 12) / 64
+ROWS = {
+    "cubic_up_8uc3":   lambda: [cv.resize(hd3[i], (W4, H4), interpolation=2, dst=up3[i]) for i in range(4)],
+    "lanczos_up_8uc3": lambda: [cv.resize(hd3[i], (W4, H4), interpolation=4, dst=up3[i]) for i in range(4)],
+    "persp_8uc1":      lambda: cv.warpPerspectiveBatch(gray, P3, (W4, H4), dst=out1),
+    "affine_8uc1":     lambda: cv.warpAffineBatch(gray, cv.getRotationMatrix2D((W4 / 2.0, H4 / 2.0), 7.0, 1.0), (W4, H4), dst=out1),
+    "integral":        lambda: [cv.integral(gray[i]) for i in range(4)],
+    "sobel_16s":       lambda: cv.SobelBatch(gray, cv.CV_16S, 1, 0, 3, dst=s16),
+    "harris":          lambda: cv.cornerHarrisBatch(gray, 2, 3, 0.04, dst=f32),
+    "gauss_8uc3":      lambda: cv.GaussianBlurBatch(bgr, 5, dst=out3),
+    "filter2d_5x5":    lambda: cv.filter2DBatch(gray, -1, k5, dst=out1),
+    "lab_8uc3":        lambda: [cv.cvtColor(bgr[i], cv.COLOR_BGR2Lab, dst=out3[i]) for i in range(4)],
+    "median5":         lambda: [cv.medianBlur(gray[i], 5, dst=out1[i]) for i in range(8)],
+}
+want = sys.argv[1:] or list(ROWS)
+for name in want:
+    try:
+        for _ in range(3):
+            ROWS[name]()
+        torch.cuda.synchronize()
+        print("ran", name, cv._lib.lib.mi355cv_lastKernel().decode()[:80], flush=True)
+    except Exception as e:              # noqa: BLE001 -- one row must not take the others down
+        print("row", name, "failed:", repr(e)[:200], flush=True)
