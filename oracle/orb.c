@@ -453,7 +453,7 @@ int orc_ORBmask(const uint8_t* img, size_t step, int w, int h, const uint8_t* ma
             counters[l] = n;
             for (int i = 0; i < n; i++) { k[i].octave = l; k[i].size = patchSize * L.scale[l]; }
             if (nAll + n > capAll) { capAll = (nAll + n) * 2 + 64; all = (KP*)realloc(all, sizeof(KP) * capAll); }
-            memcpy(all + nAll, k, sizeof(KP) * n);
+            if (n) memcpy(all + nAll, k, sizeof(KP) * n);
             nAll += n;
             free(k);
         }
