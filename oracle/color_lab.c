@@ -417,7 +417,7 @@ static float cubeRootRounded(float value)
                         + 33.9905941350215598754191872) * fr + 1.0;
     const float q = (float)(num / den);
     uint32_t qi; memcpy(&qi, &q, 4);
-    qi = (uint32_t)((int32_t)qi + (ex << 23) + (int32_t)sgn) & ((vi << 1) != 0 ? 0xffffffffu : 0u);
+    qi = (qi + ((uint32_t)ex << 23) + sgn) & ((vi << 1) != 0 ? 0xffffffffu : 0u);      /* the reference's (ex << 23) on a negative ex, as unsigned arithmetic */
     float out; memcpy(&out, &qi, 4);
     return out;
 }
