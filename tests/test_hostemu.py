@@ -3,6 +3,7 @@ pinned restatement: verifies the lines the GPU runs where no GPU is present (ind
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -375,3 +376,11 @@ def test_resize_tab8_workgroups_on_the_cpu(emurt8, interp):
             else:
                 assert (sw, dw) == (500, 125)                                      # 4 x minification: more staged rows than LDS holds
     assert served >= 21
+
+
+def test_median_networks_are_what_the_generator_writes(tmp_path):
+    """opencv_amd/csrc/median_net.h is generated: tools/gen_median_net.py builds every network, verifies it (exhaustively over the 0/1 inputs that satisfy its
+    precondition; the unordered 25-input network on samples) and writes the header -- the committed header equals a fresh run"""
+    out = tmp_path / "median_net.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_median_net.py"), str(out)], stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "opencv_amd", "csrc", "median_net.h")).read()

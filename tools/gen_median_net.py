@@ -17,6 +17,7 @@ principle holds under a monotone precondition); the unordered network is checked
 import itertools
 import os
 import random
+import sys
 
 import numpy as np
 
@@ -183,7 +184,7 @@ def main():
         q = [r[i] for i in mid6_out]
         assert run(rank5, q + cols[4])[rank5_out[0]] == sorted(sum(w, []))[12]
 
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opencv_amd", "csrc", "median_net.h")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opencv_amd", "csrc", "median_net.h")
     with open(out, "w") as f:
         f.write("// median_net.h -- GENERATED by tools/gen_median_net.py (which also verifies every network); do not edit.\n")
         f.write("// CE(a, b): wire a <- min, wire b <- max.\n")
