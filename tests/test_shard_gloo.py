@@ -83,11 +83,11 @@ RAGGED_WORKER = textwrap.dedent("""
 
 def test_detector_output_gathered_over_ranks(tmp_path):
     """f3 over sharded frames: variable-length keypoint / descriptor arrays of the frames each rank owns arrive on rank 0 in frame order (shard.gather_ragged:
-    an all_gather of the counts and one of the padded bytes), world size 2 and 3 over gloo"""
+    an all_gather of the counts and one of the padded bytes), world sizes 2, 3 and 8 over gloo"""
     script = tmp_path / "ragged.py"
     script.write_text(RAGGED_WORKER % (ROOT, ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    for ws, port in ((2, 29731), (3, 29733)):
+    for ws, port in ((2, 29731), (3, 29733), (8, 29737)):                     # 8 ranks, 5 frames: three ranks own no frame at all
         p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                             str(script)], capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0, p.stderr[-3000:]
