@@ -52,6 +52,21 @@ def test_orb_with_a_mask(w, h, seed, kw):
 
 
 @needs_ref
+def test_orb_random_parameter_sets():
+    """thirty seeded draws of every ORB::create parameter (image size, feature budget, scale factor, levels, first level, edge threshold, patch size, WTA_K,
+    score type, FAST threshold): the restatement equals the reference on each -- keypoints, their order, descriptors"""
+    rng = np.random.default_rng(2024)
+    for t in range(30):
+        w, h = int(rng.integers(120, 420)), int(rng.integers(90, 320))
+        nl = int(rng.integers(1, 9)); fl = int(rng.integers(0, min(3, nl)))
+        kw = dict(nfeatures=int(rng.integers(50, 1500)), scaleFactor=float(np.round(rng.uniform(1.1, 2.0), 2)), nlevels=nl, edgeThreshold=int(rng.integers(3, 32)), firstLevel=fl,
+                  WTA_K=int(rng.choice([2, 3, 4])), scoreType=int(rng.integers(0, 2)), patchSize=int(rng.integers(5, 32)), fastThreshold=int(rng.integers(5, 40)))
+        img = o.orb_scene(w, h, 100 + t)
+        a, b = o.ref_ORB(img, **kw), o.orc_ORB(img, **kw)
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]), (t, w, h, kw)
+
+
+@needs_ref
 def test_orb_scale_factor_set_as_a_double():
     """ORB::create takes the scale factor as a float, setScaleFactor as a double (orb.cpp:660, :1262): 1.8 and float(1.8) give different level sizes.  Also the
     geometry of the reference's own regression_16197 (test_orb.cpp:127: firstLevel 3, 1.8, patch 8, edge 8 -- level 0 is a 5.8 x upscale) on a scene with corners"""
