@@ -211,7 +211,18 @@ def _orc_pyramid(img, p, blurred=False):
     return buf, out
 
 
-@pytest.mark.parametrize("w,h,seed,kw", ORB_EMU_CASES)
+def _orb_random_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for t in range(12):
+        nl = int(rng.integers(1, 8)); fl = int(rng.integers(0, min(3, nl)))
+        out.append((int(rng.integers(150, 420)), int(rng.integers(120, 320)), 200 + t,
+                    dict(nfeatures=int(rng.integers(100, 1200)), scaleFactor=float(np.round(rng.uniform(1.1, 2.0), 2)), nlevels=nl, edgeThreshold=int(rng.integers(3, 32)), firstLevel=fl,
+                         WTA_K=int(rng.choice([2, 3, 4])), scoreType=int(rng.integers(0, 2)), patchSize=int(rng.integers(5, 32)), fastThreshold=int(rng.integers(5, 30)))))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", ORB_EMU_CASES + _orb_random_cases())
 def test_orb_kernel_lines_against_the_restatement(emuorb, w, h, seed, kw):
     """layout, border pass, Harris + angle per keypoint and descriptor bytes as the kernels compute them, on the restatement's pyramid"""
     p = dict(o.ORB_DEFAULTS, **kw)
@@ -239,7 +250,7 @@ def test_orb_kernel_lines_against_the_restatement(emuorb, w, h, seed, kw):
 
     # Harris response and angle of the final keypoints
     kps, desc = o.orc_ORB(img, **kw)
-    assert len(kps) > 20
+    assert len(kps) > (20 if seed < 200 else 0)                                  # the seeded random parameter sets (seed >= 200) may leave few keypoints
     bl, _ = _orc_pyramid(img, p, blurred=True)
     blp = np.zeros((bufH, pitch), np.uint8); blp[:, :bufW] = bl
     got = np.zeros(2, np.float32)
