@@ -181,3 +181,16 @@ def test_orb_frames_across_host_threads(cv, orc):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("MI355CV_TEST_ORB_RANDOM"), reason="written after the round's GPU budget was spent: set MI355CV_TEST_ORB_RANDOM=1 (first GPU call of the next round)")
+def test_orb_random_parameter_sets(cv, orc):
+    """the thirty seeded random parameter sets of tests/test_oracle_orb.py (restatement == reference on each) through the GPU path"""
+    rng = np.random.default_rng(2024)
+    for t in range(30):
+        w, h = int(rng.integers(120, 420)), int(rng.integers(90, 320))
+        nl = int(rng.integers(1, 9)); fl = int(rng.integers(0, min(3, nl)))
+        kw = dict(nfeatures=int(rng.integers(50, 1500)), scaleFactor=float(np.round(rng.uniform(1.1, 2.0), 2)), nlevels=nl, edgeThreshold=int(rng.integers(3, 32)), firstLevel=fl,
+                  WTA_K=int(rng.choice([2, 3, 4])), scoreType=int(rng.integers(0, 2)), patchSize=int(rng.integers(5, 32)), fastThreshold=int(rng.integers(5, 40)))
+        img = orc.orb_scene(w, h, 100 + t)
+        same(cv.ORB_create(**kw).detectAndCompute(dev(img)), orc.orc_ORB(img, **kw))
