@@ -95,10 +95,25 @@ def cpu_baseline(budget_s=12.0):
             dt = time.perf_counter() - t0
             if dt > budget_s or n >= 200000:
                 break
+        # SURVEY §8d also asks for the one-thread figure: 3 s of the same calls with cv::setNumThreads(1)
+        ref.ref_setNumThreads(1)
+        run(0)
+        n1, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 3.0:
+            run(n1); n1 += 1
+        dt1 = time.perf_counter() - t1
+        ref.ref_setNumThreads(cores)
+        try:
+            allowed = len(os.sched_getaffinity(0))
+        except AttributeError:
+            allowed = os.cpu_count()
         return {"value": round(n * W4K * H4K / dt / 1e6, 1), "unit": "Mpix/s", "cores": int(cores), "kind": "reference",
-                "cpu_model": cpu_model, "cpu_llc": cpu_llc, "logical_cpus": os.cpu_count(),
+                "one_thread_Mpix_s": round(n1 * W4K * H4K / dt1 / 1e6, 1),
+                "cpu_model": cpu_model, "cpu_llc": cpu_llc, "logical_cpus": os.cpu_count(), "cpus_allowed": allowed,
                 "sample": f"{n} x cv::GaussianBlur(5x5,sigma=0,REFLECT_101) cycling over {NF} distinct 3840x2160 CV_8UC1 frames, "
-                          f"{cores} threads (oracle/_ref build of the reference: SSE3 baseline, smooth dispatched to AVX2 -- the widest its CMake lists --, "
+                          f"{cores} threads = cv::getNumberOfCPUs() of this process (the box shows {os.cpu_count()} logical CPUs, the container's cgroup / affinity "
+                          f"limit leaves {cores}); one_thread_Mpix_s = {n1} of the same calls under cv::setNumThreads(1) in {dt1:.1f} s; "
+                          f"(oracle/_ref build of the reference: SSE3 baseline, smooth dispatched to AVX2 -- the widest its CMake lists --, "
                           f"pthreads backend, no IPP / OpenCL), inputs from cv::RNG(809564), {dt:.1f} s"}
     crop = np.ascontiguousarray(frame[:540, :960])
     n, t0 = 0, time.perf_counter()
@@ -228,6 +243,71 @@ def next_rows(orc, t, gray, bgr, hd):
 
     row("f3 pipeline 1920x1080: 2x(NV12->BGR->GRAY->Gaussian5x5), goodFeaturesToTrack(1000), calcOpticalFlowPyrLK", g(pipe_gpu, 5), t(pipe_cpu))
     out[-1]["tracked_gpu_cpu"] = [ntracked.get("gpu"), ntracked.get("cpu")]
+    return out
+
+
+def host_inclusive():
+    """SURVEY §8d / BASELINE.md §4.4: H2D + D2H-inclusive throughput beside the kernel-only figure.  Frames and results live in page-locked HOST
+    memory; the library's pipelined batch entry (rt.h runHostBatch: upload of chunk k+1 and download of chunk k-1 under the kernel of chunk k) is timed
+    wall-clock around the whole call.  Reported, never `value`."""
+    import opencv_amd as cv
+    rows = []
+
+    def wall(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    n = 64
+    src = torch.randint(0, 256, (n, H4K, W4K), dtype=torch.uint8).pin_memory()
+    dst = torch.empty_like(src).pin_memory()
+    ms = wall(lambda: cv.GaussianBlurBatch(src, 5, dst=dst))
+    rows.append({"config": "host-inclusive: GaussianBlur 5x5, 64 x 4K 8UC1 from / to page-locked host memory (pipelined H2D + kernel + D2H)", "frames": n, "ms": round(ms, 3),
+                 "us_per_frame": round(ms / n * 1e3, 1), "Mpix_s": round(n * W4K * H4K / ms / 1e3, 1), "pcie_GBs_both_ways": round(2 * src.numel() / ms / 1e6, 1)})
+    d = torch.empty((n, H4K, W4K), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ms_up = wall(lambda: d.copy_(src, non_blocking=True))
+    ms_dn = wall(lambda: dst.copy_(d, non_blocking=True))
+    rows.append({"config": "host-inclusive: plain hipMemcpyAsync of the same 64 frames (the PCIe ceiling of this box)", "h2d_GBs": round(src.numel() / ms_up / 1e6, 1), "d2h_GBs": round(src.numel() / ms_dn / 1e6, 1)})
+    del d
+    try:
+        bgr = torch.randint(0, 256, (24, H4K, W4K, 3), dtype=torch.uint8).pin_memory()
+        gray = torch.empty((24, H4K, W4K), dtype=torch.uint8).pin_memory()
+        ms = wall(lambda: cv.cvtColorBatch(bgr, cv.COLOR_BGR2GRAY, dst=gray))
+        rows.append({"config": "host-inclusive: cvtColor BGR2GRAY, 24 x 4K 8UC3 from / to page-locked host memory", "frames": 24, "ms": round(ms, 3), "us_per_frame": round(ms / 24 * 1e3, 1),
+                     "Mpix_s": round(24 * W4K * H4K / ms / 1e3, 1), "pcie_GBs_both_ways": round((bgr.numel() + gray.numel()) / ms / 1e6, 1)})
+    except Exception as e:                                      # noqa: BLE001 -- reported rows only
+        rows.append({"config": "host-inclusive cvtColor", "error": repr(e)[:200]})
+    return rows
+
+
+SUMMARY_KEYS = ("cfg2a", "cfg2c", "cfg2e", "cfg2d", "cfg3a", "cfg3b", "cfg3c", "cfg4a", "cfg4b", "cfg5", "cfg5f")
+
+
+def compact_summary(rows):
+    """BASELINE cfg1-cfg5 and the weakest rows as {key: [ms per frame, fraction of the bounding roofline]} -- printed LAST in the JSON line so that all of them
+    survive a tail-only record of the output.  Fractions: of 8 TB/s for HBM rows, of the i8 (cfg5) / bf16 (cfg5f) dense MFMA peak."""
+    out = {}
+    short = {"a1 GaussianBlur 5x5 4K 8UC3 batch": "gauss_8uc3", "a1 GaussianBlur 5x5 1080p 8UC1 batch": "gauss_1080p", "a1 GaussianBlur 5x5 8K 8UC1 batch": "gauss_8k",
+             "a8 warpAffine 4K 8UC1": "affine_8uc1", "a8 warpAffine 4K 8UC3": "affine_8uc3", "a9 warpPerspective 4K 8UC1": "persp_8uc1", "a9 warpPerspective 4K 8UC3": "persp_8uc3",
+             "f1 integral 4K 8U -> 32S batch": "integral", "a7 resize 1080p 8UC3 -> 4K bilinear": "up2x_lin_8uc3", "a7 resize 1080p 8UC3 -> 4K INTER_CUBIC": "up2x_cubic_8uc3",
+             "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
+    for r in rows if isinstance(rows, list) else []:
+        c = r.get("config", "")
+        key = c.split()[0] if c.split() and c.split()[0] in SUMMARY_KEYS else next((v for k, v in short.items() if c.startswith(k)), None)
+        if key is None or "error" in r:
+            continue
+        fr = r.get("frames", 1) or 1
+        ms = r.get("ms", r.get("ms_per_frame"))
+        frac = r.get("frac", r.get("frac_of_i8_dense_peak" if key == "cfg5" else "frac_of_bf16_dense_peak"))
+        if key == "host_gauss":
+            out[key] = [r.get("us_per_frame"), r.get("Mpix_s"), r.get("pcie_GBs_both_ways")]
+        elif ms is not None:
+            out[key] = [round(ms / fr * 1e3, 2) if "ms" in r else round(ms * 1e3, 2), frac]
     return out
 
 
@@ -570,6 +650,17 @@ def main():
                 res["other_configs"] = other_configs(with_cpu=not args.no_cpu_baseline)
             except Exception as e:                           # never let the secondary numbers take the headline down
                 res["other_configs"] = {"error": repr(e)}
+            try:
+                hrows = host_inclusive()
+            except Exception as e:
+                hrows = [{"config": "host-inclusive rows", "error": repr(e)[:300]}]
+            if isinstance(res["other_configs"], list):
+                res["other_configs"] += hrows
+            else:
+                res["host_inclusive"] = hrows
+            # last key of the line: [us per frame, fraction of the bounding roofline] per BASELINE config / weak row; host_gauss = [us per frame, Mpix/s, PCIe GB/s]
+            res["summary_us_per_frame_and_frac"] = compact_summary(res["other_configs"] if isinstance(res["other_configs"], list) else hrows)
+            res["summary_us_per_frame_and_frac"]["headline"] = [round(elapsed / args.steps / B * 1e6, 3), round(achieved / HBM_PEAK_GBS, 4)]
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void k_bilateral_u8(const uchar* __restrict__ 
 extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                    int depth, int cn, int d, double sigma_color, double sigma_space, int border_type)
 {
-    if (disabled() || width <= 0 || height <= 0 || depth != MI355CV_8U || (cn != 1 && cn != 3) || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || depth != MI355CV_8U || (cn != 1 && cn != 3) || src_data == dst_data) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || depth != MI355CV_8U || (cn != 1 && cn != 3) || src_data == dst_data");
     const int isolated = border_type & MI355CV_BORDER_ISOLATED;
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
-    if (border < B_CONSTANT || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (border < B_CONSTANT || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < B_CONSTANT || border > B_REFLECT_101");
     if (!isolated && src_step != (size_t)width * cn && height > 1)
         return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: rows are not dense and BORDER_ISOLATED is not set (a submatrix is padded with its parent's pixels)");
     if (sigma_color <= 0) sigma_color = 1;
@@ -118,8 +118,8 @@ extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t
     if (radius < 1) radius = 1;
     if (radius > B_RMAX) return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: radius %d > %d", radius, B_RMAX);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     std::vector<float> cw((size_t)256 * cn), sw;
     std::vector<short> of;
     for (int i = 0; i < 256 * cn; i++) cw[i] = (float)std::exp(i * i * gcc);
@@ -137,7 +137,7 @@ extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t
     const float* dcw = (const float*)stg.param(cw.data(), cw.size() * sizeof(float));
     const float* dsw = (const float*)stg.param(sw.data(), sw.size() * sizeof(float));
     const short2* dof = (const short2*)stg.param(of.data(), of.size() * sizeof(short));
-    if (!ds || !dd || !dcw || !dsw || !dof) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd || !dcw || !dsw || !dof) return mi355::declined(__func__, __LINE__, "!ds || !dd || !dcw || !dsw || !dof");
     BilArgs a; a.W = width; a.H = height; a.radius = radius; a.maxk = maxk; a.border = border;
     a.body = cn == 1 ? (width / 8) * 8 : (width / 32) * 32;
     const int tw = BT_W + 2 * radius, th = BT_H + 2 * radius, tp = (tw * cn + 3) & ~3;

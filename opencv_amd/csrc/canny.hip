@@ -160,10 +160,10 @@ __global__ __launch_bounds__(256) void k_canny_final(const uchar* __restrict__ m
 extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int cn,
                                          double lowThreshold, double highThreshold, int ksize, bool L2gradient)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     // canny.cpp:887-896 (the aperture-7 scaling and the swap happen before the hook)
     double lo = lowThreshold, hi = highThreshold;
     if (L2gradient) {
@@ -181,7 +181,7 @@ extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step,
     short* dy = (short*)stg.scratch(gstep * height);
     uchar* map = (uchar*)stg.scratch(pitch * (((size_t)height + TH - 1) / TH * TH));
     int* flag = (int*)stg.scratch(256);
-    if (!ds || !dd || !dx || !dy || !map || !flag) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd || !dx || !dy || !map || !flag) return mi355::declined(__func__, __LINE__, "!ds || !dd || !dx || !dy || !map || !flag");
     int rc = mi355cv_sobel(ds, dss, (uchar*)dx, gstep, width, height, MI355CV_8U, MI355CV_16S, cn, 0, 0, 0, 0, 1, 0, ksize, 1.0, 0.0, B_REPLICATE);
     if (rc == MI355CV_OK) rc = mi355cv_sobel(ds, dss, (uchar*)dy, gstep, width, height, MI355CV_8U, MI355CV_16S, cn, 0, 0, 0, 0, 0, 1, ksize, 1.0, 0.0, B_REPLICATE);
     if (rc != MI355CV_OK) return rc;

@@ -135,18 +135,18 @@ int esz(int depth) { return depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 :
 int runBgr2Gray(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe,
                 int nframes, int W, int H, int depth, int scn, bool swapBlue)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int e = esz(depth);
-    if (!e || (scn != 3 && scn != 4) || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!e || (scn != 3 && scn != 4) || W <= 0 || H <= 0 || nframes <= 0) return mi355::declined(__func__, __LINE__, "!e || (scn != 3 && scn != 4) || W <= 0 || H <= 0 || nframes <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)W * H, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)W * H, minPixels())");
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {
         ds = stg.in(src, sstep, (size_t)W * scn * e, H, &dss);
         dd = stg.out(dst, dstep, (size_t)W * e, H, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     } else if (!isDevicePtr(src) || !isDevicePtr(dst))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     // coefficient order follows the source channel order: blueIdx = swapBlue ? 2 : 0 (color_rgb.simd.hpp:668-676)
@@ -194,14 +194,14 @@ MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const uchar* src_data, size_t src_step
 MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
                                      int width, int height, int depth, int dcn)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int e = esz(depth);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!e || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!e || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return mi355::declined(__func__, __LINE__, "!e || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     dim3 grid(divUp(width, 64), divUp(height, 4));
     if (depth == MI355CV_8U) {
         if (dcn == 3) pix4::launch<1, 3>(stream(), ds, dss, dd, dds, width, height, OpGray2Bgr<3>());
@@ -215,15 +215,15 @@ MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uch
 MI355CV_API int mi355cv_cvtBGRtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
                                     int width, int height, int depth, int scn, int dcn, bool swapBlue)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int e = esz(depth);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;     // in-place reorder: leave to the caller's path
+    if (!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return mi355::declined(__func__, __LINE__, "!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()");
+    if (src_data == dst_data) return mi355::declined(__func__, __LINE__, "src_data == dst_data");     // in-place reorder: leave to the caller's path
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     dim3 grid(divUp(width, 64), divUp(height, 4));
     if (depth == MI355CV_8U) {
         const int sb = swapBlue ? 1 : 0;

@@ -799,17 +799,17 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
         size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * 4, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 12, height, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
         const dim3 grid(divUp(width, 64), divUp(height, 4));
         const int bIdx = swapBlue ? 2 : 0;
         if (srgb) {
@@ -829,19 +829,19 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         noteKernel("k_bgr2lab_f32_%s<%d> grid=%ux%u x256", srgb ? "grid" : "lin", scn, grid.x, grid.y);
         return stg.finish("cvtBGRtoLab");
     }
-    if (depth != MI355CV_8U && depth != MI355CV_32F) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U && depth != MI355CV_32F) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U && depth != MI355CV_32F");
     if (!isLab && (depth == MI355CV_32F || !srgb)) {
         // L*u*v* in float: CV_32F images, and CV_8U images in linear RGB (RGB2Luv_b color_lab.cpp:3389-3392 interpolates in the grid for sRGB only)
         const int e = depth == MI355CV_32F ? 4 : 1;
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return MI355CV_NOT_IMPLEMENTED;
-        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
         size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * e, height, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
         LuvF kf;
         for (int i = 0; i < 9; i++) kf.c[i] = (float)kRgb2Xyz[i];
         if (!swapBlue) for (int i = 0; i < 3; i++) std::swap(kf.c[i * 3], kf.c[i * 3 + 2]);            // blueIdx == 0 (:2891)
@@ -856,15 +856,15 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         return stg.finish("cvtBGRtoLab");
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs && !luv) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     if (!isLab) {
         const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
         const dim3 grid(divUp(divUp(width, 4), 64), divUp(height, 4));
@@ -896,17 +896,17 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isLab, bool srgb)
 {
-    if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
         size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
         // Lab2RGBfloat's constructor (color_lab.cpp:2188-2200): XYZ -> RGB columns times the white point, in double, rounded to float
         CoefF9 kf; const int bi = swapBlue ? 2 : 0;
         for (int i = 0; i < 3; i++) {
@@ -924,14 +924,14 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     }
     if (depth == MI355CV_32F) {                             // L*u*v*, CV_32F: Luv2RGBfloat
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return MI355CV_NOT_IMPLEMENTED;
-        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
         size_t dss, dds;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * 12, height, &dss);
         uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * 4, height, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
         LuvF kf; const int bi = swapBlue ? 2 : 0;
         for (int i = 0; i < 3; i++) { kf.c[i + (bi ^ 2) * 3] = (float)kXyz2Rgb[i]; kf.c[i + 3] = (float)kXyz2Rgb[i + 3]; kf.c[i + bi * 3] = (float)kXyz2Rgb[i + 6]; }
         luvWhitePoint(&kf.un, &kf.vn);
@@ -943,17 +943,17 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
         noteKernel("k_luv2bgr_f32<%d,%s> grid=%ux%u x256", dcn, srgb ? "srgb" : "linear", grid.x, grid.y);
         return stg.finish("cvtLabtoBGR");
     }
-    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const LabTabs* tabs = deviceTabs();
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
     if (!tabs || (!isLab && !luv)) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     if (!isLab) {
         // Luv2RGBinteger's constructor (color_lab.cpp:3567-3584): XYZ -> sRGB in 2^12 fixed point, no white point (it is folded into the tables)
         Coef9 kq; const int bi = swapBlue ? 2 : 0;

@@ -230,12 +230,12 @@ struct OpPremul {
 // the checks and staging every hook below shares
 #define MISC_PROLOGUE(sRowBytes, sRows, dRowBytes, dRows)                                                                        \
     Stager stg; /* first: a declined call must also put the host's device back (~Stager) */                                       \
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;                                                  \
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;                           \
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");                                                  \
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");                           \
     size_t dss, dds;                                                                                                  \
     const uchar* ds = stg.in(src_data, src_step, (size_t)(sRowBytes), (sRows), &dss);                                             \
     uchar* dd = stg.out(dst_data, dst_step, (size_t)(dRowBytes), (dRows), &dds);                                                  \
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;                                                                               \
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");                                                                               \
     hipStream_t st = stream()
 
 } // namespace
@@ -245,15 +245,15 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_step, uchar* y_data, size_t y_step, uchar* uv_data, size_t uv_step,
                                             int width, int height, int scn, bool swapBlue, int uIdx)
 {
-    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, ys, uvs;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dy = stg.out(y_data, y_step, (size_t)width, height, &ys);
     uchar* duv = stg.out(uv_data, uv_step, (size_t)width, height / 2, &uvs);
-    if (!ds || !dy || !duv) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dy || !duv) return mi355::declined(__func__, __LINE__, "!ds || !dy || !duv");
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
     const int al = ((((uintptr_t)ds | dss | (uintptr_t)dy | ys | (uintptr_t)duv | uvs) & 3) == 0) ? 1 : 0;
     if (scn == 3) hipLaunchKernelGGL((k_enc420<3, true>), grid, dim3(256), 0, stream(), ds, dss, dy, ys, duv, uvs, width, height, swapBlue ? 1 : 0, uIdx == 2 ? 1 : 0, al);
@@ -264,7 +264,7 @@ MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int scn, bool swapBlue, int uIdx)
 {
-    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     MISC_PROLOGUE(width * scn, height, width, height * 3 / 2);
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
     uchar* uv = dd + dds * height;
@@ -278,7 +278,7 @@ MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_st
                                             int dcn, bool swapBlue, int uIdx, int ycn)
 {
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
     const int uidx = 1 - ycn + uIdx * 2, vidx = (2 + uidx) % 4;
     if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpDec422<3>{swapBlue ? 2 : 0, uidx, vidx, ycn});
@@ -290,7 +290,7 @@ MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_st
                                             int scn, bool swapBlue, int uIdx, int ycn)
 {
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
     const int uidx = 1 - ycn + uIdx * 2, vidx = (2 + uidx) % 4;
     if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpEnc422<3>{swapBlue ? 2 : 0, uidx, vidx, ycn});
@@ -301,7 +301,7 @@ MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue)
 {
-    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : 2;
     MISC_PROLOGUE(width * scn * e, height, width * 3 * e, height);
     static const int k[9] = {1689, 1465, 739, 871, 2929, 296, 79, 488, 3892};        // sRGB2XYZ_D65_i, color_lab.cpp:132
@@ -318,7 +318,7 @@ MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue)
 {
-    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : 2;
     MISC_PROLOGUE(width * 3 * e, height, width * dcn * e, height);
     static const int k[9] = {13273, -6296, -2042, -3970, 7684, 170, 228, -836, 4331};  // XYZ2sRGB_D65_i, color_lab.cpp:139
@@ -335,7 +335,7 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int scn, bool swapBlue, int greenBits)
 {
-    if (disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
     if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<3>{swapBlue ? 2 : 0, greenBits});
     else pix4::launch<4, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<4>{swapBlue ? 2 : 0, greenBits});
@@ -345,7 +345,7 @@ MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, u
 MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int dcn, bool swapBlue, int greenBits)
 {
-    if (disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
     if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpFrom5x5<3>{swapBlue ? 2 : 0, greenBits});
     else pix4::launch<2, 4>(st, ds, dss, dd, dds, width, height, OpFrom5x5<4>{swapBlue ? 2 : 0, greenBits});
@@ -354,7 +354,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, u
 
 MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
-    if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width, height);
     pix4::launch<2, 1>(st, ds, dss, dd, dds, width, height, Op5x5ToGray{greenBits});
     return stg.finish("cvtBGR5x5toGray");
@@ -362,7 +362,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
-    if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width, height, width * 2, height);
     pix4::launch<1, 2>(st, ds, dss, dd, dds, width, height, OpGrayTo5x5{greenBits});
     return stg.finish("cvtGraytoBGR5x5");
@@ -370,7 +370,7 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<false>{});
     return stg.finish("cvtRGBAtoMultipliedRGBA");
@@ -378,7 +378,7 @@ MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t sr
 
 MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<true>{});
     return stg.finish("cvtMultipliedRGBAtoRGBA");

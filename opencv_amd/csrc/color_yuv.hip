@@ -229,15 +229,15 @@ MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, ucha
                                     int depth, int scn, bool swapBlue, bool isCbCr)
 {
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * esz, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * esz, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     YuvFwd a; a.c0 = 4899; a.c1 = 9617; a.c2 = 1868; a.c3 = isCbCr ? 11682 : 14369; a.c4 = isCbCr ? 9241 : 8061;
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     if (a.bidx == 0) { const int t = a.c0; a.c0 = a.c2; a.c2 = t; }
@@ -264,15 +264,15 @@ MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, ucha
                                     int depth, int dcn, bool swapBlue, bool isCbCr)
 {
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const size_t esz = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3 * esz, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * esz, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     YuvInv a; a.c0 = isCbCr ? 22987 : 18678; a.c1 = isCbCr ? -11698 : -9519; a.c2 = isCbCr ? -5636 : -6472; a.c3 = isCbCr ? 29049 : 33292;
     a.bidx = swapBlue ? 2 : 0; a.yuvOrder = isCbCr ? 0 : 1;
     dim3 grid(divUp(width, 64), divUp(height, 4));
@@ -298,15 +298,15 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
                                               int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx)
 {
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(y_data, (size_t)dst_width * dst_height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(y_data, (size_t)dst_width * dst_height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(y_data, (size_t)dst_width * dst_height, minPixels())");
     size_t ys, uvs, dds;
     const uchar* dy = stg.in(y_data, y_step, (size_t)dst_width, dst_height, &ys);
     const uchar* duv = stg.in(uv_data, uv_step, (size_t)dst_width, dst_height / 2, &uvs);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
-    if (!dy || !duv || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!dy || !duv || !dd) return mi355::declined(__func__, __LINE__, "!dy || !duv || !dd");
     dim3 grid(divUp(divUp(dst_width, 4), 64), divUp(dst_height / 2, 4));
     const int al = ((((uintptr_t)dy | ys | (uintptr_t)duv | uvs | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
     if (dcn == 3) hipLaunchKernelGGL((k_dec420<3, false>), grid, dim3(256), 0, stream(), dy, ys, duv, uvs, dd, dds, dst_width, dst_height, swapBlue ? 2 : 0, uIdx, al);
@@ -318,20 +318,20 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
 MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    if (disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     const int hr = isFullRange ? 256 : 180;
     int tabs[512];                                                       // sdiv_table, hdiv_table (color_hsv.simd.hpp:70-78)
     tabs[0] = tabs[256] = 0;
     for (int i = 1; i < 256; i++) { tabs[i] = (int)nearbyint((255 << 12) / (1. * i)); tabs[256 + i] = (int)nearbyint((hr << 12) / (6. * i)); }
     const int* dt = (const int*)stg.param(tabs, sizeof tabs);
-    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    if (!dt) return mi355::declined(__func__, __LINE__, "!dt");
     dim3 grid(divUp(width, 64), divUp(height, 4));
     if (scn == 3) pix4::launch<3, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Hsv<3>{swapBlue ? 2 : 0, hr, dt, dt + 256});
     else pix4::launch<4, 3>(stream(), ds, dss, dd, dds, width, height, OpBgr2Hsv<4>{swapBlue ? 2 : 0, hr, dt, dt + 256});
@@ -342,14 +342,14 @@ MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_
                                               int dcn, bool swapBlue, int uIdx)
 {
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)dst_width, dst_height * 3 / 2, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * dcn, dst_height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     dim3 grid(divUp(divUp(dst_width, 4), 64), divUp(dst_height / 2, 4));
     const int al = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 3) == 0) ? 1 : 0;
     const uchar* chroma = ds + dss * (size_t)dst_height;                    // the packed quarter planes start below the luma rows
@@ -370,14 +370,14 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtHSVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    if (disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     const float hscale = 6.0f / (isFullRange ? 255 : 180);
     const int body = (width / 32) * 32;
     dim3 grid(divUp(width, 64), divUp(height, 4));

@@ -363,14 +363,14 @@ void launchPyrDown(const uchar* ds, size_t dss, size_t sframe, int sw, int sh, u
 int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe, int sw, int sh, uchar* dst, size_t dstep, size_t dframe,
                int dw, int dh, int nframes, int depth, int cn, int mL, int mT, int mR, int mB, int border)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     border &= ~MI355CV_BORDER_ISOLATED;
-    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;   // pyramids.cpp:1352 forbids CONSTANT
-    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2) return MI355CV_NOT_IMPLEMENTED;
+    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border == B_CONSTANT || border < 0 || border > B_REFLECT_101");   // pyramids.cpp:1352 forbids CONSTANT
+    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4");
+    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2) return mi355::declined(__func__, __LINE__, "sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || abs(dw * 2 - sw) > 2 || abs(dh * 2 - sh) > 2");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)sw * sh, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)sw * sh, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)sw * sh, minPixels())");
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
@@ -378,9 +378,9 @@ int runPyrDown(const char* entry, const uchar* src, size_t sstep, size_t sframe,
         const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * cn * e;
         const uchar* dtop = stg.in(top, sstep, (size_t)(mL + sw + mR) * cn * e, mT + sh + mB, &dss);
         dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds);
-        if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+        if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
         ds = dtop + (size_t)mT * dss + (size_t)mL * cn * e;
-    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
+    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return mi355::declined(__func__, __LINE__, "!isDevicePtr(src) || !isDevicePtr(dst)");
     launchPyrDown(ds, dss, sframe, sw, sh, dd, dds, dframe, dw, dh, nframes, depth, cn, mL, mT, mR, mB, border, stream());
     return stg.finish(entry);
 }
@@ -684,7 +684,7 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
     // Dx = Sobel(1,0): kx = derivative taps, ky = smoothing taps * scale; Dy = Sobel(0,1): kx = smoothing * scale, ky = derivative
     std::vector<int> dxr, dxc, dyr, dyc;
     if (!derivTaps(1, ksize, scharr, dxr) || !derivTaps(0, ksize, scharr, dxc) || !derivTaps(0, ksize, scharr, dyr) || !derivTaps(1, ksize, scharr, dyc))
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "!derivTaps(1, ksize, scharr, dxr) || !derivTaps(0, ksize, scharr, dxc) || !derivTaps(0, ksize, scharr, dyr) || !derivTaps(1, ksize, scharr, dyc)");
     a.dxNRow = (int)dxr.size(); a.dxNCol = (int)dxc.size(); a.dyNRow = (int)dyr.size(); a.dyNCol = (int)dyc.size();
     for (int i = 0; i < a.dxNRow; i++) a.dxRow[i] = (float)dxr[i];
     for (int i = 0; i < a.dxNCol; i++) a.dxCol[i] = (float)((double)dxc[i] * scale);     // `ky *= scale` (dx != 0)
@@ -714,23 +714,23 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
 int runCorner(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
               int W, int H, int src_type, int blockSize, int ksize, double k, int borderType, bool harris)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int sdepth = MI355CV_MAT_DEPTH(src_type);
-    if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return MI355CV_NOT_IMPLEMENTED;   // corner.cpp:254
+    if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return mi355::declined(__func__, __LINE__, "MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)");   // corner.cpp:254
     const int border = borderType & ~MI355CV_BORDER_ISOLATED;
-    if (border == B_WRAP || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;          // FilterEngine rejects WRAP
-    if (blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0) return MI355CV_NOT_IMPLEMENTED;
-    if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return MI355CV_NOT_IMPLEMENTED;
+    if (border == B_WRAP || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border == B_WRAP || border < 0 || border > B_REFLECT_101");          // FilterEngine rejects WRAP
+    if (blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0) return mi355::declined(__func__, __LINE__, "blockSize < 1 || blockSize > 16 || W <= 0 || H <= 0 || nframes <= 0");
+    if (!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return mi355::declined(__func__, __LINE__, "!(ksize == -1 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))");
     size_t dss = sstep, dds = dstep;
     const uchar* ds = src; uchar* dd = dst;
     if (nframes == 1) {
         ds = stg.in(src, sstep, (size_t)W * (sdepth == D8U ? 1 : 4), H, &dss);
         dd = stg.out(dst, dstep, (size_t)W * 4, H, &dds);
-        if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
-    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
+    } else if (!isDevicePtr(src) || !isDevicePtr(dst)) return mi355::declined(__func__, __LINE__, "!isDevicePtr(src) || !isDevicePtr(dst)");
     int rc = launchCorner(ds, dss, sframe, dd, dds, dframe, nframes, W, H, sdepth, blockSize, ksize, k, border, harris, stream());
     if (rc != MI355CV_OK) return rc;
     return stg.finish(entry);
@@ -834,7 +834,7 @@ MI355CV_API int mi355cv_pyrdownBatch(const uchar* src_data, size_t src_step, siz
 MI355CV_API int mi355cv_buildPyramid(const uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
                                      uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type)
 {
-    if (!dst_data || !dst_step || maxlevel < 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!dst_data || !dst_step || maxlevel < 0) return mi355::declined(__func__, __LINE__, "!dst_data || !dst_step || maxlevel < 0");
     const uchar* s = src_data; size_t ss = src_step; int w = width, h = height;
     for (int l = 0; l < maxlevel; l++) {
         const int dw = (w + 1) / 2, dh = (h + 1) / 2;
@@ -852,10 +852,10 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
                                           uchar* const* dst_data, const size_t* dst_step, const size_t* dst_frame_stride, int maxlevel, int nframes,
                                           int border_type)
 {
-    if (disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1");
     int border = border_type & ~MI355CV_BORDER_ISOLATED;
-    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
-    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border == B_CONSTANT || border < 0 || border > B_REFLECT_101");
+    if (!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!(depth == D8U || depth == D16U || depth == D16S || depth == D32F) || cn < 1 || cn > 4 || width <= 0 || height <= 0");
     // every frame and every level in host memory: chunks of frames cross PCIe through two sets of device buffers, the upload of
     // chunk i + 1 under the kernels and the downloads of chunk i; the chunk itself is this entry on device pointers
     bool allHost = hostBatchEligible(src_data, dst_data[0], nframes) && maxlevel <= HOST_BATCH_MAX_OUT;
@@ -870,7 +870,7 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
             return mi355cv_buildPyramidBatch(s, ss, sf, width, height, depth, cn, d, ds, df, maxlevel, nf, border_type); });
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (!isDevicePtr(src_data)) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: frames and levels all in device memory, or all in host memory");
     for (int l = 0; l < maxlevel; l++) if (!isDevicePtr(dst_data[l])) return setError(MI355CV_NOT_IMPLEMENTED, "buildPyramidBatch: frames and levels all in device memory, or all in host memory");
     const uchar* s = src_data; size_t ss = src_step, sf = nframes == 1 ? 0 : src_frame_stride; int w = width, h = height;

@@ -191,14 +191,14 @@ __global__ __launch_bounds__(1024) void k_fast_row_scan(const unsigned* __restri
 
 int runDense(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int w, int h, int type)
 {
-    if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst) return mi355::declined(__func__, __LINE__, "disabled() || type != 2 || w <= 0 || h <= 0 || !src || !dst");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)w * h, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)w * h, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)w * h, minPixels(HOST_HEAVY))");
     size_t ss, ds;
     const uchar* s = stg.in(src, sstep, (size_t)w, h, &ss);
     uchar* d = stg.out(dst, dstep, (size_t)w, h, &ds);
-    if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
+    if (!s || !d) return mi355::declined(__func__, __LINE__, "!s || !d");
     hipLaunchKernelGGL(k_fast_dense16, dim3(divUp(w, 256), divUp(h, 4)), dim3(256), 0, stream(), s, ss, d, ds, w, h);
     return stg.finish(entry);
 }
@@ -238,14 +238,14 @@ MI355CV_API int mi355cv_FAST_dense(const uchar* src_data, size_t src_step, uchar
 // replaces hal_ni_FAST_NMS (:87; caller fast.cpp:454)
 MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t ss, ds;
     const uchar* s = stg.in(src_data, src_step, (size_t)width, height, &ss);
     uchar* d = stg.out(dst_data, dst_step, (size_t)width, height, &ds);
-    if (!s || !d) return MI355CV_NOT_IMPLEMENTED;
+    if (!s || !d) return mi355::declined(__func__, __LINE__, "!s || !d");
     hipLaunchKernelGGL(k_fast_nms, dim3(divUp(width, 256), divUp(height, 4)), dim3(256), 0, stream(), s, ss, d, ds, width, height);
     return stg.finish("FAST_NMS");
 }

@@ -573,14 +573,14 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
     c.kind = 2;
     c.sdepth = MI355CV_MAT_DEPTH(stype); c.ddepth = MI355CV_MAT_DEPTH(dtype);
     c.cn = MI355CV_MAT_CN(stype);
-    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)) return MI355CV_NOT_IMPLEMENTED;
+    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)) return mi355::declined(__func__, __LINE__, "c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)");
     const int nx = (int)kx.size(), ny = (int)ky.size();
-    if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return MI355CV_NOT_IMPLEMENTED;
+    if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33");
     if (ax < 0) ax = nx / 2;
     if (ay < 0) ay = ny / 2;
-    if (ax >= nx || ay >= ny) return MI355CV_NOT_IMPLEMENTED;
+    if (ax >= nx || ay >= ny) return mi355::declined(__func__, __LINE__, "ax >= nx || ay >= ny");
     c.border = border & ~MI355CV_BORDER_ISOLATED;
-    if (c.border < 0 || c.border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (c.border < 0 || c.border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "c.border < 0 || c.border > B_REFLECT_101");
     SepParams& p = c.sp;
     memset(&p, 0, sizeof p);
     p.nx = nx; p.ny = ny; p.ax = ax; p.ay = ay;
@@ -611,10 +611,10 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
 int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, uchar* dst, size_t dstep,
            int W, int H, int fullW, int fullH, int offX, int offY)
 {
-    if (disabled() || W <= 0 || H <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || W <= 0 || H <= 0) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)W * H, minPixels(HOST_HEAVY))");
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
     // stage the whole parent region so that non-isolated borders can read real neighbours
     const uchar* top = src - (ptrdiff_t)offY * (ptrdiff_t)sstep - (ptrdiff_t)offX * c.cn * se;
@@ -623,7 +623,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     size_t dss, dds;
     const uchar* dtop = stg.in(top, sstep, (size_t)fullW * c.cn * se, fullH, &dss);
     uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
-    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
     const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
     const SepParams& p = c.sp;
     // a submatrix with real pixels around it stays on the rolling kernels: they run on the parent's geometry and store the window (roll.h Win)
@@ -655,9 +655,9 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
 // where they apply, the generic kernel frame by frame otherwise (all in stream order, one synchronisation at most)
 int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H)
 {
-    if (disabled() || W <= 0 || H <= 0 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || W <= 0 || H <= 0 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || nframes < 1");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
     if (overlapOnDevice(src, (size_t)(nframes - 1) * sframe + (size_t)(H - 1) * sstep + (size_t)W * c.cn * se,
@@ -720,9 +720,9 @@ int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size
              int cn, int mL, int mT, int mR, int mB, int dx, int dy, int ksize, bool scharr, double scale, double delta, int border,
              int nframes = 0, size_t sframe = 0, size_t dframe = 0)
 {
-    if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)) return MI355CV_NOT_IMPLEMENTED;
+    if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)) return mi355::declined(__func__, __LINE__, "dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)");
     std::vector<int> ix, iy;
-    if (!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)) return MI355CV_NOT_IMPLEMENTED;
+    if (!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)) return mi355::declined(__func__, __LINE__, "!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)");
     // ktype = max(CV_32F, ddepth, sdepth) = CV_32F for every depth handled here; `kx *= scale` is evaluated
     // in double and stored back as float (deriv.cpp:432-439)
     std::vector<double> kx(ix.begin(), ix.end()), ky(iy.begin(), iy.end());
@@ -748,12 +748,12 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
         double delta, int anchor_x, int anchor_y, bool allowSubmatrix, bool allowInplace)
 {
     (void)max_width; (void)max_height; (void)allowSubmatrix;
-    if (!context || !kernel_data || disabled()) return MI355CV_NOT_IMPLEMENTED;
-    if (allowInplace) return MI355CV_NOT_IMPLEMENTED;               // src == dst: a stencil cannot run in place on the GPU
+    if (!context || !kernel_data || disabled()) return mi355::declined(__func__, __LINE__, "!context || !kernel_data || disabled()");
+    if (allowInplace) return mi355::declined(__func__, __LINE__, "allowInplace");               // src == dst: a stencil cannot run in place on the GPU
     if (MI355CV_MAT_CN(kernel_type) != 1 || kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "MI355CV_MAT_CN(kernel_type) != 1 || kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024");
     FilterCtx* c = new (std::nothrow) FilterCtx();
-    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    if (!c) return mi355::declined(__func__, __LINE__, "!c");
     c->kind = 1;
     c->sdepth = MI355CV_MAT_DEPTH(src_type); c->ddepth = MI355CV_MAT_DEPTH(dst_type); c->cn = MI355CV_MAT_CN(src_type);
     c->border = borderType & ~MI355CV_BORDER_ISOLATED;
@@ -761,7 +761,7 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
     c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
     c->delta = (float)delta;                                         // saturate_cast<float>(delta), filter.simd.hpp:3113
     if (c->cn != MI355CV_MAT_CN(dst_type) || !depthPairOk(c->sdepth, c->ddepth) || c->border < 0 || c->border > B_REFLECT_101 ||
-        c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return MI355CV_NOT_IMPLEMENTED; }
+        c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return mi355::declined(__func__, __LINE__, nullptr); }
     for (int i = 0; i < kernel_height; i++)
         for (int j = 0; j < kernel_width; j++) {
             const float v = (float)kernelAt(kernel_data, kernel_step, kernel_type, i, j);   // convertTo(CV_32F), :3201-3205
@@ -809,18 +809,18 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height)
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
-    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * c->cn * depthBytes(c->sdepth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * c->cn * depthBytes(c->ddepth), height, nframes};
         return runHostBatch("filterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
             return mi355cv_filterBatch(context, s, ss, sf, d, ds, df, nf, width, height); });
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)");
     if (nframes == 1) { src_frame_stride = 0; dst_frame_stride = 0; }
     if (!tryFilterRoll(c, src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, stream())) {
         Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
-        if (!dt) return MI355CV_NOT_IMPLEMENTED;
+        if (!dt) return mi355::declined(__func__, __LINE__, "!dt");
         const int se = depthSize(c->sdepth), de = depthSize(c->ddepth); (void)se; (void)de;
         for (int f = 0; f < nframes; f++) {
             dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
@@ -840,14 +840,14 @@ MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uc
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int scn, bool swapBlue)
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
-    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * scn, height, dst_data, dst_step, dst_frame_stride, (size_t)width, height, nframes};
         return runHostBatch("cvtBGRtoGrayFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
             return mi355cv_cvtBGRtoGrayFilterBatch(context, s, ss, sf, d, ds, df, nf, width, height, scn, swapBlue); });
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(dst_data)");
     const int K = c->kw;
     if (c->cn != 1 || c->sdepth != D8U || c->ddepth != D8U || c->kw != c->kh || (K != 3 && K != 5) || c->ax != K / 2 || c->ay != K / 2)
         return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoGrayFilterBatch: needs a centred 3x3 / 5x5 CV_8UC1 filter context");
@@ -871,10 +871,10 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
         int width, int height, int full_width, int full_height, int offset_x, int offset_y)
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
-    if (!c || c->kind != 1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->kind != 1 || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     const int se = depthSize(c->sdepth), de = depthSize(c->ddepth);
     // hal::filter2D tries the hook before its own DFT path (filter.dispatch.cpp:1436-1470): for a whole image and a kernel of >= 130 taps
     // (8U -> 8U / 16S, 32F -> 32F; >= 50 otherwise) the CPU result comes from float FFTs (dftFilter2D :1274-1340), which a direct sum does
@@ -891,7 +891,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     const uchar* dtop = stg.in(top, src_step, (size_t)full_width * c->cn * se, full_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * de, height, &dds);
     Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
-    if (!dtop || !dd || !dt) return MI355CV_NOT_IMPLEMENTED;
+    if (!dtop || !dd || !dt) return mi355::declined(__func__, __LINE__, "!dtop || !dd || !dt");
     const uchar* ds = dtop + (size_t)offset_y * dss + (size_t)offset_x * c->cn * se;
     if (full_width == width && full_height == height && tryFilterRoll(c, ds, dss, 0, dd, dds, 0, 1, width, height, stream()))
         return stg.finish("filter");
@@ -911,13 +911,13 @@ MI355CV_API int mi355cv_sepFilterInit(cvhalFilter2D** context, int src_type, int
         uchar* kernelx_data, int kernelx_length, uchar* kernely_data, int kernely_length,
         int anchor_x, int anchor_y, double delta, int borderType)
 {
-    if (!context || !kernelx_data || !kernely_data || disabled()) return MI355CV_NOT_IMPLEMENTED;
-    if (MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (!context || !kernelx_data || !kernely_data || disabled()) return mi355::declined(__func__, __LINE__, "!context || !kernelx_data || !kernely_data || disabled()");
+    if (MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1) return mi355::declined(__func__, __LINE__, "MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1");
     std::vector<double> kx(kernelx_length), ky(kernely_length);
     for (int i = 0; i < kernelx_length; i++) kx[i] = kernelAt(kernelx_data, 0, kernel_type, 0, i);
     for (int i = 0; i < kernely_length; i++) ky[i] = kernelAt(kernely_data, 0, kernel_type, 0, i);
     FilterCtx* c = new (std::nothrow) FilterCtx();
-    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    if (!c) return mi355::declined(__func__, __LINE__, "!c");
     int rc = sepInit(*c, src_type, dst_type, kx, ky, anchor_x, anchor_y, delta, borderType);
     if (rc != MI355CV_OK) { delete c; return rc; }
     *context = reinterpret_cast<cvhalFilter2D*>(c);
@@ -928,7 +928,7 @@ MI355CV_API int mi355cv_sepFilter(cvhalFilter2D* context, uchar* src_data, size_
         int width, int height, int full_width, int full_height, int offset_x, int offset_y)
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
-    if (!c || c->kind != 2) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->kind != 2) return mi355::declined(__func__, __LINE__, "!c || c->kind != 2");
     return sepRun("sepFilter", *c, src_data, src_step, dst_data, dst_step, width, height, full_width, full_height, offset_x, offset_y);
 }
 
@@ -959,7 +959,7 @@ MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* ds
 MI355CV_API int mi355cv_sobelBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step, size_t dst_frame_stride,
         int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta, int border_type)
 {
-    if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (nframes < 1) return mi355::declined(__func__, __LINE__, "nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
         return runHostBatch("sobelBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -973,7 +973,7 @@ MI355CV_API int mi355cv_sepFilterBatch(cvhalFilter2D* context, const uchar* src_
         size_t dst_frame_stride, int nframes, int width, int height)
 {
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
-    if (!c || c->kind != 2 || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->kind != 2 || nframes < 1) return mi355::declined(__func__, __LINE__, "!c || c->kind != 2 || nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * c->cn * depthBytes(c->sdepth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * c->cn * depthBytes(c->ddepth), height, nframes};
         return runHostBatch("sepFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -990,7 +990,7 @@ MI355CV_API int mi355cv_boxFilterBatch(const uchar* src_data, size_t src_step, s
         int nframes, int width, int height, int src_depth, int dst_depth, int cn, size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize,
         int border_type)
 {
-    if (nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (nframes < 1) return mi355::declined(__func__, __LINE__, "nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
         return runHostBatch("boxFilterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -1013,20 +1013,20 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)");
     const int kw = (int)ksize_width, kh = (int)ksize_height;
-    if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return MI355CV_NOT_IMPLEMENTED;
+    if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return mi355::declined(__func__, __LINE__, "kw < 1 || kh < 1 || kw > 255 || kh > 255");
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
-    if (border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101");
     const bool okDepth = (src_depth == D8U && (dst_depth == D8U || dst_depth == D32F)) ||
                          (src_depth == D16U && (dst_depth == D16U || dst_depth == D32F)) ||
                          (src_depth == D16S && (dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D32F && dst_depth == D32F);
-    if (!okDepth) return MI355CV_NOT_IMPLEMENTED;
+    if (!okDepth) return mi355::declined(__func__, __LINE__, "!okDepth");
     BoxParams p; memset(&p, 0, sizeof p);
     p.kw = kw; p.kh = kh;
     p.ax = anchor_x < 0 ? kw / 2 : anchor_x; p.ay = anchor_y < 0 ? kh / 2 : anchor_y;
-    if (p.ax >= kw || p.ay >= kh) return MI355CV_NOT_IMPLEMENTED;
+    if (p.ax >= kw || p.ay >= kh) return mi355::declined(__func__, __LINE__, "p.ax >= kw || p.ay >= kh");
     p.normalize = normalize ? 1 : 0;
     const int area = kw * kh;
     const double scale = 1.0 / area;
@@ -1045,11 +1045,11 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     } else {
         p.mode = 1;
         const long long lim = src_depth == D8U ? (1LL << 23) : src_depth == D16U ? (1LL << 15) : (1LL << 16);
-        if (normalize && area > lim) return MI355CV_NOT_IMPLEMENTED;    // the reference switches to double sums there
+        if (normalize && area > lim) return mi355::declined(__func__, __LINE__, "normalize && area > lim");    // the reference switches to double sums there
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     const int se = depthSize(src_depth), de = depthSize(dst_depth);
     const int fullW = margin_left + width + margin_right, fullH = margin_top + height + margin_bottom;
     if (nframes >= 1) {
@@ -1071,7 +1071,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     const uchar* top = src_data - (ptrdiff_t)margin_top * (ptrdiff_t)src_step - (ptrdiff_t)margin_left * cn * se;
     const uchar* dtop = stg.in(top, src_step, (size_t)fullW * cn * se, fullH, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * de, height, &dds);
-    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
     const uchar* ds = dtop + (size_t)margin_top * dss + (size_t)margin_left * cn * se;
     const Roi roiv = {fullW, fullH, margin_left, margin_top};
     const Roi* roi = (fullW != width || fullH != height) ? &roiv : nullptr;       // a submatrix with real pixels around it: the rolling kernels store the window

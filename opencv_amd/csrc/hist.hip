@@ -123,18 +123,18 @@ extern "C" {
 
 MI355CV_API int mi355cv_equalize_hist(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    if (disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     // histogram -> table -> per-pixel pass, all in stream order: no host round trip, so the hook stays asynchronous for images in HBM
     unsigned* dh = (unsigned*)stg.scratch(256 * 4);
     uchar* dl = (uchar*)stg.scratch(256);
-    if (!dh || !dl) return MI355CV_NOT_IMPLEMENTED;
+    if (!dh || !dl) return mi355::declined(__func__, __LINE__, "!dh || !dl");
     hipStream_t st = stream();
     if (hipMemsetAsync(dh, 0, 256 * 4, st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
     const int rowsPerBlock = std::max(1, divUp(height, 512));
@@ -149,15 +149,15 @@ MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, u
                                        double maxValue, int thresholdType, double* thresh)
 {
     if (disabled() || !thresh || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_16U) || thresholdType < 0 || thresholdType > 4)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || !thresh || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_16U) || thresholdType < 0 || thresholdType > 4");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if ((long long)width * height > 0x7fffffffLL || !ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if ((long long)width * height > 0x7fffffffLL || !ensureDevice()) return mi355::declined(__func__, __LINE__, "(long long)width * height > 0x7fffffffLL || !ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     const int e = depth == MI355CV_8U ? 1 : 2;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * e, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     std::vector<int> h;
     if (!histogramToHost(stg, ds, dss, width, height, depth, h)) return MI355CV_ERROR_UNKNOWN;
     // getThreshVal_Otsu, thresh.cpp:1158-1192

@@ -350,14 +350,14 @@ extern "C" {
 
 MI355CV_API int mi355cv_ScharrDeriv(const uchar* src_data, size_t src_step, short* dst_data, size_t dst_step, int width, int height, int cn)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out((uchar*)dst_data, dst_step, (size_t)width * cn * 4, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     hipLaunchKernelGGL(k_scharr_deriv, dim3(divUp(width * cn, 64), divUp(height, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn);
     return stg.finish("ScharrDeriv");
 }
@@ -369,10 +369,10 @@ MI355CV_API int mi355cv_copyMakeBorder(const uchar* src_data, size_t src_step, i
 {
     border_type &= ~MI355CV_BORDER_ISOLATED;
     if (disabled() || width <= 0 || height <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || elem_size < 1 || elem_size > 64 ||
-        border_type < B_CONSTANT || border_type > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+        border_type < B_CONSTANT || border_type > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || elem_size < 1 || elem_size > 64 || border_type < B_CONSTANT || border_type > B_REFLECT_101");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return MI355CV_NOT_IMPLEMENTED;              // a host-side copy is the CPU's job
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (!isDevicePtr(src_data) || !isDevicePtr(dst_data)) return mi355::declined(__func__, __LINE__, "!isDevicePtr(src_data) || !isDevicePtr(dst_data)");              // a host-side copy is the CPU's job
     const int DW = left + width + right, DH = top + height + bottom;
     const int inPlace = src_data == dst_data + (size_t)top * dst_step + (size_t)left * elem_size && src_step == dst_step;
     hipLaunchKernelGGL(k_copy_make_border, dim3(divUp(DW, 64), divUp(DH, 4)), dim3(256), 0, stream(), src_data, src_step, width, height, dst_data, dst_step,
@@ -388,18 +388,18 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
 {
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width < 1 || win_height < 1 || win_width > 64 || win_height > 64 ||
         !prev_points || !next_points || (prev_deriv_step & 1) || point_count > 0x3fffffffu)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width < 1 || win_height < 1 || win_width > 64 || win_height > 64 || !prev_points || !next_points || (prev_deriv_step & 1) || point_count > 0x3fffffffu");
     if (point_count == 0) return MI355CV_OK;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     // the tracker reads up to one window beyond every image edge (the padded pyramids, hal_replacement.hpp:30-32): stage the padded rectangles
     const int pw = width + 2 * win_width, ph = height + 2 * win_height;
     size_t sI, sD, sJ;
     const uchar* dI = stg.in(prev_data - (size_t)win_height * prev_data_step - (size_t)win_width * cn, prev_data_step, (size_t)pw * cn, ph, &sI);
     const uchar* dD = stg.in((const uchar*)prev_deriv_data - (size_t)win_height * prev_deriv_step - (size_t)win_width * cn * 4, prev_deriv_step, (size_t)pw * cn * 4, ph, &sD);
     const uchar* dJ = stg.in(next_data - (size_t)win_height * next_step - (size_t)win_width * cn, next_step, (size_t)pw * cn, ph, &sJ);
-    if (!dI || !dD || !dJ || (sD & 1)) return MI355CV_NOT_IMPLEMENTED;
+    if (!dI || !dD || !dJ || (sD & 1)) return mi355::declined(__func__, __LINE__, "!dI || !dD || !dJ || (sD & 1)");
     size_t st;
     const float* dPrev = (const float*)stg.in((const uchar*)prev_points, point_count * 8, point_count * 8, 1, &st);
     float* dNext = inout(stg, next_points, point_count * 2);
@@ -408,7 +408,7 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
     const size_t E = (size_t)win_width * cn * win_height, ldsBytes = E * 14 + 64;
     const bool perWave = ldsBytes <= 48 * 1024 && !getenv("MI355CV_LK_THREAD_PER_POINT");
     short* win = perWave ? nullptr : (short*)stg.scratch(3 * E * point_count * sizeof(short));
-    if (!dPrev || !dNext || (status && !dStatus) || (err && !dErr) || (!perWave && !win)) return MI355CV_NOT_IMPLEMENTED;
+    if (!dPrev || !dNext || (status && !dStatus) || (err && !dErr) || (!perWave && !win)) return mi355::declined(__func__, __LINE__, "!dPrev || !dNext || (status && !dStatus) || (err && !dErr) || (!perWave && !win)");
     LkArgs a;
     a.I = dI + (size_t)win_height * sI + (size_t)win_width * cn; a.stepI = (long)sI;
     a.dI = (const short*)(dD + (size_t)win_height * sD + (size_t)win_width * cn * 4); a.dstep = (long)(sD / 2);
@@ -434,11 +434,11 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
 {
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width <= 2 || win_height <= 2 || win_width > 64 || win_height > 64 || max_level < 0 ||
         max_level > 16 || !prev_points || !next_points || !status || point_count < 0)
-        return MI355CV_NOT_IMPLEMENTED;
+        return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width <= 2 || win_height <= 2 || win_width > 64 || win_height > 64 || max_level < 0 || max_level > 16 || !prev_points || !next_points || !status || point_count < 0");
     if (point_count == 0) return MI355CV_OK;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(prev_data, (size_t)width * height, minPixels(HOST_HEAVY))");
     const bool useInitial = (flags & 4) != 0, getMinEig = (flags & 8) != 0;                // OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_LK_GET_MIN_EIGENVALS
     int maxCount = (criteria_type & 1) == 0 ? 30 : std::min(std::max(criteria_max_count, 0), 100);                     // :1386-1395
     double eps = (criteria_type & 2) == 0 ? 0.01 : std::min(std::max(criteria_epsilon, 0.), 10.);
@@ -453,7 +453,7 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
     uchar* dStatus = stg.out(status, (size_t)point_count, (size_t)point_count, 1, &tmp);
     float* dErr = err ? (float*)stg.out((uchar*)err, (size_t)point_count * 4, (size_t)point_count * 4, 1, &tmp) : nullptr;      // no err array: the tracker skips that pass (:694)
     float* dScaled = (float*)stg.scratch(n2 * 4);
-    if (!dP || !dN || !dPrev || !dNext || !dStatus || (err && !dErr) || !dScaled) return MI355CV_NOT_IMPLEMENTED;
+    if (!dP || !dN || !dPrev || !dNext || !dStatus || (err && !dErr) || !dScaled) return mi355::declined(__func__, __LINE__, "!dP || !dN || !dPrev || !dNext || !dStatus || (err && !dErr) || !dScaled");
     if (dErr && hipMemsetAsync(dErr, 0, (size_t)point_count * 4, st) != hipSuccess) return MI355CV_ERROR_UNKNOWN;
     hipLaunchKernelGGL(k_fill_u8, dim3(divUp(point_count, 256)), dim3(256), 0, st, dStatus, point_count, 1);
 
@@ -468,7 +468,7 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
             L.w = w; L.h = h;
             L.pitch = (((size_t)(w + 2 * win_width) * cn) + 255) & ~(size_t)255;
             L.whole = (uchar*)stg.scratch(L.pitch * (size_t)(h + 2 * win_height));
-            if (!L.whole) return MI355CV_NOT_IMPLEMENTED;
+            if (!L.whole) return mi355::declined(__func__, __LINE__, "!L.whole");
             L.inner = L.whole + (size_t)win_height * L.pitch + (size_t)win_width * cn;
             const int DW = w + 2 * win_width, DH = h + 2 * win_height;
             if (lv == 0)
@@ -493,7 +493,7 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
     // one derivative buffer, sized for level 0, reused by every level (as the reference does, :1398-1400)
     const size_t dpitch0 = (((size_t)(width + 2 * win_width) * cn * 4) + 255) & ~(size_t)255;
     uchar* dbuf = (uchar*)stg.scratch(dpitch0 * (size_t)(height + 2 * win_height));
-    if ((!perWave && !win) || !dbuf) return MI355CV_NOT_IMPLEMENTED;
+    if ((!perWave && !win) || !dbuf) return mi355::declined(__func__, __LINE__, "(!perWave && !win) || !dbuf");
     for (int level = levels; level >= 0; level--) {
         const Level& LI = pyr[0][level]; const Level& LJ = pyr[1][level];
         const size_t dpitch = (((size_t)(LI.w + 2 * win_width) * cn * 4) + 255) & ~(size_t)255;

@@ -152,17 +152,17 @@ __global__ __launch_bounds__(256) void k_median_generic(const uchar* __restrict_
 extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int depth, int cn, int ksize)
 {
-    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
-    if (depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
+    if (depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const bool devSrc = isDevicePtr(src_data);
-    if (!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)) return MI355CV_NOT_IMPLEMENTED;
-    if (devSrc && src_data == dst_data) return MI355CV_NOT_IMPLEMENTED;                  // in place on the device: a stencil cannot
+    if (!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)) return mi355::declined(__func__, __LINE__, "!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)");
+    if (devSrc && src_data == dst_data) return mi355::declined(__func__, __LINE__, "devSrc && src_data == dst_data");                  // in place on the device: a stencil cannot
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     hipStream_t st = stream();
     if (!roll::eligible(ds, dss, 0, dd, dds, 0, width, cn, ksize / 2, B_REPLICATE)) {
         dim3 grid(divUp(width * cn, 64), divUp(height, 4));

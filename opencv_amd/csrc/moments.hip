@@ -102,19 +102,19 @@ __global__ __launch_bounds__(256) void k_tile_moments_f(const uchar* __restrict_
 
 extern "C" MI355CV_API int mi355cv_imageMoments(const uchar* src_data, size_t src_step, int src_type, int width, int height, bool binary, double m[10])
 {
-    if (disabled() || !src_data || !m || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !src_data || !m || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !m || width <= 0 || height <= 0");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     const bool isF = depth == MI355CV_32F || depth == MI355CV_64F;
-    if (cn != 1 || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_16S && !isF)) return MI355CV_NOT_IMPLEMENTED;
+    if (cn != 1 || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_16S && !isF)) return mi355::declined(__func__, __LINE__, "cn != 1 || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_16S && !isF)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const int e = depth == MI355CV_8U ? 1 : depth == MI355CV_32F ? 4 : depth == MI355CV_64F ? 8 : 2;
     const int ntx = divUp(width, 32), nty = divUp(height, 32), ntiles = ntx * nty;
     size_t dss;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
     long long* dt = (long long*)stg.scratch((size_t)ntiles * 10 * sizeof(long long));
-    if (!ds || !dt) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dt) return mi355::declined(__func__, __LINE__, "!ds || !dt");
     dim3 grid(divUp(ntiles, 4));
     if (isF) {
         if (depth == MI355CV_32F) hipLaunchKernelGGL(k_tile_moments_f<float>, dim3(divUp(ntiles, 8)), dim3(256), 0, stream(), ds, dss, width, height, ntx, ntiles, binary ? 1 : 0, (double*)dt);

@@ -70,24 +70,24 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
         int borderType, const double borderValue[4], int iterations, bool allowSubmatrix, bool allowInplace)
 {
     (void)max_width; (void)max_height; (void)allowSubmatrix;
-    if (!context || disabled()) return MI355CV_NOT_IMPLEMENTED;
-    if (operation != 0 && operation != 1) return MI355CV_NOT_IMPLEMENTED;          // MORPH_ERODE / MORPH_DILATE
-    if (iterations != 1 || allowInplace || src_type != dst_type) return MI355CV_NOT_IMPLEMENTED;
+    if (!context || disabled()) return mi355::declined(__func__, __LINE__, "!context || disabled()");
+    if (operation != 0 && operation != 1) return mi355::declined(__func__, __LINE__, "operation != 0 && operation != 1");          // MORPH_ERODE / MORPH_DILATE
+    if (iterations != 1 || allowInplace || src_type != dst_type) return mi355::declined(__func__, __LINE__, "iterations != 1 || allowInplace || src_type != dst_type");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return MI355CV_NOT_IMPLEMENTED;
-    if (kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024) return MI355CV_NOT_IMPLEMENTED;
+    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4");
+    if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return mi355::declined(__func__, __LINE__, "!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1");
+    if (kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024) return mi355::declined(__func__, __LINE__, "kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024");
     const int border = borderType & ~MI355CV_BORDER_ISOLATED;
-    if (border < 0 || border > B_REFLECT_101 || border == B_WRAP) return MI355CV_NOT_IMPLEMENTED;
+    if (border < 0 || border > B_REFLECT_101 || border == B_WRAP) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101 || border == B_WRAP");
     MorphCtx* c = new (std::nothrow) MorphCtx();
-    if (!c) return MI355CV_NOT_IMPLEMENTED;
+    if (!c) return mi355::declined(__func__, __LINE__, "!c");
     c->magic = MORPH_MAGIC; c->op = operation; c->depth = depth; c->cn = cn; c->kw = kernel_width; c->kh = kernel_height; c->border = border;
     c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
-    if (c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return MI355CV_NOT_IMPLEMENTED; }
+    if (c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return mi355::declined(__func__, __LINE__, nullptr); }
     for (int j = 0; j < kernel_height; j++)
         for (int i = 0; i < kernel_width; i++)
             if (kernel_data[(size_t)j * kernel_step + i]) c->taps.push_back({(short)i, (short)j});
-    if (c->taps.empty()) { delete c; return MI355CV_NOT_IMPLEMENTED; }               // the reference asserts a non-empty element
+    if (c->taps.empty()) { delete c; return mi355::declined(__func__, __LINE__, nullptr); }               // the reference asserts a non-empty element
     c->rect = (int)c->taps.size() == kernel_width * kernel_height;
     c->defaultBorder = !borderValue || (borderValue[0] == DBL_MAX && borderValue[1] == DBL_MAX && borderValue[2] == DBL_MAX && borderValue[3] == DBL_MAX);
     for (int k = 0; k < 4; k++) {
@@ -105,16 +105,16 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
 {
     (void)dst_full_width; (void)dst_full_height; (void)dst_roi_x; (void)dst_roi_y;
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
-    if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data)");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
     size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;
     const uchar* dtop = stg.in(top, src_step, (size_t)src_full_width * c->cn * e, src_full_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * c->cn * e, height, &dds);
-    if (!dtop || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
     const uchar* ds = dtop + (size_t)src_roi_y * dss + (size_t)src_roi_x * c->cn * e;
     hipStream_t st = stream();
     const bool whole = src_full_width == width && src_full_height == height;
@@ -123,7 +123,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
         seprollMorph(c->op == 0, ds, dss, 0, dd, dds, 0, 1, width, height, c->cn, c->kw, c->border, st))
         return stg.finish("morph");
     MorphTap* dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
-    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    if (!dt) return mi355::declined(__func__, __LINE__, "!dt");
     dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
 #define MORPH_GEN(T) hipLaunchKernelGGL(k_morph_generic<T>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, c->cn, src_full_width, src_full_height, \
         src_roi_x, src_roi_y, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
@@ -135,7 +135,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
 MI355CV_API int mi355cv_morphFree(cvhalFilter2D* context)
 {
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
-    if (!c || c->magic != MORPH_MAGIC) return MI355CV_NOT_IMPLEMENTED;
+    if (!c || c->magic != MORPH_MAGIC) return mi355::declined(__func__, __LINE__, "!c || c->magic != MORPH_MAGIC");
     c->magic = 0;
     delete c;
     return MI355CV_OK;

@@ -36,6 +36,10 @@ size_t minPixels(int cost = HOST_CHEAP);
 // host-resident image below the policy threshold: true, and the reason is recorded for mi355cv_lastError / the decline ledger
 bool hostImageTooSmall(const void* img, size_t pixels, size_t threshold);
 int  setError(int code, const char* fmt, ...);
+// a hook answers NOT_IMPLEMENTED: records WHY for mi355cv_lastError and the decline ledger (mi355cv_noteDecline) -- "<entry>:<line>: <the condition that held>" --
+// unless a more specific reason was already recorded during this call (staging failure, host-policy threshold, foreign device ...).  Returns MI355CV_NOT_IMPLEMENTED.
+int  declined(const char* fn, int line, const char* cond);
+void beginCall();                   // start of a hook invocation (Stager's constructor): reasons recorded by earlier calls no longer count as this call's
 void bump(const char* entry);       // per-entry completed-on-GPU counter
 void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)
 bool ensureDevice();                // makes the calling thread's device current (mi355cv_setDevice, else the process default); false if no usable GPU

@@ -25,6 +25,7 @@ static std::map<std::string, long long> g_counts;
 static std::atomic<long long> g_stagedBytes{0};   // image bytes the hooks moved over PCIe (host images staged in + results staged back)
 void noteStagedBytes(long long n) { g_stagedBytes += n; }
 static thread_local char t_err[512] = "";
+static thread_local unsigned t_serial = 0, t_errSerial = ~0u;  // hook invocations on this thread (bumped when the outermost Stager opens and closes); the one that recorded t_err
 static thread_local bool t_errFresh = false;             // set by setError, taken by mi355cv_noteDecline: a reason is attributed to one declined call
 static thread_local int t_dev = -1;                 // mi355cv_setDevice; -1 = process default
 static thread_local int t_active = 0;               // device of the hook that is running = index of the per-device thread context
@@ -78,10 +79,18 @@ void noteKernel(const char* fmt, ...)
 int setError(int code, const char* fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof t_err, fmt, ap); va_end(ap);
-    t_errFresh = true;
+    t_errFresh = true; t_errSerial = t_serial;
     if (getenv("MI355CV_LOG")) fprintf(stderr, "[mi355cv] %s\n", t_err);
     return code;
 }
+
+int declined(const char* fn, int line, const char* cond)
+{
+    if (t_errFresh && t_errSerial == t_serial) return MI355CV_NOT_IMPLEMENTED;          // the specific reason (setError during this call) stands
+    if (disabled()) return setError(MI355CV_NOT_IMPLEMENTED, "%s: MI355CV_DISABLE is set", fn);
+    return setError(MI355CV_NOT_IMPLEMENTED, "%s:%d: outside the GPU path because (%s)", fn, line, cond ? cond : "no branch of the dispatcher takes this argument combination");
+}
+void beginCall() { ++t_serial; }
 
 // MI355CV_PRINT_COUNTS=1: at process exit, one line per entry point with the number of calls the GPU served -- how a host program that
 // cannot call mi355cv_callCount (the reference's own test binary, tests/test_reference_suite.py) shows that its cv:: calls ran here
@@ -222,13 +231,14 @@ bool isDevicePtr(const void* p) { return ptrKind(p) == PTR_DEVICE; }
 Stager::Stager()
 {
     // an error left behind by an earlier call on this thread (a failed copy, somebody else's HIP code) must not be charged to this hook
-    if (t_depth++ == 0) (void)hipGetLastError();
+    if (t_depth++ == 0) { (void)hipGetLastError(); beginCall(); }
 }
 Stager::~Stager()
 {
     // buffers handed out during this (outermost) hook become reusable: at once on the stream that used them (stream order), on any other
     // stream only after that one has drained (bump_ checks) -- two asynchronous calls under different streams never share scratch
     if (--t_depth == 0) {
+        beginCall();                                         // a reason recorded during this call is not the next call's
         ThreadCtx& c = tctx();
         hipStream_t s = c.async ? stream() : nullptr;
         for (auto& b : c.pool) if (b.busy) { b.busy = false; b.last = s; }
@@ -355,7 +365,7 @@ bool hostBatchEligible(const void* src, const void* dst, int nframes)
 
 int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
 {
-    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes) return mi355::declined(__func__, __LINE__, "disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes");
     Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
     const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, dp = (hb.drowBytes + 255) & ~(size_t)255;
     const size_t sfb = sp * (size_t)hb.srows, dfb = dp * (size_t)hb.drows;
@@ -364,11 +374,11 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
     uchar* din[2]; uchar* dout[2];
     for (int b = 0; b < 2; b++) {
         din[b] = (uchar*)stg.scratch(sfb * cf); dout[b] = (uchar*)stg.scratch(dfb * cf);
-        if (!din[b] || !dout[b]) return MI355CV_NOT_IMPLEMENTED;
+        if (!din[b] || !dout[b]) return mi355::declined(__func__, __LINE__, "!din[b] || !dout[b]");
     }
     hipStream_t st = stream(), aux = auxStream();
     hipEvent_t inReady[2] = {pooledEvent(40), pooledEvent(41)}, bufFree[2] = {pooledEvent(42), pooledEvent(43)};
-    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return MI355CV_NOT_IMPLEMENTED;
+    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return mi355::declined(__func__, __LINE__, "!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]");
     const int nchunks = (hb.nframes + cf - 1) / cf;
     auto upload = [&](int c) -> bool {
         const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);
@@ -406,8 +416,8 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
 
 int runHostBatchN(const char* entry, const HostBatchN& hb, const HostBatchNFn& run)
 {
-    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT) return MI355CV_NOT_IMPLEMENTED;
-    for (int o = 0; o < hb.nout; o++) if (!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT) return mi355::declined(__func__, __LINE__, "disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT");
+    for (int o = 0; o < hb.nout; o++) if (!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes) return mi355::declined(__func__, __LINE__, "!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes");
     Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
     const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, sfb = sp * (size_t)hb.srows;
     size_t dp[HOST_BATCH_MAX_OUT], dfb[HOST_BATCH_MAX_OUT], perFrame = sfb;
@@ -417,12 +427,12 @@ int runHostBatchN(const char* entry, const HostBatchN& hb, const HostBatchNFn& r
     uchar* din[2]; uchar* dout[2][HOST_BATCH_MAX_OUT]; size_t dfs[HOST_BATCH_MAX_OUT];
     for (int b = 0; b < 2; b++) {
         din[b] = (uchar*)stg.scratch(sfb * cf);
-        if (!din[b]) return MI355CV_NOT_IMPLEMENTED;
-        for (int o = 0; o < hb.nout; o++) { dout[b][o] = (uchar*)stg.scratch(dfb[o] * cf); dfs[o] = dfb[o]; if (!dout[b][o]) return MI355CV_NOT_IMPLEMENTED; }
+        if (!din[b]) return mi355::declined(__func__, __LINE__, "!din[b]");
+        for (int o = 0; o < hb.nout; o++) { dout[b][o] = (uchar*)stg.scratch(dfb[o] * cf); dfs[o] = dfb[o]; if (!dout[b][o]) return mi355::declined(__func__, __LINE__, "!dout[b][o]"); }
     }
     hipStream_t st = stream(), aux = auxStream();
     hipEvent_t inReady[2] = {pooledEvent(44), pooledEvent(45)}, bufFree[2] = {pooledEvent(46), pooledEvent(47)};
-    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return MI355CV_NOT_IMPLEMENTED;
+    if (!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]) return mi355::declined(__func__, __LINE__, "!aux || !inReady[0] || !inReady[1] || !bufFree[0] || !bufFree[1]");
     const int nchunks = (hb.nframes + cf - 1) / cf;
     auto upload = [&](int c) -> bool {
         const int b = c & 1, f0 = c * cf, nf = std::min(cf, hb.nframes - f0);

@@ -650,15 +650,15 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
               int nframes, int W, int H, int cn, int mL, int mT, int mR, int mB,
               const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, bool binomial)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
-    if (W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)) return MI355CV_NOT_IMPLEMENTED;
-    if (border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
+    if (W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4");
+    if (nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)");
+    if (border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const bool hostSrc = !isDevicePtr(src);
-    if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    if (!hostSrc && src == dst) return MI355CV_NOT_IMPLEMENTED;            // in place on the device (cv::GaussianBlur itself clones, smooth.dispatch.cpp:685)
+    if (hostSrc && (size_t)W * H < minPixels()) return mi355::declined(__func__, __LINE__, "hostSrc && (size_t)W * H < minPixels()");
+    if (!hostSrc && src == dst) return mi355::declined(__func__, __LINE__, "!hostSrc && src == dst");            // in place on the device (cv::GaussianBlur itself clones, smooth.dispatch.cpp:685)
 
     size_t dss = 0, dds = 0;
     const size_t rowB = (size_t)W * cn;
@@ -667,10 +667,10 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
         // stage the ROI together with its real margins (non-isolated borders read them)
         const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * cn;
         const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * cn, mT + H + mB, &dss);
-        if (!dtop) return MI355CV_NOT_IMPLEMENTED;
+        if (!dtop) return mi355::declined(__func__, __LINE__, "!dtop");
         dsrc = dtop + (size_t)mT * dss + (size_t)mL * cn;
         ddst = stg.out(dst, dstep, rowB, H, &dds);
-        if (!ddst) return MI355CV_NOT_IMPLEMENTED;
+        if (!ddst) return mi355::declined(__func__, __LINE__, "!ddst");
     } else {
         // batches are an HBM-resident construct: no per-frame staging
         if (hostSrc || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
@@ -705,19 +705,19 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
 // CV_16UC1, sigma = 0, 3x3 / 5x5: the rolling kernel or nothing (the reference's own Q16.16 path is the fallback)
 int runBinom16(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int mL, int mT, int mR, int mB, int ksize, int border)
 {
-    if (disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const bool hostSrc = !isDevicePtr(src);
-    if (hostSrc && (size_t)W * H < minPixels()) return MI355CV_NOT_IMPLEMENTED;
-    if (!hostSrc && src == dst) return MI355CV_NOT_IMPLEMENTED;
+    if (hostSrc && (size_t)W * H < minPixels()) return mi355::declined(__func__, __LINE__, "hostSrc && (size_t)W * H < minPixels()");
+    if (!hostSrc && src == dst) return mi355::declined(__func__, __LINE__, "!hostSrc && src == dst");
     size_t dss = 0, dds = 0;
     const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * 2;
     const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * 2, mT + H + mB, &dss);
-    if (!dtop) return MI355CV_NOT_IMPLEMENTED;
+    if (!dtop) return mi355::declined(__func__, __LINE__, "!dtop");
     const uchar* dsrc = dtop + (size_t)mT * dss + (size_t)mL * 2;
     uchar* ddst = stg.out(dst, dstep, (size_t)W * 2, H, &dds);
-    if (!ddst) return MI355CV_NOT_IMPLEMENTED;
+    if (!ddst) return mi355::declined(__func__, __LINE__, "!ddst");
     const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
     if (!seprollBinom16(dsrc, dss, 0, ddst, dds, 0, 1, W, H, ksize, border, stream(), (mL | mT | mR | mB) ? &roi : nullptr))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: CV_16U geometry outside the rolling kernel", entry);
@@ -748,9 +748,9 @@ MI355CV_API int mi355cv_gaussianBlurBinomial(const uchar* src_data, size_t src_s
     if (depth == MI355CV_16U)
         return runBinom16("gaussianBlurBinomial", src_data, src_step, dst_data, dst_step, width, height, cn, (int)margin_left, (int)margin_top, (int)margin_right,
                                  (int)margin_bottom, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED);
-    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     const uint16_t* k = binomTaps(ksize);
-    if (!k) return MI355CV_NOT_IMPLEMENTED;
+    if (!k) return mi355::declined(__func__, __LINE__, "!k");
     return runSmooth("gaussianBlurBinomial", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, cn,
                      (int)margin_left, (int)margin_top, (int)margin_right, (int)margin_bottom,
                      k, (int)ksize, k, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED, true);
@@ -773,9 +773,9 @@ MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const uchar* src_data, size_t 
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int cn, size_t ksize, int border_type)
 {
-    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     const uint16_t* k = binomTaps(ksize);
-    if (!k) return MI355CV_NOT_IMPLEMENTED;
+    if (!k) return mi355::declined(__func__, __LINE__, "!k");
     if (nframes > 1 && width > 0 && height > 0 && cn >= 1 && cn <= 4 && hostBatchEligible(src_data, dst_data, nframes))
         return gaussBatchFromHost(src_data, src_step, src_frame_stride, dst_data, dst_step, dst_frame_stride, nframes, width, height, cn, k, (int)ksize,
                                   border_type & ~MI355CV_BORDER_ISOLATED);
@@ -793,20 +793,20 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
 {
     // 8U only here: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724).
     // Other depths go through sepFilter2D in the reference (:825) -- see mi355cv_sepFilter*.
-    if (depth != MI355CV_8U) return MI355CV_NOT_IMPLEMENTED;
+    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     // Real pixels around the ROI mean the caller is the submatrix / non-isolated site (:813): the fixed-point branch (:658) is skipped there and
     // the CPU result is sepFilter2D with float Gaussian taps, which can differ from Q8.8 by 1 LSB.  Decline: the reference then calls
     // sepFilter2D itself, whose hook (mi355cv_sepFilter, ROI offsets included) reproduces that arithmetic.
     if (margin_left | margin_top | margin_right | margin_bottom)
         return mi355::setError(MI355CV_NOT_IMPLEMENTED, "gaussianBlur: submatrix with real margins is the reference's sepFilter2D case");
-    if (ksize_width > 33 || ksize_height > 33) return MI355CV_NOT_IMPLEMENTED;
+    if (ksize_width > 33 || ksize_height > 33) return mi355::declined(__func__, __LINE__, "ksize_width > 33 || ksize_height > 33");
     if (sigmaY <= 0) sigmaY = sigmaX;
     std::vector<int64_t> qx, qy;
-    if (!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)) return MI355CV_NOT_IMPLEMENTED;
-    if (!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)) return MI355CV_NOT_IMPLEMENTED;
+    if (!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)");
+    if (!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)");
     uint16_t kx[33], ky[33];
-    for (size_t i = 0; i < ksize_width; i++) { if (qx[i] < 0 || qx[i] > 65535) return MI355CV_NOT_IMPLEMENTED; kx[i] = (uint16_t)qx[i]; }
-    for (size_t i = 0; i < ksize_height; i++) { if (qy[i] < 0 || qy[i] > 65535) return MI355CV_NOT_IMPLEMENTED; ky[i] = (uint16_t)qy[i]; }
+    for (size_t i = 0; i < ksize_width; i++) { if (qx[i] < 0 || qx[i] > 65535) return mi355::declined(__func__, __LINE__, "qx[i] < 0 || qx[i] > 65535"); kx[i] = (uint16_t)qx[i]; }
+    for (size_t i = 0; i < ksize_height; i++) { if (qy[i] < 0 || qy[i] > 65535) return mi355::declined(__func__, __LINE__, "qy[i] < 0 || qy[i] > 65535"); ky[i] = (uint16_t)qy[i]; }
     bool binom = ksize_width == ksize_height && (ksize_width == 3 || ksize_width == 5);
     if (binom) {
         const uint16_t* b = binomTaps(ksize_width);
@@ -832,7 +832,7 @@ MI355CV_API int mi355cv_setParam(const char* key, int value)
 // streaming-copy probe: copies `bytes` (multiple of 16) device->device with 16 B/lane accesses
 MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int perThread, int nt)
 {
-    if (!ensureDevice() || (bytes & 15) || perThread < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || (bytes & 15) || perThread < 1) return mi355::declined(__func__, __LINE__, "!ensureDevice() || (bytes & 15) || perThread < 1");
     size_t n16 = bytes / 16;
     size_t blocks = (n16 + (size_t)256 * perThread - 1) / ((size_t)256 * perThread);
     if (nt) hipLaunchKernelGGL((k_copy16<true>), dim3((unsigned)blocks), dim3(256), 0, stream(), (const uint4*)src, (uint4*)dst, n16, perThread);
@@ -844,7 +844,7 @@ MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int 
 
 MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int H, int nframes, int segRows, int unroll)
 {
-    if (!ensureDevice() || (W & 15)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice() || (W & 15)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || (W & 15)");
     const int nchunks = W / 16, nstrips = divUp(nchunks, 64), nseg = divUp(H, segRows);
     const long long items = (long long)nstrips * nseg * nframes;
     dim3 grid((unsigned)((items + 3) / 4));
@@ -862,7 +862,7 @@ MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int 
 MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps)
 {
     std::vector<int64_t> q;
-    if (!gaussianKernelFixedQ(n, sigma, fractionBits, q)) return MI355CV_NOT_IMPLEMENTED;
+    if (!gaussianKernelFixedQ(n, sigma, fractionBits, q)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ(n, sigma, fractionBits, q)");
     for (int i = 0; i < n; i++) taps[i] = q[i];
     return MI355CV_OK;
 }
@@ -870,7 +870,7 @@ MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits
 MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double* taps)
 {
     std::vector<double> k;
-    if (!gaussianKernelBitExact(n, sigma, k)) return MI355CV_NOT_IMPLEMENTED;
+    if (!gaussianKernelBitExact(n, sigma, k)) return mi355::declined(__func__, __LINE__, "!gaussianKernelBitExact(n, sigma, k)");
     for (int i = 0; i < n; i++) taps[i] = k[i];
     return MI355CV_OK;
 }
@@ -879,7 +879,7 @@ MI355CV_API int mi355cv_sepSmoothFixedU8(const uchar* src_data, size_t src_step,
         int width, int height, int cn, size_t margin_left, size_t margin_top, size_t margin_right, size_t margin_bottom,
         const uint16_t* kx, int kxlen, const uint16_t* ky, int kylen, int border_type)
 {
-    if (!kx || !ky) return MI355CV_NOT_IMPLEMENTED;
+    if (!kx || !ky) return mi355::declined(__func__, __LINE__, "!kx || !ky");
     bool binom = kxlen == kylen && (kxlen == 3 || kxlen == 5);
     if (binom) {
         const uint16_t* b = binomTaps(kxlen);

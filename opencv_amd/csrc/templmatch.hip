@@ -1083,12 +1083,12 @@ struct WOut { unsigned* w1; unsigned* w2; int wp; size_t wframe; };
 int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, int nframes, int iw, int ih,
              const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method, WOut* wout = nullptr)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int depth = MI355CV_MAT_DEPTH(type), cn = MI355CV_MAT_CN(type);
-    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > (wout ? 6 : 5)) return MI355CV_NOT_IMPLEMENTED;   // 6: internal, see k_tm_finish_planes
-    if (tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1) return MI355CV_NOT_IMPLEMENTED;   // the size swap of :1172-1182 is left to the caller
+    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > (wout ? 6 : 5)) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > (wout ? 6 : 5)");   // 6: internal, see k_tm_finish_planes
+    if (tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1) return mi355::declined(__func__, __LINE__, "tw < 1 || th < 1 || iw < tw || ih < th || nframes < 1");   // the size swap of :1172-1182 is left to the caller
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const int e = depth == D8U ? 1 : 4;
     const int rw = iw - tw + 1, rh = ih - th + 1;
     size_t dis = istep, dts, drs = rstep;
@@ -1096,11 +1096,11 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     if (nframes == 1) {
         di = stg.in(img, istep, (size_t)iw * cn * e, ih, &dis);
         dr = stg.out(res, rstep, (size_t)rw * 4, rh, &drs);
-        if (!di || !dr) return MI355CV_NOT_IMPLEMENTED;
-    } else if (!isDevicePtr(img) || !isDevicePtr(res)) return MI355CV_NOT_IMPLEMENTED;
+        if (!di || !dr) return mi355::declined(__func__, __LINE__, "!di || !dr");
+    } else if (!isDevicePtr(img) || !isDevicePtr(res)) return mi355::declined(__func__, __LINE__, "!isDevicePtr(img) || !isDevicePtr(res)");
     // the template stays where it is (a host template is staged like any input); its statistics are computed on the device
     const uchar* dt = stg.in(tpl, tstep, (size_t)tw * cn * e, th, &dts);
-    if (!dt) return MI355CV_NOT_IMPLEMENTED;
+    if (!dt) return mi355::declined(__func__, __LINE__, "!dt");
     NormArgs na; memset(&na, 0, sizeof na);
     na.method = method; na.cn = cn; na.tw = tw; na.th = th; na.rw = rw; na.rh = rh;
     const double area = (double)tw * th; na.invArea = 1. / area;
@@ -1128,10 +1128,10 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     if (needInt) {
         dsum = (double*)stg.scratch(iframeD * nframes * sizeof(double));
         dsq = (double*)stg.scratch(iframeD * nframes * sizeof(double));
-        if (!dsum || !dsq) return MI355CV_NOT_IMPLEMENTED;
+        if (!dsum || !dsq) return mi355::declined(__func__, __LINE__, "!dsum || !dsq");
         const int nseg = divUp(ih, IS_SEG);
         double* aux = (double*)stg.scratch((size_t)nseg * isteps * nframes * sizeof(double));
-        if (!aux) return MI355CV_NOT_IMPLEMENTED;
+        if (!aux) return mi355::declined(__func__, __LINE__, "!aux");
         hipLaunchKernelGGL(k_integral_rows<double>, dim3(ih, cn, nframes), dim3(256), 0, st, di, dis, iframe, iw, ih, cn, depth, dsum, isteps, iframeD, dsq, isteps, iframeD);
         integralColumns<double>(dsum, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
         integralColumns<double>(dsq, isteps, iframeD, (int)isteps, ih, nframes, aux, st);
@@ -1156,15 +1156,15 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         unsigned* w1 = (unsigned*)stg.scratch(wframe * nframes * 4);
         unsigned* w2 = (unsigned*)stg.scratch(wframe * nframes * 4);
         uchar* dtx = (uchar*)stg.scratch((size_t)th * MT_TPITCH);                // signed, zero-padded copy of the template in the kernels' LDS layout
-        if ((!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx) return MI355CV_NOT_IMPLEMENTED;
+        if ((!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx) return mi355::declined(__func__, __LINE__, "(!fused && (!s1 || !q1)) || !w1 || !w2 || !dtx");
         na.useW = 1; na.wp = wp;
         if (wout) { wout->w1 = w1; wout->w2 = w2; wout->wp = wp; wout->wframe = wframe; }
         const NormArgs* dna = uploadStats(dtx);
-        if (!dna) return MI355CV_NOT_IMPLEMENTED;
+        if (!dna) return mi355::declined(__func__, __LINE__, "!dna");
         const bool serial = std::getenv("MI355CV_TM_SERIAL") != nullptr;            // experiments: everything on one stream
         hipStream_t aux = serial ? st : auxStream();
         hipEvent_t evIn = pooledEvent(0), evDone = pooledEvent(1);
-        if ((!serial && !aux) || !evIn || !evDone) return MI355CV_NOT_IMPLEMENTED;
+        if ((!serial && !aux) || !evIn || !evDone) return mi355::declined(__func__, __LINE__, "(!serial && !aux) || !evIn || !evDone");
         const size_t lds = (size_t)(MT_BM + th - 1) * MT_PPITCH + (size_t)th * MT_TPITCH;
         const int KS = (tw + 62) / 32;
         (void)hipEventRecord(evIn, st);                               // inputs (staged copies, template) are ordered on the main stream
@@ -1265,7 +1265,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
 #undef BF_LAUNCH
                 if (method != 2) {
                     const NormArgs* dna = uploadStats(nullptr);
-                    if (!dna) return MI355CV_NOT_IMPLEMENTED;
+                    if (!dna) return mi355::declined(__func__, __LINE__, "!dna");
                     hipLaunchKernelGGL((k_wsum_rows<float, double>), dim3(ih, 1, nframes), dim3(256), (size_t)(iw + 1) * 8, st, di, dis, nframes > 1 ? iframe : 0, iw, tw, rw, s1, q1, s1frame);
                     hipLaunchKernelGGL((k_wsum_cols<double>), dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
                     hipLaunchKernelGGL(k_tm_finish_f, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, rf, drs, rfr, w1, w2, wframe, rw, dna);
@@ -1280,7 +1280,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
             hipLaunchKernelGGL(k_ccorr_direct, grid, dim3(256), 0, st, di, dis, iframe, dt, dts, tw, th, cn, depth, reinterpret_cast<float*>(dr), drs, rframe, rw, rh);
         if (method != 2) {
             const NormArgs* dna = uploadStats(nullptr);
-            if (!dna) return MI355CV_NOT_IMPLEMENTED;
+            if (!dna) return mi355::declined(__func__, __LINE__, "!dna");
             dim3 g2(divUp(rw, 64), divUp(rh, 4), nframes);
             hipLaunchKernelGGL(k_tm_normalize, g2, dim3(256), 0, st, reinterpret_cast<float*>(dr), drs, rframe, dsum, dsq, isteps, iframeD, dna);
         }
@@ -1325,20 +1325,20 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
                                  uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
 {
     (void)tilted_step;
-    if (disabled() || tilted_data || !sum_data) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || tilted_data || !sum_data) return mi355::declined(__func__, __LINE__, "disabled() || tilted_data || !sum_data");
     const bool ok = (depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F);
-    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
+    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4");
     const size_t se = sdepth == D32S ? 4 : 8;
-    if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return MI355CV_NOT_IMPLEMENTED;
-    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;     // would wrap; the CPU wraps its own way
+    if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return mi355::declined(__func__, __LINE__, "width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))");
+    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return mi355::declined(__func__, __LINE__, "sdepth == D32S && (double)width * height * 255.0 > 2147483647.0");     // would wrap; the CPU wraps its own way
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, d1, d2 = 0;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * (depth == D8U ? 1 : 4), height, &dss);
     uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * se, height + 1, &d1);
     uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * 8, height + 1, &d2) : nullptr;
-    if (!ds || !s1 || (sqsum_data && !s2)) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !s1 || (sqsum_data && !s2)) return mi355::declined(__func__, __LINE__, "!ds || !s1 || (sqsum_data && !s2)");
     const int Wc = (width + 1) * cn, nseg = divUp(height, IS_SEG);
     hipStream_t st = stream();
     static const bool tiledOff = getenv("MI355CV_INTEGRAL_TILED") && atoi(getenv("MI355CV_INTEGRAL_TILED")) == 0;
@@ -1349,7 +1349,7 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
             return stg.finish("integral");
     }
     void* aux = stg.scratch((size_t)nseg * Wc * 8);
-    if (!aux) return MI355CV_NOT_IMPLEMENTED;
+    if (!aux) return mi355::declined(__func__, __LINE__, "!aux");
     const size_t ldsFast = (((size_t)(width + 1) * se + 15) & ~(size_t)15) + (s2 ? (size_t)(width + 1) * 8 : 0);
     const bool fastRows = depth == D8U && cn == 1 && ldsFast <= 60 * 1024;
     if (sdepth == D32S) {
@@ -1371,10 +1371,10 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
 MI355CV_API int mi355cv_integralBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* sum_data, size_t sum_step, size_t sum_frame_stride,
                                       uchar* sqsum_data, size_t sqsum_step, size_t sqsum_frame_stride, int nframes, int width, int height, int sdepth)
 {
-    if (disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)");
     const size_t se = sdepth == D32S ? 4 : 8;
-    if ((sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))) return MI355CV_NOT_IMPLEMENTED;
-    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return MI355CV_NOT_IMPLEMENTED;
+    if ((sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))) return mi355::declined(__func__, __LINE__, "(sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))");
+    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return mi355::declined(__func__, __LINE__, "sdepth == D32S && (double)width * height * 255.0 > 2147483647.0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || !isDevicePtr(src_data) || !isDevicePtr(sum_data) || (sqsum_data && !isDevicePtr(sqsum_data)))
         return setError(MI355CV_NOT_IMPLEMENTED, "integralBatch: device-resident frames only");

@@ -145,23 +145,23 @@ extern "C" MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double
 extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                      double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C)
 {
-    if (disabled() || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
-    if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return MI355CV_NOT_IMPLEMENTED;
-    if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
+    if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return mi355::declined(__func__, __LINE__, "(adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)");
+    if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return mi355::declined(__func__, __LINE__, "blockSize < 3 || !(blockSize & 1) || blockSize > 255");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     double mv = nearbyint(maxValue); mv = mv < 0 ? 0 : mv > 255 ? 255 : mv;                       // saturate_cast<uchar>(maxValue)
     const int idelta = thresholdType == 0 ? (int)ceil(C) : (int)floor(C);
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height, 4));
     if (adaptiveMethod == 0) {
         const size_t mstep = ((size_t)width + 255) & ~(size_t)255;
         uchar* mean = (uchar*)stg.scratch(mstep * height);
-        if (!mean) return MI355CV_NOT_IMPLEMENTED;
+        if (!mean) return mi355::declined(__func__, __LINE__, "!mean");
         const int rc = mi355cv_boxFilter(ds, dss, mean, mstep, width, height, D8U, D8U, 1, 0, 0, 0, 0, (size_t)blockSize, (size_t)blockSize, -1, -1, true, B_REPLICATE);
         if (rc != MI355CV_OK) return rc;
         hipLaunchKernelGGL(k_adaptive, grid, dim3(256), 0, stream(), ds, dss, mean, mstep, dd, dds, width, height, idelta, (int)mv, thresholdType);
@@ -170,9 +170,9 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
     const size_t fstep = (((size_t)width + 63) & ~(size_t)63);                                     // floats per row of the two CV_32F planes
     float* sf = (float*)stg.scratch(fstep * 4 * height);
     float* mf = (float*)stg.scratch(fstep * 4 * height);
-    if (!sf || !mf) return MI355CV_NOT_IMPLEMENTED;
+    if (!sf || !mf) return mi355::declined(__func__, __LINE__, "!sf || !mf");
     std::vector<double> kd(blockSize);
-    if (mi355cv_getGaussianKernel(blockSize, 0.0, kd.data()) != MI355CV_OK) return MI355CV_NOT_IMPLEMENTED;
+    if (mi355cv_getGaussianKernel(blockSize, 0.0, kd.data()) != MI355CV_OK) return mi355::declined(__func__, __LINE__, "mi355cv_getGaussianKernel(blockSize, 0.0, kd.data()) != MI355CV_OK");
     std::vector<float> kf(kd.begin(), kd.end());                                                   // getGaussianKernel(n, sigma, CV_32F): the double taps stored as float
     cvhalFilter2D* ctx = nullptr;
     int rc = mi355cv_sepFilterInit(&ctx, MI355CV_MAKETYPE(MI355CV_32F, 1), MI355CV_MAKETYPE(MI355CV_32F, 1), MI355CV_MAKETYPE(MI355CV_32F, 1), (uchar*)kf.data(), blockSize,
@@ -189,18 +189,18 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
 extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                              int depth, int cn, double thresh, double maxValue, int thresholdType)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (thresholdType < 0 || thresholdType > 4) return MI355CV_NOT_IMPLEMENTED;
-    if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4");
+    if (thresholdType < 0 || thresholdType > 4) return mi355::declined(__func__, __LINE__, "thresholdType < 0 || thresholdType > 4");
+    if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return mi355::declined(__func__, __LINE__, "depth != D8U && depth != D16U && depth != D16S && depth != D32F");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
     const int n = width * cn;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)n * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)n * e, height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     const int epv = 16 / e;
     const int vec = ((((uintptr_t)ds | dss | (uintptr_t)dd | dds) & 15) == 0 && n % epv == 0) ? 1 : 0;
     const int perRow = vec ? n / epv : divUp(n, epv);
@@ -224,7 +224,7 @@ extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t 
                                                   size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn, double thresh, double maxValue,
                                                   int thresholdType)
 {
-    if (nframes < 1 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (nframes < 1 || height <= 0) return mi355::declined(__func__, __LINE__, "nframes < 1 || height <= 0");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(depth), height, nframes};
         return runHostBatch("thresholdBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {

@@ -968,6 +968,8 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
 }
 
 struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; int band /* XCD-banded tile order */; int gx, gy;
+                  int rel; /* WARP_RELATIVE_MAP: the map holds offsets, the destination pixel's own (x, y) is added to the INTEGER source coordinates after their
+                              saturation to short (imgwarp.cpp:354-359, :708-712: XY[dx*2] + _offset.x + dx) */
                   size_t sframe, dframe; /* bytes between the frames of a batch (grid z = frame) */ };
 
 // Tile order.  Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2, so with the plain
@@ -1092,13 +1094,15 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
         // for bilinear, the index of the weight-table entry (ay * 32 + ax); nearest rounds with the fraction's halves (NNDeltaTab_i :237-238)
         const short2 xy = reinterpret_cast<const short2*>(mapx + (size_t)y * mxstep)[x];
         const int a = w.kind == 4 ? (int)(reinterpret_cast<const unsigned short*>(mapy + (size_t)y * mystep)[x] & 1023) : 0;
-        if (s.linear) { samplePixel(src, sstep, D, s, xy.x, xy.y, a & 31, a >> 5, tab); return; }
+        const int rx = w.rel ? x : 0, ry = w.rel ? y : 0;
+        if (s.linear) { samplePixel(src, sstep, D, s, xy.x + rx, xy.y + ry, a & 31, a >> 5, tab); return; }
         const int dx = w.kind == 4 ? ((a & 31) < 16 ? 1 : 0) : 0, dy = w.kind == 4 ? ((a >> 5) < 16 ? 1 : 0) : 0;
-        samplePixel(src, sstep, D, s, (short)(xy.x + dx), (short)(xy.y + dy), 0, 0, tab);
+        samplePixel(src, sstep, D, s, (short)(xy.x + dx) + rx, (short)(xy.y + dy) + ry, 0, 0, tab);
         return;
     }
-    if (s.linear) samplePixel(src, sstep, D, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tab);
-    else samplePixel(src, sstep, D, s, satShort(X), satShort(Y), 0, 0, tab);
+    const int rx = w.rel ? x : 0, ry = w.rel ? y : 0;
+    if (s.linear) samplePixel(src, sstep, D, s, satShort(X >> 5) + rx, satShort(Y >> 5) + ry, X & 31, Y & 31, tab);
+    else samplePixel(src, sstep, D, s, satShort(X) + rx, satShort(Y) + ry, 0, 0, tab);
 }
 
 // cv::convertMaps, float -> fixed point (imgwarp.cpp:2017-2120): ix = cvRound(x * 32), dst1 = (ix >> 5, iy >> 5) saturated to short,
@@ -1429,20 +1433,22 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const double* M, int kind, int interpolation, int borderType, const double* bv,
             const float* mapx, size_t mxstep, const float* mapy, size_t mystep, int nframes = 1, size_t sframe = 0, size_t dframe = 0)
 {
-    if (disabled()) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if (!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0");
+    const bool relative = (interpolation & 32) != 0 && kind >= 2 && kind <= 5;              // WARP_RELATIVE_MAP (cv::remap only, imgwarp.cpp:1724)
+    if (relative) interpolation &= ~32;
     if (interpolation == MI355CV_INTER_AREA) interpolation = MI355CV_INTER_LINEAR;          // imgwarp.cpp:2818
-    if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR) return MI355CV_NOT_IMPLEMENTED;
-    if (borderType < 0 || borderType > B_TRANSPARENT) return MI355CV_NOT_IMPLEMENTED;
-    if (sw > 32767 || sh > 32767) return MI355CV_NOT_IMPLEMENTED;                         // coordinates saturate to short in the reference
+    if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR) return mi355::declined(__func__, __LINE__, "interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR");
+    if (borderType < 0 || borderType > B_TRANSPARENT) return mi355::declined(__func__, __LINE__, "borderType < 0 || borderType > B_TRANSPARENT");
+    if (sw > 32767 || sh > 32767) return mi355::declined(__func__, __LINE__, "sw > 32767 || sh > 32767");                         // coordinates saturate to short in the reference
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src, (size_t)dw * dh, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src, (size_t)dw * dh, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src, (size_t)dw * dh, minPixels(HOST_HEAVY))");
     if (nframes < 1 || (nframes > 1 && (!isDevicePtr(src) || !isDevicePtr(dst))))
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const short* g_tabDev = deviceTab();
-    if (!g_tabDev) return MI355CV_NOT_IMPLEMENTED;
+    if (!g_tabDev) return mi355::declined(__func__, __LINE__, "!g_tabDev");
     const int e = eszOf(depth);
     size_t dss, dds, mxs = mxstep, mys = mystep;
     const uchar* ds = stg.in(src, sstep, (size_t)sw * cn * e, sh, &dss);
@@ -1451,35 +1457,35 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // untouched pixels must keep their previous contents: stage dst in as well
         const uchar* din = stg.in(dst, dstep, (size_t)dw * cn * e, dh, &dds);
         size_t dds2; dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds2);
-        if (!din || !dd) return MI355CV_NOT_IMPLEMENTED;
-        if (hipMemcpy2DAsync(dd, dds2, din, dds, (size_t)dw * cn * e, dh, hipMemcpyDeviceToDevice, stream()) != hipSuccess) return MI355CV_NOT_IMPLEMENTED;
+        if (!din || !dd) return mi355::declined(__func__, __LINE__, "!din || !dd");
+        if (hipMemcpy2DAsync(dd, dds2, din, dds, (size_t)dw * cn * e, dh, hipMemcpyDeviceToDevice, stream()) != hipSuccess) return mi355::declined(__func__, __LINE__, "hipMemcpy2DAsync(dd, dds2, din, dds, (size_t)dw * cn * e, dh, hipMemcpyDeviceToDevice, stream()) != hipSuccess");
         dds = dds2;
     } else dd = stg.out(dst, dstep, (size_t)dw * cn * e, dh, &dds);
     const uchar* dmx = nullptr; const uchar* dmy = nullptr;
     if (kind == 2) {
         dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
         dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 4, dh, &mys);
-        if (!dmx || !dmy) return MI355CV_NOT_IMPLEMENTED;
+        if (!dmx || !dmy) return mi355::declined(__func__, __LINE__, "!dmx || !dmy");
     } else if (kind == 3) {                                                                  // one CV_32FC2 map
         dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 8, dh, &mxs);
-        if (!dmx) return MI355CV_NOT_IMPLEMENTED;
+        if (!dmx) return mi355::declined(__func__, __LINE__, "!dmx");
     } else if (kind == 4 || kind == 5) {                                                     // CV_16SC2 (+ CV_16UC1 fractions)
         dmx = stg.in((const uchar*)mapx, mxstep, (size_t)dw * 4, dh, &mxs);
         if (kind == 4) dmy = stg.in((const uchar*)mapy, mystep, (size_t)dw * 2, dh, &mys);
-        if (!dmx || (kind == 4 && !dmy)) return MI355CV_NOT_IMPLEMENTED;
+        if (!dmx || (kind == 4 && !dmy)) return mi355::declined(__func__, __LINE__, "!dmx || (kind == 4 && !dmy)");
     } else if (kind == 7) {                                                                  // inverse warpPolar: the 512-float log table (host array)
         dmx = (const uchar*)stg.param(mapx, 512 * sizeof(float));
-        if (!dmx) return MI355CV_NOT_IMPLEMENTED;
+        if (!dmx) return mi355::declined(__func__, __LINE__, "!dmx");
     } else if (kind == 6) {                                                                  // warpPolar tables (host arrays: dw radii, dh (cos, sin) pairs)
         dmx = (const uchar*)stg.param(mapx, (size_t)dw * 4);
         dmy = (const uchar*)stg.param(mapy, (size_t)dh * 16);
-        if (!dmx || !dmy) return MI355CV_NOT_IMPLEMENTED;
+        if (!dmx || !dmy) return mi355::declined(__func__, __LINE__, "!dmx || !dmy");
     }
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR; s.border = borderType;
     for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
     WarpArgs w; memset(&w, 0, sizeof w);
-    w.dw = dw; w.dh = dh; w.kind = kind;
+    w.dw = dw; w.dh = dh; w.kind = kind; w.rel = relative ? 1 : 0;
     w.sframe = nframes > 1 ? sframe : 0; w.dframe = nframes > 1 ? dframe : 0;
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : kind == 7 ? 5 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
@@ -1561,9 +1567,9 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
                      uchar* dst_data, size_t dst_step, size_t dst_frame, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y,
                      int interpolation)
 {
-    if (disabled() || nframes < 1) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || nframes < 1");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if (!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0");
     if (inv_scale_x < 2.220446049250313e-16 || inv_scale_y < 2.220446049250313e-16) {        // resize.cpp:3834-3838
         inv_scale_x = (double)dst_width / src_width; inv_scale_y = (double)dst_height / src_height;
     }
@@ -1575,7 +1581,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     if (interpolation == MI355CV_INTER_NEAREST) a.mode = 0;
     else if (interpolation == MI355CV_INTER_NEAREST_EXACT) {
         // resizeNN_bitexact (resize.cpp:1267-1289): source pixel = (ifx * x + ifx0) >> 16 in int arithmetic, steps rounded to 16.16, pixel centres aligned
-        if (src_width >= 32768 || src_height >= 32768) return MI355CV_NOT_IMPLEMENTED;          // (size << 16) must stay an int, as in the reference
+        if (src_width >= 32768 || src_height >= 32768) return mi355::declined(__func__, __LINE__, "src_width >= 32768 || src_height >= 32768");          // (size << 16) must stay an int, as in the reference
         a.mode = 0; a.nnExact = 1;
         a.ifx = ((src_width << 16) + dst_width / 2) / dst_width; a.ifx0 = a.ifx / 2 - src_width % 2;
         a.ify = ((src_height << 16) + dst_height / 2) / dst_height; a.ify0 = a.ify / 2 - src_height % 2;
@@ -1591,11 +1597,11 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         }
         else if (interpolation == 2 /*INTER_CUBIC*/) a.mode = 5;
         else if (interpolation == 4 /*INTER_LANCZOS4*/) a.mode = 6;
-        else return MI355CV_NOT_IMPLEMENTED;                                                // LINEAR_EXACT on other depths
+        else return mi355::declined(__func__, __LINE__, nullptr);                                                // LINEAR_EXACT on other depths
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-    if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))");
     const int e = eszOf(depth);
     if (nframes > 1) {
         // batches are an HBM-resident construct; nearest / bilinear / area-fast run as ONE launch (grid z = frame), the table-driven modes frame by frame
@@ -1613,7 +1619,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)src_width * cn * e, src_height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)dst_width * cn * e, dst_height, &dds);
-    if (!ds || !dd) return MI355CV_NOT_IMPLEMENTED;
+    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     if (a.mode == 5 || a.mode == 6) {
         dim3 gt(divUp(dst_width * cn, 64), divUp(dst_height, 16)), g1(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         int rows = 0, unused = 0;
@@ -1634,7 +1640,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         if (a.mode == 5) {
             const CubicTap *dxt, *dyt;
             if (!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused, &keepX) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows, &keepY))
-                return MI355CV_NOT_IMPLEMENTED;
+                return mi355::declined(__func__, __LINE__, "!cachedTab<CubicTap>(5, dst_width, a.scale_x, 4, buildCubicTab, &dxt, &unused, &keepX) || !cachedTab<CubicTap>(5, dst_height, a.scale_y, 4, buildCubicTab, &dyt, &rows, &keepY)");
             const TapT<4>* tx = reinterpret_cast<const TapT<4>*>(dxt); const TapT<4>* ty = reinterpret_cast<const TapT<4>*>(dyt);
 #define RZ_TILED(T_, NT_) hipLaunchKernelGGL((k_resize_tiled<T_, NT_>), gt, dim3(256), (size_t)rows * 256, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, tx, ty)
 #define RZ_BY_DEPTH(M_) do { if (depth == D8U) M_(uchar); else if (depth == D16U) M_(unsigned short); else if (depth == D16S) M_(short); else M_(float); } while (0)
@@ -1647,7 +1653,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         } else {
             const LanczosTap *dxt, *dyt;
             if (!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused, &keepX) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows, &keepY))
-                return MI355CV_NOT_IMPLEMENTED;
+                return mi355::declined(__func__, __LINE__, "!cachedTab<LanczosTap>(6, dst_width, a.scale_x, 8, buildLanczosTab, &dxt, &unused, &keepX) || !cachedTab<LanczosTap>(6, dst_height, a.scale_y, 8, buildLanczosTab, &dyt, &rows, &keepY)");
             const TapT<8>* tx = reinterpret_cast<const TapT<8>*>(dxt); const TapT<8>* ty = reinterpret_cast<const TapT<8>*>(dyt);
 #define RZ_T8(T_) RZ_TILED(T_, 8)
 #define RZ_L(T_) hipLaunchKernelGGL(k_resize_lanczos<T_>, g1, dim3(256), 0, stream(), ds, dss, dd, dds, src_width, src_height, dst_width, dst_height, cn, dxt, dyt)
@@ -1669,7 +1675,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         const ExactTap *dx, *dy;
         DevRef keepX, keepY;                                        // the tables stay alive until the launch below is enqueued
         if (!cachedExactTab(inv_scale_x, src_width, dst_width, shift, &dx, &keepX) || !cachedExactTab(inv_scale_y, src_height, dst_height, shift, &dy, &keepY))
-            return MI355CV_NOT_IMPLEMENTED;
+            return mi355::declined(__func__, __LINE__, "!cachedExactTab(inv_scale_x, src_width, dst_width, shift, &dx, &keepX) || !cachedExactTab(inv_scale_y, src_height, dst_height, shift, &dy, &keepY)");
         dim3 g7(divUp(dst_width * cn, 64), divUp(dst_height, 4));
         if (depth == D8U) hipLaunchKernelGGL((k_resize_exact<uchar, 8>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
         else if (depth == D16U) hipLaunchKernelGGL((k_resize_exact<unsigned short, 16>), g7, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, dx, dy);
@@ -1693,7 +1699,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
     }
     if (a.mode == 4) {
         AreaDev ax, ay;
-        if (!cachedAreaTab(src_width, dst_width, a.scale_x, &ax) || !cachedAreaTab(src_height, dst_height, a.scale_y, &ay)) return MI355CV_NOT_IMPLEMENTED;
+        if (!cachedAreaTab(src_width, dst_width, a.scale_x, &ax) || !cachedAreaTab(src_height, dst_height, a.scale_y, &ay)) return mi355::declined(__func__, __LINE__, "!cachedAreaTab(src_width, dst_width, a.scale_x, &ax) || !cachedAreaTab(src_height, dst_height, a.scale_y, &ay)");
         const AreaTap* dxt = ax.tab; const int* dxo = ax.ofs; const AreaTap* dyt = ay.tab; const int* dyo = ay.ofs;
         dim3 g4(divUp(dst_width * cn, 64), divUp(dst_height, 4));
 #define RA(T_) hipLaunchKernelGGL(k_resize_area<T_>, g4, dim3(256), 0, stream(), ds, dss, dd, dds, dst_width, dst_height, cn, depth, dxt, dxo, dyt, dyo)
@@ -1770,7 +1776,7 @@ MI355CV_API int mi355cv_warpAffineBatch(int src_type, const uchar* src_data, siz
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[6], int interpolation, int borderType,
         const double borderValue[4])
 {
-    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (!M) return mi355::declined(__func__, __LINE__, "!M");
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
         // such a batch goes frame by frame through the single-image path, which stages dst in as well
@@ -1796,7 +1802,7 @@ MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const uchar* src_data
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[9], int interpolation, int borderType,
         const double borderValue[4])
 {
-    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (!M) return mi355::declined(__func__, __LINE__, "!M");
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
         // such a batch goes frame by frame through the single-image path, which stages dst in as well
@@ -1822,7 +1828,7 @@ MI355CV_API int mi355cv_warpAffine(int src_type, const uchar* src_data, size_t s
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[6], int interpolation, int borderType,
         const double borderValue[4])
 {
-    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (!M) return mi355::declined(__func__, __LINE__, "!M");
     return runWarp("warpAffine", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 0, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
 }
@@ -1831,7 +1837,7 @@ MI355CV_API int mi355cv_warpPerspective(int src_type, const uchar* src_data, siz
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[9], int interpolation, int borderType,
         const double borderValue[4])
 {
-    if (!M) return MI355CV_NOT_IMPLEMENTED;
+    if (!M) return mi355::declined(__func__, __LINE__, "!M");
     return runWarp("warpPerspective", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 1, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
 }
@@ -1840,7 +1846,7 @@ MI355CV_API int mi355cv_remap32f(int src_type, const uchar* src_data, size_t src
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step, float* mapy, size_t mapy_step,
         int interpolation, int border_type, const double border_value[4])
 {
-    if (!mapx || !mapy) return MI355CV_NOT_IMPLEMENTED;
+    if (!mapx || !mapy) return mi355::declined(__func__, __LINE__, "!mapx || !mapy");
     return runWarp("remap32f", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    nullptr, 2, interpolation, border_type, border_value, mapx, mapx_step, mapy, mapy_step);
 }
@@ -1852,12 +1858,12 @@ MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_st
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const void* map1, size_t map1_step, int map1_type,
         const void* map2, size_t map2_step, int map2_type, int interpolation, int border_type, const double border_value[4])
 {
-    if (!map1) return MI355CV_NOT_IMPLEMENTED;
+    if (!map1) return mi355::declined(__func__, __LINE__, "!map1");
     const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
     const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
-    if (interpolation & 32) return MI355CV_NOT_IMPLEMENTED;                                   // WARP_RELATIVE_MAP
     int interp = interpolation & 7;
     if (interp == MI355CV_INTER_AREA) interp = MI355CV_INTER_LINEAR;
+    interp |= interpolation & 32;                                                              // WARP_RELATIVE_MAP travels to runWarp
     if (map2 && map2_type == t16sc2 && (map1_type == t16uc1 || map1_type == t16sc1)) {        // either order is accepted (:1905-1909)
         std::swap(map1, map2); std::swap(map1_step, map2_step); std::swap(map1_type, map2_type);
     }
@@ -1865,8 +1871,8 @@ MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_st
     if (map1_type == t32fc1 && map2 && map2_type == t32fc1) kind = 2;
     else if (map1_type == t32fc2 && !map2) kind = 3;
     else if (map1_type == t16sc2 && map2 && (map2_type == t16uc1 || map2_type == t16sc1)) kind = 4;
-    else if (map1_type == t16sc2 && !map2 && interp == MI355CV_INTER_NEAREST) kind = 5;
-    else return MI355CV_NOT_IMPLEMENTED;
+    else if (map1_type == t16sc2 && !map2 && (interp & 7) == MI355CV_INTER_NEAREST) kind = 5;
+    else return mi355::declined(__func__, __LINE__, nullptr);
     return runWarp("remap", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    nullptr, kind, interp, border_type, border_value, (const float*)map1, map1_step, (const float*)map2, map2_step);
 }
@@ -1876,16 +1882,16 @@ MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1_type, const void* map2, size_t map2_step, int map2_type,
         void* dstmap1, size_t dstmap1_step, int dstmap1_type, void* dstmap2, size_t dstmap2_step, int width, int height, int nninterpolate)
 {
-    if (disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0");
     const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
     const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
     const bool toFixed = dstmap1_type == t16sc2 && ((map1_type == t32fc1 && map2 && map2_type == t32fc1) || (map1_type == t32fc2 && !map2));
     const bool toFloat = map1_type == t16sc2 && (!map2 || map2_type == t16uc1 || map2_type == t16sc1) && (dstmap1_type == t32fc1 || dstmap1_type == t32fc2);
-    if (!toFixed && !toFloat) return MI355CV_NOT_IMPLEMENTED;
-    if (toFixed && !nninterpolate && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
-    if (toFloat && dstmap1_type == t32fc1 && !dstmap2) return MI355CV_NOT_IMPLEMENTED;
+    if (!toFixed && !toFloat) return mi355::declined(__func__, __LINE__, "!toFixed && !toFloat");
+    if (toFixed && !nninterpolate && !dstmap2) return mi355::declined(__func__, __LINE__, "toFixed && !nninterpolate && !dstmap2");
+    if (toFloat && dstmap1_type == t32fc1 && !dstmap2) return mi355::declined(__func__, __LINE__, "toFloat && dstmap1_type == t32fc1 && !dstmap2");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     size_t s1 = 0, s2 = 0, o1 = 0, o2 = 0;
     const size_t e1 = map1_type == t32fc1 ? 4 : map1_type == t32fc2 ? 8 : 4;
     const uchar* a = stg.in((const uchar*)map1, map1_step, (size_t)width * e1, height, &s1);
@@ -1894,7 +1900,7 @@ MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1
     uchar* c = stg.out((uchar*)dstmap1, dstmap1_step, (size_t)width * f1, height, &o1);
     const bool needD2 = toFixed ? !nninterpolate : dstmap1_type == t32fc1;
     uchar* d = needD2 ? stg.out((uchar*)dstmap2, dstmap2_step, (size_t)width * (toFixed ? 2 : 4), height, &o2) : nullptr;
-    if (!a || (map2 && !b) || !c || (needD2 && !d)) return MI355CV_NOT_IMPLEMENTED;
+    if (!a || (map2 && !b) || !c || (needD2 && !d)) return mi355::declined(__func__, __LINE__, "!a || (map2 && !b) || !c || (needD2 && !d)");
     dim3 grid(divUp(width, 64), divUp(height, 4));
     if (toFixed) hipLaunchKernelGGL(k_convert_maps_to_fixed, grid, dim3(256), 0, stream(), a, s1, b, s2, map1_type == t32fc2 ? 1 : 0, c, o1, d, o2, width, height, nninterpolate ? 1 : 0);
     else hipLaunchKernelGGL(k_convert_maps_to_float, grid, dim3(256), 0, stream(), a, s1, b, s2, c, o1, d, o2, dstmap1_type == t32fc2 ? 1 : 0, width, height);
@@ -1908,22 +1914,22 @@ MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1
 MI355CV_API int mi355cv_warpPolar(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags)
 {
-    if (disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0) return MI355CV_NOT_IMPLEMENTED;
+    if (disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0");
     const bool semiLog = (flags & 256) != 0;                                                  // WARP_POLAR_LOG
     const double bv[4] = {0, 0, 0, 0};
     if (flags & MI355CV_WARP_INVERSE_MAP) {
         // polar / semi-log polar image -> Cartesian image (imgwarp.cpp:3795-3845): the source gets one wrapped row above and below (copyMakeBorder BORDER_WRAP),
         // the map is evaluated per destination pixel in the kernel (k_warp kind 7), then cv::remap's sampling
         const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-        if (!depthOk(depth) || cn < 1 || cn > 4 || src_height + 2 > 32767) return MI355CV_NOT_IMPLEMENTED;
+        if (!depthOk(depth) || cn < 1 || cn > 4 || src_height + 2 > 32767) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 4 || src_height + 2 > 32767");
         Stager outer;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice()) return MI355CV_NOT_IMPLEMENTED;
-        if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(HOST_HEAVY))) return MI355CV_NOT_IMPLEMENTED;
+        if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+        if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(HOST_HEAVY))");
         const size_t rowB = (size_t)src_width * cn * eszOf(depth), bstep = (rowB + 255) & ~(size_t)255;
         size_t dss;
         const uchar* ds = outer.in(src_data, src_step, rowB, src_height, &dss);
         uchar* bordered = (uchar*)outer.scratch(bstep * (size_t)(src_height + 2));
-        if (!ds || !bordered) return MI355CV_NOT_IMPLEMENTED;
+        if (!ds || !bordered) return mi355::declined(__func__, __LINE__, "!ds || !bordered");
         hipStream_t st = stream();
         if (hipMemcpy2DAsync(bordered + bstep, bstep, ds, dss, rowB, src_height, hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(bordered, ds + (size_t)(src_height - 1) * dss, rowB, hipMemcpyDeviceToDevice, st) != hipSuccess ||

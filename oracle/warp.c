@@ -641,6 +641,11 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
                  int depth, int cn, const float* mapx, size_t mxstep, const float* mapy, size_t mystep,
                  int interpolation, int border, const double* bv)
 {
+    /* WARP_RELATIVE_MAP (bit 5; imgwarp.cpp:1724, remapNearest :354-359, remapBilinear :708-712): the destination pixel's own (x, y) is added to the
+     * integer source coordinates AFTER their saturation to short */
+    const int rel = (interpolation & 32) != 0;
+    interpolation &= ~32;
+    if (interpolation == 3) interpolation = 1;
     if (interpolation != 0 && interpolation != 1) return 1;
     const int e = esz(depth);
     for (int y = 0; y < dh; y++) {
@@ -650,10 +655,10 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
             uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
             if (interpolation == 1) {
                 int sx = sat_int_d((double)(mx[x] * 32.f)), sy = sat_int_d((double)(my[x] * 32.f));
-                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5), sat_short_i(sy >> 5), sx & 31, sy & 31, 1, border, bv);
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + (rel ? x : 0), sat_short_i(sy >> 5) + (rel ? y : 0), sx & 31, sy & 31, 1, border, bv);
             } else {
                 int sx = sat_int_d((double)mx[x]), sy = sat_int_d((double)my[x]);
-                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx), sat_short_i(sy), 0, 0, 0, border, bv);
+                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx) + (rel ? x : 0), sat_short_i(sy) + (rel ? y : 0), 0, 0, 0, border, bv);
             }
         }
     }
@@ -666,28 +671,31 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
 int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh, int depth, int cn,
                   const void* map1, size_t m1step, const void* map2, size_t m2step, int kind, int interpolation, int border, const double* bv)
 {
+    const int rel = (interpolation & 32) != 0;                  /* WARP_RELATIVE_MAP, as in orc_remap32f */
+    interpolation &= ~32;
     if (interpolation == 3) interpolation = 1;
     if (interpolation != 0 && interpolation != 1) return 1;
     const int e = esz(depth);
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
+            const int rx = rel ? x : 0, ry = rel ? y : 0;
             if (kind == 3) {
                 const float* m = (const float*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
                 if (interpolation == 1) {
                     int sx = sat_int_d((double)(m[0] * 32.f)), sy = sat_int_d((double)(m[1] * 32.f));
-                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5), sat_short_i(sy >> 5), sx & 31, sy & 31, 1, border, bv);
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + rx, sat_short_i(sy >> 5) + ry, sx & 31, sy & 31, 1, border, bv);
                 } else {
                     int sx = sat_int_d((double)m[0]), sy = sat_int_d((double)m[1]);
-                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx), sat_short_i(sy), 0, 0, 0, border, bv);
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx) + rx, sat_short_i(sy) + ry, 0, 0, 0, border, bv);
                 }
             } else {
                 const short* xy = (const short*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
                 const int a = kind == 4 ? (((const uint16_t*)((const uint8_t*)map2 + (size_t)y * m2step))[x] & 1023) : 0;
-                if (interpolation == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, xy[0], xy[1], a & 31, a >> 5, 1, border, bv);
+                if (interpolation == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, xy[0] + rx, xy[1] + ry, a & 31, a >> 5, 1, border, bv);
                 else {
                     const int dx = kind == 4 ? (a & 31) < 16 : 0, dy = kind == 4 ? (a >> 5) < 16 : 0;
-                    sample_pixel(src, sstep, sw, sh, D, depth, cn, (short)(xy[0] + dx), (short)(xy[1] + dy), 0, 0, 0, border, bv);
+                    sample_pixel(src, sstep, sw, sh, D, depth, cn, (short)(xy[0] + dx) + rx, (short)(xy[1] + dy) + ry, 0, 0, 0, border, bv);
                 }
             }
         }

@@ -23,6 +23,9 @@ def test_median(cv, orc, cn, ksize):
         src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
         got = cv.medianBlur(torch.from_numpy(src).cuda(), ksize).cpu().numpy()
         assert np.array_equal(got, orc.orc_medianBlur(src, ksize)), (w, h, cn, ksize)
+        if w >= 64:                                   # wide enough for the rolling path whatever the row raggedness (roll.h eligible)
+            from opencv_amd import _lib
+            assert ("k_median_roll<%d,%d," % (ksize, cn)) in _lib.lib.mi355cv_lastKernel().decode(), (w, h, cn, ksize, _lib.lib.mi355cv_lastKernel().decode())
     # salt-and-pepper on a ramp: the textbook use; constant images stay constant
     ramp = np.tile(np.arange(64, dtype=np.uint8) * 4, (40, 1))
     noisy = ramp.copy(); noisy[rng.random(ramp.shape) < 0.05] = 255; noisy[rng.random(ramp.shape) < 0.05] = 0

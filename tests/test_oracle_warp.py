@@ -265,3 +265,26 @@ def test_resize_nearest_exact(orc, ref, dtype, cn):
     even = rnd(orc, (36, 52, cn) if cn > 1 else (36, 52), dtype, 5)
     for dsize in [(13, 9), (104, 72), (51, 35)]:
         assert np.array_equal(orc.orc_resize(even, dsize, interpolation=6), orc.ref_resize(even, dsize, interpolation=6)), (dsize, dtype, cn)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_remap_relative_maps(orc, ref, dtype):
+    """WARP_RELATIVE_MAP (imgwarp.cpp:1724; Imgproc_RemapRelative.validity in the reference's suite): the maps hold offsets from the destination pixel, added to the
+    integer coordinates after their saturation to short -- every map representation, nearest and bilinear, several borders"""
+    REL = 32
+    src = rnd(orc, (40, 50, 3), dtype, 61)
+    rng = np.random.default_rng(8)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    offx[2, 3] = 40000.0; offy[5, 6] = -40000.0                 # saturate to short BEFORE the pixel's own coordinate is added
+    xy = np.ascontiguousarray(np.stack([offx, offy], axis=-1))
+    f1, f2 = orc.ref_convertMaps(offx, offy, "16sc2", False)
+    n1, _ = orc.ref_convertMaps(offx, offy, "16sc2", True)
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0)]:
+            same(orc, orc.orc_remap(src, offx, offy, interp | REL, border, bval), orc.ref_remap(src, offx, offy, interp | REL, border, bval))
+            same(orc, orc.orc_remapMaps(src, xy, None, interp | REL, border, bval), orc.ref_remapMaps(src, xy, None, interp | REL, border, bval))
+            same(orc, orc.orc_remapMaps(src, f1, f2, interp | REL, border, bval), orc.ref_remapMaps(src, f1, f2, interp | REL, border, bval))
+    same(orc, orc.orc_remapMaps(src, n1, None, 0 | REL, 1, 0), orc.ref_remapMaps(src, n1, None, 0 | REL, 1, 0))
+    # an identity in relative form is the image itself
+    z = np.zeros((40, 50), np.float32)
+    assert np.array_equal(orc.orc_remap(src, z, z, 1 | REL, 1, 0), src)

@@ -183,7 +183,6 @@ def test_orb_frames_across_host_threads(cv, orc):
     assert not errors, errors
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("MI355CV_TEST_ORB_RANDOM"), reason="written after the round's GPU budget was spent: set MI355CV_TEST_ORB_RANDOM=1 (first GPU call of the next round)")
 def test_orb_random_parameter_sets(cv, orc):
     """the thirty seeded random parameter sets of tests/test_oracle_orb.py (restatement == reference on each) through the GPU path"""
     rng = np.random.default_rng(2024)

@@ -74,6 +74,9 @@ def test_ledger_on_the_fallback_names_every_hook_call_as_declined():
         for h, n in t["declined"].items():
             declined[h] = declined.get(h, 0) + n
     assert declined.get("gaussianBlurBinomial", 0) > 0 and declined.get("cvtBGRtoGray", 0) > 0 and declined.get("warpAffine", 0) > 0, declined
+    # every decline names its reason ("make every decline call setError"); here: no usable device
+    unexplained = sorted((name, h, r) for name, t in tests.items() for h, r in t["reasons"].items() if "no reason recorded" in r or not r.strip())
+    assert not unexplained, unexplained[:10]
 
 
 def test_reference_tests_pass_on_the_fallback():
@@ -138,6 +141,8 @@ def test_ledger_of_the_reference_suite_on_the_gpu():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "reference_suite_ledger.txt"), "w").write("\n".join(lines) + "\n")
     assert len(gpu_only) + len(mixed) >= 150, (len(gpu_only), len(mixed), len(cpu_only))
+    unexplained = sorted((h, e[1]) for h, e in hooks.items() if "no reason recorded" in e[1] or not e[1].strip())
+    assert not unexplained, ("hooks that declined without saying why", unexplained)
     pinned = os.path.join(ROOT, "tests", "golden", "reference_suite_gpu_only.txt")
     if os.path.exists(pinned):
         want = [l.strip() for l in open(pinned) if l.strip() and not l.startswith("#")]

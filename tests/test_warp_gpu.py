@@ -393,3 +393,49 @@ def test_resize_bilinear_u8_on_the_lean_kernel(cv, orc, cn):
     out = cv.resizeBatch(dev(frames), (960, 540))
     for i in range(3):
         assert np.array_equal(out[i].cpu().numpy(), orc.orc_resize(frames[i], (960, 540))), i
+
+
+def test_dispatch_lands_on_the_lds_tile_kernels(cv, orc):
+    """the kernels whose arithmetic the host emulation (tests/test_hostemu.py) checks line by line are the ones the GPU calls land on --
+    asserted by name (mi355cv_lastKernel) next to the result's equality with the restatement: k_warp8_lean (8-bit affine, 1 / 3 channels), k_warp8_tile (what
+    the lean plan does not take), k_resize_tab8 (8-bit cubic upscale)."""
+    from opencv_amd import _lib
+    last = lambda: _lib.lib.mi355cv_lastKernel().decode()       # noqa: E731
+    for cn in (1, 3):
+        src = rnd((540, 960, cn) if cn > 1 else (540, 960), np.uint8, 70 + cn)
+        for ang, sc in ((7.0, 1.0), (90.0, 0.95), (-33.0, 1.1)):
+            M = cv.getRotationMatrix2D((480.0, 270.0), ang, sc)
+            got = cv.warpAffine(dev(src), M, (960, 540))
+            k = last()
+            assert "k_warp8_lean<%d," % cn in k, (cn, ang, k)
+            assert np.array_equal(got.cpu().numpy(), orc.orc_warpAffine(src, cv.invertAffineTransform(M), (960, 540))), (cn, ang, k)
+        up = cv.resize(dev(src[:270, :480]), (960, 540), interpolation=2)
+        k = last()
+        assert "k_resize_tab8<4>" in k, (cn, k)
+        assert np.array_equal(up.cpu().numpy(), orc.orc_resize(np.ascontiguousarray(src[:270, :480]), (960, 540), interpolation=2)), (cn, k)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_remap_relative_maps(cv, orc, dtype):
+    """WARP_RELATIVE_MAP through cv_hal_remap32f and mi355cv_remap (240 cases of the reference's Imgproc_RemapRelative ran on the fallback): offsets
+    from the destination pixel, every map representation, nearest and bilinear, device and host images"""
+    REL = 32
+    src = rnd((40, 50, 3), dtype, 61)
+    rng = np.random.default_rng(8)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    offx[2, 3] = 40000.0; offy[5, 6] = -40000.0
+    xy = np.ascontiguousarray(np.stack([offx, offy], axis=-1))
+    f1, f2 = orc.orc_convertMaps(offx, offy, "16sc2", False)
+    n1, _ = orc.orc_convertMaps(offx, offy, "16sc2", True)
+    n0 = cv.call_count("remap32f")
+    for interp in (0, 1):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (4, 0)]:
+            check(cv.remap(dev(src), dev(offx), dev(offy), interp | REL, border, bval), orc.orc_remap(src, offx, offy, interp | REL, border, bval))
+            check(cv.remap(dev(src), dev(xy), None, interp | REL, border, bval), orc.orc_remapMaps(src, xy, None, interp | REL, border, bval))
+            check(cv.remap(dev(src), dev(f1), dev(f2), interp | REL, border, bval), orc.orc_remapMaps(src, f1, f2, interp | REL, border, bval))
+    check(cv.remap(dev(src), dev(n1), None, 0 | REL, 1, 0), orc.orc_remapMaps(src, n1, None, 0 | REL, 1, 0))
+    check(cv.remap(src, offx, offy, 1 | REL, 1, 0), orc.orc_remap(src, offx, offy, 1 | REL, 1, 0))               # host arrays
+    assert cv.call_count("remap32f") == n0 + 9
+    big = rnd((1080, 1920), dtype, 62)
+    z = torch.zeros((1080, 1920), dtype=torch.float32, device="cuda")
+    assert np.array_equal(cv.remap(dev(big), z, z, 1 | REL, 1, 0).cpu().numpy(), big)                          # the relative identity

@@ -22,7 +22,17 @@ s16 = torch.empty((8, H4, W4), dtype=torch.int16, device="cuda")
 f32 = torch.empty((8, H4, W4), dtype=torch.float32, device="cuda")
 P3 = np.array([[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]])
 k5 = (np.arange(25, dtype=np.float32).reshape(5, 5) - 12) / 64
+f8k = torch.rand((2, 4320, 7680), dtype=torch.float32, device="cuda", generator=g)
+o8k = torch.empty_like(f8k)
+hd1 = torch.randint(0, 256, (64, 1080, 1920), dtype=torch.uint8, device="cuda", generator=g)
+fhd = torch.empty((64, 1080, 1920), dtype=torch.float32, device="cuda")
+tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device="cuda", generator=g)
 ROWS = {
+    "tm_cfg5":         lambda: cv.matchTemplateBatch(gray, tpl, 3),
+    "affine_8k_32f":   lambda: cv.warpAffineBatch(f8k, cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95), (7680, 4320), dst=o8k),
+    "harris_1080p":    lambda: cv.cornerHarrisBatch(hd1, 2, 3, 0.04, dst=fhd),
+    "pyramid_1080p":   lambda: cv.buildPyramidBatch(hd1, 4),
+    "integral_batch":  lambda: cv.integralBatch(gray),
     "cubic_up_8uc3":   lambda: [cv.resize(hd3[i], (W4, H4), interpolation=2, dst=up3[i]) for i in range(4)],
     "lanczos_up_8uc3": lambda: [cv.resize(hd3[i], (W4, H4), interpolation=4, dst=up3[i]) for i in range(4)],
     "persp_8uc1":      lambda: cv.warpPerspectiveBatch(gray, P3, (W4, H4), dst=out1),
