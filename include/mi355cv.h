@@ -86,6 +86,15 @@ MI355CV_API int  mi355cv_init(int device);
 MI355CV_API int  mi355cv_deviceCount(void);
 MI355CV_API int  mi355cv_setDevice(int device);
 MI355CV_API int  mi355cv_getDevice(void);
+/* Batches across the GPUs of one node from a C / C++ host (csrc/shard.hip): device slot g of ndev takes the g-th of ndev contiguous blocks of frames whose sizes
+ * differ by at most one ([g*B/ndev, (g+1)*B/ndev) when ndev divides B; the partition bench.py --gpus N and opencv_amd/shard.py use) -- and mi355cv_runSharded runs fn(user, slot, device, first, count) for every non-empty slot on its own host thread,
+ * bound to devices[slot] (NULL: ordinals 0 .. ndev-1; an ordinal may repeat) when bind != 0; fn calls the ordinary mi355cv_* entry points on its frames, which must live
+ * on that device (or in host / managed memory).  Returns 0, or the first non-zero code in slot order (mi355cv_lastError names slot and device).  There is no data-path
+ * collective: parameters given as host arguments are uploaded by each device's own hooks; a device-resident parameter image (a matchTemplate template) is copied to every
+ * device with mi355cv_replicate (hipMemcpy, peer-to-peer over xGMI between GPUs; RCCL is only used by the Python layer's torch.distributed broadcast). */
+MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int slot, int* first, int* count);
+MI355CV_API int  mi355cv_runSharded(int ndev, const int* devices, int nframes, int (*fn)(void* user, int slot, int device, int first, int count), void* user, int bind);
+MI355CV_API int  mi355cv_replicate(const void* src, size_t bytes, int ndev, const int* devices, void** out);
 MI355CV_API const char* mi355cv_version(void);
 MI355CV_API const char* mi355cv_lastError(void);
 /* template instance + launch geometry of the dominant kernel the calling thread launched last (bench.py reports it beside the roofline) */

@@ -9,6 +9,7 @@
 //                         buildPyramid :3308 (pyramids.cpp:1616), matchTemplate :3897 (templmatch.cpp:1158)
 #pragma once
 #include <climits>
+#include <type_traits>
 #include <vector>
 #include "opencv2/core.hpp"
 #include "opencv2/imgproc.hpp"
@@ -365,5 +366,17 @@ inline void calcOpticalFlowPyrLK(cv::InputArray _prevImg, cv::InputArray _nextIm
     cv::calcOpticalFlowPyrLK(_prevImg, _nextImg, _prevPts, _nextPts, _status, _err, winSize, maxLevel, criteria, flags, minEigThreshold);
 }
 #endif
+
+// Batches across the GPUs of one node from C++: forEachShard({0,1,...,7}, nframes, [&](int slot, int device, int first, int count) { ... return 0; })
+// runs the callable once per device on its own host thread bound to that device (mi355cv_runSharded, csrc/shard.hip), frames [first, first + count) being that
+// device's share; inside, call cv:: functions of a HAL-enabled build or mi355cv:: / mi355cv_*Batch entry points on Mats whose storage lives on `device`
+// (FrameAllocator::Device allocates on the calling thread's device).  Returns 0 or the first failing slot's code (mi355cv_lastError() says which and why).
+template <typename F>
+inline int forEachShard(const std::vector<int>& devices, int nframes, F&& body)
+{
+    struct Tr { static int call(void* u, int slot, int device, int first, int count) {
+        try { return (*static_cast<typename std::remove_reference<F>::type*>(u))(slot, device, first, count); } catch (...) { return MI355CV_ERROR_UNKNOWN; } } };
+    return mi355cv_runSharded((int)devices.size(), devices.data(), nframes, &Tr::call, (void*)&body, 1);
+}
 
 } // namespace mi355cv

@@ -18,6 +18,9 @@ c_int = ctypes.c_int
 c_dbl = ctypes.c_double
 
 
+SHARD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int)     # fn(user, slot, device, first, count) of mi355cv_runSharded
+
+
 class Mi355cvError(RuntimeError):
     pass
 
@@ -33,6 +36,9 @@ def _load():
         "mi355cv_deviceCount": (c_int, []),
         "mi355cv_setDevice": (c_int, [c_int]),
         "mi355cv_getDevice": (c_int, []),
+        "mi355cv_shardRange": (None, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+        "mi355cv_runSharded": (c_int, [c_int, ctypes.POINTER(c_int), c_int, SHARD_FN, ctypes.c_void_p, c_int]),
+        "mi355cv_replicate": (c_int, [ctypes.c_void_p, c_sz, c_int, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_void_p)]),
         "mi355cv_version": (ctypes.c_char_p, []),
         "mi355cv_lastError": (ctypes.c_char_p, []),
         "mi355cv_lastKernel": (ctypes.c_char_p, []),

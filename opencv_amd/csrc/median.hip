@@ -1,6 +1,7 @@
 // median.hip -- SURVEY.md §8 f1: cv_hal_medianBlur (hal_replacement.hpp:995; caller cv::medianBlur median_blur.dispatch.cpp:300).
 // Exact median of the ksize x ksize neighbourhood per channel, BORDER_REPLICATE (median_blur.simd.hpp: sort network :493-760,
-// histogram forms :63-490 -- all of them return the exact median).  CV_8U, ksize 3 and 5, 1/3/4 channels, on the roll.h skeleton:
+// histogram forms :63-490 -- all of them return the exact median).  CV_16U / CV_16S / CV_32F with apertures 3 and 5: k_median_typed; CV_8U with apertures
+// 7 .. 31: k_median_bits_u8 (both at the end of the file).  CV_8U, ksize 3 and 5, 1/3/4 channels, on the roll.h skeleton:
 // the last K source rows stay in registers as even/odd byte planes (two pixels per 32-bit lane), min / max are v_pk_min_u16 /
 // v_pk_max_u16.
 //   3x3: the three rows are sorted per column once (shared by the three outputs that use the column), then
@@ -147,24 +148,117 @@ __global__ __launch_bounds__(256) void k_median_generic(const uchar* __restrict_
     dst[(size_t)y * dstep + e] = (uchar)r;
 }
 
+// CV_16U / CV_16S / CV_32F, apertures 3 and 5, any channel count (medianBlur_SortNet<MinMax16u / 16s / 32f>, median_blur.simd.hpp:493-760, :862-868): thread per
+// element, the same min / max exchanges on T (`a < b ? a : b` as MinMax32f's std::min / std::max: identical for everything but NaN inputs)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void k_median_typed(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int cn)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, c = e - x * cn;
+    constexpr int R = K / 2;
+    T v[K * K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const T* row = reinterpret_cast<const T*>(src + (size_t)min(max(y + j - R, 0), H - 1) * sstep);
+#pragma unroll
+        for (int i = 0; i < K; i++) v[j * K + i] = row[min(max(x + i - R, 0), W - 1) * cn + c];
+    }
+#define CE(a, b) { const T lo_ = v[a] < v[b] ? v[a] : v[b]; v[b] = v[a] < v[b] ? v[b] : v[a]; v[a] = lo_; }
+    T r;
+    if constexpr (K == 3) {
+        CE(1, 2) CE(4, 5) CE(7, 8) CE(0, 1) CE(3, 4) CE(6, 7) CE(1, 2) CE(4, 5) CE(7, 8)          // the three rows sorted
+        CE(0, 3) CE(3, 6)                                                                            // v[6] = max of the lows
+        CE(5, 8) CE(2, 5)                                                                            // v[2] = min of the highs
+        CE(4, 7) CE(1, 4) CE(4, 7)                                                                   // v[4] = med3 of the mids
+        CE(2, 4) CE(4, 6) CE(2, 4)                                                                   // v[4] = med3(v[2], v[4], v[6])
+        r = v[4];
+    } else {
+        MI355_MEDIAN25_NET(CE)
+        r = v[12];
+    }
+#undef CE
+    reinterpret_cast<T*>(dst + (size_t)y * dstep)[e] = r;
+}
+
+// CV_8U, apertures 7 .. 31 (medianBlur_8u_Om / _O1 in the reference, median_blur.simd.hpp:84, :348 -- histogram walks; any exact selection gives the same image).
+// A workgroup owns 64 x 4 output elements; the replicate-padded source patch ((64 + 2R) cn x (4 + 2R) bytes) is staged in LDS once; each thread then finds its
+// median bit by bit from the top: the median is the largest m with #{v >= m} >= (K*K + 1) / 2, so 8 counting passes over the K*K window bytes in LDS.
+__global__ __launch_bounds__(256) void k_median_bits_u8(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int cn, int K)
+{
+    extern __shared__ uchar patch[];
+    const int R = K / 2;
+    const int pw = (64 + 2 * R) * cn, ph = 4 + 2 * R;            // patch bytes per row, rows
+    const int ppitch = (pw + 3) & ~3;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    for (int i = threadIdx.x; i < pw * ph; i += 256) {
+        const int py = i / pw, pb = i - py * pw;
+        const int px = pb / cn, c = pb - px * cn;
+        const int sx = min(max(x0 + px - R, 0), W - 1), sy = min(max(y0 + py - R, 0), H - 1);
+        patch[py * ppitch + pb] = src[(size_t)sy * sstep + (size_t)sx * cn + c];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= W || y >= H) return;
+    const int need = (K * K + 1) / 2;
+    for (int c = 0; c < cn; c++) {
+        const uchar* p0 = patch + ly * ppitch + lx * cn + c;
+        int cur = 0;
+        for (int bit = 128; bit; bit >>= 1) {
+            const int m = cur | bit;
+            int cnt = 0;
+            for (int j = 0; j < K; j++) {
+                const uchar* p = p0 + j * ppitch;
+                for (int i = 0; i < K; i++) cnt += p[i * cn] >= m ? 1 : 0;
+            }
+            cur = cnt >= need ? m : cur;
+        }
+        dst[(size_t)y * dstep + (size_t)x * cn + c] = (uchar)cur;
+    }
+}
+
 } // namespace
 
 extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int depth, int cn, int ksize)
 {
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
-    if (depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U || (ksize != 3 && ksize != 5) || !(cn == 1 || cn == 3 || cn == 4)");
+    const bool small = ksize == 3 || ksize == 5;
+    const bool typed = depth == MI355CV_16U || depth == MI355CV_16S || depth == MI355CV_32F;      // sort networks: apertures 3 and 5 only, any channel count (the reference asserts the same)
+    if (ksize < 3 || !(ksize & 1) || cn < 1) return mi355::declined(__func__, __LINE__, "ksize < 3 || !(ksize & 1) || cn < 1");
+    if (typed ? !small || cn > 512 : (depth != MI355CV_8U || ksize > 31 || (small ? cn > 512 : !(cn == 1 || cn == 3 || cn == 4))))
+        return setError(MI355CV_NOT_IMPLEMENTED, "medianBlur: depth %d, %d channel(s), aperture %d (served: CV_8U with apertures 3 and 5 or, with 1 / 3 / 4 channels, up to 31; CV_16U / CV_16S / CV_32F with apertures 3 and 5)", depth, cn, ksize);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const bool devSrc = isDevicePtr(src_data);
     if (!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)) return mi355::declined(__func__, __LINE__, "!devSrc && (size_t)width * height < minPixels(HOST_HEAVY)");
     if (devSrc && src_data == dst_data) return mi355::declined(__func__, __LINE__, "devSrc && src_data == dst_data");                  // in place on the device: a stencil cannot
+    const int esz = depth == MI355CV_8U ? 1 : depth == MI355CV_32F ? 4 : 2;
     size_t dss, dds;
-    const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn, height, &dss);
-    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn, height, &dds);
+    const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * esz, height, &dss);
+    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * cn * esz, height, &dds);
     if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     hipStream_t st = stream();
-    if (!roll::eligible(ds, dss, 0, dd, dds, 0, width, cn, ksize / 2, B_REPLICATE)) {
+    if (typed) {
+        dim3 grid(divUp(width * cn, 64), divUp(height, 4));
+#define MEDT(T_) do { if (ksize == 3) hipLaunchKernelGGL((k_median_typed<T_, 3>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn); \
+                      else hipLaunchKernelGGL((k_median_typed<T_, 5>), grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn); } while (0)
+        if (depth == MI355CV_16U) MEDT(unsigned short); else if (depth == MI355CV_16S) MEDT(short); else MEDT(float);
+#undef MEDT
+        noteKernel("k_median_typed<depth %d,%d> grid=%ux%u x256", depth, ksize, grid.x, grid.y);
+        return stg.finish("medianBlur");
+    }
+    if (!small) {
+        const int R = ksize / 2;
+        const size_t lds = (size_t)((((64 + 2 * R) * cn + 3) & ~3)) * (4 + 2 * R);
+        dim3 grid(divUp(width, 64), divUp(height, 4));
+        hipLaunchKernelGGL(k_median_bits_u8, grid, dim3(256), lds, st, ds, dss, dd, dds, width, height, cn, ksize);
+        noteKernel("k_median_bits_u8 K=%d cn=%d grid=%ux%u x256 lds=%zu", ksize, cn, grid.x, grid.y, lds);
+        return stg.finish("medianBlur");
+    }
+    if (!(cn == 1 || cn == 3 || cn == 4) || !roll::eligible(ds, dss, 0, dd, dds, 0, width, cn, ksize / 2, B_REPLICATE)) {
         dim3 grid(divUp(width * cn, 64), divUp(height, 4));
         if (ksize == 3) hipLaunchKernelGGL(k_median_generic<3>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn);
         else hipLaunchKernelGGL(k_median_generic<5>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, cn);

@@ -2,8 +2,10 @@
 // morph.dispatch.cpp:190-220 from hal::morph :477, reached by cv::erode / cv::dilate / every step of cv::morphologyEx).
 // dst = min (erode) / max (dilate) of the source over the non-zero elements of the structuring element, border pixels by
 // borderInterpolate on the PARENT image (roi_* arguments) or the constant border value, whose default (all DBL_MAX) stands for
-// the identity of the operation (createMorphologyFilter morph.dispatch.cpp:110-128).  iterations == 1 only: the reference folds
-// iterated rectangles into one element before the hook (:963-972); iterated irregular elements fall back to the CPU.
+// the identity of the operation (createMorphologyFilter morph.dispatch.cpp:110-128).  The reference folds iterated rectangles into one element before
+// the hook (:963-972); iterated irregular elements (cross, ellipse) arrive with iterations > 1 and are run as that many passes, as ocvMorph does
+// (morph.dispatch.cpp:455-460: f->apply(dst, dst) for every further iteration), ping-ponging between two scratch images so that the last pass lands in dst.
+// src_data == dst_data on the device (allowInplace) goes through a scratch image and one device copy.
 //   * k_morph_generic<T>: any element / anchor / depth (8U, 16U, 16S, 32F) / ROI; thread per output element.
 //   * seprollMorph (seproll.hip): u8, full K x K rectangle, K in {3,5,7}, on the register-rolling skeleton.
 #include "rt.h"
@@ -22,7 +24,7 @@ enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_
 
 struct MorphTap { short dx, dy; };
 struct MorphCtx {
-    int magic, op, depth, cn, kw, kh, ax, ay, border;
+    int magic, op, depth, cn, kw, kh, ax, ay, border, iterations;
     bool rect, defaultBorder;
     float bv[4];                      // border value per channel, already saturated to the depth
     std::vector<MorphTap> taps;
@@ -72,7 +74,8 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
     (void)max_width; (void)max_height; (void)allowSubmatrix;
     if (!context || disabled()) return mi355::declined(__func__, __LINE__, "!context || disabled()");
     if (operation != 0 && operation != 1) return mi355::declined(__func__, __LINE__, "operation != 0 && operation != 1");          // MORPH_ERODE / MORPH_DILATE
-    if (iterations != 1 || allowInplace || src_type != dst_type) return mi355::declined(__func__, __LINE__, "iterations != 1 || allowInplace || src_type != dst_type");
+    (void)allowInplace;
+    if (iterations < 1 || iterations > 64 || src_type != dst_type) return mi355::declined(__func__, __LINE__, "iterations < 1 || iterations > 64 || src_type != dst_type");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4");
     if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return mi355::declined(__func__, __LINE__, "!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1");
@@ -81,6 +84,7 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
     if (border < 0 || border > B_REFLECT_101 || border == B_WRAP) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101 || border == B_WRAP");
     MorphCtx* c = new (std::nothrow) MorphCtx();
     if (!c) return mi355::declined(__func__, __LINE__, "!c");
+    c->iterations = iterations;
     c->magic = MORPH_MAGIC; c->op = operation; c->depth = depth; c->cn = cn; c->kw = kernel_width; c->kh = kernel_height; c->border = border;
     c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
     if (c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return mi355::declined(__func__, __LINE__, nullptr); }
@@ -103,13 +107,16 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
 MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
         int src_full_width, int src_full_height, int src_roi_x, int src_roi_y, int dst_full_width, int dst_full_height, int dst_roi_x, int dst_roi_y)
 {
-    (void)dst_full_width; (void)dst_full_height; (void)dst_roi_x; (void)dst_roi_y;
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
     if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0");
+    const int iters = c->iterations;
+    if (iters > 1 && !(dst_full_width == width && dst_full_height == height && dst_roi_x == 0 && dst_roi_y == 0))
+        return setError(MI355CV_NOT_IMPLEMENTED, "morph: %d iterations into a destination submatrix (the passes after the first would read the parent's pixels around it)", iters);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data)");
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
+    const bool inplaceDev = inPlaceOnDevice(src_data, dst_data);
     size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;
     const uchar* dtop = stg.in(top, src_step, (size_t)src_full_width * c->cn * e, src_full_height, &dss);
@@ -117,18 +124,42 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
     if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
     const uchar* ds = dtop + (size_t)src_roi_y * dss + (size_t)src_roi_x * c->cn * e;
     hipStream_t st = stream();
-    const bool whole = src_full_width == width && src_full_height == height;
-    if (c->depth == D8U && c->rect && c->kw == c->kh && c->ax == c->kw / 2 && c->ay == c->kh / 2 && whole &&
-        (c->border != B_CONSTANT || c->defaultBorder) &&
-        seprollMorph(c->op == 0, ds, dss, 0, dd, dds, 0, 1, width, height, c->cn, c->kw, c->border, st))
-        return stg.finish("morph");
-    MorphTap* dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
-    if (!dt) return mi355::declined(__func__, __LINE__, "!dt");
-    dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
-#define MORPH_GEN(T) hipLaunchKernelGGL(k_morph_generic<T>, grid, dim3(256), 0, st, ds, dss, dd, dds, width, height, c->cn, src_full_width, src_full_height, \
-        src_roi_x, src_roi_y, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
-    switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; default: MORPH_GEN(float); }
+    // intermediate images: two for the ping-pong of iterated passes, one for an in-place call on the device
+    const size_t tpitch = (((size_t)width * c->cn * e) + 255) & ~(size_t)255;
+    uchar* tmp[2] = {nullptr, nullptr};
+    if (iters > 1 || inplaceDev) {
+        tmp[0] = (uchar*)stg.scratch(tpitch * height);
+        if (iters > 2) tmp[1] = (uchar*)stg.scratch(tpitch * height);
+        if (!tmp[0] || (iters > 2 && !tmp[1])) return mi355::declined(__func__, __LINE__, "scratch for the intermediate image");
+    }
+    MorphTap* dt = nullptr;
+    auto pass = [&](const uchar* ps, size_t pss, int fullW, int fullH, int offX, int offY, uchar* pd, size_t pds) -> bool {
+        const bool whole = fullW == width && fullH == height;
+        if (c->depth == D8U && c->rect && c->kw == c->kh && c->ax == c->kw / 2 && c->ay == c->kh / 2 && whole &&
+            (c->border != B_CONSTANT || c->defaultBorder) &&
+            seprollMorph(c->op == 0, ps, pss, 0, pd, pds, 0, 1, width, height, c->cn, c->kw, c->border, st))
+            return true;
+        if (!dt) dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
+        if (!dt) return false;
+        dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
+#define MORPH_GEN(T) hipLaunchKernelGGL(k_morph_generic<T>, grid, dim3(256), 0, st, ps, pss, pd, pds, width, height, c->cn, fullW, fullH, \
+        offX, offY, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
+        switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; default: MORPH_GEN(float); }
 #undef MORPH_GEN
+        return true;
+    };
+    // pass 1 reads the source in its parent's geometry; passes 2 .. iters read the previous pass's image as a whole image (ocvMorph: f->apply(dst, dst, d_wsz, d_ofs))
+    const uchar* cur = ds; size_t curStep = dss;
+    for (int p = 1; p <= iters; p++) {
+        const bool last = p == iters;
+        uchar* out = last && !(inplaceDev && iters == 1) ? dd : tmp[(p - 1) & 1];
+        const size_t outStep = out == dd ? dds : tpitch;
+        if (!(p == 1 ? pass(cur, curStep, src_full_width, src_full_height, src_roi_x, src_roi_y, out, outStep) : pass(cur, curStep, width, height, 0, 0, out, outStep)))
+            return mi355::declined(__func__, __LINE__, "device copy of the structuring element");
+        cur = out; curStep = outStep;
+    }
+    if (cur != dd && hipMemcpy2DAsync(dd, dds, cur, curStep, (size_t)width * c->cn * e, height, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return setError(MI355CV_ERROR_UNKNOWN, "morph: %s", hipGetErrorString(hipGetLastError()));
     return stg.finish("morph");
 }
 

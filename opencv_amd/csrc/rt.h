@@ -44,6 +44,7 @@ void bump(const char* entry);       // per-entry completed-on-GPU counter
 void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)
 bool ensureDevice();                // makes the calling thread's device current (mi355cv_setDevice, else the process default); false if no usable GPU
 int  activeDevice();                // ordinal of that device (per-device caches key on it)
+int  threadDeviceBinding();         // what mi355cv_setDevice last set on the calling thread (-1: the process default)
 
 // where an image lives: plain / page-locked host memory (staged through HBM), this thread's device or managed memory (launched in place),
 // or ANOTHER GPU's memory (the hook declines: the thread is bound to the wrong device for that image)

@@ -498,6 +498,9 @@ MI355CV_API int mi355cv_setDevice(int device)
 }
 
 MI355CV_API int mi355cv_getDevice(void) { return resolveDevice(); }
+} // extern "C" (reopened below)
+namespace mi355 { int threadDeviceBinding() { return t_dev; } }
+extern "C" {
 
 MI355CV_API const char* mi355cv_version(void) { return "mi355cv 0.1 (gfx950; HAL mirror of OpenCV 4.12 imgproc hot path)"; }
 MI355CV_API const char* mi355cv_lastError(void) { return t_err; }

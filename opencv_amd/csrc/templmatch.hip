@@ -683,8 +683,11 @@ __device__ __forceinline__ void ccorrRingBody(const uchar* __restrict__ img, siz
     // (u8 -> s8) waits until the value goes into the ring, so that nothing touches the load's register while it is in flight.
     const unsigned xc = (unsigned)min(xx, iw - 4);               // unsigned: uniform row pointer + 32-bit lane offset
     auto loadRow = [&](int q) -> unsigned {
+        if (FASTROW) {                                           // ih * istep < 2^32 (the kernel's fastRow test): the row offset is one scalar 32-bit multiply (round 4: was 2 v_mul_lo_u32 +
+            const uchar* gs = img + (size_t)((unsigned)min(R0 + q, ih - 1) * (unsigned)istep);     // v_mad_u64_u32 per load, quarter-rate VALU work in the shadow of nothing)
+            return *reinterpret_cast<const unsigned*>(gs + xc);
+        }
         const uchar* g = img + (size_t)min(R0 + q, ih - 1) * istep;
-        if (FASTROW) return *reinterpret_cast<const unsigned*>(g + xc);
         return (unsigned)g[(unsigned)min(xx, iw - 1)] | ((unsigned)g[(unsigned)min(xx + 1, iw - 1)] << 8) | ((unsigned)g[(unsigned)min(xx + 2, iw - 1)] << 16) |
                ((unsigned)g[(unsigned)min(xx + 3, iw - 1)] << 24);
     };
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
     uchar* T = smem;                                             // th x MT_TPITCH signed taps, zero padded
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // scalar: the row pointers of this wave's loads are then SALU work
     uchar* rings = smem + (((size_t)th * MT_TPITCH + 15) & ~(size_t)15);
     uchar* ring = rings + (size_t)wave * (RG_RING * RG_RP);
     img += (size_t)blockIdx.z * iframe;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     RingSums ws;
     ws.w1 = SUMS ? w1 + (size_t)blockIdx.z * wframe : nullptr; ws.w2 = SUMS ? w2 + (size_t)blockIdx.z * wframe : nullptr;
     ws.wp = wp; ws.rw = rw; ws.rh = rh; ws.tw = tw; ws.wscr = rings + (size_t)4 * (RG_RING * RG_RP) + (size_t)wave * RG_WSCR;
-    const bool fastRow = (iw & 3) == 0 && ((((uintptr_t)img) | istep) & 3) == 0;
+    const bool fastRow = (iw & 3) == 0 && ((((uintptr_t)img) | istep) & 3) == 0 && (unsigned long long)ih * istep < (1ull << 32);
     if (fastRow) ccorrRingBody<KS, true, SUMS>(img, istep, iw, ih, T, ring, th, X0, R0, lane, acc, ws);
     else if (!SUMS) ccorrRingBody<KS, false, false>(img, istep, iw, ih, T, ring, th, X0, R0, lane, acc, ws);   // the host asks for SUMS on aligned rows only
     const int m = lane & 31, h = lane >> 5;
@@ -1146,7 +1149,8 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         static const bool fuseOff = std::getenv("MI355CV_TM_FUSE") && atoi(std::getenv("MI355CV_TM_FUSE")) == 0;
         static const int chunkEnv = std::getenv("MI355CV_TM_CHUNK") ? atoi(std::getenv("MI355CV_TM_CHUNK")) : 0;
         const bool ringK = !ringOff && iw >= 4;
-        const bool fused = ringK && !fuseOff && th >= 66 && (iw & 3) == 0 && ((((uintptr_t)di) | dis | (nframes > 1 ? iframe : 0)) & 3) == 0;
+        const bool fused = ringK && !fuseOff && th >= 66 && (iw & 3) == 0 && ((((uintptr_t)di) | dis | (nframes > 1 ? iframe : 0)) & 3) == 0 &&
+                           (unsigned long long)ih * dis < (1ull << 32);                      // the kernel's fastRow test: 32-bit row offsets
         static const bool finOff = std::getenv("MI355CV_TM_FIN") && atoi(std::getenv("MI355CV_TM_FIN")) == 0;
         const bool fin = fused && !finOff;                                          // bias removal + normalisation in the MFMA kernel's epilogue
         const int wp = fused ? (rw + 3) & ~3 : rw;

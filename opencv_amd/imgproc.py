@@ -627,7 +627,7 @@ def _morph(op, src, kernel, anchor, iterations, borderType, borderValue, dst, ro
     bind_stream(s, d)
     ctx = ctypes.c_void_p()
     rc = L.mi355cv_morphInit(ctypes.byref(ctx), op, s.type, d.type, s.w, s.h, 0, k.ctypes.data, k.strides[0], k.shape[1], k.shape[0], ax, ay,
-                             borderType & ~BORDER_ISOLATED, bv, iterations, roi is not None, False)
+                             borderType & ~BORDER_ISOLATED, bv, iterations, roi is not None, d.ptr == s.ptr)
     _lib.check(rc, "morphInit")
     try:
         rc = L.mi355cv_morph(ctx, _vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, fw, fh, ox, oy, s.w, s.h, 0, 0)

@@ -180,3 +180,22 @@ EXPORT int wrap_calcOpticalFlowPyrLK(const void* prev, size_t ps, const void* ne
         return 0;
     } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
+
+// mi355cv::forEachShard (include/mi355cv_cv.hpp; C ABI mi355cv_runSharded): a batch of host frames through cv::GaussianBlur of THIS HAL-enabled build, sharded over
+// `ndev` device slots (ordinals may repeat), one host thread per slot; every slot's cv:: calls are served by the hooks on the slot's device.  nframes frames of
+// w x h, `type`, stored back to back.  Returns 0, the runner's code, or 1 when there is no device.
+EXPORT int wrap_shardedGaussian(const int* devices, int ndev, const void* s, void* d, int nframes, int w, int h, int type)
+{
+    try {
+        if (mi355cv_init(-1) != 0) return 1;
+        const size_t fsz = (size_t)w * h * CV_ELEM_SIZE(type);
+        std::vector<int> devs(devices, devices + ndev);
+        return mi355cv::forEachShard(devs, nframes, [&](int, int, int first, int count) {
+            for (int f = first; f < first + count; f++) {
+                Mat src(h, w, type, (void*)((const uchar*)s + (size_t)f * fsz)), dst(h, w, type, (uchar*)d + (size_t)f * fsz);
+                cv::GaussianBlur(src, dst, Size(5, 5), 0, 0, BORDER_REFLECT_101);
+            }
+            return 0;
+        });
+    } catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}

@@ -385,7 +385,13 @@ def _bvp(bv):
     return (ctypes.c_double * 4)(*v[:4])
 
 
-def orc_morph(op, src, kernel=None, anchor=(-1, -1), border=0, borderValue=None, roi=None):
+def orc_morph(op, src, kernel=None, anchor=(-1, -1), border=0, borderValue=None, roi=None, iterations=1):
+    """iterations > 1: the element applied that many times, each pass on the previous pass's whole image (ocvMorph, morph.dispatch.cpp:455-460)"""
+    if iterations > 1:
+        out = orc_morph(op, src, kernel, anchor, border, borderValue, roi)
+        for _ in range(iterations - 1):
+            out = orc_morph(op, out, kernel, anchor, border, borderValue)
+        return out
     o = oracle()
     view, fullW, fullH, offX, offY = _roi(src, roi)
     h, w = view.shape[:2]

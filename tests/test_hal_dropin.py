@@ -463,3 +463,21 @@ def test_cv_signature_lk_wrapper_gpu(ref):
     n0 = cv.call_count("calcOpticalFlowPyrLK")
     same(_wrap_lk(hal, A, B, p, (21, 21), 3), O.ref_calcOpticalFlowPyrLK(A, B, p, (21, 21), 3), "wrapper gpu")
     assert cv.call_count("calcOpticalFlowPyrLK") == n0 + 1
+
+
+@pytest.mark.gpu
+def test_for_each_shard_cpp_helper_gpu(ref):
+    """mi355cv::forEachShard (mi355cv_cv.hpp over mi355cv_runSharded): a batch of 9 host frames through cv::GaussianBlur of the HAL-enabled build on device slots
+    (0, 0, 0) -- three host threads, each bound to its slot's device, the hooks serving every call -- equals the stock build frame by frame"""
+    import ctypes
+    import opencv_amd as cv
+    hal = O.load_ref_hal()
+    assert hal is not None
+    frames = O.ref_rng_fill((9 * 270, 480), np.uint8, 7, 0, 256).reshape(9, 270, 480)
+    out = np.zeros_like(frames)
+    n0 = cv.call_count("gaussianBlurBinomial")
+    rc = hal.wrap_shardedGaussian((ctypes.c_int * 3)(0, 0, 0), 3, O.P(frames), O.P(out), 9, 480, 270, O.cvtype(frames[0]))
+    assert rc == 0, (rc, cv._lib.lib.mi355cv_lastError())
+    assert cv.call_count("gaussianBlurBinomial") == n0 + 9
+    for i in range(9):
+        assert np.array_equal(out[i], O.ref_GaussianBlur(frames[i], 5, 0, 0, 4)), i

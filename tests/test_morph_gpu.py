@@ -64,3 +64,30 @@ def test_morph_roi_reads_real_neighbours(cv, orc):
                     orc.orc_morph(op, np.ascontiguousarray(parent[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]), np.ones((5, 3), np.uint8), (-1, -1), border & ~16)
                 got = fn(dev(parent), np.ones((5, 3), np.uint8), (-1, -1), 1, border, None, roi=roi).cpu().numpy()
                 assert np.array_equal(got, want), (roi, border, op)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32])
+def test_iterated_irregular_elements_and_in_place(cv, orc, dtype):
+    """iterations > 1 of a cross / ellipse / arbitrary element (declined before; morph.dispatch.cpp:455-460) as repeated passes on the GPU, and a call
+    whose destination IS its source on the device (allowInplace): results identical to the restatement pinned in tests/test_oracle_morph.py"""
+    CROSS = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+    ELL = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)
+    ODD = np.array([[1, 0, 0, 1, 0], [0, 0, 1, 0, 0], [1, 1, 0, 0, 1]], np.uint8)
+    n0 = cv.call_count("morph")
+    for shape in [(27, 38, 3), (270, 480)]:
+        src = _src(dtype, shape, 12)
+        for op, fn in ((0, cv.erode), (1, cv.dilate)):
+            for k, anchor in [(CROSS, (-1, -1)), (ELL, (-1, -1)), (ODD, (1, 2))]:
+                for it in (2, 3, 4):
+                    for border, bv in [(0, None), (0, 7.0), (1, None), (4, None)]:
+                        got = fn(dev(src), k, anchor, it, border, bv).cpu().numpy()
+                        assert np.array_equal(got, orc.orc_morph(op, src, k, anchor, border, bv, iterations=it)), (dtype, shape, op, k.shape, it, border)
+            assert np.array_equal(fn(src, CROSS, (-1, -1), 3), orc.orc_morph(op, src, CROSS, iterations=3))            # host arrays
+            for it in (1, 2, 3):                                                                                        # in place on the device
+                d = dev(src)
+                out = fn(d, ELL, (-1, -1), it, dst=d)
+                assert out.data_ptr() == d.data_ptr() and np.array_equal(d.cpu().numpy(), orc.orc_morph(op, src, ELL, iterations=it)), (op, it)
+                d = dev(src)
+                fn(d, np.ones((3, 3), np.uint8), dst=d)
+                assert np.array_equal(d.cpu().numpy(), orc.orc_morph(op, src, np.ones((3, 3), np.uint8)))
+    assert cv.call_count("morph") > n0

@@ -17,6 +17,12 @@ def test_median_matches_reference(ref):
         src = (rng.random((19, 27)) * 1000 - 300).astype(dtype) if dtype != np.uint16 else rng.integers(0, 65536, (19, 27), dtype=np.uint16)
         for k in (3, 5):
             assert np.array_equal(O.orc_medianBlur(src, k), O.ref_medianBlur(src, k)), (dtype, k)
+        src3 = (rng.random((14, 21, 3)) * 2000 - 700).astype(dtype) if dtype != np.uint16 else rng.integers(0, 65536, (14, 21, 3), dtype=np.uint16)
+        for k in (3, 5):
+            assert np.array_equal(O.orc_medianBlur(src3, k), O.ref_medianBlur(src3, k)), (dtype, k, "3 channels")
+    for shape, k in [((40, 52), 11), ((33, 47, 3), 13), ((70, 64, 4), 15), ((90, 100), 21), ((64, 80), 31)]:     # the histogram forms at larger apertures
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert np.array_equal(O.orc_medianBlur(src, k), O.ref_medianBlur(src, k)), (shape, k)
 
 
 def test_median_known_answer():

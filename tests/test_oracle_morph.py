@@ -44,6 +44,19 @@ def test_folded_iterations_equal_bigger_rectangle(ref):
         assert np.array_equal(O.orc_morph(op, src, np.ones((5, 9), np.uint8), (-1, -1), 4), want)
 
 
+@pytest.mark.ref
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32])
+def test_iterated_irregular_elements(ref, dtype):
+    """iterations > 1 of a cross / an arbitrary element reach cv_hal_morph as they are (only full rectangles are folded): repeated whole-image passes"""
+    src = _src(dtype, (27, 38, 3), 12)
+    ELL = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)      # getStructuringElement(MORPH_ELLIPSE, (5, 5))
+    for op in (0, 1):
+        for k, anchor in [(CROSS, (-1, -1)), (ELL, (-1, -1)), (ODD, (1, 2))]:
+            for it in (2, 3, 4):
+                for border, bv in [(0, None), (0, 7.0), (1, None), (4, None)]:
+                    assert np.array_equal(O.orc_morph(op, src, k, anchor, border, bv, iterations=it), O.ref_morph(op, src, k, anchor, it, border, bv)), (dtype, op, k.shape, it, border)
+
+
 def test_morph_known_answer():
     src = np.array([[5, 1, 9], [7, 3, 2], [4, 8, 6]], np.uint8)
     assert O.orc_morph(1, src).tolist() == [[7, 9, 9], [8, 9, 9], [8, 8, 8]]          # dilate: outside ignored
