@@ -153,6 +153,52 @@ __global__ __launch_bounds__(256) void k_hsv2bgr_u8(const uchar* __restrict__ sr
     if (DCN == 4) d[3] = 255;
 }
 
+// BGR/RGB(A) <-> HLS for CV_8U / CV_32F and <-> HSV for CV_32F (hsv_math.h has the arithmetic and its provenance): one thread per pixel.
+// MODE 0: CV_8U HLS (bytes in, bytes out, the reference's vector-body / scalar-tail split per 256-pixel block), 1: CV_32F HLS, 2: CV_32F HSV.
+template <int SCN, int MODE>
+__global__ __launch_bounds__(256) void k_bgr2hxx(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bidx, float hscale)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    if (MODE == 0) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x * SCN;
+        uchar* d = dst + (size_t)y * dstep + (size_t)x * 3;
+        float h, l, sa;
+        mi355_rgb2hls_px(s[bidx ^ 2] * (1.f / 255.f), s[1] * (1.f / 255.f), s[bidx] * (1.f / 255.f), hscale, mi355_hls_in_vector_body(x, W), h, l, sa);
+        d[0] = (uchar)mi355_round_sat8(h); d[1] = (uchar)mi355_round_sat8(l * 255.f); d[2] = (uchar)mi355_round_sat8(sa * 255.f);
+    } else {
+        const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * SCN;
+        float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * 3;
+        float o0, o1, o2;
+        if (MODE == 1) mi355_rgb2hls_px(s[bidx ^ 2], s[1], s[bidx], 1.f, false, o0, o1, o2);
+        else mi355_rgb2hsv_f(s[bidx ^ 2], s[1], s[bidx], o0, o1, o2);
+        d[0] = o0; d[1] = o1; d[2] = o2;
+    }
+}
+template <int DCN, int MODE>
+__global__ __launch_bounds__(256) void k_hxx2bgr(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int bidx, float hscale)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float b, g, r;
+    if (MODE == 0) {
+        const uchar* s = src + (size_t)y * sstep + (size_t)x * 3;
+        uchar* d = dst + (size_t)y * dstep + (size_t)x * DCN;
+        mi355_hls2rgb_px((float)s[0], s[1] * (1.f / 255.f), s[2] * (1.f / 255.f), hscale, mi355_hls_in_vector_body(x, W), b, g, r);
+        d[bidx] = (uchar)mi355_round_sat8(b * 255.f); d[1] = (uchar)mi355_round_sat8(g * 255.f); d[bidx ^ 2] = (uchar)mi355_round_sat8(r * 255.f);
+        if (DCN == 4) d[3] = 255;
+    } else {
+        const float* s = reinterpret_cast<const float*>(src + (size_t)y * sstep) + (size_t)x * 3;
+        float* d = reinterpret_cast<float*>(dst + (size_t)y * dstep) + (size_t)x * DCN;
+        if (MODE == 1) mi355_hls2rgb_px(s[0], s[1], s[2], 6.f / 360.f, false, b, g, r);
+        else mi355_hsv2rgb_f(s[0], s[1], s[2], b, g, r);
+        d[bidx] = b; d[1] = g; d[bidx ^ 2] = r;
+        if (DCN == 4) d[3] = 1.f;
+    }
+}
+
 // CV_16U / CV_32F members of the YUV / YCrCb family (RGB2YCrCb_i<ushort> color_yuv.simd.hpp:255-395, YCrCb2RGB_i<ushort> :890-1010: the 8-bit integer
 // formulas with delta = 32768; RGB2YCrCb_f<float> :134-212, YCrCb2RGB_f<float> :616-689: fused multiply-adds in the order of the reference's vector
 // loop).  One thread per pixel, 6-8 bytes (16U) / 12-16 bytes (32F) in and out per lane.
@@ -314,11 +360,32 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
     return stg.finish("cvtTwoPlaneYUVtoBGR");
 }
 
-// replaces hal_ni_cvtBGRtoHSV (hal_replacement.hpp:596; caller color_hsv.dispatch.cpp:65): CV_8U and HSV only (HLS / CV_32F decline)
+// replaces hal_ni_cvtBGRtoHSV (hal_replacement.hpp:596; caller color_hsv.dispatch.cpp:65): HSV and HLS, CV_8U and CV_32F (cvtBGRtoHSV color_hsv.simd.hpp:1270-1293)
 MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    if (disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || depth != MI355CV_8U || !isHSV || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
+        return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
+    if (depth != MI355CV_8U || !isHSV) {
+        Stager stg;
+        if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "host image below the policy threshold");
+        const size_t e = depth == MI355CV_8U ? 1 : 4;
+        size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * 3 * e, height, &dds);
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
+        dim3 grid(divUp(width, 64), divUp(height, 4));
+        const int bidx = swapBlue ? 2 : 0;
+        const float hscale = (isFullRange ? 256.f : 180.f) / 360.f;
+#define HXX_F(SCN_, MODE_) hipLaunchKernelGGL((k_bgr2hxx<SCN_, MODE_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, bidx, hscale)
+        if (depth == MI355CV_8U) { if (scn == 3) HXX_F(3, 0); else HXX_F(4, 0); }
+        else if (!isHSV)         { if (scn == 3) HXX_F(3, 1); else HXX_F(4, 1); }
+        else                     { if (scn == 3) HXX_F(3, 2); else HXX_F(4, 2); }
+#undef HXX_F
+        noteKernel("k_bgr2hxx<%d,%s> grid=%ux%u x256", scn, depth == MI355CV_8U ? "HLS 8U" : isHSV ? "HSV 32F" : "HLS 32F", grid.x, grid.y);
+        return stg.finish("cvtBGRtoHSV");
+    }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
@@ -365,12 +432,32 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_st
                                          dcn, swapBlue, uIdx);
 }
 
-// cv_hal_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95), CV_8U HSV only.  NOT yet bound in mi355cv_hal.hpp: written
-// after the last GPU session of round 1 and exercised only by a non-strict parity test until it has run on the MI355X.
+// cv_hal_cvtHSVtoBGR (hal_replacement.hpp:613; caller color_hsv.dispatch.cpp:95): HSV and HLS, CV_8U and CV_32F (cvtHSVtoBGR color_hsv.simd.hpp:1296-1320)
 MI355CV_API int mi355cv_cvtHSVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    if (disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || depth != MI355CV_8U || !isHSV || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
+        return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
+    if (depth != MI355CV_8U || !isHSV) {
+        Stager stg;
+        if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "host image below the policy threshold");
+        const size_t e = depth == MI355CV_8U ? 1 : 4;
+        size_t dss, dds;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * 3 * e, height, &dss);
+        uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);
+        if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
+        dim3 grid(divUp(width, 64), divUp(height, 4));
+        const int bidx = swapBlue ? 2 : 0;
+        const float hscale = 6.f / (isFullRange ? 255.f : 180.f);
+#define HXX_I(DCN_, MODE_) hipLaunchKernelGGL((k_hxx2bgr<DCN_, MODE_>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, bidx, hscale)
+        if (depth == MI355CV_8U) { if (dcn == 3) HXX_I(3, 0); else HXX_I(4, 0); }
+        else if (!isHSV)         { if (dcn == 3) HXX_I(3, 1); else HXX_I(4, 1); }
+        else                     { if (dcn == 3) HXX_I(3, 2); else HXX_I(4, 2); }
+#undef HXX_I
+        noteKernel("k_hxx2bgr<%d,%s> grid=%ux%u x256", dcn, depth == MI355CV_8U ? "HLS 8U" : isHSV ? "HSV 32F" : "HLS 32F", grid.x, grid.y);
+        return stg.finish("cvtHSVtoBGR");
+    }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");

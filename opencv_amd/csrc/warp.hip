@@ -1294,6 +1294,86 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 }
 
 
+// ---- CV_32FC1 bilinear warpAffine through an LDS tile (BASELINE config 3c) --------------------------------------------------------------------------
+// Why: k_warp_lin<float> gathers.  A 64-lane load of 8-byte tap pairs along a sloped source line touches ~26 cache lines (profiles/r02_warp_pmc.txt:
+// TCP_TOTAL_CACHE_ACCESSES 24.2 M for 0.93 M load instructions per 8K frame) and the vector L1 looks up one line per clock: ~95 K cycles per CU and frame, the whole
+// kernel time.  Here a workgroup owns a 64 x 32 destination tile: the reference's coordinate sums are a function of x plus a function of y, each monotone
+// (saturating double -> int of a linear term), so the four corner terms bound every pixel's source position EXACTLY; the bounding box of the 2 x 2 footprints is
+// copied into LDS row by row with consecutive lanes on consecutive floats (a handful of lines per row), and the taps come from LDS.  The per-pixel arithmetic is
+// k_warp_lin's (the reference's: imgwarp.cpp:2233-2298 coordinates in 1/1024 rounded to 1/32, remapBilinear<Cast<float,float>> :675-904 weights and
+// summation order), so results are bit-identical to it.  Tiles whose box leaves the source or exceeds the LDS allotment take the gather form pixel by pixel
+// (taps from global memory; the generic sampler where the footprint is not inside).
+constexpr int W32_TW = 64, W32_TH = 32, W32_CAP = 6144;          // tile, LDS floats (24 KB: six workgroups per CU by LDS, eight by threads)
+__global__ __launch_bounds__(256) void k_warp32_tile(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w,
+                                                     const short* __restrict__ tab)
+{
+    __shared__ float box[W32_CAP];
+    __shared__ int rowT[2 * W32_TH];                                 // X0(y), Y0(y) of the tile's rows
+    int tx, ty;
+    tileOf(w, tx, ty);
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = tx * W32_TW, y0 = ty * W32_TH;
+    const int x1 = min(x0 + W32_TW, w.dw) - 1, y1 = min(y0 + W32_TH, w.dh) - 1;
+    if (tid < W32_TH) {
+        const int y = min(y0 + tid, w.dh - 1);
+        rowT[tid] = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
+        rowT[W32_TH + tid] = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
+    }
+    const int x = x0 + lane;
+    const int xc = min(x, w.dw - 1);
+    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xc), 1024.0));
+    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xc), 1024.0));
+    __syncthreads();
+    // the box: extremes of the column terms at the tile's first / last column (lanes 0 and x1 - x0), of the row terms at its first / last row
+    const int adA = __builtin_amdgcn_readlane(ad, 0), adB = __builtin_amdgcn_readlane(ad, x1 - x0), bdA = __builtin_amdgcn_readlane(bd, 0), bdB = __builtin_amdgcn_readlane(bd, x1 - x0);
+    const int XrA = rowT[0], XrB = rowT[y1 - y0], YrA = rowT[W32_TH], YrB = rowT[W32_TH + y1 - y0];
+    const long long Xlo = (long long)min(adA, adB) + min(XrA, XrB), Xhi = (long long)max(adA, adB) + max(XrA, XrB);
+    const long long Ylo = (long long)min(bdA, bdB) + min(YrA, YrB), Yhi = (long long)max(bdA, bdB) + max(YrA, YrB);
+    bool tiled = Xlo > -(1ll << 30) && Xhi < (1ll << 30) && Ylo > -(1ll << 30) && Yhi < (1ll << 30);    // the int sums of the reference do not wrap here
+    const int bx0 = (int)(Xlo >> 10), bx1 = (int)(Xhi >> 10) + 1, by0 = (int)(Ylo >> 10), by1 = (int)(Yhi >> 10) + 1;
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    tiled = tiled && bx0 >= 0 && by0 >= 0 && bx1 <= s.sw - 1 && by1 <= s.sh - 1 && (long long)bw * bh <= W32_CAP;
+    if (tiled) {
+        // stage the box: one wave per row, consecutive lanes on consecutive floats
+        for (int r = wave; r < bh; r += 4) {
+            const float* g = reinterpret_cast<const float*>(src + (size_t)(by0 + r) * sstep) + bx0;
+            float* l = box + r * bw;
+            for (int c = lane; c < bw; c += 64) l[c] = g[c];
+        }
+        __syncthreads();
+    }
+    if (x > x1) return;
+    const uint32_t xoff = (uint32_t)x * 4u;
+#pragma unroll 2
+    for (int i = 0; i < W32_TH / 4; i++) {
+        const int ly = wave * (W32_TH / 4) + i, y = y0 + ly;
+        if (y > y1) break;
+        const int X = (rowT[ly] + ad) >> 5, Y = (rowT[W32_TH + ly] + bd) >> 5;
+        const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+        float p00, p01, p10, p11;
+        if (tiled) {
+            const float* l = box + (sy - by0) * bw + (sx - bx0);
+            p00 = l[0]; p01 = l[1]; p10 = l[bw]; p11 = l[bw + 1];
+        } else if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
+            const float* g = reinterpret_cast<const float*>(src + (size_t)sy * sstep) + sx;
+            const float* g1 = reinterpret_cast<const float*>(src + (size_t)(sy + 1) * sstep) + sx;
+            p00 = g[0]; p01 = g[1]; p10 = g1[0]; p11 = g1[1];
+        } else {
+            samplePixel(src, sstep, dst + (size_t)y * dstep + xoff, s, satShort(sx), satShort(sy), ax, ay, tab);
+            continue;
+        }
+        const float s32 = 1.f / 32;
+        const float fx = ax * s32, fy = ay * s32;
+        const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+        const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
+        float t = __fadd_rn(__fmul_rn(p00, w0), __fmul_rn(p01, w1));
+        t = __fadd_rn(t, __fmul_rn(p10, w2));
+        t = __fadd_rn(t, __fmul_rn(p11, w3));
+        *reinterpret_cast<float*>(dst + (size_t)y * dstep + xoff) = t;
+    }
+}
+
 // the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
 __global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT, uint32_t* __restrict__ work)
 {
@@ -1546,6 +1626,15 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // MI355CV_WARP_BAND=1 turns it on (tools/warp_probe.py).
         const char* ve = getenv("MI355CV_WARP_BAND");
         w.band = ve ? atoi(ve) : 0;
+        // CV_32FC1 affine: the LDS-tile kernel (MI355CV_WARP32=0 keeps the gather kernel for A/B runs)
+        static const bool warp32On = [] { const char* v = getenv("MI355CV_WARP32"); return !v || atoi(v) != 0; }();
+        if (warp32On && kind == 0 && depth == D32F && cn == 1) {
+            dim3 g3(divUp(dw, W32_TW), divUp(dh, W32_TH), nframes);
+            w.gx = g3.x; w.gy = g3.y;
+            hipLaunchKernelGGL(k_warp32_tile, g3, dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev);
+            noteKernel("k_warp32_tile grid=%ux%ux%u x256 tile %dx%d lds=%d floats band=%d", g3.x, g3.y, g3.z, W32_TW, W32_TH, W32_CAP, w.band);
+            return stg.finish(entry);
+        }
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * (depth == D32F ? warpRows<float>() : warpRows<uchar>())), nframes);
         w.gx = g2.x; w.gy = g2.y;
 #define WL(T_, CN_, K_) hipLaunchKernelGGL((k_warp_lin<T_, CN_, K_>), g2, dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev)

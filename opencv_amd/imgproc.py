@@ -260,15 +260,15 @@ def cvtColor(src, code, dst=None, dstCn=0):
         bind_stream(s, d)
         _lib.check(L.mi355cv_cvtBGRtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, scn, dcn, swap), "cvtBGRtoBGR")
         return out
-    if code in _HSV:
-        swap, full = _HSV[code]
+    if code in _HSV or code in _HLS:
+        swap, full = _HSV[code] if code in _HSV else _HLS[code]
         if s.cn not in (3, 4):
             raise ValueError("cvtColor: source must have 3 or 4 channels")
         ref3 = src[..., :3] if s.cn == 4 else src
         out = dst if dst is not None else empty_like_kind(ref3, s.h, s.w, 3, s.depth)
         d = Img(out)
         bind_stream(s, d)
-        _lib.check(L.mi355cv_cvtBGRtoHSV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(swap), bool(full), True), "cvtBGRtoHSV")
+        _lib.check(L.mi355cv_cvtBGRtoHSV(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(swap), bool(full), code in _HSV), "cvtBGRtoHSV")
         return out
     if code in _YUV_FWD:
         swap, cbcr = _YUV_FWD[code]
@@ -303,15 +303,15 @@ def cvtColor(src, code, dst=None, dstCn=0):
         else:
             _lib.check(L.mi355cv_cvtThreePlaneYUVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, dh, dcn, bool(swap), uidx), "cvtThreePlaneYUVtoBGR")
         return out
-    if code in _HSV_INV:                                                    # COLOR_HSV2BGR / RGB (54, 55) and *_FULL (70, 71)
-        swap, full = _HSV_INV[code]
+    if code in _HSV_INV or code in _HLS_INV:                                # COLOR_HSV2BGR / RGB (54, 55), COLOR_HLS2BGR / RGB (60, 61) and their *_FULL forms
+        swap, full = _HSV_INV[code] if code in _HSV_INV else _HLS_INV[code]
         dcn = dstCn if dstCn in (3, 4) else 3
-        if s.cn != 3 or s.depth != CV_8U:
-            raise ValueError("cvtColor: HSV2BGR needs a CV_8UC3 source on this path")
+        if s.cn != 3 or s.depth not in (CV_8U, CV_32F):
+            raise ValueError("cvtColor: HSV / HLS -> BGR needs a CV_8UC3 or CV_32FC3 source")
         out = dst if dst is not None else empty_like_kind(src, s.h, s.w, dcn, s.depth)
         d = Img(out)
         bind_stream(s, d)
-        _lib.check(L.mi355cv_cvtHSVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(swap), bool(full), True), "cvtHSVtoBGR")
+        _lib.check(L.mi355cv_cvtHSVtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(swap), bool(full), code in _HSV_INV), "cvtHSVtoBGR")
         return out
     if code in _MISC:
         return _cvt_misc(src, s, code, dst, dstCn)
@@ -319,6 +319,10 @@ def cvtColor(src, code, dst=None, dstCn=0):
 
 
 _HSV_INV = {54: (0, 0), 55: (1, 0), 70: (0, 1), 71: (1, 1)}
+_HLS = {52: (0, 0), 53: (1, 0), 68: (0, 1), 69: (1, 1)}                          # COLOR_BGR2HLS, RGB2HLS, BGR2HLS_FULL, RGB2HLS_FULL (imgproc.hpp:606-640)
+_HLS_INV = {60: (0, 0), 61: (1, 0), 72: (0, 1), 73: (1, 1)}                      # COLOR_HLS2BGR, HLS2RGB, HLS2BGR_FULL, HLS2RGB_FULL
+COLOR_BGR2HLS, COLOR_RGB2HLS, COLOR_HLS2BGR, COLOR_HLS2RGB = 52, 53, 60, 61
+COLOR_BGR2HLS_FULL, COLOR_RGB2HLS_FULL, COLOR_HLS2BGR_FULL, COLOR_HLS2RGB_FULL = 68, 69, 72, 73
 
 
 def _misc_table():
@@ -568,11 +572,11 @@ def moments(src, binaryImage=False):
 
 
 def bilateralFilter(src, d, sigmaColor, sigmaSpace, borderType=BORDER_DEFAULT, dst=None):
-    """cv::bilateralFilter (bilateral_filter.dispatch.cpp:393) through cv_hal_bilateralFilter: CV_8UC1 / CV_8UC3, radius <= 16.  A view with padded rows is
+    """cv::bilateralFilter (bilateral_filter.dispatch.cpp:393) through cv_hal_bilateralFilter: CV_8UC1 / CV_8UC3 / CV_32FC1 / CV_32FC3, radius <= 16.  A view with padded rows is
     treated as the image it shows (BORDER_ISOLATED): the mirror has no parent to pad from."""
     s = Img(src)
-    if s.depth != CV_8U or s.cn not in (1, 3):
-        raise NotImplementedError("bilateralFilter: CV_8UC1 / CV_8UC3")
+    if s.depth not in (CV_8U, CV_32F) or s.cn not in (1, 3):
+        raise NotImplementedError("bilateralFilter: CV_8UC1 / CV_8UC3 / CV_32FC1 / CV_32FC3")
     out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
     dd = Img(out)
     bind_stream(s, dd)

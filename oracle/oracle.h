@@ -198,4 +198,10 @@ int orc_FAST_dense(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
 void orc_FAST_nms(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h);
 int orc_FAST(const uint8_t* src, size_t sstep, int w, int h, int threshold, int nonmax, int type, float* out, int cap);
 
+/* color_hls.c: BGR/RGB(A) <-> HLS (CV_8U with the reference's vector-body / scalar-tail split, `lanes` floats per vector; CV_32F), BGR/RGB(A) <-> HSV (CV_32F) */
+void orc_cvtBGRtoHLS8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int fullRange, int lanes);
+void orc_cvtHLStoBGR8u(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int fullRange, int lanes);
+void orc_cvtBGRtoHxx32f(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int hls);
+void orc_cvtHxxtoBGR32f(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int hls);
+int orc_bilateralFilter32f(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int d, double sigma_color, double sigma_space, int border);
 #endif

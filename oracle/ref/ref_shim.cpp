@@ -238,6 +238,15 @@ int ref_bilateralFilter(const void* s, size_t ss, void* d, size_t ds, int w, int
     REF_END(dst, d)
 }
 
+// the same for any element type (CV_32FC1 / CV_32FC3: bilateralFilter_32f)
+int ref_bilateralFilterT(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type, int dd, double sigmaColor, double sigmaSpace, int border)
+{
+    REF_TRY
+    Mat src = M(s, ss, w, h, type), dst = M(d, ds, w, h, type);
+    cv::bilateralFilter(src, dst, dd, sigmaColor, sigmaSpace, border);
+    REF_END(dst, d)
+}
+
 // cv::hal::cvtBGRtoTwoPlaneYUV (no cvtColor code reaches it); dst = (h * 3/2) x w, Y rows then the interleaved chroma rows
 int ref_cvtBGRtoTwoPlaneYUV(const void* s, size_t ss, void* d, size_t ds, int w, int h, int scn, int swapBlue, int uIdx)
 {

@@ -460,6 +460,10 @@ def orc_bilateralFilter(src, d, sigmaColor, sigmaSpace, border=4):
     o = oracle()
     h, w = src.shape[:2]
     dst = np.empty_like(src)
+    if src.dtype == np.float32:
+        rc = o.orc_bilateralFilter32f(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border & ~16)
+        assert rc == 0, rc
+        return dst
     rc = o.orc_bilateralFilter8u(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border & ~16)
     assert rc == 0, rc
     return dst
@@ -469,6 +473,10 @@ def ref_bilateralFilter(src, d, sigmaColor, sigmaSpace, border=4):
     r = load_ref()
     h, w = src.shape[:2]
     dst = np.empty_like(src)
+    if src.dtype == np.float32:
+        rc = r.ref_bilateralFilterT(P(src), step(src), P(dst), step(dst), w, h, cvtype(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border)
+        assert rc == 0, rc
+        return dst
     rc = r.ref_bilateralFilter(P(src), step(src), P(dst), step(dst), w, h, cn_of(src), d, ctypes.c_double(sigmaColor), ctypes.c_double(sigmaSpace), border)
     assert rc == 0, rc
     return dst
@@ -1284,3 +1292,26 @@ def orb_scene(w, h, seed=0, texture=1.0):
             m = (xx - cx) ** 2 + (yy - cy) ** 2 < s * s
         img[m] = 0.6 * g + 0.4 * img[m]
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
+# ---------------------------------------------------------------------------------- HLS (CV_8U, CV_32F) and HSV (CV_32F)
+# cv::ColorConversionCodes: code -> (swapBlue, fullRange)
+_HLS_FWD = {52: (0, 0), 53: (1, 0), 68: (0, 1), 69: (1, 1)}           # BGR2HLS, RGB2HLS, BGR2HLS_FULL, RGB2HLS_FULL
+_HLS_INV = {60: (0, 0), 61: (1, 0), 72: (0, 1), 73: (1, 1)}           # HLS2BGR, HLS2RGB, HLS2BGR_FULL, HLS2RGB_FULL
+
+
+def orc_cvtColorHxx(src, code, dcn=3, lanes=8):
+    """BGR/RGB(A) <-> HLS for CV_8U / CV_32F and <-> HSV for CV_32F (oracle/color_hls.c)"""
+    o = oracle()
+    h, w = src.shape[:2]
+    f32 = src.dtype == np.float32
+    fwd = code in _HLS_FWD or code in _HSV
+    hls = code in _HLS_FWD or code in _HLS_INV
+    swap, full = (_HLS_FWD.get(code) or _HLS_INV.get(code) or _HSV.get(code) or _HSV_INV[code])
+    dst = np.empty((h, w, 3 if fwd else dcn), src.dtype)
+    if f32:
+        (o.orc_cvtBGRtoHxx32f if fwd else o.orc_cvtHxxtoBGR32f)(P(src), step(src), P(dst), step(dst), w, h, src.shape[2] if fwd else dcn, swap, int(hls))
+    else:
+        assert hls
+        (o.orc_cvtBGRtoHLS8u if fwd else o.orc_cvtHLStoBGR8u)(P(src), step(src), P(dst), step(dst), w, h, src.shape[2] if fwd else dcn, swap, full, lanes)
+    return dst

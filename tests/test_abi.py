@@ -78,3 +78,20 @@ def test_struct_layouts_of_the_c_abi_match_the_bindings(tmp_path):
             ctypes.sizeof(P), P.scaleFactor.offset, P.nlevels.offset, P.WTA_K.offset, P.fastThreshold.offset]
     assert got == want, (got, want)
     assert got[0] == 28 and np.dtype(f2d.KEYPOINT_DTYPE).isalignedstruct is False
+
+
+def test_the_five_hooks_left_unbound_stay_with_the_reference():
+    """hal_replacement.hpp declares 66 imgproc hooks; mi355cv_hal.hpp binds 61.  The other five stay `hal_ni_*` ON PURPOSE (INTEGRATION.md "Hooks left to the reference"):
+    cv_hal_warpAffineBlockline[NN] / cv_hal_warpPerspectiveBlockline[NN] (:286-348) are called from INSIDE the reference's worker threads for one 16 x 64 block of
+    coordinates at a time (imgwarp.cpp:2275-2277, :3204-3206) -- a GPU launch per block would cost more than the block; the whole-image hooks cv_hal_warpAffine /
+    cv_hal_warpPerspective, which are bound, pre-empt them.  cv_hal_polygonMoments (:1321) works on a contour (a point list), not on an image of the hot path."""
+    txt = open(os.path.join(ROOT, "include", "mi355cv_hal.hpp")).read()
+    for hook in ("cv_hal_warpAffineBlockline", "cv_hal_warpAffineBlocklineNN", "cv_hal_warpPerspectiveBlockline", "cv_hal_warpPerspectiveBlocklineNN", "cv_hal_polygonMoments"):
+        assert not re.search(r"#\s*(define|undef)\s+" + hook + r"\b", txt), hook
+    ref = "/root/reference/modules/imgproc/src/hal_replacement.hpp"
+    if os.path.exists(ref):
+        declared = set(re.findall(r"^#define\s+(cv_hal_\w+)\s+hal_ni_\w+", open(ref).read(), re.M))
+        bound = set(re.findall(r"#define\s+(cv_hal_\w+)\(\.\.\.\)", txt))
+        assert len(declared) == 66, len(declared)
+        assert declared - bound == {"cv_hal_warpAffineBlockline", "cv_hal_warpAffineBlocklineNN", "cv_hal_warpPerspectiveBlockline", "cv_hal_warpPerspectiveBlocklineNN",
+                                    "cv_hal_polygonMoments"}, sorted(declared - bound)

@@ -33,6 +33,29 @@ def test_bilateral_filter(cv, orc, cn):
         cv.bilateralFilter(torch.from_numpy(img).cuda(), 41, 50.0, 3.0)                                                # radius beyond the LDS tile: declined
 
 
+@pytest.mark.parametrize("cn", [1, 3])
+def test_bilateral_filter_32f(cv, orc, cn):
+    """CV_32FC1 / CV_32FC3 (declined): k_minmax_f32 + host-built table + k_bilateral_f32, within 1e-6 of the restatement (itself 1e-6 from the reference),
+    every border, radii up to 16, NaN pixels, a constant image, host arrays"""
+    from opencv_amd import _lib
+    rng = np.random.default_rng(21 + cn)
+    for (w, h) in [(97, 33), (64, 20), (41, 17), (333, 100)]:
+        src = (rng.random((h, w, cn) if cn > 1 else (h, w), dtype=np.float32) * 3 - 1).astype(np.float32)
+        for d, sc, ss in [(5, 0.3, 2.0), (9, 1.5, 7.0), (0, 0.2, 2.0), (3, 10.0, 1.0), (33, 0.5, 6.0)]:
+            for border in (4, 1, 0, 2):
+                got = cv.bilateralFilter(torch.from_numpy(src).cuda(), d, sc, ss, border).cpu().numpy()
+                want = orc.orc_bilateralFilter(src, d, sc, ss, border)
+                assert orc.rel_err(got, want) <= 1e-6 and np.abs(got - want).max() <= 3e-6, (cn, w, h, d, sc, ss, border, orc.rel_err(got, want))
+        assert "k_bilateral_f32" in _lib.lib.mi355cv_lastKernel().decode()
+    src = rng.random((30, 40, cn) if cn > 1 else (30, 40), dtype=np.float32); src[5, 7] = np.nan; src[10:12, 20] = np.nan
+    got = cv.bilateralFilter(torch.from_numpy(src).cuda(), 5, 0.3, 2.0).cpu().numpy()
+    assert not np.isnan(got).any() and np.abs(got - orc.orc_bilateralFilter(src, 5, 0.3, 2.0)).max() <= 3e-6
+    flat = np.full((20, 30, cn) if cn > 1 else (20, 30), -2.5, np.float32)
+    assert np.array_equal(cv.bilateralFilter(torch.from_numpy(flat).cuda(), 5, 0.3, 2.0).cpu().numpy(), flat)
+    img = rng.random((50, 70, cn) if cn > 1 else (50, 70), dtype=np.float32)
+    assert np.abs(cv.bilateralFilter(img, 7, 0.4, 3.0) - orc.orc_bilateralFilter(img, 7, 0.4, 3.0)).max() <= 3e-6       # host arrays
+
+
 def test_bilateral_row_range_is_filtered_as_an_image_of_its_own(cv, orc):
     """cv_hal_bilateralFilter carries no margins (hal_replacement.hpp:1068): a full-width row range of a larger image is dense, so the hook cannot tell it
     from a whole image and filters it with the border rule at its first and last rows, where cv::bilateralFilter's own code path pads with the

@@ -104,3 +104,45 @@ def test_threshold_otsu(cv, orc, dtype):
                 tv, td = orc.orc_thresholdOtsu(src, 200.4, ttype)
                 gv, gd = cv.threshold(dev(src), 0, 200.4, ttype | cv.THRESH_OTSU)
                 assert gv == tv and np.array_equal(gd.cpu().numpy(), td), (dtype, w, h, mode, ttype, gv, tv)
+
+
+@pytest.mark.parametrize("code", [52, 53, 68, 69, 60, 61, 72, 73])
+def test_hls_8u(cv, orc, code):
+    """BGR/RGB(A) <-> HLS, CV_8U (declined, Imgproc_ColorHLS ran on the fallback): bit-exact against the restatement that tests/test_oracle_hls.py pins to
+    the reference on all 2^24 inputs -- rows that split into the reference's vector body and scalar tail at every 256-pixel block, device and host images"""
+    from opencv_amd import _lib
+    rng = np.random.default_rng(code)
+    fwd = code in orc._HLS_FWD
+    n0 = cv.call_count("cvtBGRtoHSV" if fwd else "cvtHSVtoBGR")
+    for (w, h, cn) in [(256, 9, 3), (263, 7, 3), (1000, 5, 4), (7, 5, 3), (40, 3, 4), (519, 4, 4), (1, 1, 3), (1920, 270, 3)]:
+        src = rng.integers(0, 256, (h, w, cn if fwd else 3), dtype=np.uint8)
+        dcn = 3 if fwd else cn
+        got = cv.cvtColor(torch.from_numpy(src).cuda(), code, dstCn=dcn).cpu().numpy()
+        assert np.array_equal(got, orc.orc_cvtColorHxx(src, code, dcn)), (code, w, h, cn)
+        assert "HLS 8U" in _lib.lib.mi355cv_lastKernel().decode()
+    src = rng.integers(0, 256, (33, 300, 3), dtype=np.uint8)
+    assert np.array_equal(cv.cvtColor(src, code), orc.orc_cvtColorHxx(src, code, 3))          # host pointers
+    assert cv.call_count("cvtBGRtoHSV" if fwd else "cvtHSVtoBGR") == n0 + 9
+    # the ties that depend on the vector-body / scalar-tail split: every colour with b = 0 .. 255, g = 0 .. 255, r = 7 in a row of 65536 + 3 pixels
+    c = np.arange(1 << 16, dtype=np.uint32)
+    row = np.stack([c & 255, c >> 8, np.full_like(c, 7)], axis=-1).astype(np.uint8)
+    row = np.concatenate([row, row[:3]])[None]
+    assert np.array_equal(cv.cvtColor(torch.from_numpy(row).cuda(), code).cpu().numpy(), orc.orc_cvtColorHxx(row, code, 3))
+
+
+@pytest.mark.parametrize("code", [52, 53, 40, 41, 60, 61, 54, 55])
+def test_hls_hsv_32f(cv, orc, code):
+    """CV_32F HSV and HLS, both directions: within 1e-5 (norm-relative; north_star asks 1e-4) of the restatement, which is within 1e-5 of the reference"""
+    rng = np.random.default_rng(code)
+    fwd = code in orc._HLS_FWD or code in orc._HSV
+    for (w, h, cn) in [(263, 31, 3), (64, 5, 4), (7, 3, 3), (1920, 135, 3)]:
+        if fwd:
+            src = rng.random((h, w, cn), dtype=np.float32); src[0, :5] = 0.25; src[2, :2] = 0
+            dcn = 3
+        else:
+            src = rng.random((h, w, 3), dtype=np.float32); src[..., 0] *= 359.9
+            src[0, :4, 2 if code in (60, 61) else 1] = 0
+            dcn = cn
+        got = cv.cvtColor(torch.from_numpy(src).cuda(), code, dstCn=dcn).cpu().numpy()
+        want = orc.orc_cvtColorHxx(src, code, dcn)
+        assert got.shape == want.shape and orc.rel_err(got, want) <= 1e-5 and np.abs(got - want).max() <= 2e-4 * max(1.0, float(np.abs(want).max())), (code, w, h, cn, orc.rel_err(got, want))

@@ -43,6 +43,28 @@ def test_hsv2bgr_arithmetic(emu, code):
         assert np.array_equal(got, o.orc_cvtHSVtoBGR(src, code, 3, 8)), (code, w)
 
 
+@pytest.mark.parametrize("code", [52, 69, 60, 73])
+def test_hls_arithmetic_exhaustive(emu, code):
+    """the HLS lines of hsv_math.h on all 2^24 8-bit inputs, once in the reference's vector body (rows of 4096) and once in its scalar tail (rows of 7), against the
+    restatement that tests/test_oracle_hls.py pins to the reference -- the fused / unfused multiply-adds are what decides a few thousand ties"""
+    c = np.arange(1 << 24, dtype=np.uint32)
+    allc = np.stack([c & 255, (c >> 8) & 255, (c >> 16) & 255], axis=-1).astype(np.uint8)
+    fwd = code in o._HLS_FWD
+    swap, full = (o._HLS_FWD if fwd else o._HLS_INV)[code]
+    n = (1 << 24) // 7 * 7
+    for src in (allc.reshape(4096, 4096, 3), allc[:n].reshape(-1, 7, 3)):
+        got = np.empty_like(src)
+        h, w = src.shape[:2]
+        (emu.emu_bgr2hls if fwd else emu.emu_hls2bgr)(o.P(src), o.step(src), o.P(got), o.step(got), w, h, 3, swap, full)
+        assert np.array_equal(got, o.orc_cvtColorHxx(src, code, 3)), (code, w)
+    rng = np.random.default_rng(code)
+    for (w, h, cn) in [(263, 5, 4), (519, 3, 3), (1, 1, 4)]:
+        src = rng.integers(0, 256, (h, w, cn if fwd else 3), dtype=np.uint8)
+        got = np.empty((h, w, 3 if fwd else cn), np.uint8)
+        (emu.emu_bgr2hls if fwd else emu.emu_hls2bgr)(o.P(src), o.step(src), o.P(got), o.step(got), w, h, cn, swap, full)
+        assert np.array_equal(got, o.orc_cvtColorHxx(src, code, cn)), (code, w, h, cn)
+
+
 # ---- the LDS-tile warp kernel (opencv_amd/csrc/warp8.h): plan, staging, box logic and per-pixel arithmetic run thread by thread on the CPU --------
 @pytest.fixture(scope="module")
 def emu8():

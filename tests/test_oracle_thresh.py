@@ -134,3 +134,21 @@ def test_gaussian_c_float_blur_is_bit_identical_on_8bit_valued_images(ref):
         a = O.orc_sepFilter2D(src, 5, k, k, border=1)
         b = O.ref_GaussianBlur(src, bs, 0.0, 0.0, 1 | 16)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), bs
+
+
+@pytest.mark.ref
+def test_bilateral_filter_32f_matches_reference(ref):
+    """cv::bilateralFilter CV_32FC1 / CV_32FC3 (bilateralFilter_32f): colour weights from the interpolated table over the image's value range, the centre with weight 1,
+    NaN pixels skipped, a constant image copied -- the restatement's scalar form against the reference's vector bodies: 1e-6 (north_star: 1e-4)"""
+    rng = np.random.default_rng(3)
+    for shape in [(40, 53), (33, 47, 3), (9, 8), (5, 70, 3)]:
+        src = (rng.random(shape, dtype=np.float32) * 3 - 1).astype(np.float32)
+        for d, sc, ss, border in [(5, 0.3, 2.0, 4), (0, 1.5, 1.2, 1), (9, 0.05, 3.0, 2), (3, 10.0, 1.0, 0), (15, 0.5, 4.0, 4)]:
+            want = O.ref_bilateralFilter(src, d, sc, ss, border)
+            got = O.orc_bilateralFilter(src, d, sc, ss, border)
+            assert O.rel_err(got, want) <= 1e-6 and np.abs(got - want).max() <= 2e-6, (shape, d, sc, ss, border, O.rel_err(got, want))
+    src = rng.random((30, 40), dtype=np.float32); src[5, 7] = np.nan; src[10:12, 20] = np.nan
+    want = O.ref_bilateralFilter(src, 5, 0.3, 2.0, 4); got = O.orc_bilateralFilter(src, 5, 0.3, 2.0, 4)
+    assert not np.isnan(want).any() and not np.isnan(got).any() and np.abs(got - want).max() <= 2e-6
+    flat = np.full((20, 30, 3), 0.37, np.float32)
+    assert np.array_equal(O.orc_bilateralFilter(flat, 5, 0.3, 2.0, 4), O.ref_bilateralFilter(flat, 5, 0.3, 2.0, 4))
