@@ -1245,6 +1245,26 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
         }
         // (taking a pixel's upper taps from the registers of the pixel above it, where they are the same two source pixels, and masking those
         // lanes out of the load was tried: the per-lane conditions cost more than the lighter gather saves -- 8K 32F, 7 degrees: 69.7 vs 63.5 us)
+        if (sizeof(T) == 4 && CN == 1) {
+            // CV_32FC1: two rows per instruction in packed float arithmetic (v_pk_mul_f32 / v_pk_add_f32; the same products and the same order of sums per row), computed
+            // for every row pair -- rows outside the source loaded element 0 and are simply not stored.  Round 4: the kernel issues ~41 instructions per pixel and is bound
+            // by that (a pure shift is no faster than a rotation); the weights and the blend were 19 of them.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < G; i += 2) {
+                const int j = i + 1 < G ? i + 1 : i;
+                const f2 s32 = {1.f / 32, 1.f / 32}, one = {1.f, 1.f};
+                const f2 fx = f2{(float)(Xs[i] & 31), (float)(Xs[j] & 31)} * s32, fy = f2{(float)(Ys[i] & 31), (float)(Ys[j] & 31)} * s32;
+                const f2 wy0 = one - fy, wx0 = one - fx;
+                const f2 w0 = wy0 * wx0, w1 = wy0 * fx, w2 = fy * wx0, w3 = fy * fx;
+                const f2 p00 = {f0[i].x, f0[j].x}, p01 = {f0[i].y, f0[j].y}, p10 = {f1[i].x, f1[j].x}, p11 = {f1[i].y, f1[j].y};
+                f2 t = p00 * w0 + p01 * w1;
+                t = t + p10 * w2;
+                t = t + p11 * w3;
+                if (in[i]) *reinterpret_cast<float*>(dst + (uint32_t)(yb + g0 + i) * dstep + xoff) = t.x;
+                if (j != i && in[j]) *reinterpret_cast<float*>(dst + (uint32_t)(yb + g0 + j) * dstep + xoff) = t.y;
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < G; i++) {
             if (!in[i]) continue;
@@ -1303,74 +1323,186 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
 // k_warp_lin's (the reference's: imgwarp.cpp:2233-2298 coordinates in 1/1024 rounded to 1/32, remapBilinear<Cast<float,float>> :675-904 weights and
 // summation order), so results are bit-identical to it.  Tiles whose box leaves the source or exceeds the LDS allotment take the gather form pixel by pixel
 // (taps from global memory; the generic sampler where the footprint is not inside).
-constexpr int W32_TW = 64, W32_TH = 32, W32_CAP = 6144;          // tile, LDS floats (24 KB: six workgroups per CU by LDS, eight by threads)
-__global__ __launch_bounds__(256) void k_warp32_tile(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w,
-                                                     const short* __restrict__ tab)
+constexpr int W32_TW = 64, W32_TH = 32, W32_CAP = 4608;          // tile, LDS floats (18 KB: eight workgroups per CU by LDS and by threads)
+struct W32Box { int bx0, by0, bw, bh; bool tiled; };
+// the exact source bounding box of the tile [x0, x1] x [y0, y1] from its corner terms (column terms at x0 / x1, row terms at y0 / y1), and whether the LDS kernel takes it
+__device__ __forceinline__ W32Box warp32Box(const SampleArgs& s, int adA, int adB, int bdA, int bdB, int XrA, int XrB, int YrA, int YrB)
 {
-    __shared__ float box[W32_CAP];
-    __shared__ int rowT[2 * W32_TH];                                 // X0(y), Y0(y) of the tile's rows
-    int tx, ty;
-    tileOf(w, tx, ty);
-    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = tx * W32_TW, y0 = ty * W32_TH;
-    const int x1 = min(x0 + W32_TW, w.dw) - 1, y1 = min(y0 + W32_TH, w.dh) - 1;
-    if (tid < W32_TH) {
-        const int y = min(y0 + tid, w.dh - 1);
-        rowT[tid] = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16;
-        rowT[W32_TH + tid] = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16;
-    }
-    const int x = x0 + lane;
-    const int xc = min(x, w.dw - 1);
-    const int ad = satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)xc), 1024.0));
-    const int bd = satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)xc), 1024.0));
-    __syncthreads();
-    // the box: extremes of the column terms at the tile's first / last column (lanes 0 and x1 - x0), of the row terms at its first / last row
-    const int adA = __builtin_amdgcn_readlane(ad, 0), adB = __builtin_amdgcn_readlane(ad, x1 - x0), bdA = __builtin_amdgcn_readlane(bd, 0), bdB = __builtin_amdgcn_readlane(bd, x1 - x0);
-    const int XrA = rowT[0], XrB = rowT[y1 - y0], YrA = rowT[W32_TH], YrB = rowT[W32_TH + y1 - y0];
     const long long Xlo = (long long)min(adA, adB) + min(XrA, XrB), Xhi = (long long)max(adA, adB) + max(XrA, XrB);
     const long long Ylo = (long long)min(bdA, bdB) + min(YrA, YrB), Yhi = (long long)max(bdA, bdB) + max(YrA, YrB);
-    bool tiled = Xlo > -(1ll << 30) && Xhi < (1ll << 30) && Ylo > -(1ll << 30) && Yhi < (1ll << 30);    // the int sums of the reference do not wrap here
-    const int bx0 = (int)(Xlo >> 10), bx1 = (int)(Xhi >> 10) + 1, by0 = (int)(Ylo >> 10), by1 = (int)(Yhi >> 10) + 1;
-    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-    tiled = tiled && bx0 >= 0 && by0 >= 0 && bx1 <= s.sw - 1 && by1 <= s.sh - 1 && (long long)bw * bh <= W32_CAP;
-    if (tiled) {
-        // stage the box: one wave per row, consecutive lanes on consecutive floats
-        for (int r = wave; r < bh; r += 4) {
-            const float* g = reinterpret_cast<const float*>(src + (size_t)(by0 + r) * sstep) + bx0;
-            float* l = box + r * bw;
-            for (int c = lane; c < bw; c += 64) l[c] = g[c];
+    W32Box b;
+    b.tiled = Xlo > -(1ll << 30) && Xhi < (1ll << 30) && Ylo > -(1ll << 30) && Yhi < (1ll << 30);      // the int sums of the reference do not wrap here
+    b.bx0 = (int)(Xlo >> 10); b.by0 = (int)(Ylo >> 10);
+    const int bx1 = (int)(Xhi >> 10) + 1, by1 = (int)(Yhi >> 10) + 1;
+    b.bw = bx1 - b.bx0 + 1; b.bh = by1 - b.by0 + 1;
+    b.tiled = b.tiled && b.bx0 >= 0 && b.by0 >= 0 && bx1 <= s.sw - 1 && by1 <= s.sh - 1 && (long long)b.bw * b.bh <= W32_CAP;
+    return b;
+}
+__device__ __forceinline__ int warp32RowX(const WarpArgs& w, int y) { return satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)y), w.M[2]), 1024.0)) + 16; }
+__device__ __forceinline__ int warp32RowY(const WarpArgs& w, int y) { return satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)y), w.M[5]), 1024.0)) + 16; }
+__device__ __forceinline__ int warp32ColX(const WarpArgs& w, int x) { return satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0)); }
+__device__ __forceinline__ int warp32ColY(const WarpArgs& w, int x) { return satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0)); }
+
+// the coordinate terms of every destination column and row, once per call: terms = colX[dw], colY[dw], rowX[dh], rowY[dh]; work[0] = 0 (the rest list's length)
+__global__ __launch_bounds__(256) void k_warp32_terms(WarpArgs w, int* __restrict__ terms, uint32_t* __restrict__ work)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) work[0] = 0;
+    if (i < w.dw) { terms[i] = warp32ColX(w, i); terms[w.dw + i] = warp32ColY(w, i); }
+    if (i < w.dh) { terms[2 * w.dw + i] = warp32RowX(w, i); terms[2 * w.dw + w.dh + i] = warp32RowY(w, i); }
+}
+
+struct W32Bx { int bx0, by0, pitch, n4, bh; bool tiled; };       // the box widened to whole float4 columns: first column (multiple of 4), first row, floats per row, float4 elements
+__device__ __forceinline__ W32Bx warp32Widen(const SampleArgs& s, const W32Box& e)
+{
+    W32Bx b;
+    b.bx0 = e.bx0 & ~3; b.by0 = e.by0; b.bh = e.bh;
+    const int bx1 = (e.bx0 + e.bw - 1) | 3;
+    b.pitch = bx1 - b.bx0 + 1;
+    b.n4 = (b.pitch >> 2) * e.bh;
+    b.tiled = e.tiled && bx1 <= s.sw - 1 && b.n4 <= W32_CAP / 4;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_warp32_tile(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w, int tpw,
+                                                     const int* __restrict__ terms, uint32_t* __restrict__ work)
+{
+    // A workgroup walks `tpw` horizontally adjacent tiles of one tile row.  Two LDS buffers: while tile j is computed from one, the box of tile j + 1 is on its way from
+    // L2 into registers (16-byte loads: the box is widened to whole float4 columns, element i = tid + 256 u of the dense box, consecutive lanes on consecutive 16 bytes
+    // of a box row), and is parked in the other buffer afterwards -- one barrier per tile, the load latency of a tile under the arithmetic of its predecessor.
+    // History (profiles/r04_warp32_ab.txt, 8K frame, 7 degrees; the gather kernel: 75 us): staged row by row and synchronously 154 us; batched dword loads 95;
+    // double-buffered 93 -- by then bound by instruction issue (~700 instructions per thread and tile: 18 dword loads with a division each, 45 per pixel); 16-byte
+    // staging, scalar row terms and packed float arithmetic 84, of which ~24 were the second kernel evaluating the tile predicate in double arithmetic in every thread:
+    // the terms now come from a table built once per call and the tiles left over go through a list.
+    __shared__ __attribute__((aligned(16))) float box[2][W32_CAP];
+    constexpr int NE = (W32_CAP / 4 + 255) / 256;                    // float4 box elements per thread
+    constexpr int RPW = W32_TH / 4;                                  // rows per wave
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = blockIdx.y, tx0 = blockIdx.x * tpw, ntile = min(tpw, w.gx - tx0);
+    const int y0 = ty * W32_TH, y1 = min(y0 + W32_TH, w.dh) - 1;
+    const int* colX = terms; const int* colY = terms + w.dw; const int* rowX = terms + 2 * w.dw; const int* rowY = rowX + w.dh;
+    int rX[RPW], rY[RPW];                                            // uniform: scalar loads
+#pragma unroll
+    for (int i = 0; i < RPW; i++) { const int y = min(y0 + wave * RPW + i, w.dh - 1); rX[i] = rowX[y]; rY[i] = rowY[y]; }
+    const int XrA = rowX[y0], XrB = rowX[y1], YrA = rowY[y0], YrB = rowY[y1];
+    W32Bx cur, nxt;
+    int adC = 0, bdC = 0, adN = 0, bdN = 0;                          // this thread's column terms in the current / next tile
+    float4 v[NE];
+    auto prepare = [&](int j, W32Bx& b, int& ad, int& bd) {          // box of tile j and the thread's column terms; issues the loads of its elements into v
+        const int x0 = (tx0 + j) * W32_TW, x1 = min(x0 + W32_TW, w.dw) - 1;
+        const int xc = min(x0 + lane, w.dw - 1);
+        ad = colX[xc]; bd = colY[xc];
+        b = warp32Widen(s, warp32Box(s, colX[x0], colX[x1], colY[x0], colY[x1], XrA, XrB, YrA, YrB));
+        if (!b.tiled) {
+            if (tid == 0) { const uint32_t k = atomicAdd(work, 1u); work[1 + k] = ((uint32_t)blockIdx.z * (uint32_t)w.gy + (uint32_t)ty) * (uint32_t)w.gx + (uint32_t)(tx0 + j); }
+            return;
         }
+        const int c4 = b.pitch >> 2;
+        const unsigned magic = 0xffffffffu / (unsigned)c4 + (c4 > 1 ? 1u : 0u);          // i / c4 for i < 2^16 by one mul_hi (c4 == 1: i itself)
+        const uchar* gb = src + (size_t)b.by0 * sstep + (size_t)b.bx0 * 4;
+#pragma unroll
+        for (int u = 0; u < NE; u++) {
+            const int i = tid + 256 * u;
+            const int r = c4 > 1 ? (int)__umulhi((unsigned)i, magic) : i, c = i - r * c4;
+            v[u] = i < b.n4 ? *reinterpret_cast<const float4*>(gb + (size_t)r * sstep + (size_t)c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto park = [&](const W32Bx& b, float* buf) {
+        if (!b.tiled) return;
+#pragma unroll
+        for (int u = 0; u < NE; u++) { const int i = tid + 256 * u; if (i < b.n4) reinterpret_cast<float4*>(buf)[i] = v[u]; }
+    };
+    prepare(0, cur, adC, bdC);
+    park(cur, box[0]);
+    __syncthreads();
+    for (int j = 0; j < ntile; j++) {
+        const bool more = j + 1 < ntile;
+        if (more) prepare(j + 1, nxt, adN, bdN);
+        const int x0 = (tx0 + j) * W32_TW, x1 = min(x0 + W32_TW, w.dw) - 1, x = x0 + lane;
+        if (cur.tiled && x <= x1) {                                  // (tiles the LDS path does not take are on the list for k_warp32_rest)
+            const float* bx = box[j & 1];
+            const int pitch = cur.pitch, base = -cur.by0 * pitch - cur.bx0;
+            uchar* dcol = dst + (size_t)x * 4u;
+#pragma unroll
+            for (int i = 0; i < RPW; i += 2) {                       // rows i and i + 1 of the wave together: packed float arithmetic
+                const int ya = y0 + wave * RPW + i;
+                if (ya > y1) break;
+                const int Xa = (rX[i] + adC) >> 5, Ya = (rY[i] + bdC) >> 5, Xb = (rX[i + 1] + adC) >> 5, Yb = (rY[i + 1] + bdC) >> 5;
+                const float* la = bx + ((Ya >> 5) * pitch + (Xa >> 5) + base);
+                const float* lb = ya + 1 <= y1 ? bx + ((Yb >> 5) * pitch + (Xb >> 5) + base) : la;
+                const f2 p00 = {la[0], lb[0]}, p01 = {la[1], lb[1]}, p10 = {la[pitch], lb[pitch]}, p11 = {la[pitch + 1], lb[pitch + 1]};
+                const f2 s32 = {1.f / 32, 1.f / 32}, one = {1.f, 1.f};
+                const f2 fx = f2{(float)(Xa & 31), (float)(Xb & 31)} * s32, fy = f2{(float)(Ya & 31), (float)(Yb & 31)} * s32;
+                const f2 wy0 = one - fy, wx0 = one - fx;
+                const f2 w0 = wy0 * wx0, w1 = wy0 * fx, w2 = fy * wx0, w3 = fy * fx;
+                f2 t = p00 * w0 + p01 * w1;
+                t = t + p10 * w2;
+                t = t + p11 * w3;
+                *reinterpret_cast<float*>(dcol + (size_t)ya * dstep) = t.x;
+                if (ya + 1 <= y1) *reinterpret_cast<float*>(dcol + (size_t)(ya + 1) * dstep) = t.y;
+            }
+        }
+        if (more) { park(nxt, box[(j + 1) & 1]); cur = nxt; adC = adN; bdC = bdN; }
         __syncthreads();
     }
-    if (x > x1) return;
-    const uint32_t xoff = (uint32_t)x * 4u;
-#pragma unroll 2
-    for (int i = 0; i < W32_TH / 4; i++) {
-        const int ly = wave * (W32_TH / 4) + i, y = y0 + ly;
-        if (y > y1) break;
-        const int X = (rowT[ly] + ad) >> 5, Y = (rowT[W32_TH + ly] + bd) >> 5;
-        const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
-        float p00, p01, p10, p11;
-        if (tiled) {
-            const float* l = box + (sy - by0) * bw + (sx - bx0);
-            p00 = l[0]; p01 = l[1]; p10 = l[bw]; p11 = l[bw + 1];
-        } else if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
-            const float* g = reinterpret_cast<const float*>(src + (size_t)sy * sstep) + sx;
-            const float* g1 = reinterpret_cast<const float*>(src + (size_t)(sy + 1) * sstep) + sx;
-            p00 = g[0]; p01 = g[1]; p10 = g1[0]; p11 = g1[1];
-        } else {
-            samplePixel(src, sstep, dst + (size_t)y * dstep + xoff, s, satShort(sx), satShort(sy), ax, ay, tab);
+}
+
+// the tiles k_warp32_tile left (source box not wholly inside the image, or too large for its LDS allotment), from its list: the gather form, pixel by pixel
+__global__ __launch_bounds__(256) void k_warp32_rest(const uchar* __restrict__ src0, uint32_t sstep, uchar* __restrict__ dst0, uint32_t dstep, SampleArgs s, WarpArgs w,
+                                                     const short* __restrict__ tab, const int* __restrict__ terms, const uint32_t* __restrict__ work)
+{
+    const uint32_t count = work[0];
+    const int* colX = terms; const int* colY = terms + w.dw; const int* rowX = terms + 2 * w.dw; const int* rowY = rowX + w.dh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x; t < count; t += gridDim.x) {        // (launched with one block per tile of the image: blocks beyond the list's length leave at once)
+        const uint32_t id = work[1 + t];
+        const int tx = (int)(id % (uint32_t)w.gx), ty = (int)((id / (uint32_t)w.gx) % (uint32_t)w.gy), fr = (int)(id / ((uint32_t)w.gx * (uint32_t)w.gy));
+        const uchar* src = src0 + (size_t)fr * w.sframe; uchar* dst = dst0 + (size_t)fr * w.dframe;
+        const int x0 = tx * W32_TW, y0 = ty * W32_TH;
+        const int x1 = min(x0 + W32_TW, w.dw) - 1, y1 = min(y0 + W32_TH, w.dh) - 1;
+        const int x = x0 + lane;
+        if (x > x1) continue;
+        const int ad = colX[x], bd = colY[x];
+        const uint32_t xoff = (uint32_t)x * 4u;
+        // BORDER_CONSTANT and the tile's whole source box outside the image (large rotations leave such tiles by the thousand): the border value, no sampling
+        const W32Box e = warp32Box(s, colX[x0], colX[x1], colY[x0], colY[x1], rowX[y0], rowX[y1], rowY[y0], rowY[y1]);
+        if (s.border == B_CONSTANT && (e.bx0 > s.sw - 1 || e.bx0 + e.bw - 1 < 0 || e.by0 > s.sh - 1 || e.by0 + e.bh - 1 < 0)) {
+#pragma unroll
+            for (int i = 0; i < W32_TH / 4; i++) { const int y = y0 + wave * (W32_TH / 4) + i; if (y <= y1) *reinterpret_cast<float*>(dst + (size_t)y * dstep + xoff) = s.cval[0]; }
             continue;
         }
-        const float s32 = 1.f / 32;
-        const float fx = ax * s32, fy = ay * s32;
-        const float wy0 = 1.f - fy, wx0 = 1.f - fx;
-        const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
-        float t = __fadd_rn(__fmul_rn(p00, w0), __fmul_rn(p01, w1));
-        t = __fadd_rn(t, __fmul_rn(p10, w2));
-        t = __fadd_rn(t, __fmul_rn(p11, w3));
-        *reinterpret_cast<float*>(dst + (size_t)y * dstep + xoff) = t;
+        int Xs[W32_TH / 4], Ys[W32_TH / 4];
+        float q00[W32_TH / 4], q01[W32_TH / 4], q10[W32_TH / 4], q11[W32_TH / 4];
+        unsigned in = 0;
+#pragma unroll
+        for (int i = 0; i < W32_TH / 4; i++) {                       // all of the thread's taps are requested before the first is used
+            const int y = min(y0 + wave * (W32_TH / 4) + i, y1);
+            Xs[i] = (rowX[y] + ad) >> 5; Ys[i] = (rowY[y] + bd) >> 5;
+            const int sx = Xs[i] >> 5, sy = Ys[i] >> 5;
+            const bool inside = (unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1);
+            in |= inside ? 1u << i : 0u;
+            const float* g = reinterpret_cast<const float*>(src + (size_t)(inside ? sy : 0) * sstep) + (inside ? sx : 0);
+            const float* g1 = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(g) + sstep);
+            q00[i] = g[0]; q01[i] = g[1]; q10[i] = g1[0]; q11[i] = g1[1];
+        }
+#pragma unroll
+        for (int i = 0; i < W32_TH / 4; i++) {
+            const int y = y0 + wave * (W32_TH / 4) + i;
+            if (y > y1) break;
+            const int ax = Xs[i] & 31, ay = Ys[i] & 31;
+            if ((in >> i) & 1) {
+                const float s32 = 1.f / 32;
+                const float fx = ax * s32, fy = ay * s32;
+                const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+                const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
+                float tt = __fadd_rn(__fmul_rn(q00[i], w0), __fmul_rn(q01[i], w1));
+                tt = __fadd_rn(tt, __fmul_rn(q10[i], w2));
+                tt = __fadd_rn(tt, __fmul_rn(q11[i], w3));
+                *reinterpret_cast<float*>(dst + (size_t)y * dstep + xoff) = tt;
+            } else samplePixel(src, sstep, dst + (size_t)y * dstep + xoff, s, satShort(Xs[i] >> 5), satShort(Ys[i] >> 5), ax, ay, tab);
+        }
     }
 }
 
@@ -1627,12 +1759,25 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         const char* ve = getenv("MI355CV_WARP_BAND");
         w.band = ve ? atoi(ve) : 0;
         // CV_32FC1 affine: the LDS-tile kernel (MI355CV_WARP32=0 keeps the gather kernel for A/B runs)
-        static const bool warp32On = [] { const char* v = getenv("MI355CV_WARP32"); return !v || atoi(v) != 0; }();
-        if (warp32On && kind == 0 && depth == D32F && cn == 1) {
+        // Measured on 8K frames (profiles/r04_warp32_ab.txt): the LDS-tile kernel wins where a wave's 64 destination pixels spread over many source rows (33 degrees: 76 us
+        // against the gather kernel's 90; 90 degrees likewise), the gather kernel where they stay within a few rows (7 degrees, shifts: 72-75 against 79) and wherever the
+        // source box of a tile exceeds the LDS allotment (minification by ~1.5 and more: every tile would go to the list).  MI355CV_WARP32 = 0 / 1 force either kernel.
+        static const int warp32Env = [] { const char* v = getenv("MI355CV_WARP32"); return v ? atoi(v) : -1; }();
+        const bool spreadRows = std::fabs(M[3]) * 64 >= 12.0, fitsLds = (std::fabs(M[0]) * 64 + std::fabs(M[1]) * 32 + 6) * (std::fabs(M[3]) * 64 + std::fabs(M[4]) * 32 + 2) <= W32_CAP;
+        const bool warp32On = warp32Env < 0 ? (spreadRows && fitsLds) : warp32Env != 0;
+        if (warp32On && kind == 0 && depth == D32F && cn == 1 && ((((uintptr_t)ds) | dss | w.sframe) & 15) == 0) {       // (16-byte box loads)
             dim3 g3(divUp(dw, W32_TW), divUp(dh, W32_TH), nframes);
             w.gx = g3.x; w.gy = g3.y;
-            hipLaunchKernelGGL(k_warp32_tile, g3, dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev);
-            noteKernel("k_warp32_tile grid=%ux%ux%u x256 tile %dx%d lds=%d floats band=%d", g3.x, g3.y, g3.z, W32_TW, W32_TH, W32_CAP, w.band);
+            static const int tpw32 = [] { const char* v = getenv("MI355CV_WARP32_TPW"); const int t = v ? atoi(v) : 6; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            // coordinate terms of every destination column and row (double arithmetic, once per call) + the list of tiles the LDS kernel leaves to k_warp32_rest
+            const size_t ntiles = (size_t)g3.x * g3.y * nframes;
+            int* terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
+            uint32_t* work = (uint32_t*)stg.scratch((ntiles + 1) * sizeof(uint32_t));
+            if (!terms || !work) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms / the tile list");
+            hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work);
+            hipLaunchKernelGGL(k_warp32_tile, dim3(divUp((int)g3.x, tpw32), g3.y, nframes), dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, tpw32, terms, work);
+            hipLaunchKernelGGL(k_warp32_rest, dim3((unsigned)std::min<size_t>(ntiles, 1u << 22)), dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, g_tabDev, terms, work);
+            noteKernel("k_warp32_tile (+ k_warp32_rest for what it leaves) grid=%ux%ux%u x256 tile %dx%d lds=%d floats band=%d", g3.x, g3.y, g3.z, W32_TW, W32_TH, W32_CAP, w.band);
             return stg.finish(entry);
         }
         dim3 g2(divUp(dw, 64), divUp(dh, 4 * (depth == D32F ? warpRows<float>() : warpRows<uchar>())), nframes);

@@ -39,9 +39,14 @@ else:
         print("  warpPerspective 4K 8UC%%d       %%7.2f us/frame  %%.3f of HBM  digest %%s  [%%s]" %% (cn, ms / B * 1e3, B * 2 * cn * 8294400 / ms / 1e6 / 8000, d, _lib.lib.mi355cv_lastKernel().decode()[:40]), flush=True)
         del src, dst
 ''' % ROOT
-for what, var, vals in (("f32", "MI355CV_WARP32", ("0", "1")), ("persp8", "MI355CV_WARP8", ("1", "2"))):
+SETS = (("f32", "MI355CV_WARP32", ("0", "1", "auto")), ("persp8", "MI355CV_WARP8", ("1", "2")))
+if "f32" in sys.argv[1:]: SETS = SETS[:1]
+if "f32only1" in sys.argv[1:]: SETS = (("f32", "MI355CV_WARP32", ("1",)),)
+for what, var, vals in SETS:
     for v in vals:
-        env = dict(os.environ); env[var] = v; env["WARP_AB_WHAT"] = what
+        env = dict(os.environ); env["WARP_AB_WHAT"] = what
+        if v == "auto": env.pop(var, None)
+        else: env[var] = v
         print(f"== {what}: {var}={v}", flush=True)
         p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=400)
         print(p.stdout.rstrip() or ("failed: " + p.stderr[-500:]), flush=True)
