@@ -350,6 +350,9 @@ int Stager::finish(const char* entry)
     }
     // a hook called from inside another hook (device pointers, same stream) leaves the synchronisation to the outermost one
     if (anyHost_ || (!asyncMode() && t_depth == 1)) {
+        // (A synchronous hook on a 4K frame is a 3-8 us kernel and hipStreamSynchronize adds 12-15 us of completion latency: 19.6 us per synchronous
+        // cv_hal_gaussianBlurBinomial call against 8.2 us of enqueue + execution and 3.3 us of host time per asynchronous call, tools/ubench/call_latency.cpp,
+        // profiles/r04_call_latency.txt.  Polling hipStreamQuery before blocking was tried and is SLOWER, 22.1 us: the query costs more than the wake-up it saves.)
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: execution failed: %s", entry, hipGetErrorString(e));
     }
