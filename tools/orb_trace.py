@@ -1,4 +1,4 @@
-"""20 ORB calls on one device-resident 4K frame, for a rocprofv3 kernel / memory-copy trace (tools/gpu_call29.sh)"""
+"""20 ORB calls on one device-resident 4K frame, for a rocprofv3 kernel / memory-copy trace (tools/gpu_call.sh)"""
 import sys
 import time
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel durations of the secondary rows that are still below their roofline targets: run under `rocprofv3 --kernel-trace --stats` (tools/gpu_call9.sh)."""
+"""Per-kernel durations of the secondary rows that are still below their roofline targets: run under `rocprofv3 --kernel-trace --stats` (tools/gpu_call.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
