@@ -145,7 +145,7 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
     Layout L;
     buildLayout(L, width, height, nLevels, p.firstLevel, scaleFactor, p.edgeThreshold, p.patchSize);
     for (int l = 0; l < nLevels; l++) if (L.layer[l].w < 1 || L.layer[l].h < 1) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: a pyramid level is empty"); return -1; }
-    if ((long long)L.pitch * L.bufH > 0x7fffffffLL) return -1;
+    if ((long long)L.pitch * L.bufH > 0x7fffffffLL) { setError(MI355CV_NOT_IMPLEMENTED, "ORB: the pyramid buffer (%d x %d bytes) exceeds 2 GiB", L.pitch, L.bufH); return -1; }
 
     Stager stg;                                  // outermost: the resize / sepFilter hooks called below leave synchronisation and scratch recycling to this one
     if (!ensureDevice()) return -1;
@@ -248,12 +248,17 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
             std::vector<std::future<void>> side;
             int big = 0;
             for (int l = 0; l < nLevels; l++) big += cnt[l] >= 8192u;
+            std::vector<int> sideLevel;
             for (int l = nLevels - 1; l >= 0; l--) {                       // the longest list (level firstLevel or 0) on the calling thread, last
-                if (cnt[l] >= 8192u && big > 1 && l != 0) side.push_back(std::async(std::launch::async, cull, l));
-                else if (l != 0) cull(l);
+                bool spawned = false;
+                if (cnt[l] >= 8192u && big > 1 && l != 0) {
+                    try { side.push_back(std::async(std::launch::async, cull, l)); sideLevel.push_back(l); spawned = true; }
+                    catch (...) { spawned = false; }                       // no thread to be had: cull here (nothing may cross the extern "C" boundary)
+                }
+                if (!spawned && l != 0) cull(l);
             }
             cull(0);
-            for (auto& f : side) f.get();
+            for (size_t i = 0; i < side.size(); i++) { try { side[i].get(); } catch (...) { cull(sideLevel[i]); } }
         }
         std::vector<int> counts(nLevels);
         std::vector<KP> lvl;

@@ -363,13 +363,15 @@ int Stager::finish(const char* entry)
 // ------------------------------------------------------------------ pipelined host batches
 bool hostBatchEligible(const void* src, const void* dst, int nframes)
 {
-    return nframes >= 1 && src && dst && !disabled() && ensureDevice() && ptrKind(src) == PTR_HOST && ptrKind(dst) == PTR_HOST;
+    // no HIP state is touched here (resolveDevice names the device, ptrKind classifies the pointers): a batch this predicate rejects leaves the caller's device alone
+    return nframes >= 1 && src && dst && !disabled() && resolveDevice() >= 0 && ptrKind(src) == PTR_HOST && ptrKind(dst) == PTR_HOST;
 }
 
 int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
 {
-    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes) return mi355::declined(__func__, __LINE__, "disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes");
-    Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
+    if (disabled() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes) return mi355::declined(__func__, __LINE__, "disabled() || hb.nframes < 1 || hb.srows < 1 || hb.drows < 1 || !hb.srowBytes || !hb.drowBytes");
+    Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one; first, so that a declined call also puts the host's device back
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, dp = (hb.drowBytes + 255) & ~(size_t)255;
     const size_t sfb = sp * (size_t)hb.srows, dfb = dp * (size_t)hb.drows;
     int cf = (int)((size_t)(64u << 20) / std::max(sfb, dfb));           // frames per chunk: <= 64 MB per buffer, <= 16 frames
@@ -419,9 +421,10 @@ int runHostBatch(const char* entry, const HostBatch& hb, const HostBatchFn& run)
 
 int runHostBatchN(const char* entry, const HostBatchN& hb, const HostBatchNFn& run)
 {
-    if (disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT) return mi355::declined(__func__, __LINE__, "disabled() || !ensureDevice() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT");
+    if (disabled() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT) return mi355::declined(__func__, __LINE__, "disabled() || hb.nframes < 1 || hb.srows < 1 || !hb.srowBytes || hb.nout < 1 || hb.nout > HOST_BATCH_MAX_OUT");
     for (int o = 0; o < hb.nout; o++) if (!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes) return mi355::declined(__func__, __LINE__, "!hb.out[o].dst || hb.out[o].drows < 1 || !hb.out[o].drowBytes");
     Stager stg;                                                          // outermost: the chunks' own hooks leave synchronisation to this one
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const size_t sp = (hb.srowBytes + 255) & ~(size_t)255, sfb = sp * (size_t)hb.srows;
     size_t dp[HOST_BATCH_MAX_OUT], dfb[HOST_BATCH_MAX_OUT], perFrame = sfb;
     for (int o = 0; o < hb.nout; o++) { dp[o] = (hb.out[o].drowBytes + 255) & ~(size_t)255; dfb[o] = dp[o] * (size_t)hb.out[o].drows; perFrame += dfb[o]; }

@@ -497,7 +497,13 @@ __global__ __launch_bounds__(256) void k_tm_split_bf16(const uchar* __restrict__
     const unsigned short a = f32_to_bf16_rn(v);
     const float r = __fsub_rn(v, __uint_as_float((uint32_t)a << 16));                     // exact: the remainder has at most 16 significant bits
     const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
-    hi[o] = a; mid[o] = f32_to_bf16_rn(r);
+    // Inf / NaN travel in the MID plane alone, hi = 0: of the three products only mid(image) * hi(template) then sees the value, so an Inf pixel gives the Inf the fp32 kernel
+    // gives (in the hi plane it would also meet the template's small remainders of either sign: Inf - Inf = NaN); a NaN whose payload sits in the low 16 bits only keeps
+    // a quiet bit so that the truncation does not read as Inf
+    const uint32_t bits = __float_as_uint(v);
+    const bool finite = (bits & 0x7f800000u) != 0x7f800000u;
+    const unsigned short top = (unsigned short)(bits >> 16) | (unsigned short)(((bits & 0xffffu) != 0 && (bits & 0x7f0000u) == 0) ? 0x40 : 0);
+    hi[o] = finite ? a : (unsigned short)0; mid[o] = finite ? f32_to_bf16_rn(r) : top;
 }
 
 // float template -> two bf16 planes in the kernel's Toeplitz row layout (th rows of BF_TE elements)
@@ -1264,7 +1270,10 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_bf16<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet[dv_] = true; } \
                 hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 0); \
                 hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); \
-                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); } while (0)
+                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); \
+                /* TM_SQDIFF* / TM_CCOEFF*: the result is a difference of large terms (window energy - 2 corr + template energy; corr - mean product), which amplifies the \
+                   ~2^-17 relative error of the dropped mid * mid term near a perfect match and on images with a large offset: those methods take the fourth product */ \
+                if (method != 2 && method != 3) hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); } while (0)
                 switch (KS) { case 1: case 2: BF_LAUNCH(2); break; case 3: case 4: BF_LAUNCH(4); break; case 5: case 6: BF_LAUNCH(6); break; case 7: case 8: BF_LAUNCH(8); break; default: BF_LAUNCH(10); }
 #undef BF_LAUNCH
                 if (method != 2) {
@@ -1274,7 +1283,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                     hipLaunchKernelGGL((k_wsum_cols<double>), dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
                     hipLaunchKernelGGL(k_tm_finish_f, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, rf, drs, rfr, w1, w2, wframe, rw, dna);
                 }
-                noteKernel("k_ccorr_bf16<%d> x3 (hi*hi + hi*mid + mid*hi) grid=%ux%ux%u x256 lds=%zu", KS, gb.x, gb.y, gb.z, lds);
+                noteKernel("k_ccorr_bf16<%d> x%d (hi*hi + hi*mid + mid*hi%s) grid=%ux%ux%u x256 lds=%zu", KS, method != 2 && method != 3 ? 4 : 3, method != 2 && method != 3 ? " + mid*mid" : "", gb.x, gb.y, gb.z, lds);
                 done = true;
                 return stg.finish(entry);
             }

@@ -107,8 +107,12 @@ __global__ __launch_bounds__(256) void k_resize(const uchar* __restrict__ src, s
                 } else if (a.depth == D32F && a.isx == 2 && a.isy == 2) {
                     const float* r0 = reinterpret_cast<const float*>(src + (size_t)sy0 * sstep);
                     const float* r1 = reinterpret_cast<const float*>(src + (size_t)(sy0 + 1) * sstep);
-                    const float s = (r0[(dx * 2) * cn + c] + r0[(dx * 2 + 1) * cn + c]) + (r1[(dx * 2) * cn + c] + r1[(dx * 2 + 1) * cn + c]);
-                    reinterpret_cast<float*>(D)[idx] = s * 0.25f;
+                    // ResizeAreaFastVec_SIMD_32f (resize.cpp:2856-2905) sums pairwise, (s00 + s01) + (s10 + s11), for 1 channel below the last multiple of its 4 lanes and
+                    // for every 4-channel pixel; the scalar loop behind it (:3013-3025: the 1-channel tail, 2 and 3 channels) sums in order, ((s00 + s01) + s10) + s11
+                    const float s00 = r0[(dx * 2) * cn + c], s01 = r0[(dx * 2 + 1) * cn + c], s10 = r1[(dx * 2) * cn + c], s11 = r1[(dx * 2 + 1) * cn + c];
+                    const bool pairwise = cn == 4 || (cn == 1 && dx < (wfull / 4) * 4);
+                    const float s = pairwise ? __fadd_rn(__fadd_rn(s00, s01), __fadd_rn(s10, s11)) : __fadd_rn(__fadd_rn(__fadd_rn(s00, s01), s10), s11);
+                    reinterpret_cast<float*>(D)[idx] = __fmul_rn(s, 0.25f);
                 } else {
                     float s = 0;
                     for (int sy = 0; sy < a.isy; sy++) for (int sx = 0; sx < a.isx; sx++)
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(256) void k_area2x2_f32(const uchar* __restrict__ s
         o.w = __fmul_rn(__fadd_rn(__fadd_rn(a1.z, a1.w), __fadd_rn(b1.z, b1.w)), 0.25f);
         __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(D));
     } else {
-        for (int p = 0; 4 * g + p < dw; p++) D[p] = __fmul_rn(__fadd_rn(__fadd_rn(r0[2 * p], r0[2 * p + 1]), __fadd_rn(r1[2 * p], r1[2 * p + 1])), 0.25f);
+        // the last dw % 4 columns are the reference's scalar tail (resize.cpp:3013-3025): ((s00 + s01) + s10) + s11, not the vector body's pairwise sums
+        for (int p = 0; 4 * g + p < dw; p++) D[p] = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(r0[2 * p], r0[2 * p + 1]), r1[2 * p]), r1[2 * p + 1]), 0.25f);
     }
 }
 

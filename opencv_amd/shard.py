@@ -102,15 +102,22 @@ def gather_counts(n, device=None):
     return int(t[0])
 
 
-def gather_ragged(rows, dst=0, device=None):
+def gather_ragged(rows, dst=0, device=None, dtype=None):
     """Egress of a detector's output when the frames are sharded (SURVEY.md section 8e + f3): every rank holds one variable-length record array per frame it owns
     (keypoints, descriptors: the number of rows is the GPU's decision), rank `dst` wants all of them in frame order.  `rows`: a list of 2-D uint8-viewable
     numpy arrays of the same row width (one per owned frame, in frame order; ranks own contiguous frame blocks -- frame_range).  One all_gather of the
     per-frame row counts, one padded all_gather of the bytes: two collectives, off the data path of the kernels.  Returns the list of all frames' arrays on
-    `dst`, None elsewhere (single process: the input)."""
+    `dst`, None elsewhere (single process: the input).  1-D arrays of records (a structured dtype such as the keypoint records of ORB.detectAndCompute) are taken
+    as n rows of one record and come back 1-D.  `dtype`: the element type of the output; needed only where `dst` may own no frame (it cannot read it off its own list)."""
     arrs = [np.ascontiguousarray(a) for a in rows]
+    one_d = bool(arrs) and arrs[0].ndim == 1
+    if dtype is None and arrs:
+        dtype = arrs[0].dtype
+    dtype = np.dtype(dtype) if dtype is not None else None
+    one_d = one_d or (dtype is not None and dtype.names is not None)         # records travel as rows of one record
+    arrs = [a.reshape(-1, 1) if a.ndim == 1 else a for a in arrs]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return arrs
+        return [a.reshape(-1) for a in arrs] if one_d else arrs
     ws, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
     width = 0
@@ -118,7 +125,6 @@ def gather_ragged(rows, dst=0, device=None):
         if a.ndim != 2:
             raise ValueError("gather_ragged: 2-D record arrays expected")
         width = max(width, a.shape[1] * a.itemsize)
-    dtype = arrs[0].dtype if arrs else None
     # 1. how many frames and rows everybody has (frames per rank differ by at most one: pad the count vectors to the maximum)
     meta = torch.tensor([len(arrs), width], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(ws)]
@@ -151,5 +157,6 @@ def gather_ragged(rows, dst=0, device=None):
             n = int(cnts[r][f])
             block = raw[off:off + n * width].reshape(n, width)
             off += n * width
-            out.append(block.view(dtype).copy() if dtype is not None and dtype.itemsize > 1 and width % dtype.itemsize == 0 else block.copy())
+            rec = block.view(dtype).copy() if dtype is not None and dtype.itemsize > 1 and width % dtype.itemsize == 0 else block.copy()
+            out.append(rec.reshape(-1) if one_d else rec)
     return out

@@ -384,7 +384,11 @@ int orc_resize(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, s
                             float s = 0;
                             if (depth == 5 && iscale_x == 2 && iscale_y == 2) {   /* SIMD body ResizeAreaFastVec_SIMD_32f :2875 */
                                 const float* r0 = (const float*)(src + (size_t)sy0 * sstep), *r1 = (const float*)(src + (size_t)(sy0 + 1) * sstep);
-                                s = ((r0[(dx * 2) * cn + c] + r0[(dx * 2 + 1) * cn + c]) + (r1[(dx * 2) * cn + c] + r1[(dx * 2 + 1) * cn + c]));
+                                /* pairwise in the vector body (1 channel below the last multiple of its 4 lanes, every 4-channel pixel), in order ((s00 + s01) + s10) + s11
+                                 * in the scalar loop behind it (:3013-3025: the 1-channel tail, 2 and 3 channels) */
+                                const float s00 = r0[(dx * 2) * cn + c], s01 = r0[(dx * 2 + 1) * cn + c], s10 = r1[(dx * 2) * cn + c], s11 = r1[(dx * 2 + 1) * cn + c];
+                                if (cn == 4 || (cn == 1 && dx < (wfull / 4) * 4)) s = (s00 + s01) + (s10 + s11);
+                                else s = ((s00 + s01) + s10) + s11;
                                 ((float*)D)[idx] = s * 0.25f;
                                 continue;
                             }

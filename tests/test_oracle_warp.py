@@ -288,3 +288,14 @@ def test_remap_relative_maps(orc, ref, dtype):
     # an identity in relative form is the image itself
     z = np.zeros((40, 50), np.float32)
     assert np.array_equal(orc.orc_remap(src, z, z, 1 | REL, 1, 0), src)
+
+
+def test_area_fast_2x2_float_summation_orders(orc, ref):
+    """INTER_AREA by exactly 2 x 2 on CV_32F: the reference's vector body sums pairwise, (s00 + s01) + (s10 + s11) -- 1 channel below the last multiple of its 4
+    lanes, every 4-channel pixel --, the scalar loop behind it (the 1-channel tail, 2 and 3 channels) in order, ((s00 + s01) + s10) + s11.  Data of wide dynamic range
+    makes the two orders differ; the restatement equals the reference BIT FOR BIT"""
+    rng = np.random.default_rng(5)
+    for shape in [(40, 46), (40, 44), (22, 30, 3), (22, 30, 4), (22, 30, 2), (10, 14), (6, 4)]:
+        src = (rng.standard_normal(shape) * 10 ** rng.uniform(-3, 3, shape)).astype(np.float32)
+        h, w = shape[:2]
+        assert np.array_equal(orc.orc_resize(src, (w // 2, h // 2), interpolation=3), orc.ref_resize(src, (w // 2, h // 2), interpolation=3)), shape

@@ -70,6 +70,16 @@ RAGGED_WORKER = textwrap.dedent("""
     kps = shard.gather_ragged([k.reshape(-1, 1).view(np.uint8).reshape(len(k), 28) for k, d in kd])
     des = shard.gather_ragged([d for k, d in kd])
     none = shard.gather_ragged([np.zeros((0, 32), np.uint8) for _ in range(lo, hi)])           # frames without keypoints
+    # the keypoint records as the detector returns them: 1-D structured arrays; collected on the LAST rank, which owns no frame when ws > B (dtype given explicitly)
+    last = ws - 1
+    recs = shard.gather_ragged([k for k, d in kd], dst=last, dtype=kd[0][0].dtype if kd else orc.orc_ORB(frames[0], nfeatures=150, edgeThreshold=15, patchSize=15, nlevels=3)[0].dtype)
+    if rank == last:
+        assert len(recs) == B
+        for f in range(B):
+            k, _ = orc.orc_ORB(frames[f], nfeatures=150, edgeThreshold=15, patchSize=15, nlevels=3)
+            assert recs[f].ndim == 1 and recs[f].dtype == k.dtype and recs[f].tobytes() == k.tobytes(), f
+    else:
+        assert recs is None
     if rank == 0:
         assert len(kps) == B and len(des) == B and [len(x) for x in none] == [0] * B
         for f in range(B):

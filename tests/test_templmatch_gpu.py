@@ -180,6 +180,34 @@ def test_bf16_split_path_32fc1(cv, orc, method):
         assert orc.rel_err(got[f], orc.orc_matchTemplate(fr[f], tpl, 3)) <= 1e-4, f
 
 
+def test_bf16_split_path_on_offset_images_and_non_finite_pixels(cv, orc):
+    """TM_SQDIFF* / TM_CCOEFF* are differences of large terms, so the bf16 split's dropped mid * mid product (2^-17 relative) is amplified near a perfect match
+    and on images with a large offset -- those methods take the fourth product.  A high-DC float image that contains the template exactly: the match location is found and
+    the result stays within 1e-4 of the float64 restatement's scale; an Inf pixel gives Inf / NaN only in the windows that contain it, as the fp32 form does."""
+    from opencv_amd import _lib
+    rng = np.random.default_rng(77)
+    img = (1000.0 + rng.random((200, 320), dtype=np.float32) * 8).astype(np.float32)             # offset 1000, signal 8
+    tpl = np.ascontiguousarray(img[60:60 + 48, 100:100 + 64])
+    for method in (0, 1, 4, 5):
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        k = _lib.lib.mi355cv_lastKernel().decode()
+        assert "k_ccorr_bf16" in k and "mid*mid" in k, k
+        loc = np.unravel_index(np.argmin(got) if method < 2 else np.argmax(got), got.shape)
+        assert loc == (60, 100), (method, loc)
+        if method in (1, 5):
+            assert np.max(np.abs(got - want)) <= 2e-3, (method, float(np.max(np.abs(got - want))))                # normalised: [-1, 1]; the window energy is 4.9e9 in fp32
+        else:
+            scale = float((img.astype(np.float64) ** 2).mean() * tpl.size)
+            assert np.max(np.abs(got.astype(np.float64) - want)) <= 1e-4 * scale, method
+    a = rnd((150, 300), np.float32, 31); a[70, 140] = np.inf
+    t = rnd((20, 30), np.float32, 32)
+    got = cv.matchTemplate(dev(a), dev(t), 2).cpu().numpy()                                                       # TM_CCORR
+    hit = np.zeros(got.shape, bool); hit[max(0, 70 - 19):71, max(0, 140 - 29):141] = True                        # the windows that contain the pixel
+    assert np.isfinite(got[~hit]).all() and not np.isfinite(got[hit]).any()
+    assert np.isposinf(got[hit]).all(), "an Inf pixel times positive taps is +Inf, not NaN"
+
+
 def test_masked_matching_is_declined_loudly(cv):
     """matchTemplateMask (templmatch.cpp:762-905) is not served: the mirror raises (never a silent CPU path) and the decline ledger records it"""
     from opencv_amd import _lib

@@ -440,3 +440,13 @@ def test_remap_relative_maps(cv, orc, dtype):
     big = rnd((1080, 1920), dtype, 62)
     z = torch.zeros((1080, 1920), dtype=torch.float32, device="cuda")
     assert np.array_equal(cv.remap(dev(big), z, z, 1 | REL, 1, 0).cpu().numpy(), big)                          # the relative identity
+
+
+def test_area_fast_2x2_float_summation_orders(cv, orc):
+    """INTER_AREA 2 x 2 on CV_32F: bit-exact incl. the columns / channel counts where the reference sums in order instead of pairwise (k_area2x2_f32's tail, the generic kernel)"""
+    rng = np.random.default_rng(5)
+    for shape in [(40, 46), (40, 44), (22, 30, 3), (22, 30, 4), (22, 30, 2), (10, 14), (540, 962), (270, 480)]:
+        src = (rng.standard_normal(shape) * 10 ** rng.uniform(-3, 3, shape)).astype(np.float32)
+        h, w = shape[:2]
+        got = cv.resize(dev(src), (w // 2, h // 2), interpolation=3).cpu().numpy()
+        assert np.array_equal(got, orc.orc_resize(src, (w // 2, h // 2), interpolation=3)), shape
