@@ -54,7 +54,7 @@ MI355_HD void mi355_hsv2bgr_px(int h8, int s8, int v8, bool inBody, float hscale
 // `vec`: the operation order of the reference's vector body in its AVX2 + FMA3 object (which pixels of a row take it is the caller's business: CV_8U rows go in
 // blocks of 256 pixels through a float buffer, the first floor(dn / 8) * 8 pixels of a block through the vector body, RGB2HLS_b :822-960); otherwise the scalar tail,
 // in which the compiler of that object fuses the products into the sums as well.  Every fused / unfused choice below is pinned on all 2^24 8-bit inputs
-// (tests/test_oracle_hls.py for the restatement, tests/test_hostemu.py for these lines).
+// (the restatement against the reference and these lines against the restatement: tests/test_hostemu.py).
 MI355_HD void mi355_rgb2hls_px(float r, float g, float b, float hscale, bool vec, float& H, float& L, float& S)
 {
     float vmax = r, vmin = r;
