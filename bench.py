@@ -308,6 +308,8 @@ def compact_summary(rows):
             out[key] = [r.get("us_per_frame"), r.get("Mpix_s"), r.get("pcie_GBs_both_ways")]
         elif ms is not None:
             out[key] = [round(ms / fr * 1e3, 2) if "ms" in r else round(ms * 1e3, 2), frac]
+            if "ms_per_frame_after_the_other_rows" in r:         # cfg5 (clock-bound): timed first and again last
+                out[key] += [round(r["ms_per_frame_after_the_other_rows"] * 1e3, 2), r.get("frac_of_i8_dense_peak_after_the_other_rows")]
     return out
 
 

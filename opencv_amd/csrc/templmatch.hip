@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void k_tm_split_bf16(const uchar* __restrict__
     const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
     // Inf / NaN travel in the MID plane alone, hi = 0: of the three products only mid(image) * hi(template) then sees the value, so an Inf pixel gives the Inf the fp32 kernel
     // gives (in the hi plane it would also meet the template's small remainders of either sign: Inf - Inf = NaN); a NaN whose payload sits in the low 16 bits only keeps
-    // a quiet bit so that the truncation does not read as Inf
+    // a quiet bit so that the truncation does not read as Inf.  (The Toeplitz form multiplies every pixel with the zero taps that pad a template row to its K steps as
+    // well, Inf * 0 = NaN: the non-finite patch of the result is up to 31 columns wider on either side than the windows that contain the pixel.)
     const uint32_t bits = __float_as_uint(v);
     const bool finite = (bits & 0x7f800000u) != 0x7f800000u;
     const unsigned short top = (unsigned short)(bits >> 16) | (unsigned short)(((bits & 0xffffu) != 0 && (bits & 0x7f0000u) == 0) ? 0x40 : 0);

@@ -164,6 +164,24 @@ def run(quick=False, parity=True):
     g = torch.Generator(device=dev); g.manual_seed(809564)
     N, WARM = (6, 2) if quick else (20, 5)
 
+    def time_cfg5():
+        """cfg5's batch (16 x 4K, 128 x 128 template) -> (ms per call of 16 frames, ms of a single-frame call)"""
+        g5 = torch.Generator(device=dev); g5.manual_seed(809564 + 5)
+        img = torch.randint(0, 256, (16, H4, W4), dtype=torch.uint8, device=dev, generator=g5)
+        tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g5)
+        res = torch.empty((16, 2033, 3713), dtype=torch.float32, device=dev)
+        # 12 untimed calls (~30 ms) first: the chip's clock management needs ~20 ms of continuous work to settle (DESIGN section 7, "what the round-1 number was");
+        # round 3's 2 warm-up calls left the 5 timed ones inside that transient, which is the 0.16 (stand-alone, long runs) vs 0.194 ms (in bench.py) gap of VERDICT r3
+        ms = timeit(lambda: cv.matchTemplateBatch(img, tpl, cv.TM_CCORR_NORMED, result=res), n=8, warm=12)
+        ms1 = timeit(lambda: cv.matchTemplateBatch(img[:1], tpl, cv.TM_CCORR_NORMED, result=res[:1]), n=5, warm=2)
+        del img, tpl, res
+        torch.cuda.empty_cache()
+        return ms, ms1
+
+    # cfg5 is MFMA-bound, i.e. clock-bound: it is timed here, at the state every stand-alone measurement of it starts from, AND again in its old place at the end of
+    # the run, after ~25 s of back-to-back HBM-bound work (VERDICT r3: "0.16 vs 0.194 ms between standalone and in-bench runs") -- both are reported
+    cfg5_first = time_cfg5()
+
     def hbm_row(name, frames, ms, by, extra=None):
         r = {"config": name, "frames": frames, "ms": round(ms, 4), "working_set_GB": round(by / 1e9, 3), "bound": "hbm",
              "achieved_GBs": round(by / ms / 1e6, 1)}
@@ -401,16 +419,18 @@ def run(quick=False, parity=True):
     torch.cuda.empty_cache()
     # ---- config 5: matchTemplate TM_CCORR_NORMED 4K x 128x128 (MFMA-bound; two workgroups of different frames share a CU; single-frame latency beside it)
     B5 = 16
-    img = torch.randint(0, 256, (B5, H4, W4), dtype=torch.uint8, device=dev, generator=g)
-    tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g)
-    res = torch.empty((B5, 2033, 3713), dtype=torch.float32, device=dev)
-    ms = timeit(lambda: cv.matchTemplateBatch(img, tpl, cv.TM_CCORR_NORMED, result=res), n=5, warm=2)
-    ms1 = timeit(lambda: cv.matchTemplateBatch(img[:1], tpl, cv.TM_CCORR_NORMED, result=res[:1]), n=5, warm=2)
+    ms, ms1 = cfg5_first
+    ms_late, _ = time_cfg5()
     fl = B5 * 2.4735e11
     out.append({"config": "cfg5 matchTemplate TM_CCORR_NORMED 4K x 128x128 8UC1 (one i8 MFMA kernel: correlation, window sums, normalisation)", "frames": B5, "ms": round(ms, 3),
                 "ms_per_frame": round(ms / B5, 4), "ms_single_frame_call": round(ms1, 3),
                 "frames_s": round(B5 / ms * 1e3, 2), "bound": "mfma", "achieved_TFLOPs": round(fl / ms / 1e9, 1),
-                "frac_of_bf16_dense_peak": round(fl / ms / 1e9 / MFMA_BF16, 4), "frac_of_i8_dense_peak": round(fl / ms / 1e9 / (2 * MFMA_BF16), 4)})
+                "frac_of_bf16_dense_peak": round(fl / ms / 1e9 / MFMA_BF16, 4), "frac_of_i8_dense_peak": round(fl / ms / 1e9 / (2 * MFMA_BF16), 4),
+                "timed": "first row of the run, after 12 untimed calls; ms_per_frame_after_the_other_rows = the same measurement repeated at the end of the run",
+                "ms_per_frame_after_the_other_rows": round(ms_late / B5, 4), "frac_of_i8_dense_peak_after_the_other_rows": round(fl / ms_late / 1e9 / (2 * MFMA_BF16), 4)})
+    img = torch.randint(0, 256, (4, H4, W4), dtype=torch.uint8, device=dev, generator=g)
+    tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device=dev, generator=g)
+    res = torch.empty((4, 2033, 3713), dtype=torch.float32, device=dev)
     try:
         imgf = img[:4].to(torch.float32); tplf = tpl.to(torch.float32)
         ms = timeit(lambda: cv.matchTemplateBatch(imgf, tplf, cv.TM_CCORR_NORMED, result=res[:4]), n=3, warm=1)
