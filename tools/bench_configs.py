@@ -25,9 +25,19 @@ W4, H4 = 3840, 2160
 PIX4 = W4 * H4
 
 
-def timeit(fn, n=10, warm=3):
-    for _ in range(warm):
-        fn()
+def timeit(fn, n=10, warm=3, settle_ms=30.0):
+    """mean ms per call over n calls, HIP events on the launch stream.  The untimed warm-up runs for at least `warm` calls AND `settle_ms` of wall time: after any idle
+    gap (the allocations between two rows are one) the chip's clock management takes ~20 ms of continuous work to settle, and a row of 5 + 20 passes
+    of 0.5 ms each would otherwise be measured inside that transient"""
+    import time
+    t0 = time.perf_counter()
+    k = 0
+    while k < warm or (time.perf_counter() - t0) * 1e3 < settle_ms:
+        fn(); k += 1
+        if k % 4 == 0:
+            torch.cuda.synchronize()                      # (the queue must not run ahead of the clock we are waiting on)
+        if k >= 400:
+            break
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
