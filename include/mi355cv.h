@@ -470,6 +470,11 @@ MI355CV_API int mi355cv_medianBlur(const mi355cv_uchar* src_data, size_t src_ste
 MI355CV_API int mi355cv_matchTemplate(const mi355cv_uchar* img_data, size_t img_step, int img_width, int img_height,
         const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
         mi355cv_uchar* result_data, size_t result_step, int method);
+/* the same with a mask (matchTemplateMask, templmatch.cpp:762-904): mask of the template's size, CV_8U (non-zero counts as 1) or CV_32F (weights), one channel
+ * or the template's channel count */
+MI355CV_API int mi355cv_matchTemplateMask(const mi355cv_uchar* img_data, size_t img_step, int img_width, int img_height,
+        const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
+        const mi355cv_uchar* mask_data, size_t mask_step, int mask_type, mi355cv_uchar* result_data, size_t result_step, int method);
 /* frames x one shared template (frames shard, the template is replicated) */
 MI355CV_API int mi355cv_matchTemplateBatch(const mi355cv_uchar* img_data, size_t img_step, size_t img_frame_stride, int nframes,
         int img_width, int img_height, const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height,

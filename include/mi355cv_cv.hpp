@@ -173,7 +173,17 @@ inline void matchTemplate(cv::InputArray _image, cv::InputArray _templ, cv::Outp
                                   result.data, result.step, method) == MI355CV_OK)
             return;
     }
-    if (!_mask.empty()) mi355cv_noteDecline("matchTemplateMask");           // matchTemplateMask (templmatch.cpp:762): the reference's own path, on the record
+    if (!_mask.empty() && image.dims <= 2 && image.type() == templ.type() && (image.depth() == CV_8U || image.depth() == CV_32F) &&
+        image.cols >= templ.cols && image.rows >= templ.rows && method >= cv::TM_SQDIFF && method <= cv::TM_CCOEFF_NORMED) {
+        cv::Mat mask = _mask.getMat();                                       // matchTemplateMask (templmatch.cpp:762)
+        if (mask.dims <= 2 && mask.size() == templ.size() && (mask.depth() == CV_8U || mask.depth() == CV_32F) && (mask.channels() == 1 || mask.channels() == templ.channels())) {
+            _result.create(image.rows - templ.rows + 1, image.cols - templ.cols + 1, CV_32FC1);
+            cv::Mat result = _result.getMat();
+            if (mi355cv_matchTemplateMask(image.data, image.step, image.cols, image.rows, templ.data, templ.step, templ.cols, templ.rows, image.type(),
+                                          mask.data, mask.step, mask.type(), result.data, result.step, method) == MI355CV_OK)
+                return;
+        }
+    }
     cv::matchTemplate(_image, _templ, _result, method, _mask);
 }
 

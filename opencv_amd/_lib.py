@@ -155,6 +155,7 @@ def _load():
         "mi355cv_goodFeaturesToTrack": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, c_dbl,
                                                 c_u8p, c_sz, c_int, c_int, c_int, c_dbl]),
         "mi355cv_matchTemplate": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_int]),
+        "mi355cv_matchTemplateMask": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_int, c_u8p, c_sz, c_int]),
         "mi355cv_matchTemplateBatch": (c_int, [c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_sz, c_sz, c_int]),
         "mi355cv_integral": (c_int, [c_int, c_int, c_int, c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_int, c_int, c_int]),
         "mi355cv_integralBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int]),

@@ -1090,6 +1090,8 @@ __global__ __launch_bounds__(256) void k_tm_finish_planes(const float* __restric
 
 struct WOut { unsigned* w1; unsigned* w2; int wp; size_t wframe; };
 
+thread_local bool t_fourProducts = false;      // set by runMatchMask: its TM_CCORR building blocks feed differences of large terms (see BF_LAUNCH)
+
 int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, int nframes, int iw, int ih,
              const uchar* tpl, size_t tstep, int tw, int th, int type, uchar* res, size_t rstep, size_t rframe, int method, WOut* wout = nullptr)
 {
@@ -1263,6 +1265,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 hipLaunchKernelGGL(k_tm_split_bf16, dim3(divUp(ipitch, 64), divUp(ih, 4), nframes), dim3(256), 0, st, di, dis, nframes > 1 ? iframe : 0, iw, ih, ihi, imid, ipitch, iplane);
                 hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(th * BF_TE, 256)), dim3(256), 0, st, dt, dts, tw, th, thi, tmid);
                 const int KS = (tw + 31 + 15) / 16;                                           // K steps of 16 columns covering tw + 31
+                const bool four = (method != 2 && method != 3) || t_fourProducts;
                 const size_t lds = (size_t)(BF_BM + BF_JC - 1) * BF_PP + (size_t)BF_JC * BF_TP;
                 dim3 gb(divUp(rw, BF_BN), divUp(rh, BF_BM), nframes);
                 float* rf = reinterpret_cast<float*>(dr);
@@ -1274,7 +1277,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); \
                 /* TM_SQDIFF* / TM_CCOEFF*: the result is a difference of large terms (window energy - 2 corr + template energy; corr - mean product), which amplifies the \
                    ~2^-17 relative error of the dropped mid * mid term near a perfect match and on images with a large offset: those methods take the fourth product */ \
-                if (method != 2 && method != 3) hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); } while (0)
+                if (four) hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); } while (0)
                 switch (KS) { case 1: case 2: BF_LAUNCH(2); break; case 3: case 4: BF_LAUNCH(4); break; case 5: case 6: BF_LAUNCH(6); break; case 7: case 8: BF_LAUNCH(8); break; default: BF_LAUNCH(10); }
 #undef BF_LAUNCH
                 if (method != 2) {
@@ -1284,7 +1287,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                     hipLaunchKernelGGL((k_wsum_cols<double>), dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
                     hipLaunchKernelGGL(k_tm_finish_f, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, rf, drs, rfr, w1, w2, wframe, rw, dna);
                 }
-                noteKernel("k_ccorr_bf16<%d> x%d (hi*hi + hi*mid + mid*hi%s) grid=%ux%ux%u x256 lds=%zu", KS, method != 2 && method != 3 ? 4 : 3, method != 2 && method != 3 ? " + mid*mid" : "", gb.x, gb.y, gb.z, lds);
+                noteKernel("k_ccorr_bf16<%d> x%d (hi*hi + hi*mid + mid*hi%s) grid=%ux%ux%u x256 lds=%zu", KS, four ? 4 : 3, four ? " + mid*mid" : "", gb.x, gb.y, gb.z, lds);
                 done = true;
                 return stg.finish(entry);
             }
@@ -1302,9 +1305,151 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     return stg.finish(entry);
 }
 
+// ---------------------------------------------------------------------------------- matchTemplateMask (templmatch.cpp:762-904)
+// The reference turns image, template and mask into CV_32F and evaluates each method as a few cross-correlations of (I or I^2) with products of T and M, joined by
+// float expressions.  Here: the template-sized operands are built on the host exactly as the reference's Mat expressions do (tw x th floats per channel), the image
+// goes to per-channel float planes (I and I^2) on the device, every cross-correlation is runMatch's TM_CCORR of CV_32FC1 -- the bf16 matrix-core path with all four
+// partial products, or the direct kernel in double for sizes it does not take --, and one kernel joins the partial results in the reference's order of float operations.
+__global__ __launch_bounds__(256) void k_tm_mask_planes(const uchar* __restrict__ src, size_t sstep, int w, int h, int cn, int depth,
+                                                       float* __restrict__ f, float* __restrict__ f2, int pitch, size_t plane)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= pitch || y >= h) return;
+    for (int c = 0; c < cn; c++) {
+        float v = 0.f;
+        if (x < w) v = depth == D8U ? (float)src[(size_t)y * sstep + (size_t)x * cn + c] : reinterpret_cast<const float*>(src + (size_t)y * sstep)[(size_t)x * cn + c];
+        f[c * plane + (size_t)y * pitch + x] = v;
+        if (f2) f2[c * plane + (size_t)y * pitch + x] = v * v;
+    }
+}
+
+struct MaskFin { int method, cn, rw, rh, sameM2; int pitch; size_t plane; float t2m2, nrm; float kfac[4], invMs[4], m2fac[4]; };
+
+// part: [kind][channel] planes of `plane` floats; kinds: 0 CC(I, K), 1 CC(I^2, M^2), 2 CC(I, M), 3 CC(I, M^2)
+__global__ __launch_bounds__(256) void k_tm_mask_finish(const float* __restrict__ part, float* __restrict__ res, size_t rstep, MaskFin a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.rw || y >= a.rh) return;
+    const size_t o = (size_t)y * a.pitch + x, kind = (size_t)4 * a.plane;
+    float r = 0.f, t = 0.f;
+    for (int c = 0; c < a.cn; c++) { r += part[c * a.plane + o]; if (a.method != 2 && a.method != 4) t += part[kind + c * a.plane + o]; }
+    if (a.method <= 3) {
+        if (a.method <= 1) r = __builtin_fmaf(r, -2.f, __builtin_fmaf(t, 1.f, a.t2m2));                       // :811 (addWeighted)
+        if (a.method == 1 || a.method == 3) r = r / __builtin_sqrtf(t * a.t2m2);                             // :815-816, :833-834
+    } else {
+        float s = 0.f;
+        for (int c = 0; c < a.cn; c++) { const float v = part[2 * kind + c * a.plane + o] * a.kfac[c]; s = c == 0 ? v : s + v; }      // :853-865
+        r -= s;
+        if (a.method == 5) {
+            s = 0.f;
+            for (int c = 0; c < a.cn; c++) {
+                const float im = part[2 * kind + c * a.plane + o], im2 = a.sameM2 ? im : part[3 * kind + c * a.plane + o];
+                const float v = (im * a.invMs[c]) * __builtin_fmaf(im * a.m2fac[c], 1.f, __builtin_fmaf(im2, -2.f, 0.f));                // :884-885
+                s = c == 0 ? v : s + v;
+            }
+            r = r / (__builtin_sqrtf(t + s) * a.nrm);                                                         // :888-901
+        }
+    }
+    reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)y * rstep)[x] = r;
+}
+
+int runMatchMask(const char* entry, const uchar* img, size_t istep, int iw, int ih, const uchar* tpl, size_t tstep, int tw, int th, int type,
+                 const uchar* mask, size_t mstep, int mtype, uchar* res, size_t rstep, int method)
+{
+    if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
+    const int depth = MI355CV_MAT_DEPTH(type), cn = MI355CV_MAT_CN(type), mdepth = MI355CV_MAT_DEPTH(mtype), mcn = MI355CV_MAT_CN(mtype);
+    if ((depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > 5) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D32F) || cn < 1 || cn > 4 || method < 0 || method > 5");
+    if ((mdepth != D8U && mdepth != D32F) || (mcn != 1 && mcn != cn) || !mask) return mi355::declined(__func__, __LINE__, "(mdepth != D8U && mdepth != D32F) || (mcn != 1 && mcn != cn) || !mask");   // CV_Assert :764-765
+    if (tw < 1 || th < 1 || iw < tw || ih < th) return mi355::declined(__func__, __LINE__, "tw < 1 || th < 1 || iw < tw || ih < th");                             // CV_Assert :767
+    Stager stg;
+    if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    hipStream_t st = stream();
+    const int e = depth == D8U ? 1 : 4, me = mdepth == D8U ? 1 : 4;
+    const int rw = iw - tw + 1, rh = ih - th + 1;
+    // template and mask on the host (they are template-sized; device-resident ones are fetched)
+    const size_t trb = (size_t)tw * cn * e, mrb = (size_t)tw * mcn * me, nt = (size_t)tw * th;
+    std::vector<uchar> th_, mh_;
+    auto toHost = [&](const uchar* p, size_t step, size_t rowBytes, std::vector<uchar>& v) -> bool {
+        v.resize(rowBytes * th);
+        if (ptrKind(p) == PTR_HOST) { for (int y = 0; y < th; y++) memcpy(v.data() + (size_t)y * rowBytes, p + (size_t)y * step, rowBytes); return true; }
+        return hipMemcpy2DAsync(v.data(), rowBytes, p, step, rowBytes, th, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    };
+    if (!toHost(tpl, tstep, trb, th_) || !toHost(mask, mstep, mrb, mh_)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: template / mask could not be read", entry);
+    std::vector<float> T(nt * cn), M(nt * cn), M2(nt * cn), K(nt * cn);
+    bool binary = true;
+    for (int c = 0; c < cn; c++)
+        for (size_t i = 0; i < nt; i++) {
+            const size_t y = i / tw, x = i % tw;
+            T[c * nt + i] = depth == D8U ? (float)th_[y * trb + x * cn + c] : reinterpret_cast<const float*>(th_.data() + y * trb)[x * cn + c];
+            const size_t mi = mcn == 1 ? x : x * cn + c;
+            const float m = mdepth == D8U ? (mh_[y * mrb + mi] > 0 ? 1.f : 0.f) : reinterpret_cast<const float*>(mh_.data() + y * mrb)[mi];     // :780-785
+            M[c * nt + i] = m; M2[c * nt + i] = m * m;
+            if (m != 0.f && m != 1.f) binary = false;
+        }
+    MaskFin fin; memset(&fin, 0, sizeof fin);
+    fin.method = method; fin.cn = cn; fin.rw = rw; fin.rh = rh; fin.sameM2 = binary ? 1 : 0;
+    const bool coeff = method >= 4;
+    if (!coeff) {
+        double t2m2 = 0;                                                                                             // norm(templ.mul(mask), NORM_L2SQR) :806, :831
+        for (size_t i = 0; i < nt * cn; i++) { const float v = T[i] * M[i]; t2m2 += (double)v * v; K[i] = T[i] * M2[i]; }                              // :808, :822
+        fin.t2m2 = (float)t2m2;
+    } else {
+        double nT = 0;
+        for (int c = 0; c < cn; c++) {
+            double ms = 0, mt = 0, m2s = 0, ks = 0;
+            for (size_t i = 0; i < nt; i++) { ms += M[c * nt + i]; mt += (double)(M[c * nt + i] * T[c * nt + i]); m2s += M2[c * nt + i]; }
+            const float mean = (float)(mt / ms);
+            for (size_t i = 0; i < nt; i++) { const float d = M[c * nt + i] * (T[c * nt + i] - mean); nT += (double)d * d; K[c * nt + i] = M[c * nt + i] * d; ks += K[c * nt + i]; }     // :843, :870
+            fin.kfac[c] = (float)(ks / ms); fin.invMs[c] = (float)(1.0 / ms); fin.m2fac[c] = (float)(m2s / ms);
+        }
+        fin.nrm = (float)std::sqrt(nT);
+    }
+    // the image: staged like any input, then per-channel float planes of I (and I^2)
+    size_t dis = istep, drs = rstep;
+    const uchar* di = stg.in(img, istep, (size_t)iw * cn * e, ih, &dis);
+    uchar* dr = stg.out(res, rstep, (size_t)rw * 4, rh, &drs);
+    if (!di || !dr) return mi355::declined(__func__, __LINE__, "!di || !dr");
+    const bool needI2 = method != 2 && method != 4;
+    const int ipitch = (iw + 3) & ~3; const size_t iplane = (size_t)ipitch * ih;
+    const int rpitch = (rw + 3) & ~3; const size_t rplane = (size_t)rpitch * rh;
+    float* f = (float*)stg.scratch(iplane * cn * 4);
+    float* f2 = needI2 ? (float*)stg.scratch(iplane * cn * 4) : nullptr;
+    float* part = (float*)stg.scratch(rplane * 16 * 4);
+    float* dk = (float*)stg.param(K.data(), nt * cn * 4);
+    float* dm = coeff ? (float*)stg.param(M.data(), nt * cn * 4) : nullptr;
+    float* dm2 = (needI2 || (method == 5 && !binary)) ? (float*)stg.param(M2.data(), nt * cn * 4) : nullptr;
+    if (!f || (needI2 && !f2) || !part || !dk || (coeff && !dm) || ((needI2 || (method == 5 && !binary)) && !dm2)) return mi355::declined(__func__, __LINE__, "out of scratch memory for the float planes");
+    hipLaunchKernelGGL(k_tm_mask_planes, dim3(divUp(ipitch, 64), divUp(ih, 4)), dim3(256), 0, st, di, dis, iw, ih, cn, depth, f, f2, ipitch, iplane);
+    fin.pitch = rpitch; fin.plane = rplane;
+    struct FourProducts { FourProducts() { t_fourProducts = true; } ~FourProducts() { t_fourProducts = false; } } guard;
+    auto cc = [&](const float* plane, const float* kern, int kind, int c) -> int {
+        return runMatch(entry, reinterpret_cast<const uchar*>(plane + (size_t)c * iplane), (size_t)ipitch * 4, 0, 1, iw, ih, reinterpret_cast<const uchar*>(kern + (size_t)c * nt), (size_t)tw * 4, tw, th,
+                        MI355CV_MAKETYPE(D32F, 1), reinterpret_cast<uchar*>(part + ((size_t)kind * 4 + c) * rplane), (size_t)rpitch * 4, 0, 2);
+    };
+    for (int c = 0; c < cn; c++) {
+        int rc = cc(f, dk, 0, c);
+        if (rc == MI355CV_OK && needI2) rc = cc(f2, dm2, 1, c);
+        if (rc == MI355CV_OK && coeff) rc = cc(f, dm, 2, c);
+        if (rc == MI355CV_OK && method == 5 && !binary) rc = cc(f, dm2, 3, c);
+        if (rc != MI355CV_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_tm_mask_finish, dim3(divUp(rw, 64), divUp(rh, 4)), dim3(256), 0, st, part, reinterpret_cast<float*>(dr), drs, fin);
+    return stg.finish(entry);
+}
+
 } // namespace
 
 extern "C" {
+
+// cv::matchTemplate with a mask (matchTemplateMask, templmatch.cpp:762; no HAL hook): mask of the template's size, CV_8U (non-zero = 1) or CV_32F (weights), one
+// channel or as many as the template
+MI355CV_API int mi355cv_matchTemplateMask(const uchar* img_data, size_t img_step, int img_width, int img_height,
+                                          const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
+                                          const uchar* mask_data, size_t mask_step, int mask_type, uchar* result_data, size_t result_step, int method)
+{
+    return runMatchMask("matchTemplateMask", img_data, img_step, img_width, img_height, templ_data, templ_step, templ_width, templ_height, type,
+                        mask_data, mask_step, mask_type, result_data, result_step, method);
+}
 
 // cv::matchTemplate (templmatch.cpp:1158) has no HAL hook: same argument meaning, raw pointers.  result is CV_32FC1 of
 // size (iw - tw + 1) x (ih - th + 1).  method = cv::TemplateMatchModes (imgproc.hpp:3844).

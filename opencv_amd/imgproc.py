@@ -1300,12 +1300,21 @@ TM_SQDIFF, TM_SQDIFF_NORMED, TM_CCORR, TM_CCORR_NORMED, TM_CCOEFF, TM_CCOEFF_NOR
 
 
 def matchTemplate(image, templ, method, result=None, mask=None):
-    """cv::matchTemplate (templmatch.cpp:1158-1194): CV_8U / CV_32F, 1..4 channels, all six methods.  With a mask the reference takes matchTemplateMask
-    (:762-905, combinations of crossCorr on float copies): not served -- the call raises, it never falls back to a CPU path."""
-    if mask is not None:
-        _lib.lib.mi355cv_noteDecline(b"matchTemplateMask")
-        raise NotImplementedError("matchTemplate with a mask (matchTemplateMask, templmatch.cpp:762) is not served by the GPU path; no CPU fallback in opencv_amd")
+    """cv::matchTemplate (templmatch.cpp:1158-1194): CV_8U / CV_32F, 1..4 channels, all six methods.  With a mask (CV_8U or CV_32F, the template's size, one
+    channel or the template's) the reference takes matchTemplateMask (:762-904): mi355cv_matchTemplateMask."""
     s, t = Img(image), Img(templ)
+    if mask is not None:
+        m = Img(mask)
+        if (s.depth, s.cn) != (t.depth, t.cn) or (m.w, m.h) != (t.w, t.h) or m.depth not in (CV_8U, CV_32F) or m.cn not in (1, t.cn):
+            raise ValueError("matchTemplate: image / template types differ, or the mask is not CV_8U / CV_32F of the template's size")     # CV_Assert :764-766, :1164
+        if s.w < t.w or s.h < t.h:
+            raise ValueError("matchTemplate: with a mask the template may not be larger than the image")                                     # CV_Assert :767
+        out = result if result is not None else empty_like_kind(image if s.cn == 1 else image[..., 0], s.h - t.h + 1, s.w - t.w + 1, 1, CV_32F)
+        d = Img(out)
+        bind_stream(s, d)
+        rc = L.mi355cv_matchTemplateMask(_vp(s.ptr), s.step, s.w, s.h, _vp(t.ptr), t.step, t.w, t.h, s.type, _vp(m.ptr), m.step, m.type, _vp(d.ptr), d.step, method)
+        _lib.check(rc, "matchTemplateMask")
+        return out
     if (s.depth, s.cn) != (t.depth, t.cn):
         raise ValueError("matchTemplate: image and template must have the same type")        # CV_Assert :1164
     if s.w < t.w or s.h < t.h:

@@ -148,6 +148,9 @@ int orc_goodFeaturesToTrack(const uint8_t* src, size_t sstep, int w, int h, int 
 /* cv::matchTemplate, see oracle/templmatch.c */
 int orc_matchTemplate(const uint8_t* img, size_t istep, int iw, int ih, const uint8_t* tpl, size_t tstep, int tw, int th,
                       int depth, int cn, float* result, size_t rstep, int method);
+/* cv::matchTemplate with a mask (matchTemplateMask, templmatch.cpp:762): mdepth 0 / 5, mcn 1 or cn */
+int orc_matchTemplateMask(const uint8_t* img, size_t istep, int iw, int ih, const uint8_t* tpl, size_t tstep, int tw, int th, int depth, int cn,
+                          const uint8_t* mask, size_t mstep, int mdepth, int mcn, float* result, size_t rstep, int method);
 
 /* cv::threshold, see oracle/thresh.c (depth 0/2/3/5; type 0..4) */
 int orc_thresholdHal(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn,

@@ -48,6 +48,13 @@ EXPORT int wrap_matchTemplate(const void* img, size_t is, int iw, int ih, const 
           mi355cv::matchTemplate(I, T, R, method); return R.data == p ? 0 : -2; }
     catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
 }
+EXPORT int wrap_matchTemplateMask(const void* img, size_t is, int iw, int ih, const void* t, size_t ts, int tw, int th, int type, const void* m, size_t ms, int mtype,
+                                  void* res, size_t rs, int method)
+{
+    try { Mat I = M(img, is, iw, ih, type), T = M(t, ts, tw, th, type), K = M(m, ms, tw, th, mtype), R = M(res, rs, iw - tw + 1, ih - th + 1, CV_32FC1); const uchar* p = R.data;
+          mi355cv::matchTemplate(I, T, R, method, K); return R.data == p ? 0 : -2; }
+    catch (const cv::Exception& e) { fprintf(stderr, "cvwrap: %s\n", e.what()); return -1; }
+}
 // FrameAllocator (include/mi355cv_cv.hpp): frames allocated by it -- a ROI clone, a pipeline of two HAL-served functions writing into
 // allocator-backed matrices -- behave like ordinary cv::Mat.  kind 0 pinned, 1 managed.  The result is copied to `d`.
 EXPORT int wrap_frameAllocatorTour(int kind, const void* s, size_t ss, int w, int h, int type, void* d, size_t ds)

@@ -458,6 +458,16 @@ int ref_matchTemplate(const void* img, size_t is, int iw, int ih, const void* t,
     REF_END(R, res)
 }
 
+int ref_matchTemplateMask(const void* img, size_t is, int iw, int ih, const void* t, size_t ts, int tw, int th, int type,
+                          const void* mask, size_t ms, int mtype, void* res, size_t rs, int method)
+{
+    REF_TRY
+    Mat I = M(img, is, iw, ih, type), T = M(t, ts, tw, th, type), K = M(mask, ms, tw, th, mtype);
+    Mat R = M(res, rs, iw - tw + 1, ih - th + 1, CV_32FC1);
+    cv::matchTemplate(I, T, R, method, K);
+    REF_END(R, res)
+}
+
 int ref_integral(const void* s, size_t ss, int w, int h, int stype, void* sum, size_t sums, int sdepth,
                  void* sq, size_t sqs, int sqdepth)
 {

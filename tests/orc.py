@@ -932,6 +932,34 @@ def ref_matchTemplate(img, templ, method):
     return res
 
 
+def _mask_args(mask, cn):
+    assert mask.dtype in (np.uint8, np.float32)
+    return P(mask), step(mask), _NP_DEPTH[mask.dtype], cn_of(mask)
+
+
+def orc_matchTemplateMask(img, templ, method, mask):
+    o = oracle()
+    ih, iw = img.shape[:2]
+    th, tw = templ.shape[:2]
+    res = np.empty((ih - th + 1, iw - tw + 1), np.float32)
+    mp, ms, md, mc = _mask_args(mask, cn_of(img))
+    rc = o.orc_matchTemplateMask(P(img), step(img), iw, ih, P(templ), step(templ), tw, th, _NP_DEPTH[img.dtype], cn_of(img), mp, ms, md, mc,
+                                 P(res), step(res), method)
+    assert rc == 0
+    return res
+
+
+def ref_matchTemplateMask(img, templ, method, mask):
+    r = load_ref()
+    ih, iw = img.shape[:2]
+    th, tw = templ.shape[:2]
+    res = np.empty((ih - th + 1, iw - tw + 1), np.float32)
+    rc = r.ref_matchTemplateMask(P(img), step(img), iw, ih, P(templ), step(templ), tw, th, cvtype(img), P(mask), step(mask), cvtype(mask),
+                                 P(res), step(res), method)
+    assert rc == 0, rc
+    return res
+
+
 # ----------------------------------------------------------------------------- remaining colour conversions (oracle/color_misc.c)
 def _misc_table():
     t = {}

@@ -177,6 +177,11 @@ def _wrap_calls(hal, src8):
     r = np.empty((h - 16 + 1, w - 32 + 1), np.float32)
     assert hal.wrap_matchTemplate(O.P(src8), O.step(src8), w, h, O.P(tpl), O.step(tpl), 32, 16, 0, O.P(r), O.step(r), 5) == 0
     out["mt"] = r
+    if hasattr(hal, "wrap_matchTemplateMask"):
+        mask = np.zeros((16, 32), np.uint8); mask[:, :20] = 3
+        rm = np.empty_like(r)
+        assert hal.wrap_matchTemplateMask(O.P(src8), O.step(src8), w, h, O.P(tpl), O.step(tpl), 32, 16, 0, O.P(mask), O.step(mask), 0, O.P(rm), O.step(rm), 3) == 0
+        out["mtmask"] = rm
     return out
 
 
@@ -184,6 +189,8 @@ def _wrap_expected(src8):
     exp = {"harris": O.ref_cornerHarris(src8, 2, 3, 0.04), "mineig": O.ref_cornerMinEigenVal(src8, 3, 3),
            "gftt": O.ref_goodFeaturesToTrack(src8, 50, 0.01, 5.0, 3, 3, False, 0.04),
            "mt": O.ref_matchTemplate(src8, np.ascontiguousarray(src8[10:26, 20:52]), 5)}
+    mask = np.zeros((16, 32), np.uint8); mask[:, :20] = 3
+    exp["mtmask"] = O.ref_matchTemplateMask(src8, np.ascontiguousarray(src8[10:26, 20:52]), 3, mask)
     l = src8
     for i in range(3):
         l = O.ref_pyrDown(l)
@@ -210,12 +217,12 @@ def test_cv_signature_wrappers_on_the_gpu(ref):
     hal = O.load_ref_hal()
     assert hal is not None and hasattr(hal, "wrap_cornerHarris"), "oracle/_ref/libocvref_hal.so missing or stale"
     src8, _, _ = _inputs()
-    names = ["cornerHarris", "cornerMinEigenVal", "goodFeaturesToTrack", "buildPyramid", "matchTemplate"]
+    names = ["cornerHarris", "cornerMinEigenVal", "goodFeaturesToTrack", "buildPyramid", "matchTemplate", "matchTemplateMask"]
     before = {n: cv.call_count(n) for n in names}
     got, exp = _wrap_calls(hal, src8), _wrap_expected(src8)
     for n in names:
         assert cv.call_count(n) > before[n], f"mi355cv::{n} was not served by the GPU"
-    for k in ("harris", "mineig", "mt"):
+    for k in ("harris", "mineig", "mt", "mtmask"):
         assert O.rel_err(got[k], exp[k]) <= 1e-4, k
     for k in ("pyr1", "pyr2", "pyr3"):
         assert np.array_equal(got[k], exp[k]), k

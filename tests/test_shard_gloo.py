@@ -98,8 +98,13 @@ def test_detector_output_gathered_over_ranks(tmp_path):
     script.write_text(RAGGED_WORKER % (ROOT, ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     for ws, port in ((2, 29731), (3, 29733), (8, 29737)):                     # 8 ranks, 5 frames: three ranks own no frame at all
-        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                            str(script)], capture_output=True, text=True, timeout=300, env=env)
+        for attempt in (0, 1):
+            p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1", "--master-port", str(port + 40 * attempt),
+                                str(script)], capture_output=True, text=True, timeout=300, env=env)
+            # a rank killed by a signal with no Python assertion behind it is the rendezvous / transport giving up on an overloaded box (seen once with 8 ranks beside
+            # 8 pytest workers): one more try on another port; an assertion of the worker is never retried
+            if p.returncode == 0 or "AssertionError" in p.stderr or "Error:" in p.stderr.replace("ChildFailedError:", ""):
+                break
         assert p.returncode == 0, p.stderr[-3000:]
         assert '"ok": true' in p.stdout
 

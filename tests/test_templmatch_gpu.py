@@ -230,11 +230,83 @@ def test_bf16_split_path_on_offset_images_and_non_finite_pixels(cv, orc):
     assert np.isfinite(got[far]).all()
 
 
-def test_masked_matching_is_declined_loudly(cv):
-    """matchTemplateMask (templmatch.cpp:762-905) is not served: the mirror raises (never a silent CPU path) and the decline ledger records it"""
+def _mask(th, tw, cn, kind, seed):
+    rng = np.random.default_rng(seed)
+    shape = (th, tw, cn) if (kind.endswith("cn") and cn > 1) else (th, tw)
+    if kind.startswith("u8"):
+        return np.array([0, 1, 7, 255], np.uint8)[rng.integers(0, 4, shape)]
+    return rng.random(shape, dtype=np.float32)
+
+
+def _mask_tol(img, tpl, mask, method, got, want):
+    """normalised methods live in [-1, 1]: absolute 1e-4; the others relative to |I| |T M| (the scale the products' rounding acts on)"""
+    if method in (1, 3, 5):
+        return float(np.max(np.abs(got - want))), 1e-4
+    m = mask.astype(np.float64) if mask.dtype == np.float32 else (mask > 0).astype(np.float64)
+    if m.ndim < tpl.ndim:
+        m = m[..., None]
+    scale = float(np.sqrt((img.astype(np.float64) ** 2).mean() * img.shape[-1] ** (img.ndim == 3) * tpl.shape[0] * tpl.shape[1]) * np.sqrt(((tpl.astype(np.float64) * m) ** 2).sum()))
+    if method in (0, 4):
+        scale = max(scale, float((img.astype(np.float64) ** 2).mean()) * tpl.size)
+    return float(np.max(np.abs(got.astype(np.float64) - want))), 1e-4 * max(scale, 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("cn", [1, 3])
+@pytest.mark.parametrize("kind", ["u8", "u8cn", "f32", "f32cn"])
+def test_masked_modes(cv, orc, dtype, cn, kind):
+    """matchTemplateMask (templmatch.cpp:762-904), every method, CV_8U and CV_32F images, binary and weighted masks with one channel or the template's: the small
+    shapes run the direct kernel, the large ones the bf16 matrix-core correlations (four partial products); against the restatement pinned to the reference"""
+    from opencv_amd import _lib
+    if kind.endswith("cn") and cn == 1:
+        pytest.skip("same as the one-channel mask")
+    for (iw, ih, tw, th) in [(64, 48, 8, 8), (97, 61, 17, 9), (300, 200, 33, 21), (261, 190, 128, 64)]:
+        img = rnd((ih, iw, cn) if cn > 1 else (ih, iw), dtype, 300 + iw)
+        tpl = rnd((th, tw, cn) if cn > 1 else (th, tw), dtype, 400 + tw)
+        mask = _mask(th, tw, cn, kind, 500 + tw)
+        for method in range(6):
+            want = orc.orc_matchTemplateMask(img, tpl, method, mask)
+            got = cv.matchTemplate(dev(img), dev(tpl), method, mask=dev(mask)).cpu().numpy()
+            if iw >= 261:
+                assert "k_ccorr_bf16" in _lib.lib.mi355cv_lastKernel().decode() and "mid*mid" in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+            err, tol = _mask_tol(img, tpl, mask, method, got, want)
+            assert np.isfinite(got).all() and err <= tol, (iw, ih, tw, th, method, err, tol)
+    # host arrays in, host array out; a result row pitch that is not the width
+    img, tpl, mask = rnd((61, 97), dtype, 1), rnd((9, 17), dtype, 2), _mask(9, 17, 1, "u8", 3)
+    got = cv.matchTemplate(img, tpl, 5, mask=mask)
+    assert np.max(np.abs(got - orc.orc_matchTemplateMask(img, tpl, 5, mask))) <= 1e-4
+
+
+def test_masked_match_is_found(cv, orc):
+    """a template cut out of a 1080p frame with half of it masked away and the masked half of the template overwritten: every method puts its extremum there, the
+    normalised scores are 1 / 0 there; an all-ones mask gives the unmasked TM_CCORR / TM_SQDIFF results"""
+    img = rnd((1080, 1920), np.uint8, 9)
+    tpl = np.ascontiguousarray(img[400:400 + 96, 700:700 + 128]).copy()
+    mask = np.zeros(tpl.shape, np.uint8); mask[:, :64] = 255
+    tpl[:, 64:] = 99
+    for method, val in [(0, 0.0), (1, 0.0), (2, None), (3, 1.0), (4, None), (5, 1.0)]:
+        got = cv.matchTemplate(dev(img), dev(tpl), method, mask=dev(mask)).cpu().numpy()
+        if method != 2:                                                                     # (TM_CCORR without normalisation peaks where the image is bright)
+            loc = np.unravel_index(np.argmin(got) if method < 2 else np.argmax(got), got.shape)
+            assert loc == (400, 700), (method, loc)
+        if val is not None:
+            assert abs(float(got[400, 700]) - val) <= 1e-4, (method, float(got[400, 700]))
+    ones = np.ones((96, 128), np.uint8)
+    tpl2 = np.ascontiguousarray(img[400:400 + 96, 700:700 + 128])
+    for method in (0, 2):
+        a = cv.matchTemplate(dev(img), dev(tpl2), method, mask=dev(ones)).cpu().numpy()
+        b = cv.matchTemplate(dev(img), dev(tpl2), method).cpu().numpy()
+        assert np.max(np.abs(a - b)) <= 1e-6 * float(np.max(np.abs(b))), method
+
+
+def test_masked_argument_checks(cv):
+    """the reference's assertions (templmatch.cpp:764-767) are ValueErrors in the mirror; the C ABI declines what it is not given properly, with a reason"""
     from opencv_amd import _lib
     img, tpl = rnd((64, 80), np.uint8, 1), rnd((8, 8), np.uint8, 2)
-    n0 = _lib.decline_count("matchTemplateMask")
-    with pytest.raises(NotImplementedError):
-        cv.matchTemplate(dev(img), dev(tpl), 3, mask=dev(np.ones((8, 8), np.uint8)))
-    assert _lib.decline_count("matchTemplateMask") == n0 + 1
+    with pytest.raises(ValueError):
+        cv.matchTemplate(dev(img), dev(tpl), 3, mask=dev(np.ones((8, 9), np.uint8)))
+    with pytest.raises(ValueError):
+        cv.matchTemplate(dev(img), dev(tpl), 3, mask=dev(np.ones((8, 8), np.int16)))
+    d = dev(img); t = dev(tpl); r = torch.empty((57, 73), dtype=torch.float32, device="cuda")
+    rc = _lib.lib.mi355cv_matchTemplateMask(d.data_ptr(), 80, 80, 64, t.data_ptr(), 8, 8, 8, 0, None, 8, 0, r.data_ptr(), 73 * 4, 3)
+    assert rc == 1 and b"mask" in _lib.lib.mi355cv_lastError()
