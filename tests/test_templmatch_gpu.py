@@ -290,7 +290,9 @@ def test_masked_match_is_found(cv, orc):
             loc = np.unravel_index(np.argmin(got) if method < 2 else np.argmax(got), got.shape)
             assert loc == (400, 700), (method, loc)
         if val is not None:
-            assert abs(float(got[400, 700]) - val) <= 1e-4, (method, float(got[400, 700]))
+            # TM_SQDIFF is a difference of terms near |T M|^2 (no clamp at zero in matchTemplateMask, :811): zero to fp32 rounding of those terms
+            tol = 1e-4 if method != 0 else 1e-6 * float((tpl[:, :64].astype(np.float64) ** 2).sum())
+            assert abs(float(got[400, 700]) - val) <= tol, (method, float(got[400, 700]))
     ones = np.ones((96, 128), np.uint8)
     tpl2 = np.ascontiguousarray(img[400:400 + 96, 700:700 + 128])
     for method in (0, 2):
