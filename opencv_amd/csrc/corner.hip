@@ -94,12 +94,12 @@ __global__ __launch_bounds__(256) void k_pyrdown(const uchar* __restrict__ src, 
 template <int D>
 __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ src, size_t sstep, size_t sframe,
                                                       uchar* __restrict__ dst, size_t dstep, size_t dframe,
-                                                      int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border)
+                                                      int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt)
 {
     typedef roll::Ctx<2, 2, 1, 16> Cx;
     typedef typename Cx::RawT RawT;
     Cx cx;
-    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, 0)) return;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
     dst += (size_t)cx.frame * dframe;
     struct HRow { uint32_t h[4]; };                    // h[i] = (hsum of output 2i, hsum of output 2i+1) as 2 x u16
     auto hpass = [&](HRow& o, const RawT& raw) {
@@ -116,27 +116,32 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
             o.h[i] = sum146(em + ep, om + od[i + 1], ev[i + 1]);
         }
     };
+    // The segment's output rows oy0 .. oy0 + nout - 1 in walking order: downwards from source row B = y0, or (alt: every other segment, so that two segments meet at
+    // their common boundary at the same time and the four rows they both read are in L2 for the second one) upwards from B = the centre row of the last output.
+    // The taps are symmetric, so the upward walk is the same recurrence on rows B, B - 1, B - 2, ...
     const int oy0 = cx.y0 >> 1, nout = (cx.nrows + 1) >> 1;
+    const int dir = cx.up ? -1 : 1, B = cx.up ? 2 * (oy0 + nout - 1) : cx.y0;
+    auto rowAt = [&](int k) { return min(max(B + dir * k, -2), H + 1); };            // k-th source row from B in walking direction, kept inside what rowIdx resolves
     HRow h0, h1, h2;
     {
         RawT r0, r1, r2; int v;
-        cx.issueImg(r0, cx.y0 - 2, v); cx.issueImg(r1, cx.y0 - 1, v); cx.issueImg(r2, cx.y0, v);
+        cx.issueImg(r0, rowAt(-2), v); cx.issueImg(r1, rowAt(-1), v); cx.issueImg(r2, rowAt(0), v);
         hpass(h0, r0); hpass(h1, r1); hpass(h2, r2);
     }
     // ring of D source rows in flight per wave (D / 2 output rows ahead): small levels are a few thousand waves in all, so the bytes in flight
     // per wave, not the wave count, is what covers the memory latency there
     RawT raw[D]; int rv;
 #pragma unroll
-    for (int u = 0; u < D; u++) cx.issueImg(raw[u], min(cx.y0 + 1 + u, H + 1), rv);
+    for (int u = 0; u < D; u++) cx.issueImg(raw[u], rowAt(1 + u), rv);
     for (int t = 0; t < nout; t += D / 2) {
 #pragma unroll
         for (int u = 0; u < D / 2; u++) {
             if (t + u < nout) {
                 HRow h3, h4;
                 hpass(h3, raw[2 * u]); hpass(h4, raw[2 * u + 1]);
-                const int nxt = cx.y0 + 2 * (t + u) + 1 + D;
-                cx.issueImg(raw[2 * u], min(nxt, H + 1), rv);
-                cx.issueImg(raw[2 * u + 1], min(nxt + 1, H + 1), rv);
+                const int nxt = 2 * (t + u) + 1 + D;
+                cx.issueImg(raw[2 * u], rowAt(nxt), rv);
+                cx.issueImg(raw[2 * u + 1], rowAt(nxt + 1), rv);
                 uint32_t w[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_roll(const uchar* __restrict__ 
                     uint2 ov;
                     ov.x = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u);
                     ov.y = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
-                    *reinterpret_cast<uint2*>(dst + (size_t)(oy0 + t + u) * dstep + 8 * (size_t)cx.c) = ov;
+                    *reinterpret_cast<uint2*>(dst + (size_t)(cx.up ? oy0 + nout - 1 - (t + u) : oy0 + t + u) * dstep + 8 * (size_t)cx.c) = ov;
                 }
                 h0 = h2; h1 = h3; h2 = h4;
             }
@@ -351,9 +356,12 @@ void launchPyrDown(const uchar* ds, size_t dss, size_t sframe, int sw, int sh, u
         if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
         const char* ringE = getenv("MI355CV_PYR_RING"); const int ringEnv = ringE ? atoi(ringE) : 0;   // tuning experiments
         const int ring = ringEnv ? ringEnv : 8;
-        if (ring >= 12)     hipLaunchKernelGGL(k_pyrdown_roll<12>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
-        else if (ring >= 8) hipLaunchKernelGGL(k_pyrdown_roll<8>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
-        else                hipLaunchKernelGGL(k_pyrdown_roll<4>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border);
+        // neighbouring segments walk towards / away from each other (roll.h `alt`), partners one turn of the XCD round-robin apart; MI355CV_PYR_ALT=0: all downwards
+        static const int altEnv = [] { const char* v = getenv("MI355CV_PYR_ALT"); return v ? atoi(v) : -1; }();
+        const int alt = altEnv == 0 ? 0 : altEnv > 0 ? altEnv : (32 % g.nstrips == 0 ? std::max(32 / g.nstrips, 2) : 8);
+        if (ring >= 12)     hipLaunchKernelGGL(k_pyrdown_roll<12>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
+        else if (ring >= 8) hipLaunchKernelGGL(k_pyrdown_roll<8>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
+        else                hipLaunchKernelGGL(k_pyrdown_roll<4>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
         return;
     }
     dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);

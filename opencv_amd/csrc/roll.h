@@ -94,8 +94,11 @@ struct Ctx {
         if (frame >= nframes) return false;
         up = 0;
         if (alt) {
-            const int g = seg >> 4, j = seg & 15;
-            if ((g << 4) + 16 <= nseg) seg = (g << 4) + 2 * (j & 7) + (j >> 3);
+            // alt = 1: partners 8 work items apart (4 strips per row: 32 waves = 8 workgroups = one turn of the XCD round-robin); alt = D > 1: D work items apart
+            // (kernels with fewer strips per row pass 32 / nstrips)
+            const int D = alt == 1 ? 8 : alt, G2 = 2 * D;
+            const int g = seg / G2, j = seg - g * G2;
+            if ((g + 1) * G2 <= nseg) seg = g * G2 + 2 * (j % D) + j / D;
             up = seg & 1;
         }
         H = H_; nchunks = nchunks_;
