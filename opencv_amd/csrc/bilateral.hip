@@ -258,8 +258,8 @@ int bilateral32f(const uchar* src_data, size_t src_step, uchar* dst_data, size_t
 extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                    int depth, int cn, int d, double sigma_color, double sigma_space, int border_type)
 {
-    if (disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || src_data == dst_data)
-        return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || src_data == dst_data");
+    if (disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data))
+        return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data)");
     const int isolated = border_type & MI355CV_BORDER_ISOLATED;
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border < B_CONSTANT || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < B_CONSTANT || border > B_REFLECT_101");

@@ -219,7 +219,7 @@ MI355CV_API int mi355cv_cvtBGRtoBGR(const uchar* src_data, size_t src_step, ucha
     const int e = esz(depth);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()) return mi355::declined(__func__, __LINE__, "!e || (scn != 3 && scn != 4) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || !ensureDevice()");
-    if (src_data == dst_data) return mi355::declined(__func__, __LINE__, "src_data == dst_data");     // in-place reorder: leave to the caller's path
+    if (inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "inPlaceOnDevice(src_data, dst_data)");     // in-place reorder: leave to the caller's path
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * scn * e, height, &dss);
     uchar* dd = stg.out(dst_data, dst_step, (size_t)width * dcn * e, height, &dds);

@@ -802,7 +802,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
         if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
@@ -834,7 +834,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         // L*u*v* in float: CV_32F images, and CV_8U images in linear RGB (RGB2Luv_b color_lab.cpp:3389-3392 interpolates in the grid for sRGB only)
         const int e = depth == MI355CV_32F ? 4 : 1;
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e");
+        if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % e");
         if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtBGRtoLab: no device memory for the tables");
@@ -856,7 +856,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
         return stg.finish("cvtBGRtoLab");
     }
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data)");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const LabTabs* tabs = isLab ? deviceTabs() : nullptr;
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();
@@ -899,7 +899,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
         if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
@@ -924,7 +924,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     }
     if (depth == MI355CV_32F) {                             // L*u*v*, CV_32F: Luv2RGBfloat
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-        if (!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
+        if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data) || ((uintptr_t)src_data | src_step | (uintptr_t)dst_data | dst_step) % 4");
         if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         const LuvTabs* ft = deviceLuvTabs();
         if (!ft) return setError(MI355CV_NOT_IMPLEMENTED, "cvtLabtoBGR: no device memory for the tables");
@@ -945,7 +945,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
     }
     if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
-    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");
+    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data)");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
     const LabTabs* tabs = deviceTabs();
     const LuvTabs* luv = isLab ? nullptr : deviceLuvTabs();

@@ -230,7 +230,7 @@ struct OpPremul {
 // the checks and staging every hook below shares
 #define MISC_PROLOGUE(sRowBytes, sRows, dRowBytes, dRows)                                                                        \
     Stager stg; /* first: a declined call must also put the host's device back (~Stager) */                                       \
-    if (!ensureDevice() || src_data == dst_data) return mi355::declined(__func__, __LINE__, "!ensureDevice() || src_data == dst_data");                                                  \
+    if (!ensureDevice() || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || inPlaceOnDevice(src_data, dst_data)");                                                  \
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");                           \
     size_t dss, dds;                                                                                                  \
     const uchar* ds = stg.in(src_data, src_step, (size_t)(sRowBytes), (sRows), &dss);                                             \

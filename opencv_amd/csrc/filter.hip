@@ -484,7 +484,11 @@ __global__ __launch_bounds__(256) void k_box_generic(
         drow[e] = (uchar)(p.normalize ? r : (r > 255u ? 255u : r));
         return;
     }
-    if (ddepth == D32F) { reinterpret_cast<float*>(drow)[e] = p.normalize ? (float)((double)s * p.scaleD) : (float)s; return; }
+    if (ddepth == D32F) {
+        // ColumnSum<int, float> (box_filter.simd.hpp:1109-1130): the vector body multiplies in float, the last (W*cn) % 4 elements of a row in double
+        reinterpret_cast<float*>(drow)[e] = !p.normalize ? (float)s : e < ((W * cn) & ~3) ? __fmul_rn((float)s, p.scaleF) : (float)((double)s * p.scaleD);
+        return;
+    }
     if (p.normalize && e >= ((W * cn) & ~7)) {
         // the reference's scalar tail (the last (W*cn) % 8 elements of a row, box_filter.simd.hpp:380-385) multiplies in double
         const double r = rint((double)s * p.scaleD);
@@ -1018,8 +1022,10 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return mi355::declined(__func__, __LINE__, "kw < 1 || kh < 1 || kw > 255 || kh > 255");
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101");
-    const bool okDepth = (src_depth == D8U && (dst_depth == D8U || dst_depth == D32F)) ||
-                         (src_depth == D16U && (dst_depth == D16U || dst_depth == D32F)) ||
+    // integer sources: int sums into any of the destination depths the reference has a ColumnSum<int, T> for (8U -> 16S is what an un-normalised cv::boxFilter of
+    // bytes usually asks for); a signed source into an unsigned destination is left to the caller's path
+    const bool okDepth = (src_depth == D8U && (dst_depth == D8U || dst_depth == D16U || dst_depth == D16S || dst_depth == D32F)) ||
+                         (src_depth == D16U && (dst_depth == D8U || dst_depth == D16U || dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D16S && (dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D32F && dst_depth == D32F);
     if (!okDepth) return mi355::declined(__func__, __LINE__, "!okDepth");

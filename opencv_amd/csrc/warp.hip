@@ -874,6 +874,84 @@ const short* deviceTab()
     return g_tabDevs[dev];
 }
 
+// The weight tables of INTER_CUBIC / INTER_LANCZOS4 for the warps (initInterTab1D / initInterTab2D imgwarp.cpp:152-262): per-axis float taps for the 32
+// fractions, and for CV_8U their 2-D products * 2^15 rounded to short, the sum of every entry forced to 2^15 by moving the difference onto the largest /
+// smallest of the four central weights.  Built on the host once (the Lanczos taps take the host's double sin / cos, as the reference does), one copy per device.
+struct TapTabs { short cubicI[1024 * 16]; short lanczosI[1024 * 64]; float cubic1[32 * 4]; float lanczos1[32 * 8]; };
+TapTabs g_tapHost;
+std::once_flag g_tapHostOnce;
+TapTabs* g_tapDevs[TAB_MAX_DEV];
+
+void tapCubic(float x, float* c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+void tapLanczos(float x, float* c)
+{
+    const double s45 = 0.70710678118654752440084436210485;
+    const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-7f) { for (int i = 0; i < 8; i++) c[i] = 0; c[3] = 1; return; }
+    float sum = 0;
+    const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+void buildTapHost()
+{
+    for (int m = 0; m < 2; m++) {
+        const int ks = m ? 8 : 4;
+        float* t1 = m ? g_tapHost.lanczos1 : g_tapHost.cubic1;
+        short* ti = m ? g_tapHost.lanczosI : g_tapHost.cubicI;
+        for (int i = 0; i < 32; i++) { if (m) tapLanczos(i * (1.f / 32), t1 + i * ks); else tapCubic(i * (1.f / 32), t1 + i * ks); }
+        for (int i = 0; i < 32; i++)
+            for (int j = 0; j < 32; j++) {
+                short* it = ti + (i * 32 + j) * ks * ks;
+                int isum = 0;
+                for (int k1 = 0; k1 < ks; k1++)
+                    for (int k2 = 0; k2 < ks; k2++) {
+                        const float v = t1[i * ks + k1] * t1[j * ks + k2];
+                        const int q = (int)lrintf(v * 32768);
+                        it[k1 * ks + k2] = (short)(q < -32768 ? -32768 : q > 32767 ? 32767 : q);
+                        isum += it[k1 * ks + k2];
+                    }
+                if (isum != 32768) {
+                    const int diff = isum - 32768, k0 = ks / 2;
+                    int Mk1 = k0, Mk2 = k0, mk1 = k0, mk2 = k0;
+                    for (int k1 = k0; k1 < k0 + 2; k1++)
+                        for (int k2 = k0; k2 < k0 + 2; k2++) {
+                            if (it[k1 * ks + k2] < it[mk1 * ks + mk2]) { mk1 = k1; mk2 = k2; }
+                            else if (it[k1 * ks + k2] > it[Mk1 * ks + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                        }
+                    if (diff < 0) it[Mk1 * ks + Mk2] = (short)(it[Mk1 * ks + Mk2] - diff);
+                    else it[mk1 * ks + mk2] = (short)(it[mk1 * ks + mk2] - diff);
+                }
+            }
+    }
+}
+const TapTabs* deviceTapTabs()
+{
+    std::call_once(g_tapHostOnce, buildTapHost);
+    const int dev = activeDevice();
+    if (dev < 0 || dev >= TAB_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tabMu);
+    if (!g_tapDevs[dev]) {
+        TapTabs* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(TapTabs)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemcpy(d, &g_tapHost, sizeof(TapTabs), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        g_tapDevs[dev] = d;
+    }
+    return g_tapDevs[dev];
+}
+
 struct SampleArgs { int sw, sh, depth, cn, linear, border; float cval[4]; };
 
 __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
@@ -1034,15 +1112,12 @@ __device__ __forceinline__ float polarLog(float v, bool vec, const float* __rest
     return __fmaf_rn(__fmaf_rn(__fmaf_rn(A0, x0, A1), x0, A2), x0, y0);
 }
 
-__global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-                                              SampleArgs s, WarpArgs w, const short* __restrict__ tab,
-                                              const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+// Integer source coordinates (sx, sy) and 5-bit fractions (ax, ay) of destination pixel (x, y) for every map form the warps and cv::remap take (the fixed-point
+// coordinate generation of WarpAffineInvoker / WarpPerspectiveInvoker / RemapInvoker); s.linear: 0 nearest (no fractions), otherwise the 1/32 grid every
+// interpolating sampler -- bilinear, bicubic, Lanczos -- shares
+__device__ __forceinline__ void warpCoord(const SampleArgs& s, const WarpArgs& w, int x, int y, const uchar* __restrict__ mapx, size_t mxstep,
+                                          const uchar* __restrict__ mapy, size_t mystep, int& sx, int& sy, int& ax, int& ay)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w.dw || y >= w.dh) return;
-    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
-    uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
     int X, Y;
     if (w.kind == 0) {
         const int rd = s.linear ? 16 : 512;
@@ -1100,14 +1175,131 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
         const short2 xy = reinterpret_cast<const short2*>(mapx + (size_t)y * mxstep)[x];
         const int a = w.kind == 4 ? (int)(reinterpret_cast<const unsigned short*>(mapy + (size_t)y * mystep)[x] & 1023) : 0;
         const int rx = w.rel ? x : 0, ry = w.rel ? y : 0;
-        if (s.linear) { samplePixel(src, sstep, D, s, xy.x + rx, xy.y + ry, a & 31, a >> 5, tab); return; }
+        if (s.linear) { sx = xy.x + rx; sy = xy.y + ry; ax = a & 31; ay = a >> 5; return; }
         const int dx = w.kind == 4 ? ((a & 31) < 16 ? 1 : 0) : 0, dy = w.kind == 4 ? ((a >> 5) < 16 ? 1 : 0) : 0;
-        samplePixel(src, sstep, D, s, (short)(xy.x + dx) + rx, (short)(xy.y + dy) + ry, 0, 0, tab);
+        sx = (short)(xy.x + dx) + rx; sy = (short)(xy.y + dy) + ry; ax = ay = 0;
         return;
     }
     const int rx = w.rel ? x : 0, ry = w.rel ? y : 0;
-    if (s.linear) samplePixel(src, sstep, D, s, satShort(X >> 5) + rx, satShort(Y >> 5) + ry, X & 31, Y & 31, tab);
-    else samplePixel(src, sstep, D, s, satShort(X) + rx, satShort(Y) + ry, 0, 0, tab);
+    if (s.linear) { sx = satShort(X >> 5) + rx; sy = satShort(Y >> 5) + ry; ax = X & 31; ay = Y & 31; }
+    else { sx = satShort(X) + rx; sy = satShort(Y) + ry; ax = ay = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                              SampleArgs s, WarpArgs w, const short* __restrict__ tab,
+                                              const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w.dw || y >= w.dh) return;
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
+    int sx, sy, ax, ay;
+    warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+    samplePixel(src, sstep, D, s, sx, sy, ax, ay, tab);
+}
+
+// ---- INTER_CUBIC / INTER_LANCZOS4 in warpAffine / warpPerspective / remap (remapBicubic imgwarp.cpp:905-1010, remapLanczos4 :1013-1120).  KS x KS taps from
+// (sx - KS/2 + 1, sy - KS/2 + 1); weights: CV_8U the Q15 table of initInterTab2D (tabI: [ay * 32 + ax][KS * KS] shorts, built on the host with the reference's
+// sum fix-up), the other depths the float products ty[k1] * tx[k2] of the per-axis table (tab1: [fraction][KS]).  Inside the image each row's products are
+// summed left to right and the rows added one after the other (the reference's float order; CV_8U is exact integer arithmetic and the order is free); next to
+// the border sum = cval + SUM (S - cval) * w over the taps that exist.  BORDER_TRANSPARENT leaves pixels whose centre tap is outside untouched and reflects
+// (REFLECT_101) for the rest.  One thread per destination pixel, all channels.
+template <int KS>
+__device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size_t sstep, uchar* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
+                                             const short* __restrict__ tabI, const float* __restrict__ tab1)
+{
+    constexpr int OFF = KS / 2 - 1;
+    sx -= OFF; sy -= OFF;
+    const int cn = a.cn, depth = a.depth;
+    const unsigned width1 = (unsigned)max(a.sw - (KS - 1), 0), height1 = (unsigned)max(a.sh - (KS - 1), 0);
+    const bool inside = (unsigned)sx < width1 && (unsigned)sy < height1;
+    int xi[KS], yi[KS];
+    if (inside) {
+#pragma unroll
+        for (int i = 0; i < KS; i++) { xi[i] = sx + i; yi[i] = sy + i; }
+    } else {
+        if (a.border == B_TRANSPARENT && ((unsigned)(sx + OFF) >= (unsigned)a.sw || (unsigned)(sy + OFF) >= (unsigned)a.sh)) return;
+        const int b1 = a.border != B_TRANSPARENT ? a.border : B_REFLECT_101;
+        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) stRound(D, depth, k, a.cval[k]); return; }
+#pragma unroll
+        for (int i = 0; i < KS; i++) { xi[i] = mi355_borderInterpolate(sx + i, a.sw, b1); yi[i] = mi355_borderInterpolate(sy + i, a.sh, b1); }
+    }
+    if (depth == D8U) {
+        const short* __restrict__ w = tabI + (ay * 32 + ax) * (KS * KS);
+        for (int k = 0; k < cn; k++) {
+            int sum;
+            if (inside) {
+                sum = 0;
+#pragma unroll
+                for (int r = 0; r < KS; r++) {
+                    const uchar* S = src + (size_t)yi[r] * sstep + k;
+#pragma unroll
+                    for (int c = 0; c < KS; c++) sum += (int)S[xi[c] * cn] * (int)w[r * KS + c];
+                }
+            } else {
+                const int cv = (int)fminf(fmaxf(rintf(a.cval[k]), 0.f), 255.f);
+                sum = cv << 15;
+#pragma unroll
+                for (int r = 0; r < KS; r++) {
+                    if (yi[r] < 0) continue;
+                    const uchar* S = src + (size_t)yi[r] * sstep + k;
+#pragma unroll
+                    for (int c = 0; c < KS; c++) if (xi[c] >= 0) sum += ((int)S[xi[c] * cn] - cv) * (int)w[r * KS + c];
+                }
+            }
+            const int v = (sum + (1 << 14)) >> 15;
+            D[k] = (uchar)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+        return;
+    }
+    float wy[KS], wx[KS];
+#pragma unroll
+    for (int i = 0; i < KS; i++) { wy[i] = tab1[ay * KS + i]; wx[i] = tab1[ax * KS + i]; }
+    for (int k = 0; k < cn; k++) {
+        float sum;
+        if (inside) {
+            sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < KS; r++) {
+                const uchar* S = src + (size_t)yi[r] * sstep;
+                float row = __fmul_rn(ldV(S, depth, xi[0] * cn + k), __fmul_rn(wy[r], wx[0]));
+#pragma unroll
+                for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(ldV(S, depth, xi[c] * cn + k), __fmul_rn(wy[r], wx[c])));
+                // remapBicubic starts from the first row's sum, remapLanczos4 from WT sum = 0 (0 + row: differs for a row sum of -0 only, and then in CV_32F's sign bit)
+                sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
+            }
+        } else {
+            float cv = a.cval[k];
+            if (depth == D16U) cv = fminf(fmaxf(rintf(cv), 0.f), 65535.f);
+            else if (depth == D16S) cv = fminf(fmaxf(rintf(cv), -32768.f), 32767.f);
+            sum = cv;
+#pragma unroll
+            for (int r = 0; r < KS; r++) {
+                if (yi[r] < 0) continue;
+                const uchar* S = src + (size_t)yi[r] * sstep;
+#pragma unroll
+                for (int c = 0; c < KS; c++)
+                    if (xi[c] >= 0) sum = __fadd_rn(sum, __fmul_rn(__fsub_rn(ldV(S, depth, xi[c] * cn + k), cv), __fmul_rn(wy[r], wx[c])));
+            }
+        }
+        stRound(D, depth, k, sum);
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_warp_taps(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                   SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
+                                                   const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w.dw || y >= w.dh) return;
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
+    int sx, sy, ax, ay;
+    warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+    samplePixelN<KS>(src, sstep, D, s, sx, sy, ax, ay, tabI, tab1);
 }
 
 // cv::convertMaps, float -> fixed point (imgwarp.cpp:2017-2120): ix = cvRound(x * 32), dst1 = (ix >> 5, iy >> 5) saturated to short,
@@ -1656,7 +1848,10 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     const bool relative = (interpolation & 32) != 0 && kind >= 2 && kind <= 5;              // WARP_RELATIVE_MAP (cv::remap only, imgwarp.cpp:1724)
     if (relative) interpolation &= ~32;
     if (interpolation == MI355CV_INTER_AREA) interpolation = MI355CV_INTER_LINEAR;          // imgwarp.cpp:2818
-    if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR) return mi355::declined(__func__, __LINE__, "interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR");
+    if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR && interpolation != MI355CV_INTER_CUBIC && interpolation != MI355CV_INTER_LANCZOS4)
+        return mi355::declined(__func__, __LINE__, "interpolation is none of NEAREST, LINEAR, CUBIC, AREA, LANCZOS4");
+    const bool taps = interpolation == MI355CV_INTER_CUBIC || interpolation == MI355CV_INTER_LANCZOS4;
+    if (taps && (kind == 5 || kind == 6 || kind == 7)) return mi355::declined(__func__, __LINE__, "bicubic / Lanczos sampling with a CV_16SC2 map alone, or in warpPolar");
     if (borderType < 0 || borderType > B_TRANSPARENT) return mi355::declined(__func__, __LINE__, "borderType < 0 || borderType > B_TRANSPARENT");
     if (sw > 32767 || sh > 32767) return mi355::declined(__func__, __LINE__, "sw > 32767 || sh > 32767");                         // coordinates saturate to short in the reference
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -1699,7 +1894,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         if (!dmx || !dmy) return mi355::declined(__func__, __LINE__, "!dmx || !dmy");
     }
     if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
-    SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR; s.border = borderType;
+    SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR ? 1 : taps ? interpolation : 0; s.border = borderType;
     for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
     WarpArgs w; memset(&w, 0, sizeof w);
     w.dw = dw; w.dh = dh; w.kind = kind; w.rel = relative ? 1 : 0;
@@ -1707,6 +1902,16 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : kind == 7 ? 5 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
+    if (taps) {
+        // bicubic / Lanczos: the per-pixel kernel over the shared coordinate generation
+        const TapTabs* tt = deviceTapTabs();
+        if (!tt) return mi355::declined(__func__, __LINE__, "the bicubic / Lanczos weight tables could not be placed on the device");
+        dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
+        if (interpolation == MI355CV_INTER_CUBIC) hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubicI, tt->cubic1, dmx, mxs, dmy, mys);
+        else                                      hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->lanczosI, tt->lanczos1, dmx, mxs, dmy, mys);
+        noteKernel("k_warp_taps<%d> grid=%ux%ux%u x256 kind=%d", interpolation == MI355CV_INTER_CUBIC ? 4 : 8, grid.x, grid.y, grid.z, kind);
+        return stg.finish(entry);
+    }
     if ((kind == 0 || kind == 1) && s.linear && (cn == 1 || cn == 3 || cn == 4) && (depth == D32F || depth == D8U) && sw >= 3 && sh >= 2 && (dss % e) == 0 &&
         (unsigned long long)sh * dss < (1ull << 32) && (unsigned long long)dh * dds < (1ull << 32) && dss < (1u << 24) &&
         ((uintptr_t)ds % e) == 0) {

@@ -244,7 +244,8 @@ int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
                 else if (mode == 0) {
                     unsigned r = normalize ? (((unsigned)si + (unsigned)divDelta) * (unsigned)divScale) >> 23 : (unsigned)si;
                     drow[e] = (uint8_t)(normalize ? r : (r > 255 ? 255 : r));
-                } else if (ddepth == 5) ((float*)drow)[e] = normalize ? (float)((double)si * scale) : (float)si;
+                } else if (ddepth == 5)             /* ColumnSum<int, float> box_filter.simd.hpp:1109-1130: float multiply in the vector body, double in the last (w*cn) % 4 */
+                    ((float*)drow)[e] = !normalize ? (float)si : e < ((w * cn) & ~3) ? (float)si * (float)scale : (float)((double)si * scale);
                 else if (normalize && e >= ((w * cn) & ~7)) {
                     /* ColumnSum<int, uchar / short / ushort> (box_filter.simd.hpp:339-385 and siblings): the vector loops (16 then 8 elements
                      * per step on AVX2, 8 on SSE) round (float)s * (float)scale; the last (w*cn) % 8 elements of a row take the scalar

@@ -586,12 +586,152 @@ static void sample_pixel(const uint8_t* src, size_t sstep, int sw, int sh, uint8
     }
 }
 
+/* ---- INTER_CUBIC / INTER_LANCZOS4 in the warps and in cv::remap (imgwarp.cpp).  The 32 x 32 fraction pairs index a table of ks x ks weights
+ * (ks = 4 / 8): interpolateCubic :152-160 / interpolateLanczos4 :162-188 per axis (initInterTab1D :190-211), their float products and, for CV_8U, those
+ * products * 2^15 rounded to short with the sum forced to 2^15 by moving the difference onto the largest / smallest of the four central weights
+ * (initInterTab2D :213-262).  Sampling: remapBicubic :905-1010 / remapLanczos4 :1013-1120 -- inside the image the row sums are formed left to right and
+ * added row by row (CV_8U: exact integers, FixedPtCast (sum + 2^14) >> 15 saturated); at the border sum = cval + SUM (S - cval) * w over the taps that
+ * exist.  TEST INFRASTRUCTURE. */
+static void warp_cubic_coef(float x, float* c)                   /* imgwarp.cpp:152-160 */
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+static void warp_lanczos_coef(float x, float* c)                 /* imgwarp.cpp:162-188 */
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-7f) { for (int i = 0; i < 8; i++) c[i] = 0; c[3] = 1; return; }
+    float sum = 0;
+    const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+static float g_wtab1[2][32 * 8];                                 /* [cubic, lanczos][fraction][tap] */
+static short g_wtabI[2][1024 * 64];                              /* [cubic, lanczos][ay * 32 + ax][ks * ks] */
+static int g_wtab_init = 0;
+static void warp_tabs_init(void)
+{
+    if (g_wtab_init) return;
+    for (int m = 0; m < 2; m++) {
+        const int ks = m ? 8 : 4;
+        const float scale = 1.f / 32;
+        for (int i = 0; i < 32; i++) { if (m) warp_lanczos_coef(i * scale, g_wtab1[m] + i * ks); else warp_cubic_coef(i * scale, g_wtab1[m] + i * ks); }
+        for (int i = 0; i < 32; i++)
+            for (int j = 0; j < 32; j++) {
+                short* it = g_wtabI[m] + (i * 32 + j) * ks * ks;
+                int isum = 0;
+                for (int k1 = 0; k1 < ks; k1++) {
+                    const float vy = g_wtab1[m][i * ks + k1];
+                    for (int k2 = 0; k2 < ks; k2++) {
+                        const float v = vy * g_wtab1[m][j * ks + k2];
+                        it[k1 * ks + k2] = sat_short_i((int)lrintf(v * 32768));
+                        isum += it[k1 * ks + k2];
+                    }
+                }
+                if (isum != 32768) {
+                    const int diff = isum - 32768, k0 = ks / 2;
+                    int Mk1 = k0, Mk2 = k0, mk1 = k0, mk2 = k0;
+                    for (int k1 = k0; k1 < k0 + 2; k1++)
+                        for (int k2 = k0; k2 < k0 + 2; k2++) {
+                            if (it[k1 * ks + k2] < it[mk1 * ks + mk2]) { mk1 = k1; mk2 = k2; }
+                            else if (it[k1 * ks + k2] > it[Mk1 * ks + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                        }
+                    if (diff < 0) it[Mk1 * ks + Mk2] = (short)(it[Mk1 * ks + Mk2] - diff);
+                    else it[mk1 * ks + mk2] = (short)(it[mk1 * ks + mk2] - diff);
+                }
+            }
+    }
+    g_wtab_init = 1;
+}
+const short* orc_warpTabI(int lanczos) { warp_tabs_init(); return g_wtabI[lanczos ? 1 : 0]; }
+const float* orc_warpTab1D(int lanczos) { warp_tabs_init(); return g_wtab1[lanczos ? 1 : 0]; }
+
+/* one output pixel of remapBicubic (mode 2) / remapLanczos4 (mode 4): (sx, sy) = the integer coordinates as the bilinear form gets them (the first tap
+ * is ks / 2 - 1 to their left and above), (ax, ay) the 5-bit fractions */
+static void sample_pixel_n(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* D, int depth, int cn,
+                           int sx, int sy, int ax, int ay, int mode, int border, const double* bv)
+{
+    warp_tabs_init();
+    const int m = mode == 4, ks = m ? 8 : 4, off = ks / 2 - 1;
+    sx -= off; sy -= off;
+    const short* wi = g_wtabI[m] + (ay * 32 + ax) * ks * ks;
+    float wf[64];
+    for (int k1 = 0; k1 < ks; k1++) for (int k2 = 0; k2 < ks; k2++) wf[k1 * ks + k2] = g_wtab1[m][ay * ks + k1] * g_wtab1[m][ax * ks + k2];
+    const unsigned width1 = (unsigned)(sw - (ks - 1) > 0 ? sw - (ks - 1) : 0), height1 = (unsigned)(sh - (ks - 1) > 0 ? sh - (ks - 1) : 0);
+    if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+        for (int k = 0; k < cn; k++) {
+            if (depth == 0) {
+                int sum = 0;
+                for (int r = 0; r < ks; r++) for (int c = 0; c < ks; c++) sum += src[(size_t)(sy + r) * sstep + (sx + c) * cn + k] * wi[r * ks + c];
+                const int v = (sum + (1 << 14)) >> 15;
+                D[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            } else {
+                float sum = 0; int first = 1;
+                for (int r = 0; r < ks; r++) {
+                    const uint8_t* S = src + (size_t)(sy + r) * sstep;
+                    float row = (float)ldv(S, depth, sx * cn + k) * wf[r * ks];
+                    for (int c = 1; c < ks; c++) { const float p = (float)ldv(S, depth, (sx + c) * cn + k) * wf[r * ks + c]; row = row + p; }
+                    /* remapBicubic: WT sum = row0; sum += row1 ...; remapLanczos4: WT sum = 0; sum += row0 ... (0 + row0 == row0 except for -0, which the
+                     * later saturate / store cannot tell apart from +0 -- but CV_32F can: keep the reference's form) */
+                    if (first && !m) sum = row; else sum = sum + row;
+                    first = 0;
+                }
+                stv_round(D, depth, k, sum);
+            }
+        }
+        return;
+    }
+    if (border == 5 && ((unsigned)(sx + off) >= (unsigned)sw || (unsigned)(sy + off) >= (unsigned)sh)) return;
+    const int b1 = border != 5 ? border : 4;
+    if (b1 == 0 && (sx >= sw || sx + ks <= 0 || sy >= sh || sy + ks <= 0)) { for (int k = 0; k < cn; k++) stv_round(D, depth, k, (float)bv[k & 3]); return; }
+    int xi[8], yi[8];
+    for (int i = 0; i < ks; i++) { xi[i] = orc_borderInterpolate(sx + i, sw, b1); yi[i] = orc_borderInterpolate(sy + i, sh, b1); }
+    for (int k = 0; k < cn; k++) {
+        uint8_t cvb[8];
+        stv_round(cvb, depth, 0, (float)bv[k & 3]);
+        if (depth == 0) {
+            const int cv = cvb[0];
+            int sum = cv * 32768;
+            for (int r = 0; r < ks; r++) {
+                if (yi[r] < 0) continue;
+                for (int c = 0; c < ks; c++) if (xi[c] >= 0) sum += (src[(size_t)yi[r] * sstep + xi[c] * cn + k] - cv) * wi[r * ks + c];
+            }
+            const int v = (sum + (1 << 14)) >> 15;
+            D[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        } else {
+            const float cv = (float)ldv(cvb, depth, 0);
+            float sum = cv * 1;
+            for (int r = 0; r < ks; r++) {
+                if (yi[r] < 0) continue;
+                for (int c = 0; c < ks; c++) if (xi[c] >= 0) { const float d = (float)ldv(src + (size_t)yi[r] * sstep, depth, xi[c] * cn + k) - cv; const float p = d * wf[r * ks + c]; sum = sum + p; }
+            }
+            stv_round(D, depth, k, sum);
+        }
+    }
+}
+/* the sampler of a non-nearest mode (1 bilinear, 2 bicubic, 4 Lanczos) */
+static void sample_mode(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* D, int depth, int cn,
+                        int sx, int sy, int ax, int ay, int mode, int border, const double* bv)
+{
+    if (mode == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, sx, sy, ax, ay, 1, border, bv);
+    else sample_pixel_n(src, sstep, sw, sh, D, depth, cn, sx, sy, ax, ay, mode, border, bv);
+}
+
 int orc_warpAffine(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst, size_t dstep, int dw, int dh,
                    int depth, int cn, const double* M, int interpolation, int border, const double* bv)
 {
     if (interpolation == 3) interpolation = 1;
-    if (interpolation != 0 && interpolation != 1) return 1;
-    const int linear = interpolation == 1;
+    if (interpolation != 0 && interpolation != 1 && interpolation != 2 && interpolation != 4) return 1;
+    const int linear = interpolation != 0;
     const int round_delta = linear ? 1024 / 32 / 2 : 1024 / 2;
     const int e = esz(depth);
     for (int y = 0; y < dh; y++) {
@@ -602,7 +742,7 @@ int orc_warpAffine(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* ds
             uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
             if (linear) {
                 const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
-                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, 1, border, bv);
+                sample_mode(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, interpolation, border, bv);
             } else {
                 const int X = (X0 + ad) >> 10, Y = (Y0 + bd) >> 10;
                 sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X), sat_short_i(Y), 0, 0, 0, border, bv);
@@ -616,8 +756,8 @@ int orc_warpPerspective(const uint8_t* src, size_t sstep, int sw, int sh, uint8_
                         int depth, int cn, const double* M, int interpolation, int border, const double* bv)
 {
     if (interpolation == 3) interpolation = 1;
-    if (interpolation != 0 && interpolation != 1) return 1;
-    const int linear = interpolation == 1;
+    if (interpolation != 0 && interpolation != 1 && interpolation != 2 && interpolation != 4) return 1;
+    const int linear = interpolation != 0;
     const int e = esz(depth);
     int bh0 = 16 < dh ? 16 : dh;
     int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
@@ -634,7 +774,7 @@ int orc_warpPerspective(const uint8_t* src, size_t sstep, int sw, int sh, uint8_
             fY = fY < (double)INT_MIN ? (double)INT_MIN : fY > (double)INT_MAX ? (double)INT_MAX : fY;
             const int X = sat_int_d(fX), Y = sat_int_d(fY);
             uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
-            if (linear) sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, 1, border, bv);
+            if (linear) sample_mode(src, sstep, sw, sh, D, depth, cn, sat_short_i(X >> 5), sat_short_i(Y >> 5), X & 31, Y & 31, interpolation, border, bv);
             else sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(X), sat_short_i(Y), 0, 0, 0, border, bv);
         }
     return 0;
@@ -650,16 +790,16 @@ int orc_remap32f(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst,
     const int rel = (interpolation & 32) != 0;
     interpolation &= ~32;
     if (interpolation == 3) interpolation = 1;
-    if (interpolation != 0 && interpolation != 1) return 1;
+    if (interpolation != 0 && interpolation != 1 && interpolation != 2 && interpolation != 4) return 1;
     const int e = esz(depth);
     for (int y = 0; y < dh; y++) {
         const float* mx = (const float*)((const uint8_t*)mapx + (size_t)y * mxstep);
         const float* my = (const float*)((const uint8_t*)mapy + (size_t)y * mystep);
         for (int x = 0; x < dw; x++) {
             uint8_t* D = dst + (size_t)y * dstep + (size_t)x * cn * e;
-            if (interpolation == 1) {
+            if (interpolation != 0) {
                 int sx = sat_int_d((double)(mx[x] * 32.f)), sy = sat_int_d((double)(my[x] * 32.f));
-                sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + (rel ? x : 0), sat_short_i(sy >> 5) + (rel ? y : 0), sx & 31, sy & 31, 1, border, bv);
+                sample_mode(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + (rel ? x : 0), sat_short_i(sy >> 5) + (rel ? y : 0), sx & 31, sy & 31, interpolation, border, bv);
             } else {
                 int sx = sat_int_d((double)mx[x]), sy = sat_int_d((double)my[x]);
                 sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx) + (rel ? x : 0), sat_short_i(sy) + (rel ? y : 0), 0, 0, 0, border, bv);
@@ -678,7 +818,7 @@ int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst
     const int rel = (interpolation & 32) != 0;                  /* WARP_RELATIVE_MAP, as in orc_remap32f */
     interpolation &= ~32;
     if (interpolation == 3) interpolation = 1;
-    if (interpolation != 0 && interpolation != 1) return 1;
+    if (interpolation != 0 && interpolation != 1 && interpolation != 2 && interpolation != 4) return 1;
     const int e = esz(depth);
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
@@ -686,9 +826,9 @@ int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst
             const int rx = rel ? x : 0, ry = rel ? y : 0;
             if (kind == 3) {
                 const float* m = (const float*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
-                if (interpolation == 1) {
+                if (interpolation != 0) {
                     int sx = sat_int_d((double)(m[0] * 32.f)), sy = sat_int_d((double)(m[1] * 32.f));
-                    sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + rx, sat_short_i(sy >> 5) + ry, sx & 31, sy & 31, 1, border, bv);
+                    sample_mode(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx >> 5) + rx, sat_short_i(sy >> 5) + ry, sx & 31, sy & 31, interpolation, border, bv);
                 } else {
                     int sx = sat_int_d((double)m[0]), sy = sat_int_d((double)m[1]);
                     sample_pixel(src, sstep, sw, sh, D, depth, cn, sat_short_i(sx) + rx, sat_short_i(sy) + ry, 0, 0, 0, border, bv);
@@ -696,7 +836,7 @@ int orc_remapMaps(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* dst
             } else {
                 const short* xy = (const short*)((const uint8_t*)map1 + (size_t)y * m1step) + 2 * x;
                 const int a = kind == 4 ? (((const uint16_t*)((const uint8_t*)map2 + (size_t)y * m2step))[x] & 1023) : 0;
-                if (interpolation == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, xy[0] + rx, xy[1] + ry, a & 31, a >> 5, 1, border, bv);
+                if (interpolation != 0) sample_mode(src, sstep, sw, sh, D, depth, cn, xy[0] + rx, xy[1] + ry, a & 31, a >> 5, interpolation, border, bv);
                 else {
                     const int dx = kind == 4 ? (a & 31) < 16 : 0, dy = kind == 4 ? (a >> 5) < 16 : 0;
                     sample_pixel(src, sstep, sw, sh, D, depth, cn, (short)(xy[0] + dx) + rx, (short)(xy[1] + dy) + ry, 0, 0, 0, border, bv);

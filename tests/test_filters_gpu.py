@@ -253,13 +253,15 @@ def test_sobel_box_rolling_path(cv, orc):
 
 
 def test_boxfilter(cv, orc):
-    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, -1)]:
-        src = rnd((31, 66, 3), dtype, 21)
+    # (integer sources are bit-exact into every destination depth, CV_32F included: ColumnSum<int, float>'s float / double split is reproduced)
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, -1),
+                          (np.uint8, 3), (np.uint8, 2), (np.uint16, 0), (np.uint16, 3), (np.uint16, 5), (np.int16, 5)]:
+        src = rnd((31, 66 + (ddepth == 5), 3), dtype, 21)
         for ksize, anchor in [((3, 3), (-1, -1)), ((5, 5), (-1, -1)), ((2, 2), (-1, -1)), ((7, 3), (1, 2)), ((16, 16), (-1, -1)), ((17, 17), (-1, -1))]:
             for normalize in (True, False):
                 for border in (0, 1, 4):
                     check(cv.boxFilter(dev(src), ddepth, ksize, anchor, normalize, border),
-                          orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border), tol=1e-6)
+                          orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border), tol=1e-6 if dtype == np.float32 else 0.0)
     src = rnd((20, 33), np.uint8, 2)
     check(cv.blur(src, (3, 3)), orc.orc_boxFilter(src, -1, (3, 3)))
 

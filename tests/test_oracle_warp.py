@@ -299,3 +299,56 @@ def test_area_fast_2x2_float_summation_orders(orc, ref):
         src = (rng.standard_normal(shape) * 10 ** rng.uniform(-3, 3, shape)).astype(np.float32)
         h, w = shape[:2]
         assert np.array_equal(orc.orc_resize(src, (w // 2, h // 2), interpolation=3), orc.ref_resize(src, (w // 2, h // 2), interpolation=3)), shape
+
+
+def _bits(got, want):
+    """bit for bit, CV_32F included (the restatement keeps the reference's order of float operations); NaN-safe"""
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_cubic_lanczos(orc, ref, dtype, cn):
+    """INTER_CUBIC (2) / INTER_LANCZOS4 (4) in warpAffine and warpPerspective (remapBicubic / remapLanczos4 imgwarp.cpp:905-1120 behind the warps' fixed-point
+    coordinates): every border rule incl. BORDER_TRANSPARENT, maps that leave the source on every side; the weight tables (initInterTab2D :213-262) are pinned
+    through the results"""
+    src = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 515 + cn)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    for interp in (2, 4):
+        for M in mats(orc, 61, 45):
+            for dsize in [(61, 45), (100, 30)]:
+                prev = rnd(orc, (dsize[1], dsize[0], cn) if cn > 1 else (dsize[1], dsize[0]), dtype, 9)
+                for border, bval in [(0, 0.0), (0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+                    d0 = prev if border == 5 else None
+                    _bits(orc.orc_warpAffine(src, M, dsize, interp, border, bval, dst=d0), orc.ref_warpAffine(src, M, dsize, interp | 16, border, bval, dst=d0))
+        for border, bval in [(0, 5.0), (1, 0), (4, 0), (5, 0)]:
+            prev = rnd(orc, (45, 61, cn) if cn > 1 else (45, 61), dtype, 10)
+            d0 = prev if border == 5 else None
+            _bits(orc.orc_warpPerspective(src, P, (61, 45), interp, border, bval, dst=d0), orc.ref_warpPerspective(src, P, (61, 45), interp | 16, border, bval, dst=d0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_remap_cubic_lanczos(orc, ref, dtype):
+    """cv::remap with INTER_CUBIC / INTER_LANCZOS4: CV_32FC1 pairs, a CV_32FC2 map, the fixed-point maps, and all of them with WARP_RELATIVE_MAP"""
+    REL = 32
+    src = rnd(orc, (40, 50, 3), dtype, 536)
+    mapx, mapy = _float_maps(14)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.ref_convertMaps(mapx, mapy, "16sc2", False)
+    rng = np.random.default_rng(18)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    offx[2, 3] = 40000.0; offy[5, 6] = -40000.0
+    oxy = np.ascontiguousarray(np.stack([offx, offy], axis=-1))
+    o1, o2 = orc.ref_convertMaps(offx, offy, "16sc2", False)
+    prev = rnd(orc, (33, 47, 3), dtype, 37)
+    for interp in (2, 4):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+            d0 = prev if border == 5 else None
+            if border != 5:
+                _bits(orc.orc_remap(src, mapx, mapy, interp, border, bval), orc.ref_remap(src, mapx, mapy, interp, border, bval))
+                _bits(orc.orc_remap(src, offx, offy, interp | REL, border, bval), orc.ref_remap(src, offx, offy, interp | REL, border, bval))
+            _bits(orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=d0), orc.ref_remapMaps(src, xy, None, interp, border, bval, dst=d0))
+            _bits(orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=d0), orc.ref_remapMaps(src, f1, f2, interp, border, bval, dst=d0))
+            _bits(orc.orc_remapMaps(src, oxy, None, interp | REL, border, bval, dst=d0), orc.ref_remapMaps(src, oxy, None, interp | REL, border, bval, dst=d0))
+            _bits(orc.orc_remapMaps(src, o1, o2, interp | REL, border, bval, dst=d0), orc.ref_remapMaps(src, o1, o2, interp | REL, border, bval, dst=d0))

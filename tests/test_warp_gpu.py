@@ -450,3 +450,71 @@ def test_area_fast_2x2_float_summation_orders(cv, orc):
         h, w = shape[:2]
         got = cv.resize(dev(src), (w // 2, h // 2), interpolation=3).cpu().numpy()
         assert np.array_equal(got, orc.orc_resize(src, (w // 2, h // 2), interpolation=3)), shape
+
+
+def _bits(got, want):
+    """bit for bit, CV_32F included: the kernel keeps the reference's order of float operations"""
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_warp_cubic_lanczos(cv, orc, dtype, cn):
+    """INTER_CUBIC / INTER_LANCZOS4 in warpAffine and warpPerspective (k_warp_taps; remapBicubic / remapLanczos4 imgwarp.cpp:905-1120): every border rule incl.
+    BORDER_TRANSPARENT, maps that leave the source on every side, device and host images"""
+    from opencv_amd import _lib
+    src = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 515 + cn)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    for interp in (2, 4):
+        for M in mats(cv, 61, 45):
+            for dsize in [(61, 45), (100, 30)]:
+                prev = rnd((dsize[1], dsize[0], cn) if cn > 1 else (dsize[1], dsize[0]), dtype, 9)
+                for border, bval in [(0, 0.0), (0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+                    want = orc.orc_warpAffine(src, M, dsize, interp, border, bval, dst=prev if border == 5 else None)
+                    _bits(cv.warpAffine(dev(src), M, dsize, interp | cv.WARP_INVERSE_MAP, border, bval, dst=dev(prev.copy()) if border == 5 else None), want)
+        assert "k_warp_taps<%d>" % (4 if interp == 2 else 8) in _lib.lib.mi355cv_lastKernel().decode()
+        for border, bval in [(0, 5.0), (1, 0), (4, 0), (5, 0)]:
+            prev = rnd((45, 61, cn) if cn > 1 else (45, 61), dtype, 10)
+            want = orc.orc_warpPerspective(src, P, (61, 45), interp, border, bval, dst=prev if border == 5 else None)
+            _bits(cv.warpPerspective(dev(src), P, (61, 45), interp | cv.WARP_INVERSE_MAP, border, bval, dst=dev(prev.copy()) if border == 5 else None), want)
+        M = mats(cv, 61, 45)[1]
+        _bits(cv.warpAffine(src, M, (61, 45), interp | cv.WARP_INVERSE_MAP, 4), orc.orc_warpAffine(src, M, (61, 45), interp, 4))          # host arrays
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_remap_cubic_lanczos(cv, orc, dtype):
+    """cv::remap with INTER_CUBIC / INTER_LANCZOS4: CV_32FC1 pairs (cv_hal_remap32f), a CV_32FC2 map, the fixed-point maps -- plain and with WARP_RELATIVE_MAP
+    (the 150 cases of the reference's Imgproc_RemapRelative that round 4's ledger still showed on the fallback)"""
+    REL = 32
+    src = rnd((40, 50, 3), dtype, 536)
+    mapx, mapy = _float_maps(14)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.orc_convertMaps(mapx, mapy, "16sc2", False)
+    rng = np.random.default_rng(18)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    offx[2, 3] = 40000.0; offy[5, 6] = -40000.0
+    oxy = np.ascontiguousarray(np.stack([offx, offy], axis=-1))
+    o1, o2 = orc.orc_convertMaps(offx, offy, "16sc2", False)
+    prev = rnd((33, 47, 3), dtype, 37)
+    for interp in (2, 4):
+        for border, bval in [(0, 9.0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+            d0 = lambda: dev(prev.copy()) if border == 5 else None
+            p0 = prev if border == 5 else None
+            if border != 5:
+                _bits(cv.remap(dev(src), dev(mapx), dev(mapy), interp, border, bval), orc.orc_remap(src, mapx, mapy, interp, border, bval))
+                _bits(cv.remap(dev(src), dev(offx), dev(offy), interp | REL, border, bval), orc.orc_remap(src, offx, offy, interp | REL, border, bval))
+            _bits(cv.remap(dev(src), dev(xy), None, interp, border, bval, dst=d0()), orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=p0))
+            _bits(cv.remap(dev(src), dev(f1), dev(f2), interp, border, bval, dst=d0()), orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=p0))
+            _bits(cv.remap(dev(src), dev(oxy), None, interp | REL, border, bval, dst=d0()), orc.orc_remapMaps(src, oxy, None, interp | REL, border, bval, dst=p0))
+            _bits(cv.remap(dev(src), dev(o1), dev(o2), interp | REL, border, bval, dst=d0()), orc.orc_remapMaps(src, o1, o2, interp | REL, border, bval, dst=p0))
+        _bits(cv.remap(src, mapx, mapy, interp, 1, 0), orc.orc_remap(src, mapx, mapy, interp, 1, 0))                     # host arrays
+
+
+def test_warp_cubic_whole_frames(cv, orc):
+    """a whole 1080p frame per interpolation and depth: 7-degree rotation, BORDER_REFLECT_101, against the restatement"""
+    M = cv.getRotationMatrix2D((960.0, 540.0), 7.0, 0.95)
+    for dtype, interp in ((np.uint8, 2), (np.uint8, 4), (np.float32, 2)):
+        src = rnd((1080, 1920), dtype, 77)
+        _bits(cv.warpAffine(dev(src), M, (1920, 1080), interp | cv.WARP_INVERSE_MAP, 4), orc.orc_warpAffine(src, M, (1920, 1080), interp, 4))
