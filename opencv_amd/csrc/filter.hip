@@ -751,9 +751,10 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
         int kernel_width, int kernel_height, int max_width, int max_height, int src_type, int dst_type, int borderType,
         double delta, int anchor_x, int anchor_y, bool allowSubmatrix, bool allowInplace)
 {
-    (void)max_width; (void)max_height; (void)allowSubmatrix;
+    // allowInplace (src_data == dst_data at the call site, filter.dispatch.cpp:1176): a host image goes through separate device buffers, so it is served;
+    // a device image filtered in place is refused by mi355cv_filter itself (overlapOnDevice), which the caller treats as "not replaced" (:1177-1183)
+    (void)max_width; (void)max_height; (void)allowSubmatrix; (void)allowInplace;
     if (!context || !kernel_data || disabled()) return mi355::declined(__func__, __LINE__, "!context || !kernel_data || disabled()");
-    if (allowInplace) return mi355::declined(__func__, __LINE__, "allowInplace");               // src == dst: a stencil cannot run in place on the GPU
     if (MI355CV_MAT_CN(kernel_type) != 1 || kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024)
         return mi355::declined(__func__, __LINE__, "MI355CV_MAT_CN(kernel_type) != 1 || kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024");
     FilterCtx* c = new (std::nothrow) FilterCtx();

@@ -1205,6 +1205,45 @@ __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, siz
 // summed left to right and the rows added one after the other (the reference's float order; CV_8U is exact integer arithmetic and the order is free); next to
 // the border sum = cval + SUM (S - cval) * w over the taps that exist.  BORDER_TRANSPARENT leaves pixels whose centre tap is outside untouched and reflects
 // (REFLECT_101) for the rest.  One thread per destination pixel, all channels.
+// CV_8U, all KS x KS taps inside the image: a row's taps are KS * CN contiguous bytes -- KS * CN / 4 unaligned dword loads --, a tap pair of one channel is one
+// v_perm_b32 into two 16-bit halves and one v_dot2_i32_i16 with the table's weight pair (the Q15 entry read as dwordx4s): KS * KS VALU instructions per channel
+// where the byte-wise form spends that many loads.  Exact integers, so the order of the sums is free.
+template <int KS, int CN>
+__device__ __forceinline__ void tapsInside8(const uchar* __restrict__ p /* first tap of the first row */, size_t sstep, uchar* D, const short* __restrict__ w)
+{
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    constexpr int NB = KS * CN / 4, NW = KS * KS / 2;
+    uint32_t px[KS][NB], wt[NW];
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+        const u32u* q = reinterpret_cast<const u32u*>(p + (size_t)r * sstep);
+#pragma unroll
+        for (int i = 0; i < NB; i++) px[r][i] = q[i];
+    }
+    const uint4* wq = reinterpret_cast<const uint4*>(w);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int k = 0; k < CN; k++) {
+        int sum = 1 << 14;
+#pragma unroll
+        for (int r = 0; r < KS; r++)
+#pragma unroll
+            for (int j = 0; j < KS / 2; j++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k;                 // byte positions of taps 2j, 2j+1 of channel k in the row
+                const int d0 = b0 >> 2, d1 = b1 >> 2;
+                // v_perm_b32(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi, 0x0c = zero
+                const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
+                const uint32_t pair = __builtin_amdgcn_perm(px[r][d1], px[r][d0], sel);
+                sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
+            }
+        const int v = sum >> 15;
+        D[k] = (uchar)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
 template <int KS>
 __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size_t sstep, uchar* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
                                              const short* __restrict__ tabI, const float* __restrict__ tab1)
@@ -1227,6 +1266,14 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
     }
     if (depth == D8U) {
         const short* __restrict__ w = tabI + (ay * 32 + ax) * (KS * KS);
+        if (inside) {
+            const uchar* p = src + (size_t)sy * sstep + (size_t)sx * cn;
+            if (cn == 1) tapsInside8<KS, 1>(p, sstep, D, w);
+            else if (cn == 2) tapsInside8<KS, 2>(p, sstep, D, w);
+            else if (cn == 3) tapsInside8<KS, 3>(p, sstep, D, w);
+            else tapsInside8<KS, 4>(p, sstep, D, w);
+            return;
+        }
         for (int k = 0; k < cn; k++) {
             int sum;
             if (inside) {

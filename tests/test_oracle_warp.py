@@ -308,7 +308,7 @@ def _bits(got, want):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("cn", [1, 3, 4])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
 def test_warp_cubic_lanczos(orc, ref, dtype, cn):
     """INTER_CUBIC (2) / INTER_LANCZOS4 (4) in warpAffine and warpPerspective (remapBicubic / remapLanczos4 imgwarp.cpp:905-1120 behind the warps' fixed-point
     coordinates): every border rule incl. BORDER_TRANSPARENT, maps that leave the source on every side; the weight tables (initInterTab2D :213-262) are pinned

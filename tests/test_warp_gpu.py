@@ -460,7 +460,7 @@ def _bits(got, want):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("cn", [1, 3, 4])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
 def test_warp_cubic_lanczos(cv, orc, dtype, cn):
     """INTER_CUBIC / INTER_LANCZOS4 in warpAffine and warpPerspective (k_warp_taps; remapBicubic / remapLanczos4 imgwarp.cpp:905-1120): every border rule incl.
     BORDER_TRANSPARENT, maps that leave the source on every side, device and host images"""

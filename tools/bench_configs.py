@@ -260,6 +260,9 @@ def run(quick=False, parity=True):
     bline("a8 warpAffine 4K 8UC1 rot 7deg batch", lambda: cv.warpAffineBatch(gray, Mb, (W4, H4), dst=dstb), PIX4 * 2)
     P3 = np.array([[1.02, 0.03, -20.0], [0.01, 0.98, 15.0], [1e-5, -2e-5, 1.0]])
     bline("a9 warpPerspective 4K 8UC1 batch", lambda: cv.warpPerspectiveBatch(gray, P3, (W4, H4), dst=dstb), PIX4 * 2)
+    # the same warps with the reference's 4 x 4 and 8 x 8 tap samplers (k_warp_taps: one thread per destination pixel)
+    bline("f2 warpAffine 4K 8UC1 rot 7deg INTER_CUBIC batch", lambda: cv.warpAffineBatch(gray, Mb, (W4, H4), flags=2, dst=dstb), PIX4 * 2)
+    bline("f2 warpAffine 4K 8UC1 rot 7deg INTER_LANCZOS4 batch", lambda: cv.warpAffineBatch(gray, Mb, (W4, H4), flags=4, dst=dstb), PIX4 * 2)
     B3C = frames_for(PIX4 * 6, 8)
     c3d = torch.empty((B3C, H4, W4, 3), dtype=torch.uint8, device=dev)
     bline("a8 warpAffine 4K 8UC3 rot 7deg batch", lambda: cv.warpAffineBatch(bgr[:B3C], Mb, (W4, H4), dst=c3d), PIX4 * 6, B3C)

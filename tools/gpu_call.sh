@@ -14,6 +14,7 @@
 #   latency          tools/ubench/call_latency.cpp: host time per hook call through the C ABI
 #   gran             tools/probes/gran.hip: row-walking copies at 4 / 8 / 16 bytes per lane
 #   pyr-ab           tools/pyr_ab.py: buildPyramid / pyrDown, all segments downwards against alternating walks
+#   taps             tools/warp_taps_bench.py: bicubic / Lanczos warps beside the bilinear kernels
 #   mix              tools/probes/mix.hip: what HBM delivers for each rolling kernel's read : write mix with loads and stores alone
 #   refsuite         the reference's own opencv_test_imgproc on the hooks (Makefile build and cmake build) with the decline ledger
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
@@ -42,6 +43,7 @@ PY
     latency)   hipcc -O2 -Wno-unused-result -I include tools/ubench/call_latency.cpp -L opencv_amd -lmi355cv -Wl,-rpath,$R/opencv_amd -o /tmp/call_latency 2>/dev/null && /tmp/call_latency | tee $O/${T}.txt ;;
     gran)      (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 gran.hip -o /tmp/gran 2>/dev/null) && /tmp/gran | tee $O/${T}.txt ;;
     pyr-ab)    timeout 600 python tools/pyr_ab.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
+    taps)      timeout 300 python tools/warp_taps_bench.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
     mix)       (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix.hip -o /tmp/mix 2>/dev/null) && timeout 120 /tmp/mix | tee $O/${T}.txt ;;
     refsuite)  MI355CV_WRITE_LEDGER=1 timeout 1500 python -m pytest tests/test_reference_suite.py tests/test_cmake_reference_build.py -m gpu -q --timeout 1400 > $O/${T}.log 2>&1; echo "refsuite rc $?"; tail -6 $O/${T}.log | cut -c1-300 ;;
     *)         echo "unknown recipe $rec"; exit 2 ;;
