@@ -1337,7 +1337,7 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
 template <int KS>
 __global__ __launch_bounds__(256) void k_warp_taps(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                    SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
-                                                   const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+                                                   const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int onlyOutside)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1346,7 +1346,113 @@ __global__ __launch_bounds__(256) void k_warp_taps(const uchar* __restrict__ src
     uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
     int sx, sy, ax, ay;
     warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+    // onlyOutside: the second launch behind k_warp_taps_lds, which leaves the pixels whose taps are not all inside the image
+    if (onlyOutside && (unsigned)(sx - (KS / 2 - 1)) < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)(sy - (KS / 2 - 1)) < (unsigned)max(s.sh - (KS - 1), 0)) return;
     samplePixelN<KS>(src, sstep, D, s, sx, sy, ax, ay, tabI, tab1);
+}
+
+// ---- the same samplers with the per-pixel memory instructions cut down (round 4, profiles/r04_warp_taps.txt: k_warp_taps spends its time in the address
+// unit -- every per-lane load instruction of a 4K frame costs ~4 us whatever its width --, 6 of them per bicubic CV_8UC1 pixel, 24 per CV_32FC1 pixel):
+//   * the weights come from LDS: the per-axis float taps (32 x KS floats) and, for CV_8U, the whole Q15 table (32 KB bicubic, 128 KB Lanczos), copied in once by
+//     workgroups that then walk many tiles;
+//   * a tap row of a pixel inside the image is KS * CN contiguous elements: one to four 16-byte loads at element alignment, whatever the depth;
+//   * pixels whose taps leave the image are left to a second launch of k_warp_taps (which then returns at once for all the others): their border arithmetic inlined
+//     here cost every pixel its registers (166 instead of 67-100 VGPRs for the Lanczos forms).
+// Results are those of k_warp_taps bit for bit: same products, same order of sums.
+template <int N> __device__ __forceinline__ void loadRowDwords(uint32_t (&d)[N], const uchar* __restrict__ p)
+{
+    typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(1)));
+    typedef uint32_t u1u __attribute__((aligned(1)));
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) { const u4u v = *reinterpret_cast<const u4u*>(p + 4 * i); d[i] = v.x; d[i + 1] = v.y; d[i + 2] = v.z; d[i + 3] = v.w; }
+    if constexpr ((N & 3) >= 2) { const u2u v = *reinterpret_cast<const u2u*>(p + 4 * (N & ~3)); d[N & ~3] = v.x; d[(N & ~3) + 1] = v.y; }
+    if constexpr (N & 1) d[N - 1] = *reinterpret_cast<const u1u*>(p + 4 * (N - 1));
+}
+template <int DEPTH> __device__ __forceinline__ float tapElem(const uint32_t* d, int e)          // element e of a row held as dwords
+{
+    if constexpr (DEPTH == D32F) return __uint_as_float(d[e]);
+    else if constexpr (DEPTH == D16U) return (float)((d[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    else return (float)((int)(d[e >> 1] << (16 * (1 - (e & 1)))) >> 16);
+}
+
+template <int KS, int DEPTH, int CN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                         SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
+                                                         const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes)
+{
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    constexpr int ESZ = DEPTH == D8U ? 1 : DEPTH == D32F ? 4 : 2;
+    constexpr int NB = KS * CN * ESZ / 4;                             // dwords of a tap row
+    constexpr int ROWS = BLOCK / 64;                                  // tile: 64 x ROWS destination pixels, one per thread
+    extern __shared__ uint4 tapLds[];
+    float* l1 = reinterpret_cast<float*>(tapLds);                     // [32][KS] per-axis taps
+    uint4* l2 = tapLds + 32 * KS / 4;                                 // CV_8U: [1024][KS * KS / 8] Q15 weight pairs
+    for (int i = threadIdx.x; i < 32 * KS / 4; i += BLOCK) tapLds[i] = reinterpret_cast<const uint4*>(tab1)[i];
+    if constexpr (DEPTH == D8U)
+        for (int i = threadIdx.x; i < 1024 * KS * KS / 8; i += BLOCK) l2[i] = reinterpret_cast<const uint4*>(tabI)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int perFrame = tilesX * tilesY, total = perFrame * nframes;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int f = t / perFrame, tt = t - f * perFrame, ty = tt / tilesX, tx = tt - ty * tilesX;
+        const int x = tx * 64 + lane, y = ty * ROWS + wv;
+        if (x >= w.dw || y >= w.dh) continue;
+        const uchar* S = src + (size_t)f * w.sframe;
+        uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
+        int sx, sy, ax, ay;
+        warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+        const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
+        if (!((unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0))) continue;   // left to k_warp_taps(onlyOutside)
+        uint32_t px[KS][NB];
+        const uchar* p = S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ);
+#pragma unroll
+        for (int r = 0; r < KS; r++) loadRowDwords<NB>(px[r], p + (size_t)r * sstep);
+        if constexpr (DEPTH == D8U) {
+            uint32_t wt[KS * KS / 2];
+            const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
+#pragma unroll
+            for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                int sum = 1 << 14;
+#pragma unroll
+                for (int r = 0; r < KS; r++)
+#pragma unroll
+                    for (int j = 0; j < KS / 2; j++) {
+                        const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
+                        const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
+                        sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[r][d1], px[r][d0], sel)),
+                                                     __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
+                    }
+                const int v = sum >> 15;
+                out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
+            }
+            if constexpr (CN == 1) D[0] = (uchar)out;
+            else if constexpr (CN == 4) *reinterpret_cast<uint32_t*>(D) = out;
+            else { D[0] = (uchar)out; D[1] = (uchar)(out >> 8); D[2] = (uchar)(out >> 16); }
+        } else {
+            float wy[KS], wx[KS];
+#pragma unroll
+            for (int i = 0; i < KS; i += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(l1 + ay * KS + i), b = *reinterpret_cast<const float4*>(l1 + ax * KS + i);
+                wy[i] = a.x; wy[i + 1] = a.y; wy[i + 2] = a.z; wy[i + 3] = a.w; wx[i] = b.x; wx[i + 1] = b.y; wx[i + 2] = b.z; wx[i + 3] = b.w;
+            }
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < KS; r++) {
+                    float row = __fmul_rn(tapElem<DEPTH>(px[r], k), __fmul_rn(wy[r], wx[0]));
+#pragma unroll
+                    for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(tapElem<DEPTH>(px[r], c * CN + k), __fmul_rn(wy[r], wx[c])));
+                    sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
+                }
+                stRound(D, DEPTH, k, sum);
+            }
+        }
+    }
 }
 
 // cv::convertMaps, float -> fixed point (imgwarp.cpp:2017-2120): ix = cvRound(x * 32), dst1 = (ix >> 5, iy >> 5) saturated to short,
@@ -1953,9 +2059,38 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // bicubic / Lanczos: the per-pixel kernel over the shared coordinate generation
         const TapTabs* tt = deviceTapTabs();
         if (!tt) return mi355::declined(__func__, __LINE__, "the bicubic / Lanczos weight tables could not be placed on the device");
+        // the LDS form (MI355CV_WARP_TAPS_LDS=0 keeps the plain per-pixel kernel for A/B runs): 1-, 3- and 4-channel images whose rows can be read as unaligned dwords
+        static const bool tapsLds = [] { const char* v = getenv("MI355CV_WARP_TAPS_LDS"); return !v || atoi(v) != 0; }();
+        const bool lanc = interpolation == MI355CV_INTER_LANCZOS4;
+        if (tapsLds && (cn == 1 || cn == 3 || cn == 4) && sw >= (lanc ? 8 : 4) && sh >= (lanc ? 8 : 4)) {
+            const int ks = lanc ? 8 : 4;
+            const bool u8 = depth == D8U;
+            const int block = (u8 && lanc) ? 512 : 256, rows = block / 64;
+            const size_t lds = (size_t)32 * ks * 4 + (u8 ? (size_t)1024 * ks * ks * 2 : 0);
+            const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows);
+            const long long total = (long long)tilesX * tilesY * nframes;
+            const int perCU = u8 ? (lanc ? 1 : 4) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
+            const unsigned gridN = (unsigned)std::min<long long>(total, 256LL * perCU);
+            const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
+#define WTL(KS_, DEP_, CN_, BLK_) do { \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes); } while (0)
+#define WTC(KS_, DEP_, BLK_) do { if (cn == 1) WTL(KS_, DEP_, 1, BLK_); else if (cn == 3) WTL(KS_, DEP_, 3, BLK_); else WTL(KS_, DEP_, 4, BLK_); } while (0)
+#define WTD(KS_, BLK8_) do { if (depth == D8U) WTC(KS_, D8U, BLK8_); else if (depth == D16U) WTC(KS_, D16U, 256); else if (depth == D16S) WTC(KS_, D16S, 256); else WTC(KS_, D32F, 256); } while (0)
+            if (lanc) WTD(8, 512); else WTD(4, 256);
+#undef WTD
+#undef WTC
+#undef WTL
+            dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
+            if (lanc) hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1);
+            else      hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1);
+            noteKernel("k_warp_taps_lds<%d,depth %d,cn %d> grid=%u x%d lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps<%d>(pixels next to the border)", ks, depth, cn, gridN, block, lds,
+                       tilesX, tilesY, nframes, kind, ks);
+            return stg.finish(entry);
+        }
         dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
-        if (interpolation == MI355CV_INTER_CUBIC) hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubicI, tt->cubic1, dmx, mxs, dmy, mys);
-        else                                      hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->lanczosI, tt->lanczos1, dmx, mxs, dmy, mys);
+        if (interpolation == MI355CV_INTER_CUBIC) hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubicI, tt->cubic1, dmx, mxs, dmy, mys, 0);
+        else                                      hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->lanczosI, tt->lanczos1, dmx, mxs, dmy, mys, 0);
         noteKernel("k_warp_taps<%d> grid=%ux%ux%u x256 kind=%d", interpolation == MI355CV_INTER_CUBIC ? 4 : 8, grid.x, grid.y, grid.z, kind);
         return stg.finish(entry);
     }
