@@ -1185,6 +1185,16 @@ __device__ __forceinline__ void warpCoord(const SampleArgs& s, const WarpArgs& w
     else { sx = satShort(X) + rx; sy = satShort(Y) + ry; ax = ay = 0; }
 }
 
+// the same for the interpolating samplers with the affine terms of every destination column and row taken from a table built once per call (k_warp32_terms:
+// colX[dw], colY[dw], rowX[dh], rowY[dh], the rows with the rounding term 16 added): two adds and two shifts per pixel instead of ~30 double-precision instructions
+__device__ __forceinline__ void warpCoordT(const SampleArgs& s, const WarpArgs& w, const int* __restrict__ terms, int x, int y, const uchar* __restrict__ mapx, size_t mxstep,
+                                           const uchar* __restrict__ mapy, size_t mystep, int& sx, int& sy, int& ax, int& ay)
+{
+    if (!terms) { warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay); return; }
+    const int X = (terms[2 * w.dw + y] + terms[x]) >> 5, Y = (terms[2 * w.dw + w.dh + y] + terms[w.dw + x]) >> 5;
+    sx = satShort(X >> 5); sy = satShort(Y >> 5); ax = X & 31; ay = Y & 31;
+}
+
 __global__ __launch_bounds__(256) void k_warp(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                               SampleArgs s, WarpArgs w, const short* __restrict__ tab,
                                               const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
@@ -1337,7 +1347,8 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
 template <int KS>
 __global__ __launch_bounds__(256) void k_warp_taps(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                    SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
-                                                   const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int onlyOutside)
+                                                   const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int onlyOutside,
+                                                   const int* __restrict__ terms)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1345,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_warp_taps(const uchar* __restrict__ src
     src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
     uchar* D = dst + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth);
     int sx, sy, ax, ay;
-    warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+    warpCoordT(s, w, terms, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
     // onlyOutside: the second launch behind k_warp_taps_lds, which leaves the pixels whose taps are not all inside the image
     if (onlyOutside && (unsigned)(sx - (KS / 2 - 1)) < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)(sy - (KS / 2 - 1)) < (unsigned)max(s.sh - (KS - 1), 0)) return;
     samplePixelN<KS>(src, sstep, D, s, sx, sy, ax, ay, tabI, tab1);
@@ -1379,7 +1390,8 @@ template <int DEPTH> __device__ __forceinline__ float tapElem(const uint32_t* d,
 template <int KS, int DEPTH, int CN, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
-                                                         const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes)
+                                                         const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes,
+                                                         const int* __restrict__ terms)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     constexpr int ESZ = DEPTH == D8U ? 1 : DEPTH == D32F ? 4 : 2;
@@ -1401,7 +1413,7 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
         const uchar* S = src + (size_t)f * w.sframe;
         uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
         int sx, sy, ax, ay;
-        warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+        warpCoordT(s, w, terms, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
         const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
         if (!((unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0))) continue;   // left to k_warp_taps(onlyOutside)
         uint32_t px[KS][NB];
@@ -1426,7 +1438,10 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
                         sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[r][d1], px[r][d0], sel)),
                                                      __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
                     }
-                const int v = sum >> 15;
+                int v = sum >> 15;
+                // (kept opaque: left to itself the compiler folds shift + clamp + pack of two channels into v_ashr_pk_u8_i32, whose upper 16 result bits it then ORs
+                // the other channels into as if they were zero -- on the MI355X they are not: CV_8UC4 results came back with stray bits in byte 2, GPU call r04f)
+                asm volatile("" : "+v"(v));
                 out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
             }
             if constexpr (CN == 1) D[0] = (uchar)out;
@@ -2060,6 +2075,14 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         const TapTabs* tt = deviceTapTabs();
         if (!tt) return mi355::declined(__func__, __LINE__, "the bicubic / Lanczos weight tables could not be placed on the device");
         // the LDS form (MI355CV_WARP_TAPS_LDS=0 keeps the plain per-pixel kernel for A/B runs): 1-, 3- and 4-channel images whose rows can be read as unaligned dwords
+        // affine maps: the column / row terms once per call
+        int* terms = nullptr;
+        if (kind == 0) {
+            terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
+            uint32_t* work0 = (uint32_t*)stg.scratch(sizeof(uint32_t));
+            if (!terms || !work0) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
+            hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work0);
+        }
         static const bool tapsLds = [] { const char* v = getenv("MI355CV_WARP_TAPS_LDS"); return !v || atoi(v) != 0; }();
         const bool lanc = interpolation == MI355CV_INTER_LANCZOS4;
         if (tapsLds && (cn == 1 || cn == 3 || cn == 4) && sw >= (lanc ? 8 : 4) && sh >= (lanc ? 8 : 4)) {
@@ -2074,7 +2097,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
 #define WTL(KS_, DEP_, CN_, BLK_) do { \
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes); } while (0)
+                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, terms); } while (0)
 #define WTC(KS_, DEP_, BLK_) do { if (cn == 1) WTL(KS_, DEP_, 1, BLK_); else if (cn == 3) WTL(KS_, DEP_, 3, BLK_); else WTL(KS_, DEP_, 4, BLK_); } while (0)
 #define WTD(KS_, BLK8_) do { if (depth == D8U) WTC(KS_, D8U, BLK8_); else if (depth == D16U) WTC(KS_, D16U, 256); else if (depth == D16S) WTC(KS_, D16S, 256); else WTC(KS_, D32F, 256); } while (0)
             if (lanc) WTD(8, 512); else WTD(4, 256);
@@ -2082,15 +2105,15 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
 #undef WTC
 #undef WTL
             dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
-            if (lanc) hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1);
-            else      hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1);
+            if (lanc) hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
+            else      hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
             noteKernel("k_warp_taps_lds<%d,depth %d,cn %d> grid=%u x%d lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps<%d>(pixels next to the border)", ks, depth, cn, gridN, block, lds,
                        tilesX, tilesY, nframes, kind, ks);
             return stg.finish(entry);
         }
         dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
-        if (interpolation == MI355CV_INTER_CUBIC) hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubicI, tt->cubic1, dmx, mxs, dmy, mys, 0);
-        else                                      hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->lanczosI, tt->lanczos1, dmx, mxs, dmy, mys, 0);
+        if (interpolation == MI355CV_INTER_CUBIC) hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubicI, tt->cubic1, dmx, mxs, dmy, mys, 0, terms);
+        else                                      hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->lanczosI, tt->lanczos1, dmx, mxs, dmy, mys, 0, terms);
         noteKernel("k_warp_taps<%d> grid=%ux%ux%u x256 kind=%d", interpolation == MI355CV_INTER_CUBIC ? 4 : 8, grid.x, grid.y, grid.z, kind);
         return stg.finish(entry);
     }
