@@ -1387,7 +1387,7 @@ template <int DEPTH> __device__ __forceinline__ float tapElem(const uint32_t* d,
     else return (float)((int)(d[e >> 1] << (16 * (1 - (e & 1)))) >> 16);
 }
 
-template <int KS, int DEPTH, int CN, int BLOCK, bool AFF /* affine map: coordinates from the per-call term table, several pixels per thread */>
+template <int KS, int DEPTH, int CN, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
                                                          const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes,
@@ -1406,86 +1406,65 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int perFrame = tilesX * tilesY, total = perFrame * nframes;
-    // P pixels per thread and tile (rows wv, wv + ROWS, ...): their coordinates, then ALL their row loads, then the arithmetic -- with one pixel per thread a wave
-    // had one dependent chain of memory latencies per 64 pixels and the kernel ran at the latency of that chain (GPU call r04g: 53 us per 4K CV_8UC1 frame)
-    // (the other map forms -- perspective, remap -- keep one pixel per thread: their coordinate code inlined P times took every register the kernel had)
-    constexpr int P = !AFF ? 1 : KS * NB <= 10 ? 4 : KS * NB <= 20 ? 2 : 1;           // by the registers the tap rows of P pixels take (KS * NB dwords each)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int f = t / perFrame, tt = t - f * perFrame, ty = tt / tilesX, tx = tt - ty * tilesX;
-        const int x = tx * 64 + lane;
+        const int x = tx * 64 + lane, y = ty * ROWS + wv;
+        if (x >= w.dw || y >= w.dh) continue;
         const uchar* S = src + (size_t)f * w.sframe;
-        int axA[P], ayA[P]; bool ok[P];
-        uint32_t px[P][KS][NB];
+        uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
+        int sx, sy, ax, ay;
+        warpCoordT(s, w, terms, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+        const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
+        if (!((unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0))) continue;   // left to k_warp_taps(onlyOutside)
+        uint32_t px[KS][NB];
+        const uchar* p = S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ);
 #pragma unroll
-        for (int q = 0; q < P; q++) {
-            const int y = (ty * P + q) * ROWS + wv;
-            int sx = 0, sy = 0; axA[q] = 0; ayA[q] = 0;
-            const bool live = x < w.dw && y < w.dh;
-            if (live) {
-                if constexpr (AFF) {
-                    const int X = (terms[2 * w.dw + y] + terms[x]) >> 5, Y = (terms[2 * w.dw + w.dh + y] + terms[w.dw + x]) >> 5;
-                    sx = satShort(X >> 5); sy = satShort(Y >> 5); axA[q] = X & 31; ayA[q] = Y & 31;
-                } else warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, axA[q], ayA[q]);
-            }
-            const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
-            ok[q] = live && (unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0);   // the others: k_warp_taps(onlyOutside)
-            if (ok[q]) {
-                const uchar* p = S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ);
+        for (int r = 0; r < KS; r++) loadRowDwords<NB>(px[r], p + (size_t)r * sstep);
+        if constexpr (DEPTH == D8U) {
+            uint32_t wt[KS * KS / 2];
+            const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
 #pragma unroll
-                for (int r = 0; r < KS; r++) loadRowDwords<NB>(px[q][r], p + (size_t)r * sstep);
-            }
-        }
+            for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
+            uint32_t out = 0;
 #pragma unroll
-        for (int q = 0; q < P; q++) {
-            if (!ok[q]) continue;
-            const int y = (ty * P + q) * ROWS + wv, ax = axA[q], ay = ayA[q];
-            uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
-            if constexpr (DEPTH == D8U) {
-                uint32_t wt[KS * KS / 2];
-                const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
+            for (int k = 0; k < CN; k++) {
+                int sum = 1 << 14;
 #pragma unroll
-                for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
-                uint32_t out = 0;
+                for (int r = 0; r < KS; r++)
 #pragma unroll
-                for (int k = 0; k < CN; k++) {
-                    int sum = 1 << 14;
-#pragma unroll
-                    for (int r = 0; r < KS; r++)
-#pragma unroll
-                        for (int j = 0; j < KS / 2; j++) {
-                            const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
-                            const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
-                            sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[q][r][d1], px[q][r][d0], sel)),
-                                                         __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
-                        }
-                    int v = sum >> 15;
-                    // (kept opaque: left to itself the compiler folds shift + clamp + pack of two channels into v_ashr_pk_u8_i32, whose upper 16 result bits it then ORs
-                    // the other channels into as if they were zero -- on the MI355X they are not: CV_8UC4 results came back with stray bits in byte 2, GPU call r04f)
-                    asm volatile("" : "+v"(v));
-                    out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
-                }
-                if constexpr (CN == 1) D[0] = (uchar)out;
-                else if constexpr (CN == 4) *reinterpret_cast<uint32_t*>(D) = out;
-                else { D[0] = (uchar)out; D[1] = (uchar)(out >> 8); D[2] = (uchar)(out >> 16); }
-            } else {
-                float wy[KS], wx[KS];
-#pragma unroll
-                for (int i = 0; i < KS; i += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(l1 + ay * KS + i), b = *reinterpret_cast<const float4*>(l1 + ax * KS + i);
-                    wy[i] = a.x; wy[i + 1] = a.y; wy[i + 2] = a.z; wy[i + 3] = a.w; wx[i] = b.x; wx[i + 1] = b.y; wx[i + 2] = b.z; wx[i + 3] = b.w;
-                }
-#pragma unroll
-                for (int k = 0; k < CN; k++) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < KS; r++) {
-                        float row = __fmul_rn(tapElem<DEPTH>(px[q][r], k), __fmul_rn(wy[r], wx[0]));
-#pragma unroll
-                        for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(tapElem<DEPTH>(px[q][r], c * CN + k), __fmul_rn(wy[r], wx[c])));
-                        sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
+                    for (int j = 0; j < KS / 2; j++) {
+                        const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
+                        const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
+                        sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[r][d1], px[r][d0], sel)),
+                                                     __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
                     }
-                    stRound(D, DEPTH, k, sum);
+                int v = sum >> 15;
+                // (kept opaque: left to itself the compiler folds shift + clamp + pack of two channels into v_ashr_pk_u8_i32, whose upper 16 result bits it then ORs
+                // the other channels into as if they were zero -- on the MI355X they are not: CV_8UC4 results came back with stray bits in byte 2, GPU call r04f)
+                asm volatile("" : "+v"(v));
+                out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
+            }
+            if constexpr (CN == 1) D[0] = (uchar)out;
+            else if constexpr (CN == 4) *reinterpret_cast<uint32_t*>(D) = out;
+            else { D[0] = (uchar)out; D[1] = (uchar)(out >> 8); D[2] = (uchar)(out >> 16); }
+        } else {
+            float wy[KS], wx[KS];
+#pragma unroll
+            for (int i = 0; i < KS; i += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(l1 + ay * KS + i), b = *reinterpret_cast<const float4*>(l1 + ax * KS + i);
+                wy[i] = a.x; wy[i + 1] = a.y; wy[i + 2] = a.z; wy[i + 3] = a.w; wx[i] = b.x; wx[i + 1] = b.y; wx[i + 2] = b.z; wx[i + 3] = b.w;
+            }
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < KS; r++) {
+                    float row = __fmul_rn(tapElem<DEPTH>(px[r], k), __fmul_rn(wy[r], wx[0]));
+#pragma unroll
+                    for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(tapElem<DEPTH>(px[r], c * CN + k), __fmul_rn(wy[r], wx[c])));
+                    sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
                 }
+                stRound(D, DEPTH, k, sum);
             }
         }
     }
@@ -2111,23 +2090,20 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const bool u8 = depth == D8U;
             const int block = (u8 && lanc) ? 512 : 256, rows = block / 64;
             const size_t lds = (size_t)32 * ks * 4 + (u8 ? (size_t)1024 * ks * ks * 2 : 0);
-            const int esz = u8 ? 1 : depth == D32F ? 4 : 2, ksnb = ks * (ks * cn * esz / 4), ppt = !terms ? 1 : ksnb <= 10 ? 4 : ksnb <= 20 ? 2 : 1;   // pixels per thread: the kernel's P
-            const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows * ppt);
+            const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows);
             const long long total = (long long)tilesX * tilesY * nframes;
             const int perCU = u8 ? (lanc ? 1 : 4) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
             const unsigned gridN = (unsigned)std::min<long long>(total, 256LL * perCU);
             const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
-#define WTA(KS_, DEP_, CN_, BLK_, AFF_) do { \
-                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_, AFF_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_, AFF_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, terms); } while (0)
-#define WTL(KS_, DEP_, CN_, BLK_) do { if (terms) WTA(KS_, DEP_, CN_, BLK_, true); else WTA(KS_, DEP_, CN_, BLK_, false); } while (0)
+#define WTL(KS_, DEP_, CN_, BLK_) do { \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, terms); } while (0)
 #define WTC(KS_, DEP_, BLK_) do { if (cn == 1) WTL(KS_, DEP_, 1, BLK_); else if (cn == 3) WTL(KS_, DEP_, 3, BLK_); else WTL(KS_, DEP_, 4, BLK_); } while (0)
 #define WTD(KS_, BLK8_) do { if (depth == D8U) WTC(KS_, D8U, BLK8_); else if (depth == D16U) WTC(KS_, D16U, 256); else if (depth == D16S) WTC(KS_, D16S, 256); else WTC(KS_, D32F, 256); } while (0)
             if (lanc) WTD(8, 512); else WTD(4, 256);
 #undef WTD
 #undef WTC
 #undef WTL
-#undef WTA
             dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
             if (lanc) hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
             else      hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
