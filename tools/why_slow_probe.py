@@ -44,6 +44,9 @@ ROWS = {
     "filter2d_5x5":    lambda: cv.filter2DBatch(gray, -1, k5, dst=out1),
     "lab_8uc3":        lambda: [cv.cvtColor(bgr[i], cv.COLOR_BGR2Lab, dst=out3[i]) for i in range(4)],
     "median5":         lambda: [cv.medianBlur(gray[i], 5, dst=out1[i]) for i in range(8)],
+    "cubic_affine_8uc1": lambda: cv.warpAffineBatch(gray, cv.getRotationMatrix2D((W4 / 2.0, H4 / 2.0), 7.0, 0.95), (W4, H4), flags=2, dst=out1),
+    "lanczos_affine_8uc1": lambda: cv.warpAffineBatch(gray, cv.getRotationMatrix2D((W4 / 2.0, H4 / 2.0), 7.0, 0.95), (W4, H4), flags=4, dst=out1),
+    "cubic_affine_32f": lambda: cv.warpAffineBatch(f32[:4], cv.getRotationMatrix2D((W4 / 2.0, H4 / 2.0), 7.0, 0.95), (W4, H4), flags=2, dst=f32[4:]),
 }
 want = sys.argv[1:] or list(ROWS)
 for name in want:
