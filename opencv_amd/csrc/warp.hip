@@ -1387,16 +1387,16 @@ template <int DEPTH> __device__ __forceinline__ float tapElem(const uint32_t* d,
     else return (float)((int)(d[e >> 1] << (16 * (1 - (e & 1)))) >> 16);
 }
 
-template <int KS, int DEPTH, int CN, int BLOCK>
+template <int KS, int DEPTH, int CN, int BLOCK, int PP /* pixels per thread and tile; > 1 only with the affine term table */>
 __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
                                                          const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes,
-                                                         const int* __restrict__ terms)
+                                                         const int* __restrict__ terms, uint32_t* __restrict__ work, uint32_t workCap)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     constexpr int ESZ = DEPTH == D8U ? 1 : DEPTH == D32F ? 4 : 2;
     constexpr int NB = KS * CN * ESZ / 4;                             // dwords of a tap row
-    constexpr int ROWS = BLOCK / 64;                                  // tile: 64 x ROWS destination pixels, one per thread
+    constexpr int ROWS = BLOCK / 64;                                  // tile: 64 x (ROWS * PP) destination pixels, PP per thread (rows wv, wv + ROWS, ...)
     extern __shared__ uint4 tapLds[];
     float* l1 = reinterpret_cast<float*>(tapLds);                     // [32][KS] per-axis taps
     uint4* l2 = tapLds + 32 * KS / 4;                                 // CV_8U: [1024][KS * KS / 8] Q15 weight pairs
@@ -1408,65 +1408,117 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
     const int perFrame = tilesX * tilesY, total = perFrame * nframes;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int f = t / perFrame, tt = t - f * perFrame, ty = tt / tilesX, tx = tt - ty * tilesX;
-        const int x = tx * 64 + lane, y = ty * ROWS + wv;
-        if (x >= w.dw || y >= w.dh) continue;
+        const int x = tx * 64 + lane;
         const uchar* S = src + (size_t)f * w.sframe;
-        uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
-        int sx, sy, ax, ay;
-        warpCoordT(s, w, terms, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
-        const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
-        if (!((unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0))) continue;   // left to k_warp_taps(onlyOutside)
-        uint32_t px[KS][NB];
-        const uchar* p = S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ);
+        int axA[PP], ayA[PP]; bool ok[PP];
+        uint32_t px[PP][KS][NB];
+        // the coordinates of the thread's pixels, then ALL their row loads (unconditional: a pixel that is not served here reads the frame's first bytes), then the
+        // arithmetic: the loads of PP pixels are in flight together
 #pragma unroll
-        for (int r = 0; r < KS; r++) loadRowDwords<NB>(px[r], p + (size_t)r * sstep);
-        if constexpr (DEPTH == D8U) {
-            uint32_t wt[KS * KS / 2];
-            const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
-#pragma unroll
-            for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < CN; k++) {
-                int sum = 1 << 14;
-#pragma unroll
-                for (int r = 0; r < KS; r++)
-#pragma unroll
-                    for (int j = 0; j < KS / 2; j++) {
-                        const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
-                        const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
-                        sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[r][d1], px[r][d0], sel)),
-                                                     __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
-                    }
-                int v = sum >> 15;
-                // (kept opaque: left to itself the compiler folds shift + clamp + pack of two channels into v_ashr_pk_u8_i32, whose upper 16 result bits it then ORs
-                // the other channels into as if they were zero -- on the MI355X they are not: CV_8UC4 results came back with stray bits in byte 2, GPU call r04f)
-                asm volatile("" : "+v"(v));
-                out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
+        for (int q = 0; q < PP; q++) {
+            const int y = (ty * PP + q) * ROWS + wv;
+            const bool live = x < w.dw && y < w.dh;
+            int sx, sy;
+            if (PP > 1 || terms) {
+                const int xc = min(x, w.dw - 1), yc = min(y, w.dh - 1);
+                const int X = (terms[2 * w.dw + yc] + terms[xc]) >> 5, Y = (terms[2 * w.dw + w.dh + yc] + terms[w.dw + xc]) >> 5;
+                sx = satShort(X >> 5); sy = satShort(Y >> 5); axA[q] = X & 31; ayA[q] = Y & 31;
+            } else {
+                sx = sy = 0; axA[q] = ayA[q] = 0;
+                if (live) warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, axA[q], ayA[q]);
             }
-            if constexpr (CN == 1) D[0] = (uchar)out;
-            else if constexpr (CN == 4) *reinterpret_cast<uint32_t*>(D) = out;
-            else { D[0] = (uchar)out; D[1] = (uchar)(out >> 8); D[2] = (uchar)(out >> 16); }
-        } else {
-            float wy[KS], wx[KS];
-#pragma unroll
-            for (int i = 0; i < KS; i += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(l1 + ay * KS + i), b = *reinterpret_cast<const float4*>(l1 + ax * KS + i);
-                wy[i] = a.x; wy[i + 1] = a.y; wy[i + 2] = a.z; wy[i + 3] = a.w; wx[i] = b.x; wx[i + 1] = b.y; wx[i + 2] = b.z; wx[i + 3] = b.w;
+            const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
+            const bool inside = (unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0);
+            ok[q] = live && inside;
+            // a 64-pixel row strip with pixels whose taps leave the image goes on the list k_warp_taps_list works off (the strip's other pixels are skipped there)
+            if (__builtin_amdgcn_ballot_w64(live && !inside) != 0 && lane == 0) {
+                const uint32_t i = atomicAdd(work, 1u);
+                if (i < workCap) work[1 + i] = (uint32_t)((f * w.dh + y) * tilesX + tx);
             }
+            const uchar* p = ok[q] ? S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ) : S;
+            const size_t rs = ok[q] ? sstep : 0;
 #pragma unroll
-            for (int k = 0; k < CN; k++) {
-                float sum = 0.f;
+            for (int r = 0; r < KS; r++) loadRowDwords<NB>(px[q][r], p + (size_t)r * rs);
+        }
 #pragma unroll
-                for (int r = 0; r < KS; r++) {
-                    float row = __fmul_rn(tapElem<DEPTH>(px[r], k), __fmul_rn(wy[r], wx[0]));
+        for (int q = 0; q < PP; q++) {
+            if (!ok[q]) continue;
+            const int y = (ty * PP + q) * ROWS + wv, ax = axA[q], ay = ayA[q];
+            uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
+            if constexpr (DEPTH == D8U) {
+                uint32_t wt[KS * KS / 2];
+                const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
 #pragma unroll
-                    for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(tapElem<DEPTH>(px[r], c * CN + k), __fmul_rn(wy[r], wx[c])));
-                    sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
+                for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
+                uint32_t out = 0;
+#pragma unroll
+                for (int k = 0; k < CN; k++) {
+                    int sum = 1 << 14;
+#pragma unroll
+                    for (int r = 0; r < KS; r++)
+#pragma unroll
+                        for (int j = 0; j < KS / 2; j++) {
+                            const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
+                            const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
+                            sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, __builtin_amdgcn_perm(px[q][r][d1], px[q][r][d0], sel)),
+                                                         __builtin_bit_cast(s16x2, wt[r * (KS / 2) + j]), sum, false);
+                        }
+                    int v = sum >> 15;
+                    // (kept opaque: left to itself the compiler folds shift + clamp + pack of two channels into v_ashr_pk_u8_i32, whose upper 16 result bits it then ORs
+                    // the other channels into as if they were zero -- on the MI355X they are not: CV_8UC4 results came back with stray bits in byte 2, GPU call r04f)
+                    asm volatile("" : "+v"(v));
+                    out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
                 }
-                stRound(D, DEPTH, k, sum);
+                if constexpr (CN == 1) D[0] = (uchar)out;
+                else if constexpr (CN == 4) *reinterpret_cast<uint32_t*>(D) = out;
+                else { D[0] = (uchar)out; D[1] = (uchar)(out >> 8); D[2] = (uchar)(out >> 16); }
+            } else {
+                float wy[KS], wx[KS];
+#pragma unroll
+                for (int i = 0; i < KS; i += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(l1 + ay * KS + i), b = *reinterpret_cast<const float4*>(l1 + ax * KS + i);
+                    wy[i] = a.x; wy[i + 1] = a.y; wy[i + 2] = a.z; wy[i + 3] = a.w; wx[i] = b.x; wx[i + 1] = b.y; wx[i + 2] = b.z; wx[i + 3] = b.w;
+                }
+#pragma unroll
+                for (int k = 0; k < CN; k++) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < KS; r++) {
+                        float row = __fmul_rn(tapElem<DEPTH>(px[q][r], k), __fmul_rn(wy[r], wx[0]));
+#pragma unroll
+                        for (int c = 1; c < KS; c++) row = __fadd_rn(row, __fmul_rn(tapElem<DEPTH>(px[q][r], c * CN + k), __fmul_rn(wy[r], wx[c])));
+                        sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
+                    }
+                    stRound(D, DEPTH, k, sum);
+                }
             }
         }
+    }
+}
+
+// the row strips k_warp_taps_lds listed (work[0] = how many, then their ids), one wave per strip and turn, the pixels with all taps inside skipped; if the list
+// overflowed its capacity, every strip of the call is visited instead.  (A launch of one thread per pixel that returns at once for the served ones cost 13 us per
+// 4K frame in workgroup dispatch alone, a quarter of the bicubic warp: profiles/r04_why_slow_taps.txt.)
+template <int KS>
+__global__ __launch_bounds__(256) void k_warp_taps_list(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                        SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
+                                                        const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int nframes,
+                                                        const int* __restrict__ terms, const uint32_t* __restrict__ work, uint32_t workCap)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t listed = work[0], allStrips = (uint32_t)tilesX * (uint32_t)w.dh * (uint32_t)nframes;
+    const bool overflow = listed > workCap;
+    const uint32_t n = overflow ? allStrips : listed;
+    const uint32_t nwaves = gridDim.x * 4;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += nwaves) {
+        const uint32_t sid = overflow ? i : work[1 + i];
+        const int tx = (int)(sid % (uint32_t)tilesX), r = (int)(sid / (uint32_t)tilesX), y = r % w.dh, f = r / w.dh;
+        const int x = tx * 64 + lane;
+        if (x >= w.dw) continue;
+        int sx, sy, ax, ay;
+        warpCoordT(s, w, terms, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+        if ((unsigned)(sx - (KS / 2 - 1)) < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)(sy - (KS / 2 - 1)) < (unsigned)max(s.sh - (KS - 1), 0)) continue;
+        samplePixelN<KS>(src + (size_t)f * w.sframe, sstep, dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * s.cn * eszOf(s.depth), s, sx, sy, ax, ay, tabI, tab1);
     }
 }
 
@@ -2084,31 +2136,48 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work0);
         }
         static const bool tapsLds = [] { const char* v = getenv("MI355CV_WARP_TAPS_LDS"); return !v || atoi(v) != 0; }();
+        static const int tapsP = [] { const char* v = getenv("MI355CV_WARP_TAPS_P"); return v ? atoi(v) : 0; }();          // 1: one pixel per thread everywhere (A/B runs)
         const bool lanc = interpolation == MI355CV_INTER_LANCZOS4;
         if (tapsLds && (cn == 1 || cn == 3 || cn == 4) && sw >= (lanc ? 8 : 4) && sh >= (lanc ? 8 : 4)) {
             const int ks = lanc ? 8 : 4;
             const bool u8 = depth == D8U;
             const int block = (u8 && lanc) ? 512 : 256, rows = block / 64;
             const size_t lds = (size_t)32 * ks * 4 + (u8 ? (size_t)1024 * ks * ks * 2 : 0);
-            const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows);
+            // pixels per thread (affine maps only: their coordinates are two table reads): by the registers the tap rows take -- 4 where a pixel's rows are <= 10 dwords
+            // (bicubic CV_8UC1), 2 up to 20 (bicubic CV_8UC3 / CV_8UC4 / CV_32FC1, Lanczos CV_8UC1)
+            const int esz = u8 ? 1 : depth == D32F ? 4 : 2, ksnb = ks * (ks * cn * esz / 4);
+            const int ppt = (!terms || tapsP == 1 || (depth != D8U && depth != D32F)) ? 1 : ksnb <= 10 ? 4 : ksnb <= 20 ? 2 : 1;
+            const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows * ppt);
             const long long total = (long long)tilesX * tilesY * nframes;
             const int perCU = u8 ? (lanc ? 1 : 4) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
             const unsigned gridN = (unsigned)std::min<long long>(total, 256LL * perCU);
             const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
-#define WTL(KS_, DEP_, CN_, BLK_) do { \
-                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, terms); } while (0)
-#define WTC(KS_, DEP_, BLK_) do { if (cn == 1) WTL(KS_, DEP_, 1, BLK_); else if (cn == 3) WTL(KS_, DEP_, 3, BLK_); else WTL(KS_, DEP_, 4, BLK_); } while (0)
-#define WTD(KS_, BLK8_) do { if (depth == D8U) WTC(KS_, D8U, BLK8_); else if (depth == D16U) WTC(KS_, D16U, 256); else if (depth == D16S) WTC(KS_, D16S, 256); else WTC(KS_, D32F, 256); } while (0)
-            if (lanc) WTD(8, 512); else WTD(4, 256);
-#undef WTD
-#undef WTC
-#undef WTL
-            dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
-            if (lanc) hipLaunchKernelGGL(k_warp_taps<8>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
-            else      hipLaunchKernelGGL(k_warp_taps<4>, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, 1, terms);
-            noteKernel("k_warp_taps_lds<%d,depth %d,cn %d> grid=%u x%d lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps<%d>(pixels next to the border)", ks, depth, cn, gridN, block, lds,
-                       tilesX, tilesY, nframes, kind, ks);
+            // the list of row strips with pixels next to the border: [0] = count, then ids; beyond its capacity the second kernel visits every strip
+            const long long strips = (long long)tilesX * dh * nframes;
+            if (strips >= (1LL << 32)) return mi355::declined(__func__, __LINE__, "more than 2^32 row strips in one call");
+            const uint32_t workCap = (uint32_t)std::min<long long>(strips, 1 << 20);
+            uint32_t* work = (uint32_t*)stg.scratch(((size_t)workCap + 1) * sizeof(uint32_t));
+            if (!work || hipMemsetAsync(work, 0, sizeof(uint32_t), stream()) != hipSuccess) return mi355::declined(__func__, __LINE__, "scratch for the border-strip list");
+#define WTA(KS_, DEP_, CN_, BLK_, PP_) do { \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_, PP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_, PP_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, \
+                                   terms, work, workCap); } while (0)
+#define WT1(KS_, DEP_, BLK_) do { if (cn == 1) WTA(KS_, DEP_, 1, BLK_, 1); else if (cn == 3) WTA(KS_, DEP_, 3, BLK_, 1); else WTA(KS_, DEP_, 4, BLK_, 1); } while (0)
+            if (ppt == 4)      WTA(4, D8U, 1, 256, 4);                                                                  // bicubic CV_8UC1
+            else if (ppt == 2) {
+                if (lanc) WTA(8, D8U, 1, 512, 2);                                                                       // Lanczos CV_8UC1
+                else if (u8) { if (cn == 3) WTA(4, D8U, 3, 256, 2); else WTA(4, D8U, 4, 256, 2); }                      // bicubic CV_8UC3 / CV_8UC4
+                else WTA(4, D32F, 1, 256, 2);                                                                           // bicubic CV_32FC1
+            }
+            else if (lanc) { if (u8) WT1(8, D8U, 512); else if (depth == D16U) WT1(8, D16U, 256); else if (depth == D16S) WT1(8, D16S, 256); else WT1(8, D32F, 256); }
+            else           { if (u8) WT1(4, D8U, 256); else if (depth == D16U) WT1(4, D16U, 256); else if (depth == D16S) WT1(4, D16S, 256); else WT1(4, D32F, 256); }
+#undef WT1
+#undef WTA
+            const unsigned gridL = (unsigned)std::min<long long>((strips + 3) / 4, 2048);
+            if (lanc) hipLaunchKernelGGL(k_warp_taps_list<8>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, work, workCap);
+            else      hipLaunchKernelGGL(k_warp_taps_list<4>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, work, workCap);
+            noteKernel("k_warp_taps_lds<%d,depth %d,cn %d,block %d,%d px per thread> grid=%u lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps_list<%d> grid=%u (row strips next to the border)",
+                       ks, depth, cn, block, ppt, gridN, lds, tilesX, tilesY, nframes, kind, ks, gridL);
             return stg.finish(entry);
         }
         dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
