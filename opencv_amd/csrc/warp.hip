@@ -1391,7 +1391,7 @@ template <int KS, int DEPTH, int CN, int BLOCK, int PP /* pixels per thread and 
 __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
                                                          const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int tilesY, int nframes,
-                                                         const int* __restrict__ terms, uint32_t* __restrict__ work, uint32_t workCap)
+                                                         const int* __restrict__ terms, uchar* __restrict__ stripFlag)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     constexpr int ESZ = DEPTH == D8U ? 1 : DEPTH == D32F ? 4 : 2;
@@ -1430,11 +1430,8 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
             const int fx = sx - (KS / 2 - 1), fy = sy - (KS / 2 - 1);
             const bool inside = (unsigned)fx < (unsigned)max(s.sw - (KS - 1), 0) && (unsigned)fy < (unsigned)max(s.sh - (KS - 1), 0);
             ok[q] = live && inside;
-            // a 64-pixel row strip with pixels whose taps leave the image goes on the list k_warp_taps_list works off (the strip's other pixels are skipped there)
-            if (__builtin_amdgcn_ballot_w64(live && !inside) != 0 && lane == 0) {
-                const uint32_t i = atomicAdd(work, 1u);
-                if (i < workCap) work[1 + i] = (uint32_t)((f * w.dh + y) * tilesX + tx);
-            }
+            // a 64-pixel row strip with pixels whose taps leave the image is flagged for k_warp_taps_strips (which skips the strip's other pixels)
+            if (__builtin_amdgcn_ballot_w64(live && !inside) != 0 && lane == 0) stripFlag[((size_t)f * w.dh + y) * tilesX + tx] = 1;
             const uchar* p = ok[q] ? S + (size_t)fy * sstep + (size_t)fx * (CN * ESZ) : S;
             const size_t rs = ok[q] ? sstep : 0;
 #pragma unroll
@@ -1496,23 +1493,24 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
     }
 }
 
-// the row strips k_warp_taps_lds listed (work[0] = how many, then their ids), one wave per strip and turn, the pixels with all taps inside skipped; if the list
-// overflowed its capacity, every strip of the call is visited instead.  (A launch of one thread per pixel that returns at once for the served ones cost 13 us per
-// 4K frame in workgroup dispatch alone, a quarter of the bicubic warp: profiles/r04_why_slow_taps.txt.)
+// the row strips k_warp_taps_lds flagged: a workgroup looks at 16 consecutive strips (four per wave), a flagged strip's pixels with all taps inside are skipped.
+// (A launch of one thread per pixel that returns at once for the served ones cost 13 us per 4K frame in workgroup dispatch alone, a quarter of the bicubic warp; a
+// list of strips worked off by a fixed grid serialised the slow sampler in too few waves -- 200 us: profiles/r04_warp_taps.txt.)
 template <int KS>
-__global__ __launch_bounds__(256) void k_warp_taps_list(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-                                                        SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
-                                                        const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int nframes,
-                                                        const int* __restrict__ terms, const uint32_t* __restrict__ work, uint32_t workCap)
+__global__ __launch_bounds__(256) void k_warp_taps_strips(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+                                                          SampleArgs s, WarpArgs w, const short* __restrict__ tabI, const float* __restrict__ tab1,
+                                                          const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep, int tilesX, int nframes,
+                                                          const int* __restrict__ terms, const uchar* __restrict__ stripFlag)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t listed = work[0], allStrips = (uint32_t)tilesX * (uint32_t)w.dh * (uint32_t)nframes;
-    const bool overflow = listed > workCap;
-    const uint32_t n = overflow ? allStrips : listed;
-    const uint32_t nwaves = gridDim.x * 4;
-    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += nwaves) {
-        const uint32_t sid = overflow ? i : work[1 + i];
-        const int tx = (int)(sid % (uint32_t)tilesX), r = (int)(sid / (uint32_t)tilesX), y = r % w.dh, f = r / w.dh;
+    const size_t strips = (size_t)tilesX * w.dh * nframes;
+    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+        const size_t sid = base + j;
+        if (sid >= strips) return;
+        if (!__builtin_amdgcn_readfirstlane((int)stripFlag[sid])) continue;
+        const int tx = (int)(sid % (size_t)tilesX); const size_t r = sid / (size_t)tilesX; const int y = (int)(r % (size_t)w.dh), f = (int)(r / (size_t)w.dh);
         const int x = tx * 64 + lane;
         if (x >= w.dw) continue;
         int sx, sy, ax, ay;
@@ -2152,16 +2150,14 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const int perCU = u8 ? (lanc ? 1 : 4) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
             const unsigned gridN = (unsigned)std::min<long long>(total, 256LL * perCU);
             const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
-            // the list of row strips with pixels next to the border: [0] = count, then ids; beyond its capacity the second kernel visits every strip
-            const long long strips = (long long)tilesX * dh * nframes;
-            if (strips >= (1LL << 32)) return mi355::declined(__func__, __LINE__, "more than 2^32 row strips in one call");
-            const uint32_t workCap = (uint32_t)std::min<long long>(strips, 1 << 20);
-            uint32_t* work = (uint32_t*)stg.scratch(((size_t)workCap + 1) * sizeof(uint32_t));
-            if (!work || hipMemsetAsync(work, 0, sizeof(uint32_t), stream()) != hipSuccess) return mi355::declined(__func__, __LINE__, "scratch for the border-strip list");
+            // one flag byte per 64-pixel row strip: set by the LDS kernel where pixels next to the border were left out
+            const size_t strips = (size_t)tilesX * dh * nframes;
+            uchar* stripFlag = (uchar*)stg.scratch(strips);
+            if (!stripFlag || hipMemsetAsync(stripFlag, 0, strips, stream()) != hipSuccess) return mi355::declined(__func__, __LINE__, "scratch for the border-strip flags");
 #define WTA(KS_, DEP_, CN_, BLK_, PP_) do { \
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp_taps_lds<KS_, DEP_, CN_, BLK_, PP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 hipLaunchKernelGGL((k_warp_taps_lds<KS_, DEP_, CN_, BLK_, PP_>), dim3(gridN), dim3(BLK_), lds, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, tilesY, nframes, \
-                                   terms, work, workCap); } while (0)
+                                   terms, stripFlag); } while (0)
 #define WT1(KS_, DEP_, BLK_) do { if (cn == 1) WTA(KS_, DEP_, 1, BLK_, 1); else if (cn == 3) WTA(KS_, DEP_, 3, BLK_, 1); else WTA(KS_, DEP_, 4, BLK_, 1); } while (0)
             if (ppt == 4)      WTA(4, D8U, 1, 256, 4);                                                                  // bicubic CV_8UC1
             else if (ppt == 2) {
@@ -2173,10 +2169,10 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             else           { if (u8) WT1(4, D8U, 256); else if (depth == D16U) WT1(4, D16U, 256); else if (depth == D16S) WT1(4, D16S, 256); else WT1(4, D32F, 256); }
 #undef WT1
 #undef WTA
-            const unsigned gridL = (unsigned)std::min<long long>((strips + 3) / 4, 2048);
-            if (lanc) hipLaunchKernelGGL(k_warp_taps_list<8>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, work, workCap);
-            else      hipLaunchKernelGGL(k_warp_taps_list<4>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, work, workCap);
-            noteKernel("k_warp_taps_lds<%d,depth %d,cn %d,block %d,%d px per thread> grid=%u lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps_list<%d> grid=%u (row strips next to the border)",
+            const unsigned gridL = (unsigned)((strips + 15) / 16);
+            if (lanc) hipLaunchKernelGGL(k_warp_taps_strips<8>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, stripFlag);
+            else      hipLaunchKernelGGL(k_warp_taps_strips<4>, dim3(gridL), dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tI, t1, dmx, mxs, dmy, mys, tilesX, nframes, terms, stripFlag);
+            noteKernel("k_warp_taps_lds<%d,depth %d,cn %d,block %d,%d px per thread> grid=%u lds=%zu tiles=%dx%dx%d kind=%d + k_warp_taps_strips<%d> grid=%u (row strips next to the border)",
                        ks, depth, cn, block, ppt, gridN, lds, tilesX, tilesY, nframes, kind, ks, gridL);
             return stg.finish(entry);
         }
