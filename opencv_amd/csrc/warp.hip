@@ -1401,8 +1401,11 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
     float* l1 = reinterpret_cast<float*>(tapLds);                     // [32][KS] per-axis taps
     uint4* l2 = tapLds + 32 * KS / 4;                                 // CV_8U: [1024][KS * KS / 8] Q15 weight pairs
     for (int i = threadIdx.x; i < 32 * KS / 4; i += BLOCK) tapLds[i] = reinterpret_cast<const uint4*>(tab1)[i];
+    // a table entry is KS * KS / 8 uint4s; entries are ESTR uint4s apart (48 / 144 bytes): with the natural 32 / 128 bytes the 64 lanes' ds_read_b128s fell on 8 / 2
+    // bank groups (SQ_LDS_BANK_CONFLICT 67 % / 88 % of the LDS cycles, profiles/r04_why_slow_taps.txt)
+    constexpr int EU = KS * KS / 8, ESTR = EU + 1;
     if constexpr (DEPTH == D8U)
-        for (int i = threadIdx.x; i < 1024 * KS * KS / 8; i += BLOCK) l2[i] = reinterpret_cast<const uint4*>(tabI)[i];
+        for (int i = threadIdx.x; i < 1024 * EU; i += BLOCK) l2[(i / EU) * ESTR + (i % EU)] = reinterpret_cast<const uint4*>(tabI)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int perFrame = tilesX * tilesY, total = perFrame * nframes;
@@ -1444,7 +1447,7 @@ __global__ __launch_bounds__(BLOCK) void k_warp_taps_lds(const uchar* __restrict
             uchar* D = dst + (size_t)f * w.dframe + (size_t)y * dstep + (size_t)x * (CN * ESZ);
             if constexpr (DEPTH == D8U) {
                 uint32_t wt[KS * KS / 2];
-                const uint4* wq = l2 + (ay * 32 + ax) * (KS * KS / 8);
+                const uint4* wq = l2 + (ay * 32 + ax) * ESTR;
 #pragma unroll
                 for (int i = 0; i < KS * KS / 8; i++) { const uint4 v = wq[i]; wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w; }
                 uint32_t out = 0;
@@ -2140,14 +2143,14 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const int ks = lanc ? 8 : 4;
             const bool u8 = depth == D8U;
             const int block = (u8 && lanc) ? 512 : 256, rows = block / 64;
-            const size_t lds = (size_t)32 * ks * 4 + (u8 ? (size_t)1024 * ks * ks * 2 : 0);
+            const size_t lds = (size_t)32 * ks * 4 + (u8 ? (size_t)1024 * (ks * ks * 2 + 16) : 0);      // the Q15 entries padded by 16 bytes (bank spread)
             // pixels per thread (affine maps only: their coordinates are two table reads): by the registers the tap rows take -- 4 where a pixel's rows are <= 10 dwords
             // (bicubic CV_8UC1), 2 up to 20 (bicubic CV_8UC3 / CV_8UC4 / CV_32FC1, Lanczos CV_8UC1)
             const int esz = u8 ? 1 : depth == D32F ? 4 : 2, ksnb = ks * (ks * cn * esz / 4);
             const int ppt = (!terms || tapsP == 1 || (depth != D8U && depth != D32F)) ? 1 : ksnb <= 10 ? 4 : ksnb <= 20 ? 2 : 1;
             const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows * ppt);
             const long long total = (long long)tilesX * tilesY * nframes;
-            const int perCU = u8 ? (lanc ? 1 : 4) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
+            const int perCU = u8 ? (lanc ? 1 : 3) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
             const unsigned gridN = (unsigned)std::min<long long>(total, 256LL * perCU);
             const short* tI = lanc ? tt->lanczosI : tt->cubicI; const float* t1 = lanc ? tt->lanczos1 : tt->cubic1;
             // one flag byte per 64-pixel row strip: set by the LDS kernel where pixels next to the border were left out
