@@ -295,6 +295,7 @@ def compact_summary(rows):
     short = {"a1 GaussianBlur 5x5 4K 8UC3 batch": "gauss_8uc3", "a1 GaussianBlur 5x5 1080p 8UC1 batch": "gauss_1080p", "a1 GaussianBlur 5x5 8K 8UC1 batch": "gauss_8k",
              "a8 warpAffine 4K 8UC1": "affine_8uc1", "a8 warpAffine 4K 8UC3": "affine_8uc3", "a9 warpPerspective 4K 8UC1": "persp_8uc1", "a9 warpPerspective 4K 8UC3": "persp_8uc3",
              "f1 integral 4K 8U -> 32S batch": "integral", "a7 resize 1080p 8UC3 -> 4K bilinear": "up2x_lin_8uc3", "a7 resize 1080p 8UC3 -> 4K INTER_CUBIC": "up2x_cubic_8uc3",
+             "f2 warpAffine 4K 8UC1 rot 7deg INTER_CUBIC": "affine_cubic_8uc1", "f2 warpAffine 4K 8UC1 rot 7deg INTER_LANCZOS4": "affine_lanczos_8uc1",
              "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
     for r in rows if isinstance(rows, list) else []:
         c = r.get("config", "")
