@@ -952,7 +952,7 @@ const TapTabs* deviceTapTabs()
     return g_tapDevs[dev];
 }
 
-struct SampleArgs { int sw, sh, depth, cn, linear, border; float cval[4]; };
+struct SampleArgs { int sw, sh, depth, cn, linear, border; float cval[4]; double cvalD[4]; /* CV_64F images: saturate_cast<double>(borderValue) */ };
 
 __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
                             const short* __restrict__ tab)
@@ -1523,6 +1523,106 @@ __global__ __launch_bounds__(256) void k_warp_taps_strips(const uchar* __restric
     }
 }
 
+// ---- CV_64F images in warpAffine / warpPerspective / remap (remapNearest<double>, remapBilinear<Cast<double, double>, RemapNoVec, float>, remapBicubic / remapLanczos4
+// <Cast<double, double>, float, 1>: imgwarp.cpp:1736-1790): the weights are the float tables, the products and sums double, in the reference's order; one thread per pixel.
+__device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, double* D, const SampleArgs& a, int sx, int sy, int ax, int ay,
+                              const float* __restrict__ tabC, const float* __restrict__ tabL)
+{
+    const int cn = a.cn, mode = a.linear;
+    auto S = [&](int y, int x, int k) { return reinterpret_cast<const double*>(src + (size_t)y * sstep)[x * cn + k]; };
+    if (mode == 0) {
+        if (!((unsigned)sx < (unsigned)a.sw && (unsigned)sy < (unsigned)a.sh)) {
+            if (a.border == B_REPLICATE) { sx = clipI(sx, 0, a.sw); sy = clipI(sy, 0, a.sh); }
+            else if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+            else if (a.border == B_TRANSPARENT) return;
+            else { sx = mi355_borderInterpolate(sx, a.sw, a.border); sy = mi355_borderInterpolate(sy, a.sh, a.border); }
+        }
+        for (int k = 0; k < cn; k++) D[k] = S(sy, sx, k);
+        return;
+    }
+    if (mode == 1) {
+        const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32;
+        const float w[4] = {__fmul_rn(1.f - fy, 1.f - fx), __fmul_rn(1.f - fy, fx), __fmul_rn(fy, 1.f - fx), __fmul_rn(fy, fx)};
+        if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+        int x0, x1, y0, y1;
+        if ((unsigned)sx < (unsigned)(a.sw - 1) && (unsigned)sy < (unsigned)(a.sh - 1)) { x0 = sx; x1 = sx + 1; y0 = sy; y1 = sy + 1; }
+        else if (a.border == B_TRANSPARENT) {
+            if (!(sx >= 0 && sx <= a.sw - 1 && sy >= 0 && sy <= a.sh - 1)) return;
+            const bool has1 = sx < a.sw - 1, has2 = sy < a.sh - 1, has3 = has1 && has2;
+            double wTot = 0; wTot = __dadd_rn(wTot, (double)w[0]);
+            if (has1) wTot = __dadd_rn(wTot, (double)w[1]);
+            if (has2) wTot = __dadd_rn(wTot, (double)w[2]);
+            if (has3) wTot = __dadd_rn(wTot, (double)w[3]);
+            if (wTot == 0.0) return;
+            const double wIni = __dadd_rn(__dadd_rn(__dadd_rn((double)w[0], (double)w[1]), (double)w[2]), (double)w[3]);
+            for (int k = 0; k < cn; k++) {
+                double t0 = 0; t0 = __dadd_rn(t0, __dmul_rn(S(sy, sx, k), (double)w[0]));
+                if (has1) t0 = __dadd_rn(t0, __dmul_rn(S(sy, sx + 1, k), (double)w[1]));
+                if (has2) t0 = __dadd_rn(t0, __dmul_rn(S(sy + 1, sx, k), (double)w[2]));
+                if (has3) t0 = __dadd_rn(t0, __dmul_rn(S(sy + 1, sx + 1, k), (double)w[3]));
+                D[k] = __ddiv_rn(__dmul_rn(t0, (double)(float)wIni), wTot);
+            }
+            return;
+        }
+        else if (a.border == B_REPLICATE) { x0 = clipI(sx, 0, a.sw); x1 = clipI(sx + 1, 0, a.sw); y0 = clipI(sy, 0, a.sh); y1 = clipI(sy + 1, 0, a.sh); }
+        else { x0 = mi355_borderInterpolate(sx, a.sw, a.border); x1 = mi355_borderInterpolate(sx + 1, a.sw, a.border);
+               y0 = mi355_borderInterpolate(sy, a.sh, a.border); y1 = mi355_borderInterpolate(sy + 1, a.sh, a.border); }
+        for (int k = 0; k < cn; k++) {
+            const double cv = a.cvalD[k];
+            const double v0 = (x0 >= 0 && y0 >= 0) ? S(y0, x0, k) : cv, v1 = (x1 >= 0 && y0 >= 0) ? S(y0, x1, k) : cv;
+            const double v2 = (x0 >= 0 && y1 >= 0) ? S(y1, x0, k) : cv, v3 = (x1 >= 0 && y1 >= 0) ? S(y1, x1, k) : cv;
+            double t = __dadd_rn(__dmul_rn(v0, (double)w[0]), __dmul_rn(v1, (double)w[1]));
+            t = __dadd_rn(t, __dmul_rn(v2, (double)w[2]));
+            D[k] = __dadd_rn(t, __dmul_rn(v3, (double)w[3]));
+        }
+        return;
+    }
+    const int KS = mode == 4 ? 8 : 4, OFF = KS / 2 - 1;
+    const float* __restrict__ t1 = mode == 4 ? tabL : tabC;
+    sx -= OFF; sy -= OFF;
+    const bool inside = (unsigned)sx < (unsigned)max(a.sw - (KS - 1), 0) && (unsigned)sy < (unsigned)max(a.sh - (KS - 1), 0);
+    int xi[8], yi[8];
+    if (!inside) {
+        if (a.border == B_TRANSPARENT && ((unsigned)(sx + OFF) >= (unsigned)a.sw || (unsigned)(sy + OFF) >= (unsigned)a.sh)) return;
+        const int b1 = a.border != B_TRANSPARENT ? a.border : B_REFLECT_101;
+        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+        for (int i = 0; i < KS; i++) { xi[i] = mi355_borderInterpolate(sx + i, a.sw, b1); yi[i] = mi355_borderInterpolate(sy + i, a.sh, b1); }
+    }
+    for (int k = 0; k < cn; k++) {
+        double sum;
+        if (inside) {
+            sum = 0;
+            for (int r = 0; r < KS; r++) {
+                double row = __dmul_rn(S(sy + r, sx, k), (double)__fmul_rn(t1[ay * KS + r], t1[ax * KS]));
+                for (int c = 1; c < KS; c++) row = __dadd_rn(row, __dmul_rn(S(sy + r, sx + c, k), (double)__fmul_rn(t1[ay * KS + r], t1[ax * KS + c])));
+                sum = (r == 0 && KS == 4) ? row : __dadd_rn(sum, row);
+            }
+        } else {
+            const double cv = a.cvalD[k];
+            sum = cv;
+            for (int r = 0; r < KS; r++) {
+                if (yi[r] < 0) continue;
+                for (int c = 0; c < KS; c++)
+                    if (xi[c] >= 0) sum = __dadd_rn(sum, __dmul_rn(__dsub_rn(S(yi[r], xi[c], k), cv), (double)__fmul_rn(t1[ay * KS + r], t1[ax * KS + c])));
+            }
+        }
+        D[k] = sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_warp64(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, SampleArgs s, WarpArgs w,
+                                                const float* __restrict__ tabC, const float* __restrict__ tabL,
+                                                const uchar* __restrict__ mapx, size_t mxstep, const uchar* __restrict__ mapy, size_t mystep)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w.dw || y >= w.dh) return;
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    int sx, sy, ax, ay;
+    warpCoord(s, w, x, y, mapx, mxstep, mapy, mystep, sx, sy, ax, ay);
+    samplePixel64(src, sstep, reinterpret_cast<double*>(dst + (size_t)y * dstep) + (size_t)x * s.cn, s, sx, sy, ax, ay, tabC, tabL);
+}
+
 // cv::convertMaps, float -> fixed point (imgwarp.cpp:2017-2120): ix = cvRound(x * 32), dst1 = (ix >> 5, iy >> 5) saturated to short,
 // dst2 = (iy & 31) * 32 + (ix & 31); with nninterpolate dst1 = the rounded coordinates and there is no dst2
 __global__ __launch_bounds__(256) void k_convert_maps_to_fixed(const uchar* __restrict__ m1, size_t m1step, const uchar* __restrict__ m2, size_t m2step, int interleaved,
@@ -2065,7 +2165,9 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
 {
     if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if (!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0");
+    const bool is64 = depth == MI355CV_64F;                                                      // CV_64F images: the per-pixel kernel k_warp64
+    if (!(depthOk(depth) || is64) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F / 64F || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0");
+    if (is64 && (kind == 6 || kind == 7)) return mi355::declined(__func__, __LINE__, "warpPolar on CV_64F images");
     const bool relative = (interpolation & 32) != 0 && kind >= 2 && kind <= 5;              // WARP_RELATIVE_MAP (cv::remap only, imgwarp.cpp:1724)
     if (relative) interpolation &= ~32;
     if (interpolation == MI355CV_INTER_AREA) interpolation = MI355CV_INTER_LINEAR;          // imgwarp.cpp:2818
@@ -2082,7 +2184,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const short* g_tabDev = deviceTab();
     if (!g_tabDev) return mi355::declined(__func__, __LINE__, "!g_tabDev");
-    const int e = eszOf(depth);
+    const int e = is64 ? 8 : eszOf(depth);
     size_t dss, dds, mxs = mxstep, mys = mystep;
     const uchar* ds = stg.in(src, sstep, (size_t)sw * cn * e, sh, &dss);
     uchar* dd;
@@ -2116,13 +2218,21 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     }
     if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
     SampleArgs s; s.sw = sw; s.sh = sh; s.depth = depth; s.cn = cn; s.linear = interpolation == MI355CV_INTER_LINEAR ? 1 : taps ? interpolation : 0; s.border = borderType;
-    for (int k = 0; k < 4; k++) s.cval[k] = bv ? (float)bv[k] : 0.f;
+    for (int k = 0; k < 4; k++) { s.cval[k] = bv ? (float)bv[k] : 0.f; s.cvalD[k] = bv ? bv[k] : 0.0; }
     WarpArgs w; memset(&w, 0, sizeof w);
     w.dw = dw; w.dh = dh; w.kind = kind; w.rel = relative ? 1 : 0;
     w.sframe = nframes > 1 ? sframe : 0; w.dframe = nframes > 1 ? dframe : 0;
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : kind == 7 ? 5 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
+    if (is64) {
+        const TapTabs* tt = deviceTapTabs();
+        if (!tt) return mi355::declined(__func__, __LINE__, "the bicubic / Lanczos weight tables could not be placed on the device");
+        dim3 grid(divUp(dw, 64), divUp(dh, 4), nframes);
+        hipLaunchKernelGGL(k_warp64, grid, dim3(256), 0, stream(), ds, dss, dd, dds, s, w, tt->cubic1, tt->lanczos1, dmx, mxs, dmy, mys);
+        noteKernel("k_warp64 grid=%ux%ux%u x256 kind=%d mode=%d", grid.x, grid.y, grid.z, kind, s.linear);
+        return stg.finish(entry);
+    }
     if (taps) {
         // bicubic / Lanczos: the per-pixel kernel over the shared coordinate generation
         const TapTabs* tt = deviceTapTabs();

@@ -32,7 +32,7 @@ static void stv_round(uint8_t* p, int depth, int idx, float v)     /* saturate_c
     default: ((float*)p)[idx] = v;
     }
 }
-static int esz(int depth) { return depth == 0 ? 1 : depth == 5 ? 4 : 2; }
+static int esz(int depth) { return depth == 0 ? 1 : depth == 5 ? 4 : depth == 6 ? 8 : 2; }
 
 /* ------------------------------------------------------------------ resize */
 static void lin_coef(int d, double scale, double inv_scale, int ssz, int area_mode, int* so, float* f)
@@ -495,10 +495,12 @@ const short* orc_bilinearTabI(void)              /* initInterTab2D(INTER_LINEAR,
     return g_itab;
 }
 
+static void sample_pixel_d64(const uint8_t* src, size_t sstep, int sw, int sh, double* D, int cn, int sx, int sy, int ax, int ay, int mode, int border, const double* bv);
 /* one output pixel of remapBilinear / remapNearest given integer coordinates + 5-bit fractions */
 static void sample_pixel(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* D, int depth, int cn,
                          int sx, int sy, int ax, int ay, int linear, int border, const double* bv)
 {
+    if (depth == 6) { sample_pixel_d64(src, sstep, sw, sh, (double*)D, cn, sx, sy, ax, ay, linear ? 1 : 0, border, bv); return; }
     const int e = esz(depth);
     if (!linear) {
         if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) { memcpy(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, (size_t)cn * e); return; }
@@ -718,10 +720,95 @@ static void sample_pixel_n(const uint8_t* src, size_t sstep, int sw, int sh, uin
         }
     }
 }
+/* CV_64F images (imgwarp.cpp:1736-1790: remapNearest<double>, remapBilinear<Cast<double, double>, RemapNoVec, float>, remapBicubic / remapLanczos4<Cast<double, double>,
+ * float, 1>): WT = double, AT = float -- the float weight tables, double products and sums in the order of the float forms above.  mode 0 nearest, 1, 2, 4. */
+static void sample_pixel_d64(const uint8_t* src, size_t sstep, int sw, int sh, double* D, int cn, int sx, int sy, int ax, int ay, int mode, int border, const double* bv)
+{
+#define S64(y_, x_, k_) (((const double*)(src + (size_t)(y_) * sstep))[(x_) * cn + (k_)])
+    if (mode == 0) {
+        if (!((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh)) {
+            if (border == 1) { sx = clipi(sx, 0, sw); sy = clipi(sy, 0, sh); }
+            else if (border == 0) { for (int k = 0; k < cn; k++) D[k] = bv[k & 3]; return; }
+            else if (border == 5) return;
+            else { sx = orc_borderInterpolate(sx, sw, border); sy = orc_borderInterpolate(sy, sh, border); }
+        }
+        for (int k = 0; k < cn; k++) D[k] = S64(sy, sx, k);
+        return;
+    }
+    if (mode == 1) {
+        const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32;
+        const float w[4] = {(1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx};
+        if (border == 0 && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) D[k] = bv[k & 3]; return; }
+        if (border == 5 && !((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1))) {
+            if (!(sx >= 0 && sx <= sw - 1 && sy >= 0 && sy <= sh - 1)) return;
+            const int has1 = sx < sw - 1, has2 = sy < sh - 1, has3 = has1 && has2;
+            double w_tot = 0; w_tot += w[0];
+            if (has1) w_tot += w[1];
+            if (has2) w_tot += w[2];
+            if (has3) w_tot += w[3];
+            if (w_tot == 0.f) return;
+            const double w_ini = (double)w[0] + w[1] + w[2] + w[3];
+            for (int k = 0; k < cn; k++) {
+                double t0 = 0; t0 += S64(sy, sx, k) * w[0];
+                if (has1) t0 += S64(sy, sx + 1, k) * w[1];
+                if (has2) t0 += S64(sy + 1, sx, k) * w[2];
+                if (has3) t0 += S64(sy + 1, sx + 1, k) * w[3];
+                D[k] = (double)(t0 * (float)w_ini / w_tot);
+            }
+            return;
+        }
+        int x0, x1, y0, y1;
+        if (border == 1) { x0 = clipi(sx, 0, sw); x1 = clipi(sx + 1, 0, sw); y0 = clipi(sy, 0, sh); y1 = clipi(sy + 1, 0, sh); }
+        else { x0 = orc_borderInterpolate(sx, sw, border); x1 = orc_borderInterpolate(sx + 1, sw, border);
+               y0 = orc_borderInterpolate(sy, sh, border); y1 = orc_borderInterpolate(sy + 1, sh, border); }
+        for (int k = 0; k < cn; k++) {
+            const double cv = bv[k & 3];
+            const double v0 = (x0 >= 0 && y0 >= 0) ? S64(y0, x0, k) : cv, v1 = (x1 >= 0 && y0 >= 0) ? S64(y0, x1, k) : cv;
+            const double v2 = (x0 >= 0 && y1 >= 0) ? S64(y1, x0, k) : cv, v3 = (x1 >= 0 && y1 >= 0) ? S64(y1, x1, k) : cv;
+            D[k] = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+        }
+        return;
+    }
+    warp_tabs_init();
+    const int m = mode == 4, ks = m ? 8 : 4, off = ks / 2 - 1;
+    sx -= off; sy -= off;
+    float wf[64];
+    for (int k1 = 0; k1 < ks; k1++) for (int k2 = 0; k2 < ks; k2++) wf[k1 * ks + k2] = g_wtab1[m][ay * ks + k1] * g_wtab1[m][ax * ks + k2];
+    const unsigned width1 = (unsigned)(sw - (ks - 1) > 0 ? sw - (ks - 1) : 0), height1 = (unsigned)(sh - (ks - 1) > 0 ? sh - (ks - 1) : 0);
+    if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+        for (int k = 0; k < cn; k++) {
+            double sum = 0;
+            for (int r = 0; r < ks; r++) {
+                double row = S64(sy + r, sx, k) * wf[r * ks];
+                for (int c = 1; c < ks; c++) row = row + S64(sy + r, sx + c, k) * wf[r * ks + c];
+                if (r == 0 && !m) sum = row; else sum = sum + row;
+            }
+            D[k] = sum;
+        }
+        return;
+    }
+    if (border == 5 && ((unsigned)(sx + off) >= (unsigned)sw || (unsigned)(sy + off) >= (unsigned)sh)) return;
+    const int b1 = border != 5 ? border : 4;
+    if (b1 == 0 && (sx >= sw || sx + ks <= 0 || sy >= sh || sy + ks <= 0)) { for (int k = 0; k < cn; k++) D[k] = bv[k & 3]; return; }
+    int xi[8], yi[8];
+    for (int i = 0; i < ks; i++) { xi[i] = orc_borderInterpolate(sx + i, sw, b1); yi[i] = orc_borderInterpolate(sy + i, sh, b1); }
+    for (int k = 0; k < cn; k++) {
+        const double cv = bv[k & 3];
+        double sum = cv * 1;
+        for (int r = 0; r < ks; r++) {
+            if (yi[r] < 0) continue;
+            for (int c = 0; c < ks; c++) if (xi[c] >= 0) sum += (S64(yi[r], xi[c], k) - cv) * wf[r * ks + c];
+        }
+        D[k] = sum;
+    }
+#undef S64
+}
+
 /* the sampler of a non-nearest mode (1 bilinear, 2 bicubic, 4 Lanczos) */
 static void sample_mode(const uint8_t* src, size_t sstep, int sw, int sh, uint8_t* D, int depth, int cn,
                         int sx, int sy, int ax, int ay, int mode, int border, const double* bv)
 {
+    if (depth == 6) { sample_pixel_d64(src, sstep, sw, sh, (double*)D, cn, sx, sy, ax, ay, mode, border, bv); return; }
     if (mode == 1) sample_pixel(src, sstep, sw, sh, D, depth, cn, sx, sy, ax, ay, 1, border, bv);
     else sample_pixel_n(src, sstep, sw, sh, D, depth, cn, sx, sy, ax, ay, mode, border, bv);
 }

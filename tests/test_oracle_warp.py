@@ -352,3 +352,29 @@ def test_remap_cubic_lanczos(orc, ref, dtype):
             _bits(orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=d0), orc.ref_remapMaps(src, f1, f2, interp, border, bval, dst=d0))
             _bits(orc.orc_remapMaps(src, oxy, None, interp | REL, border, bval, dst=d0), orc.ref_remapMaps(src, oxy, None, interp | REL, border, bval, dst=d0))
             _bits(orc.orc_remapMaps(src, o1, o2, interp | REL, border, bval, dst=d0), orc.ref_remapMaps(src, o1, o2, interp | REL, border, bval, dst=d0))
+
+
+def test_warps_on_64f_images(orc, ref):
+    """CV_64F images (remapNearest<double>, remapBilinear / remapBicubic / remapLanczos4 with WT = double and the float weight tables, imgwarp.cpp:1736-1790): warpAffine,
+    warpPerspective and cv::remap with every map representation, plain and relative -- the 60 Imgproc_RemapRelative cases the ledger still showed on the fallback"""
+    REL = 32
+    rng = np.random.default_rng(5)
+    src = rng.random((40, 50, 3)) * 1000 - 300
+    M = orc.ref_getRotationMatrix2D((25.0, 20.0), 33.0, 1.3)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    prev = rng.random((33, 47, 3))
+    mapx, mapy = _float_maps(24)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.ref_convertMaps(mapx, mapy, "16sc2", False)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    for interp in (0, 1, 2, 4):
+        for border, bval in [(0, (1.5, -2.25, 1e3 / 3, 0)), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+            d0 = prev if border == 5 else None
+            _bits(orc.orc_warpAffine(src, M, (47, 33), interp, border, bval, dst=d0), orc.ref_warpAffine(src, M, (47, 33), interp | 16, border, bval, dst=d0))
+            _bits(orc.orc_warpPerspective(src, P, (47, 33), interp, border, bval, dst=d0), orc.ref_warpPerspective(src, P, (47, 33), interp | 16, border, bval, dst=d0))
+            if border != 5:
+                _bits(orc.orc_remap(src, mapx, mapy, interp, border, bval), orc.ref_remap(src, mapx, mapy, interp, border, bval))
+                _bits(orc.orc_remap(src, offx, offy, interp | REL, border, bval), orc.ref_remap(src, offx, offy, interp | REL, border, bval))
+            _bits(orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=d0), orc.ref_remapMaps(src, xy, None, interp, border, bval, dst=d0))
+            if interp:
+                _bits(orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=d0), orc.ref_remapMaps(src, f1, f2, interp, border, bval, dst=d0))

@@ -518,3 +518,33 @@ def test_warp_cubic_whole_frames(cv, orc):
     for dtype, interp in ((np.uint8, 2), (np.uint8, 4), (np.float32, 2)):
         src = rnd((1080, 1920), dtype, 77)
         _bits(cv.warpAffine(dev(src), M, (1920, 1080), interp | cv.WARP_INVERSE_MAP, 4), orc.orc_warpAffine(src, M, (1920, 1080), interp, 4))
+
+
+def test_warps_on_64f_images(cv, orc):
+    """CV_64F images through k_warp64 (double sums over the float weight tables, the reference's order): warpAffine, warpPerspective, cv::remap with every map representation,
+    plain and relative, every interpolation and border rule; bit for bit"""
+    from opencv_amd import _lib
+    REL = 32
+    rng = np.random.default_rng(5)
+    src = rng.random((40, 50, 3)) * 1000 - 300
+    M = cv.getRotationMatrix2D((25.0, 20.0), 33.0, 1.3)
+    P = np.array([[0.7, -0.3, 20.0], [0.25, 0.8, -5.0], [-1e-3, 5e-4, 1.2]])
+    prev = rng.random((33, 47, 3))
+    mapx, mapy = _float_maps(24)
+    xy = np.ascontiguousarray(np.stack([mapx, mapy], axis=-1))
+    f1, f2 = orc.orc_convertMaps(mapx, mapy, "16sc2", False)
+    offx = rng.uniform(-6, 6, (33, 47)).astype(np.float32); offy = rng.uniform(-6, 6, (33, 47)).astype(np.float32)
+    for interp in (0, 1, 2, 4):
+        for border, bval in [(0, (1.5, -2.25, 1e3 / 3, 0)), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0)]:
+            d0 = lambda: dev(prev.copy()) if border == 5 else None
+            p0 = prev if border == 5 else None
+            _bits(cv.warpAffine(dev(src), M, (47, 33), interp | cv.WARP_INVERSE_MAP, border, bval, dst=d0()), orc.orc_warpAffine(src, M, (47, 33), interp, border, bval, dst=p0))
+            _bits(cv.warpPerspective(dev(src), P, (47, 33), interp | cv.WARP_INVERSE_MAP, border, bval, dst=d0()), orc.orc_warpPerspective(src, P, (47, 33), interp, border, bval, dst=p0))
+            if border != 5:
+                _bits(cv.remap(dev(src), dev(mapx), dev(mapy), interp, border, bval), orc.orc_remap(src, mapx, mapy, interp, border, bval))
+                _bits(cv.remap(dev(src), dev(offx), dev(offy), interp | REL, border, bval), orc.orc_remap(src, offx, offy, interp | REL, border, bval))
+            _bits(cv.remap(dev(src), dev(xy), None, interp, border, bval, dst=d0()), orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=p0))
+            if interp:
+                _bits(cv.remap(dev(src), dev(f1), dev(f2), interp, border, bval, dst=d0()), orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=p0))
+    assert "k_warp64" in _lib.lib.mi355cv_lastKernel().decode()
+    _bits(cv.warpAffine(src, M, (47, 33), 2 | cv.WARP_INVERSE_MAP, 4), orc.orc_warpAffine(src, M, (47, 33), 2, 4))                     # host arrays
