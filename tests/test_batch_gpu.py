@@ -60,6 +60,16 @@ def test_geometry_batches(cv, dtype, cn):
     same(cv.warpAffineBatch(fr, M, (700, 300), 1 | cv.WARP_INVERSE_MAP, 1), [cv.warpAffine(f, M, (700, 300), 1 | cv.WARP_INVERSE_MAP, 1) for f in fr])
     P = np.array([[1.05, 0.04, -6.0], [0.03, 0.95, 5.0], [1e-4, -1e-4, 1.0]])
     same(cv.warpPerspectiveBatch(fr, P, (161, 120), 1 | cv.WARP_INVERSE_MAP, 0, 3.0), [cv.warpPerspective(f, P, (161, 120), 1 | cv.WARP_INVERSE_MAP, 0, 3.0) for f in fr])
+    # the tap samplers over a batch (k_warp_taps_lds walks the frames' tiles in one grid, the border strips carry their frame): bicubic and Lanczos, maps that leave the source
+    for interp in (2, 4):
+        for flags, border in [(interp, 0), (interp | cv.WARP_INVERSE_MAP, 4), (interp, 1)]:
+            same(cv.warpAffineBatch(fr, M, (161, 120), flags, border, 7.0), [cv.warpAffine(f, M, (161, 120), flags, border, 7.0) for f in fr])
+        same(cv.warpAffineBatch(fr, M, (700, 300), interp | cv.WARP_INVERSE_MAP, 0, 9.0), [cv.warpAffine(f, M, (700, 300), interp | cv.WARP_INVERSE_MAP, 0, 9.0) for f in fr])
+        same(cv.warpPerspectiveBatch(fr, P, (161, 120), interp | cv.WARP_INVERSE_MAP, 0, 3.0), [cv.warpPerspective(f, P, (161, 120), interp | cv.WARP_INVERSE_MAP, 0, 3.0) for f in fr])
+    if dtype == torch.float32:
+        f64 = fr.to(torch.float64)
+        for interp in (0, 1, 2, 4):
+            same(cv.warpAffineBatch(f64, M, (161, 120), interp, 0, 7.0), [cv.warpAffine(f, M, (161, 120), interp, 0, 7.0) for f in f64])
 
 
 def test_batch_entries_refuse_host_memory(cv):

@@ -451,6 +451,13 @@ def run(quick=False, parity=True):
                     "achieved_TFLOPs": round(4 * 2.4735e11 / ms / 1e9, 1), "frac_of_bf16_dense_peak": round(4 * 2.4735e11 / ms / 1e9 / MFMA_BF16, 4)})
     except Exception as e:
         out.append({"config": "cfg5f matchTemplate 32FC1", "error": repr(e)})
+    try:        # the same search with a binary mask over the template (matchTemplateMask: float planes, two bf16 matrix-core correlations + window sums for TM_CCORR_NORMED)
+        mask = (torch.rand((128, 128), device=dev, generator=g) > 0.3).to(torch.uint8) * 255
+        ms = timeit(lambda: [cv.matchTemplate(img[i], tpl, cv.TM_CCORR_NORMED, mask=mask, result=res[i]) for i in range(2)], n=3, warm=1)
+        out.append({"config": "cfg5m matchTemplate TM_CCORR_NORMED with a mask, 4K x 128x128 8UC1 (one call per frame)", "frames": 2, "ms": round(ms, 3), "ms_per_frame": round(ms / 2, 4),
+                    "bound": "mfma"})
+    except Exception as e:
+        out.append({"config": "cfg5m masked matchTemplate", "error": repr(e)})
     cv.set_async(False)
     for r in out:
         key = r["config"].split()[0]
