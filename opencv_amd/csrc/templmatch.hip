@@ -1323,6 +1323,28 @@ __global__ __launch_bounds__(256) void k_tm_mask_planes(const uchar* __restrict_
     }
 }
 
+// CV_8U images under a binary mask, methods TM_SQDIFF .. TM_CCORR_NORMED: every operand is a small integer -- I and T M^2 = T M are bytes, M^2 = M is 0 / 1 and
+// I^2 = 256 hi + lo is two bytes --, so the cross-correlations run on the i8 matrix-core kernel of the unmasked path (exact integer sums, one rounding to float)
+// instead of four bf16 products of float planes: per channel byte planes of I, I^2 >> 8 and I^2 & 255
+__global__ __launch_bounds__(256) void k_tm_mask_planes_u8(const uchar* __restrict__ src, size_t sstep, int w, int h, int cn, uchar* __restrict__ pI, uchar* __restrict__ pHi,
+                                                          uchar* __restrict__ pLo, int pitch, size_t plane)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= pitch || y >= h) return;
+    for (int c = 0; c < cn; c++) {
+        const unsigned v = x < w ? src[(size_t)y * sstep + (size_t)x * cn + c] : 0u, q = v * v;
+        const size_t o = c * plane + (size_t)y * pitch + x;
+        pI[o] = (uchar)v;
+        if (pHi) { pHi[o] = (uchar)(q >> 8); pLo[o] = (uchar)(q & 255u); }
+    }
+}
+// CC(I^2, M) = 256 CC(I^2 >> 8, M) + CC(I^2 & 255, M)
+__global__ __launch_bounds__(256) void k_tm_mask_join(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = __builtin_fmaf(hi[i], 256.f, lo[i]);
+}
+
 struct MaskFin { int method, cn, rw, rh, sameM2; int pitch; size_t plane; float t2m2, nrm; float kfac[4], invMs[4], m2fac[4]; };
 
 // part: [kind][channel] planes of `plane` floats; kinds: 0 CC(I, K), 1 CC(I^2, M^2), 2 CC(I, M), 3 CC(I, M^2)
@@ -1412,6 +1434,35 @@ int runMatchMask(const char* entry, const uchar* img, size_t istep, int iw, int 
     const bool needI2 = method != 2 && method != 4;
     const int ipitch = (iw + 3) & ~3; const size_t iplane = (size_t)ipitch * ih;
     const int rpitch = (rw + 3) & ~3; const size_t rplane = (size_t)rpitch * rh;
+    static const bool maskI8 = [] { const char* v = getenv("MI355CV_TM_MASK_I8"); return !v || atoi(v) != 0; }();      // 0: the float planes for every case (A/B runs)
+    if (maskI8 && depth == D8U && binary && !coeff) {
+        const int p8 = (iw + 15) & ~15; const size_t plane8 = (size_t)p8 * ih;
+        uchar* b8 = (uchar*)stg.scratch(plane8 * cn * (needI2 ? 3 : 1));
+        float* part = (float*)stg.scratch(rplane * 16 * 4);
+        std::vector<uchar> K8(nt * cn), M8(nt * cn);
+        for (size_t i = 0; i < nt * cn; i++) { K8[i] = (uchar)(T[i] * M[i]); M8[i] = (uchar)M[i]; }
+        uchar* dk8 = (uchar*)stg.param(K8.data(), nt * cn);
+        uchar* dm8 = needI2 ? (uchar*)stg.param(M8.data(), nt * cn) : nullptr;
+        if (!b8 || !part || !dk8 || (needI2 && !dm8)) return mi355::declined(__func__, __LINE__, "out of scratch memory for the byte planes");
+        uchar* pI = b8; uchar* pHi = needI2 ? b8 + plane8 * cn : nullptr; uchar* pLo = needI2 ? b8 + 2 * plane8 * cn : nullptr;
+        hipLaunchKernelGGL(k_tm_mask_planes_u8, dim3(divUp(p8, 64), divUp(ih, 4)), dim3(256), 0, st, di, dis, iw, ih, cn, pI, pHi, pLo, p8, plane8);
+        fin.pitch = rpitch; fin.plane = rplane;
+        auto cc8 = [&](const uchar* plane, const uchar* kern, int slot, int c) -> int {
+            return runMatch(entry, plane + (size_t)c * plane8, (size_t)p8, 0, 1, iw, ih, kern + (size_t)c * nt, (size_t)tw, tw, th, MI355CV_MAKETYPE(D8U, 1),
+                            reinterpret_cast<uchar*>(part + ((size_t)slot * 4 + c) * rplane), (size_t)rpitch * 4, 0, 2);
+        };
+        for (int c = 0; c < cn; c++) {
+            int rc = cc8(pI, dk8, 0, c);
+            if (rc == MI355CV_OK && needI2) rc = cc8(pHi, dm8, 2, c);                 // (slots 2 and 3 are free for these methods)
+            if (rc == MI355CV_OK && needI2) rc = cc8(pLo, dm8, 3, c);
+            if (rc != MI355CV_OK) return rc;
+            if (needI2) hipLaunchKernelGGL(k_tm_mask_join, dim3((unsigned)((rplane + 255) / 256)), dim3(256), 0, st, part + ((size_t)2 * 4 + c) * rplane,
+                                           part + ((size_t)3 * 4 + c) * rplane, part + ((size_t)1 * 4 + c) * rplane, rplane);
+        }
+        hipLaunchKernelGGL(k_tm_mask_finish, dim3(divUp(rw, 64), divUp(rh, 4)), dim3(256), 0, st, part, reinterpret_cast<float*>(dr), drs, fin);
+        noteKernel("matchTemplateMask on byte planes: %d i8 correlation(s) per channel + k_tm_mask_finish", needI2 ? 3 : 1);
+        return stg.finish(entry);
+    }
     float* f = (float*)stg.scratch(iplane * cn * 4);
     float* f2 = needI2 ? (float*)stg.scratch(iplane * cn * 4) : nullptr;
     float* part = (float*)stg.scratch(rplane * 16 * 4);

@@ -255,7 +255,8 @@ def _mask_tol(img, tpl, mask, method, got, want):
 @pytest.mark.parametrize("cn,kind", [(1, "u8"), (1, "f32"), (3, "u8"), (3, "u8cn"), (3, "f32"), (3, "f32cn")])     # (a per-channel mask of a one-channel template is the one-channel mask)
 def test_masked_modes(cv, orc, dtype, cn, kind):
     """matchTemplateMask (templmatch.cpp:762-904), every method, CV_8U and CV_32F images, binary and weighted masks with one channel or the template's: the small
-    shapes run the direct kernel, the large ones the bf16 matrix-core correlations (four partial products); against the restatement pinned to the reference"""
+    shapes run the direct kernel, the large ones the bf16 matrix-core correlations (four partial products) -- CV_8U images under a binary mask the i8 ones for the
+    methods without a mean --; against the restatement pinned to the reference"""
     from opencv_amd import _lib
     for (iw, ih, tw, th) in [(64, 48, 8, 8), (97, 61, 17, 9), (300, 200, 33, 21), (261, 190, 128, 64)]:
         img = rnd((ih, iw, cn) if cn > 1 else (ih, iw), dtype, 300 + iw)
@@ -264,8 +265,11 @@ def test_masked_modes(cv, orc, dtype, cn, kind):
         for method in range(6):
             want = orc.orc_matchTemplateMask(img, tpl, method, mask)
             got = cv.matchTemplate(dev(img), dev(tpl), method, mask=dev(mask)).cpu().numpy()
-            if iw >= 261:
-                assert "k_ccorr_bf16" in _lib.lib.mi355cv_lastKernel().decode() and "mid*mid" in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+            last = _lib.lib.mi355cv_lastKernel().decode()
+            if dtype == np.uint8 and kind.startswith("u8") and method <= 3:
+                assert "byte planes" in last, last                 # CV_8U under a binary mask: exact integer correlations on the i8 matrix-core path
+            elif iw >= 261:
+                assert "k_ccorr_bf16" in last and "mid*mid" in last, last
             err, tol = _mask_tol(img, tpl, mask, method, got, want)
             assert np.isfinite(got).all() and err <= tol, (iw, ih, tw, th, method, err, tol)
     # host arrays in, host array out; a result row pitch that is not the width
