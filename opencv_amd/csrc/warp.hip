@@ -2089,6 +2089,40 @@ __global__ __launch_bounds__(256) void k_warp8_tile_list(const uchar* __restrict
     }
 }
 
+// bicubic warpAffine of CV_8U images on the tile path of warp8.h (boxFromTerms4 / phaseC4): persistent workgroups -- the Q15 weight table is copied into LDS
+// once, 12 dwords per entry (8 used: the 48-byte pitch spreads the entries over the banks) --, then tile after tile: box terms, the source box staged with aligned
+// dwords, four destination pixels per lane from LDS, what is left (the source's rim, border rules) through samplePixelN.  NOT the default yet (written after the
+// round's GPU budget; tests/hostemu runs its phases on the CPU against the restatement): MI355CV_WARP_TAPS_TILE=1.
+template <int CN>
+__global__ __launch_bounds__(256) void k_warp8_cubic(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tabI,
+                                                     const float* __restrict__ tab1, uint32_t tileBytes, int nframes)
+{
+    extern __shared__ __align__(16) uchar w8lds[];
+    uint32_t* wq = reinterpret_cast<uint32_t*>(w8lds + tileBytes);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1024 * 8; i += 256) wq[(i >> 3) * 12 + (i & 7)] = reinterpret_cast<const uint32_t*>(tabI)[i];
+    const uint32_t perFrame = (uint32_t)a.gx * (uint32_t)a.gy, total = perFrame * (uint32_t)nframes;
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {                           // uniform
+        const uint32_t f = t / perFrame, tt = t - f * perFrame, ty = tt / (uint32_t)a.gx, tx = tt - ty * (uint32_t)a.gx;
+        const uchar* S = src + (size_t)f * a.sframe; uchar* D = dst + (size_t)f * a.dframe;
+        const int x0 = (int)tx * warp8::TW, y0 = (int)ty * a.th;
+        __syncthreads();                                                                 // the table is there / the previous tile's terms and pixels are no longer read
+        warp8::phaseA<0>(a, x0, y0, w8lds, tid);
+        __syncthreads();
+        int terms[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) terms[k] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(w8lds + warp8::OFF_TERMS)[k]);
+        const warp8::Box b = warp8::boxFromTerms4<CN>(a, terms);
+        warp8::phaseB<CN, 0>(a, b, x0, y0, S, w8lds, tid);
+        __syncthreads();
+        const unsigned redo = warp8::phaseC4<CN>(a, b, x0, y0, w8lds, wq, 12, D, tid);
+        if (redo)
+            warp8::redoGroups<CN, 0>(a, b, redo, x0, y0, w8lds, tid, [&](int x, int y, int X, int Y) {
+                samplePixelN<4>(S, a.sstep, D + (size_t)y * a.dstep + (size_t)x * CN, s, satShort(X >> 5), satShort(Y >> 5), X & 31, Y & 31, tabI, tab1);
+            });
+    }
+}
+
 // the lean path of warp8.h: one or three channels, affine.  A workgroup walks `tpw` tiles of one tile row with the NEXT tile's box in flight in registers while
 // it samples the current one (two LDS buffers, one barrier per tile); the tiles it cannot take (the source's rim under a border rule other than CONSTANT, boxes
 // beyond its staging geometry) go on a list for k_warp8_tile_list.
@@ -2245,6 +2279,29 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             uint32_t* work0 = (uint32_t*)stg.scratch(sizeof(uint32_t));
             if (!terms || !work0) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
             hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work0);
+        }
+        // CV_8U bicubic on the tile path of warp8.h (opt-in until it has run on the GPU: MI355CV_WARP_TAPS_TILE=1)
+        static const bool tapsTile = [] { const char* v = getenv("MI355CV_WARP_TAPS_TILE"); return v && atoi(v) != 0; }();
+        if (tapsTile && kind == 0 && depth == D8U && interpolation == MI355CV_INTER_CUBIC && (cn == 1 || cn == 3) && sw >= 4 && sh >= 4 && terms) {
+            warp8::Args a8; size_t lds8 = 0;
+            if (warp8::plan(a8, cn, 0, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8, 3)) {
+                a8.sframe = w.sframe; a8.dframe = w.dframe;
+                a8.constBorder = borderType == B_CONSTANT;
+                for (int k = 0; k < cn; k++) a8.cval |= (uint32_t)fminf(fmaxf(rintf(s.cval[k]), 0.f), 255.f) << (8 * k);
+                a8.colT = terms; a8.rowT = terms + 2 * dw;
+                a8.leanLW = 0;
+                const uint32_t tileBytes = (uint32_t)((lds8 + 15) & ~(size_t)15);
+                const size_t ldsAll = (size_t)tileBytes + 1024 * 12 * 4;
+                const long long ntiles = (long long)a8.gx * a8.gy * nframes;
+                const unsigned gridN = (unsigned)std::min<long long>(ntiles, 256LL * (ldsAll <= 80 * 1024 ? 2 : 1));
+                if (cn == 1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp8_cubic<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsAll);
+                               hipLaunchKernelGGL(k_warp8_cubic<1>, dim3(gridN), dim3(256), ldsAll, stream(), ds, dd, s, a8, tt->cubicI, tt->cubic1, tileBytes, nframes); }
+                else         { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp8_cubic<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsAll);
+                               hipLaunchKernelGGL(k_warp8_cubic<3>, dim3(gridN), dim3(256), ldsAll, stream(), ds, dd, s, a8, tt->cubicI, tt->cubic1, tileBytes, nframes); }
+                noteKernel("k_warp8_cubic<%d> grid=%u x256 lds=%zu (tile %u + table) tiles=%dx%dx%d box<=%dx%d", cn, gridN, ldsAll, tileBytes, a8.gx, a8.gy, nframes,
+                           (a8.ldsPitch - 8) / cn, a8.ldsRows);
+                return stg.finish(entry);
+            }
         }
         static const bool tapsLds = [] { const char* v = getenv("MI355CV_WARP_TAPS_LDS"); return !v || atoi(v) != 0; }();
         static const int tapsP = [] { const char* v = getenv("MI355CV_WARP_TAPS_P"); return v ? atoi(v) : 0; }();          // 1: one pixel per thread everywhere (A/B runs)

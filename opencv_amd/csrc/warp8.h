@@ -457,6 +457,156 @@ W8_HD void redoGroups(const Args& a, const Box& b, unsigned redo, int x0, int y0
     }
 }
 
+// ---- bicubic sampling on the tile path (affine maps, 1 / 3 channels; round 4, not yet the default: MI355CV_WARP_TAPS_TILE=1) --------------------------------
+// remapBicubic (imgwarp.cpp:905-1010) reads 4 x 4 taps from one pixel left of / above the bilinear pair's upper-left tap: the tile's box grows by that margin and
+// every destination pixel takes its taps from LDS -- per tap row the aligned dwords around its 4 * CN bytes and byte funnel shifts --, pairs them into 16-bit
+// lanes (perm) and multiplies them with the Q15 weight pairs of initInterTab2D's table (dot2; the table sits in LDS beside the tile, `wq`: 8 dwords per
+// (ay * 32 + ax) entry, ESTR dwords apart).  Exact integers: (sum + 2^14) >> 15, saturated.  Pixels whose 4 x 4 footprint is not inside the staged box are left
+// to the generic sampler (redo mask), as on the bilinear path; BORDER_CONSTANT pixels wholly outside the source are the border value.
+W8_HD uint32_t permBytes(uint32_t hi, uint32_t lo, uint32_t sel)               // v_perm_b32: selector bytes 0-3 pick from lo, 4-7 from hi, 0x0c = zero
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo; uint32_t o = 0;
+    for (int i = 0; i < 4; i++) { const uint32_t q = (sel >> (8 * i)) & 0xffu; o |= (q == 0x0cu ? 0u : (uint32_t)((v >> (8 * q)) & 0xffu)) << (8 * i); }
+    return o;
+#endif
+}
+W8_HD int sdot2(uint32_t a, uint32_t b, int c)                                 // v_dot2_i32_i16
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+#else
+    return (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16) + c;
+#endif
+}
+
+// the affine box of boxFromTerms<CN, 0> grown by the bicubic margins; same conventions (cw == 0: nothing staged; ch == -1: nothing to stage but classifiable)
+template <int CN>
+W8_HD Box boxFromTerms4(const Args& a, const int* t)
+{
+    Box b = {0, 0, 0, 0, 0, 0};
+    const int bx0 = (((t[0] < t[1] ? t[0] : t[1]) + (t[2] < t[3] ? t[2] : t[3])) >> 10) - 1, bx1 = (((t[0] > t[1] ? t[0] : t[1]) + (t[2] > t[3] ? t[2] : t[3])) >> 10) + 2;
+    const int by0 = (((t[4] < t[5] ? t[4] : t[5]) + (t[6] < t[7] ? t[6] : t[7])) >> 10) - 1, by1 = (((t[4] > t[5] ? t[4] : t[5]) + (t[6] > t[7] ? t[6] : t[7])) >> 10) + 2;
+    b.cx0 = bx0 < 0 ? 0 : bx0; b.cy0 = by0 < 0 ? 0 : by0;
+    const int ex = bx1 > a.sw - 1 ? a.sw - 1 : bx1, ey = by1 > a.sh - 1 ? a.sh - 1 : by1;
+    b.cw = ex - b.cx0 + 1; b.ch = ey - b.cy0 + 1;
+    b.shift = (b.cx0 * CN) & 3;
+    if (b.cw < 4 || b.ch < 4) { b.cw = 0; b.ch = -1; b.shift = 0; b.all = 0; return b; }
+    if (b.ch > a.ldsRows || ((b.shift + b.cw * CN + 3) & ~3) + 8 > a.ldsPitch) { b.cw = 0; b.ch = 0; b.all = 0; return b; }
+    b.all = bx0 >= 0 && by0 >= 0 && bx1 <= a.sw - 1 && by1 <= a.sh - 1;
+    return b;
+}
+
+// CN result bytes (low bits) of one pixel: `p` = its first tap in the tile, `w` = the 8 weight-pair dwords of its table entry
+template <int CN>
+W8_HD uint32_t bicubicAt(const unsigned char* p, uint32_t pitch, const uint32_t* w)
+{
+    constexpr int ND = CN == 1 ? 1 : 3;                                          // dwords of a tap row (4 * CN bytes)
+    const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;                             // the pitch is a multiple of 4: the same shift on every row
+    uint32_t d[4][ND];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 4; r++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p + (size_t)r * pitch - sh);
+        uint32_t v[ND + 1];
+        for (int i = 0; i <= ND; i++) v[i] = q[i];
+        for (int i = 0; i < ND; i++) d[r][i] = alignbyte(v[i + 1], v[i], sh);
+    }
+    uint32_t out = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < CN; k++) {
+        int sum = 1 << 14;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int r = 0; r < 4; r++)
+            for (int j = 0; j < 2; j++) {
+                const int b0 = 2 * j * CN + k, b1 = (2 * j + 1) * CN + k, d0 = b0 >> 2, d1 = b1 >> 2;
+                const uint32_t sel = (uint32_t)(b0 & 3) | (0x0cu << 8) | ((uint32_t)((d1 == d0 ? 0 : 4) + (b1 & 3)) << 16) | (0x0cu << 24);
+                sum = sdot2(permBytes(d[r][d1], d[r][d0], sel), w[r * 2 + j], sum);
+            }
+        int v = sum >> 15;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(v));                                          // (keeps shift + clamp + pack away from v_ashr_pk_u8_i32)
+#endif
+        out |= (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v) << (8 * k);
+    }
+    return out;
+}
+
+// phase C of the bicubic path: rowsC's structure (a lane = four neighbouring destination pixels of a row per step; one dword / three stored when all four are good)
+template <int CN, bool ALL>
+W8_HD unsigned rowsC4(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, const uint32_t* wq, int estr, unsigned char* dst, int tid)
+{
+    const int* col = reinterpret_cast<const int*>(lds + OFF_COL); const int* row = reinterpret_cast<const int*>(lds + OFF_ROW);
+    const unsigned char* tile = lds + OFF_TILE;
+    const int wave = tid >> 6, lane = tid & 63, lx = lane & (LX - 1), ly = lane >> 5;
+    const int x = x0 + lx * PX;
+    if (x >= a.dw) return 0;
+    const bool fullLane = x + PX <= a.dw;
+    int cX[PX], cY[PX];
+    for (int p = 0; p < PX; p++) { cX[p] = col[lx * PX + p]; cY[p] = col[TW + lx * PX + p]; }
+    const uint32_t pitch = (uint32_t)a.ldsPitch, cwm = b.cw > 3 ? (uint32_t)(b.cw - 3) : 0u, chm = b.ch > 3 ? (uint32_t)(b.ch - 3) : 0u;
+    unsigned redo = 0;
+    constexpr int NSTEPS = tileRows<CN>() / ROWS_PER_STEP;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int st = 0; st < NSTEPS; st++) {
+        const int yi = st * ROWS_PER_STEP + wave * 2 + ly, y = y0 + yi;
+        const int rX = row[yi], rY = row[MAX_TH + yi];
+        uint32_t px[PX]; bool ok = fullLane;
+        uint32_t off[PX], ent[PX]; bool outp[PX];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            const int tX = rX + cX[p], tY = rY + cY[p];                     // 1/1024 px relative to the box origin
+            const int rx = (tX >> 10) - 1, ry = (tY >> 10) - 1;             // the first of the 4 x 4 taps
+            ent[p] = (uint32_t)((((tY >> 5) & 31) * 32 + ((tX >> 5) & 31)) * estr);
+            off[p] = mad24((uint32_t)ry, pitch, (uint32_t)(rx * CN + b.shift));
+            outp[p] = false;
+            if (!ALL) {
+                const bool in = (uint32_t)rx < cwm && (uint32_t)ry < chm;
+                const int sx = rx + b.cx0, sy = ry + b.cy0;
+                outp[p] = a.constBorder && (sx >= a.sw || sx + 4 <= 0 || sy >= a.sh || sy + 4 <= 0);
+                off[p] = in ? off[p] : 0u; ok = ok && (in || outp[p]);
+            }
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int p = 0; p < PX; p++) {
+            px[p] = bicubicAt<CN>(tile + off[p], pitch, wq + ent[p]);
+            if (!ALL) px[p] = outp[p] ? a.cval : px[p];
+        }
+        if (y < a.dh) {
+            if (ok) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(dst + (size_t)y * a.dstep + (size_t)x * CN);
+                if (CN == 1) d[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                else { d[0] = px[0] | (px[1] << 24); d[1] = (px[1] >> 8) | (px[2] << 16); d[2] = (px[2] >> 16) | (px[3] << 8); }
+            } else redo |= 1u << st;
+        }
+    }
+    return redo;
+}
+
+template <int CN>
+W8_HD unsigned phaseC4(const Args& a, const Box& b, int x0, int y0, const unsigned char* lds, const uint32_t* wq, int estr, unsigned char* dst, int tid)
+{
+    if (b.cw == 0 && !(a.constBorder && b.ch == -1)) {                // nothing staged: every group is redone
+        const int lane = tid & 63, x = x0 + (lane & (LX - 1)) * PX;
+        return x < a.dw ? (1u << (tileRows<CN>() / ROWS_PER_STEP)) - 1 : 0;
+    }
+    return b.all ? rowsC4<CN, true>(a, b, x0, y0, lds, wq, estr, dst, tid) : rowsC4<CN, false>(a, b, x0, y0, lds, wq, estr, dst, tid);
+}
+
 // ---- the lean path: one channel, affine map, tiles whose box lies wholly inside the source (Box::all) --------------------------------------------------
 // Most tiles of a call are of this kind, and for them nothing of the general machinery is needed: no per-pixel inside test, no border rule, no term tables in
 // LDS.  The tile kernel above spends ~63 VALU instructions per pixel (profiles/r03_warp8.txt: VALU-issue bound at 92 % busy); this path is written against
@@ -939,7 +1089,7 @@ inline void leanGeometry(Args& a, int cn)
 // perspective: the boxes of the tiles at the image's corners, edge centres and centre are measured with the kernel's own code.  Tiles whose box exceeds
 // what was allotted take the generic sampler inside the kernel, so the estimate bounds speed, never correctness.
 inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int dw, int dh, size_t sstep, size_t dstep, const void* src, const void* dst, int bw0,
-                 size_t* ldsBytes)
+                 size_t* ldsBytes, int margin = 0 /* extra box pixels per axis: 3 for the bicubic path (affine only) */)
 {
     if (((uintptr_t)src | (uintptr_t)dst | sstep | dstep) & 3) return false;
     if (sw < 2 || sh < 2 || dw < 1 || dh < 1 || (cn != 1 && cn != 3 && cn != 4)) return false;
@@ -955,7 +1105,7 @@ inline bool plan(Args& a, int cn, int kind, const double* M, int sw, int sh, int
         // the fixed-point sums must stay far from the int range (the kernel's box relies on them being monotone)
         const double lim = 1048576.0;                                                      // 2^20 pixels
         if (!(ab(M[0]) * dw + ab(M[1]) * dh + ab(M[2]) < lim && ab(M[3]) * dw + ab(M[4]) * dh + ab(M[5]) < lim)) return false;
-        bw = ab(M[0]) * (TW - 1) + ab(M[1]) * (a.th - 1) + 4; bh = ab(M[3]) * (TW - 1) + ab(M[4]) * (a.th - 1) + 4;
+        bw = ab(M[0]) * (TW - 1) + ab(M[1]) * (a.th - 1) + 4 + margin; bh = ab(M[3]) * (TW - 1) + ab(M[4]) * (a.th - 1) + 4 + margin;
     } else {
         a.ldsPitch = 1 << 20; a.ldsRows = 1 << 20;
         bw = bh = 0;

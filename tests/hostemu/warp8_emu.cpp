@@ -142,3 +142,49 @@ extern "C" int emu_resize8(const unsigned char* src, size_t sstep, int sw, int s
     stats[0] = stats[1] = stats[2] = 0;
     return cn == 1 ? rzRun<1>(a, ldsBytes, src, dst, stats) : rzRun<3>(a, ldsBytes, src, dst, stats);
 }
+
+// ---- the bicubic tile path (boxFromTerms4 / phaseC4 of warp8.h; kernel k_warp8_cubic): plan with the bicubic margin, per-call term tables, the Q15 table laid
+// out as the kernel lays it out in LDS (12 dwords per entry, 8 used).  stats: [0] pixels from the LDS tile, [1] pixels left to the generic sampler (copied from
+// `expect`), [2] tiles with an all-inside box, [3] tiles with nothing staged (+ 1e6 per coordinate mismatch handed to the sampler)
+template <int CN>
+static void cubicRun(const warp8::Args& a, size_t ldsBytes, const unsigned char* src, unsigned char* dst, const uint32_t* wq, const unsigned char* expect, size_t estep, long long* stats)
+{
+    std::vector<unsigned char> lds(ldsBytes + 64);
+    for (int ty = 0; ty < a.gy; ty++)
+        for (int tx = 0; tx < a.gx; tx++) {
+            const int x0 = tx * warp8::TW, y0 = ty * a.th;
+            std::memset(lds.data(), 0xA5, lds.size());
+            for (int tid = 0; tid < 256; tid++) warp8::phaseA<0>(a, x0, y0, lds.data(), tid);
+            const warp8::Box b = warp8::boxFromTerms4<CN>(a, reinterpret_cast<const int*>(lds.data() + warp8::OFF_TERMS));
+            for (int tid = 0; tid < 256; tid++) warp8::phaseB<CN, 0>(a, b, x0, y0, src, lds.data(), tid);
+            stats[2] += b.all; stats[3] += b.cw == 0;
+            for (int tid = 0; tid < 256; tid++) {
+                const unsigned redo = warp8::phaseC4<CN>(a, b, x0, y0, lds.data(), wq, 12, dst, tid);
+                warp8::redoGroups<CN, 0>(a, b, redo, x0, y0, lds.data(), tid, [&](int x, int y, int X, int Y) {
+                    const int Xr = (warp8::affRowX(a, y) + warp8::affColX(a, x)) >> 5, Yr = (warp8::affRowY(a, y) + warp8::affColY(a, x)) >> 5;
+                    if (X != Xr || Y != Yr) stats[3] += 1000000;
+                    std::memcpy(dst + (size_t)y * a.dstep + (size_t)x * CN, expect + (size_t)y * estep + (size_t)x * CN, CN);
+                    stats[1]++;
+                });
+            }
+        }
+    stats[0] = (long long)a.dw * a.dh - stats[1];
+}
+
+extern "C" int emu_warp8_cubic(const unsigned char* src, size_t sstep, int sw, int sh, unsigned char* dst, size_t dstep, int dw, int dh, int cn, const double* M,
+                               const short* tabQ15 /* [1024][16] */, const unsigned char* expect, size_t estep, long long* stats, int constBorder, unsigned cval)
+{
+    warp8::Args a; size_t ldsBytes = 0;
+    if (cn != 1 && cn != 3) return 1;
+    if (!warp8::plan(a, cn, 0, M, sw, sh, dw, dh, sstep, dstep, src, dst, 1, &ldsBytes, 3)) return 1;
+    a.constBorder = constBorder; a.cval = cval;
+    std::vector<int> tt(2 * (size_t)dw + 2 * (size_t)dh);
+    for (int i = 0; i < dw; i++) { tt[i] = warp8::affColX(a, i); tt[dw + i] = warp8::affColY(a, i); }
+    for (int i = 0; i < dh; i++) { tt[2 * dw + i] = warp8::affRowX(a, i); tt[2 * dw + dh + i] = warp8::affRowY(a, i); }
+    a.colT = tt.data(); a.rowT = tt.data() + 2 * dw;
+    std::vector<uint32_t> wq(1024 * 12, 0xDEADBEEFu);
+    for (int i = 0; i < 1024 * 8; i++) std::memcpy(&wq[(size_t)(i >> 3) * 12 + (i & 7)], reinterpret_cast<const unsigned char*>(tabQ15) + 4 * (size_t)i, 4);
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (cn == 1) cubicRun<1>(a, ldsBytes, src, dst, wq.data(), expect, estep, stats); else cubicRun<3>(a, ldsBytes, src, dst, wq.data(), expect, estep, stats);
+    return 0;
+}

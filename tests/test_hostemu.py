@@ -127,6 +127,41 @@ def test_warp8_affine_tiles_on_the_cpu(emu8, cn):
     assert cn == 4 or (lean_tiles[0] > 20 and lean_tiles[1] > 10 and lean_tiles[2] > 0), lean_tiles
 
 
+@pytest.mark.parametrize("cn", [1, 3])
+def test_warp8_bicubic_tiles_on_the_cpu(emu8, cn):
+    """the bicubic tile path of warp8.h (k_warp8_cubic; opt-in on the GPU until it has run there): the plan with the bicubic margin, the grown box, staging, the 4 x 4 taps from
+    the tile through byte funnel shifts, perm + dot2 against the Q15 weight pairs in the kernel's LDS layout -- thread by thread against the restatement pinned to the reference"""
+    orc = o.oracle()
+    orc.orc_warpTabI.restype = ctypes.c_void_p
+    tab = ctypes.c_void_p(orc.orc_warpTabI(0))
+    emu8.emu_warp8_cubic.restype = ctypes.c_int
+    rng = np.random.default_rng(40 + cn)
+    served = 0
+    for (sw, sh, dw, dh, deg, sc) in [(640, 360, 640, 360, 7.0, 0.95), (400, 300, 520, 260, -33.0, 1.1), (256, 200, 131, 77, 90.0, 1.0), (512, 128, 512, 128, 0.0, 1.0),
+                                      (300, 300, 300, 300, 45.0, 0.6), (640, 480, 1280, 960, 3.0, 2.0), (400, 300, 400, 300, 33.0, 1.3), (384, 384, 384, 384, 90.0, 1.0)]:
+        if (sw * cn) % 4:
+            continue
+        src = rng.integers(0, 256, (sh, sw) if cn == 1 else (sh, sw, cn), dtype=np.uint8)
+        M = _rot(sw / 2.0, sh / 2.0, deg, sc)
+        if (dw, dh) != (sw, sh):
+            M = M.copy(); M[:, :2] *= sw / dw
+        M = np.ascontiguousarray(M, np.float64)
+        for border, bval in [(0, (0, 0, 0, 0)), (0, (17.4, 200, 3, 255)), (1, (0, 0, 0, 0)), (4, (0, 0, 0, 0)), (2, (0, 0, 0, 0))]:
+            want = o.orc_warpAffine(src, M, (dw, dh), 2, border, bval)
+            got = np.full_like(want, 0x5A)
+            stats = (ctypes.c_longlong * 4)()
+            rc = emu8.emu_warp8_cubic(o.P(src), o.step(src), sw, sh, o.P(got), o.step(got), dw, dh, cn, o.P(M), tab, o.P(want), o.step(want), stats, int(border == 0),
+                                      sum(int(min(max(round(bval[c]), 0), 255)) << (8 * c) for c in range(cn)))
+            if rc != 0:
+                continue                                                       # the plan declined (box too large for LDS): the other kernels serve it
+            st = list(stats)
+            assert np.array_equal(got, want), (cn, sw, sh, dw, dh, deg, border, int(np.count_nonzero(got != want)), st)
+            assert st[3] < 1000000, st                                         # the coordinates handed to the sampler are the pixels' own
+            assert st[0] > (0.85 if border == 0 else 0.3) * dw * dh, (cn, deg, border, st)
+            served += 1
+    assert served >= 20, served
+
+
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_warp8_perspective_tiles_on_the_cpu(emu8, cn):
     rng = np.random.default_rng(10 + cn)

@@ -15,6 +15,8 @@
 #   gran             tools/probes/gran.hip: row-walking copies at 4 / 8 / 16 bytes per lane
 #   pyr-ab           tools/pyr_ab.py: buildPyramid / pyrDown, all segments downwards against alternating walks
 #   taps             tools/warp_taps_bench.py: bicubic / Lanczos warps beside the bilinear kernels
+#   taps-tile        the bicubic tile path of warp8.h (k_warp8_cubic, opt-in): its parity tests and the same bench with MI355CV_WARP_TAPS_TILE=1 -- the first thing to run
+#                    next round; if green and faster, make it the default in runWarp (warp.hip) and add the kernel-name assert to tests/test_warp_gpu.py
 #   mix              tools/probes/mix.hip: what HBM delivers for each rolling kernel's read : write mix with loads and stores alone
 #   refsuite         the reference's own opencv_test_imgproc on the hooks (Makefile build and cmake build) with the decline ledger
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
@@ -44,6 +46,8 @@ PY
     gran)      (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 gran.hip -o /tmp/gran 2>/dev/null) && /tmp/gran | tee $O/${T}.txt ;;
     pyr-ab)    timeout 600 python tools/pyr_ab.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
     taps)      timeout 300 python tools/warp_taps_bench.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
+    taps-tile) MI355CV_WARP_TAPS_TILE=1 timeout 600 python -m pytest tests/test_warp_gpu.py tests/test_batch_gpu.py -m gpu -q -k "cubic or geometry or 64f" --timeout 400 > $O/${T}_tests.log 2>&1; echo "taps-tile tests rc $?"; tail -5 $O/${T}_tests.log | cut -c1-300
+               MI355CV_WARP_TAPS_TILE=1 timeout 300 python tools/warp_taps_bench.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
     mix)       (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix.hip -o /tmp/mix 2>/dev/null) && timeout 120 /tmp/mix | tee $O/${T}.txt ;;
     refsuite)  MI355CV_WRITE_LEDGER=1 timeout 1500 python -m pytest tests/test_reference_suite.py tests/test_cmake_reference_build.py -m gpu -q --timeout 1400 > $O/${T}.log 2>&1; echo "refsuite rc $?"; tail -6 $O/${T}.log | cut -c1-300 ;;
     *)         echo "unknown recipe $rec"; exit 2 ;;
