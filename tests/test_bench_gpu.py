@@ -18,7 +18,16 @@ def run(args, env=None):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                      # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+    assert lines[0] == p.stdout.strip().splitlines()[-1] and len(lines[0]) < 4096, len(lines[0])      # the LAST stdout line, small enough for the driver's parser
+    compact = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "scaling", "config", "roofline"):
+        assert k in compact, k
+    detail = [l for l in p.stderr.splitlines() if l.startswith('{"metric"')]
+    assert len(detail) == 1                                       # the whole record goes to stderr (and bench_detail.json)
+    d = json.loads(detail[0])
+    assert d["value"] == compact["value"] and d["roofline"]["frac"] == compact["roofline"]["frac"]
+    d["_compact"] = compact
+    return d
 
 
 def test_single_gpu_line():
@@ -32,6 +41,20 @@ def test_single_gpu_line():
     assert d["config"]["launches_per_step"] == 2 and r["launches_timed"] == 6
     assert r["algorithmic_bytes_per_launch"] == 2 * 128 * 3840 * 2160
     assert d["parity"]["result"] == "bit-exact"
+
+
+def test_default_command_line_is_parseable_and_small():
+    """the driver's own command shape (other configs, CPU baseline and PMC passes ON; only the step count reduced): the last stdout line must json.loads,
+    stay under 4 KB and carry roofline + cpu_baseline + the summary (r04's 20.5 KB line came back "parsed": null)"""
+    d = run(["--steps", "2", "--warmup", "1", "--batch", "512"])
+    c = d["_compact"]
+    assert c["roofline"]["bound"] == "hbm" and c["roofline"]["traffic"] and 0 < c["roofline"]["frac"] < 1
+    cb = c["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and len(cb["sample"]) <= 200
+    assert "headline" in c["summary"] and "cfg5" in c["summary"] and "cfg3c" in c["summary"]
+    assert isinstance(d["other_configs"], list) and len(d["other_configs"]) > 40          # the long form is in the detail record only
+    assert "other_configs" not in c and "traffic_detail" not in c["roofline"]
+    assert os.path.exists(os.path.join(ROOT, "bench_detail.json"))
 
 
 def test_two_ranks_share_one_gpu():
