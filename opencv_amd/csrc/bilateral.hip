@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_minmax_f32(const uchar* __restrict__ sr
     }
 }
 
-struct BilArgsF { int W, H, radius, maxk, border; float scale_index; };
+struct BilArgsF { int W, H, radius, maxk, border; float scale_index; int bins; };
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_bilateral_f32(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, BilArgsF a,
@@ -167,8 +167,9 @@ __global__ __launch_bounds__(256) void k_bilateral_f32(const uchar* __restrict__
             float cw = 1.f;
             if (!cnan) {
                 float alpha = __fmul_rn(dist, a.scale_index);
-                const int idx = (int)floorf(alpha);
+                int idx = (int)floorf(alpha);
                 alpha = __fsub_rn(alpha, (float)idx);
+                idx = min(max(idx, 0), a.bins);                                  // backstop only (non-finite pixels): in-range inputs never reach it, the host declines the rest
                 const float l0 = lut[idx], l1 = lut[idx + 1];
                 cw = __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0)));
             }
@@ -207,6 +208,12 @@ int bilateral32f(const uchar* src_data, size_t src_step, uchar* dst_data, size_t
         return setError(MI355CV_ERROR_UNKNOWN, "bilateralFilter: %s", hipGetErrorString(hipGetLastError()));
     auto unkey = [](int k) { const int i = k >= 0 ? k : k ^ 0x7fffffff; float f; memcpy(&f, &i, 4); return f; };
     const double mn = unkey(got[0]), mx = unkey(got[1]);
+    // the table spans the image's own [mn, mx] only (:262-300) and the reference indexes it unchecked (bilateral_filter.simd.hpp:679): values outside that range --
+    // +-Inf pixels, or the zeros of a BORDER_CONSTANT halo when 0 is not inside [mn, mx] -- walk off its heap block there, and would fault the whole process here.  Declined.
+    if (!std::isfinite(mn) || !std::isfinite(mx))
+        return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: CV_32F image with non-finite values (the colour table cannot span them)");
+    if (border == B_CONSTANT && (mn > 0.0 || mx < 0.0))
+        return setError(MI355CV_NOT_IMPLEMENTED, "bilateralFilter: CV_32F with BORDER_CONSTANT and 0 outside the image's value range [%g, %g] (the colour table does not reach the border value)", mn, mx);
     if (std::fabs(mn - mx) < 1.1920928955078125e-7) {                          // a constant image is copied (:252-256)
         if (hipMemcpy2DAsync(dd, dds, ds, dss, (size_t)width * cn * 4, height, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return setError(MI355CV_ERROR_UNKNOWN, "bilateralFilter: %s", hipGetErrorString(hipGetLastError()));
@@ -235,7 +242,7 @@ int bilateral32f(const uchar* src_data, size_t src_step, uchar* dst_data, size_t
     const float* dsw = (const float*)stg.param(sw.data(), sw.size() * sizeof(float));
     const short2* dof = (const short2*)stg.param(of.data(), of.size() * sizeof(short));
     if (!dlut || !dsw || !dof) return mi355::declined(__func__, __LINE__, "!dlut || !dsw || !dof");
-    BilArgsF a; a.W = width; a.H = height; a.radius = radius; a.maxk = maxk; a.border = border; a.scale_index = scale_index;
+    BilArgsF a; a.W = width; a.H = height; a.radius = radius; a.maxk = maxk; a.border = border; a.scale_index = scale_index; a.bins = bins;
     const int tw = BT_W + 2 * radius, th = BT_H + 2 * radius;
     const size_t lds = (size_t)maxk * 8 + (size_t)tw * th * cn * 4;
     dim3 grid(divUp(width, BT_W), divUp(height, BT_H));
@@ -258,6 +265,7 @@ int bilateral32f(const uchar* src_data, size_t src_step, uchar* dst_data, size_t
 extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                    int depth, int cn, int d, double sigma_color, double sigma_space, int border_type)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data))
         return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data)");
     const int isolated = border_type & MI355CV_BORDER_ISOLATED;

@@ -245,6 +245,7 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_step, uchar* y_data, size_t y_step, uchar* uv_data, size_t uv_step,
                                             int width, int height, int scn, bool swapBlue, int uIdx)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -264,6 +265,7 @@ MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int scn, bool swapBlue, int uIdx)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     MISC_PROLOGUE(width * scn, height, width, height * 3 / 2);
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
@@ -277,6 +279,7 @@ MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_
 MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                             int dcn, bool swapBlue, int uIdx, int ycn)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
@@ -289,6 +292,7 @@ MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                             int scn, bool swapBlue, int uIdx, int ycn)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
@@ -301,6 +305,7 @@ MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : 2;
     MISC_PROLOGUE(width * scn * e, height, width * 3 * e, height);
@@ -318,6 +323,7 @@ MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : 2;
     MISC_PROLOGUE(width * 3 * e, height, width * dcn * e, height);
@@ -335,6 +341,7 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int scn, bool swapBlue, int greenBits)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
     if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<3>{swapBlue ? 2 : 0, greenBits});
@@ -345,6 +352,7 @@ MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, u
 MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int dcn, bool swapBlue, int greenBits)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
     if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpFrom5x5<3>{swapBlue ? 2 : 0, greenBits});
@@ -354,6 +362,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, u
 
 MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width, height);
     pix4::launch<2, 1>(st, ds, dss, dd, dds, width, height, Op5x5ToGray{greenBits});
@@ -362,6 +371,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width, height, width * 2, height);
     pix4::launch<1, 2>(st, ds, dss, dd, dds, width, height, OpGrayTo5x5{greenBits});
@@ -370,6 +380,7 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<false>{});
@@ -378,6 +389,7 @@ MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t sr
 
 MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<true>{});

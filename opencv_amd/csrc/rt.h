@@ -39,6 +39,9 @@ int  setError(int code, const char* fmt, ...);
 // a hook answers NOT_IMPLEMENTED: records WHY for mi355cv_lastError and the decline ledger (mi355cv_noteDecline) -- "<entry>:<line>: <the condition that held>" --
 // unless a more specific reason was already recorded during this call (staging failure, host-policy threshold, foreign device ...).  Returns MI355CV_NOT_IMPLEMENTED.
 int  declined(const char* fn, int line, const char* cond);
+// first line of every extern "C" entry: the outermost entry on a thread starts a new call serial, so that a reason recorded by an EARLIER call that failed before it
+// opened a Stager (argument checks, runSharded / replicate errors) is never reported as this call's; nested entries keep their caller's serial
+struct EntryGuard { EntryGuard(); ~EntryGuard(); EntryGuard(const EntryGuard&) = delete; EntryGuard& operator=(const EntryGuard&) = delete; };
 void beginCall();                   // start of a hook invocation (Stager's constructor): reasons recorded by earlier calls no longer count as this call's
 void bump(const char* entry);       // per-entry completed-on-GPU counter
 void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)

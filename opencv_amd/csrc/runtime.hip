@@ -91,6 +91,9 @@ int declined(const char* fn, int line, const char* cond)
     return setError(MI355CV_NOT_IMPLEMENTED, "%s:%d: outside the GPU path because (%s)", fn, line, cond ? cond : "no branch of the dispatcher takes this argument combination");
 }
 void beginCall() { ++t_serial; }
+static thread_local int t_entryDepth = 0;
+EntryGuard::EntryGuard() { if (t_entryDepth++ == 0) ++t_serial; }
+EntryGuard::~EntryGuard() { --t_entryDepth; }
 
 // MI355CV_PRINT_COUNTS=1: at process exit, one line per entry point with the number of calls the GPU served -- how a host program that
 // cannot call mi355cv_callCount (the reference's own test binary, tests/test_reference_suite.py) shows that its cv:: calls ran here

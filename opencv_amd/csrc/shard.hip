@@ -35,6 +35,7 @@ MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int g, int* first, in
 // with mi355cv_lastError() of the CALLING thread naming the slot, its device and the failing thread's own error text.
 MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, int (*fn)(void* user, int slot, int device, int first, int count), void* user, int bind)
 {
+    mi355::EntryGuard entry_;
     if (ndev < 1 || ndev > 64 || nframes < 0 || !fn) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_runSharded: ndev %d (1 .. 64), nframes %d, fn %p", ndev, nframes, (void*)fn);
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> why(ndev);
@@ -45,14 +46,18 @@ MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, in
         mi355cv_shardRange(nframes, ndev, g, &first, &count);
         if (count <= 0) continue;
         const int dev = devices ? devices[g] : g;
-        th.emplace_back([&, g, dev, first, count] {
+        auto body = [&, g, dev, first, count] {
             try {
                 if (bind && mi355cv_setDevice(dev) != 0) { rc[g] = MI355CV_ERROR_UNKNOWN; why[g] = mi355cv_lastError(); return; }
                 rc[g] = fn(user, g, dev, first, count);
                 if (rc[g] != 0) why[g] = mi355cv_lastError();
                 if (bind) { if (rc[g] == 0 && mi355cv_synchronize() != 0) { rc[g] = MI355CV_ERROR_UNKNOWN; why[g] = mi355cv_lastError(); } (void)mi355cv_setDevice(-1); }
             } catch (...) { rc[g] = MI355CV_ERROR_UNKNOWN; why[g] = "exception in the shard function"; }      // nothing may cross the C boundary
-        });
+        };
+        // std::thread's constructor throws std::system_error when the process is out of threads (EAGAIN): the slot then runs here, on the calling thread, after
+        // which the threads already started are joined as usual -- no exception leaves this extern "C" function with joinable threads behind it
+        try { th.emplace_back(body); }
+        catch (...) { body(); }
     }
     for (auto& t : th) t.join();
     for (int g = 0; g < ndev; g++)
@@ -65,6 +70,7 @@ MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, in
 // to that device (or hipFree).  Returns 0, or -1 after freeing whatever it had allocated.
 MI355CV_API int mi355cv_replicate(const void* src, size_t bytes, int ndev, const int* devices, void** out)
 {
+    mi355::EntryGuard entry_;
     if (!src || !out || ndev < 1 || ndev > 64 || !bytes) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: bad arguments");
     const int before = threadDeviceBinding();
     int done = 0, rc = 0;

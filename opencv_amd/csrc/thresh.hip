@@ -145,6 +145,7 @@ extern "C" MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double
 extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                      double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return mi355::declined(__func__, __LINE__, "(adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)");
     if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return mi355::declined(__func__, __LINE__, "blockSize < 3 || !(blockSize & 1) || blockSize > 255");
@@ -189,6 +190,7 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
 extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                              int depth, int cn, double thresh, double maxValue, int thresholdType)
 {
+    mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4");
     if (thresholdType < 0 || thresholdType > 4) return mi355::declined(__func__, __LINE__, "thresholdType < 0 || thresholdType > 4");
     if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return mi355::declined(__func__, __LINE__, "depth != D8U && depth != D16U && depth != D16S && depth != D32F");
@@ -224,6 +226,7 @@ extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t 
                                                   size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn, double thresh, double maxValue,
                                                   int thresholdType)
 {
+    mi355::EntryGuard entry_;
     if (nframes < 1 || height <= 0) return mi355::declined(__func__, __LINE__, "nframes < 1 || height <= 0");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(depth), height, nframes};

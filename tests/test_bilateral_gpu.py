@@ -56,6 +56,24 @@ def test_bilateral_filter_32f(cv, orc, cn):
     assert np.abs(cv.bilateralFilter(img, 7, 0.4, 3.0) - orc.orc_bilateralFilter(img, 7, 0.4, 3.0)).max() <= 3e-6       # host arrays
 
 
+def test_bilateral_32f_values_the_colour_table_cannot_span_are_declined(cv, orc):
+    """the CV_32F colour table covers the image's own [min, max] only and is indexed unchecked (bilateral_filter.simd.hpp:679).  The zeros of a BORDER_CONSTANT halo
+    with 0 outside that range, and +-Inf pixels, would index far beyond it (a fault on the GPU): those calls are declined, everything in range is still served."""
+    rng = np.random.default_rng(5)
+    src = (1000 + 10 * rng.random((40, 60), dtype=np.float32)).astype(np.float32)
+    dev = torch.from_numpy(src).cuda()
+    with pytest.raises(NotImplementedError):
+        cv.bilateralFilter(dev, 5, 0.3, 2.0, 0)                                   # BORDER_CONSTANT, 0 not in [1000, 1010]
+    got = cv.bilateralFilter(dev, 5, 0.3, 2.0, 4).cpu().numpy()                   # any replicated border: served
+    assert np.abs(got - orc.orc_bilateralFilter(src, 5, 0.3, 2.0, 4)).max() <= 3e-3
+    neg = (src - 1005).astype(np.float32)                                        # 0 inside the range: BORDER_CONSTANT served
+    got = cv.bilateralFilter(torch.from_numpy(neg).cuda(), 5, 0.3, 2.0, 0).cpu().numpy()
+    assert np.abs(got - orc.orc_bilateralFilter(neg, 5, 0.3, 2.0, 0)).max() <= 3e-5
+    inf = neg.copy(); inf[7, 9] = np.inf
+    with pytest.raises(NotImplementedError):
+        cv.bilateralFilter(torch.from_numpy(inf).cuda(), 5, 0.3, 2.0, 4)
+
+
 def test_bilateral_row_range_is_filtered_as_an_image_of_its_own(cv, orc):
     """cv_hal_bilateralFilter carries no margins (hal_replacement.hpp:1068): a full-width row range of a larger image is dense, so the hook cannot tell it
     from a whole image and filters it with the border rule at its first and last rows, where cv::bilateralFilter's own code path pads with the
