@@ -544,6 +544,8 @@ __global__ __launch_bounds__(256) void k_corner_roll(const uchar* __restrict__ s
     constexpr int NS = NP + 3;                         // source columns x0-2+m / x0-2+NP+m
     Cx cx;
     if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    __shared__ __attribute__((aligned(16))) uchar tscratch[4 * Cx::template tldsBytesPerWave<4>()];      // roll.h: transposed stores
+    cx.useLds(tscratch, Cx::template tldsBytesPerWave<4>());
     dst += (size_t)cx.frame * dframe;
     struct RowR { f32x2 d[NC], s[NC]; };               // the two row passes of one source row
     struct RowC { f32x2 a[NC], b[NC], c[NC]; };        // dx*dx, dx*dy, dy*dy of one derivative row
@@ -662,6 +664,184 @@ __global__ __launch_bounds__(256) void k_corner_roll(const uchar* __restrict__ s
     }
 }
 
+// ---------------------------------------------------------------------------------- cornerHarris, packed rolling path (the default for CV_8U, ksize 3, blockSize 2)
+// The same walk as k_corner_roll, with the Sobel passes held as PACKED HALVES and the products formed by v_dot2_f32_f16 (round 5; k_corner_roll<true, 8> held its rows
+// as float pairs: 169 VGPRs, 2 waves per SIMD, 22 VALU per pixel -- issue-bound at 0.52 of the roofline, profiles/r04_why_slow_call1.txt).  Every intermediate is a small
+// integer, so half precision is EXACT here (integers up to 2048 are halves):
+//   * a source row becomes pairs of adjacent columns as halves with one v_perm per pair (bytes 0x64 : p = the half 1024 + p) and one packed subtract of 1024;
+//   * its row passes d = p[x+1] - p[x-1] (|d| <= 255) and s = p[x-1] + 2 p[x] + p[x+1] (<= 1020): 3 packed instructions per 2 columns;
+//   * the column passes dx = d0 + 2 d1 + d2, dy = s2 - s0 (|.| <= 1020): 3 more, still exact, where the reference rounds scaled floats at every tap;
+//   * the horizontal half of the 2x2 box is one v_dot2_f32_f16 on a (column x-1, column x) pair: dx.dx, dx.dy, dy.dy <= 2 * 1020^2 < 2^24, exact in float whatever the
+//     order of the hardware's internal roundings; the vertical half is a float add of two such integers (<= 2^23) -- so the three box sums A', B', C' are EXACT integers, and
+//     the only roundings are the six float operations of the response  R = s^4 (A'C' - B'^2) - k s^4 (A' + C')^2,  s = 1 / (2^(ksize-1) * blockSize * 255)  (corner.cpp:247-252:
+//     the reference scales the Sobel taps by s and rounds at every tap, product and -- in double -- box step; its A = s^2 A' (1 + O(1e-7))).
+//   Against the reference's own result the response differs by the reference's rounding noise: < 1e-6 of the global norm (bar: 1e-4, tests/test_corner_gpu.py).
+// Upward-walking segments see Dy negated: only B'^2 is used.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+struct HarrisPArgs { float s4, ks4; };
+
+// FAST: the launch serves the waves whose row pieces take the transposed store (roll.h), the !FAST launch the others (a ragged last strip, a window edge): one kernel with
+// both stores in it needed 194 VGPRs -- the element-wise store of partial chunks is the register hog --, this one 120.
+template <int RD, bool FAST>                             // RD: source rows in flight, a multiple of the three-slot row ring
+__global__ __launch_bounds__(256) void k_harris_roll_p(const uchar* __restrict__ src, size_t sstep, size_t sframe,
+                                                       uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                       int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
+                                                       HarrisPArgs a)
+{
+    typedef roll::Ctx<2, 2, 1, 8> Cx;
+    typedef typename Cx::RawT RawT;
+    constexpr int NW = Cx::NW;                           // 4 window dwords: columns x0-4 .. x0+11
+    constexpr int NJ = 5;                                // packed pairs of columns (2j-1, 2j), j = 0 .. 4: columns x0-1 .. x0+8
+    Cx cx;
+    if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt)) return;
+    __shared__ __attribute__((aligned(16))) uchar tscratch[4 * Cx::template tldsBytesPerWave<4>()];      // roll.h: the wave's 2 KiB row piece is transposed through LDS into 1 KiB stores
+    cx.useLds(tscratch, Cx::template tldsBytesPerWave<4>());
+    if (cx.transposes() != FAST) return;
+    dst += (size_t)cx.frame * dframe;
+    struct RowR { h16x2 d[NJ], s[NJ]; };                 // the two row passes of one source row, packed
+    struct RowH { f32x2 a[4], b[4], c[4]; };             // (column x-1) + (column x) of dx*dx, dx*dy, dy*dy of one derivative row, pixels (2i, 2i+1)
+    const int qx = mi355_borderInterpolate(-1, W, border);
+    const bool fixL = cx.hasFirst && cx.lane == 0;
+    const h16x2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, k2 = {(_Float16)2.f, (_Float16)2.f};
+
+    auto rowPasses = [&](RowR& r, RawT raw, int valid) {
+        uint32_t X[NW];
+        if (!valid) {                                    // BORDER_CONSTANT row (window() only moves bytes)
+#pragma unroll
+            for (int d = 0; d < Cx::MD; d++) raw.m[d] = 0;
+            raw.side[0] = 0;
+        }
+        cx.window(X, raw);
+        h16x2 P[NJ + 1];                                 // columns (2j-2, 2j-1) = window bytes (2j+2, 2j+3), as halves
+#pragma unroll
+        for (int j = 0; j <= NJ; j++)
+            P[j] = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, X[(2 * j + 2) >> 2], ((2 * j + 2) & 3) ? 0x04030402u : 0x04010400u)) - k1024;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const h16x2 C = __builtin_bit_cast(h16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, P[j + 1]), __builtin_bit_cast(uint32_t, P[j]), 16));   // columns (2j-1, 2j)
+            r.d[j] = P[j + 1] - P[j];
+            r.s[j] = __builtin_elementwise_fma(C, k2, P[j] + P[j + 1]);
+        }
+    };
+    auto products = [&](RowH& o, const RowR& r0, const RowR& r1, const RowR& r2) {
+        uint32_t dx[NJ], dy[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            dx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(r1.d[j], k2, r0.d[j] + r2.d[j]));
+            dy[j] = __builtin_bit_cast(uint32_t, r2.s[j] - r0.s[j]);
+        }
+        // the covariance column left of x = 0 is a copy of covariance column borderInterpolate(-1) (or zero)
+        const uint32_t sx = qx < 0 ? 0u : (qx == 0 ? dx[0] >> 16 : dx[1] & 0xffffu);
+        const uint32_t sy = qx < 0 ? 0u : (qx == 0 ? dy[0] >> 16 : dy[1] & 0xffffu);
+        dx[0] = fixL ? ((dx[0] & 0xffff0000u) | sx) : dx[0];
+        dy[0] = fixL ? ((dy[0] & 0xffff0000u) | sy) : dy[0];
+        // pixel 2i: columns (2i-1, 2i) = pair i; pixel 2i+1: columns (2i, 2i+1) = the high half of pair i and the low half of pair i+1
+        uint32_t xo[4], yo[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xo[i] = __builtin_amdgcn_alignbit(dx[i + 1], dx[i], 16); yo[i] = __builtin_amdgcn_alignbit(dy[i + 1], dy[i], 16); }
+        // 24 v_dot2_f32_f16 with an inline-zero accumulator in ONE asm statement.  The builtin selects v_dot2c_f32_f16, whose accumulator is its destination: a v_mov 0 per
+        // product, 24 per row.  Inline asm is opaque to the compiler's hazard recognizer, and a DOT result must not be read by another VALU instruction within 3 wait states
+        // (one asm per product gave one wrong pixel per turn of the unrolled loop on the MI355X): inside the block no product reads another's result, and the trailing
+        // s_nop 2 covers the last ones; the early-clobber outputs keep every result off the inputs still to be read.
+        float h[24];
+        asm("v_dot2_f32_f16 %0, %24, %24, 0\n\t"
+                "v_dot2_f32_f16 %1, %28, %28, 0\n\t"
+                "v_dot2_f32_f16 %2, %24, %32, 0\n\t"
+                "v_dot2_f32_f16 %3, %28, %36, 0\n\t"
+                "v_dot2_f32_f16 %4, %32, %32, 0\n\t"
+                "v_dot2_f32_f16 %5, %36, %36, 0\n\t"
+                "v_dot2_f32_f16 %6, %25, %25, 0\n\t"
+                "v_dot2_f32_f16 %7, %29, %29, 0\n\t"
+                "v_dot2_f32_f16 %8, %25, %33, 0\n\t"
+                "v_dot2_f32_f16 %9, %29, %37, 0\n\t"
+                "v_dot2_f32_f16 %10, %33, %33, 0\n\t"
+                "v_dot2_f32_f16 %11, %37, %37, 0\n\t"
+                "v_dot2_f32_f16 %12, %26, %26, 0\n\t"
+                "v_dot2_f32_f16 %13, %30, %30, 0\n\t"
+                "v_dot2_f32_f16 %14, %26, %34, 0\n\t"
+                "v_dot2_f32_f16 %15, %30, %38, 0\n\t"
+                "v_dot2_f32_f16 %16, %34, %34, 0\n\t"
+                "v_dot2_f32_f16 %17, %38, %38, 0\n\t"
+                "v_dot2_f32_f16 %18, %27, %27, 0\n\t"
+                "v_dot2_f32_f16 %19, %31, %31, 0\n\t"
+                "v_dot2_f32_f16 %20, %27, %35, 0\n\t"
+                "v_dot2_f32_f16 %21, %31, %39, 0\n\t"
+                "v_dot2_f32_f16 %22, %35, %35, 0\n\t"
+                "v_dot2_f32_f16 %23, %39, %39, 0\n\t"
+            "s_nop 2"
+            : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]), "=&v"(h[8]), "=&v"(h[9]), "=&v"(h[10]), "=&v"(h[11]),
+              "=&v"(h[12]), "=&v"(h[13]), "=&v"(h[14]), "=&v"(h[15]), "=&v"(h[16]), "=&v"(h[17]), "=&v"(h[18]), "=&v"(h[19]), "=&v"(h[20]), "=&v"(h[21]), "=&v"(h[22]), "=&v"(h[23])
+            : "v"(dx[0]), "v"(dx[1]), "v"(dx[2]), "v"(dx[3]), "v"(xo[0]), "v"(xo[1]), "v"(xo[2]), "v"(xo[3]),
+              "v"(dy[0]), "v"(dy[1]), "v"(dy[2]), "v"(dy[3]), "v"(yo[0]), "v"(yo[1]), "v"(yo[2]), "v"(yo[3]));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o.a[i] = f32x2{h[6 * i], h[6 * i + 1]};
+            o.b[i] = f32x2{h[6 * i + 2], h[6 * i + 3]};
+            o.c[i] = f32x2{h[6 * i + 4], h[6 * i + 5]};
+        }
+    };
+    // response row y from the box rows p (kept) and c (new); c replaces p
+    auto emit = [&](auto fastTag, RowH& p, const RowH& c, int y) {
+        uint32_t ow[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f32x2 A = p.a[i] + c.a[i], B = p.b[i] + c.b[i], C = p.c[i] + c.c[i];
+            p.a[i] = c.a[i]; p.b[i] = c.b[i]; p.c[i] = c.c[i];
+            const f32x2 det = __builtin_elementwise_fma(-B, B, A * C);
+            const f32x2 ac = A + C;
+            const f32x2 r = __builtin_elementwise_fma(f32x2{-a.ks4, -a.ks4}, ac * ac, det * f32x2{a.s4, a.s4});
+            ow[2 * i] = __float_as_uint(r.x); ow[2 * i + 1] = __float_as_uint(r.y);
+        }
+        if constexpr (decltype(fastTag)::value) cx.template storeT<4>(dst, dstep, y, ow);
+        else cx.template storeLanes<4>(dst, dstep, y, ow);
+    };
+
+    // rows in walking order exactly as in k_corner_roll: c_0 (prologue), c_1 .. c_n; step t emits image row gy(t-1) from (c_{t-1}, c_t)
+    const int o = cx.up;
+    RowR R[3]; RowH Hp;
+    {
+        RawT r0, r1, r2; int v0, v1, v2;
+        const bool virt = !cx.up && cx.y0 == 0;          // c_0 is the covariance row above the image
+        const int qy = mi355_borderInterpolate(-1, H, border);
+        if (virt) { const int q = max(qy, 0); cx.issueImg(r0, q - 1, v0); cx.issueImg(r1, q, v1); cx.issueImg(r2, q + 1, v2); }
+        else { cx.issueImg(r0, cx.gy(o - 2), v0); cx.issueImg(r1, cx.gy(o - 1), v1); cx.issueImg(r2, cx.gy(o), v2); }
+        rowPasses(R[0], r0, v0); rowPasses(R[1], r1, v1); rowPasses(R[2], r2, v2);
+        products(Hp, R[0], R[1], R[2]);
+        if (virt) {
+            if (qy < 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { Hp.a[i] = f32x2{0.f, 0.f}; Hp.b[i] = f32x2{0.f, 0.f}; Hp.c[i] = f32x2{0.f, 0.f}; }
+            }
+            cx.issueImg(r1, -1, v1); cx.issueImg(r2, 0, v2);
+            rowPasses(R[1], r1, v1); rowPasses(R[2], r2, v2);
+        }
+    }
+    RawT raw[RD]; int rv[RD];
+#pragma unroll
+    for (int u = 0; u < RD; u++) cx.issue(raw[u], o + 1 + u, rv[u]);
+    // The walk: whole turns of RD rows run without a condition inside (the compiler then counts the loads and stores in flight instead of draining them at every row);
+    // the last, partial turn tests each row.  Which store a wave uses is decided once, here.
+    auto walk = [&](auto fastTag) {
+        auto step = [&](int t, int u) {
+            rowPasses(R[u % 3], raw[u], rv[u]);
+            cx.issue(raw[u], t + u + o + RD, rv[u]);
+            RowH Hn;
+            products(Hn, R[(u + 1) % 3], R[(u + 2) % 3], R[u % 3]);
+            emit(fastTag, Hp, Hn, cx.gy(t + u - 1));
+            __builtin_amdgcn_sched_barrier(0);               // rows are not interleaved by the scheduler (it otherwise keeps several rows' intermediates live: 190 VGPRs)
+        };
+        int t = 1;
+        for (; t + RD - 1 <= cx.nrows; t += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; u++) step(t, u);
+        }
+#pragma unroll
+        for (int u = 0; u < RD - 1; u++)
+            if (t + u <= cx.nrows) step(t, u);
+    };
+    walk(std::integral_constant<bool, FAST>{});
+}
+
 bool derivTaps(int order, int ksize, bool scharr, std::vector<int>& k)
 {
     if (scharr) { if (order == 0) k = {3, 10, 3}; else k = {-1, 0, 1}; return true; }
@@ -702,6 +882,18 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
     a.rx = std::max(a.dxNRow, a.dyNRow) / 2; a.ry = std::max(a.dxNCol, a.dyNCol) / 2;
     if (sdepth == D8U && ksize == 3 && blockSize == 2 && H >= 2 && std::getenv("MI355CV_CORNER_LDS") == nullptr &&
         (((uintptr_t)dd | dds | dframe) & 3) == 0 && roll::eligible(ds, dss, sframe, ds, dss, sframe, W, 1, 2, border, 8)) {
+        if (harris && std::getenv("MI355CV_CORNER_FLOATROLL") == nullptr) {          // the packed-half rolling kernel; the float one stays for cornerMinEigenVal and as the A/B partner
+            const double s2 = scale * scale;
+            HarrisPArgs ia = {(float)(s2 * s2), (float)((double)a.kf * s2 * s2)};
+            const char* segEnv = std::getenv("MI355CV_CORNER_SEG");               // tuning experiments
+            const roll::Geom g = roll::geometry(W, H, 1, nframes, segEnv ? atoi(segEnv) : 36, 4, 8);
+#define HROLL(RD_, FAST_) hipLaunchKernelGGL((k_harris_roll_p<RD_, FAST_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, 1, ia)
+            HROLL(3, true);                                                       // (6 rows in flight measured the same: profiles/r05_harris.txt)
+            if (W % 8 != 0) HROLL(3, false);                                      // the ragged last strip of every row
+#undef HROLL
+            noteKernel("k_harris_roll_p grid=%u x256 seg=%d rows", g.blocks, g.seg);
+            return MI355CV_OK;
+        }
         CornerRollArgs ra = {a.dyRow[0], a.dyRow[1], a.dyRow[2], a.dxCol[1], a.dxCol[2], a.kf};
         const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W >= 16;
         const char* segEnv = std::getenv("MI355CV_CORNER_SEG");               // tuning experiments

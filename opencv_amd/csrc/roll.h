@@ -74,6 +74,8 @@ struct Ctx {
     bool active, hasFirst, hasLast, isLastChunk, rag;
     int vb;                                            // valid bytes of the last chunk (CB unless the row is ragged)
     int wx0, wx1, wy0;                                 // window: byte range of a row that is stored, first row (whole image: 0, W*CN, 0)
+    int tChunks, tByte0;                               // transposed store (below): chunks of this strip that are stored whole (0: the per-lane store is used), first byte of the strip
+    uchar* tlds;                                       // this wave's LDS scratch for it (useLds), or nullptr
     Edge<HD, MD> es;
     int rowBelow[RY > 0 ? RY : 1], rowAbove[RY > 0 ? RY : 1];
 
@@ -111,6 +113,10 @@ struct Ctx {
         active = c <= cB; hasFirst = c0 == 0; hasLast = c0 + 64 >= nchunks; isLastChunk = c == nchunks - 1;
         vb = W * CN - CB * (nchunks - 1);
         rag = vb < CB;
+        // the strip stores whole chunks only (no window edge inside it, no ragged last chunk): its row piece is min(64, chunks left) * CB * OUTB contiguous bytes
+        tByte0 = CB * c0 - win.x0b;
+        tChunks = (win.x0b % CB == 0 && (win.x1b % CB == 0 || c0 + 64 <= cB) && !(rag && hasLast)) ? min(64, cB + 1 - c0) : 0;
+        tlds = nullptr;
         mainOff = CB * (live ? c : nchunks - 1);
         if (rag && (!live || isLastChunk)) mainOff = W * CN - CB;        // the last CB bytes of the row
         const int leftOff = c0 > 0 ? CB * c0 - 4 * HD : 0;
@@ -222,8 +228,50 @@ struct Ctx {
     }
     // the lane's outputs of image row y (OUTB bytes per source byte) -> memory; a ragged last chunk writes its valid elements only, the first / last
     // chunk of a window the elements inside it
+    // LDS scratch of the transposed store: NPC = MD * OUTB / 4 pieces of 16 bytes per lane, one region of 64 pieces (+ 128 bytes of skew) per piece index
+    template <int OUTB> static constexpr int tldsBytesPerWave() { return (MD * OUTB / 4) * (1024 + 128); }
+    __device__ __forceinline__ void useLds(uchar* blockScratch, int bytesPerWave) { tlds = blockScratch + (threadIdx.x >> 6) * bytesPerWave; }
+
     template <int OUTB>
     __device__ __forceinline__ void store(uchar* __restrict__ dst, size_t dstep, int y, const uint32_t (&o)[MD * OUTB]) const
+    {
+        // A lane that owns more than 16 output bytes of a row (8U -> 16S / 32F: 32 or 64) used to write them as NPC 16-byte stores at a lane stride of 16 * NPC bytes: every
+        // store instruction then touches each 64-byte line partially, and HBM delivers half of what contiguous stores get (profiles/r05_store_geometry_probe.txt: 1 : 4 mix
+        // 0.45 of the roofline with 2 x 16 B per lane against 0.67 with 1 x 16 B; fill only 0.31 against 0.70).  So the wave TRANSPOSES its row piece through LDS first:
+        // piece h of lane L goes to region h at 16 L (contiguous ds_write_b128), store instruction q then takes piece 64 q + L of the row piece -- piece (64 q + L) % NPC of
+        // lane (64 q + L) / NPC -- back (ds_read_b128; the 128-byte skew between regions makes the 16-lane groups of the read conflict-free for NPC = 2) and writes 1 KiB of
+        // the row contiguously.  The scratch is private to the wave and LDS operations of one wave execute in order: no barrier, no double buffer.
+        if constexpr (MD * OUTB > 4) {
+            if (transposes()) { storeT<OUTB>(dst, dstep, y, o); return; }
+        }
+        storeLanes<OUTB>(dst, dstep, y, o);
+    }
+    // wave-uniform: this wave's row pieces go through the transposed store (kernels may hoist the test and call storeT / storeLanes themselves)
+    __device__ __forceinline__ bool transposes() const { return tlds != nullptr && tChunks > 0; }
+    template <int OUTB>
+    __device__ __forceinline__ void storeT(uchar* __restrict__ dst, size_t dstep, int y, const uint32_t (&o)[MD * OUTB]) const
+    {
+        constexpr int NPC = MD * OUTB / 4, RS = 1024 + 128;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int h = 0; h < NPC; h++)
+            *reinterpret_cast<u32x4*>(tlds + h * RS + 16 * lane) = u32x4{o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uchar* rowp = dst + (size_t)(y - wy0) * dstep + (ptrdiff_t)tByte0 * OUTB;
+        const int np = tChunks * NPC;
+#pragma unroll
+        for (int q = 0; q < NPC; q++) {
+            const int pc = 64 * q + lane;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tlds + (pc % NPC) * RS + 16 * (pc / NPC));
+            if (pc < np) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rowp) + pc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next row's writes stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <int OUTB>
+    __device__ __forceinline__ void storeLanes(uchar* __restrict__ dst, size_t dstep, int y, const uint32_t (&o)[MD * OUTB]) const
     {
         if (!active) return;
         const int b0 = CB * c;                                                // first byte of the chunk in the parent row

@@ -67,8 +67,13 @@ __global__ __launch_bounds__(256) void k_sep_roll(const uchar* __restrict__ src,
                                                   int W, int H, int nchunks, int nstrips, int segRows, int nseg, int nframes, int border, int alt,
                                                   roll::Win win, typename P::Args a)
 {
-    roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB> cx;
+    typedef roll::Ctx<P::KX / 2, P::KY / 2, P::CN, P::CB> Cx;
+    Cx cx;
     if (!cx.init(src, sstep, sframe, W, H, nchunks, nstrips, segRows, nseg, nframes, border, alt, win)) return;
+    if constexpr ((P::CB / 4) * P::OUTB > 4) {           // a lane owns more than 16 output bytes of a row: roll.h transposes the wave's row piece through LDS into 1 KiB stores
+        __shared__ __attribute__((aligned(16))) uchar tscratch[4 * Cx::template tldsBytesPerWave<P::OUTB>()];
+        cx.useLds(tscratch, Cx::template tldsBytesPerWave<P::OUTB>());
+    }
     dst += (size_t)cx.frame * dframe;
     if (cx.up) sepRows<P, true>(cx, dst, dstep, a);
     else       sepRows<P, false>(cx, dst, dstep, a);
