@@ -19,6 +19,7 @@
 #                    next round; if green and faster, make it the default in runWarp (warp.hip) and add the kernel-name assert to tests/test_warp_gpu.py
 #   mix              tools/probes/mix.hip: what HBM delivers for each rolling kernel's read : write mix with loads and stores alone
 #   mix2             tools/probes/mix2.hip: the write-heavy mixes under different store geometries (pixels per lane, XCD banding, plain / nt stores)
+#   shift            tools/probes/shift.hip: a bilinear-tap pure shift of 8K float frames in k_warp_lin's geometry and in wider / row-walking ones
 #   ab <row> <settings..>  tools/env_ab.py: one bench row under several environment settings, each in its own process (last recipe on the line)
 #   refsuite         the reference's own opencv_test_imgproc on the hooks (Makefile build and cmake build) with the decline ledger
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
@@ -53,6 +54,7 @@ PY
     mix)       (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix.hip -o /tmp/mix 2>/dev/null) && timeout 120 /tmp/mix | tee $O/${T}.txt ;;
     refsuite)  MI355CV_WRITE_LEDGER=1 timeout 1500 python -m pytest tests/test_reference_suite.py tests/test_cmake_reference_build.py -m gpu -q --timeout 1400 > $O/${T}.log 2>&1; echo "refsuite rc $?"; tail -6 $O/${T}.log | cut -c1-300 ;;
     mix2)      (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix2.hip -o /tmp/mix2 2>/dev/null) && timeout 200 /tmp/mix2 | tee $O/${T}.txt ;;
+    shift)     (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 shift.hip -o /tmp/shift 2>/dev/null) && timeout 200 /tmp/shift | tee $O/${T}.txt ;;
     ab)        # ab <row> <setting> [<setting> ...]  (tools/env_ab.py; must be the last recipe on the line; "" = defaults)
                timeout 900 python tools/env_ab.py "$@" 2>&1 | tee -a $O/${T}.txt; break ;;
     *)         echo "unknown recipe $rec"; exit 2 ;;
