@@ -26,11 +26,11 @@ hipEvent_t pooledEvent(int i);      // per-thread reusable events (timing disabl
 bool asyncMode();
 bool disabled();                    // MI355CV_DISABLE=1 -> every hook answers NOT_IMPLEMENTED
 // Which host-resident images a hook accepts (device / managed pointers are always served).  MI355CV_MIN_PIXELS=<n>: images below n pixels
-// are declined.  MI355CV_HOST_POLICY=auto: a host image is staged through HBM only by hooks whose CPU path costs more than the two PCIe
+// are declined.  MI355CV_HOST_POLICY=auto (the default): a host image is staged through HBM only by hooks whose CPU path costs more than the two PCIe
 // crossings (HOST_HEAVY: the reference's single-threaded FilterEngine paths -- filter2D, sepFilter2D, Sobel, box -- and medianBlur, Canny,
 // corners, cubic / Lanczos / area resize, warps, LK, Otsu, bilateralFilter, float Lab / Luv); bandwidth-bound hooks whose CPU path is multi-threaded (HOST_CHEAP: 8U Gaussian,
 // colour conversions, threshold, pyrDown, equalizeHist, morphology, integral, bilinear resize) decline and leave the image to the CPU.
-// The default policy ("always") accepts everything, which is what the parity tests and the HAL tour rely on.
+// MI355CV_HOST_POLICY=always accepts everything, which is what the parity tests and the HAL tour set (tests/conftest.py).
 enum HostCost { HOST_CHEAP = 0, HOST_HEAVY = 1 };
 size_t minPixels(int cost = HOST_CHEAP);
 // host-resident image below the policy threshold: true, and the reason is recorded for mi355cv_lastError / the decline ledger

@@ -26,6 +26,8 @@ static std::atomic<long long> g_stagedBytes{0};   // image bytes the hooks moved
 void noteStagedBytes(long long n) { g_stagedBytes += n; }
 static thread_local char t_err[512] = "";
 static thread_local unsigned t_serial = 0, t_errSerial = ~0u;  // hook invocations on this thread (bumped when the outermost Stager opens and closes); the one that recorded t_err
+static thread_local bool t_notDrained = false;            // the current outermost hook returned (or will return) without waiting for its stream: its scratch stays tied to that stream
+static thread_local bool t_sawManaged = false;           // a managed (host-visible) image was classified during the current outermost hook
 static thread_local bool t_errFresh = false;             // set by setError, taken by mi355cv_noteDecline: a reason is attributed to one declined call
 static thread_local int t_dev = -1;                 // mi355cv_setDevice; -1 = process default
 static thread_local int t_active = 0;               // device of the hook that is running = index of the per-device thread context
@@ -65,7 +67,9 @@ bool hostImageTooSmall(const void* img, size_t pixels, size_t threshold)
 size_t minPixels(int cost)
 {
     static const size_t v = getenv("MI355CV_MIN_PIXELS") ? strtoull(getenv("MI355CV_MIN_PIXELS"), nullptr, 10) : 0;
-    static const bool autoPolicy = getenv("MI355CV_HOST_POLICY") && !strcmp(getenv("MI355CV_HOST_POLICY"), "auto");
+    // "auto" is the default since round 5 (serving every host Mat by staging made the out-of-the-box drop-in slower than the reference's own CPU path on the
+    // bandwidth-bound hooks -- 40.8 against 51.5 Gpix/s for the 8-bit Gaussian on 16 host threads); MI355CV_HOST_POLICY=always stages everything (the parity suites set it)
+    static const bool autoPolicy = !(getenv("MI355CV_HOST_POLICY") && !strcmp(getenv("MI355CV_HOST_POLICY"), "always"));
     if (!autoPolicy) return v;
     return cost == HOST_HEAVY ? std::max<size_t>(v, 64 * 64) : (size_t)-1;
 }
@@ -222,7 +226,7 @@ int ptrKind(const void* p)
     hipPointerAttribute_t a;
     hipError_t e = hipPointerGetAttributes(&a, p);
     if (e != hipSuccess) { (void)hipGetLastError(); return PTR_HOST; }   // unregistered host memory
-    if (a.type == hipMemoryTypeManaged) return PTR_DEVICE;
+    if (a.type == hipMemoryTypeManaged) { t_sawManaged = true; return PTR_DEVICE; }          // host-visible: results must be complete when the hook returns (Stager::finish)
     if (a.type == hipMemoryTypeDevice) return a.device == t_active ? PTR_DEVICE : PTR_FOREIGN;
     return PTR_HOST;
 }
@@ -234,7 +238,7 @@ bool isDevicePtr(const void* p) { return ptrKind(p) == PTR_DEVICE; }
 Stager::Stager()
 {
     // an error left behind by an earlier call on this thread (a failed copy, somebody else's HIP code) must not be charged to this hook
-    if (t_depth++ == 0) { (void)hipGetLastError(); beginCall(); }
+    if (t_depth++ == 0) { (void)hipGetLastError(); beginCall(); t_sawManaged = false; t_notDrained = false; }
 }
 Stager::~Stager()
 {
@@ -243,7 +247,7 @@ Stager::~Stager()
     if (--t_depth == 0) {
         beginCall();                                         // a reason recorded during this call is not the next call's
         ThreadCtx& c = tctx();
-        hipStream_t s = c.async ? stream() : nullptr;
+        hipStream_t s = (c.async || t_notDrained) ? stream() : nullptr;
         for (auto& b : c.pool) if (b.busy) { b.busy = false; b.last = s; }
         for (auto& b : c.pinned) b.busy = false;          // the host has read them by now: every user synchronises before it looks
         restoreDevice();
@@ -352,13 +356,19 @@ int Stager::finish(const char* entry)
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: D2H failed: %s", entry, hipGetErrorString(e));
     }
     // a hook called from inside another hook (device pointers, same stream) leaves the synchronisation to the outermost one
-    if (anyHost_ || (!asyncMode() && t_depth == 1)) {
+    // Device-resident images on a stream the CALLER bound (mi355cv_setStream: the caller's own work on those images is ordered on that stream, e.g. torch's current
+    // stream) need not be complete at return -- nothing host-side can see them, and everything the caller enqueues next on that stream comes after (SURVEY 8b,
+    // threading row): the hook returns after the enqueue, which removes the 12-15 us of hipStreamSynchronize from every per-frame call (profiles/r04_call_latency.txt).
+    // Host and managed images, and calls on the library's own per-thread stream (which no caller can order against), stay synchronous.  MI355CV_DEVICE_SYNC=1: always block.
+    static const bool alwaysBlock = envFlag("MI355CV_DEVICE_SYNC");
+    const bool deferred = tctx().useUser && !t_sawManaged && !alwaysBlock;
+    if (anyHost_ || (!asyncMode() && !deferred && t_depth == 1)) {
         // (A synchronous hook on a 4K frame is a 3-8 us kernel and hipStreamSynchronize adds 12-15 us of completion latency: 19.6 us per synchronous
         // cv_hal_gaussianBlurBinomial call against 8.2 us of enqueue + execution and 3.3 us of host time per asynchronous call, tools/ubench/call_latency.cpp,
         // profiles/r04_call_latency.txt.  Polling hipStreamQuery before blocking was tried and is SLOWER, 22.1 us: the query costs more than the wake-up it saves.)
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return setError(MI355CV_ERROR_UNKNOWN, "%s: execution failed: %s", entry, hipGetErrorString(e));
-    }
+    } else if (t_depth == 1) t_notDrained = true;
     bump(entry);
     return MI355CV_OK;
 }

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The library's default host policy is "auto" (bandwidth-bound hooks decline images in plain host memory: the CPU path is faster than two PCIe crossings).  The parity
+# suites feed host arrays to EVERY hook on purpose, here and in the subprocesses they start (the reference's own test binary): they run under "always".
+# tests/test_hal_dropin.py::test_default_host_policy checks the default in a process of its own.
+os.environ.setdefault("MI355CV_HOST_POLICY", "always")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

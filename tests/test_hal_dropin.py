@@ -6,10 +6,14 @@
  * GPU (-m gpu): the same cv:: calls are served by the MI355X kernels; results identical for integer images, 1e-4 for
    CV_32F; the library's call counters prove the GPU path ran.
 """
+import os
+
 import numpy as np
 import pytest
 
 import orc as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _calls(o, src8, src8c3, srcf):
@@ -488,3 +492,36 @@ def test_for_each_shard_cpp_helper_gpu(ref):
     assert cv.call_count("gaussianBlurBinomial") == n0 + 9
     for i in range(9):
         assert np.array_equal(out[i], O.ref_GaussianBlur(frames[i], 5, 0, 0, 4)), i
+
+
+@pytest.mark.gpu
+def test_default_host_policy():
+    """the library's DEFAULT (no MI355CV_HOST_POLICY in the environment) is "auto" (VERDICT r4 item 8a): on images in plain host memory the bandwidth-bound hooks decline --
+    the reference's multi-threaded CPU path beats two PCIe crossings --, the heavy ones (corners, warps, single-threaded FilterEngine paths) stage and serve, and anything
+    in device memory is served as before.  A process of its own: the policy is read once."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch, sys
+        sys.path.insert(0, %r)
+        import opencv_amd as cv
+        rng = np.random.default_rng(3)
+        img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+        for name, fn in (("GaussianBlur", lambda: cv.GaussianBlur(img, (5, 5), 0)), ("cvtColor", lambda: cv.cvtColor(np.dstack([img] * 3), cv.COLOR_BGR2GRAY)),
+                         ("threshold", lambda: cv.threshold(img, 100, 255, 0))):
+            try:
+                fn(); print("SERVED", name)
+            except NotImplementedError:
+                print("DECLINED", name)
+        r = cv.cornerHarris(img, 2, 3, 0.04); print("SERVED cornerHarris", r.shape)
+        M = cv.getRotationMatrix2D((320.0, 240.0), 7.0, 0.95)
+        r = cv.warpAffine(img, M, (640, 480)); print("SERVED warpAffine", r.shape)
+        r = cv.GaussianBlur(torch.from_numpy(img).cuda(), (5, 5), 0); print("SERVED GaussianBlur-device", tuple(r.shape))
+    """ % ROOT)
+    env = dict(os.environ); env.pop("MI355CV_HOST_POLICY", None); env.pop("MI355CV_MIN_PIXELS", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout
+    for name in ("GaussianBlur", "cvtColor", "threshold"):
+        assert "DECLINED " + name in out, out
+    for name in ("cornerHarris", "warpAffine", "GaussianBlur-device"):
+        assert "SERVED " + name in out, out
