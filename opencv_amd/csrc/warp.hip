@@ -1051,6 +1051,7 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
 }
 
 struct WarpArgs { double M[9]; int dw, dh, kind /*0 affine, 1 perspective, 2 remap32f*/; int bw0; int band /* XCD-banded tile order */; int gx, gy;
+                  int pexact; /* MI355CV_PERSP_EXACT=1: the IEEE division in every pixel (A/B of persp::xy) */
                   int rel; /* WARP_RELATIVE_MAP: the map holds offsets, the destination pixel's own (x, y) is added to the INTEGER source coordinates after their
                               saturation to short (imgwarp.cpp:354-359, :708-712: XY[dx*2] + _offset.x + dx) */
                   size_t sframe, dframe; /* bytes between the frames of a batch (grid z = frame) */ };
@@ -1665,6 +1666,55 @@ __global__ __launch_bounds__(256) void k_convert_maps_to_float(const uchar* __re
 // generic sampler.  A wave walks down WROWS rows, so the source lines it touched for one row are in L1 for the next.
 // rows per thread: 8 for CV_32F, 4 for CV_8U (measured, tools/warp_probe.py: 8-bit sources 39 / 25 / 31 us for C3 / C1 / C4 at 4 rows against 45 / 28 / 40
 // at 8 and 61 / 38 / 56 at 16; CV_32F 63.5 us at 8, 65.9 at 4, 72.8 at 16)
+// ---- warpPerspective coordinates without the IEEE division in (almost) every pixel (round 5).
+// The reference (imgwarp.cpp:3199-3240) forms, in double,  q = RN(32 / W),  p = RN(num * q),  X = cvRound(p)  with W = W0 + M6 x1, num = X0 + M0 x1.  The exact form costs, per
+// pixel and in every lane, three row terms (12 double operations), a correctly rounded division (~14), four clamps and two saturating conversions: half the kernel's time
+// (profiles/r04_warp32_ab.txt: "the per-pixel double division dominates").  Here:
+//   * the row terms X0, Y0, W0 depend on (block start xb, row y) only; the reference's blocks are 64 columns wide and tiles are 64-aligned, so they are WAVE-UNIFORM:
+//     lane l computes them for row l of the wave's rows, every row then reads them back with v_readlane (persp::RowTerms);
+//   * the column terms M0 x1, M3 x1, M6 x1 are per-lane constants for all rows;
+//   * q' = 32 r with r from v_rcp_f64 and two Newton steps: |q' - 32 / W| <= 2^-50 |q| (the seed is good to >= 2^-13, two steps square that twice; one rounding each), so
+//     |q' - q| <= 2^-49 |q| and p' = RN(num q') lies within 2^-48 |p| of the reference's p.  cvRound(p') != cvRound(p) needs a half-integer between the two, i.e. within
+//     2^-48 |p| of p'.  A pixel whose p' (either coordinate) lies within 2^-19 of a half-integer, or beyond 2^21 in magnitude (2^-19 >= 2^-40 |p| there: a 2^8 margin on
+//     the bound), or whose W is zero / not finite, is RE-EVALUATED with the exact division -- about one pixel in 2^17; everything else is proven equal.
+//   * the clamps to [INT_MIN, INT_MAX] are what the saturating conversion does anyway.
+namespace persp {
+struct RowTerms { double X0, Y0, W0; };
+__device__ __forceinline__ double bcast(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ RowTerms rowTerms(const WarpArgs& w, int xb, int y)
+{
+    RowTerms t;
+    t.X0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[0], (double)xb), __dmul_rn(w.M[1], (double)y)), w.M[2]);
+    t.Y0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[3], (double)xb), __dmul_rn(w.M[4], (double)y)), w.M[5]);
+    t.W0 = __dadd_rn(__dadd_rn(__dmul_rn(w.M[6], (double)xb), __dmul_rn(w.M[7], (double)y)), w.M[8]);
+    return t;
+}
+// (X, Y) in 1/32 pixel from the row terms and the lane's column terms c0 = M0 x1, c3 = M3 x1, c6 = M6 x1
+__device__ __forceinline__ void xy(const RowTerms& t, double c0, double c3, double c6, int& X, int& Y)
+{
+    const double W = __dadd_rn(t.W0, c6), nx = __dadd_rn(t.X0, c0), ny = __dadd_rn(t.Y0, c3);
+    double r = __builtin_amdgcn_rcp(W);
+    r = __fma_rn(r, __fma_rn(-W, r, 1.0), r);
+    r = __fma_rn(r, __fma_rn(-W, r, 1.0), r);
+    const double q = __dmul_rn(r, 32.0);
+    const double fX = __dmul_rn(nx, q), fY = __dmul_rn(ny, q);
+    const double dX = __builtin_amdgcn_fract(fX) - 0.5, dY = __builtin_amdgcn_fract(fY) - 0.5;
+    const double big = fmax(fabs(fX), fabs(fY));
+    // (comparisons written so that a NaN anywhere -- W = 0, infinities -- lands on the exact side)
+    const bool safe = fmin(fabs(dX), fabs(dY)) > 0x1p-19 && big < 0x1p21;
+    if (safe) { X = (int)__double2int_rn(fX); Y = (int)__double2int_rn(fY); return; }
+    const double qe = W != 0 ? __ddiv_rn(32.0, W) : 0;
+    double eX = __dmul_rn(nx, qe), eY = __dmul_rn(ny, qe);
+    eX = fmax(-2147483648.0, fmin(2147483647.0, eX));
+    eY = fmax(-2147483648.0, fmin(2147483647.0, eY));
+    X = satIntD(eX); Y = satIntD(eY);
+}
+}
+
 template <typename T> constexpr int warpRows() { return sizeof(T) == 4 ? 8 : 4; }
 template <int KIND>
 __device__ __forceinline__ void warpXY(const WarpArgs& w, int y, int ad, int bd, int xb, int x1, int& X, int& Y)
@@ -1725,10 +1775,15 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
         X0v = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[1], (double)yl), w.M[2]), 1024.0)) + 16;
         Y0v = satIntD(__dmul_rn(__dadd_rn(__dmul_rn(w.M[4], (double)yl), w.M[5]), 1024.0)) + 16;
     }
+    // perspective: the reference's 64-column blocks coincide with the tiles -> the row terms are wave-uniform, lane l holds those of row l of the wave (persp:: above)
+    const bool puni = KIND == 1 && w.bw0 == 64 && !w.pexact;
+    persp::RowTerms prt = {0, 0, 0};
+    if (KIND == 1 && puni) prt = persp::rowTerms(w, tx * 64, yb + (lane & (WROWS - 1)));
     if (x >= w.dw) return;
     const int ad = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[0], (double)x), 1024.0)) : 0;
     const int bd = KIND == 0 ? satIntD(__dmul_rn(__dmul_rn(w.M[3], (double)x), 1024.0)) : 0;
     const int xb = KIND == 1 ? (x / w.bw0) * w.bw0 : 0, x1 = x - xb;
+    const double pc0 = KIND == 1 ? __dmul_rn(w.M[0], (double)x1) : 0, pc3 = KIND == 1 ? __dmul_rn(w.M[3], (double)x1) : 0, pc6 = KIND == 1 ? __dmul_rn(w.M[6], (double)x1) : 0;
     // the pair (sx, sx+1) is read as ONE load of 2*CN elements where that cannot leave the row (3 channels: an 8-byte load for 6)
     const int xlim = CN == 3 ? s.sw - 2 : s.sw - 1;
     const uint32_t xoff = (uint32_t)x * ESZ;
@@ -1745,6 +1800,10 @@ __global__ __launch_bounds__(256) void k_warp_lin(const uchar* __restrict__ src,
             if (KIND == 0) {
                 Xs[i] = (__builtin_amdgcn_readlane(X0v, g0 + i) + ad) >> 5;
                 Ys[i] = (__builtin_amdgcn_readlane(Y0v, g0 + i) + bd) >> 5;
+            } else if (KIND == 1 && puni) {
+                persp::RowTerms t;
+                t.X0 = persp::bcast(prt.X0, g0 + i); t.Y0 = persp::bcast(prt.Y0, g0 + i); t.W0 = persp::bcast(prt.W0, g0 + i);
+                persp::xy(t, pc0, pc3, pc6, Xs[i], Ys[i]);
             } else warpXY<KIND>(w, y, ad, bd, xb, x1, Xs[i], Ys[i]);
             // the saturation to short of the reference cannot turn an outside position into an inside one (sw, sh <= 32767): the unsaturated
             // values decide; the generic sampler saturates for the others
@@ -2259,6 +2318,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (M) for (int i = 0; i < (kind == 0 ? 6 : kind == 6 ? 2 : kind == 7 ? 5 : 9); i++) w.M[i] = M[i];
     int bh0 = dh < 16 ? dh : 16;
     w.bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;                                              // WarpPerspectiveInvoker :3182-3184
+    { static const int pe = [] { const char* v = getenv("MI355CV_PERSP_EXACT"); return v ? atoi(v) : 0; }(); w.pexact = pe; }
     if (is64) {
         const TapTabs* tt = deviceTapTabs();
         if (!tt) return mi355::declined(__func__, __LINE__, "the bicubic / Lanczos weight tables could not be placed on the device");
