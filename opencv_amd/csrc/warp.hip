@@ -2150,8 +2150,8 @@ __global__ __launch_bounds__(256) void k_warp8_tile_list(const uchar* __restrict
 
 // bicubic warpAffine of CV_8U images on the tile path of warp8.h (boxFromTerms4 / phaseC4): persistent workgroups -- the Q15 weight table is copied into LDS
 // once, 12 dwords per entry (8 used: the 48-byte pitch spreads the entries over the banks) --, then tile after tile: box terms, the source box staged with aligned
-// dwords, four destination pixels per lane from LDS, what is left (the source's rim, border rules) through samplePixelN.  NOT the default yet (written after the
-// round's GPU budget; tests/hostemu runs its phases on the CPU against the restatement): MI355CV_WARP_TAPS_TILE=1.
+// dwords, four destination pixels per lane from LDS, what is left (the source's rim, border rules) through samplePixelN.  The default for one channel since round 5
+// (see runWarp; tests/hostemu also runs its phases on the CPU against the restatement).
 template <int CN>
 __global__ __launch_bounds__(256) void k_warp8_cubic(const uchar* __restrict__ src, uchar* __restrict__ dst, SampleArgs s, warp8::Args a, const short* __restrict__ tabI,
                                                      const float* __restrict__ tab1, uint32_t tileBytes, int nframes)
@@ -2340,9 +2340,10 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             if (!terms || !work0) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
             hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work0);
         }
-        // CV_8U bicubic on the tile path of warp8.h (opt-in until it has run on the GPU: MI355CV_WARP_TAPS_TILE=1)
-        static const bool tapsTile = [] { const char* v = getenv("MI355CV_WARP_TAPS_TILE"); return v && atoi(v) != 0; }();
-        if (tapsTile && kind == 0 && depth == D8U && interpolation == MI355CV_INTER_CUBIC && (cn == 1 || cn == 3) && sw >= 4 && sh >= 4 && terms) {
+        // CV_8U bicubic on the tile path of warp8.h.  Round 5, first run on the GPU (profiles/r05_warp_taps_tile_call1.txt, 4K, 7 degrees): one channel 42.7 us against the
+        // tap-row kernel's 52.8-54.1 -- the default from here --, three channels 113.9 against 85.6 -- stays on the tap-row kernel.  MI355CV_WARP_TAPS_TILE=0 / 1: never / both.
+        static const int tapsTile = [] { const char* v = getenv("MI355CV_WARP_TAPS_TILE"); return v ? atoi(v) : -1; }();
+        if ((tapsTile < 0 ? cn == 1 : tapsTile != 0) && kind == 0 && depth == D8U && interpolation == MI355CV_INTER_CUBIC && (cn == 1 || cn == 3) && sw >= 4 && sh >= 4 && terms) {
             warp8::Args a8; size_t lds8 = 0;
             if (warp8::plan(a8, cn, 0, M, sw, sh, dw, dh, dss, dds, ds, dd, w.bw0, &lds8, 3)) {
                 a8.sframe = w.sframe; a8.dframe = w.dframe;
