@@ -365,7 +365,7 @@ MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const mi355cv_uchar* src_data, size_
 /* replaces hal_ni_cvtOnePlaneBGRtoYUV (:866; caller color_yuv.dispatch.cpp:281) */
 MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,
         int width, int height, int scn, bool swapBlue, int uIdx, int ycn);
-/* replace hal_ni_cvtBGRtoXYZ (:564; caller color_lab.cpp:4134) and hal_ni_cvtXYZtoBGR (:579): CV_8U, CV_16U (CV_32F declines) */
+/* replace hal_ni_cvtBGRtoXYZ (:564; caller color_lab.cpp:4134) and hal_ni_cvtXYZtoBGR (:579): CV_8U, CV_16U, CV_32F (the body / tail association of the SSE-baseline build, see csrc/color_misc.hip) */
 MI355CV_API int mi355cv_cvtBGRtoXYZ(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,
         int depth, int scn, bool swapBlue);
 MI355CV_API int mi355cv_cvtXYZtoBGR(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step, int width, int height,

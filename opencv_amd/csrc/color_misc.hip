@@ -3,7 +3,7 @@
 //                  cv_hal_cvtBGRtoThreePlaneYUV (:797)                      BGR/RGB(A) -> I420 / YV12
 //                  cv_hal_cvtOnePlaneBGRtoYUV   (:866)                      BGR/RGB(A) -> YUY2 / YVYU / UYVY
 //   frame ingest   cv_hal_cvtOnePlaneYUVtoBGR   (:833)                      YUY2 / YVYU / UYVY -> BGR/RGB(A)
-//   cv_hal_cvtBGRtoXYZ (:564), cv_hal_cvtXYZtoBGR (:579)                    CV_8U and CV_16U (12-bit fixed point)
+//   cv_hal_cvtBGRtoXYZ (:564), cv_hal_cvtXYZtoBGR (:579)                    CV_8U and CV_16U (12-bit fixed point), CV_32F (round 5)
 //   cv_hal_cvtBGRtoBGR5x5 (:411), cvtBGR5x5toBGR (:427), cvtBGR5x5toGray (:470), cvtGraytoBGR5x5 (:484)
 //   cv_hal_cvtRGBAtoMultipliedRGBA (:894), cvtMultipliedRGBAtoRGBA (:907)
 // All of it is byte shuffling plus a handful of integer MACs per pixel: HBM-bound.  The 8-bit conversions run on the pix4 launch shape
@@ -141,6 +141,26 @@ __global__ __launch_bounds__(256) void k_xyz(const uchar* __restrict__ src, size
 #pragma unroll
     for (int k = 0; k < 3; k++) d[k] = (T)min(max((a * m.c[3 * k] + b * m.c[3 * k + 1] + c * m.c[3 * k + 2] + (1 << 11)) >> 12, 0), hi);
     if (DCN == 4) d[3] = (T)hi;
+}
+
+// CV_32F (RGB2XYZ_f<float> color_lab.cpp:183-247, XYZ2RGB_f<float> :576-642): three products and two sums per output, every one rounded (the reference's v_fma is a
+// product and a sum without FMA3 in the baseline).  Its row loop associates  a*C0 + (b*C1 + c*C2)  in the vector body and  (a*C0 + b*C1) + c*C2  in the scalar tail:
+// the last W % 4 pixels of a row (4 = pixels per vector of the SSE baseline color_lab.cpp is built for; it is not a dispatched file) take the tail form.
+struct Mat3f { float c[9]; };
+template <int SCN, int DCN>
+__global__ __launch_bounds__(256) void k_xyz_f32(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int nv, Mat3f m)
+{
+    PIXEL_XY(W, H);
+    const float* s = (const float*)(src + (size_t)y * sstep) + (size_t)x * SCN;
+    float* d = (float*)(dst + (size_t)y * dstep) + (size_t)x * DCN;
+    const float a = s[0], b = s[1], c = s[2];
+    const bool vec = x < nv;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float pa = __fmul_rn(a, m.c[3 * k]), pb = __fmul_rn(b, m.c[3 * k + 1]), pc = __fmul_rn(c, m.c[3 * k + 2]);
+        d[k] = vec ? __fadd_rn(pa, __fadd_rn(pb, pc)) : __fadd_rn(__fadd_rn(pa, pb), pc);
+    }
+    if (DCN == 4) d[3] = 1.f;
 }
 
 template <int SCN, int DCN>
@@ -306,9 +326,18 @@ MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, ucha
                                     int depth, int scn, bool swapBlue)
 {
     mi355::EntryGuard entry_;
-    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
-    const int e = depth == MI355CV_8U ? 1 : 2;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
+    const int e = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     MISC_PROLOGUE(width * scn * e, height, width * 3 * e, height);
+    if (depth == MI355CV_32F) {
+        static const double kf[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};      // sRGB2XYZ_D65, color_lab.cpp:118
+        Mat3f mf; for (int i = 0; i < 9; i++) mf.c[i] = (float)kf[i];
+        if (!swapBlue) for (int r = 0; r < 3; r++) std::swap(mf.c[3 * r], mf.c[3 * r + 2]);
+        dim3 gridf(divUp(width, 64), divUp(height, 4));
+        if (scn == 3) hipLaunchKernelGGL((k_xyz_f32<3, 3>), gridf, dim3(256), 0, st, ds, dss, dd, dds, width, height, width & ~3, mf);
+        else hipLaunchKernelGGL((k_xyz_f32<4, 3>), gridf, dim3(256), 0, st, ds, dss, dd, dds, width, height, width & ~3, mf);
+        return stg.finish("cvtBGRtoXYZ");
+    }
     static const int k[9] = {1689, 1465, 739, 871, 2929, 296, 79, 488, 3892};        // sRGB2XYZ_D65_i, color_lab.cpp:132
     Mat3 m; for (int i = 0; i < 9; i++) m.c[i] = k[i];
     if (!swapBlue) for (int r = 0; r < 3; r++) std::swap(m.c[3 * r], m.c[3 * r + 2]);
@@ -324,9 +353,18 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, ucha
                                     int depth, int dcn, bool swapBlue)
 {
     mi355::EntryGuard entry_;
-    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
-    const int e = depth == MI355CV_8U ? 1 : 2;
+    if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
+    const int e = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     MISC_PROLOGUE(width * 3 * e, height, width * dcn * e, height);
+    if (depth == MI355CV_32F) {
+        static const double kf[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};   // XYZ2sRGB_D65, color_lab.cpp:125
+        Mat3f mf; for (int i = 0; i < 9; i++) mf.c[i] = (float)kf[i];
+        if (!swapBlue) for (int c = 0; c < 3; c++) std::swap(mf.c[c], mf.c[6 + c]);
+        dim3 gridf(divUp(width, 64), divUp(height, 4));
+        if (dcn == 3) hipLaunchKernelGGL((k_xyz_f32<3, 3>), gridf, dim3(256), 0, st, ds, dss, dd, dds, width, height, width & ~3, mf);
+        else hipLaunchKernelGGL((k_xyz_f32<3, 4>), gridf, dim3(256), 0, st, ds, dss, dd, dds, width, height, width & ~3, mf);
+        return stg.finish("cvtXYZtoBGR");
+    }
     static const int k[9] = {13273, -6296, -2042, -3970, 7684, 170, 228, -836, 4331};  // XYZ2sRGB_D65_i, color_lab.cpp:139
     Mat3 m; for (int i = 0; i < 9; i++) m.c[i] = k[i];
     if (!swapBlue) for (int c = 0; c < 3; c++) std::swap(m.c[c], m.c[6 + c]);

@@ -372,11 +372,11 @@ def _cvt_misc(src, s, code, dst, dstCn):
 
     a = None
     if kind == "to_xyz":
-        need(s.cn in (3, 4) and s.depth in (CV_8U, CV_16U), "BGR2XYZ: 3 or 4 channels, CV_8U / CV_16U on this path")
+        need(s.cn in (3, 4) and s.depth in (CV_8U, CV_16U, CV_32F), "BGR2XYZ: 3 or 4 channels, CV_8U / CV_16U / CV_32F")
         out = dst if dst is not None else _like(src, s.h, s.w, 3, s.depth)
         call = lambda d: L.mi355cv_cvtBGRtoXYZ(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, s.cn, bool(k[1]))
     elif kind == "from_xyz":
-        need(s.cn == 3 and s.depth in (CV_8U, CV_16U), "XYZ2BGR: 3 channels, CV_8U / CV_16U on this path")
+        need(s.cn == 3 and s.depth in (CV_8U, CV_16U, CV_32F), "XYZ2BGR: 3 channels, CV_8U / CV_16U / CV_32F")
         dcn = dstCn if dstCn in (3, 4) else 3
         out = dst if dst is not None else _like(src, s.h, s.w, dcn, s.depth)
         call = lambda d: L.mi355cv_cvtXYZtoBGR(_vp(s.ptr), s.step, _vp(d.ptr), d.step, s.w, s.h, s.depth, dcn, bool(k[1]))

@@ -97,8 +97,42 @@ static int satT(int v, int depth) { const int hi = depth == 0 ? 255 : 65535; ret
 static int ld(const uint8_t* p, int depth, int i) { return depth == 0 ? p[i] : ((const uint16_t*)p)[i]; }
 static void st(uint8_t* p, int depth, int i, int v) { if (depth == 0) p[i] = (uint8_t)v; else ((uint16_t*)p)[i] = (uint16_t)v; }
 
+/* CV_32F (RGB2XYZ_f<float> color_lab.cpp:183-247, XYZ2RGB_f<float> :576-642): no rounding to a grid, no clipping -- three products and two sums per output in float.
+ * The reference's row loop has a vector body and a scalar tail that ASSOCIATE differently: the body is  b*C0 + (g*C1 + r*C2)  (v_fma(b, c0, v_fma(g, c1, v_mul(r, c2))), which
+ * without FMA3 in the baseline -- the default x86-64 build: SSE3 -- is a product and a sum, each rounded), the tail  (b*C0 + g*C1) + r*C2.  `lanes` = pixels per vector of
+ * the build followed (4: the SSE baseline color_lab.cpp is compiled for -- it is not a dispatched file); the last w % lanes pixels of a row take the tail form. */
+static const double kRGB2XYZf[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+static const double kXYZ2RGBf[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+static float xyz3(float a, float b, float c, const float* C, int vec)
+{
+    const volatile float pa = a * C[0], pb = b * C[1], pc = c * C[2];           /* volatile: every product rounded to float on its own */
+    if (vec) { const volatile float t = pb + pc; return pa + t; }
+    const volatile float t = pa + pb;
+    return t + pc;
+}
+int orc_cvtXYZ32f(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int dcn, int swapBlue, int toXYZ, int lanes)
+{
+    float C[9];
+    for (int i = 0; i < 9; i++) C[i] = (float)(toXYZ ? kRGB2XYZf[i] : kXYZ2RGBf[i]);
+    if (!swapBlue) {                                         /* blueIdx == 0 */
+        if (toXYZ) for (int r = 0; r < 3; r++) { const float t = C[3 * r]; C[3 * r] = C[3 * r + 2]; C[3 * r + 2] = t; }
+        else for (int c = 0; c < 3; c++) { const float t = C[c]; C[c] = C[6 + c]; C[6 + c] = t; }
+    }
+    const int nv = lanes > 0 ? w - w % lanes : 0;
+    for (int y = 0; y < h; y++) {
+        const float* s = (const float*)(src + (size_t)y * sstep); float* d = (float*)(dst + (size_t)y * dstep);
+        for (int x = 0; x < w; x++) {
+            const float a = s[x * scn], b = s[x * scn + 1], c = s[x * scn + 2];
+            for (int k = 0; k < 3; k++) d[x * dcn + k] = xyz3(a, b, c, C + 3 * k, x < nv);
+            if (dcn == 4) d[x * 4 + 3] = 1.f;
+        }
+    }
+    return 0;
+}
+
 int orc_cvtBGRtoXYZ(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int swapBlue)
 {
+    if (depth == 5) return orc_cvtXYZ32f(src, sstep, dst, dstep, w, h, scn, 3, swapBlue, 1, 4);
     if (depth != 0 && depth != 2) return 1;
     int C[9];
     for (int i = 0; i < 9; i++) C[i] = kRGB2XYZ[i];
@@ -118,6 +152,7 @@ int orc_cvtBGRtoXYZ(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep
 
 int orc_cvtXYZtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int dcn, int swapBlue)
 {
+    if (depth == 5) return orc_cvtXYZ32f(src, sstep, dst, dstep, w, h, 3, dcn, swapBlue, 0, 4);
     if (depth != 0 && depth != 2) return 1;
     int C[9];
     for (int i = 0; i < 9; i++) C[i] = kXYZ2RGB[i];

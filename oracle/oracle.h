@@ -69,6 +69,8 @@ void orc_cvtOnePlaneYUVtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, siz
 void orc_cvtOnePlaneBGRtoYUV(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int uIdx, int ycn);
 int orc_cvtBGRtoXYZ(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int scn, int swapBlue);
 int orc_cvtXYZtoBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int dcn, int swapBlue);
+/* CV_32F form of both (depth 5 above calls it with lanes = 4): toXYZ 1 / 0; lanes = pixels per vector of the build whose body / tail split is followed */
+int orc_cvtXYZ32f(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int dcn, int swapBlue, int toXYZ, int lanes);
 void orc_cvtBGRtoBGR5x5(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int scn, int swapBlue, int greenBits);
 void orc_cvtBGR5x5toBGR(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int dcn, int swapBlue, int greenBits);
 void orc_cvtBGR5x5toGray(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int greenBits);

@@ -50,6 +50,23 @@ def test_xyz_16u_and_alpha(cv, orc):
         assert np.array_equal(cv.cvtColor(dev(src), code).cpu().numpy(), orc.orc_cvtColorMisc(src, code)), code
 
 
+def test_xyz_32f(cv, orc):
+    """CV_32F XYZ both ways (round 5; Imgproc_ColorXYZ.accuracy declined 310 calls): bit for bit against the restatement, which tests/test_oracle_colormisc.py pins to the
+    reference -- row lengths that end in 0-3 tail pixels, 4-channel sources / destinations, values outside [0, 1], host arrays"""
+    rng = np.random.default_rng(32)
+    for code in (32, 33, 34, 35):
+        for (w, h) in [(1, 1), (3, 2), (4, 3), (5, 3), (401, 90), (1023, 7), (1920, 64)]:
+            for cn in ((3, 4) if code in (32, 33) else (3,)):
+                src = (rng.random((h, w, cn), dtype=np.float32) * 3 - 1).astype(np.float32)
+                got = cv.cvtColor(dev(src), code).cpu().numpy()
+                assert got.dtype == np.float32 and np.array_equal(got, orc.orc_cvtColorMisc(src, code)), (code, w, h, cn)
+        src = rng.random((33, 77, 3), dtype=np.float32)
+        assert np.array_equal(cv.cvtColor(src, code), orc.orc_cvtColorMisc(src, code)), code                      # host pointers
+    x = rng.random((20, 30, 3), dtype=np.float32)
+    got = cv.cvtColor(dev(x), 34, dstCn=4).cpu().numpy()                                                          # XYZ -> BGRA: alpha = 1
+    assert got.shape == (20, 30, 4) and np.array_equal(got[..., :3], orc.orc_cvtColorMisc(x, 34)) and np.all(got[..., 3] == 1.0)
+
+
 def test_hsv_to_bgr(cv, orc):
     rng = np.random.default_rng(12)
     for code in (54, 55, 70, 71):

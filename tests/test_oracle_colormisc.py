@@ -105,3 +105,15 @@ def test_threshold_otsu(dtype):
                     tv, td = o.orc_thresholdOtsu(src, maxval, ttype)
                     rv, rd = o.ref_threshold(src, 0.0, maxval, ttype | 8)
                     assert tv == rv and np.array_equal(td, rd), (dtype, w, h, mode, ttype, maxval, tv, rv)
+
+
+@pytest.mark.parametrize("code", [32, 33, 34, 35])
+def test_xyz_32f(code):
+    """CV_32F XYZ (155 + 155 declined calls of Imgproc_ColorXYZ.accuracy): the restatement follows the body / tail split of the reference's row loop in the
+    SSE baseline build (4 pixels per vector, products and sums rounded one by one; the scalar tail associates the other way) -- bit for bit against oracle/_ref"""
+    rng = np.random.default_rng(100 + code)
+    for (w, h) in [(1, 1), (3, 2), (4, 3), (5, 3), (37, 9), (400, 20), (1023, 4)]:
+        for cn in ((3, 4) if code in (32, 33) else (3,)):
+            src = (rng.random((h, w, cn), dtype=np.float32) * 1.5 - 0.25).astype(np.float32)
+            got, want = o.orc_cvtColorMisc(src, code), o.ref_cvtColorMisc(src, code)
+            assert got.dtype == np.float32 and np.array_equal(got, want), (code, w, h, cn, float(np.abs(got - want).max()))
