@@ -10,7 +10,7 @@ using namespace mi355;
 
 namespace {
 
-enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F, D64F = MI355CV_64F };
 
 template <typename T, int TYPE> __device__ __forceinline__ T threshOne(T v, T t, T m)
 {
@@ -193,11 +193,12 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     mi355::EntryGuard entry_;
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4");
     if (thresholdType < 0 || thresholdType > 4) return mi355::declined(__func__, __LINE__, "thresholdType < 0 || thresholdType > 4");
-    if (depth != D8U && depth != D16U && depth != D16S && depth != D32F) return mi355::declined(__func__, __LINE__, "depth != D8U && depth != D16U && depth != D16S && depth != D32F");
+    // (CV_64F: thresh_64f thresh.cpp:930-1110, the same five rules on doubles -- round 5; CV_32S is not a depth cv::threshold takes, :1677)
+    if (depth != D8U && depth != D16U && depth != D16S && depth != D32F && depth != D64F) return mi355::declined(__func__, __LINE__, "depth != D8U && depth != D16U && depth != D16S && depth != D32F && depth != D64F");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
-    const int e = depth == D8U ? 1 : depth == D32F ? 4 : 2;
+    const int e = depth == D8U ? 1 : depth == D32F ? 4 : depth == D64F ? 8 : 2;
     const int n = width * cn;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)n * e, height, &dss);
@@ -214,6 +215,7 @@ extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_s
     case D8U:  THT(uchar); break;
     case D16U: THT(unsigned short); break;
     case D16S: THT(short); break;
+    case D64F: THT(double); break;
     default:   THT(float); break;
     }
 #undef THT

@@ -497,7 +497,7 @@ def threshold(src, thresh, maxval, type, dst=None):
                 out[...] = src
             return float(ithresh), out
         thresh, maxval = float(ithresh), float(imaxval)
-    elif s.depth != CV_32F:
+    elif s.depth not in (CV_32F, CV_64F):
         raise NotImplementedError("threshold: depth")
     d = Img(out)
     bind_stream(s, d)

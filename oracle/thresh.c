@@ -34,6 +34,7 @@ int orc_thresholdHal(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dste
     case 2: { const uint16_t t = (uint16_t)thresh, m = (uint16_t)maxval; THRESH_LOOP(uint16_t, t, m); return 0; }
     case 3: { const int16_t t = (int16_t)thresh, m = (int16_t)maxval; THRESH_LOOP(int16_t, t, m); return 0; }
     case 5: { const float t = (float)thresh, m = (float)maxval; THRESH_LOOP(float, t, m); return 0; }
+    case 6: { const double t = thresh, m = maxval; THRESH_LOOP(double, t, m); return 0; }               /* thresh_64f thresh.cpp:930-1110 */
     default: return 1;
     }
 }
@@ -65,7 +66,7 @@ int orc_threshold(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
         }
         return orc_thresholdHal(src, sstep, dst, dstep, w, h, depth, cn, ithresh, imaxval, type);
     }
-    if (depth != 5) return 1;
+    if (depth != 5 && depth != 6) return 1;
     *retval = thresh;
     return orc_thresholdHal(src, sstep, dst, dstep, w, h, depth, cn, thresh, maxval, type);
 }

@@ -8,13 +8,16 @@ import orc as O
 CASES = [(np.uint8, [-3.0, 0.0, 0.5, 17.9, 127.0, 254.0, 254.9, 255.0, 300.0], [200.0, 255.4, 300.0, -5.0]),
          (np.uint16, [-1.0, 0.0, 1000.3, 65534.0, 65535.0, 70000.0], [60000.0, 65535.9, 1e6]),
          (np.int16, [-40000.0, -32768.0, -5.5, 0.0, 12345.6, 32766.0, 32767.0, 40000.0], [30000.0, -123.0, 1e6]),
-         (np.float32, [-1.5, 0.0, 0.25, 0.999, 7.0], [1.0, -2.5, 255.0])]
+         (np.float32, [-1.5, 0.0, 0.25, 0.999, 7.0], [1.0, -2.5, 255.0]),
+         (np.float64, [-1.5, 0.0, 0.25, 0.999, 7.0], [1.0, -2.5, 255.0])]
 
 
 def _src(dtype, seed, shape=(37, 61, 3)):
     rng = np.random.default_rng(seed)
     if dtype == np.float32:
         return (rng.random(shape, dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    if dtype == np.float64:
+        return rng.random(shape) * 2 - 0.5
     info = np.iinfo(dtype)
     a = rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
     a.flat[:4] = [info.min, info.max, info.max - 1, info.min + 1]
