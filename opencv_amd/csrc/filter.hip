@@ -577,7 +577,8 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
     c.kind = 2;
     c.sdepth = MI355CV_MAT_DEPTH(stype); c.ddepth = MI355CV_MAT_DEPTH(dtype);
     c.cn = MI355CV_MAT_CN(stype);
-    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)) return mi355::declined(__func__, __LINE__, "c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth)");
+    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth))
+        return setError(MI355CV_NOT_IMPLEMENTED, "sepFilter: depth pair %d -> %d (channels %d -> %d) outside the GPU path", c.sdepth, c.ddepth, c.cn, MI355CV_MAT_CN(dtype));
     const int nx = (int)kx.size(), ny = (int)ky.size();
     if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33");
     if (ax < 0) ax = nx / 2;
@@ -767,7 +768,10 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
     c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
     c->delta = (float)delta;                                         // saturate_cast<float>(delta), filter.simd.hpp:3113
     if (c->cn != MI355CV_MAT_CN(dst_type) || !depthPairOk(c->sdepth, c->ddepth) || c->border < 0 || c->border > B_REFLECT_101 ||
-        c->ax >= kernel_width || c->ay >= kernel_height) { delete c; return mi355::declined(__func__, __LINE__, nullptr); }
+        c->ax >= kernel_width || c->ay >= kernel_height) {
+        const int sd = c->sdepth, dd = c->ddepth, bd = c->border; delete c;
+        return setError(MI355CV_NOT_IMPLEMENTED, "filter2D: depth pair %d -> %d, border %d, anchor (%d, %d) in %d x %d outside the GPU path", sd, dd, bd, anchor_x, anchor_y, kernel_width, kernel_height);
+    }
     for (int i = 0; i < kernel_height; i++)
         for (int j = 0; j < kernel_width; j++) {
             const float v = (float)kernelAt(kernel_data, kernel_step, kernel_type, i, j);   // convertTo(CV_32F), :3201-3205
@@ -957,7 +961,8 @@ MI355CV_API int mi355cv_sobel(const uchar* src_data, size_t src_step, uchar* dst
 {
     mi355::EntryGuard entry_;
     const bool scharr = ksize <= 0;                                   // FILTER_SCHARR == -1 (getDerivKernels, deriv.cpp:165-171)
-    return derivRun("sobel", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn,
+    // (depth arguments arrive as cv::Sobel's caller gave them: a type there carries channel bits, deriv.cpp:425-456; the destination was created from the depth bits)
+    return derivRun("sobel", src_data, src_step, dst_data, dst_step, width, height, MI355CV_MAT_DEPTH(src_depth), MI355CV_MAT_DEPTH(dst_depth), cn,
                     margin_left, margin_top, margin_right, margin_bottom, dx, dy, ksize, scharr, scale, delta, border_type);
 }
 
@@ -966,7 +971,7 @@ MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* ds
         int dx, int dy, double scale, double delta, int border_type)
 {
     mi355::EntryGuard entry_;
-    return derivRun("scharr", src_data, src_step, dst_data, dst_step, width, height, src_depth, dst_depth, cn,
+    return derivRun("scharr", src_data, src_step, dst_data, dst_step, width, height, MI355CV_MAT_DEPTH(src_depth), MI355CV_MAT_DEPTH(dst_depth), cn,
                     margin_left, margin_top, margin_right, margin_bottom, dx, dy, 0, true, scale, delta, border_type);
 }
 
@@ -1033,6 +1038,9 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)");
+    // cv::boxFilter hands its `ddepth` argument through as the caller gave it (box_filter.dispatch.cpp:451-474): a caller that passed a TYPE there (CV_8UC2 = 8 --
+    // the reference's own Imgproc_Blur test does) arrives with channel bits set; the destination Mat was created from CV_MAKETYPE(ddepth, cn), i.e. from the depth bits
+    src_depth = MI355CV_MAT_DEPTH(src_depth); dst_depth = MI355CV_MAT_DEPTH(dst_depth);
     const int kw = (int)ksize_width, kh = (int)ksize_height;
     if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return mi355::declined(__func__, __LINE__, "kw < 1 || kh < 1 || kw > 255 || kh > 255");
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
@@ -1043,7 +1051,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
                          (src_depth == D16U && (dst_depth == D8U || dst_depth == D16U || dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D16S && (dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D32F && dst_depth == D32F);
-    if (!okDepth) return mi355::declined(__func__, __LINE__, "!okDepth");
+    if (!okDepth) return setError(MI355CV_NOT_IMPLEMENTED, "boxFilter: depth pair %d -> %d outside the GPU path", src_depth, dst_depth);
     BoxParams p; memset(&p, 0, sizeof p);
     p.kw = kw; p.kh = kh;
     p.ax = anchor_x < 0 ? kw / 2 : anchor_x; p.ay = anchor_y < 0 ? kh / 2 : anchor_y;

@@ -1541,7 +1541,8 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     (void)tilted_step;
     if (disabled() || tilted_data || !sum_data) return mi355::declined(__func__, __LINE__, "disabled() || tilted_data || !sum_data");
     const bool ok = (depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F);
-    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4");
+    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4)
+        return setError(MI355CV_NOT_IMPLEMENTED, "integral: depths %d -> sum %d, sqsum %d%s, %d channels outside the GPU path", depth, sdepth, sqdepth, sqsum_data ? "" : " (no sqsum)", cn);
     const size_t se = sdepth == D32S ? 4 : 8;
     if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return mi355::declined(__func__, __LINE__, "width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))");
     if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return mi355::declined(__func__, __LINE__, "sdepth == D32S && (double)width * height * 255.0 > 2147483647.0");     // would wrap; the CPU wraps its own way

@@ -47,7 +47,7 @@ def ledger(positive="*", timeout=1500):
     for line in p.stdout.splitlines():
         m = re.match(r"\[ RUN      \] (\S+)", line)
         if m:
-            cur = tests.setdefault(m.group(1), {"served": {}, "declined": {}, "reasons": {}}); continue
+            cur = tests.setdefault(m.group(1), {"served": {}, "declined": {}, "reasons": {}, "why": {}}); continue
         if re.match(r"\[\s+(OK|FAILED)\s+\] ", line):
             cur = None; continue
         m = re.search(r"\[mi355cv\] served (\S+)", line)
@@ -57,6 +57,8 @@ def ledger(positive="*", timeout=1500):
         if m and cur is not None:
             cur["declined"][m.group(1)] = cur["declined"].get(m.group(1), 0) + 1
             cur["reasons"][m.group(1)] = m.group(2)
+            k = (m.group(1), re.sub(r"[-+]?\d+(\.\d+)?(e[-+]?\d+)?", "#", m.group(2))[:200])        # every distinct reason, numbers folded
+            cur["why"][k] = cur["why"].get(k, 0) + 1
     failed = sorted(set(re.findall(r"^\[  FAILED  \] (\S+)", p.stdout, re.M)))
     return p.returncode, tests, failed
 
@@ -133,6 +135,11 @@ def test_ledger_of_the_reference_suite_on_the_gpu():
     lines = [f"reference tests: {len(tests)}; GPU only {len(gpu_only)}, GPU + fallback {len(mixed)}, fallback only {len(cpu_only)}, no hook on their path {len(none)}", "",
              "declined calls per hook (count, last reason):"]
     lines += [f"  {h:28s} {n:7d}  {why}" for h, (n, why) in sorted(hooks.items())]
+    whys = {}
+    for d in tests.values():
+        for k, n in d.get("why", {}).items():
+            whys[k] = whys.get(k, 0) + n
+    lines += ["", "every distinct reason (numbers folded to #), by count:"] + [f"  {n:6d}  {h}: {why}" for (h, why), n in sorted(whys.items(), key=lambda kv: -kv[1])]
     lines += ["", "tests that ran on the fallback only:"] + [f"  {t}: " + ", ".join(f"{h} x{n} ({tests[t]['reasons'][h]})" for h, n in sorted(tests[t]["declined"].items())) for t in cpu_only]
     lines += ["", "tests served partly by the GPU, partly by the fallback:"] + [
         f"  {t}: served " + ", ".join(f"{h} x{n}" for h, n in sorted(tests[t]["served"].items())) + "; declined " +
