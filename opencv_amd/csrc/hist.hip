@@ -158,8 +158,9 @@ MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, u
     const int e = depth == MI355CV_8U ? 1 : 2;
     size_t dss, dds;
     const uchar* ds = stg.in(src_data, src_step, (size_t)width * e, height, &dss);
-    uchar* dd = stg.out(dst_data, dst_step, (size_t)width * e, height, &dds);
-    if (!ds || !dd) return mi355::declined(__func__, __LINE__, "!ds || !dd");
+    // THRESH_DRYRUN (thresh.cpp:1550-1557): cv::threshold wants the level only and hands an EMPTY destination (data == NULL): the histogram and the level, no pass over the image
+    uchar* dd = dst_data ? stg.out(dst_data, dst_step, (size_t)width * e, height, &dds) : nullptr;
+    if (!ds || (dst_data && !dd)) return mi355::declined(__func__, __LINE__, "!ds || (dst_data && !dd)");
     std::vector<int> h;
     if (!histogramToHost(stg, ds, dss, width, height, depth, h)) return MI355CV_ERROR_UNKNOWN;
     // getThreshVal_Otsu, thresh.cpp:1158-1192
@@ -185,8 +186,10 @@ MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, u
     int imaxval = (int)std::lrint(maxValue);
     if (thresholdType == 2) imaxval = ithresh;
     imaxval = std::min(std::max(imaxval, 0), hi);
-    const int rc = mi355cv_threshold(ds, dss, dd, dds, width, height, depth, 1, ithresh, imaxval, thresholdType);
-    if (rc != MI355CV_OK) return rc;
+    if (dd) {
+        const int rc = mi355cv_threshold(ds, dss, dd, dds, width, height, depth, 1, ithresh, imaxval, thresholdType);
+        if (rc != MI355CV_OK) return rc;
+    }
     *thresh = max_val;
     return stg.finish("threshold_otsu");
 }

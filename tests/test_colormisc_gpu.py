@@ -121,6 +121,15 @@ def test_threshold_otsu(cv, orc, dtype):
                 tv, td = orc.orc_thresholdOtsu(src, 200.4, ttype)
                 gv, gd = cv.threshold(dev(src), 0, 200.4, ttype | cv.THRESH_OTSU)
                 assert gv == tv and np.array_equal(gd.cpu().numpy(), td), (dtype, w, h, mode, ttype, gv, tv)
+    # THRESH_DRYRUN through the C ABI (thresh.cpp:1550-1557 hands the hook an EMPTY destination): the level alone, nothing written
+    import ctypes
+    from opencv_amd import _lib
+    src = rng.integers(0, top, (240, 320)).astype(dtype)
+    d = dev(src)
+    level = ctypes.c_double(-1)
+    rc = _lib.lib.mi355cv_threshold_otsu(ctypes.c_void_p(d.data_ptr()), ctypes.c_size_t(d.stride(0) * d.element_size()), None, ctypes.c_size_t(0), 320, 240,
+                                         0 if dtype == np.uint8 else 2, ctypes.c_double(255.0), 0, ctypes.byref(level))
+    assert rc == 0 and level.value == orc.orc_thresholdOtsu(src, 255.0, 0)[0]
 
 
 @pytest.mark.parametrize("code", [52, 53, 68, 69, 60, 61, 72, 73])
