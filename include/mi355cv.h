@@ -99,6 +99,10 @@ MI355CV_API const char* mi355cv_version(void);
 MI355CV_API const char* mi355cv_lastError(void);
 /* template instance + launch geometry of the dominant kernel the calling thread launched last (bench.py reports it beside the roofline) */
 MI355CV_API const char* mi355cv_lastKernel(void);
+/* MI355CV_TRACE=1: every entry point runs inside a roctx range named after it (roctxRangePushA / roctxRangePop, resolved with dlopen; rocprofv3 --marker-trace shows the
+ * hooks around their kernels -- the role of CV_INSTRUMENT_REGION, core/private.hpp:794).  Returns 1 while ranges are emitted, 0 when MI355CV_TRACE is not set, -1 when no
+ * roctx library could be loaded. */
+MI355CV_API int mi355cv_traceState(void);
 /* stream used for launches made by the calling thread on its current device (mi355cv_setDevice): exactly this hipStream_t (NULL = HIP's
  * null stream).  Until called -- or after mi355cv_resetStream() -- a library-owned per-thread, per-device stream is used. */
 MI355CV_API int  mi355cv_setStream(void* hipStream);

@@ -265,7 +265,7 @@ int bilateral32f(const uchar* src_data, size_t src_step, uchar* dst_data, size_t
 extern "C" MI355CV_API int mi355cv_bilateralFilter(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                    int depth, int cn, int d, double sigma_color, double sigma_space, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data))
         return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_32F) || (cn != 1 && cn != 3) || inPlaceOnDevice(src_data, dst_data)");
     const int isolated = border_type & MI355CV_BORDER_ISOLATED;

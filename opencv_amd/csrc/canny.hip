@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_canny_final(const uchar* __restrict__ m
 extern "C" MI355CV_API int mi355cv_canny(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int cn,
                                          double lowThreshold, double highThreshold, int ksize, bool L2gradient)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");

@@ -175,7 +175,7 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoGray(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
                                      int width, int height, int depth, int scn, bool swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runBgr2Gray("cvtBGRtoGray", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, depth, scn, swapBlue);
 }
 
@@ -183,7 +183,7 @@ MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const uchar* src_data, size_t src_step
                                           uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
                                           int width, int height, int depth, int scn, int swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * scn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * depthBytes(depth), height, nframes};
         return runHostBatch("cvtBGRtoGrayBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -196,7 +196,7 @@ MI355CV_API int mi355cv_cvtBGRtoGrayBatch(const uchar* src_data, size_t src_step
 MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
                                      int width, int height, int depth, int dcn)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int e = esz(depth);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -218,7 +218,7 @@ MI355CV_API int mi355cv_cvtGraytoBGR(const uchar* src_data, size_t src_step, uch
 MI355CV_API int mi355cv_cvtBGRtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
                                     int width, int height, int depth, int scn, int dcn, bool swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int e = esz(depth);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)

@@ -799,7 +799,7 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isLab, bool srgb)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -897,7 +897,7 @@ MI355CV_API int mi355cv_cvtBGRtoLab(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isLab, bool srgb)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     if (depth == MI355CV_32F && isLab) {
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -998,7 +998,7 @@ MI355CV_API int mi355cv_cvtLabtoBGR(const uchar* src_data, size_t src_step, ucha
 // count; needs no GPU.
 MI355CV_API int mi355cv_labTable(int which, void* out)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     std::call_once(g_hostOnce, buildHost);
     switch (which) {
     case 0: std::memcpy(out, g_host.gamma, sizeof g_host.gamma); return 256;

@@ -265,7 +265,7 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_step, uchar* y_data, size_t y_step, uchar* uv_data, size_t uv_step,
                                             int width, int height, int scn, bool swapBlue, int uIdx)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -285,7 +285,7 @@ MI355CV_API int mi355cv_cvtBGRtoTwoPlaneYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int scn, bool swapBlue, int uIdx)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (height & 1)");
     MISC_PROLOGUE(width * scn, height, width, height * 3 / 2);
     dim3 grid(divUp(divUp(width, 4), 64), divUp(height / 2, 4));
@@ -299,7 +299,7 @@ MI355CV_API int mi355cv_cvtBGRtoThreePlaneYUV(const uchar* src_data, size_t src_
 MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                             int dcn, bool swapBlue, int uIdx, int ycn)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
@@ -312,7 +312,7 @@ MI355CV_API int mi355cv_cvtOnePlaneYUVtoBGR(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                             int scn, bool swapBlue, int uIdx, int ycn)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || width <= 0 || height <= 0 || (width & 1) || (uIdx != 0 && uIdx != 1) || (ycn != 0 && ycn != 1) || (uIdx == 1 && ycn == 1)");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
@@ -325,7 +325,7 @@ MI355CV_API int mi355cv_cvtOnePlaneBGRtoYUV(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     MISC_PROLOGUE(width * scn * e, height, width * 3 * e, height);
@@ -352,7 +352,7 @@ MI355CV_API int mi355cv_cvtBGRtoXYZ(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     const int e = depth == MI355CV_8U ? 1 : depth == MI355CV_16U ? 2 : 4;
     MISC_PROLOGUE(width * 3 * e, height, width * dcn * e, height);
@@ -379,7 +379,7 @@ MI355CV_API int mi355cv_cvtXYZtoBGR(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int scn, bool swapBlue, int greenBits)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (scn != 3 && scn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * scn, height, width * 2, height);
     if (scn == 3) pix4::launch<3, 2>(st, ds, dss, dd, dds, width, height, OpTo5x5<3>{swapBlue ? 2 : 0, greenBits});
@@ -390,7 +390,7 @@ MI355CV_API int mi355cv_cvtBGRtoBGR5x5(const uchar* src_data, size_t src_step, u
 MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                        int dcn, bool swapBlue, int greenBits)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width * dcn, height);
     if (dcn == 3) pix4::launch<2, 3>(st, ds, dss, dd, dds, width, height, OpFrom5x5<3>{swapBlue ? 2 : 0, greenBits});
@@ -400,7 +400,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toBGR(const uchar* src_data, size_t src_step, u
 
 MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 2, height, width, height);
     pix4::launch<2, 1>(st, ds, dss, dd, dds, width, height, Op5x5ToGray{greenBits});
@@ -409,7 +409,7 @@ MI355CV_API int mi355cv_cvtBGR5x5toGray(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int greenBits)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || (greenBits != 5 && greenBits != 6) || width <= 0 || height <= 0");
     MISC_PROLOGUE(width, height, width * 2, height);
     pix4::launch<1, 2>(st, ds, dss, dd, dds, width, height, OpGrayTo5x5{greenBits});
@@ -418,7 +418,7 @@ MI355CV_API int mi355cv_cvtGraytoBGR5x5(const uchar* src_data, size_t src_step, 
 
 MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<false>{});
@@ -427,7 +427,7 @@ MI355CV_API int mi355cv_cvtRGBAtoMultipliedRGBA(const uchar* src_data, size_t sr
 
 MI355CV_API int mi355cv_cvtMultipliedRGBAtoRGBA(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     MISC_PROLOGUE(width * 4, height, width * 4, height);
     pix4::launch<4, 4>(st, ds, dss, dd, dds, width, height, OpPremul<true>{});

@@ -274,7 +274,7 @@ extern "C" {
 MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isCbCr)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
         return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -310,7 +310,7 @@ MI355CV_API int mi355cv_cvtBGRtoYUV(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isCbCr)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
         return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_16U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -345,7 +345,7 @@ MI355CV_API int mi355cv_cvtYUVtoBGR(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step, const uchar* uv_data, size_t uv_step, uchar* dst_data, size_t dst_step,
                                               int dst_width, int dst_height, int dcn, bool swapBlue, int uIdx)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -367,7 +367,7 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGREx(const uchar* y_data, size_t y_step
 MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int scn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0)
         return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (scn != 3 && scn != 4) || width <= 0 || height <= 0");
     if (depth != MI355CV_8U || !isHSV) {
@@ -412,7 +412,7 @@ MI355CV_API int mi355cv_cvtBGRtoHSV(const uchar* src_data, size_t src_step, ucha
 MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,
                                               int dcn, bool swapBlue, int uIdx)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1))
         return mi355::declined(__func__, __LINE__, "disabled() || (dcn != 3 && dcn != 4) || dst_width <= 0 || dst_height <= 0 || (dst_width & 1) || (dst_height & 1) || (uIdx != 0 && uIdx != 1)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -433,7 +433,7 @@ MI355CV_API int mi355cv_cvtThreePlaneYUVtoBGR(const uchar* src_data, size_t src_
 MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int dst_width, int dst_height,
                                             int dcn, bool swapBlue, int uIdx)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return mi355cv_cvtTwoPlaneYUVtoBGREx(src_data, src_step, src_data + src_step * (size_t)dst_height, src_step, dst_data, dst_step, dst_width, dst_height,
                                          dcn, swapBlue, uIdx);
 }
@@ -442,7 +442,7 @@ MI355CV_API int mi355cv_cvtTwoPlaneYUVtoBGR(const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_cvtHSVtoBGR(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                     int depth, int dcn, bool swapBlue, bool isFullRange, bool isHSV)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0)
         return mi355::declined(__func__, __LINE__, "disabled() || (depth != MI355CV_8U && depth != MI355CV_32F) || (dcn != 3 && dcn != 4) || width <= 0 || height <= 0");
     if (depth != MI355CV_8U || !isHSV) {

@@ -1004,7 +1004,7 @@ extern "C" {
 MI355CV_API int mi355cv_pyrdown(const uchar* src_data, size_t src_step, int src_width, int src_height, uchar* dst_data, size_t dst_step,
                                 int dst_width, int dst_height, int depth, int cn, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runPyrDown("pyrdown", src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, depth, cn, 0, 0, 0, 0, border_type);
 }
 
@@ -1012,7 +1012,7 @@ MI355CV_API int mi355cv_pyrdown_offset(const uchar* src_data, size_t src_step, i
                                        int dst_width, int dst_height, int depth, int cn, int margin_left, int margin_top, int margin_right,
                                        int margin_bottom, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runPyrDown("pyrdown_offset", src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, depth, cn,
                       margin_left, margin_top, margin_right, margin_bottom, border_type);
 }
@@ -1021,7 +1021,7 @@ MI355CV_API int mi355cv_pyrdownBatch(const uchar* src_data, size_t src_step, siz
                                      uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes,
                                      int depth, int cn, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         const size_t pix = (size_t)cn * depthBytes(depth);
         const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
@@ -1037,7 +1037,7 @@ MI355CV_API int mi355cv_pyrdownBatch(const uchar* src_data, size_t src_step, siz
 MI355CV_API int mi355cv_buildPyramid(const uchar* src_data, size_t src_step, int width, int height, int depth, int cn,
                                      uchar** dst_data, const size_t* dst_step, int maxlevel, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!dst_data || !dst_step || maxlevel < 0) return mi355::declined(__func__, __LINE__, "!dst_data || !dst_step || maxlevel < 0");
     const uchar* s = src_data; size_t ss = src_step; int w = width, h = height;
     for (int l = 0; l < maxlevel; l++) {
@@ -1056,7 +1056,7 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
                                           uchar* const* dst_data, const size_t* dst_step, const size_t* dst_frame_stride, int maxlevel, int nframes,
                                           int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !dst_data || !dst_step || !dst_frame_stride || maxlevel < 1 || maxlevel > 30 || nframes < 1");
     int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border == B_CONSTANT || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border == B_CONSTANT || border < 0 || border > B_REFLECT_101");
@@ -1093,14 +1093,14 @@ MI355CV_API int mi355cv_buildPyramidBatch(const uchar* src_data, size_t src_step
 MI355CV_API int mi355cv_cornerHarris(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                      int src_type, int blockSize, int ksize, double k, int borderType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runCorner("cornerHarris", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, src_type, blockSize, ksize, k, borderType, true);
 }
 
 MI355CV_API int mi355cv_cornerMinEigenVal(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                           int src_type, int blockSize, int ksize, int borderType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runCorner("cornerMinEigenVal", src_data, src_step, 0, dst_data, dst_step, 0, 1, width, height, src_type, blockSize, ksize, 0.0, borderType, false);
 }
 
@@ -1108,7 +1108,7 @@ MI355CV_API int mi355cv_cornerHarrisBatch(const uchar* src_data, size_t src_step
                                           size_t dst_frame_stride, int nframes, int width, int height, int src_type, int blockSize, int ksize,
                                           double k, int borderType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type)), height, dst_data, dst_step, dst_frame_stride, (size_t)width * 4, height, nframes};
         return runHostBatch("cornerHarrisBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -1126,7 +1126,7 @@ MI355CV_API int mi355cv_goodFeaturesToTrack(const uchar* src_data, size_t src_st
                                             const uchar* mask_data, size_t mask_step, int blockSize, int gradientSize,
                                             int useHarrisDetector, double harrisK)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !corners || qualityLevel <= 0 || minDistance < 0 || width <= 0 || height <= 0) return -1;
     const int sdepth = MI355CV_MAT_DEPTH(src_type);
     if (MI355CV_MAT_CN(src_type) != 1 || (sdepth != D8U && sdepth != D32F)) return -1;

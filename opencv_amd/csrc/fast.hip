@@ -232,14 +232,14 @@ extern "C" {
 // replaces hal_ni_FAST_dense (modules/features2d/src/hal_replacement.hpp:75; caller hal_FAST fast.cpp:445): TYPE_9_16 only
 MI355CV_API int mi355cv_FAST_dense(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runDense("FAST_dense", src_data, src_step, dst_data, dst_step, width, height, type);
 }
 
 // replaces hal_ni_FAST_NMS (:87; caller fast.cpp:454)
 MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || !src_data || !dst_data || inPlaceOnDevice(src_data, dst_data)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -258,7 +258,7 @@ MI355CV_API int mi355cv_FAST_NMS(const uchar* src_data, size_t src_step, uchar* 
 MI355CV_API int mi355cv_FAST(const uchar* src_data, size_t src_step, int width, int height, int threshold, int nonmax_suppression, int type,
                              float* keypoints_xyr, int capacity)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || type != 2 || width <= 0 || height <= 0 || !src_data || capacity < 0 || (capacity > 0 && !keypoints_xyr)) return -1;
     if ((long long)width * height > 0x7fffffffLL) return -1;
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)

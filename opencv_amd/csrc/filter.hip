@@ -752,7 +752,7 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
         int kernel_width, int kernel_height, int max_width, int max_height, int src_type, int dst_type, int borderType,
         double delta, int anchor_x, int anchor_y, bool allowSubmatrix, bool allowInplace)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     // allowInplace (src_data == dst_data at the call site, filter.dispatch.cpp:1176): a host image goes through separate device buffers, so it is served;
     // a device image filtered in place is refused by mi355cv_filter itself (overlapOnDevice), which the caller treats as "not replaced" (:1177-1183)
     (void)max_width; (void)max_height; (void)allowSubmatrix; (void)allowInplace;
@@ -818,7 +818,7 @@ static bool tryFilterRoll(const FilterCtx* c, const uchar* ds, size_t dss, size_
 MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride,
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
@@ -850,7 +850,7 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
 MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride,
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int scn, bool swapBlue)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled() || (scn != 3 && scn != 4)");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
@@ -882,7 +882,7 @@ MI355CV_API int mi355cv_cvtBGRtoGrayFilterBatch(cvhalFilter2D* context, const uc
 MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
         int width, int height, int full_width, int full_height, int offset_x, int offset_y)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
@@ -916,7 +916,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
 
 MI355CV_API int mi355cv_filterFree(cvhalFilter2D* context)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     delete reinterpret_cast<FilterCtx*>(context);
     return MI355CV_OK;
 }
@@ -925,7 +925,7 @@ MI355CV_API int mi355cv_sepFilterInit(cvhalFilter2D** context, int src_type, int
         uchar* kernelx_data, int kernelx_length, uchar* kernely_data, int kernely_length,
         int anchor_x, int anchor_y, double delta, int borderType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!context || !kernelx_data || !kernely_data || disabled()) return mi355::declined(__func__, __LINE__, "!context || !kernelx_data || !kernely_data || disabled()");
     if (MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1) return mi355::declined(__func__, __LINE__, "MI355CV_MAT_CN(kernel_type) != 1 || kernelx_length < 1 || kernely_length < 1");
     std::vector<double> kx(kernelx_length), ky(kernely_length);
@@ -942,7 +942,7 @@ MI355CV_API int mi355cv_sepFilterInit(cvhalFilter2D** context, int src_type, int
 MI355CV_API int mi355cv_sepFilter(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step,
         int width, int height, int full_width, int full_height, int offset_x, int offset_y)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 2) return mi355::declined(__func__, __LINE__, "!c || c->kind != 2");
     return sepRun("sepFilter", *c, src_data, src_step, dst_data, dst_step, width, height, full_width, full_height, offset_x, offset_y);
@@ -950,7 +950,7 @@ MI355CV_API int mi355cv_sepFilter(cvhalFilter2D* context, uchar* src_data, size_
 
 MI355CV_API int mi355cv_sepFilterFree(cvhalFilter2D* context)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     delete reinterpret_cast<FilterCtx*>(context);
     return MI355CV_OK;
 }
@@ -959,7 +959,7 @@ MI355CV_API int mi355cv_sobel(const uchar* src_data, size_t src_step, uchar* dst
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         int dx, int dy, int ksize, double scale, double delta, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     const bool scharr = ksize <= 0;                                   // FILTER_SCHARR == -1 (getDerivKernels, deriv.cpp:165-171)
     // (depth arguments arrive as cv::Sobel's caller gave them: a type there carries channel bits, deriv.cpp:425-456; the destination was created from the depth bits)
     return derivRun("sobel", src_data, src_step, dst_data, dst_step, width, height, MI355CV_MAT_DEPTH(src_depth), MI355CV_MAT_DEPTH(dst_depth), cn,
@@ -970,7 +970,7 @@ MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* ds
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         int dx, int dy, double scale, double delta, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return derivRun("scharr", src_data, src_step, dst_data, dst_step, width, height, MI355CV_MAT_DEPTH(src_depth), MI355CV_MAT_DEPTH(dst_depth), cn,
                     margin_left, margin_top, margin_right, margin_bottom, dx, dy, 0, true, scale, delta, border_type);
 }
@@ -979,7 +979,7 @@ MI355CV_API int mi355cv_scharr(const uchar* src_data, size_t src_step, uchar* ds
 MI355CV_API int mi355cv_sobelBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step, size_t dst_frame_stride,
         int nframes, int width, int height, int src_depth, int dst_depth, int cn, int dx, int dy, int ksize, double scale, double delta, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (nframes < 1) return mi355::declined(__func__, __LINE__, "nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
@@ -993,7 +993,7 @@ MI355CV_API int mi355cv_sobelBatch(const uchar* src_data, size_t src_step, size_
 MI355CV_API int mi355cv_sepFilterBatch(cvhalFilter2D* context, const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step,
         size_t dst_frame_stride, int nframes, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 2 || nframes < 1) return mi355::declined(__func__, __LINE__, "!c || c->kind != 2 || nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
@@ -1012,7 +1012,7 @@ MI355CV_API int mi355cv_boxFilterBatch(const uchar* src_data, size_t src_step, s
         int nframes, int width, int height, int src_depth, int dst_depth, int cn, size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize,
         int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (nframes < 1) return mi355::declined(__func__, __LINE__, "nframes < 1");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(src_depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(dst_depth), height, nframes};
@@ -1027,7 +1027,7 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return boxRun("boxFilter", src_data, src_step, 0, dst_data, dst_step, 0, 0, width, height, src_depth, dst_depth, cn, margin_left, margin_top, margin_right, margin_bottom,
                   ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type);
 }

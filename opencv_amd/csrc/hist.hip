@@ -123,7 +123,7 @@ extern "C" {
 
 MI355CV_API int mi355cv_equalize_hist(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -149,7 +149,7 @@ MI355CV_API int mi355cv_equalize_hist(const uchar* src_data, size_t src_step, uc
 MI355CV_API int mi355cv_threshold_otsu(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height, int depth,
                                        double maxValue, int thresholdType, double* thresh)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !thresh || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_16U) || thresholdType < 0 || thresholdType > 4)
         return mi355::declined(__func__, __LINE__, "disabled() || !thresh || width <= 0 || height <= 0 || (depth != MI355CV_8U && depth != MI355CV_16U) || thresholdType < 0 || thresholdType > 4");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)

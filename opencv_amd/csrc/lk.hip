@@ -350,7 +350,7 @@ extern "C" {
 
 MI355CV_API int mi355cv_ScharrDeriv(const uchar* src_data, size_t src_step, short* dst_data, size_t dst_step, int width, int height, int cn)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || (dst_step & 3) || ((uintptr_t)dst_data & 3)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -368,7 +368,7 @@ MI355CV_API int mi355cv_ScharrDeriv(const uchar* src_data, size_t src_step, shor
 MI355CV_API int mi355cv_copyMakeBorder(const uchar* src_data, size_t src_step, int width, int height, uchar* dst_data, size_t dst_step,
                                        int top, int bottom, int left, int right, int elem_size, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     border_type &= ~MI355CV_BORDER_ISOLATED;
     if (disabled() || width <= 0 || height <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || elem_size < 1 || elem_size > 64 ||
         border_type < B_CONSTANT || border_type > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || elem_size < 1 || elem_size > 64 || border_type < B_CONSTANT || border_type > B_REFLECT_101");
@@ -388,7 +388,7 @@ MI355CV_API int mi355cv_LKOpticalFlowLevel(const uchar* prev_data, size_t prev_d
                                            const int win_width, const int win_height, int termination_count, double termination_epsilon,
                                            bool get_min_eigen_vals, float min_eigen_vals_threshold)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width < 1 || win_height < 1 || win_width > 64 || win_height > 64 ||
         !prev_points || !next_points || (prev_deriv_step & 1) || point_count > 0x3fffffffu)
         return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width < 1 || win_height < 1 || win_width > 64 || win_height > 64 || !prev_points || !next_points || (prev_deriv_step & 1) || point_count > 0x3fffffffu");
@@ -435,7 +435,7 @@ MI355CV_API int mi355cv_calcOpticalFlowPyrLK(const uchar* prev_data, size_t prev
                                              int win_width, int win_height, int max_level, int criteria_type, int criteria_max_count, double criteria_epsilon,
                                              int flags, double min_eig_threshold)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width <= 2 || win_height <= 2 || win_width > 64 || win_height > 64 || max_level < 0 ||
         max_level > 16 || !prev_points || !next_points || !status || point_count < 0)
         return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || win_width <= 2 || win_height <= 2 || win_width > 64 || win_height > 64 || max_level < 0 || max_level > 16 || !prev_points || !next_points || !status || point_count < 0");

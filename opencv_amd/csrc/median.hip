@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_median_bits_u8(const uchar* __restrict_
 extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                               int depth, int cn, int ksize)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     const bool small = ksize == 3 || ksize == 5;
     const bool typed = depth == MI355CV_16U || depth == MI355CV_16S || depth == MI355CV_32F;      // sort networks: apertures 3 and 5 only, any channel count (the reference asserts the same)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_tile_moments_f(const uchar* __restrict_
 
 extern "C" MI355CV_API int mi355cv_imageMoments(const uchar* src_data, size_t src_step, int src_type, int width, int height, bool binary, double m[10])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !src_data || !m || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !m || width <= 0 || height <= 0");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     const bool isF = depth == MI355CV_32F || depth == MI355CV_64F;

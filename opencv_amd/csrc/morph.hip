@@ -71,7 +71,7 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
         int kernel_type, uchar* kernel_data, size_t kernel_step, int kernel_width, int kernel_height, int anchor_x, int anchor_y,
         int borderType, const double borderValue[4], int iterations, bool allowSubmatrix, bool allowInplace)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     (void)max_width; (void)max_height; (void)allowSubmatrix;
     if (!context || disabled()) return mi355::declined(__func__, __LINE__, "!context || disabled()");
     if (operation != 0 && operation != 1) return mi355::declined(__func__, __LINE__, "operation != 0 && operation != 1");          // MORPH_ERODE / MORPH_DILATE
@@ -108,7 +108,7 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
 MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
         int src_full_width, int src_full_height, int src_roi_x, int src_roi_y, int dst_full_width, int dst_full_height, int dst_roi_x, int dst_roi_y)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
     if (!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "!c || c->magic != MORPH_MAGIC || width <= 0 || height <= 0");
     const int iters = c->iterations;
@@ -167,7 +167,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
 
 MI355CV_API int mi355cv_morphFree(cvhalFilter2D* context)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     MorphCtx* c = reinterpret_cast<MorphCtx*>(context);
     if (!c || c->magic != MORPH_MAGIC) return mi355::declined(__func__, __LINE__, "!c || c->magic != MORPH_MAGIC");
     c->magic = 0;

@@ -118,7 +118,7 @@ extern "C" {
 MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, int width, int height, const uchar* mask, size_t mask_step, const mi355cv_OrbParams* prm,
                                              int use_provided_keypoints, mi355cv_KeyPoint* keypoints, int nkeypoints_in, int capacity, uchar* descriptors, size_t descriptors_step)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !image || !prm || width <= 0 || height <= 0 || capacity < 0 || (capacity > 0 && !keypoints)) return -1;
     const mi355cv_OrbParams p = *prm;
     const bool provided = use_provided_keypoints != 0, doDesc = descriptors != nullptr;

@@ -41,7 +41,10 @@ int  setError(int code, const char* fmt, ...);
 int  declined(const char* fn, int line, const char* cond);
 // first line of every extern "C" entry: the outermost entry on a thread starts a new call serial, so that a reason recorded by an EARLIER call that failed before it
 // opened a Stager (argument checks, runSharded / replicate errors) is never reported as this call's; nested entries keep their caller's serial
-struct EntryGuard { EntryGuard(); ~EntryGuard(); EntryGuard(const EntryGuard&) = delete; EntryGuard& operator=(const EntryGuard&) = delete; };
+// MI355CV_TRACE=1: the guard also opens a roctx range named after the entry (roctxRangePushA / roctxRangePop of librocprofiler-sdk-roctx.so or libroctx64.so, resolved with
+// dlopen at the first traced call -- the library itself links HIP only), so that rocprofv3 --marker-trace / a timeline shows every cv_hal_* hook as a range around its
+// kernels (the reference's CV_INSTRUMENT_REGION / CV_TRACE_REGION role, core/private.hpp:794; SURVEY section 5 tracing row).
+struct EntryGuard { explicit EntryGuard(const char* name); ~EntryGuard(); EntryGuard(const EntryGuard&) = delete; EntryGuard& operator=(const EntryGuard&) = delete; bool traced_ = false; };
 void beginCall();                   // start of a hook invocation (Stager's constructor): reasons recorded by earlier calls no longer count as this call's
 void bump(const char* entry);       // per-entry completed-on-GPU counter
 void noteKernel(const char* fmt, ...);   // name + launch geometry of the dominant kernel the calling thread launched last (mi355cv_lastKernel)

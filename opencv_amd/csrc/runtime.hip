@@ -1,5 +1,6 @@
 // runtime.hip -- process/thread runtime of libmi355cv.so (see rt.h).
 #include "rt.h"
+#include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -96,8 +97,36 @@ int declined(const char* fn, int line, const char* cond)
 }
 void beginCall() { ++t_serial; }
 static thread_local int t_entryDepth = 0;
-EntryGuard::EntryGuard() { if (t_entryDepth++ == 0) ++t_serial; }
-EntryGuard::~EntryGuard() { --t_entryDepth; }
+// roctx, resolved lazily (MI355CV_TRACE=1 only): 0 = not tried, 1 = available, -1 = no library found (tracing stays off, silently)
+typedef int (*RoctxPushFn)(const char*);
+typedef int (*RoctxPopFn)();
+static RoctxPushFn g_roctxPush = nullptr;
+static RoctxPopFn g_roctxPop = nullptr;
+static std::atomic<int> g_roctxState{0};
+static bool roctxReady()
+{
+    static const bool want = envFlag("MI355CV_TRACE");
+    if (!want) return false;
+    int st = g_roctxState.load();
+    if (st == 0) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_roctxState.load() == 0) {
+            void* h = nullptr;
+            for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) { h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+            if (h) { g_roctxPush = (RoctxPushFn)dlsym(h, "roctxRangePushA"); g_roctxPop = (RoctxPopFn)dlsym(h, "roctxRangePop"); }
+            g_roctxState = (g_roctxPush && g_roctxPop) ? 1 : -1;
+        }
+        st = g_roctxState.load();
+    }
+    return st == 1;
+}
+EntryGuard::EntryGuard(const char* name)
+{
+    if (t_entryDepth++ == 0) ++t_serial;
+    if (roctxReady()) { g_roctxPush(name ? name : "mi355cv"); traced_ = true; }
+}
+EntryGuard::~EntryGuard() { if (traced_) g_roctxPop(); --t_entryDepth; }
+extern "C" MI355CV_API int mi355cv_traceState(void) { return roctxReady() ? 1 : g_roctxState.load(); }   // 1: ranges are being emitted; 0: MI355CV_TRACE not set; -1: no roctx library
 
 // MI355CV_PRINT_COUNTS=1: at process exit, one line per entry point with the number of calls the GPU served -- how a host program that
 // cannot call mi355cv_callCount (the reference's own test binary, tests/test_reference_suite.py) shows that its cv:: calls ran here

@@ -35,7 +35,7 @@ MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int g, int* first, in
 // with mi355cv_lastError() of the CALLING thread naming the slot, its device and the failing thread's own error text.
 MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, int (*fn)(void* user, int slot, int device, int first, int count), void* user, int bind)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (ndev < 1 || ndev > 64 || nframes < 0 || !fn) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_runSharded: ndev %d (1 .. 64), nframes %d, fn %p", ndev, nframes, (void*)fn);
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> why(ndev);
@@ -70,7 +70,7 @@ MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, in
 // to that device (or hipFree).  Returns 0, or -1 after freeing whatever it had allocated.
 MI355CV_API int mi355cv_replicate(const void* src, size_t bytes, int ndev, const int* devices, void** out)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!src || !out || ndev < 1 || ndev > 64 || !bytes) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: bad arguments");
     const int before = threadDeviceBinding();
     int done = 0, rc = 0;

@@ -745,7 +745,7 @@ MI355CV_API int mi355cv_gaussianBlurBinomial(const uchar* src_data, size_t src_s
         int width, int height, int depth, int cn, size_t margin_left, size_t margin_top, size_t margin_right,
         size_t margin_bottom, size_t ksize, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (depth == MI355CV_16U)
         return runBinom16("gaussianBlurBinomial", src_data, src_step, dst_data, dst_step, width, height, cn, (int)margin_left, (int)margin_top, (int)margin_right,
                                  (int)margin_bottom, (int)ksize, border_type & ~MI355CV_BORDER_ISOLATED);
@@ -774,7 +774,7 @@ MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const uchar* src_data, size_t 
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int cn, size_t ksize, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
     const uint16_t* k = binomTaps(ksize);
     if (!k) return mi355::declined(__func__, __LINE__, "!k");
@@ -793,7 +793,7 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
         int width, int height, int depth, int cn, size_t margin_left, size_t margin_top, size_t margin_right,
         size_t margin_bottom, size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     // 8U only here: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724).
     // Other depths go through sepFilter2D in the reference (:825) -- see mi355cv_sepFilter*.
     if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
@@ -824,7 +824,7 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
 // "gauss_variant" 1|2|3
 MI355CV_API int mi355cv_setParam(const char* key, int value)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!key) return -1;
     if (!strcmp(key, "gauss_seg")) { tuneSeg() = value; return 0; }
     if (!strcmp(key, "gauss_variant")) { tuneVariant() = value; return 0; }
@@ -836,7 +836,7 @@ MI355CV_API int mi355cv_setParam(const char* key, int value)
 // streaming-copy probe: copies `bytes` (multiple of 16) device->device with 16 B/lane accesses
 MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int perThread, int nt)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!ensureDevice() || (bytes & 15) || perThread < 1) return mi355::declined(__func__, __LINE__, "!ensureDevice() || (bytes & 15) || perThread < 1");
     size_t n16 = bytes / 16;
     size_t blocks = (n16 + (size_t)256 * perThread - 1) / ((size_t)256 * perThread);
@@ -849,7 +849,7 @@ MI355CV_API int mi355cv_copyProbe(const void* src, void* dst, size_t bytes, int 
 
 MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int H, int nframes, int segRows, int unroll)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!ensureDevice() || (W & 15)) return mi355::declined(__func__, __LINE__, "!ensureDevice() || (W & 15)");
     const int nchunks = W / 16, nstrips = divUp(nchunks, 64), nseg = divUp(H, segRows);
     const long long items = (long long)nstrips * nseg * nframes;
@@ -867,7 +867,7 @@ MI355CV_API int mi355cv_copyProbeColwalk(const void* src, void* dst, int W, int 
 // host-side tap generator, exported so bindings can show / test the exact Q8.8 kernel in use
 MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* taps)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     std::vector<int64_t> q;
     if (!gaussianKernelFixedQ(n, sigma, fractionBits, q)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ(n, sigma, fractionBits, q)");
     for (int i = 0; i < n; i++) taps[i] = q[i];
@@ -876,7 +876,7 @@ MI355CV_API int mi355cv_getGaussianKernelQ(int n, double sigma, int fractionBits
 
 MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double* taps)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     std::vector<double> k;
     if (!gaussianKernelBitExact(n, sigma, k)) return mi355::declined(__func__, __LINE__, "!gaussianKernelBitExact(n, sigma, k)");
     for (int i = 0; i < n; i++) taps[i] = k[i];
@@ -887,7 +887,7 @@ MI355CV_API int mi355cv_sepSmoothFixedU8(const uchar* src_data, size_t src_step,
         int width, int height, int cn, size_t margin_left, size_t margin_top, size_t margin_right, size_t margin_bottom,
         const uint16_t* kx, int kxlen, const uint16_t* ky, int kylen, int border_type)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!kx || !ky) return mi355::declined(__func__, __LINE__, "!kx || !ky");
     bool binom = kxlen == kylen && (kxlen == 3 || kxlen == 5);
     if (binom) {

@@ -1498,7 +1498,7 @@ MI355CV_API int mi355cv_matchTemplateMask(const uchar* img_data, size_t img_step
                                           const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
                                           const uchar* mask_data, size_t mask_step, int mask_type, uchar* result_data, size_t result_step, int method)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runMatchMask("matchTemplateMask", img_data, img_step, img_width, img_height, templ_data, templ_step, templ_width, templ_height, type,
                         mask_data, mask_step, mask_type, result_data, result_step, method);
 }
@@ -1509,7 +1509,7 @@ MI355CV_API int mi355cv_matchTemplate(const uchar* img_data, size_t img_step, in
                                       const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
                                       uchar* result_data, size_t result_step, int method)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runMatch("matchTemplate", img_data, img_step, 0, 1, img_width, img_height, templ_data, templ_step, templ_width, templ_height, type,
                     result_data, result_step, 0, method);
 }
@@ -1518,7 +1518,7 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
                                            const uchar* templ_data, size_t templ_step, int templ_width, int templ_height, int type,
                                            uchar* result_data, size_t result_step, size_t result_frame_stride, int method)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     // frames and results in host memory: chunks through two sets of device buffers (rt.h runHostBatch); the template is staged per chunk
     if (nframes > 1 && img_width >= templ_width && img_height >= templ_height && templ_width >= 1 && templ_height >= 1 && hostBatchEligible(img_data, result_data, nframes)) {
         const int e = MI355CV_MAT_DEPTH(type) == D8U ? 1 : 4;
@@ -1537,7 +1537,7 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar* src_data, size_t src_step, uchar* sum_data, size_t sum_step,
                                  uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     (void)tilted_step;
     if (disabled() || tilted_data || !sum_data) return mi355::declined(__func__, __LINE__, "disabled() || tilted_data || !sum_data");
     const bool ok = (depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F);
@@ -1586,7 +1586,7 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
 MI355CV_API int mi355cv_integralBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* sum_data, size_t sum_step, size_t sum_frame_stride,
                                       uchar* sqsum_data, size_t sqsum_step, size_t sqsum_frame_stride, int nframes, int width, int height, int sdepth)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)) return mi355::declined(__func__, __LINE__, "disabled() || !src_data || !sum_data || nframes < 1 || width <= 0 || height <= 0 || (sdepth != D32S && sdepth != D64F)");
     const size_t se = sdepth == D32S ? 4 : 8;
     if ((sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))) return mi355::declined(__func__, __LINE__, "(sum_step % se) || (sum_frame_stride % se) || (sqsum_data && ((sqsum_step % 8) || (sqsum_frame_stride % 8)))");

@@ -145,7 +145,7 @@ extern "C" MI355CV_API int mi355cv_getGaussianKernel(int n, double sigma, double
 extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                                      double maxValue, int adaptiveMethod, int thresholdType, int blockSize, double C)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return mi355::declined(__func__, __LINE__, "(adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)");
     if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return mi355::declined(__func__, __LINE__, "blockSize < 3 || !(blockSize & 1) || blockSize > 255");
@@ -190,7 +190,7 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
 extern "C" MI355CV_API int mi355cv_threshold(const uchar* src_data, size_t src_step, uchar* dst_data, size_t dst_step, int width, int height,
                                              int depth, int cn, double thresh, double maxValue, int thresholdType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4");
     if (thresholdType < 0 || thresholdType > 4) return mi355::declined(__func__, __LINE__, "thresholdType < 0 || thresholdType > 4");
     // (CV_64F: thresh_64f thresh.cpp:930-1110, the same five rules on doubles -- round 5; CV_32S is not a depth cv::threshold takes, :1677)
@@ -228,7 +228,7 @@ extern "C" MI355CV_API int mi355cv_thresholdBatch(const uchar* src_data, size_t 
                                                   size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn, double thresh, double maxValue,
                                                   int thresholdType)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (nframes < 1 || height <= 0) return mi355::declined(__func__, __LINE__, "nframes < 1 || height <= 0");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * cn * depthBytes(depth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * cn * depthBytes(depth), height, nframes};

@@ -2699,7 +2699,7 @@ extern "C" {
 MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, double inv_scale_x, double inv_scale_y, int interpolation)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     return runResize("resize", src_type, src_data, src_step, 0, src_width, src_height, dst_data, dst_step, 0, dst_width, dst_height, 1, inv_scale_x, inv_scale_y, interpolation);
 }
 
@@ -2708,7 +2708,7 @@ MI355CV_API int mi355cv_resize(int src_type, const uchar* src_data, size_t src_s
 MI355CV_API int mi355cv_resizeBatch(int src_type, const uchar* src_data, size_t src_step, size_t src_frame_stride, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, double inv_scale_x, double inv_scale_y, int interpolation)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         const size_t pix = (size_t)MI355CV_MAT_CN(src_type) * depthBytes(MI355CV_MAT_DEPTH(src_type));
         const HostBatch hb = {src_data, src_step, src_frame_stride, pix * src_width, src_height, dst_data, dst_step, dst_frame_stride, pix * dst_width, dst_height, nframes};
@@ -2723,7 +2723,7 @@ MI355CV_API int mi355cv_warpAffineBatch(int src_type, const uchar* src_data, siz
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[6], int interpolation, int borderType,
         const double borderValue[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!M) return mi355::declined(__func__, __LINE__, "!M");
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
@@ -2750,7 +2750,7 @@ MI355CV_API int mi355cv_warpPerspectiveBatch(int src_type, const uchar* src_data
         uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int dst_width, int dst_height, int nframes, const double M[9], int interpolation, int borderType,
         const double borderValue[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!M) return mi355::declined(__func__, __LINE__, "!M");
     if (src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {        // frames in host memory
         // BORDER_TRANSPARENT keeps the caller's pixels where the map leaves the source: the pipeline's device buffers do not hold them, so
@@ -2777,7 +2777,7 @@ MI355CV_API int mi355cv_warpAffine(int src_type, const uchar* src_data, size_t s
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[6], int interpolation, int borderType,
         const double borderValue[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!M) return mi355::declined(__func__, __LINE__, "!M");
     return runWarp("warpAffine", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 0, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
@@ -2787,7 +2787,7 @@ MI355CV_API int mi355cv_warpPerspective(int src_type, const uchar* src_data, siz
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const double M[9], int interpolation, int borderType,
         const double borderValue[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!M) return mi355::declined(__func__, __LINE__, "!M");
     return runWarp("warpPerspective", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    M, 1, interpolation, borderType, borderValue, nullptr, 0, nullptr, 0);
@@ -2797,7 +2797,7 @@ MI355CV_API int mi355cv_remap32f(int src_type, const uchar* src_data, size_t src
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float* mapx, size_t mapx_step, float* mapy, size_t mapy_step,
         int interpolation, int border_type, const double border_value[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!mapx || !mapy) return mi355::declined(__func__, __LINE__, "!mapx || !mapy");
     return runWarp("remap32f", src_type, src_data, src_step, src_width, src_height, dst_data, dst_step, dst_width, dst_height,
                    nullptr, 2, interpolation, border_type, border_value, mapx, mapx_step, mapy, mapy_step);
@@ -2810,7 +2810,7 @@ MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_st
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, const void* map1, size_t map1_step, int map1_type,
         const void* map2, size_t map2_step, int map2_type, int interpolation, int border_type, const double border_value[4])
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (!map1) return mi355::declined(__func__, __LINE__, "!map1");
     const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
     const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
@@ -2835,7 +2835,7 @@ MI355CV_API int mi355cv_remap(int src_type, const uchar* src_data, size_t src_st
 MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1_type, const void* map2, size_t map2_step, int map2_type,
         void* dstmap1, size_t dstmap1_step, int dstmap1_type, void* dstmap2, size_t dstmap2_step, int width, int height, int nninterpolate)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || !map1 || !dstmap1 || width <= 0 || height <= 0");
     const int t32fc1 = MI355CV_MAKETYPE(MI355CV_32F, 1), t32fc2 = MI355CV_MAKETYPE(MI355CV_32F, 2), t16sc2 = MI355CV_MAKETYPE(MI355CV_16S, 2);
     const int t16uc1 = MI355CV_MAKETYPE(MI355CV_16U, 1), t16sc1 = MI355CV_MAKETYPE(MI355CV_16S, 1);
@@ -2868,7 +2868,7 @@ MI355CV_API int mi355cv_convertMaps(const void* map1, size_t map1_step, int map1
 MI355CV_API int mi355cv_warpPolar(int src_type, const uchar* src_data, size_t src_step, int src_width, int src_height,
         uchar* dst_data, size_t dst_step, int dst_width, int dst_height, float center_x, float center_y, double maxRadius, int flags)
 {
-    mi355::EntryGuard entry_;
+    mi355::EntryGuard entry_(__func__);
     if (disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || dst_width <= 0 || dst_height <= 0 || src_width <= 0 || src_height <= 0");
     const bool semiLog = (flags & 256) != 0;                                                  // WARP_POLAR_LOG
     const double bv[4] = {0, 0, 0, 0};

@@ -178,3 +178,24 @@ print("ERRORS" if errors else "TWO_ORDINALS_OK", errors)
     if "ONE_ORDINAL" in p.stdout or p.returncode != 0 and "TWO_ORDINALS_OK" not in p.stdout and "ERRORS" not in p.stdout:
         pytest.skip("the HIP runtime does not expose one GPU under two ordinals: " + (p.stdout + p.stderr)[-200:])
     assert "TWO_ORDINALS_OK" in p.stdout, (p.stdout[-500:], p.stderr[-500:])
+
+
+def test_roctx_ranges_under_trace_switch():
+    """MI355CV_TRACE=1 (SURVEY section 5 tracing row): every entry point runs inside a roctx range -- the marker library is found with dlopen, the
+    state query says so, and the hooks keep working; without the switch nothing is loaded"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch, sys
+        sys.path.insert(0, %r)
+        import opencv_amd as cv
+        from opencv_amd import _lib
+        img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (270, 480), dtype=np.uint8)).cuda()
+        out = cv.GaussianBlur(img, (5, 5), 0)
+        torch.cuda.synchronize()
+        print("STATE", _lib.lib.mi355cv_traceState(), int(out.sum()) > 0)
+    """ % ROOT)
+    for env_val, want in (("1", "STATE 1 True"), (None, "STATE 0 True")):
+        env = dict(os.environ); env.pop("MI355CV_TRACE", None)
+        if env_val: env["MI355CV_TRACE"] = env_val
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and want in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
