@@ -91,10 +91,13 @@ MI355CV_API int  mi355cv_getDevice(void);
  * bound to devices[slot] (NULL: ordinals 0 .. ndev-1; an ordinal may repeat) when bind != 0; fn calls the ordinary mi355cv_* entry points on its frames, which must live
  * on that device (or in host / managed memory).  Returns 0, or the first non-zero code in slot order (mi355cv_lastError names slot and device).  There is no data-path
  * collective: parameters given as host arguments are uploaded by each device's own hooks; a device-resident parameter image (a matchTemplate template) is copied to every
- * device with mi355cv_replicate (hipMemcpy, peer-to-peer over xGMI between GPUs; RCCL is only used by the Python layer's torch.distributed broadcast). */
+ * device with mi355cv_replicate (hipMemcpy, peer-to-peer over xGMI between GPUs; MI355CV_REPLICATE=rccl: an RCCL ncclBroadcast instead; the Python layer broadcasts through torch.distributed). */
 MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int slot, int* first, int* count);
 MI355CV_API int  mi355cv_runSharded(int ndev, const int* devices, int nframes, int (*fn)(void* user, int slot, int device, int first, int count), void* user, int bind);
 MI355CV_API int  mi355cv_replicate(const void* src, size_t bytes, int ndev, const int* devices, void** out);
+/* how the last mi355cv_replicate of this process moved its data: 0 = one hipMemcpy per device (the default), 1 = one upload to the first device + an RCCL ncclBroadcast from
+ * there over xGMI (MI355CV_REPLICATE=rccl; librccl.so is resolved with dlopen; a device list RCCL cannot take -- a device twice, no library -- uses the copies) */
+MI355CV_API int  mi355cv_replicateMode(void);
 MI355CV_API const char* mi355cv_version(void);
 MI355CV_API const char* mi355cv_lastError(void);
 /* template instance + launch geometry of the dominant kernel the calling thread launched last (bench.py reports it beside the roofline) */

@@ -43,6 +43,7 @@ def _load():
         "mi355cv_lastError": (ctypes.c_char_p, []),
         "mi355cv_lastKernel": (ctypes.c_char_p, []),
         "mi355cv_traceState": (ctypes.c_int, []),
+        "mi355cv_replicateMode": (ctypes.c_int, []),
         "mi355cv_sobelBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int]),
         "mi355cv_sepFilterBatch": (c_int, [ctypes.c_void_p, c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int]),
         "mi355cv_boxFilterBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_int, c_sz, c_sz, c_int, c_int, ctypes.c_bool, c_int]),

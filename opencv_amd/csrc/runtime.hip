@@ -158,11 +158,16 @@ void bump(const char* entry)
     if (ledgerLog()) { fprintf(stderr, "[mi355cv] served %s\n", entry); fflush(stderr); }
 }
 
+static char g_nDevWhy[160] = "";                    // what hipGetDeviceCount said when it found no device (reported by mi355cv_setDevice)
 static int deviceCount()
 {
     int n = g_nDev.load();
     if (n == -2) {
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 0; }
+        const hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            snprintf(g_nDevWhy, sizeof g_nDevWhy, "hipGetDeviceCount: %s, %d device(s)", hipGetErrorString(e), n);
+            (void)hipGetLastError(); n = 0;
+        }
         if (n > MAX_DEV) n = MAX_DEV;
         g_nDev = n;
     }
@@ -538,7 +543,7 @@ MI355CV_API int mi355cv_deviceCount(void) { return deviceCount(); }
 MI355CV_API int mi355cv_setDevice(int device)
 {
     if (device < 0) { t_dev = -1; return 0; }
-    if (device >= deviceCount()) { setError(MI355CV_ERROR_UNKNOWN, "mi355cv_setDevice(%d): %d device(s) visible", device, deviceCount()); return -1; }
+    if (device >= deviceCount()) { setError(MI355CV_ERROR_UNKNOWN, "mi355cv_setDevice(%d): %d device(s) visible%s%s", device, deviceCount(), g_nDevWhy[0] ? " -- " : "", g_nDevWhy); return -1; }
     const int before = t_dev;
     t_dev = device;
     if (resolveDevice() < 0) { t_dev = before; return -1; }

@@ -3,10 +3,15 @@
 // device binds itself with mi355cv_setDevice and runs the caller's per-shard function there -- which calls the ordinary mi355cv_* entry points (batch or
 // per-frame) on that shard's frames.  No data-path collective exists on this path (no cv:: function here has cross-frame dependencies); the only
 // thing replicated is parameters: host-side arguments (filter taps, warp matrices) are re-uploaded per call by every device's own hooks, and device-resident
-// parameter images (a matchTemplate template) are copied to every device by mi355cv_replicate -- plain hipMemcpy (peer-to-peer over xGMI when the source lives
-// on another GPU, PCIe when it is host memory); RCCL is not used by the C ABI (the Python layer's torch.distributed broadcast is, opencv_amd/shard.py).
+// parameter images (a matchTemplate template) are copied to every device by mi355cv_replicate -- by default plain hipMemcpy (peer-to-peer over xGMI when the source
+// lives on another GPU, PCIe when it is host memory); with MI355CV_REPLICATE=rccl one upload to the first device and an RCCL ncclBroadcast from there to the others over
+// xGMI (north_star: "RCCL broadcast of shared filter weights over xGMI"; librccl.so is resolved with dlopen, the library itself links HIP only).  The Python layer
+// broadcasts through torch.distributed (backend nccl = RCCL), opencv_amd/shard.py.
 #include "rt.h"
+#include <dlfcn.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -15,7 +20,88 @@
 
 using namespace mi355;
 
+namespace {
+
+// ---- RCCL broadcast of a parameter image (MI355CV_REPLICATE=rccl).  One process, one communicator per device of the list (ncclCommInitAll; kept for the list's lifetime:
+// setting one up costs tens of milliseconds), one group call: every slot posts ncclBroadcast(root = slot 0) on a stream of its own device, the data travels GPU to GPU over xGMI.
+typedef void* NcclComm;
+struct Rccl {
+    int (*commInitAll)(NcclComm*, int, const int*) = nullptr;
+    int (*broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*groupStart)() = nullptr;
+    int (*groupEnd)() = nullptr;
+    const char* (*errorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl t;
+        void* h = nullptr;
+        for (const char* lib : {"librccl.so.1", "librccl.so"}) { h = dlopen(lib, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) return t;
+        t.commInitAll = (int (*)(NcclComm*, int, const int*))dlsym(h, "ncclCommInitAll");
+        t.broadcast = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))dlsym(h, "ncclBroadcast");
+        t.groupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        t.groupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+        t.errorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        t.ok = t.commInitAll && t.broadcast && t.groupStart && t.groupEnd;
+        return t;
+    }();
+    return r;
+}
+std::mutex g_rcclMu;
+std::map<std::vector<int>, std::vector<NcclComm>> g_rcclComms;
+std::atomic<int> g_lastReplicateMode{0};
+
+// 0: done over RCCL; > 0: RCCL not usable here (the caller copies instead); < 0: failed after allocating (everything freed, error recorded)
+int replicateRccl(const void* src, size_t bytes, int ndev, const int* devices, void** out)
+{
+    Rccl& r = rccl();
+    if (!r.ok) return 1;
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; i++) devs[i] = devices ? devices[i] : i;
+    { std::vector<int> u = devs; std::sort(u.begin(), u.end()); if (std::adjacent_find(u.begin(), u.end()) != u.end()) return 1; }      // a communicator needs distinct devices
+    std::lock_guard<std::mutex> lk(g_rcclMu);                       // one broadcast at a time per process: communicators are shared
+    std::vector<NcclComm>* comms;
+    auto it = g_rcclComms.find(devs);
+    if (it == g_rcclComms.end()) {
+        std::vector<NcclComm> c(ndev, nullptr);
+        const int e = r.commInitAll(c.data(), ndev, devs.data());
+        if (e != 0) { setError(MI355CV_NOT_IMPLEMENTED, "mi355cv_replicate: ncclCommInitAll failed: %s", r.errorString ? r.errorString(e) : "?"); return 1; }
+        comms = &g_rcclComms.emplace(devs, std::move(c)).first->second;
+    } else comms = &it->second;
+    std::vector<hipStream_t> st(ndev, nullptr);
+    int rc = 0, made = 0;
+    for (; made < ndev && rc == 0; made++) {
+        out[made] = nullptr;
+        if (mi355cv_setDevice(devs[made]) != 0) { rc = -1; break; }
+        Stager stg;
+        if (!ensureDevice() || hipMalloc(&out[made], bytes) != hipSuccess || hipStreamCreateWithFlags(&st[made], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError(); rc = setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: allocation on device %d failed", devs[made]); made++; break;
+        }
+        if (made == 0 && hipMemcpy(out[0], src, bytes, hipMemcpyDefault) != hipSuccess)                      // the one upload: host -> first device (or a peer copy)
+            rc = setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: copy to device %d failed: %s", devs[0], hipGetErrorString(hipGetLastError()));
+    }
+    if (rc == 0) {
+        int e = r.groupStart();
+        for (int i = 0; i < ndev && e == 0; i++) e = r.broadcast(out[0], out[i], bytes, 0 /* ncclChar */, 0 /* root: slot 0 */, (*comms)[i], st[i]);
+        const int e2 = r.groupEnd();
+        if (e == 0) e = e2;
+        for (int i = 0; i < ndev; i++) if (st[i]) { (void)mi355cv_setDevice(devs[i]); Stager stg; if (ensureDevice() && hipStreamSynchronize(st[i]) != hipSuccess && e == 0) e = -1; }
+        if (e != 0) rc = setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: ncclBroadcast failed: %s", e > 0 && r.errorString ? r.errorString(e) : hipGetErrorString(hipGetLastError()));
+    }
+    for (int i = 0; i < ndev; i++) if (st[i]) (void)hipStreamDestroy(st[i]);
+    if (rc != 0) for (int i = 0; i < ndev; i++) if (out[i]) { (void)hipFree(out[i]); out[i] = nullptr; }
+    return rc == 0 ? 0 : -1;
+}
+
+} // namespace
+
 extern "C" {
+
+// how the last mi355cv_replicate of this process moved its data: 0 = hipMemcpy per device, 1 = one upload + RCCL ncclBroadcast (MI355CV_REPLICATE=rccl)
+MI355CV_API int mi355cv_replicateMode(void) { return g_lastReplicateMode.load(); }
 
 // frames [first, first + count) of device slot g (0 <= g < ndev): the partition every layer of this repository uses
 MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int g, int* first, int* count)
@@ -37,6 +123,9 @@ MI355CV_API int mi355cv_runSharded(int ndev, const int* devices, int nframes, in
 {
     mi355::EntryGuard entry_(__func__);
     if (ndev < 1 || ndev > 64 || nframes < 0 || !fn) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_runSharded: ndev %d (1 .. 64), nframes %d, fn %p", ndev, nframes, (void*)fn);
+    // the device list is read on the CALLING thread first: a process whose very first HIP call comes from one of the worker threads below found "no ROCm-capable device"
+    // on the MI355X box (tests/test_shard_cabi.py run on its own, round 5); from the calling thread the runtime initialises as everywhere else
+    if (bind) (void)mi355cv_deviceCount();
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> why(ndev);
     std::vector<std::thread> th;
@@ -74,6 +163,17 @@ MI355CV_API int mi355cv_replicate(const void* src, size_t bytes, int ndev, const
     if (!src || !out || ndev < 1 || ndev > 64 || !bytes) return setError(MI355CV_ERROR_UNKNOWN, "mi355cv_replicate: bad arguments");
     const int before = threadDeviceBinding();
     int done = 0, rc = 0;
+    {
+        static const bool wantRccl = [] { const char* v = getenv("MI355CV_REPLICATE"); return v && !strcmp(v, "rccl"); }();
+        g_lastReplicateMode = 0;
+        if (wantRccl) {
+            const int r = replicateRccl(src, bytes, ndev, devices, out);
+            (void)mi355cv_setDevice(before);
+            if (r == 0) { g_lastReplicateMode = 1; return 0; }
+            if (r < 0) return -1;                                   // allocation / copy failure: reported, nothing left allocated
+            // r > 0: RCCL not available for this device list (library missing, a device listed twice, communicator setup failed): the copies below
+        }
+    }
     for (; done < ndev; done++) {
         out[done] = nullptr;
         if (mi355cv_setDevice(devices ? devices[done] : done) != 0) { rc = -1; break; }

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_16S, CV_32F, _DEPTH_T,  # noqa: F401
+from .core import (Img, empty_like_kind, bind_stream, torch, CV_8U, CV_16U, CV_16S, CV_32F, CV_64F, _DEPTH_T,  # noqa: F401
                    BORDER_CONSTANT, BORDER_ISOLATED, BORDER_DEFAULT)
 
 L = _lib.lib

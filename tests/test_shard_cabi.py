@@ -3,10 +3,13 @@ opencv_amd.shard.frame_range and to what bench.py --gpus N gives each rank), mi3
 failing slot.  CPU: partition, threading, error propagation (bind = 0, no device touched).  GPU: the same runner driving a sharded GaussianBlur batch through
 device slots (0, 0) -- two host threads, own streams and scratch pools, one GPU -- and mi355cv_replicate of a matchTemplate template."""
 import ctypes
+import os
 import threading
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from opencv_amd import _lib, shard
 
@@ -96,3 +99,38 @@ def test_sharded_batch_through_the_c_abi_on_duplicated_ordinals(orc):
     back = np.empty_like(tpl)
     assert L.mi355cv_download(back.ctypes.data, ctypes.c_void_p(out[0]), back.size) == 0 and np.array_equal(back, tpl)
     L.mi355cv_deviceFree(ctypes.c_void_p(out[0]))
+
+
+@pytest.mark.gpu
+def test_replicate_over_rccl():
+    """MI355CV_REPLICATE=rccl (north_star: "RCCL broadcast of shared filter weights over xGMI"): mi355cv_replicate uploads once and broadcasts with
+    ncclBroadcast on communicators of its own (librccl through dlopen).  On the one-GPU test box the communicator has one rank -- the code path (library, communicator, group
+    call, streams) runs, the data is checked; with two GPUs the broadcast crosses xGMI; a list that names a device twice cannot form a communicator and takes the copies.
+    A process of its own: the switch is read once."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes, numpy as np, torch, sys
+        sys.path.insert(0, %r)
+        from opencv_amd import _lib
+        L = _lib.lib
+        n = min(torch.cuda.device_count(), 2)
+        tpl = np.random.default_rng(5).integers(0, 256, (128, 128), dtype=np.uint8)
+        out = (ctypes.c_void_p * 2)()
+        devs = (ctypes.c_int * 2)(0, 1)
+        rc = L.mi355cv_replicate(tpl.ctypes.data, tpl.size, n, devs, out)
+        assert rc == 0, L.mi355cv_lastError()
+        print("MODE", L.mi355cv_replicateMode(), "RANKS", n)
+        for i in range(n):
+            assert L.mi355cv_setDevice(i) == 0
+            back = np.empty_like(tpl)
+            assert L.mi355cv_download(back.ctypes.data, ctypes.c_void_p(out[i]), back.size) == 0 and np.array_equal(back, tpl), i
+            L.mi355cv_deviceFree(ctypes.c_void_p(out[i]))
+        L.mi355cv_setDevice(-1)
+        rc = L.mi355cv_replicate(tpl.ctypes.data, tpl.size, 2, (ctypes.c_int * 2)(0, 0), out)          # the same device twice: copies
+        assert rc == 0 and L.mi355cv_replicateMode() == 0
+        print("DUP ok")
+    """ % ROOT)
+    env = dict(os.environ); env["MI355CV_REPLICATE"] = "rccl"
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2500:])
+    assert "MODE 1" in p.stdout and "DUP ok" in p.stdout, p.stdout
