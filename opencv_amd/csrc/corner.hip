@@ -354,14 +354,11 @@ void launchPyrDown(const uchar* ds, size_t dss, size_t sframe, int sw, int sh, u
         // rows a segment re-reads come from L2: its vertical neighbours run at the same time)
         roll::Geom g = roll::geometry(sw, sh, 1, nframes, 32, 8, 16, 4096);
         if (g.seg & 1) { g.seg++; g.nseg = divUp(sh, g.seg); g.blocks = (unsigned)(((long long)g.nstrips * g.nseg * nframes + 3) / 4); }
-        const char* ringE = getenv("MI355CV_PYR_RING"); const int ringEnv = ringE ? atoi(ringE) : 0;   // tuning experiments
-        const int ring = ringEnv ? ringEnv : 8;
+        // (8 source rows in flight per wave: 4 and 12 measured the same or slower, profiles/r03_pyramid.txt)
         // neighbouring segments walk towards / away from each other (roll.h `alt`), partners one turn of the XCD round-robin apart; MI355CV_PYR_ALT=0: all downwards
         static const int altEnv = [] { const char* v = getenv("MI355CV_PYR_ALT"); return v ? atoi(v) : -1; }();
         const int alt = altEnv == 0 ? 0 : altEnv > 0 ? altEnv : (32 % g.nstrips == 0 ? std::max(32 / g.nstrips, 2) : 8);
-        if (ring >= 12)     hipLaunchKernelGGL(k_pyrdown_roll<12>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
-        else if (ring >= 8) hipLaunchKernelGGL(k_pyrdown_roll<8>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
-        else                hipLaunchKernelGGL(k_pyrdown_roll<4>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
+        hipLaunchKernelGGL(k_pyrdown_roll<8>, dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, sw, sh, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, alt);
         return;
     }
     dim3 grid(divUp(dw * cn, 64), divUp(dh, 4), nframes);
@@ -895,12 +892,10 @@ int launchCorner(const uchar* ds, size_t dss, size_t sframe, uchar* dd, size_t d
             return MI355CV_OK;
         }
         CornerRollArgs ra = {a.dyRow[0], a.dyRow[1], a.dyRow[2], a.dxCol[1], a.dxCol[2], a.kf};
-        const bool wide = std::getenv("MI355CV_CORNER_CB16") != nullptr && W >= 16;
         const char* segEnv = std::getenv("MI355CV_CORNER_SEG");               // tuning experiments
-        const roll::Geom g = roll::geometry(W, H, 1, nframes, segEnv ? atoi(segEnv) : 36, 4, wide ? 16 : 8);
+        const roll::Geom g = roll::geometry(W, H, 1, nframes, segEnv ? atoi(segEnv) : 36, 4, 8);
 #define CROLL(HR, CB_) hipLaunchKernelGGL((k_corner_roll<HR, CB_>), dim3(g.blocks), dim3(256), 0, st, ds, dss, sframe, dd, dds, dframe, W, H, g.nchunks, g.nstrips, g.seg, g.nseg, nframes, border, 1, ra)
-        if (wide) { if (harris) CROLL(true, 16); else CROLL(false, 16); }
-        else { if (harris) CROLL(true, 8); else CROLL(false, 8); }
+        if (harris) CROLL(true, 8); else CROLL(false, 8);                 // (16 pixels per lane: 256 VGPRs, one wave per SIMD -- removed in round 5)
 #undef CROLL
         return MI355CV_OK;
     }

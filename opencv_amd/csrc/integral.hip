@@ -367,7 +367,7 @@ bool integralTiledU8(const uchar* src, size_t sstep, size_t sframe, int W, int H
     hipLaunchKernelGGL(k_integral_carries, dim3(divUp(W, 32) + divUp(H, 256) + 1, sq ? 2 : 1, nframes), blk, ((size_t)nTx * nTy + 16 * (size_t)nTx) * 8, st,
                        S.colsum, Q.colsum, S.rowsum, Q.rowsum, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.tileTot, Q.tileTot, S.corner, Q.corner,
                        W, H, Wp, nTx, nTy, perFrame, sq ? 1 : 0);
-    static const int nt = [] { const char* v = getenv("MI355CV_INTEGRAL_NT"); return v ? atoi(v) : 0; }();      // nontemporal sum stores (A/B runs)
+    constexpr int nt = 0;                                          // (non-temporal sum stores measured 7-10 % slower, profiles/r04_integral_aligned_stores_ab.txt)
 #define ITILES(TS_, SQ_) hipLaunchKernelGGL((k_integral_tiles<TS_, SQ_>), grid, blk, 0, st, src, sstep, sframe, W, H, nTx, nTy, nframes, (TS_*)sum, sumStepElems, sumFrameElems, \
                                             sq, sqStepElems, sqFrameElems, S.colcar, Q.colcar, S.rowcar, Q.rowcar, S.corner, Q.corner, Wp, perFrame, nt)
     if (sumIsDouble) { if (sq) ITILES(double, true); else ITILES(double, false); }

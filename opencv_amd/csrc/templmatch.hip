@@ -1156,7 +1156,6 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         //  * otherwise two memory-bound kernels (k_wsum_rows / k_wsum_cols) on the auxiliary stream, under the MFMAs.
         static const bool ringOff = std::getenv("MI355CV_TM_RING") && atoi(std::getenv("MI355CV_TM_RING")) == 0;
         static const bool fuseOff = std::getenv("MI355CV_TM_FUSE") && atoi(std::getenv("MI355CV_TM_FUSE")) == 0;
-        static const int chunkEnv = std::getenv("MI355CV_TM_CHUNK") ? atoi(std::getenv("MI355CV_TM_CHUNK")) : 0;
         const bool ringK = !ringOff && iw >= 4;
         const bool fused = ringK && !fuseOff && th >= 66 && (iw & 3) == 0 && ((((uintptr_t)di) | dis | (nframes > 1 ? iframe : 0)) & 3) == 0 &&
                            (unsigned long long)ih * dis < (1ull << 32);                      // the kernel's fastRow test: 32-bit row offsets
@@ -1189,7 +1188,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                                w1 + f * wframe, w2 + f * wframe, wframe);
         }
         // frames per MFMA launch
-        const int chunk = ringK ? std::max(1, std::min(chunkEnv > 0 ? chunkEnv : (fin ? 64 : 4), nframes)) : 1;
+        const int chunk = ringK ? std::max(1, std::min(fin ? 64 : 4, nframes)) : 1;
         const size_t ldsRing = (((size_t)th * MT_TPITCH + 15) & ~(size_t)15) + (size_t)4 * RG_RING * RG_RP + (size_t)4 * RG_WSCR;
         for (int f = 0, c = 0; f < nframes; f += chunk, c++) {
             const int nf = std::min(chunk, nframes - f);

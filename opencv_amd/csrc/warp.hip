@@ -2365,7 +2365,6 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             }
         }
         static const bool tapsLds = [] { const char* v = getenv("MI355CV_WARP_TAPS_LDS"); return !v || atoi(v) != 0; }();
-        static const int tapsP = [] { const char* v = getenv("MI355CV_WARP_TAPS_P"); return v ? atoi(v) : 0; }();          // 1: one pixel per thread everywhere (A/B runs)
         const bool lanc = interpolation == MI355CV_INTER_LANCZOS4;
         if (tapsLds && (cn == 1 || cn == 3 || cn == 4) && sw >= (lanc ? 8 : 4) && sh >= (lanc ? 8 : 4)) {
             const int ks = lanc ? 8 : 4;
@@ -2375,7 +2374,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             // pixels per thread (affine maps only: their coordinates are two table reads): by the registers the tap rows take -- 4 where a pixel's rows are <= 10 dwords
             // (bicubic CV_8UC1), 2 up to 20 (bicubic CV_8UC3 / CV_8UC4 / CV_32FC1, Lanczos CV_8UC1)
             const int esz = u8 ? 1 : depth == D32F ? 4 : 2, ksnb = ks * (ks * cn * esz / 4);
-            const int ppt = (!terms || tapsP == 1 || (depth != D8U && depth != D32F)) ? 1 : ksnb <= 10 ? 4 : ksnb <= 20 ? 2 : 1;
+            const int ppt = (!terms || (depth != D8U && depth != D32F)) ? 1 : ksnb <= 10 ? 4 : ksnb <= 20 ? 2 : 1;
             const int tilesX = divUp(dw, 64), tilesY = divUp(dh, rows * ppt);
             const long long total = (long long)tilesX * tilesY * nframes;
             const int perCU = u8 ? (lanc ? 1 : 3) : 8;                                  // workgroups a CU holds (LDS for CV_8U, waves otherwise); 256 CUs
@@ -2440,7 +2439,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             static const int tpw = [] { const char* v = getenv("MI355CV_WARP8_TPW"); const int t = v ? atoi(v) : 1; return t < 1 ? 1 : t > 64 ? 64 : t; }();
             static const int fetch = [] { const char* v = getenv("MI355CV_WARP8_FETCH"); return v ? atoi(v) : 1; }();       // tap fetch form (warp8.h bilinearAt), A/B runs
             dim3 g8(divUp(a8.gx, tpw), a8.gy, nframes);
-            static const int leanTpw = [] { const char* v = getenv("MI355CV_WARP8_LEAN_TPW"); const int t = v ? atoi(v) : 6; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            constexpr int leanTpw = 6;                                 // tiles a workgroup walks (2 .. 12 measured within 2 %, profiles/r03_resize8_lean.txt)
             if (work) {
                 dim3 gl(divUp(a8.gx, leanTpw), a8.gy, nframes);
                 const size_t ldsL = 2 * (size_t)a8.leanBuf;
@@ -2479,7 +2478,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         if (warp32On && kind == 0 && depth == D32F && cn == 1 && ((((uintptr_t)ds) | dss | w.sframe) & 15) == 0) {       // (16-byte box loads)
             dim3 g3(divUp(dw, W32_TW), divUp(dh, W32_TH), nframes);
             w.gx = g3.x; w.gy = g3.y;
-            static const int tpw32 = [] { const char* v = getenv("MI355CV_WARP32_TPW"); const int t = v ? atoi(v) : 6; return t < 1 ? 1 : t > 64 ? 64 : t; }();
+            constexpr int tpw32 = 6;                                   // tiles a workgroup walks (3 / 6 / 12 / 20 within 3 %, profiles/r05_warp32_quad_ab.txt)
             // coordinate terms of every destination column and row (double arithmetic, once per call) + the list of tiles the LDS kernel leaves to k_warp32_rest
             const size_t ntiles = (size_t)g3.x * g3.y * nframes;
             int* terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
