@@ -17,19 +17,25 @@ int main()
     auto gray = [&](int i) { return mi355cv_cvtBGRtoGray(bgr + (size_t)(i % 4) * W * H * 3, (size_t)W * 3, dst + (size_t)(i % NF) * W * H, W, W, H, 0, 3, false); };
     auto thr = [&](int i) { return mi355cv_threshold(src + (size_t)(i % NF) * W * H, W, dst + (size_t)(i % NF) * W * H, W, W, H, 0, 1, 127.0, 255.0, 0); };
     struct { const char* name; int (*fn)(void*, int); void* ctx; } dummy; (void)dummy;
-    for (int mode = 1; mode >= 0; mode--) {
-        mi355cv_setAsync(mode);
+    hipStream_t user = nullptr;
+    (void)hipStreamCreateWithFlags(&user, hipStreamNonBlocking);
+    // mode 2 (round 5): the DEFAULT contract (no mi355cv_setAsync) with device-resident images on a stream the caller bound with mi355cv_setStream: the hook returns after
+    // the enqueue (nothing host-side can see the image before the caller synchronises its own stream); mode 1: explicit async; mode 0: default contract on the library's own
+    // stream = synchronous
+    for (int mode = 2; mode >= 0; mode--) {
+        mi355cv_setAsync(mode == 1);
+        if (mode == 2) mi355cv_setStream(user); else mi355cv_resetStream();
         for (int which = 0; which < 3; which++) {
             int rc = 0;
             for (int i = 0; i < 50; i++) rc |= which == 0 ? gauss(i) : which == 1 ? gray(i) : thr(i);
-            mi355cv_synchronize();
+            mi355cv_synchronize(); (void)hipStreamSynchronize(user);
             const double t0 = now();
             for (int i = 0; i < N; i++) rc |= which == 0 ? gauss(i) : which == 1 ? gray(i) : thr(i);
             const double t1 = now();
-            mi355cv_synchronize();
+            mi355cv_synchronize(); (void)hipStreamSynchronize(user);
             const double t2 = now();
             printf("%-26s %s: %6.2f us host time per call, %6.2f us per call incl. the final drain (rc %d)\n", which == 0 ? "gaussianBlurBinomial 5x5 4K" : which == 1 ? "cvtBGRtoGray 4K" : "threshold 4K",
-                   mode ? "async enqueue" : "synchronous  ", (t1 - t0) / N, (t2 - t0) / N, rc);
+                   mode == 2 ? "default, caller's stream" : mode ? "async enqueue" : "synchronous  ", (t1 - t0) / N, (t2 - t0) / N, rc);
         }
     }
     return 0;
