@@ -13,6 +13,37 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int W = 7680, H = 4320, DX = 3, DY = 2;
 __device__ __forceinline__ float blend(float a, float b, float c, float d) { return a * 0.28125f + b * 0.09375f + c * 0.46875f + d * 0.15625f; }
 
+// VR: k_warp_lin's gather under a ROTATION (7 degrees x 0.95 about the centre, float coordinates -- timing only): one pixel per lane, 8 pixels per lane in flight, 8-byte tap
+// pairs from two rows, 4-byte stores, with the wave's 64 lanes arranged LW wide x 64 / LW high.  A 64 x 1 row of destination pixels crosses ~9 source rows (26 cache lines per
+// load instruction, profiles/r02_warp_pmc.txt); 32 x 2 and 16 x 4 footprints are compact (14 / 7 lines) but store 128- / 64-byte row pieces.
+template <int LW>
+__global__ __launch_bounds__(256) void vr(const float* __restrict__ src, float* __restrict__ dst, int nframes)
+{
+    constexpr int LH = 64 / LW, G = 8;                              // a wave: LW columns x (LH * G) rows; a workgroup: 4 waves side by side
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tilesX = W / (4 * LW);
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int x = (tx * 4 + wv) * LW + (lane % LW);
+    const int yb = ty * (LH * G) + lane / LW;
+    src += (size_t)blockIdx.y * W * H; dst += (size_t)blockIdx.y * W * H;
+    const float c = 0.992546f / 0.95f, sn = 0.121869f / 0.95f, cx = W * 0.5f, cy = H * 0.5f;
+    f2u a[G], b[G]; float fx[G], fy[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const int y = yb + i * LH;
+        const float X = c * (x - cx) + sn * (y - cy) + cx, Y = -sn * (x - cx) + c * (y - cy) + cy;
+        const int sx = min(max((int)floorf(X), 0), W - 2), sy = min(max((int)floorf(Y), 0), H - 2);
+        fx[i] = X - floorf(X); fy[i] = Y - floorf(Y);
+        a[i] = *reinterpret_cast<const f2u*>(src + (size_t)sy * W + sx);
+        b[i] = *reinterpret_cast<const f2u*>(src + (size_t)(sy + 1) * W + sx);
+    }
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const float t0 = a[i].x + fx[i] * (a[i].y - a[i].x), t1 = b[i].x + fx[i] * (b[i].y - b[i].x);
+        dst[(size_t)(yb + i * LH) * W + x] = t0 + fy[i] * (t1 - t0);
+    }
+}
+
 template <int BW>   // BW = 64: workgroup 64 x 32;  BW = 256: workgroup 256 x 8
 __global__ __launch_bounds__(256) void v1(const float* __restrict__ src, float* __restrict__ dst, int nframes)
 {
@@ -127,6 +158,10 @@ int main()
 {
     float *s, *d; const int NF = 8;
     hipMalloc(&s, (size_t)NF * W * H * 4); hipMalloc(&d, (size_t)NF * W * H * 4); hipMemset(s, 0, (size_t)NF * W * H * 4);
+    timeit("VR rotation 7 deg, gather, wave = 64 x 1 lanes (k_warp_lin)", [&] { hipLaunchKernelGGL(vr<64>, dim3((W / 256) * (H / 8), NF), dim3(256), 0, 0, s, d, NF); });
+    timeit("VR rotation 7 deg, gather, wave = 32 x 2 lanes", [&] { hipLaunchKernelGGL(vr<32>, dim3((W / 128) * (H / 16), NF), dim3(256), 0, 0, s, d, NF); });
+    timeit("VR rotation 7 deg, gather, wave = 16 x 4 lanes", [&] { hipLaunchKernelGGL(vr<16>, dim3((W / 64) * (H / 32), NF), dim3(256), 0, 0, s, d, NF); });
+    timeit("VR rotation 7 deg, gather, wave = 8 x 8 lanes", [&] { hipLaunchKernelGGL(vr<8>, dim3((W / 32) * (H / 64), NF), dim3(256), 0, 0, s, d, NF); });
     timeit("V1 1 px / lane, 8 rows in flight, workgroup 64 x 32 (k_warp_lin's geometry)", [&] { hipLaunchKernelGGL(v1<64>, dim3((W / 64) * (H / 32), NF), dim3(256), 0, 0, s, d, NF); });
     timeit("V2 1 px / lane, 8 rows in flight, workgroup 256 x 8", [&] { hipLaunchKernelGGL(v1<256>, dim3((W / 256) * (H / 8), NF), dim3(256), 0, 0, s, d, NF); });
     timeit("V3 4 px / lane, 4 rows in flight, 16 B nt stores, workgroup 256 x 16", [&] { hipLaunchKernelGGL(v3, dim3((W / 256) * (H / 16), NF), dim3(256), 0, 0, s, d, NF); });
