@@ -702,25 +702,65 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
     return stg.finish(entry);
 }
 
-// CV_16UC1, sigma = 0, 3x3 / 5x5: the rolling kernel or nothing (the reference's own Q16.16 path is the fallback)
+// ---- CV_16U, sigma = 0 (cv_hal_gaussianBlurBinomial on the reference's Q16.16 path, smooth.dispatch.cpp:726-768): 3 / 5 / 7 / 9 taps, 1-4 channels, every border rule.
+// The reference's fixed-point passes (fixedSmoothInvoker<uint16_t, ufixedpoint32>: exact Q16.16 products, one rounding in the column pass) evaluate to the plain integer
+// sums with ONE rounding, (S + 2^(2s-1)) >> 2s for taps that sum to 2^s -- tests/test_oracle_smooth16.py pins that restatement to the reference bit for bit.  One channel
+// with 3 or 5 taps on a geometry the rolling skeleton takes: k_sep_roll<Binom16>; everything else -- more channels, 7 / 9 taps, BORDER_WRAP, images smaller than the
+// kernel (round 5: 80 of the 88 hook calls of GaussianBlur_Bitexact.Linear16U and overflow_20121 were declined) -- one thread per element, the K x K sum directly.
+template <int K>
+__global__ __launch_bounds__(256) void k_binom16_direct(const uchar* __restrict__ parent, size_t sstep, uchar* __restrict__ dst, size_t dstep, int W, int H, int cn,
+                                                        int mL, int mT, int fullW, int fullH, int border)
+{
+    constexpr int R = K / 2, SH = K == 3 ? 2 : K == 5 ? 4 : K == 7 ? 6 : 8;
+    constexpr uint32_t TAP[9] = {K == 3 ? 1u : K == 5 ? 1u : K == 7 ? 2u : 4u, K == 3 ? 2u : K == 5 ? 4u : K == 7 ? 7u : 13u, K == 3 ? 1u : K == 5 ? 6u : K == 7 ? 14u : 30u,
+                                 K == 5 ? 4u : K == 7 ? 18u : 51u, K == 5 ? 1u : K == 7 ? 14u : 60u, K == 7 ? 7u : 51u, K == 7 ? 2u : 30u, 13u, 4u};
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, c = e - x * cn;
+    int xs[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { const int q = mi355_borderInterpolate(x + mL + i - R, fullW, border); xs[i] = q < 0 ? -1 : q * cn + c; }
+    uint32_t acc = 0;                                      // <= 65535 * 2^16: fits, and so does the rounding term on top
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const int q = mi355_borderInterpolate(y + mT + j - R, fullH, border);
+        if (q < 0) continue;
+        const unsigned short* row = reinterpret_cast<const unsigned short*>(parent + (size_t)q * sstep);
+        uint32_t h = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) h += xs[i] < 0 ? 0u : TAP[i] * (uint32_t)row[xs[i]];
+        acc += TAP[j] * h;
+    }
+    reinterpret_cast<unsigned short*>(dst + (size_t)y * dstep)[e] = (unsigned short)((acc + (1u << (2 * SH - 1))) >> (2 * SH));
+}
+
 int runBinom16(const char* entry, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int mL, int mT, int mR, int mB, int ksize, int border)
 {
-    if (disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || cn != 1 || (ksize != 3 && ksize != 5) || border < 0 || border > B_REFLECT_101");
+    if (disabled() || W <= 0 || H <= 0 || cn < 1 || cn > 4 || (ksize != 3 && ksize != 5 && ksize != 7 && ksize != 9) || border < 0 || border > B_REFLECT_101 ||
+        mL < 0 || mT < 0 || mR < 0 || mB < 0 || ((sstep | dstep | (uintptr_t)src | (uintptr_t)dst) & 1))
+        return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || cn < 1 || cn > 4 || ksize not in {3, 5, 7, 9} || border outside CONSTANT .. REFLECT_101 || negative margins || odd pointers / steps");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     const bool hostSrc = !isDevicePtr(src);
     if (hostSrc && (size_t)W * H < minPixels()) return mi355::declined(__func__, __LINE__, "hostSrc && (size_t)W * H < minPixels()");
     if (!hostSrc && src == dst) return mi355::declined(__func__, __LINE__, "!hostSrc && src == dst");
     size_t dss = 0, dds = 0;
-    const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * 2;
-    const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * 2, mT + H + mB, &dss);
+    const size_t esz = (size_t)cn * 2;
+    const uchar* top = src - (ptrdiff_t)mT * (ptrdiff_t)sstep - (ptrdiff_t)mL * (ptrdiff_t)esz;
+    const uchar* dtop = stg.in(top, sstep, (size_t)(mL + W + mR) * esz, mT + H + mB, &dss);
     if (!dtop) return mi355::declined(__func__, __LINE__, "!dtop");
-    const uchar* dsrc = dtop + (size_t)mT * dss + (size_t)mL * 2;
-    uchar* ddst = stg.out(dst, dstep, (size_t)W * 2, H, &dds);
+    const uchar* dsrc = dtop + (size_t)mT * dss + (size_t)mL * esz;
+    uchar* ddst = stg.out(dst, dstep, (size_t)W * esz, H, &dds);
     if (!ddst) return mi355::declined(__func__, __LINE__, "!ddst");
     const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
-    if (!seprollBinom16(dsrc, dss, 0, ddst, dds, 0, 1, W, H, ksize, border, stream(), (mL | mT | mR | mB) ? &roi : nullptr))
-        return setError(MI355CV_NOT_IMPLEMENTED, "%s: CV_16U geometry outside the rolling kernel", entry);
+    if (cn == 1 && (ksize == 3 || ksize == 5) && border != B_WRAP &&
+        seprollBinom16(dsrc, dss, 0, ddst, dds, 0, 1, W, H, ksize, border, stream(), (mL | mT | mR | mB) ? &roi : nullptr))
+        return stg.finish(entry);
+    dim3 grid(divUp(W * cn, 64), divUp(H, 4));
+#define B16(K_) hipLaunchKernelGGL(k_binom16_direct<K_>, grid, dim3(256), 0, stream(), dtop, dss, ddst, dds, W, H, cn, mL, mT, mL + W + mR, mT + H + mB, border)
+    if (ksize == 3) B16(3); else if (ksize == 5) B16(5); else if (ksize == 7) B16(7); else B16(9);
+#undef B16
+    noteKernel("k_binom16_direct<%d> grid=%ux%u x256 cn=%d border=%d", ksize, grid.x, grid.y, cn, border);
     return stg.finish(entry);
 }
 

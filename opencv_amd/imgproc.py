@@ -105,8 +105,8 @@ def GaussianBlur(src, ksize, sigmaX=0.0, sigmaY=0.0, borderType=BORDER_DEFAULT, 
         # getGaussianKernel(ksize, sigma, max(depth, CV_32F))); cv_hal_gaussianBlur declines these depths, the sepFilter hook serves them
         if s.depth == CV_16U:
             # the reference's Q16.16 fixed-point path (smooth.dispatch.cpp:726-760): its only hook is cv_hal_gaussianBlurBinomial (sigma 0, square kernel)
-            if not (sigmaX == 0.0 and sigmaY == 0.0 and kw == kh and kw in (3, 5) and s.cn == 1):
-                raise NotImplementedError("GaussianBlur: CV_16U beyond the sigma-0 3x3 / 5x5 single-channel case runs the reference's Q16.16 path, not served")
+            if not (sigmaX == 0.0 and sigmaY == 0.0 and kw == kh and kw in (3, 5, 7, 9)):
+                raise NotImplementedError("GaussianBlur: CV_16U beyond the sigma-0 square 3 / 5 / 7 / 9-tap case runs the reference's Q16.16 path, which has no hook: not served")
             out = dst if dst is not None else empty_like_kind(src, s.h, s.w, s.cn, s.depth)
             d = Img(out)
             if d.ptr == s.ptr:

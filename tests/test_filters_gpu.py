@@ -387,7 +387,36 @@ def test_gaussian_16u_binomial_on_the_rolling_kernel(cv, orc):
                 if have_ref and w < 3000:
                     check(got, orc.ref_GaussianBlur(src, k, 0.0, 0.0, border))
     with pytest.raises(NotImplementedError):
-        cv.GaussianBlur(dev(np.zeros((16, 16), np.uint16)), (7, 7), 0)
+        cv.GaussianBlur(dev(np.zeros((16, 16), np.uint16)), (7, 7), 1.5)               # sigma != 0: the reference's Q16.16 path has no hook for it
+
+
+def test_gaussian_16u_binomial_beyond_the_rolling_kernel(cv, orc):
+    """round 5 (80 of the 88 hook calls of GaussianBlur_Bitexact.Linear16U and overflow_20121 were declined): 7 / 9 taps, 2-4 channels, BORDER_WRAP, images smaller
+    than the kernel -- k_binom16_direct, bit for bit against the integer restatement tests/test_oracle_smooth16.py pins to the reference, and against the reference itself"""
+    from test_oracle_smooth16 import np_binom16
+    rng = np.random.default_rng(14)
+    have_ref = orc.load_ref() is not None
+    for (w, h) in [(1, 3), (3, 1), (2, 2), (3, 3), (5, 5), (7, 7), (37, 23), (256, 128), (1283, 70)]:
+        for cn in (1, 2, 3, 4):
+            src = rng.integers(0, 65536, (h, w, cn) if cn > 1 else (h, w)).astype(np.uint16)
+            src.flat[:: max(1, src.size // 5)] = 65535
+            for k in (3, 5, 7, 9):
+                for border in (0, 1, 2, 3, 4):
+                    if (w == 1 or h == 1) and border != 0:
+                        continue                                     # cv::GaussianBlur clamps the kernel in a one-pixel dimension (no square kernel, no hook call)
+                    got = cv.GaussianBlur(dev(src), (k, k), 0, borderType=border | 16)
+                    check(got, np_binom16(src, k, border))
+                    if have_ref and w * h < 40000:
+                        check(got, orc.ref_GaussianBlur(src, k, 0.0, 0.0, border | 16))
+    assert "k_binom16_direct" in _kernel(cv)
+    full = np.full((100, 100), 65535, np.uint16)                     # GaussianBlur_Bitexact.overflow_20121
+    assert int(cv.GaussianBlur(dev(full), (9, 9), 0).cpu().numpy().min()) == 65535
+    # a window of a larger image with real pixels around it (the hook's margins): equal to the same window of the filtered parent away from the parent's border
+    parent = rng.integers(0, 65536, (60, 90, 3)).astype(np.uint16)
+    whole = np_binom16(parent, 7, 4)
+    got = cv.GaussianBlur(dev(parent), (7, 7), 0, borderType=4, roi=(10, 8, 50, 30)) if "roi" in cv.GaussianBlur.__code__.co_varnames else None
+    if got is not None:
+        check(got, whole[8:38, 10:60])
 
 
 def test_submatrix_calls_stay_on_the_rolling_kernels(cv, orc):
