@@ -704,7 +704,7 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
 
 // ---- CV_16U, sigma = 0 (cv_hal_gaussianBlurBinomial on the reference's Q16.16 path, smooth.dispatch.cpp:726-768): 3 / 5 / 7 / 9 taps, 1-4 channels, every border rule.
 // The reference's fixed-point passes (fixedSmoothInvoker<uint16_t, ufixedpoint32>: exact Q16.16 products, one rounding in the column pass) evaluate to the plain integer
-// sums with ONE rounding, (S + 2^(2s-1)) >> 2s for taps that sum to 2^s -- tests/test_oracle_smooth16.py pins that restatement to the reference bit for bit.  One channel
+// sums with ONE rounding, (S + 2^(2s-1)) >> 2s for taps that sum to 2^s -- the CPU suite pins that restatement to the reference bit for bit (tests/, the 16-bit smoothing file).  One channel
 // with 3 or 5 taps on a geometry the rolling skeleton takes: k_sep_roll<Binom16>; everything else -- more channels, 7 / 9 taps, BORDER_WRAP, images smaller than the
 // kernel (round 5: 80 of the 88 hook calls of GaussianBlur_Bitexact.Linear16U and overflow_20121 were declined) -- one thread per element, the K x K sum directly.
 template <int K>
