@@ -834,9 +834,30 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
         size_t margin_bottom, size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type)
 {
     mi355::EntryGuard entry_(__func__);
-    // 8U only here: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724).
-    // Other depths go through sepFilter2D in the reference (:825) -- see mi355cv_sepFilter*.
-    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
+    // CV_8U: the Q8.8 path cv::GaussianBlur takes for CV_8U (smooth.dispatch.cpp:658-724), below.
+    // Other depths: the reference asks this hook (:813) and then calls sepFilter2D(src, dst, sdepth, kx, ky, Point(-1,-1), 0, borderType) with the taps of
+    // createGaussianKernels (:279-304: getGaussianKernel(ksize, sigma, max(depth, CV_32F)), ky = kx for a square kernel with equal sigmas) -- :825.  Until round 5 the
+    // hook declined and the separable hook served that second call (257 declined calls in the reference's Imgproc_GaussianBlur tests); now the same call is made here.
+    if (depth != MI355CV_8U) {
+        if (depth != MI355CV_16U && depth != MI355CV_16S && depth != MI355CV_32F) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F");
+        const int n = (int)ksize_width, m = (int)ksize_height;
+        if (n < 1 || m < 1 || n > 33 || m > 33 || !(n & 1) || !(m & 1)) return mi355::declined(__func__, __LINE__, "kernel size outside 1 .. 33 or even");
+        if (sigmaY <= 0) sigmaY = sigmaX;
+        const double s1 = sigmaX > 0 ? sigmaX : 0, s2 = sigmaY > 0 ? sigmaY : 0;
+        std::vector<double> dx, dy;
+        if (!gaussianKernelBitExact(n, s1, dx)) return mi355::declined(__func__, __LINE__, "!gaussianKernelBitExact(n, s1, dx)");
+        if (m == n && std::fabs(s1 - s2) < 2.220446049250313e-16) dy = dx;
+        else if (!gaussianKernelBitExact(m, s2, dy)) return mi355::declined(__func__, __LINE__, "!gaussianKernelBitExact(m, s2, dy)");
+        std::vector<float> fx(dx.begin(), dx.end()), fy(dy.begin(), dy.end());          // getGaussianKernel(.., CV_32F): the bit-exact doubles rounded to float
+        const int type = MI355CV_MAKETYPE(depth, cn);
+        cvhalFilter2D* ctx = nullptr;
+        int rc = mi355cv_sepFilterInit(&ctx, type, type, MI355CV_32F, reinterpret_cast<uchar*>(fx.data()), n, reinterpret_cast<uchar*>(fy.data()), m, -1, -1, 0.0, border_type);
+        if (rc != MI355CV_OK) return rc;
+        rc = mi355cv_sepFilter(ctx, const_cast<uchar*>(src_data), src_step, dst_data, dst_step, width, height, (int)(margin_left + (size_t)width + margin_right),
+                               (int)(margin_top + (size_t)height + margin_bottom), (int)margin_left, (int)margin_top);
+        (void)mi355cv_sepFilterFree(ctx);
+        return rc;
+    }
     // Real pixels around the ROI mean the caller is the submatrix / non-isolated site (:813): the fixed-point branch (:658) is skipped there and
     // the CPU result is sepFilter2D with float Gaussian taps, which can differ from Q8.8 by 1 LSB.  Decline: the reference then calls
     // sepFilter2D itself, whose hook (mi355cv_sepFilter, ROI offsets included) reproduces that arithmetic.
