@@ -1,5 +1,6 @@
 """GPU parity for rows a3-a6: filter2D, sepFilter2D, Sobel/Scharr, boxFilter, cvtColor -- through the C ABI,
 against the oracle.  Integer outputs bit-exact, CV_32F within 1e-4 relative (ts/ocl_test.hpp:309 norm)."""
+import os
 import zlib
 
 import numpy as np
@@ -463,3 +464,43 @@ def test_filter2d_f32_rolling(cv, orc):
     check(cv.filter2D(dev(big), -1, k), orc.orc_filter2D(big, -1, k), tol=1e-6)
     src3 = rnd((40, 64, 3), np.float32, 5)
     check(cv.filter2D(dev(src3), -1, k), orc.orc_filter2D(src3, -1, k), tol=1e-6)
+
+
+def test_large_filter2d_opt_in(orc):
+    """filter2D with >= 130 taps on a whole image is the reference's DFT case and is declined by default (the FFTs' float error cannot be reproduced by a sum);
+    MI355CV_FILTER_LARGE=1 serves it with the direct sum = the reference's own non-DFT engine: bit for bit against the restatement of that engine, and within 1 grey level
+    (CV_8U) / 1e-5 relative (CV_32F) of what the reference's DFT path returns.  A process of its own: the switch is read once."""
+    import subprocess, sys, textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+        import opencv_amd as cv, orc
+        rng = np.random.default_rng(9)
+        k = (rng.random((13, 11), dtype=np.float32) - 0.4).astype(np.float32); k /= np.abs(k).sum()
+        for dtype in (np.uint8, np.float32):
+            src = rng.integers(0, 256, (240, 320)).astype(dtype) if dtype == np.uint8 else rng.random((240, 320), dtype=np.float32)
+            try:
+                got = cv.filter2D(torch.from_numpy(src).cuda(), -1, k).cpu().numpy()
+            except NotImplementedError:
+                print("DECLINED", np.dtype(dtype).name); continue
+            want = orc.orc_filter2D(src, -1, k)
+            exact = bool(np.array_equal(got, want)) if dtype == np.uint8 else float(np.abs(got - want).max()) <= 1e-5
+            dev = -1.0
+            if orc.load_ref() is not None:
+                ref = orc.ref_filter2D(src, -1, k)
+                dev = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if dtype == np.uint8 else float(np.abs(got - ref).max() / np.abs(ref).max())
+            print("SERVED", np.dtype(dtype).name, "direct-engine-exact", exact, "max-deviation-from-the-DFT-path", dev)
+    """ % (ROOT, ROOT))
+    for flag in ("0", "1"):
+        env = dict(os.environ); env["MI355CV_FILTER_LARGE"] = flag
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        if flag == "0":
+            assert p.stdout.count("DECLINED") == 2, p.stdout
+        else:
+            lines = [l.split() for l in p.stdout.splitlines() if l.startswith("SERVED")]
+            assert len(lines) == 2 and all(l[3] == "True" for l in lines), p.stdout
+            d8, d32 = float(lines[0][5]), float(lines[1][5])
+            assert d8 <= 1.0 and d32 <= 1e-5, p.stdout                       # (-1: the reference did not travel with the tree)
+
