@@ -486,7 +486,10 @@ MI355CV_API int mi355cv_matchTemplateMask(const mi355cv_uchar* img_data, size_t 
 MI355CV_API int mi355cv_matchTemplateBatch(const mi355cv_uchar* img_data, size_t img_step, size_t img_frame_stride, int nframes,
         int img_width, int img_height, const mi355cv_uchar* templ_data, size_t templ_step, int templ_width, int templ_height,
         int type, mi355cv_uchar* result_data, size_t result_step, size_t result_frame_stride, int method);
-/* replaces hal_ni_integral (hal_replacement.hpp:977; caller sumpixels.dispatch.cpp:415): CV_64F sum / sqsum of 8U or 32F */
+/* replaces hal_ni_integral (hal_replacement.hpp:977; caller sumpixels.dispatch.cpp:415): every (depth, sdepth, sqdepth) row of the reference's table
+ * (sumpixels.dispatch.cpp:383-406), sqsum_data / tilted_data may be NULL.  Integer-valued sums are exact; float sums, float / int squared sums and tilted sums are
+ * accumulated in the reference's order (bit for bit).  Declined: CV_8U -> CV_32F sums past 2^24 when neither sqsum nor tilted is asked for (the reference's
+ * result then depends on the CPU's vector width). */
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const mi355cv_uchar* src_data, size_t src_step,
         mi355cv_uchar* sum_data, size_t sum_step, mi355cv_uchar* sqsum_data, size_t sqsum_step,
         mi355cv_uchar* tilted_data, size_t tilted_step, int width, int height, int cn);

@@ -1530,21 +1530,45 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
                     templ_width, templ_height, type, result_data, result_step, nframes == 1 ? 0 : result_frame_stride, method);
 }
 
-// replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415): CV_8U sources with the sum in
-// CV_32S (the reference's default; exact) or CV_64F, CV_32F sources with CV_64F sums; squared sum in CV_64F; no tilted sum.
-// (CV_32F sums of 8-bit data depend on the summation order beyond 2^24 and are left to the CPU.)
+// replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415): every depth triple of the reference's table (:383-406), with or
+// without the squared and the tilted sum.  CV_8U sources with CV_32S / CV_64F sums and CV_32F sources with CV_64F sums (squared sum in CV_64F, no tilted sum) take the
+// tiled / scanned kernels below (exact integers; doubles of floats to 1e-13); everything whose value depends on the order of the additions -- CV_32F sums, CV_32F / CV_32S
+// squared sums, tilted sums -- takes integral_seq.hip, which adds in the reference's order (bit for bit).  One case is left to the CPU: CV_8U -> CV_32F sums without a
+// squared or tilted sum beyond 2^24 (the reference's vector body recovers the row prefix in its scalar tail by a subtraction, sumpixels.simd.hpp:528-533, so the bits
+// depend on the CPU's vector width).
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar* src_data, size_t src_step, uchar* sum_data, size_t sum_step,
                                  uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
 {
     mi355::EntryGuard entry_(__func__);
-    (void)tilted_step;
-    if (disabled() || tilted_data || !sum_data) return mi355::declined(__func__, __LINE__, "disabled() || tilted_data || !sum_data");
-    const bool ok = (depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F);
-    if (!ok || (sqsum_data && sqdepth != D64F) || cn < 1 || cn > 4)
-        return setError(MI355CV_NOT_IMPLEMENTED, "integral: depths %d -> sum %d, sqsum %d%s, %d channels outside the GPU path", depth, sdepth, sqdepth, sqsum_data ? "" : " (no sqsum)", cn);
+    if (disabled() || !sum_data || !src_data) return mi355::declined(__func__, __LINE__, "disabled() || !sum_data || !src_data");
+    if (!integralOrderedTriple(depth, sdepth, sqdepth) || cn < 1)
+        return setError(MI355CV_NOT_IMPLEMENTED, "integral: depths %d -> sum %d, sqsum %d%s, %d channels: not a row of the reference's table", depth, sdepth, sqdepth, sqsum_data ? "" : " (no sqsum)", cn);
+    const bool tiledKind = !tilted_data && cn <= 4 && ((depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F)) && (!sqsum_data || sqdepth == D64F) &&
+                           !(sdepth == D32S && (double)width * height * 255.0 > 2147483647.0);          // (sums that wrap: the ordered kernels wrap like the reference)
+    if (!tiledKind) {
+        if (depth == D8U && sdepth == D32F && !sqsum_data && !tilted_data && (double)width * height * 255.0 >= 16777216.0)
+            return setError(MI355CV_NOT_IMPLEMENTED, "integral: CV_8U -> CV_32F sums past 2^24 without a squared / tilted sum depend on the CPU's vector width");
+        const size_t e1 = sdepth == D64F ? 8 : 4, e2 = sqdepth == D64F ? 8 : 4, es = depth == D8U ? 1 : depth == D32F ? 4 : depth == D64F ? 8 : 2;
+        if (width <= 0 || height <= 0 || (sum_step % e1) || (sqsum_data && (sqsum_step % e2)) || (tilted_data && (tilted_step % e1)) || (src_step % es))
+            return mi355::declined(__func__, __LINE__, "width <= 0 || height <= 0 || a step that is not a multiple of its element size");
+        if ((double)(width + 1) * cn * (height + 1) >= 2147483647.0) return mi355::declined(__func__, __LINE__, "more than 2^31 elements");
+        Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
+        if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
+        size_t dss, d1, d2 = 0, d3 = 0;
+        const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * es, height, &dss);
+        uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * e1, height + 1, &d1);
+        uchar* s2 = sqsum_data ? stg.out(sqsum_data, sqsum_step, (size_t)(width + 1) * cn * e2, height + 1, &d2) : nullptr;
+        uchar* s3 = tilted_data ? stg.out(tilted_data, tilted_step, (size_t)(width + 1) * cn * e1, height + 1, &d3) : nullptr;
+        void* aux = tilted_data ? stg.scratch(integralOrderedAuxBytes(width, height, cn, sdepth, true)) : nullptr;
+        if (!ds || !s1 || (sqsum_data && !s2) || (tilted_data && (!s3 || !aux))) return mi355::declined(__func__, __LINE__, "staging / scratch for the ordered integral");
+        if (!integralOrdered(depth, sdepth, sqdepth, ds, dss, s1, d1, s2, d2, s3, d3, width, height, cn, aux, stream()))
+            return mi355::declined(__func__, __LINE__, "!integralOrdered(...)");
+        noteKernel("k_iseq_rows + k_iseq_cols%s (ordered sums, depths %d -> %d / %d)", tilted_data ? " + k_iseq_tbuf / tcol0 / tdiag" : "", depth, sdepth, sqdepth);
+        return stg.finish("integral");
+    }
     const size_t se = sdepth == D32S ? 4 : 8;
     if (width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))) return mi355::declined(__func__, __LINE__, "width <= 0 || height <= 0 || (sum_step % se) || (sqsum_data && (sqsum_step % 8))");
-    if (sdepth == D32S && (double)width * height * 255.0 > 2147483647.0) return mi355::declined(__func__, __LINE__, "sdepth == D32S && (double)width * height * 255.0 > 2147483647.0");     // would wrap; the CPU wraps its own way
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");

@@ -1343,28 +1343,33 @@ def matchTemplateBatch(frames, templ, method, result=None):
     return out
 
 
-def integral(src, sqsum=False, sdepth=-1):
-    """cv::integral: (H+1)x(W+1)[xC] sum and, optionally, squared sum (CV_64F).  sdepth -1 = the reference's default (CV_32S for
-    8-bit sources, CV_64F otherwise, sumpixels.dispatch.cpp:470-480); CV_32S and CV_64F are supported."""
+def integral(src, sqsum=False, sdepth=-1, sqdepth=-1, tilted=False):
+    """cv::integral: (H+1)x(W+1)[xC] sum and, optionally, squared and tilted sums.  sdepth / sqdepth -1 = the reference's defaults (CV_32S sums for 8-bit sources,
+    CV_64F otherwise; CV_64F squared sums, sumpixels.dispatch.cpp:417-424); any row of its type table (:383-406).  Returns sum, (sum, sqsum), (sum, tilted) or
+    (sum, sqsum, tilted)."""
     s = Img(src)
-    CV_32S, CV_64F = 4, 6
+    CV_32S, CV_32F = 4, 5
     if sdepth <= 0:
         sdepth = CV_32S if s.depth == CV_8U else CV_64F
-    if sdepth not in (CV_32S, CV_64F):
-        raise NotImplementedError("integral: sdepth")
+    if sqdepth <= 0:
+        sqdepth = CV_64F
+    if sdepth not in (CV_32S, CV_32F, CV_64F) or sqdepth not in (CV_32S, CV_32F, CV_64F):
+        raise NotImplementedError("integral: sdepth / sqdepth")
     shape = (s.h + 1, s.w + 1) if s.cn == 1 else (s.h + 1, s.w + 1, s.cn)
-    if torch is not None and isinstance(src, torch.Tensor):
-        sm = torch.empty(shape, dtype=torch.int32 if sdepth == CV_32S else torch.float64, device=src.device)
-        sq = torch.empty(shape, dtype=torch.float64, device=src.device) if sqsum else None
-    else:
-        sm = np.empty(shape, np.int32 if sdepth == CV_32S else np.float64)
-        sq = np.empty(shape, np.float64) if sqsum else None
-    a, b = Img(sm), (Img(sq) if sqsum else None)
+    on_dev = torch is not None and isinstance(src, torch.Tensor)
+
+    def new(depth):
+        if on_dev:
+            return torch.empty(shape, dtype={CV_32S: torch.int32, CV_32F: torch.float32, CV_64F: torch.float64}[depth], device=src.device)
+        return np.empty(shape, {CV_32S: np.int32, CV_32F: np.float32, CV_64F: np.float64}[depth])
+    sm, sq, tl = new(sdepth), (new(sqdepth) if sqsum else None), (new(sdepth) if tilted else None)
+    a, b, c = Img(sm), (Img(sq) if sqsum else None), (Img(tl) if tilted else None)
     bind_stream(s, a)
-    rc = L.mi355cv_integral(s.depth, sdepth, CV_64F, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
-                            None, 0, s.w, s.h, s.cn)
+    rc = L.mi355cv_integral(s.depth, sdepth, sqdepth, _vp(s.ptr), s.step, _vp(a.ptr), a.step, _vp(b.ptr) if b else None, b.step if b else 0,
+                            _vp(c.ptr) if c else None, c.step if c else 0, s.w, s.h, s.cn)
     _lib.check(rc, "integral")
-    return (sm, sq) if sqsum else sm
+    out = tuple(x for x in (sm, sq, tl) if x is not None)
+    return out if len(out) > 1 else sm
 
 
 def integralBatch(frames, sqsum=False, sdepth=-1, dst=None):

@@ -154,6 +154,10 @@ int orc_matchTemplate(const uint8_t* img, size_t istep, int iw, int ih, const ui
 int orc_matchTemplateMask(const uint8_t* img, size_t istep, int iw, int ih, const uint8_t* tpl, size_t tstep, int tw, int th, int depth, int cn,
                           const uint8_t* mask, size_t mstep, int mdepth, int mcn, float* result, size_t rstep, int method);
 
+/* cv::integral, see oracle/integral.c: the reference's depth triples (sumpixels.dispatch.cpp:383-406), 1-4 channels, sq / tilted may be NULL; steps in bytes */
+int orc_integral(int depth, int sdepth, int sqdepth, const unsigned char* src, size_t sstep, unsigned char* sum, size_t sumstep,
+                 unsigned char* sq, size_t sqstep, unsigned char* tilted, size_t tstep, int W, int H, int cn);
+
 /* cv::threshold, see oracle/thresh.c (depth 0/2/3/5; type 0..4) */
 int orc_thresholdHal(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int depth, int cn,
                      double thresh, double maxval, int type);

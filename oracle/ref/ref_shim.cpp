@@ -483,6 +483,22 @@ int ref_integral(const void* s, size_t ss, int w, int h, int stype, void* sum, s
     REF_END(S, sum)
 }
 
+// cv::integral with every output: sq / tilted may be NULL; sdepth / sqdepth as cv::integral takes them (-1: its defaults)
+int ref_integral3(const void* s, size_t ss, int w, int h, int stype, void* sum, size_t sums, int sdepth, void* sq, size_t sqs, int sqdepth, void* tilted, size_t ts)
+{
+    REF_TRY
+    const int cn = CV_MAT_CN(stype), depth = CV_MAT_DEPTH(stype);
+    const int sd = sdepth > 0 ? sdepth : depth == CV_8U ? CV_32S : CV_64F, qd = sqdepth > 0 ? sqdepth : CV_64F;
+    Mat src = M(s, ss, w, h, stype), S = M(sum, sums, w + 1, h + 1, CV_MAKETYPE(sd, cn)), Q, T;
+    if (sq) Q = M(sq, sqs, w + 1, h + 1, CV_MAKETYPE(qd, cn));
+    if (tilted) T = M(tilted, ts, w + 1, h + 1, CV_MAKETYPE(sd, cn));
+    if (tilted) { if (!sq) Q.create(h + 1, w + 1, CV_MAKETYPE(qd, cn)); cv::integral(src, S, Q, T, sdepth, sqdepth); }
+    else if (sq) cv::integral(src, S, Q, sdepth, sqdepth);
+    else cv::integral(src, S, sdepth);
+    if ((sq && (void*)Q.data != sq) || (tilted && (void*)T.data != tilted)) return -2;
+    REF_END(S, sum)
+}
+
 int ref_dilate3x3(const void* s, size_t ss, void* d, size_t ds, int w, int h, int type)
 {
     REF_TRY

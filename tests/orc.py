@@ -336,6 +336,39 @@ def ref_cvtColor(src, code, dcn):
     return dst
 
 
+# ----------------------------------------------------------------------------- integral
+_DEPTH_NP = {0: np.uint8, 2: np.uint16, 3: np.int16, 4: np.int32, 5: np.float32, 6: np.float64}
+
+
+def _integral_out(src, sdepth, sqdepth, sqsum, tilted):
+    h, w = src.shape[:2]
+    shape = (h + 1, w + 1) + tuple(src.shape[2:])
+    S = np.full(shape, 77, _DEPTH_NP[sdepth])
+    Q = np.full(shape, 77, _DEPTH_NP[sqdepth]) if sqsum else None
+    T = np.full(shape, 77, _DEPTH_NP[sdepth]) if tilted else None
+    return S, Q, T
+
+
+def orc_integral(src, sdepth, sqdepth=6, sqsum=False, tilted=False):
+    """(sum, sqsum or None, tilted or None) by oracle/integral.c"""
+    o = oracle()
+    S, Q, T = _integral_out(src, sdepth, sqdepth, sqsum, tilted)
+    rc = o.orc_integral(_NP_DEPTH[src.dtype], sdepth, sqdepth, P(src), step(src), P(S), step(S), P(Q) if sqsum else None, step(Q) if sqsum else c_sz(0),
+                        P(T) if tilted else None, step(T) if tilted else c_sz(0), src.shape[1], src.shape[0], cn_of(src))
+    assert rc == 0, rc
+    return S, Q, T
+
+
+def ref_integral(src, sdepth, sqdepth=6, sqsum=False, tilted=False):
+    """the same by cv::integral itself (oracle/_ref)"""
+    r = load_ref()
+    S, Q, T = _integral_out(src, sdepth, sqdepth, sqsum, tilted)
+    rc = r.ref_integral3(P(src), step(src), src.shape[1], src.shape[0], cvtype(src), P(S), step(S), sdepth, P(Q) if sqsum else None, step(Q) if sqsum else c_sz(0), sqdepth,
+                         P(T) if tilted else None, step(T) if tilted else c_sz(0))
+    assert rc == 0, rc
+    return S, Q, T
+
+
 # ----------------------------------------------------------------------------- threshold
 def orc_threshold(src, thresh, maxval, type):
     o = oracle()

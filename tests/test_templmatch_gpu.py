@@ -315,3 +315,64 @@ def test_masked_argument_checks(cv):
     d = dev(img); t = dev(tpl); r = torch.empty((57, 73), dtype=torch.float32, device="cuda")
     rc = _lib.lib.mi355cv_matchTemplateMask(d.data_ptr(), 80, 80, 64, t.data_ptr(), 8, 8, 8, 0, None, 8, 0, r.data_ptr(), 73 * 4, 3)
     assert rc == 1 and b"mask" in _lib.lib.mi355cv_lastError()
+
+
+ORDERED_TRIPLES = [(np.uint8, 4, 6), (np.uint8, 4, 5), (np.uint8, 4, 4), (np.uint8, 5, 6), (np.uint8, 5, 5), (np.uint8, 6, 6), (np.uint16, 6, 6), (np.int16, 6, 6),
+                   (np.float32, 5, 6), (np.float32, 5, 5), (np.float32, 6, 6), (np.float64, 6, 6)]
+
+
+def _bits(a):
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize]) if a.dtype.kind == "f" else a
+
+
+@pytest.mark.parametrize("dtype,sdepth,sqdepth", ORDERED_TRIPLES)
+def test_integral_every_triple_in_the_reference_order(cv, orc, dtype, sdepth, sqdepth):
+    """cv::integral for every row of the reference's type table, with and without the squared and the tilted sum: float sums, CV_32F / CV_32S squared sums and tilted
+    sums are accumulated in the reference's order (integral_seq.hip), so they equal the restatement (tests/test_oracle_integral.py: == cv::integral) in every BIT;
+    sizes around the kernels' chunking (64-row column chunks, 256-thread diagonal groups), widths 1 / 2, 1-4 channels."""
+    from test_oracle_integral import source
+    for (h, w) in [(1, 1), (1, 9), (9, 1), (5, 2), (3, 3), (66, 130), (130, 66), (300, 517)]:
+        for cn in (1, 2, 3, 4):
+            if cn in (2, 4) and h * w > 1000:
+                continue
+            for (sq, tl) in ((False, False), (True, False), (False, True), (True, True)):
+                if sqdepth != 6 and not sq:
+                    continue
+                src = source((h, w, cn) if cn > 1 else (h, w), dtype, 7 * h + w + cn)
+                want = orc.orc_integral(src, sdepth, sqdepth, sq, tl)
+                if dtype == np.uint8 and sdepth == 5 and not sq and not tl and h * w * 255 >= 2 ** 24:
+                    with pytest.raises(NotImplementedError):                              # the reference's bits depend on the CPU's vector width there: declined
+                        cv.integral(torch.from_numpy(src).cuda(), sdepth=sdepth, sqdepth=sqdepth)
+                    continue
+                got = cv.integral(torch.from_numpy(src).cuda(), sqsum=sq, sdepth=sdepth, sqdepth=sqdepth, tilted=tl)
+                got = list(got) if isinstance(got, tuple) else [got]
+                for g, r, name in zip(got, [x for x in want if x is not None], [n for n, x in zip(("sum", "sqsum", "tilted"), want) if x is not None]):
+                    g = g.cpu().numpy()
+                    if dtype == np.float32 and sdepth == 6 and not tl:                    # CV_32F -> CV_64F without a tilted sum: the scanned kernels (1e-13, see test_integral)
+                        scale = float(np.abs(src.astype(np.float64)).sum()) if name == "sum" else float((src.astype(np.float64) ** 2).sum())
+                        assert float(np.abs(g - r).max()) <= 1e-13 * scale, (name, h, w, cn, sq, tl)      # (the sources have signs and exponents 2^-12 .. 2^12)
+                    else:
+                        assert g.dtype == r.dtype and np.array_equal(_bits(g), _bits(r)), (name, h, w, cn, sq, tl, np.argwhere(_bits(g) != _bits(r))[:4])
+
+
+def test_integral_ordered_full_frame_and_host_images(cv, orc):
+    """a 1080p CV_32F frame with all three outputs (bit for bit), host pointers, wrapping CV_32S sums, and the one declined case"""
+    from test_oracle_integral import source
+    src = source((1080, 1920), np.float32, 5)
+    want = orc.orc_integral(src, 5, 6, True, True)
+    got = cv.integral(dev(src), sqsum=True, sdepth=5, tilted=True)
+    for g, r in zip(got, want):
+        assert np.array_equal(_bits(g.cpu().numpy()), _bits(r))
+    from opencv_amd import _lib
+    assert "k_iseq" in _lib.lib.mi355cv_lastKernel().decode()
+    small = source((40, 70, 3), np.float32, 6)
+    s, t = cv.integral(small, sdepth=5, tilted=True)                       # host pointers
+    w = orc.orc_integral(small, 5, 6, False, True)
+    assert isinstance(s, np.ndarray) and np.array_equal(_bits(s), _bits(w[0])) and np.array_equal(_bits(t), _bits(w[2]))
+    big = np.full((3000, 3000), 255, np.uint8)                             # 3000 * 3000 * 255 > 2^31: CV_32S sums wrap, like the reference's
+    got = cv.integral(dev(big)).cpu().numpy()
+    assert got[-1, -1] == np.int64(3000 * 3000 * 255).astype(np.int32) and np.array_equal(got, orc.orc_integral(big, 4)[0])
+    with pytest.raises(NotImplementedError):
+        cv.integral(dev(rnd((300, 300), np.uint8, 1)), sdepth=5)          # CV_8U -> CV_32F past 2^24 without sqsum / tilted: vector-width dependent on the CPU
+    got = cv.integral(dev(rnd((100, 100), np.uint8, 1)), sdepth=5).cpu().numpy()
+    assert np.array_equal(got, orc.orc_integral(rnd((100, 100), np.uint8, 1), 5)[0])
