@@ -1531,11 +1531,10 @@ MI355CV_API int mi355cv_matchTemplateBatch(const uchar* img_data, size_t img_ste
 }
 
 // replaces hal_ni_integral (hal_replacement.hpp:977; caller cv::integral sumpixels.dispatch.cpp:415): every depth triple of the reference's table (:383-406), with or
-// without the squared and the tilted sum.  CV_8U sources with CV_32S / CV_64F sums and CV_32F sources with CV_64F sums (squared sum in CV_64F, no tilted sum) take the
-// tiled / scanned kernels below (exact integers; doubles of floats to 1e-13); everything whose value depends on the order of the additions -- CV_32F sums, CV_32F / CV_32S
-// squared sums, tilted sums -- takes integral_seq.hip, which adds in the reference's order (bit for bit).  One case is left to the CPU: CV_8U -> CV_32F sums without a
-// squared or tilted sum beyond 2^24 (the reference's vector body recovers the row prefix in its scalar tail by a subtraction, sumpixels.simd.hpp:528-533, so the bits
-// depend on the CPU's vector width).
+// without the squared and the tilted sum.  CV_8U sources with CV_32S / CV_64F sums (squared sum in CV_64F, no tilted sum) take the tiled / scanned kernels below -- exact
+// integers in any order; everything whose value depends on the order of the additions -- float sources, CV_32F sums, CV_32F / CV_32S squared sums, tilted sums -- takes
+// integral_seq.hip, which adds in the reference's order (bit for bit).  One case is left to the CPU: CV_8U -> CV_32F sums without a squared or tilted sum beyond 2^24
+// (the reference's vector body recovers the row prefix in its scalar tail by a subtraction, sumpixels.simd.hpp:528-533, so the bits depend on the CPU's vector width).
 MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar* src_data, size_t src_step, uchar* sum_data, size_t sum_step,
                                  uchar* sqsum_data, size_t sqsum_step, uchar* tilted_data, size_t tilted_step, int width, int height, int cn)
 {
@@ -1543,7 +1542,7 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
     if (disabled() || !sum_data || !src_data) return mi355::declined(__func__, __LINE__, "disabled() || !sum_data || !src_data");
     if (!integralOrderedTriple(depth, sdepth, sqdepth) || cn < 1)
         return setError(MI355CV_NOT_IMPLEMENTED, "integral: depths %d -> sum %d, sqsum %d%s, %d channels: not a row of the reference's table", depth, sdepth, sqdepth, sqsum_data ? "" : " (no sqsum)", cn);
-    const bool tiledKind = !tilted_data && cn <= 4 && ((depth == D8U && (sdepth == D32S || sdepth == D64F)) || (depth == D32F && sdepth == D64F)) && (!sqsum_data || sqdepth == D64F) &&
+    const bool tiledKind = !tilted_data && cn <= 4 && depth == D8U && (sdepth == D32S || sdepth == D64F) && (!sqsum_data || sqdepth == D64F) &&
                            !(sdepth == D32S && (double)width * height * 255.0 > 2147483647.0);          // (sums that wrap: the ordered kernels wrap like the reference)
     if (!tiledKind) {
         if (depth == D8U && sdepth == D32F && !sqsum_data && !tilted_data && (double)width * height * 255.0 >= 16777216.0)
