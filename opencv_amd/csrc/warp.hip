@@ -961,13 +961,13 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
     if (!a.linear) {
         if ((unsigned)sx < (unsigned)a.sw && (unsigned)sy < (unsigned)a.sh) { copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e); return; }
         if (a.border == B_REPLICATE) { sx = clipI(sx, 0, a.sw); sy = clipI(sy, 0, a.sh); copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e); return; }
-        if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k]); return; }
+        if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k & 3]); return; }
         if (a.border == B_TRANSPARENT) return;
         sx = mi355_borderInterpolate(sx, a.sw, a.border); sy = mi355_borderInterpolate(sy, a.sh, a.border);
         copyPix(D, src + (size_t)sy * sstep + (size_t)sx * cn * e, cn * e);
         return;
     }
-    if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k]); return; }
+    if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) stRound(D, a.depth, k, a.cval[k & 3]); return; }
     int x0, x1, y0, y1;
     if ((unsigned)sx < (unsigned)(a.sw - 1) && (unsigned)sy < (unsigned)(a.sh - 1)) { x0 = sx; x1 = sx + 1; y0 = sy; y1 = sy + 1; }
     else if (a.border == B_TRANSPARENT) {
@@ -1021,7 +1021,7 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
         const short* w = tab + (ay * 32 + ax) * 4;
         const int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         for (int k = 0; k < cn; k++) {
-            const int cv = (int)fminf(fmaxf(rintf(a.cval[k]), 0.f), 255.f);
+            const int cv = (int)fminf(fmaxf(rintf(a.cval[k & 3]), 0.f), 255.f);
             const int v0 = (x0 >= 0 && y0 >= 0) ? r0[x0 * cn + k] : cv;
             const int v1 = (x1 >= 0 && y0 >= 0) ? r0[x1 * cn + k] : cv;
             const int v2 = (x0 >= 0 && y1 >= 0) ? r1[x0 * cn + k] : cv;
@@ -1036,7 +1036,7 @@ __device__ void samplePixel(const uchar* __restrict__ src, size_t sstep, uchar* 
     const float wy0 = 1.f - fy, wy1 = fy, wx0 = 1.f - fx, wx1 = fx;
     const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, wx1), w2 = __fmul_rn(wy1, wx0), w3 = __fmul_rn(wy1, wx1);
     for (int k = 0; k < cn; k++) {
-        float cv = a.cval[k];
+        float cv = a.cval[k & 3];
         if (a.depth == D16U) cv = fminf(fmaxf(rintf(cv), 0.f), 65535.f);
         else if (a.depth == D16S) cv = fminf(fmaxf(rintf(cv), -32768.f), 32767.f);
         const float v0 = (x0 >= 0 && y0 >= 0) ? ldV(r0, a.depth, x0 * cn + k) : cv;
@@ -1271,13 +1271,13 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
     } else {
         if (a.border == B_TRANSPARENT && ((unsigned)(sx + OFF) >= (unsigned)a.sw || (unsigned)(sy + OFF) >= (unsigned)a.sh)) return;
         const int b1 = a.border != B_TRANSPARENT ? a.border : B_REFLECT_101;
-        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) stRound(D, depth, k, a.cval[k]); return; }
+        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) stRound(D, depth, k, a.cval[k & 3]); return; }
 #pragma unroll
         for (int i = 0; i < KS; i++) { xi[i] = mi355_borderInterpolate(sx + i, a.sw, b1); yi[i] = mi355_borderInterpolate(sy + i, a.sh, b1); }
     }
     if (depth == D8U) {
         const short* __restrict__ w = tabI + (ay * 32 + ax) * (KS * KS);
-        if (inside) {
+        if (inside && cn <= 4) {
             const uchar* p = src + (size_t)sy * sstep + (size_t)sx * cn;
             if (cn == 1) tapsInside8<KS, 1>(p, sstep, D, w);
             else if (cn == 2) tapsInside8<KS, 2>(p, sstep, D, w);
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
                     for (int c = 0; c < KS; c++) sum += (int)S[xi[c] * cn] * (int)w[r * KS + c];
                 }
             } else {
-                const int cv = (int)fminf(fmaxf(rintf(a.cval[k]), 0.f), 255.f);
+                const int cv = (int)fminf(fmaxf(rintf(a.cval[k & 3]), 0.f), 255.f);
                 sum = cv << 15;
 #pragma unroll
                 for (int r = 0; r < KS; r++) {
@@ -1328,7 +1328,7 @@ __device__ __forceinline__ void samplePixelN(const uchar* __restrict__ src, size
                 sum = (r == 0 && KS == 4) ? row : __fadd_rn(sum, row);
             }
         } else {
-            float cv = a.cval[k];
+            float cv = a.cval[k & 3];
             if (depth == D16U) cv = fminf(fmaxf(rintf(cv), 0.f), 65535.f);
             else if (depth == D16S) cv = fminf(fmaxf(rintf(cv), -32768.f), 32767.f);
             sum = cv;
@@ -1534,7 +1534,7 @@ __device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, doubl
     if (mode == 0) {
         if (!((unsigned)sx < (unsigned)a.sw && (unsigned)sy < (unsigned)a.sh)) {
             if (a.border == B_REPLICATE) { sx = clipI(sx, 0, a.sw); sy = clipI(sy, 0, a.sh); }
-            else if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+            else if (a.border == B_CONSTANT) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k & 3]; return; }
             else if (a.border == B_TRANSPARENT) return;
             else { sx = mi355_borderInterpolate(sx, a.sw, a.border); sy = mi355_borderInterpolate(sy, a.sh, a.border); }
         }
@@ -1544,7 +1544,7 @@ __device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, doubl
     if (mode == 1) {
         const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32;
         const float w[4] = {__fmul_rn(1.f - fy, 1.f - fx), __fmul_rn(1.f - fy, fx), __fmul_rn(fy, 1.f - fx), __fmul_rn(fy, fx)};
-        if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+        if (a.border == B_CONSTANT && (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k & 3]; return; }
         int x0, x1, y0, y1;
         if ((unsigned)sx < (unsigned)(a.sw - 1) && (unsigned)sy < (unsigned)(a.sh - 1)) { x0 = sx; x1 = sx + 1; y0 = sy; y1 = sy + 1; }
         else if (a.border == B_TRANSPARENT) {
@@ -1569,7 +1569,7 @@ __device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, doubl
         else { x0 = mi355_borderInterpolate(sx, a.sw, a.border); x1 = mi355_borderInterpolate(sx + 1, a.sw, a.border);
                y0 = mi355_borderInterpolate(sy, a.sh, a.border); y1 = mi355_borderInterpolate(sy + 1, a.sh, a.border); }
         for (int k = 0; k < cn; k++) {
-            const double cv = a.cvalD[k];
+            const double cv = a.cvalD[k & 3];
             const double v0 = (x0 >= 0 && y0 >= 0) ? S(y0, x0, k) : cv, v1 = (x1 >= 0 && y0 >= 0) ? S(y0, x1, k) : cv;
             const double v2 = (x0 >= 0 && y1 >= 0) ? S(y1, x0, k) : cv, v3 = (x1 >= 0 && y1 >= 0) ? S(y1, x1, k) : cv;
             double t = __dadd_rn(__dmul_rn(v0, (double)w[0]), __dmul_rn(v1, (double)w[1]));
@@ -1586,7 +1586,7 @@ __device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, doubl
     if (!inside) {
         if (a.border == B_TRANSPARENT && ((unsigned)(sx + OFF) >= (unsigned)a.sw || (unsigned)(sy + OFF) >= (unsigned)a.sh)) return;
         const int b1 = a.border != B_TRANSPARENT ? a.border : B_REFLECT_101;
-        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k]; return; }
+        if (b1 == B_CONSTANT && (sx >= a.sw || sx + KS <= 0 || sy >= a.sh || sy + KS <= 0)) { for (int k = 0; k < cn; k++) D[k] = a.cvalD[k & 3]; return; }
         for (int i = 0; i < KS; i++) { xi[i] = mi355_borderInterpolate(sx + i, a.sw, b1); yi[i] = mi355_borderInterpolate(sy + i, a.sh, b1); }
     }
     for (int k = 0; k < cn; k++) {
@@ -1599,7 +1599,7 @@ __device__ void samplePixel64(const uchar* __restrict__ src, size_t sstep, doubl
                 sum = (r == 0 && KS == 4) ? row : __dadd_rn(sum, row);
             }
         } else {
-            const double cv = a.cvalD[k];
+            const double cv = a.cvalD[k & 3];
             sum = cv;
             for (int r = 0; r < KS; r++) {
                 if (yi[r] < 0) continue;
@@ -2259,7 +2259,9 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
     const bool is64 = depth == MI355CV_64F;                                                      // CV_64F images: the per-pixel kernel k_warp64
-    if (!(depthOk(depth) || is64) || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F / 64F || cn < 1 || cn > 4 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0");
+    // channels: the samplers loop over them (border value of channel k = borderValue[k & 3], imgwarp.cpp:340 / :692); the reference itself asserts <= 4 for bicubic / Lanczos
+    // (imgwarp.cpp:2795), and so does this entry further down
+    if (!(depthOk(depth) || is64) || cn < 1 || cn > 512 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F / 64F || cn < 1 || cn > 512 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0");
     if (is64 && (kind == 6 || kind == 7)) return mi355::declined(__func__, __LINE__, "warpPolar on CV_64F images");
     const bool relative = (interpolation & 32) != 0 && kind >= 2 && kind <= 5;              // WARP_RELATIVE_MAP (cv::remap only, imgwarp.cpp:1724)
     if (relative) interpolation &= ~32;
@@ -2267,6 +2269,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
     if (interpolation != MI355CV_INTER_NEAREST && interpolation != MI355CV_INTER_LINEAR && interpolation != MI355CV_INTER_CUBIC && interpolation != MI355CV_INTER_LANCZOS4)
         return mi355::declined(__func__, __LINE__, "interpolation is none of NEAREST, LINEAR, CUBIC, AREA, LANCZOS4");
     const bool taps = interpolation == MI355CV_INTER_CUBIC || interpolation == MI355CV_INTER_LANCZOS4;
+    if (taps && cn > 4) return mi355::declined(__func__, __LINE__, "bicubic / Lanczos sampling of more than 4 channels (the reference asserts on it)");
     if (taps && (kind == 5 || kind == 6 || kind == 7)) return mi355::declined(__func__, __LINE__, "bicubic / Lanczos sampling with a CV_16SC2 map alone, or in warpPolar");
     if (borderType < 0 || borderType > B_TRANSPARENT) return mi355::declined(__func__, __LINE__, "borderType < 0 || borderType > B_TRANSPARENT");
     if (sw > 32767 || sh > 32767) return mi355::declined(__func__, __LINE__, "sw > 32767 || sh > 32767");                         // coordinates saturate to short in the reference
@@ -2513,7 +2516,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
 {
     if (disabled() || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || nframes < 1");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if (!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 4 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0");
+    if (!depthOk(depth) || cn < 1 || cn > 512 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0) return mi355::declined(__func__, __LINE__, "!depthOk(depth) || cn < 1 || cn > 512 || src_width <= 0 || src_height <= 0 || dst_width <= 0 || dst_height <= 0");
     if (inv_scale_x < 2.220446049250313e-16 || inv_scale_y < 2.220446049250313e-16) {        // resize.cpp:3834-3838
         inv_scale_x = (double)dst_width / src_width; inv_scale_y = (double)dst_height / src_height;
     }
@@ -2543,6 +2546,7 @@ static int runResize(const char* entry, int src_type, const uchar* src_data, siz
         else if (interpolation == 4 /*INTER_LANCZOS4*/) a.mode = 6;
         else return mi355::declined(__func__, __LINE__, nullptr);                                                // LINEAR_EXACT on other depths
     }
+    if (a.mode == 4 && cn > 4) return mi355::declined(__func__, __LINE__, "true INTER_AREA of more than 4 channels (the reference asserts on it, resize.cpp:4045)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)dst_width * dst_height, minPixels(a.mode >= 3 ? HOST_HEAVY : HOST_CHEAP))");

@@ -560,3 +560,40 @@ def test_warps_on_64f_images(cv, orc):
                 _bits(cv.remap(dev(src), dev(f1), dev(f2), interp, border, bval, dst=d0()), orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=p0))
     assert "k_warp64" in _lib.lib.mi355cv_lastKernel().decode()
     _bits(cv.warpAffine(src, M, (47, 33), 2 | cv.WARP_INVERSE_MAP, 4), orc.orc_warpAffine(src, M, (47, 33), 2, 4))                     # host arrays
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [5, 6, 9, 14])
+def test_more_than_four_channels(cv, orc, dtype, cn):
+    """cv::warpAffine / warpPerspective / remap / resize of 5-14 channel images (Imgproc_Warp.multichannel, Resize.nearest_regression_15075): nearest and bilinear
+    sampling loop over the channels (border value of channel k = borderValue[k & 3], imgwarp.cpp:340 / :692); the reference asserts <= 4 channels for bicubic / Lanczos
+    warps and for true INTER_AREA, and those are declined.  Against the restatement (== the reference for these channel counts, checked on the CPU when oracle/_ref is there)."""
+    src = rnd((37, 53, cn), dtype, 40 + cn)
+    M = mats(cv, 53, 37)[1]
+    P = np.vstack([M, [1e-4, 2e-4, 1.0]])
+    for interp in (0, 1, 3):                                                       # (3 = INTER_AREA: bilinear in the warps)
+        for border, bval in [(0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0)]:
+            want = orc.orc_warpAffine(src, M, (61, 41), 1 if interp == 3 else interp, border, bval)
+            check(cv.warpAffine(dev(src), M, (61, 41), interp | cv.WARP_INVERSE_MAP, border, bval), want)
+            want = orc.orc_warpPerspective(src, P, (61, 41), 1 if interp == 3 else interp, border, bval)
+            check(cv.warpPerspective(dev(src), P, (61, 41), interp | cv.WARP_INVERSE_MAP, border, bval), want)
+            if orc.load_ref() is not None:
+                assert np.array_equal(want, orc.ref_warpPerspective(src, P, (61, 41), (1 if interp == 3 else interp) | 16, border, bval))
+    for interp in (2, 4):
+        with pytest.raises(NotImplementedError):
+            cv.warpAffine(dev(src), M, (61, 41), interp | cv.WARP_INVERSE_MAP)
+    yy, xx = np.mgrid[0:41, 0:61].astype(np.float32)
+    mx, my = (xx * 0.8 + yy * 0.1 - 2).astype(np.float32), (yy * 0.9 - xx * 0.05 + 1.5).astype(np.float32)
+    for interp in (0, 1):
+        check(cv.remap(dev(src), dev(mx), dev(my), interp, 1), orc.orc_remap(src, mx, my, interp, 1))
+    modes = [0, 1, 2, 4, 6] + ([5] if dtype != np.float32 else [])                 # nearest, bilinear, bicubic, Lanczos, nearest-exact, linear-exact (integer depths)
+    for interp in modes:
+        for dsize in [(80, 55), (31, 23), (106, 74)]:
+            want = orc.orc_resize(src, dsize, interpolation=interp)
+            check(cv.resize(dev(src), dsize, interpolation=interp), want, tol=1e-5 if interp in (2, 4) else 1e-6)
+            if orc.load_ref() is not None and want.dtype != np.float32:
+                assert np.array_equal(want, orc.ref_resize(src, dsize, interpolation=interp)), (interp, dsize)
+    s2 = np.ascontiguousarray(src[:36, :52])
+    check(cv.resize(dev(s2), (26, 18), interpolation=3), orc.orc_resize(s2, (26, 18), interpolation=3))          # integer-factor area: the fast kernel, any channel count
+    with pytest.raises(NotImplementedError):
+        cv.resize(dev(src), (31, 23), interpolation=3)                             # true area: the reference asserts cn <= 4 (resize.cpp:4045)
