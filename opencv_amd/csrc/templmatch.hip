@@ -1553,7 +1553,8 @@ MI355CV_API int mi355cv_integral(int depth, int sdepth, int sqdepth, const uchar
         if ((double)(width + 1) * cn * (height + 1) >= 2147483647.0) return mi355::declined(__func__, __LINE__, "more than 2^31 elements");
         Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
         if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
-        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
+        // (HOST_HEAVY: the reference's scalar loops take 10-60 ms per 4K image on one core -- worth two PCIe crossings, unlike the 8-bit vector paths of the tiled kind)
+        if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(HOST_HEAVY))");
         size_t dss, d1, d2 = 0, d3 = 0;
         const uchar* ds = stg.in(src_data, src_step, (size_t)width * cn * es, height, &dss);
         uchar* s1 = stg.out(sum_data, sum_step, (size_t)(width + 1) * cn * e1, height + 1, &d1);
