@@ -30,6 +30,13 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C opencv_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1 and opens them by path.  Loaded AFTER this library (whose DT_NEEDED search had already pulled in
+    # /opt/rocm's copies), the process holds two HIP runtimes and the second one to initialise finds "no ROCm-capable device" -- seen as mi355cv_setDevice failing in a
+    # process that imported opencv_amd._lib before torch.  Loaded first, torch's copy satisfies this library's DT_NEEDED by soname: one runtime, shared streams and memory.
+    try:
+        import torch  # noqa: F401
+    except Exception:                                    # no torch: the C ABI stands on /opt/rocm's runtime alone
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     sig = {
         "mi355cv_init": (c_int, [c_int]),
