@@ -378,3 +378,26 @@ def test_warps_on_64f_images(orc, ref):
             _bits(orc.orc_remapMaps(src, xy, None, interp, border, bval, dst=d0), orc.ref_remapMaps(src, xy, None, interp, border, bval, dst=d0))
             if interp:
                 _bits(orc.orc_remapMaps(src, f1, f2, interp, border, bval, dst=d0), orc.ref_remapMaps(src, f1, f2, interp, border, bval, dst=d0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cn", [5, 6, 9, 14])
+def test_more_than_four_channels(orc, ref, dtype, cn):
+    """5-14 channels (Imgproc_Warp.multichannel, Resize.nearest_regression_15075): the restatement's channel loops against the reference -- nearest / bilinear warps
+    (border value of channel k = borderValue[k & 3]) and every resize mode but true area; the reference itself asserts on bicubic / Lanczos warps (imgwarp.cpp:2795)
+    and on true INTER_AREA (resize.cpp:4045) of more than 4 channels."""
+    src = rnd(orc, (37, 53, cn), dtype, 40 + cn)
+    M = mats(orc, 53, 37)[1]
+    P = np.vstack([M, [1e-4, 2e-4, 1.0]])
+    for interp in (0, 1):
+        for border, bval in [(0, (10, 200, 30, 77)), (1, 0), (2, 0), (3, 0), (4, 0)]:
+            same(orc, orc.orc_warpAffine(src, M, (61, 41), interp, border, bval), orc.ref_warpAffine(src, M, (61, 41), interp | 16, border, bval))
+            same(orc, orc.orc_warpPerspective(src, P, (61, 41), interp, border, bval), orc.ref_warpPerspective(src, P, (61, 41), interp | 16, border, bval))
+    for interp in [0, 1, 2, 4, 6] + ([5] if dtype != np.float32 else []):
+        for dsize in [(80, 55), (31, 23), (106, 74)]:
+            same(orc, orc.orc_resize(src, dsize, interpolation=interp), orc.ref_resize(src, dsize, interpolation=interp), tol=1e-5 if interp in (2, 4) else 1e-6)
+    s2 = np.ascontiguousarray(src[:36, :52])
+    same(orc, orc.orc_resize(s2, (26, 18), interpolation=3), orc.ref_resize(s2, (26, 18), interpolation=3))
+    for bad in (lambda: orc.ref_warpAffine(src, M, (61, 41), 2 | 16), lambda: orc.ref_resize(src, (31, 23), interpolation=3)):
+        with pytest.raises(Exception):
+            bad()
