@@ -1041,7 +1041,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
 {
-    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 4 || inPlaceOnDevice(src_data, dst_data)");
+    if (disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 512 || inPlaceOnDevice(src_data, dst_data)) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0 || cn < 1 || cn > 512 || inPlaceOnDevice(src_data, dst_data)");
     // cv::boxFilter hands its `ddepth` argument through as the caller gave it (box_filter.dispatch.cpp:451-474): a caller that passed a TYPE there (CV_8UC2 = 8 --
     // the reference's own Imgproc_Blur test does) arrives with channel bits set; the destination Mat was created from CV_MAKETYPE(ddepth, cn), i.e. from the depth bits
     src_depth = MI355CV_MAT_DEPTH(src_depth); dst_depth = MI355CV_MAT_DEPTH(dst_depth);

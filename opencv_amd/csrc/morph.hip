@@ -78,7 +78,7 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
     (void)allowInplace;
     if (iterations < 1 || iterations > 64 || src_type != dst_type) return mi355::declined(__func__, __LINE__, "iterations < 1 || iterations > 64 || src_type != dst_type");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 4");
+    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 512) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 512");
     if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return mi355::declined(__func__, __LINE__, "!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1");
     if (kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024) return mi355::declined(__func__, __LINE__, "kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024");
     const int border = borderType & ~MI355CV_BORDER_ISOLATED;
@@ -100,6 +100,12 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
             c->bv[k] = operation == 0 ? (depth == D8U ? 255.f : depth == D16U ? 65535.f : depth == D16S ? 32767.f : FLT_MAX)
                                       : (depth == D8U || depth == D16U ? 0.f : depth == D16S ? -32768.f : -FLT_MAX);
         else c->bv[k] = satBorder(borderValue[k], depth);
+    }
+    // more than 4 channels: the reference unrolls the border Scalar over the border ELEMENTS with period 4 (FilterEngine::init, filter.dispatch.cpp:150-160), a per-channel
+    // value only when the four are equal (the default border is)
+    if (cn > 4 && border == B_CONSTANT && !(c->bv[0] == c->bv[1] && c->bv[1] == c->bv[2] && c->bv[2] == c->bv[3])) {
+        delete c;
+        return setError(MI355CV_NOT_IMPLEMENTED, "morph: %d channels with a border value that differs between channels", cn);
     }
     *context = reinterpret_cast<cvhalFilter2D*>(c);
     return MI355CV_OK;

@@ -40,6 +40,9 @@ int orc_morph(int op /*0 erode, 1 dilate*/, const uint8_t* src, size_t sstep, ui
                             : (depth == 0 || depth == 2 ? 0.0 : depth == 3 ? -32768.0 : (double)-FLT_MAX);
         else bv[c] = satv(borderValue ? borderValue[c] : 0.0, depth);
     }
+    /* more than 4 channels: FilterEngine::init unrolls the Scalar over the border ELEMENTS with period 4 (srcType1 = MIN(cn, 4) channels, filter.dispatch.cpp:150-160), which
+     * is a per-channel value only if the four are equal -- the default border, Scalar::all(...) -- and that is the case restated here */
+    if (cn > 4 && border == 0 && !(bv[0] == bv[1] && bv[1] == bv[2] && bv[2] == bv[3])) return 2;
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             for (int c = 0; c < cn; c++) {
@@ -49,7 +52,7 @@ int orc_morph(int op /*0 erode, 1 dilate*/, const uint8_t* src, size_t sstep, ui
                         if (!kernel[(size_t)j * kstep + i]) continue;
                         const int yy = orc_borderInterpolate(y + offY + j - ay, fullH, border);
                         const int xx = orc_borderInterpolate(x + offX + i - ax, fullW, border);
-                        const double v = (yy < 0 || xx < 0) ? bv[c] : ldv(src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep, depth, (xx - offX) * cn + c);
+                        const double v = (yy < 0 || xx < 0) ? bv[c & 3] : ldv(src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep, depth, (xx - offX) * cn + c);
                         if (first) { r = v; first = 0; } else r = op == 0 ? (v < r ? v : r) : (v > r ? v : r);
                     }
                 stv(dst + (size_t)y * dstep, depth, x * cn + c, r);

@@ -265,6 +265,14 @@ def test_boxfilter(cv, orc):
                           orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border), tol=1e-6 if dtype == np.float32 else 0.0)
     src = rnd((20, 33), np.uint8, 2)
     check(cv.blur(src, (3, 3)), orc.orc_boxFilter(src, -1, (3, 3)))
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, 5)]:       # 5 / 9 channels (Imgproc_FilterSupportedFormats blurs 5)
+        for cn in (5, 9):
+            src = rnd((31, 47, cn), dtype, 30 + cn)
+            for ksize in [(3, 3), (11, 11), (4, 7)]:
+                for normalize in (True, False):
+                    for border in (0, 1, 4):
+                        check(cv.boxFilter(dev(src), ddepth, ksize, (-1, -1), normalize, border),
+                              orc.orc_boxFilter(src, ddepth, ksize, (-1, -1), normalize, border), tol=1e-6 if dtype == np.float32 else 0.0)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])

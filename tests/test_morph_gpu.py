@@ -91,3 +91,18 @@ def test_iterated_irregular_elements_and_in_place(cv, orc, dtype):
                 fn(d, np.ones((3, 3), np.uint8), dst=d)
                 assert np.array_equal(d.cpu().numpy(), orc.orc_morph(op, src, np.ones((3, 3), np.uint8)))
     assert cv.call_count("morph") > n0
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_more_than_four_channels(cv, orc, dtype):
+    """erode / dilate of 5 / 6 / 9 channel images (Imgproc_FilterSupportedFormats): default and extrapolating borders; a constant border whose Scalar differs
+    between its entries is declined (the reference unrolls it over the border elements with period 4)"""
+    for shape in [(23, 40, 5), (17, 29, 6), (6, 3, 9)]:
+        src = _src(dtype, shape, 11 + shape[2])
+        for op, fn in ((0, cv.erode), (1, cv.dilate)):
+            for k, anchor in KERNELS[:6]:
+                for border in (0, 1, 2, 4):
+                    got = fn(dev(src), k, anchor, 1, border).cpu().numpy()
+                    assert np.array_equal(got, orc.orc_morph(op, src, k, anchor, border)), (dtype, shape, op, anchor, border)
+    with pytest.raises(NotImplementedError):
+        cv.erode(dev(_src(dtype, (9, 9, 5), 3)), None, (-1, -1), 1, 0, (1.0, 2.0, 3.0, 4.0))

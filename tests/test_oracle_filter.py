@@ -101,3 +101,19 @@ def test_boxfilter(orc, ref):
                             assert orc.rel_err(got, want) <= 2e-7, (dtype, ksize, normalize, border)
                         else:   # incl. the int32-sum normalisation: SIMD body in float, the last (w*cn) % 8 elements of a row in double
                             assert np.array_equal(got, want), (dtype, ksize, normalize, border)
+
+
+def test_boxfilter_more_than_four_channels(orc, ref):
+    """5 and 9 channels (Imgproc_FilterSupportedFormats blurs 5): the sums are per element, the normalisation's vector body / scalar tail split is by element count"""
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 5), (np.float32, -1), (np.uint16, -1), (np.int16, 5)]:
+        for cn in (5, 9):
+            src = rnd(orc, (31, 47, cn), dtype, 30 + cn)
+            for ksize in [(3, 3), (11, 11), (4, 7)]:
+                for normalize in (True, False):
+                    for border in (0, 1, 4):
+                        want = orc.ref_boxFilter(src, ddepth, ksize, (-1, -1), normalize, border)
+                        got = orc.orc_boxFilter(src, ddepth, ksize, (-1, -1), normalize, border)
+                        if want.dtype == np.float32 and dtype == np.float32:
+                            assert orc.rel_err(got, want) <= 2e-7, (dtype, cn, ksize, normalize, border)
+                        else:
+                            assert np.array_equal(got, want), (dtype, cn, ksize, normalize, border)

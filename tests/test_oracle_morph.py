@@ -62,3 +62,19 @@ def test_morph_known_answer():
     assert O.orc_morph(1, src).tolist() == [[7, 9, 9], [8, 9, 9], [8, 8, 8]]          # dilate: outside ignored
     assert O.orc_morph(0, src).tolist() == [[1, 1, 1], [1, 1, 1], [3, 2, 2]]          # erode
     assert O.orc_morph(0, src, None, (-1, -1), 0, 0.0)[0].tolist() == [0, 0, 0]        # explicit constant 0 border
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_more_than_four_channels(ref, dtype):
+    """5 / 6 / 9 channels (the reference's Imgproc_FilterSupportedFormats runs morphologyEx on 5): the default constant border and the extrapolating ones.  (A border
+    Scalar that differs between its four entries is unrolled over the border ELEMENTS with period 4 there -- not a per-channel value -- and is outside the restatement.)"""
+    for shape in [(23, 40, 5), (17, 29, 6), (6, 3, 9)]:
+        src = _src(dtype, shape, 11 + shape[2])
+        for op in (0, 1):
+            for k, anchor in KERNELS[:6]:
+                for border in (0, 1, 2, 4):
+                    assert np.array_equal(O.orc_morph(op, src, k, anchor, border), O.ref_morph(op, src, k, anchor, 1, border)), (dtype, shape, op, anchor, border)
+    o = O.oracle()
+    src = _src(np.uint8, (5, 5, 5), 1); dst = np.empty_like(src); k = np.ones((3, 3), np.uint8)
+    assert o.orc_morph(0, O.P(src), O.step(src), O.P(dst), O.step(dst), 5, 5, 0, 5, 5, 5, 0, 0, O.P(k), O.c_sz(3), 3, 3, 1, 1, 0, O._bvp((1.0, 2.0, 3.0, 4.0))) == 2
