@@ -32,7 +32,7 @@ using namespace mi355;
 
 namespace {
 
-enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F, D64F = MI355CV_64F };
 
 __device__ __forceinline__ float ldF(const uchar* row, int idx, int depth)
 {
@@ -431,6 +431,89 @@ __global__ __launch_bounds__(256) void k_sepfilter_generic(
 }
 
 
+// ---------------------------------------------------------------------------------- CV_64F destinations (and sources)
+// cv::filter2D / cv::sepFilter2D with a CV_64F source or destination run the reference's engines with double kernels and double intermediate rows (kdepth / bdepth =
+// CV_64F, filter.simd.hpp:3192-3210, filter.dispatch.cpp:318-330): Filter2D<ST, Cast<double, double>, FilterNoVec> -- s = delta, s += k * src over the non-zero taps in
+// raster order --, RowFilter<ST, double, RowNoVec> -- kx[0] * S[0], then s += kx[i] * S[i] -- and ColumnFilter / SymmColumnFilter<Cast<double, double>, ColumnNoVec>
+// (the pair forms for odd (anti)symmetric kernels).  The running copy of those loops is the AVX2 + FMA one (filter.simd.hpp is a dispatched file), where the compiler
+// fuses every `s += a * b`: fma() here, as fmaf() in the float kernels above.  One thread per output element; double arithmetic at half rate on a path nobody
+// benchmarks -- what matters is that a CV_64F Mat does not fall off the GPU.
+__device__ __forceinline__ double ldD(const uchar* row, int idx, int depth)
+{
+    switch (depth) {
+    case D8U:  return (double)row[idx];
+    case D16U: return (double)reinterpret_cast<const unsigned short*>(row)[idx];
+    case D16S: return (double)reinterpret_cast<const short*>(row)[idx];
+    case D32F: return (double)reinterpret_cast<const float*>(row)[idx];
+    default:   return reinterpret_cast<const double*>(row)[idx];
+    }
+}
+
+struct Tap2D64 { double k; int dx, dy; };
+
+__global__ __launch_bounds__(256) void k_filter2d_generic64(
+    const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+    int W, int H, int cn, int sdepth, int fullW, int fullH, int offX, int offY,
+    const Tap2D64* __restrict__ taps, int ntaps, int ax, int ay, double delta, int border)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const int fx = x + offX - ax, fy = y + offY - ay;              // full-image coordinates of tap (0,0)
+    double s = delta;
+    for (int t = 0; t < ntaps; t++) {
+        const Tap2D64 tp = taps[t];
+        const int yy = mi355_borderInterpolate(fy + tp.dy, fullH, border);
+        const int xx = mi355_borderInterpolate(fx + tp.dx, fullW, border);
+        double v = 0.0;
+        if (yy >= 0 && xx >= 0) v = ldD(src + (ptrdiff_t)(yy - offY) * (ptrdiff_t)sstep, (xx - offX) * cn + ch, sdepth);
+        s = __builtin_fma(tp.k, v, s);
+    }
+    reinterpret_cast<double*>(dst + (size_t)y * dstep)[e] = s;
+}
+
+struct SepParams64 { double kx[33], ky[33]; int nx, ny, ax, ay, symY; double delta; };
+
+__global__ __launch_bounds__(256) void k_sepfilter_generic64(
+    const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
+    int W, int H, int cn, int sdepth, int fullW, int fullH, int offX, int offY, int border, SepParams64 p)
+{
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (e >= W * cn || y >= H) return;
+    const int x = e / cn, ch = e - x * cn;
+    const int fx0 = x + offX - p.ax, fy0 = y + offY - p.ay;
+    int xs[33];
+    for (int i = 0; i < p.nx; i++) {
+        const int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
+        xs[i] = xx < 0 ? INT_MIN : (xx - offX) * cn + ch;
+    }
+    auto rowSum = [&](int j) -> double {
+        const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
+        const uchar* row = src + (ptrdiff_t)((yy < 0 ? offY : yy) - offY) * (ptrdiff_t)sstep;
+        double s = 0.0;
+        for (int i = 0; i < p.nx; i++) {
+            const double v = (yy < 0 || xs[i] == INT_MIN) ? 0.0 : ldD(row, xs[i], sdepth);
+            s = i == 0 ? p.kx[0] * v : __builtin_fma(p.kx[i], v, s);
+        }
+        return s;
+    };
+    double s;
+    if (p.symY) {
+        const int c = p.ay;
+        s = p.symY == 1 ? __builtin_fma(p.ky[c], rowSum(c), p.delta) : p.delta;
+        for (int k = 1; k <= p.ny / 2; k++) {
+            const double a = rowSum(c + k), b = rowSum(c - k);
+            s = __builtin_fma(p.ky[c + k], p.symY == 1 ? a + b : a - b, s);
+        }
+    } else {
+        s = __builtin_fma(p.ky[0], rowSum(0), p.delta);
+        for (int j = 1; j < p.ny; j++) s = __builtin_fma(p.ky[j], rowSum(j), s);
+    }
+    reinterpret_cast<double*>(dst + (size_t)y * dstep)[e] = s;
+}
+
 // ---------------------------------------------------------------------------------- box filter (row a5)
 // cv::boxFilter (box_filter.dispatch.cpp:440, createBoxFilter box_filter.simd.hpp:1250):
 //   8U->8U, area <= 256 : u16 sums; normalised result = ((s + dd) * ds) >> 23 with the reciprocal pair (ds, dd) of
@@ -502,7 +585,7 @@ __global__ __launch_bounds__(256) void k_box_generic(
 }
 
 // ---------------------------------------------------------------------------------- host: contexts
-int depthSize(int d) { return d == D8U ? 1 : (d == D16U || d == D16S) ? 2 : d == D32F ? 4 : 0; }
+int depthSize(int d) { return d == D8U ? 1 : (d == D16U || d == D16S) ? 2 : d == D32F ? 4 : d == D64F ? 8 : 0; }
 
 double kernelAt(const uchar* data, size_t step, int type, int r, int c)
 {
@@ -560,7 +643,17 @@ struct FilterCtx {
     float delta;
     std::vector<Tap2D> taps;
     SepParams sp;
+    bool wide = false;              // CV_64F destination: double kernels and sums (k_filter2d_generic64 / k_sepfilter_generic64)
+    double delta64 = 0;
+    std::vector<Tap2D64> taps64;
+    SepParams64 sp64;
 };
+
+// the CV_64F engines of the reference: filter2D from 8U / 16U / 16S / 64F (getLinearFilter, filter.simd.hpp:3230-3250), sepFilter2D also from 32F
+bool widePairOk(int sd, int dd, bool separable)
+{
+    return dd == D64F && (sd == D8U || sd == D16U || sd == D16S || sd == D64F || (separable && sd == D32F));
+}
 
 bool depthPairOk(int sd, int dd)
 {
@@ -577,7 +670,8 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
     c.kind = 2;
     c.sdepth = MI355CV_MAT_DEPTH(stype); c.ddepth = MI355CV_MAT_DEPTH(dtype);
     c.cn = MI355CV_MAT_CN(stype);
-    if (c.cn != MI355CV_MAT_CN(dtype) || !depthPairOk(c.sdepth, c.ddepth))
+    c.wide = c.cn == MI355CV_MAT_CN(dtype) && widePairOk(c.sdepth, c.ddepth, true);
+    if (c.cn != MI355CV_MAT_CN(dtype) || !(c.wide || depthPairOk(c.sdepth, c.ddepth)))
         return setError(MI355CV_NOT_IMPLEMENTED, "sepFilter: depth pair %d -> %d (channels %d -> %d) outside the GPU path", c.sdepth, c.ddepth, c.cn, MI355CV_MAT_CN(dtype));
     const int nx = (int)kx.size(), ny = (int)ky.size();
     if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33");
@@ -590,6 +684,16 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
     memset(&p, 0, sizeof p);
     p.nx = nx; p.ny = ny; p.ax = ax; p.ay = ay;
     const int rtype = kernelType(kx, ax), ctype = kernelType(ky, ay);
+    if (c.wide) {
+        SepParams64& q = c.sp64;
+        memset(&q, 0, sizeof q);
+        q.nx = nx; q.ny = ny; q.ax = ax; q.ay = ay; q.delta = delta;
+        for (int i = 0; i < nx; i++) q.kx[i] = kx[i];
+        for (int i = 0; i < ny; i++) q.ky[i] = ky[i];
+        q.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
+        if (!(ny & 1)) q.symY = 0;
+        return MI355CV_OK;
+    }
     p.mode = 0;
     if (c.sdepth == D8U &&
         ((rtype == K_SMOOTH + K_SYMMETRICAL && ctype == K_SMOOTH + K_SYMMETRICAL && c.ddepth == D8U) ||
@@ -630,6 +734,12 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     uchar* dd = stg.out(dst, dstep, (size_t)W * c.cn * de, H, &dds);
     if (!dtop || !dd) return mi355::declined(__func__, __LINE__, "!dtop || !dd");
     const uchar* ds = dtop + (size_t)offY * dss + (size_t)offX * c.cn * se;
+    if (c.wide) {
+        hipLaunchKernelGGL(k_sepfilter_generic64, dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth,
+                           fullW, fullH, offX, offY, c.border, c.sp64);
+        noteKernel("k_sepfilter_generic64 (depth %d -> CV_64F, %d x %d taps)", c.sdepth, c.sp64.nx, c.sp64.ny);
+        return stg.finish(entry);
+    }
     const SepParams& p = c.sp;
     // a submatrix with real pixels around it stays on the rolling kernels: they run on the parent's geometry and store the window (roll.h Win)
     const Roi roiv = {fullW, fullH, offX, offY};
@@ -663,6 +773,13 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
     if (disabled() || W <= 0 || H <= 0 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || nframes < 1");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (c.wide) {                                // CV_64F destinations: the generic double kernel, frame by frame
+        if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+        for (int f = 0; f < nframes; f++)
+            hipLaunchKernelGGL(k_sepfilter_generic64, dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep,
+                               W, H, c.cn, c.sdepth, W, H, 0, 0, c.border, c.sp64);
+        return stg.finish(entry);
+    }
     if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
     const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
     if (overlapOnDevice(src, (size_t)(nframes - 1) * sframe + (size_t)(H - 1) * sstep + (size_t)W * c.cn * se,
@@ -728,12 +845,13 @@ int derivRun(const char* entry, const uchar* src, size_t sstep, uchar* dst, size
     if (dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)) return mi355::declined(__func__, __LINE__, "dx < 0 || dy < 0 || (scharr ? dx + dy != 1 : dx + dy <= 0) || inPlaceOnDevice(src, dst)");
     std::vector<int> ix, iy;
     if (!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)) return mi355::declined(__func__, __LINE__, "!derivKernel(dx, ksize, scharr, ix) || !derivKernel(dy, ksize, scharr, iy)");
-    // ktype = max(CV_32F, ddepth, sdepth) = CV_32F for every depth handled here; `kx *= scale` is evaluated
-    // in double and stored back as float (deriv.cpp:432-439)
+    // ktype = max(CV_32F, ddepth, sdepth): `kx *= scale` is evaluated in double and stored back in the kernel's type (deriv.cpp:421, :432-439) -- float unless
+    // the source or the destination is CV_64F
+    const bool wideK = MI355CV_MAT_DEPTH(sdepth) == D64F || MI355CV_MAT_DEPTH(ddepth) == D64F;
     std::vector<double> kx(ix.begin(), ix.end()), ky(iy.begin(), iy.end());
     if (scale != 1) {
         std::vector<double>& tgt = dx == 0 ? kx : ky;
-        for (double& v : tgt) v = (double)(float)(v * scale);
+        for (double& v : tgt) v = wideK ? v * scale : (double)(float)(v * scale);
     }
     FilterCtx c;
     int rc = sepInit(c, MI355CV_MAKETYPE(sdepth, cn), MI355CV_MAKETYPE(ddepth, cn), kx, ky, -1, -1, delta, border);
@@ -767,7 +885,8 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
     c->kw = kernel_width; c->kh = kernel_height;
     c->ax = anchor_x < 0 ? kernel_width / 2 : anchor_x; c->ay = anchor_y < 0 ? kernel_height / 2 : anchor_y;
     c->delta = (float)delta;                                         // saturate_cast<float>(delta), filter.simd.hpp:3113
-    if (c->cn != MI355CV_MAT_CN(dst_type) || !depthPairOk(c->sdepth, c->ddepth) || c->border < 0 || c->border > B_REFLECT_101 ||
+    c->wide = widePairOk(c->sdepth, c->ddepth, false); c->delta64 = delta;
+    if (c->cn != MI355CV_MAT_CN(dst_type) || !(c->wide || depthPairOk(c->sdepth, c->ddepth)) || c->border < 0 || c->border > B_REFLECT_101 ||
         c->ax >= kernel_width || c->ay >= kernel_height) {
         const int sd = c->sdepth, dd = c->ddepth, bd = c->border; delete c;
         return setError(MI355CV_NOT_IMPLEMENTED, "filter2D: depth pair %d -> %d, border %d, anchor (%d, %d) in %d x %d outside the GPU path", sd, dd, bd, anchor_x, anchor_y, kernel_width, kernel_height);
@@ -779,6 +898,14 @@ MI355CV_API int mi355cv_filterInit(cvhalFilter2D** context, uchar* kernel_data, 
             c->taps.push_back({v, j, i});
         }
     if (c->taps.empty()) c->taps.push_back({0.f, 0, 0});              // nz == 0 -> one zero tap (:393-395)
+    if (c->wide) {                                                   // the kernel converted to CV_64F instead (kdepth = CV_64F, :3201-3205)
+        for (int i = 0; i < kernel_height; i++)
+            for (int j = 0; j < kernel_width; j++) {
+                const double v = kernelAt(kernel_data, kernel_step, kernel_type, i, j);
+                if (v != 0) c->taps64.push_back({v, j, i});
+            }
+        if (c->taps64.empty()) c->taps64.push_back({0.0, 0, 0});
+    }
     *context = reinterpret_cast<cvhalFilter2D*>(c);
     return MI355CV_OK;
 }
@@ -821,6 +948,7 @@ MI355CV_API int mi355cv_filterBatch(cvhalFilter2D* context, const uchar* src_dat
     mi355::EntryGuard entry_(__func__);
     FilterCtx* c = reinterpret_cast<FilterCtx*>(context);
     if (!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()) return mi355::declined(__func__, __LINE__, "!c || c->kind != 1 || width <= 0 || height <= 0 || nframes <= 0 || disabled()");
+    if (c->wide) return setError(MI355CV_NOT_IMPLEMENTED, "filterBatch: CV_64F destinations go frame by frame through mi355cv_filter");
     if (width > 0 && height > 0 && hostBatchEligible(src_data, dst_data, nframes)) {            // frames in host memory: chunks through two sets of device buffers
         const HostBatch hb = {src_data, src_step, src_frame_stride, (size_t)width * c->cn * depthBytes(c->sdepth), height, dst_data, dst_step, dst_frame_stride, (size_t)width * c->cn * depthBytes(c->ddepth), height, nframes};
         return runHostBatch("filterBatch", hb, [&](const uchar* s, size_t ss, size_t sf, uchar* d, size_t ds, size_t df, int nf) {
@@ -910,6 +1038,14 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     Tap2D* dt = (Tap2D*)stg.param(c->taps.data(), c->taps.size() * sizeof(Tap2D));
     if (!dtop || !dd || !dt) return mi355::declined(__func__, __LINE__, "!dtop || !dd || !dt");
     const uchar* ds = dtop + (size_t)offset_y * dss + (size_t)offset_x * c->cn * se;
+    if (c->wide) {
+        Tap2D64* dt64 = (Tap2D64*)stg.param(c->taps64.data(), c->taps64.size() * sizeof(Tap2D64));
+        if (!dt64) return mi355::declined(__func__, __LINE__, "!dt64");
+        hipLaunchKernelGGL(k_filter2d_generic64, dim3(divUp(width * c->cn, 64), divUp(height, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, width, height, c->cn, c->sdepth,
+                           full_width, full_height, offset_x, offset_y, dt64, (int)c->taps64.size(), c->ax, c->ay, c->delta64, c->border);
+        noteKernel("k_filter2d_generic64 (depth %d -> CV_64F, %zu taps)", c->sdepth, c->taps64.size());
+        return stg.finish("filter");
+    }
     if (full_width == width && full_height == height && tryFilterRoll(c, ds, dss, 0, dd, dds, 0, 1, width, height, stream()))
         return stg.finish("filter");
     dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));

@@ -193,10 +193,12 @@ int orc_Sobel(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int 
     double kx[34], ky[34];
     for (int i = 0; i < nx; i++) kx[i] = ix[i];
     for (int i = 0; i < ny; i++) ky[i] = iy[i];
-    if (scale != 1) {                           /* deriv.cpp:432-439: the smoothing kernel carries the scale, stored as float */
+    const int wide = sdepth == 6 || ddepth == 6;        /* ktype = max(CV_32F, max(ddepth, sdepth)), deriv.cpp:421: double kernels, double rows (filter64.c) */
+    if (scale != 1) {                           /* deriv.cpp:432-439: the smoothing kernel carries the scale, stored in the kernel type */
         double* t = dx == 0 ? kx : ky; int n = dx == 0 ? nx : ny;
-        for (int i = 0; i < n; i++) t[i] = (double)(float)(t[i] * scale);
+        for (int i = 0; i < n; i++) t[i] = wide ? t[i] * scale : (double)(float)(t[i] * scale);
     }
+    if (wide) return ddepth == 6 ? orc_sepFilter2D64(src, sstep, dst, dstep, w, h, cn, sdepth, fullW, fullH, offX, offY, kx, nx, ky, ny, -1, -1, delta, border) : 1;
     orc_sepFilter2D(src, sstep, dst, dstep, w, h, cn, sdepth, ddepth, fullW, fullH, offX, offY, kx, nx, ky, ny, -1, -1, delta, border);
     return 0;
 }

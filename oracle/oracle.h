@@ -154,6 +154,12 @@ int orc_matchTemplate(const uint8_t* img, size_t istep, int iw, int ih, const ui
 int orc_matchTemplateMask(const uint8_t* img, size_t istep, int iw, int ih, const uint8_t* tpl, size_t tstep, int tw, int th, int depth, int cn,
                           const uint8_t* mask, size_t mstep, int mdepth, int mcn, float* result, size_t rstep, int method);
 
+/* cv::filter2D / cv::sepFilter2D into CV_64F (double kernels, double rows), see oracle/filter64.c; sdepth 0 / 2 / 3 / 5 / 6 */
+int orc_filter2D64(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth,
+                   int fullW, int fullH, int offX, int offY, const double* kernel, int kw, int kh, int ax, int ay, double delta, int border);
+int orc_sepFilter2D64(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, int cn, int sdepth,
+                      int fullW, int fullH, int offX, int offY, const double* kx, int nx, const double* ky, int ny, int ax, int ay, double delta, int border);
+
 /* cv::integral, see oracle/integral.c: the reference's depth triples (sumpixels.dispatch.cpp:383-406), 1-4 channels, sq / tilted may be NULL; steps in bytes */
 int orc_integral(int depth, int sdepth, int sqdepth, const unsigned char* src, size_t sstep, unsigned char* sum, size_t sumstep,
                  unsigned char* sq, size_t sqstep, unsigned char* tilted, size_t tstep, int W, int H, int cn);

@@ -554,6 +554,12 @@ def orc_filter2D(src, ddepth, kernel, anchor=(-1, -1), delta=0.0, border=4, roi=
     if border & 16:
         fw, fh, ox, oy = v.shape[1], v.shape[0], 0, 0
     dst = _out(v, ddepth)
+    if dst.dtype == np.float64:                                                          # double kernel, double sums (oracle/filter64.c)
+        k = np.ascontiguousarray(kernel, np.float64)
+        rc = o.orc_filter2D64(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], fw, fh, ox, oy, P(k), k.shape[1], k.shape[0],
+                              anchor[0], anchor[1], c_dbl(delta), border & ~16)
+        assert rc == 0, rc
+        return dst
     k = np.ascontiguousarray(kernel, np.float32)
     o.orc_filter2D(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
                    fw, fh, ox, oy, P(k), k.shape[1], k.shape[0], anchor[0], anchor[1], c_dbl(delta), border & ~16)
@@ -568,6 +574,11 @@ def orc_sepFilter2D(src, ddepth, kx, ky, anchor=(-1, -1), delta=0.0, border=4, r
     dst = _out(v, ddepth)
     kx = np.ascontiguousarray(np.asarray(kx).ravel(), np.float64)
     ky = np.ascontiguousarray(np.asarray(ky).ravel(), np.float64)
+    if dst.dtype == np.float64:
+        rc = o.orc_sepFilter2D64(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], fw, fh, ox, oy, P(kx), len(kx), P(ky), len(ky),
+                                 anchor[0], anchor[1], c_dbl(delta), border & ~16)
+        assert rc == 0, rc
+        return dst
     o.orc_sepFilter2D(P(v), step(v), P(dst), step(dst), v.shape[1], v.shape[0], cn_of(v), _NP_DEPTH[v.dtype], _NP_DEPTH[dst.dtype],
                       fw, fh, ox, oy, P(kx), len(kx), P(ky), len(ky), anchor[0], anchor[1], c_dbl(delta), border & ~16)
     return dst

@@ -512,3 +512,38 @@ def test_large_filter2d_opt_in(orc):
             d8, d32 = float(lines[0][5]), float(lines[1][5])
             assert d8 <= 1.0 and d32 <= 1e-5, p.stdout                       # (-1: the reference did not travel with the tree)
 
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
+def test_filters_into_64f(cv, orc, dtype):
+    """filter2D / sepFilter2D / Sobel / Scharr with a CV_64F destination (the reference's Imgproc_FilterSupportedFormats pairs 8U / 16U / 16S / 64F -> 64F, 5 channels):
+    double kernels, double rows, every multiply-add fused like the reference's AVX2 + FMA copy -- bit for bit against oracle/filter64.c (tests/test_oracle_filter64.py:
+    == the reference).  CV_32F -> CV_64F exists for the separable engine only (getLinearFilter has no such pair): filter2D declines it."""
+    from test_oracle_filter64 import source, bits
+    rng = np.random.default_rng(4)
+    kx, ky = rng.uniform(-1, 1, 11).astype(np.float32), rng.uniform(-1, 1, 7).astype(np.float32)
+    for cn in (1, 3, 5):
+        src = source((31, 47, cn) if cn > 1 else (31, 47), dtype, 7 + cn)
+        d = torch.from_numpy(src).cuda()
+        for k in (rng.uniform(-10, 10, (5, 5)).astype(np.float32), rng.uniform(-1, 1, (3, 7)).astype(np.float32), rng.uniform(-1, 1, (4, 2))):
+            for border, delta, anchor in ((4, 0.0, (-1, -1)), (0, 0.5, (-1, -1)), (1, -3.25, (0, 1)), (2, 0.0, (-1, -1))):
+                if dtype == np.float32:
+                    with pytest.raises(NotImplementedError):
+                        cv.filter2D(d, 6, k, anchor, delta, border)
+                    continue
+                got = cv.filter2D(d, 6, k, anchor, delta, border).cpu().numpy()
+                assert got.dtype == np.float64 and np.array_equal(bits(got), bits(orc.orc_filter2D(src, 6, k, anchor, delta, border))), (cn, k.shape, border)
+        for (a, b) in ((kx, ky), (kx + kx[::-1], ky + ky[::-1]), (kx - kx[::-1], ky - ky[::-1]), (kx[:4], ky[:2])):
+            for border, delta in ((4, 0.0), (0, 1.5), (1, 0.0), (2, -0.75)):
+                got = cv.sepFilter2D(d, 6, a, b, (-1, -1), delta, border).cpu().numpy()
+                assert np.array_equal(bits(got), bits(orc.orc_sepFilter2D(src, 6, a, b, (-1, -1), delta, border))), (cn, len(a), border)
+        for (dx, dy, ks, scale) in ((1, 0, 3, 1.0), (2, 0, 5, 1.0), (1, 1, 5, 0.37), (0, 2, 7, 1.0)):
+            got = cv.Sobel(d, 6, dx, dy, ks, scale, 0.25, 4).cpu().numpy()
+            assert np.array_equal(bits(got), bits(orc.orc_Sobel(src, 6, dx, dy, ks, scale, 0.25, 4))), (cn, dx, dy, ks)
+        for (dx, dy, scale) in ((0, 1, 1.0), (1, 0, 2.5)):
+            got = cv.Scharr(d, 6, dx, dy, scale, 0.25, 4).cpu().numpy()
+            assert np.array_equal(bits(got), bits(orc.orc_Sobel(src, 6, dx, dy, -1, scale, 0.25, 4))), (cn, dx, dy)
+    if dtype != np.float32:
+        from opencv_amd import _lib
+        cv.filter2D(torch.from_numpy(source((31, 47), dtype, 3)).cuda(), 6, np.ones((3, 3), np.float32))
+        assert "k_filter2d_generic64" in _lib.lib.mi355cv_lastKernel().decode()
