@@ -20,13 +20,13 @@ using namespace mi355;
 
 namespace {
 
-enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F };
+enum { D8U = MI355CV_8U, D16U = MI355CV_16U, D16S = MI355CV_16S, D32F = MI355CV_32F, D64F = MI355CV_64F };
 
 struct MorphTap { short dx, dy; };
 struct MorphCtx {
     int magic, op, depth, cn, kw, kh, ax, ay, border, iterations;
     bool rect, defaultBorder;
-    float bv[4];                      // border value per channel, already saturated to the depth
+    double bv[4];                     // border value per channel, already saturated to the depth
     std::vector<MorphTap> taps;
 };
 constexpr int MORPH_MAGIC = 0x4d525048;
@@ -34,7 +34,7 @@ constexpr int MORPH_MAGIC = 0x4d525048;
 template <typename T>
 __global__ __launch_bounds__(256) void k_morph_generic(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
                                                        int W, int H, int cn, int fullW, int fullH, int offX, int offY, const MorphTap* __restrict__ taps, int ntaps,
-                                                       int ax, int ay, int erode, int border, float b0, float b1, float b2, float b3)
+                                                       int ax, int ay, int erode, int border, double b0, double b1, double b2, double b3)
 {
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -51,13 +51,14 @@ __global__ __launch_bounds__(256) void k_morph_generic(const uchar* __restrict__
     reinterpret_cast<T*>(dst + (size_t)y * dstep)[e] = r;
 }
 
-float satBorder(double v, int depth)
+double satBorder(double v, int depth)
 {
     switch (depth) {
-    case D8U:  v = std::nearbyint(v); return (float)(v < 0 ? 0 : v > 255 ? 255 : v);
-    case D16U: v = std::nearbyint(v); return (float)(v < 0 ? 0 : v > 65535 ? 65535 : v);
-    case D16S: v = std::nearbyint(v); return (float)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
-    default:   return (float)v;
+    case D8U:  v = std::nearbyint(v); return v < 0 ? 0 : v > 255 ? 255 : v;
+    case D16U: v = std::nearbyint(v); return v < 0 ? 0 : v > 65535 ? 65535 : v;
+    case D16S: v = std::nearbyint(v); return v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    case D64F: return v;
+    default:   return (double)(float)v;
     }
 }
 
@@ -78,7 +79,7 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
     (void)allowInplace;
     if (iterations < 1 || iterations > 64 || src_type != dst_type) return mi355::declined(__func__, __LINE__, "iterations < 1 || iterations > 64 || src_type != dst_type");
     const int depth = MI355CV_MAT_DEPTH(src_type), cn = MI355CV_MAT_CN(src_type);
-    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 512) return mi355::declined(__func__, __LINE__, "(depth != D8U && depth != D16U && depth != D16S && depth != D32F) || cn < 1 || cn > 512");
+    if ((depth != D8U && depth != D16U && depth != D16S && depth != D32F && depth != D64F) || cn < 1 || cn > 512) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F / 64F || cn < 1 || cn > 512");
     if (!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1) return mi355::declined(__func__, __LINE__, "!kernel_data || MI355CV_MAT_DEPTH(kernel_type) != D8U || MI355CV_MAT_CN(kernel_type) != 1");
     if (kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024) return mi355::declined(__func__, __LINE__, "kernel_width < 1 || kernel_height < 1 || kernel_width * kernel_height > 1024");
     const int border = borderType & ~MI355CV_BORDER_ISOLATED;
@@ -97,8 +98,8 @@ MI355CV_API int mi355cv_morphInit(cvhalFilter2D** context, int operation, int sr
     c->defaultBorder = !borderValue || (borderValue[0] == DBL_MAX && borderValue[1] == DBL_MAX && borderValue[2] == DBL_MAX && borderValue[3] == DBL_MAX);
     for (int k = 0; k < 4; k++) {
         if (c->defaultBorder)
-            c->bv[k] = operation == 0 ? (depth == D8U ? 255.f : depth == D16U ? 65535.f : depth == D16S ? 32767.f : FLT_MAX)
-                                      : (depth == D8U || depth == D16U ? 0.f : depth == D16S ? -32768.f : -FLT_MAX);
+            c->bv[k] = operation == 0 ? (depth == D8U ? 255.0 : depth == D16U ? 65535.0 : depth == D16S ? 32767.0 : depth == D64F ? DBL_MAX : (double)FLT_MAX)
+                                      : (depth == D8U || depth == D16U ? 0.0 : depth == D16S ? -32768.0 : depth == D64F ? -DBL_MAX : (double)-FLT_MAX);
         else c->bv[k] = satBorder(borderValue[k], depth);
     }
     // more than 4 channels: the reference unrolls the border Scalar over the border ELEMENTS with period 4 (FilterEngine::init, filter.dispatch.cpp:150-160), a per-channel
@@ -123,7 +124,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
-    const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : 2;
+    const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : c->depth == D64F ? 8 : 2;
     const bool inplaceDev = inPlaceOnDevice(src_data, dst_data);
     size_t dss, dds;
     const uchar* top = src_data - (ptrdiff_t)src_roi_y * (ptrdiff_t)src_step - (ptrdiff_t)src_roi_x * c->cn * e;
@@ -152,7 +153,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
         dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
 #define MORPH_GEN(T) hipLaunchKernelGGL(k_morph_generic<T>, grid, dim3(256), 0, st, ps, pss, pd, pds, width, height, c->cn, fullW, fullH, \
         offX, offY, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
-        switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; default: MORPH_GEN(float); }
+        switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; case D64F: MORPH_GEN(double); break; default: MORPH_GEN(float); }
 #undef MORPH_GEN
         return true;
     };

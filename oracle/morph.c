@@ -11,12 +11,12 @@
 
 static double ldv(const uint8_t* p, int depth, int idx)
 {
-    switch (depth) { case 0: return p[idx]; case 2: return ((const uint16_t*)p)[idx]; case 3: return ((const int16_t*)p)[idx]; default: return ((const float*)p)[idx]; }
+    switch (depth) { case 0: return p[idx]; case 2: return ((const uint16_t*)p)[idx]; case 3: return ((const int16_t*)p)[idx]; case 6: return ((const double*)p)[idx]; default: return ((const float*)p)[idx]; }
 }
 static void stv(uint8_t* p, int depth, int idx, double v)
 {
     switch (depth) { case 0: p[idx] = (uint8_t)v; break; case 2: ((uint16_t*)p)[idx] = (uint16_t)v; break; case 3: ((int16_t*)p)[idx] = (int16_t)v; break;
-                     default: ((float*)p)[idx] = (float)v; }
+                     case 6: ((double*)p)[idx] = v; break; default: ((float*)p)[idx] = (float)v; }
 }
 static double satv(double v, int depth)       /* saturate_cast<T>(borderValue) as FilterEngine::init does (filter.dispatch.cpp:150-160) */
 {
@@ -24,6 +24,7 @@ static double satv(double v, int depth)       /* saturate_cast<T>(borderValue) a
     case 0: v = rint(v); return v < 0 ? 0 : v > 255 ? 255 : v;
     case 2: v = rint(v); return v < 0 ? 0 : v > 65535 ? 65535 : v;
     case 3: v = rint(v); return v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    case 6: return v;
     default: return (double)(float)v;
     }
 }
@@ -32,12 +33,12 @@ int orc_morph(int op /*0 erode, 1 dilate*/, const uint8_t* src, size_t sstep, ui
               int fullW, int fullH, int offX, int offY, const uint8_t* kernel, size_t kstep, int kw, int kh, int ax, int ay,
               int border, const double* borderValue)
 {
-    if ((op != 0 && op != 1) || (depth != 0 && depth != 2 && depth != 3 && depth != 5) || ax < 0 || ay < 0 || ax >= kw || ay >= kh) return 1;
+    if ((op != 0 && op != 1) || (depth != 0 && depth != 2 && depth != 3 && depth != 5 && depth != 6) || ax < 0 || ay < 0 || ax >= kw || ay >= kh) return 1;
     double bv[4];
     for (int c = 0; c < 4; c++) {
         if (borderValue && borderValue[0] == DBL_MAX && borderValue[1] == DBL_MAX && borderValue[2] == DBL_MAX && borderValue[3] == DBL_MAX)
-            bv[c] = op == 0 ? (depth == 0 ? 255.0 : depth == 2 ? 65535.0 : depth == 3 ? 32767.0 : (double)FLT_MAX)
-                            : (depth == 0 || depth == 2 ? 0.0 : depth == 3 ? -32768.0 : (double)-FLT_MAX);
+            bv[c] = op == 0 ? (depth == 0 ? 255.0 : depth == 2 ? 65535.0 : depth == 3 ? 32767.0 : depth == 6 ? DBL_MAX : (double)FLT_MAX)
+                            : (depth == 0 || depth == 2 ? 0.0 : depth == 3 ? -32768.0 : depth == 6 ? -DBL_MAX : (double)-FLT_MAX);
         else bv[c] = satv(borderValue ? borderValue[c] : 0.0, depth);
     }
     /* more than 4 channels: FilterEngine::init unrolls the Scalar over the border ELEMENTS with period 4 (srcType1 = MIN(cn, 4) channels, filter.dispatch.cpp:150-160), which

@@ -21,7 +21,7 @@ def dev(a):
     return torch.from_numpy(a).cuda()
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
 def test_morph_generic(cv, orc, dtype):
     n0 = cv.call_count("morph")
     for shape in [(23, 40), (17, 29, 3), (1, 9), (6, 1, 4)]:

@@ -14,14 +14,14 @@ KERNELS = [(None, (-1, -1)), (np.ones((3, 3), np.uint8), (-1, -1)), (np.ones((5,
 
 def _src(dtype, shape, seed):
     rng = np.random.default_rng(seed)
-    if dtype == np.float32:
-        return (rng.random(shape, dtype=np.float32) * 4 - 2).astype(np.float32)
+    if dtype in (np.float32, np.float64):
+        return (rng.random(shape) * 4 - 2).astype(dtype)
     info = np.iinfo(dtype)
     return rng.integers(info.min, int(info.max) + 1, shape, dtype=dtype)
 
 
 @pytest.mark.ref
-@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
 def test_morph_matches_reference(ref, dtype):
     for shape in [(23, 40), (17, 29, 3), (1, 9), (6, 1, 4)]:
         src = _src(dtype, shape, 5 + len(shape))
