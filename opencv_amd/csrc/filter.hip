@@ -542,11 +542,12 @@ __global__ __launch_bounds__(256) void k_box_generic(
             double rs = 0.0;
             for (int i = 0; i < p.kw; i++) {
                 const int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
-                if (xx >= 0) rs += (double)reinterpret_cast<const float*>(row)[(xx - offX) * cn + ch];
+                if (xx >= 0) rs += sdepth == D64F ? reinterpret_cast<const double*>(row)[(xx - offX) * cn + ch] : (double)reinterpret_cast<const float*>(row)[(xx - offX) * cn + ch];
             }
             s += rs;
         }
-        reinterpret_cast<float*>(drow)[e] = (float)(p.normalize ? s * p.scaleD : s);
+        if (ddepth == D64F) reinterpret_cast<double*>(drow)[e] = p.normalize ? s * p.scaleD : s;
+        else reinterpret_cast<float*>(drow)[e] = (float)(p.normalize ? s * p.scaleD : s);
         return;
     }
     int s = 0;
@@ -565,6 +566,10 @@ __global__ __launch_bounds__(256) void k_box_generic(
     if (p.mode == 0) {
         unsigned r = p.normalize ? (((unsigned)s + (unsigned)p.divDelta) * (unsigned)p.divScale) >> 23 : (unsigned)s;
         drow[e] = (uchar)(p.normalize ? r : (r > 255u ? 255u : r));
+        return;
+    }
+    if (ddepth == D64F) {           // ColumnSum<int, double> (box_filter.simd.hpp:1195-1240): the exact int sum, one multiply in double
+        reinterpret_cast<double*>(drow)[e] = p.normalize ? (double)s * p.scaleD : (double)s;
         return;
     }
     if (ddepth == D32F) {
@@ -1190,7 +1195,8 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     const bool okDepth = (src_depth == D8U && (dst_depth == D8U || dst_depth == D16U || dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D16U && (dst_depth == D8U || dst_depth == D16U || dst_depth == D16S || dst_depth == D32F)) ||
                          (src_depth == D16S && (dst_depth == D16S || dst_depth == D32F)) ||
-                         (src_depth == D32F && dst_depth == D32F);
+                         (src_depth == D32F && (dst_depth == D32F || dst_depth == D64F)) || (src_depth == D64F && dst_depth == D64F) ||
+                         ((src_depth == D8U || src_depth == D16U || src_depth == D16S) && dst_depth == D64F);
     if (!okDepth) return setError(MI355CV_NOT_IMPLEMENTED, "boxFilter: depth pair %d -> %d outside the GPU path", src_depth, dst_depth);
     BoxParams p; memset(&p, 0, sizeof p);
     p.kw = kw; p.kh = kh;
@@ -1201,7 +1207,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     const double scale = 1.0 / area;
     p.scaleD = scale; p.scaleF = (float)scale;
     if (normalize && area == 1) p.normalize = 0;                       // scale == 1: the reference skips the multiply
-    if (src_depth == D32F) p.mode = 2;
+    if (src_depth == D32F || src_depth == D64F) p.mode = 2;
     else if (src_depth == D8U && dst_depth == D8U && area <= 256) {
         p.mode = 0;
         // ColumnSum<ushort,uchar> constructor (box_filter.simd.hpp:441-455)

@@ -211,7 +211,7 @@ int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
     const int area = kw * kh;
     const double scale = 1.0 / area;
     int mode, divScale = 1, divDelta = 0;
-    if (sdepth == 5) mode = 2;
+    if (sdepth == 5 || sdepth == 6) mode = 2;          /* float / double sources: double sums (RowSum<float|double, double>, ColumnSum<double, T>) */
     else if (sdepth == 0 && ddepth == 0 && area <= 256) {
         mode = 0;
         int d = (int)rint(1.0 / scale);
@@ -235,14 +235,17 @@ int orc_boxFilter(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, 
                         int xx = orc_borderInterpolate(x + offX + i - ax, fullW, border);
                         if (xx < 0) continue;
                         int idx = (xx - offX) * cn + c;
-                        if (mode == 2) rsd += (double)((const float*)row)[idx];
+                        if (mode == 2) rsd += sdepth == 6 ? ((const double*)row)[idx] : (double)((const float*)row)[idx];
                         else si += sdepth == 0 ? row[idx] : sdepth == 2 ? ((const uint16_t*)row)[idx] : ((const int16_t*)row)[idx];
                     }
                     sd += rsd;
                 }
                 uint8_t* drow = dst + (size_t)y * dstep;
                 const int e = x * cn + c;
-                if (mode == 2) ((float*)drow)[e] = (float)(normalize ? sd * scale : sd);
+                if (mode == 2 && ddepth == 6) ((double*)drow)[e] = normalize ? sd * scale : sd;      /* (the reference's running sums round differently in the last bits) */
+                else if (mode == 2) ((float*)drow)[e] = (float)(normalize ? sd * scale : sd);
+                else if (mode == 1 && ddepth == 6)      /* ColumnSum<int, double>: the exact int sum, one multiply in double (box_filter.simd.hpp:1195-1240) */
+                    ((double*)drow)[e] = normalize ? (double)si * scale : (double)si;
                 else if (mode == 0) {
                     unsigned r = normalize ? (((unsigned)si + (unsigned)divDelta) * (unsigned)divScale) >> 23 : (unsigned)si;
                     drow[e] = (uint8_t)(normalize ? r : (r > 255 ? 255 : r));

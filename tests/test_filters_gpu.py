@@ -547,3 +547,22 @@ def test_filters_into_64f(cv, orc, dtype):
         from opencv_amd import _lib
         cv.filter2D(torch.from_numpy(source((31, 47), dtype, 3)).cuda(), 6, np.ones((3, 3), np.float32))
         assert "k_filter2d_generic64" in _lib.lib.mi355cv_lastKernel().decode()
+
+
+def test_boxfilter_into_64f(cv, orc):
+    """boxFilter / blur with a CV_64F destination: exact for integer sources (int sum, one double multiply), 1e-13 relative for float / double sources (double sums)"""
+    rng = np.random.default_rng(1)
+    for dtype, dd in [(np.uint8, 6), (np.uint16, 6), (np.int16, 6), (np.float32, 6), (np.float64, 6), (np.float64, -1)]:
+        for cn in (1, 3, 5):
+            src = (rng.random((31, 47, cn)) * 200 - 50).astype(dtype) if dtype in (np.float32, np.float64) else rng.integers(0, 200, (31, 47, cn)).astype(dtype)
+            for ks in ((3, 3), (11, 11), (4, 7)):
+                for norm in (True, False):
+                    for border in (0, 1, 4):
+                        got = cv.boxFilter(torch.from_numpy(src).cuda(), dd, ks, (-1, -1), norm, border).cpu().numpy()
+                        want = orc.orc_boxFilter(src, dd, ks, normalize=norm, border=border)
+                        assert got.dtype == np.float64
+                        if dtype in (np.float32, np.float64):
+                            assert np.abs(got - want).max() <= 1e-13 * max(1.0, np.abs(want).max()), (dtype, cn, ks, norm, border)
+                        else:
+                            assert np.array_equal(got, want), (dtype, cn, ks, norm, border)
+

@@ -117,3 +117,22 @@ def test_boxfilter_more_than_four_channels(orc, ref):
                             assert orc.rel_err(got, want) <= 2e-7, (dtype, cn, ksize, normalize, border)
                         else:
                             assert np.array_equal(got, want), (dtype, cn, ksize, normalize, border)
+
+
+def test_boxfilter_into_64f(orc, ref):
+    """CV_64F destinations: integer sources are the exact int sum times 1 / area in double (ColumnSum<int, double>) -- bit for bit; float / double sources are summed
+    in double, where the reference's running row / column sums differ from a direct window sum in the last bits (1e-13 relative)"""
+    rng = np.random.default_rng(1)
+    for dtype, dd in [(np.uint8, 6), (np.uint16, 6), (np.int16, 6), (np.float32, 6), (np.float64, 6), (np.float64, -1)]:
+        for cn in (1, 3, 5):
+            src = (rng.random((31, 47, cn)) * 200 - 50).astype(dtype) if dtype in (np.float32, np.float64) else rng.integers(0, 200, (31, 47, cn)).astype(dtype)
+            for ks in ((3, 3), (11, 11), (4, 7)):
+                for norm in (True, False):
+                    for border in (0, 1, 4):
+                        a = orc.orc_boxFilter(src, dd, ks, normalize=norm, border=border)
+                        b = orc.ref_boxFilter(src, dd, ks, normalize=norm, border=border)
+                        assert a.dtype == b.dtype == np.float64
+                        if dtype in (np.float32, np.float64):
+                            assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max()), (dtype, cn, ks, norm, border)
+                        else:
+                            assert np.array_equal(a, b), (dtype, cn, ks, norm, border)
