@@ -346,26 +346,29 @@ __global__ __launch_bounds__(256) void k_gray_filter2d_roll(const uchar* __restr
 }
 
 // ---------------------------------------------------------------------------------- separable
-struct SepParams {
-    float kxf[33], kyf[33];
-    int   kxi[33], kyi[33];
+template <int MAXK> struct SepParamsT {
+    float kxf[MAXK], kyf[MAXK];
+    int   kxi[MAXK], kyi[MAXK];
     int nx, ny, ax, ay;
     int mode;        // 0 float, 1 int Q8 x Q8 (8U->8U), 2 int exact (8U->16S)
     int symY;        // 1 symmetrical pair form, 2 anti-symmetrical pair form, 0 plain chain
     float deltaF;
     int deltaI;
 };
+typedef SepParamsT<33> SepParams;            // what every kernel up to 33 taps per axis uses
+typedef SepParamsT<129> SepParamsL;          // up to 129 taps (a Gaussian of sigma 16 on CV_32F): the same kernel with longer per-thread tables
 
+template <int MAXK>
 __global__ __launch_bounds__(256) void k_sepfilter_generic(
     const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep,
-    int W, int H, int cn, int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border, SepParams p)
+    int W, int H, int cn, int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border, SepParamsT<MAXK> p)
 {
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (e >= W * cn || y >= H) return;
     const int x = e / cn, ch = e - x * cn;
     const int fx0 = x + offX - p.ax, fy0 = y + offY - p.ay;
-    int xs[33];
+    int xs[MAXK];
     for (int i = 0; i < p.nx; i++) {
         int xx = mi355_borderInterpolate(fx0 + i, fullW, border);
         xs[i] = xx < 0 ? INT_MIN : (xx - offX) * cn + ch;      // offsets are relative to the ROI: negative ones are real pixels of the parent
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void k_sepfilter_generic(
     if (p.mode != 0) {
         // integer modes: order of summation is irrelevant
         long long acc = p.deltaI;
-        int ri[33];
+        int ri[MAXK];
         for (int j = 0; j < p.ny; j++) {
             const int yy = mi355_borderInterpolate(fy0 + j, fullH, border);
             ri[j] = 0;
@@ -648,6 +651,11 @@ struct FilterCtx {
     float delta;
     std::vector<Tap2D> taps;
     SepParams sp;
+    SepParamsL* big = nullptr;      // separable kernels of 34 .. 129 taps per axis: their own parameter block (k_sepfilter_generic<129>)
+    FilterCtx() = default;
+    FilterCtx(const FilterCtx&) = delete;
+    FilterCtx& operator=(const FilterCtx&) = delete;
+    ~FilterCtx() { delete big; }
     bool wide = false;              // CV_64F destination: double kernels and sums (k_filter2d_generic64 / k_sepfilter_generic64)
     double delta64 = 0;
     std::vector<Tap2D64> taps64;
@@ -679,7 +687,8 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
     if (c.cn != MI355CV_MAT_CN(dtype) || !(c.wide || depthPairOk(c.sdepth, c.ddepth)))
         return setError(MI355CV_NOT_IMPLEMENTED, "sepFilter: depth pair %d -> %d (channels %d -> %d) outside the GPU path", c.sdepth, c.ddepth, c.cn, MI355CV_MAT_CN(dtype));
     const int nx = (int)kx.size(), ny = (int)ky.size();
-    if (nx < 1 || ny < 1 || nx > 33 || ny > 33) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33");
+    const bool large = nx > 33 || ny > 33;
+    if (nx < 1 || ny < 1 || nx > 129 || ny > 129 || (large && c.wide)) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 129 || ny > 129 (33 into CV_64F)");
     if (ax < 0) ax = nx / 2;
     if (ay < 0) ay = ny / 2;
     if (ax >= nx || ay >= ny) return mi355::declined(__func__, __LINE__, "ax >= nx || ay >= ny");
@@ -695,6 +704,33 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
         q.nx = nx; q.ny = ny; q.ax = ax; q.ay = ay; q.delta = delta;
         for (int i = 0; i < nx; i++) q.kx[i] = kx[i];
         for (int i = 0; i < ny; i++) q.ky[i] = ky[i];
+        q.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
+        if (!(ny & 1)) q.symY = 0;
+        return MI355CV_OK;
+    }
+    if (large) {
+        // the same set-up into the long parameter block; the rolling kernels (<= 9 taps) never apply
+        delete c.big; c.big = new (std::nothrow) SepParamsL();
+        if (!c.big) return mi355::declined(__func__, __LINE__, "!c.big");
+        SepParamsL& q = *c.big;
+        memset(&q, 0, sizeof q);
+        q.nx = nx; q.ny = ny; q.ax = ax; q.ay = ay;
+        if (c.sdepth == D8U &&
+            ((rtype == K_SMOOTH + K_SYMMETRICAL && ctype == K_SMOOTH + K_SYMMETRICAL && c.ddepth == D8U) ||
+             ((rtype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (ctype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (rtype & ctype & K_INTEGER) && c.ddepth == D16S))) {
+            const int bits = c.ddepth == D8U ? 8 : 0;
+            std::vector<int> qx, qy;
+            if (bitExactKernel(kx, bits, qx) && bitExactKernel(ky, bits, qy)) {
+                q.mode = bits ? 1 : 2;
+                for (int i = 0; i < nx; i++) q.kxi[i] = qx[i];
+                for (int i = 0; i < ny; i++) q.kyi[i] = qy[i];
+                const double d = delta * (double)(1 << (2 * bits));
+                q.deltaI = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (int)-2147483648LL : (int)nearbyint(d);
+            }
+        }
+        for (int i = 0; i < nx; i++) q.kxf[i] = (float)kx[i];
+        for (int i = 0; i < ny; i++) q.kyf[i] = (float)ky[i];
+        q.deltaF = (float)delta;
         q.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
         if (!(ny & 1)) q.symY = 0;
         return MI355CV_OK;
@@ -745,6 +781,12 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
         noteKernel("k_sepfilter_generic64 (depth %d -> CV_64F, %d x %d taps)", c.sdepth, c.sp64.nx, c.sp64.ny);
         return stg.finish(entry);
     }
+    if (c.big) {
+        hipLaunchKernelGGL((k_sepfilter_generic<129>), dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
+                           fullW, fullH, offX, offY, c.border, *c.big);
+        noteKernel("k_sepfilter_generic<129> (%d x %d taps)", c.big->nx, c.big->ny);
+        return stg.finish(entry);
+    }
     const SepParams& p = c.sp;
     // a submatrix with real pixels around it stays on the rolling kernels: they run on the parent's geometry and store the window (roll.h Win)
     const Roi roiv = {fullW, fullH, offX, offY};
@@ -766,7 +808,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
         seprollF16(ds, dss, 0, dd, dds, 0, 1, W, H, c.sdepth == D16S, c.ddepth == D32F, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream(), roi))
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
-    hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
+    hipLaunchKernelGGL((k_sepfilter_generic<33>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
                        fullW, fullH, offX, offY, c.border, c.sp);
     return stg.finish(entry);
 }
@@ -778,6 +820,13 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
     if (disabled() || W <= 0 || H <= 0 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || nframes < 1");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
+    if (c.big) {                                 // 34 .. 129 taps: the generic kernel with the long parameter block, frame by frame
+        if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+        for (int f = 0; f < nframes; f++)
+            hipLaunchKernelGGL((k_sepfilter_generic<129>), dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep,
+                               W, H, c.cn, c.sdepth, c.ddepth, W, H, 0, 0, c.border, *c.big);
+        return stg.finish(entry);
+    }
     if (c.wide) {                                // CV_64F destinations: the generic double kernel, frame by frame
         if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
         for (int f = 0; f < nframes; f++)
@@ -810,7 +859,7 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
         return stg.finish(entry);
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     for (int f = 0; f < nframes; f++)
-        hipLaunchKernelGGL(k_sepfilter_generic, grid, dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep, W, H, c.cn, c.sdepth, c.ddepth,
+        hipLaunchKernelGGL((k_sepfilter_generic<33>), grid, dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep, W, H, c.cn, c.sdepth, c.ddepth,
                            W, H, 0, 0, c.border, c.sp);
     return stg.finish(entry);
 }

@@ -83,7 +83,7 @@ void orc_sepFilter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dste
     if (ax < 0) ax = nx / 2;
     if (ay < 0) ay = ny / 2;
     const int rtype = kernel_type(kx, nx, ax), ctype = kernel_type(ky, ny, ay);
-    int mode = 0, qx[64], qy[64], deltaI = 0;
+    int mode = 0, qx[256], qy[256], deltaI = 0;
     if (sdepth == 0 && ((rtype == KT_SMOOTH + KT_SYM && ctype == KT_SMOOTH + KT_SYM && ddepth == 0) ||
                         ((rtype & (KT_SYM + KT_ASYM)) && (ctype & (KT_SYM + KT_ASYM)) && (rtype & ctype & KT_INT) && ddepth == 3))) {
         int bits = ddepth == 0 ? 8 : 0;
@@ -102,7 +102,7 @@ void orc_sepFilter2D(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dste
                 uint8_t* drow = dst + (size_t)y * dstep;
                 const int e = x * cn + c;
                 if (mode) {
-                    int acc = deltaI, ri[64];
+                    int acc = deltaI, ri[256];
                     for (int j = 0; j < ny; j++) {
                         int yy = orc_borderInterpolate(y + offY + j - ay, fullH, border);
                         ri[j] = 0;

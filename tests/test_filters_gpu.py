@@ -566,3 +566,27 @@ def test_boxfilter_into_64f(cv, orc):
                         else:
                             assert np.array_equal(got, want), (dtype, cn, ks, norm, border)
 
+
+
+def test_sepfilter_long_kernels(cv, orc):
+    """separable kernels of 34-129 taps per axis (Imgproc_GaussianBlur.regression_11303: a 71-tap Gaussian on CV_32F) on the generic kernel's long parameter block"""
+    rng = np.random.default_rng(9)
+    g71 = np.exp(-0.5 * ((np.arange(71) - 35) / 8.64421) ** 2); g71 = (g71 / g71.sum()).astype(np.float32)
+    g41 = np.exp(-0.5 * ((np.arange(41) - 20) / 6.5) ** 2); g41 = (g41 / g41.sum()).astype(np.float32)
+    kx, ky = rng.uniform(-1, 1, 41).astype(np.float32) / 8, rng.uniform(-1, 1, 37).astype(np.float32) / 8
+    for dtype, ddepth in [(np.float32, -1), (np.uint8, -1), (np.uint8, 5), (np.uint16, 5), (np.int16, -1)]:
+        for cn in (1, 3):
+            src = rnd((53, 90, cn) if cn > 1 else (53, 90), dtype, 60 + cn)
+            for (a, b) in ((g71, g71), (g41, g71), (kx, ky), (g41, ky[:5])):
+                for border in (4, 0, 1):
+                    check(cv.sepFilter2D(dev(src), ddepth, a, b, (-1, -1), 0.0, border), orc.orc_sepFilter2D(src, ddepth, a, b, (-1, -1), 0.0, border), tol=1e-6)
+    from opencv_amd import _lib
+    assert "k_sepfilter_generic<129>" in _lib.lib.mi355cv_lastKernel().decode()
+    big = rnd((211, 2115), np.float32, 3)                                              # the reference test's geometry
+    check(cv.GaussianBlur(dev(big), (0, 0), 8.64421), orc.orc_sepFilter2D(big, -1, g71_exact(orc), g71_exact(orc)), tol=1e-6)
+
+
+def g71_exact(orc):
+    """cv::getGaussianKernel(71, 8.64421, CV_32F) as the reference computes it (bit-exact taps through the library's own entry point)"""
+    import opencv_amd
+    return np.asarray(opencv_amd.getGaussianKernel(71, 8.64421, opencv_amd.CV_32F)).ravel()

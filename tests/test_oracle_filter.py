@@ -136,3 +136,23 @@ def test_boxfilter_into_64f(orc, ref):
                             assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max()), (dtype, cn, ks, norm, border)
                         else:
                             assert np.array_equal(a, b), (dtype, cn, ks, norm, border)
+
+
+def test_sepfilter_long_kernels(orc, ref):
+    """34-129 taps per axis (Imgproc_GaussianBlur.regression_11303 asks for 71): general float kernels, a Gaussian on CV_32F, and a symmetric smoothing kernel on CV_8U (the
+    fixed-point engine with its float vector body)"""
+    rng = np.random.default_rng(9)
+    g71 = np.exp(-0.5 * ((np.arange(71) - 35) / 8.64421) ** 2); g71 = (g71 / g71.sum()).astype(np.float32)
+    g41 = np.exp(-0.5 * ((np.arange(41) - 20) / 6.5) ** 2); g41 = (g41 / g41.sum()).astype(np.float32)
+    kx, ky = rng.uniform(-1, 1, 41).astype(np.float32) / 8, rng.uniform(-1, 1, 37).astype(np.float32) / 8
+    for dtype, ddepth in [(np.float32, -1), (np.uint8, -1), (np.uint8, 5), (np.uint16, 5), (np.int16, -1)]:
+        for cn in (1, 3):
+            src = rnd(orc, (53, 90, cn) if cn > 1 else (53, 90), dtype, 60 + cn)
+            for (a, b) in ((g71, g71), (g41, g71), (kx, ky), (g41, ky[:5])):
+                for border in (4, 0, 1):
+                    want = orc.ref_sepFilter2D(src, ddepth, a, b, (-1, -1), 0.0, border)
+                    got = orc.orc_sepFilter2D(src, ddepth, a, b, (-1, -1), 0.0, border)
+                    if want.dtype == np.float32:
+                        assert orc.rel_err(got, want) <= 1e-6, (dtype, ddepth, cn, len(a), len(b), border)
+                    else:
+                        assert np.array_equal(got, want), (dtype, ddepth, cn, len(a), len(b), border)
