@@ -21,6 +21,7 @@
 #   mix2             tools/probes/mix2.hip: the write-heavy mixes under different store geometries (pixels per lane, XCD banding, plain / nt stores)
 #   shift            tools/probes/shift.hip: a bilinear-tap pure shift of 8K float frames in k_warp_lin's geometry and in wider / row-walking ones
 #   ab <row> <settings..>  tools/env_ab.py: one bench row under several environment settings, each in its own process (last recipe on the line)
+#   integral-ordered tools/integral_ordered_time.py: us per call of cv::integral on one 4K image for the depth triples of integral_seq.hip, + rocprofv3 kernel stats of the same script
 #   refsuite         the reference's own opencv_test_imgproc on the hooks (Makefile build and cmake build) with the decline ledger
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 while [ $# -gt 0 ]; do
@@ -53,6 +54,9 @@ PY
                MI355CV_WARP_TAPS_TILE=1 timeout 300 python tools/warp_taps_bench.py > $O/${T}.txt 2>&1; cat $O/${T}.txt ;;
     mix)       (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix.hip -o /tmp/mix 2>/dev/null) && timeout 120 /tmp/mix | tee $O/${T}.txt ;;
     refsuite)  MI355CV_WRITE_LEDGER=1 timeout 1500 python -m pytest tests/test_reference_suite.py tests/test_cmake_reference_build.py -m gpu -q --timeout 1400 > $O/${T}.log 2>&1; echo "refsuite rc $?"; tail -6 $O/${T}.log | cut -c1-300 ;;
+    integral-ordered) timeout 200 python tools/integral_ordered_time.py > $O/${T}.txt 2>&1; cat $O/${T}.txt
+               (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/${T}_prof && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${T}_prof -- python $R/tools/integral_ordered_time.py > /dev/null 2>&1)
+               ks=$(find /tmp/${T}_prof -name "*kernel_stats.csv" | head -1); [ -n "$ks" ] && head -24 "$ks" | grep iseq | cut -c1-260 >> $O/${T}.txt ;;
     mix2)      (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix2.hip -o /tmp/mix2 2>/dev/null) && timeout 200 /tmp/mix2 | tee $O/${T}.txt ;;
     shift)     (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 shift.hip -o /tmp/shift 2>/dev/null) && timeout 200 /tmp/shift | tee $O/${T}.txt ;;
     ab)        # ab <row> <setting> [<setting> ...]  (tools/env_ab.py; must be the last recipe on the line; "" = defaults)
