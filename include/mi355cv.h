@@ -91,14 +91,24 @@ MI355CV_API int  mi355cv_getDevice(void);
  * bound to devices[slot] (NULL: ordinals 0 .. ndev-1; an ordinal may repeat) when bind != 0; fn calls the ordinary mi355cv_* entry points on its frames, which must live
  * on that device (or in host / managed memory).  Returns 0, or the first non-zero code in slot order (mi355cv_lastError names slot and device).  There is no data-path
  * collective: parameters given as host arguments are uploaded by each device's own hooks; a device-resident parameter image (a matchTemplate template) is copied to every
- * device with mi355cv_replicate (hipMemcpy, peer-to-peer over xGMI between GPUs; MI355CV_REPLICATE=rccl: an RCCL ncclBroadcast instead; the Python layer broadcasts through torch.distributed). */
+ * device with mi355cv_replicate (one upload + an RCCL ncclBroadcast over xGMI when the list names more than one device; one hipMemcpy per device otherwise or with MI355CV_REPLICATE=copy; the Python layer broadcasts through torch.distributed). */
 MI355CV_API void mi355cv_shardRange(int nframes, int ndev, int slot, int* first, int* count);
 MI355CV_API int  mi355cv_runSharded(int ndev, const int* devices, int nframes, int (*fn)(void* user, int slot, int device, int first, int count), void* user, int bind);
 MI355CV_API int  mi355cv_replicate(const void* src, size_t bytes, int ndev, const int* devices, void** out);
-/* how the last mi355cv_replicate of this process moved its data: 0 = one hipMemcpy per device (the default), 1 = one upload to the first device + an RCCL ncclBroadcast from
- * there over xGMI (MI355CV_REPLICATE=rccl; librccl.so is resolved with dlopen; a device list RCCL cannot take -- a device twice, no library -- uses the copies) */
+/* how the last mi355cv_replicate of this process moved its data: 0 = one hipMemcpy per device (a single device, MI355CV_REPLICATE=copy, or no usable librccl), 1 = one upload to the first device + an RCCL ncclBroadcast from
+ * there over xGMI (the default for more than one device since round 6; MI355CV_REPLICATE=rccl also for one; librccl.so is resolved with dlopen; a device list RCCL cannot take -- a device twice, no library -- uses the copies) */
 MI355CV_API int  mi355cv_replicateMode(void);
 MI355CV_API const char* mi355cv_version(void);
+/* Which host-resident images the hooks stage through HBM (device / managed pointers are always served).  0 = "auto" (the default: hooks whose CPU path is
+ * multi-threaded and bandwidth-bound -- 8-bit Gaussian, colour conversions, threshold, pyrDown, morphology, integral, bilinear resize -- answer NOT_IMPLEMENTED for a plain host
+ * image, because two PCIe crossings cost more than the reference's CPU path, and the caller's CPU path runs), 1 = "always" (every hook stages: for callers with no CPU path
+ * to fall back to -- opencv_amd sets it when it loads the library), -1 = back to the MI355CV_HOST_POLICY environment variable.  Process-wide. */
+MI355CV_API int mi355cv_setHostPolicy(int policy);
+MI355CV_API int mi355cv_hostPolicy(void);          /* the policy in force: 0 auto, 1 always */
+/* capacity bound of a served path by name (-1: no such key) -- "how far the GPU path was built", not the cases the reference itself has no engine for:
+ * "sep_max_taps", "sep_max_taps_64f", "gauss8u_max_ksize", "gauss_float_max_ksize", "adaptive_gaussian_max_block", "adaptive_mean_max_block", "box_max_ksize",
+ * "median8u_max_ksize", "bilateral_max_d", "orb_max_levels", "filter2d_dft_taps".  Needs no device.  A value above a bound is answered MI355CV_NOT_IMPLEMENTED by its hook. */
+MI355CV_API int mi355cv_limit(const char* key);
 MI355CV_API const char* mi355cv_lastError(void);
 /* template instance + launch geometry of the dominant kernel the calling thread launched last (bench.py reports it beside the roofline) */
 MI355CV_API const char* mi355cv_lastKernel(void);
@@ -215,6 +225,10 @@ MI355CV_API int mi355cv_sepFilterInit(struct cvhalFilter2D** context, int src_ty
 MI355CV_API int mi355cv_sepFilter(struct cvhalFilter2D* context, mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data,
         size_t dst_step, int width, int height, int full_width, int full_height, int offset_x, int offset_y);
 MI355CV_API int mi355cv_sepFilterFree(struct cvhalFilter2D* context);
+/* what mi355cv_sepFilterInit decided (no reference counterpart; needs no device): info[8] = {mode (0 float, 1 CV_8U bit-exact x 2^8, 2 integer CV_8U -> CV_16S), symY,
+ * nx, ny, anchor x, anchor y, delta as the integer modes add it, 1 if the destination is CV_64F}; kx / ky (room for mi355cv_limit("sep_max_taps") words each) receive
+ * the taps as the kernels read them: float bits in mode 0, int32 otherwise.  tests/test_hostemu.py replays the LDS-ring kernel on the CPU with these. */
+MI355CV_API int mi355cv_sepFilterDescribe(struct cvhalFilter2D* context, int* info, float* deltaF, unsigned* kx, unsigned* ky);
 
 /* replaces hal_ni_sobel (hal_replacement.hpp:1197; caller deriv.cpp:456) and hal_ni_scharr (:1224; caller deriv.cpp:511) */
 MI355CV_API int mi355cv_sobel(const mi355cv_uchar* src_data, size_t src_step, mi355cv_uchar* dst_data, size_t dst_step,

@@ -11,7 +11,7 @@ place in HBM on torch's current stream) or `numpy.ndarray` / CPU tensors (staged
 through HBM by the library).  The result has the same kind as the input.
 """
 from . import _lib
-from ._lib import call_count, Mi355cvError  # noqa: F401
+from ._lib import call_count, limit, Mi355cvError  # noqa: F401
 from .core import *  # noqa: F401,F403
 from .imgproc import *  # noqa: F401,F403
 from .video import *  # noqa: F401,F403

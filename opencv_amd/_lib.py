@@ -47,6 +47,10 @@ def _load():
         "mi355cv_runSharded": (c_int, [c_int, ctypes.POINTER(c_int), c_int, SHARD_FN, ctypes.c_void_p, c_int]),
         "mi355cv_replicate": (c_int, [ctypes.c_void_p, c_sz, c_int, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_void_p)]),
         "mi355cv_version": (ctypes.c_char_p, []),
+        "mi355cv_limit": (c_int, [ctypes.c_char_p]),
+        "mi355cv_setHostPolicy": (c_int, [c_int]),
+        "mi355cv_hostPolicy": (c_int, []),
+        "mi355cv_sepFilterDescribe": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]),
         "mi355cv_lastError": (ctypes.c_char_p, []),
         "mi355cv_lastKernel": (ctypes.c_char_p, []),
         "mi355cv_traceState": (ctypes.c_int, []),
@@ -183,6 +187,10 @@ def _load():
 
 
 lib, SIGNATURES = _load()
+# opencv_amd has no CPU path: a hook that leaves a plain host image "to the caller's CPU path" (the library's default policy for the bandwidth-bound hooks, right for the
+# HAL drop-in) would turn every numpy input into NotImplementedError here.  Stage everything unless the environment says otherwise.
+if "MI355CV_HOST_POLICY" not in os.environ:
+    lib.mi355cv_setHostPolicy(1)
 
 
 def check(code, entry):
@@ -194,6 +202,14 @@ def check(code, entry):
         lib.mi355cv_noteDecline(entry.encode())
         raise NotImplementedError(f"mi355cv_{entry}: NOT_IMPLEMENTED for these arguments ({msg}); no CPU fallback in opencv_amd")
     raise Mi355cvError(f"mi355cv_{entry} failed with {code}: {msg}")
+
+
+def limit(key: str) -> int:
+    """capacity bound of a served path (mi355cv_limit): e.g. limit("sep_max_taps"); raises KeyError for an unknown name"""
+    v = int(lib.mi355cv_limit(key.encode()))
+    if v < 0:
+        raise KeyError(key)
+    return v
 
 
 def call_count(entry: str) -> int:

@@ -22,7 +22,7 @@ using namespace mi355;
 
 namespace {
 
-constexpr int BT_W = 64, BT_H = 16, B_RMAX = 16;
+constexpr int BT_W = 64, BT_H = 16, B_RMAX = mi355::lim::BILATERAL_MAX_RADIUS;
 
 struct BilArgs { int W, H, radius, maxk, border, body; };
 

@@ -23,6 +23,7 @@
 #include <climits>
 #include "roll.h"
 #include "seproll.h"
+#include "seplong.h"
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -356,7 +357,6 @@ template <int MAXK> struct SepParamsT {
     int deltaI;
 };
 typedef SepParamsT<33> SepParams;            // what every kernel up to 33 taps per axis uses
-typedef SepParamsT<129> SepParamsL;          // up to 129 taps (a Gaussian of sigma 16 on CV_32F): the same kernel with longer per-thread tables
 
 template <int MAXK>
 __global__ __launch_bounds__(256) void k_sepfilter_generic(
@@ -650,12 +650,16 @@ struct FilterCtx {
     int ax, ay, kw, kh;
     float delta;
     std::vector<Tap2D> taps;
-    SepParams sp;
-    SepParamsL* big = nullptr;      // separable kernels of 34 .. 129 taps per axis: their own parameter block (k_sepfilter_generic<129>)
+    SepParams sp;                   // taps for the rolling kernels and k_sepfilter_generic<33> (at most 33 per axis; nx = 0 when the kernel is longer)
+    // the same taps at any length up to lim::SEP_MAX_TAPS, for the LDS-ring kernel (seplong.hip)
+    std::vector<float> lkxf, lkyf;
+    std::vector<int> lkxi, lkyi;
+    int lmode = 0, lsymY = 0, ldeltaI = 0, lnx = 0, lny = 0;
+    float ldeltaF = 0.f;
+    bool big = false;               // more than 33 taps on an axis: c.sp is not filled
     FilterCtx() = default;
     FilterCtx(const FilterCtx&) = delete;
     FilterCtx& operator=(const FilterCtx&) = delete;
-    ~FilterCtx() { delete big; }
     bool wide = false;              // CV_64F destination: double kernels and sums (k_filter2d_generic64 / k_sepfilter_generic64)
     double delta64 = 0;
     std::vector<Tap2D64> taps64;
@@ -688,15 +692,17 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
         return setError(MI355CV_NOT_IMPLEMENTED, "sepFilter: depth pair %d -> %d (channels %d -> %d) outside the GPU path", c.sdepth, c.ddepth, c.cn, MI355CV_MAT_CN(dtype));
     const int nx = (int)kx.size(), ny = (int)ky.size();
     const bool large = nx > 33 || ny > 33;
-    if (nx < 1 || ny < 1 || nx > 129 || ny > 129 || (large && c.wide)) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 129 || ny > 129 (33 into CV_64F)");
+    if (nx < 1 || ny < 1 || nx > lim::SEP_MAX_TAPS || ny > lim::SEP_MAX_TAPS || (c.wide && (nx > lim::SEP_MAX_TAPS_64F || ny > lim::SEP_MAX_TAPS_64F)))
+        return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx or ny > lim::SEP_MAX_TAPS (lim::SEP_MAX_TAPS_64F into CV_64F)");
+    if (large && c.cn > 4) return mi355::declined(__func__, __LINE__, "more than 33 taps on more than 4 channels (seplong.hip covers 1-4)");
     if (ax < 0) ax = nx / 2;
     if (ay < 0) ay = ny / 2;
     if (ax >= nx || ay >= ny) return mi355::declined(__func__, __LINE__, "ax >= nx || ay >= ny");
     c.border = border & ~MI355CV_BORDER_ISOLATED;
     if (c.border < 0 || c.border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "c.border < 0 || c.border > B_REFLECT_101");
+    c.ax = ax; c.ay = ay; c.lnx = nx; c.lny = ny; c.big = large;
     SepParams& p = c.sp;
     memset(&p, 0, sizeof p);
-    p.nx = nx; p.ny = ny; p.ax = ax; p.ay = ay;
     const int rtype = kernelType(kx, ax), ctype = kernelType(ky, ay);
     if (c.wide) {
         SepParams64& q = c.sp64;
@@ -708,54 +714,42 @@ int sepInit(FilterCtx& c, int stype, int dtype, const std::vector<double>& kx, c
         if (!(ny & 1)) q.symY = 0;
         return MI355CV_OK;
     }
-    if (large) {
-        // the same set-up into the long parameter block; the rolling kernels (<= 9 taps) never apply
-        delete c.big; c.big = new (std::nothrow) SepParamsL();
-        if (!c.big) return mi355::declined(__func__, __LINE__, "!c.big");
-        SepParamsL& q = *c.big;
-        memset(&q, 0, sizeof q);
-        q.nx = nx; q.ny = ny; q.ax = ax; q.ay = ay;
-        if (c.sdepth == D8U &&
-            ((rtype == K_SMOOTH + K_SYMMETRICAL && ctype == K_SMOOTH + K_SYMMETRICAL && c.ddepth == D8U) ||
-             ((rtype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (ctype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (rtype & ctype & K_INTEGER) && c.ddepth == D16S))) {
-            const int bits = c.ddepth == D8U ? 8 : 0;
-            std::vector<int> qx, qy;
-            if (bitExactKernel(kx, bits, qx) && bitExactKernel(ky, bits, qy)) {
-                q.mode = bits ? 1 : 2;
-                for (int i = 0; i < nx; i++) q.kxi[i] = qx[i];
-                for (int i = 0; i < ny; i++) q.kyi[i] = qy[i];
-                const double d = delta * (double)(1 << (2 * bits));
-                q.deltaI = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (int)-2147483648LL : (int)nearbyint(d);
-            }
-        }
-        for (int i = 0; i < nx; i++) q.kxf[i] = (float)kx[i];
-        for (int i = 0; i < ny; i++) q.kyf[i] = (float)ky[i];
-        q.deltaF = (float)delta;
-        q.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
-        if (!(ny & 1)) q.symY = 0;
-        return MI355CV_OK;
-    }
-    p.mode = 0;
+    // which engine the reference builds (createSeparableLinearFilter, filter.dispatch.cpp:305-420): bit-exact integer taps for CV_8U smoothing / derivative
+    // kernels, float otherwise
+    c.lmode = 0; c.ldeltaI = 0;
+    c.lkxi.assign(nx, 0); c.lkyi.assign(ny, 0);
     if (c.sdepth == D8U &&
         ((rtype == K_SMOOTH + K_SYMMETRICAL && ctype == K_SMOOTH + K_SYMMETRICAL && c.ddepth == D8U) ||
-         ((rtype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (ctype & (K_SYMMETRICAL + K_ASYMMETRICAL)) &&
-          (rtype & ctype & K_INTEGER) && c.ddepth == D16S))) {
+         ((rtype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (ctype & (K_SYMMETRICAL + K_ASYMMETRICAL)) && (rtype & ctype & K_INTEGER) && c.ddepth == D16S))) {
         const int bits = c.ddepth == D8U ? 8 : 0;
         std::vector<int> qx, qy;
         if (bitExactKernel(kx, bits, qx) && bitExactKernel(ky, bits, qy)) {
-            p.mode = bits ? 1 : 2;
-            for (int i = 0; i < nx; i++) p.kxi[i] = qx[i];
-            for (int i = 0; i < ny; i++) p.kyi[i] = qy[i];
+            c.lmode = bits ? 1 : 2;
+            c.lkxi = qx; c.lkyi = qy;
             const double d = delta * (double)(1 << (2 * bits));
-            p.deltaI = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (int)-2147483648LL : (int)nearbyint(d);
+            c.ldeltaI = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (int)-2147483648LL : (int)nearbyint(d);
         }
     }
-    for (int i = 0; i < nx; i++) p.kxf[i] = (float)kx[i];
-    for (int i = 0; i < ny; i++) p.kyf[i] = (float)ky[i];
-    p.deltaF = (float)delta;
-    p.symY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
-    if (!(ny & 1)) p.symY = 0;
+    c.lkxf.assign(kx.begin(), kx.end());
+    c.lkyf.assign(ky.begin(), ky.end());
+    c.ldeltaF = (float)delta;
+    c.lsymY = (ctype & K_SYMMETRICAL) ? 1 : (ctype & K_ASYMMETRICAL) ? 2 : 0;
+    if (!(ny & 1)) c.lsymY = 0;
+    if (!large) {
+        p.nx = nx; p.ny = ny; p.ax = ax; p.ay = ay;
+        p.mode = c.lmode; p.deltaI = c.ldeltaI; p.deltaF = c.ldeltaF; p.symY = c.lsymY;
+        for (int i = 0; i < nx; i++) { p.kxf[i] = c.lkxf[i]; p.kxi[i] = c.lkxi[i]; }
+        for (int i = 0; i < ny; i++) { p.kyf[i] = c.lkyf[i]; p.kyi[i] = c.lkyi[i]; }
+    }
     return MI355CV_OK;
+}
+
+// the LDS-ring kernel for everything the rolling kernels do not take (seplong.hip): any tap count, anchor, border, 1-4 channels
+bool sepLong(Stager& stg, const FilterCtx& c, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
+             int W, int H, int fullW, int fullH, int offX, int offY)
+{
+    const SepLongTaps t = {c.lkxf.data(), c.lkyf.data(), c.lkxi.data(), c.lkyi.data(), c.lnx, c.lny, c.ax, c.ay, c.lmode, c.lsymY, c.ldeltaF, c.ldeltaI};
+    return seplongRun(stg, src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.cn, c.sdepth, c.ddepth, fullW, fullH, offX, offY, c.border, t, stream());
 }
 
 int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep, uchar* dst, size_t dstep,
@@ -782,9 +776,7 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
         return stg.finish(entry);
     }
     if (c.big) {
-        hipLaunchKernelGGL((k_sepfilter_generic<129>), dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
-                           fullW, fullH, offX, offY, c.border, *c.big);
-        noteKernel("k_sepfilter_generic<129> (%d x %d taps)", c.big->nx, c.big->ny);
+        if (!sepLong(stg, c, ds, dss, 0, dd, dds, 0, 1, W, H, fullW, fullH, offX, offY)) return mi355::declined(__func__, __LINE__, "seplongRun refused a kernel beyond 33 taps");
         return stg.finish(entry);
     }
     const SepParams& p = c.sp;
@@ -807,9 +799,13 @@ int sepRun(const char* entry, const FilterCtx& c, const uchar* src, size_t sstep
     if (p.mode == 0 && (c.sdepth == D16U || c.sdepth == D16S) && (c.ddepth == c.sdepth || c.ddepth == D32F) && c.cn == 1 && centred &&
         seprollF16(ds, dss, 0, dd, dds, 0, 1, W, H, c.sdepth == D16S, c.ddepth == D32F, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream(), roi))
         return stg.finish(entry);
+    // everything else with 1-4 channels: the LDS-ring kernel, nx + ny multiply-adds per element
+    if (std::getenv("MI355CV_SEP_GENERIC") == nullptr && sepLong(stg, c, ds, dss, 0, dd, dds, 0, 1, W, H, fullW, fullH, offX, offY)) return stg.finish(entry);
+    // more than 4 channels (at most 33 taps, sepInit): one thread per output element, nx * ny gathers -- the correctness path of cv::sepFilter2D on exotic Mats
     dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
     hipLaunchKernelGGL((k_sepfilter_generic<33>), grid, dim3(256), 0, stream(), ds, dss, dd, dds, W, H, c.cn, c.sdepth, c.ddepth,
                        fullW, fullH, offX, offY, c.border, c.sp);
+    noteKernel("k_sepfilter_generic<33> (%d x %d taps, %d channels)", c.sp.nx, c.sp.ny, c.cn);
     return stg.finish(entry);
 }
 
@@ -820,25 +816,22 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
     if (disabled() || W <= 0 || H <= 0 || nframes < 1) return mi355::declined(__func__, __LINE__, "disabled() || W <= 0 || H <= 0 || nframes < 1");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
-    if (c.big) {                                 // 34 .. 129 taps: the generic kernel with the long parameter block, frame by frame
-        if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
-        for (int f = 0; f < nframes; f++)
-            hipLaunchKernelGGL((k_sepfilter_generic<129>), dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep,
-                               W, H, c.cn, c.sdepth, c.ddepth, W, H, 0, 0, c.border, *c.big);
-        return stg.finish(entry);
-    }
+    if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
+    const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
+    // one check for every path below, the CV_64F and long-kernel ones included (they used to launch before it)
+    if (overlapOnDevice(src, (size_t)(nframes - 1) * sframe + (size_t)(H - 1) * sstep + (size_t)W * c.cn * se,
+                        dst, (size_t)(nframes - 1) * dframe + (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
+        return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the source frames (in-place)", entry);
     if (c.wide) {                                // CV_64F destinations: the generic double kernel, frame by frame
-        if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
         for (int f = 0; f < nframes; f++)
             hipLaunchKernelGGL(k_sepfilter_generic64, dim3(divUp(W * c.cn, 64), divUp(H, 4)), dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep,
                                W, H, c.cn, c.sdepth, W, H, 0, 0, c.border, c.sp64);
         return stg.finish(entry);
     }
-    if (!isDevicePtr(src) || !isDevicePtr(dst)) return setError(MI355CV_NOT_IMPLEMENTED, "%s: batch entry needs device-resident frames", entry);
-    const int se = depthSize(c.sdepth), de = depthSize(c.ddepth);
-    if (overlapOnDevice(src, (size_t)(nframes - 1) * sframe + (size_t)(H - 1) * sstep + (size_t)W * c.cn * se,
-                        dst, (size_t)(nframes - 1) * dframe + (size_t)(H - 1) * dstep + (size_t)W * c.cn * de))
-        return setError(MI355CV_NOT_IMPLEMENTED, "%s: dst overlaps the source frames (in-place)", entry);
+    if (c.big) {                                 // 34 .. lim::SEP_MAX_TAPS taps: the LDS-ring kernel, frames along grid z
+        if (!sepLong(stg, c, src, sstep, sframe, dst, dstep, dframe, nframes, W, H, W, H, 0, 0)) return mi355::declined(__func__, __LINE__, "seplongRun refused a kernel beyond 33 taps");
+        return stg.finish(entry);
+    }
     if (nframes == 1) { sframe = 0; dframe = 0; }
     const SepParams& p = c.sp;
     const bool centred = p.nx == p.ny && p.ax == p.nx / 2 && p.ay == p.ny / 2;
@@ -857,7 +850,8 @@ int sepRunBatch(const char* entry, const FilterCtx& c, const uchar* src, size_t 
     if (p.mode == 0 && (c.sdepth == D16U || c.sdepth == D16S) && (c.ddepth == c.sdepth || c.ddepth == D32F) && c.cn == 1 && centred &&
         seprollF16(src, sstep, sframe, dst, dstep, dframe, nframes, W, H, c.sdepth == D16S, c.ddepth == D32F, p.kxf, p.kyf, p.nx, p.symY, p.deltaF, c.border, stream()))
         return stg.finish(entry);
-    dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));
+    if (std::getenv("MI355CV_SEP_GENERIC") == nullptr && sepLong(stg, c, src, sstep, sframe, dst, dstep, dframe, nframes, W, H, W, H, 0, 0)) return stg.finish(entry);
+    dim3 grid(divUp(W * c.cn, 64), divUp(H, 4));            // more than 4 channels
     for (int f = 0; f < nframes; f++)
         hipLaunchKernelGGL((k_sepfilter_generic<33>), grid, dim3(256), 0, stream(), src + (size_t)f * sframe, sstep, dst + (size_t)f * dframe, dstep, W, H, c.cn, c.sdepth, c.ddepth,
                            W, H, 0, 0, c.border, c.sp);
@@ -1080,7 +1074,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
         // DFT path carries the FFTs' float error (CV_8U results differ from it by at most 1 in isolated pixels, CV_32F by ~1e-6 relative: tests/test_filters_gpu.py reports both)
         static const bool serveLarge = [] { const char* v = getenv("MI355CV_FILTER_LARGE"); return v && atoi(v) != 0; }();
         const bool fastTypes = (c->sdepth == D8U && (c->ddepth == D8U || c->ddepth == D16S)) || (c->sdepth == D32F && c->ddepth == D32F);
-        if (!serveLarge && c->kw * c->kh >= (fastTypes ? 130 : 50) && offset_x == 0 && offset_y == 0 && width == full_width && height == full_height)
+        if (!serveLarge && c->kw * c->kh >= (fastTypes ? lim::FILTER2D_DFT_TAPS : 50) && offset_x == 0 && offset_y == 0 && width == full_width && height == full_height)
             return setError(MI355CV_NOT_IMPLEMENTED, "filter: %dx%d kernel on a whole image is the reference's DFT case", c->kw, c->kh);
     }
     const uchar* top = src_data - (ptrdiff_t)offset_y * (ptrdiff_t)src_step - (ptrdiff_t)offset_x * c->cn * se;
@@ -1146,6 +1140,20 @@ MI355CV_API int mi355cv_sepFilterFree(cvhalFilter2D* context)
 {
     mi355::EntryGuard entry_(__func__);
     delete reinterpret_cast<FilterCtx*>(context);
+    return MI355CV_OK;
+}
+
+// what mi355cv_sepFilterInit decided, for tests that replay the LDS-ring kernel on the CPU with the product's own host decisions (tests/test_hostemu.py): info = {mode, symY,
+// nx, ny, ax, ay, deltaI, wide}; kx / ky (room for lim::SEP_MAX_TAPS each) receive the taps as the kernel reads them -- float bits (mode 0) or int32; needs no device
+MI355CV_API int mi355cv_sepFilterDescribe(cvhalFilter2D* context, int* info, float* deltaF, unsigned* kx, unsigned* ky)
+{
+    const FilterCtx* c = reinterpret_cast<const FilterCtx*>(context);
+    if (!c || c->kind != 2 || !info || !deltaF || !kx || !ky) return MI355CV_ERROR_UNKNOWN;
+    info[0] = c->lmode; info[1] = c->lsymY; info[2] = c->lnx; info[3] = c->lny; info[4] = c->ax; info[5] = c->ay; info[6] = c->ldeltaI; info[7] = c->wide;
+    *deltaF = c->ldeltaF;
+    if (c->wide) return MI355CV_OK;
+    for (int i = 0; i < c->lnx; i++) { if (c->lmode == 0) memcpy(&kx[i], &c->lkxf[i], 4); else kx[i] = (unsigned)c->lkxi[i]; }
+    for (int i = 0; i < c->lny; i++) { if (c->lmode == 0) memcpy(&ky[i], &c->lkyf[i], 4); else ky[i] = (unsigned)c->lkyi[i]; }
     return MI355CV_OK;
 }
 
@@ -1236,7 +1244,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     // the reference's own Imgproc_Blur test does) arrives with channel bits set; the destination Mat was created from CV_MAKETYPE(ddepth, cn), i.e. from the depth bits
     src_depth = MI355CV_MAT_DEPTH(src_depth); dst_depth = MI355CV_MAT_DEPTH(dst_depth);
     const int kw = (int)ksize_width, kh = (int)ksize_height;
-    if (kw < 1 || kh < 1 || kw > 255 || kh > 255) return mi355::declined(__func__, __LINE__, "kw < 1 || kh < 1 || kw > 255 || kh > 255");
+    if (kw < 1 || kh < 1 || kw > lim::BOX_MAX_KSIZE || kh > lim::BOX_MAX_KSIZE) return mi355::declined(__func__, __LINE__, "kw < 1 || kh < 1 || kw or kh > lim::BOX_MAX_KSIZE");
     const int border = border_type & ~MI355CV_BORDER_ISOLATED;
     if (border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101");
     // integer sources: int sums into any of the destination depths the reference has a ColumnSum<int, T> for (8U -> 16S is what an un-normalised cv::boxFilter of

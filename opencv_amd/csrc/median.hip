@@ -229,7 +229,7 @@ extern "C" MI355CV_API int mi355cv_medianBlur(const uchar* src_data, size_t src_
     const bool small = ksize == 3 || ksize == 5;
     const bool typed = depth == MI355CV_16U || depth == MI355CV_16S || depth == MI355CV_32F;      // sort networks: apertures 3 and 5 only, any channel count (the reference asserts the same)
     if (ksize < 3 || !(ksize & 1) || cn < 1) return mi355::declined(__func__, __LINE__, "ksize < 3 || !(ksize & 1) || cn < 1");
-    if (typed ? !small || cn > 512 : (depth != MI355CV_8U || ksize > 31 || (small ? cn > 512 : !(cn == 1 || cn == 3 || cn == 4))))
+    if (typed ? !small || cn > 512 : (depth != MI355CV_8U || ksize > lim::MEDIAN8U_MAX_KSIZE || (small ? cn > 512 : !(cn == 1 || cn == 3 || cn == 4))))
         return setError(MI355CV_NOT_IMPLEMENTED, "medianBlur: depth %d, %d channel(s), aperture %d (served: CV_8U with apertures 3 and 5 or, with 1 / 3 / 4 channels, up to 31; CV_16U / CV_16S / CV_32F with apertures 3 and 5)", depth, cn, ksize);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");

@@ -198,7 +198,7 @@ MI355CV_API int mi355cv_ORB_detectAndCompute(const uchar* image, size_t step, in
         // FAST on every level: scores and suppression of all levels in one launch each (buffers of the pyramid's geometry), the candidates of all levels in
         // raster order by a row count, a scan and a write pass -- no sort, no atomics; KeyPointsFilter::runByPixelsMask / runByImageBorder
         // (keypoint.cpp:107-165), which follow FAST at once in the reference, are part of the candidate test, so nothing near the edge leaves the GPU
-        static_assert(MAX_LEVELS <= FAST_MAX_LEVELS, "level tables");
+        static_assert(MAX_LEVELS <= FAST_MAX_LEVELS && MAX_LEVELS == mi355::lim::ORB_MAX_LEVELS, "level tables; mi355cv_limit(\"orb_max_levels\")");
         FastLevels FL; memset(&FL, 0, sizeof FL);
         FL.n = nLevels;
         size_t bound = 0;

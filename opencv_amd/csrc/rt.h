@@ -18,6 +18,22 @@ namespace mi355 {
 // border codes (core/base.hpp:332)
 enum { B_CONSTANT = 0, B_REPLICATE = 1, B_REFLECT = 2, B_WRAP = 3, B_REFLECT_101 = 4, B_TRANSPARENT = 5 };
 
+// Capacity bounds of the served paths -- "how far this was built", as opposed to the cases the reference itself has no engine for.  ONE definition: the entry points
+// compare against these, mi355cv_limit() reports them, tests/test_declines_cpu.py pins their values on the CPU and the -m gpu tests derive every refusal they assert from
+// mi355cv_limit(), so that widening a path without widening its parity cases fails a CPU test.
+namespace lim {
+constexpr int SEP_MAX_TAPS = 129;          // cv_hal_sepFilter: taps per axis (seplong.hip); a Gaussian of sigma 16 on CV_32F has 97
+constexpr int SEP_MAX_TAPS_64F = 33;       // ... into CV_64F (k_sepfilter_generic64)
+constexpr int GAUSS8U_MAX_KSIZE = 129;     // cv_hal_gaussianBlur on CV_8U (Q8.8 taps)
+constexpr int GAUSS_FLOAT_MAX_KSIZE = 129; // cv_hal_gaussianBlur on CV_16U / CV_16S / CV_32F (= the separable hook's)
+constexpr int ADAPTIVE_MEAN_MAX_BLOCK = 255;
+constexpr int BOX_MAX_KSIZE = 255;
+constexpr int MEDIAN8U_MAX_KSIZE = 31;
+constexpr int BILATERAL_MAX_RADIUS = 16;
+constexpr int ORB_MAX_LEVELS = 32;
+constexpr int FILTER2D_DFT_TAPS = 130;     // whole-image filter2D from this many taps on is the reference's DFT case: declined unless MI355CV_FILTER_LARGE=1
+}
+
 struct ThreadCtx;
 ThreadCtx& tctx();
 hipStream_t stream();

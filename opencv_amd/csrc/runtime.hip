@@ -65,13 +65,17 @@ bool hostImageTooSmall(const void* img, size_t pixels, size_t threshold)
     return true;
 }
 
+// -1: what MI355CV_HOST_POLICY says (default auto); 0 auto, 1 always -- mi355cv_setHostPolicy, for hosts above the C ABI that have no CPU path of their own to fall back to
+static std::atomic<int> g_hostPolicy{-1};
+
 size_t minPixels(int cost)
 {
     static const size_t v = getenv("MI355CV_MIN_PIXELS") ? strtoull(getenv("MI355CV_MIN_PIXELS"), nullptr, 10) : 0;
     // "auto" is the default since round 5 (serving every host Mat by staging made the out-of-the-box drop-in slower than the reference's own CPU path on the
     // bandwidth-bound hooks -- 40.8 against 51.5 Gpix/s for the 8-bit Gaussian on 16 host threads); MI355CV_HOST_POLICY=always stages everything (the parity suites set it)
     static const bool autoPolicy = !(getenv("MI355CV_HOST_POLICY") && !strcmp(getenv("MI355CV_HOST_POLICY"), "always"));
-    if (!autoPolicy) return v;
+    const int pol = g_hostPolicy.load(std::memory_order_relaxed);
+    if (pol < 0 ? !autoPolicy : pol == 1) return v;
     return cost == HOST_HEAVY ? std::max<size_t>(v, 64 * 64) : (size_t)-1;
 }
 
@@ -557,17 +561,62 @@ extern "C" {
 
 MI355CV_API const char* mi355cv_version(void) { return "mi355cv 0.1 (gfx950; HAL mirror of OpenCV 4.12 imgproc hot path)"; }
 MI355CV_API const char* mi355cv_lastError(void) { return t_err; }
+MI355CV_API int mi355cv_setHostPolicy(int policy)
+{
+    if (policy < -1 || policy > 1) return MI355CV_ERROR_UNKNOWN;
+    g_hostPolicy.store(policy, std::memory_order_relaxed);
+    return MI355CV_OK;
+}
+MI355CV_API int mi355cv_hostPolicy(void)
+{
+    const int pol = g_hostPolicy.load(std::memory_order_relaxed);
+    if (pol >= 0) return pol;
+    const char* e = getenv("MI355CV_HOST_POLICY");
+    return e && !strcmp(e, "always") ? 1 : 0;
+}
+MI355CV_API int mi355cv_limit(const char* key)
+{
+    using namespace mi355::lim;
+    static const struct { const char* k; int v; } tab[] = {
+        {"sep_max_taps", SEP_MAX_TAPS}, {"sep_max_taps_64f", SEP_MAX_TAPS_64F}, {"gauss8u_max_ksize", GAUSS8U_MAX_KSIZE}, {"gauss_float_max_ksize", GAUSS_FLOAT_MAX_KSIZE},
+        {"adaptive_gaussian_max_block", SEP_MAX_TAPS}, {"adaptive_mean_max_block", ADAPTIVE_MEAN_MAX_BLOCK}, {"box_max_ksize", BOX_MAX_KSIZE},
+        {"median8u_max_ksize", MEDIAN8U_MAX_KSIZE}, {"bilateral_max_d", 2 * BILATERAL_MAX_RADIUS + 1}, {"orb_max_levels", ORB_MAX_LEVELS}, {"filter2d_dft_taps", FILTER2D_DFT_TAPS}};
+    if (!key) return -1;
+    for (const auto& e : tab) if (!strcmp(key, e.k)) return e.v;
+    return -1;
+}
 MI355CV_API const char* mi355cv_lastKernel(void) { return t_kernel; }
+
+// Scratch buffers last used asynchronously on a caller-bound stream are tagged with it (Stager::bump_ polls that stream before handing them to another).  When the binding
+// changes, the stream being left is drained once and the tags dropped: the caller may destroy it afterwards without leaving a dead handle behind for hipStreamQuery
+// (ADVICE r5).  Contract: unbind (mi355cv_setStream to another stream / mi355cv_resetStream) BEFORE destroying a stream that was bound.
+static void leaveUserStream(ThreadCtx& c, hipStream_t next, bool nextIsUser)
+{
+    if (!c.useUser || (nextIsUser && next == c.user)) return;
+    bool tagged = false;
+    for (auto& b : c.pool) if (b.last == c.user && b.last) tagged = true;
+    if (!tagged) return;
+    if (ensureDevice()) { (void)hipStreamSynchronize(c.user); (void)hipGetLastError(); restoreDevice(); }
+    for (auto& b : c.pool) if (b.last == c.user) b.last = nullptr;
+}
 
 MI355CV_API int mi355cv_setStream(void* s)
 {
     if (resolveDevice() < 0) return -1;
     ThreadCtx& c = tctx();
+    leaveUserStream(c, (hipStream_t)s, true);
     c.user = (hipStream_t)s; c.useUser = true;    // NULL is HIP's null (legacy default) stream
     return 0;
 }
 
-MI355CV_API int mi355cv_resetStream(void) { if (resolveDevice() < 0) return -1; tctx().useUser = false; return 0; }
+MI355CV_API int mi355cv_resetStream(void)
+{
+    if (resolveDevice() < 0) return -1;
+    ThreadCtx& c = tctx();
+    leaveUserStream(c, nullptr, false);
+    c.useUser = false;
+    return 0;
+}
 
 MI355CV_API int mi355cv_setAsync(int enable)
 {

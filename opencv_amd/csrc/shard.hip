@@ -72,6 +72,7 @@ int replicateRccl(const void* src, size_t bytes, int ndev, const int* devices, v
         comms = &g_rcclComms.emplace(devs, std::move(c)).first->second;
     } else comms = &it->second;
     std::vector<hipStream_t> st(ndev, nullptr);
+    for (int i = 0; i < ndev; i++) out[i] = nullptr;               // the failure path frees every non-null slot: none may still hold what the caller's array contained
     int rc = 0, made = 0;
     for (; made < ndev && rc == 0; made++) {
         out[made] = nullptr;
@@ -164,7 +165,10 @@ MI355CV_API int mi355cv_replicate(const void* src, size_t bytes, int ndev, const
     const int before = threadDeviceBinding();
     int done = 0, rc = 0;
     {
-        static const bool wantRccl = [] { const char* v = getenv("MI355CV_REPLICATE"); return v && !strcmp(v, "rccl"); }();
+        // the transport: RCCL's ncclBroadcast over xGMI whenever more than one device is listed and librccl.so loads (north_star: "RCCL broadcast of shared filter
+        // weights"; the default since round 6), one hipMemcpy per device otherwise -- MI355CV_REPLICATE=copy forces the copies, =rccl also tries RCCL for a single device
+        static const int mode = [] { const char* v = getenv("MI355CV_REPLICATE"); return !v ? 0 : !strcmp(v, "rccl") ? 1 : !strcmp(v, "copy") ? -1 : 0; }();
+        const bool wantRccl = mode > 0 || (mode == 0 && ndev > 1);
         g_lastReplicateMode = 0;
         if (wantRccl) {
             const int r = replicateRccl(src, bytes, ndev, devices, out);

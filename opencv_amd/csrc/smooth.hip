@@ -19,6 +19,7 @@
 #include "rt.h"
 #include "gausskernel.h"
 #include "seproll.h"
+#include "seplong.h"
 #include <cstring>
 #include <cstdlib>
 
@@ -652,7 +653,7 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
 {
     if (disabled()) return mi355::declined(__func__, __LINE__, "disabled()");
     if (W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4) return mi355::declined(__func__, __LINE__, "W <= 0 || H <= 0 || nframes <= 0 || cn < 1 || cn > 4");
-    if (nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx > 33 || ny > 33 || !(nx & 1) || !(ny & 1)");
+    if (nx < 1 || ny < 1 || nx > lim::GAUSS8U_MAX_KSIZE || ny > lim::GAUSS8U_MAX_KSIZE || !(nx & 1) || !(ny & 1)) return mi355::declined(__func__, __LINE__, "nx < 1 || ny < 1 || nx or ny > lim::GAUSS8U_MAX_KSIZE || !(nx & 1) || !(ny & 1)");
     if (border < 0 || border > B_REFLECT_101) return mi355::declined(__func__, __LINE__, "border < 0 || border > B_REFLECT_101");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
@@ -691,7 +692,18 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
                    // a submatrix with real pixels around it (cv_hal_gaussianBlurBinomial's margins): the rolling kernel on the parent's geometry, storing the window
                    const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
                    return seprollFixedSmooth(dsrc, dss, 0, ddst, dds, 0, 1, W, H, cn, kx, nx, ky, ny, border, st, &roi); }()) {
+    } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && [&] {
+                   // any length, any geometry, margins included: the LDS-ring kernel in its Q8.8 mode -- when no ufixedpoint16 / ufixedpoint32 sum can saturate
+                   unsigned sx = 0, sy = 0;
+                   for (int i = 0; i < nx; i++) sx += kx[i];
+                   for (int i = 0; i < ny; i++) sy += ky[i];
+                   if (sx > 256 || sy > 256) return false;
+                   std::vector<int> ix(kx, kx + nx), iy(ky, ky + ny);
+                   const SepLongTaps t = {nullptr, nullptr, ix.data(), iy.data(), nx, ny, nx / 2, ny / 2, 3, 0, 0.f, 0};
+                   return seplongRun(stg, dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, MI355CV_8U, MI355CV_8U, mL + W + mR, mT + H + mB, mL, mT, border, t, st); }()) {
     } else {
+        // taps that can saturate the reference's fixed-point types (never cv::GaussianBlur's own: they sum to 256), or MI355CV_SMOOTH_GENERIC=1: one thread per byte, <= 33 taps
+        if (nx > 33 || ny > 33) return mi355::declined(__func__, __LINE__, "Q8.8 taps that sum beyond 256 with more than 33 of them");
         FixedTaps t;
         t.nx = nx; t.ny = ny;
         for (int i = 0; i < 33; i++) { t.kx[i] = i < nx ? kx[i] : 0; t.ky[i] = i < ny ? ky[i] : 0; }
@@ -841,7 +853,7 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
     if (depth != MI355CV_8U) {
         if (depth != MI355CV_16U && depth != MI355CV_16S && depth != MI355CV_32F) return mi355::declined(__func__, __LINE__, "depth is none of 8U / 16U / 16S / 32F");
         const int n = (int)ksize_width, m = (int)ksize_height;
-        if (n < 1 || m < 1 || n > 33 || m > 33 || !(n & 1) || !(m & 1)) return mi355::declined(__func__, __LINE__, "kernel size outside 1 .. 33 or even");
+        if (n < 1 || m < 1 || n > lim::GAUSS_FLOAT_MAX_KSIZE || m > lim::GAUSS_FLOAT_MAX_KSIZE || !(n & 1) || !(m & 1)) return mi355::declined(__func__, __LINE__, "kernel size outside 1 .. lim::GAUSS_FLOAT_MAX_KSIZE or even");
         if (sigmaY <= 0) sigmaY = sigmaX;
         const double s1 = sigmaX > 0 ? sigmaX : 0, s2 = sigmaY > 0 ? sigmaY : 0;
         std::vector<double> dx, dy;
@@ -863,12 +875,12 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
     // sepFilter2D itself, whose hook (mi355cv_sepFilter, ROI offsets included) reproduces that arithmetic.
     if (margin_left | margin_top | margin_right | margin_bottom)
         return mi355::setError(MI355CV_NOT_IMPLEMENTED, "gaussianBlur: submatrix with real margins is the reference's sepFilter2D case");
-    if (ksize_width > 33 || ksize_height > 33) return mi355::declined(__func__, __LINE__, "ksize_width > 33 || ksize_height > 33");
+    if (ksize_width > (size_t)lim::GAUSS8U_MAX_KSIZE || ksize_height > (size_t)lim::GAUSS8U_MAX_KSIZE) return mi355::declined(__func__, __LINE__, "ksize_width or ksize_height > lim::GAUSS8U_MAX_KSIZE");
     if (sigmaY <= 0) sigmaY = sigmaX;
     std::vector<int64_t> qx, qy;
     if (!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx)");
     if (!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)) return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy)");
-    uint16_t kx[33], ky[33];
+    uint16_t kx[lim::GAUSS8U_MAX_KSIZE], ky[lim::GAUSS8U_MAX_KSIZE];
     for (size_t i = 0; i < ksize_width; i++) { if (qx[i] < 0 || qx[i] > 65535) return mi355::declined(__func__, __LINE__, "qx[i] < 0 || qx[i] > 65535"); kx[i] = (uint16_t)qx[i]; }
     for (size_t i = 0; i < ksize_height; i++) { if (qy[i] < 0 || qy[i] > 65535) return mi355::declined(__func__, __LINE__, "qy[i] < 0 || qy[i] > 65535"); ky[i] = (uint16_t)qy[i]; }
     bool binom = ksize_width == ksize_height && (ksize_width == 3 || ksize_width == 5);

@@ -148,7 +148,7 @@ extern "C" MI355CV_API int mi355cv_adaptiveThreshold(const uchar* src_data, size
     mi355::EntryGuard entry_(__func__);
     if (disabled() || width <= 0 || height <= 0) return mi355::declined(__func__, __LINE__, "disabled() || width <= 0 || height <= 0");
     if ((adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)) return mi355::declined(__func__, __LINE__, "(adaptiveMethod != 0 && adaptiveMethod != 1) || (thresholdType != 0 && thresholdType != 1)");
-    if (blockSize < 3 || !(blockSize & 1) || blockSize > 255) return mi355::declined(__func__, __LINE__, "blockSize < 3 || !(blockSize & 1) || blockSize > 255");
+    if (blockSize < 3 || !(blockSize & 1) || blockSize > (adaptiveMethod == 0 ? lim::ADAPTIVE_MEAN_MAX_BLOCK : lim::SEP_MAX_TAPS)) return mi355::declined(__func__, __LINE__, "blockSize < 3 || even || beyond lim::ADAPTIVE_MEAN_MAX_BLOCK (MEAN_C) / lim::SEP_MAX_TAPS (GAUSSIAN_C)");
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
     if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");

@@ -60,8 +60,8 @@ int orc_getGaussianKernel(int n, double sigma, double* r)
 
 int orc_getGaussianKernelQ(int n, double sigma, int fractionBits, int64_t* q)
 {
-    double k[64];
-    if (n > 64 || !(n & 1) || orc_getGaussianKernel(n, sigma, k)) return 1;
+    double k[256];
+    if (n > 256 || !(n & 1) || orc_getGaussianKernel(n, sigma, k)) return 1;
     int64_t mult = (int64_t)1 << fractionBits, sum = 0;
     double err = 0.0;
     int n2 = n / 2;

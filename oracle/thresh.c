@@ -106,9 +106,9 @@ int orc_getGaussianKernel(int n, double sigma, double* taps);
 int orc_adaptiveThresholdGaussian(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int w, int h, double maxValue, int type,
                                   int blockSize, double delta)
 {
-    if ((type != 0 && type != 1) || blockSize < 3 || !(blockSize & 1) || blockSize > 63) return 1;
+    if ((type != 0 && type != 1) || blockSize < 3 || !(blockSize & 1) || blockSize > 255) return 1;
     if (maxValue < 0) { for (int y = 0; y < h; y++) memset(dst + (size_t)y * dstep, 0, (size_t)w); return 0; }
-    double kd[64];
+    double kd[256];
     if (orc_getGaussianKernel(blockSize, 0.0, kd)) return 1;
     for (int i = 0; i < blockSize; i++) kd[i] = (double)(float)kd[i];                  /* the CV_32F kernel */
     float* sf = (float*)malloc(sizeof(float) * (size_t)w * h);

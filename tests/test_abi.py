@@ -1,8 +1,10 @@
-"""CPU-only: the C-ABI library loads and exports every symbol include/mi355cv.h declares; the
+"""CPU-only (but for the last test): the C-ABI library loads and exports every symbol include/mi355cv.h declares; the
 HAL header maps hooks onto exported symbols; product code never touches the oracle."""
 import ctypes
 import os
 import re
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -95,3 +97,25 @@ def test_the_five_hooks_left_unbound_stay_with_the_reference():
         assert len(declared) == 66, len(declared)
         assert declared - bound == {"cv_hal_warpAffineBlockline", "cv_hal_warpAffineBlocklineNN", "cv_hal_warpPerspectiveBlockline", "cv_hal_warpPerspectiveBlocklineNN",
                                     "cv_hal_polygonMoments"}, sorted(declared - bound)
+
+
+@pytest.mark.gpu
+def test_python_api_serves_numpy_inputs_without_the_suite_override():
+    """opencv_amd on plain numpy images in a process WITHOUT tests/conftest.py's MI355CV_HOST_POLICY=always: the bandwidth-bound hooks (threshold, 8-bit Gaussian, cvtColor,
+    pyrDown) must be served -- the Python layer has no CPU path and opts in to staging when it loads the library (they raised NotImplementedError outside pytest)"""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+        import opencv_amd as cv, orc
+        src = np.random.default_rng(1).integers(0, 256, (120, 200, 3), dtype=np.uint8)
+        assert np.array_equal(cv.GaussianBlur(src, (5, 5), 0), orc.orc_gaussianBlurBinomialU8(src, 5, 4))
+        gray = cv.cvtColor(src, cv.COLOR_BGR2GRAY)
+        assert np.array_equal(cv.threshold(gray, 100, 255, 0)[1], orc.orc_threshold(gray, 100, 255, 0)[1])
+        assert cv.pyrDown(gray).shape == (60, 100)
+        print("NUMPY ok", cv.call_count("gaussianBlurBinomial"))
+    """ % (root, root))
+    env = {k: v for k, v in os.environ.items() if k != "MI355CV_HOST_POLICY"}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "NUMPY ok 1" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])

@@ -30,7 +30,7 @@ def test_bilateral_filter(cv, orc, cn):
     img = rng.integers(0, 256, (50, 70, cn) if cn > 1 else (50, 70), dtype=np.uint8)
     assert np.array_equal(cv.bilateralFilter(img, 7, 50.0, 3.0), orc.orc_bilateralFilter(img, 7, 50.0, 3.0))            # host arrays
     with pytest.raises(NotImplementedError):
-        cv.bilateralFilter(torch.from_numpy(img).cuda(), 41, 50.0, 3.0)                                                # radius beyond the LDS tile: declined
+        cv.bilateralFilter(torch.from_numpy(img).cuda(), cv.limit("bilateral_max_d") + 2, 50.0, 3.0)                    # radius beyond the LDS tile (mi355cv_limit): declined
 
 
 @pytest.mark.parametrize("cn", [1, 3])

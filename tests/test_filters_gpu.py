@@ -569,7 +569,8 @@ def test_boxfilter_into_64f(cv, orc):
 
 
 def test_sepfilter_long_kernels(cv, orc):
-    """separable kernels of 34-129 taps per axis (Imgproc_GaussianBlur.regression_11303: a 71-tap Gaussian on CV_32F) on the generic kernel's long parameter block"""
+    """separable kernels of 34-129 taps per axis (Imgproc_GaussianBlur.regression_11303: a 71-tap Gaussian on CV_32F) on the LDS-ring kernel (seplong.hip): BIT for bit
+    against the restatement, floats included -- the kernel keeps the order of every multiply-add chain (tests/test_seplong_emu.py replays the same lines on the CPU)"""
     rng = np.random.default_rng(9)
     g71 = np.exp(-0.5 * ((np.arange(71) - 35) / 8.64421) ** 2); g71 = (g71 / g71.sum()).astype(np.float32)
     g41 = np.exp(-0.5 * ((np.arange(41) - 20) / 6.5) ** 2); g41 = (g41 / g41.sum()).astype(np.float32)
@@ -579,11 +580,58 @@ def test_sepfilter_long_kernels(cv, orc):
             src = rnd((53, 90, cn) if cn > 1 else (53, 90), dtype, 60 + cn)
             for (a, b) in ((g71, g71), (g41, g71), (kx, ky), (g41, ky[:5])):
                 for border in (4, 0, 1):
-                    check(cv.sepFilter2D(dev(src), ddepth, a, b, (-1, -1), 0.0, border), orc.orc_sepFilter2D(src, ddepth, a, b, (-1, -1), 0.0, border), tol=1e-6)
+                    got = cv.sepFilter2D(dev(src), ddepth, a, b, (-1, -1), 0.0, border).cpu().numpy()
+                    want = orc.orc_sepFilter2D(src, ddepth, a, b, (-1, -1), 0.0, border)
+                    assert np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got, want.view(np.uint32) if want.dtype == np.float32 else want), (dtype, ddepth, cn, len(a), len(b), border)
     from opencv_amd import _lib
-    assert "k_sepfilter_generic<129>" in _lib.lib.mi355cv_lastKernel().decode()
+    assert "k_seplong<0," in _lib.lib.mi355cv_lastKernel().decode()
     big = rnd((211, 2115), np.float32, 3)                                              # the reference test's geometry
-    check(cv.GaussianBlur(dev(big), (0, 0), 8.64421), orc.orc_sepFilter2D(big, -1, g71_exact(orc), g71_exact(orc)), tol=1e-6)
+    got = cv.GaussianBlur(dev(big), (0, 0), 8.64421).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), orc.orc_sepFilter2D(big, -1, g71_exact(orc), g71_exact(orc)).view(np.uint32))
+    # the tap bound itself, from the library (tests/test_declines_cpu.py pins its value): served at the bound, refused above it
+    top = cv.limit("sep_max_taps")
+    kt = np.full(top, 1.0 / top, np.float32); src = rnd((140, 300), np.float32, 8)
+    got = cv.sepFilter2D(dev(src), -1, kt, kt, (-1, -1), 0.0, 4).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), orc.orc_sepFilter2D(src, -1, kt, kt, (-1, -1), 0.0, 4).view(np.uint32))
+    with pytest.raises(NotImplementedError):
+        cv.sepFilter2D(dev(src), -1, np.full(top + 2, 1.0 / (top + 2), np.float32), kt, (-1, -1), 0.0, 4)
+
+
+def test_seplong_every_engine_and_geometry(cv, orc):
+    """what the LDS-ring kernel takes over from the one-thread-per-output kernels (10-33 taps, odd anchors, even lengths, 2 channels, ragged widths, ROI windows with real
+    pixels around them, batches): every engine of createSeparableLinearFilter bit for bit, on shapes that span several strips and segments"""
+    rng = np.random.default_rng(4)
+    g19 = np.exp(-0.5 * ((np.arange(19) - 9) / 3.0) ** 2); g19 = (g19 / g19.sum()).astype(np.float32)
+    q11 = np.round(np.exp(-0.5 * ((np.arange(11) - 5) / 2.0) ** 2) * 40); q11[5] += 256 - q11.sum(); q11 = (q11 / 256).astype(np.float32)
+    b11 = np.array([1.0]);
+    for _ in range(8): b11 = np.convolve(b11, [1, 1])
+    d11 = np.convolve(b11, [-1, 0, 1]).astype(np.float32); b11 = np.convolve(b11, [1, 2, 1]).astype(np.float32)
+    r12, r10 = (rng.uniform(-1, 1, 12) / 6).astype(np.float32), (rng.uniform(-1, 1, 10) / 6).astype(np.float32)
+    bits = lambda a: a.view(np.uint32) if a.dtype == np.float32 else a
+    from opencv_amd import _lib
+    for dtype, ddepth, kx, ky, anchor, delta, tag in [(np.float32, -1, g19, g19, (-1, -1), 0.0, "k_seplong<0,"), (np.float32, -1, r12, r10, (3, 7), 0.5, "k_seplong<0,"),
+                                                      (np.uint8, -1, g19, g19, (-1, -1), 0.0, "k_seplong<0,"), (np.uint8, -1, q11, q11, (-1, -1), 1.0, "k_seplong<1,"),
+                                                      (np.uint8, 3, b11, d11, (-1, -1), 0.0, "k_seplong<2,"), (np.uint16, 5, g19, r10, (-1, 2), 0.0, "k_seplong<0,")]:
+        for cn in (1, 2, 3, 4):
+            for (h, w) in [(300, 1000), (37, 53), (1, 40), (40, 1)]:
+                if cn in (2, 4) and h == 300:
+                    continue
+                src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, 11 * cn + h)
+                for border in (4, 0, 1, 2):
+                    got = cv.sepFilter2D(dev(src), ddepth, kx, ky, anchor, delta, border).cpu().numpy()
+                    assert tag in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+                    assert np.array_equal(bits(got), bits(orc.orc_sepFilter2D(src, ddepth, kx, ky, anchor, delta, border))), (dtype, ddepth, len(kx), cn, (h, w), border)
+        parent = rnd((96, 400), dtype, 77)
+        for roi in [(16, 8, 256, 40), (5, 4, 130, 20), (383, 90, 17, 6), (0, 0, 400, 96)]:
+            x, y, w, h = roi
+            for border in (4, 0, 1):
+                got = cv.sepFilter2D(dev(parent), ddepth, kx, ky, anchor, delta, border, roi=roi).cpu().numpy()
+                assert np.array_equal(bits(got), bits(orc.orc_sepFilter2D(parent, ddepth, kx, ky, anchor, delta, border, roi=roi))), (dtype, roi, border)
+    # a batch: frames along grid z
+    fr = rnd((5, 130, 270), np.float32, 2)
+    got = cv.sepFilter2DBatch(dev(fr), -1, g19, g19).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(bits(got[i]), bits(orc.orc_sepFilter2D(fr[i], -1, g19, g19)))
 
 
 def g71_exact(orc):

@@ -97,6 +97,37 @@ def test_gaussianblur_any_sigma_rolling_path(cv, orc, cn, ksize):
         assert np.array_equal(cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy(), orc.orc_sepSmoothFixedU8(src, kx, ky, border)), border
 
 
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_gaussian_long_kernels(cv, orc, cn):
+    """cv::GaussianBlur on CV_8U with 11 .. 129 taps (sigma 1.7 .. 21: beyond the register-rolling kernels' 9 taps) on the LDS-ring kernel's Q8.8 mode (seplong.hip) --
+    one pass per axis instead of the nx * ny gathers per byte of the kernel it replaces --, up to mi355cv_limit("gauss8u_max_ksize") and refused above it; the restatement
+    is pinned to the reference at these lengths in tests/test_oracle_smooth.py"""
+    from opencv_amd import _lib
+    rng = np.random.default_rng(5 + cn)
+    top = cv.limit("gauss8u_max_ksize")
+    for (w, h) in [(1000, 300), (53, 37), (64, 1)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for (kw, kh, sigma) in [(19, 19, 3.0), (11, 27, 2.0), (33, 33, 5.5), (61, 25, 10.0), (top, 65, 21.0)]:
+            if kw > 33 and w == 1000 and cn > 1:
+                continue
+            kx = [int(v) for v in orc.orc_getGaussianKernelQ(kw, sigma)]; ky = [int(v) for v in orc.orc_getGaussianKernelQ(kh, sigma)]
+            for border in (0, 1, 2, 4):
+                got = cv.GaussianBlur(_dev(src), (kw, kh), sigma, sigma, border).cpu().numpy()
+                assert "k_seplong<3," in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+                assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (w, h, cn, kw, kh, sigma, border)
+    src = np.full((40, 200, cn) if cn > 1 else (40, 200), 255, np.uint8)
+    assert (cv.GaussianBlur(_dev(src), (65, 65), 11.0).cpu().numpy() == 255).all()
+    with pytest.raises(NotImplementedError):
+        cv.GaussianBlur(_dev(src), (top + 2, top + 2), 25.0)
+    # CV_32F / CV_16U at the float bound (the separable hook's): the hook serves what it declined beyond 33 taps until round 6
+    if cn == 1:
+        f = rng.uniform(0, 1, (200, 333)).astype(np.float32)
+        n = cv.limit("gauss_float_max_ksize")
+        k = np.asarray(cv.getGaussianKernel(n, 21.0, cv.CV_32F)).ravel()
+        got = cv.GaussianBlur(_dev(f), (n, n), 21.0).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), orc.orc_sepFilter2D(f, -1, k, k).view(np.uint32))
+
+
 def test_non_isolated_margins(cv, orc):
     """ROI inside a larger image: borders read the real neighbours (hal margins contract)."""
     rng = np.random.default_rng(7)

@@ -44,7 +44,7 @@ def test_median_declines_what_it_does_not_cover(cv):
     with pytest.raises(NotImplementedError):
         cv.medianBlur(torch.zeros((20, 40, 2), dtype=torch.uint8, device="cuda"), 7)         # the reference asserts cn 1 / 3 / 4 for its CV_8U histogram forms
     with pytest.raises(NotImplementedError):
-        cv.medianBlur(torch.zeros((40, 40), dtype=torch.uint8, device="cuda"), 33)
+        cv.medianBlur(torch.zeros((40, 40), dtype=torch.uint8, device="cuda"), cv.limit("median8u_max_ksize") + 2)
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.int16, np.float32])

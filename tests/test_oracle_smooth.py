@@ -121,3 +121,25 @@ def test_oracle_sigma_path_matches_real_reference(orc, ref, cn):
                 ky = orc.orc_getGaussianKernelQ(kkh, max(sy, 0))
                 got = orc.orc_sepSmoothFixedU8(src, kx, ky, border)
                 assert np.array_equal(got, want), (kw, kh, s1, s2, border)
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_oracle_sigma_path_long_kernels_match_real_reference(orc, ref, cn):
+    """the same for the kernel lengths the LDS-ring kernel serves since round 6 (11 .. 129 taps: cv::GaussianBlur on CV_8U with sigma >= 1.7 is an everyday call),
+    on images larger and smaller than the kernel"""
+    for (w, h) in [(200, 150), (40, 23)]:
+        shape = (h, w, cn) if cn > 1 else (h, w)
+        src = orc.ref_rng_fill(shape, np.uint8, 99 + w, 0, 256)
+        for (kw, kh, s1, s2) in [(0, 0, 3.0, 0), (33, 33, 5.5, 0), (0, 0, 10.0, 4.0), (129, 65, 20.0, 0), (19, 19, 0, 0)]:
+            if max(kw, kh, int(s1 * 6 + 1)) // 2 >= min(w, h) and cn == 3:
+                continue
+            for border in (0, 1, 2, 4):
+                want = orc.ref_GaussianBlur(src, (kw, kh), s1, s2, border | 16)
+                sy = s2 if s2 > 0 else s1
+                kkw = kw if kw > 0 else (int(np.rint(s1 * 6 + 1)) | 1)
+                kkh = kh if kh > 0 else (int(np.rint(sy * 6 + 1)) | 1)
+                kx = orc.orc_getGaussianKernelQ(kkw, max(s1, 0))
+                ky = orc.orc_getGaussianKernelQ(kkh, max(sy, 0))
+                assert sum(kx) == 256 and sum(ky) == 256
+                got = orc.orc_sepSmoothFixedU8(src, kx, ky, border)
+                assert np.array_equal(got, want), (kw, kh, s1, s2, border)

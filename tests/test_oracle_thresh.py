@@ -79,6 +79,13 @@ def test_adaptive_threshold_gaussian_and_large_blocks_match_reference(ref):
                 want = O.ref_adaptiveThreshold(img, 200.0, 0, 0, bs, 1.5)
                 got = O.orc_adaptiveThreshold(img, 200.0, 0, bs, 1.5)
                 assert np.array_equal(got, want), ("mean", shape, bs)
+            if shape in [(37, 61), (150, 333)]:
+                # the block sizes the GPU path serves since rounds 5 / 6 (35 .. 129 Gaussian, up to 255 mean): tests/test_thresh_gpu.py asserts parity at exactly these
+                for bs in (35, 65, 101, 129):
+                    for ttype, C in ((0, 0.0), (1, -3.5)):
+                        assert np.array_equal(O.orc_adaptiveThreshold(img, 255.0, ttype, bs, C, method=1), O.ref_adaptiveThreshold(img, 255.0, 1, ttype, bs, C)), ("gaussian", shape, bs, ttype)
+                for bs in (101, 255):
+                    assert np.array_equal(O.orc_adaptiveThreshold(img, 200.0, 0, bs, 1.5), O.ref_adaptiveThreshold(img, 200.0, 0, 0, bs, 1.5)), ("mean", shape, bs)
 
 
 @pytest.mark.ref

@@ -144,7 +144,7 @@ def test_orb_declines_and_errors(cv, orc):
     with pytest.raises(ValueError):
         cv.ORB_create(firstLevel=-1)
     with pytest.raises(NotImplementedError):
-        cv.ORB_create(nlevels=40).detect(img)
+        cv.ORB_create(nlevels=cv.limit("orb_max_levels") + 1).detect(img)
     with pytest.raises(ValueError):
         cv.ORB_create().detect(img.to(torch.float32))
     k, d = cv.ORB_create().detectAndCompute(np.zeros((0, 0), np.uint8))

@@ -72,8 +72,23 @@ def test_adaptive_threshold(cv, orc):
             want = orc.orc_adaptiveThreshold(src, 200.0, 0, bs, 1.5)
             assert np.array_equal(cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 200.0, cv.ADAPTIVE_THRESH_MEAN_C, 0, bs, 1.5).cpu().numpy(), want), ("mean", shape, bs)
     assert np.array_equal(cv.adaptiveThreshold(src, 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 7, 2.0), orc.orc_adaptiveThreshold(src, 255.0, 0, 7, 2.0, method=1))   # host pointers
-    with pytest.raises(NotImplementedError):                      # more taps than the separable hook's context holds
-        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, 101, 0.0)
+    # blocks of 35 .. 129: the float blur runs on the LDS-ring separable kernel (seplong.hip); restatement pinned to thresh.cpp:1692-1727 in tests/test_oracle_thresh.py
+    top = cv.limit("adaptive_gaussian_max_block")
+    assert top == 129                                             # a wider bound needs parity cases up to it (tests/test_declines_cpu.py holds the same number)
+    for shape in [(150, 333), (37, 61), (5, 9)]:
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        for bs in (35, 65, 101, top):
+            for ttype, C in ((0, 0.0), (1, -3.5)):
+                want = orc.orc_adaptiveThreshold(src, 255.0, ttype, bs, C, method=1)
+                got = cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, ttype, bs, C).cpu().numpy()
+                assert np.array_equal(got, want), ("gaussian", shape, bs, ttype, C)
+    with pytest.raises(NotImplementedError):                      # beyond the separable hook's tap bound: refused, never a CPU path
+        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 255.0, cv.ADAPTIVE_THRESH_GAUSSIAN_C, 0, top + 2, 0.0)
+    for bs in (101, cv.limit("adaptive_mean_max_block")):         # MEAN_C up to its own bound
+        src = rng.integers(0, 256, (150, 333), dtype=np.uint8)
+        assert np.array_equal(cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 200.0, cv.ADAPTIVE_THRESH_MEAN_C, 0, bs, 1.5).cpu().numpy(), orc.orc_adaptiveThreshold(src, 200.0, 0, bs, 1.5)), bs
+    with pytest.raises(NotImplementedError):
+        cv.adaptiveThreshold(torch.from_numpy(src).cuda(), 200.0, cv.ADAPTIVE_THRESH_MEAN_C, 0, cv.limit("adaptive_mean_max_block") + 2, 1.5)
 
 
 def test_gaussian_c_float_blur_bits(cv, orc):
@@ -81,7 +96,7 @@ def test_gaussian_c_float_blur_bits(cv, orc):
     the reference's, tests/test_oracle_thresh.py): the rounded mean cannot differ by a tie"""
     rng = np.random.default_rng(7)
     src = rng.integers(0, 256, (257, 333), dtype=np.uint8).astype(np.float32)
-    for bs in (3, 5, 7, 11, 21, 33):
+    for bs in (3, 5, 7, 11, 21, 33, 65, 129):
         k = cv.getGaussianKernel(bs, 0.0, 5)
         got = cv.sepFilter2D(torch.from_numpy(src).cuda(), -1, k, k, borderType=1 | 16).cpu().numpy()
         want = orc.orc_sepFilter2D(src, 5, k, k, border=1)
