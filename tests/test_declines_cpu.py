@@ -119,7 +119,7 @@ def test_capacity_bounds_are_the_ones_the_gpu_suite_covers():
             if "pytest.raises(NotImplementedError)" in l:
                 body = " ".join(lines[i + 1:i + 3])
                 for k, v in want.items():
-                    if v < 100 and k not in ("sep_max_taps_64f", "orb_max_levels"):
+                    if v < 100:
                         continue                                                         # small numbers occur as image sizes; the large bounds are unambiguous
                     if re.search(r"\b(%d|%d)\b" % (v + 1, v + 2), body) and "limit(" not in body:
                         stale.append((os.path.basename(f), i + 1, k))
