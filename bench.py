@@ -172,6 +172,13 @@ def other_configs(with_cpu=True):
     cpu["cfg4b"] = t(pyr)
     tpl = rng.integers(0, 256, (128, 128), dtype=np.uint8)
     cpu["cfg5"] = t(lambda: orc.ref_matchTemplate(gray, tpl, 3), reps=1)
+    # the long separable kernels (seplong.hip): cv::GaussianBlur sigma 3 / 5.5 on CV_8U (19 / 33 taps), sigma 16 / 3 on CV_32F with 97 / 19 taps
+    cpu["gs3"] = t(lambda: orc.ref_GaussianBlur(gray, (19, 19), 3.0, 3.0, 4))
+    cpu["gs3c3"] = t(lambda: orc.ref_GaussianBlur(bgr, (19, 19), 3.0, 3.0, 4))
+    cpu["gs5"] = t(lambda: orc.ref_GaussianBlur(gray, (33, 33), 5.5, 5.5, 4))
+    f4k = np.ascontiguousarray(f8k[:H4K, :W4K])
+    cpu["gs16"] = t(lambda: orc.ref_GaussianBlur(f4k, (97, 97), 16.0, 16.0, 4), reps=1)
+    cpu["gs3f"] = t(lambda: orc.ref_GaussianBlur(f4k, (19, 19), 3.0, 3.0, 4))
     try:
         rows += next_rows(orc, t, gray, bgr, hd)
     except Exception as e:                                      # reported rows only: never lose the headline line over them
@@ -299,7 +306,8 @@ def compact_summary(rows):
              "a8 warpAffine 4K 8UC1": "affine_8uc1", "a8 warpAffine 4K 8UC3": "affine_8uc3", "a9 warpPerspective 4K 8UC1": "persp_8uc1", "a9 warpPerspective 4K 8UC3": "persp_8uc3",
              "f1 integral 4K 8U -> 32S batch": "integral", "a7 resize 1080p 8UC3 -> 4K bilinear": "up2x_lin_8uc3", "a7 resize 1080p 8UC3 -> 4K INTER_CUBIC": "up2x_cubic_8uc3",
              "f2 warpAffine 4K 8UC1 rot 7deg INTER_CUBIC": "affine_cubic_8uc1", "f2 warpAffine 4K 8UC1 rot 7deg INTER_LANCZOS4": "affine_lanczos_8uc1",
-             "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
+             "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "gs3 GaussianBlur": "gauss_sigma3_8uc1", "gs3c3 GaussianBlur": "gauss_sigma3_8uc3",
+             "gs16 GaussianBlur": "gauss_sigma16_32f", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
     for r in rows if isinstance(rows, list) else []:
         c = r.get("config", "")
         key = c.split()[0] if c.split() and c.split()[0] in SUMMARY_KEYS else next((v for k, v in short.items() if c.startswith(k)), None)
@@ -312,6 +320,8 @@ def compact_summary(rows):
             out[key] = [r.get("us_per_frame"), r.get("Mpix_s"), r.get("pcie_GBs_both_ways")]
         elif ms is not None:
             out[key] = [round(ms / fr * 1e3, 2) if "ms" in r else round(ms * 1e3, 2), frac]
+            if key.startswith("gauss_sigma") and "cpu_reference_ms_per_frame" in r:      # the long separable kernels: the reference's CPU time per frame beside them, in us
+                out[key].append(round(r["cpu_reference_ms_per_frame"] * 1e3, 1))
             if "ms_per_frame_after_the_other_rows" in r:         # cfg5 (clock-bound): timed first and again last
                 out[key] += [round(r["ms_per_frame_after_the_other_rows"] * 1e3, 2), r.get("frac_of_i8_dense_peak_after_the_other_rows")]
     return out

@@ -188,6 +188,11 @@ MI355CV_API int mi355cv_sepSmoothFixedU8(const mi355cv_uchar* src_data, size_t s
 /* Batched form (frames are independent units): `nframes` images of identical
  * geometry, frame f at src_data + f*src_frame_stride; one launch, grid-z = frame.  Host-resident batches: the chunked two-buffer pipeline (see the
  * batch section below). */
+/* the same for any sigma (the Q8.8 taps cv::GaussianBlur computes for CV_8U, smooth.dispatch.cpp:658-724), device-resident frames only, kernel sizes odd and at most
+ * mi355cv_limit("gauss8u_max_ksize") */
+MI355CV_API int mi355cv_gaussianBlurBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
+        mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes, int width, int height, int depth, int cn,
+        size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type);
 MI355CV_API int mi355cv_gaussianBlurBinomialBatch(const mi355cv_uchar* src_data, size_t src_step, size_t src_frame_stride,
         mi355cv_uchar* dst_data, size_t dst_step, size_t dst_frame_stride, int nframes,
         int width, int height, int depth, int cn, size_t ksize, int border_type);

@@ -93,6 +93,7 @@ def _load():
                                          c_sz, c_sz, c_sz, c_sz, c_sz, c_sz, c_dbl, c_dbl, c_int]),
         "mi355cv_getGaussianKernel": (c_int, [c_int, c_dbl, ctypes.c_void_p]),
         "mi355cv_getGaussianKernelQ": (c_int, [c_int, c_dbl, c_int, ctypes.c_void_p]),
+        "mi355cv_gaussianBlurBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int, c_int, c_int, c_int, c_int, c_sz, c_sz, c_dbl, c_dbl, c_int]),
         "mi355cv_gaussianBlurBinomialBatch": (c_int, [c_u8p, c_sz, c_sz, c_u8p, c_sz, c_sz, c_int,
                                                       c_int, c_int, c_int, c_int, c_sz, c_int]),
         "mi355cv_filterInit": (c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, c_sz, c_int, c_int, c_int, c_int, c_int,

@@ -893,6 +893,31 @@ MI355CV_API int mi355cv_gaussianBlur(const uchar* src_data, size_t src_step, uch
                      kx, (int)ksize_width, ky, (int)ksize_height, border_type & ~MI355CV_BORDER_ISOLATED, binom);
 }
 
+// cv::GaussianBlur on CV_8U with any sigma over a batch of device-resident whole frames (no reference counterpart: SURVEY section 8e, frames are independent units): the
+// Q8.8 taps of getGaussianKernelFixedPoint_ED once, then ONE launch with the frames along the grid -- the register-rolling kernels up to 9 taps, the LDS-ring kernel beyond
+MI355CV_API int mi355cv_gaussianBlurBatch(const uchar* src_data, size_t src_step, size_t src_frame_stride, uchar* dst_data, size_t dst_step, size_t dst_frame_stride,
+        int nframes, int width, int height, int depth, int cn, size_t ksize_width, size_t ksize_height, double sigmaX, double sigmaY, int border_type)
+{
+    mi355::EntryGuard entry_(__func__);
+    if (depth != MI355CV_8U) return mi355::declined(__func__, __LINE__, "depth != MI355CV_8U");
+    if (nframes < 1 || !(ksize_width & 1) || !(ksize_height & 1) || ksize_width > (size_t)lim::GAUSS8U_MAX_KSIZE || ksize_height > (size_t)lim::GAUSS8U_MAX_KSIZE)
+        return mi355::declined(__func__, __LINE__, "nframes < 1 || even kernel size || ksize > lim::GAUSS8U_MAX_KSIZE");
+    if (sigmaY <= 0) sigmaY = sigmaX;
+    std::vector<int64_t> qx, qy;
+    if (!gaussianKernelFixedQ((int)ksize_width, sigmaX > 0 ? sigmaX : 0, 8, qx) || !gaussianKernelFixedQ((int)ksize_height, sigmaY > 0 ? sigmaY : 0, 8, qy))
+        return mi355::declined(__func__, __LINE__, "!gaussianKernelFixedQ");
+    uint16_t kx[lim::GAUSS8U_MAX_KSIZE], ky[lim::GAUSS8U_MAX_KSIZE];
+    for (size_t i = 0; i < ksize_width; i++) { if (qx[i] < 0 || qx[i] > 65535) return mi355::declined(__func__, __LINE__, "qx[i] < 0 || qx[i] > 65535"); kx[i] = (uint16_t)qx[i]; }
+    for (size_t i = 0; i < ksize_height; i++) { if (qy[i] < 0 || qy[i] > 65535) return mi355::declined(__func__, __LINE__, "qy[i] < 0 || qy[i] > 65535"); ky[i] = (uint16_t)qy[i]; }
+    bool binom = ksize_width == ksize_height && (ksize_width == 3 || ksize_width == 5);
+    if (binom) {
+        const uint16_t* b = binomTaps(ksize_width);
+        for (size_t i = 0; i < ksize_width; i++) if (kx[i] != b[i] || ky[i] != b[i]) binom = false;
+    }
+    return runSmooth("gaussianBlurBatch", src_data, src_step, nframes > 1 ? src_frame_stride : 0, dst_data, dst_step, nframes > 1 ? dst_frame_stride : 0, nframes, width, height, cn,
+                     0, 0, 0, 0, kx, (int)ksize_width, ky, (int)ksize_height, border_type & ~MI355CV_BORDER_ISOLATED, binom);
+}
+
 // tuning knobs for experiments (tools/tune_gauss.py): "gauss_seg" rows per work item (0 = heuristic),
 // "gauss_variant" 1|2|3
 MI355CV_API int mi355cv_setParam(const char* key, int value)

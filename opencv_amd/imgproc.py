@@ -158,7 +158,7 @@ def sepSmoothFixedU8(src, kx, ky, borderType=BORDER_DEFAULT, dst=None, margins=(
     return out
 
 
-def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None):
+def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None, sigmaX=0.0, sigmaY=0.0):
     """N independent frames [N,H,W(,C)] resident in HBM, one launch (frames shard, never split).  Frames in HOST memory (a CPU tensor,
     ideally page-locked) take the library's pipelined path: chunks cross PCIe through two sets of device buffers, upload / filter / download overlapped."""
     if torch is None or not isinstance(frames, torch.Tensor):
@@ -185,6 +185,16 @@ def GaussianBlurBatch(frames, ksize, borderType=BORDER_DEFAULT, dst=None):
     k = ksize if isinstance(ksize, int) else ksize[0]
     s0, d0 = Img(frames[0]), Img(out[0])
     bind_stream(s0, d0)
+    if sigmaX > 0 or sigmaY > 0 or not isinstance(ksize, int):
+        # any sigma: cv::GaussianBlur's kernel-size rule for CV_8U (createGaussianKernels, smooth.dispatch.cpp:270-276: cvRound(sigma * 3 * 2 + 1) | 1) and its Q8.8 taps
+        kw, kh = (ksize, ksize) if isinstance(ksize, int) else ksize
+        sy = sigmaY if sigmaY > 0 else sigmaX
+        if kw <= 0 and sigmaX > 0: kw = int(np.rint(sigmaX * 6 + 1)) | 1
+        if kh <= 0 and sy > 0: kh = int(np.rint(sy * 6 + 1)) | 1
+        rc = L.mi355cv_gaussianBlurBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)), _vp(d0.ptr), d0.step, int(out.stride(0)), n, w, h, CV_8U, cn, kw, kh,
+                                         float(sigmaX), float(sigmaY), borderType & ~BORDER_ISOLATED)
+        _lib.check(rc, "gaussianBlurBatch")
+        return out
     rc = L.mi355cv_gaussianBlurBinomialBatch(_vp(s0.ptr), s0.step, int(frames.stride(0)), _vp(d0.ptr), d0.step,
                                              int(out.stride(0)), n, w, h, CV_8U, cn, k, borderType & ~BORDER_ISOLATED)
     _lib.check(rc, "gaussianBlurBinomialBatch")

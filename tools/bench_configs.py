@@ -247,6 +247,10 @@ def run(quick=False, parity=True):
     kxb = np.array([0.25, 0.5, 0.25], np.float32)
     bline("a4 sepFilter2D 3x3 (1/4,1/2,1/4) 4K 8U batch", lambda: cv.sepFilter2DBatch(gray, -1, kxb, kxb, dst=dstb), PIX4 * 2)
     bline("f1 threshold BINARY 4K 8U batch", lambda: cv.thresholdBatch(gray, 127, 255, 0, dst=dstb), PIX4 * 2)
+    # long separable kernels on the LDS-ring kernel (seplong.hip): cv::GaussianBlur with sigma 3 on CV_8U = 19 Q8.8 taps per axis
+    bline("gs3 GaussianBlur sigma 3 (19 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (19, 19), dst=dstb, sigmaX=3.0), PIX4 * 2)
+    bline("gs3c3 GaussianBlur sigma 3 (19 taps) 4K 8UC3 batch", lambda: cv.GaussianBlurBatch(bgr[:48], (19, 19), dst=bgr[48:96], sigmaX=3.0), PIX4 * 6, 48)
+    bline("gs5 GaussianBlur sigma 5.5 (33 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (33, 33), dst=dstb, sigmaX=5.5), PIX4 * 2)
     BH = frames_for(PIX4 + PIX4 // 4, 16)
     half = torch.empty((BH, 1080, 1920), dtype=torch.uint8, device=dev)
     g2 = gray if BH <= B2 else torch.randint(0, 256, (BH, H4, W4), dtype=torch.uint8, device=dev, generator=g)
@@ -383,6 +387,14 @@ def run(quick=False, parity=True):
             hbm_row(name, BF, ms, BF * PIX4 * 8)
         except Exception as e:
             out.append({"config": name, "error": repr(e)})
+    try:
+        g97 = np.asarray(cv.getGaussianKernel(97, 16.0, cv.CV_32F)).ravel(); g19 = np.asarray(cv.getGaussianKernel(19, 3.0, cv.CV_32F)).ravel()
+        ms = timeit(lambda: cv.sepFilter2DBatch(f32, -1, g97, g97, dst=o32), max(3, N // 4), 2)
+        hbm_row("gs16 GaussianBlur sigma 16 (97 taps) 4K 32FC1 batch", BF, ms, BF * PIX4 * 8, {"ms_per_frame": round(ms / BF, 4)})
+        ms = timeit(lambda: cv.sepFilter2DBatch(f32, -1, g19, g19, dst=o32), max(3, N // 4), 2)
+        hbm_row("gs3f GaussianBlur sigma 3 (19 taps) 4K 32FC1 batch", BF, ms, BF * PIX4 * 8, {"ms_per_frame": round(ms / BF, 4)})
+    except Exception as e:
+        out.append({"config": "gs16 / gs3f", "error": repr(e)})
     del f32, o32
     torch.cuda.empty_cache()
     # CV_16SC1 sources on the rolling kernels (72 frames: 4 B / px x 72 x 4K = 2.4 GB per pass)

@@ -22,6 +22,7 @@
 #   shift            tools/probes/shift.hip: a bilinear-tap pure shift of 8K float frames in k_warp_lin's geometry and in wider / row-walking ones
 #   ab <row> <settings..>  tools/env_ab.py: one bench row under several environment settings, each in its own process (last recipe on the line)
 #   integral-ordered tools/integral_ordered_time.py: us per call of cv::integral on one 4K image for the depth triples of integral_seq.hip, + rocprofv3 kernel stats of the same script
+#   seplong          tools/seplong_bench.py: the LDS-ring separable kernel (11 .. 129 taps) on 4K frames beside the reference's CPU time
 #   refsuite         the reference's own opencv_test_imgproc on the hooks (Makefile build and cmake build) with the decline ledger
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 while [ $# -gt 0 ]; do
@@ -59,6 +60,7 @@ PY
                ks=$(find /tmp/${T}_prof -name "*kernel_stats.csv" | head -1); [ -n "$ks" ] && head -24 "$ks" | grep iseq | cut -c1-260 >> $O/${T}.txt ;;
     mix2)      (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 mix2.hip -o /tmp/mix2 2>/dev/null) && timeout 200 /tmp/mix2 | tee $O/${T}.txt ;;
     shift)     (cd tools/probes && /opt/rocm/bin/hipcc -O3 -Wno-unused-result --offload-arch=gfx950 shift.hip -o /tmp/shift 2>/dev/null) && timeout 200 /tmp/shift | tee $O/${T}.txt ;;
+    seplong)   timeout 600 python tools/seplong_bench.py > $O/${T}.txt 2>&1; cat $O/${T}.txt | cut -c1-400 ;;
     ab)        # ab <row> <setting> [<setting> ...]  (tools/env_ab.py; must be the last recipe on the line; "" = defaults)
                timeout 900 python tools/env_ab.py "$@" 2>&1 | tee -a $O/${T}.txt; break ;;
     *)         echo "unknown recipe $rec"; exit 2 ;;
