@@ -24,10 +24,11 @@ namespace {
 typedef seplong::Geom LongGeom;
 using seplong::RB;
 
-template <int MODE, int CN>
+template <int MODE, int CN, bool LONG>
 __global__ __launch_bounds__(256) void k_seplong(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                  LongGeom g, const uint32_t* __restrict__ taps)
 {
+    constexpr int MMAX = seplong::StageOf<CN, LONG>::MMAX;
     extern __shared__ uint4 lds4[];
     uint32_t* S = reinterpret_cast<uint32_t*>(lds4);                       // [RB][CN][SP]
     uint32_t* ring = S + RB * CN * g.SP;                                   // [NR][CN][RP]
@@ -39,12 +40,15 @@ __global__ __launch_bounds__(256) void k_seplong(const uchar* __restrict__ src, 
     const uint32_t* kx = taps;
     const uint32_t* ky = taps + g.nx;
     const uint32_t* kyS = taps + g.nx + g.ny;                              // mode 1: float(ky) * 2^-16
+    uint32_t v[seplong::RPW * MMAX];                                       // the step's source elements on their way from HBM to LDS
+    seplong::stageLoad<MODE, CN, MMAX>(g, sg, 0, src, sstep, tid, v);
     int done = 0;
     for (int j = 0; j < sg.nsteps; j++) {
-        seplong::stage<MODE, CN>(g, sg, j, src, sstep, S, tid);
+        seplong::stageStore<CN, MMAX>(g, sg, j, S, tid, v);
+        if (j + 1 < sg.nsteps) seplong::stageLoad<MODE, CN, MMAX>(g, sg, j + 1, src, sstep, tid, v);      // in flight while step j is filtered
         __syncthreads();
         seplong::rowPass<MODE, CN>(g, sg, j, S, ring, kx, tid);
-        __syncthreads();
+        __syncthreads();                                                   // (also: every lane is done with S before the next stageStore)
         const int newDone = seplong::doneAfter<CN>(g, sg, j);
         seplong::colPass<MODE, CN>(g, sg, done, newDone, ring, ky, kyS, dst, dstep, tid);
         done = newDone;
@@ -52,13 +56,15 @@ __global__ __launch_bounds__(256) void k_seplong(const uchar* __restrict__ src, 
 }
 
 template <int MODE>
-void launchLong(int cn, dim3 grid, size_t lds, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const LongGeom& g, const uint32_t* taps)
+void launchLong(int cn, bool lng, dim3 grid, size_t lds, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const LongGeom& g, const uint32_t* taps)
 {
-#define LAUNCH_(CN_) do { \
+#define LAUNCH_(CN_, L_) do { \
         static bool attr[64] = {}; const int dv = activeDevice() & 63; \
-        if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seplong<MODE, CN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
-        hipLaunchKernelGGL((k_seplong<MODE, CN_>), grid, dim3(256), lds, st, src, sstep, sframe, dst, dstep, dframe, g, taps); } while (0)
-    switch (cn) { case 1: LAUNCH_(1); break; case 2: LAUNCH_(2); break; case 3: LAUNCH_(3); break; default: LAUNCH_(4); }
+        if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seplong<MODE, CN_, L_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
+        hipLaunchKernelGGL((k_seplong<MODE, CN_, L_>), grid, dim3(256), lds, st, src, sstep, sframe, dst, dstep, dframe, g, taps); } while (0)
+#define LAUNCHC_(CN_) do { if (lng) LAUNCH_(CN_, true); else LAUNCH_(CN_, false); } while (0)
+    switch (cn) { case 1: LAUNCHC_(1); break; case 2: LAUNCHC_(2); break; case 3: LAUNCHC_(3); break; default: LAUNCHC_(4); }
+#undef LAUNCHC_
 #undef LAUNCH_
 }
 
@@ -99,13 +105,14 @@ bool seplongRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, ucha
     const uint32_t* dt = static_cast<const uint32_t*>(stg.param(tb.data(), tb.size() * 4));
     if (!dt) return false;
     const dim3 grid(nstrips, nseg, nframes);
+    const bool lng = t.nx > 33;                                            // the staged row is (TP + nx - 1) * cn elements wide: registers per lane follow the class
     switch (t.mode) {
-    case 0:  launchLong<0>(cn, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    case 1:  launchLong<1>(cn, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    case 2:  launchLong<2>(cn, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    default: launchLong<3>(cn, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    case 0:  launchLong<0>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    case 1:  launchLong<1>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    case 2:  launchLong<2>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    default: launchLong<3>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
     }
-    noteKernel("k_seplong<%d,%d> grid=%ux%ux%u x256 lds=%zu taps=%dx%d seg=%d", t.mode, cn, grid.x, grid.y, grid.z, lds, t.nx, t.ny, seg);
+    noteKernel("k_seplong<%d,%d,%d> grid=%ux%ux%u x256 lds=%zu taps=%dx%d seg=%d", t.mode, cn, (int)lng, grid.x, grid.y, grid.z, lds, t.nx, t.ny, seg);
     return true;
 }
 

@@ -121,27 +121,57 @@ template <int CN> struct Seg {
     }
 };
 
-// ---- 1. stage: a wave per row, lanes along the interleaved elements (coalesced), planes in LDS
-template <int MODE, int CN>
-SL_HD void stage(const Geom& g, const Seg<CN>& sg, int step, const unsigned char* src, size_t sstep, uint32_t* S, int tid)
+// ---- 1. stage: a wave per row, lanes along the interleaved elements (coalesced), planes in LDS.  Two halves so that the loads of step j + 1 can be in flight while
+// step j is filtered: stageLoad issues every load of the step into registers (RPW rows x MMAX elements per lane, nothing depends on them), stageStore parks them in LDS.
+// (The first version loaded and stored element by element: 12 dependent global-load latencies per step and nothing else to do meanwhile -- 56 us per 4K frame for 19
+// taps, profiles/r06_seplong_first_run_latency_bound.txt.)
+constexpr int RPW = RB / 4;                                       // rows per wave and step
+// elements per lane and row: the widest staged row is (TP + nx - 1) * CN elements; LONG = kernels beyond 33 taps
+template <int CN, bool LONG> struct StageOf { static constexpr int NXMAX = LONG ? 129 : 33, MMAX = ((StripOf<CN>::TP + NXMAX - 1) * CN + 63) / 64; };
+
+template <int MODE, int CN, int MMAX>
+SL_HD void stageLoad(const Geom& g, const Seg<CN>& sg, int step, const unsigned char* src, size_t sstep, int tid, uint32_t (&v)[RPW * MMAX])
 {
     const int wv = tid >> 6, ln = tid & 63;
     const int n0 = step * RB, rlim = imin(RB, sg.nsrc - n0);
-    for (int r = wv; r < rlim; r += 4) {
-        const int yy = border(sg.y0 - g.ay + n0 + r + g.offY, g.fullH, g.border);
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+        const int r = wv + 4 * i;
+        const int yy = r < rlim ? border(sg.y0 - g.ay + n0 + r + g.offY, g.fullH, g.border) : -1;
         const unsigned char* row = src + (ptrdiff_t)((yy < 0 ? g.offY : yy) - g.offY) * (ptrdiff_t)sstep;
-        uint32_t* Sr = S + r * CN * g.SP;
-        for (int q = ln; q < sg.spn; q += 64) {
-            const int po = q / CN, c = q - po * CN;
-            const int fp = sg.fx0 + po;
-            const int xx = sg.xin ? fp : border(fp, g.fullW, g.border);
-            uint32_t v = 0;
-            if (yy >= 0 && xx >= 0) {
-                const int idx = (xx - g.offX) * CN + c;
-                if constexpr (MODE == 0) v = f2u(ldSrcF(row, idx, g.sdepth));
-                else v = row[idx];
+#pragma unroll
+        for (int m = 0; m < MMAX; m++) {
+            const int q = ln + 64 * m;
+            uint32_t val = 0;
+            if (yy >= 0 && q < sg.spn) {
+                const int po = q / CN, c = q - po * CN;
+                const int fp = sg.fx0 + po;
+                const int xx = sg.xin ? fp : border(fp, g.fullW, g.border);
+                if (xx >= 0) {
+                    const int idx = (xx - g.offX) * CN + c;
+                    if constexpr (MODE == 0) val = f2u(ldSrcF(row, idx, g.sdepth));
+                    else val = row[idx];
+                }
             }
-            Sr[c * g.SP + po] = v;
+            v[i * MMAX + m] = val;
+        }
+    }
+}
+
+template <int CN, int MMAX>
+SL_HD void stageStore(const Geom& g, const Seg<CN>& sg, int step, uint32_t* S, int tid, const uint32_t (&v)[RPW * MMAX])
+{
+    const int wv = tid >> 6, ln = tid & 63;
+    const int n0 = step * RB, rlim = imin(RB, sg.nsrc - n0);
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+        const int r = wv + 4 * i;
+        if (r >= rlim) continue;
+        uint32_t* Sr = S + r * CN * g.SP;
+#pragma unroll
+        for (int m = 0; m < MMAX; m++) {
+            const int q = ln + 64 * m;
+            if (q < sg.spn) { const int po = q / CN, c = q - po * CN; Sr[c * g.SP + po] = v[i * MMAX + m]; }
         }
     }
 }
@@ -220,8 +250,8 @@ SL_HD void colPass(const Geom& g, const Seg<CN>& sg, int done, int newDone, cons
     if constexpr (MODE == 0) { pairForm = g.symY != 0; chain = !pairForm; }
     else if constexpr (MODE == 1) { pairForm = g.ny > 1 && e0 < g.vecEnd; chain = g.ny <= 1 || e0 + CN >= g.vecEnd; }
     else { pairForm = false; chain = true; }
-    float fs[4][2] = {};
-    uint32_t is[4][2] = {};
+    float fs[4][2];
+    uint32_t is[4][2];
     if (pairForm) {
         const int half = g.ny / 2;
         V2 C[4], U[4], D[4];
@@ -264,25 +294,34 @@ SL_HD void colPass(const Geom& g, const Seg<CN>& sg, int done, int newDone, cons
         }
     }
     if (chain) {
+        // s = delta, then s = fma(ky[j], r[j], s) for j = 0 .. ny - 1 per output (ColumnFilter: s = ky[0] * r[0] + delta first -- the same value); output o of the lane
+        // takes ring row m as its tap m - o, so rows 3 .. ny - 1 feed all four outputs and only the two ends of the window are guarded
+#pragma unroll
+        for (int o = 0; o < 4; o++) { if constexpr (MODE == 0) fs[o][0] = fs[o][1] = g.deltaF; else is[o][0] = is[o][1] = (uint32_t)g.deltaI; }      // (mode 1 may hold its pair-form floats in fs)
         int i = r0 % NR;
-        for (int m = 0; m < g.ny + 3; m++) {
+        auto tapRow = [&](int m, bool guarded) {
             const V2 v = ld(i);
             i = inc(i);
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int jj = m - o;
-                if (jj >= 0 && jj < g.ny) {
+                if (!guarded || (jj >= 0 && jj < g.ny)) {
                     const uint32_t k = ky[jj];
                     if constexpr (MODE == 0) {
-                        fs[o][0] = __builtin_fmaf(u2f(k), u2f(v.x), jj == 0 ? g.deltaF : fs[o][0]);
-                        fs[o][1] = __builtin_fmaf(u2f(k), u2f(v.y), jj == 0 ? g.deltaF : fs[o][1]);
+                        fs[o][0] = __builtin_fmaf(u2f(k), u2f(v.x), fs[o][0]);
+                        fs[o][1] = __builtin_fmaf(u2f(k), u2f(v.y), fs[o][1]);
                     } else {
-                        is[o][0] = imad<MODE>(k, v.x, jj == 0 ? (uint32_t)g.deltaI : is[o][0]);
-                        is[o][1] = imad<MODE>(k, v.y, jj == 0 ? (uint32_t)g.deltaI : is[o][1]);
+                        is[o][0] = imad<MODE>(k, v.x, is[o][0]);
+                        is[o][1] = imad<MODE>(k, v.y, is[o][1]);
                     }
                 }
             }
-        }
+        };
+        const int m1 = imin(3, g.ny + 3), m2 = imax(g.ny, m1);
+        for (int m = 0; m < m1; m++) tapRow(m, true);
+#pragma unroll 4
+        for (int m = m1; m < g.ny; m++) tapRow(m, false);
+        for (int m = m2; m < g.ny + 3; m++) tapRow(m, true);
     }
 #pragma unroll
     for (int o = 0; o < 4; o++) {

@@ -2083,6 +2083,137 @@ __global__ __launch_bounds__(256) void k_warp32_rest(const uchar* __restrict__ s
     }
 }
 
+// ---- CV_32FC1 bilinear warpAffine, strip walk through an LDS ring of whole source row pieces (BASELINE config 3c, round 6) ---------------------------------------
+// What the probes of round 5 say (profiles/r05_shift_probe.txt, r05_store_geometry_probe.txt): every form that fetches the source as 64-pixel (256-byte) row pieces --
+// the gather kernel and the 64 x 32 LDS tiles alike -- stays at 0.50-0.58 of 8 TB/s with no arithmetic at all; 1 KiB row pieces with each source row fetched ONCE and one
+// 16-byte store per lane reach 0.69-0.74.  This kernel is that shape for a rotated map:
+//   * a workgroup of 8 waves owns a strip of 256 destination columns and walks DOWN a segment of rows, 8 rows per step -- one destination row per wave, 4 consecutive
+//     pixels per lane, ONE 16-byte non-temporal store per lane (1 KiB per wave and row);
+//   * the source rows the strip touches are staged as pieces of WS_PW = 288 floats (1152 bytes: the strip's horizontal footprint, |M0| 256 pixels, plus the drift
+//     over the rows that share a source row) with asynchronous global -> LDS loads (global_load_lds_dwordx4: no staging registers, 1 KiB per wave-instruction) into a ring
+//     of WS_NR = 64 row slots (slot = source row mod 64).  For |rotation| up to ~12 degrees one destination row needs |M3| 256 + 2 <= 55 source rows and each new
+//     destination row about |M4| new ones: every source byte the strip needs is fetched once per segment;
+//   * the row pieces of step j + 1 are requested after the taps of step j have been read (LDS -> registers), and land while step j blends; one s_waitcnt vmcnt(0) +
+//     s_barrier per step, BEFORE the step's stores are issued, so that the stores overlap the next step.
+// The origin of the piece of source row r is bx(r) = ((r H + C) >> 15) & ~3, a linear bound of the leftmost source column any pixel of the strip reads on that row.  It
+// only has to be right in almost every case: a tap whose row is not resident or whose columns fall outside its row's piece (and every pixel whose 2 x 2 footprint is not
+// strictly inside the source) is evaluated from global memory by the generic sampler.  The arithmetic per pixel is k_warp_lin's -- the reference's (imgwarp.cpp:2233-2298
+// coordinates in 1/1024 rounded to 1/32, remapBilinear<Cast<float, float>> :675-904 weights and summation order) -- so results are bit-identical to it.
+constexpr int WS_COLS = 256, WS_NR = 64, WS_PW = 288, WS_WAVES = 8;
+struct StripArgs { int pitch /* floats per ring slot */, segRows, H15; double g, cp; /* bx(r) = ((r H15 + C15(strip)) >> 15) & ~3, C15 from min(g x0, g x1) + cp */ };
+
+__global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w,
+                                                                StripArgs a, const int* __restrict__ terms, const short* __restrict__ tab)
+{
+    extern __shared__ __attribute__((aligned(16))) float ring[];         // WS_NR slots of a.pitch floats
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * WS_COLS, xe = min(x0 + WS_COLS, w.dw) - 1;
+    const int y0 = blockIdx.y * a.segRows, y1 = min(y0 + a.segRows, w.dh) - 1;
+    const int* colX = terms; const int* colY = terms + w.dw; const int* rowX = terms + 2 * w.dw; const int* rowY = rowX + w.dh;
+    // the lane's 4 columns and their terms (columns beyond the image repeat the last one: computed, never stored)
+    const int xl = x0 + 4 * lane;
+    int cx[4], cy[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) { const int xc = min(xl + o, w.dw - 1); cx[o] = colX[xc]; cy[o] = colY[xc]; }
+    const int cYa = colY[x0], cYb = colY[xe];
+    const int cYmin = min(cYa, cYb), cYmax = max(cYa, cYb);
+    // bx(r): origin of source row r's piece
+    const double gx0 = a.g * (double)x0, gx1 = a.g * (double)xe;
+    const int C15 = (int)floor((fmin(gx0, gx1) + a.cp) * 32768.0);
+    auto bxOf = [&](int r) { return ((r * a.H15 + C15) >> 15) & ~3; };
+    const int pitch = a.pitch;
+    // rows [lo, hi] of the source into their ring slots: row lo + i is loaded by wave i % 8; two instructions per row (64 + 8 lanes x 16 bytes)
+    auto request = [&](int lo, int hi) {
+        for (int r = lo + wave; r <= hi; r += WS_WAVES) {
+            if ((unsigned)r >= (unsigned)s.sh) continue;                                        // wave-uniform
+            const int bx = bxOf(r);
+            float* slot = ring + (r & (WS_NR - 1)) * pitch;
+            const uchar* grow = src + (size_t)r * sstep;
+            const int xa = bx + 4 * lane, xb = bx + 256 + 4 * lane;
+            if (xa >= 0 && xa + 3 < s.sw) __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(grow + (size_t)xa * 4), (__attribute__((address_space(3))) uint32_t*)(slot), 16, 0, 0);
+            if (lane < (WS_PW - 256) / 4 && xb >= 0 && xb + 3 < s.sw)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(grow + (size_t)xb * 4), (__attribute__((address_space(3))) uint32_t*)(slot + 256), 16, 0, 0);
+        }
+    };
+    auto topRow = [&](int y) { return ((rowY[min(y, y1)] + cYmax) >> 10) + 1; };               // the last source row destination rows <= y of this segment read (M4 > 0: rows grow with y)
+    // prologue: everything step 0 needs
+    int rlo = (rowY[y0] + cYmin) >> 10;                                                        // first source row of the segment
+    int have = topRow(y0 + WS_WAVES - 1);
+    request(rlo, have);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    for (int yb = y0; yb <= y1; yb += WS_WAVES) {
+        const int y = yb + wave;                                                               // this wave's destination row (wave-uniform)
+        const bool live = y <= y1;
+        const int yc = min(y, y1);
+        const int rX = rowX[yc], rY = rowY[yc];
+        // resident rows for this step: [resLo, have]; resLo also keeps clear of the slots the NEXT request overwrites
+        const int want = topRow(yb + 2 * WS_WAVES - 1);
+        const int resLo = max(max(want - (WS_NR - 1), 0), rlo);
+        const int resHi = min(have, s.sh - 1);
+        // ---- (a) coordinates, addresses, taps LDS -> registers
+        int X[4], Y[4];
+        float p00[4], p01[4], p10[4], p11[4];
+        unsigned slow = 0;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            X[o] = (rX + cx[o]) >> 5; Y[o] = (rY + cy[o]) >> 5;
+            const int sx = X[o] >> 5, sy = Y[o] >> 5;
+            const int cA = sx - bxOf(sy), cB = sx - bxOf(sy + 1);
+            const bool ok = (unsigned)sx < (unsigned)(s.sw - 1) && sy >= resLo && sy + 1 <= resHi && (unsigned)cA <= (unsigned)(WS_PW - 2) && (unsigned)cB <= (unsigned)(WS_PW - 2);
+            if (!ok) slow |= 1u << o;
+            const float* la = ring + (ok ? (sy & (WS_NR - 1)) * pitch + cA : 0);
+            const float* lb = ring + (ok ? ((sy + 1) & (WS_NR - 1)) * pitch + cB : 0);
+            p00[o] = la[0]; p01[o] = la[1]; p10[o] = lb[0]; p11[o] = lb[1];
+        }
+        // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
+        if (want > have) { request(have + 1, want); have = want; }
+        // ---- (c) weights and blend, two pixels per packed instruction (the products and the order of the sums are the reference's)
+        float out[4];
+#pragma unroll
+        for (int o = 0; o < 4; o += 2) {
+            const f2 s32 = {1.f / 32, 1.f / 32}, one = {1.f, 1.f};
+            const f2 fx = f2{(float)(X[o] & 31), (float)(X[o + 1] & 31)} * s32, fy = f2{(float)(Y[o] & 31), (float)(Y[o + 1] & 31)} * s32;
+            const f2 wy0 = one - fy, wx0 = one - fx;
+            const f2 w0 = wy0 * wx0, w1 = wy0 * fx, w2 = fy * wx0, w3 = fy * fx;
+            f2 t = f2{p00[o], p00[o + 1]} * w0 + f2{p01[o], p01[o + 1]} * w1;
+            t = t + f2{p10[o], p10[o + 1]} * w2;
+            t = t + f2{p11[o], p11[o + 1]} * w3;
+            out[o] = t.x; out[o + 1] = t.y;
+        }
+        // ---- (d) all taps of this step are in registers everywhere, the next step's pieces have landed.  (sched_barrier: the blend stays ABOVE the wait -- left to itself
+        // the scheduler sinks it below the barrier, where nothing is in flight any more)
+        asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));       // (... and the optimiser does not sink it either: the four results exist here)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (e) stores
+        if (live && xl <= xe) {
+            uchar* drow = dst + (size_t)y * dstep;
+            if (slow) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    if (!((slow >> o) & 1) || xl + o > xe) continue;
+                    float one;                                                         // (BORDER_TRANSPARENT leaves the pixel as it is: start from the destination's value)
+                    one = s.border == B_TRANSPARENT ? reinterpret_cast<const float*>(drow)[xl + o] : 0.f;
+                    samplePixel(src, sstep, reinterpret_cast<uchar*>(&one), s, satShort(X[o] >> 5), satShort(Y[o] >> 5), X[o] & 31, Y[o] & 31, tab);
+                    out[o] = one;
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                    // (the generic sampler's loads are done when this block is left: no wait for them on the common path)
+            }
+            if (xl + 3 <= xe) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f4{out[0], out[1], out[2], out[3]}, reinterpret_cast<f4*>(drow + (size_t)xl * 4));
+            } else {
+                for (int o = 0; o < 4 && xl + o <= xe; o++) reinterpret_cast<float*>(drow)[xl + o] = out[o];
+            }
+        }
+    }
+}
+
 // the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
 __global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT, uint32_t* __restrict__ work)
 {
@@ -2475,6 +2606,40 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // Measured on 8K frames (profiles/r04_warp32_ab.txt): the LDS-tile kernel wins where a wave's 64 destination pixels spread over many source rows (33 degrees: 76 us
         // against the gather kernel's 90; 90 degrees likewise), the gather kernel where they stay within a few rows (7 degrees, shifts: 72-75 against 79) and wherever the
         // source box of a tile exceeds the LDS allotment (minification by ~1.5 and more: every tile would go to the list).  MI355CV_WARP32 = 0 / 1 force either kernel.
+        // CV_32FC1 affine maps that are gentle enough (|rotation| up to ~12 degrees at scale ~1): the strip walk over an LDS ring of whole source row pieces (k_warp32_strip).
+        // MI355CV_WARP32_STRIP=0 keeps the kernels below (A/B runs); the conditions are what the ring can hold -- everything else is decided per pixel inside the kernel
+        static const int stripEnv = [] { const char* v = getenv("MI355CV_WARP32_STRIP"); return v ? atoi(v) : 1; }();
+        if (stripEnv && kind == 0 && depth == D32F && cn == 1 && M[4] > 0.25 && (sw & 3) == 0 && dw >= 64 && dh >= 16 &&
+            ((((uintptr_t)ds) | dss | w.sframe | ((uintptr_t)dd) | dds | w.dframe) & 15) == 0) {
+            const double ma = M[0], mb = M[1], md = M[3], me = M[4];
+            const double h = mb / me, gcoef = ma - mb * md / me;
+            // source rows one step reads + the next step's, and the width of a row piece: |M3| 255 + 1 rows across the strip, M4 rows per destination row (16 of them), the second
+            // tap row; |g| 255 columns across the strip + the drift 2 |h| between the rows that share a source row + the second tap column + alignment + slack
+            const double rowsNeeded = std::fabs(md) * 255 + me * (2 * WS_WAVES) + 4, colsNeeded = std::fabs(gcoef) * 255 + 2 * std::fabs(h) + 2 + 3 + 3;
+            if (rowsNeeded <= WS_NR - 2 && colsNeeded <= WS_PW && std::fabs(h) < 0.5 && std::fabs(gcoef) * sw < 1e6 && std::fabs(M[2] - mb * M[5] / me) < 1e6) {
+                StripArgs a;
+                static const int pitchEnv = [] { const char* v = getenv("MI355CV_WARP32_PITCH"); const int p = v ? atoi(v) : 292; return p < WS_PW ? WS_PW : (p + 3) & ~3; }();
+                a.pitch = pitchEnv;
+                a.H15 = (int)std::lrint(h * 32768.0);
+                a.g = gcoef;
+                a.cp = (M[2] - mb * M[5] / me) - std::fabs(h) - 2.0;            // sx >= g x + h sy + cp on every pixel of the strip that reads source row sy (2 = rounding of the 1/32 grid, of H15, slack)
+                const int strips = divUp(dw, WS_COLS);
+                const long long per = (long long)strips * nframes;
+                int segs = (int)std::min<long long>(std::max<long long>((1024 + per - 1) / per, 1), std::max(dh / 256, 1));
+                a.segRows = divUp(divUp(dh, segs), WS_WAVES) * WS_WAVES;
+                segs = divUp(dh, a.segRows);
+                int* terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
+                uint32_t* work = (uint32_t*)stg.scratch(16);
+                if (!terms || !work) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
+                const size_t lds = (size_t)WS_NR * a.pitch * sizeof(float);
+                static bool attr[64] = {}; const int dv = activeDevice() & 63;
+                if (!attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_warp32_strip), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; }
+                hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work);
+                hipLaunchKernelGGL(k_warp32_strip, dim3(strips, segs, nframes), dim3(64 * WS_WAVES), lds, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, a, terms, g_tabDev);
+                noteKernel("k_warp32_strip grid=%dx%dx%d x%d strips of %d columns, %d rows per segment, ring %d x %d floats (lds %zu)", strips, segs, nframes, 64 * WS_WAVES, WS_COLS, a.segRows, WS_NR, a.pitch, lds);
+                return stg.finish(entry);
+            }
+        }
         static const int warp32Env = [] { const char* v = getenv("MI355CV_WARP32"); return v ? atoi(v) : -1; }();
         const bool spreadRows = std::fabs(M[3]) * 64 >= 12.0, fitsLds = (std::fabs(M[0]) * 64 + std::fabs(M[1]) * 32 + 6) * (std::fabs(M[3]) * 64 + std::fabs(M[4]) * 32 + 2) <= W32_CAP;
         const bool warp32On = warp32Env < 0 ? (spreadRows && fitsLds) : warp32Env != 0;

@@ -7,7 +7,7 @@
 #include <vector>
 #include "seplong_body.h"
 
-template <int MODE, int CN>
+template <int MODE, int CN, bool LONG>
 static void runT(const seplong::Geom& g, int nstrips, int nseg, size_t ldsBytes, const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep,
                  const uint32_t* kx, const uint32_t* ky, const uint32_t* kyS)
 {
@@ -19,9 +19,13 @@ static void runT(const seplong::Geom& g, int nstrips, int nseg, size_t ldsBytes,
             std::memset(lds.data(), 0xA5, lds.size() * 4);
             seplong::Seg<CN> sg;
             sg.init(g, sx, sy);
+            constexpr int MMAX = seplong::StageOf<CN, LONG>::MMAX;
+            static uint32_t v[256][seplong::RPW * MMAX];                     // every thread's staging registers between the two halves of the staging
+            for (int tid = 0; tid < 256; tid++) seplong::stageLoad<MODE, CN, MMAX>(g, sg, 0, src, sstep, tid, v[tid]);
             int done = 0;
             for (int j = 0; j < sg.nsteps; j++) {
-                for (int tid = 0; tid < 256; tid++) seplong::stage<MODE, CN>(g, sg, j, src, sstep, S, tid);
+                for (int tid = 0; tid < 256; tid++) seplong::stageStore<CN, MMAX>(g, sg, j, S, tid, v[tid]);
+                if (j + 1 < sg.nsteps) for (int tid = 0; tid < 256; tid++) seplong::stageLoad<MODE, CN, MMAX>(g, sg, j + 1, src, sstep, tid, v[tid]);
                 for (int tid = 0; tid < 256; tid++) seplong::rowPass<MODE, CN>(g, sg, j, S, ring, kx, tid);
                 const int newDone = seplong::doneAfter<CN>(g, sg, j);
                 for (int tid = 0; tid < 256; tid++) seplong::colPass<MODE, CN>(g, sg, done, newDone, ring, ky, kyS, dst, dstep, tid);
@@ -47,7 +51,7 @@ extern "C" int emu_seplong(const unsigned char* src, size_t sstep, unsigned char
     if (planOut) { planOut[0] = nstrips; planOut[1] = nseg; planOut[2] = g.seg; planOut[3] = (int)lds; planOut[4] = g.NR; }
     std::vector<uint32_t> kyS(ny);
     for (int i = 0; i < ny; i++) { const float s = mode == 0 ? 0.f : (float)(int)ky[i] * (1.0f / 65536.0f); std::memcpy(&kyS[i], &s, 4); }
-#define RUN(M_, C_) runT<M_, C_>(g, nstrips, nseg, lds, src, sstep, dst, dstep, kx, ky, kyS.data())
+#define RUN(M_, C_) if (nx > 33) runT<M_, C_, true>(g, nstrips, nseg, lds, src, sstep, dst, dstep, kx, ky, kyS.data()); else runT<M_, C_, false>(g, nstrips, nseg, lds, src, sstep, dst, dstep, kx, ky, kyS.data())
 #define RUNC(M_) do { switch (cn) { case 1: RUN(M_, 1); break; case 2: RUN(M_, 2); break; case 3: RUN(M_, 3); break; default: RUN(M_, 4); } } while (0)
     switch (mode) { case 0: RUNC(0); break; case 1: RUNC(1); break; case 2: RUNC(2); break; default: RUNC(3); }
 #undef RUNC
