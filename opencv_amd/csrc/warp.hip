@@ -2106,7 +2106,6 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
                                                                 StripArgs a, const int* __restrict__ terms, const short* __restrict__ tab)
 {
     extern __shared__ __attribute__((aligned(16))) float ring[];         // WS_NR slots of a.pitch floats
-    typedef float f2 __attribute__((ext_vector_type(2)));
     src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * WS_COLS, xe = min(x0 + WS_COLS, w.dw) - 1;
@@ -2122,8 +2121,8 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     // bx(r): origin of source row r's piece
     const double gx0 = a.g * (double)x0, gx1 = a.g * (double)xe;
     const int C15 = (int)floor((fmin(gx0, gx1) + a.cp) * 32768.0);
-    auto bxOf = [&](int r) { return ((r * a.H15 + C15) >> 15) & ~3; };
-    const int pitch = a.pitch;
+    auto bxOf = [&](int r) { return ((__mul24(r, a.H15) + C15) >> 15) & ~3; };                  // |r| < 2^15, |H15| < 2^14: one v_mad_i32_i24
+    const int pitch = a.pitch, pitch4 = 4 * a.pitch;
     // rows [lo, hi] of the source into their ring slots: row lo + i is loaded by wave i % 8; two instructions per row (64 + 8 lanes x 16 bytes)
     auto request = [&](int lo, int hi) {
         for (int r = lo + wave; r <= hi; r += WS_WAVES) {
@@ -2144,44 +2143,63 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     request(rlo, have);
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
+    const uchar* ringB = reinterpret_cast<const uchar*>(ring);
     for (int yb = y0; yb <= y1; yb += WS_WAVES) {
         const int y = yb + wave;                                                               // this wave's destination row (wave-uniform)
         const bool live = y <= y1;
         const int yc = min(y, y1);
         const int rX = rowX[yc], rY = rowY[yc];
-        // resident rows for this step: [resLo, have]; resLo also keeps clear of the slots the NEXT request overwrites
+        // resident rows for this step: [resLo, resHi]; resLo also keeps clear of the slots the NEXT request overwrites
         const int want = topRow(yb + 2 * WS_WAVES - 1);
         const int resLo = max(max(want - (WS_NR - 1), 0), rlo);
         const int resHi = min(have, s.sh - 1);
-        // ---- (a) coordinates, addresses, taps LDS -> registers
+        // ---- (a) coordinates, addresses, taps LDS -> registers.  The instruction count per pixel is what this kernel is bound by (the first version: 75 per pixel, two
+        // 32-bit multiplies at a quarter of the rate among them, 107 us per 8K frame against the gather kernel's 74): the row / column extent of the lane's four pixels is
+        // tested once per lane (sx and sy are monotone along a row), the two piece-relative columns of a pixel by ONE comparison (the origins of neighbouring rows differ
+        // by 0 or 4), every product is a 24-bit one.
         int X[4], Y[4];
-        float p00[4], p01[4], p10[4], p11[4];
-        unsigned slow = 0;
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v pT[4], pB[4];                                                                        // (p00, p01) and (p10, p11) of each pixel: what one ds_read2_b32 returns
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            X[o] = (rX + cx[o]) >> 5; Y[o] = (rY + cy[o]) >> 5;
-            const int sx = X[o] >> 5, sy = Y[o] >> 5;
-            const int cA = sx - bxOf(sy), cB = sx - bxOf(sy + 1);
-            const bool ok = (unsigned)sx < (unsigned)(s.sw - 1) && sy >= resLo && sy + 1 <= resHi && (unsigned)cA <= (unsigned)(WS_PW - 2) && (unsigned)cB <= (unsigned)(WS_PW - 2);
-            if (!ok) slow |= 1u << o;
-            const float* la = ring + (ok ? (sy & (WS_NR - 1)) * pitch + cA : 0);
-            const float* lb = ring + (ok ? ((sy + 1) & (WS_NR - 1)) * pitch + cB : 0);
-            p00[o] = la[0]; p01[o] = la[1]; p10[o] = lb[0]; p11[o] = lb[1];
+        for (int o = 0; o < 4; o++) { X[o] = (rX + cx[o]) >> 5; Y[o] = (rY + cy[o]) >> 5; }
+        const int sxA = X[0] >> 5, sxB = X[3] >> 5, syA = Y[0] >> 5, syB = Y[3] >> 5;
+        const int sxLo = min(sxA, sxB), sxHi = max(sxA, sxB), r0 = min(syA, syB);
+        // the lane's pixels read source rows r0 .. r0 + 2 at most (|M3| * 3 < 1): their piece origins and ring bases once per lane
+        const int b0 = bxOf(r0), b1 = bxOf(r0 + 1), b2 = bxOf(r0 + 2);
+        const int bLo = min(b0, b2), bHi = max(b0, b2);                                         // (bx is monotone in r)
+        const bool laneOk = sxLo >= 0 && sxHi < s.sw - 1 && r0 >= resLo && max(syA, syB) < resHi && max(syA, syB) - r0 <= 1 &&
+                            sxLo - bHi >= 0 && sxHi + 1 - bLo <= WS_PW - 1;
+        const unsigned slow = laneOk ? 0u : 15u;
+        if (laneOk) {
+            const unsigned rb0 = __umul24((unsigned)r0 & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b0;
+            const unsigned rb1 = __umul24((unsigned)(r0 + 1) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b1;
+            const unsigned rb2 = __umul24((unsigned)(r0 + 2) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b2;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int sx = X[o] >> 5, sy = Y[o] >> 5;
+                const bool up = sy != r0;
+                const f2v* la = reinterpret_cast<const f2v*>(ringB + ((up ? rb1 : rb0) + 4u * (unsigned)sx));
+                const f2v* lb = reinterpret_cast<const f2v*>(ringB + ((up ? rb2 : rb1) + 4u * (unsigned)sx));
+                typedef float f2u4 __attribute__((ext_vector_type(2), aligned(4)));
+                pT[o] = *reinterpret_cast<const f2u4*>(la); pB[o] = *reinterpret_cast<const f2u4*>(lb);
+            }
         }
         // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
         if (want > have) { request(have + 1, want); have = want; }
-        // ---- (c) weights and blend, two pixels per packed instruction (the products and the order of the sums are the reference's)
+        // ---- (c) weights and blend: the tap PAIRS of a pixel go through packed multiplies as they came from LDS (no register shuffling); the products and the order of
+        // the sums are the reference's: t = p00 w0 + p01 w1; t += p10 w2; t += p11 w3
         float out[4];
 #pragma unroll
-        for (int o = 0; o < 4; o += 2) {
-            const f2 s32 = {1.f / 32, 1.f / 32}, one = {1.f, 1.f};
-            const f2 fx = f2{(float)(X[o] & 31), (float)(X[o + 1] & 31)} * s32, fy = f2{(float)(Y[o] & 31), (float)(Y[o + 1] & 31)} * s32;
-            const f2 wy0 = one - fy, wx0 = one - fx;
-            const f2 w0 = wy0 * wx0, w1 = wy0 * fx, w2 = fy * wx0, w3 = fy * fx;
-            f2 t = f2{p00[o], p00[o + 1]} * w0 + f2{p01[o], p01[o + 1]} * w1;
-            t = t + f2{p10[o], p10[o + 1]} * w2;
-            t = t + f2{p11[o], p11[o + 1]} * w3;
-            out[o] = t.x; out[o + 1] = t.y;
+        for (int o = 0; o < 4; o++) {
+            const float fx = (float)(X[o] & 31) * (1.f / 32), fy = (float)(Y[o] & 31) * (1.f / 32);
+            const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+            const f2v wx = {wx0, fx};
+            const f2v wT = f2v{wy0, wy0} * wx, wBm = f2v{fy, fy} * wx;                        // (w0, w1), (w2, w3)
+            const f2v a = pT[o] * wT, c = pB[o] * wBm;
+            float t = a.x + a.y;
+            t = t + c.x;
+            t = t + c.y;
+            out[o] = t;
         }
         // ---- (d) all taps of this step are in registers everywhere, the next step's pieces have landed.  (sched_barrier: the blend stays ABOVE the wait -- left to itself
         // the scheduler sinks it below the barrier, where nothing is in flight any more)

@@ -39,12 +39,20 @@ def timeit(fn, n=10, warm=3, settle_ms=30.0):
         if k >= 400:
             break
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n):
-        fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
+    # the n timed calls run back to back as before, with an event after every group of ~n/4: the MEDIAN group is reported, so that one transient (a clock dip, a
+    # neighbour on the box's host: the driver's round-5 record had gauss_8uc3 at 0.58 where five runs of the same command gave 0.68-0.71) does not set a row's value;
+    # with fewer than 4 calls it is the plain mean
+    groups = 4 if n >= 8 else 1
+    per = [n // groups + (1 if i < n % groups else 0) for i in range(groups)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+    ev[0].record()
+    for gi in range(groups):
+        for _ in range(per[gi]):
+            fn()
+        ev[gi + 1].record()
+    torch.cuda.synchronize()
+    t = sorted(ev[i].elapsed_time(ev[i + 1]) / per[i] for i in range(groups))
+    return t[len(t) // 2] if groups == 1 else 0.5 * (t[groups // 2 - 1] + t[groups // 2])
 
 
 def frames_for(bytes_per_frame, mult=8):
