@@ -2123,24 +2123,35 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     const int C15 = (int)floor((fmin(gx0, gx1) + a.cp) * 32768.0);
     auto bxOf = [&](int r) { return ((__mul24(r, a.H15) + C15) >> 15) & ~3; };                  // |r| < 2^15, |H15| < 2^14: one v_mad_i32_i24
     const int pitch = a.pitch, pitch4 = 4 * a.pitch;
-    // rows [lo, hi] of the source into their ring slots: row lo + i is loaded by wave i % 8; two instructions per row (64 + 8 lanes x 16 bytes)
-    auto request = [&](int lo, int hi) {
+    // rows [lo, hi] of the source into their ring slots: row lo + i is loaded by wave i % 8, exactly two LDS-DMA instructions per row (64 + 8 lanes x 16 bytes); returns
+    // how many this wave issued.  The instructions are inline assembly ON PURPOSE: the compiler does not see them, so it neither drains them before the next LDS read
+    // (it cannot tell which slots they write) nor counts them -- the waits below do.  Chunks that would start outside the row are fetched from a clamped position: every
+    // lane issues, the count is exact, and what lands in those slots is never read (columns outside the source fail the lane test).
+    auto glds16 = [&](const uchar* g, const float* l) {
+        unsigned keep;
+        const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)l;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(ldsAddr) : "memory");
+    };
+    auto request = [&](int lo, int hi) -> int {
+        int issued = 0;
         for (int r = lo + wave; r <= hi; r += WS_WAVES) {
             if ((unsigned)r >= (unsigned)s.sh) continue;                                        // wave-uniform
             const int bx = bxOf(r);
-            float* slot = ring + (r & (WS_NR - 1)) * pitch;
+            const float* slot = ring + (r & (WS_NR - 1)) * pitch;
             const uchar* grow = src + (size_t)r * sstep;
-            const int xa = bx + 4 * lane, xb = bx + 256 + 4 * lane;
-            if (xa >= 0 && xa + 3 < s.sw) __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(grow + (size_t)xa * 4), (__attribute__((address_space(3))) uint32_t*)(slot), 16, 0, 0);
-            if (lane < (WS_PW - 256) / 4 && xb >= 0 && xb + 3 < s.sw)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(grow + (size_t)xb * 4), (__attribute__((address_space(3))) uint32_t*)(slot + 256), 16, 0, 0);
+            const int xa = min(max(bx + 4 * lane, 0), s.sw - 4);
+            glds16(grow + (size_t)xa * 4, slot);
+            if (lane < (WS_PW - 256) / 4) { const int xb = min(max(bx + 256 + 4 * lane, 0), s.sw - 4); glds16(grow + (size_t)xb * 4, slot + 256); }
+            issued += 2;
         }
+        return issued;
     };
     auto topRow = [&](int y) { return ((rowY[min(y, y1)] + cYmax) >> 10) + 1; };               // the last source row destination rows <= y of this segment read (M4 > 0: rows grow with y)
-    // prologue: everything step 0 needs
+    // prologue: everything steps 0 and 1 need (the loop keeps TWO steps of row pieces in flight: ~33 KB per workgroup -- with one, a step waited out a whole HBM
+    // latency with 11 KB in flight per workgroup and the kernel ran at 0.27 of 8 TB/s, profiles/r06_warp32_strip.txt)
     int rlo = (rowY[y0] + cYmin) >> 10;                                                        // first source row of the segment
-    int have = topRow(y0 + WS_WAVES - 1);
-    request(rlo, have);
+    int have = topRow(y0 + 2 * WS_WAVES - 1);
+    (void)request(rlo, have);
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     const uchar* ringB = reinterpret_cast<const uchar*>(ring);
@@ -2150,7 +2161,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         const int yc = min(y, y1);
         const int rX = rowX[yc], rY = rowY[yc];
         // resident rows for this step: [resLo, resHi]; resLo also keeps clear of the slots the NEXT request overwrites
-        const int want = topRow(yb + 2 * WS_WAVES - 1);
+        const int want = topRow(yb + 3 * WS_WAVES - 1);
         const int resLo = max(max(want - (WS_NR - 1), 0), rlo);
         const int resHi = min(have, s.sh - 1);
         // ---- (a) coordinates, addresses, taps LDS -> registers.  The instruction count per pixel is what this kernel is bound by (the first version: 75 per pixel, two
@@ -2185,7 +2196,8 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
             }
         }
         // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
-        if (want > have) { request(have + 1, want); have = want; }
+        int issued = 0;
+        if (want > have) { issued = request(have + 1, want); have = want; }
         // ---- (c) weights and blend: the tap PAIRS of a pixel go through packed multiplies as they came from LDS (no register shuffling); the products and the order of
         // the sums are the reference's: t = p00 w0 + p01 w1; t += p10 w2; t += p11 w3
         float out[4];
@@ -2205,7 +2217,14 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         // the scheduler sinks it below the barrier, where nothing is in flight any more)
         asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));       // (... and the optimiser does not sink it either: the four results exist here)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // the pieces of step j + 1 (requested one step ago) must have landed; the ones just requested (for step j + 2) may stay in flight: loads complete in order, so
+        // "at most `issued` operations outstanding" says exactly that (a store of the previous step still in flight only makes the wait longer)
+        switch (issued) {
+        case 2:  __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 4:  __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 6:  __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- (e) stores
@@ -2230,6 +2249,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // nothing may still be on its way into this workgroup's LDS when it ends
 }
 
 // the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
@@ -2633,7 +2653,7 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
             const double h = mb / me, gcoef = ma - mb * md / me;
             // source rows one step reads + the next step's, and the width of a row piece: |M3| 255 + 1 rows across the strip, M4 rows per destination row (16 of them), the second
             // tap row; |g| 255 columns across the strip + the drift 2 |h| between the rows that share a source row + the second tap column + alignment + slack
-            const double rowsNeeded = std::fabs(md) * 255 + me * (2 * WS_WAVES) + 4, colsNeeded = std::fabs(gcoef) * 255 + 2 * std::fabs(h) + 2 + 3 + 3;
+            const double rowsNeeded = std::fabs(md) * 255 + me * (3 * WS_WAVES) + 4, colsNeeded = std::fabs(gcoef) * 255 + 2 * std::fabs(h) + 2 + 3 + 3;
             if (rowsNeeded <= WS_NR - 2 && colsNeeded <= WS_PW && std::fabs(h) < 0.5 && std::fabs(gcoef) * sw < 1e6 && std::fabs(M[2] - mb * M[5] / me) < 1e6) {
                 StripArgs a;
                 static const int pitchEnv = [] { const char* v = getenv("MI355CV_WARP32_PITCH"); const int p = v ? atoi(v) : 292; return p < WS_PW ? WS_PW : (p + 3) & ~3; }();
