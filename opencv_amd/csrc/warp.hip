@@ -2099,8 +2099,8 @@ __global__ __launch_bounds__(256) void k_warp32_rest(const uchar* __restrict__ s
 // only has to be right in almost every case: a tap whose row is not resident or whose columns fall outside its row's piece (and every pixel whose 2 x 2 footprint is not
 // strictly inside the source) is evaluated from global memory by the generic sampler.  The arithmetic per pixel is k_warp_lin's -- the reference's (imgwarp.cpp:2233-2298
 // coordinates in 1/1024 rounded to 1/32, remapBilinear<Cast<float, float>> :675-904 weights and summation order) -- so results are bit-identical to it.
-constexpr int WS_COLS = 256, WS_NR = 64, WS_PW = 288, WS_WAVES = 8;
-struct StripArgs { int pitch /* floats per ring slot */, segRows, H15; double g, cp; /* bx(r) = ((r H15 + C15(strip)) >> 15) & ~3, C15 from min(g x0, g x1) + cp */ };
+constexpr int WS_COLS = 256, WS_NR = 64, WS_PW = 288, WS_WAVES = 8, WS_DEFER = 40 /* deferred rows a wave can note: two workgroups must still fit a CU */;
+struct StripArgs { int pitch /* floats per ring slot */, segRows, H15, dbg /* MI355CV_WARP32_DBG: 1 no row requests after the prologue, 2 no stores, 4 no LDS tap reads (timing decomposition only: wrong pixels) */; double g, cp; /* bx(r) = ((r H15 + C15(strip)) >> 15) & ~3, C15 from min(g x0, g x1) + cp */ };
 
 __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w,
                                                                 StripArgs a, const int* __restrict__ terms, const short* __restrict__ tab)
@@ -2155,6 +2155,19 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     const uchar* ringB = reinterpret_cast<const uchar*>(ring);
+    // this wave's list of deferred rows: (row, lane mask) triples behind the ring
+    unsigned* dlist = reinterpret_cast<unsigned*>(ring + WS_NR * pitch) + wave * (3 * WS_DEFER);
+    int ndef = 0;
+    auto redoRow = [&](int yy, unsigned long long m) {
+        if (!((m >> lane) & 1)) return;
+        const int rXr = rowX[yy], rYr = rowY[yy];
+        uchar* drow = dst + (size_t)yy * dstep;
+        for (int o = 0; o < 4; o++) {
+            if (xl + o > xe) break;
+            const int Xr = (rXr + cx[o]) >> 5, Yr = (rYr + cy[o]) >> 5;
+            samplePixel(src, sstep, drow + (size_t)(xl + o) * 4, s, satShort(Xr >> 5), satShort(Yr >> 5), Xr & 31, Yr & 31, tab);     // (BORDER_TRANSPARENT leaves the pixel as it is)
+        }
+    };
     for (int yb = y0; yb <= y1; yb += WS_WAVES) {
         const int y = yb + wave;                                                               // this wave's destination row (wave-uniform)
         const bool live = y <= y1;
@@ -2180,8 +2193,14 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         const int bLo = min(b0, b2), bHi = max(b0, b2);                                         // (bx is monotone in r)
         const bool laneOk = sxLo >= 0 && sxHi < s.sw - 1 && r0 >= resLo && max(syA, syB) < resHi && max(syA, syB) - r0 <= 1 &&
                             sxLo - bHi >= 0 && sxHi + 1 - bLo <= WS_PW - 1;
-        const unsigned slow = laneOk ? 0u : 15u;
-        if (laneOk) {
+        // Three kinds of lanes: laneOk (taps from the ring); BORDER_CONSTANT with all four 2 x 2 footprints outside the source (the border value: ~10 % of the pixels of a
+        // rotated, slightly magnified frame -- no load at all); everything else -- footprints that cross the source's rim, other border rules, pieces that missed -- is
+        // DEFERRED: the wave notes the row and the lanes in an LDS list and redoes them with the generic sampler after the walk.  Sampling them on the spot costs every
+        // such wave a full drain of the row pieces in flight (any load issued after them and used before the barrier does): 93 against 56 us per 8K frame.
+        const int syLo = r0, syHi = max(syA, syB);
+        const bool laneOut = s.border == B_CONSTANT && (sxLo >= s.sw || sxHi + 1 < 0 || syLo >= s.sh || syHi + 1 < 0);
+        const bool laneDefer = !laneOk && !laneOut && xl <= xe && live;
+        if (laneOk && !(a.dbg & 4)) {
             const unsigned rb0 = __umul24((unsigned)r0 & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b0;
             const unsigned rb1 = __umul24((unsigned)(r0 + 1) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b1;
             const unsigned rb2 = __umul24((unsigned)(r0 + 2) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b2;
@@ -2197,7 +2216,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         }
         // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
         int issued = 0;
-        if (want > have) { issued = request(have + 1, want); have = want; }
+        if (want > have && !(a.dbg & 1)) { issued = request(have + 1, want); have = want; }
         // ---- (c) weights and blend: the tap PAIRS of a pixel go through packed multiplies as they came from LDS (no register shuffling); the products and the order of
         // the sums are the reference's: t = p00 w0 + p01 w1; t += p10 w2; t += p11 w3
         float out[4];
@@ -2227,20 +2246,15 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- (e) stores
-        if (live && xl <= xe) {
+        // ---- (e) stores (deferred lanes are left out; their rows go on the wave's list)
+        const unsigned long long dm = __ballot(laneDefer && !(a.dbg & 8));
+        if (dm) {
+            if (ndef < WS_DEFER) { if (lane == 0) { dlist[3 * ndef] = (unsigned)y; dlist[3 * ndef + 1] = (unsigned)dm; dlist[3 * ndef + 2] = (unsigned)(dm >> 32); } ndef++; }
+            else redoRow(y, dm);                                                               // list full (a strip that runs along the rim for hundreds of rows): on the spot
+        }
+        if (live && xl <= xe && !laneDefer && !(a.dbg & 2)) {
             uchar* drow = dst + (size_t)y * dstep;
-            if (slow) {
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    if (!((slow >> o) & 1) || xl + o > xe) continue;
-                    float one;                                                         // (BORDER_TRANSPARENT leaves the pixel as it is: start from the destination's value)
-                    one = s.border == B_TRANSPARENT ? reinterpret_cast<const float*>(drow)[xl + o] : 0.f;
-                    samplePixel(src, sstep, reinterpret_cast<uchar*>(&one), s, satShort(X[o] >> 5), satShort(Y[o] >> 5), X[o] & 31, Y[o] & 31, tab);
-                    out[o] = one;
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);                                    // (the generic sampler's loads are done when this block is left: no wait for them on the common path)
-            }
+            if (laneOut) { out[0] = out[1] = out[2] = out[3] = s.cval[0]; }
             if (xl + 3 <= xe) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(f4{out[0], out[1], out[2], out[3]}, reinterpret_cast<f4*>(drow + (size_t)xl * 4));
@@ -2250,7 +2264,14 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // nothing may still be on its way into this workgroup's LDS when it ends
+    // the deferred rows of this wave (its own list: no barrier needed)
+    for (int e = 0; e < ndef; e++) {
+        const unsigned yy = dlist[3 * e];
+        const unsigned long long m = (unsigned long long)dlist[3 * e + 1] | ((unsigned long long)dlist[3 * e + 2] << 32);
+        redoRow((int)yy, m);
+    }
 }
+
 
 // the affine coordinate terms of every destination column and row, once per call (k_warp8_tile reads them instead of redoing the double arithmetic per tile)
 __global__ __launch_bounds__(256) void k_warp8_terms(warp8::Args a, int* __restrict__ colT, int* __restrict__ rowT, uint32_t* __restrict__ work)
@@ -2658,18 +2679,31 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
                 StripArgs a;
                 static const int pitchEnv = [] { const char* v = getenv("MI355CV_WARP32_PITCH"); const int p = v ? atoi(v) : 292; return p < WS_PW ? WS_PW : (p + 3) & ~3; }();
                 a.pitch = pitchEnv;
+                static const int dbgEnv = [] { const char* v = getenv("MI355CV_WARP32_DBG"); return v ? atoi(v) : 0; }();
+                a.dbg = dbgEnv;
                 a.H15 = (int)std::lrint(h * 32768.0);
                 a.g = gcoef;
                 a.cp = (M[2] - mb * M[5] / me) - std::fabs(h) - 2.0;            // sx >= g x + h sy + cp on every pixel of the strip that reads source row sy (2 = rounding of the 1/32 grid, of H15, slack)
                 const int strips = divUp(dw, WS_COLS);
                 const long long per = (long long)strips * nframes;
+                // segments per strip: two workgroups of 512 lanes fit a CU (LDS), 512 run at once; a launch of 1200 is three rounds with the last one a third full.  Take the
+                // split that fills its last round best among those that keep >= 512 rows per segment (a segment re-fetches ~50 source rows at its top), else ~1024 workgroups
                 int segs = (int)std::min<long long>(std::max<long long>((1024 + per - 1) / per, 1), std::max(dh / 256, 1));
+                {
+                    double bestFill = 0; int bestSegs = 0;
+                    for (int sg = 1; sg <= 16 && dh / sg >= 512; sg++) {
+                        const long long blocks = per * sg, rounds = (blocks + 511) / 512;
+                        const double fill = (double)blocks / (double)(rounds * 512);
+                        if (fill >= bestFill - 1e-9) { bestFill = fill; bestSegs = sg; }      // (ties: more, shorter segments balance better)
+                    }
+                    if (bestSegs && bestFill >= 0.85) segs = bestSegs;
+                }
                 a.segRows = divUp(divUp(dh, segs), WS_WAVES) * WS_WAVES;
                 segs = divUp(dh, a.segRows);
                 int* terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
                 uint32_t* work = (uint32_t*)stg.scratch(16);
                 if (!terms || !work) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
-                const size_t lds = (size_t)WS_NR * a.pitch * sizeof(float);
+                const size_t lds = (size_t)WS_NR * a.pitch * sizeof(float) + (size_t)WS_WAVES * 3 * WS_DEFER * sizeof(unsigned);
                 static bool attr[64] = {}; const int dv = activeDevice() & 63;
                 if (!attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_warp32_strip), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; }
                 hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work);
