@@ -2099,11 +2099,11 @@ __global__ __launch_bounds__(256) void k_warp32_rest(const uchar* __restrict__ s
 // only has to be right in almost every case: a tap whose row is not resident or whose columns fall outside its row's piece (and every pixel whose 2 x 2 footprint is not
 // strictly inside the source) is evaluated from global memory by the generic sampler.  The arithmetic per pixel is k_warp_lin's -- the reference's (imgwarp.cpp:2233-2298
 // coordinates in 1/1024 rounded to 1/32, remapBilinear<Cast<float, float>> :675-904 weights and summation order) -- so results are bit-identical to it.
-constexpr int WS_COLS = 256, WS_NR = 64, WS_PW = 288, WS_WAVES = 8, WS_DEFER = 40 /* deferred rows a wave can note: two workgroups must still fit a CU */;
+constexpr int WS_COLS = 256, WS_NR = 64, WS_PW = 288, WS_WAVES = 8;
 struct StripArgs { int pitch /* floats per ring slot */, segRows, H15, dbg /* MI355CV_WARP32_DBG: 1 no row requests after the prologue, 2 no stores, 4 no LDS tap reads (timing decomposition only: wrong pixels) */; double g, cp; /* bx(r) = ((r H15 + C15(strip)) >> 15) & ~3, C15 from min(g x0, g x1) + cp */ };
 
 __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __restrict__ src, uint32_t sstep, uchar* __restrict__ dst, uint32_t dstep, SampleArgs s, WarpArgs w,
-                                                                StripArgs a, const int* __restrict__ terms, const short* __restrict__ tab)
+                                                                StripArgs a, const int* __restrict__ terms, uchar* __restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) float ring[];         // WS_NR slots of a.pitch floats
     src += (size_t)blockIdx.z * w.sframe; dst += (size_t)blockIdx.z * w.dframe;
@@ -2155,19 +2155,6 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     const uchar* ringB = reinterpret_cast<const uchar*>(ring);
-    // this wave's list of deferred rows: (row, lane mask) triples behind the ring
-    unsigned* dlist = reinterpret_cast<unsigned*>(ring + WS_NR * pitch) + wave * (3 * WS_DEFER);
-    int ndef = 0;
-    auto redoRow = [&](int yy, unsigned long long m) {
-        if (!((m >> lane) & 1)) return;
-        const int rXr = rowX[yy], rYr = rowY[yy];
-        uchar* drow = dst + (size_t)yy * dstep;
-        for (int o = 0; o < 4; o++) {
-            if (xl + o > xe) break;
-            const int Xr = (rXr + cx[o]) >> 5, Yr = (rYr + cy[o]) >> 5;
-            samplePixel(src, sstep, drow + (size_t)(xl + o) * 4, s, satShort(Xr >> 5), satShort(Yr >> 5), Xr & 31, Yr & 31, tab);     // (BORDER_TRANSPARENT leaves the pixel as it is)
-        }
-    };
     for (int yb = y0; yb <= y1; yb += WS_WAVES) {
         const int y = yb + wave;                                                               // this wave's destination row (wave-uniform)
         const bool live = y <= y1;
@@ -2199,7 +2186,37 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         // such wave a full drain of the row pieces in flight (any load issued after them and used before the barrier does): 93 against 56 us per 8K frame.
         const int syLo = r0, syHi = max(syA, syB);
         const bool laneOut = s.border == B_CONSTANT && (sxLo >= s.sw || sxHi + 1 < 0 || syLo >= s.sh || syHi + 1 < 0);
-        const bool laneDefer = !laneOk && !laneOut && xl <= xe && live;
+        // ... and a fourth kind (BORDER_CONSTANT): footprints that CROSS the source's rim take the taps that exist from the ring and the border value for the others -- the
+        // sum is the same expression (remapBilinear, imgwarp.cpp:836-870: v = inside ? S[...] : cval, then the four products in order); no global load, no drain.
+        bool laneRim = s.border == B_CONSTANT && !laneOk && !laneOut && xl <= xe && live;
+        if (laneRim) {
+            bool fail = false;
+            const float cv = s.cval[0];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int sx = X[o] >> 5, sy = Y[o] >> 5;
+                float v[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int r = sy + j;
+                    const bool rowIn = (unsigned)r < (unsigned)s.sh;
+                    fail = fail || (rowIn && (r < resLo || r > resHi));
+                    const int bxr = bxOf(r);
+                    const float* rowp = ring + (r & (WS_NR - 1)) * pitch;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int c = sx + i, cc = c - bxr;
+                        const bool in = rowIn && (unsigned)c < (unsigned)s.sw;
+                        const bool inPiece = (unsigned)cc < (unsigned)WS_PW;
+                        fail = fail || (in && !inPiece);
+                        v[j][i] = in && inPiece ? rowp[cc] : cv;
+                    }
+                }
+                pT[o] = f2v{v[0][0], v[0][1]}; pB[o] = f2v{v[1][0], v[1][1]};
+            }
+            laneRim = !fail;
+        }
+        const bool laneDefer = !laneOk && !laneOut && !laneRim && xl <= xe && live;
         if (laneOk && !(a.dbg & 4)) {
             const unsigned rb0 = __umul24((unsigned)r0 & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b0;
             const unsigned rb1 = __umul24((unsigned)(r0 + 1) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b1;
@@ -2246,12 +2263,12 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- (e) stores (deferred lanes are left out; their rows go on the wave's list)
-        const unsigned long long dm = __ballot(laneDefer && !(a.dbg & 8));
-        if (dm) {
-            if (ndef < WS_DEFER) { if (lane == 0) { dlist[3 * ndef] = (unsigned)y; dlist[3 * ndef + 1] = (unsigned)dm; dlist[3 * ndef + 2] = (unsigned)(dm >> 32); } ndef++; }
-            else redoRow(y, dm);                                                               // list full (a strip that runs along the rim for hundreds of rows): on the spot
-        }
+        // ---- (e) stores.  Deferred lanes are left out: the wave marks its row piece (one flag byte per wave and row, written every time: no clearing pass) and
+        // k_warp32_strip_rest redoes the marked pieces with the generic sampler.  (Sampling them here -- on the spot, or from a list after the walk -- was tried: a load
+        // issued after the row pieces in flight and used before the barrier drains them all, and a wave that samples a few lanes serially holds its workgroup's other
+        // seven: 93 and 134 us per 8K frame against 56 with those lanes left out, profiles/r06_warp32_strip.txt.)
+        const bool anyDefer = __ballot(laneDefer && !(a.dbg & 8)) != 0ull;
+        if (live && lane == 0) flags[((size_t)blockIdx.z * w.dh + y) * gridDim.x + blockIdx.x] = anyDefer ? 1 : 0;
         if (live && xl <= xe && !laneDefer && !(a.dbg & 2)) {
             uchar* drow = dst + (size_t)y * dstep;
             if (laneOut) { out[0] = out[1] = out[2] = out[3] = s.cval[0]; }
@@ -2264,11 +2281,44 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // nothing may still be on its way into this workgroup's LDS when it ends
-    // the deferred rows of this wave (its own list: no barrier needed)
-    for (int e = 0; e < ndef; e++) {
-        const unsigned yy = dlist[3 * e];
-        const unsigned long long m = (unsigned long long)dlist[3 * e + 1] | ((unsigned long long)dlist[3 * e + 2] << 32);
-        redoRow((int)yy, m);
+}
+
+// the row pieces k_warp32_strip marked (256 destination pixels of one row each): every pixel again, the footprints strictly inside the source by k_warp_lin's expression
+// (the same products in the same order), the others by the generic sampler.  A wave reads 64 flags and walks the marked ones.
+__global__ __launch_bounds__(256) void k_warp32_strip_rest(const uchar* __restrict__ src0, uint32_t sstep, uchar* __restrict__ dst0, uint32_t dstep, SampleArgs s, WarpArgs w,
+                                                           const int* __restrict__ terms, const short* __restrict__ tab, const uchar* __restrict__ flags, int nstrips, int nframes)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t total = (size_t)nframes * w.dh * nstrips;
+    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (base >= total) return;
+    const size_t mine = base + lane;
+    unsigned long long m = __ballot(mine < total && flags[mine] != 0);
+    const int* colX = terms; const int* colY = terms + w.dw; const int* rowX = terms + 2 * w.dw; const int* rowY = rowX + w.dh;
+    while (m) {
+        const int k = __builtin_ctzll(m);
+        m &= m - 1;
+        const size_t id = base + k;
+        const int strip = (int)(id % (size_t)nstrips), y = (int)((id / (size_t)nstrips) % (size_t)w.dh), fr = (int)(id / ((size_t)nstrips * w.dh));
+        const uchar* src = src0 + (size_t)fr * w.sframe;
+        uchar* drow = dst0 + (size_t)fr * w.dframe + (size_t)y * dstep;
+        const int rX = rowX[y], rY = rowY[y];
+        for (int q = 0; q < 4; q++) {
+            const int x = strip * WS_COLS + 64 * q + lane;                                     // consecutive lanes on consecutive pixels
+            if (x >= w.dw) break;
+            const int X = (rX + colX[x]) >> 5, Y = (rY + colY[x]) >> 5;
+            const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+            if ((unsigned)sx < (unsigned)(s.sw - 1) && (unsigned)sy < (unsigned)(s.sh - 1)) {
+                const float* g = reinterpret_cast<const float*>(src + (size_t)sy * sstep) + sx;
+                const float* g1 = reinterpret_cast<const float*>(reinterpret_cast<const uchar*>(g) + sstep);
+                const float s32 = 1.f / 32, fx = ax * s32, fy = ay * s32, wy0 = 1.f - fy, wx0 = 1.f - fx;
+                const float w0 = __fmul_rn(wy0, wx0), w1 = __fmul_rn(wy0, fx), w2 = __fmul_rn(fy, wx0), w3 = __fmul_rn(fy, fx);
+                float t = __fadd_rn(__fmul_rn(g[0], w0), __fmul_rn(g[1], w1));
+                t = __fadd_rn(t, __fmul_rn(g1[0], w2));
+                t = __fadd_rn(t, __fmul_rn(g1[1], w3));
+                reinterpret_cast<float*>(drow)[x] = t;
+            } else samplePixel(src, sstep, drow + (size_t)x * 4, s, satShort(sx), satShort(sy), ax, ay, tab);
+        }
     }
 }
 
@@ -2703,11 +2753,15 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
                 int* terms = (int*)stg.scratch((size_t)(2 * dw + 2 * dh) * sizeof(int));
                 uint32_t* work = (uint32_t*)stg.scratch(16);
                 if (!terms || !work) return mi355::declined(__func__, __LINE__, "scratch for the coordinate terms");
-                const size_t lds = (size_t)WS_NR * a.pitch * sizeof(float) + (size_t)WS_WAVES * 3 * WS_DEFER * sizeof(unsigned);
+                const size_t lds = (size_t)WS_NR * a.pitch * sizeof(float);
+                const size_t nflags = (size_t)nframes * dh * strips;                       // one byte per wave and row: "this row piece has lanes left to the generic sampler"
+                uchar* flags = (uchar*)stg.scratch(nflags);
+                if (!flags) return mi355::declined(__func__, __LINE__, "scratch for the row-piece flags");
                 static bool attr[64] = {}; const int dv = activeDevice() & 63;
                 if (!attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_warp32_strip), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; }
                 hipLaunchKernelGGL(k_warp32_terms, dim3(divUp(std::max(dw, dh), 256)), dim3(256), 0, stream(), w, terms, work);
-                hipLaunchKernelGGL(k_warp32_strip, dim3(strips, segs, nframes), dim3(64 * WS_WAVES), lds, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, a, terms, g_tabDev);
+                hipLaunchKernelGGL(k_warp32_strip, dim3(strips, segs, nframes), dim3(64 * WS_WAVES), lds, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, a, terms, flags);
+                hipLaunchKernelGGL(k_warp32_strip_rest, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, stream(), ds, (uint32_t)dss, dd, (uint32_t)dds, s, w, terms, g_tabDev, flags, strips, nframes);
                 noteKernel("k_warp32_strip grid=%dx%dx%d x%d strips of %d columns, %d rows per segment, ring %d x %d floats (lds %zu)", strips, segs, nframes, 64 * WS_WAVES, WS_COLS, a.segRows, WS_NR, a.pitch, lds);
                 return stg.finish(entry);
             }
