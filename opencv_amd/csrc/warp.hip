@@ -2132,17 +2132,24 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)l;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(ldsAddr) : "memory");
     };
+    // What lies outside the source is put into the ring as the BORDER VALUE (the host sends BORDER_CONSTANT calls only): rows above / below the image and the 16-byte
+    // chunks left / right of it are written by the lanes themselves (ds_write) instead of being fetched.  A footprint that crosses the source's rim then reads its
+    // taps like any other -- remapBilinear's border branch is the same expression with cval for the missing taps (imgwarp.cpp:836-870) -- and no lane needs a sampler.
+    const float cvf = s.cval[0];
+    const float4 cv4 = make_float4(cvf, cvf, cvf, cvf);
     auto request = [&](int lo, int hi) -> int {
         int issued = 0;
         for (int r = lo + wave; r <= hi; r += WS_WAVES) {
-            if ((unsigned)r >= (unsigned)s.sh) continue;                                        // wave-uniform
             const int bx = bxOf(r);
-            const float* slot = ring + (r & (WS_NR - 1)) * pitch;
-            const uchar* grow = src + (size_t)r * sstep;
-            const int xa = min(max(bx + 4 * lane, 0), s.sw - 4);
-            glds16(grow + (size_t)xa * 4, slot);
-            if (lane < (WS_PW - 256) / 4) { const int xb = min(max(bx + 256 + 4 * lane, 0), s.sw - 4); glds16(grow + (size_t)xb * 4, slot + 256); }
-            issued += 2;
+            float* slot = ring + (r & (WS_NR - 1)) * pitch;
+            const int xa = bx + 4 * lane, xb = bx + 256 + 4 * lane;
+            const bool rowIn = (unsigned)r < (unsigned)s.sh;                                    // wave-uniform
+            const bool inA = rowIn && xa >= 0 && xa + 3 < s.sw, inB = rowIn && xb >= 0 && xb + 3 < s.sw, tail = lane < (WS_PW - 256) / 4;
+            const uchar* grow = src + (size_t)(rowIn ? r : 0) * sstep;
+            if (__ballot(inA)) { if (inA) glds16(grow + (size_t)xa * 4, slot); issued++; }      // (issued <=> some lane is active: the count is exact)
+            if (!inA) *reinterpret_cast<float4*>(slot + 4 * lane) = cv4;
+            if (__ballot(inB && tail)) { if (inB && tail) glds16(grow + (size_t)xb * 4, slot + 256); issued++; }
+            if (!inB && tail) *reinterpret_cast<float4*>(slot + 256 + 4 * lane) = cv4;
         }
         return issued;
     };
@@ -2152,7 +2159,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     int rlo = (rowY[y0] + cYmin) >> 10;                                                        // first source row of the segment
     int have = topRow(y0 + 2 * WS_WAVES - 1);
     (void)request(rlo, have);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0070);                                                        // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     const uchar* ringB = reinterpret_cast<const uchar*>(ring);
     for (int yb = y0; yb <= y1; yb += WS_WAVES) {
@@ -2161,9 +2168,13 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         const int yc = min(y, y1);
         const int rX = rowX[yc], rY = rowY[yc];
         // resident rows for this step: [resLo, resHi]; resLo also keeps clear of the slots the NEXT request overwrites
-        const int want = topRow(yb + 3 * WS_WAVES - 1);
-        const int resLo = max(max(want - (WS_NR - 1), 0), rlo);
-        const int resHi = min(have, s.sh - 1);
+        // requests run up to two steps ahead, but never so far that they would overwrite a row THIS step still reads (slot = row mod 64): the depth adapts to the map
+        // (the 7-degree map of BASELINE config 3c needs 60-63 rows for three steps: with a fixed depth of two a few lanes per wave missed their rows in many strips)
+        const int rowMin = (rowY[min(yb, y1)] + cYmin) >> 10;                                  // the first source row this step reads (rows grow with y)
+        const int rowMinNext = (rowY[min(yb + WS_WAVES, y1)] + cYmin) >> 10;                   // ... and the first one the NEXT step reads: the barrier after (a) below lets requests overwrite everything before it
+        const int want = max(min(topRow(yb + 3 * WS_WAVES - 1), rowMinNext + (WS_NR - 1)), have);
+        const bool late = have < topRow(yb + 2 * WS_WAVES - 1);                                // rows of the NEXT step are only being requested now: the wait below must cover them
+        const int resLo = max(rowMin, rlo);
         // ---- (a) coordinates, addresses, taps LDS -> registers.  The instruction count per pixel is what this kernel is bound by (the first version: 75 per pixel, two
         // 32-bit multiplies at a quarter of the rate among them, 107 us per 8K frame against the gather kernel's 74): the row / column extent of the lane's four pixels is
         // tested once per lane (sx and sy are monotone along a row), the two piece-relative columns of a pixel by ONE comparison (the origins of neighbouring rows differ
@@ -2178,45 +2189,15 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         // the lane's pixels read source rows r0 .. r0 + 2 at most (|M3| * 3 < 1): their piece origins and ring bases once per lane
         const int b0 = bxOf(r0), b1 = bxOf(r0 + 1), b2 = bxOf(r0 + 2);
         const int bLo = min(b0, b2), bHi = max(b0, b2);                                         // (bx is monotone in r)
-        const bool laneOk = sxLo >= 0 && sxHi < s.sw - 1 && r0 >= resLo && max(syA, syB) < resHi && max(syA, syB) - r0 <= 1 &&
-                            sxLo - bHi >= 0 && sxHi + 1 - bLo <= WS_PW - 1;
-        // Three kinds of lanes: laneOk (taps from the ring); BORDER_CONSTANT with all four 2 x 2 footprints outside the source (the border value: ~10 % of the pixels of a
-        // rotated, slightly magnified frame -- no load at all); everything else -- footprints that cross the source's rim, other border rules, pieces that missed -- is
-        // DEFERRED: the wave notes the row and the lanes in an LDS list and redoes them with the generic sampler after the walk.  Sampling them on the spot costs every
-        // such wave a full drain of the row pieces in flight (any load issued after them and used before the barrier does): 93 against 56 us per 8K frame.
-        const int syLo = r0, syHi = max(syA, syB);
-        const bool laneOut = s.border == B_CONSTANT && (sxLo >= s.sw || sxHi + 1 < 0 || syLo >= s.sh || syHi + 1 < 0);
-        // ... and a fourth kind (BORDER_CONSTANT): footprints that CROSS the source's rim take the taps that exist from the ring and the border value for the others -- the
-        // sum is the same expression (remapBilinear, imgwarp.cpp:836-870: v = inside ? S[...] : cval, then the four products in order); no global load, no drain.
-        bool laneRim = s.border == B_CONSTANT && !laneOk && !laneOut && xl <= xe && live;
-        if (laneRim) {
-            bool fail = false;
-            const float cv = s.cval[0];
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int sx = X[o] >> 5, sy = Y[o] >> 5;
-                float v[2][2];
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int r = sy + j;
-                    const bool rowIn = (unsigned)r < (unsigned)s.sh;
-                    fail = fail || (rowIn && (r < resLo || r > resHi));
-                    const int bxr = bxOf(r);
-                    const float* rowp = ring + (r & (WS_NR - 1)) * pitch;
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int c = sx + i, cc = c - bxr;
-                        const bool in = rowIn && (unsigned)c < (unsigned)s.sw;
-                        const bool inPiece = (unsigned)cc < (unsigned)WS_PW;
-                        fail = fail || (in && !inPiece);
-                        v[j][i] = in && inPiece ? rowp[cc] : cv;
-                    }
-                }
-                pT[o] = f2v{v[0][0], v[0][1]}; pB[o] = f2v{v[1][0], v[1][1]};
-            }
-            laneRim = !fail;
-        }
-        const bool laneDefer = !laneOk && !laneOut && !laneRim && xl <= xe && live;
+        // a lane is served from the ring when its rows are resident and its columns inside their pieces -- wherever that is relative to the source (see request());
+        // lanes whose four footprints are all outside are the border value without a read; what remains (a piece that missed: the origin bound is approximate) is
+        // DEFERRED to k_warp32_strip_rest through a flag per row piece.  (Sampling such lanes here was tried three ways -- on the spot, from a list after the walk, taps
+        // picked one by one from the ring -- and cost 25-80 us per 8K frame each: a load issued after the row pieces in flight and used before the barrier drains them
+        // all, and a wave that does extra work holds its workgroup's other seven at the barrier.  profiles/r06_warp32_strip.txt.)
+        const int syHi = max(syA, syB);
+        const bool laneOk = r0 >= resLo && syHi < have && syHi - r0 <= 1 && sxLo - bHi >= 0 && sxHi + 1 - bLo <= WS_PW - 1;
+        const bool laneOut = sxLo >= s.sw || sxHi + 1 < 0 || r0 >= s.sh || syHi + 1 < 0;
+        const bool laneDefer = !laneOk && !laneOut && xl <= xe && live;
         if (laneOk && !(a.dbg & 4)) {
             const unsigned rb0 = __umul24((unsigned)r0 & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b0;
             const unsigned rb1 = __umul24((unsigned)(r0 + 1) & (WS_NR - 1), (unsigned)pitch4) - 4u * (unsigned)b1;
@@ -2231,6 +2212,9 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
                 pT[o] = *reinterpret_cast<const f2u4*>(la); pB[o] = *reinterpret_cast<const f2u4*>(lb);
             }
         }
+        // every wave has its taps of this step in registers before any wave requests rows that reuse their slots (a second barrier per step: it buys 8 rows of ring)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                    // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
         // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
         int issued = 0;
         if (want > have && !(a.dbg & 1)) { issued = request(have + 1, want); have = want; }
@@ -2255,11 +2239,14 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
         __builtin_amdgcn_sched_barrier(0);
         // the pieces of step j + 1 (requested one step ago) must have landed; the ones just requested (for step j + 2) may stay in flight: loads complete in order, so
         // "at most `issued` operations outstanding" says exactly that (a store of the previous step still in flight only makes the wait longer)
-        switch (issued) {
-        case 2:  __builtin_amdgcn_s_waitcnt(0x0F72); break;
-        case 4:  __builtin_amdgcn_s_waitcnt(0x0F74); break;
-        case 6:  __builtin_amdgcn_s_waitcnt(0x0F76); break;
-        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        switch (late ? 0 : issued) {
+        case 1:  __builtin_amdgcn_s_waitcnt(0x0071); break;                                     // vmcnt(n) lgkmcnt(0): the border values the lanes wrote themselves are in as well
+        case 2:  __builtin_amdgcn_s_waitcnt(0x0072); break;
+        case 3:  __builtin_amdgcn_s_waitcnt(0x0073); break;
+        case 4:  __builtin_amdgcn_s_waitcnt(0x0074); break;
+        case 5:  __builtin_amdgcn_s_waitcnt(0x0075); break;
+        case 6:  __builtin_amdgcn_s_waitcnt(0x0076); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0070); break;
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -2718,13 +2705,13 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
         // CV_32FC1 affine maps that are gentle enough (|rotation| up to ~12 degrees at scale ~1): the strip walk over an LDS ring of whole source row pieces (k_warp32_strip).
         // MI355CV_WARP32_STRIP=0 keeps the kernels below (A/B runs); the conditions are what the ring can hold -- everything else is decided per pixel inside the kernel
         static const int stripEnv = [] { const char* v = getenv("MI355CV_WARP32_STRIP"); return v ? atoi(v) : 1; }();
-        if (stripEnv && kind == 0 && depth == D32F && cn == 1 && M[4] > 0.25 && (sw & 3) == 0 && dw >= 64 && dh >= 16 &&
+        if (stripEnv && kind == 0 && depth == D32F && cn == 1 && borderType == B_CONSTANT && M[4] > 0.25 && (sw & 3) == 0 && dw >= 64 && dh >= 16 &&
             ((((uintptr_t)ds) | dss | w.sframe | ((uintptr_t)dd) | dds | w.dframe) & 15) == 0) {
             const double ma = M[0], mb = M[1], md = M[3], me = M[4];
             const double h = mb / me, gcoef = ma - mb * md / me;
             // source rows one step reads + the next step's, and the width of a row piece: |M3| 255 + 1 rows across the strip, M4 rows per destination row (16 of them), the second
             // tap row; |g| 255 columns across the strip + the drift 2 |h| between the rows that share a source row + the second tap column + alignment + slack
-            const double rowsNeeded = std::fabs(md) * 255 + me * (3 * WS_WAVES) + 4, colsNeeded = std::fabs(gcoef) * 255 + 2 * std::fabs(h) + 2 + 3 + 3;
+            const double rowsNeeded = std::fabs(md) * 255 + me * (2 * WS_WAVES) + 4, colsNeeded = std::fabs(gcoef) * 255 + 2 * std::fabs(h) + 2 + 3 + 3;
             if (rowsNeeded <= WS_NR - 2 && colsNeeded <= WS_PW && std::fabs(h) < 0.5 && std::fabs(gcoef) * sw < 1e6 && std::fabs(M[2] - mb * M[5] / me) < 1e6) {
                 StripArgs a;
                 static const int pitchEnv = [] { const char* v = getenv("MI355CV_WARP32_PITCH"); const int p = v ? atoi(v) : 292; return p < WS_PW ? WS_PW : (p + 3) & ~3; }();
