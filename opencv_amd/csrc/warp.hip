@@ -2162,19 +2162,31 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
     __builtin_amdgcn_s_waitcnt(0x0070);                                                        // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     const uchar* ringB = reinterpret_cast<const uchar*>(ring);
+    // the scalar terms of a step (its row terms, the first source row it reads, the last rows one / two steps ahead read) are fetched ONE STEP EARLY: six scalar loads
+    // at the head of every step were a ~500-cycle stall each time (they feed the very first instructions)
+    struct StepTerms { int rX, rY, rowMin, top2, top3; };
+    auto termsOf = [&](int yb) {
+        StepTerms t;
+        const int yc = min(yb + wave, y1);
+        t.rX = rowX[yc]; t.rY = rowY[yc];
+        t.rowMin = (rowY[min(yb, y1)] + cYmin) >> 10;                                          // the first source row the step reads (rows grow with y)
+        t.top2 = topRow(yb + 2 * WS_WAVES - 1); t.top3 = topRow(yb + 3 * WS_WAVES - 1);
+        return t;
+    };
+    StepTerms nx = termsOf(y0);
     for (int yb = y0; yb <= y1; yb += WS_WAVES) {
         const int y = yb + wave;                                                               // this wave's destination row (wave-uniform)
         const bool live = y <= y1;
-        const int yc = min(y, y1);
-        const int rX = rowX[yc], rY = rowY[yc];
-        // resident rows for this step: [resLo, resHi]; resLo also keeps clear of the slots the NEXT request overwrites
+        const StepTerms cur = nx;
+        const int rX = cur.rX, rY = cur.rY;
         // requests run up to two steps ahead, but never so far that they would overwrite a row THIS step still reads (slot = row mod 64): the depth adapts to the map
-        // (the 7-degree map of BASELINE config 3c needs 60-63 rows for three steps: with a fixed depth of two a few lanes per wave missed their rows in many strips)
-        const int rowMin = (rowY[min(yb, y1)] + cYmin) >> 10;                                  // the first source row this step reads (rows grow with y)
-        const int rowMinNext = (rowY[min(yb + WS_WAVES, y1)] + cYmin) >> 10;                   // ... and the first one the NEXT step reads: the barrier after (a) below lets requests overwrite everything before it
-        const int want = max(min(topRow(yb + 3 * WS_WAVES - 1), rowMinNext + (WS_NR - 1)), have);
-        const bool late = have < topRow(yb + 2 * WS_WAVES - 1);                                // rows of the NEXT step are only being requested now: the wait below must cover them
+        // (the 7-degree map of BASELINE config 3c needs 60-63 rows for three steps: with a fixed depth of two a few lanes per wave missed their rows in many strips;
+        // a second barrier per step after the tap reads, which frees 8 more slots, cost more than it bought: 68 against 64 us)
+        const int rowMin = cur.rowMin;
+        const int want = max(min(cur.top3, rowMin + (WS_NR - 1)), have);
+        const bool late = have < cur.top2;                                                     // rows of the NEXT step are only being requested now: the wait below must cover them
         const int resLo = max(rowMin, rlo);
+        nx = termsOf(min(yb + WS_WAVES, y1));                                                  // (scalar loads: they return while this step works)
         // ---- (a) coordinates, addresses, taps LDS -> registers.  The instruction count per pixel is what this kernel is bound by (the first version: 75 per pixel, two
         // 32-bit multiplies at a quarter of the rate among them, 107 us per 8K frame against the gather kernel's 74): the row / column extent of the lane's four pixels is
         // tested once per lane (sx and sy are monotone along a row), the two piece-relative columns of a pixel by ONE comparison (the origins of neighbouring rows differ
@@ -2212,9 +2224,6 @@ __global__ __launch_bounds__(64 * WS_WAVES) void k_warp32_strip(const uchar* __r
                 pT[o] = *reinterpret_cast<const f2u4*>(la); pB[o] = *reinterpret_cast<const f2u4*>(lb);
             }
         }
-        // every wave has its taps of this step in registers before any wave requests rows that reuse their slots (a second barrier per step: it buys 8 rows of ring)
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                    // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
         // ---- (b) the row pieces of the next step, straight into LDS (they overwrite rows below resLo only)
         int issued = 0;
         if (want > have && !(a.dbg & 1)) { issued = request(have + 1, want); have = want; }
@@ -2723,17 +2732,14 @@ int runWarp(const char* entry, int src_type, const uchar* src, size_t sstep, int
                 a.cp = (M[2] - mb * M[5] / me) - std::fabs(h) - 2.0;            // sx >= g x + h sy + cp on every pixel of the strip that reads source row sy (2 = rounding of the 1/32 grid, of H15, slack)
                 const int strips = divUp(dw, WS_COLS);
                 const long long per = (long long)strips * nframes;
-                // segments per strip: two workgroups of 512 lanes fit a CU (LDS), 512 run at once; a launch of 1200 is three rounds with the last one a third full.  Take the
-                // split that fills its last round best among those that keep >= 512 rows per segment (a segment re-fetches ~50 source rows at its top), else ~1024 workgroups
-                int segs = (int)std::min<long long>(std::max<long long>((1024 + per - 1) / per, 1), std::max(dh / 256, 1));
+                // segments per strip: ~272 rows each.  Measured on 8 x 8K frames (profiles/r06_warp32_strip.txt): 2 / 4 / 6 / 8 / 16 / 24 / 32 / 48 segments per strip =
+                // 62.9 / 61.2 / 60.4 / 60.9 / 58.3 / 60.8 / 61.9 / 64.9 us per frame -- short segments balance the workgroups (the ones over the frame's outside corners
+                // finish early) and that outweighs the ~50 source rows each segment fetches again at its top until ~270 rows
+                int segs = std::max(1, (dh + 136) / 272);
+                (void)per;
                 {
-                    double bestFill = 0; int bestSegs = 0;
-                    for (int sg = 1; sg <= 16 && dh / sg >= 512; sg++) {
-                        const long long blocks = per * sg, rounds = (blocks + 511) / 512;
-                        const double fill = (double)blocks / (double)(rounds * 512);
-                        if (fill >= bestFill - 1e-9) { bestFill = fill; bestSegs = sg; }      // (ties: more, shorter segments balance better)
-                    }
-                    if (bestSegs && bestFill >= 0.85) segs = bestSegs;
+                    static const int segsEnv = [] { const char* v = getenv("MI355CV_WARP32_SEGS"); return v ? atoi(v) : 0; }();
+                    if (segsEnv > 0) segs = segsEnv;
                 }
                 a.segRows = divUp(divUp(dh, segs), WS_WAVES) * WS_WAVES;
                 segs = divUp(dh, a.segRows);
