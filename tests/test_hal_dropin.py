@@ -504,6 +504,9 @@ def test_default_host_policy():
         import numpy as np, torch, sys
         sys.path.insert(0, %r)
         import opencv_amd as cv
+        # opencv_amd itself opts in to staging when it loads the library (it has no CPU path, ADVICE r5); -1 = back to what a C / C++ host of the library sees:
+        # the MI355CV_HOST_POLICY variable, absent here, i.e. the built-in default
+        assert cv._lib.lib.mi355cv_hostPolicy() == 1 and cv._lib.lib.mi355cv_setHostPolicy(-1) == 0 and cv._lib.lib.mi355cv_hostPolicy() == 0
         rng = np.random.default_rng(3)
         img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
         for name, fn in (("GaussianBlur", lambda: cv.GaussianBlur(img, (5, 5), 0)), ("cvtColor", lambda: cv.cvtColor(np.dstack([img] * 3), cv.COLOR_BGR2GRAY)),

@@ -128,9 +128,11 @@ def test_seplong_replay_matches_restatement(emu, case):
     kx, ky = taps(kxs, rng), taps(kys, rng)
     sd = DEPTH[np.dtype(dtype)]
     for cn in (1, 2, 3, 4):
-        for (h, w) in [(37, 53), (70, 200), (5, 9), (1, 33), (33, 1)]:
+        for (h, w) in [(37, 53), (70, 200), (5, 9), (1, 33), (33, 1), (21, 700)]:
             if cn > 1 and h * w > 4000 and case % 3:
-                continue                                                                   # the large shape on every channel count only for every third case
+                continue                                                                   # the large shapes on every channel count only for every third case
+            if (h, w) == (21, 700) and cn > 1:
+                continue                                                                   # (wide enough for interior strips: the one-channel vector form of the staging)
             src = rnd((h, w, cn) if cn > 1 else (h, w), dtype, case * 10 + cn)
             for border in (4, 0, 1, 2, 3):
                 if border == 3 and (case % 2 or cn == 2):
