@@ -107,7 +107,7 @@ SL_HD V4 ld4(const uint32_t* p) { V4 v; __builtin_memcpy(&v, p, 16); return v; }
 
 // the per-segment constants every phase uses
 template <int CN> struct Seg {
-    int px0, y0, rows, nsrc, nsteps, spn, fx0; bool xin, vec;
+    int px0, y0, rows, nsrc, nsteps, spn, fx0; bool xin;
     SL_HD void init(const Geom& g, int strip, int segIdx)
     {
         constexpr int TP = StripOf<CN>::TP;
@@ -118,9 +118,6 @@ template <int CN> struct Seg {
         spn = (TP + g.nx - 1) * CN;                      // staged elements per row
         fx0 = px0 - g.ax + g.offX;                       // full-image x of the first staged pixel
         xin = fx0 >= 0 && fx0 + TP + g.nx - 1 <= g.fullW;
-        // one channel, CV_8U or CV_32F, and the staged row rounded up to whole quads still inside the row: 4 elements per load (unaligned dword / 16-byte loads) and
-        // one 16-byte LDS store instead of four of each (the element-wise staging was a third of the kernel's instructions)
-        vec = CN == 1 && xin && fx0 + (spn + 3) / 4 * 4 <= g.fullW && (g.sdepth == SL_8U || g.sdepth == SL_32F);
     }
 };
 
@@ -130,10 +127,7 @@ template <int CN> struct Seg {
 // taps, profiles/r06_seplong_first_run_latency_bound.txt.)
 constexpr int RPW = RB / 4;                                       // rows per wave and step
 // elements per lane and row: the widest staged row is (TP + nx - 1) * CN elements; LONG = kernels beyond 33 taps
-template <int CN, bool LONG> struct StageOf {
-    static constexpr int NXMAX = LONG ? 129 : 33, M0 = ((StripOf<CN>::TP + NXMAX - 1) * CN + 63) / 64;
-    static constexpr int MMAX = CN == 1 ? (M0 + 3) / 4 * 4 : M0;          // one channel: whole quads, for the vector form of the staging
-};
+template <int CN, bool LONG> struct StageOf { static constexpr int NXMAX = LONG ? 129 : 33, MMAX = ((StripOf<CN>::TP + NXMAX - 1) * CN + 63) / 64; };
 
 template <int MODE, int CN, int MMAX>
 SL_HD void stageLoad(const Geom& g, const Seg<CN>& sg, int step, const unsigned char* src, size_t sstep, int tid, uint32_t (&v)[RPW * MMAX])
@@ -145,26 +139,6 @@ SL_HD void stageLoad(const Geom& g, const Seg<CN>& sg, int step, const unsigned 
         const int r = wv + 4 * i;
         const int yy = r < rlim ? border(sg.y0 - g.ay + n0 + r + g.offY, g.fullH, g.border) : -1;
         const unsigned char* row = src + (ptrdiff_t)((yy < 0 ? g.offY : yy) - g.offY) * (ptrdiff_t)sstep;
-        if constexpr (CN == 1) {
-            if (sg.vec) {                                                    // (block-uniform) quad qd = ln + 64 mm of the row -> v[i][4 mm .. 4 mm + 3]
-#pragma unroll
-                for (int mm = 0; mm < MMAX / 4; mm++) {
-                    const int qd = ln + 64 * mm;
-                    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                    if (yy >= 0 && 4 * qd < sg.spn) {
-                        const int idx = sg.fx0 - g.offX + 4 * qd;
-                        if (MODE == 0 && g.sdepth == SL_32F) { V4 t; __builtin_memcpy(&t, row + (ptrdiff_t)idx * 4, 16); e0 = t.x; e1 = t.y; e2 = t.z; e3 = t.w; }
-                        else {
-                            uint32_t d; __builtin_memcpy(&d, row + idx, 4);
-                            e0 = d & 255u; e1 = (d >> 8) & 255u; e2 = (d >> 16) & 255u; e3 = d >> 24;
-                            if constexpr (MODE == 0) { e0 = f2u((float)e0); e1 = f2u((float)e1); e2 = f2u((float)e2); e3 = f2u((float)e3); }
-                        }
-                    }
-                    v[i * MMAX + 4 * mm] = e0; v[i * MMAX + 4 * mm + 1] = e1; v[i * MMAX + 4 * mm + 2] = e2; v[i * MMAX + 4 * mm + 3] = e3;
-                }
-                continue;
-            }
-        }
 #pragma unroll
         for (int m = 0; m < MMAX; m++) {
             const int q = ln + 64 * m;
@@ -194,16 +168,6 @@ SL_HD void stageStore(const Geom& g, const Seg<CN>& sg, int step, uint32_t* S, i
         const int r = wv + 4 * i;
         if (r >= rlim) continue;
         uint32_t* Sr = S + r * CN * g.SP;
-        if constexpr (CN == 1) {
-            if (sg.vec) {
-#pragma unroll
-                for (int mm = 0; mm < MMAX / 4; mm++) {
-                    const int qd = ln + 64 * mm;
-                    if (4 * qd < sg.spn) { const V4 t = {v[i * MMAX + 4 * mm], v[i * MMAX + 4 * mm + 1], v[i * MMAX + 4 * mm + 2], v[i * MMAX + 4 * mm + 3]}; __builtin_memcpy(Sr + 4 * qd, &t, 16); }
-                }
-                continue;
-            }
-        }
 #pragma unroll
         for (int m = 0; m < MMAX; m++) {
             const int q = ln + 64 * m;
