@@ -20,6 +20,7 @@
 #include "gausskernel.h"
 #include "seproll.h"
 #include "seplong.h"
+#include "sepmx.h"
 #include <cstring>
 #include <cstdlib>
 
@@ -692,6 +693,9 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
                    // a submatrix with real pixels around it (cv_hal_gaussianBlurBinomial's margins): the rolling kernel on the parent's geometry, storing the window
                    const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
                    return seprollFixedSmooth(dsrc, dss, 0, ddst, dds, 0, 1, W, H, cn, kx, nx, ky, ny, border, st, &roi); }()) {
+    } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && !(std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') &&
+               sepmxRun(stg, dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, mL + W + mR, mT + H + mB, mL, mT, border, kx, nx, nx / 2, ky, ny, ny / 2, st)) {
+        // any geometry, margins included, both passes on the matrix cores (sepmx.hip): taps that fit int8 and span at most five 32-byte K steps
     } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && [&] {
                    // any length, any geometry, margins included: the LDS-ring kernel in its Q8.8 mode -- when no ufixedpoint16 / ufixedpoint32 sum can saturate
                    unsigned sx = 0, sy = 0;

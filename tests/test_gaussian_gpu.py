@@ -99,8 +99,8 @@ def test_gaussianblur_any_sigma_rolling_path(cv, orc, cn, ksize):
 
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_gaussian_long_kernels(cv, orc, cn):
-    """cv::GaussianBlur on CV_8U with 11 .. 129 taps (sigma 1.7 .. 21: beyond the register-rolling kernels' 9 taps) on the LDS-ring kernel's Q8.8 mode (seplong.hip) --
-    one pass per axis instead of the nx * ny gathers per byte of the kernel it replaces --, up to mi355cv_limit("gauss8u_max_ksize") and refused above it; the restatement
+    """cv::GaussianBlur on CV_8U with 11 .. 129 taps (sigma 1.7 .. 21: beyond the register-rolling kernels' 9 taps) on the matrix-core kernel (sepmx.hip; the LDS-ring kernel's
+    Q8.8 mode, seplong.hip, where a row of taps spans more than five 32-byte K steps), up to mi355cv_limit("gauss8u_max_ksize") and refused above it; the restatement
     is pinned to the reference at these lengths in tests/test_oracle_smooth.py"""
     from opencv_amd import _lib
     rng = np.random.default_rng(5 + cn)
@@ -113,7 +113,8 @@ def test_gaussian_long_kernels(cv, orc, cn):
             kx = [int(v) for v in orc.orc_getGaussianKernelQ(kw, sigma)]; ky = [int(v) for v in orc.orc_getGaussianKernelQ(kh, sigma)]
             for border in (0, 1, 2, 4):
                 got = cv.GaussianBlur(_dev(src), (kw, kh), sigma, sigma, border).cpu().numpy()
-                assert "k_seplong<3," in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+                k = _lib.lib.mi355cv_lastKernel().decode()
+                assert ("k_sepmx<" in k) if (kw - 1) * cn <= 113 else ("k_sepmx<" in k or "k_seplong<3," in k), k
                 assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (w, h, cn, kw, kh, sigma, border)
     src = np.full((40, 200, cn) if cn > 1 else (40, 200), 255, np.uint8)
     assert (cv.GaussianBlur(_dev(src), (65, 65), 11.0).cpu().numpy() == 255).all()

@@ -1,0 +1,116 @@
+"""GPU parity for k_sepmx (opencv_amd/csrc/sepmx.hip): cv::GaussianBlur on CV_8U beyond 9 taps with both passes on the matrix cores (v_mfma_i32_32x32x32_i8: the row
+pass against a Toeplitz matrix of kx, the column pass against one of ky on the two byte planes of the 16-bit row sums).  Integer arithmetic, so the bar is bit for bit
+against the restatement of fixedSmoothInvoker (smooth.simd.hpp:1926) that tests/test_oracle_smooth.py pins to the reference at these lengths: every border rule, 1-4
+channels, ragged widths around the 256-byte strips and the 32-row tiles, segment seams of tall images, ROI windows with real pixels around them (unaligned row starts: the
+staging shift delta), unequal kernels per axis, batches, and the hand-over to the vector kernel where the matrix form does not apply (a tap above 127, more than five K steps)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import opencv_amd
+    assert torch.cuda.is_available()
+    return opencv_amd
+
+
+def _dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def last_kernel():
+    from opencv_amd import _lib
+    return _lib.lib.mi355cv_lastKernel().decode()
+
+
+def taps(orc, n, sigma):
+    return [int(v) for v in orc.orc_getGaussianKernelQ(n, sigma)]
+
+
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_sepmx_shapes_and_borders(cv, orc, cn):
+    rng = np.random.default_rng(40 + cn)
+    for (w, h) in [(700, 75), (256 // cn, 32), (257, 33), (31, 5), (1, 40), (40, 1), (513, 64), (90, 300)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for (kw, kh, sigma) in [(19, 19, 3.0), (11, 33, 2.5), (33, 13, 5.0)]:
+            kx, ky = taps(orc, kw, sigma), taps(orc, kh, sigma)
+            for border in (0, 1, 2, 3, 4):
+                got = cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy()
+                k = last_kernel()
+                if (kw - 1) * cn <= 128 - 15:
+                    assert "k_sepmx<" in k, k
+                assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (w, h, cn, kw, kh, border, k)
+
+
+def test_sepmx_long_kernels_and_extremes(cv, orc):
+    rng = np.random.default_rng(50)
+    src = rng.integers(0, 256, (200, 600), dtype=np.uint8)
+    src[:40] = 255; src[40:80] = 0                                  # saturated and empty bands: the row sums' extremes (65280, 0) cross both byte planes
+    for (kw, kh, sigma) in [(65, 65, 11.0), (97, 41, 16.0), (129, 129, 21.0), (129, 11, 30.0), (15, 129, 40.0)]:
+        kx, ky = taps(orc, kw, sigma), taps(orc, kh, sigma)
+        for border in (0, 1, 4):
+            got = cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy()
+            assert "k_sepmx<" in last_kernel(), last_kernel()
+            assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (kw, kh, border, last_kernel())
+    # every byte value against the largest taps the matrix form takes (127 + 2 + 127 = 256), and the hand-over above them (an identity row of taps: 256)
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (64, 3))
+    ky = [3] + [10] * 25 + [3]
+    for kx, mx in (([0] * 4 + [127, 2, 127] + [0] * 4, True), ([0] * 5 + [256] + [0] * 5, False), ([0] * 4 + [64, 128, 64] + [0] * 4, False)):
+        for border in (1, 4):
+            got = cv.sepSmoothFixedU8(_dev(ramp), kx, ky, border).cpu().numpy()
+            assert ("k_sepmx<" in last_kernel()) == mx, last_kernel()
+            assert np.array_equal(got, orc.orc_sepSmoothFixedU8(ramp, kx, ky, border)), (kx, border, last_kernel())
+
+
+def test_sepmx_tall_images_cross_segment_seams(cv, orc):
+    rng = np.random.default_rng(51)
+    for (w, h, cn) in [(300, 1000, 1), (100, 777, 3)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for (kw, kh, sigma) in [(19, 19, 3.0), (21, 67, 11.0)]:
+            kx, ky = taps(orc, kw, sigma), taps(orc, kh, sigma)
+            got = cv.sepSmoothFixedU8(_dev(src), kx, ky, 4).cpu().numpy()
+            assert "k_sepmx<" in last_kernel() and "seg=" in last_kernel()
+            assert int(last_kernel().split("seg=")[1]) < h, last_kernel()
+            assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, 4)), (w, h, cn, kw, kh)
+
+
+def test_sepmx_roi_with_margins_and_unaligned_rows(cv, orc):
+    """windows into a larger image: borders read the real neighbours, the row start is at an arbitrary byte (the staged block shifts by delta so that its loads stay aligned)"""
+    rng = np.random.default_rng(52)
+    for cn in (1, 3):
+        parent = rng.integers(0, 256, (120, 640, cn) if cn > 1 else (120, 640), dtype=np.uint8)
+        kx, ky = taps(orc, 19, 3.0), taps(orc, 25, 4.0)
+        deltas = set()
+        for (x0, y0, w, h) in [(5, 4, 400, 90), (0, 0, 320, 20), (1, 100, 600, 20), (630, 0, 10, 120), (37, 11, 513, 66), (16, 0, 512, 120)]:
+            margins = (x0, y0, 640 - x0 - w, 120 - y0 - h)
+            roi = parent[y0:y0 + h, x0:x0 + w]
+            for border in (0, 1, 2, 4):
+                want = orc.orc_sepSmoothFixedU8(roi, kx, ky, border, margins)
+                got = cv.sepSmoothFixedU8(_dev(parent)[y0:y0 + h, x0:x0 + w], kx, ky, border, margins=margins)
+                assert "k_sepmx<" in last_kernel(), last_kernel()
+                deltas.add(int(last_kernel().split("delta=")[1].split()[0]))
+                assert np.array_equal(got.cpu().numpy(), want), (cn, x0, y0, w, h, border, last_kernel())
+        assert len(deltas) > 2, deltas
+
+
+def test_sepmx_batch_equals_frames(cv, orc):
+    rng = np.random.default_rng(53)
+    frames = rng.integers(0, 256, (5, 130, 517), dtype=np.uint8)
+    got = cv.GaussianBlurBatch(_dev(frames), (19, 19), sigmaX=3.0).cpu().numpy()
+    assert "k_sepmx<" in last_kernel(), last_kernel()
+    kx = taps(orc, 19, 3.0)
+    for i in range(5):
+        assert np.array_equal(got[i], orc.orc_sepSmoothFixedU8(frames[i], kx, kx, 4)), i
+
+
+def test_sepmx_handover(cv, orc, monkeypatch):
+    """what the matrix form does not take stays on the vector kernel (k_seplong's Q8.8 mode) with the same bits: 4 channels x 65 taps (more than five K steps)"""
+    rng = np.random.default_rng(54)
+    src = rng.integers(0, 256, (70, 300, 4), dtype=np.uint8)
+    kx = taps(orc, 65, 11.0)
+    got = cv.sepSmoothFixedU8(_dev(src), kx, kx, 4).cpu().numpy()
+    assert "k_seplong<3," in last_kernel(), last_kernel()
+    assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, kx, 4))
