@@ -11,13 +11,19 @@
 // index is permuted the same way in Ay -- the row sums never leave the lane that computed them: no ring in LDS, no transposition between the passes.
 //
 // A workgroup of 8 waves owns a strip of 256 bytes of the row (wave w: 32 of them) and walks DOWN a segment, 32 rows per step:
-//   barrier | request the next 32 source rows (16-byte loads, 1-2 per lane, parked in registers for the whole step) | row pass of this step's rows from the staged block
-//   (KSX MFMAs) | split into byte planes (20 VALU per 16 sums) | column pass over the last KSY tiles of row sums (2 KSY MFMAs) | (accH << 8) + accL, byte 2 into the
-//   transposition block | the PREVIOUS step's output tile leaves as 1 KiB per wave-instruction (16 bytes per lane, whole 256-byte row pieces) | next rows into the other block.
-// One barrier per step.  HBM traffic: the source once (+ nx - 1 columns per strip, + 32 (KSY - 1) rows per segment), the destination once.
+//   wait for this wave's share of the step's source rows | barrier | the PREVIOUS step's output tile leaves as 1 KiB per wave-instruction (16 bytes per lane, whole 256-byte
+//   row pieces) | request the rows TWO steps ahead (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into a ring of three staged blocks, no registers) | row pass
+//   of this step's rows (KSX MFMAs; the pixels become signed on their way from LDS: one v_xor per dword) | split into byte planes (20 VALU per 16 sums) | column pass over
+//   the last KSY tiles of row sums (2 KSY MFMAs) | (accH << 8) + accL, byte 2 into the transposition block.
+// One barrier per step, ~19 KB of source rows in flight per workgroup, two workgroups per CU.  The left / right border lives in the row pass' matrix (sepmx_body.h:
+// buildRowB), the top / bottom border in the address of the staged row, so staging is a plain copy of aligned 16-byte chunks.  Rows whose pitch or address rule out aligned
+// chunks go through registers instead (one step ahead; DMA = false).  HBM traffic: the source once (+ nx - 1 columns per strip, + 32 (KSY - 1) rows per segment), the
+// destination once.
 #include "sepmx.h"
 #include "sepmx_body.h"
 #include <vector>
+#include <cstdlib>
+#include <cstring>
 
 using namespace mi355;
 
@@ -29,52 +35,91 @@ using sepmx::Geom;
 using sepmx::TR;
 using sepmx::TW;
 
-template <int KSX, int KSY>
-__global__ __launch_bounds__(512, 4) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
-                                               Geom g, const v4i* __restrict__ tabs /* row B [KSX][64], then column A [KSY][64] */)
+__device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone (vector-memory operations return in order: at most n of the newest are still out)
 {
-    constexpr int NCHUNK = (TW - 32 + 32 * KSX) / 16, P = 16 * (NCHUNK | 1), NQ = (TR * NCHUNK + 511) / 512;
-    __shared__ __attribute__((aligned(16))) uchar stage[2][TR * P];
+    switch (n) {
+    case 0:  __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    case 1:  __builtin_amdgcn_s_waitcnt(0x0F71); break;
+    case 2:  __builtin_amdgcn_s_waitcnt(0x0F72); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
+
+template <int KSX, int KSY, bool DMA>
+__global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+                                                  Geom g, const int* __restrict__ bsel /* [strips][8] */, const int* __restrict__ seeds /* [classes][32] */,
+                                                  const v4i* __restrict__ rowB /* [classes][2][KSX][64] */, const v4i* __restrict__ colA /* [KSY][64] */)
+{
+    constexpr int NCHUNK = (TW - 32 + 32 * KSX) / 16, PC = NCHUNK | 1, P = 16 * PC, NSLOT = DMA ? 3 : 2, NI = (TR * PC + 511) / 512;
+    static_assert(NI <= 2, "at most two chunks per lane and step");
+    __shared__ __attribute__((aligned(16))) uchar stage[NSLOT][TR * P];
     __shared__ __attribute__((aligned(16))) uchar tr[2][TR * TW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
     src += (size_t)blockIdx.z * sframe;
     dst += (size_t)blockIdx.z * dframe;
     const int X0 = blockIdx.x * TW, y0 = blockIdx.y * g.seg;
     const int rows = min(g.seg, g.H - y0);
     const int nU = (rows + TR - 1) / TR, nT = nU + KSY - 1;
 
+    const int sel = __builtin_amdgcn_readfirstlane(bsel[blockIdx.x * 8 + wave]), cls = sel & 0xffff;
+    const bool twice = (sel >> 16) != 0;                 // some weight of this wave's matrix is beyond int8: a second product with the rest (rim waves under BORDER_REPLICATE)
     v4i Bx[KSX], Ay[KSY];
 #pragma unroll
-    for (int k = 0; k < KSX; k++) Bx[k] = tabs[k * 64 + lane];
+    for (int k = 0; k < KSX; k++) Bx[k] = rowB[(cls * 2 * KSX + k) * 64 + lane];
 #pragma unroll
-    for (int k = 0; k < KSY; k++) Ay[k] = tabs[(KSX + k) * 64 + lane];
+    for (int k = 0; k < KSY; k++) Ay[k] = colA[k * 64 + lane];
+    const int seedR = seeds[cls * 32 + n];
 
-    // staging: chunk q = tid + 512 j of the step's TR x NCHUNK chunks
-    uint4 park[NQ];
-    auto request = [&](int t) {
+    // staging: a block is TR rows of PC 16-byte chunks, chunk q at byte 16 q (the last chunk of a row is padding: the pitch is 16 * odd); wave-instruction i of wave w covers
+    // chunks 64 (w + 8 i) .. + 63
+    int cr[NI], ce[NI]; bool cok[NI];
 #pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const int q = tid + 512 * j;
-            if (q >= TR * NCHUNK) continue;
-            const int r = q / NCHUNK, c = q - r * NCHUNK;
-            const uchar* p = nullptr;
-            uchar tmp[16];
-            if (sepmx::stageChunk(g, src, sstep, X0, y0, t, r, c, &p, tmp)) __builtin_memcpy(&park[j], tmp, 16);
-            else __builtin_memcpy(&park[j], p, 16);
-        }
+    for (int i = 0; i < NI; i++) {
+        const int q = 64 * (wave + 8 * i) + lane, r = q / PC, c = q - r * PC;
+        cr[i] = r; ce[i] = X0 - g.ax * g.cn - g.delta + 16 * c; cok[i] = q < TR * PC && c < NCHUNK;
+    }
+    auto bytesOf = [&](const uchar* p, long long rel) -> uint4 {                     // a chunk that reaches outside the parent's memory: the bytes inside, zeros for the rest
+        unsigned wd[4] = {0, 0, 0, 0};
+#pragma nounroll
+        for (int b = 0; b < 16; b++) if (rel + b >= 0 && rel + b < g.span) wd[b >> 2] |= (unsigned)p[b] << (8 * (b & 3));
+        return make_uint4(wd[0], wd[1], wd[2], wd[3]);
     };
-    auto deposit = [&](int t) {
+    uint4 park[DMA ? 1 : NI];
+    // request the rows of step t; returns the number of asynchronous wave-instructions issued (DMA)
+    auto request = [&](int t) -> int {
+        int issued = 0;
 #pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const int q = tid + 512 * j;
-            if (q >= TR * NCHUNK) continue;
-            const int r = q / NCHUNK, c = q - r * NCHUNK;
-            uint4 v = park[j];
-            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;          // pixels - 128
-            *reinterpret_cast<uint4*>(&stage[t & 1][r * P + 16 * c]) = v;
+        for (int i = 0; i < NI; i++) {
+            if (64 * (wave + 8 * i) >= TR * PC) continue;                            // (wave-uniform)
+            const uchar* p = src; long long rel = 0;
+            const int kind = cok[i] ? sepmx::chunkKind(g, src, sstep, y0 - g.ay + TR * t + cr[i], ce[i], &p, &rel) : -1;
+            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + 8 * i)];
+            if (DMA) {
+                if (__ballot(kind == sepmx::CH_LOAD)) {
+                    if (kind == sepmx::CH_LOAD) {
+                        unsigned keep;
+                        const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)slot;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(ldsAddr) : "memory");
+                    }
+                    issued++;
+                }
+                if (kind == sepmx::CH_ZERO) *reinterpret_cast<uint4*>(slot + 16 * lane) = make_uint4(0, 0, 0, 0);
+                if (kind == sepmx::CH_BYTES) *reinterpret_cast<uint4*>(slot + 16 * lane) = bytesOf(p, rel);
+            } else {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kind == sepmx::CH_LOAD) __builtin_memcpy(&v, p, 16);
+                if (kind == sepmx::CH_BYTES) v = bytesOf(p, rel);
+                park[i] = v;
+            }
         }
+        return issued;
     };
-    // the output tile of step t - 1 (rows y0 + 32 u ..), 4 rows of 256 bytes per wave
+    auto deposit = [&](int t) {                                                      // (registers -> block; DMA = false)
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            if (64 * (wave + 8 * i) < TR * PC && cok[i]) *reinterpret_cast<uint4*>(&stage[t % NSLOT][16 * (64 * (wave + 8 * i) + lane)]) = park[DMA ? 0 : i];
+    };
+    // an output tile (rows y0 + 32 u ..) from its transposition block, 4 rows of 256 bytes per wave
     auto emit = [&](int u, int buf) {
         const int rr = 4 * wave + (lane >> 4), cc = 16 * (lane & 15);
         const int y = TR * u + rr, x = X0 + cc;
@@ -82,25 +127,46 @@ __global__ __launch_bounds__(512, 4) void k_sepmx(const uchar* __restrict__ src,
         const uint4 v = *reinterpret_cast<const uint4*>(&tr[buf][rr * TW + cc]);
         uchar* d = dst + (size_t)(y0 + y) * dstep + x;
         if (x + 16 <= g.WE) __builtin_memcpy(d, &v, 16);
-        else { uchar b[16]; __builtin_memcpy(b, &v, 16); for (int i = 0; i < g.WE - x; i++) d[i] = b[i]; }
+        else {
+            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma nounroll
+            for (int i = 0; i < g.WE - x; i++) d[i] = (uchar)(wd[i >> 2] >> (8 * (i & 3)));
+        }
     };
 
     v4i ringH[KSY], ringL[KSY];
 #pragma unroll
     for (int k = 0; k < KSY; k++) { ringH[k] = v4i{0, 0, 0, 0}; ringL[k] = v4i{0, 0, 0, 0}; }
 
-    request(0);
-    deposit(0);
+    int newer = 0;                                       // asynchronous instructions this wave has issued after those of the step it is about to read
+    if (DMA) { (void)request(0); newer = nT > 1 ? request(1) : 0; }
+    else { (void)request(0); deposit(0); }
     for (int t = 0; t < nT; t++) {
+        if (DMA) waitVm(newer);
         __syncthreads();
-        if (t + 1 < nT) request(t + 1);
+        const int u = t - (KSY - 1);
+        if (u >= 1) emit(u - 1, (t - 1) & 1);
+        if (DMA) newer = t + 2 < nT ? request(t + 2) : 0;
+        else if (t + 1 < nT) (void)request(t + 1);
         // ---- row pass
         v16i acc;
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = g.accR0;
-        const uchar* A = &stage[t & 1][n * P + 32 * wave + 16 * h];
+        for (int i = 0; i < 16; i++) acc[i] = seedR;
+        const uchar* A = &stage[t % NSLOT][n * P + 32 * wave + 16 * h];
 #pragma unroll
-        for (int k = 0; k < KSX; k++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(A + 32 * k), Bx[k], acc, 0, 0, 0);
+        for (int k = 0; k < KSX; k++) {
+            v4i a = *reinterpret_cast<const v4i*>(A + 32 * k);
+            a ^= v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};                 // pixels - 128
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bx[k], acc, 0, 0, 0);
+        }
+        if (twice) {
+#pragma unroll
+            for (int k = 0; k < KSX; k++) {
+                v4i a = *reinterpret_cast<const v4i*>(A + 32 * k);
+                a ^= v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, rowB[((cls * 2 + 1) * KSX + k) * 64 + lane], acc, 0, 0, 0);
+            }
+        }
         // ---- 16 row sums of column n -> the two int8 planes in the column pass' B layout (byte i <-> regRow(h, i))
 #pragma unroll
         for (int k = 0; k + 1 < KSY; k++) { ringH[k] = ringH[k + 1]; ringL[k] = ringL[k + 1]; }
@@ -111,7 +177,6 @@ __global__ __launch_bounds__(512, 4) void k_sepmx(const uchar* __restrict__ src,
             ringH[KSY - 1][q] = (int)__builtin_amdgcn_perm(t23, t01, 0x07050301u);
             ringL[KSY - 1][q] = (int)(__builtin_amdgcn_perm(t23, t01, 0x06040200u) ^ 0x80808080u);
         }
-        const int u = t - (KSY - 1);
         if (u >= 0) {
             // ---- column pass
             v16i aH, aL;
@@ -128,22 +193,33 @@ __global__ __launch_bounds__(512, 4) void k_sepmx(const uchar* __restrict__ src,
                 const unsigned v = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
                 T[sepmx::regRow(h, i) * TW] = (uchar)(v >> 16);
             }
-            if (u >= 1) emit(u - 1, (t - 1) & 1);
         }
-        if (t + 1 < nT) deposit(t + 1);
+        if (!DMA && t + 1 < nT) deposit(t + 1);
     }
     __syncthreads();
     emit(nU - 1, (nT - 1) & 1);
 }
 
-template <int KSX>
-void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g, const v4i* tabs)
+template <int KSX, bool DMA>
+void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
+             const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
     switch (ksy) {
-    case 2:  hipLaunchKernelGGL((k_sepmx<KSX, 2>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, tabs); break;
-    case 3:  hipLaunchKernelGGL((k_sepmx<KSX, 3>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, tabs); break;
-    case 4:  hipLaunchKernelGGL((k_sepmx<KSX, 4>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, tabs); break;
-    default: hipLaunchKernelGGL((k_sepmx<KSX, 5>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, tabs); break;
+    case 2:  hipLaunchKernelGGL((k_sepmx<KSX, 2, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 3:  hipLaunchKernelGGL((k_sepmx<KSX, 3, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 4:  hipLaunchKernelGGL((k_sepmx<KSX, 4, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    default: hipLaunchKernelGGL((k_sepmx<KSX, 5, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    }
+}
+template <bool DMA>
+void launchX(int ksx, int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
+             const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
+{
+    switch (ksx) {
+    case 2:  launchY<2, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 3:  launchY<3, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 4:  launchY<4, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    default: launchY<5, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     }
 }
 
@@ -158,22 +234,47 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     Geom g;
     memset(&g, 0, sizeof g);
     g.W = W; g.H = H; g.cn = cn; g.fullW = fullW; g.fullH = fullH; g.offX = offX; g.offY = offY; g.border = border; g.nx = nx; g.ny = ny; g.ax = ax; g.ay = ay;
-    if (!sepmx::plan(g, kx, ky, (uintptr_t)src, (sstep | sframe), nframes)) return false;
+    static const int dmaEnv = std::getenv("MI355CV_SEPMX_DMA") ? atoi(std::getenv("MI355CV_SEPMX_DMA")) : -1;
+    if (!sepmx::plan(g, kx, ky, (uintptr_t)src, sstep, nframes > 1 ? sframe : 0, nframes, 0, dmaEnv)) return false;
     const int nstrips = (g.WE + TW - 1) / TW, nseg = (H + g.seg - 1) / g.seg;
     if (nseg > 65535) return false;
-    std::vector<int8_t> tab((size_t)(g.ksx + g.ksy) * 64 * 16);
-    sepmx::buildRowB(g, kx, tab.data());
-    sepmx::buildColA(g, ky, tab.data() + (size_t)g.ksx * 64 * 16);
-    const v4i* dt = static_cast<const v4i*>(stg.param(tab.data(), tab.size()));
-    if (!dt) return false;
+    // the row pass' operand classes: 0 = the plain Toeplitz matrix, one more per wave whose columns reach a left / right border (or the ragged end of the row)
+    const size_t tabB = (size_t)g.ksx * 64 * 16;                                  // per class: the matrix, then the part of its weights beyond int8
+    std::vector<int> bsel((size_t)nstrips * 8, 0), seeds;
+    std::vector<int8_t> rowB;
+    bool haveInterior = false;
+    int ncls = 1;
+    rowB.resize(2 * tabB); seeds.resize(32);
+    for (int s = 0; s < nstrips; s++)
+        for (int w = 0; w < 8; w++) {
+            int8_t tab[sepmx::MAXKS * 64 * 16], tab2[sepmx::MAXKS * 64 * 16]; int sd[32]; bool interior = false, twice = false;
+            if (s * TW + 32 * w >= g.WE) continue;                                      // a wave without outputs: class 0, never stored
+            if (!sepmx::buildRowB(g, kx, s * TW, w, tab, tab2, &twice, sd, &interior)) return false;
+            if (interior) {
+                if (!haveInterior) { memcpy(rowB.data(), tab, tabB); memcpy(seeds.data(), sd, sizeof sd); haveInterior = true; }
+                continue;
+            }
+            if (ncls >= 4096) return false;
+            rowB.insert(rowB.end(), tab, tab + tabB); rowB.insert(rowB.end(), tab2, tab2 + tabB); seeds.insert(seeds.end(), sd, sd + 32);
+            bsel[(size_t)s * 8 + w] = ncls++ | (twice ? 1 << 16 : 0);
+        }
+    g.ncls = ncls;
+    std::vector<int8_t> colA((size_t)g.ksy * 64 * 16);
+    sepmx::buildColA(g, ky, colA.data());
+    // one parameter block: bsel | seeds | rowB | colA, each part 16-byte aligned
+    auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+    const size_t o1 = up16(bsel.size() * 4), o2 = o1 + up16(seeds.size() * 4), o3 = o2 + up16(rowB.size()), total = o3 + colA.size();
+    std::vector<uchar> blob(total, 0);
+    memcpy(blob.data(), bsel.data(), bsel.size() * 4); memcpy(blob.data() + o1, seeds.data(), seeds.size() * 4);
+    memcpy(blob.data() + o2, rowB.data(), rowB.size()); memcpy(blob.data() + o3, colA.data(), colA.size());
+    const uchar* d = static_cast<const uchar*>(stg.param(blob.data(), blob.size()));
+    if (!d) return false;
     const dim3 grid(nstrips, nseg, nframes);
-    switch (g.ksx) {
-    case 2:  launchY<2>(g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    case 3:  launchY<3>(g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    case 4:  launchY<4>(g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    default: launchY<5>(g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
-    }
-    noteKernel("k_sepmx<%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d seg=%d", g.ksx, g.ksy, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, g.seg);
+    const int* dsel = reinterpret_cast<const int*>(d); const int* dseed = reinterpret_cast<const int*>(d + o1);
+    const v4i* dB = reinterpret_cast<const v4i*>(d + o2); const v4i* dA = reinterpret_cast<const v4i*>(d + o3);
+    if (g.dma) launchX<true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    else       launchX<false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, ncls, g.seg);
     return true;
 }
 

@@ -1,7 +1,6 @@
 // sepmx_body.h -- the host-visible half of sepmx.hip (the 8-bit Q8.8 separable smoothing on the matrix cores): geometry plan, the two Toeplitz operand tables, the
 // staging of one 16-byte chunk and the lane <-> element maps of v_mfma_i32_32x32x32_i8.  Everything here is __host__ __device__ and is what the kernel itself runs;
-// tests/hostemu/sepmx_emu.cpp replays a whole workgroup on the CPU with these functions (the matrix instruction emulated from its operand maps) against the
-// restatement of fixedSmoothInvoker (smooth.simd.hpp:1926), so the index arithmetic is checked without a GPU.
+// the host builds the operand tables with them (and decides what the matrix form does not take), the kernel stages with them.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -26,9 +25,11 @@ struct Geom {
     int nx, ny, ax, ay;
     int ksx, ksy;
     int delta;                                 // the staged row starts at ROI element X0 - ax * cn - delta (delta makes the 16-byte loads aligned)
-    int nchunk, P;                             // 16-byte chunks staged per row, LDS pitch in bytes (16 * odd: conflict-free ds_read_b128 down a column)
+    int dma;                                   // 1: rows arrive by asynchronous global -> LDS loads (16-byte aligned chunks), 0: through registers
     int seg;                                   // output rows per segment (a multiple of TR)
-    int accR0, accL0;                          // accumulator seeds, see below
+    int accL0;                                 // column-pass seed, see below
+    int ncls;                                  // row-pass operand classes (0 = interior; one per wave whose columns see a left / right border)
+    long long span;                            // bytes from the parent image's first byte to one past its last: (fullH - 1) * step + fullW * cn
 };
 
 // v_mfma_i32_32x32x32_i8 operand maps (checked against the hardware by k_ccorr_ring_i8, templmatch.hip): lane (idx = lane & 31, h = lane >> 5), byte i of the 16-byte
@@ -58,28 +59,49 @@ MX_HD int borderIdx(int p, int len, int type)              // borderInterpolate 
 //   row pass     acc = accR0 + sum kx (s - 128),  accR0 = 128 sum(kx) + 128 - 32768           =>  acc = R + 128 - 32768 in [-32640, 32640]
 //                acc = 256 Hh + L with Hh = (signed) byte 1, L = (unsigned) byte 0; l = L - 128 =>  R = 256 Hh + l + 32768, both Hh and l in int8
 //   column pass  accH = sum ky Hh,  accL = accL0 + sum ky l,  accL0 = 32768 sum(ky) + 32768     =>  (accH << 8) + accL = sum ky R + 2^15, < 2^24: the result is its byte 2
-MX_HD void seeds(Geom& g, const uint16_t* kx, const uint16_t* ky)
-{
-    int sx = 0, sy = 0;
-    for (int i = 0; i < g.nx; i++) sx += kx[i];
-    for (int i = 0; i < g.ny; i++) sy += ky[i];
-    g.accR0 = 128 * sx + 128 - 32768;
-    g.accL0 = 32768 * sy + 32768;
-}
+MX_HD int rowSeed(int sumPresentTaps) { return 128 * sumPresentTaps + 128 - 32768; }
+MX_HD int colSeed(int sumTaps) { return 32768 * sumTaps + 32768; }
 
-// row pass B operand (Toeplitz of kx): table[ks][lane][16], lane (n, h), byte i: staged column k = 32 ks + 16 h + i (relative to the wave's first column) holds ROI element
-// x + (k - n) - ax cn - delta for output element x = first + n: tap (k - n - delta) / cn when that is a whole number in [0, nx)
-inline void buildRowB(const Geom& g, const uint16_t* kx, int8_t* tab)
+// Row-pass B operand of one wave (strip X0, wave w: output elements X0 + 32 w + n): tab[ks][lane][16], lane (n, h), byte i <-> staged column k = 32 ks + 16 h + i of the
+// wave's window, which starts at ROI element X0 + 32 w - ax cn - delta.  The LEFT / RIGHT BORDER IS FOLDED INTO THE MATRIX: tap i of output element x reads pixel
+// borderInterpolate(x / cn + i - ax) of the full image -- its weight is added at THAT pixel's column (two taps can land on one column under the reflecting rules), taps that
+// fall outside under BORDER_CONSTANT are dropped (and leave the column's seed: seed[n] = rowSeed(sum of the taps present)).  The staged bytes of columns outside the image
+// then never matter (weight 0): staging needs no border logic along x.  false: a folded weight beyond 2 x 127, or a border pixel outside the wave's window (BORDER_WRAP on
+// an image wider than the window, reflections in an image narrower than the kernel): the caller hands the call to the vector kernel.  *interior: no tap was moved; *twice: tab2 is not empty.
+inline bool buildRowB(const Geom& g, const uint16_t* kx, int X0, int w, int8_t* tab, int8_t* tab2, bool* twice, int* seed, bool* interior)
 {
+    int wt[32 * MAXKS][32];
+    memset(wt, 0, sizeof wt);
+    *interior = true; *twice = false;
+    const int win0 = X0 + 32 * w - g.ax * g.cn - g.delta;
+    for (int n = 0; n < 32; n++) {
+        const int xe = X0 + 32 * w + n;
+        int present = 0;
+        if (xe >= g.WE) { seed[n] = rowSeed(0); *interior = false; continue; }          // not an output: an empty column
+        const int px = xe / g.cn, ch = xe - px * g.cn;
+        for (int i = 0; i < g.nx; i++) {
+            const int pf = px + g.offX + i - g.ax, q = borderIdx(pf, g.fullW, g.border);
+            if ((unsigned)pf >= (unsigned)g.fullW) *interior = false;
+            if (q < 0) continue;
+            const int k = (q - g.offX) * g.cn + ch - win0;
+            if (k < 0 || k >= 32 * g.ksx) return false;
+            wt[k][n] += kx[i]; present += kx[i];
+            if (wt[k][n] > 254) return false;
+        }
+        seed[n] = rowSeed(present);
+    }
+    // a weight beyond int8 (BORDER_REPLICATE piles up to half the kernel on the rim pixel) is applied in two products: min(w, 127) here, the rest in tab2
     for (int ks = 0; ks < g.ksx; ks++)
         for (int lane = 0; lane < 64; lane++)
             for (int i = 0; i < 16; i++) {
-                const int n = lane & 31, h = lane >> 5, d = 32 * ks + 16 * h + i - n - g.delta;
-                tab[(ks * 64 + lane) * 16 + i] = (d >= 0 && d % g.cn == 0 && d / g.cn < g.nx) ? (int8_t)kx[d / g.cn] : (int8_t)0;
+                const int v = wt[32 * ks + 16 * (lane >> 5) + i][lane & 31], a = v > 127 ? 127 : v;
+                tab[(ks * 64 + lane) * 16 + i] = (int8_t)a; tab2[(ks * 64 + lane) * 16 + i] = (int8_t)(v - a);
+                if (v != a) *twice = true;
             }
+    return true;
 }
 // column pass A operand (Toeplitz of ky): table[s][lane][16], lane (m, h), byte i: row regRow(h, i) of row-sum tile u + s contributes to output row m of tile u with tap
-// 32 s + regRow(h, i) - m
+// 32 s + regRow(h, i) - m.  (The top / bottom border needs no folding: a staged row IS the source row borderInterpolate names, or zeros.)
 inline void buildColA(const Geom& g, const uint16_t* ky, int8_t* tab)
 {
     for (int s = 0; s < g.ksy; s++)
@@ -91,7 +113,7 @@ inline void buildColA(const Geom& g, const uint16_t* ky, int8_t* tab)
 }
 
 // false: outside what the kernel covers (a tap beyond int8, more K steps than MAXKS)
-inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcAddr, size_t sstep, int nframes, int segOverride = 0)
+inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcAddr, size_t sstep, size_t sframe, int nframes, int segOverride = 0, int dmaOverride = -1)
 {
     if (g.cn < 1 || g.cn > 4 || g.nx < 1 || g.ny < 1 || g.W < 1 || g.H < 1) return false;
     int sx = 0, sy = 0;
@@ -99,20 +121,22 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     for (int i = 0; i < g.ny; i++) { if (ky[i] > 127) return false; sy += ky[i]; }
     if (sx > 256 || sy > 256) return false;
     g.WE = g.W * g.cn;
+    g.span = (long long)(g.fullH - 1) * (long long)sstep + (long long)g.fullW * g.cn;
     const int spanX = (g.nx - 1) * g.cn;
-    // aligned 16-byte loads when the row pitch allows them and the shift does not cost a K step
-    int delta = (sstep % 16 == 0) ? (int)((srcAddr + (uintptr_t)(16 * 1024 * 1024) - (uintptr_t)(g.ax * g.cn)) & 15) : 0;
-    if ((32 + delta + spanX + 31) / 32 != (32 + spanX + 31) / 32) delta = 0;
-    g.delta = delta;
-    g.ksx = (32 + delta + spanX + 31) / 32;
+    // asynchronous staging wants 16-byte aligned chunks: the staged row starts delta elements early (delta < 16) -- when every row start moves by multiples of 16 and
+    // the shift does not push the row of taps beyond MAXKS K steps
+    const bool alignable = sstep % 16 == 0 && sframe % 16 == 0;
+    const int dAl = (int)((srcAddr + (uintptr_t)(16 * 1024 * 1024) - (uintptr_t)(g.ax * g.cn)) & 15);
+    g.dma = alignable && (32 + dAl + spanX + 31) / 32 <= MAXKS;
+    if (dmaOverride == 0) g.dma = 0;
+    g.delta = g.dma ? dAl : 0;
+    g.ksx = (32 + g.delta + spanX + 31) / 32;
     g.ksy = (32 + g.ny - 1 + 31) / 32;
     if (g.ksx < 2) g.ksx = 2;
     if (g.ksy < 2) g.ksy = 2;
     if (g.ksx > MAXKS || g.ksy > MAXKS) return false;
-    g.nchunk = (TW - 32 + 32 * g.ksx) / 16;
-    g.P = 16 * (g.nchunk | 1);
-    seeds(g, kx, ky);
-    // segments: enough workgroups to fill the chip (256 CUs x 2), each segment repeats (KSY - 1) tiles of row sums at its top
+    g.accL0 = colSeed(sy);
+    // segments: enough workgroups to fill the chip (256 CUs x 2 x 2), each segment repeats (KSY - 1) tiles of row sums at its top
     const int nstrips = (g.WE + TW - 1) / TW;
     int nseg = (1024 + nstrips * nframes - 1) / (nstrips * nframes);
     const int maxseg = (g.H + 4 * TR - 1) / (4 * TR);
@@ -124,25 +148,18 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     return true;
 }
 
-// One 16-byte chunk of the staged block: row r (0 .. 31) of step t of the segment starting at output row y0, chunk c of the row.  Returns false when the chunk is a plain
-// aligned-or-not 16-byte load (*ptr set), true when `out` was filled here (rows outside the image under BORDER_CONSTANT, chunks that touch the left / right rim).  The bytes
-// are unsigned pixels; the caller flips them to signed.
-MX_HD bool stageChunk(const Geom& g, const unsigned char* src, size_t sstep, int X0, int y0, int t, int r, int c, const unsigned char** ptr, unsigned char* out)
+// One 16-byte chunk of a staged row: source row (borderInterpolate of ROI row sy; -1 = zeros) and whether all 16 bytes lie inside the parent image's memory (then ONE
+// load; what the bytes of columns outside the image hold does not matter).  Only chunks that would reach before the first / past the last byte of the parent -- first and
+// last rows -- are assembled byte by byte.
+enum { CH_ZERO = 0, CH_LOAD = 1, CH_BYTES = 2 };
+MX_HD int chunkKind(const Geom& g, const unsigned char* src, size_t sstep, int sy, int e0, const unsigned char** ptr, long long* rel)
 {
-    const int sy = y0 - g.ay + TR * t + r;                             // ROI row of this row-sum row's source
     const int yy = borderIdx(sy + g.offY, g.fullH, g.border);
-    if (yy < 0) { for (int b = 0; b < 16; b++) out[b] = 0; return true; }
-    const unsigned char* row = src + (ptrdiff_t)(yy - g.offY) * (ptrdiff_t)sstep;
-    const int e0 = X0 - g.ax * g.cn - g.delta + 16 * c;                // ROI element of the chunk's first byte
-    const int f0 = e0 + g.offX * g.cn;                                 // the same in the full image
-    if (f0 >= 0 && f0 + 16 <= g.fullW * g.cn) { *ptr = row + e0; return false; }
-    for (int b = 0; b < 16; b++) {
-        const int f = f0 + b;
-        const int p = f >= 0 ? f / g.cn : -((-f + g.cn - 1) / g.cn), ch = f - p * g.cn;
-        const int q = borderIdx(p, g.fullW, g.border);
-        out[b] = q < 0 ? (unsigned char)0 : row[(ptrdiff_t)(q - g.offX) * g.cn + ch];
-    }
-    return true;
+    if (yy < 0) return CH_ZERO;
+    const long long a = (long long)yy * (long long)sstep + e0 + g.offX * g.cn;            // from the parent's first byte
+    *ptr = src + (ptrdiff_t)(yy - g.offY) * (ptrdiff_t)sstep + e0;
+    *rel = a;
+    return (a >= 0 && a + 16 <= g.span) ? CH_LOAD : CH_BYTES;
 }
 
 } // namespace sepmx

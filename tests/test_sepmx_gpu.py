@@ -40,8 +40,8 @@ def test_sepmx_shapes_and_borders(cv, orc, cn):
             for border in (0, 1, 2, 3, 4):
                 got = cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy()
                 k = last_kernel()
-                if (kw - 1) * cn <= 128 - 15:
-                    assert "k_sepmx<" in k, k
+                if (kw - 1) * cn <= 128 - 15 and border != 3 and w >= kw:
+                    assert "k_sepmx<" in k, k                                     # (BORDER_WRAP on a wide image, reflections in an image narrower than the kernel: k_seplong)
                 assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (w, h, cn, kw, kh, border, k)
 
 
