@@ -33,7 +33,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 using sepmx::Geom;
 using sepmx::TR;
-using sepmx::TW;
 
 __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone (vector-memory operations return in order: at most n of the newest are still out)
 {
@@ -41,27 +40,37 @@ __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone 
     case 0:  __builtin_amdgcn_s_waitcnt(0x0F70); break;
     case 1:  __builtin_amdgcn_s_waitcnt(0x0F71); break;
     case 2:  __builtin_amdgcn_s_waitcnt(0x0F72); break;
+    case 3:  __builtin_amdgcn_s_waitcnt(0x0F73); break;
+    case 4:  __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    case 5:  __builtin_amdgcn_s_waitcnt(0x0F75); break;
+    case 6:  __builtin_amdgcn_s_waitcnt(0x0F76); break;
     default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
 }
 
-template <int KSX, int KSY, bool DMA>
-__global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+template <int KSX, int KSY, bool DMA, int DEPTH, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 16 || KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                   Geom g, const int* __restrict__ bsel /* [strips][8] */, const int* __restrict__ seeds /* [classes][32] */,
                                                   const v4i* __restrict__ rowB /* [classes][2][KSX][64] */, const v4i* __restrict__ colA /* [KSY][64] */)
 {
-    constexpr int NCHUNK = (TW - 32 + 32 * KSX) / 16, PC = NCHUNK | 1, P = 16 * PC, NSLOT = DMA ? 3 : 2, NI = (TR * PC + 511) / 512;
+    constexpr int TW = 32 * NW, NT = 64 * NW, NCHUNK = (TW - 32 + 32 * KSX) / 16, PC = NCHUNK | 1, P = 16 * PC, NSLOT = DMA ? DEPTH + 1 : 2, NI = (TR * PC + NT - 1) / NT;
     static_assert(NI <= 2, "at most two chunks per lane and step");
-    __shared__ __attribute__((aligned(16))) uchar stage[NSLOT][TR * P];
-    __shared__ __attribute__((aligned(16))) uchar tr[2][TR * TW];
+    extern __shared__ uint4 lds16[];                     // NSLOT staged blocks of TR x P bytes, then two transposition blocks of TR x TW
+    uchar (*stage)[TR * P] = reinterpret_cast<uchar (*)[TR * P]>(lds16);
+    uchar (*tr)[TR * TW] = reinterpret_cast<uchar (*)[TR * TW]>(reinterpret_cast<uchar*>(lds16) + NSLOT * TR * P);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
-    src += (size_t)blockIdx.z * sframe;
-    dst += (size_t)blockIdx.z * dframe;
-    const int X0 = blockIdx.x * TW, y0 = blockIdx.y * g.seg;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd) {                                         // workgroups go to the XCDs round-robin by linear id: give each XCD a contiguous run of (frame, segment, strip)
+        const unsigned N = gridDim.x * gridDim.y * gridDim.z, L = bx + gridDim.x * (by + gridDim.y * bz), j = (L & 7) * (N >> 3) + (L >> 3);
+        bx = j % gridDim.x; by = (j / gridDim.x) % gridDim.y; bz = j / (gridDim.x * gridDim.y);
+    }
+    src += (size_t)bz * sframe;
+    dst += (size_t)bz * dframe;
+    const int X0 = bx * TW, y0 = by * g.seg;
     const int rows = min(g.seg, g.H - y0);
     const int nU = (rows + TR - 1) / TR, nT = nU + KSY - 1;
 
-    const int sel = __builtin_amdgcn_readfirstlane(bsel[blockIdx.x * 8 + wave]), cls = sel & 0xffff;
+    const int sel = __builtin_amdgcn_readfirstlane(bsel[bx * NW + wave]), cls = sel & 0xffff;
     const bool twice = (sel >> 16) != 0;                 // some weight of this wave's matrix is beyond int8: a second product with the rest (rim waves under BORDER_REPLICATE)
     v4i Bx[KSX], Ay[KSY];
 #pragma unroll
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const u
     int cr[NI], ce[NI]; bool cok[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        const int q = 64 * (wave + 8 * i) + lane, r = q / PC, c = q - r * PC;
+        const int q = 64 * (wave + NW * i) + lane, r = q / PC, c = q - r * PC;
         cr[i] = r; ce[i] = X0 - g.ax * g.cn - g.delta + 16 * c; cok[i] = q < TR * PC && c < NCHUNK;
     }
     auto bytesOf = [&](const uchar* p, long long rel) -> uint4 {                     // a chunk that reaches outside the parent's memory: the bytes inside, zeros for the rest
@@ -90,10 +99,10 @@ __global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const u
         int issued = 0;
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-            if (64 * (wave + 8 * i) >= TR * PC) continue;                            // (wave-uniform)
+            if (64 * (wave + NW * i) >= TR * PC) continue;                            // (wave-uniform)
             const uchar* p = src; long long rel = 0;
             const int kind = cok[i] ? sepmx::chunkKind(g, src, sstep, y0 - g.ay + TR * t + cr[i], ce[i], &p, &rel) : -1;
-            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + 8 * i)];
+            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + NW * i)];
             if (DMA) {
                 if (__ballot(kind == sepmx::CH_LOAD)) {
                     if (kind == sepmx::CH_LOAD) {
@@ -117,11 +126,11 @@ __global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const u
     auto deposit = [&](int t) {                                                      // (registers -> block; DMA = false)
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            if (64 * (wave + 8 * i) < TR * PC && cok[i]) *reinterpret_cast<uint4*>(&stage[t % NSLOT][16 * (64 * (wave + 8 * i) + lane)]) = park[DMA ? 0 : i];
+            if (64 * (wave + NW * i) < TR * PC && cok[i]) *reinterpret_cast<uint4*>(&stage[t % NSLOT][16 * (64 * (wave + NW * i) + lane)]) = park[DMA ? 0 : i];
     };
-    // an output tile (rows y0 + 32 u ..) from its transposition block, 4 rows of 256 bytes per wave
+    // an output tile (rows y0 + 32 u ..) from its transposition block, 1 KiB (4 / 2 whole row pieces) per wave
     auto emit = [&](int u, int buf) {
-        const int rr = 4 * wave + (lane >> 4), cc = 16 * (lane & 15);
+        const int rr = (TR / NW) * wave + lane / (TW / 16), cc = 16 * (lane % (TW / 16));
         const int y = TR * u + rr, x = X0 + cc;
         if (y >= rows || x >= g.WE) return;
         const uint4 v = *reinterpret_cast<const uint4*>(&tr[buf][rr * TW + cc]);
@@ -139,14 +148,26 @@ __global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const u
     for (int k = 0; k < KSY; k++) { ringH[k] = v4i{0, 0, 0, 0}; ringL[k] = v4i{0, 0, 0, 0}; }
 
     int newer = 0;                                       // asynchronous instructions this wave has issued after those of the step it is about to read
-    if (DMA) { (void)request(0); newer = nT > 1 ? request(1) : 0; }
-    else { (void)request(0); deposit(0); }
+    int inflight[DEPTH];                                 // ... per step still ahead
+    if (DMA) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) inflight[d] = d < nT ? request(d) : 0;
+    } else { (void)request(0); deposit(0); }
     for (int t = 0; t < nT; t++) {
-        if (DMA) waitVm(newer);
+        if (DMA) {
+            newer = 0;
+#pragma unroll
+            for (int d = 1; d < DEPTH; d++) newer += inflight[d];
+            waitVm(newer);
+        }
         __syncthreads();
         const int u = t - (KSY - 1);
         if (u >= 1) emit(u - 1, (t - 1) & 1);
-        if (DMA) newer = t + 2 < nT ? request(t + 2) : 0;
+        if (DMA) {
+#pragma unroll
+            for (int d = 0; d + 1 < DEPTH; d++) inflight[d] = inflight[d + 1];
+            inflight[DEPTH - 1] = t + DEPTH < nT ? request(t + DEPTH) : 0;
+        }
         else if (t + 1 < nT) (void)request(t + 1);
         // ---- row pass
         v16i acc;
@@ -200,26 +221,33 @@ __global__ __launch_bounds__(512, (KSX + KSY <= 5 ? 4 : 2)) void k_sepmx(const u
     emit(nU - 1, (nT - 1) & 1);
 }
 
-template <int KSX, bool DMA>
+template <int KSX, bool DMA, int DEPTH, int NW>
 void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
              const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
+    constexpr int TW = 32 * NW, PC = ((TW - 32 + 32 * KSX) / 16) | 1;
+    constexpr size_t lds = (size_t)(DMA ? DEPTH + 1 : 2) * TR * 16 * PC + 2 * (size_t)TR * TW;
+#define SEPMX_LAUNCH_(KSY_) do { \
+        static bool attr[64] = {}; const int dv = activeDevice() & 63; \
+        if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sepmx<KSX, KSY_, DMA, DEPTH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
+        hipLaunchKernelGGL((k_sepmx<KSX, KSY_, DMA, DEPTH, NW>), grid, dim3(64 * NW), lds, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); } while (0)
     switch (ksy) {
-    case 2:  hipLaunchKernelGGL((k_sepmx<KSX, 2, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 3:  hipLaunchKernelGGL((k_sepmx<KSX, 3, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 4:  hipLaunchKernelGGL((k_sepmx<KSX, 4, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    default: hipLaunchKernelGGL((k_sepmx<KSX, 5, DMA>), grid, dim3(512), 0, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 2:  SEPMX_LAUNCH_(2);  break;
+    case 3:  SEPMX_LAUNCH_(3);  break;
+    case 4:  SEPMX_LAUNCH_(4);  break;
+    default: SEPMX_LAUNCH_(5); break;
     }
+#undef SEPMX_LAUNCH_
 }
-template <bool DMA>
+template <bool DMA, int DEPTH, int NW>
 void launchX(int ksx, int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
              const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
     switch (ksx) {
-    case 2:  launchY<2, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 3:  launchY<3, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 4:  launchY<4, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    default: launchY<5, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 2:  launchY<2, DMA, DEPTH, NW>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 3:  launchY<3, DMA, DEPTH, NW>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 4:  launchY<4, DMA, DEPTH, NW>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    default: launchY<5, DMA, DEPTH, NW>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     }
 }
 
@@ -235,18 +263,23 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     memset(&g, 0, sizeof g);
     g.W = W; g.H = H; g.cn = cn; g.fullW = fullW; g.fullH = fullH; g.offX = offX; g.offY = offY; g.border = border; g.nx = nx; g.ny = ny; g.ax = ax; g.ay = ay;
     static const int dmaEnv = std::getenv("MI355CV_SEPMX_DMA") ? atoi(std::getenv("MI355CV_SEPMX_DMA")) : -1;
-    if (!sepmx::plan(g, kx, ky, (uintptr_t)src, sstep, nframes > 1 ? sframe : 0, nframes, 0, dmaEnv)) return false;
+    static const int segEnv = std::getenv("MI355CV_SEPMX_SEG") ? atoi(std::getenv("MI355CV_SEPMX_SEG")) : 0;
+    static const int xcdEnv = std::getenv("MI355CV_SEPMX_XCD") ? atoi(std::getenv("MI355CV_SEPMX_XCD")) : 0;
+    static const int nwEnv = std::getenv("MI355CV_SEPMX_NW") ? atoi(std::getenv("MI355CV_SEPMX_NW")) : 8;
+    if (!sepmx::plan(g, kx, ky, (uintptr_t)src, sstep, nframes > 1 ? sframe : 0, nframes, segEnv, dmaEnv, nwEnv == 16 ? 16 : 8)) return false;
+    if (!g.dma) g.nw = 8;
+    const int TW = 32 * g.nw;
     const int nstrips = (g.WE + TW - 1) / TW, nseg = (H + g.seg - 1) / g.seg;
     if (nseg > 65535) return false;
     // the row pass' operand classes: 0 = the plain Toeplitz matrix, one more per wave whose columns reach a left / right border (or the ragged end of the row)
     const size_t tabB = (size_t)g.ksx * 64 * 16;                                  // per class: the matrix, then the part of its weights beyond int8
-    std::vector<int> bsel((size_t)nstrips * 8, 0), seeds;
+    std::vector<int> bsel((size_t)nstrips * g.nw, 0), seeds;
     std::vector<int8_t> rowB;
     bool haveInterior = false;
     int ncls = 1;
     rowB.resize(2 * tabB); seeds.resize(32);
     for (int s = 0; s < nstrips; s++)
-        for (int w = 0; w < 8; w++) {
+        for (int w = 0; w < g.nw; w++) {
             int8_t tab[sepmx::MAXKS * 64 * 16], tab2[sepmx::MAXKS * 64 * 16]; int sd[32]; bool interior = false, twice = false;
             if (s * TW + 32 * w >= g.WE) continue;                                      // a wave without outputs: class 0, never stored
             if (!sepmx::buildRowB(g, kx, s * TW, w, tab, tab2, &twice, sd, &interior)) return false;
@@ -256,7 +289,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
             }
             if (ncls >= 4096) return false;
             rowB.insert(rowB.end(), tab, tab + tabB); rowB.insert(rowB.end(), tab2, tab2 + tabB); seeds.insert(seeds.end(), sd, sd + 32);
-            bsel[(size_t)s * 8 + w] = ncls++ | (twice ? 1 << 16 : 0);
+            bsel[(size_t)s * g.nw + w] = ncls++ | (twice ? 1 << 16 : 0);
         }
     g.ncls = ncls;
     std::vector<int8_t> colA((size_t)g.ksy * 64 * 16);
@@ -270,11 +303,15 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     const uchar* d = static_cast<const uchar*>(stg.param(blob.data(), blob.size()));
     if (!d) return false;
     const dim3 grid(nstrips, nseg, nframes);
+    g.xcd = xcdEnv && ((size_t)nstrips * nseg * nframes) % 8 == 0;
     const int* dsel = reinterpret_cast<const int*>(d); const int* dseed = reinterpret_cast<const int*>(d + o1);
     const v4i* dB = reinterpret_cast<const v4i*>(d + o2); const v4i* dA = reinterpret_cast<const v4i*>(d + o3);
-    if (g.dma) launchX<true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
-    else       launchX<false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
-    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, ncls, g.seg);
+    static const int depthEnv = std::getenv("MI355CV_SEPMX_DEPTH") ? atoi(std::getenv("MI355CV_SEPMX_DEPTH")) : 2;
+    if (g.dma && g.nw == 16 && depthEnv == 3) launchX<true, 3, 16>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    else if (g.dma && g.nw == 16) launchX<true, 2, 16>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    else if (g.dma)          launchX<true, 2, 8>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    else                     launchX<false, 1, 8>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x%d taps=%dx%d cn=%d delta=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, 64 * g.nw, nx, ny, cn, g.delta, ncls, g.seg);
     return true;
 }
 

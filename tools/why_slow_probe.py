@@ -27,7 +27,16 @@ o8k = torch.empty_like(f8k)
 hd1 = torch.randint(0, 256, (64, 1080, 1920), dtype=torch.uint8, device="cuda", generator=g)
 fhd = torch.empty((64, 1080, 1920), dtype=torch.float32, device="cuda")
 tpl = torch.randint(0, 256, (128, 128), dtype=torch.uint8, device="cuda", generator=g)
+gray48 = None
+def _g48():
+    global gray48
+    if gray48 is None:
+        gray48 = (torch.randint(0, 256, (48, H4, W4), dtype=torch.uint8, device="cuda", generator=g), torch.empty((48, H4, W4), dtype=torch.uint8, device="cuda"))
+    return gray48
 ROWS = {
+    "gauss_s3":        lambda: cv.GaussianBlurBatch(_g48()[0], (19, 19), sigmaX=3.0, dst=_g48()[1]),
+    "gauss_s21":       lambda: cv.GaussianBlurBatch(_g48()[0], (129, 129), sigmaX=21.0, dst=_g48()[1]),
+    "gauss_s3_c3":     lambda: cv.GaussianBlurBatch(bgr, (19, 19), sigmaX=3.0, dst=out3),
     "tm_cfg5":         lambda: cv.matchTemplateBatch(gray, tpl, 3),
     "affine_8k_32f":   lambda: cv.warpAffineBatch(f8k, cv.getRotationMatrix2D((7680 / 2.0, 4320 / 2.0), 7.0, 0.95), (7680, 4320), dst=o8k),
     "harris_1080p":    lambda: cv.cornerHarrisBatch(hd1, 2, 3, 0.04, dst=fhd),
