@@ -28,7 +28,6 @@ struct Geom {
     int dma;                                   // 1: rows arrive by asynchronous global -> LDS loads (16-byte aligned chunks), 0: through registers
     int seg;                                   // output rows per segment (a multiple of TR)
     int accL0;                                 // column-pass seed, see below
-    int nw;                                    // waves per workgroup (8 or 16): the strip is 32 nw bytes wide
     int xcd;                                   // 1: workgroup ids are dealt so that the strips of one XCD (linear id mod 8) are neighbours and share their halo columns in its L2
     int ncls;                                  // row-pass operand classes (0 = interior; one per wave whose columns see a left / right border)
     long long span;                            // bytes from the parent image's first byte to one past its last: (fullH - 1) * step + fullW * cn
@@ -115,7 +114,7 @@ inline void buildColA(const Geom& g, const uint16_t* ky, int8_t* tab)
 }
 
 // false: outside what the kernel covers (a tap beyond int8, more K steps than MAXKS)
-inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcAddr, size_t sstep, size_t sframe, int nframes, int segOverride = 0, int dmaOverride = -1, int nw = 8)
+inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcAddr, size_t sstep, size_t sframe, int nframes, int segOverride = 0, int dmaOverride = -1)
 {
     if (g.cn < 1 || g.cn > 4 || g.nx < 1 || g.ny < 1 || g.W < 1 || g.H < 1) return false;
     int sx = 0, sy = 0;
@@ -139,8 +138,7 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     if (g.ksx > MAXKS || g.ksy > MAXKS) return false;
     g.accL0 = colSeed(sy);
     // segments: enough workgroups to fill the chip (256 CUs x 2 x 2), each segment repeats (KSY - 1) tiles of row sums at its top
-    g.nw = nw;
-    const int nstrips = (g.WE + 32 * nw - 1) / (32 * nw);
+    const int nstrips = (g.WE + TW - 1) / TW;
     int nseg = (1024 + nstrips * nframes - 1) / (nstrips * nframes);
     const int maxseg = (g.H + 4 * TR - 1) / (4 * TR);
     if (nseg > maxseg) nseg = maxseg;

@@ -648,6 +648,14 @@ bool rollEligible(const uchar* s, size_t ss, size_t sf, const uchar* d, size_t d
     return true;
 }
 
+// from this many taps on (either axis) the matrix-core kernel goes first: it runs at the same speed for 3 .. 33 taps (3.8 us per 4K CV_8UC1 frame), the register-rolling
+// kernel slows down with every tap (5 / 7 / 9 taps: 3.5 / 4.3 / 5.5 us, three channels 9 taps 24 us against 11; profiles/r06_sepmx.txt)
+static int sepmxMinTaps()
+{
+    static const int v = std::getenv("MI355CV_SEPMX_MIN_TAPS") ? atoi(std::getenv("MI355CV_SEPMX_MIN_TAPS")) : 7;
+    return v;
+}
+
 int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe,
               int nframes, int W, int H, int cn, int mL, int mT, int mR, int mB,
               const uint16_t* kx, int nx, const uint16_t* ky, int ny, int border, bool binomial)
@@ -686,16 +694,19 @@ int runSmooth(const char* entry, const uchar* src, size_t sstep, size_t sframe, 
         if (nx == 5) { switch (cn) { case 1: ROLL(5, 1); break; case 2: ROLL(5, 2); break; case 3: ROLL(5, 3); break; default: ROLL(5, 4); } }
         else         { switch (cn) { case 1: ROLL(3, 1); break; case 2: ROLL(3, 2); break; case 3: ROLL(3, 3); break; default: ROLL(3, 4); } }
 #undef ROLL
+    } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && std::max(nx, ny) >= sepmxMinTaps() && !(std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') &&
+               sepmxRun(stg, dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, mL + W + mR, mT + H + mB, mL, mT, border, kx, nx, nx / 2, ky, ny, ny / 2, st)) {
+        // 7 taps or more on either axis, any geometry, margins included: both passes on the matrix cores (sepmx.hip) -- taps that fit int8 and span at most five 32-byte K steps
     } else if (noMargins && std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr &&
                seprollFixedSmooth(dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, kx, nx, ky, ny, border, st)) {
-        // any-sigma Q8.8 taps on the rolling skeleton
+        // any-sigma Q8.8 taps (<= 9) on the rolling skeleton
     } else if (!noMargins && nframes == 1 && std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && [&] {
                    // a submatrix with real pixels around it (cv_hal_gaussianBlurBinomial's margins): the rolling kernel on the parent's geometry, storing the window
                    const Roi roi = {mL + W + mR, mT + H + mB, mL, mT};
                    return seprollFixedSmooth(dsrc, dss, 0, ddst, dds, 0, 1, W, H, cn, kx, nx, ky, ny, border, st, &roi); }()) {
-    } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && !(std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') &&
+    } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && std::max(nx, ny) < sepmxMinTaps() && !(std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') &&
                sepmxRun(stg, dsrc, dss, sframe, ddst, dds, dframe, nframes, W, H, cn, mL + W + mR, mT + H + mB, mL, mT, border, kx, nx, nx / 2, ky, ny, ny / 2, st)) {
-        // any geometry, margins included, both passes on the matrix cores (sepmx.hip): taps that fit int8 and span at most five 32-byte K steps
+        // short kernels the rolling skeleton did not take (two channels, ...)
     } else if (std::getenv("MI355CV_SMOOTH_GENERIC") == nullptr && [&] {
                    // any length, any geometry, margins included: the LDS-ring kernel in its Q8.8 mode -- when no ufixedpoint16 / ufixedpoint32 sum can saturate
                    unsigned sx = 0, sy = 0;
