@@ -172,10 +172,12 @@ def other_configs(with_cpu=True):
     cpu["cfg4b"] = t(pyr)
     tpl = rng.integers(0, 256, (128, 128), dtype=np.uint8)
     cpu["cfg5"] = t(lambda: orc.ref_matchTemplate(gray, tpl, 3), reps=1)
-    # the long separable kernels (seplong.hip): cv::GaussianBlur sigma 3 / 5.5 on CV_8U (19 / 33 taps), sigma 16 / 3 on CV_32F with 97 / 19 taps
+    # the long separable kernels: cv::GaussianBlur sigma 3 / 5.5 / 21 on CV_8U (19 / 33 / 129 taps: sepmx.hip), sigma 16 / 3 on CV_32F with 97 / 19 taps (seplong.hip)
     cpu["gs3"] = t(lambda: orc.ref_GaussianBlur(gray, (19, 19), 3.0, 3.0, 4))
     cpu["gs3c3"] = t(lambda: orc.ref_GaussianBlur(bgr, (19, 19), 3.0, 3.0, 4))
     cpu["gs5"] = t(lambda: orc.ref_GaussianBlur(gray, (33, 33), 5.5, 5.5, 4))
+    cpu["gs21"] = t(lambda: orc.ref_GaussianBlur(gray, (129, 129), 21.0, 21.0, 4), reps=1)
+    cpu["gs15"] = t(lambda: orc.ref_GaussianBlur(gray, (9, 9), 1.5, 1.5, 4))
     f4k = np.ascontiguousarray(f8k[:H4K, :W4K])
     cpu["gs16"] = t(lambda: orc.ref_GaussianBlur(f4k, (97, 97), 16.0, 16.0, 4), reps=1)
     cpu["gs3f"] = t(lambda: orc.ref_GaussianBlur(f4k, (19, 19), 3.0, 3.0, 4))
@@ -306,7 +308,7 @@ def compact_summary(rows):
              "a8 warpAffine 4K 8UC1": "affine_8uc1", "a8 warpAffine 4K 8UC3": "affine_8uc3", "a9 warpPerspective 4K 8UC1": "persp_8uc1", "a9 warpPerspective 4K 8UC3": "persp_8uc3",
              "f1 integral 4K 8U -> 32S batch": "integral", "a7 resize 1080p 8UC3 -> 4K bilinear": "up2x_lin_8uc3", "a7 resize 1080p 8UC3 -> 4K INTER_CUBIC": "up2x_cubic_8uc3",
              "f2 warpAffine 4K 8UC1 rot 7deg INTER_CUBIC": "affine_cubic_8uc1", "f2 warpAffine 4K 8UC1 rot 7deg INTER_LANCZOS4": "affine_lanczos_8uc1",
-             "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "gs3 GaussianBlur": "gauss_sigma3_8uc1", "gs3c3 GaussianBlur": "gauss_sigma3_8uc3",
+             "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "gs3 GaussianBlur": "gauss_sigma3_8uc1", "gs3c3 GaussianBlur": "gauss_sigma3_8uc3", "gs21 GaussianBlur": "gauss_sigma21_8uc1",
              "gs16 GaussianBlur": "gauss_sigma16_32f", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
     for r in rows if isinstance(rows, list) else []:
         c = r.get("config", "")

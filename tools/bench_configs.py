@@ -255,10 +255,12 @@ def run(quick=False, parity=True):
     kxb = np.array([0.25, 0.5, 0.25], np.float32)
     bline("a4 sepFilter2D 3x3 (1/4,1/2,1/4) 4K 8U batch", lambda: cv.sepFilter2DBatch(gray, -1, kxb, kxb, dst=dstb), PIX4 * 2)
     bline("f1 threshold BINARY 4K 8U batch", lambda: cv.thresholdBatch(gray, 127, 255, 0, dst=dstb), PIX4 * 2)
-    # long separable kernels on the LDS-ring kernel (seplong.hip): cv::GaussianBlur with sigma 3 on CV_8U = 19 Q8.8 taps per axis
+    # cv::GaussianBlur on CV_8U beyond the 5 taps of the rolling kernels: both passes on the matrix cores (sepmx.hip); sigma 3 = 19 Q8.8 taps per axis
     bline("gs3 GaussianBlur sigma 3 (19 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (19, 19), dst=dstb, sigmaX=3.0), PIX4 * 2)
     bline("gs3c3 GaussianBlur sigma 3 (19 taps) 4K 8UC3 batch", lambda: cv.GaussianBlurBatch(bgr[:48], (19, 19), dst=bgr[48:96], sigmaX=3.0), PIX4 * 6, 48)
     bline("gs5 GaussianBlur sigma 5.5 (33 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (33, 33), dst=dstb, sigmaX=5.5), PIX4 * 2)
+    bline("gs21 GaussianBlur sigma 21 (129 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (129, 129), dst=dstb, sigmaX=21.0), PIX4 * 2)
+    bline("gs15 GaussianBlur 9x9 sigma 1.5 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (9, 9), dst=dstb, sigmaX=1.5), PIX4 * 2)
     BH = frames_for(PIX4 + PIX4 // 4, 16)
     half = torch.empty((BH, 1080, 1920), dtype=torch.uint8, device=dev)
     g2 = gray if BH <= B2 else torch.randint(0, 256, (BH, H4, W4), dtype=torch.uint8, device=dev, generator=g)
