@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
     }
     src += (size_t)bz * sframe;
     dst += (size_t)bz * dframe;
-    const int X0 = bx * TW, y0 = by * g.seg;
+    const int X0 = (int)bx * TW - g.shift, y0 = by * g.seg;
     const int rows = min(g.seg, g.H - y0);
     const int nU = (rows + TR - 1) / TR, nT = nU + KSY - 1;
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
     for (int k = 0; k < KSX; k++) Bx[k] = rowB[(cls * 2 * KSX + k) * 64 + lane];
     // the column pass' A operand is the same for every wave: it waits in LDS and is read where it is used (KSY x 4 registers less per lane: what keeps two workgroups on a CU)
     if (tid < KSY * 64) AyL[tid] = colA[tid];
-    const int seedR = seeds[cls * 32 + n];
+    const int seedC = seeds[cls * 32 + n];            // the column's constant of the column pass (sepmx_body.h: the arithmetic)
 
     // staging: a block is TR rows of PC 16-byte chunks, chunk q at byte 16 q (the last chunk of a row is padding: the pitch is 16 * odd); wave-instruction i of wave w covers
     // chunks 64 (w + 8 i) .. + 63
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
     // request the rows of step t; returns the number of asynchronous wave-instructions issued (DMA)
     auto request = [&](int t) -> int {
         int issued = 0;
+        const int syA = y0 - g.ay + TR * t + g.offY;                                 // the step's first source row in the parent
+        const bool inner = g.fast && syA >= 1 && syA + TR - 1 <= g.fullH - 2;        // (uniform)
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             if (64 * (wave + NW * i) >= TR * PC) continue;                            // (wave-uniform)
@@ -104,7 +106,12 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
             asm volatile("" : "+v"(ln));                                              // (opaque: the chunk's row / column / base pointer are recomputed per step -- hoisted out
             const int q = 64 * (wave + NW * i) + ln, cr = q / PC, cc = q - cr * PC;    //  of the walk they are six more registers per lane, and a spilled register comes back
             const int e0 = X0 - g.ax * g.cn - g.delta + 16 * cc;                       //  through vector memory, behind every row piece in flight)
-            const int kind = (q < TR * PC && cc < NCHUNK) ? sepmx::chunkKind(g, src, sstep, y0 - g.ay + TR * t + cr, e0, &p, &rel) : -1;
+            int kind = -1;
+            if (q < TR * PC && cc < NCHUNK) {
+                const int sy = y0 - g.ay + TR * t + cr;
+                if (inner) { kind = sepmx::CH_LOAD; p = src + (ptrdiff_t)sy * (ptrdiff_t)sstep + e0; }          // every row of the step is a real row away from the parent's rim: no border, no rim test
+                else kind = sepmx::chunkKind(g, src, sstep, sy, e0, &p, &rel);
+            }
             uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + NW * i)];
             if (DMA) {
                 if (__ballot(kind == sepmx::CH_LOAD)) {
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
                 park[i] = v;
             }
         }
-        return issued;
+        return __builtin_amdgcn_readfirstlane(issued);
     };
     auto deposit = [&](int t) {                                                      // (registers -> block; DMA = false)
 #pragma unroll
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
     auto emit = [&](int u, int buf) {
         const int rr = (TR / NW) * wave + lane / (TW / 16), cc = 16 * (lane % (TW / 16));
         const int y = TR * u + rr, x = X0 + cc;
-        if (y >= rows || x >= g.WE) return;
+        if (y >= rows || x < 0 || x >= g.WE) return;
         const uint4 v = *reinterpret_cast<const uint4*>(&tr[buf][rr * TW + cc]);
         uchar* d = dst + (size_t)(y0 + y) * dstep + x;
         if (x + 16 <= g.WE) __builtin_memcpy(d, &v, 16);
@@ -174,9 +181,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
         else if (t + 1 < nT) (void)request(t + 1);
         __builtin_amdgcn_sched_barrier(0);               // (phase fences: the scheduler otherwise hoists the next phase's LDS reads over this one and runs out of registers;
         // ---- row pass                                  //  a spilled register is reloaded through vector memory, behind every row piece in flight)
-        v16i acc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = seedR;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const uchar* A = &stage[t % NSLOT][n * P + 32 * wave + 16 * h];
 #pragma unroll
         for (int k = 0; k < KSX; k++) {
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
             // ---- column pass
             v16i aH, aL;
 #pragma unroll
-            for (int i = 0; i < 16; i++) { aH[i] = 0; aL[i] = g.accL0; }
+            for (int i = 0; i < 16; i++) { aH[i] = 0; aL[i] = seedC; }
 #pragma unroll
             for (int k = 0; k < KSY; k++) {
                 const v4i ay = AyL[k * 64 + lane];
@@ -274,7 +279,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     static const int xcdEnv = std::getenv("MI355CV_SEPMX_XCD") ? atoi(std::getenv("MI355CV_SEPMX_XCD")) : 1;
     if (!sepmx::plan(g, kx, ky, (uintptr_t)src, sstep, nframes > 1 ? sframe : 0, nframes, segEnv, dmaEnv)) return false;
     constexpr int TW = sepmx::TW;
-    const int nstrips = (g.WE + TW - 1) / TW, nseg = (H + g.seg - 1) / g.seg;
+    const int nstrips = (g.WE + g.shift + TW - 1) / TW, nseg = (H + g.seg - 1) / g.seg;
     if (nseg > 65535) return false;
     // The operand block (bsel | seeds | rowB | colA, each part 16-byte aligned) depends on the taps and the row geometry only: callers filter frame after frame with the same
     // parameters, so the last few blocks stay resident on the device (building one costs ~0.1 ms of host time, a per-frame call is ~20 us)
@@ -282,7 +287,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     static std::mutex mu;
     static std::vector<Block> cache;
     static unsigned long long clock = 0;
-    std::vector<int> key = {nx, ny, ax, ay, cn, W, fullW, offX, border, g.delta, g.ksx, g.ksy};
+    std::vector<int> key = {nx, ny, ax, ay, cn, W, fullW, offX, border, g.delta, g.shift, g.ksx, g.ksy};
     key.insert(key.end(), kx, kx + nx); key.insert(key.end(), ky, ky + ny);
     const int dev = activeDevice();
     const uchar* d = nullptr; size_t o1 = 0, o2 = 0, o3 = 0;
@@ -299,12 +304,12 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
         int ncls = 1;
         for (int s = 0; s < nstrips; s++)
             for (int w = 0; w < 8; w++) {
-                const int e0 = s * TW + 32 * w, e1 = e0 + 31;
-                if (e0 >= g.WE) continue;                                             // a wave without outputs: class 0, never stored
-                const bool inside = e1 < g.WE && e0 / cn + offX - ax >= 0 && e1 / cn + offX + (nx - 1 - ax) < fullW;
+                const int e0 = s * TW - g.shift + 32 * w, e1 = e0 + 31;
+                if (e1 < 0 || e0 >= g.WE) continue;                                   // a wave without outputs: class 0, never stored
+                const bool inside = e0 >= 0 && e1 < g.WE && e0 / cn + offX - ax >= 0 && e1 / cn + offX + (nx - 1 - ax) < fullW;
                 if (inside && haveInterior) continue;
                 int8_t tab[sepmx::MAXKS * 64 * 16], tab2[sepmx::MAXKS * 64 * 16]; int sd[32]; bool interior = false, twice = false;
-                if (!sepmx::buildRowB(g, kx, s * TW, w, tab, tab2, &twice, sd, &interior)) return false;
+                if (!sepmx::buildRowB(g, kx, g.sumKy, s * TW - g.shift, w, tab, tab2, &twice, sd, &interior)) return false;
                 if (interior) { memcpy(rowB.data(), tab, tabB); memcpy(seeds.data(), sd, sizeof sd); haveInterior = true; continue; }
                 if (ncls >= 4096) return false;
                 rowB.insert(rowB.end(), tab, tab + tabB); rowB.insert(rowB.end(), tab2, tab2 + tabB); seeds.insert(seeds.end(), sd, sd + 32);
@@ -338,7 +343,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     const v4i* dB = reinterpret_cast<const v4i*>(d + o2); const v4i* dA = reinterpret_cast<const v4i*>(d + o3);
     if (g.dma) launchX<true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
     else       launchX<false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
-    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, ncls, g.seg);
+    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d shift=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, g.shift, ncls, g.seg);
     return true;
 }
 

@@ -25,9 +25,11 @@ struct Geom {
     int nx, ny, ax, ay;
     int ksx, ksy;
     int delta;                                 // the staged row starts at ROI element X0 - ax * cn - delta (delta makes the 16-byte loads aligned)
+    int shift;                                 // strips start at element 256 s - shift (0 / 32 / 64 / 96): the position against the 128-byte lines at which a staged row piece touches the fewest
     int dma;                                   // 1: rows arrive by asynchronous global -> LDS loads (16-byte aligned chunks), 0: through registers
     int seg;                                   // output rows per segment (a multiple of TR)
-    int accL0;                                 // column-pass seed, see below
+    int fast;                                  // the row pitch is >= 512 bytes: a chunk of a row that is neither the parent's first nor its last lies inside the parent's memory
+    int sumKy;                                 // the column taps' sum (the seeds of the column pass depend on it)
     int xcd;                                   // 1: workgroup ids are dealt so that the strips of one XCD (linear id mod 8) are neighbours and share their halo columns in its L2
     int ncls;                                  // row-pass operand classes (0 = interior; one per wave whose columns see a left / right border)
     long long span;                            // bytes from the parent image's first byte to one past its last: (fullH - 1) * step + fullW * cn
@@ -57,19 +59,19 @@ MX_HD int borderIdx(int p, int len, int type)              // borderInterpolate 
 
 // The arithmetic.  fixedSmoothInvoker with taps that sum to <= 256 per axis (no ufixedpoint saturation): dst = (sum_j ky[j] * R[y + j] + 2^15) >> 16 with the Q8.8 row sums
 // R = sum_i kx[i] * s <= 255 * 256.  On signed 8-bit operands:
-//   row pass     acc = accR0 + sum kx (s - 128),  accR0 = 128 sum(kx) + 128 - 32768           =>  acc = R + 128 - 32768 in [-32640, 32640]
-//                acc = 256 Hh + L with Hh = (signed) byte 1, L = (unsigned) byte 0; l = L - 128 =>  R = 256 Hh + l + 32768, both Hh and l in int8
-//   column pass  accH = sum ky Hh,  accL = accL0 + sum ky l,  accL0 = 32768 sum(ky) + 32768     =>  (accH << 8) + accL = sum ky R + 2^15, < 2^24: the result is its byte 2
-MX_HD int rowSeed(int sumPresentTaps) { return 128 * sumPresentTaps + 128 - 32768; }
-MX_HD int colSeed(int sumTaps) { return 32768 * sumTaps + 32768; }
+//   row pass     acc = sum kx (s - 128) in [-32768, 32512] (it starts at the inline constant 0: no register moves)  =>  R = acc + 128 P, P = the sum of the taps present
+//                acc = 256 Hh + L with Hh = (signed) byte 1, L = (unsigned) byte 0; l = L - 128, both in int8           =>  R = 256 Hh + l + 128 + 128 P
+//   column pass  accH = sum ky Hh,  accL = C + sum ky l  =>  (accH << 8) + accL = sum ky R + 2^15 with C = (128 + 128 P) sum(ky) + 2^15: a constant of the COLUMN (P differs
+//                where BORDER_CONSTANT drops taps), i.e. of the lane; the value is < 2^24 and the result is its byte 2
+MX_HD int colSeed(int sumPresentTapsX, int sumTapsY) { return (128 + 128 * sumPresentTapsX) * sumTapsY + 32768; }
 
 // Row-pass B operand of one wave (strip X0, wave w: output elements X0 + 32 w + n): tab[ks][lane][16], lane (n, h), byte i <-> staged column k = 32 ks + 16 h + i of the
 // wave's window, which starts at ROI element X0 + 32 w - ax cn - delta.  The LEFT / RIGHT BORDER IS FOLDED INTO THE MATRIX: tap i of output element x reads pixel
 // borderInterpolate(x / cn + i - ax) of the full image -- its weight is added at THAT pixel's column (two taps can land on one column under the reflecting rules), taps that
-// fall outside under BORDER_CONSTANT are dropped (and leave the column's seed: seed[n] = rowSeed(sum of the taps present)).  The staged bytes of columns outside the image
+// fall outside under BORDER_CONSTANT are dropped (and leave the column's seed: seed[n] = colSeed(sum of the taps present, sum of ky)).  The staged bytes of columns outside the image
 // then never matter (weight 0): staging needs no border logic along x.  false: a folded weight beyond 2 x 127, or a border pixel outside the wave's window (BORDER_WRAP on
 // an image wider than the window, reflections in an image narrower than the kernel): the caller hands the call to the vector kernel.  *interior: no tap was moved; *twice: tab2 is not empty.
-inline bool buildRowB(const Geom& g, const uint16_t* kx, int X0, int w, int8_t* tab, int8_t* tab2, bool* twice, int* seed, bool* interior)
+inline bool buildRowB(const Geom& g, const uint16_t* kx, int sumKy, int X0, int w, int8_t* tab, int8_t* tab2, bool* twice, int* seed, bool* interior)
 {
     int wt[32 * MAXKS][32];
     memset(wt, 0, sizeof wt);
@@ -78,7 +80,7 @@ inline bool buildRowB(const Geom& g, const uint16_t* kx, int X0, int w, int8_t* 
     for (int n = 0; n < 32; n++) {
         const int xe = X0 + 32 * w + n;
         int present = 0;
-        if (xe >= g.WE) { seed[n] = rowSeed(0); *interior = false; continue; }          // not an output: an empty column
+        if (xe < 0 || xe >= g.WE) { seed[n] = colSeed(0, sumKy); *interior = false; continue; }   // not an output: an empty column
         const int px = xe / g.cn, ch = xe - px * g.cn;
         for (int i = 0; i < g.nx; i++) {
             const int pf = px + g.offX + i - g.ax, q = borderIdx(pf, g.fullW, g.border);
@@ -89,7 +91,7 @@ inline bool buildRowB(const Geom& g, const uint16_t* kx, int X0, int w, int8_t* 
             wt[k][n] += kx[i]; present += kx[i];
             if (wt[k][n] > 254) return false;
         }
-        seed[n] = rowSeed(present);
+        seed[n] = colSeed(present, sumKy);
     }
     // a weight beyond int8 (BORDER_REPLICATE piles up to half the kernel on the rim pixel) is applied in two products: min(w, 127) here, the rest in tab2
     for (int ks = 0; ks < g.ksx; ks++)
@@ -136,9 +138,22 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     if (g.ksx < 2) g.ksx = 2;
     if (g.ksy < 2) g.ksy = 2;
     if (g.ksx > MAXKS || g.ksy > MAXKS) return false;
-    g.accL0 = colSeed(sy);
+    g.sumKy = sy;
+    g.fast = sstep >= 512;
+    // A staged row piece is 224 + 32 KSX bytes from element X0 - ax cn - delta.  With strips at multiples of 256 it starts 16 .. 64 bytes before a 128-byte line and touches
+    // one line more than it has to (19 taps: four lines, 512 bytes, for 256 bytes of output: profiles/r06_sepmx.txt); strips moved left by whole 32-column blocks put it
+    // where it touches the fewest (the first strip's leading blocks then have no outputs).
+    {
+        const int piece = TW - 32 + 32 * g.ksx;
+        int best = 0, bestLines = 1 << 30;
+        for (int sh = 0; sh < 128; sh += 32) {
+            const int a0 = (int)((srcAddr + (uintptr_t)(16 * 1024 * 1024) - (uintptr_t)(g.ax * g.cn + g.delta + sh)) & 127), lines = (a0 + piece + 127) / 128;
+            if (lines < bestLines) { bestLines = lines; best = sh; }
+        }
+        g.shift = best;
+    }
     // segments: enough workgroups to fill the chip (256 CUs x 2 x 2), each segment repeats (KSY - 1) tiles of row sums at its top
-    const int nstrips = (g.WE + TW - 1) / TW;
+    const int nstrips = (g.WE + g.shift + TW - 1) / TW;
     int nseg = (1024 + nstrips * nframes - 1) / (nstrips * nframes);
     const int maxseg = (g.H + 4 * TR - 1) / (4 * TR);
     if (nseg > maxseg) nseg = maxseg;
