@@ -24,6 +24,7 @@
 #include "roll.h"
 #include "seproll.h"
 #include "seplong.h"
+#include "sepmx.h"
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -1235,6 +1236,20 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
 }
 
 // nframes == 0: the hook (one image, margins, host or device); nframes >= 1: a batch of device-resident whole frames
+// CV_8U -> CV_8U windows the rolling kernels do not take (9 .. 129 per axis, any anchor, 2 channels, ROI windows): the window sum is two products with banded matrices of
+// ones -- k_sepmx (sepmx.hip) computes it exactly on the matrix cores, nx + ny "taps" per byte instead of the kw * kh loads of k_box_generic, and finishes with the
+// reference's own normalisation.
+static bool boxOnMatrixCores(Stager& stg, const BoxParams& p, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int cn,
+                             int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border)
+{
+    if (sdepth != D8U || ddepth != D8U || cn > 4 || p.mode == 2 || p.kw > lim::SEP_MAX_TAPS || p.kh > lim::SEP_MAX_TAPS) return false;
+    if (std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') return false;
+    uint16_t ones[lim::SEP_MAX_TAPS];
+    for (int i = 0; i < lim::SEP_MAX_TAPS; i++) ones[i] = 1;
+    const SepmxBox b = {!p.normalize ? 3 : p.mode == 0 ? 1 : 2, p.divScale, p.divDelta, p.scaleF, p.scaleD};
+    return sepmxRun(stg, src, sstep, sframe, dst, dstep, dframe, nframes, W, H, cn, fullW, fullH, offX, offY, border, ones, p.kw, p.ax, ones, p.kh, p.ay, stream(), &b);
+}
+
 static int boxRun(const char* entry, const uchar* src_data, size_t src_step, size_t sframe, uchar* dst_data, size_t dst_step, size_t dframe, int nframes, int width, int height,
         int src_depth, int dst_depth, int cn, int margin_left, int margin_top, int margin_right, int margin_bottom,
         size_t ksize_width, size_t ksize_height, int anchor_x, int anchor_y, bool normalize, int border_type)
@@ -1293,6 +1308,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         if (p.mode == 2 && src_depth == D32F && dst_depth == D32F && cn == 1 && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
             seprollBoxF32(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, kw, p.normalize != 0, border, stream()))
             return stg.finish(entry);
+        if (boxOnMatrixCores(stg, p, src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, src_depth, dst_depth, width, height, 0, 0, border)) return stg.finish(entry);
         dim3 grid(divUp(width * cn, 64), divUp(height, 4));
         for (int f = 0; f < nframes; f++)
             hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * sframe, src_step, dst_data + (size_t)f * dframe, dst_step, width, height, cn,
@@ -1313,6 +1329,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     if (p.mode == 2 && src_depth == D32F && dst_depth == D32F && cn == 1 && kw == kh && p.ax == kw / 2 && p.ay == kh / 2 &&
         seprollBoxF32(ds, dss, 0, dd, dds, 0, 1, width, height, kw, p.normalize != 0, border, stream(), roi))
         return stg.finish(entry);
+    if (boxOnMatrixCores(stg, p, ds, dss, 0, dd, dds, 0, 1, width, height, cn, src_depth, dst_depth, fullW, fullH, margin_left, margin_top, border)) return stg.finish(entry);
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
                        fullW, fullH, margin_left, margin_top, border, p);

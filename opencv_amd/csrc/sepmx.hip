@@ -50,8 +50,8 @@ __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone 
     }
 }
 
-template <int KSX, int KSY, bool DMA>
-__global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+template <int KSX, int KSY, bool DMA, bool BOX>
+__global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 7 : KSX + KSY <= 5) ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                   Geom g, const int* __restrict__ bsel /* [strips][8] */, const int* __restrict__ seeds /* [classes][32] */,
                                                   const v4i* __restrict__ rowB /* [classes][2][KSX][64] */, const v4i* __restrict__ colA /* [KSY][64] */)
 {
@@ -221,10 +221,27 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
                 aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(ay, ringL[k], aL, 0, 0, 0);
             }
             uchar* T = &tr[t & 1][32 * wave + n];
+            if (BOX) {
+                // cv::boxFilter's normalisations on the exact window sum (box_filter.simd.hpp: ColumnSum<ushort, uchar> :429-455, ColumnSum<int, uchar> :340-385)
+                const bool tail = X0 + 32 * wave + n >= g.tailStart;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const unsigned v = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
-                T[sepmx::regRow(h, i) * TW] = (uchar)(v >> 16);
+                for (int i = 0; i < 16; i++) {
+                    const unsigned sum = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
+                    unsigned r;
+                    if (g.box == 1) r = ((sum + (unsigned)g.divDelta) * (unsigned)g.divScale) >> 23;
+                    else if (g.box == 3) r = sum > 255u ? 255u : sum;
+                    else {
+                        const float f = tail ? (float)rint((double)sum * g.scaleD) : rintf((float)sum * g.scaleF);
+                        r = (unsigned)(int)fminf(fmaxf(f, 0.f), 255.f);
+                    }
+                    T[sepmx::regRow(h, i) * TW] = (uchar)r;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned v = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
+                    T[sepmx::regRow(h, i) * TW] = (uchar)(v >> 16);
+                }
             }
         }
         if (!DMA && t + 1 < nT) deposit(t + 1);
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 5 : KSX + KSY <= 4) ? 4 :
     emit(nU - 1, (nT - 1) & 1);
 }
 
-template <int KSX, bool DMA>
+template <int KSX, bool DMA, bool BOX>
 void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
              const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
@@ -241,8 +258,8 @@ void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep,
     constexpr size_t lds = (size_t)(DMA ? 3 : 2) * TR * 16 * PC + 2 * (size_t)TR * TW + 1024 * 5;
 #define SEPMX_LAUNCH_(KSY_) do { \
         static bool attr[64] = {}; const int dv = activeDevice() & 63; \
-        if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sepmx<KSX, KSY_, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
-        hipLaunchKernelGGL((k_sepmx<KSX, KSY_, DMA>), grid, dim3(512), lds, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); } while (0)
+        if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sepmx<KSX, KSY_, DMA, BOX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
+        hipLaunchKernelGGL((k_sepmx<KSX, KSY_, DMA, BOX>), grid, dim3(512), lds, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); } while (0)
     switch (ksy) {
     case 2:  SEPMX_LAUNCH_(2);  break;
     case 3:  SEPMX_LAUNCH_(3);  break;
@@ -251,15 +268,15 @@ void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep,
     }
 #undef SEPMX_LAUNCH_
 }
-template <bool DMA>
+template <bool DMA, bool BOX>
 void launchX(int ksx, int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, const Geom& g,
              const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
     switch (ksx) {
-    case 2:  launchY<2, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 3:  launchY<3, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    case 4:  launchY<4, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    default: launchY<5, DMA>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 2:  launchY<2, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 3:  launchY<3, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 4:  launchY<4, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    default: launchY<5, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     }
 }
 
@@ -268,12 +285,14 @@ void launchX(int ksx, int ksy, dim3 grid, hipStream_t st, const uchar* src, size
 namespace mi355 {
 
 bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
-              int W, int H, int cn, int fullW, int fullH, int offX, int offY, int border, const uint16_t* kx, int nx, int ax, const uint16_t* ky, int ny, int ay, hipStream_t st)
+              int W, int H, int cn, int fullW, int fullH, int offX, int offY, int border, const uint16_t* kx, int nx, int ax, const uint16_t* ky, int ny, int ay, hipStream_t st,
+              const SepmxBox* box)
 {
     if (nframes < 1 || nframes > 65535 || border < 0 || border > B_REFLECT_101 || ax < 0 || ax >= nx || ay < 0 || ay >= ny) return false;
     Geom g;
     memset(&g, 0, sizeof g);
     g.W = W; g.H = H; g.cn = cn; g.fullW = fullW; g.fullH = fullH; g.offX = offX; g.offY = offY; g.border = border; g.nx = nx; g.ny = ny; g.ax = ax; g.ay = ay;
+    if (box) { g.box = box->mode; g.divScale = box->divScale; g.divDelta = box->divDelta; g.scaleF = box->scaleF; g.scaleD = box->scaleD; g.tailStart = (W * cn) & ~7; }
     static const int dmaEnv = std::getenv("MI355CV_SEPMX_DMA") ? atoi(std::getenv("MI355CV_SEPMX_DMA")) : -1;
     static const int segEnv = std::getenv("MI355CV_SEPMX_SEG") ? atoi(std::getenv("MI355CV_SEPMX_SEG")) : 0;
     static const int xcdEnv = std::getenv("MI355CV_SEPMX_XCD") ? atoi(std::getenv("MI355CV_SEPMX_XCD")) : 1;
@@ -287,7 +306,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     static std::mutex mu;
     static std::vector<Block> cache;
     static unsigned long long clock = 0;
-    std::vector<int> key = {nx, ny, ax, ay, cn, W, fullW, offX, border, g.delta, g.shift, g.ksx, g.ksy};
+    std::vector<int> key = {nx, ny, ax, ay, cn, W, fullW, offX, border, g.delta, g.shift, g.ksx, g.ksy, g.box != 0};
     key.insert(key.end(), kx, kx + nx); key.insert(key.end(), ky, ky + ny);
     const int dev = activeDevice();
     const uchar* d = nullptr; size_t o1 = 0, o2 = 0, o3 = 0;
@@ -341,9 +360,14 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     g.xcd = xcdEnv && ((size_t)nstrips * nseg * nframes) % 8 == 0;
     const int* dsel = reinterpret_cast<const int*>(d); const int* dseed = reinterpret_cast<const int*>(d + o1);
     const v4i* dB = reinterpret_cast<const v4i*>(d + o2); const v4i* dA = reinterpret_cast<const v4i*>(d + o3);
-    if (g.dma) launchX<true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
-    else       launchX<false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
-    noteKernel("k_sepmx<%d,%d,%d> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d shift=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, grid.x, grid.y, grid.z, nx, ny, cn, g.delta, g.shift, ncls, g.seg);
+    if (g.box) {
+        if (g.dma) launchX<true, true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+        else       launchX<false, true>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    } else {
+        if (g.dma) launchX<true, false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+        else       launchX<false, false>(g.ksx, g.ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, dsel, dseed, dB, dA);
+    }
+    noteKernel("k_sepmx<%d,%d,%d%s> grid=%ux%ux%u x512 taps=%dx%d cn=%d delta=%d shift=%d classes=%d seg=%d", g.ksx, g.ksy, g.dma, g.box ? ",box" : "", grid.x, grid.y, grid.z, nx, ny, cn, g.delta, g.shift, ncls, g.seg);
     return true;
 }
 

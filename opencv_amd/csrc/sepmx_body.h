@@ -28,6 +28,8 @@ struct Geom {
     int shift;                                 // strips start at element 256 s - shift (0 / 32 / 64 / 96): the position against the 128-byte lines at which a staged row piece touches the fewest
     int dma;                                   // 1: rows arrive by asynchronous global -> LDS loads (16-byte aligned chunks), 0: through registers
     int seg;                                   // output rows per segment (a multiple of TR)
+    int box, divScale, divDelta, tailStart;    // box filter finish (0: the Gaussian's byte 2; 1: ((s + dd) * ds) >> 23; 2: cvRound(float(s) * scaleF), the row's last (WE % 8) elements in double; 3: saturate(s))
+    float scaleF; double scaleD;
     int fast;                                  // the row pitch is >= 512 bytes: a chunk of a row that is neither the parent's first nor its last lies inside the parent's memory
     int sumKy;                                 // the column taps' sum (the seeds of the column pass depend on it)
     int xcd;                                   // 1: workgroup ids are dealt so that the strips of one XCD (linear id mod 8) are neighbours and share their halo columns in its L2
@@ -63,7 +65,7 @@ MX_HD int borderIdx(int p, int len, int type)              // borderInterpolate 
 //                acc = 256 Hh + L with Hh = (signed) byte 1, L = (unsigned) byte 0; l = L - 128, both in int8           =>  R = 256 Hh + l + 128 + 128 P
 //   column pass  accH = sum ky Hh,  accL = C + sum ky l  =>  (accH << 8) + accL = sum ky R + 2^15 with C = (128 + 128 P) sum(ky) + 2^15: a constant of the COLUMN (P differs
 //                where BORDER_CONSTANT drops taps), i.e. of the lane; the value is < 2^24 and the result is its byte 2
-MX_HD int colSeed(int sumPresentTapsX, int sumTapsY) { return (128 + 128 * sumPresentTapsX) * sumTapsY + 32768; }
+MX_HD int colSeed(int sumPresentTapsX, int sumTapsY, int box) { return (128 + 128 * sumPresentTapsX) * sumTapsY + (box ? 0 : 32768); }      // (a box filter wants the plain sum)
 
 // Row-pass B operand of one wave (strip X0, wave w: output elements X0 + 32 w + n): tab[ks][lane][16], lane (n, h), byte i <-> staged column k = 32 ks + 16 h + i of the
 // wave's window, which starts at ROI element X0 + 32 w - ax cn - delta.  The LEFT / RIGHT BORDER IS FOLDED INTO THE MATRIX: tap i of output element x reads pixel
@@ -80,7 +82,7 @@ inline bool buildRowB(const Geom& g, const uint16_t* kx, int sumKy, int X0, int 
     for (int n = 0; n < 32; n++) {
         const int xe = X0 + 32 * w + n;
         int present = 0;
-        if (xe < 0 || xe >= g.WE) { seed[n] = colSeed(0, sumKy); *interior = false; continue; }   // not an output: an empty column
+        if (xe < 0 || xe >= g.WE) { seed[n] = colSeed(0, sumKy, g.box); *interior = false; continue; }   // not an output: an empty column
         const int px = xe / g.cn, ch = xe - px * g.cn;
         for (int i = 0; i < g.nx; i++) {
             const int pf = px + g.offX + i - g.ax, q = borderIdx(pf, g.fullW, g.border);
@@ -91,7 +93,7 @@ inline bool buildRowB(const Geom& g, const uint16_t* kx, int sumKy, int X0, int 
             wt[k][n] += kx[i]; present += kx[i];
             if (wt[k][n] > 254) return false;
         }
-        seed[n] = colSeed(present, sumKy);
+        seed[n] = colSeed(present, sumKy, g.box);
     }
     // a weight beyond int8 (BORDER_REPLICATE piles up to half the kernel on the rim pixel) is applied in two products: min(w, 127) here, the rest in tab2
     for (int ks = 0; ks < g.ksx; ks++)

@@ -114,3 +114,42 @@ def test_sepmx_handover(cv, orc, monkeypatch):
     got = cv.sepSmoothFixedU8(_dev(src), kx, kx, 4).cpu().numpy()
     assert "k_seplong<3," in last_kernel(), last_kernel()
     assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, kx, 4))
+
+
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_sepmx_box_filter(cv, orc, cn):
+    """cv::boxFilter / cv::blur on CV_8U beyond the 7 x 7 of the rolling kernels: the window sum on the matrix cores (taps of 1), finished with the reference's own
+    normalisations -- ColumnSum<ushort, uchar>'s reciprocal pair for areas <= 256, ColumnSum<int, uchar>'s float multiply with its double row tail beyond, plain
+    saturation un-normalised (box_filter.simd.hpp:340-455) -- bit for bit against the restatement, with odd anchors, every border rule, ragged widths and ROI windows"""
+    rng = np.random.default_rng(60 + cn)
+    for (w, h) in [(317, 70), (256 // cn, 33), (45, 130)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for (ks, anchor, norm) in [((9, 9), (-1, -1), True), ((15, 15), (-1, -1), True), ((16, 16), (-1, -1), True), ((31, 31), (-1, -1), True), ((11, 5), (2, 4), True),
+                                   ((3, 25), (-1, 20), True), ((21, 21), (-1, -1), False), ((129, 129), (-1, -1), True), ((9, 2), (8, 0), False)]:
+            if ks[0] > w or ks[1] > h:
+                continue
+            for border in (0, 1, 2, 4):
+                got = cv.boxFilter(_dev(src), -1, ks, anchor, norm, border).cpu().numpy()
+                k = last_kernel()
+                assert "k_sepmx<" in k and ",box>" in k, (k, ks)
+                assert np.array_equal(got, orc.orc_boxFilter(src, -1, ks, anchor, norm, border)), (w, h, cn, ks, anchor, norm, border, k)
+    # a window into a larger image, and batches
+    parent = rng.integers(0, 256, (90, 400, cn) if cn > 1 else (90, 400), dtype=np.uint8)
+    for roi in [(5, 4, 300, 60), (0, 0, 128, 90), (390, 10, 10, 70)]:
+        for border in (1, 4):
+            got = cv.boxFilter(_dev(parent), -1, (13, 13), borderType=border, roi=roi).cpu().numpy()
+            assert "k_sepmx<" in last_kernel(), last_kernel()
+            assert np.array_equal(got, orc.orc_boxFilter(parent, -1, (13, 13), border=border, roi=roi)), (roi, border)
+    frames = rng.integers(0, 256, (3, 70, 300, cn) if cn > 1 else (3, 70, 300), dtype=np.uint8)
+    got = cv.boxFilterBatch(_dev(frames), -1, (25, 25)).cpu().numpy()
+    assert "k_sepmx<" in last_kernel(), last_kernel()
+    for i in range(3):
+        assert np.array_equal(got[i], orc.orc_boxFilter(frames[i], -1, (25, 25))), i
+
+
+def test_sepmx_adaptive_threshold_mean_rides_on_it(cv, orc):
+    rng = np.random.default_rng(70)
+    src = rng.integers(0, 256, (200, 333), dtype=np.uint8)
+    for bs in (15, 51, 129):
+        got = cv.adaptiveThreshold(_dev(src), 255, 0, 0, bs, 5).cpu().numpy()
+        assert np.array_equal(got, orc.orc_adaptiveThreshold(src, 255, 0, bs, 5, 0)), bs

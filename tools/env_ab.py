@@ -67,6 +67,11 @@ def child(row):
             n, nbytes = 24, 2160 * 3840 * 2
         else:
             fn, n, nbytes = (lambda: cv.GaussianBlurBatch(fr, (ks, ks), sigmaX=sg, dst=out)), fr.shape[0], 2160 * 3840 * 2 * (3 if c3 else 1)
+    elif row in ("blur15", "blur31", "blur15_c3", "blur9"):
+        c3 = row.endswith("c3")
+        fr = u8(48, 2160, 3840, 3) if c3 else u8(144, 2160, 3840); out = torch.empty_like(fr)
+        k = {"blur15": 15, "blur31": 31, "blur15_c3": 15, "blur9": 9}[row]
+        fn, n, nbytes = (lambda: cv.boxFilterBatch(fr, -1, (k, k), dst=out)), fr.shape[0], 2160 * 3840 * 2 * (3 if c3 else 1)
     else:
         sys.exit("unknown row " + row)
     for _ in range(30):
