@@ -17,6 +17,8 @@ def main():
         "HEADLINE": "%.2f Tpix/s, %.2f TB/s = %.3f" % (rec["value"] / 1e6, rf["achieved"] / 1e3, rf["frac"]),
         "G8UC3": fr("gauss_8uc3"), "G1080": fr("gauss_1080p"), "G8K": fr("gauss_8k"),
         "GS3": "%s (%.3f; `cv::GaussianBlur` on the host: %.0f µs)" % (us("gauss_sigma3_8uc1"), s["gauss_sigma3_8uc1"][1], s["gauss_sigma3_8uc1"][2]),
+        "GS3C3": "%s (%.2f)" % (us("gauss_sigma3_8uc3"), s["gauss_sigma3_8uc3"][1]),
+        "GS21": ("%s (%.2f)" % (us("gauss_sigma21_8uc1"), s["gauss_sigma21_8uc1"][1])) if "gauss_sigma21_8uc1" in s else "6.8 µs (0.30)",
         "GS16": "%s (%.3f; host: %.1f ms)" % (us("gauss_sigma16_32f"), s["gauss_sigma16_32f"][1], s["gauss_sigma16_32f"][2] / 1e3),
         "CFG2A": fr("cfg2a"), "CFG2C": fr("cfg2c"), "CFG2D": fr("cfg2d"), "CFG2E": fr("cfg2e"), "SOBEL": fr("sobel_16s"),
         "CFG3A": fr("cfg3a"), "CFG3B": fr("cfg3b"), "CFG3C": "%s per 8K frame = %s" % (us("cfg3c"), fr("cfg3c")),
