@@ -8,8 +8,11 @@
 // src_data == dst_data on the device (allowInplace) goes through a scratch image and one device copy.
 //   * k_morph_generic<T>: any element / anchor / depth (8U, 16U, 16S, 32F) / ROI; thread per output element.
 //   * seprollMorph (seproll.hip): u8, full K x K rectangle, K in {3,5,7}, on the register-rolling skeleton.
+//   * k_seplong<4 / 5> (seplong.hip): u8, any other full rectangle up to 129 x 129: row minima into an LDS ring, column minima from it (round 6).
 #include "rt.h"
 #include "seproll.h"
+#include "seplong.h"
+#include <cstdlib>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -148,6 +151,13 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
             (c->border != B_CONSTANT || c->defaultBorder) &&
             seprollMorph(c->op == 0, ps, pss, 0, pd, pds, 0, 1, width, height, c->cn, c->kw, c->border, st))
             return true;
+        // any other full rectangle on CV_8U (9 x 9 and larger, odd anchors, k x 1, two channels, ROI windows, a custom border value): the minimum / maximum is separable --
+        // the LDS-ring kernel's erode / dilate modes (seplong.hip: kw + kh comparisons per element instead of the kw * kh of k_morph_generic)
+        if (c->depth == D8U && c->rect && c->cn <= 4 && c->kw * c->kh >= 9 && c->kw <= lim::SEP_MAX_TAPS && c->kh <= lim::SEP_MAX_TAPS && !std::getenv("MI355CV_MORPH_GENERIC")) {
+            SepLongTaps t = {nullptr, nullptr, nullptr, nullptr, c->kw, c->kh, c->ax, c->ay, c->op == 0 ? 4 : 5, 0, 0.f, 0, {0, 0, 0, 0}};
+            for (int k = 0; k < 4; k++) t.bval[k] = (unsigned)c->bv[k];
+            if (seplongRun(stg, ps, pss, 0, pd, pds, 0, 1, width, height, c->cn, D8U, D8U, fullW, fullH, offX, offY, c->border, t, st)) return true;
+        }
         if (!dt) dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
         if (!dt) return false;
         dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));

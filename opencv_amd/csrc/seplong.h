@@ -13,11 +13,13 @@ namespace mi355 {
 // mode 2: CV_8U -> CV_16S, integer taps, exact int32 sums, saturate to short
 // mode 3: CV_8U -> CV_8U, Q8.8 taps of cv::GaussianBlur (fixedSmoothInvoker, smooth.simd.hpp:1926) with sum(kx) <= 256 and sum(ky) <= 256
 //         (no ufixedpoint16 / ufixedpoint32 saturation can occur): (sum_j ky[j] * sum_i kx[i] * p + 2^15) >> 16
+// modes 4 / 5: CV_8U erode / dilate with a full nx x ny rectangle (the taps are not read; bval = the border value per channel for BORDER_CONSTANT)
 struct SepLongTaps {
     const float* kxf; const float* kyf;      // mode 0 (and kyf for nothing else)
     const int* kxi; const int* kyi;          // modes 1-3
     int nx, ny, ax, ay, mode, symY;
     float deltaF; int deltaI;
+    unsigned bval[4];
 };
 
 // false: outside what the kernel covers (more than 4 channels, more taps than lim::SEP_MAX_TAPS, a depth pair it has no store for); nothing was launched

@@ -90,16 +90,17 @@ bool seplongRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, ucha
     memset(&g, 0, sizeof g);
     g.W = W; g.H = H; g.sdepth = sdepth; g.ddepth = ddepth; g.fullW = fullW; g.fullH = fullH; g.offX = offX; g.offY = offY; g.border = border;
     g.nx = t.nx; g.ny = t.ny; g.ax = t.ax; g.ay = t.ay; g.symY = t.symY; g.deltaF = t.deltaF; g.deltaI = t.deltaI;
+    for (int k = 0; k < 4; k++) g.bval[k] = t.bval[k];
     size_t lds = 0; int nstrips = 0, nseg = 0;
     if (!seplong::plan(g, cn, nframes, &lds, &nstrips, &nseg)) return false;
     const int seg = g.seg;
     if (nseg > 65535 || nframes > 65535) return false;
     // the taps: kx, ky (float bits or ints), then mode 1's float(ky) * 2^-16
     std::vector<uint32_t> tb((size_t)t.nx + 2 * (size_t)t.ny);
-    for (int i = 0; i < t.nx; i++) { if (t.mode == 0) memcpy(&tb[i], &t.kxf[i], 4); else tb[i] = (uint32_t)t.kxi[i]; }
+    for (int i = 0; i < t.nx; i++) { if (t.mode == 0) memcpy(&tb[i], &t.kxf[i], 4); else tb[i] = t.mode >= 4 ? 0u : (uint32_t)t.kxi[i]; }
     for (int i = 0; i < t.ny; i++) {
-        if (t.mode == 0) memcpy(&tb[t.nx + i], &t.kyf[i], 4); else tb[t.nx + i] = (uint32_t)t.kyi[i];
-        const float s = t.mode == 0 ? 0.f : (float)t.kyi[i] * (1.0f / 65536.0f);
+        if (t.mode == 0) memcpy(&tb[t.nx + i], &t.kyf[i], 4); else tb[t.nx + i] = t.mode >= 4 ? 0u : (uint32_t)t.kyi[i];
+        const float s = t.mode == 0 || t.mode >= 4 ? 0.f : (float)t.kyi[i] * (1.0f / 65536.0f);
         memcpy(&tb[t.nx + t.ny + i], &s, 4);
     }
     const uint32_t* dt = static_cast<const uint32_t*>(stg.param(tb.data(), tb.size() * 4));
@@ -110,6 +111,8 @@ bool seplongRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, ucha
     case 0:  launchLong<0>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
     case 1:  launchLong<1>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
     case 2:  launchLong<2>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    case 4:  launchLong<4>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
+    case 5:  launchLong<5>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
     default: launchLong<3>(cn, lng, grid, lds, st, src, sstep, sframe, dst, dstep, dframe, g, dt); break;
     }
     noteKernel("k_seplong<%d,%d,%d> grid=%ux%ux%u x256 lds=%zu taps=%dx%d seg=%d", t.mode, cn, (int)lng, grid.x, grid.y, grid.z, lds, t.nx, t.ny, seg);

@@ -39,6 +39,7 @@ struct Geom {
     int seg;                                   // output rows per segment
     int vecEnd;                                // mode 1: elements below this index take the float column form
     float deltaF; int deltaI;
+    uint32_t bval[4];                          // modes 4 / 5 (erode / dilate): the value of elements outside the image under BORDER_CONSTANT, per channel
 };
 
 template <int CN> struct StripOf { static constexpr int TP = CN == 1 ? 128 : CN == 2 ? 64 : CN == 3 ? 40 : 32; };
@@ -91,7 +92,9 @@ SL_HD void stDstF(unsigned char* row, int idx, int depth, float s)
 // integer multiply-add on the values of each mode: Q8.8 operands fit 24 bits (full-rate v_mad_u32_u24), the integer kernels of cv::sepFilter2D need all 32
 template <int MODE> SL_HD uint32_t imad(uint32_t k, uint32_t v, uint32_t acc)
 {
-    if constexpr (MODE == 3) {
+    if constexpr (MODE == 4) { (void)k; return v < acc ? v : acc; }               // erode: the "multiply-add" of a flat rectangle is a minimum
+    else if constexpr (MODE == 5) { (void)k; return v > acc ? v : acc; }          // dilate
+    else if constexpr (MODE == 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
         return __umul24(k, v) + acc;
 #else
@@ -142,9 +145,9 @@ SL_HD void stageLoad(const Geom& g, const Seg<CN>& sg, int step, const unsigned 
 #pragma unroll
         for (int m = 0; m < MMAX; m++) {
             const int q = ln + 64 * m;
-            uint32_t val = 0;
+            const int po = q / CN, c = q - po * CN;
+            uint32_t val = MODE >= 4 ? g.bval[c] : 0u;
             if (yy >= 0 && q < sg.spn) {
-                const int po = q / CN, c = q - po * CN;
                 const int fp = sg.fx0 + po;
                 const int xx = sg.xin ? fp : border(fp, g.fullW, g.border);
                 if (xx >= 0) {
@@ -195,7 +198,7 @@ SL_HD void rowPass(const Geom& g, const Seg<CN>& sg, int step, const uint32_t* S
             for (int o = 0; o < 4; o++) acc[o] = f2u(k0 * u2f(w[o]));                  // RowFilter: s = kx[0] * S[0], then s += kx[i] * S[i]
         } else {
 #pragma unroll
-            for (int o = 0; o < 4; o++) acc[o] = imad<MODE>(kx[0], w[o], 0u);
+            for (int o = 0; o < 4; o++) { if constexpr (MODE >= 4) acc[o] = w[o]; else acc[o] = imad<MODE>(kx[0], w[o], 0u); }
         }
         for (int g4 = 0; g4 < g.nx; g4 += 4) {
             { const V4 b = ld4(Sp + g4 + 4); w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; }
@@ -297,7 +300,7 @@ SL_HD void colPass(const Geom& g, const Seg<CN>& sg, int done, int newDone, cons
         // s = delta, then s = fma(ky[j], r[j], s) for j = 0 .. ny - 1 per output (ColumnFilter: s = ky[0] * r[0] + delta first -- the same value); output o of the lane
         // takes ring row m as its tap m - o, so rows 3 .. ny - 1 feed all four outputs and only the two ends of the window are guarded
 #pragma unroll
-        for (int o = 0; o < 4; o++) { if constexpr (MODE == 0) fs[o][0] = fs[o][1] = g.deltaF; else is[o][0] = is[o][1] = (uint32_t)g.deltaI; }      // (mode 1 may hold its pair-form floats in fs)
+        for (int o = 0; o < 4; o++) { if constexpr (MODE == 0) fs[o][0] = fs[o][1] = g.deltaF; else if constexpr (MODE == 4) is[o][0] = is[o][1] = 0xffffffffu; else if constexpr (MODE == 5) is[o][0] = is[o][1] = 0u; else is[o][0] = is[o][1] = (uint32_t)g.deltaI; }      // (mode 1 may hold its pair-form floats in fs)
         int i = r0 % NR;
         auto tapRow = [&](int m, bool guarded) {
             const V2 v = ld(i);
@@ -338,6 +341,8 @@ SL_HD void colPass(const Geom& g, const Seg<CN>& sg, int done, int newDone, cons
             } else if constexpr (MODE == 2) {
                 const int a = (int)is[o][h];
                 reinterpret_cast<short*>(drow)[e] = (short)(a < -32768 ? -32768 : a > 32767 ? 32767 : a);
+            } else if constexpr (MODE >= 4) {
+                drow[e] = (unsigned char)is[o][h];
             } else {
                 drow[e] = (unsigned char)((is[o][h] + 0x8000u) >> 16);
             }

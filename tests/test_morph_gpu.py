@@ -106,3 +106,30 @@ def test_more_than_four_channels(cv, orc, dtype):
                     assert np.array_equal(got, orc.orc_morph(op, src, k, anchor, border)), (dtype, shape, op, anchor, border)
     with pytest.raises(NotImplementedError):
         cv.erode(dev(_src(dtype, (9, 9, 5), 3)), None, (-1, -1), 1, 0, (1.0, 2.0, 3.0, 4.0))
+
+
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_morph_large_rectangles_are_separable(cv, orc, cn):
+    """cv::erode / cv::dilate on CV_8U with full rectangles beyond 7 x 7 (9 x 9 ... 129 x 1, odd anchors, folded iterations, custom border values, ROI windows): the
+    LDS-ring kernel's minimum / maximum modes (k_seplong<4 / 5>: kw + kh comparisons per element) instead of one thread per output walking the whole element"""
+    from opencv_amd import _lib
+    rng = np.random.default_rng(90 + cn)
+    for (w, h) in [(317, 70), (64, 33), (45, 130)]:
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        for (kw, kh, anchor) in [(9, 9, (-1, -1)), (15, 15, (-1, -1)), (31, 5, (-1, -1)), (3, 25, (1, 20)), (21, 21, (3, 17)), (129, 1, (-1, -1)), (11, 11, (0, 0))]:
+            if kw > w or kh > h:
+                continue
+            k = np.ones((kh, kw), np.uint8)
+            for op, fn in ((0, cv.erode), (1, cv.dilate)):
+                for border, bv in [(0, None), (0, 7.0), (1, None), (2, None), (4, None)]:
+                    got = fn(dev(src), k, anchor, 1, border, bv).cpu().numpy()
+                    kn = _lib.lib.mi355cv_lastKernel().decode()
+                    assert ("k_seplong<%d," % (4 + op)) in kn, kn
+                    assert np.array_equal(got, orc.orc_morph(op, src, k, anchor, border, bv)), (w, h, cn, kw, kh, anchor, op, border, bv)
+    src = rng.integers(0, 256, (60, 200, cn) if cn > 1 else (60, 200), dtype=np.uint8)
+    assert np.array_equal(cv.dilate(dev(src), None, (-1, -1), 6).cpu().numpy(), orc.orc_morph(1, src, np.ones((13, 13), np.uint8)))       # six 3 x 3 iterations fold into 13 x 13
+    parent = rng.integers(0, 256, (80, 300, cn) if cn > 1 else (80, 300), dtype=np.uint8)
+    for roi in [(5, 4, 200, 60), (0, 0, 128, 80), (290, 10, 10, 60)]:
+        for op, fn in ((0, cv.erode), (1, cv.dilate)):
+            got = fn(dev(parent), np.ones((11, 13), np.uint8), (-1, -1), 1, 1, None, roi=roi).cpu().numpy()
+            assert np.array_equal(got, orc.orc_morph(op, parent, np.ones((11, 13), np.uint8), (-1, -1), 1, None, roi=roi)), (roi, op)

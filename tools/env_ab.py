@@ -67,6 +67,11 @@ def child(row):
             n, nbytes = 24, 2160 * 3840 * 2
         else:
             fn, n, nbytes = (lambda: cv.GaussianBlurBatch(fr, (ks, ks), sigmaX=sg, dst=out)), fr.shape[0], 2160 * 3840 * 2 * (3 if c3 else 1)
+    elif row in ("erode15", "dilate31"):
+        fr = u8(48, 2160, 3840); out = torch.empty_like(fr)
+        k = np.ones((15, 15) if row == "erode15" else (31, 31), np.uint8)
+        f = cv.erode if row == "erode15" else cv.dilate
+        fn, n, nbytes = (lambda: [f(fr[i], k, dst=out[i]) for i in range(48)]), 48, 2160 * 3840 * 2
     elif row in ("blur15", "blur31", "blur15_c3", "blur9"):
         c3 = row.endswith("c3")
         fr = u8(48, 2160, 3840, 3) if c3 else u8(144, 2160, 3840); out = torch.empty_like(fr)
