@@ -38,16 +38,9 @@ using sepmx::TR;
 
 __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone (vector-memory operations return in order: at most n of the newest are still out)
 {
-    switch (n) {
-    case 0:  __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    case 1:  __builtin_amdgcn_s_waitcnt(0x0F71); break;
-    case 2:  __builtin_amdgcn_s_waitcnt(0x0F72); break;
-    case 3:  __builtin_amdgcn_s_waitcnt(0x0F73); break;
-    case 4:  __builtin_amdgcn_s_waitcnt(0x0F74); break;
-    case 5:  __builtin_amdgcn_s_waitcnt(0x0F75); break;
-    case 6:  __builtin_amdgcn_s_waitcnt(0x0F76); break;
-    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    }
+    if (n >= 2) __builtin_amdgcn_s_waitcnt(0x0F72);          // (a wave issues at most two per step: waiting for fewer than are out is merely stricter)
+    else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 template <int KSX, int KSY, bool DMA, bool BOX>
@@ -223,18 +216,23 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 7 : KSX + KSY <= 5) ? 4 :
             uchar* T = &tr[t & 1][32 * wave + n];
             if (BOX) {
                 // cv::boxFilter's normalisations on the exact window sum (box_filter.simd.hpp: ColumnSum<ushort, uchar> :429-455, ColumnSum<int, uchar> :340-385)
-                const bool tail = X0 + 32 * wave + n >= g.tailStart;
+                const bool tail = g.box == 2 && X0 + 32 * wave + n >= g.tailStart;
+                unsigned sum[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const unsigned sum = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
-                    unsigned r;
-                    if (g.box == 1) r = ((sum + (unsigned)g.divDelta) * (unsigned)g.divScale) >> 23;
-                    else if (g.box == 3) r = sum > 255u ? 255u : sum;
-                    else {
-                        const float f = tail ? (float)rint((double)sum * g.scaleD) : rintf((float)sum * g.scaleF);
-                        r = (unsigned)(int)fminf(fmaxf(f, 0.f), 255.f);
+                for (int i = 0; i < 16; i++) sum[i] = ((unsigned)aH[i] << 8) + (unsigned)aL[i];
+                if (g.box == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) T[sepmx::regRow(h, i) * TW] = (uchar)(__umul24(sum[i] + (unsigned)g.divDelta, (unsigned)g.divScale) >> 23);     // both factors < 2^24, the product < 2^32
+                } else if (g.box == 3) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) T[sepmx::regRow(h, i) * TW] = (uchar)(sum[i] > 255u ? 255u : sum[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) T[sepmx::regRow(h, i) * TW] = (uchar)(int)fminf(rintf((float)sum[i] * g.scaleF), 255.f);
+                    if (tail) {                                                          // (the last (W * cn) % 8 elements of a row: at most one wave of the last strip comes here)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) T[sepmx::regRow(h, i) * TW] = (uchar)(int)fmin(rint((double)sum[i] * g.scaleD), 255.0);
                     }
-                    T[sepmx::regRow(h, i) * TW] = (uchar)r;
                 }
             } else {
 #pragma unroll
