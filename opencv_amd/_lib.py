@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355cv.so")
+LIB_PATH = os.environ.get("MI355CV_LIB_AB") or os.path.join(_HERE, "libmi355cv.so")        # (MI355CV_LIB_AB: another build of the library, for A/B timing of two source versions on one box)
 
 OK, NOT_IMPLEMENTED = 0, 1
 

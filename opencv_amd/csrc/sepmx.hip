@@ -44,7 +44,7 @@ __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone 
 }
 
 template <int KSX, int KSY, bool DMA, bool BOX>
-__global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 7 : KSX + KSY <= 5) ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
+__global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && KSY <= 3)) : KSX + KSY <= 5) ? 4 : 2)) void k_sepmx(const uchar* __restrict__ src, size_t sstep, size_t sframe, uchar* __restrict__ dst, size_t dstep, size_t dframe,
                                                   Geom g, const int* __restrict__ bsel /* [strips][8] */, const int* __restrict__ seeds /* [classes][32] */,
                                                   const v4i* __restrict__ rowB /* [classes][2][KSX][64] */, const v4i* __restrict__ colA /* [KSY][64] */)
 {
@@ -87,6 +87,11 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 7 : KSX + KSY <= 5) ? 4 :
     };
     uint4 park[DMA ? 1 : NI];
     // request the rows of step t; returns the number of asynchronous wave-instructions issued (DMA)
+    auto glds16 = [&](const uchar* p, uchar* slot) {                                // 16 bytes per lane from p into slot + 16 * lane, asynchronously (counts on vmcnt)
+        unsigned keep;
+        const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)slot;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(ldsAddr) : "memory");
+    };
     auto request = [&](int t) -> int {
         int issued = 0;
         const int syA = y0 - g.ay + TR * t + g.offY;                                 // the step's first source row in the parent
@@ -99,20 +104,24 @@ __global__ __launch_bounds__(512, ((DMA ? KSX + KSY <= 7 : KSX + KSY <= 5) ? 4 :
             asm volatile("" : "+v"(ln));                                              // (opaque: the chunk's row / column / base pointer are recomputed per step -- hoisted out
             const int q = 64 * (wave + NW * i) + ln, cr = q / PC, cc = q - cr * PC;    //  of the walk they are six more registers per lane, and a spilled register comes back
             const int e0 = X0 - g.ax * g.cn - g.delta + 16 * cc;                       //  through vector memory, behind every row piece in flight)
+            const bool valid = q < TR * PC && cc < NCHUNK;
+            const int sy = y0 - g.ay + TR * t + cr;
+            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + NW * i)];
+            if (DMA && inner) {
+                // every row of the step is a real row away from the parent's rim: no border, no rim test; a wave-instruction's 64 chunks span three rows, so some lane always
+                // issues -- the count needs no ballot
+                if (valid) glds16(src + (ptrdiff_t)sy * (ptrdiff_t)sstep + e0, slot);
+                issued++;
+                continue;
+            }
             int kind = -1;
-            if (q < TR * PC && cc < NCHUNK) {
-                const int sy = y0 - g.ay + TR * t + cr;
-                if (inner) { kind = sepmx::CH_LOAD; p = src + (ptrdiff_t)sy * (ptrdiff_t)sstep + e0; }          // every row of the step is a real row away from the parent's rim: no border, no rim test
+            if (valid) {
+                if (inner) { kind = sepmx::CH_LOAD; p = src + (ptrdiff_t)sy * (ptrdiff_t)sstep + e0; }
                 else kind = sepmx::chunkKind(g, src, sstep, sy, e0, &p, &rel);
             }
-            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + NW * i)];
             if (DMA) {
                 if (__ballot(kind == sepmx::CH_LOAD)) {
-                    if (kind == sepmx::CH_LOAD) {
-                        unsigned keep;
-                        const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)slot;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(ldsAddr) : "memory");
-                    }
+                    if (kind == sepmx::CH_LOAD) glds16(p, slot);
                     issued++;
                 }
                 if (kind == sepmx::CH_ZERO) *reinterpret_cast<uint4*>(slot + 16 * lane) = make_uint4(0, 0, 0, 0);
