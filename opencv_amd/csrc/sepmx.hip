@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
         const unsigned ldsAddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)slot;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(ldsAddr) : "memory");
     };
-    auto request = [&](int t) -> int {
+    auto request = [&](int t, int sl) -> int {                                      // (sl = t mod NSLOT, carried by the caller: no division in the walk)
         int issued = 0;
         const int syA = y0 - g.ay + TR * t + g.offY;                                 // the step's first source row in the parent
         const bool inner = g.fast && syA >= 1 && syA + TR - 1 <= g.fullH - 2;        // (uniform)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
             const int e0 = X0 - g.ax * g.cn - g.delta + 16 * cc;                       //  through vector memory, behind every row piece in flight)
             const bool valid = q < TR * PC && cc < NCHUNK;
             const int sy = y0 - g.ay + TR * t + cr;
-            uchar* slot = &stage[t % NSLOT][16 * 64 * (wave + NW * i)];
+            uchar* slot = &stage[sl][16 * 64 * (wave + NW * i)];
             if (DMA && inner) {
                 // every row of the step is a real row away from the parent's rim: no border, no rim test; a wave-instruction's 64 chunks span three rows, so some lane always
                 // issues -- the count needs no ballot
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
         }
         return __builtin_amdgcn_readfirstlane(issued);
     };
-    auto deposit = [&](int t) {                                                      // (registers -> block; DMA = false)
+    auto deposit = [&](int sl) {                                                      // (registers -> block; DMA = false)
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            if (64 * (wave + NW * i) + lane < TR * PC && (64 * (wave + NW * i) + lane) % PC < NCHUNK) *reinterpret_cast<uint4*>(&stage[t % NSLOT][16 * (64 * (wave + NW * i) + lane)]) = park[DMA ? 0 : i];
+            if (64 * (wave + NW * i) + lane < TR * PC && (64 * (wave + NW * i) + lane) % PC < NCHUNK) *reinterpret_cast<uint4*>(&stage[sl][16 * (64 * (wave + NW * i) + lane)]) = park[DMA ? 0 : i];
     };
     // an output tile (rows y0 + 32 u ..) from its transposition block, 1 KiB (4 / 2 whole row pieces) per wave
     auto emit = [&](int u, int buf) {
@@ -163,9 +163,11 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
     int inflight[DEPTH];                                 // ... per step still ahead (two steps: three gained nothing, profiles/r06_sepmx.txt)
     if (DMA) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) inflight[d] = d < nT ? request(d) : 0;
-    } else { (void)request(0); deposit(0); }
-    for (int t = 0; t < nT; t++) {
+        for (int d = 0; d < DEPTH; d++) inflight[d] = d < nT ? request(d, d) : 0;
+    } else { (void)request(0, 0); deposit(0); }
+    int cur = 0;                                         // t mod NSLOT
+    for (int t = 0; t < nT; t++, cur = cur + 1 == NSLOT ? 0 : cur + 1) {
+        const int ahead = DMA ? (cur == 0 ? NSLOT - 1 : cur - 1) : (cur ^ 1);                  // (t + DEPTH) mod NSLOT resp. (t + 1) mod 2
         if (DMA) {
             newer = 0;
 #pragma unroll
@@ -178,13 +180,13 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
         if (DMA) {
 #pragma unroll
             for (int d = 0; d + 1 < DEPTH; d++) inflight[d] = inflight[d + 1];
-            inflight[DEPTH - 1] = t + DEPTH < nT ? request(t + DEPTH) : 0;
+            inflight[DEPTH - 1] = t + DEPTH < nT ? request(t + DEPTH, ahead) : 0;
         }
-        else if (t + 1 < nT) (void)request(t + 1);
+        else if (t + 1 < nT) (void)request(t + 1, ahead);
         __builtin_amdgcn_sched_barrier(0);               // (phase fences: the scheduler otherwise hoists the next phase's LDS reads over this one and runs out of registers;
         // ---- row pass                                  //  a spilled register is reloaded through vector memory, behind every row piece in flight)
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const uchar* A = &stage[t % NSLOT][n * P + 32 * wave + 16 * h];
+        const uchar* A = &stage[cur][n * P + 32 * wave + 16 * h];
 #pragma unroll
         for (int k = 0; k < KSX; k++) {
             v4i a = *reinterpret_cast<const v4i*>(A + 32 * k);
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
                 }
             }
         }
-        if (!DMA && t + 1 < nT) deposit(t + 1);
+        if (!DMA && t + 1 < nT) deposit(ahead);
     }
     __syncthreads();
     emit(nU - 1, (nT - 1) & 1);
