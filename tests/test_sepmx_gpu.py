@@ -153,3 +153,36 @@ def test_sepmx_adaptive_threshold_mean_rides_on_it(cv, orc):
     for bs in (15, 51, 129):
         got = cv.adaptiveThreshold(_dev(src), 255, 0, 0, bs, 5).cpu().numpy()
         assert np.array_equal(got, orc.orc_adaptiveThreshold(src, 255, 0, bs, 5, 0)), bs
+
+
+def test_sepmx_random_geometry_and_repeatability(cv, orc):
+    """the walk keeps two steps of rows in flight behind counted waits: (1) random sizes / channels / taps / borders / ROI windows against the restatement, (2) a batch of
+    full-HD frames filtered 12 times over -- every pass must give the same bytes as the first, and the first the restatement's (a race would show up as an odd pass)"""
+    rng = np.random.default_rng(1234)
+    for it in range(60):
+        cn = int(rng.integers(1, 5))
+        w, h = int(rng.integers(8, 700)), int(rng.integers(1, 260))
+        kw = int(rng.choice([7, 9, 11, 15, 19, 25, 33])); kh = int(rng.choice([7, 9, 13, 19, 31, 65]))
+        if (kw - 1) * cn > 113 or kw > w or kh > 2 * h + 1:
+            continue
+        sx, sy = max(0.9, kw / 6.0), max(0.9, kh / 6.0)
+        kx, ky = taps(orc, kw, sx), taps(orc, kh, sy)
+        border = int(rng.choice([0, 1, 2, 4]))
+        pw, ph = w + int(rng.integers(0, 40)), h + int(rng.integers(0, 20))
+        parent = rng.integers(0, 256, (ph, pw, cn) if cn > 1 else (ph, pw), dtype=np.uint8)
+        x0, y0 = int(rng.integers(0, pw - w + 1)), int(rng.integers(0, ph - h + 1))
+        margins = (x0, y0, pw - x0 - w, ph - y0 - h)
+        roi = parent[y0:y0 + h, x0:x0 + w]
+        got = cv.sepSmoothFixedU8(_dev(parent)[y0:y0 + h, x0:x0 + w], kx, ky, border, margins=margins).cpu().numpy()
+        assert np.array_equal(got, orc.orc_sepSmoothFixedU8(roi, kx, ky, border, margins)), (it, cn, w, h, kw, kh, border, margins, last_kernel())
+    frames = _dev(rng.integers(0, 256, (24, 1080, 1920), dtype=np.uint8))
+    first = cv.GaussianBlurBatch(frames, (19, 19), sigmaX=3.0).clone()
+    assert "k_sepmx<" in last_kernel()
+    kx = taps(orc, 19, 3.0)
+    host = frames.cpu().numpy()
+    for i in (0, 11, 23):
+        assert np.array_equal(first[i].cpu().numpy(), orc.orc_sepSmoothFixedU8(host[i], kx, kx, 4)), i
+    out = torch.empty_like(frames)
+    for rep in range(12):
+        cv.GaussianBlurBatch(frames, (19, 19), sigmaX=3.0, dst=out)
+        assert torch.equal(out, first), rep
