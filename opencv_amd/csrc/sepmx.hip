@@ -38,7 +38,8 @@ using sepmx::TR;
 
 __device__ __forceinline__ void waitVm(int n)       // s_waitcnt vmcnt(n) alone (vector-memory operations return in order: at most n of the newest are still out)
 {
-    if (n >= 2) __builtin_amdgcn_s_waitcnt(0x0F72);          // (a wave issues at most two per step: waiting for fewer than are out is merely stricter)
+    if (n >= 3) __builtin_amdgcn_s_waitcnt(0x0F73);          // (a wave issues at most three per step)
+    else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
     else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
     else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
                                                   const v4i* __restrict__ rowB /* [classes][2][KSX][64] */, const v4i* __restrict__ colA /* [KSY][64] */)
 {
     constexpr int NW = sepmx::NWAVE, DEPTH = 2, TW = sepmx::TW, NT = 64 * NW, NCHUNK = (TW - 32 + 32 * KSX) / 16, PC = NCHUNK | 1, P = 16 * PC, NSLOT = DMA ? DEPTH + 1 : 2, NI = (TR * PC + NT - 1) / NT;
-    static_assert(NI <= 2, "at most two chunks per lane and step");
+    static_assert(NI <= 3, "at most three chunks per lane and step");
     extern __shared__ uint4 lds16[];                     // NSLOT staged blocks of TR x P bytes, two transposition blocks of TR x TW, the column pass' A operand (KSY KB)
     uchar (*stage)[TR * P] = reinterpret_cast<uchar (*)[TR * P]>(lds16);
     uchar (*tr)[TR * TW] = reinterpret_cast<uchar (*)[TR * TW]>(reinterpret_cast<uchar*>(lds16) + NSLOT * TR * P);
@@ -285,7 +286,10 @@ void launchX(int ksx, int ksy, dim3 grid, hipStream_t st, const uchar* src, size
     case 2:  launchY<2, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     case 3:  launchY<3, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     case 4:  launchY<4, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
-    default: launchY<5, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 5:  launchY<5, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 7:  launchY<7, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    case 9:  launchY<9, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
+    default: launchY<13, DMA, BOX>(ksy, grid, st, src, sstep, sframe, dst, dstep, dframe, g, bsel, seeds, rowB, colA); break;
     }
 }
 
@@ -336,7 +340,7 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
                 if (e1 < 0 || e0 >= g.WE) continue;                                   // a wave without outputs: class 0, never stored
                 const bool inside = e0 >= 0 && e1 < g.WE && e0 / cn + offX - ax >= 0 && e1 / cn + offX + (nx - 1 - ax) < fullW;
                 if (inside && haveInterior) continue;
-                int8_t tab[sepmx::MAXKS * 64 * 16], tab2[sepmx::MAXKS * 64 * 16]; int sd[32]; bool interior = false, twice = false;
+                static thread_local int8_t tab[sepmx::MAXKSX * 64 * 16], tab2[sepmx::MAXKSX * 64 * 16]; int sd[32]; bool interior = false, twice = false;
                 if (!sepmx::buildRowB(g, kx, g.sumKy, s * TW - g.shift, w, tab, tab2, &twice, sd, &interior)) return false;
                 if (interior) { memcpy(rowB.data(), tab, tabB); memcpy(seeds.data(), sd, sizeof sd); haveInterior = true; continue; }
                 if (ncls >= 4096) return false;

@@ -17,7 +17,10 @@ namespace sepmx {
 constexpr int TW = 256;          // elements (bytes) of a row one workgroup owns
 constexpr int NWAVE = 8;         // wave w owns elements [32 w, 32 w + 32) of the strip
 constexpr int TR = 32;           // rows per step (one matrix tile)
-constexpr int MAXKS = 5;         // 32-byte K steps per pass: 32 + delta + (nx - 1) cn <= 32 KSX, 32 + ny - 1 <= 32 KSY
+constexpr int MAXKS = 5;         // 32-byte K steps of the column pass: 32 + ny - 1 <= 32 KSY (129 taps)
+constexpr int MAXKSX = 13;       // ... of the row pass: 32 + delta + (nx - 1) cn <= 32 KSX -- channels are interleaved elements, so three channels x 129 taps need 13;
+                                 // the kernel exists for KSX in {2, 3, 4, 5, 7, 9, 13}, a count in between runs on the next one (the extra steps carry zero weights)
+MX_HD int ksxClass(int k) { return k <= 5 ? (k < 2 ? 2 : k) : k <= 7 ? 7 : k <= 9 ? 9 : 13; }
 
 struct Geom {
     int W, H, cn, WE;                          // the ROI; WE = W * cn elements per row
@@ -75,8 +78,8 @@ MX_HD int colSeed(int sumPresentTapsX, int sumTapsY, int box) { return (128 + 12
 // an image wider than the window, reflections in an image narrower than the kernel): the caller hands the call to the vector kernel.  *interior: no tap was moved; *twice: tab2 is not empty.
 inline bool buildRowB(const Geom& g, const uint16_t* kx, int sumKy, int X0, int w, int8_t* tab, int8_t* tab2, bool* twice, int* seed, bool* interior)
 {
-    int wt[32 * MAXKS][32];
-    memset(wt, 0, sizeof wt);
+    static thread_local int wt[32 * MAXKSX][32];
+    memset(wt, 0, sizeof(int) * 32 * 32 * g.ksx);
     *interior = true; *twice = false;
     const int win0 = X0 + 32 * w - g.ax * g.cn - g.delta;
     for (int n = 0; n < 32; n++) {
@@ -132,14 +135,15 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     // the shift does not push the row of taps beyond MAXKS K steps
     const bool alignable = sstep % 16 == 0 && sframe % 16 == 0;
     const int dAl = (int)((srcAddr + (uintptr_t)(16 * 1024 * 1024) - (uintptr_t)(g.ax * g.cn)) & 15);
-    g.dma = alignable && (32 + dAl + spanX + 31) / 32 <= MAXKS;
+    g.dma = alignable && (32 + dAl + spanX + 31) / 32 <= MAXKSX;
     if (dmaOverride == 0) g.dma = 0;
     g.delta = g.dma ? dAl : 0;
     g.ksx = (32 + g.delta + spanX + 31) / 32;
     g.ksy = (32 + g.ny - 1 + 31) / 32;
-    if (g.ksx < 2) g.ksx = 2;
+    if (g.ksx > MAXKSX) return false;
+    g.ksx = ksxClass(g.ksx);
     if (g.ksy < 2) g.ksy = 2;
-    if (g.ksx > MAXKS || g.ksy > MAXKS) return false;
+    if (g.ksy > MAXKS) return false;
     g.sumKy = sy;
     g.fast = sstep >= 512;
     // A staged row piece is 224 + 32 KSX bytes from element X0 - ax cn - delta.  With strips at multiples of 256 it starts 16 .. 64 bytes before a 128-byte line and touches

@@ -28,7 +28,7 @@ extern "C" int emu_sepmx(const unsigned char* src, size_t sstep, unsigned char* 
         for (int w = 0; w < 8; w++) {
             const int X0 = s * TW - g.shift, e0 = X0 + 32 * w;
             if (e0 + 31 < 0 || e0 >= g.WE) continue;
-            int8_t tab[MAXKS * 64 * 16], tab2[MAXKS * 64 * 16]; int seed[32]; bool interior, twice;
+            static int8_t tab[MAXKSX * 64 * 16], tab2[MAXKSX * 64 * 16]; int seed[32]; bool interior, twice;
             if (!buildRowB(g, kx, g.sumKy, X0, w, tab, tab2, &twice, seed, &interior)) return 2;
             if (!interior) ncls++;
             const int K = 32 * g.ksx, win0 = e0 - g.ax * g.cn - g.delta;

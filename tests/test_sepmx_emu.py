@@ -49,7 +49,7 @@ def test_sepmx_host_half_gaussian(emu, cn):
     for (w, h) in [(300, 40), (256 // cn, 33), (37, 5), (19, 70), (600 // cn, 9)]:
         src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
         for (kw, kh, sigma) in [(19, 19, 3.0), (7, 33, 2.5), (33, 9, 5.0), (65, 11, 11.0)]:
-            if (kw - 1) * cn > 128:
+            if (kw - 1) * cn > 384:
                 continue
             kx, ky = gauss(kw, sigma), gauss(kh, sigma)
             for border in (0, 1, 2, 3, 4):
@@ -62,11 +62,11 @@ def test_sepmx_host_half_gaussian(emu, cn):
                     assert np.array_equal(got, o.orc_sepSmoothFixedU8(src, kx, ky, border)), (w, h, cn, kw, kh, border, info)
                     seen.add((info[0], info[1], info[4]))
     assert len(seen) >= 3, seen
-    # what the matrix form must decline: a tap above 127, taps that sum beyond 256, rows of taps beyond five K steps
+    # what the matrix form must decline: a tap above 127, taps that sum beyond 256, rows of taps beyond thirteen K steps
     src = rng.integers(0, 256, (20, 64, cn) if cn > 1 else (20, 64), dtype=np.uint8)
     assert run(emu, src, src.shape[:2], (0, 0), 4, [0, 0, 256, 0, 0], 2, gauss(9, 1.5), 4)[0] == 1
     assert run(emu, src, src.shape[:2], (0, 0), 4, [100, 100, 100], 1, gauss(9, 1.5), 4)[0] == 1
-    assert run(emu, src, src.shape[:2], (0, 0), 4, gauss(129, 21.0), 64, gauss(9, 1.5), 4)[0] == (0 if cn == 1 else 1)
+    assert run(emu, src, src.shape[:2], (0, 0), 4, gauss(129, 21.0), 64, gauss(9, 1.5), 4)[0] == (0 if cn <= 3 else 1)      # 32 + 128 cn bytes of taps: 5 / 9 / 13 K steps, 17 for four channels
 
 
 def test_sepmx_host_half_windows_and_box(emu):

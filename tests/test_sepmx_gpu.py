@@ -96,6 +96,27 @@ def test_sepmx_roi_with_margins_and_unaligned_rows(cv, orc):
         assert len(deltas) > 2, deltas
 
 
+@pytest.mark.parametrize("cn", [2, 3, 4])
+def test_sepmx_colour_images_with_long_kernels(cv, orc, cn):
+    """channels are interleaved elements, so a row of taps spans (nx - 1) * cn + 32 bytes: up to thirteen K steps of the row pass (three channels x 129 taps, four x 97)"""
+    rng = np.random.default_rng(80 + cn)
+    src = rng.integers(0, 256, (150, 700, cn), dtype=np.uint8)
+    seen = set()
+    for (kw, kh, sigma) in [(45, 45, 7.5), (65, 33, 11.0), (97, 19, 16.0), (129, 129, 21.0)]:
+        if (kw - 1) * cn + 32 > 416:
+            continue
+        kx, ky = taps(orc, kw, sigma), taps(orc, kh, sigma)
+        for border in (0, 1, 4):
+            got = cv.sepSmoothFixedU8(_dev(src), kx, ky, border).cpu().numpy()
+            assert "k_sepmx<" in last_kernel(), last_kernel()
+            seen.add(last_kernel().split("<")[1].split(",")[0])
+            assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, ky, border)), (cn, kw, kh, border, last_kernel())
+    assert seen & {"7", "9", "13"}, seen
+    got = cv.boxFilter(_dev(src), -1, (51, 51)).cpu().numpy()
+    assert "k_sepmx<" in last_kernel(), last_kernel()
+    assert np.array_equal(got, orc.orc_boxFilter(src, -1, (51, 51)))
+
+
 def test_sepmx_batch_equals_frames(cv, orc):
     rng = np.random.default_rng(53)
     frames = rng.integers(0, 256, (5, 130, 517), dtype=np.uint8)
@@ -107,10 +128,10 @@ def test_sepmx_batch_equals_frames(cv, orc):
 
 
 def test_sepmx_handover(cv, orc, monkeypatch):
-    """what the matrix form does not take stays on the vector kernel (k_seplong's Q8.8 mode) with the same bits: 4 channels x 65 taps (more than five K steps)"""
+    """what the matrix form does not take stays on the vector kernel (k_seplong's Q8.8 mode) with the same bits: 4 channels x 129 taps (17 K steps: more than thirteen)"""
     rng = np.random.default_rng(54)
     src = rng.integers(0, 256, (70, 300, 4), dtype=np.uint8)
-    kx = taps(orc, 65, 11.0)
+    kx = taps(orc, 129, 21.0)
     got = cv.sepSmoothFixedU8(_dev(src), kx, kx, 4).cpu().numpy()
     assert "k_seplong<3," in last_kernel(), last_kernel()
     assert np.array_equal(got, orc.orc_sepSmoothFixedU8(src, kx, kx, 4))

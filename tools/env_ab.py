@@ -57,12 +57,14 @@ def child(row):
     elif row == "gauss":
         fr = u8(144, 2160, 3840); out = torch.empty_like(fr)
         fn, n, nbytes = (lambda: cv.GaussianBlurBatch(fr, 5, dst=out)), 144, 2160 * 3840 * 2
-    elif row in ("gauss_s3", "gauss_s21", "gauss_s3_c3", "gauss_s15_9", "gauss_s3_one", "gauss_k7", "gauss_k5", "gauss_k7_c3", "gauss_k9_c3"):
+    elif row in ("gauss_s3", "gauss_s21", "gauss_s3_c3", "gauss_s15_9", "gauss_s3_one", "gauss_k7", "gauss_k5", "gauss_k7_c3", "gauss_k9_c3", "gauss_s11_c3", "blur51_c3"):
         c3 = row.endswith("c3")
         fr = u8(48, 2160, 3840, 3) if c3 else u8(144, 2160, 3840); out = torch.empty_like(fr)
         ks, sg = {"gauss_s3": (19, 3.0), "gauss_s21": (129, 21.0), "gauss_s3_c3": (19, 3.0), "gauss_s15_9": (9, 1.5), "gauss_s3_one": (19, 3.0), "gauss_k7": (7, 1.0), "gauss_k5": (5, 0.7),
-                  "gauss_k7_c3": (7, 1.0), "gauss_k9_c3": (9, 1.5)}[row]
-        if row == "gauss_s3_one":                                           # one call per frame: segments fill the chip
+                  "gauss_k7_c3": (7, 1.0), "gauss_k9_c3": (9, 1.5), "gauss_s11_c3": (65, 11.0), "blur51_c3": (51, 0.0)}[row]
+        if row == "blur51_c3":
+            fn, n, nbytes = (lambda: cv.boxFilterBatch(fr, -1, (51, 51), dst=out)), fr.shape[0], 2160 * 3840 * 6
+        elif row == "gauss_s3_one":                                           # one call per frame: segments fill the chip
             fn = lambda: [cv.GaussianBlur(fr[i], (ks, ks), sg, dst=out[i]) for i in range(24)]
             n, nbytes = 24, 2160 * 3840 * 2
         else:
