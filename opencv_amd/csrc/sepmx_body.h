@@ -138,6 +138,7 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     g.dma = alignable && (32 + dAl + spanX + 31) / 32 <= MAXKSX;
     if (dmaOverride == 0) g.dma = 0;
     g.delta = g.dma ? dAl : 0;
+    if (dmaOverride == 2 && !g.dma) { g.dma = 1; g.delta = 0; }       // (experiment: asynchronous loads from rows that are not 16-byte aligned)
     g.ksx = (32 + g.delta + spanX + 31) / 32;
     g.ksy = (32 + g.ny - 1 + 31) / 32;
     if (g.ksx > MAXKSX) return false;

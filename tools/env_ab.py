@@ -69,6 +69,9 @@ def child(row):
             n, nbytes = 24, 2160 * 3840 * 2
         else:
             fn, n, nbytes = (lambda: cv.GaussianBlurBatch(fr, (ks, ks), sigmaX=sg, dst=out)), fr.shape[0], 2160 * 3840 * 2 * (3 if c3 else 1)
+    elif row == "gauss_s3_odd":                                                       # rows that are not 16-byte aligned (odd width, contiguous frames)
+        fr = u8(96, 2160, 3833); out = torch.empty_like(fr)
+        fn, n, nbytes = (lambda: cv.GaussianBlurBatch(fr, (19, 19), sigmaX=3.0, dst=out)), 96, 2160 * 3833 * 2
     elif row in ("erode15", "dilate31"):
         fr = u8(48, 2160, 3840); out = torch.empty_like(fr)
         k = np.ones((15, 15) if row == "erode15" else (31, 31), np.uint8)
