@@ -131,7 +131,7 @@ SELF_SPAWN = textwrap.dedent("""
     from opencv_amd import shard
     n = int(sys.argv[sys.argv.index('--gpus') + 1])
     if 'WORLD_SIZE' not in os.environ and n > 1:               # what bench.py does when no launcher started it
-        sys.exit(shard.spawn_ranks(n, __file__, sys.argv[1:], need_gpus=False, port=29633))
+        sys.exit(shard.spawn_ranks(n, __file__, sys.argv[1:], need_gpus=False, port=int(os.environ.get('SPAWN_TEST_PORT', '29633'))))
     rank, ws, local = shard.init('gloo')
     assert ws == n, (ws, n)
     total = shard.gather_counts(1)
@@ -145,7 +145,11 @@ def test_gpus_flag_spawns_its_own_ranks(tmp_path):
     script = tmp_path / "selfspawn.py"
     script.write_text(SELF_SPAWN % (ROOT, str(tmp_path)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    for attempt in range(2):                                                             # (an overloaded box -- this file beside seven other pytest workers -- has been seen to
+        env["SPAWN_TEST_PORT"] = str(29633 + 50 * attempt)                               #  kill a rank in the rendezvous: one more try on another port; a worker's own assertion
+        out = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)      #  fails both)
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stdout + out.stderr
     assert sorted(os.listdir(tmp_path)).count("spawned_0") == 1 and (tmp_path / "spawned_1").read_text() == "2"
 
