@@ -1242,10 +1242,10 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
 static bool boxOnMatrixCores(Stager& stg, const BoxParams& p, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int cn,
                              int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border)
 {
-    if (sdepth != D8U || ddepth != D8U || cn > 4 || p.mode == 2 || p.kw > lim::SEP_MAX_TAPS || p.kh > lim::SEP_MAX_TAPS) return false;
+    if (sdepth != D8U || ddepth != D8U || cn > 4 || p.mode == 2 || p.kw > lim::BOX_MAX_KSIZE || p.kh > lim::BOX_MAX_KSIZE) return false;      // (the kernel declines rows of taps beyond its K steps: 255 for one channel)
     if (std::getenv("MI355CV_SEPMX") && std::getenv("MI355CV_SEPMX")[0] == '0') return false;
-    uint16_t ones[lim::SEP_MAX_TAPS];
-    for (int i = 0; i < lim::SEP_MAX_TAPS; i++) ones[i] = 1;
+    uint16_t ones[lim::BOX_MAX_KSIZE];
+    for (int i = 0; i < lim::BOX_MAX_KSIZE; i++) ones[i] = 1;
     const SepmxBox b = {!p.normalize ? 3 : p.mode == 0 ? 1 : 2, p.divScale, p.divDelta, p.scaleF, p.scaleD};
     return sepmxRun(stg, src, sstep, sframe, dst, dstep, dframe, nframes, W, H, cn, fullW, fullH, offX, offY, border, ones, p.kw, p.ax, ones, p.kh, p.ay, stream(), &b);
 }

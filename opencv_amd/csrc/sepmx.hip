@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, ((DMA ? (KSX + KSY <= 6 || (KSX + KSY == 7 && 
 #pragma unroll
     for (int k = 0; k < KSX; k++) Bx[k] = rowB[(cls * 2 * KSX + k) * 64 + lane];
     // the column pass' A operand is the same for every wave: it waits in LDS and is read where it is used (KSY x 4 registers less per lane: what keeps two workgroups on a CU)
-    if (tid < KSY * 64) AyL[tid] = colA[tid];
+    for (int i = tid; i < KSY * 64; i += NT) AyL[i] = colA[i];
     const int seedC = seeds[cls * 32 + n];            // the column's constant of the column pass (sepmx_body.h: the arithmetic)
 
     // staging: a block is TR rows of PC 16-byte chunks, chunk q at byte 16 q (the last chunk of a row is padding: the pitch is 16 * odd); wave-instruction i of wave w covers
@@ -265,7 +265,7 @@ void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep,
              const int* bsel, const int* seeds, const v4i* rowB, const v4i* colA)
 {
     constexpr int TW = sepmx::TW, PC = ((TW - 32 + 32 * KSX) / 16) | 1;
-    constexpr size_t lds = (size_t)(DMA ? 3 : 2) * TR * 16 * PC + 2 * (size_t)TR * TW + 1024 * 5;
+    constexpr size_t lds = (size_t)(DMA ? 3 : 2) * TR * 16 * PC + 2 * (size_t)TR * TW + 1024 * sepmx::MAXKS;
 #define SEPMX_LAUNCH_(KSY_) do { \
         static bool attr[64] = {}; const int dv = activeDevice() & 63; \
         if (lds > 48 * 1024 && !attr[dv]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sepmx<KSX, KSY_, DMA, BOX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
@@ -274,7 +274,9 @@ void launchY(int ksy, dim3 grid, hipStream_t st, const uchar* src, size_t sstep,
     case 2:  SEPMX_LAUNCH_(2);  break;
     case 3:  SEPMX_LAUNCH_(3);  break;
     case 4:  SEPMX_LAUNCH_(4);  break;
-    default: SEPMX_LAUNCH_(5); break;
+    case 5:  SEPMX_LAUNCH_(5);  break;
+    case 7:  SEPMX_LAUNCH_(7);  break;
+    default: if constexpr (KSX < 13) SEPMX_LAUNCH_(9);  break;        // (13 x 9 does not fit 256 registers without spilling: plan() declines it)
     }
 #undef SEPMX_LAUNCH_
 }

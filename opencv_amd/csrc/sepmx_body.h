@@ -17,10 +17,11 @@ namespace sepmx {
 constexpr int TW = 256;          // elements (bytes) of a row one workgroup owns
 constexpr int NWAVE = 8;         // wave w owns elements [32 w, 32 w + 32) of the strip
 constexpr int TR = 32;           // rows per step (one matrix tile)
-constexpr int MAXKS = 5;         // 32-byte K steps of the column pass: 32 + ny - 1 <= 32 KSY (129 taps)
+constexpr int MAXKS = 9;         // 32-byte K steps of the column pass: 32 + ny - 1 <= 32 KSY (255 taps: the largest box filter); the kernel exists for KSY in {2, 3, 4, 5, 7, 9}
 constexpr int MAXKSX = 13;       // ... of the row pass: 32 + delta + (nx - 1) cn <= 32 KSX -- channels are interleaved elements, so three channels x 129 taps need 13;
                                  // the kernel exists for KSX in {2, 3, 4, 5, 7, 9, 13}, a count in between runs on the next one (the extra steps carry zero weights)
 MX_HD int ksxClass(int k) { return k <= 5 ? (k < 2 ? 2 : k) : k <= 7 ? 7 : k <= 9 ? 9 : 13; }
+MX_HD int ksyClass(int k) { return k <= 5 ? (k < 2 ? 2 : k) : k <= 7 ? 7 : 9; }
 
 struct Geom {
     int W, H, cn, WE;                          // the ROI; WE = W * cn elements per row
@@ -143,8 +144,9 @@ inline bool plan(Geom& g, const uint16_t* kx, const uint16_t* ky, uintptr_t srcA
     g.ksy = (32 + g.ny - 1 + 31) / 32;
     if (g.ksx > MAXKSX) return false;
     g.ksx = ksxClass(g.ksx);
-    if (g.ksy < 2) g.ksy = 2;
     if (g.ksy > MAXKS) return false;
+    g.ksy = ksyClass(g.ksy);
+    if (g.ksx == 13 && g.ksy == 9) return false;                     // (the one pair the kernel is not built for: it would spill registers)
     g.sumKy = sy;
     g.fast = sstep >= 512;
     // A staged row piece is 224 + 32 KSX bytes from element X0 - ax cn - delta.  With strips at multiples of 256 it starts 16 .. 64 bytes before a 128-byte line and touches

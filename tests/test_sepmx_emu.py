@@ -83,7 +83,7 @@ def test_sepmx_host_half_windows_and_box(emu):
                 assert np.array_equal(got, o.orc_sepSmoothFixedU8(roi, kx, ky, border, margins)), (cn, x0, y0, w, h, border, info)
     # cv::boxFilter's three finishes with odd anchors
     src = rng.integers(0, 256, (50, 317), dtype=np.uint8)
-    for (kw, kh, anchor, norm) in [(9, 9, (-1, -1), True), (15, 15, (-1, -1), True), (31, 17, (3, 16), True), (21, 5, (-1, -1), False), (129, 3, (-1, -1), True)]:
+    for (kw, kh, anchor, norm) in [(9, 9, (-1, -1), True), (15, 15, (-1, -1), True), (31, 17, (3, 16), True), (21, 5, (-1, -1), False), (129, 3, (-1, -1), True), (255, 41, (-1, -1), True), (9, 255, (-1, -1), True)]:
         ax = kw // 2 if anchor[0] < 0 else anchor[0]; ay = kh // 2 if anchor[1] < 0 else anchor[1]
         area = kw * kh
         if not norm:

@@ -154,6 +154,14 @@ def test_sepmx_box_filter(cv, orc, cn):
                 k = last_kernel()
                 assert "k_sepmx<" in k and ",box>" in k, (k, ks)
                 assert np.array_equal(got, orc.orc_boxFilter(src, -1, ks, anchor, norm, border)), (w, h, cn, ks, anchor, norm, border, k)
+    # up to cv::boxFilter's largest window on one channel (nine K steps per pass); more channels x 255 taps do not fit the row pass and stay where they were
+    if cn in (1, 3):                                                   # (the restatement walks kw * kh taps per output: one big image is enough)
+        big = rng.integers(0, 256, (262, 270, cn) if cn > 1 else (262, 270), dtype=np.uint8)
+        for ks, border in (((255, 255), 1), ((201, 31), 4), ((131, 255), 4)):
+            got = cv.boxFilter(_dev(big), -1, ks, (-1, -1), True, border).cpu().numpy()
+            if cn == 1:
+                assert "k_sepmx<" in last_kernel(), (last_kernel(), ks)
+            assert np.array_equal(got, orc.orc_boxFilter(big, -1, ks, (-1, -1), True, border)), (cn, ks, border, last_kernel())
     # a window into a larger image, and batches
     parent = rng.integers(0, 256, (90, 400, cn) if cn > 1 else (90, 400), dtype=np.uint8)
     for roi in [(5, 4, 300, 60), (0, 0, 128, 90), (390, 10, 10, 70)]:
@@ -171,7 +179,7 @@ def test_sepmx_box_filter(cv, orc, cn):
 def test_sepmx_adaptive_threshold_mean_rides_on_it(cv, orc):
     rng = np.random.default_rng(70)
     src = rng.integers(0, 256, (200, 333), dtype=np.uint8)
-    for bs in (15, 51, 129):
+    for bs in (15, 51, 129, 201, 255):
         got = cv.adaptiveThreshold(_dev(src), 255, 0, 0, bs, 5).cpu().numpy()
         assert np.array_equal(got, orc.orc_adaptiveThreshold(src, 255, 0, bs, 5, 0)), bs
 
