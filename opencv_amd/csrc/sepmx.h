@@ -9,7 +9,7 @@ namespace mi355 {
 // 2: ColumnSum<int, uchar>'s cvRound(float(s) * scaleF) with the row's last (W * cn) % 8 elements in double, 3: un-normalised, saturate(s)
 struct SepmxBox { int mode, divScale, divDelta; float scaleF; double scaleD; };
 
-// false: outside what the kernel covers (a tap above 127, taps that sum beyond 256, more 32-byte K steps than the kernel has: (nx - 1) * cn > 384 or ny > 129); nothing was launched
+// false: outside what the kernel covers (a tap above 127, taps that sum beyond 256, more 32-byte K steps than the kernel has: (nx - 1) * cn > 384 or ny > 255 (or both at their largest)); nothing was launched
 bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes,
               int W, int H, int cn, int fullW, int fullH, int offX, int offY, int border, const uint16_t* kx, int nx, int ax, const uint16_t* ky, int ny, int ay, hipStream_t st,
               const SepmxBox* box = nullptr);
