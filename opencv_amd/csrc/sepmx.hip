@@ -325,10 +325,10 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
     key.insert(key.end(), kx, kx + nx); key.insert(key.end(), ky, ky + ny);
     const int dev = activeDevice();
     const uchar* d = nullptr; size_t o1 = 0, o2 = 0, o3 = 0;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        for (auto& e : cache) if (e.dev == dev && e.key == key) { e.stamp = ++clock; d = e.d; o1 = e.o1; o2 = e.o2; o3 = e.o3; g.ncls = e.ncls; break; }
-    }
+    // one lock from the lookup to the launch: a block found here cannot be evicted (and freed) by another host thread before the kernel that reads it is in the stream, and
+    // the eviction's hipFree waits for the device, i.e. for every kernel launched under this lock before it
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : cache) if (e.dev == dev && e.key == key) { e.stamp = ++clock; d = e.d; o1 = e.o1; o2 = e.o2; o3 = e.o3; g.ncls = e.ncls; break; }
     if (!d) {
         // the row pass' operand classes: 0 = the plain Toeplitz matrix, one more per wave whose columns reach a left / right border (or the ragged end of the row)
         const size_t tabB = (size_t)g.ksx * 64 * 16;                              // per class: the matrix, then the part of its weights beyond int8
@@ -361,7 +361,6 @@ bool sepmxRun(Stager& stg, const uchar* src, size_t sstep, size_t sframe, uchar*
         uchar* dd = nullptr;
         if (hipMalloc(&dd, total) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (hipMemcpy(dd, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dd); return false; }
-        std::lock_guard<std::mutex> lock(mu);
         if (cache.size() >= 16) {                                                     // drop the least recently used block (hipFree waits for the device: nothing still reads it)
             size_t old = 0;
             for (size_t i = 1; i < cache.size(); i++) if (cache[i].stamp < cache[old].stamp) old = i;
