@@ -500,11 +500,17 @@ def test_large_filter2d_opt_in(orc):
                 dev = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if dtype == np.uint8 else float(np.abs(got - ref).max() / np.abs(ref).max())
             print("SERVED", np.dtype(dtype).name, "direct-engine-exact", exact, "max-deviation-from-the-DFT-path", dev)
     """ % (ROOT, ROOT))
-    for flag in ("0", "1"):
-        env = dict(os.environ); env["MI355CV_FILTER_LARGE"] = flag
+    for flag in ("", "0", "1"):
+        env = dict(os.environ); env.pop("MI355CV_FILTER_LARGE", None)
+        if flag: env["MI355CV_FILTER_LARGE"] = flag
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
-        if flag == "0":
+        if flag == "":
+            # the default since round 6: CV_32F destinations are served (the float bar is 1e-4; the direct sum is ~1e-6 from the DFT result), CV_8U stays with the CPU
+            assert "DECLINED uint8" in p.stdout and "DECLINED float32" not in p.stdout, p.stdout
+            l = [l.split() for l in p.stdout.splitlines() if l.startswith("SERVED float32")]
+            assert len(l) == 1 and l[0][3] == "True" and float(l[0][5]) <= 1e-5, p.stdout
+        elif flag == "0":
             assert p.stdout.count("DECLINED") == 2, p.stdout
         else:
             lines = [l.split() for l in p.stdout.splitlines() if l.startswith("SERVED")]
@@ -512,6 +518,65 @@ def test_large_filter2d_opt_in(orc):
             d8, d32 = float(lines[0][5]), float(lines[1][5])
             assert d8 <= 1.0 and d32 <= 1e-5, p.stdout                       # (-1: the reference did not travel with the tree)
 
+
+
+def last_kernel():
+    from opencv_amd import _lib
+    return _lib.lib.mi355cv_lastKernel().decode()
+
+
+def test_filter2d_tile_kernel(cv, orc):
+    """filter2D kernels the rolling path does not take run on k_filter2d_tile (LDS-staged source box, a sliding float window per kernel row): the chain per output is the
+    reference's non-DFT engine's (delta, then fma over the non-zero taps in raster order, one rounding), so integer results are bit for bit and float results equal the
+    restatement's to the last bit.  Kernel shapes with ragged chunks, sparse rows (zero taps stay out of the chain), every depth pair / border / anchor, 1-4 channels, ROI
+    windows (the parent's pixels as border), images smaller than a tile and smaller than the kernel."""
+    rng = np.random.default_rng(21)
+    def kern(kh, kw, sparse=False):
+        k = (rng.uniform(-1, 1, (kh, kw)) / (0.3 * kh * kw)).astype(np.float32)
+        if sparse: k[rng.random((kh, kw)) < 0.6] = 0
+        return k
+    n0 = cv.call_count("filter")
+    # depth pairs on a 3-channel image, 7 x 7 (whole image: below the DFT bound)
+    k7 = kern(7, 7)
+    for dtype, ddepth in [(np.uint8, -1), (np.uint8, 3), (np.uint8, 5), (np.uint8, 2), (np.uint16, -1), (np.uint16, 5), (np.int16, -1), (np.int16, 5), (np.float32, -1)]:
+        src = rnd((45, 83, 3), dtype, 3)
+        for border in BORDERS + [3]:
+            want = orc.orc_filter2D(src, ddepth, k7, (-1, -1), 0.25, border)
+            got = cv.filter2D(dev(src), ddepth, k7, (-1, -1), 0.25, border)
+            assert "k_filter2d_tile" in last_kernel(), last_kernel()
+            check(got, want, tol=1e-6)
+    # shapes: ragged chunks, one row / one column, sparse, odd anchors; 1, 2 and 4 channels; widths across the 64-column tile edge
+    for (kh, kw), anchor, sparse in [((3, 3), (0, 2), False), ((9, 5), (-1, -1), False), ((5, 9), (8, 0), True), ((11, 11), (-1, -1), False), ((1, 9), (3, 0), False),
+                                     ((9, 1), (0, 7), False), ((4, 6), (5, 3), True), ((10, 12), (-1, -1), True)]:
+        k = kern(kh, kw, sparse)
+        for shape in [(19, 130), (16, 64, 2), (33, 65, 4), (3, 5), (1, 1)]:
+            src = rnd(shape, np.uint8, kh * 100 + kw)
+            for border in (0, 1, 4):
+                want = orc.orc_filter2D(src, -1, k, anchor, 1.5, border)
+                check(cv.filter2D(dev(src), -1, k, anchor, 1.5, border), want)
+                assert "k_filter2d_tile" in last_kernel(), last_kernel()
+    # large kernels: CV_32F whole images are served by default (the reference's DFT case, float bar), CV_8U through a ROI window (a submatrix is never the DFT case)
+    for (kh, kw) in [(13, 10), (21, 21), (31, 31), (32, 32)]:
+        k = kern(kh, kw)
+        srcf = rnd((70, 150), np.float32, kh)
+        check(cv.filter2D(dev(srcf), -1, k, (-1, -1), 0.0, 4), orc.orc_filter2D(srcf, -1, k, (-1, -1), 0.0, 4), tol=1e-6)
+        assert "k_filter2d_tile" in last_kernel(), last_kernel()
+        parent = rnd((90, 140, 3), np.uint8, kw)
+        for roi in [(20, 25, 100, 40), (0, 0, 64, 16), (130, 80, 10, 10)]:
+            for border in (1, 4):
+                want = orc.orc_filter2D(parent, -1, k, (-1, -1), 0.0, border, roi=roi)
+                check(cv.filter2D(dev(parent), -1, k, (-1, -1), 0.0, border, roi=roi), want)
+                assert "k_filter2d_tile" in last_kernel(), last_kernel()
+            with pytest.raises(NotImplementedError):         # an ISOLATED window is a whole image to cv::filter2D (filter.dispatch.cpp:1536-1538): CV_8U, the DFT case
+                cv.filter2D(dev(parent), -1, k, (-1, -1), 0.0, 4 | 16, roi=roi)
+    # the batch entry: frames along grid z
+    frames = rnd((5, 40, 70), np.uint8, 8)
+    k = kern(9, 9)
+    got = cv.filter2DBatch(dev(frames), -1, k).cpu().numpy()
+    assert "k_filter2d_tile" in last_kernel(), last_kernel()
+    for f in range(5):
+        assert np.array_equal(got[f], orc.orc_filter2D(frames[f], -1, k))
+    assert cv.call_count("filter") > n0
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
