@@ -309,7 +309,7 @@ def compact_summary(rows):
              "f1 integral 4K 8U -> 32S batch": "integral", "a7 resize 1080p 8UC3 -> 4K bilinear": "up2x_lin_8uc3", "a7 resize 1080p 8UC3 -> 4K INTER_CUBIC": "up2x_cubic_8uc3",
              "f2 warpAffine 4K 8UC1 rot 7deg INTER_CUBIC": "affine_cubic_8uc1", "f2 warpAffine 4K 8UC1 rot 7deg INTER_LANCZOS4": "affine_lanczos_8uc1",
              "a4 Sobel dx 3x3 4K 8U->16S batch": "sobel_16s", "gs3 GaussianBlur": "gauss_sigma3_8uc1", "gs3c3 GaussianBlur": "gauss_sigma3_8uc3", "gs21 GaussianBlur": "gauss_sigma21_8uc1",
-             "gs16 GaussianBlur": "gauss_sigma16_32f", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "host-inclusive: GaussianBlur": "host_gauss"}
+             "gs16 GaussianBlur": "gauss_sigma16_32f", "a3 filter2D 5x5 4K 32FC1 batch": "filter5_32f", "a3t7 filter2D": "filter7_8uc1", "a3t11 filter2D": "filter11_8uc1", "host-inclusive: GaussianBlur": "host_gauss"}
     for r in rows if isinstance(rows, list) else []:
         c = r.get("config", "")
         key = c.split()[0] if c.split() and c.split()[0] in SUMMARY_KEYS else next((v for k, v in short.items() if c.startswith(k)), None)

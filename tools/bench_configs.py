@@ -255,6 +255,12 @@ def run(quick=False, parity=True):
     kxb = np.array([0.25, 0.5, 0.25], np.float32)
     bline("a4 sepFilter2D 3x3 (1/4,1/2,1/4) 4K 8U batch", lambda: cv.sepFilter2DBatch(gray, -1, kxb, kxb, dst=dstb), PIX4 * 2)
     bline("f1 threshold BINARY 4K 8U batch", lambda: cv.thresholdBatch(gray, 127, 255, 0, dst=dstb), PIX4 * 2)
+    # filter2D beyond the 5 x 5 of the rolling kernels: the LDS-tile kernel (k_filter2d_tile, round 6); compute-bound on the vector lanes (49 / 121 multiply-adds per byte)
+    rngk = np.random.default_rng(7)
+    k7 = (rngk.uniform(-1, 1, (7, 7)) / 15.0).astype(np.float32)
+    k11 = (rngk.uniform(-1, 1, (11, 11)) / 36.0).astype(np.float32)
+    bline("a3t7 filter2D 7x7 4K 8UC1 batch", lambda: cv.filter2DBatch(gray[:16], -1, k7, dst=dstb[:16]), PIX4 * 2, 16)
+    bline("a3t11 filter2D 11x11 4K 8UC1 batch", lambda: cv.filter2DBatch(gray[:16], -1, k11, dst=dstb[:16]), PIX4 * 2, 16)
     # cv::GaussianBlur on CV_8U beyond the 5 taps of the rolling kernels: both passes on the matrix cores (sepmx.hip); sigma 3 = 19 Q8.8 taps per axis
     bline("gs3 GaussianBlur sigma 3 (19 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (19, 19), dst=dstb, sigmaX=3.0), PIX4 * 2)
     bline("gs3c3 GaussianBlur sigma 3 (19 taps) 4K 8UC3 batch", lambda: cv.GaussianBlurBatch(bgr[:48], (19, 19), dst=bgr[48:96], sigmaX=3.0), PIX4 * 6, 48)
