@@ -13,6 +13,7 @@
 #include "seproll.h"
 #include "seplong.h"
 #include <cstdlib>
+#include <climits>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -52,6 +53,92 @@ __global__ __launch_bounds__(256) void k_morph_generic(const uchar* __restrict__
         r = t == 0 ? v : (erode ? (v < r ? v : r) : (v > r ? v : r));
     }
     reinterpret_cast<T*>(dst + (size_t)y * dstep)[e] = r;
+}
+
+// ---- irregular elements (cross, ellipse, any mask) and the depths beyond CV_8U on an LDS tile: k_morph_generic interpolates two border coordinates and gathers one value per
+// element tap and output (an ellipse of 15 x 15 on a 4K frame: milliseconds).  Here a workgroup stages the source box of its 64 x 16 outputs of ONE channel once (border rule
+// resolved at staging, the constant border's value where the image ends), a lane owns 4 neighbouring outputs of a row and slides a window along each element row: one aligned
+// ds_read_b128 serves four taps x four outputs, the row's mask of set elements is a scalar and decides with real uniform branches which taps exist.  min / max do not care
+// about order: results equal the generic kernel's.
+constexpr int MT_W = 64, MT_H = 16;
+struct MorphTileArgs { int W, H, cn, fullW, fullH, offX, offY, kw, kh, ax, ay, border, pitch, ncols, erode; };
+template <typename T> struct MorphV { typedef int V; static __device__ __forceinline__ int ident(bool erode) { return erode ? INT_MAX : INT_MIN; } };
+template <> struct MorphV<float> { typedef float V; static __device__ __forceinline__ float ident(bool erode) { return erode ? INFINITY : -INFINITY; } };
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_morph_tile(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, MorphTileArgs a,
+                                                    const unsigned* __restrict__ km /* kh row masks */, double b0, double b1, double b2, double b3)
+{
+    typedef typename MorphV<T>::V V;
+    extern __shared__ __attribute__((aligned(16))) uchar mtile_[];
+    V* tile = reinterpret_cast<V*>(mtile_);                                              // (MT_H + kh - 1) rows of a.pitch values
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
+    const V bval = (V)(T)(ch == 0 ? b0 : ch == 1 ? b1 : ch == 2 ? b2 : b3);
+    const int rows = MT_H + a.kh - 1;
+    const int bx = x0 - a.ax + a.offX, by = y0 - a.ay + a.offY;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int xo[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int xx = bx + lane + 64 * q;
+        if ((unsigned)xx >= (unsigned)a.fullW) xx = mi355_borderInterpolate(xx, a.fullW, a.border);
+        xo[q] = (xx >= 0 && lane + 64 * q < a.ncols) ? (xx - a.offX) * a.cn + ch : INT_MIN;       // (columns left of a ROI window have negative offsets: INT_MIN = none)
+    }
+    for (int r = wave; r < rows; r += 4) {
+        int yy = by + r;
+        if ((unsigned)yy >= (unsigned)a.fullH) yy = mi355_borderInterpolate(yy, a.fullH, a.border);
+        yy = __builtin_amdgcn_readfirstlane(yy);
+        const T* srow = reinterpret_cast<const T*>(src + (ptrdiff_t)(max(yy, 0) - a.offY) * (ptrdiff_t)sstep);
+        V v0 = bval, v1 = bval;
+        if (yy >= 0) {
+            if (xo[0] != INT_MIN) v0 = (V)srow[xo[0]];
+            if (xo[1] != INT_MIN) v1 = (V)srow[xo[1]];
+        }
+        V* p = tile + (size_t)r * a.pitch;
+        p[lane] = v0;
+        if (lane + 64 < a.ncols) p[lane + 64] = v1;
+    }
+    __syncthreads();
+    const bool erode = a.erode != 0;
+    V acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = MorphV<T>::ident(erode);
+    typedef V v4 __attribute__((ext_vector_type(4)));
+    for (int dy = 0; dy < a.kh; dy++) {
+        const unsigned mc = km[dy];                                                       // (uniform)
+        if (!mc) continue;
+        const v4* rp = reinterpret_cast<const v4*>(tile + (size_t)(ly + dy) * a.pitch + 4 * lx);
+        V w[4 + 4 * NC];
+#pragma unroll
+        for (int q = 0; q < 1 + NC; q++) { const v4 v = rp[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int t = 0; t < 4 * NC; t++)
+            if ((mc >> t) & 1u) {
+                asm volatile("");                                                         // (a real branch, not four selects per tap)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = erode ? (w[t + i] < acc[i] ? w[t + i] : acc[i]) : (w[t + i] > acc[i] ? w[t + i] : acc[i]);
+            }
+    }
+    const int y = y0 + ly;
+    if (y >= a.H) return;
+    T* drow = reinterpret_cast<T*>(dst + (size_t)y * dstep);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + 4 * lx + i;
+        if (x < a.W) drow[x * a.cn + ch] = (T)acc[i];
+    }
+}
+
+template <typename T>
+void launchMorphTile(int nc, dim3 grid, size_t lds, hipStream_t st, const uchar* src, size_t sstep, uchar* dst, size_t dstep, const MorphTileArgs& a, const unsigned* dm, const double* bv)
+{
+    switch (nc) {
+#define MT_CASE(N_) case N_: hipLaunchKernelGGL((k_morph_tile<T, N_>), grid, dim3(256), lds, st, src, sstep, dst, dstep, a, dm, bv[0], bv[1], bv[2], bv[3]); break
+    MT_CASE(1); MT_CASE(2); MT_CASE(3); MT_CASE(4); MT_CASE(5); MT_CASE(6); MT_CASE(7); MT_CASE(8);
+#undef MT_CASE
+    }
 }
 
 double satBorder(double v, int depth)
@@ -145,6 +232,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
         if (!tmp[0] || (iters > 2 && !tmp[1])) return mi355::declined(__func__, __LINE__, "scratch for the intermediate image");
     }
     MorphTap* dt = nullptr;
+    unsigned* dmask = nullptr;
     auto pass = [&](const uchar* ps, size_t pss, int fullW, int fullH, int offX, int offY, uchar* pd, size_t pds) -> bool {
         const bool whole = fullW == width && fullH == height;
         if (c->depth == D8U && c->rect && c->kw == c->kh && c->ax == c->kw / 2 && c->ay == c->kh / 2 && whole &&
@@ -157,6 +245,31 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
             SepLongTaps t = {nullptr, nullptr, nullptr, nullptr, c->kw, c->kh, c->ax, c->ay, c->op == 0 ? 4 : 5, 0, 0.f, 0, {0, 0, 0, 0}};
             for (int k = 0; k < 4; k++) t.bval[k] = (unsigned)c->bv[k];
             if (seplongRun(stg, ps, pss, 0, pd, pds, 0, 1, width, height, c->cn, D8U, D8U, fullW, fullH, offX, offY, c->border, t, st)) return true;
+        }
+        // everything else with an element up to 32 wide and 1-4 channels: the LDS tile (k_morph_tile)
+        static const bool tileOff = [] { const char* v = std::getenv("MI355CV_MORPH_TILE"); return v && atoi(v) == 0; }();
+        const int nc = (c->kw + 3) / 4;
+        if (!tileOff && c->depth != D64F && c->cn <= 4 && nc <= 8 && c->kw * c->kh >= 4 && !c->taps.empty() && divUp(height, MT_H) <= 65535) {
+            if (!dmask) {
+                std::vector<unsigned> km((size_t)c->kh, 0u);
+                for (const MorphTap& tp : c->taps) km[tp.dy] |= 1u << tp.dx;
+                dmask = (unsigned*)stg.param(km.data(), km.size() * sizeof(unsigned));
+            }
+            MorphTileArgs a;
+            a.W = width; a.H = height; a.cn = c->cn; a.fullW = fullW; a.fullH = fullH; a.offX = offX; a.offY = offY; a.kw = c->kw; a.kh = c->kh; a.ax = c->ax; a.ay = c->ay;
+            a.border = c->border; a.ncols = MT_W + 4 * nc; a.pitch = a.ncols; a.erode = c->op == 0;
+            const size_t lds = (size_t)(MT_H + c->kh - 1) * a.pitch * 4;
+            if (dmask && lds <= 64 * 1024) {
+                const dim3 grid(divUp(width, MT_W), divUp(height, MT_H), c->cn);
+                switch (c->depth) {
+                case D8U:  launchMorphTile<uchar>(nc, grid, lds, st, ps, pss, pd, pds, a, dmask, c->bv); break;
+                case D16U: launchMorphTile<unsigned short>(nc, grid, lds, st, ps, pss, pd, pds, a, dmask, c->bv); break;
+                case D16S: launchMorphTile<short>(nc, grid, lds, st, ps, pss, pd, pds, a, dmask, c->bv); break;
+                default:   launchMorphTile<float>(nc, grid, lds, st, ps, pss, pd, pds, a, dmask, c->bv); break;
+                }
+                noteKernel("k_morph_tile<%d> %dx%d element (%zu set), depth %d, %d channel(s), lds %zu", nc, c->kw, c->kh, c->taps.size(), c->depth, c->cn, lds);
+                return true;
+            }
         }
         if (!dt) dt = (MorphTap*)stg.param(c->taps.data(), c->taps.size() * sizeof(MorphTap));
         if (!dt) return false;

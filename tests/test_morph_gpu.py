@@ -133,3 +133,53 @@ def test_morph_large_rectangles_are_separable(cv, orc, cn):
         for op, fn in ((0, cv.erode), (1, cv.dilate)):
             got = fn(dev(parent), np.ones((11, 13), np.uint8), (-1, -1), 1, 1, None, roi=roi).cpu().numpy()
             assert np.array_equal(got, orc.orc_morph(op, parent, np.ones((11, 13), np.uint8), (-1, -1), 1, None, roi=roi)), (roi, op)
+
+
+def _ellipse(kh, kw):
+    """an elliptic mask like cv::getStructuringElement(MORPH_ELLIPSE) (any mask does: the element arrives as its non-zero taps)"""
+    yy, xx = np.mgrid[0:kh, 0:kw]
+    cy, cx = (kh - 1) / 2.0, (kw - 1) / 2.0
+    return ((((yy - cy) / max(cy, 0.5)) ** 2 + ((xx - cx) / max(cx, 0.5)) ** 2) <= 1.0).astype(np.uint8)
+
+
+def _last_kernel():
+    from opencv_amd import _lib
+    return _lib.lib.mi355cv_lastKernel().decode()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_irregular_elements_on_the_lds_tile(cv, orc, dtype):
+    """crosses, ellipses and random masks up to 32 wide, every depth, 1-4 channels, ROI windows, custom border values, widths across the 64-column tile edge: k_morph_tile
+    (the source box staged once, a sliding window per element row) against the restatement, bit for bit"""
+    rng = np.random.default_rng(17)
+    cross = np.zeros((9, 9), np.uint8); cross[4, :] = 1; cross[:, 4] = 1
+    rnd31 = (rng.random((17, 31)) < 0.3).astype(np.uint8); rnd31[8, 15] = 1
+    elements = [(_ellipse(5, 5), (-1, -1)), (_ellipse(15, 15), (-1, -1)), (_ellipse(7, 21), (3, 2)), (cross, (-1, -1)), (rnd31, (30, 0)), (_ellipse(32, 32), (-1, -1)),
+                (np.ones((3, 3), np.uint8), (-1, -1))]
+    for shape in [(37, 130), (20, 65, 3), (33, 64, 4), (5, 3)]:
+        src = _src(dtype, shape, 11 + len(shape))
+        for k, anchor in elements:
+            if dtype == np.uint8 and k.all():
+                continue                                      # (full rectangles on CV_8U have kernels of their own)
+            for op, fn in ((0, cv.erode), (1, cv.dilate)):
+                for border, bv in [(0, None), (0, 9.0), (1, None), (4, None)]:
+                    want = orc.orc_morph(op, src, k, anchor, border, bv)
+                    got = fn(dev(src), k, anchor, 1, border, bv).cpu().numpy()
+                    assert "k_morph_tile" in _last_kernel(), _last_kernel()
+                    assert np.array_equal(got, want), (dtype, shape, op, k.shape, anchor, border, bv)
+    parent = _src(dtype, (40, 90, 3), 3)
+    k = _ellipse(9, 13)
+    for roi in [(7, 6, 70, 20), (0, 0, 64, 16), (86, 37, 4, 3)]:
+        for border in (1, 4, 4 | 16):
+            for op, fn in ((0, cv.erode), (1, cv.dilate)):
+                if border & 16:                               # BORDER_ISOLATED: the window is the whole image
+                    want = orc.orc_morph(op, np.ascontiguousarray(parent[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]), k, (-1, -1), border & ~16)
+                else:
+                    want = orc.orc_morph(op, parent, k, (-1, -1), border, None, roi=roi)
+                got = fn(dev(parent), k, (-1, -1), 1, border, None, roi=roi).cpu().numpy()
+                assert "k_morph_tile" in _last_kernel(), _last_kernel()
+                assert np.array_equal(got, want), (dtype, roi, border, op)
+    # iterated irregular element: as many passes
+    src = _src(dtype, (30, 70), 4)
+    want = orc.orc_morph(0, orc.orc_morph(0, src, cross), cross)
+    assert np.array_equal(cv.erode(dev(src), cross, (-1, -1), 2).cpu().numpy(), want)
