@@ -710,6 +710,120 @@ __global__ __launch_bounds__(256) void k_box_generic(
     stF(drow, e, ddepth, v);
 }
 
+// ---------------------------------------------------------------------------------- box filter in two passes (what neither the rolling kernels nor k_sepmx take)
+// RowSum then ColumnSum like the reference (box_filter.simd.hpp:60-180, 182-1240) instead of k_box_generic's kw * kh gathers per output (a 121 x 121 window of a guided
+// filter on a 4K float frame: 14 641 loads per element, slower than the CPU's running sums):
+//   k_box_rows   window sums along x of every parent row the call touches, into a scratch image of int (integer sources: exact) or double (float sources: the reference's
+//                sum type) -- a workgroup stages 1024 + kw - 1 values of one channel of one row in LDS (border rule resolved there), a lane takes 4 neighbouring windows:
+//                one sum of kw values, three slides;
+//   k_box_cols   a lane owns an output column and walks down a segment with the running column sum (add the row entering, subtract the row leaving -- ColumnSum's own
+//                recurrence), and finishes every sum exactly as k_box_generic does (the reference's normalisations per depth pair).
+// Integer results are those of k_box_generic bit for bit; double sums differ from it in the last bits of the DOUBLE (the order of the additions), i.e. not at all after
+// the rounding to float in all but isolated elements -- the float bar of the path is 1e-4.
+template <typename SUM> struct BoxStage { typedef int L; };
+template <> struct BoxStage<double> { typedef float L; };
+
+template <typename ST, typename SUM>
+__global__ __launch_bounds__(256) void k_box_rows(const uchar* __restrict__ src, size_t sstep, SUM* __restrict__ R, size_t rpitch, int W, int cn, int fullW, int offX, int offY,
+                                                  int r0, int kw, int ax, int border)
+{
+    typedef typename BoxStage<SUM>::L LT;
+    extern __shared__ __attribute__((aligned(16))) uchar boxlds_[];
+    LT* L = reinterpret_cast<LT*>(boxlds_);
+    const int tid = threadIdx.x, ch = blockIdx.z, prow = r0 + blockIdx.y, xb = blockIdx.x * 1024;
+    const ST* row = reinterpret_cast<const ST*>(src + (ptrdiff_t)(prow - offY) * (ptrdiff_t)sstep);
+    const int nout = min(1024, W - xb), nst = nout + kw + 3;
+    for (int j = tid; j < nst; j += 256) {
+        int fx = xb + j + offX - ax;
+        if ((unsigned)fx >= (unsigned)fullW) fx = mi355_borderInterpolate(fx, fullW, border);
+        L[j] = (fx >= 0 && j < nout + kw - 1) ? (LT)row[(fx - offX) * cn + ch] : (LT)0;
+    }
+    __syncthreads();
+    const int x = 4 * tid;
+    if (x >= nout) return;
+    typedef LT l4 __attribute__((ext_vector_type(4)));
+    const LT* q = L + x;
+    SUM s = 0;
+    int t = 0;
+    for (; t + 4 <= kw; t += 4) { const l4 v = *reinterpret_cast<const l4*>(q + t); s += (SUM)v.x; s += (SUM)v.y; s += (SUM)v.z; s += (SUM)v.w; }
+    for (; t < kw; t++) s += (SUM)q[t];
+    SUM* out = R + (size_t)blockIdx.y * rpitch + (size_t)(xb + x) * cn + ch;
+    out[0] = s;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if (x + i >= nout) break;
+        s += (SUM)q[kw + i - 1]; s -= (SUM)q[i - 1];
+        out[(size_t)i * cn] = s;
+    }
+}
+
+template <typename SUM>
+__device__ __forceinline__ void boxFinish(uchar* drow, int e, SUM s, int W, int cn, int ddepth, const BoxParams& p);
+template <>
+__device__ __forceinline__ void boxFinish<double>(uchar* drow, int e, double s, int W, int cn, int ddepth, const BoxParams& p)
+{
+    if (ddepth == D64F) reinterpret_cast<double*>(drow)[e] = p.normalize ? s * p.scaleD : s;
+    else reinterpret_cast<float*>(drow)[e] = (float)(p.normalize ? s * p.scaleD : s);
+}
+template <>
+__device__ __forceinline__ void boxFinish<int>(uchar* drow, int e, int s, int W, int cn, int ddepth, const BoxParams& p)
+{
+    if (p.mode == 0) {
+        unsigned r = p.normalize ? (((unsigned)s + (unsigned)p.divDelta) * (unsigned)p.divScale) >> 23 : (unsigned)s;
+        drow[e] = (uchar)(p.normalize ? r : (r > 255u ? 255u : r));
+        return;
+    }
+    if (ddepth == D64F) { reinterpret_cast<double*>(drow)[e] = p.normalize ? (double)s * p.scaleD : (double)s; return; }
+    if (ddepth == D32F) { reinterpret_cast<float*>(drow)[e] = !p.normalize ? (float)s : e < ((W * cn) & ~3) ? __fmul_rn((float)s, p.scaleF) : (float)((double)s * p.scaleD); return; }
+    if (p.normalize && e >= ((W * cn) & ~7)) {
+        const double r = rint((double)s * p.scaleD);
+        if (ddepth == D8U) drow[e] = (uchar)(int)fmin(fmax(r, 0.0), 255.0);
+        else if (ddepth == D16U) reinterpret_cast<unsigned short*>(drow)[e] = (unsigned short)(int)fmin(fmax(r, 0.0), 65535.0);
+        else reinterpret_cast<short*>(drow)[e] = (short)(int)fmin(fmax(r, -32768.0), 32767.0);
+        return;
+    }
+    const float v = p.normalize ? rintf((float)s * p.scaleF) : (float)s;
+    stF(drow, e, ddepth, v);
+}
+
+template <typename SUM>
+__global__ __launch_bounds__(256) void k_box_cols(const SUM* __restrict__ R, size_t rpitch, int r0, uchar* __restrict__ dst, size_t dstep, int W, int H, int cn, int ddepth,
+                                                  int fullH, int offY, int border, BoxParams p, int seg)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= W * cn) return;
+    const int y0 = blockIdx.y * seg, y1 = min(H, y0 + seg);
+    auto rowSum = [&](int fy) -> SUM {                                                 // (fy is uniform: the row's address is scalar work)
+        if ((unsigned)fy >= (unsigned)fullH) fy = mi355_borderInterpolate(fy, fullH, border);
+        return fy < 0 ? (SUM)0 : R[(size_t)(fy - r0) * rpitch + e];
+    };
+    SUM s = 0;
+    for (int j = 0; j < p.kh; j++) s += rowSum(y0 + offY - p.ay + j);
+    for (int y = y0; y < y1; y++) {
+        boxFinish<SUM>(dst + (size_t)y * dstep, e, s, W, cn, ddepth, p);
+        if (y + 1 < y1) { s += rowSum(y + 1 + offY - p.ay + p.kh - 1); s -= rowSum(y + offY - p.ay); }
+    }
+}
+
+// the two-pass box filter (k_box_rows / k_box_cols) for one image; false: not its case (the caller falls back to k_box_generic)
+template <typename ST, typename SUM>
+static bool boxTwoPassT(Stager& stg, const BoxParams& p, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int ddepth,
+                        int fullW, int fullH, int offX, int offY, int border, hipStream_t st)
+{
+    // parent rows the windows can touch: the window's own rows, and what a mirroring border rule folds back into them; BORDER_WRAP reaches across the image
+    int r0 = std::max(0, offY - p.kh), r1 = std::min(fullH, offY + H + p.kh);
+    if (border == B_WRAP) { r0 = 0; r1 = fullH; }
+    const int nr = r1 - r0;
+    const size_t rpitch = ((size_t)W * cn + 3) & ~(size_t)3;
+    SUM* R = (SUM*)stg.scratch(rpitch * nr * sizeof(SUM));
+    if (!R || nr < 1 || nr > 65535) return false;
+    const size_t lds = (size_t)(1024 + p.kw + 8) * 4;
+    hipLaunchKernelGGL((k_box_rows<ST, SUM>), dim3(divUp(W, 1024), nr, cn), dim3(256), lds, st, src, sstep, R, rpitch, W, cn, fullW, offX, offY, r0, p.kw, p.ax, border);
+    const int seg = 32;
+    hipLaunchKernelGGL((k_box_cols<SUM>), dim3(divUp(W * cn, 256), divUp(H, seg)), dim3(256), 0, st, R, rpitch, r0, dst, dstep, W, H, cn, ddepth, fullH, offY, border, p, seg);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------- host: contexts
 int depthSize(int d) { return d == D8U ? 1 : (d == D16U || d == D16S) ? 2 : d == D32F ? 4 : d == D64F ? 8 : 0; }
 
@@ -1393,6 +1507,28 @@ MI355CV_API int mi355cv_boxFilter(const uchar* src_data, size_t src_step, uchar*
                   ksize_width, ksize_height, anchor_x, anchor_y, normalize, border_type);
 }
 
+static bool boxTwoPass(Stager& stg, const BoxParams& p, const uchar* src, size_t sstep, size_t sframe, uchar* dst, size_t dstep, size_t dframe, int nframes, int W, int H, int cn,
+                       int sdepth, int ddepth, int fullW, int fullH, int offX, int offY, int border)
+{
+    static const bool off = [] { const char* v = getenv("MI355CV_BOX_TWOPASS"); return v && atoi(v) == 0; }();
+    if (off || p.kw * p.kh < 16 || p.kw > 1024 || cn > 64 || sdepth == D64F || divUp(H, 32) > 65535) return false;
+    hipStream_t st = stream();
+    for (int f = 0; f < nframes; f++) {                                   // frames one after the other through the same scratch image (stream order)
+        const uchar* s = src + (size_t)f * sframe; uchar* d = dst + (size_t)f * dframe;
+        bool ok;
+        switch (sdepth) {
+        case D8U:  ok = boxTwoPassT<uchar, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        case D16U: ok = boxTwoPassT<unsigned short, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        case D16S: ok = boxTwoPassT<short, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        case D32F: ok = boxTwoPassT<float, double>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        default:   ok = false;
+        }
+        if (!ok) return f == 0 ? false : false;
+    }
+    noteKernel("k_box_rows + k_box_cols %dx%d window, depth %d -> %d, %d channel(s), %d frame(s)", p.kw, p.kh, sdepth, ddepth, cn, nframes);
+    return true;
+}
+
 // nframes == 0: the hook (one image, margins, host or device); nframes >= 1: a batch of device-resident whole frames
 // CV_8U -> CV_8U windows the rolling kernels do not take (9 .. 129 per axis, any anchor, 2 channels, ROI windows): the window sum is two products with banded matrices of
 // ones -- k_sepmx (sepmx.hip) computes it exactly on the matrix cores, nx + ny "taps" per byte instead of the kw * kh loads of k_box_generic, and finishes with the
@@ -1467,6 +1603,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
             seprollBoxF32(src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, kw, p.normalize != 0, border, stream()))
             return stg.finish(entry);
         if (boxOnMatrixCores(stg, p, src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, src_depth, dst_depth, width, height, 0, 0, border)) return stg.finish(entry);
+        if (boxTwoPass(stg, p, src_data, src_step, sframe, dst_data, dst_step, dframe, nframes, width, height, cn, src_depth, dst_depth, width, height, 0, 0, border)) return stg.finish(entry);
         dim3 grid(divUp(width * cn, 64), divUp(height, 4));
         for (int f = 0; f < nframes; f++)
             hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * sframe, src_step, dst_data + (size_t)f * dframe, dst_step, width, height, cn,
@@ -1488,6 +1625,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         seprollBoxF32(ds, dss, 0, dd, dds, 0, 1, width, height, kw, p.normalize != 0, border, stream(), roi))
         return stg.finish(entry);
     if (boxOnMatrixCores(stg, p, ds, dss, 0, dd, dds, 0, 1, width, height, cn, src_depth, dst_depth, fullW, fullH, margin_left, margin_top, border)) return stg.finish(entry);
+    if (boxTwoPass(stg, p, ds, dss, 0, dd, dds, 0, 1, width, height, cn, src_depth, dst_depth, fullW, fullH, margin_left, margin_top, border)) return stg.finish(entry);
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
                        fullW, fullH, margin_left, margin_top, border, p);

@@ -23,6 +23,11 @@ def dev(a):
     return torch.from_numpy(a).cuda()
 
 
+def last_kernel():
+    from opencv_amd import _lib
+    return _lib.lib.mi355cv_lastKernel().decode()
+
+
 def rnd(shape, dtype, seed):
     rng = np.random.default_rng(seed)
     if dtype == np.float32:
@@ -275,6 +280,31 @@ def test_boxfilter(cv, orc):
                               orc.orc_boxFilter(src, ddepth, ksize, (-1, -1), normalize, border), tol=1e-6 if dtype == np.float32 else 0.0)
 
 
+def test_boxfilter_two_pass(cv, orc):
+    """windows the rolling kernels and k_sepmx do not take (CV_32F beyond 7 x 7, CV_8U into 16S / 32F, 16-bit sources, more than 4 channels) run as RowSum + ColumnSum
+    (k_box_rows / k_box_cols) instead of kw * kh gathers per output: integer sums bit for bit into every depth, double sums within 1e-6 of the restatement's running sums;
+    large windows (a guided filter's 61 x 61, 121 x 121), windows larger than the image, ROI windows, rows longer than a staging block"""
+    for dtype, ddepth, cn in [(np.float32, -1, 1), (np.float32, -1, 3), (np.uint8, 5, 1), (np.uint8, 3, 3), (np.uint16, -1, 1), (np.int16, 5, 2), (np.uint8, -1, 6), (np.uint16, 5, 1)]:
+        for shape, ksize, anchor in [((70, 1100), (61, 61), (-1, -1)), ((45, 200), (121, 121), (-1, -1)), ((33, 90), (5, 31), (2, 30)), ((20, 40), (41, 9), (0, 0)), ((9, 12), (25, 25), (-1, -1))]:
+            src = rnd(shape + (cn,) if cn > 1 else shape, dtype, ksize[0] + cn)
+            for normalize in (True, False):
+                if normalize and dtype == np.uint16 and ksize[0] * ksize[1] > (1 << 15):
+                    continue                                   # (the reference switches to double sums there: declined)
+                for border in (0, 1, 2, 4):
+                    got = cv.boxFilter(dev(src), ddepth, ksize, anchor, normalize, border)
+                    assert "k_box_rows" in last_kernel(), last_kernel()
+                    check(got, orc.orc_boxFilter(src, ddepth, ksize, anchor, normalize, border), tol=1e-6 if dtype == np.float32 else 0.0)
+    parent = rnd((60, 120, 3), np.float32, 5)
+    for roi in [(10, 8, 90, 40), (0, 0, 64, 16), (116, 57, 4, 3)]:
+        for border in (1, 4):
+            check(cv.boxFilter(dev(parent), -1, (15, 11), (-1, -1), True, border, roi=roi), orc.orc_boxFilter(parent, -1, (15, 11), (-1, -1), True, border, roi=roi), tol=1e-6)
+            assert "k_box_rows" in last_kernel(), last_kernel()
+    frames = rnd((3, 50, 70), np.float32, 6)
+    got = cv.boxFilterBatch(dev(frames), -1, (21, 21)).cpu().numpy()
+    for f in range(3):
+        check(got[f], orc.orc_boxFilter(frames[f], -1, (21, 21)), tol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 def test_cvtcolor(cv, orc, dtype):
     for (w, h) in [(1, 1), (7, 3), (64, 5), (263, 31), (1024, 4)]:
@@ -518,11 +548,6 @@ def test_large_filter2d_opt_in(orc):
             d8, d32 = float(lines[0][5]), float(lines[1][5])
             assert d8 <= 1.0 and d32 <= 1e-5, p.stdout                       # (-1: the reference did not travel with the tree)
 
-
-
-def last_kernel():
-    from opencv_amd import _lib
-    return _lib.lib.mi355cv_lastKernel().decode()
 
 
 def test_filter2d_tile_kernel(cv, orc):
