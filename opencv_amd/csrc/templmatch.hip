@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_tm_split(const uchar* __restrict__ src,
     for (int c = 0; c < cn; c++) dst[((size_t)c * nframes + f) * dplane + (size_t)y * dstep + x] = s[c];       // planes ordered [channel][frame]
 }
 
-struct PlaneSums { const unsigned* w1[4]; const unsigned* w2[4]; int wp; size_t wframe; };
+struct PlaneSums { const unsigned* w1[16]; const unsigned* w2[16]; int wp[16]; size_t wframe[16]; /* per plane: a block with in-kernel sums has a padded pitch, one without has not */ int nblocks /* > 0: the planes are BLOCKS of one single-channel template, not channels */; };
 
 // the sum over the channels and common_matchTemplate (templmatch.cpp:960-1035) from the per-channel window sums of I and I^2 the MFMA path
 // produces anyway (exact u32): no double integral images for the multi-channel image
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_tm_finish_planes(const float* __restric
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
     if (x >= a.rw || y >= a.rh) return;
     float* out = reinterpret_cast<float*>(reinterpret_cast<uchar*>(res) + (size_t)f * rframe + (size_t)y * rstep) + x;
-    const int cn = a.cn;
+    const int cn = ps.nblocks > 0 ? ps.nblocks : a.cn;
     long long total = 0;                                                                // the planes hold exact int32 correlations
     for (int c = 0; c < cn; c++) total += (long long)__float_as_int(part[((size_t)c * nframes + f) * pplane + (size_t)y * pstep + x]);
     double num = (double)(float)(double)total;                                          // crossCorr's result is CV_32F: rounded once, as the reference's
@@ -1067,14 +1067,19 @@ __global__ __launch_bounds__(256) void k_tm_finish_planes(const float* __restric
     if (a.allOne) { *out = 1.f; return; }
     const int numType = a.method == 3 ? 0 : (a.method == 4 || a.method == 5) ? 1 : 2;
     const bool isNormed = a.method == 1 || a.method == 3 || a.method == 5;
-    const size_t wi = (size_t)f * ps.wframe + (size_t)y * ps.wp + x;
+    auto wi = [&](int c) { return (size_t)f * ps.wframe[c] + (size_t)y * ps.wp[c] + x; };
     double wndMean2 = 0, wndSum2 = 0, t;
     if (numType == 1) {
-        for (int c = 0; c < cn; c++) { t = (double)ps.w1[c][wi]; wndMean2 += t * t; num -= t * a.tmean[c]; }
+        if (ps.nblocks > 0) {                                                           // blocks of ONE channel: the window sum is the sum of the blocks' window sums
+            t = 0;
+            for (int c = 0; c < cn; c++) t += (double)ps.w1[c][wi(c)];
+            wndMean2 = t * t; num -= t * a.tmean[0];
+        } else
+            for (int c = 0; c < cn; c++) { t = (double)ps.w1[c][wi(c)]; wndMean2 += t * t; num -= t * a.tmean[c]; }
         wndMean2 *= a.invArea;
     }
     if (isNormed || numType == 2) {
-        for (int c = 0; c < cn; c++) wndSum2 += (double)ps.w2[c][wi];
+        for (int c = 0; c < cn; c++) wndSum2 += (double)ps.w2[c][wi(c)];
         if (numType == 2) { num = wndSum2 - 2 * num + a.templSum2; num = num > 0. ? num : 0.; }
     }
     if (isNormed) {
@@ -1133,7 +1138,12 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     static const bool bf16Off = std::getenv("MI355CV_TM_BF16") && atoi(std::getenv("MI355CV_TM_BF16")) == 0;
     const bool bf16Path = !bf16Off && depth == D32F && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0 &&
                           (size_t)(iw + 1) * 8 <= 56 * 1024 && (dis & 3) == 0 && ((nframes > 1 ? iframe : 0) & 3) == 0 && ((uintptr_t)di & 3) == 0;
-    const bool needInt = method != 2 && !useMfma && !planes && !bf16Path;
+    // CV_8UC1 templates of 129 .. 512 per side: the correlation is linear in the template, so it is the sum of the correlations of up to 4 x 4 blocks of <= 128 x 128 with the
+    // image shifted by the block's offset -- each an exact int32 plane of the matrix-core path (method 6), summed and normalised like the channel planes.  (k_ccorr_direct walks
+    // tw * th taps per output: ~30 ms per 4K frame at 129 x 129, ~120 ms at 256 x 256.)
+    const bool blocks = depth == D8U && cn == 1 && (tw > 128 || th > 128) && tw <= 512 && th <= 512 && (size_t)rw * rh >= 4096 && !wout &&
+                        !(std::getenv("MI355CV_TM_BLOCKS") && atoi(std::getenv("MI355CV_TM_BLOCKS")) == 0);
+    const bool needInt = method != 2 && !useMfma && !planes && !bf16Path && !blocks;
     const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
     const size_t iframeD = isteps * (ih + 1);
     double* dsum = nullptr; double* dsq = nullptr;
@@ -1220,6 +1230,32 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         }
     } else {
         bool done = false;
+        if (blocks) {
+            const int nbx = divUp(tw, 128), nby = divUp(th, 128), nb = nbx * nby;                            // blocks start at multiples of 128: aligned sub-images, the last takes the rest
+            const size_t rps = ((size_t)rw + 3) & ~(size_t)3, rplane = rps * rh;                           // floats
+            float* part = (float*)stg.scratch(rplane * 4 * nframes * nb);
+            const NormArgs* dna = uploadStats(nullptr);
+            if (part && dna) {
+                PlaneSums ps; memset(&ps, 0, sizeof ps);
+                ps.nblocks = nb;
+                done = true;
+                for (int b = 0; b < nb && done; b++) {
+                    const int ox = 128 * (b % nbx), oy = 128 * (b / nbx);
+                    const int bw = std::min(128, tw - ox), bh = std::min(128, th - oy);
+                    WOut wo = {nullptr, nullptr, 0, 0};
+                    done = runMatch(entry, di + (size_t)oy * dis + ox, dis, nframes > 1 ? iframe : 0, nframes, rw + bw - 1, rh + bh - 1, dt + (size_t)oy * dts + ox, dts, bw, bh,
+                                    MI355CV_MAKETYPE(D8U, 1), (uchar*)(part + (size_t)b * nframes * rplane), rps * 4, rplane * 4, 6, &wo) == MI355CV_OK && wo.w1 && wo.w2;
+                    ps.w1[b] = wo.w1; ps.w2[b] = wo.w2; ps.wp[b] = wo.wp; ps.wframe[b] = wo.wframe;
+                }
+                if (done) {
+                    hipLaunchKernelGGL(k_tm_finish_planes, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, part, rps, rplane, nframes, reinterpret_cast<float*>(dr), drs,
+                                       nframes > 1 ? rframe : 0, ps, dna);
+                    noteKernel("matchTemplate %dx%d as %d blocks of <= 128 x 128 on the matrix cores + k_tm_finish_planes", tw, th, nb);
+                    return stg.finish(entry);
+                }
+            }
+            return setError(MI355CV_NOT_IMPLEMENTED, "%s: the block form of a %d x %d template could not be set up", entry, tw, th);
+        }
         if (planes) {
             const size_t pstep = ((size_t)iw + 15) & ~(size_t)15, pplane = pstep * ih;
             const size_t tps = ((size_t)tw + 15) & ~(size_t)15, tplane = tps * th;
@@ -1237,7 +1273,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                     WOut wo = {nullptr, nullptr, 0, 0};
                     done = runMatch(entry, pi + (size_t)c * nframes * pplane, pstep, pplane, nframes, iw, ih, tp + (size_t)c * tplane, tps, tw, th, MI355CV_MAKETYPE(D8U, 1),
                                     (uchar*)(part + (size_t)c * nframes * rplane), rps * 4, rplane * 4, 6, &wo) == MI355CV_OK && wo.w1 && wo.w2;
-                    ps.w1[c] = wo.w1; ps.w2[c] = wo.w2; ps.wp = wo.wp; ps.wframe = wo.wframe;
+                    ps.w1[c] = wo.w1; ps.w2[c] = wo.w2; ps.wp[c] = wo.wp; ps.wframe[c] = wo.wframe;
                 }
                 if (done)
                     hipLaunchKernelGGL(k_tm_finish_planes, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, part, rps, rplane, nframes, reinterpret_cast<float*>(dr), drs,

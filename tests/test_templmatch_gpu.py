@@ -56,6 +56,33 @@ def test_mfma_path_8uc1(cv, orc, method):
             assert orc.rel_err(got, want) <= 1e-6, (iw, ih, tw, th)
 
 
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+def test_templates_beyond_128_as_blocks(cv, orc, method):
+    """CV_8UC1 templates of 129 .. 512 per side: up to 4 x 4 blocks of <= 128 x 128 on the matrix cores (the correlation is linear in the template; exact int32 planes summed
+    as integers) -- the same exactness as the single-block path: TM_CCORR identical to the restatement, the normalised methods within 1e-6.  Batches go the same way."""
+    from opencv_amd import _lib
+    for (iw, ih, tw, th) in [(400, 330, 129, 129), (520, 300, 200, 90), (300, 420, 60, 256), (600, 400, 256, 256), (450, 350, 131, 255), (640, 600, 300, 385), (700, 580, 512, 130)]:
+        if tw * th > 70000 and method not in (0, 5):
+            continue                                                            # (the 9- and 10-block cases on two methods: the restatement is the slow side)
+        img = rnd((ih, iw), np.uint8, 30 + iw)
+        tpl = rnd((th, tw), np.uint8, 40 + tw)
+        if method in (1, 3, 5):
+            img[10:10 + th, 20:20 + tw] = tpl                                   # a perfect match inside: the normalised scores reach their extreme there
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        assert "blocks of <= 128 x 128" in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+        if method == 2:
+            assert np.array_equal(got, want), (iw, ih, tw, th)
+        else:
+            assert orc.rel_err(got, want) <= 1e-6, (iw, ih, tw, th)
+    frames = rnd((3, 300, 400), np.uint8, 5)
+    tpl = rnd((150, 140), np.uint8, 6)
+    got = cv.matchTemplateBatch(dev(frames), dev(tpl), method).cpu().numpy()
+    for f in range(3):
+        want = orc.orc_matchTemplate(frames[f], tpl, method)
+        assert (np.array_equal(got[f], want) if method == 2 else orc.rel_err(got[f], want) <= 1e-6), f
+
+
 @pytest.mark.parametrize("method", [1, 3, 4, 5])
 def test_mfma_fused_window_sums(cv, orc, method):
     """templates of >= 66 rows on 4-byte aligned rows: the window sums of I and I^2 come out of the MFMA kernel itself (running column
