@@ -1136,13 +1136,15 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
     // CV_32FC1: three bf16 products on the matrix cores (k_ccorr_bf16) and window sums by a separable sliding box in double; MI355CV_TM_BF16=0 keeps the
     // direct kernel + integral images
     static const bool bf16Off = std::getenv("MI355CV_TM_BF16") && atoi(std::getenv("MI355CV_TM_BF16")) == 0;
-    const bool bf16Path = !bf16Off && depth == D32F && cn == 1 && tw <= 128 && th <= 128 && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0 &&
+    static const bool blocksOff = std::getenv("MI355CV_TM_BLOCKS") && atoi(std::getenv("MI355CV_TM_BLOCKS")) == 0;
+    const int tmax = blocksOff ? 128 : 512;                                       // beyond 128 per side: blocks of <= 128 x 128 (see `blocks` below), their products accumulated
+    const bool bf16Path = !bf16Off && depth == D32F && cn == 1 && tw <= tmax && th <= tmax && (size_t)rw * rh >= 4096 && (drs & 3) == 0 && ((nframes > 1 ? rframe : 0) & 3) == 0 &&
                           (size_t)(iw + 1) * 8 <= 56 * 1024 && (dis & 3) == 0 && ((nframes > 1 ? iframe : 0) & 3) == 0 && ((uintptr_t)di & 3) == 0;
     // CV_8UC1 templates of 129 .. 512 per side: the correlation is linear in the template, so it is the sum of the correlations of up to 4 x 4 blocks of <= 128 x 128 with the
     // image shifted by the block's offset -- each an exact int32 plane of the matrix-core path (method 6), summed and normalised like the channel planes.  (k_ccorr_direct walks
     // tw * th taps per output: ~30 ms per 4K frame at 129 x 129, ~120 ms at 256 x 256.)
     const bool blocks = depth == D8U && cn == 1 && (tw > 128 || th > 128) && tw <= 512 && th <= 512 && (size_t)rw * rh >= 4096 && !wout &&
-                        !(std::getenv("MI355CV_TM_BLOCKS") && atoi(std::getenv("MI355CV_TM_BLOCKS")) == 0);
+                        !blocksOff;
     const bool needInt = method != 2 && !useMfma && !planes && !bf16Path && !blocks;
     const size_t isteps = (size_t)(iw + 1) * cn;                                   // doubles per integral row
     const size_t iframeD = isteps * (ih + 1);
@@ -1285,8 +1287,8 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         if (!done && bf16Path) {
             const int ipitch = (iw + 7) & ~7;
             const size_t iplane = (size_t)ipitch * ih;
-            unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2);
-            unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2);
+            unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2 + 1024);       // (+ 1 KB: a block's patch rows start up to 384 columns into the row)
+            unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2 + 1024);
             unsigned short* thi = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
             unsigned short* tmid = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
             // window sums of I and I^2 for every method but TM_CCORR: rows by an LDS prefix scan, columns by sliding sums, all in double
@@ -1298,23 +1300,35 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
             }
             if (ihi && imid && thi && tmid && (method == 2 || (s1 && q1 && w1 && w2))) {
                 hipLaunchKernelGGL(k_tm_split_bf16, dim3(divUp(ipitch, 64), divUp(ih, 4), nframes), dim3(256), 0, st, di, dis, nframes > 1 ? iframe : 0, iw, ih, ihi, imid, ipitch, iplane);
-                hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(th * BF_TE, 256)), dim3(256), 0, st, dt, dts, tw, th, thi, tmid);
-                const int KS = (tw + 31 + 15) / 16;                                           // K steps of 16 columns covering tw + 31
                 const bool four = (method != 2 && method != 3) || t_fourProducts;
                 const size_t lds = (size_t)(BF_BM + BF_JC - 1) * BF_PP + (size_t)BF_JC * BF_TP;
                 dim3 gb(divUp(rw, BF_BN), divUp(rh, BF_BM), nframes);
                 float* rf = reinterpret_cast<float*>(dr);
                 const size_t rfr = nframes > 1 ? rframe : 0;
-#define BF_LAUNCH(KS_) do { static bool attrSet[16] = {}; const int dv_ = activeDevice() & 15; \
-                if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_bf16<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet[dv_] = true; } \
-                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 0); \
-                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ihi, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); \
-                hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, thi, th, rf, drs, rfr, rw, rh, 1); \
-                /* TM_SQDIFF* / TM_CCOEFF*: the result is a difference of large terms (window energy - 2 corr + template energy; corr - mean product), which amplifies the \
-                   ~2^-17 relative error of the dropped mid * mid term near a perfect match and on images with a large offset: those methods take the fourth product */ \
-                if (four) hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, imid, ipitch, iplane, ih, tmid, th, rf, drs, rfr, rw, rh, 1); } while (0)
-                switch (KS) { case 1: case 2: BF_LAUNCH(2); break; case 3: case 4: BF_LAUNCH(4); break; case 5: case 6: BF_LAUNCH(6); break; case 7: case 8: BF_LAUNCH(8); break; default: BF_LAUNCH(10); }
-#undef BF_LAUNCH
+                // one product of an image plane with a template plane (block), written or accumulated into the result
+                auto product = [&](int KS, const unsigned short* ip, int ihb, const unsigned short* tp, int thb, int acc) {
+#define BF_ONE(KS_) do { static bool attrSet[16] = {}; const int dv_ = activeDevice() & 15; \
+                    if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_bf16<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet[dv_] = true; } \
+                    hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ip, ipitch, iplane, ihb, tp, thb, rf, drs, rfr, rw, rh, acc); } while (0)
+                    switch (KS) { case 1: case 2: BF_ONE(2); break; case 3: case 4: BF_ONE(4); break; case 5: case 6: BF_ONE(6); break; case 7: case 8: BF_ONE(8); break; default: BF_ONE(10); }
+#undef BF_ONE
+                };
+                // templates beyond 128 per side: blocks of <= 128 x 128 starting at multiples of 128 (the correlation is linear in the template); each block's products are
+                // accumulated onto the result with the image planes shifted by the block's offset
+                const int nbx = divUp(tw, 128), nby = divUp(th, 128);
+                int KS = 0;
+                for (int b = 0; b < nbx * nby; b++) {
+                    const int ox = 128 * (b % nbx), oy = 128 * (b / nbx), bw = std::min(128, tw - ox), bh = std::min(128, th - oy);
+                    hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(bh * BF_TE, 256)), dim3(256), 0, st, dt + (size_t)oy * dts + (size_t)ox * 4, dts, bw, bh, thi, tmid);
+                    KS = (bw + 31 + 15) / 16;                                                 // K steps of 16 columns covering bw + 31
+                    const unsigned short* ih0 = ihi + (size_t)oy * ipitch + ox; const unsigned short* im0 = imid + (size_t)oy * ipitch + ox;
+                    product(KS, ih0, ih - oy, thi, bh, b > 0);
+                    product(KS, ih0, ih - oy, tmid, bh, 1);
+                    product(KS, im0, ih - oy, thi, bh, 1);
+                    /* TM_SQDIFF* / TM_CCOEFF*: the result is a difference of large terms (window energy - 2 corr + template energy; corr - mean product), which amplifies the
+                       ~2^-17 relative error of the dropped mid * mid term near a perfect match and on images with a large offset: those methods take the fourth product */
+                    if (four) product(KS, im0, ih - oy, tmid, bh, 1);
+                }
                 if (method != 2) {
                     const NormArgs* dna = uploadStats(nullptr);
                     if (!dna) return mi355::declined(__func__, __LINE__, "!dna");
@@ -1322,7 +1336,7 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                     hipLaunchKernelGGL((k_wsum_cols<double>), dim3(divUp(rw, 256), divUp(rh, WS_CH), nframes), dim3(256), 0, st, s1, q1, s1frame, th, rw, rh, w1, w2, wframe);
                     hipLaunchKernelGGL(k_tm_finish_f, dim3(divUp(rw, 64), divUp(rh, 4), nframes), dim3(256), 0, st, rf, drs, rfr, w1, w2, wframe, rw, dna);
                 }
-                noteKernel("k_ccorr_bf16<%d> x%d (hi*hi + hi*mid + mid*hi%s) grid=%ux%ux%u x256 lds=%zu", KS, four ? 4 : 3, four ? " + mid*mid" : "", gb.x, gb.y, gb.z, lds);
+                noteKernel("k_ccorr_bf16<%d> x%d (hi*hi + hi*mid + mid*hi%s) x %d block(s) grid=%ux%ux%u x256 lds=%zu", KS, four ? 4 : 3, four ? " + mid*mid" : "", nbx * nby, gb.x, gb.y, gb.z, lds);
                 done = true;
                 return stg.finish(entry);
             }

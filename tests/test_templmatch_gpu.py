@@ -83,6 +83,27 @@ def test_templates_beyond_128_as_blocks(cv, orc, method):
         assert (np.array_equal(got[f], want) if method == 2 else orc.rel_err(got[f], want) <= 1e-6), f
 
 
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+def test_float_templates_beyond_128_as_blocks(cv, orc, method):
+    """CV_32FC1 templates of 129 .. 512 per side: the split-bf16 products of up to 4 x 4 blocks accumulated onto one result (the path's 1e-4 bar; measured ~1e-6)"""
+    from opencv_amd import _lib
+    for (iw, ih, tw, th) in [(400, 330, 129, 129), (520, 300, 200, 90), (300, 420, 60, 256), (560, 400, 300, 257)]:
+        if tw * th > 70000 and method not in (0, 5):
+            continue
+        img = rnd((ih, iw), np.float32, 50 + iw)
+        tpl = rnd((th, tw), np.float32, 60 + tw)
+        if method in (1, 3, 5):
+            img[10:10 + th, 20:20 + tw] = tpl
+        want = orc.orc_matchTemplate(img, tpl, method)
+        got = cv.matchTemplate(dev(img), dev(tpl), method).cpu().numpy()
+        assert "k_ccorr_bf16" in _lib.lib.mi355cv_lastKernel().decode() and "block" in _lib.lib.mi355cv_lastKernel().decode(), _lib.lib.mi355cv_lastKernel().decode()
+        if method in (1, 3, 5):
+            assert np.max(np.abs(got - want)) <= 1e-4, (iw, ih, tw, th, float(np.max(np.abs(got - want))))                  # normalised results live in [-1, 1]
+        else:                                                                   # un-normalised: relative to |I| |T|, the scale the products' rounding acts on (as for one block)
+            scale = float(np.sqrt((img.astype(np.float64) ** 2).sum() / img.size * tw * th) * np.sqrt((tpl.astype(np.float64) ** 2).sum()))
+            assert np.max(np.abs(got.astype(np.float64) - want)) <= 1e-4 * scale, (iw, ih, tw, th, float(np.max(np.abs(got.astype(np.float64) - want)) / scale))
+
+
 @pytest.mark.parametrize("method", [1, 3, 4, 5])
 def test_mfma_fused_window_sums(cv, orc, method):
     """templates of >= 66 rows on 4-byte aligned rows: the window sums of I and I^2 come out of the MFMA kernel itself (running column
