@@ -213,7 +213,10 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
         return setError(MI355CV_NOT_IMPLEMENTED, "morph: %d iterations into a destination submatrix (the passes after the first would read the parent's pixels around it)", iters);
     Stager stg;                                  // first: a declined call must also put the host's device back (~Stager)
     if (!ensureDevice()) return mi355::declined(__func__, __LINE__, "!ensureDevice()");
-    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels())) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels())");
+    // a host image: small CV_8U rectangles are bandwidth-bound on the CPU too and stay there under the default policy; irregular elements and deeper images cost the reference
+    // 1.3-7 ms per 4K frame (profiles/r06_filter_morph_tile.txt) against two PCIe crossings + 30-120 us here
+    const int cost = (c->depth != D8U || !c->rect) && c->taps.size() >= 5 ? HOST_HEAVY : HOST_CHEAP;
+    if (hostImageTooSmall(src_data, (size_t)width * height, minPixels(cost))) return mi355::declined(__func__, __LINE__, "hostImageTooSmall(src_data, (size_t)width * height, minPixels(cost))");
     const int e = c->depth == D8U ? 1 : c->depth == D32F ? 4 : c->depth == D64F ? 8 : 2;
     const bool inplaceDev = inPlaceOnDevice(src_data, dst_data);
     size_t dss, dds;

@@ -44,8 +44,8 @@ bool disabled();                    // MI355CV_DISABLE=1 -> every hook answers N
 // Which host-resident images a hook accepts (device / managed pointers are always served).  MI355CV_MIN_PIXELS=<n>: images below n pixels
 // are declined.  MI355CV_HOST_POLICY=auto (the default): a host image is staged through HBM only by hooks whose CPU path costs more than the two PCIe
 // crossings (HOST_HEAVY: the reference's single-threaded FilterEngine paths -- filter2D, sepFilter2D, Sobel, box -- and medianBlur, Canny,
-// corners, cubic / Lanczos / area resize, warps, LK, Otsu, bilateralFilter, float Lab / Luv); bandwidth-bound hooks whose CPU path is multi-threaded (HOST_CHEAP: 8U Gaussian,
-// colour conversions, threshold, pyrDown, equalizeHist, morphology, integral, bilinear resize) decline and leave the image to the CPU.
+// corners, cubic / Lanczos / area resize, warps, LK, Otsu, bilateralFilter, float Lab / Luv, morphology with irregular elements or on deeper images); bandwidth-bound hooks whose CPU path is multi-threaded (HOST_CHEAP: 8U Gaussian,
+// colour conversions, threshold, pyrDown, equalizeHist, morphology with CV_8U rectangles, integral, bilinear resize) decline and leave the image to the CPU.
 // MI355CV_HOST_POLICY=always accepts everything, which is what the parity tests and the HAL tour set (tests/conftest.py).
 enum HostCost { HOST_CHEAP = 0, HOST_HEAVY = 1 };
 size_t minPixels(int cost = HOST_CHEAP);

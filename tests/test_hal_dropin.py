@@ -515,6 +515,12 @@ def test_default_host_policy():
                 fn(); print("SERVED", name)
             except NotImplementedError:
                 print("DECLINED", name)
+        try:
+            cv.erode(img, np.ones((3, 3), np.uint8)); print("SERVED erode3x3")
+        except NotImplementedError:
+            print("DECLINED erode3x3")
+        cross = np.zeros((5, 5), np.uint8); cross[2, :] = 1; cross[:, 2] = 1
+        r = cv.erode(img, cross); print("SERVED erode-cross", r.shape)
         r = cv.cornerHarris(img, 2, 3, 0.04); print("SERVED cornerHarris", r.shape)
         M = cv.getRotationMatrix2D((320.0, 240.0), 7.0, 0.95)
         r = cv.warpAffine(img, M, (640, 480)); print("SERVED warpAffine", r.shape)
@@ -524,7 +530,7 @@ def test_default_host_policy():
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     out = p.stdout
-    for name in ("GaussianBlur", "cvtColor", "threshold"):
+    for name in ("GaussianBlur", "cvtColor", "threshold", "erode3x3"):
         assert "DECLINED " + name in out, out
-    for name in ("cornerHarris", "warpAffine", "GaussianBlur-device"):
+    for name in ("cornerHarris", "warpAffine", "GaussianBlur-device", "erode-cross"):
         assert "SERVED " + name in out, out
