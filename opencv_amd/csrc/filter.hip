@@ -1372,6 +1372,7 @@ MI355CV_API int mi355cv_filter(cvhalFilter2D* context, uchar* src_data, size_t s
     dim3 grid(divUp(width * c->cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_filter2d_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, c->cn, c->sdepth, c->ddepth,
                        full_width, full_height, offset_x, offset_y, dt, (int)c->taps.size(), c->ax, c->ay, c->kw, c->kh, c->delta, c->border);
+    noteKernel("k_filter2d_generic %dx%d taps, depth %d -> %d, %d channel(s)", c->kw, c->kh, c->sdepth, c->ddepth, c->cn);
     return stg.finish("filter");
 }
 
@@ -1608,6 +1609,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
         for (int f = 0; f < nframes; f++)
             hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), src_data + (size_t)f * sframe, src_step, dst_data + (size_t)f * dframe, dst_step, width, height, cn,
                                src_depth, dst_depth, width, height, 0, 0, border, p);
+        noteKernel("k_box_generic %dx%d window, depth %d -> %d, %d channel(s)", kw, kh, src_depth, dst_depth, cn);
         return stg.finish(entry);
     }
     size_t dss, dds;
@@ -1629,6 +1631,7 @@ static int boxRun(const char* entry, const uchar* src_data, size_t src_step, siz
     dim3 grid(divUp(width * cn, 64), divUp(height, 4));
     hipLaunchKernelGGL(k_box_generic, grid, dim3(256), 0, stream(), ds, dss, dd, dds, width, height, cn, src_depth, dst_depth,
                        fullW, fullH, margin_left, margin_top, border, p);
+    noteKernel("k_box_generic %dx%d window, depth %d -> %d, %d channel(s)", kw, kh, src_depth, dst_depth, cn);
     return stg.finish(entry);
 }
 

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256) void k_tm_tpl_bf16(const uchar* __restrict__ t
 
 template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ccorr_bf16(const unsigned short* __restrict__ img, int ipitch /* elements */, size_t iplane, int ih,
-        const unsigned short* __restrict__ tpl /* th x BF_TE */, int th, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, int accumulate)
+        const unsigned short* __restrict__ tpl /* th x BF_TE */, int th, float* __restrict__ res, size_t rstep, size_t rframe, int rw, int rh, int accumulate,
+        int icols /* columns of the plane's rows from img on: ipitch, less a block's column offset */)
 {
     extern __shared__ __attribute__((aligned(16))) uchar smem[];
     constexpr int R = BF_BM + BF_JC - 1;                         // row slots of the patch: image row Y0 + g lives in slot g mod R
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto fetch = [&](int g, int cb) -> uint4 {
         const int yy = Y0 + g, xx = X0 + cb * 8;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (yy < ih && xx < ipitch) v = *reinterpret_cast<const uint4*>(img + (size_t)yy * ipitch + xx);
+        if (yy < ih && xx < icols) v = *reinterpret_cast<const uint4*>(img + (size_t)yy * ipitch + xx);     // (zeros beyond the row: the zero taps that pad a template row meet them)
         return v;
     };
     // ---- the first chunk's rows 0 .. R - 1 and template rows 0 .. JC - 1; loads in batches of SB per thread
@@ -1287,8 +1288,8 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
         if (!done && bf16Path) {
             const int ipitch = (iw + 7) & ~7;
             const size_t iplane = (size_t)ipitch * ih;
-            unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2 + 1024);       // (+ 1 KB: a block's patch rows start up to 384 columns into the row)
-            unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2 + 1024);
+            unsigned short* ihi = (unsigned short*)stg.scratch(iplane * nframes * 2);
+            unsigned short* imid = (unsigned short*)stg.scratch(iplane * nframes * 2);
             unsigned short* thi = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
             unsigned short* tmid = (unsigned short*)stg.scratch((size_t)th * BF_TE * 2 + 64);
             // window sums of I and I^2 for every method but TM_CCORR: rows by an LDS prefix scan, columns by sliding sums, all in double
@@ -1306,10 +1307,10 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                 float* rf = reinterpret_cast<float*>(dr);
                 const size_t rfr = nframes > 1 ? rframe : 0;
                 // one product of an image plane with a template plane (block), written or accumulated into the result
-                auto product = [&](int KS, const unsigned short* ip, int ihb, const unsigned short* tp, int thb, int acc) {
+                auto product = [&](int KS, const unsigned short* ip, int ihb, int icols, const unsigned short* tp, int thb, int acc) {
 #define BF_ONE(KS_) do { static bool attrSet[16] = {}; const int dv_ = activeDevice() & 15; \
                     if (!attrSet[dv_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccorr_bf16<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet[dv_] = true; } \
-                    hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ip, ipitch, iplane, ihb, tp, thb, rf, drs, rfr, rw, rh, acc); } while (0)
+                    hipLaunchKernelGGL((k_ccorr_bf16<KS_>), gb, dim3(256), lds, st, ip, ipitch, iplane, ihb, tp, thb, rf, drs, rfr, rw, rh, acc, icols); } while (0)
                     switch (KS) { case 1: case 2: BF_ONE(2); break; case 3: case 4: BF_ONE(4); break; case 5: case 6: BF_ONE(6); break; case 7: case 8: BF_ONE(8); break; default: BF_ONE(10); }
 #undef BF_ONE
                 };
@@ -1322,12 +1323,12 @@ int runMatch(const char* entry, const uchar* img, size_t istep, size_t iframe, i
                     hipLaunchKernelGGL(k_tm_tpl_bf16, dim3(divUp(bh * BF_TE, 256)), dim3(256), 0, st, dt + (size_t)oy * dts + (size_t)ox * 4, dts, bw, bh, thi, tmid);
                     KS = (bw + 31 + 15) / 16;                                                 // K steps of 16 columns covering bw + 31
                     const unsigned short* ih0 = ihi + (size_t)oy * ipitch + ox; const unsigned short* im0 = imid + (size_t)oy * ipitch + ox;
-                    product(KS, ih0, ih - oy, thi, bh, b > 0);
-                    product(KS, ih0, ih - oy, tmid, bh, 1);
-                    product(KS, im0, ih - oy, thi, bh, 1);
+                    product(KS, ih0, ih - oy, ipitch - ox, thi, bh, b > 0);
+                    product(KS, ih0, ih - oy, ipitch - ox, tmid, bh, 1);
+                    product(KS, im0, ih - oy, ipitch - ox, thi, bh, 1);
                     /* TM_SQDIFF* / TM_CCOEFF*: the result is a difference of large terms (window energy - 2 corr + template energy; corr - mean product), which amplifies the
                        ~2^-17 relative error of the dropped mid * mid term near a perfect match and on images with a large offset: those methods take the fourth product */
-                    if (four) product(KS, im0, ih - oy, tmid, bh, 1);
+                    if (four) product(KS, im0, ih - oy, ipitch - ox, tmid, bh, 1);
                 }
                 if (method != 2) {
                     const NormArgs* dna = uploadStats(nullptr);

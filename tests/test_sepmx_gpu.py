@@ -152,7 +152,8 @@ def test_sepmx_box_filter(cv, orc, cn):
             for border in (0, 1, 2, 4):
                 got = cv.boxFilter(_dev(src), -1, ks, anchor, norm, border).cpu().numpy()
                 k = last_kernel()
-                assert "k_sepmx<" in k and ",box>" in k, (k, ks)
+                # (what the matrix-core kernel declines -- a border rule that piles more than 254 unit weights on a rim pixel of a narrow image -- is the two-pass box filter's)
+                assert ("k_sepmx<" in k and ",box>" in k) or "k_box_rows" in k, (k, ks)
                 assert np.array_equal(got, orc.orc_boxFilter(src, -1, ks, anchor, norm, border)), (w, h, cn, ks, anchor, norm, border, k)
     # up to cv::boxFilter's largest window on one channel (nine K steps per pass); more channels x 255 taps do not fit the row pass and stay where they were
     if cn in (1, 3):                                                   # (the restatement walks kw * kh taps per output: one big image is enough)
