@@ -281,6 +281,7 @@ MI355CV_API int mi355cv_morph(cvhalFilter2D* context, uchar* src_data, size_t sr
         offX, offY, dt, (int)c->taps.size(), c->ax, c->ay, c->op == 0, c->border, c->bv[0], c->bv[1], c->bv[2], c->bv[3])
         switch (c->depth) { case D8U: MORPH_GEN(uchar); break; case D16U: MORPH_GEN(unsigned short); break; case D16S: MORPH_GEN(short); break; case D64F: MORPH_GEN(double); break; default: MORPH_GEN(float); }
 #undef MORPH_GEN
+        noteKernel("k_morph_generic %dx%d element (%zu set), depth %d, %d channel(s)", c->kw, c->kh, c->taps.size(), c->depth, c->cn);
         return true;
     };
     // pass 1 reads the source in its parent's geometry; passes 2 .. iters read the previous pass's image as a whole image (ocvMorph: f->apply(dst, dst, d_wsz, d_ofs))

@@ -259,8 +259,15 @@ def run(quick=False, parity=True):
     rngk = np.random.default_rng(7)
     k7 = (rngk.uniform(-1, 1, (7, 7)) / 15.0).astype(np.float32)
     k11 = (rngk.uniform(-1, 1, (11, 11)) / 36.0).astype(np.float32)
-    bline("a3t7 filter2D 7x7 4K 8UC1 batch", lambda: cv.filter2DBatch(gray[:16], -1, k7, dst=dstb[:16]), PIX4 * 2, 16)
-    bline("a3t11 filter2D 11x11 4K 8UC1 batch", lambda: cv.filter2DBatch(gray[:16], -1, k11, dst=dstb[:16]), PIX4 * 2, 16)
+    FP32_VEC = 157.3e12                                            # MI355X vector fp32 peak (256 CUs x 4 SIMDs x 16 lanes x 2 (packed) x 2 flop x 2.4 GHz)
+    for nm, kk in (("a3t7 filter2D 7x7 4K 8UC1 batch", k7), ("a3t11 filter2D 11x11 4K 8UC1 batch", k11)):
+        try:
+            ms = timeit(lambda: cv.filter2DBatch(gray[:16], -1, kk, dst=dstb[:16]), N, WARM)
+            fl = 2.0 * kk.size * PIX4 * 16
+            out.append({"config": nm, "frames": 16, "ms": round(ms, 4), "bound": "valu (fp32 multiply-adds of the reference's float engine)", "achieved_TFLOPs": round(fl / ms / 1e9, 1),
+                        "frac": round(fl / (ms * 1e-3) / FP32_VEC, 4), "frac_of": "157.3 TFLOP/s vector fp32 peak", "Mpix_s": round(16 * 8.2944 / ms * 1e3, 1)})
+        except Exception as e:                                      # noqa: BLE001 -- reported rows only
+            out.append({"config": nm, "error": repr(e)})
     # cv::GaussianBlur on CV_8U beyond the 5 taps of the rolling kernels: both passes on the matrix cores (sepmx.hip); sigma 3 = 19 Q8.8 taps per axis
     bline("gs3 GaussianBlur sigma 3 (19 taps) 4K 8UC1 batch", lambda: cv.GaussianBlurBatch(gray, (19, 19), dst=dstb, sigmaX=3.0), PIX4 * 2)
     bline("gs3c3 GaussianBlur sigma 3 (19 taps) 4K 8UC3 batch", lambda: cv.GaussianBlurBatch(bgr[:48], (19, 19), dst=bgr[48:96], sigmaX=3.0), PIX4 * 6, 48)
