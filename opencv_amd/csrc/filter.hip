@@ -806,17 +806,22 @@ __global__ __launch_bounds__(256) void k_box_cols(const SUM* __restrict__ R, siz
 }
 
 // the two-pass box filter (k_box_rows / k_box_cols) for one image; false: not its case (the caller falls back to k_box_generic)
+// parent rows the windows can touch: the window's own rows, and what a mirroring border rule folds back into them; BORDER_WRAP reaches across the image
+static void boxRowRange(int H, int kh, int fullH, int offY, int border, int* r0, int* r1)
+{
+    *r0 = std::max(0, offY - kh); *r1 = std::min(fullH, offY + H + kh);
+    if (border == B_WRAP) { *r0 = 0; *r1 = fullH; }
+}
+
 template <typename ST, typename SUM>
-static bool boxTwoPassT(Stager& stg, const BoxParams& p, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int ddepth,
+static bool boxTwoPassT(void* scratch, const BoxParams& p, const uchar* src, size_t sstep, uchar* dst, size_t dstep, int W, int H, int cn, int ddepth,
                         int fullW, int fullH, int offX, int offY, int border, hipStream_t st)
 {
-    // parent rows the windows can touch: the window's own rows, and what a mirroring border rule folds back into them; BORDER_WRAP reaches across the image
-    int r0 = std::max(0, offY - p.kh), r1 = std::min(fullH, offY + H + p.kh);
-    if (border == B_WRAP) { r0 = 0; r1 = fullH; }
+    int r0, r1;
+    boxRowRange(H, p.kh, fullH, offY, border, &r0, &r1);
     const int nr = r1 - r0;
     const size_t rpitch = ((size_t)W * cn + 3) & ~(size_t)3;
-    SUM* R = (SUM*)stg.scratch(rpitch * nr * sizeof(SUM));
-    if (!R || nr < 1 || nr > 65535) return false;
+    SUM* R = (SUM*)scratch;
     const size_t lds = (size_t)(1024 + p.kw + 8) * 4;
     hipLaunchKernelGGL((k_box_rows<ST, SUM>), dim3(divUp(W, 1024), nr, cn), dim3(256), lds, st, src, sstep, R, rpitch, W, cn, fullW, offX, offY, r0, p.kw, p.ax, border);
     const int seg = 32;
@@ -1514,17 +1519,20 @@ static bool boxTwoPass(Stager& stg, const BoxParams& p, const uchar* src, size_t
     static const bool off = [] { const char* v = getenv("MI355CV_BOX_TWOPASS"); return v && atoi(v) == 0; }();
     if (off || p.kw * p.kh < 16 || p.kw > 1024 || cn > 64 || sdepth == D64F || divUp(H, 32) > 65535) return false;
     hipStream_t st = stream();
-    for (int f = 0; f < nframes; f++) {                                   // frames one after the other through the same scratch image (stream order)
+    int r0, r1;
+    boxRowRange(H, p.kh, fullH, offY, border, &r0, &r1);
+    if (r1 - r0 < 1 || r1 - r0 > 65535 || (sdepth != D8U && sdepth != D16U && sdepth != D16S && sdepth != D32F)) return false;
+    // ONE scratch image of row sums (int or double) for the whole batch: the frames go through it one after the other, in stream order
+    void* R = stg.scratch((((size_t)W * cn + 3) & ~(size_t)3) * (size_t)(r1 - r0) * (sdepth == D32F ? sizeof(double) : sizeof(int)));
+    if (!R) return false;
+    for (int f = 0; f < nframes; f++) {
         const uchar* s = src + (size_t)f * sframe; uchar* d = dst + (size_t)f * dframe;
-        bool ok;
         switch (sdepth) {
-        case D8U:  ok = boxTwoPassT<uchar, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
-        case D16U: ok = boxTwoPassT<unsigned short, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
-        case D16S: ok = boxTwoPassT<short, int>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
-        case D32F: ok = boxTwoPassT<float, double>(stg, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
-        default:   ok = false;
+        case D8U:  boxTwoPassT<uchar, int>(R, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        case D16U: boxTwoPassT<unsigned short, int>(R, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        case D16S: boxTwoPassT<short, int>(R, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
+        default:   boxTwoPassT<float, double>(R, p, s, sstep, d, dstep, W, H, cn, ddepth, fullW, fullH, offX, offY, border, st); break;
         }
-        if (!ok) return f == 0 ? false : false;
     }
     noteKernel("k_box_rows + k_box_cols %dx%d window, depth %d -> %d, %d channel(s), %d frame(s)", p.kw, p.kh, sdepth, ddepth, cn, nframes);
     return true;
