@@ -65,7 +65,7 @@ struct MorphTileArgs { int W, H, cn, fullW, fullH, offX, offY, kw, kh, ax, ay, b
 template <typename T> struct MorphV { typedef int V; static __device__ __forceinline__ int ident(bool erode) { return erode ? INT_MAX : INT_MIN; } };
 template <> struct MorphV<float> { typedef float V; static __device__ __forceinline__ float ident(bool erode) { return erode ? INFINITY : -INFINITY; } };
 
-template <typename T, int NC>
+template <typename T, int NC, bool ERODE>
 __global__ __launch_bounds__(256) void k_morph_tile(const uchar* __restrict__ src, size_t sstep, uchar* __restrict__ dst, size_t dstep, MorphTileArgs a,
                                                     const unsigned* __restrict__ km /* kh row masks */, double b0, double b1, double b2, double b3)
 {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_morph_tile(const uchar* __restrict__ sr
         if (lane + 64 < a.ncols) p[lane + 64] = v1;
     }
     __syncthreads();
-    const bool erode = a.erode != 0;
+    constexpr bool erode = ERODE;                                                        // (a run-time flag here made every comparison a min, a max and a select)
     V acc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = MorphV<T>::ident(erode);
@@ -113,13 +113,21 @@ __global__ __launch_bounds__(256) void k_morph_tile(const uchar* __restrict__ sr
         V w[4 + 4 * NC];
 #pragma unroll
         for (int q = 0; q < 1 + NC; q++) { const v4 v = rp[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+        auto tap = [&](int t) {
 #pragma unroll
-        for (int t = 0; t < 4 * NC; t++)
-            if ((mc >> t) & 1u) {
-                asm volatile("");                                                         // (a real branch, not four selects per tap)
+            for (int i = 0; i < 4; i++) acc[i] = erode ? (w[t + i] < acc[i] ? w[t + i] : acc[i]) : (w[t + i] > acc[i] ? w[t + i] : acc[i]);
+        };
+        // four taps at a time: an ellipse's rows are runs of set elements, so most groups are all set (one uniform test for 16 comparisons) or all clear; a mixed group
+        // tests its taps one by one with real branches (the empty asm keeps the compiler from turning them into four selects per tap)
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = erode ? (w[t + i] < acc[i] ? w[t + i] : acc[i]) : (w[t + i] > acc[i] ? w[t + i] : acc[i]);
+        for (int q = 0; q < NC; q++) {
+            const unsigned nib = (mc >> (4 * q)) & 15u;
+            if (nib == 15u) { asm volatile(""); tap(4 * q); tap(4 * q + 1); tap(4 * q + 2); tap(4 * q + 3); }
+            else if (nib) {
+#pragma unroll
+                for (int t = 4 * q; t < 4 * q + 4; t++) if ((mc >> t) & 1u) { asm volatile(""); tap(t); }
             }
+        }
     }
     const int y = y0 + ly;
     if (y >= a.H) return;
@@ -135,7 +143,8 @@ template <typename T>
 void launchMorphTile(int nc, dim3 grid, size_t lds, hipStream_t st, const uchar* src, size_t sstep, uchar* dst, size_t dstep, const MorphTileArgs& a, const unsigned* dm, const double* bv)
 {
     switch (nc) {
-#define MT_CASE(N_) case N_: hipLaunchKernelGGL((k_morph_tile<T, N_>), grid, dim3(256), lds, st, src, sstep, dst, dstep, a, dm, bv[0], bv[1], bv[2], bv[3]); break
+#define MT_CASE(N_) case N_: if (a.erode) hipLaunchKernelGGL((k_morph_tile<T, N_, true>), grid, dim3(256), lds, st, src, sstep, dst, dstep, a, dm, bv[0], bv[1], bv[2], bv[3]); \
+                             else hipLaunchKernelGGL((k_morph_tile<T, N_, false>), grid, dim3(256), lds, st, src, sstep, dst, dstep, a, dm, bv[0], bv[1], bv[2], bv[3]); break
     MT_CASE(1); MT_CASE(2); MT_CASE(3); MT_CASE(4); MT_CASE(5); MT_CASE(6); MT_CASE(7); MT_CASE(8);
 #undef MT_CASE
     }
