@@ -77,3 +77,42 @@ def test_nv12_decode_and_encode_bit_exact_at_baseline_sizes():
         bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         got = cv.cvtColorBGR2NV(torch.from_numpy(bgr).cuda(), False, False).cpu().numpy()
         assert np.array_equal(got, orc.orc_cvtBGRtoTwoPlaneYUV(bgr, False, 1)), (w, h)
+
+
+def test_round6_replacement_kernels_against_the_reference_at_4k():
+    """the kernels that replaced the one-gather-per-tap ones in round 6, whole 4K results against the REFERENCE itself (oracle/_ref; the restatement walks kw * kh taps per
+    output and is left to the small-size tests): filter2D 7 x 7 on CV_8U (k_filter2d_tile; the reference's non-DFT engine: bit for bit) and 21 x 21 on CV_32F (its DFT
+    case: 1e-5), erode with an ellipse 15 x 15 (k_morph_tile: bit for bit), boxFilter 61 x 61 on CV_32F (k_box_rows / k_box_cols: 1e-6) and 31 x 31 CV_8U -> CV_32F (bit for
+    bit), matchTemplate with a 200 x 200 template (four blocks on the matrix cores: 1e-4 of the normalised score)"""
+    np, torch, cv, orc = _cv_orc()
+    if orc.load_ref() is None:
+        pytest.skip("oracle/_ref did not travel with the tree")
+    from opencv_amd import _lib
+    last = lambda: _lib.lib.mi355cv_lastKernel().decode()
+    rng = np.random.default_rng(66)
+    g8 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
+    g32 = rng.random((2160, 3840), dtype=np.float32)
+    k7 = (rng.uniform(-1, 1, (7, 7)) / 15).astype(np.float32)
+    got = cv.filter2D(torch.from_numpy(g8).cuda(), -1, k7).cpu().numpy()
+    assert "k_filter2d_tile" in last(), last()
+    assert np.array_equal(got, orc.ref_filter2D(g8, -1, k7)), "filter2D 7x7 8U"
+    k21 = (rng.uniform(-1, 1, (21, 21)) / 130).astype(np.float32)
+    got = cv.filter2D(torch.from_numpy(g32).cuda(), -1, k21).cpu().numpy()
+    assert "k_filter2d_tile" in last(), last()
+    assert orc.rel_err(got, orc.ref_filter2D(g32, -1, k21)) <= 1e-5, "filter2D 21x21 32F against the reference's DFT path"
+    yy, xx = np.mgrid[0:15, 0:15]
+    ell = ((((yy - 7) / 7.0) ** 2 + ((xx - 7) / 7.0) ** 2) <= 1.0).astype(np.uint8)
+    got = cv.erode(torch.from_numpy(g8).cuda(), ell).cpu().numpy()
+    assert "k_morph_tile" in last(), last()
+    assert np.array_equal(got, orc.ref_morph(0, g8, ell)), "erode ellipse 15x15"
+    got = cv.boxFilter(torch.from_numpy(g32).cuda(), -1, (61, 61)).cpu().numpy()
+    assert "k_box_rows" in last(), last()
+    assert orc.rel_err(got, orc.ref_boxFilter(g32, -1, (61, 61))) <= 1e-6, "boxFilter 61x61 32F"
+    got = cv.boxFilter(torch.from_numpy(g8).cuda(), 5, (31, 31)).cpu().numpy()
+    assert "k_box_rows" in last(), last()
+    assert np.array_equal(got, orc.ref_boxFilter(g8, 5, (31, 31))), "boxFilter 31x31 8U -> 32F"
+    tpl = np.ascontiguousarray(g8[700:900, 1500:1700])
+    got = cv.matchTemplate(torch.from_numpy(g8).cuda(), torch.from_numpy(tpl).cuda(), 5).cpu().numpy()
+    assert "blocks of <= 128 x 128" in last(), last()
+    want = orc.ref_matchTemplate(g8, tpl, 5)
+    assert float(np.max(np.abs(got - want))) <= 1e-4 and np.unravel_index(np.argmax(got), got.shape) == (700, 1500), float(np.max(np.abs(got - want)))
